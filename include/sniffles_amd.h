@@ -1,0 +1,332 @@
+/*
+ * sniffles_amd.h - C-ABI of the MI355X-native Sniffles2 hot path.
+ *
+ * The reference (fritzsedlazeck/Sniffles, pure Python) has no FFI; the seam this
+ * library plugs into is a set of Python call sites.  Each entry
+ * point below names the reference interface it replaces.  All pointers are plain
+ * host pointers to caller-owned contiguous buffers (numpy arrays), borrowed for the
+ * duration of the call; results are library-owned until snf_batch_destroy().
+ *
+ * A "batch" is a set of independent contig tasks (reference: one CallTask per
+ * contig, src/sniffles/sniffles:298-358) executed together in fused launches on
+ * one GPU.  A batch of one task is exactly one reference Task.
+ *
+ * Error convention: every function returns 0 on success, non-zero on failure;
+ * snf_last_error() returns a thread-local message (reference convention: raise
+ * -> ErrorResult, src/sniffles/parallel.py:750-752).
+ */
+#ifndef SNIFFLES_AMD_H
+#define SNIFFLES_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNF_ABI_VERSION 1
+
+#define SNF_SVLEN_NONE INT32_MIN /* Lead.svlen is None */
+#define SNF_SEQ_NONE (-1)        /* Lead.seq is None   */
+#define SNF_PS_NONE (-1)         /* Lead.phase_set is None */
+
+/* sv.ALL_TYPES order, src/sniffles/sv.py:31-33 */
+enum snf_svtype {
+  SNF_INS = 0, SNF_DEL = 1, SNF_DUP = 2, SNF_INV = 3, SNF_BND = 4,
+  SNF_SINGLE_LEFT = 5, SNF_SINGLE_RIGHT = 6, SNF_NTYPES = 7
+};
+
+/* Lead.source values, src/sniffles/leadprov.py:591-670, 247-281, 113-131 */
+enum snf_source { SNF_SRC_INLINE = 0, SNF_SRC_SPLIT_PRIM = 1, SNF_SRC_SPLIT_SUP = 2, SNF_SRC_BND_SA = 3 };
+
+/* SVCall.filter strings, src/sniffles/postprocessing.py:133-600, genotyping.py:138,176 */
+enum snf_filter {
+  SNF_F_PASS = 0, SNF_F_STDEV_POS, SNF_F_STDEV_LEN, SNF_F_SINGLE_BREAK, SNF_F_SVLEN_MIN,
+  SNF_F_STRAND_BND, SNF_F_COV_CHANGE_DEL, SNF_F_COV_CHANGE_DUP, SNF_F_COV_CHANGE_INS,
+  SNF_F_INLINE_SA, SNF_F_COV_VAR, SNF_F_COV_CHANGE_FRAC_US, SNF_F_COV_CHANGE_FRAC_SC,
+  SNF_F_COV_CHANGE_FRAC_CE, SNF_F_COV_CHANGE_FRAC_ED, SNF_F_SUPPORT_MIN, SNF_F_GT_FAILED,
+  SNF_F_GT, SNF_F_COV_MIN_GT, SNF_F_ALN_NM, SNF_F_MOSAIC_VAF, SNF_F_SVLEN_MAX_MOSAIC,
+  SNF_F_STRAND, SNF_F_STRAND_MOSAIC, SNF_F_SVLEN_MIN_MOSAIC, SNF_F_COV_MIN,
+  SNF_F_NOT_MOSAIC_VAF, SNF_F_MOSAIC_SV_CLOSE_EDGE, SNF_F_COUNT
+};
+
+/* per-task status: the reference's own failure modes are part of its behaviour */
+enum snf_task_status {
+  SNF_TASK_OK = 0,
+  /* postprocessing.coverage raises UnboundLocalError('end') when the first candidate of a
+     task is a BND (postprocessing.py:84-106): the task yields an ErrorResult */
+  SNF_TASK_ERR_UNBOUND_END = 1
+};
+
+/*
+ * Constants that parameterise the hot path (config.py:103-619).
+ * Filled by the Python host from a SnifflesConfig-compatible namespace.
+ */
+typedef struct snf_config {
+  /* clustering, config.py:250-262,417 */
+  int32_t cluster_binsize;
+  int32_t cluster_merge_pos;
+  int32_t cluster_merge_bnd;
+  int32_t cluster_resplit_binsize;
+  double cluster_r;
+  double cluster_repeat_h;
+  double cluster_repeat_h_max;
+  double cluster_merge_len;
+  /* lengths / support, config.py:218-229,508-517,556-557 */
+  int32_t minsvlen;
+  int32_t minsvlen_screen;
+  int32_t minsvlen_hard_cap;
+  int32_t minsupport; /* -1 == "auto" */
+  double minsupport_auto_base;
+  double minsupport_auto_mult;
+  double minsupport_auto_regional_coverage_weight;
+  int32_t long_ins_length;
+  int32_t long_del_length;
+  int32_t long_dup_length;
+  int32_t long_inv_length;
+  double long_ins_rescale_base;
+  double long_ins_rescale_mult;
+  double long_del_coverage;
+  double long_dup_coverage;
+  int32_t dev_longer_del;
+  int32_t dev_longer_dup;
+  /* consensus, config.py:402,549-552 */
+  int32_t consensus_max_reads_bin;
+  int32_t consensus_min_reads;
+  int32_t consensus_kmer_len;
+  int32_t consensus_kmer_skip_base;
+  double consensus_kmer_skip_seqlen_mult;
+  /* calls / coverage, config.py:545-546,413,583 */
+  int32_t precise;
+  int32_t coverage_binsize;
+  int32_t coverage_updown_bins;
+  /* genotyping, config.py:270-271,569 */
+  int32_t genotype_ploidy;
+  int32_t genotype_min_z_score;
+  double genotype_error;
+  /* QC, config.py:224-228,443 */
+  int32_t qc_stdev;
+  int32_t qc_stdev_abs_max;
+  int32_t qc_strand;
+  int32_t qc_coverage;
+  int32_t qc_bnd_filter_strand;
+  int32_t qc_nm;
+  int32_t qc_nm_measure;
+  int32_t pass_only;
+  double qc_coverage_max_change_frac;
+  double qc_nm_mult;
+  double dev_inline_sa_support_max;
+  double dev_min_dup_vaf;
+  /* mosaic, config.py:346-362 */
+  int32_t mosaic;
+  int32_t mosaic_min_reads;
+  int32_t mosaic_use_strand_thresholds;
+  int32_t max_svlen_mosaic;
+  int32_t mosaic_qc_invdup_min_length;
+  int32_t mosaic_qc_nm;
+  int32_t mosaic_qc_strand;
+  int32_t mosaic_include_germline;
+  double mosaic_af_max;
+  double mosaic_af_min;
+  int32_t dev_min_close_edge_dist;
+  int32_t dev_minreads_extra;
+  int32_t dev_maxsvlen_extra;
+  int32_t _pad0;
+  double dev_min_read_close_edge_prop;
+  /* switches */
+  int32_t dev_min_leads_cluster;
+  int32_t repeat;
+  int32_t phase;
+  int32_t detect_large_ins;
+  int32_t no_consensus;
+  int32_t symbolic;
+  int32_t dev_no_resplit;
+  int32_t dev_no_resplit_repeat;
+  int32_t dev_output_candidates;
+  int32_t mode_call_sample; /* config.mode == "call_sample" (parallel.py:204) */
+  double phase_conflict_threshold;
+  /* combine, config.py:301-310 */
+  int32_t combine_match;
+  int32_t combine_match_max;
+  int32_t combine_separate_intra;
+  int32_t _pad1;
+  double combine_pctseq;
+} snf_config_t;
+
+/*
+ * One contig task, struct-of-arrays, rows in arrival (BAM) order
+ * (Lead dataclass, src/sniffles/leadprov.py:34-56; LeadProvider, :358-472).
+ */
+typedef struct snf_task_input {
+  int32_t task_id;      /* Task.id, used in SVCall ids (sv.py:563) */
+  int32_t sv_id_start;  /* Task.sv_id on entry */
+  int32_t contig_len;   /* len(lead_provider.coverage) */
+  int32_t ps_null_rank; /* rank of the literal phase-set string "NULL", -1 if absent */
+  double qc_nm_threshold; /* config.qc_nm_threshold side channel, leadprov.py:577-578 */
+
+  int64_t n_leads;
+  const int32_t* ref_start;
+  const int32_t* ref_end;
+  const int32_t* qry_start;
+  const int32_t* qry_end;
+  const int32_t* svlen; /* SNF_SVLEN_NONE == None */
+  const int32_t* read_len;
+  const uint32_t* qname_id; /* interned read_qname (equality only) */
+  const uint32_t* read_id;
+  const int32_t* ps_rank;        /* order-preserving rank of phase_set string, SNF_PS_NONE == None */
+  const int32_t* mate_contig;    /* order-preserving rank of bnd_info.mate_contig */
+  const int32_t* mate_ref_start;
+  const int32_t* seq_len; /* SNF_SEQ_NONE == None */
+  const int64_t* seq_off; /* into seq_pool */
+  const double* nm;
+  const uint8_t* svtype;
+  const uint8_t* strand; /* 0 '+', 1 '-' */
+  const uint8_t* mapq;
+  const uint8_t* source;
+  const uint8_t* hap; /* int(Lead.hap) in 0..2 */
+  const uint8_t* is_sa;
+  const uint8_t* bnd_is_first;
+  const uint8_t* bnd_is_reverse;
+
+  int64_t seq_pool_len;
+  const uint8_t* seq_pool;
+
+  /* alignment records: coverage (leadprov.py:510) and REF hap counts (leadprov.py:387-398) */
+  int64_t n_reads;
+  const int32_t* read_start;
+  const int32_t* read_end;
+  const uint8_t* read_hp;
+
+  /* tandem repeats, padded, sorted (util.py:121-147); n_tr < 0 == None */
+  int64_t n_tr;
+  const int32_t* tr_start;
+  const int32_t* tr_end;
+} snf_task_input_t;
+
+/*
+ * One SVCall (src/sniffles/sv.py:87-223), integer/float fields only; strings
+ * (id, filter, alt for symbolic/BND, PHASE, read names) are formatted by the host.
+ */
+typedef struct snf_call {
+  int32_t task_index; /* index into the batch's task list */
+  int32_t sv_id;      /* id = f"{svtype}.{sv_id:X}S{task_id:X}" */
+  int32_t svtype;
+  int32_t pos;
+  int32_t end;
+  int32_t svlen;
+  int32_t support;
+  int32_t support_long; /* INFO SUPPORT_LONG (INS), -1 absent */
+  int32_t support_sa;   /* INFO SUPPORT_SA (DEL), -1 absent */
+  int32_t qual;
+  int32_t precise;
+  int32_t fwd;
+  int32_t rev;
+  int32_t qc;
+  int32_t filter; /* enum snf_filter */
+  int32_t cov[5]; /* upstream, start, center, end, downstream */
+  int32_t sa_count; /* Cluster.sa_counts[0] */
+  int32_t n_leads;  /* len(cluster.leads) at call time */
+  double sa_frac;   /* Cluster.sa_counts[1] */
+  double nm;
+  double stdev_pos;
+  double stdev_len; /* NaN == None (BND) */
+  /* BND (SVCallBNDInfo, sv.py:36-43) */
+  int32_t mate_contig;
+  int32_t mate_ref_start;
+  int32_t bnd_is_first;
+  int32_t bnd_is_reverse;
+  /* genotype tuple (a, b, GQ, DR, DV, (hp, ps)), genotyping.py:182 */
+  int32_t gt_set; /* 0: genotypes dict empty (GT_FAILED) */
+  int32_t gt_a;
+  int32_t gt_b;
+  int32_t gt_gq;
+  int32_t gt_dr;
+  int32_t gt_dv;
+  int32_t gt_hp; /* -1 None, else 1/2 */
+  int32_t gt_ps; /* -1 None, -2 literal "NULL", else ps rank */
+  double vaf;    /* INFO VAF, NaN absent */
+  /* INFO PHASE = f"{hp},{ps},{hp_support},{ps_support},{hp_filter},{ps_filter}" */
+  int32_t ph_set;
+  int32_t ph_hp;
+  int32_t ph_ps; /* -2 "NULL", else rank */
+  int32_t ph_hp_support;
+  int32_t ph_ps_support;
+  int32_t ph_hp_pass;
+  int32_t ph_ps_pass;
+  /* ALT: alt_len >= 0 -> bytes in the alt pool; -1 -> "<SVTYPE>" / BND string from fields */
+  int32_t alt_len;
+  int64_t alt_off;
+  /* supporting read names (qname ids, ascending), rnames = list(support_set), sv.py:555 */
+  int64_t rn_off;
+  int32_t rn_len;
+  /* provenance of the cluster (Cluster.start/end/seed, cluster.py:27-39) */
+  int32_t cluster_start;
+  int32_t cluster_end;
+  int32_t cluster_seed_index;
+} snf_call_t;
+
+typedef struct snf_result {
+  int64_t n_calls;
+  const snf_call_t* calls; /* candidate order: task, svtype, seed, resplit */
+  int64_t alt_pool_len;
+  const uint8_t* alt_pool;
+  int64_t rnames_len;
+  const uint32_t* rnames;
+  int64_t n_tasks;
+  const int32_t* task_status;             /* enum snf_task_status per task */
+  const int64_t* task_call_off;           /* n_tasks+1 offsets into calls */
+  const double* coverage_average_total;   /* Task.coverage_average_total per task */
+} snf_result_t;
+
+typedef struct snf_batch snf_batch_t;
+
+/* library / device ---------------------------------------------------------------- */
+int snf_abi_version(void);
+const char* snf_last_error(void);
+/* number of visible HIP devices (0 => every compute entry point fails loudly) */
+int snf_device_count(void);
+
+/* batch lifecycle -------------------------------------------------------------------
+ * replaces: LeadProvider.__init__/record_lead/record_hap_ref/build_leadtab
+ * (src/sniffles/leadprov.py:361-472) as the container of one task's signatures. */
+int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out);
+/* copies the task's arrays into pinned staging; may be called n_tasks times */
+int snf_batch_add_task(snf_batch_t* b, const snf_task_input_t* task);
+/* host -> HBM; after this the caller's buffers are no longer referenced */
+int snf_batch_upload(snf_batch_t* b);
+void snf_batch_destroy(snf_batch_t* b);
+
+/* replaces Task.call_candidates (src/sniffles/parallel.py:104-127):
+ * cluster.resolve + merge_inner/resplit/resplit_bnd (cluster.py:85-353),
+ * Cluster.get_sa_count, sv.call_from/resolve_bnd (sv.py:497-639),
+ * postprocessing.coverage (postprocessing.py:69-130). Asynchronous on the batch stream. */
+int snf_batch_call_candidates(snf_batch_t* b);
+
+/* replaces Task.finalize_candidates (src/sniffles/parallel.py:129-201):
+ * qc_sv, qc_sv_support, annotate_sv (phase_sv, genotype_sv, INS consensus
+ * consensus.novel_from_reads), qc_sv_post_annotate, rescue_phasing. */
+int snf_batch_finalize(snf_batch_t* b);
+
+/* device -> host of the call records (blocks until the stream is idle).
+ * stage 0: after call_candidates, 1: after finalize. Pointers valid until the next
+ * call on the batch or snf_batch_destroy. */
+int snf_batch_fetch(snf_batch_t* b, int stage, snf_result_t* out);
+
+/* per-kernel timing (HIP events on the batch stream, recorded around every launch of the
+ * last call_candidates+finalize pass). names[i] points to a static string. */
+int snf_batch_timing_count(snf_batch_t* b);
+int snf_batch_timing_get(snf_batch_t* b, int i, const char** name, float* ms, int64_t* algo_bytes);
+/* block until everything queued on the batch stream has finished */
+int snf_batch_sync(snf_batch_t* b);
+
+/* replaces edlib.align(a, b)["editDistance"] as used by SVGroup.align_call
+ * (src/sniffles/sv.py:280-289) and snfp (src/sniffles/snfp.py:103): global unit-cost
+ * edit distance for n_pairs string pairs. a_off/b_off have n_pairs+1 entries. */
+int snf_edit_distance_batch(int device, const uint8_t* a_pool, const int64_t* a_off,
+                            const uint8_t* b_pool, const int64_t* b_off,
+                            int64_t n_pairs, int32_t* out_dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNIFFLES_AMD_H */

@@ -1,0 +1,180 @@
+"""TEST INFRASTRUCTURE ONLY - never imported by the product path.
+
+Runs the UNMODIFIED reference implementation (`/root/reference/src/sniffles`)
+on a `sniffles_amd.soa.TaskInput` and returns canonical result records.  Only
+usable in the build container (the GPU box has no /root/reference); it is how
+`oracle/make_golden.py` produces the committed fixtures under `tests/golden/`
+that pin the C restatement (`oracle/snf_oracle.c`) and, through it, the HIP
+path.
+
+pysam / spoa / edlib are not installed: pysam and spoa are stubbed exactly as
+SURVEY.md Appendix C describes (10 CIGAR constants + 4 empty classes; a `poa`
+symbol); edlib is replaced by an exact Levenshtein DP (edlib's default
+mode="NW", task="distance" is global unit-cost edit distance).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+
+REF_SRC = "/root/reference/src"
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REF_SRC, "sniffles"))
+
+
+_loaded = None
+
+
+def load_reference():
+    """Import the reference modules under the stubs; returns a namespace of modules."""
+    global _loaded
+    if _loaded is not None:
+        return _loaded
+    if not reference_available():
+        raise RuntimeError("reference sources not present (expected only in the build container)")
+    sys.dont_write_bytecode = True
+    ps = types.ModuleType("pysam")
+    for i, n in enumerate("CMATCH CINS CDEL CREF_SKIP CSOFT_CLIP CHARD_CLIP CPAD CEQUAL CDIFF CBACK".split()):
+        setattr(ps, n, i)
+    for n in "AlignedSegment AlignmentFile FastaFile VariantFile".split():
+        setattr(ps, n, type(n, (), {}))
+    sys.modules.setdefault("pysam", ps)
+    sp = types.ModuleType("spoa")
+    sp.poa = lambda *a, **k: None
+    sys.modules.setdefault("spoa", sp)
+    if REF_SRC not in sys.path:
+        sys.path.insert(0, REF_SRC)
+    from sniffles import config, leadprov, cluster, sv, parallel, postprocessing, consensus, genotyping, util
+    ns = types.SimpleNamespace(config=config, leadprov=leadprov, cluster=cluster, sv=sv, parallel=parallel,
+                               postprocessing=postprocessing, consensus=consensus, genotyping=genotyping, util=util)
+    _loaded = ns
+    return ns
+
+
+def levenshtein(a: str, b: str) -> int:
+    """Exact global unit-cost edit distance (what edlib.align(a,b)['editDistance'] returns by default)."""
+    if len(a) < len(b):
+        a, b = b, a
+    prev = list(range(len(b) + 1))
+    for i, ca in enumerate(a, 1):
+        cur = [i]
+        for j, cb in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
+        prev = cur
+    return prev[-1]
+
+
+def make_config(extra_args=(), qc_nm_threshold=0.02):
+    ref = load_reference()
+    cfg = ref.config.SnifflesConfig("--input", "x.bam", "--vcf", "out.vcf", *extra_args)
+    cfg.mode = "call_sample"
+    cfg.average_regional_nm = qc_nm_threshold
+    cfg.qc_nm_threshold = qc_nm_threshold
+    return cfg
+
+
+def build_leads(ti):
+    """TaskInput rows -> reference Lead objects, in arrival order."""
+    from sniffles_amd.soa import SVTYPES, SOURCES, SVLEN_NONE
+    ref = load_reference()
+    Lead, BND = ref.leadprov.Lead, ref.sv.SVCallBNDInfo
+    L = ti.leads
+    pool = ti.seq_pool.tobytes()
+    out = []
+    for i in range(ti.n_leads):
+        svt = SVTYPES[L["svtype"][i]]
+        sl = int(L["seq_len"][i])
+        so = int(L["seq_off"][i])
+        svlen = int(L["svlen"][i])
+        ld = Lead(read_id=int(L["read_id"][i]), read_qname=ti.qname(int(L["qname_id"][i])), contig=ti.contig,
+                  ref_start=int(L["ref_start"][i]), ref_end=int(L["ref_end"][i]),
+                  qry_start=int(L["qry_start"][i]), qry_end=int(L["qry_end"][i]),
+                  strand="-" if L["strand"][i] else "+", mapq=int(L["mapq"][i]), nm=float(L["nm"][i]),
+                  source=SOURCES[L["source"][i]], svtype=svt,
+                  svlen=None if svlen == int(SVLEN_NONE) else svlen,
+                  seq=None if sl < 0 else pool[so:so + sl].decode("latin-1"),
+                  hap=str(int(L["hap"][i])), phase_set=ti.ps_name(int(L["ps_rank"][i])),
+                  is_sa=bool(L["is_sa"][i]), read_len=int(L["read_len"][i]))
+        if svt == "BND":
+            ld.bnd_info = BND(mate_contig=ti.contig_name(int(L["mate_contig"][i])),
+                              mate_ref_start=int(L["mate_ref_start"][i]),
+                              is_first=bool(L["bnd_is_first"][i]), is_reverse=bool(L["bnd_is_reverse"][i]))
+        out.append(ld)
+    return out
+
+
+def build_task(ti, cfg):
+    """Reference CallTask with a populated LeadProvider (SURVEY.md Appendix C recipe)."""
+    ref = load_reference()
+    lp = ref.leadprov.LeadProvider(cfg, 0, ti.contig)
+    lp.coverage = np.zeros(ti.contig_len, dtype=np.uint16)
+    lp.start, lp.end = 0, ti.contig_len
+    for s, e in zip(ti.read_start.tolist(), ti.read_end.tolist()):
+        lp.coverage[s:e] += 1
+    bs = cfg.cluster_binsize
+    for ld in build_leads(ti):
+        # build_leadtab keeps only leads inside the task region (leadprov.py:464-468)
+        if lp.start <= ld.ref_start < lp.end:
+            lp.record_lead(ld, int(ld.ref_start / bs) * bs)
+    for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
+        lp.record_hap_ref(hp, int(s / bs) * bs, int(e / bs) * bs, bs)
+    task = ref.parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0,
+                                 end=ti.contig_len, config=cfg)
+    task.lead_provider = lp
+    if ti.tr_start is not None:
+        task.tandem_repeats = list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
+    else:
+        task.tandem_repeats = None
+    return task
+
+
+def _f(x):
+    return None if x is None else float(x)
+
+
+def call_record(c, stage: str) -> dict:
+    """Canonical, JSON-able record of one reference SVCall."""
+    info = c.info
+    gt = c.genotypes.get(0) if c.genotypes else None
+    rec = dict(
+        id=c.id, contig=c.contig, pos=int(c.pos), end=int(c.end), svtype=c.svtype, svlen=int(c.svlen),
+        support=int(c.support), qual=int(c.qual), precise=bool(c.precise), fwd=int(c.fwd), rev=int(c.rev),
+        filter=c.filter, qc=bool(c.qc), nm=_f(c.nm), alt=c.alt,
+        stdev_pos=_f(info.get("STDEV_POS")), stdev_len=_f(info.get("STDEV_LEN")),
+        support_long=info.get("SUPPORT_LONG"), support_sa=info.get("SUPPORT_SA"),
+        cov=[int(c.coverage_upstream), int(c.coverage_start), int(c.coverage_center), int(c.coverage_end),
+             int(c.coverage_downstream)],
+        rnames=sorted(c.rnames) if c.rnames is not None else None,
+        bnd=None if c.bnd_info is None else [c.bnd_info.mate_contig, int(c.bnd_info.mate_ref_start),
+                                            bool(c.bnd_info.is_first), bool(c.bnd_info.is_reverse)],
+    )
+    if stage == "final":
+        rec["gt"] = None if gt is None else [gt[0], gt[1], int(gt[2]), int(gt[3]), int(gt[4]),
+                                             list(gt[5]) if gt[5] is not None else None]
+        rec["vaf"] = _f(info.get("VAF"))
+        rec["phase"] = info.get("PHASE")
+    return rec
+
+
+def run_reference(ti, extra_args=(), keep_qc_fails=True, finalize_keep=False, cfg=None):
+    """Run call_candidates + finalize_candidates of the reference on one task.
+
+    Returns dict(candidates=[...], final=[...], coverage_average_total=float) or dict(error=str)
+    when the reference itself raises (e.g. UnboundLocalError for a BND-first task).
+    """
+    cfg = cfg or make_config(extra_args, ti.qc_nm_threshold)
+    task = build_task(ti, cfg)
+    try:
+        cands = task.call_candidates(keep_qc_fails, cfg)
+    except Exception as e:  # the reference's own failure mode is part of its behaviour
+        return dict(error=type(e).__name__)
+    out = dict(candidates=[call_record(c, "cand") for c in cands],
+               coverage_average_total=float(task.coverage_average_total))
+    final = task.finalize_candidates(cands, finalize_keep, cfg)
+    out["final"] = [call_record(c, "final") for c in final]
+    return out

@@ -1,0 +1,210 @@
+"""ctypes mirror of include/sniffles_amd.h (struct layouts, enums, config builder).
+
+This is the boundary definition only - no compute.  Used by the product binding
+(`sniffles_amd.lib`) and, in tests, by the oracle loader (`oracle/oracle.py`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from .soa import LEAD_FIELDS, TaskInput
+
+ABI_VERSION = 1
+
+FILTERS = [
+    "PASS", "STDEV_POS", "STDEV_LEN", "SINGLE_BREAK", "SVLEN_MIN", "STRAND_BND", "COV_CHANGE_DEL",
+    "COV_CHANGE_DUP", "COV_CHANGE_INS", "INLINE_SA", "COV_VAR", "COV_CHANGE_FRAC_US", "COV_CHANGE_FRAC_SC",
+    "COV_CHANGE_FRAC_CE", "COV_CHANGE_FRAC_ED", "SUPPORT_MIN", "GT_FAILED", "GT", "COV_MIN_GT", "ALN_NM",
+    "MOSAIC_VAF", "SVLEN_MAX_MOSAIC", "STRAND", "STRAND_MOSAIC", "SVLEN_MIN_MOSAIC", "COV_MIN",
+    "NOT_MOSAIC_VAF", "MOSAIC_SV_CLOSE_EDGE",
+]
+TASK_OK, TASK_ERR_UNBOUND_END = 0, 1
+
+i32, i64, f64, u8p = C.c_int32, C.c_int64, C.c_double, C.POINTER(C.c_uint8)
+
+
+class snf_config_t(C.Structure):
+    _fields_ = [
+        ("cluster_binsize", i32), ("cluster_merge_pos", i32), ("cluster_merge_bnd", i32),
+        ("cluster_resplit_binsize", i32),
+        ("cluster_r", f64), ("cluster_repeat_h", f64), ("cluster_repeat_h_max", f64), ("cluster_merge_len", f64),
+        ("minsvlen", i32), ("minsvlen_screen", i32), ("minsvlen_hard_cap", i32), ("minsupport", i32),
+        ("minsupport_auto_base", f64), ("minsupport_auto_mult", f64),
+        ("minsupport_auto_regional_coverage_weight", f64),
+        ("long_ins_length", i32), ("long_del_length", i32), ("long_dup_length", i32), ("long_inv_length", i32),
+        ("long_ins_rescale_base", f64), ("long_ins_rescale_mult", f64),
+        ("long_del_coverage", f64), ("long_dup_coverage", f64),
+        ("dev_longer_del", i32), ("dev_longer_dup", i32),
+        ("consensus_max_reads_bin", i32), ("consensus_min_reads", i32), ("consensus_kmer_len", i32),
+        ("consensus_kmer_skip_base", i32), ("consensus_kmer_skip_seqlen_mult", f64),
+        ("precise", i32), ("coverage_binsize", i32), ("coverage_updown_bins", i32),
+        ("genotype_ploidy", i32), ("genotype_min_z_score", i32), ("genotype_error", f64),
+        ("qc_stdev", i32), ("qc_stdev_abs_max", i32), ("qc_strand", i32), ("qc_coverage", i32),
+        ("qc_bnd_filter_strand", i32), ("qc_nm", i32), ("qc_nm_measure", i32), ("pass_only", i32),
+        ("qc_coverage_max_change_frac", f64), ("qc_nm_mult", f64), ("dev_inline_sa_support_max", f64),
+        ("dev_min_dup_vaf", f64),
+        ("mosaic", i32), ("mosaic_min_reads", i32), ("mosaic_use_strand_thresholds", i32),
+        ("max_svlen_mosaic", i32), ("mosaic_qc_invdup_min_length", i32), ("mosaic_qc_nm", i32),
+        ("mosaic_qc_strand", i32), ("mosaic_include_germline", i32),
+        ("mosaic_af_max", f64), ("mosaic_af_min", f64),
+        ("dev_min_close_edge_dist", i32), ("dev_minreads_extra", i32), ("dev_maxsvlen_extra", i32), ("_pad0", i32),
+        ("dev_min_read_close_edge_prop", f64),
+        ("dev_min_leads_cluster", i32), ("repeat", i32), ("phase", i32), ("detect_large_ins", i32),
+        ("no_consensus", i32), ("symbolic", i32), ("dev_no_resplit", i32), ("dev_no_resplit_repeat", i32),
+        ("dev_output_candidates", i32), ("mode_call_sample", i32),
+        ("phase_conflict_threshold", f64),
+        ("combine_match", i32), ("combine_match_max", i32), ("combine_separate_intra", i32), ("_pad1", i32),
+        ("combine_pctseq", f64),
+    ]
+
+
+_CT = {np.dtype(np.int32): C.c_int32, np.dtype(np.uint32): C.c_uint32, np.dtype(np.int64): C.c_int64,
+       np.dtype(np.float64): C.c_double, np.dtype(np.uint8): C.c_uint8}
+
+# order of pointer members in snf_task_input_t after n_leads
+_LEAD_PTR_ORDER = ["ref_start", "ref_end", "qry_start", "qry_end", "svlen", "read_len", "qname_id", "read_id",
+                   "ps_rank", "mate_contig", "mate_ref_start", "seq_len", "seq_off", "nm", "svtype", "strand",
+                   "mapq", "source", "hap", "is_sa", "bnd_is_first", "bnd_is_reverse"]
+_LEAD_DT = dict(LEAD_FIELDS)
+
+
+class snf_task_input_t(C.Structure):
+    _fields_ = ([("task_id", i32), ("sv_id_start", i32), ("contig_len", i32), ("ps_null_rank", i32),
+                 ("qc_nm_threshold", f64), ("n_leads", i64)] +
+                [(n, C.POINTER(_CT[np.dtype(_LEAD_DT[n])])) for n in _LEAD_PTR_ORDER] +
+                [("seq_pool_len", i64), ("seq_pool", u8p),
+                 ("n_reads", i64), ("read_start", C.POINTER(C.c_int32)), ("read_end", C.POINTER(C.c_int32)),
+                 ("read_hp", u8p),
+                 ("n_tr", i64), ("tr_start", C.POINTER(C.c_int32)), ("tr_end", C.POINTER(C.c_int32))])
+
+
+class snf_call_t(C.Structure):
+    _fields_ = [
+        ("task_index", i32), ("sv_id", i32), ("svtype", i32), ("pos", i32), ("end", i32), ("svlen", i32),
+        ("support", i32), ("support_long", i32), ("support_sa", i32), ("qual", i32), ("precise", i32),
+        ("fwd", i32), ("rev", i32), ("qc", i32), ("filter", i32), ("cov", i32 * 5),
+        ("sa_count", i32), ("n_leads", i32), ("sa_frac", f64), ("nm", f64), ("stdev_pos", f64), ("stdev_len", f64),
+        ("mate_contig", i32), ("mate_ref_start", i32), ("bnd_is_first", i32), ("bnd_is_reverse", i32),
+        ("gt_set", i32), ("gt_a", i32), ("gt_b", i32), ("gt_gq", i32), ("gt_dr", i32), ("gt_dv", i32),
+        ("gt_hp", i32), ("gt_ps", i32), ("vaf", f64),
+        ("ph_set", i32), ("ph_hp", i32), ("ph_ps", i32), ("ph_hp_support", i32), ("ph_ps_support", i32),
+        ("ph_hp_pass", i32), ("ph_ps_pass", i32),
+        ("alt_len", i32), ("alt_off", i64), ("rn_off", i64), ("rn_len", i32),
+        ("cluster_start", i32), ("cluster_end", i32), ("cluster_seed_index", i32),
+    ]
+
+
+CALL_DTYPE = np.dtype(snf_call_t)
+
+
+class snf_result_t(C.Structure):
+    _fields_ = [
+        ("n_calls", i64), ("calls", C.POINTER(snf_call_t)),
+        ("alt_pool_len", i64), ("alt_pool", u8p),
+        ("rnames_len", i64), ("rnames", C.POINTER(C.c_uint32)),
+        ("n_tasks", i64), ("task_status", C.POINTER(C.c_int32)),
+        ("task_call_off", C.POINTER(C.c_int64)), ("coverage_average_total", C.POINTER(C.c_double)),
+    ]
+
+
+def config_struct(cfg) -> snf_config_t:
+    """Build snf_config_t from a SnifflesConfig-compatible namespace (reference config.py:103-619)."""
+    s = snf_config_t()
+    g = lambda n, d=None: getattr(cfg, n, d)  # noqa: E731
+    for name, ctype in snf_config_t._fields_:
+        if name.startswith("_pad"):
+            continue
+        if name == "minsupport":
+            v = g("minsupport")
+            s.minsupport = -1 if v == "auto" else int(v)
+            continue
+        if name == "mode_call_sample":
+            s.mode_call_sample = int(g("mode", "call_sample") == "call_sample")
+            continue
+        if name == "dev_output_candidates":
+            s.dev_output_candidates = int(bool(g("dev_output_candidates", None)))
+            continue
+        v = g(name)
+        if v is None:
+            raise AttributeError(f"config is missing hot-path constant {name!r}")
+        setattr(s, name, float(v) if ctype is f64 else int(v))
+    if getattr(cfg, "dev_filter", False):
+        raise NotImplementedError("--dev-filter (multi-filter strings) is a developer mode outside the hot path")
+    return s
+
+
+def _ptr(a: np.ndarray, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def task_struct(ti: TaskInput, keep: list) -> snf_task_input_t:
+    """Borrow the numpy buffers of `ti` into a snf_task_input_t (arrays appended to `keep` stay alive)."""
+    ti.validate()
+    t = snf_task_input_t()
+    t.task_id, t.sv_id_start, t.contig_len = ti.task_id, ti.sv_id_start, ti.contig_len
+    null_rank = -1
+    if ti.ps_names is not None and "NULL" in ti.ps_names:
+        null_rank = ti.ps_names.index("NULL")
+    t.ps_null_rank = null_rank
+    t.qc_nm_threshold = float(ti.qc_nm_threshold)
+    t.n_leads = ti.n_leads
+    for n in _LEAD_PTR_ORDER:
+        a = ti.leads[n]
+        keep.append(a)
+        setattr(t, n, _ptr(a, _CT[a.dtype]))
+    keep.append(ti.seq_pool)
+    t.seq_pool_len = int(ti.seq_pool.shape[0])
+    t.seq_pool = _ptr(ti.seq_pool, C.c_uint8)
+    t.n_reads = ti.n_reads
+    for n in ("read_start", "read_end"):
+        a = getattr(ti, n)
+        keep.append(a)
+        setattr(t, n, _ptr(a, C.c_int32))
+    keep.append(ti.read_hp)
+    t.read_hp = _ptr(ti.read_hp, C.c_uint8)
+    if ti.tr_start is None:
+        t.n_tr = -1
+    else:
+        ts = np.ascontiguousarray(ti.tr_start, np.int32)
+        te = np.ascontiguousarray(ti.tr_end, np.int32)
+        keep += [ts, te]
+        t.n_tr = int(ts.shape[0])
+        t.tr_start, t.tr_end = _ptr(ts, C.c_int32), _ptr(te, C.c_int32)
+    return t
+
+
+class Result:
+    """Host copy of a snf_result_t (numpy views copied out of library-owned memory)."""
+
+    def __init__(self, r: snf_result_t):
+        n = int(r.n_calls)
+        self.calls = np.ctypeslib.as_array(C.cast(r.calls, C.POINTER(C.c_uint8)),
+                                           shape=(n * CALL_DTYPE.itemsize,)).view(CALL_DTYPE).copy() if n else np.zeros(0, CALL_DTYPE)
+        na = int(r.alt_pool_len)
+        self.alt_pool = np.ctypeslib.as_array(r.alt_pool, shape=(na,)).copy() if na else np.zeros(0, np.uint8)
+        nr = int(r.rnames_len)
+        self.rnames = np.ctypeslib.as_array(r.rnames, shape=(nr,)).copy() if nr else np.zeros(0, np.uint32)
+        nt = int(r.n_tasks)
+        self.task_status = np.ctypeslib.as_array(r.task_status, shape=(nt,)).copy()
+        self.task_call_off = np.ctypeslib.as_array(r.task_call_off, shape=(nt + 1,)).copy()
+        self.coverage_average_total = np.ctypeslib.as_array(r.coverage_average_total, shape=(nt,)).copy()
+
+    def alt(self, i: int):
+        c = self.calls[i]
+        if c["alt_len"] < 0:
+            return None
+        o = int(c["alt_off"])
+        return self.alt_pool[o:o + int(c["alt_len"])].tobytes().decode("latin-1")
+
+    def rn(self, i: int) -> np.ndarray:
+        c = self.calls[i]
+        o = int(c["rn_off"])
+        return self.rnames[o:o + int(c["rn_len"])]
+
+
+def none_if_nan(x):
+    x = float(x)
+    return None if math.isnan(x) else x

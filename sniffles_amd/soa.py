@@ -1,0 +1,131 @@
+"""Struct-of-arrays layout for SV signatures ("leads") at the C-ABI boundary.
+
+One `TaskInput` = one contig task (reference: one `CallTask` per contig,
+`src/sniffles/sniffles:298-358`).  A `Lead` of the reference
+(`src/sniffles/leadprov.py:34-56`) becomes one row of the arrays below, in
+arrival (BAM) order, which is the order `LeadProvider.record_lead`
+(`leadprov.py:400-418`) sees them.  Strings that the hot path only compares
+(read names, mate contigs, phase sets) are interned to integers whose ORDER
+matches Python string order, because the reference breaks ties on string
+order (`util.most_common`, `util.py:91-103`).
+
+The same layout is consumed by the CPU oracle (tests only) and by the HIP
+library (`include/sniffles_amd.h`).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+# svtype codes follow sv.ALL_TYPES order (`sv.py:31-33`)
+SVTYPES = ["INS", "DEL", "DUP", "INV", "BND", "SINGLE_LEFT", "SINGLE_RIGHT"]
+SVT = {n: i for i, n in enumerate(SVTYPES)}
+N_SVTYPES = 7
+
+SOURCES = ["INLINE", "SPLIT_PRIM", "SPLIT_SUP", "BND_SA"]
+SRC = {n: i for i, n in enumerate(SOURCES)}
+
+SVLEN_NONE = np.int32(-2 ** 31)   # Lead.svlen is None (clipped long-INS hint, leadprov.py:639-653)
+SEQ_NONE = np.int32(-1)           # Lead.seq is None
+PS_NONE = np.int32(-1)            # Lead.phase_set is None (BND_SA leads, leadprov.py:113-131)
+
+LEAD_FIELDS = [
+    ("ref_start", np.int32), ("ref_end", np.int32),
+    ("qry_start", np.int32), ("qry_end", np.int32),
+    ("svlen", np.int32), ("read_len", np.int32),
+    ("qname_id", np.uint32), ("read_id", np.uint32),
+    ("ps_rank", np.int32),
+    ("mate_contig", np.int32), ("mate_ref_start", np.int32),
+    ("seq_len", np.int32), ("seq_off", np.int64),
+    ("nm", np.float64),
+    ("svtype", np.uint8), ("strand", np.uint8), ("mapq", np.uint8),
+    ("source", np.uint8), ("hap", np.uint8), ("is_sa", np.uint8),
+    ("bnd_is_first", np.uint8), ("bnd_is_reverse", np.uint8),
+]
+
+
+@dataclass
+class TaskInput:
+    """All inputs of one contig task, SoA."""
+    task_id: int
+    contig: str
+    contig_len: int
+    sv_id_start: int = 0
+    # per lead arrays (length n_leads), see LEAD_FIELDS
+    leads: dict = field(default_factory=dict)
+    seq_pool: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))
+    # per read (alignment record) arrays: coverage + REF haplotype counts
+    read_start: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    read_end: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+    read_hp: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint8))
+    # tandem repeats, already padded (util.load_tandem_repeats, util.py:121-147); None = no annotation
+    tr_start: Optional[np.ndarray] = None
+    tr_end: Optional[np.ndarray] = None
+    # side channel written by iter_region (leadprov.py:577-578)
+    qc_nm_threshold: float = 0.02
+    # string tables for materialisation (host only)
+    qnames: Optional[list] = None        # qname_id -> str (None: synthesised as f"q{id}")
+    ps_names: Optional[list] = None      # ps_rank -> str, sorted in Python str order
+    contig_names: Optional[list] = None  # mate_contig rank -> str, sorted in Python str order
+
+    @property
+    def n_leads(self) -> int:
+        return int(self.leads["ref_start"].shape[0]) if self.leads else 0
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_start.shape[0])
+
+    def validate(self) -> None:
+        n = self.n_leads
+        for name, dt in LEAD_FIELDS:
+            a = self.leads[name]
+            if a.dtype != dt or a.shape != (n,) or not a.flags.c_contiguous:
+                raise ValueError(f"lead field {name}: want {np.dtype(dt)}[{n}] contiguous, got {a.dtype}{a.shape}")
+        if self.seq_pool.dtype != np.uint8:
+            raise ValueError("seq_pool must be uint8")
+        sl, so = self.leads["seq_len"], self.leads["seq_off"]
+        m = sl >= 0
+        if m.any() and int((so[m] + sl[m]).max()) > self.seq_pool.shape[0]:
+            raise ValueError("seq_off+seq_len exceeds seq_pool")
+        if np.any(self.leads["hap"] > 2):
+            raise ValueError("hap must be 0,1,2 (leadprov.py:403 indexes a 3-array with int(ld.hap))")
+        if np.any(self.leads["svtype"] >= N_SVTYPES):
+            raise ValueError("svtype code out of range")
+        for a, dt in ((self.read_start, np.int32), (self.read_end, np.int32), (self.read_hp, np.uint8)):
+            if a.dtype != dt or a.shape != (self.n_reads,):
+                raise ValueError("read arrays malformed")
+        if (self.tr_start is None) != (self.tr_end is None):
+            raise ValueError("tr_start/tr_end must both be set or both None")
+
+    def qname(self, qid: int) -> str:
+        return self.qnames[qid] if self.qnames is not None else f"q{qid}"
+
+    def ps_name(self, rank: int) -> Optional[str]:
+        if rank < 0:
+            return None
+        return self.ps_names[rank] if self.ps_names is not None else str(rank)
+
+    def contig_name(self, rank: int) -> str:
+        return self.contig_names[rank] if self.contig_names is not None else f"ctg{rank}"
+
+
+def empty_leads(n: int) -> dict:
+    d = {name: np.zeros(n, dt) for name, dt in LEAD_FIELDS}
+    d["seq_len"][:] = SEQ_NONE
+    d["ps_rank"][:] = PS_NONE
+    return d
+
+
+def concat_leads(parts: list) -> dict:
+    return {name: np.ascontiguousarray(np.concatenate([p[name] for p in parts])) if parts else np.zeros(0, dt)
+            for name, dt in LEAD_FIELDS}
+
+
+def intern_sorted(strings) -> tuple:
+    """Intern strings to ranks whose integer order equals Python str order."""
+    uniq = sorted(set(strings))
+    rank = {s: i for i, s in enumerate(uniq)}
+    return uniq, rank
