@@ -244,3 +244,108 @@ def gen_genome(coverage: float = 30.0, seed: int = 1, contigs=None, err: float =
     contigs = contigs or CONTIGS
     return [gen_task(i, c, max(200000, int(GRCH38[c] * scale)), coverage, seed, err=err,
                      mosaic_frac=mosaic_frac) for i, c in enumerate(contigs)]
+
+
+def gen_fuzz(seed: int, task_id: int = 0, n_leads: int = None, contig_len: int = None) -> TaskInput:
+    """Adversarial small task: dense hot-spots, shared reads, nested tandem repeats, zero-coverage
+    zones, thresholds-straddling lengths, non-ACGT bases.  Exercises the quirks of SURVEY.md Appendix A
+    (resplit wrap-around, merge index rule, stale BND end, seq cap, negative-index coverage)."""
+    rng = np.random.default_rng([seed, 104729])
+    L = int(contig_len or rng.integers(20_000, 120_000))
+    n = int(n_leads or rng.integers(50, 2500))
+    n_reads = int(rng.integers(30, 600))
+    rstart = np.sort(rng.integers(0, L - 10, n_reads))
+    rend = np.minimum(L + rng.integers(-5, 50, n_reads), rstart + rng.integers(200, L, n_reads))
+    rend = np.maximum(rend, rstart + 1)
+    if rng.random() < 0.5:  # carve a zero-coverage hole
+        h0 = int(rng.integers(0, L)); h1 = h0 + int(rng.integers(100, 5000))
+        kill = (rstart < h1) & (rend > h0)
+        rend = np.where(kill, np.maximum(rstart + 1, np.minimum(rend, h0)), rend)
+        rstart = np.where(kill & (rstart >= h0), np.minimum(L - 2, h1), rstart)
+        o = np.argsort(rstart, kind="stable"); rstart, rend = rstart[o], np.maximum(rend[o], rstart[o] + 1)
+    rhp = rng.integers(0, 3, n_reads).astype(np.uint8)
+    n_hot = int(rng.integers(1, 12))
+    hot = rng.integers(0, L, n_hot)
+    hot_sd = rng.choice([1, 5, 30, 120, 400], n_hot)
+    hot_len = rng.choice([48, 52, 60, 100, 300, 700, 2600, 3000], n_hot)
+    hot_type = rng.choice([0, 0, 0, 1, 1, 1, 2, 3, 4, 5, 6], n_hot)
+    which = rng.integers(0, n_hot, n)
+    leads = empty_leads(n)
+    uniform = rng.random(n) < 0.15
+    pos = np.where(uniform, rng.integers(-50, L + 50, n), hot[which] + np.rint(rng.normal(0, 1, n) * hot_sd[which])).astype(np.int64)
+    pos = np.clip(pos, -20, L + 20)
+    t = np.where(uniform | (rng.random(n) < 0.1), rng.integers(0, 7, n), hot_type[which]).astype(np.uint8)
+    ln = np.maximum(1, np.rint(hot_len[which] * (1 + rng.normal(0, 0.08, n)) + rng.integers(-25, 26, n))).astype(np.int64)
+    ln = np.where(rng.random(n) < 0.1, rng.integers(30, 140, n), ln)
+    is_ins, is_del, is_bnd = t == SVT["INS"], t == SVT["DEL"], t == SVT["BND"]
+    single = t >= SVT["SINGLE_LEFT"]
+    leads["svtype"][:] = t
+    leads["ref_start"][:] = pos
+    leads["ref_end"][:] = np.where(is_del, pos - ln, np.where(is_ins | is_bnd | single, pos, pos + ln))
+    leads["svlen"][:] = np.where(is_del, -ln, np.where(is_bnd | single, 0, ln))
+    long_clip = is_ins & (rng.random(n) < 0.12)
+    leads["svlen"][long_clip] = SVLEN_NONE
+    n_q = max(2, int(n * rng.choice([0.2, 0.5, 0.9])))
+    q = rng.integers(0, n_q, n)
+    leads["qname_id"][:] = q
+    leads["read_id"][:] = q + 1 + (rng.random(n) < 0.1) * n_q  # supplementary record of the same read
+    qstrand = rng.integers(0, 2, n_q).astype(np.uint8)
+    leads["strand"][:] = np.where(rng.random(n) < 0.9, qstrand[q], 1 - qstrand[q])
+    leads["mapq"][:] = rng.integers(0, 61, n)
+    leads["nm"][:] = np.round(rng.uniform(0, 0.09, n_q), 4)[q]
+    leads["source"][:] = np.where(is_bnd, SRC["BND_SA"], rng.choice([0, 0, 0, 1, 2], n))
+    qhap = rng.integers(0, 3, n_q).astype(np.uint8)
+    leads["hap"][:] = np.where(is_bnd, 0, qhap[q])
+    ps_strs = sorted({"NULL", "1", "10001", "9", "250001"})
+    ps_of_q = rng.integers(0, len(ps_strs), n_q).astype(np.int32)
+    leads["ps_rank"][:] = np.where(is_bnd, PS_NONE, np.where(qhap[q] > 0, ps_of_q[q], ps_strs.index("NULL")))
+    leads["is_sa"][:] = rng.random(n) < rng.choice([0.0, 0.1, 0.9])
+    qs = rng.integers(0, 30000, n)
+    leads["qry_start"][:] = qs
+    leads["qry_end"][:] = np.where(is_ins, qs + ln, qs)
+    leads["read_len"][:] = qs + rng.integers(0, 30000, n)
+    same_read_near = rng.random(n) < 0.3  # make same-read neighbours plausible for merge_inner
+    leads["qry_start"][same_read_near] = (pos[same_read_near] % 997) * 3
+    leads["qry_end"][same_read_near] = leads["qry_start"][same_read_near] + np.where(is_ins[same_read_near], ln[same_read_near], 0)
+    contig_names = sorted(["chr1", "chr10", "chr2", "chrX"])
+    leads["mate_contig"][:] = np.where(is_bnd, rng.choice([0, 0, 0, 1, 2, 3], n), 0)
+    leads["mate_ref_start"][:] = np.where(is_bnd, rng.choice([5000, 5400, 6100, 9000, 250000], n) + rng.integers(-600, 600, n), 0)
+    leads["bnd_is_first"][:] = np.where(is_bnd, rng.random(n) < 0.7, 0)
+    leads["bnd_is_reverse"][:] = np.where(is_bnd, rng.random(n) < 0.3, 0)
+    # INS sequences: per hot-spot allele, stretched, with errors and a few odd characters
+    alpha = np.frombuffer(b"ACGTNacgtR", dtype=np.uint8)
+    has_seq = is_ins & ~long_clip & (rng.random(n) < 0.92)
+    idx = np.nonzero(has_seq)[0]
+    slen = np.where(rng.random(idx.shape[0]) < 0.85, ln[idx], np.maximum(1, ln[idx] + rng.integers(-30, 30, idx.shape[0])))
+    a_len = np.maximum(8, hot_len)
+    a_off = np.cumsum(a_len) - a_len
+    allele = ACGT[rng.integers(0, 4, int(a_len.sum()))]
+    if rng.random() < 0.3:  # low-complexity allele -> repeated k-mers (taboo anchors)
+        allele[:] = np.tile(ACGT[rng.integers(0, 4, 7)], allele.shape[0] // 7 + 1)[:allele.shape[0]]
+    o_i, p = _ranges(slen)
+    w = which[idx][o_i]
+    src = (p * a_len[w]) // np.maximum(1, slen[o_i])
+    sb = allele[a_off[w] + src]
+    e = rng.random(sb.shape[0]) < rng.choice([0.0, 0.03, 0.12])
+    sb = np.where(e, ACGT[rng.integers(0, 4, sb.shape[0])], sb)
+    odd = rng.random(sb.shape[0]) < 0.002
+    sb = np.where(odd, alpha[rng.integers(0, alpha.shape[0], sb.shape[0])], sb).astype(np.uint8)
+    leads["seq_len"][idx] = slen
+    leads["seq_off"][idx] = np.cumsum(slen) - slen
+    # arrival order: by a synthetic read order
+    order = np.lexsort((pos, q))
+    for name in leads:
+        leads[name] = np.ascontiguousarray(leads[name][order])
+    # tandem repeats: random, sorted by start, may nest / overlap
+    tr_s = tr_e = None
+    if rng.random() < 0.7:
+        k = int(rng.integers(0, 8))
+        s0 = np.sort(np.concatenate([hot[rng.integers(0, n_hot, k)] - rng.integers(0, 800, k), rng.integers(0, L, 2)]))
+        tr_s = np.maximum(0, s0).astype(np.int32)
+        tr_e = (tr_s + rng.integers(10, 2500, tr_s.shape[0])).astype(np.int32)
+    ti = TaskInput(task_id=task_id, contig="chrF", contig_len=L, sv_id_start=int(rng.integers(0, 3)) * 17, leads=leads,
+                   seq_pool=np.ascontiguousarray(sb), read_start=rstart.astype(np.int32), read_end=rend.astype(np.int32),
+                   read_hp=rhp, tr_start=tr_s, tr_end=tr_e, qc_nm_threshold=float(rng.choice([0.02, 0.045])),
+                   ps_names=ps_strs, contig_names=contig_names)
+    ti.validate()
+    return ti

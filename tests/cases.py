@@ -1,0 +1,351 @@
+"""Golden-case catalogue: seeded synthetic tasks, fuzz tasks and hand-made edge cases.
+
+Every case is (name, TaskInput builder, config kwargs, reference CLI args).  The
+expected outputs under tests/golden/ are produced from the UNMODIFIED reference
+by oracle/make_golden.py (build container only) and are what pins the oracle.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from sniffles_amd import synth
+from sniffles_amd.soa import (TaskInput, SVT, SRC, SVLEN_NONE, SEQ_NONE, PS_NONE, empty_leads, intern_sorted)
+
+
+def mk_task(leads, reads, contig_len, trs=None, task_id=0, sv_id_start=0, qc_nm_threshold=0.02,
+            contig="chrT") -> TaskInput:
+    """Hand-made task.  `leads`: list of dicts with reference Lead attribute names
+    (svtype, ref_start, svlen, read, strand '+'/'-', seq, hap, ps, mate=(contig,pos,is_first,is_reverse) ...)."""
+    n = len(leads)
+    L = empty_leads(n)
+    qn, qrank = intern_sorted([str(d.get("read", f"r{i}")) for i, d in enumerate(leads)])
+    ps_all = [d["ps"] for d in leads if d.get("ps") is not None] + ["NULL"]
+    psn, psrank = intern_sorted(ps_all)
+    ctg_all = [d["mate"][0] for d in leads if d.get("mate")] + ["chr1"]
+    cn, crank = intern_sorted(ctg_all)
+    pool = bytearray()
+    read_ids = {}
+    for i, d in enumerate(leads):
+        t = d["svtype"]
+        L["svtype"][i] = SVT[t]
+        rs = int(d["ref_start"])
+        svlen = d.get("svlen", 0)
+        L["ref_start"][i] = rs
+        L["svlen"][i] = SVLEN_NONE if svlen is None else int(svlen)
+        L["ref_end"][i] = d.get("ref_end", rs - abs(svlen or 0) if t == "DEL" else rs)
+        L["qry_start"][i] = d.get("qry_start", 1000 + i * 7)
+        L["qry_end"][i] = d.get("qry_end", L["qry_start"][i] + (svlen if (t == "INS" and svlen) else 0))
+        L["read_len"][i] = d.get("read_len", 20000)
+        q = str(d.get("read", f"r{i}"))
+        L["qname_id"][i] = qrank[q]
+        L["read_id"][i] = d.get("read_id", read_ids.setdefault(q, len(read_ids) + 1))
+        L["strand"][i] = 1 if d.get("strand", "+") == "-" else 0
+        L["mapq"][i] = d.get("mapq", 60)
+        L["nm"][i] = d.get("nm", 0.01)
+        L["source"][i] = SRC[d.get("source", "BND_SA" if t == "BND" else "INLINE")]
+        L["hap"][i] = int(d.get("hap", 0))
+        ps = d.get("ps", None if t == "BND" else "NULL")
+        L["ps_rank"][i] = PS_NONE if ps is None else psrank[ps]
+        L["is_sa"][i] = int(d.get("is_sa", 0))
+        seq = d.get("seq")
+        if seq is not None:
+            L["seq_off"][i] = len(pool)
+            L["seq_len"][i] = len(seq)
+            pool += seq.encode("latin-1")
+        else:
+            L["seq_len"][i] = SEQ_NONE
+        if d.get("mate"):
+            mc, mp, fi, rv = d["mate"]
+            L["mate_contig"][i] = crank[mc]
+            L["mate_ref_start"][i] = mp
+            L["bnd_is_first"][i] = int(fi)
+            L["bnd_is_reverse"][i] = int(rv)
+    rs = np.array([r[0] for r in reads], np.int32)
+    re_ = np.array([r[1] for r in reads], np.int32)
+    rh = np.array([r[2] if len(r) > 2 else 0 for r in reads], np.uint8)
+    o = np.argsort(rs, kind="stable")
+    ti = TaskInput(task_id=task_id, contig=contig, contig_len=contig_len, sv_id_start=sv_id_start, leads=L,
+                   seq_pool=np.frombuffer(bytes(pool), np.uint8).copy(),
+                   read_start=rs[o], read_end=re_[o], read_hp=rh[o],
+                   tr_start=None if trs is None else np.array([t[0] for t in trs], np.int32),
+                   tr_end=None if trs is None else np.array([t[1] for t in trs], np.int32),
+                   qc_nm_threshold=qc_nm_threshold, qnames=qn, ps_names=psn, contig_names=cn)
+    ti.validate()
+    return ti
+
+
+def _reads(n, s, e, hp=0):
+    return [(s, e, hp)] * n
+
+
+def _rng_seq(rng, n):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+
+def _mutate(rng, s, rate):
+    b = list(s)
+    for i in range(len(b)):
+        if rng.random() < rate:
+            b[i] = "ACGT"[rng.integers(0, 4)]
+    return "".join(b)
+
+
+# ----------------------------------------------------------------------------- hand-made cases
+def case_resplit_wrap():
+    """svlens {60,80,120} -> bins 60,80,120 -> wrap-around merge into one cluster."""
+    leads = []
+    for i, sl in enumerate([60, 60, 80, 80, 120, 120, 61, 119]):
+        leads.append(dict(svtype="DEL", ref_start=10050 + i, svlen=-sl, read=f"a{i}", strand="+-"[i % 2]))
+    return mk_task(leads, _reads(20, 0, 30000), 30000)
+
+
+def case_merge_index_rule():
+    """chains of adjacent / one-bin-apart seed clusters with small and large stdev."""
+    leads = []
+    k = 0
+    for b in [10000, 10100, 10200, 10400, 10500, 10700, 10900, 11200, 11300, 11400, 11600]:
+        for j in range(3):
+            leads.append(dict(svtype="DEL", ref_start=b + [1, 50, 98][j], svlen=-(200 + (k % 3)), read=f"m{k}",
+                              strand="+-"[k % 2]))
+            k += 1
+    return mk_task(leads, _reads(25, 0, 40000), 40000)
+
+
+def case_bnd_first_error():
+    """a task whose only candidates are BNDs raises UnboundLocalError in coverage()."""
+    leads = [dict(svtype="BND", ref_start=5000 + i % 2, read=f"b{i}", strand="+-"[i % 2],
+                  mate=("chr2", 70000 + i, True, False)) for i in range(6)]
+    return mk_task(leads, _reads(20, 0, 20000), 20000)
+
+
+def case_bnd_stale_end():
+    """BND inherits `end` of the last non-BND candidate; mixed mates exercise resplit_bnd."""
+    leads = [dict(svtype="DEL", ref_start=3000 + i % 3, svlen=-400, read=f"d{i}", strand="+-"[i % 2]) for i in range(6)]
+    leads += [dict(svtype="INV", ref_start=8000 + i % 2, svlen=900, read=f"v{i}", strand="+-"[i % 2], source="SPLIT_SUP")
+              for i in range(5)]
+    mates = [("chr2", 70000, True, False), ("chr2", 70010, True, False), ("chr2", 71200, True, False),
+             ("chr2", 74000, True, False), ("chr10", 500, False, True), ("chr10", 650, False, True),
+             ("chr2", 70020, False, False), ("chr2", 70030, True, True), ("chr2", 69990, True, False)]
+    leads += [dict(svtype="BND", ref_start=12000 + (i % 3), read=f"b{i}", strand="+-"[i % 2], mate=m)
+              for i, m in enumerate(mates)]
+    leads += [dict(svtype="BND", ref_start=40, read=f"e{i}", strand="+-"[i % 2], mate=("chr1", 900 + i, True, False))
+              for i in range(4)]  # start-100 < 0 -> numpy negative-index wrap
+    leads += [dict(svtype="SINGLE_LEFT", ref_start=15000, svlen=0, read=f"s{i}") for i in range(3)]
+    return mk_task(leads, _reads(18, 0, 19950) + _reads(5, 100, 9000, 1), 20000)
+
+
+def case_merge_inner():
+    """merge_inner (cluster.py:85-122): same-read fusion within cluster_merge_pos, strand guard,
+    None-propagating seq, and a repeat cluster (threshold -1) that fuses everything per read."""
+    rng = np.random.default_rng(11)
+    allele = _rng_seq(rng, 300)
+    leads = []
+    for i in range(8):
+        q = 2000 + i
+        if i < 5:  # two pieces on one read, close on ref and query
+            leads.append(dict(svtype="INS", ref_start=5000, svlen=150, read=f"r{i}", qry_start=q, qry_end=q + 150,
+                              seq=_mutate(rng, allele[:150], 0.03), strand="+-"[i % 2]))
+            leads.append(dict(svtype="INS", ref_start=5060, svlen=150, read=f"r{i}", qry_start=q + 210, qry_end=q + 360,
+                              seq=_mutate(rng, allele[150:], 0.03) if i != 2 else None, strand="+-"[i % 2]))
+        elif i == 5:  # far on the query: no fusion
+            leads.append(dict(svtype="INS", ref_start=5001, svlen=150, read=f"r{i}", qry_start=q, qry_end=q + 150, seq=allele[:150]))
+            leads.append(dict(svtype="INS", ref_start=5061, svlen=150, read=f"r{i}", qry_start=q + 2000, qry_end=q + 2150, seq=allele[150:]))
+        elif i == 6:  # strand differs: no fusion
+            leads.append(dict(svtype="INS", ref_start=5002, svlen=150, read=f"r{i}", qry_start=q, qry_end=q + 150, seq=allele[:150], strand="+"))
+            leads.append(dict(svtype="INS", ref_start=5062, svlen=150, read=f"r{i}", qry_start=q + 200, qry_end=q + 350, seq=allele[150:], strand="-"))
+        else:
+            leads.append(dict(svtype="INS", ref_start=5003, svlen=300, read=f"r{i}", qry_start=q, qry_end=q + 300, seq=_mutate(rng, allele, 0.03)))
+    # repeat region: DEL pieces on the same reads far apart still fuse (threshold -1)
+    for i in range(6):
+        leads.append(dict(svtype="DEL", ref_start=9100 + i, svlen=-70, read=f"t{i}", qry_start=500, strand="+-"[i % 2]))
+        leads.append(dict(svtype="DEL", ref_start=9190 - i, svlen=-90, read=f"t{i}", qry_start=9000, strand="-+"[i % 2]))
+    return mk_task(leads, _reads(22, 0, 15000), 15000, trs=[(8500, 9800)])
+
+
+def case_long_ins():
+    """INS >= long_ins_length: leads_long support union, SUPPORT_LONG, rescale_support, z-score exemption."""
+    rng = np.random.default_rng(5)
+    allele = _rng_seq(rng, 2700)
+    leads = []
+    for i in range(4):
+        leads.append(dict(svtype="INS", ref_start=20010 + i, svlen=2700 + i, read=f"f{i}", seq=_mutate(rng, allele, 0.05) + "A" * i,
+                          strand="+-"[i % 2]))
+    for i in range(7):
+        leads.append(dict(svtype="INS", ref_start=20020 + i, svlen=None, read=f"c{i}" if i < 5 else f"f{i - 5}", strand="+-"[i % 2]))
+    # a second bin with only clipped leads (dropped) and one with 1 normal + clips (dropped: <2 normal)
+    for i in range(3):
+        leads.append(dict(svtype="INS", ref_start=30010, svlen=None, read=f"x{i}"))
+    leads.append(dict(svtype="INS", ref_start=31010, svlen=500, read="y0", seq=_rng_seq(rng, 500)))
+    leads.append(dict(svtype="INS", ref_start=31011, svlen=None, read="y1"))
+    return mk_task(leads, _reads(30, 0, 50000), 50000)
+
+
+def case_gt_failed_and_edges():
+    """Zero coverage -> GT_FAILED; calls next to the contig end -> IndexError samples keep 0."""
+    leads = [dict(svtype="DEL", ref_start=1000 + i, svlen=-300, read=f"z{i}", strand="+-"[i % 2]) for i in range(5)]
+    leads += [dict(svtype="DEL", ref_start=9990 - i, svlen=-120, read=f"w{i}", strand="+-"[i % 2]) for i in range(5)]
+    leads += [dict(svtype="DUP", ref_start=9800 + i, svlen=700, read=f"u{i}", strand="+-"[i % 2], source="SPLIT_SUP") for i in range(4)]
+    return mk_task(leads, _reads(12, 5000, 10000), 10000)
+
+
+def case_compute_metrics_big():
+    """compute_metrics with > 100 leads: 150 and 250 leads per bin; seq cap at 10 per bin."""
+    rng = np.random.default_rng(3)
+    allele = _rng_seq(rng, 100)
+    leads = []
+    for i in range(150):
+        leads.append(dict(svtype="DEL", ref_start=7000 + (i * 7) % 100, svlen=-(100 + i % 5), read=f"p{i}", strand="+-"[i % 2]))
+    for i in range(250):
+        leads.append(dict(svtype="INS", ref_start=7200 + (i * 3) % 100, svlen=100, read=f"q{i}", seq=_mutate(rng, allele, 0.05),
+                          strand="+-"[i % 2]))
+    for i in range(130):
+        leads.append(dict(svtype="INS", ref_start=7300 + (i * 11) % 100, svlen=100 + (i % 3), read=f"q{i + 300}",
+                          seq=_mutate(rng, allele, 0.05) + "C" * (i % 3), strand="+-"[i % 2]))
+    return mk_task(leads, _reads(260, 0, 20000), 20000)
+
+
+def case_phase_rescue():
+    """phase_sv majorities, hom-alt phase override, rescue_phasing of a MOSAIC_VAF call via hap counts."""
+    leads = []
+    # het on hap 1, low VAF (reads of hap 1 only, few) -> MOSAIC_VAF, rescued (sv_reads/all_reads >= .75)
+    for i in range(5):
+        leads.append(dict(svtype="DEL", ref_start=4000 + i % 2, svlen=-250, read=f"h{i}", hap=1, ps="4001", strand="+-"[i % 2],
+                          nm=0.01 + i * 0.003))
+    # hom-alt with phased reads -> phase tuple forced from PHASE info
+    for i in range(12):
+        leads.append(dict(svtype="DEL", ref_start=12000 + i % 3, svlen=-500, read=f"g{i}", hap=2 if i < 9 else 1,
+                          ps="12001" if i < 9 else "NULL", strand="+-"[i % 2]))
+    # conflicting phases -> FAIL
+    for i in range(8):
+        leads.append(dict(svtype="INS", ref_start=16000 + i % 2, svlen=200, read=f"k{i}", hap=1 + i % 2, ps=["9", "10"][i % 2],
+                          strand="+-"[i % 2], seq="ACGT" * 50))
+    reads = _reads(6, 3000, 5000, 1) + _reads(24, 3000, 5000, 0) + _reads(2, 3000, 5000, 2) + _reads(12, 11000, 17500, 2) + \
+        _reads(1, 11000, 17500, 1)
+    return mk_task(leads, reads, 20000)
+
+
+def case_consensus_quirks():
+    """novel_from_reads quirks: j==0 first anchor, unequal advances, short reads, N/lowercase,
+    repeated k-mers (taboo), reads longer/shorter than best, exactly 4 others (threshold)."""
+    rng = np.random.default_rng(17)
+    allele = _rng_seq(rng, 420)
+    rep = ("ACGTTG" * 40)[:230]
+    leads = []
+    def add(pos, seq, name, svlen=None):
+        leads.append(dict(svtype="INS", ref_start=pos, svlen=len(seq) if svlen is None else svlen, read=name, seq=seq,
+                          strand="+-"[len(leads) % 2]))
+    # site A: indels in the others -> unequal advances
+    add(2000, allele, "a0")
+    add(2001, allele[:100] + "GG" + allele[100:], "a1")
+    add(2002, allele[:200] + allele[203:], "a2")
+    add(2003, _mutate(rng, allele, 0.1), "a3")
+    add(2004, allele[3:], "a4")
+    add(2005, "TT" + allele, "a5")
+    add(2006, allele[:50].lower() + allele[50:300] + "N" * 5 + allele[305:], "a6")
+    add(2007, "ACG", "a7", svlen=420)          # shorter than k
+    # site B: low complexity -> taboo k-mers, exactly 4 others
+    for i in range(5):
+        add(6000 + i, _mutate(rng, rep, 0.02), f"b{i}")
+    # site C: 3 others only -> no consensus, best lead verbatim
+    for i in range(4):
+        add(9000 + i, _mutate(rng, allele[:130], 0.08), f"c{i}")
+    # site D: systematic error in the best read corrected by voters
+    base = _rng_seq(rng, 360)
+    wrong = base[:180] + ("A" if base[180] != "A" else "C") + base[181:]
+    add(12000, wrong, "d0")
+    for i in range(7):
+        add(12001 + i % 3, base, f"d{i + 1}")
+    return mk_task(leads, _reads(30, 0, 20000), 20000)
+
+
+def case_long_del_dup_cov():
+    """COV_CHANGE_DEL / COV_CHANGE_DUP / COV_MIN / SVLEN_MIN branches on >= 50 kb events."""
+    leads = []
+    for i in range(6):
+        leads.append(dict(svtype="DEL", ref_start=160000 + i % 2, svlen=-60000, read=f"l{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+    for i in range(6):
+        leads.append(dict(svtype="DUP", ref_start=300000 + i % 2, svlen=70000, read=f"m{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+    for i in range(12):
+        leads.append(dict(svtype="DEL", ref_start=500000 + i % 3, svlen=-47 - (i % 4), read=f"n{i}", strand="+-"[i % 2]))
+    for i in range(5):
+        leads.append(dict(svtype="INV", ref_start=650000 + i % 2, svlen=15000, read=f"o{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+    reads = _reads(30, 0, 125000) + _reads(12, 90000, 200000) + _reads(20, 150000, 420000) + _reads(25, 330000, 360000) + \
+        _reads(20, 400000, 640000) + _reads(9, 670000, 700000)
+    return mk_task(leads, reads, 700000)
+
+
+def case_tr_sweep():
+    """Tandem-repeat sweep semantics (cluster.py:240-246) with nested/overlapping TRs and repeat merging."""
+    leads = []
+    k = 0
+    for b, n, sl in [(3050, 3, 300), (3450, 3, 310), (4250, 2, 100), (5050, 3, 90), (5650, 3, 95), (7050, 4, 80), (9050, 2, 60)]:
+        for j in range(n):
+            leads.append(dict(svtype="INS", ref_start=b + j * 9, svlen=sl + j, read=f"t{k}", seq="ACGTTGCA" * ((sl + j) // 8) + "A" * ((sl + j) % 8),
+                              strand="+-"[k % 2]))
+            k += 1
+    trs = [(2000, 8000), (2500, 3100), (3000, 3600), (5000, 5200), (6900, 7200), (9000, 9040)]
+    return mk_task(leads, _reads(20, 0, 12000), 12000, trs=trs)
+
+
+def case_empty():
+    return mk_task([], _reads(3, 0, 5000), 5000)
+
+
+def case_single_leads_only():
+    """bins with a single lead never seed a cluster (cluster.py:262) -> no candidates."""
+    leads = [dict(svtype="DEL", ref_start=1000 + 300 * i, svlen=-100, read=f"s{i}") for i in range(8)]
+    return mk_task(leads, _reads(10, 0, 5000), 5000)
+
+
+HAND = {
+    "resplit_wrap": (case_resplit_wrap, {}, ()),
+    "merge_index_rule": (case_merge_index_rule, {}, ()),
+    "bnd_first_error": (case_bnd_first_error, {}, ()),
+    "bnd_stale_end": (case_bnd_stale_end, {}, ()),
+    "merge_inner": (case_merge_inner, {}, ()),
+    "long_ins": (case_long_ins, {}, ()),
+    "gt_failed_edges": (case_gt_failed_and_edges, {}, ()),
+    "compute_metrics_big": (case_compute_metrics_big, {}, ()),
+    "phase_rescue": (case_phase_rescue, {}, ()),
+    "consensus_quirks": (case_consensus_quirks, {}, ()),
+    "long_del_dup_cov": (case_long_del_dup_cov, {}, ()),
+    "long_del_dup_cov_mosaic": (case_long_del_dup_cov, dict(mosaic=True), ("--mosaic",)),
+    "tr_sweep": (case_tr_sweep, {}, ()),
+    "tr_sweep_repeat": (case_tr_sweep, dict(repeat=True), ("--repeat",)),
+    "empty": (case_empty, {}, ()),
+    "single_leads_only": (case_single_leads_only, {}, ()),
+    "single_leads_noqc": (case_single_leads_only, dict(no_qc=True), ("--no-qc",)),
+    "phase_off_symbolic": (case_consensus_quirks, dict(symbolic=True), ("--symbolic",)),
+    "no_consensus": (case_consensus_quirks, dict(no_consensus=True), ("--no-consensus",)),
+}
+
+# seeded synthetic (SURVEY.md 8d shapes, shrunk contigs) --------------------------------------------
+SYNTH = {
+    "chr20_30x_ont": (lambda: synth.gen_task(0, "chr20", 3_000_000, 30, 1), {}, ()),
+    "chr21_30x_mosaic": (lambda: synth.gen_task(1, "chr21", 2_500_000, 30, 3, mosaic_frac=0.3), dict(mosaic=True), ("--mosaic",)),
+    "chr22_60x_hifi": (lambda: synth.gen_task(2, "chr22", 2_000_000, 60, 2, err=0.005), {}, ()),
+    "chr19_30x_no_tr": (lambda: _no_tr(synth.gen_task(3, "chr19", 2_000_000, 30, 5)), {}, ()),
+    "chr18_20x_auto_nm": (lambda: synth.gen_task(4, "chr18", 2_000_000, 20, 6), dict(minsupport="auto", qc_nm=True),
+                          ("--minsupport", "auto", "--qc-nm")),
+    "chr17_15x_noqc": (lambda: synth.gen_task(5, "chr17", 1_500_000, 15, 7), dict(no_qc=True), ("--no-qc",)),
+}
+
+_FUZZ_CFG = [
+    ({}, ()),
+    (dict(mosaic=True), ("--mosaic",)),
+    (dict(minsupport="auto", qc_nm=True), ("--minsupport", "auto", "--qc-nm")),
+    (dict(no_qc=True), ("--no-qc",)),
+    (dict(qc_strand=True, minsvlen="50", cluster_merge_pos=50), ("--qc-strand", "True", "--minsvlen", "50", "--cluster-merge-pos", "50")),
+    (dict(repeat=True, mosaic=True, mosaic_include_germline=True), ("--repeat", "--mosaic", "--mosaic-include-germline")),
+]
+FUZZ = {f"fuzz_{s}_{ci}": ((lambda s=s: synth.gen_fuzz(s, n_leads=400 + 90 * s, contig_len=30000 + 4000 * s)), kw, args)
+        for s in range(12) for ci, (kw, args) in enumerate(_FUZZ_CFG) if (s + ci) % 3 == 0}
+
+
+def _no_tr(ti):
+    ti.tr_start = None
+    ti.tr_end = None
+    return ti
+
+
+ALL = {**HAND, **SYNTH, **FUZZ}
