@@ -47,6 +47,7 @@ def lib():
         _lib.snf_oracle_np_sum.restype = C.c_double
         _lib.snf_oracle_stdev.argtypes = [C.POINTER(C.c_int64), C.c_int64]
         _lib.snf_oracle_stdev.restype = C.c_double
+        _lib.snf_oracle_hot_seconds.restype = C.c_double
     return _lib
 
 
@@ -79,3 +80,8 @@ def np_sum(x: np.ndarray) -> float:
 def stdev(x) -> float:
     x = np.ascontiguousarray(x, np.int64)
     return float(lib().snf_oracle_stdev(x.ctypes.data_as(C.POINTER(C.c_int64)), x.shape[0]))
+
+
+def hot_seconds() -> float:
+    """Seconds the last run() spent in call_candidates + finalize_candidates (coverage-vector build excluded)."""
+    return float(lib().snf_oracle_hot_seconds())

@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef unsigned __int128 u128;
 
@@ -1118,6 +1119,12 @@ static void build_coverage(Task* T) {
   }
 }
 
+static double g_hot_seconds = 0.0;
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+/* seconds spent inside call_candidates + finalize_candidates of the last snf_oracle_run (excludes building the
+ * dense coverage vector / hap tables, which the reference does during BAM extraction, leadprov.py:474-578) */
+double snf_oracle_hot_seconds(void) { return g_hot_seconds; }
+
 static void run_task(Task* T, int do_finalize) {
   const snf_task_input_t* in = T->in; const snf_config_t* cfg = T->cfg; Arena* ar = T->ar;
   T->n = in->n_leads;
@@ -1136,6 +1143,7 @@ static void run_task(Task* T, int do_finalize) {
     l->orig = (l->ref_start >= 0 && l->ref_start < in->contig_len) ? i : -1;
   }
   build_coverage(T);
+  double t_hot0 = now_s();
   T->sv_id = in->sv_id_start;
   /* Task.call_candidates (parallel.py:104-127) */
   for (int svtype = 0; svtype < SNF_NTYPES; svtype++) {
@@ -1152,8 +1160,8 @@ static void run_task(Task* T, int do_finalize) {
     }
   }
   annotate_coverage(T);
-  if (T->status != SNF_TASK_OK) { T->calls.n = 0; return; }
-  if (!do_finalize) return;
+  if (T->status != SNF_TASK_OK) { T->calls.n = 0; g_hot_seconds += now_s() - t_hot0; return; }
+  if (!do_finalize) { g_hot_seconds += now_s() - t_hot0; return; }
   /* Task.finalize_candidates (parallel.py:129-201) */
   for (int64_t i = 0; i < T->calls.n; i++) {
     OCall* oc = &T->calls.a[i]; snf_call_t* c = &oc->c;
@@ -1168,6 +1176,7 @@ static void run_task(Task* T, int do_finalize) {
                           c->support >= (int)((double)cfg->dev_minreads_extra * 0.60));
     if (cfg->phase && !c->qc && phasing_rescue) rescue_phasing(T, oc);
   }
+  g_hot_seconds += now_s() - t_hot0;
 }
 
 /* ------------------------------------------------------------------ public (tests / bench only) */
@@ -1182,6 +1191,7 @@ int snf_oracle_run(const snf_config_t* cfg, const snf_task_input_t* tasks, int n
   Task* T = (Task*)calloc((size_t)n_tasks, sizeof(Task));
   Arena* arenas = (Arena*)calloc((size_t)n_tasks, sizeof(Arena));
   int64_t ncalls = 0, altlen = 0, rnlen = 0;
+  g_hot_seconds = 0.0;
   for (int t = 0; t < n_tasks; t++) {
     T[t].ar = &arenas[t]; T[t].cfg = cfg; T[t].in = &tasks[t]; T[t].task_index = t;
     run_task(&T[t], do_finalize);

@@ -1,0 +1,234 @@
+// snf_exact.h - bit-exact numeric building blocks shared by the kernel bodies.
+//
+// The reference computes its statistics with CPython 3.10 `statistics` (exact rational variance,
+// ONE rounding to double, then math.sqrt; util.py:25-27) and plain IEEE double arithmetic.  These
+// helpers reproduce that on gfx950 without fused multiply-add (compile with -ffp-contract=off).
+#pragma once
+#include "snf_rt.h"
+
+#include <cmath>
+
+namespace snf {
+
+SNF_HD int bitlen128(u128 x) {
+  uint64_t hi = (uint64_t)(x >> 64), lo = (uint64_t)x;
+  if (hi) return 128 - __builtin_clzll(hi);
+  if (lo) return 64 - __builtin_clzll(lo);
+  return 0;
+}
+
+// quotient and remainder of a 128-bit numerator by a 64-bit denominator (schoolbook, bitwise)
+SNF_HD void udivmod128_64(u128 num, uint64_t den, u128* q, uint64_t* r) {
+  u128 rem = 0, quo = 0;
+  int n = bitlen128(num);
+  for (int b = n - 1; b >= 0; b--) {
+    rem = (rem << 1) | ((num >> b) & 1);
+    if (rem >= den) {
+      rem -= den;
+      quo |= ((u128)1) << b;
+    }
+  }
+  *q = quo;
+  *r = (uint64_t)rem;
+}
+
+// correctly rounded (nearest-even) double of the exact rational num/den: float(Fraction(num, den))
+SNF_HD double ratio_to_double(u128 num, uint64_t den) {
+  if (num == 0) return 0.0;
+  if ((num >> 53) == 0 && (den >> 53) == 0) return (double)(uint64_t)num / (double)den;  // both exact in fp64
+  int bn = bitlen128(num), bd = 64 - __builtin_clzll(den);
+  int s = 55 - (bn - bd);  // quotient gets 55 or 56 bits
+  bool sticky = false;
+  u128 N;
+  if (s >= 0) {
+    N = num << s;  // bn + s = 55 + bd <= 119 bits
+  } else {
+    N = num >> (-s);
+    sticky = (num & ((((u128)1) << (-s)) - 1)) != 0;
+  }
+  u128 q;
+  uint64_t r;
+  udivmod128_64(N, den, &q, &r);
+  uint64_t q64 = (uint64_t)q;
+  if (r || sticky) q64 |= 1;
+  return ldexp((double)q64, -s);
+}
+
+// statistics.stdev of n integers given S1 = sum(d), S2 = sum(d*d), d = x - x0 (any offset x0)
+SNF_HD double stdev_from_sums(int64_t n, i128 S1, u128 S2) {
+  if (n < 2) return 0.0;
+  u128 num = (u128)n * S2 - (u128)(S1 * S1);
+  uint64_t den = (uint64_t)n * (uint64_t)(n - 1);
+  return sqrt(ratio_to_double(num, den));
+}
+
+// stdev of a[0..n) (already any order)
+SNF_HD double stdev_i32(const int32_t* a, int64_t n) {
+  if (n < 2) return 0.0;
+  i128 S1 = 0;
+  u128 S2 = 0;
+  int64_t x0 = a[0];
+  for (int64_t i = 0; i < n; i++) {
+    int64_t d = (int64_t)a[i] - x0;
+    S1 += d;
+    S2 += (u128)((i128)d * d);
+  }
+  return stdev_from_sums(n, S1, S2);
+}
+
+// ---- small sorts on scratch memory ------------------------------------------------------------
+// sort a[0..n) with a strict-weak `less`; callers make keys total (append the index) so the result
+// is independent of the algorithm.  Insertion for short inputs, heapsort otherwise: O(n log n), in place.
+template <class T, class Less>
+SNF_HD void sort_inplace(T* a, int64_t n, Less less) {
+  if (n < 2) return;
+  if (n <= 20) {
+    for (int64_t i = 1; i < n; i++) {
+      T x = a[i];
+      int64_t j = i - 1;
+      while (j >= 0 && less(x, a[j])) {
+        a[j + 1] = a[j];
+        j--;
+      }
+      a[j + 1] = x;
+    }
+    return;
+  }
+  for (int64_t start = n / 2 - 1; start >= 0; start--) {  // heapify
+    int64_t root = start;
+    T x = a[root];
+    for (;;) {
+      int64_t c = 2 * root + 1;
+      if (c >= n) break;
+      if (c + 1 < n && less(a[c], a[c + 1])) c++;
+      if (!less(x, a[c])) break;
+      a[root] = a[c];
+      root = c;
+    }
+    a[root] = x;
+  }
+  for (int64_t end = n - 1; end > 0; end--) {
+    T x = a[end];
+    a[end] = a[0];
+    int64_t root = 0;
+    for (;;) {
+      int64_t c = 2 * root + 1;
+      if (c >= end) break;
+      if (c + 1 < end && less(a[c], a[c + 1])) c++;
+      if (!less(x, a[c])) break;
+      a[root] = a[c];
+      root = c;
+    }
+    a[root] = x;
+  }
+}
+
+struct LessI32 {
+  SNF_HD bool operator()(int32_t a, int32_t b) const { return a < b; }
+};
+struct LessU32 {
+  SNF_HD bool operator()(uint32_t a, uint32_t b) const { return a < b; }
+};
+
+// util.median_modes (= util.center, util.py:49-58,167) on a SORTED array: values whose count is within 2
+// of the max count, upper median of those distinct values
+SNF_HD int32_t center_sorted(const int32_t* s, int64_t n) {
+  int64_t maxc = 0;
+  for (int64_t i = 0; i < n;) {
+    int64_t j = i;
+    while (j < n && s[j] == s[i]) j++;
+    if (j - i > maxc) maxc = j - i;
+    i = j;
+  }
+  int64_t k = 0;
+  for (int64_t i = 0; i < n;) {
+    int64_t j = i;
+    while (j < n && s[j] == s[i]) j++;
+    if (maxc - (j - i) < 3) k++;
+    i = j;
+  }
+  int64_t want = k / 2, seen = 0;
+  for (int64_t i = 0; i < n;) {
+    int64_t j = i;
+    while (j < n && s[j] == s[i]) j++;
+    if (maxc - (j - i) < 3) {
+      if (seen == want) return s[i];
+      seen++;
+    }
+    i = j;
+  }
+  return s[0];
+}
+
+// util.stdev(util.trim(nums)) on a SORTED array (util.py:25-27,82-88)
+SNF_HD double stdev_trim_sorted(const int32_t* s, int64_t n) {
+  int64_t trim_n = (int64_t)((double)n / 100.0 * 25.0);
+  if (trim_n > 0) return stdev_i32(s + trim_n, n - 2 * trim_n);
+  return stdev_i32(s, n);
+}
+
+// first index in [lo,hi) with a[idx] >= x / > x
+SNF_HD int64_t lower_bound_i32(const int32_t* a, int64_t lo, int64_t hi, int64_t x) {
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)a[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+SNF_HD int64_t upper_bound_i32(const int32_t* a, int64_t lo, int64_t hi, int64_t x) {
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)a[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// numpy's pairwise float64 summation (np.sum / np.nanmean, used by parallel.py:214), gather form:
+// element i is get(i).  Iterative restatement of the recursion (depth <= 40).
+template <class Get>
+SNF_HD double np_pairwise_sum(Get get, int64_t n) {
+  struct Fr { int64_t lo, n; int state; double left; };
+  Fr st[48];
+  int sp = 0;
+  st[0] = Fr{0, n, 0, 0.0};
+  double ret = 0.0;
+  while (sp >= 0) {
+    Fr& f = st[sp];
+    if (f.state == 0) {
+      if (f.n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < f.n; i++) res += get(f.lo + i);
+        ret = res; sp--;
+      } else if (f.n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = get(f.lo + j);
+        int64_t i;
+        for (i = 8; i < f.n - (f.n % 8); i += 8)
+          for (int j = 0; j < 8; j++) r[j] += get(f.lo + i + j);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < f.n; i++) res += get(f.lo + i);
+        ret = res; sp--;
+      } else {
+        int64_t n2 = f.n / 2;
+        n2 -= n2 % 8;
+        f.state = 1;
+        st[sp + 1] = Fr{f.lo, n2, 0, 0.0};
+        sp++;
+      }
+    } else if (f.state == 1) {
+      f.left = ret;
+      int64_t n2 = f.n / 2;
+      n2 -= n2 % 8;
+      f.state = 2;
+      st[sp + 1] = Fr{f.lo + n2, f.n - n2, 0, 0.0};
+      sp++;
+    } else {
+      ret = f.left + ret; sp--;
+    }
+  }
+  return ret;
+}
+
+SNF_HD int64_t iabs64(int64_t x) { return x < 0 ? -x : x; }
+
+}  // namespace snf

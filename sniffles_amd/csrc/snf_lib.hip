@@ -1,0 +1,749 @@
+// snf_lib.hip - C-ABI implementation (include/sniffles_amd.h): batch state in HBM, launch sequence,
+// per-kernel HIP-event timing.  Built for gfx950 with
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off: the reference's double arithmetic has no fused multiply-add).
+#include "snf_stage_final.h"
+
+#ifndef SNF_EMU
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#endif
+
+#include <cmath>
+#include <memory>
+
+using namespace snf;
+
+// ---------------------------------------------------------------------------------------------- kernels
+SNF_KERNEL(a1_keys, View)
+SNF_KERNEL(a2_heads, View)
+SNF_KERNEL(a3_bins, View)
+SNF_KERNEL(a4_binstats, View)
+SNF_KERNEL(a5_leadflags, View)
+SNF_KERNEL(a6_scatter, View)
+SNF_KERNEL(a7_seeds, View)
+SNF_KERNEL(b1_seedmetrics, View)
+SNF_KERNEL(b2_runs, View)
+SNF_KERNEL(c1_mergeruns, View)
+SNF_KERNEL(c2_validate, View)
+SNF_KERNEL(c3_serial, View)
+SNF_KERNEL(c4_clusters, View)
+SNF_KERNEL(d1_refine, View)
+SNF_KERNEL(d1b_rctable, View)
+SNF_KERNEL(d2_call, View)
+SNF_KERNEL(d3_compact, View)
+SNF_KERNEL(d3_taskoff, View)
+SNF_KERNEL(d3_svid, View)
+SNF_KERNEL(d3_stale, View)
+SNF_KERNEL(d3_rnames, View)
+SNF_KERNEL(d4_coverage, View)
+SNF_KERNEL(d5_covsum, View)
+SNF_KERNEL(d5_covavg, View)
+SNF_KERNEL(e1_finalize, View)
+SNF_KERNEL(e2_best, View)
+SNF_KERNEL(e3_conslist, View)
+SNF_KERNEL(e4_anchor, View)
+SNF_KERNEL(e5_align, View)
+SNF_KERNEL(e6_vote, View)
+
+// read preparation (coverage rank structures + REF haplotype prefix counts)
+struct ReadPrep {
+  const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task; const int32_t* r_start;
+  uint64_t* rk_in; uint32_t* rv_in; const uint64_t* rk_out; const uint32_t* rv_out;
+  int32_t* re_sorted; uint32_t* fs[3]; uint32_t* fe[3]; int64_t R;
+};
+namespace snf {
+SNF_HD void r1_endkeys_body(int64_t r, const ReadPrep& p) {
+  p.rk_in[r] = ((uint64_t)(uint32_t)p.r_task[r] << 32) | (uint32_t)p.r_end[r];
+  p.rv_in[r] = p.r_hp[r];
+  for (int h = 0; h < 3; h++) { p.fs[h][r] = p.r_hp[r] == h; if (r == 0) p.fs[h][p.R] = 0; }
+}
+SNF_HD void r2_unpack_body(int64_t r, const ReadPrep& p) {
+  p.re_sorted[r] = (int32_t)(uint32_t)p.rk_out[r];
+  for (int h = 0; h < 3; h++) { p.fe[h][r] = p.rv_out[r] == (uint32_t)h; if (r == 0) p.fe[h][p.R] = 0; }
+}
+}  // namespace snf
+SNF_KERNEL(r1_endkeys, ReadPrep)
+SNF_KERNEL(r2_unpack, ReadPrep)
+
+// ---------------------------------------------------------------------------------------------- batch
+namespace {
+
+thread_local std::string g_err;
+
+struct DevBuf { void* p; size_t bytes; };
+
+struct Timing { const char* name; float ms; int64_t bytes; int launches; };
+
+struct snf_batch_impl {
+  snf_config_t cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool uploaded = false;
+  int run_gap = 1000;
+  // host staging
+  std::vector<snf_task_input_t> tasks;  // scalar fields only (pointers invalid after add)
+  std::vector<int32_t> h_ref_start, h_ref_end, h_qry_start, h_qry_end, h_svlen, h_read_len, h_ps, h_mate_contig,
+      h_mate_pos, h_seq_len, h_lead_task;
+  std::vector<uint32_t> h_qname, h_read_id;
+  std::vector<int64_t> h_seq_off;
+  std::vector<double> h_nm;
+  std::vector<uint8_t> h_svtype, h_strand, h_mapq, h_source, h_hap, h_is_sa, h_first, h_rev, h_pool;
+  std::vector<int32_t> h_rstart, h_rend, h_rtask, h_trs, h_tre, h_trp;
+  std::vector<uint8_t> h_rhp;
+  std::vector<int64_t> h_lead_off{0}, h_read_off{0}, h_tr_off{0};
+  std::vector<int32_t> h_has_tr;
+  // device
+  std::vector<DevBuf> bufs;
+  View v{};
+  ReadPrep rp{};
+  Counts h_cnt{};
+  void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  // growable finalize scratch
+  int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
+  int64_t *d_sz_tab = nullptr, *d_sz_aln = nullptr, *d_sz_rd = nullptr;
+  // results (host)
+  std::vector<snf_call_t> r_calls; std::vector<uint8_t> r_alt; std::vector<uint32_t> r_rn;
+  std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
+  // timing
+  std::vector<Timing> timings;
+#ifndef SNF_EMU
+  struct Ev { hipEvent_t a, b; const char* name; int64_t bytes; };
+  std::vector<Ev> evs; size_t ev_used = 0;
+#endif
+};
+
+// ---- device memory ----
+template <class T>
+T* dalloc(snf_batch_impl* b, size_t n) {
+  size_t bytes = (n ? n : 1) * sizeof(T);
+  void* p = nullptr;
+#ifndef SNF_EMU
+  SNF_HIP(hipMalloc(&p, bytes));
+#else
+  p = calloc(1, bytes);
+#endif
+  b->bufs.push_back({p, bytes});
+  return (T*)p;
+}
+void dfree_all(snf_batch_impl* b) {
+  for (auto& d : b->bufs) {
+#ifndef SNF_EMU
+    (void)hipFree(d.p);
+#else
+    free(d.p);
+#endif
+  }
+  b->bufs.clear();
+}
+void dfree_one(snf_batch_impl* b, void* p) {
+  if (!p) return;
+  for (size_t i = 0; i < b->bufs.size(); i++)
+    if (b->bufs[i].p == p) {
+#ifndef SNF_EMU
+      (void)hipFree(p);
+#else
+      free(p);
+#endif
+      b->bufs.erase(b->bufs.begin() + i);
+      return;
+    }
+}
+void h2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+#else
+  memcpy(dst, src, bytes);
+#endif
+}
+void d2h(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream));
+#else
+  memcpy(dst, src, bytes);
+#endif
+}
+void dzero(snf_batch_impl* b, void* p, size_t bytes, int val = 0) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemsetAsync(p, val, bytes, b->stream));
+#else
+  memset(p, val, bytes);
+#endif
+}
+void dsync(snf_batch_impl* b) {
+#ifndef SNF_EMU
+  SNF_HIP(hipStreamSynchronize(b->stream));
+#endif
+}
+template <class T>
+T* upload_vec(snf_batch_impl* b, const std::vector<T>& h, size_t extra = 0) {
+  T* d = dalloc<T>(b, h.size() + extra);
+  h2d(b, d, h.data(), h.size() * sizeof(T));
+  return d;
+}
+
+// ---- timing ----
+struct Scope {
+  snf_batch_impl* b;
+#ifndef SNF_EMU
+  size_t idx;
+#endif
+  Scope(snf_batch_impl* b_, const char* name, int64_t bytes) : b(b_) {
+#ifndef SNF_EMU
+    if (b->ev_used == b->evs.size()) {
+      snf_batch_impl::Ev e{};
+      SNF_HIP(hipEventCreate(&e.a)); SNF_HIP(hipEventCreate(&e.b));
+      b->evs.push_back(e);
+    }
+    idx = b->ev_used++;
+    b->evs[idx].name = name; b->evs[idx].bytes = bytes;
+    SNF_HIP(hipEventRecord(b->evs[idx].a, b->stream));
+#else
+    (void)name; (void)bytes;
+#endif
+  }
+  ~Scope() {
+#ifndef SNF_EMU
+    (void)hipEventRecord(b->evs[idx].b, b->stream);
+#endif
+  }
+};
+
+#ifndef SNF_EMU
+#define LAUNCH(kern, view, n, bytes)                                                          \
+  do {                                                                                        \
+    int64_t _n = (n);                                                                         \
+    if (_n > 0) {                                                                             \
+      Scope _s(b, #kern, (bytes));                                                            \
+      hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->stream, view, _n); \
+      SNF_HIP(hipGetLastError());                                                             \
+    }                                                                                         \
+  } while (0)
+#else
+#define LAUNCH(kern, view, n, bytes) do { int64_t _n = (n); if (_n > 0) kern(view, _n); } while (0)
+#endif
+
+// ---- primitives: stable radix sort (key,value) and exclusive scans ----
+void prim_sort_pairs(snf_batch_impl* b, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, int64_t n,
+                     int end_bit, const char* name) {
+  if (n <= 0) return;
+#ifndef SNF_EMU
+  size_t need = 0;
+  SNF_HIP(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->stream));
+  if (need > b->sort_tmp_bytes) {
+    if (b->sort_tmp) { dsync(b); dfree_one(b, b->sort_tmp); }
+    b->sort_tmp = dalloc<uint8_t>(b, need); b->sort_tmp_bytes = need;
+  }
+  Scope s(b, name, n * 24);
+  SNF_HIP(rocprim::radix_sort_pairs(b->sort_tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->stream));
+#else
+  (void)end_bit; (void)name;
+  std::vector<int64_t> idx(n);
+  std::iota(idx.begin(), idx.end(), 0);
+  std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return kin[x] < kin[y]; });
+  for (int64_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
+#endif
+}
+template <class T>
+void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* name) {
+  if (n <= 0) return;
+#ifndef SNF_EMU
+  size_t need = 0;
+  SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->stream));
+  if (need > b->sort_tmp_bytes) {
+    if (b->sort_tmp) { dsync(b); dfree_one(b, b->sort_tmp); }
+    b->sort_tmp = dalloc<uint8_t>(b, need); b->sort_tmp_bytes = need;
+  }
+  Scope s(b, name, n * 2 * (int64_t)sizeof(T));
+  SNF_HIP(rocprim::exclusive_scan(b->sort_tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->stream));
+#else
+  (void)name;
+  T acc = 0;
+  for (int64_t i = 0; i < n; i++) { T x = in[i]; out[i] = acc; acc += x; }
+#endif
+}
+
+// ---- genotype table: exactly genotyping.py:124-171 for every (normalised support, coverage) ----
+double likelihood_ratio(double q1, double q2) {
+  if (q1 / q2 > 0) return std::log(q1 / q2) / std::log(10.0);  // math.log(x, 10)
+  return 0;
+}
+std::vector<GtEntry> build_gt_lut(const snf_config_t& cfg) {
+  std::vector<GtEntry> lut((size_t)SNF_GT_N * SNF_GT_N);
+  double p[3] = {cfg.genotype_error, 1.0 / (double)cfg.genotype_ploidy, 1.0 - cfg.genotype_error};
+  for (int ns = 0; ns < SNF_GT_N; ns++)
+    for (int ncv = 0; ncv < SNF_GT_N; ncv++) {
+      GtEntry e{0, 0, 0, 0};
+      if (ncv >= ns) {
+        double q[3]; int order[3] = {0, 1, 2};
+        for (int g = 0; g < 3; g++) q[g] = std::pow(p[g], (double)ns) * std::pow(1.0 - p[g], (double)(ncv - ns));
+        for (int a = 1; a < 3; a++) {  // list.sort(key=q, reverse=True) is stable
+          int o = order[a], bb = a - 1;
+          while (bb >= 0 && q[order[bb]] < q[o]) { order[bb + 1] = order[bb]; bb--; }
+          order[bb + 1] = o;
+        }
+        double sum = 0; for (int g = 0; g < 3; g++) sum += q[order[g]];
+        double nq[3]; for (int g = 0; g < 3; g++) nq[g] = q[order[g]] / sum;
+        double qz = 0; for (int g = 0; g < 3; g++) if (order[g] == 0) { qz = nq[g]; break; }
+        long z = (long)((-10.0) * likelihood_ratio(qz, nq[0])); if (z > 60) z = 60;
+        long gq = (long)((-10.0) * likelihood_ratio(nq[1], nq[0])); if (gq > 60) gq = 60;
+        e.order0 = (int8_t)order[0]; e.gq = (int8_t)gq; e.z = (int8_t)z;
+      }
+      lut[(size_t)ns * SNF_GT_N + ncv] = e;
+    }
+  return lut;
+}
+
+int bits_for(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b ? b : 1; }
+
+// ---------------------------------------------------------------------------------------------- upload
+void do_upload(snf_batch_impl* b) {
+  View& v = b->v;
+  int T = (int)b->tasks.size();
+  int64_t N = (int64_t)b->h_ref_start.size(), R = (int64_t)b->h_rstart.size(), NTR = (int64_t)b->h_trs.size();
+  if (T >= (1 << 16)) fail("too many tasks in one batch (max 65535)");
+  if (N >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) fail("batch too large for 32-bit lead/read indices");
+  v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
+  v.pool_len = (int64_t)b->h_pool.size(); v.pool_cap = 2 * v.pool_len + 16;
+  v.cnt = dalloc<Counts>(b, 1);
+  std::vector<int32_t> tid(T), svs(T), clen(T), psn(T); std::vector<double> nmt(T);
+  for (int t = 0; t < T; t++) {
+    tid[t] = b->tasks[t].task_id; svs[t] = b->tasks[t].sv_id_start; clen[t] = b->tasks[t].contig_len;
+    psn[t] = b->tasks[t].ps_null_rank; nmt[t] = b->tasks[t].qc_nm_threshold;
+  }
+  v.t_task_id = upload_vec(b, tid); v.t_sv_id_start = upload_vec(b, svs); v.t_contig_len = upload_vec(b, clen);
+  v.t_ps_null = upload_vec(b, psn); v.t_qc_nm_thr = upload_vec(b, nmt);
+  v.t_lead_off = upload_vec(b, b->h_lead_off); v.t_read_off = upload_vec(b, b->h_read_off); v.t_tr_off = upload_vec(b, b->h_tr_off);
+  v.t_has_tr = upload_vec(b, b->h_has_tr);
+  v.t_status = dalloc<int32_t>(b, T + 1); v.t_call_off = dalloc<int64_t>(b, T + 2); v.t_cov_avg = dalloc<double>(b, T + 1);
+  v.t_stale_end = dalloc<int32_t>(b, T + 1); v.t_cov_sum = dalloc<unsigned long long>(b, T + 1);
+  v.in_ref_start = upload_vec(b, b->h_ref_start); v.in_ref_end = upload_vec(b, b->h_ref_end);
+  v.in_qry_start = upload_vec(b, b->h_qry_start); v.in_qry_end = upload_vec(b, b->h_qry_end);
+  v.in_svlen = upload_vec(b, b->h_svlen); v.in_read_len = upload_vec(b, b->h_read_len);
+  v.in_qname = upload_vec(b, b->h_qname); v.in_read_id = upload_vec(b, b->h_read_id);
+  v.in_ps = upload_vec(b, b->h_ps); v.in_mate_contig = upload_vec(b, b->h_mate_contig); v.in_mate_pos = upload_vec(b, b->h_mate_pos);
+  v.in_seq_len = upload_vec(b, b->h_seq_len); v.in_seq_off = upload_vec(b, b->h_seq_off); v.in_nm = upload_vec(b, b->h_nm);
+  v.in_svtype = upload_vec(b, b->h_svtype); v.in_strand = upload_vec(b, b->h_strand); v.in_mapq = upload_vec(b, b->h_mapq);
+  v.in_source = upload_vec(b, b->h_source); v.in_hap = upload_vec(b, b->h_hap); v.in_is_sa = upload_vec(b, b->h_is_sa);
+  v.in_first = upload_vec(b, b->h_first); v.in_rev = upload_vec(b, b->h_rev); v.lead_task = upload_vec(b, b->h_lead_task);
+  v.pool = dalloc<uint8_t>(b, (size_t)v.pool_cap);
+  h2d(b, v.pool, b->h_pool.data(), b->h_pool.size());
+  v.r_start = upload_vec(b, b->h_rstart); v.r_end = upload_vec(b, b->h_rend); v.r_hp = upload_vec(b, b->h_rhp);
+  v.r_task = upload_vec(b, b->h_rtask);
+  v.rk_in = dalloc<uint64_t>(b, R); v.rk_out = dalloc<uint64_t>(b, R); v.rv_in = dalloc<uint32_t>(b, R); v.rv_out = dalloc<uint32_t>(b, R);
+  v.re_sorted = dalloc<int32_t>(b, R);
+  for (int h = 0; h < 3; h++) { v.pc_s[h] = dalloc<uint32_t>(b, R + 1); v.pc_e[h] = dalloc<uint32_t>(b, R + 1); }
+  ReadPrep& rp = b->rp;
+  rp.r_end = v.r_end; rp.r_hp = v.r_hp; rp.r_task = v.r_task; rp.r_start = v.r_start; rp.rk_in = v.rk_in; rp.rv_in = v.rv_in;
+  rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.R = R;
+  for (int h = 0; h < 3; h++) { rp.fs[h] = dalloc<uint32_t>(b, R + 1); rp.fe[h] = dalloc<uint32_t>(b, R + 1); }
+  v.tr_start = upload_vec(b, b->h_trs); v.tr_end = upload_vec(b, b->h_tre); v.tr_pmax = upload_vec(b, b->h_trp);
+  size_t N1 = (size_t)N + 1;
+  v.key_in = dalloc<uint64_t>(b, N); v.key_out = dalloc<uint64_t>(b, N); v.val_in = dalloc<uint32_t>(b, N); v.val_out = dalloc<uint32_t>(b, N);
+  uint32_t** u32s[] = {&v.headflag, &v.headscan, &v.eligflag, &v.eligscan, &v.fN, &v.pN, &v.fL, &v.pL, &v.runflag, &v.runscan,
+                       &v.clflag, &v.clscan, &v.rcflag, &v.rcscan, &v.cdflag, &v.cdscan};
+  for (auto pp : u32s) *pp = dalloc<uint32_t>(b, N1);
+  v.seqnull = dalloc<uint8_t>(b, N); v.bin_lo = dalloc<int32_t>(b, N1); v.bin_key = dalloc<uint64_t>(b, N);
+  v.bin_hap = dalloc<uint16_t>(b, 3 * (size_t)N); v.bin_elig = dalloc<uint8_t>(b, N);
+  v.grp_first_bin = dalloc<int32_t>(b, 8 * (size_t)T + 8);
+  v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N);
+  int32_t** i32s[] = {&v.seed_bin, &v.seed_lo, &v.seed_hi, &v.seedL_lo, &v.seedL_hi, &v.seed_start, &v.seed_grp, &v.c_last, &v.c_end,
+                      &v.nxt, &v.prv, &v.run_first, &v.run_last_head, &v.cl_head, &v.w0, &v.w1, &v.w2, &v.w3, &v.w4, &v.w5, &v.w6,
+                      &v.F_orig, &v.F_svlen, &v.F_seq_len, &v.FI, &v.rc_n_s, &v.rc_cl_s, &v.rc_lo, &v.rc_n, &v.rc_cluster};
+  for (auto pp : i32s) *pp = dalloc<int32_t>(b, N1);
+  double** f64s[] = {&v.s_mean0, &v.s_stdev0, &v.c_mean, &v.c_stdev, &v.run_b_stdev, &v.run_b_absmean};
+  for (auto pp : f64s) *pp = dalloc<double>(b, N1);
+  uint8_t** u8s[] = {&v.s_repeat0, &v.c_repeat, &v.run_b_repeat, &v.F_sel, &v.rc_keeplong_s, &v.rc_keeplong};
+  for (auto pp : u8s) *pp = dalloc<uint8_t>(b, N1);
+  v.grp_dirty = dalloc<int32_t>(b, 8 * (size_t)T + 8); v.grp_seed_lo = dalloc<int32_t>(b, 8 * (size_t)T + 8);
+  v.grp_seed_hi = dalloc<int32_t>(b, 8 * (size_t)T + 8);
+  v.F_seq_off = dalloc<int64_t>(b, N1);
+  v.cand = dalloc<snf_call_t>(b, N1); v.candx = dalloc<CallX>(b, N1);
+  v.calls = dalloc<snf_call_t>(b, N1); v.callx = dalloc<CallX>(b, N1);
+  v.rnames = dalloc<uint32_t>(b, 2 * (size_t)N + 1);
+  auto lut = build_gt_lut(b->cfg);
+  v.gt_lut = upload_vec(b, lut);
+  v.cons_call = dalloc<int32_t>(b, N1);
+  v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
+  b->d_sz_tab = dalloc<int64_t>(b, N1 + 1); b->d_sz_aln = dalloc<int64_t>(b, N1 + 1); b->d_sz_rd = dalloc<int64_t>(b, N1 + 1);
+  dsync(b);
+  b->uploaded = true;
+}
+
+// ---------------------------------------------------------------------------------------------- pipeline
+void reset_timing(snf_batch_impl* b) {
+#ifndef SNF_EMU
+  b->ev_used = 0;
+#endif
+  b->timings.clear();
+}
+
+void run_call_candidates(snf_batch_impl* b) {
+  View& v = b->v;
+  int64_t N = v.N, R = v.R; int T = v.T;
+  reset_timing(b);
+  dzero(b, v.cnt, sizeof(Counts));
+  dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
+  dzero(b, v.t_status, sizeof(int32_t) * (T + 1));
+  dzero(b, v.t_call_off, sizeof(int64_t) * (T + 2));
+  dzero(b, v.grp_first_bin, sizeof(int32_t) * (8 * T + 8), 0xff);
+  dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
+  dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
+  dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
+  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state)
+  if (R > 0) {
+    LAUNCH(r1_endkeys, b->rp, R, R * 13);
+    prim_sort_pairs(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, 32 + bits_for((uint64_t)T), "sort_read_ends");
+    LAUNCH(r2_unpack, b->rp, R, R * 16);
+    for (int h = 0; h < 3; h++) {
+      prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
+      prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
+    }
+    LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
+  }
+  LAUNCH(d5_covavg, v, T, 0);
+  if (N > 0) {
+    uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
+    for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
+    LAUNCH(a1_keys, v, N, N * 21);
+    prim_sort_pairs(b, v.key_in, v.key_out, v.val_in, v.val_out, N, 35 + bits_for((uint64_t)T), "sort_lead_keys");
+    LAUNCH(a2_heads, v, N, N * 12);
+    prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
+    LAUNCH(a3_bins, v, N, N * 8);
+    LAUNCH(a4_binstats, v, N, N * 16);
+    prim_exscan<uint32_t>(b, v.eligflag, v.eligscan, N + 1, "scan_seeds");
+    LAUNCH(a5_leadflags, v, N, N * 12);
+    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_leads");
+    prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_leads_long");
+    LAUNCH(a6_scatter, v, N, N * 16);
+    LAUNCH(a7_seeds, v, N, N * 4);
+    LAUNCH(b1_seedmetrics, v, N, N * 8);
+    prim_exscan<uint32_t>(b, v.runflag, v.runscan, N + 1, "scan_runs");
+    LAUNCH(b2_runs, v, N, N * 4);
+    LAUNCH(c1_mergeruns, v, N, N * 8);
+    LAUNCH(c2_validate, v, N, 0);
+    LAUNCH(c3_serial, v, 8 * (int64_t)T, 0);
+    prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
+    LAUNCH(c4_clusters, v, N, N * 4);
+    dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
+    LAUNCH(d1_refine, v, N, N * 36);
+    prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
+    LAUNCH(d1b_rctable, v, N, N * 4);
+    LAUNCH(d2_call, v, N, N * 32);
+    prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
+    LAUNCH(d3_compact, v, N, 0);
+    LAUNCH(d3_taskoff, v, T + 1, 0);
+    LAUNCH(d3_svid, v, N, 0);
+    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_rnames");
+    LAUNCH(d3_stale, v, T, 0);
+    LAUNCH(d3_rnames, v, N, 0);
+    LAUNCH(d4_coverage, v, N, 0);
+  }
+}
+
+void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t elem) {
+  if (need <= cap && *p) return;
+  if (*p) dfree_one(b, *p);
+  cap = need + need / 4 + 64;
+  *p = dalloc<uint8_t>(b, (size_t)cap * elem);
+}
+
+void run_finalize(snf_batch_impl* b) {
+  View& v = b->v;
+  int64_t N = v.N;
+  if (N <= 0) return;
+  LAUNCH(e1_finalize, v, N, 0);
+  LAUNCH(e2_best, v, N, 0);
+  prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_alt");
+  prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_cons");
+  // e3 writes per-consensus sizes into cons_*_off; scanned below into offsets
+  LAUNCH(e3_conslist, v, N, 0);
+  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
+  dsync(b);
+  int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
+  if (ncons > 0) {
+    // sizes were written into cons_*_off[0..ncons); copy to the size arrays, terminate, scan
+    size_t nb = (size_t)ncons * sizeof(int64_t);
+#ifndef SNF_EMU
+    SNF_HIP(hipMemcpyAsync(b->d_sz_tab, v.cons_tab_off, nb, hipMemcpyDeviceToDevice, b->stream));
+    SNF_HIP(hipMemcpyAsync(b->d_sz_aln, v.cons_aln_off, nb, hipMemcpyDeviceToDevice, b->stream));
+    SNF_HIP(hipMemcpyAsync(b->d_sz_rd, v.cons_read_off, nb, hipMemcpyDeviceToDevice, b->stream));
+#else
+    memcpy(b->d_sz_tab, v.cons_tab_off, nb); memcpy(b->d_sz_aln, v.cons_aln_off, nb); memcpy(b->d_sz_rd, v.cons_read_off, nb);
+#endif
+    dzero(b, b->d_sz_tab + ncons, sizeof(int64_t)); dzero(b, b->d_sz_aln + ncons, sizeof(int64_t)); dzero(b, b->d_sz_rd + ncons, sizeof(int64_t));
+    prim_exscan<int64_t>(b, b->d_sz_tab, v.cons_tab_off, ncons + 1, "scan_cons_sizes");
+    prim_exscan<int64_t>(b, b->d_sz_aln, v.cons_aln_off, ncons + 1, "scan_cons_sizes");
+    prim_exscan<int64_t>(b, b->d_sz_rd, v.cons_read_off, ncons + 1, "scan_cons_sizes");
+    int64_t tot[3];
+    d2h(b, &tot[0], v.cons_tab_off + ncons, sizeof(int64_t));
+    d2h(b, &tot[1], v.cons_aln_off + ncons, sizeof(int64_t));
+    d2h(b, &tot[2], v.cons_read_off + ncons, sizeof(int64_t));
+    dsync(b);
+    b->h_cnt.tab_total = tot[0]; b->h_cnt.aln_total = tot[1]; b->h_cnt.n_cons_reads = tot[2];
+    int64_t c1 = b->tab_cap, c2 = b->tab_cap, c3 = b->tab_cap;
+    ensure_cap(b, tot[0], c1, (void**)&v.tab_key, sizeof(uint64_t));
+    ensure_cap(b, tot[0], c2, (void**)&v.tab_pos, sizeof(int32_t));
+    ensure_cap(b, tot[0], c3, (void**)&v.tab_state, sizeof(uint8_t));
+    b->tab_cap = c1; v.tab_cap = c1;
+    ensure_cap(b, tot[1], b->aln_cap, (void**)&v.aln, 1); v.aln_cap = b->aln_cap;
+    int64_t r1 = b->cr_cap, r2 = b->cr_cap, r3 = b->cr_cap;
+    ensure_cap(b, tot[2], r1, (void**)&v.aln_kept, 1);
+    ensure_cap(b, tot[2], r2, (void**)&v.cr_call, sizeof(int32_t));
+    ensure_cap(b, tot[2], r3, (void**)&v.cr_read, sizeof(int32_t));
+    b->cr_cap = r1;
+    // counters the kernels read
+    h2d(b, &v.cnt->n_cons_reads, &tot[2], sizeof(int64_t));
+  }
+  ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
+  if (ncons > 0) {
+    LAUNCH(e4_anchor, v, ncons, b->h_cnt.tab_total * 13);
+    LAUNCH(e5_align, v, b->h_cnt.n_cons_reads, b->h_cnt.aln_total * 2);
+  }
+  LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
+}
+
+void collect_timings(snf_batch_impl* b) {
+  b->timings.clear();
+#ifndef SNF_EMU
+  for (size_t i = 0; i < b->ev_used; i++) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, b->evs[i].a, b->evs[i].b) != hipSuccess) ms = -1;
+    bool found = false;
+    for (auto& t : b->timings)
+      if (strcmp(t.name, b->evs[i].name) == 0) { t.ms += ms; t.bytes += b->evs[i].bytes; t.launches++; found = true; break; }
+    if (!found) b->timings.push_back({b->evs[i].name, ms, b->evs[i].bytes, 1});
+  }
+#endif
+}
+
+void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
+  (void)stage;
+  View& v = b->v;
+  int T = v.T;
+  b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
+  b->r_calls.clear(); b->r_alt.clear(); b->r_rn.clear();
+  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
+  dsync(b);
+  if (b->h_cnt.overflow) fail("internal: fused-sequence pool overflow");
+  int64_t nc = v.N > 0 ? b->h_cnt.n_calls : 0;
+  std::vector<snf_call_t> calls((size_t)nc);
+  std::vector<int64_t> off((size_t)T + 1, 0);
+  d2h(b, calls.data(), v.calls, (size_t)nc * sizeof(snf_call_t));
+  d2h(b, b->r_status.data(), v.t_status, (size_t)T * sizeof(int32_t));
+  d2h(b, off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t));
+  d2h(b, b->r_cov.data(), v.t_cov_avg, (size_t)T * sizeof(double));
+  int64_t alt_total = stage >= 1 ? b->h_cnt.alt_total : 0;
+  b->r_alt.resize((size_t)alt_total);
+  if (alt_total) d2h(b, b->r_alt.data(), v.alt_pool, (size_t)alt_total);
+  b->r_rn.resize((size_t)(v.N > 0 ? b->h_cnt.rn_total : 0));
+  d2h(b, b->r_rn.data(), v.rnames, b->r_rn.size() * sizeof(uint32_t));
+  dsync(b);
+  if (v.N <= 0) std::fill(off.begin(), off.end(), 0);
+  // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls
+  b->r_calls.reserve(calls.size());
+  for (int t = 0; t < T; t++) {
+    b->r_off[t] = (int64_t)b->r_calls.size();
+    if (b->r_status[t] != SNF_TASK_OK) continue;
+    for (int64_t i = off[t]; i < off[t + 1]; i++) {
+      snf_call_t c = calls[(size_t)i];
+      if (stage < 1) { c.alt_len = -1; c.alt_off = 0; }
+      b->r_calls.push_back(c);
+    }
+  }
+  b->r_off[T] = (int64_t)b->r_calls.size();
+  collect_timings(b);
+  out->n_calls = (int64_t)b->r_calls.size(); out->calls = b->r_calls.data();
+  out->alt_pool_len = (int64_t)b->r_alt.size(); out->alt_pool = b->r_alt.data();
+  out->rnames_len = (int64_t)b->r_rn.size(); out->rnames = b->r_rn.data();
+  out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
+  out->coverage_average_total = b->r_cov.data();
+}
+
+template <class T>
+void append(std::vector<T>& dst, const T* src, int64_t n) { dst.insert(dst.end(), src, src + n); }
+
+void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
+  if (b->uploaded) fail("snf_batch_add_task after snf_batch_upload");
+  int64_t n = t->n_leads, r = t->n_reads;
+  if (n < 0 || r < 0 || t->contig_len < 0) fail("negative sizes in task input");
+  int ti = (int)b->tasks.size();
+  int64_t pool0 = (int64_t)b->h_pool.size();
+  for (int64_t i = 0; i < n; i++) {
+    if (t->svtype[i] >= SNF_NTYPES) fail("svtype code out of range");
+    if (t->hap[i] > 2) fail("hap must be 0, 1 or 2 (leadprov.py:403)");
+    int32_t sl = t->seq_len[i];
+    if (sl >= 0 && (t->seq_off[i] < 0 || t->seq_off[i] + sl > t->seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
+  }
+  append(b->h_ref_start, t->ref_start, n); append(b->h_ref_end, t->ref_end, n); append(b->h_qry_start, t->qry_start, n);
+  append(b->h_qry_end, t->qry_end, n); append(b->h_svlen, t->svlen, n); append(b->h_read_len, t->read_len, n);
+  append(b->h_qname, t->qname_id, n); append(b->h_read_id, t->read_id, n); append(b->h_ps, t->ps_rank, n);
+  append(b->h_mate_contig, t->mate_contig, n); append(b->h_mate_pos, t->mate_ref_start, n); append(b->h_seq_len, t->seq_len, n);
+  for (int64_t i = 0; i < n; i++) b->h_seq_off.push_back(t->seq_len[i] >= 0 ? t->seq_off[i] + pool0 : 0);
+  append(b->h_nm, t->nm, n); append(b->h_svtype, t->svtype, n); append(b->h_strand, t->strand, n); append(b->h_mapq, t->mapq, n);
+  append(b->h_source, t->source, n); append(b->h_hap, t->hap, n); append(b->h_is_sa, t->is_sa, n);
+  append(b->h_first, t->bnd_is_first, n); append(b->h_rev, t->bnd_is_reverse, n);
+  b->h_lead_task.insert(b->h_lead_task.end(), (size_t)n, ti);
+  append(b->h_pool, t->seq_pool, t->seq_pool_len);
+  // reads: BAM order == ascending start; enforce (stable) so the rank queries are valid
+  std::vector<int64_t> ord((size_t)r);
+  for (int64_t i = 0; i < r; i++) ord[i] = i;
+  bool sorted = true;
+  for (int64_t i = 1; i < r; i++) if (t->read_start[i] < t->read_start[i - 1]) { sorted = false; break; }
+  if (!sorted) std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return t->read_start[x] < t->read_start[y]; });
+  for (int64_t i = 0; i < r; i++) {
+    int64_t k = ord[i];
+    int32_t s = t->read_start[k], e = t->read_end[k];
+    if (s < 0 || s >= t->contig_len || e < s) fail("read interval outside the task region (leadprov.py:497-498)");
+    if (t->read_hp[k] > 2) fail("read hp must be 0, 1 or 2");
+    b->h_rstart.push_back(s); b->h_rend.push_back(e); b->h_rhp.push_back(t->read_hp[k]); b->h_rtask.push_back(ti);
+  }
+  int64_t ntr = t->n_tr > 0 ? t->n_tr : 0;
+  int32_t pm = INT32_MIN;
+  for (int64_t i = 0; i < ntr; i++) {
+    b->h_trs.push_back(t->tr_start[i]); b->h_tre.push_back(t->tr_end[i]);
+    if (t->tr_end[i] > pm) pm = t->tr_end[i];
+    b->h_trp.push_back(pm);
+  }
+  b->h_has_tr.push_back(ntr > 0 ? 1 : 0);  // tr None or [] -> no TR handling (cluster.py:229-235)
+  b->h_lead_off.push_back((int64_t)b->h_ref_start.size());
+  b->h_read_off.push_back((int64_t)b->h_rstart.size());
+  b->h_tr_off.push_back((int64_t)b->h_trs.size());
+  snf_task_input_t s = *t;
+  b->tasks.push_back(s);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- C ABI
+#define SNF_TRY(body)                                   \
+  try { body; return 0; }                               \
+  catch (const snf::Error& e) { g_err = e.msg; return 1; } \
+  catch (const std::exception& e) { g_err = e.what(); return 1; }
+
+extern "C" {
+
+int snf_abi_version(void) { return SNF_ABI_VERSION; }
+const char* snf_last_error(void) { return g_err.c_str(); }
+
+int snf_device_count(void) {
+#ifndef SNF_EMU
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+#else
+  return 1;
+#endif
+}
+
+int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
+  SNF_TRY({
+    if (!cfg || !out) fail("null argument");
+    if (cfg->cluster_binsize <= 0 || cfg->cluster_resplit_binsize <= 0) fail("bin sizes must be positive");
+    if (cfg->consensus_kmer_len < 1 || cfg->consensus_kmer_len > 8) fail("consensus_kmer_len must be in 1..8");
+    if (cfg->genotype_ploidy != 2) fail("only genotype_ploidy 2 is supported");
+#ifndef SNF_EMU
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+      fail("no HIP device available: the sniffles_amd hot path requires an AMD GPU (there is no CPU fallback)");
+    if (device < 0 || device >= n) fail("device index out of range");
+    SNF_HIP(hipSetDevice(device));
+#endif
+    auto b = std::make_unique<snf_batch_impl>();
+    b->cfg = *cfg; b->device = device;
+    const char* g = getenv("SNF_RUN_GAP");
+    int base = cfg->cluster_merge_bnd > (int)cfg->cluster_repeat_h_max ? cfg->cluster_merge_bnd : (int)cfg->cluster_repeat_h_max;
+    b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
+#ifndef SNF_EMU
+    SNF_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+#endif
+    *out = reinterpret_cast<snf_batch_t*>(b.release());
+  })
+}
+
+int snf_batch_add_task(snf_batch_t* bb, const snf_task_input_t* task) {
+  SNF_TRY({ if (!bb || !task) fail("null argument"); do_add_task(reinterpret_cast<snf_batch_impl*>(bb), task); })
+}
+
+int snf_batch_upload(snf_batch_t* bb) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b) fail("null batch");
+    if (b->uploaded) fail("batch already uploaded");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    do_upload(b);
+  })
+}
+
+void snf_batch_destroy(snf_batch_t* bb) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b) return;
+#ifndef SNF_EMU
+  (void)hipSetDevice(b->device);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+#endif
+  dfree_all(b);
+#ifndef SNF_EMU
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+#endif
+  delete b;
+}
+
+int snf_batch_call_candidates(snf_batch_t* bb) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded) fail("batch not uploaded");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    run_call_candidates(b);
+  })
+}
+
+int snf_batch_finalize(snf_batch_t* bb) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded) fail("batch not uploaded");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    run_finalize(b);
+  })
+}
+
+int snf_batch_fetch(snf_batch_t* bb, int stage, snf_result_t* out) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !out) fail("batch not uploaded / null result");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    do_fetch(b, stage, out);
+  })
+}
+
+int snf_batch_sync(snf_batch_t* bb) {
+  SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); dsync(b); collect_timings(b); })
+}
+
+int snf_batch_timing_count(snf_batch_t* bb) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  return b ? (int)b->timings.size() : 0;
+}
+
+int snf_batch_timing_get(snf_batch_t* bb, int i, const char** name, float* ms, int64_t* algo_bytes) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b || i < 0 || i >= (int)b->timings.size()) { g_err = "timing index out of range"; return 1; }
+  if (name) *name = b->timings[i].name;
+  if (ms) *ms = b->timings[i].ms;
+  if (algo_bytes) *algo_bytes = b->timings[i].bytes;
+  return 0;
+}
+
+}  // extern "C"

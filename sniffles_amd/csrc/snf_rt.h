@@ -1,0 +1,80 @@
+// snf_rt.h - thin runtime layer: HIP on gfx950 (the product) or a serial host loop (SNF_EMU).
+//
+// SNF_EMU exists ONLY so that tests/ can execute the exact kernel bodies in the GPU-less build
+// container (tests/emu builds it with g++).  It is never compiled into libsniffles_amd.so and the
+// Python package cannot load it: the product path fails loudly when no HIP device is present.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifndef SNF_EMU
+#include <hip/hip_runtime.h>
+#define SNF_HD __host__ __device__ __forceinline__
+#define SNF_D __device__ __forceinline__
+#else
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#define SNF_HD inline
+#define SNF_D inline
+typedef void* hipStream_t;
+#endif
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+
+namespace snf {
+
+struct Error {
+  std::string msg;
+};
+[[noreturn]] inline void fail(const std::string& m) { throw Error{m}; }
+
+#ifndef SNF_EMU
+#define SNF_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      ::snf::fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
+                  std::to_string(__LINE__) + ")");                                            \
+  } while (0)
+#endif
+
+// ---- atomics usable from kernel bodies -------------------------------------------------------
+SNF_HD unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicAdd(p, v);
+#else
+  unsigned long long o = *p;
+  *p = o + v;
+  return o;
+#endif
+}
+SNF_HD void atomic_or_i32(int* p, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicOr(p, v);
+#else
+  *p |= v;
+#endif
+}
+
+// ---- kernel definition / launch ---------------------------------------------------------------
+// A kernel is a body `void name##_body(int64_t i, const View& v)`; SNF_KERNEL wraps it.
+#ifndef SNF_EMU
+#define SNF_KERNEL(name, VIEW)                                                     \
+  __global__ void __launch_bounds__(256) name(const VIEW v, int64_t n) {           \
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                    \
+    if (i < n) name##_body(i, v);                                                  \
+  }
+#else
+#define SNF_KERNEL(name, VIEW)                                \
+  static void name(const VIEW& v, int64_t n) {                \
+    for (int64_t i = 0; i < n; i++) name##_body(i, v);        \
+  }
+#endif
+
+}  // namespace snf

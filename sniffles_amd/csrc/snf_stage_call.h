@@ -1,0 +1,466 @@
+// snf_stage_call.h - kernel bodies: per-cluster refinement and candidate calls.
+//
+// Reference semantics: merge_inner (cluster.py:85-122), resplit (cluster.py:125-161), resplit_bnd
+// (cluster.py:164-216), Cluster.get_sa_count (cluster.py:79-82), sv.call_from / resolve_bnd /
+// calculate_bounds (sv.py:484-639), util.center/trim/stdev/most_common_top (util.py:25-103).
+#pragma once
+#include "snf_stage_cluster.h"
+
+namespace snf {
+
+SNF_HD bool lead_has_seq(const View& v, uint32_t o) { return v.in_seq_len[o] >= 0 && !v.seqnull[o]; }
+
+// ------------------------------------------------------------------------------------------ D1
+struct LessQnameIdx {
+  const View& v; int32_t lo;
+  SNF_HD bool operator()(int32_t a, int32_t b) const {
+    uint32_t qa = v.in_qname[v.L[lo + a]], qb = v.in_qname[v.L[lo + b]];
+    return qa != qb ? qa < qb : a < b;
+  }
+};
+struct LessFaRefIdx {
+  const View& v; int32_t lo; const int32_t* fa;
+  SNF_HD bool operator()(int32_t a, int32_t b) const {
+    if (fa[a] != fa[b]) return fa[a] < fa[b];
+    int32_t ra = v.in_ref_start[v.L[lo + a]], rb = v.in_ref_start[v.L[lo + b]];
+    return ra != rb ? ra < rb : a < b;
+  }
+};
+struct LessBinIdx {
+  const int32_t* svlen; int32_t rb;
+  SNF_HD int64_t bin(int32_t k) const { int64_t a = svlen[k] < 0 ? -(int64_t)svlen[k] : svlen[k]; return (a / rb) * rb; }
+  SNF_HD bool operator()(int32_t a, int32_t b) const {
+    int64_t ba = bin(a), bb = bin(b);
+    return ba != bb ? ba < bb : a < b;
+  }
+};
+struct LessIdentIdx {
+  const View& v; int32_t lo;
+  SNF_HD bool operator()(int32_t a, int32_t b) const {
+    uint32_t oa = v.L[lo + a], ob = v.L[lo + b];
+    if (v.in_mate_contig[oa] != v.in_mate_contig[ob]) return v.in_mate_contig[oa] < v.in_mate_contig[ob];
+    if (v.in_first[oa] != v.in_first[ob]) return v.in_first[oa] < v.in_first[ob];
+    return a < b;
+  }
+};
+struct LessFaPosbinIdx {
+  const View& v; int32_t lo; const int32_t* fa; int32_t thr;
+  SNF_HD int64_t pb(int32_t a) const { return thr > 0 ? ((int64_t)v.in_mate_pos[v.L[lo + a]] / thr) * thr : 0; }
+  SNF_HD bool operator()(int32_t a, int32_t b) const {
+    if (fa[a] != fa[b]) return fa[a] < fa[b];
+    int64_t pa = pb(a), pbb = pb(b);
+    return pa != pbb ? pa < pbb : a < b;
+  }
+};
+
+SNF_HD void rc_emit(const View& v, int32_t pos, int32_t n, int32_t c, bool keeplong) {
+  v.rcflag[pos] = 1;
+  v.rc_n_s[pos] = n;
+  v.rc_cl_s[pos] = c;
+  v.rc_keeplong_s[pos] = keeplong ? 1 : 0;
+}
+
+// one merged cluster -> fused leads (F) + refined clusters in final lead order (FI)
+SNF_HD void d1_refine_body(int64_t c, const View& v) {
+  if (c >= v.cnt->n_clusters) return;
+  const snf_config_t& cfg = v.cfg;
+  int32_t h = v.cl_head[c];
+  int32_t lo = v.seed_lo[h], hi = v.seed_hi[v.c_last[h]];
+  int32_t n = hi - lo;
+  if (n <= 0) return;
+  int svtype = grp_svtype(v.seed_grp[h]);
+  int32_t *a0 = v.w0 + lo, *a1 = v.w1 + lo, *a2 = v.w2 + lo, *a3 = v.w3 + lo, *a4 = v.w4 + lo, *a5 = v.w5 + lo,
+          *a6 = v.w6 + lo;
+  int32_t* Forig = v.F_orig + lo; int32_t* Fsvlen = v.F_svlen + lo; int32_t* Fseqlen = v.F_seq_len + lo;
+  int64_t* Fseqoff = v.F_seq_off + lo;
+  int32_t m = 0;
+
+  if (svtype == SNF_INS || svtype == SNF_DEL) {
+    // ---- merge_inner: group by read (first appearance), sort by ref_start, fuse neighbours
+    int thr = v.c_repeat[h] ? -1 : cfg.cluster_merge_pos;
+    for (int32_t j = 0; j < n; j++) a0[j] = j;
+    sort_inplace(a0, (int64_t)n, LessQnameIdx{v, lo});
+    for (int32_t x = 0; x < n;) {
+      int32_t y = x; uint32_t q = v.in_qname[v.L[lo + a0[x]]];
+      while (y < n && v.in_qname[v.L[lo + a0[y]]] == q) { a1[a0[y]] = a0[x]; y++; }
+      x = y;
+    }
+    for (int32_t j = 0; j < n; j++) a0[j] = j;
+    sort_inplace(a0, (int64_t)n, LessFaRefIdx{v, lo, a1});
+    for (int32_t x = 0; x < n;) {
+      int32_t y_end = x; while (y_end < n && a1[a0[y_end]] == a1[a0[x]]) y_end++;
+      uint32_t ho = v.L[lo + a0[x]];
+      int64_t cs = v.in_svlen[ho]; bool seq_ok = lead_has_seq(v, ho); int64_t seq_total = seq_ok ? v.in_seq_len[ho] : 0;
+      int32_t part_start = x; uint32_t head = ho;
+      int32_t l_re = v.in_ref_end[ho], l_qe = v.in_qry_end[ho], l_rs = v.in_ref_start[ho], l_qs = v.in_qry_start[ho];
+      for (int32_t y = x + 1; y <= y_end; y++) {
+        bool flush = (y == y_end);
+        uint32_t to = 0;
+        if (!flush) {
+          to = v.L[lo + a0[y]];
+          int32_t rs = v.in_ref_start[to], qs = v.in_qry_start[to];
+          bool mg = (thr == -1) ||
+                    (((iabs64((int64_t)rs - l_re) < thr || iabs64((int64_t)rs - l_rs) < thr) &&
+                      (iabs64((int64_t)qs - l_qe) < thr || iabs64((int64_t)qs - l_qs) < thr)) &&
+                     (v.in_strand[head] == v.in_strand[to]));
+          if (mg) {
+            cs += v.in_svlen[to];
+            if (!lead_has_seq(v, to) || !seq_ok) seq_ok = false; else seq_total += v.in_seq_len[to];
+          } else flush = true;
+        }
+        if (flush) {
+          Forig[m] = (int32_t)head; Fsvlen[m] = (int32_t)cs;
+          int32_t nparts = (y < y_end ? y : y_end) - part_start;
+          if (!seq_ok) { Fseqlen[m] = -1; Fseqoff[m] = 0; }
+          else if (nparts == 1) { Fseqlen[m] = v.in_seq_len[head]; Fseqoff[m] = v.in_seq_off[head]; }
+          else {  // curr_lead.seq += to_merge.seq: new string in the fused part of the pool
+            int64_t off = v.pool_len + (int64_t)atomic_add_u64(&v.cnt->pool_extra_used, (unsigned long long)seq_total);
+            if (off + seq_total > v.pool_cap) { atomic_or_i32(&v.cnt->overflow, 1); Fseqlen[m] = -1; Fseqoff[m] = 0; }
+            else {
+              int64_t w = off;
+              for (int32_t z = part_start; z < part_start + nparts; z++) {
+                uint32_t zo = v.L[lo + a0[z]];
+                const uint8_t* src = v.pool + v.in_seq_off[zo];
+                for (int32_t b = 0; b < v.in_seq_len[zo]; b++) v.pool[w++] = src[b];
+              }
+              Fseqlen[m] = (int32_t)seq_total; Fseqoff[m] = off;
+            }
+          }
+          m++;
+          if (y < y_end) {
+            head = to; cs = v.in_svlen[to]; seq_ok = lead_has_seq(v, to); seq_total = seq_ok ? v.in_seq_len[to] : 0;
+            part_start = y;
+          }
+        }
+        if (y < y_end) { l_re = v.in_ref_end[to]; l_qe = v.in_qry_end[to]; l_rs = v.in_ref_start[to]; l_qs = v.in_qry_start[to]; }
+      }
+      x = y_end;
+    }
+  } else {
+    for (int32_t j = 0; j < n; j++) {
+      uint32_t o = v.L[lo + j];
+      Forig[j] = (int32_t)o; Fsvlen[j] = v.in_svlen[o];
+      bool hs = lead_has_seq(v, o);
+      Fseqlen[j] = hs ? v.in_seq_len[o] : -1; Fseqoff[j] = hs ? v.in_seq_off[o] : 0;
+    }
+    m = n;
+  }
+  int32_t* FI = v.FI + lo;
+
+  if (svtype == SNF_BND) {
+    // ---- resplit_bnd
+    if (m <= 1 || cfg.dev_no_resplit) {
+      for (int32_t k = 0; k < m; k++) FI[k] = lo + k;
+      rc_emit(v, lo, m, (int32_t)c, true);
+      return;
+    }
+    int thr = cfg.cluster_merge_bnd;
+    for (int32_t j = 0; j < m; j++) a0[j] = j;
+    sort_inplace(a0, (int64_t)m, LessIdentIdx{v, lo});
+    for (int32_t x = 0; x < m;) {
+      int32_t y = x; uint32_t ox = v.L[lo + a0[x]];
+      while (y < m) { uint32_t oy = v.L[lo + a0[y]];
+        if (v.in_mate_contig[oy] != v.in_mate_contig[ox] || v.in_first[oy] != v.in_first[ox]) break;
+        a1[a0[y]] = a0[x]; y++; }
+      x = y;
+    }
+    for (int32_t j = 0; j < m; j++) a0[j] = j;
+    LessFaPosbinIdx lp{v, lo, a1, thr};
+    sort_inplace(a0, (int64_t)m, lp);
+    int32_t start = 0; int64_t last_bin = lp.pb(a0[0]);
+    for (int32_t x = 0; x < m; x++) {
+      FI[x] = lo + a0[x];
+      if (x > 0) {
+        int64_t pb = lp.pb(a0[x]);
+        bool brk = a1[a0[x]] != a1[a0[x - 1]] || (pb - last_bin > thr);
+        if (brk) { rc_emit(v, lo + start, x - start, (int32_t)c, false); start = x; }
+        last_bin = pb;
+      }
+    }
+    rc_emit(v, lo + start, m - start, (int32_t)c, false);
+    return;
+  }
+
+  // ---- resplit on svlen
+  if (cfg.dev_no_resplit_repeat || cfg.dev_no_resplit) {
+    for (int32_t k = 0; k < m; k++) FI[k] = lo + k;
+    rc_emit(v, lo, m, (int32_t)c, true);
+    return;
+  }
+  LessBinIdx lb{Fsvlen, cfg.cluster_resplit_binsize};
+  for (int32_t k = 0; k < m; k++) a0[k] = k;
+  sort_inplace(a0, (int64_t)m, lb);
+  // segments = distinct bins: a1 seg start, a2 seg key, a3 surviving list, a4 head, a5 tail, a6 next
+  int32_t nb = 0;
+  for (int32_t x = 0; x < m; x++)
+    if (x == 0 || lb.bin(a0[x]) != lb.bin(a0[x - 1])) { a1[nb] = x; a2[nb] = (int32_t)lb.bin(a0[x]); nb++; }
+  for (int32_t s = 0; s < nb; s++) { a3[s] = s; a4[s] = s; a5[s] = s; a6[s] = -1; }
+  int32_t cntc = nb, i = 1;
+  while (cntc > 1 && i < cntc) {
+    int32_t im1 = (i == 0) ? cntc - 1 : i - 1;  // Python negative index: new_clusters[-1]
+    int64_t last = a2[a3[im1]], curr = a2[a3[i]];
+    int64_t mn = curr < last ? curr : last;
+    double t = (double)mn * cfg.cluster_merge_len;
+    double thr = ((double)cfg.minsvlen >= t) ? (double)cfg.minsvlen : t;
+    int64_t diff = curr > last ? curr - last : last - curr;
+    if ((double)diff <= thr) {
+      int32_t cb = a3[i], lbk = a3[im1];
+      a6[a5[cb]] = a4[lbk];  // bins_leads[curr].extend(bins_leads[last])
+      a5[cb] = a5[lbk];
+      for (int32_t t2 = im1; t2 + 1 < cntc; t2++) a3[t2] = a3[t2 + 1];
+      cntc--;
+      i = (i - 2 > 0) ? i - 2 : 0;
+    } else i++;
+  }
+  int32_t outp = 0;
+  for (int32_t t2 = 0; t2 < cntc; t2++) {
+    int32_t start = outp;
+    for (int32_t s = a4[a3[t2]]; s >= 0; s = a6[s]) {
+      int32_t xe = (s + 1 < nb) ? a1[s + 1] : m;
+      for (int32_t x = a1[s]; x < xe; x++) FI[outp++] = lo + a0[x];
+    }
+    rc_emit(v, lo + start, outp - start, (int32_t)c, true);
+  }
+}
+
+// D1b: dense refined-cluster table (rcscan = exclusive scan of rcflag over the F slot space)
+SNF_HD void d1b_rctable_body(int64_t pos, const View& v) {
+  if (pos == 0) v.cnt->n_rc = v.rcscan[v.N];
+  if (pos < v.cnt->NF && v.rcflag[pos]) {
+    uint32_t r = v.rcscan[pos];
+    v.rc_lo[r] = (int32_t)pos; v.rc_n[r] = v.rc_n_s[pos]; v.rc_cluster[r] = v.rc_cl_s[pos];
+    v.rc_keeplong[r] = v.rc_keeplong_s[pos];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ D2
+SNF_HD int64_t distinct_sorted_i32(int32_t* a, int64_t n) {
+  if (n == 0) return 0;
+  int64_t k = 1;
+  for (int64_t i = 1; i < n; i++) if (a[i] != a[k - 1]) a[k++] = a[i];
+  return k;
+}
+SNF_HD bool contains_sorted_i32(const int32_t* a, int64_t n, int32_t x) {
+  int64_t p = lower_bound_i32(a, 0, n, x);
+  return p < n && a[p] == x;
+}
+
+// sv.call_from for one refined cluster -> candidate record (or nothing: minsvlen_screen)
+SNF_HD void d2_call_body(int64_t r, const View& v) {
+  if (r == 0) v.cdflag[v.N] = 0;
+  if (r >= v.cnt->n_rc) { v.cdflag[r] = 0; return; }
+  const snf_config_t& cfg = v.cfg;
+  int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
+  int32_t h = v.cl_head[c];
+  int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
+  int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo;
+  const int32_t* FI = v.FI + flo;
+  v.cdflag[r] = 0;
+  for (int32_t k = 0; k < n; k++) { a0[k] = v.F_svlen[FI[k]]; v.F_sel[FI[k]] = 1; }
+  sort_inplace(a0, (int64_t)n, LessI32{});
+  int64_t svlen = center_sorted(a0, n);
+  bool single = svtype == SNF_SINGLE_LEFT || svtype == SNF_SINGLE_RIGHT;
+  if (!single && svtype != SNF_BND && iabs64(svlen) < cfg.minsvlen_screen) return;
+
+  for (int32_t k = 0; k < n; k++) a1[k] = (int32_t)v.in_qname[v.F_orig[FI[k]]];
+  sort_inplace(a1, (int64_t)n, LessI32{});
+  int64_t nq = distinct_sorted_i32(a1, n);
+  int64_t support = nq, support_long = 0;
+  int32_t llo = v.seedL_lo[h], lhi = v.seedL_hi[v.c_last[h]];
+  bool keeplong = v.rc_keeplong[r] && svtype == SNF_INS;
+  if (svtype == SNF_INS && svlen >= cfg.long_ins_length) {
+    for (int32_t x = llo; x < lhi; x++) {
+      int32_t q = (int32_t)v.in_qname[v.LL[x]];
+      bool first = true;
+      for (int32_t y = llo; y < x; y++) if ((int32_t)v.in_qname[v.LL[y]] == q) { first = false; break; }
+      if (first) { support_long++; if (!contains_sorted_i32(a1, nq, q)) support++; }
+    }
+  }
+  for (int32_t k = 0; k < n; k++) a2[k] = v.in_ref_start[v.F_orig[FI[k]]];
+  sort_inplace(a2, (int64_t)n, LessI32{});
+  int64_t ref_start = center_sorted(a2, n);
+  double stdev_pos = stdev_trim_sorted(a2, n);
+  double stdev_len = NAN; bool precise;
+  if (svtype != SNF_BND) { stdev_len = stdev_trim_sorted(a0, n); precise = (stdev_pos + stdev_len < (double)cfg.precise); }
+  else precise = stdev_pos < (double)cfg.precise;
+  int64_t svstart, svend;
+  if (svtype == SNF_INS) { svstart = ref_start; svend = ref_start; }
+  else if (svtype == SNF_DEL) { svstart = ref_start + svlen; svend = ref_start; }
+  else { svstart = ref_start; svend = svstart + iabs64(svlen); }
+  int64_t msum = 0, fwd = 0, sa = 0, src_noninline = 0; double nmsum = 0;
+  for (int32_t k = 0; k < n; k++) {
+    uint32_t o = (uint32_t)v.F_orig[FI[k]];
+    msum += v.in_mapq[o]; fwd += (v.in_strand[o] == 0); sa += v.in_is_sa[o];
+    src_noninline += (v.in_source[o] != SNF_SRC_INLINE);
+    if (cfg.qc_nm_measure) nmsum += v.in_nm[o];
+  }
+  int64_t n_all = n;
+  if (keeplong) { for (int32_t x = llo; x < lhi; x++) sa += v.in_is_sa[v.LL[x]]; n_all += lhi - llo; }
+
+  snf_call_t cc;
+  memset(&cc, 0, sizeof(cc));
+  cc.task_index = task; cc.svtype = svtype; cc.pos = (int32_t)svstart; cc.end = (int32_t)svend; cc.svlen = (int32_t)svlen;
+  cc.support = (int32_t)support; cc.support_long = -1; cc.support_sa = -1;
+  cc.qual = (int32_t)((double)msum / (double)n); cc.precise = precise; cc.fwd = (int32_t)fwd; cc.rev = (int32_t)(n - fwd);
+  cc.qc = 1; cc.filter = SNF_F_PASS;
+  cc.nm = cfg.qc_nm_measure ? nmsum / (double)n : -1.0;
+  cc.stdev_pos = stdev_pos; cc.stdev_len = stdev_len;
+  cc.sa_count = (int32_t)sa; cc.sa_frac = (double)sa / (double)n_all; cc.n_leads = n;
+  cc.mate_contig = -1; cc.gt_hp = -1; cc.gt_ps = -1; cc.vaf = NAN; cc.alt_len = -1;
+  cc.cluster_start = v.seed_start[h]; cc.cluster_end = v.c_end[h];
+  cc.cluster_seed_index = v.seed_bin[h] - v.grp_first_bin[g];
+  int64_t rn_len = support;
+  if (svtype == SNF_BND) {  // resolve_bnd
+    for (int32_t k = 0; k < n; k++) a3[k] = v.in_mate_contig[v.F_orig[FI[k]]];
+    sort_inplace(a3, (int64_t)n, LessI32{});
+    int32_t mc = a3[0]; int64_t bc = 0;
+    for (int32_t x = 0; x < n;) { int32_t y = x; while (y < n && a3[y] == a3[x]) y++; if (y - x > bc) { bc = y - x; mc = a3[x]; } x = y; }
+    int32_t ns = 0; int64_t nfirst = 0, nrev = 0;
+    for (int32_t k = 0; k < n; k++) {
+      uint32_t o = (uint32_t)v.F_orig[FI[k]];
+      bool sel = v.in_mate_contig[o] == mc;
+      v.F_sel[FI[k]] = sel ? 1 : 0;
+      if (sel) { a3[ns] = v.in_mate_pos[o]; a1[ns] = (int32_t)v.in_qname[o]; nfirst += v.in_first[o]; nrev += v.in_rev[o]; ns++; }
+    }
+    sort_inplace(a3, (int64_t)ns, LessI32{});
+    sort_inplace(a1, (int64_t)ns, LessI32{});
+    nq = distinct_sorted_i32(a1, ns);
+    cc.support = (int32_t)nq; rn_len = nq;
+    cc.mate_contig = mc; cc.mate_ref_start = center_sorted(a3, ns);
+    cc.bnd_is_first = (nfirst > ns - nfirst) ? 1 : 0;   // most_common_top: ties -> False
+    cc.bnd_is_reverse = (nrev > ns - nrev) ? 1 : 0;
+    cc.n_leads = ns;
+  } else if (svtype == SNF_INS) cc.support_long = (int32_t)support_long;
+  else if (svtype == SNF_DEL) cc.support_sa = (int32_t)src_noninline;
+  cc.rn_len = (int32_t)rn_len;
+  cc.rn_off = nq;  // stash: number of distinct names already sorted in w1[flo..]
+  v.cand[r] = cc;
+  CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
+  v.candx[r] = x;
+  v.cdflag[r] = 1;
+}
+
+// D3a: compaction (cdscan = exclusive scan of cdflag) -> calls in candidate order
+SNF_HD void d3_compact_body(int64_t r, const View& v) {
+  if (r == 0) { v.cnt->n_calls = v.cdscan[v.N]; }
+  if (r < v.cnt->n_rc && v.cdflag[r]) { uint32_t i = v.cdscan[r]; v.calls[i] = v.cand[r]; v.callx[i] = v.candx[r]; }
+}
+
+// D3b: per task offsets into calls (calls are sorted by task), T+1 entries
+SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
+  int64_t lo = 0, hi = v.cnt->n_calls;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v.calls[mid].task_index < t) lo = mid + 1; else hi = mid; }
+  v.t_call_off[t] = lo;
+}
+
+// D3c: sv ids, stale BND `end` (postprocessing.py:84-106), rnames offsets helper
+SNF_HD void d3_svid_body(int64_t i, const View& v) {
+  if (i >= v.cnt->n_calls) { v.fN[i] = 0; return; }
+  snf_call_t& c = v.calls[i];
+  int t = c.task_index;
+  c.sv_id = v.t_sv_id_start[t] + (int32_t)(i - v.t_call_off[t]);
+  v.fN[i] = (uint32_t)c.rn_len;  // scanned into rn_off
+  if (i == 0) v.fN[v.N] = 0;
+}
+
+SNF_HD void d3_stale_body(int64_t t, const View& v) {
+  if (t >= v.T) return;
+  int64_t lo = v.t_call_off[t], hi = v.t_call_off[t + 1];
+  int64_t a = lo, b = hi;
+  while (a < b) { int64_t mid = (a + b) >> 1; if (v.calls[mid].svtype < SNF_BND) a = mid + 1; else b = mid; }
+  v.t_status[t] = SNF_TASK_OK; v.t_stale_end[t] = 0;
+  if (a < hi && v.calls[a].svtype == SNF_BND) {
+    if (a == lo) v.t_status[t] = SNF_TASK_ERR_UNBOUND_END;   // UnboundLocalError: local variable 'end'
+    else {
+      const snf_call_t& p = v.calls[a - 1];
+      v.t_stale_end[t] = p.svtype == SNF_INS ? p.pos + 1 : (int32_t)((int64_t)p.pos + iabs64(p.svlen));
+    }
+  }
+}
+
+// D3d: supporting read names (pN = exclusive scan of rn_len)
+SNF_HD void d3_rnames_body(int64_t i, const View& v) {
+  if (i == 0) v.cnt->rn_total = v.pN[v.N];
+  if (i >= v.cnt->n_calls) return;
+  snf_call_t& c = v.calls[i];
+  const CallX& x = v.callx[i];
+  int64_t nq = c.rn_off;  // stashed by d2
+  int64_t off = v.pN[i];
+  const int32_t* a1 = v.w1 + x.flo;
+  for (int64_t k = 0; k < nq; k++) v.rnames[off + k] = (uint32_t)a1[k];
+  int64_t w = nq;
+  if (c.svtype == SNF_INS && c.rn_len > nq) {
+    int32_t h = v.cl_head[x.cluster];
+    int32_t llo = v.seedL_lo[h], lhi = v.seedL_hi[v.c_last[h]];
+    for (int32_t p = llo; p < lhi; p++) {
+      int32_t q = (int32_t)v.in_qname[v.LL[p]];
+      bool first = true;
+      for (int32_t y = llo; y < p; y++) if ((int32_t)v.in_qname[v.LL[y]] == q) { first = false; break; }
+      if (first && !contains_sorted_i32(a1, nq, q)) v.rnames[off + w++] = (uint32_t)q;
+    }
+  }
+  c.rn_off = off;
+}
+
+// ------------------------------------------------------------------------------------------ coverage
+// coverage(x) of the reference's dense uint16 vector (leadprov.py:451,510) as rank queries:
+// #(start <= x) - #(end <= x) over the task's reads, modulo 2^16
+SNF_HD bool cov_get(const View& v, int t, int64_t idx, int32_t* out) {
+  int64_t len = v.t_contig_len[t];
+  if (idx < -len || idx >= len) return false;  // IndexError: the field keeps its value
+  if (idx < 0) idx += len;                      // numpy negative index
+  int64_t lo = v.t_read_off[t], hi = v.t_read_off[t + 1];
+  int64_t ns = upper_bound_i32(v.r_start, lo, hi, idx) - lo;
+  int64_t ne = upper_bound_i32(v.re_sorted, lo, hi, idx) - lo;
+  *out = (int32_t)((uint64_t)(ns - ne) & 0xffffu);
+  return true;
+}
+
+SNF_HD void d4_coverage_body(int64_t i, const View& v) {
+  if (i >= v.cnt->n_calls) return;
+  snf_call_t& c = v.calls[i];
+  int t = c.task_index;
+  if (v.t_status[t] != SNF_TASK_OK) return;
+  int bs = v.cfg.coverage_binsize, ud = v.cfg.coverage_updown_bins;
+  int64_t start = c.pos, end;
+  if (c.svtype == SNF_INS) end = start + 1;
+  else if (c.svtype == SNF_BND) { if (c.bnd_is_first) start -= 1; end = v.t_stale_end[t]; }
+  else end = (int64_t)c.pos + iabs64(c.svlen);
+  if (c.svtype == SNF_INS || c.svtype == SNF_BND) {
+    cov_get(v, t, start - bs, &c.cov[1]);
+    cov_get(v, t, start, &c.cov[2]);
+    cov_get(v, t, end + bs, &c.cov[3]);
+  } else {
+    cov_get(v, t, start, &c.cov[1]);
+    cov_get(v, t, (start + end) / 2, &c.cov[2]);
+    cov_get(v, t, end - bs, &c.cov[3]);
+  }
+  cov_get(v, t, start - (int64_t)bs * ud, &c.cov[0]);
+  cov_get(v, t, end + (int64_t)bs * ud, &c.cov[4]);
+}
+
+// coverage.mean(): sum of clipped read lengths / contig_len (exact integer sum, one division)
+#define SNF_COV_CHUNK 256
+SNF_HD void d5_covsum_body(int64_t j, const View& v) {
+  int64_t lo = j * SNF_COV_CHUNK, hi = lo + SNF_COV_CHUNK;
+  if (hi > v.R) hi = v.R;
+  if (lo >= hi) return;
+  int t = v.r_task[lo];
+  unsigned long long acc = 0;
+  for (int64_t r = lo; r < hi; r++) {
+    int tr = v.r_task[r];
+    if (tr != t) { atomic_add_u64(&v.t_cov_sum[t], acc); acc = 0; t = tr; }
+    int64_t L = v.t_contig_len[tr];
+    int64_t s = v.r_start[r], e = v.r_end[r];
+    if (s < 0) s = 0; if (s > L) s = L;
+    if (e < 0) e = 0; if (e > L) e = L;
+    if (e > s) acc += (unsigned long long)(e - s);
+  }
+  atomic_add_u64(&v.t_cov_sum[t], acc);
+}
+SNF_HD void d5_covavg_body(int64_t t, const View& v) {
+  int64_t L = v.t_contig_len[t];
+  v.t_cov_avg[t] = L > 0 ? (double)v.t_cov_sum[t] / (double)L : NAN;
+}
+
+}  // namespace snf

@@ -1,0 +1,295 @@
+// snf_stage_cluster.h - kernel bodies for lead binning, seed clusters and the adaptive merge scan.
+//
+// Reference semantics: LeadProvider.record_lead (leadprov.py:400-418), cluster.resolve seed stage
+// (cluster.py:219-275), Cluster.compute_metrics (cluster.py:48-61), merge scan (cluster.py:278-308).
+#pragma once
+#include "snf_exact.h"
+#include "snf_view.h"
+
+namespace snf {
+
+#define SNF_KEY_INVALID (~0ull)
+SNF_HD int key_grp(uint64_t key) { return (int)(key >> 32); }  // task*8 + svtype
+SNF_HD int grp_svtype(int g) { return g & 7; }
+SNF_HD int grp_task(int g) { return g >> 3; }
+
+SNF_HD bool lead_is_long(const View& v, uint32_t o) {  // INS lead with svlen None -> leads_long (cluster.py:248-250)
+  return v.in_svtype[o] == SNF_INS && v.in_svlen[o] == SNF_SVLEN_NONE;
+}
+
+// ------------------------------------------------------------------------------------------ stage A
+// A1: sort key (task, svtype, bin); leads outside the task region are dropped (leadprov.py:464-468)
+SNF_HD void a1_keys_body(int64_t i, const View& v) {
+  int t = v.lead_task[i];
+  int64_t rs = v.in_ref_start[i];
+  bool valid = rs >= 0 && rs < v.t_contig_len[t];
+  uint64_t bin = valid ? (uint64_t)(rs / v.cfg.cluster_binsize) : 0;
+  v.key_in[i] = valid ? (((uint64_t)(t * 8 + v.in_svtype[i])) << 32 | bin) : SNF_KEY_INVALID;
+  v.val_in[i] = (uint32_t)i;
+  v.seqnull[i] = 0;
+}
+
+// A2: bin heads in (stably) sorted order
+SNF_HD void a2_heads_body(int64_t p, const View& v) {
+  uint64_t k = v.key_out[p];
+  bool valid = k != SNF_KEY_INVALID;
+  v.headflag[p] = (valid && (p == 0 || v.key_out[p - 1] != k)) ? 1u : 0u;
+  if (valid && (p + 1 == v.N || v.key_out[p + 1] == SNF_KEY_INVALID)) v.cnt->n_valid = p + 1;
+  if (p == 0) v.headflag[v.N] = 0;
+}
+
+// A3: bin table (headscan = exclusive scan of headflag; headscan[N] = #bins)
+SNF_HD void a3_bins_body(int64_t p, const View& v) {
+  if (p == 0) {
+    int64_t nb = v.headscan[v.N];
+    v.cnt->n_bins = nb;
+    v.bin_lo[nb] = (int32_t)v.cnt->n_valid;
+  }
+  if (v.headflag[p]) {
+    uint32_t b = v.headscan[p];
+    v.bin_lo[b] = (int32_t)p;
+    v.bin_key[b] = v.key_out[p];
+  }
+}
+
+// A4: per bin: record_lead side effects (seq cap, hap counters) and seed eligibility (cluster.py:262)
+SNF_HD void a4_binstats_body(int64_t b, const View& v) {
+  if (b >= v.cnt->n_bins) { v.eligflag[b] = 0; return; }
+  int32_t lo = v.bin_lo[b], hi = v.bin_lo[b + 1];
+  int n_normal = 0;
+  uint32_t hc[3] = {0, 0, 0};
+  for (int32_t p = lo; p < hi; p++) {
+    uint32_t o = v.val_out[p];
+    if (p - lo + 1 > v.cfg.consensus_max_reads_bin) v.seqnull[o] = 1;
+    uint8_t h = v.in_hap[o];
+    if (hc[h] < 65535u) hc[h]++;  // array('H') OverflowError is swallowed by the reference
+    if (!lead_is_long(v, o)) n_normal++;
+  }
+  for (int h = 0; h < 3; h++) v.bin_hap[3 * b + h] = (uint16_t)hc[h];
+  bool el = n_normal >= v.cfg.dev_min_leads_cluster;
+  v.bin_elig[b] = el;
+  v.eligflag[b] = el ? 1u : 0u;
+  int g = key_grp(v.bin_key[b]);
+  if (b == 0 || key_grp(v.bin_key[b - 1]) != g) v.grp_first_bin[g] = (int32_t)b;
+}
+
+// A5: per sorted lead: member of a seed's `leads` (fN) or `leads_long` (fL)
+SNF_HD void a5_leadflags_body(int64_t p, const View& v) {
+  uint32_t fn = 0, fl = 0;
+  if (p < v.cnt->n_valid) {
+    uint32_t b = v.headscan[p + 1] - 1;
+    if (v.bin_elig[b]) {
+      if (lead_is_long(v, v.val_out[p])) fl = 1; else fn = 1;
+    }
+  }
+  v.fN[p] = fn;
+  v.fL[p] = fl;
+  if (p == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; v.eligflag[v.N] = 0; }
+}
+
+// A6: scatter into L / LL (pN/pL = exclusive scans of fN/fL)
+SNF_HD void a6_scatter_body(int64_t p, const View& v) {
+  if (p == 0) { v.cnt->NF = v.pN[v.N]; v.cnt->NLL = v.pL[v.N]; v.cnt->n_seeds = v.eligscan[v.N]; }
+  if (p >= v.cnt->n_valid) return;
+  uint32_t o = v.val_out[p];
+  if (v.fN[p]) v.L[v.pN[p]] = o;
+  if (v.fL[p]) v.LL[v.pL[p]] = o;
+}
+
+// A7: seed table (eligscan = exclusive scan of eligflag)
+SNF_HD void a7_seeds_body(int64_t b, const View& v) {
+  if (b >= v.cnt->n_bins || !v.bin_elig[b]) return;
+  uint32_t s = v.eligscan[b];
+  int32_t lo = v.bin_lo[b], hi = v.bin_lo[b + 1];
+  v.seed_bin[s] = (int32_t)b;
+  v.seed_lo[s] = (int32_t)v.pN[lo];
+  v.seed_hi[s] = (int32_t)v.pN[hi];
+  v.seedL_lo[s] = (int32_t)v.pL[lo];
+  v.seedL_hi[s] = (int32_t)v.pL[hi];
+  v.seed_start[s] = (int32_t)((uint32_t)v.bin_key[b]) * v.cfg.cluster_binsize;
+  v.seed_grp[s] = key_grp(v.bin_key[b]);
+}
+
+// ------------------------------------------------------------------------------------------ stage B
+// Cluster.compute_metrics over L[lo,hi) (cluster.py:48-61): n = min(len,100) samples every int(len/n),
+// mean divides by n (not the sample count), stdev = statistics.stdev of the sampled ref_starts
+SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean, double* sd) {
+  int64_t len = hi - lo;
+  int64_t n = len < 100 ? len : 100;
+  if (n == 0) { *mean = 0; *sd = 0; return; }
+  if (n == 1) { *mean = (double)v.in_svlen[v.L[lo]]; *sd = 0; return; }
+  int64_t step = len / n;
+  int64_t sum = 0, cnt = 0;
+  i128 S1 = 0; u128 S2 = 0;
+  int64_t x0 = v.in_ref_start[v.L[lo]];
+  for (int64_t i = 0; i < len; i += step) {
+    uint32_t o = v.L[lo + i];
+    sum += v.in_svlen[o];
+    int64_t d = (int64_t)v.in_ref_start[o] - x0;
+    S1 += d; S2 += (u128)((i128)d * d);
+    cnt++;
+  }
+  *mean = (double)sum / (double)n;
+  *sd = stdev_from_sums(cnt, S1, S2);
+}
+
+SNF_HD bool seed_first_of_group(const View& v, int64_t s) { return s == 0 || v.seed_grp[s - 1] != v.seed_grp[s]; }
+
+SNF_HD void b1_seedmetrics_body(int64_t s, const View& v) {
+  if (s == 0) v.runflag[v.N] = 0;
+  if (s >= v.cnt->n_seeds) { v.runflag[s] = 0; return; }
+  double mean, sd;
+  compute_metrics(v, v.seed_lo[s], v.seed_hi[s], &mean, &sd);
+  int g = v.seed_grp[s], t = grp_task(g);
+  int32_t seed = v.seed_start[s];
+  bool within_tr = false;
+  if (v.t_has_tr[t]) {
+    // monotone sweep of cluster.py:240-246 == first TR whose end >= seed (else the last TR)
+    int64_t lo = v.t_tr_off[t], hi = v.t_tr_off[t + 1];
+    int64_t k = lower_bound_i32(v.tr_pmax, lo, hi, seed);
+    if (k >= hi) k = hi - 1;
+    within_tr = v.tr_start[k] < seed && seed < v.tr_end[k];
+  }
+  uint8_t rep = (within_tr || v.cfg.repeat) ? 1 : 0;
+  v.s_mean0[s] = mean; v.s_stdev0[s] = sd; v.s_repeat0[s] = rep;
+  v.c_mean[s] = mean; v.c_stdev[s] = sd; v.c_repeat[s] = rep;
+  v.c_last[s] = (int32_t)s;
+  v.c_end[s] = seed + v.cfg.cluster_binsize;
+  bool first = seed_first_of_group(v, s);
+  bool last = (s + 1 == v.cnt->n_seeds) || v.seed_grp[s + 1] != g;
+  v.prv[s] = first ? -1 : (int32_t)(s - 1);
+  v.nxt[s] = last ? -1 : (int32_t)(s + 1);
+  v.clflag[s] = 1;
+  if (first) v.grp_seed_lo[g] = (int32_t)s;
+  if (last) v.grp_seed_hi[g] = (int32_t)(s + 1);
+  // run cut: a gap no merge criterion can bridge unless a cluster's start-stdev is huge (validated later)
+  bool cut = first;
+  if (!first && v.run_gap >= 0) {
+    int64_t inner = (int64_t)seed - ((int64_t)v.seed_start[s - 1] + v.cfg.cluster_binsize);
+    cut = inner > v.run_gap;
+  }
+  v.runflag[s] = cut ? 1u : 0u;
+}
+
+SNF_HD void b2_runs_body(int64_t s, const View& v) {
+  if (s == 0) {
+    int64_t nr = v.runscan[v.N];
+    v.cnt->n_runs = nr;
+    v.run_first[nr] = (int32_t)v.cnt->n_seeds;
+  }
+  if (s < v.cnt->n_seeds && v.runflag[s]) v.run_first[v.runscan[s]] = (int32_t)s;
+}
+
+// ------------------------------------------------------------------------------------------ stage C
+SNF_HD bool merge_criterion(const View& v, int svtype, int64_t inner, int64_t outer, double sd_a, double sd_b,
+                            double mean_a, double mean_b, bool rep_a, bool rep_b) {
+  double ms = sd_a < sd_b ? sd_a : sd_b;
+  bool merge = (double)inner <= ms * v.cfg.cluster_r;
+  if (!merge && (v.cfg.repeat || rep_a || rep_b)) {
+    double h = (fabs(mean_a) + fabs(mean_b)) * v.cfg.cluster_repeat_h;
+    double lim = h < v.cfg.cluster_repeat_h_max ? h : v.cfg.cluster_repeat_h_max;
+    merge = (double)outer <= lim;
+  }
+  if (!merge && svtype == SNF_BND) merge = inner <= v.cfg.cluster_merge_bnd;
+  return merge;
+}
+
+// Sequential adaptive merge scan (cluster.py:278-308) over the seeds [s0, s_end) of one group, as a
+// linked list.  `group_first`: s0 is the first cluster of its (task, svtype) sequence, i.e. the scan's
+// index rule `i = max(0, i-2) + 1` clamps at list index 0.  For a run that starts later the cluster
+// before s0 never merges with it (validated by c2_validate), so after a merge at the run's first
+// cluster the scan steps back to that boundary, fails, and returns: the position stays put.
+SNF_HD void merge_walk(const View& v, int32_t s0, int32_t s_end, bool group_first, int64_t run) {
+  int svtype = grp_svtype(v.seed_grp[s0]);
+  int32_t cur = s0;
+  int64_t idx = 0;
+  double b_sd = v.c_stdev[s0], b_am = fabs(v.c_mean[s0]);
+  uint8_t b_rep = v.c_repeat[s0];
+  for (;;) {
+    int32_t nx = v.nxt[cur];
+    if (nx < 0 || nx >= s_end) break;
+    int64_t inner = (int64_t)v.seed_start[nx] - v.c_end[cur];
+    int64_t outer = (int64_t)v.c_end[nx] - v.seed_start[cur];
+    bool merge = merge_criterion(v, svtype, inner, outer, v.c_stdev[cur], v.c_stdev[nx], v.c_mean[cur], v.c_mean[nx],
+                                 v.c_repeat[cur], v.c_repeat[nx]);
+    if (merge) {
+      int32_t nn = v.nxt[nx];
+      v.c_last[cur] = v.c_last[nx];
+      v.c_end[cur] = v.c_end[nx];
+      v.c_repeat[cur] = v.c_repeat[cur] | v.c_repeat[nx];
+      v.nxt[cur] = nn;
+      if (nn >= 0) v.prv[nn] = cur;
+      v.clflag[nx] = 0;
+      double mean, sd;
+      compute_metrics(v, v.seed_lo[cur], v.seed_hi[v.c_last[cur]], &mean, &sd);
+      v.c_mean[cur] = mean; v.c_stdev[cur] = sd;
+      if (cur == s0) {
+        if (sd > b_sd) b_sd = sd;
+        if (fabs(mean) > b_am) b_am = fabs(mean);
+        b_rep |= v.c_repeat[cur];
+      }
+      if (group_first) {
+        if (idx == 0) {          // i = max(0,-2)+1 = 1: the merged cluster 0 is not re-checked
+          int32_t n2 = v.nxt[cur];
+          if (n2 < 0 || n2 >= s_end) break;
+          cur = n2; idx = 1;
+        } else if (idx == 1) {   // i = max(0,-1)+1 = 1: stay
+        } else { cur = v.prv[cur]; idx--; }
+      } else {
+        if (cur != s0) cur = v.prv[cur];
+      }
+    } else {
+      cur = nx; idx++;
+    }
+  }
+  if (run >= 0) {
+    int32_t last = cur;
+    for (;;) { int32_t nx = v.nxt[last]; if (nx < 0 || nx >= s_end) break; last = nx; }
+    v.run_last_head[run] = last;
+    v.run_b_stdev[run] = b_sd; v.run_b_absmean[run] = b_am; v.run_b_repeat[run] = b_rep;
+  }
+}
+
+SNF_HD void c1_mergeruns_body(int64_t r, const View& v) {
+  if (r >= v.cnt->n_runs) return;
+  int32_t s0 = v.run_first[r], s_end = v.run_first[r + 1];
+  merge_walk(v, s0, s_end, seed_first_of_group(v, s0), r);
+}
+
+// C2: a run boundary is valid iff the last cluster of the previous run can merge with NO state the first
+// cluster of this run went through (conservative superset of the comparisons the serial scan makes).
+SNF_HD void c2_validate_body(int64_t r, const View& v) {
+  if (r >= v.cnt->n_runs) return;
+  int32_t s0 = v.run_first[r];
+  if (seed_first_of_group(v, s0)) return;
+  int32_t a = v.run_last_head[r - 1];
+  int g = v.seed_grp[s0];
+  int64_t inner = (int64_t)v.seed_start[s0] - v.c_end[a];
+  int64_t outer = (int64_t)v.seed_start[s0] + v.cfg.cluster_binsize - v.seed_start[a];  // smallest possible
+  bool bad = merge_criterion(v, grp_svtype(g), inner, outer, v.c_stdev[a], v.run_b_stdev[r], v.c_mean[a],
+                             v.run_b_absmean[r], v.c_repeat[a], v.run_b_repeat[r]);
+  if (bad) atomic_or_i32(&v.grp_dirty[g], 1);
+}
+
+// C3: exact serial redo of a whole (task, svtype) sequence whose run cuts were not provably safe
+SNF_HD void c3_serial_body(int64_t g, const View& v) {
+  if (!v.grp_dirty[g]) return;
+  int32_t lo = v.grp_seed_lo[g], hi = v.grp_seed_hi[g];
+  if (lo < 0) return;
+  for (int32_t s = lo; s < hi; s++) {
+    v.c_mean[s] = v.s_mean0[s]; v.c_stdev[s] = v.s_stdev0[s]; v.c_repeat[s] = v.s_repeat0[s];
+    v.c_last[s] = s; v.c_end[s] = v.seed_start[s] + v.cfg.cluster_binsize;
+    v.prv[s] = s == lo ? -1 : s - 1; v.nxt[s] = s + 1 == hi ? -1 : s + 1;
+    v.clflag[s] = 1;
+  }
+  merge_walk(v, lo, hi, true, -1);
+  atomic_add_u64((unsigned long long*)&v.cnt->n_dirty_groups, 1ull);
+}
+
+// C4: merged cluster table (clscan = exclusive scan of clflag)
+SNF_HD void c4_clusters_body(int64_t s, const View& v) {
+  if (s == 0) v.cnt->n_clusters = v.clscan[v.N];
+  if (s < v.cnt->n_seeds && v.clflag[s]) v.cl_head[v.clscan[s]] = (int32_t)s;
+}
+
+}  // namespace snf

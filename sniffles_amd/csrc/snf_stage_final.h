@@ -1,0 +1,525 @@
+// snf_stage_final.h - kernel bodies for Task.finalize_candidates (parallel.py:129-201).
+//
+// Reference semantics: qc_sv / qc_sv_support / qc_sv_post_annotate (postprocessing.py:133-600),
+// phase_sv / genotype_sv (postprocessing.py:607-654), Genotyper.calculate (genotyping.py:124-241),
+// rescue_phasing (parallel.py:203-249), annotate_sv INS branch (postprocessing.py:33-66),
+// consensus.novel_from_reads (consensus.py:280-394).
+#pragma once
+#include "snf_stage_call.h"
+
+namespace snf {
+
+#define SNF_PS_NULL_CODE 0x7fffffff
+
+struct LeadIter {  // iterates cluster.leads of a call (for BND: the leads resolve_bnd selected)
+  const View& v; const CallX& x; int32_t k;
+  SNF_HD LeadIter(const View& v_, const CallX& x_) : v(v_), x(x_), k(-1) {}
+  SNF_HD bool next(int32_t* slot, uint32_t* orig) {
+    for (k++; k < x.fn; k++) {
+      int32_t s = v.FI[x.flo + k];
+      if (v.F_sel[s]) { *slot = s; *orig = (uint32_t)v.F_orig[s]; return true; }
+    }
+    return false;
+  }
+};
+
+SNF_HD int distinct_strands(const View& v, const CallX& x) {
+  int f = 0, r = 0; int32_t s; uint32_t o;
+  for (LeadIter it(v, x); it.next(&s, &o);) { if (v.in_strand[o] == 0) f = 1; else r = 1; }
+  return f + r;
+}
+
+SNF_HD double py_round(double x) { return rint(x); }  // round-half-even (default rounding mode)
+
+SNF_HD int64_t rescale_support(const snf_call_t& c, const snf_config_t& cfg) {
+  if (c.svtype != SNF_INS || c.svlen < cfg.long_ins_length) return c.support;
+  double scale = cfg.long_ins_rescale_mult * ((double)c.svlen / (double)cfg.long_ins_length);
+  return (int64_t)py_round((double)c.support * (cfg.long_ins_rescale_base + scale));
+}
+
+SNF_HD bool qc_support_auto(const snf_call_t& c, double cov_global, const snf_config_t& cfg) {
+  int64_t support = rescale_support(c, cfg);
+  int64_t lst[3]; int k = 0;
+  if (c.cov[0] != 0) lst[k++] = c.cov[0];
+  if (c.cov[4] != 0) lst[k++] = c.cov[4];
+  if (k == 0) for (int j = 1; j <= 3; j++) if (c.cov[j] != 0) lst[k++] = c.cov[j];
+  double regional;
+  if (k == 0) regional = cov_global;
+  else {
+    int64_t s = 0; for (int j = 0; j < k; j++) s += lst[j];
+    regional = py_round((double)s / (double)k);
+    if (regional == 0) regional = cov_global;
+  }
+  double gw = 1.0 - cfg.minsupport_auto_regional_coverage_weight;
+  double cov = regional * cfg.minsupport_auto_regional_coverage_weight + cov_global * gw;
+  double min_support = py_round(cfg.minsupport_auto_base + cfg.minsupport_auto_mult * cov);
+  return (double)support >= min_support;
+}
+
+SNF_HD bool qc_sv_support(snf_call_t& c, double cov_global, const snf_config_t& cfg) {
+  bool ok = cfg.minsupport < 0 ? qc_support_auto(c, cov_global, cfg) : (c.support >= cfg.minsupport);
+  if (!ok) { c.filter = SNF_F_SUPPORT_MIN; return false; }
+  return true;
+}
+
+#define SNF_FAIL(f) do { c.filter = (f); return false; } while (0)
+
+SNF_HD bool qc_sv(const View& v, snf_call_t& c, const CallX& x) {
+  const snf_config_t& cfg = v.cfg;
+  int t = c.svtype;
+  bool single = t == SNF_SINGLE_LEFT || t == SNF_SINGLE_RIGHT;
+  double alen = (double)iabs64(c.svlen);
+  if (cfg.qc_stdev) {
+    if (c.stdev_pos > (double)cfg.qc_stdev_abs_max) SNF_FAIL(SNF_F_STDEV_POS);
+    if (t != SNF_BND && !single && c.stdev_pos / alen > 2.0) SNF_FAIL(SNF_F_STDEV_POS);
+    if (!(c.stdev_len != c.stdev_len) && c.stdev_len != 0) {
+      if (t != SNF_BND && c.stdev_len / alen > 1.0) SNF_FAIL(SNF_F_STDEV_LEN);
+      if (c.stdev_len > (double)cfg.qc_stdev_abs_max) SNF_FAIL(SNF_F_STDEV_LEN);
+    }
+  }
+  if (single && !cfg.dev_output_candidates) SNF_FAIL(SNF_F_SINGLE_BREAK);
+  if (iabs64(c.svlen) < cfg.minsvlen && t != SNF_BND) {
+    if (c.support < 10 || cfg.minsvlen_hard_cap) SNF_FAIL(SNF_F_SVLEN_MIN);
+  }
+  if (t == SNF_BND) {
+    if (cfg.qc_bnd_filter_strand && distinct_strands(v, x) < 2) SNF_FAIL(SNF_F_STRAND_BND);
+  }
+  double up = c.cov[0], ce = c.cov[2], dn = c.cov[4];
+  if (t == SNF_DEL && cfg.long_del_length != -1 && iabs64(c.svlen) >= cfg.long_del_length && !cfg.mosaic &&
+      iabs64(c.svlen) <= cfg.dev_longer_del) {
+    double scaled = cfg.long_del_coverage / 2.0;
+    if (ce > (up + dn) * scaled) {
+      if (up > ce && ce > dn) { if (dn / up < 0.7) SNF_FAIL(SNF_F_COV_CHANGE_DEL); }
+      else if (up < ce && ce < dn) { if (up / dn < 0.7) SNF_FAIL(SNF_F_COV_CHANGE_DEL); }
+    }
+    if (up > dn) { if (0.5 > dn / up || ce > dn) SNF_FAIL(SNF_F_COV_CHANGE_DEL); }
+    else if (up < dn) { if (0.5 > up / dn || up < ce) SNF_FAIL(SNF_F_COV_CHANGE_DEL); }
+  } else if (t == SNF_DUP && cfg.long_dup_length != -1 && iabs64(c.svlen) >= cfg.long_dup_length && !cfg.mosaic &&
+             iabs64(c.svlen) <= cfg.dev_longer_dup) {
+    double scaled = cfg.long_dup_coverage / 2.0;
+    if (ce < (up + dn) * scaled) {
+      if (up > ce && ce > dn) { if (dn / up < 0.7) SNF_FAIL(SNF_F_COV_CHANGE_DUP); }
+      else if (up < ce && ce < dn) { if (up / dn < 0.7) SNF_FAIL(SNF_F_COV_CHANGE_DUP); }
+      if (up > dn) { if (0.5 > dn / up || ce < dn) SNF_FAIL(SNF_F_COV_CHANGE_DUP); }
+      else if (up < dn) { if (0.5 > up / dn || up > ce) SNF_FAIL(SNF_F_COV_CHANGE_DUP); }
+    }
+  } else if (t == SNF_INS && (c.cov[0] < cfg.qc_coverage || c.cov[4] < cfg.qc_coverage)) {
+    SNF_FAIL(SNF_F_COV_CHANGE_INS);
+  }
+  if (t == SNF_INS || t == SNF_DEL) {
+    bool no_split_sa = c.support_sa <= 0;  // None or 0
+    if (c.sa_frac > cfg.dev_inline_sa_support_max && c.sa_count > 5 && no_split_sa) SNF_FAIL(SNF_F_INLINE_SA);
+  }
+  // qc_coverage_samples(): the sampler is never fed -> (True, None) (sv.py:219-223)
+  double f = cfg.qc_coverage_max_change_frac;
+  if (f != -1.0) {
+    double u = c.cov[0] ? c.cov[0] : 1.0, s = c.cov[1] ? c.cov[1] : 1.0, m = c.cov[2] ? c.cov[2] : 1.0,
+           e = c.cov[3] ? c.cov[3] : 1.0, d = c.cov[4] ? c.cov[4] : 1.0;
+    if (fabs(u - s) / fmax(u, s) > f) SNF_FAIL(SNF_F_COV_CHANGE_FRAC_US);
+    if (fabs(s - m) / fmax(s, m) > f) SNF_FAIL(SNF_F_COV_CHANGE_FRAC_SC);
+    if (fabs(m - e) / fmax(m, e) > f) SNF_FAIL(SNF_F_COV_CHANGE_FRAC_CE);
+    if (fabs(e - d) / fmax(e, d) > f) SNF_FAIL(SNF_F_COV_CHANGE_FRAC_ED);
+  }
+  return true;
+}
+
+// phase_sv: majority HP / PS over distinct read_id (last lead of a read wins)
+SNF_HD void phase_sv(const View& v, snf_call_t& c, const CallX& x, int task, int* hp_ret, int* ps_ret) {
+  int64_t hc[3] = {0, 0, 0};
+  int32_t* a0 = v.w0 + x.flo;
+  int32_t np_ = 0;
+  int32_t ps_null = v.t_ps_null[task];
+  for (int32_t k = 0; k < x.fn; k++) {
+    int32_t s = v.FI[x.flo + k];
+    if (!v.F_sel[s]) continue;
+    uint32_t o = (uint32_t)v.F_orig[s];
+    uint32_t rid = v.in_read_id[o];
+    bool later = false;
+    for (int32_t k2 = k + 1; k2 < x.fn; k2++) {
+      int32_t s2 = v.FI[x.flo + k2];
+      if (v.F_sel[s2] && v.in_read_id[(uint32_t)v.F_orig[s2]] == rid) { later = true; break; }
+    }
+    if (later) continue;
+    hc[v.in_hap[o]]++;
+    int32_t p = v.in_ps[o];
+    a0[np_++] = (p == SNF_PS_NONE || p == ps_null) ? SNF_PS_NULL_CODE : p;
+  }
+  // most_common: sorted((count, value), reverse=True)
+  int hpv = 0; int64_t hp_support = -1;
+  for (int h = 0; h < 3; h++) if (hc[h] > 0 && hc[h] >= hp_support) { hp_support = hc[h]; hpv = h; }
+  int64_t other_hp = 0;
+  for (int h = 0; h < 3; h++) if (h != hpv) other_hp += hc[h];
+  sort_inplace(a0, (int64_t)np_, LessI32{});
+  int32_t psv = 0; int64_t ps_support = -1;
+  for (int32_t i = 0; i < np_;) {
+    int32_t j = i; while (j < np_ && a0[j] == a0[i]) j++;
+    if (j - i >= ps_support) { ps_support = j - i; psv = a0[i]; }
+    i = j;
+  }
+  int64_t other_ps = 0;
+  for (int32_t i = 0; i < np_;) {
+    int32_t j = i; while (j < np_ && a0[j] == a0[i]) j++;
+    if (a0[i] != psv && a0[i] != SNF_PS_NULL_CODE) other_ps += j - i;
+    i = j;
+  }
+  bool hp_pass = ((double)other_hp / (double)(hp_support + other_hp) < v.cfg.phase_conflict_threshold) && hp_support > 0;
+  bool ps_pass = ((double)other_ps / (double)(ps_support + other_ps) < v.cfg.phase_conflict_threshold) &&
+                 psv != SNF_PS_NULL_CODE && ps_support > 0;
+  c.ph_set = 1; c.ph_hp = hpv; c.ph_ps = psv == SNF_PS_NULL_CODE ? -2 : psv;
+  c.ph_hp_support = (int32_t)hp_support; c.ph_ps_support = (int32_t)ps_support;
+  c.ph_hp_pass = hp_pass; c.ph_ps_pass = ps_pass;
+  *hp_ret = ((hpv == 1 || hpv == 2) && hp_pass) ? hpv : -1;
+  *ps_ret = ps_pass ? psv : -1;
+}
+
+SNF_HD bool coverage_from_list(const int64_t* lst, int k, int64_t* out) {
+  int64_t s = 0; int m = 0;
+  for (int j = 0; j < k; j++) if (lst[j] != 0) { s += lst[j]; m++; }
+  if (m == 0) return false;  // UnknownGenotypeError
+  *out = (int64_t)py_round((double)s / (double)m);
+  return true;
+}
+
+SNF_HD void genotype_sv(const View& v, snf_call_t& c, int hp_ret, int ps_ret) {
+  const snf_config_t& cfg = v.cfg;
+  int t = c.svtype;
+  int64_t support = t == SNF_INS ? rescale_support(c, cfg) : c.support;
+  int64_t coverage = 0, l3[3]; bool ok;
+  if (t == SNF_INS) { l3[0] = c.cov[2]; ok = coverage_from_list(l3, 1, &coverage); }
+  else if (t == SNF_DEL) {
+    int64_t sa = c.support_sa > 0 ? c.support_sa : 0;
+    l3[0] = c.cov[1] + sa; l3[1] = c.cov[2] + sa; l3[2] = c.cov[3] + sa; ok = coverage_from_list(l3, 3, &coverage);
+  } else if (t == SNF_DUP) {
+    l3[0] = c.cov[1]; l3[1] = c.cov[3]; ok = coverage_from_list(l3, 2, &coverage);
+    if (ok) coverage += (int64_t)py_round((double)support * 0.75);
+  } else if (t == SNF_INV) {
+    l3[0] = c.cov[0]; l3[1] = c.cov[4]; ok = coverage_from_list(l3, 2, &coverage);
+    if (ok) coverage += (int64_t)py_round((double)support * 0.5);
+  } else { l3[0] = c.cov[1]; l3[1] = c.cov[2]; l3[2] = c.cov[3]; ok = coverage_from_list(l3, 3, &coverage); }
+  if (!ok) { c.filter = SNF_F_GT_FAILED; c.qc = 0; return; }
+  if (support > coverage) coverage = support;
+  double af = (double)support / (double)coverage;
+  int64_t max_lead = support > coverage ? support : coverage;
+  int64_t ns = support, ncv = coverage;
+  if (max_lead > 250) {
+    double norm = 250.0 / (double)max_lead;
+    ns = (int64_t)py_round((double)support * norm);
+    ncv = (int64_t)py_round((double)coverage * norm);
+  }
+  // likelihoods p**k * (1-p)**(n-k), their ordering, GQ and z only depend on (ns, ncv) <= 250:
+  // table built on the host with CPython's libm (snf_lib: build_gt_lut)
+  GtEntry e = v.gt_lut[ns * SNF_GT_N + ncv];
+  bool update_this_dup = t == SNF_DUP && af >= cfg.dev_min_dup_vaf;
+  bool flt = e.z < cfg.genotype_min_z_score && !cfg.mosaic;
+  if (t == SNF_INS && flt && c.svlen >= cfg.long_ins_length && cfg.detect_large_ins) flt = false;
+  if (c.filter == SNF_F_PASS && flt) { c.filter = update_this_dup ? SNF_F_PASS : SNF_F_GT; c.qc = !cfg.pass_only; }
+  int a = e.order0 == 2 ? 1 : 0, b = e.order0 >= 1 ? 1 : 0;
+  if (update_this_dup && e.order0 == 0) { a = 0; b = 1; }
+  c.gt_set = 1; c.gt_a = a; c.gt_b = b; c.gt_gq = e.gq;
+  c.gt_dr = (int32_t)(coverage - support); c.gt_dv = (int32_t)support;
+  c.gt_hp = hp_ret; c.gt_ps = ps_ret;
+  c.vaf = af;
+  if (a == 1 && b == 1 && c.ph_set && c.ph_hp != 0) { c.ph_hp_pass = 1; c.gt_hp = c.ph_hp; c.gt_ps = c.ph_ps; }
+}
+
+SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const CallX& x, int task) {
+  const snf_config_t& cfg = v.cfg;
+  int t = c.svtype;
+  double af = (c.vaf != c.vaf) ? 0.0 : c.vaf;
+  bool sv_is_mosaic = af <= cfg.mosaic_af_max;
+  double cov_avg = v.t_cov_avg[task];
+  if ((c.cov[2] < cfg.qc_coverage && (!c.gt_set || (c.gt_a + c.gt_b < 2))) && (t != SNF_DEL && iabs64(c.svlen) > cfg.long_del_length))
+    SNF_FAIL(SNF_F_COV_MIN_GT);
+  if (cfg.mosaic && !sv_is_mosaic) { if (!qc_sv_support(c, cov_avg, cfg)) return false; }
+  int qc_nm = cfg.qc_nm;
+  double thr = v.t_qc_nm_thr[task] * cfg.qc_nm_mult;
+  if (cfg.mosaic && sv_is_mosaic) qc_nm = cfg.mosaic_qc_nm;
+  if (qc_nm && c.nm > thr && (!c.gt_set || c.gt_b == 0)) SNF_FAIL(SNF_F_ALN_NM);
+  if (!cfg.mosaic && sv_is_mosaic) {
+    bool skip_this_dup = t == SNF_DUP && af >= cfg.dev_min_dup_vaf;
+    if (!skip_this_dup) SNF_FAIL(SNF_F_MOSAIC_VAF);
+  }
+  if (cfg.mosaic && sv_is_mosaic) {
+    int min_mosaic_support = cfg.mosaic_min_reads;
+    bool accepted = t == SNF_INS || t == SNF_DEL || t == SNF_DUP || t == SNF_INV || t == SNF_BND;
+    if (!(c.stdev_len != c.stdev_len) && accepted) {
+      bool filter_low_supp = (!c.precise || c.stdev_len / (double)iabs64(c.svlen) > 0.1 || c.stdev_pos > 5) &&
+                             1 <= cfg.max_svlen_mosaic;
+      min_mosaic_support = (t == SNF_BND || t == SNF_INV || filter_low_supp) ? cfg.mosaic_min_reads : cfg.mosaic_min_reads - 1;
+    }
+    if (c.support < min_mosaic_support) SNF_FAIL(SNF_F_SUPPORT_MIN);
+    if (t != SNF_BND && iabs64(c.svlen) > cfg.max_svlen_mosaic) SNF_FAIL(SNF_F_SVLEN_MAX_MOSAIC);
+  }
+  if (t != SNF_BND) {
+    bool is_long_ins = t == SNF_INS && c.svlen >= cfg.long_ins_length;
+    if (!(cfg.mosaic && sv_is_mosaic) && cfg.qc_strand) {
+      if (!is_long_ins && distinct_strands(v, x) < 2) SNF_FAIL(SNF_F_STRAND);
+    } else if ((cfg.mosaic && sv_is_mosaic) && cfg.mosaic_qc_strand) {
+      if (!is_long_ins && distinct_strands(v, x) < 2 && c.support >= cfg.mosaic_use_strand_thresholds) SNF_FAIL(SNF_F_STRAND_MOSAIC);
+    }
+  }
+  if (cfg.mosaic && sv_is_mosaic) {
+    if ((t == SNF_INV || t == SNF_DUP) && c.svlen < cfg.mosaic_qc_invdup_min_length) SNF_FAIL(SNF_F_SVLEN_MIN_MOSAIC);
+  }
+  if (c.cov[2] < cfg.qc_coverage && t != SNF_DEL && t != SNF_INS) {
+    int64_t lhs = t == SNF_INV ? c.svlen : 0;  // (svtype == "INV" and svlen) > long_inv_length
+    if (lhs > cfg.long_inv_length && !(cfg.mosaic && sv_is_mosaic)) { /* pass */ }
+    else SNF_FAIL(SNF_F_COV_MIN);
+  }
+  if (cfg.mosaic) {
+    if (sv_is_mosaic && (af < cfg.mosaic_af_min || af > cfg.mosaic_af_max)) SNF_FAIL(SNF_F_MOSAIC_VAF);
+    else if (!sv_is_mosaic && !cfg.mosaic_include_germline) SNF_FAIL(SNF_F_NOT_MOSAIC_VAF);
+    if (sv_is_mosaic && t != SNF_BND && t != SNF_SINGLE_LEFT && t != SNF_SINGLE_RIGHT) {
+      int64_t close = 0; int32_t s; uint32_t o;
+      for (LeadIter it(v, x); it.next(&s, &o);) {
+        int64_t qs = v.in_qry_start[o];
+        if (qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)v.in_read_len[o] - qs) <= cfg.dev_min_close_edge_dist) close++;
+      }
+      if ((double)close / (double)c.support >= cfg.dev_min_read_close_edge_prop) SNF_FAIL(SNF_F_MOSAIC_SV_CLOSE_EDGE);
+    }
+  }
+  return true;
+}
+
+// REF haplotype count of the 100-bp bin `b` (leadprov.py:387-398) as rank queries over the sorted reads
+SNF_HD int32_t hapref_count(const View& v, int task, int h, int64_t b) {
+  int64_t lo = v.t_read_off[task], hi = v.t_read_off[task + 1];
+  int64_t lim = (b + 1) * (int64_t)v.cfg.cluster_binsize;  // start_bin <= b  <=>  start < (b+1)*binsize
+  int64_t is = lower_bound_i32(v.r_start, lo, hi, lim), ie = lower_bound_i32(v.re_sorted, lo, hi, lim);
+  int64_t cnt = (int64_t)(v.pc_s[h][is] - v.pc_s[h][lo]) - (int64_t)(v.pc_e[h][ie] - v.pc_e[h][lo]);
+  return (int32_t)(cnt > 65535 ? 65535 : cnt);
+}
+
+struct NmGet {
+  const View& v; const CallX& x;
+  SNF_HD double operator()(int64_t i) const {
+    double nm = v.in_nm[(uint32_t)v.F_orig[v.FI[x.flo + i]]];
+    return nm != nm ? 0.0 : nm;
+  }
+};
+
+SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int task) {
+  const snf_config_t& cfg = v.cfg;
+  if (!cfg.mode_call_sample) return;
+  int64_t n = x.fn, cnt = 0;
+  for (int64_t i = 0; i < n; i++) { double nm = v.in_nm[(uint32_t)v.F_orig[v.FI[x.flo + i]]]; if (nm == nm) cnt++; }
+  double sv_nm = np_pairwise_sum(NmGet{v, x}, n) / (double)cnt;  // np.nanmean
+  if (sv_nm > cfg.genotype_error || n <= 3) return;
+  if (!c.ph_set || !c.ph_hp_pass) return;
+  int hp = c.ph_hp;
+  if (hp != 1 && hp != 2) return;
+  int32_t h = v.cl_head[x.cluster];
+  int32_t b = v.seed_bin[h];
+  int32_t sv_reads = v.bin_hap[3 * b + hp];
+  int32_t all_reads = hapref_count(v, task, hp, (int64_t)v.seed_start[h] / v.cfg.cluster_binsize);
+  if (all_reads == 0) return;
+  if ((double)sv_reads / (double)all_reads >= 0.75) {
+    if (c.filter == SNF_F_MOSAIC_VAF) { c.filter = SNF_F_PASS; c.gt_b = 1; c.qc = 1; }
+  }
+}
+
+SNF_HD void e1_finalize_body(int64_t i, const View& v) {
+  if (i >= v.cnt->n_calls) return;
+  snf_call_t& cref = v.calls[i];
+  int task = cref.task_index;
+  if (v.t_status[task] != SNF_TASK_OK) return;
+  const snf_config_t& cfg = v.cfg;
+  snf_call_t c = cref;
+  const CallX x = v.callx[i];
+  c.qc = c.qc && qc_sv(v, c, x);
+  if (!cfg.mosaic && c.qc) c.qc = c.qc && qc_sv_support(c, v.t_cov_avg[task], cfg);
+  int hp_ret = -1, ps_ret = -1;
+  if (cfg.phase) phase_sv(v, c, x, task, &hp_ret, &ps_ret);
+  genotype_sv(v, c, hp_ret, ps_ret);
+  c.qc = c.qc && qc_sv_post_annotate(v, c, x, task);
+  bool phasing_rescue = c.svtype != SNF_BND && iabs64(c.svlen) <= cfg.dev_maxsvlen_extra &&
+                        c.support >= (int)((double)cfg.dev_minreads_extra * 0.60);
+  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing(v, c, x, task);
+  cref = c;
+}
+
+// ------------------------------------------------------------------------------------------ consensus
+// E2: best lead + sizes per INS call (postprocessing.py:33-66)
+SNF_HD int64_t cons_npos(int64_t L, int klen, int skip) { int64_t m = L - klen; return m <= 0 ? 0 : (m + skip - 1) / skip; }
+SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
+  return cfg.consensus_kmer_skip_base + (int)((double)L * cfg.consensus_kmer_skip_seqlen_mult);
+}
+
+SNF_HD void e2_best_body(int64_t i, const View& v) {
+  if (i == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; }
+  v.fN[i] = 0; v.fL[i] = 0;
+  if (i >= v.cnt->n_calls) return;
+  snf_call_t& c = v.calls[i];
+  CallX& x = v.callx[i];
+  x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1;
+  if (c.svtype != SNF_INS || v.cfg.symbolic || v.t_status[c.task_index] != SNF_TASK_OK) return;
+  int32_t best = -1, cnt = 0; double best_diff = 0;
+  for (int32_t k = 0; k < x.fn; k++) {
+    int32_t s = v.FI[x.flo + k];
+    if (v.F_seq_len[s] < 0) continue;
+    double d = (double)iabs64((int64_t)v.F_seq_len[s] - c.svlen) +
+               (double)iabs64((int64_t)v.in_ref_start[(uint32_t)v.F_orig[s]] - c.pos) * 1.5;
+    if (best < 0 || d < best_diff) { best = s; best_diff = d; }
+    cnt++;
+  }
+  if (best < 0) return;
+  x.best = best; x.n_others = cnt - 1;
+  x.do_cons = (x.n_others >= v.cfg.consensus_min_reads && !v.cfg.no_consensus) ? 1 : 0;
+  c.alt_len = v.F_seq_len[best];
+  v.fN[i] = (uint32_t)c.alt_len;
+  v.fL[i] = (uint32_t)x.do_cons;
+}
+
+// E3: consensus work list (pN = scan of alt lengths, pL = scan of do_cons)
+SNF_HD void e3_conslist_body(int64_t i, const View& v) {
+  if (i == 0) { v.cnt->alt_total = v.pN[v.N]; v.cnt->n_cons = v.pL[v.N]; }
+  if (i >= v.cnt->n_calls) return;
+  snf_call_t& c = v.calls[i];
+  CallX& x = v.callx[i];
+  if (c.alt_len >= 0) { c.alt_off = v.pN[i]; x.alt_off = v.pN[i]; }
+  if (x.do_cons) {
+    uint32_t cid = v.pL[i];
+    x.cons_id = (int32_t)cid;
+    v.cons_call[cid] = (int32_t)i;
+    int64_t L = c.alt_len;
+    int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
+    int64_t hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
+    v.cons_tab_off[cid] = hs;                       // sizes; scanned in place on the host side
+    v.cons_aln_off[cid] = (int64_t)x.n_others * L;
+    v.cons_read_off[cid] = x.n_others;
+  }
+}
+
+SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
+  uint64_t k = 0;
+  for (int i = 0; i < klen; i++) k = (k << 8) | s[i];
+  return k;
+}
+SNF_HD int64_t kmer_slot(uint64_t key, int64_t hs) { return (int64_t)((key * 0x9E3779B97F4A7C15ull) >> 17) & (hs - 1); }
+
+// E4: anchor table of the best read: k-mers seen exactly once among the sampled positions (consensus.py:289-299)
+SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
+  if (cid >= v.cnt->n_cons) return;
+  int32_t ci = v.cons_call[cid];
+  const CallX& x = v.callx[ci];
+  int64_t L = v.F_seq_len[x.best];
+  const uint8_t* B = v.pool + v.F_seq_off[x.best];
+  int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L);
+  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_off[cid + 1] - t0;
+  uint64_t* key = v.tab_key + t0; int32_t* pos = v.tab_pos + t0; uint8_t* st = v.tab_state + t0;
+  for (int64_t p = 0; p < hs; p++) st[p] = 0;
+  for (int64_t i = 0; i < L - klen; i += skip) {
+    uint64_t kk = kmer_key(B + i, klen);
+    int64_t p = kmer_slot(kk, hs);
+    while (st[p] && key[p] != kk) p = (p + 1) & (hs - 1);
+    if (st[p] == 0) { st[p] = 1; key[p] = kk; pos[p] = (int32_t)i; }
+    else st[p] = 2;
+  }
+  // (cid, read) work items
+  int64_t r0 = v.cons_read_off[cid];
+  for (int32_t r = 0; r < x.n_others; r++) { v.cr_call[r0 + r] = (int32_t)cid; v.cr_read[r0 + r] = r; }
+}
+
+// E5: align one other read against the best read's anchors -> aligned row (consensus.py:301-363)
+SNF_HD void e5_align_body(int64_t j, const View& v) {
+  if (j >= v.cnt->n_cons_reads) return;
+  int32_t cid = v.cr_call[j], ridx = v.cr_read[j];
+  int32_t ci = v.cons_call[cid];
+  const CallX& x = v.callx[ci];
+  // locate the ridx-th seq-bearing lead other than best, in cluster order
+  int32_t slot = -1, seen = 0;
+  for (int32_t k = 0; k < x.fn; k++) {
+    int32_t s = v.FI[x.flo + k];
+    if (v.F_seq_len[s] < 0 || s == x.best) continue;
+    if (seen == ridx) { slot = s; break; }
+    seen++;
+  }
+  int64_t L = v.F_seq_len[x.best];
+  const uint8_t* B = v.pool + v.F_seq_off[x.best];
+  const uint8_t* S = v.pool + v.F_seq_off[slot];
+  int64_t SL = v.F_seq_len[slot];
+  int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L), maxshift = klen;
+  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_off[cid + 1] - t0;
+  const uint64_t* key = v.tab_key + t0; const int32_t* pos = v.tab_pos + t0; const uint8_t* st = v.tab_state + t0;
+  uint8_t* row = v.aln + v.cons_aln_off[cid] + (int64_t)ridx * L;
+  bool have_last = false; int64_t last_i = 0, last_j = 0, clen = 0, span = 0;
+  for (int64_t jj = 0; jj < SL - klen; jj += skip) {
+    uint64_t kk = kmer_key(S + jj, klen);
+    int64_t p = kmer_slot(kk, hs);
+    while (st[p] && key[p] != kk) p = (p + 1) & (hs - 1);
+    if (st[p] != 1) continue;
+    int64_t i = pos[p];
+    if (iabs64(i - jj) > maxshift) continue;
+    if (have_last && i <= last_i) continue;
+    if (!have_last) {
+      if (jj > 0) { for (int64_t q = 0; q < i; q++) row[q] = '-'; clen = i; }
+    } else {
+      int64_t fwd_i = i - last_i, fwd_j = jj - last_j;
+      if (clen + fwd_j > L) fwd_j = L - clen;
+      if (fwd_i == fwd_j && fwd_j > 0) {
+        span += jj - last_j;
+        int64_t m = 0;
+        for (int64_t l = 1; l <= jj - last_j; l++) if (S[last_j + l] == B[last_i + l]) m++;
+        double ident = (double)m / (double)(jj - last_j);
+        if (ident >= 0.5) for (int64_t q = 0; q < fwd_j; q++) row[clen + q] = S[last_j + q];
+        else for (int64_t q = 0; q < fwd_j; q++) row[clen + q] = '-';
+        clen += fwd_j;
+      } else if (fwd_j > 0) { for (int64_t q = 0; q < fwd_j; q++) row[clen + q] = '-'; clen += fwd_j; }
+    }
+    have_last = true; last_i = i; last_j = jj;
+  }
+  for (int64_t q = clen; q < L; q++) row[q] = '-';
+  // keep a run only if it agrees with the best read: matches/len > 0.5 and matches > 5
+  for (int64_t hh = 0; hh < L;) {
+    if (row[hh] == '-') { hh++; continue; }
+    int64_t h0 = hh, ident = 0;
+    while (hh < L && row[hh] != '-') { ident += (B[hh] == row[hh]); hh++; }
+    int64_t bl = hh - h0;
+    if (!((double)ident / (double)bl > 0.5 && ident > 5)) for (int64_t q = h0; q < hh; q++) row[q] = '-';
+  }
+  v.aln_kept[j] = ((double)span / (double)L > 0.2) ? 1 : 0;
+}
+
+// E6: one output base per thread: column vote (consensus.py:365-380) or a verbatim copy of the best read
+SNF_HD void e6_vote_body(int64_t col, const View& v) {
+  if (col >= v.cnt->alt_total) return;
+  // call owning this column: last call index with pN[i] <= col (pN = alt offsets over all calls)
+  int64_t lo = 0, hi = v.cnt->n_calls;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((int64_t)v.pN[mid + 1] <= col) lo = mid + 1; else hi = mid; }
+  int64_t ci = lo;
+  const CallX& x = v.callx[ci];
+  int64_t i = col - (int64_t)v.pN[ci];
+  int64_t L = v.F_seq_len[x.best];
+  uint8_t b = v.pool[v.F_seq_off[x.best] + i];
+  uint8_t out = b;
+  if (x.do_cons) {
+    int32_t cid = x.cons_id;
+    int64_t r0 = v.cons_read_off[cid];
+    const uint8_t* rows = v.aln + v.cons_aln_off[cid];
+    int64_t nkept = 0, nvotes = 0;
+    for (int32_t r = 0; r < x.n_others; r++) if (v.aln_kept[r0 + r]) { nkept++; if (rows[(int64_t)r * L + i] != '-') nvotes++; }
+    double maxal = (double)(1 + nkept);
+    if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
+      // util.most_common([best]+votes): (count, char) descending; replace iff top beats runner-up by >= 3
+      int64_t c0 = -1, c1 = -1; int k0 = -1, k1 = -1, nd = 0;
+      for (int32_t r = -1; r < x.n_others; r++) {
+        uint8_t ch;
+        if (r < 0) ch = b;
+        else { if (!v.aln_kept[r0 + r]) continue; ch = rows[(int64_t)r * L + i]; if (ch == '-') continue; }
+        bool seen = (r >= 0 && ch == b);  // first occurrence test among [best]+votes
+        for (int32_t r2 = 0; r2 < r && !seen; r2++)
+          if (v.aln_kept[r0 + r2] && rows[(int64_t)r2 * L + i] == ch) seen = true;
+        if (seen) continue;
+        int64_t cntc = (ch == b) ? 1 : 0;
+        for (int32_t r2 = 0; r2 < x.n_others; r2++) if (v.aln_kept[r0 + r2] && rows[(int64_t)r2 * L + i] == ch) cntc++;
+        nd++;
+        if (cntc > c0 || (cntc == c0 && (int)ch > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = ch; }
+        else if (cntc > c1 || (cntc == c1 && (int)ch > k1)) { c1 = cntc; k1 = ch; }
+      }
+      if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+    }
+  }
+  v.alt_pool[col] = out;
+}
+
+}  // namespace snf

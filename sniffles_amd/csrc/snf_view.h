@@ -1,0 +1,135 @@
+// snf_view.h - the HBM-resident state of one batch, passed by value to every kernel.
+//
+// Layout: everything is struct-of-arrays, concatenated over the tasks of the
+// batch.  "lead" = one SV signature (reference Lead, leadprov.py:34-56).
+//   N   leads (input order = arrival/BAM order inside each task)
+//   R   alignment records (coverage + REF haplotype counts)
+//   NF  leads that survive into seed clusters (normal, svlen != None)   <= N
+//   NLL INS leads with svlen None that belong to a seed bin ("leads_long") <= N
+#pragma once
+#include "../../include/sniffles_amd.h"
+#include "snf_rt.h"
+
+namespace snf {
+
+// device-side counters written by the pipeline (read back once per fetch)
+struct Counts {
+  int64_t n_valid, n_bins, n_seeds, NF, NLL, n_runs, n_clusters, n_rc, n_calls;
+  int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
+  int64_t n_dirty_groups;
+  unsigned long long pool_extra_used;
+  int32_t overflow;  // scratch overflow flags
+  int32_t _pad;
+};
+
+// genotype lookup entry for (normalised support, normalised coverage), built on the host with the
+// same libm CPython uses (genotyping.py:124-183)
+struct GtEntry {
+  int8_t order0;  // index (0: 0/0, 1: 0/1, 2: 1/1) of the most likely genotype
+  int8_t gq;
+  int8_t z;
+  int8_t _pad;
+};
+#define SNF_GT_N 251
+
+struct CallX {  // per-call internals that are not part of snf_call_t
+  int32_t rc;       // refined cluster id
+  int32_t cluster;  // merged cluster id
+  int32_t flo, fn;  // range of the refined cluster in the F arrays
+  int32_t best;     // F position of the consensus best lead, -1 none
+  int32_t n_others;
+  int32_t do_cons;
+  int32_t cons_id;
+  int64_t alt_off;
+};
+
+struct View {
+  snf_config_t cfg;
+  int32_t T;          // tasks
+  int32_t run_gap;    // merge-scan run cut (bp); <0: whole group serial
+  int64_t N, R, NTR;
+  int64_t pool_len, pool_cap;
+  Counts* cnt;
+
+  // ---- tasks [T] / [T+1]
+  const int32_t* t_task_id; const int32_t* t_sv_id_start; const int32_t* t_contig_len; const int32_t* t_ps_null;
+  const double* t_qc_nm_thr;
+  const int64_t* t_lead_off; const int64_t* t_read_off; const int64_t* t_tr_off;
+  const int32_t* t_has_tr;
+  int32_t* t_status; int64_t* t_call_off; double* t_cov_avg; int32_t* t_stale_end;
+  unsigned long long* t_cov_sum;
+
+  // ---- input leads [N]
+  const int32_t *in_ref_start, *in_ref_end, *in_qry_start, *in_qry_end, *in_svlen, *in_read_len;
+  const uint32_t *in_qname, *in_read_id;
+  const int32_t *in_ps, *in_mate_contig, *in_mate_pos, *in_seq_len;
+  const int64_t* in_seq_off;  // rebased into the batch pool
+  const double* in_nm;
+  const uint8_t *in_svtype, *in_strand, *in_mapq, *in_source, *in_hap, *in_is_sa, *in_first, *in_rev;
+  const int32_t* lead_task;
+  uint8_t* pool;  // [pool_cap]: input sequences, then fused sequences (merge_inner)
+
+  // ---- reads [R] (starts sorted per task on input; ends sorted on device)
+  const int32_t* r_start; const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task;
+  uint64_t *rk_in, *rk_out; uint32_t *rv_in, *rv_out;  // end-sort scratch
+  int32_t* re_sorted;        // [R] ends, ascending per task
+  uint32_t* pc_s[3];         // [R+1] prefix count of reads with hp==h in start order
+  uint32_t* pc_e[3];         // [R+1] same in end order
+  uint32_t* rflag;           // [R+1] scan scratch
+
+  // ---- tandem repeats [NTR]
+  const int32_t* tr_start; const int32_t* tr_end; const int32_t* tr_pmax;
+
+  // ---- stage A: binning (sorted position p in [0,N))
+  uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;
+  uint32_t *headflag, *headscan;  // [N+1] bin heads in sorted order / exclusive scan (bin ids)
+  uint32_t *eligflag, *eligscan;  // [N+1] per bin: seeds a cluster / exclusive scan (seed ids)
+  uint32_t *fN, *pN;              // [N+1] per sorted lead: goes to a seed's `leads` / scatter position
+  uint32_t *fL, *pL;              // [N+1] per sorted lead: goes to a seed's `leads_long` / scatter position
+  uint32_t *runflag, *runscan;    // [N+1] per seed: starts a merge-scan run / run ids
+  uint32_t *clflag, *clscan;      // [N+1] per seed: head of a merged cluster / cluster ids
+  uint32_t *rcflag, *rcscan;      // [N+1] per F slot: refined cluster starts here / rc ids
+  uint32_t *cdflag, *cdscan;      // [N+1] per rc: produced a candidate call / call ids
+  uint8_t* seqnull;          // [N] record_lead dropped the sequence (leadprov.py:406-408)
+  int32_t* bin_lo;           // [N+1]
+  uint64_t* bin_key;         // [N]
+  uint16_t* bin_hap;         // [3N]
+  uint8_t* bin_elig;         // [N]
+  int32_t* grp_first_bin;    // [8T]
+  uint32_t* L;               // [N] seed-cluster leads, (task, svtype, bin, arrival) order -> input index
+  uint32_t* LL;              // [N] leads_long, same order
+
+  // ---- stage B/C: seeds [n_seeds <= N]
+  int32_t *seed_bin, *seed_lo, *seed_hi, *seedL_lo, *seedL_hi, *seed_start, *seed_grp;
+  double *s_mean0, *s_stdev0; uint8_t* s_repeat0;     // seed metrics (kept for the serial fallback)
+  double *c_mean, *c_stdev; uint8_t* c_repeat;        // live cluster metrics at head seeds
+  int32_t *c_last, *c_end, *nxt, *prv;
+  int32_t *run_first;        // [N+1]
+  int32_t *run_last_head;    // [N]
+  double *run_b_stdev, *run_b_absmean; uint8_t* run_b_repeat;
+  int32_t* grp_dirty;        // [8T]
+  int32_t *grp_seed_lo, *grp_seed_hi;  // [8T]
+
+  // ---- stage D: merged clusters / refined clusters / F leads
+  int32_t* cl_head;          // [N] head seed of merged cluster c
+  int32_t *w0, *w1, *w2, *w3, *w4, *w5, *w6; // per-cluster scratch over the L index space
+  // F: leads after merge_inner (fused), slot space = L index space; FI: final per-refined-cluster order -> F slot
+  int32_t *F_orig, *F_svlen, *F_seq_len; int64_t* F_seq_off; uint8_t* F_sel; int32_t* FI;
+  int32_t *rc_n_s, *rc_cl_s; uint8_t* rc_keeplong_s;   // slot space (sparse): slot = F position of the rc's first lead
+  int32_t *rc_lo, *rc_n, *rc_cluster; uint8_t* rc_keeplong;              // dense
+  snf_call_t* cand; CallX* candx;                                         // per rc
+  snf_call_t* calls; CallX* callx;                                        // compacted
+  uint32_t* rnames;          // [2N]
+
+  // ---- stage E: finalize
+  const GtEntry* gt_lut;     // [251*251]
+  int32_t* cons_call;        // [n_cons] call index
+  int64_t *cons_tab_off, *cons_aln_off, *cons_read_off;  // [n_cons+1]
+  uint64_t* tab_key; int32_t* tab_pos; uint8_t* tab_state; int64_t tab_cap;   // anchor hash tables
+  uint8_t* aln; int64_t aln_cap;         // aligned reads, n_others x L per consensus call
+  uint8_t* aln_kept;         // [n_cons_reads]
+  int32_t *cr_call, *cr_read;  // [n_cons_reads] (consensus id, other index)
+  uint8_t* alt_pool; int64_t alt_cap;
+};
+
+}  // namespace snf

@@ -1,0 +1,146 @@
+"""ctypes binding of libsniffles_amd.so (include/sniffles_amd.h) - the only compute path.
+
+There is no CPU fallback: if the library is not built, or no HIP device is present,
+every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libsniffles_amd.so")
+_lib = None
+
+
+class SnifflesAmdError(RuntimeError):
+    pass
+
+
+def bind(lib: C.CDLL) -> C.CDLL:
+    """Declare the prototypes of include/sniffles_amd.h on a loaded library."""
+    vp = C.c_void_p
+    lib.snf_abi_version.restype = C.c_int
+    lib.snf_last_error.restype = C.c_char_p
+    lib.snf_device_count.restype = C.c_int
+    lib.snf_batch_create.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(vp)]
+    lib.snf_batch_add_task.argtypes = [vp, C.POINTER(abi.snf_task_input_t)]
+    lib.snf_batch_upload.argtypes = [vp]
+    lib.snf_batch_destroy.argtypes = [vp]
+    lib.snf_batch_destroy.restype = None
+    lib.snf_batch_call_candidates.argtypes = [vp]
+    lib.snf_batch_finalize.argtypes = [vp]
+    lib.snf_batch_fetch.argtypes = [vp, C.c_int, C.POINTER(abi.snf_result_t)]
+    lib.snf_batch_sync.argtypes = [vp]
+    lib.snf_batch_timing_count.argtypes = [vp]
+    lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
+                                            C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
+    for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
+              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_timing_count",
+              "snf_batch_timing_get", "snf_edit_distance_batch"):
+        getattr(lib, f).restype = C.c_int
+    if lib.snf_abi_version() != abi.ABI_VERSION:
+        raise SnifflesAmdError("libsniffles_amd.so ABI version mismatch - rebuild (python -m sniffles_amd.build)")
+    return lib
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise SnifflesAmdError(f"{SO} is missing: build it with `python -m sniffles_amd.build` "
+                                   "(the hot path has no CPU fallback)")
+        _lib = bind(C.CDLL(SO))
+    return _lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise SnifflesAmdError(lib.snf_last_error().decode("utf-8", "replace"))
+
+
+class Batch:
+    """A set of contig tasks resident in HBM.  `tasks`: list of sniffles_amd.soa.TaskInput."""
+
+    def __init__(self, cfg, tasks, device: int = 0, _lib=None):
+        self.lib = _lib or load()
+        self.tasks = list(tasks)
+        self._h = C.c_void_p()
+        cs = abi.config_struct(cfg)
+        _check(self.lib, self.lib.snf_batch_create(C.byref(cs), device, C.byref(self._h)))
+        try:
+            for ti in self.tasks:
+                keep = []
+                ts = abi.task_struct(ti, keep)
+                _check(self.lib, self.lib.snf_batch_add_task(self._h, C.byref(ts)))
+            _check(self.lib, self.lib.snf_batch_upload(self._h))
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        if self._h:
+            self.lib.snf_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def call_candidates(self):
+        _check(self.lib, self.lib.snf_batch_call_candidates(self._h))
+
+    def finalize(self):
+        _check(self.lib, self.lib.snf_batch_finalize(self._h))
+
+    def sync(self):
+        _check(self.lib, self.lib.snf_batch_sync(self._h))
+
+    def fetch(self, stage: int) -> abi.Result:
+        r = abi.snf_result_t()
+        _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
+        return abi.Result(r)
+
+    def timings(self) -> list:
+        out = []
+        for i in range(self.lib.snf_batch_timing_count(self._h)):
+            name, ms, nb = C.c_char_p(), C.c_float(), C.c_int64()
+            _check(self.lib, self.lib.snf_batch_timing_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb)))
+            out.append((name.value.decode(), float(ms.value), int(nb.value)))
+        return out
+
+
+def device_count() -> int:
+    return int(load().snf_device_count())
+
+
+def edit_distance_batch(pairs, device: int = 0, _lib=None) -> np.ndarray:
+    """Global unit-cost edit distance for a list of (bytes, bytes) pairs (edlib.align(a,b)['editDistance'])."""
+    lib = _lib or load()
+    n = len(pairs)
+    a_off = np.zeros(n + 1, np.int64)
+    b_off = np.zeros(n + 1, np.int64)
+    for i, (a, b) in enumerate(pairs):
+        a_off[i + 1] = a_off[i] + len(a)
+        b_off[i + 1] = b_off[i] + len(b)
+    a_pool = np.frombuffer(b"".join(p[0] for p in pairs) or b"\0", np.uint8)
+    b_pool = np.frombuffer(b"".join(p[1] for p in pairs) or b"\0", np.uint8)
+    out = np.zeros(max(n, 1), np.int32)
+    u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
+    _check(lib, lib.snf_edit_distance_batch(device, a_pool.ctypes.data_as(u8p), a_off.ctypes.data_as(i64p),
+                                            b_pool.ctypes.data_as(u8p), b_off.ctypes.data_as(i64p), n,
+                                            out.ctypes.data_as(C.POINTER(C.c_int32))))
+    return out[:n]

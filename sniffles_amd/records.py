@@ -1,6 +1,6 @@
 """Canonical per-call records from a fetched result (host-side string formatting).
 
-The same dict layout is produced by `oracle/ref_harness.call_record` from the
+The same dict layout is produced by the test harness (under oracle/) from the
 reference's own `SVCall` objects, so parity tests compare like with like.
 """
 from __future__ import annotations
