@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native Sniffles2 hot path (BASELINE.json metric).
+
+One "step" = one full pass of the hot path (Task.call_candidates + Task.finalize_candidates of every
+contig task of the workload: binning, clustering, candidate calls, coverage, QC, genotyping, phasing,
+INS consensus) with the signature tables already resident in HBM, INCLUDING the device->host copy of
+the call records / ALT pool and, for N > 1, the RCCL all-gather of the per-rank call records.
+
+Workload at N = 1: BASELINE.json configs[1], "30x ONT HG002 whole-genome germline" restated as a seeded
+synthetic signature set (24 GRCh38 contigs).  N > 1: weak scaling - N genome replicas
+(seed 1..N), the 24*N contig tasks sharded longest-first over the ranks (contigs are independent,
+SURVEY.md 8e); the only collective is the final gather.
+
+Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+CPU_SAMPLE_CONTIGS = ["chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr22"]
+
+
+def shard_tasks(n_ranks: int):
+    """(replica, contig) tasks, longest-processing-time-first over ranks.  Deterministic, no communication."""
+    from sniffles_amd import synth
+    items = [(synth.GRCH38[c], rep, ci, c) for rep in range(n_ranks) for ci, c in enumerate(synth.CONTIGS)]
+    items.sort(key=lambda x: (-x[0], x[1], x[2]))
+    load = [0] * n_ranks
+    out = [[] for _ in range(n_ranks)]
+    for ln, rep, ci, c in items:
+        r = min(range(n_ranks), key=lambda k: (load[k], k))
+        load[r] += ln
+        out[r].append((rep, ci, c))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink every contig (debug only; invalid as a result)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from sniffles_amd import abi, lib, synth
+    from sniffles_amd.config import SnifflesConfig
+
+    cfg = SnifflesConfig()  # germline defaults (config.py)
+    my = shard_tasks(world)[rank]
+    t0 = time.time()
+    tasks = []
+    for k, (rep, ci, c) in enumerate(my):
+        L = max(200000, int(synth.GRCH38[c] * args.scale))
+        ti = synth.gen_task(rep * 24 + ci, c, L, args.coverage, seed=1 + rep)
+        tasks.append(ti)
+    n_sig = sum(t.n_leads for t in tasks)
+    n_reads = sum(t.n_reads for t in tasks)
+    seq_bytes = sum(int(t.seq_pool.nbytes) for t in tasks)
+    t_gen = time.time() - t0
+
+    t0 = time.time()
+    batch = lib.Batch(cfg, tasks, device=local_rank)
+    t_upload = time.time() - t0
+
+    cap_calls = max(1024, n_sig // 8)
+    rec_bytes = abi.CALL_DTYPE.itemsize
+    send = torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
+    count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
+    if world > 1:
+        gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
+        counts = torch.zeros(world, dtype=torch.int64, device="cuda")
+
+    def step():
+        batch.call_candidates()
+        batch.finalize()
+        n = batch.fetch_raw(1)  # D2H of records + ALT pool + read names (blocks)
+        if world > 1:
+            nexp = batch.export_calls_device(send.data_ptr(), cap_calls)
+            batch.sync()
+            count_t.fill_(nexp)
+            dist.all_gather_into_tensor(counts, count_t)
+            dist.all_gather_into_tensor(gathered, send)
+        return n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_calls = 0
+    for _ in range(args.warmup):
+        n_calls = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_calls = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timings = batch.timings()  # per-kernel HIP-event times of the LAST step, on the batch stream
+
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    dt_max = float(tt.item())
+    total_sig, total_calls = int(tot[0].item()), int(tot[1].item())
+
+    if rank == 0:
+        ms_per_step = dt_max / args.steps * 1e3
+        value = total_sig * args.steps / dt_max
+        # dominant kernel of the last step, measured with HIP events around each launch
+        kern = sorted(timings, key=lambda x: -x[1])
+        top = kern[0] if kern else ("none", 0.0, 0)
+        gpu_ms = sum(k[1] for k in kern)
+        achieved = (top[2] / (top[1] * 1e-3)) / 1e9 if top[1] > 0 else 0.0
+        roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                        kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
+                        gpu_ms_all_kernels=round(gpu_ms, 3),
+                        top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2])) for k in kern[:8]])
+        out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
+                   value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32/f64",
+                   data="synthetic",
+                   config=dict(workload="30x ONT HG002-shaped whole-genome germline, 24 GRCh38 contigs per replica "
+                                        "(BASELINE.json configs[1]), synthetic signature tables (SURVEY.md 8d)",
+                               replicas=world, tasks=24 * world, coverage=args.coverage, scale=args.scale,
+                               signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
+                               calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL all_gather of call records",
+                               gen_s=round(t_gen, 2), upload_s=round(t_upload, 2)),
+                   roofline=roofline)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args)
+        print(json.dumps(out))
+    batch.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, args):
+    """Oracle (scalar C restatement of the reference, oracle/snf_oracle.c) timed on this box's host cores on a
+    bounded sample of the same workload.  A reported baseline, not the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle
+    from sniffles_amd import synth
+    oracle.build()
+    tis = [synth.gen_task(synth.CONTIGS.index(c), c, max(200000, int(synth.GRCH38[c] * args.scale)), args.coverage, seed=1)
+           for c in CPU_SAMPLE_CONTIGS]
+    n = sum(t.n_leads for t in tis)
+    t0 = time.perf_counter()
+    oracle.run(cfg, tis, True)
+    wall = time.perf_counter() - t0
+    hot = oracle.hot_seconds()
+    return dict(value=n / hot, unit="signatures/s", cores=1, kind="port",
+                sample=f"{'+'.join(CPU_SAMPLE_CONTIGS)} of replica 0 ({n} signatures), call_candidates+finalize only: "
+                       f"{hot:.2f}s (wall incl. dense coverage build {wall:.2f}s); host cores available: {os.cpu_count()}")
+
+
+if __name__ == "__main__":
+    main()

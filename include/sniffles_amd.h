@@ -312,6 +312,12 @@ int snf_batch_finalize(snf_batch_t* b);
  * call on the batch or snf_batch_destroy. */
 int snf_batch_fetch(snf_batch_t* b, int stage, snf_result_t* out);
 
+/* final gather across GPUs: copies the call records (stage-1 order, ERR tasks included,
+ * see snf_result_t.task_status) device-to-device into `dst_device` (e.g. a torch CUDA tensor handed to
+ * RCCL), at most cap_calls records; *n_calls receives the record count.  Asynchronous on the batch
+ * stream; call snf_batch_sync before handing dst to another stream. */
+int snf_batch_export_calls_device(snf_batch_t* b, void* dst_device, int64_t cap_calls, int64_t* n_calls);
+
 /* per-kernel timing (HIP events on the batch stream, recorded around every launch of the
  * last call_candidates+finalize pass). names[i] points to a static string. */
 int snf_batch_timing_count(snf_batch_t* b);

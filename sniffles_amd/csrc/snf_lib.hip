@@ -728,6 +728,23 @@ int snf_batch_fetch(snf_batch_t* bb, int stage, snf_result_t* out) {
   })
 }
 
+int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap_calls, int64_t* n_calls) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !dst_device || !n_calls) fail("batch not uploaded / null argument");
+    d2h(b, &b->h_cnt, b->v.cnt, sizeof(Counts));
+    dsync(b);
+    int64_t nc = b->v.N > 0 ? b->h_cnt.n_calls : 0;
+    if (nc > cap_calls) fail("export buffer too small");
+    *n_calls = nc;
+#ifndef SNF_EMU
+    if (nc) SNF_HIP(hipMemcpyAsync(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t), hipMemcpyDeviceToDevice, b->stream));
+#else
+    if (nc) memcpy(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t));
+#endif
+  })
+}
+
 int snf_batch_sync(snf_batch_t* bb) {
   SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); dsync(b); collect_timings(b); })
 }

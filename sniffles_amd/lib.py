@@ -36,12 +36,14 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_finalize.argtypes = [vp]
     lib.snf_batch_fetch.argtypes = [vp, C.c_int, C.POINTER(abi.snf_result_t)]
     lib.snf_batch_sync.argtypes = [vp]
+    lib.snf_batch_export_calls_device.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.snf_batch_timing_count.argtypes = [vp]
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
                                             C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
-              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_timing_count",
+              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
+              "snf_batch_timing_count",
               "snf_batch_timing_get", "snf_edit_distance_batch"):
         getattr(lib, f).restype = C.c_int
     if lib.snf_abi_version() != abi.ABI_VERSION:
@@ -113,6 +115,18 @@ class Batch:
         r = abi.snf_result_t()
         _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
         return abi.Result(r)
+
+    def fetch_raw(self, stage: int) -> int:
+        """D2H of the results into library-owned host memory without materialising numpy copies; returns n_calls."""
+        r = abi.snf_result_t()
+        _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
+        return int(r.n_calls)
+
+    def export_calls_device(self, dst_ptr: int, cap_calls: int) -> int:
+        """Device-to-device copy of the call records into caller-owned HBM (for the RCCL gather)."""
+        n = C.c_int64()
+        _check(self.lib, self.lib.snf_batch_export_calls_device(self._h, C.c_void_p(dst_ptr), cap_calls, C.byref(n)))
+        return int(n.value)
 
     def timings(self) -> list:
         out = []

@@ -1,0 +1,134 @@
+"""Parity tests proper: the gfx950 library (through the C-ABI) against the reference goldens, the
+oracle on seeded inputs, and size-independent properties at larger sizes.  Run with -m gpu."""
+import numpy as np
+import pytest
+
+import cases
+import golden_util as gu
+from sniffles_amd import lib, records, synth
+from sniffles_amd.config import SnifflesConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def run(cfg, tis, fin=True):
+    with lib.Batch(cfg, tis) as b:
+        b.call_candidates()
+        if fin:
+            b.finalize()
+        return b.fetch(1 if fin else 0)
+
+
+def test_native_library_loaded_and_device_present():
+    assert lib.device_count() >= 1
+    assert lib.load().snf_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", sorted(cases.ALL))
+def test_hip_matches_reference_golden(name):
+    """Bit-exact on every integer field, float statistics and the INS consensus sequence (edit-distance
+    tolerance 0) against the unmodified reference's outputs."""
+    build, kw, _ = cases.ALL[name]
+    doc = gu.load(name)
+    ti = build()
+    assert gu.input_sha(ti) == doc["input_sha"]
+    cfg = gu.make_config(kw, ti)
+    exp = doc["expected"]
+    for stage, key, fin in (("cand", "candidates", False), ("final", "final", True)):
+        res = run(cfg, [ti], fin)
+        got = records.records(res, [ti], stage)[0]
+        if "error" in exp:
+            assert got == {"error": exp["error"]}
+            continue
+        assert gu.diff_records(got, exp[key]) == []
+        assert float(res.coverage_average_total[0]) == exp["coverage_average_total"]
+
+
+KW = [{}, dict(mosaic=True), dict(minsupport="auto", qc_nm=True), dict(no_qc=True),
+      dict(qc_strand=True, minsvlen="50", cluster_merge_pos=50), dict(repeat=True, mosaic=True, mosaic_include_germline=True)]
+
+
+@pytest.mark.parametrize("ci", range(len(KW)))
+def test_hip_matches_oracle_on_fuzz_batches(ci, oracle_mod):
+    cfg = SnifflesConfig(**KW[ci])
+    for seed in range(0, 60, 4):
+        tis = [synth.gen_fuzz(seed + k, task_id=k) for k in range(4)]
+        exp = oracle_mod.run(cfg, tis, True)
+        got = run(cfg, tis, True)
+        assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+        assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
+
+
+@pytest.mark.parametrize("gap", ["0", "150", "-1"])
+def test_hip_run_cuts_exact(gap, oracle_mod, monkeypatch):
+    monkeypatch.setenv("SNF_RUN_GAP", gap)
+    cfg = SnifflesConfig(repeat=True)
+    tis = [synth.gen_fuzz(500 + k, task_id=k) for k in range(6)]
+    assert records.records(run(cfg, tis), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+
+
+def genome(scale, cov=30, seed=1, **kw):
+    return synth.gen_genome(coverage=cov, seed=seed, scale=scale, **kw)
+
+
+def test_hip_matches_oracle_on_scaled_genome(oracle_mod):
+    """24 contigs at 1 % of GRCh38 lengths, 30x ONT-like: every call of every contig identical."""
+    tis = genome(0.01)
+    cfg = SnifflesConfig()
+    exp = oracle_mod.run(cfg, tis, True)
+    got = run(cfg, tis, True)
+    assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+
+
+def test_hip_matches_oracle_hifi_60x_and_mosaic(oracle_mod):
+    tis = genome(0.004, cov=60, seed=2, err=0.005)
+    cfg = SnifflesConfig()
+    assert records.records(run(cfg, tis), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    tis = genome(0.004, cov=30, seed=3, mosaic_frac=0.05)
+    cfg = SnifflesConfig(mosaic=True)
+    assert records.records(run(cfg, tis), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+
+
+def test_full_size_properties():
+    """At chr20 full size (BASELINE configs[0] shape): tasks are independent, so (a) a batch equals the
+    concatenation of single-task runs, (b) repeating a pass is idempotent, (c) calls are in candidate
+    order (svtype-major, sv_id consecutive), (d) every INS ALT has the length of a supporting read."""
+    t20 = synth.gen_task(19, "chr20", synth.GRCH38["chr20"], 30, 1)
+    t21 = synth.gen_task(20, "chr21", synth.GRCH38["chr21"] // 4, 30, 1)
+    cfg = SnifflesConfig()
+    both = run(cfg, [t20, t21])
+    single = [run(cfg, [t20]), run(cfg, [t21])]
+    rb = records.records(both, [t20, t21], "final")
+    assert rb[0] == records.records(single[0], [t20], "final")[0]
+    assert rb[1] == records.records(single[1], [t21], "final")[0]
+    with lib.Batch(cfg, [t20, t21]) as b:
+        b.call_candidates(); b.finalize(); r1 = b.fetch(1)
+        b.call_candidates(); b.finalize(); r2 = b.fetch(1)
+    assert r1.calls.tobytes() == r2.calls.tobytes() and r1.alt_pool.tobytes() == r2.alt_pool.tobytes()
+    c = both.calls
+    for t in range(2):
+        lo, hi = int(both.task_call_off[t]), int(both.task_call_off[t + 1])
+        assert np.all(np.diff(c["svtype"][lo:hi]) >= 0)
+        assert np.array_equal(c["sv_id"][lo:hi], np.arange(hi - lo))
+    ins = (c["svtype"] == 0) & (c["alt_len"] >= 0)
+    assert ins.sum() > 100 and np.all(c["alt_len"][ins] >= 45)
+    assert (c["filter"] == 0).sum() > 400  # ~561 planted sites on chr20
+
+
+def test_edit_distance_batch_matches_oracle(oracle_mod):
+    rng = np.random.default_rng(4)
+    pairs = [(b"", b""), (b"kitten", b"sitting"), (b"<DEL>", b"<DEL>"), (b"ACGT", b"")]
+    for _ in range(200):
+        n = int(rng.integers(1, 400))
+        a = bytes(rng.choice(list(b"ACGT"), n))
+        b = bytearray(a)
+        for _ in range(int(rng.integers(0, 30))):
+            p = int(rng.integers(0, max(1, len(b))))
+            op = rng.integers(0, 3)
+            if op == 0 and b: b[p % len(b)] = int(rng.choice(list(b"ACGT")))
+            elif op == 1: b.insert(p, int(rng.choice(list(b"ACGT"))))
+            elif b: del b[p % len(b)]
+        pairs.append((a, bytes(b)))
+    got = lib.edit_distance_batch(pairs)
+    exp = [oracle_mod.edit_distance(a, b) for a, b in pairs]
+    assert got.tolist() == exp
