@@ -121,7 +121,8 @@ T* dalloc(snf_batch_impl* b, size_t n) {
 #ifndef SNF_EMU
   SNF_HIP(hipMalloc(&p, bytes));
 #else
-  p = calloc(1, bytes);
+  p = malloc(bytes);
+  memset(p, 0xA5, bytes);  // hipMalloc does not zero: poison so the emulation catches uninitialised reads
 #endif
   b->bufs.push_back({p, bytes});
   return (T*)p;

@@ -137,7 +137,7 @@ SNF_HD bool seed_first_of_group(const View& v, int64_t s) { return s == 0 || v.s
 
 SNF_HD void b1_seedmetrics_body(int64_t s, const View& v) {
   if (s == 0) v.runflag[v.N] = 0;
-  if (s >= v.cnt->n_seeds) { v.runflag[s] = 0; return; }
+  if (s >= v.cnt->n_seeds) { v.runflag[s] = 0; v.clflag[s] = 0; return; }
   double mean, sd;
   compute_metrics(v, v.seed_lo[s], v.seed_hi[s], &mean, &sd);
   int g = v.seed_grp[s], t = grp_task(g);
