@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
 // (-ffp-contract=off: the reference's double arithmetic has no fused multiply-add).
 #include "snf_stage_final.h"
+#include "snf_wave_refine.h"
 
 #ifndef SNF_EMU
 #include <rocprim/device/device_radix_sort.hpp>
@@ -308,6 +309,11 @@ void do_upload(snf_batch_impl* b) {
   if (T >= (1 << 16)) fail("too many tasks in one batch (max 65535)");
   if (N >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) fail("batch too large for 32-bit lead/read indices");
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
+#ifndef SNF_EMU
+  v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
+#else
+  v.wave_path = 0;
+#endif
   v.pool_len = (int64_t)b->h_pool.size(); v.pool_cap = 2 * v.pool_len + 16;
   v.cnt = dalloc<Counts>(b, 1);
   std::vector<int32_t> tid(T), svs(T), clen(T), psn(T); std::vector<double> nmt(T);
@@ -430,7 +436,14 @@ void run_call_candidates(snf_batch_impl* b) {
     prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
     LAUNCH(c4_clusters, v, N, N * 4);
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
-    LAUNCH(d1_refine, v, N, N * 36);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "d1w_refine", N * 36);
+      hipLaunchKernelGGL(d1w_refine, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
+    LAUNCH(d1_refine, v, N, v.wave_path ? 0 : N * 36);
     prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
     LAUNCH(d1b_rctable, v, N, N * 4);
     LAUNCH(d2_call, v, N, N * 32);

@@ -68,6 +68,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   int32_t lo = v.seed_lo[h], hi = v.seed_hi[v.c_last[h]];
   int32_t n = hi - lo;
   if (n <= 0) return;
+  if (v.wave_path && n <= 64) return;  // handled by d1w_refine (snf_wave_refine.h)
   int svtype = grp_svtype(v.seed_grp[h]);
   int32_t *a0 = v.w0 + lo, *a1 = v.w1 + lo, *a2 = v.w2 + lo, *a3 = v.w3 + lo, *a4 = v.w4 + lo, *a5 = v.w5 + lo,
           *a6 = v.w6 + lo;

@@ -47,6 +47,8 @@ struct View {
   snf_config_t cfg;
   int32_t T;          // tasks
   int32_t run_gap;    // merge-scan run cut (bp); <0: whole group serial
+  int32_t wave_path;  // 1: gfx950 wave-cooperative kernels own the small clusters (thread kernels skip them)
+  int32_t _padv;
   int64_t N, R, NTR;
   int64_t pool_len, pool_cap;
   Counts* cnt;

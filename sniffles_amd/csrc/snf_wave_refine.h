@@ -1,0 +1,276 @@
+// snf_wave_refine.h - gfx950 wave-per-cluster implementation of the refinement stage (merge_inner,
+// resplit, resplit_bnd; cluster.py:85-216) for clusters of at most 64 leads (one lead per lane).
+//
+// Everything stays in registers: sorts are rank sorts over packed 64-bit keys (n broadcasts of one
+// lane's key via v_readlane), the same-read fusion is a segmented scan over the sorted order, and the
+// sequential resplit bin-merge state machine (k <= a handful of bins) runs on lane 0 in LDS.  Clusters
+// with more than 64 leads take the thread-per-cluster path (d1_refine_body), which is also what the
+// host emulation executes; both write the same F / FI / refined-cluster tables.
+#pragma once
+#include "snf_stage_call.h"
+
+#ifndef SNF_EMU
+namespace snf {
+
+#define SNF_WAVE 64
+
+SNF_D uint64_t wave_bcast_u64(uint64_t x, int src) {
+  uint32_t lo = __builtin_amdgcn_readlane((uint32_t)x, src), hi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+SNF_D int32_t wave_bcast_i32(int32_t x, int src) { return (int32_t)__builtin_amdgcn_readlane((uint32_t)x, src); }
+
+// inclusive prefix sum across the wave
+SNF_D int32_t wave_incl_scan(int32_t x, int lane) {
+#pragma unroll
+  for (int d = 1; d < SNF_WAVE; d <<= 1) {
+    int32_t y = __shfl_up(x, d, SNF_WAVE);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+SNF_D int64_t wave_incl_scan64(int64_t x, int lane) {
+#pragma unroll
+  for (int d = 1; d < SNF_WAVE; d <<= 1) {
+    int64_t y = __shfl_up(x, d, SNF_WAVE);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+// rank of `key` among the first n lanes' keys (keys are distinct: the lane index is part of the key)
+SNF_D int wave_rank(uint64_t key, int n) {
+  int r = 0;
+  for (int i = 0; i < n; i++) r += (wave_bcast_u64(key, i) < key) ? 1 : 0;
+  return r;
+}
+
+struct WaveLds {
+  int32_t perm[SNF_WAVE];      // scatter target for permutations
+  int32_t seg_start[SNF_WAVE]; // resplit: segment (distinct bin) start position in sorted order
+  int32_t seg_key[SNF_WAVE];
+  int32_t nc[SNF_WAVE];        // surviving bins
+  int32_t head[SNF_WAVE], tail[SNF_WAVE], nxt[SNF_WAVE];
+  int32_t seg_out[SNF_WAVE];   // output start of each segment
+  int32_t rc_start[SNF_WAVE], rc_len[SNF_WAVE];
+  int32_t n_rc;
+};
+
+// sorted-order gather: lane r receives the value held by the lane whose rank is r
+#define SNF_PERMUTE_SETUP(rank_, active_)         \
+  __syncthreads();                                \
+  if (active_) lds.perm[rank_] = lane;            \
+  __syncthreads();                                \
+  const int src_ = lds.perm[lane < n_ ? lane : 0];
+#define SNF_GATHER(x) __shfl((x), src_, SNF_WAVE)
+
+// one block = one wave = one merged cluster per loop iteration (grid-stride over clusters)
+__global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_unused) {
+  __shared__ WaveLds lds;
+  const int lane = threadIdx.x;
+  const snf_config_t& cfg = v.cfg;
+  const int64_t n_clusters = v.cnt->n_clusters;
+  for (int64_t c = blockIdx.x; c < n_clusters; c += gridDim.x) {
+    const int32_t h = v.cl_head[c];
+    const int32_t lo = v.seed_lo[h], hi = v.seed_hi[v.c_last[h]];
+    const int32_t n = hi - lo;
+    if (n <= 0 || n > SNF_WAVE) continue;  // big clusters: thread path (d1_refine with the n > 64 guard)
+    const int svtype = grp_svtype(v.seed_grp[h]);
+    const bool act = lane < n;
+    // ---- load one lead per lane
+    uint32_t o = act ? v.L[lo + lane] : 0;
+    int32_t ref_start = 0, ref_end = 0, qry_start = 0, qry_end = 0, svlen = 0, seq_len = -1, mate_pos = 0, mate_contig = 0;
+    uint32_t qname = 0; int64_t seq_off = 0; int strand = 0, is_first = 0;
+    if (act) {
+      ref_start = v.in_ref_start[o]; svlen = v.in_svlen[o];
+      bool hs = lead_has_seq(v, o);
+      seq_len = hs ? v.in_seq_len[o] : -1; seq_off = hs ? v.in_seq_off[o] : 0;
+      if (svtype == SNF_INS || svtype == SNF_DEL) {
+        ref_end = v.in_ref_end[o]; qry_start = v.in_qry_start[o]; qry_end = v.in_qry_end[o];
+        qname = v.in_qname[o]; strand = v.in_strand[o];
+      } else if (svtype == SNF_BND) {
+        mate_pos = v.in_mate_pos[o]; mate_contig = v.in_mate_contig[o]; is_first = v.in_first[o];
+      }
+    }
+    int m = n;                 // number of leads after fusion
+    int32_t f_orig = (int32_t)o, f_svlen = svlen, f_seq_len = seq_len; int64_t f_seq_off = seq_off;
+
+    if (svtype == SNF_INS || svtype == SNF_DEL) {
+      // ---- merge_inner
+      const int thr = v.c_repeat[h] ? -1 : cfg.cluster_merge_pos;
+      int fa = -1;  // first appearance of this read's qname in cluster order
+      for (int i = 0; i < n; i++) {
+        uint32_t qi = (uint32_t)wave_bcast_i32((int32_t)qname, i);
+        if (fa < 0 && qi == qname) fa = i;
+      }
+      uint64_t key = act ? (((uint64_t)(uint32_t)fa << 40) | ((uint64_t)((uint32_t)ref_start ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+      const int rank = wave_rank(key, n);
+      const int n_ = n;
+      SNF_PERMUTE_SETUP(rank, act)
+      // everything below is in sorted order: lane r holds the r-th lead of the (read, ref_start) order
+      const int s_fa = SNF_GATHER(fa);
+      const int32_t s_rs = SNF_GATHER(ref_start), s_re = SNF_GATHER(ref_end), s_qs = SNF_GATHER(qry_start), s_qe = SNF_GATHER(qry_end);
+      const int32_t s_svlen = SNF_GATHER(svlen), s_seq_len = SNF_GATHER(seq_len);
+      const int64_t s_seq_off = SNF_GATHER(seq_off);
+      const int s_strand = SNF_GATHER(strand);
+      const uint32_t s_o = SNF_GATHER(o);
+      // neighbour r-1
+      const int p_fa = __shfl_up(s_fa, 1, SNF_WAVE);
+      const int32_t p_rs = __shfl_up(s_rs, 1, SNF_WAVE), p_re = __shfl_up(s_re, 1, SNF_WAVE);
+      const int32_t p_qs = __shfl_up(s_qs, 1, SNF_WAVE), p_qe = __shfl_up(s_qe, 1, SNF_WAVE);
+      const int p_strand = __shfl_up(s_strand, 1, SNF_WAVE);
+      bool mg = false;
+      if (act && lane > 0 && p_fa == s_fa) {
+        mg = (thr == -1) ||
+             (((iabs64((int64_t)s_rs - p_re) < thr || iabs64((int64_t)s_rs - p_rs) < thr) &&
+               (iabs64((int64_t)s_qs - p_qe) < thr || iabs64((int64_t)s_qs - p_qs) < thr)) &&
+              (p_strand == s_strand));  // == head strand: every member of a fused run shares it
+      }
+      const bool start = act && !mg;
+      const unsigned long long smask = __ballot(start);
+      // segment end for a start lane: next start - 1
+      unsigned long long above = (lane < 63) ? (smask >> (lane + 1)) : 0ull;
+      const int seg_end = above ? lane + __builtin_ctzll(above) : n - 1;
+      const int64_t ps_svlen = wave_incl_scan64(act ? (int64_t)s_svlen : 0, lane);
+      const int64_t ps_seq = wave_incl_scan64((act && s_seq_len >= 0) ? (int64_t)s_seq_len : 0, lane);
+      const int32_t ps_has = wave_incl_scan((act && s_seq_len >= 0) ? 1 : 0, lane);
+      const int64_t e_svlen = __shfl(ps_svlen, seg_end, SNF_WAVE), e_seq = __shfl(ps_seq, seg_end, SNF_WAVE);
+      const int32_t e_has = __shfl(ps_has, seg_end, SNF_WAVE);
+      const int64_t x_svlen = ps_svlen - s_svlen, x_seq = ps_seq - (s_seq_len >= 0 ? s_seq_len : 0);
+      const int32_t x_has = ps_has - (s_seq_len >= 0 ? 1 : 0);
+      const int nparts = seg_end - lane + 1;
+      const int64_t tot_svlen = e_svlen - x_svlen, tot_seq = e_seq - x_seq;
+      const bool seq_ok = (e_has - x_has) == nparts;
+      // fused sequence: concatenation in the pool's fused region (curr_lead.seq += to_merge.seq)
+      int64_t new_off = 0; bool need_copy = start && seq_ok && nparts > 1;
+      if (need_copy) {
+        new_off = v.pool_len + (int64_t)atomicAdd(&v.cnt->pool_extra_used, (unsigned long long)tot_seq);
+        if (new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
+      }
+      unsigned long long cmask = __ballot(need_copy);
+      while (cmask) {  // cooperative byte copy, one fused lead at a time
+        const int r0 = __builtin_ctzll(cmask); cmask &= cmask - 1;
+        const int r1 = __shfl(seg_end, r0, SNF_WAVE);
+        int64_t dst = __shfl(new_off, r0, SNF_WAVE);
+        for (int z = r0; z <= r1; z++) {
+          const int64_t so = __shfl(s_seq_off, z, SNF_WAVE); const int32_t sl = __shfl(s_seq_len, z, SNF_WAVE);
+          for (int32_t b = lane; b < sl; b += SNF_WAVE) v.pool[dst + b] = v.pool[so + b];
+          dst += sl;
+        }
+      }
+      const bool ok_seq = start && seq_ok && (nparts == 1 || need_copy);
+      // compact the fused leads (start lanes) to lanes 0..m-1
+      m = __builtin_popcountll(smask);
+      const int kidx = __builtin_popcountll(smask & ((1ull << lane) - 1ull));
+      __syncthreads();
+      if (start) lds.perm[kidx] = lane;
+      __syncthreads();
+      const int src2 = lds.perm[lane < m ? lane : 0];
+      f_orig = (int32_t)__shfl(s_o, src2, SNF_WAVE);
+      f_svlen = (int32_t)__shfl(tot_svlen, src2, SNF_WAVE);
+      const int32_t t_seq_len = ok_seq ? (nparts == 1 ? s_seq_len : (int32_t)tot_seq) : -1;
+      const int64_t t_seq_off = ok_seq ? (nparts == 1 ? s_seq_off : new_off) : 0;
+      f_seq_len = __shfl(t_seq_len, src2, SNF_WAVE);
+      f_seq_off = __shfl(t_seq_off, src2, SNF_WAVE);
+    }
+    const bool fact = lane < m;
+    if (fact) {
+      v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen;
+      v.F_seq_len[lo + lane] = f_seq_len; v.F_seq_off[lo + lane] = f_seq_off;
+    }
+
+    if (svtype == SNF_BND) {
+      // ---- resplit_bnd: group by (mate_contig, is_first) in first-appearance order, chain 1-kb bins
+      if (m <= 1 || cfg.dev_no_resplit) {
+        if (fact) v.FI[lo + lane] = lo + lane;
+        if (lane == 0) rc_emit(v, lo, m, (int32_t)c, true);
+        continue;
+      }
+      const int thr = cfg.cluster_merge_bnd;
+      int fa = -1;
+      for (int i = 0; i < m; i++) {
+        const int32_t mc = wave_bcast_i32(mate_contig, i); const int fi = wave_bcast_i32(is_first, i);
+        if (fa < 0 && mc == mate_contig && fi == is_first) fa = i;
+      }
+      const int64_t pb = thr > 0 ? ((int64_t)mate_pos / thr) * thr : 0;
+      uint64_t key = fact ? (((uint64_t)(uint32_t)fa << 48) | ((uint64_t)(uint32_t)((int64_t)pb + 0x80000000ll) << 8) | (uint32_t)lane) : ~0ull;
+      const int rank = wave_rank(key, m);
+      const int n_ = m;
+      SNF_PERMUTE_SETUP(rank, fact)
+      const int s_fa = SNF_GATHER(fa); const int64_t s_pb = SNF_GATHER(pb); const int s_j = SNF_GATHER(lane);
+      const int p_fa = __shfl_up(s_fa, 1, SNF_WAVE); const int64_t p_pb = __shfl_up(s_pb, 1, SNF_WAVE);
+      const bool brk = fact && (lane == 0 || p_fa != s_fa || (s_pb - p_pb > thr));
+      const unsigned long long bmask = __ballot(brk);
+      if (fact) v.FI[lo + lane] = lo + s_j;
+      if (brk) {
+        unsigned long long above = (lane < 63) ? (bmask >> (lane + 1)) : 0ull;
+        const int end = above ? lane + 1 + __builtin_ctzll(above) : m;  // exclusive: position of the next chain start
+        rc_emit(v, lo + lane, end - lane, (int32_t)c, false);
+      }
+      continue;
+    }
+
+    // ---- resplit on |svlen| bins of 20 (cluster.py:125-161)
+    if (cfg.dev_no_resplit_repeat || cfg.dev_no_resplit) {
+      if (fact) v.FI[lo + lane] = lo + lane;
+      if (lane == 0) rc_emit(v, lo, m, (int32_t)c, true);
+      continue;
+    }
+    {
+      const int rb = cfg.cluster_resplit_binsize;
+      const int64_t av = f_svlen < 0 ? -(int64_t)f_svlen : f_svlen;
+      const int32_t bin = (int32_t)((av / rb) * rb);
+      uint64_t key = fact ? (((uint64_t)(uint32_t)bin << 8) | (uint32_t)lane) : ~0ull;
+      const int rank = wave_rank(key, m);
+      const int n_ = m;
+      SNF_PERMUTE_SETUP(rank, fact)
+      const int32_t s_bin = SNF_GATHER(bin); const int s_k = SNF_GATHER(lane);
+      const int32_t p_bin = __shfl_up(s_bin, 1, SNF_WAVE);
+      const bool sstart = fact && (lane == 0 || p_bin != s_bin);
+      const unsigned long long smask = __ballot(sstart);
+      const int nb = __builtin_popcountll(smask);
+      const int sidx = __builtin_popcountll(smask & ((2ull << lane) - 1ull)) - 1;  // segment of this position
+      __syncthreads();
+      if (sstart) { lds.seg_start[sidx] = lane; lds.seg_key[sidx] = s_bin; }
+      __syncthreads();
+      if (lane == 0) {  // sequential bin-merge state machine with the reference's index quirks
+        for (int s = 0; s < nb; s++) { lds.nc[s] = s; lds.head[s] = s; lds.tail[s] = s; lds.nxt[s] = -1; }
+        int cntc = nb, i = 1;
+        while (cntc > 1 && i < cntc) {
+          const int im1 = (i == 0) ? cntc - 1 : i - 1;  // Python negative index: new_clusters[-1]
+          const int64_t last = lds.seg_key[lds.nc[im1]], curr = lds.seg_key[lds.nc[i]];
+          const int64_t mn = curr < last ? curr : last;
+          const double t = (double)mn * cfg.cluster_merge_len;
+          const double thr = ((double)cfg.minsvlen >= t) ? (double)cfg.minsvlen : t;
+          const int64_t diff = curr > last ? curr - last : last - curr;
+          if ((double)diff <= thr) {
+            const int cb = lds.nc[i], lb = lds.nc[im1];
+            lds.nxt[lds.tail[cb]] = lds.head[lb];
+            lds.tail[cb] = lds.tail[lb];
+            for (int t2 = im1; t2 + 1 < cntc; t2++) lds.nc[t2] = lds.nc[t2 + 1];
+            cntc--;
+            i = (i - 2 > 0) ? i - 2 : 0;
+          } else i++;
+        }
+        int outp = 0;
+        for (int t2 = 0; t2 < cntc; t2++) {
+          const int start = outp;
+          for (int s = lds.head[lds.nc[t2]]; s >= 0; s = lds.nxt[s]) {
+            const int xe = (s + 1 < nb) ? lds.seg_start[s + 1] : m;
+            lds.seg_out[s] = outp;
+            outp += xe - lds.seg_start[s];
+          }
+          lds.rc_start[t2] = start; lds.rc_len[t2] = outp - start;
+        }
+        lds.n_rc = cntc;
+      }
+      __syncthreads();
+      if (fact) v.FI[lo + lds.seg_out[sidx] + (lane - lds.seg_start[sidx])] = lo + s_k;
+      if (lane < lds.n_rc) rc_emit(v, lo + lds.rc_start[lane], lds.rc_len[lane], (int32_t)c, true);
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace snf
+#endif  // !SNF_EMU
