@@ -4,6 +4,7 @@
 // (-ffp-contract=off: the reference's double arithmetic has no fused multiply-add).
 #include "snf_stage_final.h"
 #include "snf_wave_refine.h"
+#include "snf_wave_cons.h"
 
 #ifndef SNF_EMU
 #include <rocprim/device/device_radix_sort.hpp>
@@ -514,8 +515,17 @@ void run_finalize(snf_batch_impl* b) {
   }
   ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
   if (ncons > 0) {
-    LAUNCH(e4_anchor, v, ncons, b->h_cnt.tab_total * 13);
-    LAUNCH(e5_align, v, b->h_cnt.n_cons_reads, b->h_cnt.aln_total * 2);
+    LAUNCH(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      // algorithmic bytes: every base of every seq-bearing lead of a consensus call once + the row written
+      Scope _s(b, "e45w_consensus", b->h_cnt.aln_total * 2);
+      int64_t grid = ncons < 8192 ? ncons : 8192;
+      hipLaunchKernelGGL(e45w_consensus, dim3((unsigned)grid), dim3(256), 0, b->stream, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
+    LAUNCH(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
   }
   LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
 }
@@ -592,6 +602,8 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
     int32_t sl = t->seq_len[i];
     if (sl >= 0 && (t->seq_off[i] < 0 || t->seq_off[i] + sl > t->seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
   }
+  // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' would be a gap there
+  if (t->seq_pool_len > 0 && memchr(t->seq_pool, '-', (size_t)t->seq_pool_len)) fail("INS sequences must not contain '-'");
   append(b->h_ref_start, t->ref_start, n); append(b->h_ref_end, t->ref_end, n); append(b->h_qry_start, t->qry_start, n);
   append(b->h_qry_end, t->qry_end, n); append(b->h_svlen, t->svlen, n); append(b->h_read_len, t->read_len, n);
   append(b->h_qname, t->qname_id, n); append(b->h_read_id, t->read_id, n); append(b->h_ps, t->ps_rank, n);

@@ -390,6 +390,16 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   }
 }
 
+// calls the gfx950 workgroup kernel (snf_wave_cons.h) can take: anchor table and lists fit its LDS budget
+#define SNF_CONS_SLOTS 1024
+#define SNF_CONS_MAXPOS 512
+#define SNF_CONS_MAXOTHERS 512
+SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) {
+  int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
+  return v.wave_path && v.cfg.consensus_kmer_len <= 7 && npos < SNF_CONS_MAXPOS - 8 && 2 * npos + 2 <= SNF_CONS_SLOTS &&
+         n_others <= SNF_CONS_MAXOTHERS && L < 65000;
+}
+
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
   uint64_t k = 0;
   for (int i = 0; i < klen; i++) k = (k << 8) | s[i];
@@ -403,6 +413,10 @@ SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
   int32_t ci = v.cons_call[cid];
   const CallX& x = v.callx[ci];
   int64_t L = v.F_seq_len[x.best];
+  // (cid, read) work items
+  int64_t r0 = v.cons_read_off[cid];
+  for (int32_t r = 0; r < x.n_others; r++) { v.cr_call[r0 + r] = (int32_t)cid; v.cr_read[r0 + r] = r; }
+  if (cons_wave_eligible(v, L, x.n_others)) return;  // e45w_consensus builds its table in LDS
   const uint8_t* B = v.pool + v.F_seq_off[x.best];
   int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L);
   int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_off[cid + 1] - t0;
@@ -415,9 +429,6 @@ SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
     if (st[p] == 0) { st[p] = 1; key[p] = kk; pos[p] = (int32_t)i; }
     else st[p] = 2;
   }
-  // (cid, read) work items
-  int64_t r0 = v.cons_read_off[cid];
-  for (int32_t r = 0; r < x.n_others; r++) { v.cr_call[r0 + r] = (int32_t)cid; v.cr_read[r0 + r] = r; }
 }
 
 // E5: align one other read against the best read's anchors -> aligned row (consensus.py:301-363)
@@ -426,6 +437,7 @@ SNF_HD void e5_align_body(int64_t j, const View& v) {
   int32_t cid = v.cr_call[j], ridx = v.cr_read[j];
   int32_t ci = v.cons_call[cid];
   const CallX& x = v.callx[ci];
+  if (cons_wave_eligible(v, v.F_seq_len[x.best], x.n_others)) return;
   // locate the ridx-th seq-bearing lead other than best, in cluster order
   int32_t slot = -1, seen = 0;
   for (int32_t k = 0; k < x.fn; k++) {

@@ -1,0 +1,196 @@
+// snf_wave_cons.h - gfx950 workgroup-per-INS-call implementation of the k-mer anchored consensus
+// alignment (consensus.novel_from_reads, consensus.py:280-363): anchor table + one aligned row per
+// "other" read.  The column vote (consensus.py:365-380) stays in e6_vote.
+//
+// Per consensus call: 256 threads build the anchor hash table of the best read in LDS (unique sampled
+// 6-mers; <= ~500 positions -> 1024 slots).  Then each of the 4 waves takes reads r = w, w+4, ...:
+//   1. sampled k-mers of the read are looked up in parallel and compacted IN ORDER (ballot + popcount)
+//   2. the monotone anchor chain (accept iff i > last accepted i) is a prefix-max filter
+//   3. per segment between consecutive anchors (one lane each): clipped advance, identity on offsets
+//      1..n, column-identity of the copied slice (the column cursor has the closed form
+//      min(L, c0 + j - j0))
+//   4. lane 0 groups consecutive copied segments into runs and applies the run filter
+//      (matches/len > 0.5 and matches > 5)
+//   5. the row is written column-parallel (binary search of the owning segment), coalesced.
+// Input sequences must not contain '-' (checked at snf_batch_add_task): the reference treats it as a gap.
+#pragma once
+#include "snf_stage_final.h"
+
+#ifndef SNF_EMU
+namespace snf {
+
+#define SNF_KEY_EMPTY (~0ull)
+
+struct ConsWaveLds {
+  int32_t ai[SNF_CONS_MAXPOS];   // candidates, then accepted anchors: position in best
+  int32_t aj[SNF_CONS_MAXPOS];   //                                    position in the read
+  int32_t seg_col[SNF_CONS_MAXPOS];  // column where segment t starts (t >= 1)
+  uint16_t seg_len[SNF_CONS_MAXPOS]; // clipped advance (columns written)
+  uint16_t seg_cm[SNF_CONS_MAXPOS];  // matches of the copied slice against best at its columns
+  uint8_t seg_flag[SNF_CONS_MAXPOS]; // 0 dashes, 1 copy
+};
+struct ConsLds {
+  unsigned long long key[SNF_CONS_SLOTS];
+  int32_t pos[SNF_CONS_SLOTS];
+  int32_t cnt[SNF_CONS_SLOTS];
+  int32_t others[SNF_CONS_MAXOTHERS];
+  ConsWaveLds w[4];
+};
+
+SNF_D int wave_max_incl(int x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d && y > x) x = y; }
+  return x;
+}
+
+__global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_unused) {
+  __shared__ ConsLds lds;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
+  const int64_t n_cons = v.cnt->n_cons;
+  for (int64_t cid = blockIdx.x; cid < n_cons; cid += gridDim.x) {
+    const int32_t ci = v.cons_call[cid];
+    const CallX x = v.callx[ci];
+    const int64_t L = v.F_seq_len[x.best];
+    if (!cons_wave_eligible(v, L, x.n_others)) continue;  // thread path (e4_anchor/e5_align) owns it
+    const uint8_t* B = v.pool + v.F_seq_off[x.best];
+    const int skip = cons_skip(v.cfg, L);
+    __syncthreads();
+    // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
+    for (int s = tid; s < SNF_CONS_SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.cnt[s] = 0; }
+    if (tid == 0) {  // cluster-order list of the other seq-bearing leads
+      int k2 = 0;
+      for (int32_t k = 0; k < x.fn; k++) {
+        const int32_t s = v.FI[x.flo + k];
+        if (v.F_seq_len[s] < 0 || s == x.best) continue;
+        lds.others[k2++] = s;
+      }
+    }
+    __syncthreads();
+    const int64_t npos = cons_npos(L, klen, skip);
+    for (int64_t p = tid; p < npos; p += 256) {
+      const int64_t i = p * skip;
+      const unsigned long long kk = kmer_key(B + i, klen);
+      int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
+      for (;;) {
+        const unsigned long long old = atomicCAS(&lds.key[sl], SNF_KEY_EMPTY, kk);
+        if (old == SNF_KEY_EMPTY || old == kk) break;
+        sl = (sl + 1) & (SNF_CONS_SLOTS - 1);
+      }
+      if (atomicAdd(&lds.cnt[sl], 1) == 0) lds.pos[sl] = (int32_t)i;  // meaningful only while cnt stays 1
+    }
+    __syncthreads();
+    ConsWaveLds& W = lds.w[wid];
+    const int64_t r0 = v.cons_read_off[cid];
+    uint8_t* rows = v.aln + v.cons_aln_off[cid];
+    for (int32_t r = wid; r < x.n_others; r += 4) {
+      const int32_t slot = lds.others[r];
+      const uint8_t* S = v.pool + v.F_seq_off[slot];
+      const int64_t SL = v.F_seq_len[slot];
+      uint8_t* row = rows + (int64_t)r * L;
+      // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
+      int64_t jlim = SL - klen;                       // j < SL - klen
+      if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;  // an anchor needs i <= L-klen-1, |i-j| <= maxshift
+      const int64_t P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;
+      int ncand = 0;
+      for (int64_t p0 = 0; p0 < P; p0 += 64) {
+        const int64_t p = p0 + lane;
+        int ci_ = -1; int64_t j = p * skip;
+        if (p < P) {
+          const unsigned long long kk = kmer_key(S + j, klen);
+          int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
+          for (;;) {
+            const unsigned long long kq = lds.key[sl];
+            if (kq == SNF_KEY_EMPTY) break;
+            if (kq == kk) { if (lds.cnt[sl] == 1) { const int i = lds.pos[sl]; if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; } break; }
+            sl = (sl + 1) & (SNF_CONS_SLOTS - 1);
+          }
+        }
+        const unsigned long long mk = __ballot(ci_ >= 0);
+        if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = ci_; W.aj[w] = (int32_t)j; }
+        ncand += __builtin_popcountll(mk);
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- 2. monotone chain: accept iff i > every earlier candidate's i (== last accepted i)
+      int na = 0, runmax = -1;
+      for (int c0 = 0; c0 < ncand; c0 += 64) {
+        const int cidx = c0 + lane;
+        const int i = cidx < ncand ? W.ai[cidx] : -1, j = cidx < ncand ? W.aj[cidx] : 0;
+        int pm = wave_max_incl(i, lane);
+        int prev = __shfl_up(pm, 1, 64);
+        if (lane == 0) prev = -1;
+        if (runmax > prev) prev = runmax;
+        const bool acc = cidx < ncand && i > prev;
+        const unsigned long long mk = __ballot(acc);
+        __builtin_amdgcn_wave_barrier();
+        if (acc) { const int w = na + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = i; W.aj[w] = j; }
+        na += __builtin_popcountll(mk);
+        const int tot = __shfl(pm, 63, 64);
+        if (tot > runmax) runmax = tot;
+        __builtin_amdgcn_wave_barrier();
+      }
+      // ---- 3. segments between consecutive anchors
+      const int i0 = na ? W.ai[0] : 0, j0 = na ? W.aj[0] : 0;
+      const int64_t c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
+      int64_t span = 0;
+      for (int t0 = 1; t0 < na; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < na) {
+          const int li = W.ai[t - 1], lj = W.aj[t - 1], i = W.ai[t], j = W.aj[t];
+          int64_t col = c_first + (lj - j0); if (col > L) col = L;
+          const int64_t fwd_i = i - li; int64_t fwd_j = j - lj;
+          if (col + fwd_j > L) fwd_j = L - col;
+          uint8_t flag = 0; int cm = 0;
+          if (fwd_i == fwd_j && fwd_j > 0) {
+            const int nfull = j - lj;
+            span += nfull;
+            int m = 0;
+            for (int l = 1; l <= nfull; l++) m += (S[lj + l] == B[li + l]);
+            if ((double)m / (double)nfull >= 0.5) {
+              flag = 1;
+              for (int q = 0; q < (int)fwd_j; q++) cm += (S[lj + q] == B[col + q]);
+            }
+          }
+          W.seg_col[t] = (int32_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
+        }
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) span += __shfl_xor(span, d, 64);
+      __builtin_amdgcn_wave_barrier();
+      // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360)
+      if (lane == 0) {
+        int t = 1;
+        while (t < na) {
+          if (!W.seg_flag[t]) { t++; continue; }
+          int u = t, ident = 0, len = 0;
+          while (u < na && W.seg_flag[u]) { ident += W.seg_cm[u]; len += W.seg_len[u]; u++; }
+          if (!((double)ident / (double)len > 0.5 && ident > 5)) for (int z = t; z < u; z++) W.seg_flag[z] = 0;
+          t = u;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- 5. write the row, column-parallel
+      int64_t c_last = c_first;
+      if (na) { c_last = c_first + (W.aj[na - 1] - j0); if (c_last > L) c_last = L; }
+      for (int64_t q0 = 0; q0 < L; q0 += 64) {
+        const int64_t q = q0 + lane;
+        if (q < L) {
+          uint8_t out = '-';
+          if (na > 1 && q >= c_first && q < c_last) {
+            int lo2 = 1, hi2 = na - 1;  // last segment t with seg_col[t] <= q
+            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (W.seg_col[mid] <= q) lo2 = mid; else hi2 = mid - 1; }
+            const int t = lo2;
+            const int64_t off = q - W.seg_col[t];
+            if (W.seg_flag[t] && off < W.seg_len[t]) out = S[W.aj[t - 1] + off];
+          }
+          row[q] = out;
+        }
+      }
+      if (lane == 0) v.aln_kept[r0 + r] = ((double)span / (double)L > 0.2) ? 1 : 0;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+}  // namespace snf
+#endif  // !SNF_EMU
