@@ -31,16 +31,10 @@ CPU_SAMPLE_CONTIGS = ["chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr
 
 def shard_tasks(n_ranks: int):
     """(replica, contig) tasks, longest-processing-time-first over ranks.  Deterministic, no communication."""
-    from sniffles_amd import synth
-    items = [(synth.GRCH38[c], rep, ci, c) for rep in range(n_ranks) for ci, c in enumerate(synth.CONTIGS)]
-    items.sort(key=lambda x: (-x[0], x[1], x[2]))
-    load = [0] * n_ranks
-    out = [[] for _ in range(n_ranks)]
-    for ln, rep, ci, c in items:
-        r = min(range(n_ranks), key=lambda k: (load[k], k))
-        load[r] += ln
-        out[r].append((rep, ci, c))
-    return out
+    from sniffles_amd import dist as sdist, synth
+    items = [(rep, ci, c) for rep in range(n_ranks) for ci, c in enumerate(synth.CONTIGS)]
+    shards = sdist.shard_lpt([synth.GRCH38[c] for _, _, c in items], n_ranks)
+    return [[items[i] for i in s] for s in shards]
 
 
 def main():

@@ -1,0 +1,108 @@
+"""Input side of the drop-in: `Lead` and `LeadProvider` with the reference's names
+(reference `src/sniffles/leadprov.py:34-56, 358-472`).
+
+The reference keeps `leadtab[svtype][bin] -> list[Lead]`, per-bin hap counters and a dense uint16 coverage
+vector.  Here `record_lead` / `record_read` only append to arrival-ordered columns; binning, the 10-leads
+per bin sequence cap, hap counters and coverage queries all happen on the GPU.
+`record_read(ref_start, ref_end, hp)` replaces the pair `coverage[s:e] += 1` + `record_hap_ref(...)`
+that `iter_region` issues per alignment (leadprov.py:510, 567-571).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .soa import (TaskInput, SVT, SRC, SVLEN_NONE, SEQ_NONE, PS_NONE, empty_leads, intern_sorted)
+from .sv import SVCallBNDInfo
+
+
+@dataclass
+class Lead:
+    read_id: int = None
+    read_qname: str = None
+    contig: str = None
+    ref_start: int = None
+    ref_end: int = None
+    qry_start: int = None
+    qry_end: int = None
+    strand: str = None
+    mapq: int = None
+    nm: float = None
+    source: str = None
+    svtype: str = None
+    svlen: Optional[int] = None
+    seq: Optional[str] = None
+    svtypes_starts_lens: list = None
+    bnd_info: Optional[SVCallBNDInfo] = None
+    hap: str = "0"
+    phase_set: str = None
+    is_sa: bool = False
+    read_len: int = 0
+
+
+class LeadProvider:
+    def __init__(self, config, read_id_offset, contig: str, contig_len: int = None):
+        self.config = config
+        self.contig = contig
+        self.contig_len = contig_len
+        self.start = None
+        self.end = None
+        self.read_id = read_id_offset
+        self.read_count = 0
+        self._leads = []
+        self._reads = []
+
+    def record_lead(self, ld: Lead, pos_leadtab: int = None) -> None:
+        """Same call as the reference; `pos_leadtab` (the 100-bp bin) is recomputed on the GPU."""
+        self._leads.append(ld)
+
+    def record_read(self, ref_start: int, ref_end: int, hp: int = 0) -> None:
+        self._reads.append((int(ref_start), int(ref_end), int(hp)))
+        self.read_count += 1
+
+    def to_task_input(self, task_id: int, sv_id_start: int, tandem_repeats, qc_nm_threshold: float) -> TaskInput:
+        n = len(self._leads)
+        L = empty_leads(n)
+        qn, qrank = intern_sorted([ld.read_qname for ld in self._leads])
+        psn, psrank = intern_sorted([ld.phase_set for ld in self._leads if ld.phase_set is not None] + ["NULL"])
+        cn, crank = intern_sorted([ld.bnd_info.mate_contig for ld in self._leads if ld.bnd_info is not None] + [self.contig])
+        pool = bytearray()
+        for i, ld in enumerate(self._leads):
+            L["svtype"][i] = SVT[ld.svtype]
+            L["ref_start"][i], L["ref_end"][i] = ld.ref_start, ld.ref_end
+            L["qry_start"][i], L["qry_end"][i] = ld.qry_start, ld.qry_end
+            L["svlen"][i] = SVLEN_NONE if ld.svlen is None else ld.svlen
+            L["read_len"][i] = ld.read_len or 0
+            L["qname_id"][i] = qrank[ld.read_qname]
+            L["read_id"][i] = ld.read_id
+            L["strand"][i] = 1 if ld.strand == "-" else 0
+            L["mapq"][i] = ld.mapq
+            L["nm"][i] = float("nan") if ld.nm is None else ld.nm
+            L["source"][i] = SRC[ld.source]
+            L["hap"][i] = int(ld.hap)
+            L["ps_rank"][i] = PS_NONE if ld.phase_set is None else psrank[ld.phase_set]
+            L["is_sa"][i] = bool(ld.is_sa)
+            if ld.seq is not None:
+                L["seq_off"][i], L["seq_len"][i] = len(pool), len(ld.seq)
+                pool += ld.seq.encode("latin-1")
+            else:
+                L["seq_len"][i] = SEQ_NONE
+            if ld.bnd_info is not None:
+                L["mate_contig"][i] = crank[ld.bnd_info.mate_contig]
+                L["mate_ref_start"][i] = ld.bnd_info.mate_ref_start
+                L["bnd_is_first"][i] = bool(ld.bnd_info.is_first)
+                L["bnd_is_reverse"][i] = bool(ld.bnd_info.is_reverse)
+        reads = sorted(self._reads, key=lambda r: r[0])  # BAM order == ascending start; stable
+        clen = self.contig_len if self.contig_len is not None else self.end
+        ti = TaskInput(task_id=task_id, contig=self.contig, contig_len=int(clen), sv_id_start=sv_id_start, leads=L,
+                       seq_pool=np.frombuffer(bytes(pool), np.uint8).copy(),
+                       read_start=np.array([r[0] for r in reads], np.int32),
+                       read_end=np.array([r[1] for r in reads], np.int32),
+                       read_hp=np.array([r[2] for r in reads], np.uint8),
+                       tr_start=None if tandem_repeats is None else np.array([t[0] for t in tandem_repeats], np.int32),
+                       tr_end=None if tandem_repeats is None else np.array([t[1] for t in tandem_repeats], np.int32),
+                       qc_nm_threshold=qc_nm_threshold, qnames=qn, ps_names=psn, contig_names=cn)
+        ti.validate()
+        return ti

@@ -1,0 +1,89 @@
+"""The Python entry points mirror the reference's (Lead / LeadProvider.record_lead / Task.call_candidates /
+Task.finalize_candidates -> SVCall): same objects in, same SVCall fields out, compared with the goldens the
+unmodified reference produced.  CPU tier: kernels through the host emulation; GPU tier: the real library."""
+import pytest
+
+import cases
+import golden_util as gu
+from sniffles_amd import leadprov, parallel
+from sniffles_amd.soa import SVTYPES, SOURCES, SVLEN_NONE
+
+
+def leads_of(ti):
+    """TaskInput -> mirror Lead objects, exactly as a ported iter_region would create them."""
+    L = ti.leads
+    pool = ti.seq_pool.tobytes()
+    for i in range(ti.n_leads):
+        svt = SVTYPES[L["svtype"][i]]
+        sl, so, svlen = int(L["seq_len"][i]), int(L["seq_off"][i]), int(L["svlen"][i])
+        ld = leadprov.Lead(read_id=int(L["read_id"][i]), read_qname=ti.qname(int(L["qname_id"][i])), contig=ti.contig,
+                           ref_start=int(L["ref_start"][i]), ref_end=int(L["ref_end"][i]), qry_start=int(L["qry_start"][i]),
+                           qry_end=int(L["qry_end"][i]), strand="-" if L["strand"][i] else "+", mapq=int(L["mapq"][i]),
+                           nm=float(L["nm"][i]), source=SOURCES[L["source"][i]], svtype=svt,
+                           svlen=None if svlen == int(SVLEN_NONE) else svlen,
+                           seq=None if sl < 0 else pool[so:so + sl].decode("latin-1"), hap=str(int(L["hap"][i])),
+                           phase_set=ti.ps_name(int(L["ps_rank"][i])), is_sa=bool(L["is_sa"][i]), read_len=int(L["read_len"][i]))
+        if svt == "BND":
+            ld.bnd_info = leadprov.SVCallBNDInfo(ti.contig_name(int(L["mate_contig"][i])), int(L["mate_ref_start"][i]),
+                                                 bool(L["bnd_is_first"][i]), bool(L["bnd_is_reverse"][i]))
+        yield ld
+
+
+def as_record(c, stage):
+    gt = c.genotypes.get(0)
+    rec = dict(id=c.id, contig=c.contig, pos=c.pos, end=c.end, svtype=c.svtype, svlen=c.svlen, support=c.support, qual=c.qual,
+               precise=c.precise, fwd=c.fwd, rev=c.rev, filter=c.filter, qc=c.qc, nm=c.nm, alt=c.alt,
+               stdev_pos=c.info.get("STDEV_POS"), stdev_len=c.info.get("STDEV_LEN"), support_long=c.info.get("SUPPORT_LONG"),
+               support_sa=c.info.get("SUPPORT_SA"),
+               cov=[c.coverage_upstream, c.coverage_start, c.coverage_center, c.coverage_end, c.coverage_downstream],
+               rnames=sorted(c.rnames),
+               bnd=None if c.bnd_info is None else [c.bnd_info.mate_contig, c.bnd_info.mate_ref_start, c.bnd_info.is_first,
+                                                   c.bnd_info.is_reverse])
+    if stage == "final":
+        rec["gt"] = None if gt is None else [gt[0], gt[1], gt[2], gt[3], gt[4], list(gt[5])]
+        rec["vaf"] = c.info.get("VAF")
+        rec["phase"] = c.info.get("PHASE")
+    return rec
+
+
+def run_case(name, _lib):
+    build, kw, _ = cases.ALL[name]
+    ti = build()
+    cfg = gu.make_config(kw, ti)
+    exp = gu.load(name)["expected"]
+    lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+    for ld in leads_of(ti):
+        lp.record_lead(ld, int(ld.ref_start / cfg.cluster_binsize) * cfg.cluster_binsize)
+    for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
+        lp.record_read(s, e, hp)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                             _lib=_lib)
+    task.lead_provider = lp
+    task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
+    if "error" in exp:
+        with pytest.raises(UnboundLocalError):
+            task.call_candidates(True, cfg)
+        return
+    cands = task.call_candidates(True, cfg)
+    assert [as_record(c, "cand") for c in cands] == exp["candidates"]
+    assert task.coverage_average_total == exp["coverage_average_total"]
+    assert task.sv_id == ti.sv_id_start + len(cands)
+    final = task.finalize_candidates(cands, False, cfg)
+    assert [as_record(c, "final") for c in final] == exp["final"]
+    assert all(c.postprocess is None for c in final)
+
+
+NAMES = ["bnd_first_error", "bnd_stale_end", "merge_inner", "long_ins", "phase_rescue", "consensus_quirks",
+         "chr21_30x_mosaic", "fuzz_4_2", "single_leads_noqc"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_task_entry_points_emulated(name):
+    import emu.emu as E
+    run_case(name, E.lib())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES + ["chr20_30x_ont", "chr22_60x_hifi"])
+def test_task_entry_points_gpu(name):
+    run_case(name, None)

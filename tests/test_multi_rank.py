@@ -1,0 +1,82 @@
+"""N > 1 path on CPU: world_size-2 gloo, contig tasks sharded longest-first, per-rank hot path (kernel bodies via
+the host emulation), all-gather of the call records, and equality with a single-process run of all tasks."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tasks():
+    from sniffles_amd import synth
+    names = ["chr18", "chr19", "chr20", "chr21", "chr22"]
+    return [synth.gen_task(i, c, int(synth.GRCH38[c] * 0.01), 30, 1) for i, c in enumerate(names)]
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu.emu as E
+    from sniffles_amd import abi, dist as sdist, lib
+    from sniffles_amd.config import SnifflesConfig
+    tasks = _tasks()
+    mine = sdist.shard_lpt([t.contig_len for t in tasks], world)[rank]
+    cfg = SnifflesConfig()
+    with lib.Batch(cfg, [tasks[i] for i in mine], _lib=E.lib()) as b:
+        b.call_candidates(); b.finalize()
+        res = b.fetch(1)
+    cap = 4096
+    buf = torch.zeros(cap * abi.CALL_DTYPE.itemsize, dtype=torch.uint8)
+    raw = res.calls.tobytes()
+    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    counts, gathered = sdist.gather_calls(buf, len(res.calls), cap, world)
+    per_rank = sdist.unpack_gathered(counts, gathered, cap)
+    if rank == 0:
+        # key the records by (global task id, sv_id): task_index is rank-local, map it back through the shard lists
+        shards = sdist.shard_lpt([t.contig_len for t in tasks], world)
+        keys = []
+        for r, arr in enumerate(per_rank):
+            for c in arr:
+                keys.append((shards[r][int(c["task_index"])], int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]),
+                             int(c["support"]), int(c["gt_a"]), int(c["gt_b"])))
+        q.put(sorted(keys))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_and_gather_equals_single_process():
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import emu.emu as E
+    from sniffles_amd import lib, dist as sdist
+    from sniffles_amd.config import SnifflesConfig
+    E.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tasks = _tasks()
+    with lib.Batch(SnifflesConfig(), tasks, _lib=E.lib()) as b:
+        b.call_candidates(); b.finalize()
+        res = b.fetch(1)
+    exp = sorted((int(c["task_index"]), int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]), int(c["support"]),
+                  int(c["gt_a"]), int(c["gt_b"])) for c in res.calls)
+    assert got == exp and len(exp) > 50
+    # sharding is a partition and is balanced
+    shards = sdist.shard_lpt([t.contig_len for t in tasks], 2)
+    assert sorted(shards[0] + shards[1]) == list(range(len(tasks)))
+    loads = [sum(tasks[i].contig_len for i in s) for s in shards]
+    assert max(loads) <= 1.35 * min(loads)
