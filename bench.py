@@ -83,7 +83,10 @@ def main():
     batch = lib.Batch(cfg, tasks, device=local_rank)
     t_upload = time.time() - t0
 
-    cap_calls = max(1024, n_sig // 8)
+    cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # all_gather_into_tensor needs equal sizes on every rank
+    cap_calls = int(cap_t.item())
     rec_bytes = abi.CALL_DTYPE.itemsize
     send = torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
     count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -91,10 +94,17 @@ def main():
         gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
         counts = torch.zeros(world, dtype=torch.int64, device="cuda")
 
+    phase_s = [0.0, 0.0, 0.0, 0.0]
+
     def step():
+        t_a = time.perf_counter()
         batch.call_candidates()
+        t_b = time.perf_counter()
         batch.finalize()
+        t_c = time.perf_counter()
         n = batch.fetch_raw(1)  # D2H of records + ALT pool + read names (blocks)
+        t_d = time.perf_counter()
+        phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
         if world > 1:
             nexp = batch.export_calls_device(send.data_ptr(), cap_calls)
             batch.sync()
@@ -149,7 +159,10 @@ def main():
                                replicas=world, tasks=24 * world, coverage=args.coverage, scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL all_gather of call records",
-                               gen_s=round(t_gen, 2), upload_s=round(t_upload, 2)),
+                               gen_s=round(t_gen, 2), upload_s=round(t_upload, 2),
+                               host_ms_per_step=dict(enqueue_call_candidates=round(phase_s[0] / phase_s[3] * 1e3, 3),
+                                                     finalize_incl_2_syncs=round(phase_s[1] / phase_s[3] * 1e3, 3),
+                                                     fetch_d2h=round(phase_s[2] / phase_s[3] * 1e3, 3))),
                    roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args)

@@ -5,6 +5,7 @@
 #include "snf_stage_final.h"
 #include "snf_wave_refine.h"
 #include "snf_wave_cons.h"
+#include "snf_wave_call.h"
 
 #ifndef SNF_EMU
 #include <rocprim/device/device_radix_sort.hpp>
@@ -77,6 +78,31 @@ struct DevBuf { void* p; size_t bytes; };
 
 struct Timing { const char* name; float ms; int64_t bytes; int launches; };
 
+// ---- pinned, grow-only host buffers for results (pageable D2H is 3-4x slower) ----
+struct HostBuf {
+  void* p = nullptr; size_t cap = 0;
+  void* ensure(size_t bytes) {
+    if (bytes <= cap && p) return p;
+    release();
+    cap = bytes + bytes / 4 + 4096;
+#ifndef SNF_EMU
+    SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+#else
+    p = malloc(cap);
+#endif
+    return p;
+  }
+  void release() {
+    if (!p) return;
+#ifndef SNF_EMU
+    (void)hipHostFree(p);
+#else
+    free(p);
+#endif
+    p = nullptr; cap = 0;
+  }
+};
+
 struct snf_batch_impl {
   snf_config_t cfg;
   int device = 0;
@@ -105,7 +131,7 @@ struct snf_batch_impl {
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   int64_t *d_sz_tab = nullptr, *d_sz_aln = nullptr, *d_sz_rd = nullptr;
   // results (host)
-  std::vector<snf_call_t> r_calls; std::vector<uint8_t> r_alt; std::vector<uint32_t> r_rn;
+  HostBuf hb_calls, hb_alt, hb_rn;
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
   // timing
   std::vector<Timing> timings;
@@ -447,7 +473,14 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH(d1_refine, v, N, v.wave_path ? 0 : N * 36);
     prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
     LAUNCH(d1b_rctable, v, N, N * 4);
-    LAUNCH(d2_call, v, N, N * 32);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "d2w_call", N * 32);
+      hipLaunchKernelGGL(d2w_call, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
+    LAUNCH(d2_call, v, N, v.wave_path ? 0 : N * 32);
     prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
     LAUNCH(d3_compact, v, N, 0);
     LAUNCH(d3_taskoff, v, T + 1, 0);
@@ -470,6 +503,13 @@ void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N;
   if (N <= 0) return;
+#ifndef SNF_EMU
+  if (v.wave_path) {
+    Scope _s(b, "e1w_finalize", 0);
+    hipLaunchKernelGGL(e1w_finalize, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  }
+#endif
   LAUNCH(e1_finalize, v, N, 0);
   LAUNCH(e2_best, v, N, 0);
   prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_alt");
@@ -545,44 +585,44 @@ void collect_timings(snf_batch_impl* b) {
 }
 
 void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
-  (void)stage;
   View& v = b->v;
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
-  b->r_calls.clear(); b->r_alt.clear(); b->r_rn.clear();
   d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   if (b->h_cnt.overflow) fail("internal: fused-sequence pool overflow");
   int64_t nc = v.N > 0 ? b->h_cnt.n_calls : 0;
-  std::vector<snf_call_t> calls((size_t)nc);
-  std::vector<int64_t> off((size_t)T + 1, 0);
-  d2h(b, calls.data(), v.calls, (size_t)nc * sizeof(snf_call_t));
+  int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt.alt_total : 0;
+  int64_t rn_total = v.N > 0 ? b->h_cnt.rn_total : 0;
+  snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
+  uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);
+  uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
+  d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
   d2h(b, b->r_status.data(), v.t_status, (size_t)T * sizeof(int32_t));
-  d2h(b, off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t));
+  d2h(b, b->r_off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t));
   d2h(b, b->r_cov.data(), v.t_cov_avg, (size_t)T * sizeof(double));
-  int64_t alt_total = stage >= 1 ? b->h_cnt.alt_total : 0;
-  b->r_alt.resize((size_t)alt_total);
-  if (alt_total) d2h(b, b->r_alt.data(), v.alt_pool, (size_t)alt_total);
-  b->r_rn.resize((size_t)(v.N > 0 ? b->h_cnt.rn_total : 0));
-  d2h(b, b->r_rn.data(), v.rnames, b->r_rn.size() * sizeof(uint32_t));
+  if (alt_total) d2h(b, alt, v.alt_pool, (size_t)alt_total);
+  if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
   dsync(b);
-  if (v.N <= 0) std::fill(off.begin(), off.end(), 0);
-  // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls
-  b->r_calls.reserve(calls.size());
-  for (int t = 0; t < T; t++) {
-    b->r_off[t] = (int64_t)b->r_calls.size();
-    if (b->r_status[t] != SNF_TASK_OK) continue;
-    for (int64_t i = off[t]; i < off[t + 1]; i++) {
-      snf_call_t c = calls[(size_t)i];
-      if (stage < 1) { c.alt_len = -1; c.alt_off = 0; }
-      b->r_calls.push_back(c);
+  if (v.N <= 0) std::fill(b->r_off.begin(), b->r_off.end(), 0);
+  // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls: squeeze them out (rare; in place)
+  bool any_err = false;
+  for (int t = 0; t < T; t++) any_err |= b->r_status[t] != SNF_TASK_OK;
+  if (any_err) {
+    int64_t w = 0;
+    std::vector<int64_t> noff((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) {
+      noff[t] = w;
+      if (b->r_status[t] != SNF_TASK_OK) continue;
+      for (int64_t i = b->r_off[t]; i < b->r_off[t + 1]; i++) calls[w++] = calls[i];
     }
+    noff[T] = w; b->r_off = noff; nc = w;
   }
-  b->r_off[T] = (int64_t)b->r_calls.size();
+  if (stage < 1) for (int64_t i = 0; i < nc; i++) { calls[i].alt_len = -1; calls[i].alt_off = 0; }
   collect_timings(b);
-  out->n_calls = (int64_t)b->r_calls.size(); out->calls = b->r_calls.data();
-  out->alt_pool_len = (int64_t)b->r_alt.size(); out->alt_pool = b->r_alt.data();
-  out->rnames_len = (int64_t)b->r_rn.size(); out->rnames = b->r_rn.data();
+  out->n_calls = nc; out->calls = calls;
+  out->alt_pool_len = alt_total; out->alt_pool = alt;
+  out->rnames_len = rn_total; out->rnames = rn;
   out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
   out->coverage_average_total = b->r_cov.data();
 }
@@ -715,6 +755,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 #endif
   dfree_all(b);
+  b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release();
 #ifndef SNF_EMU
   if (b->stream) (void)hipStreamDestroy(b->stream);
 #endif

@@ -252,6 +252,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   if (r >= v.cnt->n_rc) { v.cdflag[r] = 0; return; }
   const snf_config_t& cfg = v.cfg;
   int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
+  if (v.wave_path && n <= 64) return;  // d2w_call (snf_wave_call.h)
   int32_t h = v.cl_head[c];
   int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
   int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo;

@@ -23,11 +23,14 @@ struct LeadIter {  // iterates cluster.leads of a call (for BND: the leads resol
   }
 };
 
-SNF_HD int distinct_strands(const View& v, const CallX& x) {
-  int f = 0, r = 0; int32_t s; uint32_t o;
-  for (LeadIter it(v, x); it.next(&s, &o);) { if (v.in_strand[o] == 0) f = 1; else r = 1; }
-  return f + r;
-}
+// per-call aggregates over cluster.leads that the scalar QC / phasing logic needs; the thread path collects them
+// serially (collect_agg), the wave path (snf_wave_call.h) with ballots and reductions
+struct LeadAgg {
+  int nstrands;          // len(set(lead.strand))
+  int64_t close_edge;    // leads with qry_start <= d or |read_len - qry_start| <= d (postprocessing.py:574-577)
+  int hp_val; int64_t hp_support, hp_other;          // phase_sv majorities (postprocessing.py:626-654)
+  int32_t ps_val; int64_t ps_support, ps_other;      // ps_val == SNF_PS_NULL_CODE: "NULL"
+};
 
 SNF_HD double py_round(double x) { return rint(x); }  // round-half-even (default rounding mode)
 
@@ -64,7 +67,7 @@ SNF_HD bool qc_sv_support(snf_call_t& c, double cov_global, const snf_config_t& 
 
 #define SNF_FAIL(f) do { c.filter = (f); return false; } while (0)
 
-SNF_HD bool qc_sv(const View& v, snf_call_t& c, const CallX& x) {
+SNF_HD bool qc_sv(const View& v, snf_call_t& c, const LeadAgg& g) {
   const snf_config_t& cfg = v.cfg;
   int t = c.svtype;
   bool single = t == SNF_SINGLE_LEFT || t == SNF_SINGLE_RIGHT;
@@ -82,7 +85,7 @@ SNF_HD bool qc_sv(const View& v, snf_call_t& c, const CallX& x) {
     if (c.support < 10 || cfg.minsvlen_hard_cap) SNF_FAIL(SNF_F_SVLEN_MIN);
   }
   if (t == SNF_BND) {
-    if (cfg.qc_bnd_filter_strand && distinct_strands(v, x) < 2) SNF_FAIL(SNF_F_STRAND_BND);
+    if (cfg.qc_bnd_filter_strand && g.nstrands < 2) SNF_FAIL(SNF_F_STRAND_BND);
   }
   double up = c.cov[0], ce = c.cov[2], dn = c.cov[4];
   if (t == SNF_DEL && cfg.long_del_length != -1 && iabs64(c.svlen) >= cfg.long_del_length && !cfg.mosaic &&
@@ -123,16 +126,21 @@ SNF_HD bool qc_sv(const View& v, snf_call_t& c, const CallX& x) {
   return true;
 }
 
-// phase_sv: majority HP / PS over distinct read_id (last lead of a read wins)
-SNF_HD void phase_sv(const View& v, snf_call_t& c, const CallX& x, int task, int* hp_ret, int* ps_ret) {
+// phase_sv: majority HP / PS over distinct read_id (last lead of a read wins); fills the phase part of LeadAgg
+SNF_HD void collect_agg(const View& v, const CallX& x, int task, LeadAgg* g) {
   int64_t hc[3] = {0, 0, 0};
   int32_t* a0 = v.w0 + x.flo;
   int32_t np_ = 0;
   int32_t ps_null = v.t_ps_null[task];
+  int f = 0, r = 0; int64_t close = 0;
   for (int32_t k = 0; k < x.fn; k++) {
     int32_t s = v.FI[x.flo + k];
     if (!v.F_sel[s]) continue;
     uint32_t o = (uint32_t)v.F_orig[s];
+    if (v.in_strand[o] == 0) f = 1; else r = 1;
+    int64_t qs = v.in_qry_start[o];
+    if (qs <= v.cfg.dev_min_close_edge_dist || iabs64((int64_t)v.in_read_len[o] - qs) <= v.cfg.dev_min_close_edge_dist) close++;
+    if (!v.cfg.phase) continue;
     uint32_t rid = v.in_read_id[o];
     bool later = false;
     for (int32_t k2 = k + 1; k2 < x.fn; k2++) {
@@ -144,6 +152,7 @@ SNF_HD void phase_sv(const View& v, snf_call_t& c, const CallX& x, int task, int
     int32_t p = v.in_ps[o];
     a0[np_++] = (p == SNF_PS_NONE || p == ps_null) ? SNF_PS_NULL_CODE : p;
   }
+  g->nstrands = f + r; g->close_edge = close;
   // most_common: sorted((count, value), reverse=True)
   int hpv = 0; int64_t hp_support = -1;
   for (int h = 0; h < 3; h++) if (hc[h] > 0 && hc[h] >= hp_support) { hp_support = hc[h]; hpv = h; }
@@ -162,14 +171,19 @@ SNF_HD void phase_sv(const View& v, snf_call_t& c, const CallX& x, int task, int
     if (a0[i] != psv && a0[i] != SNF_PS_NULL_CODE) other_ps += j - i;
     i = j;
   }
-  bool hp_pass = ((double)other_hp / (double)(hp_support + other_hp) < v.cfg.phase_conflict_threshold) && hp_support > 0;
-  bool ps_pass = ((double)other_ps / (double)(ps_support + other_ps) < v.cfg.phase_conflict_threshold) &&
-                 psv != SNF_PS_NULL_CODE && ps_support > 0;
-  c.ph_set = 1; c.ph_hp = hpv; c.ph_ps = psv == SNF_PS_NULL_CODE ? -2 : psv;
-  c.ph_hp_support = (int32_t)hp_support; c.ph_ps_support = (int32_t)ps_support;
+  g->hp_val = hpv; g->hp_support = hp_support; g->hp_other = other_hp;
+  g->ps_val = psv; g->ps_support = ps_support; g->ps_other = other_ps;
+}
+
+SNF_HD void phase_sv(const View& v, snf_call_t& c, const LeadAgg& g, int* hp_ret, int* ps_ret) {
+  bool hp_pass = ((double)g.hp_other / (double)(g.hp_support + g.hp_other) < v.cfg.phase_conflict_threshold) && g.hp_support > 0;
+  bool ps_pass = ((double)g.ps_other / (double)(g.ps_support + g.ps_other) < v.cfg.phase_conflict_threshold) &&
+                 g.ps_val != SNF_PS_NULL_CODE && g.ps_support > 0;
+  c.ph_set = 1; c.ph_hp = g.hp_val; c.ph_ps = g.ps_val == SNF_PS_NULL_CODE ? -2 : g.ps_val;
+  c.ph_hp_support = (int32_t)g.hp_support; c.ph_ps_support = (int32_t)g.ps_support;
   c.ph_hp_pass = hp_pass; c.ph_ps_pass = ps_pass;
-  *hp_ret = ((hpv == 1 || hpv == 2) && hp_pass) ? hpv : -1;
-  *ps_ret = ps_pass ? psv : -1;
+  *hp_ret = ((g.hp_val == 1 || g.hp_val == 2) && hp_pass) ? g.hp_val : -1;
+  *ps_ret = ps_pass ? g.ps_val : -1;
 }
 
 SNF_HD bool coverage_from_list(const int64_t* lst, int k, int64_t* out) {
@@ -222,7 +236,7 @@ SNF_HD void genotype_sv(const View& v, snf_call_t& c, int hp_ret, int ps_ret) {
   if (a == 1 && b == 1 && c.ph_set && c.ph_hp != 0) { c.ph_hp_pass = 1; c.gt_hp = c.ph_hp; c.gt_ps = c.ph_ps; }
 }
 
-SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const CallX& x, int task) {
+SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const LeadAgg& g, int task) {
   const snf_config_t& cfg = v.cfg;
   int t = c.svtype;
   double af = (c.vaf != c.vaf) ? 0.0 : c.vaf;
@@ -253,9 +267,9 @@ SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const CallX& x, in
   if (t != SNF_BND) {
     bool is_long_ins = t == SNF_INS && c.svlen >= cfg.long_ins_length;
     if (!(cfg.mosaic && sv_is_mosaic) && cfg.qc_strand) {
-      if (!is_long_ins && distinct_strands(v, x) < 2) SNF_FAIL(SNF_F_STRAND);
+      if (!is_long_ins && g.nstrands < 2) SNF_FAIL(SNF_F_STRAND);
     } else if ((cfg.mosaic && sv_is_mosaic) && cfg.mosaic_qc_strand) {
-      if (!is_long_ins && distinct_strands(v, x) < 2 && c.support >= cfg.mosaic_use_strand_thresholds) SNF_FAIL(SNF_F_STRAND_MOSAIC);
+      if (!is_long_ins && g.nstrands < 2 && c.support >= cfg.mosaic_use_strand_thresholds) SNF_FAIL(SNF_F_STRAND_MOSAIC);
     }
   }
   if (cfg.mosaic && sv_is_mosaic) {
@@ -270,11 +284,7 @@ SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const CallX& x, in
     if (sv_is_mosaic && (af < cfg.mosaic_af_min || af > cfg.mosaic_af_max)) SNF_FAIL(SNF_F_MOSAIC_VAF);
     else if (!sv_is_mosaic && !cfg.mosaic_include_germline) SNF_FAIL(SNF_F_NOT_MOSAIC_VAF);
     if (sv_is_mosaic && t != SNF_BND && t != SNF_SINGLE_LEFT && t != SNF_SINGLE_RIGHT) {
-      int64_t close = 0; int32_t s; uint32_t o;
-      for (LeadIter it(v, x); it.next(&s, &o);) {
-        int64_t qs = v.in_qry_start[o];
-        if (qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)v.in_read_len[o] - qs) <= cfg.dev_min_close_edge_dist) close++;
-      }
+      int64_t close = g.close_edge;
       if ((double)close / (double)c.support >= cfg.dev_min_read_close_edge_prop) SNF_FAIL(SNF_F_MOSAIC_SV_CLOSE_EDGE);
     }
   }
@@ -318,23 +328,31 @@ SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int tas
   }
 }
 
+// scalar tail of finalize_candidates for one call, given the lead aggregates
+SNF_HD void finalize_call(const View& v, snf_call_t& c, const CallX& x, const LeadAgg& g, int task) {
+  const snf_config_t& cfg = v.cfg;
+  c.qc = c.qc && qc_sv(v, c, g);
+  if (!cfg.mosaic && c.qc) c.qc = c.qc && qc_sv_support(c, v.t_cov_avg[task], cfg);
+  int hp_ret = -1, ps_ret = -1;
+  if (cfg.phase) phase_sv(v, c, g, &hp_ret, &ps_ret);
+  genotype_sv(v, c, hp_ret, ps_ret);
+  c.qc = c.qc && qc_sv_post_annotate(v, c, g, task);
+  bool phasing_rescue = c.svtype != SNF_BND && iabs64(c.svlen) <= cfg.dev_maxsvlen_extra &&
+                        c.support >= (int)((double)cfg.dev_minreads_extra * 0.60);
+  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing(v, c, x, task);
+}
+
 SNF_HD void e1_finalize_body(int64_t i, const View& v) {
   if (i >= v.cnt->n_calls) return;
   snf_call_t& cref = v.calls[i];
   int task = cref.task_index;
   if (v.t_status[task] != SNF_TASK_OK) return;
-  const snf_config_t& cfg = v.cfg;
-  snf_call_t c = cref;
   const CallX x = v.callx[i];
-  c.qc = c.qc && qc_sv(v, c, x);
-  if (!cfg.mosaic && c.qc) c.qc = c.qc && qc_sv_support(c, v.t_cov_avg[task], cfg);
-  int hp_ret = -1, ps_ret = -1;
-  if (cfg.phase) phase_sv(v, c, x, task, &hp_ret, &ps_ret);
-  genotype_sv(v, c, hp_ret, ps_ret);
-  c.qc = c.qc && qc_sv_post_annotate(v, c, x, task);
-  bool phasing_rescue = c.svtype != SNF_BND && iabs64(c.svlen) <= cfg.dev_maxsvlen_extra &&
-                        c.support >= (int)((double)cfg.dev_minreads_extra * 0.60);
-  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing(v, c, x, task);
+  if (v.wave_path && x.fn <= 64) return;  // e1w_finalize (snf_wave_call.h)
+  snf_call_t c = cref;
+  LeadAgg g;
+  collect_agg(v, x, task, &g);
+  finalize_call(v, c, x, g, task);
   cref = c;
 }
 

@@ -1,0 +1,274 @@
+// snf_wave_call.h - gfx950 wave-per-cluster implementations of sv.call_from / resolve_bnd (sv.py:497-639) and of
+// the lead aggregates Task.finalize_candidates needs (strand set, phase majorities; postprocessing.py:626-654).
+// One refined cluster (<= 64 leads) per wave, one lead per lane; sorts are rank sorts in registers, medians /
+// modes / trimmed variances are ballots and butterfly reductions over the sorted lanes.  Larger clusters use the
+// thread-per-cluster bodies (d2_call_body / e1_finalize_body), which are also what the host emulation runs.
+#pragma once
+#include "snf_wave_refine.h"
+
+#ifndef SNF_EMU
+namespace snf {
+
+struct CallLds { int32_t buf[SNF_WAVE]; };
+
+SNF_D int64_t wave_sum64(int64_t x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, SNF_WAVE);
+  return x;
+}
+SNF_D int wave_max32(int x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(x, d, SNF_WAVE); if (y > x) x = y; }
+  return x;
+}
+
+// ascending sort of the active lanes' values; returns the value at sorted position `lane` (lanes >= n: garbage)
+SNF_D int32_t wave_sort_i32(int32_t x, bool act, int n, int lane, int32_t* lds) {
+  const uint64_t key = act ? (((uint64_t)((uint32_t)x ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+  const int rank = wave_rank(key, n);
+  __syncthreads();
+  if (act) lds[rank] = x;
+  __syncthreads();
+  return lds[lane < n ? lane : 0];
+}
+
+// util.median_modes == center on lanes 0..n-1 holding a sorted array (util.py:49-58)
+SNF_D int32_t wave_center_sorted(int32_t s, int n, int lane) {
+  const int32_t p = __shfl_up(s, 1, SNF_WAVE);
+  const bool start = lane < n && (lane == 0 || p != s);
+  const unsigned long long smask = __ballot(start);
+  const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+  const int len = start ? ((above ? lane + 1 + __builtin_ctzll(above) : n) - lane) : 0;
+  const int maxc = wave_max32(len);
+  const bool q = start && (maxc - len < 3);
+  const unsigned long long qmask = __ballot(q);
+  const int k = __builtin_popcountll(qmask), want = k / 2;
+  // the want-th set bit of qmask
+  unsigned long long m = qmask;
+  for (int i = 0; i < want; i++) m &= m - 1;
+  const int src = __builtin_ctzll(m);
+  return __shfl(s, src, SNF_WAVE);
+}
+
+// util.stdev(util.trim(sorted)) (util.py:25-27,82-88): exact 128-bit variance, one division, sqrt
+SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
+  const int trim_n = (int)((double)n / 100.0 * 25.0);
+  const int lo = trim_n > 0 ? trim_n : 0, hi = trim_n > 0 ? n - trim_n : n;
+  const int cnt = hi - lo;
+  if (cnt < 2) return 0.0;
+  const int64_t x0 = __shfl(s, lo, SNF_WAVE);
+  const bool in = lane >= lo && lane < hi;
+  const uint64_t d = in ? (uint64_t)((int64_t)s - x0) : 0;  // sorted: d >= 0, < 2^32
+  const uint64_t d2 = d * d;
+  const int64_t S1 = wave_sum64((int64_t)d);
+  const int64_t lo32 = wave_sum64((int64_t)(d2 & 0xffffffffull)), hi32 = wave_sum64((int64_t)(d2 >> 32));
+  const u128 S2 = ((u128)(uint64_t)hi32 << 32) + (u128)(uint64_t)lo32;
+  return stdev_from_sums(cnt, (i128)S1, S2);
+}
+
+// ------------------------------------------------------------------------------------------ d2w: call_from
+__global__ void __launch_bounds__(SNF_WAVE) d2w_call(const View v, int64_t n_unused) {
+  __shared__ CallLds lds;
+  const int lane = threadIdx.x;
+  const snf_config_t& cfg = v.cfg;
+  const int64_t n_rc = v.cnt->n_rc;
+  for (int64_t r = blockIdx.x; r < n_rc; r += gridDim.x) {
+    const int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
+    if (n > SNF_WAVE) continue;  // thread path
+    const int32_t h = v.cl_head[c];
+    const int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
+    const bool act = lane < n;
+    int32_t slot = 0; uint32_t o = 0; int32_t svl = 0, rs = 0; uint32_t qn = 0;
+    int mapq = 0, strand = 0, is_sa = 0, noninline = 0; double nm = 0;
+    int32_t mctg = 0, mpos = 0; int bfirst = 0, brev = 0;
+    if (act) {
+      slot = v.FI[flo + lane]; o = (uint32_t)v.F_orig[slot]; svl = v.F_svlen[slot];
+      rs = v.in_ref_start[o]; qn = v.in_qname[o]; mapq = v.in_mapq[o]; strand = v.in_strand[o]; is_sa = v.in_is_sa[o];
+      noninline = v.in_source[o] != SNF_SRC_INLINE;
+      if (cfg.qc_nm_measure) nm = v.in_nm[o];
+      if (svtype == SNF_BND) { mctg = v.in_mate_contig[o]; mpos = v.in_mate_pos[o]; bfirst = v.in_first[o]; brev = v.in_rev[o]; }
+      v.F_sel[slot] = 1;
+    }
+    if (lane == 0) v.cdflag[r] = 0;
+    const int32_t s_svl = wave_sort_i32(svl, act, n, lane, lds.buf);
+    const int64_t svlen = wave_center_sorted(s_svl, n, lane);
+    const bool single = svtype == SNF_SINGLE_LEFT || svtype == SNF_SINGLE_RIGHT;
+    if (!single && svtype != SNF_BND && iabs64(svlen) < cfg.minsvlen_screen) continue;
+    // distinct read names, sorted (kept in w1 for d3_rnames)
+    const int32_t s_qn = wave_sort_i32((int32_t)qn, act, n, lane, lds.buf);
+    const int32_t p_qn = __shfl_up(s_qn, 1, SNF_WAVE);
+    const bool qfirst = act && (lane == 0 || p_qn != s_qn);
+    const unsigned long long qmask = __ballot(qfirst);
+    int64_t nq = __builtin_popcountll(qmask);
+    int32_t* a1 = v.w1 + flo;
+    if (qfirst) a1[__builtin_popcountll(qmask & ((1ull << lane) - 1ull))] = s_qn;
+    __syncthreads();
+    int64_t support = nq, support_long = 0;
+    const int32_t llo = v.seedL_lo[h], lhi = v.seedL_hi[v.c_last[h]];
+    const bool keeplong = v.rc_keeplong[r] && svtype == SNF_INS;
+    if (svtype == SNF_INS && svlen >= cfg.long_ins_length) {
+      int cl = 0, cu = 0;
+      for (int32_t x0 = llo; x0 < lhi; x0 += SNF_WAVE) {
+        const int32_t x = x0 + lane;
+        if (x < lhi) {
+          const int32_t q = (int32_t)v.in_qname[v.LL[x]];
+          bool first = true;
+          for (int32_t y = llo; y < x; y++) if ((int32_t)v.in_qname[v.LL[y]] == q) { first = false; break; }
+          if (first) { cl++; if (!contains_sorted_i32(a1, nq, q)) cu++; }
+        }
+      }
+      support_long = wave_sum64(cl); support += wave_sum64(cu);
+    }
+    const int32_t s_rs = wave_sort_i32(rs, act, n, lane, lds.buf);
+    const int64_t ref_start = wave_center_sorted(s_rs, n, lane);
+    const double stdev_pos = wave_stdev_trim_sorted(s_rs, n, lane);
+    double stdev_len = NAN; bool precise;
+    if (svtype != SNF_BND) { stdev_len = wave_stdev_trim_sorted(s_svl, n, lane); precise = (stdev_pos + stdev_len < (double)cfg.precise); }
+    else precise = stdev_pos < (double)cfg.precise;
+    int64_t svstart, svend;
+    if (svtype == SNF_INS) { svstart = ref_start; svend = ref_start; }
+    else if (svtype == SNF_DEL) { svstart = ref_start + svlen; svend = ref_start; }
+    else { svstart = ref_start; svend = svstart + iabs64(svlen); }
+    const int64_t msum = wave_sum64(act ? mapq : 0);
+    const int64_t fwd = __builtin_popcountll(__ballot(act && strand == 0));
+    int64_t sa = __builtin_popcountll(__ballot(act && is_sa));
+    const int64_t src_noninline = __builtin_popcountll(__ballot(act && noninline));
+    double nmsum = 0;
+    if (cfg.qc_nm_measure) {  // Python sum(): left to right
+      for (int i = 0; i < n; i++) {
+        const uint64_t bits = wave_bcast_u64((uint64_t)__double_as_longlong(nm), i);
+        nmsum += __longlong_as_double((long long)bits);
+      }
+    }
+    int64_t n_all = n;
+    if (keeplong) {
+      int cs = 0;
+      for (int32_t x = llo + lane; x < lhi; x += SNF_WAVE) cs += v.in_is_sa[v.LL[x]];
+      sa += wave_sum64(cs); n_all += lhi - llo;
+    }
+    snf_call_t cc;
+    memset(&cc, 0, sizeof(cc));
+    cc.task_index = task; cc.svtype = svtype; cc.pos = (int32_t)svstart; cc.end = (int32_t)svend; cc.svlen = (int32_t)svlen;
+    cc.support = (int32_t)support; cc.support_long = -1; cc.support_sa = -1;
+    cc.qual = (int32_t)((double)msum / (double)n); cc.precise = precise; cc.fwd = (int32_t)fwd; cc.rev = (int32_t)(n - fwd);
+    cc.qc = 1; cc.filter = SNF_F_PASS;
+    cc.nm = cfg.qc_nm_measure ? nmsum / (double)n : -1.0;
+    cc.stdev_pos = stdev_pos; cc.stdev_len = stdev_len;
+    cc.sa_count = (int32_t)sa; cc.sa_frac = (double)sa / (double)n_all; cc.n_leads = n;
+    cc.mate_contig = -1; cc.gt_hp = -1; cc.gt_ps = -1; cc.vaf = NAN; cc.alt_len = -1;
+    cc.cluster_start = v.seed_start[h]; cc.cluster_end = v.c_end[h];
+    cc.cluster_seed_index = v.seed_bin[h] - v.grp_first_bin[g];
+    int64_t rn_len = support;
+    if (svtype == SNF_BND) {  // resolve_bnd (sv.py:625-639)
+      const int32_t s_mc = wave_sort_i32(mctg, act, n, lane, lds.buf);
+      const int32_t p_mc = __shfl_up(s_mc, 1, SNF_WAVE);
+      const bool st = act && (lane == 0 || p_mc != s_mc);
+      const unsigned long long smask = __ballot(st);
+      const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+      const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : n) - lane) : 0;
+      const int maxc = wave_max32(len);
+      const unsigned long long best = __ballot(st && len == maxc);
+      const int32_t mc = __shfl(s_mc, __builtin_ctzll(best), SNF_WAVE);  // most_common_top: ties -> smallest value
+      const bool sel = act && mctg == mc;
+      if (act) v.F_sel[slot] = sel ? 1 : 0;
+      const unsigned long long selmask = __ballot(sel);
+      const int ns = __builtin_popcountll(selmask);
+      const int64_t nfirst = __builtin_popcountll(__ballot(sel && bfirst)), nrev = __builtin_popcountll(__ballot(sel && brev));
+      // selected values packed to the front by sorting with +inf for the rest
+      const int32_t s_mp = wave_sort_i32(sel ? mpos : INT32_MAX, act, n, lane, lds.buf);
+      const int64_t mate_pos = wave_center_sorted(s_mp, ns, lane);
+      const int32_t s_q2 = wave_sort_i32(sel ? (int32_t)qn : INT32_MAX, act, n, lane, lds.buf);
+      const int32_t p_q2 = __shfl_up(s_q2, 1, SNF_WAVE);
+      const bool qf2 = lane < ns && (lane == 0 || p_q2 != s_q2);
+      const unsigned long long qm2 = __ballot(qf2);
+      nq = __builtin_popcountll(qm2);
+      __syncthreads();
+      if (qf2) a1[__builtin_popcountll(qm2 & ((1ull << lane) - 1ull))] = s_q2;
+      cc.support = (int32_t)nq; rn_len = nq;
+      cc.mate_contig = mc; cc.mate_ref_start = (int32_t)mate_pos;
+      cc.bnd_is_first = (nfirst > ns - nfirst) ? 1 : 0;   // most_common_top: ties -> False
+      cc.bnd_is_reverse = (nrev > ns - nrev) ? 1 : 0;
+      cc.n_leads = ns;
+    } else if (svtype == SNF_INS) cc.support_long = (int32_t)support_long;
+    else if (svtype == SNF_DEL) cc.support_sa = (int32_t)src_noninline;
+    cc.rn_len = (int32_t)rn_len;
+    cc.rn_off = nq;  // stash: number of distinct names already sorted in w1[flo..]
+    if (lane == 0) {
+      v.cand[r] = cc;
+      CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
+      v.candx[r] = x;
+      v.cdflag[r] = 1;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------ e1w: finalize
+__global__ void __launch_bounds__(SNF_WAVE) e1w_finalize(const View v, int64_t n_unused) {
+  __shared__ CallLds lds;
+  const int lane = threadIdx.x;
+  const snf_config_t& cfg = v.cfg;
+  const int64_t n_calls = v.cnt->n_calls;
+  for (int64_t i = blockIdx.x; i < n_calls; i += gridDim.x) {
+    const int task = v.calls[i].task_index;
+    if (v.t_status[task] != SNF_TASK_OK) continue;
+    const CallX x = v.callx[i];
+    if (x.fn > SNF_WAVE) continue;  // thread path
+    const int n = x.fn;
+    bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
+    if (lane < n) {
+      const int32_t s = v.FI[x.flo + lane];
+      sel = v.F_sel[s] != 0; o = (uint32_t)v.F_orig[s];
+      strand = v.in_strand[o]; hap = v.in_hap[o]; rid = v.in_read_id[o];
+      const int32_t p = v.in_ps[o];
+      ps = (p == SNF_PS_NONE || p == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : p;
+      const int64_t qs = v.in_qry_start[o];
+      close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)v.in_read_len[o] - qs) <= cfg.dev_min_close_edge_dist;
+    }
+    LeadAgg g;
+    g.nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
+    g.close_edge = __builtin_popcountll(__ballot(sel && close));
+    g.hp_val = 0; g.hp_support = -1; g.hp_other = 0; g.ps_val = 0; g.ps_support = -1; g.ps_other = 0;
+    if (cfg.phase) {
+      // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
+      bool later = false;
+      for (int k = 0; k < n; k++) {
+        const uint32_t rk = (uint32_t)wave_bcast_i32((int32_t)rid, k);
+        const bool sk = wave_bcast_i32(sel ? 1 : 0, k) != 0;
+        if (k > lane && sk && rk == rid) later = true;
+      }
+      const bool contrib = sel && !later;
+      int64_t hc[3];
+      for (int hh = 0; hh < 3; hh++) hc[hh] = __builtin_popcountll(__ballot(contrib && hap == hh));
+      for (int hh = 0; hh < 3; hh++) if (hc[hh] > 0 && hc[hh] >= g.hp_support) { g.hp_support = hc[hh]; g.hp_val = hh; }
+      for (int hh = 0; hh < 3; hh++) if (hh != g.hp_val) g.hp_other += hc[hh];
+      const int np_ = __builtin_popcountll(__ballot(contrib));
+      // phase sets of the contributing reads, sorted (non-contributors sort behind: rank sort on a wider key)
+      const uint64_t key = contrib ? (((uint64_t)((uint32_t)ps ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+      const int rank = wave_rank(key, n);
+      __syncthreads();
+      if (contrib) lds.buf[rank] = ps;
+      __syncthreads();
+      const int32_t s_ps = lds.buf[lane < np_ ? lane : 0];
+      const int32_t p_ps = __shfl_up(s_ps, 1, SNF_WAVE);
+      const bool st = lane < np_ && (lane == 0 || p_ps != s_ps);
+      const unsigned long long smask = __ballot(st);
+      const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+      const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : np_) - lane) : 0;
+      const int maxc = wave_max32(len);
+      const unsigned long long best = __ballot(st && len == maxc);
+      const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
+      g.ps_val = __shfl(s_ps, bl, SNF_WAVE); g.ps_support = maxc;
+      g.ps_other = wave_sum64((st && s_ps != g.ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
+      __syncthreads();
+    }
+    if (lane == 0) {
+      snf_call_t c = v.calls[i];
+      finalize_call(v, c, x, g, task);
+      v.calls[i] = c;
+    }
+  }
+}
+
+}  // namespace snf
+#endif  // !SNF_EMU
