@@ -106,7 +106,12 @@ struct HostBuf {
 struct snf_batch_impl {
   snf_config_t cfg;
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // main stream (also the one fetch/sync wait on)
+  hipStream_t stream2 = nullptr;  // side stream: read preparation, finalize scalar kernels
+  hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
+  int cur_slot = 0;
+  bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
+  bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
   bool uploaded = false;
   int run_gap = 1000;
   // host staging
@@ -126,7 +131,10 @@ struct snf_batch_impl {
   View v{};
   ReadPrep rp{};
   Counts h_cnt{};
-  void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+  void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
+#ifndef SNF_EMU
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+#endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   int64_t *d_sz_tab = nullptr, *d_sz_aln = nullptr, *d_sz_rd = nullptr;
@@ -181,7 +189,7 @@ void dfree_one(snf_batch_impl* b, void* p) {
 void h2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
 #ifndef SNF_EMU
-  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->stream));
+  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->cur));
 #else
   memcpy(dst, src, bytes);
 #endif
@@ -189,7 +197,7 @@ void h2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
 void d2h(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
 #ifndef SNF_EMU
-  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->stream));
+  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->cur));
 #else
   memcpy(dst, src, bytes);
 #endif
@@ -197,14 +205,40 @@ void d2h(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
 void dzero(snf_batch_impl* b, void* p, size_t bytes, int val = 0) {
   if (!bytes) return;
 #ifndef SNF_EMU
-  SNF_HIP(hipMemsetAsync(p, val, bytes, b->stream));
+  SNF_HIP(hipMemsetAsync(p, val, bytes, b->cur));
 #else
   memset(p, val, bytes);
 #endif
 }
 void dsync(snf_batch_impl* b) {
 #ifndef SNF_EMU
-  SNF_HIP(hipStreamSynchronize(b->stream));
+  SNF_HIP(hipStreamSynchronize(b->cur));
+#endif
+}
+// enqueue on the side stream for the lifetime of this object; fork()/join() order it against the main stream
+void fork_mark(snf_batch_impl* b) {  // point on the main stream the side stream may start after
+#ifndef SNF_EMU
+  SNF_HIP(hipEventRecord(b->ev_fork, b->stream));
+#endif
+}
+struct SideStream {
+  snf_batch_impl* b;
+  SideStream(snf_batch_impl* b_) : b(b_) {
+#ifndef SNF_EMU
+    SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
+    b->cur = b->stream2; b->cur_slot = 1;
+#endif
+  }
+  ~SideStream() {
+#ifndef SNF_EMU
+    (void)hipEventRecord(b->ev_join, b->stream2);
+    b->cur = b->stream; b->cur_slot = 0;
+#endif
+  }
+};
+void join_side(snf_batch_impl* b) {  // main stream waits for everything enqueued on the side stream so far
+#ifndef SNF_EMU
+  SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
 #endif
 }
 template <class T>
@@ -229,30 +263,43 @@ struct Scope {
     }
     idx = b->ev_used++;
     b->evs[idx].name = name; b->evs[idx].bytes = bytes;
-    SNF_HIP(hipEventRecord(b->evs[idx].a, b->stream));
+    SNF_HIP(hipEventRecord(b->evs[idx].a, b->cur));
 #else
     (void)name; (void)bytes;
 #endif
   }
   ~Scope() {
 #ifndef SNF_EMU
-    (void)hipEventRecord(b->evs[idx].b, b->stream);
+    (void)hipEventRecord(b->evs[idx].b, b->cur);
 #endif
   }
 };
 
 #ifndef SNF_EMU
+// LAUNCH_Q: tiny kernels are only bracketed by events when SNF_TIME_ALL=1 (two event records cost more host time
+// than the launch itself and the stage A-C region is launch-bound)
+#define LAUNCH_Q(kern, view, n, bytes)                                                        \
+  do {                                                                                        \
+    int64_t _n = (n);                                                                         \
+    if (_n > 0) {                                                                             \
+      if (b->time_all) { Scope _s(b, #kern, (bytes));                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->cur, view, _n); } \
+      else hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->cur, view, _n); \
+      SNF_HIP(hipGetLastError());                                                             \
+    }                                                                                         \
+  } while (0)
 #define LAUNCH(kern, view, n, bytes)                                                          \
   do {                                                                                        \
     int64_t _n = (n);                                                                         \
     if (_n > 0) {                                                                             \
       Scope _s(b, #kern, (bytes));                                                            \
-      hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->stream, view, _n); \
+      hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->cur, view, _n); \
       SNF_HIP(hipGetLastError());                                                             \
     }                                                                                         \
   } while (0)
 #else
 #define LAUNCH(kern, view, n, bytes) do { int64_t _n = (n); if (_n > 0) kern(view, _n); } while (0)
+#define LAUNCH_Q(kern, view, n, bytes) LAUNCH(kern, view, n, bytes)
 #endif
 
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
@@ -261,13 +308,14 @@ void prim_sort_pairs(snf_batch_impl* b, const uint64_t* kin, uint64_t* kout, con
   if (n <= 0) return;
 #ifndef SNF_EMU
   size_t need = 0;
-  SNF_HIP(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->stream));
-  if (need > b->sort_tmp_bytes) {
-    if (b->sort_tmp) { dsync(b); dfree_one(b, b->sort_tmp); }
-    b->sort_tmp = dalloc<uint8_t>(b, need); b->sort_tmp_bytes = need;
+  SNF_HIP(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
+  void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
+  if (need > tmpb) {
+    if (tmp) { dsync(b); dfree_one(b, tmp); }
+    tmp = dalloc<uint8_t>(b, need); tmpb = need;
   }
   Scope s(b, name, n * 24);
-  SNF_HIP(rocprim::radix_sort_pairs(b->sort_tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->stream));
+  SNF_HIP(rocprim::radix_sort_pairs(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
 #else
   (void)end_bit; (void)name;
   std::vector<int64_t> idx(n);
@@ -281,13 +329,15 @@ void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* 
   if (n <= 0) return;
 #ifndef SNF_EMU
   size_t need = 0;
-  SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->stream));
-  if (need > b->sort_tmp_bytes) {
-    if (b->sort_tmp) { dsync(b); dfree_one(b, b->sort_tmp); }
-    b->sort_tmp = dalloc<uint8_t>(b, need); b->sort_tmp_bytes = need;
+  SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
+  void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
+  if (need > tmpb) {
+    if (tmp) { dsync(b); dfree_one(b, tmp); }
+    tmp = dalloc<uint8_t>(b, need); tmpb = need;
   }
-  Scope s(b, name, n * 2 * (int64_t)sizeof(T));
-  SNF_HIP(rocprim::exclusive_scan(b->sort_tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->stream));
+  if (b->time_all) { Scope s(b, name, n * 2 * (int64_t)sizeof(T));
+    SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur)); }
+  else SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
 #else
   (void)name;
   T acc = 0;
@@ -427,69 +477,78 @@ void run_call_candidates(snf_batch_impl* b) {
   dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
-  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state)
+  fork_mark(b);  // the read-preparation branch (enqueued below, after the critical path) may start here
+  if (N > 0) {
+    uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
+    for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
+    LAUNCH(a1_keys, v, N, N * 21);
+    prim_sort_pairs(b, v.key_in, v.key_out, v.val_in, v.val_out, N, 35 + bits_for((uint64_t)T), "sort_lead_keys");
+    LAUNCH_Q(a2_heads, v, N, N * 12);
+    prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
+    LAUNCH_Q(a3_bins, v, N, N * 8);
+    LAUNCH(a4_binstats, v, N, N * 16);
+    prim_exscan<uint32_t>(b, v.eligflag, v.eligscan, N + 1, "scan_seeds");
+    LAUNCH_Q(a5_leadflags, v, N, N * 12);
+    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_leads");
+    prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_leads_long");
+    LAUNCH_Q(a6_scatter, v, N, N * 16);
+    LAUNCH_Q(a7_seeds, v, N, N * 4);
+    LAUNCH(b1_seedmetrics, v, N, N * 8);
+    prim_exscan<uint32_t>(b, v.runflag, v.runscan, N + 1, "scan_runs");
+    LAUNCH_Q(b2_runs, v, N, N * 4);
+    LAUNCH(c1_mergeruns, v, N, N * 8);
+    LAUNCH_Q(c2_validate, v, N, 0);
+    LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
+    prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
+    LAUNCH_Q(c4_clusters, v, N, N * 4);
+    dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "d1w_refine", N * 36);
+      hipLaunchKernelGGL(d1w_refine, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
+    LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);
+    prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
+    LAUNCH_Q(d1b_rctable, v, N, N * 4);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "d2w_call", N * 32);
+      hipLaunchKernelGGL(d2w_call, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
+    LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
+    prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
+    LAUNCH_Q(d3_compact, v, N, 0);
+    LAUNCH_Q(d3_taskoff, v, T + 1, 0);
+    LAUNCH_Q(d3_svid, v, N, 0);
+    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_rnames");
+    LAUNCH_Q(d3_stale, v, T, 0);
+    LAUNCH(d3_rnames, v, N, 0);
+  }
+  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state); independent of the
+  // lead pipeline until d4_coverage, so it runs on the side stream
+  {
+  SideStream side(b);
   if (R > 0) {
     LAUNCH(r1_endkeys, b->rp, R, R * 13);
     prim_sort_pairs(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, 32 + bits_for((uint64_t)T), "sort_read_ends");
-    LAUNCH(r2_unpack, b->rp, R, R * 16);
+    LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
     for (int h = 0; h < 3; h++) {
       prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
       prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
     }
     LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
   }
-  LAUNCH(d5_covavg, v, T, 0);
-  if (N > 0) {
-    uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
-    for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
-    LAUNCH(a1_keys, v, N, N * 21);
-    prim_sort_pairs(b, v.key_in, v.key_out, v.val_in, v.val_out, N, 35 + bits_for((uint64_t)T), "sort_lead_keys");
-    LAUNCH(a2_heads, v, N, N * 12);
-    prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
-    LAUNCH(a3_bins, v, N, N * 8);
-    LAUNCH(a4_binstats, v, N, N * 16);
-    prim_exscan<uint32_t>(b, v.eligflag, v.eligscan, N + 1, "scan_seeds");
-    LAUNCH(a5_leadflags, v, N, N * 12);
-    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_leads");
-    prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_leads_long");
-    LAUNCH(a6_scatter, v, N, N * 16);
-    LAUNCH(a7_seeds, v, N, N * 4);
-    LAUNCH(b1_seedmetrics, v, N, N * 8);
-    prim_exscan<uint32_t>(b, v.runflag, v.runscan, N + 1, "scan_runs");
-    LAUNCH(b2_runs, v, N, N * 4);
-    LAUNCH(c1_mergeruns, v, N, N * 8);
-    LAUNCH(c2_validate, v, N, 0);
-    LAUNCH(c3_serial, v, 8 * (int64_t)T, 0);
-    prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
-    LAUNCH(c4_clusters, v, N, N * 4);
-    dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
-#ifndef SNF_EMU
-    if (v.wave_path) {
-      Scope _s(b, "d1w_refine", N * 36);
-      hipLaunchKernelGGL(d1w_refine, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    }
-#endif
-    LAUNCH(d1_refine, v, N, v.wave_path ? 0 : N * 36);
-    prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
-    LAUNCH(d1b_rctable, v, N, N * 4);
-#ifndef SNF_EMU
-    if (v.wave_path) {
-      Scope _s(b, "d2w_call", N * 32);
-      hipLaunchKernelGGL(d2w_call, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    }
-#endif
-    LAUNCH(d2_call, v, N, v.wave_path ? 0 : N * 32);
-    prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
-    LAUNCH(d3_compact, v, N, 0);
-    LAUNCH(d3_taskoff, v, T + 1, 0);
-    LAUNCH(d3_svid, v, N, 0);
-    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_rnames");
-    LAUNCH(d3_stale, v, T, 0);
-    LAUNCH(d3_rnames, v, N, 0);
-    LAUNCH(d4_coverage, v, N, 0);
+  LAUNCH_Q(d5_covavg, v, T, 0);
   }
+  if (N > 0) {
+    join_side(b);
+    LAUNCH(d4_coverage, v, N, 0);
+  } else join_side(b);
+  b->prefetched = false;
 }
 
 void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t elem) {
@@ -503,29 +562,44 @@ void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N;
   if (N <= 0) return;
+  fork_mark(b);
+  {  // QC / phasing / genotyping only touch the scalar call fields: side stream, overlapped with the consensus chain
+    SideStream side(b);
 #ifndef SNF_EMU
-  if (v.wave_path) {
-    Scope _s(b, "e1w_finalize", 0);
-    hipLaunchKernelGGL(e1w_finalize, dim3(8192), dim3(64), 0, b->stream, v, (int64_t)0);
-    SNF_HIP(hipGetLastError());
-  }
+    if (v.wave_path) {
+      Scope _s(b, "e1w_finalize", 0);
+      hipLaunchKernelGGL(e1w_finalize, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
 #endif
-  LAUNCH(e1_finalize, v, N, 0);
+    LAUNCH_Q(e1_finalize, v, N, 0);
+  }
   LAUNCH(e2_best, v, N, 0);
   prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_alt");
   prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_cons");
   // e3 writes per-consensus sizes into cons_*_off; scanned below into offsets
-  LAUNCH(e3_conslist, v, N, 0);
+  LAUNCH_Q(e3_conslist, v, N, 0);
   d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
+  {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
+     // the read names to the pinned host buffers now, overlapped with the consensus kernels
+    int64_t nc = b->h_cnt.n_calls, rn_total = b->h_cnt.rn_total;
+    snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
+    uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
+    fork_mark(b);
+    SideStream side(b);
+    d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
+    if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
+    b->prefetched = true;
+  }
   if (ncons > 0) {
     // sizes were written into cons_*_off[0..ncons); copy to the size arrays, terminate, scan
     size_t nb = (size_t)ncons * sizeof(int64_t);
 #ifndef SNF_EMU
-    SNF_HIP(hipMemcpyAsync(b->d_sz_tab, v.cons_tab_off, nb, hipMemcpyDeviceToDevice, b->stream));
-    SNF_HIP(hipMemcpyAsync(b->d_sz_aln, v.cons_aln_off, nb, hipMemcpyDeviceToDevice, b->stream));
-    SNF_HIP(hipMemcpyAsync(b->d_sz_rd, v.cons_read_off, nb, hipMemcpyDeviceToDevice, b->stream));
+    SNF_HIP(hipMemcpyAsync(b->d_sz_tab, v.cons_tab_off, nb, hipMemcpyDeviceToDevice, b->cur));
+    SNF_HIP(hipMemcpyAsync(b->d_sz_aln, v.cons_aln_off, nb, hipMemcpyDeviceToDevice, b->cur));
+    SNF_HIP(hipMemcpyAsync(b->d_sz_rd, v.cons_read_off, nb, hipMemcpyDeviceToDevice, b->cur));
 #else
     memcpy(b->d_sz_tab, v.cons_tab_off, nb); memcpy(b->d_sz_aln, v.cons_aln_off, nb); memcpy(b->d_sz_rd, v.cons_read_off, nb);
 #endif
@@ -555,19 +629,20 @@ void run_finalize(snf_batch_impl* b) {
   }
   ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
   if (ncons > 0) {
-    LAUNCH(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
+    LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
 #ifndef SNF_EMU
     if (v.wave_path) {
       // algorithmic bytes: every base of every seq-bearing lead of a consensus call once + the row written
       Scope _s(b, "e45w_consensus", b->h_cnt.aln_total * 2);
       int64_t grid = ncons < 8192 ? ncons : 8192;
-      hipLaunchKernelGGL(e45w_consensus, dim3((unsigned)grid), dim3(256), 0, b->stream, v, (int64_t)0);
+      hipLaunchKernelGGL(e45w_consensus, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
+    LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
   }
   LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
+  join_side(b);
 }
 
 void collect_timings(snf_batch_impl* b) {
@@ -597,13 +672,15 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
   uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);
   uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
-  d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
+  const bool pre = b->prefetched && stage >= 1;
+  if (!pre) d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
   d2h(b, b->r_status.data(), v.t_status, (size_t)T * sizeof(int32_t));
   d2h(b, b->r_off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t));
   d2h(b, b->r_cov.data(), v.t_cov_avg, (size_t)T * sizeof(double));
   if (alt_total) d2h(b, alt, v.alt_pool, (size_t)alt_total);
-  if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
+  if (rn_total && !pre) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
   dsync(b);
+  b->prefetched = false;  // the squeeze / stage fix-ups below edit the host copy in place
   if (v.N <= 0) std::fill(b->r_off.begin(), b->r_off.end(), 0);
   // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls: squeeze them out (rare; in place)
   bool any_err = false;
@@ -725,6 +802,11 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
 #ifndef SNF_EMU
     SNF_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    SNF_HIP(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+    b->cur = b->stream;
+    b->time_all = getenv("SNF_TIME_ALL") != nullptr;
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());
   })
@@ -752,12 +834,16 @@ void snf_batch_destroy(snf_batch_t* bb) {
 #ifndef SNF_EMU
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+  if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+  if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 #endif
   dfree_all(b);
   b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release();
 #ifndef SNF_EMU
   if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->stream2) (void)hipStreamDestroy(b->stream2);
 #endif
   delete b;
 }
@@ -805,7 +891,7 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
     if (nc > cap_calls) fail("export buffer too small");
     *n_calls = nc;
 #ifndef SNF_EMU
-    if (nc) SNF_HIP(hipMemcpyAsync(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t), hipMemcpyDeviceToDevice, b->stream));
+    if (nc) SNF_HIP(hipMemcpyAsync(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t), hipMemcpyDeviceToDevice, b->cur));
 #else
     if (nc) memcpy(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t));
 #endif

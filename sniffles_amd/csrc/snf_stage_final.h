@@ -328,6 +328,15 @@ SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int tas
   }
 }
 
+// write back only the fields finalize_call owns (the consensus chain updates alt_len/alt_off concurrently)
+SNF_HD void store_final_fields(snf_call_t& dst, const snf_call_t& c) {
+  dst.qc = c.qc; dst.filter = c.filter;
+  dst.gt_set = c.gt_set; dst.gt_a = c.gt_a; dst.gt_b = c.gt_b; dst.gt_gq = c.gt_gq; dst.gt_dr = c.gt_dr; dst.gt_dv = c.gt_dv;
+  dst.gt_hp = c.gt_hp; dst.gt_ps = c.gt_ps; dst.vaf = c.vaf;
+  dst.ph_set = c.ph_set; dst.ph_hp = c.ph_hp; dst.ph_ps = c.ph_ps; dst.ph_hp_support = c.ph_hp_support;
+  dst.ph_ps_support = c.ph_ps_support; dst.ph_hp_pass = c.ph_hp_pass; dst.ph_ps_pass = c.ph_ps_pass;
+}
+
 // scalar tail of finalize_candidates for one call, given the lead aggregates
 SNF_HD void finalize_call(const View& v, snf_call_t& c, const CallX& x, const LeadAgg& g, int task) {
   const snf_config_t& cfg = v.cfg;
@@ -353,7 +362,7 @@ SNF_HD void e1_finalize_body(int64_t i, const View& v) {
   LeadAgg g;
   collect_agg(v, x, task, &g);
   finalize_call(v, c, x, g, task);
-  cref = c;
+  store_final_fields(cref, c);
 }
 
 // ------------------------------------------------------------------------------------------ consensus

@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(SNF_WAVE) e1w_finalize(const View v, int64_t n
     if (lane == 0) {
       snf_call_t c = v.calls[i];
       finalize_call(v, c, x, g, task);
-      v.calls[i] = c;
+      store_final_fields(v.calls[i], c);
     }
   }
 }
