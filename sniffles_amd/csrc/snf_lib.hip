@@ -112,6 +112,8 @@ struct snf_batch_impl {
   int cur_slot = 0;
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
   bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
+  int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
+  int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
   bool uploaded = false;
   int run_gap = 1000;
   // host staging
@@ -388,6 +390,7 @@ void do_upload(snf_batch_impl* b) {
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
 #ifndef SNF_EMU
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
+  v.prof = getenv("SNF_PROF") ? 1 : 0;
 #else
   v.wave_path = 0;
 #endif
@@ -465,6 +468,27 @@ void reset_timing(snf_batch_impl* b) {
   b->timings.clear();
 }
 
+void enqueue_read_prep(snf_batch_impl* b) {
+  View& v = b->v;
+  int64_t R = v.R; int T = v.T;
+  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state); independent of the
+  // lead pipeline until d4_coverage, so it runs on the side stream
+  {
+  SideStream side(b);
+  if (R > 0) {
+    LAUNCH(r1_endkeys, b->rp, R, R * 13);
+    prim_sort_pairs(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, 32 + bits_for((uint64_t)T), "sort_read_ends");
+    LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
+    for (int h = 0; h < 3; h++) {
+      prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
+      prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
+    }
+    LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
+  }
+  LAUNCH_Q(d5_covavg, v, T, 0);
+  }
+}
+
 void run_call_candidates(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N, R = v.R; int T = v.T;
@@ -477,7 +501,8 @@ void run_call_candidates(snf_batch_impl* b) {
   dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
-  fork_mark(b);  // the read-preparation branch (enqueued below, after the critical path) may start here
+  fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
+  if (b->sched_readprep == 0) enqueue_read_prep(b);
   if (N > 0) {
     uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
     for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
@@ -501,6 +526,9 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
     prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
     LAUNCH_Q(c4_clusters, v, N, N * 4);
+  }
+  if (b->sched_readprep == 1) enqueue_read_prep(b);
+  if (N > 0) {
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
 #ifndef SNF_EMU
     if (v.wave_path) {
@@ -528,22 +556,7 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(d3_stale, v, T, 0);
     LAUNCH(d3_rnames, v, N, 0);
   }
-  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state); independent of the
-  // lead pipeline until d4_coverage, so it runs on the side stream
-  {
-  SideStream side(b);
-  if (R > 0) {
-    LAUNCH(r1_endkeys, b->rp, R, R * 13);
-    prim_sort_pairs(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, 32 + bits_for((uint64_t)T), "sort_read_ends");
-    LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
-    for (int h = 0; h < 3; h++) {
-      prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
-      prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
-    }
-    LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
-  }
-  LAUNCH_Q(d5_covavg, v, T, 0);
-  }
+  if (b->sched_readprep == 2) enqueue_read_prep(b);
   if (N > 0) {
     join_side(b);
     LAUNCH(d4_coverage, v, N, 0);
@@ -556,6 +569,21 @@ void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t 
   if (*p) dfree_one(b, *p);
   cap = need + need / 4 + 64;
   *p = dalloc<uint8_t>(b, (size_t)cap * elem);
+}
+
+void enqueue_prefetch(snf_batch_impl* b) {
+  View& v = b->v;
+  {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
+     // the read names to the pinned host buffers while the (latency-bound) consensus kernel runs
+    int64_t nc = b->h_cnt.n_calls, rn_total = b->h_cnt.rn_total;
+    snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
+    uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
+    fork_mark(b);
+    SideStream side(b);
+    d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
+    if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
+    b->prefetched = true;
+  }
 }
 
 void run_finalize(snf_batch_impl* b) {
@@ -582,17 +610,7 @@ void run_finalize(snf_batch_impl* b) {
   d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
-  {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
-     // the read names to the pinned host buffers now, overlapped with the consensus kernels
-    int64_t nc = b->h_cnt.n_calls, rn_total = b->h_cnt.rn_total;
-    snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
-    uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
-    fork_mark(b);
-    SideStream side(b);
-    d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
-    if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
-    b->prefetched = true;
-  }
+  if (b->sched_prefetch == 1) enqueue_prefetch(b);
   if (ncons > 0) {
     // sizes were written into cons_*_off[0..ncons); copy to the size arrays, terminate, scan
     size_t nb = (size_t)ncons * sizeof(int64_t);
@@ -628,20 +646,22 @@ void run_finalize(snf_batch_impl* b) {
     h2d(b, &v.cnt->n_cons_reads, &tot[2], sizeof(int64_t));
   }
   ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
+  const bool fallback = !v.wave_path || b->h_cnt.n_cons_fallback > 0;
   if (ncons > 0) {
-    LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
+    if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
 #ifndef SNF_EMU
     if (v.wave_path) {
       // algorithmic bytes: every base of every seq-bearing lead of a consensus call once + the row written
-      Scope _s(b, "e45w_consensus", b->h_cnt.aln_total * 2);
+      Scope _s(b, "e45w_consensus", b->h_cnt.aln_total * 2 + 2 * alt_total);
       int64_t grid = ncons < 8192 ? ncons : 8192;
       hipLaunchKernelGGL(e45w_consensus, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
+    if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
   }
-  LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
+  if (b->sched_prefetch == 2) enqueue_prefetch(b);
+  if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
   join_side(b);
 }
 
@@ -666,6 +686,11 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   if (b->h_cnt.overflow) fail("internal: fused-sequence pool overflow");
+  if (v.prof) {
+    static const char* ph[8] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy"};
+    unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += b->h_cnt.prof[k];
+    for (int k = 0; k < 8; k++) fprintf(stderr, "[SNF_PROF] e45w %-10s %6.2f %%\n", ph[k], tot ? 100.0 * (double)b->h_cnt.prof[k] / (double)tot : 0.0);
+  }
   int64_t nc = v.N > 0 ? b->h_cnt.n_calls : 0;
   int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt.alt_total : 0;
   int64_t rn_total = v.N > 0 ? b->h_cnt.rn_total : 0;
@@ -807,6 +832,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     b->cur = b->stream;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr;
+    if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
+    if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());
   })

@@ -372,6 +372,16 @@ SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
   return cfg.consensus_kmer_skip_base + (int)((double)L * cfg.consensus_kmer_skip_seqlen_mult);
 }
 
+// calls the gfx950 workgroup kernel (snf_wave_cons.h) can take: anchor table and lists fit its LDS budget
+#define SNF_CONS_SLOTS 1024
+#define SNF_CONS_MAXPOS 512
+#define SNF_CONS_MAXOTHERS 512
+SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) {
+  int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
+  return v.wave_path && v.cfg.consensus_kmer_len <= 7 && npos < SNF_CONS_MAXPOS - 8 && 2 * npos + 2 <= SNF_CONS_SLOTS &&
+         n_others <= SNF_CONS_MAXOTHERS && L < 65000;
+}
+
 SNF_HD void e2_best_body(int64_t i, const View& v) {
   if (i == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; }
   v.fN[i] = 0; v.fL[i] = 0;
@@ -394,7 +404,7 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
   x.do_cons = (x.n_others >= v.cfg.consensus_min_reads && !v.cfg.no_consensus) ? 1 : 0;
   c.alt_len = v.F_seq_len[best];
   v.fN[i] = (uint32_t)c.alt_len;
-  v.fL[i] = (uint32_t)x.do_cons;
+  v.fL[i] = 1u;  // listed for the ALT stage (consensus or verbatim copy of the best read)
 }
 
 // E3: consensus work list (pN = scan of alt lengths, pL = scan of do_cons)
@@ -404,27 +414,22 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   snf_call_t& c = v.calls[i];
   CallX& x = v.callx[i];
   if (c.alt_len >= 0) { c.alt_off = v.pN[i]; x.alt_off = v.pN[i]; }
-  if (x.do_cons) {
+  if (c.alt_len >= 0) {
     uint32_t cid = v.pL[i];
     x.cons_id = (int32_t)cid;
     v.cons_call[cid] = (int32_t)i;
     int64_t L = c.alt_len;
-    int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
-    int64_t hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
-    v.cons_tab_off[cid] = hs;                       // sizes; scanned in place on the host side
-    v.cons_aln_off[cid] = (int64_t)x.n_others * L;
-    v.cons_read_off[cid] = x.n_others;
+    int64_t hs = 0;
+    if (x.do_cons) {
+      int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
+      hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
+      if (cons_wave_eligible(v, L, x.n_others)) hs = 0;   // anchor table lives in LDS
+      else atomic_add_u64((unsigned long long*)&v.cnt->n_cons_fallback, 1ull);
+    }
+    v.cons_tab_off[cid] = hs;                       // sizes; scanned into offsets by the host
+    v.cons_aln_off[cid] = x.do_cons ? (int64_t)x.n_others * L : 0;
+    v.cons_read_off[cid] = x.do_cons ? x.n_others : 0;
   }
-}
-
-// calls the gfx950 workgroup kernel (snf_wave_cons.h) can take: anchor table and lists fit its LDS budget
-#define SNF_CONS_SLOTS 1024
-#define SNF_CONS_MAXPOS 512
-#define SNF_CONS_MAXOTHERS 512
-SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) {
-  int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
-  return v.wave_path && v.cfg.consensus_kmer_len <= 7 && npos < SNF_CONS_MAXPOS - 8 && 2 * npos + 2 <= SNF_CONS_SLOTS &&
-         n_others <= SNF_CONS_MAXOTHERS && L < 65000;
 }
 
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
@@ -440,6 +445,7 @@ SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
   int32_t ci = v.cons_call[cid];
   const CallX& x = v.callx[ci];
   int64_t L = v.F_seq_len[x.best];
+  if (!x.do_cons) return;
   // (cid, read) work items
   int64_t r0 = v.cons_read_off[cid];
   for (int32_t r = 0; r < x.n_others; r++) { v.cr_call[r0 + r] = (int32_t)cid; v.cr_read[r0 + r] = r; }
@@ -527,6 +533,7 @@ SNF_HD void e6_vote_body(int64_t col, const View& v) {
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((int64_t)v.pN[mid + 1] <= col) lo = mid + 1; else hi = mid; }
   int64_t ci = lo;
   const CallX& x = v.callx[ci];
+  if (v.wave_path && (!x.do_cons || cons_wave_eligible(v, v.F_seq_len[x.best], x.n_others))) return;  // e45w wrote it
   int64_t i = col - (int64_t)v.pN[ci];
   int64_t L = v.F_seq_len[x.best];
   uint8_t b = v.pool[v.F_seq_off[x.best] + i];

@@ -17,6 +17,8 @@ struct Counts {
   int64_t n_valid, n_bins, n_seeds, NF, NLL, n_runs, n_clusters, n_rc, n_calls;
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
+  int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
+  unsigned long long prof[8]; // SNF_PROF=1: wave-cycles per phase of e45w_consensus
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags
   int32_t _pad;
@@ -48,7 +50,7 @@ struct View {
   int32_t T;          // tasks
   int32_t run_gap;    // merge-scan run cut (bp); <0: whole group serial
   int32_t wave_path;  // 1: gfx950 wave-cooperative kernels own the small clusters (thread kernels skip them)
-  int32_t _padv;
+  int32_t prof;       // SNF_PROF=1: phase cycle counters in e45w_consensus
   int64_t N, R, NTR;
   int64_t pool_len, pool_cap;
   Counts* cnt;

@@ -1,6 +1,7 @@
 // snf_wave_cons.h - gfx950 workgroup-per-INS-call implementation of the k-mer anchored consensus
 // alignment (consensus.novel_from_reads, consensus.py:280-363): anchor table + one aligned row per
-// "other" read.  The column vote (consensus.py:365-380) stays in e6_vote.
+// "other" read, then the column vote (consensus.py:365-380) in the same workgroup.  Non-consensus INS calls (ALT = best
+// read verbatim) are copied here too; e4_anchor/e5_align/e6_vote only serve calls that do not fit the LDS budget.
 //
 // Per consensus call: 256 threads build the anchor hash table of the best read in LDS (unique sampled
 // 6-mers; <= ~500 positions -> 1024 slots).  Then each of the 4 waves takes reads r = w, w+4, ...:
@@ -34,8 +35,27 @@ struct ConsLds {
   int32_t pos[SNF_CONS_SLOTS];
   int32_t cnt[SNF_CONS_SLOTS];
   int32_t others[SNF_CONS_MAXOTHERS];
+  uint8_t kept[SNF_CONS_MAXOTHERS];
   ConsWaveLds w[4];
 };
+
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+SNF_D uint64_t load_u64(const uint8_t* p) { return *(const u64_unaligned*)p; }  // pool has >= 16 B of slack
+// number of equal bytes among the first n (<= 8) bytes of two little-endian words
+SNF_D int eq_bytes(uint64_t a, uint64_t b, int n) {
+  uint64_t x = a ^ b;
+  if (n < 8) x |= ~0ull << (8 * n);                       // bytes past n count as different
+  uint64_t t = (x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full;
+  t = ~(t | x | 0x7f7f7f7f7f7f7f7full);                   // 0x80 in every zero byte of x
+  return __builtin_popcountll(t);
+}
+SNF_D int count_eq(const uint8_t* a, const uint8_t* b, int n) {
+  int m = 0;
+  for (int q = 0; q < n; q += 8) m += eq_bytes(load_u64(a + q), load_u64(b + q), n - q < 8 ? n - q : 8);
+  return m;
+}
+// injective key of the klen (<= 7) bytes at p; only has to agree between this kernel's table build and lookups
+SNF_D unsigned long long kmer_key_le(const uint8_t* p, int klen) { return load_u64(p) & ((1ull << (8 * klen)) - 1ull); }
 
 SNF_D int wave_max_incl(int x, int lane) {
 #pragma unroll
@@ -43,8 +63,10 @@ SNF_D int wave_max_incl(int x, int lane) {
   return x;
 }
 
+#define SNF_PH(k) do { if (v.prof && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&v.cnt->prof[k], t_ - tph); tph = t_; } } while (0)
 __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_unused) {
   __shared__ ConsLds lds;
+  unsigned long long tph = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
   const int64_t n_cons = v.cnt->n_cons;
@@ -52,10 +74,16 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     const int32_t ci = v.cons_call[cid];
     const CallX x = v.callx[ci];
     const int64_t L = v.F_seq_len[x.best];
-    if (!cons_wave_eligible(v, L, x.n_others)) continue;  // thread path (e4_anchor/e5_align) owns it
     const uint8_t* B = v.pool + v.F_seq_off[x.best];
+    uint8_t* alt = v.alt_pool + x.alt_off;
+    if (!x.do_cons) {  // fewer than consensus_min_reads others: ALT = best read verbatim (postprocessing.py:65-66)
+      for (int64_t q = tid; q < L; q += 256) alt[q] = B[q];
+      continue;
+    }
+    if (!cons_wave_eligible(v, L, x.n_others)) continue;  // thread path (e4_anchor/e5_align/e6_vote) owns it
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
+    SNF_PH(7);
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SNF_CONS_SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.cnt[s] = 0; }
     if (tid == 0) {  // cluster-order list of the other seq-bearing leads
@@ -70,7 +98,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     const int64_t npos = cons_npos(L, klen, skip);
     for (int64_t p = tid; p < npos; p += 256) {
       const int64_t i = p * skip;
-      const unsigned long long kk = kmer_key(B + i, klen);
+      const unsigned long long kk = kmer_key_le(B + i, klen);
       int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
       for (;;) {
         const unsigned long long old = atomicCAS(&lds.key[sl], SNF_KEY_EMPTY, kk);
@@ -80,6 +108,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
       if (atomicAdd(&lds.cnt[sl], 1) == 0) lds.pos[sl] = (int32_t)i;  // meaningful only while cnt stays 1
     }
     __syncthreads();
+    SNF_PH(0);
     ConsWaveLds& W = lds.w[wid];
     const int64_t r0 = v.cons_read_off[cid];
     uint8_t* rows = v.aln + v.cons_aln_off[cid];
@@ -97,7 +126,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
         const int64_t p = p0 + lane;
         int ci_ = -1; int64_t j = p * skip;
         if (p < P) {
-          const unsigned long long kk = kmer_key(S + j, klen);
+          const unsigned long long kk = kmer_key_le(S + j, klen);
           int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
           for (;;) {
             const unsigned long long kq = lds.key[sl];
@@ -111,6 +140,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
         ncand += __builtin_popcountll(mk);
       }
       __builtin_amdgcn_wave_barrier();
+      SNF_PH(1);
       // ---- 2. monotone chain: accept iff i > every earlier candidate's i (== last accepted i)
       int na = 0, runmax = -1;
       for (int c0 = 0; c0 < ncand; c0 += 64) {
@@ -129,6 +159,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
         if (tot > runmax) runmax = tot;
         __builtin_amdgcn_wave_barrier();
       }
+      SNF_PH(2);
       // ---- 3. segments between consecutive anchors
       const int i0 = na ? W.ai[0] : 0, j0 = na ? W.aj[0] : 0;
       const int64_t c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
@@ -144,11 +175,10 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
           if (fwd_i == fwd_j && fwd_j > 0) {
             const int nfull = j - lj;
             span += nfull;
-            int m = 0;
-            for (int l = 1; l <= nfull; l++) m += (S[lj + l] == B[li + l]);
+            const int m = count_eq(S + lj + 1, B + li + 1, nfull);
             if ((double)m / (double)nfull >= 0.5) {
               flag = 1;
-              for (int q = 0; q < (int)fwd_j; q++) cm += (S[lj + q] == B[col + q]);
+              cm = count_eq(S + lj, B + col, (int)fwd_j);
             }
           }
           W.seg_col[t] = (int32_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
@@ -157,6 +187,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) span += __shfl_xor(span, d, 64);
       __builtin_amdgcn_wave_barrier();
+      SNF_PH(3);
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360)
       if (lane == 0) {
         int t = 1;
@@ -169,6 +200,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
         }
       }
       __builtin_amdgcn_wave_barrier();
+      SNF_PH(4);
       // ---- 5. write the row, column-parallel
       int64_t c_last = c_first;
       if (na) { c_last = c_first + (W.aj[na - 1] - j0); if (c_last > L) c_last = L; }
@@ -186,9 +218,41 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
           row[q] = out;
         }
       }
-      if (lane == 0) v.aln_kept[r0 + r] = ((double)span / (double)L > 0.2) ? 1 : 0;
+      if (lane == 0) { const uint8_t k = ((double)span / (double)L > 0.2) ? 1 : 0; v.aln_kept[r0 + r] = k; lds.kept[r] = k; }
       __builtin_amdgcn_wave_barrier();
     }
+    SNF_PH(5);
+    // ---- column vote (consensus.py:365-380) on the rows this workgroup just wrote (still in L2)
+    __syncthreads();
+    int nkept = 0;
+    for (int32_t r = 0; r < x.n_others; r++) nkept += lds.kept[r];
+    const double maxal = (double)(1 + nkept);
+    for (int64_t q = tid; q < L; q += 256) {
+      const uint8_t bq = B[q];
+      uint8_t out = bq;
+      int nvotes = 0;
+      for (int32_t r = 0; r < x.n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
+      if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
+        // util.most_common([best]+votes): (count, char) descending; replace iff top beats the runner-up by >= 3
+        int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
+        for (int32_t r = -1; r < x.n_others; r++) {
+          uint8_t ch;
+          if (r < 0) ch = bq;
+          else { if (!lds.kept[r]) continue; ch = rows[(int64_t)r * L + q]; if (ch == '-') continue; }
+          bool seen = (r >= 0 && ch == bq);
+          for (int32_t r2 = 0; r2 < r && !seen; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == ch) seen = true;
+          if (seen) continue;
+          int cntc = (ch == bq) ? 1 : 0;
+          for (int32_t r2 = 0; r2 < x.n_others; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == ch) cntc++;
+          nd++;
+          if (cntc > c0 || (cntc == c0 && (int)ch > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = ch; }
+          else if (cntc > c1 || (cntc == c1 && (int)ch > k1)) { c1 = cntc; k1 = ch; }
+        }
+        if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+      }
+      alt[q] = out;
+    }
+    SNF_PH(6);
   }
 }
 
