@@ -652,10 +652,13 @@ void run_finalize(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       // algorithmic bytes: every base of every seq-bearing lead of a consensus call once + the row written
-      Scope _s(b, "e45w_consensus", b->h_cnt.aln_total * 2 + 2 * alt_total);
-      int64_t grid = ncons < 8192 ? ncons : 8192;
-      hipLaunchKernelGGL(e45w_consensus, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
+      int64_t grid = ncons < 16384 ? ncons : 16384;
+      { Scope _s(b, "e45w_consensus_small", (int64_t)b->h_cnt.cons_bytes[1]);
+        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
+      { Scope _s(b, "e45w_consensus_large", (int64_t)b->h_cnt.cons_bytes[2]);
+        hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
     }
 #endif
     if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);

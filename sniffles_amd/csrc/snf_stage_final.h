@@ -372,15 +372,16 @@ SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
   return cfg.consensus_kmer_skip_base + (int)((double)L * cfg.consensus_kmer_skip_seqlen_mult);
 }
 
-// calls the gfx950 workgroup kernel (snf_wave_cons.h) can take: anchor table and lists fit its LDS budget
-#define SNF_CONS_SLOTS 1024
-#define SNF_CONS_MAXPOS 512
-#define SNF_CONS_MAXOTHERS 512
-SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) {
+// size class of a consensus call for the gfx950 workgroup kernel (snf_wave_cons.h): 1 SMALL (256-slot table, 128
+// positions, 64 others), 2 LARGE (1024 / 512 / 512), 0: does not fit its LDS budget -> thread kernels e4/e5/e6
+SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
+  if (!v.wave_path || v.cfg.consensus_kmer_len > 7 || L >= 65000) return 0;
   int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
-  return v.wave_path && v.cfg.consensus_kmer_len <= 7 && npos < SNF_CONS_MAXPOS - 8 && 2 * npos + 2 <= SNF_CONS_SLOTS &&
-         n_others <= SNF_CONS_MAXOTHERS && L < 65000;
+  if (npos <= 120 && n_others <= 64) return 1;
+  if (npos <= 500 && n_others <= 512) return 2;
+  return 0;
 }
+SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { return cons_class(v, L, n_others) != 0; }
 
 SNF_HD void e2_best_body(int64_t i, const View& v) {
   if (i == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; }
@@ -420,6 +421,9 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
     v.cons_call[cid] = (int32_t)i;
     int64_t L = c.alt_len;
     int64_t hs = 0;
+    // 1 B per base of every seq-bearing lead of the call + 1 B per output base
+    int cls = x.do_cons ? cons_class(v, L, x.n_others) : 1;
+    atomic_add_u64(&v.cnt->cons_bytes[cls], (unsigned long long)((x.do_cons ? (int64_t)x.n_others + 2 : 2) * L));
     if (x.do_cons) {
       int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
       hs = 16; while (hs < 2 * npos + 2) hs <<= 1;

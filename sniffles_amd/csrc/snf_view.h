@@ -18,6 +18,7 @@ struct Counts {
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
+  unsigned long long cons_bytes[3]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large)
   unsigned long long prof[8]; // SNF_PROF=1: wave-cycles per phase of e45w_consensus
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags

@@ -1,18 +1,21 @@
-// snf_wave_cons.h - gfx950 workgroup-per-INS-call implementation of the k-mer anchored consensus
-// alignment (consensus.novel_from_reads, consensus.py:280-363): anchor table + one aligned row per
-// "other" read, then the column vote (consensus.py:365-380) in the same workgroup.  Non-consensus INS calls (ALT = best
-// read verbatim) are copied here too; e4_anchor/e5_align/e6_vote only serve calls that do not fit the LDS budget.
+// snf_wave_cons.h - gfx950 workgroup-per-INS-call implementation of the ALT stage: k-mer anchored consensus
+// (consensus.novel_from_reads, consensus.py:280-394) or the verbatim copy of the best read
+// (postprocessing.py:65-66).  e4_anchor/e5_align/e6_vote (thread-per-item) only serve calls that do not fit the
+// LDS budget of the LARGE class below.
 //
-// Per consensus call: 256 threads build the anchor hash table of the best read in LDS (unique sampled
-// 6-mers; <= ~500 positions -> 1024 slots).  Then each of the 4 waves takes reads r = w, w+4, ...:
-//   1. sampled k-mers of the read are looked up in parallel and compacted IN ORDER (ballot + popcount)
+// Per consensus call: 256 threads build the anchor hash table of the best read in LDS (sampled k-mers seen
+// exactly once).  Then each of the 4 waves takes reads r = w, w+4, ...:
+//   1. all sampled k-mers of the read are loaded up front (independent 8-byte loads), looked up in LDS and
+//      compacted IN ORDER (ballot + popcount)
 //   2. the monotone anchor chain (accept iff i > last accepted i) is a prefix-max filter
-//   3. per segment between consecutive anchors (one lane each): clipped advance, identity on offsets
-//      1..n, column-identity of the copied slice (the column cursor has the closed form
+//   3. per segment between consecutive anchors (one lane each): clipped advance, identity on offsets 1..n and
+//      column identity of the copied slice with 8-byte vector compares (the column cursor has the closed form
 //      min(L, c0 + j - j0))
 //   4. lane 0 groups consecutive copied segments into runs and applies the run filter
 //      (matches/len > 0.5 and matches > 5)
-//   5. the row is written column-parallel (binary search of the owning segment), coalesced.
+//   5. the row is written column-parallel (binary search of the owning segment), coalesced;
+// finally the workgroup votes every column over the rows it just wrote (still in L2).
+// Two size classes: SMALL (<= 120 sampled positions, i.e. L < ~500 bp: ~9 KB LDS, full occupancy) and LARGE.
 // Input sequences must not contain '-' (checked at snf_batch_add_task): the reference treats it as a gap.
 #pragma once
 #include "snf_stage_final.h"
@@ -22,21 +25,20 @@ namespace snf {
 
 #define SNF_KEY_EMPTY (~0ull)
 
-struct ConsWaveLds {
-  int32_t ai[SNF_CONS_MAXPOS];   // candidates, then accepted anchors: position in best
-  int32_t aj[SNF_CONS_MAXPOS];   //                                    position in the read
-  int32_t seg_col[SNF_CONS_MAXPOS];  // column where segment t starts (t >= 1)
-  uint16_t seg_len[SNF_CONS_MAXPOS]; // clipped advance (columns written)
-  uint16_t seg_cm[SNF_CONS_MAXPOS];  // matches of the copied slice against best at its columns
-  uint8_t seg_flag[SNF_CONS_MAXPOS]; // 0 dashes, 1 copy
-};
-struct ConsLds {
-  unsigned long long key[SNF_CONS_SLOTS];
-  int32_t pos[SNF_CONS_SLOTS];
-  int32_t cnt[SNF_CONS_SLOTS];
-  int32_t others[SNF_CONS_MAXOTHERS];
-  uint8_t kept[SNF_CONS_MAXOTHERS];
-  ConsWaveLds w[4];
+template <int SLOTS, int MAXPOS, int MAXOTHERS>
+struct ConsLdsT {
+  unsigned long long key[SLOTS];
+  uint32_t pc[SLOTS];              // (position << 16) | occurrence count
+  int32_t others[MAXOTHERS];
+  uint8_t kept[MAXOTHERS];
+  struct Wave {
+    uint16_t ai[MAXPOS];           // candidates, then accepted anchors: position in best
+    uint16_t aj[MAXPOS];           //                                    position in the read
+    uint16_t seg_col[MAXPOS];      // column where segment t starts (t >= 1)
+    uint16_t seg_len[MAXPOS];      // clipped advance (columns written)
+    uint16_t seg_cm[MAXPOS];       // matches of the copied slice against best at its columns
+    uint8_t seg_flag[MAXPOS];      // 0 dashes, 1 copy
+  } w[4];
 };
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
@@ -54,8 +56,8 @@ SNF_D int count_eq(const uint8_t* a, const uint8_t* b, int n) {
   for (int q = 0; q < n; q += 8) m += eq_bytes(load_u64(a + q), load_u64(b + q), n - q < 8 ? n - q : 8);
   return m;
 }
-// injective key of the klen (<= 7) bytes at p; only has to agree between this kernel's table build and lookups
-SNF_D unsigned long long kmer_key_le(const uint8_t* p, int klen) { return load_u64(p) & ((1ull << (8 * klen)) - 1ull); }
+// injective key of the klen (<= 7) bytes in w; only has to agree between this kernel's table build and lookups
+SNF_D unsigned long long kmer_key_le(unsigned long long w, int klen) { return w & ((1ull << (8 * klen)) - 1ull); }
 
 SNF_D int wave_max_incl(int x, int lane) {
 #pragma unroll
@@ -64,8 +66,13 @@ SNF_D int wave_max_incl(int x, int lane) {
 }
 
 #define SNF_PH(k) do { if (v.prof && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&v.cnt->prof[k], t_ - tph); tph = t_; } } while (0)
+
+// CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
+template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS>
 __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_unused) {
-  __shared__ ConsLds lds;
+  typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS> Lds;
+  __shared__ Lds lds;
+  constexpr int ROUNDS = MAXPOS / 64;
   unsigned long long tph = __builtin_readcyclecounter();
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
@@ -77,15 +84,15 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     const uint8_t* B = v.pool + v.F_seq_off[x.best];
     uint8_t* alt = v.alt_pool + x.alt_off;
     if (!x.do_cons) {  // fewer than consensus_min_reads others: ALT = best read verbatim (postprocessing.py:65-66)
-      for (int64_t q = tid; q < L; q += 256) alt[q] = B[q];
+      if (CLS == 1) for (int64_t q = tid; q < L; q += 256) alt[q] = B[q];
       continue;
     }
-    if (!cons_wave_eligible(v, L, x.n_others)) continue;  // thread path (e4_anchor/e5_align/e6_vote) owns it
+    if (cons_class(v, L, x.n_others) != CLS) continue;  // other instance, or the thread path (e4/e5/e6)
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
     SNF_PH(7);
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
-    for (int s = tid; s < SNF_CONS_SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.cnt[s] = 0; }
+    for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
     if (tid == 0) {  // cluster-order list of the other seq-bearing leads
       int k2 = 0;
       for (int32_t k = 0; k < x.fn; k++) {
@@ -98,18 +105,18 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     const int64_t npos = cons_npos(L, klen, skip);
     for (int64_t p = tid; p < npos; p += 256) {
       const int64_t i = p * skip;
-      const unsigned long long kk = kmer_key_le(B + i, klen);
-      int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
+      const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
+      int64_t sl = kmer_slot(kk, SLOTS);
       for (;;) {
         const unsigned long long old = atomicCAS(&lds.key[sl], SNF_KEY_EMPTY, kk);
         if (old == SNF_KEY_EMPTY || old == kk) break;
-        sl = (sl + 1) & (SNF_CONS_SLOTS - 1);
+        sl = (sl + 1) & (SLOTS - 1);
       }
-      if (atomicAdd(&lds.cnt[sl], 1) == 0) lds.pos[sl] = (int32_t)i;  // meaningful only while cnt stays 1
+      if ((atomicAdd(&lds.pc[sl], 1u) & 0xffffu) == 0) atomicOr(&lds.pc[sl], (uint32_t)i << 16);  // position of the 1st sighting
     }
     __syncthreads();
     SNF_PH(0);
-    ConsWaveLds& W = lds.w[wid];
+    typename Lds::Wave& W = lds.w[wid];
     const int64_t r0 = v.cons_read_off[cid];
     uint8_t* rows = v.aln + v.cons_aln_off[cid];
     for (int32_t r = wid; r < x.n_others; r += 4) {
@@ -118,25 +125,36 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
       const int64_t SL = v.F_seq_len[slot];
       uint8_t* row = rows + (int64_t)r * L;
       // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
-      int64_t jlim = SL - klen;                       // j < SL - klen
-      if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;  // an anchor needs i <= L-klen-1, |i-j| <= maxshift
-      const int64_t P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;
+      int64_t jlim = SL - klen;                                     // j < SL - klen
+      if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;   // an anchor needs i <= L-klen-1, |i-j| <= maxshift
+      const int64_t P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;   // <= npos + 2 < MAXPOS
+      unsigned long long kw[ROUNDS];
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
+        const int64_t p = (int64_t)rd * 64 + lane;
+        kw[rd] = p < P ? load_u64(S + p * skip) : 0ull;
+      }
       int ncand = 0;
-      for (int64_t p0 = 0; p0 < P; p0 += 64) {
-        const int64_t p = p0 + lane;
-        int ci_ = -1; int64_t j = p * skip;
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; rd++) {
+        const int64_t p = (int64_t)rd * 64 + lane;
+        int ci_ = -1; const int64_t j = p * skip;
         if (p < P) {
-          const unsigned long long kk = kmer_key_le(S + j, klen);
-          int64_t sl = kmer_slot(kk, SNF_CONS_SLOTS);
+          const unsigned long long kk = kmer_key_le(kw[rd], klen);
+          int64_t sl = kmer_slot(kk, SLOTS);
           for (;;) {
             const unsigned long long kq = lds.key[sl];
             if (kq == SNF_KEY_EMPTY) break;
-            if (kq == kk) { if (lds.cnt[sl] == 1) { const int i = lds.pos[sl]; if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; } break; }
-            sl = (sl + 1) & (SNF_CONS_SLOTS - 1);
+            if (kq == kk) {
+              const uint32_t pc = lds.pc[sl];
+              if ((pc & 0xffffu) == 1u) { const int i = (int)(pc >> 16); if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; }
+              break;
+            }
+            sl = (sl + 1) & (SLOTS - 1);
           }
         }
         const unsigned long long mk = __ballot(ci_ >= 0);
-        if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = ci_; W.aj[w] = (int32_t)j; }
+        if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
         ncand += __builtin_popcountll(mk);
       }
       __builtin_amdgcn_wave_barrier();
@@ -145,7 +163,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
       int na = 0, runmax = -1;
       for (int c0 = 0; c0 < ncand; c0 += 64) {
         const int cidx = c0 + lane;
-        const int i = cidx < ncand ? W.ai[cidx] : -1, j = cidx < ncand ? W.aj[cidx] : 0;
+        const int i = cidx < ncand ? (int)W.ai[cidx] : -1, j = cidx < ncand ? (int)W.aj[cidx] : 0;
         int pm = wave_max_incl(i, lane);
         int prev = __shfl_up(pm, 1, 64);
         if (lane == 0) prev = -1;
@@ -153,7 +171,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
         const bool acc = cidx < ncand && i > prev;
         const unsigned long long mk = __ballot(acc);
         __builtin_amdgcn_wave_barrier();
-        if (acc) { const int w = na + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = i; W.aj[w] = j; }
+        if (acc) { const int w = na + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)i; W.aj[w] = (uint16_t)j; }
         na += __builtin_popcountll(mk);
         const int tot = __shfl(pm, 63, 64);
         if (tot > runmax) runmax = tot;
@@ -181,7 +199,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
               cm = count_eq(S + lj, B + col, (int)fwd_j);
             }
           }
-          W.seg_col[t] = (int32_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
+          W.seg_col[t] = (uint16_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
         }
       }
 #pragma unroll
@@ -210,7 +228,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
           uint8_t out = '-';
           if (na > 1 && q >= c_first && q < c_last) {
             int lo2 = 1, hi2 = na - 1;  // last segment t with seg_col[t] <= q
-            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (W.seg_col[mid] <= q) lo2 = mid; else hi2 = mid - 1; }
+            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if ((int64_t)W.seg_col[mid] <= q) lo2 = mid; else hi2 = mid - 1; }
             const int t = lo2;
             const int64_t off = q - W.seg_col[t];
             if (W.seg_flag[t] && off < W.seg_len[t]) out = S[W.aj[t - 1] + off];
@@ -230,25 +248,55 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     for (int64_t q = tid; q < L; q += 256) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
-      int nvotes = 0;
-      for (int32_t r = 0; r < x.n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
-      if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
-        // util.most_common([best]+votes): (count, char) descending; replace iff top beats the runner-up by >= 3
-        int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
-        for (int32_t r = -1; r < x.n_others; r++) {
-          uint8_t ch;
-          if (r < 0) ch = bq;
-          else { if (!lds.kept[r]) continue; ch = rows[(int64_t)r * L + q]; if (ch == '-') continue; }
-          bool seen = (r >= 0 && ch == bq);
-          for (int32_t r2 = 0; r2 < r && !seen; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == ch) seen = true;
-          if (seen) continue;
-          int cntc = (ch == bq) ? 1 : 0;
-          for (int32_t r2 = 0; r2 < x.n_others; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == ch) cntc++;
-          nd++;
-          if (cntc > c0 || (cntc == c0 && (int)ch > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = ch; }
-          else if (cntc > c1 || (cntc == c1 && (int)ch > k1)) { c1 = cntc; k1 = ch; }
+      if (x.n_others <= 16) {
+        // votes of this column in registers: (count, char) top-2 over [best] + votes
+        uint8_t ch[16]; int nv = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          uint8_t c = '-';
+          if (r < x.n_others && lds.kept[r]) c = rows[(int64_t)r * L + q];
+          ch[r] = c; nv += (c != '-');
         }
-        if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+        if (!(nv < 2 || (double)nv / maxal < 0.25)) {
+          int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
+#pragma unroll
+          for (int r = -1; r < 16; r++) {
+            const uint8_t c = r < 0 ? bq : ch[r < 0 ? 0 : r];
+            if (c == '-') continue;
+            bool seen = (r >= 0 && c == bq);
+#pragma unroll
+            for (int r2 = 0; r2 < 16; r2++) if (r2 < r && ch[r2] == c) seen = true;
+            if (seen) continue;
+            int cntc = (c == bq) ? 1 : 0;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; r2++) cntc += (ch[r2] == c);
+            nd++;
+            if (cntc > c0 || (cntc == c0 && (int)c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+            else if (cntc > c1 || (cntc == c1 && (int)c > k1)) { c1 = cntc; k1 = c; }
+          }
+          if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+        }
+      } else {
+        int nvotes = 0;
+        for (int32_t r = 0; r < x.n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
+        if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
+          // util.most_common([best]+votes): (count, char) descending; replace iff top beats the runner-up by >= 3
+          int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
+          for (int32_t r = -1; r < x.n_others; r++) {
+            uint8_t c;
+            if (r < 0) c = bq;
+            else { if (!lds.kept[r]) continue; c = rows[(int64_t)r * L + q]; if (c == '-') continue; }
+            bool seen = (r >= 0 && c == bq);
+            for (int32_t r2 = 0; r2 < r && !seen; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == c) seen = true;
+            if (seen) continue;
+            int cntc = (c == bq) ? 1 : 0;
+            for (int32_t r2 = 0; r2 < x.n_others; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == c) cntc++;
+            nd++;
+            if (cntc > c0 || (cntc == c0 && (int)c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+            else if (cntc > c1 || (cntc == c1 && (int)c > k1)) { c1 = cntc; k1 = c; }
+          }
+          if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+        }
       }
       alt[q] = out;
     }
