@@ -1,64 +1,208 @@
-// snf_myers.hip - batched global (NW) unit-cost edit distance, the quantity SVGroup.align_call reads from
-// edlib.align(a, b)["editDistance"] (sv.py:280-289; snfp.py:103).  First version: one thread per pair,
-// two-row DP; to be replaced by the bit-parallel Myers/Hyyro kernel.
+// snf_myers.hip - batched global (NW) unit-cost edit distance: the quantity SVGroup.align_call reads from
+// edlib.align(a, b)["editDistance"] with edlib's defaults (sv.py:280-289; snfp.py:103).
+//
+// Bit-parallel Myers / Hyyro block algorithm: the shorter string is the pattern, cut into blocks of 64 rows;
+// each block keeps the vertical delta vectors (Pv, Mv) and advances one text column in ~25 ALU ops given the
+// match mask Eq(c).  Eq for an arbitrary byte alphabet comes from the 8 bit-planes of the block's 64 pattern
+// bytes (16 ops), so no per-pair alphabet table is needed.  Blocks of one column are chained by the horizontal
+// delta hout -> hin (global alignment: hin = +1 at row 0).
+//   * patterns of <= 8 blocks: one THREAD per pair, block-major, per-column carries in a byte array
+//   * longer patterns: one WAVE per pair, lane = block, lanes advance along anti-diagonals (lane l works on
+//     column t - l at step t and takes hin from lane l-1 by a shuffle); patterns of > 64 blocks take several
+//     passes of 64 blocks linked through the same carry array.
+// No MFMA: this is integer/bit work; the bound is VALU issue, reported as such.
 #include "snf_exact.h"
 #include "../../include/sniffles_amd.h"
 
+#include <string>
+#include <vector>
+
 namespace snf {
+
 struct EdView {
-  const uint8_t* a; const int64_t* a_off; const uint8_t* b; const int64_t* b_off; int64_t n; int32_t* out;
-  int32_t* row; const int64_t* row_off;
+  const uint8_t* a; const int64_t* a_off; const uint8_t* b; const int64_t* b_off;
+  int32_t* out; int8_t* carry; const int64_t* carry_off;   // carry: one byte per text column per pair
+  const int32_t* list; int64_t n;                           // pair indices handled by this launch
 };
-SNF_HD void ed_pair_body(int64_t i, const EdView& v) {
-  const uint8_t* A = v.a + v.a_off[i]; int64_t la = v.a_off[i + 1] - v.a_off[i];
-  const uint8_t* B = v.b + v.b_off[i]; int64_t lb = v.b_off[i + 1] - v.b_off[i];
-  int32_t* row = v.row + v.row_off[i];
-  for (int64_t j = 0; j <= lb; j++) row[j] = (int32_t)j;
-  for (int64_t x = 1; x <= la; x++) {
-    int32_t diag = row[0];
-    row[0] = (int32_t)x;
-    for (int64_t j = 1; j <= lb; j++) {
-      int32_t up = row[j];
-      int32_t vv = diag + (A[x - 1] != B[j - 1]);
-      if (up + 1 < vv) vv = up + 1;
-      if (row[j - 1] + 1 < vv) vv = row[j - 1] + 1;
-      diag = up; row[j] = vv;
+
+// bit-planes of up to 64 pattern bytes: planes[k] bit i = bit k of p[i]; *valid bit i = (i < cnt)
+SNF_HD void block_planes(const uint8_t* p, int cnt, uint64_t planes[8], uint64_t* valid) {
+  for (int k = 0; k < 8; k++) planes[k] = 0;
+  for (int i = 0; i < cnt; i++) {
+    uint8_t c = p[i];
+    for (int k = 0; k < 8; k++) planes[k] |= (uint64_t)((c >> k) & 1) << i;
+  }
+  *valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+}
+SNF_HD uint64_t eq_mask(const uint64_t planes[8], uint64_t valid, uint8_t c) {
+  uint64_t e = valid;
+  for (int k = 0; k < 8; k++) e &= ((c >> k) & 1) ? planes[k] : ~planes[k];
+  return e;
+}
+// one block, one column (Hyyro 2003 / edlib calculateBlock); hin, hout in {-1, 0, +1}
+SNF_HD int advance_block(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin) {
+  uint64_t Xv = Eq | Mv;
+  if (hin < 0) Eq |= 1ull;
+  uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+  uint64_t Ph = Mv | ~(Xh | Pv);
+  uint64_t Mh = Pv & Xh;
+  int hout = 0;
+  if (Ph >> 63) hout = 1;
+  if (Mh >> 63) hout = -1;
+  Ph <<= 1; Mh <<= 1;
+  if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+  Pv = Mh | ~(Xv | Ph);
+  Mv = Ph & Xv;
+  return hout;
+}
+// D[m][n] from the score at the bottom row of the last (padded) block
+SNF_HD int64_t unpad_score(int64_t score, uint64_t Pv, uint64_t Mv, int pad_rows) {
+  for (int i = 0; i < pad_rows; i++) {
+    int bit = 63 - i;
+    score -= (int64_t)((Pv >> bit) & 1) - (int64_t)((Mv >> bit) & 1);
+  }
+  return score;
+}
+
+SNF_HD void pair_strings(const EdView& v, int64_t pi, const uint8_t** P, int64_t* m, const uint8_t** T, int64_t* n) {
+  const uint8_t* A = v.a + v.a_off[pi]; int64_t la = v.a_off[pi + 1] - v.a_off[pi];
+  const uint8_t* B = v.b + v.b_off[pi]; int64_t lb = v.b_off[pi + 1] - v.b_off[pi];
+  if (la <= lb) { *P = A; *m = la; *T = B; *n = lb; } else { *P = B; *m = lb; *T = A; *n = la; }
+}
+
+// thread per pair, block-major
+SNF_HD void ed_thread_body(int64_t i, const EdView& v) {
+  int64_t pi = v.list[i];
+  const uint8_t *P, *T; int64_t m, n;
+  pair_strings(v, pi, &P, &m, &T, &n);
+  if (m == 0) { v.out[pi] = (int32_t)n; return; }
+  int8_t* carry = v.carry + v.carry_off[pi];
+  int64_t nb = (m + 63) / 64;
+  int64_t score = nb * 64;
+  uint64_t Pv = ~0ull, Mv = 0;
+  for (int64_t blk = 0; blk < nb; blk++) {
+    uint64_t planes[8], valid;
+    int cnt = (int)(m - blk * 64 < 64 ? m - blk * 64 : 64);
+    block_planes(P + blk * 64, cnt, planes, &valid);
+    Pv = ~0ull; Mv = 0;
+    bool last = blk + 1 == nb;
+    for (int64_t j = 0; j < n; j++) {
+      int hin = blk == 0 ? 1 : carry[j];
+      int hout = advance_block(Pv, Mv, eq_mask(planes, valid, T[j]), hin);
+      if (last) score += hout; else carry[j] = (int8_t)hout;
     }
   }
-  v.out[i] = row[lb];
+  v.out[pi] = (int32_t)unpad_score(score, Pv, Mv, (int)(nb * 64 - m));
 }
+
 }  // namespace snf
 using namespace snf;
-SNF_KERNEL(ed_pair, EdView)
+SNF_KERNEL(ed_thread, EdView)
+
+#ifndef SNF_EMU
+// wave per pair: lane = block of the current 64-block pass, anti-diagonal schedule
+__global__ void __launch_bounds__(64) ed_wave(const EdView v, int64_t n_items) {
+  const int lane = threadIdx.x;
+  for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int64_t pi = v.list[it];
+    const uint8_t *P, *T; int64_t m, n;
+    pair_strings(v, pi, &P, &m, &T, &n);
+    int8_t* carry = v.carry + v.carry_off[pi];
+    const int64_t nb = (m + 63) / 64;
+    int64_t score = nb * 64;
+    uint64_t fPv = ~0ull, fMv = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += 64) {
+      const int nl = (int)(nb - b0 < 64 ? nb - b0 : 64);   // lanes (blocks) active in this pass
+      const int64_t blk = b0 + lane;
+      uint64_t planes[8], valid = 0, Pv = ~0ull, Mv = 0;
+      for (int k = 0; k < 8; k++) planes[k] = 0;
+      if (lane < nl) {
+        const int cnt = (int)(m - blk * 64 < 64 ? m - blk * 64 : 64);
+        block_planes(P + blk * 64, cnt, planes, &valid);
+      }
+      const bool glast = lane == nl - 1 && b0 + nl == nb;    // owns the last block of the pattern
+      int hout = 0;
+      const int64_t steps = n + nl - 1;
+      for (int64_t t = 0; t < steps; t++) {
+        const int up = __shfl_up(hout, 1, 64);               // hout of the block above, previous step
+        const int64_t j = t - lane;
+        if (lane < nl && j >= 0 && j < n) {
+          const int hin = lane == 0 ? (b0 == 0 ? 1 : (int)carry[j]) : up;
+          hout = advance_block(Pv, Mv, eq_mask(planes, valid, T[j]), hin);
+          if (glast) score += hout;
+          else if (lane == nl - 1) carry[j] = (int8_t)hout;  // feeds block b0+64 in the next pass
+        }
+      }
+      if (glast) { fPv = Pv; fMv = Mv; }
+      __syncthreads();
+    }
+    const int owner = (int)((nb - 1) & 63);
+    const int64_t sc = __shfl(score, owner, 64);
+    const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
+    if (lane == 0) v.out[pi] = (int32_t)unpad_score(sc, oPv, oMv, (int)(nb * 64 - m));
+  }
+}
+#endif
+
+namespace {
+thread_local std::string g_ed_err;
+}
 
 extern "C" int snf_edit_distance_batch(int device, const uint8_t* a_pool, const int64_t* a_off, const uint8_t* b_pool,
                                        const int64_t* b_off, int64_t n_pairs, int32_t* out_dist) {
   if (n_pairs <= 0) return 0;
-  int64_t la = a_off[n_pairs], lb = b_off[n_pairs];
-  std::vector<int64_t> row_off((size_t)n_pairs + 1, 0);
-  for (int64_t i = 0; i < n_pairs; i++) row_off[i + 1] = row_off[i] + (b_off[i + 1] - b_off[i]) + 1;
+  const int64_t la = a_off[n_pairs], lb = b_off[n_pairs];
+  std::vector<int64_t> carry_off((size_t)n_pairs + 1, 0);
+  std::vector<int32_t> thread_list, wave_list;
+  for (int64_t i = 0; i < n_pairs; i++) {
+    int64_t x = a_off[i + 1] - a_off[i], y = b_off[i + 1] - b_off[i];
+    int64_t m = x < y ? x : y, n = x < y ? y : x;
+    carry_off[i + 1] = carry_off[i] + n;
+    if ((m + 63) / 64 <= 8) thread_list.push_back((int32_t)i); else wave_list.push_back((int32_t)i);
+  }
   EdView v{};
-  v.n = n_pairs;
 #ifndef SNF_EMU
   int nd = 0;
-  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device >= nd) return 1;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) return 1;
   if (hipSetDevice(device) != hipSuccess) return 1;
-  uint8_t *da, *db; int64_t *dao, *dbo, *dro; int32_t *dout, *drow;
-  hipMalloc(&da, la + 1); hipMalloc(&db, lb + 1); hipMalloc(&dao, (n_pairs + 1) * 8); hipMalloc(&dbo, (n_pairs + 1) * 8);
-  hipMalloc(&dro, (n_pairs + 1) * 8); hipMalloc(&dout, n_pairs * 4); hipMalloc(&drow, row_off[n_pairs] * 4 + 4);
-  hipMemcpy(da, a_pool, la, hipMemcpyHostToDevice); hipMemcpy(db, b_pool, lb, hipMemcpyHostToDevice);
-  hipMemcpy(dao, a_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice); hipMemcpy(dbo, b_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice);
-  hipMemcpy(dro, row_off.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice);
-  v.a = da; v.a_off = dao; v.b = db; v.b_off = dbo; v.out = dout; v.row = drow; v.row_off = dro;
-  hipLaunchKernelGGL(ed_pair, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, 0, v, n_pairs);
-  hipError_t e = hipMemcpy(out_dist, dout, n_pairs * 4, hipMemcpyDeviceToHost);
-  hipFree(da); hipFree(db); hipFree(dao); hipFree(dbo); hipFree(dro); hipFree(dout); hipFree(drow);
-  return e == hipSuccess ? 0 : 1;
+  uint8_t *da = nullptr, *db = nullptr; int64_t *dao = nullptr, *dbo = nullptr, *dco = nullptr; int32_t *dout = nullptr, *dlist = nullptr;
+  int8_t* dcarry = nullptr;
+  bool ok = true;
+  auto chk = [&](hipError_t e) { if (e != hipSuccess) ok = false; };
+  chk(hipMalloc(&da, la + 16)); chk(hipMalloc(&db, lb + 16));
+  chk(hipMalloc(&dao, (n_pairs + 1) * 8)); chk(hipMalloc(&dbo, (n_pairs + 1) * 8)); chk(hipMalloc(&dco, (n_pairs + 1) * 8));
+  chk(hipMalloc(&dout, n_pairs * 4)); chk(hipMalloc(&dlist, n_pairs * 4 + 4)); chk(hipMalloc(&dcarry, carry_off[n_pairs] + 16));
+  if (ok) {
+    chk(hipMemcpy(da, a_pool, la, hipMemcpyHostToDevice)); chk(hipMemcpy(db, b_pool, lb, hipMemcpyHostToDevice));
+    chk(hipMemcpy(dao, a_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice)); chk(hipMemcpy(dbo, b_off, (n_pairs + 1) * 8, hipMemcpyHostToDevice));
+    chk(hipMemcpy(dco, carry_off.data(), (n_pairs + 1) * 8, hipMemcpyHostToDevice));
+    v.a = da; v.a_off = dao; v.b = db; v.b_off = dbo; v.out = dout; v.carry = dcarry; v.carry_off = dco;
+    if (!thread_list.empty()) {
+      chk(hipMemcpy(dlist, thread_list.data(), thread_list.size() * 4, hipMemcpyHostToDevice));
+      v.list = dlist; v.n = (int64_t)thread_list.size();
+      hipLaunchKernelGGL(ed_thread, dim3((unsigned)((v.n + 255) / 256)), dim3(256), 0, 0, v, v.n);
+      chk(hipDeviceSynchronize());
+    }
+    if (!wave_list.empty()) {
+      chk(hipMemcpy(dlist, wave_list.data(), wave_list.size() * 4, hipMemcpyHostToDevice));
+      v.list = dlist; v.n = (int64_t)wave_list.size();
+      int64_t grid = v.n < 16384 ? v.n : 16384;
+      hipLaunchKernelGGL(ed_wave, dim3((unsigned)grid), dim3(64), 0, 0, v, v.n);
+      chk(hipDeviceSynchronize());
+    }
+    chk(hipMemcpy(out_dist, dout, n_pairs * 4, hipMemcpyDeviceToHost));
+  }
+  hipFree(da); hipFree(db); hipFree(dao); hipFree(dbo); hipFree(dco); hipFree(dout); hipFree(dlist); hipFree(dcarry);
+  return ok ? 0 : 1;
 #else
   (void)device; (void)la; (void)lb;
-  std::vector<int32_t> row((size_t)row_off[n_pairs] + 1);
-  v.a = a_pool; v.a_off = a_off; v.b = b_pool; v.b_off = b_off; v.out = out_dist; v.row = row.data(); v.row_off = row_off.data();
-  ed_pair(v, n_pairs);
+  std::vector<int8_t> carry((size_t)carry_off[n_pairs] + 16);
+  std::vector<int32_t> all;
+  all.insert(all.end(), thread_list.begin(), thread_list.end());
+  all.insert(all.end(), wave_list.begin(), wave_list.end());
+  v.a = a_pool; v.a_off = a_off; v.b = b_pool; v.b_off = b_off; v.out = out_dist; v.carry = carry.data();
+  v.carry_off = carry_off.data(); v.list = all.data(); v.n = (int64_t)all.size();
+  ed_thread(v, v.n);
   return 0;
 #endif
 }

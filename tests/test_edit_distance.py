@@ -1,0 +1,48 @@
+"""snf_edit_distance_batch (bit-parallel Myers, replaces edlib.align(a,b)['editDistance'] in SVGroup.align_call,
+sv.py:280-289) against the exact two-row DP of the oracle.  edlib itself is absent: parity with edlib is the
+mathematical definition of its default mode (global NW, unit costs) - "parity unpinned" against the library."""
+import numpy as np
+import pytest
+
+from sniffles_amd import lib
+
+
+def make_pairs(seed, sizes, alphabet=b"ACGT"):
+    rng = np.random.default_rng(seed)
+    pairs = [(b"", b""), (b"kitten", b"sitting"), (b"<DEL>", b"<DEL>"), (b"ACGT", b""), (b"", b"ACGTN"), (b"<INS>", b"<DEL>"),
+             (b"A" * 64, b"A" * 64), (b"A" * 65, b"C" * 63), (b"ACGT" * 16, b"ACGT" * 16 + b"T")]
+    al = list(alphabet)
+    for n in sizes:
+        a = bytes(rng.choice(al, n).astype(np.uint8))
+        b = bytearray(a)
+        for _ in range(int(rng.integers(0, max(2, n // 8)))):
+            p = int(rng.integers(0, max(1, len(b))))
+            op = rng.integers(0, 3)
+            if op == 0 and b:
+                b[p % len(b)] = int(rng.choice(al))
+            elif op == 1:
+                b.insert(p, int(rng.choice(al)))
+            elif b:
+                del b[p % len(b)]
+        pairs.append((a, bytes(b)))
+        if n > 4:
+            pairs.append((a, bytes(rng.choice(al, int(rng.integers(1, n + 20))).astype(np.uint8))))  # unrelated
+    return pairs
+
+
+def test_edit_distance_emulated(oracle_mod):
+    import emu.emu as E
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 300, 511, 513, 700] + list(np.random.default_rng(0).integers(1, 400, 60))
+    pairs = make_pairs(1, sizes, alphabet=b"ACGTNacgt<>")
+    got = lib.edit_distance_batch(pairs, _lib=E.lib())
+    assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]
+
+
+@pytest.mark.gpu
+def test_edit_distance_gpu_thread_and_wave_paths(oracle_mod):
+    # <= 512: thread per pair; > 512: wave per pair; > 4096: several 64-block passes
+    sizes = [1, 63, 64, 65, 128, 300, 512, 513, 600, 1000, 2047, 4096, 4097, 5000, 9000] + \
+        list(np.random.default_rng(2).integers(1, 3000, 120))
+    pairs = make_pairs(3, sizes, alphabet=b"ACGTN")
+    got = lib.edit_distance_batch(pairs)
+    assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]

@@ -113,22 +113,3 @@ def test_full_size_properties():
     ins = (c["svtype"] == 0) & (c["alt_len"] >= 0)
     assert ins.sum() > 100 and np.all(c["alt_len"][ins] >= 45)
     assert (c["filter"] == 0).sum() > 400  # ~561 planted sites on chr20
-
-
-def test_edit_distance_batch_matches_oracle(oracle_mod):
-    rng = np.random.default_rng(4)
-    pairs = [(b"", b""), (b"kitten", b"sitting"), (b"<DEL>", b"<DEL>"), (b"ACGT", b"")]
-    for _ in range(200):
-        n = int(rng.integers(1, 400))
-        a = bytes(rng.choice(list(b"ACGT"), n))
-        b = bytearray(a)
-        for _ in range(int(rng.integers(0, 30))):
-            p = int(rng.integers(0, max(1, len(b))))
-            op = rng.integers(0, 3)
-            if op == 0 and b: b[p % len(b)] = int(rng.choice(list(b"ACGT")))
-            elif op == 1: b.insert(p, int(rng.choice(list(b"ACGT"))))
-            elif b: del b[p % len(b)]
-        pairs.append((a, bytes(b)))
-    got = lib.edit_distance_batch(pairs)
-    exp = [oracle_mod.edit_distance(a, b) for a, b in pairs]
-    assert got.tolist() == exp
