@@ -332,6 +332,45 @@ int snf_edit_distance_batch(int device, const uint8_t* a_pool, const int64_t* a_
                             const uint8_t* b_pool, const int64_t* b_off,
                             int64_t n_pairs, int32_t* out_dist);
 
+/*
+ * Multi-sample combine: group assignment of cluster.resolve_block_groups (src/sniffles/cluster.py:356-390)
+ * including SVGroup.align_call (src/sniffles/sv.py:280-289).  One problem = one call of resolve_block_groups
+ * (one svtype, one flush window of CombineTask.execute, src/sniffles/parallel.py:524-534); problems are
+ * independent and run concurrently.  Candidates are given in the order of `svcands`; the stable sort by
+ * support (descending), the greedy nearest-group search with running means (SVGroup.add_candidate,
+ * sv.py:297-318) and the on-demand edit distance happen on the GPU.  out_group[i] = index of candidate i's
+ * group in the list `groups_initial + [new groups in creation order]`.  SVGroup.call (sv.py:320-481) is
+ * host-side bookkeeping over the resulting membership (sniffles_amd/sv.py).
+ */
+typedef struct snf_combine_problem {
+  int32_t svtype;
+  int32_t n_cands;
+  int32_t n_groups;     /* len(groups_initial) */
+  int32_t n_sample_ids; /* sample_internal_id values are in [0, n_sample_ids) */
+  const int32_t* pos;
+  const int32_t* svlen;
+  const int32_t* support;
+  const int32_t* sample_id;
+  const int32_t* mate_contig;    /* BND: order-free id of bnd_info.mate_contig (equality only) */
+  const int32_t* mate_ref_start; /* BND */
+  const int64_t* alt_off;        /* n_cands + 1 offsets into alt_pool: SVCall.alt */
+  const uint8_t* alt_pool;
+  /* groups_initial: SVGroup state (sv.py:226-241) */
+  const double* g_pos_mean;
+  const double* g_len_mean;
+  const double* g_mate_mean;     /* bnd_mate_ref_start_mean */
+  const int32_t* g_size;         /* len(group.candidates) */
+  const int32_t* g_mate_contig;
+  const int64_t* g_alt_off;      /* n_groups + 1: group.candidates[0].alt */
+  const uint8_t* g_alt_pool;
+  const int64_t* g_samples_off;  /* n_groups + 1: group.included_samples */
+  const int32_t* g_samples;
+  int32_t* out_group;            /* n_cands */
+} snf_combine_problem_t;
+
+int snf_combine_resolve_batch(const snf_config_t* cfg, int device, const snf_combine_problem_t* problems,
+                              int64_t n_problems);
+
 #ifdef __cplusplus
 }
 #endif

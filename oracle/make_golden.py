@@ -52,5 +52,25 @@ def main(names=None):
         print(f"{name:32s} {ti.n_leads:7d} leads  {n}")
 
 
+
+
+def main_combine(names=None):
+    import cases
+    import ref_harness as rh
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (build, args) in cases.COMBINE.items():
+        if names and name not in names:
+            continue
+        tis = build()
+        ref = rh.run_reference_combine(tis, args)
+        doc = dict(case=name, reference_args=list(args), input_sha=[input_sha(t) for t in tis], expected=ref)
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
+            f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+        print(f"{name:32s} {len(tis)} samples  {sum(len(p['cands']) for p in ref['problems'])} cands  "
+              f"{sum(len(p['groups']) for p in ref['problems'])} groups  {sum(len(c['calls']) for c in ref['calls'])} calls")
+
+
 if __name__ == "__main__":
-    main(set(sys.argv[1:]))
+    sel = set(sys.argv[1:])
+    main(sel)
+    main_combine(sel)

@@ -48,6 +48,8 @@ def lib():
         _lib.snf_oracle_stdev.argtypes = [C.POINTER(C.c_int64), C.c_int64]
         _lib.snf_oracle_stdev.restype = C.c_double
         _lib.snf_oracle_hot_seconds.restype = C.c_double
+        _lib.snf_oracle_combine_resolve.argtypes = [C.POINTER(abi.snf_config_t), C.POINTER(abi.snf_combine_problem_t)]
+        _lib.snf_oracle_combine_resolve.restype = C.c_int
     return _lib
 
 
@@ -85,3 +87,12 @@ def stdev(x) -> float:
 def hot_seconds() -> float:
     """Seconds the last run() spent in call_candidates + finalize_candidates (coverage-vector build excluded)."""
     return float(lib().snf_oracle_hot_seconds())
+
+
+def combine_resolve(cfg, problem) -> None:
+    """Group assignment of one packed resolve_block_groups problem (abi.combine_problem); fills its out_group."""
+    from sniffles_amd import abi
+    cs = abi.config_struct(cfg)
+    rc = lib().snf_oracle_combine_resolve(C.byref(cs), C.byref(problem))
+    if rc != 0:
+        raise RuntimeError("snf_oracle_combine_resolve failed")

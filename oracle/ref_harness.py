@@ -178,3 +178,88 @@ def run_reference(ti, extra_args=(), keep_qc_fails=True, finalize_keep=False, cf
     final = task.finalize_candidates(cands, finalize_keep, cfg)
     out["final"] = [call_record(c, "final") for c in final]
     return out
+
+
+# ---------------------------------------------------------------------------------------------- combine (multi-sample)
+def cand_record(c) -> dict:
+    """Everything resolve_block_groups / SVGroup.call read from a per-sample candidate SVCall."""
+    gt = c.genotypes.get(0)
+    return dict(id=c.id, contig=c.contig, pos=int(c.pos), end=int(c.end), svtype=c.svtype, svlen=int(c.svlen),
+                support=int(c.support), qual=int(c.qual), precise=bool(c.precise), fwd=int(c.fwd), rev=int(c.rev),
+                filter=c.filter, qc=bool(c.qc), alt=c.alt, sample=int(c.sample_internal_id),
+                cov=[int(c.coverage_upstream), int(c.coverage_start), int(c.coverage_center), int(c.coverage_end),
+                     int(c.coverage_downstream)],
+                gt=None if gt is None else [gt[0], gt[1], int(gt[2]), int(gt[3]), int(gt[4]), list(gt[5])],
+                bnd=None if c.bnd_info is None else [c.bnd_info.mate_contig, int(c.bnd_info.mate_ref_start),
+                                                    bool(c.bnd_info.is_first), bool(c.bnd_info.is_reverse)])
+
+
+def group_call_record(c) -> dict:
+    return dict(id=c.id, contig=c.contig, pos=int(c.pos), end=int(c.end), svtype=c.svtype, svlen=int(c.svlen),
+                support=int(c.support), qual=c.qual, precise=bool(c.precise), fwd=int(c.fwd), rev=int(c.rev),
+                filter=c.filter, alt=c.alt,
+                cov=[c.coverage_upstream, c.coverage_start, c.coverage_center, c.coverage_end, c.coverage_downstream],
+                stdev_pos=_f(c.info.get("STDEV_POS")), stdev_len=_f(c.info.get("STDEV_LEN")),
+                genotypes={str(k): [v[0], v[1], v[2], v[3], v[4], list(v[5]), v[6]] for k, v in sorted(c.genotypes.items())})
+
+
+def fake_coverage(pos_mean: float, sample: int) -> int:
+    """Deterministic stand-in for the SNF _COVERAGE lookup of non-included samples (parallel.py:536-551)."""
+    return (int(pos_mean) + 3 * sample) % 30
+
+
+def run_reference_combine(sample_tasks, extra_args=(), split=True):
+    """Per-sample candidates from the reference's own call_candidates + finalize_candidates, then the reference's
+    resolve_block_groups (two chained windows per SV type so that `groups_initial` is exercised) and SVGroup.call."""
+    import oracle as oc  # exact DP (C) as the stand-in for edlib.align(...)['editDistance']
+    ref = load_reference()
+    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    ns = len(sample_tasks)
+    cfg = make_config(tuple(extra_args), sample_tasks[0].qc_nm_threshold)
+    per_sample = []
+    for s, ti in enumerate(sample_tasks):
+        cfg_s = make_config((), ti.qc_nm_threshold)
+        task = build_task(ti, cfg_s)
+        cands = task.call_candidates(False, cfg_s)
+        task.finalize_candidates(cands, True, cfg_s)
+        keep = []
+        for c in cands:
+            if c.svtype not in ref.sv.TYPES or c.support < cfg.combine_support_threshold:
+                continue
+            c.rnames = None            # SNFile.store drops read names (snf.py:97-98)
+            c.sample_internal_id = s
+            keep.append(c)
+        per_sample.append(keep)
+    cfg.snf_input_info = [dict(internal_id=s) for s in range(ns)]
+    cfg.mode = "combine"
+    task = ref.parallel.Task(id=7, sv_id=0, contig=sample_tasks[0].contig, start=0, end=sample_tasks[0].contig_len,
+                             config=cfg)
+    out = dict(n_samples=ns, problems=[], calls=[])
+    for svtype in ref.sv.TYPES:
+        bins = {}
+        for s in range(ns):
+            for c in per_sample[s]:
+                if c.svtype == svtype:
+                    bins.setdefault(int(c.pos / cfg.combine_min_size) * cfg.combine_min_size, []).append(c)
+        if not bins:
+            continue
+        ordered = [c for b in sorted(bins) for c in bins[b]]
+        windows = [ordered[:len(ordered) // 2], ordered[len(ordered) // 2:]] if split and len(ordered) > 3 else [ordered]
+        groups = []
+        for w in windows:
+            before = [[(c.sample_internal_id, c.id) for c in g.candidates] for g in groups]
+            state = [dict(pos_mean=g.pos_mean, len_mean=g.len_mean,
+                          mate_mean=None if g.bnd_mate_ref_start_mean is None else float(g.bnd_mate_ref_start_mean))
+                     for g in groups]
+            groups = ref.cluster.resolve_block_groups(svtype, w, groups, cfg)
+            out["problems"].append(dict(
+                svtype=svtype, cands=[cand_record(c) for c in w], groups_initial=before, groups_initial_state=state,
+                groups=[dict(members=[[c.sample_internal_id, c.id] for c in g.candidates], pos_mean=g.pos_mean,
+                             len_mean=g.len_mean,
+                             mate_mean=None if g.bnd_mate_ref_start_mean is None else float(g.bnd_mate_ref_start_mean))
+                        for g in groups]))
+        for g in groups:
+            for s in set(range(ns)) - g.included_samples:
+                g.coverages_nonincluded[s] = fake_coverage(g.pos_mean, s)
+        out["calls"].append(dict(svtype=svtype, calls=[group_call_record(c) for c in ref.sv.call_groups(groups, cfg, task)]))
+    return out

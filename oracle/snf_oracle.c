@@ -1259,3 +1259,80 @@ int64_t snf_oracle_edit_distance(const uint8_t* a, int64_t la, const uint8_t* b,
   free(prev); free(cur);
   return d;
 }
+
+/* ------------------------------------------------------------------ combine (multi-sample) -- test infrastructure
+ * cluster.resolve_block_groups (cluster.py:356-390) + SVGroup.from_candidate / align_call / add_candidate
+ * (sv.py:263-318), followed literally; edlib.align(a,b)["editDistance"] = snf_oracle_edit_distance (exact DP). */
+typedef struct OGroup {
+  double pos_mean, len_mean, mate_mean; int is_int_mate;
+  int32_t size, mate_contig;
+  const uint8_t* alt; int64_t alt_len;
+  uint8_t* included; /* [n_sample_ids] */
+} OGroup;
+
+int snf_oracle_combine_resolve(const snf_config_t* cfg, const snf_combine_problem_t* q) {
+  int nc = q->n_cands, ng = q->n_groups, ns = q->n_sample_ids > 0 ? q->n_sample_ids : 1;
+  OGroup* G = (OGroup*)calloc((size_t)(nc + ng + 1), sizeof(OGroup));
+  for (int g = 0; g < ng; g++) {
+    G[g].pos_mean = q->g_pos_mean[g]; G[g].len_mean = q->g_len_mean[g]; G[g].mate_mean = q->g_mate_mean ? q->g_mate_mean[g] : 0;
+    G[g].size = q->g_size[g]; G[g].mate_contig = q->g_mate_contig ? q->g_mate_contig[g] : 0;
+    G[g].alt = q->g_alt_pool + q->g_alt_off[g]; G[g].alt_len = q->g_alt_off[g + 1] - q->g_alt_off[g];
+    G[g].included = (uint8_t*)calloc((size_t)ns, 1);
+    for (int64_t k = q->g_samples_off[g]; k < q->g_samples_off[g + 1]; k++) G[g].included[q->g_samples[k]] = 1;
+  }
+  /* sorted(svcands, key=lambda cand: cand.support, reverse=True): stable */
+  SortKey* sk = (SortKey*)malloc((size_t)(nc + 1) * sizeof(SortKey));
+  for (int i = 0; i < nc; i++) { sk[i].key = -(int64_t)q->support[i]; sk[i].idx = i; }
+  qsort(sk, (size_t)nc, sizeof(SortKey), cmp_sortkey);
+  for (int oi = 0; oi < nc; oi++) {
+    int c = (int)sk[oi].idx;
+    int best = -1; double best_dist = INFINITY;
+    if (q->svtype == SNF_BND) {
+      for (int g = 0; g < ng; g++) {
+        double dist = fabs(G[g].pos_mean - (double)q->pos[c]) + fabs(G[g].mate_mean - (double)q->mate_ref_start[c]);
+        if (dist < best_dist && dist <= (double)(cfg->cluster_merge_bnd * 2) && G[g].mate_contig == q->mate_contig[c]) {
+          if (!cfg->combine_separate_intra || !G[g].included[q->sample_id[c]]) { best = g; best_dist = dist; }
+        }
+      }
+    } else {
+      for (int g = 0; g < ng; g++) {
+        double alen = fabs((double)q->svlen[c]);
+        double dist = fabs(G[g].pos_mean - (double)q->pos[c]) + fabs(fabs(G[g].len_mean) - alen);
+        double minlen = fabs(G[g].len_mean) < alen ? fabs(G[g].len_mean) : alen;
+        if (minlen > 0 && dist < best_dist && dist <= (double)cfg->combine_match * sqrt(minlen) && dist <= (double)cfg->combine_match_max) {
+          if (!cfg->combine_separate_intra || !G[g].included[q->sample_id[c]]) {
+            int ok = 1;
+            if (cfg->combine_pctseq != 0.0) {
+              int64_t d = snf_oracle_edit_distance(G[g].alt, G[g].alt_len, q->alt_pool + q->alt_off[c], q->alt_off[c + 1] - q->alt_off[c]);
+              ok = ((G[g].len_mean - (double)d) / G[g].len_mean) > cfg->combine_pctseq;
+            }
+            if (ok) { best = g; best_dist = dist; }
+          }
+        }
+      }
+    }
+    if (best < 0) {
+      OGroup* g = &G[ng];
+      g->pos_mean = (double)q->pos[c]; g->len_mean = fabs((double)q->svlen[c]);
+      g->mate_mean = q->mate_ref_start ? (double)q->mate_ref_start[c] : 0; g->size = 1;
+      g->mate_contig = q->mate_contig ? q->mate_contig[c] : 0;
+      g->alt = q->alt_pool + q->alt_off[c]; g->alt_len = q->alt_off[c + 1] - q->alt_off[c];
+      g->included = (uint8_t*)calloc((size_t)ns, 1); g->included[q->sample_id[c]] = 1;
+      q->out_group[c] = ng++;
+    } else {
+      OGroup* g = &G[best];
+      double n = (double)g->size;
+      g->pos_mean *= n; g->len_mean *= n;
+      g->pos_mean += (double)q->pos[c]; g->len_mean += fabs((double)q->svlen[c]);
+      if (q->svtype == SNF_BND) { g->mate_mean *= n; g->mate_mean += (double)q->mate_ref_start[c]; }
+      g->size++;
+      g->pos_mean /= (double)g->size; g->len_mean /= (double)g->size;
+      g->included[q->sample_id[c]] = 1;
+      if (q->svtype == SNF_BND) g->mate_mean /= (double)g->size;
+      q->out_group[c] = best;
+    }
+  }
+  for (int g = 0; g < ng; g++) free(G[g].included);
+  free(G); free(sk);
+  return 0;
+}

@@ -110,6 +110,68 @@ class snf_result_t(C.Structure):
     ]
 
 
+class snf_combine_problem_t(C.Structure):
+    _fields_ = [
+        ("svtype", i32), ("n_cands", i32), ("n_groups", i32), ("n_sample_ids", i32),
+        ("pos", C.POINTER(C.c_int32)), ("svlen", C.POINTER(C.c_int32)), ("support", C.POINTER(C.c_int32)),
+        ("sample_id", C.POINTER(C.c_int32)), ("mate_contig", C.POINTER(C.c_int32)), ("mate_ref_start", C.POINTER(C.c_int32)),
+        ("alt_off", C.POINTER(C.c_int64)), ("alt_pool", u8p),
+        ("g_pos_mean", C.POINTER(C.c_double)), ("g_len_mean", C.POINTER(C.c_double)), ("g_mate_mean", C.POINTER(C.c_double)),
+        ("g_size", C.POINTER(C.c_int32)), ("g_mate_contig", C.POINTER(C.c_int32)),
+        ("g_alt_off", C.POINTER(C.c_int64)), ("g_alt_pool", u8p),
+        ("g_samples_off", C.POINTER(C.c_int64)), ("g_samples", C.POINTER(C.c_int32)),
+        ("out_group", C.POINTER(C.c_int32)),
+    ]
+
+
+def combine_problem(svtype_code: int, cands: dict, groups: dict, n_sample_ids: int, keep: list):
+    """Pack one resolve_block_groups call.  `cands`: pos, svlen, support, sample_id, mate_contig, mate_ref_start
+    (int lists) and alts (list of bytes); `groups`: pos_mean, len_mean, mate_mean, size, mate_contig, alts, samples
+    (list of lists).  Returns (struct, out_group numpy array)."""
+    q = snf_combine_problem_t()
+    n, g = len(cands["pos"]), len(groups["pos_mean"])
+    q.svtype, q.n_cands, q.n_groups, q.n_sample_ids = svtype_code, n, g, max(1, n_sample_ids)
+
+    def arr(x, dt):
+        a = np.ascontiguousarray(np.asarray(x, dtype=dt).reshape(-1))
+        if a.size == 0:
+            a = np.zeros(1, dt)
+        keep.append(a)
+        return a
+
+    def pool(strs):
+        off = np.zeros(len(strs) + 1, np.int64)
+        for i, s in enumerate(strs):
+            off[i + 1] = off[i] + len(s)
+        data = np.frombuffer(b"".join(strs) + b"\0", np.uint8).copy()
+        keep.extend([off, data])
+        return off, data
+
+    for name in ("pos", "svlen", "support", "sample_id", "mate_contig", "mate_ref_start"):
+        setattr(q, name, _ptr(arr(cands[name], np.int32), C.c_int32))
+    off, data = pool(cands["alts"])
+    q.alt_off, q.alt_pool = _ptr(off, C.c_int64), _ptr(data, C.c_uint8)
+    q.g_pos_mean = _ptr(arr(groups["pos_mean"], np.float64), C.c_double)
+    q.g_len_mean = _ptr(arr(groups["len_mean"], np.float64), C.c_double)
+    q.g_mate_mean = _ptr(arr(groups["mate_mean"], np.float64), C.c_double)
+    q.g_size = _ptr(arr(groups["size"], np.int32), C.c_int32)
+    q.g_mate_contig = _ptr(arr(groups["mate_contig"], np.int32), C.c_int32)
+    off, data = pool(groups["alts"])
+    q.g_alt_off, q.g_alt_pool = _ptr(off, C.c_int64), _ptr(data, C.c_uint8)
+    soff = np.zeros(g + 1, np.int64)
+    flat = []
+    for i, ss in enumerate(groups["samples"]):
+        flat.extend(sorted(ss))
+        soff[i + 1] = len(flat)
+    keep.append(soff)
+    q.g_samples_off = _ptr(soff, C.c_int64)
+    q.g_samples = _ptr(arr(flat, np.int32), C.c_int32)
+    out = np.full(max(n, 1), -1, np.int32)
+    keep.append(out)
+    q.out_group = _ptr(out, C.c_int32)
+    return q, out
+
+
 def config_struct(cfg) -> snf_config_t:
     """Build snf_config_t from a SnifflesConfig-compatible namespace (reference config.py:103-619)."""
     s = snf_config_t()

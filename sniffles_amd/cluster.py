@@ -1,0 +1,74 @@
+"""`resolve_block_groups` with the reference's signature (reference `src/sniffles/cluster.py:356-390`).
+
+The single-sample clustering entry points of the reference's `cluster.py` (`resolve`, `merge_inner`, `resplit`,
+`resplit_bnd`) have no Python counterpart here: they run inside `Task.call_candidates` on the GPU
+(`sniffles_amd/parallel.py`)."""
+from __future__ import annotations
+
+from . import abi, lib
+from .soa import SVT
+from .sv import SVGroup
+
+
+def _alt_bytes(alt) -> bytes:
+    return alt.encode("latin-1") if isinstance(alt, str) else bytes(alt)
+
+
+def pack_problem(svtype, svcands, groups_initial, keep):
+    contig_ids = {}
+
+    def cid(name):
+        return contig_ids.setdefault(name, len(contig_ids))
+
+    bnd = svtype == "BND"
+    cands = dict(pos=[c.pos for c in svcands], svlen=[c.svlen for c in svcands], support=[c.support for c in svcands],
+                 sample_id=[c.sample_internal_id for c in svcands],
+                 mate_contig=[cid(c.bnd_info.mate_contig) if bnd else 0 for c in svcands],
+                 mate_ref_start=[c.bnd_info.mate_ref_start if bnd else 0 for c in svcands],
+                 alts=[_alt_bytes(c.alt) for c in svcands])
+    groups = dict(pos_mean=[g.pos_mean for g in groups_initial], len_mean=[g.len_mean for g in groups_initial],
+                  mate_mean=[float(g.bnd_mate_ref_start_mean) if bnd else 0.0 for g in groups_initial],
+                  size=[len(g.candidates) for g in groups_initial],
+                  mate_contig=[cid(g.bnd_mate_contig) if bnd else 0 for g in groups_initial],
+                  alts=[_alt_bytes(g.candidates[0].alt) for g in groups_initial],
+                  samples=[g.included_samples for g in groups_initial])
+    ids = [c.sample_internal_id for c in svcands] + [s for g in groups_initial for s in g.included_samples]
+    n_ids = (max(ids) + 1) if ids else 1
+    return abi.combine_problem(SVT[svtype], cands, groups, n_ids, keep)
+
+
+def apply_assignment(svcands, groups_initial, out_group):
+    """Replay SVGroup.from_candidate / add_candidate in the reference's order (support descending, stable) with the
+    group index the GPU chose for every candidate; the running means are recomputed by the same float operations."""
+    groups = groups_initial
+    n0 = len(groups_initial)
+    created = {}
+    order = sorted(range(len(svcands)), key=lambda i: svcands[i].support, reverse=True)
+    for i in order:
+        g = int(out_group[i])
+        if g < n0:
+            groups[g].add_candidate(svcands[i])
+        elif g in created:
+            created[g].add_candidate(svcands[i])
+        else:
+            created[g] = SVGroup.from_candidate(svcands[i])
+            groups.append(created[g])
+    return groups
+
+
+def resolve_block_groups(svtype, svcands, groups_initial, config, device: int = 0, _lib=None):
+    """For clustering groups of SVs when combining .snf files (multi-call).  Mutates and returns `groups_initial`."""
+    keep = []
+    q, out = pack_problem(svtype, svcands, groups_initial, keep)
+    lib.combine_resolve_batch(config, [q], device=device, _lib=_lib)
+    return apply_assignment(svcands, groups_initial, out)
+
+
+def resolve_block_groups_batch(problems, config, device: int = 0, _lib=None):
+    """Several independent (svtype, svcands, groups_initial) problems in one launch - e.g. the flush windows of
+    different contigs / SV types of CombineTask.execute (parallel.py:524-534).  Returns the list of group lists."""
+    keep, packed = [], []
+    for svtype, svcands, groups_initial in problems:
+        packed.append(pack_problem(svtype, svcands, groups_initial, keep))
+    lib.combine_resolve_batch(config, [q for q, _ in packed], device=device, _lib=_lib)
+    return [apply_assignment(sc, gi, out) for (_, sc, gi), (_, out) in zip(problems, packed)]

@@ -28,6 +28,8 @@ _DEFAULTS = dict(
     combine_match=250, combine_match_max=1000, combine_separate_intra=False, combine_pctseq=0.7,
     combine_high_confidence=0.0, combine_low_confidence=0.2, combine_low_confidence_abs=2,
     combine_null_min_coverage=5, combine_output_filtered=False, combine_support_threshold=3,
+    combine_pair_relabel=False, combine_pair_relabel_threshold=20, combine_consensus=False, combine_population=None,
+    dev_combine_medians=False,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)
@@ -101,6 +103,7 @@ class SnifflesConfig:
         if self.dev_min_leads_cluster == -1:
             self.dev_min_leads_cluster = 1 if self.no_qc else 2
         self.mode = "call_sample"
+        self.snf_input_info = []   # combine: [{'internal_id': i, ...}] per input sample (sniffles:371-420)
         # per-task side channel written by iter_region (leadprov.py:577-578)
         self.average_regional_nm = 0.02
         self.qc_nm_threshold = 0.02

@@ -11,7 +11,7 @@
 //     column t - l at step t and takes hin from lane l-1 by a shuffle); patterns of > 64 blocks take several
 //     passes of 64 blocks linked through the same carry array.
 // No MFMA: this is integer/bit work; the bound is VALU issue, reported as such.
-#include "snf_exact.h"
+#include "snf_myers.h"
 #include "../../include/sniffles_amd.h"
 
 #include <string>
@@ -25,45 +25,6 @@ struct EdView {
   const int32_t* list; int64_t n;                           // pair indices handled by this launch
 };
 
-// bit-planes of up to 64 pattern bytes: planes[k] bit i = bit k of p[i]; *valid bit i = (i < cnt)
-SNF_HD void block_planes(const uint8_t* p, int cnt, uint64_t planes[8], uint64_t* valid) {
-  for (int k = 0; k < 8; k++) planes[k] = 0;
-  for (int i = 0; i < cnt; i++) {
-    uint8_t c = p[i];
-    for (int k = 0; k < 8; k++) planes[k] |= (uint64_t)((c >> k) & 1) << i;
-  }
-  *valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
-}
-SNF_HD uint64_t eq_mask(const uint64_t planes[8], uint64_t valid, uint8_t c) {
-  uint64_t e = valid;
-  for (int k = 0; k < 8; k++) e &= ((c >> k) & 1) ? planes[k] : ~planes[k];
-  return e;
-}
-// one block, one column (Hyyro 2003 / edlib calculateBlock); hin, hout in {-1, 0, +1}
-SNF_HD int advance_block(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, int hin) {
-  uint64_t Xv = Eq | Mv;
-  if (hin < 0) Eq |= 1ull;
-  uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-  uint64_t Ph = Mv | ~(Xh | Pv);
-  uint64_t Mh = Pv & Xh;
-  int hout = 0;
-  if (Ph >> 63) hout = 1;
-  if (Mh >> 63) hout = -1;
-  Ph <<= 1; Mh <<= 1;
-  if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
-  Pv = Mh | ~(Xv | Ph);
-  Mv = Ph & Xv;
-  return hout;
-}
-// D[m][n] from the score at the bottom row of the last (padded) block
-SNF_HD int64_t unpad_score(int64_t score, uint64_t Pv, uint64_t Mv, int pad_rows) {
-  for (int i = 0; i < pad_rows; i++) {
-    int bit = 63 - i;
-    score -= (int64_t)((Pv >> bit) & 1) - (int64_t)((Mv >> bit) & 1);
-  }
-  return score;
-}
-
 SNF_HD void pair_strings(const EdView& v, int64_t pi, const uint8_t** P, int64_t* m, const uint8_t** T, int64_t* n) {
   const uint8_t* A = v.a + v.a_off[pi]; int64_t la = v.a_off[pi + 1] - v.a_off[pi];
   const uint8_t* B = v.b + v.b_off[pi]; int64_t lb = v.b_off[pi + 1] - v.b_off[pi];
@@ -73,26 +34,9 @@ SNF_HD void pair_strings(const EdView& v, int64_t pi, const uint8_t** P, int64_t
 // thread per pair, block-major
 SNF_HD void ed_thread_body(int64_t i, const EdView& v) {
   int64_t pi = v.list[i];
-  const uint8_t *P, *T; int64_t m, n;
-  pair_strings(v, pi, &P, &m, &T, &n);
-  if (m == 0) { v.out[pi] = (int32_t)n; return; }
-  int8_t* carry = v.carry + v.carry_off[pi];
-  int64_t nb = (m + 63) / 64;
-  int64_t score = nb * 64;
-  uint64_t Pv = ~0ull, Mv = 0;
-  for (int64_t blk = 0; blk < nb; blk++) {
-    uint64_t planes[8], valid;
-    int cnt = (int)(m - blk * 64 < 64 ? m - blk * 64 : 64);
-    block_planes(P + blk * 64, cnt, planes, &valid);
-    Pv = ~0ull; Mv = 0;
-    bool last = blk + 1 == nb;
-    for (int64_t j = 0; j < n; j++) {
-      int hin = blk == 0 ? 1 : carry[j];
-      int hout = advance_block(Pv, Mv, eq_mask(planes, valid, T[j]), hin);
-      if (last) score += hout; else carry[j] = (int8_t)hout;
-    }
-  }
-  v.out[pi] = (int32_t)unpad_score(score, Pv, Mv, (int)(nb * 64 - m));
+  const uint8_t* A = v.a + v.a_off[pi]; int64_t la = v.a_off[pi + 1] - v.a_off[pi];
+  const uint8_t* B = v.b + v.b_off[pi]; int64_t lb = v.b_off[pi + 1] - v.b_off[pi];
+  v.out[pi] = (int32_t)ed_serial(A, la, B, lb, v.carry + v.carry_off[pi]);
 }
 
 }  // namespace snf

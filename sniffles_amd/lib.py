@@ -41,6 +41,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
                                             C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
+    lib.snf_combine_resolve_batch.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_combine_problem_t), C.c_int64]
+    lib.snf_combine_resolve_batch.restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
               "snf_batch_timing_count",
@@ -158,3 +160,15 @@ def edit_distance_batch(pairs, device: int = 0, _lib=None) -> np.ndarray:
                                             b_pool.ctypes.data_as(u8p), b_off.ctypes.data_as(i64p), n,
                                             out.ctypes.data_as(C.POINTER(C.c_int32))))
     return out[:n]
+
+
+def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
+    """Run a list of packed resolve_block_groups problems (abi.combine_problem structs); fills their out_group arrays."""
+    lib = _lib or load()
+    if not problems:
+        return
+    arr = (abi.snf_combine_problem_t * len(problems))(*problems)
+    cs = abi.config_struct(cfg)
+    rc = lib.snf_combine_resolve_batch(C.byref(cs), device, arr, len(problems))
+    if rc != 0:
+        raise SnifflesAmdError("snf_combine_resolve_batch failed (no HIP device, or invalid sample ids)")

@@ -155,3 +155,152 @@ def new_call(svcall_cls=SVCall):
     return svcall_cls(contig=None, pos=0, id="", ref="N", alt="", qual=0, filter="PASS", info=dict(), svtype="",
                       svlen=0, end=0, genotypes=dict(), precise=False, support=0, rnames=None, qc=True, nm=-1,
                       postprocess=None)
+
+
+# ---------------------------------------------------------------------------------------------- multi-sample combine
+@dataclass
+class SVGroup:
+    """Group of per-sample SV calls merged into one multi-sample call (reference `sv.py:226-481`).
+
+    Which candidate joins which group is decided on the GPU (`sniffles_amd.cluster.resolve_block_groups`); this class
+    holds the membership, keeps the running means exactly as the reference does, and builds the combined `SVCall`."""
+    candidates: list
+    pos_mean: float
+    len_mean: float
+    included_samples: set
+    coverages_nonincluded: dict
+    bnd_mate_ref_start_mean: float = None
+    bnd_mate_contig: str = None
+
+    @classmethod
+    def from_candidate(cls, candidate) -> "SVGroup":
+        g = cls(candidates=[candidate], pos_mean=float(candidate.pos), len_mean=float(abs(candidate.svlen)),
+                included_samples={candidate.sample_internal_id}, coverages_nonincluded=dict())
+        if candidate.svtype == "BND":
+            g.bnd_mate_contig = candidate.bnd_info.mate_contig
+            g.bnd_mate_ref_start_mean = candidate.bnd_info.mate_ref_start
+        return g
+
+    def add_candidate(self, candidate) -> None:
+        n = len(self.candidates)
+        self.pos_mean *= n
+        self.len_mean *= n
+        self.pos_mean += candidate.pos
+        self.len_mean += abs(candidate.svlen)
+        bnd = candidate.svtype == "BND"
+        if bnd:
+            self.bnd_mate_ref_start_mean *= n
+            self.bnd_mate_ref_start_mean += candidate.bnd_info.mate_ref_start
+        self.candidates.append(candidate)
+        n += 1
+        self.pos_mean /= n
+        self.len_mean /= n
+        self.included_samples.add(candidate.sample_internal_id)
+        if bnd:
+            self.bnd_mate_ref_start_mean /= n
+
+    def call(self, config, task, svcall_cls=None):
+        """Combined call of this group or None (reference `SVGroup.call`, sv.py:320-481)."""
+        from . import util
+        svcall_cls = svcall_cls or SVCall
+        first = self.candidates[0]
+        n_samples = len(config.snf_input_info)
+        single_noqc = config.no_qc and n_samples == 1
+        n_pass = sum(c.qc for c in self.candidates)
+        n_present = len(self.included_samples)
+        confident = (n_pass > 0 and n_pass / float(n_samples) >= config.combine_high_confidence) or \
+                    (n_present / float(n_samples) >= config.combine_low_confidence and
+                     n_present >= config.combine_low_confidence_abs)
+        if not confident and not single_noqc:
+            return None
+        if not config.combine_output_filtered and not any(c.qc and c.filter == "PASS" for c in self.candidates) \
+                and not single_noqc:
+            return None
+        if getattr(config, "combine_consensus", False):
+            raise NotImplementedError("--combine-consensus is broken in the reference (sv.py:382 unpacks 7-tuples into 5)")
+
+        rnames = []
+        genotypes = {}
+        for c in self.candidates:
+            if c.rnames is not None:
+                rnames.extend(c.rnames)
+            if 0 not in c.genotypes:
+                c.genotypes[0] = (".", ".", 0, 0, c.support, (None, None))
+            a, b, gq, dr, dv, ps = c.genotypes[0]
+            sid = c.sample_internal_id
+            if sid in genotypes:  # several calls of one sample in the group: keep the "larger" genotype, chain the ids
+                ca, cb, cgq, cdr, cdv, cps, cid = genotypes[sid]
+                new_id = cid + "," + config.id_prefix + c.id
+                if ca == "." or (a != "." and (a, b) >= (ca, cb)):
+                    genotypes[sid] = (a, b, gq, dr, dv, ps, new_id)
+                else:
+                    genotypes[sid] = (ca, cb, cgq, cdr, cdv, cps, new_id)
+            else:
+                genotypes[sid] = (a, b, gq, dr, dv, ps, config.id_prefix + c.id)
+        for sample in config.snf_input_info:
+            sid = sample["internal_id"]
+            if sid in genotypes:
+                continue
+            cov = self.coverages_nonincluded[sid]
+            if cov >= config.combine_null_min_coverage:
+                genotypes[sid] = (0, 0, 0, cov, 0, (None, None), "NULL")
+            else:
+                genotypes[sid] = (".", ".", 0, cov, 0, (None, None), "NULL")
+
+        if config.combine_pair_relabel:
+            top = (0, 0)
+            for a, b, q, *_ in genotypes.values():
+                if q > config.combine_pair_relabel_threshold and a != ".":
+                    top = max(top, (a, b))
+            if top != (0, 0):
+                for sid, (a, b, q, dr, dv, ps, nid) in list(genotypes.items()):
+                    if q < config.combine_pair_relabel_threshold and a != ".":
+                        genotypes[sid] = (top[0], top[1], q, dr, dv, ps, nid)
+
+        med_pos = int(util.median(c.pos for c in self.candidates))
+        med_len = int(util.median(c.svlen for c in self.candidates))
+        alt = first.alt
+        if first.svtype == "INS":
+            end = med_pos
+            best = abs(len(alt) - med_len)
+            for c in self.candidates:
+                d = abs(len(c.alt) - med_len)
+                if d < best:
+                    best, alt = d, c.alt
+        else:
+            end = med_pos + abs(med_len)
+        use_med = getattr(config, "dev_combine_medians", False)
+
+        def avg(attr):
+            return util.mean_or_none_round(getattr(c, attr) for c in self.candidates if getattr(c, attr) is not None)
+
+        call = svcall_cls(contig=first.contig, pos=med_pos if use_med else first.pos,
+                          id=f"{first.svtype}.{task.sv_id:X}M{task.id:X}", ref="N", alt=alt,
+                          qual=util.mean_or_none_round(int(c.qual) for c in self.candidates if c.qual is not None),
+                          filter="PASS" if n_samples != 1 else first.filter,
+                          info=dict() if n_samples != 1 else first.info, svtype=first.svtype,
+                          svlen=med_len if use_med else first.svlen, end=end if use_med else first.end,
+                          genotypes=genotypes,
+                          precise=sum(int(c.precise) for c in self.candidates) / float(len(self.candidates)) > 0.5,
+                          support=round(util.mean(c.support for c in self.candidates)), rnames=rnames, postprocess=None,
+                          qc=True, nm=-1)
+        call.svlens = None
+        call.fwd = sum(c.fwd for c in self.candidates)
+        call.rev = sum(c.rev for c in self.candidates)
+        for attr in ("coverage_upstream", "coverage_start", "coverage_center", "coverage_end", "coverage_downstream"):
+            setattr(call, attr, avg(attr))
+        if n_samples != 1:
+            call.set_info("STDEV_POS", util.stdev(c.pos for c in self.candidates))
+            call.set_info("STDEV_LEN", util.stdev(c.svlen for c in self.candidates))
+        if abs(call.svlen) < config.minsvlen_screen:
+            return None
+        task.sv_id += 1
+        return call
+
+
+def call_groups(svgroups, config, task):
+    """Reference `sv.call_groups` (sv.py:642-646)."""
+    for g in svgroups:
+        c = g.call(config, task)
+        if c is not None:
+            yield c

@@ -40,7 +40,7 @@ def _ranges(counts: np.ndarray) -> tuple:
 
 def gen_task(task_id: int, contig: str, contig_len: int, coverage: float, seed: int,
              err: float = 0.04, mosaic_frac: float = 0.0, site_density: float = 27000 / 3.1e9,
-             contig_names=None, read_len_mean: float = 20000.0) -> TaskInput:
+             contig_names=None, read_len_mean: float = 20000.0, site_seed: int = None) -> TaskInput:
     """One contig's lead table.  `err` = per-base substitution error of INS read sequences
     (0.04 ONT-like, 0.005 HiFi-like); `mosaic_frac` = fraction of sites planted at VAF 0.05-0.2."""
     rng = np.random.default_rng([seed, task_id, 7919])
@@ -67,6 +67,10 @@ def gen_task(task_id: int, contig: str, contig_len: int, coverage: float, seed: 
     ralen = (rend - rstart).astype(np.int64)
 
     # ---------------- SV sites ----------------
+    # `site_seed`: several samples of one population share the sites (and alleles) but not the reads
+    rng_reads = rng
+    if site_seed is not None:
+        rng = np.random.default_rng([site_seed, task_id, 104723])
     n_sites = max(1, int(round(site_density * L)))
     spos = np.sort(rng.integers(6000, max(6001, L - 60000), n_sites))
     u = rng.random(n_sites)
@@ -88,6 +92,15 @@ def gen_task(task_id: int, contig: str, contig_len: int, coverage: float, seed: 
 
     tr_start = np.maximum(0, spos[str_like] - 500).astype(np.int32)
     tr_end = (spos[str_like] + 500).astype(np.int32)
+    if site_seed is not None:  # alleles belong to the sites, everything below to the sample
+        n_ins_bases = int(np.where(stype == SVT["INS"], slen, 0).sum())
+        shared_alleles = ACGT[rng.integers(0, 4, n_ins_bases)]
+        if mosaic_frac == 0.0:  # population sample: not every sample carries every site
+            present = np.random.default_rng([seed, task_id, 31]).random(n_sites) < 0.7
+            svaf = np.where(present, svaf, 0.0)
+    else:
+        shared_alleles = None
+    rng = rng_reads
 
     # ---------------- site x covering-read pairs ----------------
     extent = np.where((stype == SVT["INS"]) | (stype == SVT["BND"]), 0, slen)
@@ -138,7 +151,8 @@ def gen_task(task_id: int, contig: str, contig_len: int, coverage: float, seed: 
     ins_idx = np.nonzero(ins_mask)[0]
     a_len = slen
     a_off = np.cumsum(np.where(stype == SVT["INS"], a_len, 0)) - np.where(stype == SVT["INS"], a_len, 0)
-    allele_pool = ACGT[rng.integers(0, 4, int(np.where(stype == SVT["INS"], a_len, 0).sum()))]
+    allele_pool = shared_alleles if shared_alleles is not None else \
+        ACGT[rng.integers(0, 4, int(np.where(stype == SVT["INS"], a_len, 0).sum()))]
     out_len = jlen[ins_idx]
     o_i, p = _ranges(out_len)
     src_pos = (p * a_len[s_i[ins_idx]][o_i]) // np.maximum(1, out_len[o_i])

@@ -349,3 +349,15 @@ def _no_tr(ti):
 
 
 ALL = {**HAND, **SYNTH, **FUZZ}
+
+
+# multi-sample combine (BASELINE.json configs[4] shape, shrunk): samples share sites, not reads ------------------
+def population(n_samples, contig="chr21", length=1_500_000, cov=20, site_seed=501, task_id=0):
+    return [synth.gen_task(task_id, contig, length, cov, seed=100 + s, site_seed=site_seed) for s in range(n_samples)]
+
+
+COMBINE = {
+    "combine_4samples": (lambda: population(4), ()),
+    "combine_7samples_lowcov": (lambda: population(7, contig="chr22", length=1_000_000, cov=12, site_seed=777, task_id=3), ()),
+    "combine_3samples_no_align": (lambda: population(3, length=1_000_000, site_seed=9), ("--combine-pctseq", "0")),
+}
