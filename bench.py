@@ -145,8 +145,18 @@ def main():
         top = kern[0] if kern else ("none", 0.0, 0)
         gpu_ms = sum(k[1] for k in kern)
         achieved = (top[2] / (top[1] * 1e-3)) / 1e9 if top[1] > 0 else 0.0
+        # HBM traffic of the dominant kernel: PMC counters can not be read from inside the process; they were collected
+        # with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) on this same workload and are kept, corrected as
+        # the microarch guide prescribes, in profiles/r01_pmc_traffic.json
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            if top[0] in pmc and args.scale == 1.0 and args.coverage == 30.0:
+                traffic = pmc[top[0]]["hbm_bytes"]
+        except Exception:
+            traffic = None
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
                         gpu_ms_all_kernels=round(gpu_ms, 3),
                         top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2])) for k in kern[:8]])
