@@ -108,6 +108,7 @@ struct snf_batch_impl {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream (also the one fetch/sync wait on)
   hipStream_t stream2 = nullptr;  // side stream: read preparation, finalize scalar kernels
+  hipStream_t stream3 = nullptr;  // third stream: the LARGE consensus class next to the SMALL one
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
@@ -135,11 +136,10 @@ struct snf_batch_impl {
   Counts h_cnt{};
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
 #ifndef SNF_EMU
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
-  int64_t *d_sz_tab = nullptr, *d_sz_aln = nullptr, *d_sz_rd = nullptr;
   // results (host)
   HostBuf hb_calls, hb_alt, hb_rn;
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
@@ -455,7 +455,9 @@ void do_upload(snf_batch_impl* b) {
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
-  b->d_sz_tab = dalloc<int64_t>(b, N1 + 1); b->d_sz_aln = dalloc<int64_t>(b, N1 + 1); b->d_sz_rd = dalloc<int64_t>(b, N1 + 1);
+  v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
+  v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
+  v.sc_tab = dalloc<int64_t>(b, N1 + 1); v.sc_aln = dalloc<int64_t>(b, N1 + 1); v.sc_rd = dalloc<int64_t>(b, N1 + 1);
   dsync(b);
   b->uploaded = true;
 }
@@ -491,7 +493,7 @@ void enqueue_read_prep(snf_batch_impl* b) {
 
 void run_call_candidates(snf_batch_impl* b) {
   View& v = b->v;
-  int64_t N = v.N, R = v.R; int T = v.T;
+  int64_t N = v.N; int T = v.T;
   reset_timing(b);
   dzero(b, v.cnt, sizeof(Counts));
   dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
@@ -526,9 +528,6 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
     prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
     LAUNCH_Q(c4_clusters, v, N, N * 4);
-  }
-  if (b->sched_readprep == 1) enqueue_read_prep(b);
-  if (N > 0) {
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
 #ifndef SNF_EMU
     if (v.wave_path) {
@@ -538,6 +537,9 @@ void run_call_candidates(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);
+  }
+  if (b->sched_readprep == 1) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
+  if (N > 0) {
     prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
     LAUNCH_Q(d1b_rctable, v, N, N * 4);
 #ifndef SNF_EMU
@@ -588,62 +590,49 @@ void enqueue_prefetch(snf_batch_impl* b) {
 
 void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
-  int64_t N = v.N;
-  if (N <= 0) return;
+  if (v.N <= 0) return;
+  // one cheap round trip: the number of candidate calls makes every launch and scan below exact-sized
+  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
+  dsync(b);
+  const int64_t nc = b->h_cnt.n_calls;
+  if (nc <= 0) return;
   fork_mark(b);
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream, overlapped with the consensus chain
     SideStream side(b);
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
-      hipLaunchKernelGGL(e1w_finalize, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      int64_t grid = nc < 8192 ? nc : 8192;
+      hipLaunchKernelGGL(e1w_finalize, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH_Q(e1_finalize, v, N, 0);
+    LAUNCH_Q(e1_finalize, v, nc, 0);
   }
-  LAUNCH(e2_best, v, N, 0);
-  prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_alt");
-  prim_exscan<uint32_t>(b, v.fL, v.pL, N + 1, "scan_cons");
-  // e3 writes per-consensus sizes into cons_*_off; scanned below into offsets
-  LAUNCH_Q(e3_conslist, v, N, 0);
+  LAUNCH(e2_best, v, nc, 0);
+  prim_exscan<uint32_t>(b, v.fN, v.pN, nc + 1, "scan_alt");
+  prim_exscan<uint32_t>(b, v.fL, v.pL, nc + 1, "scan_cons");
+  prim_exscan<int64_t>(b, v.sz_tab, v.sc_tab, nc + 1, "scan_cons_sizes");
+  prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
+  prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
+  LAUNCH_Q(e3_conslist, v, nc, 0);
   d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
-  int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
+  const int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
   if (b->sched_prefetch == 1) enqueue_prefetch(b);
   if (ncons > 0) {
-    // sizes were written into cons_*_off[0..ncons); copy to the size arrays, terminate, scan
-    size_t nb = (size_t)ncons * sizeof(int64_t);
-#ifndef SNF_EMU
-    SNF_HIP(hipMemcpyAsync(b->d_sz_tab, v.cons_tab_off, nb, hipMemcpyDeviceToDevice, b->cur));
-    SNF_HIP(hipMemcpyAsync(b->d_sz_aln, v.cons_aln_off, nb, hipMemcpyDeviceToDevice, b->cur));
-    SNF_HIP(hipMemcpyAsync(b->d_sz_rd, v.cons_read_off, nb, hipMemcpyDeviceToDevice, b->cur));
-#else
-    memcpy(b->d_sz_tab, v.cons_tab_off, nb); memcpy(b->d_sz_aln, v.cons_aln_off, nb); memcpy(b->d_sz_rd, v.cons_read_off, nb);
-#endif
-    dzero(b, b->d_sz_tab + ncons, sizeof(int64_t)); dzero(b, b->d_sz_aln + ncons, sizeof(int64_t)); dzero(b, b->d_sz_rd + ncons, sizeof(int64_t));
-    prim_exscan<int64_t>(b, b->d_sz_tab, v.cons_tab_off, ncons + 1, "scan_cons_sizes");
-    prim_exscan<int64_t>(b, b->d_sz_aln, v.cons_aln_off, ncons + 1, "scan_cons_sizes");
-    prim_exscan<int64_t>(b, b->d_sz_rd, v.cons_read_off, ncons + 1, "scan_cons_sizes");
-    int64_t tot[3];
-    d2h(b, &tot[0], v.cons_tab_off + ncons, sizeof(int64_t));
-    d2h(b, &tot[1], v.cons_aln_off + ncons, sizeof(int64_t));
-    d2h(b, &tot[2], v.cons_read_off + ncons, sizeof(int64_t));
-    dsync(b);
-    b->h_cnt.tab_total = tot[0]; b->h_cnt.aln_total = tot[1]; b->h_cnt.n_cons_reads = tot[2];
+    const int64_t tab_total = b->h_cnt.tab_total, aln_total = b->h_cnt.aln_total, nreads = b->h_cnt.n_cons_reads;
     int64_t c1 = b->tab_cap, c2 = b->tab_cap, c3 = b->tab_cap;
-    ensure_cap(b, tot[0], c1, (void**)&v.tab_key, sizeof(uint64_t));
-    ensure_cap(b, tot[0], c2, (void**)&v.tab_pos, sizeof(int32_t));
-    ensure_cap(b, tot[0], c3, (void**)&v.tab_state, sizeof(uint8_t));
+    ensure_cap(b, tab_total, c1, (void**)&v.tab_key, sizeof(uint64_t));
+    ensure_cap(b, tab_total, c2, (void**)&v.tab_pos, sizeof(int32_t));
+    ensure_cap(b, tab_total, c3, (void**)&v.tab_state, sizeof(uint8_t));
     b->tab_cap = c1; v.tab_cap = c1;
-    ensure_cap(b, tot[1], b->aln_cap, (void**)&v.aln, 1); v.aln_cap = b->aln_cap;
+    ensure_cap(b, aln_total, b->aln_cap, (void**)&v.aln, 1); v.aln_cap = b->aln_cap;
     int64_t r1 = b->cr_cap, r2 = b->cr_cap, r3 = b->cr_cap;
-    ensure_cap(b, tot[2], r1, (void**)&v.aln_kept, 1);
-    ensure_cap(b, tot[2], r2, (void**)&v.cr_call, sizeof(int32_t));
-    ensure_cap(b, tot[2], r3, (void**)&v.cr_read, sizeof(int32_t));
+    ensure_cap(b, nreads, r1, (void**)&v.aln_kept, 1);
+    ensure_cap(b, nreads, r2, (void**)&v.cr_call, sizeof(int32_t));
+    ensure_cap(b, nreads, r3, (void**)&v.cr_read, sizeof(int32_t));
     b->cr_cap = r1;
-    // counters the kernels read
-    h2d(b, &v.cnt->n_cons_reads, &tot[2], sizeof(int64_t));
   }
   ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
   const bool fallback = !v.wave_path || b->h_cnt.n_cons_fallback > 0;
@@ -651,14 +640,23 @@ void run_finalize(snf_batch_impl* b) {
     if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
 #ifndef SNF_EMU
     if (v.wave_path) {
-      // algorithmic bytes: every base of every seq-bearing lead of a consensus call once + the row written
+      // algorithmic bytes are accumulated by the kernels themselves (cnt->cons_bytes) and attached to
+      // these two timing entries in collect_timings
       int64_t grid = ncons < 16384 ? ncons : 16384;
-      { Scope _s(b, "e45w_consensus_small", (int64_t)b->h_cnt.cons_bytes[1]);
+      {  // the LARGE class is independent of the SMALL one: its own stream, joined before the ALT pool is copied out
+        SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+        SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+        hipStream_t prev = b->cur; b->cur = b->stream3;
+        { Scope _s(b, "e45w_consensus_large", 0);
+          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+          SNF_HIP(hipGetLastError()); }
+        b->cur = prev;
+        SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+      }
+      { Scope _s(b, "e45w_consensus_small", 0);
         hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError()); }
-      { Scope _s(b, "e45w_consensus_large", (int64_t)b->h_cnt.cons_bytes[2]);
-        hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError()); }
+      SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
     }
 #endif
     if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
@@ -678,6 +676,10 @@ void collect_timings(snf_batch_impl* b) {
     for (auto& t : b->timings)
       if (strcmp(t.name, b->evs[i].name) == 0) { t.ms += ms; t.bytes += b->evs[i].bytes; t.launches++; found = true; break; }
     if (!found) b->timings.push_back({b->evs[i].name, ms, b->evs[i].bytes, 1});
+  }
+  for (auto& t : b->timings) {  // the consensus kernels count their own algorithmic bytes (read back with the counters)
+    if (strcmp(t.name, "e45w_consensus_small") == 0) t.bytes = (int64_t)b->h_cnt.cons_bytes[1];
+    if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt.cons_bytes[2];
   }
 #endif
 }
@@ -831,6 +833,9 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
 #ifndef SNF_EMU
     SNF_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     SNF_HIP(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+    SNF_HIP(hipStreamCreateWithFlags(&b->stream3, hipStreamNonBlocking));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_join3, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     b->cur = b->stream;
@@ -865,6 +870,9 @@ void snf_batch_destroy(snf_batch_t* bb) {
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2) (void)hipStreamSynchronize(b->stream2);
+  if (b->stream3) (void)hipStreamSynchronize(b->stream3);
+  if (b->ev_fork3) (void)hipEventDestroy(b->ev_fork3);
+  if (b->ev_join3) (void)hipEventDestroy(b->ev_join3);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -874,6 +882,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
 #ifndef SNF_EMU
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->stream2) (void)hipStreamDestroy(b->stream2);
+  if (b->stream3) (void)hipStreamDestroy(b->stream3);
 #endif
   delete b;
 }

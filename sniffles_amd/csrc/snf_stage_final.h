@@ -384,9 +384,10 @@ SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
 SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { return cons_class(v, L, n_others) != 0; }
 
 SNF_HD void e2_best_body(int64_t i, const View& v) {
-  if (i == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; }
-  v.fN[i] = 0; v.fL[i] = 0;
-  if (i >= v.cnt->n_calls) return;
+  const int64_t nc = v.cnt->n_calls;
+  if (i == 0) { v.fN[nc] = 0; v.fL[nc] = 0; v.sz_tab[nc] = 0; v.sz_aln[nc] = 0; v.sz_rd[nc] = 0; }
+  if (i >= nc) return;
+  v.fN[i] = 0; v.fL[i] = 0; v.sz_tab[i] = 0; v.sz_aln[i] = 0; v.sz_rd[i] = 0;
   snf_call_t& c = v.calls[i];
   CallX& x = v.callx[i];
   x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1;
@@ -403,37 +404,39 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
   if (best < 0) return;
   x.best = best; x.n_others = cnt - 1;
   x.do_cons = (x.n_others >= v.cfg.consensus_min_reads && !v.cfg.no_consensus) ? 1 : 0;
-  c.alt_len = v.F_seq_len[best];
-  v.fN[i] = (uint32_t)c.alt_len;
+  const int64_t L = v.F_seq_len[best];
+  c.alt_len = (int32_t)L;
+  v.fN[i] = (uint32_t)L;
   v.fL[i] = 1u;  // listed for the ALT stage (consensus or verbatim copy of the best read)
+  if (x.do_cons) {
+    v.sz_aln[i] = (int64_t)x.n_others * L;
+    v.sz_rd[i] = x.n_others;
+    if (!cons_wave_eligible(v, L, x.n_others)) {   // anchor table in HBM only for the thread-kernel fallback
+      int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
+      int64_t hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
+      v.sz_tab[i] = hs;
+    }
+  }
 }
 
-// E3: consensus work list (pN = scan of alt lengths, pL = scan of do_cons)
+// E3: ALT work list (pN/pL/sc_* = exclusive scans over the calls of alt length, has-alt flag and the sizes)
 SNF_HD void e3_conslist_body(int64_t i, const View& v) {
-  if (i == 0) { v.cnt->alt_total = v.pN[v.N]; v.cnt->n_cons = v.pL[v.N]; }
-  if (i >= v.cnt->n_calls) return;
+  const int64_t nc = v.cnt->n_calls;
+  if (i == 0) {
+    v.cnt->alt_total = v.pN[nc]; v.cnt->n_cons = v.pL[nc];
+    v.cnt->tab_total = v.sc_tab[nc]; v.cnt->aln_total = v.sc_aln[nc]; v.cnt->n_cons_reads = v.sc_rd[nc];
+  }
+  if (i >= nc) return;
   snf_call_t& c = v.calls[i];
   CallX& x = v.callx[i];
-  if (c.alt_len >= 0) { c.alt_off = v.pN[i]; x.alt_off = v.pN[i]; }
-  if (c.alt_len >= 0) {
-    uint32_t cid = v.pL[i];
-    x.cons_id = (int32_t)cid;
-    v.cons_call[cid] = (int32_t)i;
-    int64_t L = c.alt_len;
-    int64_t hs = 0;
-    // 1 B per base of every seq-bearing lead of the call + 1 B per output base
-    int cls = x.do_cons ? cons_class(v, L, x.n_others) : 1;
-    atomic_add_u64(&v.cnt->cons_bytes[cls], (unsigned long long)((x.do_cons ? (int64_t)x.n_others + 2 : 2) * L));
-    if (x.do_cons) {
-      int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
-      hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
-      if (cons_wave_eligible(v, L, x.n_others)) hs = 0;   // anchor table lives in LDS
-      else atomic_add_u64((unsigned long long*)&v.cnt->n_cons_fallback, 1ull);
-    }
-    v.cons_tab_off[cid] = hs;                       // sizes; scanned into offsets by the host
-    v.cons_aln_off[cid] = x.do_cons ? (int64_t)x.n_others * L : 0;
-    v.cons_read_off[cid] = x.do_cons ? x.n_others : 0;
-  }
+  if (c.alt_len < 0) return;
+  c.alt_off = v.pN[i]; x.alt_off = v.pN[i];
+  uint32_t cid = v.pL[i];
+  x.cons_id = (int32_t)cid;
+  v.cons_call[cid] = (int32_t)i;
+  v.cons_tab_off[cid] = v.sc_tab[i]; v.cons_tab_sz[cid] = v.sz_tab[i];
+  v.cons_aln_off[cid] = v.sc_aln[i]; v.cons_read_off[cid] = v.sc_rd[i];
+  if (v.sz_tab[i] > 0) atomic_add_u64((unsigned long long*)&v.cnt->n_cons_fallback, 1ull);   // rare
 }
 
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
@@ -456,7 +459,7 @@ SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
   if (cons_wave_eligible(v, L, x.n_others)) return;  // e45w_consensus builds its table in LDS
   const uint8_t* B = v.pool + v.F_seq_off[x.best];
   int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L);
-  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_off[cid + 1] - t0;
+  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_sz[cid];
   uint64_t* key = v.tab_key + t0; int32_t* pos = v.tab_pos + t0; uint8_t* st = v.tab_state + t0;
   for (int64_t p = 0; p < hs; p++) st[p] = 0;
   for (int64_t i = 0; i < L - klen; i += skip) {
@@ -488,7 +491,7 @@ SNF_HD void e5_align_body(int64_t j, const View& v) {
   const uint8_t* S = v.pool + v.F_seq_off[slot];
   int64_t SL = v.F_seq_len[slot];
   int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L), maxshift = klen;
-  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_off[cid + 1] - t0;
+  int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_sz[cid];
   const uint64_t* key = v.tab_key + t0; const int32_t* pos = v.tab_pos + t0; const uint8_t* st = v.tab_state + t0;
   uint8_t* row = v.aln + v.cons_aln_off[cid] + (int64_t)ridx * L;
   bool have_last = false; int64_t last_i = 0, last_j = 0, clen = 0, span = 0;

@@ -129,7 +129,9 @@ struct View {
   // ---- stage E: finalize
   const GtEntry* gt_lut;     // [251*251]
   int32_t* cons_call;        // [n_cons] call index
-  int64_t *cons_tab_off, *cons_aln_off, *cons_read_off;  // [n_cons+1]
+  int64_t *cons_tab_off, *cons_aln_off, *cons_read_off, *cons_tab_sz;  // [n_cons] offsets (+ table slots) per ALT call
+  int64_t *sz_tab, *sz_aln, *sz_rd;   // [n_calls+1] per-call sizes written by e2_best
+  int64_t *sc_tab, *sc_aln, *sc_rd;   // [n_calls+1] their exclusive scans
   uint64_t* tab_key; int32_t* tab_pos; uint8_t* tab_state; int64_t tab_cap;   // anchor hash tables
   uint8_t* aln; int64_t aln_cap;         // aligned reads, n_others x L per consensus call
   uint8_t* aln_kept;         // [n_cons_reads]

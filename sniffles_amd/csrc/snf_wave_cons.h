@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
   const int64_t n_cons = v.cnt->n_cons;
+  unsigned long long bytes_acc = 0;  // algorithmic bytes this block processed, one atomic at the end
   for (int64_t cid = blockIdx.x; cid < n_cons; cid += gridDim.x) {
     const int32_t ci = v.cons_call[cid];
     const CallX x = v.callx[ci];
@@ -84,21 +85,25 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     const uint8_t* B = v.pool + v.F_seq_off[x.best];
     uint8_t* alt = v.alt_pool + x.alt_off;
     if (!x.do_cons) {  // fewer than consensus_min_reads others: ALT = best read verbatim (postprocessing.py:65-66)
-      if (CLS == 1) for (int64_t q = tid; q < L; q += 256) alt[q] = B[q];
+      if (CLS == 1) { for (int64_t q = tid; q < L; q += 256) alt[q] = B[q]; bytes_acc += 2 * (unsigned long long)L; }
       continue;
     }
     if (cons_class(v, L, x.n_others) != CLS) continue;  // other instance, or the thread path (e4/e5/e6)
+    bytes_acc += (unsigned long long)((int64_t)x.n_others + 2) * (unsigned long long)L;
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
     SNF_PH(7);
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
-    if (tid == 0) {  // cluster-order list of the other seq-bearing leads
+    if (wid == 0) {  // cluster-order list of the other seq-bearing leads (wave 0, ordered ballot compaction)
       int k2 = 0;
-      for (int32_t k = 0; k < x.fn; k++) {
-        const int32_t s = v.FI[x.flo + k];
-        if (v.F_seq_len[s] < 0 || s == x.best) continue;
-        lds.others[k2++] = s;
+      for (int32_t k0 = 0; k0 < x.fn; k0 += 64) {
+        const int32_t k = k0 + lane;
+        int32_t s = -1; bool ok = false;
+        if (k < x.fn) { s = v.FI[x.flo + k]; ok = v.F_seq_len[s] >= 0 && s != x.best; }
+        const unsigned long long mk = __ballot(ok);
+        if (ok) lds.others[k2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = s;
+        k2 += __builtin_popcountll(mk);
       }
     }
     __syncthreads();
@@ -302,6 +307,7 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     }
     SNF_PH(6);
   }
+  if (tid == 0 && bytes_acc) atomicAdd(&v.cnt->cons_bytes[CLS], bytes_acc);
 }
 
 }  // namespace snf
