@@ -436,10 +436,10 @@ void do_upload(snf_batch_impl* b) {
   v.seqnull = dalloc<uint8_t>(b, N); v.bin_lo = dalloc<int32_t>(b, N1); v.bin_key = dalloc<uint64_t>(b, N);
   v.bin_hap = dalloc<uint16_t>(b, 3 * (size_t)N); v.bin_elig = dalloc<uint8_t>(b, N);
   v.grp_first_bin = dalloc<int32_t>(b, 8 * (size_t)T + 8);
-  v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N);
+  v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N); v.Lrec = dalloc<LeadRec>(b, N1);
   int32_t** i32s[] = {&v.seed_bin, &v.seed_lo, &v.seed_hi, &v.seedL_lo, &v.seedL_hi, &v.seed_start, &v.seed_grp, &v.c_last, &v.c_end,
                       &v.nxt, &v.prv, &v.run_first, &v.run_last_head, &v.cl_head, &v.w0, &v.w1, &v.w2, &v.w3, &v.w4, &v.w5, &v.w6,
-                      &v.F_orig, &v.F_svlen, &v.F_seq_len, &v.FI, &v.rc_n_s, &v.rc_cl_s, &v.rc_lo, &v.rc_n, &v.rc_cluster};
+                      &v.F_orig, &v.F_svlen, &v.F_seq_len, &v.FI, &v.F_lpos, &v.rc_n_s, &v.rc_cl_s, &v.rc_lo, &v.rc_n, &v.rc_cluster};
   for (auto pp : i32s) *pp = dalloc<int32_t>(b, N1);
   double** f64s[] = {&v.s_mean0, &v.s_stdev0, &v.c_mean, &v.c_stdev, &v.run_b_stdev, &v.run_b_absmean};
   for (auto pp : f64s) *pp = dalloc<double>(b, N1);

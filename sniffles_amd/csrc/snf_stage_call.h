@@ -110,7 +110,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
           } else flush = true;
         }
         if (flush) {
-          Forig[m] = (int32_t)head; Fsvlen[m] = (int32_t)cs;
+          Forig[m] = (int32_t)head; Fsvlen[m] = (int32_t)cs; v.F_lpos[lo + m] = lo + a0[part_start];
           int32_t nparts = (y < y_end ? y : y_end) - part_start;
           if (!seq_ok) { Fseqlen[m] = -1; Fseqoff[m] = 0; }
           else if (nparts == 1) { Fseqlen[m] = v.in_seq_len[head]; Fseqoff[m] = v.in_seq_off[head]; }
@@ -140,7 +140,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   } else {
     for (int32_t j = 0; j < n; j++) {
       uint32_t o = v.L[lo + j];
-      Forig[j] = (int32_t)o; Fsvlen[j] = v.in_svlen[o];
+      Forig[j] = (int32_t)o; Fsvlen[j] = v.in_svlen[o]; v.F_lpos[lo + j] = lo + j;
       bool hs = lead_has_seq(v, o);
       Fseqlen[j] = hs ? v.in_seq_len[o] : -1; Fseqoff[j] = hs ? v.in_seq_off[o] : 0;
     }

@@ -92,7 +92,20 @@ SNF_HD void a6_scatter_body(int64_t p, const View& v) {
   if (p == 0) { v.cnt->NF = v.pN[v.N]; v.cnt->NLL = v.pL[v.N]; v.cnt->n_seeds = v.eligscan[v.N]; }
   if (p >= v.cnt->n_valid) return;
   uint32_t o = v.val_out[p];
-  if (v.fN[p]) v.L[v.pN[p]] = o;
+  if (v.fN[p]) {
+    const uint32_t q = v.pN[p];
+    v.L[q] = o;
+    LeadRec r;
+    r.ref_start = v.in_ref_start[o]; r.ref_end = v.in_ref_end[o]; r.qry_start = v.in_qry_start[o]; r.qry_end = v.in_qry_end[o];
+    r.svlen = v.in_svlen[o];
+    const bool hs = v.in_seq_len[o] >= 0 && !v.seqnull[o];
+    r.seq_len = hs ? v.in_seq_len[o] : -1; r.seq_off = hs ? v.in_seq_off[o] : 0;
+    r.qname = v.in_qname[o]; r.read_id = v.in_read_id[o]; r.ps = v.in_ps[o]; r.mate_pos = v.in_mate_pos[o];
+    r.mate_contig = v.in_mate_contig[o]; r.read_len = v.in_read_len[o]; r.orig = o;
+    r.strand = v.in_strand[o]; r.mapq = v.in_mapq[o]; r.source = v.in_source[o]; r.hap = v.in_hap[o];
+    r.is_sa = v.in_is_sa[o]; r.first = v.in_first[o]; r.rev = v.in_rev[o]; r.svtype = v.in_svtype[o]; r._pad = 0;
+    v.Lrec[q] = r;
+  }
   if (v.fL[p]) v.LL[v.pL[p]] = o;
 }
 
@@ -117,15 +130,15 @@ SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean,
   int64_t len = hi - lo;
   int64_t n = len < 100 ? len : 100;
   if (n == 0) { *mean = 0; *sd = 0; return; }
-  if (n == 1) { *mean = (double)v.in_svlen[v.L[lo]]; *sd = 0; return; }
+  if (n == 1) { *mean = (double)v.Lrec[lo].svlen; *sd = 0; return; }
   int64_t step = len / n;
   int64_t sum = 0, cnt = 0;
   i128 S1 = 0; u128 S2 = 0;
-  int64_t x0 = v.in_ref_start[v.L[lo]];
+  int64_t x0 = v.Lrec[lo].ref_start;
   for (int64_t i = 0; i < len; i += step) {
-    uint32_t o = v.L[lo + i];
-    sum += v.in_svlen[o];
-    int64_t d = (int64_t)v.in_ref_start[o] - x0;
+    const LeadRec& r = v.Lrec[lo + i];
+    sum += r.svlen;
+    int64_t d = (int64_t)r.ref_start - x0;
     S1 += d; S2 += (u128)((i128)d * d);
     cnt++;
   }

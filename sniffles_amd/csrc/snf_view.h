@@ -35,6 +35,20 @@ struct GtEntry {
 };
 #define SNF_GT_N 251
 
+// one seed-cluster lead, packed in sorted (L) order by a6_scatter: the wave kernels read these coalesced instead
+// of gathering 8-10 scattered input columns through L[] -> input index
+struct LeadRec {
+  int32_t ref_start, ref_end, qry_start, qry_end;
+  int32_t svlen, seq_len;          // seq_len < 0: Lead.seq is None (incl. the 10-per-bin cap)
+  int64_t seq_off;
+  uint32_t qname, read_id;
+  int32_t ps, mate_pos;
+  int32_t mate_contig, read_len;
+  uint32_t orig;                   // input index
+  uint8_t strand, mapq, source, hap, is_sa, first, rev, svtype;
+  uint32_t _pad;
+};
+
 struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t rc;       // refined cluster id
   int32_t cluster;  // merged cluster id
@@ -103,6 +117,7 @@ struct View {
   int32_t* grp_first_bin;    // [8T]
   uint32_t* L;               // [N] seed-cluster leads, (task, svtype, bin, arrival) order -> input index
   uint32_t* LL;              // [N] leads_long, same order
+  LeadRec* Lrec;             // [N] packed records of L[] (same index)
 
   // ---- stage B/C: seeds [n_seeds <= N]
   int32_t *seed_bin, *seed_lo, *seed_hi, *seedL_lo, *seedL_hi, *seed_start, *seed_grp;
@@ -120,6 +135,7 @@ struct View {
   int32_t *w0, *w1, *w2, *w3, *w4, *w5, *w6; // per-cluster scratch over the L index space
   // F: leads after merge_inner (fused), slot space = L index space; FI: final per-refined-cluster order -> F slot
   int32_t *F_orig, *F_svlen, *F_seq_len; int64_t* F_seq_off; uint8_t* F_sel; int32_t* FI;
+  int32_t* F_lpos;           // L position (Lrec index) of the fused lead's head
   int32_t *rc_n_s, *rc_cl_s; uint8_t* rc_keeplong_s;   // slot space (sparse): slot = F position of the rc's first lead
   int32_t *rc_lo, *rc_n, *rc_cluster; uint8_t* rc_keeplong;              // dense
   snf_call_t* cand; CallX* candx;                                         // per rc

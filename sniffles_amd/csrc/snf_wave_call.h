@@ -82,11 +82,12 @@ __global__ void __launch_bounds__(SNF_WAVE) d2w_call(const View v, int64_t n_unu
     int mapq = 0, strand = 0, is_sa = 0, noninline = 0; double nm = 0;
     int32_t mctg = 0, mpos = 0; int bfirst = 0, brev = 0;
     if (act) {
-      slot = v.FI[flo + lane]; o = (uint32_t)v.F_orig[slot]; svl = v.F_svlen[slot];
-      rs = v.in_ref_start[o]; qn = v.in_qname[o]; mapq = v.in_mapq[o]; strand = v.in_strand[o]; is_sa = v.in_is_sa[o];
-      noninline = v.in_source[o] != SNF_SRC_INLINE;
+      slot = v.FI[flo + lane]; svl = v.F_svlen[slot];
+      const LeadRec r = v.Lrec[v.F_lpos[slot]];
+      o = r.orig; rs = r.ref_start; qn = r.qname; mapq = r.mapq; strand = r.strand; is_sa = r.is_sa;
+      noninline = r.source != SNF_SRC_INLINE;
       if (cfg.qc_nm_measure) nm = v.in_nm[o];
-      if (svtype == SNF_BND) { mctg = v.in_mate_contig[o]; mpos = v.in_mate_pos[o]; bfirst = v.in_first[o]; brev = v.in_rev[o]; }
+      mctg = r.mate_contig; mpos = r.mate_pos; bfirst = r.first; brev = r.rev;
       v.F_sel[slot] = 1;
     }
     if (lane == 0) v.cdflag[r] = 0;
@@ -218,12 +219,13 @@ __global__ void __launch_bounds__(SNF_WAVE) e1w_finalize(const View v, int64_t n
     bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
     if (lane < n) {
       const int32_t s = v.FI[x.flo + lane];
-      sel = v.F_sel[s] != 0; o = (uint32_t)v.F_orig[s];
-      strand = v.in_strand[o]; hap = v.in_hap[o]; rid = v.in_read_id[o];
-      const int32_t p = v.in_ps[o];
+      sel = v.F_sel[s] != 0;
+      const LeadRec r = v.Lrec[v.F_lpos[s]];
+      o = r.orig; strand = r.strand; hap = r.hap; rid = r.read_id;
+      const int32_t p = r.ps;
       ps = (p == SNF_PS_NONE || p == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : p;
-      const int64_t qs = v.in_qry_start[o];
-      close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)v.in_read_len[o] - qs) <= cfg.dev_min_close_edge_dist;
+      const int64_t qs = r.qry_start;
+      close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - qs) <= cfg.dev_min_close_edge_dist;
     }
     LeadAgg g;
     g.nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);

@@ -78,22 +78,17 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     const int svtype = grp_svtype(v.seed_grp[h]);
     const bool act = lane < n;
     // ---- load one lead per lane
-    uint32_t o = act ? v.L[lo + lane] : 0;
+    uint32_t o = 0;
     int32_t ref_start = 0, ref_end = 0, qry_start = 0, qry_end = 0, svlen = 0, seq_len = -1, mate_pos = 0, mate_contig = 0;
     uint32_t qname = 0; int64_t seq_off = 0; int strand = 0, is_first = 0;
     if (act) {
-      ref_start = v.in_ref_start[o]; svlen = v.in_svlen[o];
-      bool hs = lead_has_seq(v, o);
-      seq_len = hs ? v.in_seq_len[o] : -1; seq_off = hs ? v.in_seq_off[o] : 0;
-      if (svtype == SNF_INS || svtype == SNF_DEL) {
-        ref_end = v.in_ref_end[o]; qry_start = v.in_qry_start[o]; qry_end = v.in_qry_end[o];
-        qname = v.in_qname[o]; strand = v.in_strand[o];
-      } else if (svtype == SNF_BND) {
-        mate_pos = v.in_mate_pos[o]; mate_contig = v.in_mate_contig[o]; is_first = v.in_first[o];
-      }
+      const LeadRec r = v.Lrec[lo + lane];
+      o = r.orig; ref_start = r.ref_start; svlen = r.svlen; seq_len = r.seq_len; seq_off = r.seq_off;
+      ref_end = r.ref_end; qry_start = r.qry_start; qry_end = r.qry_end; qname = r.qname; strand = r.strand;
+      mate_pos = r.mate_pos; mate_contig = r.mate_contig; is_first = r.first;
     }
     int m = n;                 // number of leads after fusion
-    int32_t f_orig = (int32_t)o, f_svlen = svlen, f_seq_len = seq_len; int64_t f_seq_off = seq_off;
+    int32_t f_orig = (int32_t)o, f_svlen = svlen, f_seq_len = seq_len, f_lp = lane; int64_t f_seq_off = seq_off;
 
     if (svtype == SNF_INS || svtype == SNF_DEL) {
       // ---- merge_inner
@@ -113,7 +108,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int32_t s_svlen = SNF_GATHER(svlen), s_seq_len = SNF_GATHER(seq_len);
       const int64_t s_seq_off = SNF_GATHER(seq_off);
       const int s_strand = SNF_GATHER(strand);
-      const uint32_t s_o = SNF_GATHER(o);
+      const uint32_t s_o = SNF_GATHER(o); const int s_lp = SNF_GATHER(lane);
       // neighbour r-1
       const int p_fa = __shfl_up(s_fa, 1, SNF_WAVE);
       const int32_t p_rs = __shfl_up(s_rs, 1, SNF_WAVE), p_re = __shfl_up(s_re, 1, SNF_WAVE);
@@ -166,7 +161,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       if (start) lds.perm[kidx] = lane;
       __syncthreads();
       const int src2 = lds.perm[lane < m ? lane : 0];
-      f_orig = (int32_t)__shfl(s_o, src2, SNF_WAVE);
+      f_orig = (int32_t)__shfl(s_o, src2, SNF_WAVE); f_lp = __shfl(s_lp, src2, SNF_WAVE);
       f_svlen = (int32_t)__shfl(tot_svlen, src2, SNF_WAVE);
       const int32_t t_seq_len = ok_seq ? (nparts == 1 ? s_seq_len : (int32_t)tot_seq) : -1;
       const int64_t t_seq_off = ok_seq ? (nparts == 1 ? s_seq_off : new_off) : 0;
@@ -175,7 +170,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     }
     const bool fact = lane < m;
     if (fact) {
-      v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen;
+      v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen; v.F_lpos[lo + lane] = lo + f_lp;
       v.F_seq_len[lo + lane] = f_seq_len; v.F_seq_off[lo + lane] = f_seq_off;
     }
 
