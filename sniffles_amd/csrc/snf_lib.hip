@@ -48,21 +48,27 @@ SNF_KERNEL(e3_conslist, View)
 SNF_KERNEL(e4_anchor, View)
 SNF_KERNEL(e5_align, View)
 SNF_KERNEL(e6_vote, View)
+SNF_KERNEL(z1_results, View)
 
 // read preparation (coverage rank structures + REF haplotype prefix counts)
 struct ReadPrep {
   const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task; const int32_t* r_start;
   uint64_t* rk_in; uint32_t* rv_in; const uint64_t* rk_out; const uint32_t* rv_out;
   int32_t* re_sorted; uint32_t* fs[3]; uint32_t* fe[3]; int64_t R;
+  const uint64_t* t_base;  // [T+1] prefix of (max read end + 1): key = t_base[task] + end orders by (task, end)
+  int key32;               // the key space fits 32 bits: rk_in / rk_out hold uint32_t keys
 };
 namespace snf {
 SNF_HD void r1_endkeys_body(int64_t r, const ReadPrep& p) {
-  p.rk_in[r] = ((uint64_t)(uint32_t)p.r_task[r] << 32) | (uint32_t)p.r_end[r];
+  const uint64_t k = p.t_base[p.r_task[r]] + (uint64_t)(uint32_t)p.r_end[r];
+  if (p.key32) ((uint32_t*)p.rk_in)[r] = (uint32_t)k; else p.rk_in[r] = k;
   p.rv_in[r] = p.r_hp[r];
   for (int h = 0; h < 3; h++) { p.fs[h][r] = p.r_hp[r] == h; if (r == 0) p.fs[h][p.R] = 0; }
 }
 SNF_HD void r2_unpack_body(int64_t r, const ReadPrep& p) {
-  p.re_sorted[r] = (int32_t)(uint32_t)p.rk_out[r];
+  // the sort keeps every task's reads in that task's slots, so r_task[r] is also the task of sorted position r
+  const uint64_t k = p.key32 ? (uint64_t)((const uint32_t*)p.rk_out)[r] : p.rk_out[r];
+  p.re_sorted[r] = (int32_t)(k - p.t_base[p.r_task[r]]);
   for (int h = 0; h < 3; h++) { p.fe[h][r] = p.rv_out[r] == (uint32_t)h; if (r == 0) p.fe[h][p.R] = 0; }
 }
 }  // namespace snf
@@ -112,9 +118,12 @@ struct snf_batch_impl {
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
+  bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
   bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
+  int read_key_bits = 64;         // significant bits of the read-end sort key
+  std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
   int run_gap = 1000;
   // host staging
@@ -133,15 +142,15 @@ struct snf_batch_impl {
   std::vector<DevBuf> bufs;
   View v{};
   ReadPrep rp{};
-  Counts h_cnt{};
+  Counts* h_cnt = nullptr;        // counters as last read back (lives in the pinned result block hb_res)
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
 #ifndef SNF_EMU
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr;
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   // results (host)
-  HostBuf hb_calls, hb_alt, hb_rn;
+  HostBuf hb_calls, hb_alt, hb_rn, hb_res;
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
   // timing
   std::vector<Timing> timings;
@@ -277,6 +286,12 @@ struct Scope {
   }
 };
 
+void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, const char* name) {
+  if (!bytes) return;
+  if (b->time_all) { Scope _s(b, name, (int64_t)bytes); d2h(b, dst, src, bytes); }
+  else d2h(b, dst, src, bytes);
+}
+
 #ifndef SNF_EMU
 // LAUNCH_Q: tiny kernels are only bracketed by events when SNF_TIME_ALL=1 (two event records cost more host time
 // than the launch itself and the stage A-C region is launch-bound)
@@ -305,7 +320,8 @@ struct Scope {
 #endif
 
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
-void prim_sort_pairs(snf_batch_impl* b, const uint64_t* kin, uint64_t* kout, const uint32_t* vin, uint32_t* vout, int64_t n,
+template <class K>
+void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int64_t n,
                      int end_bit, const char* name) {
   if (n <= 0) return;
 #ifndef SNF_EMU
@@ -316,7 +332,7 @@ void prim_sort_pairs(snf_batch_impl* b, const uint64_t* kin, uint64_t* kout, con
     if (tmp) { dsync(b); dfree_one(b, tmp); }
     tmp = dalloc<uint8_t>(b, need); tmpb = need;
   }
-  Scope s(b, name, n * 24);
+  Scope s(b, name, n * 2 * (int64_t)(sizeof(K) + 4));
   SNF_HIP(rocprim::radix_sort_pairs(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
 #else
   (void)end_bit; (void)name;
@@ -394,8 +410,24 @@ void do_upload(snf_batch_impl* b) {
 #else
   v.wave_path = 0;
 #endif
+  const bool sort64 = getenv("SNF_SORT64") != nullptr;  // tests: force the wide-key sorts
+  {  // lead sort key: (task*8 + svtype) << bin_bits | bin, one more bit marks leads outside their contig (sorted last)
+    int64_t max_bins = 1;
+    for (auto& t : b->tasks) { int64_t nb = t.contig_len / (b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1) + 1; if (nb > max_bins) max_bins = nb; }
+    v.key_bin_bits = bits_for((uint64_t)max_bins);
+    v.key_nbits = v.key_bin_bits + bits_for((uint64_t)(8 * (T > 0 ? T : 1)));
+    v.key32 = (!sort64 && v.key_nbits + 1 <= 32) ? 1 : 0;
+  }
   v.pool_len = (int64_t)b->h_pool.size(); v.pool_cap = 2 * v.pool_len + 16;
   v.cnt = dalloc<Counts>(b, 1);
+  {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
+    size_t bytes = sizeof(Counts) + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8;
+    uint8_t* hp = (uint8_t*)b->hb_res.ensure(bytes);
+    memset(hp, 0, bytes);
+    b->h_cnt = (Counts*)hp;
+    v.res_cnt = (Counts*)hp; v.res_off = (int64_t*)(hp + sizeof(Counts)); v.res_cov = (double*)(v.res_off + T + 1);
+    v.res_status = (int32_t*)(v.res_cov + T);
+  }
   std::vector<int32_t> tid(T), svs(T), clen(T), psn(T); std::vector<double> nmt(T);
   for (int t = 0; t < T; t++) {
     tid[t] = b->tasks[t].task_id; svs[t] = b->tasks[t].sv_id_start; clen[t] = b->tasks[t].contig_len;
@@ -424,6 +456,13 @@ void do_upload(snf_batch_impl* b) {
   v.re_sorted = dalloc<int32_t>(b, R);
   for (int h = 0; h < 3; h++) { v.pc_s[h] = dalloc<uint32_t>(b, R + 1); v.pc_e[h] = dalloc<uint32_t>(b, R + 1); }
   ReadPrep& rp = b->rp;
+  {
+    std::vector<uint64_t> base((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) base[t + 1] = base[t] + (uint64_t)(uint32_t)b->h_rend_max[t] + 1;
+    rp.t_base = upload_vec(b, base);
+    b->read_key_bits = bits_for(base[T]);
+    rp.key32 = (!sort64 && b->read_key_bits <= 32) ? 1 : 0;
+  }
   rp.r_end = v.r_end; rp.r_hp = v.r_hp; rp.r_task = v.r_task; rp.r_start = v.r_start; rp.rk_in = v.rk_in; rp.rv_in = v.rv_in;
   rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.R = R;
   for (int h = 0; h < 3; h++) { rp.fs[h] = dalloc<uint32_t>(b, R + 1); rp.fe[h] = dalloc<uint32_t>(b, R + 1); }
@@ -479,7 +518,8 @@ void enqueue_read_prep(snf_batch_impl* b) {
   SideStream side(b);
   if (R > 0) {
     LAUNCH(r1_endkeys, b->rp, R, R * 13);
-    prim_sort_pairs(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, 32 + bits_for((uint64_t)T), "sort_read_ends");
+    if (b->rp.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.rk_in, (uint32_t*)v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
+    else prim_sort_pairs<uint64_t>(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
     LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
     for (int h = 0; h < 3; h++) {
       prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
@@ -495,6 +535,9 @@ void run_call_candidates(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N; int T = v.T;
   reset_timing(b);
+#ifndef SNF_EMU
+  if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
+#endif
   dzero(b, v.cnt, sizeof(Counts));
   dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
   dzero(b, v.t_status, sizeof(int32_t) * (T + 1));
@@ -509,7 +552,8 @@ void run_call_candidates(snf_batch_impl* b) {
     uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
     for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
     LAUNCH(a1_keys, v, N, N * 21);
-    prim_sort_pairs(b, v.key_in, v.key_out, v.val_in, v.val_out, N, 35 + bits_for((uint64_t)T), "sort_lead_keys");
+    if (v.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.key_in, (uint32_t*)v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
+    else prim_sort_pairs<uint64_t>(b, v.key_in, v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     LAUNCH_Q(a2_heads, v, N, N * 12);
     prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
     LAUNCH_Q(a3_bins, v, N, N * 8);
@@ -563,6 +607,7 @@ void run_call_candidates(snf_batch_impl* b) {
     join_side(b);
     LAUNCH(d4_coverage, v, N, 0);
   } else join_side(b);
+  LAUNCH_Q(z1_results, v, T + 1, 0);
   b->prefetched = false;
 }
 
@@ -577,13 +622,13 @@ void enqueue_prefetch(snf_batch_impl* b) {
   View& v = b->v;
   {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
      // the read names to the pinned host buffers while the (latency-bound) consensus kernel runs
-    int64_t nc = b->h_cnt.n_calls, rn_total = b->h_cnt.rn_total;
+    int64_t nc = b->h_cnt->n_calls, rn_total = b->h_cnt->rn_total;
     snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
     uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
     fork_mark(b);
     SideStream side(b);
-    d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
-    if (rn_total) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
+    d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
+    if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
     b->prefetched = true;
   }
 }
@@ -591,10 +636,10 @@ void enqueue_prefetch(snf_batch_impl* b) {
 void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
   if (v.N <= 0) return;
-  // one cheap round trip: the number of candidate calls makes every launch and scan below exact-sized
-  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
+  // one cheap round trip: the number of candidate calls makes every launch and scan below exact-sized (z1_results of
+  // the candidate stage has put the counters into the pinned result block)
   dsync(b);
-  const int64_t nc = b->h_cnt.n_calls;
+  const int64_t nc = b->h_cnt->n_calls;
   if (nc <= 0) return;
   fork_mark(b);
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream, overlapped with the consensus chain
@@ -616,12 +661,12 @@ void run_finalize(snf_batch_impl* b) {
   prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
   prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
   LAUNCH_Q(e3_conslist, v, nc, 0);
-  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
+  d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
-  const int64_t ncons = b->h_cnt.n_cons, alt_total = b->h_cnt.alt_total;
+  const int64_t ncons = b->h_cnt->n_cons, alt_total = b->h_cnt->alt_total;
   if (b->sched_prefetch == 1) enqueue_prefetch(b);
   if (ncons > 0) {
-    const int64_t tab_total = b->h_cnt.tab_total, aln_total = b->h_cnt.aln_total, nreads = b->h_cnt.n_cons_reads;
+    const int64_t tab_total = b->h_cnt->tab_total, aln_total = b->h_cnt->aln_total, nreads = b->h_cnt->n_cons_reads;
     int64_t c1 = b->tab_cap, c2 = b->tab_cap, c3 = b->tab_cap;
     ensure_cap(b, tab_total, c1, (void**)&v.tab_key, sizeof(uint64_t));
     ensure_cap(b, tab_total, c2, (void**)&v.tab_pos, sizeof(int32_t));
@@ -634,10 +679,12 @@ void run_finalize(snf_batch_impl* b) {
     ensure_cap(b, nreads, r3, (void**)&v.cr_read, sizeof(int32_t));
     b->cr_cap = r1;
   }
-  ensure_cap(b, alt_total, b->alt_cap, (void**)&v.alt_pool, 1); v.alt_cap = b->alt_cap;
-  const bool fallback = !v.wave_path || b->h_cnt.n_cons_fallback > 0;
+  // ALT bytes are only ever written by the GPU: the kernels store them straight into the pinned host buffer, so the
+  // PCIe transfer rides along with the (latency-bound) consensus kernels instead of trailing them
+  v.alt_pool = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1); v.alt_cap = alt_total;
+  const bool fallback = !v.wave_path || b->h_cnt->n_cons_fallback > 0;
   if (ncons > 0) {
-    if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt.tab_total * 13);
+    if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt->tab_total * 13);
 #ifndef SNF_EMU
     if (v.wave_path) {
       // algorithmic bytes are accumulated by the kernels themselves (cnt->cons_bytes) and attached to
@@ -659,11 +706,12 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
     }
 #endif
-    if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt.n_cons_reads, v.wave_path ? 0 : b->h_cnt.aln_total * 2);
+    if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt->n_cons_reads, v.wave_path ? 0 : b->h_cnt->aln_total * 2);
   }
   if (b->sched_prefetch == 2) enqueue_prefetch(b);
-  if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt.aln_total + 2 * alt_total);
+  if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt->aln_total + 2 * alt_total);
   join_side(b);
+  LAUNCH_Q(z1_results, v, v.T + 1, 0);
 }
 
 void collect_timings(snf_batch_impl* b) {
@@ -672,14 +720,19 @@ void collect_timings(snf_batch_impl* b) {
   for (size_t i = 0; i < b->ev_used; i++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, b->evs[i].a, b->evs[i].b) != hipSuccess) ms = -1;
+    if (b->timeline) {
+      float off = 0;
+      if (hipEventElapsedTime(&off, b->ev_base, b->evs[i].a) != hipSuccess) off = -1;
+      fprintf(stderr, "[SNF_TIMELINE] %9.1f %8.1f  %s\n", off * 1e3, ms * 1e3, b->evs[i].name);
+    }
     bool found = false;
     for (auto& t : b->timings)
       if (strcmp(t.name, b->evs[i].name) == 0) { t.ms += ms; t.bytes += b->evs[i].bytes; t.launches++; found = true; break; }
     if (!found) b->timings.push_back({b->evs[i].name, ms, b->evs[i].bytes, 1});
   }
   for (auto& t : b->timings) {  // the consensus kernels count their own algorithmic bytes (read back with the counters)
-    if (strcmp(t.name, "e45w_consensus_small") == 0) t.bytes = (int64_t)b->h_cnt.cons_bytes[1];
-    if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt.cons_bytes[2];
+    if (strcmp(t.name, "e45w_consensus_small") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[1];
+    if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[2];
   }
 #endif
 }
@@ -688,28 +741,28 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   View& v = b->v;
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
-  d2h(b, &b->h_cnt, v.cnt, sizeof(Counts));
-  dsync(b);
-  if (b->h_cnt.overflow) fail("internal: fused-sequence pool overflow");
+  dsync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
+  if (b->h_cnt->overflow) fail("internal: fused-sequence pool overflow");
   if (v.prof) {
     static const char* ph[8] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy"};
-    unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += b->h_cnt.prof[k];
-    for (int k = 0; k < 8; k++) fprintf(stderr, "[SNF_PROF] e45w %-10s %6.2f %%\n", ph[k], tot ? 100.0 * (double)b->h_cnt.prof[k] / (double)tot : 0.0);
+    unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += b->h_cnt->prof[k];
+    for (int k = 0; k < 8; k++) fprintf(stderr, "[SNF_PROF] e45w %-10s %6.2f %%\n", ph[k], tot ? 100.0 * (double)b->h_cnt->prof[k] / (double)tot : 0.0);
   }
-  int64_t nc = v.N > 0 ? b->h_cnt.n_calls : 0;
-  int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt.alt_total : 0;
-  int64_t rn_total = v.N > 0 ? b->h_cnt.rn_total : 0;
+  int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
+  int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;
+  int64_t rn_total = v.N > 0 ? b->h_cnt->rn_total : 0;
   snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
-  uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);
+  uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);  // filled by the kernels (zero-copy)
   uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
   const bool pre = b->prefetched && stage >= 1;
-  if (!pre) d2h(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t));
-  d2h(b, b->r_status.data(), v.t_status, (size_t)T * sizeof(int32_t));
-  d2h(b, b->r_off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t));
-  d2h(b, b->r_cov.data(), v.t_cov_avg, (size_t)T * sizeof(double));
-  if (alt_total) d2h(b, alt, v.alt_pool, (size_t)alt_total);
-  if (rn_total && !pre) d2h(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t));
-  dsync(b);
+  if (!pre) {
+    d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
+    if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
+    dsync(b);
+  }
+  memcpy(b->r_status.data(), v.res_status, (size_t)T * sizeof(int32_t));
+  memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
+  memcpy(b->r_cov.data(), v.res_cov, (size_t)T * sizeof(double));
   b->prefetched = false;  // the squeeze / stage fix-ups below edit the host copy in place
   if (v.N <= 0) std::fill(b->r_off.begin(), b->r_off.end(), 0);
   // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls: squeeze them out (rare; in place)
@@ -767,13 +820,16 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
   bool sorted = true;
   for (int64_t i = 1; i < r; i++) if (t->read_start[i] < t->read_start[i - 1]) { sorted = false; break; }
   if (!sorted) std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return t->read_start[x] < t->read_start[y]; });
+  int32_t rmax = 0;
   for (int64_t i = 0; i < r; i++) {
     int64_t k = ord[i];
     int32_t s = t->read_start[k], e = t->read_end[k];
     if (s < 0 || s >= t->contig_len || e < s) fail("read interval outside the task region (leadprov.py:497-498)");
     if (t->read_hp[k] > 2) fail("read hp must be 0, 1 or 2");
     b->h_rstart.push_back(s); b->h_rend.push_back(e); b->h_rhp.push_back(t->read_hp[k]); b->h_rtask.push_back(ti);
+    if (e > rmax) rmax = e;
   }
+  b->h_rend_max.push_back(rmax);
   int64_t ntr = t->n_tr > 0 ? t->n_tr : 0;
   int32_t pm = INT32_MIN;
   for (int64_t i = 0; i < ntr; i++) {
@@ -835,11 +891,13 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     SNF_HIP(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
     SNF_HIP(hipStreamCreateWithFlags(&b->stream3, hipStreamNonBlocking));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
+    SNF_HIP(hipEventCreate(&b->ev_base));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join3, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     b->cur = b->stream;
-    b->time_all = getenv("SNF_TIME_ALL") != nullptr;
+    b->timeline = getenv("SNF_TIMELINE") != nullptr;
+    b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
@@ -872,13 +930,14 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->stream2) (void)hipStreamSynchronize(b->stream2);
   if (b->stream3) (void)hipStreamSynchronize(b->stream3);
   if (b->ev_fork3) (void)hipEventDestroy(b->ev_fork3);
+  if (b->ev_base) (void)hipEventDestroy(b->ev_base);
   if (b->ev_join3) (void)hipEventDestroy(b->ev_join3);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 #endif
   dfree_all(b);
-  b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release();
+  b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
 #ifndef SNF_EMU
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->stream2) (void)hipStreamDestroy(b->stream2);
@@ -924,9 +983,8 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !dst_device || !n_calls) fail("batch not uploaded / null argument");
-    d2h(b, &b->h_cnt, b->v.cnt, sizeof(Counts));
     dsync(b);
-    int64_t nc = b->v.N > 0 ? b->h_cnt.n_calls : 0;
+    int64_t nc = b->v.N > 0 ? b->h_cnt->n_calls : 0;
     if (nc > cap_calls) fail("export buffer too small");
     *n_calls = nc;
 #ifndef SNF_EMU

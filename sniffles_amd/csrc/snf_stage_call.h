@@ -465,4 +465,14 @@ SNF_HD void d5_covavg_body(int64_t t, const View& v) {
   v.t_cov_avg[t] = L > 0 ? (double)v.t_cov_sum[t] / (double)L : NAN;
 }
 
+// Z1: counters, task status / call offsets / coverage averages -> the pinned host result block (zero-copy stores)
+SNF_HD void z1_results_body(int64_t t, const View& v) {
+  if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }
+  if (t <= v.T) v.res_off[t] = v.t_call_off[t];
+  if (t == 0) {
+    const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
+    for (size_t k = 0; k < sizeof(Counts) / 8; k++) d[k] = s[k];
+  }
+}
+
 }  // namespace snf

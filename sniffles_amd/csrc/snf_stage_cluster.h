@@ -24,17 +24,25 @@ SNF_HD void a1_keys_body(int64_t i, const View& v) {
   int64_t rs = v.in_ref_start[i];
   bool valid = rs >= 0 && rs < v.t_contig_len[t];
   uint64_t bin = valid ? (uint64_t)(rs / v.cfg.cluster_binsize) : 0;
-  v.key_in[i] = valid ? (((uint64_t)(t * 8 + v.in_svtype[i])) << 32 | bin) : SNF_KEY_INVALID;
+  const uint64_t k = valid ? (((uint64_t)(t * 8 + v.in_svtype[i])) << v.key_bin_bits | bin) : (1ull << v.key_nbits);
+  if (v.key32) ((uint32_t*)v.key_in)[i] = (uint32_t)k; else v.key_in[i] = k;
   v.val_in[i] = (uint32_t)i;
   v.seqnull[i] = 0;
 }
 
+// sorted key at position p in the canonical form grp << 32 | bin (SNF_KEY_INVALID for leads outside their contig)
+SNF_HD uint64_t sorted_key(const View& v, int64_t p) {
+  const uint64_t k = v.key32 ? (uint64_t)((const uint32_t*)v.key_out)[p] : v.key_out[p];
+  if (k >> v.key_nbits) return SNF_KEY_INVALID;
+  return ((k >> v.key_bin_bits) << 32) | (k & ((1ull << v.key_bin_bits) - 1ull));
+}
+
 // A2: bin heads in (stably) sorted order
 SNF_HD void a2_heads_body(int64_t p, const View& v) {
-  uint64_t k = v.key_out[p];
+  uint64_t k = sorted_key(v, p);
   bool valid = k != SNF_KEY_INVALID;
-  v.headflag[p] = (valid && (p == 0 || v.key_out[p - 1] != k)) ? 1u : 0u;
-  if (valid && (p + 1 == v.N || v.key_out[p + 1] == SNF_KEY_INVALID)) v.cnt->n_valid = p + 1;
+  v.headflag[p] = (valid && (p == 0 || sorted_key(v, p - 1) != k)) ? 1u : 0u;
+  if (valid && (p + 1 == v.N || sorted_key(v, p + 1) == SNF_KEY_INVALID)) v.cnt->n_valid = p + 1;
   if (p == 0) v.headflag[v.N] = 0;
 }
 
@@ -48,7 +56,7 @@ SNF_HD void a3_bins_body(int64_t p, const View& v) {
   if (v.headflag[p]) {
     uint32_t b = v.headscan[p];
     v.bin_lo[b] = (int32_t)p;
-    v.bin_key[b] = v.key_out[p];
+    v.bin_key[b] = sorted_key(v, p);
   }
 }
 

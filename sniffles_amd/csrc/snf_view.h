@@ -100,7 +100,8 @@ struct View {
   const int32_t* tr_start; const int32_t* tr_end; const int32_t* tr_pmax;
 
   // ---- stage A: binning (sorted position p in [0,N))
-  uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;
+  uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
+  int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
   uint32_t *headflag, *headscan;  // [N+1] bin heads in sorted order / exclusive scan (bin ids)
   uint32_t *eligflag, *eligscan;  // [N+1] per bin: seeds a cluster / exclusive scan (seed ids)
   uint32_t *fN, *pN;              // [N+1] per sorted lead: goes to a seed's `leads` / scatter position
@@ -118,6 +119,8 @@ struct View {
   uint32_t* L;               // [N] seed-cluster leads, (task, svtype, bin, arrival) order -> input index
   uint32_t* LL;              // [N] leads_long, same order
   LeadRec* Lrec;             // [N] packed records of L[] (same index)
+  // result block in pinned host memory, written by z1_results at the end of each stage (no D2H copies to wait for)
+  Counts* res_cnt; int32_t* res_status; int64_t* res_off; double* res_cov;
 
   // ---- stage B/C: seeds [n_seeds <= N]
   int32_t *seed_bin, *seed_lo, *seed_hi, *seedL_lo, *seedL_hi, *seed_start, *seed_grp;

@@ -57,3 +57,11 @@ def test_merge_scan_run_cuts_are_exact(gap, emu_lib, oracle_mod, monkeypatch):
             exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
             got = records.records(run(emu_lib, cfg, tis, True), tis, "final")
             assert got == exp
+
+
+def test_wide_sort_keys_are_exact(emu_lib, oracle_mod, monkeypatch):
+    """SNF_SORT64 forces the 64-bit sort keys used when (task, svtype, bin) or the read-end key space exceeds 32 bits."""
+    monkeypatch.setenv("SNF_SORT64", "1")
+    tis = [synth.gen_fuzz(300 + k, task_id=k) for k in range(4)]
+    cfg = SnifflesConfig()
+    assert records.records(run(emu_lib, cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")

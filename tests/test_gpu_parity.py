@@ -67,6 +67,17 @@ def test_hip_run_cuts_exact(gap, oracle_mod, monkeypatch):
     assert records.records(run(cfg, tis), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
 
 
+def test_hip_wide_sort_keys_exact(oracle_mod, monkeypatch):
+    """Batches whose key space exceeds 32 bits sort 64-bit keys; SNF_SORT64 forces that path on a small batch."""
+    monkeypatch.setenv("SNF_SORT64", "1")
+    cfg = SnifflesConfig()
+    tis = [synth.gen_fuzz(700 + k, task_id=k) for k in range(5)]
+    exp = oracle_mod.run(cfg, tis, True)
+    got = run(cfg, tis, True)
+    assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+    assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
+
+
 def genome(scale, cov=30, seed=1, **kw):
     return synth.gen_genome(coverage=cov, seed=seed, scale=scale, **kw)
 
