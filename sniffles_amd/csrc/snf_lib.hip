@@ -37,7 +37,6 @@ SNF_KERNEL(d2_call, View)
 SNF_KERNEL(d3_compact, View)
 SNF_KERNEL(d3_taskoff, View)
 SNF_KERNEL(d3_svid, View)
-SNF_KERNEL(d3_stale, View)
 SNF_KERNEL(d3_rnames, View)
 SNF_KERNEL(d4_coverage, View)
 SNF_KERNEL(d5_covsum, View)
@@ -120,8 +119,11 @@ struct snf_batch_impl {
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
   bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
   bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
+  bool res_current = false;       // z1_results has run after the last kernel that changes what it publishes
+  int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
+  int occ_s = 4, occ_l = 4;        // SNF_OCC_S / SNF_OCC_L: waves/SIMD the consensus kernels are compiled for (A/B)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
@@ -145,7 +147,8 @@ struct snf_batch_impl {
   Counts* h_cnt = nullptr;        // counters as last read back (lives in the pinned result block hb_res)
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
 #ifndef SNF_EMU
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr,
+             ev_counts = nullptr, ev_rn = nullptr;  // host waits: counters published (main), read-name total published (side)
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
@@ -421,11 +424,12 @@ void do_upload(snf_batch_impl* b) {
   v.pool_len = (int64_t)b->h_pool.size(); v.pool_cap = 2 * v.pool_len + 16;
   v.cnt = dalloc<Counts>(b, 1);
   {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
-    size_t bytes = sizeof(Counts) + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8;
+    size_t bytes = sizeof(Counts) + 8 + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8;
     uint8_t* hp = (uint8_t*)b->hb_res.ensure(bytes);
     memset(hp, 0, bytes);
     b->h_cnt = (Counts*)hp;
-    v.res_cnt = (Counts*)hp; v.res_off = (int64_t*)(hp + sizeof(Counts)); v.res_cov = (double*)(v.res_off + T + 1);
+    v.res_cnt = (Counts*)hp; v.res_rn_total = (int64_t*)(hp + sizeof(Counts)); b->h_rn_total = v.res_rn_total;
+    v.res_off = v.res_rn_total + 1; v.res_cov = (double*)(v.res_off + T + 1);
     v.res_status = (int32_t*)(v.res_cov + T);
   }
   std::vector<int32_t> tid(T), svs(T), clen(T), psn(T); std::vector<double> nmt(T);
@@ -470,7 +474,7 @@ void do_upload(snf_batch_impl* b) {
   size_t N1 = (size_t)N + 1;
   v.key_in = dalloc<uint64_t>(b, N); v.key_out = dalloc<uint64_t>(b, N); v.val_in = dalloc<uint32_t>(b, N); v.val_out = dalloc<uint32_t>(b, N);
   uint32_t** u32s[] = {&v.headflag, &v.headscan, &v.eligflag, &v.eligscan, &v.fN, &v.pN, &v.fL, &v.pL, &v.runflag, &v.runscan,
-                       &v.clflag, &v.clscan, &v.rcflag, &v.rcscan, &v.cdflag, &v.cdscan};
+                       &v.clflag, &v.clscan, &v.rcflag, &v.rcscan, &v.cdflag, &v.cdscan, &v.rnf, &v.rnp};
   for (auto pp : u32s) *pp = dalloc<uint32_t>(b, N1);
   v.seqnull = dalloc<uint8_t>(b, N); v.bin_lo = dalloc<int32_t>(b, N1); v.bin_key = dalloc<uint64_t>(b, N);
   v.bin_hap = dalloc<uint16_t>(b, 3 * (size_t)N); v.bin_elig = dalloc<uint8_t>(b, N);
@@ -596,19 +600,36 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
     prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
     LAUNCH_Q(d3_compact, v, N, 0);
-    LAUNCH_Q(d3_taskoff, v, T + 1, 0);
-    LAUNCH_Q(d3_svid, v, N, 0);
-    prim_exscan<uint32_t>(b, v.fN, v.pN, N + 1, "scan_rnames");
-    LAUNCH_Q(d3_stale, v, T, 0);
-    LAUNCH(d3_rnames, v, N, 0);
   }
-  if (b->sched_readprep == 2) enqueue_read_prep(b);
-  if (N > 0) {
-    join_side(b);
-    LAUNCH(d4_coverage, v, N, 0);
-  } else join_side(b);
-  LAUNCH_Q(z1_results, v, T + 1, 0);
-  b->prefetched = false;
+  // the number of calls is known here: publish the counters (pinned block) and let the host pick them up through
+  // ev_counts.  Nothing the ALT chain of finalize needs is produced after this point, so the rest of the candidate
+  // stage (sv ids, supporting read names, coverage annotation) continues on the side stream, behind the read preparation
+  LAUNCH_Q(d3_taskoff, v, T + 1, 0);
+#ifndef SNF_EMU
+  SNF_HIP(hipEventRecord(b->ev_counts, b->stream));
+#endif
+  if (b->sched_readprep >= 2) enqueue_read_prep(b);
+  fork_mark(b);
+  {
+    SideStream side(b);
+    if (N > 0) {
+      LAUNCH_Q(d3_svid, v, N, 0);
+      prim_exscan<uint32_t>(b, v.rnf, v.rnp, N + 1, "scan_rnames");
+      LAUNCH(d3_rnames, v, N, 0);
+    } else *b->h_rn_total = 0;
+#ifndef SNF_EMU
+    SNF_HIP(hipEventRecord(b->ev_rn, b->cur));
+#endif
+    if (N > 0) LAUNCH(d4_coverage, v, N, 0);
+  }
+  b->prefetched = false; b->res_current = false;
+}
+
+// everything enqueued on any of the batch's streams has completed and the pinned result block is current
+void full_sync(snf_batch_impl* b) {
+  join_side(b);
+  if (!b->res_current) { LAUNCH_Q(z1_results, b->v, b->v.T + 1, 0); b->res_current = true; }
+  dsync(b);
 }
 
 void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t elem) {
@@ -622,7 +643,10 @@ void enqueue_prefetch(snf_batch_impl* b) {
   View& v = b->v;
   {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
      // the read names to the pinned host buffers while the (latency-bound) consensus kernel runs
-    int64_t nc = b->h_cnt->n_calls, rn_total = b->h_cnt->rn_total;
+#ifndef SNF_EMU
+    SNF_HIP(hipEventSynchronize(b->ev_rn));  // d3_rnames (side stream, enqueued long ago) has published the total
+#endif
+    int64_t nc = b->h_cnt->n_calls, rn_total = *b->h_rn_total;
     snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
     uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
     fork_mark(b);
@@ -636,13 +660,16 @@ void enqueue_prefetch(snf_batch_impl* b) {
 void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
   if (v.N <= 0) return;
-  // one cheap round trip: the number of candidate calls makes every launch and scan below exact-sized (z1_results of
-  // the candidate stage has put the counters into the pinned result block)
-  dsync(b);
+  // one cheap wait: the number of candidate calls makes every launch and scan below exact-sized (d3_taskoff has put
+  // the counters into the pinned result block; the side stream may still be annotating the candidates)
+#ifndef SNF_EMU
+  SNF_HIP(hipEventSynchronize(b->ev_counts));
+#endif
   const int64_t nc = b->h_cnt->n_calls;
   if (nc <= 0) return;
-  fork_mark(b);
-  {  // QC / phasing / genotyping only touch the scalar call fields: side stream, overlapped with the consensus chain
+  b->res_current = false;
+  {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
+     // annotations they read), overlapped with the consensus chain
     SideStream side(b);
 #ifndef SNF_EMU
     if (v.wave_path) {
@@ -695,13 +722,16 @@ void run_finalize(snf_batch_impl* b) {
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+          if (b->occ_l == 4) hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 4>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+          else hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 3>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
         SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
       }
       { Scope _s(b, "e45w_consensus_small", 0);
-        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+        if (b->occ_s == 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+        else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 4>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError()); }
       SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
     }
@@ -712,6 +742,7 @@ void run_finalize(snf_batch_impl* b) {
   if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt->aln_total + 2 * alt_total);
   join_side(b);
   LAUNCH_Q(z1_results, v, v.T + 1, 0);
+  b->res_current = true;
 }
 
 void collect_timings(snf_batch_impl* b) {
@@ -741,12 +772,17 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   View& v = b->v;
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
-  dsync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
+  full_sync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
   if (b->h_cnt->overflow) fail("internal: fused-sequence pool overflow");
   if (v.prof) {
     static const char* ph[8] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy"};
     unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += b->h_cnt->prof[k];
     for (int k = 0; k < 8; k++) fprintf(stderr, "[SNF_PROF] e45w %-10s %6.2f %%\n", ph[k], tot ? 100.0 * (double)b->h_cnt->prof[k] / (double)tot : 0.0);
+    const Counts& c = *b->h_cnt;
+    fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
+                    "fallback %lld alt bytes %lld\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+            (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
+            (long long)c.alt_total);
   }
   int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
   int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;
@@ -892,6 +928,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     SNF_HIP(hipStreamCreateWithFlags(&b->stream3, hipStreamNonBlocking));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
     SNF_HIP(hipEventCreate(&b->ev_base));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_counts, hipEventDisableTiming));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_rn, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join3, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
@@ -899,6 +937,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
+    if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
+    if (const char* e = getenv("SNF_OCC_L")) b->occ_l = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());
@@ -931,6 +971,8 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->stream3) (void)hipStreamSynchronize(b->stream3);
   if (b->ev_fork3) (void)hipEventDestroy(b->ev_fork3);
   if (b->ev_base) (void)hipEventDestroy(b->ev_base);
+  if (b->ev_counts) (void)hipEventDestroy(b->ev_counts);
+  if (b->ev_rn) (void)hipEventDestroy(b->ev_rn);
   if (b->ev_join3) (void)hipEventDestroy(b->ev_join3);
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
@@ -983,7 +1025,7 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !dst_device || !n_calls) fail("batch not uploaded / null argument");
-    dsync(b);
+    full_sync(b);
     int64_t nc = b->v.N > 0 ? b->h_cnt->n_calls : 0;
     if (nc > cap_calls) fail("export buffer too small");
     *n_calls = nc;
@@ -996,7 +1038,7 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
 }
 
 int snf_batch_sync(snf_batch_t* bb) {
-  SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); dsync(b); collect_timings(b); })
+  SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); if (b->uploaded) full_sync(b); else dsync(b); collect_timings(b); })
 }
 
 int snf_batch_timing_count(snf_batch_t* bb) {

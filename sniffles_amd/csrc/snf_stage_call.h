@@ -348,46 +348,54 @@ SNF_HD void d3_compact_body(int64_t r, const View& v) {
   if (r < v.cnt->n_rc && v.cdflag[r]) { uint32_t i = v.cdscan[r]; v.calls[i] = v.cand[r]; v.callx[i] = v.candx[r]; }
 }
 
-// D3b: per task offsets into calls (calls are sorted by task), T+1 entries
-SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
+// D3b: per task offsets into calls (calls are sorted by task), T+1 entries; task status / stale BND `end`
+// (postprocessing.py:84-106); thread 0 publishes the counters to the pinned result block so that the host can size
+// the ALT chain while the rest of the candidate stage is still running on the side stream
+SNF_HD int64_t task_lower_bound(const View& v, int64_t t) {
   int64_t lo = 0, hi = v.cnt->n_calls;
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v.calls[mid].task_index < t) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
+  const int64_t lo = task_lower_bound(v, t);
   v.t_call_off[t] = lo;
+  if (t < v.T) {
+    const int64_t hi = task_lower_bound(v, t + 1);
+    int64_t a = lo, b = hi;
+    while (a < b) { int64_t mid = (a + b) >> 1; if (v.calls[mid].svtype < SNF_BND) a = mid + 1; else b = mid; }
+    v.t_status[t] = SNF_TASK_OK; v.t_stale_end[t] = 0;
+    if (a < hi && v.calls[a].svtype == SNF_BND) {
+      if (a == lo) v.t_status[t] = SNF_TASK_ERR_UNBOUND_END;   // UnboundLocalError: local variable 'end'
+      else {
+        const snf_call_t& p = v.calls[a - 1];
+        v.t_stale_end[t] = p.svtype == SNF_INS ? p.pos + 1 : (int32_t)((int64_t)p.pos + iabs64(p.svlen));
+      }
+    }
+  }
+  if (t == 0) {
+    const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
+    for (size_t k = 0; k < sizeof(Counts) / 8; k++) d[k] = s[k];
+  }
 }
 
-// D3c: sv ids, stale BND `end` (postprocessing.py:84-106), rnames offsets helper
+// D3c: sv ids, rnames offsets helper
 SNF_HD void d3_svid_body(int64_t i, const View& v) {
-  if (i >= v.cnt->n_calls) { v.fN[i] = 0; return; }
+  if (i >= v.cnt->n_calls) { v.rnf[i] = 0; return; }
   snf_call_t& c = v.calls[i];
   int t = c.task_index;
   c.sv_id = v.t_sv_id_start[t] + (int32_t)(i - v.t_call_off[t]);
-  v.fN[i] = (uint32_t)c.rn_len;  // scanned into rn_off
-  if (i == 0) v.fN[v.N] = 0;
-}
-
-SNF_HD void d3_stale_body(int64_t t, const View& v) {
-  if (t >= v.T) return;
-  int64_t lo = v.t_call_off[t], hi = v.t_call_off[t + 1];
-  int64_t a = lo, b = hi;
-  while (a < b) { int64_t mid = (a + b) >> 1; if (v.calls[mid].svtype < SNF_BND) a = mid + 1; else b = mid; }
-  v.t_status[t] = SNF_TASK_OK; v.t_stale_end[t] = 0;
-  if (a < hi && v.calls[a].svtype == SNF_BND) {
-    if (a == lo) v.t_status[t] = SNF_TASK_ERR_UNBOUND_END;   // UnboundLocalError: local variable 'end'
-    else {
-      const snf_call_t& p = v.calls[a - 1];
-      v.t_stale_end[t] = p.svtype == SNF_INS ? p.pos + 1 : (int32_t)((int64_t)p.pos + iabs64(p.svlen));
-    }
-  }
+  v.rnf[i] = (uint32_t)c.rn_len;  // scanned into rn_off
+  if (i == 0) v.rnf[v.N] = 0;
 }
 
 // D3d: supporting read names (pN = exclusive scan of rn_len)
 SNF_HD void d3_rnames_body(int64_t i, const View& v) {
-  if (i == 0) v.cnt->rn_total = v.pN[v.N];
+  if (i == 0) { v.cnt->rn_total = v.rnp[v.N]; *v.res_rn_total = v.rnp[v.N]; }
   if (i >= v.cnt->n_calls) return;
   snf_call_t& c = v.calls[i];
   const CallX& x = v.callx[i];
   int64_t nq = c.rn_off;  // stashed by d2
-  int64_t off = v.pN[i];
+  int64_t off = v.rnp[i];
   const int32_t* a1 = v.w1 + x.flo;
   for (int64_t k = 0; k < nq; k++) v.rnames[off + k] = (uint32_t)a1[k];
   int64_t w = nq;

@@ -121,6 +121,8 @@ struct View {
   LeadRec* Lrec;             // [N] packed records of L[] (same index)
   // result block in pinned host memory, written by z1_results at the end of each stage (no D2H copies to wait for)
   Counts* res_cnt; int32_t* res_status; int64_t* res_off; double* res_cov;
+  int64_t* res_rn_total;     // pinned: total supporting-read-name count, written by d3_rnames (side stream)
+  uint32_t *rnf, *rnp;       // [N+1] rn_len per call and its exclusive scan (own buffers: runs next to the ALT chain)
 
   // ---- stage B/C: seeds [n_seeds <= N]
   int32_t *seed_bin, *seed_lo, *seed_hi, *seedL_lo, *seedL_hi, *seed_start, *seed_grp;

@@ -68,8 +68,8 @@ SNF_D int wave_max_incl(int x, int lane) {
 #define SNF_PH(k) do { if (v.prof && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&v.cnt->prof[k], t_ - tph); tph = t_; } } while (0)
 
 // CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
-template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS>
-__global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_unused) {
+template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW>
+__global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_t n_unused) {
   typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS> Lds;
   __shared__ Lds lds;
   constexpr int ROUNDS = MAXPOS / 64;
@@ -247,41 +247,47 @@ __global__ void __launch_bounds__(256) e45w_consensus(const View v, int64_t n_un
     SNF_PH(5);
     // ---- column vote (consensus.py:365-380) on the rows this workgroup just wrote (still in L2)
     __syncthreads();
+    SNF_PH(7);
     int nkept = 0;
     for (int32_t r = 0; r < x.n_others; r++) nkept += lds.kept[r];
     const double maxal = (double)(1 + nkept);
     for (int64_t q = tid; q < L; q += 256) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
-      if (x.n_others <= 16) {
-        // votes of this column in registers: (count, char) top-2 over [best] + votes
-        uint8_t ch[16]; int nv = 0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-          uint8_t c = '-';
-          if (r < x.n_others && lds.kept[r]) c = rows[(int64_t)r * L + q];
-          ch[r] = c; nv += (c != '-');
+      {  // fast path: every character of the column is one of A C G T -> four packed 16-bit counters, one pass
+        const uint32_t ACTG = 0x47544341u;  // code (c >> 1) & 3: A 0, C 1, T 2, G 3
+        int cd = (bq >> 1) & 3;
+        bool plain = ((ACTG >> (8 * cd)) & 0xffu) == bq;
+        unsigned long long cnt4 = 1ull << (16 * cd);
+        int nv = 0;
+#pragma unroll 8
+        for (int32_t r = 0; r < x.n_others; r++) {  // no early exit: keeps the row loads independent
+          if (!lds.kept[r]) continue;
+          const uint8_t c = rows[(int64_t)r * L + q];
+          if (c == '-') continue;
+          cd = (c >> 1) & 3;
+          plain &= ((ACTG >> (8 * cd)) & 0xffu) == c;
+          cnt4 += 1ull << (16 * cd); nv++;
         }
-        if (!(nv < 2 || (double)nv / maxal < 0.25)) {
-          int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
+        if (plain) {
+          if (!(nv < 2 || (double)nv / maxal < 0.25)) {
+            int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
 #pragma unroll
-          for (int r = -1; r < 16; r++) {
-            const uint8_t c = r < 0 ? bq : ch[r < 0 ? 0 : r];
-            if (c == '-') continue;
-            bool seen = (r >= 0 && c == bq);
-#pragma unroll
-            for (int r2 = 0; r2 < 16; r2++) if (r2 < r && ch[r2] == c) seen = true;
-            if (seen) continue;
-            int cntc = (c == bq) ? 1 : 0;
-#pragma unroll
-            for (int r2 = 0; r2 < 16; r2++) cntc += (ch[r2] == c);
-            nd++;
-            if (cntc > c0 || (cntc == c0 && (int)c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
-            else if (cntc > c1 || (cntc == c1 && (int)c > k1)) { c1 = cntc; k1 = c; }
+            for (int z = 0; z < 4; z++) {
+              const int cntc = (int)((cnt4 >> (16 * z)) & 0xffffull);
+              if (!cntc) continue;
+              const int c = (int)((ACTG >> (8 * z)) & 0xffu);
+              nd++;
+              if (cntc > c0 || (cntc == c0 && c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+              else if (cntc > c1 || (cntc == c1 && c > k1)) { c1 = cntc; k1 = c; }
+            }
+            if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
           }
-          if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
+          alt[q] = out;
+          continue;
         }
-      } else {
+      }
+      {  // generic path: some character of this column is not A/C/G/T (rare)
         int nvotes = 0;
         for (int32_t r = 0; r < x.n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
         if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
