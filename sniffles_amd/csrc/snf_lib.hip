@@ -123,7 +123,6 @@ struct snf_batch_impl {
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
-  int occ_s = 4, occ_l = 4;        // SNF_OCC_S / SNF_OCC_L: waves/SIMD the consensus kernels are compiled for (A/B)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
@@ -410,6 +409,7 @@ void do_upload(snf_batch_impl* b) {
 #ifndef SNF_EMU
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
   v.prof = getenv("SNF_PROF") ? 1 : 0;
+  v.ablate = getenv("SNF_ABLATE") ? atoi(getenv("SNF_ABLATE")) : 0;
 #else
   v.wave_path = 0;
 #endif
@@ -497,6 +497,9 @@ void do_upload(snf_batch_impl* b) {
   auto lut = build_gt_lut(b->cfg);
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
+  v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
+  v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1);
+  for (int k = 0; k < 3; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
   v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
@@ -529,7 +532,14 @@ void enqueue_read_prep(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
       prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
     }
+#ifndef SNF_EMU
+    { Scope _s(b, "d5w_covsum", R * 12);
+      int64_t grid = (R + 4095) / 4096; if (grid > 2048) grid = 2048;
+      hipLaunchKernelGGL(d5w_covsum, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError()); }
+#else
     LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
+#endif
   }
   LAUNCH_Q(d5_covavg, v, T, 0);
   }
@@ -668,6 +678,7 @@ void run_finalize(snf_batch_impl* b) {
   const int64_t nc = b->h_cnt->n_calls;
   if (nc <= 0) return;
   b->res_current = false;
+  dzero(b, v.stripes, sizeof(unsigned long long) * 4 * 64 * 16);
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
      // annotations they read), overlapped with the consensus chain
     SideStream side(b);
@@ -715,24 +726,32 @@ void run_finalize(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       // algorithmic bytes are accumulated by the kernels themselves (cnt->cons_bytes) and attached to
-      // these two timing entries in collect_timings
-      int64_t grid = ncons < 16384 ? ncons : 16384;
-      {  // the LARGE class is independent of the SMALL one: its own stream, joined before the ALT pool is copied out
-        SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+      // these timing entries in collect_timings.  One launch per class, sized by the class counters of e3_conslist
+      const int64_t n_copy = (int64_t)b->h_cnt->n_cls[0], n_small = (int64_t)b->h_cnt->n_cls[1], n_large = (int64_t)b->h_cnt->n_cls[2];
+      const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
+      if (serial) SNF_HIP(hipDeviceSynchronize());
+      SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+      if (n_large > 0) {  // the LARGE class is independent of the others: its own stream, joined before z1_results
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          if (b->occ_l == 4) hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 4>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-          else hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 3>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 4>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
-        SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
       }
-      { Scope _s(b, "e45w_consensus_small", 0);
-        if (b->occ_s == 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-        else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-        else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 4>), dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError()); }
+      if (serial) SNF_HIP(hipDeviceSynchronize());
+      SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+      if (n_small > 0) {
+        Scope _s(b, "e45w_consensus_small", 0);
+        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 4>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError());
+      }
+      if (serial) SNF_HIP(hipDeviceSynchronize());
+      if (n_copy > 0) {
+        Scope _s(b, "e4c_copy", 0);
+        hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError());
+      }
       SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
     }
 #endif
@@ -764,6 +783,7 @@ void collect_timings(snf_batch_impl* b) {
   for (auto& t : b->timings) {  // the consensus kernels count their own algorithmic bytes (read back with the counters)
     if (strcmp(t.name, "e45w_consensus_small") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[1];
     if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[2];
+    if (strcmp(t.name, "e4c_copy") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[3];
   }
 #endif
 }
@@ -775,14 +795,20 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   full_sync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
   if (b->h_cnt->overflow) fail("internal: fused-sequence pool overflow");
   if (v.prof) {
-    static const char* ph[8] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy"};
-    unsigned long long tot = 0; for (int k = 0; k < 8; k++) tot += b->h_cnt->prof[k];
-    for (int k = 0; k < 8; k++) fprintf(stderr, "[SNF_PROF] e45w %-10s %6.2f %%\n", ph[k], tot ? 100.0 * (double)b->h_cnt->prof[k] / (double)tot : 0.0);
+    static const char* ph[32] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy", "kmer-load", "",
+                                 "", "", "", "", "", "", "d1w:header", "d1w:load", "d1w:sort", "d1w:fuse", "d1w:store", "d1w:resplit", "", "",
+                                 "", "", "", "", "", "", "", ""};
     const Counts& c = *b->h_cnt;
+    for (int base = 0; base < 32; base += 16) {
+      unsigned long long tot = 0; for (int k = 0; k < 16; k++) tot += c.prof[base + k];
+      for (int k = 0; k < 16; k++)
+        if (c.prof[base + k])
+          fprintf(stderr, "[SNF_PROF] %-12s %6.2f %%  %12llu ticks\n", ph[base + k], 100.0 * (double)c.prof[base + k] / (double)tot, c.prof[base + k]);
+    }
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
-                    "fallback %lld alt bytes %lld\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+                    "fallback %lld alt bytes %lld | ALT classes copy %llu small %llu large %llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
-            (long long)c.alt_total);
+            (long long)c.alt_total, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3]);
   }
   int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
   int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;
@@ -937,8 +963,6 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
-    if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
-    if (const char* e = getenv("SNF_OCC_L")) b->occ_l = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());

@@ -478,6 +478,11 @@ SNF_HD void z1_results_body(int64_t t, const View& v) {
   if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }
   if (t <= v.T) v.res_off[t] = v.t_call_off[t];
   if (t == 0) {
+    if (v.wave_path) for (int c = 0; c < 4; c++) {  // striped byte counters of the ALT kernels (snf_wave_cons.h)
+      unsigned long long sum = 0;
+      for (int k = 0; k < 64; k++) sum += v.stripes[(c * 64 + k) * 16];
+      v.cnt->cons_bytes[c] = sum;
+    }
     const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
     for (size_t k = 0; k < sizeof(Counts) / 8; k++) d[k] = s[k];
   }

@@ -385,7 +385,11 @@ SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { ret
 
 SNF_HD void e2_best_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
-  if (i == 0) { v.fN[nc] = 0; v.fL[nc] = 0; v.sz_tab[nc] = 0; v.sz_aln[nc] = 0; v.sz_rd[nc] = 0; }
+  if (i == 0) {
+    v.fN[nc] = 0; v.fL[nc] = 0; v.sz_tab[nc] = 0; v.sz_aln[nc] = 0; v.sz_rd[nc] = 0;
+    for (int k = 0; k < 4; k++) v.cnt->n_cls[k] = 0;   // filled by e3_conslist (finalize may run more than once)
+    v.cnt->n_cons_fallback = 0;
+  }
   if (i >= nc) return;
   v.fN[i] = 0; v.fL[i] = 0; v.sz_tab[i] = 0; v.sz_aln[i] = 0; v.sz_rd[i] = 0;
   snf_call_t& c = v.calls[i];
@@ -420,6 +424,30 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
 }
 
 // E3: ALT work list (pN/pL/sc_* = exclusive scans over the calls of alt length, has-alt flag and the sizes)
+// next free slot of the class list (order within a list is irrelevant).  On the GPU the lanes of a wave that append to
+// the same class share one atomic: same-address atomics serialise in L2 at ~25 ns each, tens of thousands of them
+// would dominate the kernel
+SNF_HD int64_t class_list_slot(const View& v, int cls) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int64_t slot = 0;
+  for (int c = 0; c < 4; c++) {
+    const unsigned long long m = __ballot(cls == c);
+    if (cls == c) {
+      const int lane = (int)__lane_id();
+      const int leader = __builtin_ctzll(m);
+      unsigned long long base = 0;
+      if (lane == leader) base = atomic_add_u64(&v.cnt->n_cls[c], (unsigned long long)__builtin_popcountll(m));
+      base = __shfl(base, leader, 64);
+      slot = (int64_t)base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+    }
+  }
+  return cls == 3 ? (int64_t)v.N : slot;  // cls 3: a scratch slot past every real entry
+#else
+  const int64_t slot = (int64_t)atomic_add_u64(&v.cnt->n_cls[cls], 1ull);
+  return cls == 3 ? (int64_t)v.N : slot;
+#endif
+}
+
 SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
   if (i == 0) {
@@ -437,6 +465,23 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   v.cons_tab_off[cid] = v.sc_tab[i]; v.cons_tab_sz[cid] = v.sz_tab[i];
   v.cons_aln_off[cid] = v.sc_aln[i]; v.cons_read_off[cid] = v.sc_rd[i];
   if (v.sz_tab[i] > 0) atomic_add_u64((unsigned long long*)&v.cnt->n_cons_fallback, 1ull);   // rare
+  if (!v.wave_path) return;
+  // work item for the gfx950 workgroup kernels
+  ConsDesc d;
+  d.L = v.F_seq_len[x.best]; d.best_off = v.F_seq_off[x.best]; d.alt_off = x.alt_off; d.aln_off = v.sc_aln[i];
+  d.read_off = v.sc_rd[i]; d.n_others = x.n_others; d.call = (int32_t)i;
+  d.cls = x.do_cons ? (cons_class(v, d.L, x.n_others) ? cons_class(v, d.L, x.n_others) : 3) : 0;
+  v.cdesc[cid] = d;
+  v.cls_list[d.cls < 3 ? d.cls : 0][class_list_slot(v, d.cls)] = (int32_t)cid;  // cls 3 (thread kernels) is only counted
+  if (d.cls == 1 || d.cls == 2) {  // the other sequence-bearing leads, cluster order (consensus.py:302)
+    int64_t w = d.read_off;
+    for (int32_t k = 0; k < x.fn; k++) {
+      const int32_t sl = v.FI[x.flo + k];
+      const int32_t len = v.F_seq_len[sl];
+      if (len < 0 || sl == x.best) continue;
+      v.crl_off[w] = v.F_seq_off[sl]; v.crl_len[w] = len; w++;
+    }
+  }
 }
 
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {

@@ -18,8 +18,9 @@ struct Counts {
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
-  unsigned long long cons_bytes[3]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large)
-  unsigned long long prof[8]; // SNF_PROF=1: wave-cycles per phase of e45w_consensus
+  unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
+  unsigned long long n_cls[4];      // ALT work items per class: 0 verbatim copy, 1 SMALL, 2 LARGE, 3 thread-kernel fallback
+  unsigned long long prof[32]; // SNF_PROF=1: wave-ticks per phase; 0-15 e45w_consensus, 16-31 d1w_refine
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags
   int32_t _pad;
@@ -47,6 +48,17 @@ struct LeadRec {
   uint32_t orig;                   // input index
   uint8_t strand, mapq, source, hap, is_sa, first, rev, svtype;
   uint32_t _pad;
+};
+
+// one ALT work item, written by e3_conslist: everything a consensus / copy workgroup needs to start, in one record
+// (instead of the chain cons_call -> callx -> F_seq_len/F_seq_off -> FI -> ...; the stage is latency-bound)
+struct ConsDesc {
+  int64_t best_off;   // pool offset of the best read
+  int64_t alt_off;    // output offset in alt_pool
+  int64_t aln_off;    // rows of this call in v.aln (L bytes per other read)
+  int64_t read_off;   // first entry of this call in crl_off / crl_len / aln_kept
+  int32_t L, n_others;
+  int32_t call, cls;
 };
 
 struct CallX {  // per-call internals that are not part of snf_call_t
@@ -101,6 +113,7 @@ struct View {
 
   // ---- stage A: binning (sorted position p in [0,N))
   uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
+  int ablate;  // SNF_ABLATE (dev): bitmask of consensus phases to skip (timing experiments only, results invalid)
   int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
   uint32_t *headflag, *headscan;  // [N+1] bin heads in sorted order / exclusive scan (bin ids)
   uint32_t *eligflag, *eligscan;  // [N+1] per bin: seeds a cluster / exclusive scan (seed ids)
@@ -158,6 +171,10 @@ struct View {
   uint8_t* aln_kept;         // [n_cons_reads]
   int32_t *cr_call, *cr_read;  // [n_cons_reads] (consensus id, other index)
   uint8_t* alt_pool; int64_t alt_cap;
+  unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
+  ConsDesc* cdesc;           // [n_cons] by cons id
+  int32_t* cls_list[3];      // cons ids per class (0 copy, 1 SMALL, 2 LARGE), appended with atomics (order irrelevant)
+  int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };
 
 }  // namespace snf

@@ -272,5 +272,36 @@ __global__ void __launch_bounds__(SNF_WAVE) e1w_finalize(const View v, int64_t n
   }
 }
 
+// ------------------------------------------------------------------------------------------ d5w: coverage.mean()
+// numerator of coverage.mean() (exact integer sum of the clipped read lengths per task): coalesced loads and one
+// atomic per block.  Reads are grouped by task, so a 4096-read chunk almost always belongs to one task; the few
+// chunks that straddle a task boundary fall back to per-read atomics.
+__global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused) {
+  __shared__ unsigned long long part[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t CH = 4096;
+  for (int64_t base = (int64_t)blockIdx.x * CH; base < v.R; base += (int64_t)gridDim.x * CH) {
+    const int64_t hi = base + CH < v.R ? base + CH : v.R;
+    const int t0 = v.r_task[base], t1 = v.r_task[hi - 1];
+    for (int t = t0; t <= t1; t++) {  // one pass per task present in the chunk (one, rarely two)
+      const int64_t L = v.t_contig_len[t];
+      unsigned long long acc = 0;
+      for (int64_t r = base + tid; r < hi; r += 256) {
+        if (t0 != t1 && v.r_task[r] != t) continue;
+        int64_t s = v.r_start[r], e = v.r_end[r];
+        if (s < 0) s = 0; if (s > L) s = L;
+        if (e < 0) e = 0; if (e > L) e = L;
+        if (e > s) acc += (unsigned long long)(e - s);
+      }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+      if (lane == 0) part[wid] = acc;
+      __syncthreads();
+      if (tid == 0) { const unsigned long long tot = part[0] + part[1] + part[2] + part[3]; if (tot) atomicAdd(&v.t_cov_sum[t], tot); }
+      __syncthreads();
+    }
+  }
+}
+
 }  // namespace snf
 #endif  // !SNF_EMU

@@ -29,7 +29,6 @@ template <int SLOTS, int MAXPOS, int MAXOTHERS>
 struct ConsLdsT {
   unsigned long long key[SLOTS];
   uint32_t pc[SLOTS];              // (position << 16) | occurrence count
-  int32_t others[MAXOTHERS];
   uint8_t kept[MAXOTHERS];
   struct Wave {
     uint16_t ai[MAXPOS];           // candidates, then accepted anchors: position in best
@@ -65,7 +64,11 @@ SNF_D int wave_max_incl(int x, int lane) {
   return x;
 }
 
-#define SNF_PH(k) do { if (v.prof && lane == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&v.cnt->prof[k], t_ - tph); tph = t_; } } while (0)
+SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
+  return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)x));
+}
+// SNF_PROF: per-wave tick accumulators in registers, flushed once at the end of the kernel
+#define SNF_PH(k) do { if (v.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tph; tph = t_; } } while (0)
 
 // CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
 template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW>
@@ -74,41 +77,27 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
   __shared__ Lds lds;
   constexpr int ROUNDS = MAXPOS / 64;
   unsigned long long tph = __builtin_readcyclecounter();
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  unsigned long long pacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPRs
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
-  const int64_t n_cons = v.cnt->n_cons;
+  const int64_t n_items = (int64_t)v.cnt->n_cls[CLS];
+  const int32_t* list = v.cls_list[CLS];
   unsigned long long bytes_acc = 0;  // algorithmic bytes this block processed, one atomic at the end
-  for (int64_t cid = blockIdx.x; cid < n_cons; cid += gridDim.x) {
-    const int32_t ci = v.cons_call[cid];
-    const CallX x = v.callx[ci];
-    const int64_t L = v.F_seq_len[x.best];
-    const uint8_t* B = v.pool + v.F_seq_off[x.best];
-    uint8_t* alt = v.alt_pool + x.alt_off;
-    if (!x.do_cons) {  // fewer than consensus_min_reads others: ALT = best read verbatim (postprocessing.py:65-66)
-      if (CLS == 1) { for (int64_t q = tid; q < L; q += 256) alt[q] = B[q]; bytes_acc += 2 * (unsigned long long)L; }
-      continue;
-    }
-    if (cons_class(v, L, x.n_others) != CLS) continue;  // other instance, or the thread path (e4/e5/e6)
-    bytes_acc += (unsigned long long)((int64_t)x.n_others + 2) * (unsigned long long)L;
+  for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const ConsDesc d = v.cdesc[list[it]];   // one record: no pointer chasing before the first useful load
+    const int64_t L = d.L;
+    const int32_t n_others = d.n_others;
+    const uint8_t* B = v.pool + d.best_off;
+    uint8_t* alt = v.alt_pool + d.alt_off;
+    bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
     SNF_PH(7);
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
-    if (wid == 0) {  // cluster-order list of the other seq-bearing leads (wave 0, ordered ballot compaction)
-      int k2 = 0;
-      for (int32_t k0 = 0; k0 < x.fn; k0 += 64) {
-        const int32_t k = k0 + lane;
-        int32_t s = -1; bool ok = false;
-        if (k < x.fn) { s = v.FI[x.flo + k]; ok = v.F_seq_len[s] >= 0 && s != x.best; }
-        const unsigned long long mk = __ballot(ok);
-        if (ok) lds.others[k2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = s;
-        k2 += __builtin_popcountll(mk);
-      }
-    }
     __syncthreads();
     const int64_t npos = cons_npos(L, klen, skip);
-    for (int64_t p = tid; p < npos; p += 256) {
+    for (int64_t p = tid; p < npos && !(v.ablate & 16); p += 256) {
       const int64_t i = p * skip;
       const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
       int64_t sl = kmer_slot(kk, SLOTS);
@@ -122,12 +111,11 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     __syncthreads();
     SNF_PH(0);
     typename Lds::Wave& W = lds.w[wid];
-    const int64_t r0 = v.cons_read_off[cid];
-    uint8_t* rows = v.aln + v.cons_aln_off[cid];
-    for (int32_t r = wid; r < x.n_others; r += 4) {
-      const int32_t slot = lds.others[r];
-      const uint8_t* S = v.pool + v.F_seq_off[slot];
-      const int64_t SL = v.F_seq_len[slot];
+    const int64_t r0 = d.read_off;
+    uint8_t* rows = v.aln + d.aln_off;
+    for (int32_t r = wid; r < n_others && !(v.ablate & 64); r += 4) {
+      const uint8_t* S = v.pool + rfl64(v.crl_off[r0 + r]);
+      const int64_t SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
       uint8_t* row = rows + (int64_t)r * L;
       // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
       int64_t jlim = SL - klen;                                     // j < SL - klen
@@ -137,30 +125,41 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
         const int64_t p = (int64_t)rd * 64 + lane;
-        kw[rd] = p < P ? load_u64(S + p * skip) : 0ull;
+        kw[rd] = (p < P && !(v.ablate & 8)) ? load_u64(S + p * skip) : 0ull;
       }
-      int ncand = 0;
+      if (v.prof) { unsigned long long x_ = 0;
 #pragma unroll
-      for (int rd = 0; rd < ROUNDS; rd++) {
-        const int64_t p = (int64_t)rd * 64 + lane;
-        int ci_ = -1; const int64_t j = p * skip;
-        if (p < P) {
-          const unsigned long long kk = kmer_key_le(kw[rd], klen);
-          int64_t sl = kmer_slot(kk, SLOTS);
-          for (;;) {
-            const unsigned long long kq = lds.key[sl];
-            if (kq == SNF_KEY_EMPTY) break;
-            if (kq == kk) {
-              const uint32_t pc = lds.pc[sl];
-              if ((pc & 0xffffu) == 1u) { const int i = (int)(pc >> 16); if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; }
-              break;
-            }
-            sl = (sl + 1) & (SLOTS - 1);
-          }
+        for (int rd = 0; rd < ROUNDS; rd++) x_ ^= kw[rd];
+        if (x_ == 0x0123456789abcdefull) W.ai[0] = 1;  // forces the loads to have arrived (profiling only)
+        SNF_PH(8); }
+      int ncand = 0;
+      constexpr int G = ROUNDS < 4 ? ROUNDS : 4;  // rounds probed together: their LDS reads are in flight at once
+#pragma unroll
+      for (int g = 0; g < ROUNDS; g += G) {
+        if ((int64_t)g * 64 >= P) break;
+        unsigned long long kk[G], kq[G]; int sl[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+          const int64_t p = (int64_t)(g + u) * 64 + lane;
+          kk[u] = kmer_key_le(kw[g + u], klen);
+          sl[u] = (int)kmer_slot(kk[u], SLOTS);
+          kq[u] = p < P ? lds.key[sl[u]] : SNF_KEY_EMPTY;
         }
-        const unsigned long long mk = __ballot(ci_ >= 0);
-        if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
-        ncand += __builtin_popcountll(mk);
+#pragma unroll
+        for (int u = 0; u < G; u++)   // linear probing past the first slot is rare (load factor <= 0.5)
+          while (kq[u] != SNF_KEY_EMPTY && kq[u] != kk[u]) { sl[u] = (sl[u] + 1) & (SLOTS - 1); kq[u] = lds.key[sl[u]]; }
+        uint32_t pcv[G];
+#pragma unroll
+        for (int u = 0; u < G; u++) pcv[u] = kq[u] == kk[u] ? lds.pc[sl[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+          const int64_t j = ((int64_t)(g + u) * 64 + lane) * skip;
+          int ci_ = -1;
+          if ((pcv[u] & 0xffffu) == 1u) { const int i = (int)(pcv[u] >> 16); if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; }
+          const unsigned long long mk = __ballot(ci_ >= 0);
+          if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
+          ncand += __builtin_popcountll(mk);
+        }
       }
       __builtin_amdgcn_wave_barrier();
       SNF_PH(1);
@@ -195,13 +194,18 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
           const int64_t fwd_i = i - li; int64_t fwd_j = j - lj;
           if (col + fwd_j > L) fwd_j = L - col;
           uint8_t flag = 0; int cm = 0;
-          if (fwd_i == fwd_j && fwd_j > 0) {
+          if (fwd_i == fwd_j && fwd_j > 0 && !(v.ablate & 4)) {
             const int nfull = j - lj;
             span += nfull;
-            const int m = count_eq(S + lj + 1, B + li + 1, nfull);
+            // first words of both comparisons issued together (one global round trip instead of two); consecutive
+            // anchors are usually one sampling step apart, so the tails are rare
+            const uint64_t a1 = load_u64(S + lj + 1), b1 = load_u64(B + li + 1), a2 = load_u64(S + lj), b2 = load_u64(B + col);
+            int m = eq_bytes(a1, b1, nfull < 8 ? nfull : 8);
+            if (nfull > 8) m += count_eq(S + lj + 9, B + li + 9, nfull - 8);
             if ((double)m / (double)nfull >= 0.5) {
               flag = 1;
-              cm = count_eq(S + lj, B + col, (int)fwd_j);
+              cm = eq_bytes(a2, b2, fwd_j < 8 ? (int)fwd_j : 8);
+              if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, (int)fwd_j - 8);
             }
           }
           W.seg_col[t] = (uint16_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
@@ -227,7 +231,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       // ---- 5. write the row, column-parallel
       int64_t c_last = c_first;
       if (na) { c_last = c_first + (W.aj[na - 1] - j0); if (c_last > L) c_last = L; }
-      for (int64_t q0 = 0; q0 < L; q0 += 64) {
+      for (int64_t q0 = 0; q0 < L && !(v.ablate & 2); q0 += 64) {
         const int64_t q = q0 + lane;
         if (q < L) {
           uint8_t out = '-';
@@ -249,11 +253,12 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     __syncthreads();
     SNF_PH(7);
     int nkept = 0;
-    for (int32_t r = 0; r < x.n_others; r++) nkept += lds.kept[r];
+    for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
     const double maxal = (double)(1 + nkept);
     for (int64_t q = tid; q < L; q += 256) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
+      if (v.ablate & 1) { if (!(v.ablate & 32)) alt[q] = out; continue; }
       {  // fast path: every character of the column is one of A C G T -> four packed 16-bit counters, one pass
         const uint32_t ACTG = 0x47544341u;  // code (c >> 1) & 3: A 0, C 1, T 2, G 3
         int cd = (bq >> 1) & 3;
@@ -261,7 +266,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
         unsigned long long cnt4 = 1ull << (16 * cd);
         int nv = 0;
 #pragma unroll 8
-        for (int32_t r = 0; r < x.n_others; r++) {  // no early exit: keeps the row loads independent
+        for (int32_t r = 0; r < n_others; r++) {  // no early exit: keeps the row loads independent
           if (!lds.kept[r]) continue;
           const uint8_t c = rows[(int64_t)r * L + q];
           if (c == '-') continue;
@@ -289,11 +294,11 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       }
       {  // generic path: some character of this column is not A/C/G/T (rare)
         int nvotes = 0;
-        for (int32_t r = 0; r < x.n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
+        for (int32_t r = 0; r < n_others; r++) if (lds.kept[r] && rows[(int64_t)r * L + q] != '-') nvotes++;
         if (!(nvotes < 2 || (double)nvotes / maxal < 0.25)) {
           // util.most_common([best]+votes): (count, char) descending; replace iff top beats the runner-up by >= 3
           int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
-          for (int32_t r = -1; r < x.n_others; r++) {
+          for (int32_t r = -1; r < n_others; r++) {
             uint8_t c;
             if (r < 0) c = bq;
             else { if (!lds.kept[r]) continue; c = rows[(int64_t)r * L + q]; if (c == '-') continue; }
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
             for (int32_t r2 = 0; r2 < r && !seen; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == c) seen = true;
             if (seen) continue;
             int cntc = (c == bq) ? 1 : 0;
-            for (int32_t r2 = 0; r2 < x.n_others; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == c) cntc++;
+            for (int32_t r2 = 0; r2 < n_others; r2++) if (lds.kept[r2] && rows[(int64_t)r2 * L + q] == c) cntc++;
             nd++;
             if (cntc > c0 || (cntc == c0 && (int)c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
             else if (cntc > c1 || (cntc == c1 && (int)c > k1)) { c1 = cntc; k1 = c; }
@@ -313,7 +318,23 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     }
     SNF_PH(6);
   }
-  if (tid == 0 && bytes_acc) atomicAdd(&v.cnt->cons_bytes[CLS], bytes_acc);
+  if (tid == 0 && bytes_acc) atomicAdd(&v.stripes[(CLS * 64 + (blockIdx.x & 63)) * 16], bytes_acc);  // striped: summed by z1_results
+  if (v.prof && lane == 0) for (int k = 0; k < 9; k++) atomicAdd(&v.cnt->prof[k], pacc[k]);
+}
+
+// verbatim ALT of calls with fewer than consensus_min_reads other reads (postprocessing.py:65-66): one wave per call
+__global__ void __launch_bounds__(64) e4c_copy(const View v, int64_t n_unused) {
+  const int64_t n_items = (int64_t)v.cnt->n_cls[0];
+  const int32_t* list = v.cls_list[0];
+  unsigned long long bytes_acc = 0;
+  for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const ConsDesc d = v.cdesc[list[it]];
+    const uint8_t* B = v.pool + d.best_off;
+    uint8_t* alt = v.alt_pool + d.alt_off;
+    for (int64_t q = threadIdx.x; q < d.L; q += 64) alt[q] = B[q];
+    bytes_acc += 2ull * (unsigned long long)d.L;
+  }
+  if (threadIdx.x == 0 && bytes_acc) atomicAdd(&v.stripes[(3 * 64 + (blockIdx.x & 63)) * 16], bytes_acc);
 }
 
 }  // namespace snf

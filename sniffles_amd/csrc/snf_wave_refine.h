@@ -65,9 +65,14 @@ struct WaveLds {
 #define SNF_GATHER(x) __shfl((x), src_, SNF_WAVE)
 
 // one block = one wave = one merged cluster per loop iteration (grid-stride over clusters)
+// SNF_PROF: per-wave tick accumulators in registers, flushed once at the end (per-phase atomics on one cache line
+// from every wave would serialise in L2 and distort the very thing they measure)
+#define SNF_PH1(k) do { if (v.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tph; tph = t_; } } while (0)
 __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_unused) {
   __shared__ WaveLds lds;
   const int lane = threadIdx.x;
+  unsigned long long tph = __builtin_readcyclecounter();
+  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
   const snf_config_t& cfg = v.cfg;
   const int64_t n_clusters = v.cnt->n_clusters;
   for (int64_t c = blockIdx.x; c < n_clusters; c += gridDim.x) {
@@ -77,6 +82,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     if (n <= 0 || n > SNF_WAVE) continue;  // big clusters: thread path (d1_refine with the n > 64 guard)
     const int svtype = grp_svtype(v.seed_grp[h]);
     const bool act = lane < n;
+    if (v.prof) { if (svtype == 99) lds.perm[0] = 0; SNF_PH1(0); }
     // ---- load one lead per lane
     uint32_t o = 0;
     int32_t ref_start = 0, ref_end = 0, qry_start = 0, qry_end = 0, svlen = 0, seq_len = -1, mate_pos = 0, mate_contig = 0;
@@ -87,6 +93,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       ref_end = r.ref_end; qry_start = r.qry_start; qry_end = r.qry_end; qname = r.qname; strand = r.strand;
       mate_pos = r.mate_pos; mate_contig = r.mate_contig; is_first = r.first;
     }
+    if (v.prof) { if (ref_start == -12345 && svlen == 77) lds.perm[0] = 0; SNF_PH1(1); }
     int m = n;                 // number of leads after fusion
     int32_t f_orig = (int32_t)o, f_svlen = svlen, f_seq_len = seq_len, f_lp = lane; int64_t f_seq_off = seq_off;
 
@@ -109,6 +116,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int64_t s_seq_off = SNF_GATHER(seq_off);
       const int s_strand = SNF_GATHER(strand);
       const uint32_t s_o = SNF_GATHER(o); const int s_lp = SNF_GATHER(lane);
+      SNF_PH1(2);
       // neighbour r-1
       const int p_fa = __shfl_up(s_fa, 1, SNF_WAVE);
       const int32_t p_rs = __shfl_up(s_rs, 1, SNF_WAVE), p_re = __shfl_up(s_re, 1, SNF_WAVE);
@@ -138,9 +146,15 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const bool seq_ok = (e_has - x_has) == nparts;
       // fused sequence: concatenation in the pool's fused region (curr_lead.seq += to_merge.seq)
       int64_t new_off = 0; bool need_copy = start && seq_ok && nparts > 1;
-      if (need_copy) {
-        new_off = v.pool_len + (int64_t)atomicAdd(&v.cnt->pool_extra_used, (unsigned long long)tot_seq);
-        if (new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
+      if (__ballot(need_copy)) {  // one atomic per wave (same-address atomics serialise in L2): lanes take consecutive slices
+        const int64_t mine = need_copy ? tot_seq : 0;
+        const int64_t incl = wave_incl_scan64(mine, lane);
+        const int64_t wave_total = __shfl(incl, 63, SNF_WAVE);
+        int64_t base = 0;
+        if (lane == 0) base = (int64_t)atomicAdd(&v.cnt->pool_extra_used, (unsigned long long)wave_total);
+        base = __shfl(base, 0, SNF_WAVE);
+        new_off = v.pool_len + base + (incl - mine);
+        if (need_copy && new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
       }
       unsigned long long cmask = __ballot(need_copy);
       while (cmask) {  // cooperative byte copy, one fused lead at a time
@@ -169,11 +183,13 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       f_seq_off = __shfl(t_seq_off, src2, SNF_WAVE);
     }
     const bool fact = lane < m;
+    SNF_PH1(3);
     if (fact) {
       v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen; v.F_lpos[lo + lane] = lo + f_lp;
       v.F_seq_len[lo + lane] = f_seq_len; v.F_seq_off[lo + lane] = f_seq_off;
     }
 
+    SNF_PH1(4);
     if (svtype == SNF_BND) {
       // ---- resplit_bnd: group by (mate_contig, is_first) in first-appearance order, chain 1-kb bins
       if (m <= 1 || cfg.dev_no_resplit) {
@@ -263,8 +279,10 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       if (fact) v.FI[lo + lds.seg_out[sidx] + (lane - lds.seg_start[sidx])] = lo + s_k;
       if (lane < lds.n_rc) rc_emit(v, lo + lds.rc_start[lane], lds.rc_len[lane], (int32_t)c, true);
       __syncthreads();
+      SNF_PH1(5);
     }
   }
+  if (v.prof && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&v.cnt->prof[16 + k], pacc[k]);
 }
 
 }  // namespace snf
