@@ -123,6 +123,7 @@ struct snf_batch_impl {
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
+  int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
@@ -479,7 +480,7 @@ void do_upload(snf_batch_impl* b) {
   v.seqnull = dalloc<uint8_t>(b, N); v.bin_lo = dalloc<int32_t>(b, N1); v.bin_key = dalloc<uint64_t>(b, N);
   v.bin_hap = dalloc<uint16_t>(b, 3 * (size_t)N); v.bin_elig = dalloc<uint8_t>(b, N);
   v.grp_first_bin = dalloc<int32_t>(b, 8 * (size_t)T + 8);
-  v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N); v.Lrec = dalloc<LeadRec>(b, N1);
+  v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N); v.Lrec = dalloc<LeadRec>(b, N1); v.chdr = dalloc<ClusterHdr>(b, N1);
   int32_t** i32s[] = {&v.seed_bin, &v.seed_lo, &v.seed_hi, &v.seedL_lo, &v.seedL_hi, &v.seed_start, &v.seed_grp, &v.c_last, &v.c_end,
                       &v.nxt, &v.prv, &v.run_first, &v.run_last_head, &v.cl_head, &v.w0, &v.w1, &v.w2, &v.w3, &v.w4, &v.w5, &v.w6,
                       &v.F_orig, &v.F_svlen, &v.F_seq_len, &v.FI, &v.F_lpos, &v.rc_n_s, &v.rc_cl_s, &v.rc_lo, &v.rc_n, &v.rc_cluster};
@@ -590,7 +591,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
-      hipLaunchKernelGGL(d1w_refine, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
@@ -603,7 +604,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
-      hipLaunchKernelGGL(d2w_call, dim3(8192), dim3(64), 0, b->cur, v, (int64_t)0);
+      hipLaunchKernelGGL(d2w_call, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
@@ -685,7 +686,7 @@ void run_finalize(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
-      int64_t grid = nc < 8192 ? nc : 8192;
+      int64_t grid = nc < b->slots_e1w ? nc : b->slots_e1w;
       hipLaunchKernelGGL(e1w_finalize, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
@@ -960,6 +961,17 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
     b->cur = b->stream;
+    {  // grid-stride kernels with uniform work per block: launch exactly one resident set (a partial second round of
+       // workgroups would double the kernel time)
+      hipDeviceProp_t prop; SNF_HIP(hipGetDeviceProperties(&prop, b->device));
+      const int cus = prop.multiProcessorCount;
+      int nb = 0;
+      const int mult = getenv("SNF_GRID_MULT") ? atoi(getenv("SNF_GRID_MULT")) : 1;
+      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d1w_refine, 64, 0)); if (nb > 0) b->slots_d1w = nb * cus * mult;
+      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2w_call, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
+      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, e1w_finalize, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
+      if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
+    }
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);

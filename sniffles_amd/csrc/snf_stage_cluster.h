@@ -310,7 +310,14 @@ SNF_HD void c3_serial_body(int64_t g, const View& v) {
 // C4: merged cluster table (clscan = exclusive scan of clflag)
 SNF_HD void c4_clusters_body(int64_t s, const View& v) {
   if (s == 0) v.cnt->n_clusters = v.clscan[v.N];
-  if (s < v.cnt->n_seeds && v.clflag[s]) v.cl_head[v.clscan[s]] = (int32_t)s;
+  if (s < v.cnt->n_seeds && v.clflag[s]) {
+    const uint32_t c = v.clscan[s];
+    v.cl_head[c] = (int32_t)s;
+    ClusterHdr hd;
+    hd.h = (int32_t)s; hd.lo = v.seed_lo[s]; hd.n = v.seed_hi[v.c_last[s]] - hd.lo; hd.grp = v.seed_grp[s]; hd.repeat = v.c_repeat[s];
+    hd._pad[0] = hd._pad[1] = hd._pad[2] = 0;
+    v.chdr[c] = hd;
+  }
 }
 
 }  // namespace snf

@@ -61,6 +61,9 @@ struct ConsDesc {
   int32_t call, cls;
 };
 
+// merged cluster header, written by c4_clusters: what the refine kernels need to start on cluster c in one record
+struct ClusterHdr { int32_t h, lo, n, grp; int32_t repeat, _pad[3]; };
+
 struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t rc;       // refined cluster id
   int32_t cluster;  // merged cluster id
@@ -132,6 +135,7 @@ struct View {
   uint32_t* L;               // [N] seed-cluster leads, (task, svtype, bin, arrival) order -> input index
   uint32_t* LL;              // [N] leads_long, same order
   LeadRec* Lrec;             // [N] packed records of L[] (same index)
+  ClusterHdr* chdr;          // [n_clusters]
   // result block in pinned host memory, written by z1_results at the end of each stage (no D2H copies to wait for)
   Counts* res_cnt; int32_t* res_status; int64_t* res_off; double* res_cov;
   int64_t* res_rn_total;     // pinned: total supporting-read-name count, written by d3_rnames (side stream)

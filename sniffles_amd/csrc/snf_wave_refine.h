@@ -75,12 +75,21 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
   unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
   const snf_config_t& cfg = v.cfg;
   const int64_t n_clusters = v.cnt->n_clusters;
-  for (int64_t c = blockIdx.x; c < n_clusters; c += gridDim.x) {
-    const int32_t h = v.cl_head[c];
-    const int32_t lo = v.seed_lo[h], hi = v.seed_hi[v.c_last[h]];
-    const int32_t n = hi - lo;
+  // software pipeline over this wave's clusters: the header of cluster k+2 and the lead records of cluster k+1 are
+  // in flight while cluster k is processed (the kernel is bound by dependent global-load latency, not bandwidth)
+  const int64_t stride = gridDim.x;
+  ClusterHdr hd_cur = blockIdx.x < n_clusters ? v.chdr[blockIdx.x] : ClusterHdr{};
+  ClusterHdr hd_nxt = blockIdx.x + stride < n_clusters ? v.chdr[blockIdx.x + stride] : ClusterHdr{};
+  LeadRec rec_cur{};
+  if (lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
+  for (int64_t c = blockIdx.x; c < n_clusters; c += stride) {
+    const ClusterHdr hd = hd_cur; const LeadRec rec = rec_cur;
+    hd_cur = hd_nxt;
+    if (c + stride < n_clusters && lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
+    if (c + 2 * stride < n_clusters) hd_nxt = v.chdr[c + 2 * stride];
+    const int32_t lo = hd.lo, n = hd.n;
     if (n <= 0 || n > SNF_WAVE) continue;  // big clusters: thread path (d1_refine with the n > 64 guard)
-    const int svtype = grp_svtype(v.seed_grp[h]);
+    const int svtype = grp_svtype(hd.grp);
     const bool act = lane < n;
     if (v.prof) { if (svtype == 99) lds.perm[0] = 0; SNF_PH1(0); }
     // ---- load one lead per lane
@@ -88,7 +97,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     int32_t ref_start = 0, ref_end = 0, qry_start = 0, qry_end = 0, svlen = 0, seq_len = -1, mate_pos = 0, mate_contig = 0;
     uint32_t qname = 0; int64_t seq_off = 0; int strand = 0, is_first = 0;
     if (act) {
-      const LeadRec r = v.Lrec[lo + lane];
+      const LeadRec& r = rec;
       o = r.orig; ref_start = r.ref_start; svlen = r.svlen; seq_len = r.seq_len; seq_off = r.seq_off;
       ref_end = r.ref_end; qry_start = r.qry_start; qry_end = r.qry_end; qname = r.qname; strand = r.strand;
       mate_pos = r.mate_pos; mate_contig = r.mate_contig; is_first = r.first;
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
 
     if (svtype == SNF_INS || svtype == SNF_DEL) {
       // ---- merge_inner
-      const int thr = v.c_repeat[h] ? -1 : cfg.cluster_merge_pos;
+      const int thr = hd.repeat ? -1 : cfg.cluster_merge_pos;
       int fa = -1;  // first appearance of this read's qname in cluster order
       for (int i = 0; i < n; i++) {
         uint32_t qi = (uint32_t)wave_bcast_i32((int32_t)qname, i);
