@@ -45,6 +45,10 @@ def main():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every contig (debug only; invalid as a result)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight per GPU (host threads, each with its own batch handle and streams): the "
+                         "device->host copies, host waits and launch-bound phases of one pass overlap the kernels of "
+                         "the other.  1 = strictly one pass at a time")
     args = ap.parse_args()
 
     import numpy as np
@@ -79,8 +83,10 @@ def main():
     seq_bytes = sum(int(t.seq_pool.nbytes) for t in tasks)
     t_gen = time.time() - t0
 
+    import threading
+    W = max(1, args.inflight)
     t0 = time.time()
-    batch = lib.Batch(cfg, tasks, device=local_rank)
+    batches = [lib.Batch(cfg, tasks, device=local_rank) for _ in range(W)]  # same input, W independent handles
     t_upload = time.time() - t0
 
     cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
@@ -88,29 +94,35 @@ def main():
         dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # all_gather_into_tensor needs equal sizes on every rank
     cap_calls = int(cap_t.item())
     rec_bytes = abi.CALL_DTYPE.itemsize
-    send = torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
-    count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
     if world > 1:
+        sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
         gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
         counts = torch.zeros(world, dtype=torch.int64, device="cuda")
+    coll_lock = threading.Lock()  # one collective at a time per rank; every pass issues the same-sized gather
 
     phase_s = [0.0, 0.0, 0.0, 0.0]
 
-    def step():
+    def step(w):
+        """One full pass of the hot path over batch w: candidates, finalize, D2H of the results, gather."""
+        batch = batches[w]
         t_a = time.perf_counter()
         batch.call_candidates()
         t_b = time.perf_counter()
         batch.finalize()
         t_c = time.perf_counter()
-        n = batch.fetch_raw(1)  # D2H of records + ALT pool + read names (blocks)
+        n = batch.fetch_raw(1)  # call records + ALT pool + read names on the host (blocks)
         t_d = time.perf_counter()
-        phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
+        if w == 0:
+            phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
         if world > 1:
-            nexp = batch.export_calls_device(send.data_ptr(), cap_calls)
-            batch.sync()
-            count_t.fill_(nexp)
-            dist.all_gather_into_tensor(counts, count_t)
-            dist.all_gather_into_tensor(gathered, send)
+            with coll_lock:
+                torch.cuda.set_device(local_rank)
+                nexp = batch.export_calls_device(sends[w].data_ptr(), cap_calls)
+                batch.sync()
+                count_t.fill_(nexp)
+                dist.all_gather_into_tensor(counts, count_t)
+                dist.all_gather_into_tensor(gathered, sends[w])
         return n
 
     def barrier():
@@ -118,16 +130,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_calls = 0
-    for _ in range(args.warmup):
-        n_calls = step()
+    n_calls_box = [0]
+
+    def run_passes(total):
+        """Exactly `total` passes, split evenly over the W host threads (thread w works on its own batch handle)."""
+        if W == 1:
+            for _ in range(total):
+                n_calls_box[0] = step(0)
+            return
+        errs = []
+
+        def worker(w, k):
+            try:
+                torch.cuda.set_device(local_rank)
+                for _ in range(k):
+                    n_calls_box[0] = step(w)
+            except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
+                errs.append(e)
+
+        ths = [threading.Thread(target=worker, args=(w, total // W + (1 if w < total % W else 0))) for w in range(W)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_passes(-(-args.warmup // W) * W)  # >= warmup passes, the same number on every handle
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_calls = step()
+    run_passes(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    timings = batch.timings()  # per-kernel HIP-event times of the LAST step, on the batch stream
+    n_calls = n_calls_box[0]
+    batch = batches[0]
+    timings = batch.timings()  # per-kernel HIP-event times of handle 0's LAST pass in the timed region, on its streams
 
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device="cuda")
@@ -169,6 +206,7 @@ def main():
                                replicas=world, tasks=24 * world, coverage=args.coverage, scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL all_gather of call records",
+                               batches_in_flight_per_gpu=W,
                                gen_s=round(t_gen, 2), upload_s=round(t_upload, 2),
                                host_ms_per_step=dict(enqueue_call_candidates=round(phase_s[0] / phase_s[3] * 1e3, 3),
                                                      finalize_incl_2_syncs=round(phase_s[1] / phase_s[3] * 1e3, 3),
@@ -177,7 +215,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args)
         print(json.dumps(out))
-    batch.close()
+    for bb in batches:
+        bb.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -500,7 +500,7 @@ void do_upload(snf_batch_impl* b) {
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1);
-  for (int k = 0; k < 3; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
+  for (int k = 0; k < 6; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
   v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
@@ -728,7 +728,7 @@ void run_finalize(snf_batch_impl* b) {
     if (v.wave_path) {
       // algorithmic bytes are accumulated by the kernels themselves (cnt->cons_bytes) and attached to
       // these timing entries in collect_timings.  One launch per class, sized by the class counters of e3_conslist
-      const int64_t n_copy = (int64_t)b->h_cnt->n_cls[0], n_small = (int64_t)b->h_cnt->n_cls[1], n_large = (int64_t)b->h_cnt->n_cls[2];
+      const int64_t n_copy = (int64_t)b->h_cnt->n_cls[0], n_small = (int64_t)b->h_cnt->n_cls[1], n_large = (int64_t)(b->h_cnt->n_cls[2] + b->h_cnt->n_cls[3] + b->h_cnt->n_cls[4] + b->h_cnt->n_cls[5]);
       const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
       if (serial) SNF_HIP(hipDeviceSynchronize());
       SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
@@ -807,9 +807,9 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
           fprintf(stderr, "[SNF_PROF] %-12s %6.2f %%  %12llu ticks\n", ph[base + k], 100.0 * (double)c.prof[base + k] / (double)tot, c.prof[base + k]);
     }
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
-                    "fallback %lld alt bytes %lld | ALT classes copy %llu small %llu large %llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+                    "fallback %lld alt bytes %lld | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
-            (long long)c.alt_total, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3]);
+            (long long)c.alt_total, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6]);
   }
   int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
   int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;

@@ -387,7 +387,7 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
   if (i == 0) {
     v.fN[nc] = 0; v.fL[nc] = 0; v.sz_tab[nc] = 0; v.sz_aln[nc] = 0; v.sz_rd[nc] = 0;
-    for (int k = 0; k < 4; k++) v.cnt->n_cls[k] = 0;   // filled by e3_conslist (finalize may run more than once)
+    for (int k = 0; k < 8; k++) v.cnt->n_cls[k] = 0;   // filled by e3_conslist (finalize may run more than once)
     v.cnt->n_cons_fallback = 0;
   }
   if (i >= nc) return;
@@ -427,12 +427,12 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
 // next free slot of the class list (order within a list is irrelevant).  On the GPU the lanes of a wave that append to
 // the same class share one atomic: same-address atomics serialise in L2 at ~25 ns each, tens of thousands of them
 // would dominate the kernel
-SNF_HD int64_t class_list_slot(const View& v, int cls) {
+SNF_HD int64_t class_list_slot(const View& v, int lid) {
 #if defined(__HIP_DEVICE_COMPILE__)
   int64_t slot = 0;
-  for (int c = 0; c < 4; c++) {
-    const unsigned long long m = __ballot(cls == c);
-    if (cls == c) {
+  for (int c = 0; c < 7; c++) {
+    const unsigned long long m = __ballot(lid == c);
+    if (lid == c) {
       const int lane = (int)__lane_id();
       const int leader = __builtin_ctzll(m);
       unsigned long long base = 0;
@@ -441,10 +441,9 @@ SNF_HD int64_t class_list_slot(const View& v, int cls) {
       slot = (int64_t)base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
     }
   }
-  return cls == 3 ? (int64_t)v.N : slot;  // cls 3: a scratch slot past every real entry
+  return slot;
 #else
-  const int64_t slot = (int64_t)atomic_add_u64(&v.cnt->n_cls[cls], 1ull);
-  return cls == 3 ? (int64_t)v.N : slot;
+  return (int64_t)atomic_add_u64(&v.cnt->n_cls[lid], 1ull);
 #endif
 }
 
@@ -472,7 +471,15 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   d.read_off = v.sc_rd[i]; d.n_others = x.n_others; d.call = (int32_t)i;
   d.cls = x.do_cons ? (cons_class(v, d.L, x.n_others) ? cons_class(v, d.L, x.n_others) : 3) : 0;
   v.cdesc[cid] = d;
-  v.cls_list[d.cls < 3 ? d.cls : 0][class_list_slot(v, d.cls)] = (int32_t)cid;  // cls 3 (thread kernels) is only counted
+  // work list: LARGE calls are bucketed by work (others x length) and the kernel walks the heaviest bucket first, so
+  // the few very long items do not end up as the tail of the launch
+  int lid = d.cls;
+  if (d.cls == 2) {
+    const int64_t work = (int64_t)d.n_others * d.L;
+    lid = work >= 32768 ? 2 : work >= 16384 ? 3 : work >= 8192 ? 4 : 5;
+  } else if (d.cls == 3) lid = 6;
+  const int64_t slot = class_list_slot(v, lid);
+  if (lid < 6) v.cls_list[lid][slot] = (int32_t)cid;   // list 6 (thread kernels e4/e5/e6) is only counted
   if (d.cls == 1 || d.cls == 2) {  // the other sequence-bearing leads, cluster order (consensus.py:302)
     int64_t w = d.read_off;
     for (int32_t k = 0; k < x.fn; k++) {

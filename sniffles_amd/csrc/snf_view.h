@@ -19,7 +19,7 @@ struct Counts {
   int64_t n_dirty_groups;
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
-  unsigned long long n_cls[4];      // ALT work items per class: 0 verbatim copy, 1 SMALL, 2 LARGE, 3 thread-kernel fallback
+  unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback
   unsigned long long prof[32]; // SNF_PROF=1: wave-ticks per phase; 0-15 e45w_consensus, 16-31 d1w_refine
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags
@@ -177,7 +177,7 @@ struct View {
   uint8_t* alt_pool; int64_t alt_cap;
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
   ConsDesc* cdesc;           // [n_cons] by cons id
-  int32_t* cls_list[3];      // cons ids per class (0 copy, 1 SMALL, 2 LARGE), appended with atomics (order irrelevant)
+  int32_t* cls_list[6];      // cons ids per work list (see Counts::n_cls), appended with wave-aggregated atomics
   int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };
 

@@ -80,11 +80,18 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
   unsigned long long pacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPRs
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
-  const int64_t n_items = (int64_t)v.cnt->n_cls[CLS];
-  const int32_t* list = v.cls_list[CLS];
+  // SMALL walks list 1; LARGE walks lists 2..5 (heaviest first) as one index space
+  const int64_t n1 = (int64_t)v.cnt->n_cls[CLS == 1 ? 1 : 2], n2 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[3];
+  const int64_t n3 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[4], n4 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[5];
+  const int64_t n_items = n1 + n2 + n3 + n4;
   unsigned long long bytes_acc = 0;  // algorithmic bytes this block processed, one atomic at the end
   for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    const ConsDesc d = v.cdesc[list[it]];   // one record: no pointer chasing before the first useful load
+    int32_t cid;
+    if (CLS == 1 || it < n1) cid = v.cls_list[CLS == 1 ? 1 : 2][it];
+    else if (it < n1 + n2) cid = v.cls_list[3][it - n1];
+    else if (it < n1 + n2 + n3) cid = v.cls_list[4][it - n1 - n2];
+    else cid = v.cls_list[5][it - n1 - n2 - n3];
+    const ConsDesc d = v.cdesc[cid];   // one record: no pointer chasing before the first useful load
     const int64_t L = d.L;
     const int32_t n_others = d.n_others;
     const uint8_t* B = v.pool + d.best_off;
