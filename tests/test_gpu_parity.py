@@ -78,6 +78,32 @@ def test_hip_wide_sort_keys_exact(oracle_mod, monkeypatch):
     assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
 
 
+def test_batches_in_flight_on_host_threads(oracle_mod):
+    """bench.py keeps several batch handles in flight from host threads (own streams each): concurrent passes must
+    give exactly the results of passes run one after the other."""
+    import threading
+    cfg = SnifflesConfig()
+    sets = [[synth.gen_fuzz(900 + 10 * w + k, task_id=k) for k in range(4)] for w in range(3)]
+    exp = [records.records(oracle_mod.run(cfg, tis, True), tis, "final") for tis in sets]
+    got = [None] * 3
+    errs = []
+
+    def worker(w):
+        try:
+            with lib.Batch(cfg, sets[w]) as b:
+                for _ in range(5):
+                    b.call_candidates(); b.finalize(); r = b.fetch(1)
+                got[w] = records.records(r, sets[w], "final")
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(w,)) for w in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    assert got == exp
+
+
 def genome(scale, cov=30, seed=1, **kw):
     return synth.gen_genome(coverage=cov, seed=seed, scale=scale, **kw)
 
