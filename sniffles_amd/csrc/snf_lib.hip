@@ -53,7 +53,7 @@ SNF_KERNEL(z1_results, View)
 struct ReadPrep {
   const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task; const int32_t* r_start;
   uint64_t* rk_in; uint32_t* rv_in; const uint64_t* rk_out; const uint32_t* rv_out;
-  int32_t* re_sorted; uint32_t* fs[3]; uint32_t* fe[3]; int64_t R;
+  int32_t* re_sorted; int32_t* re_top; uint64_t *fs2, *fe2; int64_t R;  // fs2/fe2: (hp == 1) << 32 | (hp == 2) in start / end order
   const uint64_t* t_base;  // [T+1] prefix of (max read end + 1): key = t_base[task] + end orders by (task, end)
   int key32;               // the key space fits 32 bits: rk_in / rk_out hold uint32_t keys
 };
@@ -62,13 +62,16 @@ SNF_HD void r1_endkeys_body(int64_t r, const ReadPrep& p) {
   const uint64_t k = p.t_base[p.r_task[r]] + (uint64_t)(uint32_t)p.r_end[r];
   if (p.key32) ((uint32_t*)p.rk_in)[r] = (uint32_t)k; else p.rk_in[r] = k;
   p.rv_in[r] = p.r_hp[r];
-  for (int h = 0; h < 3; h++) { p.fs[h][r] = p.r_hp[r] == h; if (r == 0) p.fs[h][p.R] = 0; }
+  p.fs2[r] = p.r_hp[r] == 1 ? (1ull << 32) : (p.r_hp[r] == 2 ? 1ull : 0ull);
+  if (r == 0) p.fs2[p.R] = 0;
 }
 SNF_HD void r2_unpack_body(int64_t r, const ReadPrep& p) {
   // the sort keeps every task's reads in that task's slots, so r_task[r] is also the task of sorted position r
   const uint64_t k = p.key32 ? (uint64_t)((const uint32_t*)p.rk_out)[r] : p.rk_out[r];
   p.re_sorted[r] = (int32_t)(k - p.t_base[p.r_task[r]]);
-  for (int h = 0; h < 3; h++) { p.fe[h][r] = p.rv_out[r] == (uint32_t)h; if (r == 0) p.fe[h][p.R] = 0; }
+  if ((r & ((1 << SNF_TOP_SHIFT) - 1)) == 0) p.re_top[r >> SNF_TOP_SHIFT] = p.re_sorted[r];
+  p.fe2[r] = p.rv_out[r] == 1u ? (1ull << 32) : (p.rv_out[r] == 2u ? 1ull : 0ull);
+  if (r == 0) p.fe2[p.R] = 0;
 }
 }  // namespace snf
 SNF_KERNEL(r1_endkeys, ReadPrep)
@@ -453,13 +456,35 @@ void do_upload(snf_batch_impl* b) {
   v.in_svtype = upload_vec(b, b->h_svtype); v.in_strand = upload_vec(b, b->h_strand); v.in_mapq = upload_vec(b, b->h_mapq);
   v.in_source = upload_vec(b, b->h_source); v.in_hap = upload_vec(b, b->h_hap); v.in_is_sa = upload_vec(b, b->h_is_sa);
   v.in_first = upload_vec(b, b->h_first); v.in_rev = upload_vec(b, b->h_rev); v.lead_task = upload_vec(b, b->h_lead_task);
+  {  // the same columns interleaved per lead (a6_scatter gathers one 64-B record instead of 20 scattered words)
+    std::vector<LeadRec> recs((size_t)N);
+    for (int64_t i = 0; i < N; i++) {
+      LeadRec& r = recs[(size_t)i];
+      r.ref_start = b->h_ref_start[i]; r.ref_end = b->h_ref_end[i]; r.qry_start = b->h_qry_start[i]; r.qry_end = b->h_qry_end[i];
+      r.svlen = b->h_svlen[i];
+      const bool hs = b->h_seq_len[i] >= 0;
+      r.seq_len = hs ? b->h_seq_len[i] : -1; r.seq_off = hs ? b->h_seq_off[i] : 0;
+      r.qname = b->h_qname[i]; r.read_id = b->h_read_id[i]; r.ps = b->h_ps[i]; r.mate_pos = b->h_mate_pos[i];
+      r.mate_contig = b->h_mate_contig[i]; r.read_len = b->h_read_len[i]; r.orig = (uint32_t)i;
+      r.strand = b->h_strand[i]; r.mapq = b->h_mapq[i]; r.source = b->h_source[i]; r.hap = b->h_hap[i];
+      r.is_sa = b->h_is_sa[i]; r.first = b->h_first[i]; r.rev = b->h_rev[i]; r.svtype = b->h_svtype[i]; r._pad = 0;
+    }
+    v.in_rec = upload_vec(b, recs);
+    dsync(b);  // recs goes out of scope
+  }
   v.pool = dalloc<uint8_t>(b, (size_t)v.pool_cap);
   h2d(b, v.pool, b->h_pool.data(), b->h_pool.size());
   v.r_start = upload_vec(b, b->h_rstart); v.r_end = upload_vec(b, b->h_rend); v.r_hp = upload_vec(b, b->h_rhp);
   v.r_task = upload_vec(b, b->h_rtask);
   v.rk_in = dalloc<uint64_t>(b, R); v.rk_out = dalloc<uint64_t>(b, R); v.rv_in = dalloc<uint32_t>(b, R); v.rv_out = dalloc<uint32_t>(b, R);
   v.re_sorted = dalloc<int32_t>(b, R);
-  for (int h = 0; h < 3; h++) { v.pc_s[h] = dalloc<uint32_t>(b, R + 1); v.pc_e[h] = dalloc<uint32_t>(b, R + 1); }
+  v.pc_s2 = dalloc<uint64_t>(b, R + 1); v.pc_e2 = dalloc<uint64_t>(b, R + 1);
+  {
+    std::vector<int32_t> top;
+    for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(b->h_rstart[(size_t)r]);
+    v.rs_top = upload_vec(b, top, 1); v.re_top = dalloc<int32_t>(b, top.size() + 1);
+    dsync(b);
+  }
   ReadPrep& rp = b->rp;
   {
     std::vector<uint64_t> base((size_t)T + 1, 0);
@@ -469,8 +494,8 @@ void do_upload(snf_batch_impl* b) {
     rp.key32 = (!sort64 && b->read_key_bits <= 32) ? 1 : 0;
   }
   rp.r_end = v.r_end; rp.r_hp = v.r_hp; rp.r_task = v.r_task; rp.r_start = v.r_start; rp.rk_in = v.rk_in; rp.rv_in = v.rv_in;
-  rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.R = R;
-  for (int h = 0; h < 3; h++) { rp.fs[h] = dalloc<uint32_t>(b, R + 1); rp.fe[h] = dalloc<uint32_t>(b, R + 1); }
+  rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.re_top = v.re_top; rp.R = R;
+  rp.fs2 = dalloc<uint64_t>(b, R + 1); rp.fe2 = dalloc<uint64_t>(b, R + 1);
   v.tr_start = upload_vec(b, b->h_trs); v.tr_end = upload_vec(b, b->h_tre); v.tr_pmax = upload_vec(b, b->h_trp);
   size_t N1 = (size_t)N + 1;
   v.key_in = dalloc<uint64_t>(b, N); v.key_out = dalloc<uint64_t>(b, N); v.val_in = dalloc<uint32_t>(b, N); v.val_out = dalloc<uint32_t>(b, N);
@@ -529,10 +554,9 @@ void enqueue_read_prep(snf_batch_impl* b) {
     if (b->rp.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.rk_in, (uint32_t*)v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
     else prim_sort_pairs<uint64_t>(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
     LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
-    for (int h = 0; h < 3; h++) {
-      prim_exscan<uint32_t>(b, b->rp.fs[h], v.pc_s[h], R + 1, "scan_hap_prefix");
-      prim_exscan<uint32_t>(b, b->rp.fe[h], v.pc_e[h], R + 1, "scan_hap_prefix");
-    }
+    // haplotype prefix counts: HP 1 and HP 2 packed in one 64-bit scan per order (HP 0 = rank - both)
+    prim_exscan<uint64_t>(b, b->rp.fs2, v.pc_s2, R + 1, "scan_hap_prefix");
+    prim_exscan<uint64_t>(b, b->rp.fe2, v.pc_e2, R + 1, "scan_hap_prefix");
 #ifndef SNF_EMU
     { Scope _s(b, "d5w_covsum", R * 12);
       int64_t grid = (R + 4095) / 4096; if (grid > 2048) grid = 2048;

@@ -420,8 +420,8 @@ SNF_HD bool cov_get(const View& v, int t, int64_t idx, int32_t* out) {
   if (idx < -len || idx >= len) return false;  // IndexError: the field keeps its value
   if (idx < 0) idx += len;                      // numpy negative index
   int64_t lo = v.t_read_off[t], hi = v.t_read_off[t + 1];
-  int64_t ns = upper_bound_i32(v.r_start, lo, hi, idx) - lo;
-  int64_t ne = upper_bound_i32(v.re_sorted, lo, hi, idx) - lo;
+  int64_t ns = bound_top_i32<true>(v.r_start, v.rs_top, lo, hi, idx) - lo;
+  int64_t ne = bound_top_i32<true>(v.re_sorted, v.re_top, lo, hi, idx) - lo;
   *out = (int32_t)((uint64_t)(ns - ne) & 0xffffu);
   return true;
 }

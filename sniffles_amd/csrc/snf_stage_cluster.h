@@ -103,15 +103,8 @@ SNF_HD void a6_scatter_body(int64_t p, const View& v) {
   if (v.fN[p]) {
     const uint32_t q = v.pN[p];
     v.L[q] = o;
-    LeadRec r;
-    r.ref_start = v.in_ref_start[o]; r.ref_end = v.in_ref_end[o]; r.qry_start = v.in_qry_start[o]; r.qry_end = v.in_qry_end[o];
-    r.svlen = v.in_svlen[o];
-    const bool hs = v.in_seq_len[o] >= 0 && !v.seqnull[o];
-    r.seq_len = hs ? v.in_seq_len[o] : -1; r.seq_off = hs ? v.in_seq_off[o] : 0;
-    r.qname = v.in_qname[o]; r.read_id = v.in_read_id[o]; r.ps = v.in_ps[o]; r.mate_pos = v.in_mate_pos[o];
-    r.mate_contig = v.in_mate_contig[o]; r.read_len = v.in_read_len[o]; r.orig = o;
-    r.strand = v.in_strand[o]; r.mapq = v.in_mapq[o]; r.source = v.in_source[o]; r.hap = v.in_hap[o];
-    r.is_sa = v.in_is_sa[o]; r.first = v.in_first[o]; r.rev = v.in_rev[o]; r.svtype = v.in_svtype[o]; r._pad = 0;
+    LeadRec r = v.in_rec[o];
+    if (r.seq_len >= 0 && v.seqnull[o]) { r.seq_len = -1; r.seq_off = 0; }  // 11th+ lead of a bin: Lead.seq = None
     v.Lrec[q] = r;
   }
   if (v.fL[p]) v.LL[v.pL[p]] = o;

@@ -295,8 +295,13 @@ SNF_HD bool qc_sv_post_annotate(const View& v, snf_call_t& c, const LeadAgg& g, 
 SNF_HD int32_t hapref_count(const View& v, int task, int h, int64_t b) {
   int64_t lo = v.t_read_off[task], hi = v.t_read_off[task + 1];
   int64_t lim = (b + 1) * (int64_t)v.cfg.cluster_binsize;  // start_bin <= b  <=>  start < (b+1)*binsize
-  int64_t is = lower_bound_i32(v.r_start, lo, hi, lim), ie = lower_bound_i32(v.re_sorted, lo, hi, lim);
-  int64_t cnt = (int64_t)(v.pc_s[h][is] - v.pc_s[h][lo]) - (int64_t)(v.pc_e[h][ie] - v.pc_e[h][lo]);
+  int64_t is = bound_top_i32<false>(v.r_start, v.rs_top, lo, hi, lim), ie = bound_top_i32<false>(v.re_sorted, v.re_top, lo, hi, lim);
+  const uint64_t ds = v.pc_s2[is] - v.pc_s2[lo], de = v.pc_e2[ie] - v.pc_e2[lo];  // packed (hp1, hp2) counts, no carries
+  int64_t ns, ne;
+  if (h == 1) { ns = (int64_t)(ds >> 32); ne = (int64_t)(de >> 32); }
+  else if (h == 2) { ns = (int64_t)(ds & 0xffffffffull); ne = (int64_t)(de & 0xffffffffull); }
+  else { ns = (is - lo) - (int64_t)(ds >> 32) - (int64_t)(ds & 0xffffffffull); ne = (ie - lo) - (int64_t)(de >> 32) - (int64_t)(de & 0xffffffffull); }
+  int64_t cnt = ns - ne;
   return (int32_t)(cnt > 65535 ? 65535 : cnt);
 }
 

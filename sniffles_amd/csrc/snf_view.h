@@ -107,8 +107,9 @@ struct View {
   const int32_t* r_start; const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task;
   uint64_t *rk_in, *rk_out; uint32_t *rv_in, *rv_out;  // end-sort scratch
   int32_t* re_sorted;        // [R] ends, ascending per task
-  uint32_t* pc_s[3];         // [R+1] prefix count of reads with hp==h in start order
-  uint32_t* pc_e[3];         // [R+1] same in end order
+  int32_t *rs_top, *re_top;  // every 256th entry of r_start / re_sorted (top level of the rank queries)
+  uint64_t* pc_s2;           // [R+1] prefix counts in start order: #(hp == 1) << 32 | #(hp == 2)
+  uint64_t* pc_e2;           // [R+1] same in end order
   uint32_t* rflag;           // [R+1] scan scratch
 
   // ---- tandem repeats [NTR]
@@ -135,6 +136,7 @@ struct View {
   uint32_t* L;               // [N] seed-cluster leads, (task, svtype, bin, arrival) order -> input index
   uint32_t* LL;              // [N] leads_long, same order
   LeadRec* Lrec;             // [N] packed records of L[] (same index)
+  const LeadRec* in_rec;     // [N] the input columns interleaved per lead at upload (input order): one 64-B gather in a6
   ClusterHdr* chdr;          // [n_clusters]
   // result block in pinned host memory, written by z1_results at the end of each stage (no D2H copies to wait for)
   Counts* res_cnt; int32_t* res_status; int64_t* res_off; double* res_cov;
