@@ -119,6 +119,7 @@ struct snf_batch_impl {
   hipStream_t stream3 = nullptr;  // third stream: the LARGE consensus class next to the SMALL one
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
+  bool timing = true;             // HIP events around the heavy kernels (snf_batch_set_timing)
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
   bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
   bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
@@ -269,10 +270,11 @@ T* upload_vec(snf_batch_impl* b, const std::vector<T>& h, size_t extra = 0) {
 struct Scope {
   snf_batch_impl* b;
 #ifndef SNF_EMU
-  size_t idx;
+  size_t idx = (size_t)-1;
 #endif
   Scope(snf_batch_impl* b_, const char* name, int64_t bytes) : b(b_) {
 #ifndef SNF_EMU
+    if (!b->timing) return;
     if (b->ev_used == b->evs.size()) {
       snf_batch_impl::Ev e{};
       SNF_HIP(hipEventCreate(&e.a)); SNF_HIP(hipEventCreate(&e.b));
@@ -287,7 +289,7 @@ struct Scope {
   }
   ~Scope() {
 #ifndef SNF_EMU
-    (void)hipEventRecord(b->evs[idx].b, b->cur);
+    if (idx != (size_t)-1) (void)hipEventRecord(b->evs[idx].b, b->cur);
 #endif
   }
 };
@@ -996,6 +998,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, e1w_finalize, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }
+    b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
