@@ -127,6 +127,7 @@ struct snf_batch_impl {
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
+  void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
@@ -630,7 +631,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
-      hipLaunchKernelGGL(d2w_call, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+      hipLaunchKernelGGL(b->k_d2w, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
@@ -713,7 +714,7 @@ void run_finalize(snf_batch_impl* b) {
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
       int64_t grid = nc < b->slots_e1w ? nc : b->slots_e1w;
-      hipLaunchKernelGGL(e1w_finalize, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
+      hipLaunchKernelGGL(b->k_e1w, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
@@ -994,8 +995,12 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       int nb = 0;
       const int mult = getenv("SNF_GRID_MULT") ? atoi(getenv("SNF_GRID_MULT")) : 1;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d1w_refine, 64, 0)); if (nb > 0) b->slots_d1w = nb * cus * mult;
-      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d2w_call, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
-      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, e1w_finalize, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
+      const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 6;
+      const int o1 = getenv("SNF_OCC_E1") ? atoi(getenv("SNF_OCC_E1")) : 5;
+      b->k_d2w = o2 >= 8 ? d2w_call<8> : o2 == 6 ? d2w_call<6> : o2 == 5 ? d2w_call<5> : d2w_call<4>;
+      (void)o1; b->k_e1w = e1w_finalize<4>;  // higher-occupancy variants of e1w hit a register-allocation bug of this hipcc (odd-aligned 64-bit scratch reload)
+      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
+      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;

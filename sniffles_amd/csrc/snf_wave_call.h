@@ -67,7 +67,8 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
 }
 
 // ------------------------------------------------------------------------------------------ d2w: call_from
-__global__ void __launch_bounds__(SNF_WAVE) d2w_call(const View v, int64_t n_unused) {
+template <int MINW>
+__global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t n_unused) {
   __shared__ CallLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
@@ -205,7 +206,8 @@ __global__ void __launch_bounds__(SNF_WAVE) d2w_call(const View v, int64_t n_unu
 }
 
 // ------------------------------------------------------------------------------------------ e1w: finalize
-__global__ void __launch_bounds__(SNF_WAVE) e1w_finalize(const View v, int64_t n_unused) {
+template <int MINW>
+__global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int64_t n_unused) {
   __shared__ CallLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
