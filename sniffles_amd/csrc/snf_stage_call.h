@@ -338,6 +338,19 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   cc.rn_off = nq;  // stash: number of distinct names already sorted in w1[flo..]
   v.cand[r] = cc;
   CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
+  if (svtype == SNF_INS && !cfg.symbolic) {
+    // best lead of annotate_sv (postprocessing.py:33-66): first argmin of |len(seq) - svlen| + |ref_start - pos| * 1.5
+    int32_t best = -1, cnt = 0; double best_diff = 0;
+    for (int32_t k = 0; k < n; k++) {
+      int32_t s = FI[k];
+      if (v.F_seq_len[s] < 0) continue;
+      double d = (double)iabs64((int64_t)v.F_seq_len[s] - cc.svlen) +
+                 (double)iabs64((int64_t)v.in_ref_start[(uint32_t)v.F_orig[s]] - cc.pos) * 1.5;
+      if (best < 0 || d < best_diff) { best = s; best_diff = d; }
+      cnt++;
+    }
+    if (best >= 0) { x.best = best; x.n_others = cnt - 1; x.do_cons = (x.n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; }
+  }
   v.candx[r] = x;
   v.cdflag[r] = 1;
 }

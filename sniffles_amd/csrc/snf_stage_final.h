@@ -399,20 +399,10 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
   v.fN[i] = 0; v.fL[i] = 0; v.sz_tab[i] = 0; v.sz_aln[i] = 0; v.sz_rd[i] = 0;
   snf_call_t& c = v.calls[i];
   CallX& x = v.callx[i];
-  x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1;
-  if (c.svtype != SNF_INS || v.cfg.symbolic || v.t_status[c.task_index] != SNF_TASK_OK) return;
-  int32_t best = -1, cnt = 0; double best_diff = 0;
-  for (int32_t k = 0; k < x.fn; k++) {
-    int32_t s = v.FI[x.flo + k];
-    if (v.F_seq_len[s] < 0) continue;
-    double d = (double)iabs64((int64_t)v.F_seq_len[s] - c.svlen) +
-               (double)iabs64((int64_t)v.in_ref_start[(uint32_t)v.F_orig[s]] - c.pos) * 1.5;
-    if (best < 0 || d < best_diff) { best = s; best_diff = d; }
-    cnt++;
-  }
-  if (best < 0) return;
-  x.best = best; x.n_others = cnt - 1;
-  x.do_cons = (x.n_others >= v.cfg.consensus_min_reads && !v.cfg.no_consensus) ? 1 : 0;
+  x.cons_id = -1;
+  // best lead / number of other sequence-bearing leads: chosen by the call kernels (d2w_call, d2_call)
+  if (c.svtype != SNF_INS || v.cfg.symbolic || v.t_status[c.task_index] != SNF_TASK_OK || x.best < 0) { x.best = -1; x.n_others = 0; x.do_cons = 0; return; }
+  const int32_t best = x.best;
   const int64_t L = v.F_seq_len[best];
   c.alt_len = (int32_t)L;
   v.fN[i] = (uint32_t)L;

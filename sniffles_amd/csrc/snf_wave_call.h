@@ -195,9 +195,28 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     else if (svtype == SNF_DEL) cc.support_sa = (int32_t)src_noninline;
     cc.rn_len = (int32_t)rn_len;
     cc.rn_off = nq;  // stash: number of distinct names already sorted in w1[flo..]
+    int32_t best_slot = -1, n_others = 0;
+    if (svtype == SNF_INS && !cfg.symbolic) {
+      // best lead of annotate_sv (postprocessing.py:33-66): first argmin of |len(seq) - svlen| + |ref_start - pos| * 1.5
+      // over the sequence-bearing leads in cluster (= lane) order.  d >= 0, so its bit pattern orders like the value
+      const int32_t sl = act ? v.F_seq_len[slot] : -1;
+      const bool has = act && sl >= 0;
+      const double d = (double)iabs64((int64_t)sl - svlen) + (double)iabs64((int64_t)rs - svstart) * 1.5;
+      unsigned long long key = has ? (unsigned long long)__double_as_longlong(d) : ~0ull;
+      unsigned long long mn = key;
+#pragma unroll
+      for (int dd = 32; dd >= 1; dd >>= 1) { const unsigned long long o2 = __shfl_xor(mn, dd, SNF_WAVE); if (o2 < mn) mn = o2; }
+      const unsigned long long hm = __ballot(has);
+      if (hm) {
+        const int bl = __builtin_ctzll(__ballot(has && key == mn));
+        best_slot = __shfl(slot, bl, SNF_WAVE);
+        n_others = __builtin_popcountll(hm) - 1;
+      }
+    }
     if (lane == 0) {
       v.cand[r] = cc;
-      CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
+      CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = best_slot; x.n_others = n_others;
+      x.do_cons = (best_slot >= 0 && n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; x.cons_id = -1; x.alt_off = 0;
       v.candx[r] = x;
       v.cdflag[r] = 1;
     }
