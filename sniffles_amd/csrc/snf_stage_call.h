@@ -350,6 +350,14 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       cnt++;
     }
     if (best >= 0) { x.best = best; x.n_others = cnt - 1; x.do_cons = (x.n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; }
+    if (best >= 0 && v.wave_path) {  // read list for the workgroup consensus kernel (see d2w_call)
+      int32_t w = 0;
+      for (int32_t k = 0; k < n; k++) {
+        int32_t s = FI[k];
+        if (v.F_seq_len[s] < 0 || s == best) continue;
+        v.crl_off[flo + w] = v.F_seq_off[s]; v.crl_len[flo + w] = v.F_seq_len[s]; w++;
+      }
+    }
   }
   v.candx[r] = x;
   v.cdflag[r] = 1;

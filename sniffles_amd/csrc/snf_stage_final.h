@@ -463,7 +463,8 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   // work item for the gfx950 workgroup kernels
   ConsDesc d;
   d.L = v.F_seq_len[x.best]; d.best_off = v.F_seq_off[x.best]; d.alt_off = x.alt_off; d.aln_off = v.sc_aln[i];
-  d.read_off = v.sc_rd[i]; d.n_others = x.n_others; d.call = (int32_t)i;
+  d.read_off = x.flo;   // read list (crl_*) and kept flags (aln_kept_w) live in the refined cluster's own slot range
+  d.n_others = x.n_others; d.call = (int32_t)i;
   d.cls = x.do_cons ? (cons_class(v, d.L, x.n_others) ? cons_class(v, d.L, x.n_others) : 3) : 0;
   v.cdesc[cid] = d;
   // work list: LARGE calls are bucketed by work (others x length) and the kernel walks the heaviest bucket first, so
@@ -475,15 +476,6 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   } else if (d.cls == 3) lid = 6;
   const int64_t slot = class_list_slot(v, lid);
   if (lid < 6) v.cls_list[lid][slot] = (int32_t)cid;   // list 6 (thread kernels e4/e5/e6) is only counted
-  if (d.cls == 1 || d.cls == 2) {  // the other sequence-bearing leads, cluster order (consensus.py:302)
-    int64_t w = d.read_off;
-    for (int32_t k = 0; k < x.fn; k++) {
-      const int32_t sl = v.FI[x.flo + k];
-      const int32_t len = v.F_seq_len[sl];
-      if (len < 0 || sl == x.best) continue;
-      v.crl_off[w] = v.F_seq_off[sl]; v.crl_len[w] = len; w++;
-    }
-  }
 }
 
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {

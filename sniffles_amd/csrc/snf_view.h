@@ -180,6 +180,7 @@ struct View {
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
   ConsDesc* cdesc;           // [n_cons] by cons id
   int32_t* cls_list[6];      // cons ids per work list (see Counts::n_cls), appended with wave-aggregated atomics
+  uint8_t* aln_kept_w;       // [N+1] kept flag per (call, other read) of the workgroup kernels, indexed like crl_*
   int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };
 

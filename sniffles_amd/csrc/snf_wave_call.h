@@ -211,6 +211,14 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
         const int bl = __builtin_ctzll(__ballot(has && key == mn));
         best_slot = __shfl(slot, bl, SNF_WAVE);
         n_others = __builtin_popcountll(hm) - 1;
+        // read list of the consensus kernel: the other sequence-bearing leads in cluster order, stored in this refined
+        // cluster's own slot range [flo, flo + n) (no scan needed to place it)
+        const bool oth = has && lane != bl;
+        const unsigned long long om = __ballot(oth);
+        if (oth) {
+          const int w = __builtin_popcountll(om & ((1ull << lane) - 1ull));
+          v.crl_off[flo + w] = v.F_seq_off[slot]; v.crl_len[flo + w] = sl;
+        }
       }
     }
     if (lane == 0) {

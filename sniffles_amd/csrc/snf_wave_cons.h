@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
           row[q] = out;
         }
       }
-      if (lane == 0) { const uint8_t k = ((double)span / (double)L > 0.2) ? 1 : 0; v.aln_kept[r0 + r] = k; lds.kept[r] = k; }
+      if (lane == 0) { const uint8_t k = ((double)span / (double)L > 0.2) ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       __builtin_amdgcn_wave_barrier();
     }
     SNF_PH(5);
