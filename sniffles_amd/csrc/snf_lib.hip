@@ -763,7 +763,7 @@ void run_finalize(snf_batch_impl* b) {
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 4>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 5>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
       }
@@ -771,7 +771,7 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
-        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 4>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError());
       }
       if (serial) SNF_HIP(hipDeviceSynchronize());

@@ -33,7 +33,6 @@ struct ConsLdsT {
   struct Wave {
     uint16_t ai[MAXPOS];           // candidates, then accepted anchors: position in best
     uint16_t aj[MAXPOS];           //                                    position in the read
-    uint16_t seg_col[MAXPOS];      // column where segment t starts (t >= 1)
     uint16_t seg_len[MAXPOS];      // clipped advance (columns written)
     uint16_t seg_cm[MAXPOS];       // matches of the copied slice against best at its columns
     uint8_t seg_flag[MAXPOS];      // 0 dashes, 1 copy
@@ -92,10 +91,12 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     else if (it < n1 + n2 + n3) cid = v.cls_list[4][it - n1 - n2];
     else cid = v.cls_list[5][it - n1 - n2 - n3];
     const ConsDesc d = v.cdesc[cid];   // one record: no pointer chasing before the first useful load
-    const int64_t L = d.L;
-    const int32_t n_others = d.n_others;
-    const uint8_t* B = v.pool + d.best_off;
-    uint8_t* alt = v.alt_pool + d.alt_off;
+    // everything per call is wave-uniform: keep it in SGPRs (the compiler cannot prove it for values loaded from global
+    // memory, and the kernel's occupancy is bound by VGPRs)
+    const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
+    const int32_t n_others = __builtin_amdgcn_readfirstlane(d.n_others);
+    const uint8_t* B = v.pool + rfl64(d.best_off);
+    uint8_t* alt = v.alt_pool + rfl64(d.alt_off);
     bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
@@ -103,9 +104,9 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
     __syncthreads();
-    const int64_t npos = cons_npos(L, klen, skip);
-    for (int64_t p = tid; p < npos && !(v.ablate & 16); p += 256) {
-      const int64_t i = p * skip;
+    const int npos = (int)cons_npos(L, klen, skip);
+    for (int p = tid; p < npos && !(v.ablate & 16); p += 256) {
+      const int i = p * skip;
       const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
       int64_t sl = kmer_slot(kk, SLOTS);
       for (;;) {
@@ -118,20 +119,20 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     __syncthreads();
     SNF_PH(0);
     typename Lds::Wave& W = lds.w[wid];
-    const int64_t r0 = d.read_off;
-    uint8_t* rows = v.aln + d.aln_off;
+    const int64_t r0 = rfl64(d.read_off);
+    uint8_t* rows = v.aln + rfl64(d.aln_off);
     for (int32_t r = wid; r < n_others && !(v.ablate & 64); r += 4) {
       const uint8_t* S = v.pool + rfl64(v.crl_off[r0 + r]);
-      const int64_t SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
+      const int SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
       uint8_t* row = rows + (int64_t)r * L;
       // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
-      int64_t jlim = SL - klen;                                     // j < SL - klen
+      int jlim = SL - klen;                                     // j < SL - klen
       if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;   // an anchor needs i <= L-klen-1, |i-j| <= maxshift
-      const int64_t P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;   // <= npos + 2 < MAXPOS
+      const int P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;   // <= npos + 2 < MAXPOS
       unsigned long long kw[ROUNDS];
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
-        const int64_t p = (int64_t)rd * 64 + lane;
+        const int p = rd * 64 + lane;
         kw[rd] = (p < P && !(v.ablate & 8)) ? load_u64(S + p * skip) : 0ull;
       }
       if (v.prof) { unsigned long long x_ = 0;
@@ -143,11 +144,11 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       constexpr int G = ROUNDS < 4 ? ROUNDS : 4;  // rounds probed together: their LDS reads are in flight at once
 #pragma unroll
       for (int g = 0; g < ROUNDS; g += G) {
-        if ((int64_t)g * 64 >= P) break;
+        if (g * 64 >= P) break;
         unsigned long long kk[G], kq[G]; int sl[G];
 #pragma unroll
         for (int u = 0; u < G; u++) {
-          const int64_t p = (int64_t)(g + u) * 64 + lane;
+          const int p = (g + u) * 64 + lane;
           kk[u] = kmer_key_le(kw[g + u], klen);
           sl[u] = (int)kmer_slot(kk[u], SLOTS);
           kq[u] = p < P ? lds.key[sl[u]] : SNF_KEY_EMPTY;
@@ -160,9 +161,9 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
         for (int u = 0; u < G; u++) pcv[u] = kq[u] == kk[u] ? lds.pc[sl[u]] : 0u;
 #pragma unroll
         for (int u = 0; u < G; u++) {
-          const int64_t j = ((int64_t)(g + u) * 64 + lane) * skip;
+          const int j = ((g + u) * 64 + lane) * skip;
           int ci_ = -1;
-          if ((pcv[u] & 0xffffu) == 1u) { const int i = (int)(pcv[u] >> 16); if (iabs64((int64_t)i - j) <= maxshift) ci_ = i; }
+          if ((pcv[u] & 0xffffu) == 1u) { const int i = (int)(pcv[u] >> 16); if ((i > j ? i - j : j - i) <= maxshift) ci_ = i; }
           const unsigned long long mk = __ballot(ci_ >= 0);
           if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
           ncand += __builtin_popcountll(mk);
@@ -190,15 +191,15 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       }
       SNF_PH(2);
       // ---- 3. segments between consecutive anchors
-      const int i0 = na ? W.ai[0] : 0, j0 = na ? W.aj[0] : 0;
-      const int64_t c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
-      int64_t span = 0;
+      const int i0 = __builtin_amdgcn_readfirstlane(na ? (int)W.ai[0] : 0), j0 = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[0] : 0);
+      const int c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
+      int span = 0;
       for (int t0 = 1; t0 < na; t0 += 64) {
         const int t = t0 + lane;
         if (t < na) {
           const int li = W.ai[t - 1], lj = W.aj[t - 1], i = W.ai[t], j = W.aj[t];
-          int64_t col = c_first + (lj - j0); if (col > L) col = L;
-          const int64_t fwd_i = i - li; int64_t fwd_j = j - lj;
+          int col = c_first + (lj - j0); if (col > L) col = L;
+          const int fwd_i = i - li; int fwd_j = j - lj;
           if (col + fwd_j > L) fwd_j = L - col;
           uint8_t flag = 0; int cm = 0;
           if (fwd_i == fwd_j && fwd_j > 0 && !(v.ablate & 4)) {
@@ -211,15 +212,15 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
             if (nfull > 8) m += count_eq(S + lj + 9, B + li + 9, nfull - 8);
             if ((double)m / (double)nfull >= 0.5) {
               flag = 1;
-              cm = eq_bytes(a2, b2, fwd_j < 8 ? (int)fwd_j : 8);
-              if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, (int)fwd_j - 8);
+              cm = eq_bytes(a2, b2, fwd_j < 8 ? fwd_j : 8);
+              if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, fwd_j - 8);
             }
           }
-          W.seg_col[t] = (uint16_t)col; W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
+          W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
         }
       }
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) span += __shfl_xor(span, d, 64);
+      for (int dd = 32; dd >= 1; dd >>= 1) span += __shfl_xor(span, dd, 64);
       __builtin_amdgcn_wave_barrier();
       SNF_PH(3);
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360)
@@ -236,17 +237,18 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       __builtin_amdgcn_wave_barrier();
       SNF_PH(4);
       // ---- 5. write the row, column-parallel
-      int64_t c_last = c_first;
-      if (na) { c_last = c_first + (W.aj[na - 1] - j0); if (c_last > L) c_last = L; }
-      for (int64_t q0 = 0; q0 < L && !(v.ablate & 2); q0 += 64) {
-        const int64_t q = q0 + lane;
+      int c_last = c_first;
+      if (na) { c_last = c_first + (__builtin_amdgcn_readfirstlane((int)W.aj[na - 1]) - j0); if (c_last > L) c_last = L; }
+      for (int q0 = 0; q0 < L && !(v.ablate & 2); q0 += 64) {
+        const int q = q0 + lane;
         if (q < L) {
           uint8_t out = '-';
           if (na > 1 && q >= c_first && q < c_last) {
             int lo2 = 1, hi2 = na - 1;  // last segment t with seg_col[t] <= q
-            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if ((int64_t)W.seg_col[mid] <= q) lo2 = mid; else hi2 = mid - 1; }
+            // segment t starts at column c_first + (aj[t-1] - j0) (q < c_last <= L, so the clip at L never matters here)
+            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (c_first + ((int)W.aj[mid - 1] - j0) <= q) lo2 = mid; else hi2 = mid - 1; }
             const int t = lo2;
-            const int64_t off = q - W.seg_col[t];
+            const int off = q - (c_first + ((int)W.aj[t - 1] - j0));
             if (W.seg_flag[t] && off < W.seg_len[t]) out = S[W.aj[t - 1] + off];
           }
           row[q] = out;
@@ -261,8 +263,9 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     SNF_PH(7);
     int nkept = 0;
     for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
+    nkept = __builtin_amdgcn_readfirstlane(nkept);
     const double maxal = (double)(1 + nkept);
-    for (int64_t q = tid; q < L; q += 256) {
+    for (int q = tid; q < L; q += 256) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
       if (v.ablate & 1) { if (!(v.ablate & 32)) alt[q] = out; continue; }
