@@ -5,6 +5,7 @@
 #include "snf_stage_final.h"
 #include "snf_wave_refine.h"
 #include "snf_wave_cons.h"
+#include "snf_fused.h"
 #include "snf_wave_call.h"
 
 #ifndef SNF_EMU
@@ -129,6 +130,7 @@ struct snf_batch_impl {
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
+  int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
@@ -527,6 +529,7 @@ void do_upload(snf_batch_impl* b) {
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
+  v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * 8);
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 6; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
@@ -720,6 +723,17 @@ void run_finalize(snf_batch_impl* b) {
 #endif
     LAUNCH_Q(e1_finalize, v, nc, 0);
   }
+#ifndef SNF_EMU
+  {  // E2 sizes -> offsets -> E3 work items in two launches (snf_fused.h) instead of a size kernel, five scans and E3
+    const unsigned grid = (unsigned)((nc + 255) / 256);
+    if (b->time_all) { Scope _s(b, "e2a_sizes", 0); hipLaunchKernelGGL(e2a_sizes, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0); }
+    else hipLaunchKernelGGL(e2a_sizes, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+    if (b->time_all) { Scope _s(b, "e3b_offsets", 0); hipLaunchKernelGGL(e3b_offsets, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0); }
+    else hipLaunchKernelGGL(e3b_offsets, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  }
+#else
   LAUNCH(e2_best, v, nc, 0);
   prim_exscan<uint32_t>(b, v.fN, v.pN, nc + 1, "scan_alt");
   prim_exscan<uint32_t>(b, v.fL, v.pL, nc + 1, "scan_cons");
@@ -727,6 +741,7 @@ void run_finalize(snf_batch_impl* b) {
   prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
   prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
   LAUNCH_Q(e3_conslist, v, nc, 0);
+#endif
   d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   const int64_t ncons = b->h_cnt->n_cons, alt_total = b->h_cnt->alt_total;
@@ -771,7 +786,10 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
-        hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+        const dim3 gs((unsigned)(n_small < 16384 ? n_small : 16384));
+        if (b->occ_s >= 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError());
       }
       if (serial) SNF_HIP(hipDeviceSynchronize());
@@ -1007,6 +1025,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
+    if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());

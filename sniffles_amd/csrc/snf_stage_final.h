@@ -442,6 +442,7 @@ SNF_HD int64_t class_list_slot(const View& v, int lid) {
 #endif
 }
 
+SNF_HD void e3_emit(int64_t i, const View& v);
 SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
   if (i == 0) {
@@ -449,6 +450,10 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
     v.cnt->tab_total = v.sc_tab[nc]; v.cnt->aln_total = v.sc_aln[nc]; v.cnt->n_cons_reads = v.sc_rd[nc];
   }
   if (i >= nc) return;
+  e3_emit(i, v);
+}
+// per-call part of E3 (offsets of call i are final in pN / pL / sc_*)
+SNF_HD void e3_emit(int64_t i, const View& v) {
   snf_call_t& c = v.calls[i];
   CallX& x = v.callx[i];
   if (c.alt_len < 0) return;
