@@ -783,6 +783,14 @@ void run_finalize(snf_batch_impl* b) {
         b->cur = prev;
       }
       if (serial) SNF_HIP(hipDeviceSynchronize());
+      if (n_copy > 0) {  // verbatim ALTs: short; behind LARGE on the third stream (the side stream is busy with the record copies)
+        if (n_large <= 0) SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+        hipStream_t prev = b->cur; b->cur = b->stream3;
+        { Scope _s(b, "e4c_copy", 0);
+          hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+          SNF_HIP(hipGetLastError()); }
+        b->cur = prev;
+      }
       SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
@@ -790,12 +798,6 @@ void run_finalize(snf_batch_impl* b) {
         if (b->occ_s >= 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError());
-      }
-      if (serial) SNF_HIP(hipDeviceSynchronize());
-      if (n_copy > 0) {
-        Scope _s(b, "e4c_copy", 0);
-        hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError());
       }
       SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
