@@ -3,6 +3,8 @@
 // kernels are launch- and latency-bound, so the number of dependent launches is what they cost.
 #pragma once
 #include "snf_stage_final.h"
+#include "snf_stage_cluster.h"
+#include "snf_stage_call.h"
 
 #ifndef SNF_EMU
 namespace snf {
@@ -31,6 +33,163 @@ SNF_D void block_exscan256(const unsigned long long (&val)[K], unsigned long lon
     tot[k] = all;
   }
   __syncthreads();
+}
+
+// ---- two-level tile sums: 256-element tiles, 64 tiles per super tile.  A "sizes" kernel publishes its block total
+// (plain store) and adds it to its super tile (atomics spread over N/16384 addresses, zeroed at the start of the pass);
+// the "emit" kernel of the chain sums the preceding super tiles and the preceding tiles of its own super tile
+// (<= N/16384 + 63 loads per value and block), scans the block and has every element's exclusive offset.
+template <int K>
+SNF_D void tile_publish(const View& v, int slot0, const unsigned long long (&val)[K], unsigned long long* lds) {
+  unsigned long long excl[K], tot[K];
+  block_exscan256<K>(val, excl, tot, lds);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      v.tile_sums[(int64_t)(slot0 + k) * v.tile_stride + blockIdx.x] = tot[k];
+      if (tot[k]) atomicAdd(&v.tile_super[(int64_t)(slot0 + k) * v.super_stride + (blockIdx.x >> 6)], tot[k]);
+    }
+  }
+}
+template <int K>
+SNF_D void tile_scan(const View& v, int slot0, const unsigned long long (&val)[K], unsigned long long (&off)[K], unsigned long long* lds) {
+  unsigned long long part[K], dummy[K], prefix[K], excl[K], tot[K];
+  const int64_t sup = blockIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    unsigned long long a = 0;
+    for (int64_t s = threadIdx.x; s < sup; s += 256) a += v.tile_super[(int64_t)(slot0 + k) * v.super_stride + s];
+    const int64_t t = (sup << 6) + threadIdx.x;
+    if (threadIdx.x < 64 && t < (int64_t)blockIdx.x) a += v.tile_sums[(int64_t)(slot0 + k) * v.tile_stride + t];
+    part[k] = a;
+  }
+  block_exscan256<K>(part, dummy, prefix, lds);
+  block_exscan256<K>(val, excl, tot, lds);
+#pragma unroll
+  for (int k = 0; k < K; k++) off[k] = prefix[k] + excl[k];
+}
+
+// slots of the candidate stage (the ALT chain of finalize reuses 0..4 with direct sums)
+enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7 };
+
+#define SNF_FUSED_HEAD(name)                                                  \
+  __global__ void __launch_bounds__(256) name(const View v, int64_t n) {      \
+    __shared__ unsigned long long lds[8];                                     \
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+
+// start of a pass: every small reset in one launch (instead of ~17 fill kernels in front of the first real kernel)
+__global__ void __launch_bounds__(256) z0_init(const View v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t T = v.T, G = 8 * T + 8;
+  if (i < (int64_t)(sizeof(Counts) / 8)) ((unsigned long long*)v.cnt)[i] = 0;
+  if (i <= T) { v.t_cov_sum[i] = 0; v.t_status[i] = 0; }
+  if (i <= T + 1) v.t_call_off[i] = 0;
+  if (i < G) { v.grp_first_bin[i] = -1; v.grp_seed_lo[i] = -1; v.grp_seed_hi[i] = -1; v.grp_dirty[i] = 0; }
+  if (i < 8 * v.super_stride) v.tile_super[i] = 0;
+  if (i == 0 && v.N > 0) {
+    const int64_t N = v.N;
+    v.headflag[N] = 0; v.eligflag[N] = 0; v.fN[N] = 0; v.fL[N] = 0; v.runflag[N] = 0; v.clflag[N] = 0; v.rcflag[N] = 0; v.cdflag[N] = 0;
+  }
+}
+
+// A2 + tile sums of the bin-head flags | scan + A3
+SNF_FUSED_HEAD(a2k_heads)
+  if (p < n) { a2_heads_body(p, v); v.rcflag[p] = 0; }  // rcflag: reset for d1w_refine / d1_refine (rc_emit sets it)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.headflag[p] : 0ull};
+  tile_publish<1>(v, TS_BINS, val, lds);
+}
+SNF_FUSED_HEAD(a3k_bins)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.headflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_BINS, val, off, lds);
+  if (p < n) {
+    v.headscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { const int64_t nb = (int64_t)(off[0] + val[0]); v.headscan[n] = (uint32_t)nb; v.cnt->n_bins = nb; v.bin_lo[nb] = (int32_t)v.cnt->n_valid; }
+    a3_emit(p, v);
+  }
+}
+// A4 + tile sums of the seed-eligibility flags | (A5, A6 in between) | scan + A7
+SNF_FUSED_HEAD(a4k_binstats)
+  if (p < n) a4_binstats_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.eligflag[p] : 0ull};
+  tile_publish<1>(v, TS_SEEDS, val, lds);
+}
+SNF_FUSED_HEAD(a7k_seeds)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.eligflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_SEEDS, val, off, lds);
+  if (p < n) {
+    v.eligscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.eligscan[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_seeds = (int64_t)(off[0] + val[0]); }
+    a7_seeds_body(p, v);
+  }
+}
+// A5 + tile sums of the two membership flags | scans + A6
+SNF_FUSED_HEAD(a5k_leadflags)
+  if (p < n) a5_leadflags_body(p, v);
+  unsigned long long val[2] = {p < n ? (unsigned long long)v.fN[p] : 0ull, p < n ? (unsigned long long)v.fL[p] : 0ull};
+  tile_publish<2>(v, TS_LEADS, val, lds);
+}
+SNF_FUSED_HEAD(a6k_scatter)
+  unsigned long long val[2] = {p < n ? (unsigned long long)v.fN[p] : 0ull, p < n ? (unsigned long long)v.fL[p] : 0ull}, off[2];
+  tile_scan<2>(v, TS_LEADS, val, off, lds);
+  if (p < n) {
+    v.pN[p] = (uint32_t)off[0]; v.pL[p] = (uint32_t)off[1];
+    if (p == n - 1) {
+      v.pN[n] = (uint32_t)(off[0] + val[0]); v.pL[n] = (uint32_t)(off[1] + val[1]);
+      v.cnt->NF = (int64_t)(off[0] + val[0]); v.cnt->NLL = (int64_t)(off[1] + val[1]);
+    }
+    a6_emit(p, v);
+  }
+}
+// B1 + tile sums of the run-cut flags | scan + B2
+SNF_FUSED_HEAD(b1k_seedmetrics)
+  if (p < n) b1_seedmetrics_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.runflag[p] : 0ull};
+  tile_publish<1>(v, TS_RUNS, val, lds);
+}
+SNF_FUSED_HEAD(b2k_runs)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.runflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_RUNS, val, off, lds);
+  if (p < n) {
+    v.runscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { const int64_t nr = (int64_t)(off[0] + val[0]); v.runscan[n] = (uint32_t)nr; v.cnt->n_runs = nr; v.run_first[nr] = (int32_t)v.cnt->n_seeds; }
+    b2_emit(p, v);
+  }
+}
+// generic "count an existing flag array" + scan + emit chains: clusters (C4), refined clusters (D1b), calls (D3a)
+#define SNF_FLAGSUM(name, flag, slot)                                          \
+  SNF_FUSED_HEAD(name)                                                          \
+    unsigned long long val[1] = {p < n ? (unsigned long long)v.flag[p] : 0ull}; \
+    tile_publish<1>(v, slot, val, lds);                                         \
+  }
+SNF_FLAGSUM(c4a_count, clflag, TS_CLUSTERS)
+SNF_FLAGSUM(d1a_count, rcflag, TS_REFINED)
+SNF_FLAGSUM(d3a_count, cdflag, TS_CALLS)
+SNF_FUSED_HEAD(c4k_clusters)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.clflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_CLUSTERS, val, off, lds);
+  if (p < n) {
+    v.clscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.clscan[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_clusters = (int64_t)(off[0] + val[0]); }
+    c4_emit(p, v);
+  }
+}
+SNF_FUSED_HEAD(d1bk_rctable)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.rcflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_REFINED, val, off, lds);
+  if (p < n) {
+    v.rcscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.rcscan[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_rc = (int64_t)(off[0] + val[0]); }
+    d1b_emit(p, v);
+  }
+}
+SNF_FUSED_HEAD(d3ck_compact)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.cdflag[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_CALLS, val, off, lds);
+  if (p < n) {
+    v.cdscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.cdscan[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_calls = (int64_t)(off[0] + val[0]); }
+    d3_compact_emit(p, v);
+  }
 }
 
 // ---- ALT sizing: E2 (sizes per call) + per-tile sums; E3 (offsets, totals, work descriptors)

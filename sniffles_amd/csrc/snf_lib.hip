@@ -330,6 +330,20 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
 #define LAUNCH_Q(kern, view, n, bytes) LAUNCH(kern, view, n, bytes)
 #endif
 
+#ifndef SNF_EMU
+// kernels of snf_fused.h: n elements, 256 per block; bracketed by timing events only with SNF_TIME_ALL
+#define FUSED(kern, n)                                                                                  \
+  do {                                                                                                  \
+    int64_t _n = (n);                                                                                   \
+    if (_n > 0) {                                                                                       \
+      if (b->time_all) { Scope _s(b, #kern, 0);                                                         \
+        hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->cur, v, _n); }    \
+      else hipLaunchKernelGGL(kern, dim3((unsigned)((_n + 255) / 256)), dim3(256), 0, b->cur, v, _n);   \
+      SNF_HIP(hipGetLastError());                                                                       \
+    }                                                                                                   \
+  } while (0)
+#endif
+
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
 template <class K>
 void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int64_t n,
@@ -530,6 +544,7 @@ void do_upload(snf_batch_impl* b) {
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
   v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * 8);
+  v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * 8);
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 6; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
@@ -583,6 +598,14 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
 #endif
+#ifndef SNF_EMU
+  {
+    int64_t n0 = 8 * (int64_t)T + 8;
+    if (8 * v.super_stride > n0) n0 = 8 * v.super_stride;
+    if ((int64_t)(sizeof(Counts) / 8) > n0) n0 = (int64_t)(sizeof(Counts) / 8);
+    FUSED(z0_init, n0);
+  }
+#else
   dzero(b, v.cnt, sizeof(Counts));
   dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
   dzero(b, v.t_status, sizeof(int32_t) * (T + 1));
@@ -591,14 +614,34 @@ void run_call_candidates(snf_batch_impl* b) {
   dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
   dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
+#endif
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
   if (N > 0) {
+#ifdef SNF_EMU
     uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
     for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
+#endif
     LAUNCH(a1_keys, v, N, N * 21);
     if (v.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.key_in, (uint32_t*)v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     else prim_sort_pairs<uint64_t>(b, v.key_in, v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
+#ifndef SNF_EMU
+    // flag -> device-wide scan -> emit chains as "flags + tile sums" / "tile prefix + block scan + emit" kernel pairs
+    // (snf_fused.h): 13 launches for stages A-C instead of 26 (each rocPRIM scan is an init kernel + a scan kernel)
+    FUSED(a2k_heads, N);
+    FUSED(a3k_bins, N);
+    { Scope _s(b, "a4_binstats", N * 16); FUSED(a4k_binstats, N); }
+    FUSED(a5k_leadflags, N);
+    { Scope _s(b, "a6_scatter", N * 16); FUSED(a6k_scatter, N); }
+    FUSED(a7k_seeds, N);
+    { Scope _s(b, "b1_seedmetrics", N * 8); FUSED(b1k_seedmetrics, N); }
+    FUSED(b2k_runs, N);
+    LAUNCH(c1_mergeruns, v, N, N * 8);
+    LAUNCH_Q(c2_validate, v, N, 0);
+    LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
+    FUSED(c4a_count, N);
+    FUSED(c4k_clusters, N);
+#else
     LAUNCH_Q(a2_heads, v, N, N * 12);
     prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
     LAUNCH_Q(a3_bins, v, N, N * 8);
@@ -618,6 +661,7 @@ void run_call_candidates(snf_batch_impl* b) {
     prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
     LAUNCH_Q(c4_clusters, v, N, N * 4);
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
+#endif
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
@@ -629,8 +673,13 @@ void run_call_candidates(snf_batch_impl* b) {
   }
   if (b->sched_readprep == 1) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
+#ifndef SNF_EMU
+    FUSED(d1a_count, N);
+    FUSED(d1bk_rctable, N);
+#else
     prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
     LAUNCH_Q(d1b_rctable, v, N, N * 4);
+#endif
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
@@ -639,8 +688,13 @@ void run_call_candidates(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
+#ifndef SNF_EMU
+    FUSED(d3a_count, N);
+    FUSED(d3ck_compact, N);
+#else
     prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
     LAUNCH_Q(d3_compact, v, N, 0);
+#endif
   }
   // the number of calls is known here: publish the counters (pinned block) and let the host pick them up through
   // ev_counts.  Nothing the ALT chain of finalize needs is produced after this point, so the rest of the candidate

@@ -225,8 +225,12 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
 }
 
 // D1b: dense refined-cluster table (rcscan = exclusive scan of rcflag over the F slot space)
+SNF_HD void d1b_emit(int64_t pos, const View& v);
 SNF_HD void d1b_rctable_body(int64_t pos, const View& v) {
   if (pos == 0) v.cnt->n_rc = v.rcscan[v.N];
+  d1b_emit(pos, v);
+}
+SNF_HD void d1b_emit(int64_t pos, const View& v) {
   if (pos < v.cnt->NF && v.rcflag[pos]) {
     uint32_t r = v.rcscan[pos];
     v.rc_lo[r] = (int32_t)pos; v.rc_n[r] = v.rc_n_s[pos]; v.rc_cluster[r] = v.rc_cl_s[pos];
@@ -364,9 +368,12 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
 }
 
 // D3a: compaction (cdscan = exclusive scan of cdflag) -> calls in candidate order
+SNF_HD void d3_compact_emit(int64_t r, const View& v) {
+  if (r < v.cnt->n_rc && v.cdflag[r]) { uint32_t i = v.cdscan[r]; v.calls[i] = v.cand[r]; v.callx[i] = v.candx[r]; }
+}
 SNF_HD void d3_compact_body(int64_t r, const View& v) {
   if (r == 0) { v.cnt->n_calls = v.cdscan[v.N]; }
-  if (r < v.cnt->n_rc && v.cdflag[r]) { uint32_t i = v.cdscan[r]; v.calls[i] = v.cand[r]; v.callx[i] = v.candx[r]; }
+  d3_compact_emit(r, v);
 }
 
 // D3b: per task offsets into calls (calls are sorted by task), T+1 entries; task status / stale BND `end`

@@ -47,17 +47,20 @@ SNF_HD void a2_heads_body(int64_t p, const View& v) {
 }
 
 // A3: bin table (headscan = exclusive scan of headflag; headscan[N] = #bins)
+SNF_HD void a3_emit(int64_t p, const View& v) {
+  if (v.headflag[p]) {
+    uint32_t b = v.headscan[p];
+    v.bin_lo[b] = (int32_t)p;
+    v.bin_key[b] = sorted_key(v, p);
+  }
+}
 SNF_HD void a3_bins_body(int64_t p, const View& v) {
   if (p == 0) {
     int64_t nb = v.headscan[v.N];
     v.cnt->n_bins = nb;
     v.bin_lo[nb] = (int32_t)v.cnt->n_valid;
   }
-  if (v.headflag[p]) {
-    uint32_t b = v.headscan[p];
-    v.bin_lo[b] = (int32_t)p;
-    v.bin_key[b] = sorted_key(v, p);
-  }
+  a3_emit(p, v);
 }
 
 // A4: per bin: record_lead side effects (seq cap, hap counters) and seed eligibility (cluster.py:262)
@@ -96,8 +99,12 @@ SNF_HD void a5_leadflags_body(int64_t p, const View& v) {
 }
 
 // A6: scatter into L / LL (pN/pL = exclusive scans of fN/fL)
+SNF_HD void a6_emit(int64_t p, const View& v);
 SNF_HD void a6_scatter_body(int64_t p, const View& v) {
   if (p == 0) { v.cnt->NF = v.pN[v.N]; v.cnt->NLL = v.pL[v.N]; v.cnt->n_seeds = v.eligscan[v.N]; }
+  a6_emit(p, v);
+}
+SNF_HD void a6_emit(int64_t p, const View& v) {
   if (p >= v.cnt->n_valid) return;
   uint32_t o = v.val_out[p];
   if (v.fN[p]) {
@@ -185,13 +192,16 @@ SNF_HD void b1_seedmetrics_body(int64_t s, const View& v) {
   v.runflag[s] = cut ? 1u : 0u;
 }
 
+SNF_HD void b2_emit(int64_t s, const View& v) {
+  if (s < v.cnt->n_seeds && v.runflag[s]) v.run_first[v.runscan[s]] = (int32_t)s;
+}
 SNF_HD void b2_runs_body(int64_t s, const View& v) {
   if (s == 0) {
     int64_t nr = v.runscan[v.N];
     v.cnt->n_runs = nr;
     v.run_first[nr] = (int32_t)v.cnt->n_seeds;
   }
-  if (s < v.cnt->n_seeds && v.runflag[s]) v.run_first[v.runscan[s]] = (int32_t)s;
+  b2_emit(s, v);
 }
 
 // ------------------------------------------------------------------------------------------ stage C
@@ -301,8 +311,12 @@ SNF_HD void c3_serial_body(int64_t g, const View& v) {
 }
 
 // C4: merged cluster table (clscan = exclusive scan of clflag)
+SNF_HD void c4_emit(int64_t s, const View& v);
 SNF_HD void c4_clusters_body(int64_t s, const View& v) {
   if (s == 0) v.cnt->n_clusters = v.clscan[v.N];
+  c4_emit(s, v);
+}
+SNF_HD void c4_emit(int64_t s, const View& v) {
   if (s < v.cnt->n_seeds && v.clflag[s]) {
     const uint32_t c = v.clscan[s];
     v.cl_head[c] = (int32_t)s;

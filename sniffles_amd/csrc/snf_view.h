@@ -178,6 +178,7 @@ struct View {
   int32_t *cr_call, *cr_read;  // [n_cons_reads] (consensus id, other index)
   uint8_t* alt_pool; int64_t alt_cap;
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
+  unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains
   ConsDesc* cdesc;           // [n_cons] by cons id
   int32_t* cls_list[6];      // cons ids per work list (see Counts::n_cls), appended with wave-aggregated atomics
