@@ -70,7 +70,7 @@ SNF_D void tile_scan(const View& v, int slot0, const unsigned long long (&val)[K
 }
 
 // slots of the candidate stage (the ALT chain of finalize reuses 0..4 with direct sums)
-enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7 };
+// (slot ids: enum TS_* in snf_view.h)
 
 #define SNF_FUSED_HEAD(name)                                                  \
   __global__ void __launch_bounds__(256) name(const View v, int64_t n) {      \
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) z0_init(const View v, int64_t n) {
   if (i <= T) { v.t_cov_sum[i] = 0; v.t_status[i] = 0; }
   if (i <= T + 1) v.t_call_off[i] = 0;
   if (i < G) { v.grp_first_bin[i] = -1; v.grp_seed_lo[i] = -1; v.grp_seed_hi[i] = -1; v.grp_dirty[i] = 0; }
-  if (i < 8 * v.super_stride) v.tile_super[i] = 0;
+  if (i < TS_SLOTS * v.super_stride) v.tile_super[i] = 0;
   if (i == 0 && v.N > 0) {
     const int64_t N = v.N;
     v.headflag[N] = 0; v.eligflag[N] = 0; v.fN[N] = 0; v.fL[N] = 0; v.runflag[N] = 0; v.clflag[N] = 0; v.rcflag[N] = 0; v.cdflag[N] = 0;
@@ -189,6 +189,22 @@ SNF_FUSED_HEAD(d3ck_compact)
     v.cdscan[p] = (uint32_t)off[0];
     if (p == n - 1) { v.cdscan[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_calls = (int64_t)(off[0] + val[0]); }
     d3_compact_emit(p, v);
+  }
+}
+
+// D3c (sv ids, read-name counts) + tile sums | scan + D3d (supporting read names)
+SNF_FUSED_HEAD(d3sk_svid)
+  if (p < n) d3_svid_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.rnf[p] : 0ull};
+  tile_publish<1>(v, TS_RNAMES, val, lds);
+}
+SNF_FUSED_HEAD(d3rk_rnames)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.rnf[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_RNAMES, val, off, lds);
+  if (p < n) {
+    v.rnp[p] = (uint32_t)off[0];
+    if (p == n - 1) { const int64_t tot = (int64_t)(off[0] + val[0]); v.rnp[n] = (uint32_t)tot; v.cnt->rn_total = tot; *v.res_rn_total = tot; }
+    d3_rnames_emit(p, v);
   }
 }
 

@@ -118,6 +118,7 @@ struct snf_batch_impl {
   hipStream_t stream = nullptr;   // main stream (also the one fetch/sync wait on)
   hipStream_t stream2 = nullptr;  // side stream: read preparation, finalize scalar kernels
   hipStream_t stream3 = nullptr;  // third stream: the LARGE consensus class next to the SMALL one
+  hipStream_t stream4 = nullptr;  // fourth stream: sv ids + supporting read names and their D2H copy (off the coverage / QC chain)
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
   bool timing = true;             // HIP events around the heavy kernels (snf_batch_set_timing)
@@ -155,7 +156,7 @@ struct snf_batch_impl {
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
 #ifndef SNF_EMU
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr,
-             ev_counts = nullptr, ev_rn = nullptr;  // host waits: counters published (main), read-name total published (side)
+             ev_counts = nullptr, ev_rn = nullptr, ev_join4 = nullptr;  // host waits: counters published (main), read-name total published (side)
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
@@ -543,8 +544,8 @@ void do_upload(snf_batch_impl* b) {
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
-  v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * 8);
-  v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * 8);
+  v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * TS_SLOTS);
+  v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 6; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
@@ -601,7 +602,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
   {
     int64_t n0 = 8 * (int64_t)T + 8;
-    if (8 * v.super_stride > n0) n0 = 8 * v.super_stride;
+    if (TS_SLOTS * v.super_stride > n0) n0 = TS_SLOTS * v.super_stride;
     if ((int64_t)(sizeof(Counts) / 8) > n0) n0 = (int64_t)(sizeof(Counts) / 8);
     FUSED(z0_init, n0);
   }
@@ -705,6 +706,23 @@ void run_call_candidates(snf_batch_impl* b) {
 #endif
   if (b->sched_readprep >= 2) enqueue_read_prep(b);
   fork_mark(b);
+#ifndef SNF_EMU
+  {  // sv ids + supporting read names: own stream (nothing on the coverage -> QC -> record copy chain waits for them
+     // except the copy itself, through ev_rn)
+    SNF_HIP(hipStreamWaitEvent(b->stream4, b->ev_fork, 0));
+    hipStream_t prev = b->cur; b->cur = b->stream4;
+    if (N > 0) {
+      FUSED(d3sk_svid, N);
+      { Scope _s(b, "d3_rnames", 0); FUSED(d3rk_rnames, N); }
+    } else *b->h_rn_total = 0;
+    SNF_HIP(hipEventRecord(b->ev_rn, b->stream4));
+    b->cur = prev;
+  }
+  {
+    SideStream side(b);
+    if (N > 0) LAUNCH(d4_coverage, v, N, 0);
+  }
+#else
   {
     SideStream side(b);
     if (N > 0) {
@@ -712,17 +730,22 @@ void run_call_candidates(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, v.rnf, v.rnp, N + 1, "scan_rnames");
       LAUNCH(d3_rnames, v, N, 0);
     } else *b->h_rn_total = 0;
-#ifndef SNF_EMU
-    SNF_HIP(hipEventRecord(b->ev_rn, b->cur));
-#endif
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
   }
+#endif
   b->prefetched = false; b->res_current = false;
 }
 
 // everything enqueued on any of the batch's streams has completed and the pinned result block is current
+void join_fourth(snf_batch_impl* b) {  // main stream waits for the fourth stream (sv ids, read names, their copy)
+#ifndef SNF_EMU
+  SNF_HIP(hipEventRecord(b->ev_join4, b->stream4));
+  SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join4, 0));
+#endif
+}
 void full_sync(snf_batch_impl* b) {
   join_side(b);
+  join_fourth(b);
   if (!b->res_current) { LAUNCH_Q(z1_results, b->v, b->v.T + 1, 0); b->res_current = true; }
   dsync(b);
 }
@@ -736,20 +759,28 @@ void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t 
 
 void enqueue_prefetch(snf_batch_impl* b) {
   View& v = b->v;
-  {  // the call records are final once e1 (side) and e3 (main, done: we just synchronised) have run: copy them and
-     // the read names to the pinned host buffers while the (latency-bound) consensus kernel runs
 #ifndef SNF_EMU
-    SNF_HIP(hipEventSynchronize(b->ev_rn));  // d3_rnames (side stream, enqueued long ago) has published the total
-#endif
-    int64_t nc = b->h_cnt->n_calls, rn_total = *b->h_rn_total;
-    snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
-    uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
-    fork_mark(b);
-    SideStream side(b);
-    d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
+  // the call records are final once e1w/e1 (side stream), E3 (main: done, we just synchronised) and the sv-id / read-name
+  // kernels (fourth stream) have run: copy them to the pinned host buffers while the consensus kernels run.  The read
+  // names go out on the fourth stream as soon as their total is known.
+  SNF_HIP(hipEventSynchronize(b->ev_rn));  // enqueued long ago
+  int64_t nc = b->h_cnt->n_calls, rn_total = *b->h_rn_total;
+  snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
+  uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
+  {
+    hipStream_t prev = b->cur; b->cur = b->stream4;
     if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
-    b->prefetched = true;
+    b->cur = prev;
+    SNF_HIP(hipEventRecord(b->ev_join4, b->stream4));
   }
+  fork_mark(b);
+  SideStream side(b);
+  SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_rn, 0));   // sv_id / rn_off are in the records
+  d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
+  b->prefetched = true;
+#else
+  (void)v;
+#endif
 }
 
 void run_finalize(snf_batch_impl* b) {
@@ -862,6 +893,7 @@ void run_finalize(snf_batch_impl* b) {
   if (b->sched_prefetch == 2) enqueue_prefetch(b);
   if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt->aln_total + 2 * alt_total);
   join_side(b);
+  join_fourth(b);
   LAUNCH_Q(z1_results, v, v.T + 1, 0);
   b->res_current = true;
 }
@@ -1054,6 +1086,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     SNF_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     SNF_HIP(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
     SNF_HIP(hipStreamCreateWithFlags(&b->stream3, hipStreamNonBlocking));
+    SNF_HIP(hipStreamCreateWithFlags(&b->stream4, hipStreamNonBlocking));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
     SNF_HIP(hipEventCreate(&b->ev_base));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_counts, hipEventDisableTiming));
@@ -1112,6 +1146,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2) (void)hipStreamSynchronize(b->stream2);
   if (b->stream3) (void)hipStreamSynchronize(b->stream3);
+  if (b->stream4) (void)hipStreamSynchronize(b->stream4);
   if (b->ev_fork3) (void)hipEventDestroy(b->ev_fork3);
   if (b->ev_base) (void)hipEventDestroy(b->ev_base);
   if (b->ev_counts) (void)hipEventDestroy(b->ev_counts);
@@ -1127,6 +1162,8 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->stream) (void)hipStreamDestroy(b->stream);
   if (b->stream2) (void)hipStreamDestroy(b->stream2);
   if (b->stream3) (void)hipStreamDestroy(b->stream3);
+  if (b->stream4) (void)hipStreamDestroy(b->stream4);
+  if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
 #endif
   delete b;
 }

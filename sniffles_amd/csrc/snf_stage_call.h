@@ -417,8 +417,12 @@ SNF_HD void d3_svid_body(int64_t i, const View& v) {
 }
 
 // D3d: supporting read names (pN = exclusive scan of rn_len)
+SNF_HD void d3_rnames_emit(int64_t i, const View& v);
 SNF_HD void d3_rnames_body(int64_t i, const View& v) {
   if (i == 0) { v.cnt->rn_total = v.rnp[v.N]; *v.res_rn_total = v.rnp[v.N]; }
+  d3_rnames_emit(i, v);
+}
+SNF_HD void d3_rnames_emit(int64_t i, const View& v) {
   if (i >= v.cnt->n_calls) return;
   snf_call_t& c = v.calls[i];
   const CallX& x = v.callx[i];

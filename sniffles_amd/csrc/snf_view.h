@@ -64,6 +64,9 @@ struct ConsDesc {
 // merged cluster header, written by c4_clusters: what the refine kernels need to start on cluster c in one record
 struct ClusterHdr { int32_t h, lo, n, grp; int32_t repeat, _pad[3]; };
 
+// tile-sum slots of the fused flag -> scan -> emit chains (snf_fused.h)
+enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7, TS_RNAMES = 8, TS_SLOTS = 9 };
+
 struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t rc;       // refined cluster id
   int32_t cluster;  // merged cluster id
