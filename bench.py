@@ -51,6 +51,12 @@ def main():
                          "the other.  1 = strictly one pass at a time")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the result): libraries that print banners through C stdio (RCCL prints its version
+    # block to stdout, flushed only at exit when stdout is a pipe) are sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -64,7 +70,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # SNF_BENCH_FORCE_DIST=1: run the whole collective path (RCCL process group, gathers from the worker threads) with a
+    # single rank - a dry run of the N > 1 code on a 1-GPU box
+    use_dist = world > 1 or os.environ.get("SNF_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from sniffles_amd import abi, lib, synth
@@ -90,11 +102,11 @@ def main():
     t_upload = time.time() - t0
 
     cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # all_gather_into_tensor needs equal sizes on every rank
     cap_calls = int(cap_t.item())
     rec_bytes = abi.CALL_DTYPE.itemsize
-    if world > 1:
+    if use_dist:
         sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(W)]
         count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
         gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
@@ -115,7 +127,7 @@ def main():
         t_d = time.perf_counter()
         if w == 0:
             phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
-        if world > 1:
+        if use_dist:
             with coll_lock:
                 torch.cuda.set_device(local_rank)
                 nexp = batch.export_calls_device(sends[w].data_ptr(), cap_calls)
@@ -126,7 +138,7 @@ def main():
         return n
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -177,7 +189,7 @@ def main():
 
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
@@ -229,10 +241,10 @@ def main():
                    roofline=roofline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     for bb in batches:
         bb.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
