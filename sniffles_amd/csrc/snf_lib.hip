@@ -121,6 +121,7 @@ struct snf_batch_impl {
   hipStream_t stream4 = nullptr;  // fourth stream: sv ids + supporting read names and their D2H copy (off the coverage / QC chain)
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
+  bool fused = false;             // flag -> scan -> emit chains as fused kernel pairs (snf_fused.h); off: rocPRIM scans
   bool timing = true;             // HIP events around the heavy kernels (snf_batch_set_timing)
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
   bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
@@ -343,6 +344,8 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
       SNF_HIP(hipGetLastError());                                                                       \
     }                                                                                                   \
   } while (0)
+#else
+#define FUSED(kern, n) do { } while (0)   /* the emulation build always takes the plain-scan path (b->fused == false) */
 #endif
 
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
@@ -599,34 +602,37 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
 #endif
+  // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
+  // (and in the emulation build) the plain device-wide scans are used
 #ifndef SNF_EMU
-  {
+  b->fused = getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25);
+#endif
+  if (b->fused) {
     int64_t n0 = 8 * (int64_t)T + 8;
     if (TS_SLOTS * v.super_stride > n0) n0 = TS_SLOTS * v.super_stride;
     if ((int64_t)(sizeof(Counts) / 8) > n0) n0 = (int64_t)(sizeof(Counts) / 8);
     FUSED(z0_init, n0);
+  } else {
+    dzero(b, v.cnt, sizeof(Counts));
+    dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
+    dzero(b, v.t_status, sizeof(int32_t) * (T + 1));
+    dzero(b, v.t_call_off, sizeof(int64_t) * (T + 2));
+    dzero(b, v.grp_first_bin, sizeof(int32_t) * (8 * T + 8), 0xff);
+    dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
+    dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
+    dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
   }
-#else
-  dzero(b, v.cnt, sizeof(Counts));
-  dzero(b, v.t_cov_sum, sizeof(unsigned long long) * (T + 1));
-  dzero(b, v.t_status, sizeof(int32_t) * (T + 1));
-  dzero(b, v.t_call_off, sizeof(int64_t) * (T + 2));
-  dzero(b, v.grp_first_bin, sizeof(int32_t) * (8 * T + 8), 0xff);
-  dzero(b, v.grp_seed_lo, sizeof(int32_t) * (8 * T + 8), 0xff);
-  dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
-  dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
-#endif
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
   if (N > 0) {
-#ifdef SNF_EMU
-    uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
-    for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
-#endif
+    if (!b->fused) {
+      uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
+      for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
+    }
     LAUNCH(a1_keys, v, N, N * 21);
     if (v.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.key_in, (uint32_t*)v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     else prim_sort_pairs<uint64_t>(b, v.key_in, v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
-#ifndef SNF_EMU
+    if (b->fused) {
     // flag -> device-wide scan -> emit chains as "flags + tile sums" / "tile prefix + block scan + emit" kernel pairs
     // (snf_fused.h): 13 launches for stages A-C instead of 26 (each rocPRIM scan is an init kernel + a scan kernel)
     FUSED(a2k_heads, N);
@@ -642,7 +648,7 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
     FUSED(c4a_count, N);
     FUSED(c4k_clusters, N);
-#else
+    } else {
     LAUNCH_Q(a2_heads, v, N, N * 12);
     prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
     LAUNCH_Q(a3_bins, v, N, N * 8);
@@ -662,7 +668,7 @@ void run_call_candidates(snf_batch_impl* b) {
     prim_exscan<uint32_t>(b, v.clflag, v.clscan, N + 1, "scan_clusters");
     LAUNCH_Q(c4_clusters, v, N, N * 4);
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
-#endif
+    }
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
@@ -674,13 +680,13 @@ void run_call_candidates(snf_batch_impl* b) {
   }
   if (b->sched_readprep == 1) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
-#ifndef SNF_EMU
-    FUSED(d1a_count, N);
-    FUSED(d1bk_rctable, N);
-#else
-    prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
-    LAUNCH_Q(d1b_rctable, v, N, N * 4);
-#endif
+    if (b->fused) {
+      FUSED(d1a_count, N);
+      FUSED(d1bk_rctable, N);
+    } else {
+      prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
+      LAUNCH_Q(d1b_rctable, v, N, N * 4);
+    }
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
@@ -689,13 +695,13 @@ void run_call_candidates(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
-#ifndef SNF_EMU
-    FUSED(d3a_count, N);
-    FUSED(d3ck_compact, N);
-#else
-    prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
-    LAUNCH_Q(d3_compact, v, N, 0);
-#endif
+    if (b->fused) {
+      FUSED(d3a_count, N);
+      FUSED(d3ck_compact, N);
+    } else {
+      prim_exscan<uint32_t>(b, v.cdflag, v.cdscan, N + 1, "scan_calls");
+      LAUNCH_Q(d3_compact, v, N, 0);
+    }
   }
   // the number of calls is known here: publish the counters (pinned block) and let the host pick them up through
   // ev_counts.  Nothing the ALT chain of finalize needs is produced after this point, so the rest of the candidate
@@ -707,22 +713,22 @@ void run_call_candidates(snf_batch_impl* b) {
   if (b->sched_readprep >= 2) enqueue_read_prep(b);
   fork_mark(b);
 #ifndef SNF_EMU
-  {  // sv ids + supporting read names: own stream (nothing on the coverage -> QC -> record copy chain waits for them
-     // except the copy itself, through ev_rn)
-    SNF_HIP(hipStreamWaitEvent(b->stream4, b->ev_fork, 0));
-    hipStream_t prev = b->cur; b->cur = b->stream4;
-    if (N > 0) {
-      FUSED(d3sk_svid, N);
-      { Scope _s(b, "d3_rnames", 0); FUSED(d3rk_rnames, N); }
-    } else *b->h_rn_total = 0;
-    SNF_HIP(hipEventRecord(b->ev_rn, b->stream4));
-    b->cur = prev;
-  }
-  {
+  if (b->fused) {
+    {  // sv ids + supporting read names: own stream (nothing on the coverage -> QC -> record copy chain waits for them
+       // except the copy itself, through ev_rn)
+      SNF_HIP(hipStreamWaitEvent(b->stream4, b->ev_fork, 0));
+      hipStream_t prev = b->cur; b->cur = b->stream4;
+      if (N > 0) {
+        FUSED(d3sk_svid, N);
+        { Scope _s(b, "d3_rnames", 0); FUSED(d3rk_rnames, N); }
+      } else *b->h_rn_total = 0;
+      SNF_HIP(hipEventRecord(b->ev_rn, b->stream4));
+      b->cur = prev;
+    }
     SideStream side(b);
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
-  }
-#else
+  } else
+#endif
   {
     SideStream side(b);
     if (N > 0) {
@@ -730,9 +736,11 @@ void run_call_candidates(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, v.rnf, v.rnp, N + 1, "scan_rnames");
       LAUNCH(d3_rnames, v, N, 0);
     } else *b->h_rn_total = 0;
+#ifndef SNF_EMU
+    SNF_HIP(hipEventRecord(b->ev_rn, b->cur));
+#endif
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
   }
-#endif
   b->prefetched = false; b->res_current = false;
 }
 
@@ -809,6 +817,7 @@ void run_finalize(snf_batch_impl* b) {
     LAUNCH_Q(e1_finalize, v, nc, 0);
   }
 #ifndef SNF_EMU
+  if (b->fused && nc <= ((int64_t)1 << 22))   // e3b sums every preceding 256-call tile directly
   {  // E2 sizes -> offsets -> E3 work items in two launches (snf_fused.h) instead of a size kernel, five scans and E3
     const unsigned grid = (unsigned)((nc + 255) / 256);
     if (b->time_all) { Scope _s(b, "e2a_sizes", 0); hipLaunchKernelGGL(e2a_sizes, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0); }
@@ -818,7 +827,9 @@ void run_finalize(snf_batch_impl* b) {
     else hipLaunchKernelGGL(e3b_offsets, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
   }
-#else
+  else
+#endif
+  {
   LAUNCH(e2_best, v, nc, 0);
   prim_exscan<uint32_t>(b, v.fN, v.pN, nc + 1, "scan_alt");
   prim_exscan<uint32_t>(b, v.fL, v.pL, nc + 1, "scan_cons");
@@ -826,7 +837,7 @@ void run_finalize(snf_batch_impl* b) {
   prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
   prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
   LAUNCH_Q(e3_conslist, v, nc, 0);
-#endif
+  }
   d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
   const int64_t ncons = b->h_cnt->n_cons, alt_total = b->h_cnt->alt_total;

@@ -78,6 +78,18 @@ def test_hip_wide_sort_keys_exact(oracle_mod, monkeypatch):
     assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
 
 
+def test_hip_plain_scan_chains_exact(oracle_mod, monkeypatch):
+    """Batches above 2^25 leads use device-wide scans instead of the fused flag/scan/emit kernel pairs; SNF_NO_FUSE
+    forces that path on a small batch."""
+    monkeypatch.setenv("SNF_NO_FUSE", "1")
+    cfg = SnifflesConfig()
+    tis = [synth.gen_fuzz(800 + k, task_id=k) for k in range(5)]
+    exp = oracle_mod.run(cfg, tis, True)
+    got = run(cfg, tis, True)
+    assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+    assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
+
+
 def test_batches_in_flight_on_host_threads(oracle_mod):
     """bench.py keeps several batch handles in flight from host threads (own streams each): concurrent passes must
     give exactly the results of passes run one after the other."""
