@@ -239,7 +239,9 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       // ---- 5. write the row, column-parallel
       int c_last = c_first;
       if (na) { c_last = c_first + (__builtin_amdgcn_readfirstlane((int)W.aj[na - 1]) - j0); if (c_last > L) c_last = L; }
-      for (int q0 = 0; q0 < L && !(v.ablate & 2); q0 += 64) {
+      // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): its row is never read
+      const bool keep_row = (double)span / (double)L > 0.2;
+      for (int q0 = 0; q0 < L && keep_row && !(v.ablate & 2); q0 += 64) {
         const int q = q0 + lane;
         if (q < L) {
           uint8_t out = '-';
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
           row[q] = out;
         }
       }
-      if (lane == 0) { const uint8_t k = ((double)span / (double)L > 0.2) ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
+      if (lane == 0) { const uint8_t k = keep_row ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       __builtin_amdgcn_wave_barrier();
     }
     SNF_PH(5);
