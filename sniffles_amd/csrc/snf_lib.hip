@@ -436,7 +436,6 @@ void do_upload(snf_batch_impl* b) {
 #ifndef SNF_EMU
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
   v.prof = getenv("SNF_PROF") ? 1 : 0;
-  v.ablate = getenv("SNF_ABLATE") ? atoi(getenv("SNF_ABLATE")) : 0;
 #else
   v.wave_path = 0;
 #endif
@@ -940,16 +939,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   full_sync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
   if (b->h_cnt->overflow) fail("internal: fused-sequence pool overflow");
   if (v.prof) {
-    static const char* ph[32] = {"table", "lookup", "chain", "segments", "runfilter", "rowwrite", "vote", "idle/copy", "kmer-load", "",
-                                 "", "", "", "", "", "", "d1w:header", "d1w:load", "d1w:sort", "d1w:fuse", "d1w:store", "d1w:resplit", "", "",
-                                 "", "", "", "", "", "", "", ""};
     const Counts& c = *b->h_cnt;
-    for (int base = 0; base < 32; base += 16) {
-      unsigned long long tot = 0; for (int k = 0; k < 16; k++) tot += c.prof[base + k];
-      for (int k = 0; k < 16; k++)
-        if (c.prof[base + k])
-          fprintf(stderr, "[SNF_PROF] %-12s %6.2f %%  %12llu ticks\n", ph[base + k], 100.0 * (double)c.prof[base + k] / (double)tot, c.prof[base + k]);
-    }
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
                     "fallback %lld alt bytes %lld | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,

@@ -20,7 +20,6 @@ struct Counts {
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback
-  unsigned long long prof[32]; // SNF_PROF=1: wave-ticks per phase; 0-15 e45w_consensus, 16-31 d1w_refine
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags
   int32_t _pad;
@@ -120,7 +119,6 @@ struct View {
 
   // ---- stage A: binning (sorted position p in [0,N))
   uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
-  int ablate;  // SNF_ABLATE (dev): bitmask of consensus phases to skip (timing experiments only, results invalid)
   int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
   uint32_t *headflag, *headscan;  // [N+1] bin heads in sorted order / exclusive scan (bin ids)
   uint32_t *eligflag, *eligscan;  // [N+1] per bin: seeds a cluster / exclusive scan (seed ids)

@@ -66,8 +66,6 @@ SNF_D int wave_max_incl(int x, int lane) {
 SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
   return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)x));
 }
-// SNF_PROF: per-wave tick accumulators in registers, flushed once at the end of the kernel
-#define SNF_PH(k) do { if (v.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tph; tph = t_; } } while (0)
 
 // CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
 template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW>
@@ -75,8 +73,6 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
   typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS> Lds;
   __shared__ Lds lds;
   constexpr int ROUNDS = MAXPOS / 64;
-  unsigned long long tph = __builtin_readcyclecounter();
-  unsigned long long pacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPRs
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
   // SMALL walks list 1; LARGE walks lists 2..5 (heaviest first) as one index space
@@ -100,12 +96,11 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
     const int skip = cons_skip(v.cfg, L);
     __syncthreads();
-    SNF_PH(7);
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
     __syncthreads();
     const int npos = (int)cons_npos(L, klen, skip);
-    for (int p = tid; p < npos && !(v.ablate & 16); p += 256) {
+    for (int p = tid; p < npos; p += 256) {
       const int i = p * skip;
       const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
       int64_t sl = kmer_slot(kk, SLOTS);
@@ -117,11 +112,10 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       if ((atomicAdd(&lds.pc[sl], 1u) & 0xffffu) == 0) atomicOr(&lds.pc[sl], (uint32_t)i << 16);  // position of the 1st sighting
     }
     __syncthreads();
-    SNF_PH(0);
     typename Lds::Wave& W = lds.w[wid];
     const int64_t r0 = rfl64(d.read_off);
     uint8_t* rows = v.aln + rfl64(d.aln_off);
-    for (int32_t r = wid; r < n_others && !(v.ablate & 64); r += 4) {
+    for (int32_t r = wid; r < n_others; r += 4) {
       const uint8_t* S = v.pool + rfl64(v.crl_off[r0 + r]);
       const int SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
       uint8_t* row = rows + (int64_t)r * L;
@@ -133,13 +127,8 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
         const int p = rd * 64 + lane;
-        kw[rd] = (p < P && !(v.ablate & 8)) ? load_u64(S + p * skip) : 0ull;
+        kw[rd] = (p < P) ? load_u64(S + p * skip) : 0ull;
       }
-      if (v.prof) { unsigned long long x_ = 0;
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) x_ ^= kw[rd];
-        if (x_ == 0x0123456789abcdefull) W.ai[0] = 1;  // forces the loads to have arrived (profiling only)
-        SNF_PH(8); }
       int ncand = 0;
       constexpr int G = ROUNDS < 4 ? ROUNDS : 4;  // rounds probed together: their LDS reads are in flight at once
 #pragma unroll
@@ -170,7 +159,6 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
         }
       }
       __builtin_amdgcn_wave_barrier();
-      SNF_PH(1);
       // ---- 2. monotone chain: accept iff i > every earlier candidate's i (== last accepted i)
       int na = 0, runmax = -1;
       for (int c0 = 0; c0 < ncand; c0 += 64) {
@@ -189,7 +177,6 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
         if (tot > runmax) runmax = tot;
         __builtin_amdgcn_wave_barrier();
       }
-      SNF_PH(2);
       // ---- 3. segments between consecutive anchors
       const int i0 = __builtin_amdgcn_readfirstlane(na ? (int)W.ai[0] : 0), j0 = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[0] : 0);
       const int c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
@@ -202,7 +189,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
           const int fwd_i = i - li; int fwd_j = j - lj;
           if (col + fwd_j > L) fwd_j = L - col;
           uint8_t flag = 0; int cm = 0;
-          if (fwd_i == fwd_j && fwd_j > 0 && !(v.ablate & 4)) {
+          if (fwd_i == fwd_j && fwd_j > 0) {
             const int nfull = j - lj;
             span += nfull;
             // first words of both comparisons issued together (one global round trip instead of two); consecutive
@@ -222,7 +209,6 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
 #pragma unroll
       for (int dd = 32; dd >= 1; dd >>= 1) span += __shfl_xor(span, dd, 64);
       __builtin_amdgcn_wave_barrier();
-      SNF_PH(3);
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360)
       if (lane == 0) {
         int t = 1;
@@ -235,13 +221,12 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
         }
       }
       __builtin_amdgcn_wave_barrier();
-      SNF_PH(4);
       // ---- 5. write the row, column-parallel
       int c_last = c_first;
       if (na) { c_last = c_first + (__builtin_amdgcn_readfirstlane((int)W.aj[na - 1]) - j0); if (c_last > L) c_last = L; }
       // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): its row is never read
       const bool keep_row = (double)span / (double)L > 0.2;
-      for (int q0 = 0; q0 < L && keep_row && !(v.ablate & 2); q0 += 64) {
+      for (int q0 = 0; q0 < L && keep_row; q0 += 64) {
         const int q = q0 + lane;
         if (q < L) {
           uint8_t out = '-';
@@ -259,10 +244,8 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       if (lane == 0) { const uint8_t k = keep_row ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       __builtin_amdgcn_wave_barrier();
     }
-    SNF_PH(5);
     // ---- column vote (consensus.py:365-380) on the rows this workgroup just wrote (still in L2)
     __syncthreads();
-    SNF_PH(7);
     int nkept = 0;
     for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
     nkept = __builtin_amdgcn_readfirstlane(nkept);
@@ -270,7 +253,6 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     for (int q = tid; q < L; q += 256) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
-      if (v.ablate & 1) { if (!(v.ablate & 32)) alt[q] = out; continue; }
       {  // fast path: every character of the column is one of A C G T -> four packed 16-bit counters, one pass
         const uint32_t ACTG = 0x47544341u;  // code (c >> 1) & 3: A 0, C 1, T 2, G 3
         int cd = (bq >> 1) & 3;
@@ -328,10 +310,8 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
       }
       alt[q] = out;
     }
-    SNF_PH(6);
   }
   if (tid == 0 && bytes_acc) atomicAdd(&v.stripes[(CLS * 64 + (blockIdx.x & 63)) * 16], bytes_acc);  // striped: summed by z1_results
-  if (v.prof && lane == 0) for (int k = 0; k < 9; k++) atomicAdd(&v.cnt->prof[k], pacc[k]);
 }
 
 // verbatim ALT of calls with fewer than consensus_min_reads other reads (postprocessing.py:65-66): one wave per call

@@ -65,14 +65,9 @@ struct WaveLds {
 #define SNF_GATHER(x) __shfl((x), src_, SNF_WAVE)
 
 // one block = one wave = one merged cluster per loop iteration (grid-stride over clusters)
-// SNF_PROF: per-wave tick accumulators in registers, flushed once at the end (per-phase atomics on one cache line
-// from every wave would serialise in L2 and distort the very thing they measure)
-#define SNF_PH1(k) do { if (v.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tph; tph = t_; } } while (0)
 __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_unused) {
   __shared__ WaveLds lds;
   const int lane = threadIdx.x;
-  unsigned long long tph = __builtin_readcyclecounter();
-  unsigned long long pacc[6] = {0, 0, 0, 0, 0, 0};
   const snf_config_t& cfg = v.cfg;
   const int64_t n_clusters = v.cnt->n_clusters;
   // software pipeline over this wave's clusters: the header of cluster k+2 and the lead records of cluster k+1 are
@@ -91,7 +86,6 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     if (n <= 0 || n > SNF_WAVE) continue;  // big clusters: thread path (d1_refine with the n > 64 guard)
     const int svtype = grp_svtype(hd.grp);
     const bool act = lane < n;
-    if (v.prof) { if (svtype == 99) lds.perm[0] = 0; SNF_PH1(0); }
     // ---- load one lead per lane
     uint32_t o = 0;
     int32_t ref_start = 0, ref_end = 0, qry_start = 0, qry_end = 0, svlen = 0, seq_len = -1, mate_pos = 0, mate_contig = 0;
@@ -102,7 +96,6 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       ref_end = r.ref_end; qry_start = r.qry_start; qry_end = r.qry_end; qname = r.qname; strand = r.strand;
       mate_pos = r.mate_pos; mate_contig = r.mate_contig; is_first = r.first;
     }
-    if (v.prof) { if (ref_start == -12345 && svlen == 77) lds.perm[0] = 0; SNF_PH1(1); }
     int m = n;                 // number of leads after fusion
     int32_t f_orig = (int32_t)o, f_svlen = svlen, f_seq_len = seq_len, f_lp = lane; int64_t f_seq_off = seq_off;
 
@@ -125,7 +118,6 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int64_t s_seq_off = SNF_GATHER(seq_off);
       const int s_strand = SNF_GATHER(strand);
       const uint32_t s_o = SNF_GATHER(o); const int s_lp = SNF_GATHER(lane);
-      SNF_PH1(2);
       // neighbour r-1
       const int p_fa = __shfl_up(s_fa, 1, SNF_WAVE);
       const int32_t p_rs = __shfl_up(s_rs, 1, SNF_WAVE), p_re = __shfl_up(s_re, 1, SNF_WAVE);
@@ -192,13 +184,11 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       f_seq_off = __shfl(t_seq_off, src2, SNF_WAVE);
     }
     const bool fact = lane < m;
-    SNF_PH1(3);
     if (fact) {
       v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen; v.F_lpos[lo + lane] = lo + f_lp;
       v.F_seq_len[lo + lane] = f_seq_len; v.F_seq_off[lo + lane] = f_seq_off;
     }
 
-    SNF_PH1(4);
     if (svtype == SNF_BND) {
       // ---- resplit_bnd: group by (mate_contig, is_first) in first-appearance order, chain 1-kb bins
       if (m <= 1 || cfg.dev_no_resplit) {
@@ -288,10 +278,8 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       if (fact) v.FI[lo + lds.seg_out[sidx] + (lane - lds.seg_start[sidx])] = lo + s_k;
       if (lane < lds.n_rc) rc_emit(v, lo + lds.rc_start[lane], lds.rc_len[lane], (int32_t)c, true);
       __syncthreads();
-      SNF_PH1(5);
     }
   }
-  if (v.prof && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&v.cnt->prof[16 + k], pacc[k]);
 }
 
 }  // namespace snf
