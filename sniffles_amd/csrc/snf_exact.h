@@ -202,11 +202,12 @@ SNF_HD int64_t bound_top_i32(const int32_t* a, const int32_t* top, int64_t lo, i
 }
 
 // numpy's pairwise float64 summation (np.sum / np.nanmean, used by parallel.py:214), gather form:
-// element i is get(i).  Iterative restatement of the recursion (depth <= 40).
-template <class Get>
+// element i is get(i).  Iterative restatement of the recursion; DEPTH = frames needed: n <= 128 * 2^(DEPTH-1)
+// (one frame for n <= 128: the wave kernels only see clusters of <= 64 leads and must not carry a 1.5 KB stack)
+template <int DEPTH, class Get>
 SNF_HD double np_pairwise_sum(Get get, int64_t n) {
   struct Fr { int64_t lo, n; int state; double left; };
-  Fr st[48];
+  Fr st[DEPTH + 1];
   int sp = 0;
   st[0] = Fr{0, n, 0, 0.0};
   double ret = 0.0;

@@ -1107,7 +1107,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 6;
       const int o1 = getenv("SNF_OCC_E1") ? atoi(getenv("SNF_OCC_E1")) : 5;
       b->k_d2w = o2 >= 8 ? d2w_call<8> : o2 == 6 ? d2w_call<6> : o2 == 5 ? d2w_call<5> : d2w_call<4>;
-      (void)o1; b->k_e1w = e1w_finalize<4>;  // higher-occupancy variants of e1w hit a register-allocation bug of this hipcc (odd-aligned 64-bit scratch reload)
+      b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);

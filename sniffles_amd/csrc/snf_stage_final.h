@@ -313,12 +313,13 @@ struct NmGet {
   }
 };
 
+template <int DEPTH>
 SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int task) {
   const snf_config_t& cfg = v.cfg;
   if (!cfg.mode_call_sample) return;
   int64_t n = x.fn, cnt = 0;
   for (int64_t i = 0; i < n; i++) { double nm = v.in_nm[(uint32_t)v.F_orig[v.FI[x.flo + i]]]; if (nm == nm) cnt++; }
-  double sv_nm = np_pairwise_sum(NmGet{v, x}, n) / (double)cnt;  // np.nanmean
+  double sv_nm = np_pairwise_sum<DEPTH>(NmGet{v, x}, n) / (double)cnt;  // np.nanmean
   if (sv_nm > cfg.genotype_error || n <= 3) return;
   if (!c.ph_set || !c.ph_hp_pass) return;
   int hp = c.ph_hp;
@@ -343,6 +344,8 @@ SNF_HD void store_final_fields(snf_call_t& dst, const snf_call_t& c) {
 }
 
 // scalar tail of finalize_candidates for one call, given the lead aggregates
+// DEPTH: recursion frames of the pairwise sum (1 when the call has <= 128 leads, 26 covers 2^31)
+template <int DEPTH>
 SNF_HD void finalize_call(const View& v, snf_call_t& c, const CallX& x, const LeadAgg& g, int task) {
   const snf_config_t& cfg = v.cfg;
   c.qc = c.qc && qc_sv(v, c, g);
@@ -353,7 +356,7 @@ SNF_HD void finalize_call(const View& v, snf_call_t& c, const CallX& x, const Le
   c.qc = c.qc && qc_sv_post_annotate(v, c, g, task);
   bool phasing_rescue = c.svtype != SNF_BND && iabs64(c.svlen) <= cfg.dev_maxsvlen_extra &&
                         c.support >= (int)((double)cfg.dev_minreads_extra * 0.60);
-  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing(v, c, x, task);
+  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing<DEPTH>(v, c, x, task);
 }
 
 SNF_HD void e1_finalize_body(int64_t i, const View& v) {
@@ -366,7 +369,7 @@ SNF_HD void e1_finalize_body(int64_t i, const View& v) {
   snf_call_t c = cref;
   LeadAgg g;
   collect_agg(v, x, task, &g);
-  finalize_call(v, c, x, g, task);
+  finalize_call<26>(v, c, x, g, task);
   store_final_fields(cref, c);
 }
 

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
     }
     if (lane == 0) {
       snf_call_t c = v.calls[i];
-      finalize_call(v, c, x, g, task);
+      finalize_call<1>(v, c, x, g, task);   // x.fn <= 64 leads
       store_final_fields(v.calls[i], c);
     }
   }
