@@ -129,6 +129,17 @@ def test_hip_matches_oracle_on_scaled_genome(oracle_mod):
     assert records.records(got, tis, "final") == records.records(exp, tis, "final")
 
 
+def test_hip_matches_oracle_full_size_contigs(oracle_mod):
+    """chr20-chr22 at their full GRCh38 lengths, 30x (BASELINE configs[0] shape and two more contigs) in one batch:
+    every record of every call identical to the oracle, coverage averages bit-equal."""
+    tis = [synth.gen_task(i, c, synth.GRCH38[c], 30, 1) for i, c in enumerate(["chr20", "chr21", "chr22"])]
+    cfg = SnifflesConfig()
+    exp = oracle_mod.run(cfg, tis, True)
+    got = run(cfg, tis, True)
+    assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+    assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
+
+
 def test_hip_matches_oracle_hifi_60x_and_mosaic(oracle_mod):
     tis = genome(0.004, cov=60, seed=2, err=0.005)
     cfg = SnifflesConfig()
