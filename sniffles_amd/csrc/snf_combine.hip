@@ -1,15 +1,17 @@
 // snf_combine.hip - multi-sample combine: cluster.resolve_block_groups (cluster.py:356-390) with
 // SVGroup.align_call (sv.py:280-289) and the running means of SVGroup.add_candidate (sv.py:297-318).
 //
-// One flush window = one problem = one thread: the greedy nearest-group assignment is sequential (every
-// accepted candidate moves its group's means), windows are <= a few dozen candidates, and windows of different
-// contigs / SV types are independent - so the batch dimension is the parallel one.  The edit distance is
-// evaluated on demand, only for (group, candidate) pairs that pass the distance gates, with the bit-parallel
-// Myers blocks of snf_myers.h.
+// One flush window = one problem: the greedy nearest-group assignment is sequential (every accepted candidate
+// moves its group's means), windows are <= a few dozen candidates, and windows of different contigs / SV types are
+// independent - so the batch dimension is the parallel one.  The edit distance is evaluated on demand, only for
+// (group, candidate) pairs that pass the distance gates, with the bit-parallel Myers blocks of snf_myers.h: on the
+// GPU one wave per window (lane 0 decides, all lanes align); the thread-per-window body is the emulation / reference
+// form (SNF_COMBINE_THREAD=1 selects it on the GPU).
 #include "snf_myers.h"
 #include "../../include/sniffles_amd.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -119,6 +121,103 @@ SNF_HD void combine_problem_body(int64_t p, const CombineView& v) {
   }
 }
 
+#ifndef SNF_EMU
+// gfx950: one WAVE per flush window.  Lane 0 runs the sequential greedy assignment (combine_problem_body's logic);
+// whenever a (group, candidate) pair passes the distance gates, all 64 lanes evaluate its edit distance together
+// (ed_wave_pair: lane = 64-row block, anti-diagonal schedule) - the alignment is >99 % of the work of a window with
+// kilobase insertions, and one thread doing it serially takes tens of milliseconds per pair.
+__global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, int64_t np) {
+  const int lane = threadIdx.x;
+  const snf_config_t& cfg = v.cfg;
+  for (int64_t p = blockIdx.x; p < np; p += gridDim.x) {
+    const int64_t c0 = v.c_off[p], g0 = v.g_off[p], s0 = v.s_off[p];
+    const int nc = v.n_cands[p], ng0 = v.n_groups[p], nw = v.n_words[p], svtype = v.svtype[p];
+    const int32_t *pos = v.pos + c0, *svlen = v.svlen + c0, *support = v.support + c0, *sample = v.sample_id + c0;
+    const int32_t *mctg = v.mate_contig + c0, *mpos = v.mate_pos + c0;
+    double *gpos = v.st_pos + s0, *glen = v.st_len + s0, *gmate = v.st_mate + s0;
+    int32_t *gsize = v.st_size + s0, *gmc = v.st_mctg + s0;
+    int64_t *galo = v.st_alt_lo + s0, *gahi = v.st_alt_hi + s0; uint8_t* gsrc = v.st_alt_src + s0;
+    uint64_t* bits = v.st_bits + v.w_off[p];
+    int32_t* order = v.order + c0;
+    int8_t* carry = v.carry + v.k_off[p];
+    int32_t* out = v.out_group + c0;
+    int ng = ng0;
+    if (lane == 0) {
+      for (int g = 0; g < ng0; g++) {
+        gpos[g] = v.g_pos_mean[g0 + g]; glen[g] = v.g_len_mean[g0 + g]; gmate[g] = v.g_mate_mean[g0 + g];
+        gsize[g] = v.g_size[g0 + g]; gmc[g] = v.g_mate_contig[g0 + g];
+        galo[g] = v.g_alt_off[g0 + g]; gahi[g] = v.g_alt_off[g0 + g + 1]; gsrc[g] = 1;
+        for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
+        for (int64_t k = v.g_samples_off[g0 + g]; k < v.g_samples_off[g0 + g + 1]; k++) {
+          int32_t sid = v.g_samples[k];
+          bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
+        }
+      }
+      for (int i = 0; i < nc; i++) order[i] = i;
+      sort_inplace(order, (int64_t)nc, LessSupportDesc{support});   // sorted(key=support, reverse=True) is stable
+    }
+    for (int oi = 0; oi < nc; oi++) {
+      int c = 0, sid = 0, best = -1; double best_dist = INFINITY, alen = 0;
+      if (lane == 0) { c = order[oi]; sid = sample[c]; alen = fabs((double)svlen[c]); }
+      const int ng_u = __shfl(ng, 0, 64);
+      for (int g = 0; g < ng_u; g++) {
+        int need = 0; double dist = 0;
+        unsigned long long pa = 0, pb = 0; long long la = 0, lb = 0;
+        if (lane == 0) {
+          if (svtype == SNF_BND) {
+            dist = fabs(gpos[g] - (double)pos[c]) + fabs(gmate[g] - (double)mpos[c]);
+            if (dist < best_dist && dist <= (double)(cfg.cluster_merge_bnd * 2) && gmc[g] == mctg[c]) {
+              if (!cfg.combine_separate_intra || !((bits[(int64_t)g * nw + (sid >> 6)] >> (sid & 63)) & 1)) { best = g; best_dist = dist; }
+            }
+          } else {
+            dist = fabs(gpos[g] - (double)pos[c]) + fabs(fabs(glen[g]) - alen);
+            const double minlen = fabs(glen[g]) < alen ? fabs(glen[g]) : alen;
+            if (minlen > 0 && dist < best_dist && dist <= (double)cfg.combine_match * sqrt(minlen) && dist <= (double)cfg.combine_match_max) {
+              if (!(cfg.combine_separate_intra && ((bits[(int64_t)g * nw + (sid >> 6)] >> (sid & 63)) & 1))) {
+                if (cfg.combine_pctseq != 0.0) {  // SVGroup.align_call: needs the edit distance -> whole wave
+                  need = 1;
+                  pa = (unsigned long long)((gsrc[g] ? v.g_alt_pool : v.alt_pool) + galo[g]); la = gahi[g] - galo[g];
+                  pb = (unsigned long long)(v.alt_pool + v.alt_off[c0 + c]); lb = v.alt_off[c0 + c + 1] - v.alt_off[c0 + c];
+                } else { best = g; best_dist = dist; }
+              }
+            }
+          }
+        }
+        need = __shfl(need, 0, 64);
+        if (need) {
+          pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64);
+          const int64_t d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
+          if (lane == 0 && ((glen[g] - (double)d) / glen[g]) > cfg.combine_pctseq) { best = g; best_dist = dist; }
+        }
+      }
+      if (lane == 0) {
+        if (best < 0) {  // SVGroup.from_candidate
+          const int g = ng++;
+          gpos[g] = (double)pos[c]; glen[g] = fabs((double)svlen[c]); gmate[g] = (double)mpos[c];
+          gsize[g] = 1; gmc[g] = mctg[c];
+          galo[g] = v.alt_off[c0 + c]; gahi[g] = v.alt_off[c0 + c + 1]; gsrc[g] = 0;
+          for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
+          bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
+          out[c] = g;
+        } else {         // SVGroup.add_candidate: multiply, add, append, divide
+          const int g = best;
+          const double n = (double)gsize[g];
+          gpos[g] *= n; glen[g] *= n;
+          gpos[g] += (double)pos[c]; glen[g] += fabs((double)svlen[c]);
+          if (svtype == SNF_BND) { gmate[g] *= n; gmate[g] += (double)mpos[c]; }
+          gsize[g]++;
+          const double n1 = (double)gsize[g];
+          gpos[g] /= n1; glen[g] /= n1;
+          bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
+          if (svtype == SNF_BND) gmate[g] /= n1;
+          out[c] = g;
+        }
+      }
+    }
+  }
+}
+#endif
+
 }  // namespace snf
 using namespace snf;
 SNF_KERNEL(combine_problem, CombineView)
@@ -220,7 +319,8 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   std::vector<int32_t> h_out((size_t)NC + 1);
   if (ok) {
 #ifndef SNF_EMU
-    hipLaunchKernelGGL(combine_problem, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, 0, v, np);
+    if (getenv("SNF_COMBINE_THREAD")) hipLaunchKernelGGL(combine_problem, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, 0, v, np);
+    else hipLaunchKernelGGL(combine_problem_wave, dim3((unsigned)(np < 65536 ? np : 65536)), dim3(64), 0, 0, v, np);
     if (hipDeviceSynchronize() != hipSuccess) ok = false;
     if (ok && NC && hipMemcpy(h_out.data(), d_out, (size_t)NC * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
 #else

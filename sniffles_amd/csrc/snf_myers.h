@@ -67,4 +67,48 @@ SNF_HD int64_t ed_serial(const uint8_t* A, int64_t la, const uint8_t* B, int64_t
   return unpad_score(score, Pv, Mv, (int)(nb * 64 - m));
 }
 
+#if !defined(SNF_EMU) && defined(__HIPCC__)
+// the same distance computed by one whole wave (all 64 lanes must call it together): lane = 64-row block of the current
+// 64-block pass, anti-diagonal schedule (lane l works on column t - l at step t and takes hin from lane l-1 by a
+// shuffle); patterns of more than 64 blocks take several passes linked through `carry` (>= max(la, lb) bytes)
+__device__ inline int64_t ed_wave_pair(const uint8_t* A, int64_t la, const uint8_t* B, int64_t lb, int8_t* carry) {
+  const int lane = (int)(threadIdx.x & 63);
+  const uint8_t *P = A, *T = B; int64_t m = la, n = lb;
+  if (la > lb) { P = B; m = lb; T = A; n = la; }
+  if (m == 0) return n;
+  const int64_t nb = (m + 63) / 64;
+  int64_t score = nb * 64;
+  uint64_t fPv = ~0ull, fMv = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += 64) {
+    const int nl = (int)(nb - b0 < 64 ? nb - b0 : 64);   // lanes (blocks) active in this pass
+    const int64_t blk = b0 + lane;
+    uint64_t planes[8], valid = 0, Pv = ~0ull, Mv = 0;
+    for (int k = 0; k < 8; k++) planes[k] = 0;
+    if (lane < nl) {
+      const int cnt = (int)(m - blk * 64 < 64 ? m - blk * 64 : 64);
+      block_planes(P + blk * 64, cnt, planes, &valid);
+    }
+    const bool glast = lane == nl - 1 && b0 + nl == nb;    // owns the last block of the pattern
+    int hout = 0;
+    const int64_t steps = n + nl - 1;
+    for (int64_t t = 0; t < steps; t++) {
+      const int up = __shfl_up(hout, 1, 64);               // hout of the block above, previous step
+      const int64_t j = t - lane;
+      if (lane < nl && j >= 0 && j < n) {
+        const int hin = lane == 0 ? (b0 == 0 ? 1 : (int)carry[j]) : up;
+        hout = advance_block(Pv, Mv, eq_mask(planes, valid, T[j]), hin);
+        if (glast) score += hout;
+        else if (lane == nl - 1) carry[j] = (int8_t)hout;  // feeds block b0+64 in the next pass
+      }
+    }
+    if (glast) { fPv = Pv; fMv = Mv; }
+    __syncthreads();   // one-wave workgroups: orders the carry bytes between passes
+  }
+  const int owner = (int)((nb - 1) & 63);
+  const int64_t sc = __shfl(score, owner, 64);
+  const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
+  return unpad_score(sc, oPv, oMv, (int)(nb * 64 - m));
+}
+#endif
+
 }  // namespace snf

@@ -51,39 +51,8 @@ __global__ void __launch_bounds__(64) ed_wave(const EdView v, int64_t n_items) {
     const int64_t pi = v.list[it];
     const uint8_t *P, *T; int64_t m, n;
     pair_strings(v, pi, &P, &m, &T, &n);
-    int8_t* carry = v.carry + v.carry_off[pi];
-    const int64_t nb = (m + 63) / 64;
-    int64_t score = nb * 64;
-    uint64_t fPv = ~0ull, fMv = 0;
-    for (int64_t b0 = 0; b0 < nb; b0 += 64) {
-      const int nl = (int)(nb - b0 < 64 ? nb - b0 : 64);   // lanes (blocks) active in this pass
-      const int64_t blk = b0 + lane;
-      uint64_t planes[8], valid = 0, Pv = ~0ull, Mv = 0;
-      for (int k = 0; k < 8; k++) planes[k] = 0;
-      if (lane < nl) {
-        const int cnt = (int)(m - blk * 64 < 64 ? m - blk * 64 : 64);
-        block_planes(P + blk * 64, cnt, planes, &valid);
-      }
-      const bool glast = lane == nl - 1 && b0 + nl == nb;    // owns the last block of the pattern
-      int hout = 0;
-      const int64_t steps = n + nl - 1;
-      for (int64_t t = 0; t < steps; t++) {
-        const int up = __shfl_up(hout, 1, 64);               // hout of the block above, previous step
-        const int64_t j = t - lane;
-        if (lane < nl && j >= 0 && j < n) {
-          const int hin = lane == 0 ? (b0 == 0 ? 1 : (int)carry[j]) : up;
-          hout = advance_block(Pv, Mv, eq_mask(planes, valid, T[j]), hin);
-          if (glast) score += hout;
-          else if (lane == nl - 1) carry[j] = (int8_t)hout;  // feeds block b0+64 in the next pass
-        }
-      }
-      if (glast) { fPv = Pv; fMv = Mv; }
-      __syncthreads();
-    }
-    const int owner = (int)((nb - 1) & 63);
-    const int64_t sc = __shfl(score, owner, 64);
-    const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
-    if (lane == 0) v.out[pi] = (int32_t)unpad_score(sc, oPv, oMv, (int)(nb * 64 - m));
+    const int64_t d = ed_wave_pair(P, m, T, n, v.carry + v.carry_off[pi]);
+    if (lane == 0) v.out[pi] = (int32_t)d;
   }
 }
 #endif
