@@ -75,6 +75,8 @@ def main():
     n_c = sum(len(w[1]) for w in windows)
     cluster.resolve_block_groups_batch([("INS", list(c), []) for _, c, _ in windows[:8]], cfg)   # warm-up
     t0 = time.perf_counter(); groups = cluster.resolve_block_groups_batch(windows, cfg); t_gpu = time.perf_counter() - t0
+    keep2 = []; packed = [cluster.pack_problem(svt, c, [], keep2) for svt, c, _ in windows]
+    t0 = time.perf_counter(); lib.combine_resolve_batch(cfg, [q for q, _ in packed]); t_call = time.perf_counter() - t0
     # parity of a sample of the windows against the oracle's serial resolve (same packed problems)
     keep = []; n_chk = 150; t_or = 0.0
     for svt, cands, _ in windows[:n_chk]:
@@ -85,7 +87,7 @@ def main():
         t1 = time.perf_counter(); oracle.combine_resolve(cfg, q2); t_or += time.perf_counter() - t1
         assert got == list(out_or)
     res["resolve_block_groups"] = dict(oracle_windows_checked=n_chk, oracle_windows_per_s=round(n_chk / t_or, 1),
-windows=n_windows, candidates=n_c, gpu_s_incl_pack_and_replay=round(t_gpu, 3),
+windows=n_windows, candidates=n_c, gpu_s_incl_pack_and_replay=round(t_gpu, 3), c_abi_call_s_incl_h2d_kernel_d2h=round(t_call, 4),
                                        windows_per_s=round(n_windows / t_gpu), candidates_per_s=round(n_c / t_gpu),
                                        groups=sum(len(g) for g in groups))
     print(json.dumps(res))
