@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every contig (debug only; invalid as a result)")
+    ap.add_argument("--genomes", type=int, default=1,
+                    help="genome replicas per batch and rank (SURVEY.md 8d scale knob; the headline configuration is 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU (host threads, each with its own batch handle and streams): the "
@@ -86,10 +88,11 @@ def main():
     my = shard_tasks(world)[rank]
     t0 = time.time()
     tasks = []
-    for k, (rep, ci, c) in enumerate(my):
-        L = max(200000, int(synth.GRCH38[c] * args.scale))
-        ti = synth.gen_task(rep * 24 + ci, c, L, args.coverage, seed=1 + rep)
-        tasks.append(ti)
+    for g in range(max(1, args.genomes)):
+        for k, (rep, ci, c) in enumerate(my):
+            L = max(200000, int(synth.GRCH38[c] * args.scale))
+            ti = synth.gen_task((g * world + rep) * 24 + ci, c, L, args.coverage, seed=1 + rep + 1000 * g)
+            tasks.append(ti)
     n_sig = sum(t.n_leads for t in tasks)
     n_reads = sum(t.n_reads for t in tasks)
     seq_bytes = sum(int(t.seq_pool.nbytes) for t in tasks)
@@ -229,7 +232,7 @@ def main():
                    data="synthetic",
                    config=dict(workload="30x ONT HG002-shaped whole-genome germline, 24 GRCh38 contigs per replica "
                                         "(BASELINE.json configs[1]), synthetic signature tables (SURVEY.md 8d)",
-                               replicas=world, tasks=24 * world, coverage=args.coverage, scale=args.scale,
+                               replicas=world, genomes_per_batch=max(1, args.genomes), tasks=24 * world * max(1, args.genomes), coverage=args.coverage, scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL all_gather of call records",
                                batches_in_flight_per_gpu=W,
