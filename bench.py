@@ -4,12 +4,12 @@
 One "step" = one full pass of the hot path (Task.call_candidates + Task.finalize_candidates of every
 contig task of the workload: binning, clustering, candidate calls, coverage, QC, genotyping, phasing,
 INS consensus) with the signature tables already resident in HBM, INCLUDING the device->host copy of
-the call records / ALT pool and, for N > 1, the RCCL all-gather of the per-rank call records.
+the call records / ALT pool and, for N > 1, the RCCL gather of the per-rank call records on rank 0.
 
 Workload at N = 1: BASELINE.json configs[1], "30x ONT HG002 whole-genome germline" restated as a seeded
 synthetic signature set (24 GRCh38 contigs).  N > 1: weak scaling - N genome replicas
 (seed 1..N), the 24*N contig tasks sharded longest-first over the ranks (contigs are independent,
-SURVEY.md 8e); the only collective is the final gather.
+SURVEY.md 8e); the only collective is the gather of the call records on rank 0 (counts first, then the records).
 
 Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -106,15 +106,62 @@ def main():
 
     cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
     if use_dist:
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # all_gather_into_tensor needs equal sizes on every rank
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # one capacity on every rank
     cap_calls = int(cap_t.item())
     rec_bytes = abi.CALL_DTYPE.itemsize
     if use_dist:
         sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(W)]
         count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
-        gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda")
+        # the records are gathered on rank 0 only (one gather at the end; the parent writes the output)
+        gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") if rank == 0 else None
         counts = torch.zeros(world, dtype=torch.int64, device="cuda")
-    coll_lock = threading.Lock()  # one collective at a time per rank; every pass issues the same-sized gather
+        counts_h = torch.zeros(world, dtype=torch.int64).pin_memory()
+    # Collectives run on ONE communication thread per rank, in the order the passes finish: a worker thread exports its
+    # records (device-to-device) into the handle's send buffer, queues the handle and goes on with its next pass; the
+    # gather overlaps that pass.  Every rank issues the same (counts, records) sequence, so the order matches everywhere.
+    import queue
+    comm_q = queue.Queue()
+    send_free = [threading.Event() for _ in range(W)]
+    for ev in send_free:
+        ev.set()
+    comm_err = []
+
+    def comm_loop():
+        try:
+            torch.cuda.set_device(local_rank)
+            while True:
+                item = comm_q.get()
+                if item is None:
+                    comm_q.task_done()
+                    return
+                w, nexp = item
+                count_t.fill_(nexp)
+                dist.all_gather_into_tensor(counts, count_t)          # 8 bytes per rank
+                counts_h.copy_(counts, non_blocking=True)
+                torch.cuda.current_stream().synchronize()              # (releases the GIL while it waits)
+                nmax = int(counts_h.max()) * rec_bytes                 # every rank sends the same, smallest sufficient size
+                chunk = sends[w][:nmax]
+                if rank == 0:
+                    dist.gather(chunk, gather_list=[gathered[r * nmax:(r + 1) * nmax] for r in range(world)], dst=0)
+                else:
+                    dist.gather(chunk, dst=0)
+                torch.cuda.current_stream().synchronize()              # the send buffer may be reused
+                send_free[w].set()
+                comm_q.task_done()
+        except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
+            comm_err.append(e)
+            for ev in send_free:
+                ev.set()
+            while True:   # keep draining so that queue.join() cannot hang
+                try:
+                    comm_q.get_nowait(); comm_q.task_done()
+                except queue.Empty:
+                    break
+
+    comm_thread = None
+    if use_dist:
+        comm_thread = threading.Thread(target=comm_loop, daemon=True)
+        comm_thread.start()
 
     phase_s = [0.0, 0.0, 0.0, 0.0]
 
@@ -131,17 +178,18 @@ def main():
         if w == 0:
             phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
         if use_dist:
-            with coll_lock:
-                torch.cuda.set_device(local_rank)
-                nexp = batch.export_calls_device(sends[w].data_ptr(), cap_calls)
-                batch.sync()
-                count_t.fill_(nexp)
-                dist.all_gather_into_tensor(counts, count_t)
-                dist.all_gather_into_tensor(gathered, sends[w])
+            send_free[w].wait()                                        # the previous gather of this handle has left the buffer
+            send_free[w].clear()
+            nexp = batch.export_calls_device(sends[w].data_ptr(), cap_calls)
+            batch.sync()                                               # the copy is on the handle's stream
+            comm_q.put((w, nexp))
         return n
 
     def barrier():
         if use_dist:
+            comm_q.join()                                              # every queued gather has completed
+            if comm_err:
+                raise comm_err[0]
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,6 +236,7 @@ def main():
             step(0)
         torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t1) / 5 * 1e3
+    barrier()   # also drains the communication thread before the main thread issues collectives again
     timings_alone = dict((k[0], k[1]) for k in batches[0].timings()) if lat_ms else {}
 
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -234,7 +283,7 @@ def main():
                                         "(BASELINE.json configs[1]), synthetic signature tables (SURVEY.md 8d)",
                                replicas=world, genomes_per_batch=max(1, args.genomes), tasks=24 * world * max(1, args.genomes), coverage=args.coverage, scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
-                               calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL all_gather of call records",
+                               calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL gather of the call records on rank 0",
                                batches_in_flight_per_gpu=W,
                                ms_per_pass_one_batch_in_flight=(round(lat_ms, 3) if lat_ms else None),
                                gen_s=round(t_gen, 2), upload_s=round(t_upload, 2),
@@ -245,6 +294,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if comm_thread is not None:
+        comm_q.put(None)
+        comm_thread.join(timeout=30)
     for bb in batches:
         bb.close()
     if use_dist:
