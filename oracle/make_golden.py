@@ -74,3 +74,68 @@ if __name__ == "__main__":
     sel = set(sys.argv[1:])
     main(sel)
     main_combine(sel)
+
+
+def main_consensus():
+    """Golden vectors for seam B4: the reference's own consensus.novel_from_reads on seeded random problems."""
+    import numpy as np
+    import ref_harness as rh
+    ref = rh.load_reference()
+    rng = np.random.default_rng(20260924)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    odd = np.frombuffer(b"ACGTNacgtR", dtype=np.uint8)
+
+    class L:  # only .seq is read
+        def __init__(self, seq):
+            self.seq = seq
+
+    def mutate(a, rate, indel=0.06):
+        # mostly substitutions: the reference only uses anchors within 6 positions of the diagonal
+        out = []
+        for ch in a:
+            u = rng.random()
+            if u < rate * indel:
+                continue
+            if u < 2 * rate * indel:
+                out.append(int(alpha[rng.integers(4)]))
+            out.append(int(alpha[rng.integers(4)]) if u < rate else int(ch))
+        return bytes(out)
+
+    cases_ = []
+    for k in range(160):
+        Lb = int(rng.choice([7, 20, 46, 90, 150, 320, 499, 520, 800, 1500, 3000, 6100]))
+        if k % 17 == 0:
+            Lb = int(rng.integers(1, 40))
+        base = alpha[rng.integers(0, 4, Lb)]
+        if k % 9 == 0:   # low complexity: repeated k-mers (taboo anchors)
+            base = np.tile(alpha[rng.integers(0, 4, 5)], Lb // 5 + 1)[:Lb]
+        true = bytes(base.tolist())
+        best = mutate(true, float(rng.choice([0.0, 0.03, 0.08]))) or true   # the best read has errors of its own
+        Lb = len(best)
+        n_others = int(rng.choice([0, 1, 2, 4, 5, 8, 12, 20, 40]))
+        rate = float(rng.choice([0.0, 0.02, 0.05, 0.15]))
+        others = []
+        for _ in range(n_others):
+            o = mutate(true, rate)
+            if rng.random() < 0.15:   # unrelated read
+                o = bytes(alpha[rng.integers(0, 4, max(1, int(Lb * rng.uniform(0.5, 1.5))))].tolist())
+            if rng.random() < 0.1:    # odd characters
+                o = bytes(int(odd[rng.integers(odd.shape[0])]) if rng.random() < 0.01 else c for c in o)
+            if rng.random() < 0.1:
+                o = o[: max(1, len(o) // 2)]
+            others.append(o)
+        klen = 6
+        skip = 3 + int(Lb * (1.0 / 500.0))
+        if k % 13 == 0:
+            skip = int(rng.integers(1, 9))
+            if Lb / skip > 450:      # stay inside the limits of the workgroup kernels (500 sampled positions)
+                skip = 3 + int(Lb * (1.0 / 500.0))
+        exp = ref.consensus.novel_from_reads(L(best.decode("latin-1")), [L(o.decode("latin-1")) for o in others], klen=klen,
+                                             skip=skip, skip_repetitive=skip)
+        cases_.append(dict(best=best.decode("latin-1"), others=[o.decode("latin-1") for o in others], klen=klen, skip=skip,
+                           expected=exp))
+    doc = dict(case="consensus_novel_from_reads", n=len(cases_), problems=cases_)
+    with gzip.GzipFile(os.path.join(ROOT, "tests", "golden", "consensus_novel_from_reads.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+    changed = sum(1 for c in cases_ if c["expected"] != c["best"])
+    print(f"consensus_novel_from_reads: {len(cases_)} problems, {changed} with a consensus that differs from the best read")

@@ -1044,6 +1044,74 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
 
 }  // namespace
 
+namespace {
+void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,
+                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int64_t* others_index,
+                        const int64_t* others_off, const int32_t* others_len, uint8_t* out_pool, const int64_t* out_off) {
+    if (n_problems <= 0) return;
+    if (!seq_pool || !best_off || !best_len || !skip || !others_index || !others_off || !others_len || !out_pool || !out_off)
+      fail("snf_consensus_batch: null argument");
+#ifdef SNF_EMU
+    (void)device; (void)klen; (void)seq_pool_len;
+    fail("snf_consensus_batch needs the HIP build");
+#else
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) fail("no such HIP device");
+    SNF_HIP(hipSetDevice(device));
+    if (seq_pool_len > 0 && memchr(seq_pool, '-', (size_t)seq_pool_len)) fail("sequences must not contain '-'");
+    const int64_t np = n_problems, n_reads = others_index[np];
+    std::vector<ConsDesc> descs((size_t)np);
+    std::vector<int32_t> lists[6];
+    Counts hc{};
+    int64_t aln_total = 0, alt_total = 0;
+    for (int64_t p = 0; p < np; p++) {
+      const int64_t L = best_len[p]; const int64_t no = others_index[p + 1] - others_index[p];
+      if (L < 0 || no < 0 || best_off[p] < 0 || best_off[p] + L > seq_pool_len) fail("best sequence outside the pool");
+      if (out_off[p + 1] - out_off[p] != L) fail("out_off must be the prefix sums of best_len");
+      for (int64_t k = others_index[p]; k < others_index[p + 1]; k++)
+        if (others_len[k] < 0 || others_off[k] < 0 || others_off[k] + others_len[k] > seq_pool_len) fail("other sequence outside the pool");
+      const int cls = cons_class_of(1, klen, skip[p], L, (int32_t)no);
+      if (cls == 0) fail("problem exceeds the limits of the workgroup consensus kernels (see sniffles_amd.h)");
+      ConsDesc d{};
+      d.best_off = best_off[p]; d.alt_off = out_off[p]; d.aln_off = aln_total; d.read_off = others_index[p];
+      d.L = (int32_t)L; d.n_others = (int32_t)no; d.skip = skip[p]; d.cls = cls;
+      descs[(size_t)p] = d;
+      int lid = cls;
+      if (cls == 2) { const int64_t work = no * L; lid = work >= 32768 ? 2 : work >= 16384 ? 3 : work >= 8192 ? 4 : 5; }
+      lists[lid].push_back((int32_t)p); hc.n_cls[lid]++;
+      aln_total += no * L; alt_total += L;
+    }
+    std::vector<void*> frees;
+    auto dev = [&](size_t bytes) { void* q = nullptr; SNF_HIP(hipMalloc(&q, bytes ? bytes : 1)); frees.push_back(q); return q; };
+    auto up = [&](const void* h, size_t bytes) { void* q = dev(bytes); if (bytes) SNF_HIP(hipMemcpy(q, h, bytes, hipMemcpyHostToDevice)); return q; };
+    struct Guard { std::vector<void*>& f; ~Guard() { for (void* q : f) (void)hipFree(q); } } guard{frees};
+    View v{};
+    v.cfg.consensus_kmer_len = klen;
+    v.wave_path = 1;
+    uint8_t* dpool = (uint8_t*)dev((size_t)seq_pool_len + 32);
+    SNF_HIP(hipMemset(dpool, 0, (size_t)seq_pool_len + 32));
+    if (seq_pool_len) SNF_HIP(hipMemcpy(dpool, seq_pool, (size_t)seq_pool_len, hipMemcpyHostToDevice));
+    v.pool = dpool; v.pool_len = seq_pool_len; v.pool_cap = seq_pool_len + 32;
+    v.cdesc = (ConsDesc*)up(descs.data(), descs.size() * sizeof(ConsDesc));
+    for (int k = 1; k < 6; k++) v.cls_list[k] = (int32_t*)up(lists[k].data(), lists[k].size() * sizeof(int32_t));
+    v.cnt = (Counts*)up(&hc, sizeof(Counts));
+    v.crl_off = (int64_t*)up(others_off, (size_t)n_reads * sizeof(int64_t));
+    v.crl_len = (int32_t*)up(others_len, (size_t)n_reads * sizeof(int32_t));
+    v.aln = (uint8_t*)dev((size_t)aln_total + 16);
+    v.aln_kept_w = (uint8_t*)dev((size_t)n_reads + 16);
+    v.alt_pool = (uint8_t*)dev((size_t)alt_total + 16);
+    v.stripes = (unsigned long long*)dev(4 * 64 * 16 * sizeof(unsigned long long));
+    SNF_HIP(hipMemset(v.stripes, 0, 4 * 64 * 16 * sizeof(unsigned long long)));
+    const int64_t n_small = (int64_t)hc.n_cls[1], n_large = (int64_t)(hc.n_cls[2] + hc.n_cls[3] + hc.n_cls[4] + hc.n_cls[5]);
+    if (n_large > 0) hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 5>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, 0, v, (int64_t)0);
+    if (n_small > 0) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, 0, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+    SNF_HIP(hipDeviceSynchronize());
+    if (alt_total) SNF_HIP(hipMemcpy(out_pool, v.alt_pool, (size_t)alt_total, hipMemcpyDeviceToHost));
+#endif
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------- C ABI
 #define SNF_TRY(body)                                   \
   try { body; return 0; }                               \
@@ -1216,6 +1284,13 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
     if (nc) memcpy(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t));
 #endif
   })
+}
+
+int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,
+                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int64_t* others_index,
+                        const int64_t* others_off, const int32_t* others_len, uint8_t* out_pool, const int64_t* out_off) {
+  SNF_TRY(do_consensus_batch(device, klen, seq_pool, seq_pool_len, n_problems, best_off, best_len, skip, others_index, others_off,
+                              others_len, out_pool, out_off))
 }
 
 int snf_batch_sync(snf_batch_t* bb) {

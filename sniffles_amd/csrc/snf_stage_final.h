@@ -382,6 +382,13 @@ SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
 
 // size class of a consensus call for the gfx950 workgroup kernel (snf_wave_cons.h): 1 SMALL (256-slot table, 128
 // positions, 64 others), 2 LARGE (1024 / 512 / 512), 0: does not fit its LDS budget -> thread kernels e4/e5/e6
+SNF_HD int cons_class_of(int wave_path, int klen, int skip, int64_t L, int32_t n_others) {
+  if (!wave_path || klen > 7 || klen < 1 || skip < 1 || L >= 65000) return 0;
+  int64_t npos = cons_npos(L, klen, skip);
+  if (npos <= 120 && n_others <= 64) return 1;
+  if (npos <= 500 && n_others <= 512) return 2;
+  return 0;
+}
 SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
   if (!v.wave_path || v.cfg.consensus_kmer_len > 7 || L >= 65000) return 0;
   int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
@@ -472,7 +479,7 @@ SNF_HD void e3_emit(int64_t i, const View& v) {
   ConsDesc d;
   d.L = v.F_seq_len[x.best]; d.best_off = v.F_seq_off[x.best]; d.alt_off = x.alt_off; d.aln_off = v.sc_aln[i];
   d.read_off = x.flo;   // read list (crl_*) and kept flags (aln_kept_w) live in the refined cluster's own slot range
-  d.n_others = x.n_others; d.call = (int32_t)i;
+  d.n_others = x.n_others; d.skip = cons_skip(v.cfg, d.L);
   d.cls = x.do_cons ? (cons_class(v, d.L, x.n_others) ? cons_class(v, d.L, x.n_others) : 3) : 0;
   v.cdesc[cid] = d;
   // work list: LARGE calls are bucketed by work (others x length) and the kernel walks the heaviest bucket first, so

@@ -57,7 +57,8 @@ struct ConsDesc {
   int64_t aln_off;    // rows of this call in v.aln (L bytes per other read)
   int64_t read_off;   // first entry of this call in crl_off / crl_len / aln_kept
   int32_t L, n_others;
-  int32_t call, cls;
+  int32_t skip;       // k-mer sampling step of this call (consensus_kmer_skip_base + int(L * mult), postprocessing.py:60)
+  int32_t cls;
 };
 
 // merged cluster header, written by c4_clusters: what the refine kernels need to start on cluster c in one record

@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     const uint8_t* B = v.pool + rfl64(d.best_off);
     uint8_t* alt = v.alt_pool + rfl64(d.alt_off);
     bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
-    const int skip = cons_skip(v.cfg, L);
+    const int skip = __builtin_amdgcn_readfirstlane(d.skip);
     __syncthreads();
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }

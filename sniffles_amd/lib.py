@@ -43,6 +43,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
                                             C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_combine_resolve_batch.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_combine_problem_t), C.c_int64]
     lib.snf_combine_resolve_batch.restype = C.c_int
+    u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    lib.snf_consensus_batch.argtypes = [C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p, i64p, i64p, i32p, u8p, i64p]
+    lib.snf_consensus_batch.restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
               "snf_batch_timing_count",
