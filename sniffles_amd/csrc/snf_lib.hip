@@ -129,7 +129,7 @@ struct snf_batch_impl {
   bool res_current = false;       // z1_results has run after the last kernel that changes what it publishes
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
-  int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 after c4, 2 after d3_rnames
+  int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
@@ -668,6 +668,7 @@ void run_call_candidates(snf_batch_impl* b) {
     LAUNCH_Q(c4_clusters, v, N, N * 4);
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
     }
+    if (b->sched_readprep == 3) fork_mark(b);   // mode 3: the read preparation may only start once stages A-C are through
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
@@ -677,7 +678,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #endif
     LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);
   }
-  if (b->sched_readprep == 1) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
+  if (b->sched_readprep == 1 || b->sched_readprep == 3) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
     if (b->fused) {
       FUSED(d1a_count, N);
@@ -709,7 +710,7 @@ void run_call_candidates(snf_batch_impl* b) {
 #ifndef SNF_EMU
   SNF_HIP(hipEventRecord(b->ev_counts, b->stream));
 #endif
-  if (b->sched_readprep >= 2) enqueue_read_prep(b);
+  if (b->sched_readprep == 2) enqueue_read_prep(b);
   fork_mark(b);
 #ifndef SNF_EMU
   if (b->fused) {
