@@ -139,3 +139,20 @@ def main_consensus():
         f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
     changed = sum(1 for c in cases_ if c["expected"] != c["best"])
     print(f"consensus_novel_from_reads: {len(cases_)} problems, {changed} with a consensus that differs from the best read")
+
+
+def main_combine_task(names=None):
+    """Goldens for the CombineTask.execute driver: inputs (SNF blocks per sample) and the combined calls it emits."""
+    import cases
+    import ref_harness as rh
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (build, args) in cases.COMBINE_TASK.items():
+        if names and name not in names:
+            continue
+        tis = build()
+        ref = rh.run_reference_combine_task(tis, args)
+        doc = dict(case=name, reference_args=list(args), input_sha=[input_sha(t) for t in tis], expected=ref)
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
+            f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+        ncand = sum(len(v) for smp in ref["samples"] for blk in smp for v in blk["cands"].values())
+        print(f"{name:32s} {ref['n_samples']} samples  {ncand} candidates in SNF blocks -> {len(ref['calls'])} combined calls")

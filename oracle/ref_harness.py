@@ -263,3 +263,96 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
                 g.coverages_nonincluded[s] = fake_coverage(g.pos_mean, s)
         out["calls"].append(dict(svtype=svtype, calls=[group_call_record(c) for c in ref.sv.call_groups(groups, cfg, task)]))
     return out
+
+
+def run_reference_combine_task(sample_tasks, extra_args=()):
+    """The reference's own CombineTask.execute (parallel.py:444-572) on a synthetic population.
+
+    Per-sample candidates come from the reference's call_candidates + finalize_candidates; they are put into SNF blocks by
+    the reference's SNFile.store and SNFile.annotate_block_coverages (in memory: only the gzip/pickle file layer is
+    replaced by a stand-in whose read_blocks returns those block dicts).  Returns the inputs (blocks per sample) as
+    records and the combined calls in emission order."""
+    import tempfile
+    import oracle as oc
+    ref = load_reference()
+    from sniffles import snf as ref_snf
+    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    ns = len(sample_tasks)
+    contig, contig_len = sample_tasks[0].contig, sample_tasks[0].contig_len
+    cfg = make_config(tuple(extra_args), sample_tasks[0].qc_nm_threshold)
+    blocks_per_sample = []
+    for s, ti in enumerate(sample_tasks):
+        cfg_s = make_config((), ti.qc_nm_threshold)
+        task = build_task(ti, cfg_s)
+        cands = task.call_candidates(False, cfg_s)
+        task.finalize_candidates(cands, True, cfg_s)
+        sf = ref_snf.SNFile(cfg_s, False, filename=None)
+        for c in cands:
+            sf.store(c)                                     # drops rnames, keeps sv.TYPES only (snf.py:91-100)
+        sf.annotate_block_coverages(task.lead_provider)
+        blocks_per_sample.append(sf.blocks)
+
+    class FakeSNF:
+        reqc = False
+
+        def __init__(self, blocks):
+            self.blocks = blocks
+
+        def read_header(self):
+            pass
+
+        def close(self):
+            pass
+
+        def read_blocks(self, ctg, block_index):
+            if ctg != contig or block_index not in self.blocks:
+                return None
+            return [self.blocks[block_index]]
+
+    tmpdir = tempfile.mkdtemp(prefix="snf_fake_")
+    fakes = {}
+    infos = []
+    for s in range(ns):
+        fn = os.path.join(tmpdir, f"s{s}.snf")
+        open(fn, "wb").close()
+        fakes[fn] = FakeSNF(blocks_per_sample[s])
+        infos.append(dict(internal_id=s, filename=fn))
+    cfg.snf_input_info = infos
+    cfg.mode = "combine"
+    cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(ns)]
+    cfg.combine_close_handles = False
+    cfg.combine_population = None
+
+    class Collector:
+        def __init__(self, task, svcalls, count):
+            self.calls = []
+
+        def store_calls(self, svcalls):
+            self.calls.extend(svcalls)
+
+        def finalize(self):
+            pass
+
+    orig = ref.parallel.snf.SNFile
+    ref.parallel.snf.SNFile = lambda config, handle, filename=None: (handle.close(), fakes[filename])[1]
+    try:
+        ctask = ref.parallel.CombineTask(id=7, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
+        res = ctask.execute()
+    finally:
+        ref.parallel.snf.SNFile = orig
+    inputs = []
+    for s in range(ns):
+        blk = []
+        for bi in sorted(blocks_per_sample[s]):
+            b = blocks_per_sample[s][bi]
+            recs = {}
+            for svtype in ref.sv.TYPES:
+                out = []
+                for c in b[svtype]:
+                    c.sample_internal_id = s
+                    out.append(cand_record(c))
+                recs[svtype] = out
+            blk.append(dict(block=int(bi), cands=recs, coverage={str(k): int(v) for k, v in sorted(b["_COVERAGE"].items())}))
+        inputs.append(blk)
+    return dict(n_samples=ns, contig=contig, contig_len=int(contig_len), samples=inputs,
+                calls=[group_call_record(c) for c in res.calls])

@@ -84,3 +84,91 @@ class CallTask(Task):
         if not config.no_qc:
             calls = [s for s in calls if s.qc]
         return sorted(calls, key=lambda s: s.pos)
+
+
+class CombineTask(Task):
+    """`CombineTask.execute` of the reference (parallel.py:444-572): the block / bin / flush-window driver of the
+    multi-sample merge.  The candidates are read block by block from objects with the SNF reader interface
+    (`read_blocks(contig, block_index) -> [ {svtype: [SVCall], "_COVERAGE": {bin: depth}} ] | None`, attribute `reqc`);
+    every flush window is resolved on the GPU (`cluster.resolve_block_groups`: distance gates, running means and the
+    edit distance of `SVGroup.align_call`), the keep / call decision and the combined calls are host bookkeeping
+    (`SVGroup.call`).  Groups kept at the end of a window seed the next one, also across blocks, exactly as in the
+    reference, so the windows of one SV type form a chain; different SV types are independent."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        bs = self.config.snf_block_size
+        if self.regions:
+            idx = set()
+            for r in self.regions:
+                start = r.start // bs * bs
+                idx |= set(range(start, r.end + bs, bs))
+            self.block_indices = sorted(idx)
+        else:
+            self.block_indices = list(range(self.start, self.end + bs, bs))
+
+    def execute(self, samples_snf: dict) -> list:
+        """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order."""
+        from . import cluster
+        config = self.config
+        bin_min_size = config.combine_min_size
+        bin_max_candidates = max(25, int(len(config.snf_input_info) * 0.5))
+        overlap_abs = config.combine_overlap_abs
+        support_threshold = config.combine_support_threshold
+        sample_internal_ids = set(samples_snf.keys())
+        groups_keep = {svtype: list() for svtype in sv.TYPES}
+        calls = []
+        for block_index in self.block_indices:
+            samples_blocks = {sid: snf.read_blocks(self.contig, block_index) for sid, snf in samples_snf.items()}
+            for svtype in sv.TYPES:
+                bins = {}
+                for sid, snf in samples_snf.items():
+                    blocks = samples_blocks[sid]
+                    if getattr(snf, "reqc", False):
+                        raise NotImplementedError("re-genotyping of old SNF files (--reqc) is not served")
+                    if blocks is None:
+                        continue
+                    for block in blocks:
+                        for cand in block[svtype]:
+                            if cand.support < support_threshold:
+                                continue
+                            cand.sample_internal_id = sid
+                            b = int(cand.pos / bin_min_size) * bin_min_size
+                            bins.setdefault(b, []).append(cand)
+                if len(bins) == 0:
+                    continue
+                size = 0
+                svcands = []
+                keep = groups_keep[svtype]
+                sorted_bins = sorted(bins)
+                last_bin = sorted_bins[-1]
+                for curr_bin in sorted_bins:
+                    svcands.extend(bins[curr_bin])
+                    size += bin_min_size
+                    if (not getattr(config, "combine_exhaustive", False) and len(svcands) >= bin_max_candidates) or curr_bin == last_bin:
+                        if len(svcands) == 0:
+                            size = 0
+                            continue
+                        svgroups = cluster.resolve_block_groups(svtype, svcands, keep, config, device=self.device, _lib=self._lib)
+                        groups_call = []
+                        keep = []
+                        for group in svgroups:
+                            coverage_bin = int(group.pos_mean / config.coverage_binsize_combine) * config.coverage_binsize_combine
+                            for other in sample_internal_ids - group.included_samples:
+                                blk = samples_blocks[other]
+                                coverage = blk[0]["_COVERAGE"].get(coverage_bin, 0) if blk is not None else 0
+                                if other in group.coverages_nonincluded:
+                                    group.coverages_nonincluded[other] = max(coverage, group.coverages_nonincluded[other])
+                                else:
+                                    group.coverages_nonincluded[other] = coverage
+                            if abs(group.pos_mean - curr_bin) < max(size * 0.5, overlap_abs):
+                                keep.append(group)
+                            else:
+                                groups_call.append(group)
+                        calls.extend(sv.call_groups(groups_call, config, self))
+                        size = 0
+                        svcands = []
+                groups_keep[svtype] = keep
+        for svtype in groups_keep:
+            calls.extend(sv.call_groups(groups_keep[svtype], config, self))
+        return calls

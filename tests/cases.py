@@ -361,3 +361,10 @@ COMBINE = {
     "combine_7samples_lowcov": (lambda: population(7, contig="chr22", length=1_000_000, cov=12, site_seed=777, task_id=3), ()),
     "combine_3samples_no_align": (lambda: population(3, length=1_000_000, site_seed=9), ("--combine-pctseq", "0")),
 }
+
+
+# the reference's whole CombineTask.execute (block / bin / flush-window driver) on in-memory SNF blocks
+COMBINE_TASK = {
+    "combine_task_6samples": (lambda: population(6, contig="chr21", length=3_000_000, cov=20, site_seed=4242, task_id=2), ()),
+    "combine_task_3samples_lowcov": (lambda: population(3, contig="chr22", length=1_500_000, cov=10, site_seed=99, task_id=5), ()),
+}
