@@ -366,6 +366,15 @@ typedef struct snf_combine_problem {
   const int64_t* g_samples_off;  /* n_groups + 1: group.included_samples */
   const int32_t* g_samples;
   int32_t* out_group;            /* n_cands */
+  /* Optional chain of flush windows (CombineTask.execute, parallel.py:516-558): the candidates are the concatenation
+   * of n_windows windows, window w = candidates [win_off[w], win_off[w+1]).  After a window every group with
+   * abs(pos_mean - win_bin[w]) < win_thr[w]  (win_thr = max(size * 0.5, combine_overlap_abs)) stays active for the
+   * next window ("keep"), the others are flushed; out_group then numbers the groups over the whole chain
+   * (groups_initial first, new groups in creation order).  n_windows == 0: one window, nothing is flushed. */
+  int32_t n_windows;
+  const int32_t* win_off;        /* n_windows + 1 */
+  const int32_t* win_bin;        /* curr_bin of the flush */
+  const double* win_thr;
 } snf_combine_problem_t;
 
 int snf_combine_resolve_batch(const snf_config_t* cfg, int device, const snf_combine_problem_t* problems,

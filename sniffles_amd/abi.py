@@ -121,10 +121,11 @@ class snf_combine_problem_t(C.Structure):
         ("g_alt_off", C.POINTER(C.c_int64)), ("g_alt_pool", u8p),
         ("g_samples_off", C.POINTER(C.c_int64)), ("g_samples", C.POINTER(C.c_int32)),
         ("out_group", C.POINTER(C.c_int32)),
+        ("n_windows", i32), ("win_off", C.POINTER(C.c_int32)), ("win_bin", C.POINTER(C.c_int32)), ("win_thr", C.POINTER(C.c_double)),
     ]
 
 
-def combine_problem(svtype_code: int, cands: dict, groups: dict, n_sample_ids: int, keep: list):
+def combine_problem(svtype_code: int, cands: dict, groups: dict, n_sample_ids: int, keep: list, windows=None):
     """Pack one resolve_block_groups call.  `cands`: pos, svlen, support, sample_id, mate_contig, mate_ref_start
     (int lists) and alts (list of bytes); `groups`: pos_mean, len_mean, mate_mean, size, mate_contig, alts, samples
     (list of lists).  Returns (struct, out_group numpy array)."""
@@ -169,6 +170,14 @@ def combine_problem(svtype_code: int, cands: dict, groups: dict, n_sample_ids: i
     out = np.full(max(n, 1), -1, np.int32)
     keep.append(out)
     q.out_group = _ptr(out, C.c_int32)
+    if windows is not None:   # (win_off [n+1], win_bin [n], win_thr [n]): chain of flush windows
+        woff, wbin, wthr = windows
+        q.n_windows = len(wbin)
+        q.win_off = _ptr(arr(woff, np.int32), C.c_int32)
+        q.win_bin = _ptr(arr(wbin, np.int32), C.c_int32)
+        q.win_thr = _ptr(arr(wthr, np.float64), C.c_double)
+    else:
+        q.n_windows = 0
     return q, out
 
 

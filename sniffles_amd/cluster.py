@@ -14,7 +14,7 @@ def _alt_bytes(alt) -> bytes:
     return alt.encode("latin-1") if isinstance(alt, str) else bytes(alt)
 
 
-def pack_problem(svtype, svcands, groups_initial, keep):
+def pack_problem(svtype, svcands, groups_initial, keep, windows=None):
     contig_ids = {}
 
     def cid(name):
@@ -34,7 +34,7 @@ def pack_problem(svtype, svcands, groups_initial, keep):
                   samples=[g.included_samples for g in groups_initial])
     ids = [c.sample_internal_id for c in svcands] + [s for g in groups_initial for s in g.included_samples]
     n_ids = (max(ids) + 1) if ids else 1
-    return abi.combine_problem(SVT[svtype], cands, groups, n_ids, keep)
+    return abi.combine_problem(SVT[svtype], cands, groups, n_ids, keep, windows)
 
 
 def apply_assignment(svcands, groups_initial, out_group):
@@ -72,3 +72,15 @@ def resolve_block_groups_batch(problems, config, device: int = 0, _lib=None):
         packed.append(pack_problem(svtype, svcands, groups_initial, keep))
     lib.combine_resolve_batch(config, [q for q, _ in packed], device=device, _lib=_lib)
     return [apply_assignment(sc, gi, out) for (_, sc, gi), (_, out) in zip(problems, packed)]
+
+
+def resolve_chains_batch(chains, config, device: int = 0, _lib=None):
+    """Whole chains of flush windows in one launch.  chains: list of (svtype, svcands, win_off, win_bin, win_thr) with
+    svcands the concatenation of the windows' candidates; after window w the groups with
+    abs(pos_mean - win_bin[w]) < win_thr[w] stay active for window w+1 (CombineTask.execute, parallel.py:553-556).
+    Returns per chain the group number of every candidate (new groups numbered in creation order over the chain)."""
+    keep, packed = [], []
+    for svtype, svcands, win_off, win_bin, win_thr in chains:
+        packed.append(pack_problem(svtype, svcands, [], keep, (win_off, win_bin, win_thr)))
+    lib.combine_resolve_batch(config, [q for q, _ in packed], device=device, _lib=_lib)
+    return [out for _, out in packed]

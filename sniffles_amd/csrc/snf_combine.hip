@@ -33,7 +33,10 @@ struct CombineView {
   const int64_t* g_samples_off; const int32_t* g_samples;
   // scratch / state
   double *st_pos, *st_len, *st_mate; int32_t *st_size, *st_mctg; int64_t *st_alt_lo, *st_alt_hi; uint8_t* st_alt_src;
-  uint64_t* st_bits; int32_t* order; int8_t* carry;
+  uint64_t* st_bits; int32_t* order; int8_t* carry; int32_t* st_alist;
+  // flush windows: wn_off[p] = first window of problem p; win_cand has (windows + 1) entries per problem, stored at
+  // index (wn_off[p] + p + w); win_bin / win_thr per window (thr < 0: nothing is flushed)
+  const int64_t* wn_off; const int32_t* win_cand; const int32_t* win_bin; const double* win_thr;
   int32_t* out_group;
 };
 
@@ -42,128 +45,65 @@ struct LessSupportDesc {
   SNF_HD bool operator()(int32_t a, int32_t b) const { return support[a] != support[b] ? support[a] > support[b] : a < b; }
 };
 
-SNF_HD void combine_problem_body(int64_t p, const CombineView& v) {
+// One problem (a flush window, or a whole chain of them) - the thread form (WAVE == false: emulation build and
+// SNF_COMBINE_THREAD=1) and the gfx950 wave form share this body.  WAVE: one wave per problem, lane 0 ("lead") runs the
+// sequential greedy assignment and, whenever a (group, candidate) pair passes the distance gates, all 64 lanes evaluate
+// its edit distance together (ed_wave_pair: lane = 64-row block, anti-diagonal schedule) - the alignment is > 99 % of
+// the work of a window with kilobase insertions, and one thread doing it serially takes tens of milliseconds per pair.
+template <bool WAVE>
+SNF_HD void combine_run(int64_t p, const CombineView& v) {
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  const int lane = WAVE ? (int)(threadIdx.x & 63) : 0;
+#else
+  const int lane = 0;
+#endif
+  const bool lead = lane == 0;
   const snf_config_t& cfg = v.cfg;
   const int64_t c0 = v.c_off[p], g0 = v.g_off[p], s0 = v.s_off[p];
-  const int nc = v.n_cands[p], ng0 = v.n_groups[p], nw = v.n_words[p], svtype = v.svtype[p];
+  const int ng0 = v.n_groups[p], nw = v.n_words[p], svtype = v.svtype[p];
   const int32_t *pos = v.pos + c0, *svlen = v.svlen + c0, *support = v.support + c0, *sample = v.sample_id + c0;
   const int32_t *mctg = v.mate_contig + c0, *mpos = v.mate_pos + c0;
   double *gpos = v.st_pos + s0, *glen = v.st_len + s0, *gmate = v.st_mate + s0;
-  int32_t *gsize = v.st_size + s0, *gmc = v.st_mctg + s0;
+  int32_t *gsize = v.st_size + s0, *gmc = v.st_mctg + s0, *alist = v.st_alist + s0;
   int64_t *galo = v.st_alt_lo + s0, *gahi = v.st_alt_hi + s0; uint8_t* gsrc = v.st_alt_src + s0;
   uint64_t* bits = v.st_bits + v.w_off[p];
   int32_t* order = v.order + c0;
   int8_t* carry = v.carry + v.k_off[p];
   int32_t* out = v.out_group + c0;
-  int ng = ng0;
-  for (int g = 0; g < ng0; g++) {
-    gpos[g] = v.g_pos_mean[g0 + g]; glen[g] = v.g_len_mean[g0 + g]; gmate[g] = v.g_mate_mean[g0 + g];
-    gsize[g] = v.g_size[g0 + g]; gmc[g] = v.g_mate_contig[g0 + g];
-    galo[g] = v.g_alt_off[g0 + g]; gahi[g] = v.g_alt_off[g0 + g + 1]; gsrc[g] = 1;
-    for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
-    for (int64_t k = v.g_samples_off[g0 + g]; k < v.g_samples_off[g0 + g + 1]; k++) {
-      int32_t sid = v.g_samples[k];
-      bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
-    }
-  }
-  for (int i = 0; i < nc; i++) order[i] = i;
-  sort_inplace(order, (int64_t)nc, LessSupportDesc{support});   // sorted(key=support, reverse=True) is stable
-  for (int oi = 0; oi < nc; oi++) {
-    const int c = order[oi];
-    const int sid = sample[c];
-    int best = -1; double best_dist = INFINITY;
-    if (svtype == SNF_BND) {
-      for (int g = 0; g < ng; g++) {
-        double dist = fabs(gpos[g] - (double)pos[c]) + fabs(gmate[g] - (double)mpos[c]);
-        if (dist < best_dist && dist <= (double)(cfg.cluster_merge_bnd * 2) && gmc[g] == mctg[c]) {
-          if (!cfg.combine_separate_intra || !((bits[(int64_t)g * nw + (sid >> 6)] >> (sid & 63)) & 1)) { best = g; best_dist = dist; }
-        }
-      }
-    } else {
-      const double alen = fabs((double)svlen[c]);
-      for (int g = 0; g < ng; g++) {
-        double dist = fabs(gpos[g] - (double)pos[c]) + fabs(fabs(glen[g]) - alen);
-        double minlen = fabs(glen[g]) < alen ? fabs(glen[g]) : alen;
-        if (minlen > 0 && dist < best_dist && dist <= (double)cfg.combine_match * sqrt(minlen) && dist <= (double)cfg.combine_match_max) {
-          if (cfg.combine_separate_intra && ((bits[(int64_t)g * nw + (sid >> 6)] >> (sid & 63)) & 1)) continue;
-          bool ok = true;
-          if (cfg.combine_pctseq != 0.0) {  // SVGroup.align_call
-            const uint8_t* A = (gsrc[g] ? v.g_alt_pool : v.alt_pool) + galo[g];
-            const uint8_t* B = v.alt_pool + v.alt_off[c0 + c];
-            int64_t d = ed_serial(A, gahi[g] - galo[g], B, v.alt_off[c0 + c + 1] - v.alt_off[c0 + c], carry);
-            ok = ((glen[g] - (double)d) / glen[g]) > cfg.combine_pctseq;
-          }
-          if (ok) { best = g; best_dist = dist; }
-        }
-      }
-    }
-    if (best < 0) {  // SVGroup.from_candidate
-      const int g = ng++;
-      gpos[g] = (double)pos[c]; glen[g] = fabs((double)svlen[c]); gmate[g] = (double)mpos[c];
-      gsize[g] = 1; gmc[g] = mctg[c];
-      galo[g] = v.alt_off[c0 + c]; gahi[g] = v.alt_off[c0 + c + 1]; gsrc[g] = 0;
+  int ng = ng0;   // group slots used so far (slot index == group number over the whole chain)
+  int na = ng0;   // active groups: alist[0..na) in list order (kept groups first, then the window's new groups)
+  if (lead) {
+    for (int g = 0; g < ng0; g++) {
+      gpos[g] = v.g_pos_mean[g0 + g]; glen[g] = v.g_len_mean[g0 + g]; gmate[g] = v.g_mate_mean[g0 + g];
+      gsize[g] = v.g_size[g0 + g]; gmc[g] = v.g_mate_contig[g0 + g];
+      galo[g] = v.g_alt_off[g0 + g]; gahi[g] = v.g_alt_off[g0 + g + 1]; gsrc[g] = 1;
       for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
-      bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
-      out[c] = g;
-    } else {         // SVGroup.add_candidate: multiply, add, append, divide
-      const int g = best;
-      const double n = (double)gsize[g];
-      gpos[g] *= n; glen[g] *= n;
-      gpos[g] += (double)pos[c]; glen[g] += fabs((double)svlen[c]);
-      if (svtype == SNF_BND) { gmate[g] *= n; gmate[g] += (double)mpos[c]; }
-      gsize[g]++;
-      const double n1 = (double)gsize[g];
-      gpos[g] /= n1; glen[g] /= n1;
-      bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
-      if (svtype == SNF_BND) gmate[g] /= n1;
-      out[c] = g;
+      for (int64_t k = v.g_samples_off[g0 + g]; k < v.g_samples_off[g0 + g + 1]; k++) {
+        int32_t sid = v.g_samples[k];
+        bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
+      }
+      alist[g] = g;
     }
   }
-}
-
-#ifndef SNF_EMU
-// gfx950: one WAVE per flush window.  Lane 0 runs the sequential greedy assignment (combine_problem_body's logic);
-// whenever a (group, candidate) pair passes the distance gates, all 64 lanes evaluate its edit distance together
-// (ed_wave_pair: lane = 64-row block, anti-diagonal schedule) - the alignment is >99 % of the work of a window with
-// kilobase insertions, and one thread doing it serially takes tens of milliseconds per pair.
-__global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, int64_t np) {
-  const int lane = threadIdx.x;
-  const snf_config_t& cfg = v.cfg;
-  for (int64_t p = blockIdx.x; p < np; p += gridDim.x) {
-    const int64_t c0 = v.c_off[p], g0 = v.g_off[p], s0 = v.s_off[p];
-    const int nc = v.n_cands[p], ng0 = v.n_groups[p], nw = v.n_words[p], svtype = v.svtype[p];
-    const int32_t *pos = v.pos + c0, *svlen = v.svlen + c0, *support = v.support + c0, *sample = v.sample_id + c0;
-    const int32_t *mctg = v.mate_contig + c0, *mpos = v.mate_pos + c0;
-    double *gpos = v.st_pos + s0, *glen = v.st_len + s0, *gmate = v.st_mate + s0;
-    int32_t *gsize = v.st_size + s0, *gmc = v.st_mctg + s0;
-    int64_t *galo = v.st_alt_lo + s0, *gahi = v.st_alt_hi + s0; uint8_t* gsrc = v.st_alt_src + s0;
-    uint64_t* bits = v.st_bits + v.w_off[p];
-    int32_t* order = v.order + c0;
-    int8_t* carry = v.carry + v.k_off[p];
-    int32_t* out = v.out_group + c0;
-    int ng = ng0;
-    if (lane == 0) {
-      for (int g = 0; g < ng0; g++) {
-        gpos[g] = v.g_pos_mean[g0 + g]; glen[g] = v.g_len_mean[g0 + g]; gmate[g] = v.g_mate_mean[g0 + g];
-        gsize[g] = v.g_size[g0 + g]; gmc[g] = v.g_mate_contig[g0 + g];
-        galo[g] = v.g_alt_off[g0 + g]; gahi[g] = v.g_alt_off[g0 + g + 1]; gsrc[g] = 1;
-        for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
-        for (int64_t k = v.g_samples_off[g0 + g]; k < v.g_samples_off[g0 + g + 1]; k++) {
-          int32_t sid = v.g_samples[k];
-          bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
-        }
-      }
-      for (int i = 0; i < nc; i++) order[i] = i;
-      sort_inplace(order, (int64_t)nc, LessSupportDesc{support});   // sorted(key=support, reverse=True) is stable
+  const int64_t wb = v.wn_off[p], nwin = v.wn_off[p + 1] - wb;
+  for (int64_t w = 0; w < nwin; w++) {
+    const int w0 = v.win_cand[wb + w + p], w1 = v.win_cand[wb + w + p + 1];   // (n_windows + 1) entries per problem
+    if (lead) {
+      for (int i = w0; i < w1; i++) order[i] = i;
+      sort_inplace(order + w0, (int64_t)(w1 - w0), LessSupportDesc{support});   // sorted(key=support, reverse=True) is stable
     }
-    for (int oi = 0; oi < nc; oi++) {
+    for (int oi = w0; oi < w1; oi++) {
       int c = 0, sid = 0, best = -1; double best_dist = INFINITY, alen = 0;
-      if (lane == 0) { c = order[oi]; sid = sample[c]; alen = fabs((double)svlen[c]); }
-      const int ng_u = __shfl(ng, 0, 64);
-      for (int g = 0; g < ng_u; g++) {
-        int need = 0; double dist = 0;
+      if (lead) { c = order[oi]; sid = sample[c]; alen = fabs((double)svlen[c]); }
+      int na_u = na;
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+      if (WAVE) na_u = __shfl(na, 0, 64);
+#endif
+      for (int k = 0; k < na_u; k++) {
+        int need = 0, g = 0; double dist = 0;
         unsigned long long pa = 0, pb = 0; long long la = 0, lb = 0;
-        if (lane == 0) {
+        if (lead) {
+          g = alist[k];
           if (svtype == SNF_BND) {
             dist = fabs(gpos[g] - (double)pos[c]) + fabs(gmate[g] - (double)mpos[c]);
             if (dist < best_dist && dist <= (double)(cfg.cluster_merge_bnd * 2) && gmc[g] == mctg[c]) {
@@ -174,7 +114,7 @@ __global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, 
             const double minlen = fabs(glen[g]) < alen ? fabs(glen[g]) : alen;
             if (minlen > 0 && dist < best_dist && dist <= (double)cfg.combine_match * sqrt(minlen) && dist <= (double)cfg.combine_match_max) {
               if (!(cfg.combine_separate_intra && ((bits[(int64_t)g * nw + (sid >> 6)] >> (sid & 63)) & 1))) {
-                if (cfg.combine_pctseq != 0.0) {  // SVGroup.align_call: needs the edit distance -> whole wave
+                if (cfg.combine_pctseq != 0.0) {  // SVGroup.align_call: needs the edit distance
                   need = 1;
                   pa = (unsigned long long)((gsrc[g] ? v.g_alt_pool : v.alt_pool) + galo[g]); la = gahi[g] - galo[g];
                   pb = (unsigned long long)(v.alt_pool + v.alt_off[c0 + c]); lb = v.alt_off[c0 + c + 1] - v.alt_off[c0 + c];
@@ -183,21 +123,28 @@ __global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, 
             }
           }
         }
-        need = __shfl(need, 0, 64);
-        if (need) {
-          pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64);
-          const int64_t d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
-          if (lane == 0 && ((glen[g] - (double)d) / glen[g]) > cfg.combine_pctseq) { best = g; best_dist = dist; }
-        }
+        int64_t d = 0;
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+        if (WAVE) {
+          need = __shfl(need, 0, 64);
+          if (need) {
+            pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64);
+            d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
+          }
+        } else
+#endif
+        if (need) d = ed_serial((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
+        if (need && lead && ((glen[g] - (double)d) / glen[g]) > cfg.combine_pctseq) { best = g; best_dist = dist; }
       }
-      if (lane == 0) {
+      if (lead) {
         if (best < 0) {  // SVGroup.from_candidate
           const int g = ng++;
           gpos[g] = (double)pos[c]; glen[g] = fabs((double)svlen[c]); gmate[g] = (double)mpos[c];
           gsize[g] = 1; gmc[g] = mctg[c];
           galo[g] = v.alt_off[c0 + c]; gahi[g] = v.alt_off[c0 + c + 1]; gsrc[g] = 0;
-          for (int w = 0; w < nw; w++) bits[(int64_t)g * nw + w] = 0;
+          for (int ww = 0; ww < nw; ww++) bits[(int64_t)g * nw + ww] = 0;
           bits[(int64_t)g * nw + (sid >> 6)] |= 1ull << (sid & 63);
+          alist[na++] = g;
           out[c] = g;
         } else {         // SVGroup.add_candidate: multiply, add, append, divide
           const int g = best;
@@ -214,7 +161,23 @@ __global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, 
         }
       }
     }
+    if (lead) {  // flush (parallel.py:553-556): groups near the window's last bin stay active for the next window
+      const double thr = v.win_thr[wb + w];
+      if (thr >= 0) {
+        const double bin = (double)v.win_bin[wb + w];
+        int nk = 0;
+        for (int k = 0; k < na; k++) { const int g = alist[k]; if (fabs(gpos[g] - bin) < thr) alist[nk++] = g; }
+        na = nk;
+      }
+    }
   }
+}
+
+SNF_HD void combine_problem_body(int64_t p, const CombineView& v) { combine_run<false>(p, v); }
+
+#ifndef SNF_EMU
+__global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, int64_t np) {
+  for (int64_t p = blockIdx.x; p < np; p += gridDim.x) combine_run<true>(p, v);
 }
 #endif
 
@@ -267,6 +230,24 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
     for (int g = 0; g < P[p].n_groups; g++) { int64_t l = P[p].g_alt_off[g + 1] - P[p].g_alt_off[g]; if (l > maxlen) maxlen = l; }
     k_off[p + 1] = k_off[p] + maxlen + 8;
   }
+  // flush windows per problem (a plain problem = one window that flushes nothing)
+  std::vector<int64_t> wn_off(np + 1, 0);
+  std::vector<int32_t> win_cand, win_bin; std::vector<double> win_thr;
+  for (int64_t p = 0; p < np; p++) {
+    const snf_combine_problem_t& q = P[p];
+    if (q.n_windows > 0) {
+      if (!q.win_off || !q.win_bin || !q.win_thr || q.win_off[0] != 0 || q.win_off[q.n_windows] != q.n_cands) return 1;
+      for (int w = 0; w < q.n_windows; w++) {
+        if (q.win_off[w + 1] < q.win_off[w]) return 1;
+        win_cand.push_back(q.win_off[w]); win_bin.push_back(q.win_bin[w]); win_thr.push_back(q.win_thr[w]);
+      }
+      win_cand.push_back(q.win_off[q.n_windows]);
+      wn_off[p + 1] = wn_off[p] + q.n_windows;
+    } else {
+      win_cand.push_back(0); win_cand.push_back(q.n_cands); win_bin.push_back(0); win_thr.push_back(-1.0);
+      wn_off[p + 1] = wn_off[p] + 1;
+    }
+  }
   const int64_t NC = c_off[np], NG = g_off[np];
   std::vector<int32_t> pos, svlen, support, sample, mctg, mpos, g_size, g_mctg, g_samples;
   std::vector<double> g_pm, g_lm, g_mm;
@@ -309,7 +290,9 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   v.st_pos = dev_scratch<double>(S, frees, ok); v.st_len = dev_scratch<double>(S, frees, ok); v.st_mate = dev_scratch<double>(S, frees, ok);
   v.st_size = dev_scratch<int32_t>(S, frees, ok); v.st_mctg = dev_scratch<int32_t>(S, frees, ok);
   v.st_alt_lo = dev_scratch<int64_t>(S, frees, ok); v.st_alt_hi = dev_scratch<int64_t>(S, frees, ok);
-  v.st_alt_src = dev_scratch<uint8_t>(S, frees, ok);
+  v.st_alt_src = dev_scratch<uint8_t>(S, frees, ok); v.st_alist = dev_scratch<int32_t>(S, frees, ok);
+  v.wn_off = dev_up(wn_off, frees, ok); v.win_cand = dev_up(win_cand, frees, ok); v.win_bin = dev_up(win_bin, frees, ok);
+  v.win_thr = dev_up(win_thr, frees, ok);
   v.st_bits = dev_scratch<uint64_t>((size_t)w_off[np], frees, ok);
   v.order = dev_scratch<int32_t>((size_t)NC, frees, ok);
   v.carry = dev_scratch<int8_t>((size_t)k_off[np], frees, ok);

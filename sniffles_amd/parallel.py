@@ -108,7 +108,14 @@ class CombineTask(Task):
             self.block_indices = list(range(self.start, self.end + bs, bs))
 
     def execute(self, samples_snf: dict) -> list:
-        """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order."""
+        """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order.
+
+        Three phases: (1) walk the blocks and bins exactly like the reference and record the flush windows - which
+        candidates form a window depends only on the bins, not on the grouping; the windows of one SV type form a chain
+        (kept groups seed the next window, also across blocks); (2) ONE GPU launch resolves all chains, the keep / flush
+        rule included; (3) replay in the reference's order: SVGroup bookkeeping, non-included-sample coverages, the
+        keep / call decision (recomputed from the same running means and cross-checked against the kernel's) and
+        SVGroup.call."""
         from . import cluster
         config = self.config
         bin_min_size = config.combine_min_size
@@ -116,8 +123,9 @@ class CombineTask(Task):
         overlap_abs = config.combine_overlap_abs
         support_threshold = config.combine_support_threshold
         sample_internal_ids = set(samples_snf.keys())
-        groups_keep = {svtype: list() for svtype in sv.TYPES}
-        calls = []
+        # ---- phase 1: windows
+        chains = {svtype: dict(cands=[], win_off=[0], win_bin=[], win_thr=[]) for svtype in sv.TYPES}
+        events = []   # (svtype, window index in its chain, curr_bin, size, samples_blocks of the block) in emission order
         for block_index in self.block_indices:
             samples_blocks = {sid: snf.read_blocks(self.contig, block_index) for sid, snf in samples_snf.items()}
             for svtype in sv.TYPES:
@@ -133,13 +141,12 @@ class CombineTask(Task):
                             if cand.support < support_threshold:
                                 continue
                             cand.sample_internal_id = sid
-                            b = int(cand.pos / bin_min_size) * bin_min_size
-                            bins.setdefault(b, []).append(cand)
+                            bins.setdefault(int(cand.pos / bin_min_size) * bin_min_size, []).append(cand)
                 if len(bins) == 0:
                     continue
+                ch = chains[svtype]
                 size = 0
                 svcands = []
-                keep = groups_keep[svtype]
                 sorted_bins = sorted(bins)
                 last_bin = sorted_bins[-1]
                 for curr_bin in sorted_bins:
@@ -149,26 +156,56 @@ class CombineTask(Task):
                         if len(svcands) == 0:
                             size = 0
                             continue
-                        svgroups = cluster.resolve_block_groups(svtype, svcands, keep, config, device=self.device, _lib=self._lib)
-                        groups_call = []
-                        keep = []
-                        for group in svgroups:
-                            coverage_bin = int(group.pos_mean / config.coverage_binsize_combine) * config.coverage_binsize_combine
-                            for other in sample_internal_ids - group.included_samples:
-                                blk = samples_blocks[other]
-                                coverage = blk[0]["_COVERAGE"].get(coverage_bin, 0) if blk is not None else 0
-                                if other in group.coverages_nonincluded:
-                                    group.coverages_nonincluded[other] = max(coverage, group.coverages_nonincluded[other])
-                                else:
-                                    group.coverages_nonincluded[other] = coverage
-                            if abs(group.pos_mean - curr_bin) < max(size * 0.5, overlap_abs):
-                                keep.append(group)
-                            else:
-                                groups_call.append(group)
-                        calls.extend(sv.call_groups(groups_call, config, self))
+                        events.append((svtype, len(ch["win_bin"]), curr_bin, size, samples_blocks))
+                        ch["cands"].extend(svcands)
+                        ch["win_off"].append(len(ch["cands"]))
+                        ch["win_bin"].append(curr_bin)
+                        ch["win_thr"].append(float(max(size * 0.5, overlap_abs)))
                         size = 0
                         svcands = []
-                groups_keep[svtype] = keep
-        for svtype in groups_keep:
-            calls.extend(sv.call_groups(groups_keep[svtype], config, self))
+        # ---- phase 2: one launch for all chains
+        live = [t for t in sv.TYPES if chains[t]["win_bin"]]
+        outs = cluster.resolve_chains_batch([(t, chains[t]["cands"], chains[t]["win_off"], chains[t]["win_bin"], chains[t]["win_thr"])
+                                             for t in live], config, device=self.device, _lib=self._lib) if live else []
+        assign = dict(zip(live, outs))
+        # ---- phase 3: replay
+        active = {svtype: [] for svtype in sv.TYPES}     # kept groups, list order
+        by_id = {svtype: {} for svtype in sv.TYPES}      # group number -> SVGroup (active ones only)
+        next_id = {svtype: 0 for svtype in sv.TYPES}
+        calls = []
+        for svtype, w, curr_bin, size, samples_blocks in events:
+            ch, out = chains[svtype], assign[svtype]
+            lo, hi = ch["win_off"][w], ch["win_off"][w + 1]
+            cands = ch["cands"][lo:hi]
+            groups, gmap = list(active[svtype]), by_id[svtype]
+            for i in sorted(range(len(cands)), key=lambda i: cands[i].support, reverse=True):   # stable, like the reference
+                gid = int(out[lo + i])
+                if gid in gmap:
+                    gmap[gid].add_candidate(cands[i])
+                else:
+                    if gid != next_id[svtype]:   # new groups are numbered in creation order over the whole chain
+                        raise RuntimeError("internal: the kernel's keep / flush decisions differ from the host replay")
+                    next_id[svtype] += 1
+                    gmap[gid] = sv.SVGroup.from_candidate(cands[i])
+                    groups.append(gmap[gid])
+            groups_call, keep = [], []
+            for group in groups:
+                coverage_bin = int(group.pos_mean / config.coverage_binsize_combine) * config.coverage_binsize_combine
+                for other in sample_internal_ids - group.included_samples:
+                    blk = samples_blocks[other]
+                    coverage = blk[0]["_COVERAGE"].get(coverage_bin, 0) if blk is not None else 0
+                    if other in group.coverages_nonincluded:
+                        group.coverages_nonincluded[other] = max(coverage, group.coverages_nonincluded[other])
+                    else:
+                        group.coverages_nonincluded[other] = coverage
+                if abs(group.pos_mean - curr_bin) < max(size * 0.5, overlap_abs):
+                    keep.append(group)
+                else:
+                    groups_call.append(group)
+            kept_ids = {id(g) for g in keep}
+            by_id[svtype] = {gid: g for gid, g in gmap.items() if id(g) in kept_ids}
+            active[svtype] = keep
+            calls.extend(sv.call_groups(groups_call, config, self))
+        for svtype in sv.TYPES:
+            calls.extend(sv.call_groups(active[svtype], config, self))
         return calls

@@ -367,4 +367,7 @@ COMBINE = {
 COMBINE_TASK = {
     "combine_task_6samples": (lambda: population(6, contig="chr21", length=3_000_000, cov=20, site_seed=4242, task_id=2), ()),
     "combine_task_3samples_lowcov": (lambda: population(3, contig="chr22", length=1_500_000, cov=10, site_seed=99, task_id=5), ()),
+    # dense sites: several flush windows per 100-kb block, kept groups between windows and across blocks
+    "combine_task_8samples_dense": (lambda: [synth.gen_task(4, "chr20", 600_000, 15, seed=300 + s, site_seed=31337, site_density=40 * 27000 / 3.1e9)
+                                             for s in range(8)], ()),
 }
