@@ -90,6 +90,18 @@ def main():
 windows=n_windows, candidates=n_c, gpu_s_incl_pack_and_replay=round(t_gpu, 3), c_abi_call_s_incl_h2d_kernel_d2h=round(t_call, 4),
                                        windows_per_s=round(n_windows / t_gpu), candidates_per_s=round(n_c / t_gpu),
                                        groups=sum(len(g) for g in groups))
+    # ---- (3) the same windows as CHAINS (CombineTask.execute: kept groups seed the next window): 40 chains x 100 windows
+    chains = []
+    for k in range(40):
+        cands, woff, wbin, wthr = [], [0], [], []
+        for svt, c, _ in windows[k * 100:(k + 1) * 100]:
+            cands.extend(c); woff.append(len(cands)); wbin.append(max(x.pos for x in c) // 100 * 100); wthr.append(2500.0)
+        chains.append(("INS", cands, woff, wbin, wthr))
+    keep3 = []; packed3 = [cluster.pack_problem(t, c, [], keep3, (wo, wb, wt)) for t, c, wo, wb, wt in chains]
+    lib.combine_resolve_batch(cfg, [q for q, _ in packed3[:2]])
+    t0 = time.perf_counter(); lib.combine_resolve_batch(cfg, [q for q, _ in packed3]); t_ch = time.perf_counter() - t0
+    res["resolve_chains"] = dict(chains=len(chains), windows=100 * len(chains), candidates=sum(len(c[1]) for c in chains),
+                                 c_abi_call_s_incl_h2d_kernel_d2h=round(t_ch, 4), windows_per_s=round(100 * len(chains) / t_ch))
     print(json.dumps(res))
 
 if __name__ == "__main__":
