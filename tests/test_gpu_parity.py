@@ -90,6 +90,21 @@ def test_hip_plain_scan_chains_exact(oracle_mod, monkeypatch):
     assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
 
 
+def test_hip_ragged_batch_with_empty_tasks(oracle_mod):
+    """Tasks without leads, without reads, and an entirely empty batch next to ordinary tasks: every stage has to cope
+    with empty ranges (fused scan chains, wave kernels, result block)."""
+    cfg = SnifflesConfig()
+    empty = cases.mk_task([], [], 50_000, task_id=0, contig="chrE")
+    no_leads = cases.mk_task([], [(1000, 30_000, 0), (2000, 60_000, 1)], 80_000, task_id=1, contig="chrR")
+    normal = synth.gen_fuzz(950, task_id=2)
+    for tis in ([empty], [no_leads], [empty, normal, no_leads], [normal, empty]):
+        tis = [t for t in tis]
+        exp = oracle_mod.run(cfg, tis, True)
+        got = run(cfg, tis, True)
+        assert records.records(got, tis, "final") == records.records(exp, tis, "final")
+        assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
+
+
 def test_batches_in_flight_on_host_threads(oracle_mod):
     """bench.py keeps several batch handles in flight from host threads (own streams each): concurrent passes must
     give exactly the results of passes run one after the other."""
