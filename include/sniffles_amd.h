@@ -396,6 +396,68 @@ int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
                         const int64_t* others_off, const int32_t* others_len,
                         uint8_t* out_pool, const int64_t* out_off);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Signature extraction: inflated BAM alignment records of one contig -> the task input above.
+ * Replaces, for one `Region(contig, start, end)`, LeadProvider.build_leadtab (src/sniffles/leadprov.py:445-472) and
+ * everything it drives per alignment: iter_region (:474-578: read filter, read ids, `coverage[s:e] += 1`,
+ * record_hap_ref, the NM side channel config.qc_nm_threshold), read_iterindels (:580-655), Lead.for_bnd (:57-132),
+ * CIGAR_analyze (:144-178), read_itersplits (:221-355) and sv.classify_splits (src/sniffles/sv.py:649-782).
+ * The pysam layer (bam.fetch, AlignedSegment properties, get_tag) is replaced by parsing the raw records on the GPU:
+ * one wave per alignment record, 64 CIGAR operations per step.
+ *
+ * The caller (host) inflates BGZF, finds the record boundaries and interns the strings the hot path only compares:
+ * read names (rank per record) and contig names (hash table -> rank), both ranks in Python str order.
+ */
+typedef struct snf_extract_config {
+  int32_t mapq;                    /* config.mapq (20) */
+  int32_t min_alignment_length;    /* config.min_alignment_length (1000) */
+  int32_t exclude_flags;           /* config.exclude_flags, -1 == None */
+  int32_t minsvlen_screen;         /* int(minsvlen_screen_ratio * minsvlen), config.py:517 */
+  int32_t long_ins_length;         /* 2500 */
+  int32_t dev_seq_cache_maxlen;    /* 50000 */
+  int32_t max_splits_base;         /* 3 */
+  int32_t detect_large_ins;        /* bool */
+  int32_t advanced_tags;           /* qc_nm_measure or phase (leadprov.py:477) */
+  int32_t dev_keep_lowqual_splits; /* bool */
+  double max_splits_kb;            /* 0.1 */
+} snf_extract_config_t;
+
+typedef struct snf_extract_input {
+  const uint8_t* records;   /* inflated BAM alignment records back to back, each starting with its block_size field */
+  int64_t records_len;
+  const int64_t* rec_off;   /* n_records + 1 byte offsets into `records` */
+  int64_t n_records;        /* file order; records of other contigs / unmapped records are skipped */
+  const uint32_t* qname_rank; /* per record: order-preserving rank of the read name */
+  int32_t region_ref_id;    /* BAM refID of the region's contig */
+  int32_t region_rank;      /* rank of the region's contig name (same ranking as contig_rank) */
+  int32_t region_start;     /* Region.start, Region.end (0-based, half open) */
+  int32_t region_end;
+  uint32_t read_id_offset;  /* LeadProvider.read_id on entry */
+  int32_t n_contigs;        /* header contigs: 64-bit FNV-1a of the name, ascending, and the rank of that name */
+  const uint64_t* contig_hash;
+  const int32_t* contig_rank;
+} snf_extract_input_t;
+
+typedef struct snf_extract_result {
+  snf_task_input_t task;    /* leads (record_lead order), seq pool, reads, ps_null_rank, qc_nm_threshold are filled;
+                               task_id / sv_id_start / contig_len / tandem repeats are the caller's */
+  int64_t n_ps;             /* phase sets: ps_value[rank] is the PS tag whose str() has that rank;                */
+  const int64_t* ps_value;  /* the entry at task.ps_null_rank stands for the literal "NULL" (tag absent)          */
+  uint32_t read_id;         /* LeadProvider.read_id on exit */
+  int64_t read_count;
+  float ms_count;           /* kernel time of the counting pass / the emitting pass (HIP events) */
+  float ms_emit;
+  int64_t algo_bytes;       /* record header + name + CIGAR + aux bytes of the region's records + sequence bytes out */
+} snf_extract_result_t;
+
+typedef struct snf_extract snf_extract_t;
+int snf_extract_create(const snf_extract_config_t* cfg, int device, snf_extract_t** out);
+int snf_extract_upload(snf_extract_t* x, const snf_extract_input_t* in); /* host -> HBM */
+int snf_extract_run(snf_extract_t* x);   /* a record the reference would raise on fails the call (ErrorResult) */
+int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out); /* library-owned until destroy / next run */
+void snf_extract_destroy(snf_extract_t* x);
+const char* snf_extract_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,3 +156,54 @@ def main_combine_task(names=None):
             f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
         ncand = sum(len(v) for smp in ref["samples"] for blk in smp for v in blk["cands"].values())
         print(f"{name:32s} {ref['n_samples']} samples  {ncand} candidates in SNF blocks -> {len(ref['calls'])} combined calls")
+
+
+def main_bam_fixtures():
+    """tests/golden/bam_hg008.bam.gz / bam_hg002.bam.gz: the reference's two test BAMs (src/tests/data) as inflated BAM
+    streams with the base qualities blanked (0xFF = absent; nothing on the path reads them), gzip-compressed."""
+    import struct
+    from sniffles_amd import bam
+    for name in ("hg008", "hg002"):
+        with open(f"/root/reference/src/tests/data/{name}.bam", "rb") as f:
+            raw = bytearray(bam.bgzf_inflate(f.read()))
+        recs = bam.parse_bam(bytes(raw))
+        start = len(raw) - recs.blob.shape[0]
+        for i in range(recs.n):
+            o = start + int(recs.rec_off[i])
+            l_name, n_cig, l_seq = raw[o + 12], struct.unpack_from("<H", raw, o + 16)[0], struct.unpack_from("<i", raw, o + 20)[0]
+            q = o + 36 + l_name + 4 * n_cig + (l_seq + 1) // 2
+            raw[q:q + l_seq] = b"\xff" * l_seq
+        path = os.path.join(ROOT, "tests", "golden", f"bam_{name}.bam.gz")
+        with gzip.GzipFile(path, "wb", mtime=0) as f:
+            f.write(bytes(raw))
+        print(f"{path}: {recs.n} records, {os.path.getsize(path)} bytes")
+
+
+def records_sha(recs) -> str:
+    h = hashlib.sha256()
+    h.update(recs.blob.tobytes())
+    h.update(recs.rec_off.tobytes())
+    h.update(repr((recs.ref_names, recs.ref_lens)).encode())
+    return h.hexdigest()
+
+
+def main_extract(names=None):
+    """Goldens for signature extraction: what the unmodified reference's build_leadtab produces for raw BAM records."""
+    import cases
+    import ref_harness as rh
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, case in cases.EXTRACT.items():
+        if names and name not in names:
+            continue
+        recs = cases.extract_records(case)
+        ref = rh.run_reference_extract(recs, case["contig"], case["region"][0], case["region"][1], case["args"],
+                                       case["read_id_offset"], case["overrides"])
+        doc = dict(case=name, reference_args=list(case["args"]), overrides=case["overrides"], input_sha=records_sha(recs),
+                   expected=ref)
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
+            f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+        if "error" in ref:
+            print(f"{name:28s} {recs.n:5d} records  error:{ref['error']}")
+        else:
+            print(f"{name:28s} {recs.n:5d} records  {ref['read_count']:5d} reads accepted  {len(ref['leads']):6d} leads "
+                  f"{ref['lead_counts']}")

@@ -356,3 +356,52 @@ def run_reference_combine_task(sample_tasks, extra_args=()):
         inputs.append(blk)
     return dict(n_samples=ns, contig=contig, contig_len=int(contig_len), samples=inputs,
                 calls=[group_call_record(c) for c in res.calls])
+
+
+# ---------------------------------------------------------------------------------------------- signature extraction
+def lead_record(ld) -> list:
+    """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""
+    b = ld.bnd_info
+    return [int(ld.read_id), ld.read_qname, ld.contig, int(ld.ref_start), int(ld.ref_end), int(ld.qry_start),
+            int(ld.qry_end), ld.strand, int(ld.mapq), None if ld.nm is None else float(ld.nm).hex(), ld.source,
+            ld.svtype, None if ld.svlen is None else int(ld.svlen), ld.seq, ld.hap, ld.phase_set, bool(ld.is_sa),
+            int(ld.read_len),
+            None if b is None else [b.mate_contig, int(b.mate_ref_start), bool(b.is_first), bool(b.is_reverse)]]
+
+
+def run_reference_extract(recs, contig, start, end, extra_args=(), read_id_offset=0, overrides=None) -> dict:
+    """`LeadProvider.build_leadtab([Region(contig, start, end)], bam)` of the UNMODIFIED reference
+    (`leadprov.py:445-472` -> `iter_region`, `read_iterindels`, `read_itersplits`, `Lead.for_bnd`,
+    `sv.classify_splits`) over `oracle/pysam_stub` objects decoded from the raw records `recs`
+    (`sniffles_amd.bam.BamRecords`).  Returns the leads in `record_lead` order, the coverage vector as a sparse
+    difference array, the REF haplotype bin counters, the read counters and the NM side channel; or
+    dict(error=ExceptionName) when the reference raises."""
+    import pysam_stub
+    ref = load_reference()
+    cfg = ref.config.SnifflesConfig("--input", "x.bam", "--vcf", "out.vcf", *extra_args)
+    cfg.mode = "call_sample"
+    for k, val in (overrides or {}).items():
+        if not hasattr(cfg, k):
+            raise KeyError(k)
+        setattr(cfg, k, val)
+    lp = ref.leadprov.LeadProvider(cfg, read_id_offset, contig)
+    leads = []
+    orig = lp.record_lead
+
+    def rec(ld, pos_leadtab):
+        leads.append(lead_record(ld))
+        orig(ld, pos_leadtab)
+    lp.record_lead = rec
+    bam = pysam_stub.AlignmentFile(recs)
+    try:
+        externals = lp.build_leadtab([ref.leadprov.Region(contig, start, end)], bam)
+    except Exception as e:
+        return dict(error=type(e).__name__)
+    cov = lp.coverage.astype(np.int64)
+    d = np.diff(cov, prepend=0)
+    nz = np.nonzero(d)[0]
+    hapref = sorted([int(k)] + [int(x) for x in v] for k, v in lp.leadhapcount["REF"].items())
+    return dict(leads=leads, n_externals=len(externals), cov_pos=nz.tolist(), cov_delta=d[nz].tolist(),
+                contig_len=int(cov.shape[0]), hapref=hapref, read_count=int(lp.read_count), read_id=int(lp.read_id),
+                qc_nm_threshold=float(cfg.qc_nm_threshold).hex(),
+                lead_counts={k: int(v) for k, v in lp.leadcounts.items()})

@@ -279,3 +279,39 @@ class Result:
 def none_if_nan(x):
     x = float(x)
     return None if math.isnan(x) else x
+
+
+# ---------------------------------------------------------------------------------------------- signature extraction
+class snf_extract_config_t(C.Structure):
+    _fields_ = [("mapq", i32), ("min_alignment_length", i32), ("exclude_flags", i32), ("minsvlen_screen", i32),
+                ("long_ins_length", i32), ("dev_seq_cache_maxlen", i32), ("max_splits_base", i32),
+                ("detect_large_ins", i32), ("advanced_tags", i32), ("dev_keep_lowqual_splits", i32),
+                ("max_splits_kb", f64)]
+
+
+class snf_extract_input_t(C.Structure):
+    _fields_ = [("records", u8p), ("records_len", i64), ("rec_off", C.POINTER(C.c_int64)), ("n_records", i64),
+                ("qname_rank", C.POINTER(C.c_uint32)), ("region_ref_id", i32), ("region_rank", i32),
+                ("region_start", i32), ("region_end", i32), ("read_id_offset", C.c_uint32), ("n_contigs", i32),
+                ("contig_hash", C.POINTER(C.c_uint64)), ("contig_rank", C.POINTER(C.c_int32))]
+
+
+class snf_extract_result_t(C.Structure):
+    _fields_ = [("task", snf_task_input_t), ("n_ps", i64), ("ps_value", C.POINTER(C.c_int64)),
+                ("read_id", C.c_uint32), ("read_count", i64), ("ms_count", C.c_float), ("ms_emit", C.c_float),
+                ("algo_bytes", i64)]
+
+
+def extract_config_struct(cfg) -> snf_extract_config_t:
+    """`cfg`: anything with the SnifflesConfig attribute names extraction reads (config.py:190-215, 507-617)."""
+    g = lambda name, default: getattr(cfg, name, default)
+    ex = g("exclude_flags", None)
+    qc_nm_measure = g("qc_nm_measure", g("qc_nm", True))
+    return snf_extract_config_t(
+        mapq=int(g("mapq", 20)), min_alignment_length=int(g("min_alignment_length", 1000)),
+        exclude_flags=-1 if ex is None else int(ex), minsvlen_screen=int(g("minsvlen_screen", 45)),
+        long_ins_length=int(g("long_ins_length", 2500)), dev_seq_cache_maxlen=int(g("dev_seq_cache_maxlen", 50000)),
+        max_splits_base=int(g("max_splits_base", 3)), detect_large_ins=int(bool(g("detect_large_ins", True))),
+        advanced_tags=int(bool(g("advanced_tags", qc_nm_measure or g("phase", False)))),
+        dev_keep_lowqual_splits=int(bool(g("dev_keep_lowqual_splits", False))),
+        max_splits_kb=float(g("max_splits_kb", 0.1)))

@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libsniffles_amd.so")
-SOURCES = ["snf_lib.hip", "snf_myers.hip", "snf_combine.hip"]
+SOURCES = ["snf_lib.hip", "snf_myers.hip", "snf_combine.hip", "snf_extract.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-unused-result", "-Wno-unused-value"]
 

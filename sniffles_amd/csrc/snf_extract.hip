@@ -1,0 +1,1011 @@
+// snf_extract.hip - SV-signature extraction from raw BAM alignment records.
+//
+// Reference behaviour restated on the GPU (one Region of one contig):
+//   iter_region       leadprov.py:474-578   read filter, read ids, coverage / REF-haplotype bookkeeping, NM side channel
+//   read_iterindels   leadprov.py:580-655   INS / DEL / clip signatures from the CIGAR
+//   Lead.for_bnd      leadprov.py:57-132    BND signature from the first SA element
+//   CIGAR_analyze     leadprov.py:144-178   clip / span summary of an SA CIGAR string
+//   read_itersplits   leadprov.py:221-355   split alignments -> leads
+//   classify_splits   sv.py:649-782         INS / DEL / DUP / INV geometry of consecutive splits
+//   build_leadtab     leadprov.py:445-472   keep the leads of this contig inside [start, end)
+// pysam properties are computed from the record bytes (SAM/BAM spec 4.2; htslib bam_endpos, pysam getQueryStart/End).
+//
+// Mapping: one WAVE per alignment record.  The CIGAR (4 B per operation, thousands of operations per long read) is
+// walked 256 operations per step (4 per lane, next step prefetched): two DPP wave prefix sums give every lane the read /
+// reference position of its operations, a third ranks the signature-bearing operations so leads come out in CIGAR order.
+// Inserted sequence is decoded from the 4-bit packed read by the whole wave.  Tag strings are scanned 64 bytes per
+// step.  The per-record split-alignment logic (a handful of SA elements) is sequential and runs on lane 0 with its
+// segment table in LDS.  Two passes over the records (count, emit) around three device scans give exact output
+// offsets, so the leads land in `record_lead` order without atomics.
+// HBM-bound byte/integer work: no MFMA.  Algorithmic bytes per record: 36 B core + name + 4 B x n_cigar + aux bytes,
+// plus the inserted bases read (0.5 B) and written (1 B); sequence and quality bytes of the read are never touched.
+// The thread form (WAVE == false) is what the host emulation executes (tests/emu) and SNF_EXTRACT_THREAD=1 selects.
+#include "snf_rt.h"
+#include "../../include/sniffles_amd.h"
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#ifndef SNF_EMU
+#include <rocprim/device/device_scan.hpp>
+#endif
+
+namespace snf {
+
+enum {
+  XE_OK = 0, XE_NOCIGAR, XE_CIGAROP, XE_CLIP, XE_AUX, XE_TAGTYPE, XE_HP, XE_NOSEQ, XE_SA_FIELDS, XE_SA_NUMBER,
+  XE_SA_STRAND, XE_SA_CONTIG, XE_SPLITS, XE_RANGE
+};
+static const char* const XE_TEXT[] = {
+  "ok", "mapped record without CIGAR (reference_end is None)", "CIGAR operation > 8", "invalid clipping in CIGAR (pysam ValueError)",
+  "malformed auxiliary field", "NM/HP/PS not an integer tag or SA not a Z tag", "HP tag outside 0..2 (IndexError in record_lead)",
+  "record without sequence but an inserted sequence is needed (TypeError)", "SA element without 6 fields (ValueError)",
+  "SA number field not a plain integer", "SA strand not '+' or '-'", "SA contig not in the header",
+  "more split alignments than the device table holds (64)", "value outside the 32-bit / 8-bit column range"};
+
+#define XMAXSEG 64
+
+struct RecSum {          // per record, written by the counting pass
+  int64_t seq_bytes;     // bytes this record adds to the sequence pool
+  int64_t sa_off;        // byte offset of the SA string in the blob, -1: no SA tag
+  int64_t ps;            // PS tag (has_ps)
+  double nm;             // (NM - large indels) / (query_alignment_length + 1), or -1
+  int32_t n_leads, ref_end, nm_tag;
+  int32_t walk_lo, walk_hi;   // CIGAR steps [walk_lo, walk_hi) hold every lead-bearing operation (emit pass walks only these)
+  uint32_t walk_pr, walk_pf;  // read / reference position at walk_lo
+  uint8_t accept, has_nm, has_ps, hp;
+};
+
+struct Seg {             // one (split) alignment of a read in classify_splits
+  int32_t contig, rs, re, qs, qe, mapq;
+  int32_t hint_type, hint_start, hint_len;   // hint_type -1: none; hint_len SNF_SVLEN_NONE: None
+  int32_t seq_a, seq_n;                      // slice of the read sequence attached to the split (seq_n -1: None)
+  int64_t job_dst;                           // emit pass: pool offset the slice is copied to, -1: nothing to copy
+  uint8_t rev, source;
+};
+
+struct ExView {
+  snf_extract_config_t cfg;
+  const uint8_t* blob; const int64_t* rec_off; const uint32_t* qname_rank; int64_t n_records;
+  int32_t region_ref_id, region_rank, region_start, region_end; uint32_t read_id_offset;
+  const uint64_t* ctg_hash; const int32_t* ctg_rank; int32_t n_contigs;
+  RecSum* sum;
+  unsigned long long* err;   // min over (record << 8 | code); ~0: none
+  // scan inputs / outputs (n_records + 1)
+  int64_t *c_acc, *c_leads, *c_seq;
+  const int64_t *read_idx, *lead_off, *seq_off;
+  const int64_t* ps_val; const int32_t* ps_rank; int32_t n_ps, ps_null_rank;
+  // lead columns
+  int32_t *o_ref_start, *o_ref_end, *o_qry_start, *o_qry_end, *o_svlen, *o_read_len, *o_ps, *o_mate_contig, *o_mate_pos, *o_seq_len;
+  uint32_t *o_qname, *o_read_id; int64_t* o_seq_off; double* o_nm;
+  uint8_t *o_svtype, *o_strand, *o_mapq, *o_source, *o_hap, *o_is_sa, *o_first, *o_rev;
+  uint8_t* o_pool;
+  int32_t *o_rstart, *o_rend; uint8_t* o_rhp;
+  double* nm_out;   // [0] sum, [1] count
+};
+
+// ---- lane helpers: WAVE == true only exists in device code ----------------------------------------------------
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#define XDEV 1
+#else
+#define XDEV 0
+#endif
+
+template <bool WAVE> SNF_HD int x_lane() {
+#if XDEV
+  return WAVE ? (int)(threadIdx.x & 63) : 0;
+#else
+  return 0;
+#endif
+}
+template <bool WAVE> SNF_HD uint64_t x_ballot(bool p) {
+#if XDEV
+  if (WAVE) return __ballot(p);
+#endif
+  return p ? 1ull : 0ull;
+}
+// inclusive prefix sum over the wave: Hillis-Steele inside each row of 16 lanes through DPP row shifts, then the row
+// totals are passed on with row_bcast:15 / row_bcast:31 (gfx9 DPP).  Needs all 64 lanes active.
+template <bool WAVE> SNF_HD uint32_t x_incl_scan(uint32_t x, int lane) {
+#if XDEV
+  if (WAVE) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+  }
+#endif
+  (void)lane;
+  return x;
+}
+template <bool WAVE> SNF_HD uint32_t x_bcast(uint32_t x, int src) {
+#if XDEV
+  if (WAVE) return (uint32_t)__shfl((int)x, src, 64);
+#endif
+  (void)src;
+  return x;
+}
+template <bool WAVE> SNF_HD int64_t x_bcast64(int64_t x, int src) {
+#if XDEV
+  if (WAVE) return (int64_t)__shfl((long long)x, src, 64);
+#endif
+  (void)src;
+  return x;
+}
+template <bool WAVE> SNF_HD void x_wave_sync() {
+#if XDEV
+  if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#endif
+}
+SNF_HD int x_popc(uint64_t m) { return __builtin_popcountll(m); }
+SNF_HD int x_ctz(uint64_t m) { return __builtin_ctzll(m); }
+
+SNF_HD uint32_t ld_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+// unaligned little-endian dword: two aligned loads and a funnel shift on the device (the blob is padded by 8 bytes)
+SNF_HD uint32_t ld_u32(const uint8_t* p) {
+#if XDEV
+  const uintptr_t a = (uintptr_t)p;
+  const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+  const unsigned sh = (unsigned)(a & 3) * 8;
+  const uint32_t lo = q[0];
+  if (!sh) return lo;
+  return (lo >> sh) | (q[1] << (32 - sh));
+#else
+  uint32_t v; memcpy(&v, p, 4); return v;
+#endif
+}
+// the CIGAR operations [base + lane * OPL, + OPL) of a record; operations past the end read as 0P.  Wave form: the four
+// dwords of a lane come from five aligned dwords realigned by v_alignbyte (the record is byte-aligned in the blob).
+template <bool WAVE> SNF_HD void x_load_ops(const uint8_t* cig, int n_cig, int base, int lane, uint32_t* dst) {
+#if XDEV
+  if (WAVE) {
+    const int k0 = base + lane * 4;
+    if (k0 + 4 <= n_cig) {
+      const uintptr_t a = (uintptr_t)(cig + 4 * (int64_t)k0);
+      const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+      const uint32_t mis = (uint32_t)(a & 3);
+      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+      dst[0] = __builtin_amdgcn_alignbyte(d1, d0, mis); dst[1] = __builtin_amdgcn_alignbyte(d2, d1, mis);
+      dst[2] = __builtin_amdgcn_alignbyte(d3, d2, mis); dst[3] = __builtin_amdgcn_alignbyte(d4, d3, mis);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) dst[j] = k0 + j < n_cig ? ld_u32(cig + 4 * (int64_t)(k0 + j)) : 6u;
+    }
+    return;
+  }
+#endif
+  dst[0] = base + lane < n_cig ? ld_u32(cig + 4 * (int64_t)(base + lane)) : 6u;
+}
+SNF_HD void x_error(const ExView& v, int64_t rec, int code) {
+  unsigned long long w = ((unsigned long long)rec << 8) | (unsigned)code;
+#if XDEV
+  atomicMin(v.err, w);
+#else
+  if (w < *v.err) *v.err = w;
+#endif
+}
+SNF_HD uint8_t x_base(uint32_t nib) {   // "=ACMGRSVTWYHKDBN"
+  const uint64_t t0 = 0x565352474D43413DULL;   // '=' 'A' 'C' 'M' 'G' 'R' 'S' 'V'
+  const uint64_t t1 = 0x4E42444B48595754ULL;   // 'T' 'W' 'Y' 'H' 'K' 'D' 'B' 'N'
+  return (uint8_t)(((nib & 8) ? t1 : t0) >> ((nib & 7) * 8));
+}
+#define X_REFC 0x18Du    // M D N = X consume the reference
+#define X_QRYC 0x193u    // M I S = X consume the read (OPTAB add_read, leadprov.py:182-192)
+#define X_EVENT 0x016u   // I D S (OPTAB event column)
+
+// offset of the first NUL in blob[p, end), -1 if none
+template <bool WAVE> SNF_HD int64_t x_find_nul(const uint8_t* blob, int64_t p, int64_t end, int lane) {
+  const int W = WAVE ? 64 : 1;
+  for (int64_t q = p; q < end; q += W) {
+    const bool z = (q + lane < end) && blob[q + lane] == 0;
+    const uint64_t m = x_ballot<WAVE>(z);
+    if (m) return q + x_ctz(m);
+  }
+  return -1;
+}
+
+// copy read bases [a, a + n) (4-bit packed at seq) as ASCII to dst, all lanes
+template <bool WAVE> SNF_HD void x_copy_bases(const uint8_t* seq, int32_t a, int32_t n, uint8_t* dst, int lane) {
+  const int W = WAVE ? 64 : 1;
+  for (int32_t j = lane; j < n; j += W) {
+    const int32_t i = a + j;
+    const uint32_t b = seq[i >> 1];
+    dst[j] = x_base((i & 1) ? (b & 15) : (b >> 4));
+  }
+}
+
+// ---- SA string parsing (sequential; lane 0) --------------------------------------------------------------------
+struct SaElem { int64_t f0[6], f1[6]; int nf; };   // field byte ranges [f0, f1) of one SA element
+
+// next non-empty element of the ';' separated string starting at *p (NUL terminated); false at the end
+SNF_HD bool sa_next(const uint8_t* s, int64_t* p, SaElem* e) {
+  for (;;) {
+    int64_t a = *p;
+    if (s[a] == 0) return false;
+    int64_t b = a;
+    while (s[b] != 0 && s[b] != ';') b++;
+    *p = s[b] == ';' ? b + 1 : b;
+    if (b == a) continue;
+    e->nf = 0;
+    int64_t fs = a;
+    for (int64_t k = a; k <= b; k++) {
+      if (k == b || s[k] == ',') {
+        if (e->nf < 6) { e->f0[e->nf] = fs; e->f1[e->nf] = k; }
+        e->nf++;
+        fs = k + 1;
+      }
+    }
+    return true;
+  }
+}
+SNF_HD bool sa_int(const uint8_t* s, int64_t a, int64_t b, int64_t* out) {
+  bool neg = false;
+  if (a < b && (s[a] == '-' || s[a] == '+')) { neg = s[a] == '-'; a++; }
+  if (a >= b || b - a > 18) return false;
+  int64_t v = 0;
+  for (int64_t k = a; k < b; k++) { if (s[k] < '0' || s[k] > '9') return false; v = v * 10 + (s[k] - '0'); }
+  *out = neg ? -v : v;
+  return true;
+}
+// CIGAR_analyze (leadprov.py:144-178); false = the reference raises inside its try block
+SNF_HD bool sa_cigar(const uint8_t* s, int64_t a, int64_t b, int64_t* clip0, int64_t* clip1, int64_t* refspan, int64_t* readspan) {
+  int64_t num = 0, rd = 0, rf = 0, clip = 0, first = -1; bool have = false;
+  for (int64_t k = a; k < b; k++) {
+    const uint8_t c = s[k];
+    if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); have = true; continue; }
+    if (!have) return false;
+    const bool q = c == 'M' || c == 'I' || c == 'X' || c == '=';
+    const bool r = c == 'M' || c == 'D' || c == 'X' || c == '=' || c == 'N';
+    if (q) rd += num;
+    if (r) rf += num;
+    if (!q && !r) {
+      if (c != 'S' && c != 'H') return false;
+      if (first < 0 && rd + rf > 0) first = clip;
+      clip += num;
+    }
+    num = 0; have = false;
+  }
+  if (first < 0) first = clip;
+  *clip0 = first; *clip1 = clip - first; *refspan = rf; *readspan = rd;
+  return true;
+}
+SNF_HD int32_t sa_contig(const ExView& v, const uint8_t* s, int64_t a, int64_t b) {
+  uint64_t h = 0xcbf29ce484222325ULL;
+  for (int64_t k = a; k < b; k++) h = (h ^ s[k]) * 0x100000001b3ULL;
+  int lo = 0, hi = v.n_contigs;
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (v.ctg_hash[mid] < h) lo = mid + 1; else hi = mid; }
+  return (lo < v.n_contigs && v.ctg_hash[lo] == h) ? v.ctg_rank[lo] : -1;
+}
+SNF_HD bool fits_i32(int64_t x) { return x >= INT32_MIN + 1 && x <= INT32_MAX; }
+
+// ---- one lead row ------------------------------------------------------------------------------------------------
+struct LeadRow {
+  int32_t ref_start, ref_end, qry_start, qry_end, svlen, read_len, ps, mate_contig, mate_pos, seq_len;
+  int64_t seq_off; double nm; uint8_t svtype, strand, mapq, source, hap, is_sa, first, rev;
+};
+SNF_HD void put_lead(const ExView& v, int64_t i, const LeadRow& r, uint32_t qname, uint32_t read_id) {
+  v.o_ref_start[i] = r.ref_start; v.o_ref_end[i] = r.ref_end; v.o_qry_start[i] = r.qry_start; v.o_qry_end[i] = r.qry_end;
+  v.o_svlen[i] = r.svlen; v.o_read_len[i] = r.read_len; v.o_ps[i] = r.ps; v.o_mate_contig[i] = r.mate_contig;
+  v.o_mate_pos[i] = r.mate_pos; v.o_seq_len[i] = r.seq_len; v.o_seq_off[i] = r.seq_off; v.o_nm[i] = r.nm;
+  v.o_qname[i] = qname; v.o_read_id[i] = read_id;
+  v.o_svtype[i] = r.svtype; v.o_strand[i] = r.strand; v.o_mapq[i] = r.mapq; v.o_source[i] = r.source; v.o_hap[i] = r.hap;
+  v.o_is_sa[i] = r.is_sa; v.o_first[i] = r.first; v.o_rev[i] = r.rev;
+}
+
+// classify_splits (sv.py:649-782) over segs[ord[0..n)); returns the (possibly filtered) count
+SNF_HD int classify(const ExView& v, Seg* segs, uint8_t* ord, int n, int32_t l_seq, int64_t rec) {
+  const int32_t m = v.cfg.minsvlen_screen;
+  for (int pass = 0; pass < 2; pass++) {
+    // stable insertion sort by query start
+    for (int i = 1; i < n; i++) {
+      const uint8_t x = ord[i]; int j = i;
+      while (j > 0 && segs[ord[j - 1]].qs > segs[x].qs) { ord[j] = ord[j - 1]; j--; }
+      ord[j] = x;
+    }
+    for (int i = 0; i < n; i++) segs[ord[i]].hint_type = -1;
+    int hints = 0;
+    { Seg& f = segs[ord[0]];
+      if ((double)f.qs >= (double)v.cfg.long_ins_length * 0.5) { f.hint_type = SNF_INS; f.hint_start = f.rs; f.hint_len = SNF_SVLEN_NONE; } }
+    for (int i = 1; i < n; i++) {
+      const Seg& a = segs[ord[i - 1]]; Seg& b = segs[ord[i]];
+      if (a.contig != b.contig) continue;
+      const bool fwd = !b.rev;
+      const int64_t dq = (int64_t)b.qs - a.qe;
+      if (a.rev == b.rev) {
+        const int64_t dr = fwd ? (int64_t)b.rs - a.re : (int64_t)a.rs - b.re;
+        const int32_t at = fwd ? b.rs : a.rs;
+        if (dq >= m && dq - dr >= m) {
+          if (dq <= v.cfg.dev_seq_cache_maxlen) {
+            if (l_seq == 0) x_error(v, rec, XE_NOSEQ);
+            const int32_t lo = a.qe < l_seq ? a.qe : l_seq, hi = b.qs < l_seq ? b.qs : l_seq;
+            b.seq_a = lo; b.seq_n = hi > lo ? hi - lo : 0;
+          } else b.seq_n = -1;
+          if (!fits_i32(dq)) x_error(v, rec, XE_RANGE);
+          b.hint_type = SNF_INS; b.hint_start = at; b.hint_len = (int32_t)dq; hints++;
+        } else if (dr >= m && dr - dq >= m) {
+          if (!fits_i32(dr)) x_error(v, rec, XE_RANGE);
+          b.hint_type = SNF_DEL; b.hint_start = at; b.hint_len = (int32_t)-dr; hints++;
+        } else if (dr <= 0) {
+          if (-dr >= m) { if (!fits_i32(dr)) x_error(v, rec, XE_RANGE); b.hint_type = SNF_DUP; b.hint_start = at; b.hint_len = (int32_t)-dr; hints++; }
+        }
+      } else {
+        const int64_t x = fwd ? a.rs : a.re, y = fwd ? b.rs : b.re;
+        const int64_t lo = x < y ? x : y, hi = x < y ? y : x;
+        if (hi - lo >= m) { if (!fits_i32(hi - lo)) x_error(v, rec, XE_RANGE); b.hint_type = SNF_INV; b.hint_start = (int32_t)lo; b.hint_len = (int32_t)(hi - lo); hints++; }
+      }
+    }
+    if (hints || n <= 2) return n;
+    // no hint: keep the splits on the contig / strand of the first one; exactly two left -> classify those again
+    const Seg& l = segs[ord[0]];
+    int k = 0;
+    for (int i = 0; i < n; i++) if (segs[ord[i]].contig == l.contig && segs[ord[i]].rev == l.rev) ord[k++] = ord[i];
+    n = k;
+    if (n != 2) return n;
+  }
+  return n;
+}
+
+// ---- one alignment record ----------------------------------------------------------------------------------------
+template <bool WAVE, bool EMIT>
+SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord) {
+  const int lane = x_lane<WAVE>();
+  const int W = WAVE ? 64 : 1;
+  const snf_extract_config_t& cfg = v.cfg;
+  const uint8_t* R = v.blob + v.rec_off[rec];
+  RecSum& S = v.sum[rec];
+  if (EMIT) { if (!S.accept) return; }
+  else if (lane == 0) { S.accept = 0; S.n_leads = 0; S.seq_bytes = 0; S.has_nm = 0; S.has_ps = 0; S.nm = -1.0; S.sa_off = -1; S.hp = 0; S.ps = 0; S.nm_tag = 0; S.ref_end = 0; }
+  const int32_t block_size = (int32_t)ld_u32(R);
+  const int32_t ref_id = (int32_t)ld_u32(R + 4), pos = (int32_t)ld_u32(R + 8);
+  const int l_name = R[12], mapq = R[13];
+  const int n_cig = (int)ld_u16(R + 16), flag = (int)ld_u16(R + 18);
+  const int32_t l_seq = (int32_t)ld_u32(R + 20);
+  if (ref_id != v.region_ref_id || (flag & 0x4)) return;
+  if (n_cig == 0) { if (!EMIT && lane == 0) x_error(v, rec, XE_NOCIGAR); return; }
+  const uint8_t* cig = R + 36 + l_name;
+  const uint8_t* seq = cig + 4 * (int64_t)n_cig;
+  const int64_t aux0 = (int64_t)(seq - v.blob) + (l_seq + 1) / 2 + l_seq, aux1 = v.rec_off[rec] + 4 + block_size;
+  // pysam getQueryStart / getQueryEnd
+  int32_t q0 = 0, q1 = l_seq; bool clip_bad = false;
+  for (int k = 0; k < n_cig; k++) {
+    const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
+    if (op == 5) { if (q0 != 0 && q0 != l_seq) clip_bad = true; }
+    else if (op == 4) q0 += (int32_t)(c >> 4);
+    else break;
+  }
+  if (l_seq == 0) {
+    q1 = 0;   // no sequence: length from the CIGAR (M I = X, and S while nothing was counted yet); rare, lane-serial
+    for (int k = 0; k < n_cig; k++) {
+      const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
+      if (op == 0 || op == 1 || op == 7 || op == 8 || (op == 4 && q1 == 0)) q1 += (int32_t)(c >> 4);
+    }
+  } else {
+    for (int k = n_cig - 1; k >= 1; k--) {
+      const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
+      if (op == 5) { if (q1 != l_seq) clip_bad = true; }
+      else if (op == 4) q1 -= (int32_t)(c >> 4);
+      else break;
+    }
+  }
+  const int32_t qal = q1 - q0;
+  // iter_region filter (leadprov.py:493-501).  pysam evaluates the clip properties first: a bad clip raises there.
+  if (clip_bad) { if (!EMIT && lane == 0) x_error(v, rec, XE_CLIP); return; }
+  if (mapq < cfg.mapq || (flag & 0x100) || qal < cfg.min_alignment_length) return;
+  if (cfg.exclude_flags >= 0 && (flag & cfg.exclude_flags)) return;
+  if (pos < v.region_start || pos >= v.region_end) return;
+  // ---- tags (first NM / HP / PS / SA)
+  int64_t sa_off = -1, ps = 0; int32_t nm_tag = 0; int hp = 0; bool has_nm = false, has_ps = false;
+  if (!EMIT) {
+    bool has_hp = false; int bad = 0;
+    int64_t p = aux0;
+    while (p + 3 <= aux1 && !bad) {
+      const uint8_t t0 = v.blob[p], t1 = v.blob[p + 1], ty = v.blob[p + 2];
+      p += 3;
+      int64_t val = 0; bool isint = true; int64_t zs = -1;
+      switch (ty) {
+        case 'A': isint = false; p += 1; break;
+        case 'c': val = (int8_t)v.blob[p]; p += 1; break;
+        case 'C': val = v.blob[p]; p += 1; break;
+        case 's': val = (int16_t)ld_u16(v.blob + p); p += 2; break;
+        case 'S': val = ld_u16(v.blob + p); p += 2; break;
+        case 'i': val = (int32_t)ld_u32(v.blob + p); p += 4; break;
+        case 'I': val = ld_u32(v.blob + p); p += 4; break;
+        case 'f': isint = false; p += 4; break;
+        case 'Z': case 'H': {
+          isint = false; zs = p;
+          const int64_t z = x_find_nul<WAVE>(v.blob, p, aux1, lane);
+          if (z < 0) bad = XE_AUX; else p = z + 1;
+          break; }
+        case 'B': {
+          isint = false;
+          const uint8_t sub = v.blob[p]; const int64_t cnt = (int32_t)ld_u32(v.blob + p + 1);
+          const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+          if (!sz || cnt < 0) bad = XE_AUX; else p += 5 + cnt * sz;
+          break; }
+        default: bad = XE_AUX;
+      }
+      if (bad) break;
+      if (t0 == 'N' && t1 == 'M' && !has_nm) { if (!isint) bad = XE_TAGTYPE; has_nm = true; nm_tag = (int32_t)val; if (!fits_i32(val)) bad = XE_RANGE; }
+      else if (t0 == 'H' && t1 == 'P' && !has_hp) { if (!isint) bad = XE_TAGTYPE; has_hp = true; if (val < 0 || val > 2) bad = bad ? bad : XE_HP; hp = (int)val; }
+      else if (t0 == 'P' && t1 == 'S' && !has_ps) { if (!isint) bad = XE_TAGTYPE; has_ps = true; ps = val; }
+      else if (t0 == 'S' && t1 == 'A' && sa_off < 0) { if (ty != 'Z') bad = XE_TAGTYPE; sa_off = zs; }
+    }
+    if (!bad && p > aux1) bad = XE_AUX;
+    if (bad) { if (lane == 0) x_error(v, rec, bad); return; }
+  } else {
+    sa_off = S.sa_off; ps = S.ps; nm_tag = S.nm_tag; hp = S.hp; has_nm = S.has_nm; has_ps = S.has_ps;
+  }
+  const bool supp = (flag & 0x800) != 0, rev = (flag & 0x10) != 0;
+  const bool use_clips = cfg.detect_large_ins && !supp && sa_off < 0;
+  const double half_long = (double)cfg.long_ins_length / 2.0;
+  int32_t ps_rank = v.ps_null_rank;
+  int64_t lead_base = 0, seq_base = 0; uint32_t read_id = 0, qname = 0; double nm = -1.0;
+  if (EMIT) {
+    if (has_ps) {
+      int lo = 0, hi = v.n_ps;
+      while (lo < hi) { int mid = (lo + hi) >> 1; if (v.ps_val[mid] < ps) lo = mid + 1; else hi = mid; }
+      ps_rank = v.ps_rank[lo];
+    }
+    lead_base = v.lead_off[rec]; seq_base = v.seq_off[rec];
+    read_id = v.read_id_offset + (uint32_t)v.read_idx[rec] + 1;
+    qname = v.qname_rank[rec]; nm = S.nm;
+  }
+  // ---- read_iterindels: 256 CIGAR operations per step (4 consecutive operations per lane), next step prefetched
+  constexpr int OPL = WAVE ? 4 : 1;
+  const int STEP = W * OPL;
+  uint32_t pr = 0, pf = (uint32_t)pos;
+  int32_t lead_k = 0; int64_t seqb = 0; uint32_t large = 0; int bad_op = 0;
+  int base0 = 0, base1 = n_cig;
+  int32_t w_lo = 0, w_hi = 0; uint32_t w_pr = 0, w_pf = 0;   // counting pass: the span of steps that produced leads
+  if (EMIT) { base0 = S.walk_lo; base1 = S.walk_hi; pr = S.walk_pr; pf = S.walk_pf; }
+  uint32_t cur[OPL], nxt[OPL];
+  if (base0 < base1) x_load_ops<WAVE>(cig, n_cig, base0, lane, cur);
+  for (int base = base0; base < base1; base += STEP) {
+#pragma unroll
+    for (int j = 0; j < OPL; j++) nxt[j] = 6u;
+    if (base + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + STEP, lane, nxt);
+    uint32_t aq_l = 0, ar_l = 0;
+#pragma unroll
+    for (int j = 0; j < OPL; j++) {
+      const uint32_t op = cur[j] & 15, len = cur[j] >> 4;
+      if (op > 8) bad_op = 1;
+      const uint32_t opm = op > 8 ? 0u : (1u << op);
+      aq_l += (X_QRYC & opm) ? len : 0u; ar_l += (X_REFC & opm) ? len : 0u;
+      if ((op == 1 || op == 2) && len > 10) large += len;
+    }
+    const uint32_t iq = x_incl_scan<WAVE>(aq_l, lane), ir = x_incl_scan<WAVE>(ar_l, lane);
+    const uint32_t lane_pr = pr + iq - aq_l, lane_pf = pf + ir - ar_l;
+    // signature-bearing operations of this lane
+    uint32_t cnt_l = 0, sb_l = 0;
+    { uint32_t p_r = lane_pr, p_f = lane_pf;
+#pragma unroll
+      for (int j = 0; j < OPL; j++) {
+        const uint32_t op = cur[j] & 15, len = cur[j] >> 4;
+        const uint32_t opm = op > 8 ? 0u : (1u << op);
+        if ((X_EVENT & opm) && (int64_t)len >= cfg.minsvlen_screen) {
+          const int32_t rs = (int32_t)(op == 2 ? p_f + len : p_f);
+          const bool out = rs >= v.region_start && rs < v.region_end;
+          if (op == 1 && (int64_t)len <= cfg.dev_seq_cache_maxlen) {
+            if (l_seq == 0) bad_op = 2;
+            const uint32_t ls = (uint32_t)l_seq, lo = p_r < ls ? p_r : ls, hi = p_r + len < ls ? p_r + len : ls;
+            if (out) sb_l += hi - lo;
+          }
+          cnt_l += out ? 1u : 0u;
+        }
+        p_r += (X_QRYC & opm) ? len : 0u; p_f += (X_REFC & opm) ? len : 0u;
+      } }
+    if (x_ballot<WAVE>(cnt_l != 0)) {
+      if (!EMIT) { if (w_hi == 0) { w_lo = base; w_pr = pr; w_pf = pf; } w_hi = base + STEP; }
+      const uint32_t ic = x_incl_scan<WAVE>(cnt_l, lane), isb = x_incl_scan<WAVE>(sb_l, lane);
+      if (EMIT) {
+        int64_t my_k = lead_base + lead_k + (ic - cnt_l), my_so = seq_base + seqb + (isb - sb_l);
+        int32_t cp_a[OPL], cp_n[OPL]; int64_t cp_dst[OPL];
+        uint32_t p_r = lane_pr, p_f = lane_pf;
+#pragma unroll
+        for (int j = 0; j < OPL; j++) {
+          const uint32_t op = cur[j] & 15, len = cur[j] >> 4;
+          const uint32_t opm = op > 8 ? 0u : (1u << op);
+          cp_n[j] = 0; cp_a[j] = 0; cp_dst[j] = 0;
+          if ((X_EVENT & opm) && (int64_t)len >= cfg.minsvlen_screen) {
+            LeadRow r{};
+            r.qry_start = (int32_t)p_r; r.qry_end = (int32_t)(p_r + len); r.ref_start = r.ref_end = (int32_t)p_f;
+            r.seq_len = SNF_SEQ_NONE; r.source = SNF_SRC_INLINE;
+            if (op == 1) {
+              r.svtype = SNF_INS; r.svlen = (int32_t)len;
+              if ((int64_t)len <= cfg.dev_seq_cache_maxlen) {
+                const uint32_t ls = (uint32_t)l_seq, lo = p_r < ls ? p_r : ls, hi = p_r + len < ls ? p_r + len : ls;
+                r.seq_len = (int32_t)(hi - lo); cp_a[j] = (int32_t)lo;
+              }
+            } else if (op == 2) {
+              r.svtype = SNF_DEL; r.svlen = -(int32_t)len; r.ref_start = (int32_t)(p_f + len); r.qry_end = (int32_t)p_r;
+            } else if (use_clips && (double)len >= half_long) {
+              r.svtype = SNF_INS; r.svlen = SNF_SVLEN_NONE;
+            } else {
+              r.svtype = p_f == (uint32_t)pos ? SNF_SINGLE_LEFT : SNF_SINGLE_RIGHT; r.svlen = 0;
+            }
+            if (r.ref_start >= v.region_start && r.ref_start < v.region_end) {
+              r.read_len = qal; r.ps = ps_rank; r.nm = nm; r.strand = rev; r.mapq = (uint8_t)mapq; r.hap = (uint8_t)hp; r.is_sa = supp;
+              r.seq_off = r.seq_len >= 0 ? my_so : 0;
+              put_lead(v, my_k++, r, qname, read_id);
+              if (r.seq_len > 0) { cp_n[j] = r.seq_len; cp_dst[j] = my_so; my_so += r.seq_len; }
+            }
+          }
+          p_r += (X_QRYC & opm) ? len : 0u; p_f += (X_REFC & opm) ? len : 0u;
+        }
+        // inserted bases: every lane's pending slices are decoded by the whole wave
+#pragma unroll
+        for (int j = 0; j < OPL; j++) {
+          uint64_t cm = x_ballot<WAVE>(cp_n[j] > 0);
+          while (cm) {
+            const int src = x_ctz(cm); cm &= cm - 1;
+            const int32_t ca = (int32_t)x_bcast<WAVE>((uint32_t)cp_a[j], src), cn = (int32_t)x_bcast<WAVE>((uint32_t)cp_n[j], src);
+            const int64_t dst = x_bcast64<WAVE>(cp_dst[j], src);
+            x_copy_bases<WAVE>(seq, ca, cn, v.o_pool + dst, lane);
+          }
+        }
+      }
+      lead_k += (int32_t)x_bcast<WAVE>(ic, W - 1); seqb += x_bcast<WAVE>(isb, W - 1);
+    }
+    pr += x_bcast<WAVE>(iq, W - 1); pf += x_bcast<WAVE>(ir, W - 1);
+#pragma unroll
+    for (int j = 0; j < OPL; j++) cur[j] = nxt[j];
+  }
+  if (!EMIT && x_ballot<WAVE>(bad_op != 0)) {
+    const uint64_t b2 = x_ballot<WAVE>(bad_op == 2);
+    if (lane == 0) x_error(v, rec, b2 ? XE_NOSEQ : XE_CIGAROP);
+    return;
+  }
+  const int32_t ref_end = EMIT ? S.ref_end : (pf == (uint32_t)pos ? pos + 1 : (int32_t)pf);
+  if (!EMIT) {
+    const uint32_t il = x_incl_scan<WAVE>(large, lane);
+    const uint32_t large_sum = x_bcast<WAVE>(il, W - 1);
+    if (cfg.advanced_tags && has_nm) nm = (double)((int64_t)nm_tag - (int64_t)large_sum) / (double)(qal + 1);
+  } else if (lane == 0) {
+    const int64_t ri = v.read_idx[rec];
+    v.o_rstart[ri] = pos; v.o_rend[ri] = ref_end; v.o_rhp[ri] = (uint8_t)hp;
+  }
+  // ---- supplementary alignments: Lead.for_bnd, read_itersplits (sequential, lane 0; segment table in LDS)
+  int n_seg = 0, n_raw = 0;
+  if (sa_off >= 0 && lane == 0) {
+    const uint8_t* B = v.blob;
+    SaElem e;
+    // for_bnd: side of the break from the first / last CIGAR operation
+    const uint32_t c0 = ld_u32(cig), c1 = ld_u32(cig + 4 * (int64_t)(n_cig - 1));
+    const int64_t left = ((c0 & 15) == 4 || (c0 & 15) == 5) ? (c0 >> 4) : 0, right = ((c1 & 15) == 4 || (c1 & 15) == 5) ? (c1 >> 4) : 0;
+    const bool is_first = !(left > right);
+    const int32_t b_start = is_first ? ref_end : pos + 1;
+    int64_t p = sa_off; int err = 0;
+    if (sa_next(B, &p, &e)) {
+      int64_t s_pos = 0, s_nm = 0, cl0, cl1, rfs, rds;
+      if (e.nf != 6) err = XE_SA_FIELDS;
+      else if (e.f1[2] - e.f0[2] != 1 || (B[e.f0[2]] != '+' && B[e.f0[2]] != '-')) err = XE_SA_STRAND;
+      else if ((B[e.f0[2]] == '-') != rev) {
+        const int32_t mc = sa_contig(v, B, e.f0[0], e.f1[0]);
+        if (!sa_int(B, e.f0[1], e.f1[1], &s_pos)) err = XE_SA_NUMBER;
+        else if (sa_cigar(B, e.f0[3], e.f1[3], &cl0, &cl1, &rfs, &rds)) {
+          const bool mate_rev = cl1 > cl0;
+          const int64_t z = s_pos - 1, mate = mate_rev ? z + rfs : (is_first ? z + 1 : z + 2);
+          if (has_nm && !sa_int(B, e.f0[5], e.f1[5], &s_nm)) err = XE_SA_NUMBER;
+          else if (mc < 0) err = XE_SA_CONTIG;
+          else if (!fits_i32(mate)) err = XE_RANGE;
+          else if (b_start >= v.region_start && b_start < v.region_end) {
+            if (EMIT) {
+              LeadRow r{};
+              r.ref_start = r.ref_end = b_start; r.qry_start = q0; r.qry_end = q1; r.svlen = 0; r.read_len = 0; r.ps = SNF_PS_NONE;
+              r.mate_contig = mc; r.mate_pos = (int32_t)mate; r.seq_len = SNF_SEQ_NONE;
+              r.nm = has_nm ? (double)s_nm : __builtin_nan("");
+              r.svtype = SNF_BND; r.strand = rev; r.mapq = (uint8_t)mapq; r.source = SNF_SRC_BND_SA; r.hap = 0; r.is_sa = 0;
+              r.first = is_first; r.rev = mate_rev;
+              put_lead(v, lead_base + lead_k, r, qname, read_id);
+            }
+            lead_k++;
+          }
+        }
+      }
+    }
+    // read_itersplits: primary alignments only
+    if (!err && !supp) {
+      int n_el = 0; p = sa_off;
+      while (sa_next(B, &p, &e)) n_el++;
+      if (!((double)n_el > (double)cfg.max_splits_base + cfg.max_splits_kb * ((double)l_seq / 1000.0))) {
+        if (n_el + 1 > XMAXSEG) err = XE_SPLITS;
+        else {
+          Seg& s0 = segs[0];
+          s0.contig = v.region_rank; s0.rs = pos; s0.re = ref_end; s0.qs = rev ? l_seq - q1 : q0; s0.qe = s0.qs + qal; s0.mapq = mapq;
+          s0.rev = rev; s0.source = SNF_SRC_SPLIT_PRIM; s0.seq_n = -1; s0.job_dst = -1; s0.hint_type = -1;
+          n_seg = 1; p = sa_off; bool drop = false;
+          while (!err && !drop && sa_next(B, &p, &e)) {
+            int64_t s_pos = 0, s_mq = 0, cl0, cl1, rfs, rds;
+            if (e.nf != 6) { err = XE_SA_FIELDS; break; }
+            if (!sa_int(B, e.f0[4], e.f1[4], &s_mq)) { err = XE_SA_NUMBER; break; }
+            if (e.f1[2] - e.f0[2] != 1 || (B[e.f0[2]] != '+' && B[e.f0[2]] != '-')) { err = XE_SA_STRAND; break; }
+            if (!sa_cigar(B, e.f0[3], e.f1[3], &cl0, &cl1, &rfs, &rds)) { drop = true; break; }
+            if (!sa_int(B, e.f0[1], e.f1[1], &s_pos)) { err = XE_SA_NUMBER; break; }
+            const int32_t mc = sa_contig(v, B, e.f0[0], e.f1[0]);
+            if (mc < 0) { err = XE_SA_CONTIG; break; }
+            const bool srev = B[e.f0[2]] == '-';
+            const int64_t z = s_pos - 1, sq = srev ? cl1 : cl0;
+            if (!fits_i32(z + rfs) || !fits_i32(sq + rds) || s_mq < 0 || s_mq > 255) { err = XE_RANGE; break; }
+            Seg& s = segs[n_seg];
+            s.contig = mc; s.rs = (int32_t)z; s.re = (int32_t)(z + rfs); s.qs = (int32_t)sq; s.qe = (int32_t)(sq + rds); s.mapq = (int32_t)s_mq;
+            s.rev = srev; s.source = SNF_SRC_SPLIT_SUP; s.seq_n = -1; s.job_dst = -1; s.hint_type = -1;
+            n_seg++;
+          }
+          if (err || drop) n_seg = 0;
+          if (n_seg) {
+            for (int i = 0; i < n_seg; i++) ord[i] = (uint8_t)i;
+            n_raw = n_seg;
+            n_seg = classify(v, segs, ord, n_seg, l_seq, rec);
+            for (int i = 0; i < n_seg; i++) {
+              Seg& s = segs[ord[i]];
+              if (s.hint_type < 0) continue;
+              const int32_t pm = segs[ord[i > 0 ? i - 1 : 0]].mapq;
+              if (!cfg.dev_keep_lowqual_splits && (s.mapq < pm ? s.mapq : pm) < cfg.mapq) continue;
+              if (s.contig != v.region_rank || s.hint_start < v.region_start || s.hint_start >= v.region_end) continue;
+              const bool ins = s.hint_type == SNF_INS;
+              const int32_t sl = (ins && s.seq_n >= 0) ? s.seq_n : -1;
+              if (EMIT) {
+                LeadRow r{};
+                r.ref_start = s.hint_start;
+                r.ref_end = (s.hint_len != SNF_SVLEN_NONE && !ins) ? s.hint_start + s.hint_len : s.hint_start;
+                r.qry_start = s.qs; r.qry_end = s.qe; r.svlen = s.hint_len; r.read_len = 0; r.ps = ps_rank; r.mate_contig = 0;
+                r.seq_len = sl; r.seq_off = sl >= 0 ? seq_base + seqb : 0; r.nm = nm;
+                r.svtype = (uint8_t)s.hint_type; r.strand = s.rev; r.mapq = (uint8_t)s.mapq; r.source = s.source; r.hap = (uint8_t)hp; r.is_sa = supp;
+                put_lead(v, lead_base + lead_k, r, qname, read_id);
+                if (sl > 0) s.job_dst = seq_base + seqb;
+              }
+              lead_k++;
+              if (sl > 0) seqb += sl;
+            }
+          }
+        }
+      }
+    }
+    if (err) { x_error(v, rec, err); n_raw = 0; lead_k = -1; }
+  }
+  if (!EMIT) {
+    if (lane == 0 && lead_k >= 0) {
+      S.accept = 1; S.n_leads = lead_k; S.seq_bytes = seqb; S.has_nm = has_nm; S.has_ps = has_ps; S.nm = nm; S.sa_off = sa_off;
+      S.hp = (uint8_t)hp; S.ps = ps; S.nm_tag = nm_tag; S.ref_end = ref_end;
+      S.walk_lo = w_lo; S.walk_hi = w_hi; S.walk_pr = w_pr; S.walk_pf = w_pf;
+    }
+  } else if (sa_off >= 0 && !supp) {
+    // sequence of split-read insertions: lane 0 left the copy jobs in the segment table
+    x_wave_sync<WAVE>();
+    n_raw = (int)x_bcast<WAVE>((uint32_t)n_raw, 0);
+    for (int i = 0; i < n_raw; i++) {
+      const Seg& s = segs[i];
+      if (s.job_dst >= 0) x_copy_bases<WAVE>(seq, s.seq_a, s.seq_n, v.o_pool + s.job_dst, lane);
+    }
+    x_wave_sync<WAVE>();
+  }
+}
+
+SNF_HD void x_count_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, false>(i, v, segs, ord); }
+SNF_HD void x_emit_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, true>(i, v, segs, ord); }
+SNF_HD void x_prep_body(int64_t i, const ExView& v) {
+  const bool a = i < v.n_records && v.sum[i].accept;
+  v.c_acc[i] = a ? 1 : 0; v.c_leads[i] = a ? v.sum[i].n_leads : 0; v.c_seq[i] = a ? v.sum[i].seq_bytes : 0;
+}
+
+}  // namespace snf
+using namespace snf;
+SNF_KERNEL(x_count, ExView)
+SNF_KERNEL(x_emit, ExView)
+SNF_KERNEL(x_prep, ExView)
+
+#ifndef SNF_EMU
+// one wave per record, 4 records per workgroup; grid-stride so that any record count fits one launch
+template <bool EMIT>
+__global__ void __launch_bounds__(256) x_wave(const ExView v, int64_t n) {
+  __shared__ Seg segs[4][XMAXSEG];
+  __shared__ uint8_t ord[4][XMAXSEG];
+  const int w = threadIdx.x >> 6;
+  for (int64_t rec = (int64_t)blockIdx.x * 4 + w; rec < n; rec += (int64_t)gridDim.x * 4)
+    extract_record<true, EMIT>(rec, v, segs[w], ord[w]);
+}
+// average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64
+// adds, one wave, 64 records loaded per step and folded through lane broadcasts so that every lane holds the sum.
+__global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
+  const int lane = threadIdx.x;
+  double sum = 0.0; int64_t cnt = 0;
+  for (int64_t base = 0; base < n; base += 64) {
+    const int64_t i = base + lane;
+    const bool f = i < n && v.cfg.advanced_tags && v.sum[i].accept && v.sum[i].has_nm;
+    const double x = f ? v.sum[i].nm : 0.0;
+    uint64_t m = __ballot(f);
+    while (m) {
+      const int src = __builtin_ctzll(m); m &= m - 1;
+      sum += __shfl(x, src, 64); cnt++;
+    }
+  }
+  if (lane == 0) { v.nm_out[0] = sum; v.nm_out[1] = (double)cnt; }
+}
+#endif
+
+// ================================================================================================= host side ====
+struct snf_extract {
+  snf_extract_config_t cfg;
+  int device = 0;
+  std::vector<void*> dev;        // device allocations of the current input / run
+  std::vector<void*> dev_run;
+  ExView v{};
+  int64_t n_records = 0, blob_len = 0;
+  // host results
+  std::vector<int32_t> h_i32[10]; std::vector<uint32_t> h_u32[2]; std::vector<int64_t> h_seq_off; std::vector<double> h_nm;
+  std::vector<uint8_t> h_u8[8]; std::vector<uint8_t> h_pool; std::vector<int32_t> h_rs, h_re; std::vector<uint8_t> h_rhp;
+  std::vector<int64_t> h_ps_value;
+  snf_extract_result_t res{};
+  bool have_input = false, have_result = false;
+};
+
+namespace {
+thread_local std::string g_xerr;
+
+void x_free(void* p) {
+#ifndef SNF_EMU
+  (void)hipFree(p);
+#else
+  free(p);
+#endif
+}
+template <class T> T* x_alloc(std::vector<void*>& pool, size_t n, size_t pad_bytes = 0) {
+  void* p = nullptr;
+  const size_t bytes = (n ? n : 1) * sizeof(T) + pad_bytes;
+#ifndef SNF_EMU
+  if (hipMalloc(&p, bytes) != hipSuccess) snf::fail("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+#else
+  p = calloc(1, bytes);
+  if (!p) snf::fail("out of memory");
+#endif
+  pool.push_back(p);
+  return (T*)p;
+}
+void x_h2d(void* d, const void* h, size_t bytes) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+#else
+  memcpy(d, h, bytes);
+#endif
+}
+void x_d2h(void* h, const void* d, size_t bytes) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+#else
+  memcpy(h, d, bytes);
+#endif
+}
+template <class T> T* x_up(std::vector<void*>& pool, const T* h, size_t n, size_t pad_bytes = 0) {
+  T* d = x_alloc<T>(pool, n, pad_bytes);
+  x_h2d(d, h, n * sizeof(T));
+  return d;
+}
+void x_release(std::vector<void*>& pool) { for (void* p : pool) x_free(p); pool.clear(); }
+
+int64_t* x_exscan(std::vector<void*>& pool, const int64_t* in, int64_t n) {   // exclusive prefix sums of n elements
+  int64_t* out = x_alloc<int64_t>(pool, (size_t)n);
+#ifndef SNF_EMU
+  size_t need = 0;
+  SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
+  void* tmp = x_alloc<uint8_t>(pool, need);
+  SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
+#else
+  int64_t acc = 0;
+  for (int64_t i = 0; i < n; i++) { out[i] = acc; acc += in[i]; }
+#endif
+  return out;
+}
+
+// rank of str(value) among the distinct phase sets plus the literal "NULL" (Python str order)
+bool ps_str_less(int64_t a, int64_t b) { return std::to_string(a) < std::to_string(b); }
+
+int do_upload(snf_extract* x, const snf_extract_input_t* in) {
+  if (!in || in->n_records < 0 || (in->n_records && (!in->records || !in->rec_off || !in->qname_rank))) snf::fail("extract input: null pointer");
+  if (in->n_contigs < 0 || (in->n_contigs && (!in->contig_hash || !in->contig_rank))) snf::fail("extract input: contig table missing");
+  for (int64_t i = 0; i < in->n_records; i++) {
+    const int64_t a = in->rec_off[i], b = in->rec_off[i + 1];
+    if (a < 0 || b < a + 36 || b > in->records_len) snf::fail("extract input: record offsets malformed at record " + std::to_string(i));
+    int32_t bs; memcpy(&bs, in->records + a, 4);
+    if ((int64_t)bs + 4 != b - a) snf::fail("extract input: block_size of record " + std::to_string(i) + " disagrees with rec_off");
+    const uint8_t* R = in->records + a;
+    uint16_t n_cig; int32_t l_seq; memcpy(&n_cig, R + 16, 2); memcpy(&l_seq, R + 20, 4);
+    if (l_seq < 0 || 36 + (int64_t)R[12] + 4 * (int64_t)n_cig + ((int64_t)l_seq + 1) / 2 + l_seq > b - a)
+      snf::fail("extract input: record " + std::to_string(i) + " shorter than its fixed fields say");
+  }
+  for (int i = 1; i < in->n_contigs; i++)
+    if (in->contig_hash[i - 1] >= in->contig_hash[i]) snf::fail("extract input: contig_hash must be strictly ascending");
+  x_release(x->dev); x_release(x->dev_run);
+  x->have_result = false;
+  ExView& v = x->v;
+  v = ExView{};
+  v.cfg = x->cfg;
+  v.blob = x_up(x->dev, in->records, (size_t)in->records_len, 16);
+  v.rec_off = x_up(x->dev, in->rec_off, (size_t)in->n_records + 1);
+  v.qname_rank = x_up(x->dev, in->qname_rank, (size_t)in->n_records);
+  v.ctg_hash = x_up(x->dev, in->contig_hash, (size_t)in->n_contigs);
+  v.ctg_rank = x_up(x->dev, in->contig_rank, (size_t)in->n_contigs);
+  v.n_contigs = in->n_contigs; v.n_records = in->n_records;
+  v.region_ref_id = in->region_ref_id; v.region_rank = in->region_rank; v.region_start = in->region_start; v.region_end = in->region_end;
+  v.read_id_offset = in->read_id_offset;
+  x->n_records = in->n_records; x->blob_len = in->records_len;
+  // algorithmic input bytes: everything of a record of this contig except its sequence and quality bytes
+  int64_t ab = 0;
+  for (int64_t i = 0; i < in->n_records; i++) {
+    const uint8_t* R = in->records + in->rec_off[i];
+    int32_t rid, l_seq; memcpy(&rid, R + 4, 4); memcpy(&l_seq, R + 20, 4);
+    ab += (rid == in->region_ref_id) ? (in->rec_off[i + 1] - in->rec_off[i]) - ((int64_t)l_seq + 1) / 2 - l_seq : 36;
+  }
+  x->res.algo_bytes = ab;
+  x->have_input = true;
+  return 0;
+}
+
+int do_run(snf_extract* x) {
+  if (!x->have_input) snf::fail("snf_extract_run before snf_extract_upload");
+  x_release(x->dev_run);
+  x->have_result = false;
+  ExView& v = x->v;
+  const int64_t n = x->n_records;
+  std::vector<void*>& P = x->dev_run;
+  v.sum = x_alloc<RecSum>(P, (size_t)n);
+  v.err = x_alloc<unsigned long long>(P, 1);
+  v.c_acc = x_alloc<int64_t>(P, (size_t)n + 1); v.c_leads = x_alloc<int64_t>(P, (size_t)n + 1); v.c_seq = x_alloc<int64_t>(P, (size_t)n + 1);
+  v.nm_out = x_alloc<double>(P, 2);
+  const unsigned long long none = ~0ull;
+  x_h2d(v.err, &none, 8);
+  float ms_count = 0, ms_emit = 0;
+#ifndef SNF_EMU
+  const bool thread_form = getenv("SNF_EXTRACT_THREAD") != nullptr;
+  hipEvent_t e0, e1, e2, e3;
+  SNF_HIP(hipEventCreate(&e0)); SNF_HIP(hipEventCreate(&e1)); SNF_HIP(hipEventCreate(&e2)); SNF_HIP(hipEventCreate(&e3));
+  const unsigned grid_w = (unsigned)std::min<int64_t>((n + 3) / 4 > 0 ? (n + 3) / 4 : 1, 1 << 20);
+  SNF_HIP(hipMemset(v.sum, 0, (size_t)(n ? n : 1) * sizeof(RecSum)));
+  SNF_HIP(hipEventRecord(e0, 0));
+  if (n) {
+    if (thread_form) hipLaunchKernelGGL(x_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
+    else hipLaunchKernelGGL(x_wave<false>, dim3(grid_w), dim3(256), 0, 0, v, n);
+  }
+  SNF_HIP(hipEventRecord(e1, 0));
+  hipLaunchKernelGGL(x_prep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, v, n + 1);
+  hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, 0, v, n);
+#else
+  x_count(v, n);
+  x_prep(v, n + 1);
+  { double s = 0; int64_t c = 0;
+    for (int64_t i = 0; i < n; i++) if (v.cfg.advanced_tags && v.sum[i].accept && v.sum[i].has_nm) { s += v.sum[i].nm; c++; }
+    v.nm_out[0] = s; v.nm_out[1] = (double)c; }
+#endif
+  v.read_idx = x_exscan(P, v.c_acc, n + 1); v.lead_off = x_exscan(P, v.c_leads, n + 1); v.seq_off = x_exscan(P, v.c_seq, n + 1);
+  unsigned long long err = none; int64_t n_reads = 0, n_leads = 0, n_seq = 0; double nmv[2] = {0, 0};
+  x_d2h(&err, v.err, 8); x_d2h(&n_reads, v.read_idx + n, 8); x_d2h(&n_leads, v.lead_off + n, 8); x_d2h(&n_seq, v.seq_off + n, 8);
+  x_d2h(nmv, v.nm_out, 16);
+  if (err != none) {
+    const int code = (int)(err & 0xff);
+    snf::fail("alignment record " + std::to_string((long long)(err >> 8)) + ": " + XE_TEXT[code < 14 ? code : 4]);
+  }
+  // phase sets: distinct PS values of the accepted reads -> rank of str(value) in Python str order, "NULL" last
+  std::vector<RecSum> hs((size_t)n);
+  x_d2h(hs.data(), v.sum, (size_t)n * sizeof(RecSum));
+  std::vector<int64_t> vals;
+  for (int64_t i = 0; i < n; i++) if (hs[(size_t)i].accept && hs[(size_t)i].has_ps) vals.push_back(hs[(size_t)i].ps);
+  std::sort(vals.begin(), vals.end());
+  vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+  std::vector<int64_t> by_str(vals);
+  std::sort(by_str.begin(), by_str.end(), ps_str_less);
+  std::vector<int32_t> rank_of(vals.size());
+  for (size_t r = 0; r < by_str.size(); r++) rank_of[(size_t)(std::lower_bound(vals.begin(), vals.end(), by_str[r]) - vals.begin())] = (int32_t)r;
+  v.ps_val = x_up(P, vals.data(), vals.size()); v.ps_rank = x_up(P, rank_of.data(), rank_of.size());
+  v.n_ps = (int32_t)vals.size(); v.ps_null_rank = (int32_t)vals.size();   // digits and '-' sort before 'N'
+  x->h_ps_value = by_str; x->h_ps_value.push_back(0);
+  // outputs
+  const size_t L = (size_t)n_leads;
+  v.o_ref_start = x_alloc<int32_t>(P, L); v.o_ref_end = x_alloc<int32_t>(P, L); v.o_qry_start = x_alloc<int32_t>(P, L); v.o_qry_end = x_alloc<int32_t>(P, L);
+  v.o_svlen = x_alloc<int32_t>(P, L); v.o_read_len = x_alloc<int32_t>(P, L); v.o_ps = x_alloc<int32_t>(P, L); v.o_mate_contig = x_alloc<int32_t>(P, L);
+  v.o_mate_pos = x_alloc<int32_t>(P, L); v.o_seq_len = x_alloc<int32_t>(P, L); v.o_qname = x_alloc<uint32_t>(P, L); v.o_read_id = x_alloc<uint32_t>(P, L);
+  v.o_seq_off = x_alloc<int64_t>(P, L); v.o_nm = x_alloc<double>(P, L);
+  v.o_svtype = x_alloc<uint8_t>(P, L); v.o_strand = x_alloc<uint8_t>(P, L); v.o_mapq = x_alloc<uint8_t>(P, L); v.o_source = x_alloc<uint8_t>(P, L);
+  v.o_hap = x_alloc<uint8_t>(P, L); v.o_is_sa = x_alloc<uint8_t>(P, L); v.o_first = x_alloc<uint8_t>(P, L); v.o_rev = x_alloc<uint8_t>(P, L);
+  v.o_pool = x_alloc<uint8_t>(P, (size_t)n_seq);
+  v.o_rstart = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rend = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rhp = x_alloc<uint8_t>(P, (size_t)n_reads);
+#ifndef SNF_EMU
+  SNF_HIP(hipEventRecord(e2, 0));
+  if (n) {
+    if (thread_form) hipLaunchKernelGGL(x_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
+    else hipLaunchKernelGGL(x_wave<true>, dim3(grid_w), dim3(256), 0, 0, v, n);
+  }
+  SNF_HIP(hipEventRecord(e3, 0));
+  SNF_HIP(hipDeviceSynchronize());
+  SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
+#else
+  x_emit(v, n);
+#endif
+  // results to the host
+  int32_t* const di32[10] = {v.o_ref_start, v.o_ref_end, v.o_qry_start, v.o_qry_end, v.o_svlen, v.o_read_len, v.o_ps, v.o_mate_contig, v.o_mate_pos, v.o_seq_len};
+  for (int k = 0; k < 10; k++) { x->h_i32[k].resize(L + 1); x_d2h(x->h_i32[k].data(), di32[k], L * 4); }
+  x->h_u32[0].resize(L + 1); x_d2h(x->h_u32[0].data(), v.o_qname, L * 4);
+  x->h_u32[1].resize(L + 1); x_d2h(x->h_u32[1].data(), v.o_read_id, L * 4);
+  x->h_seq_off.resize(L + 1); x_d2h(x->h_seq_off.data(), v.o_seq_off, L * 8);
+  x->h_nm.resize(L + 1); x_d2h(x->h_nm.data(), v.o_nm, L * 8);
+  uint8_t* const du8[8] = {v.o_svtype, v.o_strand, v.o_mapq, v.o_source, v.o_hap, v.o_is_sa, v.o_first, v.o_rev};
+  for (int k = 0; k < 8; k++) { x->h_u8[k].resize(L + 1); x_d2h(x->h_u8[k].data(), du8[k], L); }
+  x->h_pool.resize((size_t)n_seq + 1); x_d2h(x->h_pool.data(), v.o_pool, (size_t)n_seq);
+  x->h_rs.resize((size_t)n_reads + 1); x->h_re.resize((size_t)n_reads + 1); x->h_rhp.resize((size_t)n_reads + 1);
+  x_d2h(x->h_rs.data(), v.o_rstart, (size_t)n_reads * 4); x_d2h(x->h_re.data(), v.o_rend, (size_t)n_reads * 4); x_d2h(x->h_rhp.data(), v.o_rhp, (size_t)n_reads);
+  snf_extract_result_t& r = x->res;
+  const int64_t ab = r.algo_bytes;
+  r = snf_extract_result_t{};
+  snf_task_input_t& t = r.task;
+  t.n_leads = n_leads;
+  t.ref_start = x->h_i32[0].data(); t.ref_end = x->h_i32[1].data(); t.qry_start = x->h_i32[2].data(); t.qry_end = x->h_i32[3].data();
+  t.svlen = x->h_i32[4].data(); t.read_len = x->h_i32[5].data(); t.ps_rank = x->h_i32[6].data(); t.mate_contig = x->h_i32[7].data();
+  t.mate_ref_start = x->h_i32[8].data(); t.seq_len = x->h_i32[9].data(); t.qname_id = x->h_u32[0].data(); t.read_id = x->h_u32[1].data();
+  t.seq_off = x->h_seq_off.data(); t.nm = x->h_nm.data();
+  t.svtype = x->h_u8[0].data(); t.strand = x->h_u8[1].data(); t.mapq = x->h_u8[2].data(); t.source = x->h_u8[3].data();
+  t.hap = x->h_u8[4].data(); t.is_sa = x->h_u8[5].data(); t.bnd_is_first = x->h_u8[6].data(); t.bnd_is_reverse = x->h_u8[7].data();
+  t.seq_pool_len = n_seq; t.seq_pool = x->h_pool.data();
+  t.n_reads = n_reads; t.read_start = x->h_rs.data(); t.read_end = x->h_re.data(); t.read_hp = x->h_rhp.data();
+  t.n_tr = -1; t.ps_null_rank = v.ps_null_rank;
+  const double cnt = nmv[1] > 1.0 ? nmv[1] : 1.0;
+  t.qc_nm_threshold = nmv[0] / cnt;   // average_regional_nm = nm_sum / float(max(1, nm_count))
+  r.n_ps = (int64_t)x->h_ps_value.size(); r.ps_value = x->h_ps_value.data();
+  r.read_id = x->v.read_id_offset + (uint32_t)n_reads; r.read_count = n_reads;
+  r.ms_count = ms_count; r.ms_emit = ms_emit; r.algo_bytes = ab + n_seq + n_seq / 2;
+  x->have_result = true;
+  return 0;
+}
+}  // namespace
+
+#define X_TRY(stmt)                                                    \
+  try { stmt; }                                                        \
+  catch (const snf::Error& e) { g_xerr = e.msg; return 1; }            \
+  catch (const std::exception& e) { g_xerr = e.what(); return 1; }     \
+  return 0;
+
+extern "C" {
+const char* snf_extract_last_error(void) { return g_xerr.c_str(); }
+
+int snf_extract_create(const snf_extract_config_t* cfg, int device, snf_extract_t** out) {
+  if (!cfg || !out) { g_xerr = "snf_extract_create: null argument"; return 1; }
+#ifndef SNF_EMU
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { g_xerr = "no HIP device: the extraction kernels need a gfx950 GPU (there is no CPU fallback)"; return 1; }
+  if (device < 0 || device >= nd) { g_xerr = "device index out of range"; return 1; }
+  if (hipSetDevice(device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
+#endif
+  snf_extract* x = new snf_extract();
+  x->cfg = *cfg; x->device = device;
+  *out = x;
+  return 0;
+}
+int snf_extract_upload(snf_extract_t* x, const snf_extract_input_t* in) {
+  if (!x) { g_xerr = "null handle"; return 1; }
+#ifndef SNF_EMU
+  if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
+#endif
+  X_TRY(do_upload(x, in))
+}
+int snf_extract_run(snf_extract_t* x) {
+  if (!x) { g_xerr = "null handle"; return 1; }
+#ifndef SNF_EMU
+  if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
+#endif
+  X_TRY(do_run(x))
+}
+int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out) {
+  if (!x || !out) { g_xerr = "null argument"; return 1; }
+  if (!x->have_result) { g_xerr = "snf_extract_result before a successful snf_extract_run"; return 1; }
+  *out = x->res;
+  return 0;
+}
+void snf_extract_destroy(snf_extract_t* x) {
+  if (!x) return;
+  x_release(x->dev); x_release(x->dev_run);
+  delete x;
+}
+}

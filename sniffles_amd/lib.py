@@ -46,6 +46,15 @@ def bind(lib: C.CDLL) -> C.CDLL:
     u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     lib.snf_consensus_batch.argtypes = [C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p, i64p, i64p, i32p, u8p, i64p]
     lib.snf_consensus_batch.restype = C.c_int
+    lib.snf_extract_create.argtypes = [C.POINTER(abi.snf_extract_config_t), C.c_int, C.POINTER(vp)]
+    lib.snf_extract_upload.argtypes = [vp, C.POINTER(abi.snf_extract_input_t)]
+    lib.snf_extract_run.argtypes = [vp]
+    lib.snf_extract_result.argtypes = [vp, C.POINTER(abi.snf_extract_result_t)]
+    lib.snf_extract_destroy.argtypes = [vp]
+    lib.snf_extract_destroy.restype = None
+    lib.snf_extract_last_error.restype = C.c_char_p
+    for f in ("snf_extract_create", "snf_extract_upload", "snf_extract_run", "snf_extract_result"):
+        getattr(lib, f).restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
               "snf_batch_timing_count",

@@ -371,3 +371,53 @@ COMBINE_TASK = {
     "combine_task_8samples_dense": (lambda: [synth.gen_task(4, "chr20", 600_000, 15, seed=300 + s, site_seed=31337, site_density=40 * 27000 / 3.1e9)
                                              for s in range(8)], ()),
 }
+
+
+# ---------------------------------------------------------------------------------------------- signature extraction
+# name -> dict(gen=kwargs of synth_bam.gen_records | fixture=file under tests/golden, contig, region, read_id_offset,
+#              args=reference command line, overrides=attributes set on the reference config afterwards,
+#              cfg=the same settings as sniffles_amd / oracle extraction config keywords)
+EXTRACT = {
+    "extract_fuzz_a": dict(gen=dict(seed=11, n_reads=400, sa_frac=0.4), contig="chrA", region=(0, 400000),
+                           read_id_offset=0, args=(), overrides={}, cfg={}),
+    "extract_fuzz_window": dict(gen=dict(seed=12, n_reads=400, sa_frac=0.5), contig="chrA", region=(60000, 310000),
+                                read_id_offset=5000, args=(), overrides={}, cfg={}),
+    "extract_no_tags": dict(gen=dict(seed=13, n_reads=250, with_tags=False), contig="chrA", region=(0, 400000),
+                            read_id_offset=0, args=(), overrides={}, cfg={}),
+    "extract_lowq_short": dict(gen=dict(seed=14, n_reads=400, sa_frac=0.5, read_len_mean=1500), contig="chrA",
+                               region=(0, 400000), read_id_offset=7,
+                               args=("--mapq", "0", "--min-alignment-length", "100", "--minsvlen", "30",
+                                     "--long-ins-length", "1000", "--max-splits-base", "1", "--max-splits-kb", "0.7",
+                                     "--dev-keep-lowqual-splits", "--exclude-flags", "1536", "--dev-seq-cache-maxlen", "400"),
+                               overrides={},
+                               cfg=dict(mapq=0, min_alignment_length=100, minsvlen_screen=27, long_ins_length=1000,
+                                        max_splits_base=1, max_splits_kb=0.7, dev_keep_lowqual_splits=True,
+                                        exclude_flags=1536, dev_seq_cache_maxlen=400)),
+    "extract_no_advanced_tags": dict(gen=dict(seed=15, n_reads=300, sa_frac=0.4), contig="chrA", region=(0, 400000),
+                                     read_id_offset=0, args=("--detect-large-ins", "False"), overrides=dict(phase=False),
+                                     cfg=dict(advanced_tags=False, detect_large_ins=False)),
+    "extract_other_contig": dict(gen=dict(seed=16, n_reads=300, sa_frac=0.5, contig_index=2), contig="chr2",
+                                 region=(0, 300000), read_id_offset=0, args=(), overrides={}, cfg={}),
+    "extract_ont_long": dict(gen=dict(seed=17, n_reads=60, style="ont", read_len_mean=20000, sa_frac=0.3), contig="chrA",
+                             region=(0, 400000), read_id_offset=0, args=(), overrides={}, cfg={}),
+    "extract_hg008_chr1": dict(fixture="bam_hg008.bam.gz", contig="chr1", region=(0, 248956422), read_id_offset=0,
+                               args=(), overrides={}, cfg={}),
+    "extract_hg008_chr18": dict(fixture="bam_hg008.bam.gz", contig="chr18", region=(0, 80373285), read_id_offset=0,
+                                args=(), overrides={}, cfg={}),
+    "extract_hg008_chrX": dict(fixture="bam_hg008.bam.gz", contig="chrX", region=(0, 156040895), read_id_offset=0,
+                               args=(), overrides={}, cfg={}),
+    "extract_hg002_chr1": dict(fixture="bam_hg002.bam.gz", contig="chr1", region=(72000000, 73000000), read_id_offset=0,
+                               args=(), overrides={}, cfg={}),
+}
+
+
+def extract_records(case):
+    """The record table of an extraction case (sniffles_amd.bam.BamRecords)."""
+    import gzip
+    import os
+    from sniffles_amd import bam, synth_bam
+    if "fixture" in case:
+        with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case["fixture"]), "rb") as f:
+            return bam.parse_bam(f.read())
+    names, lens, recs = synth_bam.gen_records(**case["gen"])
+    return bam.records_from_list(names, lens, recs)

@@ -17,11 +17,11 @@ _lib = None
 
 def build():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in ("snf_lib.hip", "snf_myers.hip", "snf_combine.hip")]
+    srcs = [os.path.join(CSRC, s) for s in ("snf_lib.hip", "snf_myers.hip", "snf_combine.hip", "snf_extract.hip")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "sniffles_amd.h")]
     if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
         cmd = ["g++", "-x", "c++", "-std=c++17", "-DSNF_EMU", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function", "-Wno-misleading-indentation"] + srcs + ["-o", SO]
+               "-Wall", "-Wno-unused-function", "-Wno-misleading-indentation", "-Wno-unknown-pragmas"] + srcs + ["-o", SO]
         subprocess.run(cmd, check=True)
     return SO
 
