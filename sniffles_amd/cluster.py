@@ -74,13 +74,62 @@ def resolve_block_groups_batch(problems, config, device: int = 0, _lib=None):
     return [apply_assignment(sc, gi, out) for (_, sc, gi), (_, out) in zip(problems, packed)]
 
 
-def resolve_chains_batch(chains, config, device: int = 0, _lib=None):
+def chain_cuts(svtype, svcands, win_off, config):
+    """Window indices at which a chain of flush windows falls apart into independent sub-chains.
+
+    A candidate joins a group only if `abs(group.pos_mean - cand.pos)` (plus a non-negative length or mate term) is at
+    most `combine_match_max` (`cluster_merge_bnd * 2` for BND) - cluster.py:369-379.  A group's `pos_mean` is the mean
+    of positions of earlier candidates, so when every candidate from window w on lies further than that gate (+1 bp for
+    the rounding of the running mean) to the right of every earlier candidate, no group that exists before w can
+    ever receive another candidate: the groups kept across the cut are carried and flushed by the host replay alone
+    (CombineTask.execute) and the windows from w on are a chain of their own.  Whole-genome merges fall apart into
+    thousands of short chains this way, which is what fills the device; the greedy inside a sub-chain is unchanged."""
+    nw = len(win_off) - 1
+    if nw <= 1:
+        return [0, nw]
+    gate = float(config.cluster_merge_bnd) * 2 if svtype == "BND" else float(config.combine_match_max)
+    gate = max(gate, 0.0) + 1.0
+    lo = [min((c.pos for c in svcands[win_off[w]:win_off[w + 1]]), default=float("inf")) for w in range(nw)]
+    hi = [max((c.pos for c in svcands[win_off[w]:win_off[w + 1]]), default=float("-inf")) for w in range(nw)]
+    for w in range(nw - 2, -1, -1):      # suffix minimum / prefix maximum: no assumption about the order of the windows
+        lo[w] = min(lo[w], lo[w + 1])
+    for w in range(1, nw):
+        hi[w] = max(hi[w], hi[w - 1])
+    return [0] + [w for w in range(1, nw) if lo[w] - hi[w - 1] > gate] + [nw]
+
+
+def resolve_chains_batch(chains, config, device: int = 0, _lib=None, cut: bool = None):
     """Whole chains of flush windows in one launch.  chains: list of (svtype, svcands, win_off, win_bin, win_thr) with
     svcands the concatenation of the windows' candidates; after window w the groups with
     abs(pos_mean - win_bin[w]) < win_thr[w] stay active for window w+1 (CombineTask.execute, parallel.py:553-556).
-    Returns per chain the group number of every candidate (new groups numbered in creation order over the chain)."""
-    keep, packed = [], []
+    Returns per chain the group number of every candidate (new groups numbered in creation order over the chain).
+    Chains are cut where no candidate can reach an earlier group (`chain_cuts`; SNF_COMBINE_NO_CUT=1 / cut=False keeps
+    them whole): every sub-chain is one work item of the kernel, the group numbers are made chain-wide here."""
+    import os
+
+    import numpy as np
+    if cut is None:
+        cut = os.environ.get("SNF_COMBINE_NO_CUT", "0") != "1"
+    keep, packed, layout = [], [], []
     for svtype, svcands, win_off, win_bin, win_thr in chains:
-        packed.append(pack_problem(svtype, svcands, [], keep, (win_off, win_bin, win_thr)))
-    lib.combine_resolve_batch(config, [q for q, _ in packed], device=device, _lib=_lib)
-    return [out for _, out in packed]
+        cuts = chain_cuts(svtype, svcands, win_off, config) if cut and len(win_bin) else [0, len(win_bin)]
+        parts = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            c0, c1 = win_off[a], win_off[b]
+            q, out = pack_problem(svtype, svcands[c0:c1], [], keep,
+                                  ([o - c0 for o in win_off[a:b + 1]], win_bin[a:b], win_thr[a:b]))
+            packed.append(q)
+            parts.append(out[:c1 - c0])
+        layout.append((len(svcands), parts))
+    if packed:
+        lib.combine_resolve_batch(config, packed, device=device, _lib=_lib)
+    outs = []
+    for n, parts in layout:
+        base = 0
+        for out in parts:
+            if out.shape[0]:
+                created = int(out.max()) + 1
+                out += base
+                base += created
+        outs.append(np.concatenate(parts) if parts else np.full(max(n, 1), -1, np.int32))
+    return outs

@@ -708,19 +708,26 @@ __global__ void __launch_bounds__(256) x_wave(const ExView v, int64_t n) {
     extract_record<true, EMIT>(rec, v, segs[w], ord[w]);
 }
 // average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64
-// adds, one wave, 64 records loaded per step and folded through lane broadcasts so that every lane holds the sum.
+// adds.  One wave: 64 records are loaded per step (coalesced), records without an NM ratio contribute +0.0 (the sum
+// is never -0.0, so that add is the identity) and the 64 values are folded in lane order by constant-lane reads -
+// a chain of 64 dependent adds per step with nothing else on it; the next step's loads are issued before the fold.
 __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
   const int lane = threadIdx.x;
   double sum = 0.0; int64_t cnt = 0;
+  const bool adv = v.cfg.advanced_tags != 0;
+  auto load = [&](int64_t i, bool& f) -> double {
+    f = adv && i < n && v.sum[i].accept && v.sum[i].has_nm;
+    return f ? v.sum[i].nm : 0.0;
+  };
+  bool f = false, fn = false;
+  double x = load(lane, f);
   for (int64_t base = 0; base < n; base += 64) {
-    const int64_t i = base + lane;
-    const bool f = i < n && v.cfg.advanced_tags && v.sum[i].accept && v.sum[i].has_nm;
-    const double x = f ? v.sum[i].nm : 0.0;
-    uint64_t m = __ballot(f);
-    while (m) {
-      const int src = __builtin_ctzll(m); m &= m - 1;
-      sum += __shfl(x, src, 64); cnt++;
-    }
+    const double xn = load(base + 64 + lane, fn);
+    cnt += __popcll(__ballot(f));
+#pragma unroll
+    for (int k = 0; k < 64; k++)
+      sum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
+    x = xn; f = fn;
   }
   if (lane == 0) { v.nm_out[0] = sum; v.nm_out[1] = (double)cnt; }
 }
@@ -740,6 +747,9 @@ struct snf_extract {
   std::vector<int64_t> h_ps_value;
   snf_extract_result_t res{};
   bool have_input = false, have_result = false;
+#ifndef SNF_EMU
+  hipStream_t side = nullptr;   // the serial NM sum runs beside the scans, the host round trip and the emit pass
+#endif
 };
 
 namespace {
@@ -872,7 +882,9 @@ int do_run(snf_extract* x) {
   }
   SNF_HIP(hipEventRecord(e1, 0));
   hipLaunchKernelGGL(x_prep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, v, n + 1);
-  hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, 0, v, n);
+  if (!x->side) SNF_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
+  SNF_HIP(hipStreamWaitEvent(x->side, e1, 0));
+  hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, x->side, v, n);
 #else
   x_count(v, n);
   x_prep(v, n + 1);
@@ -883,7 +895,6 @@ int do_run(snf_extract* x) {
   v.read_idx = x_exscan(P, v.c_acc, n + 1); v.lead_off = x_exscan(P, v.c_leads, n + 1); v.seq_off = x_exscan(P, v.c_seq, n + 1);
   unsigned long long err = none; int64_t n_reads = 0, n_leads = 0, n_seq = 0; double nmv[2] = {0, 0};
   x_d2h(&err, v.err, 8); x_d2h(&n_reads, v.read_idx + n, 8); x_d2h(&n_leads, v.lead_off + n, 8); x_d2h(&n_seq, v.seq_off + n, 8);
-  x_d2h(nmv, v.nm_out, 16);
   if (err != none) {
     const int code = (int)(err & 0xff);
     snf::fail("alignment record " + std::to_string((long long)(err >> 8)) + ": " + XE_TEXT[code < 14 ? code : 4]);
@@ -919,12 +930,14 @@ int do_run(snf_extract* x) {
     else hipLaunchKernelGGL(x_wave<true>, dim3(grid_w), dim3(256), 0, 0, v, n);
   }
   SNF_HIP(hipEventRecord(e3, 0));
+  SNF_HIP(hipStreamSynchronize(x->side));
   SNF_HIP(hipDeviceSynchronize());
   SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
 #else
   x_emit(v, n);
 #endif
+  x_d2h(nmv, v.nm_out, 16);
   // results to the host
   int32_t* const di32[10] = {v.o_ref_start, v.o_ref_end, v.o_qry_start, v.o_qry_end, v.o_svlen, v.o_read_len, v.o_ps, v.o_mate_contig, v.o_mate_pos, v.o_seq_len};
   for (int k = 0; k < 10; k++) { x->h_i32[k].resize(L + 1); x_d2h(x->h_i32[k].data(), di32[k], L * 4); }
@@ -1006,6 +1019,9 @@ int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out) {
 void snf_extract_destroy(snf_extract_t* x) {
   if (!x) return;
   x_release(x->dev); x_release(x->dev_run);
+#ifndef SNF_EMU
+  if (x->side) (void)hipStreamDestroy(x->side);
+#endif
   delete x;
 }
 }

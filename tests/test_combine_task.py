@@ -52,3 +52,58 @@ def test_combine_task_driver_matches_reference_emu(name):
 @pytest.mark.parametrize("name", NAMES)
 def test_combine_task_driver_matches_reference_gpu(name):
     run_case(name)
+
+
+# ---- chains cut into independent sub-chains (cluster.chain_cuts) must give the assignment of the whole chain
+def random_chains(seed, n_chains=10):
+    import numpy as np
+    from test_combine import random_problem
+    rng = np.random.default_rng(seed)
+    chains = []
+    for k in range(n_chains):
+        svtype = ["INS", "DEL", "DUP", "INV", "BND"][k % 5]
+        gate = 2001 if svtype == "BND" else 1001
+        cands, woff, wbin, wthr = [], [0], [], []
+        base = 0
+        for w in range(int(rng.integers(1, 14))):
+            win = random_problem(rng, svtype, int(rng.integers(1, 30)))
+            lo = min(c.pos for c in win)
+            # gaps around the gate: well below, exactly at it, one above, far above
+            gap = int(rng.choice([150, 600, gate - 1, gate, gate + 1, gate + 2, 6000]))
+            shift = (base + gap - lo) if cands else 0
+            for c in win:
+                c.pos += shift
+                c.id = f"{c.id}w{w}"
+            base = max(c.pos for c in win)
+            cands.extend(win)
+            woff.append(len(cands))
+            wbin.append(base // 100 * 100)
+            wthr.append(float(rng.choice([50.0, 1250.0, 2500.0])))
+        chains.append((svtype, cands, woff, wbin, wthr))
+    return chains
+
+
+def check_cut_equals_whole(_lib):
+    import numpy as np
+    from sniffles_amd import cluster
+    from sniffles_amd.config import SnifflesConfig
+    cfg = SnifflesConfig()
+    n_cut = 0
+    for seed in (11, 12, 13):
+        chains = random_chains(seed)
+        n_cut += sum(len(cluster.chain_cuts(t, c, wo, cfg)) - 2 for t, c, wo, _, _ in chains)
+        whole = cluster.resolve_chains_batch(chains, cfg, _lib=_lib, cut=False)
+        parts = cluster.resolve_chains_batch(chains, cfg, _lib=_lib, cut=True)
+        for (t, c, wo, _, _), a, b in zip(chains, whole, parts):
+            assert np.array_equal(a[:len(c)], b[:len(c)]), (seed, t)
+    assert n_cut > 20   # the generator does produce cuts (and gaps exactly at the gate, which must not cut)
+
+
+def test_chain_cuts_keep_the_assignment_emu():
+    import emu.emu as E
+    check_cut_equals_whole(E.lib())
+
+
+@pytest.mark.gpu
+def test_chain_cuts_keep_the_assignment_gpu():
+    check_cut_equals_whole(None)

@@ -100,8 +100,15 @@ windows=n_windows, candidates=n_c, gpu_s_incl_pack_and_replay=round(t_gpu, 3), c
     keep3 = []; packed3 = [cluster.pack_problem(t, c, [], keep3, (wo, wb, wt)) for t, c, wo, wb, wt in chains]
     lib.combine_resolve_batch(cfg, [q for q, _ in packed3[:2]])
     t0 = time.perf_counter(); lib.combine_resolve_batch(cfg, [q for q, _ in packed3]); t_ch = time.perf_counter() - t0
+    whole = [out for _, out in packed3]
+    # the product path (cluster.resolve_chains_batch): chains cut where no candidate can reach an earlier group
+    n_sub = sum(len(cluster.chain_cuts(t, c, wo, cfg)) - 1 for t, c, wo, _, _ in chains)
+    t0 = time.perf_counter(); cut = cluster.resolve_chains_batch(chains, cfg); t_cut = time.perf_counter() - t0
+    assert all(np.array_equal(a[:len(c[1])], b[:len(c[1])]) for a, b, c in zip(whole, cut, chains))
     res["resolve_chains"] = dict(chains=len(chains), windows=100 * len(chains), candidates=sum(len(c[1]) for c in chains),
-                                 c_abi_call_s_incl_h2d_kernel_d2h=round(t_ch, 4), windows_per_s=round(100 * len(chains) / t_ch))
+                                 whole_chains_c_abi_call_s=round(t_ch, 4), whole_chains_windows_per_s=round(100 * len(chains) / t_ch),
+                                 sub_chains=n_sub, cut_s_incl_pack=round(t_cut, 4), windows_per_s=round(100 * len(chains) / t_cut),
+                                 identical_assignment=True)
     print(json.dumps(res))
 
 if __name__ == "__main__":
