@@ -318,6 +318,14 @@ int snf_batch_fetch(snf_batch_t* b, int stage, snf_result_t* out);
  * stream; call snf_batch_sync before handing dst to another stream. */
 int snf_batch_export_calls_device(snf_batch_t* b, void* dst_device, int64_t cap_calls, int64_t* n_calls);
 
+/* replaces SNFile.annotate_block_coverages (src/sniffles/snf.py:249-267): the coverage vector
+ * (leadprov.py:451,510) zero-padded to a multiple of `binsize`, averaged per bin and rounded with
+ * Python's round().  out[i] is the value of bin first_bin + i (positions [j*binsize, (j+1)*binsize)),
+ * or -1 when the bin lies beyond the padded vector (the reference's IndexError: the bin is skipped).
+ * Formed from the task's sparse read table on the device; needs snf_batch_call_candidates first. */
+int snf_batch_block_coverage(snf_batch_t* b, int32_t task_index, int32_t binsize, int64_t first_bin,
+                             int64_t n_bins, int32_t* out);
+
 /* per-kernel timing (HIP events on the batch stream, recorded around every launch of the
  * last call_candidates+finalize pass). names[i] points to a static string. */
 int snf_batch_timing_count(snf_batch_t* b);

@@ -207,3 +207,28 @@ def main_extract(names=None):
         else:
             print(f"{name:28s} {recs.n:5d} records  {ref['read_count']:5d} reads accepted  {len(ref['leads']):6d} leads "
                   f"{ref['lead_counts']}")
+
+
+def main_snf():
+    """SNF container fixtures: real `.snf` files written by the unmodified reference (SNFile.store /
+    annotate_block_coverages / write_and_index / write_results) for the samples of cases.SNF_FILES, committed under
+    tests/golden/ together with their canonical records (tests/snf_util.py)."""
+    import cases
+    import ref_harness as rh
+    import snf_util as su
+    ref = rh.load_reference()
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (build, per_sample_args) in cases.SNF_FILES.items():
+        tis = build()
+        files = []
+        for s, ti in enumerate(tis):
+            path = os.path.join(out_dir, f"{name}_s{s}.snf")
+            n = rh.write_reference_snf(ti, path, per_sample_args[s])
+            f = rh.open_reference_snf(path)
+            rec = su.file_record(f, ti.contig, ref.sv.TYPES)
+            f.close()
+            files.append(dict(file=os.path.basename(path), sha256=su.sha(path), args=list(per_sample_args[s]), record=rec))
+            print(f"{path}: {n} candidates, {len(rec['blocks'])} blocks, {os.path.getsize(path)} bytes")
+        doc = dict(case=name, input_sha=[input_sha(t) for t in tis], files=files)
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
+            f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())

@@ -358,6 +358,45 @@ def run_reference_combine_task(sample_tasks, extra_args=()):
                 calls=[group_call_record(c) for c in res.calls])
 
 
+# ---------------------------------------------------------------------------------------------- SNF container
+def write_reference_snf(ti, path, extra_args=()):
+    """The reference's own `.snf` of one task: CallTask.execute's SNF tail (parallel.py:278-295: SNFile.store,
+    annotate_block_coverages on the dense coverage vector, write_and_index into a part file) followed by the main
+    program's SNFile.write_results (sniffles:269, snf.py:186-223).  Returns the candidate count."""
+    load_reference()
+    from sniffles import snf as ref_snf
+    cfg = make_config(("--snf", path) + tuple(extra_args), ti.qc_nm_threshold)
+    cfg.contig_lengths = [(ti.contig, int(ti.contig_len))]
+    task = build_task(ti, cfg)
+    cands = task.call_candidates(False, cfg)
+    task.finalize_candidates(cands, True, cfg)
+    part = f"{path}.tmp_{task.id}.snf"
+    with open(part, "wb") as handle:
+        so = ref_snf.SNFile(cfg, handle)
+        for c in cands:
+            so.store(c)
+        so.annotate_block_coverages(task.lead_provider)
+        so.write_and_index()
+    res = types.SimpleNamespace(has_snf=True, contig=ti.contig, task_id=task.id, snf_filename=part, snf_index=so.get_index(),
+                                snf_total_length=so.get_total_length(), snf_candidate_count=len(cands),
+                                coverage_average_total=task.coverage_average_total)
+    out = ref_snf.SNFile(cfg, open(path, "wb"))
+    out.add_result(res)
+    n = out.write_results(cfg, [ti.contig])
+    out.close()
+    return n
+
+
+def open_reference_snf(path):
+    load_reference()
+    from sniffles import snf as ref_snf
+    cfg = make_config(())
+    cfg.combine_close_handles = False
+    f = ref_snf.SNFile(cfg, open(path, "rb"), filename=path)
+    f.read_header()
+    return f
+
+
 # ---------------------------------------------------------------------------------------------- signature extraction
 def lead_record(ld) -> list:
     """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""

@@ -29,7 +29,9 @@ _DEFAULTS = dict(
     combine_high_confidence=0.0, combine_low_confidence=0.2, combine_low_confidence_abs=2,
     combine_null_min_coverage=5, combine_output_filtered=False, combine_support_threshold=3,
     combine_pair_relabel=False, combine_pair_relabel_threshold=20, combine_consensus=False, combine_population=None,
-    dev_combine_medians=False,
+    dev_combine_medians=False, combine_close_handles=False,
+    # SNF container (config.py:272, 327, 477-479, 527)
+    sample_id=None, output_rnames=False, snf=None,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)
@@ -87,6 +89,9 @@ class SnifflesConfig:
         if self.genotype_ploidy != 2:
             raise ValueError("Currently only genotype_ploidy 2 is supported")
         self.snf_block_size = 10 ** 5
+        self.snf_format_version = "S2_rc4"       # config.py:31 - the format this package reads and writes
+        self.version, self.build = "Sniffles2", "2.8.1-dev"   # the reference build whose behaviour is reproduced
+        self.reqc = "auto"
         self.combine_overlap_abs = 2500
         self.combine_min_size = 100
         self.precise = 25

@@ -49,6 +49,7 @@ SNF_KERNEL(e4_anchor, View)
 SNF_KERNEL(e5_align, View)
 SNF_KERNEL(e6_vote, View)
 SNF_KERNEL(z1_results, View)
+SNF_KERNEL(s1_blockcov, BlockCov)
 
 // read preparation (coverage rank structures + REF haplotype prefix counts)
 struct ReadPrep {
@@ -136,6 +137,7 @@ struct snf_batch_impl {
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
   bool uploaded = false;
+  bool reads_ready = false;       // call_candidates has enqueued the read preparation (sorted ends) for the uploaded tasks
   int run_gap = 1000;
   // host staging
   std::vector<snf_task_input_t> tasks;  // scalar fields only (pointers invalid after add)
@@ -597,6 +599,7 @@ void enqueue_read_prep(snf_batch_impl* b) {
 void run_call_candidates(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N; int T = v.T;
+  b->reads_ready = true;
   reset_timing(b);
 #ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
@@ -1284,6 +1287,30 @@ int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap
 #else
     if (nc) memcpy(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t));
 #endif
+  })
+}
+
+int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsize, int64_t first_bin, int64_t n_bins, int32_t* out) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !out) fail("batch not uploaded / null argument");
+    if (!b->reads_ready) fail("snf_batch_block_coverage needs snf_batch_call_candidates first (it sorts the read ends)");
+    if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
+    if (binsize <= 0 || first_bin < 0 || n_bins < 0) fail("invalid bin range");
+    if (n_bins == 0) return 0;
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    full_sync(b);
+    BlockCov q{};
+    q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
+    q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
+    q.L = b->tasks[(size_t)task_index].contig_len; q.first_bin = first_bin; q.binsize = binsize;
+    q.out = dalloc<int32_t>(b, (size_t)n_bins);
+    LAUNCH(s1_blockcov, q, n_bins, (q.hi - q.lo) * 8 + n_bins * 4);
+    d2h(b, out, q.out, (size_t)n_bins * 4);
+    dsync(b);
+    dfree_one(b, q.out);
   })
 }
 

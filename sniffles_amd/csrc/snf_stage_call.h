@@ -505,6 +505,33 @@ SNF_HD void d5_covavg_body(int64_t t, const View& v) {
   v.t_cov_avg[t] = L > 0 ? (double)v.t_cov_sum[t] / (double)L : NAN;
 }
 
+// SNFile.annotate_block_coverages (snf.py:249-267): the dense coverage vector zero-padded to a multiple of `binsize`,
+// averaged per bin (float64 mean of exact integers) and rounded with Python's round() (half to even).  The bin sum is
+// formed from the sparse read table: sum over x in [a, b) of #(start <= x) - #(end <= x); the starts (ends) below a
+// count for the whole bin, those inside it from their position to the bin's end.
+struct BlockCov {
+  const int32_t *r_start, *re_sorted, *rs_top, *re_top;
+  int64_t lo, hi;      // the task's reads
+  int64_t L;           // contig length
+  int64_t first_bin;   // bin j covers [j * binsize, (j + 1) * binsize)
+  int32_t binsize;
+  int32_t* out;        // rounded mean depth, -1: bin beyond the padded vector (IndexError in the reference, bin skipped)
+};
+SNF_HD int64_t blockcov_side(const int32_t* a, const int32_t* top, int64_t lo, int64_t hi, int64_t x0, int64_t x1) {
+  const int64_t p0 = bound_top_i32<true>(a, top, lo, hi, x0 - 1), p1 = bound_top_i32<true>(a, top, lo, hi, x1 - 1);
+  int64_t s = (p0 - lo) * (x1 - x0);
+  for (int64_t p = p0; p < p1; p++) s += x1 - (int64_t)a[p];
+  return s;
+}
+SNF_HD void s1_blockcov_body(int64_t i, const BlockCov& q) {
+  const int64_t bs = q.binsize, x0 = (q.first_bin + i) * bs;
+  if (x0 >= q.L) { q.out[i] = -1; return; }
+  const int64_t x1 = x0 + bs < q.L ? x0 + bs : q.L;
+  const int64_t sum = blockcov_side(q.r_start, q.rs_top, q.lo, q.hi, x0, x1) - blockcov_side(q.re_sorted, q.re_top, q.lo, q.hi, x0, x1);
+  const int64_t quo = sum / bs, rem = sum % bs;   // sum >= 0: a read ends after it starts
+  q.out[i] = (int32_t)(quo + ((2 * rem > bs || (2 * rem == bs && (quo & 1))) ? 1 : 0));
+}
+
 // Z1: counters, task status / call offsets / coverage averages -> the pinned host result block (zero-copy stores)
 SNF_HD void z1_results_body(int64_t t, const View& v) {
   if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }

@@ -37,6 +37,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_fetch.argtypes = [vp, C.c_int, C.POINTER(abi.snf_result_t)]
     lib.snf_batch_sync.argtypes = [vp]
     lib.snf_batch_export_calls_device.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.snf_batch_block_coverage.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
+    lib.snf_batch_block_coverage.restype = C.c_int
     lib.snf_batch_timing_count.argtypes = [vp]
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
@@ -141,6 +143,14 @@ class Batch:
         n = C.c_int64()
         _check(self.lib, self.lib.snf_batch_export_calls_device(self._h, C.c_void_p(dst_ptr), cap_calls, C.byref(n)))
         return int(n.value)
+
+    def block_coverage(self, task_index: int, binsize: int, first_bin: int, n_bins: int) -> np.ndarray:
+        """Rounded mean depth of `n_bins` coverage bins of `binsize` bp (SNFile.annotate_block_coverages); -1 = beyond
+        the padded coverage vector.  Needs call_candidates first."""
+        out = np.empty(max(n_bins, 1), np.int32)
+        _check(self.lib, self.lib.snf_batch_block_coverage(self._h, task_index, binsize, first_bin, n_bins,
+                                                           out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out[:n_bins]
 
     def timings(self) -> list:
         out = []

@@ -39,12 +39,22 @@ class Task:
             lp.end = self.end
         self._ti = lp.to_task_input(self.id, self.sv_id, self.tandem_repeats,
                                     getattr(config, "qc_nm_threshold", 0.02))
+        self.close()
+        self._batch = lib.Batch(config, [self._ti], device=self.device, _lib=self._lib)
+        lp.device_batch = self._batch   # SNFile.annotate_block_coverages(lead_provider) reads the coverage from HBM
+
+    def close(self):
+        """Release the task's device memory.  The batch outlives finalize_candidates because the SNF writer needs the
+        read table afterwards (CallTask.execute, parallel.py:278-291); it goes with the task otherwise."""
         if self._batch is not None:
             self._batch.close()
-        self._batch = lib.Batch(config, [self._ti], device=self.device, _lib=self._lib)
+            self._batch = None
+        if self.lead_provider is not None and getattr(self.lead_provider, "device_batch", None) is not None:
+            self.lead_provider.device_batch = None
 
     def call_candidates(self, keep_qc_fails, config, svcall_cls=sv.SVCall, bnd_cls=sv.SVCallBNDInfo) -> list:
         self._open(config)
+        self._finalized = False
         self._batch.call_candidates()
         res = self._batch.fetch(0)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
@@ -59,7 +69,7 @@ class Task:
         return out
 
     def finalize_candidates(self, candidates, keep_qc_fails, config) -> list:
-        if self._batch is None:
+        if self._batch is None or getattr(self, "_finalized", False):
             raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")
         self._batch.finalize()
         res = self._batch.fetch(1)
@@ -70,8 +80,7 @@ class Task:
             sv.fill_final(c, res, i, self._ti)
             c.finalize()
             passed.append(c)
-        self._batch.close()
-        self._batch = None
+        self._finalized = True
         return passed
 
 
@@ -84,6 +93,21 @@ class CallTask(Task):
         if not config.no_qc:
             calls = [s for s in calls if s.qc]
         return sorted(calls, key=lambda s: s.pos)
+
+    def write_snf_part(self, svcandidates, snf_filename: str):
+        """The SNF tail of CallTask.execute (parallel.py:278-295): the task's candidates (after finalize_candidates) go
+        into 100-kb blocks with their downsampled coverage and are written as a part file; the returned record is what
+        `SNFile.add_result` / `write_results` consume."""
+        from . import snf
+        with open(snf_filename, "wb") as handle:
+            out = snf.SNFile(self.config, handle)
+            for cand in svcandidates:
+                out.store(cand)
+            out.annotate_block_coverages(self.lead_provider)
+            out.write_and_index()
+        return snf.SNFPart(task_id=self.id, contig=self.contig, snf_filename=snf_filename, snf_index=out.get_index(),
+                           snf_total_length=out.get_total_length(), snf_candidate_count=len(svcandidates),
+                           coverage_average_total=self.coverage_average_total)
 
 
 class CombineTask(Task):

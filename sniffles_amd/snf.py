@@ -1,0 +1,307 @@
+"""The SNF container: reference `src/sniffles/snf.py:29-267`, same class and method names.
+
+An `.snf` file is one JSON header line (`{"config": ..., "index": {contig: {block: [(offset, length), ...]}},
+"snf_candidate_count": n}`) followed by the concatenated gzip members of pickled block dicts
+`{svtype: [SVCall, ...], "_COVERAGE": {bin_start: depth}}`, one block per `snf_block_size` (100 kb) of a contig.
+Files written here are read by the reference and the other way round:
+
+* blocks are pickled under the reference's module path (`sniffles.sv.SVCall`, `SVCallBNDInfo`,
+  `ForwardDifferenceWelford`) whichever classes the calls are instances of, and read back into the classes of
+  `sniffles_amd.sv`;
+* the per-block `_COVERAGE` table (`SNFile.annotate_block_coverages`, snf.py:249-267: the coverage vector averaged per
+  `coverage_binsize_combine` bp and rounded) is computed on the GPU from the task's sparse read table
+  (`snf_batch_block_coverage`, include/sniffles_amd.h) - the dense vector is never built, and there is no CPU fallback.
+
+Everything else in this module is container I/O (gzip, pickle, JSON, file offsets), like the reference.
+"""
+from __future__ import annotations
+
+import gzip
+import io
+import json
+import os
+import pickle
+import sys
+import threading
+import types
+from dataclasses import dataclass
+from typing import Optional
+
+from . import sv
+
+REF_MODULE = "sniffles.sv"
+_CLASSES = {"SVCall": sv.SVCall, "SVCallBNDInfo": sv.SVCallBNDInfo, "ForwardDifferenceWelford": sv.ForwardDifferenceWelford,
+            "SVCallPostprocessingInfo": sv.SVCallPostprocessingInfo}
+_LOCK = threading.Lock()
+
+
+class _Unpickler(pickle.Unpickler):
+    """Blocks written by the reference name `sniffles.sv.*`; resolve them to this package's record types."""
+
+    def find_class(self, module, name):
+        if module == REF_MODULE and name in _CLASSES:
+            return _CLASSES[name]
+        return super().find_class(module, name)
+
+
+def _as_class(obj, mod):
+    """Shallow copy of a record of this package as an instance of the class of the same name in `mod`."""
+    for name, cls in _CLASSES.items():
+        if type(obj) is cls:
+            out = getattr(mod, name).__new__(getattr(mod, name))
+            out.__dict__.update({k: _as_class(v, mod) for k, v in obj.__dict__.items()})
+            return out
+    return obj
+
+
+def _dumps_as_reference(block: dict) -> bytes:
+    """pickle.dumps of a block with this package's record classes written under the reference's names.
+
+    When the real `sniffles.sv` is loaded in this process the records are handed to pickle as (shallow) instances of
+    its classes.  Otherwise the C pickler must still find the class it writes under the name it writes - it records a
+    class as (`__module__`, `__qualname__`) and verifies that the pair resolves to it - so for the duration of the dump
+    the classes carry the reference's module path and a stand-in module of that name holds them."""
+    with _LOCK:
+        real = sys.modules.get(REF_MODULE)
+        if real is not None:
+            conv = {k: ([_as_class(c, real) for c in v] if isinstance(v, list) else v) for k, v in block.items()}
+            return pickle.dumps(conv)
+        saved = {}
+        had_pkg = "sniffles" in sys.modules
+        try:
+            if not had_pkg:
+                pkg = types.ModuleType("sniffles")
+                pkg.__path__ = []
+                sys.modules["sniffles"] = pkg
+            mod = types.ModuleType(REF_MODULE)
+            sys.modules[REF_MODULE] = mod
+            for name, cls in _CLASSES.items():
+                setattr(mod, name, cls)
+                saved[cls] = (cls.__module__, cls.__qualname__)
+                cls.__module__, cls.__qualname__ = REF_MODULE, name
+            return pickle.dumps(block)
+        finally:
+            for cls, (m, q) in saved.items():
+                cls.__module__, cls.__qualname__ = m, q
+            sys.modules.pop(REF_MODULE, None)
+            if not had_pkg:
+                sys.modules.pop("sniffles", None)
+
+
+@dataclass
+class SNFPart:
+    """What `SNFile.write_results` reads from a task's result (reference `result.py:68-75`, `parallel.py:276-295`)."""
+    task_id: int
+    contig: str
+    snf_filename: str
+    snf_index: dict
+    snf_total_length: int
+    snf_candidate_count: int
+    coverage_average_total: float
+    has_snf: bool = True
+
+
+class SNFileBase:
+    header_length: int
+    _header: Optional[dict]
+
+    def __init__(self, config, handle, filename=None):
+        self.config = config
+        self.handle = handle
+        self.filename = filename
+        self.blocks = {}
+        self._header = None
+        self._index = {}
+        self.total_length = 0
+        self._results = []
+
+    @classmethod
+    def open(cls, filename: str, config=None) -> "SNFileBase":
+        if config is None:
+            from .config import SnifflesConfig
+            config = SnifflesConfig()
+        obj = cls(config, open(filename, "rb"), filename)
+        obj.read_header()
+        return obj
+
+    @property
+    def index(self) -> dict:
+        return self._index
+
+    @property
+    def header(self) -> dict:
+        return self._header
+
+    @property
+    def population(self):
+        return self.header.get("population", None)
+
+    @property
+    def reqc(self) -> bool:
+        """Was this file written by a version old enough that QC must be redone (snf.py:66-81)?"""
+        mode = getattr(self.config, "reqc", "auto")
+        if mode == "auto":
+            try:
+                build, _, _ = self.header["config"]["build"].partition("-")
+            except (KeyError, AttributeError, TypeError):
+                return True
+            return build < "2.5.3"
+        return mode
+
+    def is_open(self) -> bool:
+        return self.handle is not False
+
+    def _open(self):
+        if self.handle is not False:
+            self.close()
+        self.handle = open(self.filename, "rb")
+
+    def _close_after_use(self):
+        if getattr(self.config, "combine_close_handles", False):
+            self.close()
+
+    # ---- writing
+    def store(self, svcand):
+        bs = self.config.snf_block_size
+        block_index = int(svcand.pos / bs) * bs
+        if block_index not in self.blocks:
+            self.blocks[block_index] = {svtype: [] for svtype in sv.TYPES}
+            self.blocks[block_index]["_COVERAGE"] = {}
+        if not getattr(self.config, "output_rnames", False):
+            svcand.rnames = None
+        if svcand.svtype in sv.TYPES:
+            self.blocks[block_index][svcand.svtype].append(svcand)
+
+    def serialize_block(self, block_id) -> bytes:
+        return _dumps_as_reference(self.blocks[block_id])
+
+    def unserialize_block(self, data: bytes):
+        return _Unpickler(io.BytesIO(data)).load()
+
+    def write_and_index(self):
+        if not self.is_open():
+            self._open()
+        offset = 0
+        for block_id in sorted(self.blocks):
+            data = gzip.compress(self.serialize_block(block_id))
+            self.handle.write(data)
+            self._index[block_id] = (offset, len(data))
+            offset += len(data)
+            self.total_length += len(data)
+        self._close_after_use()
+
+    def add_result(self, result):
+        if result.has_snf:
+            self._results.append(result)
+
+    def _calculate_contig_coverages(self, contigs) -> dict:
+        per = {c: [] for c in contigs}
+        for r in self._results:
+            per[r.contig].append(r.coverage_average_total)
+        return {c: (sum(v) / len(v) if len(v) > 0 else 0) for c, v in per.items()}
+
+    def _create_header(self, config, main_index: dict, snf_candidate_count: int) -> dict:
+        return {"config": config.__dict__, "index": main_index, "snf_candidate_count": snf_candidate_count}
+
+    def write_results(self, config, contigs) -> int:
+        """Concatenate the per-task part files behind one header; returns the candidate count (snf.py:186-223)."""
+        main_index = {}
+        offset = 0
+        snf_candidate_count = sum(r.snf_candidate_count for r in self._results)
+        parts_sorted = sorted(self._results, key=lambda r: r.task_id)
+        for part in parts_sorted:
+            idx = main_index.setdefault(part.contig, {})
+            for block, (start, length) in part.snf_index.items():
+                idx.setdefault(block, []).append((start + offset, length))
+            offset += part.snf_total_length
+        config.contig_coverages = self._calculate_contig_coverages(contigs)
+        header = self._create_header(config, main_index, snf_candidate_count)
+        self.handle.write((json.dumps(header, default=lambda obj: "<Unstored_Object>") + "\n").encode())
+        for part in parts_sorted:
+            with open(part.snf_filename, "rb") as h:
+                self.handle.write(h.read())
+            os.remove(part.snf_filename)
+        return snf_candidate_count
+
+    # ---- reading
+    def read_header(self):
+        if not self.is_open():
+            self._open()
+        header_text = self.handle.readline()
+        self.header_length = len(header_text)
+        try:
+            self._header = json.loads(header_text.strip())
+        except Exception as e:
+            raise ValueError(f"'{self.filename}' is not a valid .snf file (header: {e})") from e
+        self._index = self._header["index"]
+        self._close_after_use()
+
+    def read_blocks(self, contig, block_index):
+        if not self.is_open():
+            self._open()
+        block_index = str(block_index)
+        if contig not in self.index or block_index not in self.index[contig]:
+            self._close_after_use()
+            return None
+        blocks = []
+        try:
+            for start, length in self.index[contig][block_index]:
+                self.handle.seek(self.header_length + start)
+                blocks.append(self.unserialize_block(gzip.decompress(self.handle.read(length))))
+        finally:
+            self._close_after_use()
+        return blocks
+
+    def get_index(self):
+        return self.index
+
+    def get_total_length(self):
+        return self.total_length
+
+    def close(self) -> None:
+        if self.handle is not False:
+            self.handle.close()
+            self.handle = False
+
+    def get_all_blocks(self, contig: str) -> dict:
+        blocks = {}
+        if contig in self.index:
+            for block_start in self.index[contig].keys():
+                blocks[block_start] = self.read_blocks(contig, block_start)[0]
+        return blocks
+
+    def get_full_coverage(self, contig: str) -> dict:
+        coverage = {}
+        for b in self.get_all_blocks(contig).values():
+            coverage.update(b["_COVERAGE"])
+        return coverage
+
+
+class SNFile(SNFileBase):
+    def annotate_block_coverages(self, lead_provider):
+        """Downsampled coverage of every stored block (snf.py:249-267).  `lead_provider` is the task's
+        `sniffles_amd.leadprov.LeadProvider` after `Task.call_candidates` (or the `Task` itself): its read table is in
+        HBM with the ends sorted, and one launch per task evaluates all bins of all blocks."""
+        batch = getattr(lead_provider, "device_batch", None)
+        if batch is None:
+            batch = getattr(lead_provider, "_batch", None)
+        if batch is None:
+            raise RuntimeError("annotate_block_coverages needs the task's device batch: call Task.call_candidates first "
+                               "(the coverage lives on the GPU; there is no CPU fallback)")
+        binsize = self.config.coverage_binsize_combine
+        block_size = self.config.snf_block_size
+        per_block = block_size // binsize
+        want = []   # (block_offset, bin position key, index into the downsampled vector)
+        for block_offset in self.blocks.keys():
+            block_index = block_offset // block_size
+            for i in range(per_block):
+                want.append((block_offset, block_offset + i * binsize, block_index * per_block + i))
+        if not want:
+            return
+        lo = min(w[2] for w in want)
+        hi = max(w[2] for w in want) + 1
+        depth = batch.block_coverage(0, binsize, lo, hi - lo)
+        for block_offset, key, j in want:
+            d = int(depth[j - lo])
+            if d >= 0:      # beyond the padded vector: the reference's IndexError, the bin stays unset
+                self.blocks[block_offset]["_COVERAGE"][key] = d

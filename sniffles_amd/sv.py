@@ -38,6 +38,39 @@ class SVCallPostprocessingInfo:
         raise AttributeError("cluster leads stay on the GPU; use the call's fields (support, rnames, ...) instead")
 
 
+class ForwardDifferenceWelford:
+    """State of the reference's relative forward-difference sampler (sv.py:51-87).  Nothing on the path ever feeds it
+    (`qc_coverage_samples` therefore always reports `(True, None)`, postprocessing.py:373); it exists so that pickled
+    calls carry the attribute the reference's `SVCall` has (SNF blocks, sniffles_amd/snf.py)."""
+
+    def __init__(self):
+        self.n = 0
+        self.m1 = 0
+        self.m2 = 0
+        self.last = None
+
+    def push(self, value):
+        if self.last is None:
+            self.last = value
+            return
+        rel = (value - self.last) / (self.last + 1e-10)
+        k = self.n
+        self.n = k + 1
+        d = rel - self.m1
+        step = d / self.n
+        self.m1 += step
+        self.m2 += d * step * k
+        self.last = value
+
+    @property
+    def mean(self):
+        return self.m1 if self.n else None
+
+    @property
+    def variance(self):
+        return self.m2 / self.n if self.n >= 2 else None
+
+
 @dataclass
 class SVCall:
     contig: str
@@ -61,6 +94,7 @@ class SVCall:
     svlens: Optional[list] = None
     fwd: int = None
     rev: int = None
+    forward_difference_sampler: ForwardDifferenceWelford = field(default_factory=ForwardDifferenceWelford)
     coverage_upstream: int = 0
     coverage_downstream: int = 0
     coverage_start: int = 0
@@ -88,6 +122,10 @@ class SVCall:
 
     def finalize(self):
         self.postprocess = None
+
+    def qc_coverage_samples(self):
+        var = self.forward_difference_sampler.variance
+        return (True, None) if var is None else (var < 0.3, float(var))
 
 
 def _ps(code, ti):

@@ -372,6 +372,12 @@ COMBINE_TASK = {
                                              for s in range(8)], ()),
 }
 
+# real .snf files written by the reference (one per sample; per-sample reference command line); the samples are those of
+# COMBINE_TASK["combine_task_3samples_lowcov"], so the combined calls of that golden also pin the merge over the files
+SNF_FILES = {
+    "snf_3samples_lowcov": (COMBINE_TASK["combine_task_3samples_lowcov"][0], ((), ("--output-rnames",), ())),
+}
+
 
 # ---------------------------------------------------------------------------------------------- signature extraction
 # name -> dict(gen=kwargs of synth_bam.gen_records | fixture=file under tests/golden, contig, region, read_id_offset,
