@@ -232,3 +232,41 @@ def main_snf():
         doc = dict(case=name, input_sha=[input_sha(t) for t in tis], files=files)
         with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
             f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
+def main_vcf():
+    """VCF text written by the unmodified reference writer: single-sample calls of cases.ALL (vcf_util.CASES x
+    vcf_util.VARIANTS) and the combined calls of a CombineTask golden (multi-sample columns, AC / SUPP_VEC)."""
+    import cases
+    import ref_harness as rh
+    import vcf_util as vu
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    doc = dict(single={}, combine={})
+    for name in vu.CASES:
+        build, kw, args = cases.ALL[name]
+        ti = build()
+        per = {}
+        for vname, (vargs, overrides, with_fasta) in vu.VARIANTS.items():
+            calls, cfg = rh.run_reference_call_svs(ti, tuple(args) + tuple(vargs), {k: v for k, v in overrides.items() if k != "symbolic"})
+            for k, v in vu.FIXED.items():
+                setattr(cfg, k, v)
+            cfg.sample_ids_vcf = [(0, "SAMPLE")]
+            fasta = vu.FakeFasta({ti.contig: ti.contig_len}) if with_fasta else None
+            per[vname] = rh.reference_vcf_text(calls, cfg, [(ti.contig, ti.contig_len)], fasta)
+        doc["single"][name] = dict(input_sha=input_sha(ti), text=per)
+        print(f"{name:24s}", {k: len(vu.split_text(v)[1]) for k, v in per.items()})
+    for name in ("combine_task_3samples_lowcov", "combine_task_8samples_dense"):
+        build, args = cases.COMBINE_TASK[name]
+        tis = build()
+        _, calls, cfg = rh.run_reference_combine_task(tis, args, with_objects=True)
+        for k, v in vu.FIXED.items():
+            setattr(cfg, k, v)
+        calls = sorted(calls, key=lambda c: c.pos)          # CombineResult.store_calls / finalize (result.py:137-147)
+        per = {}
+        for vname, with_fasta in (("plain", False), ("fasta", True)):
+            fasta = vu.FakeFasta({tis[0].contig: tis[0].contig_len}) if with_fasta else None
+            per[vname] = rh.reference_vcf_text(calls, cfg, [(tis[0].contig, tis[0].contig_len)], fasta)
+        doc["combine"][name] = dict(text=per)
+        print(f"{name:32s}", {k: len(vu.split_text(v)[1]) for k, v in per.items()})
+    with gzip.GzipFile(os.path.join(out_dir, "vcf_text.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())

@@ -265,7 +265,7 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     return out
 
 
-def run_reference_combine_task(sample_tasks, extra_args=()):
+def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False):
     """The reference's own CombineTask.execute (parallel.py:444-572) on a synthetic population.
 
     Per-sample candidates come from the reference's call_candidates + finalize_candidates; they are put into SNF blocks by
@@ -354,8 +354,9 @@ def run_reference_combine_task(sample_tasks, extra_args=()):
                 recs[svtype] = out
             blk.append(dict(block=int(bi), cands=recs, coverage={str(k): int(v) for k, v in sorted(b["_COVERAGE"].items())}))
         inputs.append(blk)
-    return dict(n_samples=ns, contig=contig, contig_len=int(contig_len), samples=inputs,
-                calls=[group_call_record(c) for c in res.calls])
+    doc = dict(n_samples=ns, contig=contig, contig_len=int(contig_len), samples=inputs,
+               calls=[group_call_record(c) for c in res.calls])
+    return (doc, res.calls, cfg) if with_objects else doc
 
 
 # ---------------------------------------------------------------------------------------------- SNF container
@@ -395,6 +396,40 @@ def open_reference_snf(path):
     f = ref_snf.SNFile(cfg, open(path, "rb"), filename=path)
     f.read_header()
     return f
+
+
+# ---------------------------------------------------------------------------------------------- VCF writer
+def run_reference_call_svs(ti, extra_args=(), overrides=None):
+    """CallTask.execute's calling part (parallel.py:255-271) on one task: candidates -> finalize -> QC filter -> sort.
+    Returns (calls, config)."""
+    cfg = make_config(tuple(extra_args), ti.qc_nm_threshold)
+    for k, v in (overrides or {}).items():
+        setattr(cfg, k, v)
+    task = build_task(ti, cfg)
+    qc = not (cfg.snf is not None or cfg.no_qc)
+    cands = task.call_candidates(qc, cfg)
+    calls = task.finalize_candidates(cands, not qc, cfg)
+    if not cfg.no_qc:
+        calls = [c for c in calls if c.qc]
+    if cfg.sort:
+        calls = sorted(calls, key=lambda c: c.pos)
+    return calls, cfg
+
+
+def reference_vcf_text(calls, cfg, contigs_lengths, fasta=None) -> str:
+    """Header and records as the UNMODIFIED reference writer (vcf.py) emits them for `calls` (deep-copied: the writer
+    mutates the calls it writes)."""
+    import copy
+    import io
+    load_reference()
+    from sniffles import vcf as ref_vcf
+    buf = io.StringIO()
+    w = ref_vcf.VCF(cfg, buf)
+    w.reference_handle = fasta
+    w.write_header(contigs_lengths)
+    n = sum(w.write_call(c) for c in copy.deepcopy(calls))
+    assert n == w.call_count
+    return buf.getvalue()
 
 
 # ---------------------------------------------------------------------------------------------- signature extraction

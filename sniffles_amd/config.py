@@ -32,6 +32,8 @@ _DEFAULTS = dict(
     dev_combine_medians=False, combine_close_handles=False,
     # SNF container (config.py:272, 327, 477-479, 527)
     sample_id=None, output_rnames=False, snf=None,
+    # VCF writer (config.py:166-170, 242, 332)
+    vcf=None, reference=None, max_del_seq_len=50000, max_unknown_pct=0.5,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)
@@ -92,6 +94,15 @@ class SnifflesConfig:
         self.snf_format_version = "S2_rc4"       # config.py:31 - the format this package reads and writes
         self.version, self.build = "Sniffles2", "2.8.1-dev"   # the reference build whose behaviour is reproduced
         self.reqc = "auto"
+        import datetime
+        import sys
+        self.start_date = datetime.datetime.now().strftime("%Y/%m/%d %H:%M:%S")   # config.py:472, 480
+        self.command = " ".join(sys.argv)
+        self.genotype_format = "GT:GQ:DR:DV"                                        # config.py:566-568
+        self.genotype_none = (".", ".", 0, 0, 0, (None, None))
+        self.genotype_null = (0, 0, 0, 0, 0, (None, None))
+        self.sample_ids_vcf = [(0, "SAMPLE")]   # single-sample default (sniffles:177-181 uses the input's base name)
+        self.sort = True
         self.combine_overlap_abs = 2500
         self.combine_min_size = 100
         self.precise = 25

@@ -159,10 +159,13 @@ def fill_candidate(call, res: Result, i: int, ti, bnd_cls=SVCallBNDInfo):
         info["SUPPORT_LONG"] = int(c["support_long"])
     elif svtype == "DEL":
         info["SUPPORT_SA"] = int(c["support_sa"])
-    info["STDEV_POS"] = float(c["stdev_pos"])
+    # util.stdev returns the int 0 for fewer than two values (util.py:25-27) and a float otherwise; the trimmed list
+    # is that short only for a single lead (fwd + rev = len(leads)).  0 == 0.0, but the VCF writer prints them differently.
+    single = int(c["fwd"]) + int(c["rev"]) < 2
+    info["STDEV_POS"] = 0 if single else float(c["stdev_pos"])
     sl = none_if_nan(c["stdev_len"])
     if sl is not None:
-        info["STDEV_LEN"] = sl
+        info["STDEV_LEN"] = 0 if single else sl
     call.info = info
     (call.coverage_upstream, call.coverage_start, call.coverage_center, call.coverage_end,
      call.coverage_downstream) = (int(x) for x in c["cov"])
