@@ -270,3 +270,29 @@ def main_vcf():
         print(f"{name:32s}", {k: len(vu.split_text(v)[1]) for k, v in per.items()})
     with gzip.GzipFile(os.path.join(out_dir, "vcf_text.json.gz"), "wb", mtime=0) as f:
         f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
+def main_sample():
+    """End to end: a synthetic coordinate-sorted BAM (cases.SAMPLES) through the unmodified reference's call_sample flow
+    (ref_harness.run_reference_call_sample) -> the VCF text and the content of the SNF file it writes."""
+    import tempfile
+    import cases
+    import ref_harness as rh
+    import snf_util as su
+    import vcf_util as vu
+    ref = rh.load_reference()
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (build, args) in cases.SAMPLES.items():
+        recs = build()
+        plain = rh.run_reference_call_sample(recs, args, None, vu.FIXED)
+        path = os.path.join(tempfile.mkdtemp(prefix="snf_e2e_"), "sample.snf")
+        with_snf = rh.run_reference_call_sample(recs, args, path, vu.FIXED)
+        f = rh.open_reference_snf(path)
+        snf_rec = {c: su.file_record(f, c, ref.sv.TYPES) for c, _ in plain["contig_lengths"]}
+        f.close()
+        doc = dict(case=name, reference_args=list(args), input_sha=records_sha(recs), vcf=plain["vcf"], vcf_with_snf=with_snf["vcf"],
+                   read_count=plain["read_count"], snf_candidates=with_snf["snf_candidates"], snf=snf_rec)
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as fh:
+            fh.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+        print(f"{name:24s} {recs.n} records, {plain['read_count']} reads accepted -> {len(vu.split_text(plain['vcf'])[1])} VCF records, "
+              f"{with_snf['snf_candidates']} SNF candidates")

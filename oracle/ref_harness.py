@@ -432,6 +432,54 @@ def reference_vcf_text(calls, cfg, contigs_lengths, fasta=None) -> str:
     return buf.getvalue()
 
 
+# ---------------------------------------------------------------------------------------------- whole sample
+def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
+    """The reference's `call_sample` flow on an in-memory BAM (`sniffles_amd.bam.BamRecords`): the main program's task
+    layout (sniffles:286-360; default task_count_multiplier 0 = one task per processed contig), the UNMODIFIED
+    `CallTask.execute` (build_leadtab over oracle/pysam_stub, call_candidates, finalize_candidates, SNF part) per task in
+    this process, results emitted in task order through the unmodified VCF writer and `SNFile.write_results`.
+    Returns dict(vcf=text, read_count=..., snf_candidates=...)."""
+    import io
+    import math
+    import struct
+    import pysam_stub
+    ref = load_reference()
+    from sniffles import snf as ref_snf, vcf as ref_vcf
+    args = ["--input", "x.bam", "--vcf", "out.vcf"] + (["--snf", snf_path] if snf_path else []) + list(extra_args)
+    cfg = ref.config.SnifflesConfig(*args)
+    cfg.mode = "call_sample"
+    cfg.input_is_cram, cfg.input_mode = False, "rb"
+    cfg.sample_ids_vcf = [(0, "SAMPLE")]
+    for k, v in (fixed or {}).items():
+        setattr(cfg, k, v)
+    flags = [struct.unpack_from("<H", recs.blob, int(o) + 18)[0] for o in recs.rec_off[:-1]]
+    total_mapped = sum(1 for f, r in zip(flags, recs.ref_id.tolist()) if r >= 0 and not f & 0x4)
+    cfg.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
+    contig_lengths = [(c, int(n)) for c, n in zip(recs.ref_names, recs.ref_lens) if ref.util.should_process_contig(c, int(n), cfg)]
+    cfg.contig_lengths = contig_lengths
+    buf = io.StringIO()
+    vcf_out = ref_vcf.VCF(cfg, buf)
+    vcf_out.write_header(contig_lengths)
+    snf_out = ref_snf.SNFile(cfg, open(snf_path, "wb")) if snf_path else None
+    orig = ref.parallel.pysam.AlignmentFile
+    ref.parallel.pysam.AlignmentFile = lambda *a, **k: pysam_stub.AlignmentFile(recs)
+    read_count = 0
+    try:
+        for task_id, (contig, length) in enumerate(contig_lengths):
+            task = ref.parallel.CallTask(id=task_id, contig=contig, start=0, end=length - 1, assigned_process_id=None,
+                                         tandem_repeats=None, genotype_svs=None, sv_id=0, config=cfg, regions=None)
+            result = task.execute()
+            read_count += result.processed_read_count
+            result.emit(vcf_out=vcf_out, snf_out=snf_out)
+    finally:
+        ref.parallel.pysam.AlignmentFile = orig
+    n_snf = 0
+    if snf_out is not None:
+        n_snf = snf_out.write_results(cfg, [c for c, _ in contig_lengths])
+        snf_out.close()
+    return dict(vcf=buf.getvalue(), read_count=int(read_count), snf_candidates=int(n_snf), contig_lengths=contig_lengths)
+
+
 # ---------------------------------------------------------------------------------------------- signature extraction
 def lead_record(ld) -> list:
     """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""

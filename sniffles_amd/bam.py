@@ -44,6 +44,29 @@ def bgzf_inflate(data: bytes) -> bytes:
     return b"".join(out)
 
 
+def bgzf_deflate(raw: bytes, level: int = 1) -> bytes:
+    """Raw BAM stream -> BGZF blocks (+ the empty EOF block); the inverse of `bgzf_inflate` (tests, synthetic inputs)."""
+    out = []
+    for p in list(range(0, len(raw), 0xff00)) + [None]:
+        chunk = b"" if p is None else raw[p:p + 0xff00]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        cdata = co.compress(chunk) + co.flush()
+        bsize = len(cdata) + 25
+        out.append(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + cdata +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk)))
+    return b"".join(out)
+
+
+def bam_stream(ref_names, ref_lens, records, header_text: str = "@HD\tVN:1.6\tSO:coordinate\n") -> bytes:
+    """Header + records as an inflated BAM stream (SAM/BAM spec 4.2)."""
+    text = header_text.encode("ascii")
+    parts = [b"BAM\x01", struct.pack("<i", len(text)), text, struct.pack("<i", len(ref_names))]
+    for name, ln in zip(ref_names, ref_lens):
+        nm = name.encode("ascii") + b"\0"
+        parts += [struct.pack("<i", len(nm)), nm, struct.pack("<i", int(ln))]
+    return b"".join(parts) + b"".join(records)
+
+
 @dataclass
 class BamRecords:
     """Inflated alignment records of a BAM stream (all contigs, file order)."""

@@ -1,0 +1,101 @@
+"""One sample from a BAM to VCF / SNF on one GPU: the `call_sample` flow of the reference's main program with
+`--threads`-independent results (`src/sniffles/sniffles:286-360, 487-560`, `CallTask.execute` `parallel.py:255-297`),
+wired from the pieces of this package - nothing here computes:
+
+    BGZF inflate + header (host, sniffles_amd.bam)
+    -> per contig task: signature extraction (GPU, sniffles_amd.extract) -> clustering / calling / QC / genotyping /
+       consensus (GPU, sniffles_amd.parallel.CallTask) -> calls sorted by position
+    -> VCF records in task order (sniffles_amd.vcf), SNF part files concatenated behind one header (sniffles_amd.snf)
+
+Task layout as in the reference with its default `task_count_multiplier = 0`: one task per processed contig, ids in
+header order, region [0, contig_length - 1), read ids offset by `task.id * 10 ** ceil(ln(total_mapped) + 1)`.  This is
+the configs[0]-shaped plumbing path (BASELINE.json) and the end-to-end parity harness; worker processes, the CLI and
+progress reporting stay with the reference.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+from . import bam, extract, parallel, snf, vcf
+
+
+def should_process_contig(contig: str, length: int, config) -> bool:
+    """`util.should_process_contig` (util.py:147-162): requested contigs / regions, otherwise contigs of 1 Mb and more."""
+    wanted = getattr(config, "contig", None)
+    by_region = getattr(config, "regions_by_contig", None) or {}
+    if wanted and contig not in wanted:
+        return False
+    if by_region and contig not in by_region:
+        return False
+    if not getattr(config, "all_contigs", False) and length < 1_000_000:
+        return bool((wanted and contig in wanted) or (contig in by_region))
+    return True
+
+
+@dataclass
+class SampleResult:
+    contig_lengths: list
+    read_count: int = 0
+    vcf_records: int = 0
+    snf_candidates: int = 0
+    calls: dict = field(default_factory=dict)     # task id -> sorted calls (as written)
+
+
+class _Extracted:
+    """Lead-provider stand-in for a task whose input came from the extraction kernels: the TaskInput is ready."""
+
+    def __init__(self, ti):
+        self.ti = ti
+        self.contig_len, self.end = ti.contig_len, None
+        self.device_batch = None
+
+    def to_task_input(self, task_id, sv_id_start, tandem_repeats, qc_nm_threshold):
+        return self.ti
+
+
+def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
+                _lib=None) -> SampleResult:
+    """`records`: `bam.read_bam(path)`.  `tandem_repeats`: {contig: [(start, end), ...]} (already padded, util.py:121-144).
+    Writes the VCF to `vcf_handle` and / or the SNF to `snf_path` (CallTask.execute switches QC filtering off for the
+    candidates when an SNF is requested, parallel.py:258-263)."""
+    import struct
+    flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
+    total_mapped = sum(1 for f, r in zip(flags, records.ref_id.tolist()) if r >= 0 and not f & 0x4)
+    config.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
+    config.snf = snf_path
+    contig_lengths = [(c, int(n)) for c, n in zip(records.ref_names, records.ref_lens) if should_process_contig(c, int(n), config)]
+    config.contig_lengths = contig_lengths
+    out = SampleResult(contig_lengths=contig_lengths)
+    writer = None
+    if vcf_handle is not None:
+        writer = vcf.VCF(config, vcf_handle)
+        writer.write_header(contig_lengths)
+    snf_out = snf.SNFile(config, open(snf_path, "wb")) if snf_path else None
+    qc = not (snf_path is not None or config.no_qc)
+    for task_id, (contig, length) in enumerate(contig_lengths):
+        tr = (tandem_repeats or {}).get(contig)
+        task = parallel.CallTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config,
+                                 tandem_repeats=tr, device=device, _lib=_lib)
+        ti, info = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
+                                          read_id_offset=task_id * config.task_read_id_offset_mult, task_id=task_id,
+                                          sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
+        config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
+        task.lead_provider = _Extracted(ti)
+        cands = task.call_candidates(qc, config)
+        calls = task.finalize_candidates(cands, not qc, config)
+        if not config.no_qc:
+            calls = [c for c in calls if c.qc]
+        if getattr(config, "sort", True):
+            calls = sorted(calls, key=lambda c: c.pos)
+        out.read_count += info.read_count
+        if snf_out is not None:
+            snf_out.add_result(task.write_snf_part(cands, f"{snf_path}.tmp_{task_id}.snf"))
+        task.close()
+        if writer is not None:
+            out.vcf_records += sum(writer.write_call(c) for c in calls)
+        out.calls[task_id] = calls
+    if snf_out is not None:
+        out.snf_candidates = snf_out.write_results(config, [c for c, _ in contig_lengths])
+        snf_out.close()
+    return out

@@ -128,6 +128,10 @@ class SVCall:
         return (True, None) if var is None else (var < 0.3, float(var))
 
 
+_QC_SV_EARLY_EXIT = frozenset(("STDEV_POS", "STDEV_LEN", "SINGLE_BREAK", "SVLEN_MIN", "STRAND_BND", "COV_CHANGE_DEL",
+                               "COV_CHANGE_DUP", "COV_CHANGE_INS", "INLINE_SA"))
+
+
 def _ps(code, ti):
     if code == -1:
         return None
@@ -176,7 +180,12 @@ def fill_final(call, res: Result, i: int, ti):
     """Fields set by Task.finalize_candidates (parallel.py:129-201) from record i."""
     c = res.calls[i]
     call.qc, call.filter = bool(c["qc"]), FILTERS[int(c["filter"])]
-    call.info["COVERAGE_VAR"] = None  # qc_coverage_samples() always yields (True, None), postprocessing.py:373-374
+    # qc_sv sets info["COVERAGE_VAR"] = None (qc_coverage_samples() always yields (True, None), postprocessing.py:373-374)
+    # unless it left earlier through one of its own filters (postprocessing.py:209-371); no later stage uses those
+    # names, so the final filter tells which (residual: a GT_FAILED call hides an earlier exit - the key is then present
+    # where the reference may omit it; value None either way, `get_info` and the VCF writer do not distinguish).
+    if call.filter not in _QC_SV_EARLY_EXIT:
+        call.info["COVERAGE_VAR"] = None
     if c["ph_set"]:
         call.info["PHASE"] = (f"{int(c['ph_hp'])},{_ps(int(c['ph_ps']), ti)},{int(c['ph_hp_support'])},"
                               f"{int(c['ph_ps_support'])},{'PASS' if c['ph_hp_pass'] else 'FAIL'},"

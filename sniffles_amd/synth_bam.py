@@ -188,3 +188,87 @@ def gen_records(seed: int, n_reads: int, ref_names=("chrA", "chr10", "chr2", "ch
         recs.append((pos, make_record(contig_index, pos, mapq, flag, qname, ops, seq, b"".join(tags))))
     recs.sort(key=lambda t: t[0])
     return ref_names, ref_lens, [b for _, b in recs]
+
+
+def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(1_400_000, 16_000, 1_100_000), cov=20.0,
+               read_len_mean=12000, site_spacing=18000, err=0.03):
+    """A coherent synthetic sample: SV sites shared by the reads that cross them, so that clusters and calls form.
+
+    Per contig: INS / DEL sites every ~`site_spacing` bp (lengths 50 ... 3000, 40 % homozygous, the rest on one
+    haplotype), reads with uniform starts and exponential lengths on haplotype 1 or 2 (80 % carry HP / PS tags),
+    the site's allele in the CIGAR of every read that spans it on a carrying haplotype (length jitter 1.5 %, position
+    jitter 2 bp, inserted bases = the site's allele with `err` substitutions), 1-2 bp alignment noise in between,
+    occasional sub-threshold (45-49 bp) noise events, NM tags, MAPQ 60.  Coordinate-sorted like a BAM.
+    Returns (ref_names, ref_lens, [record bytes])."""
+    rng = np.random.default_rng(seed)
+    code = np.array([1, 2, 4, 8], np.uint8)
+    recs = []
+    for cid, (name, clen) in enumerate(zip(ref_names, ref_lens)):
+        sites = []
+        p = int(rng.integers(4000, site_spacing))
+        while p < clen - 6000:
+            ln = int(rng.choice([50 + int(rng.exponential(150)), int(rng.normal(320, 15)), int(rng.normal(2800, 60))], p=[0.7, 0.2, 0.1]))
+            ln = max(50, ln)
+            ins = bool(rng.integers(2))
+            sites.append(dict(pos=p, ln=ln, ins=ins, hap=0 if rng.random() < 0.4 else int(rng.integers(1, 3)),
+                              allele=rng.integers(0, 4, ln if ins else 0)))
+            p += ln + int(rng.integers(site_spacing // 2, site_spacing * 3 // 2))
+        n_reads = int(cov * clen / read_len_mean)
+        for r in range(n_reads):
+            span = int(max(1500, min(clen // 3, rng.exponential(read_len_mean))))
+            pos = int(rng.integers(0, max(1, clen - span)))
+            hap = int(rng.integers(1, 3))
+            rev = bool(rng.integers(2))
+            ops, seq_parts, nm = [], [], 0
+            cur, end = pos, min(clen, pos + span)
+
+            def aligned(upto):
+                nonlocal cur, nm
+                while cur < upto:
+                    run = int(min(upto - cur, max(1, rng.exponential(250))))
+                    ops.append((M, run)); seq_parts.append(rng.integers(0, 4, run)); cur += run
+                    if cur < upto and rng.random() < 0.7:
+                        k = int(rng.integers(1, 3))
+                        if rng.random() < 0.5:
+                            ops.append((I, k)); seq_parts.append(rng.integers(0, 4, k))
+                        elif cur + k < upto:
+                            ops.append((D, k)); cur += k
+                        nm += k
+            for s in sites:
+                if s["pos"] <= pos + 300 or s["pos"] + (0 if s["ins"] else s["ln"]) >= end - 300:
+                    continue
+                if s["hap"] not in (0, hap):
+                    continue
+                at = s["pos"] + int(round(rng.normal(0, 2)))
+                if at <= cur + 10:
+                    continue
+                aligned(at)
+                ln = max(45, int(round(s["ln"] * (1 + rng.normal(0, 0.015)))))
+                if s["ins"]:
+                    a = np.resize(s["allele"], ln).copy()
+                    flip = rng.random(ln) < err
+                    a[flip] = rng.integers(0, 4, int(flip.sum()))
+                    ops.append((I, ln)); seq_parts.append(a)
+                else:
+                    ops.append((D, ln)); cur += ln
+                nm += ln
+                ops.append((M, 40)); seq_parts.append(rng.integers(0, 4, 40)); cur += 40
+            if rng.random() < 0.05 and end - cur > 2000:        # a sub-threshold noise event
+                aligned(cur + int(rng.integers(500, 1500)))
+                k = int(rng.integers(45, 50))
+                ops.append((D, k)); cur += k; nm += k
+                ops.append((M, 30)); seq_parts.append(rng.integers(0, 4, 30)); cur += 30
+            aligned(max(end, cur + 50))
+            merged = []
+            for op, ln in ops:                                    # adjacent M runs are one operation
+                if merged and merged[-1][0] == op == M:
+                    merged[-1] = (M, merged[-1][1] + ln)
+                else:
+                    merged.append((op, ln))
+            seq = code[np.concatenate(seq_parts)]
+            tags = [_int_tag("NM", nm + int(rng.integers(0, span // 60)), rng)]
+            if rng.random() < 0.8:
+                tags += [_int_tag("HP", hap, rng), _int_tag("PS", 1000 * (cid + 1) + 7, rng)]
+            recs.append((cid, pos, make_record(cid, pos, 60, 0x10 if rev else 0, f"s{seed}_{name}_{r}", merged, seq, b"".join(tags))))
+    recs.sort(key=lambda t: (t[0], t[1]))
+    return list(ref_names), list(ref_lens), [b for _, _, b in recs]

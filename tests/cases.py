@@ -427,3 +427,17 @@ def extract_records(case):
             return bam.parse_bam(f.read())
     names, lens, recs = synth_bam.gen_records(**case["gen"])
     return bam.records_from_list(names, lens, recs)
+
+
+# ---------------------------------------------------------------------------------------------- whole samples (BAM -> VCF / SNF)
+def _sample(seed, **kw):
+    from sniffles_amd import bam, synth_bam
+    names, lens, recs = synth_bam.gen_sample(seed, **kw)
+    return bam.records_from_list(names, lens, recs)
+
+
+SAMPLES = {
+    # two contigs above the 1-Mb cut of should_process_contig and one below it (skipped by the reference)
+    "sample_two_contigs_12x": (lambda: _sample(5, ref_lens=(1_200_000, 16_000, 1_050_000), cov=12.0), ()),
+    "sample_mosaic_20x": (lambda: _sample(6, ref_names=("chr7",), ref_lens=(1_000_001,), cov=20.0), ("--mosaic",)),
+}

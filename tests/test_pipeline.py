@@ -1,0 +1,90 @@
+"""End to end (BASELINE.json configs[0] shape: one sample, BAM in, VCF / SNF out): a synthetic coordinate-sorted BAM
+through sniffles_amd.pipeline.call_sample - extraction, clustering, calling, QC, genotyping, consensus on the device,
+VCF / SNF written by this package - against what the UNMODIFIED reference's call_sample flow produces from the same BAM
+(tests/golden/sample_*.json.gz, oracle/ref_harness.py::run_reference_call_sample): the VCF text character by character,
+the SNF content field by field.  CPU tier: kernels through the host emulation; GPU tier: the real library."""
+import io
+import json
+
+import pytest
+
+import cases
+import golden_util as gu
+import snf_util as su
+import vcf_util as vu
+from sniffles_amd import bam, pipeline, snf, sv
+from sniffles_amd.config import SnifflesConfig
+from test_vcf import assert_same_text
+
+
+def records_sha(recs):
+    import hashlib
+    h = hashlib.sha256()
+    h.update(recs.blob.tobytes())
+    h.update(recs.rec_off.tobytes())
+    h.update(repr((recs.ref_names, recs.ref_lens)).encode())
+    return h.hexdigest()
+
+
+def config_for(args):
+    cfg = SnifflesConfig(**{a[2:].replace("-", "_"): True for a in args})
+    for k, v in vu.FIXED.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def run_sample(name, tmp_path, _lib, through_file):
+    build, args = cases.SAMPLES[name]
+    doc = gu.load(name)
+    recs = build()
+    assert records_sha(recs) == doc["input_sha"]
+    if through_file:      # the container layer too: BGZF blocks on disk -> inflate -> record table
+        path = tmp_path / "sample.bam"
+        offs = recs.rec_off.tolist()
+        raw = bam.bam_stream(recs.ref_names, recs.ref_lens, [recs.blob[a:b].tobytes() for a, b in zip(offs[:-1], offs[1:])])
+        path.write_bytes(bam.bgzf_deflate(raw))
+        recs = bam.read_bam(str(path))
+        assert records_sha(recs) == doc["input_sha"]
+    # VCF only
+    buf = io.StringIO()
+    res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, _lib=_lib)
+    assert res.read_count == doc["read_count"]
+    assert_same_text(buf.getvalue(), doc["vcf"])
+    assert res.vcf_records == len(vu.split_text(doc["vcf"])[1])
+    # VCF + SNF (the candidates are not QC-filtered then)
+    buf = io.StringIO()
+    cfg = config_for(args)
+    snf_path = str(tmp_path / "sample.snf")
+    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=snf_path, _lib=_lib)
+    assert_same_text(buf.getvalue(), doc["vcf_with_snf"])
+    assert res.snf_candidates == doc["snf_candidates"]
+    f = snf.SNFile.open(snf_path, cfg)
+    got = {c: json.loads(json.dumps(su.file_record(f, c, sv.TYPES), sort_keys=True)) for c, _ in res.contig_lengths}
+    f.close()
+    assert sorted(got) == sorted(doc["snf"])
+    for c in got:
+        assert sorted(got[c]["blocks"]) == sorted(doc["snf"][c]["blocks"])
+        for b in got[c]["blocks"]:
+            assert got[c]["blocks"][b] == doc["snf"][c]["blocks"][b], (c, b)
+        assert got[c] == doc["snf"][c]
+
+
+@pytest.mark.parametrize("name", sorted(cases.SAMPLES))
+def test_bam_to_vcf_and_snf_emu(name, tmp_path):
+    import emu.emu as E
+    run_sample(name, tmp_path, E.lib(), through_file=(name == "sample_mosaic_20x"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(cases.SAMPLES))
+def test_bam_to_vcf_and_snf_gpu(name, tmp_path):
+    run_sample(name, tmp_path, None, through_file=True)
+
+
+def test_contig_selection_rule():
+    cfg = SnifflesConfig()
+    assert pipeline.should_process_contig("chr1", 2_000_000, cfg) and not pipeline.should_process_contig("chrUn", 999_999, cfg)
+    cfg.all_contigs = True
+    assert pipeline.should_process_contig("chrUn", 10, cfg)
+    cfg.all_contigs, cfg.contig = False, ["chrUn"]
+    assert pipeline.should_process_contig("chrUn", 10, cfg) and not pipeline.should_process_contig("chr1", 2_000_000, cfg)
