@@ -26,10 +26,11 @@ def main():
     ap.add_argument("--tile", type=int, default=8)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu-reads", type=int, default=150)
+    ap.add_argument("--sa-frac", type=float, default=0.2)
     a = ap.parse_args()
     from sniffles_amd import bam, extract, synth_bam
     t0 = time.time()
-    names, lens, recs = synth_bam.gen_records(2026, a.reads, style="ont", read_len_mean=20000, sa_frac=0.2,
+    names, lens, recs = synth_bam.gen_records(2026, a.reads, style="ont", read_len_mean=20000, sa_frac=a.sa_frac,
                                               ref_lens=(60_000_000, 300000, 300000, 100000))
     gen_s = time.time() - t0
     R = bam.records_from_list(names, lens, recs * a.tile)
@@ -51,6 +52,7 @@ def main():
     ms_c, ms_e = float(np.median(cnt)), float(np.median(emt))
     peak = 8000.0
     out = dict(
+        sa_frac=a.sa_frac,
         workload=f"{R.n} synthetic ONT-like alignment records ({a.reads} distinct x {a.tile}), {n_cig} CIGAR operations, "
                  f"{R.blob.nbytes / 1e6:.0f} MB of inflated BAM records in HBM",
         records=R.n, reads_accepted=info.read_count, signatures=ti.n_leads, seq_pool_bytes=int(ti.seq_pool.shape[0]),
