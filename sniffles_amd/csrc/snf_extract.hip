@@ -10,7 +10,7 @@
 //   build_leadtab     leadprov.py:445-472   keep the leads of this contig inside [start, end)
 // pysam properties are computed from the record bytes (SAM/BAM spec 4.2; htslib bam_endpos, pysam getQueryStart/End).
 //
-// Mapping: one WAVE per alignment record.  The CIGAR (4 B per operation, thousands of operations per long read) is
+// Mapping: one WAVE (and one workgroup) per alignment record.  The CIGAR (4 B per operation, thousands of operations per long read) is
 // walked 256 operations per step (4 per lane, next step prefetched): two DPP wave prefix sums give every lane the read /
 // reference position of its operations, a third ranks the signature-bearing operations so leads come out in CIGAR order.
 // Inserted sequence is decoded from the 4-bit packed read by the whole wave.  Tag strings are scanned 64 bytes per
@@ -698,14 +698,16 @@ SNF_KERNEL(x_emit, ExView)
 SNF_KERNEL(x_prep, ExView)
 
 #ifndef SNF_EMU
-// one wave per record, 4 records per workgroup; grid-stride so that any record count fits one launch
+// one wave per record and ONE wave per workgroup: a record with split alignments keeps its wave several times longer
+// than a plain one (lane-0 section), and in a four-wave workgroup the three finished waves' slots stayed taken until the
+// slow one was done - with SA tags on 20 % of the records most workgroups had one.  Grid-stride so that any record count
+// fits one launch.
 template <bool EMIT>
-__global__ void __launch_bounds__(256) x_wave(const ExView v, int64_t n) {
-  __shared__ Seg segs[4][XMAXSEG];
-  __shared__ uint8_t ord[4][XMAXSEG];
-  const int w = threadIdx.x >> 6;
-  for (int64_t rec = (int64_t)blockIdx.x * 4 + w; rec < n; rec += (int64_t)gridDim.x * 4)
-    extract_record<true, EMIT>(rec, v, segs[w], ord[w]);
+__global__ void __launch_bounds__(64) x_wave(const ExView v, int64_t n) {
+  __shared__ Seg segs[XMAXSEG];
+  __shared__ uint8_t ord[XMAXSEG];
+  for (int64_t rec = (int64_t)blockIdx.x; rec < n; rec += (int64_t)gridDim.x)
+    extract_record<true, EMIT>(rec, v, segs, ord);
 }
 // average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64
 // adds.  One wave: 64 records are loaded per step (coalesced), records without an NM ratio contribute +0.0 (the sum
@@ -873,12 +875,12 @@ int do_run(snf_extract* x) {
   const bool thread_form = getenv("SNF_EXTRACT_THREAD") != nullptr;
   hipEvent_t e0, e1, e2, e3;
   SNF_HIP(hipEventCreate(&e0)); SNF_HIP(hipEventCreate(&e1)); SNF_HIP(hipEventCreate(&e2)); SNF_HIP(hipEventCreate(&e3));
-  const unsigned grid_w = (unsigned)std::min<int64_t>((n + 3) / 4 > 0 ? (n + 3) / 4 : 1, 1 << 20);
+  const unsigned grid_w = (unsigned)std::min<int64_t>(n > 0 ? n : 1, 1 << 22);
   SNF_HIP(hipMemset(v.sum, 0, (size_t)(n ? n : 1) * sizeof(RecSum)));
   SNF_HIP(hipEventRecord(e0, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
-    else hipLaunchKernelGGL(x_wave<false>, dim3(grid_w), dim3(256), 0, 0, v, n);
+    else hipLaunchKernelGGL(x_wave<false>, dim3(grid_w), dim3(64), 0, 0, v, n);
   }
   SNF_HIP(hipEventRecord(e1, 0));
   hipLaunchKernelGGL(x_prep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, v, n + 1);
@@ -927,7 +929,7 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipEventRecord(e2, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
-    else hipLaunchKernelGGL(x_wave<true>, dim3(grid_w), dim3(256), 0, 0, v, n);
+    else hipLaunchKernelGGL(x_wave<true>, dim3(grid_w), dim3(64), 0, 0, v, n);
   }
   SNF_HIP(hipEventRecord(e3, 0));
   SNF_HIP(hipStreamSynchronize(x->side));
