@@ -133,6 +133,7 @@ struct snf_batch_impl {
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
+  int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end
@@ -894,7 +895,8 @@ void run_finalize(snf_batch_impl* b) {
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
         const dim3 gs((unsigned)(n_small < 16384 ? n_small : 16384));
-        if (b->occ_s >= 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        if (b->cons_nw == 1) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5, 1>), dim3((unsigned)(n_small < 65536 ? n_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
+        else if (b->occ_s >= 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError());
@@ -1189,6 +1191,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
+    if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());

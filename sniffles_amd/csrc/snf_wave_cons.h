@@ -25,7 +25,7 @@ namespace snf {
 
 #define SNF_KEY_EMPTY (~0ull)
 
-template <int SLOTS, int MAXPOS, int MAXOTHERS>
+template <int SLOTS, int MAXPOS, int MAXOTHERS, int NW>
 struct ConsLdsT {
   unsigned long long key[SLOTS];
   uint32_t pc[SLOTS];              // (position << 16) | occurrence count
@@ -36,7 +36,7 @@ struct ConsLdsT {
     uint16_t seg_len[MAXPOS];      // clipped advance (columns written)
     uint16_t seg_cm[MAXPOS];       // matches of the copied slice against best at its columns
     uint8_t seg_flag[MAXPOS];      // 0 dashes, 1 copy
-  } w[4];
+  } w[NW];
 };
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
@@ -68,9 +68,12 @@ SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
 }
 
 // CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
-template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW>
-__global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_t n_unused) {
-  typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS> Lds;
+// NW: waves per workgroup (= per call).  4: the reads of a call are spread over four waves; 1: a call is one wave's work
+// (no workgroup barriers, no waves idling while the wave with one read more finishes, four times as many calls in flight)
+template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, int64_t n_unused) {
+  typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS, NW> Lds;
+  constexpr int NT = 64 * NW;
   __shared__ Lds lds;
   constexpr int ROUNDS = MAXPOS / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPRs
@@ -97,10 +100,10 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     const int skip = __builtin_amdgcn_readfirstlane(d.skip);
     __syncthreads();
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
-    for (int s = tid; s < SLOTS; s += 256) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
+    for (int s = tid; s < SLOTS; s += NT) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
     __syncthreads();
     const int npos = (int)cons_npos(L, klen, skip);
-    for (int p = tid; p < npos; p += 256) {
+    for (int p = tid; p < npos; p += NT) {
       const int i = p * skip;
       const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
       int64_t sl = kmer_slot(kk, SLOTS);
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     typename Lds::Wave& W = lds.w[wid];
     const int64_t r0 = rfl64(d.read_off);
     uint8_t* rows = v.aln + rfl64(d.aln_off);
-    for (int32_t r = wid; r < n_others; r += 4) {
+    for (int32_t r = wid; r < n_others; r += NW) {
       const uint8_t* S = v.pool + rfl64(v.crl_off[r0 + r]);
       const int SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
       uint8_t* row = rows + (int64_t)r * L;
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(256, MINW) e45w_consensus(const View v, int64_
     for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
     nkept = __builtin_amdgcn_readfirstlane(nkept);
     const double maxal = (double)(1 + nkept);
-    for (int q = tid; q < L; q += 256) {
+    for (int q = tid; q < L; q += NT) {
       const uint8_t bq = B[q];
       uint8_t out = bq;
       {  // fast path: every character of the column is one of A C G T -> four packed 16-bit counters, one pass
