@@ -181,6 +181,70 @@ def combine_problem(svtype_code: int, cands: dict, groups: dict, n_sample_ids: i
     return q, out
 
 
+# numpy mirror of snf_combine_problem_t (pointers as addresses) for packing many problems without per-problem ctypes work
+COMBINE_PROBLEM_DTYPE = np.dtype(
+    [("svtype", np.int32), ("n_cands", np.int32), ("n_groups", np.int32), ("n_sample_ids", np.int32)] +
+    [(n, np.uint64) for n in ("pos", "svlen", "support", "sample_id", "mate_contig", "mate_ref_start", "alt_off", "alt_pool",
+                              "g_pos_mean", "g_len_mean", "g_mate_mean", "g_size", "g_mate_contig", "g_alt_off", "g_alt_pool",
+                              "g_samples_off", "g_samples", "out_group")] +
+    [("n_windows", np.int32), ("win_off", np.uint64), ("win_bin", np.uint64), ("win_thr", np.uint64)], align=True)
+assert COMBINE_PROBLEM_DTYPE.itemsize == C.sizeof(snf_combine_problem_t)
+assert all(COMBINE_PROBLEM_DTYPE.fields[n][1] == getattr(snf_combine_problem_t, n).offset for n, _ in snf_combine_problem_t._fields_)
+
+
+def combine_chain_problems(svtype_codes, cand_lo, cand_hi, win_lo, win_hi, cols: dict, alts: list, win_off, win_bin, win_thr,
+                           n_sample_ids: int, keep: list):
+    """Pack P sub-chains (no initial groups) that are contiguous slices of shared candidate / window tables.
+
+    svtype_codes, cand_lo, cand_hi, win_lo, win_hi: per sub-chain - its SV type, candidate range [lo, hi) in the shared
+    columns `cols` (pos, svlen, support, sample_id, mate_contig, mate_ref_start: int sequences over ALL candidates) and
+    `alts` (bytes per candidate), window range [lo, hi) in win_bin / win_thr; `win_off[w]` = first candidate of window w in
+    the shared numbering, plus one padding entry at the end of the table.  Every struct points into
+    the shared arrays, so the cost per sub-chain is a row of a numpy table.  Returns (ctypes struct array, out_group array)."""
+    n_p = len(svtype_codes)
+    n_c = len(alts)
+    a32 = {k: np.ascontiguousarray(np.asarray(v, np.int32).reshape(-1)) if n_c else np.zeros(1, np.int32) for k, v in cols.items()}
+    aoff = np.zeros(n_c + 1, np.int64)
+    if n_c:
+        np.cumsum(np.fromiter((len(a) for a in alts), np.int64, n_c), out=aoff[1:])
+    pool = np.frombuffer(b"".join(alts) + b"\0", np.uint8).copy()
+    out = np.full(max(n_c, 1), -1, np.int32)
+    cand_lo, cand_hi = np.asarray(cand_lo, np.int64), np.asarray(cand_hi, np.int64)
+    win_lo, win_hi = np.asarray(win_lo, np.int64), np.asarray(win_hi, np.int64)
+    # window offsets relative to the sub-chain's first candidate: nw + 1 entries per sub-chain
+    nw = win_hi - win_lo
+    wstart = np.zeros(n_p + 1, np.int64)
+    np.cumsum(nw + 1, out=wstart[1:])
+    idx = np.arange(int(wstart[-1]), dtype=np.int64) - np.repeat(wstart[:-1], nw + 1) + np.repeat(win_lo, nw + 1)
+    woff_all = np.asarray(win_off, np.int64)
+    rel = (woff_all[idx] - np.repeat(cand_lo, nw + 1)).astype(np.int32)
+    # the closing entry of a sub-chain is its candidate count
+    rel[wstart[1:] - 1] = (cand_hi - cand_lo).astype(np.int32)
+    wbin = np.ascontiguousarray(np.asarray(win_bin, np.int32).reshape(-1)) if len(win_bin) else np.zeros(1, np.int32)
+    wthr = np.ascontiguousarray(np.asarray(win_thr, np.float64).reshape(-1)) if len(win_thr) else np.zeros(1, np.float64)
+    dz, iz, lz = np.zeros(1, np.float64), np.zeros(1, np.int32), np.zeros(2, np.int64)
+    rec = np.zeros(n_p, COMBINE_PROBLEM_DTYPE)
+    rec["svtype"] = np.asarray(svtype_codes, np.int32)
+    rec["n_cands"] = (cand_hi - cand_lo).astype(np.int32)
+    rec["n_sample_ids"] = max(1, int(n_sample_ids))
+    for k in ("pos", "svlen", "support", "sample_id", "mate_contig", "mate_ref_start"):
+        rec[k] = a32[k].ctypes.data + 4 * cand_lo.astype(np.uint64)
+    rec["alt_off"] = aoff.ctypes.data + 8 * cand_lo.astype(np.uint64)      # absolute offsets into the shared pool
+    rec["alt_pool"] = pool.ctypes.data
+    for k in ("g_pos_mean", "g_len_mean", "g_mate_mean"):
+        rec[k] = dz.ctypes.data
+    rec["g_size"] = rec["g_mate_contig"] = rec["g_samples"] = iz.ctypes.data
+    rec["g_alt_off"] = rec["g_samples_off"] = lz.ctypes.data
+    rec["g_alt_pool"] = pool.ctypes.data
+    rec["out_group"] = out.ctypes.data + 4 * cand_lo.astype(np.uint64)
+    rec["n_windows"] = nw.astype(np.int32)
+    rec["win_off"] = rel.ctypes.data + 4 * wstart[:-1].astype(np.uint64)
+    rec["win_bin"] = wbin.ctypes.data + 4 * win_lo.astype(np.uint64)
+    rec["win_thr"] = wthr.ctypes.data + 8 * win_lo.astype(np.uint64)
+    keep.extend([a32, aoff, pool, out, rel, wbin, wthr, dz, iz, lz, rec])
+    return (snf_combine_problem_t * n_p).from_buffer(rec), out
+
+
 def config_struct(cfg) -> snf_config_t:
     """Build snf_config_t from a SnifflesConfig-compatible namespace (reference config.py:103-619)."""
     s = snf_config_t()

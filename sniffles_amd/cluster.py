@@ -104,32 +104,58 @@ def resolve_chains_batch(chains, config, device: int = 0, _lib=None, cut: bool =
     abs(pos_mean - win_bin[w]) < win_thr[w] stay active for window w+1 (CombineTask.execute, parallel.py:553-556).
     Returns per chain the group number of every candidate (new groups numbered in creation order over the chain).
     Chains are cut where no candidate can reach an earlier group (`chain_cuts`; SNF_COMBINE_NO_CUT=1 / cut=False keeps
-    them whole): every sub-chain is one work item of the kernel, the group numbers are made chain-wide here."""
+    them whole): every sub-chain is one work item of the kernel, the group numbers are made chain-wide here.
+    A whole-genome merge is tens of thousands of sub-chains, so they are packed as rows of one table over shared
+    candidate columns (`abi.combine_chain_problems`), not as one ctypes structure each."""
     import os
 
     import numpy as np
     if cut is None:
         cut = os.environ.get("SNF_COMBINE_NO_CUT", "0") != "1"
-    keep, packed, layout = [], [], []
-    for svtype, svcands, win_off, win_bin, win_thr in chains:
+    cols = {k: [] for k in ("pos", "svlen", "support", "sample_id", "mate_contig", "mate_ref_start")}
+    alts, wstart, wbin, wthr = [], [], [], []
+    codes, c_lo, c_hi, w_lo, w_hi, chain_of = [], [], [], [], [], []
+    span = []                                    # per chain: its candidate range in the shared numbering
+    for ci, (svtype, svcands, win_off, win_bin, win_thr) in enumerate(chains):
+        c0, w0 = len(alts), len(wbin)
+        bnd = svtype == "BND"
+        cols["pos"].extend(c.pos for c in svcands)
+        cols["svlen"].extend(c.svlen for c in svcands)
+        cols["support"].extend(c.support for c in svcands)
+        cols["sample_id"].extend(c.sample_internal_id for c in svcands)
+        if bnd:
+            ids = {}
+            cols["mate_contig"].extend(ids.setdefault(c.bnd_info.mate_contig, len(ids)) for c in svcands)
+            cols["mate_ref_start"].extend(c.bnd_info.mate_ref_start for c in svcands)
+        else:
+            cols["mate_contig"].extend([0] * len(svcands))
+            cols["mate_ref_start"].extend([0] * len(svcands))
+        alts.extend(_alt_bytes(c.alt) for c in svcands)
+        wstart.extend(c0 + o for o in win_off[:-1])
+        wbin.extend(win_bin)
+        wthr.extend(win_thr)
+        span.append((c0, len(alts)))
         cuts = chain_cuts(svtype, svcands, win_off, config) if cut and len(win_bin) else [0, len(win_bin)]
-        parts = []
         for a, b in zip(cuts[:-1], cuts[1:]):
-            c0, c1 = win_off[a], win_off[b]
-            q, out = pack_problem(svtype, svcands[c0:c1], [], keep,
-                                  ([o - c0 for o in win_off[a:b + 1]], win_bin[a:b], win_thr[a:b]))
-            packed.append(q)
-            parts.append(out[:c1 - c0])
-        layout.append((len(svcands), parts))
-    if packed:
-        lib.combine_resolve_batch(config, packed, device=device, _lib=_lib)
-    outs = []
-    for n, parts in layout:
-        base = 0
-        for out in parts:
-            if out.shape[0]:
-                created = int(out.max()) + 1
-                out += base
-                base += created
-        outs.append(np.concatenate(parts) if parts else np.full(max(n, 1), -1, np.int32))
-    return outs
+            if b > a:
+                codes.append(SVT[svtype]); chain_of.append(ci)
+                c_lo.append(c0 + win_off[a]); c_hi.append(c0 + win_off[b]); w_lo.append(w0 + a); w_hi.append(w0 + b)
+    n_c = len(alts)
+    if not codes:
+        return [np.full(max(hi - lo, 1), -1, np.int32) for lo, hi in span]
+    keep = []
+    n_ids = max(cols["sample_id"]) + 1 if n_c else 1
+    arr, out = abi.combine_chain_problems(codes, c_lo, c_hi, w_lo, w_hi, cols, alts, wstart + [n_c], wbin, wthr, n_ids, keep)
+    lib.combine_resolve_batch(config, arr, device=device, _lib=_lib)
+    # chain-wide group numbers: sub-chain s of a chain starts after the groups its predecessors created
+    lo, hi = np.asarray(c_lo, np.int64), np.asarray(c_hi, np.int64)
+    created = np.array([int(out[a:b].max()) + 1 if b > a else 0 for a, b in zip(c_lo, c_hi)], np.int64)
+    ch = np.asarray(chain_of, np.int64)
+    cum = np.cumsum(created) - created                                # exclusive over all sub-chains ...
+    first = np.r_[True, ch[1:] != ch[:-1]]
+    base = cum - np.maximum.accumulate(np.where(first, cum, 0))       # ... relative to the chain's first sub-chain
+    delta = np.zeros(n_c + 1, np.int64)                               # sub-chains are disjoint candidate ranges
+    np.add.at(delta, lo, base)
+    np.add.at(delta, hi, -base)
+    out[:n_c] += np.cumsum(delta[:n_c]).astype(np.int32)
+    return [out[a:b] if b > a else np.full(1, -1, np.int32) for a, b in span]

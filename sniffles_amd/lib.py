@@ -187,9 +187,9 @@ def edit_distance_batch(pairs, device: int = 0, _lib=None) -> np.ndarray:
 def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
     """Run a list of packed resolve_block_groups problems (abi.combine_problem structs); fills their out_group arrays."""
     lib = _lib or load()
-    if not problems:
+    if not len(problems):
         return
-    arr = (abi.snf_combine_problem_t * len(problems))(*problems)
+    arr = problems if isinstance(problems, C.Array) else (abi.snf_combine_problem_t * len(problems))(*problems)
     cs = abi.config_struct(cfg)
     rc = lib.snf_combine_resolve_batch(C.byref(cs), device, arr, len(problems))
     if rc != 0:

@@ -9,7 +9,8 @@
     on average), GPU windows/s against the oracle's serial resolve on the same windows.
 Prints one JSON line.
 """
-import json, os, sys, time
+import json
+import os, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -78,7 +79,7 @@ def main():
     keep2 = []; packed = [cluster.pack_problem(svt, c, [], keep2) for svt, c, _ in windows]
     t0 = time.perf_counter(); lib.combine_resolve_batch(cfg, [q for q, _ in packed]); t_call = time.perf_counter() - t0
     # parity of a sample of the windows against the oracle's serial resolve (same packed problems)
-    keep = []; n_chk = 150; t_or = 0.0
+    keep = []; n_chk = int(os.environ.get("SNF_BENCH_ORACLE_WINDOWS", "150")); t_or = 0.0
     for svt, cands, _ in windows[:n_chk]:
         q, out_gpu = cluster.pack_problem(svt, cands, [], keep)
         lib.combine_resolve_batch(cfg, [q])
