@@ -326,6 +326,17 @@ int snf_batch_export_calls_device(snf_batch_t* b, void* dst_device, int64_t cap_
 int snf_batch_block_coverage(snf_batch_t* b, int32_t task_index, int32_t binsize, int64_t first_bin,
                              int64_t n_bins, int32_t* out);
 
+/* replaces postprocessing.coverage(calls, lead_provider) (src/sniffles/postprocessing.py:69-130) for calls that are
+ * not the batch's own candidates: the target SVs of GenotypeTask.execute (src/sniffles/parallel.py:353).
+ * svtype: SNF_* codes (anything but INS / BND takes end = pos + |svlen|); cov: 5 ints per call, in/out
+ * (upstream, start, center, end, downstream) - a sample outside the coverage vector keeps its input value (the
+ * reference ignores the IndexError).  *status = 1 when a BND comes before any other call (UnboundLocalError in
+ * the reference: the calls from there on are left untouched).  *coverage_mean = coverage.mean() of the task.
+ * Needs snf_batch_call_candidates first. */
+int snf_batch_coverage_calls(snf_batch_t* b, int32_t task_index, int64_t n, const int32_t* svtype, const int32_t* pos,
+                             const int32_t* svlen, const uint8_t* bnd_is_first, int32_t* cov, int32_t* status,
+                             double* coverage_mean);
+
 /* per-kernel timing (HIP events on the batch stream, recorded around every launch of the
  * last call_candidates+finalize pass). names[i] points to a static string. */
 int snf_batch_timing_count(snf_batch_t* b);

@@ -70,10 +70,6 @@ def main_combine(names=None):
               f"{sum(len(p['groups']) for p in ref['problems'])} groups  {sum(len(c['calls']) for c in ref['calls'])} calls")
 
 
-if __name__ == "__main__":
-    sel = set(sys.argv[1:])
-    main(sel)
-    main_combine(sel)
 
 
 def main_consensus():
@@ -296,3 +292,49 @@ def main_sample():
             fh.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
         print(f"{name:24s} {recs.n} records, {plain['read_count']} reads accepted -> {len(vu.split_text(plain['vcf'])[1])} VCF records, "
               f"{with_snf['snf_candidates']} SNF candidates")
+
+
+def main_genotype():
+    """Force calling: the reference's GenotypeTask.execute on cases of cases.ALL with targets derived from the case's own
+    candidate records (tests/genotype_util.py)."""
+    import cases
+    import genotype_util as gutil
+    import ref_harness as rh
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    doc = {}
+    for i, name in enumerate(gutil.CASES):
+        build, kw, args = cases.ALL[name]
+        ti = build()
+        with gzip.open(os.path.join(out_dir, name + ".json.gz"), "rb") as f:
+            cands = json.loads(f.read().decode())["expected"]["candidates"]
+        specs = gutil.target_specs(cands, ti.contig_len, 700 + i)
+        doc[name] = dict(input_sha=input_sha(ti), specs=specs, expected=rh.run_reference_genotype(ti, specs, args))
+        exp = doc[name]["expected"]
+        print(f"{name:24s} {len(specs)} targets", "error " + exp["error"] if "error" in exp else
+              f"{sum(1 for t in exp['targets'] if t['match'])} matched")
+    # the reference's own failure: a BND target before any other one
+    build, kw, args = cases.ALL["bnd_stale_end"]
+    ti = build()
+    specs = [dict(id="T0", svtype="BND", pos=1000, svlen=0, bnd=["chr2", 5, True, False], cov=[0] * 5),
+             dict(id="T1", svtype="DEL", pos=2000, svlen=-100, bnd=None, cov=[0] * 5)]
+    doc["bnd_first"] = dict(input_sha=input_sha(ti), specs=specs, expected=rh.run_reference_genotype(ti, specs, args), case="bnd_stale_end")
+    print("bnd_first", doc["bnd_first"]["expected"])
+    with gzip.GzipFile(os.path.join(out_dir, "genotype_targets.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
+if __name__ == "__main__":
+    # python oracle/make_golden.py                 -> every fixture family
+    # python oracle/make_golden.py vcf sample      -> only these families
+    # python oracle/make_golden.py main fuzz_4_2   -> single cases of the `main` / `combine` families
+    FAMILIES = dict(main=main, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
+                    bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype)
+    argv = sys.argv[1:]
+    fams = [a for a in argv if a in FAMILIES] or list(FAMILIES)
+    names = set(a for a in argv if a not in FAMILIES)
+    for fam in fams:
+        fn = FAMILIES[fam]
+        if fam in ("main", "combine", "combine_task", "extract"):
+            fn(names or None)
+        else:
+            fn()

@@ -480,6 +480,33 @@ def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
     return dict(vcf=buf.getvalue(), read_count=int(read_count), snf_candidates=int(n_snf), contig_lengths=contig_lengths)
 
 
+# ---------------------------------------------------------------------------------------------- force calling
+def run_reference_genotype(ti, specs, extra_args=()):
+    """The UNMODIFIED reference GenotypeTask.execute (parallel.py:299-372) on one task with the target SVs `specs`
+    (tests/genotype_util.py); build_leadtab is replaced by the prepared LeadProvider.  Returns the per-target records
+    (matched candidate id, distance, coverage samples, genotype) or dict(error=...)."""
+    import genotype_util as gutil
+    ref = load_reference()
+    cfg = make_config(tuple(extra_args), ti.qc_nm_threshold)
+    base = build_task(ti, cfg)
+
+    def new_call(cls):
+        return cls(contig=None, pos=0, id="", ref="N", alt="", qual=0, filter="PASS", info=dict(), svtype="", svlen=0, end=0,
+                   genotypes=dict(), precise=False, support=0, rnames=None, qc=True, nm=-1, postprocess=None)
+    targets = gutil.make_targets(specs, ref.sv.SVCall, ref.sv.SVCallBNDInfo, new_call)
+    task = ref.parallel.GenotypeTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                                     genotype_svs=targets)
+    task.lead_provider, task.tandem_repeats = base.lead_provider, base.tandem_repeats
+    task.build_leadtab = lambda: (None, 0)
+    try:
+        res = task.execute()
+    except Exception as e:
+        return dict(error=type(e).__name__)
+    if res is None:
+        return dict(returned_none=True)
+    return dict(targets=gutil.result_records(res.svcalls))
+
+
 # ---------------------------------------------------------------------------------------------- signature extraction
 def lead_record(ld) -> list:
     """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""

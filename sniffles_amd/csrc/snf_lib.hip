@@ -50,6 +50,8 @@ SNF_KERNEL(e5_align, View)
 SNF_KERNEL(e6_vote, View)
 SNF_KERNEL(z1_results, View)
 SNF_KERNEL(s1_blockcov, BlockCov)
+SNF_KERNEL(s2_covends, CovCalls)
+SNF_KERNEL(s2_covcalls, CovCalls)
 
 // read preparation (coverage rank structures + REF haplotype prefix counts)
 struct ReadPrep {
@@ -1119,6 +1121,43 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- C ABI
+void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int32_t* svtype, const int32_t* pos,
+                       const int32_t* svlen, const uint8_t* bnd_is_first, int32_t* cov, int32_t* status, double* coverage_mean) {
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !status || !coverage_mean) fail("batch not uploaded / null argument");
+    if (!b->reads_ready) fail("snf_batch_coverage_calls needs snf_batch_call_candidates first (it sorts the read ends)");
+    if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
+    if (n < 0 || (n > 0 && (!svtype || !pos || !svlen || !bnd_is_first || !cov))) fail("invalid call arrays");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    full_sync(b);
+    *status = 0;
+    d2h(b, coverage_mean, b->v.t_cov_avg + task_index, sizeof(double));
+    dsync(b);
+    if (n == 0) return;
+    CovCalls q{};
+    q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
+    q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
+    q.L = b->tasks[(size_t)task_index].contig_len; q.n = n;
+    q.binsize = b->cfg.coverage_binsize; q.updown = b->cfg.coverage_updown_bins;
+    int32_t* d_t = dalloc<int32_t>(b, (size_t)n); int32_t* d_p = dalloc<int32_t>(b, (size_t)n); int32_t* d_l = dalloc<int32_t>(b, (size_t)n);
+    uint8_t* d_f = dalloc<uint8_t>(b, (size_t)n);
+    q.end = dalloc<int64_t>(b, (size_t)n); q.cov = dalloc<int32_t>(b, (size_t)n * 5); q.n_valid = dalloc<int32_t>(b, 2);
+    h2d(b, d_t, svtype, (size_t)n * 4); h2d(b, d_p, pos, (size_t)n * 4); h2d(b, d_l, svlen, (size_t)n * 4); h2d(b, d_f, bnd_is_first, (size_t)n);
+    h2d(b, q.cov, cov, (size_t)n * 20);
+    q.svtype = d_t; q.pos = d_p; q.svlen = d_l; q.bnd_is_first = d_f;
+    LAUNCH(s2_covends, q, 1, n * 13);
+    LAUNCH(s2_covcalls, q, n, (q.hi - q.lo) * 8 + n * 40);
+    int32_t nv[2] = {0, 0};
+    d2h(b, cov, q.cov, (size_t)n * 20);
+    d2h(b, nv, q.n_valid, 8);
+    dsync(b);
+    *status = nv[1];
+    void* tmp[] = {d_t, d_p, d_l, d_f, q.end, q.cov, q.n_valid};
+    for (void* p : tmp) dfree_one(b, p);
+}
+
 #define SNF_TRY(body)                                   \
   try { body; return 0; }                               \
   catch (const snf::Error& e) { g_err = e.msg; return 1; } \
@@ -1315,6 +1354,11 @@ int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsiz
     dsync(b);
     dfree_one(b, q.out);
   })
+}
+
+int snf_batch_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int32_t* svtype, const int32_t* pos,
+                             const int32_t* svlen, const uint8_t* bnd_is_first, int32_t* cov, int32_t* status, double* coverage_mean) {
+  SNF_TRY(do_coverage_calls(bb, task_index, n, svtype, pos, svlen, bnd_is_first, cov, status, coverage_mean))
 }
 
 int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,

@@ -532,6 +532,52 @@ SNF_HD void s1_blockcov_body(int64_t i, const BlockCov& q) {
   q.out[i] = (int32_t)(quo + ((2 * rem > bs || (2 * rem == bs && (quo & 1))) ? 1 : 0));
 }
 
+// postprocessing.coverage (postprocessing.py:69-130) for calls that are NOT this batch's own candidates - the target SVs of
+// GenotypeTask.execute (parallel.py:353).  Same five samples and the same quirks as d4_coverage: numpy's negative
+// index, an out-of-range sample keeps the field's value, and a BND takes `end` from the last non-BND call before it in
+// list order (UnboundLocalError when there is none: the calls from there on stay untouched, status 1).
+struct CovCalls {
+  const int32_t *r_start, *re_sorted, *rs_top, *re_top;
+  int64_t lo, hi, L, n;
+  int32_t binsize, updown;
+  const int32_t *svtype, *pos, *svlen; const uint8_t* bnd_is_first;
+  int64_t* end;        // [n] scratch: `end` as the loop of the reference sees it at call i
+  int32_t* cov;        // [5n] in/out: upstream, start, center, end, downstream
+  int32_t* n_valid;    // [2]: calls annotated, status
+};
+SNF_HD void s2_covends_body(int64_t, const CovCalls& q) {   // one thread: `end` is carried from call to call
+  int64_t end = 0; bool have = false; int64_t i = 0;
+  for (; i < q.n; i++) {
+    if (q.svtype[i] == SNF_INS) { end = (int64_t)q.pos[i] + 1; have = true; }
+    else if (q.svtype[i] == SNF_BND) { if (!have) break; }
+    else { end = (int64_t)q.pos[i] + iabs64(q.svlen[i]); have = true; }
+    q.end[i] = end;
+  }
+  q.n_valid[0] = (int32_t)i; q.n_valid[1] = i < q.n ? 1 : 0;
+}
+SNF_HD void covcalls_sample(const CovCalls& q, int64_t idx, int32_t* out) {
+  if (idx < -q.L || idx >= q.L) return;
+  if (idx < 0) idx += q.L;
+  const int64_t ns = bound_top_i32<true>(q.r_start, q.rs_top, q.lo, q.hi, idx) - q.lo;
+  const int64_t ne = bound_top_i32<true>(q.re_sorted, q.re_top, q.lo, q.hi, idx) - q.lo;
+  *out = (int32_t)((uint64_t)(ns - ne) & 0xffffu);
+}
+SNF_HD void s2_covcalls_body(int64_t i, const CovCalls& q) {
+  if (i >= q.n_valid[0]) return;
+  const int t = q.svtype[i];
+  int64_t start = q.pos[i]; const int64_t end = q.end[i];
+  if (t == SNF_BND && q.bnd_is_first[i]) start -= 1;
+  int32_t* c = q.cov + 5 * i;
+  const int64_t bs = q.binsize;
+  if (t == SNF_INS || t == SNF_BND) {
+    covcalls_sample(q, start - bs, &c[1]); covcalls_sample(q, start, &c[2]); covcalls_sample(q, end + bs, &c[3]);
+  } else {
+    covcalls_sample(q, start, &c[1]); covcalls_sample(q, (start + end) / 2, &c[2]); covcalls_sample(q, end - bs, &c[3]);
+  }
+  covcalls_sample(q, start - bs * q.updown, &c[0]);
+  covcalls_sample(q, end + bs * q.updown, &c[4]);
+}
+
 // Z1: counters, task status / call offsets / coverage averages -> the pinned host result block (zero-copy stores)
 SNF_HD void z1_results_body(int64_t t, const View& v) {
   if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }

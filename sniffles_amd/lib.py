@@ -39,6 +39,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_export_calls_device.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.snf_batch_block_coverage.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_batch_block_coverage.restype = C.c_int
+    lib.snf_batch_coverage_calls.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    lib.snf_batch_coverage_calls.restype = C.c_int
     lib.snf_batch_timing_count.argtypes = [vp]
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
@@ -151,6 +154,20 @@ class Batch:
         _check(self.lib, self.lib.snf_batch_block_coverage(self._h, task_index, binsize, first_bin, n_bins,
                                                            out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out[:n_bins]
+
+    def coverage_calls(self, task_index: int, svtype, pos, svlen, bnd_is_first, cov):
+        """postprocessing.coverage for arbitrary calls of a task: returns (cov [n, 5] updated, status, coverage mean)."""
+        i32p, n = C.POINTER(C.c_int32), len(pos)
+        a = [np.ascontiguousarray(np.asarray(x, np.int32).reshape(-1)) for x in (svtype, pos, svlen)]
+        f = np.ascontiguousarray(np.asarray(bnd_is_first, np.uint8).reshape(-1))
+        cv = np.ascontiguousarray(np.asarray(cov, np.int32).reshape(-1)).copy()
+        if n == 0:
+            a, f, cv = [np.zeros(1, np.int32)] * 3, np.zeros(1, np.uint8), np.zeros(5, np.int32)
+        st, mean = C.c_int32(), C.c_double()
+        _check(self.lib, self.lib.snf_batch_coverage_calls(self._h, task_index, n, a[0].ctypes.data_as(i32p), a[1].ctypes.data_as(i32p),
+                                                           a[2].ctypes.data_as(i32p), f.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                           cv.ctypes.data_as(i32p), C.byref(st), C.byref(mean)))
+        return cv[:5 * n].reshape(n, 5), int(st.value), float(mean.value)
 
     def timings(self) -> list:
         out = []

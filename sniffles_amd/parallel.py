@@ -110,6 +110,67 @@ class CallTask(Task):
                            coverage_average_total=self.coverage_average_total)
 
 
+class GenotypeTask(Task):
+    """`GenotypeTask.execute` of the reference (parallel.py:299-372): force-calling of known SVs (`--genotype-vcf`).
+    The sample's own candidates come from the GPU hot path; every target SV takes the closest candidate of its type
+    within the merge gates as `genotype_match_sv` (host bookkeeping over a 5-kb bin table, as in the reference), the
+    targets are annotated with the sample's coverage on the device (`postprocessing.coverage`) and receive the
+    reference-allele genotype that the VCF rewriter uses when nothing matched."""
+
+    def __init__(self, *args, genotype_svs=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.genotype_svs = genotype_svs if genotype_svs is not None else []
+
+    def execute(self):
+        import math
+
+        from . import postprocessing
+        config = self.config
+        svcandidates = self.call_candidates(False, config)
+        self.finalize_candidates(svcandidates, True, config)
+        binsize = 5000
+        binedge = binsize // 10
+        table = {svtype: {} for svtype in sv.TYPES}
+        for target in self.genotype_svs:
+            target.genotype_match_sv = None
+            target.genotype_match_dist = math.inf
+            if target.svtype not in table:
+                continue
+            b0 = int(target.pos / binsize)
+            bins = [b0 * binsize]
+            if target.pos % binsize < binedge:
+                bins.append((b0 - 1) * binsize)
+            if target.pos % binsize > binsize - binedge:
+                bins.append((b0 + 1) * binsize)
+            for b in bins:
+                table[target.svtype].setdefault(b, []).append(target)
+        for cand in svcandidates:
+            if cand.svtype.startswith("SINGLE"):
+                continue
+            targets = table[cand.svtype].get(int(cand.pos / binsize) * binsize)
+            if not targets:
+                continue
+            for target in targets:
+                if cand.svtype == "BND":
+                    dist = abs(target.pos - cand.pos)
+                    ok = dist <= config.cluster_merge_bnd and cand.bnd_info.mate_contig == target.bnd_info.mate_contig
+                else:
+                    dist = abs(target.pos - cand.pos) + abs(abs(target.svlen) - abs(cand.svlen))
+                    minlen = float(min(abs(target.svlen), abs(cand.svlen)))
+                    ok = minlen > 0 and dist <= config.combine_match * math.sqrt(minlen) and dist <= config.combine_match_max
+                if ok and dist < target.genotype_match_dist:
+                    target.genotype_match_sv = cand
+                    target.genotype_match_dist = dist
+        postprocessing.coverage(self.genotype_svs, self.lead_provider)
+        for target in self.genotype_svs:
+            samples = [c for c in (target.coverage_start, target.coverage_center, target.coverage_end) if c is not None]
+            if len(samples) == 0:
+                return None
+            depth = round(sum(samples) / len(samples))
+            target.genotypes = {0: (0, 0, 0, depth, 0, (None, None)) if depth > 0 else config.genotype_none}
+        return self.genotype_svs
+
+
 class CombineTask(Task):
     """`CombineTask.execute` of the reference (parallel.py:444-572): the block / bin / flush-window driver of the
     multi-sample merge.  The candidates are read block by block from objects with the SNF reader interface

@@ -1,0 +1,71 @@
+"""Force calling (seam B6 + GenotypeTask.execute, reference parallel.py:299-372, postprocessing.py:69-130): target SVs
+matched against the sample's candidates and annotated with its coverage on the device, against what the UNMODIFIED
+reference GenotypeTask.execute produces for the same task and targets (tests/golden/genotype_targets.json.gz).
+CPU tier: kernels through the host emulation; GPU tier: the real library."""
+import pytest
+
+import cases
+import genotype_util as gutil
+import golden_util as gu
+from sniffles_amd import leadprov, parallel, postprocessing, sv
+from test_dropin_api import leads_of
+
+
+def make_task(name, specs, _lib):
+    build, kw, _ = cases.ALL[name]
+    ti = build()
+    cfg = gu.make_config(kw, ti)
+    lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+    for ld in leads_of(ti):
+        lp.record_lead(ld, int(ld.ref_start / cfg.cluster_binsize) * cfg.cluster_binsize)
+    for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
+        lp.record_read(s, e, hp)
+    targets = gutil.make_targets(specs, sv.SVCall, sv.SVCallBNDInfo, sv.new_call)
+    task = parallel.GenotypeTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                                 lead_provider=lp, genotype_svs=targets, _lib=_lib)
+    task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
+    return ti, task
+
+
+def run_case(name, _lib):
+    doc = gu.load("genotype_targets")[name]
+    ti, task = make_task(doc.get("case", name), doc["specs"], _lib)
+    assert gu.input_sha(ti) == doc["input_sha"]
+    exp = doc["expected"]
+    if "error" in exp:
+        with pytest.raises(UnboundLocalError):
+            task.execute()
+        return
+    got = task.execute()
+    task.close()
+    want = exp["targets"]
+    rec = gutil.result_records(got)
+    assert len(rec) == len(want)
+    for g, w in zip(rec, want):
+        assert g == w, (g["id"], g, w)
+
+
+NAMES = gutil.CASES + ["bnd_first"]
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if n != "chr20_30x_ont"])
+def test_genotype_task_emu(name):
+    import emu.emu as E
+    run_case(name, E.lib())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_genotype_task_gpu(name):
+    run_case(name, None)
+
+
+def test_coverage_needs_the_device_batch():
+    import emu.emu as E
+    doc = gu.load("genotype_targets")["long_ins"]
+    ti, task = make_task("long_ins", doc["specs"], E.lib())
+    with pytest.raises(RuntimeError, match="device batch"):
+        postprocessing.coverage(task.genotype_svs, task.lead_provider)      # before call_candidates: nothing on the device
+    task.execute()
+    assert postprocessing.coverage([], task.lead_provider) == task.coverage_average_total
+    task.close()
