@@ -191,7 +191,7 @@ def gen_records(seed: int, n_reads: int, ref_names=("chrA", "chr10", "chr2", "ch
 
 
 def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(1_400_000, 16_000, 1_100_000), cov=20.0,
-               read_len_mean=12000, site_spacing=18000, err=0.03):
+               read_len_mean=12000, site_spacing=18000, err=0.03, split_spacing=0):
     """A coherent synthetic sample: SV sites shared by the reads that cross them, so that clusters and calls form.
 
     Per contig: INS / DEL sites every ~`site_spacing` bp (lengths 50 ... 3000, 40 % homozygous, the rest on one
@@ -199,6 +199,10 @@ def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(
     the site's allele in the CIGAR of every read that spans it on a carrying haplotype (length jitter 1.5 %, position
     jitter 2 bp, inserted bases = the site's allele with `err` substitutions), 1-2 bp alignment noise in between,
     occasional sub-threshold (45-49 bp) noise events, NM tags, MAPQ 60.  Coordinate-sorted like a BAM.
+    `split_spacing` > 0 adds a split-alignment event every ~that many bp, cycling through large deletion, tandem
+    duplication, inversion breakpoint and translocation to the next long contig: every carrying read that crosses the
+    breakpoint becomes a primary record (soft-clipped, SA tag) plus a supplementary record (0x800, hard- or soft-clipped,
+    SA tag back to the primary) - the geometry `classify_splits` / `Lead.for_bnd` turn into DEL / DUP / INV / BND leads.
     Returns (ref_names, ref_lens, [record bytes])."""
     rng = np.random.default_rng(seed)
     code = np.array([1, 2, 4, 8], np.uint8)
@@ -213,12 +217,56 @@ def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(
             sites.append(dict(pos=p, ln=ln, ins=ins, hap=0 if rng.random() < 0.4 else int(rng.integers(1, 3)),
                               allele=rng.integers(0, 4, ln if ins else 0)))
             p += ln + int(rng.integers(site_spacing // 2, site_spacing * 3 // 2))
+        splits = []
+        if split_spacing:
+            long_ids = [i for i, n in enumerate(ref_lens) if n >= 1_000_000 and i != cid]
+            bp, kind = int(split_spacing // 2), 0
+            while bp < clen - 30000:
+                ev = dict(bp=bp, kind=("DEL", "DUP", "INV", "BND")[kind % 4], ln=int(rng.integers(3000, 15000)),
+                          hap=0 if rng.random() < 0.5 else int(rng.integers(1, 3)))
+                if ev["kind"] == "BND":
+                    if long_ids:
+                        ev["cid2"] = long_ids[int(rng.integers(len(long_ids)))]
+                        ev["pos2"] = int(rng.integers(20000, ref_lens[ev["cid2"]] - 40000))
+                    else:
+                        ev["kind"] = "DEL"
+                splits.append(ev)
+                bp += int(rng.integers(split_spacing * 3 // 4, split_spacing * 5 // 4)); kind += 1
         n_reads = int(cov * clen / read_len_mean)
         for r in range(n_reads):
             span = int(max(1500, min(clen // 3, rng.exponential(read_len_mean))))
             pos = int(rng.integers(0, max(1, clen - span)))
             hap = int(rng.integers(1, 3))
             rev = bool(rng.integers(2))
+            ev = next((e for e in splits if pos + 600 <= e["bp"] <= pos + span - 600 and e["hap"] in (0, hap)), None)
+            if ev is not None:
+                # two-part split read: query [0, a) on the left of the breakpoint, [a, span) at the event's other side
+                a, b = ev["bp"] - pos, span - (ev["bp"] - pos)
+                jit = int(rng.integers(-2, 3))
+                a, b = a + jit, b - jit
+                k = ev["kind"]
+                cid2 = ev.get("cid2", cid)
+                if k == "DEL": start2, rev2 = ev["bp"] + jit + ev["ln"], rev
+                elif k == "DUP": start2, rev2 = max(0, ev["bp"] + jit - ev["ln"]), rev
+                elif k == "INV": start2, rev2 = ev["bp"] + ev["ln"] - b, not rev
+                else: start2, rev2 = ev["pos2"] + jit, rev
+                start2 = int(min(max(0, start2), ref_lens[cid2] - b - 1))
+                hard = rng.random() < 0.5
+                ops1 = [(M, a), (S, b)]
+                ops2 = ([(M, b), (H if hard else S, a)] if rev2 != rev else [(H if hard else S, a), (M, b)])
+                sa_ops2 = [(S if op == H else op, ln) for op, ln in ops2]
+                nm1, nm2 = int(rng.integers(0, a // 50 + 1)), int(rng.integers(0, b // 50 + 1))
+                qname = f"s{seed}_{name}_{r}"
+                seq_full = code[rng.integers(0, 4, span)]
+                phase = [_int_tag("HP", hap, rng), _int_tag("PS", 1000 * (cid + 1) + 7, rng)] if rng.random() < 0.8 else []
+                sa1 = f"{ref_names[cid2]},{start2 + 1},{'-' if rev2 else '+'},{cigar_string(sa_ops2)},60,{nm2};"
+                sa2 = f"{name},{pos + 1},{'-' if rev else '+'},{cigar_string(ops1)},60,{nm1};"
+                recs.append((cid, pos, make_record(cid, pos, 60, 0x10 if rev else 0, qname, ops1, seq_full,
+                                                   b"".join([_int_tag("NM", nm1, rng)] + phase + [b"SAZ" + sa1.encode() + b"\0"]))))
+                seq2 = seq_full if not hard else (seq_full[:b] if rev2 != rev else seq_full[a:])
+                recs.append((cid2, start2, make_record(cid2, start2, 60, 0x800 | (0x10 if rev2 else 0), qname, ops2, seq2,
+                                                       b"".join([_int_tag("NM", nm2, rng)] + phase + [b"SAZ" + sa2.encode() + b"\0"]))))
+                continue
             ops, seq_parts, nm = [], [], 0
             cur, end = pos, min(clen, pos + span)
 

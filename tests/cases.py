@@ -440,4 +440,6 @@ SAMPLES = {
     # two contigs above the 1-Mb cut of should_process_contig and one below it (skipped by the reference)
     "sample_two_contigs_12x": (lambda: _sample(5, ref_lens=(1_200_000, 16_000, 1_050_000), cov=12.0), ()),
     "sample_mosaic_20x": (lambda: _sample(6, ref_names=("chr7",), ref_lens=(1_000_001,), cov=20.0), ("--mosaic",)),
+    # split alignments: large deletions, tandem duplications, inversion breakpoints, translocations between the contigs
+    "sample_splits_14x": (lambda: _sample(7, ref_lens=(1_200_000, 16_000, 1_050_000), cov=14.0, split_spacing=90000), ()),
 }
