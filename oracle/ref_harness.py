@@ -467,7 +467,8 @@ def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
     try:
         for task_id, (contig, length) in enumerate(contig_lengths):
             task = ref.parallel.CallTask(id=task_id, contig=contig, start=0, end=length - 1, assigned_process_id=None,
-                                         tandem_repeats=None, genotype_svs=None, sv_id=0, config=cfg, regions=None)
+                                         tandem_repeats=(getattr(recs, "tandem_repeats", None) or {}).get(contig),
+                                         genotype_svs=None, sv_id=0, config=cfg, regions=None)
             result = task.execute()
             read_count += result.processed_read_count
             result.emit(vcf_out=vcf_out, snf_out=snf_out)

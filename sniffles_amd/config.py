@@ -34,6 +34,8 @@ _DEFAULTS = dict(
     sample_id=None, output_rnames=False, snf=None,
     # VCF writer (config.py:166-170, 242, 332)
     vcf=None, reference=None, max_del_seq_len=50000, max_unknown_pct=0.5,
+    # contig selection of the main program (config.py:168-176, util.py:147-162)
+    all_contigs=False, contig=None,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)

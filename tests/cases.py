@@ -432,8 +432,10 @@ def extract_records(case):
 # ---------------------------------------------------------------------------------------------- whole samples (BAM -> VCF / SNF)
 def _sample(seed, **kw):
     from sniffles_amd import bam, synth_bam
-    names, lens, recs = synth_bam.gen_sample(seed, **kw)
-    return bam.records_from_list(names, lens, recs)
+    out = synth_bam.gen_sample(seed, **kw)
+    recs = bam.records_from_list(out[0], out[1], out[2])
+    recs.tandem_repeats = out[3] if len(out) > 3 else None      # {contig: [(start, end)]}: handed to both pipelines
+    return recs
 
 
 SAMPLES = {
@@ -441,5 +443,8 @@ SAMPLES = {
     "sample_two_contigs_12x": (lambda: _sample(5, ref_lens=(1_200_000, 16_000, 1_050_000), cov=12.0), ()),
     "sample_mosaic_20x": (lambda: _sample(6, ref_names=("chr7",), ref_lens=(1_000_001,), cov=20.0), ("--mosaic",)),
     # split alignments: large deletions, tandem duplications, inversion breakpoints, translocations between the contigs
+    # tandem-repeat annotation (the `repeat` merge rules of cluster.resolve) and every contig processed (--all-contigs)
+    "sample_tandem_repeats_15x": (lambda: _sample(8, ref_names=("chr9", "chrUn_small"), ref_lens=(1_100_000, 120_000), cov=15.0,
+                                                  tr_frac=0.35, site_spacing=9000), ("--all-contigs",)),
     "sample_splits_14x": (lambda: _sample(7, ref_lens=(1_200_000, 16_000, 1_050_000), cov=14.0, split_spacing=90000), ()),
 }

@@ -43,11 +43,14 @@ def run_sample(name, tmp_path, _lib, through_file):
         offs = recs.rec_off.tolist()
         raw = bam.bam_stream(recs.ref_names, recs.ref_lens, [recs.blob[a:b].tobytes() for a, b in zip(offs[:-1], offs[1:])])
         path.write_bytes(bam.bgzf_deflate(raw))
+        tr_keep = getattr(recs, "tandem_repeats", None)
         recs = bam.read_bam(str(path))
+        recs.tandem_repeats = tr_keep
         assert records_sha(recs) == doc["input_sha"]
     # VCF only
     buf = io.StringIO()
-    res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, _lib=_lib)
+    tr = getattr(recs, "tandem_repeats", None)
+    res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr, _lib=_lib)
     assert res.read_count == doc["read_count"]
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert res.vcf_records == len(vu.split_text(doc["vcf"])[1])
@@ -55,7 +58,7 @@ def run_sample(name, tmp_path, _lib, through_file):
     buf = io.StringIO()
     cfg = config_for(args)
     snf_path = str(tmp_path / "sample.snf")
-    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=snf_path, _lib=_lib)
+    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=snf_path, tandem_repeats=tr, _lib=_lib)
     assert_same_text(buf.getvalue(), doc["vcf_with_snf"])
     assert res.snf_candidates == doc["snf_candidates"]
     f = snf.SNFile.open(snf_path, cfg)
