@@ -268,7 +268,7 @@ def main_vcf():
         f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
 
 
-def main_sample():
+def main_sample(names=None):
     """End to end: a synthetic coordinate-sorted BAM (cases.SAMPLES) through the unmodified reference's call_sample flow
     (ref_harness.run_reference_call_sample) -> the VCF text and the content of the SNF file it writes."""
     import tempfile
@@ -278,7 +278,9 @@ def main_sample():
     import vcf_util as vu
     ref = rh.load_reference()
     out_dir = os.path.join(ROOT, "tests", "golden")
-    for name, (build, args) in cases.SAMPLES.items():
+    for name, (build, args) in {**cases.SAMPLES, **cases.SAMPLES_EMU}.items():
+        if names and name not in names:
+            continue
         recs = build()
         plain = rh.run_reference_call_sample(recs, args, None, vu.FIXED)
         path = os.path.join(tempfile.mkdtemp(prefix="snf_e2e_"), "sample.snf")
@@ -334,7 +336,7 @@ if __name__ == "__main__":
     names = set(a for a in argv if a not in FAMILIES)
     for fam in fams:
         fn = FAMILIES[fam]
-        if fam in ("main", "combine", "combine_task", "extract"):
+        if fam in ("main", "combine", "combine_task", "extract", "sample"):
             fn(names or None)
         else:
             fn()

@@ -448,3 +448,12 @@ SAMPLES = {
                                                   tr_frac=0.35, site_spacing=9000), ("--all-contigs",)),
     "sample_splits_14x": (lambda: _sample(7, ref_lens=(1_200_000, 16_000, 1_050_000), cov=14.0, split_spacing=90000), ()),
 }
+
+# run through the host emulation only (the GPU tier keeps to SAMPLES, whose device runs have been checked on the MI355X)
+SAMPLES_EMU = {
+    "sample_hifi_40x": (lambda: _sample(9, ref_names=("chr3",), ref_lens=(1_000_500,), cov=40.0, read_len_mean=15000, err=0.005), ()),
+    "sample_noqc_10x": (lambda: _sample(10, ref_names=("chr4", "chr5"), ref_lens=(1_000_100, 1_000_200), cov=10.0, split_spacing=150000),
+                        ("--no-qc",)),
+    "sample_qcnm_auto_18x": (lambda: _sample(11, ref_names=("chr6",), ref_lens=(1_050_000,), cov=18.0, tr_frac=0.2),
+                             ("--qc-nm", "--minsupport", "auto")),
+}

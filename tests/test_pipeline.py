@@ -27,14 +27,18 @@ def records_sha(recs):
 
 
 def config_for(args):
-    cfg = SnifflesConfig(**{a[2:].replace("-", "_"): True for a in args})
+    kw, a = {}, list(args)
+    while a:
+        k = a.pop(0)[2:].replace("-", "_")
+        kw[k] = a.pop(0) if a and not a[0].startswith("--") else True
+    cfg = SnifflesConfig(**kw)
     for k, v in vu.FIXED.items():
         setattr(cfg, k, v)
     return cfg
 
 
 def run_sample(name, tmp_path, _lib, through_file):
-    build, args = cases.SAMPLES[name]
+    build, args = {**cases.SAMPLES, **cases.SAMPLES_EMU}[name]
     doc = gu.load(name)
     recs = build()
     assert records_sha(recs) == doc["input_sha"]
@@ -72,7 +76,7 @@ def run_sample(name, tmp_path, _lib, through_file):
         assert got[c] == doc["snf"][c]
 
 
-@pytest.mark.parametrize("name", sorted(cases.SAMPLES))
+@pytest.mark.parametrize("name", sorted({**cases.SAMPLES, **cases.SAMPLES_EMU}))
 def test_bam_to_vcf_and_snf_emu(name, tmp_path):
     import emu.emu as E
     run_sample(name, tmp_path, E.lib(), through_file=(name == "sample_mosaic_20x"))
@@ -91,3 +95,13 @@ def test_contig_selection_rule():
     assert pipeline.should_process_contig("chrUn", 10, cfg)
     cfg.all_contigs, cfg.contig = False, ["chrUn"]
     assert pipeline.should_process_contig("chrUn", 10, cfg) and not pipeline.should_process_contig("chr1", 2_000_000, cfg)
+
+
+def test_contig_selection_reference_vectors():
+    """The reference's own vectors for `util.should_process_contig` (src/tests/test_params.py:9-25)."""
+    cfg = SnifflesConfig()
+    assert pipeline.should_process_contig("chr1", 248956422, cfg)                       # normal contig
+    assert not pipeline.should_process_contig("fragment", 123456, cfg)                  # short contig excluded
+    assert pipeline.should_process_contig("fragment", 123456, SnifflesConfig(contig=["fragment"]))   # ... unless given by -c
+    cfg.regions_by_contig = {"fragment": ("fragment", 0, 123456)}                       # ... or by the regions
+    assert pipeline.should_process_contig("fragment", 123456, cfg)
