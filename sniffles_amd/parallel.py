@@ -59,11 +59,9 @@ class Task:
         res = self._batch.fetch(0)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
-        out = []
-        for i in range(len(res.calls)):
-            c = sv.fill_candidate(sv.new_call(svcall_cls), res, i, self._ti, bnd_cls)
+        out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls)
+        for i, c in enumerate(out):
             c.postprocess = sv.SVCallPostprocessingInfo(batch=self._batch, index=i)
-            out.append(c)
         self.sv_id += len(out)
         self.coverage_average_total = float(res.coverage_average_total[0])
         return out
@@ -75,9 +73,9 @@ class Task:
         res = self._batch.fetch(1)
         if len(res.calls) != len(candidates):
             raise RuntimeError("candidate list does not match the batch (pass the list call_candidates returned)")
+        sv.apply_final(candidates, res, self._ti)
         passed = []
-        for i, c in enumerate(candidates):
-            sv.fill_final(c, res, i, self._ti)
+        for c in candidates:
             c.finalize()
             passed.append(c)
         self._finalized = True

@@ -201,6 +201,80 @@ def fill_final(call, res: Result, i: int, ti):
     return call
 
 
+# ---- whole result sets at once: one C-level conversion of the record table to Python scalars instead of ~40 numpy scalar
+# reads per call (materialising the objects is the slowest part of a task on the host; the device pass takes milliseconds)
+def _columns(res: Result, lo: int, hi: int):
+    names = res.calls.dtype.names
+    return {n: k for k, n in enumerate(names)}, res.calls[lo:hi].tolist()
+
+
+def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo) -> list:
+    """`fill_candidate(new_call(), res, i, ti)` for i in [lo, hi), same objects."""
+    K, rows = _columns(res, lo, hi)
+    k_svtype, k_pos, k_end, k_svlen, k_svid, k_qual, k_filter, k_qc = (K[n] for n in ("svtype", "pos", "end", "svlen", "sv_id", "qual", "filter", "qc"))
+    k_prec, k_sup, k_fwd, k_rev, k_nm, k_cov = (K[n] for n in ("precise", "support", "fwd", "rev", "nm", "cov"))
+    k_mc, k_mp, k_bf, k_br, k_sl, k_ssa, k_sp, k_sln, k_ro, k_rl = (K[n] for n in ("mate_contig", "mate_ref_start", "bnd_is_first", "bnd_is_reverse", "support_long", "support_sa", "stdev_pos", "stdev_len", "rn_off", "rn_len"))
+    rn = res.rnames.tolist()
+    qn = ti.qnames
+    contig, task_id = ti.contig, ti.task_id
+    out = []
+    for r in rows:
+        svtype = SVTYPES[r[k_svtype]]
+        fwd, rev = r[k_fwd], r[k_rev]
+        ids = rn[r[k_ro]:r[k_ro] + r[k_rl]]
+        info = {}
+        alt, bi = f"<{svtype}>", None
+        if svtype == "BND":
+            bi = bnd_cls(mate_contig=ti.contig_name(r[k_mc]), mate_ref_start=r[k_mp], is_first=bool(r[k_bf]), is_reverse=bool(r[k_br]))
+            alt = bnd_alt(bi.mate_contig, bi.mate_ref_start, bi.is_first, bi.is_reverse)
+            info["CHR2"] = bi.mate_contig
+        elif svtype == "INS":
+            info["SUPPORT_LONG"] = r[k_sl]
+        elif svtype == "DEL":
+            info["SUPPORT_SA"] = r[k_ssa]
+        single = fwd + rev < 2
+        info["STDEV_POS"] = 0 if single else r[k_sp]
+        sl = r[k_sln]
+        if sl == sl:            # not NaN
+            info["STDEV_LEN"] = 0 if single else sl
+        cov = r[k_cov]
+        if not isinstance(cov, (list, tuple)):      # a sub-array field comes back as an ndarray: Python ints like everything else
+            cov = cov.tolist()
+        call = svcall_cls(contig=contig, pos=r[k_pos], id=f"{svtype}.{r[k_svid]:X}S{task_id:X}", ref="N", alt=alt, qual=r[k_qual],
+                          filter=FILTERS[r[k_filter]], info=info, svtype=svtype, svlen=r[k_svlen], end=r[k_end], genotypes={},
+                          precise=bool(r[k_prec]), support=r[k_sup],
+                          rnames=[qn[q] for q in ids] if qn is not None else [f"q{q}" for q in ids],
+                          qc=bool(r[k_qc]), nm=r[k_nm], postprocess=None)
+        call.fwd, call.rev, call.bnd_info = fwd, rev, bi
+        (call.coverage_upstream, call.coverage_start, call.coverage_center, call.coverage_end, call.coverage_downstream) = cov
+        out.append(call)
+    return out
+
+
+def apply_final(calls: list, res: Result, ti, lo: int = 0) -> None:
+    """`fill_final(call, res, lo + k, ti)` for every call of the list."""
+    K, rows = _columns(res, lo, lo + len(calls))
+    k_qc, k_filter, k_phs, k_gts, k_vaf, k_al, k_ao = (K[n] for n in ("qc", "filter", "ph_set", "gt_set", "vaf", "alt_len", "alt_off"))
+    k_ph = [K[n] for n in ("ph_hp", "ph_ps", "ph_hp_support", "ph_ps_support", "ph_hp_pass", "ph_ps_pass")]
+    k_gt = [K[n] for n in ("gt_a", "gt_b", "gt_gq", "gt_dr", "gt_dv", "gt_hp", "gt_ps")]
+    pool = res.alt_pool
+    for call, r in zip(calls, rows):
+        call.qc, call.filter = bool(r[k_qc]), FILTERS[r[k_filter]]
+        if call.filter not in _QC_SV_EARLY_EXIT:          # see fill_final
+            call.info["COVERAGE_VAR"] = None
+        if r[k_phs]:
+            hp, ps, hs, pss, hpass, ppass = (r[k] for k in k_ph)
+            call.info["PHASE"] = f"{hp},{_ps(ps, ti)},{hs},{pss},{'PASS' if hpass else 'FAIL'},{'PASS' if ppass else 'FAIL'}"
+        if r[k_gts]:
+            a, b, gq, dr, dv, ghp, gps = (r[k] for k in k_gt)
+            call.genotypes[0] = (a, b, gq, dr, dv, (None if ghp < 0 else str(ghp), _ps(gps, ti)))
+            call.info["VAF"] = r[k_vaf]
+        n = r[k_al]
+        if n >= 0:
+            o = r[k_ao]
+            call.alt = pool[o:o + n].tobytes().decode("latin-1")
+
+
 def new_call(svcall_cls=SVCall):
     return svcall_cls(contig=None, pos=0, id="", ref="N", alt="", qual=0, filter="PASS", info=dict(), svtype="",
                       svlen=0, end=0, genotypes=dict(), precise=False, support=0, rnames=None, qc=True, nm=-1,

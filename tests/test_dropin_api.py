@@ -87,3 +87,31 @@ def test_task_entry_points_emulated(name):
 @pytest.mark.parametrize("name", NAMES + ["chr20_30x_ont", "chr22_60x_hifi"])
 def test_task_entry_points_gpu(name):
     run_case(name, None)
+
+
+def test_bulk_materialisation_equals_record_by_record():
+    """sv.materialize_candidates / sv.apply_final build the same objects as fill_candidate / fill_final per record."""
+    import emu.emu as E
+    from sniffles_amd import lib, sv
+    for name in ("fuzz_4_2", "bnd_stale_end", "chr21_30x_mosaic", "single_leads_noqc"):
+        build, kw, _ = cases.ALL[name]
+        ti = build()
+        cfg = gu.make_config(kw, ti)
+        with lib.Batch(cfg, [ti], device=0, _lib=E.lib()) as b:
+            b.call_candidates()
+            r0 = b.fetch(0)
+            n = len(r0.calls)
+            one = [sv.fill_candidate(sv.new_call(), r0, i, ti) for i in range(n)]
+            bulk = sv.materialize_candidates(r0, ti, 0, n)
+            strip = lambda c: repr({k: v for k, v in c.__dict__.items() if k != "forward_difference_sampler"})  # noqa: E731
+            assert [strip(c) for c in one] == [strip(c) for c in bulk]
+            b.finalize()
+            r1 = b.fetch(1)
+            for i, c in enumerate(one):
+                sv.fill_final(c, r1, i, ti)
+            sv.apply_final(bulk, r1, ti)
+            for a, c in zip(one, bulk):
+                da, dc = dict(a.__dict__), dict(c.__dict__)
+                fa, fc = da.pop("forward_difference_sampler"), dc.pop("forward_difference_sampler")
+                assert repr(da) == repr(dc) and fa.__dict__ == fc.__dict__
+                assert [(k, type(v)) for k, v in da.items()] == [(k, type(v)) for k, v in dc.items()]
