@@ -68,27 +68,36 @@ class LeadProvider:
         qn, qrank = intern_sorted([ld.read_qname for ld in self._leads])
         psn, psrank = intern_sorted([ld.phase_set for ld in self._leads if ld.phase_set is not None] + ["NULL"])
         cn, crank = intern_sorted([ld.bnd_info.mate_contig for ld in self._leads if ld.bnd_info is not None] + [self.contig])
-        pool = bytearray()
-        for i, ld in enumerate(self._leads):
-            L["svtype"][i] = SVT[ld.svtype]
-            L["ref_start"][i], L["ref_end"][i] = ld.ref_start, ld.ref_end
-            L["qry_start"][i], L["qry_end"][i] = ld.qry_start, ld.qry_end
-            L["svlen"][i] = SVLEN_NONE if ld.svlen is None else ld.svlen
-            L["read_len"][i] = ld.read_len or 0
-            L["qname_id"][i] = qrank[ld.read_qname]
-            L["read_id"][i] = ld.read_id
-            L["strand"][i] = 1 if ld.strand == "-" else 0
-            L["mapq"][i] = ld.mapq
-            L["nm"][i] = float("nan") if ld.nm is None else ld.nm
-            L["source"][i] = SRC[ld.source]
-            L["hap"][i] = int(ld.hap)
-            L["ps_rank"][i] = PS_NONE if ld.phase_set is None else psrank[ld.phase_set]
-            L["is_sa"][i] = bool(ld.is_sa)
-            if ld.seq is not None:
-                L["seq_off"][i], L["seq_len"][i] = len(pool), len(ld.seq)
-                pool += ld.seq.encode("latin-1")
-            else:
-                L["seq_len"][i] = SEQ_NONE
+        # column at a time: one list comprehension and one array conversion per field (an element-wise fill of the numpy
+        # columns costs a scalar store per field and lead)
+        ls = self._leads
+
+        def col(name, values):
+            L[name][:] = np.fromiter(values, L[name].dtype, n) if n else L[name]
+        col("svtype", (SVT[ld.svtype] for ld in ls))
+        col("ref_start", (ld.ref_start for ld in ls)); col("ref_end", (ld.ref_end for ld in ls))
+        col("qry_start", (ld.qry_start for ld in ls)); col("qry_end", (ld.qry_end for ld in ls))
+        col("svlen", (SVLEN_NONE if ld.svlen is None else ld.svlen for ld in ls))
+        col("read_len", (ld.read_len or 0 for ld in ls))
+        col("qname_id", (qrank[ld.read_qname] for ld in ls))
+        col("read_id", (ld.read_id for ld in ls))
+        col("strand", (1 if ld.strand == "-" else 0 for ld in ls))
+        col("mapq", (ld.mapq for ld in ls))
+        col("nm", (float("nan") if ld.nm is None else ld.nm for ld in ls))
+        col("source", (SRC[ld.source] for ld in ls))
+        col("hap", (int(ld.hap) for ld in ls))
+        col("ps_rank", (PS_NONE if ld.phase_set is None else psrank[ld.phase_set] for ld in ls))
+        col("is_sa", (bool(ld.is_sa) for ld in ls))
+        seqs = [None if ld.seq is None else ld.seq.encode("latin-1") for ld in ls]
+        lens = np.fromiter((SEQ_NONE if q is None else len(q) for q in seqs), np.int64, n) if n else np.zeros(0, np.int64)
+        L["seq_len"][:] = lens
+        have = lens >= 0
+        offs = np.zeros(n, np.int64)
+        if n:
+            offs[have] = (np.cumsum(np.where(have, lens, 0)) - np.where(have, lens, 0))[have]
+        L["seq_off"][:] = offs
+        pool = b"".join(q for q in seqs if q is not None)
+        for i, ld in enumerate(ls):
             if ld.bnd_info is not None:
                 L["mate_contig"][i] = crank[ld.bnd_info.mate_contig]
                 L["mate_ref_start"][i] = ld.bnd_info.mate_ref_start
