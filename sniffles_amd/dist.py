@@ -46,3 +46,47 @@ def unpack_gathered(counts, gathered, cap_calls: int) -> list:
         lo = r * cap_calls * rec
         out.append(g[lo:lo + int(n) * rec].view(abi.CALL_DTYPE).copy())
     return out
+
+
+class TaskQueue:
+    """A shared queue of task indices, heaviest first, over the process group's key-value store (no data-path
+    collective): every rank claims the next index with one atomic add, so a rank that got short contigs simply comes
+    back earlier - the self-balancing alternative to `shard_lpt` when the cost of a contig is not known up front
+    (reference: the parent's task deque that idle workers pull from, parallel.py:652-680).
+
+        q = TaskQueue([t.n_leads for t in tasks])
+        mine = [i for i in q]           # indices this rank processed, in claim order
+    """
+
+    def __init__(self, weights, store=None, key: str = "snf_task_queue"):
+        import torch.distributed as dist
+        self.order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
+        if store is None:
+            from torch.distributed import distributed_c10d
+            store = distributed_c10d._get_default_store()
+        self.store, self.key = store, key
+        self.claimed = []
+        dist.barrier()      # every rank has built the same order before the first claim
+
+    def claim(self):
+        k = int(self.store.add(self.key, 1)) - 1
+        if k >= len(self.order):
+            return None
+        self.claimed.append(self.order[k])
+        return self.order[k]
+
+    def __iter__(self):
+        while True:
+            i = self.claim()
+            if i is None:
+                return
+            yield i
+
+
+def gather_claims(claimed, world: int) -> list:
+    """Which rank processed which tasks (per rank, in processing order): needed to map the rank-local task_index of the
+    gathered records back to the task."""
+    import torch.distributed as dist
+    out = [None] * world
+    dist.all_gather_object(out, list(claimed))
+    return out

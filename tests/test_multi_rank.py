@@ -80,3 +80,71 @@ def test_two_rank_shard_and_gather_equals_single_process():
     assert sorted(shards[0] + shards[1]) == list(range(len(tasks)))
     loads = [sum(tasks[i].contig_len for i in s) for s in shards]
     assert max(loads) <= 1.35 * min(loads)
+
+
+def _queue_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import emu.emu as E
+    from sniffles_amd import abi, dist as sdist, lib
+    from sniffles_amd.config import SnifflesConfig
+    tasks = _tasks()
+    cfg = SnifflesConfig()
+    queue = sdist.TaskQueue([t.n_leads for t in tasks])
+    recs = []
+    for i in queue:                       # one task per claim; rank 1 is slowed down so that rank 0 takes more
+        with lib.Batch(cfg, [tasks[i]], _lib=E.lib()) as b:
+            b.call_candidates(); b.finalize()
+            recs.append(b.fetch(1).calls.copy())
+        if rank == 1:
+            time.sleep(0.5)
+    claims = sdist.gather_claims(queue.claimed, world)
+    cap = 4096
+    mine = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
+    off = 0                               # task_index is batch-local (always 0 here): store the position in the claim list
+    for k, arr in enumerate(recs):
+        mine["task_index"][off:off + len(arr)] = k
+        off += len(arr)
+    buf = torch.zeros(cap * abi.CALL_DTYPE.itemsize, dtype=torch.uint8)
+    raw = mine.tobytes()
+    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    counts, gathered = sdist.gather_calls(buf, len(mine), cap, world)
+    per_rank = sdist.unpack_gathered(counts, gathered, cap)
+    if rank == 0:
+        keys = sorted((claims[r][int(c["task_index"])], int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]),
+                       int(c["support"]), int(c["gt_a"]), int(c["gt_b"])) for r, arr in enumerate(per_rank) for c in arr)
+        q.put((keys, claims))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_task_queue_equals_single_process():
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import emu.emu as E
+    from sniffles_amd import lib
+    from sniffles_amd.config import SnifflesConfig
+    E.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, claims = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tasks = _tasks()
+    with lib.Batch(SnifflesConfig(), tasks, _lib=E.lib()) as b:
+        b.call_candidates(); b.finalize()
+        res = b.fetch(1)
+    exp = sorted((int(c["task_index"]), int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]), int(c["support"]),
+                  int(c["gt_a"]), int(c["gt_b"])) for c in res.calls)
+    assert got == exp
+    assert sorted(claims[0] + claims[1]) == list(range(len(tasks)))     # every task exactly once
+    assert len(claims[0]) > len(claims[1]) >= 1                           # the faster rank came back for more
