@@ -325,18 +325,36 @@ def main_genotype():
         f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
 
 
+def main_population(names=None):
+    """BAMs -> per-sample SNF -> merged multi-sample VCF, everything by the unmodified reference (cases.POPULATIONS)."""
+    import tempfile
+    import cases
+    import ref_harness as rh
+    import vcf_util as vu
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    for name, (build, args) in cases.POPULATIONS.items():
+        if names and name not in names:
+            continue
+        recs = build()
+        res = rh.run_reference_population(recs, tempfile.mkdtemp(prefix="pop_"), args, vu.FIXED)
+        doc = dict(case=name, reference_args=list(args), input_sha=[records_sha(r) for r in recs], vcf=res["vcf"])
+        with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as fh:
+            fh.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+        print(f"{name:28s} {len(recs)} samples -> {len(vu.split_text(res['vcf'])[1])} merged VCF records")
+
+
 if __name__ == "__main__":
     # python oracle/make_golden.py                 -> every fixture family
     # python oracle/make_golden.py vcf sample      -> only these families
     # python oracle/make_golden.py main fuzz_4_2   -> single cases of the `main` / `combine` families
     FAMILIES = dict(main=main, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
-                    bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype)
+                    bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype, population=main_population)
     argv = sys.argv[1:]
     fams = [a for a in argv if a in FAMILIES] or list(FAMILIES)
     names = set(a for a in argv if a not in FAMILIES)
     for fam in fams:
         fn = FAMILIES[fam]
-        if fam in ("main", "combine", "combine_task", "extract", "sample"):
+        if fam in ("main", "combine", "combine_task", "extract", "sample", "population"):
             fn(names or None)
         else:
             fn()

@@ -508,6 +508,57 @@ def run_reference_genotype(ti, specs, extra_args=()):
     return dict(targets=gutil.result_records(res.svcalls))
 
 
+def run_reference_population(recs_list, workdir, extra_args=(), fixed=None):
+    """BAMs -> per-sample .snf (run_reference_call_sample) -> the reference's `combine` flow (sniffles:371-490 in this
+    process): headers, one unmodified CombineTask.execute per contig reading the real files (edlib replaced by the
+    exact DP, see the module header), calls sorted per task, the unmodified VCF writer.  Returns dict(vcf=text, snf=[paths])."""
+    import io
+    import oracle as oc
+    ref = load_reference()
+    from sniffles import snf as ref_snf, vcf as ref_vcf
+    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    paths = []
+    for s, recs in enumerate(recs_list):
+        path = os.path.join(workdir, f"sample{s}.snf")
+        run_reference_call_sample(recs, (), path, fixed)
+        paths.append(path)
+    cfg = ref.config.SnifflesConfig("--input", *paths, "--vcf", "out.vcf", *extra_args)
+    cfg.mode = "combine"
+    for k, v in (fixed or {}).items():
+        setattr(cfg, k, v)
+    cfg.snf_input_info, cfg.sample_ids_vcf = [], []
+    contig_lengths = None
+    for internal_id, path in enumerate(paths):
+        f = ref_snf.SNFile(cfg, open(path, "rb"), filename=path)
+        f.read_header()
+        contig_lengths = f.header["config"]["contig_lengths"]
+        sid = f.header["config"]["sample_id"] or os.path.splitext(os.path.basename(path))[0]
+        cfg.snf_input_info.append({"internal_id": internal_id, "sample_id": sid, "filename": path})
+        f.close()
+    cfg.sample_ids_vcf = [(i["internal_id"], i["sample_id"]) for i in cfg.snf_input_info]
+    cfg.combine_close_handles = False
+    buf = io.StringIO()
+    w = ref_vcf.VCF(cfg, buf)
+    w.write_header(contig_lengths)
+
+    class Collector:
+        def __init__(self, task, svcalls, count):
+            self.calls = []
+
+        def store_calls(self, svcalls):
+            self.calls.extend(svcalls)
+
+        def finalize(self):
+            pass
+    for task_id, (contig, length) in enumerate(contig_lengths):
+        task = ref.parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, assigned_process_id=None,
+                                        config=cfg, result_class=Collector, regions=None)
+        res = task.execute()
+        for c in sorted(res.calls, key=lambda c: c.pos):
+            w.write_call(c)
+    return dict(vcf=buf.getvalue(), snf=paths)
+
+
 # ---------------------------------------------------------------------------------------------- signature extraction
 def lead_record(ld) -> list:
     """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""

@@ -99,3 +99,48 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
         out.snf_candidates = snf_out.write_results(config, [c for c, _ in contig_lengths])
         snf_out.close()
     return out
+
+
+def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, _lib=None) -> list:
+    """Multi-sample calling from per-sample `.snf` files: the `combine` flow of the reference's main program
+    (`sniffles:371-490`) for one process - headers (sample ids, contig lengths, format checks), one `CombineTask` per
+    contig over `snf.SNFile` readers (group assignment on the GPU), calls of a task sorted by position
+    (`CombineResult`), VCF records in task order.  Returns the combined calls."""
+    import os
+    config.mode = "combine"
+    config.snf_input_info, readers = [], {}
+    contig_lengths = None
+    for internal_id, path in enumerate(snf_paths):
+        f = snf.SNFile(config, open(path, "rb"), filename=path)
+        f.read_header()
+        hc = f.header["config"]
+        if config.snf_block_size != hc["snf_block_size"]:
+            raise ValueError(f"SNF block size differs for {path}")
+        if config.snf_format_version != hc["snf_format_version"]:
+            raise ValueError(f"SNF format version for {path} is not supported")
+        contig_lengths = hc["contig_lengths"]                 # the last header wins, like in the reference
+        sid = (sample_ids[internal_id] if sample_ids else None) or hc.get("sample_id") or os.path.splitext(os.path.basename(path))[0]
+        config.snf_input_info.append({"internal_id": internal_id, "sample_id": sid, "filename": path})
+        readers[internal_id] = f
+    config.sample_ids_vcf = [(i["internal_id"], i["sample_id"]) for i in config.snf_input_info]
+    contig_lengths = [(c, int(n)) for c, n in (contig_lengths or [])]
+    wanted = getattr(config, "contig", None) or getattr(config, "regions_by_contig", None)
+    if wanted:
+        contig_lengths = [(c, n) for c, n in contig_lengths if c in wanted]
+    writer = None
+    if vcf_handle is not None:
+        writer = vcf.VCF(config, vcf_handle)
+        writer.write_header(contig_lengths)
+    out = []
+    for task_id, (contig, length) in enumerate(contig_lengths):
+        task = parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device, _lib=_lib)
+        calls = task.execute(readers)
+        if getattr(config, "sort", True):
+            calls = sorted(calls, key=lambda c: c.pos)
+        if writer is not None:
+            for c in calls:
+                writer.write_call(c)
+        out.extend(calls)
+    for f in readers.values():
+        f.close()
+    return out

@@ -191,7 +191,7 @@ def gen_records(seed: int, n_reads: int, ref_names=("chrA", "chr10", "chr2", "ch
 
 
 def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(1_400_000, 16_000, 1_100_000), cov=20.0,
-               read_len_mean=12000, site_spacing=18000, err=0.03, split_spacing=0, tr_frac=0.0):
+               read_len_mean=12000, site_spacing=18000, err=0.03, split_spacing=0, tr_frac=0.0, site_seed=None):
     """A coherent synthetic sample: SV sites shared by the reads that cross them, so that clusters and calls form.
 
     Per contig: INS / DEL sites every ~`site_spacing` bp (lengths 50 ... 3000, 40 % homozygous, the rest on one
@@ -205,8 +205,13 @@ def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(
     SA tag back to the primary) - the geometry `classify_splits` / `Lead.for_bnd` turn into DEL / DUP / INV / BND leads.
     `tr_frac` > 0 makes that fraction of the sites tandem-repeat-like (breakpoint scatter of 40 bp instead of 2) and
     returns the annotation as a fourth value: {contig: [(start, end), ...]} padded by 500 bp like `util.load_tandem_repeats`.
+    `site_seed`: draw the SV sites from their own generator, so that several samples (different `seed`) share the sites
+    of one population; a site is then present in a sample with probability 0.7.
     Returns (ref_names, ref_lens, [record bytes])."""
     rng = np.random.default_rng(seed)
+    read_rng = rng
+    if site_seed is not None:
+        rng = np.random.default_rng(site_seed)       # sites of the population; the reads keep this sample's generator
     code = np.array([1, 2, 4, 8], np.uint8)
     recs = []
     tandem = {}
@@ -221,6 +226,10 @@ def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(
                               allele=rng.integers(0, 4, ln if ins else 0), tr=bool(tr_frac) and rng.random() < tr_frac))
             p += ln + int(rng.integers(site_spacing // 2, site_spacing * 3 // 2))
         tandem[name] = [(max(0, x["pos"] - 150 - 500), x["pos"] + 150 + 500) for x in sites if x["tr"]]
+        site_rng = rng
+        if site_seed is not None:
+            sites = [x for x in sites if read_rng.random() < 0.7]
+            rng = read_rng
         splits = []
         if split_spacing:
             long_ids = [i for i, n in enumerate(ref_lens) if n >= 1_000_000 and i != cid]
@@ -322,6 +331,7 @@ def gen_sample(seed: int, ref_names=("chr20", "chrM_short", "chr21"), ref_lens=(
             if rng.random() < 0.8:
                 tags += [_int_tag("HP", hap, rng), _int_tag("PS", 1000 * (cid + 1) + 7, rng)]
             recs.append((cid, pos, make_record(cid, pos, 60, 0x10 if rev else 0, f"s{seed}_{name}_{r}", merged, seq, b"".join(tags))))
+        rng = site_rng
     recs.sort(key=lambda t: (t[0], t[1]))
     if tr_frac:
         return list(ref_names), list(ref_lens), [b for _, _, b in recs], tandem

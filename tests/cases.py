@@ -457,3 +457,12 @@ SAMPLES_EMU = {
     "sample_qcnm_auto_18x": (lambda: _sample(11, ref_names=("chr6",), ref_lens=(1_050_000,), cov=18.0, tr_frac=0.2),
                              ("--qc-nm", "--minsupport", "auto")),
 }
+
+
+# populations: several samples sharing SV sites (site_seed), each BAM -> .snf, then the multi-sample merge (config 5 shape)
+POPULATIONS = {
+    "population_4samples_12x": (lambda: [_sample(30 + s, ref_names=("chr8", "chr9"), ref_lens=(1_000_000, 1_000_050), cov=12.0,
+                                                 site_seed=77, site_spacing=12000) for s in range(4)], ()),
+    "population_6samples_mixed": (lambda: [_sample(50 + s, ref_names=("chr11",), ref_lens=(1_000_000,), cov=[8.0, 15.0, 25.0][s % 3],
+                                                   site_seed=78, site_spacing=9000, split_spacing=120000) for s in range(6)], ()),
+}

@@ -105,3 +105,25 @@ def test_contig_selection_reference_vectors():
     assert pipeline.should_process_contig("fragment", 123456, SnifflesConfig(contig=["fragment"]))   # ... unless given by -c
     cfg.regions_by_contig = {"fragment": ("fragment", 0, 123456)}                       # ... or by the regions
     assert pipeline.should_process_contig("fragment", 123456, cfg)
+
+
+@pytest.mark.parametrize("name", sorted(cases.POPULATIONS))
+def test_bams_to_merged_vcf_emu(name, tmp_path):
+    """BASELINE.json configs[4] shape: every sample BAM -> .snf (this package), then the multi-sample merge over those files
+    (this package) - the merged VCF equals the one the unmodified reference produces from the same BAMs through its own
+    .snf files, character by character.  (Emulation tier only: the device runs of the pieces are covered by the GPU tests
+    of SAMPLES, the combine driver and the SNF container.)"""
+    import emu.emu as E
+    build, args = cases.POPULATIONS[name]
+    doc = gu.load(name)
+    recs = build()
+    assert [records_sha(r) for r in recs] == doc["input_sha"]
+    paths = []
+    for s, r in enumerate(recs):
+        path = str(tmp_path / f"sample{s}.snf")
+        pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=getattr(r, "tandem_repeats", None), _lib=E.lib())
+        paths.append(path)
+    buf = io.StringIO()
+    calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=E.lib())
+    assert_same_text(buf.getvalue(), doc["vcf"])
+    assert len(calls) >= len(vu.split_text(doc["vcf"])[1]) > 50
