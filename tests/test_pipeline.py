@@ -30,7 +30,17 @@ def config_for(args):
     kw, a = {}, list(args)
     while a:
         k = a.pop(0)[2:].replace("-", "_")
-        kw[k] = a.pop(0) if a and not a[0].startswith("--") else True
+        if a and not a[0].startswith("--"):
+            v = a.pop(0)
+            for conv in (int, float):
+                try:
+                    v = conv(v)
+                    break
+                except ValueError:
+                    pass
+            kw[k] = v
+        else:
+            kw[k] = True
     cfg = SnifflesConfig(**kw)
     for k, v in vu.FIXED.items():
         setattr(cfg, k, v)
