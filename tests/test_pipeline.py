@@ -137,3 +137,28 @@ def test_bams_to_merged_vcf_emu(name, tmp_path):
     calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=E.lib())
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert len(calls) >= len(vu.split_text(doc["vcf"])[1]) > 50
+
+
+def test_tandem_repeat_file_loader(tmp_path):
+    """sniffles_amd.util.load_tandem_repeats against the reference's function on the same BED (build container), and
+    against a hand-checked table everywhere."""
+    import os
+    import sys
+    from sniffles_amd import util
+    bed = tmp_path / "tr.bed"
+    bed.write_text("chr1\t1000\t1200\tx\nchr1\t300\t400\nchr2\t50\t90\tmotif\t3\nbroken line\nchr2\t700\t900\n")
+    got = util.load_tandem_repeats(str(bed), 500)
+    assert got == {"chr1": [(0, 900), (500, 1700)], "chr2": [(0, 590), (200, 1400)]}
+    # the reference compares a start with the PADDED start of the previous line: 700 after 1000 (padded 500) is "sorted"
+    bed2 = tmp_path / "tr2.bed"
+    bed2.write_text("chr1\t1000\t1200\nchr1\t700\t800\n")
+    assert util.load_tandem_repeats(str(bed2), 500) == {"chr1": [(500, 1700), (200, 1300)]}
+    sys.path.insert(0, os.path.join(os.path.dirname(gu.GOLDEN_DIR), "..", "oracle"))
+    import ref_harness as rh
+    if rh.reference_available():
+        ref = rh.load_reference()
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            want = ref.util.load_tandem_repeats(str(bed), 500)
+            want2 = ref.util.load_tandem_repeats(str(bed2), 500)
+        assert got == want and util.load_tandem_repeats(str(bed2), 500) == want2
