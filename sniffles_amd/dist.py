@@ -6,7 +6,6 @@ torch.distributed on whatever backend the process group has (RCCL on GPUs: backe
 """
 from __future__ import annotations
 
-import numpy as np
 
 from . import abi
 

@@ -11,7 +11,7 @@ import pytest
 import cases
 import golden_util as gu
 import vcf_util as vu
-from sniffles_amd import leadprov, parallel, snf, sv, vcf
+from sniffles_amd import leadprov, parallel, sv, vcf
 from test_combine import make_cfg
 from test_dropin_api import leads_of
 

@@ -1,5 +1,4 @@
 """Shared by the VCF golden generator (reference writer) and the tests (this package's writer)."""
-import re
 
 FIXED = dict(command="sniffles --input sample.bam --vcf out.vcf", start_date="2026/01/01 00:00:00")
 
