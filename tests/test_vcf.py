@@ -218,3 +218,34 @@ def test_reference_writer_agrees_on_its_own_vectors():
             w.write_call(cls(**d))
             out.append(buf.getvalue())
         assert out[0] == out[1] and out[0]
+
+
+def test_formatters_agree_with_the_reference_on_random_values():
+    """format_genotype / format_info against the unmodified reference functions on seeded random inputs (build container)."""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(gu.GOLDEN_DIR), "..", "oracle"))
+    import ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("reference sources not present")
+    rh.load_reference()
+    from sniffles import vcf as ref_vcf
+    rnd = random.Random(7)
+    alleles = [0, 1, "."]
+    phases = [None, (None, None), ("1", 5), ("2", "NULL"), ("1", None), (None, 17), "1", ("2", "7")]
+    for _ in range(400):
+        gt = (rnd.choice(alleles), rnd.choice(alleles), rnd.randint(0, 60), rnd.randint(0, 80), rnd.randint(0, 80), rnd.choice(phases))
+        if rnd.random() < 0.5:
+            gt = gt + (rnd.choice(["NULL", "Sniffles2.INS.1S0", "a,b"]),)
+        for phased in (True, False):
+            def outcome(fn):
+                try:
+                    return fn(gt, phased)
+                except Exception as e:       # e.g. a one-character string as phase: both raise ValueError
+                    return type(e).__name__
+            assert outcome(vcf.format_genotype) == outcome(ref_vcf.format_genotype), (gt, phased)
+    import numpy as np
+    values = [0, 1, -3, 0.5, 1 / 3, 1e-9, 12345.6789, None, True, False, "x", "", ["a", "b"], [], np.float64(2.5), np.int64(4), float("nan")]
+    for v in values:
+        assert vcf.format_info("K", v) == ref_vcf.format_info("K", v), v
