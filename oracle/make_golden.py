@@ -343,12 +343,47 @@ def main_population(names=None):
         print(f"{name:28s} {len(recs)} samples -> {len(vu.split_text(res['vcf'])[1])} merged VCF records")
 
 
+def main_genotype_vcf():
+    """Force calling end to end: a target VCF (the reference's own calls for a sample, perturbed, plus hand-made records) and
+    the sample's BAM through the reference's --genotype-vcf flow (ref_harness.run_reference_genotype_vcf)."""
+    import numpy as np
+    import cases
+    import ref_harness as rh
+    import vcf_util as vu
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    doc = {}
+    for name, seed in (("sample_splits_14x", 3), ("sample_two_contigs_12x", 4)):
+        with gzip.open(os.path.join(out_dir, name + ".json.gz"), "rb") as f:
+            sample = json.loads(f.read().decode())
+        recs = cases.SAMPLES[name][0]()
+        hdr, body = vu.split_text(sample["vcf"])
+        rng = np.random.default_rng(seed)
+        lines = []
+        for ln in body:
+            f = ln.split("\t")
+            if rng.random() < 0.15:
+                continue
+            f[1] = str(max(1, int(f[1]) + int(rng.choice([0, 0, 3, -40, 700]))))
+            lines.append("\t".join(f[:8]))           # a site list: no FORMAT / sample columns
+        lines += ["chr20\t500000\tfar\tN\t<DEL>\t.\tPASS\tSVTYPE=DEL;SVLEN=-300;END=500300",
+                  "chr20\t600001\tseqins\tA\tAGGGTTTCCCAAAGGGTTTCCCAAAGGGTTTCCCAAAGGGTTTCCCAAAGGGTTTCCCAAAGG\t30\tPASS\tPRECISE",
+                  "chrM_short\t100\tshort\tN\t<DEL>\t.\tPASS\tSVTYPE=DEL;SVLEN=-100",
+                  "chr21\t700000\ttra\tN\tN[chr20:12345[\t.\tPASS\tSVTYPE=TRA"]
+        hdr = [h for h in hdr if not h.startswith("##FORMAT=<ID=GQ") and not h.startswith("##FORMAT=<ID=DV")]
+        text = "\n".join(hdr + lines) + "\n"
+        out = rh.run_reference_genotype_vcf(recs, text, (), vu.FIXED)
+        doc[name] = dict(input_sha=records_sha(recs), vcf_in=text, vcf_out=out)
+        print(f"{name:24s} {len(lines)} targets -> {len(vu.split_text(out)[1])} records written")
+    with gzip.GzipFile(os.path.join(out_dir, "genotype_vcf.json.gz"), "wb", mtime=0) as fh:
+        fh.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
 if __name__ == "__main__":
     # python oracle/make_golden.py                 -> every fixture family
     # python oracle/make_golden.py vcf sample      -> only these families
     # python oracle/make_golden.py main fuzz_4_2   -> single cases of the `main` / `combine` families
     FAMILIES = dict(main=main, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
-                    bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype, population=main_population)
+                    bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype, population=main_population, genotype_vcf=main_genotype_vcf)
     argv = sys.argv[1:]
     fams = [a for a in argv if a in FAMILIES] or list(FAMILIES)
     names = set(a for a in argv if a not in FAMILIES)

@@ -559,6 +559,50 @@ def run_reference_population(recs_list, workdir, extra_args=(), fixed=None):
     return dict(vcf=buf.getvalue(), snf=paths)
 
 
+def run_reference_genotype_vcf(recs, vcf_text, extra_args=(), fixed=None):
+    """The reference's `--genotype-vcf` flow in this process: its VCF reader on `vcf_text`, one unmodified
+    GenotypeTask.execute per processed contig (build_leadtab over oracle/pysam_stub), GenotypeResult.emit through the
+    unmodified rewriter.  Returns the output VCF text."""
+    import io
+    import math
+    import struct
+    import pysam_stub
+    ref = load_reference()
+    from sniffles import vcf as ref_vcf
+    cfg = ref.config.SnifflesConfig("--input", "x.bam", "--vcf", "out.vcf", "--genotype-vcf", "in.vcf", *extra_args)
+    cfg.mode = "genotype_vcf"
+    cfg.input_is_cram, cfg.input_mode = False, "rb"
+    for k, v in (fixed or {}).items():
+        setattr(cfg, k, v)
+    vcf_in = ref_vcf.VCF(cfg, io.StringIO(vcf_text))
+    order, by_contig = [], {}
+    for svcall in vcf_in.read_svs_iter():
+        order.append(svcall.raw_vcf_line_index)
+        by_contig.setdefault(svcall.contig, []).append(svcall)
+    flags = [struct.unpack_from("<H", recs.blob, int(o) + 18)[0] for o in recs.rec_off[:-1]]
+    total_mapped = sum(1 for f, r in zip(flags, recs.ref_id.tolist()) if r >= 0 and not f & 0x4)
+    cfg.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
+    contig_lengths = [(c, int(n)) for c, n in zip(recs.ref_names, recs.ref_lens) if ref.util.should_process_contig(c, int(n), cfg)]
+    cfg.contig_lengths = contig_lengths
+    buf = io.StringIO()
+    vcf_out = ref_vcf.VCF(cfg, buf)
+    vcf_out.rewrite_header_genotype(vcf_in.header_str)
+    orig = ref.parallel.pysam.AlignmentFile
+    ref.parallel.pysam.AlignmentFile = lambda *a, **k: pysam_stub.AlignmentFile(recs)
+    try:
+        for task_id, (contig, length) in enumerate(contig_lengths):
+            targets = [t for t in by_contig.get(contig, []) if 0 <= t.pos < length - 1]
+            task = ref.parallel.GenotypeTask(id=task_id, contig=contig, start=0, end=length - 1, assigned_process_id=None,
+                                             tandem_repeats=(getattr(recs, "tandem_repeats", None) or {}).get(contig),
+                                             genotype_svs=targets, sv_id=0, config=cfg, regions=None)
+            result = task.execute()
+            if result is not None:
+                result.emit(vcf_out=vcf_out, genotype_lineindex_order=order)
+    finally:
+        ref.parallel.pysam.AlignmentFile = orig
+    return buf.getvalue()
+
+
 # ---------------------------------------------------------------------------------------------- signature extraction
 def lead_record(ld) -> list:
     """Canonical JSON-able row of one reference Lead as `record_lead` receives it (before the per-bin seq cap)."""

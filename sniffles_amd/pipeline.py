@@ -144,3 +144,40 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
     for f in readers.values():
         f.close()
     return out
+
+
+def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle, tandem_repeats=None, device: int = 0,
+                 _lib=None) -> int:
+    """Force calling (`--genotype-vcf`, sniffles:190-213, 487-560 and `GenotypeTask.execute`): the SVs of the input VCF are
+    matched against this sample's candidates contig by contig and written back with the sample's genotype (contig by
+    contig, input order within a contig).  Returns the number of records written."""
+    import struct
+    config.mode = "genotype_vcf"
+    reader = vcf.VCF(config, vcf_in_handle)
+    by_contig = {}
+    for target in reader.read_svs_iter():
+        by_contig.setdefault(target.contig, []).append(target)
+    flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
+    total_mapped = sum(1 for f, r in zip(flags, records.ref_id.tolist()) if r >= 0 and not f & 0x4)
+    config.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
+    contig_lengths = [(c, int(n)) for c, n in zip(records.ref_names, records.ref_lens) if should_process_contig(c, int(n), config)]
+    config.contig_lengths = contig_lengths
+    writer = vcf.VCF(config, vcf_out_handle)
+    writer.rewrite_header_genotype(reader.header_str)
+    n = 0
+    for task_id, (contig, length) in enumerate(contig_lengths):
+        tr = (tandem_repeats or {}).get(contig)
+        targets = [t for t in by_contig.get(contig, []) if 0 <= t.pos < length - 1]
+        task = parallel.GenotypeTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, tandem_repeats=tr,
+                                     genotype_svs=targets, device=device, _lib=_lib)
+        ti, _ = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
+                                       read_id_offset=task_id * config.task_read_id_offset_mult, task_id=task_id, sv_id_start=0,
+                                       tandem_repeats=tr, device=device, _lib=_lib)
+        config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold
+        task.lead_provider = _Extracted(ti)
+        res = task.execute()
+        task.close()
+        for target in res or []:      # task by task, input order inside a task (GenotypeResult.emit, result.py:118-131);
+            writer.rewrite_genotype(target)      # targets on contigs that are not processed are dropped, like the reference
+            n += 1
+    return n

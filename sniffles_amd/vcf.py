@@ -8,7 +8,8 @@ parity can be stated on the VCF line itself - POS, SVLEN, SVTYPE, GT and every o
 reference's quirks because a drop-in must: with a reference handle the IUPAC clean-up table is applied to the whole
 ALT column (`<INS>` -> `<INN>`, `<DEL>` -> `<NEL>`, `chrY` in a BND ALT -> `chrN`).
 `reference_handle` is any object with pysam's `fetch(contig, start, end) -> str` (raising KeyError / ValueError for an
-unknown contig / range); reading VCFs back (`--genotype-vcf`) is not part of this module.
+unknown contig / range).  The force-calling side (`--genotype-vcf`, vcf.py:352-481) is here too: `read_svs_iter` (targets
+from a VCF), `rewrite_header_genotype`, `rewrite_genotype`.
 """
 from __future__ import annotations
 
@@ -276,3 +277,72 @@ class VCF:
         self.write_raw("\t".join(str(v) for v in row))
         self.call_count += 1
         return 1
+
+    # ---- force calling: targets in, the same lines with this sample's genotype out (vcf.py:352-481)
+    def read_svs_iter(self):
+        """Target SVs of `--genotype-vcf`: one `SVCall` per record of `self.handle` (text or bytes lines); header lines
+        are collected in `self.header_str`.  Type and length come from REF / ALT unless INFO gives SVTYPE (`TRA` = BND),
+        SVLEN, END; a BND's mate is parsed from its ALT.  `call.id` is the 1-based line number, like the reference."""
+        from . import sv
+        self.header_str = ""
+        for line_index, line in enumerate(self.handle, 1):
+            try:
+                if isinstance(line, bytes):
+                    line = line.decode("utf-8")
+                text = line.strip()
+                if text == "":
+                    raise IndexError("string index out of range")     # the reference indexes the empty string here
+                if text[0] == "#":
+                    self.header_str += text + "\n"
+                    continue
+                chrom, pos, _, ref, alt, qual, flt, info_text = line.split("\t")[:8]
+                info = {}
+                for item in info_text.split(";"):
+                    if "=" in item:
+                        key, value = item.split("=")
+                    else:
+                        key, value = item, True
+                    info[key] = value
+                call = sv.SVCall(contig=chrom, pos=int(pos) - 1, id=line_index, ref=ref, alt=alt, qual=int(qual) if qual != "." else None,
+                                 filter=flt, info=info, svtype=None, svlen=None, end=None, rnames=None, qc=True, postprocess=None,
+                                 genotypes=None, precise=None, support=0, fwd=0, rev=0, nm=-1)
+                if len(alt) > len(ref):
+                    call.svtype, call.svlen, call.end = "INS", len(alt), call.pos
+                else:
+                    call.svtype, call.svlen = "DEL", -len(ref)
+                    call.end = call.pos + call.svlen
+                if "SVTYPE" in info:
+                    call.svtype = "BND" if info["SVTYPE"] == "TRA" else info["SVTYPE"]
+                if "SVLEN" in info:
+                    call.svlen = int(info["SVLEN"])
+                if "END" in info:
+                    call.end = int(info["END"])
+                if call.svtype == "BND":
+                    parts = alt.replace("]", "[").split("[")
+                    if len(parts) <= 2:
+                        raise ValueError("BND ALT not formatted according to VCF 4.2 specifications")
+                    mate_contig, mate_pos = parts[1].split(":")
+                    call.bnd_info = sv.SVCallBNDInfo(mate_contig=mate_contig, mate_ref_start=int(mate_pos), is_first=(alt[0] == "N"),
+                                                     is_reverse=("]" in alt))
+                call.raw_vcf_line, call.raw_vcf_line_index = text, line_index
+            except Exception as e:
+                raise ValueError(f"Error parsing input VCF: Line {line_index}: {e}") from e     # the reference exits here
+            yield call
+
+    def rewrite_header_genotype(self, orig_header: str):
+        lines = orig_header.split("\n")
+        cfg = self.config
+        lines[1:1] = [f"##genotypeSource={cfg.version}_{cfg.build}", f'##genotypeCommand="{cfg.command}"',
+                      f'##genotypeFileDate="{cfg.start_date}"']
+        for ident, number, typ, desc in _FORMAT[:4]:          # GT, GQ, DR, DV: added if the input does not declare them
+            if not any(f"##FORMAT=<ID={ident}," in ln for ln in lines):
+                lines.insert(len(lines) - 2, f'##FORMAT=<ID={ident},Number={number},Type={typ},Description="{desc}">')
+        self.write_raw("\n".join(lines), endl="")
+
+    def rewrite_genotype(self, svcall):
+        """The target's own line (first eight columns) with FORMAT and this sample's genotype: the matched candidate's
+        if there is one and it was genotyped, else the reference-allele genotype from the coverage (parallel.py:355-366)."""
+        match = svcall.genotype_match_sv
+        gt = match.genotypes[0] if (match is not None and len(match.genotypes) > 0) else svcall.genotypes[0]
+        cols = svcall.raw_vcf_line.split("\t")[:8] + [self.config.genotype_format, format_genotype(gt, self.config.phase)]
+        self.write_raw("\t".join(cols))
