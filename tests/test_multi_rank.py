@@ -100,7 +100,7 @@ def _queue_worker(rank, world, port, q):
             b.call_candidates(); b.finalize()
             recs.append(b.fetch(1).calls.copy())
         if rank == 1:
-            time.sleep(0.5)
+            time.sleep(1.0)
     claims = sdist.gather_claims(queue.claimed, world)
     cap = 4096
     mine = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
