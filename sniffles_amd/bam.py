@@ -91,9 +91,15 @@ class BamRecords:
         lens = (self.rec_off[idx + 1] - self.rec_off[idx]).astype(np.int64)
         off = np.zeros(idx.shape[0] + 1, np.int64)
         np.cumsum(lens, out=off[1:])
-        blob = np.empty(int(off[-1]), np.uint8)
-        for k, i in enumerate(idx):
-            blob[off[k]:off[k + 1]] = self.blob[self.rec_off[i]:self.rec_off[i + 1]]
+        # consecutive records are one slice (a contig of a coordinate-sorted BAM is a single run)
+        if idx.shape[0]:
+            brk = np.nonzero(np.diff(idx) != 1)[0] + 1
+            starts = np.r_[0, brk]
+            ends = np.r_[brk, idx.shape[0]]
+            parts = [self.blob[int(self.rec_off[idx[a]]):int(self.rec_off[idx[b - 1] + 1])] for a, b in zip(starts.tolist(), ends.tolist())]
+            blob = np.concatenate(parts) if len(parts) > 1 else parts[0].copy()
+        else:
+            blob = np.zeros(0, np.uint8)
         return BamRecords(self.ref_names, self.ref_lens, blob, off, self.ref_id[idx].copy(), self.pos[idx].copy())
 
 
@@ -142,16 +148,18 @@ def records_from_list(ref_names, ref_lens, records) -> BamRecords:
     return BamRecords(list(ref_names), list(ref_lens), blob, offs, rid, pos)
 
 
+def record_flags(recs: BamRecords) -> np.ndarray:
+    """FLAG of every record (uint16 at byte 18 of the record, block_size included)."""
+    o = recs.rec_off[:-1]
+    return recs.blob[o + 18].astype(np.uint16) | (recs.blob[o + 19].astype(np.uint16) << 8)
+
+
 def contig_records(recs: BamRecords, contig: str) -> BamRecords:
     """The mapped records of one contig in file order (what `bam.fetch(contig)` iterates).  A region fetch
     additionally drops records that do not overlap the region; the kernel applies the reference's own
     `reference_start` window (leadprov.py:500), which is the stricter test, so contig granularity is enough."""
     rid = recs.ref_names.index(contig)
-    keep = []
-    for i in np.nonzero(recs.ref_id == rid)[0]:
-        flag = struct.unpack_from("<H", recs.blob, int(recs.rec_off[i]) + 18)[0]
-        if not flag & 0x4:
-            keep.append(int(i))
+    keep = np.nonzero((recs.ref_id == rid) & ((record_flags(recs) & 0x4) == 0))[0] if recs.n else np.zeros(0, np.int64)
     return recs.select(keep)
 
 
@@ -177,8 +185,20 @@ def contig_tables(ref_names):
 
 
 def qname_ranks(recs: BamRecords):
-    """Read names of the records -> (rank per record in Python str order, sorted distinct names)."""
-    names = [recs.qname(i) for i in range(recs.n)]
-    uniq = sorted(set(names))
-    rank = {s: i for i, s in enumerate(uniq)}
-    return np.array([rank[s] for s in names], np.uint32), uniq
+    """Read names of the records -> (rank per record in Python str order, sorted distinct names).  Names are ASCII
+    (SAM spec), so byte order of the NUL-padded names is Python's str order; one `np.unique` over a fixed-width view
+    replaces a Python loop over millions of records."""
+    n = recs.n
+    if n == 0:
+        return np.zeros(0, np.uint32), []
+    o = recs.rec_off[:-1]
+    ln = recs.blob[o + 12].astype(np.int64) - 1                    # l_read_name counts the terminating NUL
+    width = int(ln.max()) if n else 0
+    if width <= 0:
+        return np.zeros(n, np.uint32), [""]
+    col = np.arange(width, dtype=np.int64)
+    idx = (o + 36)[:, None] + col[None, :]
+    mat = np.where(col[None, :] < ln[:, None], recs.blob[np.minimum(idx, recs.blob.shape[0] - 1)], 0).astype(np.uint8)
+    keys = np.ascontiguousarray(mat).view(f"S{width}").reshape(n)
+    uniq, inv = np.unique(keys, return_inverse=True)
+    return inv.astype(np.uint32), [u.decode("ascii") for u in uniq.tolist()]
