@@ -71,20 +71,24 @@ def test_coverage_needs_the_device_batch():
     task.close()
 
 
-@pytest.mark.parametrize("name", ["sample_splits_14x", "sample_two_contigs_12x"])
-def test_genotype_vcf_end_to_end_emu(name):
-    """`--genotype-vcf` end to end: target VCF + BAM -> the target lines with this sample's genotypes, equal character by
-    character to what the unmodified reference writes (its VCF reader, GenotypeTask.execute per contig over the pysam
-    stand-in, its rewriter): header additions, missing FORMAT declarations, TRA -> BND, sequence-resolved records, targets
-    on unprocessed contigs dropped.  (Emulation tier; the device kernels involved are covered by the GPU tests.)"""
+def run_genotype_vcf(name, _lib):
     import io
-    import emu.emu as E
     from sniffles_amd import pipeline
     from test_pipeline import config_for, records_sha
     doc = gu.load("genotype_vcf")[name]
     recs = cases.SAMPLES[name][0]()
     assert records_sha(recs) == doc["input_sha"]
     buf = io.StringIO()
-    n = pipeline.genotype_vcf(recs, config_for(()), io.StringIO(doc["vcf_in"]), buf, _lib=E.lib())
+    n = pipeline.genotype_vcf(recs, config_for(()), io.StringIO(doc["vcf_in"]), buf, _lib=_lib)
     assert buf.getvalue() == doc["vcf_out"]
     assert n == sum(1 for ln in doc["vcf_out"].split("\n") if ln and not ln.startswith("#")) > 50
+
+
+@pytest.mark.parametrize("name", ["sample_splits_14x", "sample_two_contigs_12x"])
+def test_genotype_vcf_end_to_end_emu(name):
+    """`--genotype-vcf` end to end: target VCF + BAM -> the target lines with this sample's genotypes, equal character by
+    character to what the unmodified reference writes (its VCF reader, GenotypeTask.execute per contig over the pysam
+    stand-in, its rewriter): header additions, missing FORMAT declarations, TRA -> BND, sequence-resolved records, targets
+    on unprocessed contigs dropped."""
+    import emu.emu as E
+    run_genotype_vcf(name, E.lib())

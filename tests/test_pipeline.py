@@ -117,13 +117,7 @@ def test_contig_selection_reference_vectors():
     assert pipeline.should_process_contig("fragment", 123456, cfg)
 
 
-@pytest.mark.parametrize("name", sorted(cases.POPULATIONS))
-def test_bams_to_merged_vcf_emu(name, tmp_path):
-    """BASELINE.json configs[4] shape: every sample BAM -> .snf (this package), then the multi-sample merge over those files
-    (this package) - the merged VCF equals the one the unmodified reference produces from the same BAMs through its own
-    .snf files, character by character.  (Emulation tier only: the device runs of the pieces are covered by the GPU tests
-    of SAMPLES, the combine driver and the SNF container.)"""
-    import emu.emu as E
+def run_population(name, tmp_path, _lib):
     build, args = cases.POPULATIONS[name]
     doc = gu.load(name)
     recs = build()
@@ -131,12 +125,21 @@ def test_bams_to_merged_vcf_emu(name, tmp_path):
     paths = []
     for s, r in enumerate(recs):
         path = str(tmp_path / f"sample{s}.snf")
-        pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=getattr(r, "tandem_repeats", None), _lib=E.lib())
+        pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=getattr(r, "tandem_repeats", None), _lib=_lib)
         paths.append(path)
     buf = io.StringIO()
-    calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=E.lib())
+    calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=_lib)
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert len(calls) >= len(vu.split_text(doc["vcf"])[1]) > 50
+
+
+@pytest.mark.parametrize("name", sorted(cases.POPULATIONS))
+def test_bams_to_merged_vcf_emu(name, tmp_path):
+    """BASELINE.json configs[4] shape: every sample BAM -> .snf (this package), then the multi-sample merge over those files
+    (this package) - the merged VCF equals the one the unmodified reference produces from the same BAMs through its own
+    .snf files, character by character."""
+    import emu.emu as E
+    run_population(name, tmp_path, E.lib())
 
 
 def test_tandem_repeat_file_loader(tmp_path):
