@@ -6,10 +6,21 @@ contig task of the workload: binning, clustering, candidate calls, coverage, QC,
 INS consensus) with the signature tables already resident in HBM, INCLUDING the device->host copy of
 the call records / ALT pool and, for N > 1, the RCCL gather of the per-rank call records on rank 0.
 
-Workload at N = 1: BASELINE.json configs[1], "30x ONT HG002 whole-genome germline" restated as a seeded
-synthetic signature set (24 GRCh38 contigs).  N > 1: weak scaling - N genome replicas
-(seed 1..N), the 24*N contig tasks sharded longest-first over the ranks (contigs are independent,
-SURVEY.md 8e); the only collective is the gather of the call records on rank 0 (counts first, then the records).
+Workloads (--config, BASELINE.json `configs`; all seeded synthetic signature sets):
+  0  chr20-only 30x ONT germline (the reference's CPU-runnable plumbing case)
+  1  30x ONT HG002-shaped whole genome, germline           <- default, the configuration the metric is quoted on
+  2  60x PacBio-HiFi-shaped whole genome (INS consensus heavy: err 0.5 %, 15-kb reads)
+  3  30x ONT whole genome, --mosaic (30 % of the sites at VAF 0.05-0.2)
+  4  population merge: 10 HG002-shaped samples -> combine (CombineTask.execute over SNF blocks)
+--scaling weak (default): N genome replicas, the 24*N contig tasks sharded longest-first over the ranks.
+--scaling strong: ONE genome; its contigs are grouped into device batches which the ranks claim from a shared work queue
+  (sniffles_amd.dist.TaskQueue over the process group's store), K passes over the same genome.
+The only collective is the gather of the call records on rank 0 (counts first, then the records).
+
+At N = 1 the line also carries
+  wall_clock    one genome end to end through the drop-in boundary: upload, pass, D2H, SVCall materialisation
+  cpu_baseline  the C oracle over the WHOLE workload, one process per contig on all host cores (the reference's schedule)
+  verified      the HIP results of the exact bench workload compared record by record with that oracle run
 
 Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
@@ -26,15 +37,35 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-CPU_SAMPLE_CONTIGS = ["chr16", "chr17", "chr18", "chr19", "chr20", "chr21", "chr22"]
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# the unmodified reference (CPython) on this path, timed in the build container only (it cannot travel to the GPU box):
+# tools/time_reference.py, profiles/r01_reference_cpu.json
+REFERENCE_CPYTHON = dict(sig_s=34600.0, host="build container, 1 core (profiles/r01_reference_cpu.json: unmodified "
+                                             "Task.call_candidates + finalize_candidates on chr21 + chr22 of configs[1])")
+
+WORKLOADS = {
+    0: dict(name="chr20-only 30x ONT HG002-shaped germline (BASELINE.json configs[0])", contigs=["chr20"], coverage=30.0,
+            gen={}, cfg={}),
+    1: dict(name="30x ONT HG002-shaped whole-genome germline, 24 GRCh38 contigs per replica (BASELINE.json configs[1])",
+            contigs=None, coverage=30.0, gen={}, cfg={}),
+    2: dict(name="60x PacBio-HiFi HG002-shaped whole-genome germline, 24 GRCh38 contigs per replica (BASELINE.json configs[2])",
+            contigs=None, coverage=60.0, gen=dict(err=0.005, read_len_mean=15000.0), cfg={}),
+    3: dict(name="30x ONT HG002-shaped whole genome, --mosaic low-VAF mode (BASELINE.json configs[3])",
+            contigs=None, coverage=30.0, gen=dict(mosaic_frac=0.3), cfg=dict(mosaic=True)),
+}
 
 
-def shard_tasks(n_ranks: int):
-    """(replica, contig) tasks, longest-processing-time-first over ranks.  Deterministic, no communication."""
-    from sniffles_amd import dist as sdist, synth
-    items = [(rep, ci, c) for rep in range(n_ranks) for ci, c in enumerate(synth.CONTIGS)]
-    shards = sdist.shard_lpt([synth.GRCH38[c] for _, _, c in items], n_ranks)
-    return [[items[i] for i in s] for s in shards]
+def task_specs(args, wl, rep: int, g: int, world: int) -> list:
+    """[(contig index, synth.gen_task kwargs)] of one genome replica."""
+    from sniffles_amd import synth
+    contigs = wl["contigs"] or synth.CONTIGS
+    cov = args.coverage if args.coverage is not None else wl["coverage"]
+    out = []
+    for ci, c in enumerate(contigs):
+        L = max(200000, int(synth.GRCH38[c] * args.scale))
+        out.append((ci, dict(task_id=(g * world + rep) * 24 + ci, contig=c, contig_len=L, coverage=cov,
+                             seed=1 + rep + 1000 * g, **wl["gen"])))
+    return out
 
 
 def main():
@@ -42,11 +73,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[i]")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--coverage", type=float, default=None, help="override the workload's coverage (debug; invalid as a result)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every contig (debug only; invalid as a result)")
     ap.add_argument("--genomes", type=int, default=1,
                     help="genome replicas per batch and rank (SURVEY.md 8d scale knob; the headline configuration is 1)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the all-cores oracle run (and with it --verify)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-wall-clock", action="store_true")
+    ap.add_argument("--samples", type=int, default=10, help="config 4: samples of the population")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU (host threads, each with its own batch handle and streams): the "
                          "device->host copies, host waits and launch-bound phases of one pass overlap the kernels of "
@@ -59,7 +95,6 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -81,47 +116,86 @@ def main():
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from sniffles_amd import abi, lib, synth
+    ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist)
+    if args.config == 4:
+        from tools import bench_population
+        out = bench_population.run(ctx)
+    else:
+        out = run_calling(ctx)
+    if rank == 0:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
+        dist.destroy_process_group()
+
+
+# ======================================================================================================== configs 0-3
+def run_calling(ctx):
+    import threading
+
+    import torch
+    import torch.distributed as dist
+
+    from sniffles_amd import abi, dist as sdist, lib, synth
     from sniffles_amd.config import SnifflesConfig
 
-    cfg = SnifflesConfig()  # germline defaults (config.py)
-    my = shard_tasks(world)[rank]
+    args, rank, world, local_rank, use_dist = (ctx[k] for k in ("args", "rank", "world", "local_rank", "use_dist"))
+    wl = WORKLOADS[args.config]
+    cfg = SnifflesConfig(**wl["cfg"])
+    strong = args.scaling == "strong"
+    G = max(1, args.genomes)
     t0 = time.time()
-    tasks = []
-    for g in range(max(1, args.genomes)):
-        for k, (rep, ci, c) in enumerate(my):
-            L = max(200000, int(synth.GRCH38[c] * args.scale))
-            ti = synth.gen_task((g * world + rep) * 24 + ci, c, L, args.coverage, seed=1 + rep + 1000 * g)
-            tasks.append(ti)
+    if strong:
+        # ONE genome; contigs grouped longest-first into 2 device batches per GPU (several contigs per claim amortise the
+        # launch latency of a pass); every rank holds every group so that it can serve whichever it claims
+        specs = task_specs(args, wl, 0, 0, 1)
+        n_groups = max(1, min(len(specs), 2 * world))
+        weights = [kw["contig_len"] for _, kw in specs]
+        groups = [g for g in sdist.shard_lpt(weights, n_groups) if g]
+        group_tasks = [[synth.gen_task(**specs[i][1]) for i in sorted(g)] for g in groups]
+        tasks = [t for gt in group_tasks for t in gt]
+    else:
+        # weak: N genome replicas, (replica, contig) tasks longest-processing-time-first over the ranks
+        items = [(rep, ci, kw) for rep in range(world) for ci, kw in task_specs(args, wl, rep, 0, world)]
+        mine = sdist.shard_lpt([kw["contig_len"] for _, _, kw in items], world)[rank]
+        tasks = []
+        for g in range(G):
+            for i in mine:
+                rep, ci, _ = items[i]
+                kw = dict(task_specs(args, wl, rep, g, world)[ci][1])
+                tasks.append(synth.gen_task(**kw))
+        group_tasks = [tasks]
     n_sig = sum(t.n_leads for t in tasks)
     n_reads = sum(t.n_reads for t in tasks)
     seq_bytes = sum(int(t.seq_pool.nbytes) for t in tasks)
     t_gen = time.time() - t0
 
-    import threading
     W = max(1, args.inflight)
     t0 = time.time()
-    batches = [lib.Batch(cfg, tasks, device=local_rank) for _ in range(W)]  # same input, W independent handles
+    # handles[w][g]: batch handle of group g for host thread w (same input, independent handles)
+    handles = [[lib.Batch(cfg, gt, device=local_rank) for gt in group_tasks] for _ in range(W)]
     t_upload = time.time() - t0
+    batches = [h[0] for h in handles]
 
+    # capacity of a send buffer: weak - the records of one pass of this rank's batch; strong - of one whole-genome pass
     cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
     if use_dist:
         dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # one capacity on every rank
     cap_calls = int(cap_t.item())
     rec_bytes = abi.CALL_DTYPE.itemsize
+    n_send = 2 if strong else W
     if use_dist:
-        sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(W)]
+        sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_send)]
         count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
         # the records are gathered on rank 0 only (one gather at the end; the parent writes the output)
         gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") if rank == 0 else None
         counts = torch.zeros(world, dtype=torch.int64, device="cuda")
         counts_h = torch.zeros(world, dtype=torch.int64).pin_memory()
     # Collectives run on ONE communication thread per rank, in the order the passes finish: a worker thread exports its
-    # records (device-to-device) into the handle's send buffer, queues the handle and goes on with its next pass; the
-    # gather overlaps that pass.  Every rank issues the same (counts, records) sequence, so the order matches everywhere.
+    # records (device-to-device) into a send buffer, queues it and goes on with its next pass; the gather overlaps that
+    # pass.  Every rank issues the same (counts, records) sequence, so the order matches everywhere.
     import queue
     comm_q = queue.Queue()
-    send_free = [threading.Event() for _ in range(W)]
+    send_free = [threading.Event() for _ in range(n_send)]
     for ev in send_free:
         ev.set()
     comm_err = []
@@ -134,19 +208,19 @@ def main():
                 if item is None:
                     comm_q.task_done()
                     return
-                w, nexp = item
+                s, nexp = item
                 count_t.fill_(nexp)
                 dist.all_gather_into_tensor(counts, count_t)          # 8 bytes per rank
                 counts_h.copy_(counts, non_blocking=True)
                 torch.cuda.current_stream().synchronize()              # (releases the GIL while it waits)
                 nmax = int(counts_h.max()) * rec_bytes                 # every rank sends the same, smallest sufficient size
-                chunk = sends[w][:nmax]
+                chunk = sends[s][:nmax]
                 if rank == 0:
                     dist.gather(chunk, gather_list=[gathered[r * nmax:(r + 1) * nmax] for r in range(world)], dst=0)
                 else:
                     dist.gather(chunk, dst=0)
                 torch.cuda.current_stream().synchronize()              # the send buffer may be reused
-                send_free[w].set()
+                send_free[s].set()
                 comm_q.task_done()
         except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
             comm_err.append(e)
@@ -165,9 +239,9 @@ def main():
 
     phase_s = [0.0, 0.0, 0.0, 0.0]
 
-    def step(w):
-        """One full pass of the hot path over batch w: candidates, finalize, D2H of the results, gather."""
-        batch = batches[w]
+    def one_pass(w, g=0):
+        """One full pass of the hot path over group g on thread w's handle: candidates, finalize, D2H of the results."""
+        batch = handles[w][g]
         t_a = time.perf_counter()
         batch.call_candidates()
         t_b = time.perf_counter()
@@ -177,12 +251,6 @@ def main():
         t_d = time.perf_counter()
         if w == 0:
             phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
-        if use_dist:
-            send_free[w].wait()                                        # the previous gather of this handle has left the buffer
-            send_free[w].clear()
-            nexp = batch.export_calls_device(sends[w].data_ptr(), cap_calls)
-            batch.sync()                                               # the copy is on the handle's stream
-            comm_q.put((w, nexp))
         return n
 
     def barrier():
@@ -195,23 +263,21 @@ def main():
 
     n_calls_box = [0]
 
-    def run_passes(total):
-        """Exactly `total` passes, split evenly over the W host threads (thread w works on its own batch handle)."""
+    def run_threads(fn_of_w):
         if W == 1:
-            for _ in range(total):
-                n_calls_box[0] = step(0)
+            fn_of_w(0)
             return
         errs = []
 
-        def worker(w, k):
+        def worker(w):
             try:
                 torch.cuda.set_device(local_rank)
-                for _ in range(k):
-                    n_calls_box[0] = step(w)
+                fn_of_w(w)
             except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
                 errs.append(e)
+                pass_barrier.abort()
 
-        ths = [threading.Thread(target=worker, args=(w, total // W + (1 if w < total % W else 0))) for w in range(W)]
+        ths = [threading.Thread(target=worker, args=(w,)) for w in range(W)]
         for t in ths:
             t.start()
         for t in ths:
@@ -219,7 +285,62 @@ def main():
         if errs:
             raise errs[0]
 
-    run_passes(-(-args.warmup // W) * W)  # >= warmup passes, the same number on every handle
+    def run_passes_weak(total):
+        """Exactly `total` passes, split evenly over the W host threads (thread w works on its own batch handle)."""
+        def body(w):
+            for _ in range(total // W + (1 if w < total % W else 0)):
+                n_calls_box[0] = one_pass(w)
+                if use_dist:
+                    send_free[w].wait()                                # the previous gather of this handle has left the buffer
+                    send_free[w].clear()
+                    nexp = batches[w].export_calls_device(sends[w].data_ptr(), cap_calls)
+                    batches[w].sync()                                  # the copy is on the handle's stream
+                    comm_q.put((w, nexp))
+        run_threads(body)
+
+    pass_barrier = threading.Barrier(W)
+    ng = len(group_tasks)
+    gw = [sum(t.n_leads for t in gt) for gt in group_tasks]
+
+    def run_passes_strong(total):
+        """`total` passes over the ONE genome, one after the other.  Per pass a work queue of the contig groups, heaviest
+        first (sniffles_amd.dist.TaskQueue: one atomic add on the process group's store per claim; a plain counter for a
+        single rank); the W host threads of every rank claim groups and run them on their own handle of the group.  The
+        call records of the groups a rank served are packed into one send buffer and gathered on rank 0 once per pass,
+        on the communication thread, while the next pass is already running."""
+        lock = threading.Lock()
+        if use_dist:
+            queues = [sdist.TaskQueue(gw, key="snf_bench", barrier=False) for _ in range(total)]   # same keys on every rank
+            dist.barrier()
+        else:
+            queues = [sdist.LocalQueue(gw) for _ in range(total)]
+        acc = [0]
+
+        def body(w):
+            for p in range(total):
+                if use_dist and w == 0:
+                    send_free[p % 2].wait()                            # the gather of pass p - 2 has left the buffer
+                    send_free[p % 2].clear()
+                    acc[0] = 0
+                if W > 1:
+                    pass_barrier.wait()
+                for g in queues[p]:
+                    n = one_pass(w, g)
+                    if use_dist:
+                        with lock:
+                            off = acc[0]; acc[0] += n
+                        if off + n > cap_calls:
+                            raise RuntimeError("send buffer too small")
+                        handles[w][g].export_calls_device(sends[p % 2].data_ptr() + off * rec_bytes, cap_calls - off)
+                        handles[w][g].sync()
+                if W > 1:
+                    pass_barrier.wait()                                # every thread of this rank is through pass p
+                if use_dist and w == 0:
+                    comm_q.put((p % 2, acc[0]))
+        run_threads(body)
+
+    run_passes = run_passes_strong if strong else run_passes_weak
+    run_passes(max(1, args.warmup) if strong else -(-args.warmup // W) * W)  # >= warmup passes, the same number on every handle
     barrier()
     t0 = time.perf_counter()
     run_passes(args.steps)
@@ -229,11 +350,11 @@ def main():
     timings = batches[0].timings()  # per-kernel HIP-event times of handle 0's LAST pass in the timed region, on its streams
     # reference point outside the timed region: the same pass with ONE batch in flight (per-pass latency)
     lat_ms = None
-    if W > 1:
+    if W > 1 and not strong:
         barrier()
         t1 = time.perf_counter()
         for _ in range(5):
-            step(0)
+            one_pass(0)
         torch.cuda.synchronize()
         lat_ms = (time.perf_counter() - t1) / 5 * 1e3
     barrier()   # also drains the communication thread before the main thread issues collectives again
@@ -243,10 +364,19 @@ def main():
     tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device="cuda")
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        if not strong:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     dt_max = float(tt.item())
     total_sig, total_calls = int(tot[0].item()), int(tot[1].item())
+    if strong:
+        total_sig = n_sig                    # every rank holds the same ONE genome
+        res_calls = 0
+        for g in range(len(group_tasks)):   # calls of the whole genome (every group once, outside the timed region)
+            res_calls += one_pass(0, g)
+        barrier()
+        total_calls = res_calls
 
+    out = None
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
         value = total_sig * args.steps / dt_max
@@ -259,67 +389,146 @@ def main():
         gpu_ms = sum(k[1] for k in kern)
         achieved = (top[2] / (top[1] * 1e-3)) / 1e9 if top[1] > 0 else 0.0
         # HBM traffic of the dominant kernel: PMC counters can not be read from inside the process; they were collected
-        # with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) on this same workload and are kept, corrected as
-        # the microarch guide prescribes, in profiles/r01_pmc_traffic.json
+        # with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) on configs[1] and are kept, corrected as
+        # the microarch guide prescribes, under profiles/
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-            if top[0] in pmc and args.scale == 1.0 and args.coverage == 30.0:
+            pmc = json.load(open(PMC_FILE))["kernels"]
+            if top[0] in pmc and args.scale == 1.0 and args.coverage is None and args.config == 1 and not strong:
                 traffic = pmc[top[0]]["hbm_bytes"]
         except Exception:
             traffic = None
+        # whole pass against the roofline: SURVEY.md 8(d) algorithmic bytes of one pass (72 B/signature + consensus bytes as
+        # counted by the kernels + 8 B/read + 20 B/call) over the time of one pass
+        cons_bytes = sum(k[2] for k in kern if k[0].startswith(("e45w_consensus", "e4c_copy")))
+        pass_bytes = 72 * n_sig + cons_bytes + 8 * n_reads + 20 * n_calls
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
                         gpu_ms_all_kernels=round(gpu_ms, 3),
+                        whole_pass=dict(algorithmic_bytes=int(pass_bytes),
+                                        achieved=round(pass_bytes / (ms_per_step * 1e-3) / 1e9, 2) if not strong and world == 1 else None,
+                                        frac=round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if not strong and world == 1 else None),
                         top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2]),
                                           **({"ms_one_batch_in_flight": round(timings_alone[k[0]], 4)} if k[0] in timings_alone else {}))
                                      for k in kern[:8]])
+        n_contigs = len(wl["contigs"] or synth.CONTIGS)
         out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32/f64",
+                   ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="int32/f64",
                    data="synthetic",
-                   config=dict(workload="30x ONT HG002-shaped whole-genome germline, 24 GRCh38 contigs per replica "
-                                        "(BASELINE.json configs[1]), synthetic signature tables (SURVEY.md 8d)",
-                               replicas=world, genomes_per_batch=max(1, args.genomes), tasks=24 * world * max(1, args.genomes), coverage=args.coverage, scale=args.scale,
+                   config=dict(workload=wl["name"] + ", synthetic signature tables (SURVEY.md 8d)", baseline_config=args.config,
+                               replicas=1 if strong else world, genomes_per_batch=G,
+                               tasks=n_contigs * (1 if strong else world) * G,
+                               coverage=args.coverage if args.coverage is not None else wl["coverage"], scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
-                               calls=total_calls, parallelism=f"contig-sharded x{world}, RCCL gather of the call records on rank 0",
+                               calls=total_calls,
+                               parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
+                                            if strong else f"contig-sharded x{world}") + ", RCCL gather of the call records on rank 0",
                                batches_in_flight_per_gpu=W,
                                ms_per_pass_one_batch_in_flight=(round(lat_ms, 3) if lat_ms else None),
                                gen_s=round(t_gen, 2), upload_s=round(t_upload, 2),
-                               host_ms_per_step=dict(enqueue_call_candidates=round(phase_s[0] / phase_s[3] * 1e3, 3),
-                                                     finalize_incl_2_syncs=round(phase_s[1] / phase_s[3] * 1e3, 3),
-                                                     fetch_d2h=round(phase_s[2] / phase_s[3] * 1e3, 3))),
+                               host_ms_per_step=dict(enqueue_call_candidates=round(phase_s[0] / max(1, phase_s[3]) * 1e3, 3),
+                                                     finalize=round(phase_s[1] / max(1, phase_s[3]) * 1e3, 3),
+                                                     fetch_d2h=round(phase_s[2] / max(1, phase_s[3]) * 1e3, 3)),
+                               parity_unpinned=["edit distance vs edlib itself (edlib absent; pinned to the exact Levenshtein DP)",
+                                                "pysam stand-in of the extraction oracle (pinned by the reference's 17 known-answer reads)"]),
                    roofline=roofline)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args)
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+        if world == 1 and not strong and G == 1:
+            if not args.no_wall_clock:
+                out["wall_clock"] = wall_clock(cfg, tasks, local_rank)
+            if not args.no_cpu_baseline:
+                got = batches[0].fetch(1) if not args.no_verify else None
+                base, ver = cpu_baseline_and_verify(args, wl, got)
+                out["cpu_baseline"] = base
+                if ver is not None:
+                    out["verified"] = ver["ok"]
+                    out["verify"] = ver
     if comm_thread is not None:
         comm_q.put(None)
         comm_thread.join(timeout=30)
-    for bb in batches:
-        bb.close()
-    if use_dist:
-        dist.destroy_process_group()
+    for hs in handles:
+        for bb in hs:
+            bb.close()
+    return out
 
 
-def cpu_baseline(cfg, args):
-    """Oracle (scalar C restatement of the reference, oracle/snf_oracle.c) timed on this box's host cores on a
-    bounded sample of the same workload.  A reported baseline, not the target."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle
-    from sniffles_amd import synth
-    oracle.build()
-    tis = [synth.gen_task(synth.CONTIGS.index(c), c, max(200000, int(synth.GRCH38[c] * args.scale)), args.coverage, seed=1)
-           for c in CPU_SAMPLE_CONTIGS]
-    n = sum(t.n_leads for t in tis)
+def wall_clock(cfg, tasks, device):
+    """One genome end to end through the drop-in boundary, outside the timed region (milliseconds): `batched` = all
+    contig tasks in one device batch (the library's native shape); `per_task_api` = the reference's own call sequence,
+    Task.call_candidates + Task.finalize_candidates task by task, SVCall objects out (sniffles_amd.parallel)."""
+    from sniffles_amd import lib, parallel, pipeline, sv
     t0 = time.perf_counter()
-    oracle.run(cfg, tis, True)
-    wall = time.perf_counter() - t0
-    hot = oracle.hot_seconds()
-    return dict(value=n / hot, unit="signatures/s", cores=1, kind="port",
-                sample=f"{'+'.join(CPU_SAMPLE_CONTIGS)} of replica 0 ({n} signatures), call_candidates+finalize only: "
-                       f"{hot:.2f}s (wall incl. dense coverage build {wall:.2f}s); host cores available: {os.cpu_count()}")
+    b = lib.Batch(cfg, tasks, device=device)
+    t1 = time.perf_counter()
+    b.call_candidates(); b.finalize(); b.sync()
+    t2 = time.perf_counter()
+    res = b.fetch(1)
+    t3 = time.perf_counter()
+    n = 0
+    for t, ti in enumerate(tasks):
+        lo, hi = int(res.task_call_off[t]), int(res.task_call_off[t + 1])
+        calls = sv.materialize_candidates(res, ti, lo, hi)
+        sv.apply_final(calls, res, ti, lo)
+        n += len(calls)
+    t4 = time.perf_counter()
+    b.close()
+    batched = dict(upload_ms=round((t1 - t0) * 1e3, 2), pass_ms=round((t2 - t1) * 1e3, 2), d2h_ms=round((t3 - t2) * 1e3, 2),
+                   materialise_ms=round((t4 - t3) * 1e3, 2), end_to_end_ms=round((t4 - t0) * 1e3, 2), svcalls=n,
+                   upload_GBps=round(_input_bytes(tasks) / max(1e-9, t1 - t0) / 1e9, 2))
+    t5 = time.perf_counter()
+    n2 = 0
+    for ti in tasks:
+        task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                                 tandem_repeats=None, device=device)
+        task.lead_provider = pipeline._Extracted(ti)
+        cands = task.call_candidates(False, cfg)
+        n2 += len(task.finalize_candidates(cands, True, cfg))
+        task.close()
+    t6 = time.perf_counter()
+    return dict(batched=batched, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
+                note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
+                     "materialise = SVCall Python objects (host)")
+
+
+def _input_bytes(tasks):
+    n = 0
+    for t in tasks:
+        n += sum(int(a.nbytes) for a in t.leads.values()) + int(t.seq_pool.nbytes)
+        n += int(t.read_start.nbytes) + int(t.read_end.nbytes) + int(t.read_hp.nbytes)
+    return n
+
+
+def cpu_baseline_and_verify(args, wl, got):
+    """The C oracle (scalar restatement of the reference, oracle/snf_oracle.c) over the WHOLE workload on this box's host
+    cores: one process per contig task, at most one per core (the reference's schedule, `sniffles:495-530`).  A reported
+    baseline, not the target.  With `got` (the HIP results of the bench batch) the same run is the checker of --verify."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cpu_pool
+    from sniffles_amd import records
+    specs = task_specs(args, wl, 0, 0, 1)
+    r = cpu_pool.run_tasks(specs, wl["cfg"], weights=[kw["contig_len"] for _, kw in specs], want_results=got is not None)
+    n = sum(m["n_leads"] for m in r["items"].values())
+    base = dict(value=n / r["hot_all_core_s"], unit="signatures/s", cores=r["procs"], kind="port",
+                cores_used=r["procs"], host_cores=r["cores"],
+                all_core_sig_s=n / r["hot_all_core_s"], single_core_sig_s=n / r["hot_single_core_s"],
+                reference_cpython_sig_s=REFERENCE_CPYTHON["sig_s"], reference_cpython_host=REFERENCE_CPYTHON["host"],
+                sample=f"the whole workload ({len(specs)} contig tasks, {n} signatures), one oracle process per contig "
+                       f"({r['procs']} processes, longest contig first), call_candidates + finalize_candidates only: slowest "
+                       f"process {r['hot_all_core_s']:.3f} s, sum over tasks {r['hot_single_core_s']:.3f} s "
+                       f"(wall incl. the dense coverage vector each task builds first: {r['wall_s']:.2f} s)")
+    ver = None
+    if got is not None:
+        diffs, n_calls = [], 0
+        for t, (key, _) in enumerate(specs):
+            exp = r["items"][key]["result"]
+            n_calls += int(exp.calls.shape[0])
+            for d in records.diff_results(got, t, exp, 0):
+                diffs.append(f"task {t} ({specs[t][1]['contig']}): {d}")
+        ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls,
+                   what="every field of every call record, ALT bytes, supporting reads and coverage_average_total of the "
+                        "bench batch vs the C oracle on the same inputs", differences=diffs[:5])
+    return base, ver
 
 
 if __name__ == "__main__":

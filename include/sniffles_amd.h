@@ -290,9 +290,13 @@ int snf_device_count(void);
  * replaces: LeadProvider.__init__/record_lead/record_hap_ref/build_leadtab
  * (src/sniffles/leadprov.py:361-472) as the container of one task's signatures. */
 int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out);
-/* copies the task's arrays into pinned staging; may be called n_tasks times */
+/* registers one task; may be called n_tasks times.  The task's arrays are BORROWED until snf_batch_upload returns
+ * (nothing is copied here). */
 int snf_batch_add_task(snf_batch_t* b, const snf_task_input_t* task);
-/* host -> HBM; after this the caller's buffers are no longer referenced */
+/* host -> HBM: host threads validate the tasks and stage their columns into one pinned (process-wide, grow-only) arena,
+ * two large copies move it, kernels derive the packed per-lead records; after this the caller's buffers are no longer
+ * referenced.  A task the reference could not have produced (svtype / hap codes, sequence ranges, a read outside its
+ * region, the byte '-' in a sequence) fails the call. */
 int snf_batch_upload(snf_batch_t* b);
 void snf_batch_destroy(snf_batch_t* b);
 

@@ -13,8 +13,12 @@
 #include <rocprim/device/device_scan.hpp>
 #endif
 
+#include <atomic>
 #include <cmath>
+#include <ctime>
 #include <memory>
+#include <mutex>
+#include <thread>
 
 using namespace snf;
 
@@ -138,24 +142,18 @@ struct snf_batch_impl {
   int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
-  std::vector<int32_t> h_rend_max; // per task: largest read end
+  std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
   bool uploaded = false;
   bool reads_ready = false;       // call_candidates has enqueued the read preparation (sorted ends) for the uploaded tasks
   int run_gap = 1000;
-  // host staging
-  std::vector<snf_task_input_t> tasks;  // scalar fields only (pointers invalid after add)
-  std::vector<int32_t> h_ref_start, h_ref_end, h_qry_start, h_qry_end, h_svlen, h_read_len, h_ps, h_mate_contig,
-      h_mate_pos, h_seq_len, h_lead_task;
-  std::vector<uint32_t> h_qname, h_read_id;
-  std::vector<int64_t> h_seq_off;
-  std::vector<double> h_nm;
-  std::vector<uint8_t> h_svtype, h_strand, h_mapq, h_source, h_hap, h_is_sa, h_first, h_rev, h_pool;
-  std::vector<int32_t> h_rstart, h_rend, h_rtask, h_trs, h_tre, h_trp;
-  std::vector<uint8_t> h_rhp;
-  std::vector<int64_t> h_lead_off{0}, h_read_off{0}, h_tr_off{0};
-  std::vector<int32_t> h_has_tr;
+  // host side of the inputs: the caller's arrays are BORROWED from snf_batch_add_task until snf_batch_upload returns
+  // (validated, staged into pinned memory and copied by the upload); only the scalars are kept afterwards
+  std::vector<snf_task_input_t> tasks;
+  std::vector<int64_t> h_lead_off{0}, h_read_off{0}, h_tr_off{0}, h_pool_off{0};
+  std::vector<int32_t> h_trs, h_tre, h_trp, h_has_tr;
   // device
   std::vector<DevBuf> bufs;
+  uint8_t* slab = nullptr; size_t slab_cap = 0, slab_used = 0, slab_next = (size_t)64 << 20;  // bump allocator (dalloc)
   View v{};
   ReadPrep rp{};
   Counts* h_cnt = nullptr;        // counters as last read back (lives in the pinned result block hb_res)
@@ -178,8 +176,11 @@ struct snf_batch_impl {
 };
 
 // ---- device memory ----
+// dalloc_own: one hipMalloc per buffer (growable scratch that is freed and re-allocated: dfree_one).
+// dalloc: carved out of large slabs - a batch has ~140 arrays that live as long as the batch, and a hipMalloc costs
+// far more than the bump of a pointer (the upload of a task is on the wall clock of the drop-in path).
 template <class T>
-T* dalloc(snf_batch_impl* b, size_t n) {
+T* dalloc_own(snf_batch_impl* b, size_t n) {
   size_t bytes = (n ? n : 1) * sizeof(T);
   void* p = nullptr;
 #ifndef SNF_EMU
@@ -190,6 +191,17 @@ T* dalloc(snf_batch_impl* b, size_t n) {
 #endif
   b->bufs.push_back({p, bytes});
   return (T*)p;
+}
+template <class T>
+T* dalloc(snf_batch_impl* b, size_t n) {
+  const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+  if (b->slab_used + bytes > b->slab_cap) {
+    size_t cap = b->slab_next; if (cap < bytes) cap = bytes;
+    b->slab = dalloc_own<uint8_t>(b, cap); b->slab_cap = cap; b->slab_used = 0;
+  }
+  T* p = (T*)(b->slab + b->slab_used);
+  b->slab_used += bytes;
+  return p;
 }
 void dfree_all(snf_batch_impl* b) {
   for (auto& d : b->bufs) {
@@ -364,7 +376,7 @@ void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* v
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
   if (need > tmpb) {
     if (tmp) { dsync(b); dfree_one(b, tmp); }
-    tmp = dalloc<uint8_t>(b, need); tmpb = need;
+    tmp = dalloc_own<uint8_t>(b, need); tmpb = need;
   }
   Scope s(b, name, n * 2 * (int64_t)(sizeof(K) + 4));
   SNF_HIP(rocprim::radix_sort_pairs(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
@@ -385,7 +397,7 @@ void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* 
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
   if (need > tmpb) {
     if (tmp) { dsync(b); dfree_one(b, tmp); }
-    tmp = dalloc<uint8_t>(b, need); tmpb = need;
+    tmp = dalloc_own<uint8_t>(b, need); tmpb = need;
   }
   if (b->time_all) { Scope s(b, name, n * 2 * (int64_t)sizeof(T));
     SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur)); }
@@ -431,10 +443,121 @@ std::vector<GtEntry> build_gt_lut(const snf_config_t& cfg) {
 int bits_for(uint64_t x) { int b = 0; while (x) { b++; x >>= 1; } return b ? b : 1; }
 
 // ---------------------------------------------------------------------------------------------- upload
+// Host -> HBM in three steps: (1) host threads validate every task and copy its columns into ONE pinned staging arena,
+// at their final place in the batch-wide columns (task after task); (2) two large copies put the arena and the sequence
+// pool into HBM; (3) kernels derive what the pipeline wants besides the columns: the interleaved per-lead records
+// (a6_scatter gathers one 64-B record instead of 20 scattered words), the task of every lead / read.
+// The staging arena is process-wide and grow-only: pinning memory costs more than the copy, so it is paid once.
+struct StageArena {
+  std::mutex mu; void* p = nullptr; size_t cap = 0;
+  void* ensure(size_t bytes) {
+    if (bytes <= cap && p) return p;
+#ifndef SNF_EMU
+    if (p) (void)hipHostFree(p);
+    cap = bytes + bytes / 8 + (1u << 20);
+    SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+#else
+    free(p);
+    cap = bytes + 4096; p = malloc(cap);
+#endif
+    return p;
+  }
+};
+StageArena g_stage;
+
+enum { IC_REF_START = 0, IC_REF_END, IC_QRY_START, IC_QRY_END, IC_SVLEN, IC_READ_LEN, IC_QNAME, IC_READ_ID, IC_PS, IC_MATE_CONTIG,
+       IC_MATE_POS, IC_SEQ_LEN, IC_SEQ_OFF, IC_NM, IC_SVTYPE, IC_STRAND, IC_MAPQ, IC_SOURCE, IC_HAP, IC_IS_SA, IC_FIRST, IC_REV,
+       IC_RSTART, IC_REND, IC_RHP, IC_COUNT };
+const int kInElem[IC_COUNT] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 1, 1, 1, 1, 1, 1, 1, 1, 4, 4, 1};
+
+struct PackView {   // kernels of the upload
+  const int64_t* t_lead_off; const int64_t* t_read_off; int32_t T; int64_t N, R;
+  const int32_t *ref_start, *ref_end, *qry_start, *qry_end, *svlen, *read_len, *ps, *mate_contig, *mate_pos, *seq_len;
+  const uint32_t *qname, *read_id; const int64_t* seq_off;
+  const uint8_t *svtype, *strand, *mapq, *source, *hap, *is_sa, *first, *rev;
+  LeadRec* rec; int32_t* lead_task; int32_t* r_task;
+};
+}  // namespace
+namespace snf {
+SNF_HD int32_t task_of(const int64_t* off, int32_t T, int64_t i) {   // last t with off[t] <= i (empty tasks skipped)
+  int32_t lo = 0, hi = T - 1;
+  while (lo < hi) { const int32_t mid = (lo + hi + 1) >> 1; if (off[mid] <= i) lo = mid; else hi = mid - 1; }
+  return lo;
+}
+SNF_HD void u1_pack_body(int64_t i, const PackView& q) {
+  LeadRec r;
+  r.ref_start = q.ref_start[i]; r.ref_end = q.ref_end[i]; r.qry_start = q.qry_start[i]; r.qry_end = q.qry_end[i];
+  r.svlen = q.svlen[i];
+  const bool hs = q.seq_len[i] >= 0;
+  r.seq_len = hs ? q.seq_len[i] : -1; r.seq_off = hs ? q.seq_off[i] : 0;
+  r.qname = q.qname[i]; r.read_id = q.read_id[i]; r.ps = q.ps[i]; r.mate_pos = q.mate_pos[i];
+  r.mate_contig = q.mate_contig[i]; r.read_len = q.read_len[i]; r.orig = (uint32_t)i;
+  r.strand = q.strand[i]; r.mapq = q.mapq[i]; r.source = q.source[i]; r.hap = q.hap[i];
+  r.is_sa = q.is_sa[i]; r.first = q.first[i]; r.rev = q.rev[i]; r.svtype = q.svtype[i]; r._pad = 0;
+  q.rec[i] = r;
+  q.lead_task[i] = task_of(q.t_lead_off, q.T, i);
+}
+SNF_HD void u2_readtask_body(int64_t r, const PackView& q) { q.r_task[r] = task_of(q.t_read_off, q.T, r); }
+}  // namespace snf
+SNF_KERNEL(u1_pack, PackView)
+SNF_KERNEL(u2_readtask, PackView)
+
+namespace {
+double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
+
+// one task's columns -> their slices of the staging arena; every check of the old element-wise add_task happens here
+void stage_task(const snf_task_input_t& t, int ti, uint8_t* st, const size_t* off, size_t pool_at, int64_t l0, int64_t r0, int64_t p0,
+                int32_t* rend_max) {
+  (void)ti;
+  const int64_t n = t.n_leads, r = t.n_reads;
+  const void* src[22] = {t.ref_start, t.ref_end, t.qry_start, t.qry_end, t.svlen, t.read_len, t.qname_id, t.read_id, t.ps_rank,
+                         t.mate_contig, t.mate_ref_start, t.seq_len, t.seq_off, t.nm, t.svtype, t.strand, t.mapq, t.source, t.hap,
+                         t.is_sa, t.bnd_is_first, t.bnd_is_reverse};
+  for (int c = 0; c < 22; c++) {
+    if (c == IC_SEQ_OFF) continue;
+    if (n) memcpy(st + off[c] + (size_t)l0 * kInElem[c], src[c], (size_t)n * kInElem[c]);
+  }
+  int64_t* so = (int64_t*)(st + off[IC_SEQ_OFF]) + l0;
+  for (int64_t i = 0; i < n; i++) {
+    if (t.svtype[i] >= SNF_NTYPES) fail("svtype code out of range");
+    if (t.hap[i] > 2) fail("hap must be 0, 1 or 2 (leadprov.py:403)");
+    const int32_t sl = t.seq_len[i];
+    if (sl >= 0 && (t.seq_off[i] < 0 || t.seq_off[i] + sl > t.seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
+    so[i] = sl >= 0 ? t.seq_off[i] + p0 : 0;      // rebased into the batch pool
+  }
+  // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' would be a gap there
+  if (t.seq_pool_len > 0) {
+    if (memchr(t.seq_pool, '-', (size_t)t.seq_pool_len)) fail("INS sequences must not contain '-'");
+    memcpy(st + pool_at + (size_t)p0, t.seq_pool, (size_t)t.seq_pool_len);
+  }
+  // reads: BAM order == ascending start; enforce (stable) so the rank queries are valid
+  int32_t* rs = (int32_t*)(st + off[IC_RSTART]) + r0; int32_t* re = (int32_t*)(st + off[IC_REND]) + r0;
+  uint8_t* rh = st + off[IC_RHP] + r0;
+  bool sorted = true;
+  for (int64_t i = 1; i < r; i++) if (t.read_start[i] < t.read_start[i - 1]) { sorted = false; break; }
+  if (sorted) {
+    if (r) { memcpy(rs, t.read_start, (size_t)r * 4); memcpy(re, t.read_end, (size_t)r * 4); memcpy(rh, t.read_hp, (size_t)r); }
+  } else {
+    std::vector<int64_t> ord((size_t)r);
+    for (int64_t i = 0; i < r; i++) ord[(size_t)i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return t.read_start[x] < t.read_start[y]; });
+    for (int64_t i = 0; i < r; i++) { const int64_t k = ord[(size_t)i]; rs[i] = t.read_start[k]; re[i] = t.read_end[k]; rh[i] = t.read_hp[k]; }
+  }
+  int32_t rmax = 0;
+  for (int64_t i = 0; i < r; i++) {
+    const int32_t s = rs[i], e = re[i];
+    if (s < 0 || s >= t.contig_len || e < s) fail("read interval outside the task region (leadprov.py:497-498)");
+    if (rh[i] > 2) fail("read hp must be 0, 1 or 2");
+    if (e > rmax) rmax = e;
+  }
+  *rend_max = rmax;
+}
+
 void do_upload(snf_batch_impl* b) {
   View& v = b->v;
+  const double t_begin = now_ms();
   int T = (int)b->tasks.size();
-  int64_t N = (int64_t)b->h_ref_start.size(), R = (int64_t)b->h_rstart.size(), NTR = (int64_t)b->h_trs.size();
+  int64_t N = b->h_lead_off.back(), R = b->h_read_off.back(), NTR = (int64_t)b->h_trs.size();
   if (T >= (1 << 16)) fail("too many tasks in one batch (max 65535)");
   if (N >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) fail("batch too large for 32-bit lead/read indices");
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
@@ -452,7 +575,10 @@ void do_upload(snf_batch_impl* b) {
     v.key_nbits = v.key_bin_bits + bits_for((uint64_t)(8 * (T > 0 ? T : 1)));
     v.key32 = (!sort64 && v.key_nbits + 1 <= 32) ? 1 : 0;
   }
-  v.pool_len = (int64_t)b->h_pool.size(); v.pool_cap = 2 * v.pool_len + 16;
+  v.pool_len = b->h_pool_off.back(); v.pool_cap = 2 * v.pool_len + 16;
+  // everything allocated below fits one slab of this size (per-lead arrays ~1.9 KB/lead, the pool twice, the reads);
+  // anything beyond it simply opens another slab
+  b->slab_next = (size_t)N * 1408 + (size_t)v.pool_cap + (size_t)R * 96 + ((size_t)4 << 20);
   v.cnt = dalloc<Counts>(b, 1);
   {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
     size_t bytes = sizeof(Counts) + 8 + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8;
@@ -474,44 +600,91 @@ void do_upload(snf_batch_impl* b) {
   v.t_has_tr = upload_vec(b, b->h_has_tr);
   v.t_status = dalloc<int32_t>(b, T + 1); v.t_call_off = dalloc<int64_t>(b, T + 2); v.t_cov_avg = dalloc<double>(b, T + 1);
   v.t_stale_end = dalloc<int32_t>(b, T + 1); v.t_cov_sum = dalloc<unsigned long long>(b, T + 1);
-  v.in_ref_start = upload_vec(b, b->h_ref_start); v.in_ref_end = upload_vec(b, b->h_ref_end);
-  v.in_qry_start = upload_vec(b, b->h_qry_start); v.in_qry_end = upload_vec(b, b->h_qry_end);
-  v.in_svlen = upload_vec(b, b->h_svlen); v.in_read_len = upload_vec(b, b->h_read_len);
-  v.in_qname = upload_vec(b, b->h_qname); v.in_read_id = upload_vec(b, b->h_read_id);
-  v.in_ps = upload_vec(b, b->h_ps); v.in_mate_contig = upload_vec(b, b->h_mate_contig); v.in_mate_pos = upload_vec(b, b->h_mate_pos);
-  v.in_seq_len = upload_vec(b, b->h_seq_len); v.in_seq_off = upload_vec(b, b->h_seq_off); v.in_nm = upload_vec(b, b->h_nm);
-  v.in_svtype = upload_vec(b, b->h_svtype); v.in_strand = upload_vec(b, b->h_strand); v.in_mapq = upload_vec(b, b->h_mapq);
-  v.in_source = upload_vec(b, b->h_source); v.in_hap = upload_vec(b, b->h_hap); v.in_is_sa = upload_vec(b, b->h_is_sa);
-  v.in_first = upload_vec(b, b->h_first); v.in_rev = upload_vec(b, b->h_rev); v.lead_task = upload_vec(b, b->h_lead_task);
-  {  // the same columns interleaved per lead (a6_scatter gathers one 64-B record instead of 20 scattered words)
-    std::vector<LeadRec> recs((size_t)N);
-    for (int64_t i = 0; i < N; i++) {
-      LeadRec& r = recs[(size_t)i];
-      r.ref_start = b->h_ref_start[i]; r.ref_end = b->h_ref_end[i]; r.qry_start = b->h_qry_start[i]; r.qry_end = b->h_qry_end[i];
-      r.svlen = b->h_svlen[i];
-      const bool hs = b->h_seq_len[i] >= 0;
-      r.seq_len = hs ? b->h_seq_len[i] : -1; r.seq_off = hs ? b->h_seq_off[i] : 0;
-      r.qname = b->h_qname[i]; r.read_id = b->h_read_id[i]; r.ps = b->h_ps[i]; r.mate_pos = b->h_mate_pos[i];
-      r.mate_contig = b->h_mate_contig[i]; r.read_len = b->h_read_len[i]; r.orig = (uint32_t)i;
-      r.strand = b->h_strand[i]; r.mapq = b->h_mapq[i]; r.source = b->h_source[i]; r.hap = b->h_hap[i];
-      r.is_sa = b->h_is_sa[i]; r.first = b->h_first[i]; r.rev = b->h_rev[i]; r.svtype = b->h_svtype[i]; r._pad = 0;
-    }
-    v.in_rec = upload_vec(b, recs);
-    dsync(b);  // recs goes out of scope
-  }
+  dsync(b);   // the small host vectors above go out of scope
+  // ---- (1) stage: arena layout = the batch-wide columns back to back (256-B aligned), then the sequence pool
+  size_t off[IC_COUNT]; size_t at = 0;
+  for (int c = 0; c < IC_COUNT; c++) { off[c] = at; at += (((size_t)(c < IC_RSTART ? N : R) * kInElem[c]) + 255) & ~(size_t)255; }
+  const size_t col_bytes = at, pool_at = at;
+  at += ((size_t)v.pool_len + 255) & ~(size_t)255;
+  b->h_rend_max.assign((size_t)T, 0);
+  uint8_t* d_in = dalloc<uint8_t>(b, col_bytes + 256);
   v.pool = dalloc<uint8_t>(b, (size_t)v.pool_cap);
-  h2d(b, v.pool, b->h_pool.data(), b->h_pool.size());
-  v.r_start = upload_vec(b, b->h_rstart); v.r_end = upload_vec(b, b->h_rend); v.r_hp = upload_vec(b, b->h_rhp);
-  v.r_task = upload_vec(b, b->h_rtask);
+  double t_staged = 0, t_copied = 0;
+  std::vector<int32_t> top;
+  {
+    std::lock_guard<std::mutex> hold(g_stage.mu);   // one upload at a time stages through the arena
+    uint8_t* st = (uint8_t*)g_stage.ensure(at + 256);
+    std::vector<int> order((size_t)T);
+    for (int t = 0; t < T; t++) order[(size_t)t] = t;
+    std::sort(order.begin(), order.end(), [&](int x, int y) {   // biggest task first
+      const int64_t wx = b->tasks[x].n_leads * 72 + b->tasks[x].seq_pool_len + b->tasks[x].n_reads * 9;
+      const int64_t wy = b->tasks[y].n_leads * 72 + b->tasks[y].seq_pool_len + b->tasks[y].n_reads * 9;
+      return wx != wy ? wx > wy : x < y; });
+    int nth = (int)std::thread::hardware_concurrency(); if (nth > 16) nth = 16; if (nth > T) nth = T; if (nth < 1) nth = 1;
+    if (const char* e = getenv("SNF_UPLOAD_THREADS")) { nth = atoi(e); if (nth < 1) nth = 1; }
+    std::atomic<int> next{0}; std::mutex emu; std::string err;
+    auto work = [&]() {
+      for (;;) {
+        const int k = next.fetch_add(1);
+        if (k >= T) return;
+        const int t = order[(size_t)k];
+        try {
+          stage_task(b->tasks[(size_t)t], t, st, off, pool_at, b->h_lead_off[(size_t)t], b->h_read_off[(size_t)t], b->h_pool_off[(size_t)t],
+                     &b->h_rend_max[(size_t)t]);
+        } catch (const snf::Error& e) { std::lock_guard<std::mutex> g(emu); if (err.empty()) err = e.msg; }
+      }
+    };
+    if (nth == 1) work();
+    else {
+      std::vector<std::thread> ths;
+      for (int k = 0; k < nth; k++) ths.emplace_back(work);
+      for (auto& th : ths) th.join();
+    }
+    if (!err.empty()) fail(err);
+    for (auto& t : b->tasks) {   // the borrowed arrays are not referenced after this point
+      snf_task_input_t s{}; s.task_id = t.task_id; s.sv_id_start = t.sv_id_start; s.contig_len = t.contig_len; s.ps_null_rank = t.ps_null_rank;
+      s.qc_nm_threshold = t.qc_nm_threshold; s.n_leads = t.n_leads; s.n_reads = t.n_reads; s.n_tr = t.n_tr; s.seq_pool_len = t.seq_pool_len;
+      t = s;
+    }
+    const int32_t* rs_all = (const int32_t*)(st + off[IC_RSTART]);
+    for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(rs_all[r]);
+    t_staged = now_ms();
+    // ---- (2) two large copies
+    h2d(b, d_in, st, col_bytes);
+    h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
+    dsync(b);
+    t_copied = now_ms();
+  }
+  v.in_ref_start = (const int32_t*)(d_in + off[IC_REF_START]); v.in_ref_end = (const int32_t*)(d_in + off[IC_REF_END]);
+  v.in_qry_start = (const int32_t*)(d_in + off[IC_QRY_START]); v.in_qry_end = (const int32_t*)(d_in + off[IC_QRY_END]);
+  v.in_svlen = (const int32_t*)(d_in + off[IC_SVLEN]); v.in_read_len = (const int32_t*)(d_in + off[IC_READ_LEN]);
+  v.in_qname = (const uint32_t*)(d_in + off[IC_QNAME]); v.in_read_id = (const uint32_t*)(d_in + off[IC_READ_ID]);
+  v.in_ps = (const int32_t*)(d_in + off[IC_PS]); v.in_mate_contig = (const int32_t*)(d_in + off[IC_MATE_CONTIG]);
+  v.in_mate_pos = (const int32_t*)(d_in + off[IC_MATE_POS]); v.in_seq_len = (const int32_t*)(d_in + off[IC_SEQ_LEN]);
+  v.in_seq_off = (const int64_t*)(d_in + off[IC_SEQ_OFF]); v.in_nm = (const double*)(d_in + off[IC_NM]);
+  v.in_svtype = d_in + off[IC_SVTYPE]; v.in_strand = d_in + off[IC_STRAND]; v.in_mapq = d_in + off[IC_MAPQ];
+  v.in_source = d_in + off[IC_SOURCE]; v.in_hap = d_in + off[IC_HAP]; v.in_is_sa = d_in + off[IC_IS_SA];
+  v.in_first = d_in + off[IC_FIRST]; v.in_rev = d_in + off[IC_REV];
+  v.r_start = (const int32_t*)(d_in + off[IC_RSTART]); v.r_end = (const int32_t*)(d_in + off[IC_REND]); v.r_hp = d_in + off[IC_RHP];
+  {  // ---- (3) derived on the device
+    PackView q{};
+    q.t_lead_off = v.t_lead_off; q.t_read_off = v.t_read_off; q.T = T; q.N = N; q.R = R;
+    q.ref_start = v.in_ref_start; q.ref_end = v.in_ref_end; q.qry_start = v.in_qry_start; q.qry_end = v.in_qry_end; q.svlen = v.in_svlen;
+    q.read_len = v.in_read_len; q.ps = v.in_ps; q.mate_contig = v.in_mate_contig; q.mate_pos = v.in_mate_pos; q.seq_len = v.in_seq_len;
+    q.qname = v.in_qname; q.read_id = v.in_read_id; q.seq_off = v.in_seq_off;
+    q.svtype = v.in_svtype; q.strand = v.in_strand; q.mapq = v.in_mapq; q.source = v.in_source; q.hap = v.in_hap; q.is_sa = v.in_is_sa;
+    q.first = v.in_first; q.rev = v.in_rev;
+    LeadRec* rec = dalloc<LeadRec>(b, (size_t)N); int32_t* lt = dalloc<int32_t>(b, (size_t)N); int32_t* rt = dalloc<int32_t>(b, (size_t)R);
+    q.rec = rec; q.lead_task = lt; q.r_task = rt;
+    LAUNCH_Q(u1_pack, q, N, N * 136);
+    LAUNCH_Q(u2_readtask, q, R, R * 4);
+    v.in_rec = rec; v.lead_task = lt; v.r_task = rt;
+  }
   v.rk_in = dalloc<uint64_t>(b, R); v.rk_out = dalloc<uint64_t>(b, R); v.rv_in = dalloc<uint32_t>(b, R); v.rv_out = dalloc<uint32_t>(b, R);
   v.re_sorted = dalloc<int32_t>(b, R);
   v.pc_s2 = dalloc<uint64_t>(b, R + 1); v.pc_e2 = dalloc<uint64_t>(b, R + 1);
-  {
-    std::vector<int32_t> top;
-    for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(b->h_rstart[(size_t)r]);
-    v.rs_top = upload_vec(b, top, 1); v.re_top = dalloc<int32_t>(b, top.size() + 1);
-    dsync(b);
-  }
+  v.rs_top = upload_vec(b, top, 1); v.re_top = dalloc<int32_t>(b, top.size() + 1);
+  dsync(b);
   ReadPrep& rp = b->rp;
   {
     std::vector<uint64_t> base((size_t)T + 1, 0);
@@ -561,6 +734,8 @@ void do_upload(snf_batch_impl* b) {
   v.sc_tab = dalloc<int64_t>(b, N1 + 1); v.sc_aln = dalloc<int64_t>(b, N1 + 1); v.sc_rd = dalloc<int64_t>(b, N1 + 1);
   dsync(b);
   b->uploaded = true;
+  if (v.prof) fprintf(stderr, "[SNF_PROF] upload: %.1f ms (stage %.1f, H2D %.1f [%.1f MB], allocations + derived %.1f; %zu device allocations)\n",
+                      now_ms() - t_begin, t_staged - t_begin, t_copied - t_staged, (double)at / 1e6, now_ms() - t_copied, b->bufs.size());
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -768,7 +943,7 @@ void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t 
   if (need <= cap && *p) return;
   if (*p) dfree_one(b, *p);
   cap = need + need / 4 + 64;
-  *p = dalloc<uint8_t>(b, (size_t)cap * elem);
+  *p = dalloc_own<uint8_t>(b, (size_t)cap * elem);
 }
 
 void enqueue_prefetch(snf_batch_impl* b) {
@@ -992,49 +1167,16 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   out->coverage_average_total = b->r_cov.data();
 }
 
-template <class T>
-void append(std::vector<T>& dst, const T* src, int64_t n) { dst.insert(dst.end(), src, src + n); }
-
 void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
   if (b->uploaded) fail("snf_batch_add_task after snf_batch_upload");
   int64_t n = t->n_leads, r = t->n_reads;
-  if (n < 0 || r < 0 || t->contig_len < 0) fail("negative sizes in task input");
-  int ti = (int)b->tasks.size();
-  int64_t pool0 = (int64_t)b->h_pool.size();
-  for (int64_t i = 0; i < n; i++) {
-    if (t->svtype[i] >= SNF_NTYPES) fail("svtype code out of range");
-    if (t->hap[i] > 2) fail("hap must be 0, 1 or 2 (leadprov.py:403)");
-    int32_t sl = t->seq_len[i];
-    if (sl >= 0 && (t->seq_off[i] < 0 || t->seq_off[i] + sl > t->seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
-  }
-  // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' would be a gap there
-  if (t->seq_pool_len > 0 && memchr(t->seq_pool, '-', (size_t)t->seq_pool_len)) fail("INS sequences must not contain '-'");
-  append(b->h_ref_start, t->ref_start, n); append(b->h_ref_end, t->ref_end, n); append(b->h_qry_start, t->qry_start, n);
-  append(b->h_qry_end, t->qry_end, n); append(b->h_svlen, t->svlen, n); append(b->h_read_len, t->read_len, n);
-  append(b->h_qname, t->qname_id, n); append(b->h_read_id, t->read_id, n); append(b->h_ps, t->ps_rank, n);
-  append(b->h_mate_contig, t->mate_contig, n); append(b->h_mate_pos, t->mate_ref_start, n); append(b->h_seq_len, t->seq_len, n);
-  for (int64_t i = 0; i < n; i++) b->h_seq_off.push_back(t->seq_len[i] >= 0 ? t->seq_off[i] + pool0 : 0);
-  append(b->h_nm, t->nm, n); append(b->h_svtype, t->svtype, n); append(b->h_strand, t->strand, n); append(b->h_mapq, t->mapq, n);
-  append(b->h_source, t->source, n); append(b->h_hap, t->hap, n); append(b->h_is_sa, t->is_sa, n);
-  append(b->h_first, t->bnd_is_first, n); append(b->h_rev, t->bnd_is_reverse, n);
-  b->h_lead_task.insert(b->h_lead_task.end(), (size_t)n, ti);
-  append(b->h_pool, t->seq_pool, t->seq_pool_len);
-  // reads: BAM order == ascending start; enforce (stable) so the rank queries are valid
-  std::vector<int64_t> ord((size_t)r);
-  for (int64_t i = 0; i < r; i++) ord[i] = i;
-  bool sorted = true;
-  for (int64_t i = 1; i < r; i++) if (t->read_start[i] < t->read_start[i - 1]) { sorted = false; break; }
-  if (!sorted) std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return t->read_start[x] < t->read_start[y]; });
-  int32_t rmax = 0;
-  for (int64_t i = 0; i < r; i++) {
-    int64_t k = ord[i];
-    int32_t s = t->read_start[k], e = t->read_end[k];
-    if (s < 0 || s >= t->contig_len || e < s) fail("read interval outside the task region (leadprov.py:497-498)");
-    if (t->read_hp[k] > 2) fail("read hp must be 0, 1 or 2");
-    b->h_rstart.push_back(s); b->h_rend.push_back(e); b->h_rhp.push_back(t->read_hp[k]); b->h_rtask.push_back(ti);
-    if (e > rmax) rmax = e;
-  }
-  b->h_rend_max.push_back(rmax);
+  if (n < 0 || r < 0 || t->contig_len < 0 || t->seq_pool_len < 0) fail("negative sizes in task input");
+  if (n > 0 && (!t->ref_start || !t->ref_end || !t->qry_start || !t->qry_end || !t->svlen || !t->read_len || !t->qname_id ||
+                !t->read_id || !t->ps_rank || !t->mate_contig || !t->mate_ref_start || !t->seq_len || !t->seq_off || !t->nm ||
+                !t->svtype || !t->strand || !t->mapq || !t->source || !t->hap || !t->is_sa || !t->bnd_is_first || !t->bnd_is_reverse))
+    fail("null lead column");
+  if (r > 0 && (!t->read_start || !t->read_end || !t->read_hp)) fail("null read column");
+  if (t->seq_pool_len > 0 && !t->seq_pool) fail("null sequence pool");
   int64_t ntr = t->n_tr > 0 ? t->n_tr : 0;
   int32_t pm = INT32_MIN;
   for (int64_t i = 0; i < ntr; i++) {
@@ -1043,11 +1185,11 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
     b->h_trp.push_back(pm);
   }
   b->h_has_tr.push_back(ntr > 0 ? 1 : 0);  // tr None or [] -> no TR handling (cluster.py:229-235)
-  b->h_lead_off.push_back((int64_t)b->h_ref_start.size());
-  b->h_read_off.push_back((int64_t)b->h_rstart.size());
+  b->h_lead_off.push_back(b->h_lead_off.back() + n);
+  b->h_read_off.push_back(b->h_read_off.back() + r);
+  b->h_pool_off.push_back(b->h_pool_off.back() + t->seq_pool_len);
   b->h_tr_off.push_back((int64_t)b->h_trs.size());
-  snf_task_input_t s = *t;
-  b->tasks.push_back(s);
+  b->tasks.push_back(*t);   // the content (values, order of the reads) is checked when the upload stages it
 }
 
 }  // namespace
@@ -1141,9 +1283,9 @@ void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int
     q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
     q.L = b->tasks[(size_t)task_index].contig_len; q.n = n;
     q.binsize = b->cfg.coverage_binsize; q.updown = b->cfg.coverage_updown_bins;
-    int32_t* d_t = dalloc<int32_t>(b, (size_t)n); int32_t* d_p = dalloc<int32_t>(b, (size_t)n); int32_t* d_l = dalloc<int32_t>(b, (size_t)n);
-    uint8_t* d_f = dalloc<uint8_t>(b, (size_t)n);
-    q.end = dalloc<int64_t>(b, (size_t)n); q.cov = dalloc<int32_t>(b, (size_t)n * 5); q.n_valid = dalloc<int32_t>(b, 2);
+    int32_t* d_t = dalloc_own<int32_t>(b, (size_t)n); int32_t* d_p = dalloc_own<int32_t>(b, (size_t)n); int32_t* d_l = dalloc_own<int32_t>(b, (size_t)n);
+    uint8_t* d_f = dalloc_own<uint8_t>(b, (size_t)n);
+    q.end = dalloc_own<int64_t>(b, (size_t)n); q.cov = dalloc_own<int32_t>(b, (size_t)n * 5); q.n_valid = dalloc_own<int32_t>(b, 2);
     h2d(b, d_t, svtype, (size_t)n * 4); h2d(b, d_p, pos, (size_t)n * 4); h2d(b, d_l, svlen, (size_t)n * 4); h2d(b, d_f, bnd_is_first, (size_t)n);
     h2d(b, q.cov, cov, (size_t)n * 20);
     q.svtype = d_t; q.pos = d_p; q.svlen = d_l; q.bnd_is_first = d_f;
@@ -1348,7 +1490,7 @@ int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsiz
     q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
     q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
     q.L = b->tasks[(size_t)task_index].contig_len; q.first_bin = first_bin; q.binsize = binsize;
-    q.out = dalloc<int32_t>(b, (size_t)n_bins);
+    q.out = dalloc_own<int32_t>(b, (size_t)n_bins);
     LAUNCH(s1_blockcov, q, n_bins, (q.hi - q.lo) * 8 + n_bins * 4);
     d2h(b, out, q.out, (size_t)n_bins * 4);
     dsync(b);

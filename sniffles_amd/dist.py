@@ -55,17 +55,26 @@ class TaskQueue:
 
         q = TaskQueue([t.n_leads for t in tasks])
         mine = [i for i in q]           # indices this rank processed, in claim order
-    """
 
-    def __init__(self, weights, store=None, key: str = "snf_task_queue"):
+    Every queue counts on its own store key: `key` plus a per-process generation number, so a second queue in the same
+    process group (another pass, another sample, a retry) starts at zero again.  All ranks must therefore construct
+    their queues in the same order - which they do anyway, a queue being a collective object.  `claim` is thread-safe
+    (the store serialises the adds), so several host threads of a rank may drain one queue."""
+
+    _generation = {}
+
+    def __init__(self, weights, store=None, key: str = "snf_task_queue", barrier: bool = True):
         import torch.distributed as dist
         self.order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
         if store is None:
             from torch.distributed import distributed_c10d
             store = distributed_c10d._get_default_store()
-        self.store, self.key = store, key
+        gen = TaskQueue._generation.get(key, 0)
+        TaskQueue._generation[key] = gen + 1
+        self.store, self.key = store, f"{key}/{gen}"
         self.claimed = []
-        dist.barrier()      # every rank has built the same order before the first claim
+        if barrier:
+            dist.barrier()      # every rank has built the same order before the first claim
 
     def claim(self):
         k = int(self.store.add(self.key, 1)) - 1
@@ -80,6 +89,27 @@ class TaskQueue:
             if i is None:
                 return
             yield i
+
+
+class LocalQueue:
+    """The same interface for a single process (one rank, several host threads): a counter under a lock."""
+
+    def __init__(self, weights):
+        import threading
+        self.order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
+        self._lock, self._next = threading.Lock(), 0
+        self.claimed = []
+
+    def claim(self):
+        with self._lock:
+            k = self._next
+            self._next += 1
+        if k >= len(self.order):
+            return None
+        self.claimed.append(self.order[k])
+        return self.order[k]
+
+    __iter__ = TaskQueue.__iter__
 
 
 def gather_claims(claimed, world: int) -> list:

@@ -79,3 +79,67 @@ def records(res: Result, tasks, stage: str) -> list:
         lo, hi = int(res.task_call_off[t]), int(res.task_call_off[t + 1])
         out.append([record(res, i, tasks, stage) for i in range(lo, hi)])
     return out
+
+
+def diff_results(got: Result, gt: int, exp: Result, et: int, limit: int = 5) -> list:
+    """Vectorised bit-exact comparison of task `gt` of `got` with task `et` of `exp` (whole-genome sized results: no
+    per-call Python objects).  Every field of the call records is compared (NaN == NaN for the float fields that use
+    NaN as "absent"), the ALT bytes and the supporting read ids (as a set per call: `rnames` is `list(set)` in the
+    reference), the task status and coverage_average_total.  Returns human-readable differences (empty = identical)."""
+    import numpy as np
+    out = []
+    sg, se = int(got.task_status[gt]), int(exp.task_status[et])
+    if sg != se:
+        return [f"task status {sg} != {se}"]
+    if sg != 0:
+        return out
+    cg, ce = float(got.coverage_average_total[gt]), float(exp.coverage_average_total[et])
+    if not (cg == ce or (cg != cg and ce != ce)):
+        out.append(f"coverage_average_total {cg!r} != {ce!r}")
+    a = got.calls[int(got.task_call_off[gt]):int(got.task_call_off[gt + 1])]
+    b = exp.calls[int(exp.task_call_off[et]):int(exp.task_call_off[et + 1])]
+    if a.shape[0] != b.shape[0]:
+        return out + [f"call count {a.shape[0]} != {b.shape[0]}"]
+    n = a.shape[0]
+    if n == 0:
+        return out
+    bad = np.zeros(n, bool)
+    names_bad = []
+    for name in a.dtype.names:
+        if name in ("task_index", "alt_off", "rn_off"):
+            continue
+        x, y = a[name], b[name]
+        eq = x == y
+        if x.dtype.kind == "f":
+            eq |= np.isnan(x) & np.isnan(y)
+        if eq.ndim > 1:
+            eq = eq.all(axis=1)
+        if not eq.all():
+            names_bad.append(f"{name} ({int((~eq).sum())} calls, first at {int(np.argmin(eq))})")
+            bad |= ~eq
+    if names_bad:
+        out.append("fields differ: " + ", ".join(names_bad[:limit]))
+        return out   # lengths may differ: the byte comparisons below assume equal alt_len / rn_len
+
+    def gather(pool, off, ln):
+        ln = np.maximum(ln.astype(np.int64), 0)
+        tot = int(ln.sum())
+        seg = np.repeat(np.arange(n, dtype=np.int64), ln)
+        first = np.cumsum(ln) - ln
+        idx = np.repeat(off.astype(np.int64), ln) + (np.arange(tot, dtype=np.int64) - np.repeat(first, ln))
+        return pool[idx], seg
+
+    ba, seg = gather(got.alt_pool, a["alt_off"], a["alt_len"])
+    bb, _ = gather(exp.alt_pool, b["alt_off"], b["alt_len"])
+    ne = ba != bb
+    if ne.any():
+        calls_bad = np.unique(seg[ne])
+        out.append(f"ALT bytes differ in {calls_bad.shape[0]} calls, first call {int(calls_bad[0])} (svtype {int(a['svtype'][calls_bad[0]])}, pos {int(a['pos'][calls_bad[0]])})")
+    ra, seg = gather(got.rnames, a["rn_off"], a["rn_len"])
+    rb, _ = gather(exp.rnames, b["rn_off"], b["rn_len"])
+    ra = ra[np.lexsort((ra, seg))]
+    rb = rb[np.lexsort((rb, seg))]
+    ne = ra != rb
+    if ne.any():
+        out.append(f"supporting reads differ in {np.unique(seg[ne]).shape[0]} calls")
+    return out

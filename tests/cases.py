@@ -328,6 +328,11 @@ SYNTH = {
     "chr18_20x_auto_nm": (lambda: synth.gen_task(4, "chr18", 2_000_000, 20, 6), dict(minsupport="auto", qc_nm=True),
                           ("--minsupport", "auto", "--qc-nm")),
     "chr17_15x_noqc": (lambda: synth.gen_task(5, "chr17", 1_500_000, 15, 7), dict(no_qc=True), ("--no-qc",)),
+    # one reference-run fixture per BASELINE.json config at FULL contig size (chr21, 46.7 Mb; bench.py's own generator
+    # settings for configs[1] / [2] / [3]), so the oracle is pinned at the scale the bench runs it at
+    "chr21_full_30x_ont": (lambda: synth.gen_task(20, "chr21", synth.GRCH38["chr21"], 30, 1), {}, ()),
+    "chr21_full_60x_hifi": (lambda: synth.gen_task(20, "chr21", synth.GRCH38["chr21"], 60, 1, err=0.005, read_len_mean=15000.0), {}, ()),
+    "chr21_full_30x_mosaic": (lambda: synth.gen_task(20, "chr21", synth.GRCH38["chr21"], 30, 1, mosaic_frac=0.3), dict(mosaic=True), ("--mosaic",)),
 }
 
 _FUZZ_CFG = [

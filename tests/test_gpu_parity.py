@@ -155,6 +155,21 @@ def test_hip_matches_oracle_full_size_contigs(oracle_mod):
     assert np.array_equal(got.coverage_average_total, exp.coverage_average_total, equal_nan=True)
 
 
+def test_hip_matches_oracle_on_the_bench_workload(oracle_mod):
+    """The exact workload of bench.py's headline (BASELINE configs[1]: 24 contigs at full GRCh38 size, 30x, replica 0) in
+    ONE batch - the only place where the 31-bit lead keys and the 24-task read-end keys run at full width - against the
+    oracle, task by task: every field of every call, ALT bytes, supporting reads, coverage averages."""
+    tis = [synth.gen_task(ci, c, synth.GRCH38[c], 30.0, 1) for ci, c in enumerate(synth.CONTIGS)]
+    cfg = SnifflesConfig()
+    got = run(cfg, tis, True)
+    n = 0
+    for t, ti in enumerate(tis):
+        exp = oracle_mod.run(cfg, [ti], True)
+        assert records.diff_results(got, t, exp, 0) == [], ti.contig
+        n += len(exp.calls)
+    assert n == len(got.calls) and n > 80000
+
+
 def test_hip_matches_oracle_hifi_60x_and_mosaic(oracle_mod):
     tis = genome(0.004, cov=60, seed=2, err=0.005)
     cfg = SnifflesConfig()

@@ -102,6 +102,18 @@ def _queue_worker(rank, world, port, q):
         if rank == 1:
             time.sleep(1.0)
     claims = sdist.gather_claims(queue.claimed, world)
+    # further queues in the same process group start from zero again (own store key each), also when they are built
+    # ahead of time without a barrier, and several host threads of a rank may drain one queue
+    q2, q3 = sdist.TaskQueue([3, 1, 2, 5], barrier=False), sdist.TaskQueue([1] * 40, barrier=False)
+    dist.barrier()
+    claims2 = sdist.gather_claims(list(q2), world)
+    import threading
+    ths = [threading.Thread(target=lambda: [time.sleep(0.001) for _ in q3]) for _ in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    claims3 = sdist.gather_claims(q3.claimed, world)
     cap = 4096
     mine = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
     off = 0                               # task_index is batch-local (always 0 here): store the position in the claim list
@@ -116,7 +128,7 @@ def _queue_worker(rank, world, port, q):
     if rank == 0:
         keys = sorted((claims[r][int(c["task_index"])], int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]),
                        int(c["support"]), int(c["gt_a"]), int(c["gt_b"])) for r, arr in enumerate(per_rank) for c in arr)
-        q.put((keys, claims))
+        q.put((keys, claims, claims2, claims3))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,7 +147,7 @@ def test_two_rank_task_queue_equals_single_process():
     procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, claims = q.get(timeout=240)
+    got, claims, claims2, claims3 = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -148,3 +160,6 @@ def test_two_rank_task_queue_equals_single_process():
     assert got == exp
     assert sorted(claims[0] + claims[1]) == list(range(len(tasks)))     # every task exactly once
     assert len(claims[0]) > len(claims[1]) >= 1                           # the faster rank came back for more
+    assert sorted(claims2[0] + claims2[1]) == [0, 1, 2, 3]               # a second queue is a fresh queue
+    assert (claims2[0] + claims2[1])[0] in (3,) or 3 in (claims2[0][:1] + claims2[1][:1])   # heaviest claimed first
+    assert sorted(claims3[0] + claims3[1]) == list(range(40))            # threads x ranks: still every item exactly once

@@ -68,3 +68,32 @@ def test_edit_distance_oracle_known_answers(oracle_mod):
     assert ed(b"ACGT", b"") == 4
     assert ed(b"flaw", b"lawn") == 2
     assert ed(b"intention", b"execution") == 5
+
+
+def test_diff_results_agrees_with_record_comparison(oracle_mod):
+    """records.diff_results (the vectorised comparer of bench.py --verify and the full-size GPU test) must see what the
+    per-record comparison sees: identical results -> no differences; any edited field, ALT byte or read id -> reported."""
+    from sniffles_amd import synth
+    from sniffles_amd.config import SnifflesConfig
+    tis = [synth.gen_task(0, "chr22", 3_000_000, 30, 1), synth.gen_fuzz(5, task_id=1)]
+    cfg = SnifflesConfig()
+    a = oracle_mod.run(cfg, tis, True)
+    for t, ti in enumerate(tis):
+        b = oracle_mod.run(cfg, [ti], True)
+        assert records.diff_results(a, t, b, 0) == []
+        lo = int(a.task_call_off[t])
+        k = lo + int(np.argmax(a.calls["alt_len"][lo:int(a.task_call_off[t + 1])] > 0))
+        for field, delta in (("pos", 1), ("stdev_pos", 1e-9), ("gt_gq", 1), ("filter", 1)):
+            c = oracle_mod.run(cfg, [ti], True)
+            c.calls[field][k - lo] += delta
+            assert records.diff_results(a, t, c, 0) != []
+        c = oracle_mod.run(cfg, [ti], True)
+        c.alt_pool[int(c.calls["alt_off"][k - lo])] ^= 1
+        assert any("ALT" in d for d in records.diff_results(a, t, c, 0))
+        c = oracle_mod.run(cfg, [ti], True)
+        c.rnames[int(c.calls["rn_off"][0])] += 1000000
+        assert any("reads" in d for d in records.diff_results(a, t, c, 0))
+        c = oracle_mod.run(cfg, [ti], True)   # the order of the supporting reads of a call is free (list(set))
+        o, n = int(c.calls["rn_off"][0]), int(c.calls["rn_len"][0])
+        c.rnames[o:o + n] = c.rnames[o:o + n][::-1].copy()
+        assert records.diff_results(a, t, c, 0) == []
