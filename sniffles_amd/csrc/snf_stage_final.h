@@ -380,21 +380,21 @@ SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
   return cfg.consensus_kmer_skip_base + (int)((double)L * cfg.consensus_kmer_skip_seqlen_mult);
 }
 
-// size class of a consensus call for the gfx950 workgroup kernel (snf_wave_cons.h): 1 SMALL (256-slot table, 128
-// positions, 64 others), 2 LARGE (1024 / 512 / 512), 0: does not fit its LDS budget -> thread kernels e4/e5/e6
+// size class of a consensus call for the gfx950 workgroup kernels (snf_wave_cons.h): 1 SMALL (256-slot anchor table, 128
+// sampled positions, 64 others, vote counters for 384 columns in LDS), 2 LARGE (1024 / 512 / 254, 8192 columns),
+// 4 ROWS (1024 / 512 / 512, aligned rows in HBM), 0: fits none of them -> thread kernels e4/e5/e6
+#define SNF_CONS_SMALL_L 384
+#define SNF_CONS_LARGE_L 8192
 SNF_HD int cons_class_of(int wave_path, int klen, int skip, int64_t L, int32_t n_others) {
   if (!wave_path || klen > 7 || klen < 1 || skip < 1 || L >= 65000) return 0;
   int64_t npos = cons_npos(L, klen, skip);
-  if (npos <= 120 && n_others <= 64) return 1;
-  if (npos <= 500 && n_others <= 512) return 2;
+  if (npos <= 120 && n_others <= 64 && L <= SNF_CONS_SMALL_L) return 1;
+  if (npos <= 500 && n_others <= 254 && L <= SNF_CONS_LARGE_L) return 2;
+  if (npos <= 500 && n_others <= 512) return 4;
   return 0;
 }
 SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
-  if (!v.wave_path || v.cfg.consensus_kmer_len > 7 || L >= 65000) return 0;
-  int64_t npos = cons_npos(L, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L));
-  if (npos <= 120 && n_others <= 64) return 1;
-  if (npos <= 500 && n_others <= 512) return 2;
-  return 0;
+  return cons_class_of(v.wave_path, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L), L, n_others);
 }
 SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { return cons_class(v, L, n_others) != 0; }
 
@@ -435,7 +435,7 @@ SNF_HD void e2_best_body(int64_t i, const View& v) {
 SNF_HD int64_t class_list_slot(const View& v, int lid) {
 #if defined(__HIP_DEVICE_COMPILE__)
   int64_t slot = 0;
-  for (int c = 0; c < 7; c++) {
+  for (int c = 0; c < 8; c++) {
     const unsigned long long m = __ballot(lid == c);
     if (lid == c) {
       const int lane = (int)__lane_id();
@@ -489,8 +489,9 @@ SNF_HD void e3_emit(int64_t i, const View& v) {
     const int64_t work = (int64_t)d.n_others * d.L;
     lid = work >= 32768 ? 2 : work >= 16384 ? 3 : work >= 8192 ? 4 : 5;
   } else if (d.cls == 3) lid = 6;
+  else if (d.cls == 4) lid = 7;
   const int64_t slot = class_list_slot(v, lid);
-  if (lid < 6) v.cls_list[lid][slot] = (int32_t)cid;   // list 6 (thread kernels e4/e5/e6) is only counted
+  if (lid != 6) v.cls_list[lid][slot] = (int32_t)cid;   // list 6 (thread kernels e4/e5/e6) is only counted
 }
 
 SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
@@ -627,6 +628,54 @@ SNF_HD void e6_vote_body(int64_t col, const View& v) {
     }
   }
   v.alt_pool[col] = out;
+}
+
+// Column vote of the LDS-vote consensus kernels (snf_wave_cons.h; consensus.py:365-380, util.most_common): `cnt4` = four
+// 8-bit counters of the kept other reads' bases at this column (code (c >> 1) & 3: A 0, C 1, T 2, G 3), `esc` = the votes
+// with any other byte as (column << 8 | byte), `bq` = the best read's base, `nkept` = kept other reads of the call.
+// The output base is replaced iff at least 2 votes, votes / (1 + nkept) >= 0.25, more than one distinct character among
+// [bq] + votes and the most common one ((count, char) descending) beats the runner-up by >= 3.
+SNF_HD uint8_t vote_column(uint32_t cnt4, const uint32_t* esc, int n_esc, int q, uint8_t bq, int nkept) {
+  const uint32_t ACTG = 0x47544341u;
+  int ne = 0;
+  for (int a = 0; a < n_esc; a++) ne += (int)(esc[a] >> 8) == q;
+  const int nv = (int)(cnt4 & 0xffu) + (int)((cnt4 >> 8) & 0xffu) + (int)((cnt4 >> 16) & 0xffu) + (int)(cnt4 >> 24) + ne;
+  if (nv < 2 || (double)nv / (double)(1 + nkept) < 0.25) return bq;
+  const int cdb = (bq >> 1) & 3;
+  const bool bq_plain = ((ACTG >> (8 * cdb)) & 0xffu) == bq;
+  int c0 = -1, c1 = -1, k0 = -1, k1 = -1, nd = 0;
+  for (int z = 0; z < 4; z++) {
+    const int cntc = (int)((cnt4 >> (8 * z)) & 0xffu) + ((bq_plain && z == cdb) ? 1 : 0);
+    if (!cntc) continue;
+    const int c = (int)((ACTG >> (8 * z)) & 0xffu);
+    nd++;
+    if (cntc > c0 || (cntc == c0 && c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+    else if (cntc > c1 || (cntc == c1 && c > k1)) { c1 = cntc; k1 = c; }
+  }
+  if (ne > 0 || !bq_plain) {   // rare: characters outside A/C/G/T
+    bool bq_seen = bq_plain;
+    for (int a = 0; a < n_esc; a++) {
+      if ((int)(esc[a] >> 8) != q) continue;
+      const int c = (int)(esc[a] & 0xffu);
+      bool first = true;
+      for (int a2 = 0; a2 < a && first; a2++) if (esc[a2] == esc[a]) first = false;
+      if (!first) continue;
+      int cntc = (c == (int)bq) ? 1 : 0;
+      if (c == (int)bq) bq_seen = true;
+      for (int a2 = a; a2 < n_esc; a2++) cntc += esc[a2] == esc[a];
+      nd++;
+      if (cntc > c0 || (cntc == c0 && c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+      else if (cntc > c1 || (cntc == c1 && c > k1)) { c1 = cntc; k1 = c; }
+    }
+    if (!bq_seen) {
+      const int c = (int)bq, cntc = 1;
+      nd++;
+      if (cntc > c0 || (cntc == c0 && c > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = c; }
+      else if (cntc > c1 || (cntc == c1 && c > k1)) { c1 = cntc; k1 = c; }
+    }
+  }
+  (void)k1;
+  return (nd > 1 && c0 - c1 >= 3) ? (uint8_t)k0 : bq;
 }
 
 }  // namespace snf

@@ -13,9 +13,15 @@
 //      min(L, c0 + j - j0))
 //   4. lane 0 groups consecutive copied segments into runs and applies the run filter
 //      (matches/len > 0.5 and matches > 5)
-//   5. the row is written column-parallel (binary search of the owning segment), coalesced;
-// finally the workgroup votes every column over the rows it just wrote (still in L2).
-// Two size classes: SMALL (<= 120 sampled positions, i.e. L < ~500 bp: ~9 KB LDS, full occupancy) and LARGE.
+//   5. LDS-vote instances (LCAP > 0): the aligned row is never materialised.  Every copied segment of a kept read (one
+//      lane per segment) adds its bases to per-column vote counters in LDS (four 8-bit counters per column, one ds_add
+//      each; any byte other than A/C/G/T goes to a short escape list) - dash columns cost nothing.  The best read, and
+//      in the SMALL class the other read as well, is staged in LDS once (one coalesced pass) and every later phase reads
+//      it from there.  Rows instance (LCAP == 0, calls beyond the LDS budget of the counters, or whose escape list
+//      overflowed): the row is written column-parallel (binary search of the owning segment) to v.aln;
+// finally the workgroup votes every column: from the counters, or over the rows it just wrote (still in L2).
+// Size classes: SMALL (<= 120 sampled positions, <= 384 bp, <= 64 others: ~13 KB LDS), LARGE (<= 500 positions,
+// <= 8192 bp, <= 254 others: 72 KB LDS) and ROWS (<= 500 positions, <= 512 others, < 65000 bp; global rows).
 // Input sequences must not contain '-' (checked at snf_batch_add_task): the reference treats it as a gap.
 #pragma once
 #include "snf_stage_final.h"
@@ -25,19 +31,30 @@ namespace snf {
 
 #define SNF_KEY_EMPTY (~0ull)
 
-template <int SLOTS, int MAXPOS, int MAXOTHERS, int NW>
+template <int SLOTS, int MAXPOS, int MAXOTHERS, int NW, int LCAP, int SCAP, int ECAP>
 struct ConsLdsT {
   unsigned long long key[SLOTS];
   uint32_t pc[SLOTS];              // (position << 16) | occurrence count
   uint8_t kept[MAXOTHERS];
+  uint32_t cnt[LCAP ? LCAP : 1];   // LDS vote: per column four 8-bit counters of the other reads' bases (code 0 A, 1 C, 2 T, 3 G)
+  uint32_t esc[ECAP ? ECAP : 1];   // votes with any other byte: column << 8 | byte
+  uint32_t n_esc;
+  alignas(16) uint8_t best[LCAP ? LCAP + 32 : 16];   // the best read, staged
   struct Wave {
     uint16_t ai[MAXPOS];           // candidates, then accepted anchors: position in best
     uint16_t aj[MAXPOS];           //                                    position in the read
     uint16_t seg_len[MAXPOS];      // clipped advance (columns written)
     uint16_t seg_cm[MAXPOS];       // matches of the copied slice against best at its columns
     uint8_t seg_flag[MAXPOS];      // 0 dashes, 1 copy
+    alignas(16) uint8_t s[SCAP ? SCAP : 16];          // the other read, staged (SMALL)
   } w[NW];
 };
+
+// 16 bytes per lane from an arbitrarily aligned global address into 16-byte aligned LDS
+typedef uint4 __attribute__((aligned(1))) u128_unaligned;
+SNF_D void stage16(uint8_t* dst_lds, const uint8_t* src, int nbytes, int tid, int nthreads) {
+  for (int o = tid * 16; o < nbytes; o += nthreads * 16) *(uint4*)(dst_lds + o) = *(const u128_unaligned*)(src + o);
+}
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 SNF_D uint64_t load_u64(const uint8_t* p) { return *(const u64_unaligned*)p; }  // pool has >= 16 B of slack
@@ -66,6 +83,8 @@ SNF_D int wave_max_incl(int x, int lane) {
 SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
   return (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)x));
 }
+
+#define SNF_ACTG 0x47544341u  /* byte z = the base with code z, code(c) = (c >> 1) & 3: A 0, C 1, T 2, G 3 */
 
 // CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
 // NW: waves per workgroup (= per call).  4: the reads of a call are spread over four waves; 1: a call is one wave's work
