@@ -157,12 +157,13 @@ def run_calling(ctx):
         # weak: N genome replicas, (replica, contig) tasks longest-processing-time-first over the ranks
         items = [(rep, ci, kw) for rep in range(world) for ci, kw in task_specs(args, wl, rep, 0, world)]
         mine = sdist.shard_lpt([kw["contig_len"] for _, _, kw in items], world)[rank]
-        tasks = []
+        tasks, task_keys = [], []
         for g in range(G):
             for i in mine:
                 rep, ci, _ = items[i]
                 kw = dict(task_specs(args, wl, rep, g, world)[ci][1])
                 tasks.append(synth.gen_task(**kw))
+                task_keys.append(ci)      # batch order is longest-contig-first, not contig order
         group_tasks = [tasks]
     n_sig = sum(t.n_leads for t in tasks)
     n_reads = sum(t.n_reads for t in tasks)
@@ -439,7 +440,7 @@ def run_calling(ctx):
                 out["wall_clock"] = wall_clock(cfg, tasks, local_rank)
             if not args.no_cpu_baseline:
                 got = batches[0].fetch(1) if not args.no_verify else None
-                base, ver = cpu_baseline_and_verify(args, wl, got)
+                base, ver = cpu_baseline_and_verify(args, wl, got, task_keys)
                 out["cpu_baseline"] = base
                 if ver is not None:
                     out["verified"] = ver["ok"]
@@ -499,7 +500,7 @@ def _input_bytes(tasks):
     return n
 
 
-def cpu_baseline_and_verify(args, wl, got):
+def cpu_baseline_and_verify(args, wl, got, task_keys):
     """The C oracle (scalar restatement of the reference, oracle/snf_oracle.c) over the WHOLE workload on this box's host
     cores: one process per contig task, at most one per core (the reference's schedule, `sniffles:495-530`).  A reported
     baseline, not the target.  With `got` (the HIP results of the bench batch) the same run is the checker of --verify."""
@@ -520,11 +521,12 @@ def cpu_baseline_and_verify(args, wl, got):
     ver = None
     if got is not None:
         diffs, n_calls = [], 0
-        for t, (key, _) in enumerate(specs):
+        contig_of = {key: kw["contig"] for key, kw in specs}
+        for t, key in enumerate(task_keys):     # task t of the bench batch is the contig with this key
             exp = r["items"][key]["result"]
             n_calls += int(exp.calls.shape[0])
             for d in records.diff_results(got, t, exp, 0):
-                diffs.append(f"task {t} ({specs[t][1]['contig']}): {d}")
+                diffs.append(f"task {t} ({contig_of[key]}): {d}")
         ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls,
                    what="every field of every call record, ALT bytes, supporting reads and coverage_average_total of the "
                         "bench batch vs the C oracle on the same inputs", differences=diffs[:5])
