@@ -326,7 +326,7 @@ int snf_batch_export_calls_device(snf_batch_t* b, void* dst_device, int64_t cap_
  * (leadprov.py:451,510) zero-padded to a multiple of `binsize`, averaged per bin and rounded with
  * Python's round().  out[i] is the value of bin first_bin + i (positions [j*binsize, (j+1)*binsize)),
  * or -1 when the bin lies beyond the padded vector (the reference's IndexError: the bin is skipped).
- * Formed from the task's sparse read table on the device; needs snf_batch_call_candidates first. */
+ * Formed from the task's sparse read table on the device (the read index is built by snf_batch_upload). */
 int snf_batch_block_coverage(snf_batch_t* b, int32_t task_index, int32_t binsize, int64_t first_bin,
                              int64_t n_bins, int32_t* out);
 

@@ -201,6 +201,23 @@ SNF_HD int64_t bound_top_i32(const int32_t* a, const int32_t* top, int64_t lo, i
   return UPPER ? upper_bound_i32(a, nlo, nhi, x) : lower_bound_i32(a, nlo, nhi, x);
 }
 
+// upper bound of x in a[lo, hi) starting from a position `hint` in [lo, hi] where a nearby query ended: gallops away from
+// the hint (1, 2, 4, ... entries) and bisects the bracket.  Same result as upper_bound_i32; a query a few hundred bp from
+// the previous one stays inside the cache lines that one brought in.
+SNF_HD int64_t upper_bound_hint_i32(const int32_t* a, int64_t lo, int64_t hi, int64_t x, int64_t hint) {
+  int64_t l, h;
+  if (hint < hi && (int64_t)a[hint] <= x) {        // answer is right of the hint
+    int64_t step = 1; l = hint + 1; h = l;
+    while (h < hi && (int64_t)a[h] <= x) { l = h + 1; h += step; step <<= 1; }
+    if (h > hi) h = hi;
+  } else {                                          // a[hint] > x (or hint == hi): answer is at or left of the hint
+    int64_t step = 1; h = hint; l = h;
+    while (l > lo && (int64_t)a[l - 1] > x) { h = l - 1; l -= step; step <<= 1; }
+    if (l < lo) l = lo;
+  }
+  return upper_bound_i32(a, l, h, x);
+}
+
 // numpy's pairwise float64 summation (np.sum / np.nanmean, used by parallel.py:214), gather form:
 // element i is get(i).  Iterative restatement of the recursion; DEPTH = frames needed: n <= 128 * 2^(DEPTH-1)
 // (one frame for n <= 128: the wave kernels only see clusters of <= 64 leads and must not carry a 1.5 KB stack)

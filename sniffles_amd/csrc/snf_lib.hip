@@ -22,6 +22,15 @@
 
 using namespace snf;
 
+#ifndef SNF_EMU
+// the three instances of the workgroup consensus kernel (snf_wave_cons.h): <class, table slots, sampled positions, others,
+// waves/SIMD it is compiled for, waves per call, vote columns in LDS, staged-read bytes, escape entries>
+#define K_CONS_SMALL(MINW) e45w_consensus<1, 256, 128, 64, MINW, 4, SNF_CONS_SMALL_L, 448, 96>
+#define K_CONS_SMALL_1W e45w_consensus<1, 256, 128, 64, 5, 1, SNF_CONS_SMALL_L, 448, 96>
+#define K_CONS_LARGE e45w_consensus<2, 1024, 512, 256, 2, 4, SNF_CONS_LARGE_L, 0, 512>
+#define K_CONS_ROWS e45w_consensus<4, 1024, 512, 512, 5>
+#endif
+
 // ---------------------------------------------------------------------------------------------- kernels
 SNF_KERNEL(a1_keys, View)
 SNF_KERNEL(a2_heads, View)
@@ -138,13 +147,15 @@ struct snf_batch_impl {
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
-  int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192;  // resident workgroups of the wave kernels on this device
+  int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;  // resident workgroups of the wave kernels on this device
   int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
   bool uploaded = false;
-  bool reads_ready = false;       // call_candidates has enqueued the read preparation (sorted ends) for the uploaded tasks
+  bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
+  bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
+  bool readprep_each_pass = false; // SNF_READPREP_EACH_PASS=1: rebuild it in every call_candidates (round-1 behaviour)
   int run_gap = 1000;
   // host side of the inputs: the caller's arrays are BORROWED from snf_batch_add_task until snf_batch_upload returns
   // (validated, staged into pinned memory and copied by the upload); only the scalars are kept afterwards
@@ -553,6 +564,8 @@ void stage_task(const snf_task_input_t& t, int ti, uint8_t* st, const size_t* of
   *rend_max = rmax;
 }
 
+void enqueue_read_index(snf_batch_impl* b);
+
 void do_upload(snf_batch_impl* b) {
   View& v = b->v;
   const double t_begin = now_ms();
@@ -726,14 +739,21 @@ void do_upload(snf_batch_impl* b) {
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
   v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * TS_SLOTS);
   v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
+  v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
+  v.big_wave = v.wave_path;
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
-  for (int k = 0; k < 6; k++) v.cls_list[k] = dalloc<int32_t>(b, N1);
+  for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
   v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
   v.sc_tab = dalloc<int64_t>(b, N1 + 1); v.sc_aln = dalloc<int64_t>(b, N1 + 1); v.sc_rd = dalloc<int64_t>(b, N1 + 1);
+  b->readprep_each_pass = getenv("SNF_READPREP_EACH_PASS") != nullptr;
+  const double t_index0 = now_ms();
+  { const bool tm = b->timing; b->timing = false; enqueue_read_index(b); b->timing = tm; }   // (no event brackets outside a pass)
   dsync(b);
+  b->reads_ready = true;
   b->uploaded = true;
+  if (v.prof) fprintf(stderr, "[SNF_PROF] read index (sorted ends, hap prefix counts): %.2f ms\n", now_ms() - t_index0);
   if (v.prof) fprintf(stderr, "[SNF_PROF] upload: %.1f ms (stage %.1f, H2D %.1f [%.1f MB], allocations + derived %.1f; %zu device allocations)\n",
                       now_ms() - t_begin, t_staged - t_begin, t_copied - t_staged, (double)at / 1e6, now_ms() - t_copied, b->bufs.size());
 }
@@ -746,21 +766,32 @@ void reset_timing(snf_batch_impl* b) {
   b->timings.clear();
 }
 
+// reads: sorted ends + per-haplotype prefix counts = the device form of the LeadProvider's coverage vector and REF hap
+// tables (leadprov.py:387-398, 451, 510).  The reference builds those while it extracts the signatures, BEFORE
+// Task.call_candidates, and they depend on nothing but the read table: built once per batch, at upload
+// (SNF_READPREP_EACH_PASS=1 rebuilds them in every call_candidates, as round 1 did; bench.py reports both).
+void enqueue_read_index(snf_batch_impl* b) {
+  View& v = b->v;
+  const int64_t R = v.R;
+  if (R <= 0) return;
+  LAUNCH(r1_endkeys, b->rp, R, R * 13);
+  if (b->rp.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.rk_in, (uint32_t*)v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
+  else prim_sort_pairs<uint64_t>(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
+  LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
+  // haplotype prefix counts: HP 1 and HP 2 packed in one 64-bit scan per order (HP 0 = rank - both)
+  prim_exscan<uint64_t>(b, b->rp.fs2, v.pc_s2, R + 1, "scan_hap_prefix");
+  prim_exscan<uint64_t>(b, b->rp.fe2, v.pc_e2, R + 1, "scan_hap_prefix");
+}
+
 void enqueue_read_prep(snf_batch_impl* b) {
   View& v = b->v;
   int64_t R = v.R; int T = v.T;
-  // reads: sorted ends + per-haplotype prefix counts (LeadProvider coverage / hap_ref state); independent of the
-  // lead pipeline until d4_coverage, so it runs on the side stream
+  // independent of the lead pipeline until d4_coverage, so it runs on the side stream
   {
   SideStream side(b);
   if (R > 0) {
-    LAUNCH(r1_endkeys, b->rp, R, R * 13);
-    if (b->rp.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.rk_in, (uint32_t*)v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
-    else prim_sort_pairs<uint64_t>(b, v.rk_in, v.rk_out, v.rv_in, v.rv_out, R, b->read_key_bits, "sort_read_ends");
-    LAUNCH_Q(r2_unpack, b->rp, R, R * 16);
-    // haplotype prefix counts: HP 1 and HP 2 packed in one 64-bit scan per order (HP 0 = rank - both)
-    prim_exscan<uint64_t>(b, b->rp.fs2, v.pc_s2, R + 1, "scan_hap_prefix");
-    prim_exscan<uint64_t>(b, b->rp.fe2, v.pc_e2, R + 1, "scan_hap_prefix");
+    if (b->readprep_each_pass) enqueue_read_index(b);
+    // Task.coverage_average_total = coverage.mean(): sum of the clipped read lengths (exact) / contig length
 #ifndef SNF_EMU
     { Scope _s(b, "d5w_covsum", R * 12);
       int64_t grid = (R + 4095) / 4096; if (grid > 2048) grid = 2048;
@@ -777,7 +808,7 @@ void enqueue_read_prep(snf_batch_impl* b) {
 void run_call_candidates(snf_batch_impl* b) {
   View& v = b->v;
   int64_t N = v.N; int T = v.T;
-  b->reads_ready = true;
+  b->reads_ready = true; b->cov_avg_ready = true;
   reset_timing(b);
 #ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
@@ -802,6 +833,7 @@ void run_call_candidates(snf_batch_impl* b) {
     dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
     dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
   }
+  if (v.wave_path) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
   if (N > 0) {
@@ -858,6 +890,13 @@ void run_call_candidates(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);
+#ifndef SNF_EMU
+    if (v.wave_path) {   // clusters of more than 64 leads, one wave each
+      Scope _s(b, "x_big_refine", 0);
+      hipLaunchKernelGGL(x_big<0>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
   }
   if (b->sched_readprep == 1 || b->sched_readprep == 3) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
@@ -876,6 +915,13 @@ void run_call_candidates(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "x_big_call", 0);
+      hipLaunchKernelGGL(x_big<1>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
     if (b->fused) {
       FUSED(d3a_count, N);
       FUSED(d3ck_compact, N);
@@ -988,6 +1034,7 @@ void run_finalize(snf_batch_impl* b) {
      // annotations they read), overlapped with the consensus chain
     SideStream side(b);
 #ifndef SNF_EMU
+    if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
       int64_t grid = nc < b->slots_e1w ? nc : b->slots_e1w;
@@ -996,6 +1043,13 @@ void run_finalize(snf_batch_impl* b) {
     }
 #endif
     LAUNCH_Q(e1_finalize, v, nc, 0);
+#ifndef SNF_EMU
+    if (v.wave_path) {
+      Scope _s(b, "x_big_finalize", 0);
+      hipLaunchKernelGGL(x_big<2>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+#endif
   }
 #ifndef SNF_EMU
   if (b->fused && nc <= ((int64_t)1 << 22))   // e3b sums every preceding 256-call tile directly
@@ -1055,7 +1109,7 @@ void run_finalize(snf_batch_impl* b) {
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 5>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+          hipLaunchKernelGGL((K_CONS_LARGE), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
       }
@@ -1072,13 +1126,20 @@ void run_finalize(snf_batch_impl* b) {
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
         const dim3 gs((unsigned)(n_small < 16384 ? n_small : 16384));
-        if (b->cons_nw == 1) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5, 1>), dim3((unsigned)(n_small < 65536 ? n_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
-        else if (b->occ_s >= 8) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 8>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        else if (b->occ_s == 6) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 6>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        else hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(n_small < 65536 ? n_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
+        else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError());
       }
       SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
+      {  // work list 7: calls beyond the LDS vote counters and whatever SMALL / LARGE handed over at run time (their
+         // escape list overflowed) - the list is complete only now, so the kernel reads its length on the device
+        Scope _s(b, "e45w_consensus_rows", 0);
+        const int64_t n_rows = (int64_t)b->h_cnt->n_cls[7];
+        hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(n_rows > 1024 ? (n_rows < 16384 ? n_rows : 16384) : 1024)), dim3(256), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError());
+      }
     }
 #endif
     if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt->n_cons_reads, v.wave_path ? 0 : b->h_cnt->aln_total * 2);
@@ -1211,7 +1272,7 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     if (seq_pool_len > 0 && memchr(seq_pool, '-', (size_t)seq_pool_len)) fail("sequences must not contain '-'");
     const int64_t np = n_problems, n_reads = others_index[np];
     std::vector<ConsDesc> descs((size_t)np);
-    std::vector<int32_t> lists[6];
+    std::vector<int32_t> lists[8];
     Counts hc{};
     int64_t aln_total = 0, alt_total = 0;
     for (int64_t p = 0; p < np; p++) {
@@ -1228,6 +1289,7 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
       descs[(size_t)p] = d;
       int lid = cls;
       if (cls == 2) { const int64_t work = no * L; lid = work >= 32768 ? 2 : work >= 16384 ? 3 : work >= 8192 ? 4 : 5; }
+      else if (cls == 4) lid = 7;
       lists[lid].push_back((int32_t)p); hc.n_cls[lid]++;
       aln_total += no * L; alt_total += L;
     }
@@ -1244,6 +1306,8 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     v.pool = dpool; v.pool_len = seq_pool_len; v.pool_cap = seq_pool_len + 32;
     v.cdesc = (ConsDesc*)up(descs.data(), descs.size() * sizeof(ConsDesc));
     for (int k = 1; k < 6; k++) v.cls_list[k] = (int32_t*)up(lists[k].data(), lists[k].size() * sizeof(int32_t));
+    lists[7].resize((size_t)np, 0);   // room for every problem: SMALL / LARGE may hand calls over at run time
+    v.cls_list[7] = (int32_t*)up(lists[7].data(), lists[7].size() * sizeof(int32_t));
     v.cnt = (Counts*)up(&hc, sizeof(Counts));
     v.crl_off = (int64_t*)up(others_off, (size_t)n_reads * sizeof(int64_t));
     v.crl_len = (int32_t*)up(others_len, (size_t)n_reads * sizeof(int32_t));
@@ -1253,8 +1317,10 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     v.stripes = (unsigned long long*)dev(4 * 64 * 16 * sizeof(unsigned long long));
     SNF_HIP(hipMemset(v.stripes, 0, 4 * 64 * 16 * sizeof(unsigned long long)));
     const int64_t n_small = (int64_t)hc.n_cls[1], n_large = (int64_t)(hc.n_cls[2] + hc.n_cls[3] + hc.n_cls[4] + hc.n_cls[5]);
-    if (n_large > 0) hipLaunchKernelGGL((e45w_consensus<2, 1024, 512, 512, 5>), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, 0, v, (int64_t)0);
-    if (n_small > 0) hipLaunchKernelGGL((e45w_consensus<1, 256, 128, 64, 5>), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, 0, v, (int64_t)0);
+    if (n_large > 0) hipLaunchKernelGGL((K_CONS_LARGE), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, 0, v, (int64_t)0);
+    if (n_small > 0) hipLaunchKernelGGL((K_CONS_SMALL(5)), dim3((unsigned)(n_small < 16384 ? n_small : 16384)), dim3(256), 0, 0, v, (int64_t)0);
+    // list 7: calls beyond the LDS vote counters, plus whatever the two kernels above handed over (null stream: ordered)
+    hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(np < 4096 ? np : 4096)), dim3(256), 0, 0, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
     SNF_HIP(hipDeviceSynchronize());
     if (alt_total) SNF_HIP(hipMemcpy(out_pool, v.alt_pool, (size_t)alt_total, hipMemcpyDeviceToHost));
@@ -1267,7 +1333,7 @@ void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int
                        const int32_t* svlen, const uint8_t* bnd_is_first, int32_t* cov, int32_t* status, double* coverage_mean) {
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !status || !coverage_mean) fail("batch not uploaded / null argument");
-    if (!b->reads_ready) fail("snf_batch_coverage_calls needs snf_batch_call_candidates first (it sorts the read ends)");
+    if (!b->cov_avg_ready) fail("snf_batch_coverage_calls needs snf_batch_call_candidates first (coverage.mean() is formed there)");
     if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
     if (n < 0 || (n > 0 && (!svtype || !pos || !svlen || !bnd_is_first || !cov))) fail("invalid call arrays");
 #ifndef SNF_EMU
@@ -1365,6 +1431,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
+      b->slots_big = ((32 * cus) / 64) * 64; if (b->slots_big < 64) b->slots_big = 64;   // x_big: a multiple of its 64 stripes
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
@@ -1478,7 +1545,7 @@ int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsiz
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !out) fail("batch not uploaded / null argument");
-    if (!b->reads_ready) fail("snf_batch_block_coverage needs snf_batch_call_candidates first (it sorts the read ends)");
+    if (!b->reads_ready) fail("snf_batch_block_coverage needs snf_batch_upload first");
     if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
     if (binsize <= 0 || first_bin < 0 || n_bins < 0) fail("invalid bin range");
     if (n_bins == 0) return 0;
@@ -1509,6 +1576,13 @@ int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
   SNF_TRY(do_consensus_batch(device, klen, seq_pool, seq_pool_len, n_problems, best_off, best_len, skip, others_index, others_off,
                               others_len, out_pool, out_off))
 }
+
+#ifdef SNF_EMU
+// test hook of the emulation build only (tests/test_emu_parity.py): the column vote of the LDS-vote consensus kernels
+int snf_emu_vote_column(uint32_t cnt4, const uint32_t* esc, int n_esc, int q, int bq, int nkept) {
+  return (int)vote_column(cnt4, esc, n_esc, q, (uint8_t)bq, nkept);
+}
+#endif
 
 int snf_batch_sync(snf_batch_t* bb) {
   SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); if (b->uploaded) full_sync(b); else dsync(b); collect_timings(b); })

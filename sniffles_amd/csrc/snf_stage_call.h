@@ -68,7 +68,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   int32_t lo = v.seed_lo[h], hi = v.seed_hi[v.c_last[h]];
   int32_t n = hi - lo;
   if (n <= 0) return;
-  if (v.wave_path && n <= 64) return;  // handled by d1w_refine (snf_wave_refine.h)
+  if (v.wave_path && (n <= 64 || v.big_wave)) return;  // d1w_refine (snf_wave_refine.h) / x_big<0> (a wave of its own)
   int svtype = grp_svtype(v.seed_grp[h]);
   int32_t *a0 = v.w0 + lo, *a1 = v.w1 + lo, *a2 = v.w2 + lo, *a3 = v.w3 + lo, *a4 = v.w4 + lo, *a5 = v.w5 + lo,
           *a6 = v.w6 + lo;
@@ -256,7 +256,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   if (r >= v.cnt->n_rc) { v.cdflag[r] = 0; return; }
   const snf_config_t& cfg = v.cfg;
   int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
-  if (v.wave_path && n <= 64) return;  // d2w_call (snf_wave_call.h)
+  if (v.wave_path && (n <= 64 || v.big_wave)) return;  // d2w_call / x_big<1> (snf_wave_call.h)
   int32_t h = v.cl_head[c];
   int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
   int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo;
@@ -458,6 +458,20 @@ SNF_HD bool cov_get(const View& v, int t, int64_t idx, int32_t* out) {
   return true;
 }
 
+// the five samples of a call lie within a few hundred bp of each other: the first one pays the two-level search, the
+// others gallop from where the previous one ended (same cache lines of r_start / re_sorted)
+SNF_HD bool cov_get_near(const View& v, int t, int64_t idx, int32_t* out, int64_t* hs, int64_t* he) {
+  int64_t len = v.t_contig_len[t];
+  if (idx < -len || idx >= len) return false;  // IndexError: the field keeps its value
+  if (idx < 0) idx += len;                      // numpy negative index
+  int64_t lo = v.t_read_off[t], hi = v.t_read_off[t + 1];
+  const int64_t ps = *hs < 0 ? bound_top_i32<true>(v.r_start, v.rs_top, lo, hi, idx) : upper_bound_hint_i32(v.r_start, lo, hi, idx, *hs);
+  const int64_t pe = *he < 0 ? bound_top_i32<true>(v.re_sorted, v.re_top, lo, hi, idx) : upper_bound_hint_i32(v.re_sorted, lo, hi, idx, *he);
+  *hs = ps; *he = pe;
+  *out = (int32_t)((uint64_t)(ps - pe) & 0xffffu);
+  return true;
+}
+
 SNF_HD void d4_coverage_body(int64_t i, const View& v) {
   if (i >= v.cnt->n_calls) return;
   snf_call_t& c = v.calls[i];
@@ -468,17 +482,20 @@ SNF_HD void d4_coverage_body(int64_t i, const View& v) {
   if (c.svtype == SNF_INS) end = start + 1;
   else if (c.svtype == SNF_BND) { if (c.bnd_is_first) start -= 1; end = v.t_stale_end[t]; }
   else end = (int64_t)c.pos + iabs64(c.svlen);
+  int64_t hs = -1, he = -1;
+  int32_t cov[5] = {c.cov[0], c.cov[1], c.cov[2], c.cov[3], c.cov[4]};
+  cov_get_near(v, t, start - (int64_t)bs * ud, &cov[0], &hs, &he);
   if (c.svtype == SNF_INS || c.svtype == SNF_BND) {
-    cov_get(v, t, start - bs, &c.cov[1]);
-    cov_get(v, t, start, &c.cov[2]);
-    cov_get(v, t, end + bs, &c.cov[3]);
+    cov_get_near(v, t, start - bs, &cov[1], &hs, &he);
+    cov_get_near(v, t, start, &cov[2], &hs, &he);
+    cov_get_near(v, t, end + bs, &cov[3], &hs, &he);
   } else {
-    cov_get(v, t, start, &c.cov[1]);
-    cov_get(v, t, (start + end) / 2, &c.cov[2]);
-    cov_get(v, t, end - bs, &c.cov[3]);
+    cov_get_near(v, t, start, &cov[1], &hs, &he);
+    cov_get_near(v, t, (start + end) / 2, &cov[2], &hs, &he);
+    cov_get_near(v, t, end - bs, &cov[3], &hs, &he);
   }
-  cov_get(v, t, start - (int64_t)bs * ud, &c.cov[0]);
-  cov_get(v, t, end + (int64_t)bs * ud, &c.cov[4]);
+  cov_get_near(v, t, end + (int64_t)bs * ud, &cov[4], &hs, &he);
+  for (int k = 0; k < 5; k++) c.cov[k] = cov[k];
 }
 
 // coverage.mean(): sum of clipped read lengths / contig_len (exact integer sum, one division)

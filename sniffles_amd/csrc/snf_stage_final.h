@@ -365,7 +365,7 @@ SNF_HD void e1_finalize_body(int64_t i, const View& v) {
   int task = cref.task_index;
   if (v.t_status[task] != SNF_TASK_OK) return;
   const CallX x = v.callx[i];
-  if (v.wave_path && x.fn <= 64) return;  // e1w_finalize (snf_wave_call.h)
+  if (v.wave_path && (x.fn <= 64 || v.big_wave)) return;  // e1w_finalize / x_big<2> (snf_wave_call.h)
   snf_call_t c = cref;
   LeadAgg g;
   collect_agg(v, x, task, &g);

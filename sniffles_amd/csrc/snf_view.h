@@ -19,7 +19,8 @@ struct Counts {
   int64_t n_dirty_groups;
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
-  unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback
+  unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
+                                    // 7 ROWS (aligned rows in HBM: beyond the LDS vote counters, or handed over by SMALL / LARGE at run time)
   unsigned long long pool_extra_used;
   int32_t overflow;  // scratch overflow flags
   int32_t _pad;
@@ -183,7 +184,14 @@ struct View {
   unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains
   ConsDesc* cdesc;           // [n_cons] by cons id
-  int32_t* cls_list[6];      // cons ids per work list (see Counts::n_cls), appended with wave-aggregated atomics
+  int32_t* cls_list[8];      // cons ids per work list (see Counts::n_cls; 6 unused), appended with wave-aggregated atomics
+  // clusters / refined clusters / calls with more than 64 leads, collected by the wave kernels (kind 0 d1w_refine, 1 d2w_call,
+  // 2 e1w_finalize) in 64 stripes (item & 63) and served one wave each by x_big<kind> (snf_wave_call.h)
+  uint32_t* big_cnt;         // [3][64][16]: one counter per stripe on its own 64-B line
+  int32_t* big_list;         // [3][64][big_cap]
+  int64_t big_cap;
+  int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
+  int32_t _pad_big;
   uint8_t* aln_kept_w;       // [N+1] kept flag per (call, other read) of the workgroup kernels, indexed like crl_*
   int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
   const int64_t n_rc = v.cnt->n_rc;
   for (int64_t r = blockIdx.x; r < n_rc; r += gridDim.x) {
     const int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
-    if (n > SNF_WAVE) continue;  // thread path
+    if (n > SNF_WAVE) { if (lane == 0) big_push(v, 1, (int32_t)r); continue; }  // x_big<1>
     const int32_t h = v.cl_head[c];
     const int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
     const bool act = lane < n;
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
     const int task = v.calls[i].task_index;
     if (v.t_status[task] != SNF_TASK_OK) continue;
     const CallX x = v.callx[i];
-    if (x.fn > SNF_WAVE) continue;  // thread path
+    if (x.fn > SNF_WAVE) { if (lane == 0) big_push(v, 2, (int32_t)i); continue; }  // x_big<2>
     const int n = x.fn;
     bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
     if (lane < n) {
@@ -329,6 +329,24 @@ __global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused
       if (tid == 0) { const unsigned long long tot = part[0] + part[1] + part[2] + part[3]; if (tot) atomicAdd(&v.t_cov_sum[t], tot); }
       __syncthreads();
     }
+  }
+}
+
+// Items with more than 64 leads (rare at 30x, a quarter of the clusters at 60x): the serial bodies of the thread kernels,
+// but ONE item per wave (lane 0) instead of one per lane - 64 different clusters in one wave diverge on every branch and
+// cost the sum of their times.  KIND 0: d1_refine_body (clusters), 1: d2_call_body (refined clusters), 2: e1_finalize_body.
+template <int KIND>
+__global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
+  v.big_wave = 0;   // the bodies below are the ones that skip big items when it is set
+  const int stripe = blockIdx.x & 63, per = (int)(gridDim.x >> 6);
+  const uint32_t cnt = v.big_cnt[(KIND * 64 + stripe) * 16];
+  const int32_t* list = v.big_list + ((int64_t)KIND * 64 + stripe) * v.big_cap;
+  if (threadIdx.x != 0) return;
+  for (uint32_t k = blockIdx.x >> 6; k < cnt; k += (uint32_t)per) {
+    const int64_t item = list[k];
+    if (KIND == 0) d1_refine_body(item, v);
+    else if (KIND == 1) d2_call_body(item, v);
+    else e1_finalize_body(item, v);
   }
 }
 

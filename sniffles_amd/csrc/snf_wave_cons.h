@@ -86,25 +86,29 @@ SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
 
 #define SNF_ACTG 0x47544341u  /* byte z = the base with code z, code(c) = (c >> 1) & 3: A 0, C 1, T 2, G 3 */
 
-// CLS: 1 SMALL, 2 LARGE (cons_class); non-consensus calls (verbatim ALT) are copied by the SMALL instance
+// CLS: 1 SMALL, 2 LARGE, 4 ROWS (cons_class_of)
 // NW: waves per workgroup (= per call).  4: the reads of a call are spread over four waves; 1: a call is one wave's work
 // (no workgroup barriers, no waves idling while the wave with one read more finishes, four times as many calls in flight)
-template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW, int NW = 4>
+// LCAP > 0: LDS-vote instance for calls of at most LCAP columns; SCAP > 0: the other read is staged in LDS as well;
+// ECAP: capacity of the escape list (votes with a byte other than A/C/G/T) - a call that needs more is handed to the
+// ROWS instance through work list 7
+template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW, int NW = 4, int LCAP = 0, int SCAP = 0, int ECAP = 0>
 __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, int64_t n_unused) {
-  typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS, NW> Lds;
+  typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS, NW, LCAP, SCAP, ECAP> Lds;
   constexpr int NT = 64 * NW;
+  constexpr bool LV = LCAP > 0;
   __shared__ Lds lds;
   constexpr int ROUNDS = MAXPOS / 64;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> SGPRs
   const int klen = v.cfg.consensus_kmer_len, maxshift = klen;
-  // SMALL walks list 1; LARGE walks lists 2..5 (heaviest first) as one index space
-  const int64_t n1 = (int64_t)v.cnt->n_cls[CLS == 1 ? 1 : 2], n2 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[3];
-  const int64_t n3 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[4], n4 = CLS == 1 ? 0 : (int64_t)v.cnt->n_cls[5];
+  // SMALL walks list 1; LARGE walks lists 2..5 (heaviest first) as one index space; ROWS walks list 7
+  const int64_t n1 = (int64_t)v.cnt->n_cls[CLS == 1 ? 1 : CLS == 2 ? 2 : 7], n2 = CLS != 2 ? 0 : (int64_t)v.cnt->n_cls[3];
+  const int64_t n3 = CLS != 2 ? 0 : (int64_t)v.cnt->n_cls[4], n4 = CLS != 2 ? 0 : (int64_t)v.cnt->n_cls[5];
   const int64_t n_items = n1 + n2 + n3 + n4;
   unsigned long long bytes_acc = 0;  // algorithmic bytes this block processed, one atomic at the end
   for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     int32_t cid;
-    if (CLS == 1 || it < n1) cid = v.cls_list[CLS == 1 ? 1 : 2][it];
+    if (CLS != 2 || it < n1) cid = v.cls_list[CLS == 1 ? 1 : CLS == 2 ? 2 : 7][it];
     else if (it < n1 + n2) cid = v.cls_list[3][it - n1];
     else if (it < n1 + n2 + n3) cid = v.cls_list[4][it - n1 - n2];
     else cid = v.cls_list[5][it - n1 - n2 - n3];
@@ -113,14 +117,20 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     // memory, and the kernel's occupancy is bound by VGPRs)
     const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
     const int32_t n_others = __builtin_amdgcn_readfirstlane(d.n_others);
-    const uint8_t* B = v.pool + rfl64(d.best_off);
+    const uint8_t* Bg = v.pool + rfl64(d.best_off);
     uint8_t* alt = v.alt_pool + rfl64(d.alt_off);
-    bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
     const int skip = __builtin_amdgcn_readfirstlane(d.skip);
+    const int64_t r0 = rfl64(d.read_off);
     __syncthreads();
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += NT) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
+    if constexpr (LV) {
+      stage16(lds.best, Bg, L + 8, tid, NT);                 // the pool has >= 16 B of slack behind every sequence
+      for (int q = tid; q < L; q += NT) lds.cnt[q] = 0;
+      if (tid == 0) lds.n_esc = 0;
+    }
     __syncthreads();
+    const uint8_t* B = LV ? (const uint8_t*)lds.best : Bg;
     const int npos = (int)cons_npos(L, klen, skip);
     for (int p = tid; p < npos; p += NT) {
       const int i = p * skip;
@@ -135,16 +145,21 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     }
     __syncthreads();
     typename Lds::Wave& W = lds.w[wid];
-    const int64_t r0 = rfl64(d.read_off);
-    uint8_t* rows = v.aln + rfl64(d.aln_off);
+    uint8_t* rows = LV ? nullptr : v.aln + rfl64(d.aln_off);
     for (int32_t r = wid; r < n_others; r += NW) {
-      const uint8_t* S = v.pool + rfl64(v.crl_off[r0 + r]);
+      const uint8_t* Sg = v.pool + rfl64(v.crl_off[r0 + r]);
       const int SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
-      uint8_t* row = rows + (int64_t)r * L;
       // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
       int jlim = SL - klen;                                     // j < SL - klen
       if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;   // an anchor needs i <= L-klen-1, |i-j| <= maxshift
       const int P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;   // <= npos + 2 < MAXPOS
+      if constexpr (SCAP > 0) {
+        // every byte any phase reads lies below jlim + klen + 8 (k-mer words, segment compares, copied bases)
+        int ns = jlim + klen + 8; if (ns > SL + 8) ns = SL + 8; if (ns < 0) ns = 0;
+        stage16(W.s, Sg, ns, lane, 64);
+        __builtin_amdgcn_wave_barrier();
+      }
+      const uint8_t* S = SCAP > 0 ? (const uint8_t*)W.s : Sg;
       unsigned long long kw[ROUNDS];
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
@@ -214,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           if (fwd_i == fwd_j && fwd_j > 0) {
             const int nfull = j - lj;
             span += nfull;
-            // first words of both comparisons issued together (one global round trip instead of two); consecutive
+            // first words of both comparisons issued together (one round trip instead of two); consecutive
             // anchors are usually one sampling step apart, so the tails are rare
             const uint64_t a1 = load_u64(S + lj + 1), b1 = load_u64(B + li + 1), a2 = load_u64(S + lj), b2 = load_u64(B + col);
             int m = eq_bytes(a1, b1, nfull < 8 ? nfull : 8);
@@ -243,34 +258,69 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         }
       }
       __builtin_amdgcn_wave_barrier();
-      // ---- 5. write the row, column-parallel
-      int c_last = c_first;
-      if (na) { c_last = c_first + (__builtin_amdgcn_readfirstlane((int)W.aj[na - 1]) - j0); if (c_last > L) c_last = L; }
-      // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): its row is never read
+      // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): it has no vote
       const bool keep_row = (double)span / (double)L > 0.2;
-      for (int q0 = 0; q0 < L && keep_row; q0 += 64) {
-        const int q = q0 + lane;
-        if (q < L) {
-          uint8_t out = '-';
-          if (na > 1 && q >= c_first && q < c_last) {
-            int lo2 = 1, hi2 = na - 1;  // last segment t with seg_col[t] <= q
-            // segment t starts at column c_first + (aj[t-1] - j0) (q < c_last <= L, so the clip at L never matters here)
-            while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (c_first + ((int)W.aj[mid - 1] - j0) <= q) lo2 = mid; else hi2 = mid - 1; }
-            const int t = lo2;
-            const int off = q - (c_first + ((int)W.aj[t - 1] - j0));
-            if (W.seg_flag[t] && off < W.seg_len[t]) out = S[W.aj[t - 1] + off];
+      if constexpr (LV) {
+        // ---- 5. votes: one lane per copied segment, its bases go to the counters of its columns
+        // (segment t starts at column c_first + (aj[t-1] - j0) < L and is seg_len[t] columns long)
+        for (int t0 = 1; t0 < na && keep_row; t0 += 64) {
+          const int t = t0 + lane;
+          if (t < na && W.seg_flag[t]) {
+            const int lj = W.aj[t - 1], n = W.seg_len[t];
+            const int col = c_first + (lj - j0);
+            for (int o8 = 0; o8 < n; o8 += 8) {
+              unsigned long long w8 = load_u64(S + lj + o8);
+              const int m = n - o8 < 8 ? n - o8 : 8;
+              for (int o = 0; o < m; o++, w8 >>= 8) {
+                const uint32_t c = (uint32_t)(w8 & 0xffull), cd = (c >> 1) & 3u;
+                if (((SNF_ACTG >> (8 * cd)) & 0xffu) == c) atomicAdd(&lds.cnt[col + o8 + o], 1u << (8 * cd));
+                else { const uint32_t e = atomicAdd(&lds.n_esc, 1u); if (e < (uint32_t)ECAP) lds.esc[e] = ((uint32_t)(col + o8 + o) << 8) | c; }
+              }
+            }
           }
-          row[q] = out;
         }
+        if (lane == 0) lds.kept[r] = keep_row ? 1 : 0;
+      } else {
+        // ---- 5. write the row, column-parallel
+        uint8_t* row = rows + (int64_t)r * L;
+        int c_last = c_first;
+        if (na) { c_last = c_first + (__builtin_amdgcn_readfirstlane((int)W.aj[na - 1]) - j0); if (c_last > L) c_last = L; }
+        for (int q0 = 0; q0 < L && keep_row; q0 += 64) {
+          const int q = q0 + lane;
+          if (q < L) {
+            uint8_t out = '-';
+            if (na > 1 && q >= c_first && q < c_last) {
+              int lo2 = 1, hi2 = na - 1;  // last segment t with seg_col[t] <= q
+              // segment t starts at column c_first + (aj[t-1] - j0) (q < c_last <= L, so the clip at L never matters here)
+              while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (c_first + ((int)W.aj[mid - 1] - j0) <= q) lo2 = mid; else hi2 = mid - 1; }
+              const int t = lo2;
+              const int off = q - (c_first + ((int)W.aj[t - 1] - j0));
+              if (W.seg_flag[t] && off < W.seg_len[t]) out = S[W.aj[t - 1] + off];
+            }
+            row[q] = out;
+          }
+        }
+        if (lane == 0) { const uint8_t k = keep_row ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       }
-      if (lane == 0) { const uint8_t k = keep_row ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       __builtin_amdgcn_wave_barrier();
     }
-    // ---- column vote (consensus.py:365-380) on the rows this workgroup just wrote (still in L2)
+    // ---- column vote (consensus.py:365-380)
     __syncthreads();
     int nkept = 0;
     for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
     nkept = __builtin_amdgcn_readfirstlane(nkept);
+    if constexpr (LV) {
+      const int n_esc = __builtin_amdgcn_readfirstlane((int)lds.n_esc);
+      if (n_esc > ECAP) {
+        // more odd characters than the escape list holds: the ROWS instance redoes this call (work list 7)
+        if (tid == 0) { const unsigned long long slot = atomicAdd(&v.cnt->n_cls[7], 1ull); v.cls_list[7][slot] = cid; }
+        continue;
+      }
+      bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
+      for (int q = tid; q < L; q += NT) alt[q] = vote_column(lds.cnt[q], lds.esc, n_esc, q, lds.best[q], nkept);
+      continue;
+    }
+    bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
     const double maxal = (double)(1 + nkept);
     for (int q = tid; q < L; q += NT) {
       const uint8_t bq = B[q];
@@ -333,7 +383,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       alt[q] = out;
     }
   }
-  if (tid == 0 && bytes_acc) atomicAdd(&v.stripes[(CLS * 64 + (blockIdx.x & 63)) * 16], bytes_acc);  // striped: summed by z1_results
+  if (tid == 0 && bytes_acc) atomicAdd(&v.stripes[((CLS == 4 ? 0 : CLS) * 64 + (blockIdx.x & 63)) * 16], bytes_acc);  // striped: summed by z1_results
 }
 
 // verbatim ALT of calls with fewer than consensus_min_reads other reads (postprocessing.py:65-66): one wave per call

@@ -45,6 +45,13 @@ SNF_D int wave_rank(uint64_t key, int n) {
   return r;
 }
 
+// an item with more than 64 leads: remembered for x_big (called by one lane)
+SNF_D void big_push(const View& v, int kind, int32_t item) {
+  const int s = item & 63;
+  const uint32_t slot = atomicAdd(&v.big_cnt[(kind * 64 + s) * 16], 1u);
+  v.big_list[((int64_t)kind * 64 + s) * v.big_cap + slot] = item;
+}
+
 struct WaveLds {
   int32_t perm[SNF_WAVE];      // scatter target for permutations
   int32_t seg_start[SNF_WAVE]; // resplit: segment (distinct bin) start position in sorted order
@@ -83,7 +90,8 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     if (c + stride < n_clusters && lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
     if (c + 2 * stride < n_clusters) hd_nxt = v.chdr[c + 2 * stride];
     const int32_t lo = hd.lo, n = hd.n;
-    if (n <= 0 || n > SNF_WAVE) continue;  // big clusters: thread path (d1_refine with the n > 64 guard)
+    if (n > SNF_WAVE) { if (lane == 0) big_push(v, 0, (int32_t)c); continue; }   // big clusters: x_big<0>
+    if (n <= 0) continue;
     const int svtype = grp_svtype(hd.grp);
     const bool act = lane < n;
     // ---- load one lead per lane

@@ -65,3 +65,47 @@ def test_wide_sort_keys_are_exact(emu_lib, oracle_mod, monkeypatch):
     tis = [synth.gen_fuzz(300 + k, task_id=k) for k in range(4)]
     cfg = SnifflesConfig()
     assert records.records(run(emu_lib, cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+
+
+def test_vote_column_equals_most_common_rule(emu_lib):
+    """The column vote of the LDS-vote consensus kernels (packed per-base counters + escape list, csrc/snf_stage_final.h
+    `vote_column`) against a direct restatement of consensus.py:365-380 / util.most_common on random columns, odd
+    characters included."""
+    import ctypes as C
+    import numpy as np
+    f = emu_lib.snf_emu_vote_column
+    f.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_int, C.c_int]
+    f.restype = C.c_int
+    rng = np.random.default_rng(11)
+    code = {65: 0, 67: 1, 84: 2, 71: 3}
+    alpha_plain, alpha_odd = [65, 67, 71, 84], [78, 97, 99, 82, 45 + 1, 255, 0]
+    for trial in range(4000):
+        nkept = int(rng.integers(0, 40))
+        nvotes = int(rng.integers(0, nkept + 1))
+        odd_rate = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
+        dom = int(rng.choice(alpha_plain + alpha_odd))
+        votes = [int(dom if rng.random() < 0.6 else (rng.choice(alpha_odd) if rng.random() < odd_rate else rng.choice(alpha_plain)))
+                 for _ in range(nvotes)]
+        bq = int(rng.choice(alpha_plain + alpha_odd)) if rng.random() < 0.2 else int(rng.choice(alpha_plain))
+        q = int(rng.integers(0, 300))
+        cnt4, esc = 0, []
+        for c in votes:
+            if c in code:
+                cnt4 += 1 << (8 * code[c])
+            else:
+                esc.append((q << 8) | c)
+        for _ in range(int(rng.integers(0, 4))):        # escapes of other columns must be ignored
+            esc.append((int(rng.integers(300, 400)) << 8) | int(rng.choice(alpha_odd)))
+        order = rng.permutation(len(esc))
+        esc = [esc[i] for i in order]
+        # the rule
+        exp = bq
+        if not (len(votes) < 2 or len(votes) / (1 + nkept) < 0.25):
+            cnt = {}
+            for c in [bq] + votes:
+                cnt[c] = cnt.get(c, 0) + 1
+            ranked = sorted(((n, c) for c, n in cnt.items()), reverse=True)
+            if len(ranked) > 1 and ranked[0][0] - ranked[1][0] >= 3:
+                exp = ranked[0][1]
+        arr = (C.c_uint32 * max(1, len(esc)))(*esc)
+        assert f(cnt4, arr, len(esc), q, bq, nkept) == exp, (votes, bq, nkept)

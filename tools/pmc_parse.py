@@ -11,7 +11,8 @@ def short(n):
         m = re.search(r"(onesweep_iteration|onesweep_histograms|radix_sort\w*|scan_impl|lookback_scan\w*|scan\w*)", n)
         n = "rocprim:" + (m.group(1) if m else n[:40])
     if "e45w_consensus" in n:
-        n = "e45w_consensus_small" if "<1" in n or "ILi1" in n else "e45w_consensus_large"
+        m = re.search(r"e45w_consensus<(\d)", n)
+        n = {"1": "e45w_consensus_small", "2": "e45w_consensus_large", "4": "e45w_consensus_rows"}.get(m.group(1) if m else "", n)
     return n
 
 def load(d, counter):
@@ -25,7 +26,7 @@ def load(d, counter):
 
 fe = load(sys.argv[1], "FETCH_SIZE"); wr = load(sys.argv[2], "WRITE_SIZE")
 out = {"_about": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --inflight 1 "
-                 "--steps 2 --warmup 1 --no-cpu-baseline` on MI355X (30x WG workload). Per-launch averages, KiB. "
+                 "--steps 2 --warmup 1 --no-cpu-baseline` on MI355X (30x WG workload, BASELINE configs[1]). Per-launch averages, KiB. "
                  "hbm_bytes = (2*FETCH + WRITE) * 1024: gfx950 FETCH_SIZE counts 128-B requests as 64 B (x2, calibrated on a1_keys: "
                  "known reads 9 B/lead, known writes 13 B/lead), WRITE_SIZE is exact.", "kernels": {}}
 for k in sorted(fe, key=lambda k: -(2 * fe[k][0] + wr.get(k, (0, 1))[0])):

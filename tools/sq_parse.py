@@ -2,9 +2,11 @@
 import csv, glob, sys, collections, re
 def short(n):
     n = re.sub(r"\(.*", "", n); n = re.sub(r"^void ", "", n); n = n.replace("snf::", "")
-    if "e45w_consensus" in n: n = "e45w_small" if "<1" in n else "e45w_large"
+    if "e45w_consensus" in n:
+        m = re.search(r"e45w_consensus<(\d)", n)
+        n = {"1": "e45w_small", "2": "e45w_large", "4": "e45w_rows"}.get(m.group(1) if m else "", n)
     return n[:24]
-want = ("e45w", "d1w_refine", "d2w_call", "e1w_finalize", "e4c_copy", "d4_coverage", "c1_mergeruns", "a6_scatter")
+want = ("e45w", "d1w_refine", "d2w_call", "e1w_finalize", "e4c_copy", "d4_coverage", "c1_mergeruns", "a6k_scatter", "x_big")
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(set)
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
