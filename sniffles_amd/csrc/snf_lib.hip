@@ -1114,15 +1114,12 @@ void run_finalize(snf_batch_impl* b) {
         b->cur = prev;
       }
       if (serial) SNF_HIP(hipDeviceSynchronize());
-      if (n_copy > 0) {  // verbatim ALTs: short; behind LARGE on the third stream (the side stream is busy with the record copies)
-        if (n_large <= 0) SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
-        hipStream_t prev = b->cur; b->cur = b->stream3;
-        { Scope _s(b, "e4c_copy", 0);
-          hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
-          SNF_HIP(hipGetLastError()); }
-        b->cur = prev;
-      }
       SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+      if (n_copy > 0) {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
+        Scope _s(b, "e4c_copy", 0);
+        hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError());
+      }
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
         const dim3 gs((unsigned)(n_small < 16384 ? n_small : 16384));
@@ -1425,7 +1422,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       int nb = 0;
       const int mult = getenv("SNF_GRID_MULT") ? atoi(getenv("SNF_GRID_MULT")) : 1;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d1w_refine, 64, 0)); if (nb > 0) b->slots_d1w = nb * cus * mult;
-      const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 6;
+      const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 5;   // <6> and <8> spill (36 / 100 B of scratch); <5> does not and is as fast
       const int o1 = getenv("SNF_OCC_E1") ? atoi(getenv("SNF_OCC_E1")) : 5;
       b->k_d2w = o2 >= 8 ? d2w_call<8> : o2 == 6 ? d2w_call<6> : o2 == 5 ? d2w_call<5> : d2w_call<4>;
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc

@@ -67,6 +67,57 @@ SNF_HD int64_t ed_serial(const uint8_t* A, int64_t la, const uint8_t* B, int64_t
   return unpad_score(score, Pv, Mv, (int)(nb * 64 - m));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Banded form (Ukkonen's cut-off on the Myers / Hyyro blocks, as edlib does for its `k` argument): the distance if it is
+// <= k, otherwise -1.  With m <= n (pattern rows, text columns) a path of cost <= k stays on the diagonals
+// -kk <= j - i <= (n - m) + kk, kk = (k - (n - m)) / 2, so column j only needs the blocks that hold rows
+// [j - (n - m) - kk, j + kk].  Cells outside the band count as "one more per step" (a block entering the band starts with
+// Pv = all ones below the block above it, a block whose upper neighbour has left takes hin = +1): every value computed is
+// the cost of a real path, hence >= the true distance, and equal to it whenever that is <= k.  k < 0: no cut-off.
+struct EdBand { int64_t m, n, dl, kk; };
+SNF_HD bool ed_band(int64_t m, int64_t n, int64_t k, EdBand* bd) {   // false: the lengths alone exceed k
+  bd->m = m; bd->n = n; bd->dl = n - m;
+  if (k < 0) { bd->kk = m; return true; }
+  if (bd->dl > k) return false;
+  bd->kk = (k - bd->dl) / 2;
+  return true;
+}
+// first / last column (0-based) in which block b (rows 64b .. 64b+63) is inside the band
+SNF_HD int64_t ed_band_cs(const EdBand& bd, int64_t b) { int64_t c = 64 * b - bd.kk; return c < 0 ? 0 : c; }
+SNF_HD int64_t ed_band_ce(const EdBand& bd, int64_t b) { int64_t c = 64 * b + 63 + bd.dl + bd.kk; return c > bd.n - 1 ? bd.n - 1 : c; }
+
+// 64-bit scratch words ed_serial_k needs for a pattern (= the shorter string) of m bytes: bit-planes, valid mask, Pv, Mv
+SNF_HD int64_t ed_serial_scratch_words(int64_t m) { return 11 * ((m + 63) / 64) + 11; }
+
+// serial banded distance, column-major: the block states stay in `scratch`, hout -> hin is a register (no per-column
+// carry array); this is the form the emulation build and the thread-per-pair kernel run
+SNF_HD int64_t ed_serial_k(const uint8_t* A, int64_t la, const uint8_t* B, int64_t lb, int64_t k, uint64_t* scratch) {
+  const uint8_t *P = A, *T = B; int64_t m = la, n = lb;
+  if (la > lb) { P = B; m = lb; T = A; n = la; }
+  EdBand bd;
+  if (!ed_band(m, n, k, &bd)) return -1;
+  if (m == 0) return n;   // (n <= k, or no cut-off)
+  const int64_t nb = (m + 63) / 64;
+  uint64_t *planes = scratch, *valid = scratch + 8 * nb, *Pv = scratch + 9 * nb, *Mv = scratch + 10 * nb;
+  for (int64_t b = 0; b < nb; b++) {
+    const int cnt = (int)(m - b * 64 < 64 ? m - b * 64 : 64);
+    block_planes(P + b * 64, cnt, planes + 8 * b, &valid[b]);
+  }
+  int64_t lastb = -1, score = 0;     // score = D at the bottom row of block `lastb` in the current column
+  for (int64_t j = 0; j < n; j++) {
+    int64_t lo = j - bd.dl - bd.kk, hi = j + bd.kk;
+    if (lo < 0) lo = 0;
+    if (hi > m - 1) hi = m - 1;
+    const int64_t fb = lo / 64, lbk = hi / 64;
+    while (lastb < lbk) { lastb++; Pv[lastb] = ~0ull; Mv[lastb] = 0; score += 64; }   // enters the band: +1 per row below
+    int hin = 1;                                                                          // row 0, or the block above has left
+    for (int64_t b = fb; b <= lbk; b++) hin = advance_block(Pv[b], Mv[b], eq_mask(planes + 8 * b, valid[b], T[j]), hin);
+    score += hin;
+  }
+  const int64_t d = unpad_score(score, Pv[nb - 1], Mv[nb - 1], (int)(nb * 64 - m));
+  return (k >= 0 && d > k) ? -1 : d;
+}
+
 #if !defined(SNF_EMU) && defined(__HIPCC__)
 // the same distance computed by one whole wave (all 64 lanes must call it together): lane = 64-row block of the current
 // 64-block pass, anti-diagonal schedule (lane l works on column t - l at step t and takes hin from lane l-1 by a
