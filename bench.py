@@ -71,8 +71,8 @@ def task_specs(args, wl, rep: int, g: int, world: int) -> list:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="default 30 (config 4: 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 3 (config 4: 1)")
     ap.add_argument("--config", type=int, default=1, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[i]")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--coverage", type=float, default=None, help="override the workload's coverage (debug; invalid as a result)")
@@ -117,6 +117,9 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist)
+    if args.config != 4:
+        args.steps = 30 if args.steps is None else args.steps
+        args.warmup = 3 if args.warmup is None else args.warmup
     if args.config == 4:
         from tools import bench_population
         out = bench_population.run(ctx)
@@ -364,7 +367,7 @@ def run_calling(ctx):
     # for the record: the same passes when every call_candidates ALSO rebuilds the read index (sorted read ends, hap prefix
     # counts - the device form of the coverage vector, which the reference builds during extraction and the library at upload)
     ms_with_index = None
-    if world == 1 and not strong and not use_dist:
+    if world == 1 and not strong and not use_dist and not args.no_wall_clock:
         os.environ["SNF_READPREP_EACH_PASS"] = "1"
         extra = [[lib.Batch(cfg, tasks, device=local_rank)] for _ in range(W)]
         del os.environ["SNF_READPREP_EACH_PASS"]

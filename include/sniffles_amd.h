@@ -354,6 +354,13 @@ int snf_batch_sync(snf_batch_t* b);
 int snf_edit_distance_batch(int device, const uint8_t* a_pool, const int64_t* a_off,
                             const uint8_t* b_pool, const int64_t* b_off,
                             int64_t n_pairs, int32_t* out_dist);
+/* the same with edlib's `k` argument (edlib.align(a, b, k=...)): max_dist[i] >= 0 bounds the distances of interest of pair
+ * i - the alignment is banded accordingly (Ukkonen) and out_dist[i] is -1 when the distance exceeds it, as edlib reports;
+ * max_dist[i] < 0 (or max_dist == NULL): exact.  Both entry points stage through a persistent per-device arena (HBM +
+ * pinned mirror + stream): no allocation once it has reached its working size. */
+int snf_edit_distance_batch_k(int device, const uint8_t* a_pool, const int64_t* a_off,
+                              const uint8_t* b_pool, const int64_t* b_off,
+                              int64_t n_pairs, const int32_t* max_dist, int32_t* out_dist);
 
 /*
  * Multi-sample combine: group assignment of cluster.resolve_block_groups (src/sniffles/cluster.py:356-390)
@@ -402,6 +409,10 @@ typedef struct snf_combine_problem {
 
 int snf_combine_resolve_batch(const snf_config_t* cfg, int device, const snf_combine_problem_t* problems,
                               int64_t n_problems);
+/* measurement: kernel time (HIP events) of the last snf_combine_resolve_batch on `device` and what it aligned -
+ * stats4[0] alignments (align_call evaluations), [1] bytes of the aligned strings, [2] cells of their full DP matrices,
+ * [3] bytes staged host -> HBM */
+int snf_combine_last_stats(int device, double* kernel_ms, int64_t* stats4);
 
 /* ---------------------------------------------------------------------------------------------------------------------
  * Seam B4: consensus.novel_from_reads(best_lead, other_leads, klen, skip, skip_repetitive)

@@ -8,6 +8,7 @@
 // GPU one wave per window (lane 0 decides, all lanes align); the thread-per-window body is the emulation / reference
 // form (SNF_COMBINE_THREAD=1 selects it on the GPU).
 #include "snf_myers.h"
+#include "snf_ctx.h"
 #include "../../include/sniffles_amd.h"
 
 #include <cmath>
@@ -34,10 +35,12 @@ struct CombineView {
   // scratch / state
   double *st_pos, *st_len, *st_mate; int32_t *st_size, *st_mctg; int64_t *st_alt_lo, *st_alt_hi; uint8_t* st_alt_src;
   uint64_t* st_bits; int32_t* order; int8_t* carry; int32_t* st_alist;
+  uint64_t* ed_scratch; const int64_t* e_off;   // serial Myers block states per problem (ed_serial_scratch_words of its longest string)
   // flush windows: wn_off[p] = first window of problem p; win_cand has (windows + 1) entries per problem, stored at
   // index (wn_off[p] + p + w); win_bin / win_thr per window (thr < 0: nothing is flushed)
   const int64_t* wn_off; const int32_t* win_cand; const int32_t* win_bin; const double* win_thr;
   int32_t* out_group;
+  unsigned long long* stats;   // [3][64 stripes][16]: alignments, bytes (len a + len b), full-matrix DP cells (len a * len b)
 };
 
 struct LessSupportDesc {
@@ -69,6 +72,8 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
   uint64_t* bits = v.st_bits + v.w_off[p];
   int32_t* order = v.order + c0;
   int8_t* carry = v.carry + v.k_off[p];
+  uint64_t* ed_scr = v.ed_scratch + v.e_off[p];
+  (void)carry; (void)ed_scr;
   int32_t* out = v.out_group + c0;
   int ng = ng0;   // group slots used so far (slot index == group number over the whole chain)
   int na = ng0;   // active groups: alist[0..na) in list order (kept groups first, then the window's new groups)
@@ -123,17 +128,39 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
             }
           }
         }
+        // SVGroup.align_call accepts iff (len_mean - d) / len_mean > combine_pctseq: only distances up to the largest d that
+        // still satisfies it matter, so the alignment is banded with that cut-off (Ukkonen) and answers -1 beyond it
+        long long kmax = -1;
+        if (need && lead) {
+          const double gl = glen[g];
+          long long d0 = (long long)floor(gl * (1.0 - cfg.combine_pctseq));
+          const long long dcap = la > lb ? la : lb;          // no distance exceeds the longer string
+          if (d0 > dcap) d0 = dcap;
+          if (d0 < 0) d0 = 0;
+          while (d0 < dcap && ((gl - (double)(d0 + 1)) / gl) > cfg.combine_pctseq) d0++;
+          while (d0 >= 0 && !(((gl - (double)d0) / gl) > cfg.combine_pctseq)) d0--;
+          if (d0 < 0) need = 0;                               // not even identical strings would be accepted
+          kmax = d0;
+        }
         int64_t d = 0;
 #if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
         if (WAVE) {
           need = __shfl(need, 0, 64);
           if (need) {
-            pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64);
-            d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
+            pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64); kmax = __shfl(kmax, 0, 64);
+            if (ed_wave_band_fits((int64_t)la, (int64_t)lb, (int64_t)kmax)) d = ed_wave_pair_k((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, (int64_t)kmax);
+            else { d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry); if (d > kmax) d = -1; }
           }
         } else
 #endif
-        if (need) d = ed_serial((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry);
+        if (need) d = ed_serial_k((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, (int64_t)kmax, ed_scr);
+        if (need && lead) {
+          const int sx = (int)(p & 63);
+          atomic_add_u64(&v.stats[(0 * 64 + sx) * 16], 1ull);
+          atomic_add_u64(&v.stats[(1 * 64 + sx) * 16], (unsigned long long)(la + lb));
+          atomic_add_u64(&v.stats[(2 * 64 + sx) * 16], (unsigned long long)la * (unsigned long long)lb);
+        }
+        if (need && d < 0) need = 0;                          // beyond the cut-off: rejected
         if (need && lead && ((glen[g] - (double)d) / glen[g]) > cfg.combine_pctseq) { best = g; best_dist = dist; }
       }
       if (lead) {
@@ -186,39 +213,18 @@ using namespace snf;
 SNF_KERNEL(combine_problem, CombineView)
 
 namespace {
-template <class T>
-T* dev_up(const std::vector<T>& h, std::vector<void*>& frees, bool& ok, size_t extra = 0) {
-#ifndef SNF_EMU
-  void* p = nullptr;
-  size_t bytes = (h.size() + extra + 2) * sizeof(T);
-  if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; return nullptr; }
-  frees.push_back(p);
-  if (!h.empty() && hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) ok = false;
-  return (T*)p;
-#else
-  (void)ok;
-  T* p = (T*)malloc((h.size() + extra + 2) * sizeof(T));
-  frees.push_back(p);
-  if (!h.empty()) memcpy(p, h.data(), h.size() * sizeof(T));
-  return p;
-#endif
-}
-template <class T>
-T* dev_scratch(size_t n, std::vector<void*>& frees, bool& ok) { std::vector<T> e; return dev_up<T>(e, frees, ok, n); }
+DevArena g_combine_arenas[SNF_MAX_DEVICES];
+
+// an array of the call inside the arena: where it lives and (inputs) the host vector that fills it
+struct Slot { size_t off, bytes; const void* src; };
 }  // namespace
 
 extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, const snf_combine_problem_t* P, int64_t np) {
   if (np <= 0) return 0;
   if (!cfg || !P) return 1;
-#ifndef SNF_EMU
-  int nd = 0;
-  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) return 1;
-  if (hipSetDevice(device) != hipSuccess) return 1;
-#else
-  (void)device;
-#endif
+  if (device < 0 || device >= SNF_MAX_DEVICES) return 1;
   std::vector<int32_t> svtype(np), ncands(np), ngroups(np), nwords(np);
-  std::vector<int64_t> c_off(np + 1, 0), g_off(np + 1, 0), s_off(np + 1, 0), w_off(np + 1, 0), k_off(np + 1, 0);
+  std::vector<int64_t> c_off(np + 1, 0), g_off(np + 1, 0), s_off(np + 1, 0), w_off(np + 1, 0), k_off(np + 1, 0), e_off(np + 1, 0);
   for (int64_t p = 0; p < np; p++) {
     svtype[p] = P[p].svtype; ncands[p] = P[p].n_cands; ngroups[p] = P[p].n_groups;
     nwords[p] = (P[p].n_sample_ids + 63) / 64 > 0 ? (P[p].n_sample_ids + 63) / 64 : 1;
@@ -228,7 +234,10 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
     int64_t maxlen = 1;
     for (int i = 0; i < P[p].n_cands; i++) { int64_t l = P[p].alt_off[i + 1] - P[p].alt_off[i]; if (l > maxlen) maxlen = l; }
     for (int g = 0; g < P[p].n_groups; g++) { int64_t l = P[p].g_alt_off[g + 1] - P[p].g_alt_off[g]; if (l > maxlen) maxlen = l; }
-    k_off[p + 1] = k_off[p] + maxlen + 8;
+    // per-column carry bytes: only the multi-pass wave form needs them (a band of more than 63 blocks: strings > 4 kb
+    // that differ a lot); block states of the serial form: emulation / SNF_COMBINE_THREAD
+    k_off[p + 1] = k_off[p] + (maxlen > 4000 ? maxlen + 8 : 8);
+    e_off[p + 1] = e_off[p] + ed_serial_scratch_words(maxlen);
   }
   // flush windows per problem (a plain problem = one window that flushes nothing)
   std::vector<int64_t> wn_off(np + 1, 0);
@@ -252,74 +261,130 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   std::vector<int32_t> pos, svlen, support, sample, mctg, mpos, g_size, g_mctg, g_samples;
   std::vector<double> g_pm, g_lm, g_mm;
   std::vector<int64_t> alt_off(1, 0), g_alt_off(1, 0), g_s_off(1, 0);
-  std::vector<uint8_t> alt_pool, g_alt_pool;
+  pos.reserve(NC); svlen.reserve(NC); support.reserve(NC); sample.reserve(NC); mctg.reserve(NC); mpos.reserve(NC); alt_off.reserve(NC + 1);
+  int64_t alt_bytes = 0, g_alt_bytes = 0;
   for (int64_t p = 0; p < np; p++) {
     const snf_combine_problem_t& q = P[p];
     for (int i = 0; i < q.n_cands; i++) {
       if (q.sample_id[i] < 0 || q.sample_id[i] >= (q.n_sample_ids > 0 ? q.n_sample_ids : 1)) return 1;
       pos.push_back(q.pos[i]); svlen.push_back(q.svlen[i]); support.push_back(q.support[i]); sample.push_back(q.sample_id[i]);
       mctg.push_back(q.mate_contig ? q.mate_contig[i] : 0); mpos.push_back(q.mate_ref_start ? q.mate_ref_start[i] : 0);
-      alt_pool.insert(alt_pool.end(), q.alt_pool + q.alt_off[i], q.alt_pool + q.alt_off[i + 1]);
-      alt_off.push_back((int64_t)alt_pool.size());
+      alt_bytes += q.alt_off[i + 1] - q.alt_off[i];
+      alt_off.push_back(alt_bytes);
     }
     for (int g = 0; g < q.n_groups; g++) {
       g_pm.push_back(q.g_pos_mean[g]); g_lm.push_back(q.g_len_mean[g]); g_mm.push_back(q.g_mate_mean ? q.g_mate_mean[g] : 0.0);
       g_size.push_back(q.g_size[g]); g_mctg.push_back(q.g_mate_contig ? q.g_mate_contig[g] : 0);
-      g_alt_pool.insert(g_alt_pool.end(), q.g_alt_pool + q.g_alt_off[g], q.g_alt_pool + q.g_alt_off[g + 1]);
-      g_alt_off.push_back((int64_t)g_alt_pool.size());
+      g_alt_bytes += q.g_alt_off[g + 1] - q.g_alt_off[g];
+      g_alt_off.push_back(g_alt_bytes);
       for (int64_t k = q.g_samples_off[g]; k < q.g_samples_off[g + 1]; k++) g_samples.push_back(q.g_samples[k]);
       g_s_off.push_back((int64_t)g_samples.size());
     }
   }
-  std::vector<void*> frees;
-  bool ok = true;
+  (void)NG;
+  // ---- arena layout: inputs first (one host-to-device copy), state / scratch / output behind
+  ArenaLayout L;
+  std::vector<Slot> in;
+  auto put = [&](const auto& vec) { typedef typename std::decay<decltype(vec)>::type V; typedef typename V::value_type T;
+                                    const size_t o = L.add<T>(vec.size() + 2); in.push_back({o, vec.size() * sizeof(T), vec.data()}); return o; };
+  const size_t o_svtype = put(svtype), o_ncands = put(ncands), o_ngroups = put(ngroups), o_nwords = put(nwords);
+  const size_t o_coff = put(c_off), o_goff = put(g_off), o_soff = put(s_off), o_woff = put(w_off), o_koff = put(k_off), o_eoff = put(e_off);
+  const size_t o_pos = put(pos), o_svlen = put(svlen), o_support = put(support), o_sample = put(sample), o_mctg = put(mctg), o_mpos = put(mpos);
+  const size_t o_altoff = put(alt_off);
+  const size_t o_gpm = put(g_pm), o_glm = put(g_lm), o_gmm = put(g_mm), o_gsize = put(g_size), o_gmctg = put(g_mctg), o_galtoff = put(g_alt_off);
+  const size_t o_gsoff = put(g_s_off), o_gsamples = put(g_samples);
+  const size_t o_wnoff = put(wn_off), o_wincand = put(win_cand), o_winbin = put(win_bin), o_winthr = put(win_thr);
+  const size_t o_alt = L.add<uint8_t>((size_t)alt_bytes + 32), o_galt = L.add<uint8_t>((size_t)g_alt_bytes + 32);   // (Myers reads 8-byte words)
+  const size_t in_end = (L.at + 255) & ~(size_t)255;
+  const size_t S = (size_t)s_off[np];
+  const size_t o_stpos = L.add<double>(S), o_stlen = L.add<double>(S), o_stmate = L.add<double>(S);
+  const size_t o_stsize = L.add<int32_t>(S), o_stmctg = L.add<int32_t>(S), o_stalo = L.add<int64_t>(S), o_stahi = L.add<int64_t>(S);
+  const size_t o_stsrc = L.add<uint8_t>(S), o_stalist = L.add<int32_t>(S), o_bits = L.add<uint64_t>((size_t)w_off[np]);
+  const size_t o_order = L.add<int32_t>((size_t)NC), o_carry = L.add<int8_t>((size_t)k_off[np] + 16);
+#ifdef SNF_EMU
+  const size_t o_edscr = L.add<uint64_t>((size_t)e_off[np] + 16);
+#else
+  const bool thread_form = getenv("SNF_COMBINE_THREAD") != nullptr;
+  const size_t o_edscr = L.add<uint64_t>(thread_form ? (size_t)e_off[np] + 16 : 16);
+#endif
+  const size_t o_out = L.add<int32_t>((size_t)NC);
+  const size_t o_stats = L.add<unsigned long long>(3 * 64 * 16);
+  DevArena& A = g_combine_arenas[device];
+  std::lock_guard<std::mutex> hold(A.mu);
+  if (!A.ensure(device, L.at)) return 1;
+  uint8_t *h = A.h, *d = A.d;
+  for (const Slot& sl : in) if (sl.bytes) memcpy(h + sl.off, sl.src, sl.bytes);
+  {  // the ALT strings go straight from the caller's pools into the staging mirror
+    uint8_t* w = h + o_alt; uint8_t* wg = h + o_galt;
+    for (int64_t p = 0; p < np; p++) {
+      const snf_combine_problem_t& q = P[p];
+      if (q.n_cands > 0) { const int64_t n = q.alt_off[q.n_cands] - q.alt_off[0]; memcpy(w, q.alt_pool + q.alt_off[0], (size_t)n); w += n; }
+      if (q.n_groups > 0) { const int64_t n = q.g_alt_off[q.n_groups] - q.g_alt_off[0]; memcpy(wg, q.g_alt_pool + q.g_alt_off[0], (size_t)n); wg += n; }
+    }
+    memset(w, 0, 32); memset(wg, 0, 32);
+  }
   CombineView v{};
   v.cfg = *cfg; v.n_problems = np;
-  v.svtype = dev_up(svtype, frees, ok); v.n_cands = dev_up(ncands, frees, ok); v.n_groups = dev_up(ngroups, frees, ok);
-  v.n_words = dev_up(nwords, frees, ok);
-  v.c_off = dev_up(c_off, frees, ok); v.g_off = dev_up(g_off, frees, ok); v.s_off = dev_up(s_off, frees, ok);
-  v.w_off = dev_up(w_off, frees, ok); v.k_off = dev_up(k_off, frees, ok);
-  v.pos = dev_up(pos, frees, ok); v.svlen = dev_up(svlen, frees, ok); v.support = dev_up(support, frees, ok);
-  v.sample_id = dev_up(sample, frees, ok); v.mate_contig = dev_up(mctg, frees, ok); v.mate_pos = dev_up(mpos, frees, ok);
-  v.alt_off = dev_up(alt_off, frees, ok); v.alt_pool = dev_up(alt_pool, frees, ok, 16);
-  v.g_pos_mean = dev_up(g_pm, frees, ok); v.g_len_mean = dev_up(g_lm, frees, ok); v.g_mate_mean = dev_up(g_mm, frees, ok);
-  v.g_size = dev_up(g_size, frees, ok); v.g_mate_contig = dev_up(g_mctg, frees, ok);
-  v.g_alt_off = dev_up(g_alt_off, frees, ok); v.g_alt_pool = dev_up(g_alt_pool, frees, ok, 16);
-  v.g_samples_off = dev_up(g_s_off, frees, ok); v.g_samples = dev_up(g_samples, frees, ok);
-  const size_t S = (size_t)s_off[np];
-  v.st_pos = dev_scratch<double>(S, frees, ok); v.st_len = dev_scratch<double>(S, frees, ok); v.st_mate = dev_scratch<double>(S, frees, ok);
-  v.st_size = dev_scratch<int32_t>(S, frees, ok); v.st_mctg = dev_scratch<int32_t>(S, frees, ok);
-  v.st_alt_lo = dev_scratch<int64_t>(S, frees, ok); v.st_alt_hi = dev_scratch<int64_t>(S, frees, ok);
-  v.st_alt_src = dev_scratch<uint8_t>(S, frees, ok); v.st_alist = dev_scratch<int32_t>(S, frees, ok);
-  v.wn_off = dev_up(wn_off, frees, ok); v.win_cand = dev_up(win_cand, frees, ok); v.win_bin = dev_up(win_bin, frees, ok);
-  v.win_thr = dev_up(win_thr, frees, ok);
-  v.st_bits = dev_scratch<uint64_t>((size_t)w_off[np], frees, ok);
-  v.order = dev_scratch<int32_t>((size_t)NC, frees, ok);
-  v.carry = dev_scratch<int8_t>((size_t)k_off[np], frees, ok);
-  int32_t* d_out = dev_scratch<int32_t>((size_t)NC, frees, ok);
-  v.out_group = d_out;
-  (void)NG;
-  std::vector<int32_t> h_out((size_t)NC + 1);
+  v.svtype = (const int32_t*)(d + o_svtype); v.n_cands = (const int32_t*)(d + o_ncands); v.n_groups = (const int32_t*)(d + o_ngroups);
+  v.n_words = (const int32_t*)(d + o_nwords);
+  v.c_off = (const int64_t*)(d + o_coff); v.g_off = (const int64_t*)(d + o_goff); v.s_off = (const int64_t*)(d + o_soff);
+  v.w_off = (const int64_t*)(d + o_woff); v.k_off = (const int64_t*)(d + o_koff); v.e_off = (const int64_t*)(d + o_eoff);
+  v.pos = (const int32_t*)(d + o_pos); v.svlen = (const int32_t*)(d + o_svlen); v.support = (const int32_t*)(d + o_support);
+  v.sample_id = (const int32_t*)(d + o_sample); v.mate_contig = (const int32_t*)(d + o_mctg); v.mate_pos = (const int32_t*)(d + o_mpos);
+  v.alt_off = (const int64_t*)(d + o_altoff); v.alt_pool = d + o_alt;
+  v.g_pos_mean = (const double*)(d + o_gpm); v.g_len_mean = (const double*)(d + o_glm); v.g_mate_mean = (const double*)(d + o_gmm);
+  v.g_size = (const int32_t*)(d + o_gsize); v.g_mate_contig = (const int32_t*)(d + o_gmctg);
+  v.g_alt_off = (const int64_t*)(d + o_galtoff); v.g_alt_pool = d + o_galt;
+  v.g_samples_off = (const int64_t*)(d + o_gsoff); v.g_samples = (const int32_t*)(d + o_gsamples);
+  v.st_pos = (double*)(d + o_stpos); v.st_len = (double*)(d + o_stlen); v.st_mate = (double*)(d + o_stmate);
+  v.st_size = (int32_t*)(d + o_stsize); v.st_mctg = (int32_t*)(d + o_stmctg);
+  v.st_alt_lo = (int64_t*)(d + o_stalo); v.st_alt_hi = (int64_t*)(d + o_stahi); v.st_alt_src = d + o_stsrc; v.st_alist = (int32_t*)(d + o_stalist);
+  v.wn_off = (const int64_t*)(d + o_wnoff); v.win_cand = (const int32_t*)(d + o_wincand); v.win_bin = (const int32_t*)(d + o_winbin);
+  v.win_thr = (const double*)(d + o_winthr);
+  v.st_bits = (uint64_t*)(d + o_bits); v.order = (int32_t*)(d + o_order); v.carry = (int8_t*)(d + o_carry);
+  v.ed_scratch = (uint64_t*)(d + o_edscr);
+  v.out_group = (int32_t*)(d + o_out);
+  v.stats = (unsigned long long*)(d + o_stats);
+#ifndef SNF_EMU
+  hipStream_t st = A.stream;
+  bool ok = hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok = ok && hipMemsetAsync(d + o_stats, 0, 3 * 64 * 16 * sizeof(unsigned long long), st) == hipSuccess;
+  ok = ok && hipEventRecord(A.ev0, st) == hipSuccess;
   if (ok) {
-#ifndef SNF_EMU
-    if (getenv("SNF_COMBINE_THREAD")) hipLaunchKernelGGL(combine_problem, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, 0, v, np);
-    else hipLaunchKernelGGL(combine_problem_wave, dim3((unsigned)(np < 65536 ? np : 65536)), dim3(64), 0, 0, v, np);
-    if (hipDeviceSynchronize() != hipSuccess) ok = false;
-    if (ok && NC && hipMemcpy(h_out.data(), d_out, (size_t)NC * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-#else
-    combine_problem(v, np);
-    if (NC) memcpy(h_out.data(), d_out, (size_t)NC * sizeof(int32_t));
-#endif
+    if (thread_form) hipLaunchKernelGGL(combine_problem, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, st, v, np);
+    else hipLaunchKernelGGL(combine_problem_wave, dim3((unsigned)(np < 65536 ? np : 65536)), dim3(64), 0, st, v, np);
+    ok = hipGetLastError() == hipSuccess;
   }
-  for (void* p : frees) {
-#ifndef SNF_EMU
-    (void)hipFree(p);
-#else
-    free(p);
-#endif
-  }
+  ok = ok && hipEventRecord(A.ev1, st) == hipSuccess;
+  ok = ok && hipMemcpyAsync(h + o_stats, d + o_stats, 3 * 64 * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) == hipSuccess;
+  ok = ok && (NC == 0 || hipMemcpyAsync(h + o_out, d + o_out, (size_t)NC * sizeof(int32_t), hipMemcpyDeviceToHost, st) == hipSuccess);
+  ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return 1;
+  { float ms = 0; if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess) A.last_kernel_ms = ms; }
+#else
+  (void)in_end;
+  memset(d + o_stats, 0, 3 * 64 * 16 * sizeof(unsigned long long));
+  combine_problem(v, np);
+#endif
+  {
+    const unsigned long long* hs = (const unsigned long long*)(h + o_stats);
+    for (int c = 0; c < 3; c++) { unsigned long long t = 0; for (int k = 0; k < 64; k++) t += hs[(c * 64 + k) * 16]; A.last_stats[c] = (long long)t; }
+    A.last_stats[3] = (long long)in_end;
+  }
+  const int32_t* h_out = (const int32_t*)(h + o_out);
   for (int64_t p = 0; p < np; p++)
     for (int i = 0; i < P[p].n_cands; i++) P[p].out_group[i] = h_out[(size_t)(c_off[p] + i)];
+  return 0;
+}
+
+// measurement hook: the kernel time of the last snf_combine_resolve_batch on `device` (HIP events on the arena's stream) and
+// what it aligned: stats[0] alignments (SVGroup.align_call evaluations), [1] bytes of the aligned strings, [2] cells of their
+// full DP matrices, [3] bytes staged host -> HBM
+extern "C" int snf_combine_last_stats(int device, double* kernel_ms, int64_t* stats4) {
+  if (device < 0 || device >= SNF_MAX_DEVICES || !kernel_ms || !stats4) return 1;
+  DevArena& A = g_combine_arenas[device];
+  std::lock_guard<std::mutex> hold(A.mu);
+  *kernel_ms = A.last_kernel_ms;
+  for (int k = 0; k < 4; k++) stats4[k] = A.last_stats[k];
   return 0;
 }

@@ -119,6 +119,95 @@ SNF_HD int64_t ed_serial_k(const uint8_t* A, int64_t la, const uint8_t* B, int64
 }
 
 #if !defined(SNF_EMU) && defined(__HIPCC__)
+typedef uint64_t __attribute__((aligned(1))) ed_u64_unaligned;
+// bit-planes of the 64 pattern bytes at p (cnt of them valid) from eight 8-byte loads: bit k of byte i of a word lands on
+// bit i of the gathered byte ((x >> k) & 0x0101..01) * 0x0102040810204080 >> 56).  Reads up to 7 bytes past p + cnt.
+__device__ inline void block_planes_words(const uint8_t* p, int cnt, uint64_t planes[8], uint64_t* valid) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) planes[k] = 0;
+  for (int w = 0; w * 8 < cnt; w++) {
+    const uint64_t x = *(const ed_u64_unaligned*)(p + 8 * w);
+#pragma unroll
+    for (int k = 0; k < 8; k++) planes[k] |= ((((x >> k) & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56) << (8 * w);
+  }
+  *valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+}
+
+// Banded distance by one whole wave (all 64 lanes call it together; `k` and the strings are wave-uniform): lane = pattern
+// block modulo 64 - block b lives in lane b & 63 while it is inside the band and hands the lane to block b + 64 afterwards
+// - anti-diagonal schedule: block b works on column t - b at step t and takes hin from block b - 1 (lane - 1, rotating) by a
+// shuffle, or +1 where that block has left the band.  Every lane walks consecutive text columns, so it reads the text eight
+// bytes at a time (next word requested a word ahead); the pattern bit-planes and (Pv, Mv) stay in registers: no per-column
+// carry bytes in HBM.  The text must be readable up to 15 bytes past its end (the pools carry 16 bytes of slack).
+// Needs the band to be at most 63 blocks wide (callers fall back to ed_wave_pair otherwise).  Returns the distance if it
+// is <= k (k < 0: no cut-off), else -1.
+__device__ inline bool ed_wave_band_fits(int64_t la, int64_t lb, int64_t k) {
+  int64_t m = la < lb ? la : lb, n = la < lb ? lb : la;
+  EdBand bd;
+  if (!ed_band(m, n, k, &bd)) return true;          // answered without any work
+  return (64 + bd.dl + 2 * bd.kk) / 64 + 2 <= 63 || (m + 63) / 64 <= 63;
+}
+__device__ inline int64_t ed_wave_pair_k(const uint8_t* A, int64_t la, const uint8_t* B, int64_t lb, int64_t k) {
+  const int lane = (int)(threadIdx.x & 63);
+  const uint8_t *P = A, *T = B; int64_t m = la, n = lb;
+  if (la > lb) { P = B; m = lb; T = A; n = la; }
+  EdBand bd;
+  if (!ed_band(m, n, k, &bd)) return -1;
+  if (m == 0) return n;
+  const int64_t nb = (m + 63) / 64;
+  int64_t b = lane;                       // the block this lane holds (b, b + 64, ...)
+  int64_t cs = 0, ce = -1, nxt_cs = 0;    // its column window; first column of block b + 1 (end of this block's "own" columns)
+  uint64_t planes[8], valid = 0, Pv = ~0ull, Mv = 0;
+#pragma unroll
+  for (int q = 0; q < 8; q++) planes[q] = 0;
+  uint64_t tw = 0, tw_next = 0; int64_t jb = 0;    // text bytes [jb, jb + 8) and [jb + 8, jb + 16) of this lane's column walk
+  auto enter = [&](int64_t blk) {
+    b = blk;
+    if (b < nb) {
+      const int cnt = (int)(m - b * 64 < 64 ? m - b * 64 : 64);
+      block_planes_words(P + b * 64, cnt, planes, &valid);
+      cs = ed_band_cs(bd, b); ce = ed_band_ce(bd, b);
+      nxt_cs = b + 1 < nb ? ed_band_cs(bd, b + 1) : n;
+      Pv = ~0ull; Mv = 0;
+      jb = cs; tw = *(const ed_u64_unaligned*)(T + jb); tw_next = *(const ed_u64_unaligned*)(T + jb + 8);
+    } else { cs = 0; ce = -1; nxt_cs = 0; }
+  };
+  enter(lane);
+  int64_t acc = 0;       // sum over this lane's finished blocks b < nb - 1 of (64 + sum of hout over [cs_b, cs_{b+1}))
+  int64_t rel = 0;       // sum of hout of the current block so far
+  int64_t own = 0;       // ... over its own columns only (those before block b + 1 starts)
+  int hout = 0;
+  uint64_t fPv = ~0ull, fMv = 0; int64_t frel = 0; bool fin = false;
+  const int64_t steps = n + nb - 1;      // block b works on column j at step j + b
+  for (int64_t t = 0; t < steps; t++) {
+    const int up = __shfl(hout, (lane + 63) & 63, 64);     // hout of block b - 1 at the previous step (= the same column)
+    const int64_t j = t - b;
+    if (b < nb && j >= cs && j <= ce) {
+      // block b - 1 covers column j iff j <= ce_{b-1}; its window ends 64 columns before this one does
+      const bool above = b > 0 && j <= ed_band_ce(bd, b - 1);
+      const int hin = above ? up : 1;
+      if (j - jb >= 8) { jb += 8; tw = tw_next; tw_next = *(const ed_u64_unaligned*)(T + jb + 8); }
+      hout = advance_block(Pv, Mv, eq_mask(planes, valid, (uint8_t)(tw >> (8 * (j - jb)))), hin);
+      rel += hout;
+      if (j < nxt_cs) own += hout;
+      if (j == ce) {                      // this block is through
+        if (b == nb - 1) { fPv = Pv; fMv = Mv; frel = rel; fin = true; }
+        else acc += 64 + own;
+        rel = 0; own = 0;
+        enter(b + 64);
+      }
+    }
+  }
+  // D at the bottom of the last (padded) block in the last column = 64 + sum_{b < nb-1} (64 + own_b) + rel_{nb-1}
+  int64_t tot = acc + (fin ? frel : 0);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  const int owner = (int)((nb - 1) & 63);
+  const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
+  const int64_t dist = unpad_score(64 + tot, oPv, oMv, (int)(nb * 64 - m));
+  return (k >= 0 && dist > k) ? -1 : dist;
+}
+
 // the same distance computed by one whole wave (all 64 lanes must call it together): lane = 64-row block of the current
 // 64-block pass, anti-diagonal schedule (lane l works on column t - l at step t and takes hin from lane l-1 by a
 // shuffle); patterns of more than 64 blocks take several passes linked through `carry` (>= max(la, lb) bytes)

@@ -46,8 +46,13 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
                                             C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
+    lib.snf_edit_distance_batch_k.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
+                                              C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.snf_edit_distance_batch_k.restype = C.c_int
     lib.snf_combine_resolve_batch.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_combine_problem_t), C.c_int64]
     lib.snf_combine_resolve_batch.restype = C.c_int
+    lib.snf_combine_last_stats.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.snf_combine_last_stats.restype = C.c_int
     u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     lib.snf_consensus_batch.argtypes = [C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p, i64p, i64p, i32p, u8p, i64p]
     lib.snf_consensus_batch.restype = C.c_int
@@ -182,8 +187,10 @@ def device_count() -> int:
     return int(load().snf_device_count())
 
 
-def edit_distance_batch(pairs, device: int = 0, _lib=None) -> np.ndarray:
-    """Global unit-cost edit distance for a list of (bytes, bytes) pairs (edlib.align(a,b)['editDistance'])."""
+def edit_distance_batch(pairs, device: int = 0, _lib=None, max_dist=None) -> np.ndarray:
+    """Global unit-cost edit distance for a list of (bytes, bytes) pairs (edlib.align(a,b)['editDistance']).
+    `max_dist` (one int per pair, or one int for all; edlib's `k`): distances beyond it come back as -1 and the alignment
+    is banded accordingly; None / negative: exact."""
     lib = _lib or load()
     n = len(pairs)
     a_off = np.zeros(n + 1, np.int64)
@@ -195,9 +202,17 @@ def edit_distance_batch(pairs, device: int = 0, _lib=None) -> np.ndarray:
     b_pool = np.frombuffer(b"".join(p[1] for p in pairs) or b"\0", np.uint8)
     out = np.zeros(max(n, 1), np.int32)
     u8p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64)
-    _check(lib, lib.snf_edit_distance_batch(device, a_pool.ctypes.data_as(u8p), a_off.ctypes.data_as(i64p),
-                                            b_pool.ctypes.data_as(u8p), b_off.ctypes.data_as(i64p), n,
-                                            out.ctypes.data_as(C.POINTER(C.c_int32))))
+    if max_dist is None:
+        _check(lib, lib.snf_edit_distance_batch(device, a_pool.ctypes.data_as(u8p), a_off.ctypes.data_as(i64p),
+                                                b_pool.ctypes.data_as(u8p), b_off.ctypes.data_as(i64p), n,
+                                                out.ctypes.data_as(C.POINTER(C.c_int32))))
+    else:
+        k = np.ascontiguousarray(np.broadcast_to(np.asarray(max_dist, np.int32), (max(n, 1),)))
+        rc = lib.snf_edit_distance_batch_k(device, a_pool.ctypes.data_as(u8p), a_off.ctypes.data_as(i64p),
+                                           b_pool.ctypes.data_as(u8p), b_off.ctypes.data_as(i64p), n,
+                                           k.ctypes.data_as(C.POINTER(C.c_int32)), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise SnifflesAmdError("snf_edit_distance_batch_k failed (no HIP device?)")
     return out[:n]
 
 
@@ -211,3 +226,12 @@ def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
     rc = lib.snf_combine_resolve_batch(C.byref(cs), device, arr, len(problems))
     if rc != 0:
         raise SnifflesAmdError("snf_combine_resolve_batch failed (no HIP device, or invalid sample ids)")
+
+
+def combine_last_stats(device: int = 0, _lib=None) -> dict:
+    """Kernel time and alignment counters of the last combine_resolve_batch on `device`."""
+    lib = _lib or load()
+    ms, st = C.c_double(), (C.c_int64 * 4)()
+    if lib.snf_combine_last_stats(device, C.byref(ms), st) != 0:
+        raise SnifflesAmdError("snf_combine_last_stats failed")
+    return dict(kernel_ms=float(ms.value), alignments=int(st[0]), aligned_bytes=int(st[1]), dp_cells=int(st[2]), staged_bytes=int(st[3]))

@@ -38,6 +38,38 @@ def test_edit_distance_emulated(oracle_mod):
     assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]
 
 
+def check_banded(pairs, exact, **kw):
+    """edlib's `k`: the distance when it is <= k, otherwise -1 - for cut-offs below, at and above the true distance,
+    a cut-off smaller than the length difference, 0, and cut-offs far beyond (no band)."""
+    rng = np.random.default_rng(5)
+    for mode in range(6):
+        ks = []
+        for (a, b), d in zip(pairs, exact):
+            ks.append([d - 1, d, d + 1, abs(len(a) - len(b)) - 1, int(rng.integers(0, 2 * max(len(a), len(b)) + 2)), 0][mode])
+        ks = [max(k, 0) if mode != 3 else k for k in ks]
+        ks = [k if k >= 0 else 0 for k in ks]
+        got = lib.edit_distance_batch(pairs, max_dist=ks, **kw).tolist()
+        assert got == [d if d <= k else -1 for d, k in zip(exact, ks)], mode
+    assert lib.edit_distance_batch(pairs, max_dist=-1, **kw).tolist() == exact
+
+
+def test_edit_distance_banded_emulated(oracle_mod):
+    import emu.emu as E
+    sizes = [1, 2, 63, 64, 65, 127, 128, 129, 300, 511, 513, 700, 1500] + list(np.random.default_rng(7).integers(1, 400, 40))
+    pairs = make_pairs(8, sizes, alphabet=b"ACGTN")
+    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs], _lib=E.lib())
+
+
+@pytest.mark.gpu
+def test_edit_distance_banded_gpu(oracle_mod):
+    """thread form (<= 8 blocks, states in LDS), banded wave form (lane = block of the band, blocks rotating through the
+    lanes beyond 4 kb) and the multi-pass wave form (bands wider than 63 blocks)."""
+    sizes = [1, 63, 64, 65, 128, 300, 512, 513, 600, 1000, 2047, 4096, 4097, 5000, 6100, 9000, 12000] + \
+        list(np.random.default_rng(4).integers(1, 3000, 80))
+    pairs = make_pairs(6, sizes, alphabet=b"ACGTN")
+    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs])
+
+
 @pytest.mark.gpu
 def test_edit_distance_gpu_thread_and_wave_paths(oracle_mod):
     # <= 512: thread per pair; > 512: wave per pair; > 4096: several 64-block passes

@@ -1,0 +1,231 @@
+"""bench.py --config 4: population merge (BASELINE.json configs[4]): S HG002-shaped samples -> combined multi-sample calls.
+
+Set-up (untimed): every sample of the population (same SV sites and alleles, own reads; 70 % of the sites per sample) runs
+through the calling hot path on this GPU; its candidates go into 100-kb SNF blocks with the downsampled coverage
+(`snf_batch_block_coverage`) exactly as `CallTask.write_snf_part` stores them - kept in memory behind the SNF reader interface
+instead of gzip / pickle files (container I/O is not what is measured).
+One step = `CombineTask.execute` of every contig task of this rank over the S readers (`parallel.py:444-572`): the block / bin /
+flush-window walk and the `SVGroup.call` replay on the host, the group assignment with its on-demand banded edit distances in
+ONE `snf_combine_resolve_batch` call per contig.  N > 1: contigs sharded longest-first over the ranks (weak scaling would need
+N populations; the merge of one population is what `configs[4]` names, so this is STRONG scaling: `scaling: "strong"`).
+value = candidates merged per second (whole job); the kernel inside the C-ABI call is reported against the roofline with the
+bytes it aligned, DP cells per second next to it (the bound of this kernel is VALU issue, not HBM: integer bit-vector work).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK_GBS = 8000.0
+
+
+class MemReader:
+    """The SNF reader interface `CombineTask.execute` uses (`SNFile.read_blocks`, attribute `reqc`) over blocks in memory."""
+    reqc = False
+
+    def __init__(self):
+        self.blocks = {}            # contig -> {block_index: block dict}
+
+    def read_blocks(self, contig, block_index):
+        b = self.blocks.get(contig, {}).get(block_index)
+        return None if b is None else [b]
+
+
+def build_sample(cfg, tasks, device, sid):
+    """Candidates of one sample (all contig tasks in one device batch) -> SNF blocks in memory (snf.py:90-98, 249-267)."""
+    from sniffles_amd import lib, sv
+    reader = MemReader()
+    bs, binsize = cfg.snf_block_size, cfg.coverage_binsize_combine
+    per_block = bs // binsize
+    n = 0
+    with lib.Batch(cfg, tasks, device=device) as b:
+        b.call_candidates(); b.finalize()
+        res = b.fetch(1)
+        for t, ti in enumerate(tasks):
+            lo, hi = int(res.task_call_off[t]), int(res.task_call_off[t + 1])
+            cands = sv.materialize_candidates(res, ti, lo, hi)
+            sv.apply_final(cands, res, ti, lo)
+            blocks = reader.blocks.setdefault(ti.contig, {})
+            for c in cands:
+                c.finalize()
+                c.rnames = None
+                if c.svtype not in sv.TYPES:
+                    continue
+                bi = int(c.pos / bs) * bs
+                if bi not in blocks:
+                    blocks[bi] = {svtype: [] for svtype in sv.TYPES}
+                    blocks[bi]["_COVERAGE"] = {}
+                blocks[bi][c.svtype].append(c)
+                n += 1
+            if blocks:
+                first, last = min(blocks) // bs, max(blocks) // bs
+                depth = b.block_coverage(t, binsize, first * per_block, (last - first + 1) * per_block)
+                for bi, blk in blocks.items():
+                    base = (bi // bs - first) * per_block
+                    for i in range(per_block):
+                        d = int(depth[base + i])
+                        if d >= 0:
+                            blk["_COVERAGE"][bi + i * binsize] = d
+    return reader, n
+
+
+def run(ctx):
+    import torch
+    import torch.distributed as dist
+
+    from sniffles_amd import cluster, dist as sdist, lib, parallel, synth
+    from sniffles_amd.config import SnifflesConfig
+
+    args, rank, world, local_rank, use_dist = (ctx[k] for k in ("args", "rank", "world", "local_rank", "use_dist"))
+    S = max(2, args.samples)
+    cov = args.coverage if args.coverage is not None else 15.0
+    steps = args.steps if args.steps is not None else 3
+    warmup = args.warmup if args.warmup is not None else 1
+    contigs = [(ci, c, max(200000, int(synth.GRCH38[c] * args.scale))) for ci, c in enumerate(synth.CONTIGS)]
+    mine = sdist.shard_lpt([L for _, _, L in contigs], world)[rank]
+    my_contigs = [contigs[i] for i in mine]
+    call_cfg = SnifflesConfig()
+    t0 = time.time()
+    readers, n_cands = {}, 0
+    for s in range(S):
+        tasks = [synth.gen_task(ci, c, L, cov, seed=100 + s, site_seed=501) for ci, c, L in my_contigs]
+        readers[s], n = build_sample(call_cfg, tasks, local_rank, s)
+        n_cands += n
+    t_setup = time.time() - t0
+    cfg = SnifflesConfig()
+    cfg.mode = "combine"
+    cfg.snf_input_info = [dict(internal_id=s, sample_id=f"S{s}") for s in range(S)]
+    cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(S)]
+
+    box = dict(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
+    real_call = lib.combine_resolve_batch
+
+    def timed_call(config, problems, device=0, _lib=None):     # the C-ABI call alone (host staging + H2D + kernel + D2H)
+        t = time.perf_counter()
+        real_call(config, problems, device=device, _lib=_lib)
+        box["abi_s"] += time.perf_counter() - t
+        st = lib.combine_last_stats(device)
+        box["kernel_ms"] += st["kernel_ms"]
+        for k, name in enumerate(("alignments", "aligned_bytes", "dp_cells", "staged_bytes")):
+            box["stats"][k] += st[name]
+    lib.combine_resolve_batch = timed_call
+
+    def one_pass():
+        box.update(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
+        n = 0
+        for ci, c, L in my_contigs:
+            task = parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank)
+            n += len(task.execute(readers))
+        box["calls"] = n
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        one_pass()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass()
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.combine_resolve_batch = real_call
+    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device="cuda")
+    if use_dist:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if rank != 0:
+        return None
+    dt = float(tt.item())
+    total_cands, total_calls = int(tot[0].item()), int(tot[1].item())
+    kms = box["kernel_ms"]
+    al, ab, cells, staged = box["stats"]
+    achieved = ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    out = dict(metric="SV candidates merged/sec (multi-sample combine: group assignment with banded edit distance + SVGroup.call)",
+               value=total_cands * steps / dt, unit="candidates/s", n_gpus=world, steps=steps, warmup=warmup,
+               ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32/f64/u64 bit-vectors",
+               data="synthetic",
+               config=dict(workload=f"population merge: {S} HG002-shaped samples at {cov:g}x (shared SV sites, own reads) -> combine "
+                                    f"(BASELINE.json configs[4]), candidates from this package's calling path, SNF blocks in memory",
+                           baseline_config=4, samples=S, coverage=cov, scale=args.scale, contig_tasks=len(contigs),
+                           candidates=total_cands, combined_calls=total_calls, setup_s=round(t_setup, 1),
+                           parallelism=f"contig tasks sharded longest-first over {world} ranks, no data-path collective",
+                           rank0=dict(c_abi_call_ms=round(box["abi_s"] * 1e3, 2), kernel_ms=round(kms, 3),
+                                      host_ms=round(dt / steps * 1e3 - box["abi_s"] * 1e3, 1), staged_bytes=staged,
+                                      alignments=al, dp_cells=cells,
+                                      dp_cells_per_s=round(cells / (kms * 1e-3)) if kms > 0 else None),
+                           parity_unpinned=["edit distance vs edlib itself (edlib absent; pinned to the exact Levenshtein DP)"]),
+               roofline=dict(bound="hbm", kernel="combine_problem_wave", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=round(achieved / HBM_PEAK_GBS, 6), traffic=None, kernel_ms=round(kms, 3), algorithmic_bytes=ab,
+                             note="bit-parallel Myers blocks: the kernel is VALU-issue bound (integer work, ~25 ops per 64 DP cells), "
+                                  "not HBM bound; bytes = lengths of the aligned strings"))
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"], ver = cpu_baseline_and_verify(cfg, readers, my_contigs, S, local_rank, args)
+        if ver is not None:
+            out["verified"] = ver["ok"]
+            out["verify"] = ver
+    return out
+
+
+def sample_windows(cfg, readers, contigs, limit):
+    """Flush windows of the merge as independent resolve_block_groups problems (no kept groups): the binning walk of
+    CombineTask.execute over the first contigs, INS windows first (they carry the alignments)."""
+    from sniffles_amd import sv
+    out = []
+    bin_min = cfg.combine_min_size
+    cap = max(25, int(len(cfg.snf_input_info) * 0.5))
+    for ci, contig, L in contigs:
+        blocks = sorted(set(b for r in readers.values() for b in r.blocks.get(contig, {})))
+        for bi in blocks:
+            for svtype in sv.TYPES:
+                bins = {}
+                for sid, r in readers.items():
+                    blk = r.blocks.get(contig, {}).get(bi)
+                    if blk is None:
+                        continue
+                    for c in blk[svtype]:
+                        if c.support >= cfg.combine_support_threshold:
+                            c.sample_internal_id = sid
+                            bins.setdefault(int(c.pos / bin_min) * bin_min, []).append(c)
+                cur = []
+                keys = sorted(bins)
+                for k in keys:
+                    cur.extend(bins[k])
+                    if len(cur) >= cap or k == keys[-1]:
+                        out.append((svtype, cur))
+                        cur = []
+                if len(out) >= 4 * limit:
+                    break
+        if len(out) >= 4 * limit:
+            break
+    out.sort(key=lambda w: (w[0] != "INS",))
+    return out[:limit]
+
+
+def cpu_baseline_and_verify(cfg, readers, contigs, S, device, args):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import combine_pool
+    from sniffles_amd import cluster
+    cores = os.cpu_count() or 1
+    wins = sample_windows(cfg, readers, contigs, limit=max(64, min(2000, 12 * cores)))
+    if not wins:
+        return dict(value=0.0, unit="candidates/s", cores=0, kind="port", sample="no windows"), None
+    n_c = sum(len(c) for _, c in wins)
+    r = combine_pool.run_windows([(k, combine_pool.window_of(t, c)) for k, (t, c) in enumerate(wins)], {}, S)
+    t0 = time.perf_counter()
+    got = cluster.resolve_chains_batch([(t, c, [0, len(c)], [0], [-1.0]) for t, c in wins], cfg, device=device, cut=False)
+    t_gpu = time.perf_counter() - t0
+    bad = [k for k, ((t, c), g) in enumerate(zip(wins, got)) if list(g[:len(c)]) != r["groups"][k]]
+    base = dict(value=n_c / r["slowest_s"], unit="candidates/s", cores=r["procs"], kind="port", cores_used=r["procs"], host_cores=r["cores"],
+                all_core_cand_s=n_c / r["slowest_s"], single_core_cand_s=n_c / r["sum_s"],
+                sample=f"{len(wins)} flush windows ({n_c} candidates, INS windows first) of the same merge as independent "
+                       f"resolve_block_groups problems through the C oracle (exact edit-distance DP), {r['procs']} processes: slowest "
+                       f"{r['slowest_s']:.2f} s, sum {r['sum_s']:.2f} s; the same windows on the GPU incl. packing: {t_gpu:.3f} s")
+    ver = dict(ok=not bad, windows_compared=len(wins), candidates_compared=n_c,
+               what="group assignment of every candidate of the sampled windows, GPU vs the C oracle", differences=bad[:5])
+    return base, ver
