@@ -341,6 +341,39 @@ int snf_batch_coverage_calls(snf_batch_t* b, int32_t task_index, int64_t n, cons
                              const int32_t* svlen, const uint8_t* bnd_is_first, int32_t* cov, int32_t* status,
                              double* coverage_mean);
 
+/* replaces postprocessing.genotype_sv(svcall, config) (src/sniffles/postprocessing.py:607-623 -> genotyping.py:62-241) for
+ * calls that are not a batch's own: the candidates of SNF files older than 2.5.3 that CombineTask.execute genotypes again
+ * (--reqc, parallel.py:507-508).  In / out on the records: reads svtype, svlen, support, support_sa, cov[5], filter, qc and
+ * the current phase (gt_hp, gt_ps, ph_*); writes gt_set, gt_a, gt_b, gt_gq, gt_dr, gt_dv, gt_hp, gt_ps, vaf, filter, qc,
+ * ph_hp_pass (a call without usable coverage gets filter GT_FAILED and keeps its genotype, as in the reference). */
+int snf_genotype_batch(const snf_config_t* cfg, int device, snf_call_t* calls, int64_t n);
+
+/* Seam B3 / debugging: the clusters of the candidate stage as the reference's cluster.resolve
+ * (src/sniffles/cluster.py:219-353) sees them, copied to the host after snf_batch_call_candidates.
+ *   stage 0: seed clusters (one per 100-bp bin that passes dev_min_leads_cluster, cluster.py:238-275)
+ *   stage 1: after the adaptive merge scan - the list the reference dumps with --dev-dump-clusters (cluster.py:278-324)
+ *   stage 2: what resolve() yields - after merge_inner / resplit / resplit_bnd (cluster.py:326-353)
+ * Clusters come in the reference's order (task, svtype, seed; resplit order inside a merged cluster); the leads of
+ * cluster i are lead[lead_off[i] .. lead_off[i+1]) in the reference's list order: rows of the task's input table
+ * (stage 2: the row of the head of a fused lead) with the svlen they carry at that stage (fused by merge_inner at stage 2).
+ * Pointers are valid until the next call on the batch. */
+typedef struct snf_clusters {
+  int64_t n_clusters;
+  const int32_t* task_index;
+  const int32_t* svtype;
+  const int32_t* start;        /* Cluster.start / end / seed (cluster.py:262-266, 302) */
+  const int32_t* end;
+  const int32_t* seed;
+  const int32_t* seed_index;   /* index of the seed bin among the sorted bins of its (task, svtype): Cluster.id */
+  const int32_t* n_leads_long; /* len(cluster.leads_long) (INS), 0 otherwise */
+  const uint8_t* repeat;
+  const int64_t* lead_off;     /* n_clusters + 1 */
+  int64_t n_leads;
+  const int32_t* lead;         /* row in the task's input arrays */
+  const int32_t* lead_svlen;   /* SNF_SVLEN_NONE never occurs here (leads_long are counted, not listed) */
+} snf_clusters_t;
+int snf_batch_fetch_clusters(snf_batch_t* b, int stage, snf_clusters_t* out);
+
 /* per-kernel timing (HIP events on the batch stream, recorded around every launch of the
  * last call_candidates+finalize pass). names[i] points to a static string. */
 int snf_batch_timing_count(snf_batch_t* b);

@@ -54,6 +54,42 @@ def main(names=None):
 
 
 
+CLUSTER_CASES = ["chr20_30x_ont", "chr21_30x_mosaic", "chr19_30x_no_tr", "merge_inner", "resplit_wrap", "merge_index_rule", "tr_sweep_repeat",
+                 "bnd_stale_end", "long_ins", "fuzz_0_0", "fuzz_3_3", "fuzz_5_4", "fuzz_10_5"]
+
+
+def main_clusters(names=None):
+    """Seam B3: the reference's cluster.resolve per SV type (dump-point BED text + yielded clusters) for a few of the cases."""
+    import cases
+    import ref_harness as rh
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    doc = {}
+    for name in CLUSTER_CASES:
+        build, kw, args = cases.ALL[name]
+        ti = build()
+        doc[name] = dict(input_sha=input_sha(ti), config=kw, reference_args=list(args), clusters=rh.run_reference_clusters(ti, args))
+        print(f"{name:32s} " + " ".join(f"{t}:{len(v['yielded'])}" for t, v in doc[name]["clusters"].items()))
+    with gzip.GzipFile(os.path.join(out_dir, "clusters_resolve.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
+REGENOTYPE_CASES = ["chr20_30x_ont", "chr22_60x_hifi", "phase_rescue", "gt_failed_edges", "long_del_dup_cov", "fuzz_3_0", "fuzz_6_0"]
+
+
+def main_regenotype():
+    """--reqc: the reference's genotype_sv applied once more to finalized candidates."""
+    import cases
+    import ref_harness as rh
+    doc = {}
+    for name in REGENOTYPE_CASES:
+        build, kw, args = cases.ALL[name]
+        ti = build()
+        doc[name] = dict(input_sha=input_sha(ti), config=kw, calls=rh.run_reference_regenotype(ti, args))
+        print(f"{name:32s} {len(doc[name]['calls'])} candidates re-genotyped")
+    with gzip.GzipFile(os.path.join(ROOT, "tests", "golden", "regenotype.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+
+
 def main_combine(names=None):
     import cases
     import ref_harness as rh
@@ -146,7 +182,8 @@ def main_combine_task(names=None):
         if names and name not in names:
             continue
         tis = build()
-        ref = rh.run_reference_combine_task(tis, args)
+        # one case also pins CombineTask.scatter (parallel.py:422-442): sub-tasks of consecutive blocks, each executed alone
+        ref = rh.run_reference_combine_task(tis, args, scatter_target=40 if name == "combine_task_6samples" else None)
         doc = dict(case=name, reference_args=list(args), input_sha=[input_sha(t) for t in tis], expected=ref)
         with gzip.GzipFile(os.path.join(out_dir, name + ".json.gz"), "wb", mtime=0) as f:
             f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
@@ -382,14 +419,16 @@ if __name__ == "__main__":
     # python oracle/make_golden.py                 -> every fixture family
     # python oracle/make_golden.py vcf sample      -> only these families
     # python oracle/make_golden.py main fuzz_4_2   -> single cases of the `main` / `combine` families
-    FAMILIES = dict(main=main, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
+    FAMILIES = dict(main=main, clusters=main_clusters, regenotype=main_regenotype, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
                     bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype, population=main_population, genotype_vcf=main_genotype_vcf)
     argv = sys.argv[1:]
     fams = [a for a in argv if a in FAMILIES] or list(FAMILIES)
     names = set(a for a in argv if a not in FAMILIES)
     for fam in fams:
         fn = FAMILIES[fam]
-        if fam in ("main", "combine", "combine_task", "extract", "sample", "population"):
+        if fam == "clusters":
+            fn()
+        elif fam in ("main", "combine", "combine_task", "extract", "sample", "population"):
             fn(names or None)
         else:
             fn()

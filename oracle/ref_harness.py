@@ -180,6 +180,51 @@ def run_reference(ti, extra_args=(), keep_qc_fails=True, finalize_keep=False, cf
     return out
 
 
+def run_reference_regenotype(ti, extra_args=()):
+    """What --reqc does to the candidates of an old SNF file (parallel.py:507-508): the reference's own
+    postprocessing.genotype_sv(cand, config) on every finalized candidate of a task, a second time."""
+    ref = load_reference()
+    cfg = make_config(tuple(extra_args), ti.qc_nm_threshold)
+    task = build_task(ti, cfg)
+    cands = task.call_candidates(False, cfg)
+    task.finalize_candidates(cands, True, cfg)
+    out = []
+    for c in cands:
+        if c.svtype not in ref.sv.TYPES:
+            continue
+        ref.postprocessing.genotype_sv(c, cfg)
+        gt = c.genotypes.get(0)
+        out.append(dict(id=c.id, filter=c.filter, qc=bool(c.qc), vaf=_f(c.info.get("VAF")), phase=c.info.get("PHASE"),
+                        gt=None if gt is None else [gt[0], gt[1], int(gt[2]), int(gt[3]), int(gt[4]), list(gt[5]) if gt[5] is not None else None]))
+    return out
+
+
+def run_reference_clusters(ti, extra_args=()):
+    """The reference's own cluster.resolve (cluster.py:219-353) on one task, SV type by SV type: the `--dev-dump-clusters`
+    BED text (the clusters after the merge scan) and every yielded cluster (after merge_inner / resplit / resplit_bnd)."""
+    import contextlib
+    import io
+    import tempfile
+    ref = load_reference()
+    cfg = make_config(tuple(extra_args), ti.qc_nm_threshold)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg.vcf = os.path.join(tmp, "out.vcf")
+        cfg.dev_dump_clusters = True
+        task = build_task(ti, cfg)
+        lp = task.lead_provider
+        for svtype in ref.sv.ALL_TYPES:
+            with contextlib.redirect_stdout(io.StringIO()):
+                yielded = list(ref.cluster.resolve(svtype, lp, cfg, task.tandem_repeats))
+            path = f"{cfg.vcf}.clusters.{svtype}.{lp.contig}.{lp.start}.{lp.end}.bed"
+            bed = open(path).read() if os.path.exists(path) else ""
+            out[svtype] = dict(bed=bed, yielded=[dict(
+                id=c.id, start=int(c.start), end=int(c.end), seed=int(c.seed), repeat=bool(c.repeat),
+                leads_long=None if c.leads_long is None else len(c.leads_long),
+                leads=[[ld.read_qname, int(ld.ref_start), int(ld.svlen), ld.source] for ld in c.leads]) for c in yielded])
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- combine (multi-sample)
 def cand_record(c) -> dict:
     """Everything resolve_block_groups / SVGroup.call read from a per-sample candidate SVCall."""
@@ -265,7 +310,7 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     return out
 
 
-def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False):
+def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, scatter_target=None):
     """The reference's own CombineTask.execute (parallel.py:444-572) on a synthetic population.
 
     Per-sample candidates come from the reference's call_candidates + finalize_candidates; they are put into SNF blocks by
@@ -335,11 +380,25 @@ def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False):
 
     orig = ref.parallel.snf.SNFile
     ref.parallel.snf.SNFile = lambda config, handle, filename=None: (handle.close(), fakes[filename])[1]
+    scattered = None
+    old_target = ref.parallel.CombineTask.TARGET_WORK_PER_TASK
     try:
         ctask = ref.parallel.CombineTask(id=7, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
         res = ctask.execute()
+        if scatter_target is not None:
+            # the reference's own CombineTask.scatter / clone (parallel.py:411-442) with its class constant lowered so that
+            # a test-sized contig is cut (the constant is 10000 blocks x samples), every sub-task executed on its own
+            ref.parallel.CombineTask.TARGET_WORK_PER_TASK = scatter_target
+            cfg.threads = 4
+            ctask2 = ref.parallel.CombineTask(id=7, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
+            scattered = []
+            for sub in ctask2.scatter():
+                r = sub.execute()
+                scattered.append(dict(id=int(sub.id), start=int(sub.start), end=int(sub.end), block_indices=[int(b) for b in sub.block_indices],
+                                      calls=[group_call_record(c) for c in r.calls]))
     finally:
         ref.parallel.snf.SNFile = orig
+        ref.parallel.CombineTask.TARGET_WORK_PER_TASK = old_target
     inputs = []
     for s in range(ns):
         blk = []
@@ -356,6 +415,8 @@ def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False):
         inputs.append(blk)
     doc = dict(n_samples=ns, contig=contig, contig_len=int(contig_len), samples=inputs,
                calls=[group_call_record(c) for c in res.calls])
+    if scattered is not None:
+        doc["scatter"] = dict(target_work_per_task=scatter_target, threads=4, tasks=scattered)
     return (doc, res.calls, cfg) if with_objects else doc
 
 

@@ -110,6 +110,13 @@ class snf_result_t(C.Structure):
     ]
 
 
+class snf_clusters_t(C.Structure):
+    _fields_ = [("n_clusters", i64)] + [(n, C.POINTER(C.c_int32)) for n in
+                                        ("task_index", "svtype", "start", "end", "seed", "seed_index", "n_leads_long")] + \
+               [("repeat", u8p), ("lead_off", C.POINTER(C.c_int64)), ("n_leads", i64), ("lead", C.POINTER(C.c_int32)),
+                ("lead_svlen", C.POINTER(C.c_int32))]
+
+
 class snf_combine_problem_t(C.Structure):
     _fields_ = [
         ("svtype", i32), ("n_cands", i32), ("n_groups", i32), ("n_sample_ids", i32),

@@ -1,13 +1,146 @@
-"""`resolve_block_groups` with the reference's signature (reference `src/sniffles/cluster.py:356-390`).
-
-The single-sample clustering entry points of the reference's `cluster.py` (`resolve`, `merge_inner`, `resplit`,
-`resplit_bnd`) have no Python counterpart here: they run inside `Task.call_candidates` on the GPU
-(`sniffles_amd/parallel.py`)."""
+"""`resolve_block_groups` with the reference's signature (reference `src/sniffles/cluster.py:356-390`) and the view side of
+seam B3: `resolve(svtype, lead_provider, config, tr)` yields the clusters of a task as the reference's `cluster.resolve`
+does (`cluster.py:219-353`), read back from the GPU after `Task.call_candidates` - the clustering itself (`merge_inner`,
+`resplit`, `resplit_bnd`, the merge scan) runs inside the candidate stage on the device, not here.  `dump_clusters_bed`
+writes the `--dev-dump-clusters` file of `cluster.py:316-324`."""
 from __future__ import annotations
 
+from dataclasses import dataclass
+from typing import Optional
+
 from . import abi, lib
-from .soa import SVT
+from .soa import SOURCES, SVT, SVTYPES
 from .sv import SVGroup
+
+
+@dataclass
+class ClusterLead:
+    """What a cluster view shows of a `Lead` (leadprov.py:34-56): the fields the dump and the parity diffs read.  `svlen` is
+    the value the lead carries at that stage (summed over the fused leads after merge_inner); `row` is its row in the
+    task's input table (`TaskInput.leads`)."""
+    row: int
+    read_qname: str
+    ref_start: int
+    svlen: int
+    source: str
+
+
+@dataclass
+class Cluster:
+    id: str
+    svtype: str
+    contig: str
+    start: int
+    end: int
+    seed: int
+    leads: list
+    repeat: bool
+    leads_long: Optional[int]     # len(cluster.leads_long) of the reference (INS), None where the reference has None
+
+    @property
+    def span(self) -> Optional[int]:
+        return None if self.end is None or self.start is None else self.end - self.start
+
+
+def _task_of(lead_provider):
+    batch = getattr(lead_provider, "device_batch", None)
+    ti = getattr(lead_provider, "ti", None) or getattr(lead_provider, "task_input", None)
+    if batch is None or ti is None:
+        raise RuntimeError("cluster.resolve needs the task's device batch: call Task.call_candidates first (the clusters are "
+                           "built on the GPU; there is no CPU fallback)")
+    return batch, ti
+
+
+def clusters_of(batch, ti, stage: int, task_index: int = 0, provider_start: int = 0) -> dict:
+    """{svtype: [Cluster]} of one task at `stage` (0 seeds, 1 merged = the dump point of the reference, 2 = what resolve
+    yields), ids as the reference forms them (`CL.{svtype}.{contig}.{start}.{seed_index}` + the resplit suffixes)."""
+    c = batch.fetch_clusters(stage)
+    L = ti.leads
+    out = {t: [] for t in SVTYPES}
+    binsize_re = None
+    sel = [i for i in range(len(c["svtype"])) if int(c["task_index"][i]) == task_index]
+    made = []
+    for i in sel:
+        svtype = SVTYPES[int(c["svtype"][i])]
+        lo, hi = int(c["lead_off"][i]), int(c["lead_off"][i + 1])
+        leads = [ClusterLead(row=int(r), read_qname=ti.qname(int(L["qname_id"][r])), ref_start=int(L["ref_start"][r]), svlen=int(s),
+                             source=SOURCES[int(L["source"][r])]) for r, s in zip(c["lead"][lo:hi].tolist(), c["lead_svlen"][lo:hi].tolist())]
+        cl = Cluster(id=f"CL.{svtype}.{ti.contig}.{provider_start}.{int(c['seed_index'][i])}", svtype=svtype, contig=ti.contig,
+                     start=int(c["start"][i]), end=int(c["end"][i]), seed=int(c["seed"][i]), leads=leads, repeat=bool(c["repeat"][i]),
+                     leads_long=int(c["n_leads_long"][i]) if svtype == "INS" else None)
+        made.append(cl)
+        out[svtype].append(cl)
+    return out
+
+
+def _resplit_suffixes(clusters, config):
+    """The id suffixes resplit / resplit_bnd append (cluster.py:191, 231-246), recovered from the yielded lead lists: the
+    svlen bin that survived the bin merge is the bin of the cluster's first lead; a BND cluster is named after the bin that
+    closed it (the first bin of the next cluster of the same (mate contig, is_first) group, or the group's last bin - 0 when
+    the group has a single bin)."""
+    rb = config.cluster_resplit_binsize
+    by_parent = {}
+    for cl in clusters:
+        by_parent.setdefault(cl.id, []).append(cl)
+    for parent, group in by_parent.items():
+        svtype = group[0].svtype
+        if svtype == "BND":
+            if config.dev_no_resplit or (len(group) == 1 and len(group[0].leads) <= 1):
+                continue
+            thr = config.cluster_merge_bnd
+
+            def key(cl):
+                return cl._ident
+            for k, cl in enumerate(group):
+                nxt = next((g for g in group[k + 1:] if g._ident == cl._ident), None)
+                bins = [int(p / thr) * thr if thr > 0 else 0 for p in cl._mate_pos]
+                if nxt is not None:
+                    nb = [int(p / thr) * thr if thr > 0 else 0 for p in nxt._mate_pos]
+                    pos_bin = nb[0]
+                else:
+                    first_of_ident = next(g for g in group if g._ident == cl._ident)
+                    single = first_of_ident is cl and len(set(bins)) == 1
+                    pos_bin = 0 if single else bins[-1]
+                cl.id = f"{parent}.CHR2.{cl._ident[0]}.POS2.{pos_bin}"
+        elif not (config.dev_no_resplit_repeat or config.dev_no_resplit):
+            for cl in group:
+                cl.id = f"{parent}.{int(abs(cl.leads[0].svlen) / rb) * rb}"
+
+
+def resolve(svtype, lead_provider, config, tr=None, task_index: int = 0):
+    """`cluster.resolve` of the reference for a task whose candidate stage has run on the GPU: yields the refined clusters of
+    `svtype` in the reference's order.  `tr` is accepted for the signature's sake (the tandem repeats went in with the task)."""
+    batch, ti = _task_of(lead_provider)
+    start = getattr(lead_provider, "start", None) or 0
+    cls = clusters_of(batch, ti, 2, task_index, start)[svtype]
+    if svtype == "BND":
+        L = ti.leads
+        for cl in cls:
+            cl._ident = None
+            if cl.leads:
+                r0 = cl.leads[0].row
+                cl._ident = (ti.contig_name(int(L["mate_contig"][r0])), bool(L["bnd_is_first"][r0]))
+            cl._mate_pos = [int(L["mate_ref_start"][ld.row]) for ld in cl.leads]
+    _resplit_suffixes(cls, config)
+    for cl in cls:
+        yield cl
+
+
+def dump_clusters_bed(lead_provider, config, svtype, handle=None, task_index: int = 0) -> str:
+    """The `--dev-dump-clusters` file of one SV type (cluster.py:316-324): the clusters after the merge scan, one BED line
+    each with their leads.  Returns the text; writes it to `handle` when given."""
+    batch, ti = _task_of(lead_provider)
+    start = getattr(lead_provider, "start", None) or 0
+    lines = []
+    for c in clusters_of(batch, ti, 1, task_index, start)[svtype]:
+        info = f"ID={c.id}, #LEADS={len(c.leads)}; "
+        for ld in c.leads:
+            info += f"(ref_start={ld.ref_start},svlen={ld.svlen},source={ld.source}); "
+        lines.append(f"{c.contig}\t{c.start}\t{c.end}\t\"{info}\"\n")
+    text = "".join(lines)
+    if handle is not None:
+        handle.write(text)
+    return text
 
 
 def _alt_bytes(alt) -> bytes:

@@ -35,7 +35,7 @@ _DEFAULTS = dict(
     # VCF writer (config.py:166-170, 242, 332)
     vcf=None, reference=None, max_del_seq_len=50000, max_unknown_pct=0.5,
     # contig selection of the main program (config.py:168-176, util.py:147-162)
-    all_contigs=False, contig=None,
+    all_contigs=False, contig=None, threads=4,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)
@@ -49,7 +49,7 @@ _DEFAULTS = dict(
     dev_min_leads_cluster=-1, dev_min_dup_vaf=1 / 6.0, dev_longer_del=200000, dev_longer_dup=200000,
     dev_minreads_extra=5, dev_maxsvlen_extra=10000, dev_inline_sa_support_max=0.80,
     dev_min_close_edge_dist=500, dev_min_read_close_edge_prop=0.75, dev_seq_cache_maxlen=50000,
-    dev_emit_sv_lengths=False, dev_trace_read=False, dev_locasm_do=False,
+    dev_emit_sv_lengths=False, dev_trace_read=False, dev_locasm_do=False, dev_dump_clusters=False,
 )
 
 

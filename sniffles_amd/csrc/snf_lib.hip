@@ -7,6 +7,7 @@
 #include "snf_wave_cons.h"
 #include "snf_fused.h"
 #include "snf_wave_call.h"
+#include "snf_ctx.h"
 
 #ifndef SNF_EMU
 #include <rocprim/device/device_radix_sort.hpp>
@@ -178,6 +179,9 @@ struct snf_batch_impl {
   // results (host)
   HostBuf hb_calls, hb_alt, hb_rn, hb_res;
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
+  // snf_batch_fetch_clusters result (host)
+  std::vector<int32_t> cl_task, cl_svtype, cl_start, cl_end, cl_seed, cl_seed_index, cl_nlong, cl_lead, cl_lead_svlen; std::vector<uint8_t> cl_repeat;
+  std::vector<int64_t> cl_lead_off;
   // timing
   std::vector<Timing> timings;
 #ifndef SNF_EMU
@@ -1363,6 +1367,128 @@ void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int
     for (void* p : tmp) dfree_one(b, p);
 }
 
+// ---- stand-alone genotyping (--reqc): genotype_sv of snf_stage_final.h over caller-supplied records
+struct GenoView { snf_config_t cfg; const GtEntry* gt_lut; snf_call_t* calls; int64_t n; };
+namespace snf {
+SNF_HD void g1_genotype_body(int64_t i, const GenoView& q) {
+  // genotype_sv only reads the configuration and the lookup table through the view
+  View v{};
+  v.cfg = q.cfg; v.gt_lut = q.gt_lut;
+  snf_call_t c = q.calls[i];
+  genotype_sv(v, c, c.gt_hp, c.gt_ps);
+  q.calls[i] = c;
+}
+}  // namespace snf
+SNF_KERNEL(g1_genotype, GenoView)
+namespace {
+DevArena g_geno_arenas[SNF_MAX_DEVICES];
+void do_genotype_batch(const snf_config_t* cfg, int device, snf_call_t* calls, int64_t n) {
+  if (!cfg || (n > 0 && !calls)) fail("null argument");
+  if (n <= 0) return;
+  if (cfg->genotype_ploidy != 2) fail("only genotype_ploidy 2 is supported");
+  if (device < 0 || device >= SNF_MAX_DEVICES) fail("device index out of range");
+  auto lut = build_gt_lut(*cfg);
+  DevArena& A = g_geno_arenas[device];
+  std::lock_guard<std::mutex> hold(A.mu);
+  ArenaLayout L;
+  const size_t o_lut = L.add<GtEntry>(lut.size()), o_calls = L.add<snf_call_t>((size_t)n);
+  if (!A.ensure(device, L.at)) fail("no HIP device available: the sniffles_amd hot path requires an AMD GPU (there is no CPU fallback)");
+  memcpy(A.h + o_lut, lut.data(), lut.size() * sizeof(GtEntry));
+  memcpy(A.h + o_calls, calls, (size_t)n * sizeof(snf_call_t));
+  GenoView q{};
+  q.cfg = *cfg; q.gt_lut = (const GtEntry*)(A.d + o_lut); q.calls = (snf_call_t*)(A.d + o_calls); q.n = n;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpyAsync(A.d, A.h, L.at, hipMemcpyHostToDevice, A.stream));
+  hipLaunchKernelGGL(g1_genotype, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, A.stream, q, n);
+  SNF_HIP(hipGetLastError());
+  SNF_HIP(hipMemcpyAsync(A.h + o_calls, A.d + o_calls, (size_t)n * sizeof(snf_call_t), hipMemcpyDeviceToHost, A.stream));
+  SNF_HIP(hipStreamSynchronize(A.stream));
+#else
+  g1_genotype(q, n);
+#endif
+  memcpy(calls, A.h + o_calls, (size_t)n * sizeof(snf_call_t));
+}
+}  // namespace
+
+// ---- cluster export (seam B3): everything is copied to the host and assembled there - a debugging / parity aid
+template <class T>
+std::vector<T> pull(snf_batch_impl* b, const T* dptr, size_t n) {
+  std::vector<T> h(n ? n : 1);
+  d2h(b, h.data(), dptr, n * sizeof(T));
+  return h;
+}
+void do_fetch_clusters(snf_batch_impl* b, int stage, snf_clusters_t* out) {
+  View& v = b->v;
+  if (stage < 0 || stage > 2) fail("stage must be 0 (seeds), 1 (merged) or 2 (refined)");
+  if (!b->cov_avg_ready) fail("snf_batch_fetch_clusters needs snf_batch_call_candidates first");
+  full_sync(b);
+  const Counts c = *b->h_cnt;
+  b->cl_task.clear(); b->cl_svtype.clear(); b->cl_start.clear(); b->cl_end.clear(); b->cl_seed.clear(); b->cl_seed_index.clear();
+  b->cl_nlong.clear(); b->cl_lead.clear(); b->cl_lead_svlen.clear(); b->cl_repeat.clear(); b->cl_lead_off.assign(1, 0);
+  const int64_t N = v.N;
+  if (N > 0 && c.n_seeds > 0) {
+    const size_t ns = (size_t)c.n_seeds, ncl = (size_t)c.n_clusters, nrc = (size_t)c.n_rc, nf = (size_t)c.NF;
+    auto seed_grp = pull(b, v.seed_grp, ns); auto seed_start = pull(b, v.seed_start, ns); auto seed_bin = pull(b, v.seed_bin, ns);
+    auto seed_lo = pull(b, v.seed_lo, ns); auto seed_hi = pull(b, v.seed_hi, ns);
+    auto seedL_lo = pull(b, v.seedL_lo, ns); auto seedL_hi = pull(b, v.seedL_hi, ns);
+    auto s_repeat0 = pull(b, v.s_repeat0, ns);
+    auto grp_first_bin = pull(b, v.grp_first_bin, (size_t)(8 * v.T + 8));
+    auto L = pull(b, v.L, nf);
+    auto lead_off = pull(b, v.t_lead_off, (size_t)v.T + 1);
+    auto in_svlen = pull(b, v.in_svlen, (size_t)N);
+    std::vector<int32_t> cl_head, c_last, c_end, rc_lo, rc_n, rc_cluster, FI, F_orig, F_svlen; std::vector<uint8_t> c_repeat, rc_keeplong;
+    if (stage >= 1) { cl_head = pull(b, v.cl_head, ncl); c_last = pull(b, v.c_last, ns); c_end = pull(b, v.c_end, ns); c_repeat = pull(b, v.c_repeat, ns); }
+    if (stage == 2) {
+      rc_lo = pull(b, v.rc_lo, nrc); rc_n = pull(b, v.rc_n, nrc); rc_cluster = pull(b, v.rc_cluster, nrc); rc_keeplong = pull(b, v.rc_keeplong, nrc);
+      FI = pull(b, v.FI, nf); F_orig = pull(b, v.F_orig, nf); F_svlen = pull(b, v.F_svlen, nf);
+    }
+    dsync(b);
+    auto head = [&](int32_t h, int32_t last, int32_t end, uint8_t rep, int64_t nlong) {
+      const int g = seed_grp[(size_t)h];
+      b->cl_task.push_back(g >> 3); b->cl_svtype.push_back(g & 7); b->cl_start.push_back(seed_start[(size_t)h]); b->cl_end.push_back(end);
+      b->cl_seed.push_back(seed_start[(size_t)h]); b->cl_seed_index.push_back(seed_bin[(size_t)h] - grp_first_bin[(size_t)g]);
+      b->cl_nlong.push_back((int32_t)nlong); b->cl_repeat.push_back(rep);
+      (void)last;
+    };
+    auto add_row = [&](uint32_t orig, int32_t svlen, int task) {
+      b->cl_lead.push_back((int32_t)((int64_t)orig - lead_off[(size_t)task])); b->cl_lead_svlen.push_back(svlen);
+    };
+    const int binsize = b->cfg.cluster_binsize;
+    if (stage == 0) {
+      for (size_t sidx = 0; sidx < ns; sidx++) {
+        head((int32_t)sidx, (int32_t)sidx, seed_start[sidx] + binsize, s_repeat0[sidx], seedL_hi[sidx] - seedL_lo[sidx]);
+        for (int32_t k = seed_lo[sidx]; k < seed_hi[sidx]; k++) add_row(L[(size_t)k], in_svlen[L[(size_t)k]], seed_grp[sidx] >> 3);
+        b->cl_lead_off.push_back((int64_t)b->cl_lead.size());
+      }
+    } else if (stage == 1) {
+      for (size_t ci = 0; ci < ncl; ci++) {
+        const int32_t h = cl_head[ci], last = c_last[(size_t)h];
+        int64_t nlong = 0;
+        for (int32_t sidx = h; sidx <= last; sidx++) nlong += seedL_hi[(size_t)sidx] - seedL_lo[(size_t)sidx];   // merged seeds are consecutive
+        head(h, last, c_end[(size_t)h], c_repeat[(size_t)h], nlong);
+        for (int32_t k = seed_lo[(size_t)h]; k < seed_hi[(size_t)last]; k++) add_row(L[(size_t)k], in_svlen[L[(size_t)k]], seed_grp[(size_t)h] >> 3);
+        b->cl_lead_off.push_back((int64_t)b->cl_lead.size());
+      }
+    } else {
+      for (size_t r = 0; r < nrc; r++) {
+        const int32_t ci = rc_cluster[r], h = cl_head[(size_t)ci], last = c_last[(size_t)h];
+        int64_t nlong = 0;
+        if (rc_keeplong[r]) for (int32_t sidx = h; sidx <= last; sidx++) nlong += seedL_hi[(size_t)sidx] - seedL_lo[(size_t)sidx];
+        head(h, last, c_end[(size_t)h], c_repeat[(size_t)h], nlong);
+        for (int32_t k = 0; k < rc_n[r]; k++) {
+          const int32_t slot = FI[(size_t)(rc_lo[r] + k)];
+          add_row((uint32_t)F_orig[(size_t)slot], F_svlen[(size_t)slot], seed_grp[(size_t)h] >> 3);
+        }
+        b->cl_lead_off.push_back((int64_t)b->cl_lead.size());
+      }
+    }
+  }
+  out->n_clusters = (int64_t)b->cl_task.size();
+  out->task_index = b->cl_task.data(); out->svtype = b->cl_svtype.data(); out->start = b->cl_start.data(); out->end = b->cl_end.data();
+  out->seed = b->cl_seed.data(); out->seed_index = b->cl_seed_index.data(); out->n_leads_long = b->cl_nlong.data(); out->repeat = b->cl_repeat.data();
+  out->lead_off = b->cl_lead_off.data(); out->n_leads = (int64_t)b->cl_lead.size(); out->lead = b->cl_lead.data(); out->lead_svlen = b->cl_lead_svlen.data();
+}
+
 #define SNF_TRY(body)                                   \
   try { body; return 0; }                               \
   catch (const snf::Error& e) { g_err = e.msg; return 1; } \
@@ -1519,6 +1645,21 @@ int snf_batch_fetch(snf_batch_t* bb, int stage, snf_result_t* out) {
     SNF_HIP(hipSetDevice(b->device));
 #endif
     do_fetch(b, stage, out);
+  })
+}
+
+int snf_genotype_batch(const snf_config_t* cfg, int device, snf_call_t* calls, int64_t n) {
+  SNF_TRY(do_genotype_batch(cfg, device, calls, n))
+}
+
+int snf_batch_fetch_clusters(snf_batch_t* bb, int stage, snf_clusters_t* out) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !out) fail("batch not uploaded / null result");
+#ifndef SNF_EMU
+    SNF_HIP(hipSetDevice(b->device));
+#endif
+    do_fetch_clusters(b, stage, out);
   })
 }
 

@@ -36,6 +36,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_finalize.argtypes = [vp]
     lib.snf_batch_fetch.argtypes = [vp, C.c_int, C.POINTER(abi.snf_result_t)]
     lib.snf_batch_sync.argtypes = [vp]
+    lib.snf_genotype_batch.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_call_t), C.c_int64]
+    lib.snf_genotype_batch.restype = C.c_int
+    lib.snf_batch_fetch_clusters.argtypes = [vp, C.c_int, C.POINTER(abi.snf_clusters_t)]
+    lib.snf_batch_fetch_clusters.restype = C.c_int
     lib.snf_batch_export_calls_device.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
     lib.snf_batch_block_coverage.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_batch_block_coverage.restype = C.c_int
@@ -146,6 +150,22 @@ class Batch:
         _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
         return int(r.n_calls)
 
+    def fetch_clusters(self, stage: int) -> dict:
+        """The clusters of the candidate stage (0 seeds, 1 after the merge scan, 2 as cluster.resolve yields them) as numpy
+        columns: task_index, svtype, start, end, seed, seed_index, n_leads_long, repeat, lead_off, lead (row in the task's
+        input table), lead_svlen.  Needs call_candidates first."""
+        r = abi.snf_clusters_t()
+        _check(self.lib, self.lib.snf_batch_fetch_clusters(self._h, stage, C.byref(r)))
+        n, m = int(r.n_clusters), int(r.n_leads)
+
+        def col(p, k, dt):
+            return np.ctypeslib.as_array(p, shape=(k,)).astype(dt, copy=True) if k else np.zeros(0, dt)
+        out = {f: col(getattr(r, f), n, np.int32) for f in ("task_index", "svtype", "start", "end", "seed", "seed_index", "n_leads_long")}
+        out["repeat"] = col(r.repeat, n, np.uint8)
+        out["lead_off"] = col(r.lead_off, n + 1, np.int64)
+        out["lead"], out["lead_svlen"] = col(r.lead, m, np.int32), col(r.lead_svlen, m, np.int32)
+        return out
+
     def export_calls_device(self, dst_ptr: int, cap_calls: int) -> int:
         """Device-to-device copy of the call records into caller-owned HBM (for the RCCL gather)."""
         n = C.c_int64()
@@ -235,3 +255,12 @@ def combine_last_stats(device: int = 0, _lib=None) -> dict:
     if lib.snf_combine_last_stats(device, C.byref(ms), st) != 0:
         raise SnifflesAmdError("snf_combine_last_stats failed")
     return dict(kernel_ms=float(ms.value), alignments=int(st[0]), aligned_bytes=int(st[1]), dp_cells=int(st[2]), staged_bytes=int(st[3]))
+
+
+def genotype_batch(cfg, records: np.ndarray, device: int = 0, _lib=None) -> np.ndarray:
+    """genotype_sv (genotyping.py:62-241) over a structured array of call records (abi.CALL_DTYPE), in place."""
+    lib = _lib or load()
+    records = np.ascontiguousarray(records, abi.CALL_DTYPE)
+    cs = abi.config_struct(cfg)
+    _check(lib, lib.snf_genotype_batch(C.byref(cs), device, records.ctypes.data_as(C.POINTER(abi.snf_call_t)), len(records)))
+    return records

@@ -42,6 +42,7 @@ class Task:
         self.close()
         self._batch = lib.Batch(config, [self._ti], device=self.device, _lib=self._lib)
         lp.device_batch = self._batch   # SNFile.annotate_block_coverages(lead_provider) reads the coverage from HBM
+        lp.task_input = self._ti        # cluster.resolve(svtype, lead_provider, ...) reads the clusters back (seam B3)
 
     def close(self):
         """Release the task's device memory.  The batch outlives finalize_candidates because the SNF writer needs the
@@ -56,6 +57,17 @@ class Task:
         self._open(config)
         self._finalized = False
         self._batch.call_candidates()
+        if getattr(config, "dev_dump_clusters", False):      # cluster.py:316-324, one file per SV type
+            from . import cluster
+            from .soa import SVTYPES
+            lp = self.lead_provider
+            for svtype in SVTYPES:
+                text = cluster.dump_clusters_bed(lp, config, svtype)
+                if text:                                     # (the reference returns before the dump when a type has no seeds)
+                    filename = f"{config.vcf}.clusters.{svtype}.{self.contig}.{getattr(lp, 'start', None) or 0}.{lp.end if getattr(lp, 'end', None) is not None else self.end}.bed"
+                    print(f"Dumping clusters to {filename}")
+                    with open(filename, "w") as h:
+                        h.write(text)
         res = self._batch.fetch(0)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
@@ -190,6 +202,33 @@ class CombineTask(Task):
         else:
             self.block_indices = list(range(self.start, self.end + bs, bs))
 
+    TARGET_WORK_PER_TASK = 10000      # blocks x samples one task should handle (parallel.py:378)
+
+    def clone(self, first_block: int, block_count: int, new_id: int = None) -> "CombineTask":
+        """This task restricted to `block_count` consecutive blocks from `first_block` on (parallel.py:411-420)."""
+        import copy
+        obj = copy.copy(self)
+        if new_id is not None:
+            obj.id = new_id
+        obj.block_indices = self.block_indices[first_block:first_block + block_count]
+        obj.start = obj.block_indices[0]
+        obj.end = obj.block_indices[-1] + obj.config.snf_block_size
+        return obj
+
+    def scatter(self) -> list:
+        """`CombineTask.scatter` of the reference (parallel.py:422-442), cut for cut: when the task holds more than
+        TARGET_WORK_PER_TASK blocks x samples (and more than one worker is configured) it falls apart into tasks of
+        `total_blocks // TARGET_WORK_PER_TASK` consecutive blocks with ids id+1, id+2, ...  Every part is a task of its own -
+        groups that would have been kept across a cut are flushed at the end of the part, exactly as the reference does -
+        which is what makes the parts the unit of a multi-GPU merge of one contig (sniffles_amd.dist.shard_lpt / TaskQueue
+        over the parts; the calls of a contig are the concatenation over its parts)."""
+        total_blocks = len(self.block_indices) * len(self.config.sample_ids_vcf)
+        if total_blocks <= self.TARGET_WORK_PER_TASK or getattr(self.config, "threads", 1) <= 1:
+            return [self]
+        blocks_per_task = total_blocks // self.TARGET_WORK_PER_TASK
+        return [self.clone(fb, blocks_per_task, new_id=self.id + i + 1)
+                for i, fb in enumerate(range(0, len(self.block_indices), blocks_per_task))]
+
     def execute(self, samples_snf: dict) -> list:
         """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order.
 
@@ -199,7 +238,40 @@ class CombineTask(Task):
         rule included; (3) replay in the reference's order: SVGroup bookkeeping, non-included-sample coverages, the
         keep / call decision (recomputed from the same running means and cross-checked against the kernel's) and
         SVGroup.call."""
+        chains, events = self._collect(samples_snf)
+        assign = self._resolve([self], [chains])[0]
+        return self._replay(chains, events, assign, set(samples_snf.keys()))
+
+    @staticmethod
+    def execute_many(tasks: list, samples_snf: dict) -> list:
+        """`execute` of several tasks (the contigs of a merge, or the parts of `scatter`) with ONE group-assignment launch for
+        all of them: the flush windows of every task are walked first, all chains go to the GPU together - a contig alone
+        leaves most of the device idle and its launch lasts as long as its slowest window - then every task is replayed.
+        Returns the calls per task, each list exactly what `task.execute(samples_snf)` returns."""
+        if not tasks:
+            return []
+        collected = [t._collect(samples_snf) for t in tasks]
+        assigns = tasks[0]._resolve(tasks, [c for c, _ in collected])
+        ids = set(samples_snf.keys())
+        return [t._replay(c, e, a, ids) for t, (c, e), a in zip(tasks, collected, assigns)]
+
+    def _resolve(self, tasks: list, chains_per_task: list) -> list:
+        """Phase 2: all chains of all `tasks` in one `snf_combine_resolve_batch` call; per task {svtype: group numbers}."""
         from . import cluster
+        flat, owner = [], []
+        for k, chains in enumerate(chains_per_task):
+            for t in sv.TYPES:
+                if chains[t]["win_bin"]:
+                    flat.append((t, chains[t]["cands"], chains[t]["win_off"], chains[t]["win_bin"], chains[t]["win_thr"]))
+                    owner.append((k, t))
+        outs = cluster.resolve_chains_batch(flat, self.config, device=self.device, _lib=self._lib) if flat else []
+        assigns = [dict() for _ in chains_per_task]
+        for (k, t), o in zip(owner, outs):
+            assigns[k][t] = o
+        return assigns
+
+    def _collect(self, samples_snf: dict):
+        """Phase 1: the block / bin / flush-window walk of the reference (parallel.py:487-534)."""
         config = self.config
         bin_min_size = config.combine_min_size
         bin_max_candidates = max(25, int(len(config.snf_input_info) * 0.5))
@@ -209,20 +281,22 @@ class CombineTask(Task):
         # ---- phase 1: windows
         chains = {svtype: dict(cands=[], win_off=[0], win_bin=[], win_thr=[]) for svtype in sv.TYPES}
         events = []   # (svtype, window index in its chain, curr_bin, size, samples_blocks of the block) in emission order
+        regenotype = []
         for block_index in self.block_indices:
             samples_blocks = {sid: snf.read_blocks(self.contig, block_index) for sid, snf in samples_snf.items()}
             for svtype in sv.TYPES:
                 bins = {}
                 for sid, snf in samples_snf.items():
                     blocks = samples_blocks[sid]
-                    if getattr(snf, "reqc", False):
-                        raise NotImplementedError("re-genotyping of old SNF files (--reqc) is not served")
+                    reqc = getattr(snf, "reqc", False)
                     if blocks is None:
                         continue
                     for block in blocks:
                         for cand in block[svtype]:
                             if cand.support < support_threshold:
                                 continue
+                            if reqc:      # SNF written before 2.5.3: genotype again (parallel.py:507-508); one launch, below
+                                regenotype.append(cand)
                             cand.sample_internal_id = sid
                             bins.setdefault(int(cand.pos / bin_min_size) * bin_min_size, []).append(cand)
                 if len(bins) == 0:
@@ -246,11 +320,15 @@ class CombineTask(Task):
                         ch["win_thr"].append(float(max(size * 0.5, overlap_abs)))
                         size = 0
                         svcands = []
-        # ---- phase 2: one launch for all chains
-        live = [t for t in sv.TYPES if chains[t]["win_bin"]]
-        outs = cluster.resolve_chains_batch([(t, chains[t]["cands"], chains[t]["win_off"], chains[t]["win_bin"], chains[t]["win_thr"])
-                                             for t in live], config, device=self.device, _lib=self._lib) if live else []
-        assign = dict(zip(live, outs))
+        if regenotype:
+            from . import postprocessing
+            postprocessing.genotype_svs(regenotype, config, device=self.device, _lib=self._lib)
+        return chains, events
+
+    def _replay(self, chains, events, assign, sample_internal_ids):
+        """Phase 3: SVGroup bookkeeping in the reference's emission order (parallel.py:536-572)."""
+        config = self.config
+        overlap_abs = config.combine_overlap_abs
         # ---- phase 3: replay
         active = {svtype: [] for svtype in sv.TYPES}     # kept groups, list order
         by_id = {svtype: {} for svtype in sv.TYPES}      # group number -> SVGroup (active ones only)

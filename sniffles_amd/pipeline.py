@@ -132,9 +132,11 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
         writer = vcf.VCF(config, vcf_handle)
         writer.write_header(contig_lengths)
     out = []
-    for task_id, (contig, length) in enumerate(contig_lengths):
-        task = parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device, _lib=_lib)
-        calls = task.execute(readers)
+    tasks = [parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device, _lib=_lib,
+                                  regions=(getattr(config, "regions_by_contig", None) or {}).get(contig))
+             for task_id, (contig, length) in enumerate(contig_lengths)]
+    # all contigs share one group-assignment launch (a contig alone leaves most of the device idle)
+    for task, calls in zip(tasks, parallel.CombineTask.execute_many(tasks, readers)):
         if getattr(config, "sort", True):
             calls = sorted(calls, key=lambda c: c.pos)
         if writer is not None:

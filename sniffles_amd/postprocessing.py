@@ -4,12 +4,66 @@ Inside `Task.call_candidates` the five coverage samples of every candidate are t
 candidate stage; this entry point serves the other caller of the reference function - `GenotypeTask.execute`
 (`parallel.py:353`), whose calls come from a VCF and not from this batch.  The samples are rank queries on the task's
 read table in HBM (`snf_batch_coverage_calls`); there is no dense coverage vector and no CPU fallback.
-The other functions of the reference module (`qc_sv`, `annotate_sv`, `genotype_sv`, ...) run inside
-`Task.finalize_candidates` on the GPU and have no Python counterpart.
+`genotype_sv(svcall, config)` / `genotype_svs(svcalls, config)` serve the third caller: `CombineTask.execute` re-genotypes the
+candidates of SNF files older than 2.5.3 (`--reqc`, `parallel.py:507-508`) - the likelihood arithmetic is the device function
+the finalize kernels use (`snf_genotype_batch`), the strings (phase tuple, INFO PHASE) stay on the host.
+The other functions of the reference module (`qc_sv`, `annotate_sv`, ...) run inside `Task.finalize_candidates` on the GPU
+and have no Python counterpart.
 """
 from __future__ import annotations
 
+import numpy as np
+
+from . import abi, lib
 from .soa import SVT
+
+
+def genotype_svs(svcalls, config, device: int = 0, _lib=None) -> None:
+    """`postprocessing.genotype_sv(svcall, config)` (postprocessing.py:607-623) for a list of calls, one device launch."""
+    svcalls = list(svcalls)
+    if not svcalls:
+        return
+    rec = np.zeros(len(svcalls), abi.CALL_DTYPE)
+    for i, c in enumerate(svcalls):
+        cov = (c.coverage_upstream, c.coverage_start, c.coverage_center, c.coverage_end, c.coverage_downstream)
+        if any(x is None for x in cov):
+            raise NotImplementedError("genotype_sv: a coverage field is None (a call that never went through postprocessing.coverage)")
+        r = rec[i]
+        r["svtype"], r["svlen"], r["support"] = SVT[c.svtype], c.svlen, c.support
+        r["support_sa"] = c.info.get("SUPPORT_SA", -1) if c.info.get("SUPPORT_SA") is not None else -1
+        r["cov"] = cov
+        r["filter"], r["qc"] = abi.FILTERS.index(c.filter), int(bool(c.qc))
+        r["gt_set"], r["vaf"], r["ph_set"] = 0, np.nan, 0     # the phase strings are handled below, on the host
+    lib.genotype_batch(config, rec, device=device, _lib=_lib)
+    K = {n: k for k, n in enumerate(abi.CALL_DTYPE.names)}
+    for c, r in zip(svcalls, rec.tolist()):
+        c.filter, c.qc = abi.FILTERS[r[K["filter"]]], bool(r[K["qc"]])
+        if r[K["gt_set"]]:
+            try:
+                phase = c.genotypes[0][5]        # Genotyper._get_phase (genotyping.py:74-81)
+            except (KeyError, IndexError):
+                phase = None
+            a, b = r[K["gt_a"]], r[K["gt_b"]]
+            c.genotypes[0] = (a, b, r[K["gt_gq"]], r[K["gt_dr"]], r[K["gt_dv"]], phase)
+            c.info["VAF"] = r[K["vaf"]]
+        # hom-alt calls keep their haplotype even if the phase filter failed (postprocessing.py:612-623)
+        try:
+            a, b, gq, dr, dv, phase = c.genotypes[0]
+            phase_info = c.info.get("PHASE")
+            if a == b and a == 1 and phase_info:
+                hp, ps, hp_supp, ps_supp, hp_filt, ps_filt = phase_info.split(",")
+                if "0" != hp:
+                    hp_filt = "PASS"
+                    c.genotypes[0] = (a, b, gq, dr, dv, (hp, ps))
+                    c.info["PHASE"] = f"{hp},{ps},{hp_supp},{ps_supp},{hp_filt},{ps_filt}"
+        except KeyError:
+            pass
+
+
+def genotype_sv(svcall, config, phase=None, device: int = 0, _lib=None) -> None:
+    if phase is not None:
+        raise NotImplementedError("genotype_sv with an explicit phase is the finalize stage's call (it runs on the GPU)")
+    genotype_svs([svcall], config, device=device, _lib=_lib)
 
 
 def coverage(calls, lead_provider) -> float:

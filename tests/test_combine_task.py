@@ -29,11 +29,13 @@ class BlocksReader:
         return [self.blocks[block_index]]
 
 
-def run_case(name, _lib=None):
+def run_case(name, _lib=None, reqc=False):
     doc = gu.load(name)
     exp = doc["expected"]
     cfg = make_cfg(doc["reference_args"], exp["n_samples"])
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+    for r in readers.values():
+        r.reqc = reqc
     task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=_lib)
     got = [group_record(c) for c in task.execute(readers)]
     want = exp["calls"]
@@ -52,6 +54,58 @@ def test_combine_task_driver_matches_reference_emu(name):
 @pytest.mark.parametrize("name", NAMES)
 def test_combine_task_driver_matches_reference_gpu(name):
     run_case(name)
+
+
+def test_combine_task_reqc_regenotypes_the_candidates_emu():
+    """--reqc (SNF files older than 2.5.3, parallel.py:507-508): the candidates are genotyped again on their way into the
+    bins.  Genotyping candidates that already carry the current genotype is idempotent (tests/test_genotype.py pins the
+    function itself on the reference), so the combined calls are those of the golden."""
+    import emu.emu as E
+    run_case("combine_task_3samples_lowcov", E.lib(), reqc=True)
+
+
+@pytest.mark.gpu
+def test_combine_task_reqc_regenotypes_the_candidates_gpu():
+    run_case("combine_task_3samples_lowcov", reqc=True)
+
+
+def run_scatter_case(_lib=None):
+    """CombineTask.scatter / clone against the reference's own (parallel.py:411-442; class constant lowered to 40 blocks x
+    samples in the golden run so that a 3-Mb contig is cut): the same cuts, ids, bounds, and every part's combined calls."""
+    doc = gu.load("combine_task_6samples")
+    exp = doc["expected"]
+    sc = exp["scatter"]
+    cfg = make_cfg(doc["reference_args"], exp["n_samples"])
+    cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(exp["n_samples"])]
+    cfg.threads = sc["threads"]
+    readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=_lib)
+    task.TARGET_WORK_PER_TASK = sc["target_work_per_task"]
+    parts = task.scatter()
+    assert [(p.id, p.start, p.end, p.block_indices) for p in parts] == [(w["id"], w["start"], w["end"], w["block_indices"]) for w in sc["tasks"]]
+    assert len(parts) > 3
+    for part, want in zip(parts, sc["tasks"]):
+        got = [group_record(c) for c in part.execute(readers)]
+        assert len(got) == len(want["calls"])
+        for g, w in zip(got, want["calls"]):
+            assert gu.diff_records([g], [w]) == [], (part.id, w["id"])
+    many = parallel.CombineTask.execute_many(task.scatter(), readers)   # fresh parts (call ids count per task), one launch for all
+    for got, want in zip(many, sc["tasks"]):
+        assert [group_record(c) for c in got] == [group_record(c) for c in got] and len(got) == len(want["calls"])
+        for g, w in zip(got, want["calls"]):
+            assert gu.diff_records([group_record(g)], [w]) == [], w["id"]
+    cfg.threads = 1
+    assert task.scatter() == [task]
+
+
+def test_combine_task_scatter_matches_reference_emu():
+    import emu.emu as E
+    run_scatter_case(E.lib())
+
+
+@pytest.mark.gpu
+def test_combine_task_scatter_matches_reference_gpu():
+    run_scatter_case()
 
 
 # ---- chains cut into independent sub-chains (cluster.chain_cuts) must give the assignment of the whole chain

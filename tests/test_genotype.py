@@ -92,3 +92,42 @@ def test_genotype_vcf_end_to_end_emu(name):
     on unprocessed contigs dropped."""
     import emu.emu as E
     run_genotype_vcf(name, E.lib())
+
+
+# ---- --reqc: postprocessing.genotype_sv on finalized candidates (CombineTask.execute, parallel.py:507-508)
+def run_regenotype(name, _lib=None):
+    import cases
+    from sniffles_amd import parallel, pipeline, postprocessing, sv
+    doc = gu.load("regenotype")[name]
+    build, kw, _ = cases.ALL[name]
+    ti = build()
+    assert gu.input_sha(ti) == doc["input_sha"]
+    cfg = gu.make_config(kw, ti)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, _lib=_lib)
+    task.lead_provider = pipeline._Extracted(ti)
+    cands = task.call_candidates(False, cfg)
+    task.finalize_candidates(cands, True, cfg)
+    task.close()
+    cands = [c for c in cands if c.svtype in sv.TYPES]
+    postprocessing.genotype_svs(cands, cfg, _lib=_lib)
+    got = []
+    for c in cands:
+        gt = c.genotypes.get(0)
+        got.append(dict(id=c.id, filter=c.filter, qc=bool(c.qc), vaf=c.info.get("VAF"), phase=c.info.get("PHASE"),
+                        gt=None if gt is None else [gt[0], gt[1], gt[2], gt[3], gt[4], list(gt[5]) if gt[5] is not None else None]))
+    assert got == doc["calls"]
+
+
+REGENOTYPE = sorted(gu.load("regenotype"))
+
+
+@pytest.mark.parametrize("name", REGENOTYPE)
+def test_regenotype_matches_reference_emu(name):
+    import emu.emu as E
+    run_regenotype(name, E.lib())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REGENOTYPE)
+def test_regenotype_matches_reference_gpu(name):
+    run_regenotype(name)

@@ -163,3 +163,63 @@ def test_two_rank_task_queue_equals_single_process():
     assert sorted(claims2[0] + claims2[1]) == [0, 1, 2, 3]               # a second queue is a fresh queue
     assert (claims2[0] + claims2[1])[0] in (3,) or 3 in (claims2[0][:1] + claims2[1][:1])   # heaviest claimed first
     assert sorted(claims3[0] + claims3[1]) == list(range(40))            # threads x ranks: still every item exactly once
+
+
+def _scatter_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu.emu as E
+    import golden_util as gu
+    from sniffles_amd import dist as sdist, parallel
+    from test_combine import group_record, make_cfg
+    from test_combine_task import BlocksReader
+    doc = gu.load("combine_task_6samples")
+    exp = doc["expected"]
+    sc = exp["scatter"]
+    cfg = make_cfg(doc["reference_args"], exp["n_samples"])
+    cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(exp["n_samples"])]
+    cfg.threads = sc["threads"]
+    readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())
+    task.TARGET_WORK_PER_TASK = sc["target_work_per_task"]
+    parts = task.scatter()                                    # the same cuts on every rank
+    queue = sdist.TaskQueue([len(p.block_indices) for p in parts])   # the parts of ONE contig go to whoever is free
+    mine = {}
+    for i in queue:
+        mine[parts[i].id] = [group_record(c) for c in parts[i].execute(readers)]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_combine_scatter_equals_reference_parts():
+    """A merge of ONE contig over two ranks: the parts of CombineTask.scatter (the reference's cuts) are claimed from the
+    work queue, every part's calls equal the reference's for that part, every part is done exactly once."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import emu.emu as E
+    import golden_util as gu
+    E.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_scatter_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    per_rank = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = gu.load("combine_task_6samples")["expected"]["scatter"]["tasks"]
+    assert sorted(list(per_rank[0]) + list(per_rank[1])) == sorted(w["id"] for w in want)
+    merged = {**per_rank[0], **per_rank[1]}
+    for w in want:
+        assert len(merged[w["id"]]) == len(w["calls"])
+        for g, e in zip(merged[w["id"]], w["calls"]):
+            assert gu.diff_records([g], [e]) == []

@@ -6,7 +6,7 @@ through the calling hot path on this GPU; its candidates go into 100-kb SNF bloc
 instead of gzip / pickle files (container I/O is not what is measured).
 One step = `CombineTask.execute` of every contig task of this rank over the S readers (`parallel.py:444-572`): the block / bin /
 flush-window walk and the `SVGroup.call` replay on the host, the group assignment with its on-demand banded edit distances in
-ONE `snf_combine_resolve_batch` call per contig.  N > 1: contigs sharded longest-first over the ranks (weak scaling would need
+ONE `snf_combine_resolve_batch` call for all contig tasks of the rank.  N > 1: contigs sharded longest-first over the ranks (weak scaling would need
 N populations; the merge of one population is what `configs[4]` names, so this is STRONG scaling: `scaling: "strong"`).
 value = candidates merged per second (whole job); the kernel inside the C-ABI call is reported against the roofline with the
 bytes it aligned, DP cells per second next to it (the bound of this kernel is VALU issue, not HBM: integer bit-vector work).
@@ -114,11 +114,9 @@ def run(ctx):
 
     def one_pass():
         box.update(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
-        n = 0
-        for ci, c, L in my_contigs:
-            task = parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank)
-            n += len(task.execute(readers))
-        box["calls"] = n
+        tasks = [parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank) for ci, c, L in my_contigs]
+        # the contig tasks of this rank share one group-assignment launch (CombineTask.execute_many)
+        box["calls"] = sum(len(calls) for calls in parallel.CombineTask.execute_many(tasks, readers))
 
     def barrier():
         if use_dist:
