@@ -499,7 +499,8 @@ typedef struct snf_extract_input {
   int32_t region_rank;      /* rank of the region's contig name (same ranking as contig_rank) */
   int32_t region_start;     /* Region.start, Region.end (0-based, half open) */
   int32_t region_end;
-  uint32_t read_id_offset;  /* LeadProvider.read_id on entry */
+  uint32_t read_id_offset;  /* LeadProvider.read_id on entry, modulo 2^32: read ids are only compared for equality inside a
+                               task, so the reference's task.id * 10^k offsets (which exceed 32 bits) are reduced by the host */
   int32_t n_contigs;        /* header contigs: 64-bit FNV-1a of the name, ascending, and the rank of that name */
   const uint64_t* contig_hash;
   const int32_t* contig_rank;

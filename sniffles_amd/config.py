@@ -35,7 +35,9 @@ _DEFAULTS = dict(
     # VCF writer (config.py:166-170, 242, 332)
     vcf=None, reference=None, max_del_seq_len=50000, max_unknown_pct=0.5,
     # contig selection of the main program (config.py:168-176, util.py:147-162)
-    all_contigs=False, contig=None, threads=4,
+    all_contigs=False, contig=None, threads=4, regions_by_contig=None,
+    # read filter of the extraction (config.py:190-215, 533-536); None: derived below
+    mapq=None, min_alignment_length=None, exclude_flags=None,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)
@@ -75,6 +77,13 @@ class SnifflesConfig:
             self.minsupport = int(self.minsupport)
         if self.dev_no_qc:
             self.no_qc = True
+        # --dev-no-qc also switches the read filter off (config.py:533-536)
+        if self.mapq is None:
+            self.mapq = 0 if self.dev_no_qc else 20
+        if self.min_alignment_length is None:
+            self.min_alignment_length = 0 if self.dev_no_qc else 1000
+        if self.regions_by_contig is None:
+            self.regions_by_contig = {}
         self.minsupport_auto_base = 1.5
         self.minsupport_auto_regional_coverage_weight = 0.75
         if self.minsupport_auto_mult is None:

@@ -54,12 +54,22 @@ class _Extracted:
         return self.ti
 
 
+def _no_regions(config, what: str) -> None:
+    """`--regions` (config.regions_by_contig): the reference hands the regions of a contig to every task, so that
+    `build_leadtab` only extracts inside them (sniffles:330-341, leadprov.py:445-472).  `combine` passes them on
+    (`CombineTask(regions=...)`); the BAM flows of this module extract whole contigs, so they refuse a region list instead
+    of silently calling outside it."""
+    if getattr(config, "regions_by_contig", None):
+        raise NotImplementedError(f"{what}: --regions is not served by this flow (tasks always span their whole contig)")
+
+
 def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
                 _lib=None) -> SampleResult:
     """`records`: `bam.read_bam(path)`.  `tandem_repeats`: {contig: [(start, end), ...]} (already padded, util.py:121-144).
     Writes the VCF to `vcf_handle` and / or the SNF to `snf_path` (CallTask.execute switches QC filtering off for the
     candidates when an SNF is requested, parallel.py:258-263)."""
     import struct
+    _no_regions(config, "call_sample")
     flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
     total_mapped = sum(1 for f, r in zip(flags, records.ref_id.tolist()) if r >= 0 and not f & 0x4)
     config.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
@@ -78,7 +88,7 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
         task = parallel.CallTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config,
                                  tandem_repeats=tr, device=device, _lib=_lib)
         ti, info = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
-                                          read_id_offset=task_id * config.task_read_id_offset_mult, task_id=task_id,
+                                          read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id=task_id,
                                           sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
         task.lead_provider = _Extracted(ti)
@@ -154,6 +164,7 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
     matched against this sample's candidates contig by contig and written back with the sample's genotype (contig by
     contig, input order within a contig).  Returns the number of records written."""
     import struct
+    _no_regions(config, "genotype_vcf")
     config.mode = "genotype_vcf"
     reader = vcf.VCF(config, vcf_in_handle)
     by_contig = {}
@@ -173,7 +184,7 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
         task = parallel.GenotypeTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, tandem_repeats=tr,
                                      genotype_svs=targets, device=device, _lib=_lib)
         ti, _ = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
-                                       read_id_offset=task_id * config.task_read_id_offset_mult, task_id=task_id, sv_id_start=0,
+                                       read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id=task_id, sv_id_start=0,
                                        tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold
         task.lead_provider = _Extracted(ti)

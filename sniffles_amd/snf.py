@@ -35,38 +35,61 @@ _CLASSES = {"SVCall": sv.SVCall, "SVCallBNDInfo": sv.SVCallBNDInfo, "ForwardDiff
 _LOCK = threading.Lock()
 
 
+# what a block may name besides the record classes: containers / scalars of the standard library and numpy scalars (the
+# reference stores e.g. numpy floats in `nm`).  Anything else in an .snf file is refused instead of imported.
+_SAFE_GLOBALS = {
+    ("builtins", n) for n in ("set", "frozenset", "dict", "list", "tuple", "int", "float", "complex", "str", "bytes", "bytearray",
+                              "bool", "slice", "range", "object")
+} | {("collections", "OrderedDict"), ("collections", "defaultdict"), ("copyreg", "_reconstructor"), ("copyreg", "__newobj__"),
+     ("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+     ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct")}
+
+
 class _Unpickler(pickle.Unpickler):
-    """Blocks written by the reference name `sniffles.sv.*`; resolve them to this package's record types."""
+    """Blocks written by the reference name `sniffles.sv.*`; resolve them to this package's record types.  Only those
+    classes and a fixed list of harmless globals are accepted: an .snf file cannot make the reader import anything else."""
 
     def find_class(self, module, name):
-        if module == REF_MODULE and name in _CLASSES:
+        if module in (REF_MODULE, sv.__name__) and name in _CLASSES:
             return _CLASSES[name]
-        return super().find_class(module, name)
+        if (module, name) in _SAFE_GLOBALS:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"SNF block names {module}.{name}: not a Sniffles record class - refusing to load it")
 
 
-def _as_class(obj, mod):
-    """Shallow copy of a record of this package as an instance of the class of the same name in `mod`."""
-    for name, cls in _CLASSES.items():
-        if type(obj) is cls:
-            out = getattr(mod, name).__new__(getattr(mod, name))
-            out.__dict__.update({k: _as_class(v, mod) for k, v in obj.__dict__.items()})
-            return out
-    return obj
+_NAME_OF = {cls: name for name, cls in _CLASSES.items()}
+# stand-ins that carry the reference's module path: pickle writes a class as (module, qualname) and checks that the pair
+# resolves to the object it was given, so the records are written as instances of these (the record classes themselves are
+# never touched) while a module of that name holds them
+_PROXIES = {name: type(name, (), {"__module__": REF_MODULE, "__qualname__": name}) for name in _CLASSES}
+
+
+class _RefPickler(pickle.Pickler):
+    def __init__(self, file, classes):
+        super().__init__(file)
+        self._classes = classes
+
+    def reducer_override(self, obj):
+        name = _NAME_OF.get(type(obj))
+        if name is None:
+            return NotImplemented
+        import copyreg
+        # (copyreg.__newobj__ insists on the object's own class; _reconstructor is object.__new__(cls) as well)
+        return copyreg._reconstructor, (self._classes[name], object, None), obj.__dict__
 
 
 def _dumps_as_reference(block: dict) -> bytes:
     """pickle.dumps of a block with this package's record classes written under the reference's names.
 
-    When the real `sniffles.sv` is loaded in this process the records are handed to pickle as (shallow) instances of
-    its classes.  Otherwise the C pickler must still find the class it writes under the name it writes - it records a
-    class as (`__module__`, `__qualname__`) and verifies that the pair resolves to it - so for the duration of the dump
-    the classes carry the reference's module path and a stand-in module of that name holds them."""
+    When the real `sniffles.sv` is loaded in this process its classes are named directly.  Otherwise the pickler must still
+    find, under `sniffles.sv`, the class object it is asked to write: for the duration of the dump a stand-in module of that
+    name holds proxy classes (`_PROXIES`).  The record classes of this package are not modified at any time."""
     with _LOCK:
         real = sys.modules.get(REF_MODULE)
-        if real is not None:
-            conv = {k: ([_as_class(c, real) for c in v] if isinstance(v, list) else v) for k, v in block.items()}
-            return pickle.dumps(conv)
-        saved = {}
+        buf = io.BytesIO()
+        if real is not None and getattr(real, "__file__", None):
+            _RefPickler(buf, {name: getattr(real, name) for name in _CLASSES}).dump(block)
+            return buf.getvalue()
         had_pkg = "sniffles" in sys.modules
         try:
             if not had_pkg:
@@ -74,15 +97,12 @@ def _dumps_as_reference(block: dict) -> bytes:
                 pkg.__path__ = []
                 sys.modules["sniffles"] = pkg
             mod = types.ModuleType(REF_MODULE)
+            for name, proxy in _PROXIES.items():
+                setattr(mod, name, proxy)
             sys.modules[REF_MODULE] = mod
-            for name, cls in _CLASSES.items():
-                setattr(mod, name, cls)
-                saved[cls] = (cls.__module__, cls.__qualname__)
-                cls.__module__, cls.__qualname__ = REF_MODULE, name
-            return pickle.dumps(block)
+            _RefPickler(buf, _PROXIES).dump(block)
+            return buf.getvalue()
         finally:
-            for cls, (m, q) in saved.items():
-                cls.__module__, cls.__qualname__ = m, q
             sys.modules.pop(REF_MODULE, None)
             if not had_pkg:
                 sys.modules.pop("sniffles", None)
