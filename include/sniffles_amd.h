@@ -293,6 +293,13 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out);
 /* registers one task; may be called n_tasks times.  The task's arrays are BORROWED until snf_batch_upload returns
  * (nothing is copied here). */
 int snf_batch_add_task(snf_batch_t* b, const snf_task_input_t* task);
+/* Device-resident hand-over from the extraction (declared below: snf_extract_*): the leads, sequence pool and read table a
+ * finished snf_extract_run left in HBM become a task of the batch without a round trip through the host.  `meta` supplies
+ * what the extraction does not know: task_id, sv_id_start, contig_len and the tandem repeats (host arrays, borrowed until
+ * snf_batch_upload like those of snf_batch_add_task); its other pointers are ignored.  The extraction handle must stay
+ * alive and must not be re-run until snf_batch_upload has returned; it has to live on the batch's device. */
+struct snf_extract;
+int snf_batch_add_task_device(snf_batch_t* b, struct snf_extract* x, const snf_task_input_t* meta);
 /* host -> HBM: host threads validate the tasks and stage their columns into one pinned (process-wide, grow-only) arena,
  * two large copies move it, kernels derive the packed per-lead records; after this the caller's buffers are no longer
  * referenced.  A task the reference could not have produced (svtype / hap codes, sequence ranges, a read outside its
@@ -522,7 +529,12 @@ typedef struct snf_extract snf_extract_t;
 int snf_extract_create(const snf_extract_config_t* cfg, int device, snf_extract_t** out);
 int snf_extract_upload(snf_extract_t* x, const snf_extract_input_t* in); /* host -> HBM */
 int snf_extract_run(snf_extract_t* x);   /* a record the reference would raise on fails the call (ErrorResult) */
-int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out); /* library-owned until destroy / next run */
+int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out); /* library-owned until destroy / next run; the first
+                                                                        call after a run copies the columns to the host */
+/* counts, phase-set table, NM threshold and timings only - no column is copied to the host */
+int snf_extract_result_meta(snf_extract_t* x, snf_extract_result_t* out);
+/* the same columns as DEVICE pointers (out->... point into the HBM of *device), no copy: what snf_batch_add_task_device uses */
+int snf_extract_device_view(snf_extract_t* x, snf_task_input_t* out, int* device);
 void snf_extract_destroy(snf_extract_t* x);
 const char* snf_extract_last_error(void);
 

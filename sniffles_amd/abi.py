@@ -318,6 +318,22 @@ def task_struct(ti: TaskInput, keep: list) -> snf_task_input_t:
     return t
 
 
+def task_meta_struct(ti, keep: list) -> snf_task_input_t:
+    """What snf_batch_add_task_device reads from the host: ids, contig length and the tandem repeats of a task whose columns
+    are in HBM."""
+    t = snf_task_input_t()
+    t.task_id, t.sv_id_start, t.contig_len = ti.task_id, ti.sv_id_start, ti.contig_len
+    if ti.tr_start is None:
+        t.n_tr = -1
+    else:
+        ts = np.ascontiguousarray(ti.tr_start, np.int32)
+        te = np.ascontiguousarray(ti.tr_end, np.int32)
+        keep += [ts, te]
+        t.n_tr = int(ts.shape[0])
+        t.tr_start, t.tr_end = _ptr(ts, C.c_int32), _ptr(te, C.c_int32)
+    return t
+
+
 class Result:
     """Host copy of a snf_result_t (numpy views copied out of library-owned memory)."""
 

@@ -748,7 +748,8 @@ struct snf_extract {
   std::vector<uint8_t> h_u8[8]; std::vector<uint8_t> h_pool; std::vector<int32_t> h_rs, h_re; std::vector<uint8_t> h_rhp;
   std::vector<int64_t> h_ps_value;
   snf_extract_result_t res{};
-  bool have_input = false, have_result = false;
+  bool have_input = false, have_result = false, pulled = false;
+  int64_t n_leads = 0, n_seq = 0, n_reads = 0;
 #ifndef SNF_EMU
   hipStream_t side = nullptr;   // the serial NM sum runs beside the scans, the host round trip and the emit pass
 #endif
@@ -857,6 +858,39 @@ int do_upload(snf_extract* x, const snf_extract_input_t* in) {
   return 0;
 }
 
+// the result columns stay in HBM after a run (snf_batch_add_task_device takes them from there); the host copies are made by
+// the first snf_extract_result
+void pull_result(snf_extract* x) {
+  if (x->pulled) return;
+  ExView& v = x->v;
+  const size_t L = (size_t)x->n_leads; const int64_t n_seq = x->n_seq, n_reads = x->n_reads;
+  // results to the host
+  int32_t* const di32[10] = {v.o_ref_start, v.o_ref_end, v.o_qry_start, v.o_qry_end, v.o_svlen, v.o_read_len, v.o_ps, v.o_mate_contig, v.o_mate_pos, v.o_seq_len};
+  for (int k = 0; k < 10; k++) { x->h_i32[k].resize(L + 1); x_d2h(x->h_i32[k].data(), di32[k], L * 4); }
+  x->h_u32[0].resize(L + 1); x_d2h(x->h_u32[0].data(), v.o_qname, L * 4);
+  x->h_u32[1].resize(L + 1); x_d2h(x->h_u32[1].data(), v.o_read_id, L * 4);
+  x->h_seq_off.resize(L + 1); x_d2h(x->h_seq_off.data(), v.o_seq_off, L * 8);
+  x->h_nm.resize(L + 1); x_d2h(x->h_nm.data(), v.o_nm, L * 8);
+  uint8_t* const du8[8] = {v.o_svtype, v.o_strand, v.o_mapq, v.o_source, v.o_hap, v.o_is_sa, v.o_first, v.o_rev};
+  for (int k = 0; k < 8; k++) { x->h_u8[k].resize(L + 1); x_d2h(x->h_u8[k].data(), du8[k], L); }
+  x->h_pool.resize((size_t)n_seq + 1); x_d2h(x->h_pool.data(), v.o_pool, (size_t)n_seq);
+  x->h_rs.resize((size_t)n_reads + 1); x->h_re.resize((size_t)n_reads + 1); x->h_rhp.resize((size_t)n_reads + 1);
+  x_d2h(x->h_rs.data(), v.o_rstart, (size_t)n_reads * 4); x_d2h(x->h_re.data(), v.o_rend, (size_t)n_reads * 4); x_d2h(x->h_rhp.data(), v.o_rhp, (size_t)n_reads);
+#ifndef SNF_EMU
+  SNF_HIP(hipDeviceSynchronize());
+#endif
+  snf_task_input_t& t = x->res.task;
+  t.ref_start = x->h_i32[0].data(); t.ref_end = x->h_i32[1].data(); t.qry_start = x->h_i32[2].data(); t.qry_end = x->h_i32[3].data();
+  t.svlen = x->h_i32[4].data(); t.read_len = x->h_i32[5].data(); t.ps_rank = x->h_i32[6].data(); t.mate_contig = x->h_i32[7].data();
+  t.mate_ref_start = x->h_i32[8].data(); t.seq_len = x->h_i32[9].data(); t.qname_id = x->h_u32[0].data(); t.read_id = x->h_u32[1].data();
+  t.seq_off = x->h_seq_off.data(); t.nm = x->h_nm.data();
+  t.svtype = x->h_u8[0].data(); t.strand = x->h_u8[1].data(); t.mapq = x->h_u8[2].data(); t.source = x->h_u8[3].data();
+  t.hap = x->h_u8[4].data(); t.is_sa = x->h_u8[5].data(); t.bnd_is_first = x->h_u8[6].data(); t.bnd_is_reverse = x->h_u8[7].data();
+  t.seq_pool_len = n_seq; t.seq_pool = x->h_pool.data();
+  t.n_reads = n_reads; t.read_start = x->h_rs.data(); t.read_end = x->h_re.data(); t.read_hp = x->h_rhp.data();
+  x->pulled = true;
+}
+
 int do_run(snf_extract* x) {
   if (!x->have_input) snf::fail("snf_extract_run before snf_extract_upload");
   x_release(x->dev_run);
@@ -940,31 +974,12 @@ int do_run(snf_extract* x) {
   x_emit(v, n);
 #endif
   x_d2h(nmv, v.nm_out, 16);
-  // results to the host
-  int32_t* const di32[10] = {v.o_ref_start, v.o_ref_end, v.o_qry_start, v.o_qry_end, v.o_svlen, v.o_read_len, v.o_ps, v.o_mate_contig, v.o_mate_pos, v.o_seq_len};
-  for (int k = 0; k < 10; k++) { x->h_i32[k].resize(L + 1); x_d2h(x->h_i32[k].data(), di32[k], L * 4); }
-  x->h_u32[0].resize(L + 1); x_d2h(x->h_u32[0].data(), v.o_qname, L * 4);
-  x->h_u32[1].resize(L + 1); x_d2h(x->h_u32[1].data(), v.o_read_id, L * 4);
-  x->h_seq_off.resize(L + 1); x_d2h(x->h_seq_off.data(), v.o_seq_off, L * 8);
-  x->h_nm.resize(L + 1); x_d2h(x->h_nm.data(), v.o_nm, L * 8);
-  uint8_t* const du8[8] = {v.o_svtype, v.o_strand, v.o_mapq, v.o_source, v.o_hap, v.o_is_sa, v.o_first, v.o_rev};
-  for (int k = 0; k < 8; k++) { x->h_u8[k].resize(L + 1); x_d2h(x->h_u8[k].data(), du8[k], L); }
-  x->h_pool.resize((size_t)n_seq + 1); x_d2h(x->h_pool.data(), v.o_pool, (size_t)n_seq);
-  x->h_rs.resize((size_t)n_reads + 1); x->h_re.resize((size_t)n_reads + 1); x->h_rhp.resize((size_t)n_reads + 1);
-  x_d2h(x->h_rs.data(), v.o_rstart, (size_t)n_reads * 4); x_d2h(x->h_re.data(), v.o_rend, (size_t)n_reads * 4); x_d2h(x->h_rhp.data(), v.o_rhp, (size_t)n_reads);
+  x->n_leads = n_leads; x->n_seq = n_seq; x->n_reads = n_reads; x->pulled = false;
   snf_extract_result_t& r = x->res;
   const int64_t ab = r.algo_bytes;
   r = snf_extract_result_t{};
   snf_task_input_t& t = r.task;
-  t.n_leads = n_leads;
-  t.ref_start = x->h_i32[0].data(); t.ref_end = x->h_i32[1].data(); t.qry_start = x->h_i32[2].data(); t.qry_end = x->h_i32[3].data();
-  t.svlen = x->h_i32[4].data(); t.read_len = x->h_i32[5].data(); t.ps_rank = x->h_i32[6].data(); t.mate_contig = x->h_i32[7].data();
-  t.mate_ref_start = x->h_i32[8].data(); t.seq_len = x->h_i32[9].data(); t.qname_id = x->h_u32[0].data(); t.read_id = x->h_u32[1].data();
-  t.seq_off = x->h_seq_off.data(); t.nm = x->h_nm.data();
-  t.svtype = x->h_u8[0].data(); t.strand = x->h_u8[1].data(); t.mapq = x->h_u8[2].data(); t.source = x->h_u8[3].data();
-  t.hap = x->h_u8[4].data(); t.is_sa = x->h_u8[5].data(); t.bnd_is_first = x->h_u8[6].data(); t.bnd_is_reverse = x->h_u8[7].data();
-  t.seq_pool_len = n_seq; t.seq_pool = x->h_pool.data();
-  t.n_reads = n_reads; t.read_start = x->h_rs.data(); t.read_end = x->h_re.data(); t.read_hp = x->h_rhp.data();
+  t.n_leads = n_leads; t.seq_pool_len = n_seq; t.n_reads = n_reads;   // (array pointers: filled by the first snf_extract_result)
   t.n_tr = -1; t.ps_null_rank = v.ps_null_rank;
   const double cnt = nmv[1] > 1.0 ? nmv[1] : 1.0;
   t.qc_nm_threshold = nmv[0] / cnt;   // average_regional_nm = nm_sum / float(max(1, nm_count))
@@ -1015,7 +1030,38 @@ int snf_extract_run(snf_extract_t* x) {
 int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out) {
   if (!x || !out) { g_xerr = "null argument"; return 1; }
   if (!x->have_result) { g_xerr = "snf_extract_result before a successful snf_extract_run"; return 1; }
+#ifndef SNF_EMU
+  if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
+#endif
+  try { pull_result(x); }
+  catch (const snf::Error& e) { g_xerr = e.msg; return 1; }
   *out = x->res;
+  return 0;
+}
+// the scalar part of the result (counts, ps table, NM threshold, timings) without copying the columns to the host: the array
+// pointers of out->task are null unless an earlier snf_extract_result made the host copies
+int snf_extract_result_meta(snf_extract_t* x, snf_extract_result_t* out) {
+  if (!x || !out) { g_xerr = "null argument"; return 1; }
+  if (!x->have_result) { g_xerr = "snf_extract_result_meta before a successful snf_extract_run"; return 1; }
+  *out = x->res;
+  return 0;
+}
+// the same result as DEVICE pointers (HBM of the handle's device): what snf_batch_add_task_device reads.  Valid until the
+// next snf_extract_upload / snf_extract_run / snf_extract_destroy on the handle.
+int snf_extract_device_view(snf_extract_t* x, snf_task_input_t* out, int* device) {
+  if (!x || !out) { g_xerr = "null argument"; return 1; }
+  if (!x->have_result) { g_xerr = "snf_extract_device_view before a successful snf_extract_run"; return 1; }
+  const ExView& v = x->v;
+  snf_task_input_t t = x->res.task;    // scalars (ps_null_rank, qc_nm_threshold, counts)
+  t.n_leads = x->n_leads; t.seq_pool_len = x->n_seq; t.n_reads = x->n_reads;
+  t.ref_start = v.o_ref_start; t.ref_end = v.o_ref_end; t.qry_start = v.o_qry_start; t.qry_end = v.o_qry_end; t.svlen = v.o_svlen;
+  t.read_len = v.o_read_len; t.qname_id = v.o_qname; t.read_id = v.o_read_id; t.ps_rank = v.o_ps; t.mate_contig = v.o_mate_contig;
+  t.mate_ref_start = v.o_mate_pos; t.seq_len = v.o_seq_len; t.seq_off = v.o_seq_off; t.nm = v.o_nm;
+  t.svtype = v.o_svtype; t.strand = v.o_strand; t.mapq = v.o_mapq; t.source = v.o_source; t.hap = v.o_hap; t.is_sa = v.o_is_sa;
+  t.bnd_is_first = v.o_first; t.bnd_is_reverse = v.o_rev;
+  t.seq_pool = v.o_pool; t.read_start = v.o_rstart; t.read_end = v.o_rend; t.read_hp = v.o_rhp;
+  *out = t;
+  if (device) *device = x->device;
   return 0;
 }
 void snf_extract_destroy(snf_extract_t* x) {

@@ -161,6 +161,7 @@ struct snf_batch_impl {
   // host side of the inputs: the caller's arrays are BORROWED from snf_batch_add_task until snf_batch_upload returns
   // (validated, staged into pinned memory and copied by the upload); only the scalars are kept afterwards
   std::vector<snf_task_input_t> tasks;
+  std::vector<uint8_t> task_on_device;   // 1: the task's array pointers are HBM of this device (snf_batch_add_task_device)
   std::vector<int64_t> h_lead_off{0}, h_read_off{0}, h_tr_off{0}, h_pool_off{0};
   std::vector<int32_t> h_trs, h_tre, h_trp, h_has_tr;
   // device
@@ -253,6 +254,14 @@ void d2h(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
 #ifndef SNF_EMU
   SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->cur));
+#else
+  memcpy(dst, src, bytes);
+#endif
+}
+void d2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+#ifndef SNF_EMU
+  SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, b->cur));
 #else
   memcpy(dst, src, bytes);
 #endif
@@ -516,6 +525,11 @@ SNF_HD void u2_readtask_body(int64_t r, const PackView& q) { q.r_task[r] = task_
 }  // namespace snf
 SNF_KERNEL(u1_pack, PackView)
 SNF_KERNEL(u2_readtask, PackView)
+struct RebaseView { int64_t* seq_off; const int32_t* seq_len; int64_t base; };
+namespace snf {
+SNF_HD void u0_rebase_body(int64_t i, const RebaseView& q) { q.seq_off[i] = q.seq_len[i] >= 0 ? q.seq_off[i] + q.base : 0; }
+}  // namespace snf
+SNF_KERNEL(u0_rebase, RebaseView)
 
 namespace {
 double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
@@ -645,6 +659,10 @@ void do_upload(snf_batch_impl* b) {
         const int k = next.fetch_add(1);
         if (k >= T) return;
         const int t = order[(size_t)k];
+        if (b->task_on_device[(size_t)t]) {   // born in HBM (extraction): copied device-to-device below; its reads end inside the contig
+          b->h_rend_max[(size_t)t] = b->tasks[(size_t)t].contig_len;
+          continue;
+        }
         try {
           stage_task(b->tasks[(size_t)t], t, st, off, pool_at, b->h_lead_off[(size_t)t], b->h_read_off[(size_t)t], b->h_pool_off[(size_t)t],
                      &b->h_rend_max[(size_t)t]);
@@ -658,18 +676,44 @@ void do_upload(snf_batch_impl* b) {
       for (auto& th : ths) th.join();
     }
     if (!err.empty()) fail(err);
+    t_staged = now_ms();
+    // ---- (2) two large copies
+    h2d(b, d_in, st, col_bytes);
+    h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
+    // tasks whose columns are already in HBM (snf_batch_add_task_device): device-to-device into their slices, sequence
+    // offsets rebased into the batch pool by a kernel
+    bool any_dev = false;
+    for (int t = 0; t < T; t++) {
+      if (!b->task_on_device[(size_t)t]) continue;
+      any_dev = true;
+      const snf_task_input_t& q = b->tasks[(size_t)t];
+      const int64_t l0 = b->h_lead_off[(size_t)t], r0 = b->h_read_off[(size_t)t], p0 = b->h_pool_off[(size_t)t];
+      const void* src[22] = {q.ref_start, q.ref_end, q.qry_start, q.qry_end, q.svlen, q.read_len, q.qname_id, q.read_id, q.ps_rank,
+                             q.mate_contig, q.mate_ref_start, q.seq_len, q.seq_off, q.nm, q.svtype, q.strand, q.mapq, q.source, q.hap,
+                             q.is_sa, q.bnd_is_first, q.bnd_is_reverse};
+      for (int c = 0; c < 22; c++) d2d(b, d_in + off[c] + (size_t)l0 * kInElem[c], src[c], (size_t)q.n_leads * kInElem[c]);
+      d2d(b, v.pool + p0, q.seq_pool, (size_t)q.seq_pool_len);
+      d2d(b, d_in + off[IC_RSTART] + (size_t)r0 * 4, q.read_start, (size_t)q.n_reads * 4);
+      d2d(b, d_in + off[IC_REND] + (size_t)r0 * 4, q.read_end, (size_t)q.n_reads * 4);
+      d2d(b, d_in + off[IC_RHP] + (size_t)r0, q.read_hp, (size_t)q.n_reads);
+      RebaseView rv{(int64_t*)(d_in + off[IC_SEQ_OFF]) + l0, (const int32_t*)(d_in + off[IC_SEQ_LEN]) + l0, p0};
+      LAUNCH_Q(u0_rebase, rv, q.n_leads, q.n_leads * 12);
+    }
+    // top level of the read-start index (every 256th start): from the staging arena, or back from HBM when some of the
+    // starts never were on the host
+    if (!any_dev) {
+      const int32_t* rs_all = (const int32_t*)(st + off[IC_RSTART]);
+      for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(rs_all[r]);
+    } else {
+      for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(0);
+      for (size_t k = 0; k < top.size(); k++) d2h(b, &top[k], d_in + off[IC_RSTART] + (k << SNF_TOP_SHIFT) * 4, 4);
+    }
+    dsync(b);
     for (auto& t : b->tasks) {   // the borrowed arrays are not referenced after this point
       snf_task_input_t s{}; s.task_id = t.task_id; s.sv_id_start = t.sv_id_start; s.contig_len = t.contig_len; s.ps_null_rank = t.ps_null_rank;
       s.qc_nm_threshold = t.qc_nm_threshold; s.n_leads = t.n_leads; s.n_reads = t.n_reads; s.n_tr = t.n_tr; s.seq_pool_len = t.seq_pool_len;
       t = s;
     }
-    const int32_t* rs_all = (const int32_t*)(st + off[IC_RSTART]);
-    for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(rs_all[r]);
-    t_staged = now_ms();
-    // ---- (2) two large copies
-    h2d(b, d_in, st, col_bytes);
-    h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
-    dsync(b);
     t_copied = now_ms();
   }
   v.in_ref_start = (const int32_t*)(d_in + off[IC_REF_START]); v.in_ref_end = (const int32_t*)(d_in + off[IC_REF_END]);
@@ -1252,6 +1296,7 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
   b->h_pool_off.push_back(b->h_pool_off.back() + t->seq_pool_len);
   b->h_tr_off.push_back((int64_t)b->h_trs.size());
   b->tasks.push_back(*t);   // the content (values, order of the reads) is checked when the upload stages it
+  b->task_on_device.push_back(0);
 }
 
 }  // namespace
@@ -1489,6 +1534,26 @@ void do_fetch_clusters(snf_batch_impl* b, int stage, snf_clusters_t* out) {
   out->lead_off = b->cl_lead_off.data(); out->n_leads = (int64_t)b->cl_lead.size(); out->lead = b->cl_lead.data(); out->lead_svlen = b->cl_lead_svlen.data();
 }
 
+extern "C" int snf_extract_device_view(snf_extract_t* x, snf_task_input_t* out, int* device);
+void do_add_task_device(snf_batch_impl* b, snf_extract_t* x, const snf_task_input_t* meta) {
+  if (!b || !x || !meta) fail("null argument");
+  snf_task_input_t t{};
+  int dev = -1;
+  if (snf_extract_device_view(x, &t, &dev) != 0) fail(std::string("snf_batch_add_task_device: ") + snf_extract_last_error());
+  if (dev != b->device) fail("snf_batch_add_task_device: the extraction ran on another device");
+  t.task_id = meta->task_id; t.sv_id_start = meta->sv_id_start; t.contig_len = meta->contig_len;
+  t.n_tr = meta->n_tr; t.tr_start = meta->tr_start; t.tr_end = meta->tr_end;
+  // (ps_null_rank and qc_nm_threshold are the extraction's own)
+  const uint8_t* pool = t.seq_pool;
+  const int64_t pool_len = t.seq_pool_len, n = t.n_leads, r = t.n_reads;
+  t.seq_pool = nullptr; t.seq_pool_len = 0; t.n_leads = 0; t.n_reads = 0;   // do_add_task checks HOST pointers: the device ones go back in below
+  do_add_task(b, &t);
+  snf_task_input_t& q = b->tasks.back();
+  q.n_leads = n; q.n_reads = r; q.seq_pool = pool; q.seq_pool_len = pool_len;
+  b->h_lead_off.back() += n; b->h_read_off.back() += r; b->h_pool_off.back() += pool_len;
+  b->task_on_device.back() = 1;
+}
+
 #define SNF_TRY(body)                                   \
   try { body; return 0; }                               \
   catch (const snf::Error& e) { g_err = e.msg; return 1; } \
@@ -1571,6 +1636,10 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
 
 int snf_batch_add_task(snf_batch_t* bb, const snf_task_input_t* task) {
   SNF_TRY({ if (!bb || !task) fail("null argument"); do_add_task(reinterpret_cast<snf_batch_impl*>(bb), task); })
+}
+
+int snf_batch_add_task_device(snf_batch_t* bb, snf_extract_t* x, const snf_task_input_t* meta) {
+  SNF_TRY(do_add_task_device(reinterpret_cast<snf_batch_impl*>(bb), x, meta))
 }
 
 int snf_batch_upload(snf_batch_t* bb) {

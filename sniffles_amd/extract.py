@@ -76,6 +76,41 @@ class Extractor:
     def run(self):
         self._check(self.lib.snf_extract_run(self._h))
 
+    def host_columns(self) -> dict:
+        """The result columns copied to the host (the first call after a run makes the copies)."""
+        r = abi.snf_extract_result_t()
+        self._check(self.lib.snf_extract_result(self._h, C.byref(r)))
+        t = r.task
+        n, npool, nr = int(t.n_leads), int(t.seq_pool_len), int(t.n_reads)
+        leads = {name: (np.ctypeslib.as_array(getattr(t, name), shape=(n,)).astype(dt, copy=True) if n else np.zeros(0, dt))
+                 for name, dt in LEAD_FIELDS}
+        return dict(leads=leads,
+                    seq_pool=np.ctypeslib.as_array(t.seq_pool, shape=(npool,)).copy() if npool else np.zeros(0, np.uint8),
+                    read_start=np.ctypeslib.as_array(t.read_start, shape=(nr,)).copy() if nr else np.zeros(0, np.int32),
+                    read_end=np.ctypeslib.as_array(t.read_end, shape=(nr,)).copy() if nr else np.zeros(0, np.int32),
+                    read_hp=np.ctypeslib.as_array(t.read_hp, shape=(nr,)).copy() if nr else np.zeros(0, np.uint8))
+
+    def result_device(self, task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None):
+        """The result as a task that STAYS in HBM (soa.DeviceTaskInput): `lib.Batch` takes its columns device-to-device.
+        This extractor must stay open until the batch has been created.  Returns (DeviceTaskInput, ExtractInfo)."""
+        from .soa import DeviceTaskInput
+        r = abi.snf_extract_result_t()
+        self._check(self.lib.snf_extract_result_meta(self._h, C.byref(r)))
+        t = r.task
+        ps_vals = np.ctypeslib.as_array(r.ps_value, shape=(int(r.n_ps),)).tolist()
+        ps_names = [str(x) for x in ps_vals]
+        ps_names[int(t.ps_null_rank)] = "NULL"
+        c = self._ctx
+        ti = DeviceTaskInput(self, int(t.n_leads), int(t.n_reads), task_id=task_id, contig=c["contig"], contig_len=c["contig_len"],
+                             sv_id_start=sv_id_start,
+                             tr_start=None if tandem_repeats is None else np.array([x[0] for x in tandem_repeats], np.int32),
+                             tr_end=None if tandem_repeats is None else np.array([x[1] for x in tandem_repeats], np.int32),
+                             qc_nm_threshold=float(t.qc_nm_threshold), qnames=c["qnames"], ps_names=ps_names,
+                             contig_names=c["contig_names"])
+        info = ExtractInfo(read_id=int(r.read_id), read_count=int(r.read_count), ms_count=float(r.ms_count),
+                           ms_emit=float(r.ms_emit), algo_bytes=int(r.algo_bytes))
+        return ti, info
+
     def result(self, task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None):
         r = abi.snf_extract_result_t()
         self._check(self.lib.snf_extract_result(self._h, C.byref(r)))
@@ -117,3 +152,19 @@ def extract_region(recs: bam.BamRecords, contig: str, start: int, end: int, conf
         return x.result(task_id, sv_id_start, tandem_repeats)
     finally:
         x.close()
+
+
+def extract_region_device(recs: bam.BamRecords, contig: str, start: int, end: int, config=None, read_id_offset: int = 0,
+                          task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None, device: int = 0, _lib=None):
+    """`extract_region` whose result stays in HBM: returns (soa.DeviceTaskInput, ExtractInfo, Extractor).  The clustering
+    batch takes the columns device-to-device; close the extractor once the task is through (its memory backs the task until
+    the batch has been created, and the lazy host copies of the columns afterwards)."""
+    x = Extractor(config, device, _lib)
+    try:
+        x.upload(recs, contig, start, end, read_id_offset)
+        x.run()
+        ti, info = x.result_device(task_id, sv_id_start, tandem_repeats)
+        return ti, info, x
+    except Exception:
+        x.close()
+        raise

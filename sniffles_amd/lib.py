@@ -64,10 +64,14 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_extract_upload.argtypes = [vp, C.POINTER(abi.snf_extract_input_t)]
     lib.snf_extract_run.argtypes = [vp]
     lib.snf_extract_result.argtypes = [vp, C.POINTER(abi.snf_extract_result_t)]
+    lib.snf_extract_result_meta.argtypes = [vp, C.POINTER(abi.snf_extract_result_t)]
+    lib.snf_extract_device_view.argtypes = [vp, C.POINTER(abi.snf_task_input_t), C.POINTER(C.c_int)]
+    lib.snf_batch_add_task_device.argtypes = [vp, vp, C.POINTER(abi.snf_task_input_t)]
     lib.snf_extract_destroy.argtypes = [vp]
     lib.snf_extract_destroy.restype = None
     lib.snf_extract_last_error.restype = C.c_char_p
-    for f in ("snf_extract_create", "snf_extract_upload", "snf_extract_run", "snf_extract_result"):
+    for f in ("snf_extract_create", "snf_extract_upload", "snf_extract_run", "snf_extract_result", "snf_extract_result_meta",
+              "snf_extract_device_view", "snf_batch_add_task_device"):
         getattr(lib, f).restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
@@ -104,8 +108,13 @@ class Batch:
         cs = abi.config_struct(cfg)
         _check(self.lib, self.lib.snf_batch_create(C.byref(cs), device, C.byref(self._h)))
         try:
+            from .soa import DeviceTaskInput
+            keep = []       # the task arrays are borrowed by the library until snf_batch_upload returns
             for ti in self.tasks:
-                keep = []
+                if isinstance(ti, DeviceTaskInput):     # columns already in HBM (extraction): device-to-device hand-over
+                    ts = abi.task_meta_struct(ti, keep)
+                    _check(self.lib, self.lib.snf_batch_add_task_device(self._h, ti._extractor._h, C.byref(ts)))
+                    continue
                 ts = abi.task_struct(ti, keep)
                 _check(self.lib, self.lib.snf_batch_add_task(self._h, C.byref(ts)))
             _check(self.lib, self.lib.snf_batch_upload(self._h))

@@ -87,12 +87,16 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
         tr = (tandem_repeats or {}).get(contig)
         task = parallel.CallTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config,
                                  tandem_repeats=tr, device=device, _lib=_lib)
-        ti, info = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
-                                          read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id=task_id,
-                                          sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
+        # the signatures never leave HBM between the extraction and the clustering batch (snf_batch_add_task_device)
+        ti, info, extractor = extract.extract_region_device(bam.contig_records(records, contig), contig, task.start, task.end, config,
+                                                            read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32,
+                                                            task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
         task.lead_provider = _Extracted(ti)
-        cands = task.call_candidates(qc, config)
+        try:
+            cands = task.call_candidates(qc, config)
+        finally:
+            extractor.close()
         calls = task.finalize_candidates(cands, not qc, config)
         if not config.no_qc:
             calls = [c for c in calls if c.qc]

@@ -129,3 +129,36 @@ def intern_sorted(strings) -> tuple:
     uniq = sorted(set(strings))
     rank = {s: i for i, s in enumerate(uniq)}
     return uniq, rank
+
+
+class DeviceTaskInput(TaskInput):
+    """A task whose leads, sequence pool and read table were born in HBM (sniffles_amd.extract.Extractor) and stay there:
+    `lib.Batch` hands them to the clustering path device-to-device (`snf_batch_add_task_device`).  The host keeps what it
+    needs to format results (names, phase-set table, sizes); the columns are copied to the host only if somebody asks for
+    `.leads` / `.seq_pool` / `.read_*` (e.g. the cluster views of seam B3)."""
+
+    def __init__(self, extractor, n_leads: int, n_reads: int, **kw):
+        self._extractor, self._n_leads, self._n_reads, self._host = extractor, int(n_leads), int(n_reads), None
+        super().__init__(**kw)
+
+    def _pull(self):
+        if self._host is None:
+            self._host = self._extractor.host_columns()
+        return self._host
+
+    @property
+    def n_leads(self) -> int:
+        return self._n_leads
+
+    @property
+    def n_reads(self) -> int:
+        return self._n_reads
+
+    leads = property(lambda self: self._pull()["leads"], lambda self, v: None)
+    seq_pool = property(lambda self: self._pull()["seq_pool"], lambda self, v: None)
+    read_start = property(lambda self: self._pull()["read_start"], lambda self, v: None)
+    read_end = property(lambda self: self._pull()["read_end"], lambda self, v: None)
+    read_hp = property(lambda self: self._pull()["read_hp"], lambda self, v: None)
+
+    def validate(self) -> None:      # the columns were produced by the extraction kernels
+        pass

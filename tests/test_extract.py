@@ -183,3 +183,47 @@ def test_extracted_task_feeds_the_clustering_path(emu_lib, oracle_mod):
     exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
     assert got == exp
     assert sum(len(g) for g in got) > 20
+
+
+def check_device_handover(_lib, oracle_mod):
+    """Extraction results that stay in HBM (snf_batch_add_task_device) in one batch with a task that comes from the host:
+    the records equal the all-host batch's and the oracle's; the lazy host copy of the columns equals the eager one."""
+    from sniffles_amd import extract, lib, records, soa
+    from sniffles_amd.config import SnifflesConfig
+    names = ("extract_fuzz_a", "extract_lowq_short", "extract_fuzz_window")
+    host, dev, keep = [], [], []
+    for k, name in enumerate(names):
+        case = cases.EXTRACT[name]
+        recs = cases.extract_records(case)
+        ti, _ = extract.extract_region(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k, _lib=_lib)
+        host.append(ti)
+        if k == 1:
+            dev.append(ti)                      # a host task between two device tasks
+            continue
+        tid, _, x = extract.extract_region_device(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k, _lib=_lib)
+        assert isinstance(tid, soa.DeviceTaskInput) and tid.n_leads == ti.n_leads and tid.n_reads == ti.n_reads
+        dev.append(tid)
+        keep.append(x)
+    cfg = SnifflesConfig(minsupport=2)
+    out = []
+    for tis in (host, dev):
+        with lib.Batch(cfg, tis, _lib=_lib) as b:
+            b.call_candidates()
+            b.finalize()
+            out.append(records.records(b.fetch(1), host, "final"))
+    assert out[0] == out[1] == records.records(oracle_mod.run(cfg, host, True), host, "final")
+    for a, d in zip(host, dev):
+        for name in a.leads:
+            assert np.array_equal(a.leads[name], d.leads[name], equal_nan=a.leads[name].dtype.kind == "f"), name
+        assert np.array_equal(a.seq_pool, d.seq_pool) and np.array_equal(a.read_end, d.read_end)
+    for x in keep:
+        x.close()
+
+
+def test_device_handover_equals_host_path_emu(emu_lib, oracle_mod):
+    check_device_handover(emu_lib, oracle_mod)
+
+
+@pytest.mark.gpu
+def test_device_handover_equals_host_path_gpu(oracle_mod):
+    check_device_handover(None, oracle_mod)
