@@ -482,9 +482,11 @@ def wall_clock(cfg, tasks, device):
     contig tasks in one device batch (the library's native shape); `per_task_api` = the reference's own call sequence,
     Task.call_candidates + Task.finalize_candidates task by task, SVCall objects out (sniffles_amd.parallel)."""
     from sniffles_amd import lib, parallel, pipeline, sv
+    os.environ["SNF_PROF"] = "1"          # the library prints its own split of the upload to stderr
     t0 = time.perf_counter()
     b = lib.Batch(cfg, tasks, device=device)
     t1 = time.perf_counter()
+    del os.environ["SNF_PROF"]
     b.call_candidates(); b.finalize(); b.sync()
     t2 = time.perf_counter()
     res = b.fetch(1)

@@ -16,6 +16,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-result", "-Wno-unused-value"]
 
 
+def fast_so() -> str:
+    import sysconfig
+    return os.path.join(HERE, "_snf_fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_fast(force: bool = False) -> str:
+    """The CPython extension that turns record tables into SVCall objects (csrc/snf_pyfast.c; host-side formatting only)."""
+    import sysconfig
+    so, src = fast_so(), os.path.join(CSRC, "snf_pyfast.c")
+    hdr = os.path.join(HERE, "..", "include", "sniffles_amd.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", so]
+        subprocess.run(cmd, check=True)
+    return so
+
+
 def needs_build() -> bool:
     if not os.path.exists(SO):
         return True
@@ -25,6 +41,7 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    build_fast(force)
     if not force and not needs_build():
         return SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -100,7 +100,33 @@ namespace {
 
 thread_local std::string g_err;
 
-struct DevBuf { void* p; size_t bytes; };
+struct DevBuf { void* p; size_t bytes; bool slab = false; };
+
+// Slabs of destroyed batches are kept for the next batch of the process (a pipeline runs one task after the other, each with
+// a slab of up to a few GB: hipMalloc / hipFree of that size costs up to hundreds of milliseconds on some boxes, far more
+// than the upload itself).  At most SNF_SLAB_CACHE_MAX slabs are kept; the smallest one that is large enough is reused.
+#define SNF_SLAB_CACHE_MAX 6
+struct SlabCache {
+  struct E { void* p; size_t bytes; int device; };
+  std::mutex mu; std::vector<E> free_list;
+  void* take(int device, size_t bytes, size_t* got) {
+    std::lock_guard<std::mutex> g(mu);
+    int best = -1;
+    for (size_t i = 0; i < free_list.size(); i++)
+      if (free_list[i].device == device && free_list[i].bytes >= bytes && (best < 0 || free_list[i].bytes < free_list[(size_t)best].bytes)) best = (int)i;
+    if (best < 0) return nullptr;
+    void* p = free_list[(size_t)best].p; *got = free_list[(size_t)best].bytes;
+    free_list.erase(free_list.begin() + best);
+    return p;
+  }
+  bool give(int device, void* p, size_t bytes) {   // false: the cache is full, the caller frees the slab
+    std::lock_guard<std::mutex> g(mu);
+    if (free_list.size() >= SNF_SLAB_CACHE_MAX) return false;
+    free_list.push_back({p, bytes, device});
+    return true;
+  }
+};
+SlabCache g_slabs;
 
 struct Timing { const char* name; float ms; int64_t bytes; int launches; };
 
@@ -213,7 +239,20 @@ T* dalloc(snf_batch_impl* b, size_t n) {
   const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
   if (b->slab_used + bytes > b->slab_cap) {
     size_t cap = b->slab_next; if (cap < bytes) cap = bytes;
-    b->slab = dalloc_own<uint8_t>(b, cap); b->slab_cap = cap; b->slab_used = 0;
+    size_t got = 0;
+    void* cached = getenv("SNF_NO_SLAB_CACHE") ? nullptr : g_slabs.take(b->device, cap, &got);
+    if (cached && got <= 2 * cap + ((size_t)256 << 20)) {   // (a much larger slab is left for a batch that needs it)
+#ifdef SNF_EMU
+      memset(cached, 0xA5, got);
+#endif
+      b->bufs.push_back({cached, got, true});
+      b->slab = (uint8_t*)cached; cap = got;
+    } else {
+      if (cached) g_slabs.give(b->device, cached, got);
+      b->slab = dalloc_own<uint8_t>(b, cap);
+      b->bufs.back().slab = true;
+    }
+    b->slab_cap = cap; b->slab_used = 0;
   }
   T* p = (T*)(b->slab + b->slab_used);
   b->slab_used += bytes;
@@ -221,6 +260,7 @@ T* dalloc(snf_batch_impl* b, size_t n) {
 }
 void dfree_all(snf_batch_impl* b) {
   for (auto& d : b->bufs) {
+    if (d.slab && !getenv("SNF_NO_SLAB_CACHE") && g_slabs.give(b->device, d.p, d.bytes)) continue;   // kept for the next batch
 #ifndef SNF_EMU
     (void)hipFree(d.p);
 #else

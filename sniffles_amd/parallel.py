@@ -71,9 +71,7 @@ class Task:
         res = self._batch.fetch(0)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
-        out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls)
-        for i, c in enumerate(out):
-            c.postprocess = sv.SVCallPostprocessingInfo(batch=self._batch, index=i)
+        out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch)
         self.sv_id += len(out)
         self.coverage_average_total = float(res.coverage_average_total[0])
         return out

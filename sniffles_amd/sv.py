@@ -208,8 +208,38 @@ def _columns(res: Result, lo: int, hi: int):
     return {n: k for k, n in enumerate(names)}, res.calls[lo:hi].tolist()
 
 
-def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo) -> list:
-    """`fill_candidate(new_call(), res, i, ti)` for i in [lo, hi), same objects."""
+_fast = None
+
+
+def _load_fast():
+    """The C materialiser (csrc/snf_pyfast.c), built in-tree by `sniffles_amd.build`; None when it is not there (the
+    pure-Python twins below do the same work, ~10x slower)."""
+    global _fast
+    if _fast is None:
+        try:
+            from . import _snf_fast as m
+            _fast = m
+        except ImportError:
+            _fast = False
+    return _fast or None
+
+
+def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo, post_cls=None, batch=None) -> list:
+    """`fill_candidate(new_call(), res, i, ti)` for i in [lo, hi), same objects.  With `post_cls` every call also gets its
+    `postprocess = post_cls(batch=batch, index=i - lo)` handle."""
+    import numpy as np
+    fast = _load_fast()
+    if fast is not None and (ti.qnames is None or isinstance(ti.qnames, list)) and (ti.contig_names is None or isinstance(ti.contig_names, list)):
+        return fast.materialize(svcall_cls, bnd_cls, ForwardDifferenceWelford, post_cls, batch, np.ascontiguousarray(res.calls), lo, hi,
+                                np.ascontiguousarray(res.rnames, np.uint32), ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS)
+    out = materialize_candidates_py(res, ti, lo, hi, svcall_cls, bnd_cls)
+    if post_cls is not None:
+        for i, c in enumerate(out):
+            c.postprocess = post_cls(batch=batch, index=i)
+    return out
+
+
+def materialize_candidates_py(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo) -> list:
     K, rows = _columns(res, lo, hi)
     k_svtype, k_pos, k_end, k_svlen, k_svid, k_qual, k_filter, k_qc = (K[n] for n in ("svtype", "pos", "end", "svlen", "sv_id", "qual", "filter", "qc"))
     k_prec, k_sup, k_fwd, k_rev, k_nm, k_cov = (K[n] for n in ("precise", "support", "fwd", "rev", "nm", "cov"))
@@ -253,6 +283,16 @@ def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall,
 
 def apply_final(calls: list, res: Result, ti, lo: int = 0) -> None:
     """`fill_final(call, res, lo + k, ti)` for every call of the list."""
+    import numpy as np
+    fast = _load_fast()
+    if fast is not None and (ti.ps_names is None or isinstance(ti.ps_names, list)):
+        fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
+                         _QC_SV_EARLY_EXIT)
+        return
+    apply_final_py(calls, res, ti, lo)
+
+
+def apply_final_py(calls: list, res: Result, ti, lo: int = 0) -> None:
     K, rows = _columns(res, lo, lo + len(calls))
     k_qc, k_filter, k_phs, k_gts, k_vaf, k_al, k_ao = (K[n] for n in ("qc", "filter", "ph_set", "gt_set", "vaf", "alt_len", "alt_off"))
     k_ph = [K[n] for n in ("ph_hp", "ph_ps", "ph_hp_support", "ph_ps_support", "ph_hp_pass", "ph_ps_pass")]

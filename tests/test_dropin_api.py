@@ -115,3 +115,34 @@ def test_bulk_materialisation_equals_record_by_record():
                 fa, fc = da.pop("forward_difference_sampler"), dc.pop("forward_difference_sampler")
                 assert repr(da) == repr(dc) and fa.__dict__ == fc.__dict__
                 assert [(k, type(v)) for k, v in da.items()] == [(k, type(v)) for k, v in dc.items()]
+
+
+def test_c_materialiser_equals_the_python_twin(oracle_mod):
+    """sniffles_amd._snf_fast (csrc/snf_pyfast.c) builds the same SVCall objects as the pure-Python materialiser: every
+    attribute, dict order included, for candidates and after the finalize fields, BND / INS / phased calls alike."""
+    from sniffles_amd import sv
+    assert sv._load_fast() is not None, "python -m sniffles_amd.build builds the extension"
+    for name in ("chr20_30x_ont", "phase_rescue", "bnd_stale_end", "fuzz_3_3", "fuzz_5_4", "single_leads_noqc", "phase_off_symbolic"):
+        build, kw, _ = cases.ALL[name]
+        ti = build()
+        cfg = gu.make_config(kw, ti)
+        res = oracle_mod.run(cfg, [ti], True)
+        if int(res.task_status[0]) != 0:
+            continue
+        n = len(res.calls)
+        a = sv.materialize_candidates(res, ti, 0, n, post_cls=sv.SVCallPostprocessingInfo, batch="B")
+        b = sv.materialize_candidates_py(res, ti, 0, n)
+        for i, c in enumerate(b):
+            c.postprocess = sv.SVCallPostprocessingInfo(batch="B", index=i)
+        sv.apply_final(a, res, ti)
+        sv.apply_final_py(b, res, ti)
+
+        def flat(c):
+            d = dict(c.__dict__)
+            f = d.pop("forward_difference_sampler")
+            return list(d.items()), list(d["info"].items()), f.__dict__
+        assert len(a) == len(b) == n
+        for x, y in zip(a, b):
+            assert type(x) is type(y) and flat(x) == flat(y), (name, y.id)
+            assert [type(v) for v in x.__dict__.values()] == [type(v) for v in y.__dict__.values()], (name, y.id)
+            assert [type(v) for v in x.info.values()] == [type(v) for v in y.info.values()]
