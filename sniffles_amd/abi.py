@@ -337,14 +337,17 @@ def task_meta_struct(ti, keep: list) -> snf_task_input_t:
 class Result:
     """Host copy of a snf_result_t (numpy views copied out of library-owned memory)."""
 
-    def __init__(self, r: snf_result_t):
+    def __init__(self, r: snf_result_t, copy: bool = True):
+        """copy=False: the arrays are views of the library's own (pinned) result buffers - valid until the next call on the
+        batch; for callers that turn them into objects right away (Task.call_candidates / finalize_candidates)."""
+        own = (lambda a: a.copy()) if copy else (lambda a: a)
         n = int(r.n_calls)
-        self.calls = np.ctypeslib.as_array(C.cast(r.calls, C.POINTER(C.c_uint8)),
-                                           shape=(n * CALL_DTYPE.itemsize,)).view(CALL_DTYPE).copy() if n else np.zeros(0, CALL_DTYPE)
+        self.calls = own(np.ctypeslib.as_array(C.cast(r.calls, C.POINTER(C.c_uint8)),
+                                               shape=(n * CALL_DTYPE.itemsize,)).view(CALL_DTYPE)) if n else np.zeros(0, CALL_DTYPE)
         na = int(r.alt_pool_len)
-        self.alt_pool = np.ctypeslib.as_array(r.alt_pool, shape=(na,)).copy() if na else np.zeros(0, np.uint8)
+        self.alt_pool = own(np.ctypeslib.as_array(r.alt_pool, shape=(na,))) if na else np.zeros(0, np.uint8)
         nr = int(r.rnames_len)
-        self.rnames = np.ctypeslib.as_array(r.rnames, shape=(nr,)).copy() if nr else np.zeros(0, np.uint32)
+        self.rnames = own(np.ctypeslib.as_array(r.rnames, shape=(nr,))) if nr else np.zeros(0, np.uint32)
         nt = int(r.n_tasks)
         self.task_status = np.ctypeslib.as_array(r.task_status, shape=(nt,)).copy()
         self.task_call_off = np.ctypeslib.as_array(r.task_call_off, shape=(nt + 1,)).copy()

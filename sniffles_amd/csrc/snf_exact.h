@@ -160,6 +160,32 @@ SNF_HD int32_t center_sorted(const int32_t* s, int64_t n) {
   return s[0];
 }
 
+#if !defined(SNF_EMU) && defined(__HIPCC__)
+// sort_inplace by a whole wave that executes the surrounding code UNIFORMLY (every lane runs the same statements on the same
+// data: the x_big kernels of snf_wave_call.h): lane p ranks the elements p, p + 64, ... against all others (stable: equal
+// elements keep their order) and scatters them through `tmp` (n elements).  O(n^2 / 64) comparisons instead of
+// O(n log n) dependent ones on one lane - the sorts are what a serial cluster body spends its time in.
+template <class T, class Less>
+__device__ inline void wave_sort_inplace(T* a, int64_t n, Less less, T* tmp) {
+  if (n < 2) return;
+  const int lane = (int)(threadIdx.x & 63);
+  __syncthreads();                                   // (one-wave workgroups) the stores that filled `a` are visible
+  for (int64_t p = lane; p < n; p += 64) {
+    const T x = a[p];
+    int64_t r = 0;
+    for (int64_t q = 0; q < n; q++) { const T y = a[q]; r += (less(y, x) || (!less(x, y) && q < p)) ? 1 : 0; }
+    tmp[r] = x;
+  }
+  __syncthreads();
+  for (int64_t p = lane; p < n; p += 64) a[p] = tmp[p];
+  __syncthreads();
+}
+// `tmp`: scratch of n elements; `uniform`: the caller runs wave-uniformly (View::wave_uniform)
+#define SNF_SORT(uniform, a, n, less, tmp) do { if (uniform) wave_sort_inplace((a), (n), (less), (tmp)); else sort_inplace((a), (n), (less)); } while (0)
+#else
+#define SNF_SORT(uniform, a, n, less, tmp) sort_inplace((a), (n), (less))
+#endif
+
 // util.stdev(util.trim(nums)) on a SORTED array (util.py:25-27,82-88)
 SNF_HD double stdev_trim_sorted(const int32_t* s, int64_t n) {
   int64_t trim_n = (int64_t)((double)n / 100.0 * 25.0);

@@ -131,11 +131,39 @@ SlabCache g_slabs;
 struct Timing { const char* name; float ms; int64_t bytes; int launches; };
 
 // ---- pinned, grow-only host buffers for results (pageable D2H is 3-4x slower) ----
+// Pinning memory costs more than filling it, and a pipeline creates one batch per task: released buffers go to a small
+// process-wide cache and the next batch takes the smallest one that is large enough.
+struct PinnedCache {
+  struct E { void* p; size_t cap; };
+  std::mutex mu; std::vector<E> free_list;
+  void* take(size_t bytes, size_t* cap) {
+    std::lock_guard<std::mutex> g(mu);
+    int best = -1;
+    for (size_t i = 0; i < free_list.size(); i++)
+      if (free_list[i].cap >= bytes && (best < 0 || free_list[i].cap < free_list[(size_t)best].cap)) best = (int)i;
+    if (best < 0) return nullptr;
+    void* p = free_list[(size_t)best].p; *cap = free_list[(size_t)best].cap;
+    free_list.erase(free_list.begin() + best);
+    return p;
+  }
+  bool give(void* p, size_t cap) {
+    std::lock_guard<std::mutex> g(mu);
+    if (free_list.size() >= 16) return false;
+    free_list.push_back({p, cap});
+    return true;
+  }
+};
+PinnedCache g_pinned;
+
 struct HostBuf {
   void* p = nullptr; size_t cap = 0;
   void* ensure(size_t bytes) {
     if (bytes <= cap && p) return p;
     release();
+    size_t got = 0;
+    void* c = g_pinned.take(bytes, &got);
+    if (c && got <= 4 * bytes + ((size_t)64 << 20)) { p = c; cap = got; return p; }
+    if (c) g_pinned.give(c, got);
     cap = bytes + bytes / 4 + 4096;
 #ifndef SNF_EMU
     SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
@@ -146,11 +174,13 @@ struct HostBuf {
   }
   void release() {
     if (!p) return;
+    if (!g_pinned.give(p, cap)) {
 #ifndef SNF_EMU
-    (void)hipHostFree(p);
+      (void)hipHostFree(p);
 #else
-    free(p);
+      free(p);
 #endif
+    }
     p = nullptr; cap = 0;
   }
 };
@@ -808,7 +838,7 @@ void do_upload(snf_batch_impl* b) {
   v.grp_first_bin = dalloc<int32_t>(b, 8 * (size_t)T + 8);
   v.L = dalloc<uint32_t>(b, N); v.LL = dalloc<uint32_t>(b, N); v.Lrec = dalloc<LeadRec>(b, N1); v.chdr = dalloc<ClusterHdr>(b, N1);
   int32_t** i32s[] = {&v.seed_bin, &v.seed_lo, &v.seed_hi, &v.seedL_lo, &v.seedL_hi, &v.seed_start, &v.seed_grp, &v.c_last, &v.c_end,
-                      &v.nxt, &v.prv, &v.run_first, &v.run_last_head, &v.cl_head, &v.w0, &v.w1, &v.w2, &v.w3, &v.w4, &v.w5, &v.w6,
+                      &v.nxt, &v.prv, &v.run_first, &v.run_last_head, &v.cl_head, &v.w0, &v.w1, &v.w2, &v.w3, &v.w4, &v.w5, &v.w6, &v.w7,
                       &v.F_orig, &v.F_svlen, &v.F_seq_len, &v.FI, &v.F_lpos, &v.rc_n_s, &v.rc_cl_s, &v.rc_lo, &v.rc_n, &v.rc_cluster};
   for (auto pp : i32s) *pp = dalloc<int32_t>(b, N1);
   double** f64s[] = {&v.s_mean0, &v.s_stdev0, &v.c_mean, &v.c_stdev, &v.run_b_stdev, &v.run_b_absmean};

@@ -60,6 +60,18 @@ SNF_HD void rc_emit(const View& v, int32_t pos, int32_t n, int32_t c, bool keepl
   v.rc_keeplong_s[pos] = keeplong ? 1 : 0;
 }
 
+// room for a fused sequence behind the input sequences; in a wave that runs the body uniformly one lane reserves for all
+SNF_HD unsigned long long pool_reserve(const View& v, unsigned long long nbytes) {
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+  if (v.wave_uniform) {
+    unsigned long long o = 0;
+    if ((threadIdx.x & 63) == 0) o = atomicAdd(&v.cnt->pool_extra_used, nbytes);
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(o >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)o);
+  }
+#endif
+  return atomic_add_u64(&v.cnt->pool_extra_used, nbytes);
+}
+
 // one merged cluster -> fused leads (F) + refined clusters in final lead order (FI)
 SNF_HD void d1_refine_body(int64_t c, const View& v) {
   if (c >= v.cnt->n_clusters) return;
@@ -71,7 +83,8 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   if (v.wave_path && (n <= 64 || v.big_wave)) return;  // d1w_refine (snf_wave_refine.h) / x_big<0> (a wave of its own)
   int svtype = grp_svtype(v.seed_grp[h]);
   int32_t *a0 = v.w0 + lo, *a1 = v.w1 + lo, *a2 = v.w2 + lo, *a3 = v.w3 + lo, *a4 = v.w4 + lo, *a5 = v.w5 + lo,
-          *a6 = v.w6 + lo;
+          *a6 = v.w6 + lo, *stmp = v.w7 + lo;
+  const bool uni = v.wave_uniform != 0;
   int32_t* Forig = v.F_orig + lo; int32_t* Fsvlen = v.F_svlen + lo; int32_t* Fseqlen = v.F_seq_len + lo;
   int64_t* Fseqoff = v.F_seq_off + lo;
   int32_t m = 0;
@@ -80,14 +93,14 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
     // ---- merge_inner: group by read (first appearance), sort by ref_start, fuse neighbours
     int thr = v.c_repeat[h] ? -1 : cfg.cluster_merge_pos;
     for (int32_t j = 0; j < n; j++) a0[j] = j;
-    sort_inplace(a0, (int64_t)n, LessQnameIdx{v, lo});
+    SNF_SORT(uni, a0, (int64_t)n, (LessQnameIdx{v, lo}), stmp);
     for (int32_t x = 0; x < n;) {
       int32_t y = x; uint32_t q = v.in_qname[v.L[lo + a0[x]]];
       while (y < n && v.in_qname[v.L[lo + a0[y]]] == q) { a1[a0[y]] = a0[x]; y++; }
       x = y;
     }
     for (int32_t j = 0; j < n; j++) a0[j] = j;
-    sort_inplace(a0, (int64_t)n, LessFaRefIdx{v, lo, a1});
+    SNF_SORT(uni, a0, (int64_t)n, (LessFaRefIdx{v, lo, a1}), stmp);
     for (int32_t x = 0; x < n;) {
       int32_t y_end = x; while (y_end < n && a1[a0[y_end]] == a1[a0[x]]) y_end++;
       uint32_t ho = v.L[lo + a0[x]];
@@ -115,7 +128,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
           if (!seq_ok) { Fseqlen[m] = -1; Fseqoff[m] = 0; }
           else if (nparts == 1) { Fseqlen[m] = v.in_seq_len[head]; Fseqoff[m] = v.in_seq_off[head]; }
           else {  // curr_lead.seq += to_merge.seq: new string in the fused part of the pool
-            int64_t off = v.pool_len + (int64_t)atomic_add_u64(&v.cnt->pool_extra_used, (unsigned long long)seq_total);
+            int64_t off = v.pool_len + (int64_t)pool_reserve(v, (unsigned long long)seq_total);
             if (off + seq_total > v.pool_cap) { atomic_or_i32(&v.cnt->overflow, 1); Fseqlen[m] = -1; Fseqoff[m] = 0; }
             else {
               int64_t w = off;
@@ -157,7 +170,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
     }
     int thr = cfg.cluster_merge_bnd;
     for (int32_t j = 0; j < m; j++) a0[j] = j;
-    sort_inplace(a0, (int64_t)m, LessIdentIdx{v, lo});
+    SNF_SORT(uni, a0, (int64_t)m, (LessIdentIdx{v, lo}), stmp);
     for (int32_t x = 0; x < m;) {
       int32_t y = x; uint32_t ox = v.L[lo + a0[x]];
       while (y < m) { uint32_t oy = v.L[lo + a0[y]];
@@ -167,7 +180,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
     }
     for (int32_t j = 0; j < m; j++) a0[j] = j;
     LessFaPosbinIdx lp{v, lo, a1, thr};
-    sort_inplace(a0, (int64_t)m, lp);
+    SNF_SORT(uni, a0, (int64_t)m, lp, stmp);
     int32_t start = 0; int64_t last_bin = lp.pb(a0[0]);
     for (int32_t x = 0; x < m; x++) {
       FI[x] = lo + a0[x];
@@ -190,7 +203,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   }
   LessBinIdx lb{Fsvlen, cfg.cluster_resplit_binsize};
   for (int32_t k = 0; k < m; k++) a0[k] = k;
-  sort_inplace(a0, (int64_t)m, lb);
+  SNF_SORT(uni, a0, (int64_t)m, lb, stmp);
   // segments = distinct bins: a1 seg start, a2 seg key, a3 surviving list, a4 head, a5 tail, a6 next
   int32_t nb = 0;
   for (int32_t x = 0; x < m; x++)
@@ -259,17 +272,18 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   if (v.wave_path && (n <= 64 || v.big_wave)) return;  // d2w_call / x_big<1> (snf_wave_call.h)
   int32_t h = v.cl_head[c];
   int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
-  int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo;
+  int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo, *stmp = v.w7 + flo;
+  const bool uni = v.wave_uniform != 0;
   const int32_t* FI = v.FI + flo;
   v.cdflag[r] = 0;
   for (int32_t k = 0; k < n; k++) { a0[k] = v.F_svlen[FI[k]]; v.F_sel[FI[k]] = 1; }
-  sort_inplace(a0, (int64_t)n, LessI32{});
+  SNF_SORT(uni, a0, (int64_t)n, LessI32{}, stmp);
   int64_t svlen = center_sorted(a0, n);
   bool single = svtype == SNF_SINGLE_LEFT || svtype == SNF_SINGLE_RIGHT;
   if (!single && svtype != SNF_BND && iabs64(svlen) < cfg.minsvlen_screen) return;
 
   for (int32_t k = 0; k < n; k++) a1[k] = (int32_t)v.in_qname[v.F_orig[FI[k]]];
-  sort_inplace(a1, (int64_t)n, LessI32{});
+  SNF_SORT(uni, a1, (int64_t)n, LessI32{}, stmp);
   int64_t nq = distinct_sorted_i32(a1, n);
   int64_t support = nq, support_long = 0;
   int32_t llo = v.seedL_lo[h], lhi = v.seedL_hi[v.c_last[h]];
@@ -283,7 +297,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
     }
   }
   for (int32_t k = 0; k < n; k++) a2[k] = v.in_ref_start[v.F_orig[FI[k]]];
-  sort_inplace(a2, (int64_t)n, LessI32{});
+  SNF_SORT(uni, a2, (int64_t)n, LessI32{}, stmp);
   int64_t ref_start = center_sorted(a2, n);
   double stdev_pos = stdev_trim_sorted(a2, n);
   double stdev_len = NAN; bool precise;
@@ -318,7 +332,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   int64_t rn_len = support;
   if (svtype == SNF_BND) {  // resolve_bnd
     for (int32_t k = 0; k < n; k++) a3[k] = v.in_mate_contig[v.F_orig[FI[k]]];
-    sort_inplace(a3, (int64_t)n, LessI32{});
+    SNF_SORT(uni, a3, (int64_t)n, LessI32{}, stmp);
     int32_t mc = a3[0]; int64_t bc = 0;
     for (int32_t x = 0; x < n;) { int32_t y = x; while (y < n && a3[y] == a3[x]) y++; if (y - x > bc) { bc = y - x; mc = a3[x]; } x = y; }
     int32_t ns = 0; int64_t nfirst = 0, nrev = 0;
@@ -328,8 +342,8 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       v.F_sel[FI[k]] = sel ? 1 : 0;
       if (sel) { a3[ns] = v.in_mate_pos[o]; a1[ns] = (int32_t)v.in_qname[o]; nfirst += v.in_first[o]; nrev += v.in_rev[o]; ns++; }
     }
-    sort_inplace(a3, (int64_t)ns, LessI32{});
-    sort_inplace(a1, (int64_t)ns, LessI32{});
+    SNF_SORT(uni, a3, (int64_t)ns, LessI32{}, stmp);
+    SNF_SORT(uni, a1, (int64_t)ns, LessI32{}, stmp);
     nq = distinct_sorted_i32(a1, ns);
     cc.support = (int32_t)nq; rn_len = nq;
     cc.mate_contig = mc; cc.mate_ref_start = center_sorted(a3, ns);

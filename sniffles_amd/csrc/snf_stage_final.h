@@ -158,7 +158,7 @@ SNF_HD void collect_agg(const View& v, const CallX& x, int task, LeadAgg* g) {
   for (int h = 0; h < 3; h++) if (hc[h] > 0 && hc[h] >= hp_support) { hp_support = hc[h]; hpv = h; }
   int64_t other_hp = 0;
   for (int h = 0; h < 3; h++) if (h != hpv) other_hp += hc[h];
-  sort_inplace(a0, (int64_t)np_, LessI32{});
+  SNF_SORT(v.wave_uniform != 0, a0, (int64_t)np_, LessI32{}, v.w7 + x.flo);
   int32_t psv = 0; int64_t ps_support = -1;
   for (int32_t i = 0; i < np_;) {
     int32_t j = i; while (j < np_ && a0[j] == a0[i]) j++;

@@ -334,14 +334,17 @@ __global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused
 
 // Items with more than 64 leads (rare at 30x, a quarter of the clusters at 60x): the serial bodies of the thread kernels,
 // but ONE item per wave (lane 0) instead of one per lane - 64 different clusters in one wave diverge on every branch and
-// cost the sum of their times.  KIND 0: d1_refine_body (clusters), 1: d2_call_body (refined clusters), 2: e1_finalize_body.
+// cost the sum of their times - and with the wave running one body uniformly the sorts inside it become cooperative rank sorts
+// (SNF_SORT, snf_exact.h).  KIND 0: d1_refine_body (clusters), 1: d2_call_body (refined clusters), 2: e1_finalize_body.
 template <int KIND>
 __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
   v.big_wave = 0;   // the bodies below are the ones that skip big items when it is set
+  // all 64 lanes run the serial body in lock step on the same data (identical stores, no atomics except the one pool
+  // reservation, which one lane makes): the body's sorts - where it spends its time - are then done by the whole wave
+  v.wave_uniform = 1;
   const int stripe = blockIdx.x & 63, per = (int)(gridDim.x >> 6);
   const uint32_t cnt = v.big_cnt[(KIND * 64 + stripe) * 16];
   const int32_t* list = v.big_list + ((int64_t)KIND * 64 + stripe) * v.big_cap;
-  if (threadIdx.x != 0) return;
   for (uint32_t k = blockIdx.x >> 6; k < cnt; k += (uint32_t)per) {
     const int64_t item = list[k];
     if (KIND == 0) d1_refine_body(item, v);

@@ -148,10 +148,11 @@ class Batch:
     def sync(self):
         _check(self.lib, self.lib.snf_batch_sync(self._h))
 
-    def fetch(self, stage: int) -> abi.Result:
+    def fetch(self, stage: int, copy: bool = True) -> abi.Result:
+        """copy=False: views of the library's result buffers (valid until the next call on this batch) instead of copies."""
         r = abi.snf_result_t()
         _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
-        return abi.Result(r)
+        return abi.Result(r, copy)
 
     def fetch_raw(self, stage: int) -> int:
         """D2H of the results into library-owned host memory without materialising numpy copies; returns n_calls."""

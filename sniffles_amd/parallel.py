@@ -68,7 +68,7 @@ class Task:
                     print(f"Dumping clusters to {filename}")
                     with open(filename, "w") as h:
                         h.write(text)
-        res = self._batch.fetch(0)
+        res = self._batch.fetch(0, copy=False)      # turned into objects right here
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
         out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch)
@@ -80,7 +80,7 @@ class Task:
         if self._batch is None or getattr(self, "_finalized", False):
             raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")
         self._batch.finalize()
-        res = self._batch.fetch(1)
+        res = self._batch.fetch(1, copy=False)
         if len(res.calls) != len(candidates):
             raise RuntimeError("candidate list does not match the batch (pass the list call_candidates returned)")
         sv.apply_final(candidates, res, self._ti)
