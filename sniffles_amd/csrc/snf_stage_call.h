@@ -11,18 +11,20 @@ namespace snf {
 SNF_HD bool lead_has_seq(const View& v, uint32_t o) { return v.in_seq_len[o] >= 0 && !v.seqnull[o]; }
 
 // ------------------------------------------------------------------------------------------ D1
+// (the refinement bodies read the cluster's leads from the packed records R = Lrec + lo: one 64-byte line per lead instead
+// of a dozen columns gathered through L[] - and one array to stage when a wave keeps the cluster in LDS, x_big<0>)
 struct LessQnameIdx {
-  const View& v; int32_t lo;
+  const LeadRec* R;
   SNF_HD bool operator()(int32_t a, int32_t b) const {
-    uint32_t qa = v.in_qname[v.L[lo + a]], qb = v.in_qname[v.L[lo + b]];
+    uint32_t qa = R[a].qname, qb = R[b].qname;
     return qa != qb ? qa < qb : a < b;
   }
 };
 struct LessFaRefIdx {
-  const View& v; int32_t lo; const int32_t* fa;
+  const LeadRec* R; const int32_t* fa;
   SNF_HD bool operator()(int32_t a, int32_t b) const {
     if (fa[a] != fa[b]) return fa[a] < fa[b];
-    int32_t ra = v.in_ref_start[v.L[lo + a]], rb = v.in_ref_start[v.L[lo + b]];
+    int32_t ra = R[a].ref_start, rb = R[b].ref_start;
     return ra != rb ? ra < rb : a < b;
   }
 };
@@ -35,17 +37,16 @@ struct LessBinIdx {
   }
 };
 struct LessIdentIdx {
-  const View& v; int32_t lo;
+  const LeadRec* R;
   SNF_HD bool operator()(int32_t a, int32_t b) const {
-    uint32_t oa = v.L[lo + a], ob = v.L[lo + b];
-    if (v.in_mate_contig[oa] != v.in_mate_contig[ob]) return v.in_mate_contig[oa] < v.in_mate_contig[ob];
-    if (v.in_first[oa] != v.in_first[ob]) return v.in_first[oa] < v.in_first[ob];
+    if (R[a].mate_contig != R[b].mate_contig) return R[a].mate_contig < R[b].mate_contig;
+    if (R[a].first != R[b].first) return R[a].first < R[b].first;
     return a < b;
   }
 };
 struct LessFaPosbinIdx {
-  const View& v; int32_t lo; const int32_t* fa; int32_t thr;
-  SNF_HD int64_t pb(int32_t a) const { return thr > 0 ? ((int64_t)v.in_mate_pos[v.L[lo + a]] / thr) * thr : 0; }
+  const LeadRec* R; const int32_t* fa; int32_t thr;
+  SNF_HD int64_t pb(int32_t a) const { return thr > 0 ? ((int64_t)R[a].mate_pos / thr) * thr : 0; }
   SNF_HD bool operator()(int32_t a, int32_t b) const {
     if (fa[a] != fa[b]) return fa[a] < fa[b];
     int64_t pa = pb(a), pbb = pb(b);
@@ -84,78 +85,83 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
   int svtype = grp_svtype(v.seed_grp[h]);
   int32_t *a0 = v.w0 + lo, *a1 = v.w1 + lo, *a2 = v.w2 + lo, *a3 = v.w3 + lo, *a4 = v.w4 + lo, *a5 = v.w5 + lo,
           *a6 = v.w6 + lo, *stmp = v.w7 + lo;
+  if (v.stage_w) {   // the calling wave holds the cluster's scratch rows in LDS
+    const int32_t cap = v.stage_cap;
+    a0 = v.stage_w; a1 = a0 + cap; a2 = a1 + cap; a3 = a2 + cap; a4 = a3 + cap; a5 = a4 + cap; a6 = a5 + cap; stmp = a6 + cap;
+  }
   const bool uni = v.wave_uniform != 0;
   int32_t* Forig = v.F_orig + lo; int32_t* Fsvlen = v.F_svlen + lo; int32_t* Fseqlen = v.F_seq_len + lo;
   int64_t* Fseqoff = v.F_seq_off + lo;
   int32_t m = 0;
 
+  const LeadRec* R = v.stage_R ? v.stage_R : v.Lrec + lo;   // the cluster's leads, cluster order (in LDS when staged)
   if (svtype == SNF_INS || svtype == SNF_DEL) {
     // ---- merge_inner: group by read (first appearance), sort by ref_start, fuse neighbours
     int thr = v.c_repeat[h] ? -1 : cfg.cluster_merge_pos;
     for (int32_t j = 0; j < n; j++) a0[j] = j;
-    SNF_SORT(uni, a0, (int64_t)n, (LessQnameIdx{v, lo}), stmp);
+    SNF_SORT(uni, a0, (int64_t)n, (LessQnameIdx{R}), stmp);
     for (int32_t x = 0; x < n;) {
-      int32_t y = x; uint32_t q = v.in_qname[v.L[lo + a0[x]]];
-      while (y < n && v.in_qname[v.L[lo + a0[y]]] == q) { a1[a0[y]] = a0[x]; y++; }
+      int32_t y = x; uint32_t q = R[a0[x]].qname;
+      while (y < n && R[a0[y]].qname == q) { a1[a0[y]] = a0[x]; y++; }
       x = y;
     }
     for (int32_t j = 0; j < n; j++) a0[j] = j;
-    SNF_SORT(uni, a0, (int64_t)n, (LessFaRefIdx{v, lo, a1}), stmp);
+    SNF_SORT(uni, a0, (int64_t)n, (LessFaRefIdx{R, a1}), stmp);
     for (int32_t x = 0; x < n;) {
       int32_t y_end = x; while (y_end < n && a1[a0[y_end]] == a1[a0[x]]) y_end++;
-      uint32_t ho = v.L[lo + a0[x]];
-      int64_t cs = v.in_svlen[ho]; bool seq_ok = lead_has_seq(v, ho); int64_t seq_total = seq_ok ? v.in_seq_len[ho] : 0;
-      int32_t part_start = x; uint32_t head = ho;
-      int32_t l_re = v.in_ref_end[ho], l_qe = v.in_qry_end[ho], l_rs = v.in_ref_start[ho], l_qs = v.in_qry_start[ho];
+      LeadRec rh = R[a0[x]];       // head of the part being fused
+      int64_t cs = rh.svlen; bool seq_ok = rh.seq_len >= 0; int64_t seq_total = seq_ok ? rh.seq_len : 0;
+      int32_t part_start = x;
+      int32_t l_re = rh.ref_end, l_qe = rh.qry_end, l_rs = rh.ref_start, l_qs = rh.qry_start;
       for (int32_t y = x + 1; y <= y_end; y++) {
         bool flush = (y == y_end);
-        uint32_t to = 0;
+        LeadRec rt{};
         if (!flush) {
-          to = v.L[lo + a0[y]];
-          int32_t rs = v.in_ref_start[to], qs = v.in_qry_start[to];
+          rt = R[a0[y]];
+          int32_t rs = rt.ref_start, qs = rt.qry_start;
           bool mg = (thr == -1) ||
                     (((iabs64((int64_t)rs - l_re) < thr || iabs64((int64_t)rs - l_rs) < thr) &&
                       (iabs64((int64_t)qs - l_qe) < thr || iabs64((int64_t)qs - l_qs) < thr)) &&
-                     (v.in_strand[head] == v.in_strand[to]));
+                     (rh.strand == rt.strand));
           if (mg) {
-            cs += v.in_svlen[to];
-            if (!lead_has_seq(v, to) || !seq_ok) seq_ok = false; else seq_total += v.in_seq_len[to];
+            cs += rt.svlen;
+            if (rt.seq_len < 0 || !seq_ok) seq_ok = false; else seq_total += rt.seq_len;
           } else flush = true;
         }
         if (flush) {
-          Forig[m] = (int32_t)head; Fsvlen[m] = (int32_t)cs; v.F_lpos[lo + m] = lo + a0[part_start];
+          Forig[m] = (int32_t)rh.orig; Fsvlen[m] = (int32_t)cs; v.F_lpos[lo + m] = lo + a0[part_start];
           int32_t nparts = (y < y_end ? y : y_end) - part_start;
           if (!seq_ok) { Fseqlen[m] = -1; Fseqoff[m] = 0; }
-          else if (nparts == 1) { Fseqlen[m] = v.in_seq_len[head]; Fseqoff[m] = v.in_seq_off[head]; }
+          else if (nparts == 1) { Fseqlen[m] = rh.seq_len; Fseqoff[m] = rh.seq_off; }
           else {  // curr_lead.seq += to_merge.seq: new string in the fused part of the pool
             int64_t off = v.pool_len + (int64_t)pool_reserve(v, (unsigned long long)seq_total);
             if (off + seq_total > v.pool_cap) { atomic_or_i32(&v.cnt->overflow, 1); Fseqlen[m] = -1; Fseqoff[m] = 0; }
             else {
               int64_t w = off;
               for (int32_t z = part_start; z < part_start + nparts; z++) {
-                uint32_t zo = v.L[lo + a0[z]];
-                const uint8_t* src = v.pool + v.in_seq_off[zo];
-                for (int32_t b = 0; b < v.in_seq_len[zo]; b++) v.pool[w++] = src[b];
+                const LeadRec& rz = R[a0[z]];
+                const uint8_t* src = v.pool + rz.seq_off;
+                for (int32_t b = 0; b < rz.seq_len; b++) v.pool[w++] = src[b];
               }
               Fseqlen[m] = (int32_t)seq_total; Fseqoff[m] = off;
             }
           }
           m++;
           if (y < y_end) {
-            head = to; cs = v.in_svlen[to]; seq_ok = lead_has_seq(v, to); seq_total = seq_ok ? v.in_seq_len[to] : 0;
+            rh = rt; cs = rt.svlen; seq_ok = rt.seq_len >= 0; seq_total = seq_ok ? rt.seq_len : 0;
             part_start = y;
           }
         }
-        if (y < y_end) { l_re = v.in_ref_end[to]; l_qe = v.in_qry_end[to]; l_rs = v.in_ref_start[to]; l_qs = v.in_qry_start[to]; }
+        if (y < y_end) { l_re = rt.ref_end; l_qe = rt.qry_end; l_rs = rt.ref_start; l_qs = rt.qry_start; }
       }
       x = y_end;
     }
   } else {
     for (int32_t j = 0; j < n; j++) {
-      uint32_t o = v.L[lo + j];
-      Forig[j] = (int32_t)o; Fsvlen[j] = v.in_svlen[o]; v.F_lpos[lo + j] = lo + j;
-      bool hs = lead_has_seq(v, o);
-      Fseqlen[j] = hs ? v.in_seq_len[o] : -1; Fseqoff[j] = hs ? v.in_seq_off[o] : 0;
+      const LeadRec& r = R[j];
+      Forig[j] = (int32_t)r.orig; Fsvlen[j] = r.svlen; v.F_lpos[lo + j] = lo + j;
+      bool hs = r.seq_len >= 0;
+      Fseqlen[j] = hs ? r.seq_len : -1; Fseqoff[j] = hs ? r.seq_off : 0;
     }
     m = n;
   }
@@ -170,16 +176,16 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
     }
     int thr = cfg.cluster_merge_bnd;
     for (int32_t j = 0; j < m; j++) a0[j] = j;
-    SNF_SORT(uni, a0, (int64_t)m, (LessIdentIdx{v, lo}), stmp);
+    SNF_SORT(uni, a0, (int64_t)m, (LessIdentIdx{R}), stmp);
     for (int32_t x = 0; x < m;) {
-      int32_t y = x; uint32_t ox = v.L[lo + a0[x]];
-      while (y < m) { uint32_t oy = v.L[lo + a0[y]];
-        if (v.in_mate_contig[oy] != v.in_mate_contig[ox] || v.in_first[oy] != v.in_first[ox]) break;
+      int32_t y = x; const LeadRec& rx = R[a0[x]];
+      while (y < m) { const LeadRec& ry = R[a0[y]];
+        if (ry.mate_contig != rx.mate_contig || ry.first != rx.first) break;
         a1[a0[y]] = a0[x]; y++; }
       x = y;
     }
     for (int32_t j = 0; j < m; j++) a0[j] = j;
-    LessFaPosbinIdx lp{v, lo, a1, thr};
+    LessFaPosbinIdx lp{R, a1, thr};
     SNF_SORT(uni, a0, (int64_t)m, lp, stmp);
     int32_t start = 0; int64_t last_bin = lp.pb(a0[0]);
     for (int32_t x = 0; x < m; x++) {

@@ -193,6 +193,8 @@ struct View {
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative
   int32_t* w7;               // [N+1] scratch of the cooperative sorts (same slot space as w0..w6)
+  // x_big<0> keeps a cluster in LDS: its packed lead records and the eight scratch rows (stage_cap entries each); null otherwise
+  const LeadRec* stage_R; int32_t* stage_w; int32_t stage_cap; int32_t _pad_stage;
   uint8_t* aln_kept_w;       // [N+1] kept flag per (call, other read) of the workgroup kernels, indexed like crl_*
   int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };
