@@ -587,7 +587,7 @@ SNF_HD void u1_pack_body(int64_t i, const PackView& q) {
   r.qname = q.qname[i]; r.read_id = q.read_id[i]; r.ps = q.ps[i]; r.mate_pos = q.mate_pos[i];
   r.mate_contig = q.mate_contig[i]; r.read_len = q.read_len[i]; r.orig = (uint32_t)i;
   r.strand = q.strand[i]; r.mapq = q.mapq[i]; r.source = q.source[i]; r.hap = q.hap[i];
-  r.is_sa = q.is_sa[i]; r.first = q.first[i]; r.rev = q.rev[i]; r.svtype = q.svtype[i]; r._pad = 0;
+  r.is_sa = q.is_sa[i]; r.first = q.first[i]; r.rev = q.rev[i]; r.svtype = q.svtype[i];
   q.rec[i] = r;
   q.lead_task[i] = task_of(q.t_lead_off, q.T, i);
 }
@@ -859,6 +859,7 @@ void do_upload(snf_batch_impl* b) {
   v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
+  v.stage_cap = getenv("SNF_NO_BIG_STAGE") ? 0 : 1;   // x_big<0>: clusters up to SNF_BIG_STAGE_CAP leads are kept in LDS
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);

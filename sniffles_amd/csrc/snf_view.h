@@ -46,9 +46,10 @@ struct LeadRec {
   int32_t ps, mate_pos;
   int32_t mate_contig, read_len;
   uint32_t orig;                   // input index
-  uint8_t strand, mapq, source, hap, is_sa, first, rev, svtype;
-  uint32_t _pad;
+  // the eight small fields share one word, so that a record is exactly one 64-byte line
+  uint32_t strand : 1, mapq : 8, source : 2, hap : 2, is_sa : 1, first : 1, rev : 1, svtype : 3;
 };
+static_assert(sizeof(LeadRec) == 64, "one cache line per packed lead record");
 
 // one ALT work item, written by e3_conslist: everything a consensus / copy workgroup needs to start, in one record
 // (instead of the chain cons_call -> callx -> F_seq_len/F_seq_off -> FI -> ...; the stage is latency-bound)

@@ -336,11 +336,12 @@ __global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused
 // but ONE item per wave (lane 0) instead of one per lane - 64 different clusters in one wave diverge on every branch and
 // cost the sum of their times - and with the wave running one body uniformly the sorts inside it become cooperative rank sorts
 // (SNF_SORT, snf_exact.h).  KIND 0: d1_refine_body (clusters), 1: d2_call_body (refined clusters), 2: e1_finalize_body.
-#define SNF_BIG_STAGE_CAP 160   // leads of a cluster x_big<0> keeps in LDS (10 KB of records + 5 KB of scratch rows per wave)
+#define SNF_BIG_STAGE_CAP 160   // leads of a cluster x_big<0> keeps in LDS (11 KB of records + 5 KB of scratch rows per wave)
 template <int KIND>
 __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
-  __shared__ LeadRec s_rec[KIND == 0 ? SNF_BIG_STAGE_CAP : 1];
-  __shared__ int32_t s_scr[KIND == 0 ? 8 * SNF_BIG_STAGE_CAP : 1];
+  __shared__ alignas(16) LeadRec s_rec[KIND == 0 ? SNF_BIG_STAGE_CAP : 1];     // (filled with 16-byte stores)
+  __shared__ alignas(16) int32_t s_scr[KIND == 0 ? 8 * SNF_BIG_STAGE_CAP : 1];
+  const bool stage = v.stage_cap != 0;    // host switch (SNF_NO_BIG_STAGE=1 clears it): keep staged clusters in LDS
   v.big_wave = 0;   // the bodies below are the ones that skip big items when it is set
   // all 64 lanes run the serial body in lock step on the same data (identical stores, no atomics except the one pool
   // reservation, which one lane makes): the body's sorts are then done by the whole wave, and (refinement) the cluster's
@@ -356,9 +357,10 @@ __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
       const int32_t h = v.cl_head[item];
       const int32_t lo = v.seed_lo[h], n = v.seed_hi[v.c_last[h]] - lo;
       __syncthreads();                       // the previous cluster is through with the LDS rows
-      if (n <= SNF_BIG_STAGE_CAP) {
-        const uint4* src = (const uint4*)(v.Lrec + lo); uint4* dst = (uint4*)s_rec;      // 64-byte records, 16 bytes per lane and step
-        for (int q = lane; q < n * 4; q += SNF_WAVE) dst[q] = src[q];
+      if (stage && n <= SNF_BIG_STAGE_CAP) {
+        static_assert(sizeof(LeadRec) % 8 == 0, "LeadRec is copied in 8-byte words");
+        const uint2* src = (const uint2*)(v.Lrec + lo); uint2* dst = (uint2*)s_rec;      // 8 bytes per lane and step, coalesced
+        for (int q = lane; q < n * (int)(sizeof(LeadRec) / 8); q += SNF_WAVE) dst[q] = src[q];
         __syncthreads();
         v.stage_R = s_rec; v.stage_w = s_scr; v.stage_cap = SNF_BIG_STAGE_CAP;
       } else { v.stage_R = nullptr; v.stage_w = nullptr; }
