@@ -29,7 +29,7 @@ using namespace snf;
 #define K_CONS_SMALL(MINW) e45w_consensus<1, 256, 128, 64, MINW, 4, SNF_CONS_SMALL_L, 448, 96>
 #define K_CONS_SMALL_1W e45w_consensus<1, 256, 128, 64, 5, 1, SNF_CONS_SMALL_L, 448, 96>
 #define K_CONS_LARGE e45w_consensus<2, 1024, 512, 256, 2, 4, SNF_CONS_LARGE_L, 0, 512>
-#define K_CONS_ROWS e45w_consensus<4, 1024, 512, 512, 5>
+#define K_CONS_ROWS e45w_consensus<4, 1024, 512, 512, 3>
 #endif
 
 // ---------------------------------------------------------------------------------------------- kernels
@@ -204,7 +204,8 @@ struct snf_batch_impl {
   int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
-  int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;  // resident workgroups of the wave kernels on this device
+  int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
+  int slots_cons_s = 1280, slots_cons_l = 512;   // resident workgroups of the SMALL / LARGE consensus kernels (persistent launches)  // resident workgroups of the wave kernels on this device
   int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
@@ -1228,7 +1229,7 @@ void run_finalize(snf_batch_impl* b) {
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          hipLaunchKernelGGL((K_CONS_LARGE), dim3((unsigned)(n_large < 16384 ? n_large : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+          hipLaunchKernelGGL((K_CONS_LARGE), dim3((unsigned)(n_large < b->slots_cons_l ? n_large : b->slots_cons_l)), dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
       }
@@ -1241,7 +1242,7 @@ void run_finalize(snf_batch_impl* b) {
       }
       if (n_small > 0) {
         Scope _s(b, "e45w_consensus_small", 0);
-        const dim3 gs((unsigned)(n_small < 16384 ? n_small : 16384));
+        const dim3 gs((unsigned)(n_small < b->slots_cons_s ? n_small : b->slots_cons_s));
         if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(n_small < 65536 ? n_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
         else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
         else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
@@ -1690,6 +1691,9 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_SMALL(5)), 256, 0) == hipSuccess && nb > 0) b->slots_cons_s = nb * cus;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_LARGE), 256, 0) == hipSuccess && nb > 0) b->slots_cons_l = nb * cus;
+      if (const char* e = getenv("SNF_CONS_GRID_MULT")) { b->slots_cons_s *= atoi(e); b->slots_cons_l *= atoi(e); }
       b->slots_big = ((32 * cus) / 64) * 64; if (b->slots_big < 64) b->slots_big = 64;   // x_big: a multiple of its 64 stripes
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }

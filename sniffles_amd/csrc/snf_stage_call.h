@@ -141,6 +141,13 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
               for (int32_t z = part_start; z < part_start + nparts; z++) {
                 const LeadRec& rz = R[a0[z]];
                 const uint8_t* src = v.pool + rz.seq_off;
+#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+                if (uni) {   // the wave runs this body in lock step: the lanes share the bytes (a serial load -> store chain per
+                             // byte through the same array costs a memory round trip each)
+                  for (int32_t b = (int32_t)(threadIdx.x & 63); b < rz.seq_len; b += 64) v.pool[w + b] = src[b];
+                  w += rz.seq_len;
+                } else
+#endif
                 for (int32_t b = 0; b < rz.seq_len; b++) v.pool[w++] = src[b];
               }
               Fseqlen[m] = (int32_t)seq_total; Fseqoff[m] = off;

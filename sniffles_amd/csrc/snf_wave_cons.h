@@ -71,6 +71,19 @@ SNF_D int count_eq(const uint8_t* a, const uint8_t* b, int n) {
   for (int q = 0; q < n; q += 8) m += eq_bytes(load_u64(a + q), load_u64(b + q), n - q < 8 ? n - q : 8);
   return m;
 }
+// bytes [k, k + 8) of a 24-byte window held in three words (zero beyond the window), 0 <= k < 24
+SNF_D uint64_t win24(uint64_t w0, uint64_t w1, uint64_t w2, int k) {
+  const int wi = k >> 3, sh = (k & 7) * 8;
+  const uint64_t lo = wi == 0 ? w0 : wi == 1 ? w1 : w2;
+  const uint64_t hi = wi == 0 ? w1 : wi == 1 ? w2 : 0ull;
+  return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+// equal bytes of window[k0, k0 + n) and b[0, n)   (k0 + n <= 24)
+SNF_D int count_eq_win(uint64_t w0, uint64_t w1, uint64_t w2, int k0, const uint8_t* b, int n) {
+  int m = 0;
+  for (int q = 0; q < n; q += 8) m += eq_bytes(win24(w0, w1, w2, k0 + q), load_u64(b + q), n - q < 8 ? n - q : 8);
+  return m;
+}
 // injective key of the klen (<= 7) bytes in w; only has to agree between this kernel's table build and lookups
 SNF_D unsigned long long kmer_key_le(unsigned long long w, int klen) { return w & ((1ull << (8 * klen)) - 1ull); }
 
@@ -106,13 +119,20 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
   const int64_t n3 = CLS != 2 ? 0 : (int64_t)v.cnt->n_cls[4], n4 = CLS != 2 ? 0 : (int64_t)v.cnt->n_cls[5];
   const int64_t n_items = n1 + n2 + n3 + n4;
   unsigned long long bytes_acc = 0;  // algorithmic bytes this block processed, one atomic at the end
+  auto item_cid = [&](int64_t it) -> int32_t {
+    if (CLS != 2 || it < n1) return v.cls_list[CLS == 1 ? 1 : CLS == 2 ? 2 : 7][it];
+    if (it < n1 + n2) return v.cls_list[3][it - n1];
+    if (it < n1 + n2 + n3) return v.cls_list[4][it - n1 - n2];
+    return v.cls_list[5][it - n1 - n2 - n3];
+  };
+  // the workgroups are persistent (the launch is sized to what the device holds at once): the descriptor of the next call
+  // is requested while the current one is processed - list entry -> descriptor is two dependent round trips otherwise
+  int32_t cid_next = (int64_t)blockIdx.x < n_items ? item_cid(blockIdx.x) : 0;
+  ConsDesc d_next = (int64_t)blockIdx.x < n_items ? v.cdesc[cid_next] : ConsDesc{};
   for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
-    int32_t cid;
-    if (CLS != 2 || it < n1) cid = v.cls_list[CLS == 1 ? 1 : CLS == 2 ? 2 : 7][it];
-    else if (it < n1 + n2) cid = v.cls_list[3][it - n1];
-    else if (it < n1 + n2 + n3) cid = v.cls_list[4][it - n1 - n2];
-    else cid = v.cls_list[5][it - n1 - n2 - n3];
-    const ConsDesc d = v.cdesc[cid];   // one record: no pointer chasing before the first useful load
+    const int32_t cid = cid_next;
+    const ConsDesc d = d_next;   // one record: no pointer chasing before the first useful load
+    if (it + gridDim.x < n_items) { cid_next = item_cid(it + gridDim.x); d_next = v.cdesc[cid_next]; }
     // everything per call is wave-uniform: keep it in SGPRs (the compiler cannot prove it for values loaded from global
     // memory, and the kernel's occupancy is bound by VGPRs)
     const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
@@ -121,6 +141,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     uint8_t* alt = v.alt_pool + rfl64(d.alt_off);
     const int skip = __builtin_amdgcn_readfirstlane(d.skip);
     const int64_t r0 = rfl64(d.read_off);
+    // pool offset / length of every other read of the call, one entry per lane and slot: in flight while the best read is
+    // staged and its table built (a read then takes them by a lane broadcast instead of a dependent scalar load)
+    constexpr int NS = (MAXOTHERS + 63) / 64;
+    int64_t my_off[NS]; int32_t my_len[NS];
+#pragma unroll
+    for (int sx = 0; sx < NS; sx++) {
+      const int idx = sx * 64 + lane;
+      my_off[sx] = idx < n_others ? v.crl_off[r0 + idx] : 0; my_len[sx] = idx < n_others ? v.crl_len[r0 + idx] : 0;
+    }
     __syncthreads();
     // ---- anchor table of the best read (consensus.py:289-299): k-mers seen exactly once
     for (int s = tid; s < SLOTS; s += NT) { lds.key[s] = SNF_KEY_EMPTY; lds.pc[s] = 0; }
@@ -147,8 +176,11 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     typename Lds::Wave& W = lds.w[wid];
     uint8_t* rows = LV ? nullptr : v.aln + rfl64(d.aln_off);
     for (int32_t r = wid; r < n_others; r += NW) {
-      const uint8_t* Sg = v.pool + rfl64(v.crl_off[r0 + r]);
-      const int SL = __builtin_amdgcn_readfirstlane(v.crl_len[r0 + r]);
+      int64_t s_off = 0; int32_t s_len = 0;
+#pragma unroll
+      for (int sx = 0; sx < NS; sx++) if (sx == (r >> 6)) { s_off = __shfl(my_off[sx], r & 63, 64); s_len = __shfl(my_len[sx], r & 63, 64); }
+      const uint8_t* Sg = v.pool + rfl64(s_off);
+      const int SL = __builtin_amdgcn_readfirstlane(s_len);
       // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
       int jlim = SL - klen;                                     // j < SL - klen
       if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;   // an anchor needs i <= L-klen-1, |i-j| <= maxshift
@@ -218,8 +250,23 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       const int i0 = __builtin_amdgcn_readfirstlane(na ? (int)W.ai[0] : 0), j0 = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[0] : 0);
       const int c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
       int span = 0;
-      for (int t0 = 1; t0 < na; t0 += 64) {
-        const int t = t0 + lane;
+      // Read in HBM (SCAP == 0): the 24 bytes behind the previous anchor of every segment - all a segment of up to 23 bases
+      // is ever compared or copied from - are requested for ALL segments of the read before the first one is looked at and
+      // stay in registers through the vote (one memory round trip per read instead of two to four per 64 segments)
+      constexpr int WR = SCAP == 0 ? ROUNDS : 1;
+      uint64_t sw0[WR], sw1[WR], sw2[WR];
+      if constexpr (SCAP == 0) {
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+          const int t = 1 + it * 64 + lane;
+          sw0[it] = sw1[it] = sw2[it] = 0;
+          if (t < na) { const uint8_t* p = S + W.aj[t - 1]; sw0[it] = load_u64(p); sw1[it] = load_u64(p + 8); sw2[it] = load_u64(p + 16); }
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < ROUNDS; it++) {
+        if (1 + it * 64 >= na) break;
+        const int t = 1 + it * 64 + lane;
         if (t < na) {
           const int li = W.ai[t - 1], lj = W.aj[t - 1], i = W.ai[t], j = W.aj[t];
           int col = c_first + (lj - j0); if (col > L) col = L;
@@ -229,15 +276,25 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           if (fwd_i == fwd_j && fwd_j > 0) {
             const int nfull = j - lj;
             span += nfull;
-            // first words of both comparisons issued together (one round trip instead of two); consecutive
-            // anchors are usually one sampling step apart, so the tails are rare
-            const uint64_t a1 = load_u64(S + lj + 1), b1 = load_u64(B + li + 1), a2 = load_u64(S + lj), b2 = load_u64(B + col);
-            int m = eq_bytes(a1, b1, nfull < 8 ? nfull : 8);
-            if (nfull > 8) m += count_eq(S + lj + 9, B + li + 9, nfull - 8);
-            if ((double)m / (double)nfull >= 0.5) {
-              flag = 1;
-              cm = eq_bytes(a2, b2, fwd_j < 8 ? fwd_j : 8);
-              if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, fwd_j - 8);
+            bool done = false;
+            if constexpr (SCAP == 0) {
+              if (nfull <= 23) {
+                const int m = count_eq_win(sw0[it], sw1[it], sw2[it], 1, B + li + 1, nfull);
+                if ((double)m / (double)nfull >= 0.5) { flag = 1; cm = count_eq_win(sw0[it], sw1[it], sw2[it], 0, B + col, fwd_j); }
+                done = true;
+              }
+            }
+            if (!done) {
+              // first words of both comparisons issued together (one round trip instead of two); consecutive
+              // anchors are usually one sampling step apart, so the tails are rare
+              const uint64_t a1 = load_u64(S + lj + 1), b1 = load_u64(B + li + 1), a2 = load_u64(S + lj), b2 = load_u64(B + col);
+              int m = eq_bytes(a1, b1, nfull < 8 ? nfull : 8);
+              if (nfull > 8) m += count_eq(S + lj + 9, B + li + 9, nfull - 8);
+              if ((double)m / (double)nfull >= 0.5) {
+                flag = 1;
+                cm = eq_bytes(a2, b2, fwd_j < 8 ? fwd_j : 8);
+                if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, fwd_j - 8);
+              }
             }
           }
           W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
@@ -263,13 +320,17 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       if constexpr (LV) {
         // ---- 5. votes: one lane per copied segment, its bases go to the counters of its columns
         // (segment t starts at column c_first + (aj[t-1] - j0) < L and is seg_len[t] columns long)
-        for (int t0 = 1; t0 < na && keep_row; t0 += 64) {
-          const int t = t0 + lane;
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+          if (!keep_row || 1 + it * 64 >= na) break;
+          const int t = 1 + it * 64 + lane;
           if (t < na && W.seg_flag[t]) {
             const int lj = W.aj[t - 1], n = W.seg_len[t];
             const int col = c_first + (lj - j0);
             for (int o8 = 0; o8 < n; o8 += 8) {
-              unsigned long long w8 = load_u64(S + lj + o8);
+              unsigned long long w8;
+              if constexpr (SCAP == 0) w8 = n <= 24 ? win24(sw0[it], sw1[it], sw2[it], o8) : load_u64(S + lj + o8);
+              else w8 = load_u64(S + lj + o8);
               const int m = n - o8 < 8 ? n - o8 : 8;
               for (int o = 0; o < m; o++, w8 >>= 8) {
                 const uint32_t c = (uint32_t)(w8 & 0xffull), cd = (c >> 1) & 3u;
