@@ -205,7 +205,7 @@ struct snf_batch_impl {
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
-  int slots_cons_s = 1280, slots_cons_l = 512;   // resident workgroups of the SMALL / LARGE consensus kernels (persistent launches)  // resident workgroups of the wave kernels on this device
+  int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22;   // grid caps of the SMALL / LARGE consensus kernels
   int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
@@ -1691,9 +1691,15 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
       SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_SMALL(5)), 256, 0) == hipSuccess && nb > 0) b->slots_cons_s = nb * cus;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_LARGE), 256, 0) == hipSuccess && nb > 0) b->slots_cons_l = nb * cus;
-      if (const char* e = getenv("SNF_CONS_GRID_MULT")) { b->slots_cons_s *= atoi(e); b->slots_cons_l *= atoi(e); }
+      // The consensus kernels take one call per workgroup from the hardware dispatcher: measured alone on config 1, resident
+      // (persistent) grids were slower whether they strode statically (0.315 / 0.419 ms SMALL / LARGE, a tail of unequal calls)
+      // or claimed calls from a counter (0.498 / 0.382 ms) - against 0.286 / 0.306 ms for plain grids.  SNF_CONS_GRID_MULT=k
+      // caps the grid at k x the resident workgroups (the kernels stride) for experiments.
+      b->slots_cons_s = b->slots_cons_l = 1 << 22;
+      if (const char* e = getenv("SNF_CONS_GRID_MULT")) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_SMALL(5)), 256, 0) == hipSuccess && nb > 0) b->slots_cons_s = nb * cus * atoi(e);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_LARGE), 256, 0) == hipSuccess && nb > 0) b->slots_cons_l = nb * cus * atoi(e);
+      }
       b->slots_big = ((32 * cus) / 64) * 64; if (b->slots_big < 64) b->slots_big = 64;   // x_big: a multiple of its 64 stripes
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }

@@ -125,8 +125,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     if (it < n1 + n2 + n3) return v.cls_list[4][it - n1 - n2];
     return v.cls_list[5][it - n1 - n2 - n3];
   };
-  // the workgroups are persistent (the launch is sized to what the device holds at once): the descriptor of the next call
-  // is requested while the current one is processed - list entry -> descriptor is two dependent round trips otherwise
+  // normally one call per workgroup (the hardware dispatcher balances the unequal calls best, see the launch site); when the
+  // grid is capped the workgroup strides, and the descriptor of its next call is requested while the current one is processed
   int32_t cid_next = (int64_t)blockIdx.x < n_items ? item_cid(blockIdx.x) : 0;
   ConsDesc d_next = (int64_t)blockIdx.x < n_items ? v.cdesc[cid_next] : ConsDesc{};
   for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
