@@ -43,9 +43,9 @@ struct ConsLdsT {
   struct Wave {
     uint16_t ai[MAXPOS];           // candidates, then accepted anchors: position in best
     uint16_t aj[MAXPOS];           //                                    position in the read
-    uint16_t seg_len[MAXPOS];      // clipped advance (columns written)
-    uint16_t seg_cm[MAXPOS];       // matches of the copied slice against best at its columns
-    uint8_t seg_flag[MAXPOS];      // 0 dashes, 1 copy
+    uint32_t seg_pref[MAXPOS];     // over the copied segments up to t: matches against best (low half) | columns written (high half)
+    uint16_t seg_len[LCAP ? 1 : MAXPOS];   // rows instance: clipped advance (columns written)
+    uint8_t seg_flag[LCAP ? 1 : MAXPOS];   //                0 dashes, 1 copy
     alignas(16) uint8_t s[SCAP ? SCAP : 16];          // the other read, staged (SMALL)
   } w[NW];
 };
@@ -90,6 +90,12 @@ SNF_D unsigned long long kmer_key_le(unsigned long long w, int klen) { return w 
 SNF_D int wave_max_incl(int x, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d && y > x) x = y; }
+  return x;
+}
+
+SNF_D uint32_t wave_sum_incl_u32(uint32_t x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
   return x;
 }
 
@@ -263,6 +269,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           if (t < na) { const uint8_t* p = S + W.aj[t - 1]; sw0[it] = load_u64(p); sw1[it] = load_u64(p + 8); sw2[it] = load_u64(p + 16); }
         }
       }
+      uint32_t segn[ROUNDS];   // per segment of this lane: columns written | matches of the copied slice against best << 16; 0 = dashes
+#pragma unroll
+      for (int it = 0; it < ROUNDS; it++) segn[it] = 0u;
 #pragma unroll
       for (int it = 0; it < ROUNDS; it++) {
         if (1 + it * 64 >= na) break;
@@ -297,21 +306,59 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
               }
             }
           }
-          W.seg_len[t] = (uint16_t)fwd_j; W.seg_cm[t] = (uint16_t)cm; W.seg_flag[t] = flag;
+          segn[it] = flag ? (uint32_t)fwd_j | ((uint32_t)cm << 16) : 0u;   // flag => 0 < fwd_j, cm <= fwd_j <= L < 65000
         }
       }
 #pragma unroll
       for (int dd = 32; dd >= 1; dd >>= 1) span += __shfl_xor(span, dd, 64);
+      // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360): a group stays iff
+      // more than half of its columns agree with the best read and more than five do.  One lane per segment: prefix sums
+      // of (matches, columns) over the copied segments go to LDS, the ballots of the copy flags give every lane the first
+      // and last segment of its group, two LDS reads give the group's sums.
+      unsigned long long fmask[ROUNDS];
+      {
+        uint32_t carry = 0;
+#pragma unroll
+        for (int it = 0; it < ROUNDS; it++) {
+          fmask[it] = 0;
+          if (1 + it * 64 >= na) continue;
+          const int t = 1 + it * 64 + lane;
+          const uint32_t n = segn[it] & 0xffffu, cmv = segn[it] >> 16;
+          fmask[it] = __ballot(segn[it] != 0u);                      // lanes past na hold 0: they end a group
+          const uint32_t pre = wave_sum_incl_u32(cmv | (n << 16), lane) + carry;   // both halves stay below 65536 (disjoint columns of one row)
+          if (t < na) W.seg_pref[t] = pre;
+          carry = (uint32_t)__shfl((int)pre, 63, 64);
+        }
+      }
       __builtin_amdgcn_wave_barrier();
-      // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360)
-      if (lane == 0) {
-        int t = 1;
-        while (t < na) {
-          if (!W.seg_flag[t]) { t++; continue; }
-          int u = t, ident = 0, len = 0;
-          while (u < na && W.seg_flag[u]) { ident += W.seg_cm[u]; len += W.seg_len[u]; u++; }
-          if (!((double)ident / (double)len > 0.5 && ident > 5)) for (int z = t; z < u; z++) W.seg_flag[z] = 0;
-          t = u;
+#pragma unroll
+      for (int it = 0; it < ROUNDS; it++) {
+        if (1 + it * 64 >= na) break;
+        if (segn[it] != 0u) {
+          int fs = -1, fe = -1;   // flat index (t - 1) of the first / last segment of this lane's group
+#pragma unroll
+          for (int k = ROUNDS - 1; k >= 0; k--) {
+            if (k > it || fs >= 0) continue;
+            unsigned long long zb = ~fmask[k];
+            if (k == it) zb &= (1ull << lane) - 1ull;
+            if (zb) fs = k * 64 + 64 - __builtin_clzll(zb);
+          }
+          if (fs < 0) fs = 0;
+#pragma unroll
+          for (int k = 0; k < ROUNDS; k++) {
+            if (k < it || fe >= 0) continue;
+            unsigned long long za = ~fmask[k];
+            if (k == it) za &= ~((2ull << lane) - 1ull);
+            if (za) fe = k * 64 + __builtin_ctzll(za) - 1;
+          }
+          if (fe < 0) fe = na - 2;   // (na < MAXPOS: a lane past the last segment always ends the group before this)
+          const uint32_t hi = W.seg_pref[fe + 1], lo = fs ? W.seg_pref[fs] : 0u;   // inclusive prefix at t = fe + 1, at t = fs (flat fs - 1)
+          const int ident = (int)((hi & 0xffffu) - (lo & 0xffffu)), len = (int)((hi >> 16) - (lo >> 16));
+          if (!((double)ident / (double)len > 0.5 && ident > 5)) segn[it] = 0u;
+        }
+        if constexpr (!LV) {
+          const int t = 1 + it * 64 + lane;
+          if (t < na) { W.seg_len[t] = (uint16_t)(segn[it] & 0xffffu); W.seg_flag[t] = segn[it] != 0u ? 1 : 0; }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -324,8 +371,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         for (int it = 0; it < ROUNDS; it++) {
           if (!keep_row || 1 + it * 64 >= na) break;
           const int t = 1 + it * 64 + lane;
-          if (t < na && W.seg_flag[t]) {
-            const int lj = W.aj[t - 1], n = W.seg_len[t];
+          if (segn[it] != 0u) {
+            const int lj = W.aj[t - 1], n = (int)(segn[it] & 0xffffu);
             const int col = c_first + (lj - j0);
             for (int o8 = 0; o8 < n; o8 += 8) {
               unsigned long long w8;
