@@ -454,6 +454,67 @@ int snf_combine_resolve_batch(const snf_config_t* cfg, int device, const snf_com
  * [3] bytes staged host -> HBM */
 int snf_combine_last_stats(int device, double* kernel_ms, int64_t* stats4);
 
+/*
+ * Multi-sample combine, second half: SVGroup.call (src/sniffles/sv.py:320-481) and the keep / flush bookkeeping of
+ * CombineTask.execute (src/sniffles/parallel.py:536-572) for ALL groups of a merge at once, over a columnar candidate
+ * table - no per-object work.  The caller gives every candidate as one numeric record, the membership
+ * snf_combine_resolve_batch produced as lists in the order SVGroup.add_candidate saw the candidates (window by window,
+ * inside a window support descending, stable), and the flush windows.  Per group the device replays the running
+ * pos_mean (the same three roundings per candidate as sv.py:297-318), walks the windows the group is alive in
+ * (abs(pos_mean - win_bin[w]) < win_thr[w] keeps it), and evaluates the call: confidence rules, medians
+ * (util.median), means (util.mean_or_none_round: Python round() = rint), the ALT choice of insertions, exact
+ * statistics.stdev, and which candidate's genotype represents its sample.  Strings (ids, ALT, read names, phase tuples)
+ * stay on the host and are looked up through the indices returned here.
+ */
+#define SNF_NONE_I32 INT32_MIN
+typedef struct snf_group_cand {
+  int32_t pos, svlen, end, support;
+  int32_t qual;            /* int(c.qual); SNF_NONE_I32: None */
+  int32_t fwd, rev;
+  int32_t cov[5];          /* coverage_upstream, _start, _center, _end, _downstream; SNF_NONE_I32: None */
+  int32_t gq, dr, dv;      /* genotypes[0]; without one: 0, 0, support (sv.py:392) */
+  int32_t sample;          /* sample_internal_id */
+  int32_t alt_len;         /* len(c.alt) */
+  int8_t gt_a, gt_b;       /* -1: "." */
+  uint8_t qc, pass, precise, is_ins;   /* c.qc, c.filter == "PASS", c.precise, svtype == "INS" */
+  uint8_t _pad[2];
+} snf_group_cand_t;          /* 76 bytes */
+
+typedef struct snf_group_call_config {
+  int32_t n_samples;               /* len(config.snf_input_info) */
+  int32_t no_qc;
+  int32_t combine_low_confidence_abs;
+  int32_t combine_output_filtered;
+  int32_t dev_combine_medians;
+  int32_t minsvlen_screen;
+  double combine_high_confidence;
+  double combine_low_confidence;
+} snf_group_call_config_t;
+
+typedef struct snf_group_out {
+  int32_t flush_win;       /* window whose keep test the group failed; -1: still active at the end of its chain */
+  int32_t emit;            /* 1: SVGroup.call returns a call, 0: None, -1: a member lies behind the group's flush (caller error) */
+  int32_t n_pass, n_present;
+  int32_t pos, svlen, end; /* of the combined call */
+  int32_t alt_member;      /* position in `member` of the candidate whose ALT the call takes */
+  int32_t qual;            /* SNF_NONE_I32: None */
+  int32_t support, fwd, rev;
+  int32_t cov[5];          /* SNF_NONE_I32: None */
+  int32_t precise;
+  int32_t n;               /* candidates; 1: util.stdev returns the int 0 */
+  double stdev_pos, stdev_len;
+} snf_group_out_t;           /* 96 bytes */
+
+/* group g = member[group_off[g] .. group_off[g+1]) (indices into cand / cand_win, add order); cand_win[c] = window of
+ * candidate c, non-decreasing along a group's members; group_win_hi[g] = one past the last window of g's chain;
+ * member_chosen[k] = 1 iff member k carries the genotype of its sample (sv.py:395-404);
+ * member_pos_mean[k] = group.pos_mean after member k was added.  Returns 0, or 1 (invalid arguments, no device, or a member
+ * that lies behind the flush of its group). */
+int snf_combine_call_groups(const snf_group_call_config_t* cfg, int device, int64_t n_groups, const int64_t* group_off,
+                            const int32_t* member, int64_t n_cands, const snf_group_cand_t* cand, const int32_t* cand_win,
+                            const int32_t* group_win_hi, int64_t n_windows, const int32_t* win_bin, const double* win_thr,
+                            snf_group_out_t* out, uint8_t* member_chosen, double* member_pos_mean);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Seam B4: consensus.novel_from_reads(best_lead, other_leads, klen, skip, skip_repetitive)
  * (reference src/sniffles/consensus.py:280-394, called from postprocessing.py:63) for a batch of independent

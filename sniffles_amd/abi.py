@@ -199,7 +199,7 @@ assert COMBINE_PROBLEM_DTYPE.itemsize == C.sizeof(snf_combine_problem_t)
 assert all(COMBINE_PROBLEM_DTYPE.fields[n][1] == getattr(snf_combine_problem_t, n).offset for n, _ in snf_combine_problem_t._fields_)
 
 
-def combine_chain_problems(svtype_codes, cand_lo, cand_hi, win_lo, win_hi, cols: dict, alts: list, win_off, win_bin, win_thr,
+def combine_chain_problems(svtype_codes, cand_lo, cand_hi, win_lo, win_hi, cols: dict, alts, win_off, win_bin, win_thr,
                            n_sample_ids: int, keep: list):
     """Pack P sub-chains (no initial groups) that are contiguous slices of shared candidate / window tables.
 
@@ -209,12 +209,17 @@ def combine_chain_problems(svtype_codes, cand_lo, cand_hi, win_lo, win_hi, cols:
     the shared numbering, plus one padding entry at the end of the table.  Every struct points into
     the shared arrays, so the cost per sub-chain is a row of a numpy table.  Returns (ctypes struct array, out_group array)."""
     n_p = len(svtype_codes)
-    n_c = len(alts)
+    if isinstance(alts, tuple):          # (offsets int64[n + 1], pool bytes): the columnar store hands the pool over as it is
+        aoff = np.ascontiguousarray(alts[0], np.int64)
+        n_c = len(aoff) - 1
+        pool = alts[1] if isinstance(alts[1], np.ndarray) else np.frombuffer(alts[1] or b"\0", np.uint8)
+    else:
+        n_c = len(alts)
+        aoff = np.zeros(n_c + 1, np.int64)
+        if n_c:
+            np.cumsum(np.fromiter((len(a) for a in alts), np.int64, n_c), out=aoff[1:])
+        pool = np.frombuffer(b"".join(alts) + b"\0", np.uint8).copy()
     a32 = {k: np.ascontiguousarray(np.asarray(v, np.int32).reshape(-1)) if n_c else np.zeros(1, np.int32) for k, v in cols.items()}
-    aoff = np.zeros(n_c + 1, np.int64)
-    if n_c:
-        np.cumsum(np.fromiter((len(a) for a in alts), np.int64, n_c), out=aoff[1:])
-    pool = np.frombuffer(b"".join(alts) + b"\0", np.uint8).copy()
     out = np.full(max(n_c, 1), -1, np.int32)
     cand_lo, cand_hi = np.asarray(cand_lo, np.int64), np.asarray(cand_hi, np.int64)
     win_lo, win_hi = np.asarray(win_lo, np.int64), np.asarray(win_hi, np.int64)
@@ -405,3 +410,32 @@ def extract_config_struct(cfg) -> snf_extract_config_t:
         advanced_tags=int(bool(g("advanced_tags", qc_nm_measure or g("phase", False)))),
         dev_keep_lowqual_splits=int(bool(g("dev_keep_lowqual_splits", False))),
         max_splits_kb=float(g("max_splits_kb", 0.1)))
+
+
+# ---- columnar candidate store of the multi-sample combine (snf_combine_call_groups)
+NONE_I32 = -2**31
+GROUP_CAND_DTYPE = np.dtype([("pos", "<i4"), ("svlen", "<i4"), ("end", "<i4"), ("support", "<i4"), ("qual", "<i4"), ("fwd", "<i4"),
+                             ("rev", "<i4"), ("cov", "<i4", (5,)), ("gq", "<i4"), ("dr", "<i4"), ("dv", "<i4"), ("sample", "<i4"),
+                             ("alt_len", "<i4"), ("gt_a", "i1"), ("gt_b", "i1"), ("qc", "u1"), ("pass", "u1"), ("precise", "u1"),
+                             ("is_ins", "u1"), ("_pad", "u1", (2,))])
+GROUP_OUT_DTYPE = np.dtype([("flush_win", "<i4"), ("emit", "<i4"), ("n_pass", "<i4"), ("n_present", "<i4"), ("pos", "<i4"),
+                            ("svlen", "<i4"), ("end", "<i4"), ("alt_member", "<i4"), ("qual", "<i4"), ("support", "<i4"),
+                            ("fwd", "<i4"), ("rev", "<i4"), ("cov", "<i4", (5,)), ("precise", "<i4"), ("n", "<i4"), ("_pad", "<i4"),
+                            ("stdev_pos", "<f8"), ("stdev_len", "<f8")])
+assert GROUP_CAND_DTYPE.itemsize == 76 and GROUP_OUT_DTYPE.itemsize == 96
+
+
+class snf_group_call_config_t(C.Structure):
+    _fields_ = [("n_samples", i32), ("no_qc", i32), ("combine_low_confidence_abs", i32), ("combine_output_filtered", i32),
+                ("dev_combine_medians", i32), ("minsvlen_screen", i32), ("combine_high_confidence", f64),
+                ("combine_low_confidence", f64)]
+
+
+def group_call_config(cfg) -> snf_group_call_config_t:
+    return snf_group_call_config_t(n_samples=len(cfg.snf_input_info), no_qc=int(bool(cfg.no_qc)),
+                                   combine_low_confidence_abs=int(cfg.combine_low_confidence_abs),
+                                   combine_output_filtered=int(bool(cfg.combine_output_filtered)),
+                                   dev_combine_medians=int(bool(getattr(cfg, "dev_combine_medians", False))),
+                                   minsvlen_screen=int(cfg.minsvlen_screen),
+                                   combine_high_confidence=float(cfg.combine_high_confidence),
+                                   combine_low_confidence=float(cfg.combine_low_confidence))

@@ -1,0 +1,227 @@
+"""Columnar candidate store of the multi-sample merge (`CombineTask.execute`, reference `parallel.py:444-572`).
+
+The reference walks SNF blocks, bins, flush windows, groups and calls object by object.  Here the candidates of ALL tasks of a
+merge (contigs, or the parts of `CombineTask.scatter`) become one table the moment they leave the SNF readers:
+
+  1. `collect`  - one C pass over the blocks' `SVCall` lists fills a record per candidate (`abi.GROUP_CAND_DTYPE`), the ALT pool
+                  and the BND mate columns, in the reference's visiting order (block, SV type, reader, list order);
+  2. `windows`  - a sort by (task, SV type, block, 100-bp bin) and one linear pass give every flush window of every block
+                  (`parallel.py:516-534`); the windows of one (task, SV type) form a chain (kept groups seed the next window);
+  3. `resolve`  - chains are cut where no candidate can reach an earlier group (`cluster.chain_cuts`, vectorised) and all
+                  sub-chains go to the GPU in one `snf_combine_resolve_batch`: the group of every candidate;
+  4. `call`     - `snf_combine_call_groups`: per group the running means, the windows it stays active in, the confidence
+                  rules, medians / means / exact stdev, the ALT choice and which candidate speaks for its sample
+                  (`SVGroup.add_candidate`, `SVGroup.call`, `sv.py:297-481`; the keep rule of `parallel.py:553-556`);
+  5. `emit`     - groups leave in the reference's order (flush event, creation order; the rest at the end per SV type), get
+                  their `sv_id`s, and one C pass builds the combined `SVCall` objects (ids chained, genotypes of absent samples
+                  from the deepest `_COVERAGE` bin the group saw while it was active).
+
+No Python statement runs per candidate or per group.  `CombineTask._execute_many_objects` keeps the object-by-object replay as
+the twin the tests compare with (`SNF_COMBINE_OBJECTS=1` selects it)."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from . import abi, lib, sv
+from .soa import SVT
+
+
+last_timing = {}     # seconds per phase of the last execute_many (measurement only)
+
+
+def _walk(tasks, samples_snf, config):
+    """Blocks of all tasks in visiting order: per block the readers' `read_blocks` results and the `_COVERAGE` dicts."""
+    readers = list(samples_snf.items())
+    order = [s["internal_id"] for s in config.snf_input_info]
+    pos_of = {sid: k for k, (sid, _) in enumerate(readers)}
+    blocks, block_cov, block_task = [], [], []
+    for ti, t in enumerate(tasks):
+        contig = t.contig
+        for block_index in t.block_indices:
+            per = [snf.read_blocks(contig, block_index) for _, snf in readers]
+            blocks.append(per)
+            block_cov.append([per[pos_of[s]][0]["_COVERAGE"] if s in pos_of and per[pos_of[s]] is not None else None for s in order])
+            block_task.append(ti)
+    return readers, order, blocks, block_cov, np.asarray(block_task, np.int64)
+
+
+def _regenotype(blocks, readers, config, device, _lib):
+    """`--reqc`: candidates of SNF files older than 2.5.3 are genotyped again (parallel.py:507-508), one launch."""
+    old = [k for k, (_, snf) in enumerate(readers) if getattr(snf, "reqc", False)]
+    if not old:
+        return
+    thr = config.combine_support_threshold
+    todo = [c for per in blocks for k in old if per[k] is not None for block in per[k] for t in sv.TYPES for c in block[t]
+            if c.support >= thr]
+    if todo:
+        from . import postprocessing
+        postprocessing.genotype_svs(todo, config, device=device, _lib=_lib)
+
+
+def _segmented_running(values, seg, take_max: bool):
+    """Prefix maximum (or minimum) inside segments; `seg` non-decreasing segment numbers."""
+    big = np.int64(1) << 40
+    v = values.astype(np.int64)
+    if take_max:
+        return np.maximum.accumulate(v + seg * big) - seg * big
+    return -(np.maximum.accumulate(-v + seg * big) - seg * big)
+
+
+def execute_many(tasks: list, samples_snf: dict) -> list:
+    """`CombineTask.execute` of every task of `tasks` (one merge: same config and readers); the calls per task."""
+    fast = sv._load_fast()
+    t0 = tasks[0]
+    config, device, _lib = t0.config, t0.device, t0._lib
+    n_tasks = len(tasks)
+    tm = [("start", time.perf_counter())]
+    mark = lambda name: tm.append((name, time.perf_counter()))  # noqa: E731
+    readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
+    mark("walk_blocks")
+    _regenotype(blocks, readers, config, device, _lib)
+    sids = np.asarray([sid for sid, _ in readers], np.int32)
+    mate_ids = {}
+    objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect(blocks, sids, tuple(sv.TYPES), int(config.combine_support_threshold), mate_ids)
+    n = len(objs)
+    mark("collect_columns")
+    if n == 0:
+        return [[] for _ in tasks]
+    rec = np.frombuffer(rec, abi.GROUP_CAND_DTYPE)
+    cblk = np.frombuffer(cblk, np.int32).astype(np.int64)
+    ctyp = np.frombuffer(ctyp, np.int32).astype(np.int64)
+    mate = np.frombuffer(mate, np.int32).reshape(-1, 2)
+    ctask = block_task[cblk]
+    # ---- 2. sort into chain-major order (task, SV type, block, bin, visiting order) and cut the flush windows
+    bin_min = int(config.combine_min_size)
+    cbin = np.trunc(rec["pos"] / bin_min).astype(np.int64) * bin_min          # int(pos / bin_min_size) * bin_min_size
+    perm = np.lexsort((np.arange(n), cbin, cblk, ctyp, ctask))
+    rec, cblk, ctyp, ctask, cbin, mate = rec[perm], cblk[perm], ctyp[perm], ctask[perm], cbin[perm], mate[perm]
+    objs = [objs[i] for i in perm.tolist()]
+    aoff, apool = fast.gather_pool(aoff, apool, np.ascontiguousarray(perm, np.int64))
+    aoff = np.frombuffer(aoff, np.int64)
+    key = (ctask * 8 + ctyp) * (np.int64(1) << 32) + cblk
+    max_cands = max(25, int(len(config.snf_input_info) * 0.5))
+    wend, wbin, wsize = fast.flush_windows(np.ascontiguousarray(key), np.ascontiguousarray(cbin, np.int32), bin_min, max_cands,
+                                           bool(getattr(config, "combine_exhaustive", False)))
+    wend = np.frombuffer(wend, np.int64)
+    win_bin = np.frombuffer(wbin, np.int32)
+    nw = len(wend)
+    win_off = np.concatenate(([0], wend)).astype(np.int64)
+    win_thr = np.maximum(np.frombuffer(wsize, np.int32) * 0.5, float(config.combine_overlap_abs))
+    cand_win = np.repeat(np.arange(nw, dtype=np.int32), np.diff(win_off))
+    w_first = win_off[:-1]
+    w_task, w_typ, w_blk = ctask[w_first], ctyp[w_first], cblk[w_first]
+    w_chain = w_task * 8 + w_typ                                              # non-decreasing
+    chain_first = np.r_[True, w_chain[1:] != w_chain[:-1]]
+    chain_no = np.cumsum(chain_first) - 1                                     # chain index per window
+    chain_lo = np.flatnonzero(chain_first)
+    chain_hi = np.r_[chain_lo[1:], nw]
+    n_chains = len(chain_lo)
+    # ---- 3. cut the chains where no candidate can reach an earlier group (cluster.chain_cuts) and resolve on the GPU
+    sub_first = chain_first.copy()
+    if os.environ.get("SNF_COMBINE_NO_CUT", "0") != "1" and nw > 1:
+        pos = rec["pos"].astype(np.int64)
+        lo = np.minimum.reduceat(pos, w_first)
+        hi = np.maximum.reduceat(pos, w_first)
+        hi_run = _segmented_running(hi, chain_no, True)                       # prefix maximum inside the chain
+        rev = slice(None, None, -1)
+        lo_run = _segmented_running(lo[rev], (n_chains - 1 - chain_no)[rev], False)[rev]    # suffix minimum inside the chain
+        bnd = w_typ == sv.TYPES.index("BND")
+        gate = np.where(bnd, float(config.cluster_merge_bnd) * 2, float(config.combine_match_max))
+        gate = np.maximum(gate, 0.0) + 1.0
+        cut = np.zeros(nw, bool)
+        cut[1:] = (lo_run[1:] - hi_run[:-1]) > gate[1:]
+        sub_first |= cut
+    s_lo = np.flatnonzero(sub_first)
+    s_hi = np.r_[s_lo[1:], nw]
+    codes = np.asarray([SVT[t] for t in sv.TYPES], np.int32)[w_typ[s_lo]]
+    cols = dict(pos=rec["pos"], svlen=rec["svlen"], support=rec["support"], sample_id=rec["sample"], mate_contig=mate[:, 0],
+                mate_ref_start=mate[:, 1])
+    keep = []
+    mark("sort_and_windows")
+    n_ids = int(rec["sample"].max()) + 1
+    arr, out = abi.combine_chain_problems(codes, win_off[s_lo], win_off[s_hi], s_lo, s_hi, cols, (aoff, apool), win_off, win_bin,
+                                          win_thr, n_ids, keep)
+    lib.combine_resolve_batch(config, arr, device=device, _lib=_lib)
+    mark("resolve_groups_gpu")
+    # group numbers: sub-chain -> whole merge (creation order inside a chain is the order of the sub-chains)
+    gid_local = out[:n].astype(np.int64)
+    cand_sub = np.repeat(np.arange(len(s_lo)), win_off[s_hi] - win_off[s_lo])
+    created = np.zeros(len(s_lo), np.int64)
+    np.maximum.at(created, cand_sub, gid_local + 1)
+    base = np.cumsum(created) - created
+    gid = gid_local + base[cand_sub]
+    n_groups = int(created.sum())
+    # ---- 4. members in the order SVGroup.add_candidate saw them: window by window, support descending (stable) inside a window
+    proc = np.lexsort((np.arange(n), -rec["support"].astype(np.int64), cand_win))
+    member = proc[np.argsort(gid[proc], kind="stable")].astype(np.int32)
+    counts = np.bincount(gid, minlength=n_groups)
+    group_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
+    g_first_win = cand_win[member[group_off[:-1]]].astype(np.int64)
+    g_chain = chain_no[g_first_win]
+    g_hi = chain_hi[g_chain].astype(np.int32)
+    mark("membership")
+    gout, chosen, pos_mean = lib.combine_call_groups(config, group_off, member, rec, cand_win, g_hi, win_bin, win_thr, device=device, _lib=_lib)
+    mark("call_groups_gpu")
+    # ---- 5. emission order (parallel.py:536-572): a flushed group leaves with its window's event - events run block by block,
+    # SV type by SV type, window by window - in creation order; what is still active at the end leaves per SV type
+    if getattr(config, "combine_consensus", False) and (gout["emit"] == 1).any():
+        raise NotImplementedError("--combine-consensus is broken in the reference (sv.py:382 unpacks 7-tuples into 5)")
+    ev_rank = np.empty(nw, np.int64)
+    ev_rank[np.lexsort((np.arange(nw), w_typ, w_blk, w_task))] = np.arange(nw)
+    g_task = w_task[g_first_win]
+    g_typ = w_typ[g_first_win]
+    flushed = gout["flush_win"] >= 0
+    rank = np.where(flushed, ev_rank[np.where(flushed, gout["flush_win"], 0)], nw + g_typ)
+    em = np.flatnonzero(gout["emit"] == 1)
+    em = em[np.lexsort((em, rank[em], g_task[em]))]
+    per_task = np.bincount(g_task[em], minlength=n_tasks)
+    first_of_task = np.concatenate(([0], np.cumsum(per_task)))[:-1]
+    start_id = np.asarray([t.sv_id for t in tasks], np.int64)
+    sv_ids = start_id[g_task[em]] + (np.arange(len(em)) - first_of_task[g_task[em]])
+    task_ids = np.asarray([t.id for t in tasks], np.int64)[g_task[em]]
+    # events a group was active in: its first window .. the flush window (or the chain's last); pos_mean at an event = after the
+    # last candidate added up to that window; coverage bin of parallel.py:543
+    last_win = np.where(flushed, gout["flush_win"], g_hi - 1).astype(np.int64)
+    n_ev = (last_win[em] - g_first_win[em] + 1)
+    ev_off = np.concatenate(([0], np.cumsum(n_ev))).astype(np.int64)
+    ev_group = np.repeat(em, n_ev)
+    ev_win = np.repeat(g_first_win[em], n_ev) + (np.arange(int(ev_off[-1])) - np.repeat(ev_off[:-1], n_ev))
+    bigw = np.int64(nw + 1)
+    m_group = np.repeat(np.arange(n_groups), counts)
+    m_key = m_group * bigw + cand_win[member]
+    idx = np.searchsorted(m_key, ev_group * bigw + ev_win, side="right") - 1
+    cb = int(config.coverage_binsize_combine)
+    ev_bin = (np.trunc(pos_mean[idx] / cb).astype(np.int64) * cb).astype(np.int32)
+    ev_block = w_blk[ev_win].astype(np.int32)
+    sample_ids = np.asarray(order, np.int32)
+    spos = np.full(max(int(sample_ids.max(initial=0)), int(rec["sample"].max())) + 2, -1, np.int32)
+    spos[sample_ids] = np.arange(len(sample_ids), dtype=np.int32)
+    mark("emission_order")
+    calls = fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, objs, np.ascontiguousarray(gout), np.ascontiguousarray(em, np.int64),
+                             group_off, member, chosen, np.ascontiguousarray(sv_ids, np.int64), np.ascontiguousarray(task_ids, np.int64),
+                             sample_ids, spos, block_cov, ev_off, ev_block, np.ascontiguousarray(ev_bin),
+                             int(config.combine_null_min_coverage), str(config.id_prefix), len(config.snf_input_info) == 1)
+    if config.combine_pair_relabel:
+        thr = config.combine_pair_relabel_threshold
+        for call in calls:                                                     # sv.py:416-426 (an option; off by default)
+            top = (0, 0)
+            for a, b, q, *_ in call.genotypes.values():
+                if q > thr and a != ".":
+                    top = max(top, (a, b))
+            if top != (0, 0):
+                for sid, (a, b, q, dr, dv, ps, nid) in list(call.genotypes.items()):
+                    if q < thr and a != ".":
+                        call.genotypes[sid] = (top[0], top[1], q, dr, dv, ps, nid)
+    mark("build_svcalls")
+    last_timing.clear()
+    last_timing.update({name: t1 - t0_ for (_, t0_), (name, t1) in zip(tm[:-1], tm[1:])})
+    last_timing.update(candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(calls))
+    result = []
+    for k, t in enumerate(tasks):
+        a, b = int(first_of_task[k]), int(first_of_task[k] + per_task[k])
+        t.sv_id += int(per_task[k])
+        result.append(calls[a:b])
+    return result

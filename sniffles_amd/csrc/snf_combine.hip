@@ -9,6 +9,7 @@
 // form (SNF_COMBINE_THREAD=1 selects it on the GPU).
 #include "snf_myers.h"
 #include "snf_ctx.h"
+#include "snf_group_call.h"
 #include "../../include/sniffles_amd.h"
 
 #include <cmath>
@@ -211,9 +212,11 @@ __global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, 
 }  // namespace snf
 using namespace snf;
 SNF_KERNEL(combine_problem, CombineView)
+SNF_KERNEL(group_call, GroupCallView)
 
 namespace {
 DevArena g_combine_arenas[SNF_MAX_DEVICES];
+DevArena g_groupcall_arenas[SNF_MAX_DEVICES];
 
 // an array of the call inside the arena: where it lives and (inputs) the host vector that fills it
 struct Slot { size_t off, bytes; const void* src; };
@@ -386,5 +389,72 @@ extern "C" int snf_combine_last_stats(int device, double* kernel_ms, int64_t* st
   std::lock_guard<std::mutex> hold(A.mu);
   *kernel_ms = A.last_kernel_ms;
   for (int k = 0; k < 4; k++) stats4[k] = A.last_stats[k];
+  return 0;
+}
+
+// SVGroup.call + the keep / flush walk for all groups of a merge (include/sniffles_amd.h; body: snf_group_call.h)
+extern "C" int snf_combine_call_groups(const snf_group_call_config_t* cfg, int device, int64_t n_groups, const int64_t* group_off,
+                                       const int32_t* member, int64_t n_cands, const snf_group_cand_t* cand, const int32_t* cand_win,
+                                       const int32_t* group_win_hi, int64_t n_windows, const int32_t* win_bin, const double* win_thr,
+                                       snf_group_out_t* out, uint8_t* member_chosen, double* member_pos_mean) {
+  if (n_groups <= 0) return 0;
+  if (!cfg || !group_off || !member || !cand || !cand_win || !group_win_hi || !win_bin || !win_thr || !out || !member_chosen || !member_pos_mean) return 1;
+  if (device < 0 || device >= SNF_MAX_DEVICES || n_cands < 0 || n_windows <= 0) return 1;
+  const int64_t NM = group_off[n_groups];
+  if (group_off[0] != 0 || NM < 0) return 1;
+  for (int64_t g = 0; g < n_groups; g++) {
+    if (group_off[g + 1] < group_off[g] || group_win_hi[g] < 1 || group_win_hi[g] > n_windows) return 1;
+    int32_t wprev = -1;
+    for (int64_t k = group_off[g]; k < group_off[g + 1]; k++) {
+      const int32_t c = member[k];
+      if (c < 0 || c >= n_cands) return 1;
+      const int32_t w = cand_win[c];
+      if (w < wprev || w < 0 || w >= group_win_hi[g]) return 1;     // add order follows the windows
+      wprev = w;
+    }
+  }
+  ArenaLayout L;
+  const size_t o_goff = L.add<int64_t>((size_t)n_groups + 1), o_member = L.add<int32_t>((size_t)NM), o_cand = L.add<snf_group_cand_t>((size_t)n_cands);
+  const size_t o_cwin = L.add<int32_t>((size_t)n_cands), o_ghi = L.add<int32_t>((size_t)n_groups);
+  const size_t o_wbin = L.add<int32_t>((size_t)n_windows), o_wthr = L.add<double>((size_t)n_windows);
+  const size_t in_end = (L.at + 255) & ~(size_t)255;
+  const size_t o_out = L.add<snf_group_out_t>((size_t)n_groups), o_chosen = L.add<uint8_t>((size_t)NM), o_pm = L.add<double>((size_t)NM);
+  const size_t out_end = (L.at + 255) & ~(size_t)255;
+  const size_t o_scr = L.add<int32_t>((size_t)NM);
+  DevArena& A = g_groupcall_arenas[device];
+  std::lock_guard<std::mutex> hold(A.mu);
+  if (!A.ensure(device, L.at)) return 1;
+  uint8_t *h = A.h, *d = A.d;
+  memcpy(h + o_goff, group_off, ((size_t)n_groups + 1) * sizeof(int64_t));
+  memcpy(h + o_member, member, (size_t)NM * sizeof(int32_t));
+  memcpy(h + o_cand, cand, (size_t)n_cands * sizeof(snf_group_cand_t));
+  memcpy(h + o_cwin, cand_win, (size_t)n_cands * sizeof(int32_t));
+  memcpy(h + o_ghi, group_win_hi, (size_t)n_groups * sizeof(int32_t));
+  memcpy(h + o_wbin, win_bin, (size_t)n_windows * sizeof(int32_t));
+  memcpy(h + o_wthr, win_thr, (size_t)n_windows * sizeof(double));
+  GroupCallView v{};
+  v.cfg = *cfg; v.n_groups = n_groups;
+  v.group_off = (const int64_t*)(d + o_goff); v.member = (const int32_t*)(d + o_member); v.cand = (const snf_group_cand_t*)(d + o_cand);
+  v.cand_win = (const int32_t*)(d + o_cwin); v.group_win_hi = (const int32_t*)(d + o_ghi);
+  v.win_bin = (const int32_t*)(d + o_wbin); v.win_thr = (const double*)(d + o_wthr);
+  v.out = (snf_group_out_t*)(d + o_out); v.chosen = d + o_chosen; v.pos_mean = (double*)(d + o_pm); v.scratch = (int32_t*)(d + o_scr);
+#ifndef SNF_EMU
+  hipStream_t st = A.stream;
+  bool ok = hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok = ok && hipEventRecord(A.ev0, st) == hipSuccess;
+  if (ok) { hipLaunchKernelGGL(group_call, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, st, v, n_groups); ok = hipGetLastError() == hipSuccess; }
+  ok = ok && hipEventRecord(A.ev1, st) == hipSuccess;
+  ok = ok && hipMemcpyAsync(h + o_out, d + o_out, out_end - o_out, hipMemcpyDeviceToHost, st) == hipSuccess;
+  ok = ok && hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) return 1;
+  { float ms = 0; if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess) A.last_kernel_ms = ms; }
+#else
+  (void)in_end; (void)out_end;
+  group_call(v, n_groups);
+#endif
+  memcpy(out, h + o_out, (size_t)n_groups * sizeof(snf_group_out_t));
+  memcpy(member_chosen, h + o_chosen, (size_t)NM);
+  memcpy(member_pos_mean, h + o_pm, (size_t)NM * sizeof(double));
+  for (int64_t g = 0; g < n_groups; g++) if (out[g].emit < 0) return 1;
   return 0;
 }

@@ -237,9 +237,469 @@ done:
   return ret;
 }
 
+
+/* ======================================================================================================================
+ * Columnar candidate store of the multi-sample combine (sniffles_amd/parallel.py::CombineTask).
+ * collect():       SVCall objects of the SNF blocks -> snf_group_cand_t records + ALT pool + BND mate columns (one pass)
+ * flush_windows(): the bin walk of CombineTask.execute (parallel.py:516-534) over the sorted table
+ * group_calls():   snf_group_out_t records + membership -> the combined SVCall objects of SVGroup.call (sv.py:419-481)
+ * None of this is arithmetic of the hot path: attribute reads, string joins, dict fills.
+ * ====================================================================================================================== */
+static PyObject *S_dot, *S_comma, *O_zero, *T_none2, *I_COVERAGE;
+
+static PyObject* aget(PyObject* obj, PyObject* key) {   /* new reference; instance dict first */
+  PyObject** dp = _PyObject_GetDictPtr(obj);
+  if (dp && *dp) {
+    PyObject* v = PyDict_GetItemWithError(*dp, key);
+    if (v) { Py_INCREF(v); return v; }
+    if (PyErr_Occurred()) return NULL;
+  }
+  return PyObject_GetAttr(obj, key);
+}
+static int as_i32(PyObject* v, int32_t* out, int none_ok) {   /* steals v */
+  if (!v) return -1;
+  int rc = 0;
+  if (v == Py_None) { if (none_ok) *out = SNF_NONE_I32; else { PyErr_SetString(PyExc_TypeError, "candidate field is None"); rc = -1; } }
+  else if (PyFloat_Check(v)) *out = (int32_t)PyFloat_AS_DOUBLE(v);          /* int(x) truncates */
+  else { long x = PyLong_AsLong(v); if (x == -1 && PyErr_Occurred()) rc = -1; else *out = (int32_t)x; }
+  Py_DECREF(v);
+  return rc;
+}
+static int gt_code(PyObject* v, int8_t* out) {   /* borrowed: "." -> -1 */
+  if (PyUnicode_Check(v)) { *out = -1; return 0; }
+  long x = PyLong_AsLong(v);
+  if (x == -1 && PyErr_Occurred()) return -1;
+  *out = (int8_t)x;
+  return 0;
+}
+static int is_str(PyObject* v, PyObject* interned, const char* text) {   /* borrowed */
+  return v == interned || (PyUnicode_Check(v) && PyUnicode_CompareWithASCIIString(v, text) == 0);
+}
+
+/* collect(blocks: list (per block index: list per reader of `read_blocks(contig, index)` = list of block dicts | None),
+ *         sids: buffer int32 (per reader), types: tuple[str], support_threshold: int, mate_ids: dict)
+ *   -> (objs: list, records: bytearray, cand_block: bytearray int32, cand_type: bytearray int32, mate: bytearray int32 x 2,
+ *       alt_off: bytes int64 (n + 1), alt_pool: bytes)
+ * Candidates leave in the order CombineTask.execute visits them (parallel.py:497-512): block, SV type, reader, block part,
+ * list order; those below the support threshold are dropped; `sample_internal_id` is set on the objects as the reference does. */
+static PyObject* py_collect(PyObject* self, PyObject* args) {
+  PyObject *blocks, *types, *mate_ids;
+  Py_buffer sidb;
+  long long thr;
+  if (!PyArg_ParseTuple(args, "O!y*O!LO!", &PyList_Type, &blocks, &sidb, &PyTuple_Type, &types, &thr, &PyDict_Type, &mate_ids)) return NULL;
+  PyObject *ret = NULL, *objs = NULL, *rec = NULL, *cblk = NULL, *ctyp = NULL, *mate = NULL, **sid_objs = NULL;
+  int64_t* aoff = NULL; uint8_t* pool = NULL; size_t pool_cap = 0, pool_n = 0;
+  Py_ssize_t cap = 0, n = 0;
+  const Py_ssize_t nblk = PyList_GET_SIZE(blocks), ntyp = PyTuple_GET_SIZE(types), nsid = sidb.len / 4;
+  const int32_t* SID = (const int32_t*)sidb.buf;
+  objs = PyList_New(0);
+  rec = PyByteArray_FromStringAndSize(NULL, 0); cblk = PyByteArray_FromStringAndSize(NULL, 0); ctyp = PyByteArray_FromStringAndSize(NULL, 0);
+  mate = PyByteArray_FromStringAndSize(NULL, 0);
+  sid_objs = (PyObject**)calloc((size_t)nsid + 1, sizeof(PyObject*));
+  if (!objs || !rec || !cblk || !ctyp || !mate || !sid_objs) { if (!PyErr_Occurred()) PyErr_NoMemory(); goto done; }
+  for (Py_ssize_t i = 0; i < nsid; i++) { sid_objs[i] = PyLong_FromLong(SID[i]); if (!sid_objs[i]) goto done; }
+  for (Py_ssize_t eb = 0; eb < nblk; eb++) {
+    PyObject* per = PyList_GET_ITEM(blocks, eb);
+    if (!PyList_Check(per) || PyList_GET_SIZE(per) != nsid) { PyErr_SetString(PyExc_TypeError, "collect: one entry per reader expected"); goto done; }
+    for (Py_ssize_t ty = 0; ty < ntyp; ty++) {
+      PyObject* tkey = PyTuple_GET_ITEM(types, ty);
+      for (Py_ssize_t si = 0; si < nsid; si++) {
+        PyObject* parts = PyList_GET_ITEM(per, si);
+        if (parts == Py_None) continue;
+        if (!PyList_Check(parts)) { PyErr_SetString(PyExc_TypeError, "read_blocks must return a list or None"); goto done; }
+        for (Py_ssize_t pi = 0; pi < PyList_GET_SIZE(parts); pi++) {
+          PyObject* l = PyObject_GetItem(PyList_GET_ITEM(parts, pi), tkey);      /* block[svtype] */
+          if (!l) goto done;
+          if (!PyList_Check(l)) { Py_DECREF(l); PyErr_SetString(PyExc_TypeError, "a block's candidates must be a list"); goto done; }
+          const Py_ssize_t nl = PyList_GET_SIZE(l);
+          if (n + nl > cap) {
+            cap = (n + nl) * 2 + 1024;
+            int64_t* na = (int64_t*)realloc(aoff, ((size_t)cap + 1) * sizeof(int64_t));
+            if (!na || PyByteArray_Resize(rec, cap * (Py_ssize_t)sizeof(snf_group_cand_t)) || PyByteArray_Resize(cblk, cap * 4) ||
+                PyByteArray_Resize(ctyp, cap * 4) || PyByteArray_Resize(mate, cap * 8)) { if (na) aoff = na; if (!PyErr_Occurred()) PyErr_NoMemory(); Py_DECREF(l); goto done; }
+            aoff = na;
+          }
+          snf_group_cand_t* R = (snf_group_cand_t*)PyByteArray_AS_STRING(rec);
+          int32_t* CB = (int32_t*)PyByteArray_AS_STRING(cblk); int32_t* CT = (int32_t*)PyByteArray_AS_STRING(ctyp);
+          int32_t* MT = (int32_t*)PyByteArray_AS_STRING(mate);
+          for (Py_ssize_t q = 0; q < nl; q++) {
+            PyObject* c = PyList_GET_ITEM(l, q);
+            int32_t support;
+            if (as_i32(aget(c, K_support), &support, 0)) { Py_DECREF(l); goto done; }
+            if (support < thr) continue;
+            snf_group_cand_t* r = &R[n];
+            memset(r, 0, sizeof *r);
+            r->support = support; r->sample = SID[si];
+            int bad = PyObject_SetAttr(c, K_sample, sid_objs[si]) ||                 /* parallel.py:509 */
+                      as_i32(aget(c, K_pos), &r->pos, 0) || as_i32(aget(c, K_svlen), &r->svlen, 0) || as_i32(aget(c, K_end), &r->end, 0) ||
+                      as_i32(aget(c, K_qual), &r->qual, 1) || as_i32(aget(c, K_fwd), &r->fwd, 0) || as_i32(aget(c, K_rev), &r->rev, 0) ||
+                      as_i32(aget(c, K_cov_up), &r->cov[0], 1) || as_i32(aget(c, K_cov_st), &r->cov[1], 1) || as_i32(aget(c, K_cov_ce), &r->cov[2], 1) ||
+                      as_i32(aget(c, K_cov_en), &r->cov[3], 1) || as_i32(aget(c, K_cov_dn), &r->cov[4], 1);
+            PyObject* v = NULL;
+            if (!bad) { v = aget(c, K_qc); bad = !v; if (v) { int t = PyObject_IsTrue(v); bad = t < 0; r->qc = t > 0; Py_DECREF(v); } }
+            if (!bad) { v = aget(c, K_precise); bad = !v; if (v) { int t = PyObject_IsTrue(v); bad = t < 0; r->precise = t > 0; Py_DECREF(v); } }
+            if (!bad) { v = aget(c, K_filter); bad = !v; if (v) { r->pass = is_str(v, S_PASS, "PASS"); Py_DECREF(v); } }
+            int is_bnd = 0;
+            if (!bad) { v = aget(c, K_svtype); bad = !v; if (v) { r->is_ins = is_str(v, S_svtype[0], "INS"); is_bnd = is_str(v, S_svtype[4], "BND"); Py_DECREF(v); } }
+            if (!bad) {                                                              /* genotypes[0], or the default of sv.py:392 */
+              v = aget(c, K_genotypes); bad = !v;
+              if (v) {
+                PyObject* t = PyDict_Check(v) ? PyDict_GetItemWithError(v, O_zero) : NULL;
+                if (t && PyTuple_Check(t) && PyTuple_GET_SIZE(t) >= 5) {
+                  bad = gt_code(PyTuple_GET_ITEM(t, 0), &r->gt_a) || gt_code(PyTuple_GET_ITEM(t, 1), &r->gt_b);
+                  Py_INCREF(PyTuple_GET_ITEM(t, 2)); Py_INCREF(PyTuple_GET_ITEM(t, 3)); Py_INCREF(PyTuple_GET_ITEM(t, 4));
+                  bad = as_i32(PyTuple_GET_ITEM(t, 2), &r->gq, 0) | as_i32(PyTuple_GET_ITEM(t, 3), &r->dr, 0) | as_i32(PyTuple_GET_ITEM(t, 4), &r->dv, 0) | bad;
+                } else if (PyErr_Occurred()) bad = 1;
+                else { r->gt_a = r->gt_b = -1; r->gq = 0; r->dr = 0; r->dv = support; }
+                Py_DECREF(v);
+              }
+            }
+            MT[2 * n] = 0; MT[2 * n + 1] = 0;
+            if (!bad && is_bnd) {
+              PyObject* bi = aget(c, K_bnd_info); bad = !bi;
+              if (bi) {
+                PyObject* mc = aget(bi, B_mate_contig); bad = !mc;
+                if (mc) {
+                  PyObject* idv = PyDict_GetItemWithError(mate_ids, mc);       /* equality-only id of the mate contig */
+                  if (!idv && !PyErr_Occurred()) { PyObject* nv = PyLong_FromSsize_t(PyDict_GET_SIZE(mate_ids)); if (nv && !PyDict_SetItem(mate_ids, mc, nv)) idv = PyDict_GetItemWithError(mate_ids, mc); Py_XDECREF(nv); }
+                  if (!idv) bad = 1; else MT[2 * n] = (int32_t)PyLong_AsLong(idv);
+                  Py_DECREF(mc);
+                }
+                if (!bad) bad = as_i32(aget(bi, B_mate_ref_start), &MT[2 * n + 1], 0);
+                Py_DECREF(bi);
+              }
+            }
+            if (!bad) {                                                              /* ALT: latin-1 bytes, len(c.alt) code points */
+              v = aget(c, K_alt); bad = !v;
+              if (v) {
+                const char* data = NULL; Py_ssize_t len = 0; PyObject* enc = NULL;
+                if (PyUnicode_Check(v)) {
+                  if (PyUnicode_READY(v)) bad = 1;
+                  else if (PyUnicode_KIND(v) == PyUnicode_1BYTE_KIND) { data = (const char*)PyUnicode_1BYTE_DATA(v); len = PyUnicode_GET_LENGTH(v); }
+                  else { enc = PyUnicode_AsLatin1String(v); bad = !enc; if (enc) { data = PyBytes_AS_STRING(enc); len = PyBytes_GET_SIZE(enc); } }
+                } else if (PyBytes_Check(v)) { data = PyBytes_AS_STRING(v); len = PyBytes_GET_SIZE(v); }
+                else { PyErr_SetString(PyExc_TypeError, "SVCall.alt must be str or bytes"); bad = 1; }
+                if (!bad) {
+                  if (pool_n + (size_t)len + 64 > pool_cap) {
+                    pool_cap = (pool_n + (size_t)len + 64) * 2;
+                    uint8_t* np_ = (uint8_t*)realloc(pool, pool_cap);
+                    if (!np_) { PyErr_NoMemory(); bad = 1; } else pool = np_;
+                  }
+                  if (!bad) { memcpy(pool + pool_n, data, (size_t)len); pool_n += (size_t)len; r->alt_len = (int32_t)len; }
+                }
+                Py_XDECREF(enc); Py_DECREF(v);
+              }
+            }
+            if (bad || PyList_Append(objs, c)) { Py_DECREF(l); goto done; }
+            CB[n] = (int32_t)eb; CT[n] = (int32_t)ty;
+            if (n == 0) aoff[0] = 0;
+            aoff[n + 1] = (int64_t)pool_n;
+            n++;
+          }
+          Py_DECREF(l);
+        }
+      }
+    }
+  }
+  if (PyByteArray_Resize(rec, n * (Py_ssize_t)sizeof(snf_group_cand_t)) || PyByteArray_Resize(cblk, n * 4) || PyByteArray_Resize(ctyp, n * 4) ||
+      PyByteArray_Resize(mate, n * 8)) goto done;
+  {
+    int64_t zero = 0;
+    PyObject* ao = PyBytes_FromStringAndSize(n ? (const char*)aoff : (const char*)&zero, ((Py_ssize_t)n + 1) * 8);
+    PyObject* ap = PyBytes_FromStringAndSize(pool ? (const char*)pool : "", (Py_ssize_t)pool_n);
+    if (ao && ap) ret = PyTuple_Pack(7, objs, rec, cblk, ctyp, mate, ao, ap);
+    Py_XDECREF(ao); Py_XDECREF(ap);
+  }
+done:
+  Py_XDECREF(objs); Py_XDECREF(rec); Py_XDECREF(cblk); Py_XDECREF(ctyp); Py_XDECREF(mate);
+  if (sid_objs) { for (Py_ssize_t i = 0; i < nsid; i++) Py_XDECREF(sid_objs[i]); free(sid_objs); }
+  free(aoff); free(pool);
+  PyBuffer_Release(&sidb);
+  return ret;
+}
+
+/* gather_pool(off: buffer int64 (n + 1), pool: buffer, order: buffer int64 (m)) -> (new_off: bytes int64 (m + 1), new_pool: bytes):
+ * the strings order[0], order[1], ... back to back */
+static PyObject* py_gather_pool(PyObject* self, PyObject* args) {
+  Py_buffer ofb, plb, orb;
+  if (!PyArg_ParseTuple(args, "y*y*y*", &ofb, &plb, &orb)) return NULL;
+  PyObject* ret = NULL;
+  const int64_t* OFF = (const int64_t*)ofb.buf; const Py_ssize_t n = ofb.len / 8 - 1;
+  const int64_t* ORD = (const int64_t*)orb.buf; const Py_ssize_t m = orb.len / 8;
+  int64_t* no = (int64_t*)malloc(((size_t)m + 1) * 8);
+  size_t total = 0;
+  if (!no) { PyErr_NoMemory(); goto done; }
+  no[0] = 0;
+  for (Py_ssize_t i = 0; i < m; i++) {
+    if (ORD[i] < 0 || ORD[i] >= n || OFF[ORD[i] + 1] < OFF[ORD[i]] || OFF[ORD[i] + 1] > plb.len) { PyErr_SetString(PyExc_ValueError, "gather_pool: index or offset out of range"); goto done; }
+    total += (size_t)(OFF[ORD[i] + 1] - OFF[ORD[i]]);
+    no[i + 1] = (int64_t)total;
+  }
+  {
+    PyObject* np_ = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
+    if (np_) {
+      char* w = PyBytes_AS_STRING(np_);
+      for (Py_ssize_t i = 0; i < m; i++) { const size_t l = (size_t)(OFF[ORD[i] + 1] - OFF[ORD[i]]); memcpy(w, (const char*)plb.buf + OFF[ORD[i]], l); w += l; }
+      PyObject* oo = PyBytes_FromStringAndSize((const char*)no, ((Py_ssize_t)m + 1) * 8);
+      if (oo) ret = PyTuple_Pack(2, oo, np_);
+      Py_XDECREF(oo); Py_DECREF(np_);
+    }
+  }
+done:
+  free(no);
+  PyBuffer_Release(&ofb); PyBuffer_Release(&plb); PyBuffer_Release(&orb);
+  return ret;
+}
+
+/* flush_windows(key: buffer int64, bin: buffer int32, bin_min_size, max_candidates, exhaustive)
+ *   -> (win_end: bytes int64 - one past the last candidate of every window, win_bin: bytes int32, win_size: bytes int32)
+ * key / bin: the candidate table sorted by (key, bin); one key = one (task, SV type, block).  parallel.py:516-534: the bins of a
+ * block are visited in ascending order, `size` grows by bin_min_size per bin, a window is flushed when it holds at least
+ * max_candidates candidates (unless --combine-exhaustive) or at the block's last bin. */
+static PyObject* py_flush_windows(PyObject* self, PyObject* args) {
+  Py_buffer kb, bb;
+  long long bin_min_size, max_cands; int exhaustive;
+  if (!PyArg_ParseTuple(args, "y*y*LLp", &kb, &bb, &bin_min_size, &max_cands, &exhaustive)) return NULL;
+  PyObject* ret = NULL;
+  const Py_ssize_t n = kb.len / 8;
+  const int64_t* K = (const int64_t*)kb.buf; const int32_t* B = (const int32_t*)bb.buf;
+  int64_t* wend = (int64_t*)malloc(((size_t)n + 1) * 8); int32_t* wbin = (int32_t*)malloc(((size_t)n + 1) * 4); int32_t* wsize = (int32_t*)malloc(((size_t)n + 1) * 4);
+  if (bb.len / 4 != n || !wend || !wbin || !wsize) { PyErr_SetString(PyExc_ValueError, "flush_windows: bad arguments"); goto done; }
+  Py_ssize_t nw = 0, i = 0;
+  while (i < n) {
+    Py_ssize_t j = i;                                  /* [i, j): one (task, type, block) */
+    while (j < n && K[j] == K[i]) j++;
+    long long size = 0, cnt = 0;
+    Py_ssize_t a = i;
+    while (a < j) {
+      Py_ssize_t b = a;                                /* [a, b): one bin */
+      while (b < j && B[b] == B[a]) b++;
+      cnt += b - a; size += bin_min_size;
+      if ((!exhaustive && cnt >= max_cands) || b == j) { wend[nw] = b; wbin[nw] = B[a]; wsize[nw] = (int32_t)size; nw++; size = 0; cnt = 0; }
+      a = b;
+    }
+    i = j;
+  }
+  {
+    PyObject* o1 = PyBytes_FromStringAndSize((const char*)wend, nw * 8);
+    PyObject* o2 = PyBytes_FromStringAndSize((const char*)wbin, nw * 4);
+    PyObject* o3 = PyBytes_FromStringAndSize((const char*)wsize, nw * 4);
+    if (o1 && o2 && o3) ret = PyTuple_Pack(3, o1, o2, o3);
+    Py_XDECREF(o1); Py_XDECREF(o2); Py_XDECREF(o3);
+  }
+done:
+  free(wend); free(wbin); free(wsize);
+  PyBuffer_Release(&kb); PyBuffer_Release(&bb);
+  return ret;
+}
+
+static PyObject* int_or_none(int32_t v) { if (v == SNF_NONE_I32) { Py_RETURN_NONE; } return PyLong_FromLong(v); }
+
+/* group_calls(svcall_cls, fds_cls, objs: list, out: buffer snf_group_out_t, emit: buffer int64 (groups in emission order),
+ *             group_off: buffer int64, member: buffer int32, chosen: buffer uint8, sv_id: buffer int64, task_id: buffer int64,
+ *             sample_ids: buffer int32 (config.snf_input_info order), sample_pos: buffer int32 (internal id -> position, -1),
+ *             block_cov: list (per block: list per sample position of the block's _COVERAGE dict or None),
+ *             ev_off: buffer int64 (len(emit) + 1), ev_block: buffer int32, ev_bin: buffer int32,
+ *             null_min_coverage: int, id_prefix: str, single_sample: bool) -> list[SVCall] */
+static PyObject* py_group_calls(PyObject* self, PyObject* args) {
+  PyObject *cls, *fds_cls, *objs, *block_cov, *prefix;
+  Py_buffer ob, eb, gb, mb, cb, svb, tkb, sidb, sposb, evo, evb, evn;
+  long long null_min; int single;
+  if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*y*y*y*y*O!y*y*y*LUp", &cls, &fds_cls, &PyList_Type, &objs, &ob, &eb, &gb, &mb, &cb, &svb, &tkb, &sidb,
+                        &sposb, &PyList_Type, &block_cov, &evo, &evb, &evn, &null_min, &prefix, &single))
+    return NULL;
+  PyObject* ret = NULL;
+  const snf_group_out_t* O = (const snf_group_out_t*)ob.buf;
+  const int64_t* E = (const int64_t*)eb.buf; const Py_ssize_t ne = eb.len / 8;
+  const int64_t* GO = (const int64_t*)gb.buf; const Py_ssize_t ng = gb.len / 8 - 1;
+  const int32_t* M = (const int32_t*)mb.buf; const Py_ssize_t nm = mb.len / 4;
+  const uint8_t* CH = (const uint8_t*)cb.buf;
+  const int64_t* SV = (const int64_t*)svb.buf; const int64_t* TK = (const int64_t*)tkb.buf;
+  const int32_t* SIDS = (const int32_t*)sidb.buf; const Py_ssize_t ns = sidb.len / 4;
+  const int32_t* SPOS = (const int32_t*)sposb.buf; const Py_ssize_t nspos = sposb.len / 4;
+  const int64_t* EVO = (const int64_t*)evo.buf; const int32_t* EVB = (const int32_t*)evb.buf; const int32_t* EVN = (const int32_t*)evn.buf;
+  const Py_ssize_t nobj = PyList_GET_SIZE(objs), nblk = PyList_GET_SIZE(block_cov);
+  PyObject** sid_objs = NULL; uint8_t* present = NULL; int* head = NULL; PyObject** chain = NULL; Py_ssize_t cap = 0;
+  PyObject* out = NULL;
+  if ((Py_ssize_t)(ob.len / sizeof(snf_group_out_t)) < ng || cb.len < nm || svb.len / 8 < ne || tkb.len / 8 < ne || evo.len / 8 < ne + 1 ||
+      evb.len != evn.len) { PyErr_SetString(PyExc_ValueError, "group_calls: table sizes do not match"); goto done; }
+  sid_objs = (PyObject**)calloc((size_t)ns + 1, sizeof(PyObject*)); present = (uint8_t*)malloc((size_t)ns + 1);
+  if (!sid_objs || !present) { PyErr_NoMemory(); goto done; }
+  for (Py_ssize_t i = 0; i < ns; i++) { sid_objs[i] = PyLong_FromLong(SIDS[i]); if (!sid_objs[i]) goto done; }
+  out = PyList_New(ne);
+  if (!out) goto done;
+  for (Py_ssize_t e = 0; e < ne; e++) {
+    const int64_t g = E[e];
+    if (g < 0 || g >= ng) { PyErr_SetString(PyExc_ValueError, "group index out of range"); goto fail; }
+    const snf_group_out_t* o = &O[g];
+    const int64_t lo = GO[g], hi = GO[g + 1], n = hi - lo;
+    if (lo < 0 || hi > nm || n <= 0 || o->alt_member < lo || o->alt_member >= hi) { PyErr_SetString(PyExc_ValueError, "group range out of bounds"); goto fail; }
+    if (n > cap) {
+      free(head); free(chain);
+      cap = n + 16; head = (int*)malloc((size_t)cap * sizeof(int)); chain = (PyObject**)calloc((size_t)cap, sizeof(PyObject*));
+      if (!head || !chain) { PyErr_NoMemory(); goto fail; }
+    }
+    for (int64_t k = 0; k < n; k++) if (M[lo + k] < 0 || M[lo + k] >= nobj) { PyErr_SetString(PyExc_ValueError, "member out of range"); goto fail; }
+    PyObject* first = PyList_GET_ITEM(objs, M[lo]);
+    PyObject *d = PyDict_New(), *gts = PyDict_New(), *names = PyList_New(0), *info = NULL, *fds = NULL;
+    int bad = !d || !gts || !names;
+    memset(present, 0, (size_t)ns);
+    /* ---- genotypes of the samples in the group (sv.py:386-404): first appearance order; ids chained in add order */
+    for (int64_t k = 0; !bad && k < n; k++) {
+      PyObject* c = PyList_GET_ITEM(objs, M[lo + k]);
+      PyObject* sv = aget(c, K_sample);
+      long sidv = sv ? PyLong_AsLong(sv) : -1;
+      Py_XDECREF(sv);
+      if (sidv == -1 && PyErr_Occurred()) { bad = 1; break; }
+      head[k] = (int)k; chain[k] = NULL;
+      for (int64_t j = 0; j < k; j++) {
+        if (head[j] != j) continue;
+        PyObject* sj = aget(PyList_GET_ITEM(objs, M[lo + j]), K_sample);
+        long sjv = sj ? PyLong_AsLong(sj) : -2; Py_XDECREF(sj);
+        if (sjv == sidv) { head[k] = (int)j; break; }
+      }
+      PyObject* cid = aget(c, K_id);
+      PyObject* pid = cid ? PyUnicode_Concat(prefix, cid) : NULL;
+      Py_XDECREF(cid);
+      if (!pid) { bad = 1; break; }
+      if (head[k] == k) chain[k] = pid;
+      else {
+        PyObject* t = PyUnicode_Concat(chain[head[k]], S_comma);
+        PyObject* t2 = t ? PyUnicode_Concat(t, pid) : NULL;
+        Py_XDECREF(t); Py_DECREF(pid);
+        if (!t2) { bad = 1; break; }
+        Py_DECREF(chain[head[k]]); chain[head[k]] = t2;
+      }
+      if (sidv >= 0 && sidv < nspos && SPOS[sidv] >= 0) present[SPOS[sidv]] = 1;
+      PyObject* rn = aget(c, K_rnames);                                    /* sv.py:389-390 */
+      if (!rn) { bad = 1; break; }
+      if (rn != Py_None) { PyObject* r2 = PySequence_InPlaceConcat(names, rn); if (!r2) bad = 1; else Py_DECREF(r2); }
+      Py_DECREF(rn);
+      PyObject* cg = aget(c, K_genotypes);                                 /* sv.py:391-392: the default is stored on the candidate */
+      if (!cg) { bad = 1; break; }
+      int has = PyDict_Check(cg) ? PyDict_Contains(cg, O_zero) : -1;
+      if (has < 0) bad = 1;
+      else if (!has) {
+        PyObject* sup = aget(c, K_support);
+        PyObject* t = sup ? Py_BuildValue("(OOiiOO)", S_dot, S_dot, 0, 0, sup, T_none2) : NULL;
+        Py_XDECREF(sup);
+        bad = !t || PyDict_SetItem(cg, O_zero, t);
+        Py_XDECREF(t);
+      }
+      Py_DECREF(cg);
+    }
+    for (int64_t k = 0; !bad && k < n; k++) {
+      if (head[k] != k) continue;
+      int64_t pick = -1;
+      for (int64_t j = k; j < n; j++) if (head[j] == k && CH[lo + j]) pick = j;
+      if (pick < 0) { PyErr_SetString(PyExc_ValueError, "no chosen genotype for a sample"); bad = 1; break; }
+      PyObject* c = PyList_GET_ITEM(objs, M[lo + pick]);
+      PyObject* cg = aget(c, K_genotypes);
+      PyObject* t = cg ? PyDict_GetItemWithError(cg, O_zero) : NULL;
+      PyObject* sv = aget(PyList_GET_ITEM(objs, M[lo + k]), K_sample);
+      if (!t || !sv || !PyTuple_Check(t) || PyTuple_GET_SIZE(t) < 6) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "genotypes[0] must be a 6-tuple"); bad = 1; }
+      else {
+        PyObject* g7 = PyTuple_Pack(7, PyTuple_GET_ITEM(t, 0), PyTuple_GET_ITEM(t, 1), PyTuple_GET_ITEM(t, 2), PyTuple_GET_ITEM(t, 3),
+                                    PyTuple_GET_ITEM(t, 4), PyTuple_GET_ITEM(t, 5), chain[k]);
+        bad = !g7 || PyDict_SetItem(gts, sv, g7);
+        Py_XDECREF(g7);
+      }
+      Py_XDECREF(cg); Py_XDECREF(sv);
+    }
+    for (int64_t k = 0; k < n; k++) if (head[k] == k) Py_CLEAR(chain[k]);
+    /* ---- samples without a candidate in the group (sv.py:405-414): the deepest coverage bin the group saw while it was active */
+    for (Py_ssize_t si = 0; !bad && si < ns; si++) {
+      if (present[si]) continue;
+      long cov = 0; int firstev = 1;
+      for (int64_t q = EVO[e]; q < EVO[e + 1]; q++) {
+        long cv = 0;
+        if (EVB[q] < 0 || EVB[q] >= nblk) { PyErr_SetString(PyExc_ValueError, "block index out of range"); bad = 1; break; }
+        PyObject* per = PyList_GET_ITEM(block_cov, EVB[q]);
+        PyObject* dct = PyList_Check(per) && si < PyList_GET_SIZE(per) ? PyList_GET_ITEM(per, si) : Py_None;
+        if (dct != Py_None) {
+          PyObject* key = PyLong_FromLong(EVN[q]);
+          PyObject* val = key ? PyObject_GetItem(dct, key) : NULL;
+          if (!val && PyErr_ExceptionMatches(PyExc_KeyError)) PyErr_Clear();
+          else if (!val) { Py_XDECREF(key); bad = 1; break; }
+          if (val) { cv = PyLong_AsLong(val); Py_DECREF(val); if (cv == -1 && PyErr_Occurred()) { Py_XDECREF(key); bad = 1; break; } }
+          Py_XDECREF(key);
+        }
+        cov = firstev ? cv : (cv > cov ? cv : cov);
+        firstev = 0;
+      }
+      if (bad) break;
+      PyObject* covo = PyLong_FromLong(cov);
+      PyObject* g7 = !covo ? NULL : (cov >= null_min ? Py_BuildValue("(iiiOiOO)", 0, 0, 0, covo, 0, T_none2, S_NULL)
+                                                     : Py_BuildValue("(OOiOiOO)", S_dot, S_dot, 0, covo, 0, T_none2, S_NULL));
+      Py_XDECREF(covo);
+      bad = !g7 || PyDict_SetItem(gts, sid_objs[si], g7);
+      Py_XDECREF(g7);
+    }
+    /* ---- the call (sv.py:440-481) */
+    PyObject *contig = NULL, *svtype = NULL, *alt = NULL, *flt = NULL;
+    if (!bad) {
+      contig = aget(first, K_contig); svtype = aget(first, K_svtype);
+      alt = aget(PyList_GET_ITEM(objs, M[o->alt_member]), K_alt);
+      if (single) { flt = aget(first, K_filter); info = aget(first, K_info); } else { flt = S_PASS; Py_INCREF(flt); info = PyDict_New(); }
+      bad = !contig || !svtype || !alt || !flt || !info;
+    }
+    if (!bad && !single) {
+      bad = set_steal(info, I_STDEV_POS, o->n < 2 ? PyLong_FromLong(0) : PyFloat_FromDouble(o->stdev_pos)) ||
+            set_steal(info, I_STDEV_LEN, o->n < 2 ? PyLong_FromLong(0) : PyFloat_FromDouble(o->stdev_len));
+    }
+    if (!bad) {
+      PyObject* fd = PyDict_New();
+      PyObject* zero = PyLong_FromLong(0);
+      bad = !fd || !zero || PyDict_SetItem(fd, F_n, zero) || PyDict_SetItem(fd, F_m1, zero) || PyDict_SetItem(fd, F_m2, zero) || PyDict_SetItem(fd, F_last, Py_None);
+      Py_XDECREF(zero);
+      if (!bad) { fds = new_instance(fds_cls, fd); bad = !fds; } else Py_XDECREF(fd);
+    }
+    if (!bad) {
+      char idbuf[96];
+      const char* tname = PyUnicode_AsUTF8(svtype);
+      if (!tname) bad = 1;
+      else {
+        snprintf(idbuf, sizeof idbuf, "%.40s.%llXM%llX", tname, (unsigned long long)SV[e], (unsigned long long)TK[e]);
+        bad = PyDict_SetItem(d, K_contig, contig) || set_steal(d, K_pos, PyLong_FromLong(o->pos)) || set_steal(d, K_id, PyUnicode_FromString(idbuf)) ||
+              PyDict_SetItem(d, K_ref, S_N) || PyDict_SetItem(d, K_alt, alt) || set_steal(d, K_qual, int_or_none(o->qual)) ||
+              PyDict_SetItem(d, K_filter, flt) || PyDict_SetItem(d, K_info, info) || PyDict_SetItem(d, K_svtype, svtype) ||
+              set_steal(d, K_svlen, PyLong_FromLong(o->svlen)) || set_steal(d, K_end, PyLong_FromLong(o->end)) || PyDict_SetItem(d, K_genotypes, gts) ||
+              PyDict_SetItem(d, K_precise, o->precise ? Py_True : Py_False) || set_steal(d, K_support, PyLong_FromLong(o->support)) ||
+              PyDict_SetItem(d, K_rnames, names) || PyDict_SetItem(d, K_qc, Py_True) || set_steal(d, K_nm, PyLong_FromLong(-1)) ||
+              PyDict_SetItem(d, K_postprocess, Py_None) || PyDict_SetItem(d, K_svlens, Py_None) || set_steal(d, K_fwd, PyLong_FromLong(o->fwd)) ||
+              set_steal(d, K_rev, PyLong_FromLong(o->rev)) || PyDict_SetItem(d, K_fds, fds) || set_steal(d, K_cov_up, int_or_none(o->cov[0])) ||
+              set_steal(d, K_cov_dn, int_or_none(o->cov[4])) || set_steal(d, K_cov_st, int_or_none(o->cov[1])) ||
+              set_steal(d, K_cov_ce, int_or_none(o->cov[2])) || set_steal(d, K_cov_en, int_or_none(o->cov[3])) || PyDict_SetItem(d, K_sample, Py_None) ||
+              PyDict_SetItem(d, K_bnd_info, Py_None) || PyDict_SetItem(d, K_sup_inline, Py_None) || PyDict_SetItem(d, K_sup_splits, Py_None) ||
+              PyDict_SetItem(d, K_raw, Py_None) || PyDict_SetItem(d, K_raw_idx, Py_None);
+      }
+    }
+    Py_XDECREF(contig); Py_XDECREF(svtype); Py_XDECREF(alt); Py_XDECREF(flt); Py_XDECREF(info); Py_XDECREF(fds); Py_XDECREF(gts); Py_XDECREF(names);
+    if (bad) { Py_XDECREF(d); goto fail; }
+    PyObject* obj = new_instance(cls, d);
+    if (!obj) goto fail;
+    PyList_SET_ITEM(out, e, obj);
+  }
+  ret = out; out = NULL;
+  goto done;
+fail:
+  if (chain) for (Py_ssize_t k = 0; k < cap; k++) Py_CLEAR(chain[k]);
+done:
+  Py_XDECREF(out);
+  if (sid_objs) { for (Py_ssize_t i = 0; i < ns; i++) Py_XDECREF(sid_objs[i]); free(sid_objs); }
+  free(present); free(head); free(chain);
+  PyBuffer_Release(&ob); PyBuffer_Release(&eb); PyBuffer_Release(&gb); PyBuffer_Release(&mb); PyBuffer_Release(&cb); PyBuffer_Release(&svb);
+  PyBuffer_Release(&tkb); PyBuffer_Release(&sidb); PyBuffer_Release(&sposb); PyBuffer_Release(&evo); PyBuffer_Release(&evb); PyBuffer_Release(&evn);
+  return ret;
+}
+
 static PyMethodDef methods[] = {
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
+    {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},
+    {"gather_pool", py_gather_pool, METH_VARARGS, "strings of a pool in a given order, back to back"},
+    {"flush_windows", py_flush_windows, METH_VARARGS, "flush windows of CombineTask.execute over the sorted candidate table"},
+    {"group_calls", py_group_calls, METH_VARARGS, "group records + membership -> combined SVCall objects"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_snf_fast", "C materialiser of sniffles_amd.sv", -1, methods};
 
@@ -264,6 +724,9 @@ PyMODINIT_FUNC PyInit__snf_fast(void) {
   INTERN(I_STDEV_LEN, "STDEV_LEN"); INTERN(I_COVERAGE_VAR, "COVERAGE_VAR"); INTERN(I_PHASE, "PHASE"); INTERN(I_VAF, "VAF");
   INTERN(B_mate_contig, "mate_contig"); INTERN(B_mate_ref_start, "mate_ref_start"); INTERN(B_is_first, "is_first"); INTERN(B_is_reverse, "is_reverse");
   INTERN(P_batch, "batch"); INTERN(P_index, "index");
+  INTERN(S_dot, "."); INTERN(S_comma, ","); INTERN(I_COVERAGE, "_COVERAGE");
+  O_zero = PyLong_FromLong(0); T_none2 = PyTuple_Pack(2, Py_None, Py_None);
+  if (!O_zero || !T_none2 || sizeof(snf_group_cand_t) != 76 || sizeof(snf_group_out_t) != 96) { PyErr_SetString(PyExc_ImportError, "group record layout changed"); return NULL; }
   INTERN(F_n, "n"); INTERN(F_m1, "m1"); INTERN(F_m2, "m2"); INTERN(F_last, "last");
   return PyModule_Create(&moddef);
 }

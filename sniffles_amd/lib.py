@@ -55,6 +55,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_edit_distance_batch_k.restype = C.c_int
     lib.snf_combine_resolve_batch.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_combine_problem_t), C.c_int64]
     lib.snf_combine_resolve_batch.restype = C.c_int
+    lib.snf_combine_call_groups.argtypes = [C.POINTER(abi.snf_group_call_config_t), C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]
+    lib.snf_combine_call_groups.restype = C.c_int
     lib.snf_combine_last_stats.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.snf_combine_last_stats.restype = C.c_int
     u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
@@ -256,6 +260,33 @@ def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
     rc = lib.snf_combine_resolve_batch(C.byref(cs), device, arr, len(problems))
     if rc != 0:
         raise SnifflesAmdError("snf_combine_resolve_batch failed (no HIP device, or invalid sample ids)")
+
+
+def combine_call_groups(cfg, group_off, member, cand, cand_win, group_win_hi, win_bin, win_thr, device: int = 0, _lib=None):
+    """`SVGroup.call` and the keep / flush walk for all groups of a merge (snf_combine_call_groups).  cand: abi.GROUP_CAND_DTYPE
+    records; member / group_off: the groups' candidates in add order.  Returns (out: abi.GROUP_OUT_DTYPE per group,
+    chosen: uint8 per member, pos_mean: float64 per member)."""
+    lib = _lib or load()
+    group_off = np.ascontiguousarray(group_off, np.int64)
+    n_groups = len(group_off) - 1
+    member = np.ascontiguousarray(member, np.int32)
+    cand = np.ascontiguousarray(cand, abi.GROUP_CAND_DTYPE)
+    cand_win = np.ascontiguousarray(cand_win, np.int32)
+    group_win_hi = np.ascontiguousarray(group_win_hi, np.int32)
+    win_bin = np.ascontiguousarray(win_bin, np.int32)
+    win_thr = np.ascontiguousarray(win_thr, np.float64)
+    out = np.zeros(max(n_groups, 0), abi.GROUP_OUT_DTYPE)
+    chosen = np.zeros(len(member), np.uint8)
+    pos_mean = np.zeros(len(member), np.float64)
+    if n_groups <= 0:
+        return out, chosen, pos_mean
+    gc = abi.group_call_config(cfg)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    rc = lib.snf_combine_call_groups(C.byref(gc), device, n_groups, p(group_off), p(member), len(cand), p(cand), p(cand_win), p(group_win_hi),
+                                     len(win_bin), p(win_bin), p(win_thr), p(out), p(chosen), p(pos_mean))
+    if rc != 0:
+        raise SnifflesAmdError("snf_combine_call_groups failed (no HIP device, invalid membership, or a candidate behind its group's flush)")
+    return out, chosen, pos_mean
 
 
 def combine_last_stats(device: int = 0, _lib=None) -> dict:

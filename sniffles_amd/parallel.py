@@ -228,17 +228,9 @@ class CombineTask(Task):
                 for i, fb in enumerate(range(0, len(self.block_indices), blocks_per_task))]
 
     def execute(self, samples_snf: dict) -> list:
-        """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order.
-
-        Three phases: (1) walk the blocks and bins exactly like the reference and record the flush windows - which
-        candidates form a window depends only on the bins, not on the grouping; the windows of one SV type form a chain
-        (kept groups seed the next window, also across blocks); (2) ONE GPU launch resolves all chains, the keep / flush
-        rule included; (3) replay in the reference's order: SVGroup bookkeeping, non-included-sample coverages, the
-        keep / call decision (recomputed from the same running means and cross-checked against the kernel's) and
-        SVGroup.call."""
-        chains, events = self._collect(samples_snf)
-        assign = self._resolve([self], [chains])[0]
-        return self._replay(chains, events, assign, set(samples_snf.keys()))
+        """samples_snf: {internal_id: SNF reader}.  Returns the combined calls in the reference's emission order
+        (`execute_many` with this task alone; see `sniffles_amd.candstore`)."""
+        return CombineTask.execute_many([self], samples_snf)[0]
 
     @staticmethod
     def execute_many(tasks: list, samples_snf: dict) -> list:
@@ -248,6 +240,16 @@ class CombineTask(Task):
         Returns the calls per task, each list exactly what `task.execute(samples_snf)` returns."""
         if not tasks:
             return []
+        import os
+        if os.environ.get("SNF_COMBINE_OBJECTS", "0") != "1" and sv._load_fast() is not None:
+            from . import candstore
+            return candstore.execute_many(tasks, samples_snf)      # the columnar store: no Python per candidate or group
+        return CombineTask._execute_many_objects(tasks, samples_snf)
+
+    @staticmethod
+    def _execute_many_objects(tasks: list, samples_snf: dict) -> list:
+        """The object-by-object form of `execute_many` (the reference's own shape: `SVGroup` objects, `SVGroup.call`): the twin the
+        tests compare the columnar store with, and the path without the C extension."""
         collected = [t._collect(samples_snf) for t in tasks]
         assigns = tasks[0]._resolve(tasks, [c for c, _ in collected])
         ids = set(samples_snf.keys())

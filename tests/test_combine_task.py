@@ -161,3 +161,81 @@ def test_chain_cuts_keep_the_assignment_emu():
 @pytest.mark.gpu
 def test_chain_cuts_keep_the_assignment_gpu():
     check_cut_equals_whole(None)
+
+
+# ---- the columnar candidate store (sniffles_amd/candstore.py) against the object-by-object replay (SVGroup / SVGroup.call)
+TWIN_OPTIONS = [(), ("--dev-combine-medians",), ("--combine-pair-relabel", "--combine-pair-relabel-threshold", "10"),
+                ("--combine-output-filtered",), ("--combine-exhaustive",), ("--combine-high-confidence", "0.5"),
+                ("--combine-low-confidence", "0.5", "--combine-low-confidence-abs", "3"), ("--combine-null-min-coverage", "12"),
+                ("--combine-support-threshold", "6"), ("--combine-pctseq", "0"), ("--minsvlen", "200")]
+
+
+def _twin_cfg(doc, extra):
+    exp = doc["expected"]
+    cfg_args, kw, a = [], {}, list(tuple(doc["reference_args"]) + tuple(extra))
+    while a:
+        k = a.pop(0)
+        name = k[2:].replace("-", "_")
+        if a and not a[0].startswith("--"):
+            v = a.pop(0)
+            kw[name] = float(v) if "." in v else int(v)
+        else:
+            kw[name] = True
+    from sniffles_amd.config import SnifflesConfig
+    cfg = SnifflesConfig(**{k: v for k, v in kw.items() if k != "combine_exhaustive"})
+    if kw.get("combine_exhaustive"):
+        cfg.combine_exhaustive = True
+    cfg.snf_input_info = [dict(internal_id=s) for s in range(exp["n_samples"])]
+    cfg.mode = "combine"
+    return cfg
+
+
+def _object_fields(c):
+    d = dict(vars(c))
+    d["forward_difference_sampler"] = vars(d["forward_difference_sampler"])
+    return d
+
+
+def check_columns_equal_objects(_lib, monkeypatch):
+    for name in NAMES:
+        doc = gu.load(name)
+        exp = doc["expected"]
+        for extra in TWIN_OPTIONS:
+            out = []
+            for objects in ("0", "1"):
+                monkeypatch.setenv("SNF_COMBINE_OBJECTS", objects)
+                cfg = _twin_cfg(doc, extra)
+                readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+                half = exp["contig_len"] // 2 // cfg.snf_block_size * cfg.snf_block_size
+                tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg, _lib=_lib),
+                         parallel.CombineTask(id=9, sv_id=0, contig=exp["contig"], start=half + cfg.snf_block_size, end=exp["contig_len"],
+                                              config=cfg, _lib=_lib)]
+                calls = parallel.CombineTask.execute_many(tasks, readers)
+                cands = [c for r in readers.values() for b in r.blocks.values() for t in sv.TYPES for c in b[t]]
+                out.append(([[_object_fields(c) for c in part] for part in calls], [t.sv_id for t in tasks],
+                            [(c.sample_internal_id, dict(c.genotypes)) for c in cands]))
+            (col, col_ids, col_cands), (obj, obj_ids, obj_cands) = out
+            assert col_ids == obj_ids, (name, extra)
+            assert [len(p) for p in col] == [len(p) for p in obj], (name, extra)
+            for pc, po in zip(col, obj):
+                for a, b in zip(pc, po):
+                    assert list(a) == list(b), (name, extra, a["id"])             # the same attributes in the same order
+                    for k in a:
+                        if k == "rnames":
+                            assert a[k] == b[k], (name, extra, a["id"], k)
+                        else:
+                            assert a[k] == b[k] and type(a[k]) is type(b[k]), (name, extra, a["id"], k, a[k], b[k])
+                    assert list(a["genotypes"]) == list(b["genotypes"]), (name, extra, a["id"])   # sample order of the dict
+            assert col_cands == obj_cands, (name, extra)       # what the merge leaves on the candidates (parallel.py:509, sv.py:392)
+            if extra == ():
+                assert sum(len(p) for p in col) > 0
+
+
+def test_columnar_store_equals_the_object_replay_emu(monkeypatch):
+    import emu.emu as E
+    check_columns_equal_objects(E.lib(), monkeypatch)
+
+
+@pytest.mark.gpu
+def test_columnar_store_equals_the_object_replay_gpu(monkeypatch):
+    check_columns_equal_objects(None, monkeypatch)

@@ -75,7 +75,7 @@ def run(ctx):
     import torch
     import torch.distributed as dist
 
-    from sniffles_amd import cluster, dist as sdist, lib, parallel, synth
+    from sniffles_amd import candstore, cluster, dist as sdist, lib, parallel, synth
     from sniffles_amd.config import SnifflesConfig
 
     args, rank, world, local_rank, use_dist = (ctx[k] for k in ("args", "rank", "world", "local_rank", "use_dist"))
@@ -144,7 +144,7 @@ def run(ctx):
     kms = box["kernel_ms"]
     al, ab, cells, staged = box["stats"]
     achieved = ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    out = dict(metric="SV candidates merged/sec (multi-sample combine: group assignment with banded edit distance + SVGroup.call)",
+    out = dict(metric="SV candidates merged/sec (multi-sample combine: SNF blocks -> columnar store -> group assignment with banded edit distance -> SVGroup.call -> SVCall objects)",
                value=total_cands * steps / dt, unit="candidates/s", n_gpus=world, steps=steps, warmup=warmup,
                ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32/f64/u64 bit-vectors",
                data="synthetic",
@@ -153,6 +153,7 @@ def run(ctx):
                            baseline_config=4, samples=S, coverage=cov, scale=args.scale, contig_tasks=len(contigs),
                            candidates=total_cands, combined_calls=total_calls, setup_s=round(t_setup, 1),
                            parallelism=f"contig tasks sharded longest-first over {world} ranks, no data-path collective",
+                           host_phases_ms={k: (round(v * 1e3, 1) if isinstance(v, float) else v) for k, v in candstore.last_timing.items()},
                            rank0=dict(c_abi_call_ms=round(box["abi_s"] * 1e3, 2), kernel_ms=round(kms, 3),
                                       host_ms=round(dt / steps * 1e3 - box["abi_s"] * 1e3, 1), staged_bytes=staged,
                                       alignments=al, dp_cells=cells,
