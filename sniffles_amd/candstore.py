@@ -71,7 +71,14 @@ def _segmented_running(values, seg, take_max: bool):
 
 
 def execute_many(tasks: list, samples_snf: dict) -> list:
-    """`CombineTask.execute` of every task of `tasks` (one merge: same config and readers); the calls per task."""
+    """`CombineTask.execute` of every task of `tasks` (one merge: same config and readers); the calls per task.
+    The cyclic garbage collector is off for the duration (`sv.no_gc`): the merge creates ~10^6 acyclic containers next to the
+    millions the loaded SNF blocks consist of, and every full sweep over those costs as much as the merge itself."""
+    with sv.no_gc():
+        return _execute_many(tasks, samples_snf)
+
+
+def _execute_many(tasks: list, samples_snf: dict) -> list:
     fast = sv._load_fast()
     t0 = tasks[0]
     config, device, _lib = t0.config, t0.device, t0._lib

@@ -224,14 +224,30 @@ def _load_fast():
     return _fast or None
 
 
+class no_gc:
+    """Cyclic garbage collection off while a C pass creates objects in bulk: every generation-2 sweep walks all live containers
+    (the millions of dicts / lists / tuples of the calls already built) and finds nothing - the new objects are acyclic."""
+
+    def __enter__(self):
+        import gc
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        if self.was:
+            import gc
+            gc.enable()
+
+
 def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo, post_cls=None, batch=None) -> list:
     """`fill_candidate(new_call(), res, i, ti)` for i in [lo, hi), same objects.  With `post_cls` every call also gets its
     `postprocess = post_cls(batch=batch, index=i - lo)` handle."""
     import numpy as np
     fast = _load_fast()
     if fast is not None and (ti.qnames is None or isinstance(ti.qnames, list)) and (ti.contig_names is None or isinstance(ti.contig_names, list)):
-        return fast.materialize(svcall_cls, bnd_cls, ForwardDifferenceWelford, post_cls, batch, np.ascontiguousarray(res.calls), lo, hi,
-                                np.ascontiguousarray(res.rnames, np.uint32), ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS)
+        with no_gc():
+            return fast.materialize(svcall_cls, bnd_cls, ForwardDifferenceWelford, post_cls, batch, np.ascontiguousarray(res.calls), lo, hi,
+                                    np.ascontiguousarray(res.rnames, np.uint32), ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS)
     out = materialize_candidates_py(res, ti, lo, hi, svcall_cls, bnd_cls)
     if post_cls is not None:
         for i, c in enumerate(out):
@@ -286,8 +302,9 @@ def apply_final(calls: list, res: Result, ti, lo: int = 0) -> None:
     import numpy as np
     fast = _load_fast()
     if fast is not None and (ti.ps_names is None or isinstance(ti.ps_names, list)):
-        fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
-                         _QC_SV_EARLY_EXIT)
+        with no_gc():
+            fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
+                             _QC_SV_EARLY_EXIT)
         return
     apply_final_py(calls, res, ti, lo)
 

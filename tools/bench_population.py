@@ -94,6 +94,11 @@ def run(ctx):
         readers[s], n = build_sample(call_cfg, tasks, local_rank, s)
         n_cands += n
     t_setup = time.time() - t0
+    # the loaded SNF blocks are the resident input: take them out of the cyclic collector's sweeps, as a long-running merge
+    # process would (gc.freeze); the merge itself runs with the collector off (sniffles_amd.candstore.execute_many)
+    import gc
+    gc.collect()
+    gc.freeze()
     cfg = SnifflesConfig()
     cfg.mode = "combine"
     cfg.snf_input_info = [dict(internal_id=s, sample_id=f"S{s}") for s in range(S)]
@@ -150,6 +155,7 @@ def run(ctx):
                data="synthetic",
                config=dict(workload=f"population merge: {S} HG002-shaped samples at {cov:g}x (shared SV sites, own reads) -> combine "
                                     f"(BASELINE.json configs[4]), candidates from this package's calling path, SNF blocks in memory",
+                           python_gc="SNF blocks frozen after loading (gc.freeze); collector off inside execute_many",
                            baseline_config=4, samples=S, coverage=cov, scale=args.scale, contig_tasks=len(contigs),
                            candidates=total_cands, combined_calls=total_calls, setup_s=round(t_setup, 1),
                            parallelism=f"contig tasks sharded longest-first over {world} ranks, no data-path collective",

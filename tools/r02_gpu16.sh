@@ -1,0 +1,13 @@
+#!/bin/bash
+set -x
+O=gpurun_out/r02p; mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python bench.py --config 4 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+tail -3 $O/bench_c4.err
+python -c "
+import json
+d=json.load(open('$O/bench_c4.json')); print(round(d['value']), d['ms_per_step'], d.get('verified')); print(d['config'].get('host_phases_ms')); print(d['config']['rank0'])"
+timeout 900 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_c1.json 2> $O/bench_c1.err
+python -c "
+import json
+d=json.load(open('$O/bench_c1.json')); print(round(d['value']/1e6,1), d['ms_per_step'], d.get('wall_clock'))"
