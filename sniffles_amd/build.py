@@ -21,23 +21,53 @@ def fast_so() -> str:
     return os.path.join(HERE, "_snf_fast" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
 
+def _digest(paths, extra="") -> str:
+    """Content hash of the sources a binary was built from (file times do not survive a snapshot copy; the hash file travels
+    with the binary, so a prebuilt library is reused exactly when its sources are the ones in the tree)."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(binary: str, digest: str) -> bool:
+    try:
+        with open(binary + ".srchash") as f:
+            return not os.path.exists(binary) or f.read().strip() != digest
+    except OSError:
+        return True
+
+
+def _stamp(binary: str, digest: str) -> None:
+    with open(binary + ".srchash", "w") as f:
+        f.write(digest + "\n")
+
+
+HEADER = os.path.join(HERE, "..", "include", "sniffles_amd.h")
+
+
 def build_fast(force: bool = False) -> str:
     """The CPython extension that turns record tables into SVCall objects (csrc/snf_pyfast.c; host-side formatting only)."""
     import sysconfig
     so, src = fast_so(), os.path.join(CSRC, "snf_pyfast.c")
-    hdr = os.path.join(HERE, "..", "include", "sniffles_amd.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", so]
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", so]
+    digest = _digest([src, HEADER], " ".join(cmd[:-3]))
+    if force or _stale(so, digest):
         subprocess.run(cmd, check=True)
+        _stamp(so, digest)
     return so
 
 
+def _lib_digest() -> str:
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "snf_pyfast.c"] + [HEADER]
+    return _digest(deps, " ".join(FLAGS + SOURCES))
+
+
 def needs_build() -> bool:
-    if not os.path.exists(SO):
-        return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "sniffles_amd.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return _stale(SO, _lib_digest())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -48,7 +78,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", SO]
     if verbose:
         print(" ".join(cmd))
+    digest = _lib_digest()
     subprocess.run(cmd, check=True)
+    _stamp(SO, digest)
     return SO
 
 
