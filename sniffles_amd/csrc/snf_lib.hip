@@ -29,6 +29,8 @@ using namespace snf;
 #define K_CONS_SMALL(MINW) e45w_consensus<1, 256, 128, 64, MINW, 4, SNF_CONS_SMALL_L, 448, 96>
 #define K_CONS_SMALL_1W e45w_consensus<1, 256, 128, 64, 5, 1, SNF_CONS_SMALL_L, 448, 96>
 #define K_CONS_LARGE e45w_consensus<2, 1024, 512, 256, 2, 4, SNF_CONS_LARGE_L, 0, 512>
+#define K_CONS_LARGE_8W e45w_consensus<2, 1024, 512, 256, 2, 8, SNF_CONS_LARGE_L, 0, 512>
+#define K_CONS_LARGE_16W e45w_consensus<2, 1024, 512, 256, 4, 16, SNF_CONS_LARGE_L, 0, 512>
 #define K_CONS_ROWS e45w_consensus<4, 1024, 512, 512, 3>
 #endif
 
@@ -207,6 +209,7 @@ struct snf_batch_impl {
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
   int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22;   // grid caps of the SMALL / LARGE consensus kernels
   int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
+  int cons_large_nw = 4;          // SNF_CONS_LARGE_NW: waves per LARGE consensus call (4, 8, 16)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
@@ -1229,7 +1232,10 @@ void run_finalize(snf_batch_impl* b) {
         SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
         hipStream_t prev = b->cur; b->cur = b->stream3;
         { Scope _s(b, "e45w_consensus_large", 0);
-          hipLaunchKernelGGL((K_CONS_LARGE), dim3((unsigned)(n_large < b->slots_cons_l ? n_large : b->slots_cons_l)), dim3(256), 0, b->cur, v, (int64_t)0);
+          const dim3 gl((unsigned)(n_large < b->slots_cons_l ? n_large : b->slots_cons_l));
+          if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
+          else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
+          else hipLaunchKernelGGL((K_CONS_LARGE), gl, dim3(256), 0, b->cur, v, (int64_t)0);
           SNF_HIP(hipGetLastError()); }
         b->cur = prev;
       }
@@ -1709,6 +1715,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
+    if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
 #endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());

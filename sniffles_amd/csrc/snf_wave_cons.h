@@ -87,16 +87,35 @@ SNF_D int count_eq_win(uint64_t w0, uint64_t w1, uint64_t w2, int k0, const uint
 // injective key of the klen (<= 7) bytes in w; only has to agree between this kernel's table build and lookups
 SNF_D unsigned long long kmer_key_le(unsigned long long w, int klen) { return w & ((1ull << (8 * klen)) - 1ull); }
 
+// Wave scans through DPP (row shifts inside the rows of 16 lanes, row_bcast:15 / :31 for the row totals): six VALU
+// instructions instead of six LDS-crossbar round trips (ds_bpermute) per scan.  All 64 lanes must be active.
 SNF_D int wave_max_incl(int x, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d && y > x) x = y; }
+  (void)lane;
+#define SNF_DPP_MAX(ctrl, rows) { const int y = __builtin_amdgcn_update_dpp(x, x, ctrl, rows, 0xf, false); x = y > x ? y : x; }
+  SNF_DPP_MAX(0x111, 0xf) SNF_DPP_MAX(0x112, 0xf) SNF_DPP_MAX(0x114, 0xf) SNF_DPP_MAX(0x118, 0xf) SNF_DPP_MAX(0x142, 0xa) SNF_DPP_MAX(0x143, 0xc)
+#undef SNF_DPP_MAX
   return x;
 }
-
 SNF_D uint32_t wave_sum_incl_u32(uint32_t x, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+  (void)lane;
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
   return x;
+}
+// the value of the lane before (lane 0: `first`)
+SNF_D int wave_prev(int x, int first) {
+  // wave_shr:1 is not available on gfx9+; row_shr:1 leaves lanes 0, 16, 32, 48 to be patched from lanes 15, 31, 47
+  int y = __builtin_amdgcn_update_dpp(first, x, 0x111, 0xf, 0xf, false);
+  const int l15 = __builtin_amdgcn_readlane(x, 15), l31 = __builtin_amdgcn_readlane(x, 31), l47 = __builtin_amdgcn_readlane(x, 47);
+  const int lane = (int)(threadIdx.x & 63);
+  if (lane == 16) y = l15;
+  if (lane == 32) y = l31;
+  if (lane == 48) y = l47;
+  return y;
 }
 
 SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
@@ -240,7 +259,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         const int cidx = c0 + lane;
         const int i = cidx < ncand ? (int)W.ai[cidx] : -1, j = cidx < ncand ? (int)W.aj[cidx] : 0;
         int pm = wave_max_incl(i, lane);
-        int prev = __shfl_up(pm, 1, 64);
+        int prev = wave_prev(pm, -1);
         if (lane == 0) prev = -1;
         if (runmax > prev) prev = runmax;
         const bool acc = cidx < ncand && i > prev;
@@ -248,7 +267,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         __builtin_amdgcn_wave_barrier();
         if (acc) { const int w = na + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)i; W.aj[w] = (uint16_t)j; }
         na += __builtin_popcountll(mk);
-        const int tot = __shfl(pm, 63, 64);
+        const int tot = __builtin_amdgcn_readlane(pm, 63);
         if (tot > runmax) runmax = tot;
         __builtin_amdgcn_wave_barrier();
       }
@@ -309,8 +328,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           segn[it] = flag ? (uint32_t)fwd_j | ((uint32_t)cm << 16) : 0u;   // flag => 0 < fwd_j, cm <= fwd_j <= L < 65000
         }
       }
-#pragma unroll
-      for (int dd = 32; dd >= 1; dd >>= 1) span += __shfl_xor(span, dd, 64);
+      span = __builtin_amdgcn_readlane((int)wave_sum_incl_u32((uint32_t)span, lane), 63);
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360): a group stays iff
       // more than half of its columns agree with the best read and more than five do.  One lane per segment: prefix sums
       // of (matches, columns) over the copied segments go to LDS, the ballots of the copy flags give every lane the first
@@ -327,7 +345,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           fmask[it] = __ballot(segn[it] != 0u);                      // lanes past na hold 0: they end a group
           const uint32_t pre = wave_sum_incl_u32(cmv | (n << 16), lane) + carry;   // both halves stay below 65536 (disjoint columns of one row)
           if (t < na) W.seg_pref[t] = pre;
-          carry = (uint32_t)__shfl((int)pre, 63, 64);
+          carry = (uint32_t)__builtin_amdgcn_readlane((int)pre, 63);
         }
       }
       __builtin_amdgcn_wave_barrier();
