@@ -375,6 +375,16 @@ COMBINE_TASK = {
     # dense sites: several flush windows per 100-kb block, kept groups between windows and across blocks
     "combine_task_8samples_dense": (lambda: [synth.gen_task(4, "chr20", 600_000, 15, seed=300 + s, site_seed=31337, site_density=40 * 27000 / 3.1e9)
                                              for s in range(8)], ()),
+    # the decision rules of SVGroup.call away from their defaults (confidence thresholds, NULL coverage, pair relabelling, filtered output)
+    "combine_task_10samples_options": (lambda: [synth.gen_task(1, "chr19", 1_200_000, 15, seed=400 + s, site_seed=606, site_density=30 * 27000 / 3.1e9)
+                                                for s in range(10)],
+                                       ("--combine-high-confidence", "0.3", "--combine-low-confidence", "0.4", "--combine-low-confidence-abs", "3",
+                                        "--combine-null-min-coverage", "8", "--combine-pair-relabel", "--combine-pair-relabel-threshold", "15",
+                                        "--combine-output-filtered")),
+    # medians instead of the first candidate's coordinates, a higher support threshold and minimum length
+    "combine_task_5samples_medians": (lambda: [synth.gen_task(6, "chr18", 800_000, 25, seed=500 + s, site_seed=77, site_density=30 * 27000 / 3.1e9)
+                                               for s in range(5)],
+                                      ("--dev-combine-medians", "--combine-support-threshold", "4", "--minsvlen", "80")),
 }
 
 # real .snf files written by the reference (one per sample; per-sample reference command line); the samples are those of

@@ -32,7 +32,7 @@ class BlocksReader:
 def run_case(name, _lib=None, reqc=False):
     doc = gu.load(name)
     exp = doc["expected"]
-    cfg = make_cfg(doc["reference_args"], exp["n_samples"])
+    cfg = _twin_cfg(doc, ())
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
     for r in readers.values():
         r.reqc = reqc
