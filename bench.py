@@ -431,7 +431,7 @@ def run_calling(ctx):
                                         frac=round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if not strong and world == 1 else None),
                         top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2]),
                                           **({"ms_one_batch_in_flight": round(timings_alone[k[0]], 4)} if k[0] in timings_alone else {}))
-                                     for k in kern[:8]])
+                                     for k in kern[:int(os.environ.get("SNF_BENCH_TOPK", "8"))]])
         n_contigs = len(wl["contigs"] or synth.CONTIGS)
         out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

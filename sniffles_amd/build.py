@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libsniffles_amd.so")
 SOURCES = ["snf_lib.hip", "snf_myers.hip", "snf_combine.hip", "snf_extract.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SNF_EXTRA_FLAGS", "").split()   # e.g. -DSNF_CONS_PROFILE
 
 
 def fast_so() -> str:

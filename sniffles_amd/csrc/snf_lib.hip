@@ -1277,6 +1277,13 @@ void run_finalize(snf_batch_impl* b) {
 
 void collect_timings(snf_batch_impl* b) {
   b->timings.clear();
+#ifdef SNF_CONS_PROFILE
+  if (getenv("SNF_PROF")) {
+    static const char* nm[9] = {"setup+table", "kmers+probes", "chain", "segments", "run filter", "votes", "barrier+vote+store", "longest workgroup", "workgroups"};
+    for (int c = 0; c < 2; c++)
+      for (int k = 0; k < 9; k++) fprintf(stderr, "[SNF_CONS_PROFILE] %s %-20s %llu\n", c ? "LARGE" : "SMALL", nm[k], b->h_cnt->dbg[c * 16 + k]);
+  }
+#endif
 #ifndef SNF_EMU
   for (size_t i = 0; i < b->ev_used; i++) {
     float ms = 0;

@@ -22,6 +22,9 @@ struct Counts {
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
                                     // 7 ROWS (aligned rows in HBM: beyond the LDS vote counters, or handed over by SMALL / LARGE at run time)
   unsigned long long pool_extra_used;
+#ifdef SNF_CONS_PROFILE
+  unsigned long long dbg[32];       // instrumented build only: cycles per phase of the consensus kernels (tools/cons_profile.sh)
+#endif
   int32_t overflow;  // scratch overflow flags
   int32_t _pad;
 };

@@ -31,6 +31,19 @@ namespace snf {
 
 #define SNF_KEY_EMPTY (~0ull)
 
+// instrumented build (-DSNF_CONS_PROFILE, tools/cons_profile.sh): s_memtime stamps between the phases, summed per wave and
+// added to Counts::dbg at the end of the workgroup; [base + 0..6] phases, [base + 7] longest workgroup, [base + 8] workgroups
+#ifdef SNF_CONS_PROFILE
+#define SNF_PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = __builtin_amdgcn_s_memtime(); const unsigned long long pt_t0 = pt_t;
+#define SNF_PT(k) do { const unsigned long long pt_n = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; } while (0)
+#define SNF_PT_FLUSH(base) do { if (lane == 0) { for (int pk = 0; pk < 7; pk++) atomicAdd(&v.cnt->dbg[(base) + pk], pt_acc[pk]); \
+    if (wid == 0) { atomicMax(&v.cnt->dbg[(base) + 7], __builtin_amdgcn_s_memtime() - pt_t0); atomicAdd(&v.cnt->dbg[(base) + 8], 1ull); } } } while (0)
+#else
+#define SNF_PT_DECL
+#define SNF_PT(k) do { } while (0)
+#define SNF_PT_FLUSH(base) do { } while (0)
+#endif
+
 template <int SLOTS, int MAXPOS, int MAXOTHERS, int NW, int LCAP, int SCAP, int ECAP>
 struct ConsLdsT {
   unsigned long long key[SLOTS];
@@ -160,6 +173,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     if (it + gridDim.x < n_items) { cid_next = item_cid(it + gridDim.x); d_next = v.cdesc[cid_next]; }
     // everything per call is wave-uniform: keep it in SGPRs (the compiler cannot prove it for values loaded from global
     // memory, and the kernel's occupancy is bound by VGPRs)
+    SNF_PT_DECL
     const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
     const int32_t n_others = __builtin_amdgcn_readfirstlane(d.n_others);
     const uint8_t* Bg = v.pool + rfl64(d.best_off);
@@ -198,30 +212,66 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       if ((atomicAdd(&lds.pc[sl], 1u) & 0xffffu) == 0) atomicOr(&lds.pc[sl], (uint32_t)i << 16);  // position of the 1st sighting
     }
     __syncthreads();
+    SNF_PT(0);   // descriptor, staging, table build
     typename Lds::Wave& W = lds.w[wid];
     uint8_t* rows = LV ? nullptr : v.aln + rfl64(d.aln_off);
-    for (int32_t r = wid; r < n_others; r += NW) {
+    // Geometry of other read r: where it lives, how far the sampled positions go, how many bytes any phase touches.
+    // candidates in read order: a sampled k-mer is an anchor iff it is in the table and |i - j| <= maxshift
+    auto read_geom = [&](int32_t r, const uint8_t*& Sg, int& SL, int& jlim, int& P, int& ns) {
       int64_t s_off = 0; int32_t s_len = 0;
 #pragma unroll
       for (int sx = 0; sx < NS; sx++) if (sx == (r >> 6)) { s_off = __shfl(my_off[sx], r & 63, 64); s_len = __shfl(my_len[sx], r & 63, 64); }
-      const uint8_t* Sg = v.pool + rfl64(s_off);
-      const int SL = __builtin_amdgcn_readfirstlane(s_len);
-      // ---- 1. candidates in read order: sampled k-mer is an anchor and |i - j| <= maxshift
-      int jlim = SL - klen;                                     // j < SL - klen
+      Sg = v.pool + rfl64(s_off);
+      SL = __builtin_amdgcn_readfirstlane(s_len);
+      jlim = SL - klen;                                         // j < SL - klen
       if (L - klen + maxshift < jlim) jlim = L - klen + maxshift;   // an anchor needs i <= L-klen-1, |i-j| <= maxshift
-      const int P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;   // <= npos + 2 < MAXPOS
+      P = jlim <= 0 ? 0 : (jlim + skip - 1) / skip;             // <= npos + 2 < MAXPOS
+      // every byte any phase reads lies below jlim + klen + 8 (k-mer words, segment compares, copied bases)
+      ns = jlim + klen + 8; if (ns > SL + 8) ns = SL + 8; if (ns < 0) ns = 0;
+    };
+    // The first thing a read needs - its bytes (SMALL: staged in LDS) or its sampled k-mer words (read in HBM) - is requested
+    // one read ahead: measured with s_memtime stamps, waiting for exactly these loads was 57 % (SMALL) and 32 % (LARGE)
+    // of the waves' time when every read fetched them on demand.
+    static_assert(SCAP <= 1024, "one 16-byte load per lane covers the staged read");
+    uint4 pre_s = make_uint4(0, 0, 0, 0);
+    unsigned long long pre_kw[SCAP > 0 ? 1 : ROUNDS];
+    {
+      const uint8_t* Sg0 = v.pool; int SL0 = 0, jl0 = 0, P0 = 0, ns0 = 0;
+      if (wid < n_others) read_geom(wid, Sg0, SL0, jl0, P0, ns0);
+      if constexpr (SCAP > 0) { if (lane * 16 < ns0) pre_s = *(const u128_unaligned*)(Sg0 + lane * 16); }
+      else {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) { const int p = rd * 64 + lane; pre_kw[rd] = (p < P0) ? load_u64(Sg0 + p * skip) : 0ull; }
+      }
+    }
+    for (int32_t r = wid; r < n_others; r += NW) {
+      const uint8_t* Sg; int SL, jlim, P, ns;
+      read_geom(r, Sg, SL, jlim, P, ns);
+      // ---- 1. the read's k-mer words (requested one read ago), then the request for the next read
+      unsigned long long kw[ROUNDS];
       if constexpr (SCAP > 0) {
-        // every byte any phase reads lies below jlim + klen + 8 (k-mer words, segment compares, copied bases)
-        int ns = jlim + klen + 8; if (ns > SL + 8) ns = SL + 8; if (ns < 0) ns = 0;
-        stage16(W.s, Sg, ns, lane, 64);
+        if (lane * 16 < ns) *(uint4*)(W.s + lane * 16) = pre_s;
         __builtin_amdgcn_wave_barrier();
+      } else {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) kw[rd] = pre_kw[rd];
       }
       const uint8_t* S = SCAP > 0 ? (const uint8_t*)W.s : Sg;
-      unsigned long long kw[ROUNDS];
+      if (r + NW < n_others) {
+        const uint8_t* Sgn; int SLn, jln, Pn, nsn;
+        read_geom(r + NW, Sgn, SLn, jln, Pn, nsn);
+        if constexpr (SCAP > 0) { if (lane * 16 < nsn) pre_s = *(const u128_unaligned*)(Sgn + lane * 16); }
+        else {
 #pragma unroll
-      for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
-        const int p = rd * 64 + lane;
-        kw[rd] = (p < P) ? load_u64(S + p * skip) : 0ull;
+          for (int rd = 0; rd < ROUNDS; rd++) { const int p = rd * 64 + lane; pre_kw[rd] = (p < Pn) ? load_u64(Sgn + p * skip) : 0ull; }
+        }
+      }
+      if constexpr (SCAP > 0) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
+          const int p = rd * 64 + lane;
+          kw[rd] = (p < P) ? load_u64(S + p * skip) : 0ull;
+        }
       }
       int ncand = 0;
       constexpr int G = ROUNDS < 4 ? ROUNDS : 4;  // rounds probed together: their LDS reads are in flight at once
@@ -253,6 +303,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         }
       }
       __builtin_amdgcn_wave_barrier();
+      SNF_PT(1);   // k-mer words, probes, candidate compaction
       // ---- 2. monotone chain: accept iff i > every earlier candidate's i (== last accepted i)
       int na = 0, runmax = -1;
       for (int c0 = 0; c0 < ncand; c0 += 64) {
@@ -271,6 +322,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         if (tot > runmax) runmax = tot;
         __builtin_amdgcn_wave_barrier();
       }
+      SNF_PT(2);   // monotone chain
       // ---- 3. segments between consecutive anchors
       const int i0 = __builtin_amdgcn_readfirstlane(na ? (int)W.ai[0] : 0), j0 = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[0] : 0);
       const int c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
@@ -329,6 +381,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         }
       }
       span = __builtin_amdgcn_readlane((int)wave_sum_incl_u32((uint32_t)span, lane), 63);
+      SNF_PT(3);   // windows + segment compares
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360): a group stays iff
       // more than half of its columns agree with the best read and more than five do.  One lane per segment: prefix sums
       // of (matches, columns) over the copied segments go to LDS, the ballots of the copy flags give every lane the first
@@ -380,6 +433,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         }
       }
       __builtin_amdgcn_wave_barrier();
+      SNF_PT(4);   // run filter
       // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): it has no vote
       const bool keep_row = (double)span / (double)L > 0.2;
       if constexpr (LV) {
@@ -429,6 +483,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         if (lane == 0) { const uint8_t k = keep_row ? 1 : 0; v.aln_kept_w[r0 + r] = k; lds.kept[r] = k; }
       }
       __builtin_amdgcn_wave_barrier();
+      SNF_PT(5);   // votes into the counters
     }
     // ---- column vote (consensus.py:365-380)
     __syncthreads();
@@ -444,6 +499,8 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       }
       bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
       for (int q = tid; q < L; q += NT) alt[q] = vote_column(lds.cnt[q], lds.esc, n_esc, q, lds.best[q], nkept);
+      SNF_PT(6);   // barrier wait + column vote + ALT stores
+      SNF_PT_FLUSH(CLS == 1 ? 0 : 16);
       continue;
     }
     bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;
