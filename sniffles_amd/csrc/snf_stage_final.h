@@ -127,7 +127,102 @@ SNF_HD bool qc_sv(const View& v, snf_call_t& c, const LeadAgg& g) {
 }
 
 // phase_sv: majority HP / PS over distinct read_id (last lead of a read wins); fills the phase part of LeadAgg
+#define SNF_BIG_FINAL_CAP 512   /* leads of a call whose rows x_big<2> keeps in LDS */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+// collect_agg for a call with more than 64 leads, executed by the whole wave (x_big<2>, "uniform" mode: every lane runs the
+// finalize body in lock step).  The serial form walks the leads one by one through six dependent gathers and looks for a later
+// lead of the same read with a second loop: with a few hundred leads that is 10^4-10^5 dependent loads per call.  Here a lane
+// takes every 64th lead (one 64-byte record each), read ids / flags / the phase-set list sit in LDS rows (x_big<2>; leads beyond
+// the rows' capacity use the global scratch rows), "is there a later lead of this read" is a broadcast scan of the LDS row,
+// and the survivors are compacted with ballots.  All 64 lanes leave with the same aggregates.
+SNF_D void collect_agg_wave(const View& v, const CallX& x, int task, LeadAgg* g) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int32_t n = x.fn;
+  const bool in_lds = v.stage_w != nullptr && n <= v.stage_cap;
+  int32_t* rid = in_lds ? v.stage_w : v.w4 + x.flo;                                  // read id of lead k (w1 still holds the read names for d3_rnames)
+  int32_t* flg = in_lds ? v.stage_w + v.stage_cap : v.w5 + x.flo;                    // selected | hap << 1
+  int32_t* psv_ = in_lds ? v.stage_w + 2 * v.stage_cap : v.w6 + x.flo;               // phase-set code of lead k
+  int32_t* a0 = in_lds ? v.stage_w + 3 * v.stage_cap : v.w0 + x.flo;                 // phase sets of the contributing reads
+  int32_t* tmp = in_lds ? v.stage_w + 4 * v.stage_cap : v.w7 + x.flo;
+  const int32_t ps_null = v.t_ps_null[task];
+  int f = 0, r = 0; int64_t close = 0;
+  for (int32_t k = lane; k < n; k += 64) {
+    const int32_t s = v.FI[x.flo + k];
+    const int sel = v.F_sel[s] ? 1 : 0;
+    const LeadRec rec = v.Lrec[v.F_lpos[s]];
+    rid[k] = (int32_t)rec.read_id;
+    flg[k] = sel | ((int)rec.hap << 1);
+    const int32_t p = rec.ps;
+    psv_[k] = (p == SNF_PS_NONE || p == ps_null) ? SNF_PS_NULL_CODE : p;
+    if (sel) {
+      if (rec.strand == 0) f = 1; else r = 1;
+      const int64_t qs = rec.qry_start;
+      if (qs <= v.cfg.dev_min_close_edge_dist || iabs64((int64_t)rec.read_len - qs) <= v.cfg.dev_min_close_edge_dist) close++;
+    }
+  }
+  g->nstrands = (__ballot(f != 0) ? 1 : 0) + (__ballot(r != 0) ? 1 : 0);
+  for (int d = 32; d >= 1; d >>= 1) close += __shfl_xor(close, d, 64);
+  g->close_edge = close;
+  g->hp_val = 0; g->hp_support = -1; g->hp_other = 0; g->ps_val = 0; g->ps_support = -1; g->ps_other = 0;
+  __syncthreads();
+  int64_t hc[3] = {0, 0, 0};
+  int32_t np_ = 0;
+  if (v.cfg.phase) {
+    // reads_phases = {read_id: (hap, ps)}: the last selected lead of a read wins
+    for (int32_t base = 0; base < n; base += 64) {
+      const int32_t k = base + lane;
+      const int32_t my = k < n ? rid[k] : 0, mf = k < n ? flg[k] : 0;
+      bool later = false;
+      for (int32_t k2 = base + 1; k2 < n; k2++) later |= (k2 > k) && (flg[k2] & 1) && rid[k2] == my;   // same address in all lanes
+      const bool contrib = k < n && (mf & 1) && !later;
+      for (int hh = 0; hh < 3; hh++) hc[hh] += __builtin_popcountll(__ballot(contrib && (mf >> 1) == hh));
+      const unsigned long long m = __ballot(contrib);
+      if (contrib) a0[np_ + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = psv_[k];
+      np_ += __builtin_popcountll(m);
+    }
+    __syncthreads();
+  } else {
+    // without --phase the reference still looks at nothing but strands and edges (hc, a0 stay empty)
+  }
+  int hpv = 0; int64_t hp_support = -1;
+  for (int h = 0; h < 3; h++) if (hc[h] > 0 && hc[h] >= hp_support) { hp_support = hc[h]; hpv = h; }
+  int64_t other_hp = 0;
+  for (int h = 0; h < 3; h++) if (h != hpv) other_hp += hc[h];
+  wave_sort_inplace(a0, (int64_t)np_, LessI32{}, tmp);
+  // most_common over the sorted list: one lane per element, a run start counts its run
+  int32_t best_len = -1, best_val = 0; int64_t other_ps = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    int32_t my_len = 0, my_val = 0; int64_t oth = 0;
+    for (int32_t i = lane; i < np_; i += 64) {
+      const int32_t val = a0[i];
+      if (i > 0 && a0[i - 1] == val) continue;
+      int32_t j = i + 1; while (j < np_ && a0[j] == val) j++;
+      const int32_t len = j - i;
+      if (pass == 0) { if (len > my_len || (len == my_len && val >= my_val) || my_len == 0) { my_len = len; my_val = val; } }
+      else if (val != best_val && val != SNF_PS_NULL_CODE) oth += len;
+    }
+    if (pass == 0) {
+      // (count, value) descending: the longest run, ties -> the larger value
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int32_t ol = __shfl_xor(my_len, d, 64), ov = __shfl_xor(my_val, d, 64);
+        if (ol > my_len || (ol == my_len && ol > 0 && ov > my_val)) { my_len = ol; my_val = ov; }
+      }
+      if (my_len > 0) { best_len = my_len; best_val = my_val; }
+    } else {
+      for (int d = 32; d >= 1; d >>= 1) oth += __shfl_xor(oth, d, 64);
+      other_ps = oth;
+    }
+  }
+  g->hp_val = hpv; g->hp_support = hp_support; g->hp_other = other_hp;
+  g->ps_val = best_len > 0 ? best_val : 0; g->ps_support = best_len > 0 ? best_len : -1; g->ps_other = other_ps;
+  __syncthreads();
+}
+#endif
+
 SNF_HD void collect_agg(const View& v, const CallX& x, int task, LeadAgg* g) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+  if (v.wave_uniform) { collect_agg_wave(v, x, task, g); return; }
+#endif
   int64_t hc[3] = {0, 0, 0};
   int32_t* a0 = v.w0 + x.flo;
   int32_t np_ = 0;
