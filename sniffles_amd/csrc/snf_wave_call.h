@@ -9,7 +9,7 @@
 #ifndef SNF_EMU
 namespace snf {
 
-struct CallLds { int32_t buf[SNF_WAVE]; };
+struct CallLds { int32_t buf[SNF_WAVE]; double nm[SNF_WAVE]; };
 
 SNF_D int64_t wave_sum64(int64_t x) {
 #pragma unroll
@@ -292,6 +292,14 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
       g.ps_val = __shfl(s_ps, bl, SNF_WAVE); g.ps_support = maxc;
       g.ps_other = wave_sum64((st && s_ps != g.ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
       __syncthreads();
+    }
+    // rescue_phasing (lane 0 below) sums the leads' NM ratios in list order: one gather per lane here instead of a chain of
+    // 3 x n dependent loads there
+    g.nm_row = nullptr;
+    if (cfg.phase && cfg.mode_call_sample) {
+      lds.nm[lane] = lane < n ? v.in_nm[o] : 0.0;
+      __syncthreads();
+      g.nm_row = lds.nm;
     }
     if (lane == 0) {
       snf_call_t c = v.calls[i];
