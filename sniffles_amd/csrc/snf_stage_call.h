@@ -288,14 +288,30 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   int32_t *a0 = v.w0 + flo, *a1 = v.w1 + flo, *a2 = v.w2 + flo, *a3 = v.w3 + flo, *stmp = v.w7 + flo;
   const bool uni = v.wave_uniform != 0;
   const int32_t* FI = v.FI + flo;
+  // x_big<1> (uniform mode): the fill loops take every 64th lead per lane (SNF_LEADS), sums are wave reductions, and the rows
+  // live in LDS when the cluster fits (the sorted read names are copied to their global row at the end: d3_rnames reads them)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+  const int l0 = uni ? (int)(threadIdx.x & 63) : 0, lstep = uni ? 64 : 1;
+  const bool lds_rows = uni && v.stage_w != nullptr && n <= v.stage_cap;
+  int32_t* const a1_global = a1;
+  if (lds_rows) { a0 = v.stage_w; a1 = a0 + v.stage_cap; a2 = a1 + v.stage_cap; a3 = a2 + v.stage_cap; stmp = a3 + v.stage_cap; }
+#define SNF_LEADS(k) for (int32_t k = l0; k < n; k += lstep)
+#define SNF_UNI_SYNC() do { if (uni) __syncthreads(); } while (0)
+#define SNF_UNI_SUM(x) do { if (uni) { for (int d_ = 32; d_ >= 1; d_ >>= 1) x += __shfl_xor(x, d_, 64); } } while (0)
+#else
+  const bool lds_rows = false;
+#define SNF_LEADS(k) for (int32_t k = 0; k < n; k++)
+#define SNF_UNI_SYNC() do { } while (0)
+#define SNF_UNI_SUM(x) do { } while (0)
+#endif
   v.cdflag[r] = 0;
-  for (int32_t k = 0; k < n; k++) { a0[k] = v.F_svlen[FI[k]]; v.F_sel[FI[k]] = 1; }
+  SNF_LEADS(k) { a0[k] = v.F_svlen[FI[k]]; v.F_sel[FI[k]] = 1; }
   SNF_SORT(uni, a0, (int64_t)n, LessI32{}, stmp);
   int64_t svlen = center_sorted(a0, n);
   bool single = svtype == SNF_SINGLE_LEFT || svtype == SNF_SINGLE_RIGHT;
   if (!single && svtype != SNF_BND && iabs64(svlen) < cfg.minsvlen_screen) return;
 
-  for (int32_t k = 0; k < n; k++) a1[k] = (int32_t)v.in_qname[v.F_orig[FI[k]]];
+  SNF_LEADS(k) a1[k] = (int32_t)v.in_qname[v.F_orig[FI[k]]];
   SNF_SORT(uni, a1, (int64_t)n, LessI32{}, stmp);
   int64_t nq = distinct_sorted_i32(a1, n);
   int64_t support = nq, support_long = 0;
@@ -309,7 +325,8 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       if (first) { support_long++; if (!contains_sorted_i32(a1, nq, q)) support++; }
     }
   }
-  for (int32_t k = 0; k < n; k++) a2[k] = v.in_ref_start[v.F_orig[FI[k]]];
+  SNF_UNI_SYNC();   // (distinct_sorted_i32 compacted a1 in place on every lane)
+  SNF_LEADS(k) a2[k] = v.in_ref_start[v.F_orig[FI[k]]];
   SNF_SORT(uni, a2, (int64_t)n, LessI32{}, stmp);
   int64_t ref_start = center_sorted(a2, n);
   double stdev_pos = stdev_trim_sorted(a2, n);
@@ -321,12 +338,13 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   else if (svtype == SNF_DEL) { svstart = ref_start + svlen; svend = ref_start; }
   else { svstart = ref_start; svend = svstart + iabs64(svlen); }
   int64_t msum = 0, fwd = 0, sa = 0, src_noninline = 0; double nmsum = 0;
-  for (int32_t k = 0; k < n; k++) {
+  SNF_LEADS(k) {
     uint32_t o = (uint32_t)v.F_orig[FI[k]];
     msum += v.in_mapq[o]; fwd += (v.in_strand[o] == 0); sa += v.in_is_sa[o];
     src_noninline += (v.in_source[o] != SNF_SRC_INLINE);
-    if (cfg.qc_nm_measure) nmsum += v.in_nm[o];
   }
+  SNF_UNI_SUM(msum); SNF_UNI_SUM(fwd); SNF_UNI_SUM(sa); SNF_UNI_SUM(src_noninline);
+  if (cfg.qc_nm_measure) for (int32_t k = 0; k < n; k++) nmsum += v.in_nm[(uint32_t)v.F_orig[FI[k]]];   // Python sum(): left to right
   int64_t n_all = n;
   if (keeplong) { for (int32_t x = llo; x < lhi; x++) sa += v.in_is_sa[v.LL[x]]; n_all += lhi - llo; }
 
@@ -344,7 +362,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   cc.cluster_seed_index = v.seed_bin[h] - v.grp_first_bin[g];
   int64_t rn_len = support;
   if (svtype == SNF_BND) {  // resolve_bnd
-    for (int32_t k = 0; k < n; k++) a3[k] = v.in_mate_contig[v.F_orig[FI[k]]];
+    SNF_LEADS(k) a3[k] = v.in_mate_contig[v.F_orig[FI[k]]];
     SNF_SORT(uni, a3, (int64_t)n, LessI32{}, stmp);
     int32_t mc = a3[0]; int64_t bc = 0;
     for (int32_t x = 0; x < n;) { int32_t y = x; while (y < n && a3[y] == a3[x]) y++; if (y - x > bc) { bc = y - x; mc = a3[x]; } x = y; }
@@ -371,25 +389,58 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
   if (svtype == SNF_INS && !cfg.symbolic) {
     // best lead of annotate_sv (postprocessing.py:33-66): first argmin of |len(seq) - svlen| + |ref_start - pos| * 1.5
-    int32_t best = -1, cnt = 0; double best_diff = 0;
-    for (int32_t k = 0; k < n; k++) {
+    int32_t best = -1, cnt = 0; double best_diff = 0; int32_t best_k = 0x7fffffff;
+    SNF_LEADS(k) {
       int32_t s = FI[k];
       if (v.F_seq_len[s] < 0) continue;
       double d = (double)iabs64((int64_t)v.F_seq_len[s] - cc.svlen) +
                  (double)iabs64((int64_t)v.in_ref_start[(uint32_t)v.F_orig[s]] - cc.pos) * 1.5;
-      if (best < 0 || d < best_diff) { best = s; best_diff = d; }
+      if (best < 0 || d < best_diff) { best = s; best_diff = d; best_k = k; }
       cnt++;
     }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+    if (uni) {   // the lanes' minima: smallest d, then the earliest lead (first argmin)
+      for (int d_ = 32; d_ >= 1; d_ >>= 1) {
+        const int32_t ob = __shfl_xor(best, d_, 64), ok = __shfl_xor(best_k, d_, 64); const double od = __shfl_xor(best_diff, d_, 64);
+        if (ob >= 0 && (best < 0 || od < best_diff || (od == best_diff && ok < best_k))) { best = ob; best_diff = od; best_k = ok; }
+      }
+      SNF_UNI_SUM(cnt);
+    }
+#endif
     if (best >= 0) { x.best = best; x.n_others = cnt - 1; x.do_cons = (x.n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; }
     if (best >= 0 && v.wave_path) {  // read list for the workgroup consensus kernel (see d2w_call)
-      int32_t w = 0;
-      for (int32_t k = 0; k < n; k++) {
-        int32_t s = FI[k];
-        if (v.F_seq_len[s] < 0 || s == best) continue;
-        v.crl_off[flo + w] = v.F_seq_off[s]; v.crl_len[flo + w] = v.F_seq_len[s]; w++;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+      if (uni) {
+        int32_t w = 0;
+        for (int32_t base = 0; base < n; base += 64) {      // list order = lead order: ballots per 64 leads
+          const int32_t k = base + l0;
+          const int32_t s = k < n ? FI[k] : 0;
+          const bool oth = k < n && v.F_seq_len[s] >= 0 && s != best;
+          const unsigned long long om = __ballot(oth);
+          if (oth) { const int32_t q = w + __builtin_popcountll(om & ((1ull << l0) - 1ull)); v.crl_off[flo + q] = v.F_seq_off[s]; v.crl_len[flo + q] = v.F_seq_len[s]; }
+          w += __builtin_popcountll(om);
+        }
+      } else
+#endif
+      {
+        int32_t w = 0;
+        for (int32_t k = 0; k < n; k++) {
+          int32_t s = FI[k];
+          if (v.F_seq_len[s] < 0 || s == best) continue;
+          v.crl_off[flo + w] = v.F_seq_off[s]; v.crl_len[flo + w] = v.F_seq_len[s]; w++;
+        }
       }
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+  if (lds_rows) {   // the distinct sorted read names stay in w1 for d3_rnames
+    __syncthreads();
+    for (int32_t k = l0; k < (int32_t)nq; k += 64) a1_global[k] = a1[k];
+  }
+#endif
+#undef SNF_LEADS
+#undef SNF_UNI_SYNC
+#undef SNF_UNI_SUM
   v.candx[r] = x;
   v.cdflag[r] = 1;
 }

@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused
 template <int KIND>
 __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
   __shared__ alignas(16) LeadRec s_rec[KIND == 0 ? SNF_BIG_STAGE_CAP : 1];     // (filled with 16-byte stores)
-  __shared__ alignas(16) int32_t s_scr[KIND == 0 ? 8 * SNF_BIG_STAGE_CAP : KIND == 2 ? 5 * SNF_BIG_FINAL_CAP : 1];
+  __shared__ alignas(16) int32_t s_scr[KIND == 0 ? 8 * SNF_BIG_STAGE_CAP : 5 * SNF_BIG_FINAL_CAP];
   const bool stage = v.stage_cap != 0;    // host switch (SNF_NO_BIG_STAGE=1 clears it): keep staged clusters in LDS
   v.big_wave = 0;   // the bodies below are the ones that skip big items when it is set
   // all 64 lanes run the serial body in lock step on the same data (identical stores, no atomics except the one pool
@@ -374,10 +374,10 @@ __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
       } else { v.stage_R = nullptr; v.stage_w = nullptr; }
       d1_refine_body(item, v);
     }
-    else if (KIND == 1) d2_call_body(item, v);
     else {
-      if (stage) { v.stage_w = s_scr; v.stage_cap = SNF_BIG_FINAL_CAP; } else v.stage_w = nullptr;   // rows of collect_agg_wave
-      e1_finalize_body(item, v);
+      __syncthreads();                       // the previous item is through with the LDS rows
+      if (stage) { v.stage_w = s_scr; v.stage_cap = SNF_BIG_FINAL_CAP; } else v.stage_w = nullptr;   // rows of d2_call_body / collect_agg_wave
+      if (KIND == 1) d2_call_body(item, v); else e1_finalize_body(item, v);
     }
   }
 }
