@@ -203,3 +203,19 @@ def test_full_size_properties():
     ins = (c["svtype"] == 0) & (c["alt_len"] >= 0)
     assert ins.sum() > 100 and np.all(c["alt_len"][ins] >= 45)
     assert (c["filter"] == 0).sum() > 400  # ~561 planted sites on chr20
+
+
+@pytest.mark.parametrize("cov,no_stage", [(150, "0"), (700, "0"), (150, "1")])
+def test_hip_matches_oracle_on_very_deep_clusters(oracle_mod, monkeypatch, cov, no_stage):
+    """Clusters far beyond one wave (x_big<0/1/2>: the wave runs the serial bodies uniformly): 150x puts them into the LDS rows
+    (<= 160 / 512 leads), 700x beyond the rows' capacity (global scratch rows), SNF_NO_BIG_STAGE=1 switches the LDS staging off
+    altogether.  HiFi-like reads (low error: many leads per cluster survive), germline and mosaic settings."""
+    monkeypatch.setenv("SNF_NO_BIG_STAGE", no_stage)
+    tis = [synth.gen_task(0, "chr21", 400_000, cov, 5, err=0.005, read_len_mean=12000, site_density=2e-4),
+           synth.gen_task(1, "chr22", 250_000, cov, 6, err=0.005, read_len_mean=12000, mosaic_frac=0.2, site_density=2e-4)]
+    for cfg in (SnifflesConfig(), SnifflesConfig(mosaic=True)):
+        exp = oracle_mod.run(cfg, tis, True)
+        got = run(cfg, tis, True)
+        assert max(int(c["n_leads"]) for c in got.calls) > (512 if cov >= 700 else 64)
+        for t in range(len(tis)):
+            assert records.diff_results(got, t, exp, t) == [], (cov, no_stage, t)

@@ -1,0 +1,5 @@
+#!/bin/bash
+O=gpurun_out/r02ad; mkdir -p $O
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "deep_clusters" > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
+tail -15 $O/pytest.log
