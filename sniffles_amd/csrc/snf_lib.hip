@@ -1160,7 +1160,9 @@ void run_finalize(snf_batch_impl* b) {
     if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
-      int64_t grid = nc < b->slots_e1w ? nc : b->slots_e1w;
+      // one workgroup (= wave) per batch of SNF_E1_BATCH calls, dispatched by the hardware (a resident grid that strides would
+      // run a second, mostly empty round: ceil(calls / 16) is only slightly more than the waves the device holds)
+      int64_t grid = (nc + SNF_E1_BATCH - 1) / SNF_E1_BATCH;
       hipLaunchKernelGGL(b->k_e1w, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }

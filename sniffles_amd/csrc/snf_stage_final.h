@@ -31,6 +31,7 @@ struct LeadAgg {
   int hp_val; int64_t hp_support, hp_other;          // phase_sv majorities (postprocessing.py:626-654)
   int32_t ps_val; int64_t ps_support, ps_other;      // ps_val == SNF_PS_NULL_CODE: "NULL"
   const double* nm_row;  // NM ratio of lead k of the call, gathered by the wave (LDS), or nullptr: read from the input column
+  double nm_mean; int has_nm_mean;   // np.nanmean of the leads' NM ratios, when the wave has already formed it (e1w_finalize)
 };
 
 SNF_HD double py_round(double x) { return rint(x); }  // round-half-even (default rounding mode)
@@ -218,7 +219,7 @@ SNF_D void collect_agg_wave(const View& v, const CallX& x, int task, LeadAgg* g)
   g->ps_val = best_len > 0 ? best_val : 0; g->ps_support = best_len > 0 ? best_len : -1; g->ps_other = other_ps;
   __syncthreads();
   // rescue_phasing sums the leads' NM ratios in list order (np.nanmean): gathered by the wave into the rows that are free now
-  g->nm_row = nullptr;
+  g->nm_row = nullptr; g->has_nm_mean = 0; g->nm_mean = 0.0;
   if (in_lds && 2 * n <= 2 * v.stage_cap && v.cfg.phase && v.cfg.mode_call_sample) {
     double* row = (double*)v.stage_w;     // rid + flg rows = stage_cap doubles
     for (int32_t k = lane; k < n; k += 64) row[k] = v.in_nm[(uint32_t)v.F_orig[v.FI[x.flo + k]]];
@@ -232,7 +233,7 @@ SNF_HD void collect_agg(const View& v, const CallX& x, int task, LeadAgg* g) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
   if (v.wave_uniform) { collect_agg_wave(v, x, task, g); return; }
 #endif
-  g->nm_row = nullptr;
+  g->nm_row = nullptr; g->has_nm_mean = 0; g->nm_mean = 0.0;
   int64_t hc[3] = {0, 0, 0};
   int32_t* a0 = v.w0 + x.flo;
   int32_t np_ = 0;
@@ -420,13 +421,18 @@ struct NmGet {
 };
 
 template <int DEPTH>
-SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int task, const double* nm_row) {
+SNF_HD void rescue_phasing(const View& v, snf_call_t& c, const CallX& x, int task, const LeadAgg& g) {
   const snf_config_t& cfg = v.cfg;
   if (!cfg.mode_call_sample) return;
-  int64_t n = x.fn, cnt = 0;
-  const NmGet get{v, x, nm_row};
-  for (int64_t i = 0; i < n; i++) { double nm = get.raw(i); if (nm == nm) cnt++; }
-  double sv_nm = np_pairwise_sum<DEPTH>(get, n) / (double)cnt;  // np.nanmean
+  int64_t n = x.fn;
+  double sv_nm;
+  if (g.has_nm_mean) sv_nm = g.nm_mean;
+  else {
+    int64_t cnt = 0;
+    const NmGet get{v, x, g.nm_row};
+    for (int64_t i = 0; i < n; i++) { double nm = get.raw(i); if (nm == nm) cnt++; }
+    sv_nm = np_pairwise_sum<DEPTH>(get, n) / (double)cnt;  // np.nanmean
+  }
   if (sv_nm > cfg.genotype_error || n <= 3) return;
   if (!c.ph_set || !c.ph_hp_pass) return;
   int hp = c.ph_hp;
@@ -463,7 +469,7 @@ SNF_HD void finalize_call(const View& v, snf_call_t& c, const CallX& x, const Le
   c.qc = c.qc && qc_sv_post_annotate(v, c, g, task);
   bool phasing_rescue = c.svtype != SNF_BND && iabs64(c.svlen) <= cfg.dev_maxsvlen_extra &&
                         c.support >= (int)((double)cfg.dev_minreads_extra * 0.60);
-  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing<DEPTH>(v, c, x, task, g.nm_row);
+  if (cfg.phase && !c.qc && phasing_rescue) rescue_phasing<DEPTH>(v, c, x, task, g);
 }
 
 SNF_HD void e1_finalize_body(int64_t i, const View& v) {

@@ -233,79 +233,115 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
 }
 
 // ------------------------------------------------------------------------------------------ e1w: finalize
+// A wave takes SNF_E1_BATCH consecutive calls: the aggregates of each call are formed by the whole wave, one call after the
+// other (phase A), then lane j runs the scalar tail of call j - QC, genotype, phase filters, rescue (phase B).  That tail is a
+// chain of dependent loads and double arithmetic on ONE lane; with one call per wave it was 24-50 % of the kernel's time.
+#define SNF_E1_BATCH 16
 template <int MINW>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int64_t n_unused) {
   __shared__ CallLds lds;
+  __shared__ LeadAgg s_agg[SNF_E1_BATCH];
+  __shared__ int s_ok[SNF_E1_BATCH];
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
   const int64_t n_calls = v.cnt->n_calls;
-  for (int64_t i = blockIdx.x; i < n_calls; i += gridDim.x) {
-    const int task = v.calls[i].task_index;
-    if (v.t_status[task] != SNF_TASK_OK) continue;
-    const CallX x = v.callx[i];
-    if (x.fn > SNF_WAVE) { if (lane == 0) big_push(v, 2, (int32_t)i); continue; }  // x_big<2>
-    const int n = x.fn;
-    bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
-    if (lane < n) {
-      const int32_t s = v.FI[x.flo + lane];
-      sel = v.F_sel[s] != 0;
-      const LeadRec r = v.Lrec[v.F_lpos[s]];
-      o = r.orig; strand = r.strand; hap = r.hap; rid = r.read_id;
-      const int32_t p = r.ps;
-      ps = (p == SNF_PS_NONE || p == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : p;
-      const int64_t qs = r.qry_start;
-      close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - qs) <= cfg.dev_min_close_edge_dist;
-    }
-    LeadAgg g;
-    g.nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
-    g.close_edge = __builtin_popcountll(__ballot(sel && close));
-    g.hp_val = 0; g.hp_support = -1; g.hp_other = 0; g.ps_val = 0; g.ps_support = -1; g.ps_other = 0;
-    if (cfg.phase) {
-      // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
-      bool later = false;
-      for (int k = 0; k < n; k++) {
-        const uint32_t rk = (uint32_t)wave_bcast_i32((int32_t)rid, k);
-        const bool sk = wave_bcast_i32(sel ? 1 : 0, k) != 0;
-        if (k > lane && sk && rk == rid) later = true;
+  const bool want_nm = cfg.phase && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
+  for (int64_t base = (int64_t)blockIdx.x * SNF_E1_BATCH; base < n_calls; base += (int64_t)gridDim.x * SNF_E1_BATCH) {
+    // ---- phase A: aggregates of the calls base .. base + 15, the whole wave on one call at a time
+    for (int j = 0; j < SNF_E1_BATCH; j++) {
+      const int64_t i = base + j;
+      if (lane == 0) s_ok[j] = 0;
+      if (i >= n_calls) continue;
+      const int task = v.calls[i].task_index;
+      if (v.t_status[task] != SNF_TASK_OK) continue;
+      const CallX x = v.callx[i];
+      if (x.fn > SNF_WAVE) { if (lane == 0) big_push(v, 2, (int32_t)i); continue; }  // x_big<2>
+      const int n = x.fn;
+      bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
+      if (lane < n) {
+        const int32_t s = v.FI[x.flo + lane];
+        sel = v.F_sel[s] != 0;
+        const LeadRec r = v.Lrec[v.F_lpos[s]];
+        o = r.orig; strand = r.strand; hap = r.hap; rid = r.read_id;
+        const int32_t p = r.ps;
+        ps = (p == SNF_PS_NONE || p == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : p;
+        const int64_t qs = r.qry_start;
+        close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - qs) <= cfg.dev_min_close_edge_dist;
       }
-      const bool contrib = sel && !later;
-      int64_t hc[3];
-      for (int hh = 0; hh < 3; hh++) hc[hh] = __builtin_popcountll(__ballot(contrib && hap == hh));
-      for (int hh = 0; hh < 3; hh++) if (hc[hh] > 0 && hc[hh] >= g.hp_support) { g.hp_support = hc[hh]; g.hp_val = hh; }
-      for (int hh = 0; hh < 3; hh++) if (hh != g.hp_val) g.hp_other += hc[hh];
-      const int np_ = __builtin_popcountll(__ballot(contrib));
-      // phase sets of the contributing reads, sorted (non-contributors sort behind: rank sort on a wider key)
-      const uint64_t key = contrib ? (((uint64_t)((uint32_t)ps ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
-      const int rank = wave_rank(key, n);
-      __syncthreads();
-      if (contrib) lds.buf[rank] = ps;
-      __syncthreads();
-      const int32_t s_ps = lds.buf[lane < np_ ? lane : 0];
-      const int32_t p_ps = __shfl_up(s_ps, 1, SNF_WAVE);
-      const bool st = lane < np_ && (lane == 0 || p_ps != s_ps);
-      const unsigned long long smask = __ballot(st);
-      const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
-      const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : np_) - lane) : 0;
-      const int maxc = wave_max32(len);
-      const unsigned long long best = __ballot(st && len == maxc);
-      const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
-      g.ps_val = __shfl(s_ps, bl, SNF_WAVE); g.ps_support = maxc;
-      g.ps_other = wave_sum64((st && s_ps != g.ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
-      __syncthreads();
+      double nm = 0.0;
+      if (want_nm && lane < n) nm = v.in_nm[o];              // in flight while the aggregates are formed
+      LeadAgg g;
+      g.nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
+      g.close_edge = __builtin_popcountll(__ballot(sel && close));
+      g.hp_val = 0; g.hp_support = -1; g.hp_other = 0; g.ps_val = 0; g.ps_support = -1; g.ps_other = 0;
+      g.nm_row = nullptr; g.has_nm_mean = 0; g.nm_mean = 0.0;
+      if (cfg.phase) {
+        // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
+        bool later = false;
+        for (int k = 0; k < n; k++) {
+          const uint32_t rk = (uint32_t)wave_bcast_i32((int32_t)rid, k);
+          const bool sk = wave_bcast_i32(sel ? 1 : 0, k) != 0;
+          if (k > lane && sk && rk == rid) later = true;
+        }
+        const bool contrib = sel && !later;
+        int64_t hc[3];
+        for (int hh = 0; hh < 3; hh++) hc[hh] = __builtin_popcountll(__ballot(contrib && hap == hh));
+        for (int hh = 0; hh < 3; hh++) if (hc[hh] > 0 && hc[hh] >= g.hp_support) { g.hp_support = hc[hh]; g.hp_val = hh; }
+        for (int hh = 0; hh < 3; hh++) if (hh != g.hp_val) g.hp_other += hc[hh];
+        const int np_ = __builtin_popcountll(__ballot(contrib));
+        // phase sets of the contributing reads, sorted (non-contributors sort behind: rank sort on a wider key)
+        const uint64_t key = contrib ? (((uint64_t)((uint32_t)ps ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+        const int rank = wave_rank(key, n);
+        __syncthreads();
+        if (contrib) lds.buf[rank] = ps;
+        __syncthreads();
+        const int32_t s_ps = lds.buf[lane < np_ ? lane : 0];
+        const int32_t p_ps = __shfl_up(s_ps, 1, SNF_WAVE);
+        const bool st = lane < np_ && (lane == 0 || p_ps != s_ps);
+        const unsigned long long smask = __ballot(st);
+        const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+        const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : np_) - lane) : 0;
+        const int maxc = wave_max32(len);
+        const unsigned long long best = __ballot(st && len == maxc);
+        const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
+        g.ps_val = __shfl(s_ps, bl, SNF_WAVE); g.ps_support = maxc;
+        g.ps_other = wave_sum64((st && s_ps != g.ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
+        __syncthreads();
+      }
+      if (want_nm) {
+        // np.nanmean(nm of the leads, list order) with numpy's pairwise summation for n <= 128 (snf_exact.h::np_pairwise_sum):
+        // fewer than 8 values: left to right; otherwise eight accumulators r[q] over the positions q, q + 8, ... below
+        // n - n % 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right.  NaN counts as 0 in the sum.
+        const int cnt = __builtin_popcountll(__ballot(lane < n && nm == nm));
+        lds.nm[lane] = (lane < n && nm == nm) ? nm : 0.0;
+        __syncthreads();
+        double res = 0.0;
+        if (n < 8) { for (int q = 0; q < n; q++) res += lds.nm[q]; }
+        else {
+          const int n8 = n - n % 8;
+          double r = 0.0;
+          if (lane < 8) { r = lds.nm[lane]; for (int q = 8 + lane; q < n8; q += 8) r += lds.nm[q]; }
+          double rq[8];
+          for (int q = 0; q < 8; q++) rq[q] = __shfl(r, q, SNF_WAVE);
+          res = ((rq[0] + rq[1]) + (rq[2] + rq[3])) + ((rq[4] + rq[5]) + (rq[6] + rq[7]));
+          for (int q = n8; q < n; q++) res += lds.nm[q];
+        }
+        g.nm_mean = res / (double)cnt; g.has_nm_mean = 1;
+        __syncthreads();
+      }
+      if (lane == 0) { s_agg[j] = g; s_ok[j] = 1; }
     }
-    // rescue_phasing (lane 0 below) sums the leads' NM ratios in list order: one gather per lane here instead of a chain of
-    // 3 x n dependent loads there
-    g.nm_row = nullptr;
-    if (cfg.phase && cfg.mode_call_sample) {
-      lds.nm[lane] = lane < n ? v.in_nm[o] : 0.0;
-      __syncthreads();
-      g.nm_row = lds.nm;
-    }
-    if (lane == 0) {
+    __syncthreads();
+    // ---- phase B: the scalar tail, one call per lane
+    if (lane < SNF_E1_BATCH && s_ok[lane]) {
+      const int64_t i = base + lane;
       snf_call_t c = v.calls[i];
-      finalize_call<1>(v, c, x, g, task);   // x.fn <= 64 leads
+      const CallX x = v.callx[i];
+      const LeadAgg g = s_agg[lane];
+      finalize_call<1>(v, c, x, g, c.task_index);   // x.fn <= 64 leads
       store_final_fields(v.calls[i], c);
     }
+    __syncthreads();
   }
 }
 
