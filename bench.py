@@ -347,10 +347,13 @@ def run_calling(ctx):
     run_passes = run_passes_strong if strong else run_passes_weak
     run_passes(max(1, args.warmup) if strong else -(-args.warmup // W) * W)  # >= warmup passes, the same number on every handle
     barrier()
+    import gc
+    gc.collect(); gc.disable()           # no collector pauses inside the ~50 ms that are timed
     t0 = time.perf_counter()
     run_passes(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     n_calls = n_calls_box[0]
     timings = batches[0].timings()  # per-kernel HIP-event times of handle 0's LAST pass in the timed region, on its streams
     # reference point outside the timed region: the same pass with ONE batch in flight (per-pass latency)
