@@ -681,6 +681,18 @@ void do_upload(snf_batch_impl* b) {
     v.key32 = (!sort64 && v.key_nbits + 1 <= 32) ? 1 : 0;
   }
   v.pool_len = b->h_pool_off.back(); v.pool_cap = 2 * v.pool_len + 16;
+  v.pool_extra_base = v.pool_len; v.pool_slice = 0;
+#ifndef SNF_EMU
+  // Fused sequences (merge_inner) go behind the input sequences.  All of them together are at most pool_len bytes, and that
+  // much is kept for reservations through the shared counter; in front of it every resident wave of d1w_refine owns a private
+  // slice it fills without any atomic (the shared counter is one address: ~10^4 returning atomics per pass queue up in L2 and
+  // were a third of that kernel's time).  A wave whose slice is full falls back to the counter.
+  if (b->slots_d1w > 0 && getenv("SNF_NO_POOL_SLICES") == nullptr) {
+    v.pool_slice = (v.pool_len / b->slots_d1w) & ~(int64_t)15;
+    v.pool_extra_base = v.pool_len + v.pool_slice * b->slots_d1w;
+    v.pool_cap = v.pool_extra_base + v.pool_len + 16;
+  }
+#endif
   // everything allocated below fits one slab of this size (per-lead arrays ~1.9 KB/lead, the pool twice, the reads);
   // anything beyond it simply opens another slab
   b->slab_next = (size_t)N * 1408 + (size_t)v.pool_cap + (size_t)R * 96 + ((size_t)4 << 20);
@@ -1283,7 +1295,9 @@ void collect_timings(snf_batch_impl* b) {
   if (getenv("SNF_PROF")) {
     static const char* nm[9] = {"setup+table", "kmers+probes", "chain", "segments", "run filter", "votes", "barrier+vote+store", "longest workgroup", "workgroups"};
     for (int c = 0; c < 2; c++)
-      for (int k = 0; k < 9; k++) fprintf(stderr, "[SNF_CONS_PROFILE] %s %-20s %llu\n", c ? "LARGE" : "SMALL", nm[k], b->h_cnt->dbg[c * 16 + k]);
+      for (int k = 0; k < 9; k++) if (c * 16 + k < 24) fprintf(stderr, "[SNF_CONS_PROFILE] %s %-20s %llu\n", c ? "LARGE" : "SMALL", nm[k], b->h_cnt->dbg[c * 16 + k]);
+    static const char* rn[6] = {"load + first appearance", "rank + permute", "gathers + fuse scans", "reserve + copy + compact", "F stores", "resplit + next"};
+    for (int k = 0; k < 6; k++) fprintf(stderr, "[SNF_CONS_PROFILE] d1w %-26s %llu\n", rn[k], b->h_cnt->dbg[24 + k]);
   }
 #endif
 #ifndef SNF_EMU
@@ -1317,9 +1331,9 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   if (v.prof) {
     const Counts& c = *b->h_cnt;
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
-                    "fallback %lld alt bytes %lld | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+                    "fallback %lld alt bytes %lld fused bytes %llu | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
-            (long long)c.alt_total, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6]);
+            (long long)c.alt_total, c.pool_extra_used, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6]);
   }
   int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
   int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;

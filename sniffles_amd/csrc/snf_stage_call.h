@@ -134,7 +134,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
           if (!seq_ok) { Fseqlen[m] = -1; Fseqoff[m] = 0; }
           else if (nparts == 1) { Fseqlen[m] = rh.seq_len; Fseqoff[m] = rh.seq_off; }
           else {  // curr_lead.seq += to_merge.seq: new string in the fused part of the pool
-            int64_t off = v.pool_len + (int64_t)pool_reserve(v, (unsigned long long)seq_total);
+            int64_t off = v.pool_extra_base + (int64_t)pool_reserve(v, (unsigned long long)seq_total);
             if (off + seq_total > v.pool_cap) { atomic_or_i32(&v.cnt->overflow, 1); Fseqlen[m] = -1; Fseqoff[m] = 0; }
             else {
               int64_t w = off;

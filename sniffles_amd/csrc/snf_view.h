@@ -91,6 +91,8 @@ struct View {
   int32_t prof;       // SNF_PROF=1: phase cycle counters in e45w_consensus
   int64_t N, R, NTR;
   int64_t pool_len, pool_cap;
+  int64_t pool_extra_base;   // fused sequences reserved through Counts::pool_extra_used start here (pool_len, or behind the private slices)
+  int64_t pool_slice;        // d1w_refine: bytes of fused-sequence space every resident wave owns at pool_len + blockIdx.x * pool_slice (0: none)
   Counts* cnt;
 
   // ---- tasks [T] / [T+1]

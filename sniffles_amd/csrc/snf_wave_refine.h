@@ -71,6 +71,15 @@ struct WaveLds {
   const int src_ = lds.perm[lane < n_ ? lane : 0];
 #define SNF_GATHER(x) __shfl((x), src_, SNF_WAVE)
 
+#ifdef SNF_CONS_PROFILE
+#define SNF_RT_DECL unsigned long long rt_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long rt_t = __builtin_amdgcn_s_memtime();
+#define SNF_RT(k) do { const unsigned long long rt_n = __builtin_amdgcn_s_memtime(); rt_acc[k] += rt_n - rt_t; rt_t = rt_n; } while (0)
+#define SNF_RT_FLUSH() do { if (lane == 0) for (int pk = 0; pk < 6; pk++) atomicAdd(&v.cnt->dbg[24 + pk], rt_acc[pk]); } while (0)
+#else
+#define SNF_RT_DECL
+#define SNF_RT(k) do { } while (0)
+#define SNF_RT_FLUSH() do { } while (0)
+#endif
 // one block = one wave = one merged cluster per loop iteration (grid-stride over clusters)
 __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_unused) {
   __shared__ WaveLds lds;
@@ -84,7 +93,10 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
   ClusterHdr hd_nxt = blockIdx.x + stride < n_clusters ? v.chdr[blockIdx.x + stride] : ClusterHdr{};
   LeadRec rec_cur{};
   if (lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
+  SNF_RT_DECL
+  int64_t slice_used = 0;     // bytes of this wave's private fused-sequence slice that are taken
   for (int64_t c = blockIdx.x; c < n_clusters; c += stride) {
+    SNF_RT(5);   // tail of the previous cluster (stores, resplit)
     const ClusterHdr hd = hd_cur; const LeadRec rec = rec_cur;
     hd_cur = hd_nxt;
     if (c + stride < n_clusters && lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
@@ -116,9 +128,11 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         if (fa < 0 && qi == qname) fa = i;
       }
       uint64_t key = act ? (((uint64_t)(uint32_t)fa << 40) | ((uint64_t)((uint32_t)ref_start ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+      SNF_RT(0);   // records in registers, first appearance
       const int rank = wave_rank(key, n);
       const int n_ = n;
       SNF_PERMUTE_SETUP(rank, act)
+      SNF_RT(1);   // rank + permute
       // everything below is in sorted order: lane r holds the r-th lead of the (read, ref_start) order
       const int s_fa = SNF_GATHER(fa);
       const int32_t s_rs = SNF_GATHER(ref_start), s_re = SNF_GATHER(ref_end), s_qs = SNF_GATHER(qry_start), s_qe = SNF_GATHER(qry_end);
@@ -154,15 +168,22 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int64_t tot_svlen = e_svlen - x_svlen, tot_seq = e_seq - x_seq;
       const bool seq_ok = (e_has - x_has) == nparts;
       // fused sequence: concatenation in the pool's fused region (curr_lead.seq += to_merge.seq)
+      SNF_RT(2);   // gathers, fuse decisions, scans
       int64_t new_off = 0; bool need_copy = start && seq_ok && nparts > 1;
       if (__ballot(need_copy)) {  // one atomic per wave (same-address atomics serialise in L2): lanes take consecutive slices
         const int64_t mine = need_copy ? tot_seq : 0;
         const int64_t incl = wave_incl_scan64(mine, lane);
         const int64_t wave_total = __shfl(incl, 63, SNF_WAVE);
-        int64_t base = 0;
-        if (lane == 0) base = (int64_t)atomicAdd(&v.cnt->pool_extra_used, (unsigned long long)wave_total);
-        base = __shfl(base, 0, SNF_WAVE);
-        new_off = v.pool_len + base + (incl - mine);
+        int64_t base;
+        if (slice_used + wave_total <= v.pool_slice) {        // (wave-uniform) this wave's own slice: no atomic
+          base = v.pool_len + (int64_t)blockIdx.x * v.pool_slice + slice_used;
+          slice_used += wave_total;
+        } else {
+          int64_t got = 0;
+          if (lane == 0) got = (int64_t)atomicAdd(&v.cnt->pool_extra_used, (unsigned long long)wave_total);
+          base = v.pool_extra_base + __shfl(got, 0, SNF_WAVE);
+        }
+        new_off = base + (incl - mine);
         if (need_copy && new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
       }
       unsigned long long cmask = __ballot(need_copy);
@@ -172,7 +193,11 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         int64_t dst = __shfl(new_off, r0, SNF_WAVE);
         for (int z = r0; z <= r1; z++) {
           const int64_t so = __shfl(s_seq_off, z, SNF_WAVE); const int32_t sl = __shfl(s_seq_len, z, SNF_WAVE);
-          for (int32_t b = lane; b < sl; b += SNF_WAVE) v.pool[dst + b] = v.pool[so + b];
+          // 16 bytes per lane and step (any alignment), then the tail byte-wise
+          typedef uint4 __attribute__((aligned(1))) u128_any;
+          const int32_t nfull = sl & ~15;
+          for (int32_t b = lane * 16; b < nfull; b += SNF_WAVE * 16) *(u128_any*)(v.pool + dst + b) = *(const u128_any*)(v.pool + so + b);
+          if (nfull + lane < sl) v.pool[dst + nfull + lane] = v.pool[so + nfull + lane];
           dst += sl;
         }
       }
@@ -191,6 +216,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       f_seq_len = __shfl(t_seq_len, src2, SNF_WAVE);
       f_seq_off = __shfl(t_seq_off, src2, SNF_WAVE);
     }
+    SNF_RT(3);   // pool reservation, byte copies, compaction
     const bool fact = lane < m;
     if (fact) {
       v.F_orig[lo + lane] = f_orig; v.F_svlen[lo + lane] = f_svlen; v.F_lpos[lo + lane] = lo + f_lp;
@@ -228,6 +254,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       continue;
     }
 
+    SNF_RT(4);   // F stores
     // ---- resplit on |svlen| bins of 20 (cluster.py:125-161)
     if (cfg.dev_no_resplit_repeat || cfg.dev_no_resplit) {
       if (fact) v.FI[lo + lane] = lo + lane;
@@ -288,6 +315,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       __syncthreads();
     }
   }
+  SNF_RT_FLUSH();
 }
 
 }  // namespace snf
