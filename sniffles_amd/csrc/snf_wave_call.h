@@ -73,17 +73,27 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
   const int64_t n_rc = v.cnt->n_rc;
-  for (int64_t r = blockIdx.x; r < n_rc; r += gridDim.x) {
-    const int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
+  // software pipeline over this wave's refined clusters (the kernel is a chain of dependent loads: table entry -> cluster head
+  // -> group, lead order -> fused lead -> record): the table entry of item k+2, the cluster head and the lead order of item
+  // k+1 are requested while item k is worked on, so an item starts two round trips deep instead of six
+  const int64_t stride = gridDim.x;
+  int32_t flo1 = 0, n1 = 0, c1 = 0, flo2 = 0, n2 = 0, c2 = 0, h1 = 0, slot1 = 0;
+  if ((int64_t)blockIdx.x < n_rc) { flo1 = v.rc_lo[blockIdx.x]; n1 = v.rc_n[blockIdx.x]; c1 = v.rc_cluster[blockIdx.x]; }
+  if ((int64_t)blockIdx.x + stride < n_rc) { flo2 = v.rc_lo[blockIdx.x + stride]; n2 = v.rc_n[blockIdx.x + stride]; c2 = v.rc_cluster[blockIdx.x + stride]; }
+  if ((int64_t)blockIdx.x < n_rc) { h1 = v.cl_head[c1]; if (lane < n1 && n1 <= SNF_WAVE) slot1 = v.FI[flo1 + lane]; }
+  for (int64_t r = blockIdx.x; r < n_rc; r += stride) {
+    const int32_t flo = flo1, n = n1, c = c1, h = h1; const int32_t slot_pre = slot1;
+    flo1 = flo2; n1 = n2; c1 = c2;
+    if (r + stride < n_rc) { h1 = v.cl_head[c1]; if (lane < n1 && n1 <= SNF_WAVE) slot1 = v.FI[flo1 + lane]; }
+    if (r + 2 * stride < n_rc) { flo2 = v.rc_lo[r + 2 * stride]; n2 = v.rc_n[r + 2 * stride]; c2 = v.rc_cluster[r + 2 * stride]; }
     if (n > SNF_WAVE) { if (lane == 0) big_push(v, 1, (int32_t)r); continue; }  // x_big<1>
-    const int32_t h = v.cl_head[c];
     const int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
     const bool act = lane < n;
     int32_t slot = 0; uint32_t o = 0; int32_t svl = 0, rs = 0; uint32_t qn = 0;
     int mapq = 0, strand = 0, is_sa = 0, noninline = 0; double nm = 0;
     int32_t mctg = 0, mpos = 0; int bfirst = 0, brev = 0;
     if (act) {
-      slot = v.FI[flo + lane]; svl = v.F_svlen[slot];
+      slot = slot_pre; svl = v.F_svlen[slot];
       const LeadRec r = v.Lrec[v.F_lpos[slot]];
       o = r.orig; rs = r.ref_start; qn = r.qname; mapq = r.mapq; strand = r.strand; is_sa = r.is_sa;
       noninline = r.source != SNF_SRC_INLINE;

@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02ak; mkdir -p $O
+O=gpurun_out/r02al; mkdir -p $O
 export TMPDIR=/tmp SNF_BENCH_TOPK=12
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
 tail -3 $O/pytest.log
