@@ -284,12 +284,12 @@ def config_struct(cfg) -> snf_config_t:
 
 
 def _ptr(a: np.ndarray, ctype):
-    return a.ctypes.data_as(C.POINTER(ctype))
+    return C.cast(a.__array_interface__["data"][0], C.POINTER(ctype))     # (a.ctypes.data_as is ~4 us per array)
 
 
 def task_struct(ti: TaskInput, keep: list) -> snf_task_input_t:
     """Borrow the numpy buffers of `ti` into a snf_task_input_t (arrays appended to `keep` stay alive)."""
-    ti.validate()
+    ti.check_layout()      # values are validated by the library while it stages the columns
     t = snf_task_input_t()
     t.task_id, t.sv_id_start, t.contig_len = ti.task_id, ti.sv_id_start, ti.contig_len
     null_rank = -1

@@ -609,30 +609,34 @@ namespace {
 double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
 
 // one task's columns -> their slices of the staging arena; every check of the old element-wise add_task happens here
-void stage_task(const snf_task_input_t& t, int ti, uint8_t* st, const size_t* off, size_t pool_at, int64_t l0, int64_t r0, int64_t p0,
-                int32_t* rend_max) {
-  (void)ti;
-  const int64_t n = t.n_leads, r = t.n_reads;
+// Staging of one task's input into the pinned arena, in pieces that host threads take independently:
+//   stage_leads: rows [i0, i1) of the 22 lead columns (validated, sequence offsets rebased into the batch pool)
+//   stage_pool:  bytes [b0, b1) of the task's sequence pool (checked for the consensus gap symbol)
+//   stage_reads: the task's read table (sortedness enforced: the rank queries need ascending starts)
+void stage_leads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int64_t l0, int64_t p0, int64_t i0, int64_t i1) {
   const void* src[22] = {t.ref_start, t.ref_end, t.qry_start, t.qry_end, t.svlen, t.read_len, t.qname_id, t.read_id, t.ps_rank,
                          t.mate_contig, t.mate_ref_start, t.seq_len, t.seq_off, t.nm, t.svtype, t.strand, t.mapq, t.source, t.hap,
                          t.is_sa, t.bnd_is_first, t.bnd_is_reverse};
   for (int c = 0; c < 22; c++) {
     if (c == IC_SEQ_OFF) continue;
-    if (n) memcpy(st + off[c] + (size_t)l0 * kInElem[c], src[c], (size_t)n * kInElem[c]);
+    memcpy(st + off[c] + (size_t)(l0 + i0) * kInElem[c], (const uint8_t*)src[c] + (size_t)i0 * kInElem[c], (size_t)(i1 - i0) * kInElem[c]);
   }
   int64_t* so = (int64_t*)(st + off[IC_SEQ_OFF]) + l0;
-  for (int64_t i = 0; i < n; i++) {
+  for (int64_t i = i0; i < i1; i++) {
     if (t.svtype[i] >= SNF_NTYPES) fail("svtype code out of range");
     if (t.hap[i] > 2) fail("hap must be 0, 1 or 2 (leadprov.py:403)");
     const int32_t sl = t.seq_len[i];
     if (sl >= 0 && (t.seq_off[i] < 0 || t.seq_off[i] + sl > t.seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
     so[i] = sl >= 0 ? t.seq_off[i] + p0 : 0;      // rebased into the batch pool
   }
+}
+void stage_pool(const snf_task_input_t& t, uint8_t* st, size_t pool_at, int64_t p0, int64_t b0, int64_t b1) {
   // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' would be a gap there
-  if (t.seq_pool_len > 0) {
-    if (memchr(t.seq_pool, '-', (size_t)t.seq_pool_len)) fail("INS sequences must not contain '-'");
-    memcpy(st + pool_at + (size_t)p0, t.seq_pool, (size_t)t.seq_pool_len);
-  }
+  if (memchr(t.seq_pool + b0, '-', (size_t)(b1 - b0))) fail("INS sequences must not contain '-'");
+  memcpy(st + pool_at + (size_t)(p0 + b0), t.seq_pool + b0, (size_t)(b1 - b0));
+}
+void stage_reads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int64_t r0, int32_t* rend_max) {
+  const int64_t r = t.n_reads;
   // reads: BAM order == ascending start; enforce (stable) so the rank queries are valid
   int32_t* rs = (int32_t*)(st + off[IC_RSTART]) + r0; int32_t* re = (int32_t*)(st + off[IC_REND]) + r0;
   uint8_t* rh = st + off[IC_RHP] + r0;
@@ -731,40 +735,52 @@ void do_upload(snf_batch_impl* b) {
   {
     std::lock_guard<std::mutex> hold(g_stage.mu);   // one upload at a time stages through the arena
     uint8_t* st = (uint8_t*)g_stage.ensure(at + 256);
-    std::vector<int> order((size_t)T);
-    for (int t = 0; t < T; t++) order[(size_t)t] = t;
-    std::sort(order.begin(), order.end(), [&](int x, int y) {   // biggest task first
-      const int64_t wx = b->tasks[x].n_leads * 72 + b->tasks[x].seq_pool_len + b->tasks[x].n_reads * 9;
-      const int64_t wy = b->tasks[y].n_leads * 72 + b->tasks[y].seq_pool_len + b->tasks[y].n_reads * 9;
-      return wx != wy ? wx > wy : x < y; });
-    int nth = (int)std::thread::hardware_concurrency(); if (nth > 16) nth = 16; if (nth > T) nth = T; if (nth < 1) nth = 1;
-    if (const char* e = getenv("SNF_UPLOAD_THREADS")) { nth = atoi(e); if (nth < 1) nth = 1; }
-    std::atomic<int> next{0}; std::mutex emu; std::string err;
-    auto work = [&]() {
-      for (;;) {
-        const int k = next.fetch_add(1);
-        if (k >= T) return;
-        const int t = order[(size_t)k];
-        if (b->task_on_device[(size_t)t]) {   // born in HBM (extraction): copied device-to-device below; its reads end inside the contig
-          b->h_rend_max[(size_t)t] = b->tasks[(size_t)t].contig_len;
-          continue;
-        }
-        try {
-          stage_task(b->tasks[(size_t)t], t, st, off, pool_at, b->h_lead_off[(size_t)t], b->h_read_off[(size_t)t], b->h_pool_off[(size_t)t],
-                     &b->h_rend_max[(size_t)t]);
-        } catch (const snf::Error& e) { std::lock_guard<std::mutex> g(emu); if (err.empty()) err = e.msg; }
+    // Work items of at most ~4 MB: lead rows and read tables first (the columns' copy to HBM then runs while the sequence
+    // pools are still being staged), pool pieces second.  Up to 32 host threads take them from a counter: a whole genome is
+    // ~0.46 GB, one thread copies ~5 GB/s including the checks.
+    struct Item { int t; int kind; int64_t lo, hi; };
+    std::vector<Item> items[2];
+    for (int t = 0; t < T; t++) {
+      if (b->task_on_device[(size_t)t]) {   // born in HBM (extraction): copied device-to-device below; its reads end inside the contig
+        b->h_rend_max[(size_t)t] = b->tasks[(size_t)t].contig_len;
+        continue;
       }
-    };
-    if (nth == 1) work();
-    else {
-      std::vector<std::thread> ths;
-      for (int k = 0; k < nth; k++) ths.emplace_back(work);
-      for (auto& th : ths) th.join();
+      const snf_task_input_t& q = b->tasks[(size_t)t];
+      for (int64_t i = 0; i < q.n_leads; i += 49152) items[0].push_back({t, 0, i, i + 49152 < q.n_leads ? i + 49152 : q.n_leads});
+      items[0].push_back({t, 2, 0, 0});
+      for (int64_t p = 0; p < q.seq_pool_len; p += (4 << 20)) items[1].push_back({t, 1, p, p + (4 << 20) < q.seq_pool_len ? p + (4 << 20) : q.seq_pool_len});
     }
-    if (!err.empty()) fail(err);
+    int nth = (int)std::thread::hardware_concurrency(); if (nth > 32) nth = 32; if (nth < 1) nth = 1;
+    if (const char* e = getenv("SNF_UPLOAD_THREADS")) { nth = atoi(e); if (nth < 1) nth = 1; }
+    std::mutex emu; std::string err;
+    auto run_items = [&](const std::vector<Item>& its) {
+      std::atomic<size_t> next{0};
+      auto work = [&]() {
+        for (;;) {
+          const size_t k = next.fetch_add(1);
+          if (k >= its.size()) return;
+          const Item& it = its[k];
+          const snf_task_input_t& q = b->tasks[(size_t)it.t];
+          try {
+            if (it.kind == 0) stage_leads(q, st, off, b->h_lead_off[(size_t)it.t], b->h_pool_off[(size_t)it.t], it.lo, it.hi);
+            else if (it.kind == 1) stage_pool(q, st, pool_at, b->h_pool_off[(size_t)it.t], it.lo, it.hi);
+            else stage_reads(q, st, off, b->h_read_off[(size_t)it.t], &b->h_rend_max[(size_t)it.t]);
+          } catch (const snf::Error& e) { std::lock_guard<std::mutex> g(emu); if (err.empty()) err = e.msg; }
+        }
+      };
+      const int n_use = (size_t)nth < its.size() ? nth : (int)its.size();
+      if (n_use <= 1) work();
+      else {
+        std::vector<std::thread> ths;
+        for (int k = 0; k < n_use; k++) ths.emplace_back(work);
+        for (auto& th : ths) th.join();
+      }
+      if (!err.empty()) fail(err);
+    };
+    run_items(items[0]);
+    h2d(b, d_in, st, col_bytes);                       // (asynchronous: pinned source) overlaps the staging of the pools
+    run_items(items[1]);
     t_staged = now_ms();
-    // ---- (2) two large copies
-    h2d(b, d_in, st, col_bytes);
     h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
     // tasks whose columns are already in HBM (snf_batch_add_task_device): device-to-device into their slices, sequence
     // offsets rebased into the batch pool by a kernel

@@ -109,8 +109,13 @@ class Batch:
         self.lib = _lib or load()
         self.tasks = list(tasks)
         self._h = C.c_void_p()
+        import os
+        import time
+        prof = os.environ.get("SNF_PROF") is not None
+        t0 = time.perf_counter()
         cs = abi.config_struct(cfg)
         _check(self.lib, self.lib.snf_batch_create(C.byref(cs), device, C.byref(self._h)))
+        t1 = time.perf_counter()
         try:
             from .soa import DeviceTaskInput
             keep = []       # the task arrays are borrowed by the library until snf_batch_upload returns
@@ -121,7 +126,13 @@ class Batch:
                     continue
                 ts = abi.task_struct(ti, keep)
                 _check(self.lib, self.lib.snf_batch_add_task(self._h, C.byref(ts)))
+            t2 = time.perf_counter()
             _check(self.lib, self.lib.snf_batch_upload(self._h))
+            if prof:
+                import sys
+                t3 = time.perf_counter()
+                print(f"[SNF_PROF] Batch(): create {1e3 * (t1 - t0):.1f} ms, add_task x{len(self.tasks)} {1e3 * (t2 - t1):.1f} ms, "
+                      f"upload {1e3 * (t3 - t2):.1f} ms", file=sys.stderr)
         except Exception:
             self.close()
             raise

@@ -78,7 +78,10 @@ class TaskInput:
     def n_reads(self) -> int:
         return int(self.read_start.shape[0])
 
-    def validate(self) -> None:
+    def check_layout(self) -> None:
+        """Types, shapes and contiguity only - what has to hold before raw pointers are handed to the library.  The values
+        (type codes, haplotypes, sequence ranges, read intervals) are checked by the library while it stages the columns
+        (`snf_batch_upload` fails with the reason), so the binding does not walk every column a second time."""
         n = self.n_leads
         for name, dt in LEAD_FIELDS:
             a = self.leads[name]
@@ -86,6 +89,14 @@ class TaskInput:
                 raise ValueError(f"lead field {name}: want {np.dtype(dt)}[{n}] contiguous, got {a.dtype}{a.shape}")
         if self.seq_pool.dtype != np.uint8:
             raise ValueError("seq_pool must be uint8")
+        for a, dt in ((self.read_start, np.int32), (self.read_end, np.int32), (self.read_hp, np.uint8)):
+            if a.dtype != dt or a.shape != (self.n_reads,):
+                raise ValueError("read arrays malformed")
+        if (self.tr_start is None) != (self.tr_end is None):
+            raise ValueError("tr_start/tr_end must both be set or both None")
+
+    def validate(self) -> None:
+        self.check_layout()
         sl, so = self.leads["seq_len"], self.leads["seq_off"]
         m = sl >= 0
         if m.any() and int((so[m] + sl[m]).max()) > self.seq_pool.shape[0]:
@@ -94,11 +105,6 @@ class TaskInput:
             raise ValueError("hap must be 0,1,2 (leadprov.py:403 indexes a 3-array with int(ld.hap))")
         if np.any(self.leads["svtype"] >= N_SVTYPES):
             raise ValueError("svtype code out of range")
-        for a, dt in ((self.read_start, np.int32), (self.read_end, np.int32), (self.read_hp, np.uint8)):
-            if a.dtype != dt or a.shape != (self.n_reads,):
-                raise ValueError("read arrays malformed")
-        if (self.tr_start is None) != (self.tr_end is None):
-            raise ValueError("tr_start/tr_end must both be set or both None")
 
     def qname(self, qid: int) -> str:
         return self.qnames[qid] if self.qnames is not None else f"q{qid}"
