@@ -492,7 +492,7 @@ def wall_clock(cfg, tasks, device):
     del os.environ["SNF_PROF"]
     b.call_candidates(); b.finalize(); b.sync()
     t2 = time.perf_counter()
-    res = b.fetch(1)
+    res = b.fetch(1, copy=False)          # views of the library's pinned result block, as sniffles_amd.parallel.Task reads them
     t3 = time.perf_counter()
     n = 0
     for t, ti in enumerate(tasks):
@@ -517,7 +517,7 @@ def wall_clock(cfg, tasks, device):
     t6 = time.perf_counter()
     return dict(batched=batched, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
                 note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
-                     "materialise = SVCall Python objects (host)")
+                     "d2h = results in the library's pinned block (read in place); materialise = SVCall Python objects (host)")
 
 
 def _input_bytes(tasks):
