@@ -239,3 +239,34 @@ def test_columnar_store_equals_the_object_replay_emu(monkeypatch):
 @pytest.mark.gpu
 def test_columnar_store_equals_the_object_replay_gpu(monkeypatch):
     check_columns_equal_objects(None, monkeypatch)
+
+
+def test_candidate_store_helpers_reject_malformed_input():
+    """The C helpers of the columnar store (sniffles_amd._snf_fast) raise instead of reading out of bounds."""
+    import numpy as np
+    from sniffles_amd import abi
+    fast = sv._load_fast()
+    if fast is None:
+        pytest.skip("C extension not built")
+    # flush_windows: key / bin lengths must agree
+    with pytest.raises(ValueError):
+        fast.flush_windows(np.zeros(3, np.int64), np.zeros(2, np.int32), 100, 25, False)
+    wend, wbin, wsize = fast.flush_windows(np.array([0, 0, 0, 1], np.int64), np.array([100, 100, 300, 0], np.int32), 100, 2, False)
+    assert np.frombuffer(wend, np.int64).tolist() == [2, 3, 4] and np.frombuffer(wbin, np.int32).tolist() == [100, 300, 0]
+    assert np.frombuffer(wsize, np.int32).tolist() == [100, 100, 100]
+    # gather_pool: an index beyond the table
+    with pytest.raises(ValueError):
+        fast.gather_pool(np.array([0, 2, 5], np.int64), b"abcde", np.array([2], np.int64))
+    off, pool = fast.gather_pool(np.array([0, 2, 5], np.int64), b"abcde", np.array([1, 0, 1], np.int64))
+    assert pool == b"cdeabcde" and np.frombuffer(off, np.int64).tolist() == [0, 3, 5, 8]
+    # collect: one entry per reader expected
+    with pytest.raises(TypeError):
+        fast.collect([[None, None]], np.zeros(1, np.int32), tuple(sv.TYPES), 3, {})
+    objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect([], np.zeros(0, np.int32), tuple(sv.TYPES), 3, {})
+    assert objs == [] and len(rec) == 0 and np.frombuffer(aoff, np.int64).tolist() == [0]
+    # group_calls: a group index beyond the table
+    out = np.zeros(1, abi.GROUP_OUT_DTYPE)
+    with pytest.raises(ValueError):
+        fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, [], out, np.array([3], np.int64), np.array([0, 0], np.int64),
+                         np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int32),
+                         np.zeros(2, np.int32), [], np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 5, "", False)
