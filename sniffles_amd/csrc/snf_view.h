@@ -197,6 +197,7 @@ struct View {
   int32_t* big_list;         // [3][64][big_cap]
   int64_t big_cap;
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
+  int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32; default 8)
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative
   int32_t* w7;               // [N+1] scratch of the cooperative sorts (same slot space as w0..w6)
   // x_big<0> keeps a cluster in LDS: its packed lead records and the eight scratch rows (stage_cap entries each); null otherwise

@@ -243,22 +243,23 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
 }
 
 // ------------------------------------------------------------------------------------------ e1w: finalize
-// A wave takes SNF_E1_BATCH consecutive calls: the aggregates of each call are formed by the whole wave, one call after the
+// A wave takes View::e1_batch (8) consecutive calls: the aggregates of each call are formed by the whole wave, one call after the
 // other (phase A), then lane j runs the scalar tail of call j - QC, genotype, phase filters, rescue (phase B).  That tail is a
 // chain of dependent loads and double arithmetic on ONE lane; with one call per wave it was 24-50 % of the kernel's time.
-#define SNF_E1_BATCH 16
+#define SNF_E1_BATCH_MAX 32
 template <int MINW>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int64_t n_unused) {
   __shared__ CallLds lds;
-  __shared__ LeadAgg s_agg[SNF_E1_BATCH];
-  __shared__ int s_ok[SNF_E1_BATCH];
+  __shared__ LeadAgg s_agg[SNF_E1_BATCH_MAX];
+  __shared__ int s_ok[SNF_E1_BATCH_MAX];
+  const int E1B = v.e1_batch;      // calls per wave (the launch uses the same number)
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
   const int64_t n_calls = v.cnt->n_calls;
   const bool want_nm = cfg.phase && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
-  for (int64_t base = (int64_t)blockIdx.x * SNF_E1_BATCH; base < n_calls; base += (int64_t)gridDim.x * SNF_E1_BATCH) {
+  for (int64_t base = (int64_t)blockIdx.x * E1B; base < n_calls; base += (int64_t)gridDim.x * E1B) {
     // ---- phase A: aggregates of the calls base .. base + 15, the whole wave on one call at a time
-    for (int j = 0; j < SNF_E1_BATCH; j++) {
+    for (int j = 0; j < E1B; j++) {
       const int64_t i = base + j;
       if (lane == 0) s_ok[j] = 0;
       if (i >= n_calls) continue;
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
     }
     __syncthreads();
     // ---- phase B: the scalar tail, one call per lane
-    if (lane < SNF_E1_BATCH && s_ok[lane]) {
+    if (lane < E1B && s_ok[lane]) {
       const int64_t i = base + lane;
       snf_call_t c = v.calls[i];
       const CallX x = v.callx[i];
