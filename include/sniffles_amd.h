@@ -385,6 +385,11 @@ int snf_batch_fetch_clusters(snf_batch_t* b, int stage, snf_clusters_t* out);
  * last call_candidates+finalize pass). names[i] points to a static string. */
 int snf_batch_timing_count(snf_batch_t* b);
 int snf_batch_timing_get(snf_batch_t* b, int i, const char** name, float* ms, int64_t* algo_bytes);
+/* the same as MEANS over all passes since the last reset (what bench.py states the roofline with: a kernel's average launch
+ * duration over the timed region); `passes` = passes that contributed */
+int snf_batch_timing_mean_reset(snf_batch_t* b);
+int snf_batch_timing_mean_count(snf_batch_t* b);
+int snf_batch_timing_mean_get(snf_batch_t* b, int i, const char** name, float* ms, int64_t* algo_bytes, int* passes);
 /* block until everything queued on the batch stream has finished */
 int snf_batch_sync(snf_batch_t* b);
 

@@ -130,7 +130,7 @@ struct SlabCache {
 };
 SlabCache g_slabs;
 
-struct Timing { const char* name; float ms; int64_t bytes; int launches; };
+struct Timing { const char* name; float ms; int64_t bytes; int launches; };   // (timing_acc: ms = sum, launches = passes)
 
 // ---- pinned, grow-only host buffers for results (pageable D2H is 3-4x slower) ----
 // Pinning memory costs more than filling it, and a pipeline creates one batch per task: released buffers go to a small
@@ -245,6 +245,7 @@ struct snf_batch_impl {
   std::vector<int64_t> cl_lead_off;
   // timing
   std::vector<Timing> timings;
+  std::vector<Timing> timing_acc;   // sums over the passes since snf_batch_timing_mean_reset
 #ifndef SNF_EMU
   struct Ev { hipEvent_t a, b; const char* name; int64_t bytes; };
   std::vector<Ev> evs; size_t ev_used = 0;
@@ -1336,6 +1337,13 @@ void collect_timings(snf_batch_impl* b) {
     if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[2];
     if (strcmp(t.name, "e4c_copy") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[3];
   }
+  // running sums since snf_batch_timing_mean_reset: the mean launch duration of every kernel over the passes in between
+  for (const auto& t : b->timings) {
+    bool found = false;
+    for (auto& a : b->timing_acc)
+      if (strcmp(a.name, t.name) == 0) { a.ms += t.ms; a.bytes = t.bytes; a.launches++; found = true; break; }
+    if (!found) b->timing_acc.push_back({t.name, t.ms, t.bytes, 1});
+  }
 #endif
 }
 
@@ -1926,6 +1934,27 @@ int snf_batch_sync(snf_batch_t* bb) {
 int snf_batch_timing_count(snf_batch_t* bb) {
   auto b = reinterpret_cast<snf_batch_impl*>(bb);
   return b ? (int)b->timings.size() : 0;
+}
+
+int snf_batch_timing_mean_reset(snf_batch_t* bb) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b) return 1;
+  b->timing_acc.clear();
+  return 0;
+}
+int snf_batch_timing_mean_count(snf_batch_t* bb) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  return b ? (int)b->timing_acc.size() : 0;
+}
+int snf_batch_timing_mean_get(snf_batch_t* bb, int i, const char** name, float* ms, int64_t* algo_bytes, int* passes) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b || i < 0 || i >= (int)b->timing_acc.size()) { g_err = "timing index out of range"; return 1; }
+  const Timing& t = b->timing_acc[(size_t)i];
+  if (name) *name = t.name;
+  if (ms) *ms = t.launches > 0 ? t.ms / (float)t.launches : 0.0f;
+  if (algo_bytes) *algo_bytes = t.bytes;
+  if (passes) *passes = t.launches;
+  return 0;
 }
 
 int snf_batch_timing_get(snf_batch_t* bb, int i, const char** name, float* ms, int64_t* algo_bytes) {

@@ -48,6 +48,9 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_coverage_calls.restype = C.c_int
     lib.snf_batch_timing_count.argtypes = [vp]
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    lib.snf_batch_timing_mean_reset.argtypes = [vp]
+    lib.snf_batch_timing_mean_count.argtypes = [vp]
+    lib.snf_batch_timing_mean_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     lib.snf_edit_distance_batch.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
                                             C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_edit_distance_batch_k.argtypes = [C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint8),
@@ -224,6 +227,18 @@ class Batch:
         for i in range(self.lib.snf_batch_timing_count(self._h)):
             name, ms, nb = C.c_char_p(), C.c_float(), C.c_int64()
             _check(self.lib, self.lib.snf_batch_timing_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb)))
+            out.append((name.value.decode(), float(ms.value), int(nb.value)))
+        return out
+
+    def timings_mean_reset(self) -> None:
+        self.lib.snf_batch_timing_mean_reset(self._h)
+
+    def timings_mean(self) -> list:
+        """(name, mean ms per pass, algorithmic bytes) over the passes since `timings_mean_reset`."""
+        out = []
+        for i in range(self.lib.snf_batch_timing_mean_count(self._h)):
+            name, ms, nb, k = C.c_char_p(), C.c_float(), C.c_int64(), C.c_int()
+            _check(self.lib, self.lib.snf_batch_timing_mean_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb), C.byref(k)))
             out.append((name.value.decode(), float(ms.value), int(nb.value)))
         return out
 
