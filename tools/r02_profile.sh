@@ -8,6 +8,10 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; cd $R
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 B="python bench.py --inflight 1 --no-cpu-baseline --no-wall-clock"
+# kernel statistics of the bench command itself (three batches in flight, as the driver runs it; only the CPU legs are skipped):
+# the average durations here are what roofline.kernel_ms (mean over the timed passes) has to agree with
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -o k -- python bench.py --no-cpu-baseline --no-wall-clock --gpus 1 --steps 20 --warmup 5 > $O/stats3.log 2>&1
+cp $(find $O/stats3 -name '*kernel_stats.csv' | head -1) $O/kernel_stats_3_in_flight.csv; grep '^{"metric"' $O/stats3.log | tail -1 > $O/bench_under_rocprof.json; rm -rf $O/stats3
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o k -- $B --steps 6 --warmup 2 > $O/stats.log 2>&1
 KT=$(find $O/stats -name '*kernel_trace.csv' | head -1); ST=$(find $O/stats -name '*kernel_stats.csv' | head -1)
 python tools/timeline.py $KT > $O/timeline.txt 2>&1; cp $ST $O/kernel_stats.csv
