@@ -107,6 +107,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
+    numa = bind_to_gpu_numa(torch, local_rank)
     # SNF_BENCH_FORCE_DIST=1: run the whole collective path (RCCL process group, gathers from the worker threads) with a
     # single rank - a dry run of the N > 1 code on a 1-GPU box
     use_dist = world > 1 or os.environ.get("SNF_BENCH_FORCE_DIST") == "1"
@@ -116,7 +117,7 @@ def main():
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist)
+    ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist, numa=numa)
     if args.config != 4:
         args.steps = 30 if args.steps is None else args.steps
         args.warmup = 3 if args.warmup is None else args.warmup
@@ -451,7 +452,7 @@ def run_calling(ctx):
                                calls=total_calls,
                                parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
                                             if strong else f"contig-sharded x{world}") + ", RCCL gather of the call records on rank 0",
-                               batches_in_flight_per_gpu=W,
+                               batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
                                ms_per_pass_one_batch_in_flight=(round(lat_ms, 3) if lat_ms else None),
                                timed_region="call_candidates + finalize + D2H of the results per pass; the read index (sorted read "
                                             "ends + hap prefix counts = the coverage vector / hap tables the reference builds during "
@@ -481,6 +482,32 @@ def run_calling(ctx):
         for bb in hs:
             bb.close()
     return out
+
+
+def bind_to_gpu_numa(torch, local_rank):
+    """One process per GPU, bound to the CPUs of the NUMA node the GPU hangs off (what a launcher does for every rank): the
+    host threads that drive the batches, their pinned buffers and the staging arena then sit next to the PCIe root of the
+    device.  (Measured on the 2-socket GPU box: no difference for one rank - four runs each 2.10-2.41 ms unbound, 2.12-2.30
+    bound; the run-to-run spread of ~10 % has another cause.  Kept for the N-rank launches.)  Best effort (sysfs); SNF_BENCH_NO_NUMA=1 turns it off.  Returns what was done, for the output line."""
+    if os.environ.get("SNF_BENCH_NO_NUMA") == "1":
+        return "off"
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return "gpu has no numa node"
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return f"node {node}: no allowed cpu"
+        os.sched_setaffinity(0, cpus)
+        return f"node {node} ({len(cpus)} cpus)"
+    except Exception as e:  # noqa: BLE001 - measurement hygiene only
+        return f"unavailable ({type(e).__name__})"
 
 
 def wall_clock(cfg, tasks, device):
