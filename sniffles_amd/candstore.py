@@ -210,7 +210,8 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
     calls = fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, objs, np.ascontiguousarray(gout), np.ascontiguousarray(em, np.int64),
                              group_off, member, chosen, np.ascontiguousarray(sv_ids, np.int64), np.ascontiguousarray(task_ids, np.int64),
                              sample_ids, spos, block_cov, ev_off, ev_block, np.ascontiguousarray(ev_bin),
-                             int(config.combine_null_min_coverage), str(config.id_prefix), len(config.snf_input_info) == 1)
+                             int(config.combine_null_min_coverage), str(config.id_prefix), len(config.snf_input_info) == 1,
+                             np.ascontiguousarray(rec["sample"], np.int32))
     if config.combine_pair_relabel:
         thr = config.combine_pair_relabel_threshold
         for call in calls:                                                     # sv.py:416-426 (an option; off by default)

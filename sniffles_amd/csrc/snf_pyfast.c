@@ -93,7 +93,7 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
   for (long long i = lo; i < hi; i++) {
     const snf_call_t* c = &C[i];
     if (c->svtype < 0 || c->svtype > 6 || c->filter < 0 || c->filter >= PyList_GET_SIZE(filters)) { PyErr_SetString(PyExc_ValueError, "record field out of range"); goto fail; }
-    PyObject* d = PyDict_New();
+    PyObject* d = _PyDict_NewPresized(34);     /* 33 attributes: no rehash while the instance dict is filled */
     if (!d) goto fail;
     PyObject* info = PyDict_New();
     PyObject* alt = S_alt_sym[c->svtype]; Py_INCREF(alt);
@@ -500,14 +500,15 @@ static PyObject* int_or_none(int32_t v) { if (v == SNF_NONE_I32) { Py_RETURN_NON
  *             sample_ids: buffer int32 (config.snf_input_info order), sample_pos: buffer int32 (internal id -> position, -1),
  *             block_cov: list (per block: list per sample position of the block's _COVERAGE dict or None),
  *             ev_off: buffer int64 (len(emit) + 1), ev_block: buffer int32, ev_bin: buffer int32,
- *             null_min_coverage: int, id_prefix: str, single_sample: bool) -> list[SVCall] */
+ *             null_min_coverage: int, id_prefix: str, single_sample: bool, cand_sample: buffer int32) -> list[SVCall] */
 static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   PyObject *cls, *fds_cls, *objs, *block_cov, *prefix;
-  Py_buffer ob, eb, gb, mb, cb, svb, tkb, sidb, sposb, evo, evb, evn;
+  Py_buffer ob, eb, gb, mb, cb, svb, tkb, sidb, sposb, evo, evb, evn, csb;
   long long null_min; int single;
-  if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*y*y*y*y*O!y*y*y*LUp", &cls, &fds_cls, &PyList_Type, &objs, &ob, &eb, &gb, &mb, &cb, &svb, &tkb, &sidb,
-                        &sposb, &PyList_Type, &block_cov, &evo, &evb, &evn, &null_min, &prefix, &single))
+  if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*y*y*y*y*O!y*y*y*LUpy*", &cls, &fds_cls, &PyList_Type, &objs, &ob, &eb, &gb, &mb, &cb, &svb, &tkb, &sidb,
+                        &sposb, &PyList_Type, &block_cov, &evo, &evb, &evn, &null_min, &prefix, &single, &csb))
     return NULL;
+  const int32_t* CS = (const int32_t*)csb.buf;      /* sample_internal_id per candidate (table order) */
   PyObject* ret = NULL;
   const snf_group_out_t* O = (const snf_group_out_t*)ob.buf;
   const int64_t* E = (const int64_t*)eb.buf; const Py_ssize_t ne = eb.len / 8;
@@ -522,7 +523,7 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   PyObject** sid_objs = NULL; uint8_t* present = NULL; int* head = NULL; PyObject** chain = NULL; Py_ssize_t cap = 0;
   PyObject* out = NULL;
   if ((Py_ssize_t)(ob.len / sizeof(snf_group_out_t)) < ng || cb.len < nm || svb.len / 8 < ne || tkb.len / 8 < ne || evo.len / 8 < ne + 1 ||
-      evb.len != evn.len) { PyErr_SetString(PyExc_ValueError, "group_calls: table sizes do not match"); goto done; }
+      evb.len != evn.len || csb.len / 4 < nobj) { PyErr_SetString(PyExc_ValueError, "group_calls: table sizes do not match"); goto done; }
   sid_objs = (PyObject**)calloc((size_t)ns + 1, sizeof(PyObject*)); present = (uint8_t*)malloc((size_t)ns + 1);
   if (!sid_objs || !present) { PyErr_NoMemory(); goto done; }
   for (Py_ssize_t i = 0; i < ns; i++) { sid_objs[i] = PyLong_FromLong(SIDS[i]); if (!sid_objs[i]) goto done; }
@@ -541,22 +542,17 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
     }
     for (int64_t k = 0; k < n; k++) if (M[lo + k] < 0 || M[lo + k] >= nobj) { PyErr_SetString(PyExc_ValueError, "member out of range"); goto fail; }
     PyObject* first = PyList_GET_ITEM(objs, M[lo]);
-    PyObject *d = PyDict_New(), *gts = PyDict_New(), *names = PyList_New(0), *info = NULL, *fds = NULL;
+    PyObject *d = _PyDict_NewPresized(34), *gts = _PyDict_NewPresized(ns), *names = PyList_New(0), *info = NULL, *fds = NULL;
     int bad = !d || !gts || !names;
     memset(present, 0, (size_t)ns);
     /* ---- genotypes of the samples in the group (sv.py:386-404): first appearance order; ids chained in add order */
     for (int64_t k = 0; !bad && k < n; k++) {
       PyObject* c = PyList_GET_ITEM(objs, M[lo + k]);
-      PyObject* sv = aget(c, K_sample);
-      long sidv = sv ? PyLong_AsLong(sv) : -1;
-      Py_XDECREF(sv);
-      if (sidv == -1 && PyErr_Occurred()) { bad = 1; break; }
+      const long sidv = CS[M[lo + k]];
       head[k] = (int)k; chain[k] = NULL;
       for (int64_t j = 0; j < k; j++) {
         if (head[j] != j) continue;
-        PyObject* sj = aget(PyList_GET_ITEM(objs, M[lo + j]), K_sample);
-        long sjv = sj ? PyLong_AsLong(sj) : -2; Py_XDECREF(sj);
-        if (sjv == sidv) { head[k] = (int)j; break; }
+        if (CS[M[lo + j]] == sidv) { head[k] = (int)j; break; }
       }
       PyObject* cid = aget(c, K_id);
       PyObject* pid = cid ? PyUnicode_Concat(prefix, cid) : NULL;
@@ -596,7 +592,7 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       PyObject* c = PyList_GET_ITEM(objs, M[lo + pick]);
       PyObject* cg = aget(c, K_genotypes);
       PyObject* t = cg ? PyDict_GetItemWithError(cg, O_zero) : NULL;
-      PyObject* sv = aget(PyList_GET_ITEM(objs, M[lo + k]), K_sample);
+      PyObject* sv = PyLong_FromLong(CS[M[lo + k]]);
       if (!t || !sv || !PyTuple_Check(t) || PyTuple_GET_SIZE(t) < 6) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "genotypes[0] must be a 6-tuple"); bad = 1; }
       else {
         PyObject* g7 = PyTuple_Pack(7, PyTuple_GET_ITEM(t, 0), PyTuple_GET_ITEM(t, 1), PyTuple_GET_ITEM(t, 2), PyTuple_GET_ITEM(t, 3),
@@ -629,8 +625,8 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       }
       if (bad) break;
       PyObject* covo = PyLong_FromLong(cov);
-      PyObject* g7 = !covo ? NULL : (cov >= null_min ? Py_BuildValue("(iiiOiOO)", 0, 0, 0, covo, 0, T_none2, S_NULL)
-                                                     : Py_BuildValue("(OOiOiOO)", S_dot, S_dot, 0, covo, 0, T_none2, S_NULL));
+      PyObject* ab = cov >= null_min ? O_zero : S_dot;          /* (0, 0, 0, cov, 0, (None, None), "NULL") or (".", ".", ...) */
+      PyObject* g7 = covo ? PyTuple_Pack(7, ab, ab, O_zero, covo, O_zero, T_none2, S_NULL) : NULL;
       Py_XDECREF(covo);
       bad = !g7 || PyDict_SetItem(gts, sid_objs[si], g7);
       Py_XDECREF(g7);
@@ -690,6 +686,7 @@ done:
   free(present); free(head); free(chain);
   PyBuffer_Release(&ob); PyBuffer_Release(&eb); PyBuffer_Release(&gb); PyBuffer_Release(&mb); PyBuffer_Release(&cb); PyBuffer_Release(&svb);
   PyBuffer_Release(&tkb); PyBuffer_Release(&sidb); PyBuffer_Release(&sposb); PyBuffer_Release(&evo); PyBuffer_Release(&evb); PyBuffer_Release(&evn);
+  PyBuffer_Release(&csb);
   return ret;
 }
 

@@ -269,4 +269,4 @@ def test_candidate_store_helpers_reject_malformed_input():
     with pytest.raises(ValueError):
         fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, [], out, np.array([3], np.int64), np.array([0, 0], np.int64),
                          np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int32),
-                         np.zeros(2, np.int32), [], np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 5, "", False)
+                         np.zeros(2, np.int32), [], np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 5, "", False, np.zeros(0, np.int32))
