@@ -121,19 +121,76 @@ class SNFPart:
     has_snf: bool = True
 
 
+# ---------------------------------------------------------------------------------------------- container layout
+# A file is  <header line> <member> <member> ...  where a member is one gzip stream of one pickled block.  Offsets in the
+# header's index are relative to the first byte after the header line.  A part file (one per task, written by a worker) is
+# the members alone; `write_results` strings the parts together in task order and shifts their offsets.
+
+def _block_start(pos: int, block_size: int) -> int:
+    return int(pos / block_size) * block_size
+
+
+def _empty_block() -> dict:
+    block = {svtype: [] for svtype in sv.TYPES}
+    block["_COVERAGE"] = {}
+    return block
+
+
+def _header_line(config, index: dict, candidate_count: int) -> bytes:
+    doc = {"config": config.__dict__, "index": index, "snf_candidate_count": candidate_count}
+    return (json.dumps(doc, default=lambda obj: "<Unstored_Object>") + "\n").encode()
+
+
+def _shifted_index(parts) -> dict:
+    """{contig: {block: [(offset, length), ...]}} of the parts laid end to end in the given order."""
+    merged, base = {}, 0
+    for part in parts:
+        per_contig = merged.setdefault(part.contig, {})
+        for block, (start, length) in part.snf_index.items():
+            per_contig.setdefault(block, []).append((start + base, length))
+        base += part.snf_total_length
+    return merged
+
+
+class _Handle:
+    """The file handle of a container with the reference's conventions: `False` means closed, a reader re-opens by name on
+    demand, and with `--combine-close-handles` every operation closes the file behind itself (hundreds of samples)."""
+
+    def __init__(self, handle, filename, close_after_use: bool):
+        self.handle, self.filename, self.close_after_use = handle, filename, close_after_use
+
+    @property
+    def is_open(self) -> bool:
+        return self.handle is not False
+
+    def need(self):
+        if not self.is_open:
+            self.handle = open(self.filename, "rb")
+        return self.handle
+
+    def close(self) -> None:
+        if self.is_open:
+            self.handle.close()
+            self.handle = False
+
+    def done(self) -> None:
+        if self.close_after_use:
+            self.close()
+
+
 class SNFileBase:
-    header_length: int
-    _header: Optional[dict]
+    """Reference interface (`snf.py:29-241`: same method names and on-disk format) over the pieces above."""
 
     def __init__(self, config, handle, filename=None):
         self.config = config
-        self.handle = handle
         self.filename = filename
-        self.blocks = {}
-        self._header = None
-        self._index = {}
+        self._io = _Handle(handle, filename, bool(getattr(config, "combine_close_handles", False)))
+        self.blocks = {}            # block start -> {svtype: [SVCall], "_COVERAGE": {bin: depth}}   (writing)
+        self._header = None         # parsed header line                                               (reading)
+        self.header_length = 0
+        self._index = {}            # writing: block -> (offset, length) of this part; reading: the header's index
         self.total_length = 0
-        self._results = []
+        self._results = []          # SNFPart of every task that produced a part
 
     @classmethod
     def open(cls, filename: str, config=None) -> "SNFileBase":
@@ -143,6 +200,15 @@ class SNFileBase:
         obj = cls(config, open(filename, "rb"), filename)
         obj.read_header()
         return obj
+
+    # the reference exposes the raw handle (`False` once closed)
+    @property
+    def handle(self):
+        return self._io.handle
+
+    @handle.setter
+    def handle(self, value):
+        self._io.handle = value
 
     @property
     def index(self) -> dict:
@@ -160,37 +226,36 @@ class SNFileBase:
     def reqc(self) -> bool:
         """Was this file written by a version old enough that QC must be redone (snf.py:66-81)?"""
         mode = getattr(self.config, "reqc", "auto")
-        if mode == "auto":
-            try:
-                build, _, _ = self.header["config"]["build"].partition("-")
-            except (KeyError, AttributeError, TypeError):
-                return True
-            return build < "2.5.3"
-        return mode
+        if mode != "auto":
+            return mode
+        try:
+            build = self.header["config"]["build"].partition("-")[0]
+        except (KeyError, AttributeError, TypeError):
+            return True
+        return build < "2.5.3"
 
     def is_open(self) -> bool:
-        return self.handle is not False
+        return self._io.is_open
 
-    def _open(self):
-        if self.handle is not False:
-            self.close()
-        self.handle = open(self.filename, "rb")
+    def close(self) -> None:
+        self._io.close()
 
-    def _close_after_use(self):
-        if getattr(self.config, "combine_close_handles", False):
-            self.close()
+    def get_index(self):
+        return self.index
 
-    # ---- writing
+    def get_total_length(self):
+        return self.total_length
+
+    # ---- writing a part
     def store(self, svcand):
-        bs = self.config.snf_block_size
-        block_index = int(svcand.pos / bs) * bs
-        if block_index not in self.blocks:
-            self.blocks[block_index] = {svtype: [] for svtype in sv.TYPES}
-            self.blocks[block_index]["_COVERAGE"] = {}
+        start = _block_start(svcand.pos, self.config.snf_block_size)
+        block = self.blocks.get(start)
+        if block is None:
+            block = self.blocks[start] = _empty_block()
         if not getattr(self.config, "output_rnames", False):
             svcand.rnames = None
         if svcand.svtype in sv.TYPES:
-            self.blocks[block_index][svcand.svtype].append(svcand)
+            block[svcand.svtype].append(svcand)
 
     def serialize_block(self, block_id) -> bytes:
         return _dumps_as_reference(self.blocks[block_id])
@@ -199,101 +264,73 @@ class SNFileBase:
         return _Unpickler(io.BytesIO(data)).load()
 
     def write_and_index(self):
-        if not self.is_open():
-            self._open()
-        offset = 0
+        out = self._io.need()
         for block_id in sorted(self.blocks):
-            data = gzip.compress(self.serialize_block(block_id))
-            self.handle.write(data)
-            self._index[block_id] = (offset, len(data))
-            offset += len(data)
-            self.total_length += len(data)
-        self._close_after_use()
+            member = gzip.compress(self.serialize_block(block_id))
+            out.write(member)
+            self._index[block_id] = (self.total_length, len(member))
+            self.total_length += len(member)
+        self._io.done()
 
+    # ---- writing the final file from the parts
     def add_result(self, result):
         if result.has_snf:
             self._results.append(result)
 
     def _calculate_contig_coverages(self, contigs) -> dict:
-        per = {c: [] for c in contigs}
-        for r in self._results:
-            per[r.contig].append(r.coverage_average_total)
-        return {c: (sum(v) / len(v) if len(v) > 0 else 0) for c, v in per.items()}
-
-    def _create_header(self, config, main_index: dict, snf_candidate_count: int) -> dict:
-        return {"config": config.__dict__, "index": main_index, "snf_candidate_count": snf_candidate_count}
+        means = {}
+        for c in contigs:
+            values = [r.coverage_average_total for r in self._results if r.contig == c]
+            means[c] = sum(values) / len(values) if values else 0
+        return means
 
     def write_results(self, config, contigs) -> int:
-        """Concatenate the per-task part files behind one header; returns the candidate count (snf.py:186-223)."""
-        main_index = {}
-        offset = 0
-        snf_candidate_count = sum(r.snf_candidate_count for r in self._results)
-        parts_sorted = sorted(self._results, key=lambda r: r.task_id)
-        for part in parts_sorted:
-            idx = main_index.setdefault(part.contig, {})
-            for block, (start, length) in part.snf_index.items():
-                idx.setdefault(block, []).append((start + offset, length))
-            offset += part.snf_total_length
+        """Header, then the part files in task order (each is removed); returns the candidate count (snf.py:186-223)."""
+        parts = sorted(self._results, key=lambda r: r.task_id)
+        count = sum(r.snf_candidate_count for r in parts)
         config.contig_coverages = self._calculate_contig_coverages(contigs)
-        header = self._create_header(config, main_index, snf_candidate_count)
-        self.handle.write((json.dumps(header, default=lambda obj: "<Unstored_Object>") + "\n").encode())
-        for part in parts_sorted:
+        self.handle.write(_header_line(config, _shifted_index(parts), count))
+        for part in parts:
             with open(part.snf_filename, "rb") as h:
                 self.handle.write(h.read())
             os.remove(part.snf_filename)
-        return snf_candidate_count
+        return count
 
     # ---- reading
     def read_header(self):
-        if not self.is_open():
-            self._open()
-        header_text = self.handle.readline()
-        self.header_length = len(header_text)
+        line = self._io.need().readline()
+        self.header_length = len(line)
         try:
-            self._header = json.loads(header_text.strip())
+            self._header = json.loads(line.strip())
         except Exception as e:
             raise ValueError(f"'{self.filename}' is not a valid .snf file (header: {e})") from e
         self._index = self._header["index"]
-        self._close_after_use()
+        self._io.done()
 
     def read_blocks(self, contig, block_index):
-        if not self.is_open():
-            self._open()
-        block_index = str(block_index)
-        if contig not in self.index or block_index not in self.index[contig]:
-            self._close_after_use()
+        """The blocks stored for (contig, block start) - one per task that wrote into it - or None."""
+        members = self.index.get(contig, {}).get(str(block_index))
+        if members is None:
+            self._io.need()            # (the reference opens the file before it looks)
+            self._io.done()
             return None
-        blocks = []
+        f = self._io.need()
         try:
-            for start, length in self.index[contig][block_index]:
-                self.handle.seek(self.header_length + start)
-                blocks.append(self.unserialize_block(gzip.decompress(self.handle.read(length))))
+            blocks = []
+            for start, length in members:
+                f.seek(self.header_length + start)
+                blocks.append(self.unserialize_block(gzip.decompress(f.read(length))))
+            return blocks
         finally:
-            self._close_after_use()
-        return blocks
-
-    def get_index(self):
-        return self.index
-
-    def get_total_length(self):
-        return self.total_length
-
-    def close(self) -> None:
-        if self.handle is not False:
-            self.handle.close()
-            self.handle = False
+            self._io.done()
 
     def get_all_blocks(self, contig: str) -> dict:
-        blocks = {}
-        if contig in self.index:
-            for block_start in self.index[contig].keys():
-                blocks[block_start] = self.read_blocks(contig, block_start)[0]
-        return blocks
+        return {start: self.read_blocks(contig, start)[0] for start in self.index.get(contig, {})}
 
     def get_full_coverage(self, contig: str) -> dict:
         coverage = {}
-        for b in self.get_all_blocks(contig).values():
-            coverage.update(b["_COVERAGE"])
+        for block in self.get_all_blocks(contig).values():
+            coverage.update(block["_COVERAGE"])
         return coverage
 
 
