@@ -270,3 +270,26 @@ def test_candidate_store_helpers_reject_malformed_input():
         fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, [], out, np.array([3], np.int64), np.array([0, 0], np.int64),
                          np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(1, np.int64), np.zeros(1, np.int64), np.zeros(1, np.int32),
                          np.zeros(2, np.int32), [], np.zeros(2, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), 5, "", False, np.zeros(0, np.int32))
+
+
+def test_columnar_store_single_sample_merge_emu(monkeypatch):
+    """One input file (`sniffles --input one.snf`): the combined call keeps the candidate's own filter and info dict and has no
+    STDEV fields (sv.py:440-470); with --no-qc every group is called.  Columnar store against the object replay."""
+    import emu.emu as E
+    from sniffles_amd.config import SnifflesConfig
+    doc = gu.load("combine_task_3samples_lowcov")
+    exp = doc["expected"]
+    for no_qc in (False, True):
+        out = []
+        for objects in ("0", "1"):
+            monkeypatch.setenv("SNF_COMBINE_OBJECTS", objects)
+            cfg = SnifflesConfig(no_qc=no_qc)
+            cfg.snf_input_info = [dict(internal_id=0)]
+            cfg.mode = "combine"
+            readers = {0: BlocksReader(exp["contig"], exp["samples"][0])}
+            task = parallel.CombineTask(id=1, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())
+            out.append([_object_fields(c) for c in task.execute(readers)])
+        col, obj = out
+        assert len(col) == len(obj) and (len(col) > 0 or not no_qc)
+        for a, b in zip(col, obj):
+            assert list(a) == list(b) and a == b, a["id"]
