@@ -371,12 +371,14 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       uint32_t o = (uint32_t)v.F_orig[FI[k]];
       bool sel = v.in_mate_contig[o] == mc;
       v.F_sel[FI[k]] = sel ? 1 : 0;
-      if (sel) { a3[ns] = v.in_mate_pos[o]; a1[ns] = (int32_t)v.in_qname[o]; nfirst += v.in_first[o]; nrev += v.in_rev[o]; ns++; }
+      if (sel) { a3[ns] = v.in_mate_pos[o]; a2[ns] = (int32_t)v.in_qname[o]; nfirst += v.in_first[o]; nrev += v.in_rev[o]; ns++; }
     }
     SNF_SORT(uni, a3, (int64_t)ns, LessI32{}, stmp);
-    SNF_SORT(uni, a1, (int64_t)ns, LessI32{}, stmp);
-    nq = distinct_sorted_i32(a1, ns);
-    cc.support = (int32_t)nq; rn_len = nq;
+    SNF_SORT(uni, a2, (int64_t)ns, LessI32{}, stmp);
+    // SUPPORT counts the reads of the selected leads; RNAMES stays the read set of the whole cluster (sv.py:555 is taken
+    // before resolve_bnd narrows the leads, sv.py:636) - a1 / nq / rn_len are left as they are.  The two differ only when
+    // a cluster mixes mate contigs, i.e. with --dev-no-resplit (resplit_bnd groups by mate contig).
+    cc.support = (int32_t)distinct_sorted_i32(a2, ns);
     cc.mate_contig = mc; cc.mate_ref_start = center_sorted(a3, ns);
     cc.bnd_is_first = (nfirst > ns - nfirst) ? 1 : 0;   // most_common_top: ties -> False
     cc.bnd_is_reverse = (nrev > ns - nrev) ? 1 : 0;

@@ -193,10 +193,9 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
       const int32_t p_q2 = __shfl_up(s_q2, 1, SNF_WAVE);
       const bool qf2 = lane < ns && (lane == 0 || p_q2 != s_q2);
       const unsigned long long qm2 = __ballot(qf2);
-      nq = __builtin_popcountll(qm2);
-      __syncthreads();
-      if (qf2) a1[__builtin_popcountll(qm2 & ((1ull << lane) - 1ull))] = s_q2;
-      cc.support = (int32_t)nq; rn_len = nq;
+      // SUPPORT: reads of the selected leads; RNAMES (a1, nq, rn_len) stays the read set of the whole cluster (sv.py:555
+      // is taken before resolve_bnd narrows the leads) - they differ only when a cluster mixes mate contigs (--dev-no-resplit)
+      cc.support = (int32_t)__builtin_popcountll(qm2);
       cc.mate_contig = mc; cc.mate_ref_start = (int32_t)mate_pos;
       cc.bnd_is_first = (nfirst > ns - nfirst) ? 1 : 0;   // most_common_top: ties -> False
       cc.bnd_is_reverse = (nrev > ns - nrev) ? 1 : 0;

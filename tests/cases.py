@@ -317,6 +317,9 @@ HAND = {
     "single_leads_noqc": (case_single_leads_only, dict(no_qc=True), ("--no-qc",)),
     "phase_off_symbolic": (case_consensus_quirks, dict(symbolic=True), ("--symbolic",)),
     "no_consensus": (case_consensus_quirks, dict(no_consensus=True), ("--no-consensus",)),
+    # --dev-no-resplit keeps BND clusters with mixed mate contigs whole: SUPPORT counts the reads of the selected mate contig,
+    # RNAMES the reads of the whole cluster (sv.py:555 vs 636)
+    "bnd_mixed_mates_no_resplit": (case_bnd_stale_end, dict(dev_no_resplit=True), ("--dev-no-resplit",)),
 }
 
 # seeded synthetic (SURVEY.md 8d shapes, shrunk contigs) --------------------------------------------
@@ -353,7 +356,14 @@ def _no_tr(ti):
     return ti
 
 
-ALL = {**HAND, **SYNTH, **FUZZ}
+# the developer switches of the refinement stage on adversarial tasks (no resplit at all / none for the length bins only)
+FUZZ_DEV = {
+    "fuzz_5_no_resplit": (lambda: synth.gen_fuzz(5000, task_id=0), dict(dev_no_resplit=True), ("--dev-no-resplit",)),
+    "fuzz_7_no_resplit_mosaic": (lambda: synth.gen_fuzz(5051, task_id=3), dict(dev_no_resplit=True, mosaic=True), ("--dev-no-resplit", "--mosaic")),
+    "fuzz_9_no_resplit_repeat": (lambda: synth.gen_fuzz(5017, task_id=1), dict(dev_no_resplit_repeat=True), ("--dev-no-resplit-repeat",)),
+}
+
+ALL = {**HAND, **SYNTH, **FUZZ, **FUZZ_DEV}
 
 
 # multi-sample combine (BASELINE.json configs[4] shape, shrunk): samples share sites, not reads ------------------

@@ -1,0 +1,261 @@
+"""The product's HIP sources - all four translation units, every kernel, the gfx950 wave / workgroup kernels and the
+lock-step x_big kernels included - compiled UNCHANGED with g++ against a stand-in for the HIP runtime (tests/emu/simt:
+fibres per thread, cross-lane operations, DPP, barriers, lock step by page tracking) and run in the GPU-less container
+against the reference's goldens and the oracle.
+
+tests/emu/emu.py (test_emu_parity.py) compiles the `SNF_EMU` halves of the sources: thread-per-item bodies as serial loops,
+and none of `snf_wave_*.h`.  This tier runs the code the GPU runs: the `#ifndef SNF_EMU` halves, the launch sequence of
+snf_lib.hip with `wave_path` on, the fused scan chains, the workgroup consensus kernels, the wave form of the extraction
+kernels.  What it cannot show is anything about timing, memory ordering between workgroups, or the compiler - the parity
+tests proper remain the `-m gpu` tests."""
+import collections
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util as gu
+from sniffles_amd import lib, records, synth
+from sniffles_amd.config import SnifflesConfig
+
+
+@pytest.fixture(scope="module")
+def simt():
+    from emu import simt as S
+    S.lib()
+    return S
+
+
+@pytest.fixture()
+def as_emu(simt, monkeypatch):
+    """The CPU-tier tests of the other modules fetch their library with emu.emu.lib(): give them this tier's library."""
+    import emu.emu as E
+    monkeypatch.setattr(E, "lib", simt.lib)
+    before = simt.counters()
+    yield simt
+    after = simt.counters()
+    assert after["unmodelled"] == before["unmodelled"]              # nothing was skipped inside the library
+    assert after["lockstep_conflicts"] == before["lockstep_conflicts"]
+
+
+def run(L, cfg, tis, fin):
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.call_candidates()
+        if fin:
+            b.finalize()
+        return b.fetch(1 if fin else 0)
+
+
+# ---------------------------------------------------------------------------------------------- the shim itself
+def test_shim_models_the_cross_lane_operations(simt):
+    """Known answers for the model: DPP row shifts / broadcasts (as wave scans), shuffles, ballots with only part of the wave
+    taking part, barriers with waves that have already returned, and lock step (64 lanes incrementing one word = +1)."""
+    L = simt.lib()
+    out = (C.c_longlong * 16)()
+    L.simt_selftest.argtypes = [C.POINTER(C.c_longlong)]
+    L.simt_selftest.restype = C.c_int
+    assert L.simt_selftest(out) == 0, list(out)
+    assert list(out[:8]) == [0] * 8, list(out)           # mismatches per check
+    assert out[8] == 1 and out[9] == 64                  # one word incremented by 64 lanes: lock step 1, fibres 64
+
+
+# ---------------------------------------------------------------------------------------------- clustering + calling
+@pytest.mark.parametrize("name", sorted(cases.ALL))
+def test_wave_path_matches_reference_golden(name, simt):
+    build, kw, _ = cases.ALL[name]
+    doc = gu.load(name)
+    ti = build()
+    cfg = gu.make_config(kw, ti)
+    exp = doc["expected"]
+    before = simt.counters()
+    for stage, key, fin in (("cand", "candidates", False), ("final", "final", True)):
+        res = run(simt.lib(), cfg, [ti], fin)
+        got = records.records(res, [ti], stage)[0]
+        if "error" in exp:
+            assert got == {"error": exp["error"]}
+            continue
+        assert gu.diff_records(got, exp[key]) == []
+        assert float(res.coverage_average_total[0]) == exp["coverage_average_total"]
+    after = simt.counters()
+    assert after["unmodelled"] == before["unmodelled"] and after["lockstep_conflicts"] == before["lockstep_conflicts"]
+
+
+def test_wave_and_lockstep_kernels_really_ran(simt):
+    """Guards the tier against silently testing nothing: a deep fuzz task must go through cross-lane operations, workgroup
+    barriers and the lock-step kernels, and without lock step the same task must come out wrong."""
+    import os
+    ti = synth.gen_fuzz(903, task_id=0)
+    cfg = SnifflesConfig()
+    before = simt.counters()
+    good = records.records(run(simt.lib(), cfg, [ti], True), [ti], "final")
+    after = simt.counters()
+    assert after["wave_ops"] - before["wave_ops"] > 1000 and after["block_syncs"] > before["block_syncs"]
+    assert after["lockstep_merges"] - before["lockstep_merges"] > 10 and after["lockstep_faults"] > before["lockstep_faults"]
+    os.environ["SNF_SIMT_NO_LOCKSTEP"] = "1"
+    try:
+        bad = records.records(run(simt.lib(), cfg, [ti], True), [ti], "final")
+    finally:
+        del os.environ["SNF_SIMT_NO_LOCKSTEP"]
+    assert simt.counters()["unmodelled"] > after["unmodelled"] and bad != good
+
+
+KW = [{}, dict(mosaic=True), dict(repeat=True, mosaic=True), dict(no_qc=True, phase=True), dict(minsupport=3, long_ins_length=200),
+      dict(dev_no_resplit=True), dict(cluster_merge_pos=300, cluster_binsize=50)]
+
+
+@pytest.mark.parametrize("ci", range(len(KW)))
+def test_wave_path_matches_oracle_on_fuzz_batches(ci, simt, oracle_mod):
+    tis = [synth.gen_fuzz(1000 * ci + 17 * k, task_id=k) for k in range(4)]
+    cfg = SnifflesConfig(**KW[ci])
+    before = simt.counters()
+    got = records.records(run(simt.lib(), cfg, tis, True), tis, "final")
+    assert got == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    assert simt.counters()["unmodelled"] == before["unmodelled"]
+
+
+@pytest.mark.parametrize("env", [{"SNF_NO_BIG_STAGE": "1"}, {"SNF_E1_BATCH": "32"}, {"SNF_E1_BATCH": "2"}, {"SNF_NO_POOL_SLICES": "1"},
+                                 {"SNF_NO_FUSE": "1"}, {"SNF_SORT64": "1"}, {"SNF_RUN_GAP": "0"}, {"SNF_CONS_NW": "1"},
+                                 {"SNF_CONS_LARGE_NW": "8"}, {"SNF_NO_WAVE": "1"}])
+def test_library_switches_keep_the_results(env, simt, oracle_mod, monkeypatch):
+    """The scheduling / layout switches of the library (README) change how the kernels run, never what they return."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tis = [synth.gen_fuzz(4242 + k, task_id=k) for k in range(3)] + [synth.gen_task(3, "chrS", 150_000, 40.0, seed=5)]
+    cfg = SnifflesConfig()
+    assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+
+
+def test_very_deep_clusters_in_lock_step(simt, oracle_mod):
+    """150x: most clusters have more than 64 leads (x_big, cooperative rank sorts, LDS rows)."""
+    ti = synth.gen_task(0, "chrD", 60_000, 150.0, seed=3)
+    cfg = SnifflesConfig()
+    assert records.records(run(simt.lib(), cfg, [ti], True), [ti], "final") == records.records(oracle_mod.run(cfg, [ti], True), [ti], "final")
+
+
+# ---------------------------------------------------------------------------------------------- consensus instances
+def _cons_problems():
+    return gu.load("consensus_novel_from_reads")["problems"]
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(mode=2), dict(mode=4), dict(nw=1), dict(nw=8), dict(grid_cap=3), dict(mode=4, grid_cap=5),
+                                dict(min_reads=5)], ids=str)
+def test_consensus_instances_match_reference_vectors(kw, simt):
+    """Every template instance of the workgroup consensus kernel the library launches (SMALL 4 waves / 1 wave, LARGE 4 / 8
+    waves, ROWS), SMALL calls through LARGE, everything through ROWS, strided grids, the verbatim-copy kernel - against
+    the 160 vectors of the unmodified reference function."""
+    probs = _cons_problems()
+    got, cls, handed = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6, **kw)
+    exp = [p["expected"] if c else p["best"] for p, c in zip(probs, cls)]
+    assert [i for i, (g, e) in enumerate(zip(got, exp)) if g != e] == []
+    n = collections.Counter(cls)
+    if kw.get("mode") == 4:
+        assert n[4] == len(probs)
+    elif kw.get("mode") == 2:
+        assert n[2] == len(probs)
+    elif not kw.get("min_reads"):
+        assert n[1] >= 50 and n[2] >= 50
+
+
+def test_consensus_escape_list_overflow_is_handed_to_rows(simt):
+    """More non-ACGT votes than the escape list of the LDS-vote instances holds: the call is redone by ROWS (work list 7)
+    and still equals the plain rule - checked against the ROWS instance alone, which the vectors above pin."""
+    rng = np.random.default_rng(5)
+    probs = []
+    for k in range(6):
+        L = 300 if k < 3 else 2000
+        truth = rng.choice(list(b"ACGT"), L).astype(np.uint8)
+        best = truth.copy()
+        err = rng.random(L) < 0.03                                       # the best read carries errors the others outvote
+        best[err] = rng.choice(list(b"ACGT"), int(err.sum()))
+        others = []
+        for _ in range(12):
+            o = truth.copy()
+            hit = rng.random(L) < 0.15
+            o[hit] = rng.choice(list(b"NRYKM"), int(hit.sum()))       # odd characters everywhere
+            others.append(bytes(o))
+        probs.append((bytes(best), others, 3 + L // 100))
+    got, cls, handed = simt.consensus_batch(probs, 6)
+    ref, _, _ = simt.consensus_batch(probs, 6, mode=4)
+    assert handed == len(probs) and got == ref
+    assert any(g != p[0].decode("latin-1") for g, p in zip(got, probs))           # the vote really changes bases
+
+
+def test_consensus_entry_point_of_the_library(simt, monkeypatch):
+    """snf_consensus_batch itself (seam B4) through sniffles_amd.consensus."""
+    from sniffles_amd import consensus
+    monkeypatch.setattr(consensus._lib, "load", simt.lib)
+    probs = _cons_problems()
+    got = consensus.novel_from_reads_batch([(p["best"], p["others"], p["skip"]) for p in probs], klen=6)
+    assert [i for i, (g, p) in enumerate(zip(got, probs)) if g != p["expected"]] == []
+
+
+# ---------------------------------------------------------------------------------------------- the other seams
+def test_combine_kernels(as_emu, oracle_mod):
+    import test_combine as T
+    assert len(T.NAMES) >= 3
+    for name in T.NAMES:
+        T.test_emulated_combine_matches_reference(name)
+    for separate in (False, True):
+        T.test_emulated_combine_fuzz_vs_oracle(separate, oracle_mod)
+
+
+def test_edit_distance_kernels(as_emu, oracle_mod):
+    import test_edit_distance as T
+    T.test_edit_distance_emulated(oracle_mod)
+    T.test_edit_distance_banded_emulated(oracle_mod)
+
+
+@pytest.mark.parametrize("name", ["combine_task_10samples_options", "combine_task_5samples_medians", "combine_task_6samples",
+                                  "combine_task_8samples_dense"])
+def test_combine_task_driver(name, as_emu):
+    import test_combine_task as T
+    T.test_combine_task_driver_matches_reference_emu(name)
+
+
+def test_combine_task_scatter_and_cuts(as_emu):
+    import test_combine_task as T
+    T.test_combine_task_scatter_matches_reference_emu()
+    T.test_chain_cuts_keep_the_assignment_emu()
+    T.test_combine_task_reqc_regenotypes_the_candidates_emu()
+
+
+@pytest.mark.parametrize("name", ["bnd_stale_end", "fuzz_4_2", "chr21_30x_mosaic", "long_ins", "bnd_first"])
+def test_genotype_task(name, as_emu):
+    import test_genotype as T
+    T.test_genotype_task_emu(name)
+
+
+@pytest.mark.parametrize("name", ["chr20_30x_ont", "chr22_60x_hifi", "fuzz_3_0", "fuzz_6_0", "gt_failed_edges", "phase_rescue"])
+def test_regenotype(name, as_emu):
+    import test_genotype as T
+    T.test_regenotype_matches_reference_emu(name)
+
+
+def test_extraction_kernels_wave_form(simt, oracle_mod):
+    """tests/test_extract.py with this tier's library: the WAVE form of the extraction kernels (ballots, DPP scans)."""
+    import test_extract as T
+    L = simt.lib()
+    assert len(cases.EXTRACT) >= 3
+    for name in sorted(cases.EXTRACT):
+        T.test_kernel_bodies_match_reference(name, L)
+    T.test_reference_known_answer_reads_kernels(L)
+    T.test_empty_and_foreign_records(L)
+    T.test_extracted_task_feeds_the_clustering_path(L, oracle_mod)
+    T.check_device_handover(L, oracle_mod)
+
+
+def test_bam_to_vcf_end_to_end(as_emu, tmp_path):
+    import test_pipeline as T
+    names = [m.args[1] for m in T.test_bam_to_vcf_and_snf_emu.pytestmark if m.name == "parametrize"][0]
+    for k, name in enumerate(names):
+        d = tmp_path / str(k)
+        d.mkdir()
+        T.test_bam_to_vcf_and_snf_emu(name, d)
+
+
+def test_drop_in_entry_points(as_emu):
+    import test_dropin_api as T
+    names = [m.args[1] for m in T.test_task_entry_points_emulated.pytestmark if m.name == "parametrize"][0]
+    for name in names:
+        T.test_task_entry_points_emulated(name)
