@@ -28,6 +28,17 @@ def test_oracle_matches_reference_golden(name, oracle_mod):
         assert float(res.coverage_average_total[0]) == exp["coverage_average_total"]
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_oracle_matches_reference_under_random_options(oracle_mod, monkeypatch, capsys):
+    """oracle/ref_cfgfuzz.py: option sets drawn from the reference's own argparse definitions, the unmodified reference and the
+    oracle on the same adversarial task with the same config object (the goldens pin the option sets of tests/cases.py only)."""
+    import ref_cfgfuzz
+    monkeypatch.setattr("sys.argv", ["ref_cfgfuzz.py", "40", "5000"])
+    ref_cfgfuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out, out
+
+
 def test_oracle_batch_equals_single(oracle_mod):
     """Tasks are independent: a batch of tasks gives the concatenation of the single-task results."""
     names = ["chr20_30x_ont", "bnd_first_error", "merge_inner", "fuzz_3_0"]

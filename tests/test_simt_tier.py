@@ -126,6 +126,19 @@ def test_library_switches_keep_the_results(env, simt, oracle_mod, monkeypatch):
     assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
 
 
+def test_random_option_sets(simt, oracle_mod):
+    """tools/dev/cfgfuzz.py: random combinations of some sixty hot-path options (filters, cluster / merge widths, mosaic and
+    developer switches), three adversarial tasks each.  oracle/ref_cfgfuzz.py holds the oracle against the unmodified
+    reference over the same option space (build container only)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("cfgfuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "dev", "cfgfuzz.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    bad, calls = m.sweep(simt.lib(), 16, seed0=1000)
+    assert bad == 0 and calls > 1000
+
+
 def test_very_deep_clusters_in_lock_step(simt, oracle_mod):
     """150x: most clusters have more than 64 leads (x_big, cooperative rank sorts, LDS rows)."""
     ti = synth.gen_task(0, "chrD", 60_000, 150.0, seed=3)
