@@ -56,6 +56,17 @@ def test_combine_task_driver_matches_reference_gpu(name):
     run_case(name)
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_combine_driver_matches_reference_under_random_options(monkeypatch, capsys):
+    """oracle/ref_combinefuzz.py: --combine-* option sets drawn from the reference's argparse definitions, a small population,
+    the unmodified reference's CombineTask.execute against this driver on the same SNF blocks."""
+    import ref_combinefuzz
+    monkeypatch.setattr("sys.argv", ["ref_combinefuzz.py", "6", "7000"])
+    ref_combinefuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out and "MISMATCH" not in out, out
+
+
 def test_combine_task_reqc_regenotypes_the_candidates_emu():
     """--reqc (SNF files older than 2.5.3, parallel.py:507-508): the candidates are genotyped again on their way into the
     bins.  Genotyping candidates that already carry the current genotype is idempotent (tests/test_genotype.py pins the
