@@ -60,6 +60,17 @@ def test_kernel_bodies_match_reference(name, emu_lib):
     assert info.read_count == len(reads)
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_extraction_matches_reference_on_random_tables_and_filters(monkeypatch, capsys):
+    """oracle/ref_extractfuzz.py: random record tables, regions, read-id offsets and read filters; the unmodified reference's
+    build_leadtab against the oracle and against the kernels (the goldens pin eleven cases)."""
+    import ref_extractfuzz
+    monkeypatch.setattr("sys.argv", ["ref_extractfuzz.py", "10", "9000"])
+    ref_extractfuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
+
+
 # src/tests/test_bnd_leads.py: (contig, read name, supplementary, reverse) -> asserted Lead.for_bnd result
 # (lead.contig, lead.ref_start, mate_contig, mate_ref_start, is_first, is_reverse).  The "Red" / HG002 classes of that
 # file describe same-strand splits, for which the current reference code returns None (leadprov.py:86-87); they are
