@@ -37,7 +37,7 @@ _DEFAULTS = dict(
     # contig selection of the main program (config.py:168-176, util.py:147-162)
     all_contigs=False, contig=None, threads=4, regions_by_contig=None,
     # read filter of the extraction (config.py:190-215, 533-536); None: derived below
-    mapq=None, min_alignment_length=None, exclude_flags=None,
+    mapq=None, min_alignment_length=None, exclude_flags=None, max_splits_kb=0.1, max_splits_base=3, dev_keep_lowqual_splits=False,
     # postprocess args (config.py:325-334)
     no_consensus=False, symbolic=False,
     # mosaic args (config.py:343-362)

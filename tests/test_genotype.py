@@ -60,6 +60,17 @@ def test_genotype_task_gpu(name):
     run_case(name, None)
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_force_calling_matches_reference_on_random_targets_and_options(monkeypatch, capsys):
+    """oracle/ref_genotypefuzz.py: random adversarial tasks, target sets derived from the reference's own candidates, random
+    options; the unmodified reference's GenotypeTask.execute against this package's."""
+    import ref_genotypefuzz
+    monkeypatch.setattr("sys.argv", ["ref_genotypefuzz.py", "25", "9000"])
+    ref_genotypefuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
+
+
 def test_coverage_needs_the_device_batch():
     import emu.emu as E
     doc = gu.load("genotype_targets")["long_ins"]

@@ -98,6 +98,28 @@ def test_bam_to_vcf_and_snf_gpu(name, tmp_path):
     run_sample(name, tmp_path, None, through_file=True)
 
 
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_bam_to_vcf_matches_reference_under_random_command_lines(monkeypatch, capsys):
+    """oracle/ref_samplefuzz.py: random synthetic samples, random command lines (some thirty options), the unmodified
+    reference's call_sample flow against pipeline.call_sample, VCF text character by character."""
+    import ref_samplefuzz
+    monkeypatch.setattr("sys.argv", ["ref_samplefuzz.py", "4", "5000"])
+    ref_samplefuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_population_merge_matches_reference_under_random_command_lines(monkeypatch, capsys):
+    """oracle/ref_populationfuzz.py: random populations (2-5 samples), random --combine-* command lines; BAM records -> .snf
+    files -> merged VCF by the unmodified reference against this package, over its own files and over the reference's."""
+    import ref_populationfuzz
+    monkeypatch.setattr("sys.argv", ["ref_populationfuzz.py", "2", "7000"])
+    ref_populationfuzz.main()
+    out = capsys.readouterr().out
+    assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
+
+
 def test_contig_selection_rule():
     cfg = SnifflesConfig()
     assert pipeline.should_process_contig("chr1", 2_000_000, cfg) and not pipeline.should_process_contig("chrUn", 999_999, cfg)
