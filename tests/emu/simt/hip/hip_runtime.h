@@ -134,7 +134,7 @@ inline void yield_block() {
 
 // ------------------------------------------------------------------------------------------------ lock-step mode
 constexpr size_t PAGE = 4096;
-struct DevBlock { char* base; size_t bytes; };
+struct DevBlock { char* base; size_t bytes; char* user; bool guard; };   // the mapping without its guard page; what hipMalloc returned
 struct PageImg { char* page; std::vector<uint8_t> data; };
 struct LdsRegion { char* p; size_t n; std::vector<uint8_t> snap; };
 struct LdsImg { int region; std::vector<uint8_t> data; };
@@ -489,19 +489,30 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGl
 namespace simt { static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); } }
 
 namespace simt {
+// Device blocks end at an inaccessible page (the block is pushed against it, 16-byte granular): a kernel that reads or writes
+// behind a buffer faults here instead of picking up whatever the GPU's allocator left there.  SNF_SIMT_NO_GUARD=1 turns it off.
 inline void* dev_alloc(size_t n) {
-  const size_t bytes = ((n ? n : 1) + PAGE - 1) & ~(PAGE - 1);
-  void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-  if (q == MAP_FAILED) return nullptr;
-  std::memset(q, 0xA5, bytes);
+  const size_t data = ((n ? n : 1) + 15) & ~(size_t)15;
+  const size_t bytes = (data + PAGE - 1) & ~(PAGE - 1);
+  const bool guard = !std::getenv("SNF_SIMT_NO_GUARD");
+  char* q = (char*)mmap(nullptr, bytes + (guard ? PAGE : 0), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (q == (char*)MAP_FAILED) return nullptr;
+  const char* fill = std::getenv("SNF_SIMT_FILL");          // what fresh device memory holds (default 0xA5): results must not depend on it
+  std::memset(q, fill ? (int)std::strtol(fill, nullptr, 0) : 0xA5, bytes);
+  if (guard) mprotect(q + bytes, PAGE, PROT_NONE);
+  char* user = guard ? q + bytes - data : q;
   std::lock_guard<std::mutex> g(g_dev_mutex);
-  g_dev.push_back(DevBlock{(char*)q, bytes});
-  return q;
+  g_dev.push_back(DevBlock{q, bytes, user, guard});
+  return user;
 }
 inline bool dev_free(void* p) {
   if (!p) return true;
   std::lock_guard<std::mutex> g(g_dev_mutex);
-  for (size_t k = 0; k < g_dev.size(); k++) if (g_dev[k].base == (char*)p) { munmap(p, g_dev[k].bytes); g_dev[k] = g_dev.back(); g_dev.pop_back(); return true; }
+  for (size_t k = 0; k < g_dev.size(); k++) if (g_dev[k].user == (char*)p) {
+    munmap(g_dev[k].base, g_dev[k].bytes + (g_dev[k].guard ? PAGE : 0));
+    g_dev[k] = g_dev.back(); g_dev.pop_back();
+    return true;
+  }
   return false;
 }
 }  // namespace simt

@@ -126,6 +126,16 @@ def test_library_switches_keep_the_results(env, simt, oracle_mod, monkeypatch):
     assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
 
 
+@pytest.mark.parametrize("fill", ["0x00", "0xff", "0x7f"])
+def test_results_do_not_depend_on_fresh_device_memory(fill, simt, oracle_mod, monkeypatch):
+    """hipMalloc returns whatever was there: the stand-in fills new blocks with a byte of the test's choosing (0xA5 by default)."""
+    monkeypatch.setenv("SNF_SIMT_FILL", fill)
+    tis = [synth.gen_fuzz(77 + k, task_id=k) for k in range(3)] + [synth.gen_task(3, "chrS", 200_000, 60.0, seed=8, mosaic_frac=0.3)]
+    for kw in ({}, dict(mosaic=True, qc_nm=True)):
+        cfg = SnifflesConfig(**kw)
+        assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+
+
 def test_random_option_sets(simt, oracle_mod):
     """tools/dev/cfgfuzz.py: random combinations of some sixty hot-path options (filters, cluster / merge widths, mosaic and
     developer switches), three adversarial tasks each.  oracle/ref_cfgfuzz.py holds the oracle against the unmodified
