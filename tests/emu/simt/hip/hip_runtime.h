@@ -123,13 +123,30 @@ inline void switch_to(int k) {
   g_cur = k; threadIdx.x = (unsigned)k; g_n_switch++;
   snf_simt_switch(&g_fib[old].sp, g_fib[k].sp);
 }
-// next unfinished lane of the same wave / of the workgroup
+// next unfinished lane of the same wave / of the workgroup.  SNF_SIMT_ORDER=reverse | random[:seed] changes which lane runs
+// next (default: ascending round robin): a result that depends on it is a race between lanes that no barrier orders
+inline int g_order = 0;          // 0 ascending, 1 descending, 2 random
+inline unsigned long long g_rng = 0x9E3779B97F4A7C15ull;
+inline unsigned next_random() { g_rng ^= g_rng << 13; g_rng ^= g_rng >> 7; g_rng ^= g_rng << 17; return (unsigned)(g_rng >> 32); }
+inline void read_order() {
+  const char* e = std::getenv("SNF_SIMT_ORDER");
+  g_order = !e ? 0 : !std::strncmp(e, "reverse", 7) ? 1 : !std::strncmp(e, "random", 6) ? 2 : 0;
+  if (g_order == 2) { const char* c = std::strchr(e, ':'); g_rng = 0x9E3779B97F4A7C15ull ^ (c ? std::strtoull(c + 1, nullptr, 0) * 0xD1B54A32D192ED03ull : 0); if (!g_rng) g_rng = 1; }
+}
 inline void yield_wave() {
-  const int w0 = g_cur & ~63;
-  for (int d = 1; d < 64; d++) { const int k = w0 + ((g_cur - w0 + d) & 63); if (!g_fib[k].done) { switch_to(k); return; } }
+  const int w0 = g_cur & ~63, me = g_cur - w0;
+  const int off = g_order == 2 ? (int)(next_random() & 63) : 0;
+  for (int d = 1; d < 64; d++) {
+    const int k = w0 + (g_order == 0 ? (me + d) & 63 : g_order == 1 ? (me - d) & 63 : (me + 1 + ((d - 1 + off) % 63)) & 63);
+    if (!g_fib[k].done) { switch_to(k); return; }
+  }
 }
 inline void yield_block() {
-  for (int d = 1; d < g_n; d++) { const int k = (g_cur + d) % g_n; if (!g_fib[k].done) { switch_to(k); return; } }
+  const int off = g_order == 2 ? (int)(next_random() % (unsigned)(g_n > 1 ? g_n - 1 : 1)) : 0;
+  for (int d = 1; d < g_n; d++) {
+    const int k = g_order == 0 ? (g_cur + d) % g_n : g_order == 1 ? (g_cur - d + g_n) % g_n : (g_cur + 1 + ((d - 1 + off) % (g_n - 1))) % g_n;
+    if (!g_fib[k].done) { switch_to(k); return; }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ lock-step mode
@@ -359,8 +376,9 @@ inline void run_block(int nthreads) {
     sp[6] = (void*)&fibre_main; sp[7] = nullptr;
     g_fib[t].sp = (void*)sp; g_fib[t].done = false; g_st[t] = RUN;
   }
-  g_cur = 0; threadIdx = dim3(0, 0, 0);
-  snf_simt_switch(&g_main_sp, g_fib[0].sp);
+  g_cur = g_order == 0 ? 0 : g_order == 1 ? nthreads - 1 : (int)(next_random() % (unsigned)nthreads);
+  threadIdx = dim3((unsigned)g_cur, 0, 0);
+  snf_simt_switch(&g_main_sp, g_fib[g_cur].sp);
   if (!g_abandon) uni_merge();
   else { u_pre.clear(); u_post.clear(); u_lds_post.clear(); u_lane_dirty.clear(); }
 }
@@ -369,6 +387,7 @@ template <class K, class... A>
 inline void launch(const char* name, K kernel, unsigned grid, unsigned block, A... args) {
   std::lock_guard<std::mutex> one_launch_at_a_time(g_launch_mutex);   // host threads may drive several batches
   gridDim = dim3(grid); blockDim = dim3(block);
+  read_order();
   g_kernel = name; g_uniform = std::strncmp(name, "x_big", 5) == 0; g_abandon = false; g_n_launches++;
   g_body = [&]() { kernel(args...); };
   const bool lockstep = g_uniform && block == 64 && !std::getenv("SNF_SIMT_NO_LOCKSTEP") && uni_begin(name);

@@ -136,6 +136,19 @@ def test_results_do_not_depend_on_fresh_device_memory(fill, simt, oracle_mod, mo
         assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
 
 
+@pytest.mark.parametrize("order", ["reverse", "random:3", "random:11"])
+def test_results_do_not_depend_on_the_order_lanes_run_in(order, simt, oracle_mod, monkeypatch):
+    """Between two synchronisation points the stand-in runs the lanes of a wave one after the other, by default in ascending
+    order; a kernel whose result changes with that order has a race no barrier covers."""
+    monkeypatch.setenv("SNF_SIMT_ORDER", order)
+    tis = [synth.gen_fuzz(177 + k, task_id=k) for k in range(3)] + [synth.gen_task(3, "chrS", 200_000, 60.0, seed=9, mosaic_frac=0.3)]
+    cfg = SnifflesConfig(mosaic=True)
+    assert records.records(run(simt.lib(), cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    probs = _cons_problems()[:60]
+    got, cls, _ = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6)
+    assert got == [p["expected"] for p in probs]
+
+
 def test_random_option_sets(simt, oracle_mod):
     """tools/dev/cfgfuzz.py: random combinations of some sixty hot-path options (filters, cluster / merge widths, mosaic and
     developer switches), three adversarial tasks each.  oracle/ref_cfgfuzz.py holds the oracle against the unmodified
