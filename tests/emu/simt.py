@@ -18,45 +18,66 @@ CSRC = os.path.join(ROOT, "sniffles_amd", "csrc")
 SIMT = os.path.join(HERE, "simt")
 OBJ = os.path.join(HERE, "_build", "simt_obj")
 SO = os.path.join(HERE, "_build", "libsnf_simt.so")
+SO_UB = os.path.join(HERE, "_build", "libsnf_simt_ub.so")
 # the product's four translation units, unchanged, plus the shim's counters and the consensus-instance harness
 SOURCES = [os.path.join(CSRC, f) for f in ("snf_lib.hip", "snf_myers.hip", "snf_combine.hip", "snf_extract.hip")] + \
           [os.path.join(SIMT, f) for f in ("simt_api.cpp", "wave_cons_harness.cpp", "shim_selftest.cpp")]
-FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function",
+FLAGS = ["-x", "c++", "-std=c++17", "-O2", "-g", "-ffp-contract=off", "-fPIC", "-fno-gnu-unique", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-misleading-indentation", "-Wno-unknown-pragmas", "-Wno-attributes", "-I" + SIMT, "-I" + CSRC]
 _lib = None
+_lib_ub = None
 
 
-def build():
-    os.makedirs(OBJ, exist_ok=True)
+def build(sanitize=False):
+    """sanitize: a second library with -fsanitize=undefined,bounds-strict (shifts by the operand width or more, signed overflow,
+    indices beyond statically sized arrays - LDS arrays included - ...): what x86 tolerates silently the GPU may not."""
+    so = SO_UB if sanitize else SO
+    obj = OBJ + ("_ub" if sanitize else "")
+    os.makedirs(obj, exist_ok=True)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "sniffles_amd.h")]
     for d, _, fs in os.walk(SIMT):
         deps += [os.path.join(d, f) for f in fs]
-    if not os.path.exists(SO) or any(os.path.getmtime(d) > os.path.getmtime(SO) for d in deps):
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        flags = list(FLAGS)
+        if sanitize:
+            flags[flags.index("-O2")] = "-O1"
+            flags += ["-fsanitize=undefined", "-fsanitize=bounds-strict", "-fno-sanitize=alignment,vptr"]   # (unaligned 8 / 16-byte loads are the kernels' idiom)
         objs, procs = [], []
         for src in SOURCES:
-            o = os.path.join(OBJ, os.path.basename(src) + ".o")
+            o = os.path.join(obj, os.path.basename(src) + ".o")
             objs.append(o)
-            procs.append(subprocess.Popen(["g++"] + FLAGS + ["-c", src, "-o", o]))
+            procs.append(subprocess.Popen(["g++"] + flags + ["-c", src, "-o", o]))
         if any(p.wait() != 0 for p in procs):
             raise RuntimeError("the SIMT build of sniffles_amd/csrc failed")
-        subprocess.run(["g++", "-shared", "-o", SO] + objs + ["-lpthread", "-ldl"], check=True)
-    return SO
+        subprocess.run(["g++", "-shared", "-o", so] + (["-fsanitize=undefined"] if sanitize else []) + objs + ["-lpthread", "-ldl"], check=True)
+    return so
+
+
+def _bind(path):
+    from sniffles_amd import lib as L
+    h = L.bind(C.CDLL(path))
+    u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    h.simt_consensus_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p,
+                                       i64p, i64p, i32p, u8p, i64p, i32p, i64p]
+    h.simt_consensus_batch.restype = C.c_int
+    h.simt_last_error.restype = C.c_char_p
+    h.snf_simt_counters.argtypes = [C.POINTER(C.c_ulonglong)]
+    h.snf_simt_unmodelled.restype = C.c_ulonglong
+    return h
+
+
+def lib_sanitized():
+    global _lib_ub
+    if _lib_ub is None:
+        _lib_ub = _bind(build(sanitize=True))
+    return _lib_ub
 
 
 def lib():
     """The WHOLE library (every kernel, wave kernels included) on the host: same C-ABI as libsniffles_amd.so."""
     global _lib
     if _lib is None:
-        from sniffles_amd import lib as L
-        h = L.bind(C.CDLL(build()))
-        u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
-        h.simt_consensus_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p,
-                                           i64p, i64p, i32p, u8p, i64p, i32p, i64p]
-        h.simt_consensus_batch.restype = C.c_int
-        h.simt_last_error.restype = C.c_char_p
-        h.snf_simt_counters.argtypes = [C.POINTER(C.c_ulonglong)]
-        h.snf_simt_unmodelled.restype = C.c_ulonglong
-        _lib = h
+        _lib = _bind(build())
     return _lib
 
 
@@ -72,7 +93,7 @@ def unmodelled():
     return int(lib().snf_simt_unmodelled())
 
 
-def consensus_batch(problems, klen, mode=0, nw=4, grid_cap=0, min_reads=0):
+def consensus_batch(problems, klen, mode=0, nw=4, grid_cap=0, min_reads=0, _lib=None):
     """problems: [(best, [others], skip)] -> (list of str, classes, handed_over).  Same packing as
     sniffles_amd.consensus.novel_from_reads_batch; the kernels are the product's, run through the fibre shim.
     mode 0: the class the product picks, 2: SMALL calls through the LARGE instance, 4: everything through ROWS;
@@ -98,7 +119,7 @@ def consensus_batch(problems, klen, mode=0, nw=4, grid_cap=0, min_reads=0):
     out = np.zeros(max(1, int(out_off[-1])), np.uint8)
     cls = np.zeros(max(1, n), np.int32)
     handed = C.c_int64(0)
-    L = lib()
+    L = _lib or lib()
     u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     rc = L.simt_consensus_batch(mode, nw, grid_cap, min_reads, int(klen), pool.ctypes.data_as(u8p), C.c_int64(pos), C.c_int64(n),
                                 best_off.ctypes.data_as(i64p), best_len.ctypes.data_as(i32p), skips.ctypes.data_as(i32p),

@@ -149,6 +149,34 @@ def test_results_do_not_depend_on_the_order_lanes_run_in(order, simt, oracle_mod
     assert got == [p["expected"] for p in probs]
 
 
+def test_no_undefined_behaviour_in_the_kernels(simt, oracle_mod, capfd):
+    """The same sources with -fsanitize=undefined,bounds-strict: a shift by 64, a signed overflow or an index beyond a
+    statically sized (LDS) array gives the x86 answer here and possibly another one on the GPU - the sanitizer reports it."""
+    L = simt.lib_sanitized()
+    tis = [synth.gen_fuzz(277 + k, task_id=k) for k in range(3)] + [synth.gen_task(3, "chrS", 200_000, 90.0, seed=10, mosaic_frac=0.3)]
+    for kw in ({}, dict(mosaic=True, qc_nm=True, repeat=True)):
+        cfg = SnifflesConfig(**kw)
+        assert records.records(run(L, cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    probs = _cons_problems()
+    for kw in (dict(), dict(mode=4), dict(nw=1), dict(nw=8)):
+        got, _, _ = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6, _lib=L, **kw)
+        assert got == [p["expected"] for p in probs]
+    import emu.emu as E
+    import test_combine as TC
+    import test_edit_distance as TE
+    import test_extract as TX
+    orig = E.lib
+    E.lib = lambda: L
+    try:
+        TC.test_emulated_combine_matches_reference(TC.NAMES[-1])
+        TE.test_edit_distance_banded_emulated(oracle_mod)
+        TX.test_kernel_bodies_match_reference(sorted(cases.EXTRACT)[0], L)
+    finally:
+        E.lib = orig
+    err = capfd.readouterr().err
+    assert "runtime error" not in err, err[-3000:]
+
+
 def test_random_option_sets(simt, oracle_mod):
     """tools/dev/cfgfuzz.py: random combinations of some sixty hot-path options (filters, cluster / merge widths, mosaic and
     developer switches), three adversarial tasks each.  oracle/ref_cfgfuzz.py holds the oracle against the unmodified
