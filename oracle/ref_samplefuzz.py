@@ -80,6 +80,11 @@ def main():
                 diffs.append(f"read_count {res.read_count} != {ref['read_count']}")
             assert_same_text(canon(buf.getvalue()), canon(ref["vcf"]))
             n_rec += res.vcf_records; n_reads += res.read_count
+            # the same text straight from the record table, without SVCall objects (vcf.VCF.write_records)
+            buf2 = io.StringIO()
+            res2 = pipeline.call_sample(recs, config_for(args), vcf_handle=buf2, tandem_repeats=recs.tandem_repeats, _lib=L, objects=False)
+            assert buf2.getvalue() == buf.getvalue(), "record-table writer differs from the object path"
+            assert res2.vcf_records == res.vcf_records and not res2.calls
         except AssertionError as e:
             diffs.append(str(e)[:500])
         except Exception as e:

@@ -690,6 +690,158 @@ done:
   return ret;
 }
 
+
+/* ======================================================================================================================
+ * vcf_records(): single-sample VCF lines straight from the record table (sniffles_amd/vcf.py::VCF.write_records): what
+ * materialize + apply_final + VCF.write_call (vcf.py:216-350 of the reference) produce for the same records, without the
+ * SVCall objects in between.  Serves the BAM -> VCF flow when no reference FASTA is attached and no SNF is written.
+ * ====================================================================================================================== */
+typedef struct { char* p; size_t n, cap; } OutBuf;
+static int ob_room(OutBuf* b, size_t extra) {
+  if (b->n + extra <= b->cap) return 0;
+  size_t cap = b->cap ? b->cap : 1 << 16;
+  while (cap < b->n + extra) cap *= 2;
+  char* q = (char*)realloc(b->p, cap);
+  if (!q) { PyErr_NoMemory(); return -1; }
+  b->p = q; b->cap = cap;
+  return 0;
+}
+static int ob_put(OutBuf* b, const char* s, size_t n) { if (ob_room(b, n)) return -1; memcpy(b->p + b->n, s, n); b->n += n; return 0; }
+static int ob_str(OutBuf* b, const char* s) { return ob_put(b, s, strlen(s)); }
+static int ob_ll(OutBuf* b, long long v) { char t[32]; int n = snprintf(t, sizeof t, "%lld", v); return ob_put(b, t, (size_t)n); }
+static int ob_f3(OutBuf* b, double v) {      /* f"{v:.3f}" */
+  if (isnan(v)) return ob_str(b, "nan");
+  if (isinf(v)) return ob_str(b, v < 0 ? "-inf" : "inf");
+  char t[352]; int n = snprintf(t, sizeof t, "%.3f", v); return ob_put(b, t, (size_t)n);
+}
+static int ob_py(OutBuf* b, PyObject* s) {   /* a str */
+  Py_ssize_t n; const char* u = PyUnicode_AsUTF8AndSize(s, &n);
+  return u ? ob_put(b, u, (size_t)n) : -1;
+}
+static int ob_name(OutBuf* b, PyObject* list, long i, const char* prefix) {   /* list[i] or f"{prefix}{i}" */
+  if (list != Py_None) { PyObject* s = PyList_GetItem(list, i); return s ? ob_py(b, s) : -1; }
+  if (ob_str(b, prefix)) return -1;
+  return ob_ll(b, i);
+}
+static int ob_ps(OutBuf* b, int code, PyObject* ps_names, const char* none) {   /* sv._ps as text */
+  if (code == -1) return ob_str(b, none);
+  if (code == -2) return ob_str(b, "NULL");
+  return ob_name(b, ps_names, code, "");
+}
+
+/* vcf_records(records: buffer, order: buffer int64 (record indices in output order), rnames: buffer uint32, alt_pool: buffer,
+ *             qnames: list | None, ps_names: list | None, contig: str, task_id: int, contig_names: list | None,
+ *             filters: list[str], opts: dict(id_prefix str, mosaic, mosaic_af_max, output_rnames, nm, phase, symbolic, minsvlen,
+ *             genotype_format str, genotype_none str)) -> (bytes, records written) */
+static PyObject* py_vcf_records(PyObject* self, PyObject* args) {
+  PyObject *qnames, *ps_names, *contig, *contig_names, *filters, *opts;
+  Py_buffer rec, ord, rn, pool;
+  long long task_id;
+  if (!PyArg_ParseTuple(args, "y*y*y*y*OOULOO!O!", &rec, &ord, &rn, &pool, &qnames, &ps_names, &contig, &task_id, &contig_names,
+                        &PyList_Type, &filters, &PyDict_Type, &opts))
+    return NULL;
+  PyObject* ret = NULL;
+  OutBuf b = {NULL, 0, 0};
+  long long written = 0;
+#define OPT(name) PyDict_GetItemString(opts, name)
+  PyObject *o_prefix = OPT("id_prefix"), *o_fmt = OPT("genotype_format"), *o_none = OPT("genotype_none");
+  if (!o_prefix || !o_fmt || !o_none || !OPT("mosaic") || !OPT("mosaic_af_max") || !OPT("output_rnames") || !OPT("nm") || !OPT("phase") ||
+      !OPT("symbolic") || !OPT("minsvlen")) { PyErr_SetString(PyExc_KeyError, "vcf_records: incomplete options"); goto done; }
+  const int mosaic = PyObject_IsTrue(OPT("mosaic")), out_rn = PyObject_IsTrue(OPT("output_rnames")), with_nm = PyObject_IsTrue(OPT("nm"));
+  const int phase = PyObject_IsTrue(OPT("phase")), symbolic = PyObject_IsTrue(OPT("symbolic"));
+  const double af_max = PyFloat_AsDouble(OPT("mosaic_af_max"));
+  const long long minsvlen = PyLong_AsLongLong(OPT("minsvlen"));
+  if (PyErr_Occurred()) goto done;
+#undef OPT
+  const snf_call_t* C = (const snf_call_t*)rec.buf;
+  const long long n_rec = rec.len / (long long)sizeof(snf_call_t), n_ord = ord.len / 8, rn_n = rn.len / 4;
+  const int64_t* O = (const int64_t*)ord.buf;
+  const uint32_t* RN = (const uint32_t*)rn.buf;
+  for (long long k = 0; k < n_ord; k++) {
+    if (O[k] < 0 || O[k] >= n_rec) { PyErr_SetString(PyExc_ValueError, "record index outside the table"); goto done; }
+    const snf_call_t* c = &C[O[k]];
+    if (c->svtype < 0 || c->svtype > 6 || c->filter < 0 || c->filter >= PyList_GET_SIZE(filters)) { PyErr_SetString(PyExc_ValueError, "record field out of range"); goto done; }
+    if (c->svtype >= 5) continue;                                            /* single breaks are not written (vcf.py:218) */
+    const int bnd = c->svtype == SNF_BND, ins = c->svtype == SNF_INS;
+    const long long pos = c->pos > 0 ? c->pos : 1;
+    long long svlen = c->svlen;
+    const int resolved = ins && c->alt_len >= 0 && !symbolic;                /* the consensus / best read, not "<INS>" */
+    if (resolved) {
+      if (c->alt_off < 0 || c->alt_off + c->alt_len > pool.len) { PyErr_SetString(PyExc_ValueError, "ALT range outside the pool"); goto done; }
+      if (svlen != c->alt_len) svlen = c->alt_len;                          /* SVLEN follows the sequence (vcf.py:253-254) */
+    }
+    if (ins && svlen < minsvlen) continue;
+    const long long end = (c->precise && c->svtype == SNF_DEL) ? pos + (svlen < 0 ? -svlen : svlen) : c->end;
+    const size_t line_start = b.n;
+    /* CHROM POS ID REF ALT */
+    if (ob_py(&b, contig) || ob_str(&b, "\t") || ob_ll(&b, pos) || ob_str(&b, "\t") || ob_py(&b, o_prefix)) goto done;
+    { char idbuf[64]; snprintf(idbuf, sizeof idbuf, "%s.%XS%llX", SVTYPES[c->svtype], (unsigned)c->sv_id, (unsigned long long)task_id);
+      if (ob_str(&b, idbuf) || ob_str(&b, "\tN\t")) goto done; }
+    if (bnd) {     /* sv.py:630-634; also with --symbolic (vcf.py:322-324 leaves BND ALTs alone) */
+      const char* br = c->bnd_is_reverse ? "]" : "[";
+      if (ob_str(&b, c->bnd_is_first ? "N" : "") || ob_str(&b, br) || ob_name(&b, contig_names, c->mate_contig, "ctg") || ob_str(&b, ":") ||
+          ob_ll(&b, c->mate_ref_start) || ob_str(&b, br) || ob_str(&b, c->bnd_is_first ? "" : "N")) goto done;
+    } else if (resolved) {
+      if (ob_put(&b, (const char*)pool.buf + c->alt_off, (size_t)c->alt_len)) goto done;
+    } else {
+      if (ob_str(&b, "<") || ob_str(&b, SVTYPES[c->svtype]) || ob_str(&b, ">")) goto done;
+    }
+    /* QUAL FILTER */
+    { const long long q = c->qual < 0 ? 0 : c->qual > 60 ? 60 : c->qual;
+      if (ob_str(&b, "\t") || ob_ll(&b, q) || ob_str(&b, "\t") || ob_py(&b, PyList_GET_ITEM(filters, c->filter)) || ob_str(&b, "\t")) goto done; }
+    /* INFO */
+    if (ob_str(&b, c->precise ? "PRECISE" : "IMPRECISE")) goto done;
+    if (mosaic && (c->gt_set ? c->vaf : 0.0) <= af_max) { if (ob_str(&b, ";MOSAIC")) goto done; }
+    if (ob_str(&b, ";SVTYPE=") || ob_str(&b, SVTYPES[c->svtype])) goto done;
+    if (!bnd) { if (ob_str(&b, ";SVLEN=") || ob_ll(&b, svlen) || ob_str(&b, ";END=") || ob_ll(&b, end)) goto done; }
+    if (ob_str(&b, ";SUPPORT=") || ob_ll(&b, c->support)) goto done;
+    if (out_rn) {
+      if (c->rn_off < 0 || c->rn_len < 0 || c->rn_off + c->rn_len > rn_n) { PyErr_SetString(PyExc_ValueError, "read-name range outside the table"); goto done; }
+      if (ob_str(&b, ";RNAMES=")) goto done;
+      for (int q = 0; q < c->rn_len; q++) { if ((q && ob_str(&b, ",")) || ob_name(&b, qnames, (long)RN[c->rn_off + q], "q")) goto done; }
+    }
+    if (ob_str(&b, ";COVERAGE=")) goto done;
+    { const int idx[5] = {0, 1, 2, 3, 4};
+      for (int q = 0; q < 5; q++) { if ((q && ob_str(&b, ",")) || ob_ll(&b, c->cov[idx[q]])) goto done; } }
+    if (ob_str(&b, ";STRAND=") || ob_str(&b, c->fwd > 0 ? "+" : "") || ob_str(&b, c->rev > 0 ? "-" : "")) goto done;
+    if (with_nm) { if (ob_str(&b, ";NM=") || ob_f3(&b, c->nm)) goto done; }
+    /* call.info, sorted by key: CHR2 < COVERAGE_VAR (None: not written) < PHASE < STDEV_LEN < STDEV_POS < SUPPORT_LONG < SUPPORT_SA < VAF */
+    if (bnd) { if (ob_str(&b, ";CHR2=") || ob_name(&b, contig_names, c->mate_contig, "ctg")) goto done; }
+    if (c->ph_set) {
+      if (ob_str(&b, ";PHASE=") || ob_ll(&b, c->ph_hp) || ob_str(&b, ",") || ob_ps(&b, c->ph_ps, ps_names, "None") || ob_str(&b, ",") ||
+          ob_ll(&b, c->ph_hp_support) || ob_str(&b, ",") || ob_ll(&b, c->ph_ps_support) || ob_str(&b, c->ph_hp_pass ? ",PASS" : ",FAIL") ||
+          ob_str(&b, c->ph_ps_pass ? ",PASS" : ",FAIL")) goto done;
+    }
+    { const int single = c->fwd + c->rev < 2;      /* util.stdev returns the int 0 for fewer than two values */
+      if (!isnan(c->stdev_len)) { if (ob_str(&b, ";STDEV_LEN=") || (single ? ob_str(&b, "0") : ob_f3(&b, c->stdev_len))) goto done; }
+      if (ob_str(&b, ";STDEV_POS=") || (single ? ob_str(&b, "0") : ob_f3(&b, c->stdev_pos))) goto done; }
+    if (ins) { if (ob_str(&b, ";SUPPORT_LONG=") || ob_ll(&b, c->support_long)) goto done; }
+    if (c->svtype == SNF_DEL) { if (ob_str(&b, ";SUPPORT_SA=") || ob_ll(&b, c->support_sa)) goto done; }
+    if (c->gt_set) { if (ob_str(&b, ";VAF=") || ob_f3(&b, c->vaf)) goto done; }
+    /* FORMAT + the sample column (vcf.py:54-83) */
+    if (ob_str(&b, "\t") || ob_py(&b, o_fmt) || ob_str(&b, "\t")) goto done;
+    if (!c->gt_set) { if (ob_py(&b, o_none)) goto done; }
+    else {
+      int a = c->gt_a, bb = c->gt_b;
+      const int hp_set = c->gt_hp >= 0;
+      const char* sep = "/";
+      if (phase && hp_set && ((a == 0 && bb == 1) || (a == 1 && bb == 1))) { sep = "|"; if (c->gt_hp == 1) { const int t = a; a = bb; bb = t; } }
+      if (ob_ll(&b, a) || ob_str(&b, sep) || ob_ll(&b, bb) || ob_str(&b, ":") || ob_ll(&b, c->gt_gq) || ob_str(&b, ":") || ob_ll(&b, c->gt_dr) ||
+          ob_str(&b, ":") || ob_ll(&b, c->gt_dv)) goto done;
+      if (phase) { if (ob_str(&b, ":") || (c->gt_ps == -1 || c->gt_ps == -2 ? ob_str(&b, ".") : ob_ps(&b, c->gt_ps, ps_names, "."))) goto done; }
+    }
+    if (ob_str(&b, "\n")) goto done;
+    (void)line_start;
+    written++;
+  }
+  { PyObject* bytes = PyBytes_FromStringAndSize(b.p ? b.p : "", (Py_ssize_t)b.n);
+    if (bytes) { ret = Py_BuildValue("(NL)", bytes, written); } }
+done:
+  free(b.p);
+  PyBuffer_Release(&rec); PyBuffer_Release(&ord); PyBuffer_Release(&rn); PyBuffer_Release(&pool);
+  return ret;
+}
+
 static PyMethodDef methods[] = {
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
@@ -697,6 +849,7 @@ static PyMethodDef methods[] = {
     {"gather_pool", py_gather_pool, METH_VARARGS, "strings of a pool in a given order, back to back"},
     {"flush_windows", py_flush_windows, METH_VARARGS, "flush windows of CombineTask.execute over the sorted candidate table"},
     {"group_calls", py_group_calls, METH_VARARGS, "group records + membership -> combined SVCall objects"},
+    {"vcf_records", py_vcf_records, METH_VARARGS, "single-sample VCF lines straight from the record table"},
     {NULL, NULL, 0, NULL}};
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_snf_fast", "C materialiser of sniffles_amd.sv", -1, methods};
 

@@ -76,6 +76,21 @@ class Task:
         self.coverage_average_total = float(res.coverage_average_total[0])
         return out
 
+    def call_records(self, config):
+        """call_candidates + finalize_candidates without the `SVCall` objects: the finalized record table of the task
+        (`lib.Result`) and its input, for consumers that format or count straight from the records (vcf.VCF.write_records)."""
+        self._open(config)
+        self._batch.call_candidates()
+        res = self._batch.fetch(0, copy=False)
+        if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
+            raise UnboundLocalError("local variable 'end' referenced before assignment")
+        self._batch.finalize()
+        res = self._batch.fetch(1, copy=False)
+        self._finalized = True
+        self.sv_id += len(res.calls)
+        self.coverage_average_total = float(res.coverage_average_total[0])
+        return res, self._ti
+
     def finalize_candidates(self, candidates, keep_qc_fails, config) -> list:
         if self._batch is None or getattr(self, "_finalized", False):
             raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")

@@ -64,10 +64,12 @@ def _no_regions(config, what: str) -> None:
 
 
 def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
-                _lib=None) -> SampleResult:
+                _lib=None, objects: bool = True) -> SampleResult:
     """`records`: `bam.read_bam(path)`.  `tandem_repeats`: {contig: [(start, end), ...]} (already padded, util.py:121-144).
     Writes the VCF to `vcf_handle` and / or the SNF to `snf_path` (CallTask.execute switches QC filtering off for the
-    candidates when an SNF is requested, parallel.py:258-263)."""
+    candidates when an SNF is requested, parallel.py:258-263).
+    `objects=False`: VCF only, formatted straight from the record table (vcf.VCF.write_records) - the same text, no `SVCall`
+    objects (`SampleResult.calls` stays empty); falls back to the object path when a reference FASTA is attached."""
     import struct
     _no_regions(config, "call_sample")
     flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
@@ -93,6 +95,19 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
                                                             task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
         task.lead_provider = _Extracted(ti)
+        if not objects and snf_out is None and writer is not None and writer.can_write_records():
+            import numpy as np
+            try:
+                res, ti_used = task.call_records(config)
+            finally:
+                extractor.close()
+            keep = np.arange(len(res.calls)) if config.no_qc else np.flatnonzero(res.calls["qc"] != 0)
+            if getattr(config, "sort", True):
+                keep = keep[np.argsort(res.calls["pos"][keep], kind="stable")]
+            out.vcf_records += writer.write_records(res, ti_used, keep)
+            out.read_count += info.read_count
+            task.close()
+            continue
         try:
             cands = task.call_candidates(qc, config)
         finally:

@@ -74,6 +74,16 @@ _INFO_POPULATION = [("POPULATION_AF", "1", "Float", "Population Allele Frequency
                     ("POPULATION_SIZE", "1", "Integer", "Size of genotyped population for this variant")]
 
 
+def _fast():
+    from . import sv
+    return sv._load_fast()
+
+
+def _filters():
+    from . import sv
+    return sv.FILTERS
+
+
 def format_info(key, value) -> str:
     """One INFO entry (vcf.py:26-37): floats with three decimals, lists joined, None as '.', True as a bare flag."""
     if isinstance(value, float):
@@ -277,6 +287,30 @@ class VCF:
         self.write_raw("\t".join(str(v) for v in row))
         self.call_count += 1
         return 1
+
+    def can_write_records(self) -> bool:
+        """The record-table writer serves the plain single-sample case: no reference FASTA attached (REF / ALT stay "N" /
+        the consensus), one sample column, no SVLENGTHS."""
+        cfg = self.config
+        return (self.reference_handle is None and len(cfg.sample_ids_vcf) == 1 and cfg.sample_ids_vcf[0][0] == 0
+                and not cfg.dev_emit_sv_lengths and cfg.mode != "combine" and _fast() is not None)
+
+    def write_records(self, res, ti, order) -> int:
+        """The records `order` (indices into `res.calls`, output order) of a finalized single-sample batch as VCF lines: the
+        text `write_call` produces for the `SVCall` objects of the same records (sv.materialize_candidates + apply_final),
+        formatted straight from the record table by the C extension.  Returns the number of lines written."""
+        import numpy as np
+        cfg = self.config
+        opts = dict(id_prefix=cfg.id_prefix, mosaic=bool(cfg.mosaic), mosaic_af_max=float(cfg.mosaic_af_max),
+                    output_rnames=bool(cfg.output_rnames), nm="NM" in self.info_order, phase=bool(cfg.phase), symbolic=bool(cfg.symbolic),
+                    minsvlen=int(cfg.minsvlen), genotype_format=self.genotype_format,
+                    genotype_none=format_genotype(self.default_genotype, cfg.phase))
+        text, n = _fast().vcf_records(np.ascontiguousarray(res.calls), np.ascontiguousarray(order, np.int64),
+                                      np.ascontiguousarray(res.rnames, np.uint32), np.ascontiguousarray(res.alt_pool, np.uint8),
+                                      ti.qnames, ti.ps_names, ti.contig, int(ti.task_id), ti.contig_names, list(_filters()), opts)
+        self.handle.write(text.decode("utf-8"))
+        self.call_count += n
+        return n
 
     # ---- force calling: targets in, the same lines with this sample's genotype out (vcf.py:352-481)
     def read_svs_iter(self):

@@ -68,6 +68,11 @@ def run_sample(name, tmp_path, _lib, through_file):
     assert res.read_count == doc["read_count"]
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert res.vcf_records == len(vu.split_text(doc["vcf"])[1])
+    # the same text straight from the record table (vcf.VCF.write_records): no SVCall objects
+    buf = io.StringIO()
+    res2 = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr, _lib=_lib, objects=False)
+    assert_same_text(buf.getvalue(), doc["vcf"])
+    assert res2.vcf_records == res.vcf_records and res2.read_count == res.read_count and not res2.calls
     # VCF + SNF (the candidates are not QC-filtered then)
     buf = io.StringIO()
     cfg = config_for(args)

@@ -57,6 +57,37 @@ def single_sample_text(name, variant, _lib):
     return write_text(calls, cfg, [(ti.contig, ti.contig_len)], fasta)
 
 
+def single_sample_text_from_records(name, variant, _lib):
+    """The same case through the record-table writer (vcf.VCF.write_records): no SVCall objects."""
+    import numpy as np
+    build, kw, _ = cases.ALL[name]
+    _, overrides, with_fasta = vu.VARIANTS[variant]
+    assert not with_fasta
+    ti = build()
+    cfg = gu.make_config({**kw, **overrides}, ti)
+    for k, v in vu.FIXED.items():
+        setattr(cfg, k, v)
+    lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+    for ld in leads_of(ti):
+        lp.record_lead(ld, int(ld.ref_start / cfg.cluster_binsize) * cfg.cluster_binsize)
+    for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
+        lp.record_read(s, e, hp)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                             lead_provider=lp, _lib=_lib)
+    task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
+    res, ti_used = task.call_records(cfg)
+    buf = io.StringIO()
+    w = vcf.VCF(cfg, buf)
+    assert w.can_write_records()
+    w.write_header([(ti.contig, ti.contig_len)])
+    keep = np.arange(len(res.calls)) if cfg.no_qc else np.flatnonzero(res.calls["qc"] != 0)
+    keep = keep[np.argsort(res.calls["pos"][keep], kind="stable")]
+    n = w.write_records(res, ti_used, keep)
+    task.close()
+    assert n == w.call_count
+    return buf.getvalue()
+
+
 def assert_same_text(got, want):
     gh, gr = vu.split_text(got)
     wh, wr = vu.split_text(want)
@@ -76,6 +107,14 @@ EMU_CASES = [c for c in vu.CASES if not c.startswith("chr")] + ["chr18_20x_auto_
 def test_single_sample_vcf_emu(name, variant):
     import emu.emu as E
     assert_same_text(single_sample_text(name, variant, E.lib()), gold()["single"][name]["text"][variant])
+
+
+@pytest.mark.parametrize("variant", sorted(v for v in vu.VARIANTS if not vu.VARIANTS[v][2]))
+@pytest.mark.parametrize("name", EMU_CASES)
+def test_single_sample_vcf_from_the_record_table_emu(name, variant):
+    """vcf.VCF.write_records (C formatter over the finalized records, no SVCall objects) writes the reference's text too."""
+    import emu.emu as E
+    assert_same_text(single_sample_text_from_records(name, variant, E.lib()), gold()["single"][name]["text"][variant])
 
 
 @pytest.mark.gpu
