@@ -29,6 +29,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 #include <dlfcn.h>
 #include <elf.h>
@@ -391,7 +392,12 @@ inline void launch(const char* name, K kernel, unsigned grid, unsigned block, A.
   g_kernel = name; g_uniform = std::strncmp(name, "x_big", 5) == 0; g_abandon = false; g_n_launches++;
   g_body = [&]() { kernel(args...); };
   const bool lockstep = g_uniform && block == 64 && !std::getenv("SNF_SIMT_NO_LOCKSTEP") && uni_begin(name);
-  for (unsigned b = 0; b < grid && !g_abandon; b++) { blockIdx = dim3(b); run_block((int)block); }
+  // workgroups run one after the other; with SNF_SIMT_ORDER also in descending / shuffled order (the hardware promises none):
+  // a kernel that needs an earlier workgroup to be through, or whose result depends on who appended to a list first, shows here
+  std::vector<unsigned> blocks(grid);
+  for (unsigned b = 0; b < grid; b++) blocks[b] = g_order == 1 ? grid - 1 - b : b;
+  if (g_order == 2) for (unsigned b = grid; b > 1; b--) { const unsigned j = next_random() % b; std::swap(blocks[b - 1], blocks[j]); }
+  for (unsigned k = 0; k < grid && !g_abandon; k++) { blockIdx = dim3(blocks[k]); run_block((int)block); }
   if (lockstep) uni_end();
   g_body = nullptr; g_kernel = "";
 }
