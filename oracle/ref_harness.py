@@ -529,7 +529,8 @@ def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
         for task_id, (contig, length) in enumerate(contig_lengths):
             task = ref.parallel.CallTask(id=task_id, contig=contig, start=0, end=length - 1, assigned_process_id=None,
                                          tandem_repeats=(getattr(recs, "tandem_repeats", None) or {}).get(contig),
-                                         genotype_svs=None, sv_id=0, config=cfg, regions=None)
+                                         genotype_svs=None, sv_id=0, config=cfg,
+                                         regions=(getattr(cfg, "regions_by_contig", None) or {}).get(contig))   # sniffles:351
             result = task.execute()
             read_count += result.processed_read_count
             result.emit(vcf_out=vcf_out, snf_out=snf_out)
@@ -655,7 +656,8 @@ def run_reference_genotype_vcf(recs, vcf_text, extra_args=(), fixed=None):
             targets = [t for t in by_contig.get(contig, []) if 0 <= t.pos < length - 1]
             task = ref.parallel.GenotypeTask(id=task_id, contig=contig, start=0, end=length - 1, assigned_process_id=None,
                                              tandem_repeats=(getattr(recs, "tandem_repeats", None) or {}).get(contig),
-                                             genotype_svs=targets, sv_id=0, config=cfg, regions=None)
+                                             genotype_svs=targets, sv_id=0, config=cfg,
+                                             regions=(getattr(cfg, "regions_by_contig", None) or {}).get(contig))   # sniffles:351
             result = task.execute()
             if result is not None:
                 result.emit(vcf_out=vcf_out, genotype_lineindex_order=order)

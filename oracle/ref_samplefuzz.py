@@ -50,7 +50,7 @@ def main():
     else:
         from emu import emu as E
     L = E.lib()
-    bad = 0; n_rec = 0; n_reads = 0; t0 = time.time()
+    bad = 0; n_rec = 0; n_reads = 0; n_regions = 0; t0 = time.time()
     for it in range(seed0, seed0 + n_iter):
         rng = np.random.default_rng([it, 8388607])
         args, seen = [], set()
@@ -65,8 +65,27 @@ def main():
                                    tr_frac=float(rng.choice([0.0, 0.3])))
         recs = bam.records_from_list(out[0], out[1], out[2])
         recs.tandem_repeats = out[3] if len(out) > 3 else None
+        # --regions: a BED file of one to three intervals (overlapping ones included) on some of the contigs
+        regions, bed = None, None
+        if rng.random() < 0.35:
+            import tempfile
+            regions = {}
+            lines = []
+            for name, ln in zip(out[0], out[1]):
+                if rng.random() < 0.7:
+                    for _ in range(int(rng.integers(1, 4))):
+                        a = int(rng.integers(0, ln - 50_000)); b = a + int(rng.integers(20_000, 600_000))
+                        regions.setdefault(name, []).append((name, a, min(b, ln)))
+                        lines.append(f"{name}\t{a}\t{min(b, ln)}")
+            if regions:
+                f = tempfile.NamedTemporaryFile("w", suffix=".bed", delete=False)
+                f.write("\n".join(lines) + "\n"); f.close()
+                bed = f.name
+            else:
+                regions = None
+        ref_args = tuple(args) + (("--regions", bed) if bed else ())
         try:
-            ref = rh.run_reference_call_sample(recs, tuple(args), None, vu.FIXED)
+            ref = rh.run_reference_call_sample(recs, ref_args, None, vu.FIXED)
         except SystemExit:
             continue
         except Exception as e:
@@ -75,14 +94,18 @@ def main():
         buf = io.StringIO()
         diffs = []
         try:
-            res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=recs.tandem_repeats, _lib=L)
+            def own_cfg():
+                c = config_for(args)
+                c.regions_by_contig = regions or {}
+                return c
+            res = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf, tandem_repeats=recs.tandem_repeats, _lib=L)
             if res.read_count != ref["read_count"]:
                 diffs.append(f"read_count {res.read_count} != {ref['read_count']}")
             assert_same_text(canon(buf.getvalue()), canon(ref["vcf"]))
-            n_rec += res.vcf_records; n_reads += res.read_count
+            n_rec += res.vcf_records; n_reads += res.read_count; n_regions += 1 if regions else 0
             # the same text straight from the record table, without SVCall objects (vcf.VCF.write_records)
             buf2 = io.StringIO()
-            res2 = pipeline.call_sample(recs, config_for(args), vcf_handle=buf2, tandem_repeats=recs.tandem_repeats, _lib=L, objects=False)
+            res2 = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf2, tandem_repeats=recs.tandem_repeats, _lib=L, objects=False)
             assert buf2.getvalue() == buf.getvalue(), "record-table writer differs from the object path"
             assert res2.vcf_records == res.vcf_records and not res2.calls
         except AssertionError as e:
@@ -91,8 +114,8 @@ def main():
             diffs.append(f"raised {type(e).__name__}: {str(e)[:300]}")
         if diffs:
             bad += 1
-            print("MISMATCH it", it, " ".join(args), "|", diffs[:2], flush=True)
-    print("ref_samplefuzz: iterations", n_iter, "reads", n_reads, "VCF records", n_rec, "mismatching", bad, "seconds", round(time.time() - t0, 1))
+            print("MISMATCH it", it, " ".join(args), "regions", regions, "|", diffs[:2], flush=True)
+    print("ref_samplefuzz: iterations", n_iter, "with --regions", n_regions, "reads", n_reads, "VCF records", n_rec, "mismatching", bad, "seconds", round(time.time() - t0, 1))
 
 
 if __name__ == "__main__":

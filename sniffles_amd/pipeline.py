@@ -54,13 +54,45 @@ class _Extracted:
         return self.ti
 
 
-def _no_regions(config, what: str) -> None:
-    """`--regions` (config.regions_by_contig): the reference hands the regions of a contig to every task, so that
-    `build_leadtab` only extracts inside them (sniffles:330-341, leadprov.py:445-472).  `combine` passes them on
-    (`CombineTask(regions=...)`); the BAM flows of this module extract whole contigs, so they refuse a region list instead
-    of silently calling outside it."""
-    if getattr(config, "regions_by_contig", None):
-        raise NotImplementedError(f"{what}: --regions is not served by this flow (tasks always span their whole contig)")
+def regions_of(config, contig: str) -> list:
+    """`config.regions_by_contig.get(contig)` as [(start, end), ...] in list order; entries may be the reference's `Region`
+    objects (contig, start, end attributes) or (contig, start, end) / (start, end) tuples, one or a list of them."""
+    r = (getattr(config, "regions_by_contig", None) or {}).get(contig)
+    if not r:
+        return []
+    if not isinstance(r, list):
+        r = [r]
+    out = []
+    for x in r:
+        if hasattr(x, "start"):
+            out.append((int(x.start), int(x.end)))
+        else:
+            x = tuple(x)
+            out.append((int(x[-2]), int(x[-1])))
+    return out
+
+
+class _RegionExtractor:
+    """Stands in for the extractor of a device-resident task when the task came from a region list (host concatenation)."""
+
+    def close(self):
+        pass
+
+
+def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tandem_repeats, device, _lib):
+    """`build_leadtab(regions, bam)` (leadprov.py:445-472): one extraction per region, in list order, into one task; the
+    running read id carries on from region to region."""
+    from . import soa
+    parts, read_count, rid = [], 0, int(read_id_offset)
+    info = None
+    for start, end in regions:
+        ti, info = extract.extract_region(recs, contig, start, end, config, read_id_offset=rid % 2 ** 32, task_id=task_id, sv_id_start=0,
+                                          tandem_repeats=tandem_repeats, device=device, _lib=_lib)
+        parts.append(ti)
+        read_count += info.read_count
+        rid = info.read_id
+    info.read_count = read_count
+    return soa.concat_tasks(parts), info, _RegionExtractor()
 
 
 def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
@@ -71,7 +103,6 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     `objects=False`: VCF only, formatted straight from the record table (vcf.VCF.write_records) - the same text, no `SVCall`
     objects (`SampleResult.calls` stays empty); falls back to the object path when a reference FASTA is attached."""
     import struct
-    _no_regions(config, "call_sample")
     flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
     total_mapped = sum(1 for f, r in zip(flags, records.ref_id.tolist()) if r >= 0 and not f & 0x4)
     config.task_read_id_offset_mult = 10 ** 9 if total_mapped == 0 else 10 ** math.ceil(math.log(total_mapped) + 1)
@@ -90,9 +121,14 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
         task = parallel.CallTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config,
                                  tandem_repeats=tr, device=device, _lib=_lib)
         # the signatures never leave HBM between the extraction and the clustering batch (snf_batch_add_task_device)
-        ti, info, extractor = extract.extract_region_device(bam.contig_records(records, contig), contig, task.start, task.end, config,
-                                                            read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32,
-                                                            task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
+        regions = regions_of(config, contig)
+        if regions:      # --regions: the task's leads and coverage come from these intervals only (sniffles:330-341)
+            ti, info, extractor = _extract_regions(bam.contig_records(records, contig), contig, regions, config,
+                                                   (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device, _lib)
+        else:
+            ti, info, extractor = extract.extract_region_device(bam.contig_records(records, contig), contig, task.start, task.end, config,
+                                                                read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32,
+                                                                task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
         task.lead_provider = _Extracted(ti)
         if not objects and snf_out is None and writer is not None and writer.can_write_records():
@@ -183,7 +219,6 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
     matched against this sample's candidates contig by contig and written back with the sample's genotype (contig by
     contig, input order within a contig).  Returns the number of records written."""
     import struct
-    _no_regions(config, "genotype_vcf")
     config.mode = "genotype_vcf"
     reader = vcf.VCF(config, vcf_in_handle)
     by_contig = {}
@@ -202,9 +237,9 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
         targets = [t for t in by_contig.get(contig, []) if 0 <= t.pos < length - 1]
         task = parallel.GenotypeTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, tandem_repeats=tr,
                                      genotype_svs=targets, device=device, _lib=_lib)
-        ti, _ = extract.extract_region(bam.contig_records(records, contig), contig, task.start, task.end, config,
-                                       read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id=task_id, sv_id_start=0,
-                                       tandem_repeats=tr, device=device, _lib=_lib)
+        regions = regions_of(config, contig) or [(task.start, task.end)]       # --regions: leads and coverage from these intervals only
+        ti, _, _ = _extract_regions(bam.contig_records(records, contig), contig, regions, config,
+                                    (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device, _lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold
         task.lead_provider = _Extracted(ti)
         res = task.execute()

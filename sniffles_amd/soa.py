@@ -130,6 +130,40 @@ def concat_leads(parts: list) -> dict:
             for name, dt in LEAD_FIELDS}
 
 
+def concat_tasks(parts: list) -> "TaskInput":
+    """The tasks of several regions of ONE contig as one task, in list order: what `LeadProvider.build_leadtab` holds after
+    it has walked a region list (leadprov.py:445-472) - leads and reads appended region by region (a read that overlaps two
+    regions is there twice, as in the reference), the NM threshold of the last region (iter_region's side channel is
+    overwritten per region).  The parts must come from the same record table (same read-name and contig tables)."""
+    first = parts[0]
+    if len(parts) == 1:
+        return first
+    ps_union = sorted(set(n for p in parts for n in (p.ps_names or [])))
+    ps_rank = {n: i for i, n in enumerate(ps_union)}
+    lead_parts, pool_parts, pool_len = [], [], 0
+    for p in parts:
+        if p.contig != first.contig or p.qnames is not first.qnames and p.qnames != first.qnames:
+            raise ValueError("concat_tasks: the parts must be regions of one contig of one record table")
+        d = {k: v.copy() for k, v in p.leads.items()}
+        has_seq = d["seq_len"] >= 0
+        d["seq_off"][has_seq] += pool_len
+        if p.ps_names is not None and len(p.ps_names):
+            remap = np.array([ps_rank[n] for n in p.ps_names], np.int32)
+            has_ps = d["ps_rank"] >= 0
+            d["ps_rank"][has_ps] = remap[d["ps_rank"][has_ps]]
+        lead_parts.append(d)
+        pool_parts.append(p.seq_pool)
+        pool_len += int(p.seq_pool.shape[0])
+    return TaskInput(task_id=first.task_id, contig=first.contig, contig_len=first.contig_len, sv_id_start=first.sv_id_start,
+                     leads=concat_leads(lead_parts), seq_pool=np.ascontiguousarray(np.concatenate(pool_parts)),
+                     read_start=np.ascontiguousarray(np.concatenate([p.read_start for p in parts])),
+                     read_end=np.ascontiguousarray(np.concatenate([p.read_end for p in parts])),
+                     read_hp=np.ascontiguousarray(np.concatenate([p.read_hp for p in parts])),
+                     tr_start=first.tr_start, tr_end=first.tr_end, qc_nm_threshold=parts[-1].qc_nm_threshold,
+                     qnames=first.qnames, ps_names=ps_union if any(p.ps_names is not None for p in parts) else None,
+                     contig_names=first.contig_names)
+
+
 def intern_sorted(strings) -> tuple:
     """Intern strings to ranks whose integer order equals Python str order."""
     uniq = sorted(set(strings))

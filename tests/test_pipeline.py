@@ -125,6 +125,55 @@ def test_population_merge_matches_reference_under_random_command_lines(monkeypat
     assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
 
 
+def test_regions_restrict_extraction_and_coverage():
+    """--regions (config.regions_by_contig; sniffles:330-351, leadprov.py:445-472): one whole-contig interval is the plain run;
+    a sub-interval leaves only calls whose leads lie inside it; the same interval twice doubles the coverage the calls see."""
+    import emu.emu as E
+    name = "sample_two_contigs_12x"
+    recs = cases.SAMPLES[name][0]()
+    tr = getattr(recs, "tandem_repeats", None)
+
+    def text(regions):
+        cfg = config_for(())
+        cfg.regions_by_contig = regions
+        buf = io.StringIO()
+        res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=tr, _lib=E.lib())
+        return buf.getvalue(), res
+    big = [(c, n) for c, n in zip(recs.ref_names, recs.ref_lens) if n >= 1_000_000]
+    plain, res0 = text({})
+    whole, res1 = text({c: [(c, 0, n)] for c, n in big})
+    assert whole == plain and res1.read_count == res0.read_count
+    c0, n0 = big[0]
+    sub, res2 = text({c0: [(c0, 200_000, 600_000)]})
+    rows = [ln.split("\t") for ln in vu.split_text(sub)[1]]
+    assert 5 < len(rows) < len(vu.split_text(plain)[1]) and all(r[0] == c0 and 199_000 <= int(r[1]) <= 601_000 for r in rows)
+    assert res2.read_count < res0.read_count
+    twice, res3 = text({c0: [(c0, 200_000, 600_000), (c0, 200_000, 600_000)]})
+    assert res3.read_count == 2 * res2.read_count            # every read is walked once per region, as in the reference
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+def test_genotype_vcf_with_regions_matches_reference(tmp_path):
+    import ref_harness as rh
+    import emu.emu as E
+    name = "sample_splits_14x"
+    doc = gu.load("genotype_vcf")[name]
+    recs = cases.SAMPLES[name][0]()
+    regs, lines = {}, []
+    for c, n in zip(recs.ref_names, recs.ref_lens):
+        if n >= 1_000_000:
+            regs[c] = [(c, 100_000, 500_000), (c, 450_000, 900_000)]          # overlapping on purpose
+            lines += [f"{c}\t100000\t500000", f"{c}\t450000\t900000"]
+    bed = tmp_path / "r.bed"
+    bed.write_text("\n".join(lines) + "\n")
+    ref = rh.run_reference_genotype_vcf(recs, doc["vcf_in"], ("--regions", str(bed)), vu.FIXED)
+    cfg = config_for(())
+    cfg.regions_by_contig = regs
+    buf = io.StringIO()
+    pipeline.genotype_vcf(recs, cfg, io.StringIO(doc["vcf_in"]), buf, _lib=E.lib())
+    assert buf.getvalue() == (ref["vcf"] if isinstance(ref, dict) else ref) != doc["vcf_out"]
+
+
 def test_contig_selection_rule():
     cfg = SnifflesConfig()
     assert pipeline.should_process_contig("chr1", 2_000_000, cfg) and not pipeline.should_process_contig("chrUn", 999_999, cfg)
