@@ -15,6 +15,8 @@
 #endif
 
 #include <atomic>
+#include <map>
+#include <tuple>
 #include <cmath>
 #include <ctime>
 #include <memory>
@@ -1700,6 +1702,59 @@ int snf_device_count(void) {
 #endif
 }
 
+#ifndef SNF_EMU
+// Creating a HIP stream sets up a hardware queue: about 2 ms each, 4 per batch, and as much again to destroy them - more than the
+// kernels of a contig-sized batch take.  Streams of destroyed batches (synchronised, nothing pending) are kept per device and
+// handed to the next batch; the pool is bounded, the rest is destroyed as before.
+struct StreamPool {
+  std::mutex mu;
+  std::vector<hipStream_t> idle[64];
+  hipStream_t take(int device) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto& v = idle[device & 63];
+      if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+  }
+  void give(int device, hipStream_t s) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto& v = idle[device & 63];
+      if (v.size() < 32 && !getenv("SNF_NO_STREAM_POOL")) { v.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+  }
+};
+static StreamPool g_streams;
+#endif
+
+#ifndef SNF_EMU
+// The device's CU count and the occupancy of the three resident kernels do not change while the process lives: asked once per
+// (device, instance choice) - hipGetDeviceProperties and the occupancy queries are milliseconds, a task-sized batch is not.
+struct DevInfo { int cus, nb_d1w, nb_d2w, nb_e1w; };
+typedef void (*WaveKernel)(const View, int64_t);
+static DevInfo device_info(int device, int o2, int o1, WaveKernel k_d2w, WaveKernel k_e1w) {
+  typedef std::tuple<int, int, int> Key;
+  static std::mutex mu;
+  static std::map<Key, DevInfo> known;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = known.find(Key(device, o2, o1));
+  if (it == known.end()) {
+    hipDeviceProp_t prop;
+    SNF_HIP(hipGetDeviceProperties(&prop, device));
+    DevInfo d{prop.multiProcessorCount, 0, 0, 0};
+    SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d.nb_d1w, d1w_refine, 64, 0));
+    SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d.nb_d2w, k_d2w, 64, 0));
+    SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&d.nb_e1w, k_e1w, 64, 0));
+    it = known.emplace(Key(device, o2, o1), d).first;
+  }
+  return it->second;
+}
+#endif
+
 int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
   SNF_TRY({
     if (!cfg || !out) fail("null argument");
@@ -1719,10 +1774,10 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     int base = cfg->cluster_merge_bnd > (int)cfg->cluster_repeat_h_max ? cfg->cluster_merge_bnd : (int)cfg->cluster_repeat_h_max;
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
 #ifndef SNF_EMU
-    SNF_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    SNF_HIP(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
-    SNF_HIP(hipStreamCreateWithFlags(&b->stream3, hipStreamNonBlocking));
-    SNF_HIP(hipStreamCreateWithFlags(&b->stream4, hipStreamNonBlocking));
+    b->stream = g_streams.take(b->device);
+    b->stream2 = g_streams.take(b->device);
+    b->stream3 = g_streams.take(b->device);
+    b->stream4 = g_streams.take(b->device);
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
     SNF_HIP(hipEventCreate(&b->ev_base));
@@ -1734,17 +1789,17 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->cur = b->stream;
     {  // grid-stride kernels with uniform work per block: launch exactly one resident set (a partial second round of
        // workgroups would double the kernel time)
-      hipDeviceProp_t prop; SNF_HIP(hipGetDeviceProperties(&prop, b->device));
-      const int cus = prop.multiProcessorCount;
-      int nb = 0;
       const int mult = getenv("SNF_GRID_MULT") ? atoi(getenv("SNF_GRID_MULT")) : 1;
-      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, d1w_refine, 64, 0)); if (nb > 0) b->slots_d1w = nb * cus * mult;
       const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 5;   // <6> and <8> spill (36 / 100 B of scratch); <5> does not and is as fast
       const int o1 = getenv("SNF_OCC_E1") ? atoi(getenv("SNF_OCC_E1")) : 5;
       b->k_d2w = o2 >= 8 ? d2w_call<8> : o2 == 6 ? d2w_call<6> : o2 == 5 ? d2w_call<5> : d2w_call<4>;
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
-      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_d2w, 64, 0)); if (nb > 0) b->slots_d2w = nb * cus * mult;
-      SNF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, b->k_e1w, 64, 0)); if (nb > 0) b->slots_e1w = nb * cus * mult;
+      const DevInfo di = device_info(b->device, o2, o1, b->k_d2w, b->k_e1w);
+      const int cus = di.cus;
+      int nb = 0;
+      if (di.nb_d1w > 0) b->slots_d1w = di.nb_d1w * cus * mult;
+      if (di.nb_d2w > 0) b->slots_d2w = di.nb_d2w * cus * mult;
+      if (di.nb_e1w > 0) b->slots_e1w = di.nb_e1w * cus * mult;
       // The consensus kernels take one call per workgroup from the hardware dispatcher: measured alone on config 1, resident
       // (persistent) grids were slower whether they strode statically (0.315 / 0.419 ms SMALL / LARGE, a tail of unequal calls)
       // or claimed calls from a counter (0.498 / 0.382 ms) - against 0.286 / 0.306 ms for plain grids.  SNF_CONS_GRID_MULT=k
@@ -1811,10 +1866,10 @@ void snf_batch_destroy(snf_batch_t* bb) {
   dfree_all(b);
   b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
 #ifndef SNF_EMU
-  if (b->stream) (void)hipStreamDestroy(b->stream);
-  if (b->stream2) (void)hipStreamDestroy(b->stream2);
-  if (b->stream3) (void)hipStreamDestroy(b->stream3);
-  if (b->stream4) (void)hipStreamDestroy(b->stream4);
+  if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
+  if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
+  if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
+  if (b->stream4) g_streams.give(b->device, b->stream4);   // (synchronised above)
   if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
 #endif
   delete b;
