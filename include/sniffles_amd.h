@@ -262,6 +262,10 @@ typedef struct snf_call {
   /* provenance of the cluster (Cluster.start/end/seed, cluster.py:27-39) */
   int32_t cluster_start;
   int32_t cluster_end;
+  /* index of the seed bin among ALL occupied bins of its (task, svtype) sequence (the last field of Cluster.id,
+     cluster.py:261; the reference emits it only in --dev-dump-clusters / trace output).  -1 = not provided: batches with
+     dev_min_leads_cluster >= 2 drop the leads of single-lead bins in front of the sort (SNF_NO_PREFILTER=1 turns that
+     off); snf_batch_fetch_clusters always returns it */
   int32_t cluster_seed_index;
 } snf_call_t;
 

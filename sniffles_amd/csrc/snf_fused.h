@@ -86,12 +86,27 @@ __global__ void __launch_bounds__(256) z0_init(const View v, int64_t n) {
   if (i <= T + 1) v.t_call_off[i] = 0;
   if (i < G) { v.grp_first_bin[i] = -1; v.grp_seed_lo[i] = -1; v.grp_seed_hi[i] = -1; v.grp_dirty[i] = 0; }
   if (i < TS_SLOTS * v.super_stride) v.tile_super[i] = 0;
-  if (i == 0 && v.N > 0) {
-    const int64_t N = v.N;
+  if (i == 0 && v.NS > 0) {
+    const int64_t N = v.NS;
     v.headflag[N] = 0; v.eligflag[N] = 0; v.fN[N] = 0; v.fL[N] = 0; v.runflag[N] = 0; v.clflag[N] = 0; v.rcflag[N] = 0; v.cdflag[N] = 0;
   }
 }
 
+// A0 (occupancy prefilter): keep flags + tile sums | scan + compaction of (key, input index) + clearing of the marks
+SNF_FUSED_HEAD(a0k_keep)
+  if (p < n) a0_keep_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.pf_keep[p] : 0ull};
+  tile_publish<1>(v, TS_KEEP, val, lds);
+}
+SNF_FUSED_HEAD(a0k_compact)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.pf_keep[p] : 0ull}, off[1];
+  tile_scan<1>(v, TS_KEEP, val, off, lds);
+  if (p < n) {
+    v.pf_scan[p] = (uint32_t)off[0];
+    if (p == n - 1) v.cnt->n_kept = (int64_t)(off[0] + val[0]);
+    a0_emit(p, v);
+  }
+}
 // A2 + tile sums of the bin-head flags | scan + A3
 SNF_FUSED_HEAD(a2k_heads)
   if (p < n) { a2_heads_body(p, v); v.rcflag[p] = 0; }  // rcflag: reset for d1w_refine / d1_refine (rc_emit sets it)

@@ -38,6 +38,8 @@ using namespace snf;
 
 // ---------------------------------------------------------------------------------------------- kernels
 SNF_KERNEL(a1_keys, View)
+SNF_KERNEL(a0_keep, View)
+SNF_KERNEL(a0_compact, View)
 SNF_KERNEL(a2_heads, View)
 SNF_KERNEL(a3_bins, View)
 SNF_KERNEL(a4_binstats, View)
@@ -216,6 +218,8 @@ struct snf_batch_impl {
   int read_key_bits = 64;         // significant bits of the read-end sort key
   std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
   bool uploaded = false;
+  bool finalized = false;         // run_finalize has run on the current candidates
+  int64_t pf_words = 0;           // prefilter bitmap size (uint32 words)
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
   bool readprep_each_pass = false; // SNF_READPREP_EACH_PASS=1: rebuild it in every call_candidates (round-1 behaviour)
@@ -239,6 +243,7 @@ struct snf_batch_impl {
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
+  bool alt_hbm = false; uint8_t* d_alt = nullptr; int64_t d_alt_cap = 0;   // SNF_ALT_HBM=1 (experiment): ALT bytes to HBM + one D2H in fetch instead of kernel stores into pinned host memory
   // results (host)
   HostBuf hb_calls, hb_alt, hb_rn, hb_res;
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
@@ -664,6 +669,8 @@ void stage_reads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int6
 }
 
 void enqueue_read_index(snf_batch_impl* b);
+void enqueue_pass_init(snf_batch_impl* b);
+void enqueue_keys(snf_batch_impl* b);
 
 void do_upload(snf_batch_impl* b) {
   View& v = b->v;
@@ -865,6 +872,22 @@ void do_upload(snf_batch_impl* b) {
   v.tr_start = upload_vec(b, b->h_trs); v.tr_end = upload_vec(b, b->h_tre); v.tr_pmax = upload_vec(b, b->h_trp);
   size_t N1 = (size_t)N + 1;
   v.key_in = dalloc<uint64_t>(b, N); v.key_out = dalloc<uint64_t>(b, N); v.val_in = dalloc<uint32_t>(b, N); v.val_out = dalloc<uint32_t>(b, N);
+  {  // occupancy prefilter (snf_stage_cluster.h a0_*): only worth it when a cell with one lead can never seed a cluster
+    v.NS = N; v.prefilter = 0;
+    std::vector<int64_t> cell_off((size_t)T + 1, 0);
+    const int bs = b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1;
+    for (int t = 0; t < T; t++) cell_off[(size_t)t + 1] = cell_off[(size_t)t] + (int64_t)SNF_NTYPES * ((int64_t)b->tasks[(size_t)t].contig_len / bs + 1);
+    const int64_t cells = cell_off[(size_t)T];
+    if (N > 0 && b->cfg.dev_min_leads_cluster >= 2 && getenv("SNF_NO_PREFILTER") == nullptr && cells < ((int64_t)1 << 36)) {
+      v.prefilter = 1;
+      v.t_cell_off = upload_vec(b, cell_off);
+      b->pf_words = cells / 16 + 2;
+      v.pf_bm = dalloc<uint32_t>(b, (size_t)b->pf_words);
+      dzero(b, v.pf_bm, (size_t)b->pf_words * 4);
+      v.pf_key = dalloc<uint64_t>(b, N); v.pf_keep = dalloc<uint32_t>(b, N1); v.pf_scan = dalloc<uint32_t>(b, N1);
+      dsync(b);   // cell_off goes out of scope
+    }
+  }
   uint32_t** u32s[] = {&v.headflag, &v.headscan, &v.eligflag, &v.eligscan, &v.fN, &v.pN, &v.fL, &v.pL, &v.runflag, &v.runscan,
                        &v.clflag, &v.clscan, &v.rcflag, &v.rcscan, &v.cdflag, &v.cdscan, &v.rnf, &v.rnp};
   for (auto pp : u32s) *pp = dalloc<uint32_t>(b, N1);
@@ -903,6 +926,19 @@ void do_upload(snf_batch_impl* b) {
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
   v.sc_tab = dalloc<int64_t>(b, N1 + 1); v.sc_aln = dalloc<int64_t>(b, N1 + 1); v.sc_rd = dalloc<int64_t>(b, N1 + 1);
   b->readprep_each_pass = getenv("SNF_READPREP_EACH_PASS") != nullptr;
+  if (v.prefilter) {
+    // how many leads the prefilter keeps is a property of the input: counted once here (the same three kernels every pass
+    // runs), so that every later pass can size its sort and launches on the host without a round trip
+    const bool tm = b->timing; b->timing = false;
+    enqueue_pass_init(b);
+    enqueue_keys(b);
+    b->timing = tm;
+    Counts hc{};
+    d2h(b, &hc, v.cnt, sizeof(Counts));
+    dsync(b);
+    v.NS = hc.n_kept;
+    if (v.prof) fprintf(stderr, "[SNF_PROF] prefilter: %lld of %lld leads share their (svtype, bin) cell with another lead\n", (long long)v.NS, (long long)N);
+  }
   const double t_index0 = now_ms();
   { const bool tm = b->timing; b->timing = false; enqueue_read_index(b); b->timing = tm; }   // (no event brackets outside a pass)
   dsync(b);
@@ -960,16 +996,10 @@ void enqueue_read_prep(snf_batch_impl* b) {
   }
 }
 
-void run_call_candidates(snf_batch_impl* b) {
+// start of a pass: every small reset (one launch on the fused path)
+void enqueue_pass_init(snf_batch_impl* b) {
   View& v = b->v;
-  int64_t N = v.N; int T = v.T;
-  b->reads_ready = true; b->cov_avg_ready = true;
-  reset_timing(b);
-#ifndef SNF_EMU
-  if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
-#endif
-  // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
-  // (and in the emulation build) the plain device-wide scans are used
+  const int64_t N = v.N; const int T = v.T;
 #ifndef SNF_EMU
   b->fused = getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25);
 #endif
@@ -988,15 +1018,45 @@ void run_call_candidates(snf_batch_impl* b) {
     dzero(b, v.grp_seed_hi, sizeof(int32_t) * (8 * T + 8), 0xff);
     dzero(b, v.grp_dirty, sizeof(int32_t) * (8 * T + 8));
   }
+}
+// sort keys of the leads; with the occupancy prefilter: marks, keep flags and the compacted (key, index) pairs of the kept leads
+void enqueue_keys(snf_batch_impl* b) {
+  View& v = b->v;
+  const int64_t N = v.N;
+  if (N <= 0) return;
+  LAUNCH(a1_keys, v, N, N * 21);
+  if (!v.prefilter) return;
+  if (b->fused) {
+    { Scope _s(b, "a0_keep", N * 8); FUSED(a0k_keep, N); }
+    FUSED(a0k_compact, N);
+  } else {
+    LAUNCH(a0_keep, v, N, N * 8);
+    prim_exscan<uint32_t>(b, v.pf_keep, v.pf_scan, N + 1, "scan_keep");
+    LAUNCH_Q(a0_compact, v, N, N * 12);
+  }
+}
+
+void run_call_candidates(snf_batch_impl* b) {
+  View& v = b->v;
+  int T = v.T;
+  const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
+  b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
+  reset_timing(b);
+#ifndef SNF_EMU
+  if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
+#endif
+  // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
+  // (and in the emulation build) the plain device-wide scans are used
+  enqueue_pass_init(b);
   if (v.wave_path) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
+  enqueue_keys(b);
   if (N > 0) {
     if (!b->fused) {
       uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
       for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
     }
-    LAUNCH(a1_keys, v, N, N * 21);
     if (v.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.key_in, (uint32_t*)v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     else prim_sort_pairs<uint64_t>(b, v.key_in, v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     if (b->fused) {
@@ -1182,6 +1242,7 @@ void run_finalize(snf_batch_impl* b) {
   SNF_HIP(hipEventSynchronize(b->ev_counts));
 #endif
   const int64_t nc = b->h_cnt->n_calls;
+  b->finalized = true;
   if (nc <= 0) return;
   b->res_current = false;
   dzero(b, v.stripes, sizeof(unsigned long long) * 4 * 64 * 16);
@@ -1251,6 +1312,7 @@ void run_finalize(snf_batch_impl* b) {
   // ALT bytes are only ever written by the GPU: the kernels store them straight into the pinned host buffer, so the
   // PCIe transfer rides along with the (latency-bound) consensus kernels instead of trailing them
   v.alt_pool = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1); v.alt_cap = alt_total;
+  if (b->alt_hbm) { ensure_cap(b, alt_total + 16, b->d_alt_cap, (void**)&b->d_alt, 1); v.alt_pool = b->d_alt; }
   const bool fallback = !v.wave_path || b->h_cnt->n_cons_fallback > 0;
   if (ncons > 0) {
     if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt->tab_total * 13);
@@ -1369,6 +1431,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);  // filled by the kernels (zero-copy)
   uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
   const bool pre = b->prefetched && stage >= 1;
+  if (b->alt_hbm && alt_total && b->d_alt) { d2h_timed(b, alt, b->d_alt, (size_t)alt_total, "d2h_alt"); if (pre) dsync(b); }
   if (!pre) {
     d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
     if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
@@ -1594,6 +1657,16 @@ void do_fetch_clusters(snf_batch_impl* b, int stage, snf_clusters_t* out) {
   View& v = b->v;
   if (stage < 0 || stage > 2) fail("stage must be 0 (seeds), 1 (merged) or 2 (refined)");
   if (!b->cov_avg_ready) fail("snf_batch_fetch_clusters needs snf_batch_call_candidates first");
+  if (v.prefilter) {
+    // Cluster ids carry the seed's index among ALL occupied bins of its (task, svtype) sequence (cluster.py:238-246), which
+    // the occupancy prefilter does not keep: the candidate stage is redone over every lead (this seam is a debugging /
+    // parity aid; the calls are the same either way) and the batch stays unfiltered from here on
+    const bool fin = b->finalized;
+    full_sync(b);
+    v.prefilter = 0; v.NS = v.N;
+    run_call_candidates(b);
+    if (fin) run_finalize(b);
+  }
   full_sync(b);
   const Counts c = *b->h_cnt;
   b->cl_task.clear(); b->cl_svtype.clear(); b->cl_start.clear(); b->cl_end.clear(); b->cl_seed.clear(); b->cl_seed_index.clear();
@@ -1816,6 +1889,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
+    b->alt_hbm = getenv("SNF_ALT_HBM") != nullptr;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
     if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);

@@ -54,6 +54,13 @@ SNF_HD unsigned long long atomic_add_u64(unsigned long long* p, unsigned long lo
   return o;
 #endif
 }
+SNF_HD uint32_t atomic_fetch_or_u32(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return atomicOr(p, v);
+#else
+  const uint32_t old = *p; *p = old | v; return old;
+#endif
+}
 SNF_HD void atomic_or_i32(int* p, int v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   atomicOr(p, v);

@@ -253,7 +253,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
 // D1b: dense refined-cluster table (rcscan = exclusive scan of rcflag over the F slot space)
 SNF_HD void d1b_emit(int64_t pos, const View& v);
 SNF_HD void d1b_rctable_body(int64_t pos, const View& v) {
-  if (pos == 0) v.cnt->n_rc = v.rcscan[v.N];
+  if (pos == 0) v.cnt->n_rc = v.rcscan[v.NS];
   d1b_emit(pos, v);
 }
 SNF_HD void d1b_emit(int64_t pos, const View& v) {
@@ -278,7 +278,7 @@ SNF_HD bool contains_sorted_i32(const int32_t* a, int64_t n, int32_t x) {
 
 // sv.call_from for one refined cluster -> candidate record (or nothing: minsvlen_screen)
 SNF_HD void d2_call_body(int64_t r, const View& v) {
-  if (r == 0) v.cdflag[v.N] = 0;
+  if (r == 0) v.cdflag[v.NS] = 0;
   if (r >= v.cnt->n_rc) { v.cdflag[r] = 0; return; }
   const snf_config_t& cfg = v.cfg;
   int32_t flo = v.rc_lo[r], n = v.rc_n[r], c = v.rc_cluster[r];
@@ -359,7 +359,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   cc.sa_count = (int32_t)sa; cc.sa_frac = (double)sa / (double)n_all; cc.n_leads = n;
   cc.mate_contig = -1; cc.gt_hp = -1; cc.gt_ps = -1; cc.vaf = NAN; cc.alt_len = -1;
   cc.cluster_start = v.seed_start[h]; cc.cluster_end = v.c_end[h];
-  cc.cluster_seed_index = v.seed_bin[h] - v.grp_first_bin[g];
+  cc.cluster_seed_index = v.prefilter ? -1 : v.seed_bin[h] - v.grp_first_bin[g];   // (counts ALL occupied bins: not known behind the prefilter)
   int64_t rn_len = support;
   if (svtype == SNF_BND) {  // resolve_bnd
     SNF_LEADS(k) a3[k] = v.in_mate_contig[v.F_orig[FI[k]]];
@@ -452,7 +452,7 @@ SNF_HD void d3_compact_emit(int64_t r, const View& v) {
   if (r < v.cnt->n_rc && v.cdflag[r]) { uint32_t i = v.cdscan[r]; v.calls[i] = v.cand[r]; v.callx[i] = v.candx[r]; }
 }
 SNF_HD void d3_compact_body(int64_t r, const View& v) {
-  if (r == 0) { v.cnt->n_calls = v.cdscan[v.N]; }
+  if (r == 0) { v.cnt->n_calls = v.cdscan[v.NS]; }
   d3_compact_emit(r, v);
 }
 
@@ -493,13 +493,13 @@ SNF_HD void d3_svid_body(int64_t i, const View& v) {
   int t = c.task_index;
   c.sv_id = v.t_sv_id_start[t] + (int32_t)(i - v.t_call_off[t]);
   v.rnf[i] = (uint32_t)c.rn_len;  // scanned into rn_off
-  if (i == 0) v.rnf[v.N] = 0;
+  if (i == 0) v.rnf[v.NS] = 0;
 }
 
 // D3d: supporting read names (pN = exclusive scan of rn_len)
 SNF_HD void d3_rnames_emit(int64_t i, const View& v);
 SNF_HD void d3_rnames_body(int64_t i, const View& v) {
-  if (i == 0) { v.cnt->rn_total = v.rnp[v.N]; *v.res_rn_total = v.rnp[v.N]; }
+  if (i == 0) { v.cnt->rn_total = v.rnp[v.NS]; *v.res_rn_total = v.rnp[v.NS]; }
   d3_rnames_emit(i, v);
 }
 SNF_HD void d3_rnames_emit(int64_t i, const View& v) {

@@ -19,15 +19,65 @@ SNF_HD bool lead_is_long(const View& v, uint32_t o) {  // INS lead with svlen No
 
 // ------------------------------------------------------------------------------------------ stage A
 // A1: sort key (task, svtype, bin); leads outside the task region are dropped (leadprov.py:464-468)
+// With the occupancy prefilter (View::prefilter) the key goes to pf_key and the lead marks its (task, svtype, bin) cell:
+// bit 0 "a lead was here", bit 1 "a second one was" - a0_keep / a0_emit then hand only the leads of cells with two or
+// more leads to the sort, in arrival order.  Leads that arrive together are close on the genome (BAM order), so the
+// marks of a wave fall into a handful of cache lines.
+SNF_HD int64_t pf_cell(const View& v, int t, int svtype, uint64_t bin) {
+  const int64_t c0 = v.t_cell_off[t], nb = (v.t_cell_off[t + 1] - c0) / SNF_NTYPES;
+  return c0 + (int64_t)svtype * nb + (int64_t)bin;
+}
 SNF_HD void a1_keys_body(int64_t i, const View& v) {
   int t = v.lead_task[i];
   int64_t rs = v.in_ref_start[i];
   bool valid = rs >= 0 && rs < v.t_contig_len[t];
   uint64_t bin = valid ? (uint64_t)(rs / v.cfg.cluster_binsize) : 0;
-  const uint64_t k = valid ? (((uint64_t)(t * 8 + v.in_svtype[i])) << v.key_bin_bits | bin) : (1ull << v.key_nbits);
+  const int svtype = v.in_svtype[i];
+  const uint64_t k = valid ? (((uint64_t)(t * 8 + svtype)) << v.key_bin_bits | bin) : (1ull << v.key_nbits);
+  if (v.prefilter) {
+    if (v.key32) ((uint32_t*)v.pf_key)[i] = (uint32_t)k; else v.pf_key[i] = k;
+    if (valid) {
+      const int64_t cell = pf_cell(v, t, svtype, bin);
+      uint32_t* w = v.pf_bm + (cell >> 4);
+      const int sh = (int)(cell & 15) * 2;
+      const uint32_t old = atomic_fetch_or_u32(w, 1u << sh);
+      if (((old >> sh) & 3u) == 1u) atomic_fetch_or_u32(w, 2u << sh);
+    }
+    return;
+  }
   if (v.key32) ((uint32_t*)v.key_in)[i] = (uint32_t)k; else v.key_in[i] = k;
   v.val_in[i] = (uint32_t)i;
   v.seqnull[i] = 0;
+}
+// A0 (prefilter): keep flag per input lead | (scan) | keys and indices of the kept leads, compacted in arrival order; the
+// marks of this pass are cleared again (plain stores: nobody reads the bitmap after a0_keep)
+SNF_HD uint64_t pf_key_of(const View& v, int64_t i) { return v.key32 ? (uint64_t)((const uint32_t*)v.pf_key)[i] : v.pf_key[i]; }
+SNF_HD bool pf_cell_of_key(const View& v, uint64_t k, int64_t* cell) {
+  if (k >> v.key_nbits) return false;
+  const uint64_t g = k >> v.key_bin_bits, bin = k & ((1ull << v.key_bin_bits) - 1ull);
+  *cell = pf_cell(v, (int)(g >> 3), (int)(g & 7), bin);
+  return true;
+}
+SNF_HD void a0_keep_body(int64_t i, const View& v) {
+  int64_t cell;
+  uint32_t keep = 0;
+  if (pf_cell_of_key(v, pf_key_of(v, i), &cell)) keep = (v.pf_bm[cell >> 4] >> ((int)(cell & 15) * 2 + 1)) & 1u;
+  v.pf_keep[i] = keep;
+  if (i == 0) v.pf_keep[v.N] = 0;
+}
+SNF_HD void a0_emit(int64_t i, const View& v) {
+  const uint64_t k = pf_key_of(v, i);
+  int64_t cell;
+  if (pf_cell_of_key(v, k, &cell)) v.pf_bm[cell >> 4] = 0;
+  if (!v.pf_keep[i]) return;
+  const uint32_t q = v.pf_scan[i];
+  if (v.key32) ((uint32_t*)v.key_in)[q] = (uint32_t)k; else v.key_in[q] = k;
+  v.val_in[q] = (uint32_t)i;
+  v.seqnull[i] = 0;
+}
+SNF_HD void a0_compact_body(int64_t i, const View& v) {
+  if (i == 0) v.cnt->n_kept = v.pf_scan[v.N];
+  a0_emit(i, v);
 }
 
 // sorted key at position p in the canonical form grp << 32 | bin (SNF_KEY_INVALID for leads outside their contig)
@@ -42,8 +92,8 @@ SNF_HD void a2_heads_body(int64_t p, const View& v) {
   uint64_t k = sorted_key(v, p);
   bool valid = k != SNF_KEY_INVALID;
   v.headflag[p] = (valid && (p == 0 || sorted_key(v, p - 1) != k)) ? 1u : 0u;
-  if (valid && (p + 1 == v.N || sorted_key(v, p + 1) == SNF_KEY_INVALID)) v.cnt->n_valid = p + 1;
-  if (p == 0) v.headflag[v.N] = 0;
+  if (valid && (p + 1 == v.NS || sorted_key(v, p + 1) == SNF_KEY_INVALID)) v.cnt->n_valid = p + 1;
+  if (p == 0) v.headflag[v.NS] = 0;
 }
 
 // A3: bin table (headscan = exclusive scan of headflag; headscan[N] = #bins)
@@ -56,7 +106,7 @@ SNF_HD void a3_emit(int64_t p, const View& v) {
 }
 SNF_HD void a3_bins_body(int64_t p, const View& v) {
   if (p == 0) {
-    int64_t nb = v.headscan[v.N];
+    int64_t nb = v.headscan[v.NS];
     v.cnt->n_bins = nb;
     v.bin_lo[nb] = (int32_t)v.cnt->n_valid;
   }
@@ -95,13 +145,13 @@ SNF_HD void a5_leadflags_body(int64_t p, const View& v) {
   }
   v.fN[p] = fn;
   v.fL[p] = fl;
-  if (p == 0) { v.fN[v.N] = 0; v.fL[v.N] = 0; v.eligflag[v.N] = 0; }
+  if (p == 0) { v.fN[v.NS] = 0; v.fL[v.NS] = 0; v.eligflag[v.NS] = 0; }
 }
 
 // A6: scatter into L / LL (pN/pL = exclusive scans of fN/fL)
 SNF_HD void a6_emit(int64_t p, const View& v);
 SNF_HD void a6_scatter_body(int64_t p, const View& v) {
-  if (p == 0) { v.cnt->NF = v.pN[v.N]; v.cnt->NLL = v.pL[v.N]; v.cnt->n_seeds = v.eligscan[v.N]; }
+  if (p == 0) { v.cnt->NF = v.pN[v.NS]; v.cnt->NLL = v.pL[v.NS]; v.cnt->n_seeds = v.eligscan[v.NS]; }
   a6_emit(p, v);
 }
 SNF_HD void a6_emit(int64_t p, const View& v) {
@@ -157,7 +207,7 @@ SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean,
 SNF_HD bool seed_first_of_group(const View& v, int64_t s) { return s == 0 || v.seed_grp[s - 1] != v.seed_grp[s]; }
 
 SNF_HD void b1_seedmetrics_body(int64_t s, const View& v) {
-  if (s == 0) v.runflag[v.N] = 0;
+  if (s == 0) v.runflag[v.NS] = 0;
   if (s >= v.cnt->n_seeds) { v.runflag[s] = 0; v.clflag[s] = 0; return; }
   double mean, sd;
   compute_metrics(v, v.seed_lo[s], v.seed_hi[s], &mean, &sd);
@@ -197,7 +247,7 @@ SNF_HD void b2_emit(int64_t s, const View& v) {
 }
 SNF_HD void b2_runs_body(int64_t s, const View& v) {
   if (s == 0) {
-    int64_t nr = v.runscan[v.N];
+    int64_t nr = v.runscan[v.NS];
     v.cnt->n_runs = nr;
     v.run_first[nr] = (int32_t)v.cnt->n_seeds;
   }
@@ -313,7 +363,7 @@ SNF_HD void c3_serial_body(int64_t g, const View& v) {
 // C4: merged cluster table (clscan = exclusive scan of clflag)
 SNF_HD void c4_emit(int64_t s, const View& v);
 SNF_HD void c4_clusters_body(int64_t s, const View& v) {
-  if (s == 0) v.cnt->n_clusters = v.clscan[v.N];
+  if (s == 0) v.cnt->n_clusters = v.clscan[v.NS];
   c4_emit(s, v);
 }
 SNF_HD void c4_emit(int64_t s, const View& v) {

@@ -17,6 +17,7 @@ struct Counts {
   int64_t n_valid, n_bins, n_seeds, NF, NLL, n_runs, n_clusters, n_rc, n_calls;
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
+  int64_t n_kept;            // leads the occupancy prefilter lets through to the sort (a0_*; == NS whenever the prefilter is on)
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
@@ -70,7 +71,8 @@ struct ConsDesc {
 struct ClusterHdr { int32_t h, lo, n, grp; int32_t repeat, _pad[3]; };
 
 // tile-sum slots of the fused flag -> scan -> emit chains (snf_fused.h)
-enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7, TS_RNAMES = 8, TS_SLOTS = 9 };
+enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7, TS_RNAMES = 8, TS_KEEP = 9,
+       TS_OUT = 10 /* 11, 12 */, TS_SLOTS = 13 };
 
 struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t rc;       // refined cluster id
@@ -90,6 +92,7 @@ struct View {
   int32_t wave_path;  // 1: gfx950 wave-cooperative kernels own the small clusters (thread kernels skip them)
   int32_t prof;       // SNF_PROF=1: phase cycle counters in e45w_consensus
   int64_t N, R, NTR;
+  int64_t NS;         // positions that go through the sort and the stages behind it: N, or (prefilter) the leads of (svtype, bin) cells with >= 2 leads
   int64_t pool_len, pool_cap;
   int64_t pool_extra_base;   // fused sequences reserved through Counts::pool_extra_used start here (pool_len, or behind the private slices)
   int64_t pool_slice;        // d1w_refine: bytes of fused-sequence space every resident wave owns at pool_len + blockIdx.x * pool_slice (0: none)
@@ -125,7 +128,16 @@ struct View {
   // ---- tandem repeats [NTR]
   const int32_t* tr_start; const int32_t* tr_end; const int32_t* tr_pmax;
 
-  // ---- stage A: binning (sorted position p in [0,N))
+  // ---- occupancy prefilter (a0_*): a lead alone in its (task, svtype, bin) cell can never be part of a seed when
+  // dev_min_leads_cluster >= 2 (cluster.py:262) - 80 % of the leads of a 30x genome - and is dropped in front of the sort.
+  // Two bits per cell ("seen", "seen twice"); the words a pass touched are cleared again by the pass itself.
+  int32_t prefilter;          // 1: on
+  int32_t pf_nbin_bits;       // (unused padding of the pair)
+  uint32_t* pf_bm;            // [pf_words] 16 cells per word
+  const int64_t* t_cell_off;  // [T+1] first cell of task t (cells of a task: SNF_NTYPES x (contig_len / binsize + 1))
+  uint64_t* pf_key;           // [N] sort key per input lead (uint32_t when key32), written by a1_keys
+  uint32_t *pf_keep, *pf_scan;  // [N+1] keep flag per input lead / its exclusive scan
+  // ---- stage A: binning (sorted position p in [0,NS))
   uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
   int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
   uint32_t *headflag, *headscan;  // [N+1] bin heads in sorted order / exclusive scan (bin ids)

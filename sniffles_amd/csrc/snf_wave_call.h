@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     cc.sa_count = (int32_t)sa; cc.sa_frac = (double)sa / (double)n_all; cc.n_leads = n;
     cc.mate_contig = -1; cc.gt_hp = -1; cc.gt_ps = -1; cc.vaf = NAN; cc.alt_len = -1;
     cc.cluster_start = v.seed_start[h]; cc.cluster_end = v.c_end[h];
-    cc.cluster_seed_index = v.seed_bin[h] - v.grp_first_bin[g];
+    cc.cluster_seed_index = v.prefilter ? -1 : v.seed_bin[h] - v.grp_first_bin[g];
     int64_t rn_len = support;
     if (svtype == SNF_BND) {  // resolve_bnd (sv.py:625-639)
       const int32_t s_mc = wave_sort_i32(mctg, act, n, lane, lds.buf);

@@ -1,0 +1,75 @@
+"""The occupancy prefilter (snf_stage_cluster.h a0_*: leads alone in their (task, svtype, bin) cell are dropped in front of the
+sort when dev_min_leads_cluster >= 2, cluster.py:262) changes nothing but `cluster_seed_index`, which becomes -1 ("not
+provided"); SNF_NO_PREFILTER=1 and snf_batch_fetch_clusters give the reference's seed index."""
+import numpy as np
+import pytest
+
+from sniffles_amd import cluster, lib, records, synth
+from sniffles_amd.config import SnifflesConfig
+
+
+def tasks():
+    return [synth.gen_task(0, "chr20", 1_500_000, 30, 3), synth.gen_fuzz(11, task_id=1), synth.gen_fuzz(12, task_id=2)]
+
+
+def run(L, cfg, tis):
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.call_candidates()
+        b.finalize()
+        return b.fetch(1)
+
+
+def check(L, oracle_mod, monkeypatch):
+    tis = tasks()
+    for kw in ({}, {"mosaic": True}, {"no_qc": True}):       # no_qc: dev_min_leads_cluster = 1 -> the prefilter stays off
+        cfg = SnifflesConfig(**kw)
+        exp = oracle_mod.run(cfg, tis, True)
+        on = run(L, cfg, tis)
+        monkeypatch.setenv("SNF_NO_PREFILTER", "1")
+        off = run(L, cfg, tis)
+        monkeypatch.delenv("SNF_NO_PREFILTER")
+        for t in range(len(tis)):
+            assert records.diff_results(on, t, exp, t) == []
+            assert records.diff_results(off, t, exp, t) == []
+        assert np.array_equal(off.calls["cluster_seed_index"], exp.calls["cluster_seed_index"])
+        filtered = cfg.dev_min_leads_cluster >= 2
+        assert bool((on.calls["cluster_seed_index"] == -1).all()) == filtered
+        for f in on.calls.dtype.names:
+            if f != "cluster_seed_index":
+                a, b = on.calls[f], off.calls[f]
+                assert np.array_equal(a, b) or (a.dtype.kind == "f" and np.array_equal(a, b, equal_nan=True)), f
+        assert on.alt_pool.tobytes() == off.alt_pool.tobytes() and on.rnames.tobytes() == off.rnames.tobytes()
+
+
+def test_prefilter_changes_nothing_but_the_seed_index_emu(oracle_mod, monkeypatch):
+    import emu.emu as E
+    check(E.lib(), oracle_mod, monkeypatch)
+
+
+def test_prefilter_changes_nothing_but_the_seed_index_simt(oracle_mod, monkeypatch):
+    from emu import simt as S
+    check(S.lib(), oracle_mod, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_prefilter_changes_nothing_but_the_seed_index_gpu(oracle_mod, monkeypatch):
+    check(None, oracle_mod, monkeypatch)
+
+
+def test_cluster_views_keep_their_ids_behind_the_prefilter():
+    """`cluster.resolve` (seam B3) redoes the candidate stage unfiltered: ids (seed index included) are the same as without
+    the prefilter, and the calls fetched afterwards are unchanged."""
+    import emu.emu as E
+    ti = synth.gen_task(0, "chr20", 1_000_000, 30, 5)
+    cfg = SnifflesConfig()
+    with lib.Batch(cfg, [ti], _lib=E.lib()) as b:
+        b.call_candidates()
+        b.finalize()
+        before = b.fetch(1)
+        cl = b.fetch_clusters(2)
+        after = b.fetch(1)
+    assert (before.calls["cluster_seed_index"] == -1).all() and (after.calls["cluster_seed_index"] >= 0).all()
+    for f in before.calls.dtype.names:
+        if f != "cluster_seed_index":
+            assert np.array_equal(before.calls[f], after.calls[f], equal_nan=before.calls[f].dtype.kind == "f"), f
+    assert int(cl["seed_index"].max()) > len(cl["seed_index"])      # counts singleton bins too
