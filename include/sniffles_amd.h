@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNF_ABI_VERSION 1
+#define SNF_ABI_VERSION 2
 
 #define SNF_SVLEN_NONE INT32_MIN /* Lead.svlen is None */
 #define SNF_SEQ_NONE (-1)        /* Lead.seq is None   */
@@ -151,6 +151,9 @@ typedef struct snf_config {
   int32_t combine_separate_intra;
   int32_t _pad1;
   double combine_pctseq;
+  /* CallTask.execute: which calls leave the task and in which order (parallel.py:265-271; read by SNF_OUT_EXECUTE) */
+  int32_t no_qc;
+  int32_t sort;
 } snf_config_t;
 
 /*
@@ -322,16 +325,35 @@ int snf_batch_call_candidates(snf_batch_t* b);
  * consensus.novel_from_reads), qc_sv_post_annotate, rescue_phasing. */
 int snf_batch_finalize(snf_batch_t* b);
 
-/* device -> host of the call records (blocks until the stream is idle).
- * stage 0: after call_candidates, 1: after finalize. Pointers valid until the next
- * call on the batch or snf_batch_destroy. */
+/* What a stage-1 fetch returns (set before snf_batch_finalize; default SNF_OUT_CANDIDATES):
+ *   SNF_OUT_CANDIDATES  every candidate of every task that did not raise, in candidate order - the list
+ *                       Task.finalize_candidates returns (src/sniffles/parallel.py:129-201; its early exits are commented out)
+ *   SNF_OUT_EXECUTE     what CallTask.execute keeps of it (parallel.py:265-271): the calls with `qc` set (all of them under
+ *                       config.no_qc), per task stably sorted by pos when config.sort - the statement
+ *                       `svcalls = [s for s in svcalls if s.qc]` / `sorted(svcalls, key=pos)` on the device, so that only the
+ *                       records, ALT bytes and read names the parent process will see cross PCIe
+ *   | SNF_OUT_DEVICE    the result stays in HBM until the fetch (instead of being stored straight into pinned host memory by
+ *                       the kernels): required for snf_batch_export_device
+ * snf_call_t.alt_off / rn_off of the returned records index the returned pools. */
+enum snf_output { SNF_OUT_CANDIDATES = 0, SNF_OUT_EXECUTE = 1, SNF_OUT_DEVICE = 2 };
+int snf_batch_set_output(snf_batch_t* b, int mode);
+
+/* device -> host of the call records (blocks until the batch's streams are idle).
+ * stage 0: the candidates after call_candidates (no ALT); 1: after finalize, as selected by snf_batch_set_output.
+ * snf_batch_call_candidates + snf_batch_finalize enqueue without waiting for the device; this is the one host wait of a pass.
+ * Pointers valid until the next call on the batch or snf_batch_destroy. */
 int snf_batch_fetch(snf_batch_t* b, int stage, snf_result_t* out);
 
-/* final gather across GPUs: copies the call records (stage-1 order, ERR tasks included,
- * see snf_result_t.task_status) device-to-device into `dst_device` (e.g. a torch CUDA tensor handed to
- * RCCL), at most cap_calls records; *n_calls receives the record count.  Asynchronous on the batch
- * stream; call snf_batch_sync before handing dst to another stream. */
-int snf_batch_export_calls_device(snf_batch_t* b, void* dst_device, int64_t cap_calls, int64_t* n_calls);
+/* final gather across GPUs (the parent receives whole results, parallel.py:757): the finalized result of the
+ * batch as ONE block of bytes in HBM, copied device-to-device into `dst_device` (e.g. a torch CUDA tensor handed to RCCL):
+ *   [ snf_call_t records | read names (uint32) at layout->off_rnames | ALT bytes at layout->off_alt ]   (layout->bytes in all)
+ * Needs SNF_OUT_DEVICE.  Fails when cap_bytes is too small (layout is filled in regardless, so the caller can grow).
+ * Blocks until the copy is done. */
+typedef struct snf_export_layout {
+  int64_t n_calls, rnames_len, alt_pool_len;
+  int64_t off_rnames, off_alt, bytes;
+} snf_export_layout_t;
+int snf_batch_export_device(snf_batch_t* b, void* dst_device, int64_t cap_bytes, snf_export_layout_t* layout);
 
 /* replaces SNFile.annotate_block_coverages (src/sniffles/snf.py:249-267): the coverage vector
  * (leadprov.py:451,510) zero-padded to a multiple of `binsize`, averaged per bin and rounded with

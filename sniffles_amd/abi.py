@@ -12,7 +12,7 @@ import numpy as np
 
 from .soa import LEAD_FIELDS, TaskInput
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 FILTERS = [
     "PASS", "STDEV_POS", "STDEV_LEN", "SINGLE_BREAK", "SVLEN_MIN", "STRAND_BND", "COV_CHANGE_DEL",
@@ -58,6 +58,7 @@ class snf_config_t(C.Structure):
         ("phase_conflict_threshold", f64),
         ("combine_match", i32), ("combine_match_max", i32), ("combine_separate_intra", i32), ("_pad1", i32),
         ("combine_pctseq", f64),
+        ("no_qc", i32), ("sort", i32),
     ]
 
 
@@ -108,6 +109,14 @@ class snf_result_t(C.Structure):
         ("n_tasks", i64), ("task_status", C.POINTER(C.c_int32)),
         ("task_call_off", C.POINTER(C.c_int64)), ("coverage_average_total", C.POINTER(C.c_double)),
     ]
+
+
+class snf_export_layout_t(C.Structure):
+    _fields_ = [("n_calls", i64), ("rnames_len", i64), ("alt_pool_len", i64), ("off_rnames", i64), ("off_alt", i64), ("bytes", i64)]
+
+
+# enum snf_output (snf_batch_set_output)
+OUT_CANDIDATES, OUT_EXECUTE, OUT_DEVICE = 0, 1, 2
 
 
 class snf_clusters_t(C.Structure):

@@ -178,7 +178,12 @@ SNF_FUSED_HEAD(b2k_runs)
   }
 SNF_FLAGSUM(c4a_count, clflag, TS_CLUSTERS)
 SNF_FLAGSUM(d1a_count, rcflag, TS_REFINED)
-SNF_FLAGSUM(d3a_count, cdflag, TS_CALLS)
+// (flags behind n_rc are stale: the wave kernels only write the flags of existing refined clusters, and the thread kernel that
+// used to reset the rest is not launched next to them)
+SNF_FUSED_HEAD(d3a_count)
+  unsigned long long val[1] = {(p < n && p < v.cnt->n_rc) ? (unsigned long long)v.cdflag[p] : 0ull};
+  tile_publish<1>(v, TS_CALLS, val, lds);
+}
 SNF_FUSED_HEAD(c4k_clusters)
   unsigned long long val[1] = {p < n ? (unsigned long long)v.clflag[p] : 0ull}, off[1];
   tile_scan<1>(v, TS_CLUSTERS, val, off, lds);
@@ -198,7 +203,7 @@ SNF_FUSED_HEAD(d1bk_rctable)
   }
 }
 SNF_FUSED_HEAD(d3ck_compact)
-  unsigned long long val[1] = {p < n ? (unsigned long long)v.cdflag[p] : 0ull}, off[1];
+  unsigned long long val[1] = {(p < n && p < v.cnt->n_rc) ? (unsigned long long)v.cdflag[p] : 0ull}, off[1];
   tile_scan<1>(v, TS_CALLS, val, off, lds);
   if (p < n) {
     v.cdscan[p] = (uint32_t)off[0];
@@ -233,6 +238,7 @@ __global__ void __launch_bounds__(256) e2a_sizes(const View v, int64_t n_unused)
   __shared__ unsigned long long lds[4 * SNF_ALT_K];
   const int64_t nc = v.cnt->n_calls;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (int64_t k = i; k < 4 * 64 * 16; k += (int64_t)gridDim.x * 256) v.stripes[k] = 0;   // byte counters of the ALT kernels (this pass)
   e2_best_body(i, v);
   unsigned long long val[SNF_ALT_K], excl[SNF_ALT_K], tot[SNF_ALT_K];
   alt_values(v, i, nc, val);

@@ -6,6 +6,7 @@
 #include "snf_wave_refine.h"
 #include "snf_wave_cons.h"
 #include "snf_fused.h"
+#include "snf_stage_out.h"
 #include "snf_wave_call.h"
 #include "snf_ctx.h"
 
@@ -69,6 +70,11 @@ SNF_KERNEL(e4_anchor, View)
 SNF_KERNEL(e5_align, View)
 SNF_KERNEL(e6_vote, View)
 SNF_KERNEL(z1_results, View)
+SNF_KERNEL(f1_flags, View)
+SNF_KERNEL(f2_scan, View)
+SNF_KERNEL(f3_rank, View)
+SNF_KERNEL(f4_emit, View)
+SNF_KERNEL(f5_alt, View)
 SNF_KERNEL(s1_blockcov, BlockCov)
 SNF_KERNEL(s2_covends, CovCalls)
 SNF_KERNEL(s2_covcalls, CovCalls)
@@ -204,10 +210,8 @@ struct snf_batch_impl {
   bool timing = true;             // HIP events around the heavy kernels (snf_batch_set_timing)
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
   bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
-  bool prefetched = false;        // finalize already copied calls / read names to the pinned host buffers
   bool res_current = false;       // z1_results has run after the last kernel that changes what it publishes
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
-  int sched_prefetch = 1;         // SNF_PREFETCH: 0 off, 1 right after e3 (best in A/B), 2 after the consensus launch
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
@@ -239,13 +243,14 @@ struct snf_batch_impl {
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
 #ifndef SNF_EMU
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr,
-             ev_counts = nullptr, ev_rn = nullptr, ev_join4 = nullptr;  // host waits: counters published (main), read-name total published (side)
+             ev_counts = nullptr, ev_rn = nullptr, ev_join4 = nullptr, ev_e3 = nullptr;  // host waits: counters published (main), read-name total published (side)
 #endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
-  bool alt_hbm = false; uint8_t* d_alt = nullptr; int64_t d_alt_cap = 0;   // SNF_ALT_HBM=1 (experiment): ALT bytes to HBM + one D2H in fetch instead of kernel stores into pinned host memory
   // results (host)
-  HostBuf hb_calls, hb_alt, hb_rn, hb_res;
+  HostBuf hb_calls, hb_rn, hb_res;   // stage-0 fetch: candidate records, read names; the pinned result block
+  HostBuf hb_out;                    // stage-1 fetch: the output block (snf_stage_out.h)
+  int out_mode = 0;                  // enum snf_output
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
   // snf_batch_fetch_clusters result (host)
   std::vector<int32_t> cl_task, cl_svtype, cl_start, cl_end, cl_seed, cl_seed_index, cl_nlong, cl_lead, cl_lead_svlen; std::vector<uint8_t> cl_repeat;
@@ -712,13 +717,14 @@ void do_upload(snf_batch_impl* b) {
   b->slab_next = (size_t)N * 1408 + (size_t)v.pool_cap + (size_t)R * 96 + ((size_t)4 << 20);
   v.cnt = dalloc<Counts>(b, 1);
   {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
-    size_t bytes = sizeof(Counts) + 8 + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8;
+    size_t bytes = sizeof(Counts) + 8 + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8 + sizeof(OutHdr) + 8;
     uint8_t* hp = (uint8_t*)b->hb_res.ensure(bytes);
     memset(hp, 0, bytes);
     b->h_cnt = (Counts*)hp;
     v.res_cnt = (Counts*)hp; v.res_rn_total = (int64_t*)(hp + sizeof(Counts)); b->h_rn_total = v.res_rn_total;
     v.res_off = v.res_rn_total + 1; v.res_cov = (double*)(v.res_off + T + 1);
     v.res_status = (int32_t*)(v.res_cov + T);
+    v.res_out = (OutHdr*)(((uintptr_t)(v.res_status + T) + 7) & ~(uintptr_t)7);
   }
   std::vector<int32_t> tid(T), svs(T), clen(T), psn(T); std::vector<double> nmt(T);
   for (int t = 0; t < T; t++) {
@@ -939,6 +945,18 @@ void do_upload(snf_batch_impl* b) {
     v.NS = hc.n_kept;
     if (v.prof) fprintf(stderr, "[SNF_PROF] prefilter: %lld of %lld leads share their (svtype, bin) cell with another lead\n", (long long)v.NS, (long long)N);
   }
+  {  // ALT stage output (HBM; every ALT is the sequence of one lead of its cluster, so all of them together fit the pool) and
+     // the output stage: at most one record per position behind the sort
+    v.alt_cap = v.pool_cap; v.alt_pool = dalloc<uint8_t>(b, (size_t)v.alt_cap + 32);
+    const size_t NO = (size_t)v.NS + 1;
+    v.o_scan = dalloc<uint32_t>(b, NO + 1); v.o_src = dalloc<int32_t>(b, NO); v.o_dst = dalloc<int32_t>(b, NO); v.o_key = dalloc<int32_t>(b, NO);
+    v.o_alt = dalloc<int64_t>(b, NO); v.o_rn = dalloc<int64_t>(b, NO);
+    v.out_hdr = dalloc<OutHdr>(b, 1);
+    dzero(b, v.out_hdr, sizeof(OutHdr));
+    v.out_dev_cap = (int64_t)(NO * sizeof(snf_call_t) + (2 * (size_t)N + 1) * 4 + (size_t)v.alt_cap + 1024);
+    v.out_dev = dalloc<uint8_t>(b, (size_t)v.out_dev_cap);
+    v.out_mode = b->out_mode; v.out_valid = 0; v.out_pin = nullptr; v.out_pin_cap = 0;
+  }
   const double t_index0 = now_ms();
   { const bool tm = b->timing; b->timing = false; enqueue_read_index(b); b->timing = tm; }   // (no event brackets outside a pass)
   dsync(b);
@@ -1104,7 +1122,7 @@ void run_call_candidates(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);
+    if (!(v.wave_path && b->fused)) LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);   // (next to the wave kernels every item would return at once)
 #ifndef SNF_EMU
     if (v.wave_path) {   // clusters of more than 64 leads, one wave each
       Scope _s(b, "x_big_refine", 0);
@@ -1129,7 +1147,7 @@ void run_call_candidates(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
+    if (!(v.wave_path && b->fused)) LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "x_big_call", 0);
@@ -1183,7 +1201,8 @@ void run_call_candidates(snf_batch_impl* b) {
 #endif
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
   }
-  b->prefetched = false; b->res_current = false;
+  b->res_current = false;
+  v.out_valid = 0;
 }
 
 // everything enqueued on any of the batch's streams has completed and the pinned result block is current
@@ -1207,45 +1226,144 @@ void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t 
   *p = dalloc_own<uint8_t>(b, (size_t)cap * elem);
 }
 
-void enqueue_prefetch(snf_batch_impl* b) {
+// ---- output stage (snf_stage_out.h): flags / scan / rank / records + read names on the side stream as soon as the scalar
+// call fields are final, the ALT bytes behind the consensus kernels.  `late`: everything on the main stream (plain-scan path,
+// and the redo after the rare fallbacks of the ALT stage)
+void enqueue_output_head(snf_batch_impl* b) {
   View& v = b->v;
+  const int64_t NS = v.NS;
+  if (b->fused && NS <= ((int64_t)1 << 22) * 256) {
 #ifndef SNF_EMU
-  // the call records are final once e1w/e1 (side stream), E3 (main: done, we just synchronised) and the sv-id / read-name
-  // kernels (fourth stream) have run: copy them to the pinned host buffers while the consensus kernels run.  The read
-  // names go out on the fourth stream as soon as their total is known.
-  SNF_HIP(hipEventSynchronize(b->ev_rn));  // enqueued long ago
-  int64_t nc = b->h_cnt->n_calls, rn_total = *b->h_rn_total;
-  snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
-  uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
-  {
-    hipStream_t prev = b->cur; b->cur = b->stream4;
-    if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
-    b->cur = prev;
-    SNF_HIP(hipEventRecord(b->ev_join4, b->stream4));
-  }
-  fork_mark(b);
-  SideStream side(b);
-  SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_rn, 0));   // sv_id / rn_off are in the records
-  d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
-  b->prefetched = true;
-#else
-  (void)v;
+    const unsigned grid = (unsigned)((NS + 255) / 256);
+    FUSED(f1k_outflags, NS);
+    FUSED(f2k_outscan, NS);
+    if ((v.out_mode & SNF_OUT_EXECUTE) && v.cfg.sort) {
+      Scope _s(b, "f3_rank", 0);
+      hipLaunchKernelGGL(f3k_rank, dim3(grid < 1024u ? grid : 1024u), dim3(256), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+    { Scope _s(b, "f4_emit", 0);
+      hipLaunchKernelGGL(f4w_emit, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError()); }
 #endif
+  } else {
+    const int64_t nc = NS;   // upper bound of the number of calls (the bodies stop at the device's count)
+    LAUNCH_Q(f1_flags, v, nc + 1, 0);
+    prim_exscan<uint32_t>(b, v.o_scan, v.pL, nc + 1, "scan_out");
+    prim_exscan<int64_t>(b, v.sz_tab, v.sc_tab, nc + 1, "scan_out");
+    prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_out");
+    LAUNCH_Q(f2_scan, v, nc + 1, 0);
+    if ((v.out_mode & SNF_OUT_EXECUTE) && v.cfg.sort) LAUNCH_Q(f3_rank, v, nc, 0);
+    LAUNCH_Q(f4_emit, v, nc, 0);
+  }
 }
+void enqueue_output_alt(snf_batch_impl* b) {
+  View& v = b->v;
+  const int64_t NS = v.NS;
+#ifndef SNF_EMU
+  if (b->fused) {
+    const unsigned grid = (unsigned)((NS + 255) / 256);
+    Scope _s(b, "f5_alt", 0);
+    hipLaunchKernelGGL(f5w_alt, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+    return;
+  }
+#endif
+  LAUNCH_Q(f5_alt, v, NS, 0);
+}
+
+// Thread-kernel form of the ALT stage (e4 / e5 / e6) and the ROWS instance need scratch sized by totals that only the device
+// knows: the one place where finalize waits for the device.  Taken by the emulation build (always), by SNF_NO_WAVE, and - from
+// the fetch, after the fact - when a call fits none of the LDS classes or a workgroup handed its call over (escape list).
+void run_alt_fallback(snf_batch_impl* b) {
+  View& v = b->v;
+  d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
+  dsync(b);
+  const Counts& c = *b->h_cnt;
+  if (c.n_cons <= 0) return;
+  const int64_t tab_total = c.tab_total, aln_total = c.aln_total, nreads = c.n_cons_reads;
+  int64_t c1 = b->tab_cap, c2 = b->tab_cap, c3 = b->tab_cap;
+  ensure_cap(b, tab_total, c1, (void**)&v.tab_key, sizeof(uint64_t));
+  ensure_cap(b, tab_total, c2, (void**)&v.tab_pos, sizeof(int32_t));
+  ensure_cap(b, tab_total, c3, (void**)&v.tab_state, sizeof(uint8_t));
+  b->tab_cap = c1; v.tab_cap = c1;
+  ensure_cap(b, aln_total, b->aln_cap, (void**)&v.aln, 1); v.aln_cap = b->aln_cap;
+  int64_t r1 = b->cr_cap, r2 = b->cr_cap, r3 = b->cr_cap;
+  ensure_cap(b, nreads, r1, (void**)&v.aln_kept, 1);
+  ensure_cap(b, nreads, r2, (void**)&v.cr_call, sizeof(int32_t));
+  ensure_cap(b, nreads, r3, (void**)&v.cr_read, sizeof(int32_t));
+  b->cr_cap = r1;
+  const bool threads = !v.wave_path || c.n_cons_fallback > 0;
+  if (threads) LAUNCH_Q(e4_anchor, v, c.n_cons, v.wave_path ? 0 : c.tab_total * 13);
+#ifndef SNF_EMU
+  if (v.wave_path && c.n_cls[7] > 0) {   // work list 7: calls beyond the LDS vote counters and what SMALL / LARGE handed over at run time
+    Scope _s(b, "e45w_consensus_rows", 0);
+    const int64_t n_rows = (int64_t)c.n_cls[7];
+    hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(n_rows < 16384 ? n_rows : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  }
+#endif
+  if (threads) {
+    LAUNCH_Q(e5_align, v, c.n_cons_reads, v.wave_path ? 0 : c.aln_total * 2);
+    LAUNCH(e6_vote, v, c.alt_total, c.aln_total + 2 * c.alt_total);
+  }
+}
+
+#ifndef SNF_EMU
+// SMALL / LARGE / verbatim-copy kernels of the ALT stage, one launch per class.  The grids are upper bounds (exact when the
+// caller knows the class counts): workgroups behind the end of a class's list return at once, and the kernels stride when
+// a list is longer than the grid.
+void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large, int64_t g_copy) {
+  View& v = b->v;
+    const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
+    if (serial) SNF_HIP(hipDeviceSynchronize());
+    SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+    {  // the LARGE class is independent of the others: its own stream, joined before the ALT bytes are copied out
+      SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+      hipStream_t prev = b->cur; b->cur = b->stream3;
+      { Scope _s(b, "e45w_consensus_large", 0);
+        const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
+        if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
+        else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((K_CONS_LARGE), gl, dim3(256), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
+      b->cur = prev;
+    }
+    if (serial) SNF_HIP(hipDeviceSynchronize());
+    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+    {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
+      Scope _s(b, "e4c_copy", 0);
+      hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+    {
+      Scope _s(b, "e45w_consensus_small", 0);
+      const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
+      if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < 65536 ? g_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
+      else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+      else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+      else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
+    }
+  SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
+}
+#endif
 
 void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
-  if (v.N <= 0) return;
-  // one cheap wait: the number of candidate calls makes every launch and scan below exact-sized (d3_taskoff has put
-  // the counters into the pinned result block; the side stream may still be annotating the candidates)
-#ifndef SNF_EMU
-  SNF_HIP(hipEventSynchronize(b->ev_counts));
-#endif
-  const int64_t nc = b->h_cnt->n_calls;
+  const int64_t NS = v.NS;
   b->finalized = true;
-  if (nc <= 0) return;
   b->res_current = false;
-  dzero(b, v.stripes, sizeof(unsigned long long) * 4 * 64 * 16);
+  // Nothing below waits for the device: grids cover upper bounds derived from NS (the kernels read the real counts in HBM
+  // and stride or return), the ALT bytes go to an HBM pool sized at upload, and the fetch is the one host wait of the pass.
+  {  // pinned block for the result: sized from the input, grown by the fetch when a result did not fit
+    const size_t want = (size_t)((v.out_mode & SNF_OUT_EXECUTE) ? 8 : 16) * (size_t)(v.N > 0 ? v.N : 1) + ((size_t)1 << 20);
+    if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_out.cap < want) b->hb_out.ensure(want);
+    v.out_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_out.p;
+    v.out_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_out.cap;
+  }
+  v.out_valid = 1;
+  if (NS > 0) {
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
      // annotations they read), overlapped with the consensus chain
     SideStream side(b);
@@ -1253,14 +1371,15 @@ void run_finalize(snf_batch_impl* b) {
     if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
-      // one workgroup (= wave) per batch of e1_batch calls, dispatched by the hardware (a resident grid that strides would
-      // run a second, mostly empty round: ceil(calls / 16) is only slightly more than the waves the device holds)
-      int64_t grid = (nc + v.e1_batch - 1) / v.e1_batch;
+      // one workgroup (= wave) per batch of e1_batch calls; the grid covers an upper bound of the calls (a quarter of the
+      // positions behind the sort; the kernel strides if there are more) and workgroups behind the last call return at once
+      int64_t grid = (NS / 4 + v.e1_batch - 1) / v.e1_batch + 1;
+      if (grid > (1 << 20)) grid = 1 << 20;
       hipLaunchKernelGGL(b->k_e1w, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
 #endif
-    LAUNCH_Q(e1_finalize, v, nc, 0);
+    if (!v.wave_path) LAUNCH_Q(e1_finalize, v, NS, 0);
 #ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "x_big_finalize", 0);
@@ -1269,104 +1388,64 @@ void run_finalize(snf_batch_impl* b) {
     }
 #endif
   }
+  const bool fast_alt = v.wave_path && b->fused && NS <= ((int64_t)1 << 22) * 256;
 #ifndef SNF_EMU
-  if (b->fused && nc <= ((int64_t)1 << 22))   // e3b sums every preceding 256-call tile directly
+  if (fast_alt)
   {  // E2 sizes -> offsets -> E3 work items in two launches (snf_fused.h) instead of a size kernel, five scans and E3
-    const unsigned grid = (unsigned)((nc + 255) / 256);
+    const unsigned grid = (unsigned)((NS + 255) / 256);
     if (b->time_all) { Scope _s(b, "e2a_sizes", 0); hipLaunchKernelGGL(e2a_sizes, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0); }
     else hipLaunchKernelGGL(e2a_sizes, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
     if (b->time_all) { Scope _s(b, "e3b_offsets", 0); hipLaunchKernelGGL(e3b_offsets, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0); }
     else hipLaunchKernelGGL(e3b_offsets, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
+    SNF_HIP(hipEventRecord(b->ev_e3, b->stream));
+    {  // records + read names leave as soon as e1 (side stream), the sv ids / read names (fourth stream) and the ALT
+       // lengths (e2a, main) are there - next to the consensus kernels
+      SideStream side(b);
+      SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_e3, 0));
+      SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_rn, 0));
+      enqueue_output_head(b);
+    }
+    enqueue_consensus_wave(b, NS / 16 + 256, NS / 64 + 256, NS / 16 + 256);
+    join_side(b);
+    join_fourth(b);
+    enqueue_output_alt(b);
   }
   else
 #endif
   {
-  LAUNCH(e2_best, v, nc, 0);
-  prim_exscan<uint32_t>(b, v.fN, v.pN, nc + 1, "scan_alt");
-  prim_exscan<uint32_t>(b, v.fL, v.pL, nc + 1, "scan_cons");
-  prim_exscan<int64_t>(b, v.sz_tab, v.sc_tab, nc + 1, "scan_cons_sizes");
-  prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
-  prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
-  LAUNCH_Q(e3_conslist, v, nc, 0);
-  }
-  d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
-  dsync(b);
-  const int64_t ncons = b->h_cnt->n_cons, alt_total = b->h_cnt->alt_total;
-  if (b->sched_prefetch == 1) enqueue_prefetch(b);
-  if (ncons > 0) {
-    const int64_t tab_total = b->h_cnt->tab_total, aln_total = b->h_cnt->aln_total, nreads = b->h_cnt->n_cons_reads;
-    int64_t c1 = b->tab_cap, c2 = b->tab_cap, c3 = b->tab_cap;
-    ensure_cap(b, tab_total, c1, (void**)&v.tab_key, sizeof(uint64_t));
-    ensure_cap(b, tab_total, c2, (void**)&v.tab_pos, sizeof(int32_t));
-    ensure_cap(b, tab_total, c3, (void**)&v.tab_state, sizeof(uint8_t));
-    b->tab_cap = c1; v.tab_cap = c1;
-    ensure_cap(b, aln_total, b->aln_cap, (void**)&v.aln, 1); v.aln_cap = b->aln_cap;
-    int64_t r1 = b->cr_cap, r2 = b->cr_cap, r3 = b->cr_cap;
-    ensure_cap(b, nreads, r1, (void**)&v.aln_kept, 1);
-    ensure_cap(b, nreads, r2, (void**)&v.cr_call, sizeof(int32_t));
-    ensure_cap(b, nreads, r3, (void**)&v.cr_read, sizeof(int32_t));
-    b->cr_cap = r1;
-  }
-  // ALT bytes are only ever written by the GPU: the kernels store them straight into the pinned host buffer, so the
-  // PCIe transfer rides along with the (latency-bound) consensus kernels instead of trailing them
-  v.alt_pool = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1); v.alt_cap = alt_total;
-  if (b->alt_hbm) { ensure_cap(b, alt_total + 16, b->d_alt_cap, (void**)&b->d_alt, 1); v.alt_pool = b->d_alt; }
-  const bool fallback = !v.wave_path || b->h_cnt->n_cons_fallback > 0;
-  if (ncons > 0) {
-    if (fallback) LAUNCH_Q(e4_anchor, v, ncons, v.wave_path ? 0 : b->h_cnt->tab_total * 13);
+    // plain-scan path (emulation build, SNF_NO_FUSE, SNF_NO_WAVE): sized by the number of calls, one host wait
+    d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
+    dsync(b);
+    const int64_t nc = b->h_cnt->n_calls;
+    dzero(b, v.stripes, sizeof(unsigned long long) * 4 * 64 * 16);
+    LAUNCH(e2_best, v, nc + 1, 0);
+    prim_exscan<uint32_t>(b, v.fN, v.pN, nc + 1, "scan_alt");
+    prim_exscan<uint32_t>(b, v.fL, v.pL, nc + 1, "scan_cons");
+    prim_exscan<int64_t>(b, v.sz_tab, v.sc_tab, nc + 1, "scan_cons_sizes");
+    prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
+    prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
+    LAUNCH_Q(e3_conslist, v, nc + 1, 0);
 #ifndef SNF_EMU
     if (v.wave_path) {
-      // algorithmic bytes are accumulated by the kernels themselves (cnt->cons_bytes) and attached to
-      // these timing entries in collect_timings.  One launch per class, sized by the class counters of e3_conslist
-      const int64_t n_copy = (int64_t)b->h_cnt->n_cls[0], n_small = (int64_t)b->h_cnt->n_cls[1], n_large = (int64_t)(b->h_cnt->n_cls[2] + b->h_cnt->n_cls[3] + b->h_cnt->n_cls[4] + b->h_cnt->n_cls[5]);
-      const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
-      if (serial) SNF_HIP(hipDeviceSynchronize());
-      SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
-      if (n_large > 0) {  // the LARGE class is independent of the others: its own stream, joined before z1_results
-        SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
-        hipStream_t prev = b->cur; b->cur = b->stream3;
-        { Scope _s(b, "e45w_consensus_large", 0);
-          const dim3 gl((unsigned)(n_large < b->slots_cons_l ? n_large : b->slots_cons_l));
-          if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
-          else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
-          else hipLaunchKernelGGL((K_CONS_LARGE), gl, dim3(256), 0, b->cur, v, (int64_t)0);
-          SNF_HIP(hipGetLastError()); }
-        b->cur = prev;
-      }
-      if (serial) SNF_HIP(hipDeviceSynchronize());
-      SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
-      if (n_copy > 0) {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
-        Scope _s(b, "e4c_copy", 0);
-        hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(n_copy < 32768 ? n_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError());
-      }
-      if (n_small > 0) {
-        Scope _s(b, "e45w_consensus_small", 0);
-        const dim3 gs((unsigned)(n_small < b->slots_cons_s ? n_small : b->slots_cons_s));
-        if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(n_small < 65536 ? n_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
-        else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError());
-      }
-      SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
-      {  // work list 7: calls beyond the LDS vote counters and whatever SMALL / LARGE handed over at run time (their
-         // escape list overflowed) - the list is complete only now, so the kernel reads its length on the device
-        Scope _s(b, "e45w_consensus_rows", 0);
-        const int64_t n_rows = (int64_t)b->h_cnt->n_cls[7];
-        hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(n_rows > 1024 ? (n_rows < 16384 ? n_rows : 16384) : 1024)), dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError());
-      }
+      d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
+      dsync(b);
+      const Counts& c = *b->h_cnt;
+      enqueue_consensus_wave(b, (int64_t)c.n_cls[1] + 1, (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]) + 1, (int64_t)c.n_cls[0] + 1);
     }
 #endif
-    if (fallback) LAUNCH_Q(e5_align, v, b->h_cnt->n_cons_reads, v.wave_path ? 0 : b->h_cnt->aln_total * 2);
+    run_alt_fallback(b);     // (host wait: scratch sizes; thread kernels, and ROWS for work list 7, complete only now)
+    join_side(b);
+    join_fourth(b);
+    enqueue_output_head(b);
+    enqueue_output_alt(b);
   }
-  if (b->sched_prefetch == 2) enqueue_prefetch(b);
-  if (fallback) LAUNCH(e6_vote, v, alt_total, b->h_cnt->aln_total + 2 * alt_total);
-  join_side(b);
-  join_fourth(b);
+  } else {
+    join_side(b);
+    join_fourth(b);
+    enqueue_output_head(b);   // (no positions behind the sort: an empty block)
+  }
   LAUNCH_Q(z1_results, v, v.T + 1, 0);
   b->res_current = true;
 }
@@ -1411,6 +1490,19 @@ void collect_timings(snf_batch_impl* b) {
 #endif
 }
 
+// After everything of the pass has run: did the ALT stage leave work for the slow kernels (a call that fits none of the LDS
+// classes, or a workgroup that handed its call to work list 7)?  Rare; they run now, and the ALT bytes are copied out again.
+void settle_alt_stage(snf_batch_impl* b) {
+  View& v = b->v;
+  if (!v.wave_path || !b->fused || v.NS <= 0) return;   // (the plain path ran them inside finalize)
+  const Counts& c = *b->h_cnt;
+  if (c.n_cls[7] == 0 && c.n_cons_fallback == 0) return;
+  run_alt_fallback(b);
+  enqueue_output_alt(b);
+  LAUNCH_Q(z1_results, v, v.T + 1, 0);
+  dsync(b);
+}
+
 void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   View& v = b->v;
   int T = v.T;
@@ -1420,28 +1512,46 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   if (v.prof) {
     const Counts& c = *b->h_cnt;
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
-                    "fallback %lld alt bytes %lld fused bytes %llu | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+                    "fallback %lld alt bytes %lld fused bytes %llu | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu rows %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
-            (long long)c.alt_total, c.pool_extra_used, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6]);
-  }
-  int64_t nc = v.N > 0 ? b->h_cnt->n_calls : 0;
-  int64_t alt_total = (stage >= 1 && v.N > 0) ? b->h_cnt->alt_total : 0;
-  int64_t rn_total = v.N > 0 ? b->h_cnt->rn_total : 0;
-  snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
-  uint8_t* alt = (uint8_t*)b->hb_alt.ensure((size_t)alt_total + 1);  // filled by the kernels (zero-copy)
-  uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
-  const bool pre = b->prefetched && stage >= 1;
-  if (b->alt_hbm && alt_total && b->d_alt) { d2h_timed(b, alt, b->d_alt, (size_t)alt_total, "d2h_alt"); if (pre) dsync(b); }
-  if (!pre) {
-    d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
-    if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
-    dsync(b);
+            (long long)c.alt_total, c.pool_extra_used, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6], c.n_cls[7]);
   }
   memcpy(b->r_status.data(), v.res_status, (size_t)T * sizeof(int32_t));
-  memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
   memcpy(b->r_cov.data(), v.res_cov, (size_t)T * sizeof(double));
-  b->prefetched = false;  // the squeeze / stage fix-ups below edit the host copy in place
-  if (v.N <= 0) std::fill(b->r_off.begin(), b->r_off.end(), 0);
+  if (stage >= 1 && b->finalized) {
+    // ---- the block of the output stage: already in pinned host memory, or one copy away
+    settle_alt_stage(b);
+    const OutHdr h = *v.res_out;
+    const uint8_t* base = (const uint8_t*)b->hb_out.p;
+    if (!h.in_pinned) {
+      v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)
+      base = (const uint8_t*)b->hb_out.ensure((size_t)h.bytes + 256);
+      d2h_timed(b, (void*)base, v.out_dev, (size_t)h.bytes, "d2h_block");
+      dsync(b);
+    }
+    memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
+    collect_timings(b);
+    out->n_calls = h.n_out; out->calls = (const snf_call_t*)base;
+    out->alt_pool_len = h.alt_out; out->alt_pool = base + h.off_alt;
+    out->rnames_len = h.rn_out; out->rnames = (const uint32_t*)(base + h.off_rn);
+    out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
+    out->coverage_average_total = b->r_cov.data();
+    return;
+  }
+  // ---- candidates (stage 0, or no finalize yet): records and read names as the candidate stage left them in HBM
+  int64_t nc = v.NS > 0 ? b->h_cnt->n_calls : 0;
+  int64_t rn_total = v.NS > 0 ? b->h_cnt->rn_total : 0;
+  snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));
+  uint32_t* rn = (uint32_t*)b->hb_rn.ensure((size_t)(rn_total + 1) * sizeof(uint32_t));
+  d2h_timed(b, calls, v.calls, (size_t)nc * sizeof(snf_call_t), "d2h_calls");
+  if (rn_total) d2h_timed(b, rn, v.rnames, (size_t)rn_total * sizeof(uint32_t), "d2h_rnames");
+  dsync(b);
+  if (v.out_valid) {   // (a stage-0 fetch after finalize: the result block holds the offsets of the output block)
+    std::vector<int64_t> off((size_t)T + 1);
+    d2h(b, off.data(), v.t_call_off, ((size_t)T + 1) * sizeof(int64_t)); dsync(b);
+    b->r_off = off;
+  } else memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
+  if (v.NS <= 0) std::fill(b->r_off.begin(), b->r_off.end(), 0);
   // tasks whose reference run raises (SNF_TASK_ERR_*) yield no calls: squeeze them out (rare; in place)
   bool any_err = false;
   for (int t = 0; t < T; t++) any_err |= b->r_status[t] != SNF_TASK_OK;
@@ -1455,10 +1565,10 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     }
     noff[T] = w; b->r_off = noff; nc = w;
   }
-  if (stage < 1) for (int64_t i = 0; i < nc; i++) { calls[i].alt_len = -1; calls[i].alt_off = 0; }
+  for (int64_t i = 0; i < nc; i++) { calls[i].alt_len = -1; calls[i].alt_off = 0; }
   collect_timings(b);
   out->n_calls = nc; out->calls = calls;
-  out->alt_pool_len = alt_total; out->alt_pool = alt;
+  out->alt_pool_len = 0; out->alt_pool = (const uint8_t*)calls;
   out->rnames_len = rn_total; out->rnames = rn;
   out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
   out->coverage_average_total = b->r_cov.data();
@@ -1852,6 +1962,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->stream3 = g_streams.take(b->device);
     b->stream4 = g_streams.take(b->device);
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
+    SNF_HIP(hipEventCreateWithFlags(&b->ev_e3, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_fork3, hipEventDisableTiming));
     SNF_HIP(hipEventCreate(&b->ev_base));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_counts, hipEventDisableTiming));
@@ -1888,8 +1999,6 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
-    if (const char* e = getenv("SNF_PREFETCH")) b->sched_prefetch = atoi(e);
-    b->alt_hbm = getenv("SNF_ALT_HBM") != nullptr;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
     if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);
@@ -1929,6 +2038,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->stream3) (void)hipStreamSynchronize(b->stream3);
   if (b->stream4) (void)hipStreamSynchronize(b->stream4);
   if (b->ev_fork3) (void)hipEventDestroy(b->ev_fork3);
+  if (b->ev_e3) (void)hipEventDestroy(b->ev_e3);
   if (b->ev_base) (void)hipEventDestroy(b->ev_base);
   if (b->ev_counts) (void)hipEventDestroy(b->ev_counts);
   if (b->ev_rn) (void)hipEventDestroy(b->ev_rn);
@@ -1938,7 +2048,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 #endif
   dfree_all(b);
-  b->hb_calls.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
+  b->hb_calls.release(); b->hb_out.release(); b->hb_rn.release(); b->hb_res.release();
 #ifndef SNF_EMU
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
@@ -1997,19 +2107,33 @@ int snf_batch_fetch_clusters(snf_batch_t* bb, int stage, snf_clusters_t* out) {
   })
 }
 
-int snf_batch_export_calls_device(snf_batch_t* bb, void* dst_device, int64_t cap_calls, int64_t* n_calls) {
+int snf_batch_set_output(snf_batch_t* bb, int mode) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
-    if (!b || !b->uploaded || !dst_device || !n_calls) fail("batch not uploaded / null argument");
-    full_sync(b);
-    int64_t nc = b->v.N > 0 ? b->h_cnt->n_calls : 0;
-    if (nc > cap_calls) fail("export buffer too small");
-    *n_calls = nc;
+    if (!b) fail("null batch");
+    if (mode < 0 || mode > (SNF_OUT_EXECUTE | SNF_OUT_DEVICE)) fail("unknown output mode");
+    b->out_mode = mode; b->v.out_mode = mode;
+  })
+}
+
+int snf_batch_export_device(snf_batch_t* bb, void* dst_device, int64_t cap_bytes, snf_export_layout_t* layout) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded || !layout) fail("batch not uploaded / null argument");
+    if (!b->finalized) fail("snf_batch_export_device needs snf_batch_finalize first");
+    if (!(b->v.out_mode & SNF_OUT_DEVICE)) fail("snf_batch_export_device needs snf_batch_set_output(... | SNF_OUT_DEVICE) before the finalize");
 #ifndef SNF_EMU
-    if (nc) SNF_HIP(hipMemcpyAsync(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t), hipMemcpyDeviceToDevice, b->cur));
-#else
-    if (nc) memcpy(dst_device, b->v.calls, (size_t)nc * sizeof(snf_call_t));
+    SNF_HIP(hipSetDevice(b->device));
 #endif
+    full_sync(b);
+    settle_alt_stage(b);
+    const OutHdr h = *b->v.res_out;
+    layout->n_calls = h.n_out; layout->rnames_len = h.rn_out; layout->alt_pool_len = h.alt_out;
+    layout->off_rnames = h.off_rn; layout->off_alt = h.off_alt; layout->bytes = h.bytes;
+    if (h.bytes > cap_bytes) fail("export buffer too small");
+    if (h.bytes > 0 && !dst_device) fail("null destination");
+    d2d(b, dst_device, b->v.out_dev, (size_t)h.bytes);
+    dsync(b);
   })
 }
 

@@ -678,8 +678,10 @@ SNF_HD void s2_covcalls_body(int64_t i, const CovCalls& q) {
 // Z1: counters, task status / call offsets / coverage averages -> the pinned host result block (zero-copy stores)
 SNF_HD void z1_results_body(int64_t t, const View& v) {
   if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }
-  if (t <= v.T) v.res_off[t] = v.t_call_off[t];
+  // offsets of the tasks' records: candidate list, or (after finalize) the block of the output stage
+  if (t <= v.T) v.res_off[t] = v.out_valid ? (int64_t)v.o_scan[v.t_call_off[t]] : v.t_call_off[t];
   if (t == 0) {
+    if (v.out_valid) *v.res_out = *v.out_hdr;
     if (v.wave_path) for (int c = 0; c < 4; c++) {  // striped byte counters of the ALT kernels (snf_wave_cons.h)
       unsigned long long sum = 0;
       for (int k = 0; k < 64; k++) sum += v.stripes[(c * 64 + k) * 16];

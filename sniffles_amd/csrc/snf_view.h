@@ -74,6 +74,14 @@ struct ClusterHdr { int32_t h, lo, n, grp; int32_t repeat, _pad[3]; };
 enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7, TS_RNAMES = 8, TS_KEEP = 9,
        TS_OUT = 10 /* 11, 12 */, TS_SLOTS = 13 };
 
+// totals and layout of the output block (f* kernels, snf_stage_out.h); copied to the pinned result block by z1_results
+struct OutHdr {
+  int64_t n_out, rn_out, alt_out;     // records, read names (uint32), ALT bytes
+  int64_t off_rn, off_alt, bytes;     // sections of the block: [records | read names | ALT bytes], 256-byte aligned
+  int32_t in_pinned;                  // 1: the kernels stored the block straight into pinned host memory
+  int32_t _pad;
+};
+
 struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t rc;       // refined cluster id
   int32_t cluster;  // merged cluster id
@@ -159,6 +167,16 @@ struct View {
   LeadRec* Lrec;             // [N] packed records of L[] (same index)
   const LeadRec* in_rec;     // [N] the input columns interleaved per lead at upload (input order): one 64-B gather in a6
   ClusterHdr* chdr;          // [n_clusters]
+  // ---- output stage (snf_stage_out.h): the calls a stage-1 fetch returns, compacted into one block
+  int32_t out_mode;          // enum snf_output
+  int32_t out_valid;         // host: the output stage of this pass has been enqueued (z1_results publishes its offsets)
+  uint32_t* o_scan;          // [n_calls+1] exclusive scan of the keep flags (defined for every call)
+  int32_t *o_src, *o_dst, *o_key;   // [n_out] compacted index -> call index / final record index / pos (sort key)
+  int64_t *o_alt, *o_rn;     // [n_out] offsets inside the ALT / read-name sections
+  OutHdr* out_hdr;           // device
+  OutHdr* res_out;           // pinned copy (z1_results)
+  uint8_t* out_dev; int64_t out_dev_cap;   // block in HBM
+  uint8_t* out_pin; int64_t out_pin_cap;   // block in pinned host memory (0: none)
   // result block in pinned host memory, written by z1_results at the end of each stage (no D2H copies to wait for)
   Counts* res_cnt; int32_t* res_status; int64_t* res_off; double* res_cov;
   int64_t* res_rn_total;     // pinned: total supporting-read-name count, written by d3_rnames (side stream)

@@ -40,7 +40,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_genotype_batch.restype = C.c_int
     lib.snf_batch_fetch_clusters.argtypes = [vp, C.c_int, C.POINTER(abi.snf_clusters_t)]
     lib.snf_batch_fetch_clusters.restype = C.c_int
-    lib.snf_batch_export_calls_device.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int64)]
+    lib.snf_batch_export_device.argtypes = [vp, vp, C.c_int64, C.POINTER(abi.snf_export_layout_t)]
+    lib.snf_batch_set_output.argtypes = [vp, C.c_int]
     lib.snf_batch_block_coverage.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_batch_block_coverage.restype = C.c_int
     lib.snf_batch_coverage_calls.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -81,7 +82,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
               "snf_extract_device_view", "snf_batch_add_task_device"):
         getattr(lib, f).restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
-              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_calls_device",
+              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_device", "snf_batch_set_output",
               "snf_batch_timing_count",
               "snf_batch_timing_get", "snf_edit_distance_batch"):
         getattr(lib, f).restype = C.c_int
@@ -194,11 +195,18 @@ class Batch:
         out["lead"], out["lead_svlen"] = col(r.lead, m, np.int32), col(r.lead_svlen, m, np.int32)
         return out
 
-    def export_calls_device(self, dst_ptr: int, cap_calls: int) -> int:
-        """Device-to-device copy of the call records into caller-owned HBM (for the RCCL gather)."""
-        n = C.c_int64()
-        _check(self.lib, self.lib.snf_batch_export_calls_device(self._h, C.c_void_p(dst_ptr), cap_calls, C.byref(n)))
-        return int(n.value)
+    def set_output(self, mode: int) -> None:
+        """What a stage-1 fetch returns (before `finalize`): abi.OUT_CANDIDATES (default: every candidate, candidate order - what
+        Task.finalize_candidates returns), abi.OUT_EXECUTE (what CallTask.execute keeps: qc-passing calls, per task sorted by
+        pos, compacted on the device), optionally | abi.OUT_DEVICE (the block stays in HBM: `export_device`)."""
+        _check(self.lib, self.lib.snf_batch_set_output(self._h, int(mode)))
+
+    def export_device(self, dst_ptr: int, cap_bytes: int) -> dict:
+        """Device-to-device copy of the finalized result block [records | read names | ALT bytes] into caller-owned HBM (for
+        the RCCL gather); returns its layout (n_calls, rnames_len, alt_pool_len, off_rnames, off_alt, bytes)."""
+        lay = abi.snf_export_layout_t()
+        _check(self.lib, self.lib.snf_batch_export_device(self._h, C.c_void_p(dst_ptr), int(cap_bytes), C.byref(lay)))
+        return {f: int(getattr(lay, f)) for f, _ in abi.snf_export_layout_t._fields_}
 
     def block_coverage(self, task_index: int, binsize: int, first_bin: int, n_bins: int) -> np.ndarray:
         """Rounded mean depth of `n_bins` coverage bins of `binsize` bp (SNFile.annotate_block_coverages); -1 = beyond

@@ -1,0 +1,191 @@
+"""snf_batch_set_output (include/sniffles_amd.h): SNF_OUT_EXECUTE returns what `CallTask.execute` keeps of the finalized
+candidates (`/root/reference/src/sniffles/parallel.py:265-271`: `[s for s in svcalls if s.qc]` unless `config.no_qc`, then
+`sorted(svcalls, key=pos)` - a stable sort) - filtered, sorted and compacted on the device.  Checked against the same two
+statements applied on the host to the SNF_OUT_CANDIDATES result (which the other parity tests pin on the oracle and the
+reference's goldens); `snf_batch_export_device` hands out the same block in HBM."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from sniffles_amd import abi, lib, synth
+from sniffles_amd.config import SnifflesConfig
+
+
+def tasks():
+    # a BND-first task raises in the reference (UnboundLocalError): no records in either mode
+    import cases
+    return [synth.gen_task(0, "chr20", 1_200_000, 30, 3, mosaic_frac=0.3), cases.ALL["bnd_first_error"][0](), synth.gen_fuzz(21, task_id=2),
+            synth.gen_fuzz(22, task_id=3), synth.gen_task(4, "chr21", 400_000, 25, 9)]
+
+
+def run(L, cfg, tis, mode):
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.set_output(mode)
+        b.call_candidates()
+        b.finalize()
+        return b.fetch(1)
+
+
+def expected_execute(cand, cfg):
+    """CallTask.execute's two statements over the candidate-mode result: per task (order of kept call indices)."""
+    keep = []
+    for t in range(len(cand.task_status)):
+        lo, hi = int(cand.task_call_off[t]), int(cand.task_call_off[t + 1])
+        idx = np.arange(lo, hi)
+        if not cfg.no_qc:
+            idx = idx[cand.calls["qc"][lo:hi] != 0]
+        if cfg.sort:
+            idx = idx[np.argsort(cand.calls["pos"][idx], kind="stable")]
+        keep.append(idx)
+    return keep
+
+
+def check(L):
+    tis = tasks()
+    for kw in ({}, {"mosaic": True}, {"no_qc": True}):
+        cfg = SnifflesConfig(**kw)
+        cand = run(L, cfg, tis, abi.OUT_CANDIDATES)
+        got = run(L, cfg, tis, abi.OUT_EXECUTE)
+        assert np.array_equal(got.task_status, cand.task_status) and int(cand.task_status[1]) == 1
+        assert np.array_equal(got.coverage_average_total, cand.coverage_average_total, equal_nan=True)
+        keep = expected_execute(cand, cfg)
+        assert got.task_call_off.tolist() == np.concatenate([[0], np.cumsum([len(k) for k in keep])]).tolist()
+        idx = np.concatenate(keep)
+        assert len(got.calls) == len(idx) and (len(idx) > 0 or cfg.mosaic)
+        if not cfg.no_qc:
+            assert len(idx) < len(cand.calls) and (got.calls["qc"] != 0).all()
+        for f in got.calls.dtype.names:
+            if f in ("alt_off", "rn_off"):
+                continue
+            a, e = got.calls[f], cand.calls[f][idx]
+            assert np.array_equal(a, e, equal_nan=a.dtype.kind == "f"), f
+        for k, i in enumerate(idx.tolist()):
+            assert got.alt(k) == cand.alt(i)
+            assert got.rn(k).tolist() == cand.rn(i).tolist()
+        # nothing but the kept calls' bytes travels
+        assert len(got.alt_pool) == int(np.maximum(cand.calls["alt_len"][idx], 0).sum())
+        assert len(got.rnames) == int(cand.calls["rn_len"][idx].sum())
+
+
+def test_execute_mode_is_the_filter_and_sort_of_the_candidates_emu():
+    import emu.emu as E
+    check(E.lib())
+
+
+def test_execute_mode_is_the_filter_and_sort_of_the_candidates_simt():
+    from emu import simt as S
+    check(S.lib())
+
+
+@pytest.mark.gpu
+def test_execute_mode_is_the_filter_and_sort_of_the_candidates_gpu():
+    check(None)
+
+
+def export_equals_fetch(L, device_alloc):
+    tis = tasks()
+    cfg = SnifflesConfig()
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.set_output(abi.OUT_EXECUTE | abi.OUT_DEVICE)
+        b.call_candidates()
+        b.finalize()
+        res = b.fetch(1)
+        with pytest.raises(lib.SnifflesAmdError, match="too small"):
+            b.export_device(0, 16)
+        ptr, read_back = device_alloc(1 << 24)
+        lay = b.export_device(ptr, 1 << 24)
+        blob = read_back(lay["bytes"])
+    assert lay["n_calls"] == len(res.calls) and lay["rnames_len"] == len(res.rnames) and lay["alt_pool_len"] == len(res.alt_pool)
+    rec = np.frombuffer(blob[:lay["n_calls"] * abi.CALL_DTYPE.itemsize], abi.CALL_DTYPE)
+    assert rec.tobytes() == res.calls.tobytes()
+    assert blob[lay["off_rnames"]:lay["off_rnames"] + 4 * lay["rnames_len"]] == res.rnames.tobytes()
+    assert blob[lay["off_alt"]:lay["off_alt"] + lay["alt_pool_len"]] == res.alt_pool.tobytes()
+    with lib.Batch(cfg, tis, _lib=L) as b:     # without SNF_OUT_DEVICE the block may never have been in HBM
+        b.call_candidates()
+        b.finalize()
+        with pytest.raises(lib.SnifflesAmdError, match="SNF_OUT_DEVICE"):
+            b.export_device(0, 1 << 24)
+
+
+def test_export_device_hands_out_the_fetched_block_emu():
+    import emu.emu as E
+    buf = {}
+
+    def alloc(n):
+        buf["a"] = np.zeros(n, np.uint8)
+        return buf["a"].ctypes.data, lambda k: buf["a"][:k].tobytes()
+    export_equals_fetch(E.lib(), alloc)
+
+
+@pytest.mark.gpu
+def test_export_device_hands_out_the_fetched_block_gpu():
+    import torch
+    buf = {}
+
+    def alloc(n):
+        buf["a"] = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        return buf["a"].data_ptr(), lambda k: buf["a"][:k].cpu().numpy().tobytes()
+    export_equals_fetch(None, alloc)
+
+
+# ---------------------------------------------------------------------------------------------- the rare ALT kernels
+def slow_alt_task():
+    """INS calls the LDS classes of the consensus stage do not serve: alleles of more than 8192 columns (ROWS instance) and
+    an allele whose reads carry more non-ACGT bytes than the escape list of the vote counters holds (handed to work list 7
+    at run time) - next to an ordinary call.  finalize enqueues without knowing; the fetch finds the work lists and runs the
+    slow kernels after the fact."""
+    import cases
+    rng = np.random.default_rng(5)
+    leads = []
+
+    def site(pos, allele, n, tag, err=0.03, odd=0):
+        for i in range(n):
+            s = cases._mutate(rng, allele, err)
+            if odd:
+                b = list(s)
+                for k in rng.choice(len(b), odd, replace=False):
+                    b[k] = "N"
+                s = "".join(b)
+            leads.append(dict(svtype="INS", ref_start=pos + i % 3, svlen=len(s), seq=s, read=f"{tag}{i}", strand="+-"[i % 2]))
+    site(20_000, cases._rng_seq(rng, 9000), 6, "L")
+    site(60_000, cases._rng_seq(rng, 300), 8, "N", odd=40)
+    site(90_000, cases._rng_seq(rng, 250), 7, "S")
+    return cases.mk_task(leads, cases._reads(30, 0, 119_000), 120_000)
+
+
+def check_slow_alt(L, oracle_mod):
+    from sniffles_amd import records
+    ti = slow_alt_task()
+    cfg = SnifflesConfig()
+    exp = oracle_mod.run(cfg, [ti], True)
+    for mode in (abi.OUT_CANDIDATES, abi.OUT_EXECUTE):
+        with lib.Batch(cfg, [ti], _lib=L) as b:
+            b.set_output(mode)
+            b.call_candidates()
+            b.finalize()
+            got = b.fetch(1)
+            again = b.fetch(1)            # (the settled state is stable)
+        assert got.alt_pool.tobytes() == again.alt_pool.tobytes()
+        if mode == abi.OUT_CANDIDATES:
+            assert records.diff_results(got, 0, exp, 0) == []
+        alts = sorted(got.alt(i) for i in range(len(got.calls)) if got.calls["alt_len"][i] > 0)
+        want = sorted(exp.alt(i) for i in range(len(exp.calls)) if exp.calls["alt_len"][i] > 0 and (mode == abi.OUT_CANDIDATES or exp.calls["qc"][i]))
+        assert alts == want and len(alts) == 3 and max(map(len, alts)) > 8192
+
+
+def test_slow_alt_kernels_are_settled_by_the_fetch_simt(oracle_mod):
+    from emu import simt as S
+    before = S.counters()["launches"]
+    check_slow_alt(S.lib(), oracle_mod)
+    assert S.counters()["launches"] > before
+
+
+def test_slow_alt_kernels_emu(oracle_mod):
+    import emu.emu as E
+    check_slow_alt(E.lib(), oracle_mod)
+
+
+@pytest.mark.gpu
+def test_slow_alt_kernels_are_settled_by_the_fetch_gpu(oracle_mod):
+    check_slow_alt(None, oracle_mod)
