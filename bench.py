@@ -36,8 +36,79 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# SNF_BENCH_EMU=1 (tests only, tests/test_multi_rank.py): the N > 1 code of this file - process group, work queue, result
+# export, gather - on a GPU-less box: gloo instead of RCCL, CPU tensors, the kernels through the test tier's host emulation
+# (tests/emu).  Never a result: the line says so.
+EMU = os.environ.get("SNF_BENCH_EMU") == "1"
+DEV = "cpu" if EMU else "cuda"
+
+
+def emu_lib():
+    if not EMU:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu.emu as E
+    return E.lib()
+
+
+def dev_sync(torch):
+    if not EMU:
+        torch.cuda.synchronize()
+
+
+def set_dev(torch, local_rank):
+    if not EMU:
+        torch.cuda.set_device(local_rank)
+
+
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# rocprofv3 summaries of this round, collected with tools/r03_profile.sh.  They are only quoted when they were measured on the
+# kernels this run executes: profiles/r03_profile_meta.json records the hash of sniffles_amd/csrc they belong to.
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+ROCPROF_STATS = os.path.join(ROOT, "profiles", "r03_kernel_stats_3_in_flight.csv")
+PROFILE_META = os.path.join(ROOT, "profiles", "r03_profile_meta.json")
+ROCPROF_NAMES = {"e45w_consensus_large": "e45w_consensus<2,", "e45w_consensus_small": "e45w_consensus<1,", "d2w_call": "d2w_call<", "e1w_finalize": "e1w_finalize<",
+                 "d1w_refine": "d1w_refine", "d4_coverage": "d4_coverage", "a4_binstats": "a4k_binstats", "a6_scatter": "a6k_scatter", "e4c_copy": "e4c_copy",
+                 "a1_keys": "a1_keys", "a0_keep": "a0k_keep", "c1_mergeruns": "c1_mergeruns", "d3_rnames": "d3rk_rnames", "b1_seedmetrics": "b1k_seedmetrics",
+                 "d5w_covsum": "d5w_covsum", "f4_emit": "f4w_emit", "f5_alt": "f5w_alt", "f3_rank": "f3k_rank"}
+
+
+def committed_profiles():
+    """(rocprofv3 average ms per kernel name, PMC traffic per kernel, note) of the committed round-3 profiles - or empty dicts and
+    the reason when they belong to other kernel sources than the ones built here."""
+    try:
+        from sniffles_amd import build
+        meta = json.load(open(PROFILE_META))
+        if meta.get("csrc_sha") != build._lib_digest():
+            return {}, {}, "profiles/r03_* were collected on other kernel sources (stale): not quoted"
+        import csv
+        avg = {}
+        for r in csv.DictReader(open(ROCPROF_STATS)):
+            for short, pat in ROCPROF_NAMES.items():
+                if pat in r["Name"].replace("snf::", "").replace(" ", "").replace("void", "") or pat in r["Name"]:
+                    avg.setdefault(short, float(r["AverageNs"]) / 1e6)
+        pmc = json.load(open(PMC_FILE))["kernels"] if os.path.exists(PMC_FILE) else {}
+        return avg, pmc, "rocprofv3 --kernel-trace --stats of the default command, profiles/r03_kernel_stats_3_in_flight.csv (same kernel sources: hash checked)"
+    except Exception as e:  # noqa: BLE001
+        return {}, {}, f"no committed profile for these sources ({type(e).__name__})"
+
+
+def pcie_d2h_peak_gbs(torch, nbytes=32 << 20, reps=8):
+    """Device -> pinned host copy rate of this box (GB/s): the roof of the result path, measured, not assumed."""
+    if EMU:
+        return float("nan")
+    src = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    for _ in range(2):
+        dst.copy_(src, non_blocking=True)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src, non_blocking=True)
+    b.record()
+    torch.cuda.synchronize()
+    return nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 # the unmodified reference (CPython) on this path, timed in the build container only (it cannot travel to the GPU box):
 # tools/time_reference.py, profiles/r01_reference_cpu.json
 REFERENCE_CPYTHON = dict(sig_s=34600.0, host="build container, 1 core (profiles/r01_reference_cpu.json: unmodified "
@@ -79,6 +150,11 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink every contig (debug only; invalid as a result)")
     ap.add_argument("--genomes", type=int, default=1,
                     help="genome replicas per batch and rank (SURVEY.md 8d scale knob; the headline configuration is 1)")
+    ap.add_argument("--output", choices=["execute", "candidates"], default="execute",
+                    help="what a pass returns to the host: execute = what the reference's CallTask.execute returns (QC-passing calls, "
+                         "per task sorted by position, parallel.py:265-271), filtered / sorted / compacted on the device; candidates = "
+                         "every candidate record (what Task.finalize_candidates returns; the --snf shape)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the compact block of the other BASELINE configs (default run only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the all-cores oracle run (and with it --verify)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-wall-clock", action="store_true")
@@ -104,10 +180,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
+    if not EMU and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    numa = bind_to_gpu_numa(torch, local_rank)
+    set_dev(torch, local_rank)
+    numa = bind_to_gpu_numa(torch, local_rank) if not EMU else "emulation"
     # SNF_BENCH_FORCE_DIST=1: run the whole collective path (RCCL process group, gathers from the worker threads) with a
     # single rank - a dry run of the N > 1 code on a 1-GPU box
     use_dist = world > 1 or os.environ.get("SNF_BENCH_FORCE_DIST") == "1"
@@ -115,7 +191,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if EMU:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist, numa=numa)
     if args.config != 4:
@@ -177,55 +256,56 @@ def run_calling(ctx):
     W = max(1, args.inflight)
     t0 = time.time()
     # handles[w][g]: batch handle of group g for host thread w (same input, independent handles)
-    handles = [[lib.Batch(cfg, gt, device=local_rank) for gt in group_tasks] for _ in range(W)]
+    handles = [[lib.Batch(cfg, gt, device=local_rank, _lib=emu_lib()) for gt in group_tasks] for _ in range(W)]
     t_upload = time.time() - t0
+    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist else 0)
+    for hs in handles:
+        for bb in hs:
+            bb.set_output(out_mode)
     batches = [h[0] for h in handles]
     handles_box = [handles]
 
-    # capacity of a send buffer: weak - the records of one pass of this rank's batch; strong - of one whole-genome pass
-    cap_t = torch.tensor([max(1024, n_sig // 8)], dtype=torch.int64, device="cuda")
-    if use_dist:
-        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)  # one capacity on every rank
-    cap_calls = int(cap_t.item())
-    rec_bytes = abi.CALL_DTYPE.itemsize
+    # capacity of a send buffer (bytes of one result block [records | read names | ALT bytes]): from the first pass, the same
+    # on every rank (the largest), with headroom
     n_send = 2 if strong else W
+    task_ids_local = [t.task_id for t in tasks]
     if use_dist:
-        sends = [torch.empty(cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(n_send)]
-        count_t = torch.zeros(1, dtype=torch.int64, device="cuda")
-        # the records are gathered on rank 0 only (one gather at the end; the parent writes the output)
-        gathered = torch.empty(world * cap_calls * rec_bytes, dtype=torch.uint8, device="cuda") if rank == 0 else None
-        counts = torch.zeros(world, dtype=torch.int64, device="cuda")
-        counts_h = torch.zeros(world, dtype=torch.int64).pin_memory()
+        probe = handles[0][0]
+        probe.call_candidates(); probe.finalize()
+        res0 = probe.fetch(1)
+        blk = 256 * 3 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames) + len(res0.alt_pool)
+        cap_t = torch.tensor([blk * (len(group_tasks) if strong else 1) * 3 // 2 + (1 << 20)], dtype=torch.int64, device=DEV)
+        dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
+        cap_bytes = int(cap_t.item())
+        sends = [torch.zeros(cap_bytes, dtype=torch.uint8, device=DEV) for _ in range(n_send)]
+        recv = torch.empty(world * cap_bytes, dtype=torch.uint8, device=DEV) if rank == 0 else None
+        ids_all = [None] * world
+        dist.all_gather_object(ids_all, task_ids_local)          # once: which rank holds which tasks (batch order)
     # Collectives run on ONE communication thread per rank, in the order the passes finish: a worker thread exports its
-    # records (device-to-device) into a send buffer, queues it and goes on with its next pass; the gather overlaps that
-    # pass.  Every rank issues the same (counts, records) sequence, so the order matches everywhere.
+    # result block (device-to-device) into a send buffer, queues it and goes on with its next pass; the gather
+    # (sniffles_amd.dist.gather_results: layouts, then the blocks onto rank 0, merged there by task id) overlaps that pass.
+    # Every rank issues the same sequence of collectives, so the order matches everywhere.
     import queue
     comm_q = queue.Queue()
     send_free = [threading.Event() for _ in range(n_send)]
     for ev in send_free:
         ev.set()
     comm_err = []
+    gathered_box = [None]
 
     def comm_loop():
         try:
-            torch.cuda.set_device(local_rank)
+            set_dev(torch, local_rank)
             while True:
                 item = comm_q.get()
                 if item is None:
                     comm_q.task_done()
                     return
-                s, nexp = item
-                count_t.fill_(nexp)
-                dist.all_gather_into_tensor(counts, count_t)          # 8 bytes per rank
-                counts_h.copy_(counts, non_blocking=True)
-                torch.cuda.current_stream().synchronize()              # (releases the GIL while it waits)
-                nmax = int(counts_h.max()) * rec_bytes                 # every rank sends the same, smallest sufficient size
-                chunk = sends[s][:nmax]
-                if rank == 0:
-                    dist.gather(chunk, gather_list=[gathered[r * nmax:(r + 1) * nmax] for r in range(world)], dst=0)
-                else:
-                    dist.gather(chunk, dst=0)
-                torch.cuda.current_stream().synchronize()              # the send buffer may be reused
+                s, lay, ids = item
+                g = sdist.gather_results(sends[s], lay, ids, dst=0, recv_buffer=recv,
+                                         task_ids_per_rank=None if strong else ids_all)
+                if g is not None:
+                    gathered_box[0] = g
                 send_free[s].set()
                 comm_q.task_done()
         except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
@@ -253,7 +333,9 @@ def run_calling(ctx):
         t_b = time.perf_counter()
         batch.finalize()
         t_c = time.perf_counter()
-        n = batch.fetch_raw(1)  # call records + ALT pool + read names on the host (blocks)
+        # the one host wait of the pass: the result block [records | read names | ALT bytes] is in pinned host memory when this
+        # returns (N > 1: it stays in HBM for the gather, the export below is the wait)
+        n = batch.fetch_raw(1) if not use_dist else 0
         t_d = time.perf_counter()
         if w == 0:
             phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
@@ -266,7 +348,7 @@ def run_calling(ctx):
             if comm_err:
                 raise comm_err[0]
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync(torch)
 
     n_calls_box = [0]
 
@@ -278,7 +360,7 @@ def run_calling(ctx):
 
         def worker(w):
             try:
-                torch.cuda.set_device(local_rank)
+                set_dev(torch, local_rank)
                 fn_of_w(w)
             except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
                 errs.append(e)
@@ -300,9 +382,9 @@ def run_calling(ctx):
                 if use_dist:
                     send_free[w].wait()                                # the previous gather of this handle has left the buffer
                     send_free[w].clear()
-                    nexp = batches[w].export_calls_device(sends[w].data_ptr(), cap_calls)
-                    batches[w].sync()                                  # the copy is on the handle's stream
-                    comm_q.put((w, nexp))
+                    lay = batches[w].export_device(sends[w].data_ptr(), cap_bytes)     # (blocks until the block is there)
+                    n_calls_box[0] = lay["n_calls"]
+                    comm_q.put((w, lay, task_ids_local))
         run_threads(body)
 
     pass_barrier = threading.Barrier(W)
@@ -321,29 +403,32 @@ def run_calling(ctx):
             dist.barrier()
         else:
             queues = [sdist.LocalQueue(gw) for _ in range(total)]
-        acc = [0]
+        acc = [[]]
+        ident = list(range(max(t.task_id for t in tasks) + 1))
 
         def body(w):
             for p in range(total):
                 if use_dist and w == 0:
                     send_free[p % 2].wait()                            # the gather of pass p - 2 has left the buffer
                     send_free[p % 2].clear()
-                    acc[0] = 0
+                    acc[0] = []
                 if W > 1:
                     pass_barrier.wait()
                 for g in queues[p]:
-                    n = one_pass(w, g)
-                    if use_dist:
+                    one_pass(w, g)
+                    if use_dist:                                       # the blocks of the groups this rank served are merged on its host
+                        blk = sdist.result_block(handles[w][g].fetch(1))
                         with lock:
-                            off = acc[0]; acc[0] += n
-                        if off + n > cap_calls:
-                            raise RuntimeError("send buffer too small")
-                        handles[w][g].export_calls_device(sends[p % 2].data_ptr() + off * rec_bytes, cap_calls - off)
-                        handles[w][g].sync()
+                            acc[0].append((blk, [t.task_id for t in group_tasks[g]]))
                 if W > 1:
                     pass_barrier.wait()                                # every thread of this rank is through pass p
                 if use_dist and w == 0:
-                    comm_q.put((p % 2, acc[0]))
+                    local = sdist.merge_blocks([b_ for b_, _ in acc[0]], [i_ for _, i_ in acc[0]])
+                    lay, blob = sdist.result_block(local)
+                    if lay["bytes"] > cap_bytes:
+                        raise RuntimeError("send buffer too small")
+                    sends[p % 2][:lay["bytes"]].copy_(torch.from_numpy(blob))
+                    comm_q.put((p % 2, lay, ident))
         run_threads(body)
 
     run_passes = run_passes_strong if strong else run_passes_weak
@@ -367,7 +452,7 @@ def run_calling(ctx):
         t1 = time.perf_counter()
         for _ in range(5):
             one_pass(0)
-        torch.cuda.synchronize()
+        dev_sync(torch)
         lat_ms = (time.perf_counter() - t1) / 5 * 1e3
     barrier()   # also drains the communication thread before the main thread issues collectives again
     timings_alone = dict((k[0], k[1]) for k in batches[0].timings()) if lat_ms else {}
@@ -376,19 +461,19 @@ def run_calling(ctx):
     ms_with_index = None
     if world == 1 and not strong and not use_dist and not args.no_wall_clock:
         os.environ["SNF_READPREP_EACH_PASS"] = "1"
-        extra = [[lib.Batch(cfg, tasks, device=local_rank)] for _ in range(W)]
+        extra = [[lib.Batch(cfg, tasks, device=local_rank, _lib=emu_lib())] for _ in range(W)]
         del os.environ["SNF_READPREP_EACH_PASS"]
         handles_box[0] = extra
         k2 = max(W, args.steps // 2)
-        run_passes_weak(W); torch.cuda.synchronize()
-        t1 = time.perf_counter(); run_passes_weak(k2); torch.cuda.synchronize()
+        run_passes_weak(W); dev_sync(torch)
+        t1 = time.perf_counter(); run_passes_weak(k2); dev_sync(torch)
         ms_with_index = (time.perf_counter() - t1) / k2 * 1e3
         handles_box[0] = handles
         for hs in extra:
             hs[0].close()
 
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=DEV)
+    tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device=DEV)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if not strong:
@@ -399,7 +484,8 @@ def run_calling(ctx):
         total_sig = n_sig                    # every rank holds the same ONE genome
         res_calls = 0
         for g in range(len(group_tasks)):   # calls of the whole genome (every group once, outside the timed region)
-            res_calls += one_pass(0, g)
+            n_g = one_pass(0, g)
+            res_calls += int(len(handles[0][g].fetch(1).calls)) if use_dist else n_g
         barrier()
         total_calls = res_calls
 
@@ -419,31 +505,48 @@ def run_calling(ctx):
         # with rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) on configs[1] and are kept, corrected as
         # the microarch guide prescribes, under profiles/
         traffic = None
-        try:
-            pmc = json.load(open(PMC_FILE))["kernels"]
-            if top[0] in pmc and args.scale == 1.0 and args.coverage is None and args.config == 1 and not strong:
-                traffic = pmc[top[0]]["hbm_bytes"]
-        except Exception:
-            traffic = None
+        prof_avg, pmc, prof_note = committed_profiles()
+        same_workload = args.scale == 1.0 and args.coverage is None and args.config == 1 and not strong and world == 1 and W == 3
+        if same_workload and top[0] in pmc:
+            traffic = pmc[top[0]]["hbm_bytes"]
+        rocprof_ms = prof_avg.get(top[0]) if same_workload else None
+        # result path: what one pass sends to the host over PCIe, against the measured device -> pinned-host copy rate of this box
+        res_one = batches[0].fetch(1) if not use_dist else None
+        result_bytes = (len(res_one.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res_one.rnames) + len(res_one.alt_pool)) if res_one is not None else None
+        pcie_peak = pcie_d2h_peak_gbs(torch)
+        result_path = dict(bound="pcie", what="bytes of the result block one pass hands to the host (records + read names + ALT bytes of the "
+                           + ("calls CallTask.execute keeps" if args.output == "execute" else "candidates") + "), stored by the kernels straight into pinned "
+                           "host memory, over the time of a step; peak = device -> pinned host copy rate measured in this run",
+                           bytes_per_pass=result_bytes, records_per_pass=(len(res_one.calls) if res_one is not None else None),
+                           achieved=(round(result_bytes / (ms_per_step * 1e-3) / 1e9, 2) if result_bytes else None), peak=round(pcie_peak, 2), unit="GB/s",
+                           frac=(round(result_bytes / (ms_per_step * 1e-3) / 1e9 / pcie_peak, 4) if result_bytes else None))
         # whole pass against the roofline: SURVEY.md 8(d) algorithmic bytes of one pass (72 B/signature + consensus bytes as
         # counted by the kernels + 8 B/read + 20 B/call) over the time of one pass
         cons_bytes = sum(k[2] for k in kern if k[0].startswith(("e45w_consensus", "e4c_copy")))
         pass_bytes = 72 * n_sig + cons_bytes + 8 * n_reads + 20 * n_calls
+        # The stage is latency-bound (dependent LDS / L2 round trips at 2-5 waves per SIMD), far below either roof: the HBM
+        # fraction is stated because the data is HBM-resident integer / byte work (no MFMA), the PCIe fraction of the result
+        # path sits next to it in `result_path`
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
+                        kernel_ms_source="mean HIP-event duration of the kernel's launches on its own stream over the timed passes of handle 0 (3 batches in flight)",
+                        rocprof_ms=(round(rocprof_ms, 4) if rocprof_ms else None),
+                        rocprof_frac=(round(top[2] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if rocprof_ms else None),
+                        profile_note=prof_note, result_path=result_path,
                         gpu_ms_all_kernels=round(gpu_ms, 3),
                         whole_pass=dict(algorithmic_bytes=int(pass_bytes),
                                         achieved=round(pass_bytes / (ms_per_step * 1e-3) / 1e9, 2) if not strong and world == 1 else None,
                                         frac=round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if not strong and world == 1 else None),
                         top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2]),
+                                          **({"rocprof_ms": round(prof_avg[k[0]], 4)} if same_workload and k[0] in prof_avg else {}),
                                           **({"ms_one_batch_in_flight": round(timings_alone[k[0]], 4)} if k[0] in timings_alone else {}))
                                      for k in kern[:int(os.environ.get("SNF_BENCH_TOPK", "8"))]])
         n_contigs = len(wl["contigs"] or synth.CONTIGS)
         out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="int32/f64",
-                   data="synthetic",
+                   data="synthetic" + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU else ""),
                    config=dict(workload=wl["name"] + ", synthetic signature tables (SURVEY.md 8d)", baseline_config=args.config,
                                replicas=1 if strong else world, genomes_per_batch=G,
                                tasks=n_contigs * (1 if strong else world) * G,
@@ -453,8 +556,15 @@ def run_calling(ctx):
                                parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
                                             if strong else f"contig-sharded x{world}") + ", RCCL gather of the call records on rank 0",
                                batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
+                               gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)), alt_bytes=int(len(gathered_box[0].alt_pool)),
+                                                       read_names=int(len(gathered_box[0].rnames)), tasks=int(len(gathered_box[0].task_ids)),
+                                                       order="task id, then position (parallel.py:270-271, sniffles:544)")
+                                                  if use_dist and gathered_box[0] is not None else None),
                                ms_per_pass_one_batch_in_flight=(round(lat_ms, 3) if lat_ms else None),
-                               timed_region="call_candidates + finalize + D2H of the results per pass; the read index (sorted read "
+                               output=args.output + (": what CallTask.execute returns (parallel.py:265-271) - QC-passing calls, per task sorted by position, "
+                                                     "filtered / sorted / compacted on the device" if args.output == "execute" else ": every candidate record"),
+                               timed_region="call_candidates + finalize (both enqueue only) + the one host wait of the pass, after which the result block "
+                                            "(records, read names, ALT bytes) is in pinned host memory; the read index (sorted read "
                                             "ends + hap prefix counts = the coverage vector / hap tables the reference builds during "
                                             "extraction, excluded from cpu_baseline as well) is built once at upload",
                                ms_per_step_with_read_index_rebuilt_every_pass=(round(ms_with_index, 3) if ms_with_index else None),
@@ -469,12 +579,18 @@ def run_calling(ctx):
             if not args.no_wall_clock:
                 out["wall_clock"] = wall_clock(cfg, tasks, local_rank)
             if not args.no_cpu_baseline:
-                got = batches[0].fetch(1) if not args.no_verify else None
-                base, ver = cpu_baseline_and_verify(args, wl, got, task_keys)
+                got = exe = None
+                if not args.no_verify:       # every candidate record against the oracle, and the execute-mode block against its definition
+                    bb = batches[0]
+                    bb.set_output(abi.OUT_CANDIDATES); bb.call_candidates(); bb.finalize(); got = bb.fetch(1)
+                    bb.set_output(abi.OUT_EXECUTE); bb.call_candidates(); bb.finalize(); exe = bb.fetch(1)
+                base, ver = cpu_baseline_and_verify(args, wl, got, task_keys, exe, cfg)
                 out["cpu_baseline"] = base
                 if ver is not None:
                     out["verified"] = ver["ok"]
                     out["verify"] = ver
+            if args.config == 1 and not args.no_configs and args.scale == 1.0 and args.coverage is None:
+                out["configs"] = other_configs(ctx)
     if comm_thread is not None:
         comm_q.put(None)
         comm_thread.join(timeout=30)
@@ -579,7 +695,113 @@ def _input_bytes(tasks):
     return n
 
 
-def cpu_baseline_and_verify(args, wl, got, task_keys):
+def other_configs(ctx) -> dict:
+    """The other BASELINE.json configs in the default line (compact: a few steps each, verified against the oracle), so that
+    they are measured wherever the headline is: configs[0] (chr20 only), [2] (60x HiFi), [3] (--mosaic) through the same
+    passes as the headline, configs[4] (10-sample merge) through tools/bench_population.  Outside the headline's timed region."""
+    import copy
+    import threading
+
+    import torch
+
+    from sniffles_amd import abi, lib, synth
+    from sniffles_amd.config import SnifflesConfig
+    args, local_rank = ctx["args"], ctx["local_rank"]
+    out = {}
+    for k in (0, 2, 3):
+        t_all = time.time()
+        try:
+            wl = WORKLOADS[k]
+            a = copy.copy(args); a.config = k
+            cfg = SnifflesConfig(**wl["cfg"])
+            specs = task_specs(a, wl, 0, 0, 1)
+            tasks = [synth.gen_task(**kw) for _, kw in specs]
+            W, steps, warm = 3, 12, 3
+            hs = [lib.Batch(cfg, tasks, device=local_rank, _lib=emu_lib()) for _ in range(W)]
+            for h in hs:
+                h.set_output(abi.OUT_EXECUTE)
+
+            def passes(n_each):
+                def body(h):
+                    set_dev(torch, local_rank)
+                    for _ in range(n_each):
+                        h.call_candidates(); h.finalize(); h.fetch_raw(1)
+                ths = [threading.Thread(target=body, args=(h,)) for h in hs]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            passes(warm)
+            dev_sync(torch)
+            t0 = time.perf_counter()
+            passes(steps // W)
+            dev_sync(torch)
+            dt = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            hs[0].call_candidates(); hs[0].finalize(); n_ret = hs[0].fetch_raw(1)
+            lat = (time.perf_counter() - t1) * 1e3
+            hs[0].set_output(abi.OUT_CANDIDATES); hs[0].call_candidates(); hs[0].finalize(); got = hs[0].fetch(1)
+            hs[0].set_output(abi.OUT_EXECUTE); hs[0].call_candidates(); hs[0].finalize(); exe = hs[0].fetch(1)
+            base, ver = cpu_baseline_and_verify(a, wl, got, [ci for ci, _ in specs], exe, cfg)
+            n_sig = sum(t.n_leads for t in tasks)
+            out[str(k)] = dict(workload=wl["name"], signatures=n_sig, steps=steps // W * W, batches_in_flight=W,
+                               ms_per_step=round(dt / (steps // W * W) * 1e3, 3), ms_one_batch_in_flight=round(lat, 3),
+                               signatures_per_s=round(n_sig * (steps // W * W) / dt), candidates=int(len(got.calls)), records_returned=int(n_ret),
+                               verified=ver["ok"], differences=ver["differences"], cpu_all_core_sig_s=round(base["all_core_sig_s"]),
+                               cpu_cores=base["cores"], seconds=round(time.time() - t_all, 1))
+            for h in hs:
+                h.close()
+        except Exception as e:  # noqa: BLE001 - the headline must not die with a side measurement
+            out[str(k)] = dict(error=f"{type(e).__name__}: {e}")
+    try:
+        t_all = time.time()
+        from tools import bench_population
+        a = copy.copy(args); a.config = 4; a.steps = 2; a.warmup = 1
+        r = bench_population.run(dict(ctx, args=a))
+        out["4"] = dict(workload=r["config"]["workload"], metric=r["metric"], candidates=r["config"]["candidates"], combined_calls=r["config"]["combined_calls"],
+                        ms_per_step=round(r["ms_per_step"], 1), candidates_per_s=round(r["value"]), steps=r["steps"], verified=r.get("verified"),
+                        kernel_ms=r["config"].get("rank0", {}).get("kernel_ms"), parity_unpinned=r["config"].get("parity_unpinned"),
+                        seconds=round(time.time() - t_all, 1))
+    except Exception as e:  # noqa: BLE001
+        out["4"] = dict(error=f"{type(e).__name__}: {e}")
+    return out
+
+
+def execute_mode_differences(got, exe, cfg) -> list:
+    """SNF_OUT_EXECUTE against its definition (parallel.py:265-271) applied to the candidate-mode result on the host."""
+    import numpy as np
+    diffs = []
+    keep = []
+    for t in range(len(got.task_status)):
+        lo, hi = int(got.task_call_off[t]), int(got.task_call_off[t + 1])
+        idx = np.arange(lo, hi)
+        if not cfg.no_qc:
+            idx = idx[got.calls["qc"][lo:hi] != 0]
+        if cfg.sort:
+            idx = idx[np.argsort(got.calls["pos"][idx], kind="stable")]
+        keep.append(idx)
+    idx = np.concatenate(keep) if keep else np.zeros(0, np.int64)
+    if len(idx) != len(exe.calls) or exe.task_call_off.tolist() != np.concatenate([[0], np.cumsum([len(k) for k in keep])]).tolist():
+        return [f"execute mode: {len(exe.calls)} records, expected {len(idx)}"]
+    for f in exe.calls.dtype.names:
+        if f in ("alt_off", "rn_off"):
+            continue
+        a, e = exe.calls[f], got.calls[f][idx]
+        if not np.array_equal(a, e, equal_nan=a.dtype.kind == "f"):
+            diffs.append(f"execute mode: field {f} differs")
+
+    def gather(pool, off, ln):
+        ln = np.maximum(ln.astype(np.int64), 0)
+        first = np.cumsum(ln) - ln
+        return pool[np.repeat(off.astype(np.int64) - first, ln) + np.arange(int(ln.sum()), dtype=np.int64)]
+    if not np.array_equal(gather(exe.alt_pool, exe.calls["alt_off"], exe.calls["alt_len"]), gather(got.alt_pool, got.calls["alt_off"][idx], got.calls["alt_len"][idx])):
+        diffs.append("execute mode: ALT bytes differ")
+    if not np.array_equal(gather(exe.rnames, exe.calls["rn_off"], exe.calls["rn_len"]), gather(got.rnames, got.calls["rn_off"][idx], got.calls["rn_len"][idx])):
+        diffs.append("execute mode: read names differ")
+    return diffs
+
+
+def cpu_baseline_and_verify(args, wl, got, task_keys, exe=None, cfg=None):
     """The C oracle (scalar restatement of the reference, oracle/snf_oracle.c) over the WHOLE workload on this box's host
     cores: one process per contig task, at most one per core (the reference's schedule, `sniffles:495-530`).  A reported
     baseline, not the target.  With `got` (the HIP results of the bench batch) the same run is the checker of --verify."""
@@ -606,9 +828,12 @@ def cpu_baseline_and_verify(args, wl, got, task_keys):
             n_calls += int(exp.calls.shape[0])
             for d in records.diff_results(got, t, exp, 0):
                 diffs.append(f"task {t} ({contig_of[key]}): {d}")
-        ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls,
-                   what="every field of every call record, ALT bytes, supporting reads and coverage_average_total of the "
-                        "bench batch vs the C oracle on the same inputs", differences=diffs[:5])
+        if exe is not None:
+            diffs += execute_mode_differences(got, exe, cfg)
+        ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls, records_returned=(int(len(exe.calls)) if exe is not None else None),
+                   what="every field of every candidate record, ALT bytes, supporting reads and coverage_average_total of the "
+                        "bench batch vs the C oracle on the same inputs; the block the timed passes return (--output execute) vs "
+                        "CallTask.execute's filter + sort applied to those candidates", differences=diffs[:5])
     return base, ver
 
 

@@ -1479,6 +1479,11 @@ void collect_timings(snf_batch_impl* b) {
     if (strcmp(t.name, "e45w_consensus_small") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[1];
     if (strcmp(t.name, "e45w_consensus_large") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[2];
     if (strcmp(t.name, "e4c_copy") == 0) t.bytes = (int64_t)b->h_cnt->cons_bytes[3];
+    // a finalized call is one 240-byte record written; coverage = 8 B per read (start, end) + 20 B of queries per call
+    if (strcmp(t.name, "e1w_finalize") == 0) t.bytes = (int64_t)sizeof(snf_call_t) * b->h_cnt->n_calls;
+    if (strcmp(t.name, "d4_coverage") == 0) t.bytes = 8 * b->v.R + 20 * b->h_cnt->n_calls;
+    if (strcmp(t.name, "f4_emit") == 0 && b->v.res_out) t.bytes = 2 * ((int64_t)sizeof(snf_call_t) * b->v.res_out->n_out + 4 * b->v.res_out->rn_out);
+    if (strcmp(t.name, "f5_alt") == 0 && b->v.res_out) t.bytes = 2 * b->v.res_out->alt_out;
   }
   // running sums since snf_batch_timing_mean_reset: the mean launch duration of every kernel over the passes in between
   for (const auto& t : b->timings) {

@@ -23,28 +23,153 @@ def shard_lpt(weights, n_ranks: int) -> list:
     return out
 
 
-def gather_calls(calls_tensor, n_calls: int, cap_calls: int, world: int):
-    """All-gather fixed-capacity record buffers + counts; returns (counts[world], gathered uint8 tensor).
-    `calls_tensor`: uint8 tensor of cap_calls * sizeof(snf_call_t) bytes on the group's device."""
+LAYOUT_FIELDS = ("n_calls", "rnames_len", "alt_pool_len", "off_rnames", "off_alt", "bytes")
+
+
+class GatheredResult:
+    """What rank `dst` holds after `gather_results`: the calls of every rank in ONE record table, ordered by task id, and
+    inside a task in the order the ranks produced (position order for SNF_OUT_EXECUTE results - the order the reference's
+    parent writes, `sniffles:544` over the per-task `sorted(svcalls, key=pos)` of `parallel.py:270-271`).  `calls["task_index"]`
+    holds the GLOBAL task id; `alt_off` / `rn_off` index `alt_pool` / `rnames` of this object (same interface as
+    `abi.Result`, so `vcf.VCF.write_records(res, ti, order)` takes it as it is).  `names`: optional {task id: {qname id: str}}
+    of the supporting reads (gathered on request: `--output-rnames`)."""
+
+    def __init__(self, calls, alt_pool, rnames, task_ids, names=None):
+        import numpy as np
+        self.calls, self.alt_pool, self.rnames = calls, alt_pool, rnames
+        self.task_ids = np.asarray(task_ids, np.int64)
+        t = calls["task_index"].astype(np.int64)
+        self.task_call_off = np.searchsorted(t, np.concatenate([self.task_ids, [np.iinfo(np.int64).max]]), side="left")
+        self.task_call_off[-1] = len(calls)
+        self.names = names
+
+    def task_rows(self, task_id: int):
+        """Row indices of a task's calls (output order)."""
+        import numpy as np
+        k = int(np.searchsorted(self.task_ids, task_id))
+        if k >= len(self.task_ids) or int(self.task_ids[k]) != task_id:
+            return np.zeros(0, np.int64)
+        return np.arange(int(self.task_call_off[k]), int(self.task_call_off[k + 1]), dtype=np.int64)
+
+    alt = abi.Result.alt
+    rn = abi.Result.rn
+
+
+def merge_blocks(blocks, task_ids_per_rank) -> GatheredResult:
+    """blocks: per rank (layout dict, bytes-like of the rank's result block [records | read names | ALT bytes], see
+    `snf_batch_export_device`); task_ids_per_rank[r][k] = global id of rank r's batch-local task k.  Pure host code."""
+    import numpy as np
+    recs, alts, rns = [], [], []
+    alt_base = rn_base = 0
+    for (lay, blob), ids in zip(blocks, task_ids_per_rank):
+        raw = np.frombuffer(blob, np.uint8, count=int(lay["bytes"])) if int(lay["bytes"]) else np.zeros(0, np.uint8)
+        n = int(lay["n_calls"])
+        c = raw[:n * abi.CALL_DTYPE.itemsize].view(abi.CALL_DTYPE).copy()
+        c["task_index"] = np.asarray(ids, np.int32)[c["task_index"]] if n else c["task_index"]
+        c["alt_off"] += alt_base
+        c["rn_off"] += rn_base
+        recs.append(c)
+        alts.append(raw[int(lay["off_alt"]):int(lay["off_alt"]) + int(lay["alt_pool_len"])])
+        rns.append(raw[int(lay["off_rnames"]):int(lay["off_rnames"]) + 4 * int(lay["rnames_len"])].view(np.uint32))
+        alt_base += int(lay["alt_pool_len"]); rn_base += int(lay["rnames_len"])
+    calls = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
+    order = np.argsort(calls["task_index"], kind="stable")      # by task id; a task's calls all come from one rank, in its order
+    all_ids = sorted(int(i) for ids in task_ids_per_rank for i in ids)
+    return GatheredResult(calls[order], np.concatenate(alts) if alts else np.zeros(0, np.uint8),
+                          np.concatenate(rns) if rns else np.zeros(0, np.uint32), all_ids)
+
+
+def gather_results(block, layout: dict, task_ids, dst: int = 0, group=None, names=None, recv_buffer=None, task_ids_per_rank=None):
+    """The final gather (the reference's parent receives whole `SVCall`s, parallel.py:757): every rank hands in
+    its finalized result block - `block`, a uint8 tensor on the process group's device holding [records | read names | ALT
+    bytes] as `Batch.export_device` (or a fetch) left it, with its `layout` - and rank `dst` returns the `GatheredResult` of
+    all ranks (None elsewhere).  Collectives, in this order on every rank: one all-gather of the layouts (6 x int64), one
+    gather of the blocks onto `dst` (every rank sends the largest block size, so `dst` receives world x max bytes over
+    its point-to-point links), and - only when `names` is given ({local task index: {qname id: str}} of the supporting
+    reads, for `--output-rnames`) - one gather_object.  `task_ids[k]` = global task id of the batch-local task k.
+    `task_ids_per_rank` (every rank's list, e.g. from a deterministic `shard_lpt`) saves the all_gather_object that otherwise
+    collects them.  `recv_buffer`: optional uint8 tensor on `dst` to receive into (reused across passes)."""
+    import numpy as np
     import torch
     import torch.distributed as dist
-    count = torch.tensor([n_calls], dtype=torch.int64, device=calls_tensor.device)
-    counts = torch.zeros(world, dtype=torch.int64, device=calls_tensor.device)
-    gathered = torch.empty(world * calls_tensor.numel(), dtype=torch.uint8, device=calls_tensor.device)
-    dist.all_gather_into_tensor(counts, count)
-    dist.all_gather_into_tensor(gathered, calls_tensor)
-    return counts, gathered
-
-
-def unpack_gathered(counts, gathered, cap_calls: int) -> list:
-    """Per rank: numpy structured array of its call records."""
-    rec = abi.CALL_DTYPE.itemsize
-    g = gathered.cpu().numpy()
-    out = []
-    for r, n in enumerate(counts.cpu().tolist()):
-        lo = r * cap_calls * rec
-        out.append(g[lo:lo + int(n) * rec].view(abi.CALL_DTYPE).copy())
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = block.device
+    mine = torch.tensor([int(layout[f]) for f in LAYOUT_FIELDS] + [len(task_ids)], dtype=torch.int64, device=dev)
+    lays = torch.zeros(world * mine.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(lays, mine, group=group)
+    lays = lays.cpu().view(world, -1)
+    nmax = int(lays[:, 5].max())
+    nmax = (nmax + 255) & ~255
+    if block.numel() < nmax:      # (the caller's buffer is at least its own block; pad to the common size)
+        block = torch.cat([block, torch.zeros(nmax - block.numel(), dtype=torch.uint8, device=dev)])
+    chunk = block[:nmax]
+    ids_all = task_ids_per_rank
+    if ids_all is None:
+        ids_all = [None] * world
+        dist.all_gather_object(ids_all, [int(i) for i in task_ids], group=group)
+    if rank == dst:
+        if recv_buffer is None or recv_buffer.numel() < world * max(nmax, 1):
+            recv_buffer = torch.empty(world * max(nmax, 1), dtype=torch.uint8, device=dev)
+        parts = [recv_buffer[r * nmax:(r + 1) * nmax] for r in range(world)]
+        if nmax:
+            dist.gather(chunk, gather_list=parts, dst=dst, group=group)
+    elif nmax:
+        dist.gather(chunk, dst=dst, group=group)
+    names_all = None
+    if names is not None:
+        names_all = [None] * world if rank == dst else None
+        dist.gather_object({int(task_ids[k]): v for k, v in names.items()}, names_all, dst=dst, group=group)
+    if rank != dst:
+        return None
+    host = recv_buffer[:world * nmax].cpu().numpy() if nmax else np.zeros(0, np.uint8)
+    blocks = []
+    for r in range(world):
+        lay = dict(zip(LAYOUT_FIELDS, (int(x) for x in lays[r, :6])))
+        blocks.append((lay, host[r * nmax:r * nmax + lay["bytes"]]))
+    out = merge_blocks(blocks, ids_all)
+    if names_all is not None:
+        out.names = {}
+        for d in names_all:
+            out.names.update(d)
     return out
+
+
+def result_block(res):
+    """(layout, bytes) of a fetched stage-1 result in the export format - for ranks whose result is already on the host
+    (tests over gloo; `Batch.export_device` is the device form)."""
+    import numpy as np
+    n = len(res.calls)
+    off_rn = (n * abi.CALL_DTYPE.itemsize + 255) & ~255
+    off_alt = (off_rn + 4 * len(res.rnames) + 255) & ~255
+    blob = np.zeros(off_alt + len(res.alt_pool), np.uint8)
+    blob[:n * abi.CALL_DTYPE.itemsize] = np.frombuffer(res.calls.tobytes(), np.uint8)
+    blob[off_rn:off_rn + 4 * len(res.rnames)] = np.frombuffer(np.ascontiguousarray(res.rnames, np.uint32).tobytes(), np.uint8)
+    blob[off_alt:] = res.alt_pool
+    return dict(n_calls=n, rnames_len=len(res.rnames), alt_pool_len=len(res.alt_pool), off_rnames=off_rn, off_alt=off_alt,
+                bytes=len(blob)), blob
+
+
+_STORE = None
+
+
+def set_store(store) -> None:
+    """The key-value store `TaskQueue` counts on when none is passed: the one the process group was initialised with
+    (`dist.init_process_group(..., store=store)`), or any `torch.distributed.Store` every rank can reach."""
+    global _STORE
+    _STORE = store
+
+
+def default_store():
+    """A store shared by all ranks.  `set_store` wins; otherwise a TCPStore client of the rendezvous the process group itself
+    was built from (MASTER_ADDR / MASTER_PORT of the env:// rendezvous; rank 0 hosts the server there) - public API only."""
+    global _STORE
+    if _STORE is None:
+        import os
+        import torch.distributed as dist
+        _STORE = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), dist.get_world_size(),
+                               is_master=False, timeout=__import__("datetime").timedelta(seconds=120), wait_for_workers=False)
+    return _STORE
 
 
 class TaskQueue:
@@ -67,8 +192,7 @@ class TaskQueue:
         import torch.distributed as dist
         self.order = sorted(range(len(weights)), key=lambda i: (-weights[i], i))
         if store is None:
-            from torch.distributed import distributed_c10d
-            store = distributed_c10d._get_default_store()
+            store = default_store()
         gen = TaskQueue._generation.get(key, 0)
         TaskQueue._generation[key] = gen + 1
         self.store, self.key = store, f"{key}/{gen}"

@@ -17,6 +17,29 @@ def _tasks():
     return [synth.gen_task(i, c, int(synth.GRCH38[c] * 0.01), 30, 1) for i, c in enumerate(names)]
 
 
+def vcf_text(cfg, tasks, results_of_task):
+    """VCF records (no header) of the tasks in id order straight from record tables: `results_of_task(ti)` -> (res, rows)."""
+    import io
+    from sniffles_amd import vcf
+    buf = io.StringIO()
+    w = vcf.VCF(cfg, buf)
+    for ti in sorted(tasks, key=lambda t: t.task_id):
+        res, rows = results_of_task(ti)
+        w.write_records(res, ti, rows)
+    return buf.getvalue()
+
+
+def single_process_text(cfg, tasks, L, mode):
+    """Every task in ONE batch of ONE process, CallTask.execute's filter and sort on the device."""
+    from sniffles_amd import lib
+    with lib.Batch(cfg, tasks, _lib=L) as b:
+        b.set_output(mode)
+        b.call_candidates(); b.finalize()
+        res = b.fetch(1)
+    index = {t.task_id: k for k, t in enumerate(tasks)}
+    return vcf_text(cfg, tasks, lambda ti: (res, np.arange(int(res.task_call_off[index[ti.task_id]]), int(res.task_call_off[index[ti.task_id] + 1])))), res
+
+
 def _worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -26,36 +49,46 @@ def _worker(rank, world, port, q):
     from sniffles_amd import abi, dist as sdist, lib
     from sniffles_amd.config import SnifflesConfig
     tasks = _tasks()
-    mine = sdist.shard_lpt([t.contig_len for t in tasks], world)[rank]
-    cfg = SnifflesConfig()
+    shards = sdist.shard_lpt([t.contig_len for t in tasks], world)
+    mine = shards[rank]
+    cfg = SnifflesConfig(output_rnames=True)
     with lib.Batch(cfg, [tasks[i] for i in mine], _lib=E.lib()) as b:
+        b.set_output(abi.OUT_EXECUTE | abi.OUT_DEVICE)
         b.call_candidates(); b.finalize()
+        # the block leaves the batch as it would for RCCL: device-to-device into a tensor of the process group's device
+        send = torch.zeros(1 << 22, dtype=torch.uint8)
+        lay = b.export_device(send.data_ptr(), send.numel())
         res = b.fetch(1)
-    cap = 4096
-    buf = torch.zeros(cap * abi.CALL_DTYPE.itemsize, dtype=torch.uint8)
-    raw = res.calls.tobytes()
-    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-    counts, gathered = sdist.gather_calls(buf, len(res.calls), cap, world)
-    per_rank = sdist.unpack_gathered(counts, gathered, cap)
+    # names of the supporting reads of this rank's calls (the parent has no qname tables of other ranks' contigs)
+    names = {}
+    for k, g in enumerate(mine):
+        rows = range(int(res.task_call_off[k]), int(res.task_call_off[k + 1]))
+        ids = np.unique(np.concatenate([res.rn(i) for i in rows])) if len(rows) else []
+        names[k] = {int(i): tasks[g].qname(int(i)) for i in ids}
+    merged = sdist.gather_results(send, lay, [tasks[i].task_id for i in mine], dst=0, names=names)
+    again = sdist.gather_results(send, lay, [tasks[i].task_id for i in mine], dst=0,
+                                 task_ids_per_rank=[[tasks[i].task_id for i in s] for s in shards])
     if rank == 0:
-        # key the records by (global task id, sv_id): task_index is rank-local, map it back through the shard lists
-        shards = sdist.shard_lpt([t.contig_len for t in tasks], world)
-        keys = []
-        for r, arr in enumerate(per_rank):
-            for c in arr:
-                keys.append((shards[r][int(c["task_index"])], int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]),
-                             int(c["support"]), int(c["gt_a"]), int(c["gt_b"])))
-        q.put(sorted(keys))
+        assert again.calls.tobytes() == merged.calls.tobytes() and again.alt_pool.tobytes() == merged.alt_pool.tobytes()
+        text = vcf_text(cfg, tasks, lambda ti: (merged, merged.task_rows(ti.task_id)))
+        # read names through the gathered name tables only
+        names_ok = all(merged.names[int(c["task_index"])][int(i)] == tasks[int(c["task_index"])].qname(int(i))
+                       for k, c in enumerate(merged.calls) for i in merged.rn(k))
+        q.put((text, merged.calls["task_index"].tolist(), merged.calls["pos"].tolist(), int(len(merged.alt_pool)), names_ok))
+    else:
+        assert merged is None and again is None
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_two_rank_shard_and_gather_equals_single_process():
+    """Rank 0's result after `dist.gather_results` - records, INS ALT bytes, supporting read names, ordered by task id then
+    position (`sniffles:544`, `parallel.py:270-271`) - written as VCF text equals the text of a single process over all tasks."""
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     import emu.emu as E
-    from sniffles_amd import lib, dist as sdist
+    from sniffles_amd import abi, dist as sdist
     from sniffles_amd.config import SnifflesConfig
     E.build()
     ctx = mp.get_context("spawn")
@@ -64,17 +97,17 @@ def test_two_rank_shard_and_gather_equals_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=240)
+    text, task_col, pos_col, alt_bytes, names_ok = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     tasks = _tasks()
-    with lib.Batch(SnifflesConfig(), tasks, _lib=E.lib()) as b:
-        b.call_candidates(); b.finalize()
-        res = b.fetch(1)
-    exp = sorted((int(c["task_index"]), int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]), int(c["support"]),
-                  int(c["gt_a"]), int(c["gt_b"])) for c in res.calls)
-    assert got == exp and len(exp) > 50
+    exp_text, res = single_process_text(SnifflesConfig(output_rnames=True), tasks, E.lib(), abi.OUT_EXECUTE)
+    assert text == exp_text and text.count("\n") > 20 and "SVTYPE=INS" in text and "RNAMES=" in text
+    assert names_ok and alt_bytes == len(res.alt_pool) > 1000
+    # ordered by task id, then position
+    assert task_col == sorted(task_col)
+    assert all(pos_col[i] <= pos_col[i + 1] for i in range(len(pos_col) - 1) if task_col[i] == task_col[i + 1])
     # sharding is a partition and is balanced
     shards = sdist.shard_lpt([t.contig_len for t in tasks], 2)
     assert sorted(shards[0] + shards[1]) == list(range(len(tasks)))
@@ -94,11 +127,12 @@ def _queue_worker(rank, world, port, q):
     tasks = _tasks()
     cfg = SnifflesConfig()
     queue = sdist.TaskQueue([t.n_leads for t in tasks])
-    recs = []
+    blocks = []
     for i in queue:                       # one task per claim; rank 1 is slowed down so that rank 0 takes more
         with lib.Batch(cfg, [tasks[i]], _lib=E.lib()) as b:
+            b.set_output(abi.OUT_EXECUTE)
             b.call_candidates(); b.finalize()
-            recs.append(b.fetch(1).calls.copy())
+            blocks.append(sdist.result_block(b.fetch(1)))
         if rank == 1:
             time.sleep(1.0)
     claims = sdist.gather_claims(queue.claimed, world)
@@ -114,21 +148,17 @@ def _queue_worker(rank, world, port, q):
     for t in ths:
         t.join()
     claims3 = sdist.gather_claims(q3.claimed, world)
-    cap = 4096
-    mine = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
-    off = 0                               # task_index is batch-local (always 0 here): store the position in the claim list
-    for k, arr in enumerate(recs):
-        mine["task_index"][off:off + len(arr)] = k
-        off += len(arr)
-    buf = torch.zeros(cap * abi.CALL_DTYPE.itemsize, dtype=torch.uint8)
-    raw = mine.tobytes()
-    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-    counts, gathered = sdist.gather_calls(buf, len(mine), cap, world)
-    per_rank = sdist.unpack_gathered(counts, gathered, cap)
+    # the claims of a rank become one block (task_index = global task id), then the gather
+    local = sdist.merge_blocks(blocks, [[tasks[i].task_id] for i in queue.claimed])
+    lay, blob = sdist.result_block(local)
+    ident = list(range(max(t.task_id for t in tasks) + 1))
+    merged = sdist.gather_results(torch.from_numpy(blob), lay, ident, dst=0)
     if rank == 0:
-        keys = sorted((claims[r][int(c["task_index"])], int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]),
-                       int(c["support"]), int(c["gt_a"]), int(c["gt_b"])) for r, arr in enumerate(per_rank) for c in arr)
-        q.put((keys, claims, claims2, claims3))
+        have = set(int(t) for t in merged.calls["task_index"])
+        merged.task_ids = np.asarray(sorted(t.task_id for t in tasks), np.int64)
+        merged.task_call_off = np.searchsorted(merged.calls["task_index"], np.concatenate([merged.task_ids, [1 << 30]]))
+        text = vcf_text(cfg, tasks, lambda ti: (merged, merged.task_rows(ti.task_id)))
+        q.put((text, claims, claims2, claims3, sorted(have)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -138,7 +168,7 @@ def test_two_rank_task_queue_equals_single_process():
         if p not in sys.path:
             sys.path.insert(0, p)
     import emu.emu as E
-    from sniffles_amd import lib
+    from sniffles_amd import abi
     from sniffles_amd.config import SnifflesConfig
     E.build()
     ctx = mp.get_context("spawn")
@@ -147,17 +177,13 @@ def test_two_rank_task_queue_equals_single_process():
     procs = [ctx.Process(target=_queue_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got, claims, claims2, claims3 = q.get(timeout=240)
+    text, claims, claims2, claims3, have = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     tasks = _tasks()
-    with lib.Batch(SnifflesConfig(), tasks, _lib=E.lib()) as b:
-        b.call_candidates(); b.finalize()
-        res = b.fetch(1)
-    exp = sorted((int(c["task_index"]), int(c["sv_id"]), int(c["pos"]), int(c["svlen"]), int(c["filter"]), int(c["support"]),
-                  int(c["gt_a"]), int(c["gt_b"])) for c in res.calls)
-    assert got == exp
+    exp_text, _ = single_process_text(SnifflesConfig(), tasks, E.lib(), abi.OUT_EXECUTE)
+    assert text == exp_text and len(have) >= 4
     assert sorted(claims[0] + claims[1]) == list(range(len(tasks)))     # every task exactly once
     assert len(claims[0]) > len(claims[1]) >= 1                           # the faster rank came back for more
     assert sorted(claims2[0] + claims2[1]) == [0, 1, 2, 3]               # a second queue is a fresh queue
@@ -223,3 +249,32 @@ def test_two_rank_combine_scatter_equals_reference_parts():
         assert len(merged[w["id"]]) == len(w["calls"])
         for g, e in zip(merged[w["id"]], w["calls"]):
             assert gu.diff_records([g], [e]) == []
+
+
+def _bench_two_ranks(extra, port):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per device), on this GPU-less box:
+    SNF_BENCH_EMU=1 = gloo + CPU tensors + the kernels through the host emulation.  The code that runs is the code of the
+    N > 1 GPU run: process group, work queue, result export per pass, `dist.gather_results` on the communication thread."""
+    import json
+    import subprocess
+    env = dict(os.environ, SNF_BENCH_EMU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--scale", "0.004",
+           "--no-cpu-baseline", "--no-wall-clock"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_weak_scaling_emu():
+    d = _bench_two_ranks([], 32500 + (os.getpid() % 500))
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks"] == 48 and d["value"] > 0
+    assert d["config"]["gathered_on_rank0"]["ranks"] == 2 and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+
+
+def test_bench_two_ranks_strong_scaling_emu():
+    d = _bench_two_ranks(["--scaling", "strong"], 33500 + (os.getpid() % 500))
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["tasks"] == 24 and d["value"] > 0
+    assert d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
