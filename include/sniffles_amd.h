@@ -293,6 +293,11 @@ const char* snf_last_error(void);
 /* number of visible HIP devices (0 => every compute entry point fails loudly) */
 int snf_device_count(void);
 
+/* The library keeps a few things of finished batches for the next one (HBM slabs, pinned result buffers, HIP streams: creating
+ * them costs more than a contig's kernels).  They are released on their own when an allocation fails; this hands them back
+ * explicitly - `device` < 0: every device.  Returns the bytes released. */
+int64_t snf_trim_caches(int device);
+
 /* batch lifecycle -------------------------------------------------------------------
  * replaces: LeadProvider.__init__/record_lead/record_hap_ref/build_leadtab
  * (src/sniffles/leadprov.py:361-472) as the container of one task's signatures. */
@@ -343,6 +348,9 @@ int snf_batch_set_output(snf_batch_t* b, int mode);
  * snf_batch_call_candidates + snf_batch_finalize enqueue without waiting for the device; this is the one host wait of a pass.
  * Pointers valid until the next call on the batch or snf_batch_destroy. */
 int snf_batch_fetch(snf_batch_t* b, int stage, snf_result_t* out);
+/* number of candidate calls of the last snf_batch_call_candidates (all tasks; what Task.sv_id advances by, sv.py:563), as of
+ * the last fetch / sync; -1 on error */
+int64_t snf_batch_n_candidates(snf_batch_t* b);
 
 /* final gather across GPUs (the parent receives whole results, parallel.py:757): the finalized result of the
  * batch as ONE block of bytes in HBM, copied device-to-device into `dst_device` (e.g. a torch CUDA tensor handed to RCCL):

@@ -249,6 +249,7 @@ __global__ void __launch_bounds__(256) e3b_offsets(const View v, int64_t n_unuse
   __shared__ unsigned long long lds[4 * SNF_ALT_K];
   const int64_t nc = v.cnt->n_calls;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if ((int64_t)blockIdx.x * 256 >= nc) return;   // (the grid covers an upper bound of the calls; whole blocks leave)
   unsigned long long part[SNF_ALT_K], dummy[SNF_ALT_K], prefix[SNF_ALT_K];
 #pragma unroll
   for (int k = 0; k < SNF_ALT_K; k++) {
@@ -269,6 +270,7 @@ __global__ void __launch_bounds__(256) e3b_offsets(const View v, int64_t n_unuse
       v.sc_tab[nc] = (int64_t)(o2 + val[2]); v.sc_aln[nc] = (int64_t)(o3 + val[3]); v.sc_rd[nc] = (int64_t)(o4 + val[4]);
       v.cnt->alt_total = (int64_t)(o0 + val[0]); v.cnt->n_cons = (int64_t)(o1 + val[1]);
       v.cnt->tab_total = (int64_t)(o2 + val[2]); v.cnt->aln_total = (int64_t)(o3 + val[3]); v.cnt->n_cons_reads = (int64_t)(o4 + val[4]);
+      alt_decide(v, (int64_t)(o0 + val[0]));
     }
     e3_emit(i, v);
   }

@@ -74,7 +74,6 @@ SNF_KERNEL(f1_flags, View)
 SNF_KERNEL(f2_scan, View)
 SNF_KERNEL(f3_rank, View)
 SNF_KERNEL(f4_emit, View)
-SNF_KERNEL(f5_alt, View)
 SNF_KERNEL(s1_blockcov, BlockCov)
 SNF_KERNEL(s2_covends, CovCalls)
 SNF_KERNEL(s2_covcalls, CovCalls)
@@ -117,10 +116,31 @@ struct DevBuf { void* p; size_t bytes; bool slab = false; };
 // Slabs of destroyed batches are kept for the next batch of the process (a pipeline runs one task after the other, each with
 // a slab of up to a few GB: hipMalloc / hipFree of that size costs up to hundreds of milliseconds on some boxes, far more
 // than the upload itself).  At most SNF_SLAB_CACHE_MAX slabs are kept; the smallest one that is large enough is reused.
-#define SNF_SLAB_CACHE_MAX 6
+#define SNF_SLAB_CACHE_MAX 6   /* per device */
 struct SlabCache {
   struct E { void* p; size_t bytes; int device; };
   std::mutex mu; std::vector<E> free_list;
+  // every cached slab of `device` (< 0: of all devices) goes back to the driver; returns the bytes released
+  size_t trim(int device) {
+    std::vector<E> gone;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (size_t i = 0; i < free_list.size();)
+        if (device < 0 || free_list[i].device == device) { gone.push_back(free_list[i]); free_list.erase(free_list.begin() + (long)i); }
+        else i++;
+    }
+    size_t bytes = 0;
+    for (auto& e : gone) {
+#ifndef SNF_EMU
+      int cur = 0; (void)hipGetDevice(&cur);
+      (void)hipSetDevice(e.device); (void)hipFree(e.p); (void)hipSetDevice(cur);
+#else
+      free(e.p);
+#endif
+      bytes += e.bytes;
+    }
+    return bytes;
+  }
   void* take(int device, size_t bytes, size_t* got) {
     std::lock_guard<std::mutex> g(mu);
     int best = -1;
@@ -133,7 +153,9 @@ struct SlabCache {
   }
   bool give(int device, void* p, size_t bytes) {   // false: the cache is full, the caller frees the slab
     std::lock_guard<std::mutex> g(mu);
-    if (free_list.size() >= SNF_SLAB_CACHE_MAX) return false;
+    size_t mine = 0;
+    for (auto& e : free_list) mine += e.device == device;
+    if (mine >= SNF_SLAB_CACHE_MAX) return false;
     free_list.push_back({p, bytes, device});
     return true;
   }
@@ -148,6 +170,20 @@ struct Timing { const char* name; float ms; int64_t bytes; int launches; };   //
 struct PinnedCache {
   struct E { void* p; size_t cap; };
   std::mutex mu; std::vector<E> free_list;
+  size_t trim() {
+    std::vector<E> gone;
+    { std::lock_guard<std::mutex> g(mu); gone.swap(free_list); }
+    size_t bytes = 0;
+    for (auto& e : gone) {
+#ifndef SNF_EMU
+      (void)hipHostFree(e.p);
+#else
+      free(e.p);
+#endif
+      bytes += e.cap;
+    }
+    return bytes;
+  }
   void* take(size_t bytes, size_t* cap) {
     std::lock_guard<std::mutex> g(mu);
     int best = -1;
@@ -178,7 +214,12 @@ struct HostBuf {
     if (c) g_pinned.give(c, got);
     cap = bytes + bytes / 4 + 4096;
 #ifndef SNF_EMU
-    SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {   // idle pinned buffers of finished batches go first, then once more
+      (void)hipGetLastError();
+      p = nullptr;
+      g_pinned.trim();
+      SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    }
 #else
     p = malloc(cap);
 #endif
@@ -249,7 +290,9 @@ struct snf_batch_impl {
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   // results (host)
   HostBuf hb_calls, hb_rn, hb_res;   // stage-0 fetch: candidate records, read names; the pinned result block
-  HostBuf hb_out;                    // stage-1 fetch: the output block (snf_stage_out.h)
+  HostBuf hb_out, hb_alt;            // stage-1 fetch: the output block (snf_stage_out.h), the ALT section
+  // class sizes of this handle's previous finalize (same input -> same sizes; first pass: one host wait for them)
+  bool have_hist = false; int64_t hist_calls = 0, hist_small = 0, hist_large = 0, hist_copy = 0;
   int out_mode = 0;                  // enum snf_output
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
   // snf_batch_fetch_clusters result (host)
@@ -273,7 +316,14 @@ T* dalloc_own(snf_batch_impl* b, size_t n) {
   size_t bytes = (n ? n : 1) * sizeof(T);
   void* p = nullptr;
 #ifndef SNF_EMU
-  SNF_HIP(hipMalloc(&p, bytes));
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    // out of device memory while idle slabs of finished batches sit in this process's own cache: hand them back and try
+    // once more (several ranks / threads on one GPU, torch or RCCL next door, a large contig after many small ones)
+    (void)hipGetLastError();
+    p = nullptr;
+    g_slabs.trim(b->device);
+    SNF_HIP(hipMalloc(&p, bytes));
+  }
 #else
   p = malloc(bytes);
   memset(p, 0xA5, bytes);  // hipMalloc does not zero: poison so the emulation catches uninitialised reads
@@ -483,14 +533,16 @@ void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* v
   if (n <= 0) return;
 #ifndef SNF_EMU
   size_t need = 0;
-  SNF_HIP(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
+  // (rocPRIM's default takes a block sort + ~20 merge launches up to 1 M items: 140 us for the 0.7 M pairs behind the prefilter)
+  using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
+  SNF_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
   if (need > tmpb) {
     if (tmp) { dsync(b); dfree_one(b, tmp); }
     tmp = dalloc_own<uint8_t>(b, need); tmpb = need;
   }
   Scope s(b, name, n * 2 * (int64_t)(sizeof(K) + 4));
-  SNF_HIP(rocprim::radix_sort_pairs(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
+  SNF_HIP(rocprim::radix_sort_pairs<SortCfg>(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
 #else
   (void)end_bit; (void)name;
   std::vector<int64_t> idx(n);
@@ -638,6 +690,9 @@ void stage_leads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int6
   for (int64_t i = i0; i < i1; i++) {
     if (t.svtype[i] >= SNF_NTYPES) fail("svtype code out of range");
     if (t.hap[i] > 2) fail("hap must be 0, 1 or 2 (leadprov.py:403)");
+    // the packed per-lead record keeps these in bit fields (snf_view.h LeadRec): anything wider would be cut silently
+    if (t.strand[i] > 1 || t.source[i] > 3 || t.is_sa[i] > 1 || t.bnd_is_first[i] > 1 || t.bnd_is_reverse[i] > 1)
+      fail("strand / is_sa / bnd_is_first / bnd_is_reverse must be 0 or 1, source one of the four lead sources");
     const int32_t sl = t.seq_len[i];
     if (sl >= 0 && (t.seq_off[i] < 0 || t.seq_off[i] + sl > t.seq_pool_len)) fail("seq_off/seq_len outside seq_pool");
     so[i] = sl >= 0 ? t.seq_off[i] + p0 : 0;      // rebased into the batch pool
@@ -795,7 +850,14 @@ void do_upload(snf_batch_impl* b) {
     };
     run_items(items[0]);
     h2d(b, d_in, st, col_bytes);                       // (asynchronous: pinned source) overlaps the staging of the pools
-    run_items(items[1]);
+    try { run_items(items[1]); }
+    catch (...) {
+      // the copy above still reads the shared arena: it must have landed before the lock is released to another upload, and
+      // the caller's arrays are not ours to keep after a failed upload
+      dsync(b);
+      for (auto& t : b->tasks) { snf_task_input_t e{}; e.task_id = t.task_id; e.contig_len = t.contig_len; t = e; }
+      throw;
+    }
     t_staged = now_ms();
     h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
     // tasks whose columns are already in HBM (snf_batch_add_task_device): device-to-device into their slices, sequence
@@ -824,7 +886,12 @@ void do_upload(snf_batch_impl* b) {
       for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(rs_all[r]);
     } else {
       for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(0);
+#ifndef SNF_EMU
+      // every 256th start in ONE strided copy (width 4 bytes, source pitch 1 KB) instead of a 4-byte copy per entry
+      if (!top.empty()) SNF_HIP(hipMemcpy2DAsync(top.data(), 4, d_in + off[IC_RSTART], (size_t)4 << SNF_TOP_SHIFT, 4, top.size(), hipMemcpyDeviceToHost, b->cur));
+#else
       for (size_t k = 0; k < top.size(); k++) d2h(b, &top[k], d_in + off[IC_RSTART] + (k << SNF_TOP_SHIFT) * 4, 4);
+#endif
     }
     dsync(b);
     for (auto& t : b->tasks) {   // the borrowed arrays are not referenced after this point
@@ -887,7 +954,8 @@ void do_upload(snf_batch_impl* b) {
     if (N > 0 && b->cfg.dev_min_leads_cluster >= 2 && getenv("SNF_NO_PREFILTER") == nullptr && cells < ((int64_t)1 << 36)) {
       v.prefilter = 1;
       v.t_cell_off = upload_vec(b, cell_off);
-      b->pf_words = cells / 16 + 2;
+      b->pf_words = (((cells >> 19) + 1) << 19) / 16 + 2;   // (whole 2^19-cell blocks: pf_slot permutes inside a block)
+      v.pf_spread = (getenv("SNF_PF_SPREAD") && atoi(getenv("SNF_PF_SPREAD")) == 0) ? 0 : 1;
       v.pf_bm = dalloc<uint32_t>(b, (size_t)b->pf_words);
       dzero(b, v.pf_bm, (size_t)b->pf_words * 4);
       v.pf_key = dalloc<uint64_t>(b, N); v.pf_keep = dalloc<uint32_t>(b, N1); v.pf_scan = dalloc<uint32_t>(b, N1);
@@ -950,12 +1018,12 @@ void do_upload(snf_batch_impl* b) {
     v.alt_cap = v.pool_cap; v.alt_pool = dalloc<uint8_t>(b, (size_t)v.alt_cap + 32);
     const size_t NO = (size_t)v.NS + 1;
     v.o_scan = dalloc<uint32_t>(b, NO + 1); v.o_src = dalloc<int32_t>(b, NO); v.o_dst = dalloc<int32_t>(b, NO); v.o_key = dalloc<int32_t>(b, NO);
-    v.o_alt = dalloc<int64_t>(b, NO); v.o_rn = dalloc<int64_t>(b, NO);
+    v.o_rn = dalloc<int64_t>(b, NO);
     v.out_hdr = dalloc<OutHdr>(b, 1);
     dzero(b, v.out_hdr, sizeof(OutHdr));
-    v.out_dev_cap = (int64_t)(NO * sizeof(snf_call_t) + (2 * (size_t)N + 1) * 4 + (size_t)v.alt_cap + 1024);
+    v.out_dev_cap = (int64_t)(NO * sizeof(snf_call_t) + (2 * (size_t)N + 1) * 4 + 1024);
     v.out_dev = dalloc<uint8_t>(b, (size_t)v.out_dev_cap);
-    v.out_mode = b->out_mode; v.out_valid = 0; v.out_pin = nullptr; v.out_pin_cap = 0;
+    v.out_mode = b->out_mode; v.out_valid = 0; v.out_pin = nullptr; v.out_pin_cap = 0; v.alt_pin = nullptr; v.alt_pin_cap = 0;
   }
   const double t_index0 = now_ms();
   { const bool tm = b->timing; b->timing = false; enqueue_read_index(b); b->timing = tm; }   // (no event brackets outside a pass)
@@ -1250,28 +1318,12 @@ void enqueue_output_head(snf_batch_impl* b) {
     const int64_t nc = NS;   // upper bound of the number of calls (the bodies stop at the device's count)
     LAUNCH_Q(f1_flags, v, nc + 1, 0);
     prim_exscan<uint32_t>(b, v.o_scan, v.pL, nc + 1, "scan_out");
-    prim_exscan<int64_t>(b, v.sz_tab, v.sc_tab, nc + 1, "scan_out");
     prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_out");
     LAUNCH_Q(f2_scan, v, nc + 1, 0);
     if ((v.out_mode & SNF_OUT_EXECUTE) && v.cfg.sort) LAUNCH_Q(f3_rank, v, nc, 0);
     LAUNCH_Q(f4_emit, v, nc, 0);
   }
 }
-void enqueue_output_alt(snf_batch_impl* b) {
-  View& v = b->v;
-  const int64_t NS = v.NS;
-#ifndef SNF_EMU
-  if (b->fused) {
-    const unsigned grid = (unsigned)((NS + 255) / 256);
-    Scope _s(b, "f5_alt", 0);
-    hipLaunchKernelGGL(f5w_alt, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
-    SNF_HIP(hipGetLastError());
-    return;
-  }
-#endif
-  LAUNCH_Q(f5_alt, v, NS, 0);
-}
-
 // Thread-kernel form of the ALT stage (e4 / e5 / e6) and the ROWS instance need scratch sized by totals that only the device
 // knows: the one place where finalize waits for the device.  Taken by the emulation build (always), by SNF_NO_WAVE, and - from
 // the fetch, after the fact - when a call fits none of the LDS classes or a workgroup handed its call over (escape list).
@@ -1361,8 +1413,23 @@ void run_finalize(snf_batch_impl* b) {
     if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_out.cap < want) b->hb_out.ensure(want);
     v.out_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_out.p;
     v.out_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_out.cap;
+    // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
+    const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
+    if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
+    v.alt_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_alt.p;
+    v.alt_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_alt.cap;
   }
   v.out_valid = 1;
+  // Launch sizes of the data-dependent kernels.  Grids much larger than the work flood the dispatcher with empty workgroups
+  // (measured: every co-running kernel of the device slows down), grids smaller make the kernels stride.  A handle that
+  // has finalized before knows its sizes (same input); the first pass waits once for the counters d3_taskoff published.
+  int64_t n_calls_hint = b->hist_calls;
+  if (!b->have_hist && NS > 0) {
+#ifndef SNF_EMU
+    SNF_HIP(hipEventSynchronize(b->ev_counts));
+#endif
+    n_calls_hint = b->h_cnt->n_calls;
+  }
   if (NS > 0) {
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
      // annotations they read), overlapped with the consensus chain
@@ -1371,9 +1438,9 @@ void run_finalize(snf_batch_impl* b) {
     if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
-      // one workgroup (= wave) per batch of e1_batch calls; the grid covers an upper bound of the calls (a quarter of the
-      // positions behind the sort; the kernel strides if there are more) and workgroups behind the last call return at once
-      int64_t grid = (NS / 4 + v.e1_batch - 1) / v.e1_batch + 1;
+      // one workgroup (= wave) per batch of e1_batch calls, dispatched by the hardware (the kernel strides when there are
+      // more calls than the grid covers, workgroups behind the last call return at once)
+      int64_t grid = (n_calls_hint + v.e1_batch - 1) / v.e1_batch + 1;
       if (grid > (1 << 20)) grid = 1 << 20;
       hipLaunchKernelGGL(b->k_e1w, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -1407,10 +1474,16 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_rn, 0));
       enqueue_output_head(b);
     }
-    enqueue_consensus_wave(b, NS / 16 + 256, NS / 64 + 256, NS / 16 + 256);
+    if (!b->have_hist) {   // first finalize of this handle: the class sizes e3b has just written, one host wait
+      d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
+      dsync(b);
+      const Counts& c = *b->h_cnt;
+      b->hist_small = (int64_t)c.n_cls[1]; b->hist_large = (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]); b->hist_copy = (int64_t)c.n_cls[0];
+      b->hist_calls = c.n_calls; b->have_hist = true;
+    }
+    enqueue_consensus_wave(b, b->hist_small + 1, b->hist_large + 1, b->hist_copy + 1);
     join_side(b);
     join_fourth(b);
-    enqueue_output_alt(b);
   }
   else
 #endif
@@ -1439,7 +1512,6 @@ void run_finalize(snf_batch_impl* b) {
     join_side(b);
     join_fourth(b);
     enqueue_output_head(b);
-    enqueue_output_alt(b);
   }
   } else {
     join_side(b);
@@ -1483,7 +1555,6 @@ void collect_timings(snf_batch_impl* b) {
     if (strcmp(t.name, "e1w_finalize") == 0) t.bytes = (int64_t)sizeof(snf_call_t) * b->h_cnt->n_calls;
     if (strcmp(t.name, "d4_coverage") == 0) t.bytes = 8 * b->v.R + 20 * b->h_cnt->n_calls;
     if (strcmp(t.name, "f4_emit") == 0 && b->v.res_out) t.bytes = 2 * ((int64_t)sizeof(snf_call_t) * b->v.res_out->n_out + 4 * b->v.res_out->rn_out);
-    if (strcmp(t.name, "f5_alt") == 0 && b->v.res_out) t.bytes = 2 * b->v.res_out->alt_out;
   }
   // running sums since snf_batch_timing_mean_reset: the mean launch duration of every kernel over the passes in between
   for (const auto& t : b->timings) {
@@ -1502,8 +1573,7 @@ void settle_alt_stage(snf_batch_impl* b) {
   if (!v.wave_path || !b->fused || v.NS <= 0) return;   // (the plain path ran them inside finalize)
   const Counts& c = *b->h_cnt;
   if (c.n_cls[7] == 0 && c.n_cons_fallback == 0) return;
-  run_alt_fallback(b);
-  enqueue_output_alt(b);
+  run_alt_fallback(b);     // (they store into the pass's ALT section like the fast kernels)
   LAUNCH_Q(z1_results, v, v.T + 1, 0);
   dsync(b);
 }
@@ -1526,6 +1596,11 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   if (stage >= 1 && b->finalized) {
     // ---- the block of the output stage: already in pinned host memory, or one copy away
     settle_alt_stage(b);
+    {
+      const Counts& c = *b->h_cnt;
+      b->hist_small = (int64_t)c.n_cls[1]; b->hist_large = (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]); b->hist_copy = (int64_t)c.n_cls[0];
+      b->hist_calls = c.n_calls; b->have_hist = true;
+    }
     const OutHdr h = *v.res_out;
     const uint8_t* base = (const uint8_t*)b->hb_out.p;
     if (!h.in_pinned) {
@@ -1534,10 +1609,17 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
       d2h_timed(b, (void*)base, v.out_dev, (size_t)h.bytes, "d2h_block");
       dsync(b);
     }
+    const int64_t alt_total = b->h_cnt->alt_total;
+    const uint8_t* alt = (const uint8_t*)b->hb_alt.p;
+    if (!b->h_cnt->alt_in_pinned) {
+      v.alt_pin = nullptr; v.alt_pin_cap = 0;
+      alt = (const uint8_t*)b->hb_alt.ensure((size_t)alt_total + 256);
+      if (alt_total) { d2h_timed(b, (void*)alt, v.alt_pool, (size_t)alt_total, "d2h_alt"); dsync(b); }
+    }
     memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
     collect_timings(b);
     out->n_calls = h.n_out; out->calls = (const snf_call_t*)base;
-    out->alt_pool_len = h.alt_out; out->alt_pool = base + h.off_alt;
+    out->alt_pool_len = alt_total; out->alt_pool = alt;
     out->rnames_len = h.rn_out; out->rnames = (const uint32_t*)(base + h.off_rn);
     out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
     out->coverage_average_total = b->r_cov.data();
@@ -1907,6 +1989,17 @@ struct StreamPool {
     SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
+  int trim(int device) {      // idle streams of `device` (< 0: all) are destroyed
+    std::vector<std::pair<int, hipStream_t>> gone;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); }
+    }
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (auto& e : gone) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
+    (void)hipSetDevice(cur);
+    return (int)gone.size();
+  }
   void give(int device, hipStream_t s) {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -2053,7 +2146,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
 #endif
   dfree_all(b);
-  b->hb_calls.release(); b->hb_out.release(); b->hb_rn.release(); b->hb_res.release();
+  b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
 #ifndef SNF_EMU
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
@@ -2112,6 +2205,21 @@ int snf_batch_fetch_clusters(snf_batch_t* bb, int stage, snf_clusters_t* out) {
   })
 }
 
+int64_t snf_batch_n_candidates(snf_batch_t* bb) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b || !b->uploaded || !b->h_cnt) return -1;
+  return b->v.NS > 0 ? b->h_cnt->n_calls : 0;
+}
+
+int64_t snf_trim_caches(int device) {
+  int64_t bytes = (int64_t)g_slabs.trim(device);
+  bytes += (int64_t)g_pinned.trim();
+#ifndef SNF_EMU
+  (void)g_streams.trim(device);
+#endif
+  return bytes;
+}
+
 int snf_batch_set_output(snf_batch_t* bb, int mode) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
@@ -2133,11 +2241,13 @@ int snf_batch_export_device(snf_batch_t* bb, void* dst_device, int64_t cap_bytes
     full_sync(b);
     settle_alt_stage(b);
     const OutHdr h = *b->v.res_out;
-    layout->n_calls = h.n_out; layout->rnames_len = h.rn_out; layout->alt_pool_len = h.alt_out;
-    layout->off_rnames = h.off_rn; layout->off_alt = h.off_alt; layout->bytes = h.bytes;
-    if (h.bytes > cap_bytes) fail("export buffer too small");
-    if (h.bytes > 0 && !dst_device) fail("null destination");
+    const int64_t alt_total = b->h_cnt->alt_total;
+    layout->n_calls = h.n_out; layout->rnames_len = h.rn_out; layout->alt_pool_len = alt_total;
+    layout->off_rnames = h.off_rn; layout->off_alt = h.bytes; layout->bytes = h.bytes + alt_total;
+    if (layout->bytes > cap_bytes) fail("export buffer too small");
+    if (layout->bytes > 0 && !dst_device) fail("null destination");
     d2d(b, dst_device, b->v.out_dev, (size_t)h.bytes);
+    d2d(b, (uint8_t*)dst_device + h.bytes, b->v.alt_pool, (size_t)alt_total);
     dsync(b);
   })
 }

@@ -27,6 +27,15 @@ SNF_HD int64_t pf_cell(const View& v, int t, int svtype, uint64_t bin) {
   const int64_t c0 = v.t_cell_off[t], nb = (v.t_cell_off[t + 1] - c0) / SNF_NTYPES;
   return c0 + (int64_t)svtype * nb + (int64_t)bin;
 }
+// Leads that arrive together lie within a read length of each other, i.e. in a few hundred neighbouring bins: packed 16 cells
+// to a word their marks would all hit the same two or three cache lines, and atomics on one line are served one after the
+// other by one L2 channel.  pf_slot moves the low five bits of the cell index to the top of a 2^19-cell block: neighbouring
+// cells end up 4 KB apart (another channel each), the working set of a neighbourhood stays one 128-KB block.
+SNF_HD int64_t pf_slot(const View& v, int64_t cell) {
+  if (!v.pf_spread) return cell;
+  const int64_t in = cell & (((int64_t)1 << 19) - 1);
+  return (cell - in) | ((in & 31) << 14) | (in >> 5);
+}
 SNF_HD void a1_keys_body(int64_t i, const View& v) {
   int t = v.lead_task[i];
   int64_t rs = v.in_ref_start[i];
@@ -37,7 +46,7 @@ SNF_HD void a1_keys_body(int64_t i, const View& v) {
   if (v.prefilter) {
     if (v.key32) ((uint32_t*)v.pf_key)[i] = (uint32_t)k; else v.pf_key[i] = k;
     if (valid) {
-      const int64_t cell = pf_cell(v, t, svtype, bin);
+      const int64_t cell = pf_slot(v, pf_cell(v, t, svtype, bin));
       uint32_t* w = v.pf_bm + (cell >> 4);
       const int sh = (int)(cell & 15) * 2;
       const uint32_t old = atomic_fetch_or_u32(w, 1u << sh);
@@ -55,7 +64,7 @@ SNF_HD uint64_t pf_key_of(const View& v, int64_t i) { return v.key32 ? (uint64_t
 SNF_HD bool pf_cell_of_key(const View& v, uint64_t k, int64_t* cell) {
   if (k >> v.key_nbits) return false;
   const uint64_t g = k >> v.key_bin_bits, bin = k & ((1ull << v.key_bin_bits) - 1ull);
-  *cell = pf_cell(v, (int)(g >> 3), (int)(g & 7), bin);
+  *cell = pf_slot(v, pf_cell(v, (int)(g >> 3), (int)(g & 7), bin));
   return true;
 }
 SNF_HD void a0_keep_body(int64_t i, const View& v) {

@@ -511,12 +511,19 @@ SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
 }
 SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { return cons_class(v, L, n_others) != 0; }
 
+// where this pass's ALT bytes live (pinned host memory when the total fits the batch's pinned buffer, else the HBM pool)
+SNF_HD uint8_t* alt_base(const View& v) { return v.cnt->alt_in_pinned ? v.alt_pin : v.alt_pool; }
+SNF_HD void alt_decide(const View& v, int64_t alt_total) {
+  v.cnt->alt_in_pinned = (!(v.out_mode & SNF_OUT_DEVICE) && v.alt_pin && alt_total <= v.alt_pin_cap) ? 1 : 0;
+}
+
 SNF_HD void e2_best_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
   if (i == 0) {
     v.fN[nc] = 0; v.fL[nc] = 0; v.sz_tab[nc] = 0; v.sz_aln[nc] = 0; v.sz_rd[nc] = 0;
     for (int k = 0; k < 8; k++) v.cnt->n_cls[k] = 0;   // filled by e3_conslist (finalize may run more than once)
     v.cnt->n_cons_fallback = 0;
+    if (nc == 0) alt_decide(v, 0);
   }
   if (i >= nc) return;
   v.fN[i] = 0; v.fL[i] = 0; v.sz_tab[i] = 0; v.sz_aln[i] = 0; v.sz_rd[i] = 0;
@@ -571,6 +578,7 @@ SNF_HD void e3_conslist_body(int64_t i, const View& v) {
   if (i == 0) {
     v.cnt->alt_total = v.pN[nc]; v.cnt->n_cons = v.pL[nc];
     v.cnt->tab_total = v.sc_tab[nc]; v.cnt->aln_total = v.sc_aln[nc]; v.cnt->n_cons_reads = v.sc_rd[nc];
+    alt_decide(v, (int64_t)v.pN[nc]);
   }
   if (i >= nc) return;
   e3_emit(i, v);
@@ -740,7 +748,7 @@ SNF_HD void e6_vote_body(int64_t col, const View& v) {
       if (nd > 1 && c0 - c1 >= 3) out = (uint8_t)k0;
     }
   }
-  v.alt_pool[col] = out;
+  alt_base(v)[col] = out;
 }
 
 // Column vote of the LDS-vote consensus kernels (snf_wave_cons.h; consensus.py:365-380, util.most_common): `cnt4` = four

@@ -9,11 +9,12 @@
 //   f1  keep flag + sizes per call                     (| tile sums)
 //   f2  scan: compacted index, offsets inside the read-name / ALT sections; totals and block layout (OutHdr)
 //   f3  per-task stable rank by pos (SNF_OUT_EXECUTE with config.sort)
-//   f4  record (offsets rewritten) + read names -> block          (needs e1: qc, filter, genotype ...)
-//   f5  ALT bytes -> block                                         (needs the consensus kernels)
-// The block is [records | read names | ALT bytes]; it goes straight into pinned host memory when it fits the pinned
-// buffer the batch holds (zero-copy stores: nothing trails the last kernel but one host wait), otherwise into HBM and the
-// fetch copies it.
+//   f4  record (read-name offset rewritten) + read names -> block          (needs e1: qc, filter, genotype ...)
+// The block is [records | read names]; it goes straight into pinned host memory when it fits the pinned buffer the batch
+// holds (zero-copy stores: nothing trails the last kernel but one host wait), otherwise into HBM and the fetch copies it.
+// The ALT bytes are a section of their own: all candidates' ALTs in candidate order, written by the ALT kernels themselves
+// (pinned host memory or the HBM pool, `alt_base`), so a record keeps its `alt_off`; the few ALT bytes of calls the filter
+// drops travel along (a copy behind the consensus kernels would cost the pass more than they do).
 #pragma once
 #include "snf_stage_final.h"
 #include "snf_fused.h"
@@ -29,30 +30,29 @@ SNF_HD int64_t out_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
 SNF_HD uint8_t* out_base(const View& v) { return v.out_hdr->in_pinned ? v.out_pin : v.out_dev; }
 
 // F1: keep flag (o_scan doubles as the flag array until f2 has scanned it), sizes
-SNF_HD void f1_values(const View& v, int64_t i, int64_t nc, unsigned long long (&val)[3]) {
-  val[0] = val[1] = val[2] = 0;
+SNF_HD void f1_values(const View& v, int64_t i, int64_t nc, unsigned long long (&val)[2]) {
+  val[0] = val[1] = 0;
   if (i >= nc) return;
   const snf_call_t& c = v.calls[i];
   if (!out_keep(v, c)) return;
-  val[0] = 1; val[1] = c.alt_len > 0 ? (unsigned long long)c.alt_len : 0ull; val[2] = (unsigned long long)c.rn_len;
+  val[0] = 1; val[1] = (unsigned long long)c.rn_len;
 }
 // totals -> block layout; written once per pass by whoever holds the totals (last call's thread, or thread 0 when there are no calls)
-SNF_HD void out_layout(const View& v, int64_t n_out, int64_t alt_out, int64_t rn_out) {
+SNF_HD void out_layout(const View& v, int64_t n_out, int64_t rn_out) {
   OutHdr h;
-  h.n_out = n_out; h.alt_out = alt_out; h.rn_out = rn_out;
+  h.n_out = n_out; h.rn_out = rn_out;
   h.off_rn = out_align(n_out * (int64_t)sizeof(snf_call_t));
-  h.off_alt = out_align(h.off_rn + rn_out * 4);
-  h.bytes = h.off_alt + alt_out;
+  h.bytes = out_align(h.off_rn + rn_out * 4);
   h.in_pinned = (!(v.out_mode & SNF_OUT_DEVICE) && v.out_pin && h.bytes <= v.out_pin_cap) ? 1 : 0;
   h._pad = 0;
   *v.out_hdr = h;
 }
 // F2 per call, given its exclusive offsets
-SNF_HD void f2_emit(const View& v, int64_t i, unsigned long long keep, unsigned long long q, unsigned long long alt_off, unsigned long long rn_off) {
+SNF_HD void f2_emit(const View& v, int64_t i, unsigned long long keep, unsigned long long q, unsigned long long rn_off) {
   v.o_scan[i] = (uint32_t)q;
   if (!keep) return;
   v.o_src[q] = (int32_t)i; v.o_dst[q] = (int32_t)q; v.o_key[q] = v.calls[i].pos;
-  v.o_alt[q] = (int64_t)alt_off; v.o_rn[q] = (int64_t)rn_off;
+  v.o_rn[q] = (int64_t)rn_off;
 }
 // F3: final record index of compacted call q = first slot of its task + stable rank by pos among the task's kept calls
 SNF_HD void f3_rank_body(int64_t q, const View& v) {
@@ -72,36 +72,26 @@ SNF_HD void f4_emit_body(int64_t q, const View& v) {
   uint8_t* base = out_base(v);
   const snf_call_t& src = v.calls[v.o_src[q]];
   snf_call_t c = src;
-  c.alt_off = c.alt_len >= 0 ? v.o_alt[q] : 0;
   c.rn_off = v.o_rn[q];
   ((snf_call_t*)base)[v.o_dst[q]] = c;
   uint32_t* rn = (uint32_t*)(base + h.off_rn) + v.o_rn[q];
   for (int32_t k = 0; k < src.rn_len; k++) rn[k] = v.rnames[src.rn_off + k];
 }
-// F5 (thread form): ALT bytes
-SNF_HD void f5_alt_body(int64_t q, const View& v) {
-  if (q >= v.out_hdr->n_out) return;
-  const snf_call_t& src = v.calls[v.o_src[q]];
-  if (src.alt_len <= 0) return;
-  uint8_t* dst = out_base(v) + v.out_hdr->off_alt + v.o_alt[q];
-  const uint8_t* a = v.alt_pool + src.alt_off;
-  for (int32_t k = 0; k < src.alt_len; k++) dst[k] = a[k];
-}
 // plain-scan path (emulation build, SNF_NO_FUSE): F1 writes the three value arrays, three device-wide scans, F2 reads them
 SNF_HD void f1_flags_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
-  unsigned long long val[3];
+  unsigned long long val[2];
   f1_values(v, i, nc, val);
-  v.o_scan[i] = (uint32_t)val[0]; v.sz_tab[i] = (int64_t)val[1]; v.sz_rd[i] = (int64_t)val[2];   // (sz_* of the ALT sizing are free again)
+  v.o_scan[i] = (uint32_t)val[0]; v.sz_rd[i] = (int64_t)val[1];   // (sz_rd of the ALT sizing is free again)
 }
 SNF_HD void f2_scan_body(int64_t i, const View& v) {
   const int64_t nc = v.cnt->n_calls;
-  if (i == 0) out_layout(v, (int64_t)v.pL[nc], v.sc_tab[nc], v.sc_rd[nc]);
+  if (i == 0) out_layout(v, (int64_t)v.pL[nc], v.sc_rd[nc]);
   if (i > nc) return;
   if (i == nc) { v.o_scan[nc] = v.pL[nc]; return; }
-  unsigned long long val[3];
+  unsigned long long val[2];
   f1_values(v, i, nc, val);
-  f2_emit(v, i, val[0], v.pL[i], (unsigned long long)v.sc_tab[i], (unsigned long long)v.sc_rd[i]);
+  f2_emit(v, i, val[0], v.pL[i], (unsigned long long)v.sc_rd[i]);
 }
 
 #ifndef SNF_EMU
@@ -110,42 +100,54 @@ SNF_HD void f2_scan_body(int64_t i, const View& v) {
 // atomically accumulated super-tile sums of the candidate stage's chains are not used here).  The grid covers the upper bound
 // NS; blocks behind the last call publish zeros / return.
 __global__ void __launch_bounds__(256) f1k_outflags(const View v, int64_t n) {
-  __shared__ unsigned long long lds[4 * 3];
+  __shared__ unsigned long long lds[4 * 2];
   const int64_t nc = v.cnt->n_calls;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned long long val[3], excl[3], tot[3];
+  unsigned long long val[2], excl[2], tot[2];
   f1_values(v, i, nc, val);
-  block_exscan256<3>(val, excl, tot, lds);
-  if (threadIdx.x == 0) for (int k = 0; k < 3; k++) v.tile_sums[(int64_t)(TS_OUT + k) * v.tile_stride + blockIdx.x] = tot[k];
-  if (i == 0 && nc == 0) { out_layout(v, 0, 0, 0); v.o_scan[0] = 0; }
+  block_exscan256<2>(val, excl, tot, lds);
+  if (threadIdx.x == 0) for (int k = 0; k < 2; k++) v.tile_sums[(int64_t)(TS_OUT + k) * v.tile_stride + blockIdx.x] = tot[k];
+  if (i == 0 && nc == 0) { out_layout(v, 0, 0); v.o_scan[0] = 0; }
 }
 __global__ void __launch_bounds__(256) f2k_outscan(const View v, int64_t n) {
-  __shared__ unsigned long long lds[4 * 3];
+  __shared__ unsigned long long lds[4 * 2];
   const int64_t nc = v.cnt->n_calls;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if ((int64_t)blockIdx.x * 256 >= nc) return;      // (whole block: no barrier is skipped by part of it)
-  unsigned long long part[3], dummy[3], prefix[3], val[3], excl[3], tot[3];
+  unsigned long long part[2], dummy[2], prefix[2], val[2], excl[2], tot[2];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 2; k++) {
     unsigned long long a = 0;
     for (int64_t j = threadIdx.x; j < (int64_t)blockIdx.x; j += 256) a += v.tile_sums[(int64_t)(TS_OUT + k) * v.tile_stride + j];
     part[k] = a;
   }
-  block_exscan256<3>(part, dummy, prefix, lds);     // prefix = sums of all preceding tiles
+  block_exscan256<2>(part, dummy, prefix, lds);     // prefix = sums of all preceding tiles
   f1_values(v, i, nc, val);
-  block_exscan256<3>(val, excl, tot, lds);
+  block_exscan256<2>(val, excl, tot, lds);
   if (i < nc) {
-    const unsigned long long o0 = prefix[0] + excl[0], o1 = prefix[1] + excl[1], o2 = prefix[2] + excl[2];
-    f2_emit(v, i, val[0], o0, o1, o2);
+    const unsigned long long o0 = prefix[0] + excl[0], o1 = prefix[1] + excl[1];
+    f2_emit(v, i, val[0], o0, o1);
     if (i == nc - 1) {
       v.o_scan[nc] = (uint32_t)(o0 + val[0]);
-      out_layout(v, (int64_t)(o0 + val[0]), (int64_t)(o1 + val[1]), (int64_t)(o2 + val[2]));
+      out_layout(v, (int64_t)(o0 + val[0]), (int64_t)(o1 + val[1]));
     }
   }
 }
+// one wave per kept call: the lanes stride over the keys of the call's task (contiguous, cache-resident) and the ballots are counted
 __global__ void __launch_bounds__(256) f3k_rank(const View v, int64_t n) {
   const int64_t n_out = v.out_hdr->n_out;
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n_out; q += (int64_t)gridDim.x * 256) f3_rank_body(q, v);
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t q = wave; q < n_out; q += nw) {
+    const int t = v.calls[v.o_src[q]].task_index;
+    const int64_t qlo = v.o_scan[v.t_call_off[t]], qhi = v.o_scan[v.t_call_off[t + 1]];
+    const int32_t key = v.o_key[q];
+    int rank = 0;
+    for (int64_t j = qlo + lane; j < qhi; j += 64) { const int32_t kj = v.o_key[j]; rank += (kj < key || (kj == key && j < q)) ? 1 : 0; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) rank += __shfl_xor(rank, d, 64);
+    if (lane == 0) v.o_dst[q] = (int32_t)(qlo + rank);
+  }
 }
 typedef uint4 __attribute__((aligned(1))) out_u128_unaligned;
 // one wave per kept call: the 240-byte record as fifteen 16-byte words (offsets patched in registers), read names lane-strided
@@ -158,36 +160,18 @@ __global__ void __launch_bounds__(256) f4w_emit(const View v, int64_t n) {
   for (int64_t q = wave; q < h.n_out; q += nw) {
     const int32_t i = v.o_src[q];
     const snf_call_t* src = v.calls + i;
-    const int64_t rn_src = src->rn_off; const int32_t rn_len = src->rn_len, alt_len = src->alt_len;
-    const int64_t rn_dst = v.o_rn[q], alt_dst = alt_len >= 0 ? v.o_alt[q] : 0;
+    const int64_t rn_src = src->rn_off; const int32_t rn_len = src->rn_len;
+    const int64_t rn_dst = v.o_rn[q];
     if (lane < (int)(sizeof(snf_call_t) / 16)) {
       union { uint4 w; uint8_t b[16]; } u;
       u.w = ((const uint4*)src)[lane];
-      constexpr int oa = (int)offsetof(snf_call_t, alt_off), orn = (int)offsetof(snf_call_t, rn_off);
-      static_assert(oa % 8 == 0 && orn % 8 == 0, "64-bit fields inside one 16-byte word");
-      if (lane == oa / 16) memcpy(u.b + oa % 16, &alt_dst, 8);
+      constexpr int orn = (int)offsetof(snf_call_t, rn_off);
+      static_assert(orn % 8 == 0, "the 64-bit field lies inside one 16-byte word");
       if (lane == orn / 16) memcpy(u.b + orn % 16, &rn_dst, 8);
       ((uint4*)(base + (int64_t)v.o_dst[q] * (int64_t)sizeof(snf_call_t)))[lane] = u.w;
     }
     uint32_t* rn = (uint32_t*)(base + h.off_rn) + rn_dst;
     for (int32_t k = lane; k < rn_len; k += 64) rn[k] = v.rnames[rn_src + k];
-  }
-}
-// one wave per kept call with ALT bytes: 16 bytes per lane and step (unaligned vector accesses), byte tail
-__global__ void __launch_bounds__(256) f5w_alt(const View v, int64_t n) {
-  const OutHdr h = *v.out_hdr;
-  uint8_t* base = (h.in_pinned ? v.out_pin : v.out_dev) + h.off_alt;
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * 256) >> 6;
-  for (int64_t q = wave; q < h.n_out; q += nw) {
-    const snf_call_t* src = v.calls + v.o_src[q];
-    const int32_t len = src->alt_len;
-    if (len <= 0) continue;
-    const uint8_t* a = v.alt_pool + src->alt_off;
-    uint8_t* d = base + v.o_alt[q];
-    const int32_t full = len & ~15;
-    for (int32_t o = lane * 16; o < full; o += 64 * 16) *(out_u128_unaligned*)(d + o) = *(const out_u128_unaligned*)(a + o);
-    if (lane < len - full) d[full + lane] = a[full + lane];
   }
 }
 #endif  // !SNF_EMU

@@ -27,7 +27,7 @@ struct Counts {
   unsigned long long dbg[32];       // instrumented build only: cycles per phase of the consensus kernels (tools/cons_profile.sh)
 #endif
   int32_t overflow;  // scratch overflow flags
-  int32_t _pad;
+  int32_t alt_in_pinned;     // this pass's ALT bytes go straight to the pinned buffer (View::alt_pin) instead of the HBM pool: decided once the total is known (e3)
 };
 
 // genotype lookup entry for (normalised support, normalised coverage), built on the host with the
@@ -76,8 +76,9 @@ enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUS
 
 // totals and layout of the output block (f* kernels, snf_stage_out.h); copied to the pinned result block by z1_results
 struct OutHdr {
-  int64_t n_out, rn_out, alt_out;     // records, read names (uint32), ALT bytes
-  int64_t off_rn, off_alt, bytes;     // sections of the block: [records | read names | ALT bytes], 256-byte aligned
+  int64_t n_out, rn_out;              // records, read names (uint32)
+  int64_t off_rn, bytes;              // sections of the block: [records | read names], 256-byte aligned; the ALT bytes are a section
+                                      // of their own (all candidates, candidate order: written by the ALT kernels themselves)
   int32_t in_pinned;                  // 1: the kernels stored the block straight into pinned host memory
   int32_t _pad;
 };
@@ -140,7 +141,7 @@ struct View {
   // dev_min_leads_cluster >= 2 (cluster.py:262) - 80 % of the leads of a 30x genome - and is dropped in front of the sort.
   // Two bits per cell ("seen", "seen twice"); the words a pass touched are cleared again by the pass itself.
   int32_t prefilter;          // 1: on
-  int32_t pf_nbin_bits;       // (unused padding of the pair)
+  int32_t pf_spread;          // 1: neighbouring cells are spread over the L2 channels (pf_slot); SNF_PF_SPREAD=0 keeps them adjacent
   uint32_t* pf_bm;            // [pf_words] 16 cells per word
   const int64_t* t_cell_off;  // [T+1] first cell of task t (cells of a task: SNF_NTYPES x (contig_len / binsize + 1))
   uint64_t* pf_key;           // [N] sort key per input lead (uint32_t when key32), written by a1_keys
@@ -172,7 +173,7 @@ struct View {
   int32_t out_valid;         // host: the output stage of this pass has been enqueued (z1_results publishes its offsets)
   uint32_t* o_scan;          // [n_calls+1] exclusive scan of the keep flags (defined for every call)
   int32_t *o_src, *o_dst, *o_key;   // [n_out] compacted index -> call index / final record index / pos (sort key)
-  int64_t *o_alt, *o_rn;     // [n_out] offsets inside the ALT / read-name sections
+  int64_t* o_rn;             // [n_out] offset inside the read-name section
   OutHdr* out_hdr;           // device
   OutHdr* res_out;           // pinned copy (z1_results)
   uint8_t* out_dev; int64_t out_dev_cap;   // block in HBM
@@ -215,7 +216,8 @@ struct View {
   uint8_t* aln; int64_t aln_cap;         // aligned reads, n_others x L per consensus call
   uint8_t* aln_kept;         // [n_cons_reads]
   int32_t *cr_call, *cr_read;  // [n_cons_reads] (consensus id, other index)
-  uint8_t* alt_pool; int64_t alt_cap;
+  uint8_t* alt_pool; int64_t alt_cap;    // ALT bytes of all candidates, candidate order (HBM)
+  uint8_t* alt_pin; int64_t alt_pin_cap; // the same section in pinned host memory (0: none); Counts::alt_in_pinned says which one a pass uses
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
   unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains

@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
     const int32_t n_others = __builtin_amdgcn_readfirstlane(d.n_others);
     const uint8_t* Bg = v.pool + rfl64(d.best_off);
-    uint8_t* alt = v.alt_pool + rfl64(d.alt_off);
+    uint8_t* alt = alt_base(v) + rfl64(d.alt_off);
     const int skip = __builtin_amdgcn_readfirstlane(d.skip);
     const int64_t r0 = rfl64(d.read_off);
     // pool offset / length of every other read of the call, one entry per lane and slot: in flight while the best read is
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(64) e4c_copy(const View v, int64_t n_unused) {
   for (int64_t it = blockIdx.x; it < n_items; it += gridDim.x) {
     const ConsDesc d = v.cdesc[list[it]];
     const uint8_t* B = v.pool + d.best_off;
-    uint8_t* alt = v.alt_pool + d.alt_off;
+    uint8_t* alt = alt_base(v) + d.alt_off;
     for (int64_t q = threadIdx.x; q < d.L; q += 64) alt[q] = B[q];
     bytes_acc += 2ull * (unsigned long long)d.L;
   }

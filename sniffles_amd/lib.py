@@ -42,6 +42,10 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_fetch_clusters.restype = C.c_int
     lib.snf_batch_export_device.argtypes = [vp, vp, C.c_int64, C.POINTER(abi.snf_export_layout_t)]
     lib.snf_batch_set_output.argtypes = [vp, C.c_int]
+    lib.snf_trim_caches.argtypes = [C.c_int]
+    lib.snf_batch_n_candidates.argtypes = [vp]
+    lib.snf_batch_n_candidates.restype = C.c_int64
+    lib.snf_trim_caches.restype = C.c_int64
     lib.snf_batch_block_coverage.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.POINTER(C.c_int32)]
     lib.snf_batch_block_coverage.restype = C.c_int
     lib.snf_batch_coverage_calls.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -173,6 +177,10 @@ class Batch:
         _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
         return abi.Result(r, copy)
 
+    def n_candidates(self) -> int:
+        """Candidate calls of the last call_candidates (all tasks), as of the last fetch / sync."""
+        return int(self.lib.snf_batch_n_candidates(self._h))
+
     def fetch_raw(self, stage: int) -> int:
         """D2H of the results into library-owned host memory without materialising numpy copies; returns n_calls."""
         r = abi.snf_result_t()
@@ -249,6 +257,11 @@ class Batch:
             _check(self.lib, self.lib.snf_batch_timing_mean_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb), C.byref(k)))
             out.append((name.value.decode(), float(ms.value), int(nb.value)))
         return out
+
+
+def trim_caches(device: int = -1, _lib=None) -> int:
+    """Release what the library keeps of finished batches (HBM slabs, pinned buffers, idle streams); bytes released."""
+    return int((_lib or load()).snf_trim_caches(device))
 
 
 def device_count() -> int:

@@ -76,18 +76,23 @@ class Task:
         self.coverage_average_total = float(res.coverage_average_total[0])
         return out
 
-    def call_records(self, config):
+    def call_records(self, config, execute: bool = False):
         """call_candidates + finalize_candidates without the `SVCall` objects: the finalized record table of the task
-        (`lib.Result`) and its input, for consumers that format or count straight from the records (vcf.VCF.write_records)."""
+        (`lib.Result`) and its input, for consumers that format or count straight from the records (vcf.VCF.write_records).
+        `execute`: only what `CallTask.execute` keeps (QC-passing calls unless `config.no_qc`, sorted by position when
+        `config.sort`; parallel.py:265-271), filtered and ordered on the device.
+        The arrays of the result are VIEWS of the batch's pinned block: they die with `close()` or the next call on this task
+        (the buffer is handed to the next batch) - copy what has to outlive it."""
+        from .abi import OUT_CANDIDATES, OUT_EXECUTE
         self._open(config)
+        self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
         self._batch.call_candidates()
-        res = self._batch.fetch(0, copy=False)
+        self._batch.finalize()            # (both only enqueue; the fetch is the one wait)
+        res = self._batch.fetch(1, copy=False)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
-        self._batch.finalize()
-        res = self._batch.fetch(1, copy=False)
         self._finalized = True
-        self.sv_id += len(res.calls)
+        self.sv_id += int(self._batch.n_candidates())
         self.coverage_average_total = float(res.coverage_average_total[0])
         return res, self._ti
 

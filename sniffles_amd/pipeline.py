@@ -134,29 +134,28 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
         if not objects and snf_out is None and writer is not None and writer.can_write_records():
             import numpy as np
             try:
-                res, ti_used = task.call_records(config)
+                # CallTask.execute's QC filter and position sort happen on the device (SNF_OUT_EXECUTE): only the records the
+                # VCF will hold cross PCIe, already in output order
+                res, ti_used = task.call_records(config, execute=True)
+                out.vcf_records += writer.write_records(res, ti_used, np.arange(len(res.calls)))
+                out.read_count += info.read_count
             finally:
-                extractor.close()
-            keep = np.arange(len(res.calls)) if config.no_qc else np.flatnonzero(res.calls["qc"] != 0)
-            if getattr(config, "sort", True):
-                keep = keep[np.argsort(res.calls["pos"][keep], kind="stable")]
-            out.vcf_records += writer.write_records(res, ti_used, keep)
-            out.read_count += info.read_count
-            task.close()
+                task.close()
+                extractor.close()      # (backs the lazy host copies of the task input: goes after the task)
             continue
         try:
             cands = task.call_candidates(qc, config)
+            calls = task.finalize_candidates(cands, not qc, config)
+            if not config.no_qc:
+                calls = [c for c in calls if c.qc]
+            if getattr(config, "sort", True):
+                calls = sorted(calls, key=lambda c: c.pos)
+            out.read_count += info.read_count
+            if snf_out is not None:
+                snf_out.add_result(task.write_snf_part(cands, f"{snf_path}.tmp_{task_id}.snf"))
         finally:
+            task.close()
             extractor.close()
-        calls = task.finalize_candidates(cands, not qc, config)
-        if not config.no_qc:
-            calls = [c for c in calls if c.qc]
-        if getattr(config, "sort", True):
-            calls = sorted(calls, key=lambda c: c.pos)
-        out.read_count += info.read_count
-        if snf_out is not None:
-            snf_out.add_result(task.write_snf_part(cands, f"{snf_path}.tmp_{task_id}.snf"))
-        task.close()
         if writer is not None:
             out.vcf_records += sum(writer.write_call(c) for c in calls)
         out.calls[task_id] = calls

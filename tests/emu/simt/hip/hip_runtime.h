@@ -551,6 +551,12 @@ static inline hipError_t hipMemset(void* d, int c, size_t n) { std::lock_guard<s
 static inline hipError_t hipMemsetAsync(void* d, int c, size_t n, hipStream_t = nullptr) { std::lock_guard<std::mutex> g(simt::g_launch_mutex); if (n) std::memset(d, c, n); return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : 101; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
+  std::lock_guard<std::mutex> g(simt::g_launch_mutex);
+  for (size_t r = 0; r < height; r++) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+  return hipSuccess;
+}
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {

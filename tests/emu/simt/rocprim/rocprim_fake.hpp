@@ -9,8 +9,11 @@
 namespace rocprim {
 template <class T> struct plus { T operator()(const T& a, const T& b) const { return a + b; } };
 
-// stable, by the key bits [begin_bit, end_bit)
-template <class K, class V>
+struct default_config {};
+template <class A = default_config, class B = default_config, class C = default_config, size_t MergeSortLimit = 1024 * 1024> struct radix_sort_config {};
+
+// stable, by the key bits [begin_bit, end_bit)   (Config: the algorithm selection of the real library; nothing to select here)
+template <class Config = default_config, class K, class V>
 inline hipError_t radix_sort_pairs(void* tmp, size_t& need, const K* kin, K* kout, const V* vin, V* vout, size_t n,
                                    unsigned begin_bit, unsigned end_bit, hipStream_t = nullptr, bool = false) {
   if (!tmp) { need = 16; return hipSuccess; }

@@ -21,7 +21,8 @@ def run(cfg, tis, fin=True):
 
 def test_native_library_loaded_and_device_present():
     assert lib.device_count() >= 1
-    assert lib.load().snf_abi_version() == 1
+    from sniffles_amd import abi
+    assert lib.load().snf_abi_version() == abi.ABI_VERSION
 
 
 @pytest.mark.parametrize("name", sorted(cases.ALL))
