@@ -224,7 +224,7 @@ SNF_FUSED_HEAD(d3rk_rnames)
   if (p < n) {
     v.rnp[p] = (uint32_t)off[0];
     if (p == n - 1) { const int64_t tot = (int64_t)(off[0] + val[0]); v.rnp[n] = (uint32_t)tot; v.cnt->rn_total = tot; *v.res_rn_total = tot; }
-    d3_rnames_emit(p, v);
+    if (!v.rn_defer) d3_rnames_emit(p, v);
   }
 }
 

@@ -70,6 +70,7 @@ SNF_KERNEL(e4_anchor, View)
 SNF_KERNEL(e5_align, View)
 SNF_KERNEL(e6_vote, View)
 SNF_KERNEL(z1_results, View)
+SNF_KERNEL(d3l_rnames_late, View)
 SNF_KERNEL(f1_flags, View)
 SNF_KERNEL(f2_scan, View)
 SNF_KERNEL(f3_rank, View)
@@ -264,6 +265,7 @@ struct snf_batch_impl {
   std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
   bool uploaded = false;
   bool finalized = false;         // run_finalize has run on the current candidates
+  int rn_state = 0;               // supporting read names of the current candidates: 0 all written, 1 deferred (sizes only), 2 written for the kept calls
   int64_t pf_words = 0;           // prefilter bitmap size (uint32 words)
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
@@ -955,7 +957,7 @@ void do_upload(snf_batch_impl* b) {
       v.prefilter = 1;
       v.t_cell_off = upload_vec(b, cell_off);
       b->pf_words = (((cells >> 19) + 1) << 19) / 16 + 2;   // (whole 2^19-cell blocks: pf_slot permutes inside a block)
-      v.pf_spread = (getenv("SNF_PF_SPREAD") && atoi(getenv("SNF_PF_SPREAD")) == 0) ? 0 : 1;
+      v.pf_spread = (getenv("SNF_PF_SPREAD") && atoi(getenv("SNF_PF_SPREAD")) == 1) ? 1 : 0;   // (measured: a1_keys 0.146 ms spread / 0.111 adjacent)
       v.pf_bm = dalloc<uint32_t>(b, (size_t)b->pf_words);
       dzero(b, v.pf_bm, (size_t)b->pf_words * 4);
       v.pf_key = dalloc<uint64_t>(b, N); v.pf_keep = dalloc<uint32_t>(b, N1); v.pf_scan = dalloc<uint32_t>(b, N1);
@@ -1129,6 +1131,14 @@ void run_call_candidates(snf_batch_impl* b) {
   b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
   reset_timing(b);
 #ifndef SNF_EMU
+  // SNF_OUT_EXECUTE (set before this call): the names of the supporting reads are only written for the calls that pass QC,
+  // once finalize knows them (a stage-0 fetch writes them all, late)
+  v.rn_defer = ((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc && getenv("SNF_NO_RN_DEFER") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25)) ? 1 : 0;
+#else
+  v.rn_defer = 0;
+#endif
+  b->rn_state = v.rn_defer ? 1 : 0;
+#ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
 #endif
   // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
@@ -1297,14 +1307,33 @@ void ensure_cap(snf_batch_impl* b, int64_t need, int64_t& cap, void** p, size_t 
 // ---- output stage (snf_stage_out.h): flags / scan / rank / records + read names on the side stream as soon as the scalar
 // call fields are final, the ALT bytes behind the consensus kernels.  `late`: everything on the main stream (plain-scan path,
 // and the redo after the rare fallbacks of the ALT stage)
+// supporting read names that the candidate stage only sized (View::rn_defer): for the calls the output keeps, or for all
+void enqueue_rnames_late(snf_batch_impl* b, bool all) {
+  View& v = b->v;
+  if (b->rn_state == 0 || (b->rn_state == 2 && !all) || v.NS <= 0) return;
+  const int keep = v.rn_defer;
+  v.rn_defer = all ? 2 : 1;
+#ifndef SNF_EMU
+  { Scope _s(b, "d3_rnames_late", 0);
+    unsigned grid = (unsigned)((v.NS / 4 + 255) / 256) + 1u; if (grid > 4096u) grid = 4096u;
+    hipLaunchKernelGGL(d3lk_rnames_late, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError()); }
+#else
+  LAUNCH_Q(d3l_rnames_late, v, v.NS, 0);
+#endif
+  v.rn_defer = keep;
+  b->rn_state = all ? 0 : 2;
+}
+
 void enqueue_output_head(snf_batch_impl* b) {
   View& v = b->v;
   const int64_t NS = v.NS;
+  enqueue_rnames_late(b, !((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc));
   if (b->fused && NS <= ((int64_t)1 << 22) * 256) {
 #ifndef SNF_EMU
-    const unsigned grid = (unsigned)((NS + 255) / 256);
-    FUSED(f1k_outflags, NS);
-    FUSED(f2k_outscan, NS);
+    const unsigned grid = (unsigned)((NS + 255) / 256) > 0u ? (unsigned)((NS + 255) / 256) : 1u;
+    FUSED(f1k_outflags, NS > 0 ? NS : 1);
+    FUSED(f2k_outscan, NS > 0 ? NS : 1);
     if ((v.out_mode & SNF_OUT_EXECUTE) && v.cfg.sort) {
       Scope _s(b, "f3_rank", 0);
       hipLaunchKernelGGL(f3k_rank, dim3(grid < 1024u ? grid : 1024u), dim3(256), 0, b->cur, v, (int64_t)0);
@@ -1626,6 +1655,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     return;
   }
   // ---- candidates (stage 0, or no finalize yet): records and read names as the candidate stage left them in HBM
+  if (b->rn_state != 0) { enqueue_rnames_late(b, true); dsync(b); }   // (names were deferred for an execute-mode finalize: all of them now)
   int64_t nc = v.NS > 0 ? b->h_cnt->n_calls : 0;
   int64_t rn_total = v.NS > 0 ? b->h_cnt->rn_total : 0;
   snf_call_t* calls = (snf_call_t*)b->hb_calls.ensure((size_t)(nc + 1) * sizeof(snf_call_t));

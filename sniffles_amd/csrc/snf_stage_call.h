@@ -389,6 +389,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   cc.rn_off = nq;  // stash: number of distinct names already sorted in w1[flo..]
   v.cand[r] = cc;
   CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
+  x.rn_nq = (int32_t)nq; x._pad = 0;
   if (svtype == SNF_INS && !cfg.symbolic) {
     // best lead of annotate_sv (postprocessing.py:33-66): first argmin of |len(seq) - svlen| + |ref_start - pos| * 1.5
     int32_t best = -1, cnt = 0; double best_diff = 0; int32_t best_k = 0x7fffffff;
@@ -506,7 +507,7 @@ SNF_HD void d3_rnames_emit(int64_t i, const View& v) {
   if (i >= v.cnt->n_calls) return;
   snf_call_t& c = v.calls[i];
   const CallX& x = v.callx[i];
-  int64_t nq = c.rn_off;  // stashed by d2
+  int64_t nq = x.rn_nq;   // stashed by d2 (not in c.rn_off: this function may run again - late pass, repeated finalize)
   int64_t off = v.rnp[i];
   const int32_t* a1 = v.w1 + x.flo;
   for (int64_t k = 0; k < nq; k++) v.rnames[off + k] = (uint32_t)a1[k];

@@ -28,9 +28,10 @@ SNF_HD int64_t pf_cell(const View& v, int t, int svtype, uint64_t bin) {
   return c0 + (int64_t)svtype * nb + (int64_t)bin;
 }
 // Leads that arrive together lie within a read length of each other, i.e. in a few hundred neighbouring bins: packed 16 cells
-// to a word their marks would all hit the same two or three cache lines, and atomics on one line are served one after the
-// other by one L2 channel.  pf_slot moves the low five bits of the cell index to the top of a 2^19-cell block: neighbouring
-// cells end up 4 KB apart (another channel each), the working set of a neighbourhood stays one 128-KB block.
+// to a word their marks hit the same two or three cache lines.  Experiment (SNF_PF_SPREAD=1, off by default): pf_slot moves
+// the low five bits of the cell index to the top of a 2^19-cell block, so that neighbouring cells end up 4 KB apart (another L2
+// channel each).  Measured on the 30x genome: the marking kernel gets SLOWER (0.146 ms against 0.111) - the adjacent marks are
+// not queueing on a channel, they share cache lines that the spread version has to fetch one by one.
 SNF_HD int64_t pf_slot(const View& v, int64_t cell) {
   if (!v.pf_spread) return cell;
   const int64_t in = cell & (((int64_t)1 << 19) - 1);

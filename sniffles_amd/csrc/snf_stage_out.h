@@ -29,6 +29,12 @@ SNF_HD bool out_keep(const View& v, const snf_call_t& c) {
 SNF_HD int64_t out_align(int64_t x) { return (x + 255) & ~(int64_t)255; }
 SNF_HD uint8_t* out_base(const View& v) { return v.out_hdr->in_pinned ? v.out_pin : v.out_dev; }
 
+// deferred supporting read names (View::rn_defer): written now, for the calls the output keeps (2: for all of them)
+SNF_HD void d3l_rnames_late_body(int64_t i, const View& v) {
+  if (i >= v.cnt->n_calls) return;
+  if (v.rn_defer == 2 || out_keep(v, v.calls[i])) d3_rnames_emit(i, v);
+}
+
 // F1: keep flag (o_scan doubles as the flag array until f2 has scanned it), sizes
 SNF_HD void f1_values(const View& v, int64_t i, int64_t nc, unsigned long long (&val)[2]) {
   val[0] = val[1] = 0;
@@ -99,6 +105,10 @@ SNF_HD void f2_scan_body(int64_t i, const View& v) {
 // every block of F2 sums the preceding 256-call tiles directly (finalize may run more than once per candidate stage, so the
 // atomically accumulated super-tile sums of the candidate stage's chains are not used here).  The grid covers the upper bound
 // NS; blocks behind the last call publish zeros / return.
+__global__ void __launch_bounds__(256) d3lk_rnames_late(const View v, int64_t n) {
+  const int64_t nc = v.cnt->n_calls;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nc; i += (int64_t)gridDim.x * 256) d3l_rnames_late_body(i, v);
+}
 __global__ void __launch_bounds__(256) f1k_outflags(const View v, int64_t n) {
   __shared__ unsigned long long lds[4 * 2];
   const int64_t nc = v.cnt->n_calls;

@@ -92,6 +92,8 @@ struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t do_cons;
   int32_t cons_id;
   int64_t alt_off;
+  int32_t rn_nq;    // distinct read names d2 left sorted in w1[flo..] (the rest come from leads_long): input of d3_rnames_emit
+  int32_t _pad;
 };
 
 struct View {
@@ -171,6 +173,9 @@ struct View {
   // ---- output stage (snf_stage_out.h): the calls a stage-1 fetch returns, compacted into one block
   int32_t out_mode;          // enum snf_output
   int32_t out_valid;         // host: the output stage of this pass has been enqueued (z1_results publishes its offsets)
+  int32_t rn_defer;          // 1: the candidate stage only sizes the supporting read names; finalize writes them for the calls the
+                             //    output keeps (SNF_OUT_EXECUTE: 70 % of the candidates' names would never be looked at); 2: late pass over ALL calls
+  int32_t _pad_out;
   uint32_t* o_scan;          // [n_calls+1] exclusive scan of the keep flags (defined for every call)
   int32_t *o_src, *o_dst, *o_key;   // [n_out] compacted index -> call index / final record index / pos (sort key)
   int64_t* o_rn;             // [n_out] offset inside the read-name section

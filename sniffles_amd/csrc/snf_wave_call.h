@@ -234,6 +234,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
       v.cand[r] = cc;
       CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = best_slot; x.n_others = n_others;
       x.do_cons = (best_slot >= 0 && n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; x.cons_id = -1; x.alt_off = 0;
+      x.rn_nq = (int32_t)nq; x._pad = 0;
       v.candx[r] = x;
       v.cdflag[r] = 1;
     }

@@ -190,3 +190,49 @@ def test_slow_alt_kernels_emu(oracle_mod):
 @pytest.mark.gpu
 def test_slow_alt_kernels_are_settled_by_the_fetch_gpu(oracle_mod):
     check_slow_alt(None, oracle_mod)
+
+
+# ---------------------------------------------------------------------------------------------- deferred read names
+def check_deferred_names(L):
+    """SNF_OUT_EXECUTE set before call_candidates: the supporting read names are written late, for the kept calls only.  A
+    stage-0 fetch in between still sees every candidate's names, and a later switch of the mode still gets them all."""
+    tis = tasks()
+    cfg = SnifflesConfig()
+    ref0 = None
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.call_candidates()
+        ref0 = b.fetch(0)
+        b.finalize()
+        ref1 = b.fetch(1)
+    with lib.Batch(cfg, tis, _lib=L) as b:
+        b.set_output(abi.OUT_EXECUTE)
+        b.call_candidates()
+        got0 = b.fetch(0)                       # all names, written by the late pass
+        b.finalize()
+        exe = b.fetch(1)
+        b.finalize()                            # (again: idempotent)
+        exe2 = b.fetch(1)
+        b.set_output(abi.OUT_CANDIDATES)        # mode switched after the candidate stage
+        b.finalize()
+        cand = b.fetch(1)
+    assert got0.calls.tobytes() == ref0.calls.tobytes() and got0.rnames.tobytes() == ref0.rnames.tobytes()
+    assert exe.calls.tobytes() == exe2.calls.tobytes() and exe.rnames.tobytes() == exe2.rnames.tobytes()
+    assert cand.calls.tobytes() == ref1.calls.tobytes() and cand.rnames.tobytes() == ref1.rnames.tobytes()
+    keep = np.concatenate(expected_execute(ref1, cfg))
+    assert [exe.rn(k).tolist() for k in range(len(exe.calls))] == [ref1.rn(i).tolist() for i in keep.tolist()]
+    with lib.Batch(cfg, tis, _lib=L) as b:      # finalize straight after the candidate stage: names of the kept calls only
+        b.set_output(abi.OUT_EXECUTE)
+        b.call_candidates()
+        b.finalize()
+        exe3 = b.fetch(1)
+    assert exe3.calls.tobytes() == exe.calls.tobytes() and exe3.rnames.tobytes() == exe.rnames.tobytes()
+
+
+def test_deferred_read_names_simt():
+    from emu import simt as S
+    check_deferred_names(S.lib())
+
+
+@pytest.mark.gpu
+def test_deferred_read_names_gpu():
+    check_deferred_names(None)
