@@ -204,6 +204,14 @@ typedef struct snf_task_input {
   int64_t n_tr;
   const int32_t* tr_start;
   const int32_t* tr_end;
+
+  /* LeadProvider._mask_N_coverage (leadprov.py:420-443): with --reference the coverage vector is set to 0 wherever the
+   * reference base is 'N' (byte 78).  The mask as intervals [nmask_start[k], nmask_end[k]) - sorted, disjoint, inside
+   * [0, contig_len); n_nmask == 0: no mask.  Reading the FASTA is the host's business (sniffles_amd.soa.nmask_intervals
+   * turns a sequence into the intervals). */
+  int64_t n_nmask;
+  const int32_t* nmask_start;
+  const int32_t* nmask_end;
 } snf_task_input_t;
 
 /*

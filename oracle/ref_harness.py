@@ -116,6 +116,25 @@ def build_task(ti, cfg):
     lp.start, lp.end = 0, ti.contig_len
     for s, e in zip(ti.read_start.tolist(), ti.read_end.tolist()):
         lp.coverage[s:e] += 1
+    if getattr(ti, "nmask_start", None) is not None and len(ti.nmask_start):
+        # the reference's own _mask_N_coverage (leadprov.py:420-443) over a FASTA stand-in that has 'N' exactly on the task's
+        # mask intervals (build_leadtab calls it after the regions have been read)
+        seq = np.full(ti.contig_len, ord("A"), np.uint8)
+        for a, e in zip(ti.nmask_start.tolist(), ti.nmask_end.tolist()):
+            seq[a:e] = ord("N")
+
+        class _Fasta:
+            def __init__(self, path):
+                pass
+
+            def fetch(self, contig, start=None, end=None):
+                return seq[start:end].tobytes().decode("ascii")
+        keep_ref, keep_cls = cfg.reference, ref.leadprov.pysam.FastaFile
+        cfg.reference, ref.leadprov.pysam.FastaFile = "reference.fa", _Fasta
+        try:
+            lp._mask_N_coverage()
+        finally:
+            cfg.reference, ref.leadprov.pysam.FastaFile = keep_ref, keep_cls
     bs = cfg.cluster_binsize
     for ld in build_leads(ti):
         # build_leadtab keeps only leads inside the task region (leadprov.py:464-468)

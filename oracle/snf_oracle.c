@@ -1108,8 +1108,12 @@ static void build_coverage(Task* T) {
   }
   T->coverage = (uint16_t*)malloc((size_t)(L + 1) * sizeof(uint16_t));
   int64_t run = 0; uint64_t total = 0;
-  for (int64_t i = 0; i < L; i++) { run += diff[i]; T->coverage[i] = (uint16_t)run; total += (uint16_t)run; }
+  for (int64_t i = 0; i < L; i++) { run += diff[i]; T->coverage[i] = (uint16_t)run; }
   free(diff);
+  /* LeadProvider._mask_N_coverage (leadprov.py:420-443): coverage[mask == 78] = 0, after all regions have been read */
+  for (int64_t k = 0; k < in->n_nmask; k++)
+    for (int64_t i = in->nmask_start[k]; i < in->nmask_end[k] && i < L; i++) T->coverage[i] = 0;
+  for (int64_t i = 0; i < L; i++) total += T->coverage[i];
   T->coverage_average_total = L > 0 ? (double)total / (double)L : NAN;
   for (int h = 0; h < 3; h++) {
     T->hapref[h] = (uint16_t*)malloc((size_t)(nb + 1) * sizeof(uint16_t));

@@ -79,7 +79,8 @@ class snf_task_input_t(C.Structure):
                 [("seq_pool_len", i64), ("seq_pool", u8p),
                  ("n_reads", i64), ("read_start", C.POINTER(C.c_int32)), ("read_end", C.POINTER(C.c_int32)),
                  ("read_hp", u8p),
-                 ("n_tr", i64), ("tr_start", C.POINTER(C.c_int32)), ("tr_end", C.POINTER(C.c_int32))])
+                 ("n_tr", i64), ("tr_start", C.POINTER(C.c_int32)), ("tr_end", C.POINTER(C.c_int32)),
+                 ("n_nmask", i64), ("nmask_start", C.POINTER(C.c_int32)), ("nmask_end", C.POINTER(C.c_int32))])
 
 
 class snf_call_t(C.Structure):
@@ -329,7 +330,18 @@ def task_struct(ti: TaskInput, keep: list) -> snf_task_input_t:
         keep += [ts, te]
         t.n_tr = int(ts.shape[0])
         t.tr_start, t.tr_end = _ptr(ts, C.c_int32), _ptr(te, C.c_int32)
+    _nmask(t, ti, keep)
     return t
+
+
+def _nmask(t, ti, keep: list) -> None:
+    ns, ne = getattr(ti, "nmask_start", None), getattr(ti, "nmask_end", None)
+    t.n_nmask = 0
+    if ns is not None and len(ns):
+        ns, ne = np.ascontiguousarray(ns, np.int32), np.ascontiguousarray(ne, np.int32)
+        keep += [ns, ne]
+        t.n_nmask = int(ns.shape[0])
+        t.nmask_start, t.nmask_end = _ptr(ns, C.c_int32), _ptr(ne, C.c_int32)
 
 
 def task_meta_struct(ti, keep: list) -> snf_task_input_t:
@@ -345,6 +357,7 @@ def task_meta_struct(ti, keep: list) -> snf_task_input_t:
         keep += [ts, te]
         t.n_tr = int(ts.shape[0])
         t.tr_start, t.tr_end = _ptr(ts, C.c_int32), _ptr(te, C.c_int32)
+    _nmask(t, ti, keep)
     return t
 
 

@@ -78,6 +78,8 @@ SNF_KERNEL(f4_emit, View)
 SNF_KERNEL(s1_blockcov, BlockCov)
 SNF_KERNEL(s2_covends, CovCalls)
 SNF_KERNEL(s2_covcalls, CovCalls)
+SNF_KERNEL(d5x_covexact, CovExact)
+SNF_KERNEL(r3_maxdepth, MaxDepth)
 
 // read preparation (coverage rank structures + REF haplotype prefix counts)
 struct ReadPrep {
@@ -277,6 +279,9 @@ struct snf_batch_impl {
   std::vector<uint8_t> task_on_device;   // 1: the task's array pointers are HBM of this device (snf_batch_add_task_device)
   std::vector<int64_t> h_lead_off{0}, h_read_off{0}, h_tr_off{0}, h_pool_off{0};
   std::vector<int32_t> h_trs, h_tre, h_trp, h_has_tr;
+  std::vector<int32_t> h_nms, h_nme; std::vector<int64_t> h_nm_off{0};   // reference 'N' mask intervals per task
+  std::vector<int32_t> h_cov_exact;                                        // per task: coverage means by the exact walk
+  int32_t* d_max_depth = nullptr;
   // device
   std::vector<DevBuf> bufs;
   uint8_t* slab = nullptr; size_t slab_cap = 0, slab_used = 0, slab_next = (size_t)64 << 20;  // bump allocator (dalloc)
@@ -945,6 +950,10 @@ void do_upload(snf_batch_impl* b) {
   rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.re_top = v.re_top; rp.R = R;
   rp.fs2 = dalloc<uint64_t>(b, R + 1); rp.fe2 = dalloc<uint64_t>(b, R + 1);
   v.tr_start = upload_vec(b, b->h_trs); v.tr_end = upload_vec(b, b->h_tre); v.tr_pmax = upload_vec(b, b->h_trp);
+  v.nm_start = nullptr; v.nm_end = nullptr; v.t_nm_off = nullptr; v.t_cov_exact = nullptr;
+  if (!b->h_nms.empty()) { v.nm_start = upload_vec(b, b->h_nms); v.nm_end = upload_vec(b, b->h_nme); v.t_nm_off = upload_vec(b, b->h_nm_off); }
+  b->d_max_depth = dalloc<int32_t>(b, (size_t)T + 1);
+  dzero(b, b->d_max_depth, sizeof(int32_t) * ((size_t)T + 1));
   size_t N1 = (size_t)N + 1;
   v.key_in = dalloc<uint64_t>(b, N); v.key_out = dalloc<uint64_t>(b, N); v.val_in = dalloc<uint32_t>(b, N); v.val_out = dalloc<uint32_t>(b, N);
   {  // occupancy prefilter (snf_stage_cluster.h a0_*): only worth it when a cell with one lead can never seed a cluster
@@ -1029,6 +1038,27 @@ void do_upload(snf_batch_impl* b) {
   }
   const double t_index0 = now_ms();
   { const bool tm = b->timing; b->timing = false; enqueue_read_index(b); b->timing = tm; }   // (no event brackets outside a pass)
+  {  // can the uint16 coverage vector wrap (leadprov.py:451)?  Only where 65536 reads overlap: the largest depth of every task,
+     // once - tasks with fewer reads than that are skipped on the host
+    bool any_deep = false;
+    for (int t = 0; t < T; t++) any_deep |= b->tasks[(size_t)t].n_reads >= 65536;
+    std::vector<int32_t> maxd((size_t)T, 0);
+    if (any_deep && R > 0) {
+      MaxDepth md{v.r_start, v.re_sorted, v.rs_top, v.re_top, v.r_task, v.t_read_off, b->d_max_depth};
+      const bool tm = b->timing; b->timing = false;
+      LAUNCH_Q(r3_maxdepth, md, R, R * 8);
+      b->timing = tm;
+      d2h(b, maxd.data(), b->d_max_depth, sizeof(int32_t) * (size_t)T);
+      dsync(b);
+    }
+    b->h_cov_exact.assign((size_t)T, 0);
+    bool any = false;
+    for (int t = 0; t < T; t++) {
+      const bool masked = b->h_nm_off[(size_t)t + 1] > b->h_nm_off[(size_t)t];
+      if (masked || maxd[(size_t)t] >= 65536 || getenv("SNF_COV_EXACT")) { b->h_cov_exact[(size_t)t] = 1; any = true; }
+    }
+    if (any) v.t_cov_exact = upload_vec(b, b->h_cov_exact);
+  }
   dsync(b);
   b->reads_ready = true;
   b->uploaded = true;
@@ -1080,6 +1110,15 @@ void enqueue_read_prep(snf_batch_impl* b) {
     LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
 #endif
   }
+  if (v.t_cov_exact)
+    for (int t = 0; t < T; t++) if (b->h_cov_exact[(size_t)t]) {   // (rare: masked / wrapping tasks) the exact sum of the masked uint16 vector
+      CovExact p{};
+      p.q.r_start = v.r_start; p.q.re_sorted = v.re_sorted; p.q.rs_top = v.rs_top; p.q.re_top = v.re_top;
+      p.q.lo = b->h_read_off[(size_t)t]; p.q.hi = b->h_read_off[(size_t)t + 1]; p.q.L = b->tasks[(size_t)t].contig_len;
+      p.q.nm_start = v.nm_start; p.q.nm_end = v.nm_end; p.q.nm_lo = b->h_nm_off[(size_t)t]; p.q.nm_hi = b->h_nm_off[(size_t)t + 1];
+      p.out = v.t_cov_sum + t;
+      LAUNCH_Q(d5x_covexact, p, (p.q.L + SNF_COVX_CHUNK - 1) / SNF_COVX_CHUNK, 0);
+    }
   LAUNCH_Q(d5_covavg, v, T, 0);
   }
 }
@@ -1709,6 +1748,17 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
     b->h_trp.push_back(pm);
   }
   b->h_has_tr.push_back(ntr > 0 ? 1 : 0);  // tr None or [] -> no TR handling (cluster.py:229-235)
+  {
+    const int64_t nn = t->n_nmask > 0 ? t->n_nmask : 0;
+    if (nn > 0 && (!t->nmask_start || !t->nmask_end)) fail("null mask arrays");
+    int32_t prev = 0;
+    for (int64_t i = 0; i < nn; i++) {
+      const int32_t a = t->nmask_start[i], e = t->nmask_end[i];
+      if (a < prev || e <= a || e > t->contig_len) fail("mask intervals must be sorted, disjoint, non-empty and inside the contig (leadprov.py:434-441)");
+      b->h_nms.push_back(a); b->h_nme.push_back(e); prev = e;
+    }
+    b->h_nm_off.push_back((int64_t)b->h_nms.size());
+  }
   b->h_lead_off.push_back(b->h_lead_off.back() + n);
   b->h_read_off.push_back(b->h_read_off.back() + r);
   b->h_pool_off.push_back(b->h_pool_off.back() + t->seq_pool_len);
@@ -1812,6 +1862,7 @@ void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int
     q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
     q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
     q.L = b->tasks[(size_t)task_index].contig_len; q.n = n;
+    q.nm_start = b->v.nm_start; q.nm_end = b->v.nm_end; q.nm_lo = b->h_nm_off[(size_t)task_index]; q.nm_hi = b->h_nm_off[(size_t)task_index + 1];
     q.binsize = b->cfg.coverage_binsize; q.updown = b->cfg.coverage_updown_bins;
     int32_t* d_t = dalloc_own<int32_t>(b, (size_t)n); int32_t* d_p = dalloc_own<int32_t>(b, (size_t)n); int32_t* d_l = dalloc_own<int32_t>(b, (size_t)n);
     uint8_t* d_f = dalloc_own<uint8_t>(b, (size_t)n);
@@ -1971,6 +2022,7 @@ void do_add_task_device(snf_batch_impl* b, snf_extract_t* x, const snf_task_inpu
   if (dev != b->device) fail("snf_batch_add_task_device: the extraction ran on another device");
   t.task_id = meta->task_id; t.sv_id_start = meta->sv_id_start; t.contig_len = meta->contig_len;
   t.n_tr = meta->n_tr; t.tr_start = meta->tr_start; t.tr_end = meta->tr_end;
+  t.n_nmask = meta->n_nmask; t.nmask_start = meta->nmask_start; t.nmask_end = meta->nmask_end;
   // (ps_null_rank and qc_nm_threshold are the extraction's own)
   const uint8_t* pool = t.seq_pool;
   const int64_t pool_len = t.seq_pool_len, n = t.n_leads, r = t.n_reads;
@@ -2298,6 +2350,8 @@ int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsiz
     q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
     q.lo = b->h_read_off[(size_t)task_index]; q.hi = b->h_read_off[(size_t)task_index + 1];
     q.L = b->tasks[(size_t)task_index].contig_len; q.first_bin = first_bin; q.binsize = binsize;
+    q.nm_start = b->v.nm_start; q.nm_end = b->v.nm_end; q.nm_lo = b->h_nm_off[(size_t)task_index]; q.nm_hi = b->h_nm_off[(size_t)task_index + 1];
+    q.exact = b->h_cov_exact.empty() ? 0 : b->h_cov_exact[(size_t)task_index];
     q.out = dalloc_own<int32_t>(b, (size_t)n_bins);
     LAUNCH(s1_blockcov, q, n_bins, (q.hi - q.lo) * 8 + n_bins * 4);
     d2h(b, out, q.out, (size_t)n_bins * 4);

@@ -5,6 +5,7 @@
 // calculate_bounds (sv.py:484-639), util.center/trim/stdev/most_common_top (util.py:25-103).
 #pragma once
 #include "snf_stage_cluster.h"
+#include "snf_cov.h"
 
 namespace snf {
 
@@ -528,6 +529,15 @@ SNF_HD void d3_rnames_emit(int64_t i, const View& v) {
 // ------------------------------------------------------------------------------------------ coverage
 // coverage(x) of the reference's dense uint16 vector (leadprov.py:451,510) as rank queries:
 // #(start <= x) - #(end <= x) over the task's reads, modulo 2^16
+SNF_HD Reads reads_of(const View& v, int t) {
+  Reads q;
+  q.r_start = v.r_start; q.re_sorted = v.re_sorted; q.rs_top = v.rs_top; q.re_top = v.re_top;
+  q.lo = v.t_read_off[t]; q.hi = v.t_read_off[t + 1]; q.L = v.t_contig_len[t];
+  q.nm_start = v.nm_start; q.nm_end = v.nm_end;
+  q.nm_lo = v.t_nm_off ? v.t_nm_off[t] : 0; q.nm_hi = v.t_nm_off ? v.t_nm_off[t + 1] : 0;
+  return q;
+}
+SNF_HD bool view_masked(const View& v, int t, int64_t idx) { return v.t_nm_off && v.t_nm_off[t] < v.t_nm_off[t + 1] && cov_masked(reads_of(v, t), idx); }
 SNF_HD bool cov_get(const View& v, int t, int64_t idx, int32_t* out) {
   int64_t len = v.t_contig_len[t];
   if (idx < -len || idx >= len) return false;  // IndexError: the field keeps its value
@@ -535,7 +545,7 @@ SNF_HD bool cov_get(const View& v, int t, int64_t idx, int32_t* out) {
   int64_t lo = v.t_read_off[t], hi = v.t_read_off[t + 1];
   int64_t ns = bound_top_i32<true>(v.r_start, v.rs_top, lo, hi, idx) - lo;
   int64_t ne = bound_top_i32<true>(v.re_sorted, v.re_top, lo, hi, idx) - lo;
-  *out = (int32_t)((uint64_t)(ns - ne) & 0xffffu);
+  *out = view_masked(v, t, idx) ? 0 : (int32_t)((uint64_t)(ns - ne) & 0xffffu);
   return true;
 }
 
@@ -549,7 +559,7 @@ SNF_HD bool cov_get_near(const View& v, int t, int64_t idx, int32_t* out, int64_
   const int64_t ps = *hs < 0 ? bound_top_i32<true>(v.r_start, v.rs_top, lo, hi, idx) : upper_bound_hint_i32(v.r_start, lo, hi, idx, *hs);
   const int64_t pe = *he < 0 ? bound_top_i32<true>(v.re_sorted, v.re_top, lo, hi, idx) : upper_bound_hint_i32(v.re_sorted, lo, hi, idx, *he);
   *hs = ps; *he = pe;
-  *out = (int32_t)((uint64_t)(ps - pe) & 0xffffu);
+  *out = view_masked(v, t, idx) ? 0 : (int32_t)((uint64_t)(ps - pe) & 0xffffu);
   return true;
 }
 
@@ -590,6 +600,7 @@ SNF_HD void d5_covsum_body(int64_t j, const View& v) {
   for (int64_t r = lo; r < hi; r++) {
     int tr = v.r_task[r];
     if (tr != t) { atomic_add_u64(&v.t_cov_sum[t], acc); acc = 0; t = tr; }
+    if (v.t_cov_exact && v.t_cov_exact[tr]) continue;      // d5x_covexact forms this task's sum (mask / uint16 wrap)
     int64_t L = v.t_contig_len[tr];
     int64_t s = v.r_start[r], e = v.r_end[r];
     if (s < 0) s = 0; if (s > L) s = L;
@@ -597,6 +608,32 @@ SNF_HD void d5_covsum_body(int64_t j, const View& v) {
     if (e > s) acc += (unsigned long long)(e - s);
   }
   atomic_add_u64(&v.t_cov_sum[t], acc);
+}
+// coverage.mean() of a task whose vector is masked or wraps: the exact sum of the masked uint16 vector, 4096 positions per thread
+#define SNF_COVX_CHUNK 4096
+struct CovExact { Reads q; unsigned long long* out; };
+SNF_HD void d5x_covexact_body(int64_t j, const CovExact& p) {
+  const int64_t a = j * SNF_COVX_CHUNK;
+  if (a >= p.q.L) return;
+  const int64_t b = a + SNF_COVX_CHUNK < p.q.L ? a + SNF_COVX_CHUNK : p.q.L;
+  const uint64_t s = cov_range_sum(p.q, a, b);
+  if (s) atomic_add_u64(p.out, (unsigned long long)s);
+}
+// largest depth of a task = the depth right at some read's start: decides at upload whether uint16 can wrap at all
+struct MaxDepth { const int32_t *r_start, *re_sorted, *rs_top, *re_top; const int32_t* r_task; const int64_t* t_read_off; int32_t* t_max_depth; };
+SNF_HD void r3_maxdepth_body(int64_t r, const MaxDepth& p) {
+  const int t = p.r_task[r];
+  const int64_t lo = p.t_read_off[t], hi = p.t_read_off[t + 1];
+  const int64_t x = p.r_start[r];
+  if (r + 1 < hi && p.r_start[r + 1] == x) return;     // (the last read of equal starts sees them all)
+  const int64_t ns = r + 1 - lo;
+  const int64_t ne = bound_top_i32<true>(p.re_sorted, p.re_top, lo, hi, x) - lo;
+  const int32_t d = (int32_t)(ns - ne);
+#if defined(__HIP_DEVICE_COMPILE__)
+  atomicMax(&p.t_max_depth[t], d);
+#else
+  if (d > p.t_max_depth[t]) p.t_max_depth[t] = d;
+#endif
 }
 SNF_HD void d5_covavg_body(int64_t t, const View& v) {
   int64_t L = v.t_contig_len[t];
@@ -611,6 +648,7 @@ struct BlockCov {
   const int32_t *r_start, *re_sorted, *rs_top, *re_top;
   int64_t lo, hi;      // the task's reads
   int64_t L;           // contig length
+  const int32_t *nm_start, *nm_end; int64_t nm_lo, nm_hi; int32_t exact, _pad;   // mask intervals; exact: sum by cov_range_sum
   int64_t first_bin;   // bin j covers [j * binsize, (j + 1) * binsize)
   int32_t binsize;
   int32_t* out;        // rounded mean depth, -1: bin beyond the padded vector (IndexError in the reference, bin skipped)
@@ -625,7 +663,12 @@ SNF_HD void s1_blockcov_body(int64_t i, const BlockCov& q) {
   const int64_t bs = q.binsize, x0 = (q.first_bin + i) * bs;
   if (x0 >= q.L) { q.out[i] = -1; return; }
   const int64_t x1 = x0 + bs < q.L ? x0 + bs : q.L;
-  const int64_t sum = blockcov_side(q.r_start, q.rs_top, q.lo, q.hi, x0, x1) - blockcov_side(q.re_sorted, q.re_top, q.lo, q.hi, x0, x1);
+  int64_t sum;
+  if (q.exact) {
+    Reads r; r.r_start = q.r_start; r.re_sorted = q.re_sorted; r.rs_top = q.rs_top; r.re_top = q.re_top; r.lo = q.lo; r.hi = q.hi; r.L = q.L;
+    r.nm_start = q.nm_start; r.nm_end = q.nm_end; r.nm_lo = q.nm_lo; r.nm_hi = q.nm_hi;
+    sum = (int64_t)cov_range_sum(r, x0, x1);
+  } else sum = blockcov_side(q.r_start, q.rs_top, q.lo, q.hi, x0, x1) - blockcov_side(q.re_sorted, q.re_top, q.lo, q.hi, x0, x1);
   const int64_t quo = sum / bs, rem = sum % bs;   // sum >= 0: a read ends after it starts
   q.out[i] = (int32_t)(quo + ((2 * rem > bs || (2 * rem == bs && (quo & 1))) ? 1 : 0));
 }
@@ -637,6 +680,7 @@ SNF_HD void s1_blockcov_body(int64_t i, const BlockCov& q) {
 struct CovCalls {
   const int32_t *r_start, *re_sorted, *rs_top, *re_top;
   int64_t lo, hi, L, n;
+  const int32_t *nm_start, *nm_end; int64_t nm_lo, nm_hi;   // mask intervals of the task
   int32_t binsize, updown;
   const int32_t *svtype, *pos, *svlen; const uint8_t* bnd_is_first;
   int64_t* end;        // [n] scratch: `end` as the loop of the reference sees it at call i
@@ -658,7 +702,8 @@ SNF_HD void covcalls_sample(const CovCalls& q, int64_t idx, int32_t* out) {
   if (idx < 0) idx += q.L;
   const int64_t ns = bound_top_i32<true>(q.r_start, q.rs_top, q.lo, q.hi, idx) - q.lo;
   const int64_t ne = bound_top_i32<true>(q.re_sorted, q.re_top, q.lo, q.hi, idx) - q.lo;
-  *out = (int32_t)((uint64_t)(ns - ne) & 0xffffu);
+  Reads r; r.nm_start = q.nm_start; r.nm_end = q.nm_end; r.nm_lo = q.nm_lo; r.nm_hi = q.nm_hi;
+  *out = cov_masked(r, idx) ? 0 : (int32_t)((uint64_t)(ns - ne) & 0xffffu);
 }
 SNF_HD void s2_covcalls_body(int64_t i, const CovCalls& q) {
   if (i >= q.n_valid[0]) return;

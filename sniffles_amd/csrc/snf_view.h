@@ -136,6 +136,11 @@ struct View {
   uint64_t* pc_e2;           // [R+1] same in end order
   uint32_t* rflag;           // [R+1] scan scratch
 
+  // ---- reference 'N' mask of the coverage vector (leadprov.py:420-443) and tasks whose coverage means need the exact walk
+  const int32_t *nm_start, *nm_end;   // [NNM] mask intervals, concatenated over the tasks
+  const int64_t* t_nm_off;            // [T+1] (null: no task has a mask)
+  const int32_t* t_cov_exact;         // [T] 1: mask present or depth >= 65536 somewhere (uint16 wrap): means by cov_range_sum (snf_cov.h)
+
   // ---- tandem repeats [NTR]
   const int32_t* tr_start; const int32_t* tr_end; const int32_t* tr_pmax;
 

@@ -368,6 +368,7 @@ __global__ void __launch_bounds__(256) d5w_covsum(const View v, int64_t n_unused
     const int64_t hi = base + CH < v.R ? base + CH : v.R;
     const int t0 = v.r_task[base], t1 = v.r_task[hi - 1];
     for (int t = t0; t <= t1; t++) {  // one pass per task present in the chunk (one, rarely two)
+      if (v.t_cov_exact && v.t_cov_exact[t]) continue;   // d5x_covexact forms this task's sum (mask / uint16 wrap; uniform for the block)
       const int64_t L = v.t_contig_len[t];
       unsigned long long acc = 0;
       for (int64_t r = base + tid; r < hi; r += 256) {

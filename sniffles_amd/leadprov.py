@@ -53,6 +53,7 @@ class LeadProvider:
         self.read_count = 0
         self._leads = []
         self._reads = []
+        self._nmask = None
 
     def record_lead(self, ld: Lead, pos_leadtab: int = None) -> None:
         """Same call as the reference; `pos_leadtab` (the 100-bp bin) is recomputed on the GPU."""
@@ -61,6 +62,26 @@ class LeadProvider:
     def record_read(self, ref_start: int, ref_end: int, hp: int = 0) -> None:
         self._reads.append((int(ref_start), int(ref_end), int(hp)))
         self.read_count += 1
+
+    def _mask_N_coverage(self, regions=None, fasta=None) -> None:
+        """`LeadProvider._mask_N_coverage` (leadprov.py:420-443): with `config.reference`, coverage reads as 0 wherever the
+        reference base is 'N'.  `fasta`: anything with pysam's `fetch(contig[, start, end])` (the host's business; the
+        device takes the mask as intervals).  Failures to open / fetch only skip the masking, as in the reference."""
+        import logging
+        from .soa import nmask_intervals
+        if not getattr(self.config, "reference", None) or fasta is None:
+            return
+        try:
+            if regions is None:
+                self._nmask = nmask_intervals(fasta.fetch(self.contig), self.contig_len)
+            else:
+                starts, ends = [], []
+                for region in sorted(regions, key=lambda r: r.start):
+                    s, e = nmask_intervals(fasta.fetch(region.contig, region.start, region.end))
+                    starts.append(s + region.start); ends.append(e + region.start)
+                self._nmask = (np.concatenate(starts).astype(np.int32), np.concatenate(ends).astype(np.int32)) if starts else None
+        except Exception as e:  # noqa: BLE001 - the reference logs and goes on unmasked
+            logging.warning(f"Unable to mask N regions in coverage vector, reference could not be fetched: {e}")
 
     def to_task_input(self, task_id: int, sv_id_start: int, tandem_repeats, qc_nm_threshold: float) -> TaskInput:
         n = len(self._leads)
@@ -113,5 +134,7 @@ class LeadProvider:
                        tr_start=None if tandem_repeats is None else np.array([t[0] for t in tandem_repeats], np.int32),
                        tr_end=None if tandem_repeats is None else np.array([t[1] for t in tandem_repeats], np.int32),
                        qc_nm_threshold=qc_nm_threshold, qnames=qn, ps_names=psn, contig_names=cn)
+        if self._nmask is not None:
+            ti.nmask_start, ti.nmask_end = self._nmask
         ti.validate()
         return ti

@@ -46,6 +46,19 @@ LEAD_FIELDS = [
 ]
 
 
+def nmask_intervals(sequence, contig_len: int = None):
+    """`_mask_N_coverage` masks `coverage[mask == 78]` (leadprov.py:434-441): the runs of the byte 'N' (upper case only) of the
+    reference sequence as sorted, disjoint intervals (start[], end[]), clipped to the contig."""
+    if isinstance(sequence, str):
+        sequence = sequence.encode("ascii")
+    a = np.frombuffer(sequence, np.uint8) if not isinstance(sequence, np.ndarray) else sequence
+    if contig_len is not None:
+        a = a[:contig_len]
+    m = np.concatenate([[0], (a == 78).astype(np.int8), [0]])
+    d = np.diff(m)
+    return np.flatnonzero(d == 1).astype(np.int32), np.flatnonzero(d == -1).astype(np.int32)
+
+
 @dataclass
 class TaskInput:
     """All inputs of one contig task, SoA."""
@@ -63,6 +76,10 @@ class TaskInput:
     # tandem repeats, already padded (util.load_tandem_repeats, util.py:121-147); None = no annotation
     tr_start: Optional[np.ndarray] = None
     tr_end: Optional[np.ndarray] = None
+    # LeadProvider._mask_N_coverage (leadprov.py:420-443): intervals [start, end) where the reference base is 'N' (coverage
+    # reads as 0 there); None = no reference given
+    nmask_start: Optional[np.ndarray] = None
+    nmask_end: Optional[np.ndarray] = None
     # side channel written by iter_region (leadprov.py:577-578)
     qc_nm_threshold: float = 0.02
     # string tables for materialisation (host only)
@@ -105,6 +122,10 @@ class TaskInput:
             raise ValueError("hap must be 0,1,2 (leadprov.py:403 indexes a 3-array with int(ld.hap))")
         if np.any(self.leads["svtype"] >= N_SVTYPES):
             raise ValueError("svtype code out of range")
+
+    def set_nmask(self, sequence) -> None:
+        """`sequence`: the contig's reference bases (str / bytes / uint8 array, as `fasta.fetch(contig)` returns them)"""
+        self.nmask_start, self.nmask_end = nmask_intervals(sequence, self.contig_len)
 
     def qname(self, qid: int) -> str:
         return self.qnames[qid] if self.qnames is not None else f"q{qid}"

@@ -363,7 +363,45 @@ FUZZ_DEV = {
     "fuzz_9_no_resplit_repeat": (lambda: synth.gen_fuzz(5017, task_id=1), dict(dev_no_resplit_repeat=True), ("--dev-no-resplit-repeat",)),
 }
 
-ALL = {**HAND, **SYNTH, **FUZZ, **FUZZ_DEV}
+def case_nmask_cov():
+    """LeadProvider._mask_N_coverage (leadprov.py:420-443): runs of 'N' in the reference zero the coverage vector - under a
+    DEL's centre sample, around an INS, across the start of the contig (the negative-index wrap of `cv[start-100]` lands in a
+    masked stretch at the contig's end) and over a whole call; coverage.mean() drops accordingly."""
+    rng = np.random.default_rng(17)
+    leads = []
+    for i in range(9):
+        leads.append(dict(svtype="DEL", ref_start=20_600 + i % 4, svlen=-1200, read=f"d{i}", strand="+-"[i % 2]))
+    allele = _rng_seq(rng, 220)
+    for i in range(8):
+        leads.append(dict(svtype="INS", ref_start=60_010 + i % 3, svlen=220, seq=_mutate(rng, allele, 0.03), read=f"i{i}", strand="+-"[i % 2]))
+    for i in range(7):
+        leads.append(dict(svtype="DEL", ref_start=90 + i % 2, svlen=-60, read=f"e{i}", strand="+-"[i % 2]))       # start - 100 < 0
+    for i in range(6):
+        leads.append(dict(svtype="DUP", ref_start=100_000 + i % 3, svlen=3000, read=f"u{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+    ti = mk_task(leads, _reads(24, 0, 70_000) + _reads(11, 30_000, 139_000) + _reads(9, 95_000, 140_000, 1), 140_000)
+    ti.nmask_start = np.array([19_900, 59_850, 60_090, 99_000, 139_700], np.int32)
+    ti.nmask_end = np.array([20_050, 59_950, 60_300, 104_500, 140_000], np.int32)
+    return ti
+
+
+def case_deep_wrap_cov():
+    """The coverage vector is uint16 (leadprov.py:451): 65 536 + k reads over a position read as k - in the five samples of a
+    call, in coverage.mean() and (test_snf.py) in the per-bin means of the SNF writer.  A 3-kb amplicon at 66 000x next to
+    an ordinary stretch."""
+    leads = []
+    for i in range(12):
+        leads.append(dict(svtype="DEL", ref_start=1500 + i % 3, svlen=-300, read=f"a{i}", strand="+-"[i % 2]))
+    for i in range(8):
+        leads.append(dict(svtype="DEL", ref_start=6200 + i % 2, svlen=-80, read=f"b{i}", strand="+-"[i % 2]))
+    reads = _reads(66_000, 400, 2_900) + _reads(200, 1_000, 2_000, 1) + _reads(30, 3_000, 9_000) + _reads(65_535, 2_950, 2_960)
+    return mk_task(leads, reads, 10_000)
+
+
+HAND_COV = {
+    "nmask_cov": (case_nmask_cov, {}, ()),
+    "deep_wrap_cov": (case_deep_wrap_cov, {}, ()),
+}
+ALL = {**HAND, **SYNTH, **FUZZ, **FUZZ_DEV, **HAND_COV}
 
 
 # multi-sample combine (BASELINE.json configs[4] shape, shrunk): samples share sites, not reads ------------------

@@ -56,6 +56,18 @@ def run_case(name, _lib):
         lp.record_lead(ld, int(ld.ref_start / cfg.cluster_binsize) * cfg.cluster_binsize)
     for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
         lp.record_read(s, e, hp)
+    if ti.nmask_start is not None:       # _mask_N_coverage through a FASTA stand-in with 'N' on the task's mask intervals
+        import numpy as np
+        seq = np.full(ti.contig_len, ord("a"), np.uint8)
+        for a, e in zip(ti.nmask_start.tolist(), ti.nmask_end.tolist()):
+            seq[a:e] = ord("N")
+
+        class Fasta:
+            def fetch(self, contig, start=None, end=None):
+                assert contig == ti.contig
+                return seq[start:end].tobytes().decode("ascii")
+        cfg.reference = "reference.fa"
+        lp._mask_N_coverage(fasta=Fasta())
     task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
                              _lib=_lib)
     task.lead_provider = lp
@@ -74,7 +86,7 @@ def run_case(name, _lib):
 
 
 NAMES = ["bnd_first_error", "bnd_stale_end", "merge_inner", "long_ins", "phase_rescue", "consensus_quirks",
-         "chr21_30x_mosaic", "fuzz_4_2", "single_leads_noqc"]
+         "chr21_30x_mosaic", "fuzz_4_2", "single_leads_noqc", "nmask_cov"]
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -177,7 +177,10 @@ def test_reference_reads_our_files(tmp_path):
 def dense_block_coverage(ti, binsize):
     cov = np.zeros(ti.contig_len, np.uint16)
     for s, e in zip(ti.read_start.tolist(), ti.read_end.tolist()):
-        cov[s:e] += 1
+        cov[s:e] += 1                                   # (uint16: wraps at 65536 like the reference's vector, leadprov.py:451, 510)
+    if getattr(ti, "nmask_start", None) is not None:    # _mask_N_coverage (leadprov.py:420-443)
+        for a, e in zip(ti.nmask_start.tolist(), ti.nmask_end.tolist()):
+            cov[a:e] = 0
     pad = -len(cov) % binsize
     return [round(x) for x in np.pad(cov, (0, pad), mode="constant").reshape(-1, binsize).mean(axis=1)]
 
@@ -208,6 +211,46 @@ def test_block_coverage_kernel_emu():
     from sniffles_amd import synth
     tis = [synth.gen_fuzz(7, task_id=0), synth.gen_task(1, "chr20", 777_777, 30, 3), cases.SNF_FILES[NAME][0]()[0]]
     check_block_coverage(tis, E.lib(), (500, 7, 2, 1000))
+
+
+def masked_and_deep_tasks():
+    a, b = cases.case_nmask_cov(), cases.case_deep_wrap_cov()
+    b.task_id = 1
+    return [a, b]
+
+
+def test_block_coverage_of_masked_and_wrapping_vectors_emu():
+    """Reference 'N' mask and the uint16 wrap at depth >= 65536 in the per-bin means of the SNF writer (snf.py:249-267 on the
+    vector of leadprov.py:420-451)."""
+    import emu.emu as E
+    check_block_coverage(masked_and_deep_tasks(), E.lib(), (500, 7, 100))
+
+
+def test_block_coverage_of_masked_and_wrapping_vectors_simt():
+    from emu import simt as S
+    check_block_coverage(masked_and_deep_tasks(), S.lib(), (500, 100))
+
+
+@pytest.mark.gpu
+def test_block_coverage_of_masked_and_wrapping_vectors_gpu():
+    check_block_coverage(masked_and_deep_tasks(), None, (500, 7, 100))
+
+
+def test_exact_coverage_walk_equals_the_closed_forms(monkeypatch, oracle_mod):
+    """SNF_COV_EXACT=1 sends every task through the walk over read starts / ends that masked or wrapping tasks take
+    (snf_cov.h): same coverage.mean(), same block coverages, same calls as the closed forms on ordinary data."""
+    import emu.emu as E
+    from sniffles_amd import lib, records, synth
+    tis = [synth.gen_fuzz(7, task_id=0), synth.gen_task(1, "chr20", 777_777, 30, 3)]
+    cfg = SnifflesConfig()
+    exp = oracle_mod.run(cfg, tis, True)
+    monkeypatch.setenv("SNF_COV_EXACT", "1")
+    with lib.Batch(cfg, tis, _lib=E.lib()) as b:
+        b.call_candidates(); b.finalize()
+        got = b.fetch(1)
+    for t in range(2):
+        assert records.diff_results(got, t, exp, t) == []
+    check_block_coverage(tis, E.lib(), (500, 7))
 
 
 @pytest.mark.gpu
