@@ -256,7 +256,7 @@ def run_calling(ctx):
     W = max(1, args.inflight)
     t0 = time.time()
     # handles[w][g]: batch handle of group g for host thread w (same input, independent handles)
-    handles = [[lib.Batch(cfg, gt, device=local_rank, _lib=emu_lib()) for gt in group_tasks] for _ in range(W)]
+    handles = [[lib.Batch(cfg, gt, device=(0 if EMU else local_rank), _lib=emu_lib()) for gt in group_tasks] for _ in range(W)]
     t_upload = time.time() - t0
     out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist else 0)
     for hs in handles:
@@ -461,7 +461,7 @@ def run_calling(ctx):
     ms_with_index = None
     if world == 1 and not strong and not use_dist and not args.no_wall_clock:
         os.environ["SNF_READPREP_EACH_PASS"] = "1"
-        extra = [[lib.Batch(cfg, tasks, device=local_rank, _lib=emu_lib())] for _ in range(W)]
+        extra = [[lib.Batch(cfg, tasks, device=(0 if EMU else local_rank), _lib=emu_lib())] for _ in range(W)]
         del os.environ["SNF_READPREP_EACH_PASS"]
         handles_box[0] = extra
         k2 = max(W, args.steps // 2)
@@ -717,7 +717,7 @@ def other_configs(ctx) -> dict:
             specs = task_specs(a, wl, 0, 0, 1)
             tasks = [synth.gen_task(**kw) for _, kw in specs]
             W, steps, warm = 3, 12, 3
-            hs = [lib.Batch(cfg, tasks, device=local_rank, _lib=emu_lib()) for _ in range(W)]
+            hs = [lib.Batch(cfg, tasks, device=(0 if EMU else local_rank), _lib=emu_lib()) for _ in range(W)]
             for h in hs:
                 h.set_output(abi.OUT_EXECUTE)
 

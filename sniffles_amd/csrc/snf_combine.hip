@@ -56,7 +56,7 @@ struct LessSupportDesc {
 // the work of a window with kilobase insertions, and one thread doing it serially takes tens of milliseconds per pair.
 template <bool WAVE>
 SNF_HD void combine_run(int64_t p, const CombineView& v) {
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   const int lane = WAVE ? (int)(threadIdx.x & 63) : 0;
 #else
   const int lane = 0;
@@ -102,7 +102,7 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
       int c = 0, sid = 0, best = -1; double best_dist = INFINITY, alen = 0;
       if (lead) { c = order[oi]; sid = sample[c]; alen = fabs((double)svlen[c]); }
       int na_u = na;
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
       if (WAVE) na_u = __shfl(na, 0, 64);
 #endif
       for (int k = 0; k < na_u; k++) {
@@ -144,7 +144,7 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
           kmax = d0;
         }
         int64_t d = 0;
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         if (WAVE) {
           need = __shfl(need, 0, 64);
           if (need) {
@@ -203,11 +203,9 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
 
 SNF_HD void combine_problem_body(int64_t p, const CombineView& v) { combine_run<false>(p, v); }
 
-#ifndef SNF_EMU
 __global__ void __launch_bounds__(64) combine_problem_wave(const CombineView v, int64_t np) {
   for (int64_t p = blockIdx.x; p < np; p += gridDim.x) combine_run<true>(p, v);
 }
-#endif
 
 }  // namespace snf
 using namespace snf;
@@ -304,12 +302,8 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   const size_t o_stsize = L.add<int32_t>(S), o_stmctg = L.add<int32_t>(S), o_stalo = L.add<int64_t>(S), o_stahi = L.add<int64_t>(S);
   const size_t o_stsrc = L.add<uint8_t>(S), o_stalist = L.add<int32_t>(S), o_bits = L.add<uint64_t>((size_t)w_off[np]);
   const size_t o_order = L.add<int32_t>((size_t)NC), o_carry = L.add<int8_t>((size_t)k_off[np] + 16);
-#ifdef SNF_EMU
-  const size_t o_edscr = L.add<uint64_t>((size_t)e_off[np] + 16);
-#else
   const bool thread_form = getenv("SNF_COMBINE_THREAD") != nullptr;
   const size_t o_edscr = L.add<uint64_t>(thread_form ? (size_t)e_off[np] + 16 : 16);
-#endif
   const size_t o_out = L.add<int32_t>((size_t)NC);
   const size_t o_stats = L.add<unsigned long long>(3 * 64 * 16);
   DevArena& A = g_combine_arenas[device];
@@ -348,7 +342,6 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   v.ed_scratch = (uint64_t*)(d + o_edscr);
   v.out_group = (int32_t*)(d + o_out);
   v.stats = (unsigned long long*)(d + o_stats);
-#ifndef SNF_EMU
   hipStream_t st = A.stream;
   bool ok = hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, st) == hipSuccess;
   ok = ok && hipMemsetAsync(d + o_stats, 0, 3 * 64 * 16 * sizeof(unsigned long long), st) == hipSuccess;
@@ -364,11 +357,6 @@ extern "C" int snf_combine_resolve_batch(const snf_config_t* cfg, int device, co
   ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return 1;
   { float ms = 0; if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess) A.last_kernel_ms = ms; }
-#else
-  (void)in_end;
-  memset(d + o_stats, 0, 3 * 64 * 16 * sizeof(unsigned long long));
-  combine_problem(v, np);
-#endif
   {
     const unsigned long long* hs = (const unsigned long long*)(h + o_stats);
     for (int c = 0; c < 3; c++) { unsigned long long t = 0; for (int k = 0; k < 64; k++) t += hs[(c * 64 + k) * 16]; A.last_stats[c] = (long long)t; }
@@ -438,7 +426,6 @@ extern "C" int snf_combine_call_groups(const snf_group_call_config_t* cfg, int d
   v.cand_win = (const int32_t*)(d + o_cwin); v.group_win_hi = (const int32_t*)(d + o_ghi);
   v.win_bin = (const int32_t*)(d + o_wbin); v.win_thr = (const double*)(d + o_wthr);
   v.out = (snf_group_out_t*)(d + o_out); v.chosen = d + o_chosen; v.pos_mean = (double*)(d + o_pm); v.scratch = (int32_t*)(d + o_scr);
-#ifndef SNF_EMU
   hipStream_t st = A.stream;
   bool ok = hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, st) == hipSuccess;
   ok = ok && hipEventRecord(A.ev0, st) == hipSuccess;
@@ -448,10 +435,6 @@ extern "C" int snf_combine_call_groups(const snf_group_call_config_t* cfg, int d
   ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return 1;
   { float ms = 0; if (hipEventElapsedTime(&ms, A.ev0, A.ev1) == hipSuccess) A.last_kernel_ms = ms; }
-#else
-  (void)in_end; (void)out_end;
-  group_call(v, n_groups);
-#endif
   memcpy(out, h + o_out, (size_t)n_groups * sizeof(snf_group_out_t));
   memcpy(member_chosen, h + o_chosen, (size_t)NM);
   memcpy(member_pos_mean, h + o_pm, (size_t)NM * sizeof(double));

@@ -15,13 +15,10 @@ struct DevArena {                // one per (entry point, device)
   std::mutex mu;                 // one call at a time per arena
   int device = -1;
   uint8_t* d = nullptr; uint8_t* h = nullptr; size_t cap = 0;
-#ifndef SNF_EMU
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the kernel(s) of the last call
-#endif
   double last_kernel_ms = 0; long long last_stats[4] = {0, 0, 0, 0};
   bool ensure(int dev, size_t bytes) {
-#ifndef SNF_EMU
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || dev < 0 || dev >= nd) return false;   // no HIP device: the call fails
     if (hipSetDevice(dev) != hipSuccess) return false;
@@ -34,15 +31,6 @@ struct DevArena {                // one per (entry point, device)
     if (hipMalloc((void**)&d, cap) != hipSuccess) { d = nullptr; cap = 0; return false; }
     if (hipHostMalloc((void**)&h, cap, hipHostMallocDefault) != hipSuccess) { (void)hipFree(d); d = h = nullptr; cap = 0; return false; }
     return true;
-#else
-    device = dev;
-    if (bytes <= cap && d) return true;
-    free(d);
-    cap = bytes + 4096;
-    d = h = (uint8_t*)malloc(cap);        // emulation: one buffer is both
-    memset(d, 0xA5, cap);
-    return d != nullptr;
-#endif
   }
 };
 

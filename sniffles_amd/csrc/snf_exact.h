@@ -160,7 +160,7 @@ SNF_HD int32_t center_sorted(const int32_t* s, int64_t n) {
   return s[0];
 }
 
-#if !defined(SNF_EMU) && defined(__HIPCC__)
+#if defined(__HIPCC__)
 // sort_inplace by a whole wave that executes the surrounding code UNIFORMLY (every lane runs the same statements on the same
 // data: the x_big kernels of snf_wave_call.h): lane p ranks the elements p, p + 64, ... against all others (stable: equal
 // elements keep their order) and scatters them through `tmp` (n elements).  O(n^2 / 64) comparisons instead of

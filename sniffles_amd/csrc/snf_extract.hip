@@ -27,9 +27,7 @@
 #include <string>
 #include <vector>
 
-#ifndef SNF_EMU
 #include <rocprim/device/device_scan.hpp>
-#endif
 
 namespace snf {
 
@@ -86,7 +84,7 @@ struct ExView {
 };
 
 // ---- lane helpers: WAVE == true only exists in device code ----------------------------------------------------
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define XDEV 1
 #else
 #define XDEV 0
@@ -697,7 +695,6 @@ SNF_KERNEL(x_count, ExView)
 SNF_KERNEL(x_emit, ExView)
 SNF_KERNEL(x_prep, ExView)
 
-#ifndef SNF_EMU
 // one wave per record and ONE wave per workgroup: a record with split alignments keeps its wave several times longer
 // than a plain one (lane-0 section), and in a four-wave workgroup the three finished waves' slots stayed taken until the
 // slow one was done - with SA tags on 20 % of the records most workgroups had one.  Grid-stride so that any record count
@@ -733,7 +730,6 @@ __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
   }
   if (lane == 0) { v.nm_out[0] = sum; v.nm_out[1] = (double)cnt; }
 }
-#endif
 
 // ================================================================================================= host side ====
 struct snf_extract {
@@ -750,48 +746,29 @@ struct snf_extract {
   snf_extract_result_t res{};
   bool have_input = false, have_result = false, pulled = false;
   int64_t n_leads = 0, n_seq = 0, n_reads = 0;
-#ifndef SNF_EMU
   hipStream_t side = nullptr;   // the serial NM sum runs beside the scans, the host round trip and the emit pass
-#endif
 };
 
 namespace {
 thread_local std::string g_xerr;
 
 void x_free(void* p) {
-#ifndef SNF_EMU
   (void)hipFree(p);
-#else
-  free(p);
-#endif
 }
 template <class T> T* x_alloc(std::vector<void*>& pool, size_t n, size_t pad_bytes = 0) {
   void* p = nullptr;
   const size_t bytes = (n ? n : 1) * sizeof(T) + pad_bytes;
-#ifndef SNF_EMU
   if (hipMalloc(&p, bytes) != hipSuccess) snf::fail("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
-#else
-  p = calloc(1, bytes);
-  if (!p) snf::fail("out of memory");
-#endif
   pool.push_back(p);
   return (T*)p;
 }
 void x_h2d(void* d, const void* h, size_t bytes) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
-#else
-  memcpy(d, h, bytes);
-#endif
 }
 void x_d2h(void* h, const void* d, size_t bytes) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
-#else
-  memcpy(h, d, bytes);
-#endif
 }
 template <class T> T* x_up(std::vector<void*>& pool, const T* h, size_t n, size_t pad_bytes = 0) {
   T* d = x_alloc<T>(pool, n, pad_bytes);
@@ -802,15 +779,10 @@ void x_release(std::vector<void*>& pool) { for (void* p : pool) x_free(p); pool.
 
 int64_t* x_exscan(std::vector<void*>& pool, const int64_t* in, int64_t n) {   // exclusive prefix sums of n elements
   int64_t* out = x_alloc<int64_t>(pool, (size_t)n);
-#ifndef SNF_EMU
   size_t need = 0;
   SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
   void* tmp = x_alloc<uint8_t>(pool, need);
   SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
-#else
-  int64_t acc = 0;
-  for (int64_t i = 0; i < n; i++) { out[i] = acc; acc += in[i]; }
-#endif
   return out;
 }
 
@@ -876,9 +848,7 @@ void pull_result(snf_extract* x) {
   x->h_pool.resize((size_t)n_seq + 1); x_d2h(x->h_pool.data(), v.o_pool, (size_t)n_seq);
   x->h_rs.resize((size_t)n_reads + 1); x->h_re.resize((size_t)n_reads + 1); x->h_rhp.resize((size_t)n_reads + 1);
   x_d2h(x->h_rs.data(), v.o_rstart, (size_t)n_reads * 4); x_d2h(x->h_re.data(), v.o_rend, (size_t)n_reads * 4); x_d2h(x->h_rhp.data(), v.o_rhp, (size_t)n_reads);
-#ifndef SNF_EMU
   SNF_HIP(hipDeviceSynchronize());
-#endif
   snf_task_input_t& t = x->res.task;
   t.ref_start = x->h_i32[0].data(); t.ref_end = x->h_i32[1].data(); t.qry_start = x->h_i32[2].data(); t.qry_end = x->h_i32[3].data();
   t.svlen = x->h_i32[4].data(); t.read_len = x->h_i32[5].data(); t.ps_rank = x->h_i32[6].data(); t.mate_contig = x->h_i32[7].data();
@@ -905,7 +875,6 @@ int do_run(snf_extract* x) {
   const unsigned long long none = ~0ull;
   x_h2d(v.err, &none, 8);
   float ms_count = 0, ms_emit = 0;
-#ifndef SNF_EMU
   const bool thread_form = getenv("SNF_EXTRACT_THREAD") != nullptr;
   hipEvent_t e0, e1, e2, e3;
   SNF_HIP(hipEventCreate(&e0)); SNF_HIP(hipEventCreate(&e1)); SNF_HIP(hipEventCreate(&e2)); SNF_HIP(hipEventCreate(&e3));
@@ -921,13 +890,6 @@ int do_run(snf_extract* x) {
   if (!x->side) SNF_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
   SNF_HIP(hipStreamWaitEvent(x->side, e1, 0));
   hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, x->side, v, n);
-#else
-  x_count(v, n);
-  x_prep(v, n + 1);
-  { double s = 0; int64_t c = 0;
-    for (int64_t i = 0; i < n; i++) if (v.cfg.advanced_tags && v.sum[i].accept && v.sum[i].has_nm) { s += v.sum[i].nm; c++; }
-    v.nm_out[0] = s; v.nm_out[1] = (double)c; }
-#endif
   v.read_idx = x_exscan(P, v.c_acc, n + 1); v.lead_off = x_exscan(P, v.c_leads, n + 1); v.seq_off = x_exscan(P, v.c_seq, n + 1);
   unsigned long long err = none; int64_t n_reads = 0, n_leads = 0, n_seq = 0; double nmv[2] = {0, 0};
   x_d2h(&err, v.err, 8); x_d2h(&n_reads, v.read_idx + n, 8); x_d2h(&n_leads, v.lead_off + n, 8); x_d2h(&n_seq, v.seq_off + n, 8);
@@ -959,7 +921,6 @@ int do_run(snf_extract* x) {
   v.o_hap = x_alloc<uint8_t>(P, L); v.o_is_sa = x_alloc<uint8_t>(P, L); v.o_first = x_alloc<uint8_t>(P, L); v.o_rev = x_alloc<uint8_t>(P, L);
   v.o_pool = x_alloc<uint8_t>(P, (size_t)n_seq);
   v.o_rstart = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rend = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rhp = x_alloc<uint8_t>(P, (size_t)n_reads);
-#ifndef SNF_EMU
   SNF_HIP(hipEventRecord(e2, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
@@ -970,9 +931,6 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipDeviceSynchronize());
   SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
-#else
-  x_emit(v, n);
-#endif
   x_d2h(nmv, v.nm_out, 16);
   x->n_leads = n_leads; x->n_seq = n_seq; x->n_reads = n_reads; x->pulled = false;
   snf_extract_result_t& r = x->res;
@@ -1002,12 +960,10 @@ const char* snf_extract_last_error(void) { return g_xerr.c_str(); }
 
 int snf_extract_create(const snf_extract_config_t* cfg, int device, snf_extract_t** out) {
   if (!cfg || !out) { g_xerr = "snf_extract_create: null argument"; return 1; }
-#ifndef SNF_EMU
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { g_xerr = "no HIP device: the extraction kernels need a gfx950 GPU (there is no CPU fallback)"; return 1; }
   if (device < 0 || device >= nd) { g_xerr = "device index out of range"; return 1; }
   if (hipSetDevice(device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
-#endif
   snf_extract* x = new snf_extract();
   x->cfg = *cfg; x->device = device;
   *out = x;
@@ -1015,24 +971,18 @@ int snf_extract_create(const snf_extract_config_t* cfg, int device, snf_extract_
 }
 int snf_extract_upload(snf_extract_t* x, const snf_extract_input_t* in) {
   if (!x) { g_xerr = "null handle"; return 1; }
-#ifndef SNF_EMU
   if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
-#endif
   X_TRY(do_upload(x, in))
 }
 int snf_extract_run(snf_extract_t* x) {
   if (!x) { g_xerr = "null handle"; return 1; }
-#ifndef SNF_EMU
   if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
-#endif
   X_TRY(do_run(x))
 }
 int snf_extract_result(snf_extract_t* x, snf_extract_result_t* out) {
   if (!x || !out) { g_xerr = "null argument"; return 1; }
   if (!x->have_result) { g_xerr = "snf_extract_result before a successful snf_extract_run"; return 1; }
-#ifndef SNF_EMU
   if (hipSetDevice(x->device) != hipSuccess) { g_xerr = "hipSetDevice failed"; return 1; }
-#endif
   try { pull_result(x); }
   catch (const snf::Error& e) { g_xerr = e.msg; return 1; }
   *out = x->res;
@@ -1067,9 +1017,7 @@ int snf_extract_device_view(snf_extract_t* x, snf_task_input_t* out, int* device
 void snf_extract_destroy(snf_extract_t* x) {
   if (!x) return;
   x_release(x->dev); x_release(x->dev_run);
-#ifndef SNF_EMU
   if (x->side) (void)hipStreamDestroy(x->side);
-#endif
   delete x;
 }
 }

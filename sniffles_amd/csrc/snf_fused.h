@@ -6,7 +6,6 @@
 #include "snf_stage_cluster.h"
 #include "snf_stage_call.h"
 
-#ifndef SNF_EMU
 namespace snf {
 
 // exclusive scan of K 64-bit values per thread over a 256-thread block; tot = block totals.  lds: 4 * K words.
@@ -277,4 +276,3 @@ __global__ void __launch_bounds__(256) e3b_offsets(const View v, int64_t n_unuse
 }
 
 }  // namespace snf
-#endif  // !SNF_EMU

@@ -10,10 +10,8 @@
 #include "snf_wave_call.h"
 #include "snf_ctx.h"
 
-#ifndef SNF_EMU
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#endif
 
 #include <atomic>
 #include <map>
@@ -26,7 +24,6 @@
 
 using namespace snf;
 
-#ifndef SNF_EMU
 // the three instances of the workgroup consensus kernel (snf_wave_cons.h): <class, table slots, sampled positions, others,
 // waves/SIMD it is compiled for, waves per call, vote columns in LDS, staged-read bytes, escape entries>
 #define K_CONS_SMALL(MINW) e45w_consensus<1, 256, 128, 64, MINW, 4, SNF_CONS_SMALL_L, 448, 96>
@@ -35,7 +32,6 @@ using namespace snf;
 #define K_CONS_LARGE_8W e45w_consensus<2, 1024, 512, 256, 2, 8, SNF_CONS_LARGE_L, 0, 512>
 #define K_CONS_LARGE_16W e45w_consensus<2, 1024, 512, 256, 4, 16, SNF_CONS_LARGE_L, 0, 512>
 #define K_CONS_ROWS e45w_consensus<4, 1024, 512, 512, 3>
-#endif
 
 // ---------------------------------------------------------------------------------------------- kernels
 SNF_KERNEL(a1_keys, View)
@@ -134,12 +130,8 @@ struct SlabCache {
     }
     size_t bytes = 0;
     for (auto& e : gone) {
-#ifndef SNF_EMU
       int cur = 0; (void)hipGetDevice(&cur);
       (void)hipSetDevice(e.device); (void)hipFree(e.p); (void)hipSetDevice(cur);
-#else
-      free(e.p);
-#endif
       bytes += e.bytes;
     }
     return bytes;
@@ -178,11 +170,7 @@ struct PinnedCache {
     { std::lock_guard<std::mutex> g(mu); gone.swap(free_list); }
     size_t bytes = 0;
     for (auto& e : gone) {
-#ifndef SNF_EMU
       (void)hipHostFree(e.p);
-#else
-      free(e.p);
-#endif
       bytes += e.cap;
     }
     return bytes;
@@ -216,26 +204,18 @@ struct HostBuf {
     if (c && got <= 4 * bytes + ((size_t)64 << 20)) { p = c; cap = got; return p; }
     if (c) g_pinned.give(c, got);
     cap = bytes + bytes / 4 + 4096;
-#ifndef SNF_EMU
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {   // idle pinned buffers of finished batches go first, then once more
       (void)hipGetLastError();
       p = nullptr;
       g_pinned.trim();
       SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
     }
-#else
-    p = malloc(cap);
-#endif
     return p;
   }
   void release() {
     if (!p) return;
     if (!g_pinned.give(p, cap)) {
-#ifndef SNF_EMU
       (void)hipHostFree(p);
-#else
-      free(p);
-#endif
     }
     p = nullptr; cap = 0;
   }
@@ -289,10 +269,8 @@ struct snf_batch_impl {
   ReadPrep rp{};
   Counts* h_cnt = nullptr;        // counters as last read back (lives in the pinned result block hb_res)
   void* sort_tmp[2] = {nullptr, nullptr}; size_t sort_tmp_bytes[2] = {0, 0};  // rocPRIM temp storage per stream
-#ifndef SNF_EMU
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr, ev_base = nullptr,
              ev_counts = nullptr, ev_rn = nullptr, ev_join4 = nullptr, ev_e3 = nullptr;  // host waits: counters published (main), read-name total published (side)
-#endif
   // growable finalize scratch
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   // results (host)
@@ -308,10 +286,8 @@ struct snf_batch_impl {
   // timing
   std::vector<Timing> timings;
   std::vector<Timing> timing_acc;   // sums over the passes since snf_batch_timing_mean_reset
-#ifndef SNF_EMU
   struct Ev { hipEvent_t a, b; const char* name; int64_t bytes; };
   std::vector<Ev> evs; size_t ev_used = 0;
-#endif
 };
 
 // ---- device memory ----
@@ -322,7 +298,6 @@ template <class T>
 T* dalloc_own(snf_batch_impl* b, size_t n) {
   size_t bytes = (n ? n : 1) * sizeof(T);
   void* p = nullptr;
-#ifndef SNF_EMU
   if (hipMalloc(&p, bytes) != hipSuccess) {
     // out of device memory while idle slabs of finished batches sit in this process's own cache: hand them back and try
     // once more (several ranks / threads on one GPU, torch or RCCL next door, a large contig after many small ones)
@@ -331,10 +306,6 @@ T* dalloc_own(snf_batch_impl* b, size_t n) {
     g_slabs.trim(b->device);
     SNF_HIP(hipMalloc(&p, bytes));
   }
-#else
-  p = malloc(bytes);
-  memset(p, 0xA5, bytes);  // hipMalloc does not zero: poison so the emulation catches uninitialised reads
-#endif
   b->bufs.push_back({p, bytes});
   return (T*)p;
 }
@@ -346,9 +317,6 @@ T* dalloc(snf_batch_impl* b, size_t n) {
     size_t got = 0;
     void* cached = getenv("SNF_NO_SLAB_CACHE") ? nullptr : g_slabs.take(b->device, cap, &got);
     if (cached && got <= 2 * cap + ((size_t)256 << 20)) {   // (a much larger slab is left for a batch that needs it)
-#ifdef SNF_EMU
-      memset(cached, 0xA5, got);
-#endif
       b->bufs.push_back({cached, got, true});
       b->slab = (uint8_t*)cached; cap = got;
     } else {
@@ -365,11 +333,7 @@ T* dalloc(snf_batch_impl* b, size_t n) {
 void dfree_all(snf_batch_impl* b) {
   for (auto& d : b->bufs) {
     if (d.slab && !getenv("SNF_NO_SLAB_CACHE") && g_slabs.give(b->device, d.p, d.bytes)) continue;   // kept for the next batch
-#ifndef SNF_EMU
     (void)hipFree(d.p);
-#else
-    free(d.p);
-#endif
   }
   b->bufs.clear();
 }
@@ -377,77 +341,47 @@ void dfree_one(snf_batch_impl* b, void* p) {
   if (!p) return;
   for (size_t i = 0; i < b->bufs.size(); i++)
     if (b->bufs[i].p == p) {
-#ifndef SNF_EMU
       (void)hipFree(p);
-#else
-      free(p);
-#endif
       b->bufs.erase(b->bufs.begin() + i);
       return;
     }
 }
 void h2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, b->cur));
-#else
-  memcpy(dst, src, bytes);
-#endif
 }
 void d2h(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, b->cur));
-#else
-  memcpy(dst, src, bytes);
-#endif
 }
 void d2d(snf_batch_impl* b, void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, b->cur));
-#else
-  memcpy(dst, src, bytes);
-#endif
 }
 void dzero(snf_batch_impl* b, void* p, size_t bytes, int val = 0) {
   if (!bytes) return;
-#ifndef SNF_EMU
   SNF_HIP(hipMemsetAsync(p, val, bytes, b->cur));
-#else
-  memset(p, val, bytes);
-#endif
 }
 void dsync(snf_batch_impl* b) {
-#ifndef SNF_EMU
   SNF_HIP(hipStreamSynchronize(b->cur));
-#endif
 }
 // enqueue on the side stream for the lifetime of this object; fork()/join() order it against the main stream
 void fork_mark(snf_batch_impl* b) {  // point on the main stream the side stream may start after
-#ifndef SNF_EMU
   SNF_HIP(hipEventRecord(b->ev_fork, b->stream));
-#endif
 }
 struct SideStream {
   snf_batch_impl* b;
   SideStream(snf_batch_impl* b_) : b(b_) {
-#ifndef SNF_EMU
     SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_fork, 0));
     b->cur = b->stream2; b->cur_slot = 1;
-#endif
   }
   ~SideStream() {
-#ifndef SNF_EMU
     (void)hipEventRecord(b->ev_join, b->stream2);
     b->cur = b->stream; b->cur_slot = 0;
-#endif
   }
 };
 void join_side(snf_batch_impl* b) {  // main stream waits for everything enqueued on the side stream so far
-#ifndef SNF_EMU
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join, 0));
-#endif
 }
 template <class T>
 T* upload_vec(snf_batch_impl* b, const std::vector<T>& h, size_t extra = 0) {
@@ -459,11 +393,8 @@ T* upload_vec(snf_batch_impl* b, const std::vector<T>& h, size_t extra = 0) {
 // ---- timing ----
 struct Scope {
   snf_batch_impl* b;
-#ifndef SNF_EMU
   size_t idx = (size_t)-1;
-#endif
   Scope(snf_batch_impl* b_, const char* name, int64_t bytes) : b(b_) {
-#ifndef SNF_EMU
     if (!b->timing) return;
     if (b->ev_used == b->evs.size()) {
       snf_batch_impl::Ev e{};
@@ -473,14 +404,9 @@ struct Scope {
     idx = b->ev_used++;
     b->evs[idx].name = name; b->evs[idx].bytes = bytes;
     SNF_HIP(hipEventRecord(b->evs[idx].a, b->cur));
-#else
-    (void)name; (void)bytes;
-#endif
   }
   ~Scope() {
-#ifndef SNF_EMU
     if (idx != (size_t)-1) (void)hipEventRecord(b->evs[idx].b, b->cur);
-#endif
   }
 };
 
@@ -490,7 +416,6 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
   else d2h(b, dst, src, bytes);
 }
 
-#ifndef SNF_EMU
 // LAUNCH_Q: tiny kernels are only bracketed by events when SNF_TIME_ALL=1 (two event records cost more host time
 // than the launch itself and the stage A-C region is launch-bound)
 #define LAUNCH_Q(kern, view, n, bytes)                                                        \
@@ -512,12 +437,7 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
       SNF_HIP(hipGetLastError());                                                             \
     }                                                                                         \
   } while (0)
-#else
-#define LAUNCH(kern, view, n, bytes) do { int64_t _n = (n); if (_n > 0) kern(view, _n); } while (0)
-#define LAUNCH_Q(kern, view, n, bytes) LAUNCH(kern, view, n, bytes)
-#endif
 
-#ifndef SNF_EMU
 // kernels of snf_fused.h: n elements, 256 per block; bracketed by timing events only with SNF_TIME_ALL
 #define FUSED(kern, n)                                                                                  \
   do {                                                                                                  \
@@ -529,16 +449,12 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
       SNF_HIP(hipGetLastError());                                                                       \
     }                                                                                                   \
   } while (0)
-#else
-#define FUSED(kern, n) do { } while (0)   /* the emulation build always takes the plain-scan path (b->fused == false) */
-#endif
 
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
 template <class K>
 void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, int64_t n,
                      int end_bit, const char* name) {
   if (n <= 0) return;
-#ifndef SNF_EMU
   size_t need = 0;
   // (rocPRIM's default takes a block sort + ~20 merge launches up to 1 M items: 140 us for the 0.7 M pairs behind the prefilter)
   using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
@@ -550,18 +466,10 @@ void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* v
   }
   Scope s(b, name, n * 2 * (int64_t)(sizeof(K) + 4));
   SNF_HIP(rocprim::radix_sort_pairs<SortCfg>(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
-#else
-  (void)end_bit; (void)name;
-  std::vector<int64_t> idx(n);
-  std::iota(idx.begin(), idx.end(), 0);
-  std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return kin[x] < kin[y]; });
-  for (int64_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
-#endif
 }
 template <class T>
 void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* name) {
   if (n <= 0) return;
-#ifndef SNF_EMU
   size_t need = 0;
   SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
@@ -572,11 +480,6 @@ void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* 
   if (b->time_all) { Scope s(b, name, n * 2 * (int64_t)sizeof(T));
     SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur)); }
   else SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
-#else
-  (void)name;
-  T acc = 0;
-  for (int64_t i = 0; i < n; i++) { T x = in[i]; out[i] = acc; acc += x; }
-#endif
 }
 
 // ---- genotype table: exactly genotyping.py:124-171 for every (normalised support, coverage) ----
@@ -622,14 +525,9 @@ struct StageArena {
   std::mutex mu; void* p = nullptr; size_t cap = 0;
   void* ensure(size_t bytes) {
     if (bytes <= cap && p) return p;
-#ifndef SNF_EMU
     if (p) (void)hipHostFree(p);
     cap = bytes + bytes / 8 + (1u << 20);
     SNF_HIP(hipHostMalloc(&p, cap, hipHostMallocDefault));
-#else
-    free(p);
-    cap = bytes + 4096; p = malloc(cap);
-#endif
     return p;
   }
 };
@@ -747,12 +645,8 @@ void do_upload(snf_batch_impl* b) {
   if (T >= (1 << 16)) fail("too many tasks in one batch (max 65535)");
   if (N >= (int64_t)1 << 31 || R >= (int64_t)1 << 31) fail("batch too large for 32-bit lead/read indices");
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
-#ifndef SNF_EMU
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
   v.prof = getenv("SNF_PROF") ? 1 : 0;
-#else
-  v.wave_path = 0;
-#endif
   const bool sort64 = getenv("SNF_SORT64") != nullptr;  // tests: force the wide-key sorts
   {  // lead sort key: (task*8 + svtype) << bin_bits | bin, one more bit marks leads outside their contig (sorted last)
     int64_t max_bins = 1;
@@ -763,7 +657,6 @@ void do_upload(snf_batch_impl* b) {
   }
   v.pool_len = b->h_pool_off.back(); v.pool_cap = 2 * v.pool_len + 16;
   v.pool_extra_base = v.pool_len; v.pool_slice = 0;
-#ifndef SNF_EMU
   // Fused sequences (merge_inner) go behind the input sequences.  All of them together are at most pool_len bytes, and that
   // much is kept for reservations through the shared counter; in front of it every resident wave of d1w_refine owns a private
   // slice it fills without any atomic (the shared counter is one address: ~10^4 returning atomics per pass queue up in L2 and
@@ -773,7 +666,6 @@ void do_upload(snf_batch_impl* b) {
     v.pool_extra_base = v.pool_len + v.pool_slice * b->slots_d1w;
     v.pool_cap = v.pool_extra_base + v.pool_len + 16;
   }
-#endif
   // everything allocated below fits one slab of this size (per-lead arrays ~1.9 KB/lead, the pool twice, the reads);
   // anything beyond it simply opens another slab
   b->slab_next = (size_t)N * 1408 + (size_t)v.pool_cap + (size_t)R * 96 + ((size_t)4 << 20);
@@ -893,12 +785,8 @@ void do_upload(snf_batch_impl* b) {
       for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(rs_all[r]);
     } else {
       for (int64_t r = 0; r < R; r += (1 << SNF_TOP_SHIFT)) top.push_back(0);
-#ifndef SNF_EMU
       // every 256th start in ONE strided copy (width 4 bytes, source pitch 1 KB) instead of a 4-byte copy per entry
       if (!top.empty()) SNF_HIP(hipMemcpy2DAsync(top.data(), 4, d_in + off[IC_RSTART], (size_t)4 << SNF_TOP_SHIFT, 4, top.size(), hipMemcpyDeviceToHost, b->cur));
-#else
-      for (size_t k = 0; k < top.size(); k++) d2h(b, &top[k], d_in + off[IC_RSTART] + (k << SNF_TOP_SHIFT) * 4, 4);
-#endif
     }
     dsync(b);
     for (auto& t : b->tasks) {   // the borrowed arrays are not referenced after this point
@@ -1069,9 +957,7 @@ void do_upload(snf_batch_impl* b) {
 
 // ---------------------------------------------------------------------------------------------- pipeline
 void reset_timing(snf_batch_impl* b) {
-#ifndef SNF_EMU
   b->ev_used = 0;
-#endif
   b->timings.clear();
 }
 
@@ -1101,14 +987,10 @@ void enqueue_read_prep(snf_batch_impl* b) {
   if (R > 0) {
     if (b->readprep_each_pass) enqueue_read_index(b);
     // Task.coverage_average_total = coverage.mean(): sum of the clipped read lengths (exact) / contig length
-#ifndef SNF_EMU
     { Scope _s(b, "d5w_covsum", R * 12);
       int64_t grid = (R + 4095) / 4096; if (grid > 2048) grid = 2048;
       hipLaunchKernelGGL(d5w_covsum, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError()); }
-#else
-    LAUNCH(d5_covsum, v, (R + SNF_COV_CHUNK - 1) / SNF_COV_CHUNK, R * 12);
-#endif
   }
   if (v.t_cov_exact)
     for (int t = 0; t < T; t++) if (b->h_cov_exact[(size_t)t]) {   // (rare: masked / wrapping tasks) the exact sum of the masked uint16 vector
@@ -1127,9 +1009,7 @@ void enqueue_read_prep(snf_batch_impl* b) {
 void enqueue_pass_init(snf_batch_impl* b) {
   View& v = b->v;
   const int64_t N = v.N; const int T = v.T;
-#ifndef SNF_EMU
   b->fused = getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25);
-#endif
   if (b->fused) {
     int64_t n0 = 8 * (int64_t)T + 8;
     if (TS_SLOTS * v.super_stride > n0) n0 = TS_SLOTS * v.super_stride;
@@ -1169,17 +1049,11 @@ void run_call_candidates(snf_batch_impl* b) {
   const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
   b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
   reset_timing(b);
-#ifndef SNF_EMU
   // SNF_OUT_EXECUTE (set before this call): the names of the supporting reads are only written for the calls that pass QC,
   // once finalize knows them (a stage-0 fetch writes them all, late)
   v.rn_defer = ((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc && getenv("SNF_NO_RN_DEFER") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25)) ? 1 : 0;
-#else
-  v.rn_defer = 0;
-#endif
   b->rn_state = v.rn_defer ? 1 : 0;
-#ifndef SNF_EMU
   if (b->timeline) SNF_HIP(hipEventRecord(b->ev_base, b->stream));
-#endif
   // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
   // (and in the emulation build) the plain device-wide scans are used
   enqueue_pass_init(b);
@@ -1232,21 +1106,17 @@ void run_call_candidates(snf_batch_impl* b) {
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
     }
     if (b->sched_readprep == 3) fork_mark(b);   // mode 3: the read preparation may only start once stages A-C are through
-#ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
       hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
     if (!(v.wave_path && b->fused)) LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);   // (next to the wave kernels every item would return at once)
-#ifndef SNF_EMU
     if (v.wave_path) {   // clusters of more than 64 leads, one wave each
       Scope _s(b, "x_big_refine", 0);
       hipLaunchKernelGGL(x_big<0>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
   }
   if (b->sched_readprep == 1 || b->sched_readprep == 3) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
@@ -1257,21 +1127,17 @@ void run_call_candidates(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
       LAUNCH_Q(d1b_rctable, v, N, N * 4);
     }
-#ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
       hipLaunchKernelGGL(b->k_d2w, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
     if (!(v.wave_path && b->fused)) LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
-#ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "x_big_call", 0);
       hipLaunchKernelGGL(x_big<1>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
     if (b->fused) {
       FUSED(d3a_count, N);
       FUSED(d3ck_compact, N);
@@ -1284,12 +1150,9 @@ void run_call_candidates(snf_batch_impl* b) {
   // ev_counts.  Nothing the ALT chain of finalize needs is produced after this point, so the rest of the candidate
   // stage (sv ids, supporting read names, coverage annotation) continues on the side stream, behind the read preparation
   LAUNCH_Q(d3_taskoff, v, T + 1, 0);
-#ifndef SNF_EMU
   SNF_HIP(hipEventRecord(b->ev_counts, b->stream));
-#endif
   if (b->sched_readprep == 2) enqueue_read_prep(b);
   fork_mark(b);
-#ifndef SNF_EMU
   if (b->fused) {
     {  // sv ids + supporting read names: own stream (nothing on the coverage -> QC -> record copy chain waits for them
        // except the copy itself, through ev_rn)
@@ -1305,7 +1168,6 @@ void run_call_candidates(snf_batch_impl* b) {
     SideStream side(b);
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
   } else
-#endif
   {
     SideStream side(b);
     if (N > 0) {
@@ -1313,9 +1175,7 @@ void run_call_candidates(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, v.rnf, v.rnp, N + 1, "scan_rnames");
       LAUNCH(d3_rnames, v, N, 0);
     } else *b->h_rn_total = 0;
-#ifndef SNF_EMU
     SNF_HIP(hipEventRecord(b->ev_rn, b->cur));
-#endif
     if (N > 0) LAUNCH(d4_coverage, v, N, 0);
   }
   b->res_current = false;
@@ -1324,10 +1184,8 @@ void run_call_candidates(snf_batch_impl* b) {
 
 // everything enqueued on any of the batch's streams has completed and the pinned result block is current
 void join_fourth(snf_batch_impl* b) {  // main stream waits for the fourth stream (sv ids, read names, their copy)
-#ifndef SNF_EMU
   SNF_HIP(hipEventRecord(b->ev_join4, b->stream4));
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join4, 0));
-#endif
 }
 void full_sync(snf_batch_impl* b) {
   join_side(b);
@@ -1352,14 +1210,10 @@ void enqueue_rnames_late(snf_batch_impl* b, bool all) {
   if (b->rn_state == 0 || (b->rn_state == 2 && !all) || v.NS <= 0) return;
   const int keep = v.rn_defer;
   v.rn_defer = all ? 2 : 1;
-#ifndef SNF_EMU
   { Scope _s(b, "d3_rnames_late", 0);
     unsigned grid = (unsigned)((v.NS / 4 + 255) / 256) + 1u; if (grid > 4096u) grid = 4096u;
     hipLaunchKernelGGL(d3lk_rnames_late, dim3(grid), dim3(256), 0, b->cur, v, (int64_t)0);
     SNF_HIP(hipGetLastError()); }
-#else
-  LAUNCH_Q(d3l_rnames_late, v, v.NS, 0);
-#endif
   v.rn_defer = keep;
   b->rn_state = all ? 0 : 2;
 }
@@ -1369,7 +1223,6 @@ void enqueue_output_head(snf_batch_impl* b) {
   const int64_t NS = v.NS;
   enqueue_rnames_late(b, !((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc));
   if (b->fused && NS <= ((int64_t)1 << 22) * 256) {
-#ifndef SNF_EMU
     const unsigned grid = (unsigned)((NS + 255) / 256) > 0u ? (unsigned)((NS + 255) / 256) : 1u;
     FUSED(f1k_outflags, NS > 0 ? NS : 1);
     FUSED(f2k_outscan, NS > 0 ? NS : 1);
@@ -1381,7 +1234,6 @@ void enqueue_output_head(snf_batch_impl* b) {
     { Scope _s(b, "f4_emit", 0);
       hipLaunchKernelGGL(f4w_emit, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError()); }
-#endif
   } else {
     const int64_t nc = NS;   // upper bound of the number of calls (the bodies stop at the device's count)
     LAUNCH_Q(f1_flags, v, nc + 1, 0);
@@ -1415,21 +1267,18 @@ void run_alt_fallback(snf_batch_impl* b) {
   b->cr_cap = r1;
   const bool threads = !v.wave_path || c.n_cons_fallback > 0;
   if (threads) LAUNCH_Q(e4_anchor, v, c.n_cons, v.wave_path ? 0 : c.tab_total * 13);
-#ifndef SNF_EMU
   if (v.wave_path && c.n_cls[7] > 0) {   // work list 7: calls beyond the LDS vote counters and what SMALL / LARGE handed over at run time
     Scope _s(b, "e45w_consensus_rows", 0);
     const int64_t n_rows = (int64_t)c.n_cls[7];
     hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(n_rows < 16384 ? n_rows : 16384)), dim3(256), 0, b->cur, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
   }
-#endif
   if (threads) {
     LAUNCH_Q(e5_align, v, c.n_cons_reads, v.wave_path ? 0 : c.aln_total * 2);
     LAUNCH(e6_vote, v, c.alt_total, c.aln_total + 2 * c.alt_total);
   }
 }
 
-#ifndef SNF_EMU
 // SMALL / LARGE / verbatim-copy kernels of the ALT stage, one launch per class.  The grids are upper bounds (exact when the
 // caller knows the class counts): workgroups behind the end of a class's list return at once, and the kernels stride when
 // a list is longer than the grid.
@@ -1467,7 +1316,6 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
     }
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
-#endif
 
 void run_finalize(snf_batch_impl* b) {
   View& v = b->v;
@@ -1493,16 +1341,13 @@ void run_finalize(snf_batch_impl* b) {
   // has finalized before knows its sizes (same input); the first pass waits once for the counters d3_taskoff published.
   int64_t n_calls_hint = b->hist_calls;
   if (!b->have_hist && NS > 0) {
-#ifndef SNF_EMU
     SNF_HIP(hipEventSynchronize(b->ev_counts));
-#endif
     n_calls_hint = b->h_cnt->n_calls;
   }
   if (NS > 0) {
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
      // annotations they read), overlapped with the consensus chain
     SideStream side(b);
-#ifndef SNF_EMU
     if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
@@ -1513,18 +1358,14 @@ void run_finalize(snf_batch_impl* b) {
       hipLaunchKernelGGL(b->k_e1w, dim3((unsigned)grid), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
     if (!v.wave_path) LAUNCH_Q(e1_finalize, v, NS, 0);
-#ifndef SNF_EMU
     if (v.wave_path) {
       Scope _s(b, "x_big_finalize", 0);
       hipLaunchKernelGGL(x_big<2>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-#endif
   }
   const bool fast_alt = v.wave_path && b->fused && NS <= ((int64_t)1 << 22) * 256;
-#ifndef SNF_EMU
   if (fast_alt)
   {  // E2 sizes -> offsets -> E3 work items in two launches (snf_fused.h) instead of a size kernel, five scans and E3
     const unsigned grid = (unsigned)((NS + 255) / 256);
@@ -1554,7 +1395,6 @@ void run_finalize(snf_batch_impl* b) {
     join_fourth(b);
   }
   else
-#endif
   {
     // plain-scan path (emulation build, SNF_NO_FUSE, SNF_NO_WAVE): sized by the number of calls, one host wait
     d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
@@ -1568,14 +1408,12 @@ void run_finalize(snf_batch_impl* b) {
     prim_exscan<int64_t>(b, v.sz_aln, v.sc_aln, nc + 1, "scan_cons_sizes");
     prim_exscan<int64_t>(b, v.sz_rd, v.sc_rd, nc + 1, "scan_cons_sizes");
     LAUNCH_Q(e3_conslist, v, nc + 1, 0);
-#ifndef SNF_EMU
     if (v.wave_path) {
       d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
       dsync(b);
       const Counts& c = *b->h_cnt;
       enqueue_consensus_wave(b, (int64_t)c.n_cls[1] + 1, (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]) + 1, (int64_t)c.n_cls[0] + 1);
     }
-#endif
     run_alt_fallback(b);     // (host wait: scratch sizes; thread kernels, and ROWS for work list 7, complete only now)
     join_side(b);
     join_fourth(b);
@@ -1601,7 +1439,6 @@ void collect_timings(snf_batch_impl* b) {
     for (int k = 0; k < 6; k++) fprintf(stderr, "[SNF_CONS_PROFILE] d1w %-26s %llu\n", rn[k], b->h_cnt->dbg[24 + k]);
   }
 #endif
-#ifndef SNF_EMU
   for (size_t i = 0; i < b->ev_used; i++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, b->evs[i].a, b->evs[i].b) != hipSuccess) ms = -1;
@@ -1631,7 +1468,6 @@ void collect_timings(snf_batch_impl* b) {
       if (strcmp(a.name, t.name) == 0) { a.ms += t.ms; a.bytes = t.bytes; a.launches++; found = true; break; }
     if (!found) b->timing_acc.push_back({t.name, t.ms, t.bytes, 1});
   }
-#endif
 }
 
 // After everything of the pass has run: did the ALT stage leave work for the slow kernels (a call that fits none of the LDS
@@ -1776,10 +1612,6 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     if (n_problems <= 0) return;
     if (!seq_pool || !best_off || !best_len || !skip || !others_index || !others_off || !others_len || !out_pool || !out_off)
       fail("snf_consensus_batch: null argument");
-#ifdef SNF_EMU
-    (void)device; (void)klen; (void)seq_pool_len;
-    fail("snf_consensus_batch needs the HIP build");
-#else
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) fail("no such HIP device");
     SNF_HIP(hipSetDevice(device));
@@ -1838,7 +1670,6 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     SNF_HIP(hipGetLastError());
     SNF_HIP(hipDeviceSynchronize());
     if (alt_total) SNF_HIP(hipMemcpy(out_pool, v.alt_pool, (size_t)alt_total, hipMemcpyDeviceToHost));
-#endif
 }
 }  // namespace
 
@@ -1850,9 +1681,7 @@ void do_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, const int
     if (!b->cov_avg_ready) fail("snf_batch_coverage_calls needs snf_batch_call_candidates first (coverage.mean() is formed there)");
     if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
     if (n < 0 || (n > 0 && (!svtype || !pos || !svlen || !bnd_is_first || !cov))) fail("invalid call arrays");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     full_sync(b);
     *status = 0;
     d2h(b, coverage_mean, b->v.t_cov_avg + task_index, sizeof(double));
@@ -1911,15 +1740,11 @@ void do_genotype_batch(const snf_config_t* cfg, int device, snf_call_t* calls, i
   memcpy(A.h + o_calls, calls, (size_t)n * sizeof(snf_call_t));
   GenoView q{};
   q.cfg = *cfg; q.gt_lut = (const GtEntry*)(A.d + o_lut); q.calls = (snf_call_t*)(A.d + o_calls); q.n = n;
-#ifndef SNF_EMU
   SNF_HIP(hipMemcpyAsync(A.d, A.h, L.at, hipMemcpyHostToDevice, A.stream));
   hipLaunchKernelGGL(g1_genotype, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, A.stream, q, n);
   SNF_HIP(hipGetLastError());
   SNF_HIP(hipMemcpyAsync(A.h + o_calls, A.d + o_calls, (size_t)n * sizeof(snf_call_t), hipMemcpyDeviceToHost, A.stream));
   SNF_HIP(hipStreamSynchronize(A.stream));
-#else
-  g1_genotype(q, n);
-#endif
   memcpy(calls, A.h + o_calls, (size_t)n * sizeof(snf_call_t));
 }
 }  // namespace
@@ -2045,16 +1870,11 @@ int snf_abi_version(void) { return SNF_ABI_VERSION; }
 const char* snf_last_error(void) { return g_err.c_str(); }
 
 int snf_device_count(void) {
-#ifndef SNF_EMU
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-#else
-  return 1;
-#endif
 }
 
-#ifndef SNF_EMU
 // Creating a HIP stream sets up a hardware queue: about 2 ms each, 4 per batch, and as much again to destroy them - more than the
 // kernels of a contig-sized batch take.  Streams of destroyed batches (synchronised, nothing pending) are kept per device and
 // handed to the next batch; the pool is bounded, the rest is destroyed as before.
@@ -2092,9 +1912,7 @@ struct StreamPool {
   }
 };
 static StreamPool g_streams;
-#endif
 
-#ifndef SNF_EMU
 // The device's CU count and the occupancy of the three resident kernels do not change while the process lives: asked once per
 // (device, instance choice) - hipGetDeviceProperties and the occupancy queries are milliseconds, a task-sized batch is not.
 struct DevInfo { int cus, nb_d1w, nb_d2w, nb_e1w; };
@@ -2116,7 +1934,6 @@ static DevInfo device_info(int device, int o2, int o1, WaveKernel k_d2w, WaveKer
   }
   return it->second;
 }
-#endif
 
 int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
   SNF_TRY({
@@ -2124,19 +1941,16 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     if (cfg->cluster_binsize <= 0 || cfg->cluster_resplit_binsize <= 0) fail("bin sizes must be positive");
     if (cfg->consensus_kmer_len < 1 || cfg->consensus_kmer_len > 8) fail("consensus_kmer_len must be in 1..8");
     if (cfg->genotype_ploidy != 2) fail("only genotype_ploidy 2 is supported");
-#ifndef SNF_EMU
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
       fail("no HIP device available: the sniffles_amd hot path requires an AMD GPU (there is no CPU fallback)");
     if (device < 0 || device >= n) fail("device index out of range");
     SNF_HIP(hipSetDevice(device));
-#endif
     auto b = std::make_unique<snf_batch_impl>();
     b->cfg = *cfg; b->device = device;
     const char* g = getenv("SNF_RUN_GAP");
     int base = cfg->cluster_merge_bnd > (int)cfg->cluster_repeat_h_max ? cfg->cluster_merge_bnd : (int)cfg->cluster_repeat_h_max;
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
-#ifndef SNF_EMU
     b->stream = g_streams.take(b->device);
     b->stream2 = g_streams.take(b->device);
     b->stream3 = g_streams.take(b->device);
@@ -2183,7 +1997,6 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
     if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
-#endif
     *out = reinterpret_cast<snf_batch_t*>(b.release());
   })
 }
@@ -2201,9 +2014,7 @@ int snf_batch_upload(snf_batch_t* bb) {
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b) fail("null batch");
     if (b->uploaded) fail("batch already uploaded");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     do_upload(b);
   })
 }
@@ -2211,7 +2022,6 @@ int snf_batch_upload(snf_batch_t* bb) {
 void snf_batch_destroy(snf_batch_t* bb) {
   auto b = reinterpret_cast<snf_batch_impl*>(bb);
   if (!b) return;
-#ifndef SNF_EMU
   (void)hipSetDevice(b->device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   if (b->stream2) (void)hipStreamSynchronize(b->stream2);
@@ -2226,16 +2036,13 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-#endif
   dfree_all(b);
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
-#ifndef SNF_EMU
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
   if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
   if (b->stream4) g_streams.give(b->device, b->stream4);   // (synchronised above)
   if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
-#endif
   delete b;
 }
 
@@ -2243,9 +2050,7 @@ int snf_batch_call_candidates(snf_batch_t* bb) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded) fail("batch not uploaded");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     run_call_candidates(b);
   })
 }
@@ -2254,9 +2059,7 @@ int snf_batch_finalize(snf_batch_t* bb) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded) fail("batch not uploaded");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     run_finalize(b);
   })
 }
@@ -2265,9 +2068,7 @@ int snf_batch_fetch(snf_batch_t* bb, int stage, snf_result_t* out) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !out) fail("batch not uploaded / null result");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     do_fetch(b, stage, out);
   })
 }
@@ -2280,9 +2081,7 @@ int snf_batch_fetch_clusters(snf_batch_t* bb, int stage, snf_clusters_t* out) {
   SNF_TRY({
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b || !b->uploaded || !out) fail("batch not uploaded / null result");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     do_fetch_clusters(b, stage, out);
   })
 }
@@ -2296,9 +2095,7 @@ int64_t snf_batch_n_candidates(snf_batch_t* bb) {
 int64_t snf_trim_caches(int device) {
   int64_t bytes = (int64_t)g_slabs.trim(device);
   bytes += (int64_t)g_pinned.trim();
-#ifndef SNF_EMU
   (void)g_streams.trim(device);
-#endif
   return bytes;
 }
 
@@ -2317,9 +2114,7 @@ int snf_batch_export_device(snf_batch_t* bb, void* dst_device, int64_t cap_bytes
     if (!b || !b->uploaded || !layout) fail("batch not uploaded / null argument");
     if (!b->finalized) fail("snf_batch_export_device needs snf_batch_finalize first");
     if (!(b->v.out_mode & SNF_OUT_DEVICE)) fail("snf_batch_export_device needs snf_batch_set_output(... | SNF_OUT_DEVICE) before the finalize");
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     full_sync(b);
     settle_alt_stage(b);
     const OutHdr h = *b->v.res_out;
@@ -2342,9 +2137,7 @@ int snf_batch_block_coverage(snf_batch_t* bb, int32_t task_index, int32_t binsiz
     if (task_index < 0 || task_index >= b->v.T) fail("task index out of range");
     if (binsize <= 0 || first_bin < 0 || n_bins < 0) fail("invalid bin range");
     if (n_bins == 0) return 0;
-#ifndef SNF_EMU
     SNF_HIP(hipSetDevice(b->device));
-#endif
     full_sync(b);
     BlockCov q{};
     q.r_start = b->v.r_start; q.re_sorted = b->v.re_sorted; q.rs_top = b->v.rs_top; q.re_top = b->v.re_top;
@@ -2372,12 +2165,6 @@ int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
                               others_len, out_pool, out_off))
 }
 
-#ifdef SNF_EMU
-// test hook of the emulation build only (tests/test_emu_parity.py): the column vote of the LDS-vote consensus kernels
-int snf_emu_vote_column(uint32_t cnt4, const uint32_t* esc, int n_esc, int q, int bq, int nkept) {
-  return (int)vote_column(cnt4, esc, n_esc, q, (uint8_t)bq, nkept);
-}
-#endif
 
 int snf_batch_sync(snf_batch_t* bb) {
   SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); if (b->uploaded) full_sync(b); else dsync(b); collect_timings(b); })

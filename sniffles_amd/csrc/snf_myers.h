@@ -118,7 +118,7 @@ SNF_HD int64_t ed_serial_k(const uint8_t* A, int64_t la, const uint8_t* B, int64
   return (k >= 0 && d > k) ? -1 : d;
 }
 
-#if !defined(SNF_EMU) && defined(__HIPCC__)
+#if defined(__HIPCC__)
 typedef uint64_t __attribute__((aligned(1))) ed_u64_unaligned;
 // bit-planes of the 64 pattern bytes at p (cnt of them valid) from eight 8-byte loads: bit k of byte i of a word lands on
 // bit i of the gathered byte ((x >> k) & 0x0101..01) * 0x0102040810204080 >> 56).  Reads up to 7 bytes past p + cnt.

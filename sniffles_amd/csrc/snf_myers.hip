@@ -48,7 +48,6 @@ SNF_HD void ed_thread_body(int64_t i, const EdView& v) {
 using namespace snf;
 SNF_KERNEL(ed_thread, EdView)
 
-#ifndef SNF_EMU
 // thread per pair, patterns of at most SNF_ED_THREAD_BLOCKS blocks: bit-planes and (Pv, Mv) of every block in LDS
 #define SNF_ED_THREAD_BLOCKS 8
 __global__ void __launch_bounds__(64) ed_thread_lds(const EdView v, int64_t n_items) {
@@ -74,7 +73,6 @@ __global__ void __launch_bounds__(64) ed_wave(const EdView v, int64_t n_items) {
     if (lane == 0) v.out[pi] = (int32_t)d;
   }
 }
-#endif
 
 namespace {
 DevArena g_ed_arenas[SNF_MAX_DEVICES];
@@ -99,11 +97,7 @@ static int ed_batch(int device, const uint8_t* a_pool, const int64_t* a_off, con
     bool wide = false;   // needs the multi-pass wave form (per-column carry bytes)
     if (!small && ed_band(m, n, k, &bd)) wide = !((64 + bd.dl + 2 * bd.kk) / 64 + 2 <= 63 || (m + 63) / 64 <= 63);
     carry_off[i + 1] = carry_off[i] + (wide ? n : 0);
-#ifdef SNF_EMU
-    scratch_off[i + 1] = scratch_off[i] + ed_serial_scratch_words(m);
-#else
     scratch_off[i + 1] = scratch_off[i];
-#endif
     if (small) thread_list.push_back((int32_t)i); else wave_list.push_back((int32_t)i);
   }
   if (device < 0 || device >= SNF_MAX_DEVICES) return 1;
@@ -131,7 +125,6 @@ static int ed_batch(int device, const uint8_t* a_pool, const int64_t* a_off, con
   v.out = (int32_t*)(d + o_out); v.kmax = max_dist ? (const int32_t*)(d + o_k) : nullptr;
   v.scratch = (uint64_t*)(d + o_scr); v.scratch_off = (const int64_t*)(d + o_so);
   v.carry = (int8_t*)(d + o_carry); v.carry_off = (const int64_t*)(d + o_co);
-#ifndef SNF_EMU
   hipStream_t st = g_ed_arena.stream;
   bool ok = hipMemcpyAsync(d, h, in_end, hipMemcpyHostToDevice, st) == hipSuccess;
   if (ok && !thread_list.empty()) {
@@ -146,14 +139,6 @@ static int ed_batch(int device, const uint8_t* a_pool, const int64_t* a_off, con
   ok = ok && hipMemcpyAsync(h + o_out, d + o_out, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
   ok = ok && hipStreamSynchronize(st) == hipSuccess;
   if (!ok) return 1;
-#else
-  (void)in_end;
-  std::vector<int32_t> all;
-  all.insert(all.end(), thread_list.begin(), thread_list.end());
-  all.insert(all.end(), wave_list.begin(), wave_list.end());
-  v.list = all.data(); v.n = (int64_t)all.size();
-  ed_thread(v, v.n);
-#endif
   memcpy(out_dist, h + o_out, (size_t)n_pairs * 4);
   return 0;
 }

@@ -1,8 +1,7 @@
-// snf_rt.h - thin runtime layer: HIP on gfx950 (the product) or a serial host loop (SNF_EMU).
-//
-// SNF_EMU exists ONLY so that tests/ can execute the exact kernel bodies in the GPU-less build
-// container (tests/emu builds it with g++).  It is never compiled into libsniffles_amd.so and the
-// Python package cannot load it: the product path fails loudly when no HIP device is present.
+// snf_rt.h - thin runtime layer over HIP (gfx950 only): error handling, atomics usable from kernel bodies, the
+// kernel-definition macro.  There is one build of these sources: hipcc for the product.  The GPU-less test tier
+// (tests/emu/simt) compiles the SAME sources with g++ against a stand-in for <hip/hip_runtime.h> - nothing in here knows
+// about it; the `__HIP_DEVICE_COMPILE__` branches below are the usual host / device halves of __host__ __device__ code.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -11,18 +10,9 @@
 #include <string>
 #include <vector>
 
-#ifndef SNF_EMU
 #include <hip/hip_runtime.h>
 #define SNF_HD __host__ __device__ __forceinline__
 #define SNF_D __device__ __forceinline__
-#else
-#include <algorithm>
-#include <cmath>
-#include <numeric>
-#define SNF_HD inline
-#define SNF_D inline
-typedef void* hipStream_t;
-#endif
 
 typedef unsigned __int128 u128;
 typedef __int128 i128;
@@ -34,7 +24,6 @@ struct Error {
 };
 [[noreturn]] inline void fail(const std::string& m) { throw Error{m}; }
 
-#ifndef SNF_EMU
 #define SNF_HIP(expr)                                                                         \
   do {                                                                                        \
     hipError_t _e = (expr);                                                                   \
@@ -42,7 +31,6 @@ struct Error {
       ::snf::fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
                   std::to_string(__LINE__) + ")");                                            \
   } while (0)
-#endif
 
 // ---- atomics usable from kernel bodies -------------------------------------------------------
 SNF_HD unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {
@@ -71,17 +59,10 @@ SNF_HD void atomic_or_i32(int* p, int v) {
 
 // ---- kernel definition / launch ---------------------------------------------------------------
 // A kernel is a body `void name##_body(int64_t i, const View& v)`; SNF_KERNEL wraps it.
-#ifndef SNF_EMU
 #define SNF_KERNEL(name, VIEW)                                                     \
   __global__ void __launch_bounds__(256) name(const VIEW v, int64_t n) {           \
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;                    \
     if (i < n) name##_body(i, v);                                                  \
   }
-#else
-#define SNF_KERNEL(name, VIEW)                                \
-  static void name(const VIEW& v, int64_t n) {                \
-    for (int64_t i = 0; i < n; i++) name##_body(i, v);        \
-  }
-#endif
 
 }  // namespace snf

@@ -64,7 +64,7 @@ SNF_HD void rc_emit(const View& v, int32_t pos, int32_t n, int32_t c, bool keepl
 
 // room for a fused sequence behind the input sequences; in a wave that runs the body uniformly one lane reserves for all
 SNF_HD unsigned long long pool_reserve(const View& v, unsigned long long nbytes) {
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   if (v.wave_uniform) {
     unsigned long long o = 0;
     if ((threadIdx.x & 63) == 0) o = atomicAdd(&v.cnt->pool_extra_used, nbytes);
@@ -142,7 +142,7 @@ SNF_HD void d1_refine_body(int64_t c, const View& v) {
               for (int32_t z = part_start; z < part_start + nparts; z++) {
                 const LeadRec& rz = R[a0[z]];
                 const uint8_t* src = v.pool + rz.seq_off;
-#if !defined(SNF_EMU) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
                 if (uni) {   // the wave runs this body in lock step: the lanes share the bytes (a serial load -> store chain per
                              // byte through the same array costs a memory round trip each)
                   for (int32_t b = (int32_t)(threadIdx.x & 63); b < rz.seq_len; b += 64) v.pool[w + b] = src[b];
@@ -291,7 +291,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   const int32_t* FI = v.FI + flo;
   // x_big<1> (uniform mode): the fill loops take every 64th lead per lane (SNF_LEADS), sums are wave reductions, and the rows
   // live in LDS when the cluster fits (the sorted read names are copied to their global row at the end: d3_rnames reads them)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
   const int l0 = uni ? (int)(threadIdx.x & 63) : 0, lstep = uni ? 64 : 1;
   const bool lds_rows = uni && v.stage_w != nullptr && n <= v.stage_cap;
   int32_t* const a1_global = a1;
@@ -402,7 +402,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       if (best < 0 || d < best_diff) { best = s; best_diff = d; best_k = k; }
       cnt++;
     }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
     if (uni) {   // the lanes' minima: smallest d, then the earliest lead (first argmin)
       for (int d_ = 32; d_ >= 1; d_ >>= 1) {
         const int32_t ob = __shfl_xor(best, d_, 64), ok = __shfl_xor(best_k, d_, 64); const double od = __shfl_xor(best_diff, d_, 64);
@@ -413,7 +413,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
 #endif
     if (best >= 0) { x.best = best; x.n_others = cnt - 1; x.do_cons = (x.n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; }
     if (best >= 0 && v.wave_path) {  // read list for the workgroup consensus kernel (see d2w_call)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
       if (uni) {
         int32_t w = 0;
         for (int32_t base = 0; base < n; base += 64) {      // list order = lead order: ballots per 64 leads
@@ -436,7 +436,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
       }
     }
   }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
   if (lds_rows) {   // the distinct sorted read names stay in w1 for d3_rnames
     __syncthreads();
     for (int32_t k = l0; k < (int32_t)nq; k += 64) a1_global[k] = a1[k];

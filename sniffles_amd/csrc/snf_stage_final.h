@@ -130,7 +130,7 @@ SNF_HD bool qc_sv(const View& v, snf_call_t& c, const LeadAgg& g) {
 
 // phase_sv: majority HP / PS over distinct read_id (last lead of a read wins); fills the phase part of LeadAgg
 #define SNF_BIG_FINAL_CAP 512   /* leads of a call whose rows x_big<2> keeps in LDS */
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
 // collect_agg for a call with more than 64 leads, executed by the whole wave (x_big<2>, "uniform" mode: every lane runs the
 // finalize body in lock step).  The serial form walks the leads one by one through six dependent gathers and looks for a later
 // lead of the same read with a second loop: with a few hundred leads that is 10^4-10^5 dependent loads per call.  Here a lane
@@ -230,7 +230,7 @@ SNF_D void collect_agg_wave(const View& v, const CallX& x, int task, LeadAgg* g)
 #endif
 
 SNF_HD void collect_agg(const View& v, const CallX& x, int task, LeadAgg* g) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNF_EMU)
+#if defined(__HIP_DEVICE_COMPILE__)
   if (v.wave_uniform) { collect_agg_wave(v, x, task, g); return; }
 #endif
   g->nm_row = nullptr; g->has_nm_mean = 0; g->nm_mean = 0.0;

@@ -100,7 +100,6 @@ SNF_HD void f2_scan_body(int64_t i, const View& v) {
   f2_emit(v, i, val[0], v.pL[i], (unsigned long long)v.sc_rd[i]);
 }
 
-#ifndef SNF_EMU
 // ---- gfx950: F1 | F2 as a "sizes + tile sums" / "tile prefix + block scan + emit" pair like e2a_sizes / e3b_offsets (snf_fused.h):
 // every block of F2 sums the preceding 256-call tiles directly (finalize may run more than once per candidate stage, so the
 // atomically accumulated super-tile sums of the candidate stage's chains are not used here).  The grid covers the upper bound
@@ -184,6 +183,5 @@ __global__ void __launch_bounds__(256) f4w_emit(const View v, int64_t n) {
     for (int32_t k = lane; k < rn_len; k += 64) rn[k] = v.rnames[rn_src + k];
   }
 }
-#endif  // !SNF_EMU
 
 }  // namespace snf

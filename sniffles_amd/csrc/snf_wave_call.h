@@ -6,7 +6,6 @@
 #pragma once
 #include "snf_wave_refine.h"
 
-#ifndef SNF_EMU
 namespace snf {
 
 struct CallLds { int32_t buf[SNF_WAVE]; double nm[SNF_WAVE]; };
@@ -431,4 +430,3 @@ __global__ void __launch_bounds__(SNF_WAVE) x_big(View v, int64_t n_unused) {
 }
 
 }  // namespace snf
-#endif  // !SNF_EMU

@@ -26,7 +26,6 @@
 #pragma once
 #include "snf_stage_final.h"
 
-#ifndef SNF_EMU
 namespace snf {
 
 #define SNF_KEY_EMPTY (~0ull)
@@ -585,4 +584,3 @@ __global__ void __launch_bounds__(64) e4c_copy(const View v, int64_t n_unused) {
 }
 
 }  // namespace snf
-#endif  // !SNF_EMU

@@ -9,7 +9,6 @@
 #pragma once
 #include "snf_stage_call.h"
 
-#ifndef SNF_EMU
 namespace snf {
 
 #define SNF_WAVE 64
@@ -319,4 +318,3 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
 }
 
 }  // namespace snf
-#endif  // !SNF_EMU

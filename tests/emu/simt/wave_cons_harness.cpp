@@ -20,6 +20,11 @@ using namespace snf;
 static char g_err[512];
 extern "C" const char* simt_last_error() { return g_err; }
 
+// the column vote of the LDS-vote instances on its own (tests/test_emu_parity.py pins it on the plain rule)
+extern "C" int snf_emu_vote_column(uint32_t cnt4, const uint32_t* esc, int n_esc, int q, int bq, int nkept) {
+  return (int)vote_column(cnt4, esc, n_esc, q, (uint8_t)bq, nkept);
+}
+
 // cls_out[p]: class the call ran in (1 SMALL, 2 LARGE, 4 ROWS, 0 verbatim copy); handed_over: calls SMALL / LARGE passed on to ROWS
 extern "C" int simt_consensus_batch(int mode, int nw, int grid_cap, int min_reads, int klen, const uint8_t* seq_pool, int64_t seq_pool_len,
                                     int64_t np, const int64_t* best_off, const int32_t* best_len, const int32_t* skip,

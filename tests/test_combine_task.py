@@ -207,11 +207,11 @@ def _object_fields(c):
     return d
 
 
-def check_columns_equal_objects(_lib, monkeypatch):
-    for name in NAMES:
+def check_columns_equal_objects(_lib, monkeypatch, names=None, options=None):
+    for name in (names or NAMES):
         doc = gu.load(name)
         exp = doc["expected"]
-        for extra in TWIN_OPTIONS:
+        for extra in (options or TWIN_OPTIONS):
             out = []
             for objects in ("0", "1"):
                 monkeypatch.setenv("SNF_COMBINE_OBJECTS", objects)
@@ -243,8 +243,11 @@ def check_columns_equal_objects(_lib, monkeypatch):
 
 
 def test_columnar_store_equals_the_object_replay_emu(monkeypatch):
+    """(Host tier: two goldens x a cross-section of the option sets - the wave-per-window edit distance is slow on fibres; the
+    GPU twin below runs all of them.)"""
     import emu.emu as E
-    check_columns_equal_objects(E.lib(), monkeypatch)
+    check_columns_equal_objects(E.lib(), monkeypatch, names=["combine_task_3samples_lowcov", "combine_task_5samples_medians"],
+                                options=[TWIN_OPTIONS[0]] + list(TWIN_OPTIONS[1::3]))
 
 
 @pytest.mark.gpu

@@ -1,7 +1,8 @@
-"""Kernel-logic parity WITHOUT a GPU: the exact kernel bodies of sniffles_amd/csrc (compiled for the
-host by tests/emu, serial loops instead of launches) against the reference goldens and the oracle.
-This is a development aid for the GPU-less build container; the parity tests proper are
-tests/test_gpu_parity.py (-m gpu), which run the real gfx950 library."""
+"""The fallback forms of the pass WITHOUT a GPU: SNF_NO_WAVE=1 (thread-per-item kernels instead of the wave / workgroup kernels -
+the bodies the big-cluster kernels and the rare ALT fallbacks also run) and SNF_NO_FUSE=1 (device-wide scans instead of the
+fused flag / scan / emit pairs - what batches beyond 2^25 positions take), through the host tier (tests/emu/simt), against the
+reference goldens and the oracle.  tests/test_simt_tier.py runs the default (wave, fused) forms the same way; the parity tests
+proper are tests/test_gpu_parity.py (-m gpu) on the real gfx950 library."""
 import numpy as np
 import pytest
 
@@ -15,6 +16,12 @@ from sniffles_amd.config import SnifflesConfig
 def emu_lib():
     import emu.emu as E
     return E.lib()
+
+
+@pytest.fixture(autouse=True)
+def fallback_forms(monkeypatch):
+    monkeypatch.setenv("SNF_NO_WAVE", "1")
+    monkeypatch.setenv("SNF_NO_FUSE", "1")
 
 
 def run(L, cfg, tis, fin):

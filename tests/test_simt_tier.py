@@ -3,10 +3,10 @@ lock-step x_big kernels included - compiled UNCHANGED with g++ against a stand-i
 fibres per thread, cross-lane operations, DPP, barriers, lock step by page tracking) and run in the GPU-less container
 against the reference's goldens and the oracle.
 
-tests/emu/emu.py (test_emu_parity.py) compiles the `SNF_EMU` halves of the sources: thread-per-item bodies as serial loops,
-and none of `snf_wave_*.h`.  This tier runs the code the GPU runs: the `#ifndef SNF_EMU` halves, the launch sequence of
-snf_lib.hip with `wave_path` on, the fused scan chains, the workgroup consensus kernels, the wave form of the extraction
-kernels.  What it cannot show is anything about timing, memory ordering between workgroups, or the compiler - the parity
+This is the only host tier (a second one, serial-loop halves behind `#ifdef SNF_EMU` inside the product sources, was retired in
+round 3): it runs the code the GPU runs - the launch sequence of snf_lib.hip with `wave_path` on, the fused scan chains, the
+workgroup consensus kernels, the wave form of the extraction kernels; tests/test_emu_parity.py runs the fallback forms
+(SNF_NO_WAVE / SNF_NO_FUSE) through the same library.  What it cannot show is anything about timing, memory ordering between workgroups, or the compiler - the parity
 tests proper remain the `-m gpu` tests."""
 import collections
 import ctypes as C
@@ -25,18 +25,6 @@ def simt():
     from emu import simt as S
     S.lib()
     return S
-
-
-@pytest.fixture()
-def as_emu(simt, monkeypatch):
-    """The CPU-tier tests of the other modules fetch their library with emu.emu.lib(): give them this tier's library."""
-    import emu.emu as E
-    monkeypatch.setattr(E, "lib", simt.lib)
-    before = simt.counters()
-    yield simt
-    after = simt.counters()
-    assert after["unmodelled"] == before["unmodelled"]              # nothing was skipped inside the library
-    assert after["lockstep_conflicts"] == before["lockstep_conflicts"]
 
 
 def run(L, cfg, tis, fin):
@@ -254,72 +242,5 @@ def test_consensus_entry_point_of_the_library(simt, monkeypatch):
     assert [i for i, (g, p) in enumerate(zip(got, probs)) if g != p["expected"]] == []
 
 
-# ---------------------------------------------------------------------------------------------- the other seams
-def test_combine_kernels(as_emu, oracle_mod):
-    import test_combine as T
-    assert len(T.NAMES) >= 3
-    for name in T.NAMES:
-        T.test_emulated_combine_matches_reference(name)
-    for separate in (False, True):
-        T.test_emulated_combine_fuzz_vs_oracle(separate, oracle_mod)
-
-
-def test_edit_distance_kernels(as_emu, oracle_mod):
-    import test_edit_distance as T
-    T.test_edit_distance_emulated(oracle_mod)
-    T.test_edit_distance_banded_emulated(oracle_mod)
-
-
-@pytest.mark.parametrize("name", ["combine_task_10samples_options", "combine_task_5samples_medians", "combine_task_6samples",
-                                  "combine_task_8samples_dense"])
-def test_combine_task_driver(name, as_emu):
-    import test_combine_task as T
-    T.test_combine_task_driver_matches_reference_emu(name)
-
-
-def test_combine_task_scatter_and_cuts(as_emu):
-    import test_combine_task as T
-    T.test_combine_task_scatter_matches_reference_emu()
-    T.test_chain_cuts_keep_the_assignment_emu()
-    T.test_combine_task_reqc_regenotypes_the_candidates_emu()
-
-
-@pytest.mark.parametrize("name", ["bnd_stale_end", "fuzz_4_2", "chr21_30x_mosaic", "long_ins", "bnd_first"])
-def test_genotype_task(name, as_emu):
-    import test_genotype as T
-    T.test_genotype_task_emu(name)
-
-
-@pytest.mark.parametrize("name", ["chr20_30x_ont", "chr22_60x_hifi", "fuzz_3_0", "fuzz_6_0", "gt_failed_edges", "phase_rescue"])
-def test_regenotype(name, as_emu):
-    import test_genotype as T
-    T.test_regenotype_matches_reference_emu(name)
-
-
-def test_extraction_kernels_wave_form(simt, oracle_mod):
-    """tests/test_extract.py with this tier's library: the WAVE form of the extraction kernels (ballots, DPP scans)."""
-    import test_extract as T
-    L = simt.lib()
-    assert len(cases.EXTRACT) >= 3
-    for name in sorted(cases.EXTRACT):
-        T.test_kernel_bodies_match_reference(name, L)
-    T.test_reference_known_answer_reads_kernels(L)
-    T.test_empty_and_foreign_records(L)
-    T.test_extracted_task_feeds_the_clustering_path(L, oracle_mod)
-    T.check_device_handover(L, oracle_mod)
-
-
-def test_bam_to_vcf_end_to_end(as_emu, tmp_path):
-    import test_pipeline as T
-    names = [m.args[1] for m in T.test_bam_to_vcf_and_snf_emu.pytestmark if m.name == "parametrize"][0]
-    for k, name in enumerate(names):
-        d = tmp_path / str(k)
-        d.mkdir()
-        T.test_bam_to_vcf_and_snf_emu(name, d)
-
-
-def test_drop_in_entry_points(as_emu):
-    import test_dropin_api as T
-    names = [m.args[1] for m in T.test_task_entry_points_emulated.pytestmark if m.name == "parametrize"][0]
-    for name in names:
-        T.test_task_entry_points_emulated(name)
+# (The combine / edit-distance / CombineTask / genotype / extraction / BAM -> VCF / drop-in tests live in their own modules and
+# run on this same library since the serial-emulation tier was retired: tests/emu/emu.py hands out this tier.)
