@@ -78,3 +78,48 @@ def test_edit_distance_gpu_thread_and_wave_paths(oracle_mod):
     pairs = make_pairs(3, sizes, alphabet=b"ACGTN")
     got = lib.edit_distance_batch(pairs)
     assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]
+
+
+def test_population_variant_match_is_the_reference_rule(oracle_mod):
+    """`snfp.PopulationVariant.match` (`/root/reference/src/sniffles/snfp.py:91-107`): position / length gate, then for insertions
+    `edlib.align(self.alt, svcall.alt)['editDistance']` against `combine_pctseq` - restated with the exact DP (edlib is absent:
+    parity unpinned against edlib itself) and compared with the batched GPU form."""
+    import math
+    import numpy as np
+    import emu.emu as E
+    from types import SimpleNamespace as NS
+    from sniffles_amd import snfp
+    from sniffles_amd.config import SnifflesConfig
+    rng = np.random.default_rng(3)
+    cfg = SnifflesConfig()
+
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+    pairs = []
+    for _ in range(120):
+        n = int(rng.integers(60, 900))
+        a = rnd(n)
+        b = list(a)
+        for i in range(len(b)):
+            if rng.random() < float(rng.choice([0.0, 0.05, 0.3, 0.45, 0.8])):
+                b[i] = "ACGT"[rng.integers(0, 4)]
+        b = "".join(b)[:max(50, n - int(rng.integers(0, 30)))]
+        t = "INS" if rng.random() < 0.8 else "DEL"
+        pv = snfp.PopulationVariant("chr1", int(rng.integers(1000, 1200)), "x", a, t, n if t == "INS" else -n, 0, 0.1, 10, 2)
+        sv = NS(pos=pv.pos + int(rng.integers(-1300, 1300)), svlen=(len(b) if t == "INS" else -len(b)), svtype=t, alt=b)
+        pairs.append((pv, sv))
+    got = snfp.match_batch(pairs, cfg, _lib=E.lib())
+    exp = []
+    for pv, sv in pairs:
+        dist = abs(pv.pos - sv.pos) + abs(abs(pv.svlen) - abs(sv.svlen))
+        minlen = float(min(abs(pv.svlen), abs(sv.svlen)))
+        if dist > cfg.combine_match * math.sqrt(minlen) or dist > cfg.combine_match_max:
+            exp.append(None); continue
+        if pv.svtype == "INS" and cfg.combine_pctseq:
+            d = oracle_mod.edit_distance(pv.alt.encode(), sv.alt.encode())
+            if (pv.svlen - d) / pv.svlen <= cfg.combine_pctseq:
+                exp.append(None); continue
+        exp.append(dist)
+    assert got == exp and sum(e is not None for e in exp) > 10 and sum(e is None for e in exp) > 10
+    assert pairs[0][0].match(pairs[0][1], cfg, _lib=E.lib()) == exp[0]
+    assert snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)}) == (0.75, 2, 2)
