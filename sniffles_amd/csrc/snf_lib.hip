@@ -247,6 +247,7 @@ struct snf_batch_impl {
   std::vector<int32_t> h_rend_max; // per task: largest read end (filled by the upload's validation pass)
   bool uploaded = false;
   bool finalized = false;         // run_finalize has run on the current candidates
+  int finalize_runs = 0;          // finalize calls since the last call_candidates
   int rn_state = 0;               // supporting read names of the current candidates: 0 all written, 1 deferred (sizes only), 2 written for the kept calls
   int64_t pf_words = 0;           // prefilter bitmap size (uint32 words)
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
@@ -638,6 +639,7 @@ void enqueue_pass_init(snf_batch_impl* b);
 void enqueue_keys(snf_batch_impl* b);
 
 void do_upload(snf_batch_impl* b) {
+  SNF_TRACE("snf_batch_upload");
   View& v = b->v;
   const double t_begin = now_ms();
   int T = (int)b->tasks.size();
@@ -979,6 +981,7 @@ void enqueue_read_index(snf_batch_impl* b) {
 }
 
 void enqueue_read_prep(snf_batch_impl* b) {
+  SNF_TRACE("coverage mean (side stream)");
   View& v = b->v;
   int64_t R = v.R; int T = v.T;
   // independent of the lead pipeline until d4_coverage, so it runs on the side stream
@@ -1014,6 +1017,7 @@ void enqueue_pass_init(snf_batch_impl* b) {
     int64_t n0 = 8 * (int64_t)T + 8;
     if (TS_SLOTS * v.super_stride > n0) n0 = TS_SLOTS * v.super_stride;
     if ((int64_t)(sizeof(Counts) / 8) > n0) n0 = (int64_t)(sizeof(Counts) / 8);
+    if (3 * 64 * 16 > n0) n0 = 3 * 64 * 16;
     FUSED(z0_init, n0);
   } else {
     dzero(b, v.cnt, sizeof(Counts));
@@ -1028,6 +1032,7 @@ void enqueue_pass_init(snf_batch_impl* b) {
 }
 // sort keys of the leads; with the occupancy prefilter: marks, keep flags and the compacted (key, index) pairs of the kept leads
 void enqueue_keys(snf_batch_impl* b) {
+  SNF_TRACE("A0: keys + occupancy prefilter");
   View& v = b->v;
   const int64_t N = v.N;
   if (N <= 0) return;
@@ -1044,6 +1049,7 @@ void enqueue_keys(snf_batch_impl* b) {
 }
 
 void run_call_candidates(snf_batch_impl* b) {
+  SNF_TRACE("snf_batch_call_candidates (enqueue)");
   View& v = b->v;
   int T = v.T;
   const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
@@ -1057,7 +1063,8 @@ void run_call_candidates(snf_batch_impl* b) {
   // fused chains: two-level tile sums cost O(N / 16384) loads per block, fine up to a few 10^7 elements; beyond that
   // (and in the emulation build) the plain device-wide scans are used
   enqueue_pass_init(b);
-  if (v.wave_path) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);
+  if (v.wave_path && !b->fused) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);   // (fused: z0_init)
+  b->finalize_runs = 0;
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
   enqueue_keys(b);
@@ -1219,6 +1226,7 @@ void enqueue_rnames_late(snf_batch_impl* b, bool all) {
 }
 
 void enqueue_output_head(snf_batch_impl* b) {
+  SNF_TRACE("F: output stage (filter, rank, records + read names)");
   View& v = b->v;
   const int64_t NS = v.NS;
   enqueue_rnames_late(b, !((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc));
@@ -1248,6 +1256,7 @@ void enqueue_output_head(snf_batch_impl* b) {
 // knows: the one place where finalize waits for the device.  Taken by the emulation build (always), by SNF_NO_WAVE, and - from
 // the fetch, after the fact - when a call fits none of the LDS classes or a workgroup handed its call over (escape list).
 void run_alt_fallback(snf_batch_impl* b) {
+  SNF_TRACE("E: slow ALT kernels (ROWS / thread form)");
   View& v = b->v;
   d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
   dsync(b);
@@ -1283,6 +1292,7 @@ void run_alt_fallback(snf_batch_impl* b) {
 // caller knows the class counts): workgroups behind the end of a class's list return at once, and the kernels stride when
 // a list is longer than the grid.
 void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large, int64_t g_copy) {
+  SNF_TRACE("E4/E5: INS consensus (SMALL / LARGE / verbatim)");
   View& v = b->v;
     const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
     if (serial) SNF_HIP(hipDeviceSynchronize());
@@ -1318,6 +1328,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
 }
 
 void run_finalize(snf_batch_impl* b) {
+  SNF_TRACE("snf_batch_finalize (enqueue)");
   View& v = b->v;
   const int64_t NS = v.NS;
   b->finalized = true;
@@ -1348,7 +1359,7 @@ void run_finalize(snf_batch_impl* b) {
   {  // QC / phasing / genotyping only touch the scalar call fields: side stream (behind d4_coverage, whose
      // annotations they read), overlapped with the consensus chain
     SideStream side(b);
-    if (v.wave_path) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // finalize may run more than once per candidate stage
+    if (v.wave_path && b->finalize_runs++ > 0) dzero(b, v.big_cnt + 2 * 64 * 16, sizeof(uint32_t) * 64 * 16);   // (the first finalize finds the list empty; a repeated one empties it again)
     if (v.wave_path) {
       Scope _s(b, "e1w_finalize", 0);
       // one workgroup (= wave) per batch of e1_batch calls, dispatched by the hardware (the kernel strides when there are
@@ -1483,6 +1494,7 @@ void settle_alt_stage(snf_batch_impl* b) {
 }
 
 void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
+  SNF_TRACE(stage >= 1 ? "snf_batch_fetch(1): wait + result block" : "snf_batch_fetch(0): wait + candidates");
   View& v = b->v;
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);

@@ -10,6 +10,8 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime.h>
 #define SNF_HD __host__ __device__ __forceinline__
 #define SNF_D __device__ __forceinline__
@@ -31,6 +33,35 @@ struct Error {
       ::snf::fail(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ + ":" + \
                   std::to_string(__LINE__) + ")");                                            \
   } while (0)
+
+// ---- roctx ranges (the reference has per-stage debug output; here the stages of a pass show up as named
+// ranges in rocprofv3 --marker-trace / omnitrace).  libroctx64 is looked up at run time and only when SNF_ROCTX=1, so the
+// library has no link-time dependency on the tracer and the default path pays one predictable branch per range.
+struct Roctx {
+  typedef int (*push_t)(const char*); typedef int (*pop_t)();
+  push_t push = nullptr; pop_t pop = nullptr;
+  static Roctx& get() {
+    static Roctx r = [] {
+      Roctx q;
+      const char* e = getenv("SNF_ROCTX");
+      if (e && atoi(e) != 0) {
+        void* h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h) { q.push = (push_t)dlsym(h, "roctxRangePushA"); q.pop = (pop_t)dlsym(h, "roctxRangePop"); }
+        if (!q.push || !q.pop) { q.push = nullptr; q.pop = nullptr; fprintf(stderr, "[sniffles_amd] SNF_ROCTX=1 but libroctx64.so could not be loaded\n"); }
+      }
+      return q;
+    }();
+    return r;
+  }
+};
+struct TraceRange {
+  bool on;
+  explicit TraceRange(const char* name) : on(Roctx::get().push != nullptr) { if (on) Roctx::get().push(name); }
+  ~TraceRange() { if (on) Roctx::get().pop(); }
+  TraceRange(const TraceRange&) = delete; TraceRange& operator=(const TraceRange&) = delete;
+};
+#define SNF_TRACE(name) ::snf::TraceRange _snf_trace_##__LINE__(name)
 
 // ---- atomics usable from kernel bodies -------------------------------------------------------
 SNF_HD unsigned long long atomic_add_u64(unsigned long long* p, unsigned long long v) {

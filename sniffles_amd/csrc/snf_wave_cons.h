@@ -577,7 +577,9 @@ __global__ void __launch_bounds__(64) e4c_copy(const View v, int64_t n_unused) {
     const ConsDesc d = v.cdesc[list[it]];
     const uint8_t* B = v.pool + d.best_off;
     uint8_t* alt = alt_base(v) + d.alt_off;
-    for (int64_t q = threadIdx.x; q < d.L; q += 64) alt[q] = B[q];
+    const int32_t full = d.L & ~15;     // 16 bytes per lane and step (unaligned vector accesses; the pool has slack behind every sequence), byte tail
+    for (int32_t o = (int32_t)threadIdx.x * 16; o < full; o += 64 * 16) *(u128_unaligned*)(alt + o) = *(const u128_unaligned*)(B + o);
+    if ((int32_t)threadIdx.x < d.L - full) alt[full + threadIdx.x] = B[full + threadIdx.x];
     bytes_acc += 2ull * (unsigned long long)d.L;
   }
   if (threadIdx.x == 0 && bytes_acc) atomicAdd(&v.stripes[(3 * 64 + (blockIdx.x & 63)) * 16], bytes_acc);
