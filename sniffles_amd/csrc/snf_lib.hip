@@ -326,6 +326,7 @@ T* dalloc(snf_batch_impl* b, size_t n) {
       b->bufs.back().slab = true;
     }
     b->slab_cap = cap; b->slab_used = 0;
+    b->slab_next = (size_t)256 << 20;   // a batch that outgrows its first slab continues in small ones
   }
   T* p = (T*)(b->slab + b->slab_used);
   b->slab_used += bytes;
@@ -670,7 +671,14 @@ void do_upload(snf_batch_impl* b) {
   }
   // everything allocated below fits one slab of this size (per-lead arrays ~1.9 KB/lead, the pool twice, the reads);
   // anything beyond it simply opens another slab
-  b->slab_next = (size_t)N * 1408 + (size_t)v.pool_cap + (size_t)R * 96 + ((size_t)4 << 20);
+  // (+ the ALT pool, the prefilter's columns and bitmap, and the output block sized for half of the leads behind the sort;
+  // whatever does not fit opens a second, small slab)
+  {
+    size_t cells = 0;
+    const int bs0 = b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1;
+    for (auto& t : b->tasks) cells += (size_t)SNF_NTYPES * ((size_t)t.contig_len / bs0 + 1);
+    b->slab_next = (size_t)N * (1408 + 16 + 8) + 2 * (size_t)v.pool_cap + (size_t)R * 96 + cells / 4 + ((size_t)N / 2) * (sizeof(snf_call_t) + 32) + ((size_t)8 << 20);
+  }
   v.cnt = dalloc<Counts>(b, 1);
   {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
     size_t bytes = sizeof(Counts) + 8 + ((size_t)T + 1) * 8 + (size_t)T * 8 + (size_t)T * 4 + 8 + sizeof(OutHdr) + 8;
