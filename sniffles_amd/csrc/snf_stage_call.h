@@ -630,7 +630,8 @@ SNF_HD void r3_maxdepth_body(int64_t r, const MaxDepth& p) {
   const int64_t ne = bound_top_i32<true>(p.re_sorted, p.re_top, lo, hi, x) - lo;
   const int32_t d = (int32_t)(ns - ne);
 #if defined(__HIP_DEVICE_COMPILE__)
-  atomicMax(&p.t_max_depth[t], d);
+  // (millions of reads of a task would queue on one address: only a depth above what is already recorded goes to the atomic)
+  if (d > __atomic_load_n(&p.t_max_depth[t], __ATOMIC_RELAXED)) atomicMax(&p.t_max_depth[t], d);
 #else
   if (d > p.t_max_depth[t]) p.t_max_depth[t] = d;
 #endif
