@@ -173,6 +173,66 @@ def main_consensus():
     print(f"consensus_novel_from_reads: {len(cases_)} problems, {changed} with a consensus that differs from the best read")
 
 
+def main_consensus_long():
+    """Golden vectors for seam B4 with LONG copied segments (anchors far apart): stretches of an other read in which every
+    sampled k-mer carries a substitution (the stretch stays > 50 % identical: copied as one segment), stretches that leave
+    the +-6 shift window and come back to the same shift (not copied), the same with odd characters - from the reference's
+    own consensus.novel_from_reads."""
+    import numpy as np
+    import ref_harness as rh
+    ref = rh.load_reference()
+    rng = np.random.default_rng(20260925)
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    class L:
+        def __init__(self, seq):
+            self.seq = seq
+
+    def other_base(c):
+        return int(alpha[(int(np.searchsorted(alpha, c)) + int(rng.integers(1, 4))) % 4])
+
+    cases_ = []
+    for k in range(60):
+        Lb = int([300, 380, 1500, 3000, 6100, 8000][k % 6])
+        skip = 3 + int(Lb * (1.0 / 500.0))
+        if k >= 36:     # sampling steps longer than the 24-byte register window of the kernels (consensus_kmer_skip_base is free)
+            skip = int([24, 31, 40, 23][k % 4])
+        truth = alpha[rng.integers(0, 4, Lb)].copy()
+        best = truth.copy()
+        err = rng.random(Lb) < float(rng.choice([0.0, 0.02, 0.05]))
+        best[err] = [other_base(c) for c in best[err]]
+        others = []
+        for r in range(int(rng.choice([3, 5, 9, 14]))):
+            o = truth.copy()
+            sub = rng.random(Lb) < 0.01
+            o[sub] = [other_base(c) for c in o[sub]]
+            o = bytearray(o.tobytes())
+            kind = int(rng.integers(0, 5))
+            a = int(rng.integers(0, max(1, Lb // 2)))
+            b = min(Lb - 12, a + int(rng.choice([60, 100, 200, 520, 1100, 2600])))
+            if kind <= 2 and b > a + 20:
+                # every k-mer sampled inside [a, b) broken by one substitution (kind 2: two per sampling step where the step allows)
+                for j in range((a // skip + 1) * skip, b, skip):
+                    o[j + 2] = other_base(o[j + 2])
+                    if kind == 2 and skip >= 8:
+                        o[j + 5] = other_base(o[j + 5])
+            elif kind == 3 and b > a + 40:
+                ins = bytes(alpha[rng.integers(0, 4, 8)].tolist())      # shift +8 inside [a, b), back to 0 behind it
+                o = o[:a] + ins + o[a:b] + o[b + 8:]
+            if rng.random() < 0.2:
+                for j in rng.integers(0, len(o), 6):
+                    o[int(j)] = int(rng.choice(list(b"Nnacgt")))
+            others.append(bytes(o))
+        bs = best.tobytes().decode("latin-1")
+        exp = ref.consensus.novel_from_reads(L(bs), [L(o.decode("latin-1")) for o in others], klen=6, skip=skip, skip_repetitive=skip)
+        cases_.append(dict(best=bs, others=[o.decode("latin-1") for o in others], klen=6, skip=skip, expected=exp))
+    doc = dict(case="consensus_long_segments", n=len(cases_), problems=cases_)
+    with gzip.GzipFile(os.path.join(ROOT, "tests", "golden", "consensus_long_segments.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(doc, sort_keys=True, separators=(",", ":")).encode())
+    changed = sum(1 for c in cases_ if c["expected"] != c["best"])
+    print(f"consensus_long_segments: {len(cases_)} problems, {changed} with a consensus that differs from the best read")
+
+
 def main_combine_task(names=None):
     """Goldens for the CombineTask.execute driver: inputs (SNF blocks per sample) and the combined calls it emits."""
     import cases
@@ -419,7 +479,7 @@ if __name__ == "__main__":
     # python oracle/make_golden.py                 -> every fixture family
     # python oracle/make_golden.py vcf sample      -> only these families
     # python oracle/make_golden.py main fuzz_4_2   -> single cases of the `main` / `combine` families
-    FAMILIES = dict(main=main, clusters=main_clusters, regenotype=main_regenotype, combine=main_combine, consensus=main_consensus, combine_task=main_combine_task,
+    FAMILIES = dict(main=main, clusters=main_clusters, regenotype=main_regenotype, combine=main_combine, consensus=main_consensus, consensus_long=main_consensus_long, combine_task=main_combine_task,
                     bam=main_bam_fixtures, extract=main_extract, snf=main_snf, vcf=main_vcf, sample=main_sample, genotype=main_genotype, population=main_population, genotype_vcf=main_genotype_vcf)
     argv = sys.argv[1:]
     fams = [a for a in argv if a in FAMILIES] or list(FAMILIES)

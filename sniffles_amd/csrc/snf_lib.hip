@@ -904,6 +904,9 @@ void do_upload(snf_batch_impl* b) {
   v.stage_cap = getenv("SNF_NO_BIG_STAGE") ? 0 : 1;   // x_big<0>: clusters up to SNF_BIG_STAGE_CAP leads are kept in LDS
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);
+#ifdef SNF_WG_TRACE
+  if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 16)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 16)); }
+#endif
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
   v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
@@ -1316,14 +1319,8 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
         SNF_HIP(hipGetLastError()); }
       b->cur = prev;
     }
-    if (serial) SNF_HIP(hipDeviceSynchronize());
-    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
-    {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
-      Scope _s(b, "e4c_copy", 0);
-      hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    }
-    {
+    static const int small_after = getenv("SNF_SMALL_AFTER_LARGE") ? atoi(getenv("SNF_SMALL_AFTER_LARGE")) : 0;
+    auto launch_small = [&]() {
       Scope _s(b, "e45w_consensus_small", 0);
       const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
       if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < 65536 ? g_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
@@ -1331,7 +1328,16 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
       else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
+    };
+    if (small_after) { hipStream_t prev = b->cur; b->cur = b->stream3; launch_small(); b->cur = prev; }
+    if (serial) SNF_HIP(hipDeviceSynchronize());
+    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+    {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
+      Scope _s(b, "e4c_copy", 0);
+      hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+      SNF_HIP(hipGetLastError());
     }
+    if (!small_after) launch_small();
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
@@ -1351,8 +1357,9 @@ void run_finalize(snf_batch_impl* b) {
     // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
     const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
-    v.alt_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_alt.p;
-    v.alt_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_alt.cap;
+    static const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr;   // measurement: ALT bytes into the HBM pool, copied at fetch
+    v.alt_pin = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? nullptr : (uint8_t*)b->hb_alt.p;
+    v.alt_pin_cap = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? 0 : (int64_t)b->hb_alt.cap;
   }
   v.out_valid = 1;
   // Launch sizes of the data-dependent kernels.  Grids much larger than the work flood the dispatcher with empty workgroups
@@ -1449,6 +1456,37 @@ void run_finalize(snf_batch_impl* b) {
 
 void collect_timings(snf_batch_impl* b) {
   b->timings.clear();
+#ifdef SNF_WG_TRACE
+  if (getenv("SNF_PROF") && b->v.wgtrace) {
+    const int64_t n = 1 << 19;
+    std::vector<unsigned long long> h((size_t)n * 4);
+    (void)hipMemcpy(h.data(), b->v.wgtrace, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipMemset(b->v.wgtrace, 0, h.size() * 8);
+    for (int cls = 1; cls <= 2; cls++) {
+      struct E { unsigned long long t0, dur; int L, no; unsigned long long ph, rp; };
+      std::vector<E> es;
+      for (int64_t i = 0; i < n; i++) { const unsigned long long m = h[2 * i + 1]; if (m && (int)((m >> 28) & 15) == cls) es.push_back({h[2 * i], m >> 32, (int)(m & 0xffff), (int)((m >> 16) & 0xff), h[2 * (i + n)], h[2 * (i + n) + 1]}); }
+      if (es.empty()) continue;
+      unsigned long long t_min = ~0ull, t_max = 0, sum = 0;
+      for (auto& e : es) { t_min = std::min(t_min, e.t0); t_max = std::max(t_max, e.t0 + e.dur); sum += e.dur; }
+      std::sort(es.begin(), es.end(), [](const E& a, const E& c) { return a.dur > c.dur; });
+      fprintf(stderr, "[SNF_WG_TRACE] %s: %zu workgroups, span %.1f us, sum of durations %.1f us (mean %.2f), longest:\n", cls == 1 ? "SMALL" : "LARGE", es.size(),
+              (t_max - t_min) * 0.01, sum * 0.01, sum * 0.01 / es.size());
+      for (size_t k = 0; k < es.size() && k < 8; k++)
+        fprintf(stderr, "[SNF_WG_TRACE]    start +%.1f us, %.1f us, L %d, others %d | wave 0: setup %.1f reads %.1f barrier %.1f vote+store %.1f | reads: probes %.1f scan(+filter) %.1f segments %.1f geom+prefetch %.1f votes %.1f\n", (es[k].t0 - t_min) * 0.01, es[k].dur * 0.01, es[k].L, es[k].no,
+          (es[k].ph & 0xffff) * 0.01, ((es[k].ph >> 16) & 0xffff) * 0.01, ((es[k].ph >> 32) & 0xffff) * 0.01, (es[k].ph >> 48) * 0.01,
+          (es[k].rp & 0xfff) * 0.1, ((es[k].rp >> 12) & 0xfff) * 0.1, ((es[k].rp >> 24) & 0xfff) * 0.1, ((es[k].rp >> 36) & 0xfff) * 0.1, ((es[k].rp >> 48) & 0xfff) * 0.1);
+      { std::vector<E> byt = es; std::sort(byt.begin(), byt.end(), [](const E& a, const E& c) { return a.t0 < c.t0; });
+        for (size_t k = 0; k < byt.size(); k += byt.size() / 10 + 1) fprintf(stderr, "[SNF_WG_TRACE]    #%zu by start: +%.1f us, %.1f us, L %d, others %d | setup %.1f reads %.1f barrier %.1f vote+store %.1f\n", k, (byt[k].t0 - t_min) * 0.01, byt[k].dur * 0.01, byt[k].L, byt[k].no,
+          (byt[k].ph & 0xffff) * 0.01, ((byt[k].ph >> 16) & 0xffff) * 0.01, ((byt[k].ph >> 32) & 0xffff) * 0.01, (byt[k].ph >> 48) * 0.01); }
+      const int NB = 12; std::vector<int> act(NB, 0), fin(NB, 0);
+      for (auto& e : es) for (int k = 0; k < NB; k++) { const unsigned long long t = t_min + (t_max - t_min) * (2 * k + 1) / (2 * NB); if (e.t0 <= t && t < e.t0 + e.dur) act[k]++; }
+      fprintf(stderr, "[SNF_WG_TRACE]    workgroups in flight at 12 points of the span:");
+      for (int k = 0; k < NB; k++) fprintf(stderr, " %d", act[k]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 #ifdef SNF_CONS_PROFILE
   if (getenv("SNF_PROF")) {
     static const char* nm[9] = {"setup+table", "kmers+probes", "chain", "segments", "run filter", "votes", "barrier+vote+store", "longest workgroup", "workgroups"};
@@ -1901,6 +1939,7 @@ int snf_device_count(void) {
 struct StreamPool {
   std::mutex mu;
   std::vector<hipStream_t> idle[64];
+  std::vector<hipStream_t> idle_hi[64];   // streams of the highest priority the device offers (the LARGE consensus class, see take_high)
   hipStream_t take(int device) {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -1911,11 +1950,35 @@ struct StreamPool {
     SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
+  // A kernel of few, large workgroups (72 KB of LDS, 4 x 199 VGPRs each) only gets a compute unit when that much is free at
+  // once: next to kernels of many small workgroups it is starved until they have drained (measured: LARGE 0.2 ms alone,
+  // 0.7 ms next to SMALL + e1w - the ALT stage ran them one after the other with the longest one last).  Its queue gets the
+  // dispatcher's priority instead.
+  hipStream_t take_high(int device) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto& v = idle_hi[device & 63];
+      if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    int least = 0, greatest = 0;
+    if (!getenv("SNF_STREAM_PRIO") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    SNF_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+    return s;
+  }
+  void give_high(int device, hipStream_t s) {
+    {
+      std::lock_guard<std::mutex> g(mu);
+      auto& v = idle_hi[device & 63];
+      if (v.size() < 32 && !getenv("SNF_NO_STREAM_POOL")) { v.push_back(s); return; }
+    }
+    (void)hipStreamDestroy(s);
+  }
   int trim(int device) {      // idle streams of `device` (< 0: all) are destroyed
     std::vector<std::pair<int, hipStream_t>> gone;
     {
       std::lock_guard<std::mutex> g(mu);
-      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); }
+      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); for (auto s : idle_hi[d]) gone.push_back({d, s}); idle_hi[d].clear(); }
     }
     int cur = 0; (void)hipGetDevice(&cur);
     for (auto& e : gone) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
@@ -1973,7 +2036,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
     b->stream = g_streams.take(b->device);
     b->stream2 = g_streams.take(b->device);
-    b->stream3 = g_streams.take(b->device);
+    b->stream3 = g_streams.take_high(b->device);
     b->stream4 = g_streams.take(b->device);
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_e3, hipEventDisableTiming));
@@ -2060,7 +2123,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
-  if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
+  if (b->stream3) g_streams.give_high(b->device, b->stream3);   // (synchronised above)
   if (b->stream4) g_streams.give(b->device, b->stream4);   // (synchronised above)
   if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
   delete b;

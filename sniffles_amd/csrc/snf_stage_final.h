@@ -620,7 +620,10 @@ SNF_HD uint64_t kmer_key(const uint8_t* s, int klen) {
   for (int i = 0; i < klen; i++) k = (k << 8) | s[i];
   return k;
 }
-SNF_HD int64_t kmer_slot(uint64_t key, int64_t hs) { return (int64_t)((key * 0x9E3779B97F4A7C15ull) >> 17) & (hs - 1); }
+// slot of a k-mer key in a table of hs (power of two, <= 2^24) entries: HIGH bits of the multiplicative hash - the low bits of a
+// product depend only on the low bits of the key, i.e. on the first three or four bases of the k-mer, and k-mers that share
+// them would all start probing at the same slot (measured: probe chains of tens of slots, the lookups were half of a read's time)
+SNF_HD int64_t kmer_slot(uint64_t key, int64_t hs) { return (int64_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & (hs - 1); }
 
 // E4: anchor table of the best read: k-mers seen exactly once among the sampled positions (consensus.py:289-299)
 SNF_HD void e4_anchor_body(int64_t cid, const View& v) {

@@ -232,6 +232,9 @@ struct View {
   unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains
   ConsDesc* cdesc;           // [n_cons] by cons id
+#ifdef SNF_WG_TRACE
+  unsigned long long* wgtrace;   // measurement build only (-DSNF_WG_TRACE): per consensus call {start, duration | shape} in 100 MHz ticks
+#endif
   int32_t* cls_list[8];      // cons ids per work list (see Counts::n_cls; 6 unused), appended with wave-aggregated atomics
   // clusters / refined clusters / calls with more than 64 leads, collected by the wave kernels (kind 0 d1w_refine, 1 d2w_call,
   // 2 e1w_finalize) in 64 stripes (item & 63) and served one wave each by x_big<kind> (snf_wave_call.h)

@@ -37,6 +37,10 @@ namespace snf {
 #define SNF_PT(k) do { const unsigned long long pt_n = __builtin_amdgcn_s_memtime(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; } while (0)
 #define SNF_PT_FLUSH(base) do { if (lane == 0) { for (int pk = 0; pk < 7; pk++) atomicAdd(&v.cnt->dbg[(base) + pk], pt_acc[pk]); \
     if (wid == 0) { atomicMax(&v.cnt->dbg[(base) + 7], __builtin_amdgcn_s_memtime() - pt_t0); atomicAdd(&v.cnt->dbg[(base) + 8], 1ull); } } } while (0)
+#elif defined(SNF_WG_TRACE)
+#define SNF_PT_DECL unsigned long long pt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt_t = wall_clock64();
+#define SNF_PT(k) do { const unsigned long long pt_n = wall_clock64(); pt_acc[k] += pt_n - pt_t; pt_t = pt_n; } while (0)
+#define SNF_PT_FLUSH(base) do { } while (0)
 #else
 #define SNF_PT_DECL
 #define SNF_PT(k) do { } while (0)
@@ -48,6 +52,7 @@ struct ConsLdsT {
   unsigned long long key[SLOTS];
   uint32_t pc[SLOTS];              // (position << 16) | occurrence count
   uint8_t kept[MAXOTHERS];
+  unsigned long long uq[MAXPOS / 64];   // sampled position p of the best read holds a k-mer seen exactly once (an anchor)
   uint32_t cnt[LCAP ? LCAP : 1];   // LDS vote: per column four 8-bit counters of the other reads' bases (code 0 A, 1 C, 2 T, 3 G)
   uint32_t esc[ECAP ? ECAP : 1];   // votes with any other byte: column << 8 | byte
   uint32_t n_esc;
@@ -70,6 +75,20 @@ SNF_D void stage16(uint8_t* dst_lds, const uint8_t* src, int nbytes, int tid, in
 
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
 SNF_D uint64_t load_u64(const uint8_t* p) { return *(const u64_unaligned*)p; }  // pool has >= 16 B of slack
+// 8 bytes at an arbitrary byte address.  In LDS an unaligned ds_read_b64 is served lane by lane (SQ_LDS_UNALIGNED_STALL was 80 %
+// of the LDS pipe's busy cycles of these kernels - and the LDS pipe, shared by all waves of the CU, was their bottleneck):
+// there the two aligned words around the address are read (one ds_read2_b64) and funnel-shifted.  The staged arrays have
+// >= 16 B of slack behind what is ever addressed.
+typedef uint64_t __attribute__((may_alias, aligned(8))) u64_alias;
+template <bool IN_LDS> SNF_D uint64_t ld8(const uint8_t* p) {
+  if constexpr (IN_LDS) {
+    const uintptr_t a = (uintptr_t)p;
+    const u64_alias* q = (const u64_alias*)(a & ~(uintptr_t)7);
+    const uint64_t lo = q[0], hi = q[1];
+    const int sh = (int)(a & 7) * 8;
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+  } else return load_u64(p);
+}
 // number of equal bytes among the first n (<= 8) bytes of two little-endian words
 SNF_D int eq_bytes(uint64_t a, uint64_t b, int n) {
   uint64_t x = a ^ b;
@@ -78,9 +97,9 @@ SNF_D int eq_bytes(uint64_t a, uint64_t b, int n) {
   t = ~(t | x | 0x7f7f7f7f7f7f7f7full);                   // 0x80 in every zero byte of x
   return __builtin_popcountll(t);
 }
-SNF_D int count_eq(const uint8_t* a, const uint8_t* b, int n) {
+template <bool A_LDS, bool B_LDS> SNF_D int count_eq(const uint8_t* a, const uint8_t* b, int n) {
   int m = 0;
-  for (int q = 0; q < n; q += 8) m += eq_bytes(load_u64(a + q), load_u64(b + q), n - q < 8 ? n - q : 8);
+  for (int q = 0; q < n; q += 8) m += eq_bytes(ld8<A_LDS>(a + q), ld8<B_LDS>(b + q), n - q < 8 ? n - q : 8);
   return m;
 }
 // bytes [k, k + 8) of a 24-byte window held in three words (zero beyond the window), 0 <= k < 24
@@ -91,9 +110,9 @@ SNF_D uint64_t win24(uint64_t w0, uint64_t w1, uint64_t w2, int k) {
   return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
 }
 // equal bytes of window[k0, k0 + n) and b[0, n)   (k0 + n <= 24)
-SNF_D int count_eq_win(uint64_t w0, uint64_t w1, uint64_t w2, int k0, const uint8_t* b, int n) {
+template <bool B_LDS> SNF_D int count_eq_win(uint64_t w0, uint64_t w1, uint64_t w2, int k0, const uint8_t* b, int n) {
   int m = 0;
-  for (int q = 0; q < n; q += 8) m += eq_bytes(win24(w0, w1, w2, k0 + q), load_u64(b + q), n - q < 8 ? n - q : 8);
+  for (int q = 0; q < n; q += 8) m += eq_bytes(win24(w0, w1, w2, k0 + q), ld8<B_LDS>(b + q), n - q < 8 ? n - q : 8);
   return m;
 }
 // injective key of the klen (<= 7) bytes in w; only has to agree between this kernel's table build and lookups
@@ -173,6 +192,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     // everything per call is wave-uniform: keep it in SGPRs (the compiler cannot prove it for values loaded from global
     // memory, and the kernel's occupancy is bound by VGPRs)
     SNF_PT_DECL
+#ifdef SNF_WG_TRACE
+    const unsigned long long wg_t0 = wall_clock64();
+#endif
     const int L = __builtin_amdgcn_readfirstlane(d.L);   // < 65000 (cons_class): 32-bit column arithmetic throughout
     const int32_t n_others = __builtin_amdgcn_readfirstlane(d.n_others);
     const uint8_t* Bg = v.pool + rfl64(d.best_off);
@@ -201,7 +223,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
     const int npos = (int)cons_npos(L, klen, skip);
     for (int p = tid; p < npos; p += NT) {
       const int i = p * skip;
-      const unsigned long long kk = kmer_key_le(load_u64(B + i), klen);
+      const unsigned long long kk = kmer_key_le(ld8<LV>(B + i), klen);
       int64_t sl = kmer_slot(kk, SLOTS);
       for (;;) {
         const unsigned long long old = atomicCAS(&lds.key[sl], SNF_KEY_EMPTY, kk);
@@ -211,7 +233,27 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       if ((atomicAdd(&lds.pc[sl], 1u) & 0xffffu) == 0) atomicOr(&lds.pc[sl], (uint32_t)i << 16);  // position of the 1st sighting
     }
     __syncthreads();
+    // which sampled positions hold a k-mer seen exactly once.  The other reads never probe the table: an anchor needs
+    // |i - j| <= maxshift with i and j on the same sampling grid, so position p of a read can only anchor at positions
+    // p - dmax .. p + dmax of the best read (dmax = maxshift / skip, 0 once skip > maxshift) - a direct compare of the k-mer
+    // words plus this bit replaces a chain of dependent LDS probes per sampled k-mer (measured: half of a read's time)
+    for (int p0 = wid * 64; p0 < npos; p0 += NT) {
+      const int p = p0 + lane;
+      bool u = false;
+      if (p < npos) {
+        const unsigned long long kk = kmer_key_le(ld8<LV>(B + p * skip), klen);
+        int sl = (int)kmer_slot(kk, SLOTS);
+        while (lds.key[sl] != kk) sl = (sl + 1) & (SLOTS - 1);
+        u = (lds.pc[sl] & 0xffffu) == 1u;
+      }
+      const unsigned long long mk = __ballot(u);
+      if (lane == 0) lds.uq[p0 >> 6] = mk;
+    }
+    __syncthreads();
     SNF_PT(0);   // descriptor, staging, table build
+#ifdef SNF_WG_TRACE
+    const unsigned long long wg_t1 = wall_clock64();
+#endif
     typename Lds::Wave& W = lds.w[wid];
     uint8_t* rows = LV ? nullptr : v.aln + rfl64(d.aln_off);
     // Geometry of other read r: where it lives, how far the sampled positions go, how many bytes any phase touches.
@@ -265,41 +307,31 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
           for (int rd = 0; rd < ROUNDS; rd++) { const int p = rd * 64 + lane; pre_kw[rd] = (p < Pn) ? load_u64(Sgn + p * skip) : 0ull; }
         }
       }
+#ifdef SNF_WG_TRACE
+      SNF_PT(7);
+#endif
       if constexpr (SCAP > 0) {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
           const int p = rd * 64 + lane;
-          kw[rd] = (p < P) ? load_u64(S + p * skip) : 0ull;
+          kw[rd] = (p < P) ? ld8<true>(S + p * skip) : 0ull;
         }
       }
       int ncand = 0;
-      constexpr int G = ROUNDS < 4 ? ROUNDS : 4;  // rounds probed together: their LDS reads are in flight at once
+      const int dmax = maxshift / skip;
 #pragma unroll
-      for (int g = 0; g < ROUNDS; g += G) {
-        if (g * 64 >= P) break;
-        unsigned long long kk[G], kq[G]; int sl[G];
-#pragma unroll
-        for (int u = 0; u < G; u++) {
-          const int p = (g + u) * 64 + lane;
-          kk[u] = kmer_key_le(kw[g + u], klen);
-          sl[u] = (int)kmer_slot(kk[u], SLOTS);
-          kq[u] = p < P ? lds.key[sl[u]] : SNF_KEY_EMPTY;
+      for (int rd = 0; rd < ROUNDS; rd++) {
+        if (rd * 64 >= P) break;
+        const int p = rd * 64 + lane, j = p * skip;
+        const unsigned long long kk = kmer_key_le(kw[rd], klen);
+        int ci_ = -1;
+        for (int dd = -dmax; dd <= dmax; dd++) {      // (one candidate whenever skip > maxshift)
+          const int ip = p + dd;
+          if (p < P && ip >= 0 && ip < npos && kmer_key_le(ld8<LV>(B + ip * skip), klen) == kk && ((lds.uq[ip >> 6] >> (ip & 63)) & 1ull)) ci_ = ip * skip;
         }
-#pragma unroll
-        for (int u = 0; u < G; u++)   // linear probing past the first slot is rare (load factor <= 0.5)
-          while (kq[u] != SNF_KEY_EMPTY && kq[u] != kk[u]) { sl[u] = (sl[u] + 1) & (SLOTS - 1); kq[u] = lds.key[sl[u]]; }
-        uint32_t pcv[G];
-#pragma unroll
-        for (int u = 0; u < G; u++) pcv[u] = kq[u] == kk[u] ? lds.pc[sl[u]] : 0u;
-#pragma unroll
-        for (int u = 0; u < G; u++) {
-          const int j = ((g + u) * 64 + lane) * skip;
-          int ci_ = -1;
-          if ((pcv[u] & 0xffffu) == 1u) { const int i = (int)(pcv[u] >> 16); if ((i > j ? i - j : j - i) <= maxshift) ci_ = i; }
-          const unsigned long long mk = __ballot(ci_ >= 0);
-          if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
-          ncand += __builtin_popcountll(mk);
-        }
+        const unsigned long long mk = __ballot(ci_ >= 0);
+        if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
+        ncand += __builtin_popcountll(mk);
       }
       __builtin_amdgcn_wave_barrier();
       SNF_PT(1);   // k-mer words, probes, candidate compaction
@@ -323,62 +355,111 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       }
       SNF_PT(2);   // monotone chain
       // ---- 3. segments between consecutive anchors
+      // The comparisons (and later the votes) run one lane per SAMPLING STEP of the read, not per segment: a step is `skip`
+      // bases wherever it lies, so every lane has the same amount of work whatever the distances between the anchors are
+      // (one lane per segment left a wave waiting for its longest segment - a segment of 2 000 bases between two anchors
+      // held a workgroup for 100 us).  Step p belongs to segment t when aj[t-1] <= p * skip < aj[t]; the partial counts of
+      // a segment's steps meet in one LDS word per segment.
       const int i0 = __builtin_amdgcn_readfirstlane(na ? (int)W.ai[0] : 0), j0 = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[0] : 0);
       const int c_first = na ? ((j0 > 0) ? i0 : 0) : 0;   // '-' * i only when j > 0 (consensus.py:316-318)
+      const int j_end = __builtin_amdgcn_readfirstlane(na ? (int)W.aj[na - 1] : 0);
       int span = 0;
-      // Read in HBM (SCAP == 0): the 24 bytes behind the previous anchor of every segment - all a segment of up to 23 bases
-      // is ever compared or copied from - are requested for ALL segments of the read before the first one is looked at and
-      // stay in registers through the vote (one memory round trip per read instead of two to four per 64 segments)
+      // Read in HBM (SCAP == 0): the skip + 1 <= 24 bytes a step is compared and copied from are the step's k-mer word (already
+      // here) and up to two more words, requested for all steps of the read at once and kept in registers through the vote
       constexpr int WR = SCAP == 0 ? ROUNDS : 1;
-      uint64_t sw0[WR], sw1[WR], sw2[WR];
+      const bool use_win = SCAP == 0 && skip <= 23;
+      uint64_t sw1[WR], sw2[WR];
       if constexpr (SCAP == 0) {
 #pragma unroll
-        for (int it = 0; it < ROUNDS; it++) {
-          const int t = 1 + it * 64 + lane;
-          sw0[it] = sw1[it] = sw2[it] = 0;
-          if (t < na) { const uint8_t* p = S + W.aj[t - 1]; sw0[it] = load_u64(p); sw1[it] = load_u64(p + 8); sw2[it] = load_u64(p + 16); }
+        for (int rd = 0; rd < ROUNDS; rd++) {
+          const int p = rd * 64 + lane;
+          sw1[rd] = sw2[rd] = 0;
+          if (use_win && p + 1 < P) {   // (a step inside a segment ends at or before the last sampled position)
+            if (skip >= 8) sw1[rd] = load_u64(S + p * skip + 8);
+            if (skip >= 16) sw2[rd] = load_u64(S + p * skip + 16);
+          }
         }
       }
-      uint32_t segn[ROUNDS];   // per segment of this lane: columns written | matches of the copied slice against best << 16; 0 = dashes
+      // step -> segment: every segment marks its first step, a running maximum carries the mark over the segment's steps
 #pragma unroll
-      for (int it = 0; it < ROUNDS; it++) segn[it] = 0u;
+      for (int rd = 0; rd < ROUNDS; rd++) { const int p = rd * 64 + lane; if (p < P) W.seg_pref[p] = 0u; }
+      __builtin_amdgcn_wave_barrier();
+      const float rskip = 1.0f / (float)skip;   // positions are multiples of skip below 65536: the rounded product is the exact quotient
 #pragma unroll
       for (int it = 0; it < ROUNDS; it++) {
-        if (1 + it * 64 >= na) break;
         const int t = 1 + it * 64 + lane;
-        if (t < na) {
-          const int li = W.ai[t - 1], lj = W.aj[t - 1], i = W.ai[t], j = W.aj[t];
-          int col = c_first + (lj - j0); if (col > L) col = L;
-          const int fwd_i = i - li; int fwd_j = j - lj;
-          if (col + fwd_j > L) fwd_j = L - col;
-          uint8_t flag = 0; int cm = 0;
-          if (fwd_i == fwd_j && fwd_j > 0) {
-            const int nfull = j - lj;
-            span += nfull;
-            bool done = false;
-            if constexpr (SCAP == 0) {
-              if (nfull <= 23) {
-                const int m = count_eq_win(sw0[it], sw1[it], sw2[it], 1, B + li + 1, nfull);
-                if ((double)m / (double)nfull >= 0.5) { flag = 1; cm = count_eq_win(sw0[it], sw1[it], sw2[it], 0, B + col, fwd_j); }
-                done = true;
-              }
-            }
-            if (!done) {
-              // first words of both comparisons issued together (one round trip instead of two); consecutive
-              // anchors are usually one sampling step apart, so the tails are rare
-              const uint64_t a1 = load_u64(S + lj + 1), b1 = load_u64(B + li + 1), a2 = load_u64(S + lj), b2 = load_u64(B + col);
-              int m = eq_bytes(a1, b1, nfull < 8 ? nfull : 8);
-              if (nfull > 8) m += count_eq(S + lj + 9, B + li + 9, nfull - 8);
-              if ((double)m / (double)nfull >= 0.5) {
-                flag = 1;
-                cm = eq_bytes(a2, b2, fwd_j < 8 ? fwd_j : 8);
-                if (fwd_j > 8) cm += count_eq(S + lj + 8, B + col + 8, fwd_j - 8);
-              }
-            }
-          }
-          segn[it] = flag ? (uint32_t)fwd_j | ((uint32_t)cm << 16) : 0u;   // flag => 0 < fwd_j, cm <= fwd_j <= L < 65000
+        if (t < na) W.seg_pref[(int)((float)W.aj[t - 1] * rskip + 0.5f)] = (uint32_t)t;
+      }
+      __builtin_amdgcn_wave_barrier();
+      int tseg[ROUNDS];
+      {
+        int carry = 0;
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+          tseg[rd] = 0;
+          if (rd * 64 >= P) continue;
+          const int p = rd * 64 + lane;
+          int pm = wave_max_incl(p < P ? (int)W.seg_pref[p] : 0, lane);
+          if (carry > pm) pm = carry;
+          carry = __builtin_amdgcn_readlane(pm, 63);
+          tseg[rd] = p * skip < j_end ? pm : 0;
         }
       }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < ROUNDS; it++) { const int t = 1 + it * 64 + lane; if (t < na) W.seg_pref[t] = 0u; }
+      __builtin_amdgcn_wave_barrier();
+#ifdef SNF_WG_TRACE
+      SNF_PT(4);
+#endif
+      // geometry of segment t (same arithmetic for the step lanes and the segment lanes)
+      auto seg_geom = [&](int t, int& li, int& lj, int& col, int& nfull, int& fwd_j) -> bool {
+        li = W.ai[t - 1]; lj = W.aj[t - 1];
+        const int i = W.ai[t], j = W.aj[t];
+        col = c_first + (lj - j0); if (col > L) col = L;
+        const int fwd_i = i - li; fwd_j = j - lj; nfull = fwd_j;
+        if (col + fwd_j > L) fwd_j = L - col;
+        return fwd_i == fwd_j && fwd_j > 0;      // copied (if it passes the identity test), else dashes
+      };
+#pragma unroll
+      for (int rd = 0; rd < ROUNDS; rd++) {
+        if (rd * 64 >= P) break;
+        const int t = tseg[rd];
+        if (t > 0) {
+          int li, lj, col, nfull, fwd_j;
+          if (seg_geom(t, li, lj, col, nfull, fwd_j)) {
+            // identity on offsets off + 1 .. off + skip of the segment, column identity of the copied slice on off .. off + nc - 1
+            const int x0 = (rd * 64 + lane) * skip, off = x0 - lj;
+            const int nc = fwd_j - off < skip ? fwd_j - off : skip;
+            int m, cm = 0;
+            if (use_win) {
+              m = count_eq_win<LV>(kw[rd], sw1[SCAP == 0 ? rd : 0], sw2[SCAP == 0 ? rd : 0], 1, B + li + off + 1, skip);
+              if (nc > 0) cm = count_eq_win<LV>(kw[rd], sw1[SCAP == 0 ? rd : 0], sw2[SCAP == 0 ? rd : 0], 0, B + col + off, nc);
+            } else {
+              m = count_eq<(SCAP > 0), LV>(S + x0 + 1, B + li + off + 1, skip);
+              if (nc > 0) cm = count_eq<(SCAP > 0), LV>(S + x0, B + col + off, nc);
+            }
+            atomicAdd(&W.seg_pref[t], (uint32_t)m | ((uint32_t)cm << 16));   // both sums stay below 65536 (a segment is shorter than the read)
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      uint32_t segn[ROUNDS];   // per segment of this lane: columns written | matches of the copied slice against best << 16; 0 = dashes
+#pragma unroll
+      for (int it = 0; it < ROUNDS; it++) {
+        segn[it] = 0u;
+        if (1 + it * 64 >= na) continue;
+        const int t = 1 + it * 64 + lane;
+        if (t < na) {
+          int li, lj, col, nfull, fwd_j;
+          if (seg_geom(t, li, lj, col, nfull, fwd_j)) {
+            span += nfull;
+            const uint32_t acc = W.seg_pref[t];
+            if ((double)(acc & 0xffffu) / (double)nfull >= 0.5) segn[it] = (uint32_t)fwd_j | (acc & 0xffff0000u);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // (the run filter reuses seg_pref)
       span = __builtin_amdgcn_readlane((int)wave_sum_incl_u32((uint32_t)span, lane), 63);
       SNF_PT(3);   // windows + segment compares
       // ---- 4. run filter over maximal groups of consecutive copied segments (consensus.py:343-360): a group stays iff
@@ -436,24 +517,29 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       // a read whose copied span is <= 20 % of the best read is dropped (consensus.py:361-363): it has no vote
       const bool keep_row = (double)span / (double)L > 0.2;
       if constexpr (LV) {
-        // ---- 5. votes: one lane per copied segment, its bases go to the counters of its columns
-        // (segment t starts at column c_first + (aj[t-1] - j0) < L and is seg_len[t] columns long)
+        // ---- 5. votes: one lane per sampling step again; the bases a kept segment copied from this step go to the counters of
+        // their columns (a base at position x of the read sits in column c_first + (x - j0))
+        if (keep_row) {
 #pragma unroll
-        for (int it = 0; it < ROUNDS; it++) {
-          if (!keep_row || 1 + it * 64 >= na) break;
-          const int t = 1 + it * 64 + lane;
-          if (segn[it] != 0u) {
-            const int lj = W.aj[t - 1], n = (int)(segn[it] & 0xffffu);
-            const int col = c_first + (lj - j0);
-            for (int o8 = 0; o8 < n; o8 += 8) {
-              unsigned long long w8;
-              if constexpr (SCAP == 0) w8 = n <= 24 ? win24(sw0[it], sw1[it], sw2[it], o8) : load_u64(S + lj + o8);
-              else w8 = load_u64(S + lj + o8);
-              const int m = n - o8 < 8 ? n - o8 : 8;
-              for (int o = 0; o < m; o++, w8 >>= 8) {
-                const uint32_t c = (uint32_t)(w8 & 0xffull), cd = (c >> 1) & 3u;
-                if (((SNF_ACTG >> (8 * cd)) & 0xffu) == c) atomicAdd(&lds.cnt[col + o8 + o], 1u << (8 * cd));
-                else { const uint32_t e = atomicAdd(&lds.n_esc, 1u); if (e < (uint32_t)ECAP) lds.esc[e] = ((uint32_t)(col + o8 + o) << 8) | c; }
+          for (int it = 0; it < ROUNDS; it++) { const int t = 1 + it * 64 + lane; if (t < na) W.seg_pref[t] = segn[it] & 0xffffu; }   // columns written, 0: dashes
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int rd = 0; rd < ROUNDS; rd++) {
+            if (rd * 64 >= P) break;
+            const int t = tseg[rd];
+            const int n = t > 0 ? (int)W.seg_pref[t] : 0;
+            if (n > 0) {
+              const int x0 = (rd * 64 + lane) * skip, off = x0 - (int)W.aj[t - 1];
+              const int nc = n - off < skip ? n - off : skip;
+              const int col = c_first + (x0 - j0);
+              for (int o8 = 0; o8 < nc; o8 += 8) {
+                unsigned long long w8 = use_win ? win24(kw[rd], sw1[SCAP == 0 ? rd : 0], sw2[SCAP == 0 ? rd : 0], o8) : ld8<(SCAP > 0)>(S + x0 + o8);
+                const int m = nc - o8 < 8 ? nc - o8 : 8;
+                for (int o = 0; o < m; o++, w8 >>= 8) {
+                  const uint32_t c = (uint32_t)(w8 & 0xffull), cd = (c >> 1) & 3u;
+                  if (((SNF_ACTG >> (8 * cd)) & 0xffu) == c) atomicAdd(&lds.cnt[col + o8 + o], 1u << (8 * cd));
+                  else { const uint32_t e = atomicAdd(&lds.n_esc, 1u); if (e < (uint32_t)ECAP) lds.esc[e] = ((uint32_t)(col + o8 + o) << 8) | c; }
+                }
               }
             }
           }
@@ -485,7 +571,13 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       SNF_PT(5);   // votes into the counters
     }
     // ---- column vote (consensus.py:365-380)
+#ifdef SNF_WG_TRACE
+    const unsigned long long wg_t2 = wall_clock64();
+#endif
     __syncthreads();
+#ifdef SNF_WG_TRACE
+    const unsigned long long wg_t3 = wall_clock64();
+#endif
     int nkept = 0;
     for (int32_t r = 0; r < n_others; r++) nkept += lds.kept[r];
     nkept = __builtin_amdgcn_readfirstlane(nkept);
@@ -500,6 +592,15 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       for (int q = tid; q < L; q += NT) alt[q] = vote_column(lds.cnt[q], lds.esc, n_esc, q, lds.best[q], nkept);
       SNF_PT(6);   // barrier wait + column vote + ALT stores
       SNF_PT_FLUSH(CLS == 1 ? 0 : 16);
+#ifdef SNF_WG_TRACE
+      __syncthreads();
+      const unsigned long long wg_t4 = wall_clock64();
+      __syncthreads();
+      if (tid == 0) { v.wgtrace[2 * (int64_t)cid] = wg_t0;
+        v.wgtrace[2 * ((int64_t)cid + (1 << 19)) + 1] = (pt_acc[1] / 10) | ((pt_acc[4] / 10) << 12) | ((pt_acc[3] / 10) << 24) | ((pt_acc[7] / 10) << 36) | ((pt_acc[5] / 10) << 48);
+        v.wgtrace[2 * ((int64_t)cid + (1 << 19))] = (wg_t1 - wg_t0) | ((wg_t2 - wg_t1) << 16) | ((wg_t3 - wg_t2) << 32) | ((wg_t4 - wg_t3) << 48);
+        v.wgtrace[2 * (int64_t)cid + 1] = ((wall_clock64() - wg_t0) << 32) | ((unsigned long long)CLS << 28) | ((unsigned long long)(n_others & 0xff) << 16) | (unsigned long long)(L & 0xffff); }
+#endif
       continue;
     }
     bytes_acc += (unsigned long long)((int64_t)n_others + 2) * (unsigned long long)L;

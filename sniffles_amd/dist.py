@@ -27,21 +27,101 @@ LAYOUT_FIELDS = ("n_calls", "rnames_len", "alt_pool_len", "off_rnames", "off_alt
 
 
 class GatheredResult:
-    """What rank `dst` holds after `gather_results`: the calls of every rank in ONE record table, ordered by task id, and
-    inside a task in the order the ranks produced (position order for SNF_OUT_EXECUTE results - the order the reference's
-    parent writes, `sniffles:544` over the per-task `sorted(svcalls, key=pos)` of `parallel.py:270-271`).  `calls["task_index"]`
-    holds the GLOBAL task id; `alt_off` / `rn_off` index `alt_pool` / `rnames` of this object (same interface as
-    `abi.Result`, so `vcf.VCF.write_records(res, ti, order)` takes it as it is).  `names`: optional {task id: {qname id: str}}
-    of the supporting reads (gathered on request: `--output-rnames`)."""
+    """What rank `dst` holds after `gather_results`: every rank's result block in host memory plus the index that makes ONE
+    record table of them - `calls` ordered by task id, and inside a task in the order the ranks produced (position order for
+    SNF_OUT_EXECUTE results - the order the reference's parent writes, `sniffles:544` over the per-task
+    `sorted(svcalls, key=pos)` of `parallel.py:270-271`).  `calls["task_index"]` holds the GLOBAL task id; `alt_off` /
+    `rn_off` index `alt_pool` / `rnames` of this object (same interface as `abi.Result`, so
+    `vcf.VCF.write_records(res, ti, order)` takes it as it is).  `names`: optional {task id: {qname id: str}} of the
+    supporting reads (gathered on request: `--output-rnames`).
 
-    def __init__(self, calls, alt_pool, rnames, task_ids, names=None):
+    The table is assembled on first use (`calls` / `alt_pool` / `rnames`): the gather itself only lands the blocks and builds
+    the per-task index (`n_calls`, `task_ids`, `task_call_off` cost nothing) - what the reference's parent holds right after
+    `recv()`.  A result whose blocks live in a landing buffer of `gather_results` is valid until the gather after next
+    reuses that buffer; `detach()` copies it out."""
+
+    def __init__(self, calls=None, alt_pool=None, rnames=None, task_ids=(), names=None, blocks=None, task_ids_per_rank=None):
         import numpy as np
-        self.calls, self.alt_pool, self.rnames = calls, alt_pool, rnames
-        self.task_ids = np.asarray(task_ids, np.int64)
-        t = calls["task_index"].astype(np.int64)
-        self.task_call_off = np.searchsorted(t, np.concatenate([self.task_ids, [np.iinfo(np.int64).max]]), side="left")
-        self.task_call_off[-1] = len(calls)
         self.names = names
+        self._blocks, self._ids = blocks, task_ids_per_rank
+        self._calls, self._alt, self._rn = calls, alt_pool, rnames
+        self.task_ids = np.asarray(sorted(set(int(i) for i in task_ids)), np.int64)   # (a task id listed by several ranks: held by one)
+        if blocks is None:
+            t = calls["task_index"].astype(np.int64)
+            self.task_call_off = np.searchsorted(t, np.concatenate([self.task_ids, [np.iinfo(np.int64).max]]), side="left")
+            self.task_call_off[-1] = len(calls)
+            self._runs = None
+            return
+        # per global task: (rank, first row, rows) in its rank's block - from the local task index column of the records
+        # (a strided 4-byte read per record; the records themselves are not touched until `calls` is asked for)
+        runs = {}
+        for r, ((lay, blob), ids) in enumerate(zip(blocks, task_ids_per_rank)):
+            n = int(lay["n_calls"])
+            if not n:
+                continue
+            loc = np.frombuffer(blob, abi.CALL_DTYPE, count=n)["task_index"]
+            cut = np.flatnonzero(np.diff(loc)) + 1                       # a task's calls are contiguous in its rank's block
+            starts = np.concatenate([[0], cut]); ends = np.concatenate([cut, [n]])
+            for s0, e0 in zip(starts.tolist(), ends.tolist()):
+                runs[int(ids[int(loc[s0])])] = (r, s0, e0 - s0)
+        self._runs = [runs.get(int(t), (0, 0, 0)) for t in self.task_ids]
+        self.task_call_off = np.concatenate([[0], np.cumsum([k[2] for k in self._runs])]).astype(np.int64)
+
+    @property
+    def n_calls(self) -> int:
+        return int(self.task_call_off[-1])
+
+    def _assemble(self):
+        import numpy as np
+        if self._calls is not None:
+            return
+        blocks = self._blocks
+        alt_base, rn_base, a0, r0 = [], [], 0, 0
+        for lay, _ in blocks:
+            alt_base.append(a0); rn_base.append(r0)
+            a0 += int(lay["alt_pool_len"]); r0 += int(lay["rnames_len"])
+        calls = np.empty(self.n_calls, abi.CALL_DTYPE)
+        tabs = [np.frombuffer(blob, abi.CALL_DTYPE, count=int(lay["n_calls"])) for lay, blob in blocks]
+        for t, (r, s0, n), o in zip(self.task_ids.tolist(), self._runs, self.task_call_off.tolist()):
+            if not n:
+                continue
+            c = calls[o:o + n]
+            c[:] = tabs[r][s0:s0 + n]                                    # one contiguous copy per task
+            c["task_index"] = t
+            if alt_base[r]:
+                c["alt_off"] += alt_base[r]
+            if rn_base[r]:
+                c["rn_off"] += rn_base[r]
+        def part(lay, blob, off, nbytes):
+            return np.frombuffer(blob, np.uint8, count=int(lay["bytes"]))[int(lay[off]):int(lay[off]) + nbytes]
+        alts = [part(lay, blob, "off_alt", int(lay["alt_pool_len"])) for lay, blob in blocks]
+        rns = [part(lay, blob, "off_rnames", 4 * int(lay["rnames_len"])).view(np.uint32) for lay, blob in blocks]
+        self._alt = alts[0] if len(alts) == 1 else np.concatenate(alts) if alts else np.zeros(0, np.uint8)   # (one rank: a view)
+        self._rn = rns[0] if len(rns) == 1 else np.concatenate(rns) if rns else np.zeros(0, np.uint32)
+        self._calls = calls
+
+    @property
+    def calls(self):
+        self._assemble()
+        return self._calls
+
+    @property
+    def alt_pool(self):
+        self._assemble()
+        return self._alt
+
+    @property
+    def rnames(self):
+        self._assemble()
+        return self._rn
+
+    def detach(self):
+        """The table in memory of its own (independent of the landing buffer)."""
+        import numpy as np
+        self._assemble()
+        self._alt, self._rn = np.array(self._alt), np.array(self._rn)
+        self._blocks = None
+        return self
 
     def task_rows(self, task_id: int):
         """Row indices of a task's calls (output order)."""
@@ -58,25 +138,22 @@ class GatheredResult:
 def merge_blocks(blocks, task_ids_per_rank) -> GatheredResult:
     """blocks: per rank (layout dict, bytes-like of the rank's result block [records | read names | ALT bytes], see
     `snf_batch_export_device`); task_ids_per_rank[r][k] = global id of rank r's batch-local task k.  Pure host code."""
-    import numpy as np
-    recs, alts, rns = [], [], []
-    alt_base = rn_base = 0
-    for (lay, blob), ids in zip(blocks, task_ids_per_rank):
-        raw = np.frombuffer(blob, np.uint8, count=int(lay["bytes"])) if int(lay["bytes"]) else np.zeros(0, np.uint8)
-        n = int(lay["n_calls"])
-        c = raw[:n * abi.CALL_DTYPE.itemsize].view(abi.CALL_DTYPE).copy()
-        c["task_index"] = np.asarray(ids, np.int32)[c["task_index"]] if n else c["task_index"]
-        c["alt_off"] += alt_base
-        c["rn_off"] += rn_base
-        recs.append(c)
-        alts.append(raw[int(lay["off_alt"]):int(lay["off_alt"]) + int(lay["alt_pool_len"])])
-        rns.append(raw[int(lay["off_rnames"]):int(lay["off_rnames"]) + 4 * int(lay["rnames_len"])].view(np.uint32))
-        alt_base += int(lay["alt_pool_len"]); rn_base += int(lay["rnames_len"])
-    calls = np.concatenate(recs) if recs else np.zeros(0, abi.CALL_DTYPE)
-    order = np.argsort(calls["task_index"], kind="stable")      # by task id; a task's calls all come from one rank, in its order
-    all_ids = sorted(int(i) for ids in task_ids_per_rank for i in ids)
-    return GatheredResult(calls[order], np.concatenate(alts) if alts else np.zeros(0, np.uint8),
-                          np.concatenate(rns) if rns else np.zeros(0, np.uint32), all_ids)
+    return GatheredResult(task_ids=[int(i) for ids in task_ids_per_rank for i in ids], blocks=list(blocks),
+                          task_ids_per_rank=[list(ids) for ids in task_ids_per_rank])
+
+
+_LANDING = {}     # (device, slot) -> pinned host tensor the gathered blocks are copied into (two slots, used in turn)
+_LANDING_TURN = [0]
+
+
+def _landing(nbytes: int, pinned: bool):
+    import torch
+    slot = _LANDING_TURN[0] = (_LANDING_TURN[0] + 1) & 1
+    t = _LANDING.get((pinned, slot))
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20) * 5 // 4, dtype=torch.uint8, pin_memory=pinned)
+        _LANDING[(pinned, slot)] = t
+    return t
 
 
 def gather_results(block, layout: dict, task_ids, dst: int = 0, group=None, names=None, recv_buffer=None, task_ids_per_rank=None):
@@ -122,11 +199,22 @@ def gather_results(block, layout: dict, task_ids, dst: int = 0, group=None, name
         dist.gather_object({int(task_ids[k]): v for k, v in names.items()}, names_all, dst=dst, group=group)
     if rank != dst:
         return None
-    host = recv_buffer[:world * nmax].cpu().numpy() if nmax else np.zeros(0, np.uint8)
+    # the blocks land in (pinned) host memory: one copy per rank of exactly its bytes, at 256-byte aligned offsets
+    sizes = [int(lays[r, 5]) for r in range(world)]
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot); tot += (n + 255) & ~255
+    land = _landing(tot, dev.type == "cuda")
+    for r in range(world):
+        if sizes[r]:
+            land[offs[r]:offs[r] + sizes[r]].copy_(recv_buffer[r * nmax:r * nmax + sizes[r]], non_blocking=True)
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+    host = land.numpy()
     blocks = []
     for r in range(world):
         lay = dict(zip(LAYOUT_FIELDS, (int(x) for x in lays[r, :6])))
-        blocks.append((lay, host[r * nmax:r * nmax + lay["bytes"]]))
+        blocks.append((lay, host[offs[r]:offs[r] + sizes[r]]))
     out = merge_blocks(blocks, ids_all)
     if names_all is not None:
         out.names = {}

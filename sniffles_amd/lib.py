@@ -98,10 +98,11 @@ def bind(lib: C.CDLL) -> C.CDLL:
 def load() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(SO):
-            raise SnifflesAmdError(f"{SO} is missing: build it with `python -m sniffles_amd.build` "
+        so = os.environ.get("SNF_LIB_SO") or SO      # SNF_LIB_SO: another build of the same sources (A/B measurements)
+        if not os.path.exists(so):
+            raise SnifflesAmdError(f"{so} is missing: build it with `python -m sniffles_amd.build` "
                                    "(the hot path has no CPU fallback)")
-        _lib = bind(C.CDLL(SO))
+        _lib = bind(C.CDLL(so))
     return _lib
 
 

@@ -564,6 +564,8 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->multiProcessorCount = 4; p->warpSize = 64; p->totalGlobalMem = (size_t)8 << 30; return hipSuccess;
 }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = std::malloc(1); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = std::malloc(1); return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = std::malloc(1); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { std::free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

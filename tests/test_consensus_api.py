@@ -26,6 +26,17 @@ def test_novel_from_reads_batch_matches_reference():
 
 
 @pytest.mark.gpu
+def test_long_copied_segments_match_reference():
+    """Segments of hundreds to thousands of bases between two anchors (processed by the whole wave), shift excursions, odd
+    characters inside them: tests/golden/consensus_long_segments.json.gz, from the unmodified reference function."""
+    from sniffles_amd import consensus
+    probs = gu.load("consensus_long_segments")["problems"]
+    got = consensus.novel_from_reads_batch([(p["best"], p["others"], p["skip"]) for p in probs], klen=6)
+    assert [i for i, (g, p) in enumerate(zip(got, probs)) if g != p["expected"]] == []
+    assert sum(p["expected"] != p["best"] for p in probs) >= 20
+
+
+@pytest.mark.gpu
 def test_novel_from_reads_signature_and_errors():
     from sniffles_amd import consensus, lib
 

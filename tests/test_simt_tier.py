@@ -209,6 +209,18 @@ def test_consensus_instances_match_reference_vectors(kw, simt):
         assert n[1] >= 50 and n[2] >= 50
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(mode=2), dict(mode=4), dict(nw=8), dict(grid_cap=2)], ids=str)
+def test_consensus_long_segments_match_reference_vectors(kw, simt):
+    """Copied segments far longer than a lane walks on its own (SNF_CONS_LONGSEG: the whole wave compares and votes them),
+    segments that leave the shift window and return, odd characters inside them - 60 vectors of the unmodified reference
+    function (oracle/make_golden.py::main_consensus_long)."""
+    probs = gu.load("consensus_long_segments")["problems"]
+    got, cls, handed = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6, **kw)
+    assert all(cls)
+    assert [i for i, (g, p) in enumerate(zip(got, probs)) if g != p["expected"]] == []
+    assert sum(p["expected"] != p["best"] for p in probs) >= 20
+
+
 def test_consensus_escape_list_overflow_is_handed_to_rows(simt):
     """More non-ACGT votes than the escape list of the LDS-vote instances holds: the call is redone by ROWS (work list 7)
     and still equals the plain rule - checked against the ROWS instance alone, which the vectors above pin."""
