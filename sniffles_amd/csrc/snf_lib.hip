@@ -240,7 +240,8 @@ struct snf_batch_impl {
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
   int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22;   // grid caps of the SMALL / LARGE consensus kernels
-  int cons_nw = 4;                // SNF_CONS_NW: waves per SMALL consensus call (4, or 1 = one wave per call)
+  int cons_nw = 1;                // waves per SMALL consensus call: 1 = one wave per call (default: single-wave workgroups leave room for the
+                                  // LARGE class next to them - LARGE in place 0.75 -> 0.5 ms, the pass 2.5 % shorter), SNF_CONS_NW=4: four
   int cons_large_nw = 4;          // SNF_CONS_LARGE_NW: waves per LARGE consensus call (4, 8, 16)
   int occ_s = 5;                  // SNF_OCC_S: waves/SIMD the SMALL consensus kernel is compiled for (5, 6, 8)
   int read_key_bits = 64;         // significant bits of the read-end sort key
@@ -1240,7 +1241,11 @@ void enqueue_output_head(snf_batch_impl* b) {
   SNF_TRACE("F: output stage (filter, rank, records + read names)");
   View& v = b->v;
   const int64_t NS = v.NS;
-  enqueue_rnames_late(b, !((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc));
+  const bool rn_all = !((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc);
+  // deferred names of the kept calls: written by f4w_emit itself, from the leads into the block (no pass over the candidates
+  // and no intermediate copy in HBM); everything else (all names wanted, the thread form) takes the late kernel
+  const bool rn_src = b->rn_state == 1 && !rn_all && b->fused && NS > 0 && NS <= ((int64_t)1 << 22) * 256 && getenv("SNF_NO_RN_FUSE") == nullptr;
+  if (!rn_src) enqueue_rnames_late(b, rn_all);
   if (b->fused && NS <= ((int64_t)1 << 22) * 256) {
     const unsigned grid = (unsigned)((NS + 255) / 256) > 0u ? (unsigned)((NS + 255) / 256) : 1u;
     FUSED(f1k_outflags, NS > 0 ? NS : 1);
@@ -1251,7 +1256,9 @@ void enqueue_output_head(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
     { Scope _s(b, "f4_emit", 0);
+      v.rn_from_src = rn_src ? 1 : 0;
       hipLaunchKernelGGL(f4w_emit, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
+      v.rn_from_src = 0;
       SNF_HIP(hipGetLastError()); }
   } else {
     const int64_t nc = NS;   // upper bound of the number of calls (the bodies stop at the device's count)
@@ -1319,7 +1326,6 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
         SNF_HIP(hipGetLastError()); }
       b->cur = prev;
     }
-    static const int small_after = getenv("SNF_SMALL_AFTER_LARGE") ? atoi(getenv("SNF_SMALL_AFTER_LARGE")) : 0;
     auto launch_small = [&]() {
       Scope _s(b, "e45w_consensus_small", 0);
       const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
@@ -1329,7 +1335,6 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
       else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     };
-    if (small_after) { hipStream_t prev = b->cur; b->cur = b->stream3; launch_small(); b->cur = prev; }
     if (serial) SNF_HIP(hipDeviceSynchronize());
     SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
     {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
@@ -1337,7 +1342,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
       hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-    if (!small_after) launch_small();
+    launch_small();
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
@@ -1939,7 +1944,6 @@ int snf_device_count(void) {
 struct StreamPool {
   std::mutex mu;
   std::vector<hipStream_t> idle[64];
-  std::vector<hipStream_t> idle_hi[64];   // streams of the highest priority the device offers (the LARGE consensus class, see take_high)
   hipStream_t take(int device) {
     {
       std::lock_guard<std::mutex> g(mu);
@@ -1950,35 +1954,11 @@ struct StreamPool {
     SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
-  // A kernel of few, large workgroups (72 KB of LDS, 4 x 199 VGPRs each) only gets a compute unit when that much is free at
-  // once: next to kernels of many small workgroups it is starved until they have drained (measured: LARGE 0.2 ms alone,
-  // 0.7 ms next to SMALL + e1w - the ALT stage ran them one after the other with the longest one last).  Its queue gets the
-  // dispatcher's priority instead.
-  hipStream_t take_high(int device) {
-    {
-      std::lock_guard<std::mutex> g(mu);
-      auto& v = idle_hi[device & 63];
-      if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
-    }
-    hipStream_t s = nullptr;
-    int least = 0, greatest = 0;
-    if (!getenv("SNF_STREAM_PRIO") || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
-    SNF_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
-    return s;
-  }
-  void give_high(int device, hipStream_t s) {
-    {
-      std::lock_guard<std::mutex> g(mu);
-      auto& v = idle_hi[device & 63];
-      if (v.size() < 32 && !getenv("SNF_NO_STREAM_POOL")) { v.push_back(s); return; }
-    }
-    (void)hipStreamDestroy(s);
-  }
   int trim(int device) {      // idle streams of `device` (< 0: all) are destroyed
     std::vector<std::pair<int, hipStream_t>> gone;
     {
       std::lock_guard<std::mutex> g(mu);
-      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); for (auto s : idle_hi[d]) gone.push_back({d, s}); idle_hi[d].clear(); }
+      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); }
     }
     int cur = 0; (void)hipGetDevice(&cur);
     for (auto& e : gone) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
@@ -2036,7 +2016,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
     b->stream = g_streams.take(b->device);
     b->stream2 = g_streams.take(b->device);
-    b->stream3 = g_streams.take_high(b->device);
+    b->stream3 = g_streams.take(b->device);
     b->stream4 = g_streams.take(b->device);
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_e3, hipEventDisableTiming));
@@ -2123,7 +2103,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
-  if (b->stream3) g_streams.give_high(b->device, b->stream3);   // (synchronised above)
+  if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
   if (b->stream4) g_streams.give(b->device, b->stream4);   // (synchronised above)
   if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
   delete b;

@@ -180,7 +180,30 @@ __global__ void __launch_bounds__(256) f4w_emit(const View v, int64_t n) {
       ((uint4*)(base + (int64_t)v.o_dst[q] * (int64_t)sizeof(snf_call_t)))[lane] = u.w;
     }
     uint32_t* rn = (uint32_t*)(base + h.off_rn) + rn_dst;
-    for (int32_t k = lane; k < rn_len; k += 64) rn[k] = v.rnames[rn_src + k];
+    if (!v.rn_from_src) { for (int32_t k = lane; k < rn_len; k += 64) rn[k] = v.rnames[rn_src + k]; continue; }
+    // names the candidate stage only sized (View::rn_defer): d3_rnames_emit, one wave per call, straight into the block
+    const CallX& x = v.callx[i];
+    const int32_t nq = x.rn_nq;
+    const int32_t* a1 = v.w1 + x.flo;
+    for (int32_t k = lane; k < nq; k += 64) rn[k] = (uint32_t)a1[k];
+    if (src->svtype == SNF_INS && rn_len > nq) {
+      const int32_t hd = v.cl_head[x.cluster];
+      const int32_t llo = v.seedL_lo[hd], lhi = v.seedL_hi[v.c_last[hd]];
+      int32_t w = nq;
+      for (int32_t p0 = llo; p0 < lhi; p0 += 64) {      // in lead order: first appearance of a read that is not among the call's own
+        const int32_t p = p0 + lane;
+        bool add = false; int32_t qn = 0;
+        if (p < lhi) {
+          qn = (int32_t)v.in_qname[v.LL[p]];
+          add = true;
+          for (int32_t y = llo; y < p; y++) if ((int32_t)v.in_qname[v.LL[y]] == qn) { add = false; break; }
+          if (add && contains_sorted_i32(a1, nq, qn)) add = false;
+        }
+        const unsigned long long mk = __ballot(add);
+        if (add) rn[w + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = (uint32_t)qn;
+        w += __builtin_popcountll(mk);
+      }
+    }
   }
 }
 

@@ -180,7 +180,7 @@ struct View {
   int32_t out_valid;         // host: the output stage of this pass has been enqueued (z1_results publishes its offsets)
   int32_t rn_defer;          // 1: the candidate stage only sizes the supporting read names; finalize writes them for the calls the
                              //    output keeps (SNF_OUT_EXECUTE: 70 % of the candidates' names would never be looked at); 2: late pass over ALL calls
-  int32_t _pad_out;
+  int32_t rn_from_src;       // this launch of f4w_emit writes the supporting read names straight from the leads (names deferred, kept calls only)
   uint32_t* o_scan;          // [n_calls+1] exclusive scan of the keep flags (defined for every call)
   int32_t *o_src, *o_dst, *o_key;   // [n_out] compacted index -> call index / final record index / pos (sort key)
   int64_t* o_rn;             // [n_out] offset inside the read-name section
