@@ -37,19 +37,27 @@ def build(sanitize=False):
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(ROOT, "include", "sniffles_amd.h")]
     for d, _, fs in os.walk(SIMT):
         deps += [os.path.join(d, f) for f in fs]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        flags = list(FLAGS)
-        if sanitize:
-            flags[flags.index("-O2")] = "-O1"
-            flags += ["-fsanitize=undefined", "-fsanitize=bounds-strict", "-fno-sanitize=alignment,vptr"]   # (unaligned 8 / 16-byte loads are the kernels' idiom)
-        objs, procs = [], []
-        for src in SOURCES:
-            o = os.path.join(obj, os.path.basename(src) + ".o")
-            objs.append(o)
-            procs.append(subprocess.Popen(["g++"] + flags + ["-c", src, "-o", o]))
-        if any(p.wait() != 0 for p in procs):
-            raise RuntimeError("the SIMT build of sniffles_amd/csrc failed")
-        subprocess.run(["g++", "-shared", "-o", so] + (["-fsanitize=undefined"] if sanitize else []) + objs + ["-lpthread", "-ldl"], check=True)
+    def stale():
+        return not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps)
+    if stale():
+        import fcntl
+        with open(os.path.join(obj, ".lock"), "w") as lock:      # one builder at a time (pytest-xdist workers start together)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if stale():
+                flags = list(FLAGS)
+                if sanitize:
+                    flags[flags.index("-O2")] = "-O1"
+                    flags += ["-fsanitize=undefined", "-fsanitize=bounds-strict", "-fno-sanitize=alignment,vptr"]   # (unaligned 8 / 16-byte loads are the kernels' idiom)
+                objs, procs = [], []
+                for src in SOURCES:
+                    o = os.path.join(obj, os.path.basename(src) + ".o")
+                    objs.append(o)
+                    procs.append(subprocess.Popen(["g++"] + flags + ["-c", src, "-o", o]))
+                if any(p.wait() != 0 for p in procs):
+                    raise RuntimeError("the SIMT build of sniffles_amd/csrc failed")
+                tmp = so + ".tmp%d" % os.getpid()
+                subprocess.run(["g++", "-shared", "-o", tmp] + (["-fsanitize=undefined"] if sanitize else []) + objs + ["-lpthread", "-ldl"], check=True)
+                os.replace(tmp, so)      # (a reader never sees a half-written library)
     return so
 
 
