@@ -4,7 +4,7 @@
 One "step" = one full pass of the hot path (Task.call_candidates + Task.finalize_candidates of every
 contig task of the workload: binning, clustering, candidate calls, coverage, QC, genotyping, phasing,
 INS consensus) with the signature tables already resident in HBM, INCLUDING the device->host copy of
-the call records / ALT pool and, for N > 1, the RCCL gather of the per-rank call records on rank 0.
+the call records / ALT pool and, for N > 1, the gather of the per-rank results on rank 0.
 
 Workloads (--config, BASELINE.json `configs`; all seeded synthetic signature sets):
   0  chr20-only 30x ONT germline (the reference's CPU-runnable plumbing case)
@@ -15,7 +15,9 @@ Workloads (--config, BASELINE.json `configs`; all seeded synthetic signature set
 --scaling weak (default): N genome replicas, the 24*N contig tasks sharded longest-first over the ranks.
 --scaling strong: ONE genome; its contigs are grouped into device batches which the ranks claim from a shared work queue
   (sniffles_amd.dist.TaskQueue over the process group's store), K passes over the same genome.
-The only collective is the gather of the call records on rank 0 (counts first, then the records).
+The only collective is the gather on rank 0.  On one node (the default) every rank's kernels store its result into a
+shared-memory segment that rank 0 maps as well (sniffles_amd.dist.SharedLanding: N PCIe links in parallel) and only the
+layouts are gathered; SNF_BENCH_GATHER=rccl and --scaling strong gather the result blocks over RCCL (dist.gather_results).
 
 At N = 1 the line also carries
   wall_clock    one genome end to end through the drop-in boundary: upload, pass, D2H, SVCall materialisation
@@ -259,18 +261,51 @@ def run_calling(ctx):
     # handles[w][g]: batch handle of group g for host thread w (same input, independent handles)
     handles = [[lib.Batch(cfg, gt, device=(0 if EMU else local_rank), _lib=emu_lib()) for gt in group_tasks] for _ in range(W)]
     t_upload = time.time() - t0
-    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist else 0)
+    # N > 1 on one node: every rank's kernels store the result into a shared-memory segment the parent rank maps as well
+    # (sniffles_amd.dist.SharedLanding: N PCIe links in parallel, the gather exchanges layouts only).  SNF_BENCH_GATHER=rccl (and
+    # --scaling strong) take the block gather over RCCL instead: result blocks in HBM, dist.gather onto rank 0, landed there.
+    shared = use_dist and not strong and os.environ.get("SNF_BENCH_GATHER", "shared") != "rccl"
+    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist and not shared else 0)
     for hs in handles:
         for bb in hs:
             bb.set_output(out_mode)
     batches = [h[0] for h in handles]
+    if os.environ.get("SNF_BENCH_RESMEM") and not use_dist:     # measurement: results into caller memory (numpy heap / a /dev/shm file)
+        import numpy as _np
+        _keep = []
+        for w_, h_ in enumerate(handles):
+            if os.environ["SNF_BENCH_RESMEM"] == "shm":
+                path = "/dev/shm/snf_bench_resmem_%d_%d" % (os.getpid(), w_)
+                with open(path, "wb") as f_:
+                    f_.truncate(96 << 20)
+                m_ = _np.memmap(path, _np.uint8, "r+", shape=(96 << 20,)); os.unlink(path)
+            else:
+                m_ = _np.zeros(96 << 20, _np.uint8)
+            _keep.append(m_)
+            h_[0].set_result_memory(m_[:48 << 20], m_[48 << 20:])
     handles_box = [handles]
 
     # capacity of a send buffer (bytes of one result block [records | read names | ALT bytes]): from the first pass, the same
     # on every rank (the largest), with headroom
-    n_send = 2 if strong else W
+    n_send = 2 if strong else (2 * W if shared else W)
     task_ids_local = [t.task_id for t in tasks]
-    if use_dist:
+    landing = None
+    if shared:
+        probe = handles[0][0]
+        probe.call_candidates(); probe.finalize()
+        res0 = probe.fetch(1)
+        need = torch.tensor([256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames), len(res0.alt_pool)], dtype=torch.int64, device=DEV)
+        dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        # two segments per handle, used in turn: pass k + 1 of a handle writes one while the parent still indexes the other
+        # the layouts travel over a host-side (gloo) group: a 72-byte collective must not queue behind the passes' kernels
+        meta_group = dist.new_group(backend="gloo")
+        landing = sdist.SharedLanding(slots=2 * W, block_bytes=int(need[0]) * 3 // 2 + (1 << 20), alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
+        for w in range(W):
+            for k in (1, 0):
+                handles[w][0].set_result_memory(*landing.memory(2 * w + k))     # (page-locked here, once)
+        ids_all = [None] * world
+        dist.all_gather_object(ids_all, task_ids_local)
+    elif use_dist:
         probe = handles[0][0]
         probe.call_candidates(); probe.finalize()
         res0 = probe.fetch(1)
@@ -303,8 +338,11 @@ def run_calling(ctx):
                     comm_q.task_done()
                     return
                 s, lay, ids = item
-                g = sdist.gather_results(sends[s], lay, ids, dst=0, recv_buffer=recv,
-                                         task_ids_per_rank=None if strong else ids_all)
+                if shared:
+                    g = sdist.gather_results_shared(landing, s, lay, ids, group=meta_group, task_ids_per_rank=ids_all)
+                else:
+                    g = sdist.gather_results(sends[s], lay, ids, dst=0, recv_buffer=recv,
+                                             task_ids_per_rank=None if strong else ids_all)
                 if g is not None:
                     gathered_box[0] = g
                 send_free[s].set()
@@ -325,6 +363,8 @@ def run_calling(ctx):
         comm_thread.start()
 
     phase_s = [0.0, 0.0, 0.0, 0.0]
+    lay_box = [None] * W
+    turn_box = [0] * W
 
     def one_pass(w, g=0):
         """One full pass of the hot path over group g on thread w's handle: candidates, finalize, D2H of the results."""
@@ -337,6 +377,8 @@ def run_calling(ctx):
         # the one host wait of the pass: the result block [records | read names | ALT bytes] is in pinned host memory when this
         # returns (N > 1: it stays in HBM for the gather, the export below is the wait)
         n = batch.fetch_raw(1) if not use_dist else 0
+        if shared:
+            lay_box[w] = batch.fetch_layout()      # (the same one host wait: the result lies in this handle's shared segment)
         t_d = time.perf_counter()
         if w == 0:
             phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
@@ -379,6 +421,15 @@ def run_calling(ctx):
         """Exactly `total` passes, split evenly over the W host threads (thread w works on its own batch handle)."""
         def body(w):
             for _ in range(total // W + (1 if w < total % W else 0)):
+                if shared:
+                    slot = 2 * w + (turn_box[w] & 1); turn_box[w] += 1
+                    send_free[slot].wait()                             # the parent has indexed the result this segment held two passes ago
+                    send_free[slot].clear()
+                    handles_box[0][w][0].set_result_memory(*landing.memory(slot))
+                    one_pass(w)
+                    n_calls_box[0] = lay_box[w]["n_calls"]
+                    comm_q.put((slot, lay_box[w], task_ids_local))
+                    continue
                 n_calls_box[0] = one_pass(w)
                 if use_dist:
                     send_free[w].wait()                                # the previous gather of this handle has left the buffer
@@ -443,6 +494,8 @@ def run_calling(ctx):
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    if shared and gathered_box[0] is not None:
+        gathered_box[0].detach()          # (the passes below write the segments again)
     n_calls = n_calls_box[0]
     # per-kernel HIP-event times (on the kernels' own streams), AVERAGED over handle 0's passes inside the timed region
     timings = batches[0].timings_mean() or batches[0].timings()
@@ -555,7 +608,7 @@ def run_calling(ctx):
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls,
                                parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
-                                            if strong else f"contig-sharded x{world}") + ", RCCL gather of the call records on rank 0",
+                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if shared else ", RCCL gather of the result blocks on rank 0"),
                                batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
                                gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)), alt_bytes=int(len(gathered_box[0].alt_pool)),
                                                        read_names=int(len(gathered_box[0].rnames)), tasks=int(len(gathered_box[0].task_ids)),

@@ -351,6 +351,16 @@ int snf_batch_finalize(snf_batch_t* b);
 enum snf_output { SNF_OUT_CANDIDATES = 0, SNF_OUT_EXECUTE = 1, SNF_OUT_DEVICE = 2 };
 int snf_batch_set_output(snf_batch_t* b, int mode);
 
+/* Where the stage-1 result lands on the host: `block` receives [ records | read names ] and `alt` the ALT section, both
+ * written by the kernels themselves (zero-copy), so the memory must be page-locked for the device: the library registers the
+ * two ranges (hipHostRegister) the first time it sees them and unpins them at snf_batch_destroy - switching between a few
+ * segments (one per pass in flight) costs nothing after the first round.  Meant for memory
+ * ANOTHER PROCESS maps as well - one process per GPU, the parent (the reference's `Main`, parallel.py:757 receives whole
+ * results) reads every worker's result from a shared-memory segment without a copy and without funnelling it through one
+ * GPU's PCIe link.  A result that does not fit fails the fetch with the sizes needed.  NULL, 0, NULL, 0: the library's own
+ * pinned buffers again.  Call it between passes (it waits for the batch's streams). */
+int snf_batch_set_result_memory(snf_batch_t* b, void* block, int64_t block_bytes, void* alt, int64_t alt_bytes);
+
 /* device -> host of the call records (blocks until the batch's streams are idle).
  * stage 0: the candidates after call_candidates (no ALT); 1: after finalize, as selected by snf_batch_set_output.
  * snf_batch_call_candidates + snf_batch_finalize enqueue without waiting for the device; this is the one host wait of a pass.

@@ -196,8 +196,28 @@ PinnedCache g_pinned;
 
 struct HostBuf {
   void* p = nullptr; size_t cap = 0;
+  bool external = false;      // caller's memory (snf_batch_set_result_memory): registered with the device here, never freed here
+  // `registered`: the caller's ranges this batch has page-locked so far (switching between them - one segment per pass in
+  // flight - must not pin again; they are unpinned when the batch goes)
+  void adopt(void* mem, size_t bytes, std::vector<std::pair<void*, size_t>>& registered) {
+    release();
+    if (!mem || !bytes) return;
+    bool known = false;
+    for (auto& e : registered) known |= e.first == mem && e.second >= bytes;
+    if (!known) {
+      SNF_HIP(hipHostRegister(mem, bytes, hipHostRegisterDefault));
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, mem, 0) != hipSuccess || dp != mem) {     // (the kernels and the host use one address)
+        (void)hipGetLastError(); (void)hipHostUnregister(mem);
+        fail("snf_batch_set_result_memory: the device maps this memory at another address");
+      }
+      registered.push_back({mem, bytes});
+    }
+    p = mem; cap = bytes; external = true;
+  }
   void* ensure(size_t bytes) {
     if (bytes <= cap && p) return p;
+    if (external) fail("the result does not fit the memory given to snf_batch_set_result_memory (" + std::to_string(bytes) + " bytes needed, " + std::to_string(cap) + " given)");
     release();
     size_t got = 0;
     void* c = g_pinned.take(bytes, &got);
@@ -214,7 +234,8 @@ struct HostBuf {
   }
   void release() {
     if (!p) return;
-    if (!g_pinned.give(p, cap)) {
+    if (external) external = false;          // (unpinned with the batch: snf_batch_impl::ext_ranges)
+    else if (!g_pinned.give(p, cap)) {
       (void)hipHostFree(p);
     }
     p = nullptr; cap = 0;
@@ -277,7 +298,9 @@ struct snf_batch_impl {
   int64_t tab_cap = 0, aln_cap = 0, cr_cap = 0, alt_cap = 0;
   // results (host)
   HostBuf hb_calls, hb_rn, hb_res;   // stage-0 fetch: candidate records, read names; the pinned result block
+  bool pass_idle = false;            // a fetch has waited for the pass and neither stage has been enqueued since (set_result_memory need not wait again)
   HostBuf hb_out, hb_alt;            // stage-1 fetch: the output block (snf_stage_out.h), the ALT section
+  std::vector<std::pair<void*, size_t>> ext_ranges;   // caller memory page-locked for them (snf_batch_set_result_memory)
   // class sizes of this handle's previous finalize (same input -> same sizes; first pass: one host wait for them)
   bool have_hist = false; int64_t hist_calls = 0, hist_small = 0, hist_large = 0, hist_copy = 0;
   int out_mode = 0;                  // enum snf_output
@@ -1062,6 +1085,7 @@ void enqueue_keys(snf_batch_impl* b) {
 
 void run_call_candidates(snf_batch_impl* b) {
   SNF_TRACE("snf_batch_call_candidates (enqueue)");
+  b->pass_idle = false;
   View& v = b->v;
   int T = v.T;
   const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
@@ -1348,6 +1372,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
 
 void run_finalize(snf_batch_impl* b) {
   SNF_TRACE("snf_batch_finalize (enqueue)");
+  b->pass_idle = false;
   View& v = b->v;
   const int64_t NS = v.NS;
   b->finalized = true;
@@ -1356,12 +1381,12 @@ void run_finalize(snf_batch_impl* b) {
   // and stride or return), the ALT bytes go to an HBM pool sized at upload, and the fetch is the one host wait of the pass.
   {  // pinned block for the result: sized from the input, grown by the fetch when a result did not fit
     const size_t want = (size_t)((v.out_mode & SNF_OUT_EXECUTE) ? 8 : 16) * (size_t)(v.N > 0 ? v.N : 1) + ((size_t)1 << 20);
-    if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_out.cap < want) b->hb_out.ensure(want);
+    if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_out.external && b->hb_out.cap < want) b->hb_out.ensure(want);
     v.out_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_out.p;
     v.out_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_out.cap;
     // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
     const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
-    if (!(v.out_mode & SNF_OUT_DEVICE) && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
+    if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_alt.external && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
     static const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr;   // measurement: ALT bytes into the HBM pool, copied at fetch
     v.alt_pin = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? nullptr : (uint8_t*)b->hb_alt.p;
     v.alt_pin_cap = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? 0 : (int64_t)b->hb_alt.cap;
@@ -1590,6 +1615,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     out->rnames_len = h.rn_out; out->rnames = (const uint32_t*)(base + h.off_rn);
     out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
     out->coverage_average_total = b->r_cov.data();
+    b->pass_idle = true;
     return;
   }
   // ---- candidates (stage 0, or no finalize yet): records and read names as the candidate stage left them in HBM
@@ -1627,6 +1653,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   out->rnames_len = rn_total; out->rnames = rn;
   out->n_tasks = T; out->task_status = b->r_status.data(); out->task_call_off = b->r_off.data();
   out->coverage_average_total = b->r_cov.data();
+  b->pass_idle = true;
 }
 
 void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
@@ -2101,6 +2128,8 @@ void snf_batch_destroy(snf_batch_t* bb) {
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   dfree_all(b);
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
+  for (auto& e : b->ext_ranges) (void)hipHostUnregister(e.first);
+  b->ext_ranges.clear();
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
   if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
@@ -2168,6 +2197,18 @@ int snf_batch_set_output(snf_batch_t* bb, int mode) {
     if (!b) fail("null batch");
     if (mode < 0 || mode > (SNF_OUT_EXECUTE | SNF_OUT_DEVICE)) fail("unknown output mode");
     b->out_mode = mode; b->v.out_mode = mode;
+  })
+}
+
+int snf_batch_set_result_memory(snf_batch_t* bb, void* block, int64_t block_bytes, void* alt, int64_t alt_bytes) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b) fail("null batch");
+    if ((block == nullptr) != (alt == nullptr) || block_bytes < 0 || alt_bytes < 0) fail("snf_batch_set_result_memory: both sections or none");
+    if (b->uploaded && !b->pass_idle) full_sync(b);     // (no pass of this batch is writing the old buffers)
+    SNF_HIP(hipSetDevice(b->device));
+    if (!block) { b->hb_out.release(); b->hb_alt.release(); }
+    else { b->hb_out.adopt(block, (size_t)block_bytes, b->ext_ranges); b->hb_alt.adopt(alt, (size_t)alt_bytes, b->ext_ranges); }
   })
 }
 

@@ -223,6 +223,84 @@ def gather_results(block, layout: dict, task_ids, dst: int = 0, group=None, name
     return out
 
 
+class SharedLanding:
+    """Node-local landing of the results (one process per GPU on ONE node): every rank owns `slots` shared-memory segments
+    under /dev/shm, `Batch.set_result_memory` makes its kernels write the finalized result straight into one of them - over
+    that GPU's own PCIe link -, and rank `dst` maps all of them.  The gather (`gather_results_shared`) then only exchanges the
+    layouts: no result byte crosses a second link or is copied on the host, and N GPUs land their results through N links
+    instead of funnelling them through the one of rank `dst` (the block gather of `gather_results` is what a multi-node job,
+    or a node without /dev/shm, uses).  A segment is [ block: records | read names ][ ALT section at `block_bytes` ]."""
+
+    def __init__(self, slots: int, block_bytes: int, alt_bytes: int, dst: int = 0, group=None, directory: str = "/dev/shm"):
+        import os
+        import numpy as np
+        import torch.distributed as dist
+        self.world, self.rank, self.dst = dist.get_world_size(group), dist.get_rank(group), dst
+        self.slots, self.block_bytes, self.alt_bytes = int(slots), (int(block_bytes) + 4095) & ~4095, (int(alt_bytes) + 4095) & ~4095
+        tag = [None]
+        if self.rank == dst:
+            tag[0] = "snf_%d_%s" % (os.getpid(), os.urandom(4).hex())
+        dist.broadcast_object_list(tag, src=dst, group=group)
+        self._paths = {(r, k): os.path.join(directory, "%s_r%d_s%d" % (tag[0], r, k)) for r in range(self.world) for k in range(self.slots)}
+        size = self.block_bytes + self.alt_bytes
+        self._own = []
+        for k in range(self.slots):
+            path = self._paths[(self.rank, k)]
+            with open(path, "wb") as f:
+                f.truncate(size)
+            self._own.append(np.memmap(path, np.uint8, "r+", shape=(size,)))
+        dist.barrier(group)                                  # every segment exists
+        self._all = {}
+        if self.rank == dst:
+            for (r, k), path in self._paths.items():
+                self._all[(r, k)] = self._own[k] if r == self.rank else np.memmap(path, np.uint8, "r", shape=(size,))
+        dist.barrier(group)                                  # ... and is mapped where it is read: the names can go
+        for k in range(self.slots):
+            try:
+                os.unlink(self._paths[(self.rank, k)])
+            except OSError:
+                pass
+
+    def memory(self, slot: int):
+        """(block, alt) of this rank's segment `slot`, for `Batch.set_result_memory`."""
+        m = self._own[slot]
+        return m[:self.block_bytes], m[self.block_bytes:]
+
+    def view(self, rank: int, slot: int):
+        return self._all[(rank, slot)]
+
+
+def gather_results_shared(landing: SharedLanding, slot: int, layout: dict, task_ids, group=None, task_ids_per_rank=None,
+                          device=None):
+    """The gather over a `SharedLanding`: this rank's finalized result lies in its segment `slot` (`Batch.fetch_layout` returned
+    `layout`); one all-gather of the layouts (9 x int64) and rank `dst` returns the `GatheredResult` over the segments of all
+    ranks (None elsewhere) - views, valid until the owning batches run their next pass into the same segments (`detach()`
+    copies).  `device`: where the small collective's tensor lives (the process group's device; default: CPU)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lay = dict(layout)
+    lay["off_alt"] = landing.block_bytes
+    lay["bytes"] = landing.block_bytes + int(lay["alt_pool_len"])
+    if int(lay["off_rnames"]) + 4 * int(lay["rnames_len"]) > landing.block_bytes or int(lay["alt_pool_len"]) > landing.alt_bytes:
+        raise ValueError("the result does not fit the shared segment")
+    mine = torch.tensor([int(lay[f]) for f in LAYOUT_FIELDS] + [len(task_ids), int(slot), 0], dtype=torch.int64, device=device or "cpu")
+    lays = torch.zeros(world * mine.numel(), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(lays, mine, group=group)
+    ids_all = task_ids_per_rank
+    if ids_all is None:
+        ids_all = [None] * world
+        dist.all_gather_object(ids_all, [int(i) for i in task_ids], group=group)
+    if rank != landing.dst:
+        return None
+    lays = lays.cpu().view(world, -1)
+    blocks = []
+    for r in range(world):
+        d = dict(zip(LAYOUT_FIELDS, (int(x) for x in lays[r, :6])))
+        blocks.append((d, landing.view(r, int(lays[r, 7]))[:d["bytes"]]))
+    return merge_blocks(blocks, ids_all)
+
+
 def result_block(res):
     """(layout, bytes) of a fetched stage-1 result in the export format - for ranks whose result is already on the host
     (tests over gloo; `Batch.export_device` is the device form)."""

@@ -42,6 +42,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_fetch_clusters.restype = C.c_int
     lib.snf_batch_export_device.argtypes = [vp, vp, C.c_int64, C.POINTER(abi.snf_export_layout_t)]
     lib.snf_batch_set_output.argtypes = [vp, C.c_int]
+    lib.snf_batch_set_result_memory.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
     lib.snf_trim_caches.argtypes = [C.c_int]
     lib.snf_batch_n_candidates.argtypes = [vp]
     lib.snf_batch_n_candidates.restype = C.c_int64
@@ -86,7 +87,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
               "snf_extract_device_view", "snf_batch_add_task_device"):
         getattr(lib, f).restype = C.c_int
     for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
-              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_device", "snf_batch_set_output",
+              "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_device", "snf_batch_set_output", "snf_batch_set_result_memory",
               "snf_batch_timing_count",
               "snf_batch_timing_get", "snf_edit_distance_batch"):
         getattr(lib, f).restype = C.c_int
@@ -188,6 +189,16 @@ class Batch:
         _check(self.lib, self.lib.snf_batch_fetch(self._h, stage, C.byref(r)))
         return int(r.n_calls)
 
+    def fetch_layout(self) -> dict:
+        """The one host wait of a pass (stage-1 fetch) and where the result lies in the memory given to `set_result_memory`:
+        `block` holds the records at 0 and the read names at `off_rnames`, `alt` the ALT section at 0 (the layout keys of
+        `export_device`, with `off_alt` / `bytes` left to the caller, who knows how the two arrays are placed)."""
+        r = abi.snf_result_t()
+        _check(self.lib, self.lib.snf_batch_fetch(self._h, 1, C.byref(r)))
+        n = int(r.n_calls)
+        return dict(n_calls=n, rnames_len=int(r.rnames_len), alt_pool_len=int(r.alt_pool_len),
+                    off_rnames=(n * abi.CALL_DTYPE.itemsize + 255) & ~255)
+
     def fetch_clusters(self, stage: int) -> dict:
         """The clusters of the candidate stage (0 seeds, 1 after the merge scan, 2 as cluster.resolve yields them) as numpy
         columns: task_index, svtype, start, end, seed, seed_index, n_leads_long, repeat, lead_off, lead (row in the task's
@@ -209,6 +220,23 @@ class Batch:
         Task.finalize_candidates returns), abi.OUT_EXECUTE (what CallTask.execute keeps: qc-passing calls, per task sorted by
         pos, compacted on the device), optionally | abi.OUT_DEVICE (the block stays in HBM: `export_device`)."""
         _check(self.lib, self.lib.snf_batch_set_output(self._h, int(mode)))
+
+    def set_result_memory(self, block=None, alt=None) -> None:
+        """Where stage-1 results land on the host: two writable uint8 numpy arrays (e.g. views of a shared-memory segment another
+        process maps as well) receive [records | read names] and the ALT section, written by the kernels themselves; the library
+        page-locks them for the device (once per array: switching between a few segments is cheap).  None, None: the library's
+        own pinned buffers again.  The arrays must outlive the batch; call it between passes."""
+        if block is None or alt is None:
+            _check(self.lib, self.lib.snf_batch_set_result_memory(self._h, None, 0, None, 0))
+            return
+        for a in (block, alt):
+            if a.dtype != np.uint8 or not a.flags["C_CONTIGUOUS"] or not a.flags["WRITEABLE"]:
+                raise ValueError("set_result_memory takes writable, contiguous uint8 arrays")
+        _check(self.lib, self.lib.snf_batch_set_result_memory(self._h, C.c_void_p(block.ctypes.data), int(block.nbytes),
+                                                              C.c_void_p(alt.ctypes.data), int(alt.nbytes)))
+        if not hasattr(self, "_result_mems"):
+            self._result_mems = {}
+        self._result_mems[(block.ctypes.data, alt.ctypes.data)] = (block, alt)   # (page-locked by the library until the batch is closed)
 
     def export_device(self, dst_ptr: int, cap_bytes: int) -> dict:
         """Device-to-device copy of the finalized result block [records | read names | ALT bytes] into caller-owned HBM (for

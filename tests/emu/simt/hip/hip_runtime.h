@@ -543,6 +543,10 @@ inline bool dev_free(void* p) {
 }  // namespace simt
 template <class T> static inline hipError_t hipMalloc(T** p, size_t n) { void* q = simt::dev_alloc(n); if (!q) return 2; *p = (T*)q; return hipSuccess; }
 static inline hipError_t hipFree(void* p) { return simt::dev_free(p) ? hipSuccess : 1; }
+#define hipHostRegisterDefault 0u
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned) { *dp = hp; return hipSuccess; }
 template <class T> static inline hipError_t hipHostMalloc(T** p, size_t n, unsigned flags = 0) { (void)flags; void* q = std::malloc(n ? n : 1); if (!q) return 2; *p = (T*)q; return hipSuccess; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::lock_guard<std::mutex> g(simt::g_launch_mutex); if (n) std::memmove(d, s, n); return hipSuccess; }

@@ -115,6 +115,77 @@ def test_two_rank_shard_and_gather_equals_single_process():
     assert max(loads) <= 1.35 * min(loads)
 
 
+def _shared_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emu.emu as E
+    from sniffles_amd import abi, dist as sdist, lib
+    from sniffles_amd.config import SnifflesConfig
+    tasks = _tasks()
+    shards = sdist.shard_lpt([t.contig_len for t in tasks], world)
+    mine = shards[rank]
+    cfg = SnifflesConfig()
+    landing = sdist.SharedLanding(slots=2, block_bytes=1 << 21, alt_bytes=1 << 20)
+    ids = [tasks[i].task_id for i in mine]
+    texts = []
+    with lib.Batch(cfg, [tasks[i] for i in mine], _lib=E.lib()) as b:
+        b.set_output(abi.OUT_EXECUTE)
+        for slot in (0, 1, 0):                               # three passes: both segments, and one of them again
+            b.set_result_memory(*landing.memory(slot))
+            b.call_candidates(); b.finalize()
+            lay = b.fetch_layout()
+            merged = sdist.gather_results_shared(landing, slot, lay, ids)
+            if rank == 0:
+                texts.append(vcf_text(cfg, tasks, lambda ti: (merged, merged.task_rows(ti.task_id))))
+            else:
+                assert merged is None
+            dist.barrier()                                   # (the parent is done with the segments before the next pass writes them)
+        # a result that does not fit the caller's memory is refused, never truncated
+        small = np.zeros(512, np.uint8)
+        b.set_result_memory(small, small.copy())
+        b.call_candidates(); b.finalize()
+        try:
+            b.fetch_layout()
+            refused = False
+        except lib.SnifflesAmdError as e:
+            refused = "does not fit" in str(e)
+        b.set_result_memory(None, None)
+        b.call_candidates(); b.finalize()
+        own = b.fetch(1)
+    if rank == 0:
+        q.put((texts, refused, int(len(own.calls))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_shared_landing_equals_single_process():
+    """`SharedLanding` + `gather_results_shared`: every rank's kernels write the result into a shared-memory segment
+    (`Batch.set_result_memory`), rank 0 reads all segments in place - its VCF text equals the single process's, pass after pass;
+    memory that is too small is refused; the library's own buffers come back."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import emu.emu as E
+    from sniffles_amd import abi
+    from sniffles_amd.config import SnifflesConfig
+    E.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_shared_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    texts, refused, n_own = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_text, _ = single_process_text(SnifflesConfig(), _tasks(), E.lib(), abi.OUT_EXECUTE)
+    assert texts == [exp_text] * 3 and "SVTYPE=INS" in exp_text
+    assert refused and n_own > 10
+
+
 def _queue_worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -251,13 +322,13 @@ def test_two_rank_combine_scatter_equals_reference_parts():
             assert gu.diff_records([g], [e]) == []
 
 
-def _bench_two_ranks(extra, port):
+def _bench_two_ranks(extra, port, **env_extra):
     """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per device), on this GPU-less box:
     SNF_BENCH_EMU=1 = gloo + CPU tensors + the kernels through the host emulation.  The code that runs is the code of the
     N > 1 GPU run: process group, work queue, result export per pass, `dist.gather_results` on the communication thread."""
     import json
     import subprocess
-    env = dict(os.environ, SNF_BENCH_EMU="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, SNF_BENCH_EMU="1", OMP_NUM_THREADS="1", **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--scale", "0.004",
            "--no-cpu-baseline", "--no-wall-clock"] + extra
@@ -269,9 +340,19 @@ def _bench_two_ranks(extra, port):
 
 
 def test_bench_two_ranks_weak_scaling_emu():
+    """The default N > 1 line: results into node-shared memory by every rank's own kernels, layouts gathered."""
     d = _bench_two_ranks([], 32500 + (os.getpid() % 500))
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks"] == 48 and d["value"] > 0
     assert d["config"]["gathered_on_rank0"]["ranks"] == 2 and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+    assert "SharedLanding" in d["config"]["parallelism"]
+
+
+def test_bench_two_ranks_weak_scaling_block_gather_emu():
+    """The same line with the result blocks gathered through the process group (`dist.gather_results`: what a multi-node job takes)."""
+    d = _bench_two_ranks([], 34500 + (os.getpid() % 500), SNF_BENCH_GATHER="rccl")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks"] == 48 and d["value"] > 0
+    assert d["config"]["gathered_on_rank0"]["ranks"] == 2 and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+    assert "RCCL gather" in d["config"]["parallelism"]
 
 
 def test_bench_two_ranks_strong_scaling_emu():
