@@ -924,7 +924,7 @@ void do_upload(snf_batch_impl* b) {
   v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
-  { const int eb = getenv("SNF_E1_BATCH") ? atoi(getenv("SNF_E1_BATCH")) : 8; v.e1_batch = (eb == 2 || eb == 4 || eb == 16 || eb == 32) ? eb : 8; }
+  { const int eb = getenv("SNF_E1_BATCH") ? atoi(getenv("SNF_E1_BATCH")) : 64; v.e1_batch = (eb == 2 || eb == 4 || eb == 8 || eb == 16 || eb == 32) ? eb : 64; }
   v.stage_cap = getenv("SNF_NO_BIG_STAGE") ? 0 : 1;   // x_big<0>: clusters up to SNF_BIG_STAGE_CAP leads are kept in LDS
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);

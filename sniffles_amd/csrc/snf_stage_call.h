@@ -391,6 +391,7 @@ SNF_HD void d2_call_body(int64_t r, const View& v) {
   v.cand[r] = cc;
   CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = -1; x.n_others = 0; x.do_cons = 0; x.cons_id = -1; x.alt_off = 0;
   x.rn_nq = (int32_t)nq; x._pad = 0;
+  x.ag_valid = 0; x.ag_nstrands = x.ag_close_edge = x.ag_hp_val = x.ag_hp_support = x.ag_hp_other = x.ag_ps_val = x.ag_ps_support = x.ag_ps_other = x.ag_has_nm = 0; x.ag_nm_mean = 0.0;   // (collected by the finalize body itself)
   if (svtype == SNF_INS && !cfg.symbolic) {
     // best lead of annotate_sv (postprocessing.py:33-66): first argmin of |len(seq) - svlen| + |ref_start - pos| * 1.5
     int32_t best = -1, cnt = 0; double best_diff = 0; int32_t best_k = 0x7fffffff;

@@ -93,7 +93,12 @@ struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t cons_id;
   int64_t alt_off;
   int32_t rn_nq;    // distinct read names d2 left sorted in w1[flo..] (the rest come from leads_long): input of d3_rnames_emit
+  // aggregates over the call's leads that QC / phasing need (LeadAgg, snf_stage_final.h), formed by d2w_call while the leads
+  // are in its registers - e1w_finalize used to gather every lead's 64-byte record a second time for them (193 MB per pass)
+  int32_t ag_valid; // 1: set (wave path, <= 64 leads); 0: whoever finalizes the call collects them itself
+  int32_t ag_nstrands, ag_close_edge, ag_hp_val, ag_hp_support, ag_hp_other, ag_ps_val, ag_ps_support, ag_ps_other, ag_has_nm;
   int32_t _pad;
+  double ag_nm_mean;
 };
 
 struct View {
@@ -242,7 +247,7 @@ struct View {
   int32_t* big_list;         // [3][64][big_cap]
   int64_t big_cap;
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
-  int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32; default 8)
+  int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32, 64; default 64)
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative
   int32_t* w7;               // [N+1] scratch of the cooperative sorts (same slot space as w0..w6)
   // x_big<0> keeps a cluster in LDS: its packed lead records and the eight scratch rows (stage_cap entries each); null otherwise

@@ -65,6 +65,75 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
   return stdev_from_sums(cnt, (i128)S1, S2);
 }
 
+// ------------------------------------------------------------------------------------------ lead aggregates of a call
+// len(set(strands)), leads close to a read edge (postprocessing.py:574-577), the HP / PS majorities of phase_sv over distinct
+// reads (the last lead of a read wins, postprocessing.py:626-654), np.nanmean of the NM ratios (rescue_phasing) - over the
+// SELECTED leads of a cluster of n <= 64 leads, one lead per lane.  All lanes must call it.
+SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n, bool sel, int strand, int hap, uint32_t rid, int32_t ps,
+                         bool close, bool want_nm, double nm, CallX& x) {
+  x.ag_valid = 1;
+  x.ag_nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
+  x.ag_close_edge = __builtin_popcountll(__ballot(sel && close));
+  int hp_val = 0, hp_support = -1, hp_other = 0; int32_t ps_val = 0; int ps_support = -1, ps_other = 0;
+  if (cfg.phase) {
+    // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
+    bool later = false;
+    for (int k = 0; k < n; k++) {
+      const uint32_t rk = (uint32_t)wave_bcast_i32((int32_t)rid, k);
+      const bool sk = wave_bcast_i32(sel ? 1 : 0, k) != 0;
+      if (k > lane && sk && rk == rid) later = true;
+    }
+    const bool contrib = sel && !later;
+    int hc[3];
+    for (int hh = 0; hh < 3; hh++) hc[hh] = __builtin_popcountll(__ballot(contrib && hap == hh));
+    for (int hh = 0; hh < 3; hh++) if (hc[hh] > 0 && hc[hh] >= hp_support) { hp_support = hc[hh]; hp_val = hh; }
+    for (int hh = 0; hh < 3; hh++) if (hh != hp_val) hp_other += hc[hh];
+    const int np_ = __builtin_popcountll(__ballot(contrib));
+    // phase sets of the contributing reads, sorted (non-contributors sort behind: rank sort on a wider key)
+    const uint64_t key = contrib ? (((uint64_t)((uint32_t)ps ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
+    const int rank = wave_rank(key, n);
+    __syncthreads();
+    if (contrib) lds.buf[rank] = ps;
+    __syncthreads();
+    const int32_t s_ps = lds.buf[lane < np_ ? lane : 0];
+    const int32_t p_ps = __shfl_up(s_ps, 1, SNF_WAVE);
+    const bool st = lane < np_ && (lane == 0 || p_ps != s_ps);
+    const unsigned long long smask = __ballot(st);
+    const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
+    const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : np_) - lane) : 0;
+    const int maxc = wave_max32(len);
+    const unsigned long long best = __ballot(st && len == maxc);
+    const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
+    ps_val = __shfl(s_ps, bl, SNF_WAVE); ps_support = maxc;
+    ps_other = (int)wave_sum64((st && s_ps != ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
+    __syncthreads();
+  }
+  x.ag_hp_val = hp_val; x.ag_hp_support = hp_support; x.ag_hp_other = hp_other;
+  x.ag_ps_val = ps_val; x.ag_ps_support = ps_support; x.ag_ps_other = ps_other;
+  x.ag_has_nm = 0; x.ag_nm_mean = 0.0;
+  if (want_nm) {
+    // np.nanmean(nm of the leads, list order) with numpy's pairwise summation for n <= 128 (snf_exact.h::np_pairwise_sum):
+    // fewer than 8 values: left to right; otherwise eight accumulators r[q] over the positions q, q + 8, ... below
+    // n - n % 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right.  NaN counts as 0 in the sum.
+    const int cnt = __builtin_popcountll(__ballot(lane < n && nm == nm));
+    lds.nm[lane] = (lane < n && nm == nm) ? nm : 0.0;
+    __syncthreads();
+    double res = 0.0;
+    if (n < 8) { for (int q = 0; q < n; q++) res += lds.nm[q]; }
+    else {
+      const int n8 = n - n % 8;
+      double r = 0.0;
+      if (lane < 8) { r = lds.nm[lane]; for (int q = 8 + lane; q < n8; q += 8) r += lds.nm[q]; }
+      double rq[8];
+      for (int q = 0; q < 8; q++) rq[q] = __shfl(r, q, SNF_WAVE);
+      res = ((rq[0] + rq[1]) + (rq[2] + rq[3])) + ((rq[4] + rq[5]) + (rq[6] + rq[7]));
+      for (int q = n8; q < n; q++) res += lds.nm[q];
+    }
+    x.ag_nm_mean = res / (double)cnt; x.ag_has_nm = 1;
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------ d2w: call_from
 template <int MINW>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t n_unused) {
@@ -91,12 +160,17 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     int32_t slot = 0; uint32_t o = 0; int32_t svl = 0, rs = 0; uint32_t qn = 0;
     int mapq = 0, strand = 0, is_sa = 0, noninline = 0; double nm = 0;
     int32_t mctg = 0, mpos = 0; int bfirst = 0, brev = 0;
+    int hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;    // for the lead aggregates (wave_lead_agg)
+    const bool want_nm = cfg.phase && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
     if (act) {
       slot = slot_pre; svl = v.F_svlen[slot];
       const LeadRec r = v.Lrec[v.F_lpos[slot]];
       o = r.orig; rs = r.ref_start; qn = r.qname; mapq = r.mapq; strand = r.strand; is_sa = r.is_sa;
       noninline = r.source != SNF_SRC_INLINE;
-      if (cfg.qc_nm_measure) nm = v.in_nm[o];
+      hap = r.hap; rid = r.read_id;
+      ps = (r.ps == SNF_PS_NONE || r.ps == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : r.ps;
+      close = (int64_t)r.qry_start <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - (int64_t)r.qry_start) <= cfg.dev_min_close_edge_dist;
+      if (cfg.qc_nm_measure || want_nm) nm = v.in_nm[o];
       mctg = r.mate_contig; mpos = r.mate_pos; bfirst = r.first; brev = r.rev;
       v.F_sel[slot] = 1;
     }
@@ -170,6 +244,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     cc.cluster_start = v.seed_start[h]; cc.cluster_end = v.c_end[h];
     cc.cluster_seed_index = v.prefilter ? -1 : v.seed_bin[h] - v.grp_first_bin[g];
     int64_t rn_len = support;
+    bool sel_final = act;     // the leads the call keeps (resolve_bnd narrows them)
     if (svtype == SNF_BND) {  // resolve_bnd (sv.py:625-639)
       const int32_t s_mc = wave_sort_i32(mctg, act, n, lane, lds.buf);
       const int32_t p_mc = __shfl_up(s_mc, 1, SNF_WAVE);
@@ -181,6 +256,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
       const unsigned long long best = __ballot(st && len == maxc);
       const int32_t mc = __shfl(s_mc, __builtin_ctzll(best), SNF_WAVE);  // most_common_top: ties -> smallest value
       const bool sel = act && mctg == mc;
+      sel_final = sel;
       if (act) v.F_sel[slot] = sel ? 1 : 0;
       const unsigned long long selmask = __ballot(sel);
       const int ns = __builtin_popcountll(selmask);
@@ -229,11 +305,12 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
         }
       }
     }
+    CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = best_slot; x.n_others = n_others;
+    x.do_cons = (best_slot >= 0 && n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; x.cons_id = -1; x.alt_off = 0;
+    x.rn_nq = (int32_t)nq; x._pad = 0;
+    wave_lead_agg(cfg, lds, lane, n, sel_final, strand, hap, rid, ps, close, want_nm, nm, x);
     if (lane == 0) {
       v.cand[r] = cc;
-      CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = best_slot; x.n_others = n_others;
-      x.do_cons = (best_slot >= 0 && n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; x.cons_id = -1; x.alt_off = 0;
-      x.rn_nq = (int32_t)nq; x._pad = 0;
       v.candx[r] = x;
       v.cdflag[r] = 1;
     }
@@ -242,116 +319,30 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
 }
 
 // ------------------------------------------------------------------------------------------ e1w: finalize
-// A wave takes View::e1_batch (8) consecutive calls: the aggregates of each call are formed by the whole wave, one call after the
-// other (phase A), then lane j runs the scalar tail of call j - QC, genotype, phase filters, rescue (phase B).  That tail is a
-// chain of dependent loads and double arithmetic on ONE lane; with one call per wave it was 24-50 % of the kernel's time.
+// The scalar tail of Task.finalize_candidates - QC, genotype, phase filters, rescue - one call per lane, View::e1_batch calls
+// per wave (the tail is a chain of dependent loads and double arithmetic; more calls per wave would leave too few waves to
+// hide it).  The aggregates over a call's leads come with the call (CallX::ag_*, formed by d2w_call); calls without them
+// (clusters of more than 64 leads) go to x_big<2>.
 #define SNF_E1_BATCH_MAX 32
 template <int MINW>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int64_t n_unused) {
-  __shared__ CallLds lds;
-  __shared__ LeadAgg s_agg[SNF_E1_BATCH_MAX];
-  __shared__ int s_ok[SNF_E1_BATCH_MAX];
   const int E1B = v.e1_batch;      // calls per wave (the launch uses the same number)
   const int lane = threadIdx.x;
-  const snf_config_t& cfg = v.cfg;
   const int64_t n_calls = v.cnt->n_calls;
-  const bool want_nm = cfg.phase && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
   for (int64_t base = (int64_t)blockIdx.x * E1B; base < n_calls; base += (int64_t)gridDim.x * E1B) {
-    // ---- phase A: aggregates of the calls base .. base + 15, the whole wave on one call at a time
-    for (int j = 0; j < E1B; j++) {
-      const int64_t i = base + j;
-      if (lane == 0) s_ok[j] = 0;
-      if (i >= n_calls) continue;
-      const int task = v.calls[i].task_index;
-      if (v.t_status[task] != SNF_TASK_OK) continue;
-      const CallX x = v.callx[i];
-      if (x.fn > SNF_WAVE) { if (lane == 0) big_push(v, 2, (int32_t)i); continue; }  // x_big<2>
-      const int n = x.fn;
-      bool sel = false; uint32_t o = 0; int strand = 0, hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;
-      if (lane < n) {
-        const int32_t s = v.FI[x.flo + lane];
-        sel = v.F_sel[s] != 0;
-        const LeadRec r = v.Lrec[v.F_lpos[s]];
-        o = r.orig; strand = r.strand; hap = r.hap; rid = r.read_id;
-        const int32_t p = r.ps;
-        ps = (p == SNF_PS_NONE || p == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : p;
-        const int64_t qs = r.qry_start;
-        close = qs <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - qs) <= cfg.dev_min_close_edge_dist;
-      }
-      double nm = 0.0;
-      if (want_nm && lane < n) nm = v.in_nm[o];              // in flight while the aggregates are formed
-      LeadAgg g;
-      g.nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
-      g.close_edge = __builtin_popcountll(__ballot(sel && close));
-      g.hp_val = 0; g.hp_support = -1; g.hp_other = 0; g.ps_val = 0; g.ps_support = -1; g.ps_other = 0;
-      g.nm_row = nullptr; g.has_nm_mean = 0; g.nm_mean = 0.0;
-      if (cfg.phase) {
-        // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
-        bool later = false;
-        for (int k = 0; k < n; k++) {
-          const uint32_t rk = (uint32_t)wave_bcast_i32((int32_t)rid, k);
-          const bool sk = wave_bcast_i32(sel ? 1 : 0, k) != 0;
-          if (k > lane && sk && rk == rid) later = true;
-        }
-        const bool contrib = sel && !later;
-        int64_t hc[3];
-        for (int hh = 0; hh < 3; hh++) hc[hh] = __builtin_popcountll(__ballot(contrib && hap == hh));
-        for (int hh = 0; hh < 3; hh++) if (hc[hh] > 0 && hc[hh] >= g.hp_support) { g.hp_support = hc[hh]; g.hp_val = hh; }
-        for (int hh = 0; hh < 3; hh++) if (hh != g.hp_val) g.hp_other += hc[hh];
-        const int np_ = __builtin_popcountll(__ballot(contrib));
-        // phase sets of the contributing reads, sorted (non-contributors sort behind: rank sort on a wider key)
-        const uint64_t key = contrib ? (((uint64_t)((uint32_t)ps ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
-        const int rank = wave_rank(key, n);
-        __syncthreads();
-        if (contrib) lds.buf[rank] = ps;
-        __syncthreads();
-        const int32_t s_ps = lds.buf[lane < np_ ? lane : 0];
-        const int32_t p_ps = __shfl_up(s_ps, 1, SNF_WAVE);
-        const bool st = lane < np_ && (lane == 0 || p_ps != s_ps);
-        const unsigned long long smask = __ballot(st);
-        const unsigned long long above = lane < 63 ? (smask >> (lane + 1)) : 0ull;
-        const int len = st ? ((above ? lane + 1 + __builtin_ctzll(above) : np_) - lane) : 0;
-        const int maxc = wave_max32(len);
-        const unsigned long long best = __ballot(st && len == maxc);
-        const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
-        g.ps_val = __shfl(s_ps, bl, SNF_WAVE); g.ps_support = maxc;
-        g.ps_other = wave_sum64((st && s_ps != g.ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
-        __syncthreads();
-      }
-      if (want_nm) {
-        // np.nanmean(nm of the leads, list order) with numpy's pairwise summation for n <= 128 (snf_exact.h::np_pairwise_sum):
-        // fewer than 8 values: left to right; otherwise eight accumulators r[q] over the positions q, q + 8, ... below
-        // n - n % 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right.  NaN counts as 0 in the sum.
-        const int cnt = __builtin_popcountll(__ballot(lane < n && nm == nm));
-        lds.nm[lane] = (lane < n && nm == nm) ? nm : 0.0;
-        __syncthreads();
-        double res = 0.0;
-        if (n < 8) { for (int q = 0; q < n; q++) res += lds.nm[q]; }
-        else {
-          const int n8 = n - n % 8;
-          double r = 0.0;
-          if (lane < 8) { r = lds.nm[lane]; for (int q = 8 + lane; q < n8; q += 8) r += lds.nm[q]; }
-          double rq[8];
-          for (int q = 0; q < 8; q++) rq[q] = __shfl(r, q, SNF_WAVE);
-          res = ((rq[0] + rq[1]) + (rq[2] + rq[3])) + ((rq[4] + rq[5]) + (rq[6] + rq[7]));
-          for (int q = n8; q < n; q++) res += lds.nm[q];
-        }
-        g.nm_mean = res / (double)cnt; g.has_nm_mean = 1;
-        __syncthreads();
-      }
-      if (lane == 0) { s_agg[j] = g; s_ok[j] = 1; }
-    }
-    __syncthreads();
-    // ---- phase B: the scalar tail, one call per lane
-    if (lane < E1B && s_ok[lane]) {
-      const int64_t i = base + lane;
-      snf_call_t c = v.calls[i];
-      const CallX x = v.callx[i];
-      const LeadAgg g = s_agg[lane];
-      finalize_call<1>(v, c, x, g, c.task_index);   // x.fn <= 64 leads
-      store_final_fields(v.calls[i], c);
-    }
-    __syncthreads();
+    const int64_t i = base + lane;
+    if (lane >= E1B || i >= n_calls) continue;
+    snf_call_t c = v.calls[i];
+    if (v.t_status[c.task_index] != SNF_TASK_OK) continue;
+    const CallX x = v.callx[i];
+    if (x.fn > SNF_WAVE || !x.ag_valid) { big_push(v, 2, (int32_t)i); continue; }  // x_big<2>
+    LeadAgg g;
+    g.nstrands = x.ag_nstrands; g.close_edge = x.ag_close_edge;
+    g.hp_val = x.ag_hp_val; g.hp_support = x.ag_hp_support; g.hp_other = x.ag_hp_other;
+    g.ps_val = x.ag_ps_val; g.ps_support = x.ag_ps_support; g.ps_other = x.ag_ps_other;
+    g.nm_row = nullptr; g.has_nm_mean = x.ag_has_nm; g.nm_mean = x.ag_nm_mean;
+    finalize_call<1>(v, c, x, g, c.task_index);   // x.fn <= 64 leads
+    store_final_fields(v.calls[i], c);
   }
 }
 
