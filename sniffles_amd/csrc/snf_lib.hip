@@ -2007,6 +2007,10 @@ static StreamPool g_streams;
 // (device, instance choice) - hipGetDeviceProperties and the occupancy queries are milliseconds, a task-sized batch is not.
 struct DevInfo { int cus, nb_d1w, nb_d2w, nb_e1w; };
 typedef void (*WaveKernel)(const View, int64_t);
+static WaveKernel pick_d2w(int o2, bool phase) {   // waves per SIMD the instance is compiled for x config.phase
+  if (phase) return o2 >= 8 ? d2w_call<8, true> : o2 == 6 ? d2w_call<6, true> : o2 == 5 ? d2w_call<5, true> : d2w_call<4, true>;
+  return o2 >= 8 ? d2w_call<8, false> : o2 == 6 ? d2w_call<6, false> : o2 == 5 ? d2w_call<5, false> : d2w_call<4, false>;
+}
 static DevInfo device_info(int device, int o2, int o1, WaveKernel k_d2w, WaveKernel k_e1w) {
   typedef std::tuple<int, int, int> Key;
   static std::mutex mu;
@@ -2060,7 +2064,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       const int mult = getenv("SNF_GRID_MULT") ? atoi(getenv("SNF_GRID_MULT")) : 1;
       const int o2 = getenv("SNF_OCC_D2") ? atoi(getenv("SNF_OCC_D2")) : 5;   // <6> and <8> spill (36 / 100 B of scratch); <5> does not and is as fast
       const int o1 = getenv("SNF_OCC_E1") ? atoi(getenv("SNF_OCC_E1")) : 5;
-      b->k_d2w = o2 >= 8 ? d2w_call<8> : o2 == 6 ? d2w_call<6> : o2 == 5 ? d2w_call<5> : d2w_call<4>;
+      b->k_d2w = pick_d2w(o2, b->cfg.phase != 0);
       b->k_e1w = o1 == 6 ? e1w_finalize<6> : o1 == 5 ? e1w_finalize<5> : e1w_finalize<4>;  // <8> trips a register-allocation bug of this hipcc
       const DevInfo di = device_info(b->device, o2, o1, b->k_d2w, b->k_e1w);
       const int cus = di.cus;

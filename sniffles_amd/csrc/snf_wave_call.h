@@ -69,13 +69,14 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
 // len(set(strands)), leads close to a read edge (postprocessing.py:574-577), the HP / PS majorities of phase_sv over distinct
 // reads (the last lead of a read wins, postprocessing.py:626-654), np.nanmean of the NM ratios (rescue_phasing) - over the
 // SELECTED leads of a cluster of n <= 64 leads, one lead per lane.  All lanes must call it.
+template <bool PHASE>
 SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n, bool sel, int strand, int hap, uint32_t rid, int32_t ps,
                          bool close, bool want_nm, double nm, CallX& x) {
   x.ag_valid = 1;
   x.ag_nstrands = (__ballot(sel && strand == 0) ? 1 : 0) + (__ballot(sel && strand != 0) ? 1 : 0);
   x.ag_close_edge = __builtin_popcountll(__ballot(sel && close));
   int hp_val = 0, hp_support = -1, hp_other = 0; int32_t ps_val = 0; int ps_support = -1, ps_other = 0;
-  if (cfg.phase) {
+  if (PHASE) {
     // reads_phases = {read_id: (hap, ps)}: the last lead of a read wins
     bool later = false;
     for (int k = 0; k < n; k++) {
@@ -111,7 +112,7 @@ SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n,
   x.ag_hp_val = hp_val; x.ag_hp_support = hp_support; x.ag_hp_other = hp_other;
   x.ag_ps_val = ps_val; x.ag_ps_support = ps_support; x.ag_ps_other = ps_other;
   x.ag_has_nm = 0; x.ag_nm_mean = 0.0;
-  if (want_nm) {
+  if (PHASE && want_nm) {
     // np.nanmean(nm of the leads, list order) with numpy's pairwise summation for n <= 128 (snf_exact.h::np_pairwise_sum):
     // fewer than 8 values: left to right; otherwise eight accumulators r[q] over the positions q, q + 8, ... below
     // n - n % 8, combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail left to right.  NaN counts as 0 in the sum.
@@ -135,7 +136,9 @@ SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n,
 }
 
 // ------------------------------------------------------------------------------------------ d2w: call_from
-template <int MINW>
+// PHASE: config.phase (a launch-time constant: the phase majorities and the NM mean are only formed, and their inputs only
+// loaded, by the instance that needs them - the other one must not pay registers for them)
+template <int MINW, bool PHASE>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t n_unused) {
   __shared__ CallLds lds;
   const int lane = threadIdx.x;
@@ -161,14 +164,16 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     int mapq = 0, strand = 0, is_sa = 0, noninline = 0; double nm = 0;
     int32_t mctg = 0, mpos = 0; int bfirst = 0, brev = 0;
     int hap = 0; uint32_t rid = 0; int32_t ps = SNF_PS_NULL_CODE; bool close = false;    // for the lead aggregates (wave_lead_agg)
-    const bool want_nm = cfg.phase && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
+    const bool want_nm = PHASE && cfg.mode_call_sample;     // rescue_phasing may ask for the mean NM ratio of the leads
     if (act) {
       slot = slot_pre; svl = v.F_svlen[slot];
       const LeadRec r = v.Lrec[v.F_lpos[slot]];
       o = r.orig; rs = r.ref_start; qn = r.qname; mapq = r.mapq; strand = r.strand; is_sa = r.is_sa;
       noninline = r.source != SNF_SRC_INLINE;
-      hap = r.hap; rid = r.read_id;
-      ps = (r.ps == SNF_PS_NONE || r.ps == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : r.ps;
+      if (PHASE) {
+        hap = r.hap; rid = r.read_id;
+        ps = (r.ps == SNF_PS_NONE || r.ps == v.t_ps_null[task]) ? SNF_PS_NULL_CODE : r.ps;
+      }
       close = (int64_t)r.qry_start <= cfg.dev_min_close_edge_dist || iabs64((int64_t)r.read_len - (int64_t)r.qry_start) <= cfg.dev_min_close_edge_dist;
       if (cfg.qc_nm_measure || want_nm) nm = v.in_nm[o];
       mctg = r.mate_contig; mpos = r.mate_pos; bfirst = r.first; brev = r.rev;
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     CallX x; x.rc = (int32_t)r; x.cluster = c; x.flo = flo; x.fn = n; x.best = best_slot; x.n_others = n_others;
     x.do_cons = (best_slot >= 0 && n_others >= cfg.consensus_min_reads && !cfg.no_consensus) ? 1 : 0; x.cons_id = -1; x.alt_off = 0;
     x.rn_nq = (int32_t)nq; x._pad = 0;
-    wave_lead_agg(cfg, lds, lane, n, sel_final, strand, hap, rid, ps, close, want_nm, nm, x);
+    wave_lead_agg<PHASE>(cfg, lds, lane, n, sel_final, strand, hap, rid, ps, close, want_nm, nm, x);
     if (lane == 0) {
       v.cand[r] = cc;
       v.candx[r] = x;
