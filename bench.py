@@ -296,16 +296,44 @@ def run_calling(ctx):
         res0 = probe.fetch(1)
         need = torch.tensor([256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames), len(res0.alt_pool)], dtype=torch.int64, device=DEV)
         dist.all_reduce(need, op=dist.ReduceOp.MAX)
+        # /dev/shm must hold every rank's segments (containers often cap it): otherwise the block gather over RCCL is taken
+        seg_bytes = 2 * W * (int(need[0]) * 3 // 2 + int(need[1]) * 3 // 2 + (2 << 20) + 8192)
+        try:
+            st = os.statvfs("/dev/shm")
+            room = st.f_bavail * st.f_frsize >= int(world * seg_bytes * 1.25) and os.environ.get("SNF_BENCH_SHM_FULL") != "1"   # (SNF_BENCH_SHM_FULL=1: the test of this fallback)
+        except OSError:
+            room = False
+        ok_t = torch.tensor([1 if room else 0], dtype=torch.int64, device=DEV)
+        dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
+        if not int(ok_t.item()):
+            if rank == 0:
+                print(f"[bench] /dev/shm cannot hold {world} x {seg_bytes >> 20} MiB of result segments: gathering the blocks over RCCL instead", file=sys.stderr)
+            shared = False
+            out_mode |= abi.OUT_DEVICE
+            for hs in handles:
+                for bb in hs:
+                    bb.set_output(out_mode)
+    if shared:
         # two segments per handle, used in turn: pass k + 1 of a handle writes one while the parent still indexes the other
         # the layouts travel over a host-side (gloo) group: a 72-byte collective must not queue behind the passes' kernels
-        meta_group = dist.new_group(backend="gloo")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the box's hostname need not resolve)
+        meta_group, meta_dev = None, DEV
+        try:
+            import datetime
+            meta_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=60))
+            probe_t = torch.zeros(1, dtype=torch.int64)
+            dist.all_reduce(probe_t, group=meta_group)
+            meta_dev = None
+        except Exception as e:                               # no host-side group here: the layouts go over the default group
+            print(f"[bench] gloo group for the layouts unavailable ({type(e).__name__}: {e}); using the default group", file=sys.stderr)
+            meta_group, meta_dev = None, DEV
         landing = sdist.SharedLanding(slots=2 * W, block_bytes=int(need[0]) * 3 // 2 + (1 << 20), alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
         for w in range(W):
             for k in (1, 0):
                 handles[w][0].set_result_memory(*landing.memory(2 * w + k))     # (page-locked here, once)
         ids_all = [None] * world
         dist.all_gather_object(ids_all, task_ids_local)
-    elif use_dist:
+    if use_dist and not shared:
         probe = handles[0][0]
         probe.call_candidates(); probe.finalize()
         res0 = probe.fetch(1)
@@ -339,7 +367,7 @@ def run_calling(ctx):
                     return
                 s, lay, ids = item
                 if shared:
-                    g = sdist.gather_results_shared(landing, s, lay, ids, group=meta_group, task_ids_per_rank=ids_all)
+                    g = sdist.gather_results_shared(landing, s, lay, ids, group=meta_group, task_ids_per_rank=ids_all, device=meta_dev)
                 else:
                     g = sdist.gather_results(sends[s], lay, ids, dst=0, recv_buffer=recv,
                                              task_ids_per_rank=None if strong else ids_all)

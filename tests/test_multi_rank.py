@@ -355,6 +355,13 @@ def test_bench_two_ranks_weak_scaling_block_gather_emu():
     assert "RCCL gather" in d["config"]["parallelism"]
 
 
+def test_bench_two_ranks_falls_back_when_shm_is_full_emu():
+    """/dev/shm too small for the result segments (a container's 64 MB default): the line is produced over the block gather."""
+    d = _bench_two_ranks([], 35500 + (os.getpid() % 500), SNF_BENCH_SHM_FULL="1")
+    assert d["n_gpus"] == 2 and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+    assert "RCCL gather" in d["config"]["parallelism"]
+
+
 def test_bench_two_ranks_strong_scaling_emu():
     d = _bench_two_ranks(["--scaling", "strong"], 33500 + (os.getpid() % 500))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["tasks"] == 24 and d["value"] > 0
