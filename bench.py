@@ -636,7 +636,7 @@ def run_calling(ctx):
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls,
                                parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
-                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if shared else ", RCCL gather of the result blocks on rank 0"),
+                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if shared else ", RCCL gather of the result blocks on rank 0" if use_dist else ", one process: no gather"),
                                batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
                                gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)), alt_bytes=int(len(gathered_box[0].alt_pool)),
                                                        read_names=int(len(gathered_box[0].rnames)), tasks=int(len(gathered_box[0].task_ids)),
