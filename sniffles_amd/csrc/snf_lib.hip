@@ -8,6 +8,7 @@
 #include "snf_fused.h"
 #include "snf_stage_out.h"
 #include "snf_wave_call.h"
+#include "snf_wave_call_g.h"
 #include "snf_ctx.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -261,6 +262,7 @@ struct snf_batch_impl {
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
   int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22;   // grid caps of the SMALL / LARGE consensus kernels
+  bool d2_groups = true;          // call_from: small refined clusters several per wave (snf_wave_call_g.h); SNF_NO_D2_GROUPS=1: a wave per cluster
   int cons_nw = 1;                // waves per SMALL consensus call: 1 = one wave per call (default: single-wave workgroups leave room for the
                                   // LARGE class next to them - LARGE in place 0.75 -> 0.5 ms, the pass 2.5 % shorter), SNF_CONS_NW=4: four
   int cons_large_nw = 4;          // SNF_CONS_LARGE_NW: waves per LARGE consensus call (4, 8, 16)
@@ -701,7 +703,7 @@ void do_upload(snf_batch_impl* b) {
     size_t cells = 0;
     const int bs0 = b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1;
     for (auto& t : b->tasks) cells += (size_t)SNF_NTYPES * ((size_t)t.contig_len / bs0 + 1);
-    b->slab_next = (size_t)N * (1408 + 16 + 8) + 2 * (size_t)v.pool_cap + (size_t)R * 96 + cells / 4 + ((size_t)N / 2) * (sizeof(snf_call_t) + 32) + ((size_t)8 << 20);
+    b->slab_next = (size_t)N * (1408 + 104 + 16 + 8) + 2 * (size_t)v.pool_cap + (size_t)R * 96 + cells / 4 + ((size_t)N / 2) * (sizeof(snf_call_t) + 32) + ((size_t)8 << 20);
   }
   v.cnt = dalloc<Counts>(b, 1);
   {  // pinned result block: Counts | call offsets [T+1] | coverage averages [T] | status [T]
@@ -928,6 +930,10 @@ void do_upload(snf_batch_impl* b) {
   v.stage_cap = getenv("SNF_NO_BIG_STAGE") ? 0 : 1;   // x_big<0>: clusters up to SNF_BIG_STAGE_CAP leads are kept in LDS
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);
+  v.d2cap = (int64_t)(N1 / 64 + 64);
+  for (int k = 0; k < 2; k++) v.d2_list[k] = dalloc<int32_t>(b, (size_t)(64 * v.d2cap));
+  v.d2cnt = dalloc<uint32_t>(b, 2 * 64 * 16);
+  v.d2_from_list = 0;
 #ifdef SNF_WG_TRACE
   if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 16)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 16)); }
 #endif
@@ -1100,6 +1106,7 @@ void run_call_candidates(snf_batch_impl* b) {
   // (and in the emulation build) the plain device-wide scans are used
   enqueue_pass_init(b);
   if (v.wave_path && !b->fused) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);   // (fused: z0_init)
+  if (v.wave_path && !b->fused) dzero(b, v.d2cnt, sizeof(uint32_t) * 2 * 64 * 16);
   b->finalize_runs = 0;
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
@@ -1170,7 +1177,25 @@ void run_call_candidates(snf_batch_impl* b) {
       prim_exscan<uint32_t>(b, v.rcflag, v.rcscan, N + 1, "scan_refined");
       LAUNCH_Q(d1b_rctable, v, N, N * 4);
     }
-    if (v.wave_path) {
+    if (v.wave_path && b->d2_groups) {
+      // call_from by cluster size (snf_wave_call_g.h): eight clusters of <= 8 leads per wave, then two of <= 32 from the list
+      // the first kernel left, then d2w_call - a wave per cluster - for what the second handed on
+      const bool ph = b->cfg.phase != 0;
+      { Scope _s(b, "d2g_call8", N * 32);
+        if (ph) hipLaunchKernelGGL((d2g_call<8, 4, true>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((d2g_call<8, 4, false>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
+      static const bool mid = getenv("SNF_D2_MID") != nullptr;   // A/B: clusters of 9..32 leads two per wave (measured slower than a wave each)
+      if (mid) { Scope _s(b, "d2g_call32", 0);
+        if (ph) hipLaunchKernelGGL((d2g_call<32, 4, true>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+        else hipLaunchKernelGGL((d2g_call<32, 4, false>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
+      { Scope _s(b, "d2w_call", 0);
+        v.d2_from_list = mid ? 2 : 1;
+        hipLaunchKernelGGL(b->k_d2w, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
+        v.d2_from_list = 0;
+        SNF_HIP(hipGetLastError()); }
+    } else if (v.wave_path) {
       Scope _s(b, "d2w_call", N * 32);
       hipLaunchKernelGGL(b->k_d2w, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -1522,6 +1547,8 @@ void collect_timings(snf_batch_impl* b) {
     static const char* nm[9] = {"setup+table", "kmers+probes", "chain", "segments", "run filter", "votes", "barrier+vote+store", "longest workgroup", "workgroups"};
     for (int c = 0; c < 2; c++)
       for (int k = 0; k < 9; k++) if (c * 16 + k < 24) fprintf(stderr, "[SNF_CONS_PROFILE] %s %-20s %llu\n", c ? "LARGE" : "SMALL", nm[k], b->h_cnt->dbg[c * 16 + k]);
+    static const char* dn[7] = {"loads + svlen sort", "names sort + a1", "ref_start sort + stdevs", "sums + record", "BND block", "INS best lead", "aggregates"};
+    for (int k = 0; k < 7; k++) fprintf(stderr, "[SNF_CONS_PROFILE] d2g8 %-26s %llu\n", dn[k], b->h_cnt->dbg[9 + k]);
     static const char* rn[6] = {"load + first appearance", "rank + permute", "gathers + fuse scans", "reserve + copy + compact", "F stores", "resplit + next"};
     for (int k = 0; k < 6; k++) fprintf(stderr, "[SNF_CONS_PROFILE] d1w %-26s %llu\n", rn[k], b->h_cnt->dbg[24 + k]);
   }
@@ -2089,6 +2116,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
+    b->d2_groups = getenv("SNF_NO_D2_GROUPS") == nullptr;
     if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
     *out = reinterpret_cast<snf_batch_t*>(b.release());

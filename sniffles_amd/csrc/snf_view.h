@@ -240,6 +240,11 @@ struct View {
 #ifdef SNF_WG_TRACE
   unsigned long long* wgtrace;   // measurement build only (-DSNF_WG_TRACE): per consensus call {start, duration | shape} in 100 MHz ticks
 #endif
+  // refined clusters handed on by the grouped call kernels (snf_wave_call_g.h): list 0 more than 8 leads (d2g_call<8> -> <32>),
+  // list 1 more than 32 (-> d2w_call).  64 stripes per list (stripe = workgroup & 63) with a counter each, d2cnt[(list * 64 +
+  // stripe) * 16]: ten thousand returning atomics on ONE counter took 0.1 ms by themselves.  Stripe s owns d2_list[k][s * d2cap ...)
+  int32_t* d2_list[2]; uint32_t* d2cnt; int64_t d2cap;
+  int32_t d2_from_list, _pad_d2;   // != 0: this launch of d2w_call takes its refined clusters from d2_list[d2_from_list - 1]
   int32_t* cls_list[8];      // cons ids per work list (see Counts::n_cls; 6 unused), appended with wave-aggregated atomics
   // clusters / refined clusters / calls with more than 64 leads, collected by the wave kernels (kind 0 d1w_refine, 1 d2w_call,
   // 2 e1w_finalize) in 64 stripes (item & 63) and served one wave each by x_big<kind> (snf_wave_call.h)

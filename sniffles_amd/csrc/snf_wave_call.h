@@ -65,6 +65,33 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
   return stdev_from_sums(cnt, (i128)S1, S2);
 }
 
+// ------------------------------------------------------------------------------------------ striped hand-over lists (View::d2_list)
+// consumer side: prefix of the 64 stripes' counts in LDS (pre[0..64]); item i of the flat index space is entry i - pre[s] of stripe s
+SNF_D int64_t d2list_prefix(const View& v, int k, int lane, int32_t* pre) {
+  const int32_t cnt = (int32_t)v.d2cnt[(k * 64 + lane) * 16];
+  const int32_t inc = wave_incl_scan(cnt, lane);
+  if (lane == 0) pre[0] = 0;
+  pre[lane + 1] = inc;
+  __syncthreads();
+  return pre[64];
+}
+SNF_D int32_t d2list_at(const View& v, int k, int64_t i, const int32_t* pre) {
+  int lo = 0, hi = 63;   // last stripe s with pre[s] <= i
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= (int32_t)i) lo = mid; else hi = mid - 1; }
+  return v.d2_list[k][(int64_t)lo * v.d2cap + (i - pre[lo])];
+}
+// producer side: the lanes with `hand` append their cluster to list k, one atomic per wave on the workgroup's stripe
+SNF_D void d2list_push(const View& v, int k, bool hand, int32_t r, int lane) {
+  const unsigned long long hm = __ballot(hand);
+  if (!hm) return;
+  const int stripe = (int)(blockIdx.x & 63);
+  const int leader = __builtin_ctzll(hm);
+  uint32_t at = 0;
+  if (lane == leader) at = atomicAdd(&v.d2cnt[(k * 64 + stripe) * 16], (uint32_t)__builtin_popcountll(hm));
+  at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+  if (hand) v.d2_list[k][(int64_t)stripe * v.d2cap + at + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = r;
+}
+
 // ------------------------------------------------------------------------------------------ lead aggregates of a call
 // len(set(strands)), leads close to a read edge (postprocessing.py:574-577), the HP / PS majorities of phase_sv over distinct
 // reads (the last lead of a read wins, postprocessing.py:626-654), np.nanmean of the NM ratios (rescue_phasing) - over the
@@ -143,20 +170,26 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
   __shared__ CallLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
-  const int64_t n_rc = v.cnt->n_rc;
+  // the refined clusters of this launch: all of them, or (View::d2_from_list) the ones the grouped kernels handed on
+  // (more than 32 leads, snf_wave_call_g.h)
+  __shared__ int32_t d2pre[65];
+  const bool from_list = v.d2_from_list != 0;      // 1 + the list's number
+  const int64_t n_rc = from_list ? d2list_prefix(v, v.d2_from_list - 1, lane, d2pre) : v.cnt->n_rc;
+  auto RC = [&](int64_t it) -> int32_t { return from_list ? d2list_at(v, v.d2_from_list - 1, it, d2pre) : (int32_t)it; };
   // software pipeline over this wave's refined clusters (the kernel is a chain of dependent loads: table entry -> cluster head
   // -> group, lead order -> fused lead -> record): the table entry of item k+2, the cluster head and the lead order of item
   // k+1 are requested while item k is worked on, so an item starts two round trips deep instead of six
   const int64_t stride = gridDim.x;
-  int32_t flo1 = 0, n1 = 0, c1 = 0, flo2 = 0, n2 = 0, c2 = 0, h1 = 0, slot1 = 0;
-  if ((int64_t)blockIdx.x < n_rc) { flo1 = v.rc_lo[blockIdx.x]; n1 = v.rc_n[blockIdx.x]; c1 = v.rc_cluster[blockIdx.x]; }
-  if ((int64_t)blockIdx.x + stride < n_rc) { flo2 = v.rc_lo[blockIdx.x + stride]; n2 = v.rc_n[blockIdx.x + stride]; c2 = v.rc_cluster[blockIdx.x + stride]; }
+  int32_t flo1 = 0, n1 = 0, c1 = 0, flo2 = 0, n2 = 0, c2 = 0, h1 = 0, slot1 = 0, r1 = 0, r2 = 0;
+  if ((int64_t)blockIdx.x < n_rc) { r1 = RC(blockIdx.x); flo1 = v.rc_lo[r1]; n1 = v.rc_n[r1]; c1 = v.rc_cluster[r1]; }
+  if ((int64_t)blockIdx.x + stride < n_rc) { r2 = RC(blockIdx.x + stride); flo2 = v.rc_lo[r2]; n2 = v.rc_n[r2]; c2 = v.rc_cluster[r2]; }
   if ((int64_t)blockIdx.x < n_rc) { h1 = v.cl_head[c1]; if (lane < n1 && n1 <= SNF_WAVE) slot1 = v.FI[flo1 + lane]; }
-  for (int64_t r = blockIdx.x; r < n_rc; r += stride) {
+  for (int64_t it = blockIdx.x; it < n_rc; it += stride) {
+    const int32_t r = r1;
     const int32_t flo = flo1, n = n1, c = c1, h = h1; const int32_t slot_pre = slot1;
-    flo1 = flo2; n1 = n2; c1 = c2;
-    if (r + stride < n_rc) { h1 = v.cl_head[c1]; if (lane < n1 && n1 <= SNF_WAVE) slot1 = v.FI[flo1 + lane]; }
-    if (r + 2 * stride < n_rc) { flo2 = v.rc_lo[r + 2 * stride]; n2 = v.rc_n[r + 2 * stride]; c2 = v.rc_cluster[r + 2 * stride]; }
+    flo1 = flo2; n1 = n2; c1 = c2; r1 = r2;
+    if (it + stride < n_rc) { h1 = v.cl_head[c1]; if (lane < n1 && n1 <= SNF_WAVE) slot1 = v.FI[flo1 + lane]; }
+    if (it + 2 * stride < n_rc) { r2 = RC(it + 2 * stride); flo2 = v.rc_lo[r2]; n2 = v.rc_n[r2]; c2 = v.rc_cluster[r2]; }
     if (n > SNF_WAVE) { if (lane == 0) big_push(v, 1, (int32_t)r); continue; }  // x_big<1>
     const int g = v.seed_grp[h], svtype = grp_svtype(g), task = grp_task(g);
     const bool act = lane < n;
