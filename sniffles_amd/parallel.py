@@ -103,6 +103,12 @@ class Task:
         res = self._batch.fetch(1, copy=False)
         if len(res.calls) != len(candidates):
             raise RuntimeError("candidate list does not match the batch (pass the list call_candidates returned)")
+        n = len(candidates)
+        for i in sorted(set([0, n - 1] + [k * n // 61 for k in range(61)])) if n else ():     # identity, by sample: same calls, same order
+            c = candidates[i]
+            if int(c.pos) != int(res.calls["pos"][i]) or int(c.svlen) != int(res.calls["svlen"][i]):
+                raise RuntimeError(f"candidate {i} is not the call the batch holds at that place (pass the list call_candidates "
+                                   "returned, unchanged and in its order)")
         sv.apply_final(candidates, res, self._ti)
         passed = []
         for c in candidates:

@@ -80,6 +80,11 @@ def run_case(name, _lib):
     assert [as_record(c, "cand") for c in cands] == exp["candidates"]
     assert task.coverage_average_total == exp["coverage_average_total"]
     assert task.sv_id == ti.sv_id_start + len(cands)
+    if len(cands) >= 2 and (cands[0].pos, cands[0].svlen) != (cands[-1].pos, cands[-1].svlen):
+        with pytest.raises(RuntimeError):          # the list call_candidates returned, in its order - anything else is refused
+            task.finalize_candidates(cands[::-1], False, cfg)
+        with pytest.raises(RuntimeError):
+            task.finalize_candidates(cands[:-1], False, cfg)
     final = task.finalize_candidates(cands, False, cfg)
     assert [as_record(c, "final") for c in final] == exp["final"]
     assert all(c.postprocess is None for c in final)
