@@ -1602,7 +1602,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
   full_sync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
-  if (b->h_cnt->overflow) fail("internal: fused-sequence pool overflow");
+  if (b->h_cnt->overflow) fail(b->h_cnt->overflow & 2 ? "internal: hand-over list of the call kernels overflowed" : "internal: fused-sequence pool overflow");
   if (v.prof) {
     const Counts& c = *b->h_cnt;
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "

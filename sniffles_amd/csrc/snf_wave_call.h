@@ -68,7 +68,8 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
 // ------------------------------------------------------------------------------------------ striped hand-over lists (View::d2_list)
 // consumer side: prefix of the 64 stripes' counts in LDS (pre[0..64]); item i of the flat index space is entry i - pre[s] of stripe s
 SNF_D int64_t d2list_prefix(const View& v, int k, int lane, int32_t* pre) {
-  const int32_t cnt = (int32_t)v.d2cnt[(k * 64 + lane) * 16];
+  int32_t cnt = (int32_t)v.d2cnt[(k * 64 + lane) * 16];
+  if (cnt > (int32_t)v.d2cap) cnt = (int32_t)v.d2cap;       // (overflowed stripe: flagged by the producer, the fetch fails)
   const int32_t inc = wave_incl_scan(cnt, lane);
   if (lane == 0) pre[0] = 0;
   pre[lane + 1] = inc;
@@ -89,7 +90,11 @@ SNF_D void d2list_push(const View& v, int k, bool hand, int32_t r, int lane) {
   uint32_t at = 0;
   if (lane == leader) at = atomicAdd(&v.d2cnt[(k * 64 + stripe) * 16], (uint32_t)__builtin_popcountll(hm));
   at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
-  if (hand) v.d2_list[k][(int64_t)stripe * v.d2cap + at + __builtin_popcountll(hm & ((1ull << lane) - 1ull))] = r;
+  if (hand) {
+    const int64_t slot = (int64_t)at + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
+    if (slot < v.d2cap) v.d2_list[k][(int64_t)stripe * v.d2cap + slot] = r;
+    else atomicOr(&v.cnt->overflow, 2);      // (a stripe holds a 64th of all clusters + 64: cannot happen with a grid that is a multiple of 64)
+  }
 }
 
 // ------------------------------------------------------------------------------------------ lead aggregates of a call
