@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the compact block of the other BASELINE configs (default run only)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the all-cores oracle run (and with it --verify)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-reference-baseline", action="store_true",
+                    help="skip timing the unmodified reference (oracle/_ref) on the host cores; cpu_baseline.kind is then \"port\"")
     ap.add_argument("--no-wall-clock", action="store_true")
     ap.add_argument("--samples", type=int, default=10, help="config 4: samples of the population")
     ap.add_argument("--inflight", type=int, default=2,
@@ -668,6 +670,19 @@ def run_calling(ctx):
                     bb.set_output(abi.OUT_EXECUTE); bb.call_candidates(); bb.finalize(); exe = bb.fetch(1)
                 base, ver = cpu_baseline_and_verify(args, wl, got, task_keys, exe, cfg)
                 out["cpu_baseline"] = base
+                if not args.no_reference_baseline:
+                    # the UNMODIFIED reference on this box's host cores (oracle/_ref, staged by oracle/make_ref.py), same tables
+                    try:
+                        ref_base = reference_baseline(args, wl, exe, tasks, task_keys, out)
+                    except Exception as e:  # noqa: BLE001 - a baseline that cannot run must not take the line down; it says why
+                        ref_base = None
+                        base["reference_error"] = f"{type(e).__name__}: {str(e)[:600]}"
+                    if ref_base is not None:
+                        ref_base["port"] = base          # the C restatement stays beside it
+                        out["cpu_baseline"] = ref_base
+                    else:
+                        base["reference_note"] = ("the staged reference build (oracle/_ref, made by oracle/make_ref.py during build() where "
+                                                  "/root/reference exists) is not on this box: kind stays \"port\"")
                 if ver is not None:
                     out["verified"] = ver["ok"]
                     out["verify"] = ver
@@ -917,6 +932,65 @@ def cpu_baseline_and_verify(args, wl, got, task_keys, exe=None, cfg=None):
                         "bench batch vs the C oracle on the same inputs; the block the timed passes return (--output execute) vs "
                         "CallTask.execute's filter + sort applied to those candidates", differences=diffs[:5])
     return base, ver
+
+
+def reference_baseline(args, wl, exe, tasks, task_keys, out):
+    """`cpu_baseline` with kind = "reference" (SURVEY.md 8d): the UNMODIFIED reference's `Task.call_candidates` +
+    `finalize_candidates` (`parallel.py:104-201`) on the same 24 signature tables, one OS process per contig task, pool =
+    min(tasks, host cores) - its own schedule (`sniffles:495-530`).  The reference is the byte-compiled staged build `oracle/_ref`
+    (or the checkout in the build container).  With `exe` (the execute-mode block of the timed passes) the same run checks
+    the GPU's records against the reference ITSELF: what `CallTask.execute` sends to the parent, record by record."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_pool
+    if not ref_pool.available():
+        return None
+    from sniffles_amd import records
+    specs = task_specs(args, wl, 0, 0, 1)
+    extra = ["--mosaic"] if wl["cfg"].get("mosaic") else []
+    r = ref_pool.run_tasks(specs, extra, weights=[kw["contig_len"] for _, kw in specs], want_results=exe is not None,
+                           max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
+    n = sum(m["n_leads"] for m in r["items"].values())
+    ref_sig_s = n / r["hot_all_core_s"]
+    base = dict(value=ref_sig_s, unit="signatures/s", cores=r["procs"], kind="reference", host_cores=r["cores"],
+                all_core_sig_s=ref_sig_s, single_core_sig_s=n / r["hot_single_core_s"],
+                hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
+                reference=ref_pool.kind(),
+                sample=f"the whole workload ({len(specs)} contig tasks, {n} signatures): the unmodified reference's Task.call_candidates + "
+                       f"finalize_candidates, one process per contig ({r['procs']} processes on {r['cores']} usable cores, longest contig first; "
+                       f"the reference cannot use more processes than contigs), every process starts at a barrier once its Lead tables / "
+                       f"coverage vector are built (untimed: {r['build_single_core_s']:.0f} core-seconds of record_lead / record_hap_ref): "
+                       f"slowest process {r['hot_all_core_s']:.2f} s, sum over tasks {r['hot_single_core_s']:.1f} s; whole leg {r['total_wall_s']:.0f} s")
+    # speed-ups against the reference on THIS box (north_star: >= 20x wall clock at 1 MI355X vs all host cores)
+    vs = dict(gpu_pass=round(out["value"] / ref_sig_s, 1))
+    wc = out.get("wall_clock") or {}
+    if wc.get("batched"):
+        vs["wall_clock_batched"] = round(r["hot_all_core_s"] * 1e3 / wc["batched"]["end_to_end_ms"], 1)
+        vs["wall_clock_per_task_api"] = round(r["hot_all_core_s"] * 1e3 / wc["per_task_api"]["end_to_end_ms"], 1)
+    vs["note"] = ("reference all-core seconds for one genome / this package's seconds for one genome: gpu_pass = the timed step (inputs in HBM, "
+                  "result block on the host); wall_clock_batched = numpy columns -> upload -> pass -> SVCall objects; per_task_api = 24 x "
+                  "Task.call_candidates / finalize_candidates")
+    base["vs_baseline"] = vs
+    if exe is not None:
+        got = records.records(exe, tasks, "final")
+        diffs, n_cmp = [], 0
+        for t, key in enumerate(task_keys):
+            exp = r["items"][key]["records"]
+            g = got[t]
+            n_cmp += len(exp)
+            if isinstance(g, dict) or len(g) != len(exp):
+                diffs.append(f"task {t}: {len(exp)} reference records, got {g if isinstance(g, dict) else len(g)}")
+                continue
+            for a, b in zip(g, exp):
+                if a != b:
+                    diffs.append(f"task {t} {b['id']}: " + ", ".join(k for k in b if a.get(k) != b.get(k)))
+                    if len(diffs) > 5:
+                        break
+        base["verified_vs_reference"] = dict(ok=not diffs, records_compared=n_cmp, differences=diffs[:5],
+                                             what="the execute-mode block of the timed passes (every field: POS, END, SVLEN, SVTYPE, support, GT/GQ/DR/DV, "
+                                                  "filters, fp64 statistics, INS consensus ALT, supporting read names) vs what the unmodified reference's "
+                                                  "CallTask.execute keeps (parallel.py:265-271) on the same signature tables, on this box")
+        out["verified_vs_reference"] = not diffs
+    return base
 
 
 if __name__ == "__main__":

@@ -1,8 +1,8 @@
 """TEST INFRASTRUCTURE ONLY - never imported by the product path.
 
 Runs the UNMODIFIED reference implementation (`/root/reference/src/sniffles`)
-on a `sniffles_amd.soa.TaskInput` and returns canonical result records.  Only
-usable in the build container (the GPU box has no /root/reference); it is how
+on a `sniffles_amd.soa.TaskInput` and returns canonical result records.  Usable
+where the reference checkout or its staged build (oracle/_ref, see make_ref.py) is present; it is how
 `oracle/make_golden.py` produces the committed fixtures under `tests/golden/`
 that pin the C restatement (`oracle/snf_oracle.c`) and, through it, the HIP
 path.
@@ -20,11 +20,24 @@ import types
 
 import numpy as np
 
-REF_SRC = "/root/reference/src"
+_HERE = os.path.dirname(os.path.abspath(__file__))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+import make_ref  # noqa: E402
+
+# the reference checkout in the build container; elsewhere the byte-compiled, unmodified copy `oracle/make_ref.py` staged
+# under the git-ignored oracle/_ref/ (it travels to the GPU box like a built .so)
+REF_SRC = make_ref.ref_root() or make_ref.SRC_ROOT
 
 
 def reference_available() -> bool:
-    return os.path.isdir(os.path.join(REF_SRC, "sniffles"))
+    return make_ref.ref_root() is not None
+
+
+def reference_kind() -> str:
+    """"checkout" (build container), "staged" (oracle/_ref, compiled by make_ref.py) or "absent"."""
+    r = make_ref.ref_root()
+    return "absent" if r is None else ("checkout" if r == make_ref.SRC_ROOT else "staged")
 
 
 _loaded = None
@@ -513,11 +526,24 @@ def reference_vcf_text(calls, cfg, contigs_lengths, fasta=None) -> str:
 
 
 # ---------------------------------------------------------------------------------------------- whole sample
-def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
+class DictFasta:
+    """pysam.FastaFile stand-in over {contig: sequence} (fetch with pysam's clipping; unknown contig -> KeyError)."""
+
+    def __init__(self, seqs):
+        self.seqs = seqs
+
+    def fetch(self, contig, start=None, end=None):
+        s = self.seqs[contig]
+        return s[(0 if start is None else start):(len(s) if end is None else end)]
+
+
+def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None, fasta=None):
     """The reference's `call_sample` flow on an in-memory BAM (`sniffles_amd.bam.BamRecords`): the main program's task
     layout (sniffles:286-360; default task_count_multiplier 0 = one task per processed contig), the UNMODIFIED
     `CallTask.execute` (build_leadtab over oracle/pysam_stub, call_candidates, finalize_candidates, SNF part) per task in
     this process, results emitted in task order through the unmodified VCF writer and `SNFile.write_results`.
+    `fasta`: {contig: sequence} - the run then has `--reference`: `_mask_N_coverage` (leadprov.py:420-443) and the writer's REF / ALT
+    resolution read it through a pysam.FastaFile stand-in.
     Returns dict(vcf=text, read_count=..., snf_candidates=...)."""
     import io
     import math
@@ -543,6 +569,11 @@ def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
     snf_out = ref_snf.SNFile(cfg, open(snf_path, "wb")) if snf_path else None
     orig = ref.parallel.pysam.AlignmentFile
     ref.parallel.pysam.AlignmentFile = lambda *a, **k: pysam_stub.AlignmentFile(recs)
+    orig_fasta = ref.leadprov.pysam.FastaFile
+    if fasta is not None:
+        cfg.reference = "reference.fa"
+        ref.leadprov.pysam.FastaFile = lambda *a, **k: DictFasta(fasta)
+        vcf_out.reference_handle = DictFasta(fasta)      # (VCF.open_reference, vcf.py:108-120, without the file system)
     read_count = 0
     try:
         for task_id, (contig, length) in enumerate(contig_lengths):
@@ -555,6 +586,7 @@ def run_reference_call_sample(recs, extra_args=(), snf_path=None, fixed=None):
             result.emit(vcf_out=vcf_out, snf_out=snf_out)
     finally:
         ref.parallel.pysam.AlignmentFile = orig
+        ref.leadprov.pysam.FastaFile = orig_fasta
     n_snf = 0
     if snf_out is not None:
         n_snf = snf_out.write_results(cfg, [c for c, _ in contig_lengths])

@@ -68,19 +68,16 @@ class LeadProvider:
         reference base is 'N'.  `fasta`: anything with pysam's `fetch(contig[, start, end])` (the host's business; the
         device takes the mask as intervals).  Failures to open / fetch only skip the masking, as in the reference."""
         import logging
-        from .soa import nmask_intervals
+        from .soa import paint_nmask
         if not getattr(self.config, "reference", None) or fasta is None:
             return
         try:
-            if regions is None:
-                self._nmask = nmask_intervals(fasta.fetch(self.contig), self.contig_len)
-            else:
-                starts, ends = [], []
-                for region in sorted(regions, key=lambda r: r.start):
-                    s, e = nmask_intervals(fasta.fetch(region.contig, region.start, region.end))
-                    starts.append(s + region.start); ends.append(e + region.start)
-                self._nmask = (np.concatenate(starts).astype(np.int32), np.concatenate(ends).astype(np.int32)) if starts else None
+            regs = None if regions is None else [(r.start, r.end) if hasattr(r, "start") else (r[-2], r[-1]) for r in regions]
+            clen = self.contig_len if self.contig_len is not None else self.end
+            # dense-paint semantics (list order, later regions overwrite), irregular input fails as in the reference -> unmasked
+            self._nmask = paint_nmask(fasta.fetch, self.contig, regs, int(clen))
         except Exception as e:  # noqa: BLE001 - the reference logs and goes on unmasked
+            self._nmask = None
             logging.warning(f"Unable to mask N regions in coverage vector, reference could not be fetched: {e}")
 
     def to_task_input(self, task_id: int, sv_id_start: int, tandem_repeats, qc_nm_threshold: float) -> TaskInput:

@@ -72,6 +72,40 @@ def regions_of(config, contig: str) -> list:
     return out
 
 
+def open_reference(config, reference=None):
+    """The FASTA handle `_mask_N_coverage` reads (leadprov.py:424-429: `pysam.FastaFile(config.reference)`; a failure to open is
+    logged and the sample goes on unmasked).  `reference`: an object with pysam's `fetch(contig[, start, end])`, else
+    `config.reference` is opened with this package's plain reader (sniffles_amd.fasta)."""
+    if reference is not None:
+        return reference
+    path = getattr(config, "reference", None)
+    if not path or not isinstance(path, str):
+        return None
+    import logging
+    from . import fasta
+    try:
+        return fasta.FastaFile(path)
+    except Exception as e:  # noqa: BLE001 - as the reference: warn, no mask
+        logging.warning(f"Unable to mask N regions in coverage vector, reference could not be opened: {e}")
+        return None
+
+
+def mask_N_coverage(ti, fasta_handle, contig: str, regions) -> None:
+    """`LeadProvider._mask_N_coverage(regions)` for a task input that came from the extraction kernels: the task's coverage
+    reads as 0 where the reference base is 'N' (`build_leadtab` calls it unconditionally once the regions are read,
+    leadprov.py:470).  `regions`: the task's [(start, end)] in list order - `build_leadtab` always passes a list, the whole task
+    being `[Region(contig, task.start, task.end)]` (parallel.py:101).  Failures leave the task unmasked with the reference's warning."""
+    if fasta_handle is None:
+        return
+    import logging
+    from . import soa
+    try:
+        ti.nmask_start, ti.nmask_end = soa.paint_nmask(fasta_handle.fetch, contig, regions, int(ti.contig_len))
+    except Exception as e:  # noqa: BLE001
+        ti.nmask_start = ti.nmask_end = None
+        logging.warning(f"Unable to mask N regions in coverage vector, reference could not be fetched: {e}")
+
+
 class _RegionExtractor:
     """Stands in for the extractor of a device-resident task when the task came from a region list (host concatenation)."""
 
@@ -96,12 +130,14 @@ def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tan
 
 
 def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
-                _lib=None, objects: bool = True) -> SampleResult:
+                _lib=None, objects: bool = True, reference=None) -> SampleResult:
     """`records`: `bam.read_bam(path)`.  `tandem_repeats`: {contig: [(start, end), ...]} (already padded, util.py:121-144).
     Writes the VCF to `vcf_handle` and / or the SNF to `snf_path` (CallTask.execute switches QC filtering off for the
     candidates when an SNF is requested, parallel.py:258-263).
     `objects=False`: VCF only, formatted straight from the record table (vcf.VCF.write_records) - the same text, no `SVCall`
-    objects (`SampleResult.calls` stays empty); falls back to the object path when a reference FASTA is attached."""
+    objects (`SampleResult.calls` stays empty); falls back to the object path when a reference FASTA is attached.
+    `reference` / `config.reference`: the reference FASTA (see `open_reference`) - with it the coverage of every task is masked
+    where the reference base is 'N' (`_mask_N_coverage`, leadprov.py:420-443, 470) and the writer resolves REF / ALT."""
     import struct
     flags = [struct.unpack_from("<H", records.blob, int(o) + 18)[0] for o in records.rec_off[:-1]]
     total_mapped = sum(1 for f, r in zip(flags, records.ref_id.tolist()) if r >= 0 and not f & 0x4)
@@ -111,8 +147,11 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     config.contig_lengths = contig_lengths
     out = SampleResult(contig_lengths=contig_lengths)
     writer = None
+    fasta_handle = open_reference(config, reference) if (reference is not None or getattr(config, "reference", None)) else None
     if vcf_handle is not None:
         writer = vcf.VCF(config, vcf_handle)
+        if fasta_handle is not None and writer.reference_handle is None:
+            writer.reference_handle = fasta_handle          # (vcf.py:108-120 open_reference: the same file)
         writer.write_header(contig_lengths)
     snf_out = snf.SNFile(config, open(snf_path, "wb")) if snf_path else None
     qc = not (snf_path is not None or config.no_qc)
@@ -130,6 +169,7 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
                                                                 read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32,
                                                                 task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
+        mask_N_coverage(ti, fasta_handle, contig, regions or [(task.start, task.end)])
         task.lead_provider = _Extracted(ti)
         if not objects and snf_out is None and writer is not None and writer.can_write_records():
             import numpy as np
@@ -213,7 +253,7 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
 
 
 def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle, tandem_repeats=None, device: int = 0,
-                 _lib=None) -> int:
+                 _lib=None, reference=None) -> int:
     """Force calling (`--genotype-vcf`, sniffles:190-213, 487-560 and `GenotypeTask.execute`): the SVs of the input VCF are
     matched against this sample's candidates contig by contig and written back with the sample's genotype (contig by
     contig, input order within a contig).  Returns the number of records written."""
@@ -230,6 +270,7 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
     config.contig_lengths = contig_lengths
     writer = vcf.VCF(config, vcf_out_handle)
     writer.rewrite_header_genotype(reader.header_str)
+    fasta_handle = open_reference(config, reference) if (reference is not None or getattr(config, "reference", None)) else None
     n = 0
     for task_id, (contig, length) in enumerate(contig_lengths):
         tr = (tandem_repeats or {}).get(contig)
@@ -240,6 +281,7 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
         ti, _, _ = _extract_regions(bam.contig_records(records, contig), contig, regions, config,
                                     (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device, _lib)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold
+        mask_N_coverage(ti, fasta_handle, contig, regions)
         task.lead_provider = _Extracted(ti)
         res = task.execute()
         task.close()

@@ -59,6 +59,54 @@ def nmask_intervals(sequence, contig_len: int = None):
     return np.flatnonzero(d == 1).astype(np.int32), np.flatnonzero(d == -1).astype(np.int32)
 
 
+def paint_nmask(fetch, contig: str, regions, contig_len: int):
+    """The mask `_mask_N_coverage(regions)` paints (leadprov.py:431-441), as sorted disjoint intervals (start[], end[]):
+    `mask = zeros(len(coverage))`, then per region IN LIST ORDER `mask[start:end] = fetch(contig, start, end)` - a later region
+    overwrites an earlier one where they overlap - and coverage is zeroed where the mask byte is 'N'.  `fetch`: pysam's
+    `FastaFile.fetch`.  `regions`: [(start, end)], or None for the whole contig (`fetch(contig)`, the mask then is the boolean index
+    itself and must have the coverage vector's length).  Raises what the reference's numpy statements raise (a fetched sequence
+    whose length is neither the slice's nor 1; a whole-contig sequence of another length than the coverage vector): the caller
+    logs and leaves the task unmasked, like the reference."""
+    def as_bytes(x):
+        return x.encode("ascii") if isinstance(x, str) else bytes(x)
+    if regions is None:
+        seq = as_bytes(fetch(contig))
+        if len(seq) != contig_len:      # `self.coverage[mask == 78] = 0`: boolean index of another length -> IndexError
+            raise IndexError(f"boolean index did not match indexed array: dimension is {contig_len} but corresponding boolean dimension is {len(seq)}")
+        return nmask_intervals(seq)
+    cur = []                            # sorted disjoint [s, e) painted 'N' so far
+    for start, end in regions:
+        start, end = int(start), int(end)
+        seq = as_bytes(fetch(contig, start, end))
+        lo, hi, _ = slice(start, end).indices(contig_len)
+        width = max(0, hi - lo)
+        if len(seq) != width and len(seq) != 1:
+            raise ValueError(f"could not broadcast input array from shape ({len(seq)},) into shape ({width},)")
+        if width == 0:
+            continue
+        if len(seq) == 1 and width != 1:
+            seq = seq * width
+        cut = []                        # the slice is overwritten: what was painted inside it goes first
+        for s, e in cur:
+            if e <= lo or s >= hi:
+                cut.append((s, e))
+            else:
+                if s < lo:
+                    cut.append((s, lo))
+                if e > hi:
+                    cut.append((hi, e))
+        ns, ne = nmask_intervals(seq)
+        cut.extend((int(a) + lo, int(b) + lo) for a, b in zip(ns.tolist(), ne.tolist()))
+        cut.sort()
+        cur = []
+        for s, e in cut:                # neighbours that touch become one interval (the library wants them disjoint and sorted)
+            if cur and s <= cur[-1][1]:
+                cur[-1] = (cur[-1][0], max(cur[-1][1], e))
+            else:
+                cur.append((s, e))
+    return np.array([s for s, _ in cur], np.int32), np.array([e for _, e in cur], np.int32)
+
+
 @dataclass
 class TaskInput:
     """All inputs of one contig task, SoA."""

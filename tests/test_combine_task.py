@@ -56,7 +56,7 @@ def test_combine_task_driver_matches_reference_gpu(name):
     run_case(name)
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_combine_driver_matches_reference_under_random_options(monkeypatch, capsys):
     """oracle/ref_combinefuzz.py: --combine-* option sets drawn from the reference's argparse definitions, a small population,
     the unmodified reference's CombineTask.execute against this driver on the same SNF blocks."""

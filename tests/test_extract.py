@@ -60,7 +60,7 @@ def test_kernel_bodies_match_reference(name, emu_lib):
     assert info.read_count == len(reads)
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_extraction_matches_reference_on_random_tables_and_filters(monkeypatch, capsys):
     """oracle/ref_extractfuzz.py: random record tables, regions, read-id offsets and read filters; the unmodified reference's
     build_leadtab against the oracle and against the kernels (the goldens pin eleven cases)."""

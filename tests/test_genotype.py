@@ -60,7 +60,7 @@ def test_genotype_task_gpu(name):
     run_case(name, None)
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_force_calling_matches_reference_on_random_targets_and_options(monkeypatch, capsys):
     """oracle/ref_genotypefuzz.py: random adversarial tasks, target sets derived from the reference's own candidates, random
     options; the unmodified reference's GenotypeTask.execute against this package's."""

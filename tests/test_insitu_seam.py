@@ -4,7 +4,7 @@
 accepted), and the reference's own `CallTask.execute` (`/root/reference/src/sniffles/parallel.py:255-297`) runs around the
 library.  Every `CallResult` is pickled through a `multiprocessing` pipe as the worker protocol does (`parallel.py:757`),
 then the reference's VCF writer writes it; the text must equal the unpatched reference's on the same BAM.
-Needs the reference checkout: build container only (the GPU twin runs wherever a GPU and the checkout meet)."""
+Needs the reference: its checkout (build container) or the byte-compiled staged build `oracle/_ref` that `oracle/make_ref.py` makes during `build()` and that travels to the GPU box - the GPU twin runs there."""
 import os
 import pickle
 
@@ -12,7 +12,7 @@ import pytest
 
 import cases
 
-pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+pytestmark = pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 
 FIXED = dict(command="sniffles --input sample.bam --vcf out.vcf", start_date="2026/01/01 00:00:00")
 NAMES = ["sample_two_contigs_12x", "sample_mosaic_20x", "sample_tandem_repeats_15x", "sample_splits_14x", "sample_noqc_10x"]

@@ -28,7 +28,7 @@ def test_oracle_matches_reference_golden(name, oracle_mod):
         assert float(res.coverage_average_total[0]) == exp["coverage_average_total"]
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_oracle_matches_reference_under_random_options(oracle_mod, monkeypatch, capsys):
     """oracle/ref_cfgfuzz.py: option sets drawn from the reference's own argparse definitions, the unmodified reference and the
     oracle on the same adversarial task with the same config object (the goldens pin the option sets of tests/cases.py only)."""

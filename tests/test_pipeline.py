@@ -103,7 +103,7 @@ def test_bam_to_vcf_and_snf_gpu(name, tmp_path):
     run_sample(name, tmp_path, None, through_file=True)
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_bam_to_vcf_matches_reference_under_random_command_lines(monkeypatch, capsys):
     """oracle/ref_samplefuzz.py: random synthetic samples, random command lines (some thirty options), the unmodified
     reference's call_sample flow against pipeline.call_sample, VCF text character by character."""
@@ -114,7 +114,7 @@ def test_bam_to_vcf_matches_reference_under_random_command_lines(monkeypatch, ca
     assert "mismatching 0 " in out and "MISMATCH" not in out, out[-2000:]
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_population_merge_matches_reference_under_random_command_lines(monkeypatch, capsys):
     """oracle/ref_populationfuzz.py: random populations (2-5 samples), random --combine-* command lines; BAM records -> .snf
     files -> merged VCF by the unmodified reference against this package, over its own files and over the reference's."""
@@ -152,7 +152,7 @@ def test_regions_restrict_extraction_and_coverage():
     assert res3.read_count == 2 * res2.read_count            # every read is walked once per region, as in the reference
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/src/sniffles"), reason="needs the reference checkout (build container)")
+@pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
 def test_genotype_vcf_with_regions_matches_reference(tmp_path):
     import ref_harness as rh
     import emu.emu as E
@@ -241,3 +241,84 @@ def test_tandem_repeat_file_loader(tmp_path):
             want = ref.util.load_tandem_repeats(str(bed), 500)
             want2 = ref.util.load_tandem_repeats(str(bed2), 500)
         assert got == want and util.load_tandem_repeats(str(bed2), 500) == want2
+
+
+# ------------------------------------------------------------------------------------------------ --reference: the N mask end to end
+def _fasta_with_N(recs, seed, frac=0.35):
+    """{contig: sequence}: random bases with runs of 'N' (200-6000 bp) over about `frac` of every contig, so that many of
+    the five coverage samples of a call fall on masked positions."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = {}
+    for name, n in zip(recs.ref_names, recs.ref_lens):
+        n = int(n)
+        a = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+        covered = 0
+        while covered < frac * n:
+            w = int(rng.integers(200, 6000))
+            s = int(rng.integers(0, max(1, n - w)))
+            a[s:s + w] = ord("N")
+            covered += w
+        out[name] = a.tobytes().decode("ascii")
+    return out
+
+
+def _with_reference(_lib, name, regions=None, fasta_len_delta=0):
+    import ref_harness as rh
+    build, args = {**cases.SAMPLES, **cases.SAMPLES_EMU}[name]
+    recs = build()
+    fasta = _fasta_with_N(recs, 11)
+    if fasta_len_delta:      # a FASTA whose contigs are longer / shorter than the BAM header says
+        fasta = {k: (v + "N" * fasta_len_delta if fasta_len_delta > 0 else v[:fasta_len_delta]) for k, v in fasta.items()}
+    fixed = dict(vu.FIXED)
+    cfg = config_for(args)
+    cfg.reference = "reference.fa"
+    if regions:
+        from sniffles_amd.pipeline import regions_of  # noqa: F401
+        fixed["regions_by_contig"] = {c: [rh.load_reference().parallel.Region(c, a, b) for a, b in rs] for c, rs in regions.items()}
+        cfg.regions_by_contig = {c: [(c, a, b) for a, b in rs] for c, rs in regions.items()}
+    exp = rh.run_reference_call_sample(recs, args, fixed=fixed, fasta=fasta)
+    plain = rh.run_reference_call_sample(recs, args, fixed=fixed)
+    buf = io.StringIO()
+    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=getattr(recs, "tandem_repeats", None), _lib=_lib,
+                               reference=rh.DictFasta(fasta))
+    assert res.read_count == exp["read_count"]
+    assert_same_text(buf.getvalue(), exp["vcf"])
+    return exp, plain
+
+
+needs_ref = pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
+
+
+@needs_ref
+@pytest.mark.parametrize("name", ["sample_two_contigs_12x", "sample_splits_14x"])
+def test_sample_with_reference_masks_N_coverage_emu(name):
+    """`build_leadtab` masks the coverage vector where the reference base is 'N' whenever `--reference` is given
+    (leadprov.py:470): genotypes, coverage filters and DR / DV change against the unmasked run, and equal the reference's."""
+    import emu.emu as E
+    exp, plain = _with_reference(E.lib(), name)
+    assert exp["vcf"] != plain["vcf"]           # the mask matters on this sample (otherwise the test shows nothing)
+
+
+@needs_ref
+def test_sample_with_reference_and_regions_emu():
+    """--regions: the mask is painted region by region in list order, a later region over an earlier one (leadprov.py:436-440)."""
+    import emu.emu as E
+    exp, _ = _with_reference(E.lib(), "sample_two_contigs_12x", regions={"chr20": [(400_000, 900_000), (100_000, 500_000)], "chr21": [(0, 1_000_000)]})
+    assert len(vu.split_text(exp["vcf"])[1]) > 20
+
+
+@needs_ref
+@pytest.mark.parametrize("delta", [7, -5000])
+def test_sample_with_reference_of_other_length_goes_unmasked_emu(delta):
+    """A FASTA whose contig is longer than the BAM header's length: the reference's slice assignment raises, it logs and goes on
+    unmasked (leadprov.py:441-442) - so does the pipeline.  Shorter: pysam clips the fetch, same outcome."""
+    import emu.emu as E
+    _with_reference(E.lib(), "sample_two_contigs_12x", fasta_len_delta=delta)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_sample_with_reference_masks_N_coverage_gpu():
+    exp, plain = _with_reference(None, "sample_two_contigs_12x")
+    assert exp["vcf"] != plain["vcf"]
