@@ -233,10 +233,14 @@ def run_calling(ctx):
     G = max(1, args.genomes)
     t0 = time.time()
     if strong:
-        # ONE genome; contigs grouped longest-first into 2 device batches per GPU (several contigs per claim amortise the
-        # launch latency of a pass); every rank holds every group so that it can serve whichever it claims
+        # ONE genome; the contigs are partitioned longest-first into one contig set per GPU (LPT-balanced: a claim is ONE device
+        # batch of several contigs, which amortises the launch chain of a pass); every rank holds every set resident in HBM so
+        # that it can serve whichever it claims from the queue
         specs = task_specs(args, wl, 0, 0, 1)
-        n_groups = max(1, min(len(specs), 2 * world))
+        # one contig SET per rank and pass: at one rank a set is the whole genome and the W host threads pipeline the passes exactly
+        # as the N = 1 line does (measured: two half-genome sets per pass cost 2.44 ms per genome against 1.62 - a pass of half the
+        # size is only 1.6x shorter, the launch chain does not shrink); SNF_BENCH_SETS_PER_RANK overrides
+        n_groups = max(1, min(len(specs), int(os.environ.get("SNF_BENCH_SETS_PER_RANK", "1")) * world))
         weights = [kw["contig_len"] for _, kw in specs]
         groups = [g for g in sdist.shard_lpt(weights, n_groups) if g]
         group_tasks = [[synth.gen_task(**specs[i][1]) for i in sorted(g)] for g in groups]
@@ -267,7 +271,8 @@ def run_calling(ctx):
     # (sniffles_amd.dist.SharedLanding: N PCIe links in parallel, the gather exchanges layouts only).  SNF_BENCH_GATHER=rccl (and
     # --scaling strong) take the block gather over RCCL instead: result blocks in HBM, dist.gather onto rank 0, landed there.
     shared = use_dist and not strong and os.environ.get("SNF_BENCH_GATHER", "shared") != "rccl"
-    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist and not shared else 0)
+    strong_shared = use_dist and strong and os.environ.get("SNF_BENCH_GATHER", "shared") != "rccl"
+    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist and not shared and not strong_shared else 0)
     for hs in handles:
         for bb in hs:
             bb.set_output(out_mode)
@@ -292,14 +297,18 @@ def run_calling(ctx):
     n_send = 2 if strong else (2 * W if shared else W)
     task_ids_local = [t.task_id for t in tasks]
     landing = None
-    if shared:
-        probe = handles[0][0]
-        probe.call_candidates(); probe.finalize()
-        res0 = probe.fetch(1)
-        need = torch.tensor([256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames), len(res0.alt_pool)], dtype=torch.int64, device=DEV)
+    NGEN = 3      # strong: segment generations (pass p writes generation p % 3 once its own gather of pass p - 2 has completed)
+    if shared or strong_shared:
+        need_b = need_a = 0
+        for probe in (handles[0] if strong_shared else handles[0][:1]):     # strong: the largest contig set sizes the segments
+            probe.call_candidates(); probe.finalize()
+            res0 = probe.fetch(1)
+            need_b = max(need_b, 256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames)); need_a = max(need_a, len(res0.alt_pool))
+        need = torch.tensor([need_b, need_a], dtype=torch.int64, device=DEV)
         dist.all_reduce(need, op=dist.ReduceOp.MAX)
         # /dev/shm must hold every rank's segments (containers often cap it): otherwise the block gather over RCCL is taken
-        seg_bytes = 2 * W * (int(need[0]) * 3 // 2 + int(need[1]) * 3 // 2 + (2 << 20) + 8192)
+        n_slots = NGEN * W * len(group_tasks) if strong_shared else 2 * W
+        seg_bytes = n_slots * (int(need[0]) * 3 // 2 + int(need[1]) * 3 // 2 + (2 << 20) + 8192)
         try:
             st = os.statvfs("/dev/shm")
             room = st.f_bavail * st.f_frsize >= int(world * seg_bytes * 1.25) and os.environ.get("SNF_BENCH_SHM_FULL") != "1"   # (SNF_BENCH_SHM_FULL=1: the test of this fallback)
@@ -310,12 +319,12 @@ def run_calling(ctx):
         if not int(ok_t.item()):
             if rank == 0:
                 print(f"[bench] /dev/shm cannot hold {world} x {seg_bytes >> 20} MiB of result segments: gathering the blocks over RCCL instead", file=sys.stderr)
-            shared = False
+            shared = strong_shared = False
             out_mode |= abi.OUT_DEVICE
             for hs in handles:
                 for bb in hs:
                     bb.set_output(out_mode)
-    if shared:
+    if shared or strong_shared:
         # two segments per handle, used in turn: pass k + 1 of a handle writes one while the parent still indexes the other
         # the layouts travel over a host-side (gloo) group: a 72-byte collective must not queue behind the passes' kernels
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the box's hostname need not resolve)
@@ -329,13 +338,23 @@ def run_calling(ctx):
         except Exception as e:                               # no host-side group here: the layouts go over the default group
             print(f"[bench] gloo group for the layouts unavailable ({type(e).__name__}: {e}); using the default group", file=sys.stderr)
             meta_group, meta_dev = None, DEV
-        landing = sdist.SharedLanding(slots=2 * W, block_bytes=int(need[0]) * 3 // 2 + (1 << 20), alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
-        for w in range(W):
-            for k in (1, 0):
-                handles[w][0].set_result_memory(*landing.memory(2 * w + k))     # (page-locked here, once)
-        ids_all = [None] * world
-        dist.all_gather_object(ids_all, task_ids_local)
-    if use_dist and not shared:
+        landing = sdist.SharedLanding(slots=n_slots, block_bytes=int(need[0]) * 3 // 2 + (1 << 20), alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
+        if strong_shared:
+            # segment of (generation, host thread, contig set): every handle stores into memory of its own
+            ngs = len(group_tasks)
+            slot_of = lambda gen, w, g: (gen * W + w) * ngs + g     # noqa: E731
+            for w in range(W):
+                for g in range(ngs):
+                    for gen in reversed(range(NGEN)):
+                        handles[w][g].set_result_memory(*landing.memory(slot_of(gen, w, g)))     # (page-locked here, once)
+            set_ids = [[t.task_id for t in gt] for gt in group_tasks]
+        else:
+            for w in range(W):
+                for k in (1, 0):
+                    handles[w][0].set_result_memory(*landing.memory(2 * w + k))     # (page-locked here, once)
+            ids_all = [None] * world
+            dist.all_gather_object(ids_all, task_ids_local)
+    if use_dist and not shared and not strong_shared:
         probe = handles[0][0]
         probe.call_candidates(); probe.finalize()
         res0 = probe.fetch(1)
@@ -368,6 +387,13 @@ def run_calling(ctx):
                     comm_q.task_done()
                     return
                 s, lay, ids = item
+                if strong_shared:      # s = (entries of this rank in the pass, event to set)
+                    g = sdist.gather_sets_shared(landing, s[0], len(group_tasks), set_ids, group=meta_group, device=meta_dev)
+                    if g is not None:
+                        gathered_box[0] = g
+                    s[1].set()
+                    comm_q.task_done()
+                    continue
                 if shared:
                     g = sdist.gather_results_shared(landing, s, lay, ids, group=meta_group, task_ids_per_rank=ids_all, device=meta_dev)
                 else:
@@ -513,7 +539,52 @@ def run_calling(ctx):
                     comm_q.put((p % 2, lay, ident))
         run_threads(body)
 
-    run_passes = run_passes_strong if strong else run_passes_weak
+    def run_passes_strong_shared(total):
+        """`total` passes over the ONE genome, pipelined: per pass a work queue of the contig SETS, heaviest first
+        (`dist.TaskQueue`: one atomic add on the process group's store per claim - issued while the previous claim's kernels run);
+        a claimed set is ONE device batch whose result the kernels store into this rank's shared-memory segment of (generation,
+        thread, set) - exactly the weak-scaling landing.  When the threads of a rank are through a pass, its communication
+        thread issues the pass's one collective (`dist.gather_sets_shared`: layouts only) while the threads are already in the
+        next pass; rank 0 then holds the whole genome's result, tasks in id order, in place.  No host copy, no merge."""
+        queues = [sdist.TaskQueue(gw, key="snf_bench", barrier=False) for _ in range(total)]   # same keys on every rank
+        dist.barrier()
+        lock = threading.Lock()
+        entries = [[] for _ in range(total)]
+        through = [0] * total
+        done = [threading.Event() for _ in range(total)]
+
+        def body(w):
+            nxt = queues[0].claim()
+            for p in range(total):
+                if p >= NGEN - 1:
+                    done[p - (NGEN - 1)].wait()                        # rank 0 has indexed what generation p % NGEN held
+                    if comm_err:
+                        return
+                g = nxt
+                while g is not None:
+                    bb = handles[w][g]
+                    t_a = time.perf_counter()
+                    bb.set_result_memory(*landing.memory(slot_of(p % NGEN, w, g)))
+                    bb.call_candidates(); bb.finalize()                # (both only enqueue)
+                    t_b = time.perf_counter()
+                    nxt = queues[p].claim()                            # the next claim travels while the kernels run
+                    t_c = time.perf_counter()
+                    lay = bb.fetch_layout()                            # the one host wait: the result lies in the segment
+                    t_d = time.perf_counter()
+                    if w == 0:
+                        phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
+                    with lock:
+                        entries[p].append((slot_of(p % NGEN, w, g), lay, g))
+                    g = nxt
+                nxt = queues[p + 1].claim() if p + 1 < total else None
+                with lock:
+                    through[p] += 1
+                    last = through[p] == W
+                if last:
+                    comm_q.put(((entries[p], done[p]), None, None))
+        run_threads(body)
+
+    run_passes = (run_passes_strong_shared if strong_shared else run_passes_strong) if strong else run_passes_weak
     run_passes(max(1, args.warmup) if strong else -(-args.warmup // W) * W)  # >= warmup passes, the same number on every handle
     barrier()
     import gc
@@ -637,8 +708,8 @@ def run_calling(ctx):
                                coverage=args.coverage if args.coverage is not None else wl["coverage"], scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls,
-                               parallelism=(f"one genome, {len(group_tasks)} contig groups claimed from a shared work queue by {world} ranks"
-                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if shared else ", RCCL gather of the result blocks on rank 0" if use_dist else ", one process: no gather"),
+                               parallelism=(f"one genome, {len(group_tasks)} contig sets (LPT-balanced, one device batch each) claimed from a shared work queue by {world} ranks x {W} host threads, passes pipelined"
+                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if (shared or strong_shared) else ", RCCL gather of the result blocks on rank 0" if use_dist else ", one process: no gather"),
                                batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
                                gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)), alt_bytes=int(len(gathered_box[0].alt_pool)),
                                                        read_names=int(len(gathered_box[0].rnames)), tasks=int(len(gathered_box[0].task_ids)),
@@ -730,9 +801,13 @@ def wall_clock(cfg, tasks, device):
     from sniffles_amd import lib, parallel, pipeline, sv
     os.environ["SNF_PROF"] = "1"          # the library prints its own split of the upload to stderr
     t0 = time.perf_counter()
+    from sniffles_amd import abi
     b = lib.Batch(cfg, tasks, device=device)
     t1 = time.perf_counter()
     del os.environ["SNF_PROF"]
+    # what the reference's workers hand to the parent - CallTask.execute's result (parallel.py:264-271): the QC-passing calls of
+    # every task sorted by position, filtered and ordered on the device; those (26.8 k of the 94 k candidates) become objects
+    b.set_output(abi.OUT_EXECUTE)
     b.call_candidates(); b.finalize(); b.sync()
     t2 = time.perf_counter()
     res = b.fetch(1, copy=False)          # views of the library's pinned result block, as sniffles_amd.parallel.Task reads them
@@ -742,8 +817,26 @@ def wall_clock(cfg, tasks, device):
         lo, hi = int(res.task_call_off[t]), int(res.task_call_off[t + 1])
         calls = sv.materialize_candidates(res, ti, lo, hi)
         sv.apply_final(calls, res, ti, lo)
+        for c in calls:
+            c.finalize()
         n += len(calls)
     t4 = time.perf_counter()
+    # for the record: every candidate as an object (what Task.finalize_candidates returns with keep_qc_fails - the --snf shape)
+    b.set_output(abi.OUT_CANDIDATES)
+    b.call_candidates(); b.finalize(); b.sync()
+    res_all = b.fetch(1, copy=False)
+    tc = time.perf_counter()
+    n_all = 0
+    for t, ti in enumerate(tasks):
+        lo, hi = int(res_all.task_call_off[t]), int(res_all.task_call_off[t + 1])
+        calls = sv.materialize_candidates(res_all, ti, lo, hi)
+        sv.apply_final(calls, res_all, ti, lo)
+        n_all += len(calls)
+    all_ms = (time.perf_counter() - tc) * 1e3
+    del calls
+    b.set_output(abi.OUT_EXECUTE)
+    b.call_candidates(); b.finalize(); b.sync()
+    res = b.fetch(1, copy=False)
     # the same records as VCF text without the objects in between (vcf.VCF.write_records, the BAM -> VCF flow with objects=False)
     vcf_ms, vcf_bytes = None, None
     try:
@@ -767,7 +860,18 @@ def wall_clock(cfg, tasks, device):
     b.close()
     batched = dict(vcf_text_from_records_ms=vcf_ms, vcf_text_bytes=vcf_bytes, upload_ms=round((t1 - t0) * 1e3, 2), pass_ms=round((t2 - t1) * 1e3, 2), d2h_ms=round((t3 - t2) * 1e3, 2),
                    materialise_ms=round((t4 - t3) * 1e3, 2), end_to_end_ms=round((t4 - t0) * 1e3, 2), svcalls=n,
+                   materialise_all_candidates_ms=round(all_ms, 2), candidates=n_all,
                    upload_GBps=round(_input_bytes(tasks) / max(1e-9, t1 - t0) / 1e9, 2))
+    # the reference's worker loop with the one-step drop-in: per contig task CallTask.execute_calls (upload, pass, objects of the kept calls)
+    t7 = time.perf_counter()
+    n3 = 0
+    for ti in tasks:
+        task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                                 tandem_repeats=None, device=device)
+        task.lead_provider = pipeline._Extracted(ti)
+        n3 += len(task.execute_calls(cfg))
+        task.close()
+    t8 = time.perf_counter()
     t5 = time.perf_counter()
     n2 = 0
     for ti in tasks:
@@ -779,7 +883,11 @@ def wall_clock(cfg, tasks, device):
         task.close()
     t6 = time.perf_counter()
     return dict(batched=batched, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
+                per_task_execute=dict(end_to_end_ms=round((t8 - t7) * 1e3, 2), tasks=len(tasks), svcalls=n3),
                 note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
+                     "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, sorted; "
+                     "materialise_all_candidates_ms: every candidate instead); per_task_api = 24 x Task.call_candidates + finalize_candidates "
+                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x CallTask.execute_calls; "
                      "d2h = results in the library's pinned block (read in place); materialise = SVCall Python objects (host); "
                      "vcf_text_from_records = the QC-passing records as VCF lines straight from the record table (no objects)")
 
@@ -966,6 +1074,8 @@ def reference_baseline(args, wl, exe, tasks, task_keys, out):
     if wc.get("batched"):
         vs["wall_clock_batched"] = round(r["hot_all_core_s"] * 1e3 / wc["batched"]["end_to_end_ms"], 1)
         vs["wall_clock_per_task_api"] = round(r["hot_all_core_s"] * 1e3 / wc["per_task_api"]["end_to_end_ms"], 1)
+        if wc.get("per_task_execute"):
+            vs["wall_clock_per_task_execute"] = round(r["hot_all_core_s"] * 1e3 / wc["per_task_execute"]["end_to_end_ms"], 1)
     vs["note"] = ("reference all-core seconds for one genome / this package's seconds for one genome: gpu_pass = the timed step (inputs in HBM, "
                   "result block on the host); wall_clock_batched = numpy columns -> upload -> pass -> SVCall objects; per_task_api = 24 x "
                   "Task.call_candidates / finalize_candidates")

@@ -301,6 +301,46 @@ def gather_results_shared(landing: SharedLanding, slot: int, layout: dict, task_
     return merge_blocks(blocks, ids_all)
 
 
+def gather_sets_shared(landing: SharedLanding, entries, max_entries: int, set_task_ids, group=None, device=None):
+    """The gather of one pass of the strong-scaling shape (ONE genome over N ranks, the reference's pull queue, `sniffles:495-530`,
+    `parallel.py:652-717`): the contig tasks are partitioned into SETS, every rank claims sets from a `TaskQueue` and runs each as
+    one device batch whose result its kernels store into a segment of the rank's `SharedLanding`.  `entries`: what this rank
+    produced in this pass, [(slot, layout from `Batch.fetch_layout`, set index)] - possibly empty, at most `max_entries`.  ONE
+    all-gather of (1 + 8 x max_entries) int64 per rank - whichever sets a rank happened to claim, every rank issues the same
+    collective - and rank `dst` returns the `GatheredResult` of the whole genome (None elsewhere): per set the task ids
+    `set_task_ids[set index]` in batch order, blocks read in place (views; `detach()` copies).  No result byte is copied on the
+    host or crosses a second link."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if len(entries) > max_entries:
+        raise ValueError("more sets in one pass than the gather was sized for")
+    row = [len(entries)]
+    for slot, layout, set_index in entries:
+        if int(layout["off_rnames"]) + 4 * int(layout["rnames_len"]) > landing.block_bytes or int(layout["alt_pool_len"]) > landing.alt_bytes:
+            raise ValueError("the result does not fit the shared segment")
+        row += [int(layout["n_calls"]), int(layout["rnames_len"]), int(layout["alt_pool_len"]), int(layout["off_rnames"]),
+                landing.block_bytes, landing.block_bytes + int(layout["alt_pool_len"]), int(slot), int(set_index)]
+    row += [0] * (1 + 8 * max_entries - len(row))
+    mine = torch.tensor(row, dtype=torch.int64, device=device or "cpu")
+    lays = torch.zeros(world * mine.numel(), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(lays, mine, group=group)
+    if rank != landing.dst:
+        return None
+    lays = lays.cpu().view(world, -1).tolist()
+    blocks, ids, seen = [], [], set()
+    for r in range(world):
+        for k in range(int(lays[r][0])):
+            f = lays[r][1 + 8 * k:9 + 8 * k]
+            d = dict(zip(LAYOUT_FIELDS, f[:6]))
+            if f[7] in seen:
+                raise RuntimeError(f"set {f[7]} was served twice in one pass")
+            seen.add(f[7])
+            blocks.append((d, landing.view(r, int(f[6]))[:d["bytes"]]))
+            ids.append(list(set_task_ids[int(f[7])]))
+    return merge_blocks(blocks, ids)
+
+
 def result_block(res):
     """(layout, bytes) of a fetched stage-1 result in the export format - for ranks whose result is already on the host
     (tests over gloo; `Batch.export_device` is the device form)."""

@@ -128,6 +128,19 @@ class CallTask(Task):
             calls = [s for s in calls if s.qc]
         return sorted(calls, key=lambda s: s.pos)
 
+    def execute_calls(self, config, svcall_cls=sv.SVCall, bnd_cls=sv.SVCallBNDInfo) -> list:
+        """What `CallTask.execute` hands to its `CallResult` (parallel.py:264-271) in one step: `call_candidates`,
+        `finalize_candidates`, `[s for s in svcalls if s.qc]` (unless `config.no_qc`) and `sorted(key=pos)` all happen on the
+        device (SNF_OUT_EXECUTE), and only the calls the worker would send to its parent become `SVCall` objects - for a 30x
+        genome 26.8 k objects instead of the 94 k candidates the two-call form has to materialise first.  Same objects, same
+        order as `call_svs()` (tests/test_dropin_api.py); `self.sv_id` advances by the number of candidates like there."""
+        res, ti = self.call_records(config, execute=True)
+        calls = sv.materialize_candidates(res, ti, 0, len(res.calls), svcall_cls, bnd_cls)
+        sv.apply_final(calls, res, ti)
+        for c in calls:
+            c.finalize()
+        return calls
+
     def write_snf_part(self, svcandidates, snf_filename: str):
         """The SNF tail of CallTask.execute (parallel.py:278-295): the task's candidates (after finalize_candidates) go
         into 100-kb blocks with their downsampled coverage and are written as a part file; the returned record is what

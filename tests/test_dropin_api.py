@@ -88,6 +88,21 @@ def run_case(name, _lib):
     final = task.finalize_candidates(cands, False, cfg)
     assert [as_record(c, "final") for c in final] == exp["final"]
     assert all(c.postprocess is None for c in final)
+    # CallTask.execute's tail in one step (filter + sort on the device, only the kept calls become objects): the same objects
+    task2 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, _lib=_lib)
+    task2.lead_provider, task2.tandem_repeats = lp, task.tandem_repeats
+    kept = task2.execute_calls(cfg)
+    want = final if cfg.no_qc else [c for c in final if c.qc]
+    want = sorted(want, key=lambda c: c.pos) if cfg.sort else want
+
+    def flat(c):
+        d = dict(c.__dict__)
+        d.pop("forward_difference_sampler")
+        d["rnames"] = sorted(d["rnames"])
+        return repr(d)
+    assert [flat(c) for c in kept] == [flat(c) for c in want]
+    assert task2.sv_id == task.sv_id and task2.coverage_average_total == task.coverage_average_total
+    task.close(); task2.close()
 
 
 NAMES = ["bnd_first_error", "bnd_stale_end", "merge_inner", "long_ins", "phase_rescue", "consensus_quirks",

@@ -80,24 +80,15 @@ def test_edit_distance_gpu_thread_and_wave_paths(oracle_mod):
     assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]
 
 
-def test_population_variant_match_is_the_reference_rule(oracle_mod):
-    """`snfp.PopulationVariant.match` (`/root/reference/src/sniffles/snfp.py:91-107`): position / length gate, then for insertions
-    `edlib.align(self.alt, svcall.alt)['editDistance']` against `combine_pctseq` - restated with the exact DP (edlib is absent:
-    parity unpinned against edlib itself) and compared with the batched GPU form."""
-    import math
-    import numpy as np
-    import emu.emu as E
+def _population_pairs(seed=3, n_pairs=160):
     from types import SimpleNamespace as NS
-    from sniffles_amd import snfp
-    from sniffles_amd.config import SnifflesConfig
-    rng = np.random.default_rng(3)
-    cfg = SnifflesConfig()
+    rng = np.random.default_rng(seed)
 
     def rnd(n):
         return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
-    pairs = []
-    for _ in range(120):
-        n = int(rng.integers(60, 900))
+    out = []
+    for _ in range(n_pairs):
+        n = int(rng.integers(60, 900)) if rng.random() < 0.9 else int(rng.integers(900, 7000))
         a = rnd(n)
         b = list(a)
         for i in range(len(b)):
@@ -105,21 +96,51 @@ def test_population_variant_match_is_the_reference_rule(oracle_mod):
                 b[i] = "ACGT"[rng.integers(0, 4)]
         b = "".join(b)[:max(50, n - int(rng.integers(0, 30)))]
         t = "INS" if rng.random() < 0.8 else "DEL"
-        pv = snfp.PopulationVariant("chr1", int(rng.integers(1000, 1200)), "x", a, t, n if t == "INS" else -n, 0, 0.1, 10, 2)
-        sv = NS(pos=pv.pos + int(rng.integers(-1300, 1300)), svlen=(len(b) if t == "INS" else -len(b)), svtype=t, alt=b)
-        pairs.append((pv, sv))
-    got = snfp.match_batch(pairs, cfg, _lib=E.lib())
-    exp = []
-    for pv, sv in pairs:
-        dist = abs(pv.pos - sv.pos) + abs(abs(pv.svlen) - abs(sv.svlen))
-        minlen = float(min(abs(pv.svlen), abs(sv.svlen)))
-        if dist > cfg.combine_match * math.sqrt(minlen) or dist > cfg.combine_match_max:
-            exp.append(None); continue
-        if pv.svtype == "INS" and cfg.combine_pctseq:
-            d = oracle_mod.edit_distance(pv.alt.encode(), sv.alt.encode())
-            if (pv.svlen - d) / pv.svlen <= cfg.combine_pctseq:
-                exp.append(None); continue
-        exp.append(dist)
+        fields = dict(contig="chr1", pos=int(rng.integers(1000, 1200)), id="x", alt=a, svtype=t, svlen=n if t == "INS" else -n, end=0,
+                      af=0.1, genotyped_sample_count=10, variant_sample_count=2)
+        call = NS(pos=fields["pos"] + int(rng.integers(-1300, 1300)), svlen=(len(b) if t == "INS" else -len(b)), svtype=t, alt=b)
+        out.append((fields, call))
+    return out
+
+
+def _check_population_match(L, extra_args=()):
+    """`snfp.match_batch` against the UNMODIFIED reference's own `PopulationVariant.match` (`snfp.py:91-107`), its `align`
+    (edlib, absent here) patched to the exact global unit-cost DP - edlib's default mode="NW", task="distance"; parity against
+    edlib itself stays unpinned.  The option values (`--combine-match`, `--combine-match-max`,
+    `--combine-pctseq`) come from the reference's own parser."""
+    import ref_harness as rh
+    import oracle
+    from sniffles_amd import snfp
+    rh.load_reference()
+    from sniffles import snfp as ref_snfp
+    cfg = rh.make_config(tuple(extra_args))            # (SnifflesConfig.__init__ makes it SnifflesConfig.GLOBAL, config.py:619)
+    keep = ref_snfp.align
+    ref_snfp.align = lambda a, b: {"editDistance": oracle.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    try:
+        pairs = _population_pairs()
+        exp = [ref_snfp.PopulationVariant(**f).match(call) for f, call in pairs]
+    finally:
+        ref_snfp.align = keep
+    mine = [(snfp.PopulationVariant(**f), call) for f, call in pairs]
+    got = snfp.match_batch(mine, cfg, _lib=L)
     assert got == exp and sum(e is not None for e in exp) > 10 and sum(e is None for e in exp) > 10
-    assert pairs[0][0].match(pairs[0][1], cfg, _lib=E.lib()) == exp[0]
-    assert snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)}) == (0.75, 2, 2)
+    assert mine[0][0].match(mine[0][1], cfg, _lib=L) == exp[0]
+    assert snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)}) == \
+        tuple(ref_snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)})) == (0.75, 2, 2)
+
+
+needs_ref = pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="needs the reference (its checkout, or the staged build oracle/_ref that make_ref.py compiles)")
+
+
+@needs_ref
+@pytest.mark.parametrize("extra", [(), ("--combine-pctseq", "0.9", "--combine-match", "100"), ("--combine-pctseq", "0")])
+def test_population_variant_match_equals_the_reference_emu(oracle_mod, extra):
+    import emu.emu as E
+    _check_population_match(E.lib(), extra)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_population_variant_match_equals_the_reference_gpu(oracle_mod):
+    _check_population_match(None)
+    _check_population_match(None, ("--combine-pctseq", "0.9", "--combine-match", "100"))

@@ -262,6 +262,87 @@ def test_two_rank_task_queue_equals_single_process():
     assert sorted(claims3[0] + claims3[1]) == list(range(40))            # threads x ranks: still every item exactly once
 
 
+def _sets_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    import emu.emu as E
+    from sniffles_amd import abi, dist as sdist, lib
+    from sniffles_amd.config import SnifflesConfig
+    tasks = _tasks()
+    cfg = SnifflesConfig()
+    sets = [sorted(g) for g in sdist.shard_lpt([t.n_leads for t in tasks], 3) if g]       # contig SETS: the claimable unit
+    set_ids = [[tasks[i].task_id for i in g] for g in sets]
+    weights = [sum(tasks[i].n_leads for i in g) for g in sets]
+    # every rank holds every set resident (it serves whichever it claims); a segment per (generation, set)
+    handles = [lib.Batch(cfg, [tasks[i] for i in g], _lib=E.lib()) for g in sets]
+    for b in handles:
+        b.set_output(abi.OUT_EXECUTE)
+    landing = sdist.SharedLanding(slots=2 * len(sets), block_bytes=1 << 21, alt_bytes=1 << 20)
+    texts, served = [], []
+    for p in range(3):
+        queue = sdist.TaskQueue(weights, key="sets")
+        entries = []
+        for g in queue:
+            slot = (p & 1) * len(sets) + g
+            handles[g].set_result_memory(*landing.memory(slot))
+            handles[g].call_candidates(); handles[g].finalize()
+            entries.append((slot, handles[g].fetch_layout(), g))
+            if rank == (p & 1):
+                time.sleep(0.5)                           # the slow rank changes from pass to pass: so does who serves what
+        served.append(len(entries))
+        merged = sdist.gather_sets_shared(landing, entries, len(sets), set_ids)
+        if rank == 0:
+            assert merged.task_ids.tolist() == sorted(t.task_id for t in tasks)
+            texts.append(vcf_text(cfg, tasks, lambda ti: (merged, merged.task_rows(ti.task_id))))
+        else:
+            assert merged is None
+        dist.barrier()
+    too_many = False
+    try:
+        sdist.gather_sets_shared(landing, [(0, dict(n_calls=0, rnames_len=0, alt_pool_len=0, off_rnames=0), 0)] * 4, 3, set_ids)
+    except ValueError:
+        too_many = True
+    counts = sdist.gather_claims(served, world)
+    for b in handles:
+        b.close()
+    if rank == 0:
+        q.put((texts, counts, too_many))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_contig_sets_from_a_queue_land_shared_equals_single_process():
+    """The strong-scaling shape of `bench.py --scaling strong` (one genome over N ranks, the reference's pull queue,
+    `sniffles:495-530`): contig sets claimed from `TaskQueue`, each ONE device batch whose result lands in the rank's shared
+    segment; `dist.gather_sets_shared` gives rank 0 the whole genome - its VCF text equals the single process's in every pass,
+    whichever rank served which set."""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import emu.emu as E
+    from sniffles_amd import abi
+    from sniffles_amd.config import SnifflesConfig
+    E.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_sets_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    texts, counts, too_many = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp_text, _ = single_process_text(SnifflesConfig(), _tasks(), E.lib(), abi.OUT_EXECUTE)
+    assert texts == [exp_text] * 3 and "SVTYPE=INS" in exp_text
+    assert all(a + b == 3 for a, b in zip(counts[0], counts[1]))          # every set exactly once per pass
+    assert counts[0] != counts[1] or counts[0][0] != counts[0][1]           # ... served by whoever was free
+    assert too_many
+
+
 def _scatter_worker(rank, world, port, q):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
@@ -365,4 +446,12 @@ def test_bench_two_ranks_falls_back_when_shm_is_full_emu():
 def test_bench_two_ranks_strong_scaling_emu():
     d = _bench_two_ranks(["--scaling", "strong"], 33500 + (os.getpid() % 500))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["tasks"] == 24 and d["value"] > 0
-    assert d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+    assert d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0 and d["config"]["gathered_on_rank0"]["tasks"] == 24
+    assert "2 contig sets" in d["config"]["parallelism"] and "SharedLanding" in d["config"]["parallelism"]
+
+
+def test_bench_two_ranks_strong_scaling_block_gather_emu():
+    """... and where /dev/shm is not an option (several nodes): the blocks of the sets a rank served, gathered over the process group."""
+    d = _bench_two_ranks(["--scaling", "strong"], 37500 + (os.getpid() % 500), SNF_BENCH_GATHER="rccl")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
+    assert "RCCL gather" in d["config"]["parallelism"]
