@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNF_ABI_VERSION 2
+#define SNF_ABI_VERSION 3
 
 #define SNF_SVLEN_NONE INT32_MIN /* Lead.svlen is None */
 #define SNF_SEQ_NONE (-1)        /* Lead.seq is None   */
@@ -576,14 +576,18 @@ int snf_combine_call_groups(const snf_group_call_config_t* cfg, int device, int6
  * Seam B4: consensus.novel_from_reads(best_lead, other_leads, klen, skip, skip_repetitive)
  * (reference src/sniffles/consensus.py:280-394, called from postprocessing.py:63) for a batch of independent
  * problems.  Only the `.seq` of the leads is read, so a problem is the best sequence plus the other sequences, all
- * given as (offset, length) into one byte pool.  `skip` is both the sampling step of the other reads and of the best
- * read's anchors (the reference call site passes skip_repetitive = skip).  The output of problem p has the length of
- * its best sequence and is written to out_pool + out_off[p]  (out_off[p+1] - out_off[p] == best_len[p]).
- * Limits of the workgroup kernels: klen 1..7, best_len < 65000, at most 512 other sequences and 500 sampled positions
- * (best_len / skip); sequences must not contain '-' (the reference's gap symbol).  Returns 0, or 1 with snf_last_error().
+ * given as (offset, length) into one byte pool.  `skip[p]` is the sampling step of the other reads, `skip_repetitive[p]` the
+ * one of the best read's anchors (NULL: the same as `skip`, which is what the reference's call site passes,
+ * postprocessing.py:60-61).  The output of problem p has the length of its best sequence and is written to
+ * out_pool + out_off[p]  (out_off[p+1] - out_off[p] == best_len[p]).
+ * klen 1..8.  Problems within klen <= 7, best_len < 65000, <= 512 other sequences, <= 500 sampled positions (best_len / skip),
+ * skip_repetitive == skip and a pool without the byte '-' (the reference's gap symbol: a read base '-' IS a gap there,
+ * consensus.py:317-380) run on the workgroup kernels; every other problem is served by the literal thread kernels (anchor table,
+ * one thread per other read, one thread per column - the reference's rows with '-' as the gap byte).
+ * Returns 0, or 1 with snf_last_error().
  */
 int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,
-                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip,
+                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int32_t* skip_repetitive,
                         const int64_t* others_index, /* n_problems + 1: range of a problem in others_off / others_len */
                         const int64_t* others_off, const int32_t* others_len,
                         uint8_t* out_pool, const int64_t* out_off);

@@ -631,9 +631,11 @@ void stage_leads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int6
     so[i] = sl >= 0 ? t.seq_off[i] + p0 : 0;      // rebased into the batch pool
   }
 }
-void stage_pool(const snf_task_input_t& t, uint8_t* st, size_t pool_at, int64_t p0, int64_t b0, int64_t b1) {
-  // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' would be a gap there
-  if (memchr(t.seq_pool + b0, '-', (size_t)(b1 - b0))) fail("INS sequences must not contain '-'");
+void stage_pool(const snf_task_input_t& t, uint8_t* st, size_t pool_at, int64_t p0, int64_t b0, int64_t b1, std::atomic<int>* has_dash) {
+  // the reference's consensus uses '-' as its gap symbol (consensus.py:317-380): a read base '-' IS a gap there.  BAM sequences
+  // cannot hold one; a batch whose pool does (Lead objects built by hand) takes the literal thread kernels e4 / e5 / e6 for every
+  // consensus call - they keep the reference's rows with '-' as the gap byte - instead of the LDS-vote kernels (View::cons_thread_only)
+  if (memchr(t.seq_pool + b0, '-', (size_t)(b1 - b0))) has_dash->store(1);
   memcpy(st + pool_at + (size_t)(p0 + b0), t.seq_pool + b0, (size_t)(b1 - b0));
 }
 void stage_reads(const snf_task_input_t& t, uint8_t* st, const size_t* off, int64_t r0, int32_t* rend_max) {
@@ -759,6 +761,7 @@ void do_upload(snf_batch_impl* b) {
     int nth = (int)std::thread::hardware_concurrency(); if (nth > 32) nth = 32; if (nth < 1) nth = 1;
     if (const char* e = getenv("SNF_UPLOAD_THREADS")) { nth = atoi(e); if (nth < 1) nth = 1; }
     std::mutex emu; std::string err;
+    std::atomic<int> has_dash{0};
     auto run_items = [&](const std::vector<Item>& its) {
       std::atomic<size_t> next{0};
       auto work = [&]() {
@@ -769,7 +772,7 @@ void do_upload(snf_batch_impl* b) {
           const snf_task_input_t& q = b->tasks[(size_t)it.t];
           try {
             if (it.kind == 0) stage_leads(q, st, off, b->h_lead_off[(size_t)it.t], b->h_pool_off[(size_t)it.t], it.lo, it.hi);
-            else if (it.kind == 1) stage_pool(q, st, pool_at, b->h_pool_off[(size_t)it.t], it.lo, it.hi);
+            else if (it.kind == 1) stage_pool(q, st, pool_at, b->h_pool_off[(size_t)it.t], it.lo, it.hi, &has_dash);
             else stage_reads(q, st, off, b->h_read_off[(size_t)it.t], &b->h_rend_max[(size_t)it.t]);
           } catch (const snf::Error& e) { std::lock_guard<std::mutex> g(emu); if (err.empty()) err = e.msg; }
         }
@@ -794,6 +797,7 @@ void do_upload(snf_batch_impl* b) {
       throw;
     }
     t_staged = now_ms();
+    v.cons_thread_only = has_dash.load();
     h2d(b, v.pool, st + pool_at, (size_t)v.pool_len);
     // tasks whose columns are already in HBM (snf_batch_add_task_device): device-to-device into their slices, sequence
     // offsets rebased into the batch pool by a kernel
@@ -1724,7 +1728,7 @@ void do_add_task(snf_batch_impl* b, const snf_task_input_t* t) {
 
 namespace {
 void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,
-                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int64_t* others_index,
+                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int32_t* skip_rep, const int64_t* others_index,
                         const int64_t* others_off, const int32_t* others_len, uint8_t* out_pool, const int64_t* out_off) {
     if (n_problems <= 0) return;
     if (!seq_pool || !best_off || !best_len || !skip || !others_index || !others_off || !others_len || !out_pool || !out_off)
@@ -1732,20 +1736,24 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     int nd = 0;
     if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) fail("no such HIP device");
     SNF_HIP(hipSetDevice(device));
-    if (seq_pool_len > 0 && memchr(seq_pool, '-', (size_t)seq_pool_len)) fail("sequences must not contain '-'");
+    if (klen < 1 || klen > 8) fail("snf_consensus_batch: klen must be 1..8 (a k-mer is compared as one 64-bit word)");
+    // '-' is the reference's gap symbol (consensus.py:317-380): a pool that holds one goes to the literal thread kernels as a whole
+    const bool has_dash = seq_pool_len > 0 && memchr(seq_pool, '-', (size_t)seq_pool_len) != nullptr;
     const int64_t np = n_problems, n_reads = others_index[np];
     std::vector<ConsDesc> descs((size_t)np);
     std::vector<int32_t> lists[8];
+    std::vector<int64_t> generic;      // problems for the thread kernels e4 / e5 / e6: '-' bytes, skip_repetitive != skip, beyond the workgroup kernels' limits
     Counts hc{};
     int64_t aln_total = 0, alt_total = 0;
     for (int64_t p = 0; p < np; p++) {
       const int64_t L = best_len[p]; const int64_t no = others_index[p + 1] - others_index[p];
       if (L < 0 || no < 0 || best_off[p] < 0 || best_off[p] + L > seq_pool_len) fail("best sequence outside the pool");
       if (out_off[p + 1] - out_off[p] != L) fail("out_off must be the prefix sums of best_len");
+      if (skip[p] < 1 || (skip_rep && skip_rep[p] < 1)) fail("sampling steps must be >= 1 (range() of the reference raises on 0)");
       for (int64_t k = others_index[p]; k < others_index[p + 1]; k++)
         if (others_len[k] < 0 || others_off[k] < 0 || others_off[k] + others_len[k] > seq_pool_len) fail("other sequence outside the pool");
-      const int cls = cons_class_of(1, klen, skip[p], L, (int32_t)no);
-      if (cls == 0) fail("problem exceeds the limits of the workgroup consensus kernels (see sniffles_amd.h)");
+      const int cls = (has_dash || (skip_rep && skip_rep[p] != skip[p])) ? 0 : cons_class_of(1, klen, skip[p], L, (int32_t)no);
+      if (cls == 0) { generic.push_back(p); continue; }
       ConsDesc d{};
       d.best_off = best_off[p]; d.alt_off = out_off[p]; d.aln_off = aln_total; d.read_off = others_index[p];
       d.L = (int32_t)L; d.n_others = (int32_t)no; d.skip = skip[p]; d.cls = cls;
@@ -1754,8 +1762,9 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
       if (cls == 2) { const int64_t work = no * L; lid = work >= 32768 ? 2 : work >= 16384 ? 3 : work >= 8192 ? 4 : 5; }
       else if (cls == 4) lid = 7;
       lists[lid].push_back((int32_t)p); hc.n_cls[lid]++;
-      aln_total += no * L; alt_total += L;
+      aln_total += no * L;
     }
+    alt_total = out_off[np];
     std::vector<void*> frees;
     auto dev = [&](size_t bytes) { void* q = nullptr; SNF_HIP(hipMalloc(&q, bytes ? bytes : 1)); frees.push_back(q); return q; };
     auto up = [&](const void* h, size_t bytes) { void* q = dev(bytes); if (bytes) SNF_HIP(hipMemcpy(q, h, bytes, hipMemcpyHostToDevice)); return q; };
@@ -1767,6 +1776,8 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     SNF_HIP(hipMemset(dpool, 0, (size_t)seq_pool_len + 32));
     if (seq_pool_len) SNF_HIP(hipMemcpy(dpool, seq_pool, (size_t)seq_pool_len, hipMemcpyHostToDevice));
     v.pool = dpool; v.pool_len = seq_pool_len; v.pool_cap = seq_pool_len + 32;
+    v.alt_pool = (uint8_t*)dev((size_t)alt_total + 16);
+    if ((int64_t)generic.size() < np) {
     v.cdesc = (ConsDesc*)up(descs.data(), descs.size() * sizeof(ConsDesc));
     for (int k = 1; k < 6; k++) v.cls_list[k] = (int32_t*)up(lists[k].data(), lists[k].size() * sizeof(int32_t));
     lists[7].resize((size_t)np, 0);   // room for every problem: SMALL / LARGE may hand calls over at run time
@@ -1776,7 +1787,6 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     v.crl_len = (int32_t*)up(others_len, (size_t)n_reads * sizeof(int32_t));
     v.aln = (uint8_t*)dev((size_t)aln_total + 16);
     v.aln_kept_w = (uint8_t*)dev((size_t)n_reads + 16);
-    v.alt_pool = (uint8_t*)dev((size_t)alt_total + 16);
     v.stripes = (unsigned long long*)dev(4 * 64 * 16 * sizeof(unsigned long long));
     SNF_HIP(hipMemset(v.stripes, 0, 4 * 64 * 16 * sizeof(unsigned long long)));
     const int64_t n_small = (int64_t)hc.n_cls[1], n_large = (int64_t)(hc.n_cls[2] + hc.n_cls[3] + hc.n_cls[4] + hc.n_cls[5]);
@@ -1785,6 +1795,60 @@ void do_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
     // list 7: calls beyond the LDS vote counters, plus whatever the two kernels above handed over (null stream: ordered)
     hipLaunchKernelGGL((K_CONS_ROWS), dim3((unsigned)(np < 4096 ? np : 4096)), dim3(256), 0, 0, v, (int64_t)0);
     SNF_HIP(hipGetLastError());
+    }
+    if (!generic.empty()) {
+      // The literal thread kernels of the batch pipeline (e4_anchor: anchor table with `skip_repetitive`; e5_align: one thread per other
+      // read, rows with '-' as the gap byte; e6_vote: one thread per column) over a synthetic call table: call k = generic problem k,
+      // F slots = its sequences (best first), alt offsets = the caller's out_off.
+      const int64_t ng = (int64_t)generic.size();
+      std::vector<CallX> cx((size_t)ng);
+      std::vector<int32_t> ccall((size_t)ng), fi, flen, sk((size_t)ng), skr((size_t)ng);
+      std::vector<int64_t> foff, roff((size_t)ng + 1), toff((size_t)ng + 1), tsz((size_t)ng), aoff((size_t)ng + 1);
+      std::vector<uint32_t> pn((size_t)np + 1);
+      // e6_vote finds the call of a column by its alt offset: every problem is a call there, the generic ones flagged for consensus
+      std::vector<CallX> call_all((size_t)np);
+      for (int64_t p = 0; p < np; p++) { pn[(size_t)p] = (uint32_t)out_off[p]; CallX x{}; x.do_cons = 0; x.best = -1; x.cons_id = -1; call_all[(size_t)p] = x; }
+      pn[(size_t)np] = (uint32_t)out_off[np];
+      if (out_off[np] >= ((int64_t)1 << 32)) fail("snf_consensus_batch: more than 4 GB of output");
+      int64_t r_tot = 0, t_tot = 0, a_tot = 0;
+      for (int64_t k = 0; k < ng; k++) {
+        const int64_t p = generic[(size_t)k], L = best_len[p], no = others_index[p + 1] - others_index[p];
+        CallX x{};
+        x.flo = (int32_t)fi.size(); x.fn = (int32_t)(no + 1); x.best = x.flo; x.n_others = (int32_t)no; x.do_cons = 1; x.cons_id = (int32_t)k;
+        fi.push_back((int32_t)fi.size()); flen.push_back((int32_t)L); foff.push_back(best_off[p]);
+        for (int64_t q = others_index[p]; q < others_index[p + 1]; q++) { fi.push_back((int32_t)fi.size()); flen.push_back(others_len[q]); foff.push_back(others_off[q]); }
+        if (fi.size() >= ((size_t)1 << 31)) fail("snf_consensus_batch: too many sequences");
+        call_all[(size_t)p] = x; ccall[(size_t)k] = (int32_t)p;
+        sk[(size_t)k] = skip[p]; skr[(size_t)k] = skip_rep ? skip_rep[p] : skip[p];
+        const int64_t npos = cons_npos(L, klen, skr[(size_t)k]);
+        int64_t hs = 16; while (hs < 2 * npos + 2) hs <<= 1;
+        roff[(size_t)k] = r_tot; toff[(size_t)k] = t_tot; tsz[(size_t)k] = hs; aoff[(size_t)k] = a_tot;
+        r_tot += no; t_tot += hs; a_tot += no * L;
+      }
+      roff[(size_t)ng] = r_tot; toff[(size_t)ng] = t_tot; aoff[(size_t)ng] = a_tot;
+      View g{};
+      g.cfg.consensus_kmer_len = klen; g.wave_path = 1; g.cons_thread_only = 1;   // (e6_vote leaves the columns of the other problems alone)
+      g.pool = dpool; g.pool_len = seq_pool_len; g.pool_cap = seq_pool_len + 32;
+      Counts gc{}; gc.n_cons = ng; gc.n_cons_reads = r_tot; gc.alt_total = out_off[np]; gc.n_calls = np; gc.alt_in_pinned = 0;
+      g.cnt = (Counts*)up(&gc, sizeof(Counts));
+      g.cons_call = (int32_t*)up(ccall.data(), ccall.size() * 4);
+      g.callx = (CallX*)up(call_all.data(), call_all.size() * sizeof(CallX));
+      g.F_seq_len = (int32_t*)up(flen.data(), flen.size() * 4); g.F_seq_off = (int64_t*)up(foff.data(), foff.size() * 8);
+      g.FI = (int32_t*)up(fi.data(), fi.size() * 4);
+      g.cons_read_off = (int64_t*)up(roff.data(), roff.size() * 8); g.cons_tab_off = (int64_t*)up(toff.data(), toff.size() * 8);
+      g.cons_tab_sz = (int64_t*)up(tsz.data(), tsz.size() * 8); g.cons_aln_off = (int64_t*)up(aoff.data(), aoff.size() * 8);
+      g.cons_skip_arr = (int32_t*)up(sk.data(), sk.size() * 4); g.cons_skiprep_arr = (int32_t*)up(skr.data(), skr.size() * 4);
+      g.pN = (uint32_t*)up(pn.data(), pn.size() * 4);
+      g.tab_key = (uint64_t*)dev((size_t)t_tot * 8); g.tab_pos = (int32_t*)dev((size_t)t_tot * 4); g.tab_state = (uint8_t*)dev((size_t)t_tot);
+      g.aln = (uint8_t*)dev((size_t)a_tot + 16); g.aln_kept = (uint8_t*)dev((size_t)r_tot + 16);
+      g.cr_call = (int32_t*)dev((size_t)r_tot * 4 + 4); g.cr_read = (int32_t*)dev((size_t)r_tot * 4 + 4);
+      g.alt_pool = v.alt_pool;
+      auto grid = [](int64_t n) { return dim3((unsigned)((n + 255) / 256)); };
+      hipLaunchKernelGGL(e4_anchor, grid(ng), dim3(256), 0, 0, g, ng);
+      if (r_tot > 0) hipLaunchKernelGGL(e5_align, grid(r_tot), dim3(256), 0, 0, g, r_tot);
+      if (out_off[np] > 0) hipLaunchKernelGGL(e6_vote, grid(out_off[np]), dim3(256), 0, 0, g, out_off[np]);
+      SNF_HIP(hipGetLastError());
+    }
     SNF_HIP(hipDeviceSynchronize());
     if (alt_total) SNF_HIP(hipMemcpy(out_pool, v.alt_pool, (size_t)alt_total, hipMemcpyDeviceToHost));
 }
@@ -2295,10 +2359,11 @@ int snf_batch_coverage_calls(snf_batch_t* bb, int32_t task_index, int64_t n, con
 }
 
 int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t seq_pool_len, int64_t n_problems,
-                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int64_t* others_index,
-                        const int64_t* others_off, const int32_t* others_len, uint8_t* out_pool, const int64_t* out_off) {
-  SNF_TRY(do_consensus_batch(device, klen, seq_pool, seq_pool_len, n_problems, best_off, best_len, skip, others_index, others_off,
-                              others_len, out_pool, out_off))
+                        const int64_t* best_off, const int32_t* best_len, const int32_t* skip, const int32_t* skip_repetitive,
+                        const int64_t* others_index, const int64_t* others_off, const int32_t* others_len, uint8_t* out_pool,
+                        const int64_t* out_off) {
+  SNF_TRY(do_consensus_batch(device, klen, seq_pool, seq_pool_len, n_problems, best_off, best_len, skip, skip_repetitive, others_index,
+                              others_off, others_len, out_pool, out_off))
 }
 
 

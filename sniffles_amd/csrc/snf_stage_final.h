@@ -507,8 +507,12 @@ SNF_HD int cons_class_of(int wave_path, int klen, int skip, int64_t L, int32_t n
   return 0;
 }
 SNF_HD int cons_class(const View& v, int64_t L, int32_t n_others) {
+  if (v.cons_thread_only) return 0;
   return cons_class_of(v.wave_path, v.cfg.consensus_kmer_len, cons_skip(v.cfg, L), L, n_others);
 }
+// sampling steps of consensus call `cid` (consensus.py:280: `skip` for the other reads, `skip_repetitive` for the best read's anchors)
+SNF_HD int cons_skip_reads(const View& v, int64_t cid, int64_t L) { return v.cons_skip_arr ? v.cons_skip_arr[cid] : cons_skip(v.cfg, L); }
+SNF_HD int cons_skip_anchors(const View& v, int64_t cid, int64_t L) { return v.cons_skiprep_arr ? v.cons_skiprep_arr[cid] : cons_skip(v.cfg, L); }
 SNF_HD bool cons_wave_eligible(const View& v, int64_t L, int32_t n_others) { return cons_class(v, L, n_others) != 0; }
 
 // where this pass's ALT bytes live (pinned host memory when the total fits the batch's pinned buffer, else the HBM pool)
@@ -637,7 +641,7 @@ SNF_HD void e4_anchor_body(int64_t cid, const View& v) {
   for (int32_t r = 0; r < x.n_others; r++) { v.cr_call[r0 + r] = (int32_t)cid; v.cr_read[r0 + r] = r; }
   if (cons_wave_eligible(v, L, x.n_others)) return;  // e45w_consensus builds its table in LDS
   const uint8_t* B = v.pool + v.F_seq_off[x.best];
-  int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L);
+  int klen = v.cfg.consensus_kmer_len, skip = cons_skip_anchors(v, cid, L);
   int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_sz[cid];
   uint64_t* key = v.tab_key + t0; int32_t* pos = v.tab_pos + t0; uint8_t* st = v.tab_state + t0;
   for (int64_t p = 0; p < hs; p++) st[p] = 0;
@@ -669,7 +673,7 @@ SNF_HD void e5_align_body(int64_t j, const View& v) {
   const uint8_t* B = v.pool + v.F_seq_off[x.best];
   const uint8_t* S = v.pool + v.F_seq_off[slot];
   int64_t SL = v.F_seq_len[slot];
-  int klen = v.cfg.consensus_kmer_len, skip = cons_skip(v.cfg, L), maxshift = klen;
+  int klen = v.cfg.consensus_kmer_len, skip = cons_skip_reads(v, cid, L), maxshift = klen;
   int64_t t0 = v.cons_tab_off[cid], hs = v.cons_tab_sz[cid];
   const uint64_t* key = v.tab_key + t0; const int32_t* pos = v.tab_pos + t0; const uint8_t* st = v.tab_state + t0;
   uint8_t* row = v.aln + v.cons_aln_off[cid] + (int64_t)ridx * L;
@@ -743,7 +747,8 @@ SNF_HD void e6_vote_body(int64_t col, const View& v) {
           if (v.aln_kept[r0 + r2] && rows[(int64_t)r2 * L + i] == ch) seen = true;
         if (seen) continue;
         int64_t cntc = (ch == b) ? 1 : 0;
-        for (int32_t r2 = 0; r2 < x.n_others; r2++) if (v.aln_kept[r0 + r2] && rows[(int64_t)r2 * L + i] == ch) cntc++;
+        if (ch != '-')   // (the best read's own '-' is a character of the vote; a '-' in a row is a gap, never a vote)
+          for (int32_t r2 = 0; r2 < x.n_others; r2++) if (v.aln_kept[r0 + r2] && rows[(int64_t)r2 * L + i] == ch) cntc++;
         nd++;
         if (cntc > c0 || (cntc == c0 && (int)ch > k0)) { c1 = c0; k1 = k0; c0 = cntc; k0 = ch; }
         else if (cntc > c1 || (cntc == c1 && (int)ch > k1)) { c1 = cntc; k1 = ch; }

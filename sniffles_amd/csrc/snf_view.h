@@ -106,6 +106,12 @@ struct View {
   int32_t T;          // tasks
   int32_t run_gap;    // merge-scan run cut (bp); <0: whole group serial
   int32_t wave_path;  // 1: gfx950 wave-cooperative kernels own the small clusters (thread kernels skip them)
+  int32_t cons_thread_only;  // 1: a sequence of the batch holds the byte '-' (the reference's gap symbol): every consensus call takes
+                             //    the literal thread kernels e4 / e5 / e6, which keep the reference's rows (consensus.py:317-380)
+  int32_t _pad_cto;
+  // stand-alone consensus seam (snf_consensus_batch): sampling step of the other reads / of the best read's anchors per
+  // consensus id, instead of the pipeline's formula (postprocessing.py:60-61 passes the same value for both); null in a batch
+  const int32_t* cons_skip_arr; const int32_t* cons_skiprep_arr;
   int32_t prof;       // SNF_PROF=1: phase cycle counters in e45w_consensus
   int64_t N, R, NTR;
   int64_t NS;         // positions that go through the sort and the stages behind it: N, or (prefilter) the leads of (svtype, bin) cells with >= 2 leads

@@ -71,7 +71,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_combine_last_stats.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.snf_combine_last_stats.restype = C.c_int
     u8p, i64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
-    lib.snf_consensus_batch.argtypes = [C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p, i64p, i64p, i32p, u8p, i64p]
+    lib.snf_consensus_batch.argtypes = [C.c_int, C.c_int, u8p, C.c_int64, C.c_int64, i64p, i32p, i32p, i32p, i64p, i64p, i32p, u8p, i64p]
     lib.snf_consensus_batch.restype = C.c_int
     lib.snf_extract_create.argtypes = [C.POINTER(abi.snf_extract_config_t), C.c_int, C.POINTER(vp)]
     lib.snf_extract_upload.argtypes = [vp, C.POINTER(abi.snf_extract_input_t)]
