@@ -6,6 +6,7 @@
 #include "snf_wave_refine.h"
 #include "snf_wave_cons.h"
 #include "snf_fused.h"
+#include "snf_stage_window.h"
 #include "snf_stage_out.h"
 #include "snf_wave_call.h"
 #include "snf_wave_call_g.h"
@@ -274,6 +275,7 @@ struct snf_batch_impl {
   int finalize_runs = 0;          // finalize calls since the last call_candidates
   int rn_state = 0;               // supporting read names of the current candidates: 0 all written, 1 deferred (sizes only), 2 written for the kept calls
   int64_t pf_words = 0;           // prefilter bitmap size (uint32 words)
+  int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
   bool readprep_each_pass = false; // SNF_READPREP_EACH_PASS=1: rebuild it in every call_candidates (round-1 behaviour)
@@ -901,6 +903,31 @@ void do_upload(snf_batch_impl* b) {
       dsync(b);   // cell_off goes out of scope
     }
   }
+  // window front end (snf_stage_window.h): same precondition as the prefilter (a one-lead bin can never seed a cluster); the window
+  // width is chosen below, once the leads can be counted per window - the arrays are sized for the narrowest window tried
+  const int WIN_W_MAX = 10, WIN_W_MIN = 6;
+  auto win_layout = [&](int W, std::vector<int64_t>& off) {
+    const int bs = b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1;
+    off.assign((size_t)T + 1, 0);
+    for (int t = 0; t < T; t++) off[(size_t)t + 1] = off[(size_t)t] + (int64_t)SNF_NTYPES * ((((int64_t)b->tasks[(size_t)t].contig_len / bs + 1) >> W) + 1);
+    return off[(size_t)T];
+  };
+  int64_t win_slots_max = 0;
+  const bool front_wanted = v.prefilter && v.wave_path && getenv("SNF_NO_WINFRONT") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25);
+  if (front_wanted) {
+    std::vector<int64_t> off;
+    win_slots_max = win_layout(WIN_W_MIN, off);
+    if (win_slots_max >= ((int64_t)1 << 31)) win_slots_max = 0;
+  }
+  v.front = 0; v.NW = 0;
+  if (win_slots_max > 0) {
+    const size_t W1 = (size_t)win_slots_max + 1;
+    v.wcnt = dalloc<uint32_t>(b, W1); v.wfill = dalloc<uint32_t>(b, W1); v.wbase = dalloc<uint32_t>(b, W1);
+    const size_t occ_max = (size_t)(N < win_slots_max ? N : win_slots_max) + 2;
+    v.wlist = dalloc<uint32_t>(b, occ_max); v.ws_seeds = dalloc<uint32_t>(b, occ_max); v.ws_nf = dalloc<uint32_t>(b, occ_max); v.ws_nl = dalloc<uint32_t>(b, occ_max);
+    v.whead = dalloc<uint64_t>(b, N1);
+    dzero(b, v.wcnt, W1 * 4); dzero(b, v.wfill, W1 * 4);
+  }
   uint32_t** u32s[] = {&v.headflag, &v.headscan, &v.eligflag, &v.eligscan, &v.fN, &v.pN, &v.fL, &v.pL, &v.runflag, &v.runscan,
                        &v.clflag, &v.clscan, &v.rcflag, &v.rcscan, &v.cdflag, &v.cdscan, &v.rnf, &v.rnp};
   for (auto pp : u32s) *pp = dalloc<uint32_t>(b, N1);
@@ -926,7 +953,7 @@ void do_upload(snf_batch_impl* b) {
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
-  v.tile_stride = (int64_t)(N1 / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * TS_SLOTS);
+  v.tile_stride = (int64_t)((N1 > (size_t)win_slots_max + 1 ? N1 : (size_t)win_slots_max + 1) / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * TS_SLOTS);
   v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
@@ -958,6 +985,37 @@ void do_upload(snf_batch_impl* b) {
     dsync(b);
     v.NS = hc.n_kept;
     if (v.prof) fprintf(stderr, "[SNF_PROF] prefilter: %lld of %lld leads share their (svtype, bin) cell with another lead\n", (long long)v.NS, (long long)N);
+  }
+  if (win_slots_max > 0 && v.NS > 0) {
+    // window width: the widest whose largest window fits the 256-lead instance of the window kernels, else the widest that fits the
+    // 1024-lead one; occupied windows and the largest window are properties of the input (counted here, like NS): the passes size
+    // their launches on the host
+    int forced = getenv("SNF_WIN_BITS") ? atoi(getenv("SNF_WIN_BITS")) : 0;
+    int best_w = -1; int64_t best_occ = 0, best_max = 0;
+    std::vector<int64_t> off;
+    if (forced && (forced < WIN_W_MIN || forced > WIN_W_MAX)) forced = 0;
+    for (int W = forced ? forced : WIN_W_MAX; W >= (forced ? forced : WIN_W_MIN); W--) {
+      v.NW = win_layout(W, off); v.win_bits = W;
+      const int64_t* d_off = upload_vec(b, off);
+      v.t_win_off = d_off;
+      const bool tm = b->timing; b->timing = false;
+      enqueue_pass_init(b);
+      LAUNCH_Q(w1_hist, v, N, 0);
+      LAUNCH_Q(w0_stats, v, v.NW, 0);
+      b->timing = tm;
+      Counts hc{};
+      d2h(b, &hc, v.cnt, sizeof(Counts));
+      dzero(b, v.wcnt, ((size_t)v.NW + 1) * 4);
+      dsync(b);
+      if (hc.max_win <= 256 || (best_w < 0 && hc.max_win <= SNF_WIN_MAXCAP)) { best_w = W; best_occ = hc.n_occ; best_max = hc.max_win; }
+      if (hc.max_win <= 256) break;
+    }
+    if (best_w >= 0) {
+      if (v.win_bits != best_w) { v.NW = win_layout(best_w, off); v.win_bits = best_w; v.t_win_off = upload_vec(b, off); dsync(b); }
+      v.front = 1; b->h_n_occ = best_occ; b->win_cap = best_max <= 64 ? 64 : best_max <= 256 ? 256 : SNF_WIN_MAXCAP;
+    }
+    if (v.prof) fprintf(stderr, "[SNF_PROF] window front end: %s (W = %d: %lld windows, %lld occupied, largest %lld leads)\n", v.front ? "on" : "off",
+                        v.win_bits, (long long)v.NW, (long long)best_occ, (long long)best_max);
   }
   {  // ALT stage output (HBM; every ALT is the sequence of one lead of its cluster, so all of them together fit the pool) and
      // the output stage: at most one record per position behind the sort
@@ -1093,6 +1151,31 @@ void enqueue_keys(snf_batch_impl* b) {
   }
 }
 
+// the window front end (snf_stage_window.h): from the input leads to the seed table and the packed lead records in six launches
+void enqueue_window_front(snf_batch_impl* b) {
+  SNF_TRACE("A: window front end");
+  View& v = b->v;
+  const int64_t N = v.N, NW = v.NW, n_occ = b->h_n_occ;
+  if (N <= 0 || n_occ <= 0) return;
+  Scope _all(b, "front_window", N * 21);
+  LAUNCH_Q(w1_hist, v, N, 0);
+  FUSED(w2a_sums, NW);
+  FUSED(w2b_offsets, NW);
+  LAUNCH_Q(w3_scatter, v, N, 0);
+  auto wave_per_window = [&](auto k64, auto k256, auto k1024, const char* name) {
+    Scope* sc = b->time_all ? new Scope(b, name, 0) : nullptr;
+    if (b->win_cap == 64) hipLaunchKernelGGL(k64, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
+    else if (b->win_cap == 256) hipLaunchKernelGGL(k256, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
+    else hipLaunchKernelGGL(k1024, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
+    delete sc;
+    SNF_HIP(hipGetLastError());
+  };
+  wave_per_window(w4_local<64>, w4_local<256>, w4_local<SNF_WIN_MAXCAP>, "w4_local");
+  FUSED(w5a_sums, n_occ);
+  FUSED(w5b_offsets, n_occ);
+  wave_per_window(w6_emit<64>, w6_emit<256>, w6_emit<SNF_WIN_MAXCAP>, "w6_emit");
+}
+
 void run_call_candidates(snf_batch_impl* b) {
   SNF_TRACE("snf_batch_call_candidates (enqueue)");
   b->pass_idle = false;
@@ -1114,23 +1197,28 @@ void run_call_candidates(snf_batch_impl* b) {
   b->finalize_runs = 0;
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
-  enqueue_keys(b);
+  const bool front = v.front && b->fused && N > 0;
+  if (front) enqueue_window_front(b); else enqueue_keys(b);
   if (N > 0) {
     if (!b->fused) {
       uint32_t* tails[] = {v.headflag, v.eligflag, v.fN, v.fL, v.runflag, v.clflag, v.rcflag, v.cdflag};
       for (auto p : tails) dzero(b, p + N, sizeof(uint32_t));
     }
+    if (!front) {
     if (v.key32) prim_sort_pairs<uint32_t>(b, (uint32_t*)v.key_in, (uint32_t*)v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
     else prim_sort_pairs<uint64_t>(b, v.key_in, v.key_out, v.val_in, v.val_out, N, v.key_nbits + 1, "sort_lead_keys");
+    }
     if (b->fused) {
     // flag -> device-wide scan -> emit chains as "flags + tile sums" / "tile prefix + block scan + emit" kernel pairs
     // (snf_fused.h): 13 launches for stages A-C instead of 26 (each rocPRIM scan is an init kernel + a scan kernel)
+    if (!front) {
     FUSED(a2k_heads, N);
     FUSED(a3k_bins, N);
     { Scope _s(b, "a4_binstats", N * 16); FUSED(a4k_binstats, N); }
     FUSED(a5k_leadflags, N);
     { Scope _s(b, "a6_scatter", N * 16); FUSED(a6k_scatter, N); }
     FUSED(a7k_seeds, N);
+    }
     { Scope _s(b, "b1_seedmetrics", N * 8); FUSED(b1k_seedmetrics, N); }
     FUSED(b2k_runs, N);
     LAUNCH(c1_mergeruns, v, N, N * 8);
@@ -1947,7 +2035,7 @@ void do_fetch_clusters(snf_batch_impl* b, int stage, snf_clusters_t* out) {
     // parity aid; the calls are the same either way) and the batch stays unfiltered from here on
     const bool fin = b->finalized;
     full_sync(b);
-    v.prefilter = 0; v.NS = v.N;
+    v.prefilter = 0; v.front = 0; v.NS = v.N;
     run_call_candidates(b);
     if (fin) run_finalize(b);
   }

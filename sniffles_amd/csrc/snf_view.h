@@ -18,6 +18,8 @@ struct Counts {
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
   int64_t n_kept;            // leads the occupancy prefilter lets through to the sort (a0_*; == NS whenever the prefilter is on)
+  int64_t n_occ;             // window front end (snf_stage_window.h): occupied windows of this pass
+  int64_t max_win;           // ... and the largest window (only formed at upload, w0_stats)
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
@@ -72,7 +74,7 @@ struct ClusterHdr { int32_t h, lo, n, grp; int32_t repeat, _pad[3]; };
 
 // tile-sum slots of the fused flag -> scan -> emit chains (snf_fused.h)
 enum { TS_BINS = 0, TS_SEEDS = 1, TS_LEADS = 2 /* and 3 */, TS_RUNS = 4, TS_CLUSTERS = 5, TS_REFINED = 6, TS_CALLS = 7, TS_RNAMES = 8, TS_KEEP = 9,
-       TS_OUT = 10 /* 11, 12 */, TS_SLOTS = 13 };
+       TS_OUT = 10 /* 11, 12 */, TS_WIN = 13 /* 14 */, TS_WINC = 15 /* 16, 17 */, TS_SLOTS = 18 };
 
 // totals and layout of the output block (f* kernels, snf_stage_out.h); copied to the pinned result block by z1_results
 struct OutHdr {
@@ -164,6 +166,17 @@ struct View {
   const int64_t* t_cell_off;  // [T+1] first cell of task t (cells of a task: SNF_NTYPES x (contig_len / binsize + 1))
   uint64_t* pf_key;           // [N] sort key per input lead (uint32_t when key32), written by a1_keys
   uint32_t *pf_keep, *pf_scan;  // [N+1] keep flag per input lead / its exclusive scan
+  // ---- window front end (snf_stage_window.h): leads bucketed by WINDOW = 2^win_bits consecutive bins of one (task, svtype), every
+  // occupied window ordered and binned by one wave.  Replaces the prefilter + sort + a2..a7 chain when `front` is set.
+  int32_t front;              // 1: on
+  int32_t win_bits;           // W
+  int64_t NW;                 // window slots of the batch (dense: per task SNF_NTYPES x windows of its contig)
+  const int64_t* t_win_off;   // [T+1] first window of task t
+  uint32_t *wcnt, *wfill;     // [NW+1] leads per window / fill cursor of the scatter (both zero between passes)
+  uint32_t* wbase;            // [NW+1] bucket offsets (exclusive scan of wcnt)
+  uint32_t* wlist;            // [n_occ] occupied windows, ascending
+  uint32_t *ws_seeds, *ws_nf, *ws_nl;   // [n_occ+1] per occupied window: seeds / `leads` / `leads_long` it contributes, then their exclusive scans
+  uint64_t* whead;            // [N] per seed head (bucket position): leads with a length | leads << 16 | hap 1 << 32 | hap 2 << 48
   // ---- stage A: binning (sorted position p in [0,NS))
   uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
   int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
