@@ -882,7 +882,36 @@ def wall_clock(cfg, tasks, device):
         n2 += len(task.finalize_candidates(cands, True, cfg))
         task.close()
     t6 = time.perf_counter()
-    return dict(batched=batched, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
+    # the INPUT half of the object boundary: Lead objects -> LeadProvider.record_lead / record_read -> TaskInput columns
+    # (leadprov.py:400-418 on the reference's side).  Measured on the smallest contig task of the workload (building the Lead objects
+    # themselves is the extraction's work and is not timed); the genome figure is that rate x all signatures
+    ingest = None
+    try:
+        from sniffles_amd import leadprov
+        ti_s = min(tasks, key=lambda t: t.n_leads)
+        objs = list(leadprov.iter_leads(ti_s))
+        rs_, re_, hp_ = ti_s.read_start.tolist(), ti_s.read_end.tolist(), ti_s.read_hp.tolist()
+        lp = leadprov.LeadProvider(cfg, 0, ti_s.contig, contig_len=ti_s.contig_len)
+        ti0 = time.perf_counter()
+        for ld in objs:
+            lp.record_lead(ld, 0)
+        for a_, b_, c_ in zip(rs_, re_, hp_):
+            lp.record_read(a_, b_, c_)
+        ti1 = time.perf_counter()
+        lp.to_task_input(ti_s.task_id, 0, None, ti_s.qc_nm_threshold)
+        ti2 = time.perf_counter()
+        n_all_leads = sum(t.n_leads for t in tasks)
+        per_lead = (ti2 - ti0) / max(1, ti_s.n_leads)
+        ingest = dict(contig=ti_s.contig, leads=int(ti_s.n_leads), reads=int(ti_s.n_reads), record_ms=round((ti1 - ti0) * 1e3, 2),
+                      to_task_input_ms=round((ti2 - ti1) * 1e3, 2), us_per_lead=round(per_lead * 1e6, 3),
+                      ingest_ms_genome_one_core=round(per_lead * n_all_leads * 1e3, 1),
+                      ingest_ms_largest_task=round(per_lead * max(t.n_leads for t in tasks) * 1e3, 1),
+                      note="record_lead / record_read append; to_task_input = ONE walk over the Lead objects in C (_snf_fast.lead_columns) + name "
+                           "interning; one process per contig in the reference's layout: the largest task bounds the wall clock")
+        del objs
+    except Exception as e:  # noqa: BLE001
+        ingest = f"failed: {type(e).__name__}: {e}"
+    return dict(batched=batched, ingest=ingest, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
                 per_task_execute=dict(end_to_end_ms=round((t8 - t7) * 1e3, 2), tasks=len(tasks), svcalls=n3),
                 note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
                      "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, sorted; "

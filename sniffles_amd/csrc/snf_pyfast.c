@@ -842,7 +842,145 @@ done:
   return ret;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * lead_columns(leads: list, cols: dict[str, writable buffer], svt: dict[str, int], src: dict[str, int], svlen_none: int,
+ *              seq_none: int, ps_none: int, contig: str)
+ *   -> (qnames: list[str] unique in first-seen order, ps: list[str] unique first-seen, contigs: list[str] unique first-seen, pool: bytes)
+ * The input side of the drop-in (reference `Lead`, leadprov.py:34-56; `LeadProvider.record_lead`, :400-418): ONE walk over the Lead
+ * objects fills the typed columns of a TaskInput (sniffles_amd/soa.py LEAD_FIELDS).  The string attributes the path only compares
+ * (read_qname, phase_set, bnd_info.mate_contig) are interned to first-seen indices here (columns qname_id / ps_rank / mate_contig);
+ * the caller turns those into ranks in Python string order with one sort of the unique names.  The INS sequences are appended to
+ * one pool (seq_off / seq_len).  Pure marshalling: the pure-Python twin is leadprov.LeadProvider._columns_py.
+ */
+typedef struct { Py_buffer b; int ok; } Col;
+static int col_get(PyObject* cols, const char* name, Py_ssize_t n, Py_ssize_t item, Col* c) {
+  c->ok = 0;
+  PyObject* o = PyDict_GetItemString(cols, name);
+  if (!o) { PyErr_Format(PyExc_KeyError, "column %s missing", name); return -1; }
+  if (PyObject_GetBuffer(o, &c->b, PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) return -1;
+  c->ok = 1;
+  if (c->b.len != n * item) { PyErr_Format(PyExc_ValueError, "column %s has the wrong size", name); return -1; }
+  return 0;
+}
+static long intern_first_seen(PyObject* dict, PyObject* list, PyObject* key) {   /* index of key in list, appended if new; -1 on error */
+  PyObject* v = PyDict_GetItemWithError(dict, key);
+  if (v) return PyLong_AsLong(v);
+  if (PyErr_Occurred()) return -1;
+  const long k = (long)PyList_GET_SIZE(list);
+  PyObject* kv = PyLong_FromLong(k);
+  if (!kv || PyDict_SetItem(dict, key, kv) != 0 || PyList_Append(list, key) != 0) { Py_XDECREF(kv); return -1; }
+  Py_DECREF(kv);
+  return k;
+}
+static PyObject* py_lead_columns(PyObject* self, PyObject* args) {
+  PyObject *leads, *cols, *svt, *src, *contig;
+  long long svlen_none, seq_none, ps_none;
+  if (!PyArg_ParseTuple(args, "O!O!O!O!LLLU", &PyList_Type, &leads, &PyDict_Type, &cols, &PyDict_Type, &svt, &PyDict_Type, &src,
+                        &svlen_none, &seq_none, &ps_none, &contig)) return NULL;
+  const Py_ssize_t n = PyList_GET_SIZE(leads);
+  enum { C_RS, C_RE, C_QS, C_QE, C_SVLEN, C_RLEN, C_QN, C_RID, C_PS, C_MC, C_MP, C_SLEN, C_SOFF, C_NM, C_SVT, C_STR, C_MAPQ, C_SRC,
+         C_HAP, C_SA, C_BF, C_BR, NCOL };
+  static const char* names[NCOL] = {"ref_start", "ref_end", "qry_start", "qry_end", "svlen", "read_len", "qname_id", "read_id", "ps_rank",
+                                    "mate_contig", "mate_ref_start", "seq_len", "seq_off", "nm", "svtype", "strand", "mapq", "source",
+                                    "hap", "is_sa", "bnd_is_first", "bnd_is_reverse"};
+  static const int items[NCOL] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 1, 1, 1, 1, 1, 1, 1, 1};
+  Col c[NCOL]; memset(c, 0, sizeof(c));
+  PyObject *qd = NULL, *ql = NULL, *pd = NULL, *pl = NULL, *cd = NULL, *cl = NULL, *pool = NULL, *out = NULL;
+  PyObject *a_read_id = NULL, *a_qname = NULL, *a_rs = NULL, *a_re = NULL, *a_qs = NULL, *a_qe = NULL, *a_strand = NULL, *a_mapq = NULL, *a_nm = NULL,
+           *a_source = NULL, *a_svtype = NULL, *a_svlen = NULL, *a_seq = NULL, *a_bnd = NULL, *a_hap = NULL, *a_ps = NULL, *a_sa = NULL, *a_rlen = NULL,
+           *a_mc = NULL, *a_mp = NULL, *a_bf = NULL, *a_br = NULL;
+  int fail = 1;
+  for (int k = 0; k < NCOL; k++) if (col_get(cols, names[k], n, items[k], &c[k]) != 0) goto done;
+#define ATTR(var, nm) if (!(var = PyUnicode_InternFromString(nm))) goto done;
+  ATTR(a_read_id, "read_id") ATTR(a_qname, "read_qname") ATTR(a_rs, "ref_start") ATTR(a_re, "ref_end") ATTR(a_qs, "qry_start") ATTR(a_qe, "qry_end")
+  ATTR(a_strand, "strand") ATTR(a_mapq, "mapq") ATTR(a_nm, "nm") ATTR(a_source, "source") ATTR(a_svtype, "svtype") ATTR(a_svlen, "svlen")
+  ATTR(a_seq, "seq") ATTR(a_bnd, "bnd_info") ATTR(a_hap, "hap") ATTR(a_ps, "phase_set") ATTR(a_sa, "is_sa") ATTR(a_rlen, "read_len")
+  ATTR(a_mc, "mate_contig") ATTR(a_mp, "mate_ref_start") ATTR(a_bf, "is_first") ATTR(a_br, "is_reverse")
+  qd = PyDict_New(); ql = PyList_New(0); pd = PyDict_New(); pl = PyList_New(0); cd = PyDict_New(); cl = PyList_New(0);
+  if (!qd || !ql || !pd || !pl || !cd || !cl) goto done;
+  if (intern_first_seen(cd, cl, contig) < 0) goto done;            /* the task's own contig is always in the table (index 0) */
+  {
+    /* pass 1: sequence bytes */
+    int64_t total = 0;
+    for (Py_ssize_t i = 0; i < n; i++) {
+      PyObject* q = PyObject_GetAttr(PyList_GET_ITEM(leads, i), a_seq);
+      if (!q) goto done;
+      if (q != Py_None) {
+        if (!PyUnicode_Check(q)) { Py_DECREF(q); PyErr_SetString(PyExc_TypeError, "Lead.seq must be str or None"); goto done; }
+        if (PyUnicode_MAX_CHAR_VALUE(q) > 255) { Py_DECREF(q); PyErr_SetString(PyExc_ValueError, "Lead.seq must be latin-1"); goto done; }
+        total += (int64_t)PyUnicode_GET_LENGTH(q);
+      }
+      Py_DECREF(q);
+    }
+    pool = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
+    if (!pool) goto done;
+    char* pb = PyBytes_AS_STRING(pool);
+    int64_t off = 0;
+    int32_t *rs = (int32_t*)c[C_RS].b.buf, *re = (int32_t*)c[C_RE].b.buf, *qs = (int32_t*)c[C_QS].b.buf, *qe = (int32_t*)c[C_QE].b.buf,
+            *svl = (int32_t*)c[C_SVLEN].b.buf, *rl = (int32_t*)c[C_RLEN].b.buf, *psr = (int32_t*)c[C_PS].b.buf, *mc = (int32_t*)c[C_MC].b.buf,
+            *mp = (int32_t*)c[C_MP].b.buf, *sl = (int32_t*)c[C_SLEN].b.buf;
+    uint32_t *qn = (uint32_t*)c[C_QN].b.buf, *rid = (uint32_t*)c[C_RID].b.buf;
+    int64_t* so = (int64_t*)c[C_SOFF].b.buf;
+    double* nm = (double*)c[C_NM].b.buf;
+    uint8_t *svtc = (uint8_t*)c[C_SVT].b.buf, *str = (uint8_t*)c[C_STR].b.buf, *mq = (uint8_t*)c[C_MAPQ].b.buf, *srcc = (uint8_t*)c[C_SRC].b.buf,
+            *hp = (uint8_t*)c[C_HAP].b.buf, *sa = (uint8_t*)c[C_SA].b.buf, *bf = (uint8_t*)c[C_BF].b.buf, *br = (uint8_t*)c[C_BR].b.buf;
+#define GET(var, attr) PyObject* var = PyObject_GetAttr(ld, attr); if (!var) goto done;
+#define AS_I32(dst, obj) { const long long _x = PyLong_AsLongLong(obj); Py_DECREF(obj); if (_x == -1 && PyErr_Occurred()) goto done; dst = (int32_t)_x; }
+    for (Py_ssize_t i = 0; i < n; i++) {
+      PyObject* ld = PyList_GET_ITEM(leads, i);
+      { GET(o, a_rs) AS_I32(rs[i], o) } { GET(o, a_re) AS_I32(re[i], o) } { GET(o, a_qs) AS_I32(qs[i], o) } { GET(o, a_qe) AS_I32(qe[i], o) }
+      { GET(o, a_svlen) if (o == Py_None) { Py_DECREF(o); svl[i] = (int32_t)svlen_none; } else AS_I32(svl[i], o) }
+      { GET(o, a_rlen) if (o == Py_None) { Py_DECREF(o); rl[i] = 0; } else AS_I32(rl[i], o) }
+      { GET(o, a_read_id) const unsigned long long x = PyLong_AsUnsignedLongLongMask(o); Py_DECREF(o); if (PyErr_Occurred()) goto done; rid[i] = (uint32_t)x; }
+      { GET(o, a_mapq) AS_I32(psr[i], o) mq[i] = (uint8_t)psr[i]; }
+      { GET(o, a_nm) if (o == Py_None) { nm[i] = Py_NAN; Py_DECREF(o); } else { const double x = PyFloat_AsDouble(o); Py_DECREF(o); if (x == -1.0 && PyErr_Occurred()) goto done; nm[i] = x; } }
+      { GET(o, a_strand) const int minus = PyUnicode_Check(o) && PyUnicode_GET_LENGTH(o) == 1 && PyUnicode_READ_CHAR(o, 0) == '-'; Py_DECREF(o); str[i] = minus ? 1 : 0; }
+      { GET(o, a_sa) const int t = PyObject_IsTrue(o); Py_DECREF(o); if (t < 0) goto done; sa[i] = (uint8_t)t; }
+      { GET(o, a_hap) PyObject* h = PyNumber_Long(o); Py_DECREF(o); if (!h) goto done; const long x = PyLong_AsLong(h); Py_DECREF(h); if (x == -1 && PyErr_Occurred()) goto done; hp[i] = (uint8_t)x; }
+      { GET(o, a_svtype) PyObject* k = PyDict_GetItemWithError(svt, o); Py_DECREF(o); if (!k) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_KeyError, "unknown svtype"); goto done; } svtc[i] = (uint8_t)PyLong_AsLong(k); }
+      { GET(o, a_source) PyObject* k = PyDict_GetItemWithError(src, o); Py_DECREF(o); if (!k) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_KeyError, "unknown lead source"); goto done; } srcc[i] = (uint8_t)PyLong_AsLong(k); }
+      { GET(o, a_qname) const long k = intern_first_seen(qd, ql, o); Py_DECREF(o); if (k < 0) goto done; qn[i] = (uint32_t)k; }
+      { GET(o, a_ps) if (o == Py_None) { psr[i] = (int32_t)ps_none; Py_DECREF(o); } else { const long k = intern_first_seen(pd, pl, o); Py_DECREF(o); if (k < 0) goto done; psr[i] = (int32_t)k; } }
+      { GET(q, a_seq)
+        if (q == Py_None) { sl[i] = (int32_t)seq_none; so[i] = 0; }
+        else {
+          const Py_ssize_t L = PyUnicode_GET_LENGTH(q);
+          sl[i] = (int32_t)L; so[i] = off;
+          if (PyUnicode_KIND(q) == PyUnicode_1BYTE_KIND) memcpy(pb + off, PyUnicode_1BYTE_DATA(q), (size_t)L);
+          else for (Py_ssize_t k = 0; k < L; k++) pb[off + k] = (char)PyUnicode_READ_CHAR(q, k);
+          off += L;
+        }
+        Py_DECREF(q); }
+      mc[i] = -1; mp[i] = 0; bf[i] = 0; br[i] = 0;      /* -1: no bnd_info */
+      { GET(bi, a_bnd)
+        if (bi != Py_None) {
+          PyObject* x = PyObject_GetAttr(bi, a_mc); if (!x) { Py_DECREF(bi); goto done; }
+          const long k = intern_first_seen(cd, cl, x); Py_DECREF(x); if (k < 0) { Py_DECREF(bi); goto done; }
+          mc[i] = (int32_t)k;
+          x = PyObject_GetAttr(bi, a_mp); if (!x) { Py_DECREF(bi); goto done; }
+          { const long long y = PyLong_AsLongLong(x); Py_DECREF(x); if (y == -1 && PyErr_Occurred()) { Py_DECREF(bi); goto done; } mp[i] = (int32_t)y; }
+          x = PyObject_GetAttr(bi, a_bf); if (!x) { Py_DECREF(bi); goto done; } bf[i] = (uint8_t)(PyObject_IsTrue(x) == 1); Py_DECREF(x);
+          x = PyObject_GetAttr(bi, a_br); if (!x) { Py_DECREF(bi); goto done; } br[i] = (uint8_t)(PyObject_IsTrue(x) == 1); Py_DECREF(x);
+        }
+        Py_DECREF(bi); }
+    }
+#undef GET
+#undef AS_I32
+  }
+  out = Py_BuildValue("(OOOO)", ql, pl, cl, pool);
+  fail = 0;
+done:
+  for (int k = 0; k < NCOL; k++) if (c[k].ok) PyBuffer_Release(&c[k].b);
+  Py_XDECREF(qd); Py_XDECREF(ql); Py_XDECREF(pd); Py_XDECREF(pl); Py_XDECREF(cd); Py_XDECREF(cl); Py_XDECREF(pool);
+  Py_XDECREF(a_read_id); Py_XDECREF(a_qname); Py_XDECREF(a_rs); Py_XDECREF(a_re); Py_XDECREF(a_qs); Py_XDECREF(a_qe); Py_XDECREF(a_strand);
+  Py_XDECREF(a_mapq); Py_XDECREF(a_nm); Py_XDECREF(a_source); Py_XDECREF(a_svtype); Py_XDECREF(a_svlen); Py_XDECREF(a_seq); Py_XDECREF(a_bnd);
+  Py_XDECREF(a_hap); Py_XDECREF(a_ps); Py_XDECREF(a_sa); Py_XDECREF(a_rlen); Py_XDECREF(a_mc); Py_XDECREF(a_mp); Py_XDECREF(a_bf); Py_XDECREF(a_br);
+  if (fail) { Py_XDECREF(out); return NULL; }
+  return out;
+}
+
 static PyMethodDef methods[] = {
+    {"lead_columns", py_lead_columns, METH_VARARGS, "Lead objects -> typed TaskInput columns in one walk (input side of the drop-in)"},
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
     {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},

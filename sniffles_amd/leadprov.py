@@ -42,6 +42,27 @@ class Lead:
     read_len: int = 0
 
 
+def iter_leads(ti):
+    """The rows of a TaskInput as `Lead` objects, in arrival order - what a ported `iter_region` would hand to `record_lead`
+    (the inverse of `LeadProvider.to_task_input`; used by tests and by bench.py's ingest measurement)."""
+    from .soa import SVTYPES, SOURCES
+    L = ti.leads
+    pool = ti.seq_pool.tobytes()
+    cols = {k: L[k].tolist() for k in L}
+    for i in range(ti.n_leads):
+        svt = SVTYPES[cols["svtype"][i]]
+        sl, so, svlen = cols["seq_len"][i], cols["seq_off"][i], cols["svlen"][i]
+        ld = Lead(read_id=cols["read_id"][i], read_qname=ti.qname(cols["qname_id"][i]), contig=ti.contig,
+                  ref_start=cols["ref_start"][i], ref_end=cols["ref_end"][i], qry_start=cols["qry_start"][i], qry_end=cols["qry_end"][i],
+                  strand="-" if cols["strand"][i] else "+", mapq=cols["mapq"][i], nm=cols["nm"][i], source=SOURCES[cols["source"][i]], svtype=svt,
+                  svlen=None if svlen == int(SVLEN_NONE) else svlen, seq=None if sl < 0 else pool[so:so + sl].decode("latin-1"),
+                  hap=str(cols["hap"][i]), phase_set=ti.ps_name(cols["ps_rank"][i]), is_sa=bool(cols["is_sa"][i]), read_len=cols["read_len"][i])
+        if svt == "BND":
+            ld.bnd_info = SVCallBNDInfo(ti.contig_name(cols["mate_contig"][i]), cols["mate_ref_start"][i], bool(cols["bnd_is_first"][i]),
+                                        bool(cols["bnd_is_reverse"][i]))
+        yield ld
+
+
 class LeadProvider:
     def __init__(self, config, read_id_offset, contig: str, contig_len: int = None):
         self.config = config
@@ -52,7 +73,8 @@ class LeadProvider:
         self.read_id = read_id_offset
         self.read_count = 0
         self._leads = []
-        self._reads = []
+        import array
+        self._rs, self._re, self._rhp = array.array("i"), array.array("i"), array.array("B")      # typed growable read columns
         self._nmask = None
 
     def record_lead(self, ld: Lead, pos_leadtab: int = None) -> None:
@@ -60,7 +82,7 @@ class LeadProvider:
         self._leads.append(ld)
 
     def record_read(self, ref_start: int, ref_end: int, hp: int = 0) -> None:
-        self._reads.append((int(ref_start), int(ref_end), int(hp)))
+        self._rs.append(int(ref_start)); self._re.append(int(ref_end)); self._rhp.append(int(hp))
         self.read_count += 1
 
     def _mask_N_coverage(self, regions=None, fasta=None) -> None:
@@ -80,7 +102,43 @@ class LeadProvider:
             self._nmask = None
             logging.warning(f"Unable to mask N regions in coverage vector, reference could not be fetched: {e}")
 
+    def _columns_fast(self):
+        """The lead columns in ONE walk over the Lead objects (`_snf_fast.lead_columns`, csrc/snf_pyfast.c) instead of one Python
+        generator pass per field: (columns, qnames, ps names, contig names, pool), or None when the extension is not built."""
+        from .sv import _load_fast
+        fast = _load_fast()
+        if fast is None or not hasattr(fast, "lead_columns"):
+            return None
+        n = len(self._leads)
+        L = empty_leads(n)
+        ql, pl, cl, pool = fast.lead_columns(self._leads, L, SVT, SRC, int(SVLEN_NONE), int(SEQ_NONE), int(PS_NONE), self.contig)
+
+        def ranks(first_seen, extra=()):
+            """first-seen indices -> ranks in Python string order (the reference breaks ties on string order)"""
+            names = list(first_seen) + [x for x in extra if x not in set(first_seen)]
+            order = sorted(range(len(names)), key=names.__getitem__)
+            rank = np.empty(len(names), np.int64)
+            rank[order] = np.arange(len(names))
+            return [names[j] for j in order], rank
+        qn, qr = ranks(ql)
+        if n:
+            L["qname_id"][:] = qr[L["qname_id"]]
+        psn, pr = ranks(pl, ("NULL",))
+        if n:
+            has = L["ps_rank"] != PS_NONE
+            L["ps_rank"][has] = pr[L["ps_rank"][has]]
+        cn, cr = ranks(cl)
+        if n:
+            bnd = L["mate_contig"] >= 0
+            L["mate_contig"][bnd] = cr[L["mate_contig"][bnd]]
+            L["mate_contig"][~bnd] = 0
+        return L, qn, psn, cn, pool
+
     def to_task_input(self, task_id: int, sv_id_start: int, tandem_repeats, qc_nm_threshold: float) -> TaskInput:
+        fastcols = self._columns_fast() if not getattr(self, "_force_py", False) else None
+        if fastcols is not None:
+            L, qn, psn, cn, pool = fastcols
+            return self._finish_task_input(L, qn, psn, cn, pool, task_id, sv_id_start, tandem_repeats, qc_nm_threshold)
         n = len(self._leads)
         L = empty_leads(n)
         qn, qrank = intern_sorted([ld.read_qname for ld in self._leads])
@@ -121,13 +179,15 @@ class LeadProvider:
                 L["mate_ref_start"][i] = ld.bnd_info.mate_ref_start
                 L["bnd_is_first"][i] = bool(ld.bnd_info.is_first)
                 L["bnd_is_reverse"][i] = bool(ld.bnd_info.is_reverse)
-        reads = sorted(self._reads, key=lambda r: r[0])  # BAM order == ascending start; stable
+        return self._finish_task_input(L, qn, psn, cn, bytes(pool), task_id, sv_id_start, tandem_repeats, qc_nm_threshold)
+
+    def _finish_task_input(self, L, qn, psn, cn, pool, task_id, sv_id_start, tandem_repeats, qc_nm_threshold) -> TaskInput:
+        rs, re_, rhp = (np.frombuffer(a, dt) if len(a) else np.zeros(0, dt) for a, dt in ((self._rs, np.int32), (self._re, np.int32), (self._rhp, np.uint8)))
+        order = np.argsort(rs, kind="stable")  # BAM order == ascending start; stable
         clen = self.contig_len if self.contig_len is not None else self.end
         ti = TaskInput(task_id=task_id, contig=self.contig, contig_len=int(clen), sv_id_start=sv_id_start, leads=L,
                        seq_pool=np.frombuffer(bytes(pool), np.uint8).copy(),
-                       read_start=np.array([r[0] for r in reads], np.int32),
-                       read_end=np.array([r[1] for r in reads], np.int32),
-                       read_hp=np.array([r[2] for r in reads], np.uint8),
+                       read_start=np.ascontiguousarray(rs[order]), read_end=np.ascontiguousarray(re_[order]), read_hp=np.ascontiguousarray(rhp[order]),
                        tr_start=None if tandem_repeats is None else np.array([t[0] for t in tandem_repeats], np.int32),
                        tr_end=None if tandem_repeats is None else np.array([t[1] for t in tandem_repeats], np.int32),
                        qc_nm_threshold=qc_nm_threshold, qnames=qn, ps_names=psn, contig_names=cn)

@@ -178,3 +178,32 @@ def test_c_materialiser_equals_the_python_twin(oracle_mod):
             assert type(x) is type(y) and flat(x) == flat(y), (name, y.id)
             assert [type(v) for v in x.__dict__.values()] == [type(v) for v in y.__dict__.values()], (name, y.id)
             assert [type(v) for v in x.info.values()] == [type(v) for v in y.info.values()]
+
+
+def test_one_walk_lead_columns_equal_the_python_passes():
+    """`_snf_fast.lead_columns` (one walk over the Lead objects in C) fills the same TaskInput as the per-field Python passes:
+    every column, the interned name tables in Python string order, the sequence pool."""
+    import numpy as np
+    from sniffles_amd import sv
+    assert sv._load_fast() is not None and hasattr(sv._load_fast(), "lead_columns")
+    for name in ("bnd_stale_end", "phase_rescue", "consensus_quirks", "fuzz_4_2", "long_ins", "single_leads_noqc", "chr21_30x_mosaic"):
+        build, kw, _ = cases.ALL[name]
+        ti = build()
+        cfg = gu.make_config(kw, ti)
+        out = []
+        for force_py in (False, True):
+            lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+            lp._force_py = force_py
+            for ld in leads_of(ti):
+                lp.record_lead(ld, 0)
+            for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
+                lp.record_read(s, e, hp)
+            out.append(lp.to_task_input(ti.task_id, ti.sv_id_start, None, ti.qc_nm_threshold))
+        a, b = out
+        assert a.n_leads == b.n_leads == ti.n_leads
+        for f in a.leads:
+            x, y = a.leads[f], b.leads[f]
+            assert x.dtype == y.dtype and (np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)), (name, f)
+        assert a.qnames == b.qnames and a.ps_names == b.ps_names and a.contig_names == b.contig_names
+        assert np.array_equal(a.seq_pool, b.seq_pool)
+        assert np.array_equal(a.read_start, b.read_start) and np.array_equal(a.read_end, b.read_end) and np.array_equal(a.read_hp, b.read_hp)
