@@ -1,13 +1,15 @@
 #!/bin/bash
-# round 3 profile set of the default bench workload (BASELINE configs[1]):
-#   kernel statistics of the EXACT command the driver runs (two batches in flight, the default) + the line that traced run printed,
-#   kernel statistics + launch timeline with one batch in flight, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc
-#   passes; --pmc is never combined with anything but --kernel-trace), and the hash of the kernel sources they belong to
-#   (bench.py refuses to quote them for other sources).
-# usage: bash tools/r03_profile.sh <tag>      -> gpurun_out/prof_<tag>/  (copy into profiles/ as r03_*)
-TAG=${1:-r03}
+# tools/profile.sh TAG [nopmc]: the profile set of the default bench workload (BASELINE configs[1]) -> gpurun_out/prof_TAG/
+#   kernel_stats_default.csv   rocprofv3 --kernel-trace --stats of the EXACT command the driver runs (two batches in flight)
+#   bench_under_rocprof.json   the line that traced run printed
+#   kernel_stats.csv, timeline.txt   one batch in flight: kernel statistics and the launch timeline of one pass (tools/timeline.py)
+#   pmc_traffic.json           HBM traffic: FETCH_SIZE / WRITE_SIZE in separate --pmc passes (never combined with anything but
+#                              --kernel-trace), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (tools/pmc_parse.py)
+#   profile_meta.json          hash of the kernel sources the files belong to (bench.py refuses to quote them for other sources)
+# Copy what is to be judged into profiles/ as rNN_*.
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; cd $R
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O
 python -c "from sniffles_amd import build; import json; print(json.dumps(dict(csrc_sha=build._lib_digest(), command='python bench.py --gpus 1 --steps 20 --warmup 5 (CPU legs skipped)')))" > $O/profile_meta.json
 D="python bench.py --no-cpu-baseline --no-wall-clock --no-configs --gpus 1 --steps 20 --warmup 5"
@@ -24,4 +26,4 @@ done
 python tools/pmc_parse.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE > $O/pmc_traffic.json
 fi
 rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
-ls -la $O; head -c 400 $O/pmc_traffic.json; head -70 $O/timeline.txt
+ls -la $O; head -c 400 $O/pmc_traffic.json 2>/dev/null; head -70 $O/timeline.txt

@@ -16,7 +16,7 @@ def short(n):
     return n[:60]
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "a1_keys"
+marker = sys.argv[2] if len(sys.argv) > 2 else "z0_init"     # the first launch of a pass
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"]) for r in rows))
 starts = [i for i, e in enumerate(ev) if marker in e[3]]
 if len(starts) < 3:
