@@ -163,7 +163,7 @@ def main():
                     help="skip timing the unmodified reference (oracle/_ref) on the host cores; cpu_baseline.kind is then \"port\"")
     ap.add_argument("--no-wall-clock", action="store_true")
     ap.add_argument("--samples", type=int, default=10, help="config 4: samples of the population")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("SNF_BENCH_INFLIGHT", "2")),
                     help="batches in flight per GPU (host threads, each with its own batch handle and streams): the "
                          "device->host copies, host waits and launch-bound phases of one pass overlap the kernels of "
                          "the other.  1 = strictly one pass at a time.  (Measured in round 3, same box, three alternations: 2 in "
@@ -426,10 +426,9 @@ def run_calling(ctx):
         """One full pass of the hot path over group g on thread w's handle: candidates, finalize, D2H of the results."""
         batch = handles_box[0][w][g]
         t_a = time.perf_counter()
-        batch.call_candidates()
+        batch.run_pass()                      # call_candidates + finalize as one unit (snf_batch_pass: a HIP graph from the second pass on)
         t_b = time.perf_counter()
-        batch.finalize()
-        t_c = time.perf_counter()
+        t_c = t_b
         # the one host wait of the pass: the result block [records | read names | ALT bytes] is in pinned host memory when this
         # returns (N > 1: it stays in HBM for the gather, the export below is the wait)
         n = batch.fetch_raw(1) if not use_dist else 0
@@ -565,7 +564,7 @@ def run_calling(ctx):
                     bb = handles[w][g]
                     t_a = time.perf_counter()
                     bb.set_result_memory(*landing.memory(slot_of(p % NGEN, w, g)))
-                    bb.call_candidates(); bb.finalize()                # (both only enqueue)
+                    bb.run_pass()                                      # (enqueues only)
                     t_b = time.perf_counter()
                     nxt = queues[p].claim()                            # the next claim travels while the kernels run
                     t_c = time.perf_counter()

@@ -338,6 +338,13 @@ int snf_batch_call_candidates(snf_batch_t* b);
  * consensus.novel_from_reads), qc_sv_post_annotate, rescue_phasing. */
 int snf_batch_finalize(snf_batch_t* b);
 
+/* snf_batch_call_candidates + snf_batch_finalize back to back - the two statements of CallTask.execute
+ * (reference src/sniffles/parallel.py:264-266) - enqueued as ONE unit.  Same results as the two calls.  From the second pass of a
+ * handle on (same input: every launch size is known) the pass is replayed from a HIP graph captured per result configuration
+ * (output mode, result memory): one host call per pass instead of ~40 launches on four streams.  SNF_NO_GRAPH=1 keeps it eager.
+ * Returns 0, or 1 with snf_last_error(). */
+int snf_batch_pass(snf_batch_t* batch);
+
 /* What a stage-1 fetch returns (set before snf_batch_finalize; default SNF_OUT_CANDIDATES):
  *   SNF_OUT_CANDIDATES  every candidate of every task that did not raise, in candidate order - the list
  *                       Task.finalize_candidates returns (src/sniffles/parallel.py:129-201; its early exits are commented out)

@@ -68,6 +68,77 @@ SNF_D void tile_scan(const View& v, int slot0, const unsigned long long (&val)[K
   for (int k = 0; k < K; k++) off[k] = prefix[k] + excl[k];
 }
 
+// ---- the same chain in ONE launch: decoupled look-back.  A block takes a ticket (= its tile: tiles start in ticket order, so every
+// predecessor of a tile is running or done), scans its 256 elements, publishes the tile aggregate, sums the aggregates of the tiles
+// before it back to the nearest one whose inclusive prefix is known (64 predecessors per step, one per lane of wave 0), publishes its
+// own inclusive prefix and emits.  Every published word carries the tag of its launch - the pass (View::chain_epoch, a counter in
+// HBM that z0_init bumps) and the slot, which is used once per pass: nothing is zeroed between launches; the last ticket holder
+// resets the ticket counter.  Values stay below 2^38.
+#define SNF_CHAIN_TAG_SHIFT 38
+SNF_D int64_t chain_ticket(const View& v, int slot0, unsigned long long* lds) {
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(&v.chain_ticket[slot0], 1u);
+    if (t + 1 == gridDim.x) v.chain_ticket[slot0] = 0;      // every block holds its ticket: clean for the next launch on this slot
+    lds[0] = t;
+  }
+  __syncthreads();
+  const int64_t tile = (int64_t)lds[0];
+  __syncthreads();
+  return tile;
+}
+template <int K>
+SNF_D void chain_scan(const View& v, int slot0, int64_t tile, const unsigned long long (&val)[K], unsigned long long (&off)[K],
+                      unsigned long long (&total)[K], unsigned long long* lds) {
+  unsigned long long excl[K], tot[K];
+  block_exscan256<K>(val, excl, tot, lds);
+  const unsigned long long launch = (((unsigned long long)(*v.chain_epoch) & 0x7ffffull) << 5) | (unsigned long long)slot0;
+  const unsigned long long tagA = (launch * 4 + 1) << SNF_CHAIN_TAG_SHIFT, tagI = tagA + (1ull << SNF_CHAIN_TAG_SHIFT);
+  const unsigned long long vmask = (1ull << SNF_CHAIN_TAG_SHIFT) - 1ull;
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      unsigned long long* st = v.chain + ((int64_t)(slot0 + k) * v.chain_stride) * 2;
+      if (lane == 0 && tile > 0) st_agent_u64(&st[2 * tile], tagA | tot[k]);
+      unsigned long long ex = 0;
+      int64_t j = tile - 1;
+      bool done = tile == 0;
+      while (!done) {
+        const int64_t t = j - lane;
+        unsigned long long w = 0; int state = 2;      // (a lane before tile 0 stands for the empty prefix)
+        if (t >= 0) {
+          for (;;) {
+            const unsigned long long wi = ld_agent_u64(&st[2 * t + 1]);
+            if ((wi & ~vmask) == tagI) { w = wi & vmask; state = 2; break; }
+            const unsigned long long wa = ld_agent_u64(&st[2 * t]);
+            if ((wa & ~vmask) == tagA) { w = wa & vmask; state = 1; break; }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_s_sleep(1);
+#endif
+          }
+        }
+        const unsigned long long inc = __ballot(state == 2);
+        const int first = __ffsll((long long)inc) - 1;      // nearest tile with a known inclusive prefix (or the start)
+        unsigned long long part = (inc == 0 || lane <= first) ? w : 0ull;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+        ex += part;
+        if (inc) done = true; else j -= 64;
+      }
+      if (lane == 0) { st_agent_u64(&st[2 * tile + 1], tagI | (ex + tot[k])); lds[k] = ex; }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) { off[k] = lds[k] + excl[k]; total[k] = lds[k] + tot[k]; }
+  __syncthreads();
+}
+#define SNF_CHAIN_HEAD(name, slot)                                            \
+  __global__ void __launch_bounds__(256) name(const View v, int64_t n) {      \
+    __shared__ unsigned long long lds[24];                                    \
+    const int64_t tile = chain_ticket(v, slot, lds);                          \
+    const int64_t p = tile * 256 + threadIdx.x;
+
 // slots of the candidate stage (the ALT chain of finalize reuses 0..4 with direct sums)
 // (slot ids: enum TS_* in snf_view.h)
 
@@ -85,6 +156,7 @@ __global__ void __launch_bounds__(256) z0_init(const View v, int64_t n) {
   if (i <= T + 1) v.t_call_off[i] = 0;
   if (i < G) { v.grp_first_bin[i] = -1; v.grp_seed_lo[i] = -1; v.grp_seed_hi[i] = -1; v.grp_dirty[i] = 0; }
   if (i < TS_SLOTS * v.super_stride) v.tile_super[i] = 0;
+  if (i == 0) *v.chain_epoch += 1u;                          // tags of this pass's chain launches (chain_scan)
   if (v.wave_path && i < 3 * 64 * 16) v.big_cnt[i] = 0;      // lists of the big-cluster kernels (x_big)
   if (v.wave_path && i < 2 * 64 * 16) v.d2cnt[i] = 0;       // lists of the grouped call kernels (snf_wave_call_g.h)
   if (i == 0 && v.NS > 0) {
@@ -225,6 +297,60 @@ SNF_FUSED_HEAD(d3rk_rnames)
   if (p < n) {
     v.rnp[p] = (uint32_t)off[0];
     if (p == n - 1) { const int64_t tot = (int64_t)(off[0] + val[0]); v.rnp[n] = (uint32_t)tot; v.cnt->rn_total = tot; *v.res_rn_total = tot; }
+    if (!v.rn_defer) d3_rnames_emit(p, v);
+  }
+}
+
+// ---- single-launch forms of the pairs above (chain_scan)
+// B1 + B2: seed metrics, run cuts, run table
+SNF_CHAIN_HEAD(b12c_seedruns, TS_RUNS)
+  if (p < n) b1_seedmetrics_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.runflag[p] : 0ull}, off[1], tot[1];
+  chain_scan<1>(v, TS_RUNS, tile, val, off, tot, lds);
+  if (p < n) {
+    v.runscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { const int64_t nr = (int64_t)tot[0]; v.runscan[n] = (uint32_t)nr; v.cnt->n_runs = nr; v.run_first[nr] = (int32_t)v.cnt->n_seeds; }
+    b2_emit(p, v);
+  }
+}
+// C4: merged cluster table
+SNF_CHAIN_HEAD(c4c_clusters, TS_CLUSTERS)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.clflag[p] : 0ull}, off[1], tot[1];
+  chain_scan<1>(v, TS_CLUSTERS, tile, val, off, tot, lds);
+  if (p < n) {
+    v.clscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.clscan[n] = (uint32_t)tot[0]; v.cnt->n_clusters = (int64_t)tot[0]; }
+    c4_emit(p, v);
+  }
+}
+// D1b: refined cluster table
+SNF_CHAIN_HEAD(d1bc_rctable, TS_REFINED)
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.rcflag[p] : 0ull}, off[1], tot[1];
+  chain_scan<1>(v, TS_REFINED, tile, val, off, tot, lds);
+  if (p < n) {
+    v.rcscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.rcscan[n] = (uint32_t)tot[0]; v.cnt->n_rc = (int64_t)tot[0]; }
+    d1b_emit(p, v);
+  }
+}
+// D3: candidate compaction
+SNF_CHAIN_HEAD(d3cc_compact, TS_CALLS)
+  unsigned long long val[1] = {(p < n && p < v.cnt->n_rc) ? (unsigned long long)v.cdflag[p] : 0ull}, off[1], tot[1];
+  chain_scan<1>(v, TS_CALLS, tile, val, off, tot, lds);
+  if (p < n) {
+    v.cdscan[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.cdscan[n] = (uint32_t)tot[0]; v.cnt->n_calls = (int64_t)tot[0]; }
+    d3_compact_emit(p, v);
+  }
+}
+// D3c + D3d: sv ids, read-name counts, supporting read names
+SNF_CHAIN_HEAD(d3src_svid_rnames, TS_RNAMES)
+  if (p < n) d3_svid_body(p, v);
+  unsigned long long val[1] = {p < n ? (unsigned long long)v.rnf[p] : 0ull}, off[1], tot[1];
+  chain_scan<1>(v, TS_RNAMES, tile, val, off, tot, lds);
+  if (p < n) {
+    v.rnp[p] = (uint32_t)off[0];
+    if (p == n - 1) { v.rnp[n] = (uint32_t)tot[0]; v.cnt->rn_total = (int64_t)tot[0]; *v.res_rn_total = (int64_t)tot[0]; }
     if (!v.rn_defer) d3_rnames_emit(p, v);
   }
 }

@@ -275,6 +275,13 @@ struct snf_batch_impl {
   int finalize_runs = 0;          // finalize calls since the last call_candidates
   int rn_state = 0;               // supporting read names of the current candidates: 0 all written, 1 deferred (sizes only), 2 written for the kept calls
   int64_t pf_words = 0;           // prefilter bitmap size (uint32 words)
+  // a whole pass (call_candidates + finalize) as ONE HIP graph per result configuration (snf_batch_pass): captured on the second
+  // pass of a configuration - every launch size is known from the first -, replayed afterwards
+  struct PassGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int passes = 0; int rn_state = 0; int rn_defer = 0; size_t cap_out = 0, cap_alt = 0; };
+  std::map<std::tuple<void*, void*, int>, PassGraph> graphs;   // key: (result block, ALT block, output mode)
+  int graph_mode = 1;             // SNF_NO_GRAPH=1: 0
+  bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
+  int graph_eager_every = 8;      // with per-kernel timing on, every n-th pass of a configuration runs eagerly so that the HIP-event means keep coming (0: never)
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
@@ -479,6 +486,9 @@ void d2h_timed(snf_batch_impl* b, void* dst, const void* src, size_t bytes, cons
       SNF_HIP(hipGetLastError());                                                                       \
     }                                                                                                   \
   } while (0)
+
+// single-launch scan chains (snf_fused.h chain_scan)
+#define CHAIN(kern, n) FUSED(kern, n)
 
 // ---- primitives: stable radix sort (key,value) and exclusive scans ----
 template <class K>
@@ -905,7 +915,7 @@ void do_upload(snf_batch_impl* b) {
   }
   // window front end (snf_stage_window.h): same precondition as the prefilter (a one-lead bin can never seed a cluster); the window
   // width is chosen below, once the leads can be counted per window - the arrays are sized for the narrowest window tried
-  const int WIN_W_MAX = 10, WIN_W_MIN = 6;
+  const int WIN_W_MAX = getenv("SNF_WIN_BITS_MAX") ? atoi(getenv("SNF_WIN_BITS_MAX")) : 10, WIN_W_MIN = 6;   // (measured on the 30x genome: 10 beats 9 and 8)
   auto win_layout = [&](int W, std::vector<int64_t>& off) {
     const int bs = b->cfg.cluster_binsize > 0 ? b->cfg.cluster_binsize : 1;
     off.assign((size_t)T + 1, 0);
@@ -955,6 +965,10 @@ void do_upload(snf_batch_impl* b) {
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
   v.tile_stride = (int64_t)((N1 > (size_t)win_slots_max + 1 ? N1 : (size_t)win_slots_max + 1) / 256 + 2); v.tile_sums = dalloc<unsigned long long>(b, (size_t)v.tile_stride * TS_SLOTS);
   v.super_stride = v.tile_stride / 64 + 2; v.tile_super = dalloc<unsigned long long>(b, (size_t)v.super_stride * TS_SLOTS);
+  v.chain_stride = v.tile_stride; v.chain = dalloc<unsigned long long>(b, (size_t)v.chain_stride * TS_SLOTS * 2);
+  v.chain_ticket = dalloc<uint32_t>(b, TS_SLOTS + 2); v.chain_epoch = v.chain_ticket + TS_SLOTS;
+  dzero(b, v.chain, (size_t)v.chain_stride * TS_SLOTS * 16); dzero(b, v.chain_ticket, (TS_SLOTS + 2) * 4);   // (a recycled slab may hold another batch's tags)
+  v.chain_on = getenv("SNF_NO_CHAIN") == nullptr ? 1 : 0;
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
   { const int eb = getenv("SNF_E1_BATCH") ? atoi(getenv("SNF_E1_BATCH")) : 64; v.e1_batch = (eb == 2 || eb == 4 || eb == 8 || eb == 16 || eb == 32) ? eb : 64; }
@@ -1159,8 +1173,8 @@ void enqueue_window_front(snf_batch_impl* b) {
   if (N <= 0 || n_occ <= 0) return;
   Scope _all(b, "front_window", N * 21);
   LAUNCH_Q(w1_hist, v, N, 0);
-  FUSED(w2a_sums, NW);
-  FUSED(w2b_offsets, NW);
+  if (v.chain_on) CHAIN(w2c_offsets, NW);
+  else { FUSED(w2a_sums, NW); FUSED(w2b_offsets, NW); }
   LAUNCH_Q(w3_scatter, v, N, 0);
   auto wave_per_window = [&](auto k64, auto k256, auto k1024, const char* name) {
     Scope* sc = b->time_all ? new Scope(b, name, 0) : nullptr;
@@ -1171,8 +1185,8 @@ void enqueue_window_front(snf_batch_impl* b) {
     SNF_HIP(hipGetLastError());
   };
   wave_per_window(w4_local<64>, w4_local<256>, w4_local<SNF_WIN_MAXCAP>, "w4_local");
-  FUSED(w5a_sums, n_occ);
-  FUSED(w5b_offsets, n_occ);
+  if (v.chain_on) CHAIN(w5c_offsets, n_occ);
+  else { FUSED(w5a_sums, n_occ); FUSED(w5b_offsets, n_occ); }
   wave_per_window(w6_emit<64>, w6_emit<256>, w6_emit<SNF_WIN_MAXCAP>, "w6_emit");
 }
 
@@ -1219,13 +1233,19 @@ void run_call_candidates(snf_batch_impl* b) {
     { Scope _s(b, "a6_scatter", N * 16); FUSED(a6k_scatter, N); }
     FUSED(a7k_seeds, N);
     }
+    if (v.chain_on) { Scope _s(b, "b1_seedmetrics", N * 8); CHAIN(b12c_seedruns, N); }
+    else {
     { Scope _s(b, "b1_seedmetrics", N * 8); FUSED(b1k_seedmetrics, N); }
     FUSED(b2k_runs, N);
+    }
     LAUNCH(c1_mergeruns, v, N, N * 8);
     LAUNCH_Q(c2_validate, v, N, 0);
     LAUNCH_Q(c3_serial, v, 8 * (int64_t)T, 0);
+    if (v.chain_on) CHAIN(c4c_clusters, N);
+    else {
     FUSED(c4a_count, N);
     FUSED(c4k_clusters, N);
+    }
     } else {
     LAUNCH_Q(a2_heads, v, N, N * 12);
     prim_exscan<uint32_t>(b, v.headflag, v.headscan, N + 1, "scan_bins");
@@ -1262,7 +1282,8 @@ void run_call_candidates(snf_batch_impl* b) {
   }
   if (b->sched_readprep == 1 || b->sched_readprep == 3) enqueue_read_prep(b);  // while the long refine kernel keeps the main stream busy
   if (N > 0) {
-    if (b->fused) {
+    if (b->fused && v.chain_on) CHAIN(d1bc_rctable, N);
+    else if (b->fused) {
       FUSED(d1a_count, N);
       FUSED(d1bk_rctable, N);
     } else {
@@ -1298,7 +1319,8 @@ void run_call_candidates(snf_batch_impl* b) {
       hipLaunchKernelGGL(x_big<1>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-    if (b->fused) {
+    if (b->fused && v.chain_on) CHAIN(d3cc_compact, N);
+    else if (b->fused) {
       FUSED(d3a_count, N);
       FUSED(d3ck_compact, N);
     } else {
@@ -1318,7 +1340,8 @@ void run_call_candidates(snf_batch_impl* b) {
        // except the copy itself, through ev_rn)
       SNF_HIP(hipStreamWaitEvent(b->stream4, b->ev_fork, 0));
       hipStream_t prev = b->cur; b->cur = b->stream4;
-      if (N > 0) {
+      if (N > 0 && v.chain_on) { Scope _s(b, "d3_rnames", 0); CHAIN(d3src_svid_rnames, N); }
+      else if (N > 0) {
         FUSED(d3sk_svid, N);
         { Scope _s(b, "d3_rnames", 0); FUSED(d3rk_rnames, N); }
       } else *b->h_rn_total = 0;
@@ -1599,6 +1622,66 @@ void run_finalize(snf_batch_impl* b) {
   }
   LAUNCH_Q(z1_results, v, v.T + 1, 0);
   b->res_current = true;
+}
+
+// ---- one pass = Task.call_candidates + Task.finalize_candidates back to back (CallTask.execute, parallel.py:264-266), as a HIP graph
+// once the launch sizes of this handle are known.  The pass is ~40 dependent launches on four streams; replayed from a graph the
+// host enqueues it with one call and the device-side launch-to-launch gaps shrink.  Everything a pass needs from the host is
+// constant for a handle (same input): grids, pointers, modes - except the memory the result lands in and the output mode, which
+// key the graph.  Kernels take the pass-dependent state (counters, chain tags, window cursors) from HBM.
+bool pass_graph_ok(snf_batch_impl* b) {
+  const View& v = b->v;
+  return b->graph_mode && !b->graph_failed && b->have_hist && b->fused && v.front && v.chain_on && v.wave_path && !b->timeline && !b->time_all &&
+         v.NS > 0 && !b->readprep_each_pass && getenv("SNF_SERIAL") == nullptr;
+}
+void run_pass(snf_batch_impl* b) {
+  View& v = b->v;
+  if (!pass_graph_ok(b)) { run_call_candidates(b); run_finalize(b); return; }
+  // (the pinned blocks of the result are chosen by run_finalize from b->hb_out / hb_alt: stable once they have been sized by a first pass)
+  const auto key = std::make_tuple((void*)b->hb_out.p, (void*)b->hb_alt.p, v.out_mode);
+  auto& g = b->graphs[key];
+  if (g.exec && (g.cap_out != b->hb_out.cap || g.cap_alt != b->hb_alt.cap)) {      // the same address with another size: a new configuration
+    (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g = snf_batch_impl::PassGraph{};
+  }
+  g.passes++;
+  if (g.exec && !(b->timing && b->graph_eager_every > 0 && g.passes % b->graph_eager_every == 0)) {
+    b->pass_idle = false;
+    reset_timing(b);
+    SNF_HIP(hipGraphLaunch(g.exec, b->stream));
+    // host-side state the two calls leave behind
+    b->reads_ready = true; b->cov_avg_ready = true; b->finalized = true; b->finalize_runs = 1; b->res_current = true;
+    b->rn_state = g.rn_state; v.rn_defer = g.rn_defer; v.out_valid = 1;
+    return;
+  }
+  if (g.exec || g.passes < 2) { run_call_candidates(b); run_finalize(b); return; }    // eager: first pass of the configuration / timing pass
+  // capture
+  const bool tm = b->timing;
+  b->timing = false;
+  hipGraph_t graph = nullptr;
+  bool ok = hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    try { run_call_candidates(b); run_finalize(b); }
+    catch (...) { (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); b->timing = tm; b->graph_failed = true; throw; }
+    ok = hipStreamEndCapture(b->stream, &graph) == hipSuccess && graph != nullptr;
+  }
+  b->timing = tm;
+  hipGraphExec_t exec = nullptr;
+  if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec != nullptr;
+  if (!ok) {
+    (void)hipGetLastError();
+    if (graph) (void)hipGraphDestroy(graph);
+    b->graph_failed = true;
+    if (v.prof) fprintf(stderr, "[SNF_PROF] pass graph: capture failed, passes stay eager\n");
+    run_call_candidates(b); run_finalize(b);
+    return;
+  }
+  g.graph = graph; g.exec = exec; g.rn_state = b->rn_state; g.rn_defer = v.rn_defer; g.cap_out = b->hb_out.cap; g.cap_alt = b->hb_alt.cap;
+  if (v.prof) { size_t nn = 0; (void)hipGraphGetNodes(graph, nullptr, &nn); fprintf(stderr, "[SNF_PROF] pass graph: captured (%zu nodes)\n", nn); }
+  SNF_HIP(hipGraphLaunch(g.exec, b->stream));
+}
+void destroy_graphs(snf_batch_impl* b) {
+  for (auto& kv : b->graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
+  b->graphs.clear();
 }
 
 void collect_timings(snf_batch_impl* b) {
@@ -2265,6 +2348,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
+    b->graph_mode = getenv("SNF_NO_GRAPH") == nullptr ? 1 : 0;
+    if (const char* e = getenv("SNF_GRAPH_EAGER_EVERY")) b->graph_eager_every = atoi(e);
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
@@ -2310,6 +2395,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  destroy_graphs(b);
   dfree_all(b);
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
   for (auto& e : b->ext_ranges) (void)hipHostUnregister(e.first);
@@ -2328,6 +2414,15 @@ int snf_batch_call_candidates(snf_batch_t* bb) {
     if (!b || !b->uploaded) fail("batch not uploaded");
     SNF_HIP(hipSetDevice(b->device));
     run_call_candidates(b);
+  })
+}
+
+int snf_batch_pass(snf_batch_t* bb) {
+  SNF_TRY({
+    auto b = reinterpret_cast<snf_batch_impl*>(bb);
+    if (!b || !b->uploaded) fail("batch not uploaded");
+    SNF_HIP(hipSetDevice(b->device));
+    run_pass(b);
   })
 }
 
@@ -2389,8 +2484,8 @@ int snf_batch_set_result_memory(snf_batch_t* bb, void* block, int64_t block_byte
     auto b = reinterpret_cast<snf_batch_impl*>(bb);
     if (!b) fail("null batch");
     if ((block == nullptr) != (alt == nullptr) || block_bytes < 0 || alt_bytes < 0) fail("snf_batch_set_result_memory: both sections or none");
-    if (b->uploaded && !b->pass_idle) full_sync(b);     // (no pass of this batch is writing the old buffers)
     SNF_HIP(hipSetDevice(b->device));
+    if (b->uploaded && !b->pass_idle) full_sync(b);     // (no pass of this batch is writing the old buffers)
     if (!block) { b->hb_out.release(); b->hb_alt.release(); }
     else { b->hb_out.adopt(block, (size_t)block_bytes, b->ext_ranges); b->hb_alt.adopt(alt, (size_t)alt_bytes, b->ext_ranges); }
   })

@@ -88,6 +88,22 @@ SNF_HD void atomic_or_i32(int* p, int v) {
 #endif
 }
 
+// loads / stores that go to L2 (agent scope): the words blocks of one kernel publish to each other (snf_fused.h chain_scan)
+SNF_HD unsigned long long ld_agent_u64(const unsigned long long* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+SNF_HD void st_agent_u64(unsigned long long* p, unsigned long long x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = x;
+#endif
+}
+
 // ---- kernel definition / launch ---------------------------------------------------------------
 // A kernel is a body `void name##_body(int64_t i, const View& v)`; SNF_KERNEL wraps it.
 #define SNF_KERNEL(name, VIEW)                                                     \

@@ -109,6 +109,17 @@ SNF_FUSED_HEAD(w2b_offsets)
   }
 }
 
+SNF_CHAIN_HEAD(w2c_offsets, TS_WIN)      // (the pair above in one launch: snf_fused.h chain_scan)
+  const uint32_t c = p < n ? v.wcnt[p] : 0u;
+  unsigned long long val[2] = {(unsigned long long)c, c ? 1ull : 0ull}, off[2], tot[2];
+  chain_scan<2>(v, TS_WIN, tile, val, off, tot, lds);
+  if (p < n) {
+    v.wbase[p] = (uint32_t)off[0];
+    if (c) v.wlist[off[1]] = (uint32_t)p;
+    if (p == n - 1) { v.wbase[n] = (uint32_t)tot[0]; v.cnt->n_valid = (int64_t)tot[0]; v.cnt->n_occ = (int64_t)tot[1]; }
+  }
+}
+
 // W3: every lead into its window's bucket: (attributes << 32 | input index), any order inside the bucket
 __global__ void __launch_bounds__(256) w3_scatter(const View v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -260,6 +271,20 @@ SNF_FUSED_HEAD(w5b_offsets)
     if (p == n - 1) {
       const int64_t ns = (int64_t)(off[0] + val[0]);
       v.cnt->n_seeds = ns; v.cnt->n_bins = ns; v.cnt->NF = (int64_t)(off[1] + val[1]); v.cnt->NLL = (int64_t)(off[2] + val[2]);
+      v.eligscan[v.NS] = (uint32_t)ns;
+    }
+  }
+}
+
+SNF_CHAIN_HEAD(w5c_offsets, TS_WINC)     // (the pair above in one launch)
+  unsigned long long val[3] = {p < n ? (unsigned long long)v.ws_seeds[p] : 0ull, p < n ? (unsigned long long)v.ws_nf[p] : 0ull,
+                               p < n ? (unsigned long long)v.ws_nl[p] : 0ull}, off[3], tot[3];
+  chain_scan<3>(v, TS_WINC, tile, val, off, tot, lds);
+  if (p < n) {
+    v.ws_seeds[p] = (uint32_t)off[0]; v.ws_nf[p] = (uint32_t)off[1]; v.ws_nl[p] = (uint32_t)off[2];
+    if (p == n - 1) {
+      const int64_t ns = (int64_t)tot[0];
+      v.cnt->n_seeds = ns; v.cnt->n_bins = ns; v.cnt->NF = (int64_t)tot[1]; v.cnt->NLL = (int64_t)tot[2];
       v.eligscan[v.NS] = (uint32_t)ns;
     }
   }

@@ -254,6 +254,11 @@ struct View {
   uint8_t* alt_pin; int64_t alt_pin_cap; // the same section in pinned host memory (0: none); Counts::alt_in_pinned says which one a pass uses
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
   unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
+  // single-launch "flags -> exclusive scan -> emit" chains (snf_fused.h chain_scan): per slot and 256-element tile two words
+  // (tile aggregate, inclusive prefix), each tagged with the launch it belongs to; one ticket counter per slot
+  unsigned long long* chain; int64_t chain_stride; uint32_t* chain_ticket; uint32_t* chain_epoch; int32_t chain_on, _pad_chain;
+                             // chain_epoch: one word in HBM, bumped by z0_init at the start of every pass (a pass replayed from a HIP graph
+                             // has no host-side counter to take its tags from)
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains
   ConsDesc* cdesc;           // [n_cons] by cons id
 #ifdef SNF_WG_TRACE

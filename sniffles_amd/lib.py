@@ -86,7 +86,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
     for f in ("snf_extract_create", "snf_extract_upload", "snf_extract_run", "snf_extract_result", "snf_extract_result_meta",
               "snf_extract_device_view", "snf_batch_add_task_device"):
         getattr(lib, f).restype = C.c_int
-    for f in ("snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
+    lib.snf_batch_pass.argtypes = [vp]
+    for f in ("snf_batch_pass", "snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_device", "snf_batch_set_output", "snf_batch_set_result_memory",
               "snf_batch_timing_count",
               "snf_batch_timing_get", "snf_edit_distance_batch"):
@@ -169,6 +170,11 @@ class Batch:
 
     def finalize(self):
         _check(self.lib, self.lib.snf_batch_finalize(self._h))
+
+    def run_pass(self):
+        """`call_candidates()` + `finalize()` as one unit (`snf_batch_pass`): the same results; from the second pass of a handle on
+        the pass is replayed from a HIP graph (one host call instead of ~40 launches)."""
+        _check(self.lib, self.lib.snf_batch_pass(self._h))
 
     def sync(self):
         _check(self.lib, self.lib.snf_batch_sync(self._h))

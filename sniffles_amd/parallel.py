@@ -86,8 +86,7 @@ class Task:
         from .abi import OUT_CANDIDATES, OUT_EXECUTE
         self._open(config)
         self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
-        self._batch.call_candidates()
-        self._batch.finalize()            # (both only enqueue; the fetch is the one wait)
+        self._batch.run_pass()            # call_candidates + finalize (both only enqueue; the fetch is the one wait)
         res = self._batch.fetch(1, copy=False)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")

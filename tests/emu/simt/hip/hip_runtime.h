@@ -453,6 +453,10 @@ inline int dpp_at(const void* site, int old, int src, int ctrl, int row_mask, in
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) ::simt::dpp_at(SIMT_SITE, (old), (src), (ctrl), (rm), (bm), (bc))
 #define __builtin_amdgcn_s_memtime() 0ull
 #define __builtin_amdgcn_fence(...) ((void)0)      /* one thread runs at a time: program order is the memory order */
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(p, order, scope) (*(p))
+#define __hip_atomic_store(p, x, order, scope) ((void)(*(p) = (x)))
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_alignbyte(hi, lo, sh) ::simt::alignbyte((hi), (lo), (sh))   /* v_alignbyte_b32 */
 #define __shfl(...) ::simt::shfl_at(SIMT_SITE, __VA_ARGS__)
 #define __shfl_xor(...) ::simt::shfl_xor_at(SIMT_SITE, __VA_ARGS__)
@@ -578,6 +582,16 @@ static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (hipEvent_t)std::c
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { std::free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t_ms = simt::now_ms(); return hipSuccess; }
+/* graphs: not modelled - a capture cannot begin, so the library's passes stay eager on this tier (snf_lib.hip run_pass) */
+typedef struct simtGraph* hipGraph_t; typedef struct simtGraphExec* hipGraphExec_t; typedef struct simtGraphNode* hipGraphNode_t;
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 };
+static inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return 801; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { if (g) *g = nullptr; return 801; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, hipGraphNode_t*, char*, size_t) { if (e) *e = nullptr; return 801; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 801; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+static inline hipError_t hipGraphGetNodes(hipGraph_t, hipGraphNode_t*, size_t* n) { if (n) *n = 0; return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
