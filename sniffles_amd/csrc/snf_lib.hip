@@ -279,7 +279,10 @@ struct snf_batch_impl {
   // pass of a configuration - every launch size is known from the first -, replayed afterwards
   struct PassGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int passes = 0; int rn_state = 0; int rn_defer = 0; size_t cap_out = 0, cap_alt = 0; };
   std::map<std::tuple<void*, void*, int>, PassGraph> graphs;   // key: (result block, ALT block, output mode)
-  int graph_mode = 1;             // SNF_NO_GRAPH=1: 0
+  int graph_mode = 1;             // 1 (default): replay when no other batch of this process has a pass in flight - measured: a replayed pass is
+                                  // 4 % shorter alone (1.83 against 1.90 ms) and 2.5 % LONGER next to a second batch's pass (1.67 against 1.63 ms
+                                  // per step: two graphs interleave worse than two eager launch sequences); 2 (SNF_GRAPH=1): always; 0 (SNF_NO_GRAPH=1): never
+  bool in_flight = false;         // counted in g_passes_in_flight
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
   int graph_eager_every = 8;      // with per-kernel timing on, every n-th pass of a configuration runs eagerly so that the HIP-event means keep coming (0: never)
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
@@ -1629,13 +1632,18 @@ void run_finalize(snf_batch_impl* b) {
 // host enqueues it with one call and the device-side launch-to-launch gaps shrink.  Everything a pass needs from the host is
 // constant for a handle (same input): grids, pointers, modes - except the memory the result lands in and the output mode, which
 // key the graph.  Kernels take the pass-dependent state (counters, chain tags, window cursors) from HBM.
+std::atomic<int> g_passes_in_flight{0};
+void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; g_passes_in_flight.fetch_add(1); } }
+void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; g_passes_in_flight.fetch_sub(1); } }
 bool pass_graph_ok(snf_batch_impl* b) {
   const View& v = b->v;
+  if (b->graph_mode == 1 && g_passes_in_flight.load() > 1) return false;      // (this batch itself is counted)
   return b->graph_mode && !b->graph_failed && b->have_hist && b->fused && v.front && v.chain_on && v.wave_path && !b->timeline && !b->time_all &&
          v.NS > 0 && !b->readprep_each_pass && getenv("SNF_SERIAL") == nullptr;
 }
 void run_pass(snf_batch_impl* b) {
   View& v = b->v;
+  pass_begins(b);
   if (!pass_graph_ok(b)) { run_call_candidates(b); run_finalize(b); return; }
   // (the pinned blocks of the result are chosen by run_finalize from b->hb_out / hb_alt: stable once they have been sized by a first pass)
   const auto key = std::make_tuple((void*)b->hb_out.p, (void*)b->hb_alt.p, v.out_mode);
@@ -1777,6 +1785,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   int T = v.T;
   b->r_status.assign(T, 0); b->r_off.assign(T + 1, 0); b->r_cov.assign(T, NAN);
   full_sync(b);  // everything enqueued so far, incl. z1_results -> the pinned result block is current
+  pass_waited(b);
   if (b->h_cnt->overflow) fail(b->h_cnt->overflow & 2 ? "internal: hand-over list of the call kernels overflowed" : "internal: fused-sequence pool overflow");
   if (v.prof) {
     const Counts& c = *b->h_cnt;
@@ -2348,7 +2357,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
-    b->graph_mode = getenv("SNF_NO_GRAPH") == nullptr ? 1 : 0;
+    b->graph_mode = getenv("SNF_NO_GRAPH") != nullptr ? 0 : (getenv("SNF_GRAPH") != nullptr && atoi(getenv("SNF_GRAPH")) == 1) ? 2 : 1;
     if (const char* e = getenv("SNF_GRAPH_EAGER_EVERY")) b->graph_eager_every = atoi(e);
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
@@ -2396,6 +2405,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   if (b->ev_join) (void)hipEventDestroy(b->ev_join);
   for (auto& e : b->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   destroy_graphs(b);
+  pass_waited(b);
   dfree_all(b);
   b->hb_calls.release(); b->hb_out.release(); b->hb_alt.release(); b->hb_rn.release(); b->hb_res.release();
   for (auto& e : b->ext_ranges) (void)hipHostUnregister(e.first);
