@@ -937,7 +937,7 @@ void do_upload(snf_batch_impl* b) {
     const size_t W1 = (size_t)win_slots_max + 1;
     v.wcnt = dalloc<uint32_t>(b, W1); v.wfill = dalloc<uint32_t>(b, W1); v.wbase = dalloc<uint32_t>(b, W1);
     const size_t occ_max = (size_t)(N < win_slots_max ? N : win_slots_max) + 2;
-    v.wlist = dalloc<uint32_t>(b, occ_max); v.ws_seeds = dalloc<uint32_t>(b, occ_max); v.ws_nf = dalloc<uint32_t>(b, occ_max); v.ws_nl = dalloc<uint32_t>(b, occ_max);
+    v.wlist = dalloc<uint32_t>(b, 3 * occ_max); v.ws_seeds = dalloc<uint32_t>(b, occ_max); v.ws_nf = dalloc<uint32_t>(b, occ_max); v.ws_nl = dalloc<uint32_t>(b, occ_max);
     v.whead = dalloc<uint64_t>(b, N1);
     dzero(b, v.wcnt, W1 * 4); dzero(b, v.wfill, W1 * 4);
   }

@@ -103,8 +103,9 @@ SNF_FUSED_HEAD(w2b_offsets)
   unsigned long long val[2] = {(unsigned long long)c, c ? 1ull : 0ull}, off[2];
   tile_scan<2>(v, TS_WIN, val, off, lds);
   if (p < n) {
+    v.wcnt[p] = 0; v.wfill[p] = 0;      // spent / not yet used in this pass: both counters are clean for w3_scatter and the next pass
     v.wbase[p] = (uint32_t)off[0];
-    if (c) v.wlist[off[1]] = (uint32_t)p;
+    if (c) { v.wlist[3 * off[1]] = (uint32_t)p; v.wlist[3 * off[1] + 1] = c; v.wlist[3 * off[1] + 2] = (uint32_t)off[0]; }
     if (p == n - 1) { v.wbase[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_valid = (int64_t)(off[0] + val[0]); v.cnt->n_occ = (int64_t)(off[1] + val[1]); }
   }
 }
@@ -114,8 +115,9 @@ SNF_CHAIN_HEAD(w2c_offsets, TS_WIN)      // (the pair above in one launch: snf_f
   unsigned long long val[2] = {(unsigned long long)c, c ? 1ull : 0ull}, off[2], tot[2];
   chain_scan<2>(v, TS_WIN, tile, val, off, tot, lds);
   if (p < n) {
+    v.wcnt[p] = 0; v.wfill[p] = 0;      // spent / not yet used in this pass: both counters are clean for w3_scatter and the next pass
     v.wbase[p] = (uint32_t)off[0];
-    if (c) v.wlist[off[1]] = (uint32_t)p;
+    if (c) { v.wlist[3 * off[1]] = (uint32_t)p; v.wlist[3 * off[1] + 1] = c; v.wlist[3 * off[1] + 2] = (uint32_t)off[0]; }
     if (p == n - 1) { v.wbase[n] = (uint32_t)tot[0]; v.cnt->n_valid = (int64_t)tot[0]; v.cnt->n_occ = (int64_t)tot[1]; }
   }
 }
@@ -172,9 +174,8 @@ __global__ void __launch_bounds__(64) w4_local(const View v, int64_t n_unused) {
   __shared__ uint32_t sA[CAP], sB[CAP];      // per bin (at its head position): leads | leads with a length << 16;  hap 1 | hap 2 << 16
   const int lane = threadIdx.x;
   const int64_t k = blockIdx.x;
-  const uint32_t w = v.wlist[k];
-  const int n = (int)v.wcnt[w];
-  const int64_t base = v.wbase[w];
+  const int n = (int)v.wlist[3 * k + 1];                     // {window, leads, bucket offset}: one record per occupied window (w2)
+  const int64_t base = v.wlist[3 * k + 2];
   uint64_t e[E];
 #pragma unroll
   for (int j = 0; j < E; j++) {
@@ -296,9 +297,9 @@ __global__ void __launch_bounds__(64) w6_emit(const View v, int64_t n_unused) {
   constexpr int E = CAP / 64;
   const int lane = threadIdx.x;
   const int64_t k = blockIdx.x;
-  const uint32_t w = v.wlist[k];
-  const int n = (int)v.wcnt[w];
-  const int64_t base = v.wbase[w];
+  const uint32_t w = v.wlist[3 * k];
+  const int n = (int)v.wlist[3 * k + 1];
+  const int64_t base = v.wlist[3 * k + 2];
   const int64_t S0 = v.ws_seeds[k], F0 = v.ws_nf[k], L0 = v.ws_nl[k];
   int grp; int64_t bin0;
   win_decode(v, w, &grp, &bin0);
@@ -321,7 +322,6 @@ __global__ void __launch_bounds__(64) w6_emit(const View v, int64_t n_unused) {
       v.Lrec[qf] = rec;
     }
     if (f_long) v.LL[ql] = o;
-    if (f_norm || f_long) v.seqnull[o] = (a & SNF_WF_SEQNULL) ? 1 : 0;
     if (f_seed) {
       const uint64_t hd = v.whead[base + p];
       const int with_len = (int)(hd & 0xffffu), all = (int)((hd >> 16) & 0xffffu), h1 = (int)((hd >> 32) & 0xffffu), h2 = (int)(hd >> 48);
@@ -334,7 +334,6 @@ __global__ void __launch_bounds__(64) w6_emit(const View v, int64_t n_unused) {
     }
     cs += __popcll(bs); cf += __popcll(bn); cl += __popcll(bl);
   }
-  if (lane == 0) { v.wcnt[w] = 0; v.wfill[w] = 0; }      // the counters of this pass are spent: clean for the next one
 }
 
 }  // namespace snf

@@ -174,7 +174,7 @@ struct View {
   const int64_t* t_win_off;   // [T+1] first window of task t
   uint32_t *wcnt, *wfill;     // [NW+1] leads per window / fill cursor of the scatter (both zero between passes)
   uint32_t* wbase;            // [NW+1] bucket offsets (exclusive scan of wcnt)
-  uint32_t* wlist;            // [n_occ] occupied windows, ascending
+  uint32_t* wlist;            // [3 x n_occ] occupied windows, ascending: {window, leads, bucket offset}
   uint32_t *ws_seeds, *ws_nf, *ws_nl;   // [n_occ+1] per occupied window: seeds / `leads` / `leads_long` it contributes, then their exclusive scans
   uint64_t* whead;            // [N] per seed head (bucket position): leads with a length | leads << 16 | hap 1 << 32 | hap 2 << 48
   // ---- stage A: binning (sorted position p in [0,NS))
