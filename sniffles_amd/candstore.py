@@ -48,6 +48,94 @@ def _walk(tasks, samples_snf, config):
     return readers, order, blocks, block_cov, np.asarray(block_task, np.int64)
 
 
+_MATE_IDS = {}      # mate contig name -> id, process-wide: the ids inside cached column tables stay valid from merge to merge
+
+
+class ContigColumns:
+    """The candidates of ONE reader on ONE contig as columns, built once from the reader's blocks (`_snf_fast.collect` with the
+    reader alone: block, SV type, list order) and kept with the reader: a merge - and every later merge over the same readers, or
+    the parts of a scattered one - starts from these tables instead of walking `read_blocks` block by block and reading the
+    attributes off ~10^5 `SVCall` objects again.  `blk`: block start of every candidate; `cov`: {block start: `_COVERAGE` dict}."""
+
+    def __init__(self, reader, contig, sid, thr, fast):
+        starts = sorted(int(b) for b in reader.block_starts(contig))
+        per = [[reader.read_blocks(contig, b)] for b in starts]
+        self.cov = {b: (p[0][0]["_COVERAGE"] if p[0] is not None else None) for b, p in zip(starts, per)}
+        objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect(per, np.asarray([sid], np.int32), tuple(sv.TYPES), int(thr), _MATE_IDS)
+        self.objs = objs
+        self.rec = np.frombuffer(rec, abi.GROUP_CAND_DTYPE).copy()
+        self.blk = np.asarray(starts, np.int64)[np.frombuffer(cblk, np.int32)] if len(objs) else np.zeros(0, np.int64)
+        self.typ = np.frombuffer(ctyp, np.int32).astype(np.int64)
+        self.mate = np.frombuffer(mate, np.int32).reshape(-1, 2).copy()
+        self.aoff = np.frombuffer(aoff, np.int64).copy()
+        self.apool = np.frombuffer(apool, np.uint8).copy() if len(apool) else np.zeros(0, np.uint8)
+
+
+def reader_columns(reader, contig, sid, thr, fast):
+    """Cached `ContigColumns` of a reader that can list its blocks (`block_starts(contig)`); None for any other reader."""
+    if not hasattr(reader, "block_starts") or getattr(reader, "reqc", False):
+        return None
+    cache = reader.__dict__.setdefault("_snf_columns", {})
+    key = (contig, int(sid), int(thr))
+    if key not in cache:
+        cache[key] = ContigColumns(reader, contig, sid, thr, fast)
+    return cache[key]
+
+
+def _collect_from_columns(tasks, samples_snf, config, fast):
+    """What `_walk` + `collect` return, assembled from the readers' cached tables; None when a reader cannot provide them."""
+    readers = list(samples_snf.items())
+    order = [s["internal_id"] for s in config.snf_input_info]
+    pos_of = {sid: k for k, (sid, _) in enumerate(readers)}
+    thr = int(config.combine_support_threshold)
+    tabs = {}
+    for t in tasks:
+        for sid, r in readers:
+            if (sid, t.contig) not in tabs:
+                c = reader_columns(r, t.contig, sid, thr, fast)
+                if c is None:
+                    return None
+                tabs[(sid, t.contig)] = c
+    block_cov, block_task, parts = [], [], []
+    eb0 = 0
+    for ti, t in enumerate(tasks):
+        bis = np.asarray(t.block_indices, np.int64)
+        covs = [tabs[(s, t.contig)].cov if s in pos_of else None for s in order]
+        block_cov.extend([[c.get(b) if c is not None else None for c in covs] for b in t.block_indices])
+        block_task.extend([ti] * len(bis))
+        for sid, _ in readers:
+            c = tabs[(sid, t.contig)]
+            if not len(c.objs):
+                continue
+            eb = np.searchsorted(bis, c.blk)
+            ok = (eb < len(bis)) & (bis[np.minimum(eb, len(bis) - 1)] == c.blk)      # candidates of the blocks this task holds
+            parts.append((c, np.flatnonzero(ok), eb[ok] + eb0))
+        eb0 += len(bis)
+    if not parts:
+        return readers, order, block_cov, np.asarray(block_task, np.int64), ([], None, None, None, None, None, None)
+    rec = np.concatenate([c.rec[idx] for c, idx, _ in parts])
+    cblk = np.concatenate([e for _, _, e in parts]).astype(np.int32)
+    ctyp = np.concatenate([c.typ[idx] for c, idx, _ in parts]).astype(np.int32)
+    mate = np.concatenate([c.mate[idx] for c, idx, _ in parts])
+    objs = []
+    for c, idx, _ in parts:
+        objs.extend([c.objs[i] for i in idx.tolist()] if len(idx) != len(c.objs) else c.objs)
+    # ALT strings: one pool, offsets rebased
+    lens = np.concatenate([(c.aoff[1:] - c.aoff[:-1])[idx] for c, idx, _ in parts])
+    aoff = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    pools, base = [], 0
+    for c, idx, _ in parts:
+        if len(idx) == len(c.objs):
+            pools.append(c.apool[:int(c.aoff[-1])])
+        else:
+            a, l = c.aoff[:-1][idx], (c.aoff[1:] - c.aoff[:-1])[idx]
+            tot = int(l.sum())
+            src = np.repeat(a - (np.cumsum(l) - l), l) + np.arange(tot)
+            pools.append(c.apool[src])
+    apool = np.concatenate(pools) if pools else np.zeros(0, np.uint8)
+    return readers, order, block_cov, np.asarray(block_task, np.int64), (objs, rec, cblk, ctyp, mate, aoff, apool)
+
+
 def _regenotype(blocks, readers, config, device, _lib):
     """`--reqc`: candidates of SNF files older than 2.5.3 are genotyped again (parallel.py:507-508), one launch."""
     old = [k for k, (_, snf) in enumerate(readers) if getattr(snf, "reqc", False)]
@@ -85,20 +173,30 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
     n_tasks = len(tasks)
     tm = [("start", time.perf_counter())]
     mark = lambda name: tm.append((name, time.perf_counter()))  # noqa: E731
-    readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
-    mark("walk_blocks")
-    _regenotype(blocks, readers, config, device, _lib)
-    sids = np.asarray([sid for sid, _ in readers], np.int32)
-    mate_ids = {}
-    objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect(blocks, sids, tuple(sv.TYPES), int(config.combine_support_threshold), mate_ids)
-    n = len(objs)
-    mark("collect_columns")
-    if n == 0:
-        return [[] for _ in tasks]
-    rec = np.frombuffer(rec, abi.GROUP_CAND_DTYPE)
-    cblk = np.frombuffer(cblk, np.int32).astype(np.int64)
-    ctyp = np.frombuffer(ctyp, np.int32).astype(np.int64)
-    mate = np.frombuffer(mate, np.int32).reshape(-1, 2)
+    cached = _collect_from_columns(tasks, samples_snf, config, fast) if os.environ.get("SNF_COMBINE_NO_COLUMNS", "0") != "1" else None
+    if cached is not None:      # readers that list their blocks: their candidates are resident as columns (ContigColumns)
+        readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool) = cached
+        mark("walk_blocks")
+        n = len(objs)
+        mark("collect_columns")
+        if n == 0:
+            return [[] for _ in tasks]
+        cblk = cblk.astype(np.int64); ctyp = ctyp.astype(np.int64)
+        aoff, apool = np.ascontiguousarray(aoff, np.int64), np.ascontiguousarray(apool, np.uint8)
+    else:
+        readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
+        mark("walk_blocks")
+        _regenotype(blocks, readers, config, device, _lib)
+        sids = np.asarray([sid for sid, _ in readers], np.int32)
+        objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect(blocks, sids, tuple(sv.TYPES), int(config.combine_support_threshold), _MATE_IDS)
+        n = len(objs)
+        mark("collect_columns")
+        if n == 0:
+            return [[] for _ in tasks]
+        rec = np.frombuffer(rec, abi.GROUP_CAND_DTYPE)
+        cblk = np.frombuffer(cblk, np.int32).astype(np.int64)
+        ctyp = np.frombuffer(ctyp, np.int32).astype(np.int64)
+        mate = np.frombuffer(mate, np.int32).reshape(-1, 2)
     ctask = block_task[cblk]
     # ---- 2. sort into chain-major order (task, SV type, block, bin, visiting order) and cut the flush windows
     bin_min = int(config.combine_min_size)

@@ -279,9 +279,8 @@ struct snf_batch_impl {
   // pass of a configuration - every launch size is known from the first -, replayed afterwards
   struct PassGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int passes = 0; int rn_state = 0; int rn_defer = 0; size_t cap_out = 0, cap_alt = 0; };
   std::map<std::tuple<void*, void*, int>, PassGraph> graphs;   // key: (result block, ALT block, output mode)
-  int graph_mode = 1;             // 1 (default): replay when no other batch of this process has a pass in flight - measured: a replayed pass is
-                                  // 4 % shorter alone (1.83 against 1.90 ms) and 2.5 % LONGER next to a second batch's pass (1.67 against 1.63 ms
-                                  // per step: two graphs interleave worse than two eager launch sequences); 2 (SNF_GRAPH=1): always; 0 (SNF_NO_GRAPH=1): never
+  int graph_mode = 0;             // set at upload: 2 = replay (small batches, or SNF_GRAPH=1), 0 = eager, 1 = replay only while no other batch of
+                                  // this process has a pass in flight
   bool in_flight = false;         // counted in g_passes_in_flight
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
   int graph_eager_every = 8;      // with per-kernel timing on, every n-th pass of a configuration runs eagerly so that the HIP-event means keep coming (0: never)
@@ -971,7 +970,14 @@ void do_upload(snf_batch_impl* b) {
   v.chain_stride = v.tile_stride; v.chain = dalloc<unsigned long long>(b, (size_t)v.chain_stride * TS_SLOTS * 2);
   v.chain_ticket = dalloc<uint32_t>(b, TS_SLOTS + 2); v.chain_epoch = v.chain_ticket + TS_SLOTS;
   dzero(b, v.chain, (size_t)v.chain_stride * TS_SLOTS * 16); dzero(b, v.chain_ticket, (TS_SLOTS + 2) * 4);   // (a recycled slab may hold another batch's tags)
-  v.chain_on = getenv("SNF_NO_CHAIN") == nullptr ? 1 : 0;
+  // Single-launch chains and the pass graph pay where a pass is launch-bound, i.e. for small batches (measured on MI355X, same box:
+  // chr20 alone, 60 k signatures: 0.435 against 0.462 ms per step replayed from a graph; whole genome, 2.87 M signatures: the
+  // look-back chains cost what their launch pairs cost - 2 700 tiles queue behind each other at ~22 ns a tile: c4 59 us against
+  // 7.6 + 6.8 - and two replayed passes next to each other are 2.5 % SLOWER than two eager ones, 1.67 against 1.63 ms per step).
+  // SNF_CHAIN / SNF_GRAPH = 0 / 1 force either way.
+  const bool small_batch = N <= 400000;
+  v.chain_on = getenv("SNF_CHAIN") ? (atoi(getenv("SNF_CHAIN")) != 0) : (getenv("SNF_NO_CHAIN") ? 0 : (small_batch ? 1 : 0));
+  b->graph_mode = getenv("SNF_GRAPH") ? (atoi(getenv("SNF_GRAPH")) != 0 ? 2 : 0) : (getenv("SNF_NO_GRAPH") ? 0 : (small_batch ? 2 : 0));
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
   { const int eb = getenv("SNF_E1_BATCH") ? atoi(getenv("SNF_E1_BATCH")) : 64; v.e1_batch = (eb == 2 || eb == 4 || eb == 8 || eb == 16 || eb == 32) ? eb : 64; }
@@ -1638,7 +1644,7 @@ void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; 
 bool pass_graph_ok(snf_batch_impl* b) {
   const View& v = b->v;
   if (b->graph_mode == 1 && g_passes_in_flight.load() > 1) return false;      // (this batch itself is counted)
-  return b->graph_mode && !b->graph_failed && b->have_hist && b->fused && v.front && v.chain_on && v.wave_path && !b->timeline && !b->time_all &&
+  return b->graph_mode && !b->graph_failed && b->have_hist && b->fused && v.front && v.wave_path && !b->timeline && !b->time_all &&
          v.NS > 0 && !b->readprep_each_pass && getenv("SNF_SERIAL") == nullptr;
 }
 void run_pass(snf_batch_impl* b) {
@@ -2357,7 +2363,6 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
-    b->graph_mode = getenv("SNF_NO_GRAPH") != nullptr ? 0 : (getenv("SNF_GRAPH") != nullptr && atoi(getenv("SNF_GRAPH")) == 1) ? 2 : 1;
     if (const char* e = getenv("SNF_GRAPH_EAGER_EVERY")) b->graph_eager_every = atoi(e);
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);

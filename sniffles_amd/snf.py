@@ -324,6 +324,10 @@ class SNFileBase:
         finally:
             self._io.done()
 
+    def block_starts(self, contig) -> list:
+        """Block starts stored for `contig` (what `candstore.ContigColumns` walks once to keep the reader's candidates as columns)."""
+        return [int(k) for k in self.index.get(contig, {})]
+
     def get_all_blocks(self, contig: str) -> dict:
         return {start: self.read_blocks(contig, start)[0] for start in self.index.get(contig, {})}
 

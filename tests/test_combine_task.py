@@ -28,6 +28,10 @@ class BlocksReader:
             return None
         return [self.blocks[block_index]]
 
+    def block_starts(self, contig):
+        """(a reader that lists its blocks keeps its candidates as columns: candstore.ContigColumns)"""
+        return list(self.blocks) if contig == self.contig else []
+
 
 def run_case(name, _lib=None, reqc=False):
     doc = gu.load(name)
@@ -307,3 +311,30 @@ def test_columnar_store_single_sample_merge_emu(monkeypatch):
         assert len(col) == len(obj) and (len(col) > 0 or not no_qc)
         for a, b in zip(col, obj):
             assert list(a) == list(b) and a == b, a["id"]
+
+
+def test_cached_reader_columns_equal_the_block_walk_emu(monkeypatch):
+    """Readers that list their blocks keep their candidates as columns (`candstore.ContigColumns`): a second merge over the same
+    readers - also with another support threshold, and as two part tasks - starts from the cached tables and gives the calls of
+    the block-by-block walk (`SNF_COMBINE_NO_COLUMNS=1`)."""
+    import emu.emu as E
+    name = "combine_task_5samples_medians"
+    doc = gu.load(name)
+    exp = doc["expected"]
+
+    def merge(readers, extra, split, no_columns):
+        monkeypatch.setenv("SNF_COMBINE_NO_COLUMNS", "1" if no_columns else "0")
+        cfg = _twin_cfg(doc, extra)
+        if split:
+            half = exp["contig_len"] // 2 // cfg.snf_block_size * cfg.snf_block_size
+            tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg, _lib=E.lib()),
+                     parallel.CombineTask(id=9, sv_id=0, contig=exp["contig"], start=half + cfg.snf_block_size, end=exp["contig_len"], config=cfg, _lib=E.lib())]
+        else:
+            tasks = [parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())]
+        return [[_object_fields(c) for c in part] for part in parallel.CombineTask.execute_many(tasks, readers)]
+    readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+    for extra, split in (((), False), ((), True), (("--combine-support-threshold", "6"), False), ((), False)):
+        walk = merge({s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}, extra, split, True)
+        cached = merge(readers, extra, split, False)          # the SAME readers throughout: tables cached by (contig, sample, threshold)
+        assert cached == walk and sum(len(p) for p in cached) > 0, (extra, split)
+    assert len(readers[0].__dict__["_snf_columns"]) == 2       # two thresholds -> two tables; the part tasks reused the first

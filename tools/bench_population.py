@@ -32,6 +32,9 @@ class MemReader:
         b = self.blocks.get(contig, {}).get(block_index)
         return None if b is None else [b]
 
+    def block_starts(self, contig):
+        return list(self.blocks.get(contig, {}))
+
 
 def build_sample(cfg, tasks, device, sid):
     """Candidates of one sample (all contig tasks in one device batch) -> SNF blocks in memory (snf.py:90-98, 249-267)."""
