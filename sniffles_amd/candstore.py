@@ -69,6 +69,45 @@ class ContigColumns:
         self.mate = np.frombuffer(mate, np.int32).reshape(-1, 2).copy()
         self.aoff = np.frombuffer(aoff, np.int64).copy()
         self.apool = np.frombuffer(apool, np.uint8).copy() if len(apool) else np.zeros(0, np.uint8)
+        self._dense = {}
+        # strings a merged record prints per candidate, as one pool: the id (chained per sample) and the phase set of genotypes[0]
+        # (vcf.py:40-51 unpack_phase: None / "NULL" print as "."); hp: the haplotype ("1" puts the ALT allele first), -1 = None
+        ids = [c.id.encode("utf-8") for c in objs]
+        hp, pss = np.full(len(objs), -1, np.int8), []
+        for k, c in enumerate(objs):
+            g = c.genotypes.get(0) if c.genotypes else None
+            h, ps = (None, None)
+            if g is not None and g[5] is not None:
+                try:
+                    h, ps = g[5]
+                except TypeError:
+                    h, ps = g[5], None
+            if h is not None:
+                hp[k] = 1 if h == "1" else 2 if h == "2" else 3
+            pss.append(None if ps is None or ps == "NULL" else str(ps).encode("utf-8"))
+        self.id_len = np.fromiter((len(b) for b in ids), np.int32, len(ids))
+        self.id_start = np.concatenate(([0], np.cumsum(self.id_len, dtype=np.int64)))[:-1] if len(ids) else np.zeros(0, np.int64)
+        self.ph_hp = hp
+        self.ps_len = np.fromiter((-1 if b is None else len(b) for b in pss), np.int32, len(pss))
+        base = int(self.id_len.sum())
+        self.ps_start = base + (np.concatenate(([0], np.cumsum(np.maximum(self.ps_len, 0), dtype=np.int64)))[:-1] if len(pss) else np.zeros(0, np.int64))
+        self.id_pool = np.frombuffer(b"".join(ids) + b"".join(b for b in pss if b is not None) or b"\0", np.uint8)
+
+    def dense_coverage(self, cb: int):
+        """The blocks' `_COVERAGE` dicts as one int32 vector per contig: entry `bin // cb` for every key that is a multiple of `cb`
+        (the only keys a merge with this bin size can ask for), -1 elsewhere.  A lookup then costs an index (`group_calls`)."""
+        if cb not in self._dense:
+            keys = [k for c in self.cov.values() if c for k in c if k % cb == 0 and k >= 0]
+            if not keys:
+                self._dense[cb] = np.full(1, -1, np.int32)
+            else:
+                v = np.full(max(keys) // cb + 1, -1, np.int32)
+                for c in self.cov.values():
+                    if c:
+                        ks = np.fromiter((k for k in c if k % cb == 0 and k >= 0), np.int64)
+                        v[ks // cb] = np.fromiter((c[k] for k in ks.tolist()), np.int64).astype(np.int32)
+                self._dense[cb] = v
+        return self._dense[cb]
 
 
 def reader_columns(reader, contig, sid, thr, fast):
@@ -98,42 +137,66 @@ def _collect_from_columns(tasks, samples_snf, config, fast):
                 tabs[(sid, t.contig)] = c
     block_cov, block_task, parts = [], [], []
     eb0 = 0
+    cb = int(config.coverage_binsize_combine)
+    dense, eb_start = [], []
     for ti, t in enumerate(tasks):
         bis = np.asarray(t.block_indices, np.int64)
-        covs = [tabs[(s, t.contig)].cov if s in pos_of else None for s in order]
-        block_cov.extend([[c.get(b) if c is not None else None for c in covs] for b in t.block_indices])
-        block_task.extend([ti] * len(bis))
+        dense.append([tabs[(s, t.contig)].dense_coverage(cb) if s in pos_of else None for s in order])
+        eb_start.append(bis)
+        block_task.append(np.full(len(bis), ti, np.int64))
+        regular = len(bis) > 1 and bool(np.all(np.diff(bis) == bis[1] - bis[0]))      # the usual range(start, end + bs, bs)
         for sid, _ in readers:
             c = tabs[(sid, t.contig)]
             if not len(c.objs):
                 continue
-            eb = np.searchsorted(bis, c.blk)
-            ok = (eb < len(bis)) & (bis[np.minimum(eb, len(bis) - 1)] == c.blk)      # candidates of the blocks this task holds
-            parts.append((c, np.flatnonzero(ok), eb[ok] + eb0))
+            if regular:
+                step = int(bis[1] - bis[0])
+                eb = (c.blk - bis[0]) // step
+                ok = (c.blk >= bis[0]) & (c.blk <= bis[-1]) & ((c.blk - bis[0]) % step == 0)
+            else:
+                eb = np.searchsorted(bis, c.blk)
+                ok = (eb < len(bis)) & (bis[np.minimum(eb, len(bis) - 1)] == c.blk)      # candidates of the blocks this task holds
+            if ok.all():
+                parts.append((c, None, eb + eb0))
+            else:
+                parts.append((c, np.flatnonzero(ok), eb[ok] + eb0))
         eb0 += len(bis)
+    block_task = np.concatenate(block_task) if block_task else np.zeros(0, np.int64)
+    block_cov = [None] * int(eb0)          # (the dicts themselves are not consulted: covx below)
+    covx = dict(dense=dense, eb_task=np.ascontiguousarray(block_task, np.int32), eb_start=np.ascontiguousarray(np.concatenate(eb_start) if eb_start else np.zeros(0), np.int64),
+                cb=cb, block_size=int(config.snf_block_size), ids=None)
     if not parts:
-        return readers, order, block_cov, np.asarray(block_task, np.int64), ([], None, None, None, None, None, None)
-    rec = np.concatenate([c.rec[idx] for c, idx, _ in parts])
-    cblk = np.concatenate([e for _, _, e in parts]).astype(np.int32)
-    ctyp = np.concatenate([c.typ[idx] for c, idx, _ in parts]).astype(np.int32)
-    mate = np.concatenate([c.mate[idx] for c, idx, _ in parts])
-    objs = []
-    for c, idx, _ in parts:
-        objs.extend([c.objs[i] for i in idx.tolist()] if len(idx) != len(c.objs) else c.objs)
-    # ALT strings: one pool, offsets rebased
-    lens = np.concatenate([(c.aoff[1:] - c.aoff[:-1])[idx] for c, idx, _ in parts])
-    aoff = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-    pools, base = [], 0
-    for c, idx, _ in parts:
-        if len(idx) == len(c.objs):
+        return readers, order, block_cov, block_task, ([], None, None, None, None, None, None), covx
+    sizes = [len(c.objs) if idx is None else len(idx) for c, idx, _ in parts]
+    offs = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    n = int(offs[-1])
+    rec = np.empty(n, abi.GROUP_CAND_DTYPE)
+    cblk, ctyp, mate = np.empty(n, np.int32), np.empty(n, np.int32), np.empty((n, 2), np.int32)
+    id_start, id_len, ph_hp, ps_start, ps_len = np.empty(n, np.int64), np.empty(n, np.int32), np.empty(n, np.int8), np.empty(n, np.int64), np.empty(n, np.int32)
+    lens = np.empty(n, np.int64)
+    objs, pools, id_pools = [], [], []
+    id_base = 0
+    for (c, idx, eb), a, b in zip(parts, offs[:-1].tolist(), offs[1:].tolist()):
+        sel = slice(None) if idx is None else idx
+        rec[a:b] = c.rec[sel]; cblk[a:b] = eb; ctyp[a:b] = c.typ[sel]; mate[a:b] = c.mate[sel]
+        id_start[a:b] = c.id_start[sel] + id_base; id_len[a:b] = c.id_len[sel]; ph_hp[a:b] = c.ph_hp[sel]
+        ps_start[a:b] = c.ps_start[sel] + id_base; ps_len[a:b] = c.ps_len[sel]
+        id_pools.append(c.id_pool); id_base += len(c.id_pool)
+        al = c.aoff[1:] - c.aoff[:-1]
+        lens[a:b] = al[sel]
+        if idx is None:
+            objs.extend(c.objs)
             pools.append(c.apool[:int(c.aoff[-1])])
         else:
-            a, l = c.aoff[:-1][idx], (c.aoff[1:] - c.aoff[:-1])[idx]
+            objs.extend([c.objs[i] for i in idx.tolist()])
+            st, l = c.aoff[:-1][idx], al[idx]
             tot = int(l.sum())
-            src = np.repeat(a - (np.cumsum(l) - l), l) + np.arange(tot)
-            pools.append(c.apool[src])
+            pools.append(c.apool[np.repeat(st - (np.cumsum(l) - l), l) + np.arange(tot)] if tot else np.zeros(0, np.uint8))
+    aoff = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
     apool = np.concatenate(pools) if pools else np.zeros(0, np.uint8)
-    return readers, order, block_cov, np.asarray(block_task, np.int64), (objs, rec, cblk, ctyp, mate, aoff, apool)
+    id_cols = (np.concatenate(id_pools), id_start, id_len, ph_hp, ps_start, ps_len)
+    covx["ids"] = id_cols
+    return readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool), covx
 
 
 def _regenotype(blocks, readers, config, device, _lib):
@@ -158,15 +221,17 @@ def _segmented_running(values, seg, take_max: bool):
     return -(np.maximum.accumulate(-v + seg * big) - seg * big)
 
 
-def execute_many(tasks: list, samples_snf: dict) -> list:
+def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     """`CombineTask.execute` of every task of `tasks` (one merge: same config and readers); the calls per task.
     The cyclic garbage collector is off for the duration (`sv.no_gc`): the merge creates ~10^6 acyclic containers next to the
-    millions the loaded SNF blocks consist of, and every full sweep over those costs as much as the merge itself."""
+    millions the loaded SNF blocks consist of, and every full sweep over those costs as much as the merge itself.
+    `text_writer` (a `vcf.VCF` whose `can_write_merged()` holds): no `SVCall` objects are built - per task `(lines: bytes,
+    line_off, pos)`, the VCF records `write_call` would print for them, straight from the group table (`VCF.write_merged`)."""
     with sv.no_gc():
-        return _execute_many(tasks, samples_snf)
+        return _execute_many(tasks, samples_snf, text_writer)
 
 
-def _execute_many(tasks: list, samples_snf: dict) -> list:
+def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     fast = sv._load_fast()
     t0 = tasks[0]
     config, device, _lib = t0.config, t0.device, t0._lib
@@ -175,7 +240,7 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
     mark = lambda name: tm.append((name, time.perf_counter()))  # noqa: E731
     cached = _collect_from_columns(tasks, samples_snf, config, fast) if os.environ.get("SNF_COMBINE_NO_COLUMNS", "0") != "1" else None
     if cached is not None:      # readers that list their blocks: their candidates are resident as columns (ContigColumns)
-        readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool) = cached
+        readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool), covx = cached
         mark("walk_blocks")
         n = len(objs)
         mark("collect_columns")
@@ -184,6 +249,7 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
         cblk = cblk.astype(np.int64); ctyp = ctyp.astype(np.int64)
         aoff, apool = np.ascontiguousarray(aoff, np.int64), np.ascontiguousarray(apool, np.uint8)
     else:
+        covx = None
         readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
         mark("walk_blocks")
         _regenotype(blocks, readers, config, device, _lib)
@@ -204,6 +270,9 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
     perm = np.lexsort((np.arange(n), cbin, cblk, ctyp, ctask))
     rec, cblk, ctyp, ctask, cbin, mate = rec[perm], cblk[perm], ctyp[perm], ctask[perm], cbin[perm], mate[perm]
     objs = [objs[i] for i in perm.tolist()]
+    id_cols = None
+    if covx is not None and covx.get("ids") is not None:
+        id_cols = (covx["ids"][0],) + tuple(np.ascontiguousarray(a[perm]) for a in covx["ids"][1:])
     aoff, apool = fast.gather_pool(aoff, apool, np.ascontiguousarray(perm, np.int64))
     aoff = np.frombuffer(aoff, np.int64)
     key = (ctask * 8 + ctyp) * (np.int64(1) << 32) + cblk
@@ -305,11 +374,29 @@ def _execute_many(tasks: list, samples_snf: dict) -> list:
     spos = np.full(max(int(sample_ids.max(initial=0)), int(rec["sample"].max())) + 2, -1, np.int32)
     spos[sample_ids] = np.arange(len(sample_ids), dtype=np.int32)
     mark("emission_order")
+    topt = text_writer.merged_text_options() if text_writer is not None else None
+    if topt is not None and id_cols is not None:      # candidate columns: the records are formatted from arrays (no candidate object is read)
+        topt.update(rec=np.ascontiguousarray(rec), id_pool=np.ascontiguousarray(id_cols[0]), id_start=id_cols[1], id_len=id_cols[2],
+                    ph_hp=id_cols[3], ph_ps_start=id_cols[4], ph_ps_len=id_cols[5])
+    gc_covx = None if covx is None else {k: v for k, v in covx.items() if k != "ids"}
     calls = fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, objs, np.ascontiguousarray(gout), np.ascontiguousarray(em, np.int64),
                              group_off, member, chosen, np.ascontiguousarray(sv_ids, np.int64), np.ascontiguousarray(task_ids, np.int64),
                              sample_ids, spos, block_cov, ev_off, ev_block, np.ascontiguousarray(ev_bin),
                              int(config.combine_null_min_coverage), str(config.id_prefix), len(config.snf_input_info) == 1,
-                             np.ascontiguousarray(rec["sample"], np.int32))
+                             np.ascontiguousarray(rec["sample"], np.int32), topt, gc_covx)
+    if topt is not None:
+        text, line_off, line_pos = calls
+        line_off, line_pos = np.frombuffer(line_off, np.int64), np.frombuffer(line_pos, np.int64)
+        mark("build_svcalls")
+        last_timing.clear()
+        last_timing.update({name: t1 - t0_ for (_, t0_), (name, t1) in zip(tm[:-1], tm[1:])})
+        last_timing.update(candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(em))
+        result = []
+        for k, t in enumerate(tasks):
+            a, b = int(first_of_task[k]), int(first_of_task[k] + per_task[k])
+            t.sv_id += int(per_task[k])
+            result.append((text, line_off[a:b + 1], line_pos[a:b]))
+        return result
     if config.combine_pair_relabel:
         thr = config.combine_pair_relabel_threshold
         for call in calls:                                                     # sv.py:416-426 (an option; off by default)

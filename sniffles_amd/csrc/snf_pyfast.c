@@ -501,13 +501,118 @@ static PyObject* int_or_none(int32_t v) { if (v == SNF_NONE_I32) { Py_RETURN_NON
  *             block_cov: list (per block: list per sample position of the block's _COVERAGE dict or None),
  *             ev_off: buffer int64 (len(emit) + 1), ev_block: buffer int32, ev_bin: buffer int32,
  *             null_min_coverage: int, id_prefix: str, single_sample: bool, cand_sample: buffer int32) -> list[SVCall] */
+typedef struct { char* p; size_t n, cap; } OutBuf;
+static int ob_room(OutBuf* b, size_t extra) {
+  if (b->n + extra <= b->cap) return 0;
+  size_t cap = b->cap ? b->cap : 1 << 16;
+  while (cap < b->n + extra) cap *= 2;
+  char* q = (char*)realloc(b->p, cap);
+  if (!q) { PyErr_NoMemory(); return -1; }
+  b->p = q; b->cap = cap;
+  return 0;
+}
+static int ob_put(OutBuf* b, const char* s, size_t n) { if (ob_room(b, n)) return -1; memcpy(b->p + b->n, s, n); b->n += n; return 0; }
+static int ob_str(OutBuf* b, const char* s) { return ob_put(b, s, strlen(s)); }
+static int ob_ll(OutBuf* b, long long v) {     /* decimal digits by hand: a merged record prints ~40 integers, snprintf costs ~100 ns each */
+  char t[24]; int n = 24;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) t[--n] = '-';
+  return ob_put(b, t + n, (size_t)(24 - n));
+}
+static int ob_f3(OutBuf* b, double v) {      /* f"{v:.3f}" */
+  if (isnan(v)) return ob_str(b, "nan");
+  if (isinf(v)) return ob_str(b, v < 0 ? "-inf" : "inf");
+  char t[352]; int n = snprintf(t, sizeof t, "%.3f", v); return ob_put(b, t, (size_t)n);
+}
+static int ob_py(OutBuf* b, PyObject* s) {   /* a str */
+  Py_ssize_t n; const char* u = PyUnicode_AsUTF8AndSize(s, &n);
+  return u ? ob_put(b, u, (size_t)n) : -1;
+}
+static int ob_name(OutBuf* b, PyObject* list, long i, const char* prefix) {   /* list[i] or f"{prefix}{i}" */
+  if (list != Py_None) { PyObject* s = PyList_GetItem(list, i); return s ? ob_py(b, s) : -1; }
+  if (ob_str(b, prefix)) return -1;
+  return ob_ll(b, i);
+}
+static int ob_ps(OutBuf* b, int code, PyObject* ps_names, const char* none) {   /* sv._ps as text */
+  if (code == -1) return ob_str(b, none);
+  if (code == -2) return ob_str(b, "NULL");
+  return ob_name(b, ps_names, code, "");
+}
+
+static int ob_obj(OutBuf* b, PyObject* o) {   /* str(o) */
+  if (PyUnicode_Check(o)) return ob_py(b, o);
+  if (PyLong_Check(o)) { int ovf = 0; const long long v = PyLong_AsLongLongAndOverflow(o, &ovf); if (!ovf && !(v == -1 && PyErr_Occurred())) return ob_ll(b, v); PyErr_Clear(); }
+  PyObject* t = PyObject_Str(o);
+  if (!t) return -1;
+  const int rc = ob_py(b, t);
+  Py_DECREF(t);
+  return rc;
+}
+/* one sample column of a merged record (vcf.py:54-83 format_genotype on a 7-tuple): a, b, qual, dr, dv, phase, id */
+static int ob_genotype(OutBuf* b, PyObject* a, PyObject* bb, PyObject* qual, PyObject* dr, PyObject* dv, PyObject* phase, PyObject* id, int phased) {
+  PyObject *hp = Py_None, *ps = NULL;      /* unpack_phase (vcf.py:40-51) */
+  if (phase != Py_None) {
+    if (PyTuple_Check(phase) && PyTuple_GET_SIZE(phase) == 2) { hp = PyTuple_GET_ITEM(phase, 0); ps = PyTuple_GET_ITEM(phase, 1); }
+    else hp = phase;
+  }
+  if (ps && (ps == Py_None || (PyUnicode_Check(ps) && PyUnicode_CompareWithASCIIString(ps, "NULL") == 0))) ps = NULL;
+  int swap = 0; const char* sep = "/";
+  if (phased && hp != Py_None && PyLong_Check(a) && PyLong_Check(bb)) {
+    const long x = PyLong_AsLong(a), y = PyLong_AsLong(bb);
+    if ((x == 0 && y == 1) || (x == 1 && y == 1)) { sep = "|"; swap = PyUnicode_Check(hp) && PyUnicode_CompareWithASCIIString(hp, "1") == 0; }
+  }
+  if (ob_obj(b, swap ? bb : a) || ob_str(b, sep) || ob_obj(b, swap ? a : bb) || ob_str(b, ":") || ob_obj(b, qual) || ob_str(b, ":") || ob_obj(b, dr) ||
+      ob_str(b, ":") || ob_obj(b, dv)) return -1;
+  if (phased) { if (ob_str(b, ":")) return -1; if (ps ? ob_obj(b, ps) : ob_str(b, ".")) return -1; }
+  return ob_str(b, ":") || (id ? ob_obj(b, id) : 0);      /* (id NULL: the caller appends the chained ids itself) */
+}
+
 static PyObject* py_group_calls(PyObject* self, PyObject* args) {
-  PyObject *cls, *fds_cls, *objs, *block_cov, *prefix;
+  PyObject *cls, *fds_cls, *objs, *block_cov, *prefix, *topt = Py_None, *covx = Py_None;
   Py_buffer ob, eb, gb, mb, cb, svb, tkb, sidb, sposb, evo, evb, evn, csb;
   long long null_min; int single;
-  if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*y*y*y*y*O!y*y*y*LUpy*", &cls, &fds_cls, &PyList_Type, &objs, &ob, &eb, &gb, &mb, &cb, &svb, &tkb, &sidb,
-                        &sposb, &PyList_Type, &block_cov, &evo, &evb, &evn, &null_min, &prefix, &single, &csb))
+  if (!PyArg_ParseTuple(args, "OOO!y*y*y*y*y*y*y*y*y*O!y*y*y*LUpy*|OO", &cls, &fds_cls, &PyList_Type, &objs, &ob, &eb, &gb, &mb, &cb, &svb, &tkb, &sidb,
+                        &sposb, &PyList_Type, &block_cov, &evo, &evb, &evn, &null_min, &prefix, &single, &csb, &topt, &covx))
     return NULL;
+  /* covx (dict, optional): the `_COVERAGE` dicts of the blocks as dense vectors - dense[task][sample] = int32 depth per bin of `cb`
+   * bp (-1: no entry), eb_task / eb_start = task and start of every block of `block_cov`.  A lookup `block["_COVERAGE"][bin]`
+   * (parallel.py:543-551) is then dense[task][sample][bin / cb] when the bin lies inside the block, else "no entry": the coverage
+   * of the samples without a candidate costs an index instead of a dict probe with a freshly built key (most of this function's time). */
+  const int32_t** dn_ptr = NULL; Py_ssize_t* dn_len = NULL; Py_buffer* dn_buf = NULL; Py_ssize_t dn_n = 0, dn_tasks = 0;
+  const int32_t* EBT = NULL; const int64_t* EBS = NULL; long long cvx_cb = 0, cvx_bs = 0; Py_buffer ebtb, ebsb; int have_covx = 0;
+  /* text mode (topt: dict): the merged calls as VCF lines - what VCF.write_call (vcf.py:216-350) prints for the objects the other mode
+   * builds - without building them: returns (text: bytes, line_off: bytes int64 (ne + 1), pos: bytes int64 (ne)); a call that is not
+   * written (no supporting sample, INS below minsvlen) has an empty line.  Plain multi-sample merges only (the caller checks). */
+  const int text = topt != Py_None;
+  int t_phase = 0, t_symbolic = 0, t_mosaic = 0, t_rnames = 0, t_nm = 0; long long t_minsvlen = 0; PyObject *t_fmt = NULL;
+  OutBuf tb = {NULL, 0, 0}, *scol = NULL, *idc = NULL; int64_t *t_off = NULL, *t_pos = NULL;
+  Py_buffer fr_rec, fr_pool, fr_st, fr_ln, fr_hp, fr_pss, fr_psl; int fast_cols = 0, have_ph = 0;
+  if (text) {
+    if (!PyDict_Check(topt)) { PyErr_SetString(PyExc_TypeError, "group_calls: text options must be a dict"); return NULL; }
+#define TOPT(name) PyDict_GetItemString(topt, name)
+    if (!TOPT("phase") || !TOPT("symbolic") || !TOPT("mosaic") || !TOPT("output_rnames") || !TOPT("nm") || !TOPT("minsvlen") || !TOPT("genotype_format")) {
+      PyErr_SetString(PyExc_KeyError, "group_calls: incomplete text options"); return NULL; }
+    t_phase = PyObject_IsTrue(TOPT("phase")); t_symbolic = PyObject_IsTrue(TOPT("symbolic")); t_mosaic = PyObject_IsTrue(TOPT("mosaic"));
+    t_rnames = PyObject_IsTrue(TOPT("output_rnames")); t_nm = PyObject_IsTrue(TOPT("nm")); t_minsvlen = PyLong_AsLongLong(TOPT("minsvlen"));
+    t_fmt = TOPT("genotype_format");
+    if (PyErr_Occurred()) return NULL;
+    /* candidate columns (optional): with them a record is
+     * formatted from arrays alone: the genotype of a sample from its chosen candidate's record, the chained ids and the phase set
+     * from a string pool (ph_hp: haplotype of genotypes[0]'s phase, -1 None; ph_ps_len -1: no phase set) */
+    if (TOPT("rec") && TOPT("id_pool") && TOPT("id_start") && TOPT("id_len") && TOPT("ph_hp") && TOPT("ph_ps_start") && TOPT("ph_ps_len")) {
+      if (PyObject_GetBuffer(TOPT("ph_hp"), &fr_hp, PyBUF_SIMPLE) != 0) return NULL;
+      if (PyObject_GetBuffer(TOPT("ph_ps_start"), &fr_pss, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_hp); return NULL; }
+      if (PyObject_GetBuffer(TOPT("ph_ps_len"), &fr_psl, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_hp); PyBuffer_Release(&fr_pss); return NULL; }
+      have_ph = 1;
+      if (PyObject_GetBuffer(TOPT("rec"), &fr_rec, PyBUF_SIMPLE) != 0) return NULL;
+      if (PyObject_GetBuffer(TOPT("id_pool"), &fr_pool, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); return NULL; }
+      if (PyObject_GetBuffer(TOPT("id_start"), &fr_st, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); return NULL; }
+      if (PyObject_GetBuffer(TOPT("id_len"), &fr_ln, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); PyBuffer_Release(&fr_st); return NULL; }
+      fast_cols = 1;
+    }
+#undef TOPT
+  }
   const int32_t* CS = (const int32_t*)csb.buf;      /* sample_internal_id per candidate (table order) */
   PyObject* ret = NULL;
   const snf_group_out_t* O = (const snf_group_out_t*)ob.buf;
@@ -524,11 +629,47 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   PyObject* out = NULL;
   if ((Py_ssize_t)(ob.len / sizeof(snf_group_out_t)) < ng || cb.len < nm || svb.len / 8 < ne || tkb.len / 8 < ne || evo.len / 8 < ne + 1 ||
       evb.len != evn.len || csb.len / 4 < nobj) { PyErr_SetString(PyExc_ValueError, "group_calls: table sizes do not match"); goto done; }
+  if (fast_cols && ((Py_ssize_t)(fr_rec.len / sizeof(snf_group_cand_t)) < nobj || fr_st.len / 8 < nobj || fr_ln.len / 4 < nobj || fr_hp.len < nobj ||
+                    fr_pss.len / 8 < nobj || fr_psl.len / 4 < nobj)) {
+    PyErr_SetString(PyExc_ValueError, "group_calls: candidate columns shorter than the candidate list"); goto done; }
   sid_objs = (PyObject**)calloc((size_t)ns + 1, sizeof(PyObject*)); present = (uint8_t*)malloc((size_t)ns + 1);
   if (!sid_objs || !present) { PyErr_NoMemory(); goto done; }
   for (Py_ssize_t i = 0; i < ns; i++) { sid_objs[i] = PyLong_FromLong(SIDS[i]); if (!sid_objs[i]) goto done; }
-  out = PyList_New(ne);
+  if (covx != Py_None) {
+    PyObject *dense = PyDict_Check(covx) ? PyDict_GetItemString(covx, "dense") : NULL, *o_ebt = dense ? PyDict_GetItemString(covx, "eb_task") : NULL,
+             *o_ebs = dense ? PyDict_GetItemString(covx, "eb_start") : NULL, *o_cb = dense ? PyDict_GetItemString(covx, "cb") : NULL,
+             *o_bs = dense ? PyDict_GetItemString(covx, "block_size") : NULL;
+    if (!dense || !PyList_Check(dense) || !o_ebt || !o_ebs || !o_cb || !o_bs) { PyErr_SetString(PyExc_TypeError, "group_calls: malformed coverage vectors"); goto done; }
+    cvx_cb = PyLong_AsLongLong(o_cb); cvx_bs = PyLong_AsLongLong(o_bs);
+    if (PyErr_Occurred() || cvx_cb <= 0 || cvx_bs <= 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "group_calls: bin / block size"); goto done; }
+    if (PyObject_GetBuffer(o_ebt, &ebtb, PyBUF_SIMPLE) != 0) goto done;
+    if (PyObject_GetBuffer(o_ebs, &ebsb, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&ebtb); goto done; }
+    have_covx = 1;
+    EBT = (const int32_t*)ebtb.buf; EBS = (const int64_t*)ebsb.buf;
+    if (ebtb.len / 4 < nblk || ebsb.len / 8 < nblk) { PyErr_SetString(PyExc_ValueError, "group_calls: block tables too short"); goto done; }
+    dn_tasks = PyList_GET_SIZE(dense);
+    dn_ptr = (const int32_t**)calloc((size_t)(dn_tasks * ns) + 1, sizeof(int32_t*)); dn_len = (Py_ssize_t*)calloc((size_t)(dn_tasks * ns) + 1, sizeof(Py_ssize_t));
+    dn_buf = (Py_buffer*)calloc((size_t)(dn_tasks * ns) + 1, sizeof(Py_buffer));
+    if (!dn_ptr || !dn_len || !dn_buf) { PyErr_NoMemory(); goto done; }
+    for (Py_ssize_t t = 0; t < dn_tasks; t++) {
+      PyObject* row = PyList_GET_ITEM(dense, t);
+      if (!PyList_Check(row) || PyList_GET_SIZE(row) != ns) { PyErr_SetString(PyExc_TypeError, "group_calls: one coverage vector per sample expected"); goto done; }
+      for (Py_ssize_t si = 0; si < ns; si++) {
+        PyObject* a = PyList_GET_ITEM(row, si);
+        if (a == Py_None) continue;
+        if (PyObject_GetBuffer(a, &dn_buf[dn_n], PyBUF_SIMPLE) != 0) goto done;
+        dn_ptr[t * ns + si] = (const int32_t*)dn_buf[dn_n].buf; dn_len[t * ns + si] = dn_buf[dn_n].len / 4;
+        dn_n++;
+      }
+    }
+    for (Py_ssize_t q = 0; q < nblk; q++) if (EBT[q] < 0 || EBT[q] >= dn_tasks) { PyErr_SetString(PyExc_ValueError, "group_calls: block task out of range"); goto done; }
+  }
+  out = PyList_New(text ? 0 : ne);
   if (!out) goto done;
+  if (text) {
+    scol = (OutBuf*)calloc((size_t)ns + 1, sizeof(OutBuf)); idc = (OutBuf*)calloc((size_t)ns + 1, sizeof(OutBuf)); t_off = (int64_t*)calloc((size_t)ne + 1, 8); t_pos = (int64_t*)calloc((size_t)ne + 1, 8);
+    if (!scol || !idc || !t_off || !t_pos) { PyErr_NoMemory(); goto done; }
+  }
   for (Py_ssize_t e = 0; e < ne; e++) {
     const int64_t g = E[e];
     if (g < 0 || g >= ng) { PyErr_SetString(PyExc_ValueError, "group index out of range"); goto fail; }
@@ -542,8 +683,10 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
     }
     for (int64_t k = 0; k < n; k++) if (M[lo + k] < 0 || M[lo + k] >= nobj) { PyErr_SetString(PyExc_ValueError, "member out of range"); goto fail; }
     PyObject* first = PyList_GET_ITEM(objs, M[lo]);
-    PyObject *d = _PyDict_NewPresized(34), *gts = _PyDict_NewPresized(ns), *names = PyList_New(0), *info = NULL, *fds = NULL;
-    int bad = !d || !gts || !names;
+    PyObject *d = text ? NULL : _PyDict_NewPresized(34), *gts = text ? NULL : _PyDict_NewPresized(ns), *names = PyList_New(0), *info = NULL, *fds = NULL;
+    int bad = (!text && (!d || !gts)) || !names;
+    long long t_ac = 0;
+    if (text) for (Py_ssize_t si = 0; si < ns; si++) { scol[si].n = 0; idc[si].n = 0; }
     memset(present, 0, (size_t)ns);
     /* ---- genotypes of the samples in the group (sv.py:386-404): first appearance order; ids chained in add order */
     for (int64_t k = 0; !bad && k < n; k++) {
@@ -554,7 +697,30 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
         if (head[j] != j) continue;
         if (CS[M[lo + j]] == sidv) { head[k] = (int)j; break; }
       }
+      if (fast_cols) {      /* arrays only: id from the pool, nothing of the candidate object is touched */
+        const Py_ssize_t sx = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
+        const int64_t is_ = ((const int64_t*)fr_st.buf)[M[lo + k]]; const int32_t il = ((const int32_t*)fr_ln.buf)[M[lo + k]];
+        if (is_ < 0 || il < 0 || is_ + il > fr_pool.len) { PyErr_SetString(PyExc_ValueError, "group_calls: id outside the pool"); bad = 1; break; }
+        if (sx >= 0 && sx < ns) bad = (idc[sx].n && ob_str(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_put(&idc[sx], (const char*)fr_pool.buf + is_, (size_t)il);
+        if (bad) break;
+        if (sx >= 0) present[sx] = 1;
+        if (t_rnames) {
+          PyObject* rn = aget(c, K_rnames);
+          if (!rn) { bad = 1; break; }
+          if (rn != Py_None) { PyObject* r2 = PySequence_InPlaceConcat(names, rn); if (!r2) bad = 1; else Py_DECREF(r2); }
+          Py_DECREF(rn);
+        }
+        continue;
+      }
       PyObject* cid = aget(c, K_id);
+      if (text) {      /* the chained ids of a sample go straight into its id buffer (no string objects) */
+        const Py_ssize_t sx = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
+        if (!cid) { bad = 1; break; }
+        if (sx >= 0 && sx < ns) bad = (idc[sx].n && ob_str(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_obj(&idc[sx], cid);
+        Py_DECREF(cid);
+        if (bad) break;
+        goto chained;
+      }
       PyObject* pid = cid ? PyUnicode_Concat(prefix, cid) : NULL;
       Py_XDECREF(cid);
       if (!pid) { bad = 1; break; }
@@ -566,11 +732,14 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
         if (!t2) { bad = 1; break; }
         Py_DECREF(chain[head[k]]); chain[head[k]] = t2;
       }
+    chained:
       if (sidv >= 0 && sidv < nspos && SPOS[sidv] >= 0) present[SPOS[sidv]] = 1;
-      PyObject* rn = aget(c, K_rnames);                                    /* sv.py:389-390 */
-      if (!rn) { bad = 1; break; }
-      if (rn != Py_None) { PyObject* r2 = PySequence_InPlaceConcat(names, rn); if (!r2) bad = 1; else Py_DECREF(r2); }
-      Py_DECREF(rn);
+      if (!text || t_rnames) {
+        PyObject* rn = aget(c, K_rnames);                                    /* sv.py:389-390 */
+        if (!rn) { bad = 1; break; }
+        if (rn != Py_None) { PyObject* r2 = PySequence_InPlaceConcat(names, rn); if (!r2) bad = 1; else Py_DECREF(r2); }
+        Py_DECREF(rn);
+      }
       PyObject* cg = aget(c, K_genotypes);                                 /* sv.py:391-392: the default is stored on the candidate */
       if (!cg) { bad = 1; break; }
       int has = PyDict_Check(cg) ? PyDict_Contains(cg, O_zero) : -1;
@@ -589,11 +758,48 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       int64_t pick = -1;
       for (int64_t j = k; j < n; j++) if (head[j] == k && CH[lo + j]) pick = j;
       if (pick < 0) { PyErr_SetString(PyExc_ValueError, "no chosen genotype for a sample"); bad = 1; break; }
+      if (fast_cols) {
+        const snf_group_cand_t* r = &((const snf_group_cand_t*)fr_rec.buf)[M[lo + pick]];
+        const long sidv = CS[M[lo + k]];
+        const Py_ssize_t si = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
+        if (si >= 0 && si < ns) {
+          OutBuf* sc = &scol[si];
+          int ga = r->gt_a, gb_ = r->gt_b; const char* sep = "/";
+          const int8_t hp = ((const int8_t*)fr_hp.buf)[M[lo + pick]];
+          if (t_phase && hp >= 0 && ((ga == 0 && gb_ == 1) || (ga == 1 && gb_ == 1))) { sep = "|"; if (hp == 1) { const int x = ga; ga = gb_; gb_ = x; } }   /* vcf.py:66-72 */
+          bad = (ga < 0 ? ob_str(sc, ".") : ob_ll(sc, ga)) || ob_str(sc, sep) || (gb_ < 0 ? ob_str(sc, ".") : ob_ll(sc, gb_)) || ob_str(sc, ":") ||
+                ob_ll(sc, r->gq) || ob_str(sc, ":") || ob_ll(sc, r->dr) || ob_str(sc, ":") || ob_ll(sc, r->dv) || ob_str(sc, ":");
+          if (!bad && t_phase) {
+            const int64_t ps0 = ((const int64_t*)fr_pss.buf)[M[lo + pick]]; const int32_t psl = ((const int32_t*)fr_psl.buf)[M[lo + pick]];
+            if (psl < 0) bad = ob_str(sc, ".:");
+            else if (ps0 < 0 || ps0 + psl > fr_pool.len) { PyErr_SetString(PyExc_ValueError, "group_calls: phase set outside the pool"); bad = 1; }
+            else bad = ob_put(sc, (const char*)fr_pool.buf + ps0, (size_t)psl) || ob_str(sc, ":");
+          }
+          if (!bad) bad = ob_put(sc, idc[si].p, idc[si].n);
+          if (!bad && r->gt_a >= 0 && r->dv > 0) { t_ac += (long long)r->gt_a + r->gt_b; present[si] = 2; }
+        }
+        continue;
+      }
       PyObject* c = PyList_GET_ITEM(objs, M[lo + pick]);
       PyObject* cg = aget(c, K_genotypes);
       PyObject* t = cg ? PyDict_GetItemWithError(cg, O_zero) : NULL;
       PyObject* sv = PyLong_FromLong(CS[M[lo + k]]);
       if (!t || !sv || !PyTuple_Check(t) || PyTuple_GET_SIZE(t) < 6) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "genotypes[0] must be a 6-tuple"); bad = 1; }
+      else if (text) {
+        const long sidv = CS[M[lo + k]];
+        const Py_ssize_t si = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
+        if (si >= 0 && si < ns) {      /* (a sample that has no VCF column is not printed) */
+          PyObject *ga = PyTuple_GET_ITEM(t, 0), *gb_ = PyTuple_GET_ITEM(t, 1), *gdv = PyTuple_GET_ITEM(t, 4);
+          bad = ob_genotype(&scol[si], ga, gb_, PyTuple_GET_ITEM(t, 2), PyTuple_GET_ITEM(t, 3), gdv, PyTuple_GET_ITEM(t, 5), NULL, t_phase) != 0 ||
+                ob_put(&scol[si], idc[si].p, idc[si].n);
+          /* vcf.py:238-242: allele count and support vector */
+          if (!bad && !(PyUnicode_Check(ga) && PyUnicode_CompareWithASCIIString(ga, ".") == 0)) {
+            const int pos_dv = PyObject_RichCompareBool(gdv, O_zero, Py_GT);
+            if (pos_dv < 0) bad = 1;
+            else if (pos_dv) { t_ac += PyLong_AsLongLong(ga) + PyLong_AsLongLong(gb_); if (PyErr_Occurred()) bad = 1; present[si] = 2; }
+          }
+        }
+      }
       else {
         PyObject* g7 = PyTuple_Pack(7, PyTuple_GET_ITEM(t, 0), PyTuple_GET_ITEM(t, 1), PyTuple_GET_ITEM(t, 2), PyTuple_GET_ITEM(t, 3),
                                     PyTuple_GET_ITEM(t, 4), PyTuple_GET_ITEM(t, 5), chain[k]);
@@ -610,6 +816,17 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       for (int64_t q = EVO[e]; q < EVO[e + 1]; q++) {
         long cv = 0;
         if (EVB[q] < 0 || EVB[q] >= nblk) { PyErr_SetString(PyExc_ValueError, "block index out of range"); bad = 1; break; }
+        if (have_covx) {
+          const int32_t* dv_ = dn_ptr[(Py_ssize_t)EBT[EVB[q]] * ns + si];
+          const long long key = EVN[q], bstart = EBS[EVB[q]];
+          if (dv_ && key >= bstart && key < bstart + cvx_bs && key % cvx_cb == 0 && key / cvx_cb < dn_len[(Py_ssize_t)EBT[EVB[q]] * ns + si]) {
+            const int32_t x = dv_[key / cvx_cb];
+            if (x >= 0) cv = x;
+          }
+          cov = firstev ? cv : (cv > cov ? cv : cov);
+          firstev = 0;
+          continue;
+        }
         PyObject* per = PyList_GET_ITEM(block_cov, EVB[q]);
         PyObject* dct = PyList_Check(per) && si < PyList_GET_SIZE(per) ? PyList_GET_ITEM(per, si) : Py_None;
         if (dct != Py_None) {
@@ -624,6 +841,12 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
         firstev = 0;
       }
       if (bad) break;
+      if (text) {                                               /* (0, 0, 0, cov, 0, (None, None), "NULL") or (".", ".", ...) as a column */
+        const char* ab = cov >= null_min ? "0" : ".";
+        bad = ob_str(&scol[si], ab) || ob_str(&scol[si], "/") || ob_str(&scol[si], ab) || ob_str(&scol[si], ":0:") || ob_ll(&scol[si], cov) ||
+              ob_str(&scol[si], t_phase ? ":0:.:NULL" : ":0:NULL");
+        continue;
+      }
       PyObject* covo = PyLong_FromLong(cov);
       PyObject* ab = cov >= null_min ? O_zero : S_dot;          /* (0, 0, 0, cov, 0, (None, None), "NULL") or (".", ".", ...) */
       PyObject* g7 = covo ? PyTuple_Pack(7, ab, ab, O_zero, covo, O_zero, T_none2, S_NULL) : NULL;
@@ -631,6 +854,69 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       bad = !g7 || PyDict_SetItem(gts, sid_objs[si], g7);
       Py_XDECREF(g7);
     }
+    if (text && !bad) {
+      /* ---- the record (vcf.py:216-300 write_call over the call of sv.py:440-481) */
+      PyObject* contig = aget(first, K_contig); PyObject* svtype = aget(first, K_svtype);
+      PyObject* alt = aget(PyList_GET_ITEM(objs, M[o->alt_member]), K_alt);
+      const char* tname = svtype ? PyUnicode_AsUTF8(svtype) : NULL;
+      t_off[e] = (int64_t)tb.n; t_pos[e] = o->pos;
+      int skip = 0, any = 0;
+      for (Py_ssize_t si = 0; si < ns; si++) any |= present[si] == 2;
+      if (!contig || !tname || !alt || !PyUnicode_Check(alt)) bad = 1;
+      else if (ns > 1 && !any) skip = 1;                        /* int(supp_vec) == 0 (vcf.py:246-247) */
+      if (!bad && !skip) {
+        const int bnd = strcmp(tname, "BND") == 0, ins = strcmp(tname, "INS") == 0, del = strcmp(tname, "DEL") == 0;
+        long long svlen = o->svlen;
+        const Py_ssize_t alen = PyUnicode_GET_LENGTH(alt);
+        if (ins && !t_symbolic && svlen != alen && PyUnicode_CompareWithASCIIString(alt, "<INS>") != 0) svlen = alen;   /* vcf.py:253-254 */
+        if (ins && svlen < t_minsvlen) skip = 1;
+        if (!skip) {
+          const long long pos = o->pos > 0 ? o->pos : 1;
+          const long long end = (o->precise && del) ? pos + (svlen < 0 ? -svlen : svlen) : o->end;
+          char idbuf[96];
+          snprintf(idbuf, sizeof idbuf, "%.40s.%llXM%llX", tname, (unsigned long long)SV[e], (unsigned long long)TK[e]);
+          bad = ob_py(&tb, contig) || ob_str(&tb, "\t") || ob_ll(&tb, pos) || ob_str(&tb, "\t") || ob_py(&tb, prefix) || ob_str(&tb, idbuf) || ob_str(&tb, "\tN\t");
+          if (!bad) {
+            if (t_symbolic && !bnd) bad = ob_str(&tb, "<") || ob_str(&tb, tname) || ob_str(&tb, ">");
+            else bad = ob_py(&tb, alt);
+          }
+          if (!bad) {
+            if (o->qual == SNF_NONE_I32) bad = ob_str(&tb, "\t.");
+            else { const long long q = o->qual < 0 ? 0 : o->qual > 60 ? 60 : o->qual; bad = ob_str(&tb, "\t") || ob_ll(&tb, q); }
+          }
+          if (!bad) bad = ob_str(&tb, (ns > 1 && t_ac == 0) ? "\tGT\t" : "\tPASS\t") || ob_str(&tb, o->precise ? "PRECISE" : "IMPRECISE") || (t_mosaic && ob_str(&tb, ";MOSAIC")) ||
+                          ob_str(&tb, ";SVTYPE=") || ob_str(&tb, tname);
+          if (!bad && !bnd) bad = ob_str(&tb, ";SVLEN=") || ob_ll(&tb, svlen) || ob_str(&tb, ";END=") || ob_ll(&tb, end);
+          if (!bad) bad = ob_str(&tb, ";SUPPORT=") || ob_ll(&tb, o->support);
+          if (!bad && t_rnames) {
+            bad = ob_str(&tb, ";RNAMES=");
+            for (Py_ssize_t q = 0; !bad && q < PyList_GET_SIZE(names); q++) bad = (q && ob_str(&tb, ",")) || ob_obj(&tb, PyList_GET_ITEM(names, q));
+          }
+          if (!bad) {
+            bad = ob_str(&tb, ";COVERAGE=");
+            for (int q = 0; !bad && q < 5; q++) {
+              bad = q && ob_str(&tb, ",");
+              if (!bad) bad = o->cov[q] == SNF_NONE_I32 ? ob_str(&tb, "None") : ob_ll(&tb, o->cov[q]);
+            }
+          }
+          if (!bad) bad = ob_str(&tb, ";STRAND=") || ob_str(&tb, o->fwd > 0 ? "+" : "") || ob_str(&tb, o->rev > 0 ? "-" : "") || (t_nm && ob_str(&tb, ";NM=-1"));
+          if (!bad && ns > 1) bad = ob_str(&tb, ";AC=") || ob_ll(&tb, t_ac);      /* call.info, sorted: AC, STDEV_LEN, STDEV_POS, SUPP_VEC */
+          if (!bad) {
+            if (o->n < 2) bad = ob_str(&tb, ";STDEV_LEN=0;STDEV_POS=0");
+            else bad = ob_str(&tb, ";STDEV_LEN=") || ob_f3(&tb, o->stdev_len) || ob_str(&tb, ";STDEV_POS=") || ob_f3(&tb, o->stdev_pos);
+          }
+          if (!bad && ns > 1) { bad = ob_str(&tb, ";SUPP_VEC="); for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = ob_str(&tb, present[si] == 2 ? "1" : "0"); }
+          if (!bad) bad = ob_str(&tb, "\t") || ob_py(&tb, t_fmt);
+          for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = ob_str(&tb, "\t") || ob_put(&tb, scol[si].p, scol[si].n);
+          if (!bad) bad = ob_str(&tb, "\n");
+        }
+      }
+      Py_XDECREF(contig); Py_XDECREF(svtype); Py_XDECREF(alt); Py_XDECREF(names);
+      if (bad) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "group_calls: cannot format a merged record"); goto fail; }
+      t_off[e + 1] = (int64_t)tb.n;
+      continue;
+    }
+    if (text) { Py_XDECREF(names); if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "group_calls: cannot format a merged record"); goto fail; }
     /* ---- the call (sv.py:440-481) */
     PyObject *contig = NULL, *svtype = NULL, *alt = NULL, *flt = NULL;
     if (!bad) {
@@ -676,6 +962,14 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
     if (!obj) goto fail;
     PyList_SET_ITEM(out, e, obj);
   }
+  if (text) {
+    PyObject* a = PyBytes_FromStringAndSize(tb.p ? tb.p : "", (Py_ssize_t)tb.n);
+    PyObject* b2 = PyBytes_FromStringAndSize((const char*)t_off, ((Py_ssize_t)ne + 1) * 8);
+    PyObject* c2 = PyBytes_FromStringAndSize((const char*)t_pos, (Py_ssize_t)ne * 8);
+    if (a && b2 && c2) ret = PyTuple_Pack(3, a, b2, c2);
+    Py_XDECREF(a); Py_XDECREF(b2); Py_XDECREF(c2);
+    goto done;
+  }
   ret = out; out = NULL;
   goto done;
 fail:
@@ -684,6 +978,14 @@ done:
   Py_XDECREF(out);
   if (sid_objs) { for (Py_ssize_t i = 0; i < ns; i++) Py_XDECREF(sid_objs[i]); free(sid_objs); }
   free(present); free(head); free(chain);
+  if (scol) { for (Py_ssize_t si = 0; si < ns; si++) free(scol[si].p); free(scol); }
+  if (idc) { for (Py_ssize_t si = 0; si < ns; si++) free(idc[si].p); free(idc); }
+  if (fast_cols) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); PyBuffer_Release(&fr_st); PyBuffer_Release(&fr_ln); }
+  if (have_ph) { PyBuffer_Release(&fr_hp); PyBuffer_Release(&fr_pss); PyBuffer_Release(&fr_psl); }
+  if (dn_buf) { for (Py_ssize_t k = 0; k < dn_n; k++) PyBuffer_Release(&dn_buf[k]); free(dn_buf); }
+  free(dn_ptr); free(dn_len);
+  if (have_covx) { PyBuffer_Release(&ebtb); PyBuffer_Release(&ebsb); }
+  free(tb.p); free(t_off); free(t_pos);
   PyBuffer_Release(&ob); PyBuffer_Release(&eb); PyBuffer_Release(&gb); PyBuffer_Release(&mb); PyBuffer_Release(&cb); PyBuffer_Release(&svb);
   PyBuffer_Release(&tkb); PyBuffer_Release(&sidb); PyBuffer_Release(&sposb); PyBuffer_Release(&evo); PyBuffer_Release(&evb); PyBuffer_Release(&evn);
   PyBuffer_Release(&csb);
@@ -696,39 +998,6 @@ done:
  * materialize + apply_final + VCF.write_call (vcf.py:216-350 of the reference) produce for the same records, without the
  * SVCall objects in between.  Serves the BAM -> VCF flow when no reference FASTA is attached and no SNF is written.
  * ====================================================================================================================== */
-typedef struct { char* p; size_t n, cap; } OutBuf;
-static int ob_room(OutBuf* b, size_t extra) {
-  if (b->n + extra <= b->cap) return 0;
-  size_t cap = b->cap ? b->cap : 1 << 16;
-  while (cap < b->n + extra) cap *= 2;
-  char* q = (char*)realloc(b->p, cap);
-  if (!q) { PyErr_NoMemory(); return -1; }
-  b->p = q; b->cap = cap;
-  return 0;
-}
-static int ob_put(OutBuf* b, const char* s, size_t n) { if (ob_room(b, n)) return -1; memcpy(b->p + b->n, s, n); b->n += n; return 0; }
-static int ob_str(OutBuf* b, const char* s) { return ob_put(b, s, strlen(s)); }
-static int ob_ll(OutBuf* b, long long v) { char t[32]; int n = snprintf(t, sizeof t, "%lld", v); return ob_put(b, t, (size_t)n); }
-static int ob_f3(OutBuf* b, double v) {      /* f"{v:.3f}" */
-  if (isnan(v)) return ob_str(b, "nan");
-  if (isinf(v)) return ob_str(b, v < 0 ? "-inf" : "inf");
-  char t[352]; int n = snprintf(t, sizeof t, "%.3f", v); return ob_put(b, t, (size_t)n);
-}
-static int ob_py(OutBuf* b, PyObject* s) {   /* a str */
-  Py_ssize_t n; const char* u = PyUnicode_AsUTF8AndSize(s, &n);
-  return u ? ob_put(b, u, (size_t)n) : -1;
-}
-static int ob_name(OutBuf* b, PyObject* list, long i, const char* prefix) {   /* list[i] or f"{prefix}{i}" */
-  if (list != Py_None) { PyObject* s = PyList_GetItem(list, i); return s ? ob_py(b, s) : -1; }
-  if (ob_str(b, prefix)) return -1;
-  return ob_ll(b, i);
-}
-static int ob_ps(OutBuf* b, int code, PyObject* ps_names, const char* none) {   /* sv._ps as text */
-  if (code == -1) return ob_str(b, none);
-  if (code == -2) return ob_str(b, "NULL");
-  return ob_name(b, ps_names, code, "");
-}
-
 /* vcf_records(records: buffer, order: buffer int64 (record indices in output order), rnames: buffer uint32, alt_pool: buffer,
  *             qnames: list | None, ps_names: list | None, contig: str, task_id: int, contig_names: list | None,
  *             filters: list[str], opts: dict(id_prefix str, mosaic, mosaic_af_max, output_rnames, nm, phase, symbolic, minsvlen,

@@ -271,7 +271,7 @@ class CombineTask(Task):
         return CombineTask.execute_many([self], samples_snf)[0]
 
     @staticmethod
-    def execute_many(tasks: list, samples_snf: dict) -> list:
+    def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         """`execute` of several tasks (the contigs of a merge, or the parts of `scatter`) with ONE group-assignment launch for
         all of them: the flush windows of every task are walked first, all chains go to the GPU together - a contig alone
         leaves most of the device idle and its launch lasts as long as its slowest window - then every task is replayed.
@@ -281,7 +281,9 @@ class CombineTask(Task):
         import os
         if os.environ.get("SNF_COMBINE_OBJECTS", "0") != "1" and sv._load_fast() is not None:
             from . import candstore
-            return candstore.execute_many(tasks, samples_snf)      # the columnar store: no Python per candidate or group
+            return candstore.execute_many(tasks, samples_snf, text_writer)      # the columnar store: no Python per candidate or group
+        if text_writer is not None:
+            raise RuntimeError("merged VCF text without objects needs the columnar store (sniffles_amd._snf_fast)")
         return CombineTask._execute_many_objects(tasks, samples_snf)
 
     @staticmethod

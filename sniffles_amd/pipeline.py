@@ -205,11 +205,12 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     return out
 
 
-def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, _lib=None) -> list:
+def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, _lib=None, objects: bool = True) -> list:
     """Multi-sample calling from per-sample `.snf` files: the `combine` flow of the reference's main program
     (`sniffles:371-490`) for one process - headers (sample ids, contig lengths, format checks), one `CombineTask` per
     contig over `snf.SNFile` readers (group assignment on the GPU), calls of a task sorted by position
-    (`CombineResult`), VCF records in task order.  Returns the combined calls."""
+    (`CombineResult`), VCF records in task order.  Returns the combined calls.  `objects=False`: VCF only, the records formatted
+    straight from the group table when the writer can (`VCF.can_write_merged`) - the same text; returns []."""
     import os
     config.mode = "combine"
     config.snf_input_info, readers = [], {}
@@ -239,6 +240,13 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
     tasks = [parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device, _lib=_lib,
                                   regions=(getattr(config, "regions_by_contig", None) or {}).get(contig))
              for task_id, (contig, length) in enumerate(contig_lengths)]
+    if not objects and writer is not None and writer.can_write_merged():
+        # VCF only: the merged records are formatted straight from the group table (vcf.VCF.write_merged) - the same text, no SVCall objects
+        for part in parallel.CombineTask.execute_many(tasks, readers, text_writer=writer):
+            writer.write_merged(part, sort=getattr(config, "sort", True))
+        for f in readers.values():
+            f.close()
+        return []
     # all contigs share one group-assignment launch (a contig alone leaves most of the device idle)
     for task, calls in zip(tasks, parallel.CombineTask.execute_many(tasks, readers)):
         if getattr(config, "sort", True):

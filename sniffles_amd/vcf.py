@@ -288,6 +288,39 @@ class VCF:
         self.call_count += 1
         return 1
 
+    # ---- merged records without the objects
+    def can_write_merged(self) -> bool:
+        """The group-table writer (`write_merged`) serves the plain multi-sample merge: two or more sample columns in the order of
+        `config.snf_input_info`, no reference FASTA attached, no SVLENGTHS, no pair relabelling."""
+        cfg = self.config
+        ids = [i for i, _ in cfg.sample_ids_vcf]
+        return (self.reference_handle is None and cfg.mode == "combine" and len(ids) > 1 and not cfg.dev_emit_sv_lengths
+                and not getattr(cfg, "combine_pair_relabel", False) and not getattr(cfg, "combine_consensus", False)
+                and ids == [s["internal_id"] for s in cfg.snf_input_info] and _fast() is not None)
+
+    def merged_text_options(self) -> dict:
+        cfg = self.config
+        return dict(phase=bool(cfg.phase), symbolic=bool(cfg.symbolic), mosaic=bool(cfg.mosaic) and 0 <= cfg.mosaic_af_max,
+                    output_rnames=bool(cfg.output_rnames), nm="NM" in self.info_order, minsvlen=int(cfg.minsvlen),
+                    genotype_format=self.genotype_format)
+
+    def write_merged(self, part, sort: bool = True) -> int:
+        """One task's merged records as `candstore.execute_many(..., text_writer=self)` returned them - `(text, line_off, pos)` - in the
+        order `sorted(calls, key=pos)` gives the objects (stable), or as they are.  Returns the number of lines written."""
+        import numpy as np
+        text, off, pos = part
+        order = np.argsort(pos, kind="stable") if sort else np.arange(len(pos))
+        n = 0
+        out = []
+        for k in order.tolist():
+            a, b = int(off[k]), int(off[k + 1])
+            if b > a:
+                out.append(text[a:b])
+                n += 1
+        self.handle.write(b"".join(out).decode("utf-8"))
+        self.call_count += n
+        return n
+
     def can_write_records(self) -> bool:
         """The record-table writer serves the plain single-sample case: no reference FASTA attached (REF / ALT stay "N" /
         the consensus), one sample column, no SVLENGTHS."""

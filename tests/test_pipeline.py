@@ -207,6 +207,17 @@ def run_population(name, tmp_path, _lib):
     calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=_lib)
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert len(calls) >= len(vu.split_text(doc["vcf"])[1]) > 50
+    # the same text straight from the group table (vcf.VCF.write_merged): no SVCall objects; also with the options that change the columns
+    for extra in ((), ("--phase",), ("--symbolic",), ("--output-rnames",), ("--qc-nm",), ("--mosaic",), ("--minsvlen", "300")):
+        with_objects, without = io.StringIO(), io.StringIO()
+        if extra:
+            pipeline.combine(paths, config_for(tuple(args) + extra), vcf_handle=with_objects, _lib=_lib)
+        else:
+            with_objects = buf
+        cfg = config_for(tuple(args) + extra)
+        assert pipeline.combine(paths, cfg, vcf_handle=without, _lib=_lib, objects=False) == []
+        assert without.getvalue() == with_objects.getvalue(), extra
+        assert without.getvalue().count("\n") > 50
 
 
 @pytest.mark.parametrize("name", sorted(cases.POPULATIONS))

@@ -120,11 +120,27 @@ def run(ctx):
             box["stats"][k] += st[name]
     lib.combine_resolve_batch = timed_call
 
-    def one_pass():
+    import io
+    from sniffles_amd import vcf
+    text_box = [None]
+
+    def one_pass(objects=False):
+        """The merge of this rank's contig tasks -> the merged VCF records (what the reference's combine run produces): formatted
+        straight from the group table (vcf.VCF.write_merged); objects=True builds the SVCall objects and lets write_call print them."""
         box.update(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
         tasks = [parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank) for ci, c, L in my_contigs]
+        buf = io.StringIO()
+        w = vcf.VCF(cfg, buf)
         # the contig tasks of this rank share one group-assignment launch (CombineTask.execute_many)
-        box["calls"] = sum(len(calls) for calls in parallel.CombineTask.execute_many(tasks, readers))
+        if objects or not w.can_write_merged():
+            n = 0
+            for calls in parallel.CombineTask.execute_many(tasks, readers):
+                for c in sorted(calls, key=lambda c: c.pos):
+                    n += w.write_call(c)
+            box["calls"] = n
+        else:
+            box["calls"] = sum(w.write_merged(part) for part in parallel.CombineTask.execute_many(tasks, readers, text_writer=w))
+        text_box[0] = buf.getvalue()
 
     def barrier():
         if use_dist:
@@ -139,6 +155,12 @@ def run(ctx):
         one_pass()
     barrier()
     dt = time.perf_counter() - t0
+    phases = dict(candstore.last_timing)
+    text_fast = text_box[0]
+    t1 = time.perf_counter()
+    one_pass(objects=True)                 # for the record (and as a check): the same records through SVCall objects + write_call
+    objects_ms = (time.perf_counter() - t1) * 1e3
+    text_equal = text_box[0] == text_fast
     lib.combine_resolve_batch = real_call
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
     tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device="cuda")
@@ -152,7 +174,7 @@ def run(ctx):
     kms = box["kernel_ms"]
     al, ab, cells, staged = box["stats"]
     achieved = ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    out = dict(metric="SV candidates merged/sec (multi-sample combine: SNF blocks -> columnar store -> group assignment with banded edit distance -> SVGroup.call -> SVCall objects)",
+    out = dict(metric="SV candidates merged/sec (multi-sample combine: candidates resident as columns -> group assignment with banded edit distance -> SVGroup.call -> merged VCF records)",
                value=total_cands * steps / dt, unit="candidates/s", n_gpus=world, steps=steps, warmup=warmup,
                ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32/f64/u64 bit-vectors",
                data="synthetic",
@@ -162,7 +184,9 @@ def run(ctx):
                            baseline_config=4, samples=S, coverage=cov, scale=args.scale, contig_tasks=len(contigs),
                            candidates=total_cands, combined_calls=total_calls, setup_s=round(t_setup, 1),
                            parallelism=f"contig tasks sharded longest-first over {world} ranks, no data-path collective",
-                           host_phases_ms={k: (round(v * 1e3, 1) if isinstance(v, float) else v) for k, v in candstore.last_timing.items()},
+                           host_phases_ms={k: (round(v * 1e3, 1) if isinstance(v, float) else v) for k, v in phases.items()},
+                           output="merged VCF records as text straight from the group table (vcf.VCF.write_merged), sorted by position per contig task",
+                           through_svcall_objects_ms=round(objects_ms, 1), text_equals_object_path=bool(text_equal), vcf_bytes=len(text_fast or ""),
                            rank0=dict(c_abi_call_ms=round(box["abi_s"] * 1e3, 2), kernel_ms=round(kms, 3),
                                       host_ms=round(dt / steps * 1e3 - box["abi_s"] * 1e3, 1), staged_bytes=staged,
                                       alignments=al, dp_cells=cells,
@@ -175,7 +199,7 @@ def run(ctx):
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"], ver = cpu_baseline_and_verify(cfg, readers, my_contigs, S, local_rank, args)
         if ver is not None:
-            out["verified"] = ver["ok"]
+            out["verified"] = bool(ver["ok"] and text_equal)      # group assignment vs the oracle AND the text path vs the object path
             out["verify"] = ver
     return out
 
