@@ -64,25 +64,26 @@ def set_dev(torch, local_rank):
 
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# rocprofv3 summaries of this round, collected with tools/r03_profile.sh.  They are only quoted when they were measured on the
-# kernels this run executes: profiles/r03_profile_meta.json records the hash of sniffles_amd/csrc they belong to.
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-ROCPROF_STATS = os.path.join(ROOT, "profiles", "r03_kernel_stats_default.csv")
-PROFILE_META = os.path.join(ROOT, "profiles", "r03_profile_meta.json")
+# rocprofv3 summaries of this round, collected with tools/profile.sh.  They are only quoted when they were measured on the
+# kernels this run executes: profiles/r04_profile_meta.json records the hash of sniffles_amd/csrc they belong to.
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+ROCPROF_STATS = os.path.join(ROOT, "profiles", "r04_kernel_stats_default.csv")
+PROFILE_META = os.path.join(ROOT, "profiles", "r04_profile_meta.json")
 ROCPROF_NAMES = {"e45w_consensus_large": "e45w_consensus<2,", "e45w_consensus_small": "e45w_consensus<1,", "d2w_call": "d2w_call<", "e1w_finalize": "e1w_finalize<",
                  "d1w_refine": "d1w_refine", "d4_coverage": "d4_coverage", "a4_binstats": "a4k_binstats", "a6_scatter": "a6k_scatter", "e4c_copy": "e4c_copy",
                  "a1_keys": "a1_keys", "a0_keep": "a0k_keep", "c1_mergeruns": "c1_mergeruns", "d3_rnames": "d3rk_rnames", "b1_seedmetrics": "b1k_seedmetrics",
-                 "d5w_covsum": "d5w_covsum", "f4_emit": "f4w_emit", "f5_alt": "f5w_alt", "f3_rank": "f3k_rank"}
+                 "d5w_covsum": "d5w_covsum", "f4_emit": "f4w_emit", "f5_alt": "f5w_alt", "f3_rank": "f3k_rank", "w1_hist": "w1_hist", "w3_scatter": "w3_scatter",
+                 "w4_local": "w4_local<", "w6_emit": "w6_emit<", "d2g_call8": "d2g_call<8"}
 
 
 def committed_profiles():
-    """(rocprofv3 average ms per kernel name, PMC traffic per kernel, note) of the committed round-3 profiles - or empty dicts and
+    """(rocprofv3 average ms per kernel name, PMC traffic per kernel, note) of the committed round-4 profiles - or empty dicts and
     the reason when they belong to other kernel sources than the ones built here."""
     try:
         from sniffles_amd import build
         meta = json.load(open(PROFILE_META))
         if meta.get("csrc_sha") != build._lib_digest():
-            return {}, {}, "profiles/r03_* were collected on other kernel sources (stale): not quoted"
+            return {}, {}, "profiles/r04_* were collected on other kernel sources (stale): not quoted"
         import csv
         avg = {}
         for r in csv.DictReader(open(ROCPROF_STATS)):
@@ -90,7 +91,7 @@ def committed_profiles():
                 if pat in r["Name"].replace("snf::", "").replace(" ", "").replace("void", "") or pat in r["Name"]:
                     avg.setdefault(short, float(r["AverageNs"]) / 1e6)
         pmc = json.load(open(PMC_FILE))["kernels"] if os.path.exists(PMC_FILE) else {}
-        return avg, pmc, "rocprofv3 --kernel-trace --stats of the default command, profiles/r03_kernel_stats_default.csv (same kernel sources: hash checked)"
+        return avg, pmc, "rocprofv3 --kernel-trace --stats of the default command, profiles/r04_kernel_stats_default.csv (same kernel sources: hash checked)"
     except Exception as e:  # noqa: BLE001
         return {}, {}, f"no committed profile for these sources ({type(e).__name__})"
 
@@ -651,7 +652,7 @@ def run_calling(ctx):
         kern = sorted(timings, key=lambda x: -x[1])
         # dominant KERNEL: entries that bracket a sequence of library launches (rocPRIM sort / scan passes) or a copy are
         # listed in top_kernels but are not a kernel whose roofline could be stated
-        single = [k for k in kern if not k[0].startswith(("sort_", "scan_", "d2h_"))]
+        single = [k for k in kern if not k[0].startswith(("sort_", "scan_", "d2h_", "front_"))]      # (front_window brackets the six launches of the window front end)
         top = single[0] if single else ("none", 0.0, 0)
         gpu_ms = sum(k[1] for k in kern)
         achieved = (top[2] / (top[1] * 1e-3)) / 1e9 if top[1] > 0 else 0.0

@@ -365,7 +365,8 @@ int snf_batch_set_output(snf_batch_t* b, int mode);
  * ANOTHER PROCESS maps as well - one process per GPU, the parent (the reference's `Main`, parallel.py:757 receives whole
  * results) reads every worker's result from a shared-memory segment without a copy and without funnelling it through one
  * GPU's PCIe link.  A result that does not fit fails the fetch with the sizes needed.  NULL, 0, NULL, 0: the library's own
- * pinned buffers again.  Call it between passes (it waits for the batch's streams). */
+ * pinned buffers again.  Call it between passes (it waits for the batch's streams).  The memory must stay mapped until
+ * snf_batch_destroy (the registration is only dropped there); a range given again with a larger size is registered anew. */
 int snf_batch_set_result_memory(snf_batch_t* b, void* block, int64_t block_bytes, void* alt, int64_t alt_bytes);
 
 /* device -> host of the call records (blocks until the batch's streams are idle).

@@ -205,7 +205,11 @@ struct HostBuf {
     release();
     if (!mem || !bytes) return;
     bool known = false;
-    for (auto& e : registered) known |= e.first == mem && e.second >= bytes;
+    for (auto it = registered.begin(); it != registered.end();) {
+      if (it->first == mem && it->second >= bytes) { known = true; ++it; }
+      else if (it->first == mem) { (void)hipHostUnregister(mem); it = registered.erase(it); }     // the same base with a larger size: pinned anew below
+      else ++it;
+    }
     if (!known) {
       SNF_HIP(hipHostRegister(mem, bytes, hipHostRegisterDefault));
       void* dp = nullptr;
@@ -316,6 +320,8 @@ struct snf_batch_impl {
   std::vector<std::pair<void*, size_t>> ext_ranges;   // caller memory page-locked for them (snf_batch_set_result_memory)
   // class sizes of this handle's previous finalize (same input -> same sizes; first pass: one host wait for them)
   bool have_hist = false; int64_t hist_calls = 0, hist_small = 0, hist_large = 0, hist_copy = 0;
+  bool have_big_hist = false; int64_t hist_big[3] = {0, 0, 0};   // items of the previous whole pass for x_big<0 / 1 / 2> (0: that launch is skipped)
+  bool skipped_big[3] = {false, false, false};
   int out_mode = 0;                  // enum snf_output
   std::vector<int32_t> r_status; std::vector<int64_t> r_off; std::vector<double> r_cov;
   // snf_batch_fetch_clusters result (host)
@@ -1044,8 +1050,10 @@ void do_upload(snf_batch_impl* b) {
      // the output stage: at most one record per position behind the sort
     v.alt_cap = v.pool_cap; v.alt_pool = dalloc<uint8_t>(b, (size_t)v.alt_cap + 32);
     const size_t NO = (size_t)v.NS + 1;
-    v.o_scan = dalloc<uint32_t>(b, NO + 1); v.o_src = dalloc<int32_t>(b, NO); v.o_dst = dalloc<int32_t>(b, NO); v.o_key = dalloc<int32_t>(b, NO);
-    v.o_rn = dalloc<int64_t>(b, NO);
+    // (indexed by positions behind the sort: sized by N, not NS - snf_batch_fetch_clusters turns the prefilter off and the plain-scan
+    // form of the output stage then walks N + 1 positions)
+    v.o_scan = dalloc<uint32_t>(b, N1 + 1); v.o_src = dalloc<int32_t>(b, N1); v.o_dst = dalloc<int32_t>(b, N1); v.o_key = dalloc<int32_t>(b, N1);
+    v.o_rn = dalloc<int64_t>(b, N1);
     v.out_hdr = dalloc<OutHdr>(b, 1);
     dzero(b, v.out_hdr, sizeof(OutHdr));
     v.out_dev_cap = (int64_t)(NO * sizeof(snf_call_t) + (2 * (size_t)N + 1) * 4 + 1024);
@@ -1283,7 +1291,9 @@ void run_call_candidates(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
     if (!(v.wave_path && b->fused)) LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);   // (next to the wave kernels every item would return at once)
-    if (v.wave_path) {   // clusters of more than 64 leads, one wave each
+    b->skipped_big[0] = b->skipped_big[1] = b->skipped_big[2] = false;
+    if (v.wave_path && b->have_big_hist && b->hist_big[0] == 0) b->skipped_big[0] = true;      // (same input: no cluster of more than 64 leads)
+    else if (v.wave_path) {   // clusters of more than 64 leads, one wave each
       Scope _s(b, "x_big_refine", 0);
       hipLaunchKernelGGL(x_big<0>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -1323,7 +1333,8 @@ void run_call_candidates(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
     if (!(v.wave_path && b->fused)) LAUNCH_Q(d2_call, v, N, v.wave_path ? 0 : N * 32);
-    if (v.wave_path) {
+    if (v.wave_path && b->have_big_hist && b->hist_big[1] == 0) b->skipped_big[1] = true;
+    else if (v.wave_path) {
       Scope _s(b, "x_big_call", 0);
       hipLaunchKernelGGL(x_big<1>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -1564,7 +1575,8 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipGetLastError());
     }
     if (!v.wave_path) LAUNCH_Q(e1_finalize, v, NS, 0);
-    if (v.wave_path) {
+    if (v.wave_path && b->have_big_hist && b->hist_big[2] == 0 && b->finalize_runs == 1) b->skipped_big[2] = true;
+    else if (v.wave_path) {
       Scope _s(b, "x_big_finalize", 0);
       hipLaunchKernelGGL(x_big<2>, dim3(b->slots_big), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -1807,6 +1819,11 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     settle_alt_stage(b);
     {
       const Counts& c = *b->h_cnt;
+      for (int k = 0; k < 3; k++) {
+        if (b->skipped_big[k] && c.n_big[k] > 0) fail("internal: a pass skipped x_big although items were handed to it");
+        b->hist_big[k] = c.n_big[k];
+      }
+      b->have_big_hist = true;
       b->hist_small = (int64_t)c.n_cls[1]; b->hist_large = (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]); b->hist_copy = (int64_t)c.n_cls[0];
       b->hist_calls = c.n_calls; b->have_hist = true;
     }

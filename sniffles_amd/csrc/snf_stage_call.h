@@ -4,6 +4,7 @@
 // (cluster.py:164-216), Cluster.get_sa_count (cluster.py:79-82), sv.call_from / resolve_bnd /
 // calculate_bounds (sv.py:484-639), util.center/trim/stdev/most_common_top (util.py:25-103).
 #pragma once
+#include <cstddef>
 #include "snf_stage_cluster.h"
 #include "snf_cov.h"
 
@@ -483,9 +484,10 @@ SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
       }
     }
   }
-  if (t == 0) {
+  {  // the counters go to the pinned result block: the T + 1 threads of this launch share the words (one thread storing ~40 words over
+     // PCIe one after the other was most of this kernel's 20 us, and the kernel sits on the critical path of the pass)
     const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
-    for (size_t k = 0; k < sizeof(Counts) / 8; k++) d[k] = s[k];
+    for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)v.T + 1) d[k] = s[k];
   }
 }
 
@@ -728,16 +730,27 @@ SNF_HD void z1_results_body(int64_t t, const View& v) {
   if (t < v.T) { v.res_status[t] = v.t_status[t]; v.res_cov[t] = v.t_cov_avg[t]; }
   // offsets of the tasks' records: candidate list, or (after finalize) the block of the output stage
   if (t <= v.T) v.res_off[t] = v.out_valid ? (int64_t)v.o_scan[v.t_call_off[t]] : v.t_call_off[t];
-  if (t == 0) {
-    if (v.out_valid) *v.res_out = *v.out_hdr;
-    if (v.wave_path) for (int c = 0; c < 4; c++) {  // striped byte counters of the ALT kernels (snf_wave_cons.h)
-      unsigned long long sum = 0;
-      for (int k = 0; k < 64; k++) sum += v.stripes[(c * 64 + k) * 16];
-      v.cnt->cons_bytes[c] = sum;
-    }
-    const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
-    for (size_t k = 0; k < sizeof(Counts) / 8; k++) d[k] = s[k];
+  if (t == 0 && v.out_valid) *v.res_out = *v.out_hdr;
+  // striped byte counters of the ALT kernels (snf_wave_cons.h): class c summed by thread c % (T + 1), straight into the pinned copy
+  // (the copy of the other counters below skips these four words)
+  const size_t cb0 = offsetof(Counts, cons_bytes) / 8;
+  if (v.wave_path) for (int c = (int)t; c < 4; c += v.T + 1) {
+    unsigned long long sum = 0;
+    for (int k = 0; k < 64; k++) sum += v.stripes[(c * 64 + k) * 16];
+    v.cnt->cons_bytes[c] = sum;
+    ((unsigned long long*)v.res_cnt)[cb0 + c] = sum;
   }
+  // how many clusters / calls went to the one-wave-each kernels x_big<kind>: a handle whose pass found none skips those launches next time
+  const size_t nb0 = offsetof(Counts, n_big) / 8;
+  if (v.wave_path) for (int c = (int)t; c < 3; c += v.T + 1) {
+    long long sum = 0;
+    for (int k = 0; k < 64; k++) sum += v.big_cnt[(c * 64 + k) * 16];
+    v.cnt->n_big[c] = sum;
+    ((long long*)v.res_cnt)[nb0 + c] = sum;
+  }
+  const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
+  for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)v.T + 1)
+    if (!(v.wave_path && ((k >= cb0 && k < cb0 + 4) || (k >= nb0 && k < nb0 + 3)))) d[k] = s[k];
 }
 
 }  // namespace snf

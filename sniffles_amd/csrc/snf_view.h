@@ -18,6 +18,7 @@ struct Counts {
   int64_t n_ins_calls, alt_total, n_cons, tab_total, aln_total, n_cons_reads, rn_total;
   int64_t n_dirty_groups;
   int64_t n_kept;            // leads the occupancy prefilter lets through to the sort (a0_*; == NS whenever the prefilter is on)
+  int64_t n_big[3];          // items the wave kernels handed to x_big<0 / 1 / 2> in this pass (sums of View::big_cnt, formed by z1_results)
   int64_t n_occ;             // window front end (snf_stage_window.h): occupied windows of this pass
   int64_t max_win;           // ... and the largest window (only formed at upload, w0_stats)
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel

@@ -116,3 +116,4 @@ def test_vote_column_equals_most_common_rule(emu_lib):
                 exp = ranked[0][1]
         arr = (C.c_uint32 * max(1, len(esc)))(*esc)
         assert f(cnt4, arr, len(esc), q, bq, nkept) == exp, (votes, bq, nkept)
+

@@ -73,3 +73,39 @@ def test_cluster_views_keep_their_ids_behind_the_prefilter():
         if f != "cluster_seed_index":
             assert np.array_equal(before.calls[f], after.calls[f], equal_nan=before.calls[f].dtype.kind == "f"), f
     assert int(cl["seed_index"].max()) > len(cl["seed_index"])      # counts singleton bins too
+
+
+# ---- the window front end (snf_stage_window.h), the sort path it replaces, and the scan chains in both forms
+FRONT_VARIANTS = [dict(SNF_CHAIN="0"), dict(SNF_CHAIN="1"), dict(SNF_NO_WINFRONT="1"), dict(SNF_WIN_BITS="6"), dict(SNF_WIN_BITS="8", SNF_CHAIN="0"),
+                  dict(SNF_WIN_BITS_MAX="12"), dict(SNF_GRAPH="1", SNF_CHAIN="1"), dict(SNF_GRAPH="1", SNF_CHAIN="0")]
+
+
+def check_front_variants(L, oracle_mod, monkeypatch, env, passes=3):
+    """Window widths down to windows that need the 1024-lead instance and up to 12 bits, the sort path (SNF_NO_WINFRONT=1), the scan
+    chains as single launches (decoupled look-back) and as launch pairs, the pass replayed from a HIP graph: the calls of the oracle,
+    pass after pass over the same handle (the counters, cursors and chain tags a pass leaves behind are right for the next one)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tis = [synth.gen_task(0, "chr20", 2_500_000, 30, 11), synth.gen_fuzz(41, task_id=1), synth.gen_task(2, "chr21", 1_500_000, 60, 12, err=0.005),
+           synth.gen_fuzz(42, task_id=3)]
+    for kw in ({}, dict(mosaic=True)):
+        cfg = SnifflesConfig(**kw)
+        exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+        with lib.Batch(cfg, tis, **(dict(_lib=L) if L is not None else {})) as b:
+            for _ in range(passes):
+                b.run_pass()
+                assert records.records(b.fetch(1), tis, "final") == exp
+            b.call_candidates(); b.finalize()                      # ... and the two calls on their own afterwards
+            assert records.records(b.fetch(1), tis, "final") == exp
+
+
+@pytest.mark.parametrize("env", FRONT_VARIANTS[:6])
+def test_front_end_and_scan_chain_variants_are_exact_emu(oracle_mod, monkeypatch, env):
+    import emu.emu as E
+    check_front_variants(E.lib(), oracle_mod, monkeypatch, env, passes=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", FRONT_VARIANTS)
+def test_front_end_chain_and_graph_variants_are_exact_gpu(oracle_mod, monkeypatch, env):
+    check_front_variants(None, oracle_mod, monkeypatch, env, passes=5)
