@@ -1,28 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native Sniffles2 hot path (BASELINE.json metric).
 
-One "step" = one full pass of the hot path (Task.call_candidates + Task.finalize_candidates of every
-contig task of the workload: binning, clustering, candidate calls, coverage, QC, genotyping, phasing,
-INS consensus) with the signature tables already resident in HBM, INCLUDING the device->host copy of
-the call records / ALT pool and, for N > 1, the gather of the per-rank results on rank 0.
+One "step" = one full pass of the hot path (Task.call_candidates + Task.finalize_candidates of every contig task of the workload:
+binning, clustering, candidate calls, coverage, QC, genotyping, phasing, INS consensus - `snf_batch_pass`) with the signature
+tables already resident in HBM, INCLUDING the arrival of the result block in host memory (what `CallTask.execute` returns: the
+QC-passing calls per task sorted by position, their read names and ALT bytes; `--output candidates`: every candidate record) and,
+for N > 1, the gather on rank 0.
 
 Workloads (--config, BASELINE.json `configs`; all seeded synthetic signature sets):
   0  chr20-only 30x ONT germline (the reference's CPU-runnable plumbing case)
   1  30x ONT HG002-shaped whole genome, germline           <- default, the configuration the metric is quoted on
   2  60x PacBio-HiFi-shaped whole genome (INS consensus heavy: err 0.5 %, 15-kb reads)
   3  30x ONT whole genome, --mosaic (30 % of the sites at VAF 0.05-0.2)
-  4  population merge: 10 HG002-shaped samples -> combine (CombineTask.execute over SNF blocks)
+  4  population merge: 10 HG002-shaped samples -> combine (CombineTask.execute: candidates resident as columns -> merged VCF records)
 --scaling weak (default): N genome replicas, the 24*N contig tasks sharded longest-first over the ranks.
---scaling strong: ONE genome; its contigs are grouped into device batches which the ranks claim from a shared work queue
-  (sniffles_amd.dist.TaskQueue over the process group's store), K passes over the same genome.
+--scaling strong: ONE genome; its contigs are partitioned into one LPT-balanced contig SET per rank and pass, which the ranks claim
+  from a shared work queue (sniffles_amd.dist.TaskQueue over the process group's store); a set is one device batch; passes pipelined.
 The only collective is the gather on rank 0.  On one node (the default) every rank's kernels store its result into a
 shared-memory segment that rank 0 maps as well (sniffles_amd.dist.SharedLanding: N PCIe links in parallel) and only the
-layouts are gathered; SNF_BENCH_GATHER=rccl and --scaling strong gather the result blocks over RCCL (dist.gather_results).
+layouts are gathered; SNF_BENCH_GATHER=rccl gathers the result blocks over RCCL (dist.gather_results).
 
 At N = 1 the line also carries
-  wall_clock    one genome end to end through the drop-in boundary: upload, pass, D2H, SVCall materialisation
-  cpu_baseline  the C oracle over the WHOLE workload, one process per contig on all host cores (the reference's schedule)
-  verified      the HIP results of the exact bench workload compared record by record with that oracle run
+  wall_clock    one genome end to end through the drop-in boundary: ingest of Lead objects, upload, pass, the SVCall objects
+  cpu_baseline  kind "reference": the UNMODIFIED reference (oracle/_ref, byte-compiled by oracle/make_ref.py) on the same 24 signature
+                tables, one process per contig on this box's cores, with vs_baseline; the C oracle beside it (cpu_baseline.port)
+  verified / verified_vs_reference   the HIP results of the exact bench workload compared record by record with the oracle run and
+                with what the reference's CallTask.execute keeps
 
 Usage: python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
 Prints ONE JSON line on rank 0.
