@@ -49,6 +49,8 @@ DEV = "cpu" if EMU else "cuda"
 
 
 def emu_lib():
+    """SNF_BENCH_EMU=1: the host tier of the test suite becomes the library this process works on (emu.emu.lib() calls
+    sniffles_amd.lib.use_library)."""
     if not EMU:
         return None
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -183,6 +185,7 @@ def main():
     import torch
     import torch.distributed as dist
 
+    emu_lib()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -269,7 +272,7 @@ def run_calling(ctx):
     W = max(1, args.inflight)
     t0 = time.time()
     # handles[w][g]: batch handle of group g for host thread w (same input, independent handles)
-    handles = [[lib.Batch(cfg, gt, device=(0 if EMU else local_rank), _lib=emu_lib()) for gt in group_tasks] for _ in range(W)]
+    handles = [[lib.Batch(cfg, gt, device=(0 if EMU else local_rank)) for gt in group_tasks] for _ in range(W)]
     t_upload = time.time() - t0
     # N > 1 on one node: every rank's kernels store the result into a shared-memory segment the parent rank maps as well
     # (sniffles_amd.dist.SharedLanding: N PCIe links in parallel, the gather exchanges layouts only).  SNF_BENCH_GATHER=rccl (and
@@ -619,7 +622,7 @@ def run_calling(ctx):
     ms_with_index = None
     if world == 1 and not strong and not use_dist and not args.no_wall_clock:
         os.environ["SNF_READPREP_EACH_PASS"] = "1"
-        extra = [[lib.Batch(cfg, tasks, device=(0 if EMU else local_rank), _lib=emu_lib())] for _ in range(W)]
+        extra = [[lib.Batch(cfg, tasks, device=(0 if EMU else local_rank))] for _ in range(W)]
         del os.environ["SNF_READPREP_EACH_PASS"]
         handles_box[0] = extra
         k2 = max(W, args.steps // 2)
@@ -954,7 +957,7 @@ def other_configs(ctx) -> dict:
             specs = task_specs(a, wl, 0, 0, 1)
             tasks = [synth.gen_task(**kw) for _, kw in specs]
             W, steps, warm = 2, 12, 2
-            hs = [lib.Batch(cfg, tasks, device=(0 if EMU else local_rank), _lib=emu_lib()) for _ in range(W)]
+            hs = [lib.Batch(cfg, tasks, device=(0 if EMU else local_rank)) for _ in range(W)]
             for h in hs:
                 h.set_output(abi.OUT_EXECUTE)
 

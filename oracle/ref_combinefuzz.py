@@ -83,7 +83,7 @@ def main():
             print("skipped", args, type(e).__name__, e)
             continue
         readers = {s: T.BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
-        task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=L)
+        task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
         got = [group_record(c) for c in task.execute(readers)]
         want = exp["calls"]
         n_calls += len(want)

@@ -76,7 +76,7 @@ def main():
             if "error" not in ref:
                 diffs.append(f"oracle raised {type(e).__name__}: {e}")
         try:
-            ti, info = extract.extract_region(recs, contig, st, en, DevCfg(**cfg), rid0, _lib=L)
+            ti, info = extract.extract_region(recs, contig, st, en, DevCfg(**cfg), rid0)
             if "error" in ref:
                 diffs.append(f"kernels: the reference raised {ref['error']}")
             else:

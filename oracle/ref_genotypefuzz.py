@@ -64,7 +64,7 @@ def main():
             lp.record_read(s, e, hp)
         targets = gutil.make_targets(specs, sv.SVCall, sv.SVCallBNDInfo, sv.new_call)
         task = parallel.GenotypeTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                                     lead_provider=lp, genotype_svs=targets, _lib=L)
+                                     lead_provider=lp, genotype_svs=targets)
         task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
         diffs = []
         try:

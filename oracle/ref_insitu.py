@@ -69,8 +69,7 @@ def patched(emu_lib=None, device: int = 0):
 
     def call_candidates(self, keep_qc_fails, config):
         t = amd_parallel.Task(id=self.id, sv_id=self.sv_id, contig=self.contig, start=self.start, end=self.end, config=config,
-                              lead_provider=self.lead_provider._amd, tandem_repeats=self.tandem_repeats, device=device,
-                              _lib=emu_lib)
+                              lead_provider=self.lead_provider._amd, tandem_repeats=self.tandem_repeats, device=device)
         self._amd_task = t
         out = t.call_candidates(keep_qc_fails, config, svcall_cls=ref.sv.SVCall, bnd_cls=ref.sv.SVCallBNDInfo)
         self.sv_id, self.coverage_average_total = t.sv_id, t.coverage_average_total

@@ -74,7 +74,7 @@ def main():
                 paths = []
                 for s, r in enumerate(recs_list):
                     path = os.path.join(wd, f"own{s}.snf")
-                    pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=r.tandem_repeats, _lib=L)
+                    pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=r.tandem_repeats)
                     paths.append(path)
                 # the sample ids in the header come from the file names: same basenames as the reference's files
                 renamed = []
@@ -82,12 +82,12 @@ def main():
                 for s, pth in enumerate(paths):
                     q = os.path.join(od, f"sample{s}.snf"); os.rename(pth, q); renamed.append(q)
                 buf = io.StringIO()
-                pipeline.combine(renamed, config_for(args), vcf_handle=buf, _lib=L)
+                pipeline.combine(renamed, config_for(args), vcf_handle=buf)
                 assert_same_text(buf.getvalue(), ref["vcf"])
                 n_rec += len(vu.split_text(ref["vcf"])[1]); n_samples += ns
                 # and over the reference's own files
                 buf2 = io.StringIO()
-                pipeline.combine(ref["snf"], config_for(args), vcf_handle=buf2, _lib=L)
+                pipeline.combine(ref["snf"], config_for(args), vcf_handle=buf2)
                 assert_same_text(buf2.getvalue(), ref["vcf"])
             except AssertionError as e:
                 diffs.append(str(e)[:500])

@@ -98,14 +98,14 @@ def main():
                 c = config_for(args)
                 c.regions_by_contig = regions or {}
                 return c
-            res = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf, tandem_repeats=recs.tandem_repeats, _lib=L)
+            res = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf, tandem_repeats=recs.tandem_repeats)
             if res.read_count != ref["read_count"]:
                 diffs.append(f"read_count {res.read_count} != {ref['read_count']}")
             assert_same_text(canon(buf.getvalue()), canon(ref["vcf"]))
             n_rec += res.vcf_records; n_reads += res.read_count; n_regions += 1 if regions else 0
             # the same text straight from the record table, without SVCall objects (vcf.VCF.write_records)
             buf2 = io.StringIO()
-            res2 = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf2, tandem_repeats=recs.tandem_repeats, _lib=L, objects=False)
+            res2 = pipeline.call_sample(recs, own_cfg(), vcf_handle=buf2, tandem_repeats=recs.tandem_repeats, objects=False)
             assert buf2.getvalue() == buf.getvalue(), "record-table writer differs from the object path"
             assert res2.vcf_records == res.vcf_records and not res2.calls
         except AssertionError as e:

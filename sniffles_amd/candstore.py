@@ -199,7 +199,7 @@ def _collect_from_columns(tasks, samples_snf, config, fast):
     return readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool), covx
 
 
-def _regenotype(blocks, readers, config, device, _lib):
+def _regenotype(blocks, readers, config, device):
     """`--reqc`: candidates of SNF files older than 2.5.3 are genotyped again (parallel.py:507-508), one launch."""
     old = [k for k, (_, snf) in enumerate(readers) if getattr(snf, "reqc", False)]
     if not old:
@@ -209,7 +209,7 @@ def _regenotype(blocks, readers, config, device, _lib):
             if c.support >= thr]
     if todo:
         from . import postprocessing
-        postprocessing.genotype_svs(todo, config, device=device, _lib=_lib)
+        postprocessing.genotype_svs(todo, config, device=device)
 
 
 def _segmented_running(values, seg, take_max: bool):
@@ -234,7 +234,7 @@ def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
 def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     fast = sv._load_fast()
     t0 = tasks[0]
-    config, device, _lib = t0.config, t0.device, t0._lib
+    config, device = t0.config, t0.device
     n_tasks = len(tasks)
     tm = [("start", time.perf_counter())]
     mark = lambda name: tm.append((name, time.perf_counter()))  # noqa: E731
@@ -252,7 +252,7 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         covx = None
         readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
         mark("walk_blocks")
-        _regenotype(blocks, readers, config, device, _lib)
+        _regenotype(blocks, readers, config, device)
         sids = np.asarray([sid for sid, _ in readers], np.int32)
         objs, rec, cblk, ctyp, mate, aoff, apool = fast.collect(blocks, sids, tuple(sv.TYPES), int(config.combine_support_threshold), _MATE_IDS)
         n = len(objs)
@@ -318,7 +318,7 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     n_ids = int(rec["sample"].max()) + 1
     arr, out = abi.combine_chain_problems(codes, win_off[s_lo], win_off[s_hi], s_lo, s_hi, cols, (aoff, apool), win_off, win_bin,
                                           win_thr, n_ids, keep)
-    lib.combine_resolve_batch(config, arr, device=device, _lib=_lib)
+    lib.combine_resolve_batch(config, arr, device=device)
     mark("resolve_groups_gpu")
     # group numbers: sub-chain -> whole merge (creation order inside a chain is the order of the sub-chains)
     gid_local = out[:n].astype(np.int64)
@@ -337,7 +337,7 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     g_chain = chain_no[g_first_win]
     g_hi = chain_hi[g_chain].astype(np.int32)
     mark("membership")
-    gout, chosen, pos_mean = lib.combine_call_groups(config, group_off, member, rec, cand_win, g_hi, win_bin, win_thr, device=device, _lib=_lib)
+    gout, chosen, pos_mean = lib.combine_call_groups(config, group_off, member, rec, cand_win, g_hi, win_bin, win_thr, device=device)
     mark("call_groups_gpu")
     # ---- 5. emission order (parallel.py:536-572): a flushed group leaves with its window's event - events run block by block,
     # SV type by SV type, window by window - in creation order; what is still active at the end leaves per SV type

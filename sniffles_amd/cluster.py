@@ -189,21 +189,21 @@ def apply_assignment(svcands, groups_initial, out_group):
     return groups
 
 
-def resolve_block_groups(svtype, svcands, groups_initial, config, device: int = 0, _lib=None):
+def resolve_block_groups(svtype, svcands, groups_initial, config, device: int = 0):
     """For clustering groups of SVs when combining .snf files (multi-call).  Mutates and returns `groups_initial`."""
     keep = []
     q, out = pack_problem(svtype, svcands, groups_initial, keep)
-    lib.combine_resolve_batch(config, [q], device=device, _lib=_lib)
+    lib.combine_resolve_batch(config, [q], device=device)
     return apply_assignment(svcands, groups_initial, out)
 
 
-def resolve_block_groups_batch(problems, config, device: int = 0, _lib=None):
+def resolve_block_groups_batch(problems, config, device: int = 0):
     """Several independent (svtype, svcands, groups_initial) problems in one launch - e.g. the flush windows of
     different contigs / SV types of CombineTask.execute (parallel.py:524-534).  Returns the list of group lists."""
     keep, packed = [], []
     for svtype, svcands, groups_initial in problems:
         packed.append(pack_problem(svtype, svcands, groups_initial, keep))
-    lib.combine_resolve_batch(config, [q for q, _ in packed], device=device, _lib=_lib)
+    lib.combine_resolve_batch(config, [q for q, _ in packed], device=device)
     return [apply_assignment(sc, gi, out) for (_, sc, gi), (_, out) in zip(problems, packed)]
 
 
@@ -231,7 +231,7 @@ def chain_cuts(svtype, svcands, win_off, config):
     return [0] + [w for w in range(1, nw) if lo[w] - hi[w - 1] > gate] + [nw]
 
 
-def resolve_chains_batch(chains, config, device: int = 0, _lib=None, cut: bool = None):
+def resolve_chains_batch(chains, config, device: int = 0, cut: bool = None):
     """Whole chains of flush windows in one launch.  chains: list of (svtype, svcands, win_off, win_bin, win_thr) with
     svcands the concatenation of the windows' candidates; after window w the groups with
     abs(pos_mean - win_bin[w]) < win_thr[w] stay active for window w+1 (CombineTask.execute, parallel.py:553-556).
@@ -279,7 +279,7 @@ def resolve_chains_batch(chains, config, device: int = 0, _lib=None, cut: bool =
     keep = []
     n_ids = max(cols["sample_id"]) + 1 if n_c else 1
     arr, out = abi.combine_chain_problems(codes, c_lo, c_hi, w_lo, w_hi, cols, alts, wstart + [n_c], wbin, wthr, n_ids, keep)
-    lib.combine_resolve_batch(config, arr, device=device, _lib=_lib)
+    lib.combine_resolve_batch(config, arr, device=device)
     # chain-wide group numbers: sub-chain s of a chain starts after the groups its predecessors created
     lo, hi = np.asarray(c_lo, np.int64), np.asarray(c_hi, np.int64)
     created = np.array([int(out[a:b].max()) + 1 if b > a else 0 for a, b in zip(c_lo, c_hi)], np.int64)

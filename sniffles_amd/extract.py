@@ -30,9 +30,9 @@ class ExtractInfo:
 class Extractor:
     """One extraction handle (device allocations are reused per upload)."""
 
-    def __init__(self, config=None, device: int = 0, _lib=None):
+    def __init__(self, config=None, device: int = 0):
         from . import lib as L
-        self.lib = _lib or L.load()
+        self.lib = L.load()
         self._err = L.SnifflesAmdError
         self._h = C.c_void_p()
         cs = abi.extract_config_struct(config if config is not None else object())
@@ -142,10 +142,10 @@ class Extractor:
 
 
 def extract_region(recs: bam.BamRecords, contig: str, start: int, end: int, config=None, read_id_offset: int = 0,
-                   task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None, device: int = 0, _lib=None):
+                   task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None, device: int = 0):
     """`LeadProvider(config, read_id_offset, contig).build_leadtab([Region(contig, start, end)], bam)` on the GPU.
     Returns (TaskInput, ExtractInfo)."""
-    x = Extractor(config, device, _lib)
+    x = Extractor(config, device)
     try:
         x.upload(recs, contig, start, end, read_id_offset)
         x.run()
@@ -155,11 +155,11 @@ def extract_region(recs: bam.BamRecords, contig: str, start: int, end: int, conf
 
 
 def extract_region_device(recs: bam.BamRecords, contig: str, start: int, end: int, config=None, read_id_offset: int = 0,
-                          task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None, device: int = 0, _lib=None):
+                          task_id: int = 0, sv_id_start: int = 0, tandem_repeats=None, device: int = 0):
     """`extract_region` whose result stays in HBM: returns (soa.DeviceTaskInput, ExtractInfo, Extractor).  The clustering
     batch takes the columns device-to-device; close the extractor once the task is through (its memory backs the task until
     the batch has been created, and the lazy host copies of the columns afterwards)."""
-    x = Extractor(config, device, _lib)
+    x = Extractor(config, device)
     try:
         x.upload(recs, contig, start, end, read_id_offset)
         x.run()

@@ -97,8 +97,22 @@ def bind(lib: C.CDLL) -> C.CDLL:
     return lib
 
 
+_override = None
+
+
+def use_library(handle) -> None:
+    """Every entry point of this package goes through the library `load()` returns.  `use_library(h)` makes that an already bound
+    library `h` - another build of the same sources: `bind(ctypes.CDLL(path))`, the programmatic form of `SNF_LIB_SO`; the test
+    suite's host tier (the unchanged HIP sources on a fibre stand-in for the HIP runtime) comes in this way - `use_library(None)`
+    the default again.  Objects keep the library they were created with."""
+    global _override
+    _override = handle
+
+
 def load() -> C.CDLL:
     global _lib
+    if _override is not None:
+        return _override
     if _lib is None:
         so = os.environ.get("SNF_LIB_SO") or SO      # SNF_LIB_SO: another build of the same sources (A/B measurements)
         if not os.path.exists(so):
@@ -116,8 +130,8 @@ def _check(lib, rc):
 class Batch:
     """A set of contig tasks resident in HBM.  `tasks`: list of sniffles_amd.soa.TaskInput."""
 
-    def __init__(self, cfg, tasks, device: int = 0, _lib=None):
-        self.lib = _lib or load()
+    def __init__(self, cfg, tasks, device: int = 0):
+        self.lib = load()
         self.tasks = list(tasks)
         self._h = C.c_void_p()
         import os
@@ -294,20 +308,20 @@ class Batch:
         return out
 
 
-def trim_caches(device: int = -1, _lib=None) -> int:
+def trim_caches(device: int = -1) -> int:
     """Release what the library keeps of finished batches (HBM slabs, pinned buffers, idle streams); bytes released."""
-    return int((_lib or load()).snf_trim_caches(device))
+    return int(load().snf_trim_caches(device))
 
 
 def device_count() -> int:
     return int(load().snf_device_count())
 
 
-def edit_distance_batch(pairs, device: int = 0, _lib=None, max_dist=None) -> np.ndarray:
+def edit_distance_batch(pairs, device: int = 0, max_dist=None) -> np.ndarray:
     """Global unit-cost edit distance for a list of (bytes, bytes) pairs (edlib.align(a,b)['editDistance']).
     `max_dist` (one int per pair, or one int for all; edlib's `k`): distances beyond it come back as -1 and the alignment
     is banded accordingly; None / negative: exact."""
-    lib = _lib or load()
+    lib = load()
     n = len(pairs)
     a_off = np.zeros(n + 1, np.int64)
     b_off = np.zeros(n + 1, np.int64)
@@ -332,9 +346,9 @@ def edit_distance_batch(pairs, device: int = 0, _lib=None, max_dist=None) -> np.
     return out[:n]
 
 
-def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
+def combine_resolve_batch(cfg, problems, device: int = 0) -> None:
     """Run a list of packed resolve_block_groups problems (abi.combine_problem structs); fills their out_group arrays."""
-    lib = _lib or load()
+    lib = load()
     if not len(problems):
         return
     arr = problems if isinstance(problems, C.Array) else (abi.snf_combine_problem_t * len(problems))(*problems)
@@ -344,11 +358,11 @@ def combine_resolve_batch(cfg, problems, device: int = 0, _lib=None) -> None:
         raise SnifflesAmdError("snf_combine_resolve_batch failed (no HIP device, or invalid sample ids)")
 
 
-def combine_call_groups(cfg, group_off, member, cand, cand_win, group_win_hi, win_bin, win_thr, device: int = 0, _lib=None):
+def combine_call_groups(cfg, group_off, member, cand, cand_win, group_win_hi, win_bin, win_thr, device: int = 0):
     """`SVGroup.call` and the keep / flush walk for all groups of a merge (snf_combine_call_groups).  cand: abi.GROUP_CAND_DTYPE
     records; member / group_off: the groups' candidates in add order.  Returns (out: abi.GROUP_OUT_DTYPE per group,
     chosen: uint8 per member, pos_mean: float64 per member)."""
-    lib = _lib or load()
+    lib = load()
     group_off = np.ascontiguousarray(group_off, np.int64)
     n_groups = len(group_off) - 1
     member = np.ascontiguousarray(member, np.int32)
@@ -371,18 +385,18 @@ def combine_call_groups(cfg, group_off, member, cand, cand_win, group_win_hi, wi
     return out, chosen, pos_mean
 
 
-def combine_last_stats(device: int = 0, _lib=None) -> dict:
+def combine_last_stats(device: int = 0) -> dict:
     """Kernel time and alignment counters of the last combine_resolve_batch on `device`."""
-    lib = _lib or load()
+    lib = load()
     ms, st = C.c_double(), (C.c_int64 * 4)()
     if lib.snf_combine_last_stats(device, C.byref(ms), st) != 0:
         raise SnifflesAmdError("snf_combine_last_stats failed")
     return dict(kernel_ms=float(ms.value), alignments=int(st[0]), aligned_bytes=int(st[1]), dp_cells=int(st[2]), staged_bytes=int(st[3]))
 
 
-def genotype_batch(cfg, records: np.ndarray, device: int = 0, _lib=None) -> np.ndarray:
+def genotype_batch(cfg, records: np.ndarray, device: int = 0) -> np.ndarray:
     """genotype_sv (genotyping.py:62-241) over a structured array of call records (abi.CALL_DTYPE), in place."""
-    lib = _lib or load()
+    lib = load()
     records = np.ascontiguousarray(records, abi.CALL_DTYPE)
     cs = abi.config_struct(cfg)
     _check(lib, lib.snf_genotype_batch(C.byref(cs), device, records.ctypes.data_as(C.POINTER(abi.snf_call_t)), len(records)))

@@ -20,7 +20,7 @@ from .abi import TASK_ERR_UNBOUND_END
 
 class Task:
     def __init__(self, id, sv_id, contig, start, end, config, assigned_process_id=None, lead_provider=None,
-                 tandem_repeats=None, regions=None, device: int = 0, _lib=None):
+                 tandem_repeats=None, regions=None, device: int = 0):
         self.id, self.sv_id, self.contig, self.start, self.end = id, sv_id, contig, start, end
         self.config = config
         self.assigned_process_id = assigned_process_id
@@ -29,7 +29,6 @@ class Task:
         self.regions = regions
         self.device = device
         self.coverage_average_total = None
-        self._lib = _lib
         self._batch = None
         self._ti = None
 
@@ -40,7 +39,7 @@ class Task:
         self._ti = lp.to_task_input(self.id, self.sv_id, self.tandem_repeats,
                                     getattr(config, "qc_nm_threshold", 0.02))
         self.close()
-        self._batch = lib.Batch(config, [self._ti], device=self.device, _lib=self._lib)
+        self._batch = lib.Batch(config, [self._ti], device=self.device)
         lp.device_batch = self._batch   # SNFile.annotate_block_coverages(lead_provider) reads the coverage from HBM
         lp.task_input = self._ti        # cluster.resolve(svtype, lead_provider, ...) reads the clusters back (seam B3)
 
@@ -304,7 +303,7 @@ class CombineTask(Task):
                 if chains[t]["win_bin"]:
                     flat.append((t, chains[t]["cands"], chains[t]["win_off"], chains[t]["win_bin"], chains[t]["win_thr"]))
                     owner.append((k, t))
-        outs = cluster.resolve_chains_batch(flat, self.config, device=self.device, _lib=self._lib) if flat else []
+        outs = cluster.resolve_chains_batch(flat, self.config, device=self.device) if flat else []
         assigns = [dict() for _ in chains_per_task]
         for (k, t), o in zip(owner, outs):
             assigns[k][t] = o
@@ -362,7 +361,7 @@ class CombineTask(Task):
                         svcands = []
         if regenotype:
             from . import postprocessing
-            postprocessing.genotype_svs(regenotype, config, device=self.device, _lib=self._lib)
+            postprocessing.genotype_svs(regenotype, config, device=self.device)
         return chains, events
 
     def _replay(self, chains, events, assign, sample_internal_ids):

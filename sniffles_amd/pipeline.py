@@ -113,7 +113,7 @@ class _RegionExtractor:
         pass
 
 
-def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tandem_repeats, device, _lib):
+def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tandem_repeats, device):
     """`build_leadtab(regions, bam)` (leadprov.py:445-472): one extraction per region, in list order, into one task; the
     running read id carries on from region to region."""
     from . import soa
@@ -121,7 +121,7 @@ def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tan
     info = None
     for start, end in regions:
         ti, info = extract.extract_region(recs, contig, start, end, config, read_id_offset=rid % 2 ** 32, task_id=task_id, sv_id_start=0,
-                                          tandem_repeats=tandem_repeats, device=device, _lib=_lib)
+                                          tandem_repeats=tandem_repeats, device=device)
         parts.append(ti)
         read_count += info.read_count
         rid = info.read_id
@@ -129,8 +129,7 @@ def _extract_regions(recs, contig, regions, config, read_id_offset, task_id, tan
     return soa.concat_tasks(parts), info, _RegionExtractor()
 
 
-def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0,
-                _lib=None, objects: bool = True, reference=None) -> SampleResult:
+def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None, tandem_repeats=None, device: int = 0, objects: bool = True, reference=None) -> SampleResult:
     """`records`: `bam.read_bam(path)`.  `tandem_repeats`: {contig: [(start, end), ...]} (already padded, util.py:121-144).
     Writes the VCF to `vcf_handle` and / or the SNF to `snf_path` (CallTask.execute switches QC filtering off for the
     candidates when an SNF is requested, parallel.py:258-263).
@@ -158,16 +157,16 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     for task_id, (contig, length) in enumerate(contig_lengths):
         tr = (tandem_repeats or {}).get(contig)
         task = parallel.CallTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config,
-                                 tandem_repeats=tr, device=device, _lib=_lib)
+                                 tandem_repeats=tr, device=device)
         # the signatures never leave HBM between the extraction and the clustering batch (snf_batch_add_task_device)
         regions = regions_of(config, contig)
         if regions:      # --regions: the task's leads and coverage come from these intervals only (sniffles:330-341)
             ti, info, extractor = _extract_regions(bam.contig_records(records, contig), contig, regions, config,
-                                                   (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device, _lib)
+                                                   (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device)
         else:
             ti, info, extractor = extract.extract_region_device(bam.contig_records(records, contig), contig, task.start, task.end, config,
                                                                 read_id_offset=(task_id * config.task_read_id_offset_mult) % 2 ** 32,
-                                                                task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device, _lib=_lib)
+                                                                task_id=task_id, sv_id_start=0, tandem_repeats=tr, device=device)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold      # iter_region's side channel
         mask_N_coverage(ti, fasta_handle, contig, regions or [(task.start, task.end)])
         task.lead_provider = _Extracted(ti)
@@ -205,7 +204,7 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     return out
 
 
-def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, _lib=None, objects: bool = True) -> list:
+def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, objects: bool = True) -> list:
     """Multi-sample calling from per-sample `.snf` files: the `combine` flow of the reference's main program
     (`sniffles:371-490`) for one process - headers (sample ids, contig lengths, format checks), one `CombineTask` per
     contig over `snf.SNFile` readers (group assignment on the GPU), calls of a task sorted by position
@@ -237,7 +236,7 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
         writer = vcf.VCF(config, vcf_handle)
         writer.write_header(contig_lengths)
     out = []
-    tasks = [parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device, _lib=_lib,
+    tasks = [parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, device=device,
                                   regions=(getattr(config, "regions_by_contig", None) or {}).get(contig))
              for task_id, (contig, length) in enumerate(contig_lengths)]
     if not objects and writer is not None and writer.can_write_merged():
@@ -260,8 +259,7 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
     return out
 
 
-def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle, tandem_repeats=None, device: int = 0,
-                 _lib=None, reference=None) -> int:
+def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle, tandem_repeats=None, device: int = 0, reference=None) -> int:
     """Force calling (`--genotype-vcf`, sniffles:190-213, 487-560 and `GenotypeTask.execute`): the SVs of the input VCF are
     matched against this sample's candidates contig by contig and written back with the sample's genotype (contig by
     contig, input order within a contig).  Returns the number of records written."""
@@ -284,10 +282,10 @@ def genotype_vcf(records: bam.BamRecords, config, vcf_in_handle, vcf_out_handle,
         tr = (tandem_repeats or {}).get(contig)
         targets = [t for t in by_contig.get(contig, []) if 0 <= t.pos < length - 1]
         task = parallel.GenotypeTask(id=task_id, sv_id=0, contig=contig, start=0, end=length - 1, config=config, tandem_repeats=tr,
-                                     genotype_svs=targets, device=device, _lib=_lib)
+                                     genotype_svs=targets, device=device)
         regions = regions_of(config, contig) or [(task.start, task.end)]       # --regions: leads and coverage from these intervals only
         ti, _, _ = _extract_regions(bam.contig_records(records, contig), contig, regions, config,
-                                    (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device, _lib)
+                                    (task_id * config.task_read_id_offset_mult) % 2 ** 32, task_id, tr, device)
         config.qc_nm_threshold = config.average_regional_nm = ti.qc_nm_threshold
         mask_N_coverage(ti, fasta_handle, contig, regions)
         task.lead_provider = _Extracted(ti)

@@ -18,7 +18,7 @@ from . import abi, lib
 from .soa import SVT
 
 
-def genotype_svs(svcalls, config, device: int = 0, _lib=None) -> None:
+def genotype_svs(svcalls, config, device: int = 0) -> None:
     """`postprocessing.genotype_sv(svcall, config)` (postprocessing.py:607-623) for a list of calls, one device launch."""
     svcalls = list(svcalls)
     if not svcalls:
@@ -34,7 +34,7 @@ def genotype_svs(svcalls, config, device: int = 0, _lib=None) -> None:
         r["cov"] = cov
         r["filter"], r["qc"] = abi.FILTERS.index(c.filter), int(bool(c.qc))
         r["gt_set"], r["vaf"], r["ph_set"] = 0, np.nan, 0     # the phase strings are handled below, on the host
-    lib.genotype_batch(config, rec, device=device, _lib=_lib)
+    lib.genotype_batch(config, rec, device=device)
     K = {n: k for k, n in enumerate(abi.CALL_DTYPE.names)}
     for c, r in zip(svcalls, rec.tolist()):
         c.filter, c.qc = abi.FILTERS[r[K["filter"]]], bool(r[K["qc"]])
@@ -60,10 +60,10 @@ def genotype_svs(svcalls, config, device: int = 0, _lib=None) -> None:
             pass
 
 
-def genotype_sv(svcall, config, phase=None, device: int = 0, _lib=None) -> None:
+def genotype_sv(svcall, config, phase=None, device: int = 0) -> None:
     if phase is not None:
         raise NotImplementedError("genotype_sv with an explicit phase is the finalize stage's call (it runs on the GPU)")
-    genotype_svs([svcall], config, device=device, _lib=_lib)
+    genotype_svs([svcall], config, device=device)
 
 
 def coverage(calls, lead_provider) -> float:

@@ -44,9 +44,9 @@ class PopulationVariant:
                 carrying += 1
         return variant / total, genotyped, carrying
 
-    def match(self, svcall, config, device: int = 0, _lib=None) -> Optional[int]:
+    def match(self, svcall, config, device: int = 0) -> Optional[int]:
         """The distance (smaller is better) or None when `svcall` is not this variant (snfp.py:91-107)."""
-        return match_batch([(self, svcall)], config, device, _lib)[0]
+        return match_batch([(self, svcall)], config, device)[0]
 
 
 def _gate(pv, svcall, config) -> Optional[int]:
@@ -57,7 +57,7 @@ def _gate(pv, svcall, config) -> Optional[int]:
     return dist
 
 
-def match_batch(pairs, config, device: int = 0, _lib=None) -> list:
+def match_batch(pairs, config, device: int = 0) -> list:
     """`pv.match(svcall)` for every (population variant, call) pair; the insertions' sequence comparisons of all pairs go to
     the GPU in one launch.  The reference rejects when `(svlen - d) / svlen <= combine_pctseq`, i.e. accepts iff
     d < (1 - pctseq) * svlen: that bound is the band of the alignment (distances beyond it need not be exact)."""
@@ -68,7 +68,7 @@ def match_batch(pairs, config, device: int = 0, _lib=None) -> list:
         seqs = [(pairs[k][0].alt.encode("latin-1"), pairs[k][1].alt.encode("latin-1")) for k in todo]
         # reject iff (svlen - d) / svlen <= limit  <=>  d >= svlen * (1 - limit): any distance >= that bound may come back as -1
         bounds = [max(0, int(math.ceil(abs(pairs[k][0].svlen) * (1.0 - limit))) + 1) for k in todo]
-        d = lib.edit_distance_batch(seqs, device=device, _lib=_lib, max_dist=bounds)
+        d = lib.edit_distance_batch(seqs, device=device, max_dist=bounds)
         for k, dk in zip(todo, d.tolist()):
             pv = pairs[k][0]
             if dk < 0 or (pv.svlen - dk) / pv.svlen <= limit:

@@ -13,6 +13,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _library_selection(request):
+    """Every test starts on the real library; the host-tier tests switch to theirs by asking for it (`emu.emu.lib()` calls
+    `sniffles_amd.lib.use_library`)."""
+    from sniffles_amd import lib
+    lib.use_library(None)
+    yield
+    lib.use_library(None)
+
+
 @pytest.fixture(scope="session")
 def oracle_mod():
     import oracle  # test infrastructure (oracle/oracle.py)

@@ -16,4 +16,5 @@ def build():
 
 
 def lib():
+    """The host-tier library, bound; handing it out also makes it the library the product package works on (see simt.lib)."""
     return _simt.lib()

@@ -74,10 +74,18 @@ def _bind(path):
     return h
 
 
+def _activate(h):
+    """Handing the host tier out makes it the library the product package works on (`sniffles_amd.lib.use_library`);
+    tests/conftest.py selects the real one again before every test."""
+    from sniffles_amd import lib as _plib
+    _plib.use_library(h)
+
+
 def lib_sanitized():
     global _lib_ub
     if _lib_ub is None:
         _lib_ub = _bind(build(sanitize=True))
+    _activate(_lib_ub)
     return _lib_ub
 
 
@@ -86,6 +94,7 @@ def lib():
     global _lib
     if _lib is None:
         _lib = _bind(build())
+    _activate(_lib)
     return _lib
 
 

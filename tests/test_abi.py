@@ -62,8 +62,9 @@ def test_more_than_65535_tasks_in_one_batch_are_refused():
     """Documented limit of a batch (include/sniffles_amd.h): the task index travels in 16 bits of the packed
     keys.  The upload fails with the reason - nothing is truncated; several batches serve larger jobs."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import lib, synth
     from sniffles_amd.config import SnifflesConfig
     ti = synth.gen_fuzz(3, task_id=0)
     with pytest.raises(lib.SnifflesAmdError, match="too many tasks in one batch"):
-        lib.Batch(SnifflesConfig(), [ti] * 65536, _lib=E.lib())
+        lib.Batch(SnifflesConfig(), [ti] * 65536)

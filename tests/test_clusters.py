@@ -20,7 +20,7 @@ def run_case(name, _lib=None):
     doc = DOC[name]
     assert gu.input_sha(ti) == doc["input_sha"]
     cfg = gu.make_config(kw, ti)
-    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, _lib=_lib)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
     task.lead_provider = pipeline._Extracted(ti)
     try:
         task.call_candidates(True, cfg)

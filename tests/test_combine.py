@@ -101,7 +101,8 @@ def test_oracle_combine_matches_reference(name, oracle_mod):
 @pytest.mark.parametrize("name", NAMES)
 def test_emulated_combine_matches_reference(name):
     import emu.emu as E
-    run_case(name, lambda t, c, g, cfg: cluster.resolve_block_groups(t, c, g, cfg, _lib=E.lib()))
+    E.lib()                                              # the host tier becomes the library of this test
+    run_case(name, lambda t, c, g, cfg: cluster.resolve_block_groups(t, c, g, cfg))
 
 
 @pytest.mark.gpu
@@ -141,13 +142,14 @@ def random_problem(rng, svtype, n):
 def test_emulated_combine_fuzz_vs_oracle(separate, oracle_mod):
     import copy
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     rng = np.random.default_rng(5)
     cfg = SnifflesConfig(combine_separate_intra=separate)
     for it in range(30):
         svtype = ["INS", "DEL", "DUP", "INV", "BND"][it % 5]
         a, b = random_problem(rng, svtype, int(rng.integers(1, 40))), random_problem(rng, svtype, int(rng.integers(1, 40)))
         g_o = oracle_resolve(oracle_mod)(svtype, b, oracle_resolve(oracle_mod)(svtype, a, [], cfg), cfg)
-        g_e = cluster.resolve_block_groups(svtype, b, cluster.resolve_block_groups(svtype, a, [], cfg, _lib=E.lib()), cfg, _lib=E.lib())
+        g_e = cluster.resolve_block_groups(svtype, b, cluster.resolve_block_groups(svtype, a, [], cfg), cfg)
         key = lambda gs: [([c.id for c in g.candidates], g.pos_mean, g.len_mean, g.bnd_mate_ref_start_mean) for g in gs]  # noqa: E731
         assert key(g_o) == key(g_e)
 

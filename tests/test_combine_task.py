@@ -40,7 +40,7 @@ def run_case(name, _lib=None, reqc=False):
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
     for r in readers.values():
         r.reqc = reqc
-    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=_lib)
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
     got = [group_record(c) for c in task.execute(readers)]
     want = exp["calls"]
     assert len(got) == len(want)
@@ -94,7 +94,7 @@ def run_scatter_case(_lib=None):
     cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(exp["n_samples"])]
     cfg.threads = sc["threads"]
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
-    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=_lib)
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
     task.TARGET_WORK_PER_TASK = sc["target_work_per_task"]
     parts = task.scatter()
     assert [(p.id, p.start, p.end, p.block_indices) for p in parts] == [(w["id"], w["start"], w["end"], w["block_indices"]) for w in sc["tasks"]]
@@ -161,8 +161,8 @@ def check_cut_equals_whole(_lib):
     for seed in (11, 12, 13):
         chains = random_chains(seed)
         n_cut += sum(len(cluster.chain_cuts(t, c, wo, cfg)) - 2 for t, c, wo, _, _ in chains)
-        whole = cluster.resolve_chains_batch(chains, cfg, _lib=_lib, cut=False)
-        parts = cluster.resolve_chains_batch(chains, cfg, _lib=_lib, cut=True)
+        whole = cluster.resolve_chains_batch(chains, cfg, cut=False)
+        parts = cluster.resolve_chains_batch(chains, cfg, cut=True)
         for (t, c, wo, _, _), a, b in zip(chains, whole, parts):
             assert np.array_equal(a[:len(c)], b[:len(c)]), (seed, t)
     assert n_cut > 20   # the generator does produce cuts (and gaps exactly at the gate, which must not cut)
@@ -222,9 +222,9 @@ def check_columns_equal_objects(_lib, monkeypatch, names=None, options=None):
                 cfg = _twin_cfg(doc, extra)
                 readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
                 half = exp["contig_len"] // 2 // cfg.snf_block_size * cfg.snf_block_size
-                tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg, _lib=_lib),
+                tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg),
                          parallel.CombineTask(id=9, sv_id=0, contig=exp["contig"], start=half + cfg.snf_block_size, end=exp["contig_len"],
-                                              config=cfg, _lib=_lib)]
+                                              config=cfg)]
                 calls = parallel.CombineTask.execute_many(tasks, readers)
                 cands = [c for r in readers.values() for b in r.blocks.values() for t in sv.TYPES for c in b[t]]
                 out.append(([[_object_fields(c) for c in part] for part in calls], [t.sv_id for t in tasks],
@@ -294,6 +294,7 @@ def test_columnar_store_single_sample_merge_emu(monkeypatch):
     """One input file (`sniffles --input one.snf`): the combined call keeps the candidate's own filter and info dict and has no
     STDEV fields (sv.py:440-470); with --no-qc every group is called.  Columnar store against the object replay."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd.config import SnifflesConfig
     doc = gu.load("combine_task_3samples_lowcov")
     exp = doc["expected"]
@@ -305,7 +306,7 @@ def test_columnar_store_single_sample_merge_emu(monkeypatch):
             cfg.snf_input_info = [dict(internal_id=0)]
             cfg.mode = "combine"
             readers = {0: BlocksReader(exp["contig"], exp["samples"][0])}
-            task = parallel.CombineTask(id=1, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())
+            task = parallel.CombineTask(id=1, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
             out.append([_object_fields(c) for c in task.execute(readers)])
         col, obj = out
         assert len(col) == len(obj) and (len(col) > 0 or not no_qc)
@@ -318,6 +319,7 @@ def test_cached_reader_columns_equal_the_block_walk_emu(monkeypatch):
     readers - also with another support threshold, and as two part tasks - starts from the cached tables and gives the calls of
     the block-by-block walk (`SNF_COMBINE_NO_COLUMNS=1`)."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     name = "combine_task_5samples_medians"
     doc = gu.load(name)
     exp = doc["expected"]
@@ -327,10 +329,10 @@ def test_cached_reader_columns_equal_the_block_walk_emu(monkeypatch):
         cfg = _twin_cfg(doc, extra)
         if split:
             half = exp["contig_len"] // 2 // cfg.snf_block_size * cfg.snf_block_size
-            tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg, _lib=E.lib()),
-                     parallel.CombineTask(id=9, sv_id=0, contig=exp["contig"], start=half + cfg.snf_block_size, end=exp["contig_len"], config=cfg, _lib=E.lib())]
+            tasks = [parallel.CombineTask(id=7, sv_id=3, contig=exp["contig"], start=0, end=half, config=cfg),
+                     parallel.CombineTask(id=9, sv_id=0, contig=exp["contig"], start=half + cfg.snf_block_size, end=exp["contig_len"], config=cfg)]
         else:
-            tasks = [parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())]
+            tasks = [parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)]
         return [[_object_fields(c) for c in part] for part in parallel.CombineTask.execute_many(tasks, readers)]
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
     for extra, split in (((), False), ((), True), (("--combine-support-threshold", "6"), False), ((), False)):

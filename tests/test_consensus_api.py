@@ -126,6 +126,7 @@ needs_ref = pytest.mark.skipif(not __import__("make_ref").ref_root(), reason="ne
 @needs_ref
 def test_gap_bytes_other_anchor_steps_and_oversize_problems_match_the_reference_emu(monkeypatch):
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     _check_generic(monkeypatch, E.lib)
 
 
@@ -150,7 +151,7 @@ def _check_pipeline_with_gap_bytes(L, oracle_mod):
     ti.seq_pool = pool
     cfg = SnifflesConfig()
     cfg.qc_nm_threshold = cfg.average_regional_nm = ti.qc_nm_threshold
-    kw = dict(_lib=L) if L is not None else dict(device=0)
+    kw = dict(device=0)
     with lib.Batch(cfg, [ti], **kw) as b:
         b.call_candidates(); b.finalize()
         got = records.records(b.fetch(1), [ti], "final")[0]

@@ -68,8 +68,7 @@ def run_case(name, _lib):
                 return seq[start:end].tobytes().decode("ascii")
         cfg.reference = "reference.fa"
         lp._mask_N_coverage(fasta=Fasta())
-    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                             _lib=_lib)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
     task.lead_provider = lp
     task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
     if "error" in exp:
@@ -89,7 +88,7 @@ def run_case(name, _lib):
     assert [as_record(c, "final") for c in final] == exp["final"]
     assert all(c.postprocess is None for c in final)
     # CallTask.execute's tail in one step (filter + sort on the device, only the kept calls become objects): the same objects
-    task2 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, _lib=_lib)
+    task2 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
     task2.lead_provider, task2.tandem_repeats = lp, task.tandem_repeats
     kept = task2.execute_calls(cfg)
     want = final if cfg.no_qc else [c for c in final if c.qc]
@@ -124,12 +123,13 @@ def test_task_entry_points_gpu(name):
 def test_bulk_materialisation_equals_record_by_record():
     """sv.materialize_candidates / sv.apply_final build the same objects as fill_candidate / fill_final per record."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import lib, sv
     for name in ("fuzz_4_2", "bnd_stale_end", "chr21_30x_mosaic", "single_leads_noqc"):
         build, kw, _ = cases.ALL[name]
         ti = build()
         cfg = gu.make_config(kw, ti)
-        with lib.Batch(cfg, [ti], device=0, _lib=E.lib()) as b:
+        with lib.Batch(cfg, [ti], device=0) as b:
             b.call_candidates()
             r0 = b.fetch(0)
             n = len(r0.calls)

@@ -32,9 +32,10 @@ def make_pairs(seed, sizes, alphabet=b"ACGT"):
 
 def test_edit_distance_emulated(oracle_mod):
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 300, 511, 513, 700] + list(np.random.default_rng(0).integers(1, 400, 60))
     pairs = make_pairs(1, sizes, alphabet=b"ACGTNacgt<>")
-    got = lib.edit_distance_batch(pairs, _lib=E.lib())
+    got = lib.edit_distance_batch(pairs)
     assert got.tolist() == [oracle_mod.edit_distance(a, b) for a, b in pairs]
 
 
@@ -55,9 +56,10 @@ def check_banded(pairs, exact, **kw):
 
 def test_edit_distance_banded_emulated(oracle_mod):
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     sizes = [1, 2, 63, 64, 65, 127, 128, 129, 300, 511, 513, 700, 1500] + list(np.random.default_rng(7).integers(1, 400, 40))
     pairs = make_pairs(8, sizes, alphabet=b"ACGTN")
-    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs], _lib=E.lib())
+    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs])
 
 
 @pytest.mark.gpu
@@ -122,9 +124,9 @@ def _check_population_match(L, extra_args=()):
     finally:
         ref_snfp.align = keep
     mine = [(snfp.PopulationVariant(**f), call) for f, call in pairs]
-    got = snfp.match_batch(mine, cfg, _lib=L)
+    got = snfp.match_batch(mine, cfg)
     assert got == exp and sum(e is not None for e in exp) > 10 and sum(e is None for e in exp) > 10
-    assert mine[0][0].match(mine[0][1], cfg, _lib=L) == exp[0]
+    assert mine[0][0].match(mine[0][1], cfg) == exp[0]
     assert snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)}) == \
         tuple(ref_snfp.PopulationVariant._calculate_frequency({0: (0, 1, 9), 1: ('.', '.', 0), 2: (1, 1, 5)})) == (0.75, 2, 2)
 

@@ -12,7 +12,7 @@ from sniffles_amd import lib, records, synth
 from sniffles_amd.config import SnifflesConfig
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def emu_lib():
     import emu.emu as E
     return E.lib()
@@ -25,7 +25,7 @@ def fallback_forms(monkeypatch):
 
 
 def run(L, cfg, tis, fin):
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates()
         if fin:
             b.finalize()

@@ -15,7 +15,7 @@ import extract_util as xu
 import golden_util as gu
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def emu_lib():
     from emu import emu
     return emu.lib()
@@ -53,7 +53,7 @@ def test_kernel_bodies_match_reference(name, emu_lib):
     recs = cases.extract_records(case)
     doc = gu.load(name)
     st, en = case["region"]
-    ti, info = extract.extract_region(recs, case["contig"], st, en, DevCfg(**case["cfg"]), case["read_id_offset"], _lib=emu_lib)
+    ti, info = extract.extract_region(recs, case["contig"], st, en, DevCfg(**case["cfg"]), case["read_id_offset"])
     reads = list(zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()))
     xu.check_against_golden(doc["expected"], xu.canon_leads(ti), reads, float(ti.qc_nm_threshold).hex(), info.read_id,
                             ti.contig_len)
@@ -115,7 +115,7 @@ def test_reference_known_answer_reads_kernels(emu_lib):
     recs = cases.extract_records(cases.EXTRACT["extract_hg008_chr1"])
     rows = {}
     for contig in ("chr1", "chr18"):
-        ti, _ = extract.extract_region(recs, contig, 0, 2 ** 31 - 1, DevCfg(mapq=0, min_alignment_length=0), _lib=emu_lib)
+        ti, _ = extract.extract_region(recs, contig, 0, 2 ** 31 - 1, DevCfg(mapq=0, min_alignment_length=0))
         rows[contig] = xu.canon_leads(ti)
     known_bnd_rows(rows)
 
@@ -146,25 +146,25 @@ def test_inputs_the_reference_raises_on_fail_the_call(tags, match, emu_lib):
         with pytest.raises((eo.ExtractError, ValueError)):
             eo.extract_region(recs.blob, recs.rec_off, recs.ref_names, "c1", 0, 100000)
     with pytest.raises(Exception, match=match):
-        extract.extract_region(recs, "c1", 0, 100000, _lib=emu_lib)
+        extract.extract_region(recs, "c1", 0, 100000)
 
 
 def test_missing_sequence_with_insertion_fails(emu_lib):
     from sniffles_amd import extract
     recs = _one_read(b"", ops=((0, 1000), (1, 60), (0, 1000)), seq=False)
     with pytest.raises(Exception, match="without sequence"):
-        extract.extract_region(recs, "c1", 0, 100000, _lib=emu_lib)
+        extract.extract_region(recs, "c1", 0, 100000)
 
 
 def test_empty_and_foreign_records(emu_lib):
     from sniffles_amd import bam, extract
     empty = bam.records_from_list(["c1"], [1000], [])
-    ti, info = extract.extract_region(empty, "c1", 0, 1000, _lib=emu_lib)
+    ti, info = extract.extract_region(empty, "c1", 0, 1000)
     assert ti.n_leads == 0 and ti.n_reads == 0 and info.read_count == 0 and ti.qc_nm_threshold == 0.0
     recs = _one_read(b"NMC\x05")
-    ti, info = extract.extract_region(recs, "c2", 0, 50000, _lib=emu_lib)      # the record is on c1
+    ti, info = extract.extract_region(recs, "c2", 0, 50000)      # the record is on c1
     assert ti.n_leads == 0 and ti.n_reads == 0
-    ti, info = extract.extract_region(recs, "c1", 0, 100000, read_id_offset=41, _lib=emu_lib)
+    ti, info = extract.extract_region(recs, "c1", 0, 100000, read_id_offset=41)
     assert ti.n_reads == 1 and info.read_id == 42 and ti.qc_nm_threshold == 5 / 2001.0
 
 
@@ -173,7 +173,7 @@ def test_record_table_is_validated(emu_lib):
     recs = _one_read(b"")
     recs.rec_off[1] -= 4
     with pytest.raises(Exception, match="block_size"):
-        extract.extract_region(recs, "c1", 0, 100000, _lib=emu_lib)
+        extract.extract_region(recs, "c1", 0, 100000)
 
 
 def test_extracted_task_feeds_the_clustering_path(emu_lib, oracle_mod):
@@ -184,10 +184,10 @@ def test_extracted_task_feeds_the_clustering_path(emu_lib, oracle_mod):
     for k, name in enumerate(("extract_fuzz_a", "extract_lowq_short")):
         case = cases.EXTRACT[name]
         recs = cases.extract_records(case)
-        ti, _ = extract.extract_region(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k, _lib=emu_lib)
+        ti, _ = extract.extract_region(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k)
         tis.append(ti)
     cfg = SnifflesConfig(minsupport=2)
-    with lib.Batch(cfg, tis, _lib=emu_lib) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates()
         b.finalize()
         got = records.records(b.fetch(1), tis, "final")
@@ -206,19 +206,19 @@ def check_device_handover(_lib, oracle_mod):
     for k, name in enumerate(names):
         case = cases.EXTRACT[name]
         recs = cases.extract_records(case)
-        ti, _ = extract.extract_region(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k, _lib=_lib)
+        ti, _ = extract.extract_region(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k)
         host.append(ti)
         if k == 1:
             dev.append(ti)                      # a host task between two device tasks
             continue
-        tid, _, x = extract.extract_region_device(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k, _lib=_lib)
+        tid, _, x = extract.extract_region_device(recs, case["contig"], *case["region"], DevCfg(**case["cfg"]), task_id=k)
         assert isinstance(tid, soa.DeviceTaskInput) and tid.n_leads == ti.n_leads and tid.n_reads == ti.n_reads
         dev.append(tid)
         keep.append(x)
     cfg = SnifflesConfig(minsupport=2)
     out = []
     for tis in (host, dev):
-        with lib.Batch(cfg, tis, _lib=_lib) as b:
+        with lib.Batch(cfg, tis) as b:
             b.call_candidates()
             b.finalize()
             out.append(records.records(b.fetch(1), host, "final"))

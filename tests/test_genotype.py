@@ -22,7 +22,7 @@ def make_task(name, specs, _lib):
         lp.record_read(s, e, hp)
     targets = gutil.make_targets(specs, sv.SVCall, sv.SVCallBNDInfo, sv.new_call)
     task = parallel.GenotypeTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                                 lead_provider=lp, genotype_svs=targets, _lib=_lib)
+                                 lead_provider=lp, genotype_svs=targets)
     task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
     return ti, task
 
@@ -90,7 +90,7 @@ def run_genotype_vcf(name, _lib):
     recs = cases.SAMPLES[name][0]()
     assert records_sha(recs) == doc["input_sha"]
     buf = io.StringIO()
-    n = pipeline.genotype_vcf(recs, config_for(()), io.StringIO(doc["vcf_in"]), buf, _lib=_lib)
+    n = pipeline.genotype_vcf(recs, config_for(()), io.StringIO(doc["vcf_in"]), buf)
     assert buf.getvalue() == doc["vcf_out"]
     assert n == sum(1 for ln in doc["vcf_out"].split("\n") if ln and not ln.startswith("#")) > 50
 
@@ -114,13 +114,13 @@ def run_regenotype(name, _lib=None):
     ti = build()
     assert gu.input_sha(ti) == doc["input_sha"]
     cfg = gu.make_config(kw, ti)
-    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, _lib=_lib)
+    task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
     task.lead_provider = pipeline._Extracted(ti)
     cands = task.call_candidates(False, cfg)
     task.finalize_candidates(cands, True, cfg)
     task.close()
     cands = [c for c in cands if c.svtype in sv.TYPES]
-    postprocessing.genotype_svs(cands, cfg, _lib=_lib)
+    postprocessing.genotype_svs(cands, cfg)
     got = []
     for c in cands:
         gt = c.genotypes.get(0)

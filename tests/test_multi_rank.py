@@ -32,7 +32,7 @@ def vcf_text(cfg, tasks, results_of_task):
 def single_process_text(cfg, tasks, L, mode):
     """Every task in ONE batch of ONE process, CallTask.execute's filter and sort on the device."""
     from sniffles_amd import lib
-    with lib.Batch(cfg, tasks, _lib=L) as b:
+    with lib.Batch(cfg, tasks) as b:
         b.set_output(mode)
         b.call_candidates(); b.finalize()
         res = b.fetch(1)
@@ -46,13 +46,14 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import abi, dist as sdist, lib
     from sniffles_amd.config import SnifflesConfig
     tasks = _tasks()
     shards = sdist.shard_lpt([t.contig_len for t in tasks], world)
     mine = shards[rank]
     cfg = SnifflesConfig(output_rnames=True)
-    with lib.Batch(cfg, [tasks[i] for i in mine], _lib=E.lib()) as b:
+    with lib.Batch(cfg, [tasks[i] for i in mine]) as b:
         b.set_output(abi.OUT_EXECUTE | abi.OUT_DEVICE)
         b.call_candidates(); b.finalize()
         # the block leaves the batch as it would for RCCL: device-to-device into a tensor of the process group's device
@@ -121,6 +122,7 @@ def _shared_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import abi, dist as sdist, lib
     from sniffles_amd.config import SnifflesConfig
     tasks = _tasks()
@@ -130,7 +132,7 @@ def _shared_worker(rank, world, port, q):
     landing = sdist.SharedLanding(slots=2, block_bytes=1 << 21, alt_bytes=1 << 20)
     ids = [tasks[i].task_id for i in mine]
     texts = []
-    with lib.Batch(cfg, [tasks[i] for i in mine], _lib=E.lib()) as b:
+    with lib.Batch(cfg, [tasks[i] for i in mine]) as b:
         b.set_output(abi.OUT_EXECUTE)
         for slot in (0, 1, 0):                               # three passes: both segments, and one of them again
             b.set_result_memory(*landing.memory(slot))
@@ -193,6 +195,7 @@ def _queue_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import time
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import abi, dist as sdist, lib
     from sniffles_amd.config import SnifflesConfig
     tasks = _tasks()
@@ -200,7 +203,7 @@ def _queue_worker(rank, world, port, q):
     queue = sdist.TaskQueue([t.n_leads for t in tasks])
     blocks = []
     for i in queue:                       # one task per claim; rank 1 is slowed down so that rank 0 takes more
-        with lib.Batch(cfg, [tasks[i]], _lib=E.lib()) as b:
+        with lib.Batch(cfg, [tasks[i]]) as b:
             b.set_output(abi.OUT_EXECUTE)
             b.call_candidates(); b.finalize()
             blocks.append(sdist.result_block(b.fetch(1)))
@@ -269,6 +272,7 @@ def _sets_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import time
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     from sniffles_amd import abi, dist as sdist, lib
     from sniffles_amd.config import SnifflesConfig
     tasks = _tasks()
@@ -277,7 +281,7 @@ def _sets_worker(rank, world, port, q):
     set_ids = [[tasks[i].task_id for i in g] for g in sets]
     weights = [sum(tasks[i].n_leads for i in g) for g in sets]
     # every rank holds every set resident (it serves whichever it claims); a segment per (generation, set)
-    handles = [lib.Batch(cfg, [tasks[i] for i in g], _lib=E.lib()) for g in sets]
+    handles = [lib.Batch(cfg, [tasks[i] for i in g]) for g in sets]
     for b in handles:
         b.set_output(abi.OUT_EXECUTE)
     landing = sdist.SharedLanding(slots=2 * len(sets), block_bytes=1 << 21, alt_bytes=1 << 20)
@@ -349,6 +353,7 @@ def _scatter_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     import golden_util as gu
     from sniffles_amd import dist as sdist, parallel
     from test_combine import group_record, make_cfg
@@ -360,7 +365,7 @@ def _scatter_worker(rank, world, port, q):
     cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(exp["n_samples"])]
     cfg.threads = sc["threads"]
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
-    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=E.lib())
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
     task.TARGET_WORK_PER_TASK = sc["target_work_per_task"]
     parts = task.scatter()                                    # the same cuts on every rank
     queue = sdist.TaskQueue([len(p.block_indices) for p in parts])   # the parts of ONE contig go to whoever is free
@@ -382,6 +387,7 @@ def test_two_rank_combine_scatter_equals_reference_parts():
         if p not in sys.path:
             sys.path.insert(0, p)
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     import golden_util as gu
     E.build()
     ctx = mp.get_context("spawn")

@@ -20,7 +20,7 @@ def tasks():
 
 
 def run(L, cfg, tis, mode):
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.set_output(mode)
         b.call_candidates()
         b.finalize()
@@ -87,7 +87,7 @@ def test_execute_mode_is_the_filter_and_sort_of_the_candidates_gpu():
 def export_equals_fetch(L, device_alloc):
     tis = tasks()
     cfg = SnifflesConfig()
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.set_output(abi.OUT_EXECUTE | abi.OUT_DEVICE)
         b.call_candidates()
         b.finalize()
@@ -102,7 +102,7 @@ def export_equals_fetch(L, device_alloc):
     assert rec.tobytes() == res.calls.tobytes()
     assert blob[lay["off_rnames"]:lay["off_rnames"] + 4 * lay["rnames_len"]] == res.rnames.tobytes()
     assert blob[lay["off_alt"]:lay["off_alt"] + lay["alt_pool_len"]] == res.alt_pool.tobytes()
-    with lib.Batch(cfg, tis, _lib=L) as b:     # without SNF_OUT_DEVICE the block may never have been in HBM
+    with lib.Batch(cfg, tis) as b:     # without SNF_OUT_DEVICE the block may never have been in HBM
         b.call_candidates()
         b.finalize()
         with pytest.raises(lib.SnifflesAmdError, match="SNF_OUT_DEVICE"):
@@ -161,7 +161,7 @@ def check_slow_alt(L, oracle_mod):
     cfg = SnifflesConfig()
     exp = oracle_mod.run(cfg, [ti], True)
     for mode in (abi.OUT_CANDIDATES, abi.OUT_EXECUTE):
-        with lib.Batch(cfg, [ti], _lib=L) as b:
+        with lib.Batch(cfg, [ti]) as b:
             b.set_output(mode)
             b.call_candidates()
             b.finalize()
@@ -199,12 +199,12 @@ def check_deferred_names(L):
     tis = tasks()
     cfg = SnifflesConfig()
     ref0 = None
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates()
         ref0 = b.fetch(0)
         b.finalize()
         ref1 = b.fetch(1)
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.set_output(abi.OUT_EXECUTE)
         b.call_candidates()
         got0 = b.fetch(0)                       # all names, written by the late pass
@@ -220,7 +220,7 @@ def check_deferred_names(L):
     assert cand.calls.tobytes() == ref1.calls.tobytes() and cand.rnames.tobytes() == ref1.rnames.tobytes()
     keep = np.concatenate(expected_execute(ref1, cfg))
     assert [exe.rn(k).tolist() for k in range(len(exe.calls))] == [ref1.rn(i).tolist() for i in keep.tolist()]
-    with lib.Batch(cfg, tis, _lib=L) as b:      # finalize straight after the candidate stage: names of the kept calls only
+    with lib.Batch(cfg, tis) as b:      # finalize straight after the candidate stage: names of the kept calls only
         b.set_output(abi.OUT_EXECUTE)
         b.call_candidates()
         b.finalize()

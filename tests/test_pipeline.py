@@ -64,20 +64,20 @@ def run_sample(name, tmp_path, _lib, through_file):
     # VCF only
     buf = io.StringIO()
     tr = getattr(recs, "tandem_repeats", None)
-    res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr, _lib=_lib)
+    res = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr)
     assert res.read_count == doc["read_count"]
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert res.vcf_records == len(vu.split_text(doc["vcf"])[1])
     # the same text straight from the record table (vcf.VCF.write_records): no SVCall objects
     buf = io.StringIO()
-    res2 = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr, _lib=_lib, objects=False)
+    res2 = pipeline.call_sample(recs, config_for(args), vcf_handle=buf, tandem_repeats=tr, objects=False)
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert res2.vcf_records == res.vcf_records and res2.read_count == res.read_count and not res2.calls
     # VCF + SNF (the candidates are not QC-filtered then)
     buf = io.StringIO()
     cfg = config_for(args)
     snf_path = str(tmp_path / "sample.snf")
-    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=snf_path, tandem_repeats=tr, _lib=_lib)
+    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=snf_path, tandem_repeats=tr)
     assert_same_text(buf.getvalue(), doc["vcf_with_snf"])
     assert res.snf_candidates == doc["snf_candidates"]
     f = snf.SNFile.open(snf_path, cfg)
@@ -129,6 +129,7 @@ def test_regions_restrict_extraction_and_coverage():
     """--regions (config.regions_by_contig; sniffles:330-351, leadprov.py:445-472): one whole-contig interval is the plain run;
     a sub-interval leaves only calls whose leads lie inside it; the same interval twice doubles the coverage the calls see."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     name = "sample_two_contigs_12x"
     recs = cases.SAMPLES[name][0]()
     tr = getattr(recs, "tandem_repeats", None)
@@ -137,7 +138,7 @@ def test_regions_restrict_extraction_and_coverage():
         cfg = config_for(())
         cfg.regions_by_contig = regions
         buf = io.StringIO()
-        res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=tr, _lib=E.lib())
+        res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=tr)
         return buf.getvalue(), res
     big = [(c, n) for c, n in zip(recs.ref_names, recs.ref_lens) if n >= 1_000_000]
     plain, res0 = text({})
@@ -156,6 +157,7 @@ def test_regions_restrict_extraction_and_coverage():
 def test_genotype_vcf_with_regions_matches_reference(tmp_path):
     import ref_harness as rh
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     name = "sample_splits_14x"
     doc = gu.load("genotype_vcf")[name]
     recs = cases.SAMPLES[name][0]()
@@ -170,7 +172,7 @@ def test_genotype_vcf_with_regions_matches_reference(tmp_path):
     cfg = config_for(())
     cfg.regions_by_contig = regs
     buf = io.StringIO()
-    pipeline.genotype_vcf(recs, cfg, io.StringIO(doc["vcf_in"]), buf, _lib=E.lib())
+    pipeline.genotype_vcf(recs, cfg, io.StringIO(doc["vcf_in"]), buf)
     assert buf.getvalue() == (ref["vcf"] if isinstance(ref, dict) else ref) != doc["vcf_out"]
 
 
@@ -201,21 +203,21 @@ def run_population(name, tmp_path, _lib):
     paths = []
     for s, r in enumerate(recs):
         path = str(tmp_path / f"sample{s}.snf")
-        pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=getattr(r, "tandem_repeats", None), _lib=_lib)
+        pipeline.call_sample(r, config_for(()), snf_path=path, tandem_repeats=getattr(r, "tandem_repeats", None))
         paths.append(path)
     buf = io.StringIO()
-    calls = pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=_lib)
+    calls = pipeline.combine(paths, config_for(args), vcf_handle=buf)
     assert_same_text(buf.getvalue(), doc["vcf"])
     assert len(calls) >= len(vu.split_text(doc["vcf"])[1]) > 50
     # the same text straight from the group table (vcf.VCF.write_merged): no SVCall objects; also with the options that change the columns
     for extra in ((), ("--phase",), ("--symbolic",), ("--output-rnames",), ("--qc-nm",), ("--mosaic",), ("--minsvlen", "300")):
         with_objects, without = io.StringIO(), io.StringIO()
         if extra:
-            pipeline.combine(paths, config_for(tuple(args) + extra), vcf_handle=with_objects, _lib=_lib)
+            pipeline.combine(paths, config_for(tuple(args) + extra), vcf_handle=with_objects)
         else:
             with_objects = buf
         cfg = config_for(tuple(args) + extra)
-        assert pipeline.combine(paths, cfg, vcf_handle=without, _lib=_lib, objects=False) == []
+        assert pipeline.combine(paths, cfg, vcf_handle=without, objects=False) == []
         assert without.getvalue() == with_objects.getvalue(), extra
         assert without.getvalue().count("\n") > 50
 
@@ -291,7 +293,7 @@ def _with_reference(_lib, name, regions=None, fasta_len_delta=0):
     exp = rh.run_reference_call_sample(recs, args, fixed=fixed, fasta=fasta)
     plain = rh.run_reference_call_sample(recs, args, fixed=fixed)
     buf = io.StringIO()
-    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=getattr(recs, "tandem_repeats", None), _lib=_lib,
+    res = pipeline.call_sample(recs, cfg, vcf_handle=buf, tandem_repeats=getattr(recs, "tandem_repeats", None),
                                reference=rh.DictFasta(fasta))
     assert res.read_count == exp["read_count"]
     assert_same_text(buf.getvalue(), exp["vcf"])

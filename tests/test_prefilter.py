@@ -13,7 +13,7 @@ def tasks():
 
 
 def run(L, cfg, tis):
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates()
         b.finalize()
         return b.fetch(1)
@@ -60,9 +60,10 @@ def test_cluster_views_keep_their_ids_behind_the_prefilter():
     """`cluster.resolve` (seam B3) redoes the candidate stage unfiltered: ids (seed index included) are the same as without
     the prefilter, and the calls fetched afterwards are unchanged."""
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     ti = synth.gen_task(0, "chr20", 1_000_000, 30, 5)
     cfg = SnifflesConfig()
-    with lib.Batch(cfg, [ti], _lib=E.lib()) as b:
+    with lib.Batch(cfg, [ti]) as b:
         b.call_candidates()
         b.finalize()
         before = b.fetch(1)
@@ -91,7 +92,7 @@ def check_front_variants(L, oracle_mod, monkeypatch, env, passes=3):
     for kw in ({}, dict(mosaic=True)):
         cfg = SnifflesConfig(**kw)
         exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
-        with lib.Batch(cfg, tis, **(dict(_lib=L) if L is not None else {})) as b:
+        with lib.Batch(cfg, tis) as b:
             for _ in range(passes):
                 b.run_pass()
                 assert records.records(b.fetch(1), tis, "final") == exp

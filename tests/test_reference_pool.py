@@ -24,7 +24,7 @@ def check(L, extra, cfg_kw, device=None, gen=None):
     assert r["procs"] == 2 and set(r["items"]) == {0, 1, 2}
     assert r["hot_all_core_s"] > 0 and r["hot_single_core_s"] >= r["hot_all_core_s"]
     tis = [synth.gen_task(**kw) for _, kw in SPECS]
-    kw = dict(_lib=L) if L is not None else dict(device=device or 0)
+    kw = dict(device=device or 0)
     with lib.Batch(SnifflesConfig(**cfg_kw), tis, **kw) as b:
         b.set_output(abi.OUT_EXECUTE)
         b.call_candidates(); b.finalize()

@@ -31,7 +31,7 @@ def bnd_task(contig, pos, mate_contig, mate_pos, is_first, is_reverse):
 
 
 def run(ti, _lib=None):
-    with lib.Batch(SnifflesConfig(), [ti], _lib=_lib) as b:
+    with lib.Batch(SnifflesConfig(), [ti]) as b:
         b.call_candidates(); b.finalize()
         return records.records(b.fetch(1), [ti], "final")[0]
 

@@ -20,7 +20,7 @@ from sniffles_amd import lib, records, synth
 from sniffles_amd.config import SnifflesConfig
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def simt():
     from emu import simt as S
     S.lib()
@@ -28,7 +28,7 @@ def simt():
 
 
 def run(L, cfg, tis, fin):
-    with lib.Batch(cfg, tis, _lib=L) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates()
         if fin:
             b.finalize()
@@ -147,9 +147,10 @@ def test_no_undefined_behaviour_in_the_kernels(simt, oracle_mod, capfd):
         assert records.records(run(L, cfg, tis, True), tis, "final") == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
     probs = _cons_problems()
     for kw in (dict(), dict(mode=4), dict(nw=1), dict(nw=8)):
-        got, _, _ = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6, _lib=L, **kw)
+        got, _, _ = simt.consensus_batch([(p["best"], p["others"], p["skip"]) for p in probs], 6, **kw)
         assert got == [p["expected"] for p in probs]
     import emu.emu as E
+    E.lib()                                              # the host tier becomes the library of this test
     import test_combine as TC
     import test_edit_distance as TE
     import test_extract as TX

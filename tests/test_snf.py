@@ -57,7 +57,7 @@ def run_combine_over_files(_lib):
     want = exp["expected"]
     cfg = make_cfg(exp["reference_args"], want["n_samples"])
     readers = {s: snf.SNFile.open(golden_path(doc, s), cfg) for s in range(want["n_samples"])}
-    task = parallel.CombineTask(id=7, sv_id=0, contig=want["contig"], start=0, end=want["contig_len"], config=cfg, _lib=_lib)
+    task = parallel.CombineTask(id=7, sv_id=0, contig=want["contig"], start=0, end=want["contig_len"], config=cfg)
     got = [group_record(c) for c in task.execute(readers)]
     for r in readers.values():
         r.close()
@@ -89,7 +89,7 @@ def write_sample(ti, path, cfg, _lib):
     for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
         lp.record_read(s, e, hp)
     task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                             lead_provider=lp, _lib=_lib)
+                             lead_provider=lp)
     task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
     cands = task.call_candidates(False, cfg)
     task.finalize_candidates(cands, True, cfg)
@@ -189,7 +189,7 @@ def check_block_coverage(tis, _lib, binsizes):
     """`snf_batch_block_coverage` against the reference's formula on the dense vector (snf.py:257-258), for every task of
     a batch, odd bin sizes (ties of the half-to-even rounding), sub-ranges and bins beyond the padded vector."""
     from sniffles_amd import lib
-    with lib.Batch(SnifflesConfig(), tis, device=0, _lib=_lib) as b:
+    with lib.Batch(SnifflesConfig(), tis, device=0) as b:
         early = b.block_coverage(0, 500, 0, 4)      # the read index exists from the upload on
         b.call_candidates()
         assert b.block_coverage(0, 500, 0, 4).tolist() == early.tolist()
@@ -241,11 +241,12 @@ def test_exact_coverage_walk_equals_the_closed_forms(monkeypatch, oracle_mod):
     (snf_cov.h): same coverage.mean(), same block coverages, same calls as the closed forms on ordinary data."""
     import emu.emu as E
     from sniffles_amd import lib, records, synth
+    E.lib()                                              # the host tier becomes the library of this test
     tis = [synth.gen_fuzz(7, task_id=0), synth.gen_task(1, "chr20", 777_777, 30, 3)]
     cfg = SnifflesConfig()
     exp = oracle_mod.run(cfg, tis, True)
     monkeypatch.setenv("SNF_COV_EXACT", "1")
-    with lib.Batch(cfg, tis, _lib=E.lib()) as b:
+    with lib.Batch(cfg, tis) as b:
         b.call_candidates(); b.finalize()
         got = b.fetch(1)
     for t in range(2):

@@ -49,7 +49,7 @@ def single_sample_text(name, variant, _lib):
     for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
         lp.record_read(s, e, hp)
     task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                             lead_provider=lp, _lib=_lib)
+                             lead_provider=lp)
     task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
     calls = task.call_svs(cfg)
     task.close()
@@ -73,7 +73,7 @@ def single_sample_text_from_records(name, variant, _lib):
     for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
         lp.record_read(s, e, hp)
     task = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                             lead_provider=lp, _lib=_lib)
+                             lead_provider=lp)
     task.tandem_repeats = None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist()))
     res, ti_used = task.call_records(cfg)
     buf = io.StringIO()
@@ -134,7 +134,7 @@ def combine_text(name, variant, _lib):
         setattr(cfg, k, v)
     cfg.sample_ids_vcf = [(s, f"S{s}") for s in range(exp["n_samples"])]
     readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
-    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg, _lib=_lib)
+    task = parallel.CombineTask(id=7, sv_id=0, contig=exp["contig"], start=0, end=exp["contig_len"], config=cfg)
     calls = sorted(task.execute(readers), key=lambda c: c.pos)
     fasta = vu.FakeFasta({exp["contig"]: exp["contig_len"]}) if variant == "fasta" else None
     return write_text(calls, cfg, [(exp["contig"], exp["contig_len"])], fasta)

@@ -110,9 +110,9 @@ def run(ctx):
     box = dict(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
     real_call = lib.combine_resolve_batch
 
-    def timed_call(config, problems, device=0, _lib=None):     # the C-ABI call alone (host staging + H2D + kernel + D2H)
+    def timed_call(config, problems, device=0):     # the C-ABI call alone (host staging + H2D + kernel + D2H)
         t = time.perf_counter()
-        real_call(config, problems, device=device, _lib=_lib)
+        real_call(config, problems, device=device)
         box["abi_s"] += time.perf_counter() - t
         st = lib.combine_last_stats(device)
         box["kernel_ms"] += st["kernel_ms"]

@@ -39,7 +39,7 @@ def sweep(L, n_iter, seed0=0, verbose=True):
         tis.append(synth.gen_task(2, "chrG", 120_000, float(rng.choice([12, 30, 90])), seed=it, err=float(rng.choice([0.005, 0.04])),
                                   site_density=2e-4, mosaic_frac=float(rng.choice([0.0, 0.3]))))
         exp = oracle.run(cfg, tis, True)
-        with lib.Batch(cfg, tis, _lib=L) as b:
+        with lib.Batch(cfg, tis) as b:
             b.call_candidates(); b.finalize(); got = b.fetch(1)
         calls += len(exp.calls)
         diffs = [d for t in range(len(tis)) for d in records.diff_results(got, t, exp, t)]

@@ -41,10 +41,10 @@ def main():
         for s, r in enumerate(recs):
             p = os.path.join(d, "ours", f"sample{s}.snf")
             os.makedirs(os.path.dirname(p), exist_ok=True)
-            pipeline.call_sample(r, config_for(()), snf_path=p, _lib=E.lib())
+            pipeline.call_sample(r, config_for(()), snf_path=p)
             paths.append(p)
         buf = io.StringIO()
-        pipeline.combine(paths, config_for(args), vcf_handle=buf, _lib=E.lib())
+        pipeline.combine(paths, config_for(args), vcf_handle=buf)
         ok = buf.getvalue() == want["vcf"]
         print(f"seed {seed} {ns} samples {args}: {len(vu.split_text(want['vcf'])[1])} merged records  {'ok' if ok else 'DIFF'}", flush=True)
         if not ok:

@@ -44,7 +44,7 @@ def main():
         f.close()
         buf = io.StringIO()
         cfg = config_for(args)
-        res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=os.path.join(d, "our.snf"), tandem_repeats=recs.tandem_repeats, _lib=E.lib())
+        res = pipeline.call_sample(recs, cfg, vcf_handle=buf, snf_path=os.path.join(d, "our.snf"), tandem_repeats=recs.tandem_repeats)
         g = snf.SNFile.open(os.path.join(d, "our.snf"), cfg)
         got_snf = {c: json.loads(json.dumps(su.file_record(g, c, sv.TYPES), sort_keys=True)) for c, _ in res.contig_lengths}
         g.close()

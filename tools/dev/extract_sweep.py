@@ -32,7 +32,7 @@ def main():
         args, kw = variants[seed % len(variants)]
         want = rh.run_reference_extract(R, "chrA", st, en, args, read_id_offset=seed * 1000)
         try:
-            ti, info = extract.extract_region(R, "chrA", st, en, DevCfg(**kw), seed * 1000, _lib=E.lib())
+            ti, info = extract.extract_region(R, "chrA", st, en, DevCfg(**kw), seed * 1000)
             got_err = None
         except Exception as e:
             got_err = str(e)
