@@ -236,6 +236,9 @@ def run_calling(ctx):
     args, rank, world, local_rank, use_dist = (ctx[k] for k in ("args", "rank", "world", "local_rank", "use_dist"))
     wl = WORKLOADS[args.config]
     cfg = SnifflesConfig(**wl["cfg"])
+    if os.environ.get("SNF_BENCH_CFG"):   # ablation experiments only (e.g. '{"symbolic": true}'): the line says so and is no result
+        for k, val in json.loads(os.environ["SNF_BENCH_CFG"]).items():
+            setattr(cfg, k, val)
     strong = args.scaling == "strong"
     G = max(1, args.genomes)
     t0 = time.time()
@@ -610,6 +613,7 @@ def run_calling(ctx):
     lat_ms = None
     if W > 1 and not strong:
         barrier()
+        batches[0].timing_every(1)        # (every one of these passes carries the event brackets: their times are reported as such)
         t1 = time.perf_counter()
         for _ in range(5):
             one_pass(0)
@@ -691,7 +695,8 @@ def run_calling(ctx):
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
-                        kernel_ms_source="mean HIP-event duration of the kernel's launches on its own stream over the timed passes of handle 0 (batches in flight as configured)",
+                        kernel_ms_source="mean HIP-event duration of the kernel's launches on its own stream over the timed passes of handle 0 (batches in flight as configured); "
+                                         "the LARGE consensus kernel is bracketed on every pass, the other kernels on every 8th pass of the handle (snf_batch_timing_every)",
                         rocprof_ms=(round(rocprof_ms, 4) if rocprof_ms else None),
                         rocprof_frac=(round(top[2] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if rocprof_ms else None),
                         profile_note=prof_note, result_path=result_path,
@@ -707,7 +712,8 @@ def run_calling(ctx):
         out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="int32/f64",
-                   data="synthetic" + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU else ""),
+                   data="synthetic" + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU else "")
+                   + (" - SNF_BENCH_CFG overrides the workload's configuration: an ablation, NOT a result" if os.environ.get("SNF_BENCH_CFG") else ""),
                    config=dict(workload=wl["name"] + ", synthetic signature tables (SURVEY.md 8d)", baseline_config=args.config,
                                replicas=1 if strong else world, genomes_per_batch=G,
                                tasks=n_contigs * (1 if strong else world) * G,

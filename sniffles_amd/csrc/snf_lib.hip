@@ -254,19 +254,23 @@ struct snf_batch_impl {
   hipStream_t stream = nullptr;   // main stream (also the one fetch/sync wait on)
   hipStream_t stream2 = nullptr;  // side stream: read preparation, finalize scalar kernels
   hipStream_t stream3 = nullptr;  // third stream: the LARGE consensus class next to the SMALL one
+  bool stream3_high = false;      // ... created with the device's highest stream priority
   hipStream_t stream4 = nullptr;  // fourth stream: sv ids + supporting read names and their D2H copy (off the coverage / QC chain)
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
   int cur_slot = 0;
   bool fused = false;             // flag -> scan -> emit chains as fused kernel pairs (snf_fused.h); off: rocPRIM scans
   bool timing = true;             // HIP events around the heavy kernels (snf_batch_set_timing)
   bool time_all = false;          // SNF_TIME_ALL=1: HIP events around every launch, not only the heavy kernels
+  int time_every = 8;             // the event brackets are recorded on every n-th pass of the handle (1: every pass; snf_batch_timing_every):
+  bool time_now = true;           //   two records per launch keep the streams from running launches back to back - measured 80 us of a
+  uint64_t pass_count = 0;        //   1.29-ms step with two batches in flight when every pass carried them
   bool timeline = false;          // SNF_TIMELINE=1: print (offset, duration) of every bracketed op of the step to stderr
   bool res_current = false;       // z1_results has run after the last kernel that changes what it publishes
   int64_t* h_rn_total = nullptr;  // pinned (hb_res): see View::res_rn_total
   int sched_readprep = 1;         // SNF_READPREP: 0 first, 1 enqueued behind d1w (may start at once), 2 after d3_taskoff, 3 starts with d1w
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
-  int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22;   // grid caps of the SMALL / LARGE consensus kernels
+  int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22, slots_cons_s1 = 65536;   // grid caps of the SMALL / LARGE consensus kernels
   bool d2_groups = true;          // call_from: small refined clusters several per wave (snf_wave_call_g.h); SNF_NO_D2_GROUPS=1: a wave per cluster
   int cons_nw = 1;                // waves per SMALL consensus call: 1 = one wave per call (default: single-wave workgroups leave room for the
                                   // LARGE class next to them - LARGE in place 0.75 -> 0.5 ms, the pass 2.5 % shorter), SNF_CONS_NW=4: four
@@ -439,8 +443,9 @@ T* upload_vec(snf_batch_impl* b, const std::vector<T>& h, size_t extra = 0) {
 struct Scope {
   snf_batch_impl* b;
   size_t idx = (size_t)-1;
-  Scope(snf_batch_impl* b_, const char* name, int64_t bytes) : b(b_) {
-    if (!b->timing) return;
+  // always: bracketed on every pass (the kernel bench.py states the roofline on); the others only on the handle's sampled passes
+  Scope(snf_batch_impl* b_, const char* name, int64_t bytes, bool always = false) : b(b_) {
+    if (!b->timing || !(always || b->time_now)) return;
     if (b->ev_used == b->evs.size()) {
       snf_batch_impl::Ev e{};
       SNF_HIP(hipEventCreate(&e.a)); SNF_HIP(hipEventCreate(&e.b));
@@ -995,7 +1000,7 @@ void do_upload(snf_batch_impl* b) {
   v.d2cnt = dalloc<uint32_t>(b, 2 * 64 * 16);
   v.d2_from_list = 0;
 #ifdef SNF_WG_TRACE
-  if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 16)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 16)); }
+  if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 24)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 24)); }
 #endif
   v.cons_tab_off = dalloc<int64_t>(b, N1 + 1); v.cons_aln_off = dalloc<int64_t>(b, N1 + 1); v.cons_read_off = dalloc<int64_t>(b, N1 + 1);
   v.cons_tab_sz = dalloc<int64_t>(b, N1 + 1);
@@ -1095,6 +1100,11 @@ void do_upload(snf_batch_impl* b) {
 void reset_timing(snf_batch_impl* b) {
   b->ev_used = 0;
   b->timings.clear();
+}
+void begin_pass_timing(snf_batch_impl* b) {   // a pass begins: is it one of the sampled ones?
+  reset_timing(b);
+  b->time_now = b->timing && (b->time_all || b->time_every == 1 || (b->time_every > 1 && b->pass_count % (uint64_t)b->time_every == 0));
+  b->pass_count++;
 }
 
 // reads: sorted ends + per-haplotype prefix counts = the device form of the LeadProvider's coverage vector and REF hap
@@ -1214,7 +1224,7 @@ void run_call_candidates(snf_batch_impl* b) {
   int T = v.T;
   const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
   b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
-  reset_timing(b);
+  begin_pass_timing(b);
   // SNF_OUT_EXECUTE (set before this call): the names of the supporting reads are only written for the calls that pass QC,
   // once finalize knows them (a stage-0 fetch writes them all, late)
   v.rn_defer = ((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc && getenv("SNF_NO_RN_DEFER") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25)) ? 1 : 0;
@@ -1502,7 +1512,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
     {  // the LARGE class is independent of the others: its own stream, joined before the ALT bytes are copied out
       SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
       hipStream_t prev = b->cur; b->cur = b->stream3;
-      { Scope _s(b, "e45w_consensus_large", 0);
+      { Scope _s(b, "e45w_consensus_large", 0, true);
         const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
         if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
         else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
@@ -1513,12 +1523,14 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
     auto launch_small = [&]() {
       Scope _s(b, "e45w_consensus_small", 0);
       const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
-      if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < 65536 ? g_small : 65536)), dim3(64), 0, b->cur, v, (int64_t)0);
+      if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < b->slots_cons_s1 ? g_small : b->slots_cons_s1)), dim3(64), 0, b->cur, v, (int64_t)0);
       else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     };
+    static const int order = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : 0;   // experiment: 1 = SMALL behind LARGE on LARGE's stream
+    if (order == 1) { hipStream_t prev = b->cur; b->cur = b->stream3; launch_small(); b->cur = prev; }
     if (serial) SNF_HIP(hipDeviceSynchronize());
     SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
     {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
@@ -1526,7 +1538,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
       hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
-    launch_small();
+    if (order != 1) launch_small();
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
@@ -1672,7 +1684,7 @@ void run_pass(snf_batch_impl* b) {
   g.passes++;
   if (g.exec && !(b->timing && b->graph_eager_every > 0 && g.passes % b->graph_eager_every == 0)) {
     b->pass_idle = false;
-    reset_timing(b);
+    reset_timing(b); b->pass_count++;
     SNF_HIP(hipGraphLaunch(g.exec, b->stream));
     // host-side state the two calls leave behind
     b->reads_ready = true; b->cov_avg_ready = true; b->finalized = true; b->finalize_runs = 1; b->res_current = true;
@@ -1715,9 +1727,18 @@ void collect_timings(snf_batch_impl* b) {
 #ifdef SNF_WG_TRACE
   if (getenv("SNF_PROF") && b->v.wgtrace) {
     const int64_t n = 1 << 19;
-    std::vector<unsigned long long> h((size_t)n * 4);
+    std::vector<unsigned long long> h((size_t)n * 6);
     (void)hipMemcpy(h.data(), b->v.wgtrace, h.size() * 8, hipMemcpyDeviceToHost);
     (void)hipMemset(b->v.wgtrace, 0, h.size() * 8);
+    bool any_wg = false;
+    for (int64_t i = 0; i < n && !any_wg; i++) any_wg = h[2 * i + 1] != 0;
+    if (const char* path = any_wg ? getenv("SNF_WG_TRACE_FILE") : nullptr) {   // every workgroup: class, start, duration (100 MHz ticks), L, others, phases, HW_ID, XCC_ID
+      if (FILE* f = fopen(path, "w")) {
+        for (int64_t i = 0; i < n; i++) { const unsigned long long m = h[2 * i + 1]; if (!m) continue;
+          fprintf(f, "%d %llu %llu %d %d %llu %llu %llu\n", (int)((m >> 28) & 15), h[2 * i], m >> 32, (int)(m & 0xffff), (int)((m >> 16) & 0xff), h[2 * (i + n)], h[2 * (i + n) + 1], h[2 * (i + 2 * n)]); }
+        fclose(f);
+      }
+    }
     for (int cls = 1; cls <= 2; cls++) {
       struct E { unsigned long long t0, dur; int L, no; unsigned long long ph, rp; };
       std::vector<E> es;
@@ -2264,32 +2285,40 @@ int snf_device_count(void) {
 // handed to the next batch; the pool is bounded, the rest is destroyed as before.
 struct StreamPool {
   std::mutex mu;
-  std::vector<hipStream_t> idle[64];
-  hipStream_t take(int device) {
+  std::vector<hipStream_t> idle[64], idle_hi[64];   // (idle_hi: streams of the highest priority - the LARGE consensus kernel's)
+  hipStream_t take(int device, bool high = false) {
     {
       std::lock_guard<std::mutex> g(mu);
-      auto& v = idle[device & 63];
+      auto& v = (high ? idle_hi : idle)[device & 63];
       if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
     }
     hipStream_t s = nullptr;
-    SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (high) {
+      int least = 0, greatest = 0;
+      SNF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      SNF_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest));
+    } else SNF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
   }
   int trim(int device) {      // idle streams of `device` (< 0: all) are destroyed
     std::vector<std::pair<int, hipStream_t>> gone;
     {
       std::lock_guard<std::mutex> g(mu);
-      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) { for (auto s : idle[d]) gone.push_back({d, s}); idle[d].clear(); }
+      for (int d = 0; d < 64; d++) if (device < 0 || (device & 63) == d) {
+        for (auto s : idle[d]) gone.push_back({d, s});
+        for (auto s : idle_hi[d]) gone.push_back({d, s});
+        idle[d].clear(); idle_hi[d].clear();
+      }
     }
     int cur = 0; (void)hipGetDevice(&cur);
     for (auto& e : gone) { (void)hipSetDevice(e.first); (void)hipStreamDestroy(e.second); }
     (void)hipSetDevice(cur);
     return (int)gone.size();
   }
-  void give(int device, hipStream_t s) {
+  void give(int device, hipStream_t s, bool high = false) {
     {
       std::lock_guard<std::mutex> g(mu);
-      auto& v = idle[device & 63];
+      auto& v = (high ? idle_hi : idle)[device & 63];
       if (v.size() < 32 && !getenv("SNF_NO_STREAM_POOL")) { v.push_back(s); return; }
     }
     (void)hipStreamDestroy(s);
@@ -2341,7 +2370,8 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     b->run_gap = g ? atoi(g) : (base > 1000 ? base : 1000);
     b->stream = g_streams.take(b->device);
     b->stream2 = g_streams.take(b->device);
-    b->stream3 = g_streams.take(b->device);
+    b->stream3_high = getenv("SNF_LARGE_PRIO") != nullptr && atoi(getenv("SNF_LARGE_PRIO")) != 0;
+    b->stream3 = g_streams.take(b->device, b->stream3_high);
     b->stream4 = g_streams.take(b->device);
     SNF_HIP(hipEventCreateWithFlags(&b->ev_join4, hipEventDisableTiming));
     SNF_HIP(hipEventCreateWithFlags(&b->ev_e3, hipEventDisableTiming));
@@ -2375,12 +2405,15 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_SMALL(5)), 256, 0) == hipSuccess && nb > 0) b->slots_cons_s = nb * cus * atoi(e);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (K_CONS_LARGE), 256, 0) == hipSuccess && nb > 0) b->slots_cons_l = nb * cus * atoi(e);
       }
+      b->slots_cons_s1 = 65536;
+      if (const char* e = getenv("SNF_CONS_SMALL_GRID")) { if (atoi(e) > 0) b->slots_cons_s1 = atoi(e); }   // experiments: the one-wave SMALL kernel strides beyond this many workgroups
       b->slots_big = ((32 * cus) / 64) * 64; if (b->slots_big < 64) b->slots_big = 64;   // x_big: a multiple of its 64 stripes
       if (getenv("SNF_PROF")) fprintf(stderr, "[SNF_PROF] resident workgroups: d1w %d d2w %d e1w %d (CUs %d)\n", b->slots_d1w, b->slots_d2w, b->slots_e1w, cus);
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
     if (const char* e = getenv("SNF_GRAPH_EAGER_EVERY")) b->graph_eager_every = atoi(e);
+    if (const char* e = getenv("SNF_TIME_EVERY")) b->time_every = atoi(e) < 0 ? 0 : atoi(e);
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
@@ -2434,7 +2467,7 @@ void snf_batch_destroy(snf_batch_t* bb) {
   b->ext_ranges.clear();
   if (b->stream) g_streams.give(b->device, b->stream);   // (synchronised above)
   if (b->stream2) g_streams.give(b->device, b->stream2);   // (synchronised above)
-  if (b->stream3) g_streams.give(b->device, b->stream3);   // (synchronised above)
+  if (b->stream3) g_streams.give(b->device, b->stream3, b->stream3_high);   // (synchronised above)
   if (b->stream4) g_streams.give(b->device, b->stream4);   // (synchronised above)
   if (b->ev_join4) (void)hipEventDestroy(b->ev_join4);
   delete b;
@@ -2591,6 +2624,12 @@ int snf_batch_timing_count(snf_batch_t* bb) {
   return b ? (int)b->timings.size() : 0;
 }
 
+int snf_batch_timing_every(snf_batch_t* bb, int n) {
+  auto b = reinterpret_cast<snf_batch_impl*>(bb);
+  if (!b) return 1;
+  b->time_every = n < 0 ? 0 : n;
+  return 0;
+}
 int snf_batch_timing_mean_reset(snf_batch_t* bb) {
   auto b = reinterpret_cast<snf_batch_impl*>(bb);
   if (!b) return 1;

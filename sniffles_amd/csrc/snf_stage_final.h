@@ -501,7 +501,7 @@ SNF_HD int cons_skip(const snf_config_t& cfg, int64_t L) {
 SNF_HD int cons_class_of(int wave_path, int klen, int skip, int64_t L, int32_t n_others) {
   if (!wave_path || klen > 7 || klen < 1 || skip < 1 || L >= 65000) return 0;
   int64_t npos = cons_npos(L, klen, skip);
-  if (npos <= 120 && n_others <= 64 && L <= SNF_CONS_SMALL_L) return 1;
+  if (npos <= 120 && n_others <= 64 && L <= SNF_CONS_SMALL_L && skip <= 7) return 1;   // (skip <= 7: a step's bytes fit the k-mer word, snf_wave_cons.h)
   if (npos <= 500 && n_others <= 254 && L <= SNF_CONS_LARGE_L) return 2;
   if (npos <= 500 && n_others <= 512) return 4;
   return 0;

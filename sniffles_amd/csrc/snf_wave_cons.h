@@ -52,7 +52,6 @@ struct ConsLdsT {
   unsigned long long key[SLOTS];
   uint32_t pc[SLOTS];              // (position << 16) | occurrence count
   uint8_t kept[MAXOTHERS];
-  unsigned long long uq[MAXPOS / 64];   // sampled position p of the best read holds a k-mer seen exactly once (an anchor)
   uint32_t cnt[LCAP ? LCAP : 1];   // LDS vote: per column four 8-bit counters of the other reads' bases (code 0 A, 1 C, 2 T, 3 G)
   uint32_t esc[ECAP ? ECAP : 1];   // votes with any other byte: column << 8 | byte
   uint32_t n_esc;
@@ -233,21 +232,32 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       if ((atomicAdd(&lds.pc[sl], 1u) & 0xffffu) == 0) atomicOr(&lds.pc[sl], (uint32_t)i << 16);  // position of the 1st sighting
     }
     __syncthreads();
-    // which sampled positions hold a k-mer seen exactly once.  The other reads never probe the table: an anchor needs
-    // |i - j| <= maxshift with i and j on the same sampling grid, so position p of a read can only anchor at positions
-    // p - dmax .. p + dmax of the best read (dmax = maxshift / skip, 0 once skip > maxshift) - a direct compare of the k-mer
-    // words plus this bit replaces a chain of dependent LDS probes per sampled k-mer (measured: half of a read's time)
-    for (int p0 = wid * 64; p0 < npos; p0 += NT) {
-      const int p = p0 + lane;
-      bool u = false;
-      if (p < npos) {
-        const unsigned long long kk = kmer_key_le(ld8<LV>(B + p * skip), klen);
-        int sl = (int)kmer_slot(kk, SLOTS);
-        while (lds.key[sl] != kk) sl = (sl + 1) & (SLOTS - 1);
-        u = (lds.pc[sl] & 0xffffu) == 1u;
+    // The anchor keys by sampled position.  The other reads never probe the table: an anchor needs |i - j| <= maxshift with i
+    // and j on the same sampling grid, so position p of a read can only anchor at positions p - dmax .. p + dmax of the best
+    // read (dmax = maxshift / skip, 0 once skip > maxshift).  kb[KPAD + p] = the k-mer key at sampled position p of the best
+    // read if it is seen exactly once there, else a word no key equals (keys have at most 7 bytes) - also on KPAD >= dmax
+    // positions either side: a probe is one aligned 8-byte LDS read and one compare, no bounds, no second look-up.  The table
+    // is only needed up to here: kb takes its storage.
+    constexpr int KPAD = 8, KIT = (MAXPOS + NT - 1) / NT;
+    static_assert(SLOTS >= MAXPOS + 2 * KPAD, "the anchor keys by position reuse the table's storage");
+    unsigned long long* const kb = lds.key;
+    {
+      unsigned long long kbv[KIT];
+#pragma unroll
+      for (int k = 0; k < KIT; k++) {
+        const int p = k * NT + tid;
+        kbv[k] = SNF_KEY_EMPTY;
+        if (p < npos) {
+          const unsigned long long kk = kmer_key_le(ld8<LV>(B + p * skip), klen);
+          int sl = (int)kmer_slot(kk, SLOTS);
+          while (lds.key[sl] != kk) sl = (sl + 1) & (SLOTS - 1);
+          if ((lds.pc[sl] & 0xffffu) == 1u) kbv[k] = kk;
+        }
       }
-      const unsigned long long mk = __ballot(u);
-      if (lane == 0) lds.uq[p0 >> 6] = mk;
+      __syncthreads();   // every look-up is done
+#pragma unroll
+      for (int k = 0; k < KIT; k++) { const int p = k * NT + tid; if (p < MAXPOS) kb[KPAD + p] = kbv[k]; }
+      if (tid < KPAD) { kb[tid] = SNF_KEY_EMPTY; kb[KPAD + MAXPOS + tid] = SNF_KEY_EMPTY; }
     }
     __syncthreads();
     SNF_PT(0);   // descriptor, staging, table build
@@ -325,10 +335,22 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
         const int p = rd * 64 + lane, j = p * skip;
         const unsigned long long kk = kmer_key_le(kw[rd], klen);
         int ci_ = -1;
-        for (int dd = -dmax; dd <= dmax; dd++) {      // (one candidate whenever skip > maxshift)
-          const int ip = p + dd;
-          if (p < P && ip >= 0 && ip < npos && kmer_key_le(ld8<LV>(B + ip * skip), klen) == kk && ((lds.uq[ip >> 6] >> (ip & 63)) & 1ull)) ci_ = ip * skip;
+        // (one candidate whenever skip > maxshift; at most one matches: anchors are unique)
+#ifdef SNF_CONS_PROBE_LOOP
+        if (false) {
+#else
+        if (dmax <= 2) {   // the usual cases: all reads in flight at once
+#endif
+          const unsigned long long* kq = kb + KPAD + p;
+          const unsigned long long k0 = kq[-2], k1 = kq[-1], k2 = kq[0], k3 = kq[1], k4 = kq[2];
+          if (k2 == kk) ci_ = j;
+          if (dmax >= 1) { if (k1 == kk) ci_ = j - skip; if (k3 == kk) ci_ = j + skip; }
+          if (dmax == 2) { if (k0 == kk) ci_ = j - 2 * skip; if (k4 == kk) ci_ = j + 2 * skip; }
+        } else {
+          for (int dd = -dmax; dd <= dmax; dd++)
+            if (kb[KPAD + p + dd] == kk) ci_ = (p + dd) * skip;
         }
+        if (p >= P) ci_ = -1;
         const unsigned long long mk = __ballot(ci_ >= 0);
         if (ci_ >= 0) { const int w = ncand + __builtin_popcountll(mk & ((1ull << lane) - 1ull)); W.ai[w] = (uint16_t)ci_; W.aj[w] = (uint16_t)j; }
         ncand += __builtin_popcountll(mk);
@@ -367,8 +389,9 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       // Read in HBM (SCAP == 0): the skip + 1 <= 24 bytes a step is compared and copied from are the step's k-mer word (already
       // here) and up to two more words, requested for all steps of the read at once and kept in registers through the vote
       constexpr int WR = SCAP == 0 ? ROUNDS : 1;
-      const bool use_win = SCAP == 0 && skip <= 23;
-      uint64_t sw1[WR], sw2[WR];
+      // Read staged in LDS (SCAP > 0, the SMALL class: skip <= 7 by cons_class_of): the k-mer word alone holds the skip + 1 bytes of a step
+      const bool use_win = SCAP == 0 ? skip <= 23 : true;
+      uint64_t sw1[WR] = {}, sw2[WR] = {};
       if constexpr (SCAP == 0) {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; rd++) {
@@ -599,6 +622,7 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       if (tid == 0) { v.wgtrace[2 * (int64_t)cid] = wg_t0;
         v.wgtrace[2 * ((int64_t)cid + (1 << 19)) + 1] = (pt_acc[1] / 10) | ((pt_acc[4] / 10) << 12) | ((pt_acc[3] / 10) << 24) | ((pt_acc[7] / 10) << 36) | ((pt_acc[5] / 10) << 48);
         v.wgtrace[2 * ((int64_t)cid + (1 << 19))] = (wg_t1 - wg_t0) | ((wg_t2 - wg_t1) << 16) | ((wg_t3 - wg_t2) << 32) | ((wg_t4 - wg_t3) << 48);
+        v.wgtrace[2 * ((int64_t)cid + (1 << 20))] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32);   // HW_ID | XCC_ID
         v.wgtrace[2 * (int64_t)cid + 1] = ((wall_clock64() - wg_t0) << 32) | ((unsigned long long)CLS << 28) | ((unsigned long long)(n_others & 0xff) << 16) | (unsigned long long)(L & 0xffff); }
 #endif
       continue;

@@ -54,6 +54,7 @@ def bind(lib: C.CDLL) -> C.CDLL:
     lib.snf_batch_coverage_calls.restype = C.c_int
     lib.snf_batch_timing_count.argtypes = [vp]
     lib.snf_batch_timing_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    lib.snf_batch_timing_every.argtypes = [vp, C.c_int]
     lib.snf_batch_timing_mean_reset.argtypes = [vp]
     lib.snf_batch_timing_mean_count.argtypes = [vp]
     lib.snf_batch_timing_mean_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
@@ -294,6 +295,10 @@ class Batch:
             _check(self.lib, self.lib.snf_batch_timing_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb)))
             out.append((name.value.decode(), float(ms.value), int(nb.value)))
         return out
+
+    def timing_every(self, n: int) -> None:
+        """HIP-event brackets around the launches on every n-th pass of this handle (default 8; 1: every pass; 0: never)."""
+        self.lib.snf_batch_timing_every(self._h, int(n))
 
     def timings_mean_reset(self) -> None:
         self.lib.snf_batch_timing_mean_reset(self._h)
