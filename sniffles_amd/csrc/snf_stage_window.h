@@ -19,6 +19,7 @@
 // holds more leads than the largest instance of w4_local / w6_emit takes; otherwise the sort path (snf_stage_cluster.h) runs.
 #pragma once
 #include "snf_fused.h"
+#include "snf_wave_refine.h"   // wave_incl_max (DPP scan)
 
 namespace snf {
 
@@ -159,9 +160,7 @@ SNF_D void win_decode(const View& v, uint32_t w, int* grp, int64_t* bin0) {
 
 // inclusive running maximum along the positions of a window, 64 positions per round (carry: the maximum of the rounds before)
 SNF_D int wave_runmax(int x, int carry) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d && y > x) x = y; }
+  x = wave_incl_max(x);      // (six DPP steps; the __shfl_up form was six round trips through the LDS crossbar)
   return x > carry ? x : carry;
 }
 
@@ -191,10 +190,16 @@ __global__ void __launch_bounds__(64) w4_local(const View v, int64_t n_unused) {
   for (int j = 0; j < E; j++) r[j] = 0;
   // (the attribute bits above the bin do not disturb the order: the comparison masks them)
   const uint64_t mask = ((uint64_t)0xfffu << 32) | 0xffffffffull;
-  for (int q = 0; q < n; q++) {
-    const uint64_t kq = keys[q] & mask;
+  // (a window holds ~23 leads on a 30x genome and the instance is sized by the largest one: only the rounds that hold leads compare)
+  if (n <= 64) {
+    const uint64_t e0 = e[0] & mask;
+    for (int q = 0; q < n; q++) r[0] += (keys[q] & mask) < e0 ? 1 : 0;
+  } else {
+    for (int q = 0; q < n; q++) {
+      const uint64_t kq = keys[q] & mask;
 #pragma unroll
-    for (int j = 0; j < E; j++) r[j] += kq < (e[j] & mask) ? 1 : 0;
+      for (int j = 0; j < E; j++) if (64 * j < n) r[j] += kq < (e[j] & mask) ? 1 : 0;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -220,6 +225,7 @@ __global__ void __launch_bounds__(64) w4_local(const View v, int64_t n_unused) {
 #pragma unroll
   for (int j = 0; j < E; j++) {
     const int p = lane + 64 * j;
+    if (64 * j >= n) break;
     if (p < n) {
       const uint32_t a = (uint32_t)(keys[p] >> 32);
       const int h = hpos[p];
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(64) w4_local(const View v, int64_t n_unused) {
 #pragma unroll
   for (int j = 0; j < E; j++) {
     const int p = lane + 64 * j;
+    if (64 * j >= n) break;
     bool f_seed = false, f_norm = false, f_long = false;
     if (p < n) {
       const uint64_t key = keys[p];

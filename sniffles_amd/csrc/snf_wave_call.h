@@ -10,16 +10,8 @@ namespace snf {
 
 struct CallLds { int32_t buf[SNF_WAVE]; double nm[SNF_WAVE]; };
 
-SNF_D int64_t wave_sum64(int64_t x) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, SNF_WAVE);
-  return x;
-}
-SNF_D int wave_max32(int x) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { int y = __shfl_xor(x, d, SNF_WAVE); if (y > x) x = y; }
-  return x;
-}
+SNF_D int64_t wave_sum64(int64_t x) { return wave_last64(wave_incl_scan64(x, 0)); }     // (DPP scans, snf_wave_refine.h)
+SNF_D int wave_max32(int x) { return (int)__builtin_amdgcn_readlane((uint32_t)wave_incl_max(x), 63); }
 
 // ascending sort of the active lanes' values; returns the value at sorted position `lane` (lanes >= n: garbage)
 SNF_D int32_t wave_sort_i32(int32_t x, bool act, int n, int lane, int32_t* lds) {

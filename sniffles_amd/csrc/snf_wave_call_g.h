@@ -34,14 +34,31 @@ template <int G> SNF_D uint64_t gshfl_u64(uint64_t x, int src, int gbase) {
   const uint32_t lo = (uint32_t)__shfl((int32_t)(uint32_t)x, gbase + src, SNF_WAVE), hi = (uint32_t)__shfl((int32_t)(uint32_t)(x >> 32), gbase + src, SNF_WAVE);
   return ((uint64_t)hi << 32) | lo;
 }
+// group-wide all-reduce.  G = 8: three DPP steps (lanes ^1 and ^2 inside the quad, then the mirror image inside the half row:
+// lane i <- lane 7 - i, which lies in the other quad) instead of three round trips through the LDS crossbar
+#define SNF_DPP_G8(STEP) STEP(0xB1) STEP(0x4E) STEP(0x141)   /* quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], row_half_mirror */
 template <int G> SNF_D int64_t gsum64(int64_t x) {
+  if constexpr (G == 8) {
+#define SNF_STEP(ctrl) { const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)x, ctrl, 0xf, 0xf, false), \
+                                        hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)x >> 32), ctrl, 0xf, 0xf, false); \
+                         x += (int64_t)(((uint64_t)hi_ << 32) | lo_); }
+    SNF_DPP_G8(SNF_STEP)
+#undef SNF_STEP
+  } else {
 #pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, SNF_WAVE);
+    for (int d = G / 2; d >= 1; d >>= 1) x += __shfl_xor(x, d, SNF_WAVE);
+  }
   return x;
 }
 template <int G> SNF_D int gmax32(int x) {
+  if constexpr (G == 8) {
+#define SNF_STEP(ctrl) { const int y_ = __builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false); x = y_ > x ? y_ : x; }
+    SNF_DPP_G8(SNF_STEP)
+#undef SNF_STEP
+  } else {
 #pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) { const int y = __shfl_xor(x, d, SNF_WAVE); if (y > x) x = y; }
+    for (int d = G / 2; d >= 1; d >>= 1) { const int y = __shfl_xor(x, d, SNF_WAVE); if (y > x) x = y; }
+  }
   return x;
 }
 // rank of `key` among the group's keys (inactive lanes hold ~0: never smaller); nmax = the largest cluster of the wave

@@ -3,7 +3,8 @@
 //
 // Everything stays in registers: sorts are rank sorts over packed 64-bit keys (n broadcasts of one
 // lane's key via v_readlane), the same-read fusion is a segmented scan over the sorted order, and the
-// sequential resplit bin-merge state machine (k <= a handful of bins) runs on lane 0 in LDS.  Clusters
+// sequential resplit bin-merge state machine (k <= a handful of bins) keeps its arrays one element per lane and walks them with
+// v_readlane.  The common shapes leave early: every read once in the cluster (nothing to sort or fuse), one |svlen| bin.  Clusters
 // with more than 64 leads take the thread-per-cluster path (d1_refine_body), which is also what the
 // host emulation executes; both write the same F / FI / refined-cluster tables.
 #pragma once
@@ -19,22 +20,37 @@ SNF_D uint64_t wave_bcast_u64(uint64_t x, int src) {
 }
 SNF_D int32_t wave_bcast_i32(int32_t x, int src) { return (int32_t)__builtin_amdgcn_readlane((uint32_t)x, src); }
 
-// inclusive prefix sum across the wave
-SNF_D int32_t wave_incl_scan(int32_t x, int lane) {
-#pragma unroll
-  for (int d = 1; d < SNF_WAVE; d <<= 1) {
-    int32_t y = __shfl_up(x, d, SNF_WAVE);
-    if (lane >= d) x += y;
-  }
+// Wave-wide scans and reductions through DPP (row shifts inside the rows of 16 lanes, then row_bcast:15 / :31 for the row
+// totals): six dependent VALU operations of a few cycles each.  The `__shfl_up` / `__shfl_xor` forms these replace compile to
+// ds_bpermute - six dependent round trips through the LDS crossbar (~100 cycles each) per scan, and the wave kernels are
+// chains of them.  All 64 lanes must be active (the wave kernels' control flow is wave-uniform; idle lanes carry zeros).
+#define SNF_DPP_STEPS(STEP) STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+SNF_D int32_t wave_incl_scan(int32_t x, int lane) {   // inclusive prefix sum across the wave
+  (void)lane;
+#define SNF_STEP(ctrl, rows) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rows, 0xf, false);
+  SNF_DPP_STEPS(SNF_STEP)
+#undef SNF_STEP
   return x;
 }
 SNF_D int64_t wave_incl_scan64(int64_t x, int lane) {
-#pragma unroll
-  for (int d = 1; d < SNF_WAVE; d <<= 1) {
-    int64_t y = __shfl_up(x, d, SNF_WAVE);
-    if (lane >= d) x += y;
-  }
+  (void)lane;
+#define SNF_STEP(ctrl, rows) { const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(uint64_t)x, ctrl, rows, 0xf, false), \
+                                              hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)x >> 32), ctrl, rows, 0xf, false); \
+                               x += (int64_t)(((uint64_t)hi_ << 32) | lo_); }
+  SNF_DPP_STEPS(SNF_STEP)
+#undef SNF_STEP
   return x;
+}
+SNF_D int32_t wave_incl_max(int32_t x) {
+#define SNF_STEP(ctrl, rows) { const int32_t y_ = __builtin_amdgcn_update_dpp(x, x, ctrl, rows, 0xf, false); x = y_ > x ? y_ : x; }
+  SNF_DPP_STEPS(SNF_STEP)
+#undef SNF_STEP
+  return x;
+}
+// the value lane 63 holds, as a wave-uniform value
+SNF_D int64_t wave_last64(int64_t x) {
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)x, 63), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)x >> 32), 63);
+  return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // rank of `key` among the first n lanes' keys (keys are distinct: the lane index is part of the key)
@@ -54,12 +70,7 @@ SNF_D void big_push(const View& v, int kind, int32_t item) {
 struct WaveLds {
   int32_t perm[SNF_WAVE];      // scatter target for permutations
   int32_t seg_start[SNF_WAVE]; // resplit: segment (distinct bin) start position in sorted order
-  int32_t seg_key[SNF_WAVE];
-  int32_t nc[SNF_WAVE];        // surviving bins
-  int32_t head[SNF_WAVE], tail[SNF_WAVE], nxt[SNF_WAVE];
-  int32_t seg_out[SNF_WAVE];   // output start of each segment
-  int32_t rc_start[SNF_WAVE], rc_len[SNF_WAVE];
-  int32_t n_rc;
+  int32_t seg_key[SNF_WAVE];   //          its bin
 };
 
 // sorted-order gather: lane r receives the value held by the lane whose rank is r
@@ -126,8 +137,11 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         uint32_t qi = (uint32_t)wave_bcast_i32((int32_t)qname, i);
         if (fa < 0 && qi == qname) fa = i;
       }
-      uint64_t key = act ? (((uint64_t)(uint32_t)fa << 40) | ((uint64_t)((uint32_t)ref_start ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
       SNF_RT(0);   // records in registers, first appearance
+      // Every read of the cluster appears once (the usual case): the (read, ref_start) order is the cluster order and nothing can
+      // fuse - the leads stay where they are (m = n, f_* as loaded).  Wave-uniform.
+      if (__ballot(act && fa != lane) != 0ull) {
+      uint64_t key = act ? (((uint64_t)(uint32_t)fa << 40) | ((uint64_t)((uint32_t)ref_start ^ 0x80000000u) << 8) | (uint32_t)lane) : ~0ull;
       const int rank = wave_rank(key, n);
       const int n_ = n;
       SNF_PERMUTE_SETUP(rank, act)
@@ -214,6 +228,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int64_t t_seq_off = ok_seq ? (nparts == 1 ? s_seq_off : new_off) : 0;
       f_seq_len = __shfl(t_seq_len, src2, SNF_WAVE);
       f_seq_off = __shfl(t_seq_off, src2, SNF_WAVE);
+      }
     }
     SNF_RT(3);   // pool reservation, byte copies, compaction
     const bool fact = lane < m;
@@ -264,6 +279,12 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       const int rb = cfg.cluster_resplit_binsize;
       const int64_t av = f_svlen < 0 ? -(int64_t)f_svlen : f_svlen;
       const int32_t bin = (int32_t)((av / rb) * rb);
+      // one bin (wave-uniform test): the cluster stays whole, in its order
+      if (__ballot(fact && bin != __builtin_amdgcn_readfirstlane(bin)) == 0ull) {
+        if (fact) v.FI[lo + lane] = lo + lane;
+        if (lane == 0) rc_emit(v, lo, m, (int32_t)c, true);
+        continue;
+      }
       uint64_t key = fact ? (((uint64_t)(uint32_t)bin << 8) | (uint32_t)lane) : ~0ull;
       const int rank = wave_rank(key, m);
       const int n_ = m;
@@ -277,40 +298,42 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
       __syncthreads();
       if (sstart) { lds.seg_start[sidx] = lane; lds.seg_key[sidx] = s_bin; }
       __syncthreads();
-      if (lane == 0) {  // sequential bin-merge state machine with the reference's index quirks
-        for (int s = 0; s < nb; s++) { lds.nc[s] = s; lds.head[s] = s; lds.tail[s] = s; lds.nxt[s] = -1; }
-        int cntc = nb, i = 1;
-        while (cntc > 1 && i < cntc) {
-          const int im1 = (i == 0) ? cntc - 1 : i - 1;  // Python negative index: new_clusters[-1]
-          const int64_t last = lds.seg_key[lds.nc[im1]], curr = lds.seg_key[lds.nc[i]];
-          const int64_t mn = curr < last ? curr : last;
-          const double t = (double)mn * cfg.cluster_merge_len;
-          const double thr = ((double)cfg.minsvlen >= t) ? (double)cfg.minsvlen : t;
-          const int64_t diff = curr > last ? curr - last : last - curr;
-          if ((double)diff <= thr) {
-            const int cb = lds.nc[i], lb = lds.nc[im1];
-            lds.nxt[lds.tail[cb]] = lds.head[lb];
-            lds.tail[cb] = lds.tail[lb];
-            for (int t2 = im1; t2 + 1 < cntc; t2++) lds.nc[t2] = lds.nc[t2 + 1];
-            cntc--;
-            i = (i - 2 > 0) ? i - 2 : 0;
-          } else i++;
-        }
-        int outp = 0;
-        for (int t2 = 0; t2 < cntc; t2++) {
-          const int start = outp;
-          for (int s = lds.head[lds.nc[t2]]; s >= 0; s = lds.nxt[s]) {
-            const int xe = (s + 1 < nb) ? lds.seg_start[s + 1] : m;
-            lds.seg_out[s] = outp;
-            outp += xe - lds.seg_start[s];
-          }
-          lds.rc_start[t2] = start; lds.rc_len[t2] = outp - start;
-        }
-        lds.n_rc = cntc;
+      // Sequential bin-merge state machine with the reference's index quirks.  Its arrays live ONE ELEMENT PER LANE (lane s: segment s,
+      // lane t: surviving bin t) and the walk reads them with v_readlane at wave-uniform indices: a few cycles per access where the
+      // LDS form (one lane walking arrays in LDS) paid a round trip of ~100 cycles for each of its ~50 dependent accesses.
+      const int32_t K = lane < nb ? lds.seg_key[lane] : 0, ST = lane < nb ? lds.seg_start[lane] : m;
+      int32_t NC = lane, HEAD = lane, TAIL = lane, NXT = -1, SEGOUT = 0, RCS = 0, RCL = 0;
+      int cntc = nb, i = 1;
+      while (cntc > 1 && i < cntc) {
+        const int im1 = (i == 0) ? cntc - 1 : i - 1;  // Python negative index: new_clusters[-1]
+        const int lb = wave_bcast_i32(NC, im1), cb = wave_bcast_i32(NC, i);
+        const int64_t last = wave_bcast_i32(K, lb), curr = wave_bcast_i32(K, cb);
+        const int64_t mn = curr < last ? curr : last;
+        const double t = (double)mn * cfg.cluster_merge_len;
+        const double thr = ((double)cfg.minsvlen >= t) ? (double)cfg.minsvlen : t;
+        const int64_t diff = curr > last ? curr - last : last - curr;
+        if ((double)diff <= thr) {
+          const int tcb = wave_bcast_i32(TAIL, cb), hlb = wave_bcast_i32(HEAD, lb), tlb = wave_bcast_i32(TAIL, lb);
+          if (lane == tcb) NXT = hlb;
+          if (lane == cb) TAIL = tlb;
+          const int32_t up = __shfl_down(NC, 1, SNF_WAVE);      // new_clusters.pop(im1)
+          if (lane >= im1 && lane + 1 < cntc) NC = up;
+          cntc--;
+          i = (i - 2 > 0) ? i - 2 : 0;
+        } else i++;
       }
-      __syncthreads();
-      if (fact) v.FI[lo + lds.seg_out[sidx] + (lane - lds.seg_start[sidx])] = lo + s_k;
-      if (lane < lds.n_rc) rc_emit(v, lo + lds.rc_start[lane], lds.rc_len[lane], (int32_t)c, true);
+      int outp = 0;
+      for (int t2 = 0; t2 < cntc; t2++) {
+        const int start = outp;
+        for (int sg = wave_bcast_i32(HEAD, wave_bcast_i32(NC, t2)); sg >= 0; sg = wave_bcast_i32(NXT, sg)) {
+          if (lane == sg) SEGOUT = outp;
+          outp += (sg + 1 < nb ? wave_bcast_i32(ST, sg + 1) : m) - wave_bcast_i32(ST, sg);
+        }
+        if (lane == t2) { RCS = start; RCL = outp - start; }
+      }
+      const int32_t my_out = __shfl(SEGOUT, sidx < 0 ? 0 : sidx, SNF_WAVE), my_st = __shfl(ST, sidx < 0 ? 0 : sidx, SNF_WAVE);
+      if (fact) v.FI[lo + my_out + (lane - my_st)] = lo + s_k;
+      if (lane < cntc) rc_emit(v, lo + RCS, RCL, (int32_t)c, true);
       __syncthreads();
     }
   }

@@ -9,7 +9,8 @@
 //   * __shfl / __shfl_xor / __shfl_up / __shfl_down / __ballot / readlane / readfirstlane exchange through a per-wave
 //     buffer bracketed by two wave barriers; all 64 lanes must take part (a divergent call is reported as a deadlock);
 //   * __builtin_amdgcn_update_dpp implements the controls the kernels use: row_shr:1..15 (0x111..0x11f), row_bcast:15
-//     (0x142), row_bcast:31 (0x143), with row_mask and bound_ctrl = false semantics (disabled / sourceless lanes keep `old`);
+//     (0x142), row_bcast:31 (0x143), quad_perm (0x00..0xff), row_mirror (0x140), row_half_mirror (0x141), with row_mask and
+//     bound_ctrl = false semantics (disabled / sourceless lanes keep `old`);
 //   * atomics are plain read-modify-writes (switches are cooperative, so they are atomic by construction);
 //   * __shared__ is a function-local static: one workgroup at a time;
 //   * LOCK STEP for the kernels that need it (x_big: all 64 lanes of a wave run one serial body on the same data, so a
@@ -432,6 +433,9 @@ inline int dpp_at(const void* site, int old, int src, int ctrl, int row_mask, in
   if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if ((l & 15) >= n) from = l - n; }
   else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }
   else if (ctrl == 0x143) { if (row >= 2) from = 31; }
+  else if (ctrl >= 0 && ctrl <= 0xff) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);      // quad_perm
+  else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));                                // row_mirror
+  else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));                                   // row_half_mirror
   else die("update_dpp: control not modelled");
   const uint64_t grp = wave_op_begin(site, to_bits(src));
   int r = old;

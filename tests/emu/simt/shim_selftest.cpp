@@ -41,6 +41,17 @@ __global__ void k_shuffles(long long* out) {
   unsigned long long want = 0;
   for (int k = 0; k < 64; k++) if (k % 5 == 0) want |= 1ull << k;
   bad += __ballot(lane % 5 == 0) != want;
+  // the in-group DPP steps of snf_wave_call_g.h: quad_perm:[1,0,3,2], quad_perm:[2,3,0,1], row_half_mirror, and row_mirror
+  bad += __builtin_amdgcn_update_dpp(0, lane, 0xB1, 0xf, 0xf, false) != (lane ^ 1);
+  bad += __builtin_amdgcn_update_dpp(0, lane, 0x4E, 0xf, 0xf, false) != (lane ^ 2);
+  bad += __builtin_amdgcn_update_dpp(0, lane, 0x141, 0xf, 0xf, false) != ((lane & ~7) | (7 - (lane & 7)));
+  bad += __builtin_amdgcn_update_dpp(0, lane, 0x140, 0xf, 0xf, false) != ((lane & ~15) | (15 - (lane & 15)));
+  { int g = (lane * 13 + 3) % 17, want_g = 0;           // all-reduce over groups of 8 lanes
+    for (int k = (lane & ~7); k < (lane & ~7) + 8; k++) want_g += (k * 13 + 3) % 17;
+    g += __builtin_amdgcn_update_dpp(0, g, 0xB1, 0xf, 0xf, false);
+    g += __builtin_amdgcn_update_dpp(0, g, 0x4E, 0xf, 0xf, false);
+    g += __builtin_amdgcn_update_dpp(0, g, 0x141, 0xf, 0xf, false);
+    bad += g != want_g; }
   atomicAdd(out, bad);
 }
 
