@@ -1097,6 +1097,11 @@ void do_upload(snf_batch_impl* b) {
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
+// passes that have been enqueued and not yet waited for, over all handles of the process (a pass = snf_batch_pass, or
+// call_candidates .. the fetch / sync that waits for it)
+std::atomic<int> g_passes_in_flight{0};
+void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; g_passes_in_flight.fetch_add(1); } }
+void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; g_passes_in_flight.fetch_sub(1); } }
 void reset_timing(snf_batch_impl* b) {
   b->ev_used = 0;
   b->timings.clear();
@@ -1225,6 +1230,7 @@ void run_call_candidates(snf_batch_impl* b) {
   const int64_t N = v.NS;   // positions behind the sort (the prefilter's count is known since the upload)
   b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
   begin_pass_timing(b);
+  pass_begins(b);
   // SNF_OUT_EXECUTE (set before this call): the names of the supporting reads are only written for the calls that pass QC,
   // once finalize knows them (a stage-0 fetch writes them all, late)
   v.rn_defer = ((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc && getenv("SNF_NO_RN_DEFER") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25)) ? 1 : 0;
@@ -1361,7 +1367,7 @@ void run_call_candidates(snf_batch_impl* b) {
   // the number of calls is known here: publish the counters (pinned block) and let the host pick them up through
   // ev_counts.  Nothing the ALT chain of finalize needs is produced after this point, so the rest of the candidate
   // stage (sv ids, supporting read names, coverage annotation) continues on the side stream, behind the read preparation
-  LAUNCH_Q(d3_taskoff, v, T + 1, 0);
+  LAUNCH_Q(d3_taskoff, v, tail_threads(v), 0);
   SNF_HIP(hipEventRecord(b->ev_counts, b->stream));
   if (b->sched_readprep == 2) enqueue_read_prep(b);
   fork_mark(b);
@@ -1403,7 +1409,7 @@ void join_fourth(snf_batch_impl* b) {  // main stream waits for the fourth strea
 void full_sync(snf_batch_impl* b) {
   join_side(b);
   join_fourth(b);
-  if (!b->res_current) { LAUNCH_Q(z1_results, b->v, b->v.T + 1, 0); b->res_current = true; }
+  if (!b->res_current) { LAUNCH_Q(z1_results, b->v, tail_threads(b->v), 0); b->res_current = true; }
   dsync(b);
 }
 
@@ -1506,39 +1512,57 @@ void run_alt_fallback(snf_batch_impl* b) {
 void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large, int64_t g_copy) {
   SNF_TRACE("E4/E5: INS consensus (SMALL / LARGE / verbatim)");
   View& v = b->v;
-    const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
-    if (serial) SNF_HIP(hipDeviceSynchronize());
+  const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
+  // Order of the two consensus classes.  0: LARGE on its own stream NEXT TO SMALL - alone on the device SMALL fills the tail of
+  // LARGE's unequal calls (one batch in flight: 1.466 ms per step against 1.494 for order 2).  2: LARGE BEHIND SMALL (its stream
+  // waits for SMALL) - next to each other a LARGE workgroup (71 KB of LDS, 4 x 256 VGPRs on one CU at once) only finds room when
+  // SMALL's queue of one-wave workgroups runs dry: LARGE spans 0.51 ms in place against 0.22 behind SMALL (SMALL: 0.27 / 0.17), and
+  // with a second pass in flight that pass fills the tails instead (two in flight: 1.238 against 1.242).  So: 2 when another pass is
+  // in flight on the device, 0 otherwise; SNF_CONS_ORDER forces one (1 = SMALL behind LARGE on LARGE's stream: slower than both).
+  static const int order_env = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : -1;
+  const int order = order_env >= 0 ? order_env : (g_passes_in_flight.load() > 1 ? 2 : 0);
+  auto launch_large = [&]() {   // (on b->cur = stream3)
+    Scope _s(b, "e45w_consensus_large", 0, true);
+    const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
+    if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
+    else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
+    else hipLaunchKernelGGL((K_CONS_LARGE), gl, dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  };
+  auto launch_small = [&]() {
+    Scope _s(b, "e45w_consensus_small", 0);
+    const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
+    if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < b->slots_cons_s1 ? g_small : b->slots_cons_s1)), dim3(64), 0, b->cur, v, (int64_t)0);
+    else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+    else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+    else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  };
+  auto launch_copy = [&]() {    // verbatim ALTs: short; on the main stream ahead of SMALL
+    Scope _s(b, "e4c_copy", 0);
+    hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
+    SNF_HIP(hipGetLastError());
+  };
+  auto on_stream3 = [&](auto&& f) { hipStream_t prev = b->cur; b->cur = b->stream3; f(); b->cur = prev; };
+  if (serial) SNF_HIP(hipDeviceSynchronize());
+  if (order == 2) {
+    launch_small();
     SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
-    {  // the LARGE class is independent of the others: its own stream, joined before the ALT bytes are copied out
-      SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
-      hipStream_t prev = b->cur; b->cur = b->stream3;
-      { Scope _s(b, "e45w_consensus_large", 0, true);
-        const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
-        if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
-        else if (b->cons_large_nw == 8) hipLaunchKernelGGL((K_CONS_LARGE_8W), gl, dim3(512), 0, b->cur, v, (int64_t)0);
-        else hipLaunchKernelGGL((K_CONS_LARGE), gl, dim3(256), 0, b->cur, v, (int64_t)0);
-        SNF_HIP(hipGetLastError()); }
-      b->cur = prev;
-    }
-    auto launch_small = [&]() {
-      Scope _s(b, "e45w_consensus_small", 0);
-      const dim3 gs((unsigned)(g_small < b->slots_cons_s ? g_small : b->slots_cons_s));
-      if (b->cons_nw == 1) hipLaunchKernelGGL((K_CONS_SMALL_1W), dim3((unsigned)(g_small < b->slots_cons_s1 ? g_small : b->slots_cons_s1)), dim3(64), 0, b->cur, v, (int64_t)0);
-      else if (b->occ_s >= 8) hipLaunchKernelGGL((K_CONS_SMALL(8)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-      else if (b->occ_s == 6) hipLaunchKernelGGL((K_CONS_SMALL(6)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-      else hipLaunchKernelGGL((K_CONS_SMALL(5)), gs, dim3(256), 0, b->cur, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    };
-    static const int order = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : 0;   // experiment: 1 = SMALL behind LARGE on LARGE's stream
-    if (order == 1) { hipStream_t prev = b->cur; b->cur = b->stream3; launch_small(); b->cur = prev; }
+    SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+    on_stream3(launch_large);
+    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
+    launch_copy();
+  } else {
+    // the LARGE class is independent of the others: its own stream, joined before the ALT bytes are copied out
+    SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+    SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+    on_stream3(launch_large);
+    if (order == 1) on_stream3(launch_small);
     if (serial) SNF_HIP(hipDeviceSynchronize());
     SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
-    {  // verbatim ALTs: short; on the main stream ahead of SMALL (LARGE is the longer of the two chains)
-      Scope _s(b, "e4c_copy", 0);
-      hipLaunchKernelGGL(e4c_copy, dim3((unsigned)(g_copy < 32768 ? g_copy : 32768)), dim3(64), 0, b->cur, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    }
+    launch_copy();
     if (order != 1) launch_small();
+  }
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
@@ -1653,7 +1677,7 @@ void run_finalize(snf_batch_impl* b) {
     join_fourth(b);
     enqueue_output_head(b);   // (no positions behind the sort: an empty block)
   }
-  LAUNCH_Q(z1_results, v, v.T + 1, 0);
+  LAUNCH_Q(z1_results, v, tail_threads(v), 0);
   b->res_current = true;
 }
 
@@ -1662,9 +1686,6 @@ void run_finalize(snf_batch_impl* b) {
 // host enqueues it with one call and the device-side launch-to-launch gaps shrink.  Everything a pass needs from the host is
 // constant for a handle (same input): grids, pointers, modes - except the memory the result lands in and the output mode, which
 // key the graph.  Kernels take the pass-dependent state (counters, chain tags, window cursors) from HBM.
-std::atomic<int> g_passes_in_flight{0};
-void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; g_passes_in_flight.fetch_add(1); } }
-void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; g_passes_in_flight.fetch_sub(1); } }
 bool pass_graph_ok(snf_batch_impl* b) {
   const View& v = b->v;
   if (b->graph_mode == 1 && g_passes_in_flight.load() > 1) return false;      // (this batch itself is counted)
@@ -1814,7 +1835,7 @@ void settle_alt_stage(snf_batch_impl* b) {
   const Counts& c = *b->h_cnt;
   if (c.n_cls[7] == 0 && c.n_cons_fallback == 0) return;
   run_alt_fallback(b);     // (they store into the pass's ALT section like the fast kernels)
-  LAUNCH_Q(z1_results, v, v.T + 1, 0);
+  LAUNCH_Q(z1_results, v, tail_threads(v), 0);
   dsync(b);
 }
 
@@ -2616,7 +2637,7 @@ int snf_consensus_batch(int device, int klen, const uint8_t* seq_pool, int64_t s
 
 
 int snf_batch_sync(snf_batch_t* bb) {
-  SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); if (b->uploaded) full_sync(b); else dsync(b); collect_timings(b); })
+  SNF_TRY({ auto b = reinterpret_cast<snf_batch_impl*>(bb); if (!b) fail("null batch"); if (b->uploaded) full_sync(b); else dsync(b); pass_waited(b); collect_timings(b); })
 }
 
 int snf_batch_timing_count(snf_batch_t* bb) {

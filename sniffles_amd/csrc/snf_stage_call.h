@@ -468,9 +468,14 @@ SNF_HD int64_t task_lower_bound(const View& v, int64_t t) {
   while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (v.calls[mid].task_index < t) lo = mid + 1; else hi = mid; }
   return lo;
 }
+// threads of the two launches that publish per-task words and the counters into the pinned result block (d3_taskoff, z1_results):
+// at least 128, so that the ~60 words of the counters and the striped sums are one PCIe store / one short loop per thread whatever
+// the number of tasks (with T + 1 threads a one-contig batch had two threads storing 30 words each, one after the other: 26 us
+// at the end of a 0.5-ms pass)
+SNF_HD int64_t tail_threads(const View& v) { return v.T + 1 > 128 ? (int64_t)v.T + 1 : 128; }
 SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
-  const int64_t lo = task_lower_bound(v, t);
-  v.t_call_off[t] = lo;
+  const int64_t lo = t <= v.T ? task_lower_bound(v, t) : 0;
+  if (t <= v.T) v.t_call_off[t] = lo;
   if (t < v.T) {
     const int64_t hi = task_lower_bound(v, t + 1);
     int64_t a = lo, b = hi;
@@ -487,7 +492,7 @@ SNF_HD void d3_taskoff_body(int64_t t, const View& v) {
   {  // the counters go to the pinned result block: the T + 1 threads of this launch share the words (one thread storing ~40 words over
      // PCIe one after the other was most of this kernel's 20 us, and the kernel sits on the critical path of the pass)
     const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
-    for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)v.T + 1) d[k] = s[k];
+    for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)tail_threads(v)) d[k] = s[k];
   }
 }
 
@@ -734,7 +739,7 @@ SNF_HD void z1_results_body(int64_t t, const View& v) {
   // striped byte counters of the ALT kernels (snf_wave_cons.h): class c summed by thread c % (T + 1), straight into the pinned copy
   // (the copy of the other counters below skips these four words)
   const size_t cb0 = offsetof(Counts, cons_bytes) / 8;
-  if (v.wave_path) for (int c = (int)t; c < 4; c += v.T + 1) {
+  if (v.wave_path) for (int c = (int)t; c < 4; c += (int)tail_threads(v)) {
     unsigned long long sum = 0;
     for (int k = 0; k < 64; k++) sum += v.stripes[(c * 64 + k) * 16];
     v.cnt->cons_bytes[c] = sum;
@@ -742,14 +747,14 @@ SNF_HD void z1_results_body(int64_t t, const View& v) {
   }
   // how many clusters / calls went to the one-wave-each kernels x_big<kind>: a handle whose pass found none skips those launches next time
   const size_t nb0 = offsetof(Counts, n_big) / 8;
-  if (v.wave_path) for (int c = (int)t; c < 3; c += v.T + 1) {
+  if (v.wave_path) for (int c = (int)t - 4; c >= 0 && c < 3; c += (int)tail_threads(v)) {   // (threads 4..6)
     long long sum = 0;
     for (int k = 0; k < 64; k++) sum += v.big_cnt[(c * 64 + k) * 16];
     v.cnt->n_big[c] = sum;
     ((long long*)v.res_cnt)[nb0 + c] = sum;
   }
   const unsigned long long* s = (const unsigned long long*)v.cnt; unsigned long long* d = (unsigned long long*)v.res_cnt;
-  for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)v.T + 1)
+  for (size_t k = (size_t)t; k < sizeof(Counts) / 8; k += (size_t)tail_threads(v))
     if (!(v.wave_path && ((k >= cb0 && k < cb0 + 4) || (k >= nb0 && k < nb0 + 3)))) d[k] = s[k];
 }
 

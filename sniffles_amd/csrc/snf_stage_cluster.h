@@ -203,12 +203,24 @@ SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean,
   int64_t sum = 0, cnt = 0;
   i128 S1 = 0; u128 S2 = 0;
   int64_t x0 = v.Lrec[lo].ref_start;
-  for (int64_t i = 0; i < len; i += step) {
-    const LeadRec& r = v.Lrec[lo + i];
-    sum += r.svlen;
-    int64_t d = (int64_t)r.ref_start - x0;
-    S1 += d; S2 += (u128)((i128)d * d);
-    cnt++;
+  // eight records requested before the first is used: called from the merge walk (one thread, a chain of dependent loads already)
+  // a loop that waits for every record costs a round trip per lead, and a merge re-reads every lead of the merged cluster
+  for (int64_t i = 0; i < len; i += 8 * step) {
+    int32_t sv[8], rs[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t q = i + u * step;
+      const LeadRec& r = v.Lrec[lo + (q < len ? q : i)];
+      sv[u] = r.svlen; rs[u] = r.ref_start;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (i + u * step >= len) break;
+      sum += sv[u];
+      int64_t d = (int64_t)rs[u] - x0;
+      S1 += d; S2 += (u128)((i128)d * d);
+      cnt++;
+    }
   }
   *mean = (double)sum / (double)n;
   *sd = stdev_from_sums(cnt, S1, S2);
@@ -283,52 +295,63 @@ SNF_HD bool merge_criterion(const View& v, int svtype, int64_t inner, int64_t ou
 // index rule `i = max(0, i-2) + 1` clamps at list index 0.  For a run that starts later the cluster
 // before s0 never merges with it (validated by c2_validate), so after a merge at the run's first
 // cluster the scan steps back to that boundary, fails, and returns: the position stays put.
+// The walk is a chain of dependent loads (thread per run; the longest run of a batch is the duration of c1_mergeruns): a node's
+// fields - its link included - are fetched together, one round trip, and a node that becomes the current one is carried over in
+// registers instead of being read again (the SoA form `nxt[cur]`, then the fields of that node, cost two round trips per step).
+struct MergeNode { int32_t start, end, nxt; double sd, mean; uint8_t rep; };
+SNF_HD MergeNode merge_node(const View& v, int32_t s) {
+  MergeNode n;
+  n.start = v.seed_start[s]; n.end = v.c_end[s]; n.nxt = v.nxt[s]; n.sd = v.c_stdev[s]; n.mean = v.c_mean[s]; n.rep = v.c_repeat[s];
+  return n;
+}
 SNF_HD void merge_walk(const View& v, int32_t s0, int32_t s_end, bool group_first, int64_t run) {
   int svtype = grp_svtype(v.seed_grp[s0]);
   int32_t cur = s0;
   int64_t idx = 0;
-  double b_sd = v.c_stdev[s0], b_am = fabs(v.c_mean[s0]);
-  uint8_t b_rep = v.c_repeat[s0];
+  MergeNode A = merge_node(v, s0);
+  double b_sd = A.sd, b_am = fabs(A.mean);
+  uint8_t b_rep = A.rep;
   for (;;) {
-    int32_t nx = v.nxt[cur];
+    const int32_t nx = A.nxt;
     if (nx < 0 || nx >= s_end) break;
-    int64_t inner = (int64_t)v.seed_start[nx] - v.c_end[cur];
-    int64_t outer = (int64_t)v.c_end[nx] - v.seed_start[cur];
-    bool merge = merge_criterion(v, svtype, inner, outer, v.c_stdev[cur], v.c_stdev[nx], v.c_mean[cur], v.c_mean[nx],
-                                 v.c_repeat[cur], v.c_repeat[nx]);
+    const MergeNode B = merge_node(v, nx);
+    int64_t inner = (int64_t)B.start - A.end;
+    int64_t outer = (int64_t)B.end - A.start;
+    bool merge = merge_criterion(v, svtype, inner, outer, A.sd, B.sd, A.mean, B.mean, A.rep, B.rep);
     if (merge) {
-      int32_t nn = v.nxt[nx];
-      v.c_last[cur] = v.c_last[nx];
-      v.c_end[cur] = v.c_end[nx];
-      v.c_repeat[cur] = v.c_repeat[cur] | v.c_repeat[nx];
-      v.nxt[cur] = nn;
+      int32_t nn = B.nxt;
+      const int32_t last = v.c_last[nx];
+      v.c_last[cur] = last;
+      v.c_end[cur] = B.end; A.end = B.end;
+      A.rep = A.rep | B.rep; v.c_repeat[cur] = A.rep;
+      v.nxt[cur] = nn; A.nxt = nn;
       if (nn >= 0) v.prv[nn] = cur;
       v.clflag[nx] = 0;
       double mean, sd;
-      compute_metrics(v, v.seed_lo[cur], v.seed_hi[v.c_last[cur]], &mean, &sd);
-      v.c_mean[cur] = mean; v.c_stdev[cur] = sd;
+      compute_metrics(v, v.seed_lo[cur], v.seed_hi[last], &mean, &sd);
+      v.c_mean[cur] = mean; v.c_stdev[cur] = sd; A.mean = mean; A.sd = sd;
       if (cur == s0) {
         if (sd > b_sd) b_sd = sd;
         if (fabs(mean) > b_am) b_am = fabs(mean);
-        b_rep |= v.c_repeat[cur];
+        b_rep |= A.rep;
       }
       if (group_first) {
         if (idx == 0) {          // i = max(0,-2)+1 = 1: the merged cluster 0 is not re-checked
-          int32_t n2 = v.nxt[cur];
+          int32_t n2 = A.nxt;
           if (n2 < 0 || n2 >= s_end) break;
-          cur = n2; idx = 1;
+          cur = n2; idx = 1; A = merge_node(v, cur);
         } else if (idx == 1) {   // i = max(0,-1)+1 = 1: stay
-        } else { cur = v.prv[cur]; idx--; }
+        } else { cur = v.prv[cur]; idx--; A = merge_node(v, cur); }
       } else {
-        if (cur != s0) cur = v.prv[cur];
+        if (cur != s0) { cur = v.prv[cur]; A = merge_node(v, cur); }
       }
     } else {
-      cur = nx; idx++;
+      cur = nx; idx++; A = B;
     }
   }
   if (run >= 0) {
-    int32_t last = cur;
-    for (;;) { int32_t nx = v.nxt[last]; if (nx < 0 || nx >= s_end) break; last = nx; }
+    int32_t last = cur, nx = A.nxt;     // (A is the node of `cur` wherever the walk stops)
+    while (!(nx < 0 || nx >= s_end)) { last = nx; nx = v.nxt[last]; }
     v.run_last_head[run] = last;
     v.run_b_stdev[run] = b_sd; v.run_b_absmean[run] = b_am; v.run_b_repeat[run] = b_rep;
   }
