@@ -695,7 +695,7 @@ def run_calling(ctx):
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
-                        kernel_ms_source="mean HIP-event duration of the kernel's launches on its own stream over the timed passes of handle 0 (batches in flight as configured); "
+                        kernel_ms_source="mean HIP-event duration of the kernel's launches (events on the stream it is launched on) over the timed passes of handle 0 (batches in flight as configured); "
                                          "the LARGE consensus kernel is bracketed on every pass, the other kernels on every 8th pass of the handle (snf_batch_timing_every)",
                         rocprof_ms=(round(rocprof_ms, 4) if rocprof_ms else None),
                         rocprof_frac=(round(top[2] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if rocprof_ms else None),

@@ -445,8 +445,8 @@ int snf_batch_fetch_clusters(snf_batch_t* b, int stage, snf_clusters_t* out);
  * last call_candidates+finalize pass). names[i] points to a static string.
  * The brackets are recorded on every n-th pass of a handle (default 8, the first pass included; snf_batch_timing_every(b, 1):
  * every pass, 0: none): two event records per launch keep a stream from issuing its launches back to back, which costs a
- * whole-genome pass 3-6 %.  The one kernel bench.py states the roofline on (the LARGE consensus class, on a stream of its
- * own) is bracketed on every pass.  A pass that was not sampled reports only that kernel. */
+ * whole-genome pass 3-6 %.  The one kernel bench.py states the roofline on (the LARGE consensus class, the last kernel
+ * of its stream) is bracketed on every pass.  A pass that was not sampled reports only that kernel. */
 int snf_batch_timing_every(snf_batch_t* b, int n);
 int snf_batch_timing_count(snf_batch_t* b);
 int snf_batch_timing_get(snf_batch_t* b, int i, const char** name, float* ms, int64_t* algo_bytes);

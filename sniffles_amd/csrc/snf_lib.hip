@@ -253,7 +253,7 @@ struct snf_batch_impl {
   int device = 0;
   hipStream_t stream = nullptr;   // main stream (also the one fetch/sync wait on)
   hipStream_t stream2 = nullptr;  // side stream: read preparation, finalize scalar kernels
-  hipStream_t stream3 = nullptr;  // third stream: the LARGE consensus class next to the SMALL one
+  hipStream_t stream3 = nullptr;  // third stream: the SMALL consensus class and the verbatim copies next to the LARGE class
   bool stream3_high = false;      // ... created with the device's highest stream priority
   hipStream_t stream4 = nullptr;  // fourth stream: sv ids + supporting read names and their D2H copy (off the coverage / QC chain)
   hipStream_t cur = nullptr;      // stream the LAUNCH / prim_* helpers enqueue on
@@ -291,7 +291,6 @@ struct snf_batch_impl {
                                   // this process has a pass in flight
   bool in_flight = false;         // counted in g_passes_in_flight
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
-  int graph_eager_every = 8;      // with per-kernel timing on, every n-th pass of a configuration runs eagerly so that the HIP-event means keep coming (0: never)
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
@@ -1513,15 +1512,15 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
   SNF_TRACE("E4/E5: INS consensus (SMALL / LARGE / verbatim)");
   View& v = b->v;
   const bool serial = getenv("SNF_SERIAL") != nullptr;  // dev: every ALT kernel alone on the device (isolated timings)
-  // Order of the two consensus classes.  0: LARGE on its own stream NEXT TO SMALL - alone on the device SMALL fills the tail of
-  // LARGE's unequal calls (one batch in flight: 1.466 ms per step against 1.494 for order 2).  2: LARGE BEHIND SMALL (its stream
-  // waits for SMALL) - next to each other a LARGE workgroup (71 KB of LDS, 4 x 256 VGPRs on one CU at once) only finds room when
-  // SMALL's queue of one-wave workgroups runs dry: LARGE spans 0.51 ms in place against 0.22 behind SMALL (SMALL: 0.27 / 0.17), and
-  // with a second pass in flight that pass fills the tails instead (two in flight: 1.238 against 1.242).  So: 2 when another pass is
-  // in flight on the device, 0 otherwise; SNF_CONS_ORDER forces one (1 = SMALL behind LARGE on LARGE's stream: slower than both).
-  static const int order_env = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : -1;
+  // Order of the two consensus classes.  0: LARGE (main stream) NEXT TO SMALL (third stream) - alone on the device SMALL fills the
+  // tail of LARGE's unequal calls (one batch in flight: 1.466 ms per step against 1.494 for order 2).  2: LARGE BEHIND SMALL on one
+  // stream - next to each other a LARGE workgroup (70 KB of LDS, 4 x 256 VGPRs on one CU at once) only finds room when SMALL's queue
+  // of one-wave workgroups runs dry: LARGE spans 0.51 ms in place against 0.22 behind SMALL (SMALL: 0.27 / 0.17), and with a second
+  // pass in flight that pass fills the tails instead (two in flight: 1.238 against 1.242).  So: 2 when another pass is in flight on
+  // the device, 0 otherwise; SNF_CONS_ORDER forces one (1 = SMALL behind LARGE: slower than both).
+  const int order_env = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : -1;
   const int order = order_env >= 0 ? order_env : (g_passes_in_flight.load() > 1 ? 2 : 0);
-  auto launch_large = [&]() {   // (on b->cur = stream3)
+  auto launch_large = [&]() {
     Scope _s(b, "e45w_consensus_large", 0, true);
     const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
     if (b->cons_large_nw == 16) hipLaunchKernelGGL((K_CONS_LARGE_16W), gl, dim3(1024), 0, b->cur, v, (int64_t)0);
@@ -1544,25 +1543,24 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
     SNF_HIP(hipGetLastError());
   };
   auto on_stream3 = [&](auto&& f) { hipStream_t prev = b->cur; b->cur = b->stream3; f(); b->cur = prev; };
+  // LARGE - the longer chain - stays on the main stream, right behind the kernel that built its work lists: a kernel behind a
+  // cross-stream event starts 30-45 us after the event's kernel has ended, one on the same stream 5 us after
   if (serial) SNF_HIP(hipDeviceSynchronize());
-  if (order == 2) {
+  if (order == 2) {            // one stream: verbatim copies, SMALL, LARGE
+    launch_copy();
     launch_small();
-    SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
-    SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
-    on_stream3(launch_large);
-    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
-    launch_copy();
-  } else {
-    // the LARGE class is independent of the others: its own stream, joined before the ALT bytes are copied out
-    SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
-    SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
-    on_stream3(launch_large);
-    if (order == 1) on_stream3(launch_small);
     if (serial) SNF_HIP(hipDeviceSynchronize());
-    SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
-    launch_copy();
-    if (order != 1) launch_small();
+    launch_large();
+    return;
   }
+  SNF_HIP(hipEventRecord(b->ev_fork3, b->stream));
+  SNF_HIP(hipStreamWaitEvent(b->stream3, b->ev_fork3, 0));
+  launch_large();
+  if (serial) SNF_HIP(hipDeviceSynchronize());
+  if (order == 1) launch_small();
+  on_stream3(launch_copy);
+  if (order != 1) on_stream3(launch_small);
+  SNF_HIP(hipEventRecord(b->ev_join3, b->stream3));
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
@@ -1703,7 +1701,9 @@ void run_pass(snf_batch_impl* b) {
     (void)hipGraphExecDestroy(g.exec); (void)hipGraphDestroy(g.graph); g = snf_batch_impl::PassGraph{};
   }
   g.passes++;
-  if (g.exec && !(b->timing && b->graph_eager_every > 0 && g.passes % b->graph_eager_every == 0)) {
+  // (a pass that carries the event brackets - every time_every-th of the handle - runs eagerly: a replayed graph has no events)
+  const bool sampled = b->timing && (b->time_all || b->time_every == 1 || (b->time_every > 1 && b->pass_count % (uint64_t)b->time_every == 0));
+  if (g.exec && !sampled) {
     b->pass_idle = false;
     reset_timing(b); b->pass_count++;
     SNF_HIP(hipGraphLaunch(g.exec, b->stream));
@@ -2433,7 +2433,6 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     }
     b->timing = getenv("SNF_NO_TIMING") == nullptr;
     b->timeline = getenv("SNF_TIMELINE") != nullptr;
-    if (const char* e = getenv("SNF_GRAPH_EAGER_EVERY")) b->graph_eager_every = atoi(e);
     if (const char* e = getenv("SNF_TIME_EVERY")) b->time_every = atoi(e) < 0 ? 0 : atoi(e);
     b->time_all = getenv("SNF_TIME_ALL") != nullptr || b->timeline;
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);

@@ -136,6 +136,76 @@ def test_gap_bytes_other_anchor_steps_and_oversize_problems_match_the_reference_
     _check_generic(monkeypatch, None)
 
 
+# The workgroup kernels over the sampling steps they can meet (skip == skip_repetitive, no gap bytes): skip 1-2 probe more than five
+# positions per k-mer (the loop form), 3-7 the unrolled form, >= 8 sends even a short call to the LARGE class (a step's bytes no longer
+# fit the k-mer word) and >= 16 needs the third register word; k-mer lengths 4-7; calls with more than 64 other reads.
+def _wave_class_problems(seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for k in range(96):
+        L = int(rng.integers(20, 385)) if k % 3 == 0 else int(rng.integers(385, 1500)) if k % 3 == 1 else int(rng.integers(1500, 7000))
+        if k % 16 == 15 or k % 32 == 14:
+            L = int(rng.integers(40, 300))
+        truth = rng.choice(acgt, L)
+
+        def noisy(err):
+            o = truth.copy()
+            hit = rng.random(L) < err
+            o[hit] = rng.choice(acgt, int(hit.sum()))
+            for _ in range(int(rng.integers(0, 3))):     # indels: the anchors leave the diagonal for a while
+                c = int(rng.integers(0, len(o)))
+                o = np.concatenate([o[:c], rng.choice(acgt, int(rng.integers(1, 12))), o[c:]]) if rng.random() < 0.5 \
+                    else np.concatenate([o[:c], o[min(len(o), c + int(rng.integers(1, 12))):]])
+            if rng.random() < 0.1:
+                o[int(rng.integers(0, len(o)))] = ord("N")                     # a byte outside A/C/G/T: the vote's escape list
+            return o.tobytes().decode()
+        klen = int(rng.integers(4, 8))
+        smin = max(1, -(-(L - klen) // 500))              # at most 500 sampled positions: the workgroup kernels' limit
+        if L <= 384 and k % 4:
+            skip = int(rng.integers(smin, 8))             # SMALL when the call has at most 120 positions, else LARGE
+        else:
+            skip = max(smin, int(rng.choice([1, 2, 3, 5, 7, 8, 9, 15, 16, 17, 23]))) if k % 2 else smin + int(rng.integers(0, 10))
+        n_others = int(rng.integers(65, 90)) if k % 16 == 15 else int(rng.integers(255, 270)) if k % 32 == 14 else int(rng.integers(0, 18))
+        out.append(dict(best=noisy(0.04), others=[noisy(float(rng.choice([0.02, 0.06, 0.3]))) for _ in range(n_others)],
+                        klen=klen, skip=skip, skip_rep=skip))
+    return out
+
+
+def _check_wave_classes(monkeypatch, load):
+    import ref_harness as rh
+    from sniffles_amd import consensus
+    if load is not None:
+        monkeypatch.setattr(consensus._lib, "load", load)
+    ref = rh.load_reference()
+
+    class Lead:
+        def __init__(self, seq):
+            self.seq = seq
+    probs = _wave_class_problems(29)
+    exp = [ref.consensus.novel_from_reads(Lead(p["best"]), [Lead(o) for o in p["others"]], p["klen"], p["skip"], p["skip_rep"]) for p in probs]
+    assert sum(e != p["best"] for e, p in zip(exp, probs)) >= 25
+    by_klen = {}
+    for i, p in enumerate(probs):
+        by_klen.setdefault(p["klen"], []).append(i)
+    for klen, idx in by_klen.items():
+        got = consensus.novel_from_reads_batch([(probs[i]["best"], probs[i]["others"], probs[i]["skip"], probs[i]["skip_rep"]) for i in idx], klen=klen)
+        assert [(i, probs[i]["skip"], len(probs[i]["best"])) for i, g in zip(idx, got) if g != exp[i]] == []
+
+
+@needs_ref
+def test_workgroup_kernels_over_sampling_steps_and_kmer_lengths_match_the_reference_emu(monkeypatch):
+    import emu.emu as E
+    _check_wave_classes(monkeypatch, E.lib)
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_workgroup_kernels_over_sampling_steps_and_kmer_lengths_match_the_reference_gpu(monkeypatch):
+    _check_wave_classes(monkeypatch, None)
+
+
 def _check_pipeline_with_gap_bytes(L, oracle_mod):
     """INS sequences that hold the byte '-' inside a whole task (Lead objects built by hand can; BAM records cannot): the batch takes
     the literal thread kernels for every consensus call (View::cons_thread_only) and equals the unmodified reference - and the C

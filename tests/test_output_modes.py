@@ -236,3 +236,62 @@ def test_deferred_read_names_simt():
 @pytest.mark.gpu
 def test_deferred_read_names_gpu():
     check_deferred_names(None)
+
+
+def check_timing_is_sampled():
+    """`snf_batch_timing_every`: the HIP-event brackets ride on every n-th pass of a handle (the first one included), the LARGE
+    consensus kernel - the one bench.py states the roofline on - on every pass; a pass that was not sampled reports nothing else."""
+    from sniffles_amd import lib, synth
+    from sniffles_amd.config import SnifflesConfig
+    ti = synth.gen_task(0, "chr21", 1_500_000, 30, 5)
+    with lib.Batch(SnifflesConfig(), [ti]) as b:
+        seen = []
+        for _ in range(10):
+            b.run_pass(); b.fetch(1)
+            seen.append({n for n, _, _ in b.timings()})
+        assert len(seen[0]) > 5 and len(seen[8]) > 5 and "e45w_consensus_small" in seen[8], (seen[0], seen[8])   # passes 0 and 8: every bracket
+        for k in (1, 2, 7, 9):
+            assert seen[k] <= {"e45w_consensus_large"}, (k, seen[k])
+        b.timing_every(1)
+        b.run_pass(); b.fetch(1)
+        assert {n for n, _, _ in b.timings()} == seen[8]
+        b.timing_every(0)
+        b.run_pass(); b.fetch(1)
+        assert {n for n, _, _ in b.timings()} <= {"e45w_consensus_large"}
+
+
+def test_kernel_timing_is_sampled_emu():
+    import emu.emu as E
+    E.lib()
+    check_timing_is_sampled()
+
+
+@pytest.mark.gpu
+def test_kernel_timing_is_sampled_gpu():
+    check_timing_is_sampled()
+
+
+def check_consensus_class_order(oracle_mod, monkeypatch):
+    """The two consensus classes side by side, SMALL behind LARGE, LARGE behind SMALL (what the library picks when another pass
+    is in flight): the same records."""
+    from sniffles_amd import lib, records, synth
+    from sniffles_amd.config import SnifflesConfig
+    tis = [synth.gen_task(0, "chr21", 2_500_000, 30, 11), synth.gen_fuzz(5, task_id=1)]
+    cfg = SnifflesConfig()
+    exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    for order in ("0", "1", "2"):
+        monkeypatch.setenv("SNF_CONS_ORDER", order)
+        with lib.Batch(cfg, tis) as b:
+            b.run_pass()
+            assert records.records(b.fetch(1), tis, "final") == exp, order
+
+
+def test_consensus_class_order_emu(oracle_mod, monkeypatch):
+    import emu.emu as E
+    E.lib()
+    check_consensus_class_order(oracle_mod, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_consensus_class_order_gpu(oracle_mod, monkeypatch):
+    check_consensus_class_order(oracle_mod, monkeypatch)
