@@ -17,17 +17,31 @@ SNF_HD int bitlen128(u128 x) {
   return 0;
 }
 
-// quotient and remainder of a 128-bit numerator by a 64-bit denominator (schoolbook, bitwise)
+// quotient and remainder of a 128-bit numerator by a 64-bit denominator, the quotient below 2^63 (ratio_to_double asks for 55-56 bits).
+// A double-precision quotient is off by a few units at most; the remainder it leaves is formed exactly in 128-bit integers and a
+// second estimate plus at most a few unit steps settle it - the result is exact whatever the floating-point division rounds to
+// (host tier and GPU agree by construction).  The bitwise schoolbook loop this replaces ran ~3 000 dependent instructions per
+// division; a lone wave doing four of them in a row was the duration of c1_mergeruns.
 SNF_HD void udivmod128_64(u128 num, uint64_t den, u128* q, uint64_t* r) {
-  u128 rem = 0, quo = 0;
-  int n = bitlen128(num);
-  for (int b = n - 1; b >= 0; b--) {
-    rem = (rem << 1) | ((num >> b) & 1);
-    if (rem >= den) {
-      rem -= den;
-      quo |= ((u128)1) << b;
-    }
+  const double dd = (double)den;
+  const double dn = (double)(uint64_t)(num >> 64) * 18446744073709551616.0 + (double)(uint64_t)num;
+  double e = dn / dd;
+  if (e < 0.0) e = 0.0;
+  if (e > 9223372036854775807.0) e = 9223372036854775807.0;
+  uint64_t quo = (uint64_t)e;
+  i128 rem = (i128)num - (i128)((u128)quo * den);       // |rem| is a small multiple of den: exact in 128 bits
+  for (int it = 0; it < 2; it++) {                      // the estimate of what is left (each pass gains ~50 bits)
+    const bool neg = rem < 0;
+    const u128 mag = neg ? (u128)(-rem) : (u128)rem;
+    if (!neg && mag < den) break;
+    const double dm = (double)(uint64_t)(mag >> 64) * 18446744073709551616.0 + (double)(uint64_t)mag;
+    double c = dm / dd;
+    if (c > 9.0e18) c = 9.0e18;
+    const uint64_t dq = (uint64_t)c;
+    if (neg) { quo -= dq; rem += (i128)((u128)dq * den); } else { quo += dq; rem -= (i128)((u128)dq * den); }
   }
+  while (rem < 0) { quo--; rem += den; }
+  while (rem >= (i128)den) { quo++; rem -= den; }
   *q = quo;
   *r = (uint64_t)rem;
 }

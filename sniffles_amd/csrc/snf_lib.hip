@@ -965,6 +965,7 @@ void do_upload(snf_batch_impl* b) {
   for (auto pp : f64s) *pp = dalloc<double>(b, N1);
   uint8_t** u8s[] = {&v.s_repeat0, &v.c_repeat, &v.run_b_repeat, &v.F_sel, &v.rc_keeplong_s, &v.rc_keeplong};
   for (auto pp : u8s) *pp = dalloc<uint8_t>(b, N1);
+  v.c_ms = dalloc<ClusterSums>(b, N1);
   v.grp_dirty = dalloc<int32_t>(b, 8 * (size_t)T + 8); v.grp_seed_lo = dalloc<int32_t>(b, 8 * (size_t)T + 8);
   v.grp_seed_hi = dalloc<int32_t>(b, 8 * (size_t)T + 8);
   v.F_seq_off = dalloc<int64_t>(b, N1);
@@ -1784,6 +1785,11 @@ void collect_timings(snf_batch_impl* b) {
       fprintf(stderr, "\n");
     }
   }
+#endif
+#ifdef SNF_C1_PROFILE
+  if (getenv("SNF_PROF")) { const unsigned long long* c = b->h_cnt->c1p; const double w = (double)(c[8] ? c[8] : 1);
+    fprintf(stderr, "[SNF_C1_PROFILE] c1_mergeruns, mean us per wave (%llu waves): first node %.2f | next node %.2f criterion %.2f | merge: stores %.2f metrics %.2f movement %.2f | loop exit %.2f tail %.2f; longest wave %.1f us\n",
+            c[8], c[0] * 0.01 / w, c[1] * 0.01 / w, c[2] * 0.01 / w, c[3] * 0.01 / w, c[4] * 0.01 / w, c[5] * 0.01 / w, c[6] * 0.01 / w, c[7] * 0.01 / w, c[9] * 0.01); }
 #endif
 #ifdef SNF_CONS_PROFILE
   if (getenv("SNF_PROF")) {

@@ -194,36 +194,61 @@ SNF_HD void a7_seeds_body(int64_t b, const View& v) {
 // ------------------------------------------------------------------------------------------ stage B
 // Cluster.compute_metrics over L[lo,hi) (cluster.py:48-61): n = min(len,100) samples every int(len/n),
 // mean divides by n (not the sample count), stdev = statistics.stdev of the sampled ref_starts
-SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean, double* sd) {
+// sums of compute_metrics in 128-bit integers (positions further apart than 2^27: never inside one contig's cluster in practice)
+SNF_HD void compute_metrics_wide(const View& v, int32_t lo, int64_t len, int64_t step, i128* S1, u128* S2) {
+  const int64_t x0 = v.Lrec[lo].ref_start;
+  i128 a = 0; u128 b = 0;
+  for (int64_t i = 0; i < len; i += step) {
+    const int64_t d = (int64_t)v.Lrec[lo + i].ref_start - x0;
+    a += d; b += (u128)((i128)d * d);
+  }
+  *S1 = a; *S2 = b;
+}
+SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean, double* sd, ClusterSums* out = nullptr) {
   int64_t len = hi - lo;
   int64_t n = len < 100 ? len : 100;
+  if (out) { out->sum = 0; out->s1 = 0; out->s2 = ~0ull; out->x0 = 0; out->hi = hi; }
   if (n == 0) { *mean = 0; *sd = 0; return; }
-  if (n == 1) { *mean = (double)v.Lrec[lo].svlen; *sd = 0; return; }
+  if (n == 1) {
+    const LeadRec& r = v.Lrec[lo];
+    *mean = (double)r.svlen; *sd = 0;
+    if (out) { out->sum = r.svlen; out->s2 = 0; out->x0 = r.ref_start; }
+    return;
+  }
   int64_t step = len / n;
   int64_t sum = 0, cnt = 0;
-  i128 S1 = 0; u128 S2 = 0;
-  int64_t x0 = v.Lrec[lo].ref_start;
-  // eight records requested before the first is used: called from the merge walk (one thread, a chain of dependent loads already)
-  // a loop that waits for every record costs a round trip per lead, and a merge re-reads every lead of the merged cluster
-  for (int64_t i = 0; i < len; i += 8 * step) {
-    int32_t sv[8], rs[8];
+  // The sums of the (at most 199) sampled deviations d = ref_start - x0 and of their squares stay in 64 bits while |d| < 2^27
+  // (d^2 < 2^54): 128-bit arithmetic per element cost ~15 instructions, and c1_mergeruns executes this loop for a whole wave
+  // whenever one of its 64 runs merges (a lone wave, every instruction at full latency: the loop was most of that kernel).
+  int64_t S1 = 0; uint64_t S2 = 0, wide = 0;
+  int64_t x0 = 0;     // (the first record's ref_start: arrives with the first batch)
+  // MCH records are requested before the first is used (a loop that waits for every record costs a round trip per lead)
+  constexpr int MCH = 32;
+  for (int64_t i = 0; i < len; i += MCH * step) {
+    int32_t sv[MCH], rs[MCH];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < MCH; u++) {
       const int64_t q = i + u * step;
       const LeadRec& r = v.Lrec[lo + (q < len ? q : i)];
       sv[u] = r.svlen; rs[u] = r.ref_start;
     }
+    if (i == 0) x0 = rs[0];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
+    for (int u = 0; u < MCH; u++) {
       if (i + u * step >= len) break;
       sum += sv[u];
-      int64_t d = (int64_t)rs[u] - x0;
-      S1 += d; S2 += (u128)((i128)d * d);
+      const int64_t d = (int64_t)rs[u] - x0;
+      S1 += d; S2 += (uint64_t)(d * d);
+      wide |= (uint64_t)(d < 0 ? -d : d) >> 27;
       cnt++;
     }
   }
   *mean = (double)sum / (double)n;
-  *sd = stdev_from_sums(cnt, S1, S2);
+  if (out && step == 1 && !wide) { out->sum = sum; out->s1 = S1; out->s2 = S2; out->x0 = (int32_t)x0; }     // (every lead was read: the sums add up under merges)
+  if (!wide) { *sd = stdev_from_sums(cnt, (i128)S1, (u128)S2); return; }
+  i128 W1; u128 W2;
+  compute_metrics_wide(v, lo, len, step, &W1, &W2);
+  *sd = stdev_from_sums(cnt, W1, W2);
 }
 
 SNF_HD bool seed_first_of_group(const View& v, int64_t s) { return s == 0 || v.seed_grp[s - 1] != v.seed_grp[s]; }
@@ -232,7 +257,9 @@ SNF_HD void b1_seedmetrics_body(int64_t s, const View& v) {
   if (s == 0) v.runflag[v.NS] = 0;
   if (s >= v.cnt->n_seeds) { v.runflag[s] = 0; v.clflag[s] = 0; return; }
   double mean, sd;
-  compute_metrics(v, v.seed_lo[s], v.seed_hi[s], &mean, &sd);
+  ClusterSums cs;
+  compute_metrics(v, v.seed_lo[s], v.seed_hi[s], &mean, &sd, &cs);
+  v.c_ms[s] = cs;
   int g = v.seed_grp[s], t = grp_task(g);
   int32_t seed = v.seed_start[s];
   bool within_tr = false;
@@ -268,6 +295,9 @@ SNF_HD void b2_emit(int64_t s, const View& v) {
   if (s < v.cnt->n_seeds && v.runflag[s]) v.run_first[v.runscan[s]] = (int32_t)s;
 }
 SNF_HD void b2_runs_body(int64_t s, const View& v) {
+#ifdef SNF_C1_PROFILE
+  if (s == 0) for (int k = 0; k < 16; k++) v.cnt->c1p[k] = 0;
+#endif
   if (s == 0) {
     int64_t nr = v.runscan[v.NS];
     v.cnt->n_runs = nr;
@@ -298,37 +328,74 @@ SNF_HD bool merge_criterion(const View& v, int svtype, int64_t inner, int64_t ou
 // The walk is a chain of dependent loads (thread per run; the longest run of a batch is the duration of c1_mergeruns): a node's
 // fields - its link included - are fetched together, one round trip, and a node that becomes the current one is carried over in
 // registers instead of being read again (the SoA form `nxt[cur]`, then the fields of that node, cost two round trips per step).
-struct MergeNode { int32_t start, end, nxt; double sd, mean; uint8_t rep; };
+struct MergeNode { int32_t start, end, nxt, prv, last, lo; double sd, mean; uint8_t rep; ClusterSums cs; };
 SNF_HD MergeNode merge_node(const View& v, int32_t s) {
   MergeNode n;
-  n.start = v.seed_start[s]; n.end = v.c_end[s]; n.nxt = v.nxt[s]; n.sd = v.c_stdev[s]; n.mean = v.c_mean[s]; n.rep = v.c_repeat[s];
+  n.start = v.seed_start[s]; n.end = v.c_end[s]; n.nxt = v.nxt[s]; n.prv = v.prv[s]; n.last = v.c_last[s]; n.lo = v.seed_lo[s];
+  n.sd = v.c_stdev[s]; n.mean = v.c_mean[s]; n.rep = v.c_repeat[s]; n.cs = v.c_ms[s];
   return n;
 }
+#if defined(SNF_C1_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define C1P_DECL unsigned long long c1t = wall_clock64(), c1a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define C1P(k) do { const unsigned long long n_ = wall_clock64(); c1a[k] += n_ - c1t; c1t = n_; } while (0)
+#define C1P_FLUSH() do { if ((threadIdx.x & 63) == __builtin_ctzll(__ballot(1))) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&v.cnt->c1p[k_], c1a[k_]); atomicAdd(&v.cnt->c1p[8], 1ull); \
+    unsigned long long tot_ = 0; for (int k_ = 0; k_ < 8; k_++) tot_ += c1a[k_]; atomicMax(&v.cnt->c1p[9], tot_); } } while (0)
+#else
+#define C1P_DECL
+#define C1P(k) do { } while (0)
+#define C1P_FLUSH() do { } while (0)
+#endif
 SNF_HD void merge_walk(const View& v, int32_t s0, int32_t s_end, bool group_first, int64_t run) {
+  C1P_DECL
   int svtype = grp_svtype(v.seed_grp[s0]);
   int32_t cur = s0;
   int64_t idx = 0;
   MergeNode A = merge_node(v, s0);
   double b_sd = A.sd, b_am = fabs(A.mean);
   uint8_t b_rep = A.rep;
+  C1P(0);   // group + first node
   for (;;) {
     const int32_t nx = A.nxt;
     if (nx < 0 || nx >= s_end) break;
     const MergeNode B = merge_node(v, nx);
+    C1P(1);   // next node
     int64_t inner = (int64_t)B.start - A.end;
     int64_t outer = (int64_t)B.end - A.start;
     bool merge = merge_criterion(v, svtype, inner, outer, A.sd, B.sd, A.mean, B.mean, A.rep, B.rep);
+    C1P(2);   // criterion
     if (merge) {
       int32_t nn = B.nxt;
-      const int32_t last = v.c_last[nx];
-      v.c_last[cur] = last;
+      const int32_t last = B.last;
+      v.c_last[cur] = last; A.last = last;
       v.c_end[cur] = B.end; A.end = B.end;
       A.rep = A.rep | B.rep; v.c_repeat[cur] = A.rep;
       v.nxt[cur] = nn; A.nxt = nn;
       if (nn >= 0) v.prv[nn] = cur;
       v.clflag[nx] = 0;
       double mean, sd;
-      compute_metrics(v, v.seed_lo[cur], v.seed_hi[last], &mean, &sd);
+      C1P(3);   // merge: stores
+      // metrics of the merged cluster (cluster.py:300: compute_metrics over its leads).  Below 200 leads the reference reads EVERY
+      // lead (step = len // min(len, 100) = 1), so the sums of the two parts add up - the part that joins re-based from its own
+      // first position to this cluster's (exact integer arithmetic) - and no lead is read again; otherwise the leads are read
+      const int32_t hi = B.cs.hi;
+      const int64_t Lm = (int64_t)hi - A.lo;
+      bool added = false;
+      if (Lm < 200 && A.cs.s2 != ~0ull && B.cs.s2 != ~0ull && A.cs.hi == B.lo) {
+        const int64_t nb = (int64_t)hi - B.lo, dx = (int64_t)B.cs.x0 - A.cs.x0;
+        const i128 S1m = (i128)A.cs.s1 + B.cs.s1 + (i128)nb * dx;
+        const i128 S2m = (i128)A.cs.s2 + (i128)B.cs.s2 + (i128)2 * dx * B.cs.s1 + (i128)nb * dx * dx;
+        const int64_t sum = A.cs.sum + B.cs.sum;
+        const int64_t nn_ = Lm < 100 ? Lm : 100;
+        mean = (double)sum / (double)nn_;
+        sd = stdev_from_sums(Lm, S1m, (u128)S2m);
+        const bool fits = S2m < ((i128)1 << 62) && S1m < ((i128)1 << 62) && S1m > -((i128)1 << 62);
+        A.cs.sum = sum; A.cs.s1 = (int64_t)S1m; A.cs.s2 = fits ? (uint64_t)S2m : ~0ull;
+        added = true;
+      }
+      if (!added) { compute_metrics(v, A.lo, hi, &mean, &sd); A.cs.s2 = ~0ull; }
+      A.cs.hi = hi;
+      v.c_ms[cur] = A.cs;
+      C1P(4);   // merge: metrics
       v.c_mean[cur] = mean; v.c_stdev[cur] = sd; A.mean = mean; A.sd = sd;
       if (cur == s0) {
         if (sd > b_sd) b_sd = sd;
@@ -341,20 +408,24 @@ SNF_HD void merge_walk(const View& v, int32_t s0, int32_t s_end, bool group_firs
           if (n2 < 0 || n2 >= s_end) break;
           cur = n2; idx = 1; A = merge_node(v, cur);
         } else if (idx == 1) {   // i = max(0,-1)+1 = 1: stay
-        } else { cur = v.prv[cur]; idx--; A = merge_node(v, cur); }
+        } else { cur = A.prv; idx--; A = merge_node(v, cur); }
       } else {
-        if (cur != s0) { cur = v.prv[cur]; A = merge_node(v, cur); }
+        if (cur != s0) { cur = A.prv; A = merge_node(v, cur); }
       }
+      C1P(5);   // merge: movement
     } else {
       cur = nx; idx++; A = B;
     }
   }
+  C1P(6);
   if (run >= 0) {
     int32_t last = cur, nx = A.nxt;     // (A is the node of `cur` wherever the walk stops)
     while (!(nx < 0 || nx >= s_end)) { last = nx; nx = v.nxt[last]; }
     v.run_last_head[run] = last;
     v.run_b_stdev[run] = b_sd; v.run_b_absmean[run] = b_am; v.run_b_repeat[run] = b_rep;
   }
+  C1P(7);   // tail
+  C1P_FLUSH();
 }
 
 SNF_HD void c1_mergeruns_body(int64_t r, const View& v) {
@@ -386,6 +457,7 @@ SNF_HD void c3_serial_body(int64_t g, const View& v) {
   for (int32_t s = lo; s < hi; s++) {
     v.c_mean[s] = v.s_mean0[s]; v.c_stdev[s] = v.s_stdev0[s]; v.c_repeat[s] = v.s_repeat0[s];
     v.c_last[s] = s; v.c_end[s] = v.seed_start[s] + v.cfg.cluster_binsize;
+    { ClusterSums cs = v.c_ms[s]; cs.s2 = ~0ull; cs.hi = v.seed_hi[s]; v.c_ms[s] = cs; }     // (the serial redo reads the leads at every merge)
     v.prv[s] = s == lo ? -1 : s - 1; v.nxt[s] = s + 1 == hi ? -1 : s + 1;
     v.clflag[s] = 1;
   }

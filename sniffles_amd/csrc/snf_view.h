@@ -29,6 +29,9 @@ struct Counts {
 #ifdef SNF_CONS_PROFILE
   unsigned long long dbg[32];       // instrumented build only: cycles per phase of the consensus kernels (tools/cons_profile.sh)
 #endif
+#ifdef SNF_C1_PROFILE
+  unsigned long long c1p[16];       // instrumented build only: phases of c1_mergeruns (100-MHz ticks summed over the waves' first lanes)
+#endif
   int32_t overflow;  // scratch overflow flags
   int32_t alt_in_pinned;     // this pass's ALT bytes go straight to the pinned buffer (View::alt_pin) instead of the HBM pool: decided once the total is known (e3)
 };
@@ -103,6 +106,11 @@ struct CallX {  // per-call internals that are not part of snf_call_t
   int32_t _pad;
   double ag_nm_mean;
 };
+
+// Sums of compute_metrics over ALL leads of a cluster (kept while the cluster has fewer than 200 leads - the reference then samples
+// every lead - and the sums fit 63 bits): sum of svlen, sum / sum of squares of ref_start - x0, x0 = ref_start of the cluster's first
+// lead, hi = end of its lead range.  s2 == ~0: not kept, a merge reads the leads.
+struct ClusterSums { int64_t sum, s1; uint64_t s2; int32_t x0, hi; };
 
 struct View {
   snf_config_t cfg;
@@ -223,6 +231,7 @@ struct View {
   double *s_mean0, *s_stdev0; uint8_t* s_repeat0;     // seed metrics (kept for the serial fallback)
   double *c_mean, *c_stdev; uint8_t* c_repeat;        // live cluster metrics at head seeds
   int32_t *c_last, *c_end, *nxt, *prv;
+  ClusterSums* c_ms;         // [N] at head seeds: the sums behind c_mean / c_stdev, so that a merge adds them instead of reading the leads again
   int32_t *run_first;        // [N+1]
   int32_t *run_last_head;    // [N]
   double *run_b_stdev, *run_b_absmean; uint8_t* run_b_repeat;

@@ -50,3 +50,19 @@ def test_cluster_views_match_reference_emu(name):
 @pytest.mark.parametrize("name", NAMES)
 def test_cluster_views_match_reference_gpu(name):
     run_case(name)
+
+
+def test_cluster_metrics_with_positions_far_apart_emu(oracle_mod):
+    """compute_metrics keeps its sums in 64 bits while the sampled positions of a bin lie within 2^27 bp of the first one and
+    falls back to 128-bit sums otherwise: a bin size larger than the contig puts leads 200 Mb apart into one bin."""
+    import emu.emu as E
+    from sniffles_amd import lib, records, synth
+    from sniffles_amd.config import SnifflesConfig
+    E.lib()
+    ti = synth.gen_task(0, "chr1", 248_956_422, 1, 3)
+    cfg = SnifflesConfig(cluster_binsize=300_000_000)
+    exp = records.records(oracle_mod.run(cfg, [ti], False), [ti], "cand")
+    with lib.Batch(cfg, [ti]) as b:
+        b.call_candidates()
+        assert records.records(b.fetch(0), [ti], "cand") == exp
+    assert int(ti.leads["ref_start"].max()) - int(ti.leads["ref_start"].min()) > (1 << 27) and len(exp[0]) > 0

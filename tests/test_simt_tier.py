@@ -48,6 +48,14 @@ def test_shim_models_the_cross_lane_operations(simt):
     assert out[8] == 1 and out[9] == 64                  # one word incremented by 64 lanes: lock step 1, fibres 64
 
 
+def test_exact_division_matches_the_host_compilers(simt):
+    """snf_exact.h::udivmod128_64 (double-precision estimates, exact 128-bit remainders) against __int128 division."""
+    L = simt.lib()
+    L.snf_simt_divcheck.argtypes = [C.c_long, C.c_ulonglong]
+    L.snf_simt_divcheck.restype = C.c_long
+    assert L.snf_simt_divcheck(3_000_000, 11) == 0
+
+
 # ---------------------------------------------------------------------------------------------- clustering + calling
 @pytest.mark.parametrize("name", sorted(cases.ALL))
 def test_wave_path_matches_reference_golden(name, simt):
