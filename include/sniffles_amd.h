@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNF_ABI_VERSION 3
+#define SNF_ABI_VERSION 4   /* 4: snf_batch_timing_every */
 
 #define SNF_SVLEN_NONE INT32_MIN /* Lead.svlen is None */
 #define SNF_SEQ_NONE (-1)        /* Lead.seq is None   */
