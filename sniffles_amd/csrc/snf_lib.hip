@@ -702,6 +702,7 @@ void do_upload(snf_batch_impl* b) {
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
   v.prof = getenv("SNF_PROF") ? 1 : 0;
+  v.merge_reread = getenv("SNF_MERGE_REREAD") ? 1 : 0;
   const bool sort64 = getenv("SNF_SORT64") != nullptr;  // tests: force the wide-key sorts
   {  // lead sort key: (task*8 + svtype) << bin_bits | bin, one more bit marks leads outside their contig (sorted last)
     int64_t max_bins = 1;

@@ -380,7 +380,7 @@ SNF_HD void merge_walk(const View& v, int32_t s0, int32_t s_end, bool group_firs
       const int32_t hi = B.cs.hi;
       const int64_t Lm = (int64_t)hi - A.lo;
       bool added = false;
-      if (Lm < 200 && A.cs.s2 != ~0ull && B.cs.s2 != ~0ull && A.cs.hi == B.lo) {
+      if (!v.merge_reread && Lm < 200 && A.cs.s2 != ~0ull && B.cs.s2 != ~0ull && A.cs.hi == B.lo) {
         const int64_t nb = (int64_t)hi - B.lo, dx = (int64_t)B.cs.x0 - A.cs.x0;
         const i128 S1m = (i128)A.cs.s1 + B.cs.s1 + (i128)nb * dx;
         const i128 S2m = (i128)A.cs.s2 + (i128)B.cs.s2 + (i128)2 * dx * B.cs.s1 + (i128)nb * dx * dx;

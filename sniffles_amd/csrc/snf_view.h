@@ -124,6 +124,7 @@ struct View {
   // consensus id, instead of the pipeline's formula (postprocessing.py:60-61 passes the same value for both); null in a batch
   const int32_t* cons_skip_arr; const int32_t* cons_skiprep_arr;
   int32_t prof;       // SNF_PROF=1: phase cycle counters in e45w_consensus
+  int32_t merge_reread;   // SNF_MERGE_REREAD=1 (tests): the merge walk reads the leads of every merged cluster instead of adding the kept sums
   int64_t N, R, NTR;
   int64_t NS;         // positions that go through the sort and the stages behind it: N, or (prefilter) the leads of (svtype, bin) cells with >= 2 leads
   int64_t pool_len, pool_cap;

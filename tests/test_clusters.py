@@ -66,3 +66,37 @@ def test_cluster_metrics_with_positions_far_apart_emu(oracle_mod):
         b.call_candidates()
         assert records.records(b.fetch(0), [ti], "cand") == exp
     assert int(ti.leads["ref_start"].max()) - int(ti.leads["ref_start"].min()) > (1 << 27) and len(exp[0]) > 0
+
+
+def check_merged_cluster_metrics_added_or_read(oracle_mod, monkeypatch):
+    """The merge scan keeps the sums behind a cluster's mean / stdev and adds them under merges (snf_stage_cluster.h::merge_walk);
+    SNF_MERGE_REREAD=1 makes it read the merged cluster's leads instead, as the reference does: the same clusters, candidates and
+    final records either way - on deep data too, where merged clusters pass 200 leads and the sums are dropped."""
+    from sniffles_amd import lib, records, synth
+    from sniffles_amd.config import SnifflesConfig
+    tis = [synth.gen_task(0, "chr21", 1_200_000, 30, 21), synth.gen_task(1, "chr22", 400_000, 150, 22), synth.gen_fuzz(9, task_id=2)]
+    cfg = SnifflesConfig()
+    exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    got = {}
+    for mode in ("0", "1"):
+        if mode == "1":
+            monkeypatch.setenv("SNF_MERGE_REREAD", "1")
+        with lib.Batch(cfg, tis) as b:
+            b.run_pass()
+            got[mode] = (records.records(b.fetch(1), tis, "final"), b.fetch_clusters(1))
+    assert got["0"][0] == exp and got["1"][0] == exp
+    ca, cb = got["0"][1], got["1"][1]
+    assert sorted(ca) == sorted(cb)
+    for k in ca:
+        assert (ca[k] == cb[k]).all() if hasattr(ca[k], "all") else ca[k] == cb[k], k
+
+
+def test_merged_cluster_metrics_added_or_read_emu(oracle_mod, monkeypatch):
+    import emu.emu as E
+    E.lib()
+    check_merged_cluster_metrics_added_or_read(oracle_mod, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_merged_cluster_metrics_added_or_read_gpu(oracle_mod, monkeypatch):
+    check_merged_cluster_metrics_added_or_read(oracle_mod, monkeypatch)
