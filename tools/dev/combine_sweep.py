@@ -19,6 +19,7 @@ FLAGS = [(), ("--combine-output-filtered",), ("--combine-pair-relabel",), ("--co
 def main():
     import numpy as np
     import emu.emu as E
+    E.lib()  # host tier: becomes the library sniffles_amd works on
     import ref_harness as rh
     import vcf_util as vu
     from sniffles_amd import bam, pipeline, synth_bam

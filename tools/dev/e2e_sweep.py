@@ -16,6 +16,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 def main():
     import numpy as np
     import emu.emu as E
+    E.lib()  # host tier: becomes the library sniffles_amd works on
     import ref_harness as rh
     import snf_util as su
     import vcf_util as vu

@@ -11,6 +11,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 def main():
     import numpy as np
     import emu.emu as E
+    E.lib()  # host tier: becomes the library sniffles_amd works on
     import extract_util as xu
     import ref_harness as rh
     from sniffles_amd import bam, extract, synth_bam

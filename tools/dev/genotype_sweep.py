@@ -12,6 +12,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
 def main():
     import cases
     import emu.emu as E
+    E.lib()  # host tier: becomes the library sniffles_amd works on
     import genotype_util as gutil
     import ref_harness as rh
     from test_genotype import make_task
