@@ -74,7 +74,7 @@ def check_merged_cluster_metrics_added_or_read(oracle_mod, monkeypatch):
     final records either way - on deep data too, where merged clusters pass 200 leads and the sums are dropped."""
     from sniffles_amd import lib, records, synth
     from sniffles_amd.config import SnifflesConfig
-    tis = [synth.gen_task(0, "chr21", 1_200_000, 30, 21), synth.gen_task(1, "chr22", 400_000, 150, 22), synth.gen_fuzz(9, task_id=2)]
+    tis = [synth.gen_task(0, "chr21", 800_000, 30, 21), synth.gen_task(1, "chr22", 200_000, 150, 22), synth.gen_fuzz(9, task_id=2)]
     cfg = SnifflesConfig()
     exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
     got = {}

@@ -276,7 +276,7 @@ def check_consensus_class_order(oracle_mod, monkeypatch):
     is in flight): the same records."""
     from sniffles_amd import lib, records, synth
     from sniffles_amd.config import SnifflesConfig
-    tis = [synth.gen_task(0, "chr21", 2_500_000, 30, 11), synth.gen_fuzz(5, task_id=1)]
+    tis = [synth.gen_task(0, "chr21", 1_200_000, 30, 11), synth.gen_fuzz(5, task_id=1)]
     cfg = SnifflesConfig()
     exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
     for order in ("0", "1", "2"):
