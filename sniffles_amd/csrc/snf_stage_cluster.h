@@ -222,16 +222,21 @@ SNF_HD void compute_metrics(const View& v, int32_t lo, int32_t hi, double* mean,
   // whenever one of its 64 runs merges (a lone wave, every instruction at full latency: the loop was most of that kernel).
   int64_t S1 = 0; uint64_t S2 = 0, wide = 0;
   int64_t x0 = 0;     // (the first record's ref_start: arrives with the first batch)
-  // MCH records are requested before the first is used (a loop that waits for every record costs a round trip per lead)
+  // MCH records are requested before the first is used (a loop that waits for every record costs a round trip per lead).  A lane
+  // whose range does not reach that far asks for record 0 of the table - the same line for every such lane of the wave, one access
+  // for all of them (clamped to its own range, a seed of six leads sent 32 requests of its own per batch through the L1).
   constexpr int MCH = 32;
   for (int64_t i = 0; i < len; i += MCH * step) {
     int32_t sv[MCH], rs[MCH];
 #pragma unroll
     for (int u = 0; u < MCH; u++) {
       const int64_t q = i + u * step;
-      const LeadRec& r = v.Lrec[lo + (q < len ? q : i)];
+      const LeadRec& r = v.Lrec[q < len ? lo + q : 0];
       sv[u] = r.svlen; rs[u] = r.ref_start;
     }
+    // every request of the batch is issued before the first value is used: left alone the compiler sinks each load to its use
+    // (fewer live registers) and the batch becomes 32 dependent round trips (seen in the ISA; b1k_seedmetrics 32.5 -> 26.0 us)
+    asm volatile("" ::: "memory");
     if (i == 0) x0 = rs[0];
 #pragma unroll
     for (int u = 0; u < MCH; u++) {
