@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) z0_init(const View v, int64_t n) {
   if (i < TS_SLOTS * v.super_stride) v.tile_super[i] = 0;
   if (i == 0) *v.chain_epoch += 1u;                          // tags of this pass's chain launches (chain_scan)
   if (v.wave_path && i < 3 * 64 * 16) v.big_cnt[i] = 0;      // lists of the big-cluster kernels (x_big)
-  if (v.wave_path && i < 2 * 64 * 16) v.d2cnt[i] = 0;       // lists of the grouped call kernels (snf_wave_call_g.h)
+  if (v.wave_path && i < 3 * 64 * 16) v.d2cnt[i] = 0;       // lists of the grouped call kernels (snf_wave_call_g.h)
   if (i == 0 && v.NS > 0) {
     const int64_t N = v.NS;
     v.headflag[N] = 0; v.eligflag[N] = 0; v.fN[N] = 0; v.fL[N] = 0; v.runflag[N] = 0; v.clflag[N] = 0; v.rcflag[N] = 0; v.cdflag[N] = 0;

@@ -10,6 +10,7 @@
 #include "snf_stage_out.h"
 #include "snf_wave_call.h"
 #include "snf_wave_call_g.h"
+#include "snf_wave_refine_g.h"
 #include "snf_ctx.h"
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -271,6 +272,7 @@ struct snf_batch_impl {
   void (*k_d2w)(const View, int64_t) = nullptr; void (*k_e1w)(const View, int64_t) = nullptr;  // occupancy variants
   int slots_d1w = 8192, slots_d2w = 8192, slots_e1w = 8192, slots_big = 8192;
   int slots_cons_s = 1 << 22, slots_cons_l = 1 << 22, slots_cons_s1 = 65536;   // grid caps of the SMALL / LARGE consensus kernels
+  bool d1_groups = true;          // merge_inner / resplit: small merged clusters eight per wave (snf_wave_refine_g.h); SNF_NO_D1_GROUPS=1: a wave per cluster
   bool d2_groups = true;          // call_from: small refined clusters several per wave (snf_wave_call_g.h); SNF_NO_D2_GROUPS=1: a wave per cluster
   int cons_nw = 1;                // waves per SMALL consensus call: 1 = one wave per call (default: single-wave workgroups leave room for the
                                   // LARGE class next to them - LARGE in place 0.75 -> 0.5 ms, the pass 2.5 % shorter), SNF_CONS_NW=4: four
@@ -947,8 +949,10 @@ void do_upload(snf_batch_impl* b) {
     const size_t W1 = (size_t)win_slots_max + 1;
     v.wcnt = dalloc<uint32_t>(b, W1); v.wfill = dalloc<uint32_t>(b, W1); v.wbase = dalloc<uint32_t>(b, W1);
     const size_t occ_max = (size_t)(N < win_slots_max ? N : win_slots_max) + 2;
-    v.wlist = dalloc<uint32_t>(b, 3 * occ_max); v.ws_seeds = dalloc<uint32_t>(b, occ_max); v.ws_nf = dalloc<uint32_t>(b, occ_max); v.ws_nl = dalloc<uint32_t>(b, occ_max);
-    v.whead = dalloc<uint64_t>(b, N1);
+    const size_t nblk = (size_t)N / 64 + 2;
+    v.wlist = dalloc<uint32_t>(b, 4 * occ_max); v.blk_k0 = dalloc<uint32_t>(b, nblk);
+    v.ws_seeds = dalloc<uint32_t>(b, nblk); v.ws_nf = dalloc<uint32_t>(b, nblk); v.ws_nl = dalloc<uint32_t>(b, nblk);
+    v.whead = dalloc<uint64_t>(b, N1); v.whead2 = dalloc<uint64_t>(b, N1);
     dzero(b, v.wcnt, W1 * 4); dzero(b, v.wfill, W1 * 4);
   }
   uint32_t** u32s[] = {&v.headflag, &v.headscan, &v.eligflag, &v.eligscan, &v.fN, &v.pN, &v.fL, &v.pL, &v.runflag, &v.runscan,
@@ -997,9 +1001,9 @@ void do_upload(snf_batch_impl* b) {
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
   for (int k = 0; k < 8; k++) v.cls_list[k] = k == 6 ? nullptr : dalloc<int32_t>(b, N1);
   v.d2cap = (int64_t)(N1 / 64 + 64);
-  for (int k = 0; k < 2; k++) v.d2_list[k] = dalloc<int32_t>(b, (size_t)(64 * v.d2cap));
-  v.d2cnt = dalloc<uint32_t>(b, 2 * 64 * 16);
-  v.d2_from_list = 0;
+  for (int k = 0; k < 3; k++) v.d2_list[k] = dalloc<int32_t>(b, (size_t)(64 * v.d2cap));
+  v.d2cnt = dalloc<uint32_t>(b, 3 * 64 * 16);
+  v.d2_from_list = 0; v.d1_from_list = 0;
 #ifdef SNF_WG_TRACE
   if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 24)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 24)); }
 #endif
@@ -1209,18 +1213,18 @@ void enqueue_window_front(snf_batch_impl* b) {
   if (v.chain_on) CHAIN(w2c_offsets, NW);
   else { FUSED(w2a_sums, NW); FUSED(w2b_offsets, NW); }
   LAUNCH_Q(w3_scatter, v, N, 0);
-  auto wave_per_window = [&](auto k64, auto k256, auto k1024, const char* name) {
-    Scope* sc = b->time_all ? new Scope(b, name, 0) : nullptr;
-    if (b->win_cap == 64) hipLaunchKernelGGL(k64, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
-    else if (b->win_cap == 256) hipLaunchKernelGGL(k256, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
-    else hipLaunchKernelGGL(k1024, dim3((unsigned)n_occ), dim3(64), 0, b->cur, v, (int64_t)0);
+  const int64_t n_blk = (N + 63) / 64;      // waves of w4s_segment: one per 64 positions of the bucket array
+  {
+    Scope* sc = b->time_all ? new Scope(b, "w4s_segment", 0) : nullptr;
+    if (b->win_cap == 64) hipLaunchKernelGGL(w4s_segment<64>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
+    else if (b->win_cap == 256) hipLaunchKernelGGL(w4s_segment<256>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
+    else hipLaunchKernelGGL(w4s_segment<SNF_WIN_MAXCAP>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
     delete sc;
     SNF_HIP(hipGetLastError());
-  };
-  wave_per_window(w4_local<64>, w4_local<256>, w4_local<SNF_WIN_MAXCAP>, "w4_local");
-  if (v.chain_on) CHAIN(w5c_offsets, n_occ);
-  else { FUSED(w5a_sums, n_occ); FUSED(w5b_offsets, n_occ); }
-  wave_per_window(w6_emit<64>, w6_emit<256>, w6_emit<SNF_WIN_MAXCAP>, "w6_emit");
+  }
+  if (v.chain_on) CHAIN(w5c_offsets, n_blk);
+  else { FUSED(w5a_sums, n_blk); FUSED(w5b_offsets, n_blk); }
+  LAUNCH_Q(w6t_emit, v, N, 0);
 }
 
 void run_call_candidates(snf_batch_impl* b) {
@@ -1241,7 +1245,7 @@ void run_call_candidates(snf_batch_impl* b) {
   // (and in the emulation build) the plain device-wide scans are used
   enqueue_pass_init(b);
   if (v.wave_path && !b->fused) dzero(b, v.big_cnt, sizeof(uint32_t) * 3 * 64 * 16);   // (fused: z0_init)
-  if (v.wave_path && !b->fused) dzero(b, v.d2cnt, sizeof(uint32_t) * 2 * 64 * 16);
+  if (v.wave_path && !b->fused) dzero(b, v.d2cnt, sizeof(uint32_t) * 3 * 64 * 16);
   b->finalize_runs = 0;
   fork_mark(b);  // the read-preparation branch may start here, wherever it is enqueued below
   if (b->sched_readprep == 0) enqueue_read_prep(b);
@@ -1302,7 +1306,18 @@ void run_call_candidates(snf_batch_impl* b) {
     dzero(b, v.rcflag, sizeof(uint32_t) * (N + 1));
     }
     if (b->sched_readprep == 3) fork_mark(b);   // mode 3: the read preparation may only start once stages A-C are through
-    if (v.wave_path) {
+    if (v.wave_path && b->d1_groups) {
+      // merge_inner / resplit by cluster size (snf_wave_refine_g.h): eight clusters of <= 8 leads per wave, then d1w_refine - a wave
+      // per cluster - for what that kernel handed on
+      { Scope _s(b, "d1g_refine8", N * 36);
+        hipLaunchKernelGGL(d1g_refine<8>, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
+        SNF_HIP(hipGetLastError()); }
+      { Scope _s(b, "d1w_refine", 0);
+        v.d1_from_list = 1;
+        hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
+        v.d1_from_list = 0;
+        SNF_HIP(hipGetLastError()); }
+    } else if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
       hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
@@ -2421,9 +2436,10 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
       const DevInfo di = device_info(b->device, o2, o1, b->k_d2w, b->k_e1w);
       const int cus = di.cus;
       int nb = 0;
-      if (di.nb_d1w > 0) b->slots_d1w = di.nb_d1w * cus * mult;
-      if (di.nb_d2w > 0) b->slots_d2w = di.nb_d2w * cus * mult;
-      if (di.nb_e1w > 0) b->slots_e1w = di.nb_e1w * cus * mult;
+      const int div = getenv("SNF_GRID_DIV") && atoi(getenv("SNF_GRID_DIV")) > 0 ? atoi(getenv("SNF_GRID_DIV")) : 1;   // experiments: a fraction of the resident set (room for the other pass in flight)
+      if (di.nb_d1w > 0) b->slots_d1w = di.nb_d1w * cus * mult / div;
+      if (di.nb_d2w > 0) b->slots_d2w = di.nb_d2w * cus * mult / div;
+      if (di.nb_e1w > 0) b->slots_e1w = di.nb_e1w * cus * mult / div;
       // The consensus kernels take one call per workgroup from the hardware dispatcher: measured alone on config 1, resident
       // (persistent) grids were slower whether they strode statically (0.315 / 0.419 ms SMALL / LARGE, a tail of unequal calls)
       // or claimed calls from a counter (0.498 / 0.382 ms) - against 0.286 / 0.306 ms for plain grids.  SNF_CONS_GRID_MULT=k
@@ -2445,6 +2461,7 @@ int snf_batch_create(const snf_config_t* cfg, int device, snf_batch_t** out) {
     if (const char* e = getenv("SNF_OCC_S")) b->occ_s = atoi(e);
     if (const char* e = getenv("SNF_CONS_NW")) b->cons_nw = atoi(e);
     b->d2_groups = getenv("SNF_NO_D2_GROUPS") == nullptr;
+    b->d1_groups = getenv("SNF_NO_D1_GROUPS") == nullptr;
     if (const char* e = getenv("SNF_CONS_LARGE_NW")) b->cons_large_nw = atoi(e);
     if (const char* e = getenv("SNF_READPREP")) b->sched_readprep = atoi(e);
     *out = reinterpret_cast<snf_batch_t*>(b.release());

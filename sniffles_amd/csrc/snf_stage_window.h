@@ -5,18 +5,22 @@
 //   w1_hist     per lead: (task, svtype, 100-bp bin) -> its WINDOW (2^W consecutive bins of one (task, svtype)); one count per window
 //   w2a / w2b   exclusive scan of the window counts (bucket offsets) + the list of occupied windows
 //   w3_scatter  per lead: into its window's bucket (any order inside a bucket)
-//   w4_local    one wave per occupied window: the bucket's leads ordered by (bin, arrival) in LDS (rank sort: a window holds tens of
-//               leads), bin heads, per-bin record_lead side effects (leadprov.py:400-418: the 10-per-bin sequence cap, the hap
-//               counters) and seed eligibility (cluster.py:262); per window the number of seeds / `leads` / `leads_long`
-//   w5a / w5b   exclusive scan of those three counts over the occupied windows
-//   w6_emit     one wave per occupied window: seeds, L / LL / packed lead records at their global places
+//   w4s_segment one wave per 64 positions of the bucket array = the handful of windows that start there (a large window: the whole
+//               wave, in rounds): every window's leads ordered by (bin, arrival) in LDS (rank sort inside the window), bin heads,
+//               per-bin record_lead side effects (leadprov.py:400-418: the 10-per-bin sequence cap, the hap counters) and seed
+//               eligibility (cluster.py:262); per wave the number of seeds / `leads` / `leads_long`, per lead its rank among them
+//   w5a / w5b   exclusive scan of those three counts over the waves
+//   w6t_emit    one thread per bucket position: seeds, L / LL / packed lead records at their global places (offset of the owning
+//               wave + rank)
+// (Rounds 4's w4_local / w6_emit gave every occupied window a wave of its own: 122 k waves for windows of ~23 leads of which six
+// are kept - 36 % and 9 % of the lanes had a lead.)
 //
 // Reference semantics are those of snf_stage_cluster.h (stage A): a bin = (task, svtype, int(ref_start / 100)), leads of a bin in
 // arrival order, `ld.seq = None` from the 11th lead of a bin on, hap counters per bin, a seed where a bin holds at least
 // dev_min_leads_cluster leads with a length.  Everything behind it (b1k_seedmetrics onwards) reads the same arrays as before;
 // the bin id of a seed (seed_bin) is the seed id itself here - only eligible bins get a row in bin_hap.
 // Used when a one-lead bin can never seed a cluster (dev_min_leads_cluster >= 2: the condition of the old prefilter) and no window
-// holds more leads than the largest instance of w4_local / w6_emit takes; otherwise the sort path (snf_stage_cluster.h) runs.
+// holds more leads than the largest instance of w4s_segment takes; otherwise the sort path (snf_stage_cluster.h) runs.
 #pragma once
 #include "snf_fused.h"
 #include "snf_wave_refine.h"   // wave_incl_max (DPP scan)
@@ -30,12 +34,6 @@ SNF_HD uint32_t win_pack(const View& v, uint32_t bin_low, bool is_long, uint32_t
 SNF_HD uint32_t win_bin_low(uint32_t a) { return a & 0xfffu; }
 SNF_HD bool win_is_long(uint32_t a) { return (a >> 12) & 1u; }
 SNF_HD uint32_t win_hap(uint32_t a) { return (a >> 13) & 3u; }
-// flags added by w4_local (same word): lead of an eligible bin with a length / without one, Lead.seq dropped, first lead of an eligible bin
-#define SNF_WF_NORM (1u << 16)
-#define SNF_WF_LONG (1u << 17)
-#define SNF_WF_SEQNULL (1u << 18)
-#define SNF_WF_SEED (1u << 19)
-
 // window of a lead; false: the lead lies outside its contig (dropped, leadprov.py:464-468)
 SNF_D bool win_of_lead(const View& v, int64_t i, uint32_t* w, uint32_t* attr) {
   const int t = v.lead_task[i];
@@ -93,6 +91,18 @@ __global__ void __launch_bounds__(256) w0_stats(const View v, int64_t n) {
   }
 }
 
+// one record per occupied window, ascending: {window, leads, bucket offset, task}; and per 64-position block of the bucket array the
+// first window that starts in it or behind it (blk_k0: the windows of block i are blk_k0[i] .. blk_k0[i + 1] - 1 - what w4s_segment's
+// wave i owns).  Window k answers for the blocks whose first position lies inside it or is its end: every block has one writer.
+SNF_D void win_list(const View& v, int64_t p, uint32_t c, unsigned long long off, unsigned long long k) {
+  if (p == 0) v.blk_k0[0] = 0;
+  if (!c) return;
+  int lo = 0, hi = v.T;            // last task with t_win_off[t] <= p
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.t_win_off[mid] <= p) lo = mid; else hi = mid; }
+  ((uint4*)v.wlist)[k] = make_uint4((uint32_t)p, c, (uint32_t)off, (uint32_t)lo);
+  for (unsigned long long bb = off / 64 + 1; bb <= (off + c) / 64; bb++) v.blk_k0[bb] = (uint32_t)(k + 1);
+}
+
 // W2: bucket offsets = exclusive scan of the window counts; occupied windows listed in ascending order
 SNF_FUSED_HEAD(w2a_sums)
   const uint32_t c = p < n ? v.wcnt[p] : 0u;
@@ -106,7 +116,7 @@ SNF_FUSED_HEAD(w2b_offsets)
   if (p < n) {
     v.wcnt[p] = 0; v.wfill[p] = 0;      // spent / not yet used in this pass: both counters are clean for w3_scatter and the next pass
     v.wbase[p] = (uint32_t)off[0];
-    if (c) { v.wlist[3 * off[1]] = (uint32_t)p; v.wlist[3 * off[1] + 1] = c; v.wlist[3 * off[1] + 2] = (uint32_t)off[0]; }
+    win_list(v, p, c, off[0], off[1]);
     if (p == n - 1) { v.wbase[n] = (uint32_t)(off[0] + val[0]); v.cnt->n_valid = (int64_t)(off[0] + val[0]); v.cnt->n_occ = (int64_t)(off[1] + val[1]); }
   }
 }
@@ -118,7 +128,7 @@ SNF_CHAIN_HEAD(w2c_offsets, TS_WIN)      // (the pair above in one launch: snf_f
   if (p < n) {
     v.wcnt[p] = 0; v.wfill[p] = 0;      // spent / not yet used in this pass: both counters are clean for w3_scatter and the next pass
     v.wbase[p] = (uint32_t)off[0];
-    if (c) { v.wlist[3 * off[1]] = (uint32_t)p; v.wlist[3 * off[1] + 1] = c; v.wlist[3 * off[1] + 2] = (uint32_t)off[0]; }
+    win_list(v, p, c, off[0], off[1]);
     if (p == n - 1) { v.wbase[n] = (uint32_t)tot[0]; v.cnt->n_valid = (int64_t)tot[0]; v.cnt->n_occ = (int64_t)tot[1]; }
   }
 }
@@ -148,120 +158,164 @@ __global__ void __launch_bounds__(256) w3_scatter(const View v, int64_t n) {
   if (valid) v.key_in[(int64_t)v.wbase[w] + mine + rank] = ((uint64_t)v.val_out[i] << 32) | (uint64_t)(uint32_t)i;
 }
 
-// (task, svtype, first bin) of window w
-SNF_D void win_decode(const View& v, uint32_t w, int* grp, int64_t* bin0) {
-  int lo = 0, hi = v.T;            // last task with t_win_off[t] <= w
-  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (v.t_win_off[mid] <= (int64_t)w) lo = mid; else hi = mid; }
-  const int64_t w0 = v.t_win_off[lo], nwin = (v.t_win_off[lo + 1] - w0) / SNF_NTYPES;
-  const int64_t rem = (int64_t)w - w0;
-  *grp = lo * 8 + (int)(rem / nwin);
-  *bin0 = (rem % nwin) << v.win_bits;
-}
-
 // inclusive running maximum along the positions of a window, 64 positions per round (carry: the maximum of the rounds before)
 SNF_D int wave_runmax(int x, int carry) {
   x = wave_incl_max(x);      // (six DPP steps; the __shfl_up form was six round trips through the LDS crossbar)
   return x > carry ? x : carry;
 }
 
-// W4: one wave per occupied window.  CAP: leads a window may hold (the host picks the instance from the largest window of the batch)
+// flags of a key_out word (high half) as w4s_segment leaves it for w6t_emit: lead of an eligible bin with a length / without one,
+// Lead.seq dropped, first lead of an eligible bin; bits 4-15 the lead's rank among the wave's `leads` (or `leads_long`), bits 16-20
+// how many 64-position blocks before the lead's own block the wave sits that owns it, bits 21-31 (seeds) the seed's rank in the wave
+#define SNF_WS_NORM 1u
+#define SNF_WS_LONG 2u
+#define SNF_WS_SEQNULL 4u
+#define SNF_WS_SEED 8u
+
+// W4: one wave per SEGMENT of the bucket array.  Wave i owns the occupied windows whose bucket starts in positions [64 i, 64 i + 64)
+// (blk_k0, written by w2): a handful of small windows - a window of a 30x genome holds ~23 leads, most hold fewer than eight - or
+// one large one that reaches into the following blocks.  One lead per lane and round, whatever window it belongs to: every wave-wide
+// step of the old wave-per-window kernel (ballots, running maxima, the rank sort's broadcast reads) works on the lead's own window
+// through its start and length in LDS.  CAP: leads the largest window may hold (the host picks the instance).
 template <int CAP>
-__global__ void __launch_bounds__(64) w4_local(const View v, int64_t n_unused) {
-  constexpr int E = CAP / 64;
-  __shared__ uint64_t keys[CAP];
-  __shared__ uint16_t hpos[CAP];
-  __shared__ uint32_t sA[CAP], sB[CAP];      // per bin (at its head position): leads | leads with a length << 16;  hap 1 | hap 2 << 16
+__global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused) {
+  constexpr int CAPW = CAP + 64, E = CAPW / 64;
+  __shared__ uint64_t keys[CAPW];
+  __shared__ uint16_t widx[CAPW], hpos[CAPW];
+  __shared__ uint32_t sA[CAPW], sB[CAPW];      // per bin (at its head position): leads | leads with a length << 16;  hap 1 | hap 2 << 16
+  __shared__ uint32_t wS[64], wN[64], wG[64], wB[64];   // per window of the wave: first position (relative), leads, group, first bin
   const int lane = threadIdx.x;
-  const int64_t k = blockIdx.x;
-  const int n = (int)v.wlist[3 * k + 1];                     // {window, leads, bucket offset}: one record per occupied window (w2)
-  const int64_t base = v.wlist[3 * k + 2];
+  const int64_t i = blockIdx.x;
+  const int64_t n_valid = v.cnt->n_valid;
+  uint32_t k0 = 0, k1 = 0;
+  if (64 * i < n_valid) { k0 = v.blk_k0[i]; k1 = 64 * (i + 1) <= n_valid ? v.blk_k0[i + 1] : (uint32_t)v.cnt->n_occ; }
+  const int nw = (int)(k1 - k0);                 // <= 64: every window holds a lead and starts inside the block
+  if (nw <= 0) { if (lane == 0) { v.ws_seeds[i] = 0; v.ws_nf[i] = 0; v.ws_nl[i] = 0; } return; }
+  uint4 wr = make_uint4(0, 0, 0, 0);             // {window, leads, bucket offset, task}
+  if (lane < nw) wr = ((const uint4*)v.wlist)[k0 + lane];
+  const int64_t P0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wr.z);
+  const int64_t P1 = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wr.z + wr.y), nw - 1);
+  const int M = (int)(P1 - P0);                  // <= 63 + CAP
+  if (lane < nw) {
+    const int t = (int)wr.w;
+    const int64_t w0 = v.t_win_off[t], nwin = (v.t_win_off[t + 1] - w0) / SNF_NTYPES, rem = (int64_t)wr.x - w0;
+    wS[lane] = (uint32_t)((int64_t)wr.z - P0); wN[lane] = wr.y; wG[lane] = (uint32_t)(t * 8 + (int)(rem / nwin)); wB[lane] = (uint32_t)((rem % nwin) << v.win_bits);
+  }
   uint64_t e[E];
 #pragma unroll
   for (int j = 0; j < E; j++) {
-    const int p = lane + 64 * j;
-    e[j] = p < n ? v.key_in[base + p] : ~0ull;
-    if (p < n) { keys[p] = e[j]; sA[p] = 0; sB[p] = 0; }
+    const int x = lane + 64 * j;
+    e[j] = x < M ? v.key_in[P0 + x] : ~0ull;
+    if (x < M) { keys[x] = e[j]; sA[x] = 0; sB[x] = 0; widx[x] = 0; }
   }
   __syncthreads();
-  // rank sort by (bin, arrival): keys are distinct (the input index is part of them), a window holds tens of leads; every lane
-  // reads the same LDS word per step (a broadcast)
-  int r[E];
+  if (lane < nw) widx[wS[lane]] = (uint16_t)(lane + 1);
+  __syncthreads();
+  // the window of every position: a running maximum over the marks at the windows' first positions
+  int wi[E];
+  {
+    int carry = 0;
 #pragma unroll
-  for (int j = 0; j < E; j++) r[j] = 0;
-  // (the attribute bits above the bin do not disturb the order: the comparison masks them)
+    for (int j = 0; j < E; j++) {
+      wi[j] = 0;
+      if (64 * j < M) {
+        const int x = lane + 64 * j;
+        const int m = wave_runmax(x < M ? (int)widx[x] : 0, carry);
+        wi[j] = m - 1;
+        carry = __shfl(m, 63, 64);
+      }
+    }
+  }
+  // rank sort by (bin, arrival) inside every window: keys are distinct (the input index is part of them); the lanes of a window read
+  // the same LDS word per step (a broadcast per window).  (The attribute bits above the bin do not disturb the order: masked.)
   const uint64_t mask = ((uint64_t)0xfffu << 32) | 0xffffffffull;
-  // (a window holds ~23 leads on a 30x genome and the instance is sized by the largest one: only the rounds that hold leads compare)
-  if (n <= 64) {
-    const uint64_t e0 = e[0] & mask;
-    for (int q = 0; q < n; q++) r[0] += (keys[q] & mask) < e0 ? 1 : 0;
-  } else {
-    for (int q = 0; q < n; q++) {
-      const uint64_t kq = keys[q] & mask;
+  int r[E], ws[E];
 #pragma unroll
-      for (int j = 0; j < E; j++) if (64 * j < n) r[j] += kq < (e[j] & mask) ? 1 : 0;
+  for (int j = 0; j < E; j++) {
+    r[j] = 0; ws[j] = 0;
+    if (64 * j < M) {
+      const int x = lane + 64 * j;
+      const int n = x < M ? (int)wN[wi[j]] : 0;
+      ws[j] = x < M ? (int)wS[wi[j]] : 0;
+      const int nmax = __shfl(wave_incl_max(n), 63, 64);
+      const uint64_t ek = e[j] & mask;
+      for (int q = 0; q < nmax; q++) {
+        const uint64_t kq = keys[q < n ? ws[j] + q : 0] & mask;
+        r[j] += (q < n && kq < ek) ? 1 : 0;
+      }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < E; j++) if (lane + 64 * j < n) keys[r[j]] = e[j];
+  for (int j = 0; j < E; j++) if (lane + 64 * j < M) keys[ws[j] + r[j]] = e[j];
   __syncthreads();
   // bin heads and the head position of every lead
-  int carry = -1;
+  {
+    int carry = -1;
 #pragma unroll
-  for (int j = 0; j < E; j++) {
-    const int p = lane + 64 * j;
-    if (64 * j < n) {
-      int h = -1;
-      if (p < n) {
-        const uint32_t b = win_bin_low((uint32_t)(keys[p] >> 32));
-        if (p == 0 || win_bin_low((uint32_t)(keys[p - 1] >> 32)) != b) h = p;
+    for (int j = 0; j < E; j++) {
+      const int x = lane + 64 * j;
+      if (64 * j < M) {
+        int h = -1;
+        if (x < M) {
+          const uint32_t bn = win_bin_low((uint32_t)(keys[x] >> 32));
+          if (x == ws[j] || win_bin_low((uint32_t)(keys[x - 1] >> 32)) != bn) h = x;
+        }
+        const int m = wave_runmax(h, carry);
+        if (x < M) hpos[x] = (uint16_t)m;
+        carry = __shfl(m, 63, 64);
       }
-      const int m = wave_runmax(h, carry);
-      if (p < n) hpos[p] = (uint16_t)m;
-      carry = __shfl(m, 63, 64);
     }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < E; j++) {
-    const int p = lane + 64 * j;
-    if (64 * j >= n) break;
-    if (p < n) {
-      const uint32_t a = (uint32_t)(keys[p] >> 32);
-      const int h = hpos[p];
+    const int x = lane + 64 * j;
+    if (64 * j >= M) break;
+    if (x < M) {
+      const uint32_t a = (uint32_t)(keys[x] >> 32);
+      const int h = hpos[x];
       atomicAdd(&sA[h], 1u + (win_is_long(a) ? 0u : (1u << 16)));
       const uint32_t hp = win_hap(a);
       if (hp) atomicAdd(&sB[h], hp == 1 ? 1u : (1u << 16));
     }
   }
   __syncthreads();
-  int n_seed = 0, n_norm = 0, n_long = 0;
+  int cs = 0, cf = 0, cl = 0;      // seeds / leads / long leads of the rounds before
+  const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
   for (int j = 0; j < E; j++) {
-    const int p = lane + 64 * j;
-    if (64 * j >= n) break;
-    bool f_seed = false, f_norm = false, f_long = false;
-    if (p < n) {
-      const uint64_t key = keys[p];
-      uint32_t a = (uint32_t)(key >> 32);
-      const int h = hpos[p];
+    const int x = lane + 64 * j;
+    if (64 * j >= M) break;
+    bool f_seed = false, f_norm = false, f_long = false, f_null = false;
+    uint64_t key = 0; uint32_t a = 0; int h = 0, all = 0, with_len = 0;
+    if (x < M) {
+      key = keys[x]; a = (uint32_t)(key >> 32); h = hpos[x];
       const uint32_t A = sA[h];
-      const int all = (int)(A & 0xffffu), with_len = (int)(A >> 16);
+      all = (int)(A & 0xffffu); with_len = (int)(A >> 16);
       const bool elig = with_len >= v.cfg.dev_min_leads_cluster;
-      f_norm = elig && !win_is_long(a); f_long = elig && win_is_long(a); f_seed = elig && p == h;
-      if (f_norm) a |= SNF_WF_NORM;
-      if (f_long) a |= SNF_WF_LONG;
-      if (p - h + 1 > v.cfg.consensus_max_reads_bin) a |= SNF_WF_SEQNULL;      // leadprov.py:406-408 (counts every lead of the bin)
-      if (f_seed) {
-        a |= SNF_WF_SEED;
-        const uint32_t B = sB[h];
-        v.whead[base + p] = (uint64_t)with_len | ((uint64_t)all << 16) | ((uint64_t)(B & 0xffffu) << 32) | ((uint64_t)(B >> 16) << 48);
-      }
-      v.key_out[base + p] = ((uint64_t)a << 32) | (key & 0xffffffffull);
+      f_norm = elig && !win_is_long(a); f_long = elig && win_is_long(a); f_seed = elig && x == h;
+      f_null = x - h + 1 > v.cfg.consensus_max_reads_bin;      // leadprov.py:406-408 (counts every lead of the bin)
     }
-    n_seed += __popcll(__ballot(f_seed)); n_norm += __popcll(__ballot(f_norm)); n_long += __popcll(__ballot(f_long));
+    const unsigned long long bn = __ballot(f_norm), bl = __ballot(f_long), bs = __ballot(f_seed);
+    const uint32_t rn = (uint32_t)(cf + __popcll(bn & below)), rl = (uint32_t)(cl + __popcll(bl & below)), rs = (uint32_t)(cs + __popcll(bs & below));
+    if (x < M) {
+      const uint32_t delta = (uint32_t)((P0 + x) / 64 - i);
+      const uint32_t hi = (f_norm ? SNF_WS_NORM : 0u) | (f_long ? SNF_WS_LONG : 0u) | (f_null ? SNF_WS_SEQNULL : 0u) | (f_seed ? SNF_WS_SEED : 0u) |
+                          ((f_norm ? rn : rl) << 4) | (delta << 16) | (f_seed ? rs << 21 : 0u);
+      v.key_out[P0 + x] = ((uint64_t)hi << 32) | (key & 0xffffffffull);
+      if (f_seed) {
+        const uint32_t B = sB[h];
+        const int wl = wi[j];
+        const int64_t start = ((int64_t)wB[wl] + (int64_t)win_bin_low(a)) * v.cfg.cluster_binsize;
+        v.whead[P0 + x] = (uint64_t)with_len | ((uint64_t)all << 16) | ((uint64_t)(B & 0xffffu) << 32) | ((uint64_t)(B >> 16) << 48);
+        // seed start | group << 32 | the seed's offset in the OTHER list (`leads_long` for a seed lead with a length and vice versa) << 52
+        v.whead2[P0 + x] = (uint64_t)(uint32_t)(int32_t)start | ((uint64_t)wG[wl] << 32) | ((uint64_t)(f_norm ? rl : rn) << 52);
+      }
+    }
+    cs += __popcll(bs); cf += __popcll(bn); cl += __popcll(bl);
   }
-  if (lane == 0) { v.ws_seeds[k] = (uint32_t)n_seed; v.ws_nf[k] = (uint32_t)n_norm; v.ws_nl[k] = (uint32_t)n_long; }
+  if (lane == 0) { v.ws_seeds[i] = (uint32_t)cs; v.ws_nf[i] = (uint32_t)cf; v.ws_nl[i] = (uint32_t)cl; }
 }
 
 // W5: exclusive scans of the three per-window counts (in place) + the totals of the stage
@@ -298,48 +352,43 @@ SNF_CHAIN_HEAD(w5c_offsets, TS_WINC)     // (the pair above in one launch)
   }
 }
 
-// W6: one wave per occupied window: its seeds, `leads` (L, packed records) and `leads_long` (LL) at their global places
-template <int CAP>
-__global__ void __launch_bounds__(64) w6_emit(const View v, int64_t n_unused) {
-  constexpr int E = CAP / 64;
-  const int lane = threadIdx.x;
-  const int64_t k = blockIdx.x;
-  const uint32_t w = v.wlist[3 * k];
-  const int n = (int)v.wlist[3 * k + 1];
-  const int64_t base = v.wlist[3 * k + 2];
-  const int64_t S0 = v.ws_seeds[k], F0 = v.ws_nf[k], L0 = v.ws_nl[k];
-  int grp; int64_t bin0;
-  win_decode(v, w, &grp, &bin0);
-  int cs = 0, cf = 0, cl = 0;      // seeds / leads / long leads of the rounds before
-#pragma unroll
-  for (int j = 0; j < E; j++) {
-    const int p = lane + 64 * j;
-    if (64 * j >= n) break;
-    uint64_t key = 0; uint32_t a = 0;
-    if (p < n) { key = v.key_out[base + p]; a = (uint32_t)(key >> 32); }
-    const bool f_norm = (a & SNF_WF_NORM) != 0, f_long = (a & SNF_WF_LONG) != 0, f_seed = (a & SNF_WF_SEED) != 0;
-    const unsigned long long bn = __ballot(f_norm), bl = __ballot(f_long), bs = __ballot(f_seed);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int64_t qf = F0 + cf + __popcll(bn & below), ql = L0 + cl + __popcll(bl & below), qs = S0 + cs + __popcll(bs & below);
-    const uint32_t o = (uint32_t)key;
-    if (f_norm) {
-      v.L[qf] = o;
-      LeadRec rec = v.in_rec[o];
-      if (rec.seq_len >= 0 && (a & SNF_WF_SEQNULL)) { rec.seq_len = -1; rec.seq_off = 0; }   // 11th+ lead of a bin: Lead.seq = None
-      v.Lrec[qf] = rec;
-    }
-    if (f_long) v.LL[ql] = o;
-    if (f_seed) {
-      const uint64_t hd = v.whead[base + p];
-      const int with_len = (int)(hd & 0xffffu), all = (int)((hd >> 16) & 0xffffu), h1 = (int)((hd >> 32) & 0xffffu), h2 = (int)(hd >> 48);
-      v.seed_bin[qs] = (int32_t)qs;
-      v.seed_lo[qs] = (int32_t)qf; v.seed_hi[qs] = (int32_t)(qf + with_len);
-      v.seedL_lo[qs] = (int32_t)ql; v.seedL_hi[qs] = (int32_t)(ql + all - with_len);
-      v.seed_start[qs] = (int32_t)((bin0 + win_bin_low(a)) * v.cfg.cluster_binsize);
-      v.seed_grp[qs] = grp;
-      v.bin_hap[3 * qs + 0] = (uint16_t)(all - h1 - h2); v.bin_hap[3 * qs + 1] = (uint16_t)h1; v.bin_hap[3 * qs + 2] = (uint16_t)h2;
-    }
-    cs += __popcll(bs); cf += __popcll(bn); cl += __popcll(bl);
+// W6: one THREAD per bucket position: the seeds, `leads` (L, packed records) and `leads_long` (LL) at their global places = the
+// offsets of the wave that owns the position (w5's scans) + the rank w4s_segment left in the word.  The pass's one gather (in_rec).
+__global__ void __launch_bounds__(256) w6t_emit(const View v, int64_t n_unused) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= v.cnt->n_valid) return;
+  const uint64_t word = v.key_out[p];
+  const uint32_t hi = (uint32_t)(word >> 32), o = (uint32_t)word;
+  if (!(hi & (SNF_WS_NORM | SNF_WS_LONG))) return;      // (a seed lead is one of the two)
+  const int64_t owner = p / 64 - (int64_t)((hi >> 16) & 31u);
+  const uint32_t rank = (hi >> 4) & 0xfffu;
+  int64_t qf = 0, ql = 0;
+  if (hi & SNF_WS_NORM) {
+    qf = (int64_t)v.ws_nf[owner] + rank;
+    v.L[qf] = o;
+    // the record as four 16-byte words (a LeadRec object patched in place ends up in LDS: "promote alloca")
+    const uint4* src = (const uint4*)&v.in_rec[o];
+    uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+    static_assert(offsetof(LeadRec, seq_len) == 20 && offsetof(LeadRec, seq_off) == 24, "words of q1");
+    if ((int32_t)q1.y >= 0 && (hi & SNF_WS_SEQNULL)) { q1.y = 0xffffffffu; q1.z = 0; q1.w = 0; }   // 11th+ lead of a bin: Lead.seq = None
+    uint4* dst = (uint4*)&v.Lrec[qf];
+    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+  } else {
+    ql = (int64_t)v.ws_nl[owner] + rank;
+    v.LL[ql] = o;
+  }
+  if (hi & SNF_WS_SEED) {
+    const uint64_t hd = v.whead[p], h2 = v.whead2[p];
+    const uint32_t other = (uint32_t)(h2 >> 52);
+    if (hi & SNF_WS_NORM) ql = (int64_t)v.ws_nl[owner] + other; else qf = (int64_t)v.ws_nf[owner] + other;
+    const int64_t qs = (int64_t)v.ws_seeds[owner] + (hi >> 21);
+    const int with_len = (int)(hd & 0xffffu), all = (int)((hd >> 16) & 0xffffu), h1 = (int)((hd >> 32) & 0xffffu), hh2 = (int)(hd >> 48);
+    v.seed_bin[qs] = (int32_t)qs;
+    v.seed_lo[qs] = (int32_t)qf; v.seed_hi[qs] = (int32_t)(qf + with_len);
+    v.seedL_lo[qs] = (int32_t)ql; v.seedL_hi[qs] = (int32_t)(ql + all - with_len);
+    v.seed_start[qs] = (int32_t)(uint32_t)h2;
+    v.seed_grp[qs] = (int)((h2 >> 32) & 0xfffffu);
+    v.bin_hap[3 * qs + 0] = (uint16_t)(all - h1 - hh2); v.bin_hap[3 * qs + 1] = (uint16_t)h1; v.bin_hap[3 * qs + 2] = (uint16_t)hh2;
   }
 }
 

@@ -184,9 +184,11 @@ struct View {
   const int64_t* t_win_off;   // [T+1] first window of task t
   uint32_t *wcnt, *wfill;     // [NW+1] leads per window / fill cursor of the scatter (both zero between passes)
   uint32_t* wbase;            // [NW+1] bucket offsets (exclusive scan of wcnt)
-  uint32_t* wlist;            // [3 x n_occ] occupied windows, ascending: {window, leads, bucket offset}
-  uint32_t *ws_seeds, *ws_nf, *ws_nl;   // [n_occ+1] per occupied window: seeds / `leads` / `leads_long` it contributes, then their exclusive scans
+  uint32_t* wlist;            // [4 x n_occ] occupied windows, ascending: {window, leads, bucket offset, task}
+  uint32_t* blk_k0;           // [N / 64 + 2] per 64 positions of the bucket array: the first occupied window starting there or behind
+  uint32_t *ws_seeds, *ws_nf, *ws_nl;   // [N / 64 + 2] per wave of w4s_segment: seeds / `leads` / `leads_long` it contributes, then their exclusive scans
   uint64_t* whead;            // [N] per seed head (bucket position): leads with a length | leads << 16 | hap 1 << 32 | hap 2 << 48
+  uint64_t* whead2;           // [N] ... seed start | group << 32 | offset in the other lead list of the wave << 52
   // ---- stage A: binning (sorted position p in [0,NS))
   uint64_t *key_in, *key_out; uint32_t *val_in, *val_out;   // uint32_t keys when key32
   int key32, key_bin_bits, key_nbits;  // sort key = grp << key_bin_bits | bin; bit key_nbits set: lead outside its contig
@@ -278,8 +280,9 @@ struct View {
   // refined clusters handed on by the grouped call kernels (snf_wave_call_g.h): list 0 more than 8 leads (d2g_call<8> -> <32>),
   // list 1 more than 32 (-> d2w_call).  64 stripes per list (stripe = workgroup & 63) with a counter each, d2cnt[(list * 64 +
   // stripe) * 16]: ten thousand returning atomics on ONE counter took 0.1 ms by themselves.  Stripe s owns d2_list[k][s * d2cap ...)
-  int32_t* d2_list[2]; uint32_t* d2cnt; int64_t d2cap;
-  int32_t d2_from_list, _pad_d2;   // != 0: this launch of d2w_call takes its refined clusters from d2_list[d2_from_list - 1]
+  // list 2: merged clusters of more than 8 leads, handed by d1g_refine<8> to d1w_refine (snf_wave_refine_g.h)
+  int32_t* d2_list[3]; uint32_t* d2cnt; int64_t d2cap;
+  int32_t d2_from_list, d1_from_list;   // != 0: this launch of d2w_call takes its refined clusters from d2_list[d2_from_list - 1] / d1w_refine its clusters from list 2
   int32_t* cls_list[8];      // cons ids per work list (see Counts::n_cls; 6 unused), appended with wave-aggregated atomics
   // clusters / refined clusters / calls with more than 64 leads, collected by the wave kernels (kind 0 d1w_refine, 1 d2w_call,
   // 2 e1w_finalize) in 64 stripes (item & 63) and served one wave each by x_big<kind> (snf_wave_call.h)

@@ -67,6 +67,23 @@ SNF_D void big_push(const View& v, int kind, int32_t item) {
   v.big_list[((int64_t)kind * 64 + s) * v.big_cap + slot] = item;
 }
 
+// hand-over list 2 (clusters d1g_refine<8> left to d1w_refine): 64 stripes with a counter each, as the lists of the call kernels
+// (snf_wave_call.h); consumer side: prefix of the stripes' counts in LDS, item i = entry i - pre[s] of stripe s
+SNF_D int64_t d1list_prefix(const View& v, int lane, int32_t* pre) {
+  int32_t cnt = (int32_t)v.d2cnt[(2 * 64 + lane) * 16];
+  if (cnt > (int32_t)v.d2cap) cnt = (int32_t)v.d2cap;       // (overflowed stripe: flagged by the producer, the fetch fails)
+  const int32_t inc = wave_incl_scan(cnt, lane);
+  if (lane == 0) pre[0] = 0;
+  pre[lane + 1] = inc;
+  __syncthreads();
+  return pre[64];
+}
+SNF_D int32_t d1list_at(const View& v, int64_t i, const int32_t* pre) {
+  int lo = 0, hi = 63;   // last stripe s with pre[s] <= i
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= (int32_t)i) lo = mid; else hi = mid - 1; }
+  return v.d2_list[2][(int64_t)lo * v.d2cap + (i - pre[lo])];
+}
+
 struct WaveLds {
   int32_t perm[SNF_WAVE];      // scatter target for permutations
   int32_t seg_start[SNF_WAVE]; // resplit: segment (distinct bin) start position in sorted order
@@ -95,22 +112,30 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
   __shared__ WaveLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
-  const int64_t n_clusters = v.cnt->n_clusters;
+  // the clusters of this launch: all of them, or (View::d1_from_list) those d1g_refine<8> handed on through list 2
+  __shared__ int32_t d1pre[65];
+  const bool from_list = v.d1_from_list != 0;
+  const int64_t n_clusters = from_list ? d1list_prefix(v, lane, d1pre) : v.cnt->n_clusters;
+  auto CL = [&](int64_t it) -> int64_t { return from_list ? (int64_t)d1list_at(v, it, d1pre) : it; };
   // software pipeline over this wave's clusters: the header of cluster k+2 and the lead records of cluster k+1 are
   // in flight while cluster k is processed (the kernel is bound by dependent global-load latency, not bandwidth)
   const int64_t stride = gridDim.x;
-  ClusterHdr hd_cur = blockIdx.x < n_clusters ? v.chdr[blockIdx.x] : ClusterHdr{};
-  ClusterHdr hd_nxt = blockIdx.x + stride < n_clusters ? v.chdr[blockIdx.x + stride] : ClusterHdr{};
+  int64_t c_cur = blockIdx.x < n_clusters ? CL(blockIdx.x) : 0, c_nxt = blockIdx.x + stride < n_clusters ? CL(blockIdx.x + stride) : 0;
+  ClusterHdr hd_cur = blockIdx.x < n_clusters ? v.chdr[c_cur] : ClusterHdr{};
+  ClusterHdr hd_nxt = blockIdx.x + stride < n_clusters ? v.chdr[c_nxt] : ClusterHdr{};
   LeadRec rec_cur{};
   if (lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
   SNF_RT_DECL
-  int64_t slice_used = 0;     // bytes of this wave's private fused-sequence slice that are taken
-  for (int64_t c = blockIdx.x; c < n_clusters; c += stride) {
+  // bytes of this wave's private fused-sequence slice that are taken (behind d1g_refine<8> the second half of the slice: the
+  // first is that kernel's)
+  int64_t slice_used = from_list ? (v.pool_slice >> 1) : 0;
+  for (int64_t it = blockIdx.x; it < n_clusters; it += stride) {
     SNF_RT(5);   // tail of the previous cluster (stores, resplit)
     const ClusterHdr hd = hd_cur; const LeadRec rec = rec_cur;
-    hd_cur = hd_nxt;
-    if (c + stride < n_clusters && lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
-    if (c + 2 * stride < n_clusters) hd_nxt = v.chdr[c + 2 * stride];
+    const int64_t c = c_cur;
+    hd_cur = hd_nxt; c_cur = c_nxt;
+    if (it + stride < n_clusters && lane < hd_cur.n && hd_cur.n <= SNF_WAVE) rec_cur = v.Lrec[hd_cur.lo + lane];
+    if (it + 2 * stride < n_clusters) { c_nxt = CL(it + 2 * stride); hd_nxt = v.chdr[c_nxt]; }
     const int32_t lo = hd.lo, n = hd.n;
     if (n > SNF_WAVE) { if (lane == 0) big_push(v, 0, (int32_t)c); continue; }   // big clusters: x_big<0>
     if (n <= 0) continue;
