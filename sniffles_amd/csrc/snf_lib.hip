@@ -1473,7 +1473,8 @@ void enqueue_output_head(snf_batch_impl* b) {
     }
     { Scope _s(b, "f4_emit", 0);
       v.rn_from_src = rn_src ? 1 : 0;
-      hipLaunchKernelGGL(f4w_emit, dim3(grid < 2048u ? grid : 2048u), dim3(256), 0, b->cur, v, (int64_t)0);
+      static const unsigned f4cap = getenv("SNF_F4_GRID") && atoi(getenv("SNF_F4_GRID")) > 0 ? (unsigned)atoi(getenv("SNF_F4_GRID")) : 2048u;   // experiments
+      hipLaunchKernelGGL(f4w_emit, dim3(grid < f4cap ? grid : f4cap), dim3(256), 0, b->cur, v, (int64_t)0);
       v.rn_from_src = 0;
       SNF_HIP(hipGetLastError()); }
   } else {
@@ -1593,12 +1594,14 @@ void run_finalize(snf_batch_impl* b) {
   {  // pinned block for the result: sized from the input, grown by the fetch when a result did not fit
     const size_t want = (size_t)((v.out_mode & SNF_OUT_EXECUTE) ? 8 : 16) * (size_t)(v.N > 0 ? v.N : 1) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_out.external && b->hb_out.cap < want) b->hb_out.ensure(want);
-    v.out_pin = (v.out_mode & SNF_OUT_DEVICE) ? nullptr : (uint8_t*)b->hb_out.p;
-    v.out_pin_cap = (v.out_mode & SNF_OUT_DEVICE) ? 0 : (int64_t)b->hb_out.cap;
+    static const int stage_env = getenv("SNF_STAGE_OUT") ? atoi(getenv("SNF_STAGE_OUT")) : 0;   // measurement: the whole result through HBM, copied at fetch
+    const bool out_hbm = (v.out_mode & SNF_OUT_DEVICE) || stage_env == 1;
+    v.out_pin = out_hbm ? nullptr : (uint8_t*)b->hb_out.p;
+    v.out_pin_cap = out_hbm ? 0 : (int64_t)b->hb_out.cap;
     // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
     const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_alt.external && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
-    static const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr;   // measurement: ALT bytes into the HBM pool, copied at fetch
+    static const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr || stage_env == 1;   // measurement: ALT bytes into the HBM pool, copied at fetch
     v.alt_pin = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? nullptr : (uint8_t*)b->hb_alt.p;
     v.alt_pin_cap = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? 0 : (int64_t)b->hb_alt.cap;
   }

@@ -175,94 +175,120 @@ SNF_D int wave_runmax(int x, int carry) {
 // W4: one wave per SEGMENT of the bucket array.  Wave i owns the occupied windows whose bucket starts in positions [64 i, 64 i + 64)
 // (blk_k0, written by w2): a handful of small windows - a window of a 30x genome holds ~23 leads, most hold fewer than eight - or
 // one large one that reaches into the following blocks.  One lead per lane and round, whatever window it belongs to: every wave-wide
-// step of the old wave-per-window kernel (ballots, running maxima, the rank sort's broadcast reads) works on the lead's own window
-// through its start and length in LDS.  CAP: leads the largest window may hold (the host picks the instance).
+// step of the old wave-per-window kernel (ballots, running maxima, the rank sort's broadcast reads) works on the lead's own window.
+// The sort key of a lead carries its window's index in the wave above (bin, input index): a rank loop that runs past the end of a
+// window only meets larger keys, so it needs no bound per lane - one LDS read at an immediate offset, one compare, one add per step.
+// CAP: leads the largest window may hold (the host picks the instance).
+//   key = window in the wave << 47 | bin in the window << 35 | input index << 3 | hap << 1 | is_long
+SNF_D uint64_t wkey_make(uint32_t widx, uint64_t word) {
+  const uint32_t a = (uint32_t)(word >> 32);
+  return ((uint64_t)widx << 47) | ((uint64_t)win_bin_low(a) << 35) | ((uint64_t)(uint32_t)word << 3) | ((uint64_t)win_hap(a) << 1) | (win_is_long(a) ? 1ull : 0ull);
+}
+SNF_D uint32_t wkey_group(uint64_t k) { return (uint32_t)(k >> 35); }     // (window, bin): equal for the leads of one bin
+SNF_D uint32_t wkey_bin(uint64_t k) { return (uint32_t)(k >> 35) & 0xfffu; }
+SNF_D uint32_t wkey_widx(uint64_t k) { return (uint32_t)(k >> 47); }
+SNF_D uint32_t wkey_index(uint64_t k) { return (uint32_t)(k >> 3); }
+SNF_D bool wkey_long(uint64_t k) { return (k & 1ull) != 0; }
+SNF_D uint32_t wkey_hap(uint64_t k) { return (uint32_t)(k >> 1) & 3u; }
+
 template <int CAP>
 __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused) {
-  constexpr int CAPW = CAP + 64, E = CAPW / 64;
-  __shared__ uint64_t keys[CAPW];
-  __shared__ uint16_t widx[CAPW], hpos[CAPW];
+  constexpr int CAPW = CAP + 64, E = CAPW / 64, PAD = 8;
+  __shared__ uint64_t keys[CAPW + CAP + PAD];  // by position relative to the block's first (64 i); sorted in place; behind them "infinity"
+  __shared__ uint16_t widx[CAPW];              // window marks, later the head position of every lead's bin
+  uint16_t* const hpos = widx;
   __shared__ uint32_t sA[CAPW], sB[CAPW];      // per bin (at its head position): leads | leads with a length << 16;  hap 1 | hap 2 << 16
-  __shared__ uint32_t wS[64], wN[64], wG[64], wB[64];   // per window of the wave: first position (relative), leads, group, first bin
+  __shared__ uint32_t wS[64], wG[64], wB[64];  // per window of the wave: first position (relative), group, first bin
   const int lane = threadIdx.x;
-  const int64_t i = blockIdx.x;
+  const int64_t i = blockIdx.x, B0 = 64 * i;
   const int64_t n_valid = v.cnt->n_valid;
+  // the first 64 positions are this block's own: their words are requested before the wave knows which of them it owns
+  uint64_t w0 = 0;
+  if (B0 + lane < n_valid) w0 = v.key_in[B0 + lane];
   uint32_t k0 = 0, k1 = 0;
-  if (64 * i < n_valid) { k0 = v.blk_k0[i]; k1 = 64 * (i + 1) <= n_valid ? v.blk_k0[i + 1] : (uint32_t)v.cnt->n_occ; }
+  if (B0 < n_valid) { k0 = v.blk_k0[i]; k1 = B0 + 64 <= n_valid ? v.blk_k0[i + 1] : (uint32_t)v.cnt->n_occ; }
   const int nw = (int)(k1 - k0);                 // <= 64: every window holds a lead and starts inside the block
   if (nw <= 0) { if (lane == 0) { v.ws_seeds[i] = 0; v.ws_nf[i] = 0; v.ws_nl[i] = 0; } return; }
   uint4 wr = make_uint4(0, 0, 0, 0);             // {window, leads, bucket offset, task}
   if (lane < nw) wr = ((const uint4*)v.wlist)[k0 + lane];
-  const int64_t P0 = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wr.z);
-  const int64_t P1 = (int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wr.z + wr.y), nw - 1);
-  const int M = (int)(P1 - P0);                  // <= 63 + CAP
+  const int xlo = (int)((int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wr.z) - B0);                 // owned positions: [xlo, xhi)
+  const int xhi = (int)((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wr.z + wr.y), nw - 1) - B0);   // <= 63 + CAP
+  uint64_t wd[E];
+  wd[0] = w0;
+#pragma unroll
+  for (int j = 1; j < E; j++) { const int x = lane + 64 * j; wd[j] = x < xhi ? v.key_in[B0 + x] : 0ull; }
   if (lane < nw) {
     const int t = (int)wr.w;
-    const int64_t w0 = v.t_win_off[t], nwin = (v.t_win_off[t + 1] - w0) / SNF_NTYPES, rem = (int64_t)wr.x - w0;
-    wS[lane] = (uint32_t)((int64_t)wr.z - P0); wN[lane] = wr.y; wG[lane] = (uint32_t)(t * 8 + (int)(rem / nwin)); wB[lane] = (uint32_t)((rem % nwin) << v.win_bits);
+    const int64_t o0 = v.t_win_off[t], nwin = (v.t_win_off[t + 1] - o0) / SNF_NTYPES, rem = (int64_t)wr.x - o0;
+    wS[lane] = (uint32_t)((int64_t)wr.z - B0); wG[lane] = (uint32_t)(t * 8 + (int)(rem / nwin)); wB[lane] = (uint32_t)((rem % nwin) << v.win_bits);
   }
-  uint64_t e[E];
 #pragma unroll
-  for (int j = 0; j < E; j++) {
-    const int x = lane + 64 * j;
-    e[j] = x < M ? v.key_in[P0 + x] : ~0ull;
-    if (x < M) { keys[x] = e[j]; sA[x] = 0; sB[x] = 0; widx[x] = 0; }
-  }
+  for (int j = 0; j < E; j++) { const int x = lane + 64 * j; if (x < xhi) { sA[x] = 0; sB[x] = 0; widx[x] = 0; } }
+  // what a rank loop reads behind the last window: it runs as far as the wave's largest window is long, from any window's start
+  const int nall = __shfl(wave_incl_max(lane < nw ? (int)wr.y : 0), 63, 64);
+  for (int p = lane; p < nall + PAD; p += 64) keys[xhi + p] = ~0ull;
   __syncthreads();
   if (lane < nw) widx[wS[lane]] = (uint16_t)(lane + 1);
   __syncthreads();
-  // the window of every position: a running maximum over the marks at the windows' first positions
-  int wi[E];
+  // the window of every position (a running maximum over the marks at the windows' first positions) -> its sort key
+  uint64_t e[E];
+  int nmax_r[E];      // per round: the largest number of keys a lane's window holds from the lane's window start on
   {
     int carry = 0;
 #pragma unroll
     for (int j = 0; j < E; j++) {
-      wi[j] = 0;
-      if (64 * j < M) {
+      e[j] = 0; nmax_r[j] = 0;
+      if (64 * j < xhi) {
         const int x = lane + 64 * j;
-        const int m = wave_runmax(x < M ? (int)widx[x] : 0, carry);
-        wi[j] = m - 1;
+        const int m = wave_runmax(x < xhi ? (int)widx[x] : 0, carry);
         carry = __shfl(m, 63, 64);
+        const bool own = x >= xlo && x < xhi;
+        if (own) e[j] = wkey_make((uint32_t)(m - 1), wd[j]);
+        if (x < xhi) keys[x] = e[j];
       }
     }
   }
-  // rank sort by (bin, arrival) inside every window: keys are distinct (the input index is part of them); the lanes of a window read
-  // the same LDS word per step (a broadcast per window).  (The attribute bits above the bin do not disturb the order: masked.)
-  const uint64_t mask = ((uint64_t)0xfffu << 32) | 0xffffffffull;
+  __syncthreads();
+  // rank sort by (bin, arrival) inside every window
   int r[E], ws[E];
 #pragma unroll
   for (int j = 0; j < E; j++) {
     r[j] = 0; ws[j] = 0;
-    if (64 * j < M) {
+    if (64 * j < xhi) {
       const int x = lane + 64 * j;
-      const int n = x < M ? (int)wN[wi[j]] : 0;
-      ws[j] = x < M ? (int)wS[wi[j]] : 0;
-      const int nmax = __shfl(wave_incl_max(n), 63, 64);
-      const uint64_t ek = e[j] & mask;
-      for (int q = 0; q < nmax; q++) {
-        const uint64_t kq = keys[q < n ? ws[j] + q : 0] & mask;
-        r[j] += (q < n && kq < ek) ? 1 : 0;
+      const bool own = x >= xlo && x < xhi;
+      const int wl = own ? (int)wkey_widx(e[j]) : 0;
+      ws[j] = own ? (int)wS[wl] : 0;
+      const int wend = own ? (wl + 1 < nw ? (int)wS[wl + 1] : xhi) : 0;
+      const int nmax = __shfl(wave_incl_max(wend - ws[j]), 63, 64);
+      const uint64_t* kp = keys + ws[j];
+      const uint64_t ek = e[j];
+      for (int q = 0; q < nmax; q += PAD) {
+#pragma unroll
+        for (int u = 0; u < PAD; u++) r[j] += kp[q + u] < ek ? 1 : 0;
       }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < E; j++) if (lane + 64 * j < M) keys[ws[j] + r[j]] = e[j];
+  for (int j = 0; j < E; j++) { const int x = lane + 64 * j; if (x >= xlo && x < xhi) keys[ws[j] + r[j]] = e[j]; }
   __syncthreads();
   // bin heads and the head position of every lead
+  uint64_t sk[E];
   {
     int carry = -1;
 #pragma unroll
     for (int j = 0; j < E; j++) {
       const int x = lane + 64 * j;
-      if (64 * j < M) {
+      sk[j] = 0;
+      if (64 * j < xhi) {
         int h = -1;
-        if (x < M) {
-          const uint32_t bn = win_bin_low((uint32_t)(keys[x] >> 32));
-          if (x == ws[j] || win_bin_low((uint32_t)(keys[x - 1] >> 32)) != bn) h = x;
+        if (x >= xlo && x < xhi) {
+          sk[j] = keys[x];
+          if (x == xlo || wkey_group(keys[x - 1]) != wkey_group(sk[j])) h = x;
         }
         const int m = wave_runmax(h, carry);
-        if (x < M) hpos[x] = (uint16_t)m;
+        if (x >= xlo && x < xhi) hpos[x] = (uint16_t)m;
         carry = __shfl(m, 63, 64);
       }
     }
@@ -271,12 +297,11 @@ __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused
 #pragma unroll
   for (int j = 0; j < E; j++) {
     const int x = lane + 64 * j;
-    if (64 * j >= M) break;
-    if (x < M) {
-      const uint32_t a = (uint32_t)(keys[x] >> 32);
+    if (64 * j >= xhi) break;
+    if (x >= xlo && x < xhi) {
       const int h = hpos[x];
-      atomicAdd(&sA[h], 1u + (win_is_long(a) ? 0u : (1u << 16)));
-      const uint32_t hp = win_hap(a);
+      atomicAdd(&sA[h], 1u + (wkey_long(sk[j]) ? 0u : (1u << 16)));
+      const uint32_t hp = wkey_hap(sk[j]);
       if (hp) atomicAdd(&sB[h], hp == 1 ? 1u : (1u << 16));
     }
   }
@@ -286,31 +311,31 @@ __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused
 #pragma unroll
   for (int j = 0; j < E; j++) {
     const int x = lane + 64 * j;
-    if (64 * j >= M) break;
+    if (64 * j >= xhi) break;
+    const bool own = x >= xlo && x < xhi;
     bool f_seed = false, f_norm = false, f_long = false, f_null = false;
-    uint64_t key = 0; uint32_t a = 0; int h = 0, all = 0, with_len = 0;
-    if (x < M) {
-      key = keys[x]; a = (uint32_t)(key >> 32); h = hpos[x];
+    int h = 0, all = 0, with_len = 0;
+    if (own) {
+      h = hpos[x];
       const uint32_t A = sA[h];
       all = (int)(A & 0xffffu); with_len = (int)(A >> 16);
       const bool elig = with_len >= v.cfg.dev_min_leads_cluster;
-      f_norm = elig && !win_is_long(a); f_long = elig && win_is_long(a); f_seed = elig && x == h;
+      f_norm = elig && !wkey_long(sk[j]); f_long = elig && wkey_long(sk[j]); f_seed = elig && x == h;
       f_null = x - h + 1 > v.cfg.consensus_max_reads_bin;      // leadprov.py:406-408 (counts every lead of the bin)
     }
     const unsigned long long bn = __ballot(f_norm), bl = __ballot(f_long), bs = __ballot(f_seed);
     const uint32_t rn = (uint32_t)(cf + __popcll(bn & below)), rl = (uint32_t)(cl + __popcll(bl & below)), rs = (uint32_t)(cs + __popcll(bs & below));
-    if (x < M) {
-      const uint32_t delta = (uint32_t)((P0 + x) / 64 - i);
+    if (own) {
       const uint32_t hi = (f_norm ? SNF_WS_NORM : 0u) | (f_long ? SNF_WS_LONG : 0u) | (f_null ? SNF_WS_SEQNULL : 0u) | (f_seed ? SNF_WS_SEED : 0u) |
-                          ((f_norm ? rn : rl) << 4) | (delta << 16) | (f_seed ? rs << 21 : 0u);
-      v.key_out[P0 + x] = ((uint64_t)hi << 32) | (key & 0xffffffffull);
+                          ((f_norm ? rn : rl) << 4) | ((uint32_t)j << 16) | (f_seed ? rs << 21 : 0u);
+      v.key_out[B0 + x] = ((uint64_t)hi << 32) | (uint64_t)wkey_index(sk[j]);
       if (f_seed) {
         const uint32_t B = sB[h];
-        const int wl = wi[j];
-        const int64_t start = ((int64_t)wB[wl] + (int64_t)win_bin_low(a)) * v.cfg.cluster_binsize;
-        v.whead[P0 + x] = (uint64_t)with_len | ((uint64_t)all << 16) | ((uint64_t)(B & 0xffffu) << 32) | ((uint64_t)(B >> 16) << 48);
+        const int wl = (int)wkey_widx(sk[j]);
+        const int64_t start = ((int64_t)wB[wl] + (int64_t)wkey_bin(sk[j])) * v.cfg.cluster_binsize;
+        v.whead[B0 + x] = (uint64_t)with_len | ((uint64_t)all << 16) | ((uint64_t)(B & 0xffffu) << 32) | ((uint64_t)(B >> 16) << 48);
         // seed start | group << 32 | the seed's offset in the OTHER list (`leads_long` for a seed lead with a length and vice versa) << 52
-        v.whead2[P0 + x] = (uint64_t)(uint32_t)(int32_t)start | ((uint64_t)wG[wl] << 32) | ((uint64_t)(f_norm ? rl : rn) << 52);
+        v.whead2[B0 + x] = (uint64_t)(uint32_t)(int32_t)start | ((uint64_t)wG[wl] << 32) | ((uint64_t)(f_norm ? rl : rn) << 52);
       }
     }
     cs += __popcll(bs); cf += __popcll(bn); cl += __popcll(bl);

@@ -302,8 +302,8 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
     }
     {
       const int rb = cfg.cluster_resplit_binsize;
-      const int64_t av = f_svlen < 0 ? -(int64_t)f_svlen : f_svlen;
-      const int32_t bin = (int32_t)((av / rb) * rb);
+      const uint32_t av = f_svlen < 0 ? (uint32_t)(-(int64_t)f_svlen) : (uint32_t)f_svlen;      // (32-bit: a 64-bit division is ~150 instructions here)
+      const int32_t bin = (int32_t)((av / (uint32_t)rb) * (uint32_t)rb);
       // one bin (wave-uniform test): the cluster stays whole, in its order
       if (__ballot(fact && bin != __builtin_amdgcn_readfirstlane(bin)) == 0ull) {
         if (fact) v.FI[lo + lane] = lo + lane;

@@ -31,6 +31,43 @@ class Task:
         self.coverage_average_total = None
         self._batch = None
         self._ti = None
+        self._prep = None
+
+    def prepare(self, config, execute=None):
+        """Start this task's upload and its pass in the background; the next `call_candidates` (execute=None) / `call_records` /
+        `execute_calls` (execute=False / True) on this task picks the running work up instead of starting it.  A worker loop that
+        calls `tasks[k + 1].prepare(config)` before it turns task k's records into objects overlaps the two (the library calls release
+        the GIL; every task has its own batch handle and streams): the reference's worker processes get the same overlap from being
+        several (`sniffles:495-530`).  Optional: a task that was not prepared does the same work when it is called."""
+        import threading
+        if self._prep is not None:
+            return
+        box = {"mode": execute, "err": None}
+
+        def body():
+            try:
+                self._open(config)
+                if execute is None:
+                    self._batch.call_candidates()
+                else:
+                    from .abi import OUT_CANDIDATES, OUT_EXECUTE
+                    self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
+                    self._batch.run_pass()
+            except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
+                box["err"] = e
+        box["thread"] = threading.Thread(target=body, daemon=True)
+        self._prep = box
+        box["thread"].start()
+
+    def _prepared(self, execute) -> bool:
+        """True: `prepare` has already enqueued exactly this call's device work on this task's batch."""
+        box, self._prep = self._prep, None
+        if box is None:
+            return False
+        box["thread"].join()
+        if box["err"] is not None:
+            raise box["err"]
+        return box["mode"] == execute and self._batch is not None
 
     def _open(self, config):
         lp = self.lead_provider
@@ -38,7 +75,7 @@ class Task:
             lp.end = self.end
         self._ti = lp.to_task_input(self.id, self.sv_id, self.tandem_repeats,
                                     getattr(config, "qc_nm_threshold", 0.02))
-        self.close()
+        self._release()
         self._batch = lib.Batch(config, [self._ti], device=self.device)
         lp.device_batch = self._batch   # SNFile.annotate_block_coverages(lead_provider) reads the coverage from HBM
         lp.task_input = self._ti        # cluster.resolve(svtype, lead_provider, ...) reads the clusters back (seam B3)
@@ -46,6 +83,12 @@ class Task:
     def close(self):
         """Release the task's device memory.  The batch outlives finalize_candidates because the SNF writer needs the
         read table afterwards (CallTask.execute, parallel.py:278-291); it goes with the task otherwise."""
+        if getattr(self, "_prep", None) is not None:
+            self._prep["thread"].join()
+            self._prep = None
+        self._release()
+
+    def _release(self):
         if self._batch is not None:
             self._batch.close()
             self._batch = None
@@ -53,9 +96,10 @@ class Task:
             self.lead_provider.device_batch = None
 
     def call_candidates(self, keep_qc_fails, config, svcall_cls=sv.SVCall, bnd_cls=sv.SVCallBNDInfo) -> list:
-        self._open(config)
+        if not self._prepared(None):
+            self._open(config)
+            self._batch.call_candidates()
         self._finalized = False
-        self._batch.call_candidates()
         if getattr(config, "dev_dump_clusters", False):      # cluster.py:316-324, one file per SV type
             from . import cluster
             from .soa import SVTYPES
@@ -83,9 +127,10 @@ class Task:
         The arrays of the result are VIEWS of the batch's pinned block: they die with `close()` or the next call on this task
         (the buffer is handed to the next batch) - copy what has to outlive it."""
         from .abi import OUT_CANDIDATES, OUT_EXECUTE
-        self._open(config)
-        self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
-        self._batch.run_pass()            # call_candidates + finalize (both only enqueue; the fetch is the one wait)
+        if not self._prepared(bool(execute)):
+            self._open(config)
+            self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
+            self._batch.run_pass()            # call_candidates + finalize (both only enqueue; the fetch is the one wait)
         res = self._batch.fetch(1, copy=False)
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")

@@ -101,7 +101,23 @@ def run_case(name, _lib):
         return repr(d)
     assert [flat(c) for c in kept] == [flat(c) for c in want]
     assert task2.sv_id == task.sv_id and task2.coverage_average_total == task.coverage_average_total
-    task.close(); task2.close()
+    # the same two shapes with the device work started ahead of the call (Task.prepare: a worker loop's two-deep pipeline): same objects
+    task3 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task4 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    for t_ in (task3, task4):
+        t_.lead_provider, t_.tandem_repeats = lp, task.tandem_repeats
+    task3.prepare(cfg); task4.prepare(cfg, execute=True)
+    cands3 = task3.call_candidates(True, cfg)
+    assert [as_record(c, "cand") for c in cands3] == exp["candidates"]
+    assert [as_record(c, "final") for c in task3.finalize_candidates(cands3, False, cfg)] == exp["final"]
+    assert [flat(c) for c in task4.execute_calls(cfg)] == [flat(c) for c in want]
+    assert task4.sv_id == task.sv_id
+    task5 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task5.lead_provider, task5.tandem_repeats = lp, task.tandem_repeats
+    task5.prepare(cfg, execute=True)               # prepared for another call than the one that comes: redone, not reused
+    assert [as_record(c, "cand") for c in task5.call_candidates(True, cfg)] == exp["candidates"]
+    for t_ in (task, task2, task3, task4, task5):
+        t_.close()
 
 
 NAMES = ["bnd_first_error", "bnd_stale_end", "merge_inner", "long_ins", "phase_rescue", "consensus_quirks",
