@@ -217,6 +217,24 @@ def main():
         out = bench_population.run(ctx)
     else:
         out = run_calling(ctx)
+        # N > 1, default (weak) scaling: the SAME line also carries the strong-scaling value - ONE genome over the N ranks (north_star's
+        # "30x whole genome at 1/2/4/8 MI355X") - measured by a second run of the same command's ranks over the contig-set queue
+        if world > 1 and args.scaling == "weak" and os.environ.get("SNF_BENCH_NO_STRONG") != "1":
+            import copy
+            a2 = copy.copy(args)
+            a2.scaling, a2.no_cpu_baseline, a2.no_wall_clock, a2.no_configs = "strong", True, True, True
+            try:
+                out2 = run_calling(dict(ctx, args=a2))
+                if rank == 0:
+                    out["strong"] = dict(value=out2["value"], unit=out2["unit"], ms_per_step=out2["ms_per_step"], steps=out2["steps"], scaling="strong",
+                                         signatures=out2["config"]["signatures"], calls=out2["config"]["calls"], parallelism=out2["config"]["parallelism"],
+                                         gathered_on_rank0=out2["config"]["gathered_on_rank0"], ranks_seen=out2.get("ranks_seen"),
+                                         sets_served=out2.get("sets_served"),
+                                         note="ONE genome over the ranks of this run (one LPT-balanced contig set per rank and pass, claimed from the "
+                                              "work queue); `value` of the line is the weak-scaling figure (N genome replicas)")
+            except Exception as e:  # noqa: BLE001 - the weak line stands on its own
+                if rank == 0:
+                    out["strong"] = dict(error=f"{type(e).__name__}: {str(e)[:400]}")
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -459,6 +477,7 @@ def run_calling(ctx):
         dev_sync(torch)
 
     n_calls_box = [0]
+    served_box = [0]          # device batches (weak: passes, strong: contig sets) this rank ran inside the timed region
 
     def run_threads(fn_of_w):
         if W == 1:
@@ -492,10 +511,12 @@ def run_calling(ctx):
                     send_free[slot].clear()
                     handles_box[0][w][0].set_result_memory(*landing.memory(slot))
                     one_pass(w)
+                    served_box[0] += 1
                     n_calls_box[0] = lay_box[w]["n_calls"]
                     comm_q.put((slot, lay_box[w], task_ids_local))
                     continue
                 n_calls_box[0] = one_pass(w)
+                served_box[0] += 1
                 if use_dist:
                     send_free[w].wait()                                # the previous gather of this handle has left the buffer
                     send_free[w].clear()
@@ -533,6 +554,7 @@ def run_calling(ctx):
                     pass_barrier.wait()
                 for g in queues[p]:
                     one_pass(w, g)
+                    served_box[0] += 1
                     if use_dist:                                       # the blocks of the groups this rank served are merged on its host
                         blk = sdist.result_block(handles[w][g].fetch(1))
                         with lock:
@@ -584,6 +606,7 @@ def run_calling(ctx):
                         phase_s[0] += t_b - t_a; phase_s[1] += t_c - t_b; phase_s[2] += t_d - t_c; phase_s[3] += 1
                     with lock:
                         entries[p].append((slot_of(p % NGEN, w, g), lay, g))
+                        served_box[0] += 1
                     g = nxt
                 nxt = queues[p + 1].claim() if p + 1 < total else None
                 with lock:
@@ -599,11 +622,18 @@ def run_calling(ctx):
     import gc
     gc.collect(); gc.disable()           # no collector pauses inside the ~50 ms that are timed
     batches[0].timings_mean_reset()       # the library averages every kernel's HIP-event duration over the passes from here on
+    served_box[0] = 0
     t0 = time.perf_counter()
     run_passes(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     gc.enable()
+    served = served_box[0]
+    ranks_seen, sets_served = 1, [served]
+    if use_dist:              # who took part, and how the device batches of the timed region were spread over the ranks
+        ranks_seen = dist.get_world_size()
+        sets_served = [None] * ranks_seen
+        dist.all_gather_object(sets_served, served)
     if shared and gathered_box[0] is not None:
         gathered_box[0].detach()          # (the passes below write the segments again)
     n_calls = n_calls_box[0]
@@ -712,6 +742,7 @@ def run_calling(ctx):
         out = dict(metric="SV-signatures clustered/sec (clustering + calling + QC + genotype + INS consensus)",
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="int32/f64",
+                   ranks_seen=ranks_seen, sets_served=sets_served,
                    data="synthetic" + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU else "")
                    + (" - SNF_BENCH_CFG overrides the workload's configuration: an ablation, NOT a result" if os.environ.get("SNF_BENCH_CFG") else ""),
                    config=dict(workload=wl["name"] + ", synthetic signature tables (SURVEY.md 8d)", baseline_config=args.config,
@@ -744,7 +775,7 @@ def run_calling(ctx):
                    roofline=roofline)
         if world == 1 and not strong and G == 1:
             if not args.no_wall_clock:
-                out["wall_clock"] = wall_clock(cfg, tasks, local_rank)
+                out["wall_clock"] = wall_clock(cfg, tasks, local_rank, task_specs(args, wl, 0, 0, 1), wl["cfg"])
             if not args.no_cpu_baseline:
                 got = exe = None
                 if not args.no_verify:       # every candidate record against the oracle, and the execute-mode block against its definition
@@ -809,7 +840,29 @@ def bind_to_gpu_numa(torch, local_rank):
         return f"unavailable ({type(e).__name__})"
 
 
-def wall_clock(cfg, tasks, device):
+def worker_processes(specs, cfg_kw, device):
+    """The per-task seam in the reference's deployment shape (tools/bench_workers.py): P worker processes share this GPU, each runs
+    Task.call_candidates + finalize_candidates over its contigs (longest first), two tasks in flight per worker; `leads`: the lead
+    providers hold Lead objects (the one walk that turns them into columns is inside call_candidates), `columns`: typed columns."""
+    from tools import bench_workers
+    out = {}
+    plan = [(4, "columns", "api"), (4, "leads", "api"), (8, "columns", "api"), (8, "columns", "execute"), (8, "leads", "api"),
+            (24, "columns", "api"), (24, "leads", "api")]
+    if os.environ.get("SNF_BENCH_WORKERS"):      # e.g. "8" or "4,24"
+        want = {int(x) for x in os.environ["SNF_BENCH_WORKERS"].split(",") if x}
+        plan = [p for p in plan if p[0] in want]
+    for procs, form, shape in plan:
+        key = f"P{procs}_{form}_{shape}"
+        try:
+            out[key] = bench_workers.run(specs, cfg_kw, procs, form, shape, device)
+        except Exception as e:  # noqa: BLE001 - an extra measurement must not take the line down
+            out[key] = f"failed: {type(e).__name__}: {str(e)[:300]}"
+    out["note"] = ("hot_all_ms = the slowest worker's time over its tasks from a common barrier (inputs built and device context warm before it, as "
+                   "oracle/ref_pool.py times the reference); ingest_all_ms = that worker's Lead objects -> columns walk alone; one MI355X shared by all workers")
+    return out
+
+
+def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
     """One genome end to end through the drop-in boundary, outside the timed region (milliseconds): `batched` = all
     contig tasks in one device batch (the library's native shape); `per_task_api` = the reference's own call sequence,
     Task.call_candidates + Task.finalize_candidates task by task, SVCall objects out (sniffles_amd.parallel)."""
@@ -885,26 +938,34 @@ def wall_clock(cfg, tasks, device):
                    materialise_all_candidates_ms=round(all_ms, 2), candidates=n_all,
                    upload_GBps=round(_input_bytes(tasks) / max(1e-9, t1 - t0) / 1e9, 2),
                    upload_slab_reused_ms=round(warm_ms, 2), end_to_end_slab_reused_ms=round((t4 - t1) * 1e3 + warm_ms, 2))
-    # the reference's worker loop with the one-step drop-in: per contig task CallTask.execute_calls (upload, pass, objects of the kept calls)
-    t7 = time.perf_counter()
-    n3 = 0
-    for ti in tasks:
-        task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                                 tandem_repeats=None, device=device)
-        task.lead_provider = pipeline._Extracted(ti)
-        n3 += len(task.execute_calls(cfg))
-        task.close()
-    t8 = time.perf_counter()
-    t5 = time.perf_counter()
-    n2 = 0
-    for ti in tasks:
-        task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
-                                 tandem_repeats=None, device=device)
-        task.lead_provider = pipeline._Extracted(ti)
-        cands = task.call_candidates(False, cfg)
-        n2 += len(task.finalize_candidates(cands, True, cfg))
-        task.close()
-    t6 = time.perf_counter()
+    # the reference's worker loop, one process: per contig task the two-call seam (Task.call_candidates + finalize_candidates, every candidate
+    # an object) or the one-step drop-in (CallTask.execute_calls: upload, pass, objects of the kept calls).  `pipelined`: the loop keeps two
+    # tasks in flight (Task.prepare: task k + 1 uploads and runs on the device while task k's records become objects)
+    def per_task(shape, pipelined):
+        ts = []
+        for ti in tasks:
+            task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=None, device=device)
+            task.lead_provider = pipeline._Extracted(ti)
+            ts.append(task)
+        ex = True if shape == "execute" else None
+        ta = time.perf_counter()
+        n_ = 0
+        if pipelined and ts:
+            ts[0].prepare(cfg, execute=ex)
+        for k, task in enumerate(ts):
+            if pipelined and k + 1 < len(ts):
+                ts[k + 1].prepare(cfg, execute=ex)
+            if shape == "execute":
+                n_ += len(task.execute_calls(cfg))
+            else:
+                cands = task.call_candidates(False, cfg)
+                n_ += len(task.finalize_candidates(cands, True, cfg))
+            task.close()
+        return (time.perf_counter() - ta) * 1e3, n_
+    exe_serial_ms, n3 = per_task("execute", False)
+    exe_ms, _ = per_task("execute", True)
+    api_serial_ms, n2 = per_task("api", False)
+    api_ms, _ = per_task("api", True)
     # the INPUT half of the object boundary: Lead objects -> LeadProvider.record_lead / record_read -> TaskInput columns
     # (leadprov.py:400-418 on the reference's side).  Measured on the smallest contig task of the workload (building the Lead objects
     # themselves is the extraction's work and is not timed); the genome figure is that rate x all signatures
@@ -934,12 +995,17 @@ def wall_clock(cfg, tasks, device):
         del objs
     except Exception as e:  # noqa: BLE001
         ingest = f"failed: {type(e).__name__}: {e}"
-    return dict(batched=batched, ingest=ingest, per_task_api=dict(end_to_end_ms=round((t6 - t5) * 1e3, 2), tasks=len(tasks), svcalls=n2),
-                per_task_execute=dict(end_to_end_ms=round((t8 - t7) * 1e3, 2), tasks=len(tasks), svcalls=n3),
+    workers = None
+    if specs is not None and not EMU and os.environ.get("SNF_BENCH_NO_WORKERS") != "1":
+        workers = worker_processes(specs, cfg_kw or {}, device)
+    return dict(batched=batched, ingest=ingest, worker_processes=workers,
+                per_task_api=dict(end_to_end_ms=round(api_ms, 2), one_task_at_a_time_ms=round(api_serial_ms, 2), tasks=len(tasks), svcalls=n2),
+                per_task_execute=dict(end_to_end_ms=round(exe_ms, 2), one_task_at_a_time_ms=round(exe_serial_ms, 2), tasks=len(tasks), svcalls=n3),
                 note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
                      "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, sorted; "
                      "materialise_all_candidates_ms: every candidate instead); per_task_api = 24 x Task.call_candidates + finalize_candidates "
-                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x CallTask.execute_calls; "
+                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x CallTask.execute_calls; both with two "
+                     "tasks in flight (Task.prepare: the next task uploads and runs while this one's records become objects), one_task_at_a_time_ms without; "
                      "d2h = results in the library's pinned block (read in place); materialise = SVCall Python objects (host); "
                      "vcf_text_from_records = the QC-passing records as VCF lines straight from the record table (no objects)")
 
@@ -1007,9 +1073,18 @@ def other_configs(ctx) -> dict:
                                ms_per_step=round(dt / (steps // W * W) * 1e3, 3), ms_one_batch_in_flight=round(lat, 3),
                                signatures_per_s=round(n_sig * (steps // W * W) / dt), candidates=int(len(got.calls)), records_returned=int(n_ret),
                                verified=ver["ok"], differences=ver["differences"], cpu_all_core_sig_s=round(base["all_core_sig_s"]),
-                               cpu_cores=base["cores"], seconds=round(time.time() - t_all, 1))
+                               cpu_cores=base["cores"])
             for h in hs:
                 h.close()
+            if not args.no_reference_baseline:       # ... and against the unmodified reference itself, on this box
+                try:
+                    rc = reference_check(a, wl, exe, tasks, specs)
+                    if rc is not None:
+                        out[str(k)].update(rc)
+                        out[str(k)]["vs_reference_all_cores"] = round(out[str(k)]["signatures_per_s"] / max(1, rc["reference_all_core_sig_s"]), 1)
+                except Exception as e:  # noqa: BLE001
+                    out[str(k)]["reference_error"] = f"{type(e).__name__}: {str(e)[:300]}"
+            out[str(k)]["seconds"] = round(time.time() - t_all, 1)
         except Exception as e:  # noqa: BLE001 - the headline must not die with a side measurement
             out[str(k)] = dict(error=f"{type(e).__name__}: {e}")
     try:
@@ -1096,6 +1171,43 @@ def cpu_baseline_and_verify(args, wl, got, task_keys, exe=None, cfg=None):
     return base, ver
 
 
+def reference_differences(r, exe, tasks, task_keys):
+    """The execute-mode block `exe` against what the unmodified reference's CallTask.execute keeps (the records a ref_pool run `r`
+    returned), record by record and field by field: (differences, records compared)."""
+    from sniffles_amd import records
+    got = records.records(exe, tasks, "final")
+    diffs, n_cmp = [], 0
+    for t, key in enumerate(task_keys):
+        exp = r["items"][key]["records"]
+        g = got[t]
+        n_cmp += len(exp)
+        if isinstance(g, dict) or len(g) != len(exp):
+            diffs.append(f"task {t}: {len(exp)} reference records, got {g if isinstance(g, dict) else len(g)}")
+            continue
+        for a, b in zip(g, exp):
+            if a != b:
+                diffs.append(f"task {t} {b['id']}: " + ", ".join(k for k in b if a.get(k) != b.get(k)))
+                if len(diffs) > 5:
+                    break
+    return diffs, n_cmp
+
+
+def reference_check(a, wl, exe, tasks, specs):
+    """A side configuration against the LIVE reference on this box (oracle/_ref through oracle/ref_pool.py): the reference's rate on the
+    host cores and the record-by-record comparison of the execute-mode block.  None where the staged reference is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_pool
+    if not ref_pool.available():
+        return None
+    extra = ["--mosaic"] if wl["cfg"].get("mosaic") else []
+    r = ref_pool.run_tasks(specs, extra, weights=[kw["contig_len"] for _, kw in specs], want_results=True,
+                           max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
+    diffs, n_cmp = reference_differences(r, exe, tasks, [ci for ci, _ in specs])
+    n = sum(m["n_leads"] for m in r["items"].values())
+    return dict(verified_vs_reference=not diffs, records_compared=n_cmp, differences=diffs[:5], reference_all_core_sig_s=round(n / r["hot_all_core_s"]),
+                reference_hot_all_core_s=round(r["hot_all_core_s"], 3), reference_procs=r["procs"], reference_leg_s=round(r["total_wall_s"], 1))
+
+
 def reference_baseline(args, wl, exe, tasks, task_keys, out):
     """`cpu_baseline` with kind = "reference" (SURVEY.md 8d): the UNMODIFIED reference's `Task.call_candidates` +
     `finalize_candidates` (`parallel.py:104-201`) on the same 24 signature tables, one OS process per contig task, pool =
@@ -1130,25 +1242,15 @@ def reference_baseline(args, wl, exe, tasks, task_keys, out):
         vs["wall_clock_per_task_api"] = round(r["hot_all_core_s"] * 1e3 / wc["per_task_api"]["end_to_end_ms"], 1)
         if wc.get("per_task_execute"):
             vs["wall_clock_per_task_execute"] = round(r["hot_all_core_s"] * 1e3 / wc["per_task_execute"]["end_to_end_ms"], 1)
+        if isinstance(wc.get("worker_processes"), dict):
+            vs["wall_clock_worker_processes"] = {k: round(r["hot_all_core_s"] * 1e3 / m["hot_all_ms"], 1)
+                                                 for k, m in wc["worker_processes"].items() if isinstance(m, dict) and m.get("hot_all_ms")}
     vs["note"] = ("reference all-core seconds for one genome / this package's seconds for one genome: gpu_pass = the timed step (inputs in HBM, "
                   "result block on the host); wall_clock_batched = numpy columns -> upload -> pass -> SVCall objects; per_task_api = 24 x "
                   "Task.call_candidates / finalize_candidates")
     base["vs_baseline"] = vs
     if exe is not None:
-        got = records.records(exe, tasks, "final")
-        diffs, n_cmp = [], 0
-        for t, key in enumerate(task_keys):
-            exp = r["items"][key]["records"]
-            g = got[t]
-            n_cmp += len(exp)
-            if isinstance(g, dict) or len(g) != len(exp):
-                diffs.append(f"task {t}: {len(exp)} reference records, got {g if isinstance(g, dict) else len(g)}")
-                continue
-            for a, b in zip(g, exp):
-                if a != b:
-                    diffs.append(f"task {t} {b['id']}: " + ", ".join(k for k in b if a.get(k) != b.get(k)))
-                    if len(diffs) > 5:
-                        break
+        diffs, n_cmp = reference_differences(r, exe, tasks, task_keys)
         base["verified_vs_reference"] = dict(ok=not diffs, records_compared=n_cmp, differences=diffs[:5],
                                              what="the execute-mode block of the timed passes (every field: POS, END, SVLEN, SVTYPE, support, GT/GQ/DR/DV, "
                                                   "filters, fp64 statistics, INS consensus ALT, supporting read names) vs what the unmodified reference's "

@@ -292,6 +292,12 @@ struct snf_batch_impl {
   int graph_mode = 0;             // set at upload: 2 = replay (small batches, or SNF_GRAPH=1), 0 = eager, 1 = replay only while no other batch of
                                   // this process has a pass in flight
   bool in_flight = false;         // counted in g_passes_in_flight
+  bool capturing = false;         // run_pass is capturing this pass into a graph
+  // Result staged through HBM (run_finalize): with another pass in flight on the device the kernels of a pass store the result block
+  // and the ALT section into HBM and two copies take them to the pinned buffers (sizes from the handle's previous pass: same input);
+  // the fetch checks what the pass really produced against what the copies moved
+  bool staged = false; size_t staged_out = 0, staged_alt = 0;
+  int64_t hist_out_bytes = -1, hist_alt_total = -1;
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
@@ -1582,6 +1588,25 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
+// staged result (snf_batch_impl::staged): the copies that take the block / the ALT section from HBM to the pinned buffers, enqueued on
+// the stream their producers ran on.  Sizes are those of the handle's previous pass (same input -> same result); the fetch compares.
+void stage_copy_block(snf_batch_impl* b) {
+  if (!b->staged || b->hist_out_bytes <= 0) return;
+  size_t n = (size_t)b->hist_out_bytes;
+  if (!b->hb_out.p || n > b->hb_out.cap || (int64_t)n > b->v.out_dev_cap) return;
+  Scope _s(b, "d2h_block", (int64_t)n);
+  SNF_HIP(hipMemcpyAsync(b->hb_out.p, b->v.out_dev, n, hipMemcpyDeviceToHost, b->cur));
+  b->staged_out = n;
+}
+void stage_copy_alt(snf_batch_impl* b) {
+  if (!b->staged || b->hist_alt_total <= 0) return;
+  size_t n = (size_t)b->hist_alt_total;
+  if (!b->hb_alt.p || n > b->hb_alt.cap) return;
+  Scope _s(b, "d2h_alt", (int64_t)n);
+  SNF_HIP(hipMemcpyAsync(b->hb_alt.p, b->v.alt_pool, n, hipMemcpyDeviceToHost, b->cur));
+  b->staged_alt = n;
+}
+
 void run_finalize(snf_batch_impl* b) {
   SNF_TRACE("snf_batch_finalize (enqueue)");
   b->pass_idle = false;
@@ -1594,14 +1619,24 @@ void run_finalize(snf_batch_impl* b) {
   {  // pinned block for the result: sized from the input, grown by the fetch when a result did not fit
     const size_t want = (size_t)((v.out_mode & SNF_OUT_EXECUTE) ? 8 : 16) * (size_t)(v.N > 0 ? v.N : 1) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_out.external && b->hb_out.cap < want) b->hb_out.ensure(want);
-    static const int stage_env = getenv("SNF_STAGE_OUT") ? atoi(getenv("SNF_STAGE_OUT")) : 0;   // measurement: the whole result through HBM, copied at fetch
-    const bool out_hbm = (v.out_mode & SNF_OUT_DEVICE) || stage_env == 1;
+    // Where the kernels store the result.  Alone on the device: straight into the pinned buffers (zero-copy stores over PCIe - the
+    // shortest pass).  With ANOTHER pass in flight: into HBM, and two copies behind the kernels take it to the host.  The stores of a
+    // pass are ~19 MB at ~40 GB/s = the last 0.45 ms of its kernels, during which waves that wait for PCIe hold the wave slots, LDS
+    // and registers the other pass's kernels need; staged, those kernels end at HBM speed and the copy engines' traffic overlaps the
+    // other pass's compute (same box, two in flight: 0.945 ms per step against 1.17; one in flight 1.48 against 1.36 - hence the
+    // switch).  SNF_STAGE_OUT=1 / 0 force either.  (Not while a pass is captured: a replayed graph keeps the direct stores.)
+    const int stage_env = getenv("SNF_STAGE_OUT") ? atoi(getenv("SNF_STAGE_OUT")) : -1;
+    // (a handle's first pass has no sizes for the copies yet: it stores directly)
+    const bool stage = !(v.out_mode & SNF_OUT_DEVICE) && !b->capturing &&
+                       (stage_env == 1 || (stage_env < 0 && g_passes_in_flight.load() > 1 && b->hist_out_bytes > 0));
+    b->staged = stage; b->staged_out = 0; b->staged_alt = 0;
+    const bool out_hbm = (v.out_mode & SNF_OUT_DEVICE) || stage;
     v.out_pin = out_hbm ? nullptr : (uint8_t*)b->hb_out.p;
     v.out_pin_cap = out_hbm ? 0 : (int64_t)b->hb_out.cap;
     // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
     const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_alt.external && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
-    static const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr || stage_env == 1;   // measurement: ALT bytes into the HBM pool, copied at fetch
+    const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr || stage;   // (SNF_ALT_HBM: measurement - only the ALT bytes into HBM, copied at fetch)
     v.alt_pin = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? nullptr : (uint8_t*)b->hb_alt.p;
     v.alt_pin_cap = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? 0 : (int64_t)b->hb_alt.cap;
   }
@@ -1653,6 +1688,7 @@ void run_finalize(snf_batch_impl* b) {
       SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_e3, 0));
       SNF_HIP(hipStreamWaitEvent(b->stream2, b->ev_rn, 0));
       enqueue_output_head(b);
+      stage_copy_block(b);      // (staged result: the block leaves behind f4w_emit, next to the consensus kernels)
     }
     if (!b->have_hist) {   // first finalize of this handle: the class sizes e3b has just written, one host wait
       d2h(b, b->h_cnt, v.cnt, sizeof(Counts));
@@ -1662,6 +1698,7 @@ void run_finalize(snf_batch_impl* b) {
       b->hist_calls = c.n_calls; b->have_hist = true;
     }
     enqueue_consensus_wave(b, b->hist_small + 1, b->hist_large + 1, b->hist_copy + 1);
+    stage_copy_alt(b);          // (staged result: the ALT section leaves behind the last ALT kernel)
     join_side(b);
     join_fourth(b);
   }
@@ -1739,9 +1776,13 @@ void run_pass(snf_batch_impl* b) {
   hipGraph_t graph = nullptr;
   bool ok = hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (ok) {
+    b->capturing = true;
+    // (an exception while capturing - a call that is illegal in a capture, a host wait only this path reaches - does not mean the
+    // pass cannot run: the capture is ended, the handle stays eager from here on and the pass is enqueued the plain way below)
     try { run_call_candidates(b); run_finalize(b); }
-    catch (...) { (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); b->timing = tm; b->graph_failed = true; throw; }
-    ok = hipStreamEndCapture(b->stream, &graph) == hipSuccess && graph != nullptr;
+    catch (...) { (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; ok = false; (void)hipGetLastError(); }
+    b->capturing = false;
+    if (ok) ok = hipStreamEndCapture(b->stream, &graph) == hipSuccess && graph != nullptr;
   }
   b->timing = tm;
   hipGraphExec_t exec = nullptr;
@@ -1854,14 +1895,15 @@ void collect_timings(snf_batch_impl* b) {
 
 // After everything of the pass has run: did the ALT stage leave work for the slow kernels (a call that fits none of the LDS
 // classes, or a workgroup that handed its call to work list 7)?  Rare; they run now, and the ALT bytes are copied out again.
-void settle_alt_stage(snf_batch_impl* b) {
+bool settle_alt_stage(snf_batch_impl* b) {      // true: ALT bytes were produced here, behind the pass
   View& v = b->v;
-  if (!v.wave_path || !b->fused || v.NS <= 0) return;   // (the plain path ran them inside finalize)
+  if (!v.wave_path || !b->fused || v.NS <= 0) return false;   // (the plain path ran them inside finalize)
   const Counts& c = *b->h_cnt;
-  if (c.n_cls[7] == 0 && c.n_cons_fallback == 0) return;
+  if (c.n_cls[7] == 0 && c.n_cons_fallback == 0) return false;
   run_alt_fallback(b);     // (they store into the pass's ALT section like the fast kernels)
   LAUNCH_Q(z1_results, v, tail_threads(v), 0);
   dsync(b);
+  return true;
 }
 
 void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
@@ -1883,20 +1925,27 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   memcpy(b->r_cov.data(), v.res_cov, (size_t)T * sizeof(double));
   if (stage >= 1 && b->finalized) {
     // ---- the block of the output stage: already in pinned host memory, or one copy away
-    settle_alt_stage(b);
+    const bool alt_late = settle_alt_stage(b);
     {
       const Counts& c = *b->h_cnt;
+      bool skipped_work = false;
       for (int k = 0; k < 3; k++) {
-        if (b->skipped_big[k] && c.n_big[k] > 0) fail("internal: a pass skipped x_big although items were handed to it");
-        b->hist_big[k] = c.n_big[k];
+        if (b->skipped_big[k] && c.n_big[k] > 0) skipped_work = true;
+        b->hist_big[k] = c.n_big[k];        // (refreshed first: the next pass of this handle launches what this one skipped)
       }
+      if (skipped_work) { b->pass_idle = true; fail("internal: a pass skipped x_big although items were handed to it (the handle's next pass launches it)"); }
       b->have_big_hist = true;
       b->hist_small = (int64_t)c.n_cls[1]; b->hist_large = (int64_t)(c.n_cls[2] + c.n_cls[3] + c.n_cls[4] + c.n_cls[5]); b->hist_copy = (int64_t)c.n_cls[0];
       b->hist_calls = c.n_calls; b->have_hist = true;
     }
     const OutHdr h = *v.res_out;
     const uint8_t* base = (const uint8_t*)b->hb_out.p;
-    if (!h.in_pinned) {
+    const int64_t alt_total_now = b->h_cnt->alt_total;
+    // staged result: the pass's own copies moved the sizes of the previous pass - enough when this pass produced no more
+    const bool block_there = !h.in_pinned && b->staged && b->staged_out >= (size_t)h.bytes && h.bytes > 0;
+    const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged && !alt_late && b->staged_alt >= (size_t)alt_total_now && alt_total_now > 0;
+    b->hist_out_bytes = h.bytes; b->hist_alt_total = alt_total_now;
+    if (!h.in_pinned && !block_there) {
       v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)
       base = (const uint8_t*)b->hb_out.ensure((size_t)h.bytes + 256);
       d2h_timed(b, (void*)base, v.out_dev, (size_t)h.bytes, "d2h_block");
@@ -1904,7 +1953,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     }
     const int64_t alt_total = b->h_cnt->alt_total;
     const uint8_t* alt = (const uint8_t*)b->hb_alt.p;
-    if (!b->h_cnt->alt_in_pinned) {
+    if (!b->h_cnt->alt_in_pinned && !alt_there) {
       v.alt_pin = nullptr; v.alt_pin_cap = 0;
       alt = (const uint8_t*)b->hb_alt.ensure((size_t)alt_total + 256);
       if (alt_total) { d2h_timed(b, (void*)alt, v.alt_pool, (size_t)alt_total, "d2h_alt"); dsync(b); }

@@ -232,12 +232,11 @@ __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused
   __syncthreads();
   // the window of every position (a running maximum over the marks at the windows' first positions) -> its sort key
   uint64_t e[E];
-  int nmax_r[E];      // per round: the largest number of keys a lane's window holds from the lane's window start on
   {
     int carry = 0;
 #pragma unroll
     for (int j = 0; j < E; j++) {
-      e[j] = 0; nmax_r[j] = 0;
+      e[j] = 0;
       if (64 * j < xhi) {
         const int x = lane + 64 * j;
         const int m = wave_runmax(x < xhi ? (int)widx[x] : 0, carry);

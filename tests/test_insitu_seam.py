@@ -71,7 +71,7 @@ def test_reference_worker_process_sends_the_result_to_the_parent_emu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", NAMES[:3])
+@pytest.mark.parametrize("name", NAMES)          # all of them, `sample_noqc_10x` (the --no-qc sort path) included
 def test_reference_execute_around_the_library_gpu(name):
     plain, got, SVCall, BND, _ = run_both(name, None)
     check(plain, got, SVCall, BND)

@@ -432,6 +432,11 @@ def test_bench_two_ranks_weak_scaling_emu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["tasks"] == 48 and d["value"] > 0
     assert d["config"]["gathered_on_rank0"]["ranks"] == 2 and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
     assert "SharedLanding" in d["config"]["parallelism"]
+    assert d["ranks_seen"] == 2 and d["sets_served"] == [4, 4]             # four passes per rank, each over the rank's genome replica
+    # the same line carries the strong-scaling value: ONE genome over the two ranks, its sets served by whoever claimed them
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["value"] > 0 and st["ranks_seen"] == 2 and sum(st["sets_served"]) == 2 * st["steps"]
+    assert st["gathered_on_rank0"]["tasks"] == 24 and st["gathered_on_rank0"]["records"] == st["calls"] > 0
 
 
 def test_bench_two_ranks_weak_scaling_block_gather_emu():

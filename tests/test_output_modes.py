@@ -295,3 +295,66 @@ def test_consensus_class_order_emu(oracle_mod, monkeypatch):
 @pytest.mark.gpu
 def test_consensus_class_order_gpu(oracle_mod, monkeypatch):
     check_consensus_class_order(oracle_mod, monkeypatch)
+
+
+# ---------------------------------------------------------------------------------------------- result staged through HBM
+def check_staged_result(oracle_mod, monkeypatch):
+    """With another pass in flight the kernels store the result into HBM and two copies behind them take it to the pinned buffers
+    (sized by the handle's previous pass; the fetch checks and completes): the same block as the direct stores, pass after pass, in
+    both output modes, also when the slow ALT kernels run at the fetch, and with two handles driven from two threads."""
+    import threading
+    from sniffles_amd import records
+    tis = tasks()
+    cfg = SnifflesConfig()
+
+    def blocks(b, n):
+        out = []
+        for _ in range(n):
+            b.run_pass()
+            r = b.fetch(1)
+            out.append((r.calls.tobytes(), r.rnames.tobytes(), r.alt_pool.tobytes(), r.task_call_off.tobytes()))
+        return out
+    for mode in (abi.OUT_CANDIDATES, abi.OUT_EXECUTE):
+        monkeypatch.setenv("SNF_STAGE_OUT", "0")
+        with lib.Batch(cfg, tis) as b:
+            b.set_output(mode)
+            want = blocks(b, 1)[0]
+        monkeypatch.setenv("SNF_STAGE_OUT", "1")
+        with lib.Batch(cfg, tis) as b:
+            b.set_output(mode)
+            assert blocks(b, 3) == [want] * 3            # first pass: copied at the fetch; then by the pass itself
+            b.set_output(abi.OUT_EXECUTE if mode == abi.OUT_CANDIDATES else abi.OUT_CANDIDATES)   # another block size on the same handle
+            other = blocks(b, 2)
+            assert other[0] == other[1] and other[0] != want
+    # slow ALT kernels (settled by the fetch): the ALT section is taken again behind them
+    ti = slow_alt_task()
+    exp = oracle_mod.run(cfg, [ti], True)
+    with lib.Batch(cfg, [ti]) as b:
+        for _ in range(3):
+            b.run_pass()
+            assert records.diff_results(b.fetch(1), 0, exp, 0) == []
+    # default rule (no knob): staged when another pass is in flight - two handles, two threads, the same blocks
+    monkeypatch.delenv("SNF_STAGE_OUT")
+    with lib.Batch(cfg, tis) as b1, lib.Batch(cfg, tis) as b2:
+        b1.set_output(abi.OUT_EXECUTE); b2.set_output(abi.OUT_EXECUTE)
+        got = {}
+
+        def body(key, b):
+            got[key] = blocks(b, 4)
+        ths = [threading.Thread(target=body, args=(k, b)) for k, b in (("a", b1), ("b", b2))]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    assert got["a"] == [want] * 4 and got["b"] == [want] * 4
+
+
+def test_staged_result_emu(oracle_mod, monkeypatch):
+    import emu.emu as E
+    E.lib()
+    check_staged_result(oracle_mod, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_staged_result_gpu(oracle_mod, monkeypatch):
+    check_staged_result(oracle_mod, monkeypatch)
