@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SNF_ABI_VERSION 4   /* 4: snf_batch_timing_every */
+#define SNF_ABI_VERSION 5   /* 4: snf_batch_timing_every; 5: snf_batch_open */
 
 #define SNF_SVLEN_NONE INT32_MIN /* Lead.svlen is None */
 #define SNF_SEQ_NONE (-1)        /* Lead.seq is None   */
@@ -325,6 +325,16 @@ int snf_batch_add_task_device(snf_batch_t* b, struct snf_extract* x, const snf_t
  * referenced.  A task the reference could not have produced (svtype / hap codes, sequence ranges, a read outside its
  * region, the byte '-' in a sequence) fails the call. */
 int snf_batch_upload(snf_batch_t* b);
+/* snf_batch_create + snf_batch_add_task x n_tasks + snf_batch_upload and, with `run`, the first device work of the batch, in ONE
+ * call: run = SNF_RUN_NONE, SNF_RUN_CANDIDATES (snf_batch_call_candidates), or SNF_RUN_PASS | an output mode
+ * (snf_batch_set_output(mode) + snf_batch_pass).  What a worker loop calls for task k + 1 from a helper thread while it turns task
+ * k's records into objects (reference: the worker processes of `sniffles:495-530` get that overlap from being several): a caller
+ * whose host language serialises its threads between foreign calls (CPython's GIL) then pays one hand-over per task, not five.
+ * On failure nothing is left behind (*out = NULL).  The tasks' arrays are borrowed until the call returns. */
+#define SNF_RUN_NONE 0
+#define SNF_RUN_CANDIDATES 1
+#define SNF_RUN_PASS 0x100   /* | SNF_OUT_CANDIDATES or SNF_OUT_EXECUTE (| SNF_OUT_DEVICE) */
+int snf_batch_open(const snf_config_t* cfg, int device, const snf_task_input_t* tasks, int32_t n_tasks, int run, snf_batch_t** out);
 void snf_batch_destroy(snf_batch_t* b);
 
 /* replaces Task.call_candidates (src/sniffles/parallel.py:104-127):

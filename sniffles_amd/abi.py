@@ -12,7 +12,7 @@ import numpy as np
 
 from .soa import LEAD_FIELDS, TaskInput
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 FILTERS = [
     "PASS", "STDEV_POS", "STDEV_LEN", "SINGLE_BREAK", "SVLEN_MIN", "STRAND_BND", "COV_CHANGE_DEL",

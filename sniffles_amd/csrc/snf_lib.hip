@@ -294,10 +294,9 @@ struct snf_batch_impl {
   bool in_flight = false;         // counted in g_passes_in_flight
   bool capturing = false;         // run_pass is capturing this pass into a graph
   // Result staged through HBM (run_finalize): with another pass in flight on the device the kernels of a pass store the result block
-  // and the ALT section into HBM and two copies take them to the pinned buffers (sizes from the handle's previous pass: same input);
-  // the fetch checks what the pass really produced against what the copies moved
-  bool staged = false; size_t staged_out = 0, staged_alt = 0;
-  int64_t hist_out_bytes = -1, hist_alt_total = -1;
+  // and the ALT section into HBM; they are taken to the pinned buffers by two copies at the fetch (default) or by two small copy
+  // kernels behind their producers (SNF_STAGE_COPY=kernel: z2_stage_copy reads the sizes on the device)
+  bool staged = false; bool staged_kernel = false, stage_block_copied = false, stage_alt_copied = false;
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
@@ -1111,8 +1110,12 @@ void do_upload(snf_batch_impl* b) {
 // passes that have been enqueued and not yet waited for, over all handles of the process (a pass = snf_batch_pass, or
 // call_candidates .. the fetch / sync that waits for it)
 std::atomic<int> g_passes_in_flight{0};
-void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; g_passes_in_flight.fetch_add(1); } }
-void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; g_passes_in_flight.fetch_sub(1); } }
+std::atomic<long long> g_last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
+void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; if (g_passes_in_flight.fetch_add(1) >= 1) g_last_overlap_ms.store((long long)now_ms()); } }
+void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; if (g_passes_in_flight.fetch_sub(1) >= 2) g_last_overlap_ms.store((long long)now_ms()); } }
+// is this process driving several passes at a time?  (Asked when a pass is enqueued: the other handle may be between its fetch and its
+// next pass at that very moment - what counts is whether passes overlapped a moment ago.)
+bool passes_overlap() { return g_passes_in_flight.load() > 1 || (long long)now_ms() - g_last_overlap_ms.load() < 100; }
 void reset_timing(snf_batch_impl* b) {
   b->ev_used = 0;
   b->timings.clear();
@@ -1588,23 +1591,21 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
   SNF_HIP(hipStreamWaitEvent(b->stream, b->ev_join3, 0));
 }
 
-// staged result (snf_batch_impl::staged): the copies that take the block / the ALT section from HBM to the pinned buffers, enqueued on
-// the stream their producers ran on.  Sizes are those of the handle's previous pass (same input -> same result); the fetch compares.
+// staged result with SNF_STAGE_COPY=kernel: a small copy kernel behind the producers of the block / the ALT section, on their stream
+// (64 workgroups: enough stores in flight for the PCIe link, a handful of wave slots)
 void stage_copy_block(snf_batch_impl* b) {
-  if (!b->staged || b->hist_out_bytes <= 0) return;
-  size_t n = (size_t)b->hist_out_bytes;
-  if (!b->hb_out.p || n > b->hb_out.cap || (int64_t)n > b->v.out_dev_cap) return;
-  Scope _s(b, "d2h_block", (int64_t)n);
-  SNF_HIP(hipMemcpyAsync(b->hb_out.p, b->v.out_dev, n, hipMemcpyDeviceToHost, b->cur));
-  b->staged_out = n;
+  if (!b->staged_kernel || !b->v.stage_out_pin) return;
+  Scope _s(b, "d2h_block", 0);
+  hipLaunchKernelGGL(z2_stage_copy, dim3(64), dim3(256), 0, b->cur, b->v, (int64_t)0);
+  SNF_HIP(hipGetLastError());
+  b->stage_block_copied = true;
 }
 void stage_copy_alt(snf_batch_impl* b) {
-  if (!b->staged || b->hist_alt_total <= 0) return;
-  size_t n = (size_t)b->hist_alt_total;
-  if (!b->hb_alt.p || n > b->hb_alt.cap) return;
-  Scope _s(b, "d2h_alt", (int64_t)n);
-  SNF_HIP(hipMemcpyAsync(b->hb_alt.p, b->v.alt_pool, n, hipMemcpyDeviceToHost, b->cur));
-  b->staged_alt = n;
+  if (!b->staged_kernel || !b->v.stage_alt_pin) return;
+  Scope _s(b, "d2h_alt", 0);
+  hipLaunchKernelGGL(z2_stage_copy, dim3(64), dim3(256), 0, b->cur, b->v, (int64_t)1);
+  SNF_HIP(hipGetLastError());
+  b->stage_alt_copied = true;
 }
 
 void run_finalize(snf_batch_impl* b) {
@@ -1626,19 +1627,21 @@ void run_finalize(snf_batch_impl* b) {
     // other pass's compute (same box, two in flight: 0.945 ms per step against 1.17; one in flight 1.48 against 1.36 - hence the
     // switch).  SNF_STAGE_OUT=1 / 0 force either.  (Not while a pass is captured: a replayed graph keeps the direct stores.)
     const int stage_env = getenv("SNF_STAGE_OUT") ? atoi(getenv("SNF_STAGE_OUT")) : -1;
-    // (a handle's first pass has no sizes for the copies yet: it stores directly)
-    const bool stage = !(v.out_mode & SNF_OUT_DEVICE) && !b->capturing &&
-                       (stage_env == 1 || (stage_env < 0 && g_passes_in_flight.load() > 1 && b->hist_out_bytes > 0));
-    b->staged = stage; b->staged_out = 0; b->staged_alt = 0;
+    const bool stage = !(v.out_mode & SNF_OUT_DEVICE) && !b->capturing && (stage_env == 1 || (stage_env < 0 && passes_overlap()));
+    const char* copy_env = getenv("SNF_STAGE_COPY");
+    b->staged = stage; b->staged_kernel = stage && copy_env && strcmp(copy_env, "kernel") == 0;
+    b->stage_block_copied = b->stage_alt_copied = false;
     const bool out_hbm = (v.out_mode & SNF_OUT_DEVICE) || stage;
     v.out_pin = out_hbm ? nullptr : (uint8_t*)b->hb_out.p;
     v.out_pin_cap = out_hbm ? 0 : (int64_t)b->hb_out.cap;
+    v.stage_out_pin = b->staged_kernel ? (uint8_t*)b->hb_out.p : nullptr; v.stage_out_cap = b->staged_kernel ? (int64_t)b->hb_out.cap : 0;
     // ALT section: an eighth of the input sequence bytes (a 30x genome needs a twentieth); the fetch grows it when a pass overflowed into HBM
     const size_t want_alt = (size_t)(v.pool_len / 8) + ((size_t)1 << 20);
     if (!(v.out_mode & SNF_OUT_DEVICE) && !b->hb_alt.external && b->hb_alt.cap < want_alt) b->hb_alt.ensure(want_alt);
     const bool alt_hbm = getenv("SNF_ALT_HBM") != nullptr || stage;   // (SNF_ALT_HBM: measurement - only the ALT bytes into HBM, copied at fetch)
     v.alt_pin = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? nullptr : (uint8_t*)b->hb_alt.p;
     v.alt_pin_cap = ((v.out_mode & SNF_OUT_DEVICE) || alt_hbm) ? 0 : (int64_t)b->hb_alt.cap;
+    v.stage_alt_pin = b->staged_kernel ? (uint8_t*)b->hb_alt.p : nullptr; v.stage_alt_cap = b->staged_kernel ? (int64_t)b->hb_alt.cap : 0;
   }
   v.out_valid = 1;
   // Launch sizes of the data-dependent kernels.  Grids much larger than the work flood the dispatcher with empty workgroups
@@ -1941,10 +1944,9 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     const OutHdr h = *v.res_out;
     const uint8_t* base = (const uint8_t*)b->hb_out.p;
     const int64_t alt_total_now = b->h_cnt->alt_total;
-    // staged result: the pass's own copies moved the sizes of the previous pass - enough when this pass produced no more
-    const bool block_there = !h.in_pinned && b->staged && b->staged_out >= (size_t)h.bytes && h.bytes > 0;
-    const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged && !alt_late && b->staged_alt >= (size_t)alt_total_now && alt_total_now > 0;
-    b->hist_out_bytes = h.bytes; b->hist_alt_total = alt_total_now;
+    // staged result, copied by the pass's own copy kernels (they read the sizes on the device and do nothing when a section does not fit)
+    const bool block_there = !h.in_pinned && b->staged_kernel && b->stage_block_copied && v.stage_out_pin == (uint8_t*)b->hb_out.p && h.bytes <= v.stage_out_cap;
+    const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged_kernel && b->stage_alt_copied && !alt_late && v.stage_alt_pin == (uint8_t*)b->hb_alt.p && alt_total_now <= v.stage_alt_cap;
     if (!h.in_pinned && !block_there) {
       v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)
       base = (const uint8_t*)b->hb_out.ensure((size_t)h.bytes + 256);
@@ -2536,6 +2538,23 @@ int snf_batch_upload(snf_batch_t* bb) {
     SNF_HIP(hipSetDevice(b->device));
     do_upload(b);
   })
+}
+
+int snf_batch_open(const snf_config_t* cfg, int device, const snf_task_input_t* tasks, int32_t n_tasks, int run, snf_batch_t** out) {
+  if (out) *out = nullptr;
+  if (!out || (n_tasks > 0 && !tasks) || n_tasks < 0) { g_err = "snf_batch_open: null argument"; return 1; }
+  if (run != SNF_RUN_NONE && run != SNF_RUN_CANDIDATES && !((run & SNF_RUN_PASS) && (run & ~SNF_RUN_PASS) <= (SNF_OUT_EXECUTE | SNF_OUT_DEVICE))) {
+    g_err = "snf_batch_open: unknown run mode"; return 1;
+  }
+  snf_batch_t* h = nullptr;
+  int rc = snf_batch_create(cfg, device, &h);
+  for (int32_t t = 0; rc == 0 && t < n_tasks; t++) rc = snf_batch_add_task(h, &tasks[t]);
+  if (rc == 0) rc = snf_batch_upload(h);
+  if (rc == 0 && run == SNF_RUN_CANDIDATES) rc = snf_batch_call_candidates(h);
+  if (rc == 0 && (run & SNF_RUN_PASS)) { rc = snf_batch_set_output(h, run & ~SNF_RUN_PASS); if (rc == 0) rc = snf_batch_pass(h); }
+  if (rc != 0) { const std::string keep = g_err; if (h) snf_batch_destroy(h); g_err = keep; return rc; }      // (the first error is the one reported)
+  *out = h;
+  return 0;
 }
 
 void snf_batch_destroy(snf_batch_t* bb) {

@@ -207,4 +207,16 @@ __global__ void __launch_bounds__(256) f4w_emit(const View v, int64_t n) {
   }
 }
 
+// staged result: HBM -> pinned host memory, 16 bytes per lane (which = 0: the result block, 1: the ALT section); sizes read here
+__global__ void __launch_bounds__(256) z2_stage_copy(const View v, int64_t which) {
+  const int64_t n = which == 0 ? v.out_hdr->bytes : v.cnt->alt_total;
+  const uint8_t* src = which == 0 ? v.out_dev : v.alt_pool;
+  uint8_t* dst = which == 0 ? v.stage_out_pin : v.stage_alt_pin;
+  if (!dst || n > (which == 0 ? v.stage_out_cap : v.stage_alt_cap)) return;      // (the fetch sees the same sizes and copies itself)
+  const int64_t n16 = n >> 4, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) ((uint4*)dst)[i] = ((const uint4*)src)[i];
+  const int64_t tail = (n16 << 4) + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (tail < n) dst[tail] = src[tail];
+}
+
 }  // namespace snf

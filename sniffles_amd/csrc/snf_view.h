@@ -265,6 +265,8 @@ struct View {
   int32_t *cr_call, *cr_read;  // [n_cons_reads] (consensus id, other index)
   uint8_t* alt_pool; int64_t alt_cap;    // ALT bytes of all candidates, candidate order (HBM)
   uint8_t* alt_pin; int64_t alt_pin_cap; // the same section in pinned host memory (0: none); Counts::alt_in_pinned says which one a pass uses
+  // staged result (another pass in flight: the kernels store into HBM): where z2_stage_copy takes the block / the ALT section (0: the fetch copies)
+  uint8_t* stage_out_pin; int64_t stage_out_cap; uint8_t* stage_alt_pin; int64_t stage_alt_cap;
   unsigned long long* stripes;  // [4 classes][64 stripes][16] striped byte counters (one 128-B line each): cons_bytes
   unsigned long long* tile_super; int64_t super_stride;  // sums per 64 tiles (8 slots), zeroed at the start of a pass
   // single-launch "flags -> exclusive scan -> emit" chains (snf_fused.h chain_scan): per slot and 256-element tile two words

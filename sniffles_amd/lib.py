@@ -88,7 +88,8 @@ def bind(lib: C.CDLL) -> C.CDLL:
               "snf_extract_device_view", "snf_batch_add_task_device"):
         getattr(lib, f).restype = C.c_int
     lib.snf_batch_pass.argtypes = [vp]
-    for f in ("snf_batch_pass", "snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
+    lib.snf_batch_open.argtypes = [C.POINTER(abi.snf_config_t), C.c_int, C.POINTER(abi.snf_task_input_t), C.c_int32, C.c_int, C.POINTER(vp)]
+    for f in ("snf_batch_open", "snf_batch_pass", "snf_batch_create", "snf_batch_add_task", "snf_batch_upload", "snf_batch_call_candidates",
               "snf_batch_finalize", "snf_batch_fetch", "snf_batch_sync", "snf_batch_export_device", "snf_batch_set_output", "snf_batch_set_result_memory",
               "snf_batch_timing_count",
               "snf_batch_timing_get", "snf_edit_distance_batch"):
@@ -162,6 +163,38 @@ class Batch:
         except Exception:
             self.close()
             raise
+
+    RUN_NONE, RUN_CANDIDATES, RUN_PASS = 0, 1, 0x100      # include/sniffles_amd.h SNF_RUN_*
+
+    @classmethod
+    def open_in_background(cls, cfg, tasks, device: int = 0, run: int = 0) -> "PendingBatch":
+        """`Batch(cfg, tasks, device)` and, with `run`, its first device work (RUN_CANDIDATES: `call_candidates()`; RUN_PASS | output mode:
+        `set_output(mode)` + `run_pass()`), started on a helper thread: everything that needs the interpreter (the structs of the C-ABI) is
+        built here, on the caller's thread; the helper makes ONE library call (`snf_batch_open`: create, add, upload, enqueue), during which
+        the interpreter lock is released.  `.result()` waits and returns the batch (or raises what the call raised)."""
+        import threading
+        lib_ = load()
+        tasks = list(tasks)
+        cs = abi.config_struct(cfg)
+        keep = []
+        arr = (abi.snf_task_input_t * max(1, len(tasks)))()
+        for i, ti in enumerate(tasks):
+            arr[i] = abi.task_struct(ti, keep)
+        pend = PendingBatch()
+
+        def body():
+            h = C.c_void_p()
+            try:
+                _check(lib_, lib_.snf_batch_open(C.byref(cs), device, arr, len(tasks), int(run), C.byref(h)))
+                b = cls.__new__(cls)
+                b.lib, b.tasks, b._h = lib_, tasks, h
+                pend._batch = b
+            except BaseException as e:  # noqa: BLE001 - re-raised by result()
+                pend._err = e
+            keep.clear()
+        pend._thread = threading.Thread(target=body, daemon=True)
+        pend._thread.start()
+        return pend
 
     def close(self):
         if self._h:
@@ -311,6 +344,25 @@ class Batch:
             _check(self.lib, self.lib.snf_batch_timing_mean_get(self._h, i, C.byref(name), C.byref(ms), C.byref(nb), C.byref(k)))
             out.append((name.value.decode(), float(ms.value), int(nb.value)))
         return out
+
+
+class PendingBatch:
+    """A batch that is being opened on a helper thread (`Batch.open_in_background`)."""
+    _batch = None
+    _err = None
+    _thread = None
+
+    def result(self) -> Batch:
+        self._thread.join()
+        if self._err is not None:
+            raise self._err
+        return self._batch
+
+    def discard(self):
+        self._thread.join()
+        if self._batch is not None:
+            self._batch.close()
+            self._batch = None
 
 
 def trim_caches(device: int = -1) -> int:

@@ -36,55 +36,53 @@ class Task:
     def prepare(self, config, execute=None):
         """Start this task's upload and its pass in the background; the next `call_candidates` (execute=None) / `call_records` /
         `execute_calls` (execute=False / True) on this task picks the running work up instead of starting it.  A worker loop that
-        calls `tasks[k + 1].prepare(config)` before it turns task k's records into objects overlaps the two (the library calls release
-        the GIL; every task has its own batch handle and streams): the reference's worker processes get the same overlap from being
-        several (`sniffles:495-530`).  Optional: a task that was not prepared does the same work when it is called."""
-        import threading
+        calls `tasks[k + 1].prepare(config)` before it turns task k's records into objects overlaps the two: the task's columns and
+        the structs of the C-ABI are built here, the helper thread makes ONE library call (`snf_batch_open`: create, upload, enqueue -
+        the interpreter lock is released for all of it); every task has its own batch handle and streams.  The reference's worker
+        processes get the same overlap from being several (`sniffles:495-530`).  Optional: a task that was not prepared does the same
+        work when it is called."""
+        from .abi import OUT_CANDIDATES, OUT_EXECUTE
         if self._prep is not None:
             return
-        box = {"mode": execute, "err": None}
-
-        def body():
-            try:
-                self._open(config)
-                if execute is None:
-                    self._batch.call_candidates()
-                else:
-                    from .abi import OUT_CANDIDATES, OUT_EXECUTE
-                    self._batch.set_output(OUT_EXECUTE if execute else OUT_CANDIDATES)
-                    self._batch.run_pass()
-            except BaseException as e:  # noqa: BLE001 - re-raised on the caller's thread
-                box["err"] = e
-        box["thread"] = threading.Thread(target=body, daemon=True)
-        self._prep = box
-        box["thread"].start()
+        self._release()
+        self._ti = self._task_input(config)
+        run = lib.Batch.RUN_CANDIDATES if execute is None else (lib.Batch.RUN_PASS | (OUT_EXECUTE if execute else OUT_CANDIDATES))
+        self._prep = {"mode": execute, "pending": lib.Batch.open_in_background(config, [self._ti], device=self.device, run=run)}
 
     def _prepared(self, execute) -> bool:
         """True: `prepare` has already enqueued exactly this call's device work on this task's batch."""
         box, self._prep = self._prep, None
         if box is None:
             return False
-        box["thread"].join()
-        if box["err"] is not None:
-            raise box["err"]
-        return box["mode"] == execute and self._batch is not None
+        if box["mode"] != execute:            # prepared for another call than the one that comes: redone, not reused
+            box["pending"].discard()
+            return False
+        self._batch = box["pending"].result()
+        self._adopt()
+        return True
 
-    def _open(self, config):
+    def _task_input(self, config):
         lp = self.lead_provider
         if lp.contig_len is None and lp.end is None:
             lp.end = self.end
-        self._ti = lp.to_task_input(self.id, self.sv_id, self.tandem_repeats,
-                                    getattr(config, "qc_nm_threshold", 0.02))
-        self._release()
-        self._batch = lib.Batch(config, [self._ti], device=self.device)
+        return lp.to_task_input(self.id, self.sv_id, self.tandem_repeats, getattr(config, "qc_nm_threshold", 0.02))
+
+    def _adopt(self):
+        lp = self.lead_provider
         lp.device_batch = self._batch   # SNFile.annotate_block_coverages(lead_provider) reads the coverage from HBM
         lp.task_input = self._ti        # cluster.resolve(svtype, lead_provider, ...) reads the clusters back (seam B3)
+
+    def _open(self, config):
+        self._ti = self._task_input(config)
+        self._release()
+        self._batch = lib.Batch(config, [self._ti], device=self.device)
+        self._adopt()
 
     def close(self):
         """Release the task's device memory.  The batch outlives finalize_candidates because the SNF writer needs the
         read table afterwards (CallTask.execute, parallel.py:278-291); it goes with the task otherwise."""
         if getattr(self, "_prep", None) is not None:
-            self._prep["thread"].join()
+            self._prep["pending"].discard()
             self._prep = None
         self._release()
 

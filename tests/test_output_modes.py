@@ -300,7 +300,7 @@ def test_consensus_class_order_gpu(oracle_mod, monkeypatch):
 # ---------------------------------------------------------------------------------------------- result staged through HBM
 def check_staged_result(oracle_mod, monkeypatch):
     """With another pass in flight the kernels store the result into HBM and two copies behind them take it to the pinned buffers
-    (sized by the handle's previous pass; the fetch checks and completes): the same block as the direct stores, pass after pass, in
+    (at the fetch, or by two small copy kernels inside the pass): the same block as the direct stores, pass after pass, in
     both output modes, also when the slow ALT kernels run at the fetch, and with two handles driven from two threads."""
     import threading
     from sniffles_amd import records
@@ -314,15 +314,16 @@ def check_staged_result(oracle_mod, monkeypatch):
             r = b.fetch(1)
             out.append((r.calls.tobytes(), r.rnames.tobytes(), r.alt_pool.tobytes(), r.task_call_off.tobytes()))
         return out
-    for mode in (abi.OUT_CANDIDATES, abi.OUT_EXECUTE):
+    for mode, copy in ((abi.OUT_CANDIDATES, "fetch"), (abi.OUT_EXECUTE, "fetch"), (abi.OUT_CANDIDATES, "kernel"), (abi.OUT_EXECUTE, "kernel")):
         monkeypatch.setenv("SNF_STAGE_OUT", "0")
         with lib.Batch(cfg, tis) as b:
             b.set_output(mode)
             want = blocks(b, 1)[0]
         monkeypatch.setenv("SNF_STAGE_OUT", "1")
+        monkeypatch.setenv("SNF_STAGE_COPY", copy)         # the two copies at the fetch, or two copy kernels inside the pass
         with lib.Batch(cfg, tis) as b:
             b.set_output(mode)
-            assert blocks(b, 3) == [want] * 3            # first pass: copied at the fetch; then by the pass itself
+            assert blocks(b, 3) == [want] * 3
             b.set_output(abi.OUT_EXECUTE if mode == abi.OUT_CANDIDATES else abi.OUT_CANDIDATES)   # another block size on the same handle
             other = blocks(b, 2)
             assert other[0] == other[1] and other[0] != want
@@ -334,7 +335,7 @@ def check_staged_result(oracle_mod, monkeypatch):
             b.run_pass()
             assert records.diff_results(b.fetch(1), 0, exp, 0) == []
     # default rule (no knob): staged when another pass is in flight - two handles, two threads, the same blocks
-    monkeypatch.delenv("SNF_STAGE_OUT")
+    monkeypatch.delenv("SNF_STAGE_OUT"); monkeypatch.delenv("SNF_STAGE_COPY")
     with lib.Batch(cfg, tis) as b1, lib.Batch(cfg, tis) as b2:
         b1.set_output(abi.OUT_EXECUTE); b2.set_output(abi.OUT_EXECUTE)
         got = {}

@@ -24,10 +24,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q):
+def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0):
     try:
         if ROOT not in sys.path:
             sys.path.insert(0, ROOT)
+        if hw_queues:            # hardware queues this process may open (read by the HIP runtime when it starts): P processes x their streams
+            os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues)     # must not oversubscribe the device's queues, or the driver time-slices them
         from sniffles_amd import leadprov, lib, parallel, pipeline, synth
         from sniffles_amd.config import SnifflesConfig
         if os.environ.get("SNF_BENCH_EMU") == "1":      # tests only: the plumbing of this file on a GPU-less box (host tier of the test suite)
@@ -68,11 +70,15 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q):
             ingest_s = time.perf_counter() - t0
             t_all0 = time.perf_counter()
         n_out = 0
+
+        def prepare(k):      # (the reference's build_leadtab leaves the task's NM threshold on the config: the lead provider's columns take it from there)
+            cfg.qc_nm_threshold = built[k][1].qc_nm_threshold
+            tasks[k].prepare(cfg, execute=ex)
         if tasks:
-            tasks[0].prepare(cfg, execute=ex)
+            prepare(0)
         for k, t in enumerate(tasks):
             if k + 1 < len(tasks):
-                tasks[k + 1].prepare(cfg, execute=ex)
+                prepare(k + 1)
             if shape == "execute":
                 n_out += len(t.execute_calls(cfg))
             else:
@@ -86,7 +92,7 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q):
         out_q.put(dict(error=f"worker {wid}: {e!r}\n{traceback.format_exc()}"))
 
 
-def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str = "api", device: int = 0, weights=None) -> dict:
+def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str = "api", device: int = 0, weights=None, hw_queues: int = 0) -> dict:
     """specs: [(key, kwargs of synth.gen_task)].  Returns {procs, hot_all_s (slowest worker), hot_sum_s, ingest_all_s (slowest worker's
     object walk, `leads` form), n_out, setup_wall_s}."""
     n = len(specs)
@@ -101,7 +107,7 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(procs + 1), ctx.Queue()
     t0 = time.perf_counter()
-    ps = [ctx.Process(target=_worker, args=(w, shards[w], cfg_kw, form, shape, device, barrier, q), daemon=True) for w in range(procs)]
+    ps = [ctx.Process(target=_worker, args=(w, shards[w], cfg_kw, form, shape, device, barrier, q, hw_queues), daemon=True) for w in range(procs)]
     for p in ps:
         p.start()
     import queue as _queue
@@ -131,7 +137,7 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
         p.join(timeout=30)
     if err is not None:
         raise RuntimeError(err)
-    return dict(procs=procs, form=form, shape=shape, hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
+    return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None, hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
                 hot_sum_ms=round(sum(m["hot_s"] for m in got) * 1e3, 1), ingest_all_ms=round(max(m["ingest_s"] for m in got) * 1e3, 1),
                 n_out=sum(m["n_out"] for m in got), setup_wall_s=round(t1 - t0, 1))
 
@@ -145,8 +151,10 @@ def genome_specs(coverage=30.0, scale=1.0, gen=None):
 
 if __name__ == "__main__":
     import json
-    P = [int(x) for x in sys.argv[1:]] or [4, 8, 24]
+    P = [int(x) for x in sys.argv[1:] if not x.startswith("q")] or [4, 8, 24]
+    Q = [int(x[1:]) for x in sys.argv[1:] if x.startswith("q")] or [0]      # q2: GPU_MAX_HW_QUEUES=2 in every worker
     specs = genome_specs()
     for p in P:
-        for form, shape in (("columns", "api"), ("columns", "execute"), ("leads", "api")):
-            print(json.dumps(run(specs, {}, p, form, shape)), flush=True)
+        for hq in Q:
+            for form, shape in (("columns", "api"), ("columns", "execute"), ("leads", "api")):
+                print(json.dumps(run(specs, {}, p, form, shape, hw_queues=hq)), flush=True)
