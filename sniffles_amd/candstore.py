@@ -110,15 +110,47 @@ class ContigColumns:
         return self._dense[cb]
 
 
+# How many contigs' column tables a reader keeps (least recently used first out; None: all).  A cached table holds every candidate
+# object, record, ALT byte and coverage vector of a contig - the SNF file's content, in memory; the reference streams a contig's blocks
+# and lets them go.  The merge driver (`pipeline.combine`) drops the tables when the merge has been written (`clear_columns`); a caller
+# that merges the same readers again (bench.py --config 4: candidates resident as columns) keeps them.  `SNF_COLUMNS_CACHE=N` bounds the
+# number of contigs a reader holds at a time (0: nothing is kept between calls).
+COLUMNS_CACHE_CONTIGS = None
+
+
 def reader_columns(reader, contig, sid, thr, fast):
-    """Cached `ContigColumns` of a reader that can list its blocks (`block_starts(contig)`); None for any other reader."""
+    """Cached `ContigColumns` of a reader that can list its blocks (`block_starts(contig)`); None for any other reader.
+    The cache lives on the reader (keyed by contig, sample id, support threshold and the identity of the reader's block index, so a
+    reader that re-reads its header starts afresh), is bounded (`COLUMNS_CACHE_CONTIGS`) and can be dropped with `clear_columns`.
+    The cached candidates are SHARED between the merges that use them: `group_calls` writes the default genotype into
+    `genotypes[0]` of candidates that lack one, which every later merge then sees (the value is the same for all of them)."""
+    import os
     if not hasattr(reader, "block_starts") or getattr(reader, "reqc", False):
         return None
     cache = reader.__dict__.setdefault("_snf_columns", {})
-    key = (contig, int(sid), int(thr))
-    if key not in cache:
-        cache[key] = ContigColumns(reader, contig, sid, thr, fast)
-    return cache[key]
+    key = (contig, int(sid), int(thr), id(getattr(reader, "index", None)))
+    if key in cache:
+        cache[key] = cache.pop(key)             # (most recently used last)
+        return cache[key]
+    cols = ContigColumns(reader, contig, sid, thr, fast)
+    keep = os.environ.get("SNF_COLUMNS_CACHE", COLUMNS_CACHE_CONTIGS)
+    keep = None if keep is None else int(keep)
+    if keep is None or keep > 0:
+        cache[key] = cols
+        contigs = []
+        for k in cache:
+            if k[0] not in contigs:
+                contigs.append(k[0])
+        for old in contigs[:-keep] if keep is not None and len(contigs) > keep else ():
+            for k in [k for k in cache if k[0] == old]:
+                del cache[k]
+    return cols
+
+
+def clear_columns(reader=None) -> None:
+    """Drop the cached column tables of `reader` (every table of the process-wide mate-contig ids stays valid)."""
+    if reader is not None:
+        reader.__dict__.pop("_snf_columns", None)
 
 
 def _collect_from_columns(tasks, samples_snf, config, fast):

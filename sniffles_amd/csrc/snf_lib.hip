@@ -519,10 +519,7 @@ void prim_sort_pairs(snf_batch_impl* b, const K* kin, K* kout, const uint32_t* v
   using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 65536>;
   SNF_HIP(rocprim::radix_sort_pairs<SortCfg>(nullptr, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
-  if (need > tmpb) {
-    if (tmp) { dsync(b); dfree_one(b, tmp); }
-    tmp = dalloc_own<uint8_t>(b, need); tmpb = need;
-  }
+  if (need > tmpb) { tmp = dalloc<uint8_t>(b, need); tmpb = need; }      // (from the batch's slab: a hipMalloc + hipFree per task cost more than a contig's upload copies; an outgrown region stays in the slab)
   Scope s(b, name, n * 2 * (int64_t)(sizeof(K) + 4));
   SNF_HIP(rocprim::radix_sort_pairs<SortCfg>(tmp, need, kin, kout, vin, vout, (size_t)n, 0, end_bit, b->cur));
 }
@@ -532,10 +529,7 @@ void prim_exscan(snf_batch_impl* b, const T* in, T* out, int64_t n, const char* 
   size_t need = 0;
   SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
   void*& tmp = b->sort_tmp[b->cur_slot]; size_t& tmpb = b->sort_tmp_bytes[b->cur_slot];
-  if (need > tmpb) {
-    if (tmp) { dsync(b); dfree_one(b, tmp); }
-    tmp = dalloc_own<uint8_t>(b, need); tmpb = need;
-  }
+  if (need > tmpb) { tmp = dalloc<uint8_t>(b, need); tmpb = need; }
   if (b->time_all) { Scope s(b, name, n * 2 * (int64_t)sizeof(T));
     SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur)); }
   else SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), b->cur));
@@ -709,7 +703,7 @@ void do_upload(snf_batch_impl* b) {
   v.cfg = b->cfg; v.T = T; v.N = N; v.R = R; v.NTR = NTR; v.run_gap = b->run_gap;
   v.wave_path = getenv("SNF_NO_WAVE") ? 0 : 1;
   v.prof = getenv("SNF_PROF") ? 1 : 0;
-  v.merge_reread = getenv("SNF_MERGE_REREAD") ? 1 : 0;
+  v.merge_reread = (getenv("SNF_MERGE_REREAD") && atoi(getenv("SNF_MERGE_REREAD")) != 0) ? 1 : 0;
   const bool sort64 = getenv("SNF_SORT64") != nullptr;  // tests: force the wide-key sorts
   {  // lead sort key: (task*8 + svtype) << bin_bits | bin, one more bit marks leads outside their contig (sorted last)
     int64_t max_bins = 1;
@@ -1017,6 +1011,7 @@ void do_upload(snf_batch_impl* b) {
   v.sz_tab = dalloc<int64_t>(b, N1 + 1); v.sz_aln = dalloc<int64_t>(b, N1 + 1); v.sz_rd = dalloc<int64_t>(b, N1 + 1);
   v.sc_tab = dalloc<int64_t>(b, N1 + 1); v.sc_aln = dalloc<int64_t>(b, N1 + 1); v.sc_rd = dalloc<int64_t>(b, N1 + 1);
   b->readprep_each_pass = getenv("SNF_READPREP_EACH_PASS") != nullptr;
+  const double t_alloc = now_ms();
   if (v.prefilter) {
     // how many leads the prefilter keeps is a property of the input: counted once here (the same three kernels every pass
     // runs), so that every later pass can size its sort and launches on the host without a round trip
@@ -1030,6 +1025,7 @@ void do_upload(snf_batch_impl* b) {
     v.NS = hc.n_kept;
     if (v.prof) fprintf(stderr, "[SNF_PROF] prefilter: %lld of %lld leads share their (svtype, bin) cell with another lead\n", (long long)v.NS, (long long)N);
   }
+  const double t_pfcount = now_ms();
   if (win_slots_max > 0 && v.NS > 0) {
     // window width: the widest whose largest window fits the 256-lead instance of the window kernels, else the widest that fits the
     // 1024-lead one; occupied windows and the largest window are properties of the input (counted here, like NS): the passes size
@@ -1061,6 +1057,7 @@ void do_upload(snf_batch_impl* b) {
     if (v.prof) fprintf(stderr, "[SNF_PROF] window front end: %s (W = %d: %lld windows, %lld occupied, largest %lld leads)\n", v.front ? "on" : "off",
                         v.win_bits, (long long)v.NW, (long long)best_occ, (long long)best_max);
   }
+  const double t_winsel = now_ms();
   {  // ALT stage output (HBM; every ALT is the sequence of one lead of its cluster, so all of them together fit the pool) and
      // the output stage: at most one record per position behind the sort
     v.alt_cap = v.pool_cap; v.alt_pool = dalloc<uint8_t>(b, (size_t)v.alt_cap + 32);
@@ -1102,8 +1099,10 @@ void do_upload(snf_batch_impl* b) {
   b->reads_ready = true;
   b->uploaded = true;
   if (v.prof) fprintf(stderr, "[SNF_PROF] read index (sorted ends, hap prefix counts): %.2f ms\n", now_ms() - t_index0);
-  if (v.prof) fprintf(stderr, "[SNF_PROF] upload: %.1f ms (stage %.1f, H2D %.1f [%.1f MB], allocations + derived %.1f; %zu device allocations)\n",
-                      now_ms() - t_begin, t_staged - t_begin, t_copied - t_staged, (double)at / 1e6, now_ms() - t_copied, b->bufs.size());
+  if (v.prof) fprintf(stderr, "[SNF_PROF] upload: %.1f ms (stage %.1f, H2D %.1f [%.1f MB], allocations + derived %.1f = packing + arrays %.2f, prefilter count %.2f, "
+                              "window width %.2f, read index %.2f; %zu device allocations)\n",
+                      now_ms() - t_begin, t_staged - t_begin, t_copied - t_staged, (double)at / 1e6, now_ms() - t_copied, t_alloc - t_copied, t_pfcount - t_alloc,
+                      t_winsel - t_pfcount, now_ms() - t_winsel, b->bufs.size());
 }
 
 // ---------------------------------------------------------------------------------------------- pipeline
@@ -1318,10 +1317,10 @@ void run_call_candidates(snf_batch_impl* b) {
     if (v.wave_path && b->d1_groups) {
       // merge_inner / resplit by cluster size (snf_wave_refine_g.h): eight clusters of <= 8 leads per wave, then d1w_refine - a wave
       // per cluster - for what that kernel handed on
-      { Scope _s(b, "d1g_refine8", N * 36);
+      { Scope _s(b, "d1g_refine8", N * 36 / 3);
         hipLaunchKernelGGL(d1g_refine<8>, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError()); }
-      { Scope _s(b, "d1w_refine", 0);
+      { Scope _s(b, "d1w_refine", N * 36 - N * 36 / 3);
         v.d1_from_list = 1;
         hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
         v.d1_from_list = 0;
@@ -1354,7 +1353,9 @@ void run_call_candidates(snf_batch_impl* b) {
       // call_from by cluster size (snf_wave_call_g.h): eight clusters of <= 8 leads per wave, then two of <= 32 from the list
       // the first kernel left, then d2w_call - a wave per cluster - for what the second handed on
       const bool ph = b->cfg.phase != 0;
-      { Scope _s(b, "d2g_call8", N * 32);
+      // (32 B per signature for the call stage, split by the share of the leads each kernel sees on a 30x genome - a third of
+      //  them sit in refined clusters of at most eight leads)
+      { Scope _s(b, "d2g_call8", N * 32 / 3);
         if (ph) hipLaunchKernelGGL((d2g_call<8, 4, true>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
         else hipLaunchKernelGGL((d2g_call<8, 4, false>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError()); }
@@ -1363,7 +1364,7 @@ void run_call_candidates(snf_batch_impl* b) {
         if (ph) hipLaunchKernelGGL((d2g_call<32, 4, true>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
         else hipLaunchKernelGGL((d2g_call<32, 4, false>), dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
         SNF_HIP(hipGetLastError()); }
-      { Scope _s(b, "d2w_call", 0);
+      { Scope _s(b, "d2w_call", N * 32 - N * 32 / 3);
         v.d2_from_list = mid ? 2 : 1;
         hipLaunchKernelGGL(b->k_d2w, dim3(b->slots_d2w), dim3(64), 0, b->cur, v, (int64_t)0);
         v.d2_from_list = 0;

@@ -588,31 +588,36 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   int t_phase = 0, t_symbolic = 0, t_mosaic = 0, t_rnames = 0, t_nm = 0; long long t_minsvlen = 0; PyObject *t_fmt = NULL;
   OutBuf tb = {NULL, 0, 0}, *scol = NULL, *idc = NULL; int64_t *t_off = NULL, *t_pos = NULL;
   Py_buffer fr_rec, fr_pool, fr_st, fr_ln, fr_hp, fr_pss, fr_psl; int fast_cols = 0, have_ph = 0;
+  /* (an error while the options are read leaves through here: the thirteen buffers PyArg_ParseTuple acquired - and whatever column
+   * buffers were taken so far - are released; a numpy array stays export-locked otherwise) */
+  Py_buffer* fr_all[7] = {&fr_hp, &fr_pss, &fr_psl, &fr_rec, &fr_pool, &fr_st, &fr_ln}; int fr_got = 0;
+#define EARLY_FAIL() do { for (int k_ = 0; k_ < fr_got; k_++) PyBuffer_Release(fr_all[k_]); \
+    PyBuffer_Release(&ob); PyBuffer_Release(&eb); PyBuffer_Release(&gb); PyBuffer_Release(&mb); PyBuffer_Release(&cb); PyBuffer_Release(&svb); \
+    PyBuffer_Release(&tkb); PyBuffer_Release(&sidb); PyBuffer_Release(&sposb); PyBuffer_Release(&evo); PyBuffer_Release(&evb); PyBuffer_Release(&evn); \
+    PyBuffer_Release(&csb); return NULL; } while (0)
   if (text) {
-    if (!PyDict_Check(topt)) { PyErr_SetString(PyExc_TypeError, "group_calls: text options must be a dict"); return NULL; }
+    if (!PyDict_Check(topt)) { PyErr_SetString(PyExc_TypeError, "group_calls: text options must be a dict"); EARLY_FAIL(); }
 #define TOPT(name) PyDict_GetItemString(topt, name)
     if (!TOPT("phase") || !TOPT("symbolic") || !TOPT("mosaic") || !TOPT("output_rnames") || !TOPT("nm") || !TOPT("minsvlen") || !TOPT("genotype_format")) {
-      PyErr_SetString(PyExc_KeyError, "group_calls: incomplete text options"); return NULL; }
+      PyErr_SetString(PyExc_KeyError, "group_calls: incomplete text options"); EARLY_FAIL(); }
     t_phase = PyObject_IsTrue(TOPT("phase")); t_symbolic = PyObject_IsTrue(TOPT("symbolic")); t_mosaic = PyObject_IsTrue(TOPT("mosaic"));
     t_rnames = PyObject_IsTrue(TOPT("output_rnames")); t_nm = PyObject_IsTrue(TOPT("nm")); t_minsvlen = PyLong_AsLongLong(TOPT("minsvlen"));
     t_fmt = TOPT("genotype_format");
-    if (PyErr_Occurred()) return NULL;
+    if (PyErr_Occurred()) EARLY_FAIL();
     /* candidate columns (optional): with them a record is
      * formatted from arrays alone: the genotype of a sample from its chosen candidate's record, the chained ids and the phase set
      * from a string pool (ph_hp: haplotype of genotypes[0]'s phase, -1 None; ph_ps_len -1: no phase set) */
     if (TOPT("rec") && TOPT("id_pool") && TOPT("id_start") && TOPT("id_len") && TOPT("ph_hp") && TOPT("ph_ps_start") && TOPT("ph_ps_len")) {
-      if (PyObject_GetBuffer(TOPT("ph_hp"), &fr_hp, PyBUF_SIMPLE) != 0) return NULL;
-      if (PyObject_GetBuffer(TOPT("ph_ps_start"), &fr_pss, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_hp); return NULL; }
-      if (PyObject_GetBuffer(TOPT("ph_ps_len"), &fr_psl, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_hp); PyBuffer_Release(&fr_pss); return NULL; }
-      have_ph = 1;
-      if (PyObject_GetBuffer(TOPT("rec"), &fr_rec, PyBUF_SIMPLE) != 0) return NULL;
-      if (PyObject_GetBuffer(TOPT("id_pool"), &fr_pool, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); return NULL; }
-      if (PyObject_GetBuffer(TOPT("id_start"), &fr_st, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); return NULL; }
-      if (PyObject_GetBuffer(TOPT("id_len"), &fr_ln, PyBUF_SIMPLE) != 0) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); PyBuffer_Release(&fr_st); return NULL; }
-      fast_cols = 1;
+      static const char* names[7] = {"ph_hp", "ph_ps_start", "ph_ps_len", "rec", "id_pool", "id_start", "id_len"};
+      for (int k_ = 0; k_ < 7; k_++) {
+        if (PyObject_GetBuffer(TOPT(names[k_]), fr_all[k_], PyBUF_SIMPLE) != 0) EARLY_FAIL();
+        fr_got = k_ + 1;
+      }
+      have_ph = 1; fast_cols = 1;
     }
 #undef TOPT
   }
+#undef EARLY_FAIL
   const int32_t* CS = (const int32_t*)csb.buf;      /* sample_internal_id per candidate (table order) */
   PyObject* ret = NULL;
   const snf_group_out_t* O = (const snf_group_out_t*)ob.buf;

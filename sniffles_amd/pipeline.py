@@ -204,6 +204,9 @@ def call_sample(records: bam.BamRecords, config, vcf_handle=None, snf_path=None,
     return out
 
 
+from . import candstore  # noqa: E402
+
+
 def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0, objects: bool = True) -> list:
     """Multi-sample calling from per-sample `.snf` files: the `combine` flow of the reference's main program
     (`sniffles:371-490`) for one process - headers (sample ids, contig lengths, format checks), one `CombineTask` per
@@ -244,6 +247,7 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
         for part in parallel.CombineTask.execute_many(tasks, readers, text_writer=writer):
             writer.write_merged(part, sort=getattr(config, "sort", True))
         for f in readers.values():
+            candstore.clear_columns(f)      # (the merge is written: the readers' column tables go with it)
             f.close()
         return []
     # all contigs share one group-assignment launch (a contig alone leaves most of the device idle)
@@ -255,6 +259,7 @@ def combine(snf_paths, config, vcf_handle=None, sample_ids=None, device: int = 0
                 writer.write_call(c)
         out.extend(calls)
     for f in readers.values():
+        candstore.clear_columns(f)
         f.close()
     return out
 

@@ -18,7 +18,10 @@ for k in acc:
     wc = c.get("SQ_WAVE_CYCLES", 0)
     rows.append((d, k, valu_us, c, wc))
 rows.sort(reverse=True)
-print("%-44s %8s %8s %9s %9s %9s %9s %9s %9s" % ("kernel (per launch)", "us", "VALU us", "waves", "VALU", "SALU", "LDS", "VMEM_RD", "VMEM_WR"))
+# LDS: SQ_LDS_BANK_CONFLICT = cycles the LDS pipe spent on bank conflicts, SQ_LDS_IDX_ACTIVE = cycles it was busy with indexed accesses:
+# their ratio is the share of the LDS pipe's time that conflicts cost (0 where a kernel has no LDS traffic)
+print("%-44s %8s %8s %9s %9s %9s %9s %9s %9s %11s %11s %8s" % ("kernel (per launch)", "us", "VALU us", "waves", "VALU", "SALU", "LDS", "VMEM_RD", "VMEM_WR", "LDS_BANK_CF", "LDS_IDX_ACT", "cf/act"))
 for d, k, vu, c, wc in rows:
-    print("%-44s %8.1f %8.1f %9.0f %9.3g %9.3g %9.3g %9.3g %9.3g  wave_cycles %.3g busy %.3g" % (k, d, vu, c.get("SQ_WAVES", 0), c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_SALU", 0),
-          c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), wc, c.get("SQ_BUSY_CYCLES", 0)))
+    bc, ia = c.get("SQ_LDS_BANK_CONFLICT", 0), c.get("SQ_LDS_IDX_ACTIVE", 0)
+    print("%-44s %8.1f %8.1f %9.0f %9.3g %9.3g %9.3g %9.3g %9.3g %11.3g %11.3g %8.3f  wave_cycles %.3g busy %.3g" % (k, d, vu, c.get("SQ_WAVES", 0), c.get("SQ_INSTS_VALU", 0), c.get("SQ_INSTS_SALU", 0),
+          c.get("SQ_INSTS_LDS", 0), c.get("SQ_INSTS_VMEM_RD", 0), c.get("SQ_INSTS_VMEM_WR", 0), bc, ia, (bc / ia if ia else 0.0), wc, c.get("SQ_BUSY_CYCLES", 0)))
