@@ -43,6 +43,8 @@ def lib():
         _lib.snf_oracle_free.restype = None
         _lib.snf_oracle_edit_distance.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
         _lib.snf_oracle_edit_distance.restype = C.c_int64
+        _lib.snf_oracle_edit_distance_myers.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+        _lib.snf_oracle_edit_distance_myers.restype = C.c_int64
         _lib.snf_oracle_np_sum.argtypes = [C.POINTER(C.c_double), C.c_int64]
         _lib.snf_oracle_np_sum.restype = C.c_double
         _lib.snf_oracle_stdev.argtypes = [C.POINTER(C.c_int64), C.c_int64]
@@ -72,6 +74,11 @@ def run(cfg, tasks, finalize: bool = True):
 
 def edit_distance(a: bytes, b: bytes) -> int:
     return int(lib().snf_oracle_edit_distance(a, len(a), b, len(b)))
+
+
+def edit_distance_myers(a: bytes, b: bytes) -> int:
+    """The same distance by the bit-parallel algorithm edlib implements (the edlib stand-in of the config-4 reference baseline)."""
+    return int(lib().snf_oracle_edit_distance_myers(a, len(a), b, len(b)))
 
 
 def np_sum(x: np.ndarray) -> float:

@@ -290,7 +290,10 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     resolve_block_groups (two chained windows per SV type so that `groups_initial` is exercised) and SVGroup.call."""
     import oracle as oc  # exact DP (C) as the stand-in for edlib.align(...)['editDistance']
     ref = load_reference()
-    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    # edlib.align(a, b)["editDistance"]: the exact DP (goldens), or - `align="myers"`, the baseline of bench.py --config 4 - the bit-parallel
+    # algorithm edlib implements (oracle/snf_oracle.c::snf_oracle_edit_distance_myers, pinned to the DP)
+    dist_fn = oc.edit_distance_myers if align == "myers" else oc.edit_distance
+    ref.sv.align = lambda a, b: {"editDistance": dist_fn(a.encode("latin-1"), b.encode("latin-1"))}
     ns = len(sample_tasks)
     cfg = make_config(tuple(extra_args), sample_tasks[0].qc_nm_threshold)
     per_sample = []
@@ -342,7 +345,7 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     return out
 
 
-def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, scatter_target=None):
+def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, scatter_target=None, align=None, before_execute=None, timing=None):
     """The reference's own CombineTask.execute (parallel.py:444-572) on a synthetic population.
 
     Per-sample candidates come from the reference's call_candidates + finalize_candidates; they are put into SNF blocks by
@@ -416,7 +419,14 @@ def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, 
     old_target = ref.parallel.CombineTask.TARGET_WORK_PER_TASK
     try:
         ctask = ref.parallel.CombineTask(id=7, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
+        if before_execute is not None:
+            before_execute()                 # (a barrier: every worker of a pool holds its samples' blocks)
+        import time as _time
+        _t0 = _time.perf_counter()
         res = ctask.execute()
+        if timing is not None:
+            timing["execute_s"] = _time.perf_counter() - _t0
+            timing["candidates"] = sum(len(b[t]) for blocks in blocks_per_sample for b in blocks.values() for t in ref.sv.TYPES)
         if scatter_target is not None:
             # the reference's own CombineTask.scatter / clone (parallel.py:411-442) with its class constant lowered so that
             # a test-sized contig is cut (the constant is 10000 blocks x samples), every sub-task executed on its own

@@ -1264,6 +1264,51 @@ int64_t snf_oracle_edit_distance(const uint8_t* a, int64_t la, const uint8_t* b,
   return d;
 }
 
+/* The same distance by the bit-parallel algorithm edlib implements (Myers 1999 in Hyyro's formulation for the GLOBAL distance, 64 rows of the DP
+ * matrix per machine word, blocks chained through the horizontal carries): what a CPU run of the reference spends its alignment time in when
+ * edlib is present.  Used as the edlib STAND-IN of bench.py --config 4's reference baseline (edlib itself is absent from this image); pinned to
+ * snf_oracle_edit_distance by tests/test_edit_distance.py.  O(ceil(m / 64) * n) word operations. */
+int64_t snf_oracle_edit_distance_myers(const uint8_t* a, int64_t la, const uint8_t* b, int64_t lb) {
+  /* pattern = the shorter string (rows), text = the longer one (columns) */
+  if (la > lb) { const uint8_t* t = a; a = b; b = t; int64_t tl = la; la = lb; lb = tl; }
+  const int64_t m = la, n = lb;
+  if (m == 0) return n;
+  const int64_t W = (m + 63) / 64;
+  uint64_t* peq = (uint64_t*)calloc((size_t)(256 * W), sizeof(uint64_t));
+  uint64_t* Pv = (uint64_t*)malloc((size_t)W * sizeof(uint64_t));
+  uint64_t* Mv = (uint64_t*)calloc((size_t)W, sizeof(uint64_t));
+  for (int64_t i = 0; i < m; i++) peq[(size_t)a[i] * (size_t)W + (size_t)(i >> 6)] |= 1ull << (i & 63);
+  for (int64_t w = 0; w < W; w++) Pv[w] = ~0ull;
+  const int last_bits = (int)(m - 64 * (W - 1));            /* rows in the last word: 1..64 */
+  const uint64_t last_mask = 1ull << (last_bits - 1);
+  int64_t score = m;
+  for (int64_t j = 0; j < n; j++) {
+    const uint64_t* eqc = peq + (size_t)b[j] * (size_t)W;
+    int hin = 1;                                            /* global alignment: the top row of the matrix is 0, 1, 2, ... (+1 per column) */
+    for (int64_t w = 0; w < W; w++) {
+      uint64_t Eq = eqc[w];
+      const uint64_t pv = Pv[w], mv = Mv[w];
+      const uint64_t hin_neg = hin < 0 ? 1ull : 0ull;
+      const uint64_t Xv = Eq | mv;
+      Eq |= hin_neg;
+      const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+      uint64_t Ph = mv | ~(Xh | pv);
+      uint64_t Mh = pv & Xh;
+      int hout = 0;
+      const uint64_t top = (w == W - 1) ? last_mask : (1ull << 63);
+      if (Ph & top) hout = 1; else if (Mh & top) hout = -1;
+      Ph <<= 1; Mh <<= 1;
+      if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+      Pv[w] = Mh | ~(Xv | Ph);
+      Mv[w] = Ph & Xv;
+      hin = hout;
+    }
+    score += hin;                                           /* hin is now the horizontal delta of the last row */
+  }
+  free(peq); free(Pv); free(Mv);
+  return score;
+}
+
 /* ------------------------------------------------------------------ combine (multi-sample) -- test infrastructure
  * cluster.resolve_block_groups (cluster.py:356-390) + SVGroup.from_candidate / align_call / add_candidate
  * (sv.py:263-318), followed literally; edlib.align(a,b)["editDistance"] = snf_oracle_edit_distance (exact DP). */

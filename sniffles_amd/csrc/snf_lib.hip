@@ -540,7 +540,19 @@ double likelihood_ratio(double q1, double q2) {
   if (q1 / q2 > 0) return std::log(q1 / q2) / std::log(10.0);  // math.log(x, 10)
   return 0;
 }
-std::vector<GtEntry> build_gt_lut(const snf_config_t& cfg) {
+// (the table depends on two scalars of the configuration only and costs ~0.4 M libm calls - 2 ms, two thirds of a contig task's upload:
+//  built once per process and configuration)
+std::vector<GtEntry> build_gt_lut_uncached(const snf_config_t& cfg);
+const std::vector<GtEntry>& build_gt_lut(const snf_config_t& cfg) {
+  static std::mutex mu;
+  static std::map<std::pair<uint64_t, int>, std::vector<GtEntry>> known;
+  uint64_t bits; memcpy(&bits, &cfg.genotype_error, sizeof(bits));
+  std::lock_guard<std::mutex> g(mu);
+  auto it = known.find({bits, (int)cfg.genotype_ploidy});
+  if (it == known.end()) it = known.emplace(std::make_pair(bits, (int)cfg.genotype_ploidy), build_gt_lut_uncached(cfg)).first;
+  return it->second;      // (entries are never erased: the reference stays valid)
+}
+std::vector<GtEntry> build_gt_lut_uncached(const snf_config_t& cfg) {
   std::vector<GtEntry> lut((size_t)SNF_GT_N * SNF_GT_N);
   double p[3] = {cfg.genotype_error, 1.0 / (double)cfg.genotype_ploidy, 1.0 - cfg.genotype_error};
   for (int ns = 0; ns < SNF_GT_N; ns++)
@@ -976,7 +988,7 @@ void do_upload(snf_batch_impl* b) {
   v.cand = dalloc<snf_call_t>(b, N1); v.candx = dalloc<CallX>(b, N1);
   v.calls = dalloc<snf_call_t>(b, N1); v.callx = dalloc<CallX>(b, N1);
   v.rnames = dalloc<uint32_t>(b, 2 * (size_t)N + 1);
-  auto lut = build_gt_lut(b->cfg);
+  const auto& lut = build_gt_lut(b->cfg);
   v.gt_lut = upload_vec(b, lut);
   v.cons_call = dalloc<int32_t>(b, N1);
   v.stripes = dalloc<unsigned long long>(b, 4 * 64 * 16);
@@ -1948,19 +1960,21 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     // staged result, copied by the pass's own copy kernels (they read the sizes on the device and do nothing when a section does not fit)
     const bool block_there = !h.in_pinned && b->staged_kernel && b->stage_block_copied && v.stage_out_pin == (uint8_t*)b->hb_out.p && h.bytes <= v.stage_out_cap;
     const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged_kernel && b->stage_alt_copied && !alt_late && v.stage_alt_pin == (uint8_t*)b->hb_alt.p && alt_total_now <= v.stage_alt_cap;
+    bool need_sync = false;
     if (!h.in_pinned && !block_there) {
       v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)
       base = (const uint8_t*)b->hb_out.ensure((size_t)h.bytes + 256);
       d2h_timed(b, (void*)base, v.out_dev, (size_t)h.bytes, "d2h_block");
-      dsync(b);
+      need_sync = true;
     }
     const int64_t alt_total = b->h_cnt->alt_total;
     const uint8_t* alt = (const uint8_t*)b->hb_alt.p;
     if (!b->h_cnt->alt_in_pinned && !alt_there) {
       v.alt_pin = nullptr; v.alt_pin_cap = 0;
       alt = (const uint8_t*)b->hb_alt.ensure((size_t)alt_total + 256);
-      if (alt_total) { d2h_timed(b, (void*)alt, v.alt_pool, (size_t)alt_total, "d2h_alt"); dsync(b); }
+      if (alt_total) { d2h_timed(b, (void*)alt, v.alt_pool, (size_t)alt_total, "d2h_alt"); need_sync = true; }
     }
+    if (need_sync) dsync(b);      // (both copies behind each other on the stream, one wait)
     memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
     collect_timings(b);
     out->n_calls = h.n_out; out->calls = (const snf_call_t*)base;
@@ -2233,7 +2247,7 @@ void do_genotype_batch(const snf_config_t* cfg, int device, snf_call_t* calls, i
   if (n <= 0) return;
   if (cfg->genotype_ploidy != 2) fail("only genotype_ploidy 2 is supported");
   if (device < 0 || device >= SNF_MAX_DEVICES) fail("device index out of range");
-  auto lut = build_gt_lut(*cfg);
+  const auto& lut = build_gt_lut(*cfg);
   DevArena& A = g_geno_arenas[device];
   std::lock_guard<std::mutex> hold(A.mu);
   ArenaLayout L;

@@ -146,3 +146,29 @@ def test_population_variant_match_equals_the_reference_emu(oracle_mod, extra):
 def test_population_variant_match_equals_the_reference_gpu(oracle_mod):
     _check_population_match(None)
     _check_population_match(None, ("--combine-pctseq", "0.9", "--combine-match", "100"))
+
+
+def test_oracle_myers_stand_in_equals_the_exact_dp():
+    """oracle/snf_oracle.c::snf_oracle_edit_distance_myers - the bit-parallel algorithm edlib implements, the edlib stand-in of the config-4
+    reference baseline (bench.py --config 4) - against the exact DP: lengths around the 64-row word boundaries, near and unrelated strings."""
+    import random
+    import oracle as oc
+    oc.build()
+    rng = random.Random(77)
+    for _ in range(1500):
+        la = rng.choice([0, 1, 2, 5, 17, 63, 64, 65, 100, 127, 128, 129, 200, 511])
+        a = bytes(rng.choice(b"ACGT") for _ in range(la))
+        if rng.random() < 0.5 and la:
+            b = bytearray(a)
+            for _ in range(rng.randint(0, max(1, la // 8))):
+                op, p = rng.random(), rng.randrange(len(b) + 1)
+                if op < 0.33 and b:
+                    b[min(p, len(b) - 1)] = rng.choice(b"ACGT")
+                elif op < 0.66:
+                    b.insert(p, rng.choice(b"ACGT"))
+                elif b:
+                    del b[min(p, len(b) - 1)]
+            b = bytes(b)
+        else:
+            b = bytes(rng.choice(b"ACGTN") for _ in range(rng.choice([0, 1, 3, 64, 65, 127, 128, 300])))
+        assert oc.edit_distance_myers(a, b) == oc.edit_distance(a, b), (a, b)

@@ -201,7 +201,40 @@ def run(ctx):
         if ver is not None:
             out["verified"] = bool(ver["ok"] and text_equal)      # group assignment vs the oracle AND the text path vs the object path
             out["verify"] = ver
+        if not getattr(args, "no_reference_baseline", False):
+            # the UNMODIFIED reference's CombineTask.execute on the same population, on this box's cores (edlib -> the bit-parallel stand-in)
+            try:
+                ref_base = reference_baseline(my_contigs, S, cov, total_cands, total_calls, dt / steps)
+            except Exception as e:  # noqa: BLE001 - a baseline that cannot run must not take the line down; it says why
+                ref_base = None
+                out["cpu_baseline"]["reference_error"] = f"{type(e).__name__}: {str(e)[:400]}"
+            if ref_base is not None:
+                ref_base["port"] = out["cpu_baseline"]
+                out["cpu_baseline"] = ref_base
     return out
+
+
+def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge):
+    """`cpu_baseline` of kind "reference (edlib stand-in)": oracle/ref_combine_pool.py - the unmodified reference's `CombineTask.execute`
+    (parallel.py:444-572), one process per contig, on the same seeded population (its samples called by the reference's own path, untimed),
+    `sv.align` = the bit-parallel algorithm edlib implements (edlib is absent from this image: parity unpinned)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_combine_pool
+    if not ref_combine_pool.available():
+        return None
+    r = ref_combine_pool.run(list(contigs), S, cov, max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
+    return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)", host_cores=r["cores"],
+                hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
+                candidates=r["candidates"], combined_calls=r["combined"],
+                same_population=dict(candidates_equal=bool(r["candidates"] == n_cands), combined_calls_equal=bool(r["combined"] == n_calls),
+                                     here=dict(candidates=n_cands, combined_calls=n_calls)),
+                vs_baseline=dict(merge=round(r["hot_all_core_s"] / gpu_s_per_merge, 1),
+                                 note="reference all-core seconds for the merge / this package's seconds per merge (candidates resident as columns -> merged VCF records)"),
+                parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, pinned to the exact DP), not edlib",
+                sample=f"the whole workload: {len(contigs)} contig tasks x {S} samples, the unmodified reference's CombineTask.execute, one process per contig "
+                       f"({r['procs']} processes on {r['cores']} usable cores), every process starts its first merge at a barrier once its samples' SNF blocks "
+                       f"exist (built by the reference's own calling path, untimed): slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; "
+                       f"whole leg {r['total_wall_s']:.0f} s")
 
 
 def sample_windows(cfg, readers, contigs, limit):

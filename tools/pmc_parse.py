@@ -30,7 +30,7 @@ out = {"_about": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "hbm_bytes = (2*FETCH + WRITE) * 1024: gfx950 FETCH_SIZE counts 128-B requests as 64 B (x2, calibrated on a1_keys: "
                  "known reads 9 B/lead, known writes 13 B/lead), WRITE_SIZE is exact.  hbm_bytes is therefore an UPPER bound: "
                  "tools/probe/fetch_calib.hip (profiles/r04_fetch_calib.txt) shows that FETCH_SIZE counts requests x 64 B - a coalesced "
-                 "stream (128-B requests) is reported at half, a gather of 64-byte records (64-B requests: w6_emit, d1w_refine, the call "
+                 "stream (128-B requests) is reported at half, a gather of 64-byte records (64-B requests: w6t_emit, d1g / d1w_refine, the call "
                  "kernels, d4_coverage) exactly; hbm_bytes_lo = (FETCH + WRITE) * 1024 is the lower bound.", "kernels": {}}
 for k in sorted(fe, key=lambda k: -(2 * fe[k][0] + wr.get(k, (0, 1))[0])):
     n = fe[k][1]; f = fe[k][0] / n; w = wr.get(k, (0.0, n))[0] / max(1, wr.get(k, (0, n))[1])
