@@ -204,7 +204,8 @@ def run(ctx):
         if not getattr(args, "no_reference_baseline", False):
             # the UNMODIFIED reference's CombineTask.execute on the same population, on this box's cores (edlib -> the bit-parallel stand-in)
             try:
-                ref_base = reference_baseline(my_contigs, S, cov, total_cands, total_calls, dt / steps)
+                ref_base = reference_baseline(my_contigs, S, cov, total_cands, int(phases.get("calls", total_calls)), dt / steps,
+                                              sample=getattr(args, "reference_sample_contigs", None))
             except Exception as e:  # noqa: BLE001 - a baseline that cannot run must not take the line down; it says why
                 ref_base = None
                 out["cpu_baseline"]["reference_error"] = f"{type(e).__name__}: {str(e)[:400]}"
@@ -214,7 +215,7 @@ def run(ctx):
     return out
 
 
-def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge):
+def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sample=None):
     """`cpu_baseline` of kind "reference (edlib stand-in)": oracle/ref_combine_pool.py - the unmodified reference's `CombineTask.execute`
     (parallel.py:444-572), one process per contig, on the same seeded population (its samples called by the reference's own path, untimed),
     `sv.align` = the bit-parallel algorithm edlib implements (edlib is absent from this image: parity unpinned)."""
@@ -222,6 +223,22 @@ def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge):
     import ref_combine_pool
     if not ref_combine_pool.available():
         return None
+    if sample:      # a bounded sample (bench.py's default line): the `sample` smallest contig tasks, one process each; the whole workload: bench.py --config 4
+        part = sorted(contigs, key=lambda c: c[2])[:int(sample)]
+        r = ref_combine_pool.run(part, S, cov)
+        per_cand = r["hot_single_core_s"] / max(1, r["candidates"])
+        share = max(c[2] for c in contigs) / float(sum(c[2] for c in contigs))
+        return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)", host_cores=r["cores"],
+                    hot_all_core_s=round(r["hot_all_core_s"], 3), candidates=r["candidates"], combined_calls=r["combined"],
+                    single_core_cand_s=round(1.0 / per_cand, 1),
+                    # the reference merges one contig per process: the wall clock of a whole merge is its largest contig task
+                    whole_merge_estimate=dict(all_core_s=round(per_cand * n_cands * share, 1),
+                                              vs_this_package=round(per_cand * n_cands * share / gpu_s_per_merge, 1),
+                                              note="single-core seconds per candidate of the sample x the candidates of the largest contig task (one process "
+                                                   "per contig); measured on the whole workload by `bench.py --config 4`: profiles/r05_final_bench_config4.json"),
+                    parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, pinned to the exact DP), not edlib",
+                    sample=f"the {len(part)} smallest contig tasks ({', '.join(c[1] for c in part)}) x {S} samples, the unmodified reference's CombineTask.execute, one process "
+                           f"per contig: slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; whole leg {r['total_wall_s']:.0f} s")
     r = ref_combine_pool.run(list(contigs), S, cov, max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
     return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)", host_cores=r["cores"],
                 hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
