@@ -292,6 +292,7 @@ struct snf_batch_impl {
   int graph_mode = 0;             // set at upload: 2 = replay (small batches, or SNF_GRAPH=1), 0 = eager, 1 = replay only while no other batch of
                                   // this process has a pass in flight
   bool in_flight = false;         // counted in g_passes_in_flight
+  double pass_start_ms = 0.0;     // when this handle's pass in flight began (pacing of overlapping passes)
   bool capturing = false;         // run_pass is capturing this pass into a graph
   // Result staged through HBM (run_finalize): with another pass in flight on the device the kernels of a pass store the result block
   // and the ALT section into HBM; they are taken to the pinned buffers by two copies at the fetch (default) or by two small copy
@@ -1122,8 +1123,48 @@ void do_upload(snf_batch_impl* b) {
 // call_candidates .. the fetch / sync that waits for it)
 std::atomic<int> g_passes_in_flight{0};
 std::atomic<long long> g_last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
-void pass_begins(snf_batch_impl* b) { if (!b->in_flight) { b->in_flight = true; if (g_passes_in_flight.fetch_add(1) >= 1) g_last_overlap_ms.store((long long)now_ms()); } }
-void pass_waited(snf_batch_impl* b) { if (b->in_flight) { b->in_flight = false; if (g_passes_in_flight.fetch_sub(1) >= 2) g_last_overlap_ms.store((long long)now_ms()); } }
+// Pacing of overlapping passes.  Two passes in flight run best OUT OF PHASE - one computes while the other's result crosses PCIe
+// (staged result, run_finalize).  Left alone, two host threads fall into step in about one run of five and stay there: both passes start
+// together, share the device through all their kernels, reach their copies together and share the link too - 1.24-1.38 ms per step
+// instead of 0.95-1.0 (profiles/r05_pace.log: 2 of 10 runs; 3 of 12 in ab_r05_5.log).  Two cheap rules keep them apart, each sufficient
+// in 8 of 8 runs, both together the default: (1) the copies of a staged result are taken one pass at a time (g_copy_mu: the link is
+// shared anyway; the pass that waited starts its next pass later - a stagger), (2) a pass does not START sooner than a quarter of the
+// recent pass latency after the other in-flight pass did (the second of two simultaneous starts waits ~0.4 ms once; passes that are
+// half a period apart never wait).  SNF_PACE=0 turns both off (2: rule 1 only, 3: rule 2 only), SNF_PACE_FRAC sets the fraction.
+std::mutex g_copy_mu, g_pace_mu;
+double g_last_pass_start_ms = -1e12, g_pass_latency_ms = 0.0;      // (under g_pace_mu) start of the latest pass; smoothed enqueue -> waited time
+int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : 1; return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
+bool pace_on() { return pace_mode() == 1 || pace_mode() == 3; }
+bool pace_copy_turn() { return pace_mode() == 1 || pace_mode() == 2; }
+double pace_frac() { static const double f = getenv("SNF_PACE_FRAC") ? atof(getenv("SNF_PACE_FRAC")) : 0.25; return f; }
+void pass_begins(snf_batch_impl* b) {
+  if (b->in_flight) return;
+  b->in_flight = true;
+  const bool other = g_passes_in_flight.fetch_add(1) >= 1;
+  if (other) g_last_overlap_ms.store((long long)now_ms());
+  if (!pace_on()) { b->pass_start_ms = now_ms(); return; }
+  double wait = 0.0;
+  {
+    std::lock_guard<std::mutex> g(g_pace_mu);
+    const double now = now_ms();
+    if (other && g_pass_latency_ms > 0.0) wait = g_last_pass_start_ms + pace_frac() * g_pass_latency_ms - now;
+    if (wait > 2.0) wait = 2.0;                 // (never more than 2 ms, whatever the history says)
+    if (wait < 0.0) wait = 0.0;
+    g_last_pass_start_ms = now + wait;          // (the slot is taken; the wait itself happens outside the lock)
+  }
+  if (wait > 0.0) { struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)(wait * 1e6); nanosleep(&ts, nullptr); }
+  b->pass_start_ms = now_ms();
+}
+void pass_waited(snf_batch_impl* b) {
+  if (!b->in_flight) return;
+  b->in_flight = false;
+  if (g_passes_in_flight.fetch_sub(1) >= 2) g_last_overlap_ms.store((long long)now_ms());
+  if (pace_on() && b->pass_start_ms > 0.0) {
+    std::lock_guard<std::mutex> g(g_pace_mu);
+    const double lat = now_ms() - b->pass_start_ms;
+    g_pass_latency_ms = g_pass_latency_ms > 0.0 ? 0.75 * g_pass_latency_ms + 0.25 * lat : lat;
+  }
+}
 // is this process driving several passes at a time?  (Asked when a pass is enqueued: the other handle may be between its fetch and its
 // next pass at that very moment - what counts is whether passes overlapped a moment ago.)
 bool passes_overlap() { return g_passes_in_flight.load() > 1 || (long long)now_ms() - g_last_overlap_ms.load() < 100; }
@@ -1961,6 +2002,9 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     const bool block_there = !h.in_pinned && b->staged_kernel && b->stage_block_copied && v.stage_out_pin == (uint8_t*)b->hb_out.p && h.bytes <= v.stage_out_cap;
     const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged_kernel && b->stage_alt_copied && !alt_late && v.stage_alt_pin == (uint8_t*)b->hb_alt.p && alt_total_now <= v.stage_alt_cap;
     bool need_sync = false;
+    // (the copies of a staged result: one pass at a time - see pass_begins)
+    std::unique_lock<std::mutex> copy_turn(g_copy_mu, std::defer_lock);
+    if (b->staged && pace_copy_turn() && ((!h.in_pinned && !block_there) || (!b->h_cnt->alt_in_pinned && !alt_there))) copy_turn.lock();
     if (!h.in_pinned && !block_there) {
       v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)
       base = (const uint8_t*)b->hb_out.ensure((size_t)h.bytes + 256);
@@ -1975,6 +2019,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
       if (alt_total) { d2h_timed(b, (void*)alt, v.alt_pool, (size_t)alt_total, "d2h_alt"); need_sync = true; }
     }
     if (need_sync) dsync(b);      // (both copies behind each other on the stream, one wait)
+    if (copy_turn.owns_lock()) copy_turn.unlock();
     memcpy(b->r_off.data(), v.res_off, ((size_t)T + 1) * sizeof(int64_t));
     collect_timings(b);
     out->n_calls = h.n_out; out->calls = (const snf_call_t*)base;

@@ -67,6 +67,42 @@ SNF_D void big_push(const View& v, int kind, int32_t item) {
   v.big_list[((int64_t)kind * 64 + s) * v.big_cap + slot] = item;
 }
 
+// merge_inner's fused sequences (curr_lead.seq += to_merge.seq): every part - one per lane that holds one - is copied from its place in
+// the input pool to its place in the fused lead's slice, all 64 lanes on one part at a time.  The parts are taken FOUR at a time: their
+// loads are requested together and stored together.  (One part after the other - load, store, next part - was a dependent round trip per
+// part: ~100 us per fusing cluster, a third of a wave's time in d1w_refine; source and destination never overlap - the slices lie behind
+// the input sequences.)
+SNF_D void wave_copy_parts(const View& v, int lane, bool p_act, int64_t p_src, int32_t p_len, int64_t p_dst) {
+  typedef uint4 __attribute__((aligned(1))) u128_any;
+  unsigned long long pm = __ballot(p_act && p_len > 0);
+  while (pm) {
+    int z[4] = {0, 0, 0, 0}, np = 0;
+    while (pm && np < 4) { z[np++] = __builtin_ctzll(pm); pm &= pm - 1ull; }
+    int64_t so[4], dt[4]; int32_t sl[4]; uint4 buf[4]; uint8_t tb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      so[k] = __shfl(p_src, z[k], SNF_WAVE); dt[k] = __shfl(p_dst, z[k], SNF_WAVE);
+      const int32_t l = __shfl(p_len, z[k], SNF_WAVE);
+      sl[k] = k < np ? l : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t nfull = sl[k] & ~15;
+      buf[k] = make_uint4(0, 0, 0, 0); tb[k] = 0;
+      if (lane * 16 < nfull) buf[k] = *(const u128_any*)(v.pool + so[k] + lane * 16);
+      if (nfull + lane < sl[k]) tb[k] = v.pool[so[k] + nfull + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t nfull = sl[k] & ~15;
+      if (lane * 16 < nfull) *(u128_any*)(v.pool + dt[k] + lane * 16) = buf[k];
+      if (nfull + lane < sl[k]) v.pool[dt[k] + nfull + lane] = tb[k];
+      for (int32_t bb = SNF_WAVE * 16 + lane * 16; bb < nfull; bb += SNF_WAVE * 16)      // (sequences beyond 1 KB: the rest, 1 KB per step)
+        *(u128_any*)(v.pool + dt[k] + bb) = *(const u128_any*)(v.pool + so[k] + bb);
+    }
+  }
+}
+
 // hand-over list 2 (clusters d1g_refine<8> left to d1w_refine): 64 stripes with a counter each, as the lists of the call kernels
 // (snf_wave_call.h); consumer side: prefix of the stripes' counts in LDS, item i = entry i - pre[s] of stripe s
 SNF_D int64_t d1list_prefix(const View& v, int lane, int32_t* pre) {
@@ -224,20 +260,13 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         new_off = base + (incl - mine);
         if (need_copy && new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
       }
-      unsigned long long cmask = __ballot(need_copy);
-      while (cmask) {  // cooperative byte copy, one fused lead at a time
-        const int r0 = __builtin_ctzll(cmask); cmask &= cmask - 1;
-        const int r1 = __shfl(seg_end, r0, SNF_WAVE);
-        int64_t dst = __shfl(new_off, r0, SNF_WAVE);
-        for (int z = r0; z <= r1; z++) {
-          const int64_t so = __shfl(s_seq_off, z, SNF_WAVE); const int32_t sl = __shfl(s_seq_len, z, SNF_WAVE);
-          // 16 bytes per lane and step (any alignment), then the tail byte-wise
-          typedef uint4 __attribute__((aligned(1))) u128_any;
-          const int32_t nfull = sl & ~15;
-          for (int32_t b = lane * 16; b < nfull; b += SNF_WAVE * 16) *(u128_any*)(v.pool + dst + b) = *(const u128_any*)(v.pool + so + b);
-          if (nfull + lane < sl) v.pool[dst + nfull + lane] = v.pool[so + nfull + lane];
-          dst += sl;
-        }
+      {  // the parts of the fused leads that are copied: every sorted lane knows its source, its length and - the start lane's slice + the
+         // lengths of the parts before it in the same fused lead - its destination
+        const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        const int my_start = (act && (smask & upto)) ? 63 - __builtin_clzll(smask & upto) : 0;
+        const bool p_act = act && __shfl((int)need_copy, my_start, SNF_WAVE) != 0;
+        const int64_t p_dst = __shfl(new_off, my_start, SNF_WAVE) + (x_seq - __shfl(x_seq, my_start, SNF_WAVE));
+        wave_copy_parts(v, lane, p_act, s_seq_off, p_act ? s_seq_len : 0, p_dst);
       }
       const bool ok_seq = start && seq_ok && (nparts == 1 || need_copy);
       // compact the fused leads (start lanes) to lanes 0..m-1

@@ -145,20 +145,12 @@ __global__ void __launch_bounds__(SNF_WAVE) d1g_refine(const View v, int64_t n_u
         new_off = pbase + (incl - mine);
         if (need_copy && new_off + tot_seq > v.pool_cap) { atomicOr(&v.cnt->overflow, 1); need_copy = false; }
       }
-      unsigned long long cmask = __ballot(need_copy);
-      const int seg_end_abs = gbase + se;
-      while (cmask) {  // cooperative byte copy, one fused lead at a time, all 64 lanes
-        const int r0 = __builtin_ctzll(cmask); cmask &= cmask - 1;
-        const int r1 = __shfl(seg_end_abs, r0, SNF_WAVE);
-        int64_t dst = __shfl(new_off, r0, SNF_WAVE);
-        for (int z = r0; z <= r1; z++) {
-          const int64_t so = __shfl(s_seq_off, z, SNF_WAVE); const int32_t sl = __shfl(s_seq_len, z, SNF_WAVE);
-          typedef uint4 __attribute__((aligned(1))) u128_any;
-          const int32_t nfull = sl & ~15;
-          for (int32_t bb = lane * 16; bb < nfull; bb += SNF_WAVE * 16) *(u128_any*)(v.pool + dst + bb) = *(const u128_any*)(v.pool + so + bb);
-          if (nfull + lane < sl) v.pool[dst + nfull + lane] = v.pool[so + nfull + lane];
-          dst += sl;
-        }
+      {  // the parts that are copied, as in d1w_refine (the copy itself is the wave's: all groups' parts, four at a time)
+        const unsigned long long upto = (2ull << gl) - 1ull;
+        const int my_start = (fact0 && (smask & upto)) ? 63 - __builtin_clzll(smask & upto) : 0;      // (group-relative)
+        const bool p_act = fact0 && __shfl((int)need_copy, gbase + my_start, SNF_WAVE) != 0;
+        const int64_t p_dst = __shfl(new_off, gbase + my_start, SNF_WAVE) + (x_seq - __shfl(x_seq, gbase + my_start, SNF_WAVE));
+        wave_copy_parts(v, lane, p_act, s_seq_off, p_act ? s_seq_len : 0, p_dst);
       }
       const bool ok_seq = start && seq_ok && (nparts == 1 || need_copy);
       // compact the fused leads (start lanes) to the front of the group
