@@ -77,3 +77,20 @@ def test_paint_nmask_is_the_dense_paint():
         soa.paint_nmask(lambda c, a=None, b=None: s + "N", "c", None, L)
     with pytest.raises(ValueError):
         soa.paint_nmask(lambda c, a=None, b=None: s[a:b] + "NN", "c", [(0, 100)], L)
+
+
+def test_gzip_with_fai_uses_the_index_and_scan_equals_fai(tmp_path):
+    """A `.fai` next to a gzip FASTA is used (its offsets index the decompressed text); without one the vectorised scan builds the
+    same table - also for "\r\n" line ends and a last line without a newline."""
+    p, seqs = _write(tmp_path, 37, gz=True, fai=True)
+    f = fasta.FastaFile(p)
+    (tmp_path / "ref.fa.gz.fai").write_text((tmp_path / "ref.fa.fai").read_text())
+    g = fasta.FastaFile(p)                      # with the index
+    (tmp_path / "ref.fa.gz.fai").unlink()
+    assert f._index == g._index                 # scan == .fai
+    for name, seq in seqs.items():
+        assert g.fetch(name) == seq and f.fetch(name, 5, 50) == seq[5:50]
+    q = tmp_path / "crlf.fa"
+    q.write_bytes(b">a x\r\nACGT\r\nAC\r\n>b\r\nGG")
+    h = fasta.FastaFile(str(q))
+    assert h.fetch("a") == "ACGTAC" and h.fetch("b") == "GG" and h._index["a"] == (6, 6, 4, 6)
