@@ -68,3 +68,63 @@ def test_more_than_65535_tasks_in_one_batch_are_refused():
     ti = synth.gen_fuzz(3, task_id=0)
     with pytest.raises(lib.SnifflesAmdError, match="too many tasks in one batch"):
         lib.Batch(SnifflesConfig(), [ti] * 65536)
+
+
+def test_batch_open_is_create_add_upload_and_the_first_call_in_one(oracle_mod):
+    """`snf_batch_open` (ABI 5; what `Task.prepare` runs on its helper thread): the same results as the call sequence it stands for,
+    for every run mode; a failure (unknown mode, a task the reference could not have produced, no device) leaves no handle behind and
+    reports the FIRST error; without a device the real library refuses like `snf_batch_create`."""
+    import numpy as np
+    import emu.emu as E
+    from sniffles_amd import abi, lib, records, synth
+    from sniffles_amd.config import SnifflesConfig
+    cfg = SnifflesConfig()
+    tis = [synth.gen_task(0, "chr21", 600_000, 30, 5), synth.gen_fuzz(9, task_id=1)]
+    if lib.device_count() == 0:
+        with pytest.raises(lib.SnifflesAmdError, match="no HIP device"):      # (the product library, no GPU: fails loudly here too)
+            lib.Batch.open_in_background(cfg, tis, run=lib.Batch.RUN_CANDIDATES).result()
+    E.lib()                                              # the host tier becomes the library of this test
+    exp = records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    with lib.Batch(cfg, tis) as b:
+        b.set_output(abi.OUT_EXECUTE); b.run_pass()
+        want_exe = b.fetch(1)
+    for run in (lib.Batch.RUN_NONE, lib.Batch.RUN_CANDIDATES, lib.Batch.RUN_PASS | abi.OUT_CANDIDATES, lib.Batch.RUN_PASS | abi.OUT_EXECUTE):
+        b = lib.Batch.open_in_background(cfg, tis, run=run).result()
+        try:
+            if run == lib.Batch.RUN_NONE:
+                b.call_candidates()
+            if run in (lib.Batch.RUN_NONE, lib.Batch.RUN_CANDIDATES):
+                b.finalize()
+            got = b.fetch(1)
+            if run == lib.Batch.RUN_PASS | abi.OUT_EXECUTE:
+                assert got.calls.tobytes() == want_exe.calls.tobytes() and got.alt_pool.tobytes() == want_exe.alt_pool.tobytes()
+            else:
+                assert records.records(got, tis, "final") == exp
+        finally:
+            b.close()
+    with pytest.raises(lib.SnifflesAmdError, match="unknown run mode"):
+        lib.Batch.open_in_background(cfg, tis, run=7).result()
+    bad = synth.gen_fuzz(9, task_id=2)
+    bad.leads["svtype"] = bad.leads["svtype"].copy()
+    bad.leads["svtype"][0] = 99                          # not a code the reference's SV types have: the upload refuses the task
+    with pytest.raises(lib.SnifflesAmdError):
+        lib.Batch.open_in_background(cfg, [tis[0], bad], run=lib.Batch.RUN_CANDIDATES).result()
+    pend = lib.Batch.open_in_background(cfg, tis, run=lib.Batch.RUN_CANDIDATES)
+    pend.discard()                                       # prepared and not wanted: closed, no handle leaks
+    assert pend._batch is None
+
+
+def test_worker_processes_plumbing_on_the_host_tier(monkeypatch):
+    """tools/bench_workers.py (bench.py's `wall_clock.worker_processes` leg): spawned workers, a common barrier, every input form and
+    call shape - on the host tier of the test suite, so that the leg cannot rot unseen (never a measurement)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_workers as W
+    monkeypatch.setenv("SNF_BENCH_EMU", "1")
+    specs = W.genome_specs(scale=0.003)[:4]
+    out = {}
+    for form, shape in (("columns", "api"), ("columns", "execute"), ("leads", "api")):
+        r = W.run(specs, {}, 2, form, shape, hw_queues=2)
+        assert r["procs"] == 2 and r["hot_all_ms"] > 0 and r["n_out"] > 0
+        out[(form, shape)] = r["n_out"]
+    assert out[("columns", "api")] == out[("leads", "api")] > out[("columns", "execute")]      # same candidates from objects and columns; execute keeps the QC-passing ones
