@@ -406,14 +406,18 @@ def run_calling(ctx):
         def body(w):
             for _ in range(total // W + (1 if w < total % W else 0)):
                 if shared:
-                    slot = 2 * w + (turn_box[w] & 1); turn_box[w] += 1
-                    send_free[slot].wait()                             # the parent has indexed the result this segment held two passes ago
-                    send_free[slot].clear()
-                    handles_box[0][w][0].set_result_memory(*landing.memory(slot))
+                    dbg = os.environ.get("SNF_BENCH_SHARED_DEBUG", "")      # probes of this path only: "oneslot", "nogather", "noset"
+                    slot = 2 * w + (0 if "oneslot" in dbg else (turn_box[w] & 1)); turn_box[w] += 1
+                    if "nogather" not in dbg:
+                        send_free[slot].wait()                         # the parent has indexed the result this segment held two passes ago
+                        send_free[slot].clear()
+                    if "noset" not in dbg or turn_box[w] <= 2:
+                        handles_box[0][w][0].set_result_memory(*landing.memory(slot))
                     one_pass(w)
                     served_box[0] += 1
                     n_calls_box[0] = lay_box[w]["n_calls"]
-                    comm_q.put((slot, lay_box[w], task_ids_local))
+                    if "nogather" not in dbg:
+                        comm_q.put((slot, lay_box[w], task_ids_local))
                     continue
                 n_calls_box[0] = one_pass(w)
                 served_box[0] += 1

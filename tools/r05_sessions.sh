@@ -149,5 +149,16 @@ SNF_BENCH_RESMEM=shm python bench.py --gpus 1 $Q 2>/dev/null | show "plain, resu
 python bench.py --gpus 1 $Q 2>/dev/null | show "plain"
 done
   ;;
-*) echo "usage: bash tools/r05_sessions.sh 1..12"; exit 2 ;;
+13)
+# round 5, thirteenth GPU session: what costs the shared-landing path (the N > 1 result path, one rank) its 16 % and its spread
+Q="--no-configs --no-cpu-baseline --no-wall-clock --steps 20 --warmup 5"
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1: ms_per_step %.3f' % d['ms_per_step'], [(k['name'], k['ms']) for k in d['roofline']['top_kernels'][:4]])"; }
+for i in 1 2 3; do
+SNF_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $Q 2>/dev/null | show "shared"
+SNF_BENCH_FORCE_DIST=1 SNF_PACE=0 python bench.py --gpus 1 $Q 2>/dev/null | show "shared, no pacing"
+SNF_BENCH_FORCE_DIST=1 SNF_BENCH_SHARED_DEBUG=nogather python bench.py --gpus 1 $Q 2>/dev/null | show "shared, no gather"
+SNF_BENCH_FORCE_DIST=1 SNF_BENCH_SHARED_DEBUG=nogather,oneslot,noset python bench.py --gpus 1 $Q 2>/dev/null | show "shared, no gather, one segment per handle set once"
+done
+;;
+*) echo "usage: bash tools/r05_sessions.sh 1..13"; exit 2 ;;
 esac
