@@ -160,5 +160,17 @@ SNF_BENCH_FORCE_DIST=1 SNF_BENCH_SHARED_DEBUG=nogather python bench.py --gpus 1 
 SNF_BENCH_FORCE_DIST=1 SNF_BENCH_SHARED_DEBUG=nogather,oneslot,noset python bench.py --gpus 1 $Q 2>/dev/null | show "shared, no gather, one segment per handle set once"
 done
 ;;
-*) echo "usage: bash tools/r05_sessions.sh 1..13"; exit 2 ;;
+14)
+# round 5, fourteenth GPU session: the shared-landing path with more hardware queues (RCCL's streams + eight of ours share four by default)
+Q="--no-configs --no-cpu-baseline --no-wall-clock --steps 20 --warmup 5"
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1: ms_per_step %.3f' % d['ms_per_step'], [(k['name'], k['ms']) for k in d['roofline']['top_kernels'][:4]])"; }
+for i in 1 2; do
+SNF_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $Q 2>/dev/null | show "shared"
+GPU_MAX_HW_QUEUES=8 SNF_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $Q 2>/dev/null | show "shared, 8 hardware queues"
+GPU_MAX_HW_QUEUES=16 SNF_BENCH_FORCE_DIST=1 python bench.py --gpus 1 $Q 2>/dev/null | show "shared, 16 hardware queues"
+GPU_MAX_HW_QUEUES=8 python bench.py --gpus 1 $Q 2>/dev/null | show "plain, 8 hardware queues"
+python bench.py --gpus 1 $Q 2>/dev/null | show "plain"
+done
+;;
+*) echo "usage: bash tools/r05_sessions.sh 1..14"; exit 2 ;;
 esac
