@@ -172,5 +172,13 @@ GPU_MAX_HW_QUEUES=8 python bench.py --gpus 1 $Q 2>/dev/null | show "plain, 8 har
 python bench.py --gpus 1 $Q 2>/dev/null | show "plain"
 done
 ;;
-*) echo "usage: bash tools/r05_sessions.sh 1..14"; exit 2 ;;
+15)
+# round 5, fifteenth GPU session: the plain line over the number of hardware queues the runtime may open (default 4: two handles' eight streams share them)
+Q="--no-configs --no-cpu-baseline --no-wall-clock --steps 20 --warmup 5"
+show() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1: ms_per_step %.3f' % d['ms_per_step'], [(k['name'], k['ms']) for k in d['roofline']['top_kernels'][:4]])"; }
+for i in 1 2; do
+for q in 2 3 4 5 6; do GPU_MAX_HW_QUEUES=$q python bench.py --gpus 1 $Q 2>/dev/null | show "plain, $q hardware queues"; done
+done
+;;
+*) echo "usage: bash tools/r05_sessions.sh 1..15"; exit 2 ;;
 esac
