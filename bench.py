@@ -42,8 +42,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from tools.bench_common import DEV, EMU, WORKLOADS, dev_sync, emu_lib, set_dev, task_specs  # noqa: E402,F401
-from tools.bench_legs import (bind_to_gpu_numa, cpu_baseline_and_verify, other_configs, reference_baseline, reference_check,  # noqa: E402,F401
-                              wall_clock, worker_processes)
+from tools.bench_legs import (bind_to_gpu_numa, cpu_baseline_and_verify, other_configs, reference_baseline,  # noqa: E402,F401
+                              reference_check, wall_clock, worker_processes)
 from tools.bench_roofline import HBM_PEAK_GBS, committed_issue, committed_profiles, pcie_d2h_peak_gbs  # noqa: E402,F401
 
 
@@ -126,11 +126,14 @@ def main():
             try:
                 out2 = run_calling(dict(ctx, args=a2))
                 if rank == 0:
-                    out["strong"] = dict(value=out2["value"], unit=out2["unit"], ms_per_step=out2["ms_per_step"], steps=out2["steps"], scaling="strong",
-                                         signatures=out2["config"]["signatures"], calls=out2["config"]["calls"], parallelism=out2["config"]["parallelism"],
+                    out["strong"] = dict(value=out2["value"], unit=out2["unit"], ms_per_step=out2["ms_per_step"], steps=out2["steps"],
+                                         scaling="strong",
+                                         signatures=out2["config"]["signatures"], calls=out2["config"]["calls"],
+                                         parallelism=out2["config"]["parallelism"],
                                          gathered_on_rank0=out2["config"]["gathered_on_rank0"], ranks_seen=out2.get("ranks_seen"),
                                          sets_served=out2.get("sets_served"),
-                                         note="ONE genome over the ranks of this run (one LPT-balanced contig set per rank and pass, claimed from the "
+                                         note="ONE genome over the ranks of this run (one LPT-balanced contig set per rank and pass, "
+                                              "claimed from the "
                                               "work queue); `value` of the line is the weak-scaling figure (N genome replicas)")
             except Exception as e:  # noqa: BLE001 - the weak line stands on its own
                 if rank == 0:
@@ -200,7 +203,8 @@ def run_calling(ctx):
     # --scaling strong) take the block gather over RCCL instead: result blocks in HBM, dist.gather onto rank 0, landed there.
     shared = use_dist and not strong and os.environ.get("SNF_BENCH_GATHER", "shared") != "rccl"
     strong_shared = use_dist and strong and os.environ.get("SNF_BENCH_GATHER", "shared") != "rccl"
-    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist and not shared and not strong_shared else 0)
+    out_mode = (abi.OUT_EXECUTE if args.output == "execute" else abi.OUT_CANDIDATES) | (abi.OUT_DEVICE if use_dist and not shared
+                                                                                        and not strong_shared else 0)
     for hs in handles:
         for bb in hs:
             bb.set_output(out_mode)
@@ -231,7 +235,8 @@ def run_calling(ctx):
         for probe in (handles[0] if strong_shared else handles[0][:1]):     # strong: the largest contig set sizes the segments
             probe.call_candidates(); probe.finalize()
             res0 = probe.fetch(1)
-            need_b = max(need_b, 256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames)); need_a = max(need_a, len(res0.alt_pool))
+            need_b = max(need_b, 256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames))
+            need_a = max(need_a, len(res0.alt_pool))
         need = torch.tensor([need_b, need_a], dtype=torch.int64, device=DEV)
         dist.all_reduce(need, op=dist.ReduceOp.MAX)
         # /dev/shm must hold every rank's segments (containers often cap it): otherwise the block gather over RCCL is taken
@@ -239,14 +244,16 @@ def run_calling(ctx):
         seg_bytes = n_slots * (int(need[0]) * 3 // 2 + int(need[1]) * 3 // 2 + (2 << 20) + 8192)
         try:
             st = os.statvfs("/dev/shm")
-            room = st.f_bavail * st.f_frsize >= int(world * seg_bytes * 1.25) and os.environ.get("SNF_BENCH_SHM_FULL") != "1"   # (SNF_BENCH_SHM_FULL=1: the test of this fallback)
+            # (SNF_BENCH_SHM_FULL=1: the test of this fallback)
+            room = st.f_bavail * st.f_frsize >= int(world * seg_bytes * 1.25) and os.environ.get("SNF_BENCH_SHM_FULL") != "1"
         except OSError:
             room = False
         ok_t = torch.tensor([1 if room else 0], dtype=torch.int64, device=DEV)
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         if not int(ok_t.item()):
             if rank == 0:
-                print(f"[bench] /dev/shm cannot hold {world} x {seg_bytes >> 20} MiB of result segments: gathering the blocks over RCCL instead", file=sys.stderr)
+                print(f"[bench] /dev/shm cannot hold {world} x {seg_bytes >> 20} MiB of result segments: gathering the blocks over RCCL "
+                      f"instead", file=sys.stderr)
             shared = strong_shared = False
             out_mode |= abi.OUT_DEVICE
             for hs in handles:
@@ -266,7 +273,8 @@ def run_calling(ctx):
         except Exception as e:                               # no host-side group here: the layouts go over the default group
             print(f"[bench] gloo group for the layouts unavailable ({type(e).__name__}: {e}); using the default group", file=sys.stderr)
             meta_group, meta_dev = None, DEV
-        landing = sdist.SharedLanding(slots=n_slots, block_bytes=int(need[0]) * 3 // 2 + (1 << 20), alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
+        landing = sdist.SharedLanding(slots=n_slots, block_bytes=int(need[0]) * 3 // 2 + (1 << 20),
+                                      alt_bytes=int(need[1]) * 3 // 2 + (1 << 20), group=meta_group)
         if strong_shared:
             # segment of (generation, host thread, contig set): every handle stores into memory of its own
             ngs = len(group_tasks)
@@ -547,7 +555,8 @@ def run_calling(ctx):
     lat_ms = None
     if W > 1 and not strong:
         barrier()
-        time.sleep(0.25)                  # (the library stages results through HBM while passes overlapped within the last 0.1 s: this is the lone-pass reference point)
+        # (the library stages results through HBM while passes overlapped within the last 0.1 s: this is the lone-pass reference point)
+        time.sleep(0.25)
         batches[0].timing_every(1)        # (every one of these passes carries the event brackets: their times are reported as such)
         t1 = time.perf_counter()
         for _ in range(5):
@@ -597,11 +606,13 @@ def run_calling(ctx):
         kern = sorted(timings, key=lambda x: -x[1])
         # dominant KERNEL: entries that bracket a sequence of library launches (rocPRIM sort / scan passes) or a copy are
         # listed in top_kernels but are not a kernel whose roofline could be stated
-        single = [k for k in kern if not k[0].startswith(("sort_", "scan_", "d2h_", "front_"))]      # (front_window brackets the launches of the window front end: a stage, below)
+        # (front_window brackets the launches of the window front end: a stage, below)
+        single = [k for k in kern if not k[0].startswith(("sort_", "scan_", "d2h_", "front_"))]
         top = single[0] if single else ("none", 0.0, 0)
         # stages of the pass (several launches each) with SURVEY.md 8(d)'s bytes: the dominant STAGE stands next to the dominant kernel
         by_name = {k[0]: k for k in kern}
-        stage_def = [("window front end (w1 .. w6t)", ["front_window"], 21 * n_sig), ("refine: merge_inner / resplit (d1g + d1w)", ["d1g_refine8", "d1w_refine"], 36 * n_sig),
+        stage_def = [("window front end (w1 .. w6t)", ["front_window"], 21 * n_sig),
+                     ("refine: merge_inner / resplit (d1g + d1w)", ["d1g_refine8", "d1w_refine"], 36 * n_sig),
                      ("call_from (d2g + d2w)", ["d2g_call8", "d2w_call"], 32 * n_sig),
                      ("INS consensus (SMALL + LARGE + verbatim)", ["e45w_consensus_small", "e45w_consensus_large", "e4c_copy"], None),
                      ("coverage annotation (d4 + d5w)", ["d4_coverage", "d5w_covsum"], 8 * n_reads + 20 * n_calls)]
@@ -611,7 +622,8 @@ def run_calling(ctx):
             if ms_ <= 0:
                 continue
             nb_ = nbytes if nbytes is not None else sum(by_name[p][2] for p in parts if p in by_name)
-            stages.append(dict(stage=nm, ms=round(ms_, 4), algorithmic_bytes=int(nb_), frac=round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)))
+            stages.append(dict(stage=nm, ms=round(ms_, 4), algorithmic_bytes=int(nb_),
+                               frac=round(nb_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)))
         stages.sort(key=lambda x: -x["ms"])
         issue = committed_issue()
         gpu_ms = sum(k[1] for k in kern)
@@ -627,13 +639,17 @@ def run_calling(ctx):
         rocprof_ms = prof_avg.get(top[0]) if same_workload else None
         # result path: what one pass sends to the host over PCIe, against the measured device -> pinned-host copy rate of this box
         res_one = batches[0].fetch(1) if not use_dist else None
-        result_bytes = (len(res_one.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res_one.rnames) + len(res_one.alt_pool)) if res_one is not None else None
+        result_bytes = (len(res_one.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res_one.rnames)
+                        + len(res_one.alt_pool)) if res_one is not None else None
         pcie_peak = pcie_d2h_peak_gbs(torch)
-        result_path = dict(bound="pcie", what="bytes of the result block one pass hands to the host (records + read names + ALT bytes of the "
-                           + ("calls CallTask.execute keeps" if args.output == "execute" else "candidates") + "), stored by the kernels straight into pinned "
+        result_path = dict(bound="pcie",
+                           what="bytes of the result block one pass hands to the host (records + read names + ALT bytes of the "
+                           + ("calls CallTask.execute keeps" if args.output == "execute" else "candidates")
+                           + "), stored by the kernels straight into pinned "
                            "host memory, over the time of a step; peak = device -> pinned host copy rate measured in this run",
                            bytes_per_pass=result_bytes, records_per_pass=(len(res_one.calls) if res_one is not None else None),
-                           achieved=(round(result_bytes / (ms_per_step * 1e-3) / 1e9, 2) if result_bytes else None), peak=round(pcie_peak, 2), unit="GB/s",
+                           achieved=(round(result_bytes / (ms_per_step * 1e-3) / 1e9, 2) if result_bytes else None),
+                           peak=round(pcie_peak, 2), unit="GB/s",
                            frac=(round(result_bytes / (ms_per_step * 1e-3) / 1e9 / pcie_peak, 4) if result_bytes else None))
         # whole pass against the roofline: SURVEY.md 8(d) algorithmic bytes of one pass (72 B/signature + consensus bytes as
         # counted by the kernels + 8 B/read + 20 B/call) over the time of one pass
@@ -645,8 +661,10 @@ def run_calling(ctx):
         roofline = dict(bound="hbm", kernel=top[0], achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         kernel_ms=round(top[1], 4), algorithmic_bytes=int(top[2]),
-                        kernel_ms_source="mean HIP-event duration of the kernel's launches (events on the stream it is launched on) over the timed passes of handle 0 (batches in flight as configured); "
-                                         "the LARGE consensus kernel is bracketed on every pass, the other kernels on every 8th pass of the handle (snf_batch_timing_every)",
+                        kernel_ms_source="mean HIP-event duration of the kernel's launches (events on the stream it is launched on) over "
+                                         "the timed passes of handle 0 (batches in flight as configured); "
+                                         "the LARGE consensus kernel is bracketed on every pass, the other kernels on every 8th pass of "
+                                         "the handle (snf_batch_timing_every)",
                         rocprof_ms=(round(rocprof_ms, 4) if rocprof_ms else None),
                         rocprof_frac=(round(top[2] / (rocprof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if rocprof_ms else None),
                         profile_note=prof_note, result_path=result_path,
@@ -657,7 +675,8 @@ def run_calling(ctx):
                         gpu_ms_all_kernels=round(gpu_ms, 3),
                         whole_pass=dict(algorithmic_bytes=int(pass_bytes),
                                         achieved=round(pass_bytes / (ms_per_step * 1e-3) / 1e9, 2) if not strong and world == 1 else None,
-                                        frac=round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if not strong and world == 1 else None),
+                                        frac=round(pass_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                   5) if not strong and world == 1 else None),
                         top_kernels=[dict(name=k[0], ms=round(k[1], 4), algorithmic_bytes=int(k[2]),
                                           **({"rocprof_ms": round(prof_avg[k[0]], 4)} if same_workload and k[0] in prof_avg else {}),
                                           **({"ms_one_batch_in_flight": round(timings_alone[k[0]], 4)} if k[0] in timings_alone else {}))
@@ -667,25 +686,38 @@ def run_calling(ctx):
                    value=value, unit="signatures/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=ms_per_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype="int32/f64",
                    ranks_seen=ranks_seen, sets_served=sets_served,
-                   data="synthetic" + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU else "")
-                   + (" - SNF_BENCH_CFG overrides the workload's configuration: an ablation, NOT a result" if os.environ.get("SNF_BENCH_CFG") else ""),
+                   data="synthetic"
+                   + (" - SNF_BENCH_EMU=1: host emulation of the kernels over gloo, a test of the N > 1 plumbing, NOT a result" if EMU
+                      else "")
+                   + (" - SNF_BENCH_CFG overrides the workload's configuration: an ablation, NOT a result"
+                      if os.environ.get("SNF_BENCH_CFG") else ""),
                    config=dict(workload=wl["name"] + ", synthetic signature tables (SURVEY.md 8d)", baseline_config=args.config,
                                replicas=1 if strong else world, genomes_per_batch=G,
                                tasks=n_contigs * (1 if strong else world) * G,
                                coverage=args.coverage if args.coverage is not None else wl["coverage"], scale=args.scale,
                                signatures=total_sig, reads_rank0=n_reads, ins_seq_bytes_rank0=seq_bytes,
                                calls=total_calls,
-                               parallelism=(f"one genome, {len(group_tasks)} contig sets (LPT-balanced, one device batch each) claimed from a shared work queue by {world} ranks x {W} host threads, passes pipelined"
-                                            if strong else f"contig-sharded x{world}") + (", every rank's result stored into node-shared host memory by its own kernels, layouts gathered on rank 0 (dist.SharedLanding)" if (shared or strong_shared) else ", RCCL gather of the result blocks on rank 0" if use_dist else ", one process: no gather"),
+                               parallelism=(f"one genome, {len(group_tasks)} contig sets (LPT-balanced, one device batch each) claimed "
+                                            f"from a shared work queue by {world} ranks x {W} host threads, passes pipelined"
+                                            if strong else f"contig-sharded x{world}")
+                                            + (", every rank's result stored into node-shared host memory by its own kernels, layouts "
+                                               "gathered on rank 0 (dist.SharedLanding)" if (shared or strong_shared)
+                                               else ", RCCL gather of the result blocks on rank 0" if use_dist
+                                               else ", one process: no gather"),
                                batches_in_flight_per_gpu=W, host_binding=ctx.get("numa"),
-                               gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)), alt_bytes=int(len(gathered_box[0].alt_pool)),
-                                                       read_names=int(len(gathered_box[0].rnames)), tasks=int(len(gathered_box[0].task_ids)),
+                               gathered_on_rank0=(dict(ranks=world, records=int(len(gathered_box[0].calls)),
+                                                       alt_bytes=int(len(gathered_box[0].alt_pool)),
+                                                       read_names=int(len(gathered_box[0].rnames)),
+                                                       tasks=int(len(gathered_box[0].task_ids)),
                                                        order="task id, then position (parallel.py:270-271, sniffles:544)")
                                                   if use_dist and gathered_box[0] is not None else None),
                                ms_per_pass_one_batch_in_flight=(round(lat_ms, 3) if lat_ms else None),
-                               output=args.output + (": what CallTask.execute returns (parallel.py:265-271) - QC-passing calls, per task sorted by position, "
-                                                     "filtered / sorted / compacted on the device" if args.output == "execute" else ": every candidate record"),
-                               timed_region="call_candidates + finalize (both enqueue only) + the one host wait of the pass, after which the result block "
+                               output=args.output
+                               + (": what CallTask.execute returns (parallel.py:265-271) - QC-passing calls, per task sorted by position, "
+                                                     "filtered / sorted / compacted on the device" if args.output == "execute"
+                                                     else ": every candidate record"),
+                               timed_region="call_candidates + finalize (both enqueue only) + the one host wait of the pass, after which "
+                                            "the result block "
                                             "(records, read names, ALT bytes) is in pinned host memory; the read index (sorted read "
                                             "ends + hap prefix counts = the coverage vector / hap tables the reference builds during "
                                             "extraction, excluded from cpu_baseline as well) is built once at upload",
@@ -695,7 +727,8 @@ def run_calling(ctx):
                                                      finalize=round(phase_s[1] / max(1, phase_s[3]) * 1e3, 3),
                                                      fetch_d2h=round(phase_s[2] / max(1, phase_s[3]) * 1e3, 3)),
                                parity_unpinned=["edit distance vs edlib itself (edlib absent; pinned to the exact Levenshtein DP)",
-                                                "pysam stand-in of the extraction oracle (pinned by the reference's 17 known-answer reads)"]),
+                                                "pysam stand-in of the extraction oracle (pinned by the reference's 17 "
+                                                "known-answer reads)"]),
                    roofline=roofline)
         if world == 1 and not strong and G == 1:
             if not args.no_wall_clock:
@@ -719,7 +752,8 @@ def run_calling(ctx):
                         ref_base["port"] = base          # the C restatement stays beside it
                         out["cpu_baseline"] = ref_base
                     else:
-                        base["reference_note"] = ("the staged reference build (oracle/_ref, made by oracle/make_ref.py during build() where "
+                        base["reference_note"] = ("the staged reference build (oracle/_ref, made by oracle/make_ref.py during build() "
+                                                  "where "
                                                   "/root/reference exists) is not on this box: kind stays \"port\"")
                 if ver is not None:
                     out["verified"] = ver["ok"]

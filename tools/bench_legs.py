@@ -14,7 +14,8 @@ def bind_to_gpu_numa(torch, local_rank):
     """One process per GPU, bound to the CPUs of the NUMA node the GPU hangs off (what a launcher does for every rank): the
     host threads that drive the batches, their pinned buffers and the staging arena then sit next to the PCIe root of the
     device.  (Measured on the 2-socket GPU box: no difference for one rank - four runs each 2.10-2.41 ms unbound, 2.12-2.30
-    bound; the run-to-run spread of ~10 % has another cause.  Kept for the N-rank launches.)  Best effort (sysfs); SNF_BENCH_NO_NUMA=1 turns it off.  Returns what was done, for the output line."""
+    bound; the run-to-run spread of ~10 % has another cause.  Kept for the N-rank launches.)  Best effort (sysfs); SNF_BENCH_NO_NUMA=1
+    turns it off.  Returns what was done, for the output line."""
     if os.environ.get("SNF_BENCH_NO_NUMA") == "1":
         return "off"
     try:
@@ -42,10 +43,11 @@ def worker_processes(specs, cfg_kw, device):
     providers hold Lead objects (the one walk that turns them into columns is inside call_candidates), `columns`: typed columns."""
     from tools import bench_workers
     out = {}
-    # (processes, input form, call shape, hardware queues per process): from eight processes on every worker is held to two hardware queues -
-    # P x (four streams each) would oversubscribe the device's queues and the driver would time-slice them (same box: P = 24 columns / api
-    # 720 ms with two queues each against 1 219 ms)
-    plan = [(4, "columns", "api", 0), (4, "columns", "execute", 0), (4, "leads", "api", 0), (8, "columns", "api", 2), (8, "leads", "api", 2),
+    # (processes, input form, call shape, hardware queues per process): from eight processes on every worker is held to two hardware
+    # queues - P x (four streams each) would oversubscribe the device's queues and the driver would time-slice them (same box:
+    # P = 24 columns / api 720 ms with two queues each against 1 219 ms)
+    plan = [(4, "columns", "api", 0), (4, "columns", "execute", 0), (4, "leads", "api", 0), (8, "columns", "api", 2),
+            (8, "leads", "api", 2),
             (24, "columns", "api", 2), (24, "leads", "api", 2)]
     if os.environ.get("SNF_BENCH_WORKERS"):      # e.g. "8" or "4,24"
         want = {int(x) for x in os.environ["SNF_BENCH_WORKERS"].split(",") if x}
@@ -56,8 +58,10 @@ def worker_processes(specs, cfg_kw, device):
             out[key] = bench_workers.run(specs, cfg_kw, procs, form, shape, device, hw_queues=hq)
         except Exception as e:  # noqa: BLE001 - an extra measurement must not take the line down
             out[key] = f"failed: {type(e).__name__}: {str(e)[:300]}"
-    out["note"] = ("hot_all_ms = the slowest worker's time over its tasks from a common barrier (inputs built and device context warm before it, as "
-                   "oracle/ref_pool.py times the reference); ingest_all_ms = that worker's Lead objects -> columns walk alone; one MI355X shared by all workers")
+    out["note"] = ("hot_all_ms = the slowest worker's time over its tasks from a common barrier (inputs built and device context warm "
+                   "before it, as "
+                   "oracle/ref_pool.py times the reference); ingest_all_ms = that worker's Lead objects -> columns walk alone; one "
+                   "MI355X shared by all workers")
     return out
 
 
@@ -132,18 +136,20 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
     b2 = lib.Batch(cfg, tasks, device=device)
     warm_ms = (time.perf_counter() - tw) * 1e3
     b2.close()
-    batched = dict(vcf_text_from_records_ms=vcf_ms, vcf_text_bytes=vcf_bytes, upload_ms=round((t1 - t0) * 1e3, 2), pass_ms=round((t2 - t1) * 1e3, 2), d2h_ms=round((t3 - t2) * 1e3, 2),
+    batched = dict(vcf_text_from_records_ms=vcf_ms, vcf_text_bytes=vcf_bytes, upload_ms=round((t1 - t0) * 1e3, 2),
+                   pass_ms=round((t2 - t1) * 1e3, 2), d2h_ms=round((t3 - t2) * 1e3, 2),
                    materialise_ms=round((t4 - t3) * 1e3, 2), end_to_end_ms=round((t4 - t0) * 1e3, 2), svcalls=n,
                    materialise_all_candidates_ms=round(all_ms, 2), candidates=n_all,
                    upload_GBps=round(_input_bytes(tasks) / max(1e-9, t1 - t0) / 1e9, 2),
                    upload_slab_reused_ms=round(warm_ms, 2), end_to_end_slab_reused_ms=round((t4 - t1) * 1e3 + warm_ms, 2))
-    # the reference's worker loop, one process: per contig task the two-call seam (Task.call_candidates + finalize_candidates, every candidate
-    # an object) or the one-step drop-in (CallTask.execute_calls: upload, pass, objects of the kept calls).  `pipelined`: the loop keeps two
-    # tasks in flight (Task.prepare: task k + 1 uploads and runs on the device while task k's records become objects)
+    # the reference's worker loop, one process: per contig task the two-call seam (Task.call_candidates + finalize_candidates, every
+    # candidate an object) or the one-step drop-in (CallTask.execute_calls: upload, pass, objects of the kept calls).  `pipelined`: the loop
+    # keeps two tasks in flight (Task.prepare: task k + 1 uploads and runs on the device while task k's records become objects)
     def per_task(shape, pipelined):
         ts = []
         for ti in tasks:
-            task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=None, device=device)
+            task = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg,
+                                     tandem_repeats=None, device=device)
             task.lead_provider = pipeline._Extracted(ti)
             ts.append(task)
         ex = True if shape == "execute" else None
@@ -189,7 +195,8 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
                       to_task_input_ms=round((ti2 - ti1) * 1e3, 2), us_per_lead=round(per_lead * 1e6, 3),
                       ingest_ms_genome_one_core=round(per_lead * n_all_leads * 1e3, 1),
                       ingest_ms_largest_task=round(per_lead * max(t.n_leads for t in tasks) * 1e3, 1),
-                      note="record_lead / record_read append; to_task_input = ONE walk over the Lead objects in C (_snf_fast.lead_columns) + name "
+                      note="record_lead / record_read append; to_task_input = ONE walk over the Lead objects in C "
+                           "(_snf_fast.lead_columns) + name "
                            "interning; one process per contig in the reference's layout: the largest task bounds the wall clock")
         del objs
     except Exception as e:  # noqa: BLE001
@@ -198,17 +205,21 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
     if specs is not None and not EMU and os.environ.get("SNF_BENCH_NO_WORKERS") != "1":
         workers = worker_processes(specs, cfg_kw or {}, device)
     return dict(batched=batched, ingest=ingest, worker_processes=workers,
-                # (the better of the two loop shapes is the leg's figure: preparing the next task pays for the one-step shape, whose host part is
-                #  short; in the two-call shape one interpreter creates 94 k objects and the helper thread only adds hand-overs)
+                # (the better of the two loop shapes is the leg's figure: preparing the next task pays for the one-step shape, whose host
+                # part is short; in the two-call shape one interpreter creates 94 k objects and the helper thread only adds hand-overs)
                 per_task_api=dict(end_to_end_ms=round(min(api_ms, api_serial_ms), 2), two_tasks_in_flight_ms=round(api_ms, 2),
                                   one_task_at_a_time_ms=round(api_serial_ms, 2), tasks=len(tasks), svcalls=n2),
                 per_task_execute=dict(end_to_end_ms=round(min(exe_ms, exe_serial_ms), 2), two_tasks_in_flight_ms=round(exe_ms, 2),
                                       one_task_at_a_time_ms=round(exe_serial_ms, 2), tasks=len(tasks), svcalls=n3),
                 note="one genome, inputs in host numpy columns; upload = snf_batch_create + add_task + upload; "
-                     "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, sorted; "
-                     "materialise_all_candidates_ms: every candidate instead); per_task_api = 24 x Task.call_candidates + finalize_candidates "
-                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x CallTask.execute_calls; both with two "
-                     "tasks in flight (Task.prepare: the next task uploads and runs while this one's records become objects), one_task_at_a_time_ms without; "
+                     "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, "
+                     "sorted; "
+                     "materialise_all_candidates_ms: every candidate instead); per_task_api = 24 x Task.call_candidates + "
+                     "finalize_candidates "
+                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x "
+                     "CallTask.execute_calls; both with two "
+                     "tasks in flight (Task.prepare: the next task uploads and runs while this one's records become objects), "
+                     "one_task_at_a_time_ms without; "
                      "d2h = results in the library's pinned block (read in place); materialise = SVCall Python objects (host); "
                      "vcf_text_from_records = the QC-passing records as VCF lines straight from the record table (no objects)")
 
@@ -244,7 +255,8 @@ def other_configs(ctx) -> dict:
             tasks = [synth.gen_task(**kw) for _, kw in specs]
             W, steps, warm = 2, 24, 4
             if k == 0:
-                steps, warm = 48, 8      # (a small batch is replayed as a HIP graph: its first few launches cost milliseconds each - not the steady state)
+                # (a small batch is replayed as a HIP graph: its first few launches cost milliseconds each - not the steady state)
+                steps, warm = 48, 8
             hs = [lib.Batch(cfg, tasks, device=(0 if EMU else local_rank)) for _ in range(W)]
             for h in hs:
                 h.set_output(abi.OUT_EXECUTE)
@@ -253,7 +265,9 @@ def other_configs(ctx) -> dict:
                 def body(h):
                     set_dev(torch, local_rank)
                     for _ in range(n_each):
-                        h.run_pass(); h.fetch_raw(1)     # one pass = snf_batch_pass (call_candidates + finalize; replayed as a graph for small batches), as the headline runs it
+                        # one pass = snf_batch_pass (call_candidates + finalize; replayed as a graph for small batches), as the
+                        # headline runs it
+                        h.run_pass(); h.fetch_raw(1)
                 ths = [threading.Thread(target=body, args=(h,)) for h in hs]
                 for t in ths:
                     t.start()
@@ -274,7 +288,8 @@ def other_configs(ctx) -> dict:
             n_sig = sum(t.n_leads for t in tasks)
             out[str(k)] = dict(workload=wl["name"], signatures=n_sig, steps=steps // W * W, batches_in_flight=W,
                                ms_per_step=round(dt / (steps // W * W) * 1e3, 3), ms_one_batch_in_flight=round(lat, 3),
-                               signatures_per_s=round(n_sig * (steps // W * W) / dt), candidates=int(len(got.calls)), records_returned=int(n_ret),
+                               signatures_per_s=round(n_sig * (steps // W * W) / dt), candidates=int(len(got.calls)),
+                               records_returned=int(n_ret),
                                verified=ver["ok"], differences=ver["differences"], cpu_all_core_sig_s=round(base["all_core_sig_s"]),
                                cpu_cores=base["cores"])
             for h in hs:
@@ -284,7 +299,8 @@ def other_configs(ctx) -> dict:
                     rc = reference_check(a, wl, exe, tasks, specs)
                     if rc is not None:
                         out[str(k)].update(rc)
-                        out[str(k)]["vs_reference_all_cores"] = round(out[str(k)]["signatures_per_s"] / max(1, rc["reference_all_core_sig_s"]), 1)
+                        out[str(k)]["vs_reference_all_cores"] = round(out[str(k)]["signatures_per_s"] / max(1,
+                        rc["reference_all_core_sig_s"]), 1)
                 except Exception as e:  # noqa: BLE001
                     out[str(k)]["reference_error"] = f"{type(e).__name__}: {str(e)[:300]}"
             out[str(k)]["seconds"] = round(time.time() - t_all, 1)
@@ -294,13 +310,18 @@ def other_configs(ctx) -> dict:
         t_all = time.time()
         from tools import bench_population
         a = copy.copy(args); a.config = 4; a.steps = 2; a.warmup = 1
-        a.reference_sample_contigs = 4      # (the reference leg of the merge on a bounded sample: the whole workload takes two minutes of host time)
+        # (the reference leg of the merge on a bounded sample: the whole workload takes two minutes of host time)
+        a.reference_sample_contigs = 4
         r = bench_population.run(dict(ctx, args=a))
-        out["4"] = dict(workload=r["config"]["workload"], metric=r["metric"], candidates=r["config"]["candidates"], combined_calls=r["config"]["combined_calls"],
-                        ms_per_step=round(r["ms_per_step"], 1), candidates_per_s=round(r["value"]), steps=r["steps"], verified=r.get("verified"),
+        out["4"] = dict(workload=r["config"]["workload"], metric=r["metric"], candidates=r["config"]["candidates"],
+                        combined_calls=r["config"]["combined_calls"],
+                        ms_per_step=round(r["ms_per_step"], 1), candidates_per_s=round(r["value"]), steps=r["steps"],
+                        verified=r.get("verified"),
                         kernel_ms=r["config"].get("rank0", {}).get("kernel_ms"), parity_unpinned=r["config"].get("parity_unpinned"),
-                        cpu_baseline={k: (r.get("cpu_baseline") or {}).get(k) for k in ("kind", "value", "unit", "cores", "hot_all_core_s", "vs_baseline",
-                                                                                         "same_population", "whole_merge_estimate", "reference_error", "sample")},
+                        cpu_baseline={k: (r.get("cpu_baseline") or {}).get(k) for k in ("kind", "value", "unit", "cores",
+                                                                                        "hot_all_core_s", "vs_baseline",
+                                                                                         "same_population", "whole_merge_estimate",
+                                                                                         "reference_error", "sample")},
                         seconds=round(time.time() - t_all, 1))
     except Exception as e:  # noqa: BLE001
         out["4"] = dict(error=f"{type(e).__name__}: {e}")
@@ -334,9 +355,11 @@ def execute_mode_differences(got, exe, cfg) -> list:
         ln = np.maximum(ln.astype(np.int64), 0)
         first = np.cumsum(ln) - ln
         return pool[np.repeat(off.astype(np.int64) - first, ln) + np.arange(int(ln.sum()), dtype=np.int64)]
-    if not np.array_equal(gather(exe.alt_pool, exe.calls["alt_off"], exe.calls["alt_len"]), gather(got.alt_pool, got.calls["alt_off"][idx], got.calls["alt_len"][idx])):
+    if not np.array_equal(gather(exe.alt_pool, exe.calls["alt_off"], exe.calls["alt_len"]),
+                          gather(got.alt_pool, got.calls["alt_off"][idx], got.calls["alt_len"][idx])):
         diffs.append("execute mode: ALT bytes differ")
-    if not np.array_equal(gather(exe.rnames, exe.calls["rn_off"], exe.calls["rn_len"]), gather(got.rnames, got.calls["rn_off"][idx], got.calls["rn_len"][idx])):
+    if not np.array_equal(gather(exe.rnames, exe.calls["rn_off"], exe.calls["rn_len"]),
+                          gather(got.rnames, got.calls["rn_off"][idx], got.calls["rn_len"][idx])):
         diffs.append("execute mode: read names differ")
     return diffs
 
@@ -370,7 +393,8 @@ def cpu_baseline_and_verify(args, wl, got, task_keys, exe=None, cfg=None):
                 diffs.append(f"task {t} ({contig_of[key]}): {d}")
         if exe is not None:
             diffs += execute_mode_differences(got, exe, cfg)
-        ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls, records_returned=(int(len(exe.calls)) if exe is not None else None),
+        ver = dict(ok=not diffs, tasks=len(specs), calls_compared=n_calls,
+                   records_returned=(int(len(exe.calls)) if exe is not None else None),
                    what="every field of every candidate record, ALT bytes, supporting reads and coverage_average_total of the "
                         "bench batch vs the C oracle on the same inputs; the block the timed passes return (--output execute) vs "
                         "CallTask.execute's filter + sort applied to those candidates", differences=diffs[:5])
@@ -410,8 +434,10 @@ def reference_check(a, wl, exe, tasks, specs):
                            max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
     diffs, n_cmp = reference_differences(r, exe, tasks, [ci for ci, _ in specs])
     n = sum(m["n_leads"] for m in r["items"].values())
-    return dict(verified_vs_reference=not diffs, records_compared=n_cmp, differences=diffs[:5], reference_all_core_sig_s=round(n / r["hot_all_core_s"]),
-                reference_hot_all_core_s=round(r["hot_all_core_s"], 3), reference_procs=r["procs"], reference_leg_s=round(r["total_wall_s"], 1))
+    return dict(verified_vs_reference=not diffs, records_compared=n_cmp, differences=diffs[:5],
+                reference_all_core_sig_s=round(n / r["hot_all_core_s"]),
+                reference_hot_all_core_s=round(r["hot_all_core_s"], 3), reference_procs=r["procs"],
+                reference_leg_s=round(r["total_wall_s"], 1))
 
 
 def reference_baseline(args, wl, exe, tasks, task_keys, out):
@@ -436,10 +462,12 @@ def reference_baseline(args, wl, exe, tasks, task_keys, out):
                 hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
                 reference=ref_pool.kind(),
                 sample=f"the whole workload ({len(specs)} contig tasks, {n} signatures): the unmodified reference's Task.call_candidates + "
-                       f"finalize_candidates, one process per contig ({r['procs']} processes on {r['cores']} usable cores, longest contig first; "
+                       f"finalize_candidates, one process per contig ({r['procs']} processes on {r['cores']} usable cores, longest "
+                       f"contig first; "
                        f"the reference cannot use more processes than contigs), every process starts at a barrier once its Lead tables / "
                        f"coverage vector are built (untimed: {r['build_single_core_s']:.0f} core-seconds of record_lead / record_hap_ref): "
-                       f"slowest process {r['hot_all_core_s']:.2f} s, sum over tasks {r['hot_single_core_s']:.1f} s; whole leg {r['total_wall_s']:.0f} s")
+                       f"slowest process {r['hot_all_core_s']:.2f} s, sum over tasks {r['hot_single_core_s']:.1f} s; whole leg "
+                       f"{r['total_wall_s']:.0f} s")
     # speed-ups against the reference on THIS box (north_star: >= 20x wall clock at 1 MI355X vs all host cores)
     vs = dict(gpu_pass=round(out["value"] / ref_sig_s, 1))
     wc = out.get("wall_clock") or {}
@@ -451,15 +479,18 @@ def reference_baseline(args, wl, exe, tasks, task_keys, out):
         if isinstance(wc.get("worker_processes"), dict):
             vs["wall_clock_worker_processes"] = {k: round(r["hot_all_core_s"] * 1e3 / m["hot_all_ms"], 1)
                                                  for k, m in wc["worker_processes"].items() if isinstance(m, dict) and m.get("hot_all_ms")}
-    vs["note"] = ("reference all-core seconds for one genome / this package's seconds for one genome: gpu_pass = the timed step (inputs in HBM, "
+    vs["note"] = ("reference all-core seconds for one genome / this package's seconds for one genome: gpu_pass = the timed step (inputs "
+                  "in HBM, "
                   "result block on the host); wall_clock_batched = numpy columns -> upload -> pass -> SVCall objects; per_task_api = 24 x "
                   "Task.call_candidates / finalize_candidates")
     base["vs_baseline"] = vs
     if exe is not None:
         diffs, n_cmp = reference_differences(r, exe, tasks, task_keys)
         base["verified_vs_reference"] = dict(ok=not diffs, records_compared=n_cmp, differences=diffs[:5],
-                                             what="the execute-mode block of the timed passes (every field: POS, END, SVLEN, SVTYPE, support, GT/GQ/DR/DV, "
-                                                  "filters, fp64 statistics, INS consensus ALT, supporting read names) vs what the unmodified reference's "
+                                             what="the execute-mode block of the timed passes (every field: POS, END, SVLEN, SVTYPE, "
+                                                  "support, GT/GQ/DR/DV, "
+                                                  "filters, fp64 statistics, INS consensus ALT, supporting read names) vs what the "
+                                                  "unmodified reference's "
                                                   "CallTask.execute keeps (parallel.py:265-271) on the same signature tables, on this box")
         out["verified_vs_reference"] = not diffs
     return base

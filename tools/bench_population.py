@@ -6,7 +6,8 @@ through the calling hot path on this GPU; its candidates go into 100-kb SNF bloc
 instead of gzip / pickle files (container I/O is not what is measured).
 One step = `CombineTask.execute` of every contig task of this rank over the S readers (`parallel.py:444-572`): the block / bin /
 flush-window walk and the `SVGroup.call` replay on the host, the group assignment with its on-demand banded edit distances in
-ONE `snf_combine_resolve_batch` call for all contig tasks of the rank.  N > 1: contigs sharded longest-first over the ranks (weak scaling would need
+ONE `snf_combine_resolve_batch` call for all contig tasks of the rank.  N > 1: contigs sharded longest-first over the ranks (weak scaling
+would need
 N populations; the merge of one population is what `configs[4]` names, so this is STRONG scaling: `scaling: "strong"`).
 value = candidates merged per second (whole job); the kernel inside the C-ABI call is reported against the roofline with the
 bytes it aligned, DP cells per second next to it (the bound of this kernel is VALU issue, not HBM: integer bit-vector work).
@@ -128,7 +129,8 @@ def run(ctx):
         """The merge of this rank's contig tasks -> the merged VCF records (what the reference's combine run produces): formatted
         straight from the group table (vcf.VCF.write_merged); objects=True builds the SVCall objects and lets write_call print them."""
         box.update(calls=0, kernel_ms=0.0, stats=[0, 0, 0, 0], abi_s=0.0)
-        tasks = [parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank) for ci, c, L in my_contigs]
+        tasks = [parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=local_rank) for ci, c,
+                 L in my_contigs]
         buf = io.StringIO()
         w = vcf.VCF(cfg, buf)
         # the contig tasks of this rank share one group-assignment launch (CombineTask.execute_many)
@@ -174,7 +176,8 @@ def run(ctx):
     kms = box["kernel_ms"]
     al, ab, cells, staged = box["stats"]
     achieved = ab / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    out = dict(metric="SV candidates merged/sec (multi-sample combine: candidates resident as columns -> group assignment with banded edit distance -> SVGroup.call -> merged VCF records)",
+    out = dict(metric="SV candidates merged/sec (multi-sample combine: candidates resident as columns -> group assignment with banded "
+                      "edit distance -> SVGroup.call -> merged VCF records)",
                value=total_cands * steps / dt, unit="candidates/s", n_gpus=world, steps=steps, warmup=warmup,
                ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling="strong", vs_baseline=None, dtype="int32/f64/u64 bit-vectors",
                data="synthetic",
@@ -185,8 +188,10 @@ def run(ctx):
                            candidates=total_cands, combined_calls=total_calls, setup_s=round(t_setup, 1),
                            parallelism=f"contig tasks sharded longest-first over {world} ranks, no data-path collective",
                            host_phases_ms={k: (round(v * 1e3, 1) if isinstance(v, float) else v) for k, v in phases.items()},
-                           output="merged VCF records as text straight from the group table (vcf.VCF.write_merged), sorted by position per contig task",
-                           through_svcall_objects_ms=round(objects_ms, 1), text_equals_object_path=bool(text_equal), vcf_bytes=len(text_fast or ""),
+                           output="merged VCF records as text straight from the group table (vcf.VCF.write_merged), sorted by position "
+                                  "per contig task",
+                           through_svcall_objects_ms=round(objects_ms, 1), text_equals_object_path=bool(text_equal),
+                           vcf_bytes=len(text_fast or ""),
                            rank0=dict(c_abi_call_ms=round(box["abi_s"] * 1e3, 2), kernel_ms=round(kms, 3),
                                       host_ms=round(dt / steps * 1e3 - box["abi_s"] * 1e3, 1), staged_bytes=staged,
                                       alignments=al, dp_cells=cells,
@@ -202,7 +207,8 @@ def run(ctx):
             out["verified"] = bool(ver["ok"] and text_equal)      # group assignment vs the oracle AND the text path vs the object path
             out["verify"] = ver
         if not getattr(args, "no_reference_baseline", False):
-            # the UNMODIFIED reference's CombineTask.execute on the same population, on this box's cores (edlib -> the bit-parallel stand-in)
+            # the UNMODIFIED reference's CombineTask.execute on the same population, on this box's cores (edlib -> the bit-parallel
+            # stand-in)
             try:
                 ref_base = reference_baseline(my_contigs, S, cov, total_cands, int(phases.get("calls", total_calls)), dt / steps,
                                               sample=getattr(args, "reference_sample_contigs", None))
@@ -223,34 +229,48 @@ def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sampl
     import ref_combine_pool
     if not ref_combine_pool.available():
         return None
-    if sample:      # a bounded sample (bench.py's default line): the `sample` smallest contig tasks, one process each; the whole workload: bench.py --config 4
+    # a bounded sample (bench.py's default line): the `sample` smallest contig tasks, one process each; the whole workload: bench.py
+    # --config 4
+    if sample:
         part = sorted(contigs, key=lambda c: c[2])[:int(sample)]
         r = ref_combine_pool.run(part, S, cov)
         per_cand = r["hot_single_core_s"] / max(1, r["candidates"])
         share = max(c[2] for c in contigs) / float(sum(c[2] for c in contigs))
-        return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)", host_cores=r["cores"],
+        return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"],
+                    kind="reference (edlib stand-in)", host_cores=r["cores"],
                     hot_all_core_s=round(r["hot_all_core_s"], 3), candidates=r["candidates"], combined_calls=r["combined"],
                     single_core_cand_s=round(1.0 / per_cand, 1),
                     # the reference merges one contig per process: the wall clock of a whole merge is its largest contig task
                     whole_merge_estimate=dict(all_core_s=round(per_cand * n_cands * share, 1),
                                               vs_this_package=round(per_cand * n_cands * share / gpu_s_per_merge, 1),
-                                              note="single-core seconds per candidate of the sample x the candidates of the largest contig task (one process "
-                                                   "per contig); measured on the whole workload by `bench.py --config 4`: profiles/r05_final_bench_config4.json"),
-                    parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, pinned to the exact DP), not edlib",
-                    sample=f"the {len(part)} smallest contig tasks ({', '.join(c[1] for c in part)}) x {S} samples, the unmodified reference's CombineTask.execute, one process "
-                           f"per contig: slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; whole leg {r['total_wall_s']:.0f} s")
+                                              note="single-core seconds per candidate of the sample x the candidates of the largest "
+                                                   "contig task (one process "
+                                                   "per contig); measured on the whole workload by `bench.py --config 4`: "
+                                                   "profiles/r05_final_bench_config4.json"),
+                    parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, "
+                                    "pinned to the exact DP), not edlib",
+                    sample=f"the {len(part)} smallest contig tasks ({', '.join(c[1] for c in part)}) x {S} samples, the unmodified "
+                           f"reference's CombineTask.execute, one process "
+                           f"per contig: slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; whole leg "
+                           f"{r['total_wall_s']:.0f} s")
     r = ref_combine_pool.run(list(contigs), S, cov, max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
-    return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)", host_cores=r["cores"],
+    return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)",
+                host_cores=r["cores"],
                 hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
                 candidates=r["candidates"], combined_calls=r["combined"],
                 same_population=dict(candidates_equal=bool(r["candidates"] == n_cands), combined_calls_equal=bool(r["combined"] == n_calls),
                                      here=dict(candidates=n_cands, combined_calls=n_calls)),
                 vs_baseline=dict(merge=round(r["hot_all_core_s"] / gpu_s_per_merge, 1),
-                                 note="reference all-core seconds for the merge / this package's seconds per merge (candidates resident as columns -> merged VCF records)"),
-                parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, pinned to the exact DP), not edlib",
-                sample=f"the whole workload: {len(contigs)} contig tasks x {S} samples, the unmodified reference's CombineTask.execute, one process per contig "
-                       f"({r['procs']} processes on {r['cores']} usable cores), every process starts its first merge at a barrier once its samples' SNF blocks "
-                       f"exist (built by the reference's own calling path, untimed): slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; "
+                                 note="reference all-core seconds for the merge / this package's seconds per merge (candidates resident "
+                                      "as columns -> merged VCF records)"),
+                parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, pinned "
+                                "to the exact DP), not edlib",
+                sample=f"the whole workload: {len(contigs)} contig tasks x {S} samples, the unmodified reference's CombineTask.execute, "
+                       f"one process per contig "
+                       f"({r['procs']} processes on {r['cores']} usable cores), every process starts its first merge at a barrier once "
+                       f"its samples' SNF blocks "
+                       f"exist (built by the reference's own calling path, untimed): slowest process {r['hot_all_core_s']:.2f} s, sum "
+                       f"{r['hot_single_core_s']:.1f} s; "
                        f"whole leg {r['total_wall_s']:.0f} s")
 
 
@@ -303,7 +323,8 @@ def cpu_baseline_and_verify(cfg, readers, contigs, S, device, args):
     got = cluster.resolve_chains_batch([(t, c, [0, len(c)], [0], [-1.0]) for t, c in wins], cfg, device=device, cut=False)
     t_gpu = time.perf_counter() - t0
     bad = [k for k, ((t, c), g) in enumerate(zip(wins, got)) if list(g[:len(c)]) != r["groups"][k]]
-    base = dict(value=n_c / r["slowest_s"], unit="candidates/s", cores=r["procs"], kind="port", cores_used=r["procs"], host_cores=r["cores"],
+    base = dict(value=n_c / r["slowest_s"], unit="candidates/s", cores=r["procs"], kind="port", cores_used=r["procs"],
+                host_cores=r["cores"],
                 all_core_cand_s=n_c / r["slowest_s"], single_core_cand_s=n_c / r["sum_s"],
                 sample=f"{len(wins)} flush windows ({n_c} candidates, INS windows first) of the same merge as independent "
                        f"resolve_block_groups problems through the C oracle (exact edit-distance DP), {r['procs']} processes: slowest "

@@ -28,11 +28,14 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
     try:
         if ROOT not in sys.path:
             sys.path.insert(0, ROOT)
-        if hw_queues:            # hardware queues this process may open (read by the HIP runtime when it starts): P processes x their streams
-            os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues)     # must not oversubscribe the device's queues, or the driver time-slices them
+        # hardware queues this process may open (read by the HIP runtime when it starts): P processes x their streams
+        if hw_queues:
+            # must not oversubscribe the device's queues, or the driver time-slices them
+            os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues)
         from sniffles_amd import leadprov, lib, parallel, pipeline, synth
         from sniffles_amd.config import SnifflesConfig
-        if os.environ.get("SNF_BENCH_EMU") == "1":      # tests only: the plumbing of this file on a GPU-less box (host tier of the test suite)
+        # tests only: the plumbing of this file on a GPU-less box (host tier of the test suite)
+        if os.environ.get("SNF_BENCH_EMU") == "1":
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import emu.emu as E
             E.lib()
@@ -58,7 +61,8 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
         t_all0 = time.perf_counter()
         tasks = []
         for key, ti, lp in built:
-            t = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=None, device=device)
+            t = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=None,
+                                  device=device)
             t.lead_provider = lp
             tasks.append(t)
         ex = True if shape == "execute" else None
@@ -71,7 +75,8 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
             t_all0 = time.perf_counter()
         n_out = 0
 
-        def prepare(k):      # (the reference's build_leadtab leaves the task's NM threshold on the config: the lead provider's columns take it from there)
+        # (the reference's build_leadtab leaves the task's NM threshold on the config: the lead provider's columns take it from there)
+        def prepare(k):
             cfg.qc_nm_threshold = built[k][1].qc_nm_threshold
             tasks[k].prepare(cfg, execute=ex)
         if tasks:
@@ -92,7 +97,8 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
         out_q.put(dict(error=f"worker {wid}: {e!r}\n{traceback.format_exc()}"))
 
 
-def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str = "api", device: int = 0, weights=None, hw_queues: int = 0) -> dict:
+def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str = "api", device: int = 0, weights=None,
+        hw_queues: int = 0) -> dict:
     """specs: [(key, kwargs of synth.gen_task)].  Returns {procs, hot_all_s (slowest worker), hot_sum_s, ingest_all_s (slowest worker's
     object walk, `leads` form), n_out, setup_wall_s}."""
     n = len(specs)
@@ -107,7 +113,8 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
     ctx = mp.get_context("spawn")
     barrier, q = ctx.Barrier(procs + 1), ctx.Queue()
     t0 = time.perf_counter()
-    ps = [ctx.Process(target=_worker, args=(w, shards[w], cfg_kw, form, shape, device, barrier, q, hw_queues), daemon=True) for w in range(procs)]
+    ps = [ctx.Process(target=_worker, args=(w, shards[w], cfg_kw, form, shape, device, barrier, q, hw_queues),
+                      daemon=True) for w in range(procs)]
     for p in ps:
         p.start()
     import queue as _queue
@@ -137,7 +144,8 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
         p.join(timeout=30)
     if err is not None:
         raise RuntimeError(err)
-    return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None, hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
+    return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None,
+                hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
                 hot_sum_ms=round(sum(m["hot_s"] for m in got) * 1e3, 1), ingest_all_ms=round(max(m["ingest_s"] for m in got) * 1e3, 1),
                 n_out=sum(m["n_out"] for m in got), setup_wall_s=round(t1 - t0, 1))
 
