@@ -48,6 +48,9 @@ def _walk(tasks, samples_snf, config):
     return readers, order, blocks, block_cov, np.asarray(block_task, np.int64)
 
 
+_EXT_DTYPE = np.dtype([("blk", np.int64), ("id_start", np.int64), ("ps_start", np.int64), ("alen", np.int64), ("astart", np.int64), ("typ", np.int32), ("mate0", np.int32),
+                       ("mate1", np.int32), ("id_len", np.int32), ("ps_len", np.int32), ("ph_hp", np.int8)], align=True)
+
 _MATE_IDS = {}      # mate contig name -> id, process-wide: the ids inside cached column tables stay valid from merge to merge
 
 
@@ -69,6 +72,7 @@ class ContigColumns:
         self.mate = np.frombuffer(mate, np.int32).reshape(-1, 2).copy()
         self.aoff = np.frombuffer(aoff, np.int64).copy()
         self.apool = np.frombuffer(apool, np.uint8).copy() if len(apool) else np.zeros(0, np.uint8)
+        self.alt_ascii = not bool((self.apool >= 128).any())      # (the pool holds latin-1 bytes: as text they are these bytes only if ASCII)
         self._dense = {}
         # strings a merged record prints per candidate, as one pool: the id (chained per sample) and the phase set of genotypes[0]
         # (vcf.py:40-51 unpack_phase: None / "NULL" print as "."); hp: the haplotype ("1" puts the ALT allele first), -1 = None
@@ -92,6 +96,12 @@ class ContigColumns:
         base = int(self.id_len.sum())
         self.ps_start = base + (np.concatenate(([0], np.cumsum(np.maximum(self.ps_len, 0), dtype=np.int64)))[:-1] if len(pss) else np.zeros(0, np.int64))
         self.id_pool = np.frombuffer(b"".join(ids) + b"".join(b for b in pss if b is not None) or b"\0", np.uint8)
+        # everything but the records as ONE table: a merge concatenates two arrays per reader and contig instead of ten
+        self.ext = np.zeros(len(objs), _EXT_DTYPE)
+        for name, col in (("blk", self.blk), ("typ", self.typ), ("mate0", self.mate[:, 0]), ("mate1", self.mate[:, 1]), ("id_start", self.id_start),
+                          ("id_len", self.id_len), ("ph_hp", self.ph_hp), ("ps_start", self.ps_start), ("ps_len", self.ps_len),
+                          ("alen", self.aoff[1:] - self.aoff[:-1]), ("astart", self.aoff[:-1])):
+            self.ext[name] = col
 
     def dense_coverage(self, cb: int):
         """The blocks' `_COVERAGE` dicts as one int32 vector per contig: entry `bin // cb` for every key that is a multiple of `cb`
@@ -167,9 +177,12 @@ def _collect_from_columns(tasks, samples_snf, config, fast):
                 if c is None:
                     return None
                 tabs[(sid, t.contig)] = c
+    cb = int(config.coverage_binsize_combine)
+    whole = _collect_whole_tables(tasks, readers, order, pos_of, tabs, cb, config)
+    if whole is not None:
+        return whole
     block_cov, block_task, parts = [], [], []
     eb0 = 0
-    cb = int(config.coverage_binsize_combine)
     dense, eb_start = [], []
     for ti, t in enumerate(tasks):
         bis = np.asarray(t.block_indices, np.int64)
@@ -228,7 +241,72 @@ def _collect_from_columns(tasks, samples_snf, config, fast):
     apool = np.concatenate(pools) if pools else np.zeros(0, np.uint8)
     id_cols = (np.concatenate(id_pools), id_start, id_len, ph_hp, ps_start, ps_len)
     covx["ids"] = id_cols
+    covx["alt_ascii"] = all(c.alt_ascii for c, _, _ in parts)
     return readers, order, block_cov, block_task, (objs, rec, cblk, ctyp, mate, aoff, apool), covx
+
+
+class _PoolParts:
+    """Strings of a merge that still lie in the pools of their tables: pool, first byte and length of every string."""
+
+    def __init__(self, pools, part, start, length):
+        self.pools, self.part, self.start, self.length = pools, part, start, length
+
+
+def _collect_whole_tables(tasks, readers, order, pos_of, tabs, cb, config):
+    """`_collect_from_columns` for the usual merge - every task holds a regular run of blocks (`range(start, end + bs, bs)`) that contains
+    all candidates of its contig's tables: the tables are concatenated whole (two `np.concatenate` over all readers and contigs) and
+    block numbers, id offsets and ALT offsets follow from per-part scalars.  None when a task holds something else (regions, the parts
+    of `scatter`): the caller then walks part by part."""
+    n_t = len(tasks)
+    bis0, step, last, eb0 = np.zeros(n_t, np.int64), np.ones(n_t, np.int64), np.zeros(n_t, np.int64), np.zeros(n_t, np.int64)
+    dense, eb_start, block_task = [], [], []
+    nb = 0
+    for ti, t in enumerate(tasks):
+        bis = np.asarray(t.block_indices, np.int64)
+        if len(bis) == 0 or (len(bis) > 1 and not bool(np.all(np.diff(bis) == bis[1] - bis[0]))) or (len(bis) > 1 and bis[1] <= bis[0]):
+            return None
+        bis0[ti], last[ti], eb0[ti] = bis[0], bis[-1], nb
+        step[ti] = bis[1] - bis[0] if len(bis) > 1 else 1
+        nb += len(bis)
+        dense.append([tabs[(s, t.contig)].dense_coverage(cb) if s in pos_of else None for s in order])
+        eb_start.append(bis)
+        block_task.append(np.full(len(bis), ti, np.int64))
+    parts, p_task = [], []
+    for ti, t in enumerate(tasks):
+        for sid, _ in readers:
+            c = tabs[(sid, t.contig)]
+            if len(c.objs):
+                parts.append(c); p_task.append(ti)
+    block_task = np.concatenate(block_task)
+    covx = dict(dense=dense, eb_task=np.ascontiguousarray(block_task, np.int32), eb_start=np.ascontiguousarray(np.concatenate(eb_start), np.int64),
+                cb=cb, block_size=int(config.snf_block_size), ids=None)
+    block_cov = [None] * int(nb)
+    if not parts:
+        return readers, order, block_cov, block_task, ([], None, None, None, None, None, None), covx
+    sizes = np.fromiter((len(c.objs) for c in parts), np.int64, len(parts))
+    # (as bytes: numpy copies structured elements field by field - 10 ms for these tables - and bytes with memcpy)
+    ext = np.concatenate([c.ext.view(np.uint8) for c in parts]).view(_EXT_DTYPE)
+    t_of = np.repeat(np.asarray(p_task, np.int64), sizes)
+    d = ext["blk"] - bis0[t_of]
+    st = step[t_of]
+    if not bool(((d >= 0) & (ext["blk"] <= last[t_of]) & (d % st == 0)).all()):
+        return None                                   # a table reaches beyond the blocks of its task
+    rec = np.concatenate([c.rec.view(np.uint8) for c in parts]).view(abi.GROUP_CAND_DTYPE)
+    cblk = (d // st + eb0[t_of]).astype(np.int32)
+    pool_len = np.fromiter((len(c.id_pool) for c in parts), np.int64, len(parts))
+    id_base = np.repeat(np.cumsum(pool_len) - pool_len, sizes)
+    objs = []
+    for c in parts:
+        objs.extend(c.objs)
+    mate = np.stack((ext["mate0"], ext["mate1"]), axis=1)
+    # the ALT bytes stay in the pools of their tables until the sort order is known (`_PoolParts`: gathered once, in that order)
+    aoff = None
+    apool = _PoolParts([c.apool for c in parts], np.repeat(np.arange(len(parts), dtype=np.int32), sizes), np.ascontiguousarray(ext["astart"]),
+                       np.ascontiguousarray(ext["alen"]))
+    covx["ids"] = (np.concatenate([c.id_pool for c in parts]), ext["id_start"] + id_base, np.ascontiguousarray(ext["id_len"]),
+                   np.ascontiguousarray(ext["ph_hp"]), ext["ps_start"] + id_base, np.ascontiguousarray(ext["ps_len"]))
+    covx["alt_ascii"] = all(c.alt_ascii for c in parts)
+    return readers, order, block_cov, block_task, (objs, rec, cblk, np.ascontiguousarray(ext["typ"]), mate, aoff, apool), covx
 
 
 def _regenotype(blocks, readers, config, device):
@@ -279,7 +357,8 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         if n == 0:
             return [[] for _ in tasks]
         cblk = cblk.astype(np.int64); ctyp = ctyp.astype(np.int64)
-        aoff, apool = np.ascontiguousarray(aoff, np.int64), np.ascontiguousarray(apool, np.uint8)
+        if not isinstance(apool, _PoolParts):
+            aoff, apool = np.ascontiguousarray(aoff, np.int64), np.ascontiguousarray(apool, np.uint8)
     else:
         covx = None
         readers, order, blocks, block_cov, block_task = _walk(tasks, samples_snf, config)
@@ -299,13 +378,28 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     # ---- 2. sort into chain-major order (task, SV type, block, bin, visiting order) and cut the flush windows
     bin_min = int(config.combine_min_size)
     cbin = np.trunc(rec["pos"] / bin_min).astype(np.int64) * bin_min          # int(pos / bin_min_size) * bin_min_size
-    perm = np.lexsort((np.arange(n), cbin, cblk, ctyp, ctask))
-    rec, cblk, ctyp, ctask, cbin, mate = rec[perm], cblk[perm], ctyp[perm], ctask[perm], cbin[perm], mate[perm]
-    objs = [objs[i] for i in perm.tolist()]
+    bin_no = cbin // bin_min
+    if n and int(ctask.max()) < (1 << 12) and int(cblk.max()) < (1 << 22) and 0 <= int(bin_no.min()) and int(bin_no.max()) < (1 << 26):
+        perm = np.argsort((((ctask * 8 + ctyp) << 22 | cblk) << 26) | bin_no, kind="stable")      # one key of 63 bits: one sort instead of five
+    else:
+        perm = np.lexsort((np.arange(n), cbin, cblk, ctyp, ctask))
+    # (np.take: a structured array indexed with [perm] is copied field by field, 20x slower)
+    rec, cblk, ctyp, ctask, cbin, mate = np.take(rec, perm), cblk[perm], ctyp[perm], ctask[perm], cbin[perm], np.take(mate, perm, axis=0)
     id_cols = None
     if covx is not None and covx.get("ids") is not None:
         id_cols = (covx["ids"][0],) + tuple(np.ascontiguousarray(a[perm]) for a in covx["ids"][1:])
-    aoff, apool = fast.gather_pool(aoff, apool, np.ascontiguousarray(perm, np.int64))
+    # the candidate objects in table order - unless the records are formatted from arrays alone (text, candidate and head columns, no
+    # RNAMES): then nothing reads them and the list only stands for its length
+    arrays_only = (text_writer is not None and id_cols is not None and bool(covx.get("alt_ascii")) and not getattr(config, "output_rnames", False))
+    if arrays_only:
+        objs = [None] * n
+    else:
+        import operator
+        objs = list(operator.itemgetter(*perm.tolist())(objs)) if n > 1 else list(objs)
+    if isinstance(apool, _PoolParts):
+        aoff, apool = fast.gather_pool_parts(apool.pools, apool.part, apool.start, apool.length, np.ascontiguousarray(perm, np.int64))
+    else:
+        aoff, apool = fast.gather_pool(aoff, apool, np.ascontiguousarray(perm, np.int64))
     aoff = np.frombuffer(aoff, np.int64)
     key = (ctask * 8 + ctyp) * (np.int64(1) << 32) + cblk
     max_cands = max(25, int(len(config.snf_input_info) * 0.5))
@@ -410,7 +504,10 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     if topt is not None and id_cols is not None:      # candidate columns: the records are formatted from arrays (no candidate object is read)
         topt.update(rec=np.ascontiguousarray(rec), id_pool=np.ascontiguousarray(id_cols[0]), id_start=id_cols[1], id_len=id_cols[2],
                     ph_hp=id_cols[3], ph_ps_start=id_cols[4], ph_ps_len=id_cols[5])
-    gc_covx = None if covx is None else {k: v for k, v in covx.items() if k != "ids"}
+        if covx.get("alt_ascii"):      # CHROM / ID / ALT of a record from arrays too: no candidate object is read
+            topt.update(contigs=[t.contig for t in tasks], types=tuple(sv.TYPES), em_task=np.ascontiguousarray(g_task[em], np.int32),
+                        em_typ=np.ascontiguousarray(g_typ[em], np.int32), alt_off=np.ascontiguousarray(aoff, np.int64), alt_pool=apool)
+    gc_covx = None if covx is None else {k: v for k, v in covx.items() if k not in ("ids", "alt_ascii")}
     calls = fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, objs, np.ascontiguousarray(gout), np.ascontiguousarray(em, np.int64),
                              group_off, member, chosen, np.ascontiguousarray(sv_ids, np.int64), np.ascontiguousarray(task_ids, np.int64),
                              sample_ids, spos, block_cov, ev_off, ev_block, np.ascontiguousarray(ev_bin),

@@ -451,6 +451,48 @@ done:
   return ret;
 }
 
+/* gather_pool_parts(pools: list of buffers, part: buffer int32 (pool of every string), start: buffer int64 (its first byte there),
+ *                   length: buffer int64, order: buffer int64) -> (offsets: bytes int64 (len(order) + 1), pool: bytes)
+ * gather_pool over strings that still lie in the pools of their tables (one per reader and contig): the merge's ALT pool is written
+ * once, in sorted order, instead of being concatenated first and permuted then. */
+static PyObject* py_gather_pool_parts(PyObject* self, PyObject* args) {
+  PyObject* pools; Py_buffer ptb, stb, lnb, orb;
+  if (!PyArg_ParseTuple(args, "O!y*y*y*y*", &PyList_Type, &pools, &ptb, &stb, &lnb, &orb)) return NULL;
+  PyObject* ret = NULL;
+  const Py_ssize_t np_ = PyList_GET_SIZE(pools), n = ptb.len / 4, m = orb.len / 8;
+  const int32_t* PT = (const int32_t*)ptb.buf; const int64_t* ST = (const int64_t*)stb.buf; const int64_t* LN = (const int64_t*)lnb.buf;
+  const int64_t* ORD = (const int64_t*)orb.buf;
+  Py_buffer* pb = (Py_buffer*)calloc((size_t)np_ + 1, sizeof(Py_buffer)); Py_ssize_t got = 0;
+  int64_t* no = (int64_t*)malloc(((size_t)m + 1) * 8);
+  size_t total = 0;
+  if (!pb || !no) { PyErr_NoMemory(); goto done; }
+  if (stb.len / 8 < n || lnb.len / 8 < n) { PyErr_SetString(PyExc_ValueError, "gather_pool_parts: columns of different lengths"); goto done; }
+  for (; got < np_; got++) if (PyObject_GetBuffer(PyList_GET_ITEM(pools, got), &pb[got], PyBUF_SIMPLE) != 0) goto done;
+  no[0] = 0;
+  for (Py_ssize_t i = 0; i < m; i++) {
+    const int64_t c = ORD[i];
+    if (c < 0 || c >= n || PT[c] < 0 || PT[c] >= np_ || ST[c] < 0 || LN[c] < 0 || ST[c] + LN[c] > pb[PT[c]].len) {
+      PyErr_SetString(PyExc_ValueError, "gather_pool_parts: index or range out of bounds"); goto done; }
+    total += (size_t)LN[c];
+    no[i + 1] = (int64_t)total;
+  }
+  {
+    PyObject* out = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
+    if (out) {
+      char* w = PyBytes_AS_STRING(out);
+      for (Py_ssize_t i = 0; i < m; i++) { const int64_t c = ORD[i]; memcpy(w, (const char*)pb[PT[c]].buf + ST[c], (size_t)LN[c]); w += LN[c]; }
+      PyObject* oo = PyBytes_FromStringAndSize((const char*)no, ((Py_ssize_t)m + 1) * 8);
+      if (oo) ret = PyTuple_Pack(2, oo, out);
+      Py_XDECREF(oo); Py_DECREF(out);
+    }
+  }
+done:
+  if (pb) for (Py_ssize_t k = 0; k < got; k++) PyBuffer_Release(&pb[k]);
+  free(pb); free(no);
+  PyBuffer_Release(&ptb); PyBuffer_Release(&stb); PyBuffer_Release(&lnb); PyBuffer_Release(&orb);
+  return ret;
+}
+
 /* flush_windows(key: buffer int64, bin: buffer int32, bin_min_size, max_candidates, exhaustive)
  *   -> (win_end: bytes int64 - one past the last candidate of every window, win_bin: bytes int32, win_size: bytes int32)
  * key / bin: the candidate table sorted by (key, bin); one key = one (task, SV type, block).  parallel.py:516-534: the bins of a
@@ -511,18 +553,53 @@ static int ob_room(OutBuf* b, size_t extra) {
   b->p = q; b->cap = cap;
   return 0;
 }
-static int ob_put(OutBuf* b, const char* s, size_t n) { if (ob_room(b, n)) return -1; memcpy(b->p + b->n, s, n); b->n += n; return 0; }
+static inline int ob_put(OutBuf* b, const char* s, size_t n) {
+  if (__builtin_expect(b->n + n > b->cap, 0) && ob_room(b, n)) return -1;
+  memcpy(b->p + b->n, s, n); b->n += n; return 0;
+}
 static int ob_str(OutBuf* b, const char* s) { return ob_put(b, s, strlen(s)); }
-static int ob_ll(OutBuf* b, long long v) {     /* decimal digits by hand: a merged record prints ~40 integers, snprintf costs ~100 ns each */
+/* a string LITERAL: its length is known to the compiler, the copy becomes a few moves (a merged record is ~300 such pieces) */
+#define OB_LIT(b, lit) ob_put((b), "" lit, sizeof(lit) - 1)
+static inline int ob_ull(OutBuf* b, unsigned long long u, int neg) {     /* decimal digits by hand: snprintf costs ~100 ns each */
+  if (__builtin_expect(b->n + 24 > b->cap, 0) && ob_room(b, 24)) return -1;
+  char t[24]; int n = 24;
+  do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (neg) t[--n] = '-';
+  memcpy(b->p + b->n, t + n, (size_t)(24 - n)); b->n += (size_t)(24 - n);
+  return 0;
+}
+static inline int ob_ll(OutBuf* b, long long v) { return ob_ull(b, v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v, v < 0); }
+/* raw writers: the caller has reserved the room (ob_room), `w` runs through it */
+static inline char* raw_ll(char* w, long long v) {
   char t[24]; int n = 24;
   unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
   do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
   if (v < 0) t[--n] = '-';
-  return ob_put(b, t + n, (size_t)(24 - n));
+  memcpy(w, t + n, (size_t)(24 - n));
+  return w + (24 - n);
 }
-static int ob_f3(OutBuf* b, double v) {      /* f"{v:.3f}" */
-  if (isnan(v)) return ob_str(b, "nan");
-  if (isinf(v)) return ob_str(b, v < 0 ? "-inf" : "inf");
+static int ob_hex(OutBuf* b, unsigned long long u) {     /* "%llX" */
+  char t[16]; int n = 16;
+  do { t[--n] = "0123456789ABCDEF"[u & 15]; u >>= 4; } while (u);
+  return ob_put(b, t + n, (size_t)(16 - n));
+}
+/* f"{v:.3f}" = "%.3f": the exactly rounded decimal (ties of the binary value to even, as printf and Python print it).  printf's own
+ * conversion costs ~0.3 us a value; below 10^12 the thousandths are one multiplication, with the product's rounding error taken from
+ * an fma (v * 1000 = s + e exactly): the fraction d of s is a multiple of ulp(s) and |e| <= ulp(s) / 2, so d alone decides unless it is
+ * exactly one half, where the sign of e does - and e == 0 is a true tie. */
+static int ob_f3(OutBuf* b, double v) {
+  if (isnan(v)) return OB_LIT(b, "nan");
+  if (isinf(v)) return v < 0 ? OB_LIT(b, "-inf") : OB_LIT(b, "inf");
+  const double a = fabs(v);
+  if (a < 1e12) {
+    const double s = a * 1000.0, e = fma(a, 1000.0, -s), f = floor(s), d = s - f;
+    unsigned long long r = (unsigned long long)f;
+    if (d > 0.5 || (d == 0.5 && (e > 0.0 || (e == 0.0 && (r & 1))))) r++;
+    if (ob_ull(b, r / 1000, signbit(v) != 0)) return -1;
+    const unsigned m = (unsigned)(r % 1000);
+    const char t[4] = {'.', (char)('0' + m / 100), (char)('0' + m / 10 % 10), (char)('0' + m % 10)};
+    return ob_put(b, t, 4);
+  }
   char t[352]; int n = snprintf(t, sizeof t, "%.3f", v); return ob_put(b, t, (size_t)n);
 }
 static int ob_py(OutBuf* b, PyObject* s) {   /* a str */
@@ -536,7 +613,7 @@ static int ob_name(OutBuf* b, PyObject* list, long i, const char* prefix) {   /*
 }
 static int ob_ps(OutBuf* b, int code, PyObject* ps_names, const char* none) {   /* sv._ps as text */
   if (code == -1) return ob_str(b, none);
-  if (code == -2) return ob_str(b, "NULL");
+  if (code == -2) return OB_LIT(b, "NULL");
   return ob_name(b, ps_names, code, "");
 }
 
@@ -562,10 +639,10 @@ static int ob_genotype(OutBuf* b, PyObject* a, PyObject* bb, PyObject* qual, PyO
     const long x = PyLong_AsLong(a), y = PyLong_AsLong(bb);
     if ((x == 0 && y == 1) || (x == 1 && y == 1)) { sep = "|"; swap = PyUnicode_Check(hp) && PyUnicode_CompareWithASCIIString(hp, "1") == 0; }
   }
-  if (ob_obj(b, swap ? bb : a) || ob_str(b, sep) || ob_obj(b, swap ? a : bb) || ob_str(b, ":") || ob_obj(b, qual) || ob_str(b, ":") || ob_obj(b, dr) ||
-      ob_str(b, ":") || ob_obj(b, dv)) return -1;
-  if (phased) { if (ob_str(b, ":")) return -1; if (ps ? ob_obj(b, ps) : ob_str(b, ".")) return -1; }
-  return ob_str(b, ":") || (id ? ob_obj(b, id) : 0);      /* (id NULL: the caller appends the chained ids itself) */
+  if (ob_obj(b, swap ? bb : a) || ob_str(b, sep) || ob_obj(b, swap ? a : bb) || OB_LIT(b, ":") || ob_obj(b, qual) || OB_LIT(b, ":") || ob_obj(b, dr) ||
+      OB_LIT(b, ":") || ob_obj(b, dv)) return -1;
+  if (phased) { if (OB_LIT(b, ":")) return -1; if (ps ? ob_obj(b, ps) : OB_LIT(b, ".")) return -1; }
+  return OB_LIT(b, ":") || (id ? ob_obj(b, id) : 0);      /* (id NULL: the caller appends the chained ids itself) */
 }
 
 static PyObject* py_group_calls(PyObject* self, PyObject* args) {
@@ -588,9 +665,13 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   int t_phase = 0, t_symbolic = 0, t_mosaic = 0, t_rnames = 0, t_nm = 0; long long t_minsvlen = 0; PyObject *t_fmt = NULL;
   OutBuf tb = {NULL, 0, 0}, *scol = NULL, *idc = NULL; int64_t *t_off = NULL, *t_pos = NULL;
   Py_buffer fr_rec, fr_pool, fr_st, fr_ln, fr_hp, fr_pss, fr_psl; int fast_cols = 0, have_ph = 0;
+  /* head columns (optional, with the candidate columns): contig and SV type of every emitted group and the ALT pool of the candidate
+   * table - the record's CHROM / ID / ALT then come from arrays too and no candidate object is read at all (they are ~2 KB each and
+   * cold: three attribute reads per record were a fifth of this function) */
+  Py_buffer hd_task, hd_typ, hd_aoff, hd_apool; int head_cols = 0; PyObject *hd_contigs = NULL, *hd_types = NULL;
   /* (an error while the options are read leaves through here: the thirteen buffers PyArg_ParseTuple acquired - and whatever column
    * buffers were taken so far - are released; a numpy array stays export-locked otherwise) */
-  Py_buffer* fr_all[7] = {&fr_hp, &fr_pss, &fr_psl, &fr_rec, &fr_pool, &fr_st, &fr_ln}; int fr_got = 0;
+  Py_buffer* fr_all[11] = {&fr_hp, &fr_pss, &fr_psl, &fr_rec, &fr_pool, &fr_st, &fr_ln, &hd_task, &hd_typ, &hd_aoff, &hd_apool}; int fr_got = 0;
 #define EARLY_FAIL() do { for (int k_ = 0; k_ < fr_got; k_++) PyBuffer_Release(fr_all[k_]); \
     PyBuffer_Release(&ob); PyBuffer_Release(&eb); PyBuffer_Release(&gb); PyBuffer_Release(&mb); PyBuffer_Release(&cb); PyBuffer_Release(&svb); \
     PyBuffer_Release(&tkb); PyBuffer_Release(&sidb); PyBuffer_Release(&sposb); PyBuffer_Release(&evo); PyBuffer_Release(&evb); PyBuffer_Release(&evn); \
@@ -614,6 +695,15 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
         fr_got = k_ + 1;
       }
       have_ph = 1; fast_cols = 1;
+      if (TOPT("contigs") && TOPT("types") && TOPT("em_task") && TOPT("em_typ") && TOPT("alt_off") && TOPT("alt_pool") &&
+          PyList_Check(TOPT("contigs")) && PyTuple_Check(TOPT("types"))) {
+        static const char* hnames[4] = {"em_task", "em_typ", "alt_off", "alt_pool"};
+        for (int k_ = 0; k_ < 4; k_++) {
+          if (PyObject_GetBuffer(TOPT(hnames[k_]), fr_all[7 + k_], PyBUF_SIMPLE) != 0) EARLY_FAIL();
+          fr_got = 8 + k_;
+        }
+        hd_contigs = TOPT("contigs"); hd_types = TOPT("types"); head_cols = 1;
+      }
     }
 #undef TOPT
   }
@@ -631,12 +721,15 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   const int64_t* EVO = (const int64_t*)evo.buf; const int32_t* EVB = (const int32_t*)evb.buf; const int32_t* EVN = (const int32_t*)evn.buf;
   const Py_ssize_t nobj = PyList_GET_SIZE(objs), nblk = PyList_GET_SIZE(block_cov);
   PyObject** sid_objs = NULL; uint8_t* present = NULL; int* head = NULL; PyObject** chain = NULL; Py_ssize_t cap = 0;
+  Py_ssize_t* evx_row = NULL; long long* evx_idx = NULL; int64_t evx_cap = 0;
   PyObject* out = NULL;
   if ((Py_ssize_t)(ob.len / sizeof(snf_group_out_t)) < ng || cb.len < nm || svb.len / 8 < ne || tkb.len / 8 < ne || evo.len / 8 < ne + 1 ||
       evb.len != evn.len || csb.len / 4 < nobj) { PyErr_SetString(PyExc_ValueError, "group_calls: table sizes do not match"); goto done; }
   if (fast_cols && ((Py_ssize_t)(fr_rec.len / sizeof(snf_group_cand_t)) < nobj || fr_st.len / 8 < nobj || fr_ln.len / 4 < nobj || fr_hp.len < nobj ||
                     fr_pss.len / 8 < nobj || fr_psl.len / 4 < nobj)) {
     PyErr_SetString(PyExc_ValueError, "group_calls: candidate columns shorter than the candidate list"); goto done; }
+  if (head_cols && (hd_task.len / 4 < ne || hd_typ.len / 4 < ne || hd_aoff.len / 8 < nobj + 1)) {
+    PyErr_SetString(PyExc_ValueError, "group_calls: head columns shorter than the tables"); goto done; }
   sid_objs = (PyObject**)calloc((size_t)ns + 1, sizeof(PyObject*)); present = (uint8_t*)malloc((size_t)ns + 1);
   if (!sid_objs || !present) { PyErr_NoMemory(); goto done; }
   for (Py_ssize_t i = 0; i < ns; i++) { sid_objs[i] = PyLong_FromLong(SIDS[i]); if (!sid_objs[i]) goto done; }
@@ -706,7 +799,7 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
         const Py_ssize_t sx = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
         const int64_t is_ = ((const int64_t*)fr_st.buf)[M[lo + k]]; const int32_t il = ((const int32_t*)fr_ln.buf)[M[lo + k]];
         if (is_ < 0 || il < 0 || is_ + il > fr_pool.len) { PyErr_SetString(PyExc_ValueError, "group_calls: id outside the pool"); bad = 1; break; }
-        if (sx >= 0 && sx < ns) bad = (idc[sx].n && ob_str(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_put(&idc[sx], (const char*)fr_pool.buf + is_, (size_t)il);
+        if (sx >= 0 && sx < ns) bad = (idc[sx].n && OB_LIT(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_put(&idc[sx], (const char*)fr_pool.buf + is_, (size_t)il);
         if (bad) break;
         if (sx >= 0) present[sx] = 1;
         if (t_rnames) {
@@ -721,7 +814,7 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       if (text) {      /* the chained ids of a sample go straight into its id buffer (no string objects) */
         const Py_ssize_t sx = (sidv >= 0 && sidv < nspos) ? SPOS[sidv] : -1;
         if (!cid) { bad = 1; break; }
-        if (sx >= 0 && sx < ns) bad = (idc[sx].n && ob_str(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_obj(&idc[sx], cid);
+        if (sx >= 0 && sx < ns) bad = (idc[sx].n && OB_LIT(&idc[sx], ",")) || ob_py(&idc[sx], prefix) || ob_obj(&idc[sx], cid);
         Py_DECREF(cid);
         if (bad) break;
         goto chained;
@@ -772,15 +865,21 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
           int ga = r->gt_a, gb_ = r->gt_b; const char* sep = "/";
           const int8_t hp = ((const int8_t*)fr_hp.buf)[M[lo + pick]];
           if (t_phase && hp >= 0 && ((ga == 0 && gb_ == 1) || (ga == 1 && gb_ == 1))) { sep = "|"; if (hp == 1) { const int x = ga; ga = gb_; gb_ = x; } }   /* vcf.py:66-72 */
-          bad = (ga < 0 ? ob_str(sc, ".") : ob_ll(sc, ga)) || ob_str(sc, sep) || (gb_ < 0 ? ob_str(sc, ".") : ob_ll(sc, gb_)) || ob_str(sc, ":") ||
-                ob_ll(sc, r->gq) || ob_str(sc, ":") || ob_ll(sc, r->dr) || ob_str(sc, ":") || ob_ll(sc, r->dv) || ob_str(sc, ":");
-          if (!bad && t_phase) {
-            const int64_t ps0 = ((const int64_t*)fr_pss.buf)[M[lo + pick]]; const int32_t psl = ((const int32_t*)fr_psl.buf)[M[lo + pick]];
-            if (psl < 0) bad = ob_str(sc, ".:");
-            else if (ps0 < 0 || ps0 + psl > fr_pool.len) { PyErr_SetString(PyExc_ValueError, "group_calls: phase set outside the pool"); bad = 1; }
-            else bad = ob_put(sc, (const char*)fr_pool.buf + ps0, (size_t)psl) || ob_str(sc, ":");
+          const int64_t ps0 = t_phase ? ((const int64_t*)fr_pss.buf)[M[lo + pick]] : 0; const int32_t psl = t_phase ? ((const int32_t*)fr_psl.buf)[M[lo + pick]] : -1;
+          if (t_phase && psl >= 0 && (ps0 < 0 || ps0 + psl > fr_pool.len)) { PyErr_SetString(PyExc_ValueError, "group_calls: phase set outside the pool"); bad = 1; }
+          else if (!(bad = ob_room(sc, 160 + (size_t)(psl > 0 ? psl : 0) + idc[si].n))) {      /* a / b : GQ : DR : DV [: PS] : ids, one reservation */
+            char* w = sc->p + sc->n;
+            if (ga < 0) *w++ = '.'; else w = raw_ll(w, ga);
+            *w++ = sep[0];
+            if (gb_ < 0) *w++ = '.'; else w = raw_ll(w, gb_);
+            *w++ = ':'; w = raw_ll(w, r->gq); *w++ = ':'; w = raw_ll(w, r->dr); *w++ = ':'; w = raw_ll(w, r->dv); *w++ = ':';
+            if (t_phase) {
+              if (psl < 0) *w++ = '.'; else { memcpy(w, (const char*)fr_pool.buf + ps0, (size_t)psl); w += psl; }
+              *w++ = ':';
+            }
+            memcpy(w, idc[si].p, idc[si].n); w += idc[si].n;
+            sc->n = (size_t)(w - sc->p);
           }
-          if (!bad) bad = ob_put(sc, idc[si].p, idc[si].n);
           if (!bad && r->gt_a >= 0 && r->dv > 0) { t_ac += (long long)r->gt_a + r->gt_b; present[si] = 2; }
         }
         continue;
@@ -815,23 +914,38 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
     }
     for (int64_t k = 0; k < n; k++) if (head[k] == k) Py_CLEAR(chain[k]);
     /* ---- samples without a candidate in the group (sv.py:405-414): the deepest coverage bin the group saw while it was active */
+    if (have_covx && !bad) {      /* the events of the group once: row of the block's task, index of the bin in a coverage vector (-1: no entry) */
+      const int64_t nev = EVO[e + 1] - EVO[e];
+      if (nev > evx_cap) {
+        free(evx_row); free(evx_idx);
+        evx_cap = nev + 16; evx_row = (Py_ssize_t*)malloc((size_t)evx_cap * sizeof(Py_ssize_t)); evx_idx = (long long*)malloc((size_t)evx_cap * sizeof(long long));
+        if (!evx_row || !evx_idx) { PyErr_NoMemory(); Py_XDECREF(d); Py_XDECREF(gts); Py_XDECREF(names); goto fail; }
+      }
+      for (int64_t q = EVO[e]; q < EVO[e + 1]; q++) {
+        if (EVB[q] < 0 || EVB[q] >= nblk) { PyErr_SetString(PyExc_ValueError, "block index out of range"); bad = 1; break; }
+        const long long key = EVN[q], bstart = EBS[EVB[q]];
+        evx_row[q - EVO[e]] = (Py_ssize_t)EBT[EVB[q]] * ns;
+        evx_idx[q - EVO[e]] = (key >= bstart && key < bstart + cvx_bs && key % cvx_cb == 0) ? key / cvx_cb : -1;
+      }
+    }
     for (Py_ssize_t si = 0; !bad && si < ns; si++) {
       if (present[si]) continue;
       long cov = 0; int firstev = 1;
-      for (int64_t q = EVO[e]; q < EVO[e + 1]; q++) {
-        long cv = 0;
-        if (EVB[q] < 0 || EVB[q] >= nblk) { PyErr_SetString(PyExc_ValueError, "block index out of range"); bad = 1; break; }
-        if (have_covx) {
-          const int32_t* dv_ = dn_ptr[(Py_ssize_t)EBT[EVB[q]] * ns + si];
-          const long long key = EVN[q], bstart = EBS[EVB[q]];
-          if (dv_ && key >= bstart && key < bstart + cvx_bs && key % cvx_cb == 0 && key / cvx_cb < dn_len[(Py_ssize_t)EBT[EVB[q]] * ns + si]) {
-            const int32_t x = dv_[key / cvx_cb];
+      if (have_covx) {
+        for (int64_t q = 0; q < EVO[e + 1] - EVO[e]; q++) {
+          long cv = 0;
+          const int32_t* dv_ = dn_ptr[evx_row[q] + si];
+          if (dv_ && evx_idx[q] >= 0 && evx_idx[q] < dn_len[evx_row[q] + si]) {
+            const int32_t x = dv_[evx_idx[q]];
             if (x >= 0) cv = x;
           }
           cov = firstev ? cv : (cv > cov ? cv : cov);
           firstev = 0;
-          continue;
         }
+      }
+      else for (int64_t q = EVO[e]; q < EVO[e + 1]; q++) {
+        long cv = 0;
+        if (EVB[q] < 0 || EVB[q] >= nblk) { PyErr_SetString(PyExc_ValueError, "block index out of range"); bad = 1; break; }
         PyObject* per = PyList_GET_ITEM(block_cov, EVB[q]);
         PyObject* dct = PyList_Check(per) && si < PyList_GET_SIZE(per) ? PyList_GET_ITEM(per, si) : Py_None;
         if (dct != Py_None) {
@@ -847,9 +961,12 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       }
       if (bad) break;
       if (text) {                                               /* (0, 0, 0, cov, 0, (None, None), "NULL") or (".", ".", ...) as a column */
-        const char* ab = cov >= null_min ? "0" : ".";
-        bad = ob_str(&scol[si], ab) || ob_str(&scol[si], "/") || ob_str(&scol[si], ab) || ob_str(&scol[si], ":0:") || ob_ll(&scol[si], cov) ||
-              ob_str(&scol[si], t_phase ? ":0:.:NULL" : ":0:NULL");
+        if (!(bad = ob_room(&scol[si], 64))) {
+          char* w = scol[si].p + scol[si].n;
+          memcpy(w, cov >= null_min ? "0/0:0:" : "./.:0:", 6); w = raw_ll(w + 6, cov);
+          if (t_phase) { memcpy(w, ":0:.:NULL", 9); w += 9; } else { memcpy(w, ":0:NULL", 7); w += 7; }
+          scol[si].n = (size_t)(w - scol[si].p);
+        }
         continue;
       }
       PyObject* covo = PyLong_FromLong(cov);
@@ -861,59 +978,73 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
     }
     if (text && !bad) {
       /* ---- the record (vcf.py:216-300 write_call over the call of sv.py:440-481) */
-      PyObject* contig = aget(first, K_contig); PyObject* svtype = aget(first, K_svtype);
-      PyObject* alt = aget(PyList_GET_ITEM(objs, M[o->alt_member]), K_alt);
-      const char* tname = svtype ? PyUnicode_AsUTF8(svtype) : NULL;
+      PyObject *contig = NULL, *svtype = NULL, *alt = NULL;
+      const char* altp = NULL; Py_ssize_t alen = 0;             /* head columns: the ALT as bytes of the pool (ASCII: the caller checks) */
+      if (head_cols) {
+        const int32_t tk = ((const int32_t*)hd_task.buf)[e], ty = ((const int32_t*)hd_typ.buf)[e];
+        const int64_t a0 = ((const int64_t*)hd_aoff.buf)[M[o->alt_member]], a1 = ((const int64_t*)hd_aoff.buf)[M[o->alt_member] + 1];
+        if (tk < 0 || tk >= PyList_GET_SIZE(hd_contigs) || ty < 0 || ty >= PyTuple_GET_SIZE(hd_types) || a0 < 0 || a1 < a0 || a1 > hd_apool.len) {
+          PyErr_SetString(PyExc_ValueError, "group_calls: head column out of range"); bad = 1; }
+        else {
+          contig = PyList_GET_ITEM(hd_contigs, tk); svtype = PyTuple_GET_ITEM(hd_types, ty); Py_INCREF(contig); Py_INCREF(svtype);
+          altp = (const char*)hd_apool.buf + a0; alen = (Py_ssize_t)(a1 - a0);
+        }
+      } else {
+        contig = aget(first, K_contig); svtype = aget(first, K_svtype);
+        alt = aget(PyList_GET_ITEM(objs, M[o->alt_member]), K_alt);
+      }
+      const char* tname = svtype && PyUnicode_Check(svtype) ? PyUnicode_AsUTF8(svtype) : NULL;
       t_off[e] = (int64_t)tb.n; t_pos[e] = o->pos;
       int skip = 0, any = 0;
       for (Py_ssize_t si = 0; si < ns; si++) any |= present[si] == 2;
-      if (!contig || !tname || !alt || !PyUnicode_Check(alt)) bad = 1;
+      if (bad || !contig || !PyUnicode_Check(contig) || !tname || (!altp && (!alt || !PyUnicode_Check(alt)))) bad = 1;
       else if (ns > 1 && !any) skip = 1;                        /* int(supp_vec) == 0 (vcf.py:246-247) */
       if (!bad && !skip) {
         const int bnd = strcmp(tname, "BND") == 0, ins = strcmp(tname, "INS") == 0, del = strcmp(tname, "DEL") == 0;
         long long svlen = o->svlen;
-        const Py_ssize_t alen = PyUnicode_GET_LENGTH(alt);
-        if (ins && !t_symbolic && svlen != alen && PyUnicode_CompareWithASCIIString(alt, "<INS>") != 0) svlen = alen;   /* vcf.py:253-254 */
+        if (!altp) alen = PyUnicode_GET_LENGTH(alt);
+        if (ins && !t_symbolic && svlen != alen &&
+            (altp ? !(alen == 5 && memcmp(altp, "<INS>", 5) == 0) : PyUnicode_CompareWithASCIIString(alt, "<INS>") != 0)) svlen = alen;   /* vcf.py:253-254 */
         if (ins && svlen < t_minsvlen) skip = 1;
         if (!skip) {
           const long long pos = o->pos > 0 ? o->pos : 1;
           const long long end = (o->precise && del) ? pos + (svlen < 0 ? -svlen : svlen) : o->end;
-          char idbuf[96];
-          snprintf(idbuf, sizeof idbuf, "%.40s.%llXM%llX", tname, (unsigned long long)SV[e], (unsigned long long)TK[e]);
-          bad = ob_py(&tb, contig) || ob_str(&tb, "\t") || ob_ll(&tb, pos) || ob_str(&tb, "\t") || ob_py(&tb, prefix) || ob_str(&tb, idbuf) || ob_str(&tb, "\tN\t");
+          const size_t tlen = strlen(tname);      /* the id: f"{svtype}.{sv_id:X}M{task_id:X}" behind the prefix */
+          bad = ob_py(&tb, contig) || OB_LIT(&tb, "\t") || ob_ll(&tb, pos) || OB_LIT(&tb, "\t") || ob_py(&tb, prefix) || ob_put(&tb, tname, tlen < 40 ? tlen : 40) ||
+                OB_LIT(&tb, ".") || ob_hex(&tb, (unsigned long long)SV[e]) || OB_LIT(&tb, "M") || ob_hex(&tb, (unsigned long long)TK[e]) || OB_LIT(&tb, "\tN\t");
           if (!bad) {
-            if (t_symbolic && !bnd) bad = ob_str(&tb, "<") || ob_str(&tb, tname) || ob_str(&tb, ">");
-            else bad = ob_py(&tb, alt);
+            if (t_symbolic && !bnd) bad = OB_LIT(&tb, "<") || ob_put(&tb, tname, tlen) || OB_LIT(&tb, ">");
+            else bad = altp ? ob_put(&tb, altp, (size_t)alen) : ob_py(&tb, alt);
           }
           if (!bad) {
-            if (o->qual == SNF_NONE_I32) bad = ob_str(&tb, "\t.");
-            else { const long long q = o->qual < 0 ? 0 : o->qual > 60 ? 60 : o->qual; bad = ob_str(&tb, "\t") || ob_ll(&tb, q); }
+            if (o->qual == SNF_NONE_I32) bad = OB_LIT(&tb, "\t.");
+            else { const long long q = o->qual < 0 ? 0 : o->qual > 60 ? 60 : o->qual; bad = OB_LIT(&tb, "\t") || ob_ll(&tb, q); }
           }
-          if (!bad) bad = ob_str(&tb, (ns > 1 && t_ac == 0) ? "\tGT\t" : "\tPASS\t") || ob_str(&tb, o->precise ? "PRECISE" : "IMPRECISE") || (t_mosaic && ob_str(&tb, ";MOSAIC")) ||
-                          ob_str(&tb, ";SVTYPE=") || ob_str(&tb, tname);
-          if (!bad && !bnd) bad = ob_str(&tb, ";SVLEN=") || ob_ll(&tb, svlen) || ob_str(&tb, ";END=") || ob_ll(&tb, end);
-          if (!bad) bad = ob_str(&tb, ";SUPPORT=") || ob_ll(&tb, o->support);
+          if (!bad) bad = ((ns > 1 && t_ac == 0) ? OB_LIT(&tb, "\tGT\t") : OB_LIT(&tb, "\tPASS\t")) || (o->precise ? OB_LIT(&tb, "PRECISE") : OB_LIT(&tb, "IMPRECISE")) ||
+                          (t_mosaic && OB_LIT(&tb, ";MOSAIC")) || OB_LIT(&tb, ";SVTYPE=") || ob_put(&tb, tname, tlen);
+          if (!bad && !bnd) bad = OB_LIT(&tb, ";SVLEN=") || ob_ll(&tb, svlen) || OB_LIT(&tb, ";END=") || ob_ll(&tb, end);
+          if (!bad) bad = OB_LIT(&tb, ";SUPPORT=") || ob_ll(&tb, o->support);
           if (!bad && t_rnames) {
-            bad = ob_str(&tb, ";RNAMES=");
-            for (Py_ssize_t q = 0; !bad && q < PyList_GET_SIZE(names); q++) bad = (q && ob_str(&tb, ",")) || ob_obj(&tb, PyList_GET_ITEM(names, q));
+            bad = OB_LIT(&tb, ";RNAMES=");
+            for (Py_ssize_t q = 0; !bad && q < PyList_GET_SIZE(names); q++) bad = (q && OB_LIT(&tb, ",")) || ob_obj(&tb, PyList_GET_ITEM(names, q));
           }
           if (!bad) {
-            bad = ob_str(&tb, ";COVERAGE=");
+            bad = OB_LIT(&tb, ";COVERAGE=");
             for (int q = 0; !bad && q < 5; q++) {
-              bad = q && ob_str(&tb, ",");
-              if (!bad) bad = o->cov[q] == SNF_NONE_I32 ? ob_str(&tb, "None") : ob_ll(&tb, o->cov[q]);
+              bad = q && OB_LIT(&tb, ",");
+              if (!bad) bad = o->cov[q] == SNF_NONE_I32 ? OB_LIT(&tb, "None") : ob_ll(&tb, o->cov[q]);
             }
           }
-          if (!bad) bad = ob_str(&tb, ";STRAND=") || ob_str(&tb, o->fwd > 0 ? "+" : "") || ob_str(&tb, o->rev > 0 ? "-" : "") || (t_nm && ob_str(&tb, ";NM=-1"));
-          if (!bad && ns > 1) bad = ob_str(&tb, ";AC=") || ob_ll(&tb, t_ac);      /* call.info, sorted: AC, STDEV_LEN, STDEV_POS, SUPP_VEC */
+          if (!bad) bad = OB_LIT(&tb, ";STRAND=") || (o->fwd > 0 && OB_LIT(&tb, "+")) || (o->rev > 0 && OB_LIT(&tb, "-")) || (t_nm && OB_LIT(&tb, ";NM=-1"));
+          if (!bad && ns > 1) bad = OB_LIT(&tb, ";AC=") || ob_ll(&tb, t_ac);      /* call.info, sorted: AC, STDEV_LEN, STDEV_POS, SUPP_VEC */
           if (!bad) {
-            if (o->n < 2) bad = ob_str(&tb, ";STDEV_LEN=0;STDEV_POS=0");
-            else bad = ob_str(&tb, ";STDEV_LEN=") || ob_f3(&tb, o->stdev_len) || ob_str(&tb, ";STDEV_POS=") || ob_f3(&tb, o->stdev_pos);
+            if (o->n < 2) bad = OB_LIT(&tb, ";STDEV_LEN=0;STDEV_POS=0");
+            else bad = OB_LIT(&tb, ";STDEV_LEN=") || ob_f3(&tb, o->stdev_len) || OB_LIT(&tb, ";STDEV_POS=") || ob_f3(&tb, o->stdev_pos);
           }
-          if (!bad && ns > 1) { bad = ob_str(&tb, ";SUPP_VEC="); for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = ob_str(&tb, present[si] == 2 ? "1" : "0"); }
-          if (!bad) bad = ob_str(&tb, "\t") || ob_py(&tb, t_fmt);
-          for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = ob_str(&tb, "\t") || ob_put(&tb, scol[si].p, scol[si].n);
-          if (!bad) bad = ob_str(&tb, "\n");
+          if (!bad && ns > 1) { bad = OB_LIT(&tb, ";SUPP_VEC="); for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = ob_put(&tb, present[si] == 2 ? "1" : "0", 1); }
+          if (!bad) bad = OB_LIT(&tb, "\t") || ob_py(&tb, t_fmt);
+          for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = OB_LIT(&tb, "\t") || ob_put(&tb, scol[si].p, scol[si].n);
+          if (!bad) bad = OB_LIT(&tb, "\n");
         }
       }
       Py_XDECREF(contig); Py_XDECREF(svtype); Py_XDECREF(alt); Py_XDECREF(names);
@@ -982,11 +1113,12 @@ fail:
 done:
   Py_XDECREF(out);
   if (sid_objs) { for (Py_ssize_t i = 0; i < ns; i++) Py_XDECREF(sid_objs[i]); free(sid_objs); }
-  free(present); free(head); free(chain);
+  free(present); free(head); free(chain); free(evx_row); free(evx_idx);
   if (scol) { for (Py_ssize_t si = 0; si < ns; si++) free(scol[si].p); free(scol); }
   if (idc) { for (Py_ssize_t si = 0; si < ns; si++) free(idc[si].p); free(idc); }
   if (fast_cols) { PyBuffer_Release(&fr_rec); PyBuffer_Release(&fr_pool); PyBuffer_Release(&fr_st); PyBuffer_Release(&fr_ln); }
   if (have_ph) { PyBuffer_Release(&fr_hp); PyBuffer_Release(&fr_pss); PyBuffer_Release(&fr_psl); }
+  if (head_cols) { PyBuffer_Release(&hd_task); PyBuffer_Release(&hd_typ); PyBuffer_Release(&hd_aoff); PyBuffer_Release(&hd_apool); }
   if (dn_buf) { for (Py_ssize_t k = 0; k < dn_n; k++) PyBuffer_Release(&dn_buf[k]); free(dn_buf); }
   free(dn_ptr); free(dn_len);
   if (have_covx) { PyBuffer_Release(&ebtb); PyBuffer_Release(&ebsb); }
@@ -1048,63 +1180,63 @@ static PyObject* py_vcf_records(PyObject* self, PyObject* args) {
     const long long end = (c->precise && c->svtype == SNF_DEL) ? pos + (svlen < 0 ? -svlen : svlen) : c->end;
     const size_t line_start = b.n;
     /* CHROM POS ID REF ALT */
-    if (ob_py(&b, contig) || ob_str(&b, "\t") || ob_ll(&b, pos) || ob_str(&b, "\t") || ob_py(&b, o_prefix)) goto done;
+    if (ob_py(&b, contig) || OB_LIT(&b, "\t") || ob_ll(&b, pos) || OB_LIT(&b, "\t") || ob_py(&b, o_prefix)) goto done;
     { char idbuf[64]; snprintf(idbuf, sizeof idbuf, "%s.%XS%llX", SVTYPES[c->svtype], (unsigned)c->sv_id, (unsigned long long)task_id);
-      if (ob_str(&b, idbuf) || ob_str(&b, "\tN\t")) goto done; }
+      if (ob_str(&b, idbuf) || OB_LIT(&b, "\tN\t")) goto done; }
     if (bnd) {     /* sv.py:630-634; also with --symbolic (vcf.py:322-324 leaves BND ALTs alone) */
       const char* br = c->bnd_is_reverse ? "]" : "[";
-      if (ob_str(&b, c->bnd_is_first ? "N" : "") || ob_str(&b, br) || ob_name(&b, contig_names, c->mate_contig, "ctg") || ob_str(&b, ":") ||
+      if (ob_str(&b, c->bnd_is_first ? "N" : "") || ob_str(&b, br) || ob_name(&b, contig_names, c->mate_contig, "ctg") || OB_LIT(&b, ":") ||
           ob_ll(&b, c->mate_ref_start) || ob_str(&b, br) || ob_str(&b, c->bnd_is_first ? "" : "N")) goto done;
     } else if (resolved) {
       if (ob_put(&b, (const char*)pool.buf + c->alt_off, (size_t)c->alt_len)) goto done;
     } else {
-      if (ob_str(&b, "<") || ob_str(&b, SVTYPES[c->svtype]) || ob_str(&b, ">")) goto done;
+      if (OB_LIT(&b, "<") || ob_str(&b, SVTYPES[c->svtype]) || OB_LIT(&b, ">")) goto done;
     }
     /* QUAL FILTER */
     { const long long q = c->qual < 0 ? 0 : c->qual > 60 ? 60 : c->qual;
-      if (ob_str(&b, "\t") || ob_ll(&b, q) || ob_str(&b, "\t") || ob_py(&b, PyList_GET_ITEM(filters, c->filter)) || ob_str(&b, "\t")) goto done; }
+      if (OB_LIT(&b, "\t") || ob_ll(&b, q) || OB_LIT(&b, "\t") || ob_py(&b, PyList_GET_ITEM(filters, c->filter)) || OB_LIT(&b, "\t")) goto done; }
     /* INFO */
     if (ob_str(&b, c->precise ? "PRECISE" : "IMPRECISE")) goto done;
-    if (mosaic && (c->gt_set ? c->vaf : 0.0) <= af_max) { if (ob_str(&b, ";MOSAIC")) goto done; }
-    if (ob_str(&b, ";SVTYPE=") || ob_str(&b, SVTYPES[c->svtype])) goto done;
-    if (!bnd) { if (ob_str(&b, ";SVLEN=") || ob_ll(&b, svlen) || ob_str(&b, ";END=") || ob_ll(&b, end)) goto done; }
-    if (ob_str(&b, ";SUPPORT=") || ob_ll(&b, c->support)) goto done;
+    if (mosaic && (c->gt_set ? c->vaf : 0.0) <= af_max) { if (OB_LIT(&b, ";MOSAIC")) goto done; }
+    if (OB_LIT(&b, ";SVTYPE=") || ob_str(&b, SVTYPES[c->svtype])) goto done;
+    if (!bnd) { if (OB_LIT(&b, ";SVLEN=") || ob_ll(&b, svlen) || OB_LIT(&b, ";END=") || ob_ll(&b, end)) goto done; }
+    if (OB_LIT(&b, ";SUPPORT=") || ob_ll(&b, c->support)) goto done;
     if (out_rn) {
       if (c->rn_off < 0 || c->rn_len < 0 || c->rn_off + c->rn_len > rn_n) { PyErr_SetString(PyExc_ValueError, "read-name range outside the table"); goto done; }
-      if (ob_str(&b, ";RNAMES=")) goto done;
-      for (int q = 0; q < c->rn_len; q++) { if ((q && ob_str(&b, ",")) || ob_name(&b, qnames, (long)RN[c->rn_off + q], "q")) goto done; }
+      if (OB_LIT(&b, ";RNAMES=")) goto done;
+      for (int q = 0; q < c->rn_len; q++) { if ((q && OB_LIT(&b, ",")) || ob_name(&b, qnames, (long)RN[c->rn_off + q], "q")) goto done; }
     }
-    if (ob_str(&b, ";COVERAGE=")) goto done;
+    if (OB_LIT(&b, ";COVERAGE=")) goto done;
     { const int idx[5] = {0, 1, 2, 3, 4};
-      for (int q = 0; q < 5; q++) { if ((q && ob_str(&b, ",")) || ob_ll(&b, c->cov[idx[q]])) goto done; } }
-    if (ob_str(&b, ";STRAND=") || ob_str(&b, c->fwd > 0 ? "+" : "") || ob_str(&b, c->rev > 0 ? "-" : "")) goto done;
-    if (with_nm) { if (ob_str(&b, ";NM=") || ob_f3(&b, c->nm)) goto done; }
+      for (int q = 0; q < 5; q++) { if ((q && OB_LIT(&b, ",")) || ob_ll(&b, c->cov[idx[q]])) goto done; } }
+    if (OB_LIT(&b, ";STRAND=") || ob_str(&b, c->fwd > 0 ? "+" : "") || ob_str(&b, c->rev > 0 ? "-" : "")) goto done;
+    if (with_nm) { if (OB_LIT(&b, ";NM=") || ob_f3(&b, c->nm)) goto done; }
     /* call.info, sorted by key: CHR2 < COVERAGE_VAR (None: not written) < PHASE < STDEV_LEN < STDEV_POS < SUPPORT_LONG < SUPPORT_SA < VAF */
-    if (bnd) { if (ob_str(&b, ";CHR2=") || ob_name(&b, contig_names, c->mate_contig, "ctg")) goto done; }
+    if (bnd) { if (OB_LIT(&b, ";CHR2=") || ob_name(&b, contig_names, c->mate_contig, "ctg")) goto done; }
     if (c->ph_set) {
-      if (ob_str(&b, ";PHASE=") || ob_ll(&b, c->ph_hp) || ob_str(&b, ",") || ob_ps(&b, c->ph_ps, ps_names, "None") || ob_str(&b, ",") ||
-          ob_ll(&b, c->ph_hp_support) || ob_str(&b, ",") || ob_ll(&b, c->ph_ps_support) || ob_str(&b, c->ph_hp_pass ? ",PASS" : ",FAIL") ||
+      if (OB_LIT(&b, ";PHASE=") || ob_ll(&b, c->ph_hp) || OB_LIT(&b, ",") || ob_ps(&b, c->ph_ps, ps_names, "None") || OB_LIT(&b, ",") ||
+          ob_ll(&b, c->ph_hp_support) || OB_LIT(&b, ",") || ob_ll(&b, c->ph_ps_support) || ob_str(&b, c->ph_hp_pass ? ",PASS" : ",FAIL") ||
           ob_str(&b, c->ph_ps_pass ? ",PASS" : ",FAIL")) goto done;
     }
     { const int single = c->fwd + c->rev < 2;      /* util.stdev returns the int 0 for fewer than two values */
-      if (!isnan(c->stdev_len)) { if (ob_str(&b, ";STDEV_LEN=") || (single ? ob_str(&b, "0") : ob_f3(&b, c->stdev_len))) goto done; }
-      if (ob_str(&b, ";STDEV_POS=") || (single ? ob_str(&b, "0") : ob_f3(&b, c->stdev_pos))) goto done; }
-    if (ins) { if (ob_str(&b, ";SUPPORT_LONG=") || ob_ll(&b, c->support_long)) goto done; }
-    if (c->svtype == SNF_DEL) { if (ob_str(&b, ";SUPPORT_SA=") || ob_ll(&b, c->support_sa)) goto done; }
-    if (c->gt_set) { if (ob_str(&b, ";VAF=") || ob_f3(&b, c->vaf)) goto done; }
+      if (!isnan(c->stdev_len)) { if (OB_LIT(&b, ";STDEV_LEN=") || (single ? OB_LIT(&b, "0") : ob_f3(&b, c->stdev_len))) goto done; }
+      if (OB_LIT(&b, ";STDEV_POS=") || (single ? OB_LIT(&b, "0") : ob_f3(&b, c->stdev_pos))) goto done; }
+    if (ins) { if (OB_LIT(&b, ";SUPPORT_LONG=") || ob_ll(&b, c->support_long)) goto done; }
+    if (c->svtype == SNF_DEL) { if (OB_LIT(&b, ";SUPPORT_SA=") || ob_ll(&b, c->support_sa)) goto done; }
+    if (c->gt_set) { if (OB_LIT(&b, ";VAF=") || ob_f3(&b, c->vaf)) goto done; }
     /* FORMAT + the sample column (vcf.py:54-83) */
-    if (ob_str(&b, "\t") || ob_py(&b, o_fmt) || ob_str(&b, "\t")) goto done;
+    if (OB_LIT(&b, "\t") || ob_py(&b, o_fmt) || OB_LIT(&b, "\t")) goto done;
     if (!c->gt_set) { if (ob_py(&b, o_none)) goto done; }
     else {
       int a = c->gt_a, bb = c->gt_b;
       const int hp_set = c->gt_hp >= 0;
       const char* sep = "/";
       if (phase && hp_set && ((a == 0 && bb == 1) || (a == 1 && bb == 1))) { sep = "|"; if (c->gt_hp == 1) { const int t = a; a = bb; bb = t; } }
-      if (ob_ll(&b, a) || ob_str(&b, sep) || ob_ll(&b, bb) || ob_str(&b, ":") || ob_ll(&b, c->gt_gq) || ob_str(&b, ":") || ob_ll(&b, c->gt_dr) ||
-          ob_str(&b, ":") || ob_ll(&b, c->gt_dv)) goto done;
-      if (phase) { if (ob_str(&b, ":") || (c->gt_ps == -1 || c->gt_ps == -2 ? ob_str(&b, ".") : ob_ps(&b, c->gt_ps, ps_names, "."))) goto done; }
+      if (ob_ll(&b, a) || ob_str(&b, sep) || ob_ll(&b, bb) || OB_LIT(&b, ":") || ob_ll(&b, c->gt_gq) || OB_LIT(&b, ":") || ob_ll(&b, c->gt_dr) ||
+          OB_LIT(&b, ":") || ob_ll(&b, c->gt_dv)) goto done;
+      if (phase) { if (OB_LIT(&b, ":") || (c->gt_ps == -1 || c->gt_ps == -2 ? OB_LIT(&b, ".") : ob_ps(&b, c->gt_ps, ps_names, "."))) goto done; }
     }
-    if (ob_str(&b, "\n")) goto done;
+    if (OB_LIT(&b, "\n")) goto done;
     (void)line_start;
     written++;
   }
@@ -1253,12 +1385,26 @@ done:
   return out;
 }
 
+/* format_f3(values: buffer float64) -> bytes: the values as this module prints them (ob_f3), '\n' between: lets the test suite pin the
+ * hand-written "%.3f" against Python's own f"{v:.3f}" */
+static PyObject* py_format_f3(PyObject* self, PyObject* args) {
+  Py_buffer vb;
+  if (!PyArg_ParseTuple(args, "y*", &vb)) return NULL;
+  OutBuf b = {NULL, 0, 0}; PyObject* ret = NULL; int bad = 0;
+  for (Py_ssize_t i = 0; !bad && i < vb.len / 8; i++) bad = ob_f3(&b, ((const double*)vb.buf)[i]) || OB_LIT(&b, "\n");
+  if (!bad) ret = PyBytes_FromStringAndSize(b.p ? b.p : "", (Py_ssize_t)b.n);
+  free(b.p); PyBuffer_Release(&vb);
+  return ret;
+}
+
 static PyMethodDef methods[] = {
+    {"format_f3", py_format_f3, METH_VARARGS, "float64 values as f\"{v:.3f}\" lines (test hook of the formatter)"},
     {"lead_columns", py_lead_columns, METH_VARARGS, "Lead objects -> typed TaskInput columns in one walk (input side of the drop-in)"},
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
     {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},
     {"gather_pool", py_gather_pool, METH_VARARGS, "strings of a pool in a given order, back to back"},
+    {"gather_pool_parts", py_gather_pool_parts, METH_VARARGS, "gather_pool over strings that lie in several pools"},
     {"flush_windows", py_flush_windows, METH_VARARGS, "flush windows of CombineTask.execute over the sorted candidate table"},
     {"group_calls", py_group_calls, METH_VARARGS, "group records + membership -> combined SVCall objects"},
     {"vcf_records", py_vcf_records, METH_VARARGS, "single-sample VCF lines straight from the record table"},

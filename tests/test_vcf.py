@@ -288,3 +288,25 @@ def test_formatters_agree_with_the_reference_on_random_values():
     values = [0, 1, -3, 0.5, 1 / 3, 1e-9, 12345.6789, None, True, False, "x", "", ["a", "b"], [], np.float64(2.5), np.int64(4), float("nan")]
     for v in values:
         assert vcf.format_info("K", v) == ref_vcf.format_info("K", v), v
+
+
+def test_three_decimals_formatter_equals_python_formatting():
+    """The C extension prints f"{v:.3f}" values (STDEV_*, VAF, NM) with its own conversion (one multiplication, the rounding error from
+    an fma) instead of printf: it has to give the exactly rounded decimal like Python does - ties of the binary value included."""
+    import numpy as np
+    from sniffles_amd import sv
+    fast = sv._load_fast()
+    if fast is None:
+        pytest.skip("C extension not built")
+    rng = np.random.default_rng(7)
+    vals = list(rng.random(50000) * 10.0 ** rng.integers(-6, 13, 50000)) + list(-rng.random(5000) * 10.0 ** rng.integers(-6, 6, 5000))
+    vals += [k / 8 for k in range(-2000, 2000)] + [k / 2048 for k in range(5000)] + [k / 16 + 0.0005 for k in range(100)]
+    vals += [0.0, -0.0, 0.0005, 0.0015, 0.0025, 1e-9, -1e-9, 0.9995, 999999999999.9995, 1e12, 1e12 - 0.0005, 1e15, 1e22, 1.7976931348623157e308,
+             5e-324, float("nan"), float("inf"), -float("inf"), 0.5, 1.0005, 2.0005, 1024.0005, 123456.7895, 123456.7885]
+    for k in range(1, 20000, 7):          # the neighbours of every kind of decimal tie
+        t = k / 1000 + 0.0005
+        vals += [t, float(np.nextafter(t, 0)), float(np.nextafter(t, 1e9))]
+    a = np.asarray(vals, np.float64)
+    got = fast.format_f3(a.tobytes()).decode().split("\n")[:-1]
+    assert len(got) == len(a)
+    assert [g for v, g in zip(a.tolist(), got) if g != f"{v:.3f}"] == []

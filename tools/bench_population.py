@@ -18,6 +18,8 @@ import os
 import sys
 import time
 
+from tools.bench_common import DEV, dev_sync
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0
 
@@ -147,7 +149,7 @@ def run(ctx):
     def barrier():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync(torch)
 
     for _ in range(warmup):
         one_pass()
@@ -164,8 +166,8 @@ def run(ctx):
     objects_ms = (time.perf_counter() - t1) * 1e3
     text_equal = text_box[0] == text_fast
     lib.combine_resolve_batch = real_call
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device="cuda")
+    tt = torch.tensor([dt], dtype=torch.float64, device=DEV)
+    tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device=DEV)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
