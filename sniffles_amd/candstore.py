@@ -21,6 +21,7 @@ the twin the tests compare with (`SNF_COMBINE_OBJECTS=1` selects it)."""
 from __future__ import annotations
 
 import os
+import threading
 import time
 
 import numpy as np
@@ -126,6 +127,7 @@ class ContigColumns:
 # that merges the same readers again (bench.py --config 4: candidates resident as columns) keeps them.  `SNF_COLUMNS_CACHE=N` bounds the
 # number of contigs a reader holds at a time (0: nothing is kept between calls).
 COLUMNS_CACHE_CONTIGS = None
+_COLUMNS_LOCK = threading.Lock()
 
 
 def reader_columns(reader, contig, sid, thr, fast):
@@ -137,6 +139,11 @@ def reader_columns(reader, contig, sid, thr, fast):
     import os
     if not hasattr(reader, "block_starts") or getattr(reader, "reqc", False):
         return None
+    with _COLUMNS_LOCK:      # (the chunks of a merge run on two threads: one builds or evicts at a time)
+        return _reader_columns_locked(reader, contig, sid, thr, fast, os)
+
+
+def _reader_columns_locked(reader, contig, sid, thr, fast, os):
     cache = reader.__dict__.setdefault("_snf_columns", {})
     key = (contig, int(sid), int(thr), id(getattr(reader, "index", None)))
     if key in cache:
@@ -338,10 +345,67 @@ def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     `text_writer` (a `vcf.VCF` whose `can_write_merged()` holds): no `SVCall` objects are built - per task `(lines: bytes,
     line_off, pos)`, the VCF records `write_call` would print for them, straight from the group table (`VCF.write_merged`)."""
     with sv.no_gc():
-        return _execute_many(tasks, samples_snf, text_writer)
+        chunks = _task_chunks(tasks, samples_snf)
+        if len(chunks) == 1:
+            return _execute_many(tasks, samples_snf, text_writer)
+        # tasks share nothing (a chain never leaves its contig task): the merge of a run of tasks is a merge of its own.  Two threads
+        # take the runs in turn - while one waits for the group assignment of its run on the GPU (the C-ABI call releases the
+        # interpreter lock; the library admits one such call per device at a time) the other sorts, cuts or formats its own
+        from concurrent.futures import ThreadPoolExecutor
+        t0 = time.perf_counter()
+        timings = []
+
+        def one(chunk):
+            out = _execute_many(chunk, samples_snf, text_writer, timings)
+            return out
+        with ThreadPoolExecutor(2) as pool:
+            parts = list(pool.map(one, chunks))
+        last_timing.clear()
+        for tm in timings:
+            for k, v in tm.items():
+                last_timing[k] = last_timing.get(k, 0) + v
+        last_timing["chunks"] = len(chunks)
+        last_timing["wall"] = time.perf_counter() - t0
+        return [r for part in parts for r in part]
 
 
-def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
+# A merge of at least this many blocks x samples is cut into runs of tasks that overlap host work and GPU work (`execute_many`);
+# SNF_COMBINE_CHUNKS=k sets the number of runs (1: one launch for all tasks, as before)
+CHUNK_MIN_WORK = 40000
+CHUNKS = 4
+
+
+def _task_chunks(tasks, samples_snf) -> list:
+    """`tasks` as consecutive runs of about equal numbers of blocks."""
+    k = os.environ.get("SNF_COMBINE_CHUNKS")
+    weights = [max(1, len(t.block_indices)) for t in tasks]
+    if k is None:
+        k = CHUNKS if len(tasks) >= 2 * CHUNKS and sum(weights) * max(1, len(samples_snf)) >= CHUNK_MIN_WORK else 1
+    k = max(1, min(int(k), len(tasks)))
+    if k == 1:
+        return [list(tasks)]
+    total, out, cur, acc = float(sum(weights)), [], [], 0.0
+    for t, w in zip(tasks, weights):
+        cur.append(t); acc += w
+        if len(out) < k - 1 and acc >= total * (len(out) + 1) / k:
+            out.append(cur); cur = []
+    if cur:
+        out.append(cur)
+    return out
+
+
+def _record_timing(timings, marks, **counts) -> None:
+    """Phases of one `_execute_many`: into `last_timing`, or (a chunk of a merge) appended to `timings` for the caller to add up."""
+    d = {name: t1 - t0 for (_, t0), (name, t1) in zip(marks[:-1], marks[1:])}
+    d.update(counts)
+    if timings is not None:
+        timings.append(d)
+    else:
+        last_timing.clear()
+        last_timing.update(d)
+
+
+def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: list = None) -> list:
     fast = sv._load_fast()
     t0 = tasks[0]
     config, device = t0.config, t0.device
@@ -482,6 +546,11 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
     start_id = np.asarray([t.sv_id for t in tasks], np.int64)
     sv_ids = start_id[g_task[em]] + (np.arange(len(em)) - first_of_task[g_task[em]])
     task_ids = np.asarray([t.id for t in tasks], np.int64)[g_task[em]]
+    if text_writer is not None:
+        # text: the ids are given (emission order) - the records themselves are formatted in the order they are written, per task by
+        # position with the emission order among equals (`sorted(calls, key=pos)`, stable): a task's text is then one slice of the buffer
+        by_pos = np.lexsort((np.arange(len(em)), gout["pos"][em], g_task[em]))
+        em, sv_ids, task_ids = em[by_pos], sv_ids[by_pos], task_ids[by_pos]
     # events a group was active in: its first window .. the flush window (or the chain's last); pos_mean at an event = after the
     # last candidate added up to that window; coverage bin of parallel.py:543
     last_win = np.where(flushed, gout["flush_win"], g_hi - 1).astype(np.int64)
@@ -517,9 +586,7 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         text, line_off, line_pos = calls
         line_off, line_pos = np.frombuffer(line_off, np.int64), np.frombuffer(line_pos, np.int64)
         mark("build_svcalls")
-        last_timing.clear()
-        last_timing.update({name: t1 - t0_ for (_, t0_), (name, t1) in zip(tm[:-1], tm[1:])})
-        last_timing.update(candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(em))
+        _record_timing(timings, tm, candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(em))
         result = []
         for k, t in enumerate(tasks):
             a, b = int(first_of_task[k]), int(first_of_task[k] + per_task[k])
@@ -538,9 +605,7 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
                     if q < thr and a != ".":
                         call.genotypes[sid] = (top[0], top[1], q, dr, dv, ps, nid)
     mark("build_svcalls")
-    last_timing.clear()
-    last_timing.update({name: t1 - t0_ for (_, t0_), (name, t1) in zip(tm[:-1], tm[1:])})
-    last_timing.update(candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(calls))
+    _record_timing(timings, tm, candidates=n, windows=nw, sub_chains=len(s_lo), groups=n_groups, calls=len(calls))
     result = []
     for k, t in enumerate(tasks):
         a, b = int(first_of_task[k]), int(first_of_task[k] + per_task[k])

@@ -23,6 +23,7 @@ static PyObject *K_contig, *K_pos, *K_id, *K_ref, *K_alt, *K_qual, *K_filter, *K
     *K_cov_st, *K_cov_ce, *K_cov_en, *K_sample, *K_bnd_info, *K_sup_inline, *K_sup_splits, *K_raw, *K_raw_idx;
 static PyObject *I_CHR2, *I_SUPPORT_LONG, *I_SUPPORT_SA, *I_STDEV_POS, *I_STDEV_LEN, *I_COVERAGE_VAR, *I_PHASE, *I_VAF;
 static PyObject *F_n, *F_m1, *F_m2, *F_last;
+static PyObject *S_dot, *S_comma, *O_zero, *T_none2, *I_COVERAGE;
 static PyObject *B_mate_contig, *B_mate_ref_start, *B_is_first, *B_is_reverse, *P_batch, *P_index, *S_NULL, *S_PASS, *S_FAIL;
 
 static int set_steal(PyObject* d, PyObject* k, PyObject* v) {   /* d[k] = v, steals v */
@@ -30,6 +31,21 @@ static int set_steal(PyObject* d, PyObject* k, PyObject* v) {   /* d[k] = v, ste
   int rc = PyDict_SetItem(d, k, v);
   Py_DECREF(v);
   return rc;
+}
+/* raw writers: the caller has reserved the room (a local buffer, or ob_room below), `w` runs through it */
+static inline char* raw_ll(char* w, long long v) {
+  char t[24]; int n = 24;
+  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
+  do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) t[--n] = '-';
+  memcpy(w, t + n, (size_t)(24 - n));
+  return w + (24 - n);
+}
+static inline char* raw_hex(char* w, unsigned long long u) {     /* "%llX" */
+  char t[16]; int n = 16;
+  do { t[--n] = "0123456789ABCDEF"[u & 15]; u >>= 4; } while (u);
+  memcpy(w, t + n, (size_t)(16 - n));
+  return w + (16 - n);
 }
 static PyObject* new_instance(PyObject* cls, PyObject* dict) {  /* object.__new__(cls) with __dict__ = dict (steals dict) */
   PyObject* empty = PyTuple_New(0);
@@ -83,19 +99,29 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
   if (!PyArg_ParseTuple(args, "OOOOOy*LLy*OOLOO", &cls, &bnd_cls, &fds_cls, &post_cls, &batch, &calls, &lo, &hi, &rn, &qnames, &contig,
                         &task_id, &contig_names, &filters))
     return NULL;
-  PyObject* out = NULL;
+  PyObject *out = NULL, *tmpl = NULL;
   if (lo < 0 || hi < lo || (size_t)hi * sizeof(snf_call_t) > (size_t)calls.len) { PyErr_SetString(PyExc_ValueError, "call range outside the record table"); goto done; }
   const snf_call_t* C = (const snf_call_t*)calls.buf;
   const uint32_t* RN = (const uint32_t*)rn.buf;
   const long long rn_n = rn.len / 4;
   out = PyList_New(hi - lo);
   if (!out) goto done;
+  /* the instance dict of a call: 33 attributes in the dataclass's order.  A template holds the keys and the eight values that are the
+   * same for every call of the task; a call's dict is a copy of it (one allocation, no inserts) with the other 25 values replaced */
+  tmpl = _PyDict_NewPresized(34);
+  {
+    PyObject* keys33[33] = {K_contig, K_pos, K_id, K_ref, K_alt, K_qual, K_filter, K_info, K_svtype, K_svlen, K_end, K_genotypes, K_precise, K_support,
+                            K_rnames, K_qc, K_nm, K_postprocess, K_svlens, K_fwd, K_rev, K_fds, K_cov_up, K_cov_dn, K_cov_st, K_cov_ce, K_cov_en, K_sample,
+                            K_bnd_info, K_sup_inline, K_sup_splits, K_raw, K_raw_idx};
+    for (int k = 0; tmpl && k < 33; k++) if (PyDict_SetItem(tmpl, keys33[k], keys33[k] == K_contig ? contig : keys33[k] == K_ref ? S_N : Py_None)) Py_CLEAR(tmpl);
+    if (!tmpl) goto fail;
+  }
   for (long long i = lo; i < hi; i++) {
     const snf_call_t* c = &C[i];
     if (c->svtype < 0 || c->svtype > 6 || c->filter < 0 || c->filter >= PyList_GET_SIZE(filters)) { PyErr_SetString(PyExc_ValueError, "record field out of range"); goto fail; }
-    PyObject* d = _PyDict_NewPresized(34);     /* 33 attributes: no rehash while the instance dict is filled */
+    PyObject* d = PyDict_Copy(tmpl);
     if (!d) goto fail;
-    PyObject* info = PyDict_New();
+    PyObject* info = _PyDict_NewPresized(6);   /* up to six keys by the end of finalize (COVERAGE_VAR, PHASE, VAF): no rehash on the way */
     PyObject* alt = S_alt_sym[c->svtype]; Py_INCREF(alt);
     PyObject* bi = Py_None; Py_INCREF(bi);
     int bad = !info;
@@ -137,8 +163,13 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
         }
       }
     }
-    char idbuf[64];
-    snprintf(idbuf, sizeof idbuf, "%s.%XS%llX", SVTYPES[c->svtype], (unsigned)c->sv_id, (unsigned long long)task_id);
+    char idbuf[64]; Py_ssize_t idlen;      /* f"{svtype}.{sv_id:X}S{task_id:X}" (sv.py call_id) by hand: snprintf costs more than the 33 dict fills */
+    {
+      const size_t tl = strlen(SVTYPES[c->svtype]);
+      char* w = idbuf; memcpy(w, SVTYPES[c->svtype], tl); w += tl; *w++ = '.';
+      w = raw_hex(w, (unsigned)c->sv_id); *w++ = 'S'; w = raw_hex(w, (unsigned long long)task_id);
+      idlen = (Py_ssize_t)(w - idbuf);
+    }
     /* ForwardDifferenceWelford(): n = m1 = m2 = 0, last = None (sniffles_amd/sv.py; the test suite compares with the class) */
     PyObject* fds = NULL;
     if (!bad) {
@@ -156,20 +187,18 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
       else Py_XDECREF(pd);
     }
     if (!bad)
-      bad = PyDict_SetItem(d, K_contig, contig) || set_steal(d, K_pos, PyLong_FromLong(c->pos)) || set_steal(d, K_id, PyUnicode_FromString(idbuf)) ||
-            PyDict_SetItem(d, K_ref, S_N) || PyDict_SetItem(d, K_alt, alt) || set_steal(d, K_qual, PyLong_FromLong(c->qual)) ||
+      bad = set_steal(d, K_pos, PyLong_FromLong(c->pos)) || set_steal(d, K_id, PyUnicode_FromStringAndSize(idbuf, idlen)) ||
+            PyDict_SetItem(d, K_alt, alt) || set_steal(d, K_qual, PyLong_FromLong(c->qual)) ||
             PyDict_SetItem(d, K_filter, PyList_GET_ITEM(filters, c->filter)) || PyDict_SetItem(d, K_info, info) ||
             PyDict_SetItem(d, K_svtype, S_svtype[c->svtype]) || set_steal(d, K_svlen, PyLong_FromLong(c->svlen)) ||
             set_steal(d, K_end, PyLong_FromLong(c->end)) || set_steal(d, K_genotypes, PyDict_New()) ||
             PyDict_SetItem(d, K_precise, c->precise ? Py_True : Py_False) || set_steal(d, K_support, PyLong_FromLong(c->support)) ||
             PyDict_SetItem(d, K_rnames, names) || PyDict_SetItem(d, K_qc, c->qc ? Py_True : Py_False) ||
-            set_steal(d, K_nm, PyFloat_FromDouble(c->nm)) || PyDict_SetItem(d, K_postprocess, post) || PyDict_SetItem(d, K_svlens, Py_None) ||
+            set_steal(d, K_nm, PyFloat_FromDouble(c->nm)) || (post != Py_None && PyDict_SetItem(d, K_postprocess, post)) ||
             set_steal(d, K_fwd, PyLong_FromLong(c->fwd)) || set_steal(d, K_rev, PyLong_FromLong(c->rev)) || PyDict_SetItem(d, K_fds, fds) ||
             set_steal(d, K_cov_up, PyLong_FromLong(c->cov[0])) || set_steal(d, K_cov_dn, PyLong_FromLong(c->cov[4])) ||
             set_steal(d, K_cov_st, PyLong_FromLong(c->cov[1])) || set_steal(d, K_cov_ce, PyLong_FromLong(c->cov[2])) ||
-            set_steal(d, K_cov_en, PyLong_FromLong(c->cov[3])) || PyDict_SetItem(d, K_sample, Py_None) || PyDict_SetItem(d, K_bnd_info, bi) ||
-            PyDict_SetItem(d, K_sup_inline, Py_None) || PyDict_SetItem(d, K_sup_splits, Py_None) || PyDict_SetItem(d, K_raw, Py_None) ||
-            PyDict_SetItem(d, K_raw_idx, Py_None);
+            set_steal(d, K_cov_en, PyLong_FromLong(c->cov[3])) || (bi != Py_None && PyDict_SetItem(d, K_bnd_info, bi));
     Py_XDECREF(info); Py_XDECREF(alt); Py_XDECREF(bi); Py_XDECREF(names); Py_XDECREF(fds); Py_XDECREF(post);
     if (bad) { Py_DECREF(d); goto fail; }
     PyObject* obj = new_instance(cls, d);
@@ -180,16 +209,22 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
 fail:
   Py_CLEAR(out);
 done:
+  Py_XDECREF(tmpl);
   PyBuffer_Release(&calls); PyBuffer_Release(&rn);
   return out;
 }
 
-/* apply_final(calls: list, records: buffer, lo, alt_pool: buffer, ps_names: list | None, filters: list[str], early_exit: frozenset) */
+/* apply_final(calls: list, records: buffer, lo, alt_pool: buffer, ps_names: list | None, filters: list[str], early_exit: frozenset,
+ *             finalize: bool = False)      finalize: also what SVCall.finalize() does (postprocess = None; sv.py:293-294) */
+static PyObject* small_int_str(int v) {      /* str(v), new reference; 0..9 without the format machinery */
+  if (v >= 0 && v <= 9) { PyObject* s = PyUnicode_New(1, 127); if (s) PyUnicode_1BYTE_DATA(s)[0] = (Py_UCS1)('0' + v); return s; }
+  return PyUnicode_FromFormat("%d", v);
+}
 static PyObject* py_apply_final(PyObject* self, PyObject* args) {
   PyObject *lst, *ps_names, *filters, *early;
   Py_buffer rec, pool;
-  long long lo;
-  if (!PyArg_ParseTuple(args, "Oy*Ly*OOO", &lst, &rec, &lo, &pool, &ps_names, &filters, &early)) return NULL;
+  long long lo; int fin = 0;
+  if (!PyArg_ParseTuple(args, "Oy*Ly*OOO|p", &lst, &rec, &lo, &pool, &ps_names, &filters, &early, &fin)) return NULL;
   PyObject* ret = NULL;
   const Py_ssize_t n = PyList_Size(lst);
   if (n < 0 || lo < 0 || (size_t)(lo + n) * sizeof(snf_call_t) > (size_t)rec.len) { PyErr_SetString(PyExc_ValueError, "calls do not match the record table"); goto done; }
@@ -205,25 +240,49 @@ static PyObject* py_apply_final(PyObject* self, PyObject* args) {
     PyObject* gts = PyDict_GetItemWithError(d, K_genotypes);
     if (!info || !gts) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "call without info / genotypes"); goto done; }
     if (PyDict_SetItem(d, K_qc, c->qc ? Py_True : Py_False) || PyDict_SetItem(d, K_filter, flt)) goto done;
+    if (fin && PyDict_SetItem(d, K_postprocess, Py_None)) goto done;
     int ee = PySet_Contains(early, flt);
     if (ee < 0) goto done;
     if (!ee && PyDict_SetItem(info, I_COVERAGE_VAR, Py_None)) goto done;     /* see sv.fill_final */
     if (c->ph_set) {
+      /* f"{hp},{ps},{hp_support},{ps_support},{hp_filter},{ps_filter}" (postprocessing.py:651) - every call carries one: written by hand
+       * when the phase-set name is ASCII (PyUnicode_FromFormat takes ~0.5 us a call) */
       PyObject* ps = ps_str(c->ph_ps, ps_names);
       if (!ps) goto done;
-      PyObject* s = PyUnicode_FromFormat("%d,%S,%d,%d,%s,%s", (int)c->ph_hp, ps, (int)c->ph_hp_support, (int)c->ph_ps_support,
-                                         c->ph_hp_pass ? "PASS" : "FAIL", c->ph_ps_pass ? "PASS" : "FAIL");
+      PyObject* s = NULL;
+      const char* pu = NULL; Py_ssize_t pl = 0;
+      if (ps == Py_None) { pu = "None"; pl = 4; }
+      else if (PyUnicode_Check(ps) && PyUnicode_IS_COMPACT_ASCII(ps)) pu = PyUnicode_AsUTF8AndSize(ps, &pl);
+      if (pu && pl <= 160) {
+        char buf[256]; char* w = raw_ll(buf, (int)c->ph_hp);
+        *w++ = ','; memcpy(w, pu, (size_t)pl); w += pl; *w++ = ',';
+        w = raw_ll(w, (int)c->ph_hp_support); *w++ = ','; w = raw_ll(w, (int)c->ph_ps_support);
+        memcpy(w, c->ph_hp_pass ? ",PASS" : ",FAIL", 5); w += 5; memcpy(w, c->ph_ps_pass ? ",PASS" : ",FAIL", 5); w += 5;
+        s = PyUnicode_New(w - buf, 127);
+        if (s) memcpy(PyUnicode_1BYTE_DATA(s), buf, (size_t)(w - buf));
+      } else {
+        PyErr_Clear();
+        s = PyUnicode_FromFormat("%d,%S,%d,%d,%s,%s", (int)c->ph_hp, ps, (int)c->ph_hp_support, (int)c->ph_ps_support,
+                                 c->ph_hp_pass ? "PASS" : "FAIL", c->ph_ps_pass ? "PASS" : "FAIL");
+      }
       Py_DECREF(ps);
       if (set_steal(info, I_PHASE, s)) goto done;
     }
     if (c->gt_set) {
-      PyObject* hp = c->gt_hp < 0 ? (Py_INCREF(Py_None), Py_None) : PyUnicode_FromFormat("%d", (int)c->gt_hp);
+      PyObject* hp = c->gt_hp < 0 ? (Py_INCREF(Py_None), Py_None) : small_int_str((int)c->gt_hp);
       PyObject* ps = ps_str(c->gt_ps, ps_names);
-      PyObject* t = (hp && ps) ? Py_BuildValue("(iiiii(OO))", (int)c->gt_a, (int)c->gt_b, (int)c->gt_gq, (int)c->gt_dr, (int)c->gt_dv, hp, ps) : NULL;
-      Py_XDECREF(hp); Py_XDECREF(ps);
-      PyObject* zero = PyLong_FromLong(0);
-      int bad = !t || !zero || PyDict_SetItem(gts, zero, t);
-      Py_XDECREF(t); Py_XDECREF(zero);
+      /* (a, b, gq, dr, dv, (hp, ps)) built by hand: Py_BuildValue parses its format string for every call */
+      PyObject* t = (hp && ps) ? PyTuple_New(6) : NULL; PyObject* ph = t ? PyTuple_New(2) : NULL;
+      int bad = !t || !ph;
+      if (!bad) {
+        PyTuple_SET_ITEM(ph, 0, hp); PyTuple_SET_ITEM(ph, 1, ps); hp = ps = NULL;
+        const int v5[5] = {(int)c->gt_a, (int)c->gt_b, (int)c->gt_gq, (int)c->gt_dr, (int)c->gt_dv};
+        for (int q = 0; q < 5 && !bad; q++) { PyObject* x = PyLong_FromLong(v5[q]); if (!x) bad = 1; else PyTuple_SET_ITEM(t, q, x); }
+        PyTuple_SET_ITEM(t, 5, ph); ph = NULL;
+      }
+      Py_XDECREF(hp); Py_XDECREF(ps); Py_XDECREF(ph);
+      bad = bad || PyDict_SetItem(gts, O_zero, t);
+      Py_XDECREF(t);
       if (bad || set_steal(info, I_VAF, PyFloat_FromDouble(c->vaf))) goto done;
     }
     if (c->alt_len >= 0) {
@@ -245,7 +304,6 @@ done:
  * group_calls():   snf_group_out_t records + membership -> the combined SVCall objects of SVGroup.call (sv.py:419-481)
  * None of this is arithmetic of the hot path: attribute reads, string joins, dict fills.
  * ====================================================================================================================== */
-static PyObject *S_dot, *S_comma, *O_zero, *T_none2, *I_COVERAGE;
 
 static PyObject* aget(PyObject* obj, PyObject* key) {   /* new reference; instance dict first */
   PyObject** dp = _PyObject_GetDictPtr(obj);
@@ -569,15 +627,6 @@ static inline int ob_ull(OutBuf* b, unsigned long long u, int neg) {     /* deci
   return 0;
 }
 static inline int ob_ll(OutBuf* b, long long v) { return ob_ull(b, v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v, v < 0); }
-/* raw writers: the caller has reserved the room (ob_room), `w` runs through it */
-static inline char* raw_ll(char* w, long long v) {
-  char t[24]; int n = 24;
-  unsigned long long u = v < 0 ? 0ull - (unsigned long long)v : (unsigned long long)v;
-  do { t[--n] = (char)('0' + u % 10); u /= 10; } while (u);
-  if (v < 0) t[--n] = '-';
-  memcpy(w, t + n, (size_t)(24 - n));
-  return w + (24 - n);
-}
 static int ob_hex(OutBuf* b, unsigned long long u) {     /* "%llX" */
   char t[16]; int n = 16;
   do { t[--n] = "0123456789ABCDEF"[u & 15]; u >>= 4; } while (u);

@@ -150,13 +150,9 @@ class Task:
             if int(c.pos) != int(res.calls["pos"][i]) or int(c.svlen) != int(res.calls["svlen"][i]):
                 raise RuntimeError(f"candidate {i} is not the call the batch holds at that place (pass the list call_candidates "
                                    "returned, unchanged and in its order)")
-        sv.apply_final(candidates, res, self._ti)
-        passed = []
-        for c in candidates:
-            c.finalize()
-            passed.append(c)
+        sv.apply_final(candidates, res, self._ti, finalize=True)      # (with `c.finalize()` for every call, parallel.py:199-200)
         self._finalized = True
-        return passed
+        return list(candidates)
 
 
 class CallTask(Task):
@@ -177,9 +173,7 @@ class CallTask(Task):
         order as `call_svs()` (tests/test_dropin_api.py); `self.sv_id` advances by the number of candidates like there."""
         res, ti = self.call_records(config, execute=True)
         calls = sv.materialize_candidates(res, ti, 0, len(res.calls), svcall_cls, bnd_cls)
-        sv.apply_final(calls, res, ti)
-        for c in calls:
-            c.finalize()
+        sv.apply_final(calls, res, ti, finalize=True)
         return calls
 
     def write_snf_part(self, svcandidates, snf_filename: str):

@@ -297,16 +297,23 @@ def materialize_candidates_py(res: Result, ti, lo: int, hi: int, svcall_cls=SVCa
     return out
 
 
-def apply_final(calls: list, res: Result, ti, lo: int = 0) -> None:
-    """`fill_final(call, res, lo + k, ti)` for every call of the list."""
+def apply_final(calls: list, res: Result, ti, lo: int = 0, finalize: bool = False) -> None:
+    """`fill_final(call, res, lo + k, ti)` for every call of the list.  `finalize`: followed by `call.finalize()` (the reference's
+    `Task.finalize_candidates` ends with it, parallel.py:199-200) - in the same pass over the calls when their class keeps
+    `SVCall.finalize` (postprocess = None), by calling the method otherwise."""
     import numpy as np
     fast = _load_fast()
+    plain = finalize and all(getattr(type(c), "finalize", None) is SVCall.finalize for c in calls[:1] + calls[-1:])
     if fast is not None and (ti.ps_names is None or isinstance(ti.ps_names, list)):
         with no_gc():
             fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
-                             _QC_SV_EARLY_EXIT)
-        return
-    apply_final_py(calls, res, ti, lo)
+                             _QC_SV_EARLY_EXIT, plain)
+    else:
+        apply_final_py(calls, res, ti, lo)
+        plain = False
+    if finalize and not plain:
+        for c in calls:
+            c.finalize()
 
 
 def apply_final_py(calls: list, res: Result, ti, lo: int = 0) -> None:

@@ -309,7 +309,14 @@ class VCF:
         order `sorted(calls, key=pos)` gives the objects (stable), or as they are.  Returns the number of lines written."""
         import numpy as np
         text, off, pos = part
-        order = np.argsort(pos, kind="stable") if sort else np.arange(len(pos))
+        if len(pos) == 0:
+            return 0
+        if not sort or bool((pos[1:] >= pos[:-1]).all()):      # in order already (candstore formats them so): one slice
+            n = int(np.count_nonzero(off[1:] > off[:-1]))
+            self.handle.write(str(memoryview(text)[int(off[0]):int(off[-1])], "utf-8"))
+            self.call_count += n
+            return n
+        order = np.argsort(pos, kind="stable")
         n = 0
         out = []
         for k in order.tolist():

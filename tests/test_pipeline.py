@@ -220,6 +220,22 @@ def run_population(name, tmp_path, _lib):
         assert pipeline.combine(paths, cfg, vcf_handle=without, objects=False) == []
         assert without.getvalue() == with_objects.getvalue(), extra
         assert without.getvalue().count("\n") > 50
+    # the merge in runs of contig tasks that overlap host and device work (candstore.execute_many; the default of a big merge): same text,
+    # same objects
+    import os
+    from sniffles_amd import candstore
+    try:
+        for k in ("2", "3"):
+            os.environ["SNF_COMBINE_CHUNKS"] = k
+            in_runs, in_runs_objects = io.StringIO(), io.StringIO()
+            assert pipeline.combine(paths, config_for(args), vcf_handle=in_runs, objects=False) == []
+            n_runs = candstore.last_timing.get("chunks", 1)
+            assert in_runs.getvalue() == buf.getvalue()
+            calls_runs = pipeline.combine(paths, config_for(args), vcf_handle=in_runs_objects)
+            assert in_runs_objects.getvalue() == buf.getvalue() and len(calls_runs) == len(calls)
+    finally:
+        os.environ.pop("SNF_COMBINE_CHUNKS", None)
+    return n_runs
 
 
 @pytest.mark.parametrize("name", sorted(cases.POPULATIONS))
@@ -228,7 +244,7 @@ def test_bams_to_merged_vcf_emu(name, tmp_path):
     (this package) - the merged VCF equals the one the unmodified reference produces from the same BAMs through its own
     .snf files, character by character."""
     import emu.emu as E
-    run_population(name, tmp_path, E.lib())
+    assert run_population(name, tmp_path, E.lib()) == (2 if name == "population_4samples_12x" else 1)      # (two contig tasks / one)
 
 
 def test_tandem_repeat_file_loader(tmp_path):
