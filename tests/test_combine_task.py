@@ -340,3 +340,30 @@ def test_cached_reader_columns_equal_the_block_walk_emu(monkeypatch):
         cached = merge(readers, extra, split, False)          # the SAME readers throughout: tables cached by (contig, sample, threshold)
         assert cached == walk and sum(len(p) for p in cached) > 0, (extra, split)
     assert len(readers[0].__dict__["_snf_columns"]) == 2       # two thresholds -> two tables; the part tasks reused the first
+
+
+def test_merge_in_runs_of_tasks_equals_one_launch_emu(monkeypatch):
+    """`candstore.execute_many` cuts a big merge into runs of contig tasks that two threads work on in turn (host work of one run under
+    the GPU call of the other; `SNF_COMBINE_CHUNKS`): tasks share nothing, so the calls - objects, ids, order - are those of the one
+    launch for all tasks."""
+    import emu.emu as E
+    from sniffles_amd import candstore
+    E.lib()
+    name = "combine_task_5samples_medians"
+    doc = gu.load(name)
+    exp = doc["expected"]
+
+    def merge(chunks):
+        monkeypatch.setenv("SNF_COMBINE_CHUNKS", str(chunks))
+        cfg = _twin_cfg(doc, ())
+        bs = cfg.snf_block_size
+        cuts = [0] + [exp["contig_len"] * k // 3 // bs * bs for k in (1, 2)] + [exp["contig_len"] + bs]
+        tasks = [parallel.CombineTask(id=5 + 2 * k, sv_id=k, contig=exp["contig"], start=cuts[k], end=cuts[k + 1] - bs, config=cfg) for k in range(3)]
+        readers = {s: BlocksReader(exp["contig"], exp["samples"][s]) for s in range(exp["n_samples"])}
+        out = [[_object_fields(c) for c in part] for part in parallel.CombineTask.execute_many(tasks, readers)]
+        return out, candstore.last_timing.get("chunks", 1)
+    whole, n1 = merge(1)
+    assert n1 == 1 and sum(len(p) for p in whole) > 0 and len(whole) == 3
+    for k in (2, 3):
+        runs, nk = merge(k)
+        assert 1 < nk <= k and runs == whole, k
