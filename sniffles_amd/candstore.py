@@ -372,7 +372,7 @@ def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
 # A merge of at least this many blocks x samples is cut into runs of tasks that overlap host work and GPU work (`execute_many`);
 # SNF_COMBINE_CHUNKS=k sets the number of runs (1: one launch for all tasks, as before)
 CHUNK_MIN_WORK = 40000
-CHUNKS = 4
+CHUNKS = 1      # (measured, 10 samples x 24 contigs: 156 ms in one launch, 181 / 216 / 261 ms in 2 / 3 / 4 runs - see DESIGN.md section 7)
 
 
 def _task_chunks(tasks, samples_snf) -> list:
@@ -506,6 +506,8 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
     keep = []
     mark("sort_and_windows")
     n_ids = int(rec["sample"].max()) + 1
+    # (the launch works a sub-chain per wave and lasts as long as its slowest one - a window of kilobase insertions, ~60 ms - whatever the
+    # order of the problems: putting the heaviest first changed nothing, 67.6 against 68.0 ms, profiles/r05_merge_runs.log)
     arr, out = abi.combine_chain_problems(codes, win_off[s_lo], win_off[s_hi], s_lo, s_hi, cols, (aoff, apool), win_off, win_bin,
                                           win_thr, n_ids, keep)
     lib.combine_resolve_batch(config, arr, device=device)

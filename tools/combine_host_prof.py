@@ -4,8 +4,11 @@ built through the test tier's host emulation (tests/emu), the group assignment (
 its output is replayed for the timed passes - what is measured is everything around that call (column assembly, sort and flush
 windows, membership, emission order, the text of the merged records), which is host code and the same on any box.
 Development tool: prints the phases of `candstore.last_timing`; with `--cprofile` the Python-level profile of one pass.
+`--gpu`: on a box with a GPU - the library itself, nothing replayed: the merge as bench.py --config 4 times it, for every number of
+runs of tasks in `--chunks` (SNF_COMBINE_CHUNKS) on ONE population.
 
-    python tools/combine_host_prof.py [--scale 0.2] [--samples 10] [--passes 5] [--cprofile]"""
+    python tools/combine_host_prof.py [--scale 0.2] [--samples 10] [--passes 5] [--cprofile]
+    python tools/combine_host_prof.py --gpu --scale 1.0 --chunks 1,2,3,4,6"""
 import argparse
 import ctypes
 import io
@@ -15,10 +18,11 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SNF_BENCH_EMU"] = "1"
-from tools.bench_common import emu_lib  # noqa: E402
-
-emu_lib()
+GPU = "--gpu" in sys.argv
+if not GPU:
+    os.environ["SNF_BENCH_EMU"] = "1"
+    from tools.bench_common import emu_lib  # noqa: E402
+    emu_lib()
 import numpy as np  # noqa: E402
 
 from sniffles_amd import candstore, lib, parallel, synth, vcf  # noqa: E402
@@ -33,6 +37,8 @@ def main():
     ap.add_argument("--coverage", type=float, default=15.0)
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--cprofile", action="store_true")
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--chunks", default=None, help="comma-separated SNF_COMBINE_CHUNKS values to time one after the other")
     ap.add_argument("--cache", default=None, help="pickle of the emulated population and group assignment (built when absent)")
     a = ap.parse_args()
     contigs = [(ci, c, max(200000, int(synth.GRCH38[c] * a.scale))) for ci, c in enumerate(synth.CONTIGS)]
@@ -63,7 +69,7 @@ def main():
 
     def replayed(config, problems, device=0):
         n = sum(int(p.n_cands) for p in problems)
-        out = ctypes.cast(problems[0].out_group, ctypes.POINTER(ctypes.c_int32))
+        out = ctypes.cast(min(ctypes.cast(p.out_group, ctypes.c_void_p).value for p in problems), ctypes.POINTER(ctypes.c_int32))      # (the problems come in any order)
         if n not in saved:
             t = time.time()
             real_call(config, problems, device=device)
@@ -71,7 +77,8 @@ def main():
             print(f"group assignment of {n} candidates emulated once in {time.time() - t:.1f} s; replayed from here on", flush=True)
         else:
             ctypes.memmove(out, saved[n].ctypes.data, 4 * n)
-    lib.combine_resolve_batch = replayed
+    if not GPU:
+        lib.combine_resolve_batch = replayed
 
     text = [None]
 
@@ -93,17 +100,23 @@ def main():
         one_pass()
     import hashlib
     print("text sha1", hashlib.sha1(first.encode()).hexdigest(), flush=True)
-    best = None
-    for k in range(a.passes):
-        t = time.perf_counter()
-        n = one_pass()
-        dt = (time.perf_counter() - t) * 1e3
-        ph = {k_: (round(v * 1e3, 2) if isinstance(v, float) else v) for k_, v in candstore.last_timing.items()}
-        host = dt - ph.get("resolve_groups_gpu", 0.0)
-        print(f"pass {k}: {dt:.1f} ms, without the replayed call {host:.1f} ms, {n} records, text {len(text[0])} B  {ph}", flush=True)
-        best = host if best is None else min(best, host)
-    assert text[0] == first
-    print(f"best host time around the call: {best:.1f} ms")
+    for chunks in (a.chunks.split(",") if a.chunks else [None]):
+        if chunks is not None:
+            os.environ["SNF_COMBINE_CHUNKS"] = chunks
+            one_pass()
+        best, best_all = None, None
+        for k in range(a.passes):
+            t = time.perf_counter()
+            n = one_pass()
+            dt = (time.perf_counter() - t) * 1e3
+            ph = {k_: (round(v * 1e3, 2) if isinstance(v, float) else v) for k_, v in candstore.last_timing.items()}
+            host = dt - ph.get("resolve_groups_gpu", 0.0)
+            print(f"chunks {chunks} pass {k}: {dt:.1f} ms" + ("" if GPU else f", without the replayed call {host:.1f} ms") +
+                  f", {n} records, text {len(text[0])} B  {ph}", flush=True)
+            best = host if best is None else min(best, host)
+            best_all = dt if best_all is None else min(best_all, dt)
+        assert text[0] == first
+        print(f"chunks {chunks}: best pass {best_all:.1f} ms" + ("" if GPU else f", best host time around the call {best:.1f} ms"), flush=True)
     if a.cprofile:
         import cProfile
         import pstats

@@ -180,5 +180,18 @@ for i in 1 2; do
 for q in 2 3 4 5 6; do GPU_MAX_HW_QUEUES=$q python bench.py --gpus 1 $Q 2>/dev/null | show "plain, $q hardware queues"; done
 done
 ;;
-*) echo "usage: bash tools/r05_sessions.sh 1..15"; exit 2 ;;
+16)
+# round 5, sixteenth GPU session: the host side of the population merge after its rework (records from arrays, whole-table assembly, one
+# sort key, runs of tasks on two threads) over the number of runs; the per-task legs after the object materialiser's rework; the GPU
+# tests the two touch
+timeout 600 python tools/combine_host_prof.py --gpu --scale 1.0 --passes 4 --chunks 1,2,3,4,6,8 2>&1 | grep -v "^chunks [0-9]* pass [0-2]" | cut -c1-600 | tee gpurun_out/r05_merge_runs.log
+( time timeout 900 python bench.py --config 4 --no-cpu-baseline --no-reference-baseline > gpurun_out/bench_config4_16.json 2> gpurun_out/bench_config4_16.err ) 2>&1 | grep real
+python -c "
+import json; d=json.loads(open('gpurun_out/bench_config4_16.json').read().strip().splitlines()[-1]); print('config 4 ms_per_step', d['ms_per_step'], d['config']['host_phases_ms'], 'text equal', d['config'].get('text_equals_object_path'), 'verified', d.get('verified'))"
+( time timeout 900 python bench.py --no-cpu-baseline --no-configs --no-verify --steps 20 --warmup 5 > gpurun_out/bench_wall_16.json 2> gpurun_out/bench_wall_16.err ) 2>&1 | grep real
+python -c "
+import json; d=json.loads(open('gpurun_out/bench_wall_16.json').read().strip().splitlines()[-1]); w=d['wall_clock']; print('ms_per_step', d['ms_per_step']); print(json.dumps({k: w[k] for k in w if k.startswith('per_task') or k in ('batched',)})[:3000])"
+timeout 900 python -m pytest tests/test_dropin_api.py tests/test_insitu_seam.py tests/test_combine_task.py tests/test_pipeline.py tests/test_reference_pool.py -m gpu -x -q 2>&1 | tail -3
+;;
+*) echo "usage: bash tools/r05_sessions.sh 1..16"; exit 2 ;;
 esac
