@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--cprofile", action="store_true")
     ap.add_argument("--gpu", action="store_true")
     ap.add_argument("--chunks", default=None, help="comma-separated SNF_COMBINE_CHUNKS values to time one after the other")
+    ap.add_argument("--sweep", default=None, help="environment settings to time one after the other on the one population, e.g. "
+                    "SNF_COMBINE_WAVES=8+SNF_COMBINE_HEAVY=1e7,SNF_COMBINE_WAVES=1 (the library reads them at every call)")
     ap.add_argument("--cache", default=None, help="pickle of the emulated population and group assignment (built when absent)")
     a = ap.parse_args()
     contigs = [(ci, c, max(200000, int(synth.GRCH38[c] * a.scale))) for ci, c in enumerate(synth.CONTIGS)]
@@ -100,9 +102,15 @@ def main():
         one_pass()
     import hashlib
     print("text sha1", hashlib.sha1(first.encode()).hexdigest(), flush=True)
-    for chunks in (a.chunks.split(",") if a.chunks else [None]):
+    settings = [("SNF_COMBINE_CHUNKS=" + c) for c in a.chunks.split(",")] if a.chunks else a.sweep.split(",") if a.sweep else [None]
+    touched = set()
+    for chunks in settings:
         if chunks is not None:
-            os.environ["SNF_COMBINE_CHUNKS"] = chunks
+            for name in touched:
+                os.environ.pop(name, None)
+            for kv in chunks.split("+"):
+                name, val = kv.split("=", 1)
+                os.environ[name] = val; touched.add(name)
             one_pass()
         best, best_all = None, None
         for k in range(a.passes):
