@@ -136,14 +136,13 @@ def reader_columns(reader, contig, sid, thr, fast):
     reader that re-reads its header starts afresh), is bounded (`COLUMNS_CACHE_CONTIGS`) and can be dropped with `clear_columns`.
     The cached candidates are SHARED between the merges that use them: `group_calls` writes the default genotype into
     `genotypes[0]` of candidates that lack one, which every later merge then sees (the value is the same for all of them)."""
-    import os
     if not hasattr(reader, "block_starts") or getattr(reader, "reqc", False):
         return None
-    with _COLUMNS_LOCK:      # (the chunks of a merge run on two threads: one builds or evicts at a time)
-        return _reader_columns_locked(reader, contig, sid, thr, fast, os)
+    with _COLUMNS_LOCK:      # (the runs of a merge may be on two threads, SNF_COMBINE_CHUNKS: one builds or evicts at a time)
+        return _reader_columns_locked(reader, contig, sid, thr, fast)
 
 
-def _reader_columns_locked(reader, contig, sid, thr, fast, os):
+def _reader_columns_locked(reader, contig, sid, thr, fast):
     cache = reader.__dict__.setdefault("_snf_columns", {})
     key = (contig, int(sid), int(thr), id(getattr(reader, "index", None)))
     if key in cache:
@@ -348,9 +347,11 @@ def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         chunks = _task_chunks(tasks, samples_snf)
         if len(chunks) == 1:
             return _execute_many(tasks, samples_snf, text_writer)
-        # tasks share nothing (a chain never leaves its contig task): the merge of a run of tasks is a merge of its own.  Two threads
-        # take the runs in turn - while one waits for the group assignment of its run on the GPU (the C-ABI call releases the
-        # interpreter lock; the library admits one such call per device at a time) the other sorts, cuts or formats its own
+        # SNF_COMBINE_CHUNKS=k (an experiment, off by default): tasks share nothing (a chain never leaves its contig task), so the merge
+        # of a run of tasks is a merge of its own.  Two threads take the runs in turn - while one waits for the group assignment of its
+        # run on the GPU (the C-ABI call releases the interpreter lock; the library admits one such call per device at a time) the
+        # other sorts, cuts or formats its own.  It loses: the launch lasts as long as its slowest sub-chain whatever the number of
+        # problems, so k runs pay that k times (10 samples x 24 contigs: 156 ms in one launch, 181 / 216 / 261 ms in 2 / 3 / 4 runs)
         from concurrent.futures import ThreadPoolExecutor
         t0 = time.perf_counter()
         timings = []
@@ -369,19 +370,10 @@ def execute_many(tasks: list, samples_snf: dict, text_writer=None) -> list:
         return [r for part in parts for r in part]
 
 
-# A merge of at least this many blocks x samples is cut into runs of tasks that overlap host work and GPU work (`execute_many`);
-# SNF_COMBINE_CHUNKS=k sets the number of runs (1: one launch for all tasks, as before)
-CHUNK_MIN_WORK = 40000
-CHUNKS = 1      # (measured, 10 samples x 24 contigs: 156 ms in one launch, 181 / 216 / 261 ms in 2 / 3 / 4 runs - see DESIGN.md section 7)
-
-
 def _task_chunks(tasks, samples_snf) -> list:
-    """`tasks` as consecutive runs of about equal numbers of blocks."""
-    k = os.environ.get("SNF_COMBINE_CHUNKS")
+    """`tasks` as SNF_COMBINE_CHUNKS (default 1) consecutive runs of about equal numbers of blocks."""
     weights = [max(1, len(t.block_indices)) for t in tasks]
-    if k is None:
-        k = CHUNKS if len(tasks) >= 2 * CHUNKS and sum(weights) * max(1, len(samples_snf)) >= CHUNK_MIN_WORK else 1
-    k = max(1, min(int(k), len(tasks)))
+    k = max(1, min(int(os.environ.get("SNF_COMBINE_CHUNKS", "1")), len(tasks)))
     if k == 1:
         return [list(tasks)]
     total, out, cur, acc = float(sum(weights)), [], [], 0.0
@@ -510,18 +502,35 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
     # order of the problems: putting the heaviest first changed nothing, 67.6 against 68.0 ms, profiles/r05_merge_runs.log)
     arr, out = abi.combine_chain_problems(codes, win_off[s_lo], win_off[s_hi], s_lo, s_hi, cols, (aoff, apool), win_off, win_bin,
                                           win_thr, n_ids, keep)
-    lib.combine_resolve_batch(config, arr, device=device)
+    # the call waits for the GPU with the interpreter lock released: what does not need its answer is computed meanwhile (the order
+    # in which SVGroup.add_candidate sees the candidates - window by window, support descending (stable) inside a window - the rank of the
+    # flush events, the ids of the sub-chains)
+    failure = []
+
+    def resolve():
+        try:
+            lib.combine_resolve_batch(config, arr, device=device)
+        except BaseException as e:      # noqa: BLE001 - raised again on the caller's thread
+            failure.append(e)
+    call = threading.Thread(target=resolve)
+    call.start()
+    try:
+        proc = np.argsort(cand_win.astype(np.int64) << 32 | (np.int64(1) << 31) - rec["support"].astype(np.int64), kind="stable")
+        cand_sub = np.repeat(np.arange(len(s_lo)), win_off[s_hi] - win_off[s_lo])
+        ev_rank = np.empty(nw, np.int64)
+        ev_rank[np.lexsort((np.arange(nw), w_typ, w_blk, w_task))] = np.arange(nw)
+    finally:
+        call.join()
+    if failure:
+        raise failure[0]
     mark("resolve_groups_gpu")
     # group numbers: sub-chain -> whole merge (creation order inside a chain is the order of the sub-chains)
     gid_local = out[:n].astype(np.int64)
-    cand_sub = np.repeat(np.arange(len(s_lo)), win_off[s_hi] - win_off[s_lo])
-    created = np.zeros(len(s_lo), np.int64)
-    np.maximum.at(created, cand_sub, gid_local + 1)
+    created = np.maximum.reduceat(gid_local + 1, win_off[s_lo])      # (a sub-chain's candidates are consecutive; none is empty)
     base = np.cumsum(created) - created
     gid = gid_local + base[cand_sub]
     n_groups = int(created.sum())
-    # ---- 4. members in the order SVGroup.add_candidate saw them: window by window, support descending (stable) inside a window
-    proc = np.lexsort((np.arange(n), -rec["support"].astype(np.int64), cand_win))
+    # ---- 4. members in the order SVGroup.add_candidate saw them (`proc`, above)
     member = proc[np.argsort(gid[proc], kind="stable")].astype(np.int32)
     counts = np.bincount(gid, minlength=n_groups)
     group_off = np.concatenate(([0], np.cumsum(counts))).astype(np.int64)
@@ -535,8 +544,6 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
     # SV type by SV type, window by window - in creation order; what is still active at the end leaves per SV type
     if getattr(config, "combine_consensus", False) and (gout["emit"] == 1).any():
         raise NotImplementedError("--combine-consensus is broken in the reference (sv.py:382 unpacks 7-tuples into 5)")
-    ev_rank = np.empty(nw, np.int64)
-    ev_rank[np.lexsort((np.arange(nw), w_typ, w_blk, w_task))] = np.arange(nw)
     g_task = w_task[g_first_win]
     g_typ = w_typ[g_first_win]
     flushed = gout["flush_win"] >= 0
