@@ -61,7 +61,9 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
         t_all0 = time.perf_counter()
         tasks = []
         for key, ti, lp in built:
-            t = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=None,
+            # (the object form carries the task's tandem-repeat regions as the reference's Task does; the column form has them inside)
+            trs = list(zip(ti.tr_start.tolist(), ti.tr_end.tolist())) if form == "leads" and ti.tr_start is not None else None
+            t = parallel.CallTask(id=ti.task_id, sv_id=0, contig=ti.contig, start=0, end=ti.contig_len, config=cfg, tandem_repeats=trs,
                                   device=device)
             t.lead_provider = lp
             tasks.append(t)
@@ -70,7 +72,8 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
         if form == "leads":      # the object walk alone, for the share (the timed loop below does it again inside the calls)
             t0 = time.perf_counter()
             for key, ti, lp in built:
-                lp.to_task_input(ti.task_id, 0, None, ti.qc_nm_threshold)
+                lp.to_task_input(ti.task_id, 0, None if ti.tr_start is None else list(zip(ti.tr_start.tolist(), ti.tr_end.tolist())),
+                                 ti.qc_nm_threshold)
             ingest_s = time.perf_counter() - t0
             t_all0 = time.perf_counter()
         n_out = 0
