@@ -53,7 +53,7 @@ def build_fast(force: bool = False) -> str:
     """The CPython extension that turns record tables into SVCall objects (csrc/snf_pyfast.c; host-side formatting only)."""
     import sysconfig
     so, src = fast_so(), os.path.join(CSRC, "snf_pyfast.c")
-    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I", sysconfig.get_paths()["include"], src, "-o", so]
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-pthread", "-I", sysconfig.get_paths()["include"], src, "-o", so]
     digest = _digest([src, HEADER], " ".join(cmd[:-3]))
     if force or _stale(so, digest):
         subprocess.run(cmd, check=True)

@@ -386,6 +386,15 @@ def _task_chunks(tasks, samples_snf) -> list:
     return out
 
 
+def _text_threads(n_records: int) -> int:
+    """Threads that format the merged records when they come from arrays alone (`_snf_fast.group_calls`, outside the interpreter
+    lock): SNF_TEXT_THREADS, else one per ~2 000 records up to eight and half the cores."""
+    env = os.environ.get("SNF_TEXT_THREADS")
+    if env is not None:
+        return max(1, int(env))
+    return max(1, min(8, (os.cpu_count() or 2) // 2, n_records // 2000))
+
+
 def _record_timing(timings, marks, **counts) -> None:
     """Phases of one `_execute_many`: into `last_timing`, or (a chunk of a merge) appended to `timings` for the caller to add up."""
     d = {name: t1 - t0 for (_, t0), (name, t1) in zip(marks[:-1], marks[1:])}
@@ -584,7 +593,8 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
                     ph_hp=id_cols[3], ph_ps_start=id_cols[4], ph_ps_len=id_cols[5])
         if covx.get("alt_ascii"):      # CHROM / ID / ALT of a record from arrays too: no candidate object is read
             topt.update(contigs=[t.contig for t in tasks], types=tuple(sv.TYPES), em_task=np.ascontiguousarray(g_task[em], np.int32),
-                        em_typ=np.ascontiguousarray(g_typ[em], np.int32), alt_off=np.ascontiguousarray(aoff, np.int64), alt_pool=apool)
+                        em_typ=np.ascontiguousarray(g_typ[em], np.int32), alt_off=np.ascontiguousarray(aoff, np.int64), alt_pool=apool,
+                        threads=_text_threads(len(em)))
     gc_covx = None if covx is None else {k: v for k, v in covx.items() if k not in ("ids", "alt_ascii")}
     calls = fast.group_calls(sv.SVCall, sv.ForwardDifferenceWelford, objs, np.ascontiguousarray(gout), np.ascontiguousarray(em, np.int64),
                              group_off, member, chosen, np.ascontiguousarray(sv_ids, np.int64), np.ascontiguousarray(task_ids, np.int64),

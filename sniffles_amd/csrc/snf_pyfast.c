@@ -9,6 +9,7 @@
  * (`materialize_candidates_py`, `apply_final_py`) that the tests compare it with.
  */
 #define PY_SSIZE_T_CLEAN
+#include <pthread.h>
 #include <Python.h>
 #include <math.h>
 #include <stdint.h>
@@ -694,6 +695,194 @@ static int ob_genotype(OutBuf* b, PyObject* a, PyObject* bb, PyObject* qual, PyO
   return OB_LIT(b, ":") || (id ? ob_obj(b, id) : 0);      /* (id NULL: the caller appends the chained ids itself) */
 }
 
+/* ---- merged records from arrays alone, on several threads ------------------------------------------------------------------------
+ * group_calls' text mode when every column is there (candidate columns, head columns, coverage vectors) and RNAMES are not printed:
+ * nothing of the record is a Python object, so the emitted groups are cut into consecutive ranges and formatted by one thread each,
+ * outside the interpreter lock, into buffers of their own (the caller joins them).  fmt_range is the loop body of py_group_calls for
+ * that case, statement for statement (vcf.py:216-300 over sv.py:386-481); tests/test_pipeline.py holds its text against the objects'. */
+typedef struct {
+  const snf_group_out_t* O; const int64_t* E; Py_ssize_t ne; const int64_t* GO; Py_ssize_t ng; const int32_t* M; Py_ssize_t nm; const uint8_t* CH;
+  const int64_t *SV, *TK; Py_ssize_t ns; const int32_t* SPOS; Py_ssize_t nspos; const int32_t* CS; Py_ssize_t nobj;
+  const int64_t* EVO; const int32_t *EVB, *EVN; Py_ssize_t nblk; long long null_min;
+  const snf_group_cand_t* REC; const char* idpool; Py_ssize_t idpool_len; const int64_t* ID_ST; const int32_t* ID_LN; const int8_t* PH_HP;
+  const int64_t* PS_ST; const int32_t* PS_LN;
+  const int32_t *EM_TASK, *EM_TYP; const int64_t* AOFF; const char* apool; Py_ssize_t apool_len;
+  const char** ctg; size_t* ctg_len; Py_ssize_t n_ctg; const char** typ; size_t* typ_len; Py_ssize_t n_typ;
+  const char* prefix; size_t prefix_len; const char* fmt; size_t fmt_len;
+  const int32_t** dn_ptr; const Py_ssize_t* dn_len; const int32_t* EBT; const int64_t* EBS; long long cvx_cb, cvx_bs;
+  int t_phase, t_symbolic, t_mosaic, t_nm; long long t_minsvlen;
+} FmtCtx;
+typedef struct { const FmtCtx* c; Py_ssize_t e0, e1; OutBuf tb; int64_t* off; const char* err; } FmtJob;      /* off: e1 - e0 + 1 offsets inside tb */
+
+static int ob_room_quiet(OutBuf* b, size_t extra) {      /* ob_room without the Python error (no interpreter lock here) */
+  if (b->n + extra <= b->cap) return 0;
+  size_t cap = b->cap ? b->cap : 1 << 16;
+  while (cap < b->n + extra) cap *= 2;
+  char* q = (char*)realloc(b->p, cap);
+  if (!q) return -1;
+  b->p = q; b->cap = cap;
+  return 0;
+}
+static inline int qb_put(OutBuf* b, const char* s, size_t n) {
+  if (__builtin_expect(b->n + n > b->cap, 0) && ob_room_quiet(b, n)) return -1;
+  memcpy(b->p + b->n, s, n); b->n += n; return 0;
+}
+#define QB_LIT(b, lit) qb_put((b), "" lit, sizeof(lit) - 1)
+static inline int qb_ll(OutBuf* b, long long v) { if (ob_room_quiet(b, 24)) return -1; b->n = (size_t)(raw_ll(b->p + b->n, v) - b->p); return 0; }
+static inline int qb_hex(OutBuf* b, unsigned long long u) { if (ob_room_quiet(b, 16)) return -1; b->n = (size_t)(raw_hex(b->p + b->n, u) - b->p); return 0; }
+static int qb_f3(OutBuf* b, double v) {      /* ob_f3 (the same conversion) into a quiet buffer */
+  OutBuf t = {NULL, 0, 0}; char tmp[400]; t.p = tmp; t.cap = sizeof tmp;      /* (352 characters at most: never grows) */
+  if (ob_f3(&t, v)) return -1;
+  return qb_put(b, tmp, t.n);
+}
+
+static void fmt_range(FmtJob* J) {
+  const FmtCtx* c = J->c; OutBuf* tb = &J->tb; const Py_ssize_t ns = c->ns;
+  OutBuf *scol = (OutBuf*)calloc((size_t)ns + 1, sizeof(OutBuf)), *idc = (OutBuf*)calloc((size_t)ns + 1, sizeof(OutBuf));
+  uint8_t* present = (uint8_t*)malloc((size_t)ns + 1);
+  int* head = NULL; Py_ssize_t cap = 0; Py_ssize_t* evx_row = NULL; long long* evx_idx = NULL; int64_t evx_cap = 0;
+#define FAIL(msg) do { J->err = (msg); goto out; } while (0)
+  if (!scol || !idc || !present) FAIL("out of memory");
+  J->off[0] = 0;
+  for (Py_ssize_t e = J->e0; e < J->e1; e++) {
+    const int64_t g = c->E[e];
+    if (g < 0 || g >= c->ng) FAIL("group index out of range");
+    const snf_group_out_t* o = &c->O[g];
+    const int64_t lo = c->GO[g], hi = c->GO[g + 1], n = hi - lo;
+    if (lo < 0 || hi > c->nm || n <= 0 || o->alt_member < lo || o->alt_member >= hi) FAIL("group range out of bounds");
+    if (n > cap) { free(head); cap = n + 16; head = (int*)malloc((size_t)cap * sizeof(int)); if (!head) FAIL("out of memory"); }
+    const int32_t* M = c->M;
+    for (int64_t k = 0; k < n; k++) if (M[lo + k] < 0 || M[lo + k] >= c->nobj) FAIL("member out of range");
+    long long t_ac = 0;
+    for (Py_ssize_t si = 0; si < ns; si++) { scol[si].n = 0; idc[si].n = 0; }
+    memset(present, 0, (size_t)ns);
+    /* ---- the chained ids of every sample in the group, in add order (sv.py:386-404) */
+    for (int64_t k = 0; k < n; k++) {
+      const long sidv = c->CS[M[lo + k]];
+      head[k] = (int)k;
+      for (int64_t j = 0; j < k; j++) { if (head[j] != j) continue; if (c->CS[M[lo + j]] == sidv) { head[k] = (int)j; break; } }
+      const Py_ssize_t sx = (sidv >= 0 && sidv < c->nspos) ? c->SPOS[sidv] : -1;
+      const int64_t is_ = c->ID_ST[M[lo + k]]; const int32_t il = c->ID_LN[M[lo + k]];
+      if (is_ < 0 || il < 0 || is_ + il > c->idpool_len) FAIL("id outside the pool");
+      if (sx >= 0 && sx < ns) {
+        if ((idc[sx].n && QB_LIT(&idc[sx], ",")) || qb_put(&idc[sx], c->prefix, c->prefix_len) || qb_put(&idc[sx], c->idpool + is_, (size_t)il)) FAIL("out of memory");
+        present[sx] = 1;
+      }
+    }
+    /* ---- the genotype column of every sample: from the record of the candidate that speaks for it */
+    for (int64_t k = 0; k < n; k++) {
+      if (head[k] != k) continue;
+      int64_t pick = -1;
+      for (int64_t j = k; j < n; j++) if (head[j] == k && c->CH[lo + j]) pick = j;
+      if (pick < 0) FAIL("no chosen genotype for a sample");
+      const snf_group_cand_t* r = &c->REC[M[lo + pick]];
+      const long sidv = c->CS[M[lo + k]];
+      const Py_ssize_t si = (sidv >= 0 && sidv < c->nspos) ? c->SPOS[sidv] : -1;
+      if (si < 0 || si >= ns) continue;
+      OutBuf* sc = &scol[si];
+      int ga = r->gt_a, gb_ = r->gt_b; char sep = '/';
+      const int8_t hp = c->PH_HP[M[lo + pick]];
+      if (c->t_phase && hp >= 0 && ((ga == 0 && gb_ == 1) || (ga == 1 && gb_ == 1))) { sep = '|'; if (hp == 1) { const int x = ga; ga = gb_; gb_ = x; } }   /* vcf.py:66-72 */
+      const int64_t ps0 = c->t_phase ? c->PS_ST[M[lo + pick]] : 0; const int32_t psl = c->t_phase ? c->PS_LN[M[lo + pick]] : -1;
+      if (c->t_phase && psl >= 0 && (ps0 < 0 || ps0 + psl > c->idpool_len)) FAIL("phase set outside the pool");
+      if (ob_room_quiet(sc, 160 + (size_t)(psl > 0 ? psl : 0) + idc[si].n)) FAIL("out of memory");
+      char* w = sc->p + sc->n;
+      if (ga < 0) *w++ = '.'; else w = raw_ll(w, ga);
+      *w++ = sep;
+      if (gb_ < 0) *w++ = '.'; else w = raw_ll(w, gb_);
+      *w++ = ':'; w = raw_ll(w, r->gq); *w++ = ':'; w = raw_ll(w, r->dr); *w++ = ':'; w = raw_ll(w, r->dv); *w++ = ':';
+      if (c->t_phase) { if (psl < 0) *w++ = '.'; else { memcpy(w, c->idpool + ps0, (size_t)psl); w += psl; } *w++ = ':'; }
+      memcpy(w, idc[si].p, idc[si].n); w += idc[si].n;
+      sc->n = (size_t)(w - sc->p);
+      if (r->gt_a >= 0 && r->dv > 0) { t_ac += (long long)r->gt_a + r->gt_b; present[si] = 2; }
+    }
+    /* ---- samples without a candidate in the group (sv.py:405-414): the deepest coverage bin the group saw while it was active */
+    const int64_t nev = c->EVO[e + 1] - c->EVO[e];
+    if (nev > evx_cap) {
+      free(evx_row); free(evx_idx);
+      evx_cap = nev + 16; evx_row = (Py_ssize_t*)malloc((size_t)evx_cap * sizeof(Py_ssize_t)); evx_idx = (long long*)malloc((size_t)evx_cap * sizeof(long long));
+      if (!evx_row || !evx_idx) FAIL("out of memory");
+    }
+    for (int64_t q = c->EVO[e]; q < c->EVO[e + 1]; q++) {
+      if (c->EVB[q] < 0 || c->EVB[q] >= c->nblk) FAIL("block index out of range");
+      const long long key = c->EVN[q], bstart = c->EBS[c->EVB[q]];
+      evx_row[q - c->EVO[e]] = (Py_ssize_t)c->EBT[c->EVB[q]] * ns;
+      evx_idx[q - c->EVO[e]] = (key >= bstart && key < bstart + c->cvx_bs && key % c->cvx_cb == 0) ? key / c->cvx_cb : -1;
+    }
+    for (Py_ssize_t si = 0; si < ns; si++) {
+      if (present[si]) continue;
+      long cov = 0; int firstev = 1;
+      for (int64_t q = 0; q < nev; q++) {
+        long cv = 0;
+        const int32_t* dv_ = c->dn_ptr[evx_row[q] + si];
+        if (dv_ && evx_idx[q] >= 0 && evx_idx[q] < c->dn_len[evx_row[q] + si]) { const int32_t x = dv_[evx_idx[q]]; if (x >= 0) cv = x; }
+        cov = firstev ? cv : (cv > cov ? cv : cov);
+        firstev = 0;
+      }
+      if (ob_room_quiet(&scol[si], 64)) FAIL("out of memory");
+      char* w = scol[si].p + scol[si].n;
+      memcpy(w, cov >= c->null_min ? "0/0:0:" : "./.:0:", 6); w = raw_ll(w + 6, cov);
+      if (c->t_phase) { memcpy(w, ":0:.:NULL", 9); w += 9; } else { memcpy(w, ":0:NULL", 7); w += 7; }
+      scol[si].n = (size_t)(w - scol[si].p);
+    }
+    /* ---- the record (vcf.py:216-300 write_call over the call of sv.py:440-481) */
+    {
+      const int32_t tk = c->EM_TASK[e], ty = c->EM_TYP[e];
+      const int64_t a0 = c->AOFF[M[o->alt_member]], a1 = c->AOFF[M[o->alt_member] + 1];
+      if (tk < 0 || tk >= c->n_ctg || ty < 0 || ty >= c->n_typ || a0 < 0 || a1 < a0 || a1 > c->apool_len) FAIL("head column out of range");
+      const char* tname = c->typ[ty]; const size_t tlen = c->typ_len[ty];
+      const char* altp = c->apool + a0; const Py_ssize_t alen = (Py_ssize_t)(a1 - a0);
+      int skip = 0, any = 0;
+      for (Py_ssize_t si = 0; si < ns; si++) any |= present[si] == 2;
+      if (ns > 1 && !any) skip = 1;                        /* int(supp_vec) == 0 (vcf.py:246-247) */
+      if (!skip) {
+        const int bnd = strcmp(tname, "BND") == 0, ins = strcmp(tname, "INS") == 0, del = strcmp(tname, "DEL") == 0;
+        long long svlen = o->svlen;
+        if (ins && !c->t_symbolic && svlen != alen && !(alen == 5 && memcmp(altp, "<INS>", 5) == 0)) svlen = alen;   /* vcf.py:253-254 */
+        if (ins && svlen < c->t_minsvlen) skip = 1;
+        if (!skip) {
+          const long long pos = o->pos > 0 ? o->pos : 1;
+          const long long end = (o->precise && del) ? pos + (svlen < 0 ? -svlen : svlen) : o->end;
+          int bad = qb_put(tb, c->ctg[tk], c->ctg_len[tk]) || QB_LIT(tb, "\t") || qb_ll(tb, pos) || QB_LIT(tb, "\t") || qb_put(tb, c->prefix, c->prefix_len) ||
+                    qb_put(tb, tname, tlen < 40 ? tlen : 40) || QB_LIT(tb, ".") || qb_hex(tb, (unsigned long long)c->SV[e]) || QB_LIT(tb, "M") ||
+                    qb_hex(tb, (unsigned long long)c->TK[e]) || QB_LIT(tb, "\tN\t");
+          if (!bad) bad = (c->t_symbolic && !bnd) ? (QB_LIT(tb, "<") || qb_put(tb, tname, tlen) || QB_LIT(tb, ">")) : qb_put(tb, altp, (size_t)alen);
+          if (!bad) {
+            if (o->qual == SNF_NONE_I32) bad = QB_LIT(tb, "\t.");
+            else { const long long q = o->qual < 0 ? 0 : o->qual > 60 ? 60 : o->qual; bad = QB_LIT(tb, "\t") || qb_ll(tb, q); }
+          }
+          if (!bad) bad = ((ns > 1 && t_ac == 0) ? QB_LIT(tb, "\tGT\t") : QB_LIT(tb, "\tPASS\t")) || (o->precise ? QB_LIT(tb, "PRECISE") : QB_LIT(tb, "IMPRECISE")) ||
+                          (c->t_mosaic && QB_LIT(tb, ";MOSAIC")) || QB_LIT(tb, ";SVTYPE=") || qb_put(tb, tname, tlen);
+          if (!bad && !bnd) bad = QB_LIT(tb, ";SVLEN=") || qb_ll(tb, svlen) || QB_LIT(tb, ";END=") || qb_ll(tb, end);
+          if (!bad) bad = QB_LIT(tb, ";SUPPORT=") || qb_ll(tb, o->support) || QB_LIT(tb, ";COVERAGE=");
+          for (int q = 0; !bad && q < 5; q++) {
+            bad = q && QB_LIT(tb, ",");
+            if (!bad) bad = o->cov[q] == SNF_NONE_I32 ? QB_LIT(tb, "None") : qb_ll(tb, o->cov[q]);
+          }
+          if (!bad) bad = QB_LIT(tb, ";STRAND=") || (o->fwd > 0 && QB_LIT(tb, "+")) || (o->rev > 0 && QB_LIT(tb, "-")) || (c->t_nm && QB_LIT(tb, ";NM=-1"));
+          if (!bad && ns > 1) bad = QB_LIT(tb, ";AC=") || qb_ll(tb, t_ac);      /* call.info, sorted: AC, STDEV_LEN, STDEV_POS, SUPP_VEC */
+          if (!bad) {
+            if (o->n < 2) bad = QB_LIT(tb, ";STDEV_LEN=0;STDEV_POS=0");
+            else bad = QB_LIT(tb, ";STDEV_LEN=") || qb_f3(tb, o->stdev_len) || QB_LIT(tb, ";STDEV_POS=") || qb_f3(tb, o->stdev_pos);
+          }
+          if (!bad && ns > 1) { bad = QB_LIT(tb, ";SUPP_VEC="); for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = qb_put(tb, present[si] == 2 ? "1" : "0", 1); }
+          if (!bad) bad = QB_LIT(tb, "\t") || qb_put(tb, c->fmt, c->fmt_len);
+          for (Py_ssize_t si = 0; !bad && si < ns; si++) bad = QB_LIT(tb, "\t") || qb_put(tb, scol[si].p, scol[si].n);
+          if (!bad) bad = QB_LIT(tb, "\n");
+          if (bad) FAIL("out of memory");
+        }
+      }
+    }
+    J->off[e - J->e0 + 1] = (int64_t)tb->n;
+  }
+out:
+#undef FAIL
+  if (scol) { for (Py_ssize_t si = 0; si < ns; si++) free(scol[si].p); free(scol); }
+  if (idc) { for (Py_ssize_t si = 0; si < ns; si++) free(idc[si].p); free(idc); }
+  free(present); free(head); free(evx_row); free(evx_idx);
+}
+static void* fmt_thread(void* arg) { fmt_range((FmtJob*)arg); return NULL; }
+
 static PyObject* py_group_calls(PyObject* self, PyObject* args) {
   PyObject *cls, *fds_cls, *objs, *block_cov, *prefix, *topt = Py_None, *covx = Py_None;
   Py_buffer ob, eb, gb, mb, cb, svb, tkb, sidb, sposb, evo, evb, evn, csb;
@@ -810,6 +999,81 @@ static PyObject* py_group_calls(PyObject* self, PyObject* args) {
       }
     }
     for (Py_ssize_t q = 0; q < nblk; q++) if (EBT[q] < 0 || EBT[q] >= dn_tasks) { PyErr_SetString(PyExc_ValueError, "group_calls: block task out of range"); goto done; }
+  }
+  if (text && fast_cols && head_cols && have_covx && !t_rnames) {
+    /* every column is there and no RNAMES: the records from arrays alone, by `threads` threads outside the interpreter lock (fmt_range) */
+    FmtCtx c; memset(&c, 0, sizeof c);
+    FmtJob* jobs = NULL; pthread_t* tids = NULL; int64_t* all_off = NULL; int64_t* all_pos = NULL; int failed = 0;
+    PyObject* thr_o = PyDict_GetItemString(topt, "threads");
+    long nthr = thr_o ? PyLong_AsLong(thr_o) : 1;
+    if (PyErr_Occurred()) goto done;
+    if (nthr < 1) nthr = 1;
+    if (nthr > 64) nthr = 64;
+    if (nthr > ne / 64 + 1) nthr = (long)(ne / 64 + 1);
+    c.n_ctg = PyList_GET_SIZE(hd_contigs); c.n_typ = PyTuple_GET_SIZE(hd_types);
+    c.ctg = (const char**)calloc((size_t)c.n_ctg + 1, sizeof(char*)); c.ctg_len = (size_t*)calloc((size_t)c.n_ctg + 1, sizeof(size_t));
+    c.typ = (const char**)calloc((size_t)c.n_typ + 1, sizeof(char*)); c.typ_len = (size_t*)calloc((size_t)c.n_typ + 1, sizeof(size_t));
+    jobs = (FmtJob*)calloc((size_t)nthr, sizeof(FmtJob)); tids = (pthread_t*)calloc((size_t)nthr, sizeof(pthread_t));
+    all_off = (int64_t*)calloc((size_t)ne + 1, 8); all_pos = (int64_t*)calloc((size_t)ne + 1, 8);
+    if (!c.ctg || !c.ctg_len || !c.typ || !c.typ_len || !jobs || !tids || !all_off || !all_pos) { PyErr_NoMemory(); failed = 1; }
+    for (Py_ssize_t k = 0; !failed && k < c.n_ctg + c.n_typ; k++) {      /* the strings of the head as UTF-8, taken while the lock is held */
+      PyObject* u = k < c.n_ctg ? PyList_GET_ITEM(hd_contigs, k) : PyTuple_GET_ITEM(hd_types, k - c.n_ctg);
+      Py_ssize_t ul = 0; const char* us = PyUnicode_Check(u) ? PyUnicode_AsUTF8AndSize(u, &ul) : NULL;
+      if (!us) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "group_calls: contig / type names must be str"); failed = 1; break; }
+      if (k < c.n_ctg) { c.ctg[k] = us; c.ctg_len[k] = (size_t)ul; } else { c.typ[k - c.n_ctg] = us; c.typ_len[k - c.n_ctg] = (size_t)ul; }
+    }
+    if (!failed) {
+      Py_ssize_t pl = 0, fl = 0;
+      c.prefix = PyUnicode_AsUTF8AndSize(prefix, &pl); c.fmt = PyUnicode_Check(t_fmt) ? PyUnicode_AsUTF8AndSize(t_fmt, &fl) : NULL;
+      if (!c.prefix || !c.fmt) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "group_calls: genotype_format must be str"); failed = 1; }
+      c.prefix_len = (size_t)pl; c.fmt_len = (size_t)fl;
+    }
+    if (!failed) {
+      c.O = O; c.E = E; c.ne = ne; c.GO = GO; c.ng = ng; c.M = M; c.nm = nm; c.CH = CH; c.SV = SV; c.TK = TK; c.ns = ns; c.SPOS = SPOS; c.nspos = nspos;
+      c.CS = CS; c.nobj = nobj; c.EVO = EVO; c.EVB = EVB; c.EVN = EVN; c.nblk = nblk; c.null_min = null_min;
+      c.REC = (const snf_group_cand_t*)fr_rec.buf; c.idpool = (const char*)fr_pool.buf; c.idpool_len = fr_pool.len; c.ID_ST = (const int64_t*)fr_st.buf;
+      c.ID_LN = (const int32_t*)fr_ln.buf; c.PH_HP = (const int8_t*)fr_hp.buf; c.PS_ST = (const int64_t*)fr_pss.buf; c.PS_LN = (const int32_t*)fr_psl.buf;
+      c.EM_TASK = (const int32_t*)hd_task.buf; c.EM_TYP = (const int32_t*)hd_typ.buf; c.AOFF = (const int64_t*)hd_aoff.buf; c.apool = (const char*)hd_apool.buf;
+      c.apool_len = hd_apool.len; c.dn_ptr = dn_ptr; c.dn_len = dn_len; c.EBT = EBT; c.EBS = EBS; c.cvx_cb = cvx_cb; c.cvx_bs = cvx_bs;
+      c.t_phase = t_phase; c.t_symbolic = t_symbolic; c.t_mosaic = t_mosaic; c.t_nm = t_nm; c.t_minsvlen = t_minsvlen;
+      for (long t = 0; t < nthr; t++) {
+        jobs[t].c = &c; jobs[t].e0 = ne * t / nthr; jobs[t].e1 = ne * (t + 1) / nthr;
+        jobs[t].off = (int64_t*)calloc((size_t)(jobs[t].e1 - jobs[t].e0) + 1, 8);
+        if (!jobs[t].off) { PyErr_NoMemory(); failed = 1; }
+      }
+    }
+    if (!failed) {
+      int started[64]; memset(started, 0, sizeof started);
+      Py_BEGIN_ALLOW_THREADS
+      for (long t = 1; t < nthr; t++) started[t] = pthread_create(&tids[t], NULL, fmt_thread, &jobs[t]) == 0;
+      fmt_range(&jobs[0]);
+      for (long t = 1; t < nthr; t++) { if (started[t]) pthread_join(tids[t], NULL); else fmt_range(&jobs[t]); }      /* (no thread to be had: here) */
+      Py_END_ALLOW_THREADS
+      size_t total = 0;
+      for (long t = 0; t < nthr && !failed; t++) {
+        if (jobs[t].err) { PyErr_Format(strcmp(jobs[t].err, "out of memory") == 0 ? PyExc_MemoryError : PyExc_ValueError, "group_calls: %s", jobs[t].err); failed = 1; }
+        total += jobs[t].tb.n;
+      }
+      if (!failed) {
+        PyObject* a = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
+        if (a) {
+          char* w = PyBytes_AS_STRING(a); size_t base = 0;
+          for (long t = 0; t < nthr; t++) {
+            if (jobs[t].tb.n) memcpy(w + base, jobs[t].tb.p, jobs[t].tb.n);
+            for (Py_ssize_t e = jobs[t].e0; e <= jobs[t].e1; e++) all_off[e] = (int64_t)base + jobs[t].off[e - jobs[t].e0];
+            base += jobs[t].tb.n;
+          }
+          for (Py_ssize_t e = 0; e < ne; e++) all_pos[e] = O[E[e]].pos;      /* (E checked by the ranges) */
+        }
+        PyObject* b2 = a ? PyBytes_FromStringAndSize((const char*)all_off, ((Py_ssize_t)ne + 1) * 8) : NULL;
+        PyObject* c2 = b2 ? PyBytes_FromStringAndSize((const char*)all_pos, (Py_ssize_t)ne * 8) : NULL;
+        if (a && b2 && c2) ret = PyTuple_Pack(3, a, b2, c2);
+        Py_XDECREF(a); Py_XDECREF(b2); Py_XDECREF(c2);
+      }
+    }
+    if (jobs) for (long t = 0; t < nthr; t++) { free(jobs[t].tb.p); free(jobs[t].off); }
+    free(jobs); free(tids); free(all_off); free(all_pos); free((void*)c.ctg); free(c.ctg_len); free((void*)c.typ); free(c.typ_len);
+    goto done;
   }
   out = PyList_New(text ? 0 : ne);
   if (!out) goto done;

@@ -220,9 +220,18 @@ def run_population(name, tmp_path, _lib):
         assert pipeline.combine(paths, cfg, vcf_handle=without, objects=False) == []
         assert without.getvalue() == with_objects.getvalue(), extra
         assert without.getvalue().count("\n") > 50
+    # the records formatted by several threads outside the interpreter lock (ranges of the emitted groups): the same text
+    import os
+    try:
+        for k in ("1", "3", "7"):
+            os.environ["SNF_TEXT_THREADS"] = k
+            threaded = io.StringIO()
+            assert pipeline.combine(paths, config_for(args), vcf_handle=threaded, objects=False) == []
+            assert threaded.getvalue() == buf.getvalue(), k
+    finally:
+        os.environ.pop("SNF_TEXT_THREADS", None)
     # the merge in runs of contig tasks that overlap host and device work (candstore.execute_many; the default of a big merge): same text,
     # same objects
-    import os
     from sniffles_amd import candstore
     try:
         for k in ("2", "3"):
