@@ -277,6 +277,24 @@ def test_candidate_store_helpers_reject_malformed_input():
         fast.gather_pool(np.array([0, 2, 5], np.int64), b"abcde", np.array([2], np.int64))
     off, pool = fast.gather_pool(np.array([0, 2, 5], np.int64), b"abcde", np.array([1, 0, 1], np.int64))
     assert pool == b"cdeabcde" and np.frombuffer(off, np.int64).tolist() == [0, 3, 5, 8]
+    # gather_pool_parts: strings that lie in several pools; a range beyond its pool, a pool number beyond the list
+    pools = [np.frombuffer(b"abcde", np.uint8), np.frombuffer(b"XYZ", np.uint8)]
+    part, start, length = np.array([0, 1, 0], np.int32), np.array([1, 0, 3], np.int64), np.array([2, 3, 2], np.int64)
+    off, pool = fast.gather_pool_parts(pools, part, start, length, np.array([2, 1, 0, 1], np.int64))
+    assert pool == b"deXYZbcXYZ" and np.frombuffer(off, np.int64).tolist() == [0, 2, 5, 7, 10]
+    with pytest.raises(ValueError):
+        fast.gather_pool_parts(pools, part, start, np.array([2, 4, 2], np.int64), np.array([1], np.int64))
+    with pytest.raises(ValueError):
+        fast.gather_pool_parts(pools, np.array([0, 2, 0], np.int32), start, length, np.array([1], np.int64))
+    with pytest.raises(ValueError):
+        fast.gather_pool_parts(pools, part, start, length, np.array([3], np.int64))
+    big = [np.frombuffer(bytes(range(256)) * 4096, np.uint8)] * 3      # megabytes: the copies are shared by four threads
+    rng = np.random.default_rng(3)
+    bp, bs, bl = rng.integers(0, 3, 20000).astype(np.int32), rng.integers(0, 1 << 19, 20000).astype(np.int64), rng.integers(0, 900, 20000).astype(np.int64)
+    order = rng.permutation(20000).astype(np.int64)
+    off, pool = fast.gather_pool_parts(big, bp, bs, bl, order)
+    want = b"".join(big[0][int(bs[i]):int(bs[i] + bl[i])].tobytes() for i in order.tolist())
+    assert pool == want and len(want) > (4 << 20) and np.frombuffer(off, np.int64)[-1] == len(want)
     # collect: one entry per reader expected
     with pytest.raises(TypeError):
         fast.collect([[None, None]], np.zeros(1, np.int32), tuple(sv.TYPES), 3, {})
