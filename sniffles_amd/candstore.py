@@ -445,7 +445,8 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
     cbin = np.trunc(rec["pos"] / bin_min).astype(np.int64) * bin_min          # int(pos / bin_min_size) * bin_min_size
     bin_no = cbin // bin_min
     if n and int(ctask.max()) < (1 << 12) and int(cblk.max()) < (1 << 22) and 0 <= int(bin_no.min()) and int(bin_no.max()) < (1 << 26):
-        perm = np.argsort((((ctask * 8 + ctyp) << 22 | cblk) << 26) | bin_no, kind="stable")      # one key of 63 bits: one sort instead of five
+        # one key of 63 bits: one stable sort instead of five (a radix sort that skips the digits all keys share)
+        perm = np.frombuffer(fast.argsort_i64(np.ascontiguousarray((((ctask * 8 + ctyp) << 22 | cblk) << 26) | bin_no, np.int64)), np.int64)
     else:
         perm = np.lexsort((np.arange(n), cbin, cblk, ctyp, ctask))
     # (np.take: a structured array indexed with [perm] is copied field by field, 20x slower)

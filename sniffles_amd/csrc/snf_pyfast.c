@@ -514,6 +514,39 @@ done:
  *                   length: buffer int64, order: buffer int64) -> (offsets: bytes int64 (len(order) + 1), pool: bytes)
  * gather_pool over strings that still lie in the pools of their tables (one per reader and contig): the merge's ALT pool is written
  * once, in sorted order, instead of being concatenated first and permuted then. */
+/* argsort_i64(keys: buffer int64) -> bytes int64: the stable ascending order of the keys (numpy.argsort(kind="stable")) by a radix sort,
+ * eleven bits a pass, passes in which every key has the same digit skipped - the merge sorts its candidate table by ONE 63-bit key
+ * (task, SV type, block, bin), whose upper digits are mostly equal */
+static PyObject* py_argsort_i64(PyObject* self, PyObject* args) {
+  Py_buffer kb;
+  if (!PyArg_ParseTuple(args, "y*", &kb)) return NULL;
+  const Py_ssize_t n = kb.len / 8;
+  PyObject* ret = NULL;
+  uint64_t *k0 = (uint64_t*)malloc((size_t)n * 8 + 8), *k1 = (uint64_t*)malloc((size_t)n * 8 + 8);
+  int64_t *i0 = (int64_t*)malloc((size_t)n * 8 + 8), *i1 = (int64_t*)malloc((size_t)n * 8 + 8);
+  if (!k0 || !k1 || !i0 || !i1) { PyErr_NoMemory(); goto done; }
+  Py_BEGIN_ALLOW_THREADS
+  for (Py_ssize_t i = 0; i < n; i++) { k0[i] = ((const uint64_t*)kb.buf)[i] ^ 0x8000000000000000ull; i0[i] = i; }      /* signed order as unsigned order */
+  for (int pass = 0; pass < 6; pass++) {
+    const int shift = 11 * pass;
+    size_t hist[2048]; memset(hist, 0, sizeof hist);
+    for (Py_ssize_t i = 0; i < n; i++) hist[(k0[i] >> shift) & 2047]++;
+    int single = 0;
+    for (int d = 0; d < 2048; d++) if (hist[d] == (size_t)n) single = 1;
+    if (single || n == 0) continue;
+    size_t at = 0;
+    for (int d = 0; d < 2048; d++) { const size_t c = hist[d]; hist[d] = at; at += c; }
+    for (Py_ssize_t i = 0; i < n; i++) { const size_t to = hist[(k0[i] >> shift) & 2047]++; k1[to] = k0[i]; i1[to] = i0[i]; }
+    { uint64_t* tk = k0; k0 = k1; k1 = tk; int64_t* ti = i0; i0 = i1; i1 = ti; }
+  }
+  Py_END_ALLOW_THREADS
+  ret = PyBytes_FromStringAndSize((const char*)i0, n * 8);
+done:
+  free(k0); free(k1); free(i0); free(i1);
+  PyBuffer_Release(&kb);
+  return ret;
+}
+
 typedef struct { const Py_buffer* pb; const int32_t* PT; const int64_t *ST, *LN, *ORD, *no; char* w; Py_ssize_t i0, i1; } GatherJob;
 static void* gather_thread(void* arg) {
   const GatherJob* j = (const GatherJob*)arg;
@@ -1733,6 +1766,7 @@ static PyMethodDef methods[] = {
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
     {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},
     {"gather_pool", py_gather_pool, METH_VARARGS, "strings of a pool in a given order, back to back"},
+    {"argsort_i64", py_argsort_i64, METH_VARARGS, "stable ascending order of int64 keys (radix sort)"},
     {"gather_pool_parts", py_gather_pool_parts, METH_VARARGS, "gather_pool over strings that lie in several pools"},
     {"flush_windows", py_flush_windows, METH_VARARGS, "flush windows of CombineTask.execute over the sorted candidate table"},
     {"group_calls", py_group_calls, METH_VARARGS, "group records + membership -> combined SVCall objects"},

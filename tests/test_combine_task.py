@@ -385,3 +385,18 @@ def test_merge_in_runs_of_tasks_equals_one_launch_emu(monkeypatch):
     for k in (2, 3):
         runs, nk = merge(k)
         assert 1 < nk <= k and runs == whole, k
+
+
+def test_radix_argsort_equals_numpy_stable():
+    """`_snf_fast.argsort_i64` (the merge's one sort: candidates by a 63-bit key) against numpy's stable argsort: negative keys, equal
+    keys (stability), keys whose upper digits all agree (skipped passes), the empty table."""
+    import numpy as np
+    fast = sv._load_fast()
+    if fast is None:
+        pytest.skip("C extension not built")
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 2, 7, 1000, 50000):
+        for keys in (rng.integers(-5, 50, n), rng.integers(-(1 << 62), 1 << 62, n), np.full(n, 1 << 40) + rng.integers(0, 3, n),
+                     (rng.integers(0, 24, n) << 51) | (rng.integers(0, 5, n) << 48) | (rng.integers(0, 3000, n) << 26) | rng.integers(0, 2500000, n)):
+            k = np.ascontiguousarray(keys, np.int64)
+            assert np.array_equal(np.frombuffer(fast.argsort_i64(k), np.int64), np.argsort(k, kind="stable")), n
