@@ -578,12 +578,21 @@ static PyObject* py_gather_pool_parts(PyObject* self, PyObject* args) {
     PyObject* out = PyBytes_FromStringAndSize(NULL, (Py_ssize_t)total);
     if (out) {
       /* the copies read cold memory all over the tables' pools: four threads share them when there are megabytes to move */
-      GatherJob jobs[4]; pthread_t tids[4]; int started[4] = {0, 0, 0, 0};
-      const int nt = total >= ((size_t)4 << 20) && m >= 4096 ? 4 : 1;
+      GatherJob jobs[8]; pthread_t tids[8]; int started[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int nt = total >= ((size_t)32 << 20) && m >= 8192 ? 8 : total >= ((size_t)4 << 20) && m >= 4096 ? 4 : 1;
       for (int t = 0; t < nt; t++) {
         jobs[t].pb = pb; jobs[t].PT = PT; jobs[t].ST = ST; jobs[t].LN = LN; jobs[t].ORD = ORD; jobs[t].no = no; jobs[t].w = PyBytes_AS_STRING(out);
-        jobs[t].i0 = m * t / nt; jobs[t].i1 = m * (t + 1) / nt;
       }
+      /* equal BYTES per thread (the sorted table keeps the long strings - insertions - together): cut where the output offset passes
+       * t / nt of the total */
+      jobs[0].i0 = 0;
+      for (int t = 1; t < nt; t++) {
+        const int64_t want = (int64_t)(total / (size_t)nt) * t;
+        Py_ssize_t lo_ = jobs[t - 1].i0, hi_ = m;
+        while (lo_ < hi_) { const Py_ssize_t mid = lo_ + (hi_ - lo_) / 2; if (no[mid] < want) lo_ = mid + 1; else hi_ = mid; }
+        jobs[t].i0 = lo_; jobs[t - 1].i1 = lo_;
+      }
+      jobs[nt - 1].i1 = m;
       Py_BEGIN_ALLOW_THREADS
       for (int t = 1; t < nt; t++) started[t] = pthread_create(&tids[t], NULL, gather_thread, &jobs[t]) == 0;
       gather_thread(&jobs[0]);
