@@ -313,7 +313,12 @@ class VCF:
             return 0
         if not sort or bool((pos[1:] >= pos[:-1]).all()):      # in order already (candstore formats them so): one slice
             n = int(np.count_nonzero(off[1:] > off[:-1]))
-            self.handle.write(str(memoryview(text)[int(off[0]):int(off[-1])], "utf-8"))
+            raw = getattr(self.handle, "buffer", None)      # a text file over a binary one (open(path, "w")): the bytes go as they are
+            if raw is not None and getattr(self.handle, "encoding", "").lower().replace("-", "") == "utf8":
+                self.handle.flush()
+                raw.write(memoryview(text)[int(off[0]):int(off[-1])])
+            else:
+                self.handle.write(str(memoryview(text)[int(off[0]):int(off[-1])], "utf-8"))
             self.call_count += n
             return n
         order = np.argsort(pos, kind="stable")

@@ -220,6 +220,13 @@ def run_population(name, tmp_path, _lib):
         assert pipeline.combine(paths, cfg, vcf_handle=without, objects=False) == []
         assert without.getvalue() == with_objects.getvalue(), extra
         assert without.getvalue().count("\n") > 50
+    # into a text file over a binary one (what open(path, "w") hands the writer): the record bytes go to the binary layer as they are,
+    # behind whatever the text layer still held
+    raw = io.BytesIO()
+    handle = io.TextIOWrapper(raw, encoding="utf-8", newline="")
+    assert pipeline.combine(paths, config_for(args), vcf_handle=handle, objects=False) == []
+    handle.flush()
+    assert raw.getvalue().decode("utf-8") == buf.getvalue()
     # the records formatted by several threads outside the interpreter lock (ranges of the emitted groups): the same text
     import os
     try:

@@ -86,14 +86,15 @@ def main():
 
     def one_pass():
         tasks = [parallel.CombineTask(id=ci, sv_id=0, contig=c, start=0, end=L - 1, config=cfg, device=0) for ci, c, L in contigs]
-        buf = io.StringIO()
+        buf = io.TextIOWrapper(io.BytesIO(), encoding="utf-8", newline="", write_through=True)      # (as open(path, "w") gives the writer)
         w = vcf.VCF(cfg, buf)
         n = sum(w.write_merged(part) for part in parallel.CombineTask.execute_many(tasks, readers, text_writer=w))
-        text[0] = buf.getvalue()
+        buf.flush()
+        text[0] = buf
         return n
 
     one_pass()
-    first = text[0]
+    first = text[0].buffer.getvalue().decode("utf-8")
     if a.cache and not os.path.exists(a.cache):
         for r in readers.values():
             r.__dict__.pop("_snf_columns", None)
@@ -120,10 +121,10 @@ def main():
             ph = {k_: (round(v * 1e3, 2) if isinstance(v, float) else v) for k_, v in candstore.last_timing.items()}
             host = dt - ph.get("resolve_groups_gpu", 0.0)
             print(f"chunks {chunks} pass {k}: {dt:.1f} ms" + ("" if GPU else f", without the replayed call {host:.1f} ms") +
-                  f", {n} records, text {len(text[0])} B  {ph}", flush=True)
+                  f", {n} records, text {text[0].buffer.tell()} B  {ph}", flush=True)
             best = host if best is None else min(best, host)
             best_all = dt if best_all is None else min(best_all, dt)
-        assert text[0] == first
+        assert text[0].buffer.getvalue().decode("utf-8") == first
         print(f"chunks {chunks}: best pass {best_all:.1f} ms" + ("" if GPU else f", best host time around the call {best:.1f} ms"), flush=True)
     if a.cprofile:
         import cProfile
