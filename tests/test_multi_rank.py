@@ -466,3 +466,23 @@ def test_bench_two_ranks_strong_scaling_block_gather_emu():
     d = _bench_two_ranks(["--scaling", "strong"], 37500 + (os.getpid() % 500), SNF_BENCH_GATHER="rccl")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["gathered_on_rank0"]["records"] == d["config"]["calls"] > 0
     assert "RCCL gather" in d["config"]["parallelism"]
+
+
+def test_bench_population_merge_line_emu():
+    """`bench.py --config 4` (the population merge; also a block of the driver's default line) on this GPU-less box: the host tier's
+    kernels, a tiny population - the line's plumbing (phases, the merged text against the object path, the handle the records are
+    written into) must not rot unseen.  Never a measurement."""
+    import json
+    import subprocess
+    env = dict(os.environ, SNF_BENCH_EMU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--scale", "0.004", "--samples", "3", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-reference-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["unit"] == "candidates/s" and d["value"] > 0 and c["baseline_config"] == 4 and c["samples"] == 3
+    assert c["text_equals_object_path"] is True and c["vcf_bytes"] > 1000 and 0 < c["combined_calls"] <= c["candidates"]
+    assert {"walk_blocks", "sort_and_windows", "resolve_groups_gpu", "build_svcalls"} <= set(c["host_phases_ms"])
