@@ -164,4 +164,3 @@ def test_gpu_combine_batch_fuzz_vs_oracle(oracle_mod):
     got = cluster.resolve_block_groups_batch(problems, cfg)
     key = lambda gs: [([c.id for c in g.candidates], g.pos_mean, g.len_mean, g.bnd_mate_ref_start_mean) for g in gs]  # noqa: E731
     assert [key(g) for g in got] == [key(g) for g in exp]
-
