@@ -89,6 +89,19 @@ def main():
                 buf2 = io.StringIO()
                 pipeline.combine(ref["snf"], config_for(args), vcf_handle=buf2)
                 assert_same_text(buf2.getvalue(), ref["vcf"])
+                # the same merge straight from the group table (no SVCall objects; records formatted by threads when every column is
+                # there), into a text handle and into a text file over a binary buffer: the text of the object path
+                buf3 = io.StringIO()
+                pipeline.combine(renamed, config_for(args), vcf_handle=buf3, objects=False)
+                assert buf3.getvalue() == buf.getvalue(), "text path (objects=False) differs from the object path"
+                raw = io.BytesIO(); h4 = io.TextIOWrapper(raw, encoding="utf-8", newline="")
+                os.environ["SNF_TEXT_THREADS"] = "3"
+                try:
+                    pipeline.combine(renamed, config_for(args), vcf_handle=h4, objects=False)
+                finally:
+                    os.environ.pop("SNF_TEXT_THREADS", None)
+                h4.flush()
+                assert raw.getvalue().decode("utf-8") == buf.getvalue(), "text path into a binary-backed handle differs from the object path"
             except AssertionError as e:
                 diffs.append(str(e)[:500])
             except Exception as e:
