@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/r05_sessions.sh N: the GPU sessions of round 5 (one `gpurun -- bash tools/r05_sessions.sh N` each), in the order they were run;
-# what they wrote is under profiles/ (profiles/README.md, "Round 5").  Sessions 1-5 and 8-12 are same-box A/Bs and probes, 6 is the profile
-# set of the round (run again on the final sources), 7 what the driver runs at round end.
+# what they wrote is under profiles/ (profiles/README.md, "Round 5").  Sessions 1-5 and 8-15 are same-box A/Bs and probes, 6 is the profile
+# set of the round (run again on the final sources), 7 what the driver runs at round end, 16 the population merge over its runs of tasks.
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 mkdir -p gpurun_out
