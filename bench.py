@@ -763,6 +763,14 @@ def run_calling(ctx):
                     for bb in hs:            #  instead of 0.35 ms per step - more streams than hardware queues)
                         bb.close()
                 out["configs"] = other_configs(ctx)
+            # (the driver's record keeps `config` whole but only the NAMES of the other extra keys: the outcome of the checks goes there too)
+            out["config"]["verified"] = out.get("verified")
+            out["config"]["verified_vs_reference"] = out.get("verified_vs_reference")
+            if "configs" in out:
+                out["config"]["configs_verified"] = {k: dict(verified=v.get("verified"), verified_vs_reference=(
+                    v["verified_vs_reference"].get("ok") if isinstance(v.get("verified_vs_reference"), dict) else v.get("verified_vs_reference")),
+                    records_compared=(v["verified_vs_reference"].get("records_compared") if isinstance(v.get("verified_vs_reference"), dict)
+                                      else v.get("records_compared"))) for k, v in out["configs"].items()}
     if comm_thread is not None:
         comm_q.put(None)
         comm_thread.join(timeout=30)

@@ -46,10 +46,13 @@ def _worker(wid, contigs, n_samples, coverage, barrier, out_q, want_records):
         #  its other contigs' samples exist too would cost memory - a worker holds one contig in the usual one-process-per-contig layout)
         for ci, tis in prepared:
             timing = {}
-            doc = rh.run_reference_combine_task(tis, (), align="myers", before_execute=wait_once, timing=timing)
+            doc, calls, cfg = rh.run_reference_combine_task(tis, (), align="myers", before_execute=wait_once, timing=timing, task_id=ci,
+                                                            with_objects=True)
             item = dict(key=ci, worker=wid, execute_s=timing["execute_s"], candidates=timing["candidates"], combined=len(doc["calls"]))
             if want_records:
-                item["calls"] = doc["calls"]
+                # the merged records as the reference's OWN writer prints them (vcf.py:216-350), in the order its result object emits a
+                # task's calls (result.py:137-149: sorted by position, stable): what bench.py --config 4 diffs its text against
+                item["vcf"] = rh.reference_vcf_records(sorted(calls, key=lambda c: c.pos), cfg)
             out.append(item)
         for item in out:
             out_q.put(item)

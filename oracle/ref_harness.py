@@ -290,10 +290,7 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     resolve_block_groups (two chained windows per SV type so that `groups_initial` is exercised) and SVGroup.call."""
     import oracle as oc  # exact DP (C) as the stand-in for edlib.align(...)['editDistance']
     ref = load_reference()
-    # edlib.align(a, b)["editDistance"]: the exact DP (goldens), or - `align="myers"`, the baseline of bench.py --config 4 - the bit-parallel
-    # algorithm edlib implements (oracle/snf_oracle.c::snf_oracle_edit_distance_myers, pinned to the DP)
-    dist_fn = oc.edit_distance_myers if align == "myers" else oc.edit_distance
-    ref.sv.align = lambda a, b: {"editDistance": dist_fn(a.encode("latin-1"), b.encode("latin-1"))}
+    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
     ns = len(sample_tasks)
     cfg = make_config(tuple(extra_args), sample_tasks[0].qc_nm_threshold)
     per_sample = []
@@ -345,7 +342,8 @@ def run_reference_combine(sample_tasks, extra_args=(), split=True):
     return out
 
 
-def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, scatter_target=None, align=None, before_execute=None, timing=None):
+def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, scatter_target=None, align=None, before_execute=None, timing=None,
+                               task_id=7):
     """The reference's own CombineTask.execute (parallel.py:444-572) on a synthetic population.
 
     Per-sample candidates come from the reference's call_candidates + finalize_candidates; they are put into SNF blocks by
@@ -356,7 +354,10 @@ def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, 
     import oracle as oc
     ref = load_reference()
     from sniffles import snf as ref_snf
-    ref.sv.align = lambda a, b: {"editDistance": oc.edit_distance(a.encode("latin-1"), b.encode("latin-1"))}
+    # edlib.align(a, b)["editDistance"]: the exact DP (goldens), or - `align="myers"`, the baseline of bench.py --config 4 - the bit-parallel
+    # algorithm edlib implements (oracle/snf_oracle.c::snf_oracle_edit_distance_myers, pinned to the DP)
+    dist_fn = oc.edit_distance_myers if align == "myers" else oc.edit_distance
+    ref.sv.align = lambda a, b: {"editDistance": dist_fn(a.encode("latin-1"), b.encode("latin-1"))}
     ns = len(sample_tasks)
     contig, contig_len = sample_tasks[0].contig, sample_tasks[0].contig_len
     cfg = make_config(tuple(extra_args), sample_tasks[0].qc_nm_threshold)
@@ -418,7 +419,7 @@ def run_reference_combine_task(sample_tasks, extra_args=(), with_objects=False, 
     scattered = None
     old_target = ref.parallel.CombineTask.TARGET_WORK_PER_TASK
     try:
-        ctask = ref.parallel.CombineTask(id=7, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
+        ctask = ref.parallel.CombineTask(id=task_id, sv_id=0, contig=contig, start=0, end=contig_len, config=cfg, result_class=Collector)
         if before_execute is not None:
             before_execute()                 # (a barrier: every worker of a pool holds its samples' blocks)
         import time as _time
@@ -532,6 +533,19 @@ def reference_vcf_text(calls, cfg, contigs_lengths, fasta=None) -> str:
     w.write_header(contigs_lengths)
     n = sum(w.write_call(c) for c in copy.deepcopy(calls))
     assert n == w.call_count
+    return buf.getvalue()
+
+
+def reference_vcf_records(calls, cfg, fasta=None) -> str:
+    """The record lines alone (no header) of the UNMODIFIED reference writer for `calls`, which it may mutate."""
+    import io
+    load_reference()
+    from sniffles import vcf as ref_vcf
+    buf = io.StringIO()
+    w = ref_vcf.VCF(cfg, buf)
+    w.reference_handle = fasta
+    for c in calls:
+        w.write_call(c)
     return buf.getvalue()
 
 

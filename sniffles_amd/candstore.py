@@ -565,9 +565,10 @@ def _execute_many(tasks: list, samples_snf: dict, text_writer=None, timings: lis
     start_id = np.asarray([t.sv_id for t in tasks], np.int64)
     sv_ids = start_id[g_task[em]] + (np.arange(len(em)) - first_of_task[g_task[em]])
     task_ids = np.asarray([t.id for t in tasks], np.int64)[g_task[em]]
-    if text_writer is not None:
+    if text_writer is not None and getattr(config, "sort", True):
         # text: the ids are given (emission order) - the records themselves are formatted in the order they are written, per task by
-        # position with the emission order among equals (`sorted(calls, key=pos)`, stable): a task's text is then one slice of the buffer
+        # position with the emission order among equals (`sorted(calls, key=pos)`, stable): a task's text is then one slice of the buffer.
+        # With --no-sort the reference writes a task's calls as they were emitted (result.py:139, :148): that order is kept
         by_pos = np.lexsort((np.arange(len(em)), gout["pos"][em], g_task[em]))
         em, sv_ids, task_ids = em[by_pos], sv_ids[by_pos], task_ids[by_pos]
     # events a group was active in: its first window .. the flush window (or the chain's last); pos_mean at an event = after the

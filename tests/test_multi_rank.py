@@ -475,8 +475,7 @@ def test_bench_population_merge_line_emu():
     import json
     import subprocess
     env = dict(os.environ, SNF_BENCH_EMU="1", OMP_NUM_THREADS="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--scale", "0.004", "--samples", "3", "--steps", "1", "--warmup", "1",
-           "--no-cpu-baseline", "--no-reference-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--scale", "0.004", "--samples", "3", "--steps", "1", "--warmup", "1"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -486,3 +485,12 @@ def test_bench_population_merge_line_emu():
     assert d["unit"] == "candidates/s" and d["value"] > 0 and c["baseline_config"] == 4 and c["samples"] == 3
     assert c["text_equals_object_path"] is True and c["vcf_bytes"] > 1000 and 0 < c["combined_calls"] <= c["candidates"]
     assert {"walk_blocks", "sort_and_windows", "resolve_groups_gpu", "build_svcalls"} <= set(c["host_phases_ms"])
+    # ... and the checks of the line: the group assignment against the C oracle, every merged record against the text the unmodified
+    # reference's own writer prints for its CombineTask.execute on the same population (where the reference is staged)
+    assert d["verified"] is True and c["verified"] is True
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_combine_pool
+    if ref_combine_pool.available():
+        v = d["verified_vs_reference"]
+        assert v["ok"] is True and v["differences"] == [] and v["records_compared"] == c["combined_calls"] > 50 and v["contigs_compared"] == 24
+        assert c["verified_vs_reference"] is True

@@ -220,6 +220,14 @@ def run_population(name, tmp_path, _lib):
         assert pipeline.combine(paths, cfg, vcf_handle=without, objects=False) == []
         assert without.getvalue() == with_objects.getvalue(), extra
         assert without.getvalue().count("\n") > 50
+    # --no-sort (config.sort = False): a task's records leave in emission order on both paths (result.py:139, :148) - not by position
+    unsorted_objects, unsorted_text = io.StringIO(), io.StringIO()
+    cfg_a, cfg_b = config_for(args), config_for(args)
+    cfg_a.sort = cfg_b.sort = False
+    pipeline.combine(paths, cfg_a, vcf_handle=unsorted_objects)
+    assert pipeline.combine(paths, cfg_b, vcf_handle=unsorted_text, objects=False) == []
+    assert unsorted_text.getvalue() == unsorted_objects.getvalue()
+    assert unsorted_text.getvalue() != buf.getvalue() and sorted(unsorted_text.getvalue().splitlines()) == sorted(buf.getvalue().splitlines())
     # into a text file over a binary one (what open(path, "w") hands the writer): the record bytes go to the binary layer as they are,
     # behind whatever the text layer still held
     raw = io.BytesIO()

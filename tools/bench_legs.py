@@ -316,7 +316,7 @@ def other_configs(ctx) -> dict:
         out["4"] = dict(workload=r["config"]["workload"], metric=r["metric"], candidates=r["config"]["candidates"],
                         combined_calls=r["config"]["combined_calls"],
                         ms_per_step=round(r["ms_per_step"], 1), candidates_per_s=round(r["value"]), steps=r["steps"],
-                        verified=r.get("verified"),
+                        verified=r.get("verified"), verified_vs_reference=r.get("verified_vs_reference"),
                         kernel_ms=r["config"].get("rank0", {}).get("kernel_ms"), parity_unpinned=r["config"].get("parity_unpinned"),
                         cpu_baseline={k: (r.get("cpu_baseline") or {}).get(k) for k in ("kind", "value", "unit", "cores",
                                                                                         "hot_all_core_s", "vs_baseline",

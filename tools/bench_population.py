@@ -57,12 +57,12 @@ def build_sample(cfg, tasks, device, sid):
             for c in cands:
                 c.finalize()
                 c.rnames = None
+                bi = int(c.pos / bs) * bs
+                if bi not in blocks:          # (SNFile.store, snf.py:91-100: a single-break candidate opens its block too - the block
+                    blocks[bi] = {svtype: [] for svtype in sv.TYPES}      # then carries the sample's coverage for the other samples' calls)
+                    blocks[bi]["_COVERAGE"] = {}
                 if c.svtype not in sv.TYPES:
                     continue
-                bi = int(c.pos / bs) * bs
-                if bi not in blocks:
-                    blocks[bi] = {svtype: [] for svtype in sv.TYPES}
-                    blocks[bi]["_COVERAGE"] = {}
                 blocks[bi][c.svtype].append(c)
                 n += 1
             if blocks:
@@ -215,17 +215,68 @@ def run(ctx):
             # stand-in)
             try:
                 ref_base = reference_baseline(my_contigs, S, cov, total_cands, int(phases.get("calls", total_calls)), dt / steps,
-                                              sample=getattr(args, "reference_sample_contigs", None))
+                                              sample=getattr(args, "reference_sample_contigs", None), text=text_fast)
             except Exception as e:  # noqa: BLE001 - a baseline that cannot run must not take the line down; it says why
                 ref_base = None
                 out["cpu_baseline"]["reference_error"] = f"{type(e).__name__}: {str(e)[:400]}"
             if ref_base is not None:
                 ref_base["port"] = out["cpu_baseline"]
                 out["cpu_baseline"] = ref_base
+                vr = ref_base.pop("verified_vs_reference", None)
+                if vr is not None:
+                    out["verified_vs_reference"] = vr
+        # (the driver's record keeps `config` whole and only the names of other keys: the checks' outcome goes there too)
+        out["config"]["verified"] = out.get("verified")
+        out["config"]["verified_vs_reference"] = (out.get("verified_vs_reference") or {}).get("ok")
     return out
 
 
-def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sample=None):
+def records_by_contig(text) -> dict:
+    """VCF record lines grouped by CHROM, in the order they were written."""
+    out = {}
+    if isinstance(text, str):
+        text = text.encode("utf-8")
+    for line in text.split(b"\n"):
+        if line and not line.startswith(b"#"):
+            out.setdefault(line[:line.index(b"\t")].decode(), []).append(line)
+    return out
+
+
+VCF_COLUMNS = ("CHROM", "POS", "ID", "REF", "ALT", "QUAL", "FILTER", "INFO", "FORMAT")
+
+
+def reference_differences(items, contigs, text, n_samples) -> dict:
+    """The merged VCF records this package wrote (`text`) against the UNMODIFIED reference's: its `CombineTask.execute`
+    (parallel.py:444-572, sv.py:320-481) on the same population, printed by its own writer (vcf.py:216-350) - line by line, every
+    column (CHROM POS ID REF ALT QUAL FILTER, INFO incl. SVTYPE / SVLEN / END / SUPPORT / COVERAGE / STDEV_* / AF, the per-sample
+    GT:GQ:DR:DV:ID columns with the chained candidate ids)."""
+    mine = records_by_contig(text)
+    diffs, n_cmp = [], 0
+    for ci, c, _ in contigs:
+        if ci not in items:
+            continue
+        exp = records_by_contig(items[ci]["vcf"]).get(c, [])
+        got = mine.get(c, [])
+        n_cmp += len(exp)
+        if len(exp) != len(got):
+            diffs.append(f"{c}: {len(exp)} reference records, {len(got)} here")
+            continue
+        for k, (a, b) in enumerate(zip(got, exp)):
+            if a != b:
+                fa, fb = a.split(b"\t"), b.split(b"\t")
+                cols = [(VCF_COLUMNS[i] if i < len(VCF_COLUMNS) else f"sample {i - len(VCF_COLUMNS)}") for i in range(min(len(fa), len(fb)))
+                        if fa[i] != fb[i]]
+                first = next((i for i in range(min(len(fa), len(fb))) if fa[i] != fb[i]), None)
+                shown = "" if first is None else f" [here {fa[first][:80].decode()!r}, reference {fb[first][:80].decode()!r}]"
+                diffs.append(f"{c} record {k} ({fb[2].decode()} at {fb[1].decode()}): {', '.join(cols) or 'column count'}{shown}")
+                if len(diffs) > 5:
+                    break
+    return dict(ok=not diffs, records_compared=n_cmp, contigs_compared=sum(1 for ci, _, _ in contigs if ci in items), differences=diffs[:5],
+                what="every merged VCF record (all columns, per-sample genotype columns and id chains included) vs the text the unmodified "
+                     "reference's own writer prints for its CombineTask.execute on the same population, on this box")
+
+
+def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sample=None, text=None):
     """`cpu_baseline` of kind "reference (edlib stand-in)": oracle/ref_combine_pool.py - the unmodified reference's `CombineTask.execute`
     (parallel.py:444-572), one process per contig, on the same seeded population (its samples called by the reference's own path, untimed),
     `sv.align` = the bit-parallel algorithm edlib implements (edlib is absent from this image: parity unpinned)."""
@@ -237,11 +288,12 @@ def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sampl
     # --config 4
     if sample:
         part = sorted(contigs, key=lambda c: c[2])[:int(sample)]
-        r = ref_combine_pool.run(part, S, cov)
+        r = ref_combine_pool.run(part, S, cov, want_records=text is not None)
+        ver = reference_differences(r["items"], part, text, S) if text is not None else None
         per_cand = r["hot_single_core_s"] / max(1, r["candidates"])
         share = max(c[2] for c in contigs) / float(sum(c[2] for c in contigs))
         return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"],
-                    kind="reference (edlib stand-in)", host_cores=r["cores"],
+                    kind="reference (edlib stand-in)", host_cores=r["cores"], verified_vs_reference=ver,
                     hot_all_core_s=round(r["hot_all_core_s"], 3), candidates=r["candidates"], combined_calls=r["combined"],
                     single_core_cand_s=round(1.0 / per_cand, 1),
                     # the reference merges one contig per process: the wall clock of a whole merge is its largest contig task
@@ -257,9 +309,11 @@ def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sampl
                            f"reference's CombineTask.execute, one process "
                            f"per contig: slowest process {r['hot_all_core_s']:.2f} s, sum {r['hot_single_core_s']:.1f} s; whole leg "
                            f"{r['total_wall_s']:.0f} s")
-    r = ref_combine_pool.run(list(contigs), S, cov, max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None)
+    r = ref_combine_pool.run(list(contigs), S, cov, max_procs=int(os.environ.get("SNF_BENCH_REF_PROCS", "0")) or None,
+                             want_records=text is not None)
+    ver = reference_differences(r["items"], list(contigs), text, S) if text is not None else None
     return dict(value=r["candidates"] / r["hot_all_core_s"], unit="candidates/s", cores=r["procs"], kind="reference (edlib stand-in)",
-                host_cores=r["cores"],
+                host_cores=r["cores"], verified_vs_reference=ver,
                 hot_all_core_s=round(r["hot_all_core_s"], 3), hot_single_core_s=round(r["hot_single_core_s"], 2),
                 candidates=r["candidates"], combined_calls=r["combined"],
                 same_population=dict(candidates_equal=bool(r["candidates"] == n_cands), combined_calls_equal=bool(r["combined"] == n_calls),
