@@ -149,7 +149,7 @@ SNF_HD void combine_run(int64_t p, const CombineView& v) {
           need = __shfl(need, 0, 64);
           if (need) {
             pa = __shfl(pa, 0, 64); pb = __shfl(pb, 0, 64); la = __shfl(la, 0, 64); lb = __shfl(lb, 0, 64); kmax = __shfl(kmax, 0, 64);
-            if (ed_wave_band_fits((int64_t)la, (int64_t)lb, (int64_t)kmax)) d = ed_wave_pair_k((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, (int64_t)kmax);
+            if (ed_wave_band_fits((int64_t)la, (int64_t)lb, (int64_t)kmax)) d = ed_wave_pair_k_any((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, (int64_t)kmax);
             else { d = ed_wave_pair((const uint8_t*)pa, (int64_t)la, (const uint8_t*)pb, (int64_t)lb, carry); if (d > kmax) d = -1; }
           }
         } else

@@ -241,6 +241,54 @@ SNF_HD int64_t bound_top_i32(const int32_t* a, const int32_t* top, int64_t lo, i
   return UPPER ? upper_bound_i32(a, nlo, nhi, x) : lower_bound_i32(a, nlo, nhi, x);
 }
 
+// ---- the same upper bound as a 16-ary descent: three sampled levels over the GLOBAL positions of the array - top[k] == a[k << 8]
+// (above), mid[j] == a[j << 4] - so that a query is a short binary search over every 16th entry of `top` (a few KB per task: cache
+// resident) followed by THREE aligned 64-byte node reads (16 samples of level 8, of level 4, 16 entries of the array itself) instead
+// of ~19 dependent 4-byte probes.  What bounds the coverage queries of a pass is the length of that dependent chain (a thread per
+// query has nothing else to do), not bytes.  The arrays live in 256-byte granules, so a node read never leaves its allocation; the
+// entries of a node outside [lo, hi) are masked by position.
+SNF_HD void load16_i32(const int32_t* p, int32_t (&o)[16]) {
+  typedef uint4 __attribute__((aligned(4))) uint4_dw;     // (a column of the input arena is only known to be 4-byte aligned here)
+  const uint4_dw* q = (const uint4_dw*)p;
+  const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+  o[0] = (int32_t)a.x; o[1] = (int32_t)a.y; o[2] = (int32_t)a.z; o[3] = (int32_t)a.w;
+  o[4] = (int32_t)b.x; o[5] = (int32_t)b.y; o[6] = (int32_t)b.z; o[7] = (int32_t)b.w;
+  o[8] = (int32_t)c.x; o[9] = (int32_t)c.y; o[10] = (int32_t)c.z; o[11] = (int32_t)c.w;
+  o[12] = (int32_t)d.x; o[13] = (int32_t)d.y; o[14] = (int32_t)d.z; o[15] = (int32_t)d.w;
+}
+// one level: lvl[p >> S] == a[p] for the positions p that are multiples of 2^S.  In: the answer lies in [bl, bh] and [bl, bh) sits
+// inside one aligned block of 2^(S+4) positions.  Out: the same with 2^S.
+template <int S>
+SNF_HD void rank_level16(const int32_t* lvl, int64_t x, int64_t& bl, int64_t& bh) {
+  if (bl >= bh) return;
+  const int64_t B = (bl >> (S + 4)) << (S + 4);
+  int32_t val[16];
+  load16_i32(lvl + (B >> S), val);
+  const int j0 = (int)((bl - B + ((int64_t)1 << S) - 1) >> S);      // first sampled position >= bl ...
+  const int j1 = (int)((bh - B + ((int64_t)1 << S) - 1) >> S);      // ... and the first >= bh (at most 16)
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 16; j++) c += (j >= j0 && j < j1 && (int64_t)val[j] <= x) ? 1 : 0;
+  const int jf = j0 + c;                                             // the first sample past x (the samples ascend)
+  if (c > 0) bl = B + ((int64_t)(jf - 1) << S);
+  if (jf < j1) bh = B + ((int64_t)jf << S);
+}
+SNF_HD int64_t rank_upper_16ary(const int32_t* a, const int32_t* mid, const int32_t* top, int64_t lo, int64_t hi, int64_t x) {
+  if (lo >= hi) return lo;
+  int64_t kl = (lo + 4095) >> 12, kh = (hi + 4095) >> 12;          // level 12 = every 16th entry of `top`
+  const int64_t k0 = kl, kend = kh;
+  while (kl < kh) {
+    const int64_t m = (kl + kh) >> 1;
+    if ((int64_t)top[m << 4] <= x) kl = m + 1; else kh = m;
+  }
+  int64_t bl = kl > k0 ? ((kl - 1) << 12) : lo;
+  int64_t bh = kl < kend ? (kl << 12) : hi;
+  rank_level16<8>(top, x, bl, bh);
+  rank_level16<4>(mid, x, bl, bh);
+  rank_level16<0>(a, x, bl, bh);
+  return bh;
+}
+
 // upper bound of x in a[lo, hi) starting from a position `hint` in [lo, hi] where a nearby query ended: gallops away from
 // the hint (1, 2, 4, ... entries) and bisects the bracket.  Same result as upper_bound_i32; a query a few hundred bp from
 // the previous one stays inside the cache lines that one brought in.

@@ -85,6 +85,7 @@ struct ReadPrep {
   const int32_t* r_end; const uint8_t* r_hp; const int32_t* r_task; const int32_t* r_start;
   uint64_t* rk_in; uint32_t* rv_in; const uint64_t* rk_out; const uint32_t* rv_out;
   int32_t* re_sorted; int32_t* re_top; uint64_t *fs2, *fe2; int64_t R;  // fs2/fe2: (hp == 1) << 32 | (hp == 2) in start / end order
+  int32_t *rs_mid, *re_mid;  // every 16th start / sorted end (View::rs_mid)
   const uint64_t* t_base;  // [T+1] prefix of (max read end + 1): key = t_base[task] + end orders by (task, end)
   int key32;               // the key space fits 32 bits: rk_in / rk_out hold uint32_t keys
 };
@@ -94,6 +95,7 @@ SNF_HD void r1_endkeys_body(int64_t r, const ReadPrep& p) {
   if (p.key32) ((uint32_t*)p.rk_in)[r] = (uint32_t)k; else p.rk_in[r] = k;
   p.rv_in[r] = p.r_hp[r];
   p.fs2[r] = p.r_hp[r] == 1 ? (1ull << 32) : (p.r_hp[r] == 2 ? 1ull : 0ull);
+  if ((r & 15) == 0) p.rs_mid[r >> 4] = p.r_start[r];
   if (r == 0) p.fs2[p.R] = 0;
 }
 SNF_HD void r2_unpack_body(int64_t r, const ReadPrep& p) {
@@ -101,6 +103,7 @@ SNF_HD void r2_unpack_body(int64_t r, const ReadPrep& p) {
   const uint64_t k = p.key32 ? (uint64_t)((const uint32_t*)p.rk_out)[r] : p.rk_out[r];
   p.re_sorted[r] = (int32_t)(k - p.t_base[p.r_task[r]]);
   if ((r & ((1 << SNF_TOP_SHIFT) - 1)) == 0) p.re_top[r >> SNF_TOP_SHIFT] = p.re_sorted[r];
+  if ((r & 15) == 0) p.re_mid[r >> 4] = p.re_sorted[r];
   p.fe2[r] = p.rv_out[r] == 1u ? (1ull << 32) : (p.rv_out[r] == 2u ? 1ull : 0ull);
   if (r == 0) p.fe2[p.R] = 0;
 }
@@ -904,6 +907,7 @@ void do_upload(snf_batch_impl* b) {
   v.re_sorted = dalloc<int32_t>(b, R);
   v.pc_s2 = dalloc<uint64_t>(b, R + 1); v.pc_e2 = dalloc<uint64_t>(b, R + 1);
   v.rs_top = upload_vec(b, top, 1); v.re_top = dalloc<int32_t>(b, top.size() + 1);
+  v.rs_mid = dalloc<int32_t>(b, (size_t)(R + 15) / 16 + 16); v.re_mid = dalloc<int32_t>(b, (size_t)(R + 15) / 16 + 16);
   dsync(b);
   ReadPrep& rp = b->rp;
   {
@@ -915,6 +919,7 @@ void do_upload(snf_batch_impl* b) {
   }
   rp.r_end = v.r_end; rp.r_hp = v.r_hp; rp.r_task = v.r_task; rp.r_start = v.r_start; rp.rk_in = v.rk_in; rp.rv_in = v.rv_in;
   rp.rk_out = v.rk_out; rp.rv_out = v.rv_out; rp.re_sorted = v.re_sorted; rp.re_top = v.re_top; rp.R = R;
+  rp.rs_mid = v.rs_mid; rp.re_mid = v.re_mid;
   rp.fs2 = dalloc<uint64_t>(b, R + 1); rp.fe2 = dalloc<uint64_t>(b, R + 1);
   v.tr_start = upload_vec(b, b->h_trs); v.tr_end = upload_vec(b, b->h_tre); v.tr_pmax = upload_vec(b, b->h_trp);
   v.nm_start = nullptr; v.nm_end = nullptr; v.t_nm_off = nullptr; v.t_cov_exact = nullptr;
@@ -1223,6 +1228,18 @@ void enqueue_read_prep(snf_batch_impl* b) {
   }
 }
 
+// the five coverage samples of every call: a thread per (call, sample) over a grid that covers a genome's calls in one round
+// (d4s_coverage, snf_wave_call.h); SNF_D4=thread: the former thread-per-call kernel with its hinted binary searches
+void launch_coverage(snf_batch_impl* b, int64_t N) {
+  View& v = b->v;
+  static const bool per_call = getenv("SNF_D4") && strcmp(getenv("SNF_D4"), "thread") == 0;
+  if (per_call || !v.wave_path) { LAUNCH(d4_coverage, v, N, 0); return; }
+  Scope _s(b, "d4_coverage", 0);
+  int64_t grid = (5 * N + 255) / 256; if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(d4s_coverage, dim3((unsigned)grid), dim3(256), 0, b->cur, v, (int64_t)0);
+  SNF_HIP(hipGetLastError());
+}
+
 // start of a pass: every small reset (one launch on the fused path)
 void enqueue_pass_init(snf_batch_impl* b) {
   View& v = b->v;
@@ -1464,7 +1481,7 @@ void run_call_candidates(snf_batch_impl* b) {
       b->cur = prev;
     }
     SideStream side(b);
-    if (N > 0) LAUNCH(d4_coverage, v, N, 0);
+    if (N > 0) launch_coverage(b, N);
   } else
   {
     SideStream side(b);
@@ -1474,7 +1491,7 @@ void run_call_candidates(snf_batch_impl* b) {
       LAUNCH(d3_rnames, v, N, 0);
     } else *b->h_rn_total = 0;
     SNF_HIP(hipEventRecord(b->ev_rn, b->cur));
-    if (N > 0) LAUNCH(d4_coverage, v, N, 0);
+    if (N > 0) launch_coverage(b, N);
   }
   b->res_current = false;
   v.out_valid = 0;

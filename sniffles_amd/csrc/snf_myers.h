@@ -208,6 +208,140 @@ __device__ inline int64_t ed_wave_pair_k(const uint8_t* A, int64_t la, const uin
   return (k >= 0 && dist > k) ? -1 : dist;
 }
 
+// ---- the same banded wavefront for patterns over {A, C, G, T} (what an insertion's ALT is; anything else - 'N', lower case, a
+// symbolic "<DEL>" - takes ed_wave_pair_k above).  What bounds a window of kilobase insertions is the LATENCY of one column step of
+// one wave (the pairs of a window are evaluated one after the other: an accepted candidate moves its group's means), so the step is
+// cut down to what Myers' recurrence needs:
+//   * Peq[code] (edlib's per-symbol match vectors, code = (c >> 1) & 3: A 0, C 1, T 2, G 3) built once per block instead of a match
+//     mask rebuilt from eight bit-planes per column: three 64-bit selects instead of eight selects + eight ANDs; a text byte that is
+//     not one of the four letters matches nothing;
+//   * hout -> hin as two bits (plus, minus) ORed into the vectors - no compares - and handed to the next lane by a DPP wave rotate
+//     (v_mov_b32_dpp wave_ror:1, a VALU move) instead of a ds_bpermute round trip through the LDS crossbar;
+//   * 32-bit column bookkeeping (strings are shorter than 2^30 here; the caller checks).
+SNF_D uint32_t ed_acgt_code(uint32_t c) { return (c >> 1) & 3u; }
+SNF_D bool ed_is_acgt(uint32_t c) { return ((0x47544341u >> (8 * ed_acgt_code(c))) & 0xffu) == c; }
+// all n bytes of p in {A, C, G, T}?  (whole wave; reads up to 7 bytes past p + n)
+__device__ inline bool ed_wave_all_acgt(const uint8_t* p, int32_t n) {
+  const int lane = (int)(threadIdx.x & 63);
+  bool ok = true;
+  for (int32_t o = lane * 8; o < n; o += 64 * 8) {
+    uint64_t x = *(const ed_u64_unaligned*)(p + o);
+    const int cnt = n - o < 8 ? n - o : 8;
+    for (int q = 0; q < cnt; q++, x >>= 8) ok = ok && ed_is_acgt((uint32_t)(x & 0xffu));
+  }
+  return __ballot(!ok) == 0ull;
+}
+// Peq of the 64 pattern bytes at p (cnt valid): pe[code] bit i = (p[i] == letter(code)).  Reads up to 7 bytes past p + cnt.
+__device__ inline void block_peq_words(const uint8_t* p, int cnt, uint64_t pe[4]) {
+  pe[0] = pe[1] = pe[2] = pe[3] = 0;
+  for (int w = 0; w * 8 < cnt; w++) {
+    const uint64_t x = *(const ed_u64_unaligned*)(p + 8 * w);
+#pragma unroll
+    for (int z = 0; z < 4; z++) {
+      const uint64_t y = x ^ (0x0101010101010101ull * (uint64_t)((0x47544341u >> (8 * z)) & 0xffu));   // zero byte <=> that letter
+      uint64_t t = (y & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full;
+      t = ~(t | y | 0x7f7f7f7f7f7f7f7full);                                                              // 0x80 in every zero byte
+      pe[z] |= (((t >> 7) * 0x0102040810204080ull) >> 56) << (8 * w);
+    }
+  }
+  const uint64_t valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+  pe[0] &= valid; pe[1] &= valid; pe[2] &= valid; pe[3] &= valid;
+}
+// one block, one column; h = horizontal delta as bits: 1 plus, 2 minus
+SNF_D uint32_t advance_block2(uint64_t& Pv, uint64_t& Mv, uint64_t Eq, uint32_t hin) {
+  const uint64_t hm = (uint64_t)(hin >> 1), hp = (uint64_t)(hin & 1u);
+  const uint64_t Xv = Eq | Mv;
+  Eq |= hm;
+  const uint64_t Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+  uint64_t Ph = Mv | ~(Xh | Pv);
+  uint64_t Mh = Pv & Xh;
+  const uint32_t hout = (uint32_t)(Ph >> 63) | ((uint32_t)(Mh >> 63) << 1);
+  Ph = (Ph << 1) | hp; Mh = (Mh << 1) | hm;
+  Pv = Mh | ~(Xv | Ph);
+  Mv = Ph & Xv;
+  return hout;
+}
+SNF_D int32_t ed_band_cs32(int32_t kk, int32_t b) { const int32_t c = 64 * b - kk; return c < 0 ? 0 : c; }
+SNF_D int32_t ed_band_ce32(int32_t kk, int32_t dl, int32_t n, int32_t b) { const int32_t c = 64 * b + 63 + dl + kk; return c > n - 1 ? n - 1 : c; }
+// P (m bytes, all of them A/C/G/T, m <= n < 2^30) against T; same contract as ed_wave_pair_k
+__device__ inline int64_t ed_wave_pair_k_acgt(const uint8_t* P, int32_t m, const uint8_t* T, int32_t n, int64_t k) {
+  const int lane = (int)(threadIdx.x & 63);
+  EdBand bd;
+  if (!ed_band((int64_t)m, (int64_t)n, k, &bd)) return -1;
+  if (m == 0) return n;
+  const int32_t nb = (m + 63) / 64, kk = (int32_t)bd.kk, dl = (int32_t)bd.dl;
+  int32_t b = lane;
+  int32_t cs = 0, ce = -1, nxt_cs = 0, ce_up = -1;   // ce_up: last column the block above is in the band for (-1: none above)
+  uint64_t pe[4] = {0, 0, 0, 0}, Pv = ~0ull, Mv = 0;
+  uint64_t tw = 0, tw_next = 0; int32_t jb = 0;
+  auto enter = [&](int32_t blk) {
+    b = blk;
+    if (b < nb) {
+      const int cnt = m - b * 64 < 64 ? m - b * 64 : 64;
+      block_peq_words(P + b * 64, cnt, pe);
+      cs = ed_band_cs32(kk, b); ce = ed_band_ce32(kk, dl, n, b);
+      nxt_cs = b + 1 < nb ? ed_band_cs32(kk, b + 1) : n;
+      ce_up = b > 0 ? ed_band_ce32(kk, dl, n, b - 1) : -1;
+      Pv = ~0ull; Mv = 0;
+      jb = cs; tw = *(const ed_u64_unaligned*)(T + jb); tw_next = *(const ed_u64_unaligned*)(T + jb + 8);
+    } else { cs = 0; ce = -1; nxt_cs = 0; ce_up = -1; }
+  };
+  enter(lane);
+  int32_t acc = 0, rel = 0, own = 0;     // as in ed_wave_pair_k (sums of +-1 over at most n columns: 32 bits)
+  uint32_t hout = 0;
+  uint64_t fPv = ~0ull, fMv = 0; int32_t frel = 0; bool fin = false;
+  const int32_t steps = n + nb - 1;
+  for (int32_t t = 0; t < steps; t++) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x13C, 0xf, 0xf, false);   // wave_ror:1: lane - 1, lane 0 <- 63
+    const int32_t j = t - b;
+    if (j >= cs && j <= ce) {               // (a lane without a block holds ce = -1 < cs = 0)
+      const uint32_t hin = j <= ce_up ? up : 1u;
+      if (j - jb >= 8) { jb += 8; tw = tw_next; tw_next = *(const ed_u64_unaligned*)(T + jb + 8); }
+      const uint32_t c = (uint32_t)(tw >> (8 * (j - jb))) & 0xffu;
+      const uint32_t cd = ed_acgt_code(c);
+      const uint64_t e01 = (cd & 1u) ? pe[1] : pe[0], e23 = (cd & 1u) ? pe[3] : pe[2];
+      uint64_t eq = (cd & 2u) ? e23 : e01;
+      if (!ed_is_acgt(c)) eq = 0;
+      hout = advance_block2(Pv, Mv, eq, hin);
+      const int32_t dh = (int32_t)(hout & 1u) - (int32_t)(hout >> 1);
+      rel += dh;
+      if (j < nxt_cs) own += dh;
+      if (j == ce) {
+        if (b == nb - 1) { fPv = Pv; fMv = Mv; frel = rel; fin = true; }
+        else acc += 64 + own;
+        rel = 0; own = 0;
+        enter(b + 64);
+      }
+    }
+  }
+  int64_t tot = (int64_t)acc + (fin ? frel : 0);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  const int owner = (int)((nb - 1) & 63);
+  const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
+  const int64_t dist = unpad_score(64 + tot, oPv, oMv, (int)(nb * 64 - m));
+  return (k >= 0 && dist > k) ? -1 : dist;
+}
+// the banded wave form for any pair the band of which fits (ed_wave_band_fits): equal strings answer at once, patterns over
+// {A, C, G, T} take the short column step, everything else the bit-plane form
+__device__ inline int64_t ed_wave_pair_k_any(const uint8_t* A, int64_t la, const uint8_t* B, int64_t lb, int64_t k) {
+  const uint8_t *P = A, *T = B; int64_t m = la, n = lb;
+  if (la > lb) { P = B; m = lb; T = A; n = la; }
+  if (n >= ((int64_t)1 << 30)) return ed_wave_pair_k(A, la, B, lb, k);
+  if (m == n) {   // identical strings (every symbolic ALT of a type, a shared allele): distance 0 without a column step
+    const int lane = (int)(threadIdx.x & 63);
+    bool same = true;
+    for (int64_t o = (int64_t)lane * 8; o < m && same; o += 64 * 8) {
+      uint64_t x = *(const ed_u64_unaligned*)(P + o), y = *(const ed_u64_unaligned*)(T + o);
+      if (m - o < 8) { const uint64_t keep = (1ull << (8 * (m - o))) - 1ull; x &= keep; y &= keep; }
+      same = x == y;
+    }
+    if (__ballot(!same) == 0ull) return 0;
+  }
+  if (ed_wave_all_acgt(P, (int32_t)m)) return ed_wave_pair_k_acgt(P, (int32_t)m, T, (int32_t)n, k);
+  return ed_wave_pair_k(A, la, B, lb, k);
+}
+
 // the same distance computed by one whole wave (all 64 lanes must call it together): lane = 64-row block of the current
 // 64-block pass, anti-diagonal schedule (lane l works on column t - l at step t and takes hin from lane l-1 by a
 // shuffle); patterns of more than 64 blocks take several passes linked through `carry` (>= max(la, lb) bytes)

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) ed_wave(const EdView v, int64_t n_items) {
     pair_strings(v, pi, &P, &m, &T, &n);
     const int64_t k = v.kmax ? (int64_t)v.kmax[pi] : -1;
     int64_t d;
-    if (ed_wave_band_fits(m, n, k)) d = ed_wave_pair_k(P, m, T, n, k);
+    if (ed_wave_band_fits(m, n, k)) d = ed_wave_pair_k_any(P, m, T, n, k);
     else { d = ed_wave_pair(P, m, T, n, v.carry + v.carry_off[pi]); if (k >= 0 && d > k) d = -1; }
     if (lane == 0) v.out[pi] = (int32_t)d;
   }

@@ -571,6 +571,39 @@ SNF_HD bool cov_get_near(const View& v, int t, int64_t idx, int32_t* out, int64_
   return true;
 }
 
+// d4s_coverage: a thread per (call, sample) - 5 x 2 independent rank queries per call run side by side instead of one thread walking
+// them in turn (a pass has ~94 k calls: 1.4 waves per SIMD with a thread per call, nothing to hide the chain behind) - and every query
+// a 16-ary descent (snf_exact.h::rank_upper_16ary).  Same five samples, same quirks (postprocessing.py:69-130): numpy's negative
+// index, an out-of-range sample keeps the field's value, a BND takes `end` from the last non-BND call before it.
+SNF_HD void d4s_sample_body(int64_t q, const View& v) {
+  const int64_t i = q / 5; const int k = (int)(q - 5 * i);
+  snf_call_t& c = v.calls[i];
+  const int t = c.task_index;
+  if (v.t_status[t] != SNF_TASK_OK) return;
+  const int64_t bs = v.cfg.coverage_binsize, ud = v.cfg.coverage_updown_bins;
+  const int svtype = c.svtype;
+  int64_t start = c.pos, end;
+  if (svtype == SNF_INS) end = start + 1;
+  else if (svtype == SNF_BND) { if (c.bnd_is_first) start -= 1; end = v.t_stale_end[t]; }
+  else end = (int64_t)c.pos + iabs64(c.svlen);
+  const bool point = svtype == SNF_INS || svtype == SNF_BND;
+  int64_t idx;
+  switch (k) {
+    case 0: idx = start - bs * ud; break;
+    case 1: idx = point ? start - bs : start; break;
+    case 2: idx = point ? start : (start + end) / 2; break;
+    case 3: idx = point ? end + bs : end - bs; break;
+    default: idx = end + bs * ud; break;
+  }
+  const int64_t len = v.t_contig_len[t];
+  if (idx < -len || idx >= len) return;        // IndexError: the field keeps its value
+  if (idx < 0) idx += len;                      // numpy negative index
+  const int64_t lo = v.t_read_off[t], hi = v.t_read_off[t + 1];
+  const int64_t ps = rank_upper_16ary(v.r_start, v.rs_mid, v.rs_top, lo, hi, idx);
+  const int64_t pe = rank_upper_16ary(v.re_sorted, v.re_mid, v.re_top, lo, hi, idx);
+  c.cov[k] = view_masked(v, t, idx) ? 0 : (int32_t)((uint64_t)(ps - pe) & 0xffffu);
+}
+
 SNF_HD void d4_coverage_body(int64_t i, const View& v) {
   if (i >= v.cnt->n_calls) return;
   snf_call_t& c = v.calls[i];

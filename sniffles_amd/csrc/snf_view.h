@@ -155,6 +155,7 @@ struct View {
   uint64_t *rk_in, *rk_out; uint32_t *rv_in, *rv_out;  // end-sort scratch
   int32_t* re_sorted;        // [R] ends, ascending per task
   int32_t *rs_top, *re_top;  // every 256th entry of r_start / re_sorted (top level of the rank queries)
+  int32_t *rs_mid, *re_mid;  // every 16th entry (the 16-ary descent of the pass's coverage queries, snf_exact.h::rank_upper_16ary)
   uint64_t* pc_s2;           // [R+1] prefix counts in start order: #(hp == 1) << 32 | #(hp == 2)
   uint64_t* pc_e2;           // [R+1] same in end order
   uint32_t* rflag;           // [R+1] scan scratch

@@ -381,6 +381,13 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
   }
 }
 
+// ------------------------------------------------------------------------------------------ d4s: the five coverage samples of every call
+// (snf_stage_call.h::d4s_sample_body) over a grid that does not depend on the number of calls (known on the device only)
+__global__ void __launch_bounds__(256) d4s_coverage(const View v, int64_t n_unused) {
+  const int64_t n = 5 * (int64_t)v.cnt->n_calls;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) d4s_sample_body(q, v);
+}
+
 // ------------------------------------------------------------------------------------------ d5w: coverage.mean()
 // numerator of coverage.mean() (exact integer sum of the clipped read lengths per task): coalesced loads and one
 // atomic per block.  Reads are grouped by task, so a 4096-read chunk almost always belongs to one task; the few

@@ -174,6 +174,39 @@ def test_no_undefined_behaviour_in_the_kernels(simt, oracle_mod, capfd):
     assert "runtime error" not in err, err[-3000:]
 
 
+def _with_reads(ti, n_reads, seed, max_len=1500):
+    """`ti` with `n_reads` more alignment records (read table only: coverage and REF haplotype counts), starts kept sorted."""
+    rng = np.random.default_rng([seed, 991])
+    L = int(ti.contig_len)
+    rs = rng.integers(0, max(1, L - 10), n_reads)
+    re_ = np.minimum(L, rs + rng.integers(50, max_len, n_reads))
+    hp = rng.integers(0, 3, n_reads).astype(np.uint8)
+    start = np.concatenate([ti.read_start.astype(np.int64), rs]); end = np.concatenate([ti.read_end.astype(np.int64), re_])
+    hps = np.concatenate([ti.read_hp, hp])
+    o = np.argsort(start, kind="stable")
+    ti.read_start, ti.read_end, ti.read_hp = (np.ascontiguousarray(start[o], np.int32), np.ascontiguousarray(end[o], np.int32),
+                                              np.ascontiguousarray(hps[o], np.uint8))
+    return ti
+
+
+@pytest.mark.parametrize("d4", [None, "thread"])
+def test_coverage_samples_over_large_read_tables(d4, simt, oracle_mod, monkeypatch):
+    """The five coverage samples of every call (d4s_coverage: a thread per sample, rank queries as a 16-ary descent over sampled
+    levels of the GLOBAL read arrays, snf_exact.h::rank_upper_16ary) on read tables that reach every level: task segments that start
+    at unaligned offsets, cross 4096- and 65536-entry boundaries, hold fewer than 16 reads, end in a partial node; runs of equal
+    starts; samples left and right of every read.  SNF_D4=thread: the former thread-per-call kernel stays selectable."""
+    if d4:
+        monkeypatch.setenv("SNF_D4", d4)
+    sizes = (3, 4090, 9, 70_001, 12_345, 17)
+    tis = [_with_reads(synth.gen_fuzz(900 + k, task_id=k, n_leads=300), n, k) for k, n in enumerate(sizes)]
+    tis[3].read_start[1000:1400] = tis[3].read_start[1000]            # a run of equal starts across node borders
+    tis[3].read_end[2000:2300] = int(tis[3].read_start[2299]) + 100   # ... and of equal ends
+    cfg = SnifflesConfig()
+    got = records.records(run(simt.lib(), cfg, tis, True), tis, "final")
+    assert got == records.records(oracle_mod.run(cfg, tis, True), tis, "final")
+    assert sum(len(g) for g in got) > 50
+
+
 def test_random_option_sets(simt, oracle_mod):
     """tools/dev/cfgfuzz.py: random combinations of some sixty hot-path options (filters, cluster / merge widths, mosaic and
     developer switches), three adversarial tasks each.  oracle/ref_cfgfuzz.py holds the oracle against the unmodified
