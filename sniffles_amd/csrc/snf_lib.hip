@@ -16,6 +16,10 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <map>
 #include <tuple>
@@ -294,7 +298,8 @@ struct snf_batch_impl {
   std::map<std::tuple<void*, void*, int>, PassGraph> graphs;   // key: (result block, ALT block, output mode)
   int graph_mode = 0;             // set at upload: 2 = replay (small batches, or SNF_GRAPH=1), 0 = eager, 1 = replay only while no other batch of
                                   // this process has a pass in flight
-  bool in_flight = false;         // counted in g_passes_in_flight
+  bool in_flight = false;         // counted in its device's DevicePacing::passes_in_flight
+  int slot_fd = -1;               // the GPU slot this pass holds (SNF_GPU_SLOTS)
   double pass_start_ms = 0.0;     // when this handle's pass in flight began (pacing of overlapping passes)
   bool capturing = false;         // run_pass is capturing this pass into a graph
   // Result staged through HBM (run_finalize): with another pass in flight on the device the kernels of a pass store the result block
@@ -1126,36 +1131,70 @@ void do_upload(snf_batch_impl* b) {
 // ---------------------------------------------------------------------------------------------- pipeline
 // passes that have been enqueued and not yet waited for, over all handles of the process (a pass = snf_batch_pass, or
 // call_candidates .. the fetch / sync that waits for it)
-std::atomic<int> g_passes_in_flight{0};
-std::atomic<long long> g_last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
+// All of it is state of ONE device (what overlaps is the work on that device and the traffic on its PCIe link): a process that drives
+// several devices from one handle each must not see one device's passes switch another device's handle to the staged result or pace
+// its starts (tests/test_output_modes.py::test_pacing_state_is_per_device).
+struct DevicePacing {
+  std::atomic<int> passes_in_flight{0};
+  std::atomic<long long> last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
+  std::mutex copy_mu, pace_mu;
+  double last_pass_start_ms = -1e12, pass_latency_ms = 0.0;      // (under pace_mu) start of the latest pass; smoothed enqueue -> waited time
+};
+DevicePacing g_pacing[SNF_MAX_DEVICES];
+DevicePacing& pacing_of(const snf_batch_impl* b) { return g_pacing[(b->device >= 0 && b->device < SNF_MAX_DEVICES) ? b->device : 0]; }
 // Pacing of overlapping passes.  Two passes in flight run best OUT OF PHASE - one computes while the other's result crosses PCIe
 // (staged result, run_finalize).  Left alone, two host threads fall into step in about one run of five and stay there: both passes start
 // together, share the device through all their kernels, reach their copies together and share the link too - 1.24-1.38 ms per step
 // instead of 0.95-1.0 (profiles/r05_pace.log: 2 of 10 runs; 3 of 12 in ab_r05_5.log).  Two cheap rules keep them apart, each sufficient
-// in 8 of 8 runs, both together the default: (1) the copies of a staged result are taken one pass at a time (g_copy_mu: the link is
+// in 8 of 8 runs, both together the default: (1) the copies of a staged result are taken one pass at a time (copy_mu: the link is
 // shared anyway; the pass that waited starts its next pass later - a stagger), (2) a pass does not START sooner than a quarter of the
 // recent pass latency after the other in-flight pass did (the second of two simultaneous starts waits ~0.4 ms once; passes that are
 // half a period apart never wait).  SNF_PACE=0 turns both off (2: rule 1 only, 3: rule 2 only), SNF_PACE_FRAC sets the fraction.
-std::mutex g_copy_mu, g_pace_mu;
-double g_last_pass_start_ms = -1e12, g_pass_latency_ms = 0.0;      // (under g_pace_mu) start of the latest pass; smoothed enqueue -> waited time
 int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : 1; return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
 bool pace_on() { return pace_mode() == 1 || pace_mode() == 3; }
 bool pace_copy_turn() { return pace_mode() == 1 || pace_mode() == 2; }
 double pace_frac() { static const double f = getenv("SNF_PACE_FRAC") ? atof(getenv("SNF_PACE_FRAC")) : 0.25; return f; }
+// GPU slots (SNF_GPU_SLOTS=n, off by default): at most n passes - of any process of this user - drive a device at a time.  The
+// reference's deployment is a pool of worker PROCESSES (one per contig at most: 24); each of them brings its own HIP context, and the
+// hardware schedules a limited number of queues: two dozen processes with four streams each are time-sliced by the driver and a
+// pass that takes a millisecond alone takes tens (profiles/r05_workers_hw_queues.log).  A slot is an exclusive lock on one of n
+// files under /dev/shm, taken when a pass is enqueued and dropped when its result has been waited for: the workers' host work -
+// records into objects - goes on beside the n passes that hold the device.
+int gpu_slots() { static const int n = getenv("SNF_GPU_SLOTS") ? atoi(getenv("SNF_GPU_SLOTS")) : 0; return n; }
+int slot_acquire(int device) {
+  const int n = gpu_slots();
+  if (n <= 0) return -1;
+  char path[160];
+  const int start = (int)((unsigned)getpid() % (unsigned)n);
+  for (int k = 0; k < n; k++) {       // any free slot, starting at one that depends on the process
+    snprintf(path, sizeof path, "/dev/shm/snf_gpu_slot_%u_d%d_%d", (unsigned)getuid(), device, (start + k) % n);
+    const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+    if (fd < 0) return -1;
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) return fd;
+    close(fd);
+  }
+  snprintf(path, sizeof path, "/dev/shm/snf_gpu_slot_%u_d%d_%d", (unsigned)getuid(), device, start);
+  const int fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+  if (fd < 0) return -1;
+  while (flock(fd, LOCK_EX) != 0) if (errno != EINTR) { close(fd); return -1; }
+  return fd;
+}
 void pass_begins(snf_batch_impl* b) {
   if (b->in_flight) return;
   b->in_flight = true;
-  const bool other = g_passes_in_flight.fetch_add(1) >= 1;
-  if (other) g_last_overlap_ms.store((long long)now_ms());
+  if (b->slot_fd < 0) b->slot_fd = slot_acquire(b->device);
+  DevicePacing& P = pacing_of(b);
+  const bool other = P.passes_in_flight.fetch_add(1) >= 1;
+  if (other) P.last_overlap_ms.store((long long)now_ms());
   if (!pace_on()) { b->pass_start_ms = now_ms(); return; }
   double wait = 0.0;
   {
-    std::lock_guard<std::mutex> g(g_pace_mu);
+    std::lock_guard<std::mutex> g(P.pace_mu);
     const double now = now_ms();
-    if (other && g_pass_latency_ms > 0.0) wait = g_last_pass_start_ms + pace_frac() * g_pass_latency_ms - now;
+    if (other && P.pass_latency_ms > 0.0) wait = P.last_pass_start_ms + pace_frac() * P.pass_latency_ms - now;
     if (wait > 2.0) wait = 2.0;                 // (never more than 2 ms, whatever the history says)
     if (wait < 0.0) wait = 0.0;
-    g_last_pass_start_ms = now + wait;          // (the slot is taken; the wait itself happens outside the lock)
+    P.last_pass_start_ms = now + wait;          // (the slot is taken; the wait itself happens outside the lock)
   }
   if (wait > 0.0) { struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = (long)(wait * 1e6); nanosleep(&ts, nullptr); }
   b->pass_start_ms = now_ms();
@@ -1163,16 +1202,21 @@ void pass_begins(snf_batch_impl* b) {
 void pass_waited(snf_batch_impl* b) {
   if (!b->in_flight) return;
   b->in_flight = false;
-  if (g_passes_in_flight.fetch_sub(1) >= 2) g_last_overlap_ms.store((long long)now_ms());
+  if (b->slot_fd >= 0) { close(b->slot_fd); b->slot_fd = -1; }
+  DevicePacing& P = pacing_of(b);
+  if (P.passes_in_flight.fetch_sub(1) >= 2) P.last_overlap_ms.store((long long)now_ms());
   if (pace_on() && b->pass_start_ms > 0.0) {
-    std::lock_guard<std::mutex> g(g_pace_mu);
+    std::lock_guard<std::mutex> g(P.pace_mu);
     const double lat = now_ms() - b->pass_start_ms;
-    g_pass_latency_ms = g_pass_latency_ms > 0.0 ? 0.75 * g_pass_latency_ms + 0.25 * lat : lat;
+    P.pass_latency_ms = P.pass_latency_ms > 0.0 ? 0.75 * P.pass_latency_ms + 0.25 * lat : lat;
   }
 }
 // is this process driving several passes at a time?  (Asked when a pass is enqueued: the other handle may be between its fetch and its
 // next pass at that very moment - what counts is whether passes overlapped a moment ago.)
-bool passes_overlap() { return g_passes_in_flight.load() > 1 || (long long)now_ms() - g_last_overlap_ms.load() < 100; }
+bool passes_overlap(const snf_batch_impl* b) {
+  DevicePacing& P = pacing_of(b);
+  return P.passes_in_flight.load() > 1 || (long long)now_ms() - P.last_overlap_ms.load() < 100;
+}
 void reset_timing(snf_batch_impl* b) {
   b->ev_used = 0;
   b->timings.clear();
@@ -1617,7 +1661,7 @@ void enqueue_consensus_wave(snf_batch_impl* b, int64_t g_small, int64_t g_large,
   // pass in flight that pass fills the tails instead (two in flight: 1.238 against 1.242).  So: 2 when another pass is in flight on
   // the device, 0 otherwise; SNF_CONS_ORDER forces one (1 = SMALL behind LARGE: slower than both).
   const int order_env = getenv("SNF_CONS_ORDER") ? atoi(getenv("SNF_CONS_ORDER")) : -1;
-  const int order = order_env >= 0 ? order_env : (g_passes_in_flight.load() > 1 ? 2 : 0);
+  const int order = order_env >= 0 ? order_env : (pacing_of(b).passes_in_flight.load() > 1 ? 2 : 0);
   auto launch_large = [&]() {
     Scope _s(b, "e45w_consensus_large", 0, true);
     const dim3 gl((unsigned)(g_large < b->slots_cons_l ? g_large : b->slots_cons_l));
@@ -1698,7 +1742,7 @@ void run_finalize(snf_batch_impl* b) {
     // other pass's compute (same box, two in flight: 0.945 ms per step against 1.17; one in flight 1.48 against 1.36 - hence the
     // switch).  SNF_STAGE_OUT=1 / 0 force either.  (Not while a pass is captured: a replayed graph keeps the direct stores.)
     const int stage_env = getenv("SNF_STAGE_OUT") ? atoi(getenv("SNF_STAGE_OUT")) : -1;
-    const bool stage = !(v.out_mode & SNF_OUT_DEVICE) && !b->capturing && (stage_env == 1 || (stage_env < 0 && passes_overlap()));
+    const bool stage = !(v.out_mode & SNF_OUT_DEVICE) && !b->capturing && (stage_env == 1 || (stage_env < 0 && passes_overlap(b)));
     const char* copy_env = getenv("SNF_STAGE_COPY");
     b->staged = stage; b->staged_kernel = stage && copy_env && strcmp(copy_env, "kernel") == 0;
     b->stage_block_copied = b->stage_alt_copied = false;
@@ -1817,7 +1861,7 @@ void run_finalize(snf_batch_impl* b) {
 // key the graph.  Kernels take the pass-dependent state (counters, chain tags, window cursors) from HBM.
 bool pass_graph_ok(snf_batch_impl* b) {
   const View& v = b->v;
-  if (b->graph_mode == 1 && g_passes_in_flight.load() > 1) return false;      // (this batch itself is counted)
+  if (b->graph_mode == 1 && pacing_of(b).passes_in_flight.load() > 1) return false;      // (this batch itself is counted)
   return b->graph_mode && !b->graph_failed && b->have_hist && b->fused && v.front && v.wave_path && !b->timeline && !b->time_all &&
          v.NS > 0 && !b->readprep_each_pass && getenv("SNF_SERIAL") == nullptr;
 }
@@ -2020,7 +2064,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
     const bool alt_there = !b->h_cnt->alt_in_pinned && b->staged_kernel && b->stage_alt_copied && !alt_late && v.stage_alt_pin == (uint8_t*)b->hb_alt.p && alt_total_now <= v.stage_alt_cap;
     bool need_sync = false;
     // (the copies of a staged result: one pass at a time - see pass_begins)
-    std::unique_lock<std::mutex> copy_turn(g_copy_mu, std::defer_lock);
+    std::unique_lock<std::mutex> copy_turn(pacing_of(b).copy_mu, std::defer_lock);
     if (b->staged && pace_copy_turn() && ((!h.in_pinned && !block_there) || (!b->h_cnt->alt_in_pinned && !alt_there))) copy_turn.lock();
     if (!h.in_pinned && !block_there) {
       v.out_pin = nullptr; v.out_pin_cap = 0;   // (a larger pinned block replaces the old one: the next finalize takes it)

@@ -26,6 +26,7 @@ static PyObject *I_CHR2, *I_SUPPORT_LONG, *I_SUPPORT_SA, *I_STDEV_POS, *I_STDEV_
 static PyObject *F_n, *F_m1, *F_m2, *F_last;
 static PyObject *S_dot, *S_comma, *O_zero, *T_none2, *I_COVERAGE;
 static PyObject *B_mate_contig, *B_mate_ref_start, *B_is_first, *B_is_reverse, *P_batch, *P_index, *S_NULL, *S_PASS, *S_FAIL;
+static PyObject *K_class, *K_lz, *K_lzi;
 
 static int set_steal(PyObject* d, PyObject* k, PyObject* v) {   /* d[k] = v, steals v */
   if (!v) return -1;
@@ -94,18 +95,26 @@ static PyObject* ps_str(int code, PyObject* ps_names) {       /* records._ps_str
 /* materialize(svcall_cls, bnd_cls, fds_cls, post_cls | None, batch | None, calls: buffer, lo, hi, rnames: buffer(uint32),
  *             qnames: list | None, contig: str, task_id: int, contig_names: list | None, filters: list[str]) -> list */
 static PyObject* py_materialize(PyObject* self, PyObject* args) {
-  PyObject *cls, *bnd_cls, *fds_cls, *post_cls, *batch, *qnames, *contig, *contig_names, *filters;
-  Py_buffer calls, rn;
+  PyObject *cls, *bnd_cls, *fds_cls, *post_cls, *batch, *qnames, *contig, *contig_names, *filters, *targets = NULL;
+  Py_buffer calls, rn, idx; idx.buf = NULL; idx.obj = NULL; idx.len = 0;
   long long lo, hi, task_id;
-  if (!PyArg_ParseTuple(args, "OOOOOy*LLy*OOLOO", &cls, &bnd_cls, &fds_cls, &post_cls, &batch, &calls, &lo, &hi, &rn, &qnames, &contig,
-                        &task_id, &contig_names, &filters))
+  /* the two optional arguments: `idx` (int64 record indices relative to lo; the calls built are those records, in that order) and
+   * `targets` (existing objects - the lazy stand-ins of sv.py - that BECOME those calls: their instance dict is replaced and their
+   * class set to `cls`; the list returned holds them) */
+  if (!PyArg_ParseTuple(args, "OOOOOy*LLy*OOLOO|y*O", &cls, &bnd_cls, &fds_cls, &post_cls, &batch, &calls, &lo, &hi, &rn, &qnames, &contig,
+                        &task_id, &contig_names, &filters, &idx, &targets))
     return NULL;
   PyObject *out = NULL, *tmpl = NULL;
   if (lo < 0 || hi < lo || (size_t)hi * sizeof(snf_call_t) > (size_t)calls.len) { PyErr_SetString(PyExc_ValueError, "call range outside the record table"); goto done; }
   const snf_call_t* C = (const snf_call_t*)calls.buf;
   const uint32_t* RN = (const uint32_t*)rn.buf;
   const long long rn_n = rn.len / 4;
-  out = PyList_New(hi - lo);
+  const int64_t* IDX = idx.buf ? (const int64_t*)idx.buf : NULL;
+  const long long n_out = IDX ? (long long)(idx.len / 8) : hi - lo;
+  if (targets == Py_None) targets = NULL;
+  if (targets && (!PyList_Check(targets) || PyList_GET_SIZE(targets) != n_out)) { PyErr_SetString(PyExc_ValueError, "targets do not match the records"); goto done; }
+  for (long long k = 0; IDX && k < n_out; k++) if (IDX[k] < 0 || IDX[k] >= hi - lo) { PyErr_SetString(PyExc_ValueError, "record index outside the range"); goto done; }
+  out = PyList_New(n_out);
   if (!out) goto done;
   /* the instance dict of a call: 33 attributes in the dataclass's order.  A template holds the keys and the eight values that are the
    * same for every call of the task; a call's dict is a copy of it (one allocation, no inserts) with the other 25 values replaced */
@@ -117,7 +126,8 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
     for (int k = 0; tmpl && k < 33; k++) if (PyDict_SetItem(tmpl, keys33[k], keys33[k] == K_contig ? contig : keys33[k] == K_ref ? S_N : Py_None)) Py_CLEAR(tmpl);
     if (!tmpl) goto fail;
   }
-  for (long long i = lo; i < hi; i++) {
+  for (long long kk = 0; kk < n_out; kk++) {
+    const long long i = lo + (IDX ? IDX[kk] : kk);
     const snf_call_t* c = &C[i];
     if (c->svtype < 0 || c->svtype > 6 || c->filter < 0 || c->filter >= PyList_GET_SIZE(filters)) { PyErr_SetString(PyExc_ValueError, "record field out of range"); goto fail; }
     PyObject* d = PyDict_Copy(tmpl);
@@ -202,9 +212,19 @@ static PyObject* py_materialize(PyObject* self, PyObject* args) {
             set_steal(d, K_cov_en, PyLong_FromLong(c->cov[3])) || (bi != Py_None && PyDict_SetItem(d, K_bnd_info, bi));
     Py_XDECREF(info); Py_XDECREF(alt); Py_XDECREF(bi); Py_XDECREF(names); Py_XDECREF(fds); Py_XDECREF(post);
     if (bad) { Py_DECREF(d); goto fail; }
-    PyObject* obj = new_instance(cls, d);
-    if (!obj) goto fail;
-    PyList_SET_ITEM(out, i - lo, obj);
+    PyObject* obj;
+    if (targets) {       /* the stand-in becomes the call: its dict is replaced, its class set through object's own __class__ setter */
+      obj = PyList_GET_ITEM(targets, kk);
+      PyObject** dp = _PyObject_GetDictPtr(obj);
+      if (!dp) { Py_DECREF(d); PyErr_SetString(PyExc_TypeError, "target without an instance dict"); goto fail; }
+      PyObject* old = *dp; *dp = d; Py_XDECREF(old);
+      if ((PyObject*)Py_TYPE(obj) != cls && PyObject_GenericSetAttr(obj, K_class, cls) != 0) goto fail;
+      Py_INCREF(obj);
+    } else {
+      obj = new_instance(cls, d);
+      if (!obj) goto fail;
+    }
+    PyList_SET_ITEM(out, kk, obj);
   }
   goto done;
 fail:
@@ -212,7 +232,53 @@ fail:
 done:
   Py_XDECREF(tmpl);
   PyBuffer_Release(&calls); PyBuffer_Release(&rn);
+  if (idx.obj) PyBuffer_Release(&idx);
   return out;
+}
+
+/* make_stubs(lazy_cls, src, records: buffer, lo, hi) -> list: the stand-ins of sv.py's lazy calls, one per record of [lo, hi): an
+ * instance of `lazy_cls` whose dict holds `qc` (what `[s for s in svcalls if s.qc]`, parallel.py:267, reads), the source that can
+ * turn it into the real call, and its place there.  stub_refresh_qc(calls: list, records: buffer, lo): `qc` of the final records for
+ * the elements that still are stand-ins. */
+static PyObject* py_make_stubs(PyObject* self, PyObject* args) {
+  PyObject *cls, *src; Py_buffer calls; long long lo, hi;
+  if (!PyArg_ParseTuple(args, "OOy*LL", &cls, &src, &calls, &lo, &hi)) return NULL;
+  PyObject* out = NULL;
+  if (lo < 0 || hi < lo || (size_t)hi * sizeof(snf_call_t) > (size_t)calls.len) { PyErr_SetString(PyExc_ValueError, "call range outside the record table"); goto done; }
+  const snf_call_t* C = (const snf_call_t*)calls.buf;
+  out = PyList_New(hi - lo);
+  for (long long i = lo; out && i < hi; i++) {
+    PyObject* d = _PyDict_NewPresized(3);
+    PyObject* ix = d ? PyLong_FromLongLong(i - lo) : NULL;
+    if (!ix || PyDict_SetItem(d, K_qc, C[i].qc ? Py_True : Py_False) || PyDict_SetItem(d, K_lz, src) || PyDict_SetItem(d, K_lzi, ix)) { Py_XDECREF(d); Py_XDECREF(ix); Py_CLEAR(out); break; }
+    Py_DECREF(ix);
+    PyObject* obj = new_instance(cls, d);
+    if (!obj) { Py_CLEAR(out); break; }
+    PyList_SET_ITEM(out, i - lo, obj);
+  }
+done:
+  PyBuffer_Release(&calls);
+  return out;
+}
+static PyObject* py_stub_refresh_qc(PyObject* self, PyObject* args) {
+  PyObject* lst; Py_buffer calls; long long lo;
+  if (!PyArg_ParseTuple(args, "O!y*L", &PyList_Type, &lst, &calls, &lo)) return NULL;
+  PyObject* ret = NULL;
+  const snf_call_t* C = (const snf_call_t*)calls.buf;
+  const long long n_rec = (long long)(calls.len / (Py_ssize_t)sizeof(snf_call_t));
+  for (Py_ssize_t k = 0; k < PyList_GET_SIZE(lst); k++) {
+    PyObject** dp = _PyObject_GetDictPtr(PyList_GET_ITEM(lst, k));
+    if (!dp || !*dp) continue;
+    PyObject* ix = PyDict_GetItemWithError(*dp, K_lzi);
+    if (!ix) { if (PyErr_Occurred()) goto done; continue; }      /* a real call: apply_final's business */
+    const long long i = lo + PyLong_AsLongLong(ix);
+    if (i < lo || i >= n_rec) { PyErr_SetString(PyExc_ValueError, "stand-in outside the record table"); goto done; }
+    if (PyDict_SetItem(*dp, K_qc, C[i].qc ? Py_True : Py_False)) goto done;
+  }
+  ret = Py_None; Py_INCREF(ret);
+done:
+  PyBuffer_Release(&calls);
+  return ret;
 }
 
 /* apply_final(calls: list, records: buffer, lo, alt_pool: buffer, ps_names: list | None, filters: list[str], early_exit: frozenset,
@@ -223,15 +289,19 @@ static PyObject* small_int_str(int v) {      /* str(v), new reference; 0..9 with
 }
 static PyObject* py_apply_final(PyObject* self, PyObject* args) {
   PyObject *lst, *ps_names, *filters, *early;
-  Py_buffer rec, pool;
+  Py_buffer rec, pool, idx; idx.buf = NULL; idx.obj = NULL; idx.len = 0;
   long long lo; int fin = 0;
-  if (!PyArg_ParseTuple(args, "Oy*Ly*OOO|p", &lst, &rec, &lo, &pool, &ps_names, &filters, &early, &fin)) return NULL;
+  /* optional `idx` (int64, relative to lo): call k takes record lo + idx[k] instead of lo + k */
+  if (!PyArg_ParseTuple(args, "Oy*Ly*OOO|py*", &lst, &rec, &lo, &pool, &ps_names, &filters, &early, &fin, &idx)) return NULL;
   PyObject* ret = NULL;
   const Py_ssize_t n = PyList_Size(lst);
-  if (n < 0 || lo < 0 || (size_t)(lo + n) * sizeof(snf_call_t) > (size_t)rec.len) { PyErr_SetString(PyExc_ValueError, "calls do not match the record table"); goto done; }
+  const int64_t* IDX = idx.buf ? (const int64_t*)idx.buf : NULL;
+  const long long n_rec = (long long)(rec.len / (Py_ssize_t)sizeof(snf_call_t));
+  if (n < 0 || lo < 0 || (!IDX && lo + n > n_rec) || (IDX && idx.len / 8 != n)) { PyErr_SetString(PyExc_ValueError, "calls do not match the record table"); goto done; }
+  for (Py_ssize_t k = 0; IDX && k < n; k++) if (IDX[k] < 0 || lo + IDX[k] >= n_rec) { PyErr_SetString(PyExc_ValueError, "record index outside the table"); goto done; }
   const snf_call_t* C = (const snf_call_t*)rec.buf + lo;
   for (Py_ssize_t i = 0; i < n; i++) {
-    const snf_call_t* c = &C[i];
+    const snf_call_t* c = &C[IDX ? IDX[i] : i];
     PyObject* obj = PyList_GET_ITEM(lst, i);
     PyObject** dp = _PyObject_GetDictPtr(obj);
     if (!dp || !*dp || c->filter < 0 || c->filter >= PyList_GET_SIZE(filters)) { PyErr_SetString(PyExc_TypeError, "not a materialised call"); goto done; }
@@ -294,6 +364,7 @@ static PyObject* py_apply_final(PyObject* self, PyObject* args) {
   ret = Py_None; Py_INCREF(ret);
 done:
   PyBuffer_Release(&rec); PyBuffer_Release(&pool);
+  if (idx.obj) PyBuffer_Release(&idx);
   return ret;
 }
 
@@ -1756,6 +1827,217 @@ done:
   return out;
 }
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * LeadSink: `LeadProvider.record_lead` (reference leadprov.py:400-418) as the place where a `Lead` becomes columns.  The reference
+ * pays its binning when a lead is recorded (dict / list inserts, the hap counters); here `record(ld)` reads the object's attributes
+ * ONCE, appends the 22 typed values to growable buffers, interns read_qname / phase_set / bnd_info.mate_contig to first-seen indices
+ * and appends `seq` to the sequence pool - what `lead_columns` does for a whole list, one lead at a time - so that
+ * `LeadProvider.to_task_input` is a copy of finished columns (`take`) plus the string-rank remap instead of a walk over ~10^5 objects
+ * inside `Task.call_candidates`.  The lead is a snapshot at record time (the reference's `record_lead` is called with the finished lead).
+ *   LeadSink(svt: dict, src: dict, svlen_none, seq_none, ps_none, contig)
+ *   .record(ld[, pos_leadtab])      .take(cols: dict[str, writable buffer of len(self) rows]) -> (qnames, ps, contigs, pool: bytes)
+ */
+enum { LC_RS, LC_RE, LC_QS, LC_QE, LC_SVLEN, LC_RLEN, LC_QN, LC_RID, LC_PS, LC_MC, LC_MP, LC_SLEN, LC_SOFF, LC_NM, LC_SVT, LC_STR, LC_MAPQ, LC_SRC,
+       LC_HAP, LC_SA, LC_BF, LC_BR, LC_NCOL };
+static const char* LC_NAMES[LC_NCOL] = {"ref_start", "ref_end", "qry_start", "qry_end", "svlen", "read_len", "qname_id", "read_id", "ps_rank",
+                                        "mate_contig", "mate_ref_start", "seq_len", "seq_off", "nm", "svtype", "strand", "mapq", "source",
+                                        "hap", "is_sa", "bnd_is_first", "bnd_is_reverse"};
+static const int LC_ITEMS[LC_NCOL] = {4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 8, 8, 1, 1, 1, 1, 1, 1, 1, 1};
+static PyObject *A_read_id, *A_qname, *A_rs, *A_re, *A_qs, *A_qe, *A_strand, *A_mapq, *A_nm, *A_source, *A_svtype, *A_svlen, *A_seq, *A_bnd, *A_hap,
+                *A_ps, *A_sa, *A_rlen;
+typedef struct {
+  PyObject_HEAD
+  char* col[LC_NCOL];
+  Py_ssize_t n, cap;
+  char* pool; int64_t pool_n, pool_cap;
+  PyObject *qd, *ql, *pd, *pl, *cd, *cl, *svt, *src;
+  long long svlen_none, seq_none, ps_none;
+} LeadSink;
+
+static int sink_grow(LeadSink* S) {
+  const Py_ssize_t cap = S->cap ? S->cap * 2 : 1024;
+  for (int k = 0; k < LC_NCOL; k++) {
+    char* q = (char*)realloc(S->col[k], (size_t)cap * (size_t)LC_ITEMS[k]);
+    if (!q) { PyErr_NoMemory(); return -1; }
+    S->col[k] = q;
+  }
+  S->cap = cap;
+  return 0;
+}
+static int sink_pool_room(LeadSink* S, int64_t extra) {
+  if (S->pool_n + extra <= S->pool_cap) return 0;
+  int64_t cap = S->pool_cap ? S->pool_cap * 2 : (1 << 16);
+  while (cap < S->pool_n + extra) cap *= 2;
+  char* q = (char*)realloc(S->pool, (size_t)cap);
+  if (!q) { PyErr_NoMemory(); return -1; }
+  S->pool = q; S->pool_cap = cap;
+  return 0;
+}
+/* one Lead -> row i of the sink's columns (the body of lead_columns' walk) */
+static int sink_row(LeadSink* S, PyObject* ld, Py_ssize_t i) {
+  int32_t *rs = (int32_t*)S->col[LC_RS], *re = (int32_t*)S->col[LC_RE], *qs = (int32_t*)S->col[LC_QS], *qe = (int32_t*)S->col[LC_QE],
+          *svl = (int32_t*)S->col[LC_SVLEN], *rl = (int32_t*)S->col[LC_RLEN], *psr = (int32_t*)S->col[LC_PS], *mc = (int32_t*)S->col[LC_MC],
+          *mp = (int32_t*)S->col[LC_MP], *sl = (int32_t*)S->col[LC_SLEN];
+  uint32_t *qn = (uint32_t*)S->col[LC_QN], *rid = (uint32_t*)S->col[LC_RID];
+  int64_t* so = (int64_t*)S->col[LC_SOFF];
+  double* nm = (double*)S->col[LC_NM];
+  uint8_t *svtc = (uint8_t*)S->col[LC_SVT], *str = (uint8_t*)S->col[LC_STR], *mq = (uint8_t*)S->col[LC_MAPQ], *srcc = (uint8_t*)S->col[LC_SRC],
+          *hp = (uint8_t*)S->col[LC_HAP], *sa = (uint8_t*)S->col[LC_SA], *bf = (uint8_t*)S->col[LC_BF], *br = (uint8_t*)S->col[LC_BR];
+#define GET(var, attr) PyObject* var = PyObject_GetAttr(ld, attr); if (!var) return -1;
+#define AS_I32(dst, obj) { const long long _x = PyLong_AsLongLong(obj); Py_DECREF(obj); if (_x == -1 && PyErr_Occurred()) return -1; dst = (int32_t)_x; }
+  { GET(o, A_rs) AS_I32(rs[i], o) } { GET(o, A_re) AS_I32(re[i], o) } { GET(o, A_qs) AS_I32(qs[i], o) } { GET(o, A_qe) AS_I32(qe[i], o) }
+  { GET(o, A_svlen) if (o == Py_None) { Py_DECREF(o); svl[i] = (int32_t)S->svlen_none; } else AS_I32(svl[i], o) }
+  { GET(o, A_rlen) if (o == Py_None) { Py_DECREF(o); rl[i] = 0; } else AS_I32(rl[i], o) }
+  { GET(o, A_read_id) const unsigned long long x = PyLong_AsUnsignedLongLongMask(o); Py_DECREF(o); if (PyErr_Occurred()) return -1; rid[i] = (uint32_t)x; }
+  { GET(o, A_mapq) int32_t m; AS_I32(m, o) mq[i] = (uint8_t)m; }
+  { GET(o, A_nm) if (o == Py_None) { nm[i] = Py_NAN; Py_DECREF(o); } else { const double x = PyFloat_AsDouble(o); Py_DECREF(o); if (x == -1.0 && PyErr_Occurred()) return -1; nm[i] = x; } }
+  { GET(o, A_strand) const int minus = PyUnicode_Check(o) && PyUnicode_GET_LENGTH(o) == 1 && PyUnicode_READ_CHAR(o, 0) == '-'; Py_DECREF(o); str[i] = minus ? 1 : 0; }
+  { GET(o, A_sa) const int t = PyObject_IsTrue(o); Py_DECREF(o); if (t < 0) return -1; sa[i] = (uint8_t)t; }
+  { GET(o, A_hap) PyObject* h = PyNumber_Long(o); Py_DECREF(o); if (!h) return -1; const long x = PyLong_AsLong(h); Py_DECREF(h); if (x == -1 && PyErr_Occurred()) return -1; hp[i] = (uint8_t)x; }
+  { GET(o, A_svtype) PyObject* k = PyDict_GetItemWithError(S->svt, o); Py_DECREF(o); if (!k) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_KeyError, "unknown svtype"); return -1; } svtc[i] = (uint8_t)PyLong_AsLong(k); }
+  { GET(o, A_source) PyObject* k = PyDict_GetItemWithError(S->src, o); Py_DECREF(o); if (!k) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_KeyError, "unknown lead source"); return -1; } srcc[i] = (uint8_t)PyLong_AsLong(k); }
+  { GET(o, A_qname) const long k = intern_first_seen(S->qd, S->ql, o); Py_DECREF(o); if (k < 0) return -1; qn[i] = (uint32_t)k; }
+  { GET(o, A_ps) if (o == Py_None) { psr[i] = (int32_t)S->ps_none; Py_DECREF(o); } else { const long k = intern_first_seen(S->pd, S->pl, o); Py_DECREF(o); if (k < 0) return -1; psr[i] = (int32_t)k; } }
+  { GET(q, A_seq)
+    if (q == Py_None) { sl[i] = (int32_t)S->seq_none; so[i] = 0; }
+    else {
+      if (!PyUnicode_Check(q)) { Py_DECREF(q); PyErr_SetString(PyExc_TypeError, "Lead.seq must be str or None"); return -1; }
+      if (PyUnicode_MAX_CHAR_VALUE(q) > 255) { Py_DECREF(q); PyErr_SetString(PyExc_ValueError, "Lead.seq must be latin-1"); return -1; }
+      const Py_ssize_t L = PyUnicode_GET_LENGTH(q);
+      if (sink_pool_room(S, (int64_t)L) != 0) { Py_DECREF(q); return -1; }
+      sl[i] = (int32_t)L; so[i] = S->pool_n;
+      if (PyUnicode_KIND(q) == PyUnicode_1BYTE_KIND) memcpy(S->pool + S->pool_n, PyUnicode_1BYTE_DATA(q), (size_t)L);
+      else for (Py_ssize_t k = 0; k < L; k++) S->pool[S->pool_n + k] = (char)PyUnicode_READ_CHAR(q, k);
+      S->pool_n += L;
+    }
+    Py_DECREF(q); }
+  mc[i] = -1; mp[i] = 0; bf[i] = 0; br[i] = 0;      /* -1: no bnd_info */
+  { GET(bi, A_bnd)
+    if (bi != Py_None) {
+      PyObject* x = PyObject_GetAttr(bi, B_mate_contig); if (!x) { Py_DECREF(bi); return -1; }
+      const long k = intern_first_seen(S->cd, S->cl, x); Py_DECREF(x); if (k < 0) { Py_DECREF(bi); return -1; }
+      mc[i] = (int32_t)k;
+      x = PyObject_GetAttr(bi, B_mate_ref_start); if (!x) { Py_DECREF(bi); return -1; }
+      { const long long y = PyLong_AsLongLong(x); Py_DECREF(x); if (y == -1 && PyErr_Occurred()) { Py_DECREF(bi); return -1; } mp[i] = (int32_t)y; }
+      x = PyObject_GetAttr(bi, B_is_first); if (!x) { Py_DECREF(bi); return -1; } bf[i] = (uint8_t)(PyObject_IsTrue(x) == 1); Py_DECREF(x);
+      x = PyObject_GetAttr(bi, B_is_reverse); if (!x) { Py_DECREF(bi); return -1; } br[i] = (uint8_t)(PyObject_IsTrue(x) == 1); Py_DECREF(x);
+    }
+    Py_DECREF(bi); }
+#undef GET
+#undef AS_I32
+  return 0;
+}
+static void sink_dealloc(LeadSink* S) {
+  for (int k = 0; k < LC_NCOL; k++) free(S->col[k]);
+  free(S->pool);
+  Py_XDECREF(S->qd); Py_XDECREF(S->ql); Py_XDECREF(S->pd); Py_XDECREF(S->pl); Py_XDECREF(S->cd); Py_XDECREF(S->cl); Py_XDECREF(S->svt); Py_XDECREF(S->src);
+  Py_TYPE(S)->tp_free((PyObject*)S);
+}
+static int sink_init(LeadSink* S, PyObject* args, PyObject* kw) {
+  PyObject *svt, *src, *contig;
+  if (!PyArg_ParseTuple(args, "O!O!LLLU", &PyDict_Type, &svt, &PyDict_Type, &src, &S->svlen_none, &S->seq_none, &S->ps_none, &contig)) return -1;
+  Py_INCREF(svt); Py_INCREF(src); S->svt = svt; S->src = src;
+  S->qd = PyDict_New(); S->ql = PyList_New(0); S->pd = PyDict_New(); S->pl = PyList_New(0); S->cd = PyDict_New(); S->cl = PyList_New(0);
+  if (!S->qd || !S->ql || !S->pd || !S->pl || !S->cd || !S->cl) return -1;
+  if (intern_first_seen(S->cd, S->cl, contig) < 0) return -1;      /* the task's own contig is always in the table (index 0) */
+  return 0;
+}
+static PyObject* sink_record(LeadSink* S, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs < 1 || nargs > 2) { PyErr_SetString(PyExc_TypeError, "record(lead[, pos_leadtab])"); return NULL; }
+  if (!S->qd) { PyErr_SetString(PyExc_RuntimeError, "LeadSink was not initialised"); return NULL; }
+  if (S->n == S->cap && sink_grow(S) != 0) return NULL;
+  const int64_t pool_before = S->pool_n;
+  if (sink_row(S, args[0], S->n) != 0) { S->pool_n = pool_before; return NULL; }     /* (a lead that fails leaves no row) */
+  S->n++;
+  Py_RETURN_NONE;
+}
+static PyObject* sink_take(LeadSink* S, PyObject* cols) {
+  if (!PyDict_Check(cols)) { PyErr_SetString(PyExc_TypeError, "take(cols: dict)"); return NULL; }
+  Col c[LC_NCOL]; memset(c, 0, sizeof(c));
+  PyObject* out = NULL;
+  for (int k = 0; k < LC_NCOL; k++) if (col_get(cols, LC_NAMES[k], S->n, LC_ITEMS[k], &c[k]) != 0) goto done;
+  for (int k = 0; k < LC_NCOL; k++) if (S->n) memcpy(c[k].b.buf, S->col[k], (size_t)S->n * (size_t)LC_ITEMS[k]);
+  {
+    PyObject* pool = PyBytes_FromStringAndSize(S->pool ? S->pool : "", (Py_ssize_t)S->pool_n);
+    if (!pool) goto done;
+    out = Py_BuildValue("(OOON)", S->ql, S->pl, S->cl, pool);
+  }
+done:
+  for (int k = 0; k < LC_NCOL; k++) if (c[k].ok) PyBuffer_Release(&c[k].b);
+  return out;
+}
+static Py_ssize_t sink_len(LeadSink* S) { return S->n; }
+static PyMethodDef sink_methods[] = {
+    {"record", (PyCFunction)(void (*)(void))sink_record, METH_FASTCALL, "append one Lead (attributes read now)"},
+    {"take", (PyCFunction)sink_take, METH_O, "copy the columns into the given buffers -> (qnames, ps, contigs, pool)"},
+    {NULL, NULL, 0, NULL}};
+static PySequenceMethods sink_seq = {(lenfunc)sink_len};
+static PyTypeObject LeadSinkType = {
+    PyVarObject_HEAD_INIT(NULL, 0).tp_name = "_snf_fast.LeadSink", .tp_basicsize = sizeof(LeadSink), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_new = PyType_GenericNew, .tp_init = (initproc)sink_init, .tp_dealloc = (destructor)sink_dealloc, .tp_methods = sink_methods,
+    .tp_as_sequence = &sink_seq, .tp_doc = "record-time columns of LeadProvider.record_lead"};
+
+/* rank_strings(names: list[str]) -> (sorted: list[str], rank: bytes int64[n]): the names in Python string order (code points; equal
+ * to the byte order of UTF-8) and rank[i] = place of names[i] in it; names must be distinct (an interning table).  The remap of
+ * first-seen indices to ranks whose integer order is the reference's string order (leadprov: read_qname, phase_set, mate contig).
+ * An LSD radix sort over the first eight bytes (big-endian, zero-padded), then the runs of equal prefixes by comparison. */
+typedef struct { uint64_t pre; const char* p; Py_ssize_t len; int64_t idx; } RankKey;
+static int rank_cmp(const void* a, const void* b) {
+  const RankKey *x = (const RankKey*)a, *y = (const RankKey*)b;
+  if (x->pre != y->pre) return x->pre < y->pre ? -1 : 1;
+  const Py_ssize_t m = x->len < y->len ? x->len : y->len;
+  const int c = m > 8 ? memcmp(x->p + 8, y->p + 8, (size_t)(m - 8)) : 0;
+  if (c) return c;
+  return x->len < y->len ? -1 : (x->len > y->len ? 1 : 0);
+}
+static PyObject* py_rank_strings(PyObject* self, PyObject* names) {
+  if (!PyList_Check(names)) { PyErr_SetString(PyExc_TypeError, "rank_strings(list[str])"); return NULL; }
+  const Py_ssize_t n = PyList_GET_SIZE(names);
+  RankKey *k = (RankKey*)malloc((size_t)(n ? n : 1) * sizeof(RankKey)), *k2 = (RankKey*)malloc((size_t)(n ? n : 1) * sizeof(RankKey));
+  PyObject *sorted = PyList_New(n), *rank = PyBytes_FromStringAndSize(NULL, n * 8), *out = NULL;
+  if (!k || !k2 || !sorted || !rank) { PyErr_NoMemory(); goto done; }
+  uint64_t all_or = 0, all_and = ~0ull;
+  for (Py_ssize_t i = 0; i < n; i++) {
+    PyObject* o = PyList_GET_ITEM(names, i);
+    if (!PyUnicode_Check(o)) { PyErr_SetString(PyExc_TypeError, "rank_strings: names must be str"); goto done; }
+    k[i].p = PyUnicode_AsUTF8AndSize(o, &k[i].len);
+    if (!k[i].p) goto done;
+    uint64_t pre = 0;
+    for (int b = 0; b < 8; b++) pre = (pre << 8) | (uint64_t)(b < k[i].len ? (unsigned char)k[i].p[b] : 0);
+    k[i].pre = pre; k[i].idx = i;
+    all_or |= pre; all_and &= pre;
+  }
+  if (n > 64) {
+    for (int byte = 0; byte < 8; byte++) {      /* least significant byte first; a byte all keys share is skipped */
+      const int sh = 8 * byte;
+      if ((((all_or ^ all_and) >> sh) & 0xffu) == 0) continue;
+      size_t cnt[257]; memset(cnt, 0, sizeof(cnt));
+      for (Py_ssize_t i = 0; i < n; i++) cnt[((k[i].pre >> sh) & 0xffu) + 1]++;
+      for (int c = 0; c < 256; c++) cnt[c + 1] += cnt[c];
+      for (Py_ssize_t i = 0; i < n; i++) k2[cnt[(k[i].pre >> sh) & 0xffu]++] = k[i];
+      RankKey* t = k; k = k2; k2 = t;
+    }
+    for (Py_ssize_t a = 0; a < n;) {            /* runs of equal prefixes: longer names that share eight bytes */
+      Py_ssize_t b = a + 1;
+      while (b < n && k[b].pre == k[a].pre) b++;
+      if (b - a > 1) qsort(k + a, (size_t)(b - a), sizeof(RankKey), rank_cmp);
+      a = b;
+    }
+  } else qsort(k, (size_t)n, sizeof(RankKey), rank_cmp);
+  {
+    int64_t* rd = (int64_t*)PyBytes_AS_STRING(rank);
+    for (Py_ssize_t j = 0; j < n; j++) {
+      rd[k[j].idx] = j;
+      PyObject* o = PyList_GET_ITEM(names, k[j].idx);
+      Py_INCREF(o); PyList_SET_ITEM(sorted, j, o);
+    }
+  }
+  out = Py_BuildValue("(OO)", sorted, rank);
+done:
+  free(k); free(k2); Py_XDECREF(sorted); Py_XDECREF(rank);
+  return out;
+}
+
 /* format_f3(values: buffer float64) -> bytes: the values as this module prints them (ob_f3), '\n' between: lets the test suite pin the
  * hand-written "%.3f" against Python's own f"{v:.3f}" */
 static PyObject* py_format_f3(PyObject* self, PyObject* args) {
@@ -1770,8 +2052,11 @@ static PyObject* py_format_f3(PyObject* self, PyObject* args) {
 
 static PyMethodDef methods[] = {
     {"format_f3", py_format_f3, METH_VARARGS, "float64 values as f\"{v:.3f}\" lines (test hook of the formatter)"},
+    {"rank_strings", py_rank_strings, METH_O, "order and rank of distinct names in Python string order"},
     {"lead_columns", py_lead_columns, METH_VARARGS, "Lead objects -> typed TaskInput columns in one walk (input side of the drop-in)"},
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
+    {"make_stubs", py_make_stubs, METH_VARARGS, "lazy stand-ins of the calls of a record range"},
+    {"stub_refresh_qc", py_stub_refresh_qc, METH_VARARGS, "qc of the final records onto the stand-ins of a list"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
     {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},
     {"gather_pool", py_gather_pool, METH_VARARGS, "strings of a pool in a given order, back to back"},
@@ -1803,10 +2088,19 @@ PyMODINIT_FUNC PyInit__snf_fast(void) {
   INTERN(I_CHR2, "CHR2"); INTERN(I_SUPPORT_LONG, "SUPPORT_LONG"); INTERN(I_SUPPORT_SA, "SUPPORT_SA"); INTERN(I_STDEV_POS, "STDEV_POS");
   INTERN(I_STDEV_LEN, "STDEV_LEN"); INTERN(I_COVERAGE_VAR, "COVERAGE_VAR"); INTERN(I_PHASE, "PHASE"); INTERN(I_VAF, "VAF");
   INTERN(B_mate_contig, "mate_contig"); INTERN(B_mate_ref_start, "mate_ref_start"); INTERN(B_is_first, "is_first"); INTERN(B_is_reverse, "is_reverse");
-  INTERN(P_batch, "batch"); INTERN(P_index, "index");
+  INTERN(P_batch, "batch"); INTERN(P_index, "index"); INTERN(K_class, "__class__"); INTERN(K_lz, "_lz"); INTERN(K_lzi, "_lzi");
   INTERN(S_dot, "."); INTERN(S_comma, ","); INTERN(I_COVERAGE, "_COVERAGE");
   O_zero = PyLong_FromLong(0); T_none2 = PyTuple_Pack(2, Py_None, Py_None);
   if (!O_zero || !T_none2 || sizeof(snf_group_cand_t) != 76 || sizeof(snf_group_out_t) != 96) { PyErr_SetString(PyExc_ImportError, "group record layout changed"); return NULL; }
   INTERN(F_n, "n"); INTERN(F_m1, "m1"); INTERN(F_m2, "m2"); INTERN(F_last, "last");
-  return PyModule_Create(&moddef);
+  INTERN(A_read_id, "read_id"); INTERN(A_qname, "read_qname"); INTERN(A_rs, "ref_start"); INTERN(A_re, "ref_end"); INTERN(A_qs, "qry_start");
+  INTERN(A_qe, "qry_end"); INTERN(A_strand, "strand"); INTERN(A_mapq, "mapq"); INTERN(A_nm, "nm"); INTERN(A_source, "source");
+  INTERN(A_svtype, "svtype"); INTERN(A_svlen, "svlen"); INTERN(A_seq, "seq"); INTERN(A_bnd, "bnd_info"); INTERN(A_hap, "hap");
+  INTERN(A_ps, "phase_set"); INTERN(A_sa, "is_sa"); INTERN(A_rlen, "read_len");
+  if (PyType_Ready(&LeadSinkType) < 0) return NULL;
+  PyObject* mod = PyModule_Create(&moddef);
+  if (!mod) return NULL;
+  Py_INCREF(&LeadSinkType);
+  if (PyModule_AddObject(mod, "LeadSink", (PyObject*)&LeadSinkType) < 0) { Py_DECREF(&LeadSinkType); Py_DECREF(mod); return NULL; }
+  return mod;
 }

@@ -64,7 +64,7 @@ def iter_leads(ti):
 
 
 class LeadProvider:
-    def __init__(self, config, read_id_offset, contig: str, contig_len: int = None):
+    def __init__(self, config, read_id_offset, contig: str, contig_len: int = None, record_time_columns: bool = None):
         self.config = config
         self.contig = contig
         self.contig_len = contig_len
@@ -76,6 +76,21 @@ class LeadProvider:
         import array
         self._rs, self._re, self._rhp = array.array("i"), array.array("i"), array.array("B")      # typed growable read columns
         self._nmask = None
+        # Where the reference pays its binning - at record time (leadprov.py:400-418) - a lead becomes a row of typed columns here
+        # (`_snf_fast.LeadSink`: attributes read once, names interned, `seq` appended to the pool), so that `to_task_input` inside
+        # `Task.call_candidates` is a copy of finished columns.  The row is a snapshot: a lead mutated after `record_lead` keeps its
+        # recorded values (the reference's callers record finished leads).  `record_time_columns=False` / SNF_LEADS_LATE=1 (or no C
+        # extension): the objects are kept and walked once in `to_task_input`, as before.
+        self._sink = None
+        import os
+        if record_time_columns is None:
+            record_time_columns = os.environ.get("SNF_LEADS_LATE") != "1"
+        if record_time_columns:
+            from .sv import _load_fast
+            fast = _load_fast()
+            if fast is not None and hasattr(fast, "LeadSink"):
+                self._sink = fast.LeadSink(SVT, SRC, int(SVLEN_NONE), int(SEQ_NONE), int(PS_NONE), contig)
+                self.record_lead = self._sink.record          # record_lead(ld[, pos_leadtab]) straight into the sink
 
     def record_lead(self, ld: Lead, pos_leadtab: int = None) -> None:
         """Same call as the reference; `pos_leadtab` (the 100-bp bin) is recomputed on the GPU."""
@@ -109,13 +124,24 @@ class LeadProvider:
         fast = _load_fast()
         if fast is None or not hasattr(fast, "lead_columns"):
             return None
-        n = len(self._leads)
-        L = empty_leads(n)
-        ql, pl, cl, pool = fast.lead_columns(self._leads, L, SVT, SRC, int(SVLEN_NONE), int(SEQ_NONE), int(PS_NONE), self.contig)
+        if self._sink is not None:
+            if self._leads:
+                raise RuntimeError("leads were appended behind the record-time sink")
+            n = len(self._sink)
+            L = empty_leads(n)
+            ql, pl, cl, pool = self._sink.take(L)
+        else:
+            n = len(self._leads)
+            L = empty_leads(n)
+            ql, pl, cl, pool = fast.lead_columns(self._leads, L, SVT, SRC, int(SVLEN_NONE), int(SEQ_NONE), int(PS_NONE), self.contig)
 
         def ranks(first_seen, extra=()):
             """first-seen indices -> ranks in Python string order (the reference breaks ties on string order)"""
-            names = list(first_seen) + [x for x in extra if x not in set(first_seen)]
+            have = set(first_seen) if extra else ()
+            names = list(first_seen) + [x for x in extra if x not in have]
+            if hasattr(fast, "rank_strings"):
+                in_order, rank = fast.rank_strings(names)
+                return in_order, np.frombuffer(rank, np.int64)
             order = sorted(range(len(names)), key=names.__getitem__)
             rank = np.empty(len(names), np.int64)
             rank[order] = np.arange(len(names))

@@ -8,14 +8,19 @@
     calls = task.finalize_candidates(cands, keep_qc_fails, config)
 
 Differences forced by the device boundary: `svcall.postprocess` is a handle to the cluster in HBM, not a
-`Cluster` with Python `Lead`s, and `finalize_candidates` must receive the list `call_candidates` returned.
+`Cluster` with Python `Lead`s, and `finalize_candidates` takes calls of this task's `call_candidates` (any selection, any order).
 Failure modes of the reference are preserved: a task whose first candidate is a BND raises
 UnboundLocalError exactly like `postprocessing.coverage` does.
 """
 from __future__ import annotations
 
+import os
+
 from . import lib, sv
 from .abi import TASK_ERR_UNBOUND_END
+
+# SNF_EAGER_CALLS=1: `call_candidates` builds every candidate object at once (the behaviour up to round 5) instead of stand-ins
+LAZY_CALLS = os.environ.get("SNF_EAGER_CALLS") != "1"
 
 
 class Task:
@@ -87,6 +92,7 @@ class Task:
         self._release()
 
     def _release(self):
+        self._drop_lazy()
         if self._batch is not None:
             self._batch.close()
             self._batch = None
@@ -109,13 +115,27 @@ class Task:
                     print(f"Dumping clusters to {filename}")
                     with open(filename, "w") as h:
                         h.write(text)
-        res = self._batch.fetch(0, copy=False)      # turned into objects right here
+        res = self._batch.fetch(0, copy=False)      # turned into objects (or their stand-ins) right here
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
-        out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch)
+        self._drop_lazy()
+        if LAZY_CALLS and sv.lazy_calls_supported(self._ti):
+            # a real list of stand-ins that become `svcall_cls` objects when they are first touched (sv.LazySource): the reference's
+            # consumers read `.qc` of every candidate and the rest only of the calls they keep (parallel.py:265-271)
+            self._lazy = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch, keep_all=bool(config.no_qc))
+            out = self._lazy.make()
+        else:
+            out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch)
         self.sv_id += len(out)
         self.coverage_average_total = float(res.coverage_average_total[0])
         return out
+
+    def _drop_lazy(self):
+        """The stand-ins of the previous candidate list lose their bulk source (each still fills alone); breaks the list <-> source cycle."""
+        src = getattr(self, "_lazy", None)
+        if src is not None:
+            src.stubs = None
+        self._lazy = None
 
     def call_records(self, config, execute: bool = False):
         """call_candidates + finalize_candidates without the `SVCall` objects: the finalized record table of the task
@@ -138,21 +158,39 @@ class Task:
         return res, self._ti
 
     def finalize_candidates(self, candidates, keep_qc_fails, config) -> list:
+        """`candidates`: calls of this task's `call_candidates` - the list itself, or any selection of it in any order (the reference
+        iterates whatever it is given, parallel.py:129-147; `GenotypeTask`-style callers filter in between): every call carries its
+        place in the batch (`postprocess.index`, a stand-in its own index), the records are mapped through that."""
+        import numpy as np
         if self._batch is None or getattr(self, "_finalized", False):
             raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")
         self._batch.finalize()
         res = self._batch.fetch(1, copy=False)
-        if len(res.calls) != len(candidates):
-            raise RuntimeError("candidate list does not match the batch (pass the list call_candidates returned)")
-        n = len(candidates)
-        for i in sorted(set([0, n - 1] + [k * n // 61 for k in range(61)])) if n else ():     # identity, by sample: same calls, same order
-            c = candidates[i]
-            if int(c.pos) != int(res.calls["pos"][i]) or int(c.svlen) != int(res.calls["svlen"][i]):
-                raise RuntimeError(f"candidate {i} is not the call the batch holds at that place (pass the list call_candidates "
-                                   "returned, unchanged and in its order)")
-        sv.apply_final(candidates, res, self._ti, finalize=True)      # (with `c.finalize()` for every call, parallel.py:199-200)
+        candidates = list(candidates)
+        n_rec = len(res.calls)
+        src = getattr(self, "_lazy", None)
+        if src is not None:
+            src.set_final(res)          # the stand-ins take the final `qc`; whoever is touched from now on is built in its final state
+        real, idx = [], []
+        for c in candidates:
+            if sv.is_stand_in(c):
+                if sv._raw_dict(c).get("_lz") is not src:
+                    raise RuntimeError("a candidate of another task's (or an earlier) call_candidates was passed")
+                continue
+            pp = getattr(c, "postprocess", None)
+            i = getattr(pp, "index", None)
+            if pp is None or getattr(pp, "batch", None) is not self._batch or i is None or not 0 <= int(i) < n_rec:
+                raise RuntimeError("finalize_candidates takes calls that this task's call_candidates returned (each carries its place in "
+                                   "the batch in `postprocess`)")
+            real.append(c); idx.append(int(i))
+        if real:
+            idx = np.asarray(idx, np.int64)
+            if not (np.array_equal(res.calls["pos"][idx], np.fromiter((int(c.pos) for c in real), np.int64, len(real)))
+                    and np.array_equal(res.calls["svlen"][idx], np.fromiter((int(c.svlen) for c in real), np.int64, len(real)))):
+                raise RuntimeError("a candidate is not the call the batch holds at its place (POS / SVLEN were changed)")
+            sv.apply_final(real, res, self._ti, finalize=True, idx=idx)      # (with `c.finalize()` for every call, parallel.py:199-200)
         self._finalized = True
-        return list(candidates)
+        return candidates
 
 
 class CallTask(Task):

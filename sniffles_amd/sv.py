@@ -297,23 +297,203 @@ def materialize_candidates_py(res: Result, ti, lo: int, hi: int, svcall_cls=SVCa
     return out
 
 
-def apply_final(calls: list, res: Result, ti, lo: int = 0, finalize: bool = False) -> None:
-    """`fill_final(call, res, lo + k, ti)` for every call of the list.  `finalize`: followed by `call.finalize()` (the reference's
-    `Task.finalize_candidates` ends with it, parallel.py:199-200) - in the same pass over the calls when their class keeps
-    `SVCall.finalize` (postprocess = None), by calling the method otherwise."""
+def apply_final(calls: list, res: Result, ti, lo: int = 0, finalize: bool = False, idx=None) -> None:
+    """`fill_final(call, res, lo + k, ti)` for every call of the list (`idx`: call k takes record lo + idx[k]).  `finalize`: followed
+    by `call.finalize()` (the reference's `Task.finalize_candidates` ends with it, parallel.py:199-200) - in the same pass over the
+    calls when their classes keep `SVCall.finalize` (postprocess = None), by calling the method otherwise."""
     import numpy as np
     fast = _load_fast()
-    plain = finalize and all(getattr(type(c), "finalize", None) is SVCall.finalize for c in calls[:1] + calls[-1:])
+    plain = finalize and all(getattr(t, "finalize", None) is SVCall.finalize for t in {type(c) for c in calls})
     if fast is not None and (ti.ps_names is None or isinstance(ti.ps_names, list)):
         with no_gc():
-            fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
-                             _QC_SV_EARLY_EXIT, plain)
+            if idx is None:
+                fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
+                                 _QC_SV_EARLY_EXIT, plain)
+            else:
+                fast.apply_final(calls, np.ascontiguousarray(res.calls), lo, np.ascontiguousarray(res.alt_pool, np.uint8), ti.ps_names, FILTERS,
+                                 _QC_SV_EARLY_EXIT, plain, np.ascontiguousarray(idx, np.int64))
     else:
-        apply_final_py(calls, res, ti, lo)
+        if idx is None:
+            apply_final_py(calls, res, ti, lo)
+        else:
+            for c, i in zip(calls, np.asarray(idx).tolist()):
+                fill_final(c, res, lo + int(i), ti)
         plain = False
     if finalize and not plain:
         for c in calls:
             c.finalize()
+
+
+# ---- lazy calls: `Task.call_candidates` hands out a real list whose elements BECOME `SVCall` objects when they are first touched.
+# The reference's consumers (CallTask.execute, parallel.py:265-271) read `.qc` of every candidate and everything else only of the
+# calls they keep; a 30x genome has 94 k candidates of which 26.8 k are kept, and creating + finalizing + freeing an object with 33
+# attributes costs ~2.3 us.  A stand-in is an instance of a subclass of the call class whose dict holds only `qc`, its source and its
+# place there; any other access - attribute, method, assignment, pickling, `__dict__` - first turns it into the real thing: the full
+# instance dict (the very dict `materialize_candidates` + `apply_final` build) replaces the stand-in's and its class is set to the
+# call class, after which nothing distinguishes it from an eagerly built call.  The source turns stand-ins into calls in bulk: the
+# first touch materialises every stand-in a consumer is going to touch (those with `qc` set, or all under `no_qc`) in one C pass.
+_LAZY_CLASSES = {}
+
+
+def _raw_dict(obj) -> dict:
+    """The instance dict itself (a stand-in's class answers `__dict__` with the filled object's)."""
+    get = getattr(type(obj), "_lz_rawdict", None)
+    return get(obj) if get is not None else object.__getattribute__(obj, "__dict__")
+
+
+def _lazy_fill(obj) -> None:
+    src = _raw_dict(obj).get("_lz")
+    if src is not None:
+        src.fill(obj)
+
+
+def lazy_class(cls):
+    """The stand-in class of call class `cls` (cached)."""
+    lz = _LAZY_CLASSES.get(cls)
+    if lz is not None:
+        return lz
+    import dataclasses
+
+    def __getattr__(self, name):          # only reached when the normal look-up fails: a field that has no class-level default
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        if _raw_dict(self).get("_lz") is None:
+            raise AttributeError(name)
+        _lazy_fill(self)
+        return getattr(self, name)
+
+    def __setattr__(self, name, value):
+        _lazy_fill(self)
+        object.__setattr__(self, name, value)
+
+    def __delattr__(self, name):
+        _lazy_fill(self)
+        object.__delattr__(self, name)
+
+    def __reduce_ex__(self, protocol):
+        _lazy_fill(self)
+        return self.__reduce_ex__(protocol)     # (the object's class is the call class by now)
+
+    raw = None
+    for k in cls.__mro__:              # the descriptor that hands out an instance's dict, from whichever base introduced it
+        if "__dict__" in vars(k) and hasattr(vars(k)["__dict__"], "__get__"):
+            raw = vars(k)["__dict__"].__get__
+            break
+    if raw is None:
+        raise TypeError(f"{cls.__name__} instances have no __dict__")
+
+    def _dict(self):
+        _lazy_fill(self)
+        return raw(self)
+    ns = {"__getattr__": __getattr__, "__setattr__": __setattr__, "__delattr__": __delattr__, "__reduce_ex__": __reduce_ex__,
+          "__dict__": property(_dict), "__slots__": (), "_lz_rawdict": staticmethod(raw)}
+
+    def forward(name):
+        def get(self):
+            _lazy_fill(self)
+            return getattr(self, name)
+        return get
+    # every name the class itself answers (fields with defaults, methods, properties) is shadowed by a data descriptor that fills first;
+    # a data descriptor wins over the instance dict, and once filled the object has left this class
+    skip = {"__class__", "__dict__", "__weakref__", "__module__", "__doc__", "__slots__", "__new__", "__init__", "__init_subclass__",
+            "__subclasshook__", "__getattribute__", "__getattr__", "__setattr__", "__delattr__", "__reduce_ex__", "__reduce__",
+            "__sizeof__", "__dir__", "__del__", "__dataclass_fields__", "__dataclass_params__", "__annotations__", "__match_args__",
+            "__class_getitem__", "__hash__"}
+    for name in dir(cls):
+        if name in skip or name in ("qc", "_lz_rawdict"):
+            continue
+        if name.startswith("__") and name.endswith("__"):
+            # special methods are looked up on the type: repr / eq / ordering of a stand-in go through the real object
+            if name in ("__repr__", "__str__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__format__", "__getstate__",
+                        "__copy__", "__deepcopy__"):
+                def special(self, *a, _n=name, **k):
+                    _lazy_fill(self)
+                    return getattr(self, _n)(*a, **k)
+                ns[name] = special
+            continue
+        ns[name] = property(forward(name), lambda self, v, _n=name: (_lazy_fill(self), object.__setattr__(self, _n, v))[1])
+    lz = type("_Lazy" + cls.__name__, (cls,), ns)
+    _LAZY_CLASSES[cls] = lz
+    return lz
+
+
+class LazySource:
+    """Where the stand-ins of one task's candidate list come from: the record tables (copies - the batch's pinned block is handed on),
+    the task input and the classes.  `stage` 0: the candidates of `call_candidates`; `set_final` moves it to the records of
+    `finalize_candidates`."""
+
+    def __init__(self, res: Result, ti, svcall_cls, bnd_cls, post_cls, batch, keep_all: bool):
+        import numpy as np
+        self.calls = np.ascontiguousarray(res.calls).copy()
+        self.rnames = np.ascontiguousarray(res.rnames, np.uint32).copy()
+        self.alt_pool = None
+        self.ti, self.cls, self.bnd_cls, self.post_cls, self.batch = ti, svcall_cls, bnd_cls, post_cls, batch
+        self.final = False
+        self.keep_all = keep_all
+        self.stubs = None            # the list call_candidates returned (the stand-ins in record order)
+        self.n_filled = 0
+
+    def make(self) -> list:
+        fast = _load_fast()
+        with no_gc():
+            self.stubs = fast.make_stubs(lazy_class(self.cls), self, self.calls, 0, len(self.calls))
+        return list(self.stubs)
+
+    def set_final(self, res: Result) -> None:
+        import numpy as np
+        self.calls = np.ascontiguousarray(res.calls).copy()
+        self.rnames = np.ascontiguousarray(res.rnames, np.uint32).copy()
+        self.alt_pool = np.ascontiguousarray(res.alt_pool, np.uint8).copy()
+        self.final = True
+        _load_fast().stub_refresh_qc(self.stubs, self.calls, 0)
+
+    def fill(self, obj) -> None:
+        """`obj` (a stand-in of this source) was touched: it and every stand-in the consumer is about to touch become real calls -
+        all of them at the candidate stage (`finalize_candidates` then works on objects, as before), the ones with `qc` set (all
+        under `no_qc`) after it.  What is left out stays a stand-in and is filled alone if it is ever touched."""
+        import numpy as np
+        d = _raw_dict(obj)
+        me = d.get("_lzi")
+        if me is None:
+            return
+        lz = lazy_class(self.cls)
+        idx = [me]
+        if self.stubs is not None and (not self.final or self.keep_all or d.get("qc")):
+            want_all = not self.final or self.keep_all
+            idx = []
+            for k, c in enumerate(self.stubs):
+                if type(c) is lz:
+                    cd = _raw_dict(c)
+                    if cd.get("_lz") is self and (want_all or cd.get("qc") or k == me):
+                        idx.append(k)
+        targets = [self.stubs[k] for k in idx] if self.stubs is not None else [obj]
+        self.fill_many(targets, np.asarray(idx, np.int64))
+
+    def fill_many(self, targets: list, idx) -> None:
+        import numpy as np
+        fast = _load_fast()
+        ti = self.ti
+        idx = np.ascontiguousarray(idx, np.int64)
+        with no_gc():
+            fast.materialize(self.cls, self.bnd_cls, ForwardDifferenceWelford, None if self.final else self.post_cls, self.batch, self.calls,
+                             0, len(self.calls), self.rnames, ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS, idx, targets)
+            if self.final:
+                plain = all(getattr(type(c), "finalize", None) is SVCall.finalize for c in targets)
+                fast.apply_final(targets, self.calls, 0, self.alt_pool, ti.ps_names, FILTERS, _QC_SV_EARLY_EXIT, plain, idx)
+                if not plain:
+                    for c in targets:
+                        c.finalize()
+        self.n_filled += len(targets)
+
+
+def lazy_calls_supported(ti) -> bool:
+    fast = _load_fast()
+    return (fast is not None and hasattr(fast, "make_stubs") and (ti.qnames is None or isinstance(ti.qnames, list))
+            and (ti.contig_names is None or isinstance(ti.contig_names, list)) and (ti.ps_names is None or isinstance(ti.ps_names, list)))
+
+
+def is_stand_in(c) -> bool:
+    return getattr(type(c), "_lz_rawdict", None) is not None and _raw_dict(c).get("_lz") is not None
 
 
 def apply_final_py(calls: list, res: Result, ti, lo: int = 0) -> None:

@@ -9,7 +9,8 @@
 //   * __shfl / __shfl_xor / __shfl_up / __shfl_down / __ballot / readlane / readfirstlane exchange through a per-wave
 //     buffer bracketed by two wave barriers; all 64 lanes must take part (a divergent call is reported as a deadlock);
 //   * __builtin_amdgcn_update_dpp implements the controls the kernels use: row_shr:1..15 (0x111..0x11f), row_bcast:15
-//     (0x142), row_bcast:31 (0x143), quad_perm (0x00..0xff), row_mirror (0x140), row_half_mirror (0x141), with row_mask and
+//     (0x142), row_bcast:31 (0x143), quad_perm (0x00..0xff), row_mirror (0x140), row_half_mirror (0x141), wave_shr / wave_ror /
+//     wave_shl / wave_rol by one lane (0x138, 0x13C, 0x130, 0x134), with row_mask and
 //     bound_ctrl = false semantics (disabled / sourceless lanes keep `old`);
 //   * atomics are plain read-modify-writes (switches are cooperative, so they are atomic by construction);
 //   * __shared__ is a function-local static: one workgroup at a time;
@@ -436,6 +437,11 @@ inline int dpp_at(const void* site, int old, int src, int ctrl, int row_mask, in
   else if (ctrl >= 0 && ctrl <= 0xff) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);      // quad_perm
   else if (ctrl == 0x140) from = (l & ~15) | (15 - (l & 15));                                // row_mirror
   else if (ctrl == 0x141) from = (l & ~7) | (7 - (l & 7));                                   // row_half_mirror
+  // whole-wave shifts / rotates by one lane (GFX9 only; checked on the MI355X by tools/probe/dpp_wave.hip)
+  else if (ctrl == 0x138) { if (l >= 1) from = l - 1; }                                      // wave_shr:1
+  else if (ctrl == 0x13C) from = (l + 63) & 63;                                              // wave_ror:1
+  else if (ctrl == 0x130) { if (l <= 62) from = l + 1; }                                     // wave_shl:1
+  else if (ctrl == 0x134) from = (l + 1) & 63;                                               // wave_rol:1
   else die("update_dpp: control not modelled");
   const uint64_t grp = wave_op_begin(site, to_bits(src));
   int r = old;
@@ -561,9 +567,13 @@ static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::lock_guard<std::mutex> g(simt::g_launch_mutex); if (n) std::memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int c, size_t n) { std::lock_guard<std::mutex> g(simt::g_launch_mutex); if (n) std::memset(d, c, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int c, size_t n, hipStream_t = nullptr) { std::lock_guard<std::mutex> g(simt::g_launch_mutex); if (n) std::memset(d, c, n); return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : 101; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// SNF_SIMT_DEVICES=n: the stand-in reports n devices (all of them this host; what differs per device in the library is its own
+// bookkeeping - arenas, caches, the pacing state of the passes - which is what a test with two device indices exercises)
+static inline int simt_device_count() { const char* e = getenv("SNF_SIMT_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+static inline int& simt_current_device() { static thread_local int d = 0; return d; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = simt_device_count(); return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= simt_device_count()) return 101; simt_current_device() = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = simt_current_device(); return hipSuccess; }
 static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
   std::lock_guard<std::mutex> g(simt::g_launch_mutex);
   for (size_t r = 0; r < height; r++) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);

@@ -46,6 +46,13 @@ def as_record(c, stage):
     return rec
 
 
+def flat_call(c):
+    d = dict(c.__dict__)
+    d.pop("forward_difference_sampler")
+    d["rnames"] = sorted(d["rnames"])
+    return repr(d)
+
+
 def run_case(name, _lib):
     build, kw, _ = cases.ALL[name]
     ti = build()
@@ -79,14 +86,46 @@ def run_case(name, _lib):
     assert [as_record(c, "cand") for c in cands] == exp["candidates"]
     assert task.coverage_average_total == exp["coverage_average_total"]
     assert task.sv_id == ti.sv_id_start + len(cands)
-    if len(cands) >= 2 and (cands[0].pos, cands[0].svlen) != (cands[-1].pos, cands[-1].svlen):
-        with pytest.raises(RuntimeError):          # the list call_candidates returned, in its order - anything else is refused
-            task.finalize_candidates(cands[::-1], False, cfg)
-        with pytest.raises(RuntimeError):
-            task.finalize_candidates(cands[:-1], False, cfg)
     final = task.finalize_candidates(cands, False, cfg)
     assert [as_record(c, "final") for c in final] == exp["final"]
     assert all(c.postprocess is None for c in final)
+    # any selection of the candidates, in any order (the reference iterates whatever it is given, parallel.py:129-147): every call
+    # carries its place in the batch.  Untouched, the elements are stand-ins that become calls - in their final state - when touched
+    from sniffles_amd import sv as _sv
+    task6 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task6.lead_provider, task6.tandem_repeats = lp, task.tandem_repeats
+    c6 = task6.call_candidates(True, cfg)
+    assert type(c6) is list and len(c6) == len(cands) and all(_sv.is_stand_in(c) and isinstance(c, _sv.SVCall) for c in c6)
+    with pytest.raises(RuntimeError):              # a call of another task's list (finalized: it no longer carries its place)
+        task6.finalize_candidates([final[0]], False, cfg)
+    sel = c6[::-1][1:]
+    f6 = task6.finalize_candidates(sel, False, cfg)
+    assert len(f6) == len(sel) and all(a is b for a, b in zip(f6, sel)) and all(_sv.is_stand_in(c) for c in f6)
+    assert [bool(c.qc) for c in f6] == [r["qc"] for r in exp["final"][::-1][1:]] and all(_sv.is_stand_in(c) for c in f6)   # (`qc` alone fills nothing)
+    assert [as_record(c, "final") for c in f6] == exp["final"][::-1][1:]
+    assert not any(_sv.is_stand_in(c) for c in f6) and all(type(c) is _sv.SVCall and c.postprocess is None for c in f6)
+    assert [flat_call(c) for c in f6] == [flat_call(c) for c in final[::-1][1:]]
+    # ... and touched between the two calls (a caller that filters on the candidates' fields): objects at the candidate stage, mapped back
+    task7 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task7.lead_provider, task7.tandem_repeats = lp, task.tandem_repeats
+    c7 = task7.call_candidates(True, cfg)
+    pick = [k for k, c in enumerate(c7) if k % 2 == 0 or c.svtype == "BND"]
+    assert [as_record(c7[k], "cand") for k in pick] == [exp["candidates"][k] for k in pick]
+    assert [as_record(c, "final") for c in task7.finalize_candidates([c7[k] for k in pick], False, cfg)] == [exp["final"][k] for k in pick]
+    import copy
+    import pickle
+    task8 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task8.lead_provider, task8.tandem_repeats = lp, task.tandem_repeats
+    c8 = task8.finalize_candidates(task8.call_candidates(True, cfg), False, cfg)
+    if c8:
+        # a stand-in pickles, copies, compares and prints as the call it stands for; its `__dict__` is the call's
+        k8 = len(c8) // 2
+        assert flat_call(pickle.loads(pickle.dumps(c8[k8]))) == flat_call(final[k8]) and type(c8[k8]) is _sv.SVCall
+        assert list(c8[0].__dict__) == list(final[0].__dict__)
+        if len(c8) > 2:
+            assert flat_call(copy.deepcopy(c8[-1])) == flat_call(final[-1])
+    for t_ in (task6, task7, task8):
+        t_.close()
     # CallTask.execute's tail in one step (filter + sort on the device, only the kept calls become objects): the same objects
     task2 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
     task2.lead_provider, task2.tandem_repeats = lp, task.tandem_repeats
@@ -207,19 +246,60 @@ def test_one_walk_lead_columns_equal_the_python_passes():
         ti = build()
         cfg = gu.make_config(kw, ti)
         out = []
-        for force_py in (False, True):
-            lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+        # the three forms of the input side: columns written when a lead is recorded (`_snf_fast.LeadSink`, the default), one walk over
+        # the kept objects in `to_task_input` (`lead_columns`), the per-field Python passes
+        for at_record_time, force_py in ((True, False), (False, False), (False, True)):
+            lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len, record_time_columns=at_record_time)
+            assert (lp._sink is not None) == at_record_time
             lp._force_py = force_py
-            for ld in leads_of(ti):
-                lp.record_lead(ld, 0)
+            for k, ld in enumerate(leads_of(ti)):
+                if k % 2:
+                    lp.record_lead(ld, 0)
+                else:
+                    lp.record_lead(ld)            # (pos_leadtab is optional, as in the mirror's signature)
             for s, e, hp in zip(ti.read_start.tolist(), ti.read_end.tolist(), ti.read_hp.tolist()):
                 lp.record_read(s, e, hp)
             out.append(lp.to_task_input(ti.task_id, ti.sv_id_start, None, ti.qc_nm_threshold))
-        a, b = out
-        assert a.n_leads == b.n_leads == ti.n_leads
-        for f in a.leads:
-            x, y = a.leads[f], b.leads[f]
-            assert x.dtype == y.dtype and (np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)), (name, f)
-        assert a.qnames == b.qnames and a.ps_names == b.ps_names and a.contig_names == b.contig_names
-        assert np.array_equal(a.seq_pool, b.seq_pool)
-        assert np.array_equal(a.read_start, b.read_start) and np.array_equal(a.read_end, b.read_end) and np.array_equal(a.read_hp, b.read_hp)
+        b = out[-1]
+        for a in out[:-1]:
+            assert a.n_leads == b.n_leads == ti.n_leads
+            for f in a.leads:
+                x, y = a.leads[f], b.leads[f]
+                assert x.dtype == y.dtype and (np.array_equal(x, y, equal_nan=True) if x.dtype.kind == "f" else np.array_equal(x, y)), (name, f)
+            assert a.qnames == b.qnames and a.ps_names == b.ps_names and a.contig_names == b.contig_names
+            assert np.array_equal(a.seq_pool, b.seq_pool)
+            assert np.array_equal(a.read_start, b.read_start) and np.array_equal(a.read_end, b.read_end) and np.array_equal(a.read_hp, b.read_hp)
+
+
+def test_record_time_columns_are_a_snapshot_and_reject_bad_leads():
+    """`record_lead` reads the lead when it is recorded: a later change of the object does not reach the task input (the reference's
+    callers record finished leads); a lead whose attributes cannot be read raises there and leaves no row; name ranks follow Python
+    string order (code points) also beyond ASCII."""
+    import numpy as np
+    from sniffles_amd import sv
+    fast = sv._load_fast()
+    assert hasattr(fast, "LeadSink") and hasattr(fast, "rank_strings")
+    build, kw, _ = cases.ALL["fuzz_4_2"]
+    ti = build()
+    cfg = gu.make_config(kw, ti)
+    lp = leadprov.LeadProvider(cfg, 0, ti.contig, contig_len=ti.contig_len)
+    leads = list(leads_of(ti))
+    for ld in leads:
+        lp.record_lead(ld, 0)
+    before = lp.to_task_input(ti.task_id, ti.sv_id_start, None, ti.qc_nm_threshold)
+    bad = leadprov.Lead(**{**leads[0].__dict__, "svtype": "NOT_A_TYPE"})
+    with pytest.raises(KeyError):
+        lp.record_lead(bad, 0)
+    leads[0].ref_start += 1000                      # after the fact: not seen
+    after = lp.to_task_input(ti.task_id, ti.sv_id_start, None, ti.qc_nm_threshold)
+    assert after.n_leads == before.n_leads == len(leads)
+    for f in before.leads:
+        assert np.array_equal(before.leads[f], after.leads[f], equal_nan=before.leads[f].dtype.kind == "f")
+    assert np.array_equal(before.seq_pool, after.seq_pool)
+    names = ["read\u00e9", "read", "Read", "read10", "read2", "\U0001f600", "z" * 40, "z" * 39 + "y", "", "readZ", "\u4e2d"]
+    rng = np.random.default_rng(5)
+    many = sorted({"".join(chr(int(c)) for c in rng.choice([48, 49, 65, 97, 233, 0x4e2d, 0x1f600], int(rng.integers(0, 14)))) for _ in range(4000)})
+    for pool in (names, [many[j] for j in rng.permutation(len(many))]):       # (more than 64 names: the radix path)
+        in_order, rank = fast.rank_strings(pool)
+        rank = np.frombuffer(rank, np.int64)
+        assert in_order == sorted(pool) and [int(r) for r in rank] == [in_order.index(x) for x in pool]

@@ -350,6 +350,51 @@ def check_staged_result(oracle_mod, monkeypatch):
     assert got["a"] == [want] * 4 and got["b"] == [want] * 4
 
 
+def test_pacing_state_is_per_device(monkeypatch):
+    """Whether a pass stages its result through HBM (and whether its start is paced) is decided by what is in flight on ITS device:
+    two handles that overlap on device 0 switch to the staged result (the fetch then copies: a `d2h_block` entry in the timings), a
+    handle that works alone on device 1 of the same process keeps its direct stores all the while (host tier with two device indices)."""
+    import threading
+    import time
+    monkeypatch.setenv("SNF_SIMT_DEVICES", "2")
+    monkeypatch.setenv("SNF_TIME_ALL", "1")           # (the copies of a staged result are bracketed by timing events only then)
+    import emu.emu as E
+    E.lib()
+    assert lib.device_count() == 2
+    tis = tasks()
+    cfg = SnifflesConfig()
+    with lib.Batch(cfg, tis, device=0) as a1, lib.Batch(cfg, tis, device=0) as a2, lib.Batch(cfg, tis, device=1) as lone:
+        for b in (a1, a2, lone):
+            b.set_output(abi.OUT_EXECUTE)
+            b.timing_every(1)
+        stop = threading.Event()
+        staged = {"a": 0}
+
+        def busy(b):
+            while not stop.is_set():
+                b.run_pass(); b.fetch(1)
+                staged["a"] += any(t[0] == "d2h_block" for t in b.timings())
+        ths = [threading.Thread(target=busy, args=(b,)) for b in (a1, a2)]
+        for t in ths:
+            t.start()
+        lone_staged, want = 0, None
+        t_end = time.time() + 60
+        n = 0
+        while (n < 6 or staged["a"] < 3) and time.time() < t_end:
+            lone.run_pass()
+            r = lone.fetch(1)
+            blk = (r.calls.tobytes(), r.alt_pool.tobytes())
+            want = want or blk
+            assert blk == want
+            lone_staged += any(t[0] == "d2h_block" for t in lone.timings())
+            n += 1
+        stop.set()
+        for t in ths:
+            t.join()
+    assert staged["a"] >= 3, "the two handles of device 0 never overlapped"
+    assert lone_staged == 0 and n >= 6
+
+
 def test_staged_result_emu(oracle_mod, monkeypatch):
     import emu.emu as E
     E.lib()

@@ -163,8 +163,9 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
             if shape == "execute":
                 n_ += len(task.execute_calls(cfg))
             else:
-                cands = task.call_candidates(False, cfg)
-                n_ += len(task.finalize_candidates(cands, True, cfg))
+                # Task.call_candidates + Task.finalize_candidates and CallTask.execute's own tail on their result (parallel.py:265-271):
+                # `[s for s in svcalls if s.qc]`, `sorted(key=pos)` - reads `qc` of every candidate, `pos` of every kept call
+                n_ += len(task.call_svs(cfg))
             task.close()
         return (time.perf_counter() - ta) * 1e3, n_
     exe_serial_ms, n3 = per_task("execute", False)
@@ -215,8 +216,9 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
                      "batched = all contig tasks in one device batch, the objects of what CallTask.execute returns (QC-passing calls, "
                      "sorted; "
                      "materialise_all_candidates_ms: every candidate instead); per_task_api = 24 x Task.call_candidates + "
-                     "finalize_candidates "
-                     "(every candidate an object twice over, the reference's two-call shape); per_task_execute = 24 x "
+                     "finalize_candidates + CallTask.execute's filter on `qc` and sort by `pos` "
+                     "(the reference's two-call shape; candidates are stand-ins that become objects when touched - the kept calls do); "
+                     "per_task_execute = 24 x "
                      "CallTask.execute_calls; both with two "
                      "tasks in flight (Task.prepare: the next task uploads and runs while this one's records become objects), "
                      "one_task_at_a_time_ms without; "

@@ -8,8 +8,9 @@ context), contigs assigned longest-first, every worker builds its inputs BEFORE 
 the `leads` input form, the `Lead` objects fed through `LeadProvider.record_lead` / `record_read` (extraction's work, untimed on
 both sides) - then runs its tasks; the figure is the slowest worker's time over its tasks.  Input forms:
   columns   the lead provider already holds typed columns (what this package's extraction produces): no object walk
-  leads     a LeadProvider filled with Lead objects, as a ported `iter_region` would fill it: `call_candidates` starts with the
-            one walk over the objects that turns them into columns (`to_task_input`) - the ingest share is reported
+  leads     a LeadProvider filled with Lead objects through `record_lead`, as a ported `iter_region` would fill it (a lead becomes a row
+            of typed columns when it is recorded - where the reference pays its binning); `call_candidates` starts with `to_task_input`
+            (a copy of the finished columns + the string-rank remap) - its share is reported
 Every worker keeps two tasks in flight (`Task.prepare`: task k + 1 uploads and runs while task k's records become objects).
 
     python tools/bench_workers.py [P ...]          (default 4 8 24)
@@ -90,8 +91,9 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
             if shape == "execute":
                 n_out += len(t.execute_calls(cfg))
             else:
-                cands = t.call_candidates(False, cfg)
-                n_out += len(t.finalize_candidates(cands, True, cfg))
+                # the two calls and what CallTask.execute does with their result (parallel.py:265-271): `[s for s in svcalls if s.qc]`,
+                # `sorted(key=pos)` - every candidate's `qc` is read, every kept call is a finished object when the loop moves on
+                n_out += len(t.call_svs(cfg))
             t.close()
         hot = time.perf_counter() - t_all0
         out_q.put(dict(worker=wid, hot_s=hot, ingest_s=ingest_s, n_out=n_out, tasks=len(tasks), leads=sum(x[1].n_leads for x in built)))
