@@ -103,12 +103,22 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the box's hostname need not resolve)
         if EMU:
             dist.init_process_group(backend="gloo")
-        else:
+        elif os.environ.get("SNF_BENCH_PG") == "nccl":
+            # (the process group of rounds 2-5: RCCL's communicator - its streams and proxy thread on the device - exists from the start)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # control words (a few int64 per run and per pass: sizes, layouts, the timing reduction, barriers) travel as CPU tensors
+            # over gloo; RCCL - backend "nccl" for CUDA tensors - builds its communicator with the first CUDA collective, i.e. only where
+            # result BLOCKS are gathered (no /dev/shm: several nodes, SNF_BENCH_GATHER=rccl).  On one node no result byte needs it
+            # (dist.SharedLanding), and a communicator that merely exists cost the passes 14-16 % (profiles/r05_shared_probe.log)
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl")
 
-    ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist, numa=numa)
+    # where the control tensors of the collectives live: host memory unless the whole group is RCCL
+    ctl_dev = DEV if (not use_dist or EMU or os.environ.get("SNF_BENCH_PG") == "nccl") else "cpu"
+    ctx = dict(args=args, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist, numa=numa, ctl_dev=ctl_dev)
     if args.config != 4:
         args.steps = 30 if args.steps is None else args.steps
         args.warmup = 3 if args.warmup is None else args.warmup
@@ -155,6 +165,7 @@ def run_calling(ctx):
     from sniffles_amd.config import SnifflesConfig
 
     args, rank, world, local_rank, use_dist = (ctx[k] for k in ("args", "rank", "world", "local_rank", "use_dist"))
+    CTL = ctx.get("ctl_dev", DEV)
     wl = WORKLOADS[args.config]
     cfg = SnifflesConfig(**wl["cfg"])
     if os.environ.get("SNF_BENCH_CFG"):   # ablation experiments only (e.g. '{"symbolic": true}'): the line says so and is no result
@@ -237,7 +248,7 @@ def run_calling(ctx):
             res0 = probe.fetch(1)
             need_b = max(need_b, 256 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames))
             need_a = max(need_a, len(res0.alt_pool))
-        need = torch.tensor([need_b, need_a], dtype=torch.int64, device=DEV)
+        need = torch.tensor([need_b, need_a], dtype=torch.int64, device=CTL)
         dist.all_reduce(need, op=dist.ReduceOp.MAX)
         # /dev/shm must hold every rank's segments (containers often cap it): otherwise the block gather over RCCL is taken
         n_slots = NGEN * W * len(group_tasks) if strong_shared else 2 * W
@@ -248,7 +259,7 @@ def run_calling(ctx):
             room = st.f_bavail * st.f_frsize >= int(world * seg_bytes * 1.25) and os.environ.get("SNF_BENCH_SHM_FULL") != "1"
         except OSError:
             room = False
-        ok_t = torch.tensor([1 if room else 0], dtype=torch.int64, device=DEV)
+        ok_t = torch.tensor([1 if room else 0], dtype=torch.int64, device=CTL)
         dist.all_reduce(ok_t, op=dist.ReduceOp.MIN)
         if not int(ok_t.item()):
             if rank == 0:
@@ -295,7 +306,7 @@ def run_calling(ctx):
         probe.call_candidates(); probe.finalize()
         res0 = probe.fetch(1)
         blk = 256 * 3 + len(res0.calls) * abi.CALL_DTYPE.itemsize + 4 * len(res0.rnames) + len(res0.alt_pool)
-        cap_t = torch.tensor([blk * (len(group_tasks) if strong else 1) * 3 // 2 + (1 << 20)], dtype=torch.int64, device=DEV)
+        cap_t = torch.tensor([blk * (len(group_tasks) if strong else 1) * 3 // 2 + (1 << 20)], dtype=torch.int64, device=CTL)
         dist.all_reduce(cap_t, op=dist.ReduceOp.MAX)
         cap_bytes = int(cap_t.item())
         sends = [torch.zeros(cap_bytes, dtype=torch.uint8, device=DEV) for _ in range(n_send)]
@@ -581,8 +592,8 @@ def run_calling(ctx):
         for hs in extra:
             hs[0].close()
 
-    tt = torch.tensor([dt], dtype=torch.float64, device=DEV)
-    tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device=DEV)
+    tt = torch.tensor([dt], dtype=torch.float64, device=CTL)
+    tot = torch.tensor([n_sig, n_calls], dtype=torch.int64, device=CTL)
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         if not strong:

@@ -2035,7 +2035,7 @@ void do_fetch(snf_batch_impl* b, int stage, snf_result_t* out) {
   if (v.prof) {
     const Counts& c = *b->h_cnt;
     fprintf(stderr, "[SNF_PROF] counts: valid %lld bins %lld seeds %lld clusters %lld refined %lld calls %lld | cons calls %lld reads %lld "
-                    "fallback %lld alt bytes %lld fused bytes %llu | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu rows %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
+                    "fallback %lld alt bytes %lld fused bytes through the shared counter %llu (the rest in the waves' own slices; the split depends on scheduling, the total and the capacity do not) | ALT lists copy %llu small %llu large %llu/%llu/%llu/%llu thread %llu rows %llu\n", (long long)c.n_valid, (long long)c.n_bins, (long long)c.n_seeds, (long long)c.n_clusters,
             (long long)c.n_rc, (long long)c.n_calls, (long long)c.n_cons, (long long)c.n_cons_reads, (long long)c.n_cons_fallback,
             (long long)c.alt_total, c.pool_extra_used, c.n_cls[0], c.n_cls[1], c.n_cls[2], c.n_cls[3], c.n_cls[4], c.n_cls[5], c.n_cls[6], c.n_cls[7]);
   }

@@ -240,6 +240,19 @@ done:
  * instance of `lazy_cls` whose dict holds `qc` (what `[s for s in svcalls if s.qc]`, parallel.py:267, reads), the source that can
  * turn it into the real call, and its place there.  stub_refresh_qc(calls: list, records: buffer, lo): `qc` of the final records for
  * the elements that still are stand-ins. */
+static PyObject** g_idx_cache = NULL; static Py_ssize_t g_idx_cache_n = 0;      /* the ints 0 .. n-1, made once (a stand-in's place) */
+static PyObject* idx_object(long long i) {      /* borrowed */
+  if (i >= g_idx_cache_n) {
+    Py_ssize_t n = g_idx_cache_n ? g_idx_cache_n : 4096;
+    while (n <= i) n *= 2;
+    PyObject** q = (PyObject**)realloc(g_idx_cache, (size_t)n * sizeof(PyObject*));
+    if (!q) { PyErr_NoMemory(); return NULL; }
+    g_idx_cache = q;
+    for (Py_ssize_t k = g_idx_cache_n; k < n; k++) { g_idx_cache[k] = PyLong_FromSsize_t(k); if (!g_idx_cache[k]) { g_idx_cache_n = k; return NULL; } }
+    g_idx_cache_n = n;
+  }
+  return g_idx_cache[i];
+}
 static PyObject* py_make_stubs(PyObject* self, PyObject* args) {
   PyObject *cls, *src; Py_buffer calls; long long lo, hi;
   if (!PyArg_ParseTuple(args, "OOy*LL", &cls, &src, &calls, &lo, &hi)) return NULL;
@@ -249,15 +262,61 @@ static PyObject* py_make_stubs(PyObject* self, PyObject* args) {
   out = PyList_New(hi - lo);
   for (long long i = lo; out && i < hi; i++) {
     PyObject* d = _PyDict_NewPresized(3);
-    PyObject* ix = d ? PyLong_FromLongLong(i - lo) : NULL;
-    if (!ix || PyDict_SetItem(d, K_qc, C[i].qc ? Py_True : Py_False) || PyDict_SetItem(d, K_lz, src) || PyDict_SetItem(d, K_lzi, ix)) { Py_XDECREF(d); Py_XDECREF(ix); Py_CLEAR(out); break; }
-    Py_DECREF(ix);
+    PyObject* ix = d ? idx_object(i - lo) : NULL;
+    if (!ix || PyDict_SetItem(d, K_qc, C[i].qc ? Py_True : Py_False) || PyDict_SetItem(d, K_lz, src) || PyDict_SetItem(d, K_lzi, ix)) { Py_XDECREF(d); Py_CLEAR(out); break; }
     PyObject* obj = new_instance(cls, d);
     if (!obj) { Py_CLEAR(out); break; }
     PyList_SET_ITEM(out, i - lo, obj);
   }
 done:
   PyBuffer_Release(&calls);
+  return out;
+}
+/* stub_select(stubs: list, src, mode) -> (targets: list, idx: bytes int64): the elements of `stubs` that still are stand-ins of `src`
+ * (mode 1: those whose `qc` is set; mode 2: those that something besides the list `stubs` refers to) and their places.  stub_others(calls: list, src) -> list: the elements that are NOT
+ * stand-ins of `src` (real calls - or stand-ins of another source, which the caller refuses), in list order. */
+static PyObject* py_stub_select(PyObject* self, PyObject* args) {
+  PyObject *lst, *src; int mode = 0;      /* 0: every stand-in of src; 1: those with qc set; 2: those somebody besides `stubs` holds */
+  if (!PyArg_ParseTuple(args, "O!Oi", &PyList_Type, &lst, &src, &mode)) return NULL;
+  const int only_qc = mode == 1;
+  const Py_ssize_t n = PyList_GET_SIZE(lst);
+  PyObject* targets = PyList_New(0);
+  int64_t* idx = (int64_t*)malloc((size_t)(n ? n : 1) * 8);
+  PyObject* out = NULL;
+  Py_ssize_t m = 0;
+  if (!targets || !idx) { PyErr_NoMemory(); goto done; }
+  for (Py_ssize_t k = 0; k < n; k++) {
+    PyObject* o = PyList_GET_ITEM(lst, k);
+    PyObject** dp = _PyObject_GetDictPtr(o);
+    if (!dp || !*dp) continue;
+    PyObject* s = PyDict_GetItemWithError(*dp, K_lz);
+    if (!s) { if (PyErr_Occurred()) goto done; continue; }
+    if (s != src) continue;
+    if (only_qc) { PyObject* q = PyDict_GetItemWithError(*dp, K_qc); if (!q) { if (PyErr_Occurred()) goto done; continue; } if (q != Py_True) continue; }
+    if (mode == 2 && Py_REFCNT(o) <= 1) continue;
+    if (PyList_Append(targets, o) != 0) goto done;
+    idx[m++] = (int64_t)k;
+  }
+  {
+    PyObject* ib = PyBytes_FromStringAndSize((const char*)idx, m * 8);
+    if (ib) out = Py_BuildValue("(ON)", targets, ib);
+  }
+done:
+  free(idx); Py_XDECREF(targets);
+  return out;
+}
+static PyObject* py_stub_others(PyObject* self, PyObject* args) {
+  PyObject *lst, *src;
+  if (!PyArg_ParseTuple(args, "O!O", &PyList_Type, &lst, &src)) return NULL;
+  PyObject* out = PyList_New(0);
+  for (Py_ssize_t k = 0; out && k < PyList_GET_SIZE(lst); k++) {
+    PyObject* o = PyList_GET_ITEM(lst, k);
+    PyObject** dp = _PyObject_GetDictPtr(o);
+    PyObject* s = (dp && *dp) ? PyDict_GetItemWithError(*dp, K_lz) : NULL;
+    if (!s && PyErr_Occurred()) { Py_CLEAR(out); break; }
+    if (s == src && src != Py_None) continue;
+    if (PyList_Append(out, o) != 0) Py_CLEAR(out);
+  }
   return out;
 }
 static PyObject* py_stub_refresh_qc(PyObject* self, PyObject* args) {
@@ -2056,6 +2115,8 @@ static PyMethodDef methods[] = {
     {"lead_columns", py_lead_columns, METH_VARARGS, "Lead objects -> typed TaskInput columns in one walk (input side of the drop-in)"},
     {"materialize", py_materialize, METH_VARARGS, "records [lo, hi) -> list of SVCall objects (candidate-stage fields)"},
     {"make_stubs", py_make_stubs, METH_VARARGS, "lazy stand-ins of the calls of a record range"},
+    {"stub_select", py_stub_select, METH_VARARGS, "the stand-ins of a source in a list, and their places"},
+    {"stub_others", py_stub_others, METH_VARARGS, "the elements of a list that are not stand-ins of a source"},
     {"stub_refresh_qc", py_stub_refresh_qc, METH_VARARGS, "qc of the final records onto the stand-ins of a list"},
     {"apply_final", py_apply_final, METH_VARARGS, "finalize-stage fields of the records onto materialised calls"},
     {"collect", py_collect, METH_VARARGS, "SVCall objects of SNF blocks -> candidate records, ALT pool, BND mates"},

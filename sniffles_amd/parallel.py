@@ -131,11 +131,12 @@ class Task:
         return out
 
     def _drop_lazy(self):
-        """The stand-ins of the previous candidate list lose their bulk source (each still fills alone); breaks the list <-> source cycle."""
+        """Before the batch's result block is handed on (the task runs again, or is closed): the stand-ins of the previous candidate list
+        that are still held become calls, their source lets go of the block (sv.LazySource.detach)."""
         src = getattr(self, "_lazy", None)
-        if src is not None:
-            src.stubs = None
         self._lazy = None
+        if src is not None:
+            src.detach()
 
     def call_records(self, config, execute: bool = False):
         """call_candidates + finalize_candidates without the `SVCall` objects: the finalized record table of the task
@@ -172,11 +173,11 @@ class Task:
         if src is not None:
             src.set_final(res)          # the stand-ins take the final `qc`; whoever is touched from now on is built in its final state
         real, idx = [], []
-        for c in candidates:
+        # (the stand-ins of this task's source need nothing: whoever touches them finds the final records)
+        others = sv._load_fast().stub_others(candidates, src) if src is not None else candidates
+        for c in others:
             if sv.is_stand_in(c):
-                if sv._raw_dict(c).get("_lz") is not src:
-                    raise RuntimeError("a candidate of another task's (or an earlier) call_candidates was passed")
-                continue
+                raise RuntimeError("a candidate of another task's (or an earlier) call_candidates was passed")
             pp = getattr(c, "postprocess", None)
             i = getattr(pp, "index", None)
             if pp is None or getattr(pp, "batch", None) is not self._batch or i is None or not 0 <= int(i) < n_rec:

@@ -418,14 +418,16 @@ def lazy_class(cls):
 
 
 class LazySource:
-    """Where the stand-ins of one task's candidate list come from: the record tables (copies - the batch's pinned block is handed on),
-    the task input and the classes.  `stage` 0: the candidates of `call_candidates`; `set_final` moves it to the records of
-    `finalize_candidates`."""
+    """Where the stand-ins of one task's candidate list come from: the record tables - VIEWS of the batch's pinned result block, valid
+    until the task's next call on the batch -, the task input and the classes.  At first the candidates of `call_candidates`;
+    `set_final` moves it to the records of `finalize_candidates`; `detach` - before the block is handed on: the task's next call, its
+    `close()` - turns every stand-in somebody still holds into its call and lets go of the tables (no copy of the records is ever made:
+    a consumer that keeps the calls it wants and drops the rest, as `CallTask.execute` does, pays for the calls it keeps)."""
 
     def __init__(self, res: Result, ti, svcall_cls, bnd_cls, post_cls, batch, keep_all: bool):
         import numpy as np
-        self.calls = np.ascontiguousarray(res.calls).copy()
-        self.rnames = np.ascontiguousarray(res.rnames, np.uint32).copy()
+        self.calls = np.ascontiguousarray(res.calls)
+        self.rnames = np.ascontiguousarray(res.rnames, np.uint32)
         self.alt_pool = None
         self.ti, self.cls, self.bnd_cls, self.post_cls, self.batch = ti, svcall_cls, bnd_cls, post_cls, batch
         self.final = False
@@ -441,11 +443,23 @@ class LazySource:
 
     def set_final(self, res: Result) -> None:
         import numpy as np
-        self.calls = np.ascontiguousarray(res.calls).copy()
-        self.rnames = np.ascontiguousarray(res.rnames, np.uint32).copy()
-        self.alt_pool = np.ascontiguousarray(res.alt_pool, np.uint8).copy()
+        self.calls = np.ascontiguousarray(res.calls)
+        self.rnames = np.ascontiguousarray(res.rnames, np.uint32)
+        self.alt_pool = np.ascontiguousarray(res.alt_pool, np.uint8)
         self.final = True
         _load_fast().stub_refresh_qc(self.stubs, self.calls, 0)
+
+    def detach(self) -> None:
+        """The record tables are about to be handed on: the stand-ins that anything besides this source's own list still refers to
+        become calls now; the others are garbage.  Breaks the list <-> source cycle."""
+        import numpy as np
+        if self.stubs is not None and self.calls is not None:
+            targets, idx = _load_fast().stub_select(self.stubs, self, 2)
+            if targets:
+                self.fill_many(targets, np.frombuffer(idx, np.int64))
+            del targets
+        self.stubs = None
+        self.calls = self.rnames = self.alt_pool = None
 
     def fill(self, obj) -> None:
         """`obj` (a stand-in of this source) was touched: it and every stand-in the consumer is about to touch become real calls -
@@ -456,18 +470,13 @@ class LazySource:
         me = d.get("_lzi")
         if me is None:
             return
-        lz = lazy_class(self.cls)
-        idx = [me]
+        if self.calls is None:
+            raise RuntimeError("this call's task was closed (or ran again) while nothing referred to the call")
         if self.stubs is not None and (not self.final or self.keep_all or d.get("qc")):
-            want_all = not self.final or self.keep_all
-            idx = []
-            for k, c in enumerate(self.stubs):
-                if type(c) is lz:
-                    cd = _raw_dict(c)
-                    if cd.get("_lz") is self and (want_all or cd.get("qc") or k == me):
-                        idx.append(k)
-        targets = [self.stubs[k] for k in idx] if self.stubs is not None else [obj]
-        self.fill_many(targets, np.asarray(idx, np.int64))
+            targets, idx = _load_fast().stub_select(self.stubs, self, 1 if (self.final and not self.keep_all) else 0)
+            self.fill_many(targets, np.frombuffer(idx, np.int64))
+        else:
+            self.fill_many([obj], np.asarray([me], np.int64))
 
     def fill_many(self, targets: list, idx) -> None:
         import numpy as np

@@ -124,7 +124,18 @@ def run_case(name, _lib):
         assert list(c8[0].__dict__) == list(final[0].__dict__)
         if len(c8) > 2:
             assert flat_call(copy.deepcopy(c8[-1])) == flat_call(final[-1])
-    for t_ in (task6, task7, task8):
+    # the stand-ins' source reads the batch's own result block: before the block is handed on (close, the task's next call) whatever
+    # is still held becomes a call, the rest is garbage - and nothing is copied for the calls nobody kept
+    task9 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)
+    task9.lead_provider, task9.tandem_repeats = lp, task.tandem_repeats
+    f9 = task9.finalize_candidates(task9.call_candidates(True, cfg), False, cfg)
+    if len(f9) >= 2:
+        held, k9 = f9[-1], len(f9) - 1
+        assert _sv.is_stand_in(held)
+        del f9
+        task9.close()
+        assert not _sv.is_stand_in(held) and type(held) is _sv.SVCall and flat_call(held) == flat_call(final[k9])
+    for t_ in (task6, task7, task8, task9):
         t_.close()
     # CallTask.execute's tail in one step (filter + sort on the device, only the kept calls become objects): the same objects
     task2 = parallel.CallTask(id=ti.task_id, sv_id=ti.sv_id_start, contig=ti.contig, start=0, end=ti.contig_len, config=cfg)

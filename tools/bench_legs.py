@@ -196,9 +196,10 @@ def wall_clock(cfg, tasks, device, specs=None, cfg_kw=None):
                       to_task_input_ms=round((ti2 - ti1) * 1e3, 2), us_per_lead=round(per_lead * 1e6, 3),
                       ingest_ms_genome_one_core=round(per_lead * n_all_leads * 1e3, 1),
                       ingest_ms_largest_task=round(per_lead * max(t.n_leads for t in tasks) * 1e3, 1),
-                      note="record_lead / record_read append; to_task_input = ONE walk over the Lead objects in C "
-                           "(_snf_fast.lead_columns) + name "
-                           "interning; one process per contig in the reference's layout: the largest task bounds the wall clock")
+                      note="record_lead turns the Lead into a row of typed columns when it is recorded (_snf_fast.LeadSink: where the "
+                           "reference pays its binning, outside the call seam); to_task_input - inside Task.call_candidates - is a copy of the "
+                           "finished columns + the string-rank remap; us_per_lead / the genome figures = record + to_task_input together; one "
+                           "process per contig in the reference's layout: the largest task bounds the wall clock")
         del objs
     except Exception as e:  # noqa: BLE001
         ingest = f"failed: {type(e).__name__}: {e}"

@@ -168,8 +168,8 @@ def run(ctx):
     objects_ms = (time.perf_counter() - t1) * 1e3
     text_equal = text_box[0].buffer.getvalue() == text_fast
     lib.combine_resolve_batch = real_call
-    tt = torch.tensor([dt], dtype=torch.float64, device=DEV)
-    tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device=DEV)
+    tt = torch.tensor([dt], dtype=torch.float64, device=ctx.get("ctl_dev", DEV))
+    tot = torch.tensor([n_cands, box["calls"]], dtype=torch.int64, device=ctx.get("ctl_dev", DEV))
     if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)

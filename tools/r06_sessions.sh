@@ -48,4 +48,48 @@ print('$tag', 'ms_per_step', round(d['ms_per_step'],1), 'kernel_ms', d['config']
 done 2>&1 | tee gpurun_out/ab_r06_2.log
 unset SNF_LIB_SO
   ;;
+4)
+# round 6, fourth session: record-time columns + lazy calls at the seam: the GPU tests of the drop-in boundary, the default line without the
+# side configs (wall_clock legs, worker processes, the reference beside them), P = 24 worker processes with a bounded number of GPU slots
+timeout 900 python -m pytest tests/test_dropin_api.py tests/test_insitu_seam.py tests/test_output_modes.py tests/test_reference_pool.py tests/test_genotype.py tests/test_snf.py -m gpu -x -q > gpurun_out/pytest_gpu_4.log 2>&1; tail -3 gpurun_out/pytest_gpu_4.log
+( time timeout 900 python bench.py --no-configs > gpurun_out/bench_noconf_4.json 2> gpurun_out/bench_noconf_4.err ) 2>&1 | grep real
+python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/bench_noconf_4.json").read().splitlines() if l.startswith('{"metric"')][-1])
+print("ms_per_step", d["ms_per_step"], "verified", d.get("verified"), d.get("verified_vs_reference"))
+print("vs_baseline", json.dumps(d["cpu_baseline"].get("vs_baseline")))
+wc = d.get("wall_clock", {})
+print("batched", json.dumps(wc.get("batched")))
+print("ingest", json.dumps(wc.get("ingest")))
+print("per_task", json.dumps(wc.get("per_task_api")), json.dumps(wc.get("per_task_execute")))
+for k, v in (wc.get("worker_processes") or {}).items():
+    print("workers", k, v if not isinstance(v, dict) else {x: v[x] for x in ("hot_all_ms", "ingest_all_ms", "hw_queues_per_process", "n_out")})
+PY
+tail -3 gpurun_out/bench_noconf_4.err
+for slots in 0 2 4 8; do timeout 240 python tools/workers_slots.py 24 $slots columns; done 2>&1 | grep '^{' | tee gpurun_out/workers_slots_4.log
+  ;;
+5)
+# round 6, fifth session (bounded: every leg under its own timeout): the seam with the stand-in loops in C and no record copies; P = 24
+# workers with GPU slots; LARGE consensus with the step words requested at the top of a read (A/B against the library before it); the N > 1
+# code with one rank on the mixed gloo / RCCL group against the RCCL-only group of rounds 2-5
+timeout 300 python -m pytest tests/test_dropin_api.py tests/test_insitu_seam.py -m gpu -x -q 2>&1 | tail -2
+timeout 400 python bench.py --no-configs --no-reference-baseline --no-verify > gpurun_out/bench_wc_5.json 2> /dev/null
+python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/bench_wc_5.json").read().splitlines() if l.startswith('{"metric"')][-1])
+wc = d.get("wall_clock", {})
+print("ms_per_step", d["ms_per_step"]); print("ingest", json.dumps(wc.get("ingest"))[:400])
+print("per_task", json.dumps(wc.get("per_task_api")), json.dumps(wc.get("per_task_execute")))
+for k, v in (wc.get("worker_processes") or {}).items():
+    print("workers", k, v if not isinstance(v, dict) else {x: v[x] for x in ("hot_all_ms", "ingest_all_ms", "n_out")})
+PY
+for slots in 2 4 8; do timeout 200 python tools/workers_slots.py 24 $slots columns; done 2>&1 | grep '^{' | tee gpurun_out/workers_slots_5.log
+timeout 150 python tools/workers_slots.py 24 4 leads 2>&1 | grep '^{' | tee -a gpurun_out/workers_slots_5.log
+timeout 400 bash tools/run_ab.sh -n 2 base:SNF_LIB_SO=$R/variants/base_r06a.so new: 2>&1 | tee gpurun_out/ab_r06_3.log
+for k in 1 2; do
+  SNF_BENCH_FORCE_DIST=1 SNF_BENCH_PG=nccl timeout 120 python bench.py --gpus 1 $Q --steps 40 --warmup 5 2>/dev/null | ms "shared landing, one rank, RCCL-only group"
+  SNF_BENCH_FORCE_DIST=1 timeout 120 python bench.py --gpus 1 $Q --steps 40 --warmup 5 2>/dev/null | ms "shared landing, one rank, gloo + lazy RCCL"
+  timeout 120 python bench.py $Q --steps 40 --warmup 5 2>/dev/null | ms "plain line"
+done 2>&1 | tee gpurun_out/shared_probe_5.log
+  ;;
 esac
