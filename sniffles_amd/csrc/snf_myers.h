@@ -322,6 +322,89 @@ __device__ inline int64_t ed_wave_pair_k_acgt(const uint8_t* P, int32_t m, const
   const int64_t dist = unpad_score(64 + tot, oPv, oMv, (int)(nb * 64 - m));
   return (k >= 0 && dist > k) ? -1 : dist;
 }
+// ---- eight columns per step.  The wavefront above hands ONE column's carry to the next lane per step; here a lane works through a
+// GROUP of eight consecutive columns (one 8-byte text word) of its block and hands the eight carries on as one 16-bit word: one DPP
+// move, one window test, one text load and one score update per eight columns instead of per column, and the eight column steps of a
+// group are straight-line code.  For that the band is widened to whole groups - a block enters at its first column rounded DOWN to a
+// multiple of eight and is followed to the end of the group its last column lies in (clipped at the text's end: only that last group
+// can be partial) - which keeps the staircase shape the banded recurrence needs (every value computed still is the cost of a real path,
+// and the band still holds every path of cost <= k).  The skew between neighbouring blocks is one group, so a pair takes
+// ceil(n / 8) + nb - 1 group steps: the fill of the pipeline costs eight times as many columns as above - ~750 of 6 200 for a 6-kb
+// insertion - against a column step of ~45 instructions instead of ~75.  T_ACGT: the text too is over {A, C, G, T} (no per-column test).
+template <bool T_ACGT>
+__device__ inline int64_t ed_wave_pair_k_acgt8(const uint8_t* P, int32_t m, const uint8_t* T, int32_t n, int64_t k) {
+  const int lane = (int)(threadIdx.x & 63);
+  EdBand bd;
+  if (!ed_band((int64_t)m, (int64_t)n, k, &bd)) return -1;
+  if (m == 0) return n;
+  const int32_t nb = (m + 63) / 64, kk = (int32_t)bd.kk, dl = (int32_t)bd.dl;
+  int32_t b = lane;
+  int32_t g_lo = 0, g_hi = -1, g_own_end = 0, g_up_hi = -1, n_last = 8;   // groups of the block's window; first group of block b + 1; last
+  uint64_t pe[4] = {0, 0, 0, 0}, Pv = ~0ull, Mv = 0;                        // group the block above covers; columns of the last group
+  uint64_t tw = 0, tw_next = 0;
+  auto enter = [&](int32_t blk) {
+    b = blk;
+    if (b < nb) {
+      const int cnt = m - b * 64 < 64 ? m - b * 64 : 64;
+      block_peq_words(P + b * 64, cnt, pe);
+      int32_t ce = ed_band_ce32(kk, dl, n, b) | 7;          // to the end of its group ...
+      if (ce > n - 1) ce = n - 1;                            // ... or of the text: the only group that can be partial
+      g_lo = ed_band_cs32(kk, b) >> 3; g_hi = ce >> 3; n_last = (ce & 7) + 1;
+      g_own_end = b + 1 < nb ? (ed_band_cs32(kk, b + 1) >> 3) : 0x7fffffff;
+      g_up_hi = b > 0 ? (ed_band_ce32(kk, dl, n, b - 1) >> 3) : -1;
+      Pv = ~0ull; Mv = 0;
+      tw = *(const ed_u64_unaligned*)(T + 8 * g_lo); tw_next = *(const ed_u64_unaligned*)(T + 8 * g_lo + 8);
+    } else { g_lo = 0; g_hi = -1; g_own_end = 0; g_up_hi = -1; n_last = 8; }
+  };
+  enter(lane);
+  int32_t acc = 0, rel = 0, own = 0;
+  uint32_t hout = 0;                       // the group's carries: bit q = +1 after column q, bit 8 + q = -1
+  uint64_t fPv = ~0ull, fMv = 0; int32_t frel = 0; bool fin = false;
+  const int32_t steps = ((n + 7) >> 3) + nb - 1;
+  auto column = [&](int q, uint32_t hin_p, uint32_t hin_m, uint32_t& out_p, uint32_t& out_m) {
+    const uint32_t c = (uint32_t)(tw >> (8 * q)) & 0xffu;
+    const uint64_t e01 = (c & 2u) ? pe[1] : pe[0], e23 = (c & 2u) ? pe[3] : pe[2];
+    uint64_t eq = (c & 4u) ? e23 : e01;
+    if (!T_ACGT) { if (!ed_is_acgt(c)) eq = 0; }
+    const uint32_t h = advance_block2(Pv, Mv, eq, ((hin_p >> q) & 1u) | (((hin_m >> q) & 1u) << 1));
+    out_p |= (h & 1u) << q; out_m |= (h >> 1) << q;
+  };
+  for (int32_t t = 0; t < steps; t++) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hout, 0x13C, 0xf, 0xf, false);   // wave_ror:1: lane - 1, lane 0 <- 63
+    const int32_t G = t - b;
+    if (G >= g_lo && G <= g_hi) {          // (a lane without a block holds g_hi = -1 < g_lo = 0)
+      const bool above = G <= g_up_hi;     // whole groups: the block above is in the band for all of this group's columns or for none
+      const uint32_t hin_p = above ? (up & 0xffu) : 0xffu, hin_m = above ? (up >> 8) : 0u;
+      uint32_t out_p = 0, out_m = 0;
+      if (G < g_hi || n_last == 8) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) column(q, hin_p, hin_m, out_p, out_m);
+      } else {
+        for (int q = 0; q < n_last; q++) column(q, hin_p, hin_m, out_p, out_m);
+      }
+      hout = out_p | (out_m << 8);
+      const int32_t dsum = __builtin_popcount(out_p) - __builtin_popcount(out_m);
+      rel += dsum;
+      if (G < g_own_end) own += dsum;
+      if (G == g_hi) {
+        if (b == nb - 1) { fPv = Pv; fMv = Mv; frel = rel; fin = true; }
+        else acc += 64 + own;
+        rel = 0; own = 0;
+        enter(b + 64);
+      } else {
+        tw = tw_next; tw_next = *(const ed_u64_unaligned*)(T + 8 * (G + 2));
+      }
+    }
+  }
+  int64_t tot = (int64_t)acc + (fin ? frel : 0);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  const int owner = (int)((nb - 1) & 63);
+  const uint64_t oPv = __shfl(fPv, owner, 64), oMv = __shfl(fMv, owner, 64);
+  const int64_t dist = unpad_score(64 + tot, oPv, oMv, (int)(nb * 64 - m));
+  return (k >= 0 && dist > k) ? -1 : dist;
+}
+
 // the banded wave form for any pair the band of which fits (ed_wave_band_fits): equal strings answer at once, patterns over
 // {A, C, G, T} take the short column step, everything else the bit-plane form
 __device__ inline int64_t ed_wave_pair_k_any(const uint8_t* A, int64_t la, const uint8_t* B, int64_t lb, int64_t k) {
@@ -338,7 +421,15 @@ __device__ inline int64_t ed_wave_pair_k_any(const uint8_t* A, int64_t la, const
     }
     if (__ballot(!same) == 0ull) return 0;
   }
-  if (ed_wave_all_acgt(P, (int32_t)m)) return ed_wave_pair_k_acgt(P, (int32_t)m, T, (int32_t)n, k);
+  if (ed_wave_all_acgt(P, (int32_t)m)) {
+#ifdef SNF_MYERS_ONE_COLUMN
+    return ed_wave_pair_k_acgt(P, (int32_t)m, T, (int32_t)n, k);
+#else
+    // (the text may be read up to 23 bytes past its end here: the words of the group behind the last one; the pools carry that slack)
+    return ed_wave_all_acgt(T, (int32_t)n) ? ed_wave_pair_k_acgt8<true>(P, (int32_t)m, T, (int32_t)n, k)
+                                           : ed_wave_pair_k_acgt8<false>(P, (int32_t)m, T, (int32_t)n, k);
+#endif
+  }
   return ed_wave_pair_k(A, la, B, lb, k);
 }
 

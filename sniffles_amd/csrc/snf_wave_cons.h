@@ -320,25 +320,6 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
 #ifdef SNF_WG_TRACE
       SNF_PT(7);
 #endif
-      // Read in HBM (SCAP == 0): the up to two further words of every sampling step (bytes 8 .. 23: what the segment compares and
-      // the votes read beside the k-mer word) are requested HERE, before the probes and the chain filter, and first used in phase 3:
-      // their round trip runs under phases 1 and 2 instead of in front of phase 3 (a LARGE workgroup has two waves per SIMD: nothing
-      // else hides it)
-      constexpr int WR = SCAP == 0 ? ROUNDS : 1;
-      // Read staged in LDS (SCAP > 0, the SMALL class: skip <= 7 by cons_class_of): the k-mer word alone holds the skip + 1 bytes of a step
-      const bool use_win = SCAP == 0 ? skip <= 23 : true;
-      uint64_t sw1[WR] = {}, sw2[WR] = {};
-      if constexpr (SCAP == 0) {
-#pragma unroll
-        for (int rd = 0; rd < ROUNDS; rd++) {
-          const int p = rd * 64 + lane;
-          sw1[rd] = sw2[rd] = 0;
-          if (use_win && p + 1 < P) {   // (a step inside a segment ends at or before the last sampled position)
-            if (skip >= 8) sw1[rd] = load_u64(S + p * skip + 8);
-            if (skip >= 16) sw2[rd] = load_u64(S + p * skip + 16);
-          }
-        }
-      }
       if constexpr (SCAP > 0) {
 #pragma unroll
         for (int rd = 0; rd < ROUNDS; rd++) {                          // all loads in flight before the first use
@@ -407,7 +388,21 @@ __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, in
       int span = 0;
       // Read in HBM (SCAP == 0): the skip + 1 <= 24 bytes a step is compared and copied from are the step's k-mer word (already
       // here) and up to two more words, requested for all steps of the read at once and kept in registers through the vote
-      // (requested at the top of the read, see there)
+      constexpr int WR = SCAP == 0 ? ROUNDS : 1;
+      // Read staged in LDS (SCAP > 0, the SMALL class: skip <= 7 by cons_class_of): the k-mer word alone holds the skip + 1 bytes of a step
+      const bool use_win = SCAP == 0 ? skip <= 23 : true;
+      uint64_t sw1[WR] = {}, sw2[WR] = {};
+      if constexpr (SCAP == 0) {
+#pragma unroll
+        for (int rd = 0; rd < ROUNDS; rd++) {
+          const int p = rd * 64 + lane;
+          sw1[rd] = sw2[rd] = 0;
+          if (use_win && p + 1 < P) {   // (a step inside a segment ends at or before the last sampled position)
+            if (skip >= 8) sw1[rd] = load_u64(S + p * skip + 8);
+            if (skip >= 16) sw2[rd] = load_u64(S + p * skip + 16);
+          }
+        }
+      }
       // step -> segment: every segment marks its first step, a running maximum carries the mark over the segment's steps
 #pragma unroll
       for (int rd = 0; rd < ROUNDS; rd++) { const int p = rd * 64 + lane; if (p < P) W.seg_pref[p] = 0u; }

@@ -62,6 +62,52 @@ def test_edit_distance_banded_emulated(oracle_mod):
     check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs])
 
 
+def acgt_pairs(seed, sizes):
+    """Pairs whose shorter string is over {A, C, G, T} (what the ACGT column step of the banded wave form takes: Peq selects, two-bit
+    carries, eight columns per step): a mutated copy over the same letters, one with a few other bytes in it ('N', lower case: the text
+    may hold anything), an unrelated string, the string itself, and every residue of the text's length modulo eight."""
+    rng = np.random.default_rng(seed)
+    al = list(b"ACGT")
+    out = []
+    for n in sizes:
+        a = bytes(rng.choice(al, n).astype(np.uint8))
+        b = bytearray(a)
+        for _ in range(int(rng.integers(1, max(2, n // 12)))):
+            p = int(rng.integers(0, len(b)))
+            op = rng.integers(0, 3)
+            if op == 0:
+                b[p] = int(rng.choice(al))
+            elif op == 1:
+                b.insert(p, int(rng.choice(al)))
+            elif len(b) > 1:
+                del b[p]
+        b = bytes(b)
+        out.append((a, b))
+        out.append((a, a))
+        odd = bytearray(b + bytes(rng.choice(al, int(rng.integers(8, 40))).astype(np.uint8)))      # the longer one: the text
+        for p in rng.integers(0, len(odd), 5):
+            odd[int(p)] = int(rng.choice(list(b"Nacgt-")))
+        out.append((a, bytes(odd)))
+        out.append((bytes(odd), a))
+        out.append((a, bytes(rng.choice(al, int(n + rng.integers(0, 60))).astype(np.uint8))))
+        for r in range(8):                                                                         # the text's last group: 1 .. 8 columns
+            out.append((a, b + bytes(rng.choice(al, (r - len(b)) % 8 + 8).astype(np.uint8))))
+    return out
+
+
+def test_edit_distance_acgt_wave_forms_emulated(oracle_mod):
+    import emu.emu as E
+    E.lib()
+    pairs = acgt_pairs(11, [513, 519, 640, 1100, 2050])
+    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs])
+
+
+@pytest.mark.gpu
+def test_edit_distance_acgt_wave_forms_gpu(oracle_mod):
+    pairs = acgt_pairs(12, [513, 519, 640, 1100, 2050, 4096, 4097, 5003, 6100, 9000] + list(np.random.default_rng(9).integers(513, 7000, 30)))
+    check_banded(pairs, [oracle_mod.edit_distance(a, b) for a, b in pairs])
+
+
 @pytest.mark.gpu
 def test_edit_distance_banded_gpu(oracle_mod):
     """thread form (<= 8 blocks, states in LDS), banded wave form (lane = block of the band, blocks rotating through the
