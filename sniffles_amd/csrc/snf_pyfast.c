@@ -254,8 +254,8 @@ static PyObject* idx_object(long long i) {      /* borrowed */
   return g_idx_cache[i];
 }
 static PyObject* py_make_stubs(PyObject* self, PyObject* args) {
-  PyObject *cls, *src; Py_buffer calls; long long lo, hi;
-  if (!PyArg_ParseTuple(args, "OOy*LL", &cls, &src, &calls, &lo, &hi)) return NULL;
+  PyObject *cls, *src; Py_buffer calls; long long lo, hi; int all_qc = 0;      /* all_qc: every stand-in starts with qc = True */
+  if (!PyArg_ParseTuple(args, "OOy*LL|p", &cls, &src, &calls, &lo, &hi, &all_qc)) return NULL;
   PyObject* out = NULL;
   if (lo < 0 || hi < lo || (size_t)hi * sizeof(snf_call_t) > (size_t)calls.len) { PyErr_SetString(PyExc_ValueError, "call range outside the record table"); goto done; }
   const snf_call_t* C = (const snf_call_t*)calls.buf;
@@ -263,7 +263,7 @@ static PyObject* py_make_stubs(PyObject* self, PyObject* args) {
   for (long long i = lo; out && i < hi; i++) {
     PyObject* d = _PyDict_NewPresized(3);
     PyObject* ix = d ? idx_object(i - lo) : NULL;
-    if (!ix || PyDict_SetItem(d, K_qc, C[i].qc ? Py_True : Py_False) || PyDict_SetItem(d, K_lz, src) || PyDict_SetItem(d, K_lzi, ix)) { Py_XDECREF(d); Py_CLEAR(out); break; }
+    if (!ix || PyDict_SetItem(d, K_qc, (all_qc || C[i].qc) ? Py_True : Py_False) || PyDict_SetItem(d, K_lz, src) || PyDict_SetItem(d, K_lzi, ix)) { Py_XDECREF(d); Py_CLEAR(out); break; }
     PyObject* obj = new_instance(cls, d);
     if (!obj) { Py_CLEAR(out); break; }
     PyList_SET_ITEM(out, i - lo, obj);

@@ -140,7 +140,7 @@ class Batch:
         import time
         prof = os.environ.get("SNF_PROF") is not None
         t0 = time.perf_counter()
-        cs = abi.config_struct(cfg)
+        cs = cfg if isinstance(cfg, abi.snf_config_t) else abi.config_struct(cfg)      # (a struct built elsewhere: sniffles_amd.server)
         _check(self.lib, self.lib.snf_batch_create(C.byref(cs), device, C.byref(self._h)))
         t1 = time.perf_counter()
         try:

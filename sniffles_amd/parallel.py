@@ -37,6 +37,8 @@ class Task:
         self._batch = None
         self._ti = None
         self._prep = None
+        self._lazy = None
+        self._served = False
 
     def prepare(self, config, execute=None):
         """Start this task's upload and its pass in the background; the next `call_candidates` (execute=None) / `call_records` /
@@ -47,7 +49,7 @@ class Task:
         processes get the same overlap from being several (`sniffles:495-530`).  Optional: a task that was not prepared does the same
         work when it is called."""
         from .abi import OUT_CANDIDATES, OUT_EXECUTE
-        if self._prep is not None:
+        if self._prep is not None or self._server() is not None:      # (through a GPU server the call itself hands the task over)
             return
         self._release()
         self._ti = self._task_input(config)
@@ -99,7 +101,47 @@ class Task:
         if self.lead_provider is not None and getattr(self.lead_provider, "device_batch", None) is not None:
             self.lead_provider.device_batch = None
 
+    # ---- through a GPU server (sniffles_amd.server: SNF_GPU_SERVER names its socket): many worker processes, one process on the device
+    def _server(self):
+        if os.environ.get("SNF_GPU_SERVER"):
+            from . import server
+            return server.client()
+        return None
+
+    def _served_result(self, srv, config):
+        """This task through the server: its FINALIZED record table (views of the batch's result segment) and the reply to release."""
+        self.close()
+        self._ti = self._task_input(config)
+        rep = srv.run_task(config, self._ti)
+        res = rep.result
+        if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
+            rep.release()
+            raise UnboundLocalError("local variable 'end' referenced before assignment")
+        self.coverage_average_total = float(res.coverage_average_total[0])
+        return rep, res
+
+    def _call_candidates_served(self, srv, config, svcall_cls, bnd_cls) -> list:
+        rep, res = self._served_result(srv, config)
+        self._finalized = False
+        if sv.lazy_calls_supported(self._ti):
+            # stand-ins over the final records; `qc` as the candidate stage has it (True) until finalize_candidates
+            src = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, None, None, keep_all=bool(config.no_qc))
+            src.alt_pool, src.final, src.on_detach = res.alt_pool, True, rep.release
+            self._lazy = src
+            out = src.make(all_qc=True)
+        else:
+            out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls)
+            sv.apply_final(out, res, self._ti)
+            rep.release()
+        self._served = True
+        self.sv_id += len(out)
+        return out
+
     def call_candidates(self, keep_qc_fails, config, svcall_cls=sv.SVCall, bnd_cls=sv.SVCallBNDInfo) -> list:
+        srv = self._server()
+        if srv is not None:
+            return self._call_candidates_served(srv, config, svcall_cls, bnd_cls)
+        self._served = False
         if not self._prepared(None):
             self._open(config)
             self._batch.call_candidates()
@@ -163,6 +205,16 @@ class Task:
         iterates whatever it is given, parallel.py:129-147; `GenotypeTask`-style callers filter in between): every call carries its
         place in the batch (`postprocess.index`, a stand-in its own index), the records are mapped through that."""
         import numpy as np
+        if getattr(self, "_served", False):
+            # through a GPU server the records were final from the start: the stand-ins take their final `qc`, calls that were touched
+            # before carry their final fields already; `finalize()` (postprocess = None) holds for both
+            if getattr(self, "_finalized", False):
+                raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")
+            candidates = list(candidates)
+            if self._lazy is not None:
+                self._lazy.refresh_qc()
+            self._finalized = True
+            return candidates
         if self._batch is None or getattr(self, "_finalized", False):
             raise RuntimeError("finalize_candidates needs the candidates of this task's call_candidates")
         self._batch.finalize()
@@ -210,6 +262,18 @@ class CallTask(Task):
         device (SNF_OUT_EXECUTE), and only the calls the worker would send to its parent become `SVCall` objects - for a 30x
         genome 26.8 k objects instead of the 94 k candidates the two-call form has to materialise first.  Same objects, same
         order as `call_svs()` (tests/test_dropin_api.py); `self.sv_id` advances by the number of candidates like there."""
+        srv = self._server()
+        if srv is not None:       # through a GPU server: the kept calls are picked and ordered here, from the finalized record table
+            import numpy as np
+            rep, res = self._served_result(srv, config)
+            idx = np.arange(len(res.calls)) if config.no_qc else np.flatnonzero(res.calls["qc"] != 0)
+            if getattr(config, "sort", True):
+                idx = idx[np.argsort(res.calls["pos"][idx], kind="stable")]
+            calls = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, idx=idx)
+            sv.apply_final(calls, res, self._ti, finalize=True, idx=idx)
+            self.sv_id += len(res.calls)
+            rep.release()
+            return calls
         res, ti = self.call_records(config, execute=True)
         calls = sv.materialize_candidates(res, ti, 0, len(res.calls), svcall_cls, bnd_cls)
         sv.apply_final(calls, res, ti, finalize=True)

@@ -239,15 +239,24 @@ class no_gc:
             gc.enable()
 
 
-def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo, post_cls=None, batch=None) -> list:
+def materialize_candidates(res: Result, ti, lo: int, hi: int, svcall_cls=SVCall, bnd_cls=SVCallBNDInfo, post_cls=None, batch=None, idx=None) -> list:
     """`fill_candidate(new_call(), res, i, ti)` for i in [lo, hi), same objects.  With `post_cls` every call also gets its
-    `postprocess = post_cls(batch=batch, index=i - lo)` handle."""
+    `postprocess = post_cls(batch=batch, index=i - lo)` handle.  `idx` (int64, relative to lo): only those records, in that order."""
     import numpy as np
     fast = _load_fast()
     if fast is not None and (ti.qnames is None or isinstance(ti.qnames, list)) and (ti.contig_names is None or isinstance(ti.contig_names, list)):
         with no_gc():
+            extra = () if idx is None else (np.ascontiguousarray(idx, np.int64),)
             return fast.materialize(svcall_cls, bnd_cls, ForwardDifferenceWelford, post_cls, batch, np.ascontiguousarray(res.calls), lo, hi,
-                                    np.ascontiguousarray(res.rnames, np.uint32), ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS)
+                                    np.ascontiguousarray(res.rnames, np.uint32), ti.qnames, ti.contig, ti.task_id, ti.contig_names, FILTERS, *extra)
+    if idx is not None:
+        out = []
+        for i in np.asarray(idx).tolist():
+            c = materialize_candidates_py(res, ti, lo + int(i), lo + int(i) + 1, svcall_cls, bnd_cls)[0]
+            if post_cls is not None:
+                c.postprocess = post_cls(batch=batch, index=int(i))
+            out.append(c)
+        return out
     out = materialize_candidates_py(res, ti, lo, hi, svcall_cls, bnd_cls)
     if post_cls is not None:
         for i, c in enumerate(out):
@@ -434,12 +443,18 @@ class LazySource:
         self.keep_all = keep_all
         self.stubs = None            # the list call_candidates returned (the stand-ins in record order)
         self.n_filled = 0
+        self.on_detach = None        # called when the tables are let go of (a GPU server's result segment: sniffles_amd.server)
 
-    def make(self) -> list:
+    def make(self, all_qc: bool = False) -> list:
         fast = _load_fast()
         with no_gc():
-            self.stubs = fast.make_stubs(lazy_class(self.cls), self, self.calls, 0, len(self.calls))
+            self.stubs = fast.make_stubs(lazy_class(self.cls), self, self.calls, 0, len(self.calls), bool(all_qc))
         return list(self.stubs)
+
+    def refresh_qc(self) -> None:
+        """`qc` of the records onto the stand-ins (a source that was final from the start: sniffles_amd.server)."""
+        if self.stubs is not None:
+            _load_fast().stub_refresh_qc(self.stubs, self.calls, 0)
 
     def set_final(self, res: Result) -> None:
         import numpy as np
@@ -460,6 +475,9 @@ class LazySource:
             del targets
         self.stubs = None
         self.calls = self.rnames = self.alt_pool = None
+        cb, self.on_detach = self.on_detach, None
+        if cb is not None:
+            cb()
 
     def fill(self, obj) -> None:
         """`obj` (a stand-in of this source) was touched: it and every stand-in the consumer is about to touch become real calls -

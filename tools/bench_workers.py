@@ -53,8 +53,15 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
             else:
                 lp = pipeline._Extracted(ti)
             built.append((key, ti, lp))
-        # process warm-up: HIP context, the pinned arena, a device slab of this worker's largest task
-        if built:
+        # process warm-up: HIP context, the pinned arena, a device slab of this worker's largest task - or, through a GPU server
+        # (SNF_GPU_SERVER: this process never opens the device), the connection, the worker's input segment and the server's own arenas
+        if built and os.environ.get("SNF_GPU_SERVER"):
+            key, big, lp_big = max(built, key=lambda x: x[1].n_leads)
+            wt = parallel.CallTask(id=big.task_id, sv_id=0, contig=big.contig, start=0, end=big.contig_len, config=cfg, device=device)
+            wt.lead_provider = pipeline._Extracted(big)
+            cfg.qc_nm_threshold = big.qc_nm_threshold
+            wt.execute_calls(cfg); wt.close()
+        elif built:
             big = max(built, key=lambda x: x[1].n_leads)[1]
             with lib.Batch(cfg, [big], device=device) as b:
                 b.run_pass(); b.fetch(1, copy=False)
@@ -103,7 +110,18 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
 
 
 def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str = "api", device: int = 0, weights=None,
-        hw_queues: int = 0) -> dict:
+        hw_queues: int = 0, gpu_server: bool = False) -> dict:
+    if gpu_server:       # ONE process on the device (sniffles_amd.server), the workers hand their tasks over in shared memory
+        from sniffles_amd import server
+        srv = server.start(device=device)
+        os.environ["SNF_GPU_SERVER"] = srv.address           # (spawned workers inherit it)
+        try:
+            out = run(specs, cfg_kw, procs, form, shape, device, weights, 0, False)
+            out["gpu_server"] = True
+            return out
+        finally:
+            os.environ.pop("SNF_GPU_SERVER", None)
+            srv.stop()
     """specs: [(key, kwargs of synth.gen_task)].  Returns {procs, hot_all_s (slowest worker), hot_sum_s, ingest_all_s (slowest worker's
     object walk, `leads` form), n_out, setup_wall_s}."""
     n = len(specs)
@@ -149,7 +167,7 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
         p.join(timeout=30)
     if err is not None:
         raise RuntimeError(err)
-    return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None,
+    return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None, gpu_server=bool(os.environ.get("SNF_GPU_SERVER")),
                 hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
                 hot_sum_ms=round(sum(m["hot_s"] for m in got) * 1e3, 1), ingest_all_ms=round(max(m["ingest_s"] for m in got) * 1e3, 1),
                 n_out=sum(m["n_out"] for m in got), setup_wall_s=round(t1 - t0, 1))

@@ -92,4 +92,25 @@ for k in 1 2; do
   timeout 120 python bench.py $Q --steps 40 --warmup 5 2>/dev/null | ms "plain line"
 done 2>&1 | tee gpurun_out/shared_probe_5.log
   ;;
+6)
+# round 6, sixth session (every leg bounded): the GPU server for many workers, the eight-column Myers step against the one-column one
+# (variants/myers1.so), the one-rank N > 1 line on both process groups again (three alternations)
+timeout 600 python -m pytest tests/test_server.py tests/test_edit_distance.py tests/test_combine.py tests/test_combine_task.py tests/test_dropin_api.py -m gpu -x -q 2>&1 | tail -3
+for spec in "24 server columns leads" "8 server columns" "4 server columns"; do timeout 300 python tools/workers_slots.py $spec; done 2>&1 | grep '^{' | tee gpurun_out/workers_server_6.log
+for k in 1 2; do
+  for tag in one eight; do
+    if [ $tag == one ]; then export SNF_LIB_SO=$R/variants/myers1.so; else unset SNF_LIB_SO; fi
+    timeout 300 python bench.py --config 4 --no-reference-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{\"metric\"')][-1])
+print('$tag columns per step:', 'ms_per_step', round(d['ms_per_step'],1), 'kernel_ms', d['config']['rank0']['kernel_ms'], 'abi', d['config']['rank0']['c_abi_call_ms'], 'verified', d.get('verified'), 'cells/s %.3g' % d['config']['rank0']['dp_cells_per_s'])"
+  done
+done 2>&1 | tee gpurun_out/ab_r06_4.log
+unset SNF_LIB_SO
+for k in 1 2 3; do
+  SNF_BENCH_FORCE_DIST=1 SNF_BENCH_PG=nccl timeout 120 python bench.py --gpus 1 $Q --steps 40 --warmup 5 2>/dev/null | ms "shared landing, one rank, RCCL-only group"
+  SNF_BENCH_FORCE_DIST=1 timeout 120 python bench.py --gpus 1 $Q --steps 40 --warmup 5 2>/dev/null | ms "shared landing, one rank, gloo + lazy RCCL"
+  timeout 120 python bench.py $Q --steps 40 --warmup 5 2>/dev/null | ms "plain line"
+done 2>&1 | tee gpurun_out/shared_probe_6.log
+  ;;
 esac
