@@ -1897,8 +1897,19 @@ void run_pass(snf_batch_impl* b) {
     b->capturing = true;
     // (an exception while capturing - a call that is illegal in a capture, a host wait only this path reaches - does not mean the
     // pass cannot run: the capture is ended, the handle stays eager from here on and the pass is enqueued the plain way below)
+    // The message of what was swallowed is kept (SNF_PROF prints it; a genuine failure surfaces again, with its own message, from the eager
+    // run below) and the pass counter the capture attempt advanced is put back, so that the sampled-timing cadence does not shift.
+    const uint64_t count_before = b->pass_count;
     try { run_call_candidates(b); run_finalize(b); }
-    catch (...) { (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; ok = false; (void)hipGetLastError(); }
+    catch (const std::exception& e) {
+      (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; ok = false; (void)hipGetLastError();
+      b->pass_count = count_before;
+      if (v.prof) fprintf(stderr, "[SNF_PROF] pass graph: capture gave up (%s); the pass runs eagerly\n", e.what());
+    }
+    catch (...) {
+      (void)hipStreamEndCapture(b->stream, &graph); if (graph) (void)hipGraphDestroy(graph); graph = nullptr; ok = false; (void)hipGetLastError();
+      b->pass_count = count_before;
+    }
     b->capturing = false;
     if (ok) ok = hipStreamEndCapture(b->stream, &graph) == hipSuccess && graph != nullptr;
   }

@@ -173,8 +173,13 @@ class Batch:
         built here, on the caller's thread; the helper makes ONE library call (`snf_batch_open`: create, add, upload, enqueue), during which
         the interpreter lock is released.  `.result()` waits and returns the batch (or raises what the call raised)."""
         import threading
+        from .soa import DeviceTaskInput
         lib_ = load()
         tasks = list(tasks)
+        if any(isinstance(t, DeviceTaskInput) for t in tasks):
+            # (columns that already live in HBM are handed over device-to-device by the synchronous constructor; snf_batch_open takes
+            # host columns only - pulling them back to re-upload them would defeat the hand-over)
+            raise TypeError("open_in_background takes host task inputs; use Batch(cfg, tasks) for device-resident ones")
         cs = abi.config_struct(cfg)
         keep = []
         arr = (abi.snf_task_input_t * max(1, len(tasks)))()
@@ -356,7 +361,16 @@ class PendingBatch:
         self._thread.join()
         if self._err is not None:
             raise self._err
-        return self._batch
+        b, self._batch = self._batch, None        # (handed over: the caller closes it)
+        return b
+
+    def __del__(self):
+        # a pending batch nobody asked for any more: its handle goes with it (not at interpreter exit only)
+        try:
+            if self._thread is not None and self._batch is not None:
+                self.discard()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
     def discard(self):
         self._thread.join()

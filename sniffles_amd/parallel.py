@@ -53,6 +53,9 @@ class Task:
             return
         self._release()
         self._ti = self._task_input(config)
+        from .soa import DeviceTaskInput
+        if isinstance(self._ti, DeviceTaskInput):      # columns already in HBM: the call itself hands them over device-to-device
+            return
         run = lib.Batch.RUN_CANDIDATES if execute is None else (lib.Batch.RUN_PASS | (OUT_EXECUTE if execute else OUT_CANDIDATES))
         self._prep = {"mode": execute, "pending": lib.Batch.open_in_background(config, [self._ti], device=self.device, run=run)}
 

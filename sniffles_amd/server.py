@@ -191,34 +191,27 @@ def _serve(address: str, device: int, init: str, extra_path, ready):
             except (OSError, ValueError):
                 pass
 
-    while not stop.is_set():
-        item = q.get()
-        if item is None:
-            break
-        group = [item]
-        try:                                    # everything that has arrived for the same configuration runs as one device batch
-            while len(group) < 256:
-                nxt = q.get_nowait()
-                if nxt is None:
-                    stop.set(); break
-                if nxt[1]["cfg"] == item[1]["cfg"]:
-                    group.append(nxt)
-                else:
-                    q.put(nxt); break
-        except queue.Empty:
-            pass
+    prof = os.environ.get("SNF_PROF") is not None
+
+    def run_group(group):
+        import time
+        t0 = time.perf_counter()
         try:
             tis = []
             for conn, m in group:
-                seg = in_maps.get(m["seg"])
-                if seg is None or seg.size < max(off + cnt * np.dtype(dt).itemsize for _, dt, off, cnt in m["fields"]):
-                    seg = in_maps[m["seg"]] = Segment(m["seg"])
+                with lock:
+                    seg = in_maps.get(m["seg"])
+                    if seg is None or seg.size < max(off + cnt * np.dtype(dt).itemsize for _, dt, off, cnt in m["fields"]):
+                        seg = in_maps[m["seg"]] = Segment(m["seg"])
                 tis.append(_unpack_task(seg.buf, m["fields"], m["meta"]))
-            cs = abi.snf_config_t.from_buffer_copy(item[1]["cfg"])
+            cs = abi.snf_config_t.from_buffer_copy(group[0][1]["cfg"])
+            t1 = time.perf_counter()
             with lib.Batch(cs, tis, device=device) as b:
+                t2 = time.perf_counter()
                 b.set_output(abi.OUT_CANDIDATES)
                 b.run_pass()
                 res = b.fetch(1, copy=False)
+                t3 = time.perf_counter()
                 n = len(res.calls)
                 rec_bytes = n * abi.CALL_DTYPE.itemsize
                 off_rn = (rec_bytes + 255) & ~255
@@ -238,11 +231,50 @@ def _serve(address: str, device: int, init: str, extra_path, ready):
                                     rnames_len=int(len(res.rnames)), alt_len=int(len(res.alt_pool)), off_rnames=off_rn, off_alt=off_alt,
                                     status=int(res.task_status[t]), coverage_average_total=float(res.coverage_average_total[t]),
                                     batch_tasks=len(group)))
+                if prof:
+                    print(f"[SNF_PROF] server batch: {len(group)} tasks, {sum(t.n_leads for t in tis)} leads, {n} calls | map {1e3 * (t1 - t0):.2f} "
+                          f"upload {1e3 * (t2 - t1):.2f} pass {1e3 * (t3 - t2):.2f} copy + replies {1e3 * (time.perf_counter() - t3):.2f} ms",
+                          file=sys.stderr, flush=True)
         except BaseException as e:  # noqa: BLE001 - reported to the workers of the batch, the server goes on
             import traceback
             text = f"{type(e).__name__}: {e}\n{traceback.format_exc()[-1500:]}"
             for conn, m in group:
                 send(conn, dict(error=text))
+
+    gather_lock = threading.Lock()        # one dispatcher gathers at a time; the other one is running its batch on the device
+
+    def dispatcher():
+        import time
+        while not stop.is_set():
+            with gather_lock:
+                item = q.get()
+                if item is None:
+                    q.put(None)            # (the other dispatcher sees it too)
+                    return
+                group, other = [item], []
+                # everything that arrives for the same configuration within a moment runs as ONE device batch: workers released by a
+                # common event submit within a fraction of a millisecond of each other, and a batch of one costs what a batch of
+                # twenty does (the launches are shared); the wait ends as soon as nothing new has come for 0.2 ms, after 2 ms at most
+                t_end, quiet = time.perf_counter() + 2e-3, 0
+                while len(group) < 256 and quiet < 2 and time.perf_counter() < t_end:
+                    try:
+                        nxt = q.get(timeout=2e-4)
+                    except queue.Empty:
+                        quiet += 1
+                        continue
+                    quiet = 0
+                    if nxt is None:
+                        q.put(None); stop.set(); break
+                    (group if nxt[1]["cfg"] == item[1]["cfg"] else other).append(nxt)
+                for x in other:
+                    q.put(x)
+            run_group(group)
+
+    workers = [threading.Thread(target=dispatcher, daemon=True) for _ in range(2)]
+    for w in workers:
+        w.start()
+    for w in workers:
+        w.join()
     try:
         listener.close()
     except OSError:

@@ -127,4 +127,14 @@ def test_worker_processes_plumbing_on_the_host_tier(monkeypatch):
         r = W.run(specs, {}, 2, form, shape, hw_queues=2)
         assert r["procs"] == 2 and r["hot_all_ms"] > 0 and r["n_out"] > 0
         out[(form, shape)] = r["n_out"]
-    assert out[("columns", "api")] == out[("leads", "api")] > out[("columns", "execute")]      # same candidates from objects and columns; execute keeps the QC-passing ones
+    # the same calls from objects and from columns, through the two calls + CallTask.execute's own filter and sort, and in one step
+    assert out[("columns", "api")] == out[("leads", "api")] == out[("columns", "execute")] > 0
+    # ... and with ONE process on the device (sniffles_amd.server; here: the host tier started inside the server process)
+    from sniffles_amd import server
+    srv = server.start(device=0, init="emu.emu:lib", extra_path=[os.path.join(ROOT, "tests")])
+    monkeypatch.setenv("SNF_GPU_SERVER", srv.address)
+    try:
+        r = W.run(specs, {}, 3, "leads", "api")
+        assert r["gpu_server"] is True and r["n_out"] == out[("columns", "api")]
+    finally:
+        srv.stop()

@@ -48,9 +48,8 @@ def worker_processes(specs, cfg_kw, device):
     # P = 24 columns / api 720 ms with two queues each against 1 219 ms)
     # ... and P = 24 - the pool size the reference's CPU baseline uses - through ONE GPU server process (sniffles_amd.server): two dozen
     # processes that each open the device are time-sliced by the driver (0.4-0.9 s for the genome, whatever bounds the passes in flight)
-    plan = [(4, "columns", "api", 0), (4, "columns", "execute", 0), (4, "leads", "api", 0), (8, "columns", "api", 2),
-            (8, "leads", "api", 2),
-            (24, "columns", "api", "server"), (24, "leads", "api", "server"), (8, "columns", "api", "server"), (24, "columns", "api", 2)]
+    plan = [(4, "columns", "api", 0), (4, "leads", "api", 0), (8, "columns", "api", 2), (8, "leads", "api", 2),
+            (24, "columns", "api", "server"), (24, "leads", "api", "server"), (24, "columns", "api", 2)]
     if os.environ.get("SNF_BENCH_WORKERS"):      # e.g. "8" or "4,24"
         want = {int(x) for x in os.environ["SNF_BENCH_WORKERS"].split(",") if x}
         plan = [p for p in plan if p[0] in want]
