@@ -113,7 +113,7 @@ def main():
             # control words (a few int64 per run and per pass: sizes, layouts, the timing reduction, barriers) travel as CPU tensors
             # over gloo; RCCL - backend "nccl" for CUDA tensors - builds its communicator with the first CUDA collective, i.e. only where
             # result BLOCKS are gathered (no /dev/shm: several nodes, SNF_BENCH_GATHER=rccl).  On one node no result byte needs it
-            # (dist.SharedLanding), and a communicator that merely exists cost the passes 14-16 % (profiles/r05_shared_probe.log)
+            # (dist.SharedLanding), and a communicator that merely exists cost the passes 14-16 % (profiles/r05_shared_probe.log, r06_shared_probe.log)
             dist.init_process_group(backend="cpu:gloo,cuda:nccl")
 
     # where the control tensors of the collectives live: host memory unless the whole group is RCCL
@@ -681,7 +681,7 @@ def run_calling(ctx):
                         profile_note=prof_note, result_path=result_path,
                         dominant_stage=(stages[0] if stages else None), stages=stages,
                         # the kernels of this path are integer / branch work bound by instruction issue and dependent latency, not by bytes:
-                        # next to the HBM fraction the share of a kernel's time its VALU instructions alone need (profiles/r05_sq_all.txt)
+                        # next to the HBM fraction the share of a kernel's time its VALU instructions alone need (profiles/r06_sq_all.txt)
                         issue=[dict(kernel=k[0], **issue[k[0]]) for k in kern if k[0] in issue][:8] or None,
                         gpu_ms_all_kernels=round(gpu_ms, 3),
                         whole_pass=dict(algorithmic_bytes=int(pass_bytes),

@@ -302,7 +302,7 @@ def reference_baseline(contigs, S, cov, n_cands, n_calls, gpu_s_per_merge, sampl
                                               note="single-core seconds per candidate of the sample x the candidates of the largest "
                                                    "contig task (one process "
                                                    "per contig); measured on the whole workload by `bench.py --config 4`: "
-                                                   "profiles/r05_final_bench_config4.json"),
+                                                   "profiles/r06_final_bench_config4.json"),
                     parity_unpinned="sv.align is oracle/snf_oracle.c::snf_oracle_edit_distance_myers (the algorithm edlib implements, "
                                     "pinned to the exact DP), not edlib",
                     sample=f"the {len(part)} smallest contig tasks ({', '.join(c[1] for c in part)}) x {S} samples, the unmodified "

@@ -9,10 +9,10 @@ from tools.bench_common import EMU, ROOT
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # rocprofv3 summaries of this round, collected with tools/profile.sh.  They are only quoted when they were measured on the
-# kernels this run executes: profiles/r05_profile_meta.json records the hash of sniffles_amd/csrc they belong to.
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
-ROCPROF_STATS = os.path.join(ROOT, "profiles", "r05_kernel_stats_default.csv")
-PROFILE_META = os.path.join(ROOT, "profiles", "r05_profile_meta.json")
+# kernels this run executes: profiles/r06_profile_meta.json records the hash of sniffles_amd/csrc they belong to.
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+ROCPROF_STATS = os.path.join(ROOT, "profiles", "r06_kernel_stats_default.csv")
+PROFILE_META = os.path.join(ROOT, "profiles", "r06_profile_meta.json")
 ROCPROF_NAMES = {"e45w_consensus_large": "e45w_consensus<2,", "e45w_consensus_small": "e45w_consensus<1,", "d2w_call": "d2w_call<",
                  "e1w_finalize": "e1w_finalize<",
                  "d1w_refine": "d1w_refine", "d4_coverage": "d4_coverage", "a4_binstats": "a4k_binstats", "a6_scatter": "a6k_scatter",
@@ -22,7 +22,7 @@ ROCPROF_NAMES = {"e45w_consensus_large": "e45w_consensus<2,", "e45w_consensus_sm
                  "d5w_covsum": "d5w_covsum", "f4_emit": "f4w_emit", "f5_alt": "f5w_alt", "f3_rank": "f3k_rank", "w1_hist": "w1_hist",
                  "w3_scatter": "w3_scatter",
                  "w4s_segment": "w4s_segment<", "w6t_emit": "w6t_emit", "d2g_call8": "d2g_call<8", "d1g_refine8": "d1g_refine<8"}
-SQ_FILE = os.path.join(ROOT, "profiles", "r05_sq_all.txt")
+SQ_FILE = os.path.join(ROOT, "profiles", "r06_sq_all.txt")
 
 
 def committed_profiles():
@@ -32,7 +32,7 @@ def committed_profiles():
         from sniffles_amd import build
         meta = json.load(open(PROFILE_META))
         if meta.get("csrc_sha") != build._lib_digest():
-            return {}, {}, "profiles/r05_* were collected on other kernel sources (stale): not quoted"
+            return {}, {}, "profiles/r06_* were collected on other kernel sources (stale): not quoted"
         import csv
         avg = {}
         for r in csv.DictReader(open(ROCPROF_STATS)):
@@ -40,14 +40,14 @@ def committed_profiles():
                 if pat in r["Name"].replace("snf::", "").replace(" ", "").replace("void", "") or pat in r["Name"]:
                     avg.setdefault(short, float(r["AverageNs"]) / 1e6)
         pmc = json.load(open(PMC_FILE))["kernels"] if os.path.exists(PMC_FILE) else {}
-        return avg, pmc, ("rocprofv3 --kernel-trace --stats of the default command, profiles/r05_kernel_stats_default.csv "
+        return avg, pmc, ("rocprofv3 --kernel-trace --stats of the default command, profiles/r06_kernel_stats_default.csv "
                           "(same kernel sources: hash checked)")
     except Exception as e:  # noqa: BLE001
         return {}, {}, f"no committed profile for these sources ({type(e).__name__})"
 
 
 def committed_issue():
-    """{kernel name: dict(valu_us, kernel_us, frac, lds_conflict_share)} from profiles/r05_sq_all.txt (tools/sq_all.sh: SQ_INSTS_VALU x
+    """{kernel name: dict(valu_us, kernel_us, frac, lds_conflict_share)} from profiles/r06_sq_all.txt (tools/sq_all.sh: SQ_INSTS_VALU x
     4 cycles on the 1024 SIMDs at 2.4 GHz against the kernel's duration, one batch in flight; SQ_LDS_BANK_CONFLICT /
     SQ_LDS_IDX_ACTIVE) - the ISSUE roof of the kernels that are bound by instruction issue rather than by bytes.
     Empty when the file belongs to other kernel sources."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/final_set.sh [TAG]: the bench lines that are kept for judging, one box -> gpurun_out/final_TAG/ (copy into profiles/ as rNN_final_bench_*.json)
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=$R/gpurun_out/final_$TAG; rm -rf $O; mkdir -p $O

@@ -7,7 +7,7 @@
 #                              --kernel-trace), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes (tools/pmc_parse.py)
 #   profile_meta.json          hash of the kernel sources the files belong to (bench.py refuses to quote them for other sources)
 # Copy what is to be judged into profiles/ as rNN_*.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 O=$R/gpurun_out/prof_$TAG; rm -rf $O; mkdir -p $O

@@ -113,4 +113,31 @@ for k in 1 2 3; do
   timeout 120 python bench.py $Q --steps 40 --warmup 5 2>/dev/null | ms "plain line"
 done 2>&1 | tee gpurun_out/shared_probe_6.log
   ;;
+7)
+# round 6, seventh session: the GPU server with two dispatchers and a gather window - its own split per batch (SNF_PROF), P = 24 / 8
+SNF_PROF=1 timeout 300 python tools/workers_slots.py 24 server columns 2>&1 | grep -E '^\{|server batch' | cut -c1-250 | tee gpurun_out/workers_server_7.log
+for spec in "24 server leads" "8 server columns" "24 server columns"; do timeout 300 python tools/workers_slots.py $spec; done 2>&1 | grep '^{' | tee -a gpurun_out/workers_server_7.log
+  ;;
+8)
+# round 6, eighth session: the whole GPU suite on the final sources, then the profile set of the round (kernel statistics of the driver's
+# command and of one batch in flight, launch timeline, HBM traffic at one and at four genomes per batch, SQ counters), extraction re-profiled
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_8.log 2>&1; tail -3 gpurun_out/pytest_gpu_8.log
+timeout 1200 bash tools/profile.sh r06 > gpurun_out/profile_r06.log 2>&1; tail -5 gpurun_out/profile_r06.log
+B="python bench.py --inflight 1 --no-cpu-baseline --no-wall-clock --no-configs --genomes 4"
+O=$R/gpurun_out/prof_r06
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc4_$C -o pmc -- $B --steps 2 --warmup 1 > $O/pmc4_$C.log 2>&1
+done
+python tools/pmc_parse.py $O/pmc4_FETCH_SIZE $O/pmc4_WRITE_SIZE > $O/pmc_traffic_genomes4.json; rm -rf $O/pmc4_FETCH_SIZE $O/pmc4_WRITE_SIZE
+timeout 900 bash tools/sq_all.sh > /dev/null 2>&1; cp gpurun_out/sq_all/summary.txt $O/sq_all.txt; head -50 $O/sq_all.txt
+timeout 300 python tools/bench_extract.py > $O/extract_bench.json 2> /dev/null; tail -c 1500 $O/extract_bench.json
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/xstats -o k -- python tools/bench_extract.py --steps 5 --cpu-reads 5 > $O/xstats.log 2>&1
+cp $(find $O/xstats -name '*kernel_stats.csv' | head -1) $O/extract_kernel_stats.csv; rm -rf $O/xstats
+timeout 600 bash tools/pmc_extract.sh > /dev/null 2>&1; cp gpurun_out/pmc_extract_traffic.json $O/extract_pmc_traffic.json
+ls -la $O
+  ;;
+9)
+# round 6, ninth session: the bench lines that are kept (tools/final_set.sh)
+timeout 2000 bash tools/final_set.sh r06 2>&1 | tail -15
+  ;;
 esac
