@@ -113,9 +113,15 @@ class Task:
 
     def _served_result(self, srv, config):
         """This task through the server: its FINALIZED record table (views of the batch's result segment) and the reply to release."""
+        import time
         self.close()
+        t0 = time.perf_counter()
         self._ti = self._task_input(config)
+        t1 = time.perf_counter()
         rep = srv.run_task(config, self._ti)
+        # (where a served call's time goes, for tools/bench_workers.py: the task input, the hand-over + the server's batch)
+        self.served_timing = dict(task_input_ms=(t1 - t0) * 1e3, server_ms=(time.perf_counter() - t1) * 1e3, batch_tasks=rep.msg.get("batch_tasks"),
+                                  pack_ms=getattr(srv, "last_pack_ms", None))
         res = rep.result
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             rep.release()

@@ -370,8 +370,11 @@ class Client:
 
     def run_task(self, cfg, ti: TaskInput) -> Reply:
         cs = cfg if isinstance(cfg, abi.snf_config_t) else abi.config_struct(cfg)
+        import time
         with self.lock:
+            t0 = time.perf_counter()
             name, fields, meta = _pack_task(ti, self._in, self._tag)
+            self.last_pack_ms = (time.perf_counter() - t0) * 1e3
             self.conn.send(dict(op="task", seg=name, fields=fields, meta=meta, cfg=bytes(cs)))
             msg = self.conn.recv()
         if "error" in msg:

@@ -85,6 +85,7 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
             ingest_s = time.perf_counter() - t0
             t_all0 = time.perf_counter()
         n_out = 0
+        served = []
 
         # (the reference's build_leadtab leaves the task's NM threshold on the config: the lead provider's columns take it from there)
         def prepare(k):
@@ -101,9 +102,11 @@ def _worker(wid, specs, cfg_kw, form, shape, device, barrier, out_q, hw_queues=0
                 # the two calls and what CallTask.execute does with their result (parallel.py:265-271): `[s for s in svcalls if s.qc]`,
                 # `sorted(key=pos)` - every candidate's `qc` is read, every kept call is a finished object when the loop moves on
                 n_out += len(t.call_svs(cfg))
+            if getattr(t, "served_timing", None):
+                served.append(dict(t.served_timing, leads=built[k][1].n_leads))
             t.close()
         hot = time.perf_counter() - t_all0
-        out_q.put(dict(worker=wid, hot_s=hot, ingest_s=ingest_s, n_out=n_out, tasks=len(tasks), leads=sum(x[1].n_leads for x in built)))
+        out_q.put(dict(worker=wid, hot_s=hot, ingest_s=ingest_s, n_out=n_out, tasks=len(tasks), leads=sum(x[1].n_leads for x in built), served=served))
     except BaseException as e:  # noqa: BLE001 - reported to the parent
         import traceback
         out_q.put(dict(error=f"worker {wid}: {e!r}\n{traceback.format_exc()}"))
@@ -170,7 +173,10 @@ def run(specs: list, cfg_kw: dict, procs: int, form: str = "columns", shape: str
     return dict(procs=procs, form=form, shape=shape, hw_queues_per_process=hw_queues or None, gpu_server=bool(os.environ.get("SNF_GPU_SERVER")),
                 hot_all_ms=round(max(m["hot_s"] for m in got) * 1e3, 1), wall_ms=round(wall * 1e3, 1),
                 hot_sum_ms=round(sum(m["hot_s"] for m in got) * 1e3, 1), ingest_all_ms=round(max(m["ingest_s"] for m in got) * 1e3, 1),
-                n_out=sum(m["n_out"] for m in got), setup_wall_s=round(t1 - t0, 1))
+                n_out=sum(m["n_out"] for m in got), setup_wall_s=round(t1 - t0, 1),
+                # through a GPU server: the slowest worker's calls split into task input / packing / hand-over + server batch
+                slowest_worker_served=[{k: (round(v, 2) if isinstance(v, float) else v) for k, v in d.items()}
+                                       for d in max(got, key=lambda m: m["hot_s"]).get("served", [])][:6] or None)
 
 
 def genome_specs(coverage=30.0, scale=1.0, gen=None):

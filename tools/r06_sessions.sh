@@ -140,4 +140,9 @@ ls -la $O
 # round 6, ninth session: the bench lines that are kept (tools/final_set.sh)
 timeout 2000 bash tools/final_set.sh r06 2>&1 | tail -15
   ;;
+10)
+# round 6, tenth session: where the time of 24 object-fed workers goes through the GPU server (the slowest worker's split + the server's batches)
+SNF_PROF=1 timeout 300 python tools/workers_slots.py 24 server leads 2>&1 | grep -E '^\{|server batch' | cut -c1-900 | tee gpurun_out/workers_server_10.log
+timeout 300 python tools/workers_slots.py 24 server columns 2>&1 | grep '^{' | cut -c1-600 | tee -a gpurun_out/workers_server_10.log
+  ;;
 esac

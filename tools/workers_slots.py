@@ -22,4 +22,4 @@ if __name__ == "__main__":
     for form in forms:
         r = W.run(specs, {}, procs, form, "api", hw_queues=2 if procs >= 8 else 0, gpu_server=use_server)
         print(json.dumps(dict(procs=procs, gpu_slots=slots, gpu_server=use_server, form=form,
-                              **{k: r[k] for k in ("hot_all_ms", "wall_ms", "ingest_all_ms", "n_out")})), flush=True)
+                              **{k: r[k] for k in ("hot_all_ms", "wall_ms", "ingest_all_ms", "n_out", "slowest_worker_served")})), flush=True)
