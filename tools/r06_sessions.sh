@@ -145,4 +145,13 @@ timeout 2000 bash tools/final_set.sh r06 2>&1 | tail -15
 SNF_PROF=1 timeout 300 python tools/workers_slots.py 24 server leads 2>&1 | grep -E '^\{|server batch' | cut -c1-900 | tee gpurun_out/workers_server_10.log
 timeout 300 python tools/workers_slots.py 24 server columns 2>&1 | grep '^{' | cut -c1-600 | tee -a gpurun_out/workers_server_10.log
   ;;
+11)
+# round 6, eleventh session: a lone pass with only its ALT bytes staged through HBM (SNF_ALT_HBM=1: the LARGE consensus workgroups no longer
+# hold their LDS while ALT stores wait for PCIe; one copy at the fetch) against the direct stores, three alternations
+for k in 1 2 3; do
+  timeout 120 python bench.py $Q --steps 30 --warmup 5 --inflight 1 2>/dev/null | ms "one in flight, direct stores"
+  SNF_ALT_HBM=1 timeout 120 python bench.py $Q --steps 30 --warmup 5 --inflight 1 2>/dev/null | ms "one in flight, ALT through HBM"
+done 2>&1 | tee gpurun_out/ab_r06_5.log
+SNF_ALT_HBM=1 timeout 120 python bench.py $Q --steps 30 --warmup 5 2>/dev/null | ms "two in flight with SNF_ALT_HBM (no effect expected: staged anyway)" | tee -a gpurun_out/ab_r06_5.log
+  ;;
 esac
