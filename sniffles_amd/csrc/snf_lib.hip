@@ -230,6 +230,11 @@ struct HostBuf {
     p = mem; cap = bytes; external = true;
   }
   void* ensure(size_t bytes) {
+    // SNF_STAGE_ARENA_MB: the arena is never smaller than this.  A process that serves batches of unknown size (sniffles_amd/server.py)
+    // reserves for the largest it expects once, at its first upload, instead of growing when that batch arrives: pinning ~0.5 GB takes
+    // ~0.15 s, during which every other thread of the process that faults a page waits as well
+    static const size_t floor_b = getenv("SNF_STAGE_ARENA_MB") ? (size_t)atoll(getenv("SNF_STAGE_ARENA_MB")) << 20 : 0;
+    if (bytes < floor_b) bytes = floor_b;
     if (bytes <= cap && p) return p;
     if (external) fail("the result does not fit the memory given to snf_batch_set_result_memory (" + std::to_string(bytes) + " bytes needed, " + std::to_string(cap) + " given)");
     release();

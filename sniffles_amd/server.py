@@ -125,9 +125,11 @@ class _NullAt:
 
 
 # ---------------------------------------------------------------------------------------------- server process
-def _serve(address: str, device: int, init: str, extra_path, ready):
+def _serve(address: str, device: int, init: str, extra_path, ready, arena_mb: int = 0):
     import queue
     import sys
+    if arena_mb > 0:       # (read by the library at its first upload)
+        os.environ.setdefault("SNF_STAGE_ARENA_MB", str(int(arena_mb)))
     from multiprocessing.connection import Listener
     for p in extra_path or ():
         if p not in sys.path:
@@ -304,14 +306,16 @@ class ServerHandle:
             self.process.terminate()
 
 
-def start(device: int = 0, address: str = None, init: str = None, extra_path=None, timeout: float = 120.0) -> ServerHandle:
-    """Spawn the server of `device` (a fresh interpreter: it opens the device itself) and wait until it listens."""
+def start(device: int = 0, address: str = None, init: str = None, extra_path=None, timeout: float = 120.0, arena_mb: int = 768) -> ServerHandle:
+    """Spawn the server of `device` (a fresh interpreter: it opens the device itself) and wait until it listens.  `arena_mb`: pinned
+    staging memory the server reserves at its first upload (SNF_STAGE_ARENA_MB; a 30x human genome in one batch stages 0.46 GB) - a batch
+    beyond it makes the arena grow when it arrives, which stalls the whole server for the ~0.15 s the pinning takes."""
     import multiprocessing as mp
     import tempfile
     address = address or os.path.join(tempfile.gettempdir(), "snf_gpu_%d_%s.sock" % (os.getpid(), os.urandom(3).hex()))
     ctx = mp.get_context("spawn")
     ready = ctx.Event()
-    p = ctx.Process(target=_serve, args=(address, device, init, list(extra_path or ()), ready), daemon=True)
+    p = ctx.Process(target=_serve, args=(address, device, init, list(extra_path or ()), ready, int(arena_mb)), daemon=True)
     p.start()
     if not ready.wait(timeout):
         p.terminate()

@@ -131,7 +131,7 @@ def test_worker_processes_plumbing_on_the_host_tier(monkeypatch):
     assert out[("columns", "api")] == out[("leads", "api")] == out[("columns", "execute")] > 0
     # ... and with ONE process on the device (sniffles_amd.server; here: the host tier started inside the server process)
     from sniffles_amd import server
-    srv = server.start(device=0, init="emu.emu:lib", extra_path=[os.path.join(ROOT, "tests")])
+    srv = server.start(device=0, init="emu.emu:lib", extra_path=[os.path.join(ROOT, "tests")], arena_mb=0)
     monkeypatch.setenv("SNF_GPU_SERVER", srv.address)
     try:
         r = W.run(specs, {}, 3, "leads", "api")

@@ -33,7 +33,7 @@ def make_task(name):
 
 @pytest.fixture(scope="module")
 def srv():
-    h = server.start(device=0, init="emu.emu:lib", extra_path=[HERE])
+    h = server.start(device=0, init="emu.emu:lib", extra_path=[HERE], arena_mb=0)
     os.environ["SNF_GPU_SERVER"] = h.address
     yield h
     os.environ.pop("SNF_GPU_SERVER", None)

@@ -154,4 +154,19 @@ for k in 1 2 3; do
 done 2>&1 | tee gpurun_out/ab_r06_5.log
 SNF_ALT_HBM=1 timeout 120 python bench.py $Q --steps 30 --warmup 5 2>/dev/null | ms "two in flight with SNF_ALT_HBM (no effect expected: staged anyway)" | tee -a gpurun_out/ab_r06_5.log
   ;;
+12)
+# round 6, twelfth session: the default line once more on the final tree (what the driver runs), timed, and what it leaves in /dev/shm
+( time timeout 1200 python bench.py > gpurun_out/bench_default_12.json 2> gpurun_out/bench_default_12.err ) 2>&1 | grep real
+ls /dev/shm | head; python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/bench_default_12.json").read().splitlines() if l.startswith('{"metric"')][-1])
+print("ms_per_step", d["ms_per_step"], d["config"]["verified"], d["config"]["verified_vs_reference"], d["config"]["configs_verified"])
+print(json.dumps(d["cpu_baseline"]["vs_baseline"])[:700])
+PY
+  ;;
+13)
+# round 6, thirteenth session: the GPU server with its staging arena reserved up front (SNF_STAGE_ARENA_MB through server.start): 24 workers,
+# three runs of each input form
+for k in 1 2 3; do timeout 200 python tools/workers_slots.py 24 server columns leads; done 2>&1 | grep '^{' | cut -c1-330 | tee gpurun_out/workers_server_13.log
+  ;;
 esac
