@@ -132,7 +132,7 @@ class Task:
     def _call_candidates_served(self, srv, config, svcall_cls, bnd_cls) -> list:
         rep, res = self._served_result(srv, config)
         self._finalized = False
-        if sv.lazy_calls_supported(self._ti):
+        if sv.lazy_calls_supported(self._ti, svcall_cls):
             # stand-ins over the final records; `qc` as the candidate stage has it (True) until finalize_candidates
             src = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, None, None, keep_all=bool(config.no_qc))
             src.alt_pool, src.final, src.on_detach = res.alt_pool, True, rep.release
@@ -170,7 +170,7 @@ class Task:
         if int(res.task_status[0]) == TASK_ERR_UNBOUND_END:
             raise UnboundLocalError("local variable 'end' referenced before assignment")
         self._drop_lazy()
-        if LAZY_CALLS and sv.lazy_calls_supported(self._ti):
+        if LAZY_CALLS and sv.lazy_calls_supported(self._ti, svcall_cls):
             # a real list of stand-ins that become `svcall_cls` objects when they are first touched (sv.LazySource): the reference's
             # consumers read `.qc` of every candidate and the rest only of the calls they keep (parallel.py:265-271)
             self._lazy = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch, keep_all=bool(config.no_qc))

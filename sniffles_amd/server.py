@@ -26,7 +26,6 @@ server.
 from __future__ import annotations
 
 import os
-import pickle
 import threading
 
 import numpy as np
@@ -147,24 +146,49 @@ def _serve(address: str, device: int, init: str, extra_path, ready, arena_mb: in
     lock = threading.Lock()
     stop = threading.Event()
 
+    held = {}                                  # id(conn) -> {result segment: replies not yet released}: a worker that dies gives them back
+    conn_in = {}                               # id(conn) -> name of the worker's current input segment
+
+    def give_back(name, times=1):
+        with lock:
+            ent = busy.get(name)
+            if ent is not None:
+                ent[1] -= times
+                if ent[1] <= 0:
+                    del busy[name]
+                    free.append(ent[0])
+
     def reader(conn):
+        mine = held.setdefault(id(conn), {})
         try:
             while True:
                 m = conn.recv()
                 if m.get("op") == "release":
                     with lock:
-                        ent = busy.get(m["seg"])
-                        if ent is not None:
-                            ent[1] -= 1
-                            if ent[1] <= 0:
-                                del busy[m["seg"]]
-                                free.append(ent[0])
+                        if mine.get(m["seg"], 0) > 0:
+                            mine[m["seg"]] -= 1
+                    give_back(m["seg"])
                 elif m.get("op") == "stop":
                     stop.set(); q.put(None)
                 else:
+                    with lock:                 # a worker that grew its input segment has unlinked the old one: let go of the mapping
+                        old = conn_in.get(id(conn))
+                        if old is not None and old != m["seg"]:
+                            in_maps.pop(old, None)
+                        conn_in[id(conn)] = m["seg"]
                     q.put((conn, m))
         except (EOFError, OSError):
             pass
+        finally:                               # the worker is gone: what it still held, and the mapping of its input segment
+            with lock:
+                left = {k: v for k, v in mine.items() if v > 0}
+                mine.clear()
+                held.pop(id(conn), None)
+                old = conn_in.pop(id(conn), None)
+                if old is not None:
+                    in_maps.pop(old, None)
+            for name, times in left.items():
+                give_back(name, times)
 
     def acceptor():
         while not stop.is_set():
@@ -228,6 +252,15 @@ def _serve(address: str, device: int, init: str, extra_path, ready, arena_mb: in
                     out.buf[off_alt:off_alt + len(res.alt_pool)] = res.alt_pool
                 with lock:
                     busy[out.name] = [out, len(group)]
+                    for conn, m in group:
+                        h = held.get(id(conn))
+                        if h is None:          # (the worker left while its batch ran)
+                            busy[out.name][1] -= 1
+                        else:
+                            h[out.name] = h.get(out.name, 0) + 1
+                    if busy[out.name][1] <= 0:
+                        del busy[out.name]
+                        free.append(out)
                 for t, (conn, m) in enumerate(group):
                     send(conn, dict(seg=out.name, lo=int(res.task_call_off[t]), hi=int(res.task_call_off[t + 1]), n_calls=n,
                                     rnames_len=int(len(res.rnames)), alt_len=int(len(res.alt_pool)), off_rnames=off_rn, off_alt=off_alt,

@@ -444,6 +444,8 @@ class LazySource:
         self.stubs = None            # the list call_candidates returned (the stand-ins in record order)
         self.n_filled = 0
         self.on_detach = None        # called when the tables are let go of (a GPU server's result segment: sniffles_amd.server)
+        import threading
+        self._lock = threading.RLock()      # two threads touching stand-ins of one list: one bulk fill at a time
 
     def make(self, all_qc: bool = False) -> list:
         fast = _load_fast()
@@ -468,6 +470,10 @@ class LazySource:
         """The record tables are about to be handed on: the stand-ins that anything besides this source's own list still refers to
         become calls now; the others are garbage.  Breaks the list <-> source cycle."""
         import numpy as np
+        with self._lock:
+            self._detach_locked(np)
+
+    def _detach_locked(self, np) -> None:
         if self.stubs is not None and self.calls is not None:
             targets, idx = _load_fast().stub_select(self.stubs, self, 2)
             if targets:
@@ -484,9 +490,13 @@ class LazySource:
         all of them at the candidate stage (`finalize_candidates` then works on objects, as before), the ones with `qc` set (all
         under `no_qc`) after it.  What is left out stays a stand-in and is filled alone if it is ever touched."""
         import numpy as np
+        with self._lock:
+            self._fill_locked(obj, np)
+
+    def _fill_locked(self, obj, np) -> None:
         d = _raw_dict(obj)
         me = d.get("_lzi")
-        if me is None:
+        if me is None:                  # (became a call while this thread waited)
             return
         if self.calls is None:
             raise RuntimeError("this call's task was closed (or ran again) while nothing referred to the call")
@@ -513,10 +523,17 @@ class LazySource:
         self.n_filled += len(targets)
 
 
-def lazy_calls_supported(ti) -> bool:
+def lazy_calls_supported(ti, cls=None) -> bool:
     fast = _load_fast()
-    return (fast is not None and hasattr(fast, "make_stubs") and (ti.qnames is None or isinstance(ti.qnames, list))
-            and (ti.contig_names is None or isinstance(ti.contig_names, list)) and (ti.ps_names is None or isinstance(ti.ps_names, list)))
+    if not (fast is not None and hasattr(fast, "make_stubs") and (ti.qnames is None or isinstance(ti.qnames, list))
+            and (ti.contig_names is None or isinstance(ti.contig_names, list)) and (ti.ps_names is None or isinstance(ti.ps_names, list))):
+        return False
+    if cls is not None:                 # a call class whose instances have no `__dict__` (or that cannot be subclassed) is built eagerly
+        try:
+            lazy_class(cls)
+        except TypeError:
+            return False
+    return True
 
 
 def is_stand_in(c) -> bool:

@@ -72,6 +72,32 @@ def test_error_of_the_reference_comes_through(srv):
     t2.close()
 
 
+def test_a_client_that_leaves_gives_its_segments_back(srv):
+    """A worker that disappears with a reply it never released (killed, crashed): the server takes the result segment back when the
+    connection closes, drops the mapping of the worker's input segment, and goes on serving."""
+    import glob
+    task, cfg, ti, exp = make_task("long_ins")
+    c = server.Client(srv.address)
+    rep = c.run_task(cfg, task._task_input(cfg))
+    seg_name = rep.msg["seg"]
+    assert len(rep.result.calls) == len(exp["final"])
+    c.conn.close()                                  # no release, no goodbye
+    for s_ in c._in:
+        s_.unlink()
+    import time
+    for _ in range(50):                             # the same segment serves the next batch of that size once it is free again
+        t2, cfg2, _, exp2 = make_task("long_ins")
+        cands = t2.call_candidates(True, cfg2)
+        name2 = sv._raw_dict(cands[0])["_lz"].on_detach.__self__.msg["seg"] if cands else None
+        assert [as_final(c_) for c_ in t2.finalize_candidates(cands, True, cfg2)] == exp2["final"]
+        t2.close()
+        if name2 == seg_name:
+            break
+        time.sleep(0.05)
+    assert name2 == seg_name
+    assert len(glob.glob("/dev/shm/snfsrv_*")) <= 8
+
+
 def _worker(address, names, barrier, out_q):
     try:
         for p in (os.path.dirname(HERE), HERE):
