@@ -134,7 +134,7 @@ class Task:
         self._finalized = False
         if sv.lazy_calls_supported(self._ti, svcall_cls):
             # stand-ins over the final records; `qc` as the candidate stage has it (True) until finalize_candidates
-            src = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, None, None, keep_all=bool(config.no_qc))
+            src = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, None, None, keep_all=bool(config.no_qc or getattr(config, "snf", None) is not None))
             src.alt_pool, src.final, src.on_detach = res.alt_pool, True, rep.release
             self._lazy = src
             out = src.make(all_qc=True)
@@ -173,7 +173,8 @@ class Task:
         if LAZY_CALLS and sv.lazy_calls_supported(self._ti, svcall_cls):
             # a real list of stand-ins that become `svcall_cls` objects when they are first touched (sv.LazySource): the reference's
             # consumers read `.qc` of every candidate and the rest only of the calls they keep (parallel.py:265-271)
-            self._lazy = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch, keep_all=bool(config.no_qc))
+            self._lazy = sv.LazySource(res, self._ti, svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch,
+                                       keep_all=bool(config.no_qc or getattr(config, "snf", None) is not None))
             out = self._lazy.make()
         else:
             out = sv.materialize_candidates(res, self._ti, 0, len(res.calls), svcall_cls, bnd_cls, sv.SVCallPostprocessingInfo, self._batch)

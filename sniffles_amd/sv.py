@@ -443,6 +443,7 @@ class LazySource:
         self.keep_all = keep_all
         self.stubs = None            # the list call_candidates returned (the stand-ins in record order)
         self.n_filled = 0
+        self.n_single = 0            # stand-ins outside the bulk selection that were filled alone
         self.on_detach = None        # called when the tables are let go of (a GPU server's result segment: sniffles_amd.server)
         import threading
         self._lock = threading.RLock()      # two threads touching stand-ins of one list: one bulk fill at a time
@@ -503,7 +504,14 @@ class LazySource:
         if self.stubs is not None and (not self.final or self.keep_all or d.get("qc")):
             targets, idx = _load_fast().stub_select(self.stubs, self, 1 if (self.final and not self.keep_all) else 0)
             self.fill_many(targets, np.frombuffer(idx, np.int64))
+        elif self.stubs is not None and self.n_single >= 1:
+            # a second call that failed QC is touched: the consumer walks all of them (the SNF writer stores every candidate,
+            # parallel.py:278-291) - the rest in one pass, not one by one
+            self.keep_all = True
+            targets, idx = _load_fast().stub_select(self.stubs, self, 0)
+            self.fill_many(targets, np.frombuffer(idx, np.int64))
         else:
+            self.n_single += 1
             self.fill_many([obj], np.asarray([me], np.int64))
 
     def fill_many(self, targets: list, idx) -> None:
