@@ -169,4 +169,21 @@ PY
 # three runs of each input form
 for k in 1 2 3; do timeout 200 python tools/workers_slots.py 24 server columns leads; done 2>&1 | grep '^{' | cut -c1-330 | tee gpurun_out/workers_server_13.log
   ;;
+14)
+# round 6, fourteenth session: what an LDS double buffer would cost LARGE in occupancy - the kernel as it is with 24 KB of unused LDS per
+# workgroup (one workgroup per CU instead of two; built from a copy of the sources, variants/large_1wg.so)
+for k in 1 2; do
+  for tag in base one_wg; do
+    if [ $tag == one_wg ]; then export SNF_LIB_SO=$R/variants/large_1wg.so; else unset SNF_LIB_SO; fi
+    for fl in 2 1; do
+      timeout 120 python bench.py $Q --steps 40 --warmup 5 --inflight $fl 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{\"metric\"')][-1])
+k=[x for x in d['roofline']['top_kernels'] if x['name']=='e45w_consensus_large'][0]
+print('$tag in flight $fl: ms_per_step', round(d['ms_per_step'],3), 'LARGE ms', k['ms'])"
+    done
+  done
+done 2>&1 | tee gpurun_out/ab_r06_6.log
+unset SNF_LIB_SO
+  ;;
 esac
