@@ -186,4 +186,13 @@ print('$tag in flight $fl: ms_per_step', round(d['ms_per_step'],3), 'LARGE ms', 
 done 2>&1 | tee gpurun_out/ab_r06_6.log
 unset SNF_LIB_SO
   ;;
+15)
+# round 6, fifteenth session: what the two-in-flight step is sensitive to - ablations of whole stages (not results: the lines say so)
+for spec in "plain:" "symbolic:SNF_BENCH_CFG={\"symbolic\":true}" "no_consensus:SNF_BENCH_CFG={\"no_consensus\":true}" "three_in_flight:X=1" "pace_off:SNF_PACE=0" "plain2:"; do
+  tag=${spec%%:*}; envs=${spec#*:}; fl=2; [ $tag == three_in_flight ] && fl=3
+  for k in 1 2; do
+    env $envs timeout 120 python bench.py $Q --no-verify --steps 40 --warmup 5 --inflight $fl 2>/dev/null | ms "$tag"
+  done
+done 2>&1 | tee gpurun_out/ab_r06_7.log
+  ;;
 esac
