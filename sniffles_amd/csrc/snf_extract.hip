@@ -10,13 +10,17 @@
 //   build_leadtab     leadprov.py:445-472   keep the leads of this contig inside [start, end)
 // pysam properties are computed from the record bytes (SAM/BAM spec 4.2; htslib bam_endpos, pysam getQueryStart/End).
 //
-// Mapping: one WAVE (and one workgroup) per alignment record.  The CIGAR (4 B per operation, thousands of operations per long read) is
-// walked 256 operations per step (4 per lane, next step prefetched): two DPP wave prefix sums give every lane the read /
-// reference position of its operations, a third ranks the signature-bearing operations so leads come out in CIGAR order.
-// Inserted sequence is decoded from the 4-bit packed read by the whole wave.  Tag strings are scanned 64 bytes per
-// step.  The per-record split-alignment logic (a handful of SA elements) is sequential and runs on lane 0 with its
-// segment table in LDS.  Two passes over the records (count, emit) around three device scans give exact output
-// offsets, so the leads land in `record_lead` order without atomics.
+// Mapping: one WAVE (and one workgroup) per alignment record.  A record is a chain of dependent accesses (offset -> fixed fields ->
+// CIGAR ends / tags / CIGAR body -> SA string); what the wave form does about it: the 24 bytes of fixed fields arrive as ONE load
+// (a dword per lane, read back into scalar registers); then, in one round trip, the first and last four CIGAR operations (the
+// clip scans of getQueryStart / getQueryEnd), the record's whole auxiliary region (16 bytes per lane into LDS: the tag walk and
+// the lane-0 SA parser then read LDS, a tag costing one 8-byte read) and the first two steps of the CIGAR.  The CIGAR (4 B per
+// operation, thousands of operations per long read) is walked 256 operations per step (one 16-byte load per lane, two steps
+// ahead): two DPP wave prefix sums give every lane the read / reference position of its operations, a third ranks the
+// signature-bearing operations so leads come out in CIGAR order.
+// Inserted sequence is decoded from the 4-bit packed read by the whole wave.  The per-record split-alignment logic (a handful of
+// SA elements) is sequential and runs on lane 0 with its segment table in LDS.  Two passes over the records (count, emit)
+// around three device scans give exact output offsets, so the leads land in `record_lead` order without atomics.
 // HBM-bound byte/integer work: no MFMA.  Algorithmic bytes per record: 36 B core + name + 4 B x n_cigar + aux bytes,
 // plus the inserted bases read (0.5 B) and written (1 B); sequence and quality bytes of the read are never touched.
 // The thread form (WAVE == false) is what the host emulation executes (tests/emu) and SNF_EXTRACT_THREAD=1 selects.
@@ -44,16 +48,17 @@ static const char* const XE_TEXT[] = {
 
 #define XMAXSEG 64
 
-struct RecSum {          // per record, written by the counting pass
+struct RecSum {          // per record, written by the counting pass (64 bytes)
   int64_t seq_bytes;     // bytes this record adds to the sequence pool
-  int64_t sa_off;        // byte offset of the SA string in the blob, -1: no SA tag
   int64_t ps;            // PS tag (has_ps)
   double nm;             // (NM - large indels) / (query_alignment_length + 1), or -1
+  int32_t sa_rel, sa_len;     // the SA string: byte offset inside the record's auxiliary region (-1: no SA tag), length without its NUL
   int32_t n_leads, ref_end, nm_tag;
   int32_t walk_lo, walk_hi;   // CIGAR steps [walk_lo, walk_hi) hold every lead-bearing operation (emit pass walks only these)
   uint32_t walk_pr, walk_pf;  // read / reference position at walk_lo
   uint8_t accept, has_nm, has_ps, hp;
 };
+static_assert(sizeof(RecSum) == 64, "one 64-byte record per alignment record");
 
 struct Seg {             // one (split) alignment of a read in classify_splits
   int32_t contig, rs, re, qs, qe, mapq;
@@ -81,7 +86,23 @@ struct ExView {
   uint8_t* o_pool;
   int32_t *o_rstart, *o_rend; uint8_t* o_rhp;
   double* nm_out;   // [0] sum, [1] count
+#ifdef SNF_XTRACE
+  uint32_t* xtrace;   // instrumented build (tools/xtrace.sh): per record {start, total, tags + clips, SA section} in wall-clock ticks (10 ns)
+  int xtrace_emit;    // which pass leaves its stamps
+#endif
 };
+#ifdef SNF_XTRACE
+#define XT_DECL unsigned long long xt_[4] = {(unsigned long long)wall_clock64(), 0, 0, 0};
+#define XT(k) xt_[k] = wall_clock64();
+#define XT_ADD(k, t0) xt_[k] += wall_clock64() - (t0);
+#define XT_FLUSH() do { if (v.xtrace && lane == 0 && (int)EMIT == v.xtrace_emit) { uint32_t* o_ = v.xtrace + 4 * rec; o_[0] = (uint32_t)xt_[0]; \
+    o_[1] = (uint32_t)(wall_clock64() - xt_[0]); o_[2] = (uint32_t)(xt_[1] ? xt_[1] - xt_[0] : 0); o_[3] = (uint32_t)xt_[2]; } } while (0)
+#else
+#define XT_DECL
+#define XT(k)
+#define XT_ADD(k, t0)
+#define XT_FLUSH()
+#endif
 
 // ---- lane helpers: WAVE == true only exists in device code ----------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -138,6 +159,13 @@ template <bool WAVE> SNF_HD void x_wave_sync() {
   if (WAVE) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 #endif
 }
+// a value every lane holds alike, moved to a scalar register (v_readfirstlane)
+template <bool WAVE> SNF_HD uint32_t x_uni(uint32_t x) {
+#if XDEV
+  if (WAVE) return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#endif
+  return x;
+}
 SNF_HD int x_popc(uint64_t m) { return __builtin_popcountll(m); }
 SNF_HD int x_ctz(uint64_t m) { return __builtin_ctzll(m); }
 
@@ -155,22 +183,51 @@ SNF_HD uint32_t ld_u32(const uint8_t* p) {
   uint32_t v; memcpy(&v, p, 4); return v;
 #endif
 }
-// the CIGAR operations [base + lane * OPL, + OPL) of a record; operations past the end read as 0P.  Wave form: the four
-// dwords of a lane come from five aligned dwords realigned by v_alignbyte (the record is byte-aligned in the blob).
+// Loads at any byte address of GLOBAL memory (records are byte-aligned in the blob; the device serves misaligned global accesses
+// in hardware, so one instruction fetches what two aligned loads and a shift did).  The blob is padded by 16 bytes.
+typedef uint32_t __attribute__((aligned(1))) x_u32_any;
+typedef uint4 __attribute__((aligned(1))) x_u128_any;
+// 8 bytes at any address of the blob OR of the LDS copy of a record's auxiliary region: the two aligned words around the
+// address and a funnel shift (an unaligned 8-byte LDS read is served lane by lane); both have >= 16 bytes of slack behind them
+SNF_HD uint64_t x_ld8(const uint8_t* p) {
+#if XDEV
+  const uintptr_t a = (uintptr_t)p;
+  const uint64_t* q = (const uint64_t*)(a & ~(uintptr_t)7);
+  const unsigned sh = (unsigned)(a & 7) * 8;
+  const uint64_t lo = q[0], hi = q[1];
+  return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+#else
+  uint64_t w; memcpy(&w, p, 8); return w;
+#endif
+}
+// the first six dwords of a record (block_size, refID, pos, l_read_name | mapq | bin, n_cigar_op | flag, l_seq).  Wave form: one
+// dword per lane, read back with v_readlane - the values sit in scalar registers from then on (everything derived from them is
+// wave-uniform and costs no vector registers)
+template <bool WAVE> SNF_HD void x_header(const uint8_t* R, int lane, uint32_t* hd) {
+#if XDEV
+  if (WAVE) {
+    uint32_t w = 0;
+    if (lane < 6) w = *(const x_u32_any*)(R + 4 * lane);
+#pragma unroll
+    for (int k = 0; k < 6; k++) hd[k] = (uint32_t)__builtin_amdgcn_readlane((int)w, k);
+    return;
+  }
+#endif
+  (void)lane;
+  for (int k = 0; k < 6; k++) hd[k] = ld_u32(R + 4 * k);
+}
+// the CIGAR operations [base + lane * OPL, + OPL) of a record; operations past the end read as 0P.  Wave form: one 16-byte
+// load per lane (64 lanes: 1 KB of consecutive operations, sixteen 64-byte lines per instruction).
 template <bool WAVE> SNF_HD void x_load_ops(const uint8_t* cig, int n_cig, int base, int lane, uint32_t* dst) {
 #if XDEV
   if (WAVE) {
     const int k0 = base + lane * 4;
     if (k0 + 4 <= n_cig) {
-      const uintptr_t a = (uintptr_t)(cig + 4 * (int64_t)k0);
-      const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
-      const uint32_t mis = (uint32_t)(a & 3);
-      const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
-      dst[0] = __builtin_amdgcn_alignbyte(d1, d0, mis); dst[1] = __builtin_amdgcn_alignbyte(d2, d1, mis);
-      dst[2] = __builtin_amdgcn_alignbyte(d3, d2, mis); dst[3] = __builtin_amdgcn_alignbyte(d4, d3, mis);
+      const uint4 q = *(const x_u128_any*)(cig + 4 * (int64_t)k0);
+      dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++) dst[j] = k0 + j < n_cig ? ld_u32(cig + 4 * (int64_t)(k0 + j)) : 6u;
+      for (int j = 0; j < 4; j++) dst[j] = k0 + j < n_cig ? *(const x_u32_any*)(cig + 4 * (int64_t)(k0 + j)) : 6u;
     }
     return;
   }
@@ -216,63 +273,87 @@ template <bool WAVE> SNF_HD void x_copy_bases(const uint8_t* seq, int32_t a, int
 }
 
 // ---- SA string parsing (sequential; lane 0) --------------------------------------------------------------------
-struct SaElem { int64_t f0[6], f1[6]; int nf; };   // field byte ranges [f0, f1) of one SA element
+// `s` points at the first byte of the SA string - in the LDS copy of the record's auxiliary region (wave form) or in the blob;
+// positions are byte offsets from there
+struct SaElem { int32_t f0[6], f1[6]; int nf; };   // field byte ranges [f0, f1) of one SA element
 
+// field number e->nf is [fs, b).  (Constant indices only: the element stays in registers - indexed by nf it lived in scratch memory,
+// and the parser, a chain of dependent accesses on one lane, waited a memory round trip for every field it wrote and read back:
+// a record with an SA tag took ~250 us, which is what a whole pass over 24 000 records then took)
+SNF_HD void sa_field(SaElem* e, int32_t fs, int32_t b) {
+#pragma unroll
+  for (int q = 0; q < 6; q++) if (e->nf == q) { e->f0[q] = fs; e->f1[q] = b; }
+  e->nf++;
+}
 // next non-empty element of the ';' separated string starting at *p (NUL terminated); false at the end
-SNF_HD bool sa_next(const uint8_t* s, int64_t* p, SaElem* e) {
+SNF_HD bool sa_next(const uint8_t* s, int32_t* p, SaElem* e) {
   for (;;) {
-    int64_t a = *p;
+    int32_t a = *p;
     if (s[a] == 0) return false;
-    int64_t b = a;
-    while (s[b] != 0 && s[b] != ';') b++;
-    *p = s[b] == ';' ? b + 1 : b;
-    if (b == a) continue;
+    // one pass: the element's end and its field borders (eight bytes per read)
     e->nf = 0;
-    int64_t fs = a;
-    for (int64_t k = a; k <= b; k++) {
-      if (k == b || s[k] == ',') {
-        if (e->nf < 6) { e->f0[e->nf] = fs; e->f1[e->nf] = k; }
-        e->nf++;
-        fs = k + 1;
+    int32_t fs = a, b = a; bool end = false;
+    while (!end) {
+      uint64_t w = x_ld8(s + b);
+      for (int k = 0; k < 8; k++, w >>= 8) {
+        const uint8_t c = (uint8_t)w;
+        if (c == 0 || c == ';') { end = true; break; }
+        if (c == ',') { sa_field(e, fs, b); fs = b + 1; }
+        b++;
       }
     }
+    *p = s[b] == ';' ? b + 1 : b;
+    if (b == a) continue;
+    sa_field(e, fs, b);
     return true;
   }
 }
-SNF_HD bool sa_int(const uint8_t* s, int64_t a, int64_t b, int64_t* out) {
+SNF_HD bool sa_int(const uint8_t* s, int32_t a, int32_t b, int64_t* out) {
   bool neg = false;
   if (a < b && (s[a] == '-' || s[a] == '+')) { neg = s[a] == '-'; a++; }
   if (a >= b || b - a > 18) return false;
   int64_t v = 0;
-  for (int64_t k = a; k < b; k++) { if (s[k] < '0' || s[k] > '9') return false; v = v * 10 + (s[k] - '0'); }
+  for (int32_t k = a; k < b; k += 8) {
+    uint64_t w = x_ld8(s + k);
+    const int m = b - k < 8 ? b - k : 8;
+    for (int j = 0; j < m; j++, w >>= 8) { const uint8_t c = (uint8_t)w; if (c < '0' || c > '9') return false; v = v * 10 + (c - '0'); }
+  }
   *out = neg ? -v : v;
   return true;
 }
 // CIGAR_analyze (leadprov.py:144-178); false = the reference raises inside its try block
-SNF_HD bool sa_cigar(const uint8_t* s, int64_t a, int64_t b, int64_t* clip0, int64_t* clip1, int64_t* refspan, int64_t* readspan) {
+SNF_HD bool sa_cigar(const uint8_t* s, int32_t a, int32_t b, int64_t* clip0, int64_t* clip1, int64_t* refspan, int64_t* readspan) {
   int64_t num = 0, rd = 0, rf = 0, clip = 0, first = -1; bool have = false;
-  for (int64_t k = a; k < b; k++) {
-    const uint8_t c = s[k];
-    if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); have = true; continue; }
-    if (!have) return false;
-    const bool q = c == 'M' || c == 'I' || c == 'X' || c == '=';
-    const bool r = c == 'M' || c == 'D' || c == 'X' || c == '=' || c == 'N';
-    if (q) rd += num;
-    if (r) rf += num;
-    if (!q && !r) {
-      if (c != 'S' && c != 'H') return false;
-      if (first < 0 && rd + rf > 0) first = clip;
-      clip += num;
+  for (int32_t k0 = a; k0 < b; k0 += 8) {
+    uint64_t w = x_ld8(s + k0);
+    const int m = b - k0 < 8 ? b - k0 : 8;
+    for (int j = 0; j < m; j++, w >>= 8) {
+      const uint8_t c = (uint8_t)w;
+      if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); have = true; continue; }
+      if (!have) return false;
+      const bool q = c == 'M' || c == 'I' || c == 'X' || c == '=';
+      const bool r = c == 'M' || c == 'D' || c == 'X' || c == '=' || c == 'N';
+      if (q) rd += num;
+      if (r) rf += num;
+      if (!q && !r) {
+        if (c != 'S' && c != 'H') return false;
+        if (first < 0 && rd + rf > 0) first = clip;
+        clip += num;
+      }
+      num = 0; have = false;
     }
-    num = 0; have = false;
   }
   if (first < 0) first = clip;
   *clip0 = first; *clip1 = clip - first; *refspan = rf; *readspan = rd;
   return true;
 }
-SNF_HD int32_t sa_contig(const ExView& v, const uint8_t* s, int64_t a, int64_t b) {
+SNF_HD int32_t sa_contig(const ExView& v, const uint8_t* s, int32_t a, int32_t b) {
   uint64_t h = 0xcbf29ce484222325ULL;
-  for (int64_t k = a; k < b; k++) h = (h ^ s[k]) * 0x100000001b3ULL;
+  for (int32_t k0 = a; k0 < b; k0 += 8) {
+    uint64_t w = x_ld8(s + k0);
+    const int m = b - k0 < 8 ? b - k0 : 8;
+    for (int j = 0; j < m; j++, w >>= 8) h = (h ^ (uint8_t)w) * 0x100000001b3ULL;
+  }
   int lo = 0, hi = v.n_contigs;
   while (lo < hi) { int mid = (lo + hi) >> 1; if (v.ctg_hash[mid] < h) lo = mid + 1; else hi = mid; }
   return (lo < v.n_contigs && v.ctg_hash[lo] == h) ? v.ctg_rank[lo] : -1;
@@ -346,33 +427,151 @@ SNF_HD int classify(const ExView& v, Seg* segs, uint8_t* ord, int n, int32_t l_s
   return n;
 }
 
+// ---- the tags of a record (first NM / HP / PS / SA), counting pass ------------------------------------------------
+// `A` points at the record's auxiliary region (its LDS copy in the wave form, the blob otherwise), positions are byte offsets
+// from there.  A tag is ONE 8-byte read: two name bytes, the type, and up to five bytes of value (the sub-type and count of a
+// B array); only Z / H strings are looked at further (the NUL, 64 bytes per step by the whole wave).
+struct TagSum { int64_t ps; int32_t sa_rel, sa_len, nm_tag; int hp; bool has_nm, has_ps; int bad; };
+template <bool WAVE> SNF_HD void x_parse_tags(const uint8_t* A, int32_t aux_len, int lane, TagSum& t) {
+  t.ps = 0; t.sa_rel = -1; t.sa_len = 0; t.nm_tag = 0; t.hp = 0; t.has_nm = false; t.has_ps = false;
+  bool has_hp = false; int bad = 0;
+  int64_t p = 0;
+  while (p + 3 <= aux_len && !bad) {
+    const uint64_t w = x_ld8(A + p);
+    const uint8_t t0 = (uint8_t)w, t1 = (uint8_t)(w >> 8), ty = (uint8_t)(w >> 16);
+    const uint32_t pay = (uint32_t)(w >> 24);   // value bytes 0..3 (byte 4 of a B array's count is w >> 56)
+    p += 3;
+    int64_t val = 0; bool isint = true; int64_t zs = -1, zn = 0;
+    switch (ty) {
+      case 'A': isint = false; p += 1; break;
+      case 'c': val = (int8_t)pay; p += 1; break;
+      case 'C': val = (uint8_t)pay; p += 1; break;
+      case 's': val = (int16_t)pay; p += 2; break;
+      case 'S': val = (uint16_t)pay; p += 2; break;
+      case 'i': val = (int32_t)pay; p += 4; break;
+      case 'I': val = pay; p += 4; break;
+      case 'f': isint = false; p += 4; break;
+      case 'Z': case 'H': {
+        isint = false; zs = p;
+        const int64_t z = x_find_nul<WAVE>(A, p, aux_len, lane);
+        if (z < 0) bad = XE_AUX; else { zn = z - p; p = z + 1; }
+        break; }
+      case 'B': {
+        isint = false;
+        const uint8_t sub = (uint8_t)pay; const int64_t cnt = (int32_t)(uint32_t)(w >> 32);
+        const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
+        if (!sz || cnt < 0) bad = XE_AUX; else p += 5 + cnt * sz;
+        break; }
+      default: bad = XE_AUX;
+    }
+    if (bad) break;
+    if (t0 == 'N' && t1 == 'M' && !t.has_nm) { if (!isint) bad = XE_TAGTYPE; t.has_nm = true; t.nm_tag = (int32_t)val; if (!fits_i32(val)) bad = XE_RANGE; }
+    else if (t0 == 'H' && t1 == 'P' && !has_hp) { if (!isint) bad = XE_TAGTYPE; has_hp = true; if (val < 0 || val > 2) bad = bad ? bad : XE_HP; t.hp = (int)val; }
+    else if (t0 == 'P' && t1 == 'S' && !t.has_ps) { if (!isint) bad = XE_TAGTYPE; t.has_ps = true; t.ps = val; }
+    else if (t0 == 'S' && t1 == 'A' && t.sa_rel < 0) { if (ty != 'Z') bad = XE_TAGTYPE; t.sa_rel = (int32_t)zs; t.sa_len = (int32_t)zn; }
+  }
+  if (!bad && p > aux_len) bad = XE_AUX;
+  t.bad = bad;
+}
+
 // ---- one alignment record ----------------------------------------------------------------------------------------
+#define XAUXCAP 1024   // bytes of a record's auxiliary region (counting pass) / of its SA string (emit pass) the wave form keeps in LDS;
+                       // a longer one (base-modification arrays ...) is parsed where it lies in the blob
 template <bool WAVE, bool EMIT>
-SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord) {
+SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord, uint8_t* auxl, int32_t* sab) {
   const int lane = x_lane<WAVE>();
   const int W = WAVE ? 64 : 1;
   const snf_extract_config_t& cfg = v.cfg;
-  const uint8_t* R = v.blob + v.rec_off[rec];
+  XT_DECL
+  const int64_t roff = v.rec_off[rec];
+  const uint8_t* R = v.blob + roff;
   RecSum& S = v.sum[rec];
-  if (EMIT) { if (!S.accept) return; }
-  else if (lane == 0) { S.accept = 0; S.n_leads = 0; S.seq_bytes = 0; S.has_nm = 0; S.has_ps = 0; S.nm = -1.0; S.sa_off = -1; S.hp = 0; S.ps = 0; S.nm_tag = 0; S.ref_end = 0; }
-  const int32_t block_size = (int32_t)ld_u32(R);
-  const int32_t ref_id = (int32_t)ld_u32(R + 4), pos = (int32_t)ld_u32(R + 8);
-  const int l_name = R[12], mapq = R[13];
-  const int n_cig = (int)ld_u16(R + 16), flag = (int)ld_u16(R + 18);
-  const int32_t l_seq = (int32_t)ld_u32(R + 20);
+  RecSum sv{};   // emit pass: what the counting pass left, requested together with the fixed fields (wave-uniform: into scalar registers)
+  if (EMIT) {
+    sv = S;
+    sv.accept = (uint8_t)x_uni<WAVE>(sv.accept); sv.sa_rel = (int32_t)x_uni<WAVE>((uint32_t)sv.sa_rel); sv.sa_len = (int32_t)x_uni<WAVE>((uint32_t)sv.sa_len);
+    sv.walk_lo = (int32_t)x_uni<WAVE>((uint32_t)sv.walk_lo); sv.walk_hi = (int32_t)x_uni<WAVE>((uint32_t)sv.walk_hi);
+    sv.walk_pr = x_uni<WAVE>(sv.walk_pr); sv.walk_pf = x_uni<WAVE>(sv.walk_pf);
+    sv.nm_tag = (int32_t)x_uni<WAVE>((uint32_t)sv.nm_tag); sv.ref_end = (int32_t)x_uni<WAVE>((uint32_t)sv.ref_end);
+    sv.hp = (uint8_t)x_uni<WAVE>(sv.hp); sv.has_nm = (uint8_t)x_uni<WAVE>(sv.has_nm); sv.has_ps = (uint8_t)x_uni<WAVE>(sv.has_ps);
+  }
+  else if (lane == 0) { S.accept = 0; S.n_leads = 0; S.seq_bytes = 0; S.has_nm = 0; S.has_ps = 0; S.nm = -1.0; S.sa_rel = -1; S.sa_len = 0; S.hp = 0; S.ps = 0; S.nm_tag = 0; S.ref_end = 0; }
+  uint32_t hd[6];
+  x_header<WAVE>(R, lane, hd);
+  if (EMIT) { if (!sv.accept) return; }
+  const int32_t block_size = (int32_t)hd[0];
+  const int32_t ref_id = (int32_t)hd[1], pos = (int32_t)hd[2];
+  const int l_name = (int)(hd[3] & 0xffu), mapq = (int)((hd[3] >> 8) & 0xffu);
+  const int n_cig = (int)(hd[4] & 0xffffu), flag = (int)(hd[4] >> 16);
+  const int32_t l_seq = (int32_t)hd[5];
   if (ref_id != v.region_ref_id || (flag & 0x4)) return;
   if (n_cig == 0) { if (!EMIT && lane == 0) x_error(v, rec, XE_NOCIGAR); return; }
   const uint8_t* cig = R + 36 + l_name;
   const uint8_t* seq = cig + 4 * (int64_t)n_cig;
-  const int64_t aux0 = (int64_t)(seq - v.blob) + (l_seq + 1) / 2 + l_seq, aux1 = v.rec_off[rec] + 4 + block_size;
+  const int64_t aux0 = (int64_t)(seq - v.blob) + (l_seq + 1) / 2 + l_seq, aux1 = roff + 4 + block_size;
+  const int32_t aux_len = (int32_t)(aux1 - aux0);
+  // ---- everything the record needs next is requested here, in one round trip:
+  // (a) the first and the last four CIGAR operations (lanes 0..3: operation k; lanes 4..7: operation n_cig - 1 - (lane - 4), while
+  //     that is >= 1): the clip scans of getQueryStart / getQueryEnd and the break side of Lead.for_bnd
+  uint32_t cw = 6u;   // 0P: ends a clip scan
+#if XDEV
+  if (WAVE) {
+    const int k = lane < 4 ? lane : n_cig - 1 - (lane - 4);
+    if (lane < 4 ? k < n_cig : (lane < 8 && k >= 1)) cw = *(const x_u32_any*)(cig + 4 * k);
+  }
+#endif
+  // (b) counting pass: the auxiliary region; emit pass: the SA string - 16 bytes per lane into LDS
+  const uint8_t* A = v.blob + aux0;   // where the tags are parsed
+  const int32_t sa_rel_in = EMIT ? sv.sa_rel : -1, sa_len_in = EMIT ? sv.sa_len : 0;
+  const uint8_t* SAs = EMIT ? v.blob + aux0 + sa_rel_in : nullptr;   // first byte of the SA string
+#if XDEV
+  if (WAVE) {
+    x_wave_sync<WAVE>();     // the record before is through with the LDS copy
+    const int64_t src = EMIT ? aux0 + sa_rel_in : aux0;
+    const int32_t nb = EMIT ? (sa_rel_in >= 0 ? sa_len_in + 1 : 0) : aux_len;
+    if (nb <= XAUXCAP) {
+      for (int32_t o = lane * 16; o < nb; o += 64 * 16) *(uint4*)(auxl + o) = *(const x_u128_any*)(v.blob + src + o);
+      if (EMIT) SAs = auxl; else A = auxl;
+    }
+  }
+#endif
+  // (c) the first two steps of the CIGAR walk
+  constexpr int OPL = WAVE ? 4 : 1;
+  const int STEP = W * OPL;
+  int base0 = 0, base1 = n_cig;
+  if (EMIT) { base0 = sv.walk_lo; base1 = sv.walk_hi; }
+  uint32_t cur[OPL], nx1[OPL], nx2[OPL];
+#pragma unroll
+  for (int j = 0; j < OPL; j++) { cur[j] = 6u; nx1[j] = 6u; }
+  if (base0 < base1) x_load_ops<WAVE>(cig, n_cig, base0, lane, cur);
+  if (WAVE && base0 + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base0 + STEP, lane, nx1);
   // pysam getQueryStart / getQueryEnd
   int32_t q0 = 0, q1 = l_seq; bool clip_bad = false;
-  for (int k = 0; k < n_cig; k++) {
-    const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
-    if (op == 5) { if (q0 != 0 && q0 != l_seq) clip_bad = true; }
-    else if (op == 4) q0 += (int32_t)(c >> 4);
-    else break;
+  uint32_t c_first, c_last;
+  {
+    int k = 0; bool more = true;
+#if XDEV
+    if (WAVE) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (!more) continue;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw, j); const int op = c & 15;
+        if (op == 5) { if (q0 != 0 && q0 != l_seq) clip_bad = true; }
+        else if (op == 4) q0 += (int32_t)(c >> 4);
+        else more = false;
+      }
+      k = 4;
+      c_first = (uint32_t)__builtin_amdgcn_readlane((int)cw, 0);
+      c_last = n_cig >= 2 ? (uint32_t)__builtin_amdgcn_readlane((int)cw, 4) : c_first;
+    } else
+#endif
+    { c_first = ld_u32(cig); c_last = ld_u32(cig + 4 * (int64_t)(n_cig - 1)); }
+    for (; more && k < n_cig; k++) {
+      const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
+      if (op == 5) { if (q0 != 0 && q0 != l_seq) clip_bad = true; }
+      else if (op == 4) q0 += (int32_t)(c >> 4);
+      else break;
+    }
   }
   if (l_seq == 0) {
     q1 = 0;   // no sequence: length from the CIGAR (M I = X, and S while nothing was counted yet); rare, lane-serial
@@ -381,7 +580,21 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
       if (op == 0 || op == 1 || op == 7 || op == 8 || (op == 4 && q1 == 0)) q1 += (int32_t)(c >> 4);
     }
   } else {
-    for (int k = n_cig - 1; k >= 1; k--) {
+    int k = n_cig - 1; bool more = true;
+#if XDEV
+    if (WAVE) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {   // (a lane whose operation would be operation 0, or none, holds 0P)
+        if (!more) continue;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cw, 4 + j); const int op = c & 15;
+        if (op == 5) { if (q1 != l_seq) clip_bad = true; }
+        else if (op == 4) q1 -= (int32_t)(c >> 4);
+        else more = false;
+      }
+      k = n_cig - 5;
+    }
+#endif
+    for (; more && k >= 1; k--) {
       const uint32_t c = ld_u32(cig + 4 * k); const int op = c & 15;
       if (op == 5) { if (q1 != l_seq) clip_bad = true; }
       else if (op == 4) q1 -= (int32_t)(c >> 4);
@@ -395,49 +608,21 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
   if (cfg.exclude_flags >= 0 && (flag & cfg.exclude_flags)) return;
   if (pos < v.region_start || pos >= v.region_end) return;
   // ---- tags (first NM / HP / PS / SA)
-  int64_t sa_off = -1, ps = 0; int32_t nm_tag = 0; int hp = 0; bool has_nm = false, has_ps = false;
+  int32_t sa_rel = -1, sa_len = 0; int64_t ps = 0; int32_t nm_tag = 0; int hp = 0; bool has_nm = false, has_ps = false;
   if (!EMIT) {
-    bool has_hp = false; int bad = 0;
-    int64_t p = aux0;
-    while (p + 3 <= aux1 && !bad) {
-      const uint8_t t0 = v.blob[p], t1 = v.blob[p + 1], ty = v.blob[p + 2];
-      p += 3;
-      int64_t val = 0; bool isint = true; int64_t zs = -1;
-      switch (ty) {
-        case 'A': isint = false; p += 1; break;
-        case 'c': val = (int8_t)v.blob[p]; p += 1; break;
-        case 'C': val = v.blob[p]; p += 1; break;
-        case 's': val = (int16_t)ld_u16(v.blob + p); p += 2; break;
-        case 'S': val = ld_u16(v.blob + p); p += 2; break;
-        case 'i': val = (int32_t)ld_u32(v.blob + p); p += 4; break;
-        case 'I': val = ld_u32(v.blob + p); p += 4; break;
-        case 'f': isint = false; p += 4; break;
-        case 'Z': case 'H': {
-          isint = false; zs = p;
-          const int64_t z = x_find_nul<WAVE>(v.blob, p, aux1, lane);
-          if (z < 0) bad = XE_AUX; else p = z + 1;
-          break; }
-        case 'B': {
-          isint = false;
-          const uint8_t sub = v.blob[p]; const int64_t cnt = (int32_t)ld_u32(v.blob + p + 1);
-          const int sz = (sub == 'c' || sub == 'C') ? 1 : (sub == 's' || sub == 'S') ? 2 : (sub == 'i' || sub == 'I' || sub == 'f') ? 4 : 0;
-          if (!sz || cnt < 0) bad = XE_AUX; else p += 5 + cnt * sz;
-          break; }
-        default: bad = XE_AUX;
-      }
-      if (bad) break;
-      if (t0 == 'N' && t1 == 'M' && !has_nm) { if (!isint) bad = XE_TAGTYPE; has_nm = true; nm_tag = (int32_t)val; if (!fits_i32(val)) bad = XE_RANGE; }
-      else if (t0 == 'H' && t1 == 'P' && !has_hp) { if (!isint) bad = XE_TAGTYPE; has_hp = true; if (val < 0 || val > 2) bad = bad ? bad : XE_HP; hp = (int)val; }
-      else if (t0 == 'P' && t1 == 'S' && !has_ps) { if (!isint) bad = XE_TAGTYPE; has_ps = true; ps = val; }
-      else if (t0 == 'S' && t1 == 'A' && sa_off < 0) { if (ty != 'Z') bad = XE_TAGTYPE; sa_off = zs; }
-    }
-    if (!bad && p > aux1) bad = XE_AUX;
-    if (bad) { if (lane == 0) x_error(v, rec, bad); return; }
+    x_wave_sync<WAVE>();     // the LDS copy is complete
+    TagSum t;
+    x_parse_tags<WAVE>(A, aux_len, lane, t);
+    if (t.bad) { if (lane == 0) x_error(v, rec, t.bad); return; }
+    sa_rel = t.sa_rel; sa_len = t.sa_len; ps = t.ps; nm_tag = t.nm_tag; hp = t.hp; has_nm = t.has_nm; has_ps = t.has_ps;
+    if (sa_rel >= 0) SAs = A + sa_rel;
   } else {
-    sa_off = S.sa_off; ps = S.ps; nm_tag = S.nm_tag; hp = S.hp; has_nm = S.has_nm; has_ps = S.has_ps;
+    sa_rel = sa_rel_in; sa_len = sa_len_in; ps = sv.ps; nm_tag = sv.nm_tag; hp = sv.hp; has_nm = sv.has_nm; has_ps = sv.has_ps;
   }
+  XT(1)
+  const bool has_sa = sa_rel >= 0;
   const bool supp = (flag & 0x800) != 0, rev = (flag & 0x10) != 0;
-  const bool use_clips = cfg.detect_large_ins && !supp && sa_off < 0;
+  const bool use_clips = cfg.detect_large_ins && !supp && !has_sa;
   const double half_long = (double)cfg.long_ins_length / 2.0;
   int32_t ps_rank = v.ps_null_rank;
   int64_t lead_base = 0, seq_base = 0; uint32_t read_id = 0, qname = 0; double nm = -1.0;
@@ -449,22 +634,18 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     }
     lead_base = v.lead_off[rec]; seq_base = v.seq_off[rec];
     read_id = v.read_id_offset + (uint32_t)v.read_idx[rec] + 1;
-    qname = v.qname_rank[rec]; nm = S.nm;
+    qname = v.qname_rank[rec]; nm = sv.nm;
   }
-  // ---- read_iterindels: 256 CIGAR operations per step (4 consecutive operations per lane), next step prefetched
-  constexpr int OPL = WAVE ? 4 : 1;
-  const int STEP = W * OPL;
+  // ---- read_iterindels: 256 CIGAR operations per step (4 consecutive operations per lane), two steps requested ahead
   uint32_t pr = 0, pf = (uint32_t)pos;
   int32_t lead_k = 0; int64_t seqb = 0; uint32_t large = 0; int bad_op = 0;
-  int base0 = 0, base1 = n_cig;
   int32_t w_lo = 0, w_hi = 0; uint32_t w_pr = 0, w_pf = 0;   // counting pass: the span of steps that produced leads
-  if (EMIT) { base0 = S.walk_lo; base1 = S.walk_hi; pr = S.walk_pr; pf = S.walk_pf; }
-  uint32_t cur[OPL], nxt[OPL];
-  if (base0 < base1) x_load_ops<WAVE>(cig, n_cig, base0, lane, cur);
+  if (EMIT) { pr = sv.walk_pr; pf = sv.walk_pf; }
   for (int base = base0; base < base1; base += STEP) {
 #pragma unroll
-    for (int j = 0; j < OPL; j++) nxt[j] = 6u;
-    if (base + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + STEP, lane, nxt);
+    for (int j = 0; j < OPL; j++) nx2[j] = 6u;
+    if (WAVE) { if (base + 2 * STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + 2 * STEP, lane, nx2); }
+    else if (base + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + STEP, lane, nx1);
     uint32_t aq_l = 0, ar_l = 0;
 #pragma unroll
     for (int j = 0; j < OPL; j++) {
@@ -549,14 +730,14 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     }
     pr += x_bcast<WAVE>(iq, W - 1); pf += x_bcast<WAVE>(ir, W - 1);
 #pragma unroll
-    for (int j = 0; j < OPL; j++) cur[j] = nxt[j];
+    for (int j = 0; j < OPL; j++) { cur[j] = nx1[j]; if (WAVE) nx1[j] = nx2[j]; }
   }
   if (!EMIT && x_ballot<WAVE>(bad_op != 0)) {
     const uint64_t b2 = x_ballot<WAVE>(bad_op == 2);
     if (lane == 0) x_error(v, rec, b2 ? XE_NOSEQ : XE_CIGAROP);
     return;
   }
-  const int32_t ref_end = EMIT ? S.ref_end : (pf == (uint32_t)pos ? pos + 1 : (int32_t)pf);
+  const int32_t ref_end = EMIT ? sv.ref_end : (pf == (uint32_t)pos ? pos + 1 : (int32_t)pf);
   if (!EMIT) {
     const uint32_t il = x_incl_scan<WAVE>(large, lane);
     const uint32_t large_sum = x_bcast<WAVE>(il, W - 1);
@@ -565,17 +746,143 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     const int64_t ri = v.read_idx[rec];
     v.o_rstart[ri] = pos; v.o_rend[ri] = ref_end; v.o_rhp[ri] = (uint8_t)hp;
   }
-  // ---- supplementary alignments: Lead.for_bnd, read_itersplits (sequential, lane 0; segment table in LDS)
-  int n_seg = 0, n_raw = 0;
-  if (sa_off >= 0 && lane == 0) {
-    const uint8_t* B = v.blob;
+  // ---- supplementary alignments: Lead.for_bnd, read_itersplits
+  // Part A turns the SA string into the break-end lead of its first element and the segment table of classify_splits; part B
+  // (lane 0: a handful of segments) classifies and emits.  Wave form of part A: the string is cut into its elements by the whole
+  // wave (a byte per lane: ballots give every non-empty element its number, its first byte and its terminator), then EVERY
+  // ELEMENT IS PARSED BY A LANE OF ITS OWN - the checks of the reference's loop are evaluated per element and the first element
+  // that fails decides, as the loop's `break` does.  (Lane 0 walking the string byte by byte, three times over, took 35 us per
+  // element - 330 us for a read with nine - and a pass over 24 000 records was as long as its slowest record.)
+  int n_seg = 0, n_raw = 0, err = 0;
+  if (EMIT && has_sa) x_wave_sync<WAVE>();   // the LDS copy of the SA string is complete
+#ifdef SNF_XTRACE
+  const unsigned long long xt_sa0 = wall_clock64();
+#endif
+  // for_bnd: side of the break from the first / last CIGAR operation
+  const int64_t clip_l = ((c_first & 15) == 4 || (c_first & 15) == 5) ? (c_first >> 4) : 0, clip_r = ((c_last & 15) == 4 || (c_last & 15) == 5) ? (c_last >> 4) : 0;
+  const bool is_first = !(clip_l > clip_r);
+  const int32_t b_start = is_first ? ref_end : pos + 1;
+  auto primary_seg = [&]() {
+    Seg& s0 = segs[0];
+    s0.contig = v.region_rank; s0.rs = pos; s0.re = ref_end; s0.qs = rev ? l_seq - q1 : q0; s0.qe = s0.qs + qal; s0.mapq = mapq;
+    s0.rev = rev; s0.source = SNF_SRC_SPLIT_PRIM; s0.seq_n = -1; s0.job_dst = -1; s0.hint_type = -1;
+  };
+  auto bnd_lead = [&](int32_t mc, int64_t mate, bool mate_rev, int64_t s_nm) {
+    if (EMIT) {
+      LeadRow r{};
+      r.ref_start = r.ref_end = b_start; r.qry_start = q0; r.qry_end = q1; r.svlen = 0; r.read_len = 0; r.ps = SNF_PS_NONE;
+      r.mate_contig = mc; r.mate_pos = (int32_t)mate; r.seq_len = SNF_SEQ_NONE;
+      r.nm = has_nm ? (double)s_nm : __builtin_nan("");
+      r.svtype = SNF_BND; r.strand = rev; r.mapq = (uint8_t)mapq; r.source = SNF_SRC_BND_SA; r.hap = 0; r.is_sa = 0;
+      r.first = is_first; r.rev = mate_rev;
+      put_lead(v, lead_base + lead_k, r, qname, read_id);
+    }
+    lead_k++;
+  };
+  bool part_a_done = false;
+#if XDEV
+  if (WAVE && has_sa) {
+    part_a_done = true;
+    const uint8_t* B = SAs;
+    // -- the elements: first byte and terminator of every non-empty one (the NUL at sa_len ends the last like a ';')
+    int32_t ns = 0, ne = 0;
+    for (int32_t c0 = 0; c0 <= sa_len; c0 += 64) {
+      const int32_t p = c0 + lane;
+      const bool in = p <= sa_len;
+      const uint8_t ch = (in && p < sa_len) ? B[p] : (uint8_t)';';
+      const uint8_t pv = (in && p >= 1) ? B[p - 1] : (uint8_t)';';
+      const bool st = in && ch != ';' && pv == ';', en = in && ch == ';' && pv != ';';
+      const uint64_t ms = __ballot(st), me = __ballot(en), below = (1ull << lane) - 1ull;
+      if (st) { const int e = ns + x_popc(ms & below); if (e < XMAXSEG) sab[e] = p; }
+      if (en) { const int e = ne + x_popc(me & below); if (e < XMAXSEG) sab[XMAXSEG + e] = p; }
+      ns += x_popc(ms); ne += x_popc(me);
+    }
+    const int n_el = ns;
+    x_wave_sync<WAVE>();
+    // -- element `lane`: its fields, parsed
+    const bool mine = lane < n_el;
+    int nf = 0; bool strand_ok = false, srev = false, pos_ok = false, mq_ok = false, nm_ok = false, cig_ok = false;
+    int64_t s_pos = 0, s_mq = 0, s_nm = 0, cl0 = 0, cl1 = 0, rfs = 0, rds = 0; int32_t mc = -1;
+    if (mine) {
+      const int32_t ea = sab[lane], eb = sab[XMAXSEG + lane];
+      int32_t cm[5] = {eb, eb, eb, eb, eb}; int nc = 0;
+      for (int32_t k0 = ea; k0 < eb; k0 += 8) {
+        const uint64_t w = x_ld8(B + k0), x = w ^ 0x2c2c2c2c2c2c2c2cull;
+        uint64_t z = ~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x | 0x7f7f7f7f7f7f7f7full);   // 0x80 in every ',' byte
+        if (eb - k0 < 8) z &= (1ull << (8 * (eb - k0))) - 1ull;
+        for (; z; z &= z - 1ull) {
+          const int32_t at = k0 + (x_ctz(z) >> 3);
+#pragma unroll
+          for (int q = 0; q < 5; q++) if (nc == q) cm[q] = at;
+          nc++;
+        }
+      }
+      nf = nc + 1;
+      if (nf == 6) {
+        const uint8_t sc = B[cm[1] + 1];
+        strand_ok = cm[2] - (cm[1] + 1) == 1 && (sc == '+' || sc == '-'); srev = sc == '-';
+        mq_ok = sa_int(B, cm[3] + 1, cm[4], &s_mq);
+        cig_ok = sa_cigar(B, cm[2] + 1, cm[3], &cl0, &cl1, &rfs, &rds);
+        pos_ok = sa_int(B, cm[0] + 1, cm[1], &s_pos);
+        mc = sa_contig(v, B, ea, cm[0]);
+        if (lane == 0 && has_nm) nm_ok = sa_int(B, cm[4] + 1, eb, &s_nm);
+      }
+    }
+    // -- Lead.for_bnd: the first element
+    if (lane == 0 && n_el >= 1) {
+      if (nf != 6) err = XE_SA_FIELDS;
+      else if (!strand_ok) err = XE_SA_STRAND;
+      else if (srev != rev) {
+        if (!pos_ok) err = XE_SA_NUMBER;
+        else if (cig_ok) {
+          const bool mate_rev = cl1 > cl0;
+          const int64_t z = s_pos - 1, mate = mate_rev ? z + rfs : (is_first ? z + 1 : z + 2);
+          if (has_nm && !nm_ok) err = XE_SA_NUMBER;
+          else if (mc < 0) err = XE_SA_CONTIG;
+          else if (!fits_i32(mate)) err = XE_RANGE;
+          else if (b_start >= v.region_start && b_start < v.region_end) bnd_lead(mc, mate, mate_rev, s_nm);
+        }
+      }
+    }
+    // -- read_itersplits: primary alignments only; every element a segment
+    const bool stop = x_bcast<WAVE>((uint32_t)err, 0) != 0 || supp;
+    if (!stop && !((double)n_el > (double)cfg.max_splits_base + cfg.max_splits_kb * ((double)l_seq / 1000.0))) {
+      if (n_el + 1 > XMAXSEG) err = XE_SPLITS;
+      else {
+        int st = 0;   // this element in the order the reference's loop checks it: an error code, -1 = the read's splits are dropped
+        int64_t z = 0, sq = 0;
+        if (mine) {
+          z = s_pos - 1; sq = srev ? cl1 : cl0;
+          if (nf != 6) st = XE_SA_FIELDS;
+          else if (!mq_ok) st = XE_SA_NUMBER;
+          else if (!strand_ok) st = XE_SA_STRAND;
+          else if (!cig_ok) st = -1;
+          else if (!pos_ok) st = XE_SA_NUMBER;
+          else if (mc < 0) st = XE_SA_CONTIG;
+          else if (!fits_i32(z + rfs) || !fits_i32(sq + rds) || s_mq < 0 || s_mq > 255) st = XE_RANGE;
+        }
+        const uint64_t bad = __ballot(st != 0);
+        if (bad) {   // the first element that fails ends the loop: an error, or no splits for this read
+          const int st1 = (int)x_bcast<WAVE>((uint32_t)st, x_ctz(bad));
+          if (st1 > 0) err = st1;
+        } else {
+          if (lane == 0) primary_seg();
+          if (mine) {
+            Seg& sg = segs[1 + lane];
+            sg.contig = mc; sg.rs = (int32_t)z; sg.re = (int32_t)(z + rfs); sg.qs = (int32_t)sq; sg.qe = (int32_t)(sq + rds); sg.mapq = (int32_t)s_mq;
+            sg.rev = srev; sg.source = SNF_SRC_SPLIT_SUP; sg.seq_n = -1; sg.job_dst = -1; sg.hint_type = -1;
+          }
+          n_seg = n_el + 1;
+        }
+      }
+    }
+    x_wave_sync<WAVE>();
+  }
+#endif
+  if (!part_a_done && has_sa && lane == 0) {   // thread form: the reference's loops as they are
+    const uint8_t* B = SAs;
     SaElem e;
-    // for_bnd: side of the break from the first / last CIGAR operation
-    const uint32_t c0 = ld_u32(cig), c1 = ld_u32(cig + 4 * (int64_t)(n_cig - 1));
-    const int64_t left = ((c0 & 15) == 4 || (c0 & 15) == 5) ? (c0 >> 4) : 0, right = ((c1 & 15) == 4 || (c1 & 15) == 5) ? (c1 >> 4) : 0;
-    const bool is_first = !(left > right);
-    const int32_t b_start = is_first ? ref_end : pos + 1;
-    int64_t p = sa_off; int err = 0;
+    int32_t p = 0;
     if (sa_next(B, &p, &e)) {
       int64_t s_pos = 0, s_nm = 0, cl0, cl1, rfs, rds;
       if (e.nf != 6) err = XE_SA_FIELDS;
@@ -589,32 +896,19 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
           if (has_nm && !sa_int(B, e.f0[5], e.f1[5], &s_nm)) err = XE_SA_NUMBER;
           else if (mc < 0) err = XE_SA_CONTIG;
           else if (!fits_i32(mate)) err = XE_RANGE;
-          else if (b_start >= v.region_start && b_start < v.region_end) {
-            if (EMIT) {
-              LeadRow r{};
-              r.ref_start = r.ref_end = b_start; r.qry_start = q0; r.qry_end = q1; r.svlen = 0; r.read_len = 0; r.ps = SNF_PS_NONE;
-              r.mate_contig = mc; r.mate_pos = (int32_t)mate; r.seq_len = SNF_SEQ_NONE;
-              r.nm = has_nm ? (double)s_nm : __builtin_nan("");
-              r.svtype = SNF_BND; r.strand = rev; r.mapq = (uint8_t)mapq; r.source = SNF_SRC_BND_SA; r.hap = 0; r.is_sa = 0;
-              r.first = is_first; r.rev = mate_rev;
-              put_lead(v, lead_base + lead_k, r, qname, read_id);
-            }
-            lead_k++;
-          }
+          else if (b_start >= v.region_start && b_start < v.region_end) bnd_lead(mc, mate, mate_rev, s_nm);
         }
       }
     }
     // read_itersplits: primary alignments only
     if (!err && !supp) {
-      int n_el = 0; p = sa_off;
+      int n_el = 0; p = 0;
       while (sa_next(B, &p, &e)) n_el++;
       if (!((double)n_el > (double)cfg.max_splits_base + cfg.max_splits_kb * ((double)l_seq / 1000.0))) {
         if (n_el + 1 > XMAXSEG) err = XE_SPLITS;
         else {
-          Seg& s0 = segs[0];
-          s0.contig = v.region_rank; s0.rs = pos; s0.re = ref_end; s0.qs = rev ? l_seq - q1 : q0; s0.qe = s0.qs + qal; s0.mapq = mapq;
-          s0.rev = rev; s0.source = SNF_SRC_SPLIT_PRIM; s0.seq_n = -1; s0.job_dst = -1; s0.hint_type = -1;
-          n_seg = 1; p = sa_off; bool drop = false;
+          primary_seg();
+          n_seg = 1; p = 0; bool drop = false;
           while (!err && !drop && sa_next(B, &p, &e)) {
             int64_t s_pos = 0, s_mq = 0, cl0, cl1, rfs, rds;
             if (e.nf != 6) { err = XE_SA_FIELDS; break; }
@@ -633,44 +927,48 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
             n_seg++;
           }
           if (err || drop) n_seg = 0;
-          if (n_seg) {
-            for (int i = 0; i < n_seg; i++) ord[i] = (uint8_t)i;
-            n_raw = n_seg;
-            n_seg = classify(v, segs, ord, n_seg, l_seq, rec);
-            for (int i = 0; i < n_seg; i++) {
-              Seg& s = segs[ord[i]];
-              if (s.hint_type < 0) continue;
-              const int32_t pm = segs[ord[i > 0 ? i - 1 : 0]].mapq;
-              if (!cfg.dev_keep_lowqual_splits && (s.mapq < pm ? s.mapq : pm) < cfg.mapq) continue;
-              if (s.contig != v.region_rank || s.hint_start < v.region_start || s.hint_start >= v.region_end) continue;
-              const bool ins = s.hint_type == SNF_INS;
-              const int32_t sl = (ins && s.seq_n >= 0) ? s.seq_n : -1;
-              if (EMIT) {
-                LeadRow r{};
-                r.ref_start = s.hint_start;
-                r.ref_end = (s.hint_len != SNF_SVLEN_NONE && !ins) ? s.hint_start + s.hint_len : s.hint_start;
-                r.qry_start = s.qs; r.qry_end = s.qe; r.svlen = s.hint_len; r.read_len = 0; r.ps = ps_rank; r.mate_contig = 0;
-                r.seq_len = sl; r.seq_off = sl >= 0 ? seq_base + seqb : 0; r.nm = nm;
-                r.svtype = (uint8_t)s.hint_type; r.strand = s.rev; r.mapq = (uint8_t)s.mapq; r.source = s.source; r.hap = (uint8_t)hp; r.is_sa = supp;
-                put_lead(v, lead_base + lead_k, r, qname, read_id);
-                if (sl > 0) s.job_dst = seq_base + seqb;
-              }
-              lead_k++;
-              if (sl > 0) seqb += sl;
-            }
-          }
         }
+      }
+    }
+  }
+  // part B (lane 0): classify_splits over the segment table, the leads of the hints
+  if (has_sa && lane == 0) {
+    if (!err && n_seg) {
+      for (int i = 0; i < n_seg; i++) ord[i] = (uint8_t)i;
+      n_raw = n_seg;
+      n_seg = classify(v, segs, ord, n_seg, l_seq, rec);
+      for (int i = 0; i < n_seg; i++) {
+        Seg& s = segs[ord[i]];
+        if (s.hint_type < 0) continue;
+        const int32_t pm = segs[ord[i > 0 ? i - 1 : 0]].mapq;
+        if (!cfg.dev_keep_lowqual_splits && (s.mapq < pm ? s.mapq : pm) < cfg.mapq) continue;
+        if (s.contig != v.region_rank || s.hint_start < v.region_start || s.hint_start >= v.region_end) continue;
+        const bool ins = s.hint_type == SNF_INS;
+        const int32_t sl = (ins && s.seq_n >= 0) ? s.seq_n : -1;
+        if (EMIT) {
+          LeadRow r{};
+          r.ref_start = s.hint_start;
+          r.ref_end = (s.hint_len != SNF_SVLEN_NONE && !ins) ? s.hint_start + s.hint_len : s.hint_start;
+          r.qry_start = s.qs; r.qry_end = s.qe; r.svlen = s.hint_len; r.read_len = 0; r.ps = ps_rank; r.mate_contig = 0;
+          r.seq_len = sl; r.seq_off = sl >= 0 ? seq_base + seqb : 0; r.nm = nm;
+          r.svtype = (uint8_t)s.hint_type; r.strand = s.rev; r.mapq = (uint8_t)s.mapq; r.source = s.source; r.hap = (uint8_t)hp; r.is_sa = supp;
+          put_lead(v, lead_base + lead_k, r, qname, read_id);
+          if (sl > 0) s.job_dst = seq_base + seqb;
+        }
+        lead_k++;
+        if (sl > 0) seqb += sl;
       }
     }
     if (err) { x_error(v, rec, err); n_raw = 0; lead_k = -1; }
   }
+  XT_ADD(2, xt_sa0)
   if (!EMIT) {
     if (lane == 0 && lead_k >= 0) {
-      S.accept = 1; S.n_leads = lead_k; S.seq_bytes = seqb; S.has_nm = has_nm; S.has_ps = has_ps; S.nm = nm; S.sa_off = sa_off;
+      S.accept = 1; S.n_leads = lead_k; S.seq_bytes = seqb; S.has_nm = has_nm; S.has_ps = has_ps; S.nm = nm; S.sa_rel = sa_rel; S.sa_len = sa_len;
       S.hp = (uint8_t)hp; S.ps = ps; S.nm_tag = nm_tag; S.ref_end = ref_end;
       S.walk_lo = w_lo; S.walk_hi = w_hi; S.walk_pr = w_pr; S.walk_pf = w_pf;
     }
-  } else if (sa_off >= 0 && !supp) {
+  } else if (has_sa && !supp) {
     // sequence of split-read insertions: lane 0 left the copy jobs in the segment table
     x_wave_sync<WAVE>();
     n_raw = (int)x_bcast<WAVE>((uint32_t)n_raw, 0);
@@ -680,10 +978,11 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     }
     x_wave_sync<WAVE>();
   }
+  XT_FLUSH();
 }
 
-SNF_HD void x_count_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, false>(i, v, segs, ord); }
-SNF_HD void x_emit_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, true>(i, v, segs, ord); }
+SNF_HD void x_count_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, false>(i, v, segs, ord, nullptr, nullptr); }
+SNF_HD void x_emit_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t ord[XMAXSEG]; extract_record<false, true>(i, v, segs, ord, nullptr, nullptr); }
 SNF_HD void x_prep_body(int64_t i, const ExView& v) {
   const bool a = i < v.n_records && v.sum[i].accept;
   v.c_acc[i] = a ? 1 : 0; v.c_leads[i] = a ? v.sum[i].n_leads : 0; v.c_seq[i] = a ? v.sum[i].seq_bytes : 0;
@@ -699,18 +998,24 @@ SNF_KERNEL(x_prep, ExView)
 // than a plain one (lane-0 section), and in a four-wave workgroup the three finished waves' slots stayed taken until the
 // slow one was done - with SA tags on 20 % of the records most workgroups had one.  Grid-stride so that any record count
 // fits one launch.
-template <bool EMIT>
-__global__ void __launch_bounds__(64) x_wave(const ExView v, int64_t n) {
+// MINW: waves per SIMD the register allocation leaves room for (what it costs in registers is spilled - the lane-0 SA section
+// takes most of it); SNF_EXTRACT_WAVES selects the instance
+template <bool EMIT, int MINW>
+__global__ void __launch_bounds__(64, MINW) x_wave(const ExView v, int64_t n) {
   __shared__ Seg segs[XMAXSEG];
   __shared__ uint8_t ord[XMAXSEG];
+  __shared__ alignas(16) uint8_t auxl[XAUXCAP + 16];   // (reads of up to 15 bytes past the last copied byte stay inside)
+  __shared__ int32_t sab[2 * XMAXSEG];                 // first byte / terminator of the SA string's elements
   for (int64_t rec = (int64_t)blockIdx.x; rec < n; rec += (int64_t)gridDim.x)
-    extract_record<true, EMIT>(rec, v, segs, ord);
+    extract_record<true, EMIT>(rec, v, segs, ord, auxl, sab);
 }
 // average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64
-// adds.  One wave: 64 records are loaded per step (coalesced), records without an NM ratio contribute +0.0 (the sum
-// is never -0.0, so that add is the identity) and the 64 values are folded in lane order by constant-lane reads -
-// a chain of 64 dependent adds per step with nothing else on it; the next step's loads are issued before the fold.
+// adds.  One wave: 64 records are loaded per step (coalesced) and laid out in LDS, records without an NM ratio as +0.0 (the
+// sum is never -0.0, so that add is the identity); the 64 values are then folded in order - a chain of 64 dependent adds per
+// step whose operands are LDS reads at constant addresses (issued ahead of the chain; every lane folds the same values).
+// The next step's loads are in flight meanwhile.
 __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
+  __shared__ double buf[2][64];
   const int lane = threadIdx.x;
   double sum = 0.0; int64_t cnt = 0;
   const bool adv = v.cfg.advanced_tags != 0;
@@ -720,13 +1025,15 @@ __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
   };
   bool f = false, fn = false;
   double x = load(lane, f);
+  int cur = 0;
   for (int64_t base = 0; base < n; base += 64) {
     const double xn = load(base + 64 + lane, fn);
+    buf[cur][lane] = x;
+    x_wave_sync<true>();
     cnt += __popcll(__ballot(f));
 #pragma unroll
-    for (int k = 0; k < 64; k++)
-      sum += __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), k), __builtin_amdgcn_readlane(__double2loint(x), k));
-    x = xn; f = fn;
+    for (int k = 0; k < 64; k++) sum += buf[cur][k];
+    x = xn; f = fn; cur ^= 1;
   }
   if (lane == 0) { v.nm_out[0] = sum; v.nm_out[1] = (double)cnt; }
 }
@@ -788,6 +1095,14 @@ int64_t* x_exscan(std::vector<void*>& pool, const int64_t* in, int64_t n) {   //
 
 // rank of str(value) among the distinct phase sets plus the literal "NULL" (Python str order)
 bool ps_str_less(int64_t a, int64_t b) { return std::to_string(a) < std::to_string(b); }
+
+#define X_WAVES_DEFAULT 4
+template <bool EMIT> void x_launch_wave(int waves, unsigned grid, const ExView& v, int64_t n) {
+  if (waves >= 8) hipLaunchKernelGGL((x_wave<EMIT, 8>), dim3(grid), dim3(64), 0, 0, v, n);
+  else if (waves >= 6) hipLaunchKernelGGL((x_wave<EMIT, 6>), dim3(grid), dim3(64), 0, 0, v, n);
+  else if (waves == 5) hipLaunchKernelGGL((x_wave<EMIT, 5>), dim3(grid), dim3(64), 0, 0, v, n);
+  else hipLaunchKernelGGL((x_wave<EMIT, 4>), dim3(grid), dim3(64), 0, 0, v, n);
+}
 
 int do_upload(snf_extract* x, const snf_extract_input_t* in) {
   if (!in || in->n_records < 0 || (in->n_records && (!in->records || !in->rec_off || !in->qname_rank))) snf::fail("extract input: null pointer");
@@ -874,8 +1189,14 @@ int do_run(snf_extract* x) {
   v.nm_out = x_alloc<double>(P, 2);
   const unsigned long long none = ~0ull;
   x_h2d(v.err, &none, 8);
+#ifdef SNF_XTRACE
+  v.xtrace = x_alloc<uint32_t>(P, (size_t)n * 4);
+  SNF_HIP(hipMemset(v.xtrace, 0, (size_t)(n ? n : 1) * 16));
+  v.xtrace_emit = getenv("SNF_XTRACE_PASS") && !strcmp(getenv("SNF_XTRACE_PASS"), "emit");
+#endif
   float ms_count = 0, ms_emit = 0;
   const bool thread_form = getenv("SNF_EXTRACT_THREAD") != nullptr;
+  const int waves = getenv("SNF_EXTRACT_WAVES") ? atoi(getenv("SNF_EXTRACT_WAVES")) : X_WAVES_DEFAULT;
   hipEvent_t e0, e1, e2, e3;
   SNF_HIP(hipEventCreate(&e0)); SNF_HIP(hipEventCreate(&e1)); SNF_HIP(hipEventCreate(&e2)); SNF_HIP(hipEventCreate(&e3));
   const unsigned grid_w = (unsigned)std::min<int64_t>(n > 0 ? n : 1, 1 << 22);
@@ -883,7 +1204,7 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipEventRecord(e0, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
-    else hipLaunchKernelGGL(x_wave<false>, dim3(grid_w), dim3(64), 0, 0, v, n);
+    else x_launch_wave<false>(waves, grid_w, v, n);
   }
   SNF_HIP(hipEventRecord(e1, 0));
   hipLaunchKernelGGL(x_prep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, v, n + 1);
@@ -924,7 +1245,7 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipEventRecord(e2, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
-    else hipLaunchKernelGGL(x_wave<true>, dim3(grid_w), dim3(64), 0, 0, v, n);
+    else x_launch_wave<true>(waves, grid_w, v, n);
   }
   SNF_HIP(hipEventRecord(e3, 0));
   SNF_HIP(hipStreamSynchronize(x->side));
@@ -932,6 +1253,13 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
   x_d2h(nmv, v.nm_out, 16);
+#ifdef SNF_XTRACE
+  if (const char* path = getenv("SNF_XTRACE_OUT")) {
+    std::vector<uint32_t> t((size_t)n * 4);
+    x_d2h(t.data(), v.xtrace, (size_t)n * 16);
+    if (FILE* f = fopen(path, "wb")) { fwrite(t.data(), 16, (size_t)n, f); fclose(f); }
+  }
+#endif
   x->n_leads = n_leads; x->n_seq = n_seq; x->n_reads = n_reads; x->pulled = false;
   snf_extract_result_t& r = x->res;
   const int64_t ab = r.algo_bytes;

@@ -27,10 +27,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu-reads", type=int, default=150)
     ap.add_argument("--sa-frac", type=float, default=0.2)
+    ap.add_argument("--no-tags", action="store_true", help="records without auxiliary fields (what the tag walk and the SA parser cost)")
+    ap.add_argument("--read-len", type=int, default=20000)
     a = ap.parse_args()
     from sniffles_amd import bam, extract, synth_bam
     t0 = time.time()
-    names, lens, recs = synth_bam.gen_records(2026, a.reads, style="ont", read_len_mean=20000, sa_frac=a.sa_frac,
+    names, lens, recs = synth_bam.gen_records(2026, a.reads, style="ont", read_len_mean=a.read_len, sa_frac=a.sa_frac, with_tags=not a.no_tags,
                                               ref_lens=(60_000_000, 300000, 300000, 100000))
     gen_s = time.time() - t0
     R = bam.records_from_list(names, lens, recs * a.tile)

@@ -195,4 +195,74 @@ for spec in "plain:" "symbolic:SNF_BENCH_CFG={\"symbolic\":true}" "no_consensus:
   done
 done 2>&1 | tee gpurun_out/ab_r06_7.log
   ;;
+16)
+# round 6, sixteenth session: the extraction kernels rebuilt around the record's chain of dependent accesses (fixed fields as one load,
+# clip operations + auxiliary region into LDS + two CIGAR steps in one round trip, tags as one 8-byte read each, the SA parser on the LDS
+# copy): GPU tests of the extraction, then the same-box A/B against the library built from the sources before (variants/x_base.so)
+# at four register budgets (SNF_EXTRACT_WAVES)
+timeout 900 python -m pytest tests/test_extract_gpu.py tests/test_extract.py -m gpu -x -q > gpurun_out/pytest_gpu_16.log 2>&1; tail -3 gpurun_out/pytest_gpu_16.log
+xb() { python tools/bench_extract.py --steps 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3), 'frac', round(d['roofline']['count_pass']['frac'],4), round(d['roofline']['emit_pass']['frac'],4), 'leads', d['signatures'])"; }
+for k in 1 2; do
+  SNF_LIB_SO=$R/variants/x_base.so xb base
+  for w in 4 5 6 8; do SNF_EXTRACT_WAVES=$w xb new_w$w; done
+done 2>&1 | tee gpurun_out/ab_r06_8.log
+SNF_EXTRACT_THREAD=1 xb thread_form | tee -a gpurun_out/ab_r06_8.log
+  ;;
+17)
+# round 6, seventeenth session: what bounds the extraction passes - SQ counters of x_wave, and the same passes without SA tags, without
+# any tag, on a table twice as long, on short reads
+xb() { tag=$1; shift; python tools/bench_extract.py --steps 6 --cpu-reads 3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'algo MB', round(d['algo_bytes']/1e6,1), 'records', d['records'], 'accepted', d['reads_accepted'], 'leads', d['signatures'])"; }
+{
+xb new_default
+xb new_sa0 --sa-frac 0
+xb new_notags --no-tags --sa-frac 0
+xb new_tile16 --tile 16
+xb new_short --read-len 3000 --reads 12000
+SNF_LIB_SO=$R/variants/x_base.so xb base_sa0 --sa-frac 0
+SNF_LIB_SO=$R/variants/x_base.so xb base_notags --no-tags --sa-frac 0
+} 2>&1 | tee gpurun_out/ab_r06_9.log
+i=0
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1)); rm -rf gpurun_out/sqx_$i; mkdir -p gpurun_out/sqx_$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/sqx_$i -o sq -- python tools/bench_extract.py --steps 2 --cpu-reads 3 > gpurun_out/sqx_$i/bench.log 2>&1
+done
+python tools/sq_parse.py gpurun_out/sqx_1 gpurun_out/sqx_2 gpurun_out/sqx_3 | tee gpurun_out/sqx_summary.txt
+find gpurun_out/sqx_* -name '*.csv' -size +1M -delete
+  ;;
+18)
+# round 6, eighteenth session: the SA element in registers (it lived in scratch memory: the lane-0 parser waited a memory round trip per field)
+xb() { tag=$1; shift; python tools/bench_extract.py --steps 6 --cpu-reads 3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3), 'algo MB', round(d['algo_bytes']/1e6,1), 'records', d['records'], 'leads', d['signatures'])"; }
+{
+timeout 600 python -m pytest tests/test_extract_gpu.py -m gpu -x -q 2>&1 | tail -1
+for k in 1 2; do
+xb new_default
+SNF_LIB_SO=$R/variants/x_base.so xb base_default
+done
+for w in 5 6 8; do SNF_EXTRACT_WAVES=$w xb new_w$w; done
+xb new_sa0 --sa-frac 0
+xb new_sa50 --sa-frac 0.5
+xb new_tile16 --tile 16
+xb new_tile32 --tile 32
+} 2>&1 | tee gpurun_out/ab_r06_10.log
+  ;;
+19)
+# round 6, nineteenth session: the SA string parsed by the wave (a lane per element) - GPU tests, per-record stamps, same-box A/B
+xb() { tag=$1; shift; python tools/bench_extract.py --steps 6 --cpu-reads 3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3), 'algo MB', round(d['algo_bytes']/1e6,1), 'records', d['records'], 'leads', d['signatures'])"; }
+{
+timeout 600 python -m pytest tests/test_extract_gpu.py tests/test_extract.py -m gpu -x -q 2>&1 | tail -1
+SNF_LIB_SO=$R/variants/xtrace.so python tools/xtrace.py --pass count 2>&1 | grep -v "in flight at some"
+SNF_LIB_SO=$R/variants/xtrace.so python tools/xtrace.py --pass emit 2>&1 | grep -v "in flight at some"
+for k in 1 2; do
+xb new_default
+SNF_LIB_SO=$R/variants/x_base.so xb base_default
+done
+for w in 5 6; do SNF_EXTRACT_WAVES=$w xb new_w$w; done
+xb new_sa0 --sa-frac 0
+xb new_sa50 --sa-frac 0.5
+xb new_tile32 --tile 32
+SNF_LIB_SO=$R/variants/x_base.so xb base_tile32 --tile 32
+} 2>&1 | tee gpurun_out/ab_r06_11.log
+  ;;
 esac

@@ -6,7 +6,7 @@ def short(n):
         m = re.search(r"e45w_consensus<(\d)", n)
         n = {"1": "e45w_small", "2": "e45w_large", "4": "e45w_rows"}.get(m.group(1) if m else "", n)
     return n[:24]
-want = ("e45w", "d1w_refine", "d2w_call", "e1w_finalize", "e4c_copy", "d4_coverage", "c1_mergeruns", "a6k_scatter", "x_big")
+want = ("e45w", "d1w_refine", "d2w_call", "e1w_finalize", "e4c_copy", "d4_coverage", "c1_mergeruns", "a6k_scatter", "x_big", "x_wave", "x_nmsum")
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(set)
 for d in sys.argv[1:]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
