@@ -77,6 +77,8 @@ struct ExView {
   unsigned long long* err;   // min over (record << 8 | code); ~0: none
   // scan inputs / outputs (n_records + 1)
   int64_t *c_acc, *c_leads, *c_seq;
+  int64_t* c_ps; uint8_t* c_psf;      // per record: its PS tag and whether it counts (accepted, tag present) - what the host ranks
+  unsigned long long* tot;            // [0] first error (= err), [1..3] reads, leads, sequence bytes: one copy to the host
   const int64_t *read_idx, *lead_off, *seq_off;
   const int64_t* ps_val; const int32_t* ps_rank; int32_t n_ps, ps_null_rank;
   // lead columns
@@ -166,6 +168,7 @@ template <bool WAVE> SNF_HD uint32_t x_uni(uint32_t x) {
 #endif
   return x;
 }
+template <bool WAVE> SNF_HD uint64_t x_uni64(uint64_t x) { return ((uint64_t)x_uni<WAVE>((uint32_t)(x >> 32)) << 32) | x_uni<WAVE>((uint32_t)x); }
 SNF_HD int x_popc(uint64_t m) { return __builtin_popcountll(m); }
 SNF_HD int x_ctz(uint64_t m) { return __builtin_ctzll(m); }
 
@@ -437,7 +440,9 @@ template <bool WAVE> SNF_HD void x_parse_tags(const uint8_t* A, int32_t aux_len,
   bool has_hp = false; int bad = 0;
   int64_t p = 0;
   while (p + 3 <= aux_len && !bad) {
-    const uint64_t w = x_ld8(A + p);
+    // (every lane walks the same tags: with the word in scalar registers the walk is scalar code - branches on SCC instead of
+    // saved and restored execution masks, which is what the compiler makes of a `switch` on a value it must assume differs per lane)
+    const uint64_t w = x_uni64<WAVE>(x_ld8(A + p));
     const uint8_t t0 = (uint8_t)w, t1 = (uint8_t)(w >> 8), ty = (uint8_t)(w >> 16);
     const uint32_t pay = (uint32_t)(w >> 24);   // value bytes 0..3 (byte 4 of a B array's count is w >> 56)
     p += 3;
@@ -475,6 +480,9 @@ template <bool WAVE> SNF_HD void x_parse_tags(const uint8_t* A, int32_t aux_len,
 }
 
 // ---- one alignment record ----------------------------------------------------------------------------------------
+#ifndef X_AHEAD
+#define X_AHEAD 2      /* measured: 2 = 3 = 4 steps ahead (0.108 / 0.111 / 0.114 ms per counting pass); the walk is not what a pass waits for */
+#endif
 #define XAUXCAP 1024   // bytes of a record's auxiliary region (counting pass) / of its SA string (emit pass) the wave form keeps in LDS;
                        // a longer one (base-modification arrays ...) is parsed where it lies in the blob
 template <bool WAVE, bool EMIT>
@@ -535,16 +543,18 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     }
   }
 #endif
-  // (c) the first two steps of the CIGAR walk
+  // (c) the first steps of the CIGAR walk
   constexpr int OPL = WAVE ? 4 : 1;
   const int STEP = W * OPL;
   int base0 = 0, base1 = n_cig;
   if (EMIT) { base0 = sv.walk_lo; base1 = sv.walk_hi; }
-  uint32_t cur[OPL], nx1[OPL], nx2[OPL];
+  constexpr int XD = WAVE ? X_AHEAD : 1;      // steps requested ahead of the one that is worked on
+  uint32_t cur[OPL], nx[XD][OPL];
 #pragma unroll
-  for (int j = 0; j < OPL; j++) { cur[j] = 6u; nx1[j] = 6u; }
+  for (int j = 0; j < OPL; j++) { cur[j] = 6u; for (int d = 0; d < XD; d++) nx[d][j] = 6u; }
   if (base0 < base1) x_load_ops<WAVE>(cig, n_cig, base0, lane, cur);
-  if (WAVE && base0 + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base0 + STEP, lane, nx1);
+#pragma unroll
+  for (int d = 0; d + 1 < XD; d++) if (base0 + (d + 1) * STEP < base1) x_load_ops<WAVE>(cig, n_cig, base0 + (d + 1) * STEP, lane, nx[d]);
   // pysam getQueryStart / getQueryEnd
   int32_t q0 = 0, q1 = l_seq; bool clip_bad = false;
   uint32_t c_first, c_last;
@@ -636,16 +646,15 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     read_id = v.read_id_offset + (uint32_t)v.read_idx[rec] + 1;
     qname = v.qname_rank[rec]; nm = sv.nm;
   }
-  // ---- read_iterindels: 256 CIGAR operations per step (4 consecutive operations per lane), two steps requested ahead
+  // ---- read_iterindels: 256 CIGAR operations per step (4 consecutive operations per lane), X_AHEAD steps requested ahead
   uint32_t pr = 0, pf = (uint32_t)pos;
   int32_t lead_k = 0; int64_t seqb = 0; uint32_t large = 0; int bad_op = 0;
   int32_t w_lo = 0, w_hi = 0; uint32_t w_pr = 0, w_pf = 0;   // counting pass: the span of steps that produced leads
   if (EMIT) { pr = sv.walk_pr; pf = sv.walk_pf; }
   for (int base = base0; base < base1; base += STEP) {
 #pragma unroll
-    for (int j = 0; j < OPL; j++) nx2[j] = 6u;
-    if (WAVE) { if (base + 2 * STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + 2 * STEP, lane, nx2); }
-    else if (base + STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + STEP, lane, nx1);
+    for (int j = 0; j < OPL; j++) nx[XD - 1][j] = 6u;
+    if (base + XD * STEP < base1) x_load_ops<WAVE>(cig, n_cig, base + XD * STEP, lane, nx[XD - 1]);
     uint32_t aq_l = 0, ar_l = 0;
 #pragma unroll
     for (int j = 0; j < OPL; j++) {
@@ -730,7 +739,11 @@ SNF_HD void extract_record(int64_t rec, const ExView& v, Seg* segs, uint8_t* ord
     }
     pr += x_bcast<WAVE>(iq, W - 1); pf += x_bcast<WAVE>(ir, W - 1);
 #pragma unroll
-    for (int j = 0; j < OPL; j++) { cur[j] = nx1[j]; if (WAVE) nx1[j] = nx2[j]; }
+    for (int j = 0; j < OPL; j++) {
+      cur[j] = nx[0][j];
+#pragma unroll
+      for (int d = 0; d + 1 < XD; d++) nx[d][j] = nx[d + 1][j];
+    }
   }
   if (!EMIT && x_ballot<WAVE>(bad_op != 0)) {
     const uint64_t b2 = x_ballot<WAVE>(bad_op == 2);
@@ -986,6 +999,11 @@ SNF_HD void x_emit_body(int64_t i, const ExView& v) { Seg segs[XMAXSEG]; uint8_t
 SNF_HD void x_prep_body(int64_t i, const ExView& v) {
   const bool a = i < v.n_records && v.sum[i].accept;
   v.c_acc[i] = a ? 1 : 0; v.c_leads[i] = a ? v.sum[i].n_leads : 0; v.c_seq[i] = a ? v.sum[i].seq_bytes : 0;
+  if (i < v.n_records) { const bool p = a && v.sum[i].has_ps; v.c_psf[i] = p ? 1 : 0; v.c_ps[i] = p ? v.sum[i].ps : 0; }
+}
+SNF_HD void x_totals_body(int64_t i, const ExView& v) {
+  const int64_t n = v.n_records;
+  v.tot[1] = (unsigned long long)v.read_idx[n]; v.tot[2] = (unsigned long long)v.lead_off[n]; v.tot[3] = (unsigned long long)v.seq_off[n];
 }
 
 }  // namespace snf
@@ -993,6 +1011,7 @@ using namespace snf;
 SNF_KERNEL(x_count, ExView)
 SNF_KERNEL(x_emit, ExView)
 SNF_KERNEL(x_prep, ExView)
+SNF_KERNEL(x_totals, ExView)
 
 // one wave per record and ONE wave per workgroup: a record with split alignments keeps its wave several times longer
 // than a plain one (lane-0 section), and in a four-wave workgroup the three finished waves' slots stayed taken until the
@@ -1039,11 +1058,39 @@ __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
 }
 
 // ================================================================================================= host side ====
+// One grow-only device allocation carved into arrays.  (A run made some forty hipMalloc / hipFree calls - 0.5 ms of a 1.4-ms run;
+// repeated runs over tables of similar size now allocate nothing.)
+struct XSlab {
+  uint8_t* base = nullptr; size_t cap = 0, used = 0; bool measuring = false;
+  void measure() { measuring = true; used = 0; }
+  void reserve() {      // after a measuring pass: room for what it added up
+    const size_t need = used + 256;
+    if (need > cap) {
+      if (base) (void)hipFree(base);
+      base = nullptr; cap = 0;
+      const size_t want = need + need / 4;
+      void* p = nullptr;
+      if (hipMalloc(&p, want) != hipSuccess) snf::fail("hipMalloc failed (" + std::to_string(want) + " bytes)");
+      base = (uint8_t*)p; cap = want;
+    }
+    measuring = false; used = 0;
+  }
+  template <class T> T* take(size_t n, size_t pad_bytes = 0) {
+    used = (used + 255) & ~(size_t)255;
+    T* p = measuring ? nullptr : (T*)(base + used);
+    used += (n ? n : 1) * sizeof(T) + pad_bytes;
+    return p;
+  }
+  void release() { if (base) (void)hipFree(base); base = nullptr; cap = 0; used = 0; }
+};
+
 struct snf_extract {
   snf_extract_config_t cfg;
   int device = 0;
   std::vector<void*> dev;        // device allocations of the current input / run
-  std::vector<void*> dev_run;
+  XSlab run_a, run_b;            // what a run needs before / after the scans: two grow-only device blocks carved into arrays
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t scan_tmp = 0; int64_t scan_n = -1;
   ExView v{};
   int64_t n_records = 0, blob_len = 0;
   // host results
@@ -1084,15 +1131,6 @@ template <class T> T* x_up(std::vector<void*>& pool, const T* h, size_t n, size_
 }
 void x_release(std::vector<void*>& pool) { for (void* p : pool) x_free(p); pool.clear(); }
 
-int64_t* x_exscan(std::vector<void*>& pool, const int64_t* in, int64_t n) {   // exclusive prefix sums of n elements
-  int64_t* out = x_alloc<int64_t>(pool, (size_t)n);
-  size_t need = 0;
-  SNF_HIP(rocprim::exclusive_scan(nullptr, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
-  void* tmp = x_alloc<uint8_t>(pool, need);
-  SNF_HIP(rocprim::exclusive_scan(tmp, need, in, out, (int64_t)0, (size_t)n, rocprim::plus<int64_t>(), 0));
-  return out;
-}
-
 // rank of str(value) among the distinct phase sets plus the literal "NULL" (Python str order)
 bool ps_str_less(int64_t a, int64_t b) { return std::to_string(a) < std::to_string(b); }
 
@@ -1119,7 +1157,7 @@ int do_upload(snf_extract* x, const snf_extract_input_t* in) {
   }
   for (int i = 1; i < in->n_contigs; i++)
     if (in->contig_hash[i - 1] >= in->contig_hash[i]) snf::fail("extract input: contig_hash must be strictly ascending");
-  x_release(x->dev); x_release(x->dev_run);
+  x_release(x->dev);
   x->have_result = false;
   ExView& v = x->v;
   v = ExView{};
@@ -1178,29 +1216,44 @@ void pull_result(snf_extract* x) {
 
 int do_run(snf_extract* x) {
   if (!x->have_input) snf::fail("snf_extract_run before snf_extract_upload");
-  x_release(x->dev_run);
   x->have_result = false;
   ExView& v = x->v;
   const int64_t n = x->n_records;
-  std::vector<void*>& P = x->dev_run;
-  v.sum = x_alloc<RecSum>(P, (size_t)n);
-  v.err = x_alloc<unsigned long long>(P, 1);
-  v.c_acc = x_alloc<int64_t>(P, (size_t)n + 1); v.c_leads = x_alloc<int64_t>(P, (size_t)n + 1); v.c_seq = x_alloc<int64_t>(P, (size_t)n + 1);
-  v.nm_out = x_alloc<double>(P, 2);
+  const size_t N1 = (size_t)n + 1;
+  if (x->scan_n != n) {      // temporary storage of the three scans (one after the other on the stream: shared)
+    size_t need = 0;
+    SNF_HIP(rocprim::exclusive_scan(nullptr, need, (const int64_t*)nullptr, (int64_t*)nullptr, (int64_t)0, N1, rocprim::plus<int64_t>(), 0));
+    x->scan_tmp = need; x->scan_n = n;
+  }
+  int64_t *d_read_idx = nullptr, *d_lead_off = nullptr, *d_seq_off = nullptr; void* d_tmp = nullptr;
+  auto carve_a = [&](XSlab& s) {
+    v.sum = s.take<RecSum>((size_t)n);
+    v.tot = s.take<unsigned long long>(4); v.err = v.tot;
+    v.c_acc = s.take<int64_t>(N1); v.c_leads = s.take<int64_t>(N1); v.c_seq = s.take<int64_t>(N1);
+    v.c_ps = s.take<int64_t>((size_t)n); v.c_psf = s.take<uint8_t>((size_t)n);
+    v.nm_out = s.take<double>(2);
+    d_read_idx = s.take<int64_t>(N1); d_lead_off = s.take<int64_t>(N1); d_seq_off = s.take<int64_t>(N1);
+    d_tmp = s.take<uint8_t>(x->scan_tmp);
+#ifdef SNF_XTRACE
+    v.xtrace = s.take<uint32_t>((size_t)n * 4);
+#endif
+  };
+  x->run_a.measure(); carve_a(x->run_a); x->run_a.reserve(); carve_a(x->run_a);
+  v.read_idx = d_read_idx; v.lead_off = d_lead_off; v.seq_off = d_seq_off;
   const unsigned long long none = ~0ull;
   x_h2d(v.err, &none, 8);
 #ifdef SNF_XTRACE
-  v.xtrace = x_alloc<uint32_t>(P, (size_t)n * 4);
   SNF_HIP(hipMemset(v.xtrace, 0, (size_t)(n ? n : 1) * 16));
   v.xtrace_emit = getenv("SNF_XTRACE_PASS") && !strcmp(getenv("SNF_XTRACE_PASS"), "emit");
 #endif
   float ms_count = 0, ms_emit = 0;
   const bool thread_form = getenv("SNF_EXTRACT_THREAD") != nullptr;
   const int waves = getenv("SNF_EXTRACT_WAVES") ? atoi(getenv("SNF_EXTRACT_WAVES")) : X_WAVES_DEFAULT;
-  hipEvent_t e0, e1, e2, e3;
-  SNF_HIP(hipEventCreate(&e0)); SNF_HIP(hipEventCreate(&e1)); SNF_HIP(hipEventCreate(&e2)); SNF_HIP(hipEventCreate(&e3));
-  const unsigned grid_w = (unsigned)std::min<int64_t>(n > 0 ? n : 1, 1 << 22);
-  SNF_HIP(hipMemset(v.sum, 0, (size_t)(n ? n : 1) * sizeof(RecSum)));
+  for (hipEvent_t& e : x->ev) if (!e) SNF_HIP(hipEventCreate(&e));
+  hipEvent_t e0 = x->ev[0], e1 = x->ev[1], e2 = x->ev[2], e3 = x->ev[3];
+  const int64_t grid_cap = getenv("SNF_EXTRACT_GRID") ? std::max(1, atoi(getenv("SNF_EXTRACT_GRID"))) : (1 << 22);   // (a capped grid strides: measured, slower - the dispatcher balances unequal records better)
+  const unsigned grid_w = (unsigned)std::min<int64_t>(n > 0 ? n : 1, grid_cap);
+  // (every record's summary is initialised by the counting pass itself, whatever becomes of the record)
   SNF_HIP(hipEventRecord(e0, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
@@ -1211,37 +1264,50 @@ int do_run(snf_extract* x) {
   if (!x->side) SNF_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
   SNF_HIP(hipStreamWaitEvent(x->side, e1, 0));
   hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, x->side, v, n);
-  v.read_idx = x_exscan(P, v.c_acc, n + 1); v.lead_off = x_exscan(P, v.c_leads, n + 1); v.seq_off = x_exscan(P, v.c_seq, n + 1);
-  unsigned long long err = none; int64_t n_reads = 0, n_leads = 0, n_seq = 0; double nmv[2] = {0, 0};
-  x_d2h(&err, v.err, 8); x_d2h(&n_reads, v.read_idx + n, 8); x_d2h(&n_leads, v.lead_off + n, 8); x_d2h(&n_seq, v.seq_off + n, 8);
+  {
+    size_t need = x->scan_tmp;
+    SNF_HIP(rocprim::exclusive_scan(d_tmp, need, (const int64_t*)v.c_acc, d_read_idx, (int64_t)0, N1, rocprim::plus<int64_t>(), 0));
+    SNF_HIP(rocprim::exclusive_scan(d_tmp, need, (const int64_t*)v.c_leads, d_lead_off, (int64_t)0, N1, rocprim::plus<int64_t>(), 0));
+    SNF_HIP(rocprim::exclusive_scan(d_tmp, need, (const int64_t*)v.c_seq, d_seq_off, (int64_t)0, N1, rocprim::plus<int64_t>(), 0));
+  }
+  hipLaunchKernelGGL(x_totals, dim3(1), dim3(64), 0, 0, v, (int64_t)1);
+  unsigned long long tot[4] = {none, 0, 0, 0}; double nmv[2] = {0, 0};
+  x_d2h(tot, v.tot, 32);
+  const unsigned long long err = tot[0]; const int64_t n_reads = (int64_t)tot[1], n_leads = (int64_t)tot[2], n_seq = (int64_t)tot[3];
   if (err != none) {
     const int code = (int)(err & 0xff);
     snf::fail("alignment record " + std::to_string((long long)(err >> 8)) + ": " + XE_TEXT[code < 14 ? code : 4]);
   }
   // phase sets: distinct PS values of the accepted reads -> rank of str(value) in Python str order, "NULL" last
-  std::vector<RecSum> hs((size_t)n);
-  x_d2h(hs.data(), v.sum, (size_t)n * sizeof(RecSum));
+  std::vector<int64_t> h_ps((size_t)n); std::vector<uint8_t> h_psf((size_t)n);
+  x_d2h(h_ps.data(), v.c_ps, (size_t)n * 8); x_d2h(h_psf.data(), v.c_psf, (size_t)n);
   std::vector<int64_t> vals;
-  for (int64_t i = 0; i < n; i++) if (hs[(size_t)i].accept && hs[(size_t)i].has_ps) vals.push_back(hs[(size_t)i].ps);
+  for (int64_t i = 0; i < n; i++) if (h_psf[(size_t)i]) vals.push_back(h_ps[(size_t)i]);
   std::sort(vals.begin(), vals.end());
   vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
   std::vector<int64_t> by_str(vals);
   std::sort(by_str.begin(), by_str.end(), ps_str_less);
   std::vector<int32_t> rank_of(vals.size());
   for (size_t r = 0; r < by_str.size(); r++) rank_of[(size_t)(std::lower_bound(vals.begin(), vals.end(), by_str[r]) - vals.begin())] = (int32_t)r;
-  v.ps_val = x_up(P, vals.data(), vals.size()); v.ps_rank = x_up(P, rank_of.data(), rank_of.size());
   v.n_ps = (int32_t)vals.size(); v.ps_null_rank = (int32_t)vals.size();   // digits and '-' sort before 'N'
   x->h_ps_value = by_str; x->h_ps_value.push_back(0);
   // outputs
   const size_t L = (size_t)n_leads;
-  v.o_ref_start = x_alloc<int32_t>(P, L); v.o_ref_end = x_alloc<int32_t>(P, L); v.o_qry_start = x_alloc<int32_t>(P, L); v.o_qry_end = x_alloc<int32_t>(P, L);
-  v.o_svlen = x_alloc<int32_t>(P, L); v.o_read_len = x_alloc<int32_t>(P, L); v.o_ps = x_alloc<int32_t>(P, L); v.o_mate_contig = x_alloc<int32_t>(P, L);
-  v.o_mate_pos = x_alloc<int32_t>(P, L); v.o_seq_len = x_alloc<int32_t>(P, L); v.o_qname = x_alloc<uint32_t>(P, L); v.o_read_id = x_alloc<uint32_t>(P, L);
-  v.o_seq_off = x_alloc<int64_t>(P, L); v.o_nm = x_alloc<double>(P, L);
-  v.o_svtype = x_alloc<uint8_t>(P, L); v.o_strand = x_alloc<uint8_t>(P, L); v.o_mapq = x_alloc<uint8_t>(P, L); v.o_source = x_alloc<uint8_t>(P, L);
-  v.o_hap = x_alloc<uint8_t>(P, L); v.o_is_sa = x_alloc<uint8_t>(P, L); v.o_first = x_alloc<uint8_t>(P, L); v.o_rev = x_alloc<uint8_t>(P, L);
-  v.o_pool = x_alloc<uint8_t>(P, (size_t)n_seq);
-  v.o_rstart = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rend = x_alloc<int32_t>(P, (size_t)n_reads); v.o_rhp = x_alloc<uint8_t>(P, (size_t)n_reads);
+  int64_t* d_ps_val = nullptr; int32_t* d_ps_rank = nullptr;
+  auto carve_b = [&](XSlab& s) {
+    d_ps_val = s.take<int64_t>(vals.size()); d_ps_rank = s.take<int32_t>(rank_of.size());
+    v.o_ref_start = s.take<int32_t>(L); v.o_ref_end = s.take<int32_t>(L); v.o_qry_start = s.take<int32_t>(L); v.o_qry_end = s.take<int32_t>(L);
+    v.o_svlen = s.take<int32_t>(L); v.o_read_len = s.take<int32_t>(L); v.o_ps = s.take<int32_t>(L); v.o_mate_contig = s.take<int32_t>(L);
+    v.o_mate_pos = s.take<int32_t>(L); v.o_seq_len = s.take<int32_t>(L); v.o_qname = s.take<uint32_t>(L); v.o_read_id = s.take<uint32_t>(L);
+    v.o_seq_off = s.take<int64_t>(L); v.o_nm = s.take<double>(L);
+    v.o_svtype = s.take<uint8_t>(L); v.o_strand = s.take<uint8_t>(L); v.o_mapq = s.take<uint8_t>(L); v.o_source = s.take<uint8_t>(L);
+    v.o_hap = s.take<uint8_t>(L); v.o_is_sa = s.take<uint8_t>(L); v.o_first = s.take<uint8_t>(L); v.o_rev = s.take<uint8_t>(L);
+    v.o_pool = s.take<uint8_t>((size_t)n_seq);
+    v.o_rstart = s.take<int32_t>((size_t)n_reads); v.o_rend = s.take<int32_t>((size_t)n_reads); v.o_rhp = s.take<uint8_t>((size_t)n_reads);
+  };
+  x->run_b.measure(); carve_b(x->run_b); x->run_b.reserve(); carve_b(x->run_b);
+  x_h2d(d_ps_val, vals.data(), vals.size() * 8); x_h2d(d_ps_rank, rank_of.data(), rank_of.size() * 4);
+  v.ps_val = d_ps_val; v.ps_rank = d_ps_rank;
   SNF_HIP(hipEventRecord(e2, 0));
   if (n) {
     if (thread_form) hipLaunchKernelGGL(x_emit, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, v, n);
@@ -1251,7 +1317,6 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipStreamSynchronize(x->side));
   SNF_HIP(hipDeviceSynchronize());
   SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2); (void)hipEventDestroy(e3);
   x_d2h(nmv, v.nm_out, 16);
 #ifdef SNF_XTRACE
   if (const char* path = getenv("SNF_XTRACE_OUT")) {
@@ -1344,7 +1409,8 @@ int snf_extract_device_view(snf_extract_t* x, snf_task_input_t* out, int* device
 }
 void snf_extract_destroy(snf_extract_t* x) {
   if (!x) return;
-  x_release(x->dev); x_release(x->dev_run);
+  x_release(x->dev); x->run_a.release(); x->run_b.release();
+  for (hipEvent_t e : x->ev) if (e) (void)hipEventDestroy(e);
   if (x->side) (void)hipStreamDestroy(x->side);
   delete x;
 }

@@ -238,3 +238,83 @@ def test_device_handover_equals_host_path_emu(emu_lib, oracle_mod):
 @pytest.mark.gpu
 def test_device_handover_equals_host_path_gpu(oracle_mod):
     check_device_handover(None, oracle_mod)
+
+
+# ---- SA strings the wave form cuts into elements by ballots (a lane per element, csrc/snf_extract.hip part A): shapes the random
+# tables rarely produce.  Every case: the live reference (when its checkout or staged build is here), the oracle, the wave form
+# and the thread form (the reference's loops as they are) must agree on the leads - or all must fail.
+_E = "c1,%d,%s,%s,%d,%d"
+
+
+def _sa(*parts):
+    return ("SAZ" + "".join(parts)).encode() + b"\0"
+
+
+def _el(pos=5000, strand="+", cigar="1000S500M500S", mapq=60, nm=3, contig="c1"):
+    return f"{contig},{pos},{strand},{cigar},{mapq},{nm}"
+
+
+SA_SHAPES = {
+    "empty_string": _sa(""),
+    "only_semicolons": _sa(";;;"),
+    "no_trailing_semicolon": _sa(_el()),
+    "leading_and_doubled_semicolons": _sa(";;", _el(pos=9000), ";;", _el(pos=20000, strand="-"), ";;"),
+    "three_elements": _sa(_el(pos=3100, cigar="300M1700S"), ";", _el(pos=8000, strand="-", cigar="1500S500M"), ";", _el(contig="c2", pos=77, cigar="900S400M700S"), ";"),
+    "second_dropped_third_bad_number": _sa(_el(), ";", _el(cigar="10M5Q"), ";", _el(pos="1x"), ";"),       # CIGAR_analyze fails first: no splits, no error
+    "second_bad_number_third_dropped": _sa(_el(), ";", _el(pos="1x"), ";", _el(cigar="10M5Q"), ";"),       # the number fails first: the call fails
+    "seven_fields_in_the_second": _sa(_el(), ";", _el() + ",9", ";"),
+    "five_fields_in_the_first": _sa("c1,5000,+,100M,60;", _el(), ";"),
+    "bad_strand_in_the_third": _sa(_el(), ";", _el(pos=7000), ";", _el(strand="*"), ";"),
+    "mapq_out_of_range": _sa(_el(), ";", _el(mapq=300), ";"),
+    "empty_fields": _sa("c1,,+,,60,1;"),
+    "long_string_beyond_the_lds_copy": _sa(";".join(_el(pos=1000 + 37 * k, cigar=f"{k + 1}S{1500 - k}M{500 - 1}S") for k in range(40)), ";"),
+    "more_elements_than_the_table": _sa(";".join(_el(pos=1000 + 10 * k) for k in range(70)), ";"),
+}
+
+
+@pytest.mark.parametrize("shape", sorted(SA_SHAPES))
+@pytest.mark.parametrize("splits", ["default", "many"])
+def test_sa_string_shapes(shape, splits, emu_lib, monkeypatch):
+    import extract_oracle as eo
+    from sniffles_amd import extract
+    tags = b"NMC\x07" + SA_SHAPES[shape]
+    recs = _one_read(tags, ops=((4, 300), (0, 1200), (1, 80), (0, 400), (4, 100)))
+    kw = dict(max_splits_base=100) if splits == "many" else {}
+    outcomes = {}
+
+    def run(name, fn):
+        try:
+            outcomes[name] = ("ok", fn())
+        except Exception as e:
+            outcomes[name] = ("raised", f"{type(e).__name__}: {e}"[:200])
+
+    def kernels():
+        ti, info = extract.extract_region(recs, "c1", 0, 100000, DevCfg(**kw))
+        return xu.canon_leads(ti)
+
+    run("oracle", lambda: eo.extract_region(recs.blob, recs.rec_off, recs.ref_names, "c1", 0, 100000, eo.Cfg(**kw))["rows"])
+    run("wave", kernels)
+    monkeypatch.setenv("SNF_EXTRACT_THREAD", "1")
+    run("thread", kernels)
+    monkeypatch.delenv("SNF_EXTRACT_THREAD")
+    import make_ref
+    if make_ref.ref_root():
+        import ref_harness as rh
+        args = ("--max-splits-base", "100") if splits == "many" else ()
+        ref = rh.run_reference_extract(recs, "c1", 0, 100000, args, 0, {})
+        outcomes["reference"] = ("raised", ref["error"]) if "error" in ref else ("ok", ref["leads"])
+    kinds = {k: v[0] for k, v in outcomes.items()}
+    if shape == "more_elements_than_the_table" and splits == "many":      # a limit of the device table (64 segments), not of the reference
+        assert kinds["wave"] == kinds["thread"] == "raised" and "more split alignments" in outcomes["wave"][1], outcomes
+        return
+    restricted = {"bad_strand_in_the_third": "SA strand",      # the reference keeps any strand string (and compares strings); the device table holds a bit
+                  "mapq_out_of_range": "column range"}         # ... and any integer as MAPQ; the column has eight bits
+    if shape in restricted:
+        assert kinds["wave"] == kinds["thread"] == "raised" and restricted[shape] in outcomes["wave"][1] and outcomes["wave"][1] == outcomes["thread"][1], outcomes
+        return
+    assert len(set(kinds.values())) == 1, {k: (v[0], v[1] if v[0] == "raised" else len(v[1])) for k, v in outcomes.items()}
+    if kinds["wave"] == "ok":
+        for k, v in outcomes.items():
+            assert v[1] == outcomes["wave"][1], k
+    else:
+        assert outcomes["wave"][1] == outcomes["thread"][1], outcomes      # the same first error, in the same words

@@ -88,6 +88,35 @@ def test_long_reads_wave_equals_thread_and_oracle(monkeypatch):
     assert rows == want["rows"] and reads == want["reads"] and nm_hex == want["qc_nm_threshold"]
 
 
+def test_sa_string_shapes_on_the_device(monkeypatch):
+    """The SA shapes of tests/test_extract.py (empty / doubled elements, the first failing element decides, strings beyond the LDS
+    copy, more elements than the segment table) in ONE record table: wave form == thread form == oracle on the MI355X."""
+    import extract_oracle as eo
+    from sniffles_amd import bam, synth_bam
+    from test_extract import SA_SHAPES
+    ok = [k for k in sorted(SA_SHAPES) if k not in ("second_bad_number_third_dropped", "seven_fields_in_the_second", "five_fields_in_the_first",
+                                                     "bad_strand_in_the_third", "mapq_out_of_range", "empty_fields")]
+    ops = [(4, 300), (0, 1200), (1, 80), (0, 400), (4, 100)]
+    qlen = sum(n for op, n in ops if op in (0, 1, 4))
+    recs = [synth_bam.make_record(0, 1000 + 50 * i, 60, 0x10 * (i % 2), f"r{i}", ops, np.full(qlen, 1 + (i % 4), np.uint8), b"NMC\x07" + SA_SHAPES[k])
+            for i, k in enumerate(ok * 3)]
+    R = bam.records_from_list(["c1", "c2"], [100000, 50000], recs)
+    for kw in ({}, dict(max_splits_base=60)):
+        want = eo.extract_region(R.blob, R.rec_off, R.ref_names, "c1", 0, 100000, eo.Cfg(**kw))
+        monkeypatch.delenv("SNF_EXTRACT_THREAD", raising=False)
+        rows_w = as_tuple(*dev_extract(R, "c1", 0, 100000, DevCfg(**kw)))
+        monkeypatch.setenv("SNF_EXTRACT_THREAD", "1")
+        rows_t = as_tuple(*dev_extract(R, "c1", 0, 100000, DevCfg(**kw)))
+        assert rows_w == rows_t
+        assert rows_w[0] == want["rows"] and rows_w[1] == want["reads"] and len(want["rows"]) > 3 * len(ok)
+    monkeypatch.delenv("SNF_EXTRACT_THREAD", raising=False)
+    from sniffles_amd import lib
+    from test_extract import _one_read
+    for k, match in (("second_bad_number_third_dropped", "plain integer"), ("seven_fields_in_the_second", "6 fields"), ("empty_fields", "plain integer")):
+        with pytest.raises(lib.SnifflesAmdError, match=match):
+            dev_extract(_one_read(b"NMC\x07" + SA_SHAPES[k], ops=tuple(ops)), "c1", 0, 100000)
+
+
 def test_errors_fail_loudly():
     from sniffles_amd import lib
     from test_extract import _one_read

@@ -265,4 +265,31 @@ xb new_tile32 --tile 32
 SNF_LIB_SO=$R/variants/x_base.so xb base_tile32 --tile 32
 } 2>&1 | tee gpurun_out/ab_r06_11.log
   ;;
+20)
+# round 6, twentieth session: is the extraction pass bound by the dispatch of 24 000 one-wave workgroups?  A capped grid that strides
+xb() { tag=$1; shift; python tools/bench_extract.py --steps 6 --cpu-reads 3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3), 'algo MB', round(d['algo_bytes']/1e6,1), 'records', d['records'], 'leads', d['signatures'])"; }
+{
+SNF_LIB_SO=$R/variants/xtrace.so python tools/xtrace.py --pass count 2>&1 | head -16
+xb grid_all
+for g in 2048 4096 8192 16384; do SNF_EXTRACT_GRID=$g xb grid_$g; done
+xb grid_all_tile32 --tile 32
+for g in 4096 8192 16384; do SNF_EXTRACT_GRID=$g xb grid_${g}_tile32 --tile 32; done
+} 2>&1 | tee gpurun_out/ab_r06_12.log
+  ;;
+21)
+# round 6, twenty-first session: the tag walk as scalar code, the CIGAR walk 2 / 3 / 4 steps ahead, the run without its forty allocations
+xb() { tag=$1; shift; python tools/bench_extract.py --steps 8 --cpu-reads 3 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$tag', 'count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3), 'algo MB', round(d['algo_bytes']/1e6,1), 'records', d['records'], 'leads', d['signatures'])"; }
+{
+timeout 900 python -m pytest tests/test_extract_gpu.py tests/test_extract.py tests/test_pipeline.py -m gpu -x -q 2>&1 | tail -1
+for k in 1 2; do
+SNF_LIB_SO=$R/variants/x_ahead2.so xb ahead2
+xb ahead3
+SNF_LIB_SO=$R/variants/x_ahead4.so xb ahead4
+done
+SNF_LIB_SO=$R/variants/x_ahead2.so xb ahead2_tile32 --tile 32
+xb ahead3_tile32 --tile 32
+SNF_LIB_SO=$R/variants/x_ahead4.so xb ahead4_tile32 --tile 32
+SNF_LIB_SO=$R/variants/x_base.so xb base
+} 2>&1 | tee gpurun_out/ab_r06_13.log
+  ;;
 esac
