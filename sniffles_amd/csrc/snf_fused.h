@@ -373,6 +373,7 @@ __global__ void __launch_bounds__(256) e2a_sizes(const View v, int64_t n_unused)
   if (threadIdx.x == 0) for (int k = 0; k < SNF_ALT_K; k++) v.tile_sums[(int64_t)k * v.tile_stride + blockIdx.x] = tot[k];
 }
 __global__ void __launch_bounds__(256) e3b_offsets(const View v, int64_t n_unused) {
+  IT_SCOPE(8)
   __shared__ unsigned long long lds[4 * SNF_ALT_K];
   const int64_t nc = v.cnt->n_calls;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -1023,6 +1023,7 @@ void do_upload(snf_batch_impl* b) {
   b->graph_mode = getenv("SNF_GRAPH") ? (atoi(getenv("SNF_GRAPH")) != 0 ? 2 : 0) : (getenv("SNF_NO_GRAPH") ? 0 : (small_batch ? 2 : 0));
   v.big_cap = (int64_t)(N1 / 64 + 2); v.big_cnt = dalloc<uint32_t>(b, 3 * 64 * 16); v.big_list = dalloc<int32_t>(b, (size_t)(3 * 64 * v.big_cap));
   v.big_wave = v.wave_path;
+  { const int hn = getenv("SNF_HEAVY_N") ? atoi(getenv("SNF_HEAVY_N")) : 24; v.heavy_n = hn > 8 && hn < 64 ? hn : 0; }      // (0 / out of range: one class, as before)
   { const int eb = getenv("SNF_E1_BATCH") ? atoi(getenv("SNF_E1_BATCH")) : 64; v.e1_batch = (eb == 2 || eb == 4 || eb == 8 || eb == 16 || eb == 32) ? eb : 64; }
   v.stage_cap = getenv("SNF_NO_BIG_STAGE") ? 0 : 1;   // x_big<0>: clusters up to SNF_BIG_STAGE_CAP leads are kept in LDS
   v.cdesc = dalloc<ConsDesc>(b, N1); v.crl_off = dalloc<int64_t>(b, N1); v.crl_len = dalloc<int32_t>(b, N1); v.aln_kept_w = dalloc<uint8_t>(b, N1);
@@ -1031,6 +1032,9 @@ void do_upload(snf_batch_impl* b) {
   for (int k = 0; k < 3; k++) v.d2_list[k] = dalloc<int32_t>(b, (size_t)(64 * v.d2cap));
   v.d2cnt = dalloc<uint32_t>(b, 3 * 64 * 16);
   v.d2_from_list = 0; v.d1_from_list = 0;
+#ifdef SNF_ITRACE
+  if (!v.itrace) { SNF_HIP(hipMalloc((void**)&v.itrace, (size_t)SNF_IT_SLOTS * SNF_IT_CAP * 8)); SNF_HIP(hipMemset(v.itrace, 0, (size_t)SNF_IT_SLOTS * SNF_IT_CAP * 8)); }
+#endif
 #ifdef SNF_WG_TRACE
   if (!v.wgtrace) { SNF_HIP(hipMalloc((void**)&v.wgtrace, (size_t)(1 << 20) * 24)); SNF_HIP(hipMemset(v.wgtrace, 0, (size_t)(1 << 20) * 24)); }
 #endif
@@ -1940,6 +1944,35 @@ void destroy_graphs(snf_batch_impl* b) {
 
 void collect_timings(snf_batch_impl* b) {
   b->timings.clear();
+#ifdef SNF_ITRACE
+  if (getenv("SNF_PROF") && b->v.itrace) {      // per kernel slot: the workgroups' starts and durations of the pass that just ended
+    static const char* nm[SNF_IT_SLOTS] = {"w1_hist", "w3_scatter", "w4s_segment", "w6t_emit", "d1g_refine", "d1w_refine", "d2g_call", "d2w_call", "e3b_offsets",
+                                           "e1w_finalize", "cons SMALL", "cons LARGE", "d4s_coverage", "f4w_emit", "cons ROWS", ""};
+    std::vector<uint32_t> h((size_t)SNF_IT_SLOTS * SNF_IT_CAP * 2);
+    (void)hipMemcpy(h.data(), b->v.itrace, h.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipMemset(b->v.itrace, 0, h.size() * 4);
+    for (int k = 0; k < SNF_IT_SLOTS; k++) {
+      struct E { uint32_t t0, dur, wg; };
+      std::vector<E> es;
+      for (int64_t i = 0; i < SNF_IT_CAP; i++) { const uint32_t* o = &h[2 * ((size_t)k * SNF_IT_CAP + i)]; if (o[1] & 0x80000000u) es.push_back({o[0], o[1] & 0x7fffffffu, (uint32_t)i}); }
+      if (es.empty()) continue;
+      uint32_t base = es[0].t0;
+      for (auto& e : es) if ((int32_t)(e.t0 - base) < 0) base = e.t0;
+      uint32_t span = 0; double sum = 0;
+      for (auto& e : es) { e.t0 -= base; span = std::max(span, e.t0 + e.dur); sum += e.dur; }
+      std::vector<uint32_t> d; for (auto& e : es) d.push_back(e.dur);
+      std::sort(d.begin(), d.end());
+      auto pc = [&](double q) { return d[(size_t)(q * (d.size() - 1))] * 0.01; };
+      fprintf(stderr, "[SNF_ITRACE] %-13s %6zu workgroups, span %7.1f us, sum %9.1f us = %6.0f in flight on average; duration us p50 %.1f p90 %.1f p99 %.1f max %.1f; in flight at 12 points:",
+              nm[k], es.size(), span * 0.01, sum * 0.01, sum / (span ? span : 1), pc(0.5), pc(0.9), pc(0.99), pc(1.0));
+      for (int q = 0; q < 12; q++) { const uint32_t t = (uint32_t)((uint64_t)span * (2 * q + 1) / 24); int act = 0; for (auto& e : es) act += e.t0 <= t && t < e.t0 + e.dur; fprintf(stderr, " %d", act); }
+      std::sort(es.begin(), es.end(), [](const E& a, const E& c) { return a.t0 + a.dur > c.t0 + c.dur; });
+      fprintf(stderr, "; last to end:");
+      for (size_t q = 0; q < es.size() && q < 4; q++) fprintf(stderr, " wg %u +%.1f for %.1f", es[q].wg, es[q].t0 * 0.01, es[q].dur * 0.01);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
 #ifdef SNF_WG_TRACE
   if (getenv("SNF_PROF") && b->v.wgtrace) {
     const int64_t n = 1 << 19;

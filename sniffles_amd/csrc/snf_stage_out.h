@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(256) f3k_rank(const View v, int64_t n) {
 typedef uint4 __attribute__((aligned(1))) out_u128_unaligned;
 // one wave per kept call: the 240-byte record as fifteen 16-byte words (offsets patched in registers), read names lane-strided
 __global__ void __launch_bounds__(256) f4w_emit(const View v, int64_t n) {
+  IT_SCOPE(13)
   static_assert(sizeof(snf_call_t) == 240 && sizeof(snf_call_t) % 16 == 0, "record copied as 16-byte words");
   const OutHdr h = *v.out_hdr;
   uint8_t* base = h.in_pinned ? v.out_pin : v.out_dev;

@@ -67,6 +67,7 @@ SNF_D int win_group(bool valid, uint32_t w, int* count, bool* leader) {
 
 // W1: window histogram; the window and the packed attributes of every lead are kept for w3_scatter (val_in / val_out)
 __global__ void __launch_bounds__(256) w1_hist(const View v, int64_t n) {
+  IT_SCOPE(0)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   uint32_t w = ~0u, attr = 0;
   const bool valid = i < n && win_of_lead(v, i, &w, &attr);
@@ -135,6 +136,7 @@ SNF_CHAIN_HEAD(w2c_offsets, TS_WIN)      // (the pair above in one launch: snf_f
 
 // W3: every lead into its window's bucket: (attributes << 32 | input index), any order inside the bucket
 __global__ void __launch_bounds__(256) w3_scatter(const View v, int64_t n) {
+  IT_SCOPE(1)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const uint32_t w = i < n ? v.val_in[i] : ~0u;
   const bool valid = w != ~0u;
@@ -193,6 +195,7 @@ SNF_D uint32_t wkey_hap(uint64_t k) { return (uint32_t)(k >> 1) & 3u; }
 
 template <int CAP>
 __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused) {
+  IT_SCOPE(2)
   constexpr int CAPW = CAP + 64, E = CAPW / 64, PAD = 8;
   __shared__ uint64_t keys[CAPW + CAP + PAD];  // by position relative to the block's first (64 i); sorted in place; behind them "infinity"
   __shared__ uint16_t widx[CAPW];              // window marks, later the head position of every lead's bin
@@ -379,6 +382,7 @@ SNF_CHAIN_HEAD(w5c_offsets, TS_WINC)     // (the pair above in one launch)
 // W6: one THREAD per bucket position: the seeds, `leads` (L, packed records) and `leads_long` (LL) at their global places = the
 // offsets of the wave that owns the position (w5's scans) + the rank w4s_segment left in the word.  The pass's one gather (in_rec).
 __global__ void __launch_bounds__(256) w6t_emit(const View v, int64_t n_unused) {
+  IT_SCOPE(3)
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= v.cnt->n_valid) return;
   const uint64_t word = v.key_out[p];

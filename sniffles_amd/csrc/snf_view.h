@@ -277,6 +277,9 @@ struct View {
                              // has no host-side counter to take its tags from)
   unsigned long long* tile_sums; int64_t tile_stride;  // per-256-element-tile sums of the fused size->scan->emit chains
   ConsDesc* cdesc;           // [n_cons] by cons id
+#ifdef SNF_ITRACE
+  uint32_t* itrace;   // measurement build only (-DSNF_ITRACE, tools/itrace.sh): per kernel slot and workgroup {start, duration} in 100 MHz ticks
+#endif
 #ifdef SNF_WG_TRACE
   unsigned long long* wgtrace;   // measurement build only (-DSNF_WG_TRACE): per consensus call {start, duration | shape} in 100 MHz ticks
 #endif
@@ -294,6 +297,8 @@ struct View {
   int64_t big_cap;
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
   int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32, 64; default 64)
+  int32_t heavy_n;           // hand-over lists: an item with more leads than this goes into the first 16 stripes, i.e. to the FRONT of the index
+                             // space the next kernel walks (its workgroups start in index order: the long items first, not last); 0: off
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative
   int32_t* w7;               // [N+1] scratch of the cooperative sorts (same slot space as w0..w6)
   // x_big<0> keeps a cluster in LDS: its packed lead records and the eight scratch rows (stage_cap entries each); null otherwise
@@ -301,5 +306,22 @@ struct View {
   uint8_t* aln_kept_w;       // [N+1] kept flag per (call, other read) of the workgroup kernels, indexed like crl_*
   int64_t* crl_off; int32_t* crl_len;  // [<= N] pool offset / length of every 'other' read, in cluster order per call
 };
+
+// measurement build (-DSNF_ITRACE): every workgroup of the kernels that carry IT_SCOPE(slot) leaves when it started and how long it
+// ran - what the device's occupancy over a kernel's span looks like (ramp, plateau, tail) and which workgroups are the last
+#define SNF_IT_SLOTS 16
+#define SNF_IT_CAP (1 << 17)
+#ifdef SNF_ITRACE
+struct ItScope {
+  uint32_t* o; unsigned long long t0;
+  __device__ ItScope(const View& v, int slot) : o(nullptr), t0(wall_clock64()) {
+    if (v.itrace && threadIdx.x == 0 && blockIdx.x < (unsigned)SNF_IT_CAP) o = v.itrace + 2 * ((int64_t)slot * SNF_IT_CAP + blockIdx.x);
+  }
+  __device__ ~ItScope() { if (o) { o[0] = (uint32_t)t0; o[1] = (uint32_t)(wall_clock64() - t0) | 0x80000000u; } }
+};
+#define IT_SCOPE(slot) ItScope it_scope_(v, slot);
+#else
+#define IT_SCOPE(slot)
+#endif
 
 }  // namespace snf

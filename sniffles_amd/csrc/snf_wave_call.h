@@ -11,6 +11,10 @@ namespace snf {
 struct CallLds { int32_t buf[SNF_WAVE]; double nm[SNF_WAVE]; };
 
 SNF_D int64_t wave_sum64(int64_t x) { return wave_last64(wave_incl_scan64(x, 0)); }     // (DPP scans, snf_wave_refine.h)
+// the same for sums that stay below 2^32 (counts, MAPQ sums, the small-spread variance sums): six DPP adds instead of six 64-bit steps
+// of two moves and an add-with-carry each.  The call kernels are bound by instruction issue (d2w_call: ~2 850 instructions per cluster
+// at five waves per SIMD is its 21 us per cluster), so what they do is only worth what it costs in instructions.
+SNF_D uint32_t wave_sum32(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane(wave_incl_scan((int32_t)x, 0), 63); }
 SNF_D int wave_max32(int x) { return (int)__builtin_amdgcn_readlane((uint32_t)wave_incl_max(x), 63); }
 
 // ascending sort of the active lanes' values; returns the value at sorted position `lane` (lanes >= n: garbage)
@@ -50,6 +54,17 @@ SNF_D double wave_stdev_trim_sorted(int32_t s, int n, int lane) {
   const int64_t x0 = __shfl(s, lo, SNF_WAVE);
   const bool in = lane >= lo && lane < hi;
   const uint64_t d = in ? (uint64_t)((int64_t)s - x0) : 0;  // sorted: d >= 0, < 2^32
+  // the usual cluster: the values lie within 8191 of each other (sorted: the last one is the largest).  Then sum(d) < 2^19 and
+  // sum(d^2) < 2^32 - two 32-bit sums -, n * S2 - S1^2 < 2^38, and the exact ratio is ONE fp64 division of two exactly
+  // representable integers: what stdev_from_sums / ratio_to_double return on their first branch, without the 128-bit arithmetic
+  // in front of it
+  const uint32_t dmax = (uint32_t)(__builtin_amdgcn_readlane(s, __builtin_amdgcn_readfirstlane(hi - 1)) - (int32_t)x0);
+  if (dmax < (1u << 13)) {
+    const uint32_t d32 = (uint32_t)d;
+    const uint64_t S1s = wave_sum32(d32), S2s = wave_sum32(d32 * d32);
+    const uint64_t num = (uint64_t)cnt * S2s - S1s * S1s;
+    return sqrt((double)num / (double)((uint64_t)cnt * (uint64_t)(cnt - 1)));
+  }
   const uint64_t d2 = d * d;
   const int64_t S1 = wave_sum64((int64_t)d);
   const int64_t lo32 = wave_sum64((int64_t)(d2 & 0xffffffffull)), hi32 = wave_sum64((int64_t)(d2 >> 32));
@@ -73,19 +88,27 @@ SNF_D int32_t d2list_at(const View& v, int k, int64_t i, const int32_t* pre) {
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= (int32_t)i) lo = mid; else hi = mid - 1; }
   return v.d2_list[k][(int64_t)lo * v.d2cap + (i - pre[lo])];
 }
-// producer side: the lanes with `hand` append their cluster to list k, one atomic per wave on the workgroup's stripe
-SNF_D void d2list_push(const View& v, int k, bool hand, int32_t r, int lane) {
-  const unsigned long long hm = __ballot(hand);
-  if (!hm) return;
-  const int stripe = (int)(blockIdx.x & 63);
-  const int leader = __builtin_ctzll(hm);
-  uint32_t at = 0;
-  if (lane == leader) at = atomicAdd(&v.d2cnt[(k * 64 + stripe) * 16], (uint32_t)__builtin_popcountll(hm));
-  at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
-  if (hand) {
-    const int64_t slot = (int64_t)at + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
-    if (slot < v.d2cap) v.d2_list[k][(int64_t)stripe * v.d2cap + slot] = r;
-    else atomicOr(&v.cnt->overflow, 2);      // (a stripe holds a 64th of all clusters + 64: cannot happen with a grid that is a multiple of 64)
+// producer side: the lanes with `hand` append their cluster to list k, one atomic per wave on the workgroup's stripe.
+// `nleads`: the item's size.  The kernel that walks the list starts its workgroups in index order and takes a few items each: a
+// cluster of 60 leads costs several times what one of 10 does, and when such items sit anywhere in the list the kernel ends with a
+// handful of waves working through them (d1w_refine: 4096 waves in flight for 40 us, fewer than 30 for the following 45 us).  Items
+// above View::heavy_n go to stripes 0..15 - the front of the consumer's index space -, the others to stripes 16..63.
+SNF_D void d2list_push(const View& v, int k, bool hand, int32_t r, int lane, int nleads = 0) {
+  const bool split = v.heavy_n > 0;
+  for (int cls = 0; cls < 2; cls++) {
+    const bool mine = hand && (!split ? cls == 0 : (nleads > v.heavy_n) == (cls == 0));
+    const unsigned long long hm = __ballot(mine);
+    if (!hm) continue;
+    const int stripe = !split ? (int)(blockIdx.x & 63) : cls == 0 ? (int)(blockIdx.x & 15) : 16 + (int)(blockIdx.x % 48u);
+    const int leader = __builtin_ctzll(hm);
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(&v.d2cnt[(k * 64 + stripe) * 16], (uint32_t)__builtin_popcountll(hm));
+    at = (uint32_t)__builtin_amdgcn_readlane((int)at, leader);
+    if (mine) {
+      const int64_t slot = (int64_t)at + __builtin_popcountll(hm & ((1ull << lane) - 1ull));
+      if (slot < v.d2cap) v.d2_list[k][(int64_t)stripe * v.d2cap + slot] = r;
+      else atomicOr(&v.cnt->overflow, 2);      // (a stripe holds a 64th of all LEADS + 64 entries; the items of either class are at least 9 times fewer)
+    }
   }
 }
 
@@ -130,7 +153,7 @@ SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n,
     const unsigned long long best = __ballot(st && len == maxc);
     const int bl = 63 - __builtin_clzll(best);   // (count, value) descending: ties -> larger value
     ps_val = __shfl(s_ps, bl, SNF_WAVE); ps_support = maxc;
-    ps_other = (int)wave_sum64((st && s_ps != ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
+    ps_other = (int)wave_sum32((st && s_ps != ps_val && s_ps != SNF_PS_NULL_CODE) ? (uint32_t)len : 0u);
     __syncthreads();
   }
   x.ag_hp_val = hp_val; x.ag_hp_support = hp_support; x.ag_hp_other = hp_other;
@@ -164,6 +187,7 @@ SNF_D void wave_lead_agg(const snf_config_t& cfg, CallLds& lds, int lane, int n,
 // loaded, by the instance that needs them - the other one must not pay registers for them)
 template <int MINW, bool PHASE>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t n_unused) {
+  IT_SCOPE(7)
   __shared__ CallLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;
@@ -237,7 +261,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
           if (first) { cl++; if (!contains_sorted_i32(a1, nq, q)) cu++; }
         }
       }
-      support_long = wave_sum64(cl); support += wave_sum64(cu);
+      support_long = wave_sum32((uint32_t)cl); support += wave_sum32((uint32_t)cu);
     }
     const int32_t s_rs = wave_sort_i32(rs, act, n, lane, lds.buf);
     const int64_t ref_start = wave_center_sorted(s_rs, n, lane);
@@ -249,7 +273,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     if (svtype == SNF_INS) { svstart = ref_start; svend = ref_start; }
     else if (svtype == SNF_DEL) { svstart = ref_start + svlen; svend = ref_start; }
     else { svstart = ref_start; svend = svstart + iabs64(svlen); }
-    const int64_t msum = wave_sum64(act ? mapq : 0);
+    const int64_t msum = wave_sum32(act ? (uint32_t)mapq : 0u);      // (<= 64 x 255)
     const int64_t fwd = __builtin_popcountll(__ballot(act && strand == 0));
     int64_t sa = __builtin_popcountll(__ballot(act && is_sa));
     const int64_t src_noninline = __builtin_popcountll(__ballot(act && noninline));
@@ -264,7 +288,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
     if (keeplong) {
       int cs = 0;
       for (int32_t x = llo + lane; x < lhi; x += SNF_WAVE) cs += v.in_is_sa[v.LL[x]];
-      sa += wave_sum64(cs); n_all += lhi - llo;
+      sa += wave_sum32((uint32_t)cs); n_all += lhi - llo;
     }
     snf_call_t cc;
     memset(&cc, 0, sizeof(cc));
@@ -361,6 +385,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2w_call(const View v, int64_t
 #define SNF_E1_BATCH_MAX 32
 template <int MINW>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int64_t n_unused) {
+  IT_SCOPE(9)
   const int E1B = v.e1_batch;      // calls per wave (the launch uses the same number)
   const int lane = threadIdx.x;
   const int64_t n_calls = v.cnt->n_calls;
@@ -384,6 +409,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) e1w_finalize(const View v, int
 // ------------------------------------------------------------------------------------------ d4s: the five coverage samples of every call
 // (snf_stage_call.h::d4s_sample_body) over a grid that does not depend on the number of calls (known on the device only)
 __global__ void __launch_bounds__(256) d4s_coverage(const View v, int64_t n_unused) {
+  IT_SCOPE(12)
   const int64_t n = 5 * (int64_t)v.cnt->n_calls;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) d4s_sample_body(q, v);
 }

@@ -50,6 +50,17 @@ template <int G> SNF_D int64_t gsum64(int64_t x) {
   }
   return x;
 }
+template <int G> SNF_D uint32_t gsum32(uint32_t x) {      // sums below 2^32: one DPP add per step
+  if constexpr (G == 8) {
+#define SNF_STEP(ctrl) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, 0xf, 0xf, false);
+    SNF_DPP_G8(SNF_STEP)
+#undef SNF_STEP
+  } else {
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1) x += (uint32_t)__shfl_xor((int)x, d, SNF_WAVE);
+  }
+  return x;
+}
 template <int G> SNF_D int gmax32(int x) {
   if constexpr (G == 8) {
 #define SNF_STEP(ctrl) { const int y_ = __builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false); x = y_ > x ? y_ : x; }
@@ -107,6 +118,14 @@ template <int G> SNF_D double gstdev_trim_sorted(int32_t s, int n, int gl, int g
   const int64_t x0 = gshfl_i32<G>(s, cnt >= 2 ? lo : 0, gbase);
   const bool in = cnt >= 2 && gl >= lo && gl < hi;
   const uint64_t d = in ? (uint64_t)((int64_t)s - x0) : 0;  // sorted: d >= 0, < 2^32
+  // every group of the wave within 8191 (the usual case, wave-uniform test): 32-bit sums and one fp64 division (see wave_stdev_trim_sorted)
+  if (__ballot(d >= (1ull << 13)) == 0ull) {
+    const uint32_t d32 = (uint32_t)d;
+    const uint64_t S1s = gsum32<G>(d32), S2s = gsum32<G>(d32 * d32);
+    if (cnt < 2) return 0.0;
+    const uint64_t num = (uint64_t)cnt * S2s - S1s * S1s;
+    return sqrt((double)num / (double)((uint64_t)cnt * (uint64_t)(cnt - 1)));
+  }
   const uint64_t d2 = d * d;
   const int64_t S1 = gsum64<G>((int64_t)d);
   const int64_t lo32 = gsum64<G>((int64_t)(d2 & 0xffffffffull)), hi32 = gsum64<G>((int64_t)(d2 >> 32));
@@ -154,7 +173,7 @@ SNF_D void group_lead_agg(const snf_config_t& cfg, CallLds& lds, int gl, int gba
     const unsigned long long best = gballot<G>(st && len == maxc, gbase);
     const int bl = best ? 63 - __builtin_clzll(best) : 0;   // (count, value) descending: ties -> larger value
     ps_val = gshfl_i32<G>(s_ps, bl, gbase); ps_support = maxc;
-    ps_other = (int)gsum64<G>((st && s_ps != ps_val && s_ps != SNF_PS_NULL_CODE) ? len : 0);
+    ps_other = (int)gsum32<G>((st && s_ps != ps_val && s_ps != SNF_PS_NULL_CODE) ? (uint32_t)len : 0u);
     __syncthreads();
   }
   x.ag_hp_val = hp_val; x.ag_hp_support = hp_support; x.ag_hp_other = hp_other;
@@ -184,6 +203,7 @@ SNF_D void group_lead_agg(const snf_config_t& cfg, CallLds& lds, int gl, int gba
 // LIST: the items are the entries of hand-over list 0 (clusters d2g_call<8> handed on); otherwise every refined cluster
 template <int G, int MINW, bool PHASE>
 __global__ void __launch_bounds__(SNF_WAVE, MINW) d2g_call(const View v, int64_t n_unused) {
+  IT_SCOPE(6)
   static_assert(G == 8 || G == 32, "group widths in use");
   constexpr int NG = SNF_WAVE / G;
   constexpr bool LIST = G != 8;
@@ -216,7 +236,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2g_call(const View v, int64_t
     const int32_t r = cur.r;
     int32_t flo = cur.flo, n = cur.n, c = cur.c, h = cur.h;
     // clusters that do not fit a group go to the next kernel's list
-    d2list_push(v, LIST ? 1 : 0, valid && n > G && gl == 0, r, lane);
+    d2list_push(v, LIST ? 1 : 0, valid && n > G && gl == 0, r, lane, n);
     if (valid && n > G) valid = false;
     if (!valid) n = 0;
     int nmax = n;
@@ -303,7 +323,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2g_call(const View v, int64_t
     if (svtype == SNF_INS) { svstart = ref_start; svend = ref_start; }
     else if (svtype == SNF_DEL) { svstart = ref_start + svlen; svend = ref_start; }
     else { svstart = ref_start; svend = svstart + iabs64(svlen); }
-    const int64_t msum = gsum64<G>(act ? mapq : 0);
+    const int64_t msum = gsum32<G>(act ? (uint32_t)mapq : 0u);      // (<= 64 x 255)
     const int64_t fwd = __builtin_popcountll(gballot<G>(act && strand == 0, gbase));
     int64_t sa = __builtin_popcountll(gballot<G>(act && is_sa, gbase));
     const int64_t src_noninline = __builtin_popcountll(gballot<G>(act && noninline, gbase));
@@ -318,7 +338,7 @@ __global__ void __launch_bounds__(SNF_WAVE, MINW) d2g_call(const View v, int64_t
     {
       int cs = 0;
       if (keeplong) for (int32_t x = llo + gl; x < lhi; x += G) cs += v.in_is_sa[v.LL[x]];
-      const int64_t cst = gsum64<G>(cs);
+      const int64_t cst = gsum32<G>((uint32_t)cs);
       if (keeplong) { sa += cst; n_all += lhi - llo; }
     }
     snf_call_t cc;

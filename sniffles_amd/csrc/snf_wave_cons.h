@@ -162,6 +162,7 @@ SNF_D int64_t rfl64(int64_t x) {  // wave-uniform 64-bit value -> SGPR pair
 // ROWS instance through work list 7
 template <int CLS, int SLOTS, int MAXPOS, int MAXOTHERS, int MINW, int NW = 4, int LCAP = 0, int SCAP = 0, int ECAP = 0>
 __global__ void __launch_bounds__(64 * NW, MINW) e45w_consensus(const View v, int64_t n_unused) {
+  IT_SCOPE(CLS == 1 ? 10 : CLS == 2 ? 11 : 14)
   typedef ConsLdsT<SLOTS, MAXPOS, MAXOTHERS, NW, LCAP, SCAP, ECAP> Lds;
   constexpr int NT = 64 * NW;
   constexpr bool LV = LCAP > 0;

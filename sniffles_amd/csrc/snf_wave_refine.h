@@ -145,6 +145,7 @@ struct WaveLds {
 #endif
 // one block = one wave = one merged cluster per loop iteration (grid-stride over clusters)
 __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_unused) {
+  IT_SCOPE(5)
   __shared__ WaveLds lds;
   const int lane = threadIdx.x;
   const snf_config_t& cfg = v.cfg;

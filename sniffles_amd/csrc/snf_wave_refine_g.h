@@ -31,6 +31,7 @@ struct GroupLds { int32_t perm[SNF_WAVE], seg_start[SNF_WAVE], seg_key[SNF_WAVE]
 
 template <int G>
 __global__ void __launch_bounds__(SNF_WAVE) d1g_refine(const View v, int64_t n_unused) {
+  IT_SCOPE(4)
   static_assert(G == 8, "group width in use");
   constexpr int NG = SNF_WAVE / G;
   __shared__ GroupLds lds;
@@ -53,7 +54,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1g_refine(const View v, int64_t n_u
     const int64_t c = base + gi;
     bool valid = c < n_clusters && hd.n > 0;
     // clusters that do not fit a group: d1w_refine, from list 2
-    d2list_push(v, 2, valid && hd.n > G && gl == 0, (int32_t)c, lane);
+    d2list_push(v, 2, valid && hd.n > G && gl == 0, (int32_t)c, lane, hd.n);
     if (hd.n > G) valid = false;
     const int32_t lo = hd.lo, n = valid ? hd.n : 0;
     const int nmax = __builtin_amdgcn_readfirstlane(wave_max32(n));

@@ -298,3 +298,35 @@ def test_consensus_entry_point_of_the_library(simt, monkeypatch):
 
 # (The combine / edit-distance / CombineTask / genotype / extraction / BAM -> VCF / drop-in tests live in their own modules and
 # run on this same library since the serial-emulation tier was retired: tests/emu/emu.py hands out this tier.)
+
+
+def test_call_variances_on_both_sides_of_the_small_spread_path(simt, oracle_mod):
+    """util.stdev(util.trim(...)) in the call kernels takes two 32-bit sums and one fp64 division when a cluster's (trimmed) values lie
+    within 8191 of each other, the exact 128-bit form otherwise (snf_wave_call.h::wave_stdev_trim_sorted, the grouped form in
+    snf_wave_call_g.h decides for the whole wave): clusters of 5, 8, 9, 30 and 64 leads whose lengths / positions spread by 0 ... 17 000
+    (trimmed: on both sides of 8192) and 3e6, DEL (svlen and ref_start move together) and INV (position only), against the oracle - every fp64 bit."""
+    from sniffles_amd import lib as plib, records
+    leads, reads = [], []
+    base = 1_000_000
+    k = 0
+    for n in (5, 8, 9, 30, 64):
+        for spread in (0, 8191, 8192, 16380, 16384, 16390, 17000, 3_000_000):      # (a quarter is trimmed on either side: ~half the spread is what the sums see)
+            for svt in ("DEL", "INV"):
+                pos = base + k * 9_000_000
+                k += 1
+                for i in range(n):
+                    step = 0 if n == 1 else (spread * i) // (n - 1)
+                    if svt == "DEL":      # same end point: the deletions start `step` earlier and are that much longer
+                        leads.append(dict(svtype="DEL", ref_start=pos + 50 + (i % 3), svlen=-(40_000 + step), read=f"c{k}_{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+                    else:
+                        leads.append(dict(svtype="INV", ref_start=pos + (i % 3), svlen=20_000 + step, read=f"c{k}_{i}", strand="+-"[i % 2], source="SPLIT_SUP"))
+                reads += [(pos - 60_000, pos + 60_000, 0)] * 12
+    ti = cases.mk_task(leads, reads, base + (k + 1) * 9_000_000)
+    for kw in (dict(minsupport=2), dict(minsupport=2, repeat=True), dict(minsupport=2, phase=False, cluster_merge_len=50.0)):
+        cfg = SnifflesConfig(**kw)
+        got = records.records(run(simt, cfg, [ti], True), [ti], "final")
+        exp = records.records(oracle_mod.run(cfg, [ti], True), [ti], "final")
+        assert got == exp
+        assert len(exp[0]) >= 30
+        sd = sorted(float.fromhex(c["stdev_len"]) if isinstance(c["stdev_len"], str) else float(c["stdev_len"]) for c in exp[0] if c.get("stdev_len") is not None)
+        assert sd[0] < 10.0 and sd[-1] > 100_000.0      # both sides were reached

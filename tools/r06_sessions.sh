@@ -292,4 +292,23 @@ SNF_LIB_SO=$R/variants/x_ahead4.so xb ahead4_tile32 --tile 32
 SNF_LIB_SO=$R/variants/x_base.so xb base
 } 2>&1 | tee gpurun_out/ab_r06_13.log
   ;;
+22)
+# round 6, twenty-second session: per-workgroup stamps of the main kernels (tools/itrace.sh) showed d1w_refine ending with a handful of
+# waves on its largest clusters for half of its span; the hand-over lists now put items above SNF_HEAVY_N leads at the front.
+# GPU parity tests, the stamps again, same-box A/B over the threshold (0 = one class, as before)
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_zz_gpu_end_to_end.py -m gpu -x -q 2>&1 | tail -1
+bash tools/itrace.sh 2>&1 | grep -E "in flight$|d1w_refine|d2w_call|d2g_call|d1g_refine"
+SNF_HEAVY_N=0 bash tools/itrace.sh 2>&1 | grep -E "in flight$|d1w_refine|d2w_call"
+bash tools/run_ab.sh -n 2 h0:SNF_HEAVY_N=0 h24: h16:SNF_HEAVY_N=16 h32:SNF_HEAVY_N=32 2>&1 | tee gpurun_out/ab_r06_14.log
+  ;;
+23)
+# round 6, twenty-third session: the call kernels are bound by instruction issue - sums that stay below 2^32 as 32-bit DPP reductions, the
+# variance of a cluster whose values lie within 8191 of each other from two 32-bit sums and one fp64 division.  GPU parity, same-box A/B
+# against the build before (variants/pre_sums.so), kernel times from the timeline
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_zz_gpu_end_to_end.py tests/test_reference_vectors.py -m gpu -x -q 2>&1 | tail -1
+bash tools/run_ab.sh -n 3 before:SNF_LIB_SO=$R/variants/pre_sums.so after: 2>&1 | tee gpurun_out/ab_r06_15.log
+for so in $R/variants/pre_sums.so ""; do
+  SNF_LIB_SO=$so SNF_TIMELINE=1 python bench.py $Q --no-verify --steps 3 --warmup 2 --inflight 1 2>&1 | grep -E "SNF_TIMELINE.*(d2g_call|d2w_call|d1w_refine)" | tail -3
+done 2>&1 | tee -a gpurun_out/ab_r06_15.log
+  ;;
 esac
