@@ -311,4 +311,51 @@ for so in $R/variants/pre_sums.so ""; do
   SNF_LIB_SO=$so SNF_TIMELINE=1 python bench.py $Q --no-verify --steps 3 --warmup 2 --inflight 1 2>&1 | grep -E "SNF_TIMELINE.*(d2g_call|d2w_call|d1w_refine)" | tail -3
 done 2>&1 | tee -a gpurun_out/ab_r06_15.log
   ;;
+24)
+# round 6, twenty-fourth session: the streaming kernels of the front end with several items per thread (w1_hist / w3_scatter: four leads,
+# w6t_emit: two positions) - their workgroups lived one or two round trips and the kernels were as many rounds of that as the device
+# holds workgroups.  GPU parity, stamps, same-box A/B against the build before (variants/pre_wk.so), the timeline of the front end.
+# RESULT: no gain (0.942-0.946 against 0.935-0.939 ms; the workgroups live three times as long, the kernels as long as before - they
+# move ~26 B per lead at ~3 TB/s already) - taken back, the session stays as the record (profiles/ab_r06_16.log)
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_prefilter.py tests/test_zz_gpu_end_to_end.py -m gpu -x -q 2>&1 | tail -1
+bash tools/itrace.sh 2>&1 | grep -E "in flight$|w1_hist|w3_scatter|w6t_emit|w4s_segment" | head -5
+bash tools/run_ab.sh -n 3 before:SNF_LIB_SO=$R/variants/pre_wk.so after: 2>&1 | tee gpurun_out/ab_r06_16.log
+for so in $R/variants/pre_wk.so ""; do
+  SNF_LIB_SO=$so SNF_TIMELINE=1 python bench.py $Q --no-verify --steps 3 --warmup 2 --inflight 1 2>&1 | grep -E "SNF_TIMELINE.*(w1_hist|w3_scatter|w6t_emit|w4s_segment)" | tail -4
+done 2>&1 | tee -a gpurun_out/ab_r06_16.log
+  ;;
+25)
+# round 6, twenty-fifth session: the whole GPU suite on the final sources, then the profile set of the round again (the kernel sources
+# changed: extraction, hand-over lists, call kernels) - as session 8
+timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_25.log 2>&1; tail -3 gpurun_out/pytest_gpu_25.log
+timeout 1200 bash tools/profile.sh r06 > gpurun_out/profile_r06.log 2>&1; tail -5 gpurun_out/profile_r06.log
+B="python bench.py --inflight 1 --no-cpu-baseline --no-wall-clock --no-configs --genomes 4"
+O=$R/gpurun_out/prof_r06
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/pmc4_$C -o pmc -- $B --steps 2 --warmup 1 > $O/pmc4_$C.log 2>&1
+done
+python tools/pmc_parse.py $O/pmc4_FETCH_SIZE $O/pmc4_WRITE_SIZE > $O/pmc_traffic_genomes4.json; rm -rf $O/pmc4_FETCH_SIZE $O/pmc4_WRITE_SIZE
+timeout 900 bash tools/sq_all.sh > /dev/null 2>&1; cp gpurun_out/sq_all/summary.txt $O/sq_all.txt; head -30 $O/sq_all.txt
+timeout 300 python tools/bench_extract.py > $O/extract_bench.json 2> /dev/null; tail -c 1500 $O/extract_bench.json
+timeout 300 python tools/bench_extract.py --tile 32 > $O/extract_bench_96000.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/xstats -o k -- python tools/bench_extract.py --steps 5 --cpu-reads 5 > $O/xstats.log 2>&1
+cp $(find $O/xstats -name '*kernel_stats.csv' | head -1) $O/extract_kernel_stats.csv; rm -rf $O/xstats
+timeout 600 bash tools/pmc_extract.sh > /dev/null 2>&1; cp gpurun_out/pmc_extract_traffic.json $O/extract_pmc_traffic.json
+i=0
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM" \
+         "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1)); rm -rf gpurun_out/sqx_$i; mkdir -p gpurun_out/sqx_$i
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/sqx_$i -o sq -- python tools/bench_extract.py --steps 2 --cpu-reads 3 > gpurun_out/sqx_$i/bench.log 2>&1
+done
+python tools/sq_parse.py gpurun_out/sqx_1 gpurun_out/sqx_2 gpurun_out/sqx_3 > $O/extract_sq.txt; find gpurun_out/sqx_* -name '*.csv' -size +1M -delete
+SNF_LIB_SO=$R/variants/xtrace.so python tools/xtrace.py --pass count > $O/xtrace_count.txt 2>&1
+SNF_LIB_SO=$R/variants/xtrace.so python tools/xtrace.py --pass emit > $O/xtrace_emit.txt 2>&1
+bash tools/itrace.sh > /dev/null 2>&1; cp gpurun_out/itrace/itrace_1.txt $O/itrace_1_in_flight.txt; cp gpurun_out/itrace/itrace_2.txt $O/itrace_2_in_flight.txt
+ls -la $O
+  ;;
+26)
+# round 6, twenty-sixth session: the bench lines that are kept (tools/final_set.sh), on the final sources
+bash tools/final_set.sh r06 2>&1 | tail -14
+  ;;
 esac
