@@ -77,8 +77,9 @@ struct ExView {
   unsigned long long* err;   // min over (record << 8 | code); ~0: none
   // scan inputs / outputs (n_records + 1)
   int64_t *c_acc, *c_leads, *c_seq;
+  double* c_nm;                       // per record: its NM ratio if it counts for average_regional_nm (accepted, NM tag, advanced tags), else +0.0
   int64_t* c_ps; uint8_t* c_psf;      // per record: its PS tag and whether it counts (accepted, tag present) - what the host ranks
-  unsigned long long* tot;            // [0] first error (= err), [1..3] reads, leads, sequence bytes: one copy to the host
+  unsigned long long* tot;            // [0] first error (= err), [1..3] reads, leads, sequence bytes, [4] NM summands: one copy to the host
   const int64_t *read_idx, *lead_off, *seq_off;
   const int64_t* ps_val; const int32_t* ps_rank; int32_t n_ps, ps_null_rank;
   // lead columns
@@ -1000,6 +1001,14 @@ SNF_HD void x_prep_body(int64_t i, const ExView& v) {
   const bool a = i < v.n_records && v.sum[i].accept;
   v.c_acc[i] = a ? 1 : 0; v.c_leads[i] = a ? v.sum[i].n_leads : 0; v.c_seq[i] = a ? v.sum[i].seq_bytes : 0;
   if (i < v.n_records) { const bool p = a && v.sum[i].has_ps; v.c_psf[i] = p ? 1 : 0; v.c_ps[i] = p ? v.sum[i].ps : 0; }
+  const bool m = i < v.n_records && a && v.cfg.advanced_tags != 0 && v.sum[i].has_nm;
+  if (i < v.n_records) v.c_nm[i] = m ? v.sum[i].nm : 0.0;
+#if XDEV
+  const unsigned long long mm = __ballot(m);      // (one atomic per wave: the number of summands)
+  if (mm && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(mm)) atomicAdd((unsigned long long*)&v.tot[4], (unsigned long long)__popcll(mm));
+#else
+  if (m) v.tot[4]++;
+#endif
 }
 SNF_HD void x_totals_body(int64_t i, const ExView& v) {
   const int64_t n = v.n_records;
@@ -1028,33 +1037,36 @@ __global__ void __launch_bounds__(64, MINW) x_wave(const ExView v, int64_t n) {
   for (int64_t rec = (int64_t)blockIdx.x; rec < n; rec += (int64_t)gridDim.x)
     extract_record<true, EMIT>(rec, v, segs, ord, auxl, sab);
 }
-// average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64
-// adds.  One wave: 64 records are loaded per step (coalesced) and laid out in LDS, records without an NM ratio as +0.0 (the
-// sum is never -0.0, so that add is the identity); the 64 values are then folded in order - a chain of 64 dependent adds per
-// step whose operands are LDS reads at constant addresses (issued ahead of the chain; every lane folds the same values).
-// The next step's loads are in flight meanwhile.
+// average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64 adds.
+// x_prep has laid the summands out densely (a record that does not count as +0.0: the sum is never -0.0, so that add is the
+// identity).  One wave: 1024 of them per step go to LDS with coalesced loads (the next step's loads in flight meanwhile) and are
+// folded in order - a chain of dependent adds whose operands are LDS reads at constant addresses, issued ahead of the chain.
+// (64 records per step straight from the 64-byte summaries: a memory round trip per step, 0.3 ms for 24 000 records - longer
+// than either pass.)
+#define X_NM_CHUNK 1024
 __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
-  __shared__ double buf[2][64];
+  __shared__ double buf[2][X_NM_CHUNK];
   const int lane = threadIdx.x;
-  double sum = 0.0; int64_t cnt = 0;
-  const bool adv = v.cfg.advanced_tags != 0;
-  auto load = [&](int64_t i, bool& f) -> double {
-    f = adv && i < n && v.sum[i].accept && v.sum[i].has_nm;
-    return f ? v.sum[i].nm : 0.0;
-  };
-  bool f = false, fn = false;
-  double x = load(lane, f);
-  int cur = 0;
-  for (int64_t base = 0; base < n; base += 64) {
-    const double xn = load(base + 64 + lane, fn);
-    buf[cur][lane] = x;
-    x_wave_sync<true>();
-    cnt += __popcll(__ballot(f));
+  constexpr int PER = X_NM_CHUNK / 64;
+  double sum = 0.0;
+  double x[PER];
 #pragma unroll
-    for (int k = 0; k < 64; k++) sum += buf[cur][k];
-    x = xn; f = fn; cur ^= 1;
+  for (int j = 0; j < PER; j++) { const int64_t i = lane + 64 * j; x[j] = i < n ? v.c_nm[i] : 0.0; }
+  int cur = 0;
+  for (int64_t base = 0; base < n; base += X_NM_CHUNK) {
+#pragma unroll
+    for (int j = 0; j < PER; j++) buf[cur][lane + 64 * j] = x[j];
+#pragma unroll
+    for (int j = 0; j < PER; j++) { const int64_t i = base + X_NM_CHUNK + lane + 64 * j; x[j] = i < n ? v.c_nm[i] : 0.0; }
+    x_wave_sync<true>();
+    const int64_t m = n - base < X_NM_CHUNK ? n - base : X_NM_CHUNK;
+    for (int k0 = 0; k0 < (int)m; k0 += 64) {
+#pragma unroll
+      for (int k = 0; k < 64; k++) sum += buf[cur][k0 + k];      // (entries past n are +0.0)
+    }
+    cur ^= 1;
   }
-  if (lane == 0) { v.nm_out[0] = sum; v.nm_out[1] = (double)cnt; }
+  if (lane == 0) v.nm_out[0] = sum;
 }
 
 // ================================================================================================= host side ====
@@ -1089,7 +1101,7 @@ struct snf_extract {
   int device = 0;
   std::vector<void*> dev;        // device allocations of the current input / run
   XSlab run_a, run_b;            // what a run needs before / after the scans: two grow-only device blocks carved into arrays
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; hipEvent_t ev_prep = nullptr;
   size_t scan_tmp = 0; int64_t scan_n = -1;
   ExView v{};
   int64_t n_records = 0, blob_len = 0;
@@ -1228,9 +1240,9 @@ int do_run(snf_extract* x) {
   int64_t *d_read_idx = nullptr, *d_lead_off = nullptr, *d_seq_off = nullptr; void* d_tmp = nullptr;
   auto carve_a = [&](XSlab& s) {
     v.sum = s.take<RecSum>((size_t)n);
-    v.tot = s.take<unsigned long long>(4); v.err = v.tot;
+    v.tot = s.take<unsigned long long>(8); v.err = v.tot;
     v.c_acc = s.take<int64_t>(N1); v.c_leads = s.take<int64_t>(N1); v.c_seq = s.take<int64_t>(N1);
-    v.c_ps = s.take<int64_t>((size_t)n); v.c_psf = s.take<uint8_t>((size_t)n);
+    v.c_ps = s.take<int64_t>((size_t)n); v.c_psf = s.take<uint8_t>((size_t)n); v.c_nm = s.take<double>((size_t)n);
     v.nm_out = s.take<double>(2);
     d_read_idx = s.take<int64_t>(N1); d_lead_off = s.take<int64_t>(N1); d_seq_off = s.take<int64_t>(N1);
     d_tmp = s.take<uint8_t>(x->scan_tmp);
@@ -1241,7 +1253,7 @@ int do_run(snf_extract* x) {
   x->run_a.measure(); carve_a(x->run_a); x->run_a.reserve(); carve_a(x->run_a);
   v.read_idx = d_read_idx; v.lead_off = d_lead_off; v.seq_off = d_seq_off;
   const unsigned long long none = ~0ull;
-  x_h2d(v.err, &none, 8);
+  { const unsigned long long init[8] = {none, 0, 0, 0, 0, 0, 0, 0}; x_h2d(v.tot, init, 64); }      // [0] first error, [4] NM summands (x_prep)
 #ifdef SNF_XTRACE
   SNF_HIP(hipMemset(v.xtrace, 0, (size_t)(n ? n : 1) * 16));
   v.xtrace_emit = getenv("SNF_XTRACE_PASS") && !strcmp(getenv("SNF_XTRACE_PASS"), "emit");
@@ -1262,7 +1274,9 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipEventRecord(e1, 0));
   hipLaunchKernelGGL(x_prep, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, 0, v, n + 1);
   if (!x->side) SNF_HIP(hipStreamCreateWithFlags(&x->side, hipStreamNonBlocking));
-  SNF_HIP(hipStreamWaitEvent(x->side, e1, 0));
+  if (!x->ev_prep) SNF_HIP(hipEventCreateWithFlags(&x->ev_prep, hipEventDisableTiming));
+  SNF_HIP(hipEventRecord(x->ev_prep, 0));
+  SNF_HIP(hipStreamWaitEvent(x->side, x->ev_prep, 0));      // the serial sum runs beside the scans, the host round trip and the emit pass
   hipLaunchKernelGGL(x_nmsum, dim3(1), dim3(64), 0, x->side, v, n);
   {
     size_t need = x->scan_tmp;
@@ -1271,8 +1285,8 @@ int do_run(snf_extract* x) {
     SNF_HIP(rocprim::exclusive_scan(d_tmp, need, (const int64_t*)v.c_seq, d_seq_off, (int64_t)0, N1, rocprim::plus<int64_t>(), 0));
   }
   hipLaunchKernelGGL(x_totals, dim3(1), dim3(64), 0, 0, v, (int64_t)1);
-  unsigned long long tot[4] = {none, 0, 0, 0}; double nmv[2] = {0, 0};
-  x_d2h(tot, v.tot, 32);
+  unsigned long long tot[8] = {none, 0, 0, 0, 0, 0, 0, 0}; double nmv[2] = {0, 0};
+  x_d2h(tot, v.tot, 64);
   const unsigned long long err = tot[0]; const int64_t n_reads = (int64_t)tot[1], n_leads = (int64_t)tot[2], n_seq = (int64_t)tot[3];
   if (err != none) {
     const int code = (int)(err & 0xff);
@@ -1317,7 +1331,7 @@ int do_run(snf_extract* x) {
   SNF_HIP(hipStreamSynchronize(x->side));
   SNF_HIP(hipDeviceSynchronize());
   SNF_HIP(hipEventElapsedTime(&ms_count, e0, e1)); SNF_HIP(hipEventElapsedTime(&ms_emit, e2, e3));
-  x_d2h(nmv, v.nm_out, 16);
+  x_d2h(nmv, v.nm_out, 8); nmv[1] = (double)tot[4];
 #ifdef SNF_XTRACE
   if (const char* path = getenv("SNF_XTRACE_OUT")) {
     std::vector<uint32_t> t((size_t)n * 4);
@@ -1411,6 +1425,7 @@ void snf_extract_destroy(snf_extract_t* x) {
   if (!x) return;
   x_release(x->dev); x->run_a.release(); x->run_b.release();
   for (hipEvent_t e : x->ev) if (e) (void)hipEventDestroy(e);
+  if (x->ev_prep) (void)hipEventDestroy(x->ev_prep);
   if (x->side) (void)hipStreamDestroy(x->side);
   delete x;
 }

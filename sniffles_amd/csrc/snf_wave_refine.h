@@ -103,6 +103,19 @@ SNF_D void wave_copy_parts(const View& v, int lane, bool p_act, int64_t p_src, i
   }
 }
 
+// the copies d1w_refine left (View::cj_*): one wave per part, 16 bytes per lane and step, byte tail
+__global__ void __launch_bounds__(SNF_WAVE) d1c_copy(const View v, int64_t n_unused) {
+  typedef uint4 __attribute__((aligned(1))) u128_any;
+  const int lane = threadIdx.x;
+  const int64_t n = (int64_t)v.cnt->n_copy_jobs;
+  for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
+    const int64_t so = v.cj_src[j], dt = v.cj_dst[j]; const int32_t len = v.cj_len[j];
+    const int32_t nfull = len & ~15;
+    for (int32_t bb = lane * 16; bb < nfull; bb += SNF_WAVE * 16) *(u128_any*)(v.pool + dt + bb) = *(const u128_any*)(v.pool + so + bb);
+    if (nfull + lane < len) v.pool[dt + nfull + lane] = v.pool[so + nfull + lane];
+  }
+}
+
 // hand-over list 2 (clusters d1g_refine<8> left to d1w_refine): 64 stripes with a counter each, as the lists of the call kernels
 // (snf_wave_call.h); consumer side: prefix of the stripes' counts in LDS, item i = entry i - pre[s] of stripe s
 SNF_D int64_t d1list_prefix(const View& v, int lane, int32_t* pre) {
@@ -267,7 +280,20 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         const int my_start = (act && (smask & upto)) ? 63 - __builtin_clzll(smask & upto) : 0;
         const bool p_act = act && __shfl((int)need_copy, my_start, SNF_WAVE) != 0;
         const int64_t p_dst = __shfl(new_off, my_start, SNF_WAVE) + (x_seq - __shfl(x_seq, my_start, SNF_WAVE));
-        wave_copy_parts(v, lane, p_act, s_seq_off, p_act ? s_seq_len : 0, p_dst);
+        const int32_t p_len = p_act ? s_seq_len : 0;
+        const unsigned long long jm = __ballot(p_act && p_len > 0);
+        if (v.cj_min > 0 && __builtin_popcountll(jm) > v.cj_min) {
+          // many parts (a cluster of 64 leads of 32 reads: 64 parts = sixteen rounds of four, a memory round trip each - 40 us on ONE wave
+          // while the kernel's other waves have long finished): left to d1c_copy, where every part has a wave of its own
+          const int leader = __builtin_ctzll(jm);
+          unsigned long long at = 0;
+          if (lane == leader) at = atomicAdd(&v.cnt->n_copy_jobs, (unsigned long long)__builtin_popcountll(jm));
+          at = (unsigned long long)wave_bcast_u64(at, leader);
+          if (p_act && p_len > 0) {
+            const int64_t j = (int64_t)at + __builtin_popcountll(jm & ((1ull << lane) - 1ull));
+            v.cj_src[j] = s_seq_off; v.cj_dst[j] = p_dst; v.cj_len[j] = p_len;
+          }
+        } else wave_copy_parts(v, lane, p_act, s_seq_off, p_len, p_dst);
       }
       const bool ok_seq = start && seq_ok && (nparts == 1 || need_copy);
       // compact the fused leads (start lanes) to lanes 0..m-1

@@ -330,3 +330,36 @@ def test_call_variances_on_both_sides_of_the_small_spread_path(simt, oracle_mod)
         assert len(exp[0]) >= 30
         sd = sorted(float.fromhex(c["stdev_len"]) if isinstance(c["stdev_len"], str) else float(c["stdev_len"]) for c in exp[0] if c.get("stdev_len") is not None)
         assert sd[0] < 10.0 and sd[-1] > 100_000.0      # both sides were reached
+
+
+@pytest.mark.parametrize("defer", [None, "0", "3"])
+def test_fused_sequences_of_many_parts_are_copied_by_the_copy_kernel(defer, simt, oracle_mod, monkeypatch):
+    """merge_inner's fused sequences (cluster.py:85-122): a cluster that fuses more than View::cj_min parts (default 8) leaves the byte
+    copies to d1c_copy (one wave per part) instead of making them inside its own wave.  Clusters of 24-31 reads with two and three pieces
+    each (48-62 leads), pieces of 1 .. 2100 bases (odd tails, more than 1 KB), one piece without a sequence; a small cluster beside them
+    that copies in place.  The ALT sequences (consensus over the fused reads, or the best fused read verbatim) come out of those bytes:
+    every record against the oracle; SNF_COPY_DEFER=0 (never) and =3 (almost always) must give the same."""
+    from sniffles_amd import records
+    if defer is not None:
+        monkeypatch.setenv("SNF_COPY_DEFER", defer)
+    rng = np.random.default_rng(5)
+    leads, reads = [], []
+    for c, (n_reads, pieces, plen) in enumerate([(24, 2, 180), (31, 2, 1100), (16, 3, 37), (4, 2, 2100), (20, 3, 1)]):
+        pos = 20_000 + 40_000 * c
+        allele = cases._rng_seq(rng, pieces * plen)
+        for r in range(n_reads):
+            q = 3000 + 11 * r
+            for k in range(pieces):
+                seq = cases._mutate(rng, allele[k * plen:(k + 1) * plen], 0.02)[:plen] or "A"
+                if c == 0 and r == 5 and k == 1:
+                    seq = None
+                leads.append(dict(svtype="INS", ref_start=pos + 20 * k + (r % 3), svlen=plen, read=f"m{c}_{r}", qry_start=q + k * (plen + 40),
+                                  qry_end=q + k * (plen + 40) + plen, seq=seq, strand="+-"[r % 2]))
+        reads += [(pos - 5000, pos + 5000, 0)] * (n_reads + 6)
+    ti = cases.mk_task(leads, reads, 260_000)
+    for kw in (dict(minsupport=2), dict(minsupport=2, no_consensus=True)):
+        cfg = SnifflesConfig(**kw)
+        got = records.records(run(simt, cfg, [ti], True), [ti], "final")
+        exp = records.records(oracle_mod.run(cfg, [ti], True), [ti], "final")
+        assert got == exp
+        assert sum(1 for c in exp[0] if c["svtype"] == "INS" and c.get("alt")) >= 4
