@@ -1038,14 +1038,15 @@ __global__ void __launch_bounds__(64, MINW) x_wave(const ExView v, int64_t n) {
     extract_record<true, EMIT>(rec, v, segs, ord, auxl, sab);
 }
 // average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64 adds.
-// x_prep has laid the summands out densely (a record that does not count as +0.0: the sum is never -0.0, so that add is the
-// identity).  One wave: 1024 of them per step go to LDS with coalesced loads (the next step's loads in flight meanwhile) and are
-// folded in order - a chain of dependent adds whose operands are LDS reads at constant addresses, issued ahead of the chain.
-// (64 records per step straight from the 64-byte summaries: a memory round trip per step, 0.3 ms for 24 000 records - longer
-// than either pass.)
+// x_prep has laid the summands out densely (a record that does not count as +0.0).  Adding a zero is the identity here - the sum starts
+// at +0.0 and no summand is -0.0 (an integer over a positive integer), so it is never -0.0 itself - which is why zeros may be left out.
+// One wave: 1024 values per step (coalesced loads, the next step's in flight meanwhile), the non-zero ones compacted in order into LDS,
+// then folded - a chain of dependent adds (~19 cycles each on a lone wave: the floor of this kernel) whose operands are requested sixteen
+// ahead.  (64 records per step straight from the 64-byte summaries through 128 v_readlanes: 0.40 ms for 24 000 records - longer than
+// either pass; now 0.1 ms.)
 #define X_NM_CHUNK 1024
 __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
-  __shared__ double buf[2][X_NM_CHUNK];
+  __shared__ double buf[2][X_NM_CHUNK + 32];
   const int lane = threadIdx.x;
   constexpr int PER = X_NM_CHUNK / 64;
   double sum = 0.0;
@@ -1054,15 +1055,35 @@ __global__ void __launch_bounds__(64) x_nmsum(const ExView v, int64_t n) {
   for (int j = 0; j < PER; j++) { const int64_t i = lane + 64 * j; x[j] = i < n ? v.c_nm[i] : 0.0; }
   int cur = 0;
   for (int64_t base = 0; base < n; base += X_NM_CHUNK) {
+    // the chunk's summands that are not zero, in order (adding a zero is the identity - see above -, and four records in ten do not count
+    // at all): row j of the chunk is the 64 values x[j] of the lanes; a ballot and a prefix count give every value its place
+    int cnt = 0;
 #pragma unroll
-    for (int j = 0; j < PER; j++) buf[cur][lane + 64 * j] = x[j];
+    for (int j = 0; j < PER; j++) {
+      const unsigned long long mk = __ballot(x[j] != 0.0);
+      if (x[j] != 0.0) buf[cur][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = x[j];
+      cnt += __popcll(mk);
+    }
+    if (lane < 32) buf[cur][cnt + lane] = 0.0;      // (the fold reads sixteen at a time, sixteen ahead)
 #pragma unroll
     for (int j = 0; j < PER; j++) { const int64_t i = base + X_NM_CHUNK + lane + 64 * j; x[j] = i < n ? v.c_nm[i] : 0.0; }
     x_wave_sync<true>();
-    const int64_t m = n - base < X_NM_CHUNK ? n - base : X_NM_CHUNK;
-    for (int k0 = 0; k0 < (int)m; k0 += 64) {
+    // sixteen summands in registers, the next sixteen requested before the first is added (left to itself the compiler reads two
+    // values, waits for them, adds them, reads the next two: an LDS round trip per pair - 34 cycles per summand, 0.34 ms for 24 000)
+    const double* B = buf[cur];
+    double a[16], nx[16];
 #pragma unroll
-      for (int k = 0; k < 64; k++) sum += buf[cur][k0 + k];      // (entries past n are +0.0)
+    for (int j = 0; j < 16; j++) a[j] = B[j];
+    for (int k0 = 0; k0 < cnt; k0 += 16) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) nx[j] = B[k0 + 16 + j];
+#if XDEV
+      asm volatile("" ::: "memory");      // the reads stay in front of the adds
+#endif
+#pragma unroll
+      for (int j = 0; j < 16; j++) sum += a[j];
+#pragma unroll
+      for (int j = 0; j < 16; j++) a[j] = nx[j];
     }
     cur ^= 1;
   }

@@ -1032,8 +1032,6 @@ void do_upload(snf_batch_impl* b) {
   for (int k = 0; k < 3; k++) v.d2_list[k] = dalloc<int32_t>(b, (size_t)(64 * v.d2cap));
   v.d2cnt = dalloc<uint32_t>(b, 3 * 64 * 16);
   v.d2_from_list = 0; v.d1_from_list = 0;
-  { const int cm = getenv("SNF_COPY_DEFER") ? atoi(getenv("SNF_COPY_DEFER")) : 8; v.cj_min = cm > 0 ? cm : 0; }      // (0: every cluster copies its own parts)
-  v.cj_src = dalloc<int64_t>(b, N1); v.cj_dst = dalloc<int64_t>(b, N1); v.cj_len = dalloc<int32_t>(b, N1);
 #ifdef SNF_ITRACE
   if (!v.itrace) { SNF_HIP(hipMalloc((void**)&v.itrace, (size_t)SNF_IT_SLOTS * SNF_IT_CAP * 8)); SNF_HIP(hipMemset(v.itrace, 0, (size_t)SNF_IT_SLOTS * SNF_IT_CAP * 8)); }
 #endif
@@ -1453,11 +1451,6 @@ void run_call_candidates(snf_batch_impl* b) {
     } else if (v.wave_path) {
       Scope _s(b, "d1w_refine", N * 36);
       hipLaunchKernelGGL(d1w_refine, dim3(b->slots_d1w), dim3(64), 0, b->cur, v, (int64_t)0);
-      SNF_HIP(hipGetLastError());
-    }
-    if (v.wave_path && v.cj_min > 0) {      // the fused-sequence copies d1w_refine left behind (nothing reads those bytes before the ALT stage)
-      Scope _s(b, "d1c_copy", 0);
-      hipLaunchKernelGGL(d1c_copy, dim3(1024), dim3(64), 0, b->cur, v, (int64_t)0);
       SNF_HIP(hipGetLastError());
     }
     if (!(v.wave_path && b->fused)) LAUNCH_Q(d1_refine, v, N, v.wave_path ? 0 : N * 36);   // (next to the wave kernels every item would return at once)

@@ -26,7 +26,6 @@ struct Counts {
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
                                     // 7 ROWS (aligned rows in HBM: beyond the LDS vote counters, or handed over by SMALL / LARGE at run time)
   unsigned long long pool_extra_used;
-  unsigned long long n_copy_jobs;   // parts of fused sequences d1w_refine left to d1c_copy (View::cj_*)
 #ifdef SNF_CONS_PROFILE
   unsigned long long dbg[32];       // instrumented build only: cycles per phase of the consensus kernels (tools/cons_profile.sh)
 #endif
@@ -298,9 +297,6 @@ struct View {
   int64_t big_cap;
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
   int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32, 64; default 64)
-  // merge_inner's fused sequences: a cluster that fuses more than cj_min parts leaves their copies to d1c_copy (source, destination, length
-  // per part; at most one part per lead) instead of making them four at a time inside its own wave
-  int64_t *cj_src, *cj_dst; int32_t* cj_len; int32_t cj_min, _pad_cj;
   int32_t heavy_n;           // hand-over lists: an item with more leads than this goes into the first 16 stripes, i.e. to the FRONT of the index
                              // space the next kernel walks (its workgroups start in index order: the long items first, not last); 0: off
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative

@@ -71,7 +71,9 @@ SNF_D void big_push(const View& v, int kind, int32_t item) {
 // the input pool to its place in the fused lead's slice, all 64 lanes on one part at a time.  The parts are taken FOUR at a time: their
 // loads are requested together and stored together.  (One part after the other - load, store, next part - was a dependent round trip per
 // part: ~100 us per fusing cluster, a third of a wave's time in d1w_refine; source and destination never overlap - the slices lie behind
-// the input sequences.)
+// the input sequences.)  Measured and not kept (round 6, profiles/ab_r06_17.log): clusters with more than eight parts leaving their copies
+// to a copy kernel of their own behind d1w_refine (a wave per part) - the one workgroup d1w_refine ends with goes from 72 to 46-55 us,
+// the kernel from 72 to 63-67, and the copy kernel's launch costs the chain the 11 us back: 0.932-0.934 against 0.935-0.937 ms per step.
 SNF_D void wave_copy_parts(const View& v, int lane, bool p_act, int64_t p_src, int32_t p_len, int64_t p_dst) {
   typedef uint4 __attribute__((aligned(1))) u128_any;
   unsigned long long pm = __ballot(p_act && p_len > 0);
@@ -100,19 +102,6 @@ SNF_D void wave_copy_parts(const View& v, int lane, bool p_act, int64_t p_src, i
       for (int32_t bb = SNF_WAVE * 16 + lane * 16; bb < nfull; bb += SNF_WAVE * 16)      // (sequences beyond 1 KB: the rest, 1 KB per step)
         *(u128_any*)(v.pool + dt[k] + bb) = *(const u128_any*)(v.pool + so[k] + bb);
     }
-  }
-}
-
-// the copies d1w_refine left (View::cj_*): one wave per part, 16 bytes per lane and step, byte tail
-__global__ void __launch_bounds__(SNF_WAVE) d1c_copy(const View v, int64_t n_unused) {
-  typedef uint4 __attribute__((aligned(1))) u128_any;
-  const int lane = threadIdx.x;
-  const int64_t n = (int64_t)v.cnt->n_copy_jobs;
-  for (int64_t j = blockIdx.x; j < n; j += gridDim.x) {
-    const int64_t so = v.cj_src[j], dt = v.cj_dst[j]; const int32_t len = v.cj_len[j];
-    const int32_t nfull = len & ~15;
-    for (int32_t bb = lane * 16; bb < nfull; bb += SNF_WAVE * 16) *(u128_any*)(v.pool + dt + bb) = *(const u128_any*)(v.pool + so + bb);
-    if (nfull + lane < len) v.pool[dt + nfull + lane] = v.pool[so + nfull + lane];
   }
 }
 
@@ -280,20 +269,7 @@ __global__ void __launch_bounds__(SNF_WAVE) d1w_refine(const View v, int64_t n_u
         const int my_start = (act && (smask & upto)) ? 63 - __builtin_clzll(smask & upto) : 0;
         const bool p_act = act && __shfl((int)need_copy, my_start, SNF_WAVE) != 0;
         const int64_t p_dst = __shfl(new_off, my_start, SNF_WAVE) + (x_seq - __shfl(x_seq, my_start, SNF_WAVE));
-        const int32_t p_len = p_act ? s_seq_len : 0;
-        const unsigned long long jm = __ballot(p_act && p_len > 0);
-        if (v.cj_min > 0 && __builtin_popcountll(jm) > v.cj_min) {
-          // many parts (a cluster of 64 leads of 32 reads: 64 parts = sixteen rounds of four, a memory round trip each - 40 us on ONE wave
-          // while the kernel's other waves have long finished): left to d1c_copy, where every part has a wave of its own
-          const int leader = __builtin_ctzll(jm);
-          unsigned long long at = 0;
-          if (lane == leader) at = atomicAdd(&v.cnt->n_copy_jobs, (unsigned long long)__builtin_popcountll(jm));
-          at = (unsigned long long)wave_bcast_u64(at, leader);
-          if (p_act && p_len > 0) {
-            const int64_t j = (int64_t)at + __builtin_popcountll(jm & ((1ull << lane) - 1ull));
-            v.cj_src[j] = s_seq_off; v.cj_dst[j] = p_dst; v.cj_len[j] = p_len;
-          }
-        } else wave_copy_parts(v, lane, p_act, s_seq_off, p_len, p_dst);
+        wave_copy_parts(v, lane, p_act, s_seq_off, p_act ? s_seq_len : 0, p_dst);
       }
       const bool ok_seq = start && seq_ok && (nparts == 1 || need_copy);
       // compact the fused leads (start lanes) to lanes 0..m-1

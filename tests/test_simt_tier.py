@@ -332,16 +332,12 @@ def test_call_variances_on_both_sides_of_the_small_spread_path(simt, oracle_mod)
         assert sd[0] < 10.0 and sd[-1] > 100_000.0      # both sides were reached
 
 
-@pytest.mark.parametrize("defer", [None, "0", "3"])
-def test_fused_sequences_of_many_parts_are_copied_by_the_copy_kernel(defer, simt, oracle_mod, monkeypatch):
-    """merge_inner's fused sequences (cluster.py:85-122): a cluster that fuses more than View::cj_min parts (default 8) leaves the byte
-    copies to d1c_copy (one wave per part) instead of making them inside its own wave.  Clusters of 24-31 reads with two and three pieces
-    each (48-62 leads), pieces of 1 .. 2100 bases (odd tails, more than 1 KB), one piece without a sequence; a small cluster beside them
-    that copies in place.  The ALT sequences (consensus over the fused reads, or the best fused read verbatim) come out of those bytes:
-    every record against the oracle; SNF_COPY_DEFER=0 (never) and =3 (almost always) must give the same."""
+def test_fused_sequences_of_many_parts(simt, oracle_mod):
+    """merge_inner's fused sequences (cluster.py:85-122) in clusters that fuse many reads at once (wave_copy_parts takes the parts four at
+    a time): clusters of 24-31 reads with two and three pieces each (48-62 leads), pieces of 1 .. 2100 bases (odd tails, more than 1 KB),
+    one piece without a sequence; a small cluster beside them.  The ALT sequences (consensus over the fused reads, or the best fused read
+    verbatim) come out of those bytes: every record against the oracle."""
     from sniffles_amd import records
-    if defer is not None:
-        monkeypatch.setenv("SNF_COPY_DEFER", defer)
     rng = np.random.default_rng(5)
     leads, reads = [], []
     for c, (n_reads, pieces, plen) in enumerate([(24, 2, 180), (31, 2, 1100), (16, 3, 37), (4, 2, 2100), (20, 3, 1)]):

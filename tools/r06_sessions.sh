@@ -358,4 +358,17 @@ ls -la $O
 # round 6, twenty-sixth session: the bench lines that are kept (tools/final_set.sh), on the final sources
 bash tools/final_set.sh r06 2>&1 | tail -14
   ;;
+27)
+# round 6, twenty-seventh session: fused-sequence copies of clusters with more than SNF_COPY_DEFER parts left to a copy kernel (the one
+# workgroup d1w_refine ended with, 70 us, made sixteen rounds of four copies); the extraction's serial NM sum over a dense array
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_zz_gpu_end_to_end.py tests/test_extract_gpu.py -m gpu -x -q 2>&1 | tail -1
+bash tools/itrace.sh 2>&1 | grep -E "in flight$|d1w_refine"
+SNF_COPY_DEFER=0 bash tools/itrace.sh 2>&1 | grep -E "in flight$|d1w_refine"
+bash tools/run_ab.sh -n 3 inline:SNF_COPY_DEFER=0 defer8: defer16:SNF_COPY_DEFER=16 2>&1 | tee gpurun_out/ab_r06_17.log
+for d in 0 8; do SNF_COPY_DEFER=$d SNF_TIMELINE=1 python bench.py $Q --no-verify --steps 3 --warmup 2 --inflight 1 2>&1 | grep -E "SNF_TIMELINE.*(d1w_refine|d1c_copy|d1g_refine)" | tail -3; done 2>&1 | tee -a gpurun_out/ab_r06_17.log
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/xstats27 -o k -- python tools/bench_extract.py --steps 5 --cpu-reads 5 > gpurun_out/xstats27.log 2>&1
+head -6 $(find gpurun_out/xstats27 -name '*kernel_stats.csv' | head -1) | cut -c1-120 | tee -a gpurun_out/ab_r06_17.log
+python tools/bench_extract.py --steps 8 --cpu-reads 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('extract count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3))" | tee -a gpurun_out/ab_r06_17.log
+rm -rf gpurun_out/xstats27
+  ;;
 esac
