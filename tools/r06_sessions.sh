@@ -371,4 +371,21 @@ head -6 $(find gpurun_out/xstats27 -name '*kernel_stats.csv' | head -1) | cut -c
 python tools/bench_extract.py --steps 8 --cpu-reads 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('extract count', round(d['ms_count_pass'],4), 'emit', round(d['ms_emit_pass'],4), 'run wall', round(d['wall_ms_run_incl_scans_and_result_copy'],3))" | tee -a gpurun_out/ab_r06_17.log
 rm -rf gpurun_out/xstats27
   ;;
+28)
+# round 6, twenty-eighth session: LARGE consensus alone is as long as its longest call (itrace: the heaviest call runs 184 us of the kernel's
+# 196) - eight waves per call (SNF_CONS_LARGE_NW=8) measured again under the staged result; then the default line once more, now that
+# profiles/r06_profile_meta.json carries the hash of the built sources (the line quotes the rocprofv3 average only then)
+bash tools/run_ab.sh -n 2 nw4: nw8:SNF_CONS_LARGE_NW=8 2>&1 | tee gpurun_out/ab_r06_18.log
+python - <<'PY' | tee -a gpurun_out/ab_r06_18.log
+import json, glob
+for f in sorted(glob.glob("gpurun_out/ab/nw*_2.json")) + sorted(glob.glob("gpurun_out/ab/nw*_1.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]
+        print(f.split("/")[-1], "ms_per_step", round(d["ms_per_step"], 3), "LARGE ms", r.get("kernel_ms"), "frac", r.get("frac"))
+    except Exception as e: print(f, "unreadable", e)
+PY
+mkdir -p gpurun_out/final_r06
+python bench.py 2> gpurun_out/final_r06/default.err | grep '^{"metric"' | tail -1 > gpurun_out/final_r06/default.json
+python -c "import json; d=json.load(open('gpurun_out/final_r06/default.json')); r=d['roofline']; print('default', d['ms_per_step'], r['kernel'], r['kernel_ms'], r['frac'], r.get('rocprof_ms'), r.get('rocprof_frac'), d.get('verified'), (d.get('verified_vs_reference') or {}).get('ok'))"
+  ;;
 esac
