@@ -312,6 +312,8 @@ struct snf_batch_impl {
   // kernels behind their producers (SNF_STAGE_COPY=kernel: z2_stage_copy reads the sizes on the device)
   bool staged = false; bool staged_kernel = false, stage_block_copied = false, stage_alt_copied = false;
   bool graph_failed = false;      // a capture / instantiate error: eager from then on (reported once with SNF_PROF)
+  bool w4_split = false;          // SNF_W4_SPLIT=1 sets it (read when the batch is opened)
+  int64_t h_n_big64 = 0;          // windows of more than 64 leads (counted at upload): upper bound of the blocks the large instance of w4s_segment gets
   int64_t h_n_occ = 0; int win_cap = 0;   // window front end: occupied windows (a property of the input, counted at upload), instance of w4 / w6
   bool reads_ready = false;       // the read index (sorted ends, hap prefix counts) of the uploaded tasks exists
   bool cov_avg_ready = false;     // a call_candidates pass has formed coverage.mean() per task
@@ -1063,7 +1065,7 @@ void do_upload(snf_batch_impl* b) {
     // 1024-lead one; occupied windows and the largest window are properties of the input (counted here, like NS): the passes size
     // their launches on the host
     int forced = getenv("SNF_WIN_BITS") ? atoi(getenv("SNF_WIN_BITS")) : 0;
-    int best_w = -1; int64_t best_occ = 0, best_max = 0;
+    int best_w = -1; int64_t best_occ = 0, best_max = 0, best_big = 0;
     std::vector<int64_t> off;
     if (forced && (forced < WIN_W_MIN || forced > WIN_W_MAX)) forced = 0;
     for (int W = forced ? forced : WIN_W_MAX; W >= (forced ? forced : WIN_W_MIN); W--) {
@@ -1079,15 +1081,18 @@ void do_upload(snf_batch_impl* b) {
       d2h(b, &hc, v.cnt, sizeof(Counts));
       dzero(b, v.wcnt, ((size_t)v.NW + 1) * 4);
       dsync(b);
-      if (hc.max_win <= 256 || (best_w < 0 && hc.max_win <= SNF_WIN_MAXCAP)) { best_w = W; best_occ = hc.n_occ; best_max = hc.max_win; }
+      if (hc.max_win <= 256 || (best_w < 0 && hc.max_win <= SNF_WIN_MAXCAP)) { best_w = W; best_occ = hc.n_occ; best_max = hc.max_win; best_big = hc.n_big64; }
       if (hc.max_win <= 256) break;
     }
     if (best_w >= 0) {
       if (v.win_bits != best_w) { v.NW = win_layout(best_w, off); v.win_bits = best_w; v.t_win_off = upload_vec(b, off); dsync(b); }
       v.front = 1; b->h_n_occ = best_occ; b->win_cap = best_max <= 64 ? 64 : best_max <= 256 ? 256 : SNF_WIN_MAXCAP;
+      b->h_n_big64 = best_big; v.w4_list = dalloc<int32_t>(b, (size_t)best_big + 64); v.w4_mode = 0;
+      b->w4_split = getenv("SNF_W4_SPLIT") && atoi(getenv("SNF_W4_SPLIT")) != 0;
     }
-    if (v.prof) fprintf(stderr, "[SNF_PROF] window front end: %s (W = %d: %lld windows, %lld occupied, largest %lld leads)\n", v.front ? "on" : "off",
-                        v.win_bits, (long long)v.NW, (long long)best_occ, (long long)best_max);
+    if (v.prof) fprintf(stderr, "[SNF_PROF] window front end: %s (W = %d: %lld windows, %lld occupied, largest %lld leads, %lld of more than 64: w4s_segment in %s)\n", v.front ? "on" : "off",
+                        v.win_bits, (long long)v.NW, (long long)best_occ, (long long)best_max, (long long)best_big,
+                        (b->w4_split && b->win_cap > 64 && best_big > 0 && best_big * 8 < (N + 63) / 64) ? "two launches" : "one launch");
   }
   const double t_winsel = now_ms();
   {  // ALT stage output (HBM; every ALT is the sequence of one lead of its cluster, so all of them together fit the pool) and
@@ -1345,9 +1350,24 @@ void enqueue_window_front(snf_batch_impl* b) {
   else { FUSED(w2a_sums, NW); FUSED(w2b_offsets, NW); }
   LAUNCH_Q(w3_scatter, v, N, 0);
   const int64_t n_blk = (N + 63) / 64;      // waves of w4s_segment: one per 64 positions of the bucket array
+  // SNF_W4_SPLIT=1: two launches when few blocks need more than the 64-lead instance (82 registers and 3.6 KB of LDS against 98 and 8.6 KB:
+  // six waves per SIMD instead of four, two unrolled rounds instead of five): the small instance over every block, the large one over the
+  // list of blocks the small one left - at most as many as the input has windows of more than 64 leads (counted at upload).  Measured on the
+  // 30x genome (profiles/ab_r06_19.log): 4 700-4 900 workgroups in flight instead of 3 800-4 000, each 5-10 % slower - the kernel is bound
+  // by instruction issue -, 6 % of the blocks go through the list behind a gap: 84.7 against 82.2 us, the step 0.911-0.913 against
+  // 0.917-0.939 ms with two passes in flight, 1.344-1.351 against 1.325-1.344 with one.  Not the default.
+  const bool split = b->w4_split && b->win_cap > 64 && b->h_n_big64 > 0 && b->h_n_big64 * 8 < n_blk;
   {
     Scope* sc = b->time_all ? new Scope(b, "w4s_segment", 0) : nullptr;
-    if (b->win_cap == 64) hipLaunchKernelGGL(w4s_segment<64>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
+    if (split) {
+      v.w4_mode = 1;
+      hipLaunchKernelGGL(w4s_segment<64>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
+      v.w4_mode = 2;
+      if (b->win_cap == 256) hipLaunchKernelGGL(w4s_segment<256>, dim3((unsigned)b->h_n_big64), dim3(64), 0, b->cur, v, (int64_t)0);
+      else hipLaunchKernelGGL(w4s_segment<SNF_WIN_MAXCAP>, dim3((unsigned)b->h_n_big64), dim3(64), 0, b->cur, v, (int64_t)0);
+      v.w4_mode = 0;
+    }
+    else if (b->win_cap == 64) hipLaunchKernelGGL(w4s_segment<64>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
     else if (b->win_cap == 256) hipLaunchKernelGGL(w4s_segment<256>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
     else hipLaunchKernelGGL(w4s_segment<SNF_WIN_MAXCAP>, dim3((unsigned)n_blk), dim3(64), 0, b->cur, v, (int64_t)0);
     delete sc;

@@ -86,9 +86,11 @@ __global__ void __launch_bounds__(256) w0_stats(const View v, int64_t n) {
   uint32_t m = c;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const uint32_t y = (uint32_t)__shfl_xor((int)m, d, 64); if (y > m) m = y; }
+  const unsigned long long big = __ballot(c > 64u);
   if ((threadIdx.x & 63) == 0 && occ) {
     atomicAdd((unsigned long long*)&v.cnt->n_occ, (unsigned long long)__popcll(occ));
     atomicMax((unsigned long long*)&v.cnt->max_win, (unsigned long long)m);
+    if (big) atomicAdd((unsigned long long*)&v.cnt->n_big64, (unsigned long long)__popcll(big));
   }
 }
 
@@ -203,7 +205,12 @@ __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused
   __shared__ uint32_t sA[CAPW], sB[CAPW];      // per bin (at its head position): leads | leads with a length << 16;  hap 1 | hap 2 << 16
   __shared__ uint32_t wS[64], wG[64], wB[64];  // per window of the wave: first position (relative), group, first bin
   const int lane = threadIdx.x;
-  const int64_t i = blockIdx.x, B0 = 64 * i;
+  int64_t i = blockIdx.x;
+  if (v.w4_mode == 2) {      // the blocks the small instance left (their number is known on the device only: the grid is the host's upper bound)
+    if (i >= (int64_t)v.cnt->n_w4big) return;
+    i = v.w4_list[i];
+  }
+  const int64_t B0 = 64 * i;
   const int64_t n_valid = v.cnt->n_valid;
   // the first 64 positions are this block's own: their words are requested before the wave knows which of them it owns
   uint64_t w0 = 0;
@@ -216,6 +223,12 @@ __global__ void __launch_bounds__(64) w4s_segment(const View v, int64_t n_unused
   if (lane < nw) wr = ((const uint4*)v.wlist)[k0 + lane];
   const int xlo = (int)((int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)wr.z) - B0);                 // owned positions: [xlo, xhi)
   const int xhi = (int)((int64_t)(uint32_t)__builtin_amdgcn_readlane((int)(wr.z + wr.y), nw - 1) - B0);   // <= 63 + CAP
+  if (v.w4_mode == 1 && __shfl(wave_incl_max(lane < nw ? (int)wr.y : 0), 63, 64) > CAP) {
+    // one of its windows holds more than CAP leads (the LDS rows and the pad behind the keys are sized for CAP): the large
+    // instance's, through the list - at most as many blocks as the input has such windows
+    if (lane == 0) v.w4_list[atomicAdd(&v.cnt->n_w4big, 1ull)] = (int32_t)i;
+    return;
+  }
   uint64_t wd[E];
   wd[0] = w0;
 #pragma unroll

@@ -21,6 +21,8 @@ struct Counts {
   int64_t n_big[3];          // items the wave kernels handed to x_big<0 / 1 / 2> in this pass (sums of View::big_cnt, formed by z1_results)
   int64_t n_occ;             // window front end (snf_stage_window.h): occupied windows of this pass
   int64_t max_win;           // ... and the largest window (only formed at upload, w0_stats)
+  int64_t n_big64;           // ... and the windows of more than 64 leads (upload): at most that many blocks need the large instance of w4s_segment
+  unsigned long long n_w4big;       // blocks the small instance of w4s_segment handed on in this pass (View::w4_list)
   int64_t n_cons_fallback;   // consensus calls that do not fit the LDS workgroup kernel
   unsigned long long cons_bytes[4]; // algorithmic bytes of the ALT stage per class (0 fallback, 1 small, 2 large, 3 copy)
   unsigned long long n_cls[8];      // ALT work lists: 0 verbatim copy, 1 SMALL, 2-5 LARGE by work (2 = heaviest), 6 thread-kernel fallback,
@@ -297,6 +299,9 @@ struct View {
   int64_t big_cap;
   int32_t big_wave;          // 1: the thread kernels leave the items above to x_big
   int32_t e1_batch;          // calls per wave of e1w_finalize (SNF_E1_BATCH env: 2, 4, 8, 16, 32, 64; default 64)
+  // w4s_segment in two launches: the 64-lead instance over every block (mode 1: a block whose last window does not fit appends itself to
+  // w4_list and leaves), the large instance over that list (mode 2); mode 0: one launch of one instance
+  int32_t* w4_list; int32_t w4_mode, _pad_w4;
   int32_t heavy_n;           // hand-over lists: an item with more leads than this goes into the first 16 stripes, i.e. to the FRONT of the index
                              // space the next kernel walks (its workgroups start in index order: the long items first, not last); 0: off
   int32_t wave_uniform;      // 1 (only inside x_big): the 64 lanes of the wave run the serial body in lock step; sorts are cooperative

@@ -78,7 +78,8 @@ def test_cluster_views_keep_their_ids_behind_the_prefilter():
 
 # ---- the window front end (snf_stage_window.h), the sort path it replaces, and the scan chains in both forms
 FRONT_VARIANTS = [dict(SNF_CHAIN="0"), dict(SNF_CHAIN="1"), dict(SNF_NO_WINFRONT="1"), dict(SNF_WIN_BITS="6"), dict(SNF_WIN_BITS="8", SNF_CHAIN="0"),
-                  dict(SNF_WIN_BITS_MAX="12"), dict(SNF_GRAPH="1", SNF_CHAIN="1"), dict(SNF_GRAPH="1", SNF_CHAIN="0")]
+                  dict(SNF_WIN_BITS_MAX="12"), dict(SNF_WIN_BITS="11", SNF_W4_SPLIT="1"), dict(SNF_WIN_BITS="11"),
+                  dict(SNF_GRAPH="1", SNF_CHAIN="1"), dict(SNF_GRAPH="1", SNF_CHAIN="0")]
 
 
 def check_front_variants(L, oracle_mod, monkeypatch, env, passes=3):
@@ -100,10 +101,14 @@ def check_front_variants(L, oracle_mod, monkeypatch, env, passes=3):
             assert records.records(b.fetch(1), tis, "final") == exp
 
 
-@pytest.mark.parametrize("env", FRONT_VARIANTS[:6])
-def test_front_end_and_scan_chain_variants_are_exact_emu(oracle_mod, monkeypatch, env):
+@pytest.mark.parametrize("env", FRONT_VARIANTS[:8])
+def test_front_end_and_scan_chain_variants_are_exact_emu(oracle_mod, monkeypatch, env, capfd):
     import emu.emu as E
+    monkeypatch.setenv("SNF_PROF", "1")
     check_front_variants(E.lib(), oracle_mod, monkeypatch, env, passes=2)
+    err = capfd.readouterr().err
+    if env.get("SNF_WIN_BITS") == "11":      # windows of more than 64 leads exist: w4s_segment's small instance + the large one over a list, or one launch
+        assert ("w4s_segment in two launches" in err) == ("SNF_W4_SPLIT" in env), err[-600:]
 
 
 @pytest.mark.gpu

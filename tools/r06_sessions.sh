@@ -388,4 +388,13 @@ mkdir -p gpurun_out/final_r06
 python bench.py 2> gpurun_out/final_r06/default.err | grep '^{"metric"' | tail -1 > gpurun_out/final_r06/default.json
 python -c "import json; d=json.load(open('gpurun_out/final_r06/default.json')); r=d['roofline']; print('default', d['ms_per_step'], r['kernel'], r['kernel_ms'], r['frac'], r.get('rocprof_ms'), r.get('rocprof_frac'), d.get('verified'), (d.get('verified_vs_reference') or {}).get('ok'))"
   ;;
+29)
+# round 6, twenty-ninth session: w4s_segment in two launches - the 64-lead instance (82 registers, 3.6 KB of LDS: six waves per SIMD, two
+# unrolled rounds) over every block, the large instance over the list of blocks that own a window of more than 64 leads.  GPU parity of
+# the front end, stamps, same-box A/B against one launch (SNF_W4_SPLIT=0), the front end's timeline entries
+timeout 900 python -m pytest tests/test_prefilter.py tests/test_gpu_parity.py tests/test_zz_gpu_end_to_end.py -m gpu -x -q 2>&1 | tail -1
+bash tools/itrace.sh 2>&1 | grep -E "in flight$|w4s_segment"
+bash tools/run_ab.sh -n 3 one:SNF_W4_SPLIT=0 two: 2>&1 | tee gpurun_out/ab_r06_19.log
+for sp in 0 1; do SNF_W4_SPLIT=$sp SNF_PROF=1 SNF_TIMELINE=1 python bench.py $Q --no-verify --steps 3 --warmup 2 --inflight 1 2>&1 | grep -E "SNF_TIMELINE.*(w4s_segment|w3_scatter|w5|w6t_emit)|window front end" | tail -5; done 2>&1 | tee -a gpurun_out/ab_r06_19.log
+  ;;
 esac
