@@ -445,8 +445,6 @@ class LazySource:
         self.n_filled = 0
         self.n_single = 0            # stand-ins outside the bulk selection that were filled alone
         self.on_detach = None        # called when the tables are let go of (a GPU server's result segment: sniffles_amd.server)
-        import threading
-        self._lock = threading.RLock()      # two threads touching stand-ins of one list: one bulk fill at a time
 
     def make(self, all_qc: bool = False) -> list:
         fast = _load_fast()
@@ -471,10 +469,10 @@ class LazySource:
         """The record tables are about to be handed on: the stand-ins that anything besides this source's own list still refers to
         become calls now; the others are garbage.  Breaks the list <-> source cycle."""
         import numpy as np
-        with self._lock:
-            self._detach_locked(np)
-
-    def _detach_locked(self, np) -> None:
+        # (No lock around detach / fill: a list of stand-ins belongs to the thread that asked for it.  An RLock taken here - added for two
+        # threads touching one list - cost the two-call seam half its speed: 24 x call_candidates / finalize_candidates with two tasks in
+        # flight 122-229 ms per genome instead of 66-82 ms, one task at a time 110-120 instead of 99-108 ms, same box, same library, the
+        # lock created but not taken: 69-75 ms.  What it waits for was not found; the form before it is restored.)
         if self.stubs is not None and self.calls is not None:
             targets, idx = _load_fast().stub_select(self.stubs, self, 2)
             if targets:
@@ -491,13 +489,9 @@ class LazySource:
         all of them at the candidate stage (`finalize_candidates` then works on objects, as before), the ones with `qc` set (all
         under `no_qc`) after it.  What is left out stays a stand-in and is filled alone if it is ever touched."""
         import numpy as np
-        with self._lock:
-            self._fill_locked(obj, np)
-
-    def _fill_locked(self, obj, np) -> None:
         d = _raw_dict(obj)
         me = d.get("_lzi")
-        if me is None:                  # (became a call while this thread waited)
+        if me is None:                  # (already a call)
             return
         if self.calls is None:
             raise RuntimeError("this call's task was closed (or ran again) while nothing referred to the call")
