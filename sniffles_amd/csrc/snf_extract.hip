@@ -71,6 +71,7 @@ struct Seg {             // one (split) alignment of a read in classify_splits
 struct ExView {
   snf_extract_config_t cfg;
   const uint8_t* blob; const int64_t* rec_off; const uint32_t* qname_rank; int64_t n_records;
+  const uint32_t* order;     // wave form: the record workgroup w takes - the records of the region's contig by falling CIGAR length (built at upload)
   int32_t region_ref_id, region_rank, region_start, region_end; uint32_t read_id_offset;
   const uint64_t* ctg_hash; const int32_t* ctg_rank; int32_t n_contigs;
   RecSum* sum;
@@ -1034,8 +1035,10 @@ __global__ void __launch_bounds__(64, MINW) x_wave(const ExView v, int64_t n) {
   __shared__ uint8_t ord[XMAXSEG];
   __shared__ alignas(16) uint8_t auxl[XAUXCAP + 16];   // (reads of up to 15 bytes past the last copied byte stay inside)
   __shared__ int32_t sab[2 * XMAXSEG];                 // first byte / terminator of the SA string's elements
-  for (int64_t rec = (int64_t)blockIdx.x; rec < n; rec += (int64_t)gridDim.x)
-    extract_record<true, EMIT>(rec, v, segs, ord, auxl, sab);
+  // workgroups start in index order: the records with the longest CIGARs first (a read of 85 steps that starts among the last ones is
+  // what a pass over a small table ended with: 40 % of its span with a few hundred waves in flight)
+  for (int64_t w = (int64_t)blockIdx.x; w < n; w += (int64_t)gridDim.x)
+    extract_record<true, EMIT>((int64_t)v.order[w], v, segs, ord, auxl, sab);
 }
 // average_regional_nm needs the reads' NM ratios summed in BAM order (leadprov.py:533-534, 577): sequential fp64 adds.
 // x_prep has laid the summands out densely (a record that does not count as +0.0).  Adding a zero is the identity here - the sum starts
@@ -1200,6 +1203,19 @@ int do_upload(snf_extract* x, const snf_extract_input_t* in) {
   v.qname_rank = x_up(x->dev, in->qname_rank, (size_t)in->n_records);
   v.ctg_hash = x_up(x->dev, in->contig_hash, (size_t)in->n_contigs);
   v.ctg_rank = x_up(x->dev, in->contig_rank, (size_t)in->n_contigs);
+  {  // dispatch order of the wave form: counting sort of the records by CIGAR length, longest first; records of other contigs last
+    const int64_t n = in->n_records;
+    std::vector<uint32_t> cnt(65538, 0), ord((size_t)(n ? n : 1));
+    auto key = [&](int64_t i) -> uint32_t {
+      const uint8_t* R = in->records + in->rec_off[i];
+      int32_t rid; uint16_t nc; memcpy(&rid, R + 4, 4); memcpy(&nc, R + 16, 2);
+      return rid == in->region_ref_id ? 65535u - nc : 65536u;
+    };
+    for (int64_t i = 0; i < n; i++) cnt[key(i) + 1]++;
+    for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+    for (int64_t i = 0; i < n; i++) ord[cnt[key(i)]++] = (uint32_t)i;
+    v.order = x_up(x->dev, ord.data(), (size_t)(n ? n : 1));
+  }
   v.n_contigs = in->n_contigs; v.n_records = in->n_records;
   v.region_ref_id = in->region_ref_id; v.region_rank = in->region_rank; v.region_start = in->region_start; v.region_end = in->region_end;
   v.read_id_offset = in->read_id_offset;
