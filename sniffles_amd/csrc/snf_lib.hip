@@ -307,6 +307,7 @@ struct snf_batch_impl {
   int slot_fd = -1;               // the GPU slot this pass holds (SNF_GPU_SLOTS)
   double pass_start_ms = 0.0;     // when this handle's pass in flight began (pacing of overlapping passes)
   bool capturing = false;         // run_pass is capturing this pass into a graph
+  int chain_slot = -1;            // SNF_CHAIN_GATE: the device's event this pass records at the end of its chain
   // Result staged through HBM (run_finalize): with another pass in flight on the device the kernels of a pass store the result block
   // and the ALT section into HBM; they are taken to the pinned buffers by two copies at the fetch (default) or by two small copy
   // kernels behind their producers (SNF_STAGE_COPY=kernel: z2_stage_copy reads the sizes on the device)
@@ -1153,6 +1154,10 @@ struct DevicePacing {
   std::atomic<long long> last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
   std::mutex copy_mu, pace_mu;
   double last_pass_start_ms = -1e12, pass_latency_ms = 0.0;      // (under pace_mu) start of the latest pass; smoothed enqueue -> waited time
+  // the chain gate (under pace_mu): the passes of a device take turns with their clustering / calling chains ON THE DEVICE - a pass's
+  // main stream waits for the event the pass before it recorded where its chain ends (in front of its ALT stage), while that pass's ALT
+  // and output stages run beside the new chain
+  hipEvent_t chain_ev[2] = {nullptr, nullptr}; unsigned long long chain_seq = 0;
 };
 DevicePacing g_pacing[SNF_MAX_DEVICES];
 DevicePacing& pacing_of(const snf_batch_impl* b) { return g_pacing[(b->device >= 0 && b->device < SNF_MAX_DEVICES) ? b->device : 0]; }
@@ -1164,7 +1169,12 @@ DevicePacing& pacing_of(const snf_batch_impl* b) { return g_pacing[(b->device >=
 // shared anyway; the pass that waited starts its next pass later - a stagger), (2) a pass does not START sooner than a quarter of the
 // recent pass latency after the other in-flight pass did (the second of two simultaneous starts waits ~0.4 ms once; passes that are
 // half a period apart never wait).  SNF_PACE=0 turns both off (2: rule 1 only, 3: rule 2 only), SNF_PACE_FRAC sets the fraction.
-int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : 1; return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
+// The default since the end of round 6 (SNF_CHAIN_GATE=0: off, the two timing rules below instead): passes of one device take turns with
+// their chains ON THE DEVICE.  The timing rules kept two passes out of step in 26 of 26 runs when they were tuned and in 37 of 40 default
+// runs on the round's last day (three runs at 1.15-1.19 ms per step instead of 0.95); the gate does not depend on when a host thread gets
+// to run: 0.959-0.961 ms in 8 of 8 runs (profiles/r06_regime_gate.log), whatever the sizes of the passes are.
+bool chain_gate_on() { static const bool g = !(getenv("SNF_CHAIN_GATE") && atoi(getenv("SNF_CHAIN_GATE")) == 0); return g; }
+int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : (chain_gate_on() ? 0 : 1); return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
 bool pace_on() { return pace_mode() == 1 || pace_mode() == 3; }
 bool pace_copy_turn() { return pace_mode() == 1 || pace_mode() == 2; }
 double pace_frac() { static const double f = getenv("SNF_PACE_FRAC") ? atof(getenv("SNF_PACE_FRAC")) : 0.25; return f; }
@@ -1200,7 +1210,7 @@ void pass_begins(snf_batch_impl* b) {
   DevicePacing& P = pacing_of(b);
   const bool other = P.passes_in_flight.fetch_add(1) >= 1;
   if (other) P.last_overlap_ms.store((long long)now_ms());
-  if (!pace_on()) { b->pass_start_ms = now_ms(); return; }
+  if (!pace_on() || chain_gate_on()) { b->pass_start_ms = now_ms(); return; }
   double wait = 0.0;
   {
     std::lock_guard<std::mutex> g(P.pace_mu);
@@ -1387,6 +1397,16 @@ void run_call_candidates(snf_batch_impl* b) {
   b->reads_ready = true; b->cov_avg_ready = true; b->finalized = false;
   begin_pass_timing(b);
   pass_begins(b);
+  b->chain_slot = -1;
+  if (chain_gate_on() && !b->capturing) {
+    DevicePacing& P = pacing_of(b);
+    std::lock_guard<std::mutex> g(P.pace_mu);
+    const unsigned long long my = P.chain_seq++;
+    hipEvent_t& mine = P.chain_ev[my & 1]; hipEvent_t prev = P.chain_ev[(my + 1) & 1];
+    if (!mine) SNF_HIP(hipEventCreateWithFlags(&mine, hipEventDisableTiming));
+    b->chain_slot = (int)(my & 1);
+    if (prev && P.passes_in_flight.load() > 1) SNF_HIP(hipStreamWaitEvent(b->stream, prev, 0));
+  }
   // SNF_OUT_EXECUTE (set before this call): the names of the supporting reads are only written for the calls that pass QC,
   // once finalize knows them (a stage-0 fetch writes them all, late)
   v.rn_defer = ((v.out_mode & SNF_OUT_EXECUTE) && !v.cfg.no_qc && getenv("SNF_NO_RN_DEFER") == nullptr && getenv("SNF_NO_FUSE") == nullptr && N <= ((int64_t)1 << 25)) ? 1 : 0;
@@ -1759,6 +1779,12 @@ void run_finalize(snf_batch_impl* b) {
   const int64_t NS = v.NS;
   b->finalized = true;
   b->res_current = false;
+  if (b->chain_slot >= 0 && !b->capturing) {      // the chain of this pass ends here: the next pass of the device may start its own
+    DevicePacing& P = pacing_of(b);
+    std::lock_guard<std::mutex> g(P.pace_mu);
+    if (P.chain_ev[b->chain_slot]) SNF_HIP(hipEventRecord(P.chain_ev[b->chain_slot], b->stream));
+    b->chain_slot = -1;
+  }
   // Nothing below waits for the device: grids cover upper bounds derived from NS (the kernels read the real counts in HBM
   // and stride or return), the ALT bytes go to an HBM pool sized at upload, and the fetch is the one host wait of the pass.
   {  // pinned block for the result: sized from the input, grown by the fetch when a result did not fit
