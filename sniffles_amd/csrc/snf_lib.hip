@@ -1154,7 +1154,7 @@ struct DevicePacing {
   std::atomic<long long> last_overlap_ms{-1000000};      // when two passes were last in flight together (now_ms clock)
   std::mutex copy_mu, pace_mu;
   double last_pass_start_ms = -1e12, pass_latency_ms = 0.0;      // (under pace_mu) start of the latest pass; smoothed enqueue -> waited time
-  // the chain gate (under pace_mu): the passes of a device take turns with their clustering / calling chains ON THE DEVICE - a pass's
+  // the chain gate (SNF_CHAIN_GATE=1; under pace_mu): the passes of a device take turns with their clustering / calling chains ON THE DEVICE - a pass's
   // main stream waits for the event the pass before it recorded where its chain ends (in front of its ALT stage), while that pass's ALT
   // and output stages run beside the new chain
   hipEvent_t chain_ev[2] = {nullptr, nullptr}; unsigned long long chain_seq = 0;
@@ -1169,12 +1169,13 @@ DevicePacing& pacing_of(const snf_batch_impl* b) { return g_pacing[(b->device >=
 // shared anyway; the pass that waited starts its next pass later - a stagger), (2) a pass does not START sooner than a quarter of the
 // recent pass latency after the other in-flight pass did (the second of two simultaneous starts waits ~0.4 ms once; passes that are
 // half a period apart never wait).  SNF_PACE=0 turns both off (2: rule 1 only, 3: rule 2 only), SNF_PACE_FRAC sets the fraction.
-// The default since the end of round 6 (SNF_CHAIN_GATE=0: off, the two timing rules below instead): passes of one device take turns with
-// their chains ON THE DEVICE.  The timing rules kept two passes out of step in 26 of 26 runs when they were tuned and in 37 of 40 default
-// runs on the round's last day (three runs at 1.15-1.19 ms per step instead of 0.95); the gate does not depend on when a host thread gets
-// to run: 0.959-0.961 ms in 8 of 8 runs (profiles/r06_regime_gate.log), whatever the sizes of the passes are.
-bool chain_gate_on() { static const bool g = !(getenv("SNF_CHAIN_GATE") && atoi(getenv("SNF_CHAIN_GATE")) == 0); return g; }
-int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : (chain_gate_on() ? 0 : 1); return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
+// SNF_CHAIN_GATE=1 (off by default): passes of one device take turns with their chains ON THE DEVICE instead of being kept apart by the two
+// timing rules below.  Measured on the last day of round 6 (tools/regime.sh, profiles/r06_regime*.log): 8 of 8 and 8 of 8 runs at 0.954-0.977
+// ms per step (with rule 1) / 0.959-0.961 (without any rule) on one box - and, made the default, 12 of 16 runs at 0.955-0.97 but FOUR at
+// 1.32-1.49 (the passes one after the other) on the next.  The rules: 37 of 40 default runs of that day at 0.94-0.97, three at 1.15-1.19.
+// Not understood in the time left; the rules stay the default.
+bool chain_gate_on() { static const bool g = getenv("SNF_CHAIN_GATE") && atoi(getenv("SNF_CHAIN_GATE")) != 0; return g; }
+int pace_mode() { static const int m = getenv("SNF_PACE") ? atoi(getenv("SNF_PACE")) : 1; return m; }      // 0 off, 1 both rules, 2 copies in turn only, 3 spaced starts only
 bool pace_on() { return pace_mode() == 1 || pace_mode() == 3; }
 bool pace_copy_turn() { return pace_mode() == 1 || pace_mode() == 2; }
 double pace_frac() { static const double f = getenv("SNF_PACE_FRAC") ? atof(getenv("SNF_PACE_FRAC")) : 0.25; return f; }
